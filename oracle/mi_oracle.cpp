@@ -1,0 +1,967 @@
+/*
+ * mi_oracle.cpp -- CPU ORACLE: restatement of the reference hot path
+ * (mitsuba3 v3.9.1 `llvm_ad_rgb`: forward `path` + `prb` adjoint on triangle
+ * scenes).  TEST INFRASTRUCTURE ONLY -- see mi_oracle.h for the rules and for
+ * the "parity unpinned" statement.  Each function cites the reference
+ * file:line it follows (paths relative to /root/reference).
+ */
+#include "mi_oracle.h"
+#include "orc_math.h"
+
+#include <algorithm>
+#include <atomic>
+#include <cstdio>
+#include <cstdlib>
+#include <thread>
+#include <vector>
+
+using namespace orc;
+
+namespace {
+
+// ---------------------------------------------------------------------------
+//  Scene storage
+// ---------------------------------------------------------------------------
+
+struct Mesh {
+    std::vector<float> V;      // 8 floats / vertex
+    std::vector<uint32_t> F;   // 4 u32 / face
+    uint32_t nv, nf, bsdf; int32_t emitter; uint32_t flags;
+};
+struct Tri { V3 p0, e1, e2; uint32_t prim, shape; };
+struct BvhNode { float lo[3], hi[3]; uint32_t left, count; /* count>0: leaf, left=first */ uint32_t right; };
+struct Bvh {
+    std::vector<BvhNode> nodes;
+    std::vector<Tri> tris;
+    float lo[3], hi[3];
+    bool empty() const { return tris.empty(); }
+};
+struct Texture { std::vector<float> data; uint32_t w, h; };
+
+struct Scene {
+    std::vector<Mesh> meshes; uint32_t top_count;
+    std::vector<OrcShapeGroup> groups;
+    std::vector<OrcInstance> instances;
+    std::vector<OrcBSDF> bsdfs;
+    std::vector<Texture> textures;
+    std::vector<OrcEmitter> emitters;
+    Bvh top;                       // all top-level meshes
+    std::vector<Bvh> group_bvh;    // one per shapegroup
+    std::vector<BvhNode> inst_nodes; // BVH over instance world boxes
+    std::vector<uint32_t> inst_order;
+};
+
+struct Ray { V3 o, d; float maxt; };
+struct PI { float t = Infinity, u = 0, v = 0; uint32_t prim = 0, shape = 0, inst = 0xffffffffu; bool valid() const { return t != Infinity; } };
+
+// ---------------------------------------------------------------------------
+//  BVH (the oracle's own accel; reference uses Embree / kd-tree: kdtree.h:2206)
+// ---------------------------------------------------------------------------
+
+struct BuildPrim { float lo[3], hi[3], c[3]; uint32_t id; };
+
+static void build_rec(std::vector<BvhNode> &nodes, std::vector<BuildPrim> &prims,
+                      uint32_t begin, uint32_t end, uint32_t node_idx, uint32_t leaf_size) {
+    BvhNode n{};
+    for (int a = 0; a < 3; ++a) { n.lo[a] = Infinity; n.hi[a] = -Infinity; }
+    float clo[3] = { Infinity, Infinity, Infinity }, chi[3] = { -Infinity, -Infinity, -Infinity };
+    for (uint32_t i = begin; i < end; ++i)
+        for (int a = 0; a < 3; ++a) {
+            n.lo[a] = std::min(n.lo[a], prims[i].lo[a]); n.hi[a] = std::max(n.hi[a], prims[i].hi[a]);
+            clo[a] = std::min(clo[a], prims[i].c[a]);    chi[a] = std::max(chi[a], prims[i].c[a]);
+        }
+    uint32_t count = end - begin;
+    int axis = 0;
+    for (int a = 1; a < 3; ++a) if (chi[a] - clo[a] > chi[axis] - clo[axis]) axis = a;
+    if (count <= leaf_size || !(chi[axis] > clo[axis])) {
+        n.left = begin; n.count = count; n.right = 0;
+        nodes[node_idx] = n;
+        return;
+    }
+    // binned SAH along the widest centroid axis
+    constexpr int NB = 16;
+    struct Bin { float lo[3], hi[3]; uint32_t n; } bins[NB];
+    for (auto &b : bins) { for (int a = 0; a < 3; ++a) { b.lo[a] = Infinity; b.hi[a] = -Infinity; } b.n = 0; }
+    float scale = NB / (chi[axis] - clo[axis]);
+    auto bin_of = [&](const BuildPrim &p) { int b = (int) ((p.c[axis] - clo[axis]) * scale); return std::min(std::max(b, 0), NB - 1); };
+    for (uint32_t i = begin; i < end; ++i) {
+        Bin &b = bins[bin_of(prims[i])]; b.n++;
+        for (int a = 0; a < 3; ++a) { b.lo[a] = std::min(b.lo[a], prims[i].lo[a]); b.hi[a] = std::max(b.hi[a], prims[i].hi[a]); }
+    }
+    auto area = [](const float *lo, const float *hi) { float dx = hi[0] - lo[0], dy = hi[1] - lo[1], dz = hi[2] - lo[2]; return 2.f * (dx * dy + dy * dz + dz * dx); };
+    float best = Infinity; int best_split = -1;
+    float rlo[NB][3], rhi[NB][3]; uint32_t rn[NB];
+    { float lo[3] = { Infinity, Infinity, Infinity }, hi[3] = { -Infinity, -Infinity, -Infinity }; uint32_t c = 0;
+      for (int i = NB - 1; i >= 0; --i) { c += bins[i].n; for (int a = 0; a < 3; ++a) { lo[a] = std::min(lo[a], bins[i].lo[a]); hi[a] = std::max(hi[a], bins[i].hi[a]); rlo[i][a] = lo[a]; rhi[i][a] = hi[a]; } rn[i] = c; } }
+    { float lo[3] = { Infinity, Infinity, Infinity }, hi[3] = { -Infinity, -Infinity, -Infinity }; uint32_t c = 0;
+      for (int i = 0; i < NB - 1; ++i) { c += bins[i].n; for (int a = 0; a < 3; ++a) { lo[a] = std::min(lo[a], bins[i].lo[a]); hi[a] = std::max(hi[a], bins[i].hi[a]); }
+          if (c == 0 || rn[i + 1] == 0) continue;
+          float cost = c * area(lo, hi) + rn[i + 1] * area(rlo[i + 1], rhi[i + 1]);
+          if (cost < best) { best = cost; best_split = i; } } }
+    uint32_t mid;
+    if (best_split < 0) {
+        mid = begin + count / 2;
+        std::nth_element(prims.begin() + begin, prims.begin() + mid, prims.begin() + end,
+                         [axis](const BuildPrim &a, const BuildPrim &b) { return a.c[axis] < b.c[axis]; });
+    } else {
+        auto it = std::partition(prims.begin() + begin, prims.begin() + end,
+                                 [&](const BuildPrim &p) { return bin_of(p) <= best_split; });
+        mid = (uint32_t) (it - prims.begin());
+        if (mid == begin || mid == end) mid = begin + count / 2;
+    }
+    uint32_t l = (uint32_t) nodes.size(); nodes.emplace_back(); nodes.emplace_back();
+    n.left = l; n.right = l + 1; n.count = 0;
+    nodes[node_idx] = n;
+    build_rec(nodes, prims, begin, mid, l, leaf_size);
+    build_rec(nodes, prims, mid, end, l + 1, leaf_size);
+}
+
+static void pad_box(float *lo, float *hi) {
+    float m = 1.f;
+    for (int a = 0; a < 3; ++a) m = std::max(m, std::max(std::fabs(lo[a]), std::fabs(hi[a])));
+    float pad = 2e-5f * m;
+    for (int a = 0; a < 3; ++a) { lo[a] -= pad; hi[a] += pad; }
+}
+
+static void build_tri_bvh(Bvh &bvh, const std::vector<Mesh> &meshes, uint32_t first, uint32_t count) {
+    std::vector<BuildPrim> prims; std::vector<Tri> tris;
+    for (uint32_t s = first; s < first + count; ++s) {
+        const Mesh &m = meshes[s];
+        for (uint32_t f = 0; f < m.nf; ++f) {
+            V3 p[3];
+            for (int k = 0; k < 3; ++k) { const float *v = &m.V[8 * (size_t) m.F[4 * f + k]]; p[k] = V3(v[0], v[1], v[2]); }
+            Tri t; t.p0 = p[0]; t.e1 = p[1] - p[0]; t.e2 = p[2] - p[0]; t.prim = f; t.shape = s;
+            BuildPrim b; b.id = (uint32_t) tris.size();
+            for (int a = 0; a < 3; ++a) {
+                b.lo[a] = std::min(p[0][a], std::min(p[1][a], p[2][a]));
+                b.hi[a] = std::max(p[0][a], std::max(p[1][a], p[2][a]));
+                b.c[a] = 0.5f * (b.lo[a] + b.hi[a]);
+            }
+            pad_box(b.lo, b.hi);
+            prims.push_back(b); tris.push_back(t);
+        }
+    }
+    bvh.nodes.clear(); bvh.tris.clear();
+    if (prims.empty()) return;
+    bvh.nodes.emplace_back();
+    build_rec(bvh.nodes, prims, 0, (uint32_t) prims.size(), 0, 4);
+    bvh.tris.resize(tris.size());
+    for (size_t i = 0; i < prims.size(); ++i) bvh.tris[i] = tris[prims[i].id];
+    for (int a = 0; a < 3; ++a) { bvh.lo[a] = bvh.nodes[0].lo[a]; bvh.hi[a] = bvh.nodes[0].hi[a]; }
+}
+
+/* Mesh::moeller_trumbore, include/mitsuba/render/mesh.h:1130-1155 */
+static inline bool moeller_trumbore(const Ray &ray, const Tri &tr, float &t, float &u, float &v) {
+    V3 pvec = cross(ray.d, tr.e2);
+    float inv_det = rcp(dot(tr.e1, pvec));
+    V3 tvec = ray.o - tr.p0;
+    u = dot(tvec, pvec) * inv_det;
+    bool active = u >= 0.f && u <= 1.f;
+    V3 qvec = cross(tvec, tr.e1);
+    v = dot(ray.d, qvec) * inv_det;
+    active &= v >= 0.f && u + v <= 1.f;
+    t = dot(tr.e2, qvec) * inv_det;
+    active &= t >= 0.f && t <= ray.maxt;
+    return active;
+}
+
+static inline bool slab(const float *lo, const float *hi, const V3 &o, const V3 &id, float tmax, float &tnear) {
+    float t0 = 0.f, t1 = tmax;
+    for (int a = 0; a < 3; ++a) {
+        float ta = (lo[a] - o[a]) * id[a], tb = (hi[a] - o[a]) * id[a];
+        float mn = std::fmin(ta, tb), mx = std::fmax(ta, tb);
+        t0 = std::fmax(t0, mn); t1 = std::fmin(t1, mx);   // fmin/fmax drop NaNs (0*inf)
+    }
+    tnear = t0;
+    return t0 <= t1 * 1.0000005f;
+}
+
+/* closest hit with the brute-force tie rule of ShapeKDTree::ray_intersect_naive
+ * (kdtree.h:2433-2460): a later primitive replaces an earlier one when
+ * t <= maxt, i.e. on exact ties the larger (shape, prim) wins. */
+static inline void consider(const Ray &ray, const Tri &tr, PI &pi, uint32_t inst) {
+    float t, u, v;
+    Ray r = ray; r.maxt = std::fmin(ray.maxt, pi.t);
+    if (!moeller_trumbore(r, tr, t, u, v)) return;
+    if (t == pi.t && pi.valid()) {
+        // scene order: top-level shapes first (inst = -1 -> 0), then instances
+        auto key = [](uint32_t in, uint32_t sh, uint32_t pr, int which) -> uint64_t {
+            return which == 0 ? (uint64_t) (uint32_t) (in + 1u) : (((uint64_t) sh << 32) | pr); };
+        uint64_t a0 = key(inst, tr.shape, tr.prim, 0), b0 = key(pi.inst, pi.shape, pi.prim, 0);
+        uint64_t a1 = key(inst, tr.shape, tr.prim, 1), b1 = key(pi.inst, pi.shape, pi.prim, 1);
+        bool later = a0 != b0 ? a0 > b0 : a1 > b1;
+        if (!later) return;
+    }
+    pi.t = t; pi.u = u; pi.v = v; pi.prim = tr.prim; pi.shape = tr.shape; pi.inst = inst;
+}
+
+template <bool Shadow>
+static bool traverse(const Bvh &bvh, const Ray &ray, PI &pi, uint32_t inst) {
+    if (bvh.empty()) return false;
+    V3 id(rcp(ray.d.x), rcp(ray.d.y), rcp(ray.d.z));
+    uint32_t stack[128]; int sp = 0; stack[sp++] = 0;
+    while (sp) {
+        const BvhNode &n = bvh.nodes[stack[--sp]];
+        float tn;
+        if (!slab(n.lo, n.hi, ray.o, id, std::fmin(ray.maxt, pi.t), tn)) continue;
+        if (n.count) {
+            for (uint32_t i = 0; i < n.count; ++i) {
+                const Tri &tr = bvh.tris[n.left + i];
+                if (Shadow) { float t, u, v; if (moeller_trumbore(ray, tr, t, u, v)) return true; }
+                else consider(ray, tr, pi, inst);
+            }
+        } else { stack[sp++] = n.left; stack[sp++] = n.right; }
+    }
+    return false;
+}
+
+template <bool Shadow>
+static bool brute(const Bvh &bvh, const Ray &ray, PI &pi, uint32_t inst) {
+    for (const Tri &tr : bvh.tris) {
+        if (Shadow) { float t, u, v; if (moeller_trumbore(ray, tr, t, u, v)) return true; }
+        else consider(ray, tr, pi, inst);
+    }
+    return false;
+}
+
+/* Scene::ray_intersect_preliminary / ray_test (src/render/scene.cpp:216-238);
+ * instances: Instance::ray_intersect_preliminary_impl (src/shapes/instance.cpp:121-132)
+ * transforms the ray with to_world.inverse() and keeps `t`. */
+template <bool Shadow>
+static bool scene_trace(const Scene &sc, const Ray &ray, PI &pi, int mode) {
+    if (mode == 0) { if (traverse<Shadow>(sc.top, ray, pi, 0xffffffffu) && Shadow) return true; }
+    else           { if (brute<Shadow>(sc.top, ray, pi, 0xffffffffu) && Shadow) return true; }
+    auto do_inst = [&](uint32_t i) -> bool {
+        const OrcInstance &in = sc.instances[i];
+        Ray r; r.o = xf_point(in.to_object, ray.o); r.d = xf_vector(in.to_object, ray.d); r.maxt = ray.maxt;
+        const Bvh &b = sc.group_bvh[in.group];
+        return mode == 0 ? traverse<Shadow>(b, r, pi, i) : brute<Shadow>(b, r, pi, i);
+    };
+    if (mode != 0 || sc.inst_nodes.empty()) {
+        for (uint32_t i = 0; i < sc.instances.size(); ++i) if (do_inst(i) && Shadow) return true;
+    } else {
+        V3 id(rcp(ray.d.x), rcp(ray.d.y), rcp(ray.d.z));
+        uint32_t stack[64]; int sp = 0; stack[sp++] = 0;
+        while (sp) {
+            const BvhNode &n = sc.inst_nodes[stack[--sp]];
+            float tn;
+            if (!slab(n.lo, n.hi, ray.o, id, std::fmin(ray.maxt, pi.t), tn)) continue;
+            if (n.count) { for (uint32_t i = 0; i < n.count; ++i) if (do_inst(sc.inst_order[n.left + i]) && Shadow) return true; }
+            else { stack[sp++] = n.left; stack[sp++] = n.right; }
+        }
+    }
+    return Shadow ? false : pi.valid();
+}
+
+// ---------------------------------------------------------------------------
+//  Surface interaction
+// ---------------------------------------------------------------------------
+
+struct SI {
+    float t = Infinity; V3 p, n, sn, ss, st, wi; float uv[2] = { 0, 0 };
+    uint32_t mesh = 0; bool valid() const { return t != Infinity; }
+    V3 to_local(V3 v) const { return V3(dot(v, ss), dot(v, st), dot(v, sn)); }               // frame.h:34
+    V3 to_world(V3 v) const { return fmadd(sn, v.z, fmadd(st, v.y, ss * v.x)); }              // frame.h:39
+};
+
+/* Mesh::compute_surface_interaction (src/render/mesh.cpp:2255-2437),
+ * Instance::compute_surface_interaction (src/shapes/instance.cpp:150-266),
+ * SurfaceInteraction::finalize_surface_interaction (interaction.h:559-605). */
+static SI compute_si(const Scene &sc, const Ray &ray_w, const PI &pi) {
+    SI si;
+    if (!pi.valid()) { si.wi = -ray_w.d; return si; }     // interaction.h:812-818
+    const Mesh &m = sc.meshes[pi.shape];
+    const uint32_t *f = &m.F[4 * (size_t) pi.prim];
+    const float *r0 = &m.V[8 * (size_t) f[0]], *r1 = &m.V[8 * (size_t) f[1]], *r2 = &m.V[8 * (size_t) f[2]];
+    V3 p0(r0[0], r0[1], r0[2]), p1(r1[0], r1[1], r1[2]), p2(r2[0], r2[1], r2[2]);
+    float b1 = pi.u, b2 = pi.v, b0 = 1.f - b1 - b2;
+    V3 e1 = p1 - p0, e2 = p2 - p0;
+    si.p = fmadd(p0, b0, fmadd(p1, b1, p2 * b2));
+    si.n = normalize(cross(e1, e2));                       // mesh.h:568-572
+    si.t = pi.t;
+    if (m.flags & 1u) {
+        V3 n0(r0[3], r0[4], r0[5]), dn1 = V3(r1[3], r1[4], r1[5]) - n0, dn2 = V3(r2[3], r2[4], r2[5]) - n0;
+        V3 n = fmadd(dn1, b1, fmadd(dn2, b2, n0));
+        float il = rsqrt(squared_norm(n));
+        si.sn = n * il;
+    } else si.sn = si.n;
+    if (m.flags & 2u) {
+        float u0 = r0[6], v0 = r0[7], du0 = r1[6] - u0, dv0 = r1[7] - v0, du1 = r2[6] - u0, dv1 = r2[7] - v0;
+        si.uv[0] = fmadd(du0, b1, fmadd(du1, b2, u0));
+        si.uv[1] = fmadd(dv0, b1, fmadd(dv1, b2, v0));
+    } else { si.uv[0] = b1; si.uv[1] = b2; }
+    si.mesh = pi.shape;
+    if (pi.inst != 0xffffffffu) {                          // instance.cpp:196-224
+        const OrcInstance &in = sc.instances[pi.inst];
+        si.p = xf_point(in.to_world, si.p);
+        si.n = normalize(xf_normal(in.to_object, si.n));
+        V3 n = xf_normal(in.to_object, si.sn);
+        float inv_len = rcp(norm(n));
+        si.sn = n * inv_len;
+    }
+    // finalize: sh_frame.s == 0 for `diffuse` (no tangents packed) => coordinate_system()
+    coordinate_system(si.sn, si.ss, si.st);
+    si.wi = si.to_local(-ray_w.d);
+    return si;
+}
+
+/* Interaction::offset_p / spawn_ray / spawn_ray_to (interaction.h:161-191) */
+static inline V3 offset_p(const SI &si, V3 d) {
+    float mag = (1.f + hmax(vabs(si.p))) * RayEpsilon;
+    mag = mulsign(mag, dot(si.n, d));
+    return fmadd(si.n, mag, si.p);
+}
+static inline Ray spawn_ray(const SI &si, V3 d) { Ray r; r.o = offset_p(si, d); r.d = d; r.maxt = Largest; return r; }
+static inline Ray spawn_ray_to(const SI &si, V3 t) {
+    Ray r; r.o = offset_p(si, t - si.p);
+    V3 d = t - r.o; float dist = norm(d);
+    r.d = div(d, dist); r.maxt = dist * (1.f - ShadowEpsilon);
+    return r;
+}
+
+// ---------------------------------------------------------------------------
+//  Textures, BSDF, emitter
+// ---------------------------------------------------------------------------
+
+struct TexLookup { uint32_t idx[4]; float w[4]; };
+/* dr::Texture<Float,2>::eval, bilinear + repeat (ext/drjit texture.h, NOT IN TREE,
+ * parity unpinned; call site src/textures/bitmap.cpp:842-850) */
+static inline void tex_lookup(const Texture &t, const float uv[2], TexLookup &l) {
+    float px = fmadd(uv[0], (float) t.w, -0.5f), py = fmadd(uv[1], (float) t.h, -0.5f);
+    float fx = std::floor(px), fy = std::floor(py);
+    int32_t ix = (int32_t) fx, iy = (int32_t) fy;
+    float w1x = px - fx, w1y = py - fy, w0x = 1.f - w1x, w0y = 1.f - w1y;
+    auto wrap = [](int32_t i, int32_t n) { int32_t r = i % n; return (uint32_t) (r < 0 ? r + n : r); };
+    uint32_t x0 = wrap(ix, (int32_t) t.w), x1 = wrap(ix + 1, (int32_t) t.w);
+    uint32_t y0 = wrap(iy, (int32_t) t.h), y1 = wrap(iy + 1, (int32_t) t.h);
+    l.idx[0] = y0 * t.w + x0; l.idx[1] = y0 * t.w + x1; l.idx[2] = y1 * t.w + x0; l.idx[3] = y1 * t.w + x1;
+    l.w[0] = w0x; l.w[1] = w1x; l.w[2] = w0y; l.w[3] = w1y;
+}
+static inline V3 tex_eval(const Texture &t, const TexLookup &l) {
+    float out[3];
+    for (int c = 0; c < 3; ++c) {
+        float v00 = t.data[3 * (size_t) l.idx[0] + c], v10 = t.data[3 * (size_t) l.idx[1] + c],
+              v01 = t.data[3 * (size_t) l.idx[2] + c], v11 = t.data[3 * (size_t) l.idx[3] + c];
+        float v0 = fmadd(l.w[0], v00, l.w[1] * v10), v1 = fmadd(l.w[0], v01, l.w[1] * v11);
+        out[c] = fmadd(l.w[2], v0, l.w[3] * v1);
+    }
+    return V3(out[0], out[1], out[2]);
+}
+static inline V3 bsdf_reflectance(const Scene &sc, const OrcBSDF &b, const SI &si) {
+    if (b.texture < 0) return V3(b.reflectance[0], b.reflectance[1], b.reflectance[2]);  // srgb.cpp: m_value
+    TexLookup l; tex_lookup(sc.textures[b.texture], si.uv, l);
+    return tex_eval(sc.textures[b.texture], l);
+}
+
+/* SmoothDiffuse::eval_pdf (src/bsdfs/diffuse.cpp:159-179) */
+static inline void diffuse_eval_pdf(V3 refl, V3 wi, V3 wo, V3 &value, float &pdf) {
+    bool active = wi.z > 0.f && wo.z > 0.f;
+    value = active ? (refl * InvPi) * wo.z : V3(0.f);
+    pdf = active ? InvPi * wo.z : 0.f;
+}
+/* SmoothDiffuse::sample (src/bsdfs/diffuse.cpp:100-124) */
+static inline void diffuse_sample(V3 refl, V3 wi, float s2x, float s2y, V3 &wo, float &pdf, V3 &weight) {
+    wo = square_to_cosine_hemisphere(s2x, s2y);
+    pdf = InvPi * wo.z;
+    weight = (wi.z > 0.f && pdf > 0.f) ? refl : V3(0.f);
+}
+
+struct DS { V3 p, n, d; float dist = 0, pdf = 0; int emitter = -1; };
+
+/* AreaLight::sample_direction (src/emitters/area.cpp:118-168) over
+ * Shape::sample_direction (src/render/shape.cpp:93-110) and
+ * Rectangle::sample_position (src/shapes/rectangle.cpp:159-173) */
+static inline void emitter_sample_direction(const OrcEmitter &e, V3 ref_p, float sx, float sy, DS &ds, V3 &spec) {
+    ds.p = xf_point(e.to_world, V3(fmadd(sx, 2.f, -1.f), fmadd(sy, 2.f, -1.f), 0.f));
+    ds.n = V3(e.normal[0], e.normal[1], e.normal[2]);
+    ds.pdf = e.inv_area;
+    ds.d = ds.p - ref_p;
+    float dist2 = squared_norm(ds.d);
+    ds.dist = std::sqrt(dist2);
+    ds.d = div(ds.d, ds.dist);
+    float dp = std::fabs(dot(ds.d, ds.n));
+    float x = dist2 / dp;
+    ds.pdf *= std::isfinite(x) ? x : 0.f;
+    bool active = dot(ds.d, ds.n) < 0.f && ds.pdf != 0.f;
+    V3 rad(e.radiance[0], e.radiance[1], e.radiance[2]);
+    spec = active ? div(rad, ds.pdf) : V3(0.f);
+}
+/* AreaLight::pdf_direction (area.cpp:170-197) over Shape::pdf_direction (shape.cpp:112-124) */
+static inline float emitter_pdf_direction(const OrcEmitter &e, const DS &ds) {
+    float dp = dot(ds.d, ds.n);
+    if (!(dp < 0.f)) return 0.f;
+    float adp = std::fabs(dp);
+    float pdf = e.inv_area;
+    pdf *= (adp != 0.f) ? (ds.dist * ds.dist) / adp : 0.f;
+    return pdf;
+}
+
+/* PathIntegrator::mis_weight (src/integrators/path.cpp:359-364), common.py:1344 */
+static inline float mis_weight(float a, float b) {
+    a *= a; b *= b;
+    float w = a / (a + b);
+    return std::isfinite(w) ? w : 0.f;
+}
+
+/* Scene::sample_emitter_direction (src/render/scene.cpp:316-366), JIT branch */
+static inline bool sample_emitter_direction(const Scene &sc, const SI &si, float sx, float sy, DS &ds, V3 &spec,
+                                            OrcStats &st, Ray *shadow_out = nullptr) {
+    uint32_t n = (uint32_t) sc.emitters.size();
+    if (n == 0) { ds = DS(); spec = V3(0.f); return false; }
+    uint32_t index = 0; float weight = 1.f, pmf = 1.f / (float) n;
+    if (n > 1) {                                   // sample_emitter, scene.cpp:248-271
+        float scaled = sx * (float) n;
+        index = std::min((uint32_t) scaled, n - 1u);
+        weight = (float) n; sx = scaled - (float) index;
+    }
+    emitter_sample_direction(sc.emitters[index], si.p, sx, sy, ds, spec);
+    ds.emitter = (int) index;
+    ds.pdf *= pmf;
+    spec = spec * weight;
+    if (ds.pdf != 0.f) {
+        Ray r = spawn_ray_to(si, ds.p);
+        if (shadow_out) *shadow_out = r;
+        PI dummy; st.shadow_rays++;
+        if (scene_trace<true>(sc, r, dummy, 0)) { spec = V3(0.f); ds.pdf = 0.f; }
+    }
+    return true;
+}
+
+// ---------------------------------------------------------------------------
+//  Sensor, film
+// ---------------------------------------------------------------------------
+
+/* PerspectiveCamera::sample_ray (src/sensors/perspective.cpp:200-237) */
+static inline Ray sensor_sample_ray(const OrcSensor &s, float px, float py) {
+    const float *M = s.sample_to_camera;
+    float r[4];
+    for (int i = 0; i < 4; ++i) r[i] = M[4 * i + 3];
+    float arg[3] = { px, py, 0.f };
+    for (int j = 0; j < 3; ++j) for (int i = 0; i < 4; ++i) r[i] = fmadd(M[4 * i + j], arg[j], r[i]);   // transform.h:337-345
+    float iw = rcp(r[3]);
+    V3 near_p(r[0] * iw, r[1] * iw, r[2] * iw);
+    V3 d = normalize(near_p);
+    const float *T = s.to_world;
+    Ray ray;
+    ray.o = V3(T[3], T[7], T[11]);
+    V3 dw(T[0] * d.x, T[4] * d.x, T[8] * d.x);
+    dw = V3(fmadd(T[1], d.y, dw.x), fmadd(T[5], d.y, dw.y), fmadd(T[9], d.y, dw.z));
+    dw = V3(fmadd(T[2], d.z, dw.x), fmadd(T[6], d.z, dw.y), fmadd(T[10], d.z, dw.z));
+    ray.d = dw;
+    float inv_z = rcp(d.z);
+    float near_t = s.near_clip * inv_z, far_t = s.far_clip * inv_z;
+    ray.o = ray.o + ray.d * near_t;
+    ray.maxt = far_t - near_t;
+    return ray;
+}
+
+struct RFilter { uint32_t type; float radius; float coeff[10]; };
+/* GaussianFilter ctor + eval, LLVM branch (src/rfilters/gaussian.cpp:48-101) */
+static inline float estrin10(float x, const float *c) {
+    float x2 = x * x, x4 = x2 * x2, x8 = x4 * x4;
+    float a0 = fmadd(x, c[1], c[0]), a1 = fmadd(x, c[3], c[2]), a2 = fmadd(x, c[5], c[4]), a3 = fmadd(x, c[7], c[6]), a4 = fmadd(x, c[9], c[8]);
+    float b0 = fmadd(x2, a1, a0), b1 = fmadd(x2, a3, a2), b2 = a4;
+    float c0 = fmadd(x4, b1, b0), c1 = b2;
+    return fmadd(x8, c1, c0);
+}
+static RFilter make_rfilter(uint32_t type, float stddev) {
+    RFilter f{}; f.type = type;
+    if (type == 0) { f.radius = 0.5f; return f; }
+    f.radius = 4 * stddev;
+    const double coeff[10] = { 9.992604880e-1, -4.977025247e-1, 1.222248550e-1, -1.932406282e-2, 2.136713061e-3,
+                               -1.679873860e-4, 9.202145248e-6, -3.329417433e-7, 7.128382794e-9, -6.821193280e-11 };
+    double scale = 1;
+    for (int i = 0; i < 10; ++i) { f.coeff[i] = (float) (coeff[i] * scale); scale /= (double) stddev * (double) stddev; }
+    f.coeff[0] -= estrin10(f.radius * f.radius, f.coeff);
+    return f;
+}
+static inline float rfilter_eval(const RFilter &f, float x) { return std::fmax(estrin10(x * x, f.coeff), 0.f); }
+
+/* ImageBlock::put (src/render/imageblock.cpp:187-258 box, :444-540 coalesced JIT) */
+static inline void film_put(const OrcSensor &s, const RFilter &rf, float px, float py, const float v[4], float *film) {
+    uint32_t W = s.crop_width, H = s.crop_height;
+    if (rf.type == 0) {
+        int32_t x = (int32_t) std::floor(px) - (int32_t) s.crop_offset_x, y = (int32_t) std::floor(py) - (int32_t) s.crop_offset_y;
+        if ((uint32_t) x < W && (uint32_t) y < H) { float *p = film + 4 * ((size_t) y * W + x); for (int k = 0; k < 4; ++k) p[k] += v[k]; }
+        return;
+    }
+    uint32_t n = (uint32_t) std::ceil(rf.radius - .5f), count = 2 * n + 1;
+    int32_t ix = (int32_t) std::floor(px) - (int32_t) n, iy = (int32_t) std::floor(py) - (int32_t) n;
+    uint32_t x0 = (uint32_t) (ix - (int32_t) s.crop_offset_x), y0 = (uint32_t) (iy - (int32_t) s.crop_offset_y);
+    float relx = ((float) ix + .5f) - px, rely = ((float) iy + .5f) - py;
+    for (uint32_t ys = 0; ys < count; ++ys) {
+        float wy = rfilter_eval(rf, rely + (float) ys);
+        uint32_t y = y0 + ys;
+        if (!(y < H)) continue;
+        for (uint32_t xs = 0; xs < count; ++xs) {
+            uint32_t x = x0 + xs;
+            if (!(x < W)) continue;
+            float wx = rfilter_eval(rf, relx + (float) xs), w = wx * wy;
+            float *p = film + 4 * ((size_t) y * W + x);
+            for (int k = 0; k < 4; ++k) p[k] += v[k] * w;
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------
+//  Lane -> sample mapping (src/render/integrator.cpp:322-339, 448-520)
+// ---------------------------------------------------------------------------
+
+struct Lane { Pcg32 rng; float pos_x, pos_y, ipos_x, ipos_y; Ray ray; };
+static inline Lane make_lane(const OrcSensor &s, uint32_t seed, uint32_t spp, uint64_t idx) {
+    Lane L;
+    L.rng = sampler_seed(seed, (uint32_t) idx);
+    uint32_t lspp = 0; while ((1u << (lspp + 1)) <= spp) ++lspp;
+    uint32_t p = ((1u << lspp) == spp) ? (uint32_t) idx >> lspp : (uint32_t) idx / spp;
+    uint32_t y = p / s.crop_width, x = p - s.crop_width * y;
+    float jx = L.rng.next_float32(), jy = L.rng.next_float32();
+    L.ipos_x = (float) (int32_t) (x + s.crop_offset_x); L.ipos_y = (float) (int32_t) (y + s.crop_offset_y);
+    L.pos_x = L.ipos_x + jx;
+    L.pos_y = L.ipos_y + jy;
+    float sx = 1.f / (float) s.crop_width, sy = 1.f / (float) s.crop_height;
+    float ox = -(float) s.crop_offset_x * sx, oy = -(float) s.crop_offset_y * sy;
+    L.ray = sensor_sample_ray(s, fmadd(L.pos_x, sx, ox), fmadd(L.pos_y, sy, oy));
+    return L;
+}
+
+// ---------------------------------------------------------------------------
+//  PathIntegrator::sample (src/integrators/path.cpp:94-346), JIT semantics
+// ---------------------------------------------------------------------------
+
+static V3 path_sample(const Scene &sc, Pcg32 &rng, Ray ray, uint32_t max_depth, uint32_t rr_depth, bool &valid_ray, OrcStats &st) {
+    V3 throughput(1.f), result(0.f);
+    float eta = 1.f; uint32_t depth = 0; valid_ray = false;
+    V3 prev_p(0.f); float prev_bsdf_pdf = 1.f; bool prev_bsdf_delta = true;
+    if (max_depth == 0) return V3(0.f);
+    PI pi; st.closest_rays++; scene_trace<false>(sc, ray, pi, 0);
+    bool active = true;
+    while (active) {
+        st.vertices++;
+        SI si = compute_si(sc, ray, pi);
+        int emitter = si.valid() ? sc.meshes[si.mesh].emitter : -1;
+        if (emitter >= 0) {                                   // path.cpp:206-221
+            DS ds; ds.p = si.p; ds.n = si.sn;                 // records.h:77-79,173-180
+            V3 rel = si.p - prev_p; ds.dist = norm(rel); ds.d = div(rel, ds.dist);
+            float em_pdf = 0.f;
+            if (!prev_bsdf_delta) em_pdf = emitter_pdf_direction(sc.emitters[emitter], ds) * (1.f / (float) sc.emitters.size());
+            float mis_bsdf = mis_weight(prev_bsdf_pdf, em_pdf);
+            const OrcEmitter &e = sc.emitters[emitter];
+            V3 Le = (si.wi.z > 0.f && prev_bsdf_pdf > 0.f) ? V3(e.radiance[0], e.radiance[1], e.radiance[2]) : V3(0.f);   // area.cpp:83-90
+            result = fmadd(throughput, Le * mis_bsdf, result);
+        }
+        bool active_next = (depth + 1 < max_depth) && si.valid();
+        valid_ray |= si.valid();                              // path.cpp:307-308 (JIT: evaluated every iteration)
+        if (!active_next) break;                              // masked lane: state below is discarded
+        const OrcBSDF &bsdf = sc.bsdfs[sc.meshes[si.mesh].bsdf];
+        V3 refl = bsdf_reflectance(sc, bsdf, si);
+        // emitter sampling, path.cpp:238-258
+        float ex = rng.next_float32(), ey = rng.next_float32();
+        DS ds; V3 em_weight(0.f), wo(0.f);
+        bool active_em = sample_emitter_direction(sc, si, ex, ey, ds, em_weight, st);
+        active_em &= ds.pdf != 0.f;
+        if (active_em) wo = si.to_local(ds.d);
+        float s1 = rng.next_float32(); (void) s1;
+        float s2x = rng.next_float32(), s2y = rng.next_float32();
+        V3 bsdf_val, bsdf_weight, bwo; float bsdf_pdf, bs_pdf;
+        diffuse_eval_pdf(refl, si.wi, wo, bsdf_val, bsdf_pdf);
+        diffuse_sample(refl, si.wi, s2x, s2y, bwo, bs_pdf, bsdf_weight);
+        if (active_em) {                                      // path.cpp:271-281
+            float mis_em = mis_weight(ds.pdf, bsdf_pdf);
+            result = fmadd(throughput, (bsdf_val * em_weight) * mis_em, result);
+        }
+        ray = spawn_ray(si, si.to_world(bwo));                // path.cpp:287
+        throughput = throughput * bsdf_weight; eta *= 1.f;
+        prev_p = si.p; prev_bsdf_pdf = bs_pdf; prev_bsdf_delta = false;
+        depth += 1;                                           // path.cpp:317 (si valid here)
+        float tmax = hmax(throughput);
+        float rr_prob = std::fmin(tmax * sqr(eta), .95f);
+        bool rr_active = depth >= rr_depth, rr_continue = rng.next_float32() < rr_prob;
+        if (rr_active) throughput = throughput * rcp(rr_prob);
+        active = active_next && (!rr_active || rr_continue) && (tmax != 0.f);
+        if (active) { pi = PI(); st.closest_rays++; scene_trace<false>(sc, ray, pi, 0); }
+    }
+    return valid_ray ? result : V3(0.f);
+}
+
+// ---------------------------------------------------------------------------
+//  PRBIntegrator.sample (src/python/python/ad/integrators/prb.py:68-339)
+//  mode Primal:   returns L.
+//  mode Backward: L_in = primal L, dL = film adjoint; accumulates the
+//  hand-derived gradients of SURVEY.md Appendix B into `grad`.
+// ---------------------------------------------------------------------------
+
+struct GradSink { float *refl; float *const *tex; };
+
+static V3 prb_sample(const Scene &sc, Pcg32 &rng, Ray ray, uint32_t max_depth, uint32_t rr_depth, bool primal,
+                     V3 L_in, V3 dL, const GradSink *grad, bool &valid, OrcStats &st) {
+    uint32_t depth = 0; V3 L = primal ? V3(0.f) : L_in; V3 beta(1.f); float eta = 1.f;
+    bool active = true;
+    PI pi; st.closest_rays++; scene_trace<false>(sc, ray, pi, 0);
+    V3 prev_p(0.f); float bsdf_pdf_prev = 1.f; bool bsdf_delta_prev = true;
+    uint32_t iter = 0;
+    while (active && iter < max_depth) {                      // prb.py:121-123 (max_iterations)
+        ++iter; st.vertices++;
+        bool active_next = true;
+        SI si = compute_si(sc, ray, pi);
+        int emitter = si.valid() ? sc.meshes[si.mesh].emitter : -1;
+        // prb.py:153-161
+        V3 Le(0.f);
+        {
+            float em_pdf = 0.f;
+            DS ds; ds.p = si.p; ds.n = si.sn;
+            V3 rel = si.p - prev_p; ds.dist = norm(rel); ds.d = si.valid() ? div(rel, ds.dist) : -si.wi;
+            if (emitter >= 0 && !bsdf_delta_prev) em_pdf = emitter_pdf_direction(sc.emitters[emitter], ds) * (1.f / (float) sc.emitters.size());
+            float mis = mis_weight(bsdf_pdf_prev, em_pdf);
+            if (emitter >= 0) {
+                const OrcEmitter &e = sc.emitters[emitter];
+                V3 ev = si.wi.z > 0.f ? V3(e.radiance[0], e.radiance[1], e.radiance[2]) : V3(0.f);
+                Le = (beta * mis) * ev;
+            }
+        }
+        active_next &= (depth + 1 < max_depth) && si.valid();  // prb.py:166
+        bool active_em = active_next;                            // diffuse is Smooth
+        float ex = rng.next_float32(), ey = rng.next_float32();
+        DS ds; V3 em_weight(0.f);
+        V3 refl(0.f); TexLookup tl{}; const OrcBSDF *bsdf = nullptr;
+        if (si.valid()) {
+            bsdf = &sc.bsdfs[sc.meshes[si.mesh].bsdf];
+            if (bsdf->texture >= 0) { tex_lookup(sc.textures[bsdf->texture], si.uv, tl); refl = tex_eval(sc.textures[bsdf->texture], tl); }
+            else refl = V3(bsdf->reflectance[0], bsdf->reflectance[1], bsdf->reflectance[2]);
+        }
+        if (active_em) { sample_emitter_direction(sc, si, ex, ey, ds, em_weight, st); active_em &= ds.pdf != 0.f; }
+        // prb.py:210-216
+        V3 Lr_dir(0.f), dLr_dir_drho(0.f);
+        if (active_em) {
+            V3 wo = si.to_local(ds.d);
+            V3 bsdf_value_em; float bsdf_pdf_em;
+            diffuse_eval_pdf(refl, si.wi, wo, bsdf_value_em, bsdf_pdf_em);
+            float mis_em = mis_weight(ds.pdf, bsdf_pdf_em);
+            Lr_dir = ((beta * mis_em) * bsdf_value_em) * em_weight;
+            bool a = si.wi.z > 0.f && wo.z > 0.f;
+            if (a) dLr_dir_drho = ((beta * mis_em) * (InvPi * wo.z)) * em_weight;      // d/d rho of the line above
+        }
+        // detached BSDF sampling, prb.py:220-223 (masked lanes return zeros)
+        float s1 = rng.next_float32(); (void) s1;
+        float s2x = rng.next_float32(), s2y = rng.next_float32();
+        V3 bwo(0.f), bsdf_weight(0.f); float bs_pdf = 0.f, bs_eta = 0.f;
+        if (active_next) { diffuse_sample(refl, si.wi, s2x, s2y, bwo, bs_pdf, bsdf_weight); bs_eta = 1.f; }
+        L = primal ? (L + Le) + Lr_dir : (L - Le) - Lr_dir;      // prb.py:227
+        Ray ray_next = spawn_ray(si, si.to_world(bwo));
+        eta *= bs_eta; beta = beta * bsdf_weight;
+        prev_p = si.p; bsdf_pdf_prev = bs_pdf; bsdf_delta_prev = false;
+        float beta_max = hmax(beta);
+        active_next &= beta_max != 0.f;
+        float rr_prob = std::fmin(beta_max * (eta * eta), .95f);
+        bool rr_active = depth >= rr_depth;                      // prb.py:249 (depth NOT yet incremented)
+        if (rr_active) beta = beta * rcp(rr_prob);
+        bool rr_continue = rng.next_float32() < rr_prob;
+        active_next &= !rr_active || rr_continue;
+        PI pi_next;
+        if (active_next) { st.closest_rays++; scene_trace<false>(sc, ray_next, pi_next, 0); }
+        if (!primal && grad && si.valid() && bsdf) {            // prb.py:263-313 specialised
+            V3 wo = si.to_local(ray_next.d);
+            bool a = active_next && si.wi.z > 0.f && wo.z > 0.f; // bsdf.eval(si, wo, active_next) != 0
+            V3 g = dLr_dir_drho;
+            if (a) g = g + V3(refl.x != 0.f ? L.x / refl.x : 0.f, refl.y != 0.f ? L.y / refl.y : 0.f, refl.z != 0.f ? L.z / refl.z : 0.f);
+            g = g * dL;
+            if (bsdf->texture < 0) {
+                float *dst = grad->refl + 3 * (size_t) sc.meshes[si.mesh].bsdf;
+                dst[0] += g.x; dst[1] += g.y; dst[2] += g.z;
+            } else {
+                float *dst = grad->tex[bsdf->texture];
+                const float wts[4] = { tl.w[0] * tl.w[2], tl.w[1] * tl.w[2], tl.w[0] * tl.w[3], tl.w[1] * tl.w[3] };
+                for (int k = 0; k < 4; ++k) { float *q = dst + 3 * (size_t) tl.idx[k]; q[0] += g.x * wts[k]; q[1] += g.y * wts[k]; q[2] += g.z * wts[k]; }
+            }
+        }
+        if (si.valid()) depth += 1;                               // prb.py:326
+        active = active_next; pi = pi_next; ray = ray_next;
+    }
+    valid = depth != 0;
+    return L;
+}
+
+// ---------------------------------------------------------------------------
+//  Drivers (SamplingIntegrator::render, integrator.cpp:276-388;
+//  ADIntegrator.render / RBIntegrator.render_backward, common.py:46-110,625-783)
+// ---------------------------------------------------------------------------
+
+template <typename Fn>
+static void parallel_lanes(uint64_t begin, uint64_t end, int threads, Fn fn) {
+    if (threads <= 0) threads = (int) std::thread::hardware_concurrency();
+    if (threads < 1) threads = 1;
+    uint64_t n = end - begin;
+    if (n < 4096 || threads == 1) { fn(0, begin, end); return; }
+    std::vector<std::thread> pool;
+    std::atomic<uint64_t> next(begin);
+    const uint64_t chunk = 16384;
+    for (int t = 0; t < threads; ++t)
+        pool.emplace_back([&, t]() {
+            for (;;) { uint64_t b = next.fetch_add(chunk); if (b >= end) break; fn(t, b, std::min(end, b + chunk)); }
+        });
+    for (auto &th : pool) th.join();
+}
+
+static int resolve_threads(int threads) {
+    if (threads <= 0) threads = (int) std::thread::hardware_concurrency();
+    return threads < 1 ? 1 : threads;
+}
+
+static void merge_stats(OrcStats *dst, const std::vector<OrcStats> &src) {
+    if (!dst) return;
+    for (const auto &s : src) { dst->paths += s.paths; dst->vertices += s.vertices; dst->closest_rays += s.closest_rays; dst->shadow_rays += s.shadow_rays; }
+}
+
+static int render_forward(Scene &sc, const OrcSensor &s, uint32_t seed, uint32_t spp, int32_t max_depth, int32_t rr_depth,
+                          uint64_t lb, uint64_t le, float *film, OrcStats *stats, int threads, bool prb) {
+    uint64_t total = (uint64_t) s.crop_width * s.crop_height * spp;
+    if (lb == 0 && le == 0) le = total;
+    if (le > total || lb > le || total > 0xffffffffull) return -1;
+    RFilter rf = make_rfilter(s.rfilter, s.rfilter_stddev);
+    threads = resolve_threads(threads);
+    size_t fsz = (size_t) s.crop_width * s.crop_height * 4;
+    std::vector<std::vector<float>> films(threads);
+    std::vector<OrcStats> sts(threads, OrcStats{});
+    uint32_t md = (uint32_t) max_depth, rd = (uint32_t) rr_depth;
+    parallel_lanes(lb, le, threads, [&](int t, uint64_t b, uint64_t e) {
+        if (films[t].empty()) films[t].assign(fsz, 0.f);
+        for (uint64_t i = b; i < e; ++i) {
+            Lane L = make_lane(s, seed, spp, i);
+            bool valid; V3 rgb;
+            if (prb) rgb = prb_sample(sc, L.rng, L.ray, md, rd, true, V3(0.f), V3(0.f), nullptr, valid, sts[t]);
+            else     rgb = path_sample(sc, L.rng, L.ray, md, rd, valid, sts[t]);
+            sts[t].paths++;
+            float v[4] = { rgb.x, rgb.y, rgb.z, 1.f };
+            film_put(s, rf, rf.type == 0 ? L.ipos_x : L.pos_x, rf.type == 0 ? L.ipos_y : L.pos_y, v, films[t].data());
+        }
+    });
+    for (auto &f : films) if (!f.empty()) for (size_t i = 0; i < fsz; ++i) film[i] += f[i];
+    merge_stats(stats, sts);
+    return 0;
+}
+
+} // namespace
+
+// ===========================================================================
+//  C ABI
+// ===========================================================================
+
+extern "C" {
+
+void *orc_scene_create(const OrcSceneDesc *d) {
+    Scene *sc = new Scene();
+    sc->top_count = d->top_mesh_count;
+    for (uint32_t i = 0; i < d->mesh_count; ++i) {
+        const OrcMesh &m = d->meshes[i]; Mesh o;
+        o.V.assign(m.vertex_ptr, m.vertex_ptr + 8 * (size_t) m.vertex_count);
+        o.F.assign(m.index_ptr, m.index_ptr + 4 * (size_t) m.face_count);
+        o.nv = m.vertex_count; o.nf = m.face_count; o.bsdf = m.bsdf; o.emitter = m.emitter; o.flags = m.flags;
+        sc->meshes.push_back(std::move(o));
+    }
+    sc->groups.assign(d->groups, d->groups + d->group_count);
+    sc->instances.assign(d->instances, d->instances + d->instance_count);
+    sc->bsdfs.assign(d->bsdfs, d->bsdfs + d->bsdf_count);
+    for (uint32_t i = 0; i < d->texture_count; ++i) {
+        Texture t; t.w = d->textures[i].width; t.h = d->textures[i].height;
+        t.data.assign(d->textures[i].data, d->textures[i].data + 3 * (size_t) t.w * t.h);
+        sc->textures.push_back(std::move(t));
+    }
+    sc->emitters.assign(d->emitters, d->emitters + d->emitter_count);
+    build_tri_bvh(sc->top, sc->meshes, 0, sc->top_count);
+    sc->group_bvh.resize(sc->groups.size());
+    for (size_t g = 0; g < sc->groups.size(); ++g) build_tri_bvh(sc->group_bvh[g], sc->meshes, sc->groups[g].first_mesh, sc->groups[g].mesh_count);
+    if (!sc->instances.empty()) {                      // Instance::bbox (instance.cpp:93-103)
+        std::vector<BuildPrim> prims;
+        for (uint32_t i = 0; i < sc->instances.size(); ++i) {
+            const Bvh &b = sc->group_bvh[sc->instances[i].group];
+            BuildPrim p; p.id = i;
+            for (int a = 0; a < 3; ++a) { p.lo[a] = Infinity; p.hi[a] = -Infinity; }
+            if (!b.empty())
+                for (int c = 0; c < 8; ++c) {
+                    V3 q = xf_point(sc->instances[i].to_world, V3(c & 1 ? b.hi[0] : b.lo[0], c & 2 ? b.hi[1] : b.lo[1], c & 4 ? b.hi[2] : b.lo[2]));
+                    for (int a = 0; a < 3; ++a) { p.lo[a] = std::min(p.lo[a], q[a]); p.hi[a] = std::max(p.hi[a], q[a]); }
+                }
+            pad_box(p.lo, p.hi);
+            for (int a = 0; a < 3; ++a) p.c[a] = 0.5f * (p.lo[a] + p.hi[a]);
+            prims.push_back(p);
+        }
+        sc->inst_nodes.emplace_back();
+        build_rec(sc->inst_nodes, prims, 0, (uint32_t) prims.size(), 0, 2);
+        for (auto &p : prims) sc->inst_order.push_back(p.id);
+    }
+    return sc;
+}
+void orc_scene_destroy(void *s) { delete (Scene *) s; }
+void orc_scene_set_reflectance(void *s, uint32_t b, const float rgb[3]) { for (int i = 0; i < 3; ++i) ((Scene *) s)->bsdfs[b].reflectance[i] = rgb[i]; }
+void orc_scene_set_texture(void *s, uint32_t t, const float *data) { Texture &x = ((Scene *) s)->textures[t]; x.data.assign(data, data + 3 * (size_t) x.w * x.h); }
+
+void orc_ray_intersect(void *scene, uint32_t n, const float *o, const float *d, const float *maxt, int mode,
+                       float *t, float *u, float *v, uint32_t *prim, uint32_t *shape, uint32_t *inst) {
+    const Scene &sc = *(Scene *) scene;
+    parallel_lanes(0, n, 0, [&](int, uint64_t b, uint64_t e) {
+        for (uint64_t i = b; i < e; ++i) {
+            Ray r; r.o = V3(o[i], o[n + i], o[2 * (size_t) n + i]); r.d = V3(d[i], d[n + i], d[2 * (size_t) n + i]); r.maxt = maxt[i];
+            PI pi; scene_trace<false>(sc, r, pi, mode);
+            t[i] = pi.t; u[i] = pi.u; v[i] = pi.v; prim[i] = pi.prim; shape[i] = pi.shape; inst[i] = pi.inst;
+        }
+    });
+}
+void orc_ray_test(void *scene, uint32_t n, const float *o, const float *d, const float *maxt, int mode, uint8_t *hit) {
+    const Scene &sc = *(Scene *) scene;
+    parallel_lanes(0, n, 0, [&](int, uint64_t b, uint64_t e) {
+        for (uint64_t i = b; i < e; ++i) {
+            Ray r; r.o = V3(o[i], o[n + i], o[2 * (size_t) n + i]); r.d = V3(d[i], d[n + i], d[2 * (size_t) n + i]); r.maxt = maxt[i];
+            PI pi; hit[i] = scene_trace<true>(sc, r, pi, mode) ? 1 : 0;
+        }
+    });
+}
+
+int orc_render_path(void *scene, const OrcSensor *s, uint32_t seed, uint32_t spp, int32_t max_depth, int32_t rr_depth,
+                    uint64_t lb, uint64_t le, float *film, OrcStats *stats, int threads) {
+    return render_forward(*(Scene *) scene, *s, seed, spp, max_depth, rr_depth, lb, le, film, stats, threads, false);
+}
+int orc_render_prb(void *scene, const OrcSensor *s, uint32_t seed, uint32_t spp, int32_t max_depth, int32_t rr_depth,
+                   uint64_t lb, uint64_t le, float *film, OrcStats *stats, int threads) {
+    return render_forward(*(Scene *) scene, *s, seed, spp, max_depth, rr_depth, lb, le, film, stats, threads, true);
+}
+
+int orc_render_prb_backward(void *scene, const OrcSensor *sp, const float *grad_in, uint32_t seed, uint32_t spp,
+                            int32_t max_depth, int32_t rr_depth, float *grad_reflectance, float *const *grad_textures,
+                            OrcStats *stats, int threads) {
+    Scene &sc = *(Scene *) scene; const OrcSensor &s = *sp;
+    uint64_t total = (uint64_t) s.crop_width * s.crop_height * spp;
+    if (total > 0xffffffffull) return -1;
+    RFilter rf = make_rfilter(s.rfilter, s.rfilter_stddev);
+    threads = resolve_threads(threads);
+    uint32_t W = s.crop_width, H = s.crop_height;
+    size_t npx = (size_t) W * H;
+    // (1) weight-only splat: W[px] of the dummy L=1 film (common.py:716-746)
+    std::vector<float> wfilm(npx * 4, 0.f);
+    {
+        std::vector<std::vector<float>> films(threads);
+        parallel_lanes(0, total, threads, [&](int t, uint64_t b, uint64_t e) {
+            if (films[t].empty()) films[t].assign(npx * 4, 0.f);
+            for (uint64_t i = b; i < e; ++i) {
+                Lane L = make_lane(s, seed, spp, i);
+                float v[4] = { 0.f, 0.f, 0.f, 1.f };
+                film_put(s, rf, rf.type == 0 ? L.ipos_x : L.pos_x, rf.type == 0 ? L.ipos_y : L.pos_y, v, films[t].data());
+            }
+        });
+        for (auto &f : films) if (!f.empty()) for (size_t i = 0; i < npx * 4; ++i) wfilm[i] += f[i];
+    }
+    // adjoint image: grad_in / W  (adjoint of hdrfilm.cpp:398-399)
+    std::vector<float> adj(npx * 3);
+    for (size_t i = 0; i < npx; ++i) { float w = wfilm[4 * i + 3]; float iw = w == 0.f ? 1.f : w; for (int c = 0; c < 3; ++c) adj[3 * i + c] = grad_in[3 * i + c] / iw; }
+    // per-thread gradient buffers
+    size_t nb = sc.bsdfs.size();
+    std::vector<std::vector<float>> g_refl(threads);
+    std::vector<std::vector<std::vector<float>>> g_tex(threads);
+    std::vector<OrcStats> sts(threads, OrcStats{});
+    uint32_t md = (uint32_t) max_depth, rd = (uint32_t) rr_depth;
+    parallel_lanes(0, total, threads, [&](int t, uint64_t b, uint64_t e) {
+        if (g_refl[t].empty()) {
+            g_refl[t].assign(3 * nb + 3, 0.f);
+            g_tex[t].resize(sc.textures.size());
+            for (size_t k = 0; k < sc.textures.size(); ++k) g_tex[t][k].assign(3 * (size_t) sc.textures[k].w * sc.textures[k].h, 0.f);
+        }
+        std::vector<float *> tp(sc.textures.size() + 1, nullptr);
+        for (size_t k = 0; k < sc.textures.size(); ++k) tp[k] = g_tex[t][k].data();
+        GradSink sink{ g_refl[t].data(), tp.data() };
+        for (uint64_t i = b; i < e; ++i) {
+            Lane L = make_lane(s, seed, spp, i);
+            // dL = adjoint of the splat (gather over the filter footprint)
+            V3 dL(0.f);
+            {
+                float px = rf.type == 0 ? L.ipos_x : L.pos_x, py = rf.type == 0 ? L.ipos_y : L.pos_y;
+                if (rf.type == 0) {
+                    int32_t x = (int32_t) std::floor(px) - (int32_t) s.crop_offset_x, y = (int32_t) std::floor(py) - (int32_t) s.crop_offset_y;
+                    if ((uint32_t) x < W && (uint32_t) y < H) { const float *a = &adj[3 * ((size_t) y * W + x)]; dL = V3(a[0], a[1], a[2]); }
+                } else {
+                    uint32_t n = (uint32_t) std::ceil(rf.radius - .5f), count = 2 * n + 1;
+                    int32_t ix = (int32_t) std::floor(px) - (int32_t) n, iy = (int32_t) std::floor(py) - (int32_t) n;
+                    uint32_t x0 = (uint32_t) (ix - (int32_t) s.crop_offset_x), y0 = (uint32_t) (iy - (int32_t) s.crop_offset_y);
+                    float relx = ((float) ix + .5f) - px, rely = ((float) iy + .5f) - py;
+                    for (uint32_t ys = 0; ys < count; ++ys) {
+                        uint32_t y = y0 + ys; if (!(y < H)) continue;
+                        float wy = rfilter_eval(rf, rely + (float) ys);
+                        for (uint32_t xs = 0; xs < count; ++xs) {
+                            uint32_t x = x0 + xs; if (!(x < W)) continue;
+                            float w = rfilter_eval(rf, relx + (float) xs) * wy;
+                            const float *a = &adj[3 * ((size_t) y * W + x)];
+                            dL = V3(fmadd(a[0], w, dL.x), fmadd(a[1], w, dL.y), fmadd(a[2], w, dL.z));
+                        }
+                    }
+                }
+            }
+            bool valid;
+            Pcg32 rng2 = L.rng;                               // sampler.clone(): identical stream (common.py:755,768)
+            OrcStats dummy{};
+            V3 Lp = prb_sample(sc, rng2, L.ray, md, rd, true, V3(0.f), V3(0.f), nullptr, valid, dummy);
+            prb_sample(sc, L.rng, L.ray, md, rd, false, Lp, dL, &sink, valid, sts[t]);
+            sts[t].paths++;
+        }
+    });
+    for (int t = 0; t < threads; ++t) {
+        if (g_refl[t].empty()) continue;
+        if (grad_reflectance) for (size_t i = 0; i < 3 * nb; ++i) grad_reflectance[i] += g_refl[t][i];
+        for (size_t k = 0; k < sc.textures.size(); ++k)
+            if (grad_textures && grad_textures[k]) { float *dst = grad_textures[k]; for (size_t i = 0; i < g_tex[t][k].size(); ++i) dst[i] += g_tex[t][k][i]; }
+    }
+    merge_stats(stats, sts);
+    return 0;
+}
+
+void orc_film_develop(const float *film, uint32_t width, uint32_t height, float *image) {
+    for (size_t i = 0; i < (size_t) width * height; ++i) {
+        float w = film[4 * i + 3]; float dv = w == 0.f ? 1.f : w;
+        for (int c = 0; c < 3; ++c) image[3 * i + c] = film[4 * i + c] / dv;
+    }
+}
+
+// ---- unit-level ----
+void orc_sample_tea_32(uint32_t v0, uint32_t v1, int rounds, uint32_t out[2]) { sample_tea_32(v0, v1, rounds, out[0], out[1]); }
+/* random.h:135-140 / 160-166: mantissa fill + subtract 1 */
+float orc_sample_tea_float32(uint32_t v0, uint32_t v1, int rounds) { uint32_t a, b; sample_tea_32(v0, v1, rounds, a, b); return u2f((b >> 9) | 0x3f800000u) - 1.f; }
+double orc_sample_tea_float64(uint32_t v0, uint32_t v1, int rounds) {
+    uint32_t a, b; sample_tea_32(v0, v1, rounds, a, b);
+    uint64_t v = (uint64_t) a + ((uint64_t) b << 32);
+    uint64_t bits = (v >> 12) | 0x3ff0000000000000ull; double dd; std::memcpy(&dd, &bits, 8); return dd - 1.0;
+}
+void orc_pcg32_seed(uint64_t initstate, uint64_t initseq, uint64_t si[2]) { Pcg32 r; r.seed(initstate, initseq); si[0] = r.state; si[1] = r.inc; }
+uint32_t orc_pcg32_next_uint32(uint64_t si[2]) { Pcg32 r; r.state = si[0]; r.inc = si[1]; uint32_t v = r.next_uint32(); si[0] = r.state; return v; }
+float orc_pcg32_next_float32(uint64_t si[2]) { Pcg32 r; r.state = si[0]; r.inc = si[1]; float v = r.next_float32(); si[0] = r.state; return v; }
+void orc_sampler_stream(uint32_t seed, uint32_t lane, uint32_t n, float *out) { Pcg32 r = sampler_seed(seed, lane); for (uint32_t i = 0; i < n; ++i) out[i] = r.next_float32(); }
+float orc_rfilter_eval(uint32_t type, float stddev, float x) { RFilter f = make_rfilter(type, stddev); return type == 0 ? (std::fabs(x) <= .5f ? 1.f : 0.f) : rfilter_eval(f, x); }
+void orc_film_put(const OrcSensor *s, uint32_t n, const float *px, const float *py, const float *values4, float *film) {
+    RFilter rf = make_rfilter(s->rfilter, s->rfilter_stddev);
+    for (uint32_t i = 0; i < n; ++i) film_put(*s, rf, px[i], py[i], values4 + 4 * (size_t) i, film);
+}
+void orc_sensor_sample_ray(const OrcSensor *s, uint32_t n, const float *px, const float *py, float *o, float *d, float *maxt) {
+    for (uint32_t i = 0; i < n; ++i) {
+        Ray r = sensor_sample_ray(*s, px[i], py[i]);
+        o[i] = r.o.x; o[n + i] = r.o.y; o[2 * (size_t) n + i] = r.o.z;
+        d[i] = r.d.x; d[n + i] = r.d.y; d[2 * (size_t) n + i] = r.d.z; maxt[i] = r.maxt;
+    }
+}
+void orc_diffuse_eval_pdf(const float refl[3], const float wi[3], const float wo[3], float value[3], float *pdf) {
+    V3 v; diffuse_eval_pdf(V3(refl[0], refl[1], refl[2]), V3(wi[0], wi[1], wi[2]), V3(wo[0], wo[1], wo[2]), v, *pdf);
+    value[0] = v.x; value[1] = v.y; value[2] = v.z;
+}
+void orc_diffuse_sample(const float refl[3], const float wi[3], float, const float s2[2], float wo[3], float *pdf, float weight[3]) {
+    V3 w, wt; diffuse_sample(V3(refl[0], refl[1], refl[2]), V3(wi[0], wi[1], wi[2]), s2[0], s2[1], w, *pdf, wt);
+    wo[0] = w.x; wo[1] = w.y; wo[2] = w.z; weight[0] = wt.x; weight[1] = wt.y; weight[2] = wt.z;
+}
+void orc_square_to_cosine_hemisphere(const float s[2], float out[3]) { V3 v = square_to_cosine_hemisphere(s[0], s[1]); out[0] = v.x; out[1] = v.y; out[2] = v.z; }
+void orc_coordinate_system(const float n[3], float s[3], float t[3]) { V3 a, b; coordinate_system(V3(n[0], n[1], n[2]), a, b); s[0] = a.x; s[1] = a.y; s[2] = a.z; t[0] = b.x; t[1] = b.y; t[2] = b.z; }
+float orc_sincos(float x, float *c) { return sincos(x, c); }
+void orc_surface_interaction(void *scene, const float o[3], const float d[3], float t, float u, float v, uint32_t prim,
+                             uint32_t shape, uint32_t inst, float out[24]) {
+    const Scene &sc = *(Scene *) scene;
+    Ray r; r.o = V3(o[0], o[1], o[2]); r.d = V3(d[0], d[1], d[2]); r.maxt = Largest;
+    PI pi; pi.t = t; pi.u = u; pi.v = v; pi.prim = prim; pi.shape = shape; pi.inst = inst;
+    SI si = compute_si(sc, r, pi);
+    const V3 vs[6] = { si.p, si.n, si.sn, si.ss, si.st, si.wi };
+    for (int i = 0; i < 6; ++i) { out[3 * i] = vs[i].x; out[3 * i + 1] = vs[i].y; out[3 * i + 2] = vs[i].z; }
+    out[18] = si.uv[0]; out[19] = si.uv[1]; out[20] = si.t; out[21] = out[22] = out[23] = 0.f;
+}
+
+} // extern "C"

@@ -1,0 +1,190 @@
+/*
+ * mi_oracle.h -- C ABI of the CPU ORACLE for the hip_ad_rgb hot path.
+ *
+ * TEST INFRASTRUCTURE ONLY.  This library is a CPU restatement of the
+ * reference's (mitsuba3 v3.9.1, variant llvm_ad_rgb) wavefront path tracing
+ * path; it exists so that tests/, __graft_entry__.smoke() and bench.py's
+ * `cpu_baseline` leg can check / time the HIP product against it.  Nothing in
+ * mitsuba3_amd/ may include, link, import or call it.
+ *
+ * PARITY STATUS: the real reference cannot be built or imported in this
+ * environment (ext/drjit, ext/embree, ext/nanobind are empty; no wheel, no
+ * network -- SURVEY.md 8c).  The oracle is therefore pinned ONLY by the
+ * asset-free known-answer tests that the reference's own test-suite holds for
+ * this path (TEA KATs, diffuse closed form, Cornell pixel (124,36), stairs
+ * analytic depth, brute-force == accelerated, AD linearity / finite
+ * differences, ImageBlock-vs-NumPy) and by the published PCG32 test vector.
+ * Arithmetic that lives in Dr.Jit / Embree (NOT IN TREE: PCG32, sincos
+ * polynomial, rcp/rsqrt lowering, dot/cross fma order, bilinear texture
+ * fetch, Embree's triangle test) is restated from the published algorithms:
+ * for those pieces the header says "parity unpinned".
+ *
+ * All struct layouts below are plain C, 8-byte aligned, and intentionally
+ * identical (field for field) to include/hip_ad_rgb.h so that one set of
+ * host arrays can be fed to both the oracle and the product in a test.
+ */
+#pragma once
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+/* Triangle mesh in the reference's packed layout
+ * (include/mitsuba/render/mesh_utils.h:19-34, mesh.h:137-156):
+ * 8 x f32 per vertex {pos[3], normal[3], uv[2]}, 4 x u32 per face
+ * {v0, v1, v2, flags}. */
+typedef struct OrcMesh {
+    const float    *vertex_ptr;
+    const uint32_t *index_ptr;
+    uint32_t vertex_count, face_count;
+    uint32_t bsdf;      /* index into OrcSceneDesc::bsdfs */
+    int32_t  emitter;   /* index into OrcSceneDesc::emitters or -1 */
+    uint32_t flags;     /* bit0: has vertex normals, bit1: has texcoords */
+    uint32_t reserved;
+} OrcMesh;
+
+typedef struct OrcShapeGroup { uint32_t first_mesh, mesh_count; } OrcShapeGroup;
+
+/* column-major 3x4 affine, like ShapeIR::to_world (scene_ir.h:103-105) */
+typedef struct OrcInstance {
+    uint32_t group;
+    float to_world[12];
+    float to_object[12];
+} OrcInstance;
+
+typedef struct OrcBSDF {
+    uint32_t type;        /* 0 = diffuse (src/bsdfs/diffuse.cpp) */
+    int32_t  texture;     /* -1: constant `reflectance`, else index of bitmap */
+    float    reflectance[3];
+} OrcBSDF;
+
+/* bitmap texture, H x W x 3 f32, bilinear + repeat (src/textures/bitmap.cpp:175-206) */
+typedef struct OrcTexture { const float *data; uint32_t width, height; } OrcTexture;
+
+typedef struct OrcEmitter {
+    uint32_t type;        /* 0 = area light on a rectangle */
+    uint32_t mesh;        /* mesh that carries the emitter */
+    float radiance[3];
+    float to_world[12];   /* rectangle to_world, column-major 3x4 */
+    float normal[3];      /* m_frame.n (rectangle.cpp:118) */
+    float inv_area;       /* m_inv_surface_area (rectangle.cpp:123) */
+} OrcEmitter;
+
+typedef struct OrcSceneDesc {
+    const OrcMesh       *meshes;    uint32_t mesh_count, top_mesh_count;
+    const OrcShapeGroup *groups;    uint32_t group_count, pad0;
+    const OrcInstance   *instances; uint32_t instance_count, pad1;
+    const OrcBSDF       *bsdfs;     uint32_t bsdf_count, pad2;
+    const OrcTexture    *textures;  uint32_t texture_count, pad3;
+    const OrcEmitter    *emitters;  uint32_t emitter_count, pad4;
+} OrcSceneDesc;
+
+/* perspective sensor + hdrfilm + rfilter, everything already lowered to the
+ * matrices the reference keeps (perspective.cpp:174-198) */
+typedef struct OrcSensor {
+    float sample_to_camera[16];   /* row-major 4x4 */
+    float to_world[16];           /* row-major 4x4 (camera -> world) */
+    float near_clip, far_clip;
+    uint32_t film_width, film_height;
+    uint32_t crop_offset_x, crop_offset_y, crop_width, crop_height;
+    uint32_t rfilter;             /* 0 = box, 1 = gaussian */
+    float    rfilter_stddev;
+} OrcSensor;
+
+typedef struct OrcStats {
+    uint64_t paths;
+    uint64_t vertices;     /* loop iterations summed over paths (K-bar = vertices/paths) */
+    uint64_t closest_rays;
+    uint64_t shadow_rays;
+} OrcStats;
+
+/* ---- scene ---- */
+void *orc_scene_create(const OrcSceneDesc *desc);
+void  orc_scene_destroy(void *scene);
+/* update a constant reflectance / a texture in place (for finite differences) */
+void  orc_scene_set_reflectance(void *scene, uint32_t bsdf, const float rgb[3]);
+void  orc_scene_set_texture(void *scene, uint32_t texture, const float *data);
+
+/* ---- ray queries: Scene::ray_intersect_preliminary / ray_test / _naive ---- */
+/* mode: 0 = BVH, 1 = brute force.  rays SoA: o[3][n], d[3][n], maxt[n]. */
+void orc_ray_intersect(void *scene, uint32_t n, const float *o, const float *d,
+                       const float *maxt, int mode, float *t, float *u, float *v,
+                       uint32_t *prim, uint32_t *shape, uint32_t *inst);
+void orc_ray_test(void *scene, uint32_t n, const float *o, const float *d,
+                  const float *maxt, int mode, uint8_t *hit);
+
+/* ---- integrators ----
+ * lanes [lane_begin, lane_end) of the reference's wavefront ordering are
+ * rendered; film is the raw H x W x 4 {R,G,B,W} accumulation buffer (added
+ * to, not cleared).  Pass 0,0 for "all lanes". */
+int orc_render_path(void *scene, const OrcSensor *s, uint32_t seed, uint32_t spp,
+                    int32_t max_depth, int32_t rr_depth, uint64_t lane_begin,
+                    uint64_t lane_end, float *film, OrcStats *stats, int threads);
+/* prb primal (prb.py:68 mode=Primal) */
+int orc_render_prb(void *scene, const OrcSensor *s, uint32_t seed, uint32_t spp,
+                   int32_t max_depth, int32_t rr_depth, uint64_t lane_begin,
+                   uint64_t lane_end, float *film, OrcStats *stats, int threads);
+/* RBIntegrator.render_backward (common.py:625-783): grad_in is H x W x 3;
+ * grad_reflectance is bsdf_count x 3 (constant albedos), grad_textures[i] is
+ * H_i x W_i x 3 per bitmap (may be NULL when texture_count == 0). All added to. */
+int orc_render_prb_backward(void *scene, const OrcSensor *s, const float *grad_in,
+                            uint32_t seed, uint32_t spp, int32_t max_depth,
+                            int32_t rr_depth, float *grad_reflectance,
+                            float *const *grad_textures, OrcStats *stats, int threads);
+/* HDRFilm::develop (hdrfilm.cpp:398-399): image[h][w][3] = RGB / (W==0?1:W) */
+void orc_film_develop(const float *film, uint32_t width, uint32_t height, float *image);
+
+/* ---- unit-level entry points (KATs) ---- */
+void     orc_sample_tea_32(uint32_t v0, uint32_t v1, int rounds, uint32_t out[2]);
+float    orc_sample_tea_float32(uint32_t v0, uint32_t v1, int rounds);
+double   orc_sample_tea_float64(uint32_t v0, uint32_t v1, int rounds);
+void     orc_pcg32_seed(uint64_t initstate, uint64_t initseq, uint64_t state_inc[2]);
+uint32_t orc_pcg32_next_uint32(uint64_t state_inc[2]);
+float    orc_pcg32_next_float32(uint64_t state_inc[2]);
+/* the first n floats lane `lane` of a wavefront sampler seeded with `seed` draws
+ * (sampler.cpp:129-148 + independent.cpp:77-97) */
+void  orc_sampler_stream(uint32_t seed, uint32_t lane, uint32_t n, float *out);
+float orc_rfilter_eval(uint32_t rfilter, float stddev, float x);
+/* ImageBlock::put, coalesced JIT branch (imageblock.cpp:444-540) */
+void  orc_film_put(const OrcSensor *s, uint32_t n, const float *pos_x,
+                   const float *pos_y, const float *values4, float *film);
+/* PerspectiveCamera::sample_ray (perspective.cpp:200-237) on adjusted positions */
+void  orc_sensor_sample_ray(const OrcSensor *s, uint32_t n, const float *px,
+                            const float *py, float *o, float *d, float *maxt);
+/* SmoothDiffuse on a canonical frame (wi given in local coords) */
+void  orc_diffuse_eval_pdf(const float refl[3], const float wi[3], const float wo[3],
+                           float value[3], float *pdf);
+void  orc_diffuse_sample(const float refl[3], const float wi[3], float s1,
+                         const float s2[2], float wo[3], float *pdf, float weight[3]);
+void  orc_square_to_cosine_hemisphere(const float s[2], float out[3]);
+void  orc_coordinate_system(const float n[3], float s[3], float t[3]);
+float orc_sincos(float x, float *c); /* returns sin */
+/* full SurfaceInteraction for one hit (tests of Mesh::compute_surface_interaction) */
+void  orc_surface_interaction(void *scene, const float o[3], const float d[3],
+                              float t, float u, float v, uint32_t prim, uint32_t shape,
+                              uint32_t inst, float out[24]);
+
+/* ---- independent scene builders (restating util.py:569-703 etc.) ---- */
+/* A transform is 32 floats: row-major 4x4 `matrix` followed by the row-major
+ * 4x4 `inverse_transpose` (the pair include/mitsuba/core/transform.h keeps). */
+void orc_look_at(const float origin[3], const float target[3], const float up[3], float out[32]);
+void orc_translate(const float v[3], float out[32]);
+void orc_scale(const float v[3], float out[32]);
+void orc_rotate(const float axis[3], float angle_deg, float out[32]);
+void orc_matmul(const float a[32], const float b[32], float out[32]);   /* affine a * b */
+void orc_affine_inverse(const float m[32], float out[32]);
+void orc_perspective_sensor(const float to_world[32], double fov_deg, const char *fov_axis,
+                            float near_clip, float far_clip, uint32_t width, uint32_t height,
+                            uint32_t crop_x, uint32_t crop_y, uint32_t crop_w, uint32_t crop_h,
+                            uint32_t rfilter, float stddev, OrcSensor *out);
+/* Rectangle / Cube mesh records baked with to_world (rectangle.cpp:131-156,
+ * cube.cpp:58-113, mesh.cpp:1160-1215).  vertices: 4*8 / 24*8 floats,
+ * faces: 2*4 / 12*4 u32. */
+void orc_rectangle(const float to_world[32], float *vertices, uint32_t *faces,
+                   float normal[3], float *inv_area);
+void orc_cube(const float to_world[32], float *vertices, uint32_t *faces);
+
+#ifdef __cplusplus
+}
+#endif

@@ -1,0 +1,378 @@
+"""ctypes binding of the CPU ORACLE (oracle/libmi_oracle.so).
+
+TEST INFRASTRUCTURE ONLY: imported by tests/, __graft_entry__.smoke() and
+bench.py's cpu_baseline leg.  The product (mitsuba3_amd/) never imports it.
+Parity status: see oracle/mi_oracle.h ("parity unpinned" for Dr.Jit/Embree
+arithmetic that is not in the reference tree).
+"""
+import ctypes as C
+import os
+import subprocess
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+_LIB = None
+
+c_f32p = C.POINTER(C.c_float)
+c_u32p = C.POINTER(C.c_uint32)
+
+
+class Mesh(C.Structure):
+    _fields_ = [("vertex_ptr", c_f32p), ("index_ptr", c_u32p), ("vertex_count", C.c_uint32),
+                ("face_count", C.c_uint32), ("bsdf", C.c_uint32), ("emitter", C.c_int32),
+                ("flags", C.c_uint32), ("reserved", C.c_uint32)]
+
+
+class ShapeGroup(C.Structure):
+    _fields_ = [("first_mesh", C.c_uint32), ("mesh_count", C.c_uint32)]
+
+
+class Instance(C.Structure):
+    _fields_ = [("group", C.c_uint32), ("to_world", C.c_float * 12), ("to_object", C.c_float * 12)]
+
+
+class BSDF(C.Structure):
+    _fields_ = [("type", C.c_uint32), ("texture", C.c_int32), ("reflectance", C.c_float * 3)]
+
+
+class Texture(C.Structure):
+    _fields_ = [("data", c_f32p), ("width", C.c_uint32), ("height", C.c_uint32)]
+
+
+class Emitter(C.Structure):
+    _fields_ = [("type", C.c_uint32), ("mesh", C.c_uint32), ("radiance", C.c_float * 3),
+                ("to_world", C.c_float * 12), ("normal", C.c_float * 3), ("inv_area", C.c_float)]
+
+
+class SceneDesc(C.Structure):
+    _fields_ = [("meshes", C.POINTER(Mesh)), ("mesh_count", C.c_uint32), ("top_mesh_count", C.c_uint32),
+                ("groups", C.POINTER(ShapeGroup)), ("group_count", C.c_uint32), ("pad0", C.c_uint32),
+                ("instances", C.POINTER(Instance)), ("instance_count", C.c_uint32), ("pad1", C.c_uint32),
+                ("bsdfs", C.POINTER(BSDF)), ("bsdf_count", C.c_uint32), ("pad2", C.c_uint32),
+                ("textures", C.POINTER(Texture)), ("texture_count", C.c_uint32), ("pad3", C.c_uint32),
+                ("emitters", C.POINTER(Emitter)), ("emitter_count", C.c_uint32), ("pad4", C.c_uint32)]
+
+
+class Sensor(C.Structure):
+    _fields_ = [("sample_to_camera", C.c_float * 16), ("to_world", C.c_float * 16),
+                ("near_clip", C.c_float), ("far_clip", C.c_float),
+                ("film_width", C.c_uint32), ("film_height", C.c_uint32),
+                ("crop_offset_x", C.c_uint32), ("crop_offset_y", C.c_uint32),
+                ("crop_width", C.c_uint32), ("crop_height", C.c_uint32),
+                ("rfilter", C.c_uint32), ("rfilter_stddev", C.c_float)]
+
+
+class Stats(C.Structure):
+    _fields_ = [("paths", C.c_uint64), ("vertices", C.c_uint64), ("closest_rays", C.c_uint64),
+                ("shadow_rays", C.c_uint64)]
+
+
+def build():
+    """Compile the oracle (g++); building the checker is not using it."""
+    subprocess.check_call(["make", "-s", "-C", _HERE])
+
+
+def lib():
+    global _LIB
+    if _LIB is None:
+        path = os.path.join(_HERE, "libmi_oracle.so")
+        if not os.path.exists(path):
+            build()
+        L = C.CDLL(path)
+        L.orc_scene_create.restype = C.c_void_p
+        L.orc_scene_create.argtypes = [C.POINTER(SceneDesc)]
+        L.orc_scene_destroy.argtypes = [C.c_void_p]
+        L.orc_scene_set_reflectance.argtypes = [C.c_void_p, C.c_uint32, c_f32p]
+        L.orc_scene_set_texture.argtypes = [C.c_void_p, C.c_uint32, c_f32p]
+        L.orc_ray_intersect.argtypes = [C.c_void_p, C.c_uint32, c_f32p, c_f32p, c_f32p, C.c_int,
+                                        c_f32p, c_f32p, c_f32p, c_u32p, c_u32p, c_u32p]
+        L.orc_ray_test.argtypes = [C.c_void_p, C.c_uint32, c_f32p, c_f32p, c_f32p, C.c_int, C.POINTER(C.c_uint8)]
+        for fn in (L.orc_render_path, L.orc_render_prb):
+            fn.restype = C.c_int
+            fn.argtypes = [C.c_void_p, C.POINTER(Sensor), C.c_uint32, C.c_uint32, C.c_int32, C.c_int32,
+                           C.c_uint64, C.c_uint64, c_f32p, C.POINTER(Stats), C.c_int]
+        L.orc_render_prb_backward.restype = C.c_int
+        L.orc_render_prb_backward.argtypes = [C.c_void_p, C.POINTER(Sensor), c_f32p, C.c_uint32, C.c_uint32,
+                                              C.c_int32, C.c_int32, c_f32p, C.POINTER(c_f32p),
+                                              C.POINTER(Stats), C.c_int]
+        L.orc_film_develop.argtypes = [c_f32p, C.c_uint32, C.c_uint32, c_f32p]
+        L.orc_sample_tea_32.argtypes = [C.c_uint32, C.c_uint32, C.c_int, c_u32p]
+        L.orc_sample_tea_float32.restype = C.c_float
+        L.orc_sample_tea_float32.argtypes = [C.c_uint32, C.c_uint32, C.c_int]
+        L.orc_sample_tea_float64.restype = C.c_double
+        L.orc_sample_tea_float64.argtypes = [C.c_uint32, C.c_uint32, C.c_int]
+        u64p = C.POINTER(C.c_uint64)
+        L.orc_pcg32_seed.argtypes = [C.c_uint64, C.c_uint64, u64p]
+        L.orc_pcg32_next_uint32.restype = C.c_uint32
+        L.orc_pcg32_next_uint32.argtypes = [u64p]
+        L.orc_pcg32_next_float32.restype = C.c_float
+        L.orc_pcg32_next_float32.argtypes = [u64p]
+        L.orc_sampler_stream.argtypes = [C.c_uint32, C.c_uint32, C.c_uint32, c_f32p]
+        L.orc_rfilter_eval.restype = C.c_float
+        L.orc_rfilter_eval.argtypes = [C.c_uint32, C.c_float, C.c_float]
+        L.orc_film_put.argtypes = [C.POINTER(Sensor), C.c_uint32, c_f32p, c_f32p, c_f32p, c_f32p]
+        L.orc_sensor_sample_ray.argtypes = [C.POINTER(Sensor), C.c_uint32, c_f32p, c_f32p, c_f32p, c_f32p, c_f32p]
+        L.orc_diffuse_eval_pdf.argtypes = [c_f32p, c_f32p, c_f32p, c_f32p, c_f32p]
+        L.orc_diffuse_sample.argtypes = [c_f32p, c_f32p, C.c_float, c_f32p, c_f32p, c_f32p, c_f32p]
+        L.orc_square_to_cosine_hemisphere.argtypes = [c_f32p, c_f32p]
+        L.orc_coordinate_system.argtypes = [c_f32p, c_f32p, c_f32p]
+        L.orc_sincos.restype = C.c_float
+        L.orc_sincos.argtypes = [C.c_float, c_f32p]
+        L.orc_surface_interaction.argtypes = [C.c_void_p, c_f32p, c_f32p, C.c_float, C.c_float, C.c_float,
+                                              C.c_uint32, C.c_uint32, C.c_uint32, c_f32p]
+        L.orc_look_at.argtypes = [c_f32p, c_f32p, c_f32p, c_f32p]
+        L.orc_translate.argtypes = [c_f32p, c_f32p]
+        L.orc_scale.argtypes = [c_f32p, c_f32p]
+        L.orc_rotate.argtypes = [c_f32p, C.c_float, c_f32p]
+        L.orc_matmul.argtypes = [c_f32p, c_f32p, c_f32p]
+        L.orc_affine_inverse.argtypes = [c_f32p, c_f32p]
+        L.orc_perspective_sensor.argtypes = [c_f32p, C.c_double, C.c_char_p, C.c_float, C.c_float,
+                                             C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32,
+                                             C.c_uint32, C.c_uint32, C.c_float, C.POINTER(Sensor)]
+        L.orc_rectangle.argtypes = [c_f32p, c_f32p, c_u32p, c_f32p, c_f32p]
+        L.orc_cube.argtypes = [c_f32p, c_f32p, c_u32p]
+        _LIB = L
+    return _LIB
+
+
+def fp(a):
+    return a.ctypes.data_as(c_f32p)
+
+
+def up(a):
+    return a.ctypes.data_as(c_u32p)
+
+
+def f32(x):
+    return np.ascontiguousarray(x, dtype=np.float32)
+
+
+# --------------------------------------------------------------------------
+#  Transform helpers (32-float matrix + inverse-transpose pairs)
+# --------------------------------------------------------------------------
+
+class T:
+    """Mirror of mi.ScalarTransform4f chaining, evaluated by the oracle."""
+
+    def __init__(self, data=None):
+        if data is None:
+            data = np.concatenate([np.eye(4, dtype=np.float32).ravel()] * 2)
+        self.data = f32(data)
+
+    def _mul(self, other):
+        out = np.empty(32, np.float32)
+        lib().orc_matmul(fp(self.data), fp(other), fp(out))
+        return T(out)
+
+    def translate(self, v):
+        out = np.empty(32, np.float32); lib().orc_translate(fp(f32(v)), fp(out)); return self._mul(out)
+
+    def scale(self, v):
+        v = f32([v, v, v]) if np.isscalar(v) else f32(v)
+        out = np.empty(32, np.float32); lib().orc_scale(fp(v), fp(out)); return self._mul(out)
+
+    def rotate(self, axis, angle):
+        out = np.empty(32, np.float32); lib().orc_rotate(fp(f32(axis)), float(angle), fp(out)); return self._mul(out)
+
+    def look_at(self, origin, target, up):
+        out = np.empty(32, np.float32)
+        lib().orc_look_at(fp(f32(origin)), fp(f32(target)), fp(f32(up)), fp(out)); return self._mul(out)
+
+    def inverse(self):
+        out = np.empty(32, np.float32); lib().orc_affine_inverse(fp(self.data), fp(out)); return T(out)
+
+    @property
+    def matrix(self):
+        return self.data[:16].reshape(4, 4)
+
+    def col_major_3x4(self):
+        return np.ascontiguousarray(self.matrix[:3, :].T).ravel().astype(np.float32)
+
+
+# --------------------------------------------------------------------------
+#  Scene container: owns numpy arrays + the ctypes description
+# --------------------------------------------------------------------------
+
+class SceneData:
+    """Flat scene description (numpy-backed) usable for BOTH the oracle and the
+    product: `desc(cls)` re-emits it with the given ctypes struct classes."""
+
+    def __init__(self):
+        self.meshes = []     # dict(V, F, bsdf, emitter, flags)
+        self.top_mesh_count = 0
+        self.groups = []     # (first, count)
+        self.instances = []  # (group, to_world12, to_object12)
+        self.bsdfs = []      # (type, texture, rgb)
+        self.textures = []   # HxWx3 float32
+        self.emitters = []   # dict(mesh, radiance, to_world12, normal, inv_area)
+        self._keep = []
+
+    def add_mesh(self, V, F, bsdf, emitter=-1, flags=3):
+        self.meshes.append(dict(V=f32(V).reshape(-1, 8), F=np.ascontiguousarray(F, np.uint32).reshape(-1, 4),
+                                bsdf=bsdf, emitter=emitter, flags=flags))
+        return len(self.meshes) - 1
+
+    def desc(self, ns=None):
+        ns = ns or globals()
+        M, G, I, B, TX, E, SD = (ns[k] for k in ("Mesh", "ShapeGroup", "Instance", "BSDF", "Texture", "Emitter", "SceneDesc"))
+        keep = []
+        meshes = (M * max(1, len(self.meshes)))()
+        for i, m in enumerate(self.meshes):
+            meshes[i].vertex_ptr = fp(m["V"]); meshes[i].index_ptr = up(m["F"])
+            meshes[i].vertex_count = m["V"].shape[0]; meshes[i].face_count = m["F"].shape[0]
+            meshes[i].bsdf = m["bsdf"]; meshes[i].emitter = m["emitter"]; meshes[i].flags = m["flags"]
+        groups = (G * max(1, len(self.groups)))()
+        for i, (a, b) in enumerate(self.groups):
+            groups[i].first_mesh = a; groups[i].mesh_count = b
+        insts = (I * max(1, len(self.instances)))()
+        for i, (g, tw, to) in enumerate(self.instances):
+            insts[i].group = g
+            insts[i].to_world = (C.c_float * 12)(*[float(x) for x in tw])
+            insts[i].to_object = (C.c_float * 12)(*[float(x) for x in to])
+        bsdfs = (B * max(1, len(self.bsdfs)))()
+        for i, (t, tex, rgb) in enumerate(self.bsdfs):
+            bsdfs[i].type = t; bsdfs[i].texture = tex; bsdfs[i].reflectance = (C.c_float * 3)(*[float(x) for x in rgb])
+        texs = (TX * max(1, len(self.textures)))()
+        for i, t in enumerate(self.textures):
+            texs[i].data = fp(t); texs[i].height = t.shape[0]; texs[i].width = t.shape[1]
+        ems = (E * max(1, len(self.emitters)))()
+        for i, e in enumerate(self.emitters):
+            ems[i].type = 0; ems[i].mesh = e["mesh"]
+            ems[i].radiance = (C.c_float * 3)(*[float(x) for x in e["radiance"]])
+            ems[i].to_world = (C.c_float * 12)(*[float(x) for x in e["to_world"]])
+            ems[i].normal = (C.c_float * 3)(*[float(x) for x in e["normal"]])
+            ems[i].inv_area = float(e["inv_area"])
+        d = SD()
+        d.meshes = meshes; d.mesh_count = len(self.meshes); d.top_mesh_count = self.top_mesh_count
+        d.groups = groups; d.group_count = len(self.groups)
+        d.instances = insts; d.instance_count = len(self.instances)
+        d.bsdfs = bsdfs; d.bsdf_count = len(self.bsdfs)
+        d.textures = texs; d.texture_count = len(self.textures)
+        d.emitters = ems; d.emitter_count = len(self.emitters)
+        keep += [meshes, groups, insts, bsdfs, texs, ems]
+        self._keep.append(keep)
+        return d
+
+
+def rectangle(to_world):
+    V = np.empty((4, 8), np.float32); F = np.empty((2, 4), np.uint32)
+    n = np.empty(3, np.float32); ia = C.c_float()
+    lib().orc_rectangle(fp(to_world.data), fp(V), up(F), fp(n), C.byref(ia))
+    return V, F, n, ia.value
+
+
+def cube(to_world):
+    V = np.empty((24, 8), np.float32); F = np.empty((12, 4), np.uint32)
+    lib().orc_cube(fp(to_world.data), fp(V), up(F))
+    return V, F
+
+
+def perspective_sensor(to_world, fov, fov_axis, near, far, width, height, crop=None, rfilter="gaussian", stddev=0.5):
+    s = Sensor()
+    cx, cy, cw, ch = crop if crop else (0, 0, width, height)
+    lib().orc_perspective_sensor(fp(to_world.data), float(fov), fov_axis.encode(), near, far, width, height,
+                                 cx, cy, cw, ch, 1 if rfilter == "gaussian" else 0, stddev, C.byref(s))
+    return s
+
+
+CBOX_WHITE = [0.885809, 0.698859, 0.666422]
+CBOX_GREEN = [0.105421, 0.37798, 0.076425]
+CBOX_RED = [0.570068, 0.0430135, 0.0443706]
+CBOX_RADIANCE = [18.387, 13.9873, 6.75357]
+
+
+def cornell_box(width=256, height=256, crop=None, rfilter="gaussian", white_texture=None):
+    """Restates mi.cornell_box() (src/python/python/util.py:569-703)."""
+    sd = SceneData()
+    sd.bsdfs = [(0, -1, CBOX_WHITE), (0, -1, CBOX_GREEN), (0, -1, CBOX_RED)]
+    if white_texture is not None:
+        sd.textures.append(f32(white_texture))
+        sd.bsdfs[0] = (0, 0, CBOX_WHITE)
+    light_tf = T().translate([0.0, 0.99, 0.01]).rotate([1, 0, 0], 90).scale([0.23, 0.19, 0.19])
+    V, F, n, ia = rectangle(light_tf)
+    sd.add_mesh(V, F, 0, emitter=0)
+    sd.emitters.append(dict(mesh=0, radiance=CBOX_RADIANCE, to_world=light_tf.col_major_3x4(), normal=n, inv_area=ia))
+    for tf, b in [(T().translate([0.0, -1.0, 0.0]).rotate([1, 0, 0], -90), 0),
+                  (T().translate([0.0, 1.0, 0.0]).rotate([1, 0, 0], 90), 0),
+                  (T().translate([0.0, 0.0, -1.0]), 0),
+                  (T().translate([1.0, 0.0, 0.0]).rotate([0, 1, 0], -90), 1),
+                  (T().translate([-1.0, 0.0, 0.0]).rotate([0, 1, 0], 90), 2)]:
+        V, F, _, _ = rectangle(tf)
+        sd.add_mesh(V, F, b)
+    for tf in [T().translate([0.335, -0.7, 0.38]).rotate([0, 1, 0], -17).scale(0.3),
+               T().translate([-0.33, -0.4, -0.28]).rotate([0, 1, 0], 18.25).scale([0.3, 0.61, 0.3])]:
+        V, F = cube(tf)
+        sd.add_mesh(V, F, 0)
+    sd.top_mesh_count = len(sd.meshes)
+    cam = T().look_at([0, 0, 3.9], [0, 0, 0], [0, 1, 0])
+    sensor = perspective_sensor(cam, 39.3077, "smaller", 0.001, 100.0, width, height, crop, rfilter)
+    return sd, sensor
+
+
+class OracleScene:
+    def __init__(self, scene_data):
+        self.data = scene_data
+        self._desc = scene_data.desc()
+        self.handle = C.c_void_p(lib().orc_scene_create(C.byref(self._desc)))
+
+    def __del__(self):
+        try:
+            if self.handle:
+                lib().orc_scene_destroy(self.handle)
+        except Exception:
+            pass
+
+    def ray_intersect(self, o, d, maxt, naive=False):
+        o = f32(o); d = f32(d); maxt = f32(maxt); n = maxt.shape[0]
+        t = np.empty(n, np.float32); u = np.empty(n, np.float32); v = np.empty(n, np.float32)
+        prim = np.empty(n, np.uint32); shape = np.empty(n, np.uint32); inst = np.empty(n, np.uint32)
+        lib().orc_ray_intersect(self.handle, n, fp(o), fp(d), fp(maxt), 1 if naive else 0,
+                                fp(t), fp(u), fp(v), up(prim), up(shape), up(inst))
+        return t, u, v, prim, shape, inst
+
+    def ray_test(self, o, d, maxt, naive=False):
+        o = f32(o); d = f32(d); maxt = f32(maxt); n = maxt.shape[0]
+        hit = np.empty(n, np.uint8)
+        lib().orc_ray_test(self.handle, n, fp(o), fp(d), fp(maxt), 1 if naive else 0,
+                           hit.ctypes.data_as(C.POINTER(C.c_uint8)))
+        return hit.astype(bool)
+
+    def _render(self, fn, sensor, seed, spp, max_depth, rr_depth, lanes, threads):
+        film = np.zeros((sensor.crop_height, sensor.crop_width, 4), np.float32)
+        st = Stats()
+        lb, le = lanes if lanes else (0, 0)
+        rc = fn(self.handle, C.byref(sensor), seed, spp, max_depth, rr_depth, lb, le, fp(film), C.byref(st), threads)
+        assert rc == 0
+        return film, st
+
+    def render_path(self, sensor, seed=0, spp=4, max_depth=8, rr_depth=5, lanes=None, threads=0, raw=False):
+        film, st = self._render(lib().orc_render_path, sensor, seed, spp, max_depth, rr_depth, lanes, threads)
+        return (film if raw else develop(film)), st
+
+    def render_prb(self, sensor, seed=0, spp=4, max_depth=6, rr_depth=5, lanes=None, threads=0, raw=False):
+        film, st = self._render(lib().orc_render_prb, sensor, seed, spp, max_depth, rr_depth, lanes, threads)
+        return (film if raw else develop(film)), st
+
+    def render_prb_backward(self, sensor, grad_in, seed=0, spp=4, max_depth=6, rr_depth=5, threads=0):
+        grad_in = f32(grad_in)
+        g_refl = np.zeros((len(self.data.bsdfs), 3), np.float32)
+        g_tex = [np.zeros_like(t) for t in self.data.textures]
+        ptrs = (c_f32p * max(1, len(g_tex)))(*[fp(g) for g in g_tex])
+        st = Stats()
+        rc = lib().orc_render_prb_backward(self.handle, C.byref(sensor), fp(grad_in), seed, spp, max_depth, rr_depth,
+                                           fp(g_refl), ptrs, C.byref(st), threads)
+        assert rc == 0
+        return g_refl, g_tex, st
+
+    def set_reflectance(self, bsdf, rgb):
+        lib().orc_scene_set_reflectance(self.handle, bsdf, fp(f32(rgb)))
+
+    def set_texture(self, idx, data):
+        lib().orc_scene_set_texture(self.handle, idx, fp(f32(data)))
+
+
+def develop(film):
+    h, w, _ = film.shape
+    img = np.empty((h, w, 3), np.float32)
+    lib().orc_film_develop(fp(f32(film)), w, h, fp(img))
+    return img
