@@ -1,0 +1,253 @@
+/*
+ * hip_ad_rgb.h -- C ABI of the MI355X-native `hip_ad_rgb` hot path
+ * (forward `path` + `prb` adjoint on triangle scenes) for Mitsuba 3.
+ *
+ * This is the drop-in boundary: plain C, `extern "C"`, raw
+ * pointers + sizes, no torch / Dr.Jit types.  Every entry point names the
+ * reference interface it replaces (paths relative to the mitsuba3 tree).
+ * All array arguments marked DEVICE are device pointers in HBM (the caller
+ * owns them -- e.g. torch tensors); HOST pointers are ordinary host memory.
+ * `stream` is a hipStream_t passed as void* (NULL = default stream).
+ *
+ * Error convention: every function returns 0 on success, non-zero on failure;
+ * har_last_error() returns a thread-local message (the reference throws C++
+ * exceptions, src/render/integrator.cpp:40,178).
+ *
+ * Wavefront data layout: SoA.  A "Ray3f" wavefront of width n is three
+ * arrays o[3][n], d[3][n] (component-major) and maxt[n]; a
+ * "PreliminaryIntersection3f" is t[n], u[n], v[n], prim_index[n],
+ * shape_index[n], inst_index[n] (include/mitsuba/render/interaction.h:717-836).
+ */
+#pragma once
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+/* ------------------------------------------------------------------------
+ *  Scene IR  (replaces SceneIR / ShapeIR, include/mitsuba/render/scene_ir.h:14-176)
+ * ---------------------------------------------------------------------- */
+
+/* ShapeIR::Kind::Triangles in the packed Mesh layout
+ * (include/mitsuba/render/mesh_utils.h:19-34; Mesh::describe, src/render/mesh.cpp:2797-2813):
+ * 8 x f32 per vertex {pos[3], normal[3], uv[2]}, 4 x u32 per face {v0,v1,v2,flags}. HOST pointers. */
+typedef struct HarMesh {
+    const float    *vertex_ptr;
+    const uint32_t *index_ptr;
+    uint32_t vertex_count, face_count;
+    uint32_t bsdf;      /* index into HarSceneDesc::bsdfs */
+    int32_t  emitter;   /* index into HarSceneDesc::emitters, or -1 */
+    uint32_t flags;     /* bit0: has vertex normals, bit1: has texcoords */
+    uint32_t reserved;
+} HarMesh;
+
+/* ShapeGroup: meshes [first_mesh, first_mesh + mesh_count) (src/render/shapegroup.cpp) */
+typedef struct HarShapeGroup { uint32_t first_mesh, mesh_count; } HarShapeGroup;
+
+/* InstanceEntry (scene_ir.h:128-138): column-major 3x4 affine + its inverse */
+typedef struct HarInstance {
+    uint32_t group;
+    float to_world[12];
+    float to_object[12];
+} HarInstance;
+
+typedef struct HarBSDF {
+    uint32_t type;        /* 0 = diffuse (src/bsdfs/diffuse.cpp) */
+    int32_t  texture;     /* -1: constant `reflectance` (srgb), else bitmap index */
+    float    reflectance[3];
+} HarBSDF;
+
+/* BitmapTexture, raw H x W x 3 f32, bilinear, repeat (src/textures/bitmap.cpp:175-206). HOST pointer. */
+typedef struct HarTexture { const float *data; uint32_t width, height; } HarTexture;
+
+/* AreaLight on a Rectangle (src/emitters/area.cpp, src/shapes/rectangle.cpp:108-179) */
+typedef struct HarEmitter {
+    uint32_t type;        /* 0 = area */
+    uint32_t mesh;
+    float radiance[3];
+    float to_world[12];   /* column-major 3x4 */
+    float normal[3];
+    float inv_area;
+} HarEmitter;
+
+typedef struct HarSceneDesc {
+    const HarMesh       *meshes;    uint32_t mesh_count, top_mesh_count;
+    const HarShapeGroup *groups;    uint32_t group_count, pad0;
+    const HarInstance   *instances; uint32_t instance_count, pad1;
+    const HarBSDF       *bsdfs;     uint32_t bsdf_count, pad2;
+    const HarTexture    *textures;  uint32_t texture_count, pad3;
+    const HarEmitter    *emitters;  uint32_t emitter_count, pad4;
+} HarSceneDesc;
+
+/* PerspectiveCamera + HDRFilm + ReconstructionFilter, lowered
+ * (src/sensors/perspective.cpp:174-198, src/films/hdrfilm.cpp:241-288) */
+typedef struct HarSensor {
+    float sample_to_camera[16];   /* row-major 4x4 */
+    float to_world[16];           /* row-major 4x4 */
+    float near_clip, far_clip;
+    uint32_t film_width, film_height;
+    uint32_t crop_offset_x, crop_offset_y, crop_width, crop_height;
+    uint32_t rfilter;             /* 0 = box, 1 = gaussian (src/rfilters/gaussian.cpp) */
+    float    rfilter_stddev;
+} HarSensor;
+
+/* counters of one render call (all lanes), read back with har_render_stats */
+typedef struct HarStats {
+    uint64_t paths;
+    uint64_t vertices;      /* loop iterations (path vertices shaded) */
+    uint64_t closest_rays;
+    uint64_t shadow_rays;
+} HarStats;
+
+typedef struct HarSceneImpl      *HarScene;
+typedef struct HarIntegratorImpl *HarIntegrator;
+
+const char *har_last_error(void);
+/* returns the gfx arch string of the current device ("gfx950"), or NULL without a GPU */
+const char *har_device_arch(void);
+
+/* ------------------------------------------------------------------------
+ *  Scene + acceleration structure
+ *  replaces Scene::Scene / SceneAccel::{init, rebuild, release}
+ *  (src/render/scene.cpp:26-144, include/mitsuba/render/accel.h:36-45,
+ *   accel_native.h:26-44; closest analogue: build_metal_accel / release_metal_accel,
+ *   src/render/metal/accel.h:27-33)
+ * ---------------------------------------------------------------------- */
+int har_scene_create(const HarSceneDesc *desc, HarScene *out);
+int har_scene_destroy(HarScene scene);
+/* SceneParameters update of `<bsdf>.reflectance.value` / `<bsdf>.reflectance.data`
+ * (mi.traverse + params.update(), src/python/python/util.py). HOST data. */
+int har_scene_set_reflectance(HarScene scene, uint32_t bsdf, const float rgb[3]);
+int har_scene_set_texture(HarScene scene, uint32_t texture, const float *data);
+/* accel statistics: node count, triangle count, bytes */
+int har_scene_accel_info(HarScene scene, uint64_t info[4]);
+
+/* Scene::ray_intersect_preliminary (src/render/scene.cpp:216-230) /
+ * Scene::ray_intersect_naive (:240-244, naive != 0: brute-force kernel).  DEVICE arrays. */
+int har_ray_intersect_preliminary(HarScene scene, uint32_t n, const float *o, const float *d,
+                                  const float *maxt, int naive, float *t, float *u, float *v,
+                                  uint32_t *prim_index, uint32_t *shape_index,
+                                  uint32_t *inst_index, void *stream);
+/* Scene::ray_test (src/render/scene.cpp:232-238).  hit: u8[n]. DEVICE arrays. */
+int har_ray_test(HarScene scene, uint32_t n, const float *o, const float *d, const float *maxt,
+                 int naive, uint8_t *hit, void *stream);
+/* PreliminaryIntersection::compute_surface_interaction (interaction.h:804-829,
+ * src/render/mesh.cpp:2255-2437).  out: 21 x f32 SoA [21][n] =
+ * {p, n, sh_frame.n, sh_frame.s, sh_frame.t, wi, uv.x, uv.y, t}. DEVICE arrays. */
+int har_compute_surface_interaction(HarScene scene, uint32_t n, const float *o, const float *d,
+                                    const float *t, const float *u, const float *v,
+                                    const uint32_t *prim_index, const uint32_t *shape_index,
+                                    const uint32_t *inst_index, float *out, void *stream);
+
+/* ------------------------------------------------------------------------
+ *  Sampler  (src/render/sampler.cpp:129-148, src/samplers/independent.cpp:77-97)
+ * ---------------------------------------------------------------------- */
+/* PCG32Sampler::seed(seed, wavefront_size): state/inc are u64[n] DEVICE arrays;
+ * lane i of the wavefront gets the stream of global lane `lane_offset + i`. */
+int har_sampler_seed(uint32_t seed, uint32_t lane_offset, uint32_t n, uint64_t *state,
+                     uint64_t *inc, void *stream);
+/* IndependentSampler::next_1d(active): advances lanes with active[i] != 0 (active may be NULL) */
+int har_sampler_next_1d(uint32_t n, uint64_t *state, const uint64_t *inc, const uint8_t *active,
+                        float *out, void *stream);
+/* IndependentSampler::next_2d: out is [2][n] */
+int har_sampler_next_2d(uint32_t n, uint64_t *state, const uint64_t *inc, const uint8_t *active,
+                        float *out, void *stream);
+
+/* ------------------------------------------------------------------------
+ *  BSDF  (include/mitsuba/render/bsdf.h:322-465, src/bsdfs/diffuse.cpp:100-179)
+ *  wi/wo in the local shading frame, SoA [3][n]; uv [2][n]; DEVICE arrays.
+ * ---------------------------------------------------------------------- */
+int har_bsdf_eval_pdf(HarScene scene, uint32_t bsdf, uint32_t n, const float *wi, const float *uv,
+                      const float *wo, float *value /*[3][n]*/, float *pdf, void *stream);
+int har_bsdf_sample(HarScene scene, uint32_t bsdf, uint32_t n, const float *wi, const float *uv,
+                    const float *sample1, const float *sample2 /*[2][n]*/, float *wo /*[3][n]*/,
+                    float *pdf, float *weight /*[3][n]*/, void *stream);
+
+/* ------------------------------------------------------------------------
+ *  Sensor / film
+ * ---------------------------------------------------------------------- */
+/* PerspectiveCamera::sample_ray (src/sensors/perspective.cpp:200-237) */
+int har_sensor_sample_ray(const HarSensor *sensor, uint32_t n, const float *pos_x,
+                          const float *pos_y, float *o, float *d, float *maxt, void *stream);
+/* ImageBlock::put (src/render/imageblock.cpp:187-540): film is H x W x 4 {R,G,B,W} */
+int har_film_put(const HarSensor *sensor, uint32_t n, const float *pos_x, const float *pos_y,
+                 const float *values4 /*[n][4]*/, float *film, void *stream);
+/* HDRFilm::develop (src/films/hdrfilm.cpp:301-404): image H x W x 3 = RGB / (W==0 ? 1 : W) */
+int har_film_develop(const float *film, uint32_t width, uint32_t height, float *image, void *stream);
+
+/* ------------------------------------------------------------------------
+ *  Integrators
+ * ---------------------------------------------------------------------- */
+#define HAR_INTEGRATOR_PATH 0   /* src/integrators/path.cpp */
+#define HAR_INTEGRATOR_PRB  1   /* src/python/python/ad/integrators/prb.py */
+/* MonteCarloIntegrator ctor (src/render/integrator.cpp:539-550): max_depth -1 = infinite,
+ * rr_depth > 0.  chunk_lanes = wavefront chunk size (0 = default). */
+int har_integrator_create(int type, int32_t max_depth, int32_t rr_depth, uint32_t chunk_lanes,
+                          HarIntegrator *out);
+int har_integrator_destroy(HarIntegrator integrator);
+
+/* SamplingIntegrator::render (src/render/integrator.cpp:151-396, JIT branch) /
+ * ADIntegrator.render (common.py:46-110) restricted to lanes [lane_begin, lane_end)
+ * of the W*H*spp wavefront (0,0 = all): splats into `film` (DEVICE, H x W x 4,
+ * accumulated, not cleared, not developed) so that tiles rendered by several
+ * GPUs can be summed with one reduce before har_film_develop. */
+int har_render(HarScene scene, HarIntegrator integrator, const HarSensor *sensor, uint32_t seed,
+               uint32_t spp, uint64_t lane_begin, uint64_t lane_end, float *film, void *stream);
+
+/* RBIntegrator.render_backward (common.py:625-783), split so that the weight
+ * image can be reduced across GPUs between the two calls:
+ *  1. har_render_weights: splat W=1 of lanes [begin,end) into film (channel 3 only);
+ *  2. har_render_backward: given the (reduced) weight film and grad_in (H x W x 3),
+ *     run the primal pass + adjoint replay of lanes [begin,end) and accumulate
+ *     gradients into grad_reflectance (bsdf_count x 3) and grad_textures[i]
+ *     (H_i x W_i x 3; HOST array of DEVICE pointers, entries may be NULL). */
+int har_render_weights(const HarSensor *sensor, uint32_t seed, uint32_t spp, uint64_t lane_begin,
+                       uint64_t lane_end, float *film, void *stream);
+int har_render_backward(HarScene scene, HarIntegrator integrator, const HarSensor *sensor,
+                        const float *grad_in, const float *weight_film, uint32_t seed,
+                        uint32_t spp, uint64_t lane_begin, uint64_t lane_end,
+                        float *grad_reflectance, float *const *grad_textures, void *stream);
+
+/* counters of the last har_render / har_render_backward on this integrator (synchronises) */
+int har_render_stats(HarIntegrator integrator, HarStats *out);
+/* HIP-event timing of the last render call: per-kernel-class milliseconds, measured on
+ * `stream` when profiling was enabled with har_integrator_set_profiling(.., 1).
+ * ms[0]=raygen ms[1]=trace_closest ms[2]=shade ms[3]=trace_shadow ms[4]=splat ms[5]=total
+ * launches[i] = number of launches in that class. */
+int har_integrator_set_profiling(HarIntegrator integrator, int enable);
+int har_render_timing(HarIntegrator integrator, float ms[8], uint32_t launches[8]);
+
+
+/* ------------------------------------------------------------------------
+ *  Host-side plugin lowering (no GPU involved).  A Transform4f is 32 floats:
+ *  row-major 4x4 `matrix` followed by row-major 4x4 `inverse_transpose`, the pair
+ *  include/mitsuba/core/transform.h keeps.
+ * ---------------------------------------------------------------------- */
+/* Transform4f::translate / scale / rotate / look_at (transform.h:132-203) */
+int har_transform_translate(const float v[3], float out[32]);
+int har_transform_scale(const float v[3], float out[32]);
+int har_transform_rotate(const float axis[3], float angle_deg, float out[32]);
+int har_transform_look_at(const float origin[3], const float target[3], const float up[3], float out[32]);
+/* Transform4f::operator* (affine branch, transform.h:364-400) and inverse() (:81-84) */
+int har_transform_mul(const float a[32], const float b[32], float out[32]);
+int har_transform_inverse(const float a[32], float out[32]);
+/* PerspectiveCamera ctor + update_camera_transforms (src/sensors/perspective.cpp:137-198),
+ * parse_fov (src/render/sensor.cpp:142-190), HDRFilm crop window, rfilter: 0 box / 1 gaussian */
+int har_perspective_sensor(const float to_world[32], double fov, const char *fov_axis, float near_clip,
+                           float far_clip, uint32_t width, uint32_t height, uint32_t crop_x,
+                           uint32_t crop_y, uint32_t crop_w, uint32_t crop_h, uint32_t rfilter,
+                           float stddev, HarSensor *out);
+/* Rectangle::initialize (src/shapes/rectangle.cpp:108-156): 4 vertex + 2 face records baked with
+ * to_world, plus m_frame.n and m_inv_surface_area for area-light sampling */
+int har_shape_rectangle(const float to_world[32], int flip_normals, float vertices[32], uint32_t faces[8],
+                        float normal[3], float *inv_area);
+/* Cube ctor (src/shapes/cube.cpp:58-113): 24 vertex + 12 face records baked with to_world */
+int har_shape_cube(const float to_world[32], float vertices[192], uint32_t faces[48]);
+/* Mesh::transform + flip_winding (src/render/mesh.cpp:1160-1215) on packed records, in place */
+int har_mesh_transform(const float to_world[32], uint32_t vertex_count, float *vertices,
+                       uint32_t face_count, uint32_t *faces, int has_normals);
+
+#ifdef __cplusplus
+}
+#endif

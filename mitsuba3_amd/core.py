@@ -1,0 +1,990 @@
+"""Host-side mirror of the Mitsuba 3 Python surface for the `hip_ad_rgb` variant.
+
+Names, argument meaning and error behaviour follow the reference
+(`mi.load_dict`, `mi.cornell_box`, `mi.render`, `mi.traverse`,
+`Scene.ray_intersect_preliminary`, `Integrator.render/render_backward`,
+`Sampler.seed/next_1d/next_2d`, `BSDF.eval/pdf/sample`); all computation is
+done by the HIP kernels behind the C ABI (mitsuba3_amd/_capi.py).  PyTorch is
+used for device memory, streams and torch.distributed only.
+"""
+import ctypes as C
+import math
+
+import numpy as np
+
+from . import _capi
+from ._capi import lib, check, HarError
+
+VARIANT = "hip_ad_rgb"
+_variant = None
+
+
+def set_variant(name):
+    """mi.set_variant: only `hip_ad_rgb` is provided by this package."""
+    global _variant
+    if name != VARIANT:
+        raise ImportError("Requested an unsupported variant \"%s\". The following variants are available: %s." % (name, VARIANT))
+    _variant = name
+
+
+def variant():
+    return _variant
+
+
+def variants():
+    return [VARIANT]
+
+
+def _f32(x):
+    return np.ascontiguousarray(x, dtype=np.float32)
+
+
+def _fp(a):
+    return a.ctypes.data_as(_capi.f32p)
+
+
+def _up(a):
+    return a.ctypes.data_as(_capi.u32p)
+
+
+def _torch():
+    import torch
+    return torch
+
+
+def _device():
+    torch = _torch()
+    if not torch.cuda.is_available():
+        raise HarError("hip_ad_rgb requires a HIP device (torch.cuda.is_available() is False); there is no CPU fallback")
+    return torch.device("cuda", torch.cuda.current_device())
+
+
+def _stream():
+    return C.c_void_p(_torch().cuda.current_stream().cuda_stream)
+
+
+def _ptr(t):
+    return C.c_void_p(t.data_ptr()) if t is not None else C.c_void_p(0)
+
+
+# ---------------------------------------------------------------------------
+#  ScalarTransform4f (include/mitsuba/core/transform.h) -- evaluated in C++
+# ---------------------------------------------------------------------------
+
+class ScalarTransform4f:
+    def __init__(self, data=None):
+        if data is None:
+            data = np.concatenate([np.eye(4, dtype=np.float32).ravel()] * 2)
+        self.data = _f32(data).reshape(32)
+
+    def _chain(self, other):
+        out = np.empty(32, np.float32)
+        check(lib().har_transform_mul(_fp(self.data), _fp(other), _fp(out)))
+        return ScalarTransform4f(out)
+
+    def translate(self, v):
+        out = np.empty(32, np.float32); check(lib().har_transform_translate(_fp(_f32(v)), _fp(out))); return self._chain(out)
+
+    def scale(self, v):
+        v = _f32([v, v, v]) if np.isscalar(v) else _f32(v)
+        out = np.empty(32, np.float32); check(lib().har_transform_scale(_fp(v), _fp(out))); return self._chain(out)
+
+    def rotate(self, axis, angle):
+        out = np.empty(32, np.float32); check(lib().har_transform_rotate(_fp(_f32(axis)), float(angle), _fp(out))); return self._chain(out)
+
+    def look_at(self, origin, target, up):
+        out = np.empty(32, np.float32)
+        check(lib().har_transform_look_at(_fp(_f32(origin)), _fp(_f32(target)), _fp(_f32(up)), _fp(out))); return self._chain(out)
+
+    def inverse(self):
+        out = np.empty(32, np.float32); check(lib().har_transform_inverse(_fp(self.data), _fp(out))); return ScalarTransform4f(out)
+
+    def __matmul__(self, other):
+        return self._chain(other.data)
+
+    @property
+    def matrix(self):
+        return self.data[:16].reshape(4, 4)
+
+    def col_major_3x4(self):
+        return np.ascontiguousarray(self.matrix[:3, :].T).ravel().astype(np.float32)
+
+    def has_scale(self):
+        m = self.matrix[:3, :3].astype(np.float64)
+        return not np.allclose(m @ m.T, np.eye(3), atol=1e-3)
+
+
+Transform4f = ScalarTransform4f
+
+
+def cornell_box():
+    """mi.cornell_box() (src/python/python/util.py:569-703)."""
+    T = ScalarTransform4f
+    return {
+        'type': 'scene',
+        'integrator': {'type': 'path', 'max_depth': 8},
+        'sensor': {
+            'type': 'perspective', 'fov_axis': 'smaller', 'near_clip': 0.001, 'far_clip': 100.0,
+            'focus_distance': 1000, 'fov': 39.3077,
+            'to_world': T().look_at(origin=[0, 0, 3.90], target=[0, 0, 0], up=[0, 1, 0]),
+            'sampler': {'type': 'independent', 'sample_count': 64},
+            'film': {'type': 'hdrfilm', 'width': 256, 'height': 256, 'rfilter': {'type': 'gaussian'},
+                     'pixel_format': 'rgb', 'component_format': 'float32'},
+        },
+        'white': {'type': 'diffuse', 'reflectance': {'type': 'rgb', 'value': [0.885809, 0.698859, 0.666422]}},
+        'green': {'type': 'diffuse', 'reflectance': {'type': 'rgb', 'value': [0.105421, 0.37798, 0.076425]}},
+        'red': {'type': 'diffuse', 'reflectance': {'type': 'rgb', 'value': [0.570068, 0.0430135, 0.0443706]}},
+        'light': {'type': 'rectangle',
+                  'to_world': T().translate([0.0, 0.99, 0.01]).rotate([1, 0, 0], 90).scale([0.23, 0.19, 0.19]),
+                  'bsdf': {'type': 'ref', 'id': 'white'},
+                  'emitter': {'type': 'area', 'radiance': {'type': 'rgb', 'value': [18.387, 13.9873, 6.75357]}}},
+        'floor': {'type': 'rectangle', 'to_world': T().translate([0.0, -1.0, 0.0]).rotate([1, 0, 0], -90), 'bsdf': {'type': 'ref', 'id': 'white'}},
+        'ceiling': {'type': 'rectangle', 'to_world': T().translate([0.0, 1.0, 0.0]).rotate([1, 0, 0], 90), 'bsdf': {'type': 'ref', 'id': 'white'}},
+        'back': {'type': 'rectangle', 'to_world': T().translate([0.0, 0.0, -1.0]), 'bsdf': {'type': 'ref', 'id': 'white'}},
+        'green-wall': {'type': 'rectangle', 'to_world': T().translate([1.0, 0.0, 0.0]).rotate([0, 1, 0], -90), 'bsdf': {'type': 'ref', 'id': 'green'}},
+        'red-wall': {'type': 'rectangle', 'to_world': T().translate([-1.0, 0.0, 0.0]).rotate([0, 1, 0], 90), 'bsdf': {'type': 'ref', 'id': 'red'}},
+        'small-box': {'type': 'cube', 'to_world': T().translate([0.335, -0.7, 0.38]).rotate([0, 1, 0], -17).scale(0.3), 'bsdf': {'type': 'ref', 'id': 'white'}},
+        'large-box': {'type': 'cube', 'to_world': T().translate([-0.33, -0.4, -0.28]).rotate([0, 1, 0], 18.25).scale([0.3, 0.61, 0.3]), 'bsdf': {'type': 'ref', 'id': 'white'}},
+    }
+
+
+# ---------------------------------------------------------------------------
+#  Wavefront record types (SoA torch tensors on the GPU)
+# ---------------------------------------------------------------------------
+
+class Ray3f:
+    """Ray3f wavefront: o, d are float32 tensors [3, n]; maxt [n] (default Largest)."""
+
+    def __init__(self, o, d, maxt=None):
+        torch = _torch(); dev = _device()
+        self.o = torch.as_tensor(o, dtype=torch.float32, device=dev).reshape(3, -1).contiguous()
+        self.d = torch.as_tensor(d, dtype=torch.float32, device=dev).reshape(3, -1).contiguous()
+        n = self.o.shape[1]
+        if maxt is None:
+            maxt = torch.full((n,), 3.402823466e+38, dtype=torch.float32, device=dev)
+        self.maxt = torch.as_tensor(maxt, dtype=torch.float32, device=dev).reshape(-1).contiguous()
+        if self.maxt.numel() == 1 and n > 1:
+            self.maxt = self.maxt.expand(n).contiguous()
+
+    def __len__(self):
+        return self.o.shape[1]
+
+
+class PreliminaryIntersection3f:
+    """include/mitsuba/render/interaction.h:717-836"""
+
+    def __init__(self, scene, t, u, v, prim_index, shape_index, inst_index):
+        self.scene = scene
+        self.t = t; self.prim_uv = (u, v); self.prim_index = prim_index
+        self.shape_index = shape_index; self.instance = inst_index
+
+    def is_valid(self):
+        return ~_torch().isinf(self.t)
+
+    def compute_surface_interaction(self, ray):
+        return self.scene._compute_si(ray, self)
+
+
+class SurfaceInteraction3f:
+    def __init__(self, raw):
+        self.p = raw[0:3]; self.n = raw[3:6]
+        self.sh_frame = type("Frame3f", (), dict(n=raw[6:9], s=raw[9:12], t=raw[12:15]))()
+        self.wi = raw[15:18]; self.uv = raw[18:20]; self.t = raw[20]
+
+    def is_valid(self):
+        return ~_torch().isinf(self.t)
+
+
+class BSDFContext:
+    pass
+
+
+# ---------------------------------------------------------------------------
+#  Plugins
+# ---------------------------------------------------------------------------
+
+class Mesh:
+    """Triangle mesh in the packed layout (mesh_utils.h:19-34)."""
+
+    def __init__(self, name="mesh"):
+        self.name = name
+        self.V = np.zeros((0, 8), np.float32); self.F = np.zeros((0, 4), np.uint32); self.flags = 0
+        self.bsdf = None; self.emitter = None
+
+    def from_fields(self, faces, positions, normals=None, texcoords=None):
+        positions = _f32(positions).reshape(-1, 3)
+        V = np.zeros((positions.shape[0], 8), np.float32); V[:, 0:3] = positions
+        flags = 0
+        if normals is not None:
+            V[:, 3:6] = _f32(normals).reshape(-1, 3); flags |= 1
+        if texcoords is not None:
+            V[:, 6:8] = _f32(texcoords).reshape(-1, 2); flags |= 2
+        F = np.zeros((np.asarray(faces).reshape(-1, 3).shape[0], 4), np.uint32)
+        F[:, :3] = np.asarray(faces, dtype=np.uint32).reshape(-1, 3)
+        self.V, self.F, self.flags = V, F, flags
+        return self
+
+    def transform(self, to_world):
+        self.V = np.ascontiguousarray(self.V); self.F = np.ascontiguousarray(self.F)
+        check(lib().har_mesh_transform(_fp(to_world.data), self.V.shape[0], _fp(self.V), self.F.shape[0], _up(self.F), self.flags & 1))
+        return self
+
+    def face_count(self):
+        return self.F.shape[0]
+
+    def vertex_count(self):
+        return self.V.shape[0]
+
+
+def _rectangle(props):
+    tw = props.get('to_world', ScalarTransform4f())
+    m = Mesh("rectangle")
+    V = np.empty((4, 8), np.float32); F = np.empty((2, 4), np.uint32); n = np.empty(3, np.float32); ia = C.c_float()
+    check(lib().har_shape_rectangle(_fp(tw.data), 1 if props.get('flip_normals', False) else 0, _fp(V), _up(F), _fp(n), C.byref(ia)))
+    m.V, m.F, m.flags = V, F, 3
+    m.rect = dict(to_world=tw, normal=n, inv_area=ia.value)
+    return m
+
+
+def _cube(props):
+    tw = props.get('to_world', ScalarTransform4f())
+    m = Mesh("cube")
+    V = np.empty((24, 8), np.float32); F = np.empty((12, 4), np.uint32)
+    check(lib().har_shape_cube(_fp(tw.data), _fp(V), _up(F)))
+    m.V, m.F, m.flags = V, F, 3
+    return m
+
+
+class Sampler:
+    """IndependentSampler (src/samplers/independent.cpp) over PCG32Sampler (src/render/sampler.cpp)."""
+
+    def __init__(self, props=None):
+        props = props or {}
+        self.m_sample_count = int(props.get('sample_count', 4))
+        self.m_base_seed = int(props.get('seed', 0))
+        self.m_samples_per_wavefront = 1
+        self.m_wavefront_size = 0
+        self.state = None; self.inc = None
+
+    def sample_count(self):
+        return self.m_sample_count
+
+    def set_sample_count(self, spp):
+        self.m_sample_count = int(spp)
+
+    def set_samples_per_wavefront(self, n):
+        self.m_samples_per_wavefront = int(n)
+        if self.m_sample_count % self.m_samples_per_wavefront != 0:
+            raise RuntimeError("sample_count should be a multiple of samples_per_wavefront!")
+
+    def wavefront_size(self):
+        return self.m_wavefront_size
+
+    def seeded(self):
+        return self.state is not None
+
+    def clone(self):
+        s = Sampler(); s.__dict__.update(self.__dict__)
+        if self.state is not None:
+            s.state = self.state.clone(); s.inc = self.inc.clone()
+        return s
+
+    def fork(self):
+        s = Sampler(); s.m_sample_count = self.m_sample_count; s.m_base_seed = self.m_base_seed
+        return s
+
+    def seed(self, seed, wavefront_size=None):
+        torch = _torch(); dev = _device()
+        if wavefront_size is None:
+            if self.m_wavefront_size == 0:
+                raise RuntimeError("Sampler::seed(): wavefront_size should be specified!")
+        else:
+            self.m_wavefront_size = int(wavefront_size)
+        n = self.m_wavefront_size
+        self.state = torch.empty(n, dtype=torch.int64, device=dev); self.inc = torch.empty(n, dtype=torch.int64, device=dev)
+        check(lib().har_sampler_seed((self.m_base_seed + int(seed)) & 0xffffffff, 0, n, _ptr(self.state), _ptr(self.inc), _stream()))
+
+    def _active(self, active):
+        if active is None:
+            return None
+        torch = _torch()
+        return torch.as_tensor(active, device=_device()).to(torch.uint8).contiguous()
+
+    def next_1d(self, active=None):
+        assert self.seeded()
+        torch = _torch(); n = self.m_wavefront_size
+        out = torch.empty(n, dtype=torch.float32, device=_device()); a = self._active(active)
+        check(lib().har_sampler_next_1d(n, _ptr(self.state), _ptr(self.inc), _ptr(a), _ptr(out), _stream()))
+        return out
+
+    def next_2d(self, active=None):
+        assert self.seeded()
+        torch = _torch(); n = self.m_wavefront_size
+        out = torch.empty((2, n), dtype=torch.float32, device=_device()); a = self._active(active)
+        check(lib().har_sampler_next_2d(n, _ptr(self.state), _ptr(self.inc), _ptr(a), _ptr(out), _stream()))
+        return out
+
+
+class Film:
+    """HDRFilm (src/films/hdrfilm.cpp) + its reconstruction filter."""
+
+    def __init__(self, props=None):
+        props = props or {}
+        self.width = int(props.get('width', 768)); self.height = int(props.get('height', 576))
+        self.crop_offset = (int(props.get('crop_offset_x', 0)), int(props.get('crop_offset_y', 0)))
+        self.crop_size_ = (int(props.get('crop_width', self.width)), int(props.get('crop_height', self.height)))
+        pf = props.get('pixel_format', 'rgb')
+        if pf != 'rgb':
+            raise RuntimeError("hdrfilm: pixel_format \"%s\" is not supported by hip_ad_rgb (only 'rgb')" % pf)
+        rf = props.get('rfilter', {'type': 'gaussian'})
+        if rf['type'] == 'gaussian':
+            self.rfilter = 1; self.stddev = float(rf.get('stddev', 0.5))
+        elif rf['type'] == 'box':
+            self.rfilter = 0; self.stddev = 0.5
+        else:
+            raise RuntimeError("Plugin \"%s\" not found for variant hip_ad_rgb (rfilters: box, gaussian)" % rf['type'])
+
+    def size(self):
+        return (self.width, self.height)
+
+    def crop_size(self):
+        return self.crop_size_
+
+
+class Sensor:
+    """PerspectiveCamera (src/sensors/perspective.cpp)."""
+
+    def __init__(self, props):
+        self.props = dict(props)
+        self.m_film = props['film'] if isinstance(props.get('film'), Film) else Film(props.get('film'))
+        self.m_sampler = props['sampler'] if isinstance(props.get('sampler'), Sampler) else Sampler(props.get('sampler'))
+        self.to_world = props.get('to_world', ScalarTransform4f())
+        if self.to_world.has_scale():
+            raise RuntimeError("Scale factors in the camera-to-world transformation are not allowed!")
+        if 'fov' in props and 'focal_length' in props:
+            raise RuntimeError("Please specify either a focal length ('focal_length') or a field of view ('fov')!")
+        self.near_clip = float(props.get('near_clip', 1e-2)); self.far_clip = float(props.get('far_clip', 1e4))
+        self.update()
+
+    def update(self):
+        f = self.m_film
+        fov_axis = self.props.get('fov_axis', 'x')
+        if 'fov' in self.props:
+            fov = float(self.props['fov'])
+        else:
+            fl = str(self.props.get('focal_length', '50mm'))
+            value = float(fl[:-2] if fl.endswith('mm') else fl)
+            fov = 2.0 * math.degrees(math.atan(math.sqrt(36 * 36 + 24 * 24) / (2.0 * value))); fov_axis = 'diagonal'
+        s = _capi.HarSensor()
+        rc = lib().har_perspective_sensor(_fp(self.to_world.data), fov, fov_axis.encode(), self.near_clip, self.far_clip,
+                                          f.width, f.height, f.crop_offset[0], f.crop_offset[1], f.crop_size_[0], f.crop_size_[1],
+                                          f.rfilter, f.stddev, C.byref(s))
+        if rc == 2:
+            raise RuntimeError("The 'fov_axis' parameter must be set to one of 'smaller', 'larger', 'diagonal', 'x', or 'y'!")
+        if rc == 3:
+            raise RuntimeError("The horizontal field of view must be in the range [0, 180]!")
+        if rc:
+            raise RuntimeError("invalid sensor parameters")
+        self.har = s
+
+    def film(self):
+        return self.m_film
+
+    def sampler(self):
+        return self.m_sampler
+
+    def sample_ray(self, time, sample1, sample2, sample3=None):
+        """PerspectiveCamera::sample_ray: sample2 is the film position in [0,1]^2, tensor [2, n]."""
+        torch = _torch(); dev = _device()
+        p = torch.as_tensor(sample2, dtype=torch.float32, device=dev).reshape(2, -1).contiguous(); n = p.shape[1]
+        o = torch.empty((3, n), dtype=torch.float32, device=dev); d = torch.empty_like(o); mt = torch.empty(n, dtype=torch.float32, device=dev)
+        check(lib().har_sensor_sample_ray(C.byref(self.har), n, _ptr(p[0]), _ptr(p[1]), _ptr(o), _ptr(d), _ptr(mt), _stream()))
+        return Ray3f(o, d, mt), torch.ones(n, device=dev)
+
+
+class BSDF:
+    """SmoothDiffuse (src/bsdfs/diffuse.cpp) with an `rgb` or raw `bitmap` reflectance."""
+
+    def __init__(self, props=None, id=None):
+        props = props or {}
+        self.id = id
+        refl = props.get('reflectance', {'type': 'rgb', 'value': [0.5, 0.5, 0.5]})
+        if isinstance(refl, (int, float)):
+            refl = {'type': 'rgb', 'value': [refl] * 3}
+        self.texture = None
+        if refl['type'] == 'rgb':
+            v = refl['value']; v = [v] * 3 if np.isscalar(v) else list(v)
+            self.value = _f32(v)
+            if np.any(self.value < 0) or np.any(self.value > 1):
+                raise RuntimeError("Invalid RGB reflectance value %s, must be in the range [0, 1]!" % self.value)
+        elif refl['type'] == 'bitmap':
+            if 'data' not in refl:
+                raise RuntimeError("bitmap: hip_ad_rgb needs the texel array under 'data' (file loading is out of scope)")
+            if refl.get('filter_type', 'bilinear') != 'bilinear' or refl.get('wrap_mode', 'repeat') != 'repeat':
+                raise RuntimeError("bitmap: only filter_type='bilinear' and wrap_mode='repeat' are implemented")
+            if not refl.get('raw', False):
+                raise RuntimeError("bitmap: only raw=True float data is implemented (no sRGB conversion)")
+            t = refl['data']
+            if hasattr(t, 'detach'):
+                t = t.detach().cpu().numpy()
+            self.texture = _f32(t).reshape(np.asarray(t).shape[0], np.asarray(t).shape[1], 3)
+            self.value = _f32([0.5, 0.5, 0.5])
+        else:
+            raise RuntimeError("Plugin \"%s\" not found for variant hip_ad_rgb (textures: rgb, bitmap)" % refl['type'])
+        self.scene = None; self.index = None
+
+    def _bind(self):
+        if self.scene is None:          # stand-alone BSDF: private scene holding just this plugin
+            Scene({'_bsdf': self})
+        return self.scene._handle(), self.index
+
+    def _prep(self, si_wi, si_uv, n):
+        torch = _torch(); dev = _device()
+        wi = torch.as_tensor(si_wi, dtype=torch.float32, device=dev).reshape(3, -1)
+        wi = wi.expand(3, n).contiguous() if wi.shape[1] != n else wi.contiguous()
+        uv = torch.zeros((2, n), dtype=torch.float32, device=dev) if si_uv is None else torch.as_tensor(si_uv, dtype=torch.float32, device=dev).reshape(2, -1).contiguous()
+        return wi, uv
+
+    def eval_pdf(self, ctx, si, wo, active=True):
+        torch = _torch(); dev = _device(); h, idx = self._bind()
+        wo = torch.as_tensor(wo, dtype=torch.float32, device=dev).reshape(3, -1).contiguous(); n = wo.shape[1]
+        wi, uv = self._prep(si.wi, getattr(si, 'uv', None), n)
+        val = torch.empty((3, n), dtype=torch.float32, device=dev); pdf = torch.empty(n, dtype=torch.float32, device=dev)
+        check(lib().har_bsdf_eval_pdf(h, idx, n, _ptr(wi), _ptr(uv), _ptr(wo), _ptr(val), _ptr(pdf), _stream()))
+        return val, pdf
+
+    def eval(self, ctx, si, wo, active=True):
+        return self.eval_pdf(ctx, si, wo, active)[0]
+
+    def pdf(self, ctx, si, wo, active=True):
+        return self.eval_pdf(ctx, si, wo, active)[1]
+
+    def sample(self, ctx, si, sample1, sample2, active=True):
+        torch = _torch(); dev = _device(); h, idx = self._bind()
+        s2 = torch.as_tensor(sample2, dtype=torch.float32, device=dev).reshape(2, -1).contiguous(); n = s2.shape[1]
+        wi, uv = self._prep(si.wi, getattr(si, 'uv', None), n)
+        wo = torch.empty((3, n), dtype=torch.float32, device=dev); pdf = torch.empty(n, dtype=torch.float32, device=dev); w = torch.empty_like(wo)
+        check(lib().har_bsdf_sample(h, idx, n, _ptr(wi), _ptr(uv), C.c_void_p(0), _ptr(s2), _ptr(wo), _ptr(pdf), _ptr(w), _stream()))
+        bs = type("BSDFSample3f", (), dict(wo=wo, pdf=pdf, eta=torch.ones(n, device=dev), sampled_type=2, sampled_component=0))()
+        return bs, w
+
+
+class ShapeGroup:
+    def __init__(self, shapes):
+        self.shapes = shapes
+
+
+class Instance:
+    def __init__(self, group, to_world):
+        self.group = group; self.to_world = to_world
+
+
+class Integrator:
+    """PathIntegrator (src/integrators/path.cpp) / PRBIntegrator (ad/integrators/prb.py)."""
+
+    def __init__(self, props):
+        self.type = props['type']
+        default_depth = -1 if self.type == 'path' else 6        # integrator.cpp:539, common.py:31
+        self.max_depth = int(props.get('max_depth', default_depth))
+        self.rr_depth = int(props.get('rr_depth', 5))
+        if props.get('hide_emitters', False):
+            raise RuntimeError("hide_emitters=True is not implemented by hip_ad_rgb")
+        if self.max_depth < 0 and self.max_depth != -1:
+            raise RuntimeError("\"max_depth\" must be set to -1 (infinite) or a value >= 0")
+        if self.rr_depth <= 0:
+            raise RuntimeError("\"rr_depth\" must be set to a value greater than zero!")
+        self.chunk_lanes = int(props.get('chunk_lanes', 0))
+        self._h = None
+
+    def _handle(self):
+        if self._h is None:
+            h = C.c_void_p()
+            check(lib().har_integrator_create(0 if self.type == 'path' else 1, self.max_depth, self.rr_depth, self.chunk_lanes, C.byref(h)))
+            self._h = h
+        return self._h
+
+    def __del__(self):
+        try:
+            if self._h is not None:
+                lib().har_integrator_destroy(self._h)
+        except Exception:
+            pass
+
+    def set_profiling(self, enable):
+        check(lib().har_integrator_set_profiling(self._handle(), 1 if enable else 0))
+
+    def timing(self):
+        ms = (C.c_float * 8)(); cnt = (C.c_uint32 * 8)()
+        check(lib().har_render_timing(self._handle(), ms, cnt))
+        names = ["raygen", "trace_closest", "shade", "resolve", "splat", "total", "other", "_"]
+        return {names[i]: (ms[i], cnt[i]) for i in range(7)}
+
+    def stats(self):
+        st = _capi.HarStats()
+        check(lib().har_render_stats(self._handle(), C.byref(st)))
+        return dict(paths=st.paths, vertices=st.vertices, closest_rays=st.closest_rays, shadow_rays=st.shadow_rays)
+
+    def _sensor(self, scene, sensor):
+        return scene.sensors()[sensor] if isinstance(sensor, int) else sensor
+
+    def render_film(self, scene, sensor=0, seed=0, spp=0, lanes=None, film=None):
+        """Raw {R,G,B,W} accumulation of lanes [begin, end) (all when None); no develop."""
+        torch = _torch(); dev = _device()
+        sensor = self._sensor(scene, sensor)
+        if spp:
+            sensor.sampler().set_sample_count(spp)
+        spp = sensor.sampler().sample_count()
+        w, h = sensor.film().crop_size()
+        if film is None:
+            film = torch.zeros((h, w, 4), dtype=torch.float32, device=dev)
+        lb, le = lanes if lanes else (0, 0)
+        check(lib().har_render(scene._handle(), self._handle(), C.byref(sensor.har), (sensor.sampler().m_base_seed + int(seed)) & 0xffffffff,
+                               spp, lb, le, _ptr(film), _stream()))
+        return film
+
+    def render(self, scene, sensor=0, seed=0, spp=0, develop=True, evaluate=True):
+        """SamplingIntegrator::render (integrator.cpp:151) / ADIntegrator.render (common.py:46)."""
+        torch = _torch()
+        sensor = self._sensor(scene, sensor)
+        film = self.render_film(scene, sensor, seed, spp)
+        if not develop:
+            if self.type == 'prb':
+                raise Exception("develop=True must be specified when invoking AD integrators")
+            out = film
+        else:
+            out = develop_film(film)
+        if evaluate:
+            torch.cuda.current_stream().synchronize()
+            self.stats()                 # surfaces device-side errors (traversal stack overflow)
+        return out
+
+    def render_backward(self, scene, params, grad_in, sensor=0, seed=0, spp=0, lanes=None, weight_film=None):
+        """RBIntegrator.render_backward (common.py:625-783): returns {key: gradient tensor}."""
+        if self.type != 'prb':
+            raise RuntimeError("render_backward(): only the `prb` integrator implements the adjoint pass in hip_ad_rgb")
+        torch = _torch(); dev = _device()
+        sensor = self._sensor(scene, sensor)
+        if spp:
+            sensor.sampler().set_sample_count(spp)
+        spp = sensor.sampler().sample_count()
+        w, h = sensor.film().crop_size()
+        sd = (sensor.sampler().m_base_seed + int(seed)) & 0xffffffff
+        lb, le = lanes if lanes else (0, 0)
+        if weight_film is None:
+            weight_film = torch.zeros((h, w, 4), dtype=torch.float32, device=dev)
+            check(lib().har_render_weights(C.byref(sensor.har), sd, spp, lb, le, _ptr(weight_film), _stream()))
+        grad_in = torch.as_tensor(grad_in, dtype=torch.float32, device=dev).reshape(h, w, 3).contiguous()
+        g_refl = torch.zeros((len(scene.bsdfs), 3), dtype=torch.float32, device=dev)
+        g_tex = [torch.zeros(tuple(t.shape), dtype=torch.float32, device=dev) for t in scene.textures]
+        ptrs = (C.c_void_p * max(1, len(g_tex)))(*[t.data_ptr() for t in g_tex])
+        check(lib().har_render_backward(scene._handle(), self._handle(), C.byref(sensor.har), _ptr(grad_in), _ptr(weight_film), sd, spp,
+                                        lb, le, _ptr(g_refl), ptrs, _stream()))
+        return scene._gradients(g_refl, g_tex)
+
+
+def develop_film(film):
+    torch = _torch()
+    h, w, _ = film.shape
+    img = torch.empty((h, w, 3), dtype=torch.float32, device=film.device)
+    check(lib().har_film_develop(_ptr(film), w, h, _ptr(img), _stream()))
+    return img
+
+
+# ---------------------------------------------------------------------------
+#  Scene
+# ---------------------------------------------------------------------------
+
+class Scene:
+    """Scene (src/render/scene.cpp): owns the flat SceneIR arrays and the device accel."""
+
+    def __init__(self, children):
+        self.bsdf_objs = []; self.meshes = []; self.top_mesh_count = 0
+        self.groups = []; self.instances = []; self.emitters = []
+        self.m_sensors = []; self.m_integrator = None; self.textures = []
+        self._h = None; self._keep = []
+        named = {}
+        shapes = []; groups = []; insts = []
+        for key, obj in children.items():
+            if isinstance(obj, BSDF):
+                named[key] = obj
+                if obj.id is None:
+                    obj.id = key
+                self._add_bsdf(obj)
+        for key, obj in children.items():
+            if isinstance(obj, Sensor):
+                self.m_sensors.append(obj)
+            elif isinstance(obj, Integrator):
+                self.m_integrator = obj
+            elif isinstance(obj, Mesh):
+                shapes.append((key, obj))
+            elif isinstance(obj, ShapeGroup):
+                groups.append((key, obj))
+            elif isinstance(obj, Instance):
+                insts.append((key, obj))
+        for key, m in shapes:
+            self._add_mesh(key, m)
+        self.top_mesh_count = len(self.meshes)
+        gindex = {}
+        for key, g in groups:
+            first = len(self.meshes)
+            for i, m in enumerate(g.shapes):
+                if m.emitter is not None:
+                    raise RuntimeError("Instancing of emitters is not supported")
+                self._add_mesh("%s.%d" % (key, i), m)
+            gindex[id(g)] = len(self.groups)
+            self.groups.append((first, len(self.meshes) - first))
+        for key, it in insts:
+            if id(it.group) not in gindex:
+                raise RuntimeError("A reference to a 'shapegroup' must be specified!")
+            self.instances.append((gindex[id(it.group)], it.to_world.col_major_3x4(), it.to_world.inverse().col_major_3x4()))
+
+    # -- construction helpers
+    def _add_bsdf(self, b):
+        if b.scene is self:
+            return b.index
+        b.scene = self; b.index = len(self.bsdf_objs)
+        if b.texture is not None:
+            b.tex_index = len(self.textures); self.textures.append(b.texture)
+        self.bsdf_objs.append(b)
+        return b.index
+
+    @property
+    def bsdfs(self):
+        return self.bsdf_objs
+
+    def _add_mesh(self, key, m):
+        if m.bsdf is None:
+            m.bsdf = BSDF()
+        bi = self._add_bsdf(m.bsdf)
+        em = -1
+        if m.emitter is not None:
+            if not hasattr(m, 'rect'):
+                raise RuntimeError("area emitters are implemented for `rectangle` shapes only in hip_ad_rgb")
+            em = len(self.emitters)
+            self.emitters.append(dict(mesh=len(self.meshes), radiance=m.emitter, to_world=m.rect['to_world'].col_major_3x4(),
+                                      normal=m.rect['normal'], inv_area=m.rect['inv_area']))
+        self.meshes.append(dict(key=key, V=np.ascontiguousarray(m.V), F=np.ascontiguousarray(m.F), bsdf=bi, emitter=em, flags=m.flags))
+
+    # -- C ABI description
+    def desc(self):
+        M = _capi
+        meshes = (M.HarMesh * max(1, len(self.meshes)))()
+        for i, m in enumerate(self.meshes):
+            meshes[i].vertex_ptr = _fp(m["V"]); meshes[i].index_ptr = _up(m["F"])
+            meshes[i].vertex_count = m["V"].shape[0]; meshes[i].face_count = m["F"].shape[0]
+            meshes[i].bsdf = m["bsdf"]; meshes[i].emitter = m["emitter"]; meshes[i].flags = m["flags"]
+        groups = (M.HarShapeGroup * max(1, len(self.groups)))()
+        for i, (a, b) in enumerate(self.groups):
+            groups[i].first_mesh = a; groups[i].mesh_count = b
+        insts = (M.HarInstance * max(1, len(self.instances)))()
+        for i, (g, tw, to) in enumerate(self.instances):
+            insts[i].group = g
+            insts[i].to_world = (C.c_float * 12)(*[float(x) for x in tw]); insts[i].to_object = (C.c_float * 12)(*[float(x) for x in to])
+        bsdfs = (M.HarBSDF * max(1, len(self.bsdf_objs)))()
+        for i, b in enumerate(self.bsdf_objs):
+            bsdfs[i].type = 0; bsdfs[i].texture = b.tex_index if b.texture is not None else -1
+            bsdfs[i].reflectance = (C.c_float * 3)(*[float(x) for x in b.value])
+        texs = (M.HarTexture * max(1, len(self.textures)))()
+        for i, t in enumerate(self.textures):
+            texs[i].data = _fp(t); texs[i].height = t.shape[0]; texs[i].width = t.shape[1]
+        ems = (M.HarEmitter * max(1, len(self.emitters)))()
+        for i, e in enumerate(self.emitters):
+            ems[i].type = 0; ems[i].mesh = e["mesh"]
+            ems[i].radiance = (C.c_float * 3)(*[float(x) for x in e["radiance"]])
+            ems[i].to_world = (C.c_float * 12)(*[float(x) for x in e["to_world"]])
+            ems[i].normal = (C.c_float * 3)(*[float(x) for x in e["normal"]]); ems[i].inv_area = float(e["inv_area"])
+        d = M.HarSceneDesc()
+        d.meshes = meshes; d.mesh_count = len(self.meshes); d.top_mesh_count = self.top_mesh_count
+        d.groups = groups; d.group_count = len(self.groups)
+        d.instances = insts; d.instance_count = len(self.instances)
+        d.bsdfs = bsdfs; d.bsdf_count = len(self.bsdf_objs)
+        d.textures = texs; d.texture_count = len(self.textures)
+        d.emitters = ems; d.emitter_count = len(self.emitters)
+        self._keep = [meshes, groups, insts, bsdfs, texs, ems]
+        return d
+
+    def _handle(self):
+        if self._h is None:
+            _device()
+            d = self.desc(); h = C.c_void_p()
+            check(lib().har_scene_create(C.byref(d), C.byref(h)))
+            self._h = h
+        return self._h
+
+    def __del__(self):
+        try:
+            if self._h is not None:
+                lib().har_scene_destroy(self._h)
+        except Exception:
+            pass
+
+    # -- reference API
+    def sensors(self):
+        return self.m_sensors
+
+    def integrator(self):
+        return self.m_integrator
+
+    def shapes(self):
+        return self.meshes
+
+    def accel_info(self):
+        info = (C.c_uint64 * 4)()
+        check(lib().har_scene_accel_info(self._handle(), info))
+        return dict(nodes=info[0], triangles=info[1], bytes=info[2], depth=info[3])
+
+    def _intersect(self, ray, naive):
+        torch = _torch(); dev = _device(); n = len(ray)
+        t = torch.empty(n, dtype=torch.float32, device=dev); u = torch.empty_like(t); v = torch.empty_like(t)
+        prim = torch.empty(n, dtype=torch.int32, device=dev); shape = torch.empty_like(prim); inst = torch.empty_like(prim)
+        check(lib().har_ray_intersect_preliminary(self._handle(), n, _ptr(ray.o), _ptr(ray.d), _ptr(ray.maxt), 1 if naive else 0,
+                                                  _ptr(t), _ptr(u), _ptr(v), _ptr(prim), _ptr(shape), _ptr(inst), _stream()))
+        return PreliminaryIntersection3f(self, t, u, v, prim, shape, inst)
+
+    def ray_intersect_preliminary(self, ray, coherent=False, reorder=False, reorder_hint=0, reorder_hint_bits=0, active=True):
+        return self._intersect(ray, False)
+
+    def ray_intersect(self, ray, ray_flags=None, coherent=False, active=True):
+        return self._intersect(ray, False).compute_surface_interaction(ray)
+
+    def ray_intersect_naive(self, ray, active=True):
+        return self._intersect(ray, True).compute_surface_interaction(ray)
+
+    def ray_test(self, ray, coherent=False, active=True, naive=False):
+        torch = _torch(); dev = _device(); n = len(ray)
+        hit = torch.empty(n, dtype=torch.uint8, device=dev)
+        check(lib().har_ray_test(self._handle(), n, _ptr(ray.o), _ptr(ray.d), _ptr(ray.maxt), 1 if naive else 0, _ptr(hit), _stream()))
+        return hit.bool()
+
+    def _compute_si(self, ray, pi):
+        torch = _torch(); dev = _device(); n = len(ray)
+        out = torch.empty((21, n), dtype=torch.float32, device=dev)
+        check(lib().har_compute_surface_interaction(self._handle(), n, _ptr(ray.o), _ptr(ray.d), _ptr(pi.t), _ptr(pi.prim_uv[0]), _ptr(pi.prim_uv[1]),
+                                                    _ptr(pi.prim_index), _ptr(pi.shape_index), _ptr(pi.instance), _ptr(out), _stream()))
+        return SurfaceInteraction3f(out)
+
+    # -- parameters (mi.traverse)
+    def _param_keys(self):
+        keys = {}
+        for b in self.bsdf_objs:
+            base = b.id if b.id else "bsdf%d" % b.index
+            if b.texture is not None:
+                keys[base + ".reflectance.data"] = ("tex", b)
+            else:
+                keys[base + ".reflectance.value"] = ("rgb", b)
+        return keys
+
+    def _gradients(self, g_refl, g_tex):
+        out = {}
+        for k, (kind, b) in self._param_keys().items():
+            out[k] = g_tex[b.tex_index] if kind == "tex" else g_refl[b.index]
+        return out
+
+
+class SceneParameters(dict):
+    """mi.traverse(scene): differentiable parameters as torch tensors (util.py SceneParameters)."""
+
+    def __init__(self, scene):
+        super().__init__()
+        torch = _torch()
+        self.scene = scene
+        dev = torch.device("cuda", torch.cuda.current_device()) if torch.cuda.is_available() else torch.device("cpu")
+        for k, (kind, b) in scene._param_keys().items():
+            self[k] = torch.tensor(b.texture if kind == "tex" else b.value, dtype=torch.float32, device=dev)
+
+    def update(self, values=None):
+        if values:
+            for k, v in values.items():
+                self[k] = v
+        for k, (kind, b) in self.scene._param_keys().items():
+            v = self[k].detach().to("cpu", copy=True).numpy().astype(np.float32)
+            if kind == "tex":
+                b.texture = np.ascontiguousarray(v.reshape(b.texture.shape)); self.scene.textures[b.tex_index] = b.texture
+                if self.scene._h is not None:
+                    check(lib().har_scene_set_texture(self.scene._h, b.tex_index, _fp(b.texture)))
+            else:
+                b.value = np.ascontiguousarray(v.reshape(3))
+                if self.scene._h is not None:
+                    check(lib().har_scene_set_reflectance(self.scene._h, b.index, _fp(b.value)))
+
+
+def traverse(scene):
+    return SceneParameters(scene)
+
+
+# ---------------------------------------------------------------------------
+#  PluginManager (src/core/plugin.cpp:157-282): registry keyed by (name, variant)
+# ---------------------------------------------------------------------------
+
+_REGISTRY = {}
+
+
+def register_plugin(name, variant_name, instantiate):
+    """PluginManager::register_plugin (plugin.cpp:209-214)."""
+    _REGISTRY[(name, variant_name)] = instantiate
+
+
+def _resolve(value, named, parent_key=None):
+    if isinstance(value, dict) and 'type' in value:
+        if value['type'] == 'ref':
+            if value['id'] not in named:
+                raise RuntimeError("Referenced id \"%s\" not found" % value['id'])
+            return named[value['id']]
+        return _create(value, named, parent_key)
+    return value
+
+
+def _create(props, named, key=None):
+    t = props['type']
+    ctor = _REGISTRY.get((t, VARIANT))
+    if ctor is None:
+        raise RuntimeError("Plugin \"%s\" not found for variant \"%s\". Available: %s" % (t, VARIANT, sorted(k[0] for k in _REGISTRY)))
+    return ctor(props, named, key)
+
+
+def _shape_common(m, props, named):
+    for k, v in props.items():
+        if isinstance(v, dict) and v.get('type') in ('ref',) or isinstance(v, dict) and v.get('type') in ('diffuse',):
+            obj = _resolve(v, named, k)
+            if isinstance(obj, BSDF):
+                m.bsdf = obj
+        elif isinstance(v, BSDF):
+            m.bsdf = v
+        elif isinstance(v, dict) and v.get('type') == 'area':
+            rad = v.get('radiance', {'type': 'rgb', 'value': 1.0})
+            val = rad['value'] if isinstance(rad, dict) else rad
+            m.emitter = _f32([val] * 3 if np.isscalar(val) else val)
+        elif isinstance(v, dict) and 'type' in v and k not in ('to_world',):
+            if (v['type'], VARIANT) not in _REGISTRY:
+                raise RuntimeError("Plugin \"%s\" not found for variant \"%s\"" % (v['type'], VARIANT))
+    return m
+
+
+def _mk_scene(props, named, key):
+    children = {}
+    for k, v in props.items():
+        if k == 'type':
+            continue
+        if isinstance(v, dict) and v.get('type') == 'diffuse':
+            named[k] = _create(v, named, k); children[k] = named[k]
+    for k, v in props.items():
+        if k == 'type' or k in children:
+            continue
+        obj = _resolve(v, named, k) if isinstance(v, dict) else v
+        if isinstance(obj, (Mesh, Sensor, Integrator, BSDF, ShapeGroup, Instance)):
+            if isinstance(obj, ShapeGroup):
+                named[k] = obj
+            children[k] = obj
+    return Scene(children)
+
+
+def _mk_shapegroup(props, named, key):
+    shapes = []
+    for k, v in props.items():
+        if isinstance(v, dict) and 'type' in v:
+            obj = _resolve(v, named, k)
+            if isinstance(obj, Mesh):
+                shapes.append(obj)
+        elif isinstance(v, Mesh):
+            shapes.append(v)
+    g = ShapeGroup(shapes)
+    if key:
+        named[key] = g
+    return g
+
+
+def _mk_instance(props, named, key):
+    group = None
+    for k, v in props.items():
+        obj = _resolve(v, named, k) if isinstance(v, dict) else v
+        if isinstance(obj, ShapeGroup):
+            if group is not None:
+                raise RuntimeError("Only a single shapegroup can be specified per instance.")
+            group = obj
+    if group is None:
+        raise RuntimeError("A reference to a 'shapegroup' must be specified!")
+    return Instance(group, props.get('to_world', ScalarTransform4f()))
+
+
+def _mk_mesh(props, named, key):
+    m = Mesh(key or "mesh").from_fields(props['faces'], props['positions'], props.get('normals'), props.get('texcoords'))
+    if 'to_world' in props:
+        m.transform(props['to_world'])
+    return _shape_common(m, props, named)
+
+
+for _name, _fn in {
+    'scene': _mk_scene,
+    'path': lambda p, n, k: Integrator(p),
+    'prb': lambda p, n, k: Integrator(p),
+    'perspective': lambda p, n, k: Sensor({kk: (_resolve(v, n, kk) if isinstance(v, dict) and v.get('type') in ('hdrfilm', 'independent') else v) for kk, v in p.items()}),
+    'hdrfilm': lambda p, n, k: Film(p),
+    'independent': lambda p, n, k: Sampler(p),
+    'diffuse': lambda p, n, k: BSDF(p, id=k),
+    'rectangle': lambda p, n, k: _shape_common(_rectangle(p), p, n),
+    'cube': lambda p, n, k: _shape_common(_cube(p), p, n),
+    'mesh': _mk_mesh,
+    'shapegroup': _mk_shapegroup,
+    'instance': _mk_instance,
+    'gaussian': lambda p, n, k: p, 'box': lambda p, n, k: p, 'rgb': lambda p, n, k: p, 'bitmap': lambda p, n, k: p, 'area': lambda p, n, k: p,
+}.items():
+    register_plugin(_name, VARIANT, _fn)
+
+
+def register_integrator(name, fn):
+    """mi.register_integrator (src/render/python/scene_v.cpp:166-171)."""
+    register_plugin(name, VARIANT, lambda p, n, k: fn(p))
+
+
+def load_dict(d):
+    """mi.load_dict (src/core/python/parser.cpp:561)."""
+    if _variant is None:
+        set_variant(VARIANT)
+    return _create(d, {}, None)
+
+
+# ---------------------------------------------------------------------------
+#  mi.render + _RenderOp (src/python/python/util.py:344-528) as a torch autograd Function
+# ---------------------------------------------------------------------------
+
+def sample_tea_32(v0, v1, rounds=4):
+    v0 &= 0xffffffff; v1 &= 0xffffffff; s = 0
+    for _ in range(rounds):
+        s = (s + 0x9e3779b9) & 0xffffffff
+        v0 = (v0 + ((((v1 << 4) & 0xffffffff) + 0xa341316c) ^ ((v1 + s) & 0xffffffff) ^ ((v1 >> 5) + 0xc8013ea4))) & 0xffffffff
+        v1 = (v1 + ((((v0 << 4) & 0xffffffff) + 0xad90777d) ^ ((v0 + s) & 0xffffffff) ^ ((v0 >> 5) + 0x7e95761e))) & 0xffffffff
+    return v0, v1
+
+
+def render(scene, params=None, sensor=0, integrator=None, seed=0, seed_grad=0, spp=0, spp_grad=0):
+    torch = _torch()
+    if integrator is None:
+        integrator = scene.integrator()
+    if integrator is None:
+        raise Exception('No integrator specified! Add an integrator in the scene description or provide an integrator directly as argument.')
+    if isinstance(sensor, int):
+        if len(scene.sensors()) == 0:
+            raise Exception('No sensor specified! Add a sensor in the scene description or provide a sensor directly as argument.')
+        sensor = scene.sensors()[sensor]
+    if spp_grad == 0:
+        spp_grad = spp
+    if seed_grad == 0:
+        seed_grad = sample_tea_32(seed, 1)[0]
+    elif seed_grad == seed:
+        raise Exception('The primal and differential seed should be different to ensure unbiased gradient computation!')
+    keys = [k for k, v in (params or {}).items() if getattr(v, 'requires_grad', False)]
+    if not keys:
+        return integrator.render(scene, sensor, seed, spp)
+    params.update()
+
+    class _RenderOp(torch.autograd.Function):
+        @staticmethod
+        def forward(ctx, *tensors):
+            return integrator.render(scene, sensor, seed, spp)
+
+        @staticmethod
+        def backward(ctx, grad_out):
+            grads = integrator.render_backward(scene, params, grad_out, sensor, seed_grad, spp_grad)
+            return tuple(grads[k].reshape(params[k].shape) for k in keys)
+
+    return _RenderOp.apply(*[params[k] for k in keys])

@@ -1,0 +1,216 @@
+/*
+ * har_accel_build.cpp -- host-side builder of the compressed 8-wide BVH.
+ *
+ * Replaces the accel builders the reference delegates to third-party code
+ * (Embree rtcCommitScene, src/render/scene_embree.inl:198-292; OptiX GAS/IAS,
+ * src/render/scene_optix.inl:484-629; build_metal_accel, src/render/metal/accel.h:27-33)
+ * and consumes the same lowering as SceneIRBuilder::build
+ * (src/render/scene_ir.cpp:12-92): one BLAS for the top-level triangle geometry,
+ * one BLAS per ShapeGroup, and a flattened TLAS with one identity entry for the
+ * top-level BLAS plus one transformed entry per Instance.
+ *
+ * Pipeline: binned-SAH binary BVH (<= 3 primitives per leaf) -> greedy
+ * surface-area collapse to 8 children -> octant-ordered slot assignment ->
+ * 8-bit quantisation of the child boxes against the (padded) parent box.
+ */
+#include "har_accel_build.h"
+
+#include <algorithm>
+#include <cmath>
+#include <cstring>
+#include <limits>
+
+namespace har {
+
+namespace {
+
+struct Box {
+    float lo[3], hi[3];
+    void reset() { for (int a = 0; a < 3; ++a) { lo[a] = std::numeric_limits<float>::infinity(); hi[a] = -lo[a]; } }
+    void grow(const Box &b) { for (int a = 0; a < 3; ++a) { lo[a] = std::min(lo[a], b.lo[a]); hi[a] = std::max(hi[a], b.hi[a]); } }
+    float area() const { float dx = hi[0] - lo[0], dy = hi[1] - lo[1], dz = hi[2] - lo[2]; return 2.f * (dx * dy + dy * dz + dz * dx); }
+};
+
+struct BNode { Box box; int left = -1, right = -1; uint32_t first = 0, count = 0; };
+
+struct Builder {
+    const std::vector<PrimBox> &prims;
+    std::vector<uint32_t> order;
+    std::vector<BNode> bn;
+
+    explicit Builder(const std::vector<PrimBox> &p) : prims(p), order(p.size()) { for (uint32_t i = 0; i < p.size(); ++i) order[i] = i; }
+
+    Box prim_box(uint32_t i) const { Box b; std::memcpy(b.lo, prims[i].lo, 12); std::memcpy(b.hi, prims[i].hi, 12); return b; }
+    float centroid(uint32_t i, int a) const { return 0.5f * (prims[i].lo[a] + prims[i].hi[a]); }
+
+    int build(uint32_t begin, uint32_t end) {
+        int idx = (int) bn.size(); bn.emplace_back();
+        Box box; box.reset(); Box cb; cb.reset();
+        for (uint32_t i = begin; i < end; ++i) {
+            box.grow(prim_box(order[i]));
+            for (int a = 0; a < 3; ++a) { float c = centroid(order[i], a); cb.lo[a] = std::min(cb.lo[a], c); cb.hi[a] = std::max(cb.hi[a], c); }
+        }
+        bn[idx].box = box;
+        uint32_t count = end - begin;
+        if (count <= 3) { bn[idx].first = begin; bn[idx].count = count; return idx; }
+        constexpr int NB = 16;
+        float best = std::numeric_limits<float>::infinity(); int best_axis = -1, best_split = -1;
+        for (int axis = 0; axis < 3; ++axis) {
+            float ext = cb.hi[axis] - cb.lo[axis];
+            if (!(ext > 0.f)) continue;
+            Box bins[NB]; uint32_t cnt[NB];
+            for (int b = 0; b < NB; ++b) { bins[b].reset(); cnt[b] = 0; }
+            float scale = NB / ext;
+            for (uint32_t i = begin; i < end; ++i) {
+                int b = std::min(NB - 1, std::max(0, (int) ((centroid(order[i], axis) - cb.lo[axis]) * scale)));
+                bins[b].grow(prim_box(order[i])); cnt[b]++;
+            }
+            Box rb[NB]; uint32_t rc[NB]; Box acc; acc.reset(); uint32_t c = 0;
+            for (int b = NB - 1; b >= 0; --b) { acc.grow(bins[b]); c += cnt[b]; rb[b] = acc; rc[b] = c; }
+            acc.reset(); c = 0;
+            for (int b = 0; b < NB - 1; ++b) {
+                acc.grow(bins[b]); c += cnt[b];
+                if (c == 0 || rc[b + 1] == 0) continue;
+                float cost = c * acc.area() + rc[b + 1] * rb[b + 1].area();
+                if (cost < best) { best = cost; best_axis = axis; best_split = b; }
+            }
+        }
+        uint32_t mid;
+        if (best_axis < 0) {
+            mid = begin + count / 2;
+        } else {
+            float ext = cb.hi[best_axis] - cb.lo[best_axis], scale = NB / ext, lo = cb.lo[best_axis];
+            int axis = best_axis, split = best_split;
+            auto it = std::partition(order.begin() + begin, order.begin() + end, [&](uint32_t p) {
+                int b = std::min(NB - 1, std::max(0, (int) ((centroid(p, axis) - lo) * scale)));
+                return b <= split; });
+            mid = (uint32_t) (it - order.begin());
+            if (mid == begin || mid == end) mid = begin + count / 2;
+        }
+        int l = build(begin, mid), r = build(mid, end);
+        bn[idx].left = l; bn[idx].right = r;
+        return idx;
+    }
+};
+
+static inline uint8_t exp_byte(double extent) {
+    // smallest e with extent / 2^e <= 255
+    int e = -126;
+    if (extent > 0.0) {
+        e = (int) std::ceil(std::log2(extent / 255.0));
+        while (extent / std::ldexp(1.0, e) > 255.0) ++e;
+        while (e > -126 && extent / std::ldexp(1.0, e - 1) <= 255.0) --e;
+    }
+    e = std::max(-126, std::min(127, e));
+    return (uint8_t) (e + 127);
+}
+
+} // namespace
+
+void pad_prim_box(PrimBox &b) {
+    float m = 1.f;
+    for (int a = 0; a < 3; ++a) m = std::max(m, std::max(std::fabs(b.lo[a]), std::fabs(b.hi[a])));
+    float pad = 2e-5f * m;
+    for (int a = 0; a < 3; ++a) { b.lo[a] -= pad; b.hi[a] += pad; }
+}
+
+uint32_t build_bvh8(const std::vector<PrimBox> &prims, std::vector<Node8> &nodes, uint32_t leaf_base,
+                    std::vector<uint32_t> &leaf_order, Bvh8Stats *stats) {
+    const uint32_t root_out = (uint32_t) nodes.size();
+    nodes.emplace_back();
+    std::memset(&nodes[root_out], 0, sizeof(Node8));
+    if (prims.empty()) {            // empty BLAS: a node without children
+        nodes[root_out].ex = nodes[root_out].ey = nodes[root_out].ez = 1;
+        return root_out;
+    }
+    Builder B(prims);
+    B.bn.reserve(prims.size());
+    int broot = B.build(0, (uint32_t) prims.size());
+
+    struct Work { int b; uint32_t out; uint32_t depth; };
+    std::vector<Work> queue; queue.push_back({ broot, root_out, 1 });
+    uint32_t max_depth = 1;
+    while (!queue.empty()) {
+        Work w = queue.back(); queue.pop_back();
+        max_depth = std::max(max_depth, w.depth);
+        const BNode &bn = B.bn[w.b];
+        int child[8]; int nc = 0;
+        if (bn.count) child[nc++] = w.b;
+        else { child[nc++] = bn.left; child[nc++] = bn.right; }
+        // greedy collapse: open the internal child with the largest surface area
+        for (;;) {
+            if (nc >= 8) break;
+            int best = -1; float ba = -1.f;
+            for (int i = 0; i < nc; ++i) if (!B.bn[child[i]].count) { float a = B.bn[child[i]].box.area(); if (a > ba) { ba = a; best = i; } }
+            if (best < 0) break;
+            int c = child[best];
+            child[best] = B.bn[c].left; child[nc++] = B.bn[c].right;
+        }
+        // node box
+        Box nb; nb.reset();
+        for (int i = 0; i < nc; ++i) nb.grow(B.bn[child[i]].box);
+        // octant-ordered slot assignment (greedy on cost = <centroid offset, slot direction>)
+        int slot_of[8]; bool slot_used[8] = { false }; bool done[8] = { false };
+        float cx = 0.5f * (nb.lo[0] + nb.hi[0]), cy = 0.5f * (nb.lo[1] + nb.hi[1]), cz = 0.5f * (nb.lo[2] + nb.hi[2]);
+        for (int k = 0; k < nc; ++k) {
+            float bestc = std::numeric_limits<float>::infinity(); int bi = -1, bs = -1;
+            for (int i = 0; i < nc; ++i) {
+                if (done[i]) continue;
+                const Box &cb = B.bn[child[i]].box;
+                float ox = 0.5f * (cb.lo[0] + cb.hi[0]) - cx, oy = 0.5f * (cb.lo[1] + cb.hi[1]) - cy, oz = 0.5f * (cb.lo[2] + cb.hi[2]) - cz;
+                for (int s = 0; s < 8; ++s) {
+                    if (slot_used[s]) continue;
+                    float cost = ox * ((s & 4) ? -1.f : 1.f) + oy * ((s & 2) ? -1.f : 1.f) + oz * ((s & 1) ? -1.f : 1.f);
+                    if (cost < bestc) { bestc = cost; bi = i; bs = s; }
+                }
+            }
+            done[bi] = true; slot_used[bs] = true; slot_of[bi] = bs;
+        }
+        int child_in_slot[8]; for (int s = 0; s < 8; ++s) child_in_slot[s] = -1;
+        for (int i = 0; i < nc; ++i) child_in_slot[slot_of[i]] = child[i];
+
+        Node8 n; std::memset(&n, 0, sizeof(n));
+        n.px = nb.lo[0]; n.py = nb.lo[1]; n.pz = nb.lo[2];
+        n.ex = exp_byte((double) nb.hi[0] - (double) n.px);
+        n.ey = exp_byte((double) nb.hi[1] - (double) n.py);
+        n.ez = exp_byte((double) nb.hi[2] - (double) n.pz);
+        const double sc[3] = { std::ldexp(1.0, (int) n.ex - 127), std::ldexp(1.0, (int) n.ey - 127), std::ldexp(1.0, (int) n.ez - 127) };
+        const double org[3] = { n.px, n.py, n.pz };
+        n.child_base = (uint32_t) nodes.size();
+        n.tri_base = leaf_base + (uint32_t) leaf_order.size();
+        uint32_t n_internal = 0, tri_off = 0;
+        for (int s = 0; s < 8; ++s) {
+            int c = child_in_slot[s];
+            if (c < 0) continue;
+            const BNode &cn = B.bn[c];
+            uint8_t *q[6] = { n.qlox, n.qloy, n.qloz, n.qhix, n.qhiy, n.qhiz };
+            for (int a = 0; a < 3; ++a) {
+                double lo = std::floor(((double) cn.box.lo[a] - org[a]) / sc[a]), hi = std::ceil(((double) cn.box.hi[a] - org[a]) / sc[a]);
+                q[a][s] = (uint8_t) std::max(0.0, std::min(255.0, lo));
+                q[3 + a][s] = (uint8_t) std::max(0.0, std::min(255.0, hi));
+            }
+            if (cn.count) {
+                n.meta[s] = (uint8_t) ((((1u << cn.count) - 1u) << 5) | tri_off);
+                for (uint32_t i = 0; i < cn.count; ++i) leaf_order.push_back(B.order[cn.first + i]);
+                tri_off += cn.count;
+            } else {
+                n.meta[s] = (uint8_t) ((1u << 5) | (24u + (uint32_t) s));
+                n.imask |= (uint8_t) (1u << s);
+                ++n_internal;
+            }
+        }
+        nodes[w.out] = n;
+        uint32_t base = (uint32_t) nodes.size();
+        nodes.resize(nodes.size() + n_internal);
+        uint32_t k = 0;
+        for (int s = 0; s < 8; ++s) {
+            int c = child_in_slot[s];
+            if (c < 0 || B.bn[c].count) continue;
+            queue.push_back({ c, base + k, w.depth + 1 }); ++k;
+        }
+    }
+    if (stats) { stats->max_depth = std::max(stats->max_depth, max_depth); }
+    return root_out;
+}
+
+} // namespace har

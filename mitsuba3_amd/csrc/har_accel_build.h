@@ -1,0 +1,20 @@
+/* har_accel_build.h -- host builder interface of the compressed 8-wide BVH (see har_accel_build.cpp). */
+#pragma once
+#include "har_accel.h"
+#include <vector>
+
+namespace har {
+
+struct PrimBox { float lo[3], hi[3]; };
+struct Bvh8Stats { uint32_t max_depth = 0; };
+
+/* conservative padding applied to every primitive box before the build */
+void pad_prim_box(PrimBox &b);
+
+/* Appends a BVH8 over `prims` to `nodes`; leaves reference positions
+ * leaf_base + k of the primitive sequence appended to `leaf_order` (indices into
+ * `prims`).  Returns the index of the root node. */
+uint32_t build_bvh8(const std::vector<PrimBox> &prims, std::vector<Node8> &nodes, uint32_t leaf_base,
+                    std::vector<uint32_t> &leaf_order, Bvh8Stats *stats);
+
+} // namespace har

@@ -1,0 +1,471 @@
+/*
+ * har_capi.hip -- implementation of the C ABI declared in include/hip_ad_rgb.h.
+ *
+ * Host-side driver of the wavefront integrators: SamplingIntegrator::render
+ * (src/render/integrator.cpp:151-396, JIT branch) and RBIntegrator.render_backward
+ * (src/python/python/ad/integrators/common.py:625-783) re-expressed as an
+ * asynchronous sequence of HIP kernel launches on the caller's stream.  There is
+ * no CPU fallback anywhere in this file: without a HIP device every entry point
+ * that touches the GPU fails with an error.
+ */
+#include "../../include/hip_ad_rgb.h"
+#include "har_kernels.h"
+#include "har_scene_host.h"
+
+#include <algorithm>
+#include <cstdio>
+#include <cstring>
+#include <string>
+#include <vector>
+
+using namespace har;
+
+static thread_local std::string g_error;
+static int fail(const std::string &msg) { g_error = msg; return 1; }
+
+#define HIP_TRY(expr)                                                                          \
+    do { hipError_t _e = (expr); if (_e != hipSuccess) {                                       \
+        return fail(std::string(#expr) + ": " + hipGetErrorString(_e)); } } while (0)
+
+template <typename T> static hipError_t upload(const std::vector<T> &v, const T **dst, std::vector<void *> &owned) {
+    *dst = nullptr;
+    size_t bytes = std::max<size_t>(v.size(), 1) * sizeof(T);
+    void *p = nullptr;
+    hipError_t e = hipMalloc(&p, bytes);
+    if (e != hipSuccess) return e;
+    owned.push_back(p);
+    if (!v.empty()) { e = hipMemcpy(p, v.data(), v.size() * sizeof(T), hipMemcpyHostToDevice); if (e != hipSuccess) return e; }
+    *dst = (const T *) p;
+    return hipSuccess;
+}
+
+struct HarSceneImpl {
+    HostScene hs;
+    DScene ds{};
+    std::vector<void *> owned;
+    std::vector<float *> tex_dev;
+    DBsdf *d_bsdfs = nullptr;
+};
+
+struct HarIntegratorImpl {
+    int type = HAR_INTEGRATOR_PATH;
+    uint32_t max_depth = 0, rr_depth = 5, chunk = 1u << 20;
+    // workspace
+    uint32_t ws_lanes = 0; bool ws_adjoint = false;
+    std::vector<void *> owned;
+    WaveState st[2]{};
+    float4 *h0 = nullptr; uint2 *h1 = nullptr;
+    ItemArrays items{};
+    float4 *result = nullptr, *dL = nullptr;
+    float *adj = nullptr; size_t adj_floats = 0;
+    uint32_t *counters = nullptr;
+    unsigned long long *totals = nullptr;
+    int *status = nullptr;
+    float **d_grad_tex = nullptr; size_t grad_tex_cap = 0;
+    // profiling
+    bool profiling = false;
+    std::vector<hipEvent_t> events; std::vector<int> ev_class; size_t ev_used = 0;
+    hipStream_t last_stream = nullptr;
+    void free_ws() { for (void *p : owned) (void) hipFree(p); owned.clear(); ws_lanes = 0; }
+};
+
+namespace {
+
+enum { CLS_RAYGEN = 0, CLS_TRACE = 1, CLS_SHADE = 2, CLS_RESOLVE = 3, CLS_SPLAT = 4, CLS_OTHER = 6, CLS_START = 7 };
+
+template <typename T> int ws_alloc(HarIntegratorImpl *I, T **p, size_t count) {
+    void *q = nullptr;
+    hipError_t e = hipMalloc(&q, std::max<size_t>(count, 1) * sizeof(T));
+    if (e != hipSuccess) return fail(std::string("hipMalloc(workspace): ") + hipGetErrorString(e));
+    I->owned.push_back(q); *p = (T *) q;
+    return 0;
+}
+
+int ensure_workspace(HarIntegratorImpl *I, uint32_t lanes, bool adjoint) {
+    if (I->ws_lanes >= lanes && (I->ws_adjoint || !adjoint)) return 0;
+    I->free_ws();
+    I->counters = nullptr; I->totals = nullptr; I->status = nullptr; I->adj = nullptr; I->adj_floats = 0; I->d_grad_tex = nullptr; I->grad_tex_cap = 0;
+    for (int k = 0; k < 2; ++k) {
+        if (ws_alloc(I, &I->st[k].a0, lanes) || ws_alloc(I, &I->st[k].a1, lanes) || ws_alloc(I, &I->st[k].a2, lanes) ||
+            ws_alloc(I, &I->st[k].a3, lanes) || ws_alloc(I, &I->st[k].a4, lanes)) return 1;
+    }
+    if (ws_alloc(I, &I->h0, lanes) || ws_alloc(I, &I->h1, lanes)) return 1;
+    if (ws_alloc(I, &I->items.s0, lanes) || ws_alloc(I, &I->items.s1, lanes) || ws_alloc(I, &I->items.s2, lanes)) return 1;
+    I->items.s3 = I->items.s4 = nullptr; I->dL = nullptr;
+    if (adjoint && (ws_alloc(I, &I->items.s3, lanes) || ws_alloc(I, &I->items.s4, lanes) || ws_alloc(I, &I->dL, lanes))) return 1;
+    if (ws_alloc(I, &I->result, lanes)) return 1;
+    if (ws_alloc(I, &I->counters, 2 * HAR_MAX_BOUNCE_SLOTS) || ws_alloc(I, &I->totals, 4) || ws_alloc(I, &I->status, 1)) return 1;
+    HIP_TRY(hipMemset(I->totals, 0, 4 * sizeof(unsigned long long)));
+    HIP_TRY(hipMemset(I->status, 0, sizeof(int)));
+    I->ws_lanes = lanes; I->ws_adjoint = adjoint;
+    return 0;
+}
+
+void prof_mark(HarIntegratorImpl *I, hipStream_t s, int cls) {
+    if (!I->profiling) return;
+    if (I->ev_used == I->events.size()) {
+        hipEvent_t e; if (hipEventCreate(&e) != hipSuccess) return;
+        I->events.push_back(e); I->ev_class.push_back(cls);
+    }
+    I->ev_class[I->ev_used] = cls;
+    (void) hipEventRecord(I->events[I->ev_used++], s);
+}
+
+uint32_t log2_exact(uint32_t v) { for (uint32_t k = 0; k < 32; ++k) if ((1u << k) == v) return k; return 0xffffffffu; }
+
+uint32_t bounce_limit(const HarIntegratorImpl *I) { return std::min<uint32_t>(I->max_depth, HAR_MAX_BOUNCE_SLOTS - 2); }
+
+/* one chunk: raygen + bounce loop.  `mode` selects path / prb primal / prb adjoint kernels */
+int run_chunk(HarSceneImpl *S, HarIntegratorImpl *I, const DSensor &C, int mode, uint32_t seed, uint32_t spp, uint32_t log_spp,
+              uint32_t lane_base, uint32_t n, float *grad_refl, hipStream_t s) {
+    HIP_TRY(hipMemsetAsync(I->counters, 0, 2 * HAR_MAX_BOUNCE_SLOTS * sizeof(uint32_t), s));
+    launch_raygen(mode, s, C, seed, spp, log_spp, lane_base, n, I->st[0], I->result, I->counters, I->adj, I->dL);
+    prof_mark(I, s, CLS_RAYGEN);
+    ShadeParams P{ seed, I->max_depth, I->rr_depth };
+    const uint32_t grid = std::min<uint32_t>((n + 255) / 256, 4096u);
+    const uint32_t nb = bounce_limit(I);
+    int cur = 0; uint32_t b = 0;
+    for (; b < nb; ++b) {
+        launch_trace_closest(s, grid, S->ds.accel, I->counters + b, I->st[cur], I->h0, I->h1, I->status);
+        prof_mark(I, s, CLS_TRACE);
+        launch_shade(mode, s, grid, S->ds, P, lane_base, I->counters + b, I->st[cur], I->h0, I->h1, I->st[cur ^ 1], I->counters + b + 1,
+                     I->items, I->counters + HAR_MAX_BOUNCE_SLOTS + b, I->result);
+        prof_mark(I, s, CLS_SHADE);
+        launch_resolve(mode, s, grid, S->ds, I->counters + HAR_MAX_BOUNCE_SLOTS + b, I->items, I->result, I->dL, grad_refl, I->d_grad_tex, I->status);
+        prof_mark(I, s, CLS_RESOLVE);
+        cur ^= 1;
+        if (b >= 15 && (b & 7) == 7) {           /* deep paths are rare: poll so that max_depth = -1 terminates */
+            uint32_t alive = 0;
+            HIP_TRY(hipMemcpyAsync(&alive, I->counters + b + 1, sizeof(uint32_t), hipMemcpyDeviceToHost, s));
+            HIP_TRY(hipStreamSynchronize(s));
+            if (alive == 0) { ++b; break; }
+        }
+    }
+    if (mode != MODE_PRB_PRIMAL) {
+        launch_accumulate_stats(s, I->counters, std::min(b + 1, nb), I->totals, n);
+        prof_mark(I, s, CLS_OTHER);
+    }
+    HIP_TRY(hipGetLastError());
+    return 0;
+}
+
+int check_common(HarSceneImpl *S, HarIntegratorImpl *I, const HarSensor *sensor, uint32_t spp, uint64_t &lb, uint64_t &le, DSensor &C, uint32_t &log_spp) {
+    if (!S || !I || !sensor) return fail("null scene / integrator / sensor");
+    std::string e;
+    if (!lower_sensor(*sensor, C, e)) return fail(e);
+    if (C.rfilter == 1 && 2 * (uint32_t) ceilf(C.radius - .5f) + 1 > HAR_MAX_FILTER_TAPS) return fail("reconstruction filter radius too large (max 9 taps)");
+    if (spp == 0) return fail("spp must be > 0");
+    uint64_t total = (uint64_t) C.crop_w * C.crop_h * spp;
+    /* 2^32 wavefront limit of JIT variants (integrator.cpp:276-294, common.py:358-363) */
+    if (total > 0xffffffffull) return fail("the rendering task exceeds 2^32 - 1 Monte Carlo samples; render in several passes");
+    if (lb == 0 && le == 0) le = total;
+    if (lb > le || le > total) return fail("invalid lane range");
+    log_spp = log2_exact(spp);
+    return 0;
+}
+
+} // namespace
+
+extern "C" {
+
+const char *har_last_error(void) { return g_error.c_str(); }
+
+const char *har_device_arch(void) {
+    static thread_local std::string arch;
+    int dev = 0; hipDeviceProp_t prop;
+    if (hipGetDevice(&dev) != hipSuccess || hipGetDeviceProperties(&prop, dev) != hipSuccess) return nullptr;
+    arch = prop.gcnArchName;
+    return arch.c_str();
+}
+
+int har_scene_create(const HarSceneDesc *desc, HarScene *out) {
+    if (!desc || !out) return fail("null argument");
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev == 0) return fail("hip_ad_rgb requires a HIP device (no CPU fallback)");
+    HarSceneImpl *S = new HarSceneImpl();
+    std::string e;
+    if (!lower_scene(*desc, S->hs, e)) { delete S; return fail(e); }
+    HostScene &hs = S->hs; DScene &D = S->ds;
+    hipError_t err = hipSuccess;
+    auto up = [&](auto &vec, auto **dst) { if (err == hipSuccess) err = upload(vec, dst, S->owned); };
+    up(hs.nodes, &D.accel.nodes); up(hs.tris, &D.accel.tris); up(hs.inst_recs, &D.accel.insts);
+    up(hs.blas_tri_ranges, &D.blas_tri_ranges); up(hs.verts, &D.verts); up(hs.faces, &D.faces);
+    up(hs.meshes, &D.meshes); up(hs.bsdfs, &D.bsdfs); up(hs.emitters, &D.emitters); up(hs.insts, &D.insts);
+    std::vector<DTexture> dt;
+    for (auto &t : hs.textures) {
+        const float *p = nullptr; up(t.data, &p);
+        S->tex_dev.push_back(const_cast<float *>(p)); dt.push_back(DTexture{ p, t.w, t.h });
+    }
+    up(dt, &D.textures);
+    if (err != hipSuccess) { for (void *p : S->owned) (void) hipFree(p); delete S; return fail(std::string("scene upload: ") + hipGetErrorString(err)); }
+    S->d_bsdfs = const_cast<DBsdf *>(D.bsdfs);
+    D.accel.root = hs.root; D.accel.has_tlas = hs.has_tlas; D.accel.n_tris = (uint32_t) hs.tris.size(); D.accel.n_insts = (uint32_t) hs.inst_recs.size();
+    D.n_emitters = (uint32_t) hs.emitters.size(); D.n_meshes = (uint32_t) hs.meshes.size();
+    D.n_bsdfs = (uint32_t) hs.bsdfs.size(); D.n_textures = (uint32_t) hs.textures.size();
+    if (hs.stats.max_depth + 4 > HAR_LDS_STACK_DEPTH)
+        fprintf(stderr, "[hip_ad_rgb] warning: BVH depth %u is close to the LDS traversal stack (%d entries)\n", hs.stats.max_depth, HAR_LDS_STACK_DEPTH);
+    *out = S;
+    return 0;
+}
+
+int har_scene_destroy(HarScene S) {
+    if (!S) return 0;
+    (void) hipDeviceSynchronize();     /* accel must outlive in-flight launches (scene_native.inl:44-57) */
+    for (void *p : S->owned) (void) hipFree(p);
+    delete S;
+    return 0;
+}
+
+int har_scene_set_reflectance(HarScene S, uint32_t bsdf, const float rgb[3]) {
+    if (!S || bsdf >= S->hs.bsdfs.size()) return fail("invalid bsdf index");
+    DBsdf &b = S->hs.bsdfs[bsdf]; b.r = rgb[0]; b.g = rgb[1]; b.b = rgb[2];
+    HIP_TRY(hipMemcpy(S->d_bsdfs + bsdf, &b, sizeof(DBsdf), hipMemcpyHostToDevice));
+    return 0;
+}
+int har_scene_set_texture(HarScene S, uint32_t tex, const float *data) {
+    if (!S || tex >= S->hs.textures.size()) return fail("invalid texture index");
+    HostTexture &t = S->hs.textures[tex];
+    t.data.assign(data, data + t.data.size());
+    HIP_TRY(hipMemcpy(S->tex_dev[tex], data, t.data.size() * sizeof(float), hipMemcpyHostToDevice));
+    return 0;
+}
+int har_scene_accel_info(HarScene S, uint64_t info[4]) {
+    if (!S) return fail("null scene");
+    info[0] = S->hs.nodes.size(); info[1] = S->hs.tris.size();
+    info[2] = S->hs.nodes.size() * sizeof(Node8) + S->hs.tris.size() * sizeof(TriRec) + S->hs.inst_recs.size() * sizeof(InstRec);
+    info[3] = S->hs.stats.max_depth;
+    return 0;
+}
+
+static int read_status(int *d_status, hipStream_t s) {
+    int st = 0;
+    HIP_TRY(hipMemcpyAsync(&st, d_status, sizeof(int), hipMemcpyDeviceToHost, s));
+    HIP_TRY(hipStreamSynchronize(s));
+    if (st == HAR_STACK_OVERFLOW) return fail("BVH traversal stack overflow (scene too deep for the LDS stack)");
+    return 0;
+}
+
+int har_ray_intersect_preliminary(HarScene S, uint32_t n, const float *o, const float *d, const float *maxt, int naive, float *t, float *u,
+                                  float *v, uint32_t *prim, uint32_t *shape, uint32_t *inst, void *stream) {
+    if (!S) return fail("null scene");
+    if (n == 0) return 0;
+    int *st = nullptr; HIP_TRY(hipMalloc(&st, sizeof(int))); HIP_TRY(hipMemsetAsync(st, 0, sizeof(int), (hipStream_t) stream));
+    launch_api_intersect((hipStream_t) stream, S->ds, n, o, d, maxt, naive, t, u, v, prim, shape, inst, st);
+    HIP_TRY(hipGetLastError());
+    int rc = read_status(st, (hipStream_t) stream); (void) hipFree(st);
+    return rc;
+}
+int har_ray_test(HarScene S, uint32_t n, const float *o, const float *d, const float *maxt, int naive, uint8_t *hit, void *stream) {
+    if (!S) return fail("null scene");
+    if (n == 0) return 0;
+    int *st = nullptr; HIP_TRY(hipMalloc(&st, sizeof(int))); HIP_TRY(hipMemsetAsync(st, 0, sizeof(int), (hipStream_t) stream));
+    launch_api_ray_test((hipStream_t) stream, S->ds, n, o, d, maxt, naive, hit, st);
+    HIP_TRY(hipGetLastError());
+    int rc = read_status(st, (hipStream_t) stream); (void) hipFree(st);
+    return rc;
+}
+int har_compute_surface_interaction(HarScene S, uint32_t n, const float *o, const float *d, const float *t, const float *u, const float *v,
+                                    const uint32_t *prim, const uint32_t *shape, const uint32_t *inst, float *out, void *stream) {
+    if (!S) return fail("null scene");
+    if (n == 0) return 0;
+    launch_api_si((hipStream_t) stream, S->ds, n, o, d, t, u, v, prim, shape, inst, out);
+    HIP_TRY(hipGetLastError());
+    return 0;
+}
+int har_sampler_seed(uint32_t seed, uint32_t lane_offset, uint32_t n, uint64_t *state, uint64_t *inc, void *stream) {
+    if (n == 0) return 0;
+    launch_api_sampler_seed((hipStream_t) stream, seed, lane_offset, n, state, inc);
+    HIP_TRY(hipGetLastError());
+    return 0;
+}
+int har_sampler_next_1d(uint32_t n, uint64_t *state, const uint64_t *inc, const uint8_t *active, float *out, void *stream) {
+    if (n == 0) return 0;
+    launch_api_sampler_next((hipStream_t) stream, n, state, inc, active, out, 1);
+    HIP_TRY(hipGetLastError());
+    return 0;
+}
+int har_sampler_next_2d(uint32_t n, uint64_t *state, const uint64_t *inc, const uint8_t *active, float *out, void *stream) {
+    if (n == 0) return 0;
+    launch_api_sampler_next((hipStream_t) stream, n, state, inc, active, out, 2);
+    HIP_TRY(hipGetLastError());
+    return 0;
+}
+int har_bsdf_eval_pdf(HarScene S, uint32_t bsdf, uint32_t n, const float *wi, const float *uv, const float *wo, float *value, float *pdf, void *stream) {
+    if (!S || bsdf >= S->hs.bsdfs.size()) return fail("invalid bsdf index");
+    if (n == 0) return 0;
+    launch_api_bsdf_eval_pdf((hipStream_t) stream, S->ds, bsdf, n, wi, uv, wo, value, pdf);
+    HIP_TRY(hipGetLastError());
+    return 0;
+}
+int har_bsdf_sample(HarScene S, uint32_t bsdf, uint32_t n, const float *wi, const float *uv, const float *sample1, const float *sample2,
+                    float *wo, float *pdf, float *weight, void *stream) {
+    (void) sample1;
+    if (!S || bsdf >= S->hs.bsdfs.size()) return fail("invalid bsdf index");
+    if (n == 0) return 0;
+    launch_api_bsdf_sample((hipStream_t) stream, S->ds, bsdf, n, wi, uv, sample2, wo, pdf, weight);
+    HIP_TRY(hipGetLastError());
+    return 0;
+}
+int har_sensor_sample_ray(const HarSensor *sensor, uint32_t n, const float *px, const float *py, float *o, float *d, float *maxt, void *stream) {
+    DSensor C; std::string e;
+    if (!sensor || !lower_sensor(*sensor, C, e)) return fail(e.empty() ? "null sensor" : e);
+    if (n == 0) return 0;
+    launch_api_sensor_ray((hipStream_t) stream, C, n, px, py, o, d, maxt);
+    HIP_TRY(hipGetLastError());
+    return 0;
+}
+int har_film_put(const HarSensor *sensor, uint32_t n, const float *px, const float *py, const float *values4, float *film, void *stream) {
+    DSensor C; std::string e;
+    if (!sensor || !lower_sensor(*sensor, C, e)) return fail(e.empty() ? "null sensor" : e);
+    if (n == 0) return 0;
+    launch_api_film_put((hipStream_t) stream, C, n, px, py, values4, film);
+    HIP_TRY(hipGetLastError());
+    return 0;
+}
+int har_film_develop(const float *film, uint32_t width, uint32_t height, float *image, void *stream) {
+    if (!film || !image) return fail("null film / image");
+    launch_develop((hipStream_t) stream, film, width * height, image);
+    HIP_TRY(hipGetLastError());
+    return 0;
+}
+
+int har_integrator_create(int type, int32_t max_depth, int32_t rr_depth, uint32_t chunk_lanes, HarIntegrator *out) {
+    if (!out) return fail("null argument");
+    if (type != HAR_INTEGRATOR_PATH && type != HAR_INTEGRATOR_PRB) return fail("unknown integrator type");
+    /* MonteCarloIntegrator ctor, src/render/integrator.cpp:539-550 */
+    if (max_depth < 0 && max_depth != -1) return fail("\"max_depth\" must be set to -1 (infinite) or a value >= 0");
+    if (rr_depth <= 0) return fail("\"rr_depth\" must be set to a value greater than zero!");
+    HarIntegratorImpl *I = new HarIntegratorImpl();
+    I->type = type; I->max_depth = (uint32_t) max_depth; I->rr_depth = (uint32_t) rr_depth;
+    if (chunk_lanes) I->chunk = std::max<uint32_t>(256u, (chunk_lanes + 255u) & ~255u);
+    *out = I;
+    return 0;
+}
+int har_integrator_destroy(HarIntegrator I) {
+    if (!I) return 0;
+    (void) hipDeviceSynchronize();
+    I->free_ws();
+    for (hipEvent_t e : I->events) (void) hipEventDestroy(e);
+    delete I;
+    return 0;
+}
+
+int har_render(HarScene S, HarIntegrator I, const HarSensor *sensor, uint32_t seed, uint32_t spp, uint64_t lb, uint64_t le, float *film, void *stream) {
+    DSensor C; uint32_t log_spp;
+    if (check_common(S, I, sensor, spp, lb, le, C, log_spp)) return 1;
+    if (!film) return fail("null film");
+    hipStream_t s = (hipStream_t) stream;
+    uint32_t chunk = (uint32_t) std::min<uint64_t>(I->chunk, std::max<uint64_t>(le - lb, 256));
+    if (ensure_workspace(I, chunk, false)) return 1;
+    HIP_TRY(hipMemsetAsync(I->totals, 0, 4 * sizeof(unsigned long long), s));
+    HIP_TRY(hipMemsetAsync(I->status, 0, sizeof(int), s));
+    I->ev_used = 0; I->last_stream = s;
+    prof_mark(I, s, CLS_START);
+    const int mode = I->type == HAR_INTEGRATOR_PATH ? MODE_PATH : MODE_PRB_PRIMAL;
+    if (I->max_depth == 0) {      /* path.cpp:102-103: nothing but the weight channel */
+        for (uint64_t base = lb; base < le; base += chunk) {
+            uint32_t n = (uint32_t) std::min<uint64_t>(chunk, le - base);
+            launch_splat(s, C, seed, spp, log_spp, (uint32_t) base, n, nullptr, 1, film);
+        }
+        HIP_TRY(hipGetLastError());
+        return 0;
+    }
+    for (uint64_t base = lb; base < le; base += chunk) {
+        uint32_t n = (uint32_t) std::min<uint64_t>(chunk, le - base);
+        if (run_chunk(S, I, C, mode, seed, spp, log_spp, (uint32_t) base, n, nullptr, s)) return 1;
+        if (mode == MODE_PRB_PRIMAL) { launch_accumulate_stats(s, I->counters, bounce_limit(I), I->totals, n); prof_mark(I, s, CLS_OTHER); }
+        launch_splat(s, C, seed, spp, log_spp, (uint32_t) base, n, I->result, 0, film);
+        prof_mark(I, s, CLS_SPLAT);
+    }
+    HIP_TRY(hipGetLastError());
+    return 0;
+}
+
+int har_render_weights(const HarSensor *sensor, uint32_t seed, uint32_t spp, uint64_t lb, uint64_t le, float *film, void *stream) {
+    if (!sensor || !film) return fail("null sensor / film");
+    DSensor C; std::string e;
+    if (!lower_sensor(*sensor, C, e)) return fail(e);
+    uint64_t total = (uint64_t) C.crop_w * C.crop_h * spp;
+    if (spp == 0 || total > 0xffffffffull) return fail("invalid sample count");
+    if (lb == 0 && le == 0) le = total;
+    if (lb > le || le > total) return fail("invalid lane range");
+    uint32_t log_spp = log2_exact(spp);
+    const uint64_t chunk = 1u << 24;
+    for (uint64_t base = lb; base < le; base += chunk) {
+        uint32_t n = (uint32_t) std::min<uint64_t>(chunk, le - base);
+        launch_splat((hipStream_t) stream, C, seed, spp, log_spp, (uint32_t) base, n, nullptr, 1, film);
+    }
+    HIP_TRY(hipGetLastError());
+    return 0;
+}
+
+int har_render_backward(HarScene S, HarIntegrator I, const HarSensor *sensor, const float *grad_in, const float *weight_film, uint32_t seed,
+                        uint32_t spp, uint64_t lb, uint64_t le, float *grad_reflectance, float *const *grad_textures, void *stream) {
+    DSensor C; uint32_t log_spp;
+    if (check_common(S, I, sensor, spp, lb, le, C, log_spp)) return 1;
+    if (I->type != HAR_INTEGRATOR_PRB) return fail("render_backward is implemented by the `prb` integrator");
+    if (!grad_in || !weight_film || !grad_reflectance) return fail("null gradient buffers");
+    if (I->max_depth == 0) return 0;
+    hipStream_t s = (hipStream_t) stream;
+    uint32_t chunk = (uint32_t) std::min<uint64_t>(I->chunk, std::max<uint64_t>(le - lb, 256));
+    if (ensure_workspace(I, chunk, true)) return 1;
+    size_t npx = (size_t) C.crop_w * C.crop_h;
+    if (I->adj_floats < 3 * npx) { if (ws_alloc(I, &I->adj, 3 * npx)) return 1; I->adj_floats = 3 * npx; }
+    size_t nt = S->hs.textures.size();
+    if (I->grad_tex_cap < std::max<size_t>(nt, 1)) { if (ws_alloc(I, &I->d_grad_tex, std::max<size_t>(nt, 1))) return 1; I->grad_tex_cap = std::max<size_t>(nt, 1); }
+    if (nt) {
+        if (!grad_textures) return fail("grad_textures is null but the scene has bitmap textures");
+        for (size_t k = 0; k < nt; ++k) if (!grad_textures[k]) return fail("null texture gradient buffer");
+        HIP_TRY(hipMemcpyAsync(I->d_grad_tex, grad_textures, nt * sizeof(float *), hipMemcpyHostToDevice, s));
+        HIP_TRY(hipStreamSynchronize(s));
+    }
+    HIP_TRY(hipMemsetAsync(I->totals, 0, 4 * sizeof(unsigned long long), s));
+    HIP_TRY(hipMemsetAsync(I->status, 0, sizeof(int), s));
+    I->ev_used = 0; I->last_stream = s;
+    prof_mark(I, s, CLS_START);
+    launch_adjoint_image(s, grad_in, weight_film, (uint32_t) npx, I->adj);
+    prof_mark(I, s, CLS_OTHER);
+    for (uint64_t base = lb; base < le; base += chunk) {
+        uint32_t n = (uint32_t) std::min<uint64_t>(chunk, le - base);
+        /* pass 1: primal, keeps L per lane in `result` (common.py:752-762) */
+        if (run_chunk(S, I, C, MODE_PRB_PRIMAL, seed, spp, log_spp, (uint32_t) base, n, nullptr, s)) return 1;
+        /* pass 2: adjoint replay with the identical sample stream (common.py:765-775) */
+        if (run_chunk(S, I, C, MODE_PRB_ADJOINT, seed, spp, log_spp, (uint32_t) base, n, grad_reflectance, s)) return 1;
+    }
+    HIP_TRY(hipGetLastError());
+    return 0;
+}
+
+int har_render_stats(HarIntegrator I, HarStats *out) {
+    if (!I || !out) return fail("null argument");
+    memset(out, 0, sizeof(*out));
+    if (!I->totals) return 0;
+    hipStream_t s = I->last_stream;
+    unsigned long long t[4] = { 0, 0, 0, 0 };
+    HIP_TRY(hipMemcpyAsync(t, I->totals, sizeof(t), hipMemcpyDeviceToHost, s));
+    if (read_status(I->status, s)) return 1;
+    out->paths = t[0]; out->vertices = t[1]; out->closest_rays = t[2]; out->shadow_rays = t[3];
+    return 0;
+}
+
+int har_integrator_set_profiling(HarIntegrator I, int enable) {
+    if (!I) return fail("null integrator");
+    I->profiling = enable != 0; I->ev_used = 0;
+    return 0;
+}
+
+int har_render_timing(HarIntegrator I, float ms[8], uint32_t launches[8]) {
+    if (!I) return fail("null integrator");
+    for (int k = 0; k < 8; ++k) { ms[k] = 0.f; launches[k] = 0; }
+    if (I->ev_used < 2) return 0;
+    HIP_TRY(hipEventSynchronize(I->events[I->ev_used - 1]));
+    for (size_t k = 1; k < I->ev_used; ++k) {
+        float dt = 0.f;
+        HIP_TRY(hipEventElapsedTime(&dt, I->events[k - 1], I->events[k]));
+        int c = I->ev_class[k]; if (c < 0 || c > 6) c = CLS_OTHER;
+        ms[c] += dt; launches[c]++; ms[5] += dt;
+    }
+    return 0;
+}
+
+} // extern "C"

@@ -1,0 +1,43 @@
+/* har_kernels.h -- device buffers + launch wrappers of the hip_ad_rgb kernels (see har_kernels.hip). */
+#pragma once
+#include <hip/hip_runtime.h>
+#include "har_path.h"
+
+#define HAR_LDS_STACK_DEPTH 24
+#define HAR_SPLAT_TILE_FLOATS 8192
+#define HAR_MAX_BOUNCE_SLOTS 1026
+
+namespace har {
+
+/* packed SoA path state: 72 B / path (see store_state in har_kernels.hip) */
+struct WaveState { float4 *a0, *a1, *a2, *a3; uint2 *a4; };
+/* NEE / gradient items written by `shade`, consumed by `resolve` */
+struct ItemArrays { float4 *s0, *s1, *s2, *s3, *s4; };
+
+void launch_raygen(int mode, hipStream_t s, const DSensor &C, uint32_t seed, uint32_t spp, uint32_t log_spp, uint32_t lane_base, uint32_t n,
+                   const WaveState &out, float4 *result, uint32_t *count, const float *adj, float4 *dL);
+void launch_trace_closest(hipStream_t s, uint32_t grid, const Accel &A, const uint32_t *count, const WaveState &in, float4 *h0, uint2 *h1, int *status);
+void launch_shade(int mode, hipStream_t s, uint32_t grid, const DScene &S, const ShadeParams &P, uint32_t lane_base, const uint32_t *count_in,
+                  const WaveState &in, const float4 *h0, const uint2 *h1, const WaveState &out, uint32_t *count_out, const ItemArrays &items,
+                  uint32_t *item_count, float4 *result);
+void launch_resolve(int mode, hipStream_t s, uint32_t grid, const DScene &S, const uint32_t *item_count, const ItemArrays &items, float4 *result,
+                    const float4 *dL, float *grad_refl, float *const *grad_tex, int *status);
+void launch_splat(hipStream_t s, const DSensor &C, uint32_t seed, uint32_t spp, uint32_t log_spp, uint32_t lane_base, uint32_t n,
+                  const float4 *result, int weights_only, float *film);
+void launch_develop(hipStream_t s, const float *film, uint32_t npx, float *image);
+void launch_adjoint_image(hipStream_t s, const float *grad_in, const float *wfilm, uint32_t npx, float *adj);
+void launch_accumulate_stats(hipStream_t s, const uint32_t *counters, uint32_t n_bounces, unsigned long long *totals, uint32_t paths);
+
+void launch_api_intersect(hipStream_t s, const DScene &S, uint32_t n, const float *o, const float *d, const float *maxt, int naive,
+                          float *t, float *u, float *v, uint32_t *prim, uint32_t *shape, uint32_t *inst, int *status);
+void launch_api_ray_test(hipStream_t s, const DScene &S, uint32_t n, const float *o, const float *d, const float *maxt, int naive, uint8_t *out, int *status);
+void launch_api_si(hipStream_t s, const DScene &S, uint32_t n, const float *o, const float *d, const float *t, const float *u, const float *v,
+                   const uint32_t *prim, const uint32_t *shape, const uint32_t *inst, float *out);
+void launch_api_sampler_seed(hipStream_t s, uint32_t seed, uint32_t lane_offset, uint32_t n, uint64_t *state, uint64_t *inc);
+void launch_api_sampler_next(hipStream_t s, uint32_t n, uint64_t *state, const uint64_t *inc, const uint8_t *active, float *out, int dims);
+void launch_api_bsdf_eval_pdf(hipStream_t s, const DScene &S, uint32_t bsdf, uint32_t n, const float *wi, const float *uv, const float *wo, float *value, float *pdf);
+void launch_api_bsdf_sample(hipStream_t s, const DScene &S, uint32_t bsdf, uint32_t n, const float *wi, const float *uv, const float *s2, float *wo, float *pdf, float *weight);
+void launch_api_sensor_ray(hipStream_t s, const DSensor &C, uint32_t n, const float *px, const float *py, float *o, float *d, float *maxt);
+void launch_api_film_put(hipStream_t s, const DSensor &C, uint32_t n, const float *px, const float *py, const float *values4, float *film);
+
+} // namespace har

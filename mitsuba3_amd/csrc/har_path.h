@@ -1,0 +1,207 @@
+/*
+ * har_path.h -- per-lane stages of the wavefront integrators (HAR_HD).
+ *
+ * The HIP kernels in har_kernels.hip are thin wrappers (load SoA state ->
+ * call the stage -> ballot-compact -> store); all path logic lives here so
+ * that it is identical on the GPU and in the host test harness.
+ *
+ *  MODE_PATH        PathIntegrator::sample, src/integrators/path.cpp:94-346
+ *  MODE_PRB_PRIMAL  PRBIntegrator.sample(mode=Primal), ad/integrators/prb.py:68-339
+ *  MODE_PRB_ADJOINT PRBIntegrator.sample(mode=Backward), same file, with the
+ *                   hand-derived diffuse/albedo gradients of SURVEY.md App. B
+ */
+#pragma once
+#include "har_scene.h"
+
+namespace har {
+
+enum { MODE_PATH = 0, MODE_PRB_PRIMAL = 1, MODE_PRB_ADJOINT = 2 };
+
+#define HAR_MAX_FILTER_TAPS 9
+
+/* Loop state of one path between two bounces (LoopState, path.cpp:129-159) */
+struct PathState {
+    Vec3 o, d; float maxt;
+    Vec3 throughput;
+    uint64_t rng;
+    uint32_t lane;
+    Vec3 prev_p; float prev_bsdf_pdf;
+    uint32_t flags;            /* bits 0..15 depth, bit 16 prev_bsdf_delta */
+};
+
+struct ShadeParams {
+    uint32_t seed, max_depth, rr_depth;
+};
+
+struct ShadeResult {
+    bool alive;
+    PathState next;
+    bool add_emission; Vec3 em_a, em_b;   /* PATH: result = fma(em_a, em_b, result); PRB: L +/-= em_b */
+    bool item;                            /* enqueue an NEE (+ gradient) item */
+    bool item_ray;                        /* item carries a shadow ray to test */
+    Vec3 sh_o, sh_d; float sh_maxt;
+    Vec3 contrib;                         /* PATH: throughput*bsdf*em*mis; PRB: Lr_dir */
+    /* MODE_PRB_ADJOINT only */
+    Vec3 dLr_drho, refl; bool ind_active; uint32_t bsdf; float uv_x, uv_y;
+};
+
+/* raygen: SamplingIntegrator::render_sample up to the camera ray (integrator.cpp:448-483) */
+HAR_HD PathState raygen_lane(const DSensor &C, uint32_t seed, uint32_t spp, uint32_t log_spp, uint32_t lane, LaneSample &ls) {
+    PathState st;
+    uint64_t inc;
+    sampler_seed(seed, lane, st.rng, inc);
+    float jx = pcg32_next_float(st.rng, inc), jy = pcg32_next_float(st.rng, inc);
+    ls = lane_sample(C, lane, spp, log_spp, jx, jy);
+    lane_camera_ray(C, ls, st.o, st.d, st.maxt);
+    st.throughput = Vec3(1.f); st.lane = lane; st.prev_p = Vec3(0.f); st.prev_bsdf_pdf = 1.f; st.flags = 1u << 16;
+    return st;
+}
+
+/* film position of a lane, recomputed from its RNG stream (saves 8 B/lane of state) */
+HAR_HD LaneSample lane_film_pos(const DSensor &C, uint32_t seed, uint32_t spp, uint32_t log_spp, uint32_t lane) {
+    uint64_t rng, inc;
+    sampler_seed(seed, lane, rng, inc);
+    float jx = pcg32_next_float(rng, inc), jy = pcg32_next_float(rng, inc);
+    return lane_sample(C, lane, spp, log_spp, jx, jy);
+}
+
+/* ImageBlock::put footprint, coalesced JIT branch (imageblock.cpp:444-470): top-left pixel
+ * (crop-relative, may be "negative" = huge unsigned), per-axis weights */
+struct Footprint { uint32_t x0, y0, count; float wx[HAR_MAX_FILTER_TAPS], wy[HAR_MAX_FILTER_TAPS]; };
+HAR_HD void film_footprint(const DSensor &C, const LaneSample &L, Footprint &F) {
+    if (C.rfilter == 0) {
+        F.count = 1; F.wx[0] = 1.f; F.wy[0] = 1.f;
+        F.x0 = (uint32_t) ((int32_t) floorf(L.ipos_x) - (int32_t) C.crop_x);
+        F.y0 = (uint32_t) ((int32_t) floorf(L.ipos_y) - (int32_t) C.crop_y);
+        return;
+    }
+    uint32_t n = (uint32_t) ceilf(C.radius - .5f);
+    F.count = 2 * n + 1;
+    int32_t ix = (int32_t) floorf(L.pos_x) - (int32_t) n, iy = (int32_t) floorf(L.pos_y) - (int32_t) n;
+    F.x0 = (uint32_t) (ix - (int32_t) C.crop_x); F.y0 = (uint32_t) (iy - (int32_t) C.crop_y);
+    float relx = ((float) ix + .5f) - L.pos_x, rely = ((float) iy + .5f) - L.pos_y;
+    for (uint32_t k = 0; k < HAR_MAX_FILTER_TAPS; ++k) {
+        if (k < F.count) { F.wx[k] = rfilter_eval(C, relx + (float) k); F.wy[k] = rfilter_eval(C, rely + (float) k); }
+    }
+}
+
+template <int MODE>
+HAR_HD void shade_lane(const DScene &S, const ShadeParams &P, const PathState &st, const Hit &hit, ShadeResult &R) {
+    R.alive = false; R.add_emission = false; R.item = false; R.item_ray = false;
+    uint64_t rng = st.rng;
+    const uint64_t inc = sampler_inc(P.seed, st.lane);
+    const uint32_t depth = st.flags & 0xffffu;
+    const bool prev_delta = (st.flags >> 16) & 1u;
+
+    SurfInt si = compute_si(S, st.d, hit.t, hit.u, hit.v, hit.prim, hit.shape, hit.inst);
+    const bool valid = si.valid();
+    const DMesh M = valid ? S.meshes[si.mesh] : DMesh{};
+    const int emitter = valid ? M.emitter : -1;
+    const float pmf = S.n_emitters ? 1.f / (float) S.n_emitters : 0.f;   /* scene.cpp:139 */
+
+    /* ---- direct emission + MIS with the previous BSDF sample (path.cpp:206-221, prb.py:148-161) */
+    if (emitter >= 0) {
+        const DEmitter E = S.emitters[emitter];
+        Vec3 rel = si.p - st.prev_p;
+        float dist = norm3(rel);
+        Vec3 dd = div3(rel, dist);
+        float em_pdf = prev_delta ? 0.f : emitter_pdf_direction(E, dd, si.sn, dist) * pmf;
+        float mis = mis_weight(st.prev_bsdf_pdf, em_pdf);
+        Vec3 rad(E.radiance[0], E.radiance[1], E.radiance[2]);
+        if (MODE == MODE_PATH) {
+            Vec3 Le = (si.wi.z > 0.f && st.prev_bsdf_pdf > 0.f) ? rad : Vec3(0.f);   /* area.cpp:83-90 */
+            R.add_emission = true; R.em_a = st.throughput; R.em_b = Le * mis;
+        } else {
+            Vec3 ev = si.wi.z > 0.f ? rad : Vec3(0.f);
+            R.add_emission = true; R.em_a = Vec3(0.f); R.em_b = (st.throughput * mis) * ev;
+        }
+    }
+
+    bool active_next = (depth + 1u < P.max_depth) && valid;
+    if (MODE == MODE_PATH && !active_next) return;
+    if (MODE != MODE_PATH && !valid) return;      /* prb: nothing below contributes for a miss */
+
+    const DBsdf B = S.bsdfs[M.bsdf];
+    TexTaps taps;
+    Vec3 refl = bsdf_reflectance(S, B, si.uv_x, si.uv_y, taps);
+
+    /* ---- emitter sampling (path.cpp:238-258, prb.py:163-175; scene.cpp:316-366) */
+    float ex = pcg32_next_float(rng, inc), ey = pcg32_next_float(rng, inc);
+    DirSample ds; ds.pdf = 0.f; ds.d = Vec3(0.f); ds.p = Vec3(0.f); ds.n = Vec3(0.f); ds.dist = 0.f;
+    Vec3 em_weight(0.f);
+    bool active_em = active_next && S.n_emitters > 0;
+    if (active_em) {
+        uint32_t index = 0; float wgt = 1.f;
+        if (S.n_emitters > 1) {                                  /* sample_emitter, scene.cpp:248-271 */
+            float scaled = ex * (float) S.n_emitters;
+            index = (uint32_t) scaled; if (index > S.n_emitters - 1u) index = S.n_emitters - 1u;
+            wgt = (float) S.n_emitters; ex = scaled - (float) index;
+        }
+        emitter_sample_direction(S.emitters[index], si.p, ex, ey, ds, em_weight);
+        ds.pdf *= pmf; em_weight = em_weight * wgt;
+        active_em = ds.pdf != 0.f;
+    }
+    Vec3 wo_em = active_em ? si.to_local(ds.d) : Vec3(0.f);
+
+    /* ---- BSDF (bsdf.cpp:21-31 eval_pdf_sample) */
+    float s1 = pcg32_next_float(rng, inc); (void) s1;
+    float s2x = pcg32_next_float(rng, inc), s2y = pcg32_next_float(rng, inc);
+    Vec3 bsdf_val; float bsdf_pdf;
+    diffuse_eval_pdf(refl, si.wi, wo_em, bsdf_val, bsdf_pdf);
+    Vec3 bwo(0.f), bsdf_weight(0.f); float bs_pdf = 0.f, bs_eta = 0.f;
+    if (MODE == MODE_PATH || active_next) { diffuse_sample(refl, si.wi, s2x, s2y, bwo, bs_pdf, bsdf_weight); bs_eta = 1.f; }
+
+    /* ---- NEE contribution (path.cpp:271-281, prb.py:210-216); visibility is resolved by the shadow kernel */
+    R.contrib = Vec3(0.f); R.dLr_drho = Vec3(0.f);
+    if (active_em) {
+        float mis_em = mis_weight(ds.pdf, bsdf_pdf);
+        if (MODE == MODE_PATH) R.contrib = st.throughput * ((bsdf_val * em_weight) * mis_em);
+        else {
+            R.contrib = ((st.throughput * mis_em) * bsdf_val) * em_weight;
+            if (MODE == MODE_PRB_ADJOINT && si.wi.z > 0.f && wo_em.z > 0.f)
+                R.dLr_drho = ((st.throughput * mis_em) * (HAR_INV_PI * wo_em.z)) * em_weight;
+        }
+        if (R.contrib.x != 0.f || R.contrib.y != 0.f || R.contrib.z != 0.f) {
+            R.item = true; R.item_ray = true;
+            spawn_ray_to(si, ds.p, R.sh_o, R.sh_d, R.sh_maxt);
+        }
+    }
+
+    /* ---- continue the path (path.cpp:287-331, prb.py:227-252) */
+    PathState &N = R.next;
+    Vec3 wo_world = si.to_world(bwo);
+    N.o = offset_p(si, wo_world); N.d = wo_world; N.maxt = HAR_LARGEST;
+    N.throughput = st.throughput * bsdf_weight;
+    N.lane = st.lane; N.prev_p = si.p; N.prev_bsdf_pdf = bs_pdf;
+    float tmax = hmax3(N.throughput);
+    float eta = 1.f; (void) bs_eta;
+    float rr_prob = fminf(tmax * (eta * eta), .95f);
+    bool rr_active, alive;
+    if (MODE == MODE_PATH) {
+        uint32_t nd = depth + 1u;                                  /* path.cpp:317: depth++ BEFORE the test */
+        rr_active = nd >= P.rr_depth;
+        bool rr_continue = pcg32_next_float(rng, inc) < rr_prob;
+        if (rr_active) N.throughput = N.throughput * rcp_(rr_prob);
+        alive = active_next && (!rr_active || rr_continue) && (tmax != 0.f);
+        N.flags = nd;
+    } else {
+        active_next = active_next && (tmax != 0.f);
+        rr_active = depth >= P.rr_depth;                           /* prb.py:249: depth not yet incremented */
+        if (rr_active) N.throughput = N.throughput * rcp_(rr_prob);
+        bool rr_continue = pcg32_next_float(rng, inc) < rr_prob;
+        alive = active_next && (!rr_active || rr_continue);
+        N.flags = depth + 1u;
+    }
+    N.rng = rng;
+    R.alive = alive;
+
+    if (MODE == MODE_PRB_ADJOINT) {
+        /* Lr_ind = L * relative_grad(bsdf.eval(si, wo, active_next)) (prb.py:288-297) */
+        Vec3 wo = si.to_local(wo_world);
+        R.ind_active = alive && si.wi.z > 0.f && wo.z > 0.f;
+        R.refl = refl; R.bsdf = M.bsdf; R.uv_x = si.uv_x; R.uv_y = si.uv_y;
+        R.item = R.item_ray || R.ind_active;   /* otherwise the vertex has a zero gradient */
+    }
+}
+
+} // namespace har

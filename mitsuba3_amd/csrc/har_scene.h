@@ -1,0 +1,236 @@
+/*
+ * har_scene.h -- device-side scene records and the per-vertex shading math of
+ * the hip_ad_rgb path (surface interaction, diffuse BSDF, bitmap/srgb texture,
+ * area emitter, perspective sensor, reconstruction filter).  HAR_HD so that the
+ * same source runs in the HIP kernels and in the host test harness.
+ * Each function cites the reference code it reproduces.
+ */
+#pragma once
+#include "har_accel.h"
+
+namespace har {
+
+struct DMesh    { uint32_t voff, foff, bsdf; int32_t emitter; uint32_t flags, face_count, pad0, pad1; };
+struct DBsdf    { uint32_t type; int32_t texture; float r, g, b; float pad0, pad1, pad2; };
+struct DTexture { const float *data; uint32_t w, h; };
+struct DEmitter { float radiance[3]; float inv_area; float to_world[12]; float normal[3]; uint32_t mesh; };
+struct DInst    { float to_world[12]; float to_object[12]; };
+
+struct DScene {
+    Accel accel;
+    const uint32_t *blas_tri_ranges;   /* per TLAS record: first, count (brute-force kernel) */
+    const float    *verts;             /* packed vertices, 8 f32 each (mesh_utils.h:19-34) */
+    const uint32_t *faces;             /* packed faces, 4 u32 each */
+    const DMesh    *meshes;
+    const DBsdf    *bsdfs;
+    const DTexture *textures;
+    const DEmitter *emitters;
+    const DInst    *insts;
+    uint32_t n_emitters, n_meshes, n_bsdfs, n_textures;
+};
+
+struct DSensor {
+    float s2c[16];
+    float to_world[16];
+    float near_clip, far_clip;
+    uint32_t crop_x, crop_y, crop_w, crop_h;
+    uint32_t rfilter;            /* 0 box, 1 gaussian */
+    float radius;
+    float coeff[10];             /* GaussianFilter::m_coeff (LLVM branch) */
+};
+
+struct SurfInt {
+    float t;
+    Vec3 p, n, sn, ss, st, wi;
+    float uv_x, uv_y;
+    uint32_t mesh;
+    HAR_HD bool valid() const { return t != HAR_INF; }
+    HAR_HD Vec3 to_local(Vec3 v) const { return Vec3(dot3(v, ss), dot3(v, st), dot3(v, sn)); }   /* frame.h:34 */
+    HAR_HD Vec3 to_world(Vec3 v) const { return fma3(sn, v.z, fma3(st, v.y, ss * v.x)); }         /* frame.h:39 */
+};
+
+/* PreliminaryIntersection::compute_surface_interaction (interaction.h:804-829) ->
+ * Mesh::compute_surface_interaction (src/render/mesh.cpp:2255-2437) [+ Instance::
+ * compute_surface_interaction, src/shapes/instance.cpp:150-266] ->
+ * finalize_surface_interaction (interaction.h:559-605; `diffuse` packs no tangents so
+ * the frame comes from coordinate_system(sh_frame.n)) */
+HAR_HD SurfInt compute_si(const DScene &S, Vec3 ray_d, float t, float bu, float bv, uint32_t prim, uint32_t shape, uint32_t inst) {
+    SurfInt si;
+    si.t = t; si.uv_x = 0.f; si.uv_y = 0.f; si.mesh = 0;
+    if (t == HAR_INF) { si.wi = -ray_d; return si; }
+    const DMesh M = S.meshes[shape];
+    const uint32_t *f = S.faces + 4 * (size_t) (M.foff + prim);
+    const float *r0 = S.verts + 8 * (size_t) (M.voff + f[0]);
+    const float *r1 = S.verts + 8 * (size_t) (M.voff + f[1]);
+    const float *r2 = S.verts + 8 * (size_t) (M.voff + f[2]);
+#if defined(__HIP_DEVICE_COMPILE__)
+    const float4 qa0 = reinterpret_cast<const float4 *>(r0)[0], qa1 = reinterpret_cast<const float4 *>(r0)[1];
+    const float4 qb0 = reinterpret_cast<const float4 *>(r1)[0], qb1 = reinterpret_cast<const float4 *>(r1)[1];
+    const float4 qc0 = reinterpret_cast<const float4 *>(r2)[0], qc1 = reinterpret_cast<const float4 *>(r2)[1];
+    const float v0[8] = { qa0.x, qa0.y, qa0.z, qa0.w, qa1.x, qa1.y, qa1.z, qa1.w };
+    const float v1[8] = { qb0.x, qb0.y, qb0.z, qb0.w, qb1.x, qb1.y, qb1.z, qb1.w };
+    const float v2[8] = { qc0.x, qc0.y, qc0.z, qc0.w, qc1.x, qc1.y, qc1.z, qc1.w };
+#else
+    const float *v0 = r0, *v1 = r1, *v2 = r2;
+#endif
+    Vec3 p0(v0[0], v0[1], v0[2]), p1(v1[0], v1[1], v1[2]), p2(v2[0], v2[1], v2[2]);
+    float b1 = bu, b2 = bv, b0 = 1.f - b1 - b2;
+    Vec3 e1 = p1 - p0, e2 = p2 - p0;
+    si.p = fma3(p0, b0, fma3(p1, b1, p2 * b2));
+    si.n = normalize3(cross3(e1, e2));                       /* mesh.h:568-572 */
+    if (M.flags & 1u) {
+        Vec3 n0(v0[3], v0[4], v0[5]), dn1 = Vec3(v1[3], v1[4], v1[5]) - n0, dn2 = Vec3(v2[3], v2[4], v2[5]) - n0;
+        Vec3 n = fma3(dn1, b1, fma3(dn2, b2, n0));
+        si.sn = n * rsqrt_(dot3(n, n));
+    } else si.sn = si.n;
+    if (M.flags & 2u) {
+        float u0 = v0[6], w0 = v0[7], du0 = v1[6] - u0, dv0 = v1[7] - w0, du1 = v2[6] - u0, dv1 = v2[7] - w0;
+        si.uv_x = fma_(du0, b1, fma_(du1, b2, u0));
+        si.uv_y = fma_(dv0, b1, fma_(dv1, b2, w0));
+    } else { si.uv_x = b1; si.uv_y = b2; }
+    si.mesh = shape;
+    if (inst != 0xffffffffu) {                              /* instance.cpp:196-224 */
+        const DInst &I = S.insts[inst];
+        si.p = xf_point(I.to_world, si.p);
+        si.n = normalize3(xf_normal(I.to_object, si.n));
+        Vec3 n = xf_normal(I.to_object, si.sn);
+        si.sn = n * rcp_(norm3(n));
+    }
+    coordinate_system(si.sn, si.ss, si.st);
+    si.wi = si.to_local(-ray_d);
+    return si;
+}
+
+/* Interaction::offset_p / spawn_ray / spawn_ray_to (interaction.h:161-191) */
+HAR_HD Vec3 offset_p(const SurfInt &si, Vec3 d) {
+    float mag = (1.f + hmax3(abs3(si.p))) * HAR_RAY_EPS;
+    mag = mulsign_(mag, dot3(si.n, d));
+    return fma3(si.n, mag, si.p);
+}
+HAR_HD void spawn_ray_to(const SurfInt &si, Vec3 target, Vec3 &o, Vec3 &d, float &maxt) {
+    o = offset_p(si, target - si.p);
+    Vec3 dd = target - o;
+    float dist = norm3(dd);
+    d = div3(dd, dist);
+    maxt = dist * (1.f - HAR_SHADOW_EPS);
+}
+
+/* dr::Texture<Float, 2>::eval, bilinear + repeat (call site bitmap.cpp:842-850) */
+struct TexTaps { uint32_t idx[4]; float w0x, w1x, w0y, w1y; };
+HAR_HD void tex_taps(const DTexture &T, float u, float v, TexTaps &l) {
+    float px = fma_(u, (float) T.w, -0.5f), py = fma_(v, (float) T.h, -0.5f);
+    float fx = floorf(px), fy = floorf(py);
+    int32_t ix = (int32_t) fx, iy = (int32_t) fy, W = (int32_t) T.w, H = (int32_t) T.h;
+    l.w1x = px - fx; l.w1y = py - fy; l.w0x = 1.f - l.w1x; l.w0y = 1.f - l.w1y;
+    int32_t x0 = ix % W; if (x0 < 0) x0 += W;
+    int32_t x1 = (ix + 1) % W; if (x1 < 0) x1 += W;
+    int32_t y0 = iy % H; if (y0 < 0) y0 += H;
+    int32_t y1 = (iy + 1) % H; if (y1 < 0) y1 += H;
+    l.idx[0] = (uint32_t) (y0 * W + x0); l.idx[1] = (uint32_t) (y0 * W + x1);
+    l.idx[2] = (uint32_t) (y1 * W + x0); l.idx[3] = (uint32_t) (y1 * W + x1);
+}
+HAR_HD Vec3 tex_fetch(const DTexture &T, const TexTaps &l) {
+    float out[3];
+    for (int c = 0; c < 3; ++c) {
+        float v00 = T.data[3 * (size_t) l.idx[0] + c], v10 = T.data[3 * (size_t) l.idx[1] + c];
+        float v01 = T.data[3 * (size_t) l.idx[2] + c], v11 = T.data[3 * (size_t) l.idx[3] + c];
+        float v0 = fma_(l.w0x, v00, l.w1x * v10), v1 = fma_(l.w0x, v01, l.w1x * v11);
+        out[c] = fma_(l.w0y, v0, l.w1y * v1);
+    }
+    return Vec3(out[0], out[1], out[2]);
+}
+/* Texture::eval for `reflectance`: srgb constant (src/spectra/srgb.cpp) or bitmap */
+HAR_HD Vec3 bsdf_reflectance(const DScene &S, const DBsdf &B, float u, float v, TexTaps &taps) {
+    if (B.texture < 0) return Vec3(B.r, B.g, B.b);
+    const DTexture T = S.textures[B.texture];
+    tex_taps(T, u, v, taps);
+    return tex_fetch(T, taps);
+}
+
+/* SmoothDiffuse::eval_pdf / sample (src/bsdfs/diffuse.cpp:159-179, 100-124) */
+HAR_HD void diffuse_eval_pdf(Vec3 refl, Vec3 wi, Vec3 wo, Vec3 &value, float &pdf) {
+    bool active = wi.z > 0.f && wo.z > 0.f;
+    value = active ? (refl * HAR_INV_PI) * wo.z : Vec3(0.f);
+    pdf = active ? HAR_INV_PI * wo.z : 0.f;
+}
+HAR_HD void diffuse_sample(Vec3 refl, Vec3 wi, float s2x, float s2y, Vec3 &wo, float &pdf, Vec3 &weight) {
+    wo = square_to_cosine_hemisphere(s2x, s2y);
+    pdf = HAR_INV_PI * wo.z;
+    weight = (wi.z > 0.f && pdf > 0.f) ? refl : Vec3(0.f);
+}
+
+/* AreaLight::sample_direction (src/emitters/area.cpp:118-168), Shape::sample_direction
+ * (src/render/shape.cpp:93-110), Rectangle::sample_position (src/shapes/rectangle.cpp:159-173) */
+struct DirSample { Vec3 p, n, d; float dist, pdf; };
+HAR_HD void emitter_sample_direction(const DEmitter &E, Vec3 ref_p, float sx, float sy, DirSample &ds, Vec3 &spec) {
+    ds.p = xf_point(E.to_world, Vec3(fma_(sx, 2.f, -1.f), fma_(sy, 2.f, -1.f), 0.f));
+    ds.n = Vec3(E.normal[0], E.normal[1], E.normal[2]);
+    ds.pdf = E.inv_area;
+    ds.d = ds.p - ref_p;
+    float dist2 = dot3(ds.d, ds.d);
+    ds.dist = sqrtf(dist2);
+    ds.d = div3(ds.d, ds.dist);
+    float dp = fabsf(dot3(ds.d, ds.n));
+    float x = dist2 / dp;
+    ds.pdf *= finite_(x) ? x : 0.f;
+    bool active = dot3(ds.d, ds.n) < 0.f && ds.pdf != 0.f;
+    spec = active ? div3(Vec3(E.radiance[0], E.radiance[1], E.radiance[2]), ds.pdf) : Vec3(0.f);
+}
+/* AreaLight::pdf_direction (area.cpp:170-197) / Shape::pdf_direction (shape.cpp:112-124) */
+HAR_HD float emitter_pdf_direction(const DEmitter &E, Vec3 d, Vec3 n, float dist) {
+    float dp = dot3(d, n);
+    if (!(dp < 0.f)) return 0.f;
+    float adp = fabsf(dp);
+    float pdf = E.inv_area;
+    pdf *= (adp != 0.f) ? (dist * dist) / adp : 0.f;
+    return pdf;
+}
+
+/* PerspectiveCamera::sample_ray (src/sensors/perspective.cpp:200-237) */
+HAR_HD void sensor_sample_ray(const DSensor &C, float px, float py, Vec3 &o, Vec3 &d, float &maxt) {
+    const float *M = C.s2c;
+    float r0 = M[3], r1 = M[7], r2 = M[11], r3 = M[15];
+    r0 = fma_(M[0], px, r0); r1 = fma_(M[4], px, r1); r2 = fma_(M[8], px, r2);  r3 = fma_(M[12], px, r3);
+    r0 = fma_(M[1], py, r0); r1 = fma_(M[5], py, r1); r2 = fma_(M[9], py, r2);  r3 = fma_(M[13], py, r3);
+    r0 = fma_(M[2], 0.f, r0); r1 = fma_(M[6], 0.f, r1); r2 = fma_(M[10], 0.f, r2); r3 = fma_(M[14], 0.f, r3);
+    float iw = rcp_(r3);
+    Vec3 dl = normalize3(Vec3(r0 * iw, r1 * iw, r2 * iw));
+    const float *T = C.to_world;
+    Vec3 dw(T[0] * dl.x, T[4] * dl.x, T[8] * dl.x);
+    dw = Vec3(fma_(T[1], dl.y, dw.x), fma_(T[5], dl.y, dw.y), fma_(T[9], dl.y, dw.z));
+    dw = Vec3(fma_(T[2], dl.z, dw.x), fma_(T[6], dl.z, dw.y), fma_(T[10], dl.z, dw.z));
+    float inv_z = rcp_(dl.z);
+    float near_t = C.near_clip * inv_z, far_t = C.far_clip * inv_z;
+    d = dw;
+    o = Vec3(T[3], T[7], T[11]) + dw * near_t;
+    maxt = far_t - near_t;
+}
+
+/* GaussianFilter::eval, LLVM branch: max(estrin(x^2, coeff), 0) (src/rfilters/gaussian.cpp:57-101) */
+HAR_HD float estrin10(float x, const float *c) {
+    float x2 = x * x, x4 = x2 * x2, x8 = x4 * x4;
+    float a0 = fma_(x, c[1], c[0]), a1 = fma_(x, c[3], c[2]), a2 = fma_(x, c[5], c[4]), a3 = fma_(x, c[7], c[6]), a4 = fma_(x, c[9], c[8]);
+    float b0 = fma_(x2, a1, a0), b1 = fma_(x2, a3, a2);
+    float c0 = fma_(x4, b1, b0);
+    return fma_(x8, a4, c0);
+}
+HAR_HD float rfilter_eval(const DSensor &C, float x) { return fmaxf(estrin10(x * x, C.coeff), 0.f); }
+
+/* lane -> pixel/sample mapping of SamplingIntegrator::render (integrator.cpp:322-339) and
+ * render_sample (:448-466): returns integer pixel (crop-relative) and jittered film position */
+struct LaneSample { float pos_x, pos_y, ipos_x, ipos_y; };
+HAR_HD LaneSample lane_sample(const DSensor &C, uint32_t idx, uint32_t spp, uint32_t log_spp, float jx, float jy) {
+    uint32_t p = (log_spp != 0xffffffffu) ? (idx >> log_spp) : (idx / spp);
+    uint32_t y = p / C.crop_w, x = p - C.crop_w * y;
+    LaneSample L;
+    L.ipos_x = (float) (int32_t) (x + C.crop_x); L.ipos_y = (float) (int32_t) (y + C.crop_y);
+    L.pos_x = L.ipos_x + jx; L.pos_y = L.ipos_y + jy;
+    return L;
+}
+HAR_HD void lane_camera_ray(const DSensor &C, const LaneSample &L, Vec3 &o, Vec3 &d, float &maxt) {
+    float sx = 1.f / (float) C.crop_w, sy = 1.f / (float) C.crop_h;
+    float ox = -(float) C.crop_x * sx, oy = -(float) C.crop_y * sy;
+    sensor_sample_ray(C, fma_(L.pos_x, sx, ox), fma_(L.pos_y, sy, oy), o, d, maxt);
+}
+
+} // namespace har

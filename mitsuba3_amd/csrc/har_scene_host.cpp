@@ -1,0 +1,151 @@
+/*
+ * har_scene_host.cpp -- Scene lowering for the hip_ad_rgb path (host C++).
+ * Follows SceneIRBuilder::build (src/render/scene_ir.cpp:12-92): top-level
+ * triangle geometry -> one BLAS, each ShapeGroup -> one BLAS, TLAS with an
+ * identity entry for the top-level BLAS and one entry per Instance.
+ */
+#include "har_scene_host.h"
+#include <algorithm>
+#include <cmath>
+#include <cstring>
+
+namespace har {
+
+namespace {
+
+struct BlasInfo { uint32_t root, first_tri, tri_count; float lo[3], hi[3]; bool empty; };
+
+BlasInfo build_blas(HostScene &hs, const HarSceneDesc &d, uint32_t first_mesh, uint32_t mesh_count) {
+    std::vector<PrimBox> prims; std::vector<TriRec> recs;
+    for (uint32_t s = first_mesh; s < first_mesh + mesh_count; ++s) {
+        const HarMesh &m = d.meshes[s];
+        for (uint32_t f = 0; f < m.face_count; ++f) {
+            float p[3][3];
+            for (int k = 0; k < 3; ++k) { const float *v = m.vertex_ptr + 8 * (size_t) m.index_ptr[4 * (size_t) f + k]; p[k][0] = v[0]; p[k][1] = v[1]; p[k][2] = v[2]; }
+            TriRec t;
+            t.p0x = p[0][0]; t.p0y = p[0][1]; t.p0z = p[0][2];
+            t.e1x = p[1][0] - p[0][0]; t.e1y = p[1][1] - p[0][1]; t.e1z = p[1][2] - p[0][2];
+            t.e2x = p[2][0] - p[0][0]; t.e2y = p[2][1] - p[0][1]; t.e2z = p[2][2] - p[0][2];
+            t.prim = f; t.shape = s; t.pad = 0;
+            PrimBox b;
+            for (int a = 0; a < 3; ++a) { b.lo[a] = std::min(p[0][a], std::min(p[1][a], p[2][a])); b.hi[a] = std::max(p[0][a], std::max(p[1][a], p[2][a])); }
+            pad_prim_box(b);
+            prims.push_back(b); recs.push_back(t);
+        }
+    }
+    BlasInfo info{};
+    info.first_tri = (uint32_t) hs.tris.size(); info.tri_count = (uint32_t) recs.size(); info.empty = recs.empty();
+    std::vector<uint32_t> order;
+    info.root = build_bvh8(prims, hs.nodes, info.first_tri, order, &hs.stats);
+    for (uint32_t i : order) hs.tris.push_back(recs[i]);
+    for (int a = 0; a < 3; ++a) { info.lo[a] = INFINITY; info.hi[a] = -INFINITY; }
+    for (const PrimBox &b : prims) for (int a = 0; a < 3; ++a) { info.lo[a] = std::min(info.lo[a], b.lo[a]); info.hi[a] = std::max(info.hi[a], b.hi[a]); }
+    return info;
+}
+
+} // namespace
+
+bool lower_scene(const HarSceneDesc &d, HostScene &hs, std::string &err) {
+    if (d.top_mesh_count > d.mesh_count) { err = "top_mesh_count exceeds mesh_count"; return false; }
+    for (uint32_t i = 0; i < d.mesh_count; ++i) {
+        const HarMesh &m = d.meshes[i];
+        if (m.bsdf >= d.bsdf_count) { err = "mesh references a BSDF that does not exist"; return false; }
+        if (m.emitter >= (int32_t) d.emitter_count) { err = "mesh references an emitter that does not exist"; return false; }
+        if ((m.vertex_count && !m.vertex_ptr) || (m.face_count && !m.index_ptr)) { err = "mesh has null buffers"; return false; }
+        for (uint32_t f = 0; f < m.face_count; ++f)
+            for (int k = 0; k < 3; ++k)
+                if (m.index_ptr[4 * (size_t) f + k] >= m.vertex_count) { err = "face index out of bounds"; return false; }
+        DMesh dm{};
+        dm.voff = (uint32_t) (hs.verts.size() / 8); dm.foff = (uint32_t) (hs.faces.size() / 4);
+        dm.bsdf = m.bsdf; dm.emitter = m.emitter; dm.flags = m.flags; dm.face_count = m.face_count;
+        hs.verts.insert(hs.verts.end(), m.vertex_ptr, m.vertex_ptr + 8 * (size_t) m.vertex_count);
+        hs.faces.insert(hs.faces.end(), m.index_ptr, m.index_ptr + 4 * (size_t) m.face_count);
+        hs.meshes.push_back(dm);
+    }
+    for (uint32_t i = 0; i < d.bsdf_count; ++i) {
+        const HarBSDF &b = d.bsdfs[i];
+        if (b.type != 0) { err = "unsupported BSDF type (only `diffuse` is implemented in hip_ad_rgb)"; return false; }
+        if (b.texture >= (int32_t) d.texture_count) { err = "BSDF references a texture that does not exist"; return false; }
+        DBsdf db{}; db.type = b.type; db.texture = b.texture; db.r = b.reflectance[0]; db.g = b.reflectance[1]; db.b = b.reflectance[2];
+        hs.bsdfs.push_back(db);
+    }
+    for (uint32_t i = 0; i < d.texture_count; ++i) {
+        const HarTexture &t = d.textures[i];
+        if (!t.data || !t.width || !t.height) { err = "empty texture"; return false; }
+        HostTexture ht; ht.w = t.width; ht.h = t.height; ht.data.assign(t.data, t.data + 3 * (size_t) t.width * t.height);
+        hs.textures.push_back(std::move(ht));
+    }
+    for (uint32_t i = 0; i < d.emitter_count; ++i) {
+        const HarEmitter &e = d.emitters[i];
+        if (e.type != 0) { err = "unsupported emitter type (only `area` on a rectangle is implemented)"; return false; }
+        if (e.mesh >= d.top_mesh_count) { err = "area emitter must be attached to a top-level mesh"; return false; }
+        DEmitter de{};
+        std::memcpy(de.radiance, e.radiance, 12); de.inv_area = e.inv_area;
+        std::memcpy(de.to_world, e.to_world, 48); std::memcpy(de.normal, e.normal, 12); de.mesh = e.mesh;
+        hs.emitters.push_back(de);
+    }
+    for (uint32_t g = 0; g < d.group_count; ++g)
+        if (d.groups[g].first_mesh < d.top_mesh_count || d.groups[g].first_mesh + d.groups[g].mesh_count > d.mesh_count) { err = "shapegroup mesh range invalid"; return false; }
+    for (uint32_t i = 0; i < d.instance_count; ++i) {
+        if (d.instances[i].group >= d.group_count) { err = "instance references a shapegroup that does not exist"; return false; }
+        DInst di; std::memcpy(di.to_world, d.instances[i].to_world, 48); std::memcpy(di.to_object, d.instances[i].to_object, 48);
+        hs.insts.push_back(di);
+    }
+
+    BlasInfo top = build_blas(hs, d, 0, d.top_mesh_count);
+    if (d.instance_count == 0) {
+        hs.root = top.root; hs.has_tlas = false;
+        hs.blas_tri_ranges = { top.first_tri, top.tri_count };
+        return true;
+    }
+    std::vector<BlasInfo> groups;
+    for (uint32_t g = 0; g < d.group_count; ++g) groups.push_back(build_blas(hs, d, d.groups[g].first_mesh, d.groups[g].mesh_count));
+    std::vector<PrimBox> boxes; std::vector<InstRec> recs; std::vector<uint32_t> ranges;
+    auto identity = [](float *m) { std::memset(m, 0, 48); m[0] = m[4] = m[8] = 1.f; };
+    if (!top.empty) {
+        InstRec r{}; identity(r.to_world); identity(r.to_object); r.blas_root = top.root; r.inst_index = 0xffffffffu; r.identity = 1;
+        PrimBox b; std::memcpy(b.lo, top.lo, 12); std::memcpy(b.hi, top.hi, 12);
+        boxes.push_back(b); recs.push_back(r); ranges.push_back(top.first_tri); ranges.push_back(top.tri_count);
+    }
+    for (uint32_t i = 0; i < d.instance_count; ++i) {
+        const BlasInfo &g = groups[d.instances[i].group];
+        if (g.empty) continue;
+        InstRec r{}; std::memcpy(r.to_world, d.instances[i].to_world, 48); std::memcpy(r.to_object, d.instances[i].to_object, 48);
+        r.blas_root = g.root; r.inst_index = i; r.identity = 0;
+        PrimBox b; for (int a = 0; a < 3; ++a) { b.lo[a] = INFINITY; b.hi[a] = -INFINITY; }
+        for (int c = 0; c < 8; ++c) {          // Instance::bbox, src/shapes/instance.cpp:93-103
+            Vec3 q = xf_point(r.to_world, Vec3(c & 1 ? g.hi[0] : g.lo[0], c & 2 ? g.hi[1] : g.lo[1], c & 4 ? g.hi[2] : g.lo[2]));
+            const float qq[3] = { q.x, q.y, q.z };
+            for (int a = 0; a < 3; ++a) { b.lo[a] = std::min(b.lo[a], qq[a]); b.hi[a] = std::max(b.hi[a], qq[a]); }
+        }
+        pad_prim_box(b);
+        boxes.push_back(b); recs.push_back(r); ranges.push_back(g.first_tri); ranges.push_back(g.tri_count);
+    }
+    std::vector<uint32_t> order;
+    hs.root = build_bvh8(boxes, hs.nodes, 0, order, &hs.stats);
+    hs.has_tlas = true;
+    for (uint32_t k : order) { hs.inst_recs.push_back(recs[k]); hs.blas_tri_ranges.push_back(ranges[2 * k]); hs.blas_tri_ranges.push_back(ranges[2 * k + 1]); }
+    return true;
+}
+
+bool lower_sensor(const HarSensor &in, DSensor &out, std::string &err) {
+    if (in.crop_width == 0 || in.crop_height == 0) { err = "empty crop window"; return false; }
+    if (in.rfilter > 1) { err = "unsupported reconstruction filter (box and gaussian are implemented)"; return false; }
+    std::memcpy(out.s2c, in.sample_to_camera, 64); std::memcpy(out.to_world, in.to_world, 64);
+    out.near_clip = in.near_clip; out.far_clip = in.far_clip;
+    out.crop_x = in.crop_offset_x; out.crop_y = in.crop_offset_y; out.crop_w = in.crop_width; out.crop_h = in.crop_height;
+    out.rfilter = in.rfilter;
+    std::memset(out.coeff, 0, sizeof(out.coeff));
+    if (in.rfilter == 0) { out.radius = 0.5f; return true; }
+    float stddev = in.rfilter_stddev;
+    out.radius = 4 * stddev;
+    // Remez fit of exp(-x/2), scaled by 1/stddev^(2i) and shifted to reach 0 at the radius
+    const double coeff[10] = { 9.992604880e-1, -4.977025247e-1, 1.222248550e-1, -1.932406282e-2, 2.136713061e-3,
+                               -1.679873860e-4, 9.202145248e-6, -3.329417433e-7, 7.128382794e-9, -6.821193280e-11 };
+    double scale = 1;
+    for (int i = 0; i < 10; ++i) { out.coeff[i] = (float) (coeff[i] * scale); scale /= (double) stddev * (double) stddev; }
+    out.coeff[0] -= estrin10(out.radius * out.radius, out.coeff);
+    return true;
+}
+
+} // namespace har

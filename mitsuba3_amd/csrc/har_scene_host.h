@@ -1,0 +1,37 @@
+/* har_scene_host.h -- host-side lowering of a HarSceneDesc into flat arrays + accel
+ * (the work of Scene::Scene + SceneAccel::init, src/render/scene.cpp:26-144). */
+#pragma once
+#include "../../include/hip_ad_rgb.h"
+#include "har_scene.h"
+#include "har_accel_build.h"
+#include <string>
+#include <vector>
+
+namespace har {
+
+struct HostTexture { std::vector<float> data; uint32_t w, h; };
+
+struct HostScene {
+    std::vector<float> verts;
+    std::vector<uint32_t> faces;
+    std::vector<DMesh> meshes;
+    std::vector<DBsdf> bsdfs;
+    std::vector<HostTexture> textures;
+    std::vector<DEmitter> emitters;
+    std::vector<DInst> insts;
+    std::vector<Node8> nodes;
+    std::vector<TriRec> tris;
+    std::vector<InstRec> inst_recs;
+    std::vector<uint32_t> blas_tri_ranges;
+    uint32_t root = 0;
+    bool has_tlas = false;
+    Bvh8Stats stats;
+};
+
+/* returns false and fills `err` on invalid input */
+bool lower_scene(const HarSceneDesc &desc, HostScene &out, std::string &err);
+
+/* GaussianFilter ctor (src/rfilters/gaussian.cpp:48-93) + sensor repack */
+bool lower_sensor(const HarSensor &in, DSensor &out, std::string &err);
+
+} // namespace har

@@ -1,0 +1,36 @@
+import os
+import sys
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+
+def pytest_configure(config):
+    config.addinivalue_line("markers", "gpu: test needs a real MI355X (run with -m gpu on the GPU box)")
+
+
+@pytest.fixture(scope="session", autouse=True)
+def _native_built():
+    """Make sure the oracle, the host harness and the HIP library exist (hipcc cross-compiles on CPU)."""
+    import __graft_entry__ as g
+    need = [os.path.join(ROOT, "oracle", "libmi_oracle.so"),
+            os.path.join(ROOT, "tests", "host_harness", "libhost_harness.so"),
+            os.path.join(ROOT, "mitsuba3_amd", "libhip_ad_rgb.so")]
+    if not all(os.path.exists(p) for p in need):
+        g.build()
+
+
+@pytest.fixture(scope="session")
+def mi():
+    import mitsuba3_amd as mi
+    mi.set_variant("hip_ad_rgb")
+    return mi
+
+
+@pytest.fixture(scope="session")
+def O():
+    from oracle import oracle
+    return oracle

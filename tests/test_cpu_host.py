@@ -1,0 +1,291 @@
+"""CPU tests (no GPU): oracle known-answer tests, C ABI surface, host lowering, and the
+product's HAR_HD logic (BVH8 build + traversal, shading stages, film) executed through the
+host test harness against the oracle."""
+import ctypes as C
+import os
+import re
+
+import numpy as np
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def rel_l2(a, b):
+    return float(np.linalg.norm(a.astype(np.float64) - b.astype(np.float64)) / np.linalg.norm(b.astype(np.float64)))
+
+
+def oracle_scene_from(O, scene):
+    """Feed the product's flat scene arrays (mitsuba3_amd.Scene) to the oracle unchanged."""
+    sd = O.SceneData()
+    for m in scene.meshes:
+        sd.add_mesh(m["V"], m["F"], m["bsdf"], m["emitter"], m["flags"])
+    sd.top_mesh_count = scene.top_mesh_count
+    sd.groups = list(scene.groups); sd.instances = list(scene.instances)
+    sd.bsdfs = [(0, b.tex_index if b.texture is not None else -1, b.value) for b in scene.bsdf_objs]
+    sd.textures = list(scene.textures); sd.emitters = list(scene.emitters)
+    s = O.Sensor()
+    C.memmove(C.byref(s), C.byref(scene.sensors()[0].har), C.sizeof(s))
+    return O.OracleScene(sd), s
+
+
+# ---------------------------------------------------------------- oracle KATs
+
+def test_tea_kats(O):
+    """src/core/tests/test_random.py:8-28"""
+    L = O.lib()
+    f32 = {(1, 1): 0.5424730777740479, (1, 2): 0.5079904794692993, (1, 3): 0.4171961545944214, (1, 4): 0.008385419845581055,
+           (1, 5): 0.8085528612136841, (2, 1): 0.6939879655838013, (3, 1): 0.6978365182876587, (4, 1): 0.4897364377975464}
+    f64 = {(1, 1): 0.5424730799533735, (1, 2): 0.5079905082233922, (1, 3): 0.4171962610608142, (1, 4): 0.008385529523330604,
+           (1, 5): 0.80855288317879, (2, 1): 0.6939880404156831, (3, 1): 0.6978365636630994, (4, 1): 0.48973647949223253}
+    for (a, b), v in f32.items():
+        assert L.orc_sample_tea_float32(a, b, 4) == np.float32(v)
+    for (a, b), v in f64.items():
+        assert L.orc_sample_tea_float64(a, b, 4) == v
+
+
+def test_pcg32_published_vector(O):
+    """pcg32-demo (pcg-random.org), seed(42, 54): the published first six outputs."""
+    L = O.lib(); si = (C.c_uint64 * 2)()
+    L.orc_pcg32_seed(42, 54, si)
+    assert [L.orc_pcg32_next_uint32(si) for _ in range(6)] == [0xa15c02b7, 0x7b47f409, 0xba1d3330, 0x83d2f293, 0xbfa4784b, 0xcbed606e]
+
+
+def test_diffuse_closed_form(O):
+    """src/bsdfs/tests/test_diffuse.py:16-39"""
+    L = O.lib(); refl = O.f32([0.5, 0.5, 0.5]); wi = O.f32([0, 0, 1])
+    for i in range(20):
+        th = i / 19.0 * (np.pi / 2); wo = O.f32([np.sin(th), 0, np.cos(th)])
+        val = np.empty(3, np.float32); pdf = C.c_float()
+        L.orc_diffuse_eval_pdf(O.fp(refl), O.fp(wi), O.fp(wo), O.fp(val), C.byref(pdf))
+        assert np.isclose(pdf.value, max(wo[2], 0) / np.pi, atol=1e-7) and np.isclose(val[0], 0.5 * max(wo[2], 0) / np.pi, atol=1e-7)
+
+
+def test_cosine_hemisphere_and_sincos(O):
+    L = O.lib(); rng = np.random.default_rng(0)
+    for _ in range(2000):
+        s = rng.random(2).astype(np.float32); out = np.empty(3, np.float32)
+        L.orc_square_to_cosine_hemisphere(O.fp(s), O.fp(out))
+        assert abs(np.linalg.norm(out) - 1) < 1e-5 and out[2] >= 0
+    for x in np.linspace(-3, 3, 200):
+        c = C.c_float(); s = L.orc_sincos(float(x), C.byref(c))
+        assert abs(s - np.sin(np.float32(x))) < 3e-7 and abs(c.value - np.cos(np.float32(x))) < 3e-7
+
+
+def test_cornell_pixel_kat(O):
+    """src/integrators/tests/test_integrators.py:28-53"""
+    sd, sensor = O.cornell_box(256, 256, crop=(124, 36, 1, 1))
+    img, _ = O.OracleScene(sd).render_path(sensor, spp=64, max_depth=1)
+    assert np.allclose(img.reshape(3), [18.387, 13.9873, 6.75357], rtol=1e-5)
+
+
+def _stairs(O, n_steps=20):
+    """src/render/tests/test_kdtrees.py:8-36"""
+    v = np.zeros((4 * n_steps, 3), np.float32); f = []
+    for i in range(n_steps):
+        h = i / n_steps; s1 = i / n_steps; s2 = (i + 1) / n_steps; k = 4 * i
+        v[k] = [0, s1, h]; v[k + 1] = [1, s1, h]; v[k + 2] = [0, s2, h]; v[k + 3] = [1, s2, h]
+        f += [[k, k + 1, k + 2], [k + 1, k + 3, k + 2]]
+        if i < n_steps - 1:
+            f += [[k + 2, k + 3, k + 5], [k + 5, k + 4, k + 2]]
+    V = np.zeros((v.shape[0], 8), np.float32); V[:, :3] = v
+    F = np.zeros((len(f), 4), np.uint32); F[:, :3] = np.asarray(f, np.uint32)
+    sd = O.SceneData(); sd.bsdfs = [(0, -1, [0.5, 0.5, 0.5])]; sd.add_mesh(V, F, 0, -1, 0); sd.top_mesh_count = 1
+    return sd
+
+
+def test_stairs_analytic_depth(O):
+    """test_kdtrees.py:50-81: accel == brute force == analytic t = 2 - floor(y*20)/20"""
+    sd = _stairs(O); osc = O.OracleScene(sd)
+    n = 128; inv = 1.0 / (n - 1)
+    xs, ys = np.meshgrid(np.arange(n - 1), np.arange(n - 1), indexing="ij")
+    o = np.stack([xs.ravel() * inv, ys.ravel() * inv, np.full(xs.size, 2.0)]).astype(np.float32)
+    d = np.tile(np.array([[0], [0], [-1]], np.float32), (1, o.shape[1]))
+    maxt = np.full(o.shape[1], 100, np.float32)
+    a = osc.ray_intersect(o, d, maxt, naive=True); b = osc.ray_intersect(o, d, maxt, naive=False)
+    expected = 2.0 - np.floor((ys.ravel() * inv) * 20) / 20
+    assert np.allclose(a[0], expected, atol=1e-6) and np.array_equal(a[0], b[0])
+    assert osc.ray_test(o, d, maxt).all()
+
+
+def test_film_put_vs_numpy(O):
+    """src/render/tests/test_imageblock.py:37-124 (coalesced gaussian put vs an independent NumPy splat)."""
+    sd, sensor = O.cornell_box(32, 24)
+    rng = np.random.default_rng(3); n = 500
+    px = rng.uniform(-1, 33, n).astype(np.float32); py = rng.uniform(-1, 25, n).astype(np.float32)
+    vals = rng.random((n, 4)).astype(np.float32)
+    film = np.zeros((24, 32, 4), np.float32)
+    O.lib().orc_film_put(C.byref(sensor), n, O.fp(px), O.fp(py), O.fp(vals), O.fp(film))
+    ref = np.zeros((24, 32, 4), np.float64)
+    w = lambda x: max(float(O.lib().orc_rfilter_eval(1, 0.5, float(x))), 0.0)
+    for i in range(n):
+        x0 = int(np.floor(px[i])) - 2; y0 = int(np.floor(py[i])) - 2
+        for ys in range(5):
+            for xs in range(5):
+                x, y = x0 + xs, y0 + ys
+                if 0 <= x < 32 and 0 <= y < 24:
+                    ref[y, x] += vals[i] * w(np.float32(x0 + .5) - px[i] + xs) * w(np.float32(y0 + .5) - py[i] + ys)
+    assert np.allclose(film, ref, atol=1e-4)
+    assert abs(O.lib().orc_rfilter_eval(1, 0.5, 0.0) - 0.99925) < 1e-4 and abs(O.lib().orc_rfilter_eval(1, 0.5, 2.0)) < 1e-5
+
+
+def test_oracle_ad_linearity(O):
+    """src/render/tests/test_ad.py:55-134 adapted to an area light: with max_depth=2 the image is linear
+    in each albedo, so loss(rho + lr) == loss(rho) + lr * dloss/drho for the same seed."""
+    sd, sensor = O.cornell_box(16, 16)
+    osc = O.OracleScene(sd)
+    seed, spp = 3, 32
+    img1, _ = osc.render_prb(sensor, seed=seed, spp=spp, max_depth=2)
+    grad_in = np.ones((16, 16, 3), np.float32)
+    g_refl, _, _ = osc.render_prb_backward(sensor, grad_in, seed=seed, spp=spp, max_depth=2)
+    lr = 0.01
+    rho = np.array(O.CBOX_WHITE, np.float32); rho2 = rho.copy(); rho2[0] += lr
+    osc.set_reflectance(0, rho2)
+    img2, _ = osc.render_prb(sensor, seed=seed, spp=spp, max_depth=2)
+    assert np.isclose(img2.sum(), img1.sum() + lr * g_refl[0, 0], rtol=2e-4)
+
+
+def test_oracle_prb_gradient_vs_finite_differences(O):
+    """test_ad_integrators.py:1463-1511 recipe at test size: central differences of the oracle's own prb primal."""
+    sd, sensor = O.cornell_box(12, 12)
+    osc = O.OracleScene(sd)
+    seed, spp, md = 5, 64, 4
+    grad_in = np.ones((12, 12, 3), np.float32)
+    g_refl, _, _ = osc.render_prb_backward(sensor, grad_in, seed=seed, spp=spp, max_depth=md)
+    eps = 1e-2
+    rho = np.array(O.CBOX_WHITE, np.float32)
+    a = rho.copy(); a[1] += eps; osc.set_reflectance(0, a); ip, _ = osc.render_prb(sensor, seed=seed, spp=spp, max_depth=md)
+    b = rho.copy(); b[1] -= eps; osc.set_reflectance(0, b); im, _ = osc.render_prb(sensor, seed=seed, spp=spp, max_depth=md)
+    fd = (ip.astype(np.float64).sum() - im.astype(np.float64).sum()) / (2 * eps)
+    assert abs(fd - g_refl[0, 1]) / abs(fd) < 2e-2
+
+
+# ---------------------------------------------------------------- C ABI surface
+
+def test_capi_exports_every_declared_symbol(mi):
+    hdr = open(os.path.join(ROOT, "include", "hip_ad_rgb.h")).read()
+    declared = set(re.findall(r"\b(har_[a-z0-9_]+)\s*\(", hdr))
+    L = C.CDLL(mi.LIB_PATH)
+    missing = [n for n in sorted(declared) if not hasattr(L, n)]
+    assert not missing, missing
+    from mitsuba3_amd import _capi
+    assert declared == set(_capi.SIGNATURES)
+
+
+def test_error_behaviour_without_side_effects(mi):
+    with pytest.raises(ImportError):
+        mi.set_variant("cuda_ad_rgb")
+    with pytest.raises(RuntimeError):
+        mi.load_dict({"type": "roughconductor"})
+    with pytest.raises(RuntimeError):
+        mi.load_dict({"type": "path", "rr_depth": 0})
+    with pytest.raises(RuntimeError):
+        mi.load_dict({"type": "path", "max_depth": -2})
+    h = C.c_void_p()
+    assert mi.lib().har_integrator_create(7, 8, 5, 0, C.byref(h)) != 0 and b"unknown" in mi.lib().har_last_error()
+
+
+# ---------------------------------------------------------------- host lowering vs oracle builders
+
+def test_host_lowering_bit_identical_to_oracle(mi, O):
+    scene = mi.load_dict(mi.cornell_box())
+    sd, osens = O.cornell_box(256, 256)
+    assert len(scene.meshes) == len(sd.meshes) == 8
+    for a, b in zip(scene.meshes, sd.meshes):
+        assert np.array_equal(a["V"], b["V"]) and np.array_equal(a["F"], b["F"]) and a["bsdf"] == b["bsdf"] and a["emitter"] == b["emitter"]
+    s = scene.sensors()[0].har
+    assert bytes(s) == bytes(osens)
+    e0, e1 = scene.emitters[0], sd.emitters[0]
+    assert np.array_equal(e0["to_world"], e1["to_world"]) and np.array_equal(e0["normal"], e1["normal"]) and e0["inv_area"] == e1["inv_area"]
+
+
+# ---------------------------------------------------------------- product logic through the host harness
+
+@pytest.fixture(scope="module")
+def H(O):
+    L = C.CDLL(os.path.join(ROOT, "tests", "host_harness", "libhost_harness.so"))
+    L.hh_scene_create.restype = C.c_void_p
+    L.hh_scene_create.argtypes = [C.c_void_p, C.c_char_p, C.c_int]
+    L.hh_scene_destroy.argtypes = [C.c_void_p]
+    L.hh_scene_info.argtypes = [C.c_void_p, C.POINTER(C.c_uint64)]
+    L.hh_trace.argtypes = [C.c_void_p, C.c_uint32] + [O.c_f32p] * 3 + [C.c_int, C.c_int] + [O.c_f32p] * 3 + [O.c_u32p] * 3 + [C.POINTER(C.c_uint8)]
+    L.hh_render.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_uint32, C.c_uint32, C.c_int32, C.c_int32, C.c_uint64, C.c_uint64, O.c_f32p]
+    return L
+
+
+def _harness_scene(H, scene):
+    d = scene.desc(); err = C.create_string_buffer(256)
+    h = C.c_void_p(H.hh_scene_create(C.byref(d), err, 256))
+    assert h, err.value
+    return h
+
+
+def _trace_both(H, O, scene, osc, n, seed):
+    rng = np.random.default_rng(seed)
+    o = rng.uniform(-1, 1, (3, n)).astype(np.float32); d = rng.normal(size=(3, n)).astype(np.float32); d /= np.linalg.norm(d, axis=0)
+    d = np.ascontiguousarray(d, np.float32); maxt = np.full(n, 3.402823466e+38, np.float32)
+    ref = osc.ray_intersect(o, d, maxt, naive=True)
+    h = _harness_scene(H, scene)
+    t = np.empty(n, np.float32); u = np.empty(n, np.float32); v = np.empty(n, np.float32)
+    p = np.empty(n, np.uint32); s = np.empty(n, np.uint32); i = np.empty(n, np.uint32); hf = np.empty(n, np.uint8)
+    hfp = hf.ctypes.data_as(C.POINTER(C.c_uint8))
+    for naive in (0, 1):
+        assert H.hh_trace(h, n, O.fp(o), O.fp(d), O.fp(maxt), naive, 0, O.fp(t), O.fp(u), O.fp(v), O.up(p), O.up(s), O.up(i), hfp) == 0
+        hit = np.isfinite(ref[0])
+        assert np.array_equal(t, ref[0]) and np.array_equal(u[hit], ref[1][hit]) and np.array_equal(v[hit], ref[2][hit])
+        assert np.array_equal(p[hit], ref[3][hit]) and np.array_equal(s[hit], ref[4][hit]) and np.array_equal(i[hit], ref[5][hit])
+    maxt2 = rng.uniform(0.05, 2.5, n).astype(np.float32)
+    H.hh_trace(h, n, O.fp(o), O.fp(d), O.fp(maxt2), 0, 1, O.fp(t), O.fp(u), O.fp(v), O.up(p), O.up(s), O.up(i), hfp)
+    assert np.array_equal(hf.astype(bool), osc.ray_test(o, d, maxt2))
+    H.hh_scene_destroy(h)
+
+
+def test_bvh8_traversal_equals_brute_force_cornell(mi, O, H):
+    scene = mi.load_dict(mi.cornell_box())
+    osc, _ = oracle_scene_from(O, scene)
+    _trace_both(H, O, scene, osc, 100000, 1)
+
+
+def test_bvh8_two_level_instanced(mi, O, H):
+    scene = mi.load_dict(mi.instanced_spheres_scene(width=16, height=16, spp=1, grid=3, n_u=16, n_v=8))
+    osc, _ = oracle_scene_from(O, scene)
+    _trace_both(H, O, scene, osc, 60000, 2)
+
+
+def test_bvh8_flattened_many_triangles(mi, O, H):
+    scene = mi.load_dict(mi.instanced_spheres_scene(width=16, height=16, spp=1, grid=4, n_u=24, n_v=12, flatten=True))
+    osc, _ = oracle_scene_from(O, scene)
+    h = _harness_scene(H, scene); info = (C.c_uint64 * 4)(); H.hh_scene_info(h, info); H.hh_scene_destroy(h)
+    assert info[1] == 16 * 2 * 24 * 12 + 12 and info[2] <= 16
+    _trace_both(H, O, scene, osc, 40000, 3)
+
+
+@pytest.mark.parametrize("mode,md", [(0, 8), (1, 6)])
+def test_shading_stages_match_oracle(mi, O, H, mode, md):
+    d = mi.cornell_box(); d["sensor"]["film"]["width"] = 40; d["sensor"]["film"]["height"] = 40
+    scene = mi.load_dict(d)
+    osc, sensor = oracle_scene_from(O, scene)
+    h = _harness_scene(H, scene)
+    film = np.zeros((40, 40, 4), np.float32)
+    assert H.hh_render(h, C.byref(sensor), mode, 4, 8, md, 5, 0, 0, O.fp(film)) == 0
+    ref, _ = (osc.render_path if mode == 0 else osc.render_prb)(sensor, seed=4, spp=8, max_depth=md, raw=True, threads=2)
+    assert rel_l2(O.develop(film), O.develop(ref)) < 1e-6
+    H.hh_scene_destroy(h)
+
+
+def test_shading_textured_and_instanced(mi, O, H):
+    d = mi.textured_cornell_box(res=24, tex_res=16, spp=4)
+    scene = mi.load_dict(d)
+    osc, sensor = oracle_scene_from(O, scene)
+    h = _harness_scene(H, scene); film = np.zeros((24, 24, 4), np.float32)
+    H.hh_render(h, C.byref(sensor), 1, 0, 4, 6, 5, 0, 0, O.fp(film))
+    ref, _ = osc.render_prb(sensor, seed=0, spp=4, max_depth=6, raw=True)
+    assert rel_l2(O.develop(film), O.develop(ref)) < 1e-6
+    H.hh_scene_destroy(h)
+    scene = mi.load_dict(mi.instanced_spheres_scene(width=24, height=24, spp=4, grid=3, n_u=12, n_v=6))
+    osc, sensor = oracle_scene_from(O, scene)
+    h = _harness_scene(H, scene); film = np.zeros((24, 24, 4), np.float32)
+    H.hh_render(h, C.byref(sensor), 0, 1, 4, 8, 5, 0, 0, O.fp(film))
+    ref, _ = osc.render_path(sensor, seed=1, spp=4, max_depth=8, raw=True)
+    assert rel_l2(O.develop(film), O.develop(ref)) < 1e-6
+    H.hh_scene_destroy(h)
