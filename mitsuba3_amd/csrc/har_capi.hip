@@ -49,9 +49,9 @@ struct HarSceneImpl {
 
 struct HarIntegratorImpl {
     int type = HAR_INTEGRATOR_PATH;
-    uint32_t max_depth = 0, rr_depth = 5, chunk = 1u << 20;
+    uint32_t max_depth = 0, rr_depth = 5, chunk = 1u << 20;   /* lanes per wavefront chunk, multiple of 2048 */
     // workspace
-    uint32_t ws_lanes = 0; bool ws_adjoint = false;
+    uint32_t ws_lanes = 0; bool ws_adjoint = false; uint32_t shard_cap = 0;
     std::vector<void *> owned;
     WaveState st[2]{};
     float4 *h0 = nullptr; uint2 *h1 = nullptr;
@@ -94,10 +94,10 @@ int ensure_workspace(HarIntegratorImpl *I, uint32_t lanes, bool adjoint) {
     I->items.s3 = I->items.s4 = nullptr; I->dL = nullptr;
     if (adjoint && (ws_alloc(I, &I->items.s3, lanes) || ws_alloc(I, &I->items.s4, lanes) || ws_alloc(I, &I->dL, lanes))) return 1;
     if (ws_alloc(I, &I->result, lanes)) return 1;
-    if (ws_alloc(I, &I->counters, 2 * HAR_MAX_BOUNCE_SLOTS) || ws_alloc(I, &I->totals, 4) || ws_alloc(I, &I->status, 1)) return 1;
+    if (ws_alloc(I, &I->counters, (size_t) 2 * HAR_MAX_BOUNCE_SLOTS * HAR_SHARDS * HAR_COUNTER_STRIDE) || ws_alloc(I, &I->totals, 4) || ws_alloc(I, &I->status, 1)) return 1;
     HIP_TRY(hipMemset(I->totals, 0, 4 * sizeof(unsigned long long)));
     HIP_TRY(hipMemset(I->status, 0, sizeof(int)));
-    I->ws_lanes = lanes; I->ws_adjoint = adjoint;
+    I->ws_lanes = lanes; I->ws_adjoint = adjoint; I->shard_cap = lanes / HAR_SHARDS;
     return 0;
 }
 
@@ -115,30 +115,38 @@ uint32_t log2_exact(uint32_t v) { for (uint32_t k = 0; k < 32; ++k) if ((1u << k
 
 uint32_t bounce_limit(const HarIntegratorImpl *I) { return std::min<uint32_t>(I->max_depth, HAR_MAX_BOUNCE_SLOTS - 2); }
 
+static inline uint32_t *cnt_alive(HarIntegratorImpl *I, uint32_t b) { return I->counters + (size_t) b * HAR_SHARDS * HAR_COUNTER_STRIDE; }
+static inline uint32_t *cnt_items(HarIntegratorImpl *I, uint32_t b) { return I->counters + (size_t) (HAR_MAX_BOUNCE_SLOTS + b) * HAR_SHARDS * HAR_COUNTER_STRIDE; }
+
 /* one chunk: raygen + bounce loop.  `mode` selects path / prb primal / prb adjoint kernels */
 int run_chunk(HarSceneImpl *S, HarIntegratorImpl *I, const DSensor &C, int mode, uint32_t seed, uint32_t spp, uint32_t log_spp,
               uint32_t lane_base, uint32_t n, float *grad_refl, hipStream_t s) {
-    HIP_TRY(hipMemsetAsync(I->counters, 0, 2 * HAR_MAX_BOUNCE_SLOTS * sizeof(uint32_t), s));
-    launch_raygen(mode, s, C, seed, spp, log_spp, lane_base, n, I->st[0], I->result, I->counters, I->adj, I->dL);
+    const uint32_t nb = bounce_limit(I);
+    const size_t used = (size_t) std::min<uint32_t>(nb + 2, HAR_MAX_BOUNCE_SLOTS) * HAR_SHARDS * HAR_COUNTER_STRIDE * sizeof(uint32_t);
+    HIP_TRY(hipMemsetAsync(cnt_alive(I, 0), 0, used, s));
+    HIP_TRY(hipMemsetAsync(cnt_items(I, 0), 0, used, s));
+    launch_raygen(mode, s, C, seed, spp, log_spp, lane_base, n, I->shard_cap, I->st[0], I->result, cnt_alive(I, 0), I->adj, I->dL);
     prof_mark(I, s, CLS_RAYGEN);
     ShadeParams P{ seed, I->max_depth, I->rr_depth };
-    const uint32_t grid = std::min<uint32_t>((n + 255) / 256, 4096u);
-    const uint32_t nb = bounce_limit(I);
+    /* grid: a multiple of 8 so that block b serves shard b % 8; enough blocks to cover the chunk once */
+    const uint32_t grid = std::max<uint32_t>(HAR_SHARDS, std::min<uint32_t>(((n + 255) / 256 + HAR_SHARDS - 1) / HAR_SHARDS * HAR_SHARDS, 4096u));
+    const int small_stack = S->hs.stack_need() <= HAR_LDS_STACK_SMALL;   /* overflow is detected and reported */
     int cur = 0; uint32_t b = 0;
     for (; b < nb; ++b) {
-        launch_trace_closest(s, grid, S->ds.accel, I->counters + b, I->st[cur], I->h0, I->h1, I->status);
+        launch_trace_closest(s, grid, small_stack, S->ds.accel, cnt_alive(I, b), I->shard_cap, I->st[cur], I->h0, I->h1, I->status);
         prof_mark(I, s, CLS_TRACE);
-        launch_shade(mode, s, grid, S->ds, P, lane_base, I->counters + b, I->st[cur], I->h0, I->h1, I->st[cur ^ 1], I->counters + b + 1,
-                     I->items, I->counters + HAR_MAX_BOUNCE_SLOTS + b, I->result);
+        launch_shade(mode, s, grid, S->ds, P, lane_base, I->shard_cap, cnt_alive(I, b), I->st[cur], I->h0, I->h1, I->st[cur ^ 1], cnt_alive(I, b + 1),
+                     I->items, cnt_items(I, b), I->result);
         prof_mark(I, s, CLS_SHADE);
-        launch_resolve(mode, s, grid, S->ds, I->counters + HAR_MAX_BOUNCE_SLOTS + b, I->items, I->result, I->dL, grad_refl, I->d_grad_tex, I->status);
+        launch_resolve(mode, s, grid, small_stack, S->ds, cnt_items(I, b), I->shard_cap, I->items, I->result, I->dL, grad_refl, I->d_grad_tex, I->status);
         prof_mark(I, s, CLS_RESOLVE);
         cur ^= 1;
         if (b >= 15 && (b & 7) == 7) {           /* deep paths are rare: poll so that max_depth = -1 terminates */
-            uint32_t alive = 0;
-            HIP_TRY(hipMemcpyAsync(&alive, I->counters + b + 1, sizeof(uint32_t), hipMemcpyDeviceToHost, s));
+            uint32_t alive[HAR_SHARDS * HAR_COUNTER_STRIDE];
+            HIP_TRY(hipMemcpyAsync(alive, cnt_alive(I, b + 1), sizeof(alive), hipMemcpyDeviceToHost, s));
             HIP_TRY(hipStreamSynchronize(s));
-            if (alive == 0) { ++b; break; }
+            uint32_t total = 0; for (int k = 0; k < HAR_SHARDS; ++k) total += alive[k * HAR_COUNTER_STRIDE];
+            if (total == 0) { ++b; break; }
         }
     }
     if (mode != MODE_PRB_PRIMAL) {
@@ -202,8 +210,8 @@ int har_scene_create(const HarSceneDesc *desc, HarScene *out) {
     D.accel.root = hs.root; D.accel.has_tlas = hs.has_tlas; D.accel.n_tris = (uint32_t) hs.tris.size(); D.accel.n_insts = (uint32_t) hs.inst_recs.size();
     D.n_emitters = (uint32_t) hs.emitters.size(); D.n_meshes = (uint32_t) hs.meshes.size();
     D.n_bsdfs = (uint32_t) hs.bsdfs.size(); D.n_textures = (uint32_t) hs.textures.size();
-    if (hs.stats.max_depth + 4 > HAR_LDS_STACK_DEPTH)
-        fprintf(stderr, "[hip_ad_rgb] warning: BVH depth %u is close to the LDS traversal stack (%d entries)\n", hs.stats.max_depth, HAR_LDS_STACK_DEPTH);
+    if (hs.stack_need() > HAR_LDS_STACK_DEPTH)
+        fprintf(stderr, "[hip_ad_rgb] warning: BVH needs %u traversal stack entries, LDS stack holds %d (overflow is reported as an error)\n", hs.stack_need(), HAR_LDS_STACK_DEPTH);
     *out = S;
     return 0;
 }
@@ -233,7 +241,7 @@ int har_scene_accel_info(HarScene S, uint64_t info[4]) {
     if (!S) return fail("null scene");
     info[0] = S->hs.nodes.size(); info[1] = S->hs.tris.size();
     info[2] = S->hs.nodes.size() * sizeof(Node8) + S->hs.tris.size() * sizeof(TriRec) + S->hs.inst_recs.size() * sizeof(InstRec);
-    info[3] = S->hs.stats.max_depth;
+    info[3] = S->hs.stack_need();
     return 0;
 }
 
@@ -337,7 +345,7 @@ int har_integrator_create(int type, int32_t max_depth, int32_t rr_depth, uint32_
     if (rr_depth <= 0) return fail("\"rr_depth\" must be set to a value greater than zero!");
     HarIntegratorImpl *I = new HarIntegratorImpl();
     I->type = type; I->max_depth = (uint32_t) max_depth; I->rr_depth = (uint32_t) rr_depth;
-    if (chunk_lanes) I->chunk = std::max<uint32_t>(256u, (chunk_lanes + 255u) & ~255u);
+    if (chunk_lanes) I->chunk = std::max<uint32_t>(2048u, (chunk_lanes + 2047u) / 2048u * 2048u);
     *out = I;
     return 0;
 }
@@ -355,7 +363,7 @@ int har_render(HarScene S, HarIntegrator I, const HarSensor *sensor, uint32_t se
     if (check_common(S, I, sensor, spp, lb, le, C, log_spp)) return 1;
     if (!film) return fail("null film");
     hipStream_t s = (hipStream_t) stream;
-    uint32_t chunk = (uint32_t) std::min<uint64_t>(I->chunk, std::max<uint64_t>(le - lb, 256));
+    uint32_t chunk = (uint32_t) std::min<uint64_t>(I->chunk, (std::max<uint64_t>(le - lb, 2048) + 2047) / 2048 * 2048);
     if (ensure_workspace(I, chunk, false)) return 1;
     HIP_TRY(hipMemsetAsync(I->totals, 0, 4 * sizeof(unsigned long long), s));
     HIP_TRY(hipMemsetAsync(I->status, 0, sizeof(int), s));
@@ -407,7 +415,7 @@ int har_render_backward(HarScene S, HarIntegrator I, const HarSensor *sensor, co
     if (!grad_in || !weight_film || !grad_reflectance) return fail("null gradient buffers");
     if (I->max_depth == 0) return 0;
     hipStream_t s = (hipStream_t) stream;
-    uint32_t chunk = (uint32_t) std::min<uint64_t>(I->chunk, std::max<uint64_t>(le - lb, 256));
+    uint32_t chunk = (uint32_t) std::min<uint64_t>(I->chunk, (std::max<uint64_t>(le - lb, 2048) + 2047) / 2048 * 2048);
     if (ensure_workspace(I, chunk, true)) return 1;
     size_t npx = (size_t) C.crop_w * C.crop_h;
     if (I->adj_floats < 3 * npx) { if (ws_alloc(I, &I->adj, 3 * npx)) return 1; I->adj_floats = 3 * npx; }

@@ -27,8 +27,8 @@ namespace har {
 
 static constexpr int kBlock = 256;
 
-struct LdsStack {
-    static constexpr int Capacity = HAR_LDS_STACK_DEPTH;
+template <int CAP> struct LdsStack {
+    static constexpr int Capacity = CAP;
     uint2 *col;   /* &lds[threadIdx.x]; entry l lives at col[l * kBlock] */
     __device__ __forceinline__ void push(int l, uint32_t x, uint32_t y) { col[l * kBlock] = make_uint2(x, y); }
     __device__ __forceinline__ void pop(int l, uint32_t &x, uint32_t &y) { uint2 v = col[l * kBlock]; x = v.x; y = v.y; }
@@ -37,17 +37,68 @@ struct LdsStack {
 __device__ __forceinline__ uint32_t wave_rank(uint64_t mask) {
     return __builtin_amdgcn_mbcnt_hi((uint32_t) (mask >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t) mask, 0u));
 }
-/* reserve `popc(mask)` slots with ONE atomic per wave; returns this lane's slot */
-__device__ __forceinline__ uint32_t wave_reserve(uint32_t *counter, bool pred) {
-    uint64_t mask = __ballot(pred);
-    uint32_t cnt = (uint32_t) __popcll(mask), base = 0;
-    if (cnt == 0) return 0;
-    uint32_t rank = wave_rank(mask);
-    if (rank == 0 && pred) base = atomicAdd(counter, cnt);
-    /* broadcast from the first active lane */
-    uint32_t leader = (uint32_t) __ffsll((long long) mask) - 1u;
-    base = __shfl(base, (int) leader, 64);
-    return base + rank;
+
+/*
+ * XCD-private queues.  A chunk's paths are dealt tile-by-tile (256 lanes) to HAR_SHARDS = 8
+ * queues; block b always works on shard b % 8 -- the XCD the dispatcher places it on -- and
+ * compacts survivors back into the SAME shard, so a shard can never overflow its region and
+ * its state stays in one XCD's L2.  Slot reservation costs ONE atomic per 256-thread block and
+ * the eight counters live on separate cache lines: a single shared counter saturates at ~88
+ * atomics/us on MI355X, which made one-atomic-per-wave compaction the top cost of `shade`.
+ */
+struct ShardLoop {
+    uint32_t shard, n, base;
+    __device__ __forceinline__ ShardLoop(const uint32_t *counts, uint32_t shard_cap) {
+        shard = blockIdx.x & (HAR_SHARDS - 1); n = counts[shard * HAR_COUNTER_STRIDE]; base = shard * shard_cap;
+    }
+    __device__ __forceinline__ uint32_t first_tile() const { return blockIdx.x / HAR_SHARDS; }
+    __device__ __forceinline__ uint32_t tile_step() const { return gridDim.x / HAR_SHARDS; }
+};
+
+/* reserve slots for two predicates at once (live paths, NEE items); 2 barriers per tile */
+__device__ __forceinline__ void block_reserve2(uint32_t *cnt_a, bool pa, uint32_t *cnt_b, bool pb, uint32_t *lds /* [12] */,
+                                               uint32_t &slot_a, uint32_t &slot_b) {
+    const uint64_t ma = __ballot(pa), mb = __ballot(pb);
+    const uint32_t wave = threadIdx.x >> 6, lane = threadIdx.x & 63u;
+    if (lane == 0) { lds[wave] = (uint32_t) __popcll(ma); lds[4 + wave] = (uint32_t) __popcll(mb); }
+    __syncthreads();
+    if (threadIdx.x == 0)  { uint32_t t = lds[0] + lds[1] + lds[2] + lds[3]; lds[8] = t ? atomicAdd(cnt_a, t) : 0u; }
+    if (threadIdx.x == 64) { uint32_t t = lds[4] + lds[5] + lds[6] + lds[7]; lds[9] = t ? atomicAdd(cnt_b, t) : 0u; }
+    __syncthreads();
+    uint32_t oa = lds[8], ob = lds[9];
+    for (uint32_t w = 0; w < wave; ++w) { oa += lds[w]; ob += lds[4 + w]; }
+    slot_a = oa + wave_rank(ma); slot_b = ob + wave_rank(mb);
+    __syncthreads();
+}
+
+/* wave-wide float sum with DPP (no LDS): result valid in lane 63 */
+__device__ __forceinline__ float wave_sum_to_last(float v) {
+    v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0xB1, 0xF, 0xF, true));  /* quad_perm [1,0,3,2] */
+    v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x4E, 0xF, 0xF, true));  /* quad_perm [2,3,0,1] */
+    v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x141, 0xF, 0xF, true)); /* row_half_mirror */
+    v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x140, 0xF, 0xF, true)); /* row_mirror */
+    v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x142, 0xA, 0xF, false)); /* row_bcast:15 */
+    v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x143, 0xC, 0xF, false)); /* row_bcast:31 */
+    return v;
+}
+
+/* gradient scatter with wave-level pre-reduction: lanes that target the same address are summed
+ * (DPP) and committed by one lane, so a constant albedo costs 3 atomics per wave instead of 192 */
+__device__ __forceinline__ void wave_aggregated_add3(float *dst, Vec3 g, bool active) {
+    for (int round = 0; round < 6; ++round) {
+        uint64_t m = __ballot(active);
+        if (m == 0) return;
+        const int leader = __ffsll((long long) m) - 1;
+        const uint64_t key = __shfl((unsigned long long) (uintptr_t) dst, leader, 64);
+        const bool match = active && (uint64_t) (uintptr_t) dst == key;
+        float sx = wave_sum_to_last(match ? g.x : 0.f), sy = wave_sum_to_last(match ? g.y : 0.f), sz = wave_sum_to_last(match ? g.z : 0.f);
+        if ((threadIdx.x & 63u) == 63u) {
+            float *q = (float *) (uintptr_t) key;
+            atomicAdd(q, sx); atomicAdd(q + 1, sy); atomicAdd(q + 2, sz);
+        }
+        active = active && !match;
+    }
+    if (active) { atomicAdd(dst, g.x); atomicAdd(dst + 1, g.y); atomicAdd(dst + 2, g.z); }
 }
 
 __device__ __forceinline__ void store_state(const WaveState &W, uint32_t i, const PathState &s) {
@@ -69,16 +120,28 @@ __device__ __forceinline__ PathState load_state(const WaveState &W, uint32_t i) 
 }
 
 /* ------------------------------------------------------------------ raygen */
+/* lane i of the chunk -> (shard, slot): tile t = i / 256 goes to shard t % 8, tile t / 8 of that shard */
+__device__ __forceinline__ uint32_t shard_slot(uint32_t i, uint32_t shard_cap) {
+    const uint32_t tile = i / kBlock;
+    return (tile % HAR_SHARDS) * shard_cap + (tile / HAR_SHARDS) * kBlock + (i % kBlock);
+}
+
 template <int MODE>
 __global__ __launch_bounds__(kBlock) void k_raygen(DSensor C, uint32_t seed, uint32_t spp, uint32_t log_spp, uint32_t lane_base,
-                                                   uint32_t n, WaveState out, float4 *result, uint32_t *count,
+                                                   uint32_t n, uint32_t shard_cap, WaveState out, float4 *result, uint32_t *count,
                                                    const float *adj, float4 *dL) {
     uint32_t i = blockIdx.x * kBlock + threadIdx.x;
-    if (i == 0) *count = n;
+    if (i < HAR_SHARDS) {            /* lanes dealt to shard i */
+        const uint32_t tiles = (n + kBlock - 1) / kBlock, rem = n % kBlock;
+        uint32_t t = tiles > i ? (tiles - i + HAR_SHARDS - 1) / HAR_SHARDS : 0u;
+        uint32_t c = t * kBlock;
+        if (rem && tiles && (tiles - 1) % HAR_SHARDS == i) c -= kBlock - rem;
+        count[i * HAR_COUNTER_STRIDE] = c;
+    }
     if (i >= n) return;
     LaneSample ls;
     PathState st = raygen_lane(C, seed, spp, log_spp, lane_base + i, ls);
-    store_state(out, i, st);
+    store_state(out, shard_slot(i, shard_cap), st);
     if (MODE != MODE_PRB_ADJOINT) result[i] = make_float4(0.f, 0.f, 0.f, 0.f);
     if (MODE == MODE_PRB_ADJOINT) {
         /* adjoint of ImageBlock::put + develop (common.py:696-746): gather grad_in / W over the footprint */
@@ -98,12 +161,16 @@ __global__ __launch_bounds__(kBlock) void k_raygen(DSensor C, uint32_t seed, uin
 }
 
 /* ----------------------------------------------------------- trace_closest */
-__global__ __launch_bounds__(kBlock) void k_trace_closest(Accel A, const uint32_t *count, const float4 *a0, const float4 *a1,
+template <int CAP>
+__global__ __launch_bounds__(kBlock) void k_trace_closest(Accel A, const uint32_t *count, uint32_t shard_cap, const float4 *a0, const float4 *a1,
                                                           float4 *h0, uint2 *h1, int *status) {
-    __shared__ uint2 lds[HAR_LDS_STACK_DEPTH * kBlock];
-    LdsStack stack{ lds + threadIdx.x };
-    const uint32_t n = *count;
-    for (uint32_t i = blockIdx.x * kBlock + threadIdx.x; i < n; i += gridDim.x * kBlock) {
+    __shared__ uint2 lds[CAP * kBlock];
+    LdsStack<CAP> stack{ lds + threadIdx.x };
+    const ShardLoop Q(count, shard_cap);
+    for (uint32_t tile = Q.first_tile(); tile * kBlock < Q.n; tile += Q.tile_step()) {
+        const uint32_t local = tile * kBlock + threadIdx.x;
+        if (local >= Q.n) continue;
+        const uint32_t i = Q.base + local;
         float4 o = a0[i], d = a1[i];
         Hit hit; int st = 0;
         accel_trace<false>(A, Vec3(o.x, o.y, o.z), Vec3(d.x, d.y, d.z), o.w, hit, stack, st);
@@ -115,13 +182,16 @@ __global__ __launch_bounds__(kBlock) void k_trace_closest(Accel A, const uint32_
 
 /* ------------------------------------------------------------------- shade */
 template <int MODE>
-__global__ __launch_bounds__(kBlock) void k_shade(DScene S, ShadeParams P, uint32_t lane_base, const uint32_t *count_in, WaveState in,
+__global__ __launch_bounds__(kBlock) void k_shade(DScene S, ShadeParams P, uint32_t lane_base, uint32_t shard_cap, const uint32_t *count_in, WaveState in,
                                                   const float4 *h0, const uint2 *h1, WaveState out, uint32_t *count_out,
                                                   ItemArrays items, uint32_t *item_count, float4 *result) {
-    const uint32_t n = *count_in;
-    for (uint32_t base = blockIdx.x * kBlock; base < n; base += gridDim.x * kBlock) {
-        const uint32_t i = base + threadIdx.x;
-        const bool in_range = i < n;
+    __shared__ uint32_t lds_r[12];
+    const ShardLoop Q(count_in, shard_cap);
+    uint32_t *cnt_alive = count_out + Q.shard * HAR_COUNTER_STRIDE, *cnt_item = item_count + Q.shard * HAR_COUNTER_STRIDE;
+    for (uint32_t tile = Q.first_tile(); tile * kBlock < Q.n; tile += Q.tile_step()) {
+        const uint32_t local = tile * kBlock + threadIdx.x;
+        const bool in_range = local < Q.n;
+        const uint32_t i = Q.base + local;
         ShadeResult R; R.alive = false; R.item = false; R.add_emission = false;
         uint32_t lane = 0;
         if (in_range) {
@@ -138,12 +208,12 @@ __global__ __launch_bounds__(kBlock) void k_shade(DScene S, ShadeParams P, uint3
                 result[lane] = r;
             }
         }
-        const bool alive = in_range && R.alive;
-        uint32_t slot = wave_reserve(count_out, alive);
-        if (alive) store_state(out, slot, R.next);
-        const bool item = in_range && R.item;
-        uint32_t islot = wave_reserve(item_count, item);
+        const bool alive = in_range && R.alive, item = in_range && R.item;
+        uint32_t slot, islot;
+        block_reserve2(cnt_alive, alive, cnt_item, item, lds_r, slot, islot);
+        if (alive) store_state(out, Q.base + slot, R.next);
         if (item) {
+            islot += Q.base;
             items.s0[islot] = make_float4(R.sh_o.x, R.sh_o.y, R.sh_o.z, R.item_ray ? R.sh_maxt : -1.f);
             items.s1[islot] = make_float4(R.sh_d.x, R.sh_d.y, R.sh_d.z, __uint_as_float(lane));
             items.s2[islot] = make_float4(R.contrib.x, R.contrib.y, R.contrib.z, __uint_as_float(MODE == MODE_PRB_ADJOINT ? (R.bsdf | (R.ind_active ? 0x80000000u : 0u)) : 0u));
@@ -156,17 +226,20 @@ __global__ __launch_bounds__(kBlock) void k_shade(DScene S, ShadeParams P, uint3
 }
 
 /* ------------------------------------------------- resolve (shadow rays + NEE) */
-template <int MODE>
-__global__ __launch_bounds__(kBlock) void k_resolve(DScene S, const uint32_t *item_count, ItemArrays items, float4 *result,
+template <int MODE, int CAP>
+__global__ __launch_bounds__(kBlock) void k_resolve(DScene S, const uint32_t *item_count, uint32_t shard_cap, ItemArrays items, float4 *result,
                                                     const float4 *dL, float *grad_refl, float *const *grad_tex, int *status) {
-    __shared__ uint2 lds[HAR_LDS_STACK_DEPTH * kBlock];
-    LdsStack stack{ lds + threadIdx.x };
-    const uint32_t n = *item_count;
-    for (uint32_t i = blockIdx.x * kBlock + threadIdx.x; i < n; i += gridDim.x * kBlock) {
+    __shared__ uint2 lds[CAP * kBlock];
+    LdsStack<CAP> stack{ lds + threadIdx.x };
+    const ShardLoop Q(item_count, shard_cap);
+    for (uint32_t tile = Q.first_tile(); tile * kBlock < Q.n; tile += Q.tile_step()) {
+        const uint32_t local = tile * kBlock + threadIdx.x;
+        const bool in_range = local < Q.n;
+        const uint32_t i = Q.base + (in_range ? local : 0u);
         float4 s0 = items.s0[i], s1 = items.s1[i], s2 = items.s2[i];
         const uint32_t lane = __float_as_uint(s1.w);
         bool visible = false;
-        if (s0.w >= 0.f) {
+        if (in_range && s0.w >= 0.f) {
             Hit hit; int st = 0;
             visible = !accel_trace<true>(S.accel, Vec3(s0.x, s0.y, s0.z), Vec3(s1.x, s1.y, s1.z), s0.w, hit, stack, st);
             if (st) { atomicMax(status, st); visible = false; }
@@ -175,35 +248,36 @@ __global__ __launch_bounds__(kBlock) void k_resolve(DScene S, const uint32_t *it
             if (visible) { float4 r = result[lane]; result[lane] = make_float4(r.x + s2.x, r.y + s2.y, r.z + s2.z, 0.f); }
         } else {
             /* L <- L - Lr_dir; g = dL * (dLr_dir/drho + [bsdf_val != 0] L / rho)  (prb.py:227,288-313) */
-            float4 L = result[lane];
-            if (visible) { L = make_float4(L.x - s2.x, L.y - s2.y, L.z - s2.z, 0.f); result[lane] = L; }
-            float4 s3 = items.s3[i], s4 = items.s4[i], dl = dL[lane];
-            const uint32_t tag = __float_as_uint(s2.w), bsdf = tag & 0x7fffffffu;
-            Vec3 g = visible ? Vec3(s3.x, s3.y, s3.z) : Vec3(0.f);
-            if (tag & 0x80000000u)
-                g = g + Vec3(s4.x != 0.f ? L.x / s4.x : 0.f, s4.y != 0.f ? L.y / s4.y : 0.f, s4.z != 0.f ? L.z / s4.z : 0.f);
-            g = g * Vec3(dl.x, dl.y, dl.z);
-            if (g.x != 0.f || g.y != 0.f || g.z != 0.f) {
+            Vec3 g(0.f); float *dst = grad_refl; bool tex = false; TexTaps taps; float *tdst = nullptr;
+            if (in_range) {
+                float4 L = result[lane];
+                if (visible) { L = make_float4(L.x - s2.x, L.y - s2.y, L.z - s2.z, 0.f); result[lane] = L; }
+                float4 s3 = items.s3[i], s4 = items.s4[i], dl = dL[lane];
+                const uint32_t tag = __float_as_uint(s2.w), bsdf = tag & 0x7fffffffu;
+                g = visible ? Vec3(s3.x, s3.y, s3.z) : Vec3(0.f);
+                if (tag & 0x80000000u)
+                    g = g + Vec3(s4.x != 0.f ? L.x / s4.x : 0.f, s4.y != 0.f ? L.y / s4.y : 0.f, s4.z != 0.f ? L.z / s4.z : 0.f);
+                g = g * Vec3(dl.x, dl.y, dl.z);
                 const DBsdf B = S.bsdfs[bsdf];
-                if (B.texture < 0) {
-                    float *dst = grad_refl + 3 * (size_t) bsdf;
-                    atomicAdd(dst, g.x); atomicAdd(dst + 1, g.y); atomicAdd(dst + 2, g.z);
-                } else {
-                    TexTaps taps; tex_taps(S.textures[B.texture], s3.w, s4.w, taps);
-                    float *dst = grad_tex[B.texture];
-                    const float w[4] = { taps.w0x * taps.w0y, taps.w1x * taps.w0y, taps.w0x * taps.w1y, taps.w1x * taps.w1y };
-                    for (int k = 0; k < 4; ++k) {
-                        float *q = dst + 3 * (size_t) taps.idx[k];
-                        atomicAdd(q, g.x * w[k]); atomicAdd(q + 1, g.y * w[k]); atomicAdd(q + 2, g.z * w[k]);
-                    }
-                }
+                dst = grad_refl + 3 * (size_t) bsdf;
+                if (B.texture >= 0) { tex = true; tex_taps(S.textures[B.texture], s3.w, s4.w, taps); tdst = grad_tex[B.texture]; }
+            }
+            const bool nz = in_range && (g.x != 0.f || g.y != 0.f || g.z != 0.f);
+            /* wave-uniform control flow: every lane takes part in the pre-reduction */
+            wave_aggregated_add3(dst, g, nz && !tex);
+            if (__ballot(nz && tex)) {
+                const float w[4] = { taps.w0x * taps.w0y, taps.w1x * taps.w0y, taps.w0x * taps.w1y, taps.w1x * taps.w1y };
+                for (int k = 0; k < 4; ++k)
+                    wave_aggregated_add3(nz && tex ? tdst + 3 * (size_t) taps.idx[k] : grad_refl, nz && tex ? g * w[k] : Vec3(0.f), nz && tex);
             }
         }
     }
 }
 
 /* ------------------------------------------------------------------- splat */
-/* ImageBlock::put (imageblock.cpp:444-540) for 256 consecutive lanes, LDS tile + one global atomic per tile pixel */
+/* ImageBlock::put (imageblock.cpp:444-540) for 256 consecutive lanes.  The spp samples of a pixel are
+ * adjacent lanes, so a wave normally shares ONE footprint: its 64 contributions are summed with DPP,
+ * one lane adds the wave totals to an LDS tile, and each tile pixel costs one global atomic per block. */
 __global__ __launch_bounds__(kBlock) void k_splat(DSensor C, uint32_t seed, uint32_t spp, uint32_t log_spp, uint32_t lane_base, uint32_t n,
                                                   const float4 *result, int weights_only, float *film) {
     __shared__ float tile[HAR_SPLAT_TILE_FLOATS];
@@ -213,6 +287,7 @@ __global__ __launch_bounds__(kBlock) void k_splat(DSensor C, uint32_t seed, uint
     if (threadIdx.x == 0) { tx0 = 0x7fffffff; ty0 = 0x7fffffff; tx1 = -0x7fffffff; ty1 = -0x7fffffff; }
     __syncthreads();
     Footprint F; F.count = 0; F.x0 = 0; F.y0 = 0;
+    for (int k = 0; k < HAR_MAX_FILTER_TAPS; ++k) { F.wx[k] = 0.f; F.wy[k] = 0.f; }
     float val[4] = { 0.f, 0.f, 0.f, 1.f };
     if (act) {
         LaneSample ls = lane_film_pos(C, seed, spp, log_spp, lane_base + i);
@@ -227,7 +302,23 @@ __global__ __launch_bounds__(kBlock) void k_splat(DSensor C, uint32_t seed, uint
     if (use_tile) {
         for (int k = threadIdx.x; k < tw * th * 4; k += kBlock) tile[k] = 0.f;
         __syncthreads();
-        if (act)
+        /* does the whole wave share one footprint? (inactive lanes carry zero weights) */
+        const uint32_t fx = __shfl(F.x0, 0, 64), fy = __shfl(F.y0, 0, 64), fc = __shfl(F.count, 0, 64);
+        const bool uniform = __all(!act || (F.x0 == fx && F.y0 == fy && F.count == fc)) && __shfl((int) act, 0, 64);
+        if (uniform) {
+            const bool last = (threadIdx.x & 63u) == 63u;
+            for (uint32_t ys = 0; ys < fc; ++ys)
+                for (uint32_t xs = 0; xs < fc; ++xs) {
+                    const float w = act ? F.wx[xs] * F.wy[ys] : 0.f;
+                    float *p = tile + 4 * (((int) fy + (int) ys - oy) * tw + ((int) fx + (int) xs - ox));
+                    if (!weights_only) {
+                        float a = wave_sum_to_last(val[0] * w), b = wave_sum_to_last(val[1] * w), c = wave_sum_to_last(val[2] * w);
+                        if (last) { atomicAdd(p, a); atomicAdd(p + 1, b); atomicAdd(p + 2, c); }
+                    }
+                    float d = wave_sum_to_last(val[3] * w);
+                    if (last) atomicAdd(p + 3, d);
+                }
+        } else if (act) {
             for (uint32_t ys = 0; ys < F.count; ++ys)
                 for (uint32_t xs = 0; xs < F.count; ++xs) {
                     float w = F.wx[xs] * F.wy[ys];
@@ -235,6 +326,7 @@ __global__ __launch_bounds__(kBlock) void k_splat(DSensor C, uint32_t seed, uint
                     if (!weights_only) { atomicAdd(p, val[0] * w); atomicAdd(p + 1, val[1] * w); atomicAdd(p + 2, val[2] * w); }
                     atomicAdd(p + 3, val[3] * w);
                 }
+        }
         __syncthreads();
         for (int k = threadIdx.x; k < tw * th * 4; k += kBlock) {
             float v = tile[k];
@@ -272,9 +364,13 @@ __global__ void k_adjoint_image(const float *grad_in, const float *wfilm, uint32
 }
 __global__ void k_accumulate_stats(const uint32_t *counters, uint32_t n_bounces, unsigned long long *totals, uint32_t paths) {
     if (threadIdx.x || blockIdx.x) return;
-    unsigned long long v = 0, s = 0;
-    for (uint32_t b = 0; b < n_bounces; ++b) { v += counters[b]; s += counters[HAR_MAX_BOUNCE_SLOTS + b]; }
-    totals[0] += paths; totals[1] += v; totals[2] += v; totals[3] += s;
+    unsigned long long v = 0, sh = 0;
+    for (uint32_t b = 0; b < n_bounces; ++b)
+        for (uint32_t k = 0; k < HAR_SHARDS; ++k) {
+            v += counters[((size_t) b * HAR_SHARDS + k) * HAR_COUNTER_STRIDE];
+            sh += counters[((size_t) (HAR_MAX_BOUNCE_SLOTS + b) * HAR_SHARDS + k) * HAR_COUNTER_STRIDE];
+        }
+    totals[0] += paths; totals[1] += v; totals[2] += v; totals[3] += sh;
 }
 
 /* --- array-valued plugin surface (Scene::ray_intersect*, Sampler, BSDF, Sensor, ImageBlock) --- */
@@ -282,7 +378,7 @@ template <bool NAIVE>
 __global__ __launch_bounds__(kBlock) void k_api_intersect(DScene S, uint32_t n, const float *o, const float *d, const float *maxt,
                                                           float *t, float *u, float *v, uint32_t *prim, uint32_t *shape, uint32_t *inst, int *status) {
     __shared__ uint2 lds[HAR_LDS_STACK_DEPTH * kBlock];
-    LdsStack stack{ lds + threadIdx.x };
+    LdsStack<HAR_LDS_STACK_DEPTH> stack{ lds + threadIdx.x };
     uint32_t i = blockIdx.x * kBlock + threadIdx.x;
     if (i >= n) return;
     Vec3 O(o[i], o[n + i], o[2 * (size_t) n + i]), D(d[i], d[n + i], d[2 * (size_t) n + i]);
@@ -295,7 +391,7 @@ __global__ __launch_bounds__(kBlock) void k_api_intersect(DScene S, uint32_t n, 
 template <bool NAIVE>
 __global__ __launch_bounds__(kBlock) void k_api_ray_test(DScene S, uint32_t n, const float *o, const float *d, const float *maxt, uint8_t *out, int *status) {
     __shared__ uint2 lds[HAR_LDS_STACK_DEPTH * kBlock];
-    LdsStack stack{ lds + threadIdx.x };
+    LdsStack<HAR_LDS_STACK_DEPTH> stack{ lds + threadIdx.x };
     uint32_t i = blockIdx.x * kBlock + threadIdx.x;
     if (i >= n) return;
     Vec3 O(o[i], o[n + i], o[2 * (size_t) n + i]), D(d[i], d[n + i], d[2 * (size_t) n + i]);
@@ -373,27 +469,34 @@ __global__ void k_api_film_put(DSensor C, uint32_t n, const float *px, const flo
 static inline uint32_t blocks_for(uint32_t n) { return (n + kBlock - 1) / kBlock; }
 
 void launch_raygen(int mode, hipStream_t s, const DSensor &C, uint32_t seed, uint32_t spp, uint32_t log_spp, uint32_t lane_base, uint32_t n,
-                   const WaveState &out, float4 *result, uint32_t *count, const float *adj, float4 *dL) {
+                   uint32_t shard_cap, const WaveState &out, float4 *result, uint32_t *count, const float *adj, float4 *dL) {
     dim3 g(blocks_for(n)), b(kBlock);
-    if (mode == MODE_PRB_ADJOINT) hipLaunchKernelGGL(k_raygen<MODE_PRB_ADJOINT>, g, b, 0, s, C, seed, spp, log_spp, lane_base, n, out, result, count, adj, dL);
-    else hipLaunchKernelGGL(k_raygen<MODE_PATH>, g, b, 0, s, C, seed, spp, log_spp, lane_base, n, out, result, count, adj, dL);
+    if (mode == MODE_PRB_ADJOINT) hipLaunchKernelGGL(k_raygen<MODE_PRB_ADJOINT>, g, b, 0, s, C, seed, spp, log_spp, lane_base, n, shard_cap, out, result, count, adj, dL);
+    else hipLaunchKernelGGL(k_raygen<MODE_PATH>, g, b, 0, s, C, seed, spp, log_spp, lane_base, n, shard_cap, out, result, count, adj, dL);
 }
-void launch_trace_closest(hipStream_t s, uint32_t grid, const Accel &A, const uint32_t *count, const WaveState &in, float4 *h0, uint2 *h1, int *status) {
-    hipLaunchKernelGGL(k_trace_closest, dim3(grid), dim3(kBlock), 0, s, A, count, in.a0, in.a1, h0, h1, status);
+void launch_trace_closest(hipStream_t s, uint32_t grid, int small_stack, const Accel &A, const uint32_t *count, uint32_t shard_cap, const WaveState &in,
+                          float4 *h0, uint2 *h1, int *status) {
+    if (small_stack) hipLaunchKernelGGL(k_trace_closest<HAR_LDS_STACK_SMALL>, dim3(grid), dim3(kBlock), 0, s, A, count, shard_cap, in.a0, in.a1, h0, h1, status);
+    else hipLaunchKernelGGL(k_trace_closest<HAR_LDS_STACK_DEPTH>, dim3(grid), dim3(kBlock), 0, s, A, count, shard_cap, in.a0, in.a1, h0, h1, status);
 }
-void launch_shade(int mode, hipStream_t s, uint32_t grid, const DScene &S, const ShadeParams &P, uint32_t lane_base, const uint32_t *count_in,
+void launch_shade(int mode, hipStream_t s, uint32_t grid, const DScene &S, const ShadeParams &P, uint32_t lane_base, uint32_t shard_cap, const uint32_t *count_in,
                   const WaveState &in, const float4 *h0, const uint2 *h1, const WaveState &out, uint32_t *count_out, const ItemArrays &items,
                   uint32_t *item_count, float4 *result) {
     dim3 g(grid), b(kBlock);
-    if (mode == MODE_PATH) hipLaunchKernelGGL(k_shade<MODE_PATH>, g, b, 0, s, S, P, lane_base, count_in, in, h0, h1, out, count_out, items, item_count, result);
-    else if (mode == MODE_PRB_PRIMAL) hipLaunchKernelGGL(k_shade<MODE_PRB_PRIMAL>, g, b, 0, s, S, P, lane_base, count_in, in, h0, h1, out, count_out, items, item_count, result);
-    else hipLaunchKernelGGL(k_shade<MODE_PRB_ADJOINT>, g, b, 0, s, S, P, lane_base, count_in, in, h0, h1, out, count_out, items, item_count, result);
+    if (mode == MODE_PATH) hipLaunchKernelGGL(k_shade<MODE_PATH>, g, b, 0, s, S, P, lane_base, shard_cap, count_in, in, h0, h1, out, count_out, items, item_count, result);
+    else if (mode == MODE_PRB_PRIMAL) hipLaunchKernelGGL(k_shade<MODE_PRB_PRIMAL>, g, b, 0, s, S, P, lane_base, shard_cap, count_in, in, h0, h1, out, count_out, items, item_count, result);
+    else hipLaunchKernelGGL(k_shade<MODE_PRB_ADJOINT>, g, b, 0, s, S, P, lane_base, shard_cap, count_in, in, h0, h1, out, count_out, items, item_count, result);
 }
-void launch_resolve(int mode, hipStream_t s, uint32_t grid, const DScene &S, const uint32_t *item_count, const ItemArrays &items, float4 *result,
-                    const float4 *dL, float *grad_refl, float *const *grad_tex, int *status) {
+void launch_resolve(int mode, hipStream_t s, uint32_t grid, int small_stack, const DScene &S, const uint32_t *item_count, uint32_t shard_cap, const ItemArrays &items,
+                    float4 *result, const float4 *dL, float *grad_refl, float *const *grad_tex, int *status) {
     dim3 g(grid), b(kBlock);
-    if (mode == MODE_PRB_ADJOINT) hipLaunchKernelGGL(k_resolve<MODE_PRB_ADJOINT>, g, b, 0, s, S, item_count, items, result, dL, grad_refl, grad_tex, status);
-    else hipLaunchKernelGGL(k_resolve<MODE_PATH>, g, b, 0, s, S, item_count, items, result, dL, grad_refl, grad_tex, status);
+    if (mode == MODE_PRB_ADJOINT) {
+        if (small_stack) hipLaunchKernelGGL((k_resolve<MODE_PRB_ADJOINT, HAR_LDS_STACK_SMALL>), g, b, 0, s, S, item_count, shard_cap, items, result, dL, grad_refl, grad_tex, status);
+        else hipLaunchKernelGGL((k_resolve<MODE_PRB_ADJOINT, HAR_LDS_STACK_DEPTH>), g, b, 0, s, S, item_count, shard_cap, items, result, dL, grad_refl, grad_tex, status);
+    } else {
+        if (small_stack) hipLaunchKernelGGL((k_resolve<MODE_PATH, HAR_LDS_STACK_SMALL>), g, b, 0, s, S, item_count, shard_cap, items, result, dL, grad_refl, grad_tex, status);
+        else hipLaunchKernelGGL((k_resolve<MODE_PATH, HAR_LDS_STACK_DEPTH>), g, b, 0, s, S, item_count, shard_cap, items, result, dL, grad_refl, grad_tex, status);
+    }
 }
 void launch_splat(hipStream_t s, const DSensor &C, uint32_t seed, uint32_t spp, uint32_t log_spp, uint32_t lane_base, uint32_t n,
                   const float4 *result, int weights_only, float *film) {

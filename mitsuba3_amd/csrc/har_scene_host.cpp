@@ -93,6 +93,7 @@ bool lower_scene(const HarSceneDesc &d, HostScene &hs, std::string &err) {
     }
 
     BlasInfo top = build_blas(hs, d, 0, d.top_mesh_count);
+    hs.blas_depth = hs.stats.max_depth;
     if (d.instance_count == 0) {
         hs.root = top.root; hs.has_tlas = false;
         hs.blas_tri_ranges = { top.first_tri, top.tri_count };
@@ -121,8 +122,11 @@ bool lower_scene(const HarSceneDesc &d, HostScene &hs, std::string &err) {
         pad_prim_box(b);
         boxes.push_back(b); recs.push_back(r); ranges.push_back(g.first_tri); ranges.push_back(g.tri_count);
     }
+    hs.blas_depth = hs.stats.max_depth;
     std::vector<uint32_t> order;
-    hs.root = build_bvh8(boxes, hs.nodes, 0, order, &hs.stats);
+    Bvh8Stats tstats;
+    hs.root = build_bvh8(boxes, hs.nodes, 0, order, &tstats);
+    hs.tlas_depth = tstats.max_depth; hs.stats.max_depth = std::max(hs.stats.max_depth, tstats.max_depth);
     hs.has_tlas = true;
     for (uint32_t k : order) { hs.inst_recs.push_back(recs[k]); hs.blas_tri_ranges.push_back(ranges[2 * k]); hs.blas_tri_ranges.push_back(ranges[2 * k + 1]); }
     return true;

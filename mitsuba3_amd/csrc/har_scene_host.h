@@ -26,6 +26,8 @@ struct HostScene {
     uint32_t root = 0;
     bool has_tlas = false;
     Bvh8Stats stats;
+    uint32_t blas_depth = 0, tlas_depth = 0;   /* traversal stack need = blas_depth + (has_tlas ? tlas_depth + 1 : 0) */
+    uint32_t stack_need() const { return blas_depth + (has_tlas ? tlas_depth + 1 : 0); }
 };
 
 /* returns false and fills `err` on invalid input */
