@@ -1,0 +1,48 @@
+#!/usr/bin/env python3
+"""Summarise a rocprofv3 (rocpd sqlite) result: per-kernel launch count / total / average
+duration, and per-kernel sums of collected PMC counters.  Usage: rocpd_summary.py file.db [...]"""
+import re
+import sqlite3
+import sys
+
+
+def short(name):
+    m = re.search(r"har\d*(k_[a-z_]+)", name)
+    base = m.group(1) if m else name.split("(")[0][:60]
+    t = re.search(r"ILi(\d+)(?:ELi(\d+))?", name)
+    if m and t:
+        base += "<" + ",".join(x for x in t.groups() if x) + ">"
+    return base
+
+
+def main():
+    for path in sys.argv[1:]:
+        db = sqlite3.connect(path)
+        cur = db.cursor()
+        print("== %s" % path)
+        cols = [r[1] for r in cur.execute("pragma table_info(kernels)")]
+        rows = cur.execute("select name, count(*), sum(end - start), avg(end - start), min(end-start), max(end-start) from kernels group by name order by 3 desc").fetchall()
+        tot = sum(r[2] for r in rows) or 1
+        print("%-44s %8s %12s %12s %10s %10s %6s" % ("kernel", "calls", "total_ms", "avg_us", "min_us", "max_us", "%"))
+        for n, c, s, a, mn, mx in rows:
+            print("%-44s %8d %12.3f %12.2f %10.2f %10.2f %6.1f" % (short(n), c, s / 1e6, a / 1e3, mn / 1e3, mx / 1e3, 100.0 * s / tot))
+        try:
+            pm = cur.execute("select k.name, p.counter_name, sum(p.value), count(*) from counters_collection p join kernels k on 1=0").fetchall()
+        except Exception:
+            pm = []
+        try:
+            ccols = [r[1] for r in cur.execute("pragma table_info(counters_collection)")]
+            if ccols:
+                namecol = "kernel_name" if "kernel_name" in ccols else ("name" if "name" in ccols else None)
+                q = "select %s, counter_name, sum(value), count(*) from counters_collection group by 1, 2 order by 1, 2" % namecol
+                rows = cur.execute(q).fetchall()
+                if rows:
+                    print("-- PMC sums per kernel (sum over dispatches, dispatch count)")
+                    for n, cn, v, c in rows:
+                        print("%-44s %-24s %20.0f %8d" % (short(n), cn, v, c))
+        except Exception as e:
+            print("(no counters: %s)" % e)
+
+
+if __name__ == "__main__":
+    main()
