@@ -1,0 +1,148 @@
+#!/usr/bin/env python3
+"""Regenerates tests/golden/*.  Run from the repo root IN THE BUILD CONTAINER
+(`python tests/golden/make_golden.py`); the outputs are committed because neither
+/root/reference nor a real mitsuba install exists on the GPU box.
+
+Two kinds of fixture:
+
+1. reference_kats.json -- known-answer vectors TRANSCRIBED from the reference's own test
+   files under /root/reference (parsed, not retyped; each entry carries file:line).  These
+   pin the oracle.  The reference itself cannot be imported here (no drjit),
+   so these are the only reference-originated numbers available.
+
+2. oracle_fixtures.npz -- outputs of the CPU oracle (oracle/libmi_oracle.so) on small seeded
+   inputs: forward images, a PRB texture gradient, ray-query results, sampler streams.  The
+   `-m gpu` tests compare the HIP path against them (in addition to running the oracle
+   live), and a CPU test checks the oracle still reproduces them (drift guard).
+"""
+import json
+import os
+import re
+import sys
+
+import numpy as np
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(os.path.dirname(HERE))
+sys.path.insert(0, ROOT)
+REF = "/root/reference"
+
+
+def _lines(rel):
+    with open(os.path.join(REF, rel)) as f:
+        return f.read().splitlines()
+
+
+def transcribe_kats():
+    out = {"_comment": "transcribed by tests/golden/make_golden.py from the reference test-suite; do not edit by hand",
+           "reference_version": "mitsuba3 v3.9.1 (include/mitsuba/mitsuba.h:11-13)"}
+    # --- TEA (src/core/tests/test_random.py)
+    rel = "src/core/tests/test_random.py"
+    tea = {"float32": [], "float64": []}
+    for no, line in enumerate(_lines(rel), 1):
+        m = re.search(r"mi\.sample_tea_(float32|float64)\((\d+), (\d+), (\d+)\) == ([0-9.eE+-]+)", line)
+        if m:
+            tea[m.group(1)].append({"v0": int(m.group(2)), "v1": int(m.group(3)), "rounds": int(m.group(4)),
+                                    "value": float(m.group(5)), "src": "%s:%d" % (rel, no)})
+    assert len(tea["float32"]) == 8 and len(tea["float64"]) == 8
+    out["tea"] = tea
+    # --- Cornell pixel (src/integrators/tests/test_integrators.py: test02_path_directly_visible)
+    rel = "src/integrators/tests/test_integrators.py"
+    L = _lines(rel)
+    crop = {}
+    for no, line in enumerate(L, 1):
+        m = re.search(r"\['film'\]\['(crop_offset_x|crop_offset_y|crop_width|crop_height)'\] = (\d+)", line)
+        if m and no < 60:
+            crop[m.group(1)] = int(m.group(2))
+        m = re.search(r"dr\.allclose\(img\.array, \[([0-9., ]+)\]\)", line)
+        if m and "cornell_pixel" not in out:
+            out["cornell_pixel"] = {"crop": crop, "max_depth": 1, "value": [float(x) for x in m.group(1).split(",")],
+                                    "rtol": 1e-5, "src": "%s:%d" % (rel, no)}
+    assert out["cornell_pixel"]["crop"] == {"crop_offset_x": 124, "crop_offset_y": 36, "crop_width": 1, "crop_height": 1}
+    # --- Cornell box constants (src/python/python/util.py: cornell_box())
+    rel = "src/python/python/util.py"
+    consts = {}
+    for no, line in enumerate(_lines(rel), 1):
+        m = re.search(r"'value': \[([0-9., ]+)\]", line)
+        if m and 560 < no < 710:
+            consts.setdefault("rgb_values", []).append({"value": [float(x) for x in m.group(1).split(",")], "src": "%s:%d" % (rel, no)})
+        m = re.search(r"'fov': ([0-9.]+)", line)
+        if m and 560 < no < 710:
+            consts["fov"] = {"value": float(m.group(1)), "src": "%s:%d" % (rel, no)}
+    out["cornell_constants"] = consts
+    # --- stairs analytic depth (src/render/tests/test_kdtrees.py)
+    out["stairs"] = {"n_steps": 20, "grid": 128, "formula": "t = 2 - floor(y*20)/20", "src": "src/render/tests/test_kdtrees.py:8-81"}
+    # --- diffuse closed form (src/bsdfs/tests/test_diffuse.py:16-39)
+    out["diffuse"] = {"reflectance": 0.5, "n": 20, "formula": "eval = 0.5/pi*cos(theta_o), pdf = cos(theta_o)/pi",
+                      "src": "src/bsdfs/tests/test_diffuse.py:16-39"}
+    # --- TEA constants + epsilon used by the path (include/mitsuba/core/random.h:76-90, math.h:17-22)
+    rel = "include/mitsuba/core/random.h"
+    keys = []
+    for no, line in enumerate(_lines(rel), 1):
+        if 70 < no < 95:
+            keys += [int(x, 16) for x in re.findall(r"0x[0-9a-fA-F]{8}", line)]
+    out["tea_constants"] = {"values": keys, "src": "%s:76-90" % rel}
+    # --- published PCG32 demo vector (pcg-random.org pcg32-demo, seed 42/54); drjit is NOT in the tree
+    out["pcg32_published"] = {"initstate": 42, "initseq": 54,
+                              "outputs": [0xa15c02b7, 0x7b47f409, 0xba1d3330, 0x83d2f293, 0xbfa4784b, 0xcbed606e],
+                              "src": "pcg-random.org pcg32-demo (drjit 1.5.0 dr::PCG32 is not in /root/reference: parity unpinned)"}
+    with open(os.path.join(HERE, "reference_kats.json"), "w") as f:
+        json.dump(out, f, indent=1, sort_keys=True)
+    return out
+
+
+def random_rays(n, seed):
+    rng = np.random.default_rng(seed)
+    o = rng.uniform(-0.9, 0.9, (3, n)).astype(np.float32)
+    d = rng.normal(size=(3, n)).astype(np.float32)
+    d /= np.linalg.norm(d, axis=0, keepdims=True)
+    return o, d.astype(np.float32)
+
+
+def checker_texture(res):
+    """0.5 + 0.25 * checker(8 x 8), H x W x 3 f32"""
+    i = (np.arange(res) * 8 // res)
+    c = ((i[:, None] + i[None, :]) & 1).astype(np.float32)
+    return np.repeat((0.5 + 0.25 * (2 * c - 1))[:, :, None], 3, axis=2).astype(np.float32)
+
+
+def oracle_fixtures():
+    from oracle import oracle as O
+    fx = {}
+    # forward path, Cornell 32x32, 8 spp, seed 0, max_depth 8 (gaussian) and box filter + crop
+    sd, sensor = O.cornell_box(32, 32)
+    osc = O.OracleScene(sd)
+    fx["cornell32_spp8_seed0_path"], _ = osc.render_path(sensor, seed=0, spp=8, max_depth=8)
+    fx["cornell32_spp8_seed0_prb"], _ = osc.render_prb(sensor, seed=0, spp=8, max_depth=6)
+    # ray queries (closest hit + shadow) on seeded rays
+    n = 4096
+    o, d = random_rays(n, 1)
+    maxt = np.full(n, 3.402823466e+38, np.float32)
+    t, u, v, prim, shape, inst = osc.ray_intersect(o, d, maxt, naive=True)
+    fx["rays_o"], fx["rays_d"] = o, d
+    fx["cornell_hit_t"], fx["cornell_hit_u"], fx["cornell_hit_v"] = t, u, v
+    fx["cornell_hit_prim"], fx["cornell_hit_shape"] = prim, shape
+    fx["cornell_ray_test_maxt1"] = osc.ray_test(o, d, np.full(n, 1.0, np.float32))
+    # sampler streams: seed 7, lanes 0..15, 5 draws
+    st = np.empty((16, 5), np.float32)
+    for lane in range(16):
+        out = np.empty(5, np.float32); O.lib().orc_sampler_stream(7, lane, 5, O.fp(out)); st[lane] = out
+    fx["sampler_seed7"] = st
+    # PRB texture gradient (C4 at fixture size): 24x24 film, 8x8 texture, 8 spp, loss = mean(img^2)
+    tex = checker_texture(8)
+    sd, sensor = O.cornell_box(24, 24, white_texture=tex)
+    osc = O.OracleScene(sd)
+    img, _ = osc.render_prb(sensor, seed=0, spp=8, max_depth=6)
+    grad_in = (2.0 * img / img.size).astype(np.float32)
+    g_refl, g_tex, _ = osc.render_prb_backward(sensor, grad_in, seed=0x1234, spp=8, max_depth=6)
+    fx["c4_texture"] = tex; fx["c4_img"] = img; fx["c4_grad_in"] = grad_in
+    fx["c4_grad_refl"] = g_refl; fx["c4_grad_tex"] = g_tex[0]
+    np.savez_compressed(os.path.join(HERE, "oracle_fixtures.npz"), **fx)
+    return fx
+
+
+if __name__ == "__main__":
+    k = transcribe_kats()
+    print("reference_kats.json:", sorted(k.keys()))
+    f = oracle_fixtures()
+    print("oracle_fixtures.npz:", {n: v.shape for n, v in f.items()})

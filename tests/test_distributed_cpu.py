@@ -1,0 +1,89 @@
+"""Multi-GPU path on CPU: world_size-2 `gloo` run of the SAME host code (`lane_range` +
+`render_distributed`: pixel-row bands with global lane seeding, private films, one sum-reduce)
+with the CPU oracle standing in for the device renderer (there is no GPU in this container and
+the product has no CPU fallback).  SURVEY.md 8(e)."""
+import os
+import socket
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+WORKER = r'''
+import os, sys
+import numpy as np
+import torch
+import torch.distributed as dist
+sys.path.insert(0, os.environ["HAR_ROOT"])
+import mitsuba3_amd as mi
+from oracle import oracle as O
+
+class OracleIntegrator:
+    """Test double with Integrator.render_film's signature; renders a lane band with the oracle."""
+    def __init__(self, osc, sensor):
+        self.osc, self.sensor = osc, sensor
+    def render_film(self, scene, sensor=0, seed=0, spp=0, lanes=None, film=None):
+        raw, _ = self.osc.render_path(self.sensor, seed=seed, spp=spp, max_depth=8, lanes=lanes, raw=True)
+        return torch.from_numpy(raw)
+
+dist.init_process_group(backend="gloo", rank=int(os.environ["RANK"]), world_size=int(os.environ["WORLD_SIZE"]))
+rank, world = dist.get_rank(), dist.get_world_size()
+mi.set_variant("hip_ad_rgb")
+res, spp = 24, 4
+d = mi.cornell_box(); d["sensor"]["film"]["width"] = res; d["sensor"]["film"]["height"] = res
+scene = mi.load_dict(d)                      # host-side scene only; no device handle is created
+sd, osensor = O.cornell_box(res, res)
+osc = O.OracleScene(sd)
+film = mi.render_distributed(scene, integrator=OracleIntegrator(osc, osensor), seed=3, spp=spp, develop=False)
+lo, hi = mi.lane_range(res * res * spp, rank, world, granule=res * spp)
+assert lo % (res * spp) == 0 and (hi % (res * spp) == 0 or hi == res * res * spp)
+if rank == 0:
+    whole, _ = osc.render_path(osensor, seed=3, spp=spp, max_depth=8, raw=True)
+    got = film.numpy()
+    err = np.abs(got - whole).max() / np.abs(whole).max()
+    assert err < 1e-6, err
+    # the weight channel is exactly the sum of the bands' weights: every lane rendered once
+    assert abs(got[..., 3].sum() - whole[..., 3].sum()) / whole[..., 3].sum() < 1e-6
+    print("DIST_OK", err)
+dist.barrier()
+dist.destroy_process_group()
+'''
+
+
+def _free_port():
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); p = s.getsockname()[1]; s.close(); return p
+
+
+def test_lane_range_partitions_whole_rows():
+    sys.path.insert(0, ROOT)
+    from mitsuba3_amd.distributed import lane_range
+    for (w, h, spp) in [(512, 512, 256), (33, 7, 5), (4096, 4096, 128)]:
+        total = w * h * spp
+        for world in (1, 2, 3, 4, 8):
+            prev = 0
+            for r in range(world):
+                lo, hi = lane_range(total, r, world, granule=w * spp)
+                assert lo == prev and lo % (w * spp) == 0 and hi >= lo
+                prev = hi
+            assert prev == total
+
+
+def test_world_size_2_gloo_band_union_equals_whole():
+    port = _free_port()
+    procs = []
+    for rank in range(2):
+        env = dict(os.environ, RANK=str(rank), WORLD_SIZE="2", MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), HAR_ROOT=ROOT,
+                   OMP_NUM_THREADS="2")
+        procs.append(subprocess.Popen([sys.executable, "-c", WORKER], env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True))
+    outs = []
+    for p in procs:
+        try:
+            out, _ = p.communicate(timeout=300)
+        except subprocess.TimeoutExpired:
+            p.kill(); out, _ = p.communicate()
+        outs.append(out)
+    assert all(p.returncode == 0 for p in procs), "\n".join(outs)
+    assert "DIST_OK" in outs[0]
