@@ -113,14 +113,100 @@ HAR_HD RaySetup ray_setup(Vec3 o, Vec3 d) {
 
 #define HAR_STACK_OVERFLOW 0x7fffffff
 
+/* Probe: optional per-ray event counters (tools/ and the host harness); the default compiles to nothing */
+struct NoProbe { HAR_HD void node() {} HAR_HD void tri() {} HAR_HD void inst() {} HAR_HD void iter() {} };
+
 /*
+ * One node visit: fetch the 80-byte node `index`, intersect the ray with its 8 quantised child
+ * boxes and return the hits as a node group (child_base | hit-children bits in traversal order |
+ * imask) and a triangle group (tri_base | 24-bit triangle mask) -- Ylitie et al.'s encoding.
+ */
+HAR_HD void node_visit(const Accel &A, const RaySetup &R, float tmax, uint32_t index, uint32_t &ng_x, uint32_t &ng_y, uint32_t &tg_x, uint32_t &tg_y) {
+    const uint32_t *np = reinterpret_cast<const uint32_t *>(A.nodes + index);
+#if defined(__HIP_DEVICE_COMPILE__)
+    const uint4 n0 = reinterpret_cast<const uint4 *>(np)[0], n1 = reinterpret_cast<const uint4 *>(np)[1],
+                n2 = reinterpret_cast<const uint4 *>(np)[2], n3 = reinterpret_cast<const uint4 *>(np)[3],
+                n4 = reinterpret_cast<const uint4 *>(np)[4];
+    const uint32_t w[20] = { n0.x, n0.y, n0.z, n0.w, n1.x, n1.y, n1.z, n1.w, n2.x, n2.y, n2.z, n2.w,
+                             n3.x, n3.y, n3.z, n3.w, n4.x, n4.y, n4.z, n4.w };
+#else
+    uint32_t w[20]; for (int i = 0; i < 20; ++i) w[i] = np[i];
+#endif
+    // w[0..2] origin, w[3] = ex | ey<<8 | ez<<16 | imask<<24, w[4] child_base, w[5] tri_base,
+    // w[6..7] meta, w[8..9] qlox, w[10..11] qloy, w[12..13] qloz, w[14..15] qhix, w[16..17] qhiy, w[18..19] qhiz
+    float sx = as_f32((w[3] & 0xffu) << 23), sy = as_f32(((w[3] >> 8) & 0xffu) << 23), sz = as_f32(((w[3] >> 16) & 0xffu) << 23);
+    float ax = sx * R.idir.x, ay = sy * R.idir.y, az = sz * R.idir.z;
+    float bx = (as_f32(w[0]) - R.o.x) * R.idir.x, by = (as_f32(w[1]) - R.o.y) * R.idir.y, bz = (as_f32(w[2]) - R.o.z) * R.idir.z;
+    /* the near / far plane of a slab depends only on the ray's sign: swap the quantised words once per node */
+    const bool nx = R.idir.x < 0.f, ny = R.idir.y < 0.f, nz = R.idir.z < 0.f;
+    const uint32_t nxw[2] = { nx ? w[14] : w[8],  nx ? w[15] : w[9]  }, fxw[2] = { nx ? w[8]  : w[14], nx ? w[9]  : w[15] };
+    const uint32_t nyw[2] = { ny ? w[16] : w[10], ny ? w[17] : w[11] }, fyw[2] = { ny ? w[10] : w[16], ny ? w[11] : w[17] };
+    const uint32_t nzw[2] = { nz ? w[18] : w[12], nz ? w[19] : w[13] }, fzw[2] = { nz ? w[12] : w[18], nz ? w[13] : w[19] };
+    uint32_t hitmask = 0;
+#if defined(__HIP_DEVICE_COMPILE__)
+#pragma unroll
+#endif
+    for (int i = 0; i < 8; ++i) {
+        const int wi = i >> 2, sh = (i & 3) * 8;
+        uint32_t meta = (w[6 + wi] >> sh) & 0xffu;
+        float t0x = fma_((float) ((nxw[wi] >> sh) & 0xffu), ax, bx), t1x = fma_((float) ((fxw[wi] >> sh) & 0xffu), ax, bx);
+        float t0y = fma_((float) ((nyw[wi] >> sh) & 0xffu), ay, by), t1y = fma_((float) ((fyw[wi] >> sh) & 0xffu), ay, by);
+        float t0z = fma_((float) ((nzw[wi] >> sh) & 0xffu), az, bz), t1z = fma_((float) ((fzw[wi] >> sh) & 0xffu), az, bz);
+        float tn = fmaxf(fmaxf(t0x, t0y), fmaxf(t0z, 0.f));
+        float tf = fminf(fminf(t1x, t1y), fminf(t1z, tmax));
+        bool isect = (meta != 0u) && (tn <= tf * 1.0000005f);
+        if (isect) {
+            bool inner = (meta & 0x18u) == 0x18u;
+            uint32_t bits = meta >> 5;
+            uint32_t index = (meta ^ (inner ? R.octinv : 0u)) & 0x1fu;
+            hitmask |= bits << index;
+        }
+    }
+    ng_x = w[4]; tg_x = w[5];
+    ng_y = (hitmask & 0xff000000u) | (w[3] >> 24);
+    tg_y = hitmask & 0x00ffffffu;
+}
+
+/* pick the next child of a node group (front-to-back = highest bit); returns its node index */
+HAR_HD uint32_t ng_next_child(uint32_t ng_x, uint32_t &ng_y, uint32_t octinv) {
+    uint32_t imask = ng_y & 0xffu;
+    uint32_t bit = 31u - clz32(ng_y);
+    ng_y &= ~(1u << bit);
+    uint32_t slot = (bit - 24u) ^ octinv;
+    return ng_x + popc32(imask & ~(0xffffffffu << slot));
+}
+
+/* one triangle record against the (object-space) ray; closest-hit bookkeeping */
+template <bool AnyHit>
+HAR_HD bool tri_visit(const Accel &A, const RaySetup &R, float &tmax, uint32_t idx, uint32_t cur_inst, Hit &hit) {
+    const float *tp = reinterpret_cast<const float *>(A.tris + idx);
+#if defined(__HIP_DEVICE_COMPILE__)
+    const float4 a = reinterpret_cast<const float4 *>(tp)[0], b = reinterpret_cast<const float4 *>(tp)[1],
+                 c = reinterpret_cast<const float4 *>(tp)[2];
+    const float f[12] = { a.x, a.y, a.z, a.w, b.x, b.y, b.z, b.w, c.x, c.y, c.z, c.w };
+#else
+    float f[12]; for (int i = 0; i < 12; ++i) f[i] = tp[i];
+#endif
+    float t, u, v;
+    if (moeller_trumbore(R.o, R.d, tmax, Vec3(f[0], f[1], f[2]), Vec3(f[3], f[4], f[5]), Vec3(f[6], f[7], f[8]), t, u, v)) {
+        if (AnyHit) return true;
+        hit_update(hit, t, u, v, as_u32(f[9]), as_u32(f[10]), cur_inst);
+        tmax = hit.t;
+    }
+    return false;
+}
+
+/*
+ * Reference traversal loop (depth first, every triangle of a visited node at once).  Used by the
+ * array-valued API kernels and the host harness.
+ *
  * Stack concept: void push(int level, uint32_t x, uint32_t y); void pop(int level, uint32_t &x, uint32_t &y);
  * static constexpr int Capacity.
  * Returns true if (AnyHit and an intersection exists) or (closest hit found).
  * `status` is set to HAR_STACK_OVERFLOW if the stack capacity was exceeded.
  */
-template <bool AnyHit, typename Stack>
-HAR_HD bool accel_trace(const Accel &A, Vec3 o_w, Vec3 d_w, float maxt, Hit &hit, Stack &stack, int &status) {
+template <bool AnyHit, typename Stack, typename Probe = NoProbe>
+HAR_HD bool accel_trace(const Accel &A, Vec3 o_w, Vec3 d_w, float maxt, Hit &hit, Stack &stack, int &status, Probe probe = Probe()) {
     hit.t = HAR_INF; hit.u = 0.f; hit.v = 0.f; hit.prim = 0; hit.shape = 0; hit.inst = 0xffffffffu;
     float tmax = maxt;
     RaySetup R = ray_setup(o_w, d_w);
@@ -129,57 +215,16 @@ HAR_HD bool accel_trace(const Accel &A, Vec3 o_w, Vec3 d_w, float maxt, Hit &hit
     uint32_t ng_x = A.root, ng_y = 0x80000000u, tg_x = 0, tg_y = 0;
     int sp = 0, inst_sp = -1;
     for (;;) {
+        probe.iter();
         if (ng_y > 0x00ffffffu) {
-            uint32_t imask = ng_y & 0xffu;
-            uint32_t bit = 31u - clz32(ng_y);
-            ng_y &= ~(1u << bit);
-            if (ng_y > 0x00ffffffu) {
+            probe.node();
+            uint32_t px = ng_x, py = ng_y;
+            uint32_t child = ng_next_child(px, py, R.octinv);
+            if (py > 0x00ffffffu) {
                 if (sp >= Stack::Capacity) { status = HAR_STACK_OVERFLOW; return false; }
-                stack.push(sp++, ng_x, ng_y);
+                stack.push(sp++, px, py);
             }
-            uint32_t slot = (bit - 24u) ^ R.octinv;
-            uint32_t rel = popc32(imask & ~(0xffffffffu << slot));
-            const uint32_t *np = reinterpret_cast<const uint32_t *>(A.nodes + (ng_x + rel));
-#if defined(__HIP_DEVICE_COMPILE__)
-            const uint4 n0 = reinterpret_cast<const uint4 *>(np)[0], n1 = reinterpret_cast<const uint4 *>(np)[1],
-                        n2 = reinterpret_cast<const uint4 *>(np)[2], n3 = reinterpret_cast<const uint4 *>(np)[3],
-                        n4 = reinterpret_cast<const uint4 *>(np)[4];
-            const uint32_t w[20] = { n0.x, n0.y, n0.z, n0.w, n1.x, n1.y, n1.z, n1.w, n2.x, n2.y, n2.z, n2.w,
-                                     n3.x, n3.y, n3.z, n3.w, n4.x, n4.y, n4.z, n4.w };
-#else
-            uint32_t w[20]; for (int i = 0; i < 20; ++i) w[i] = np[i];
-#endif
-            // w[0..2] origin, w[3] = ex | ey<<8 | ez<<16 | imask<<24, w[4] child_base, w[5] tri_base,
-            // w[6..7] meta, w[8..9] qlox, w[10..11] qloy, w[12..13] qloz, w[14..15] qhix, w[16..17] qhiy, w[18..19] qhiz
-            float sx = as_f32((w[3] & 0xffu) << 23), sy = as_f32(((w[3] >> 8) & 0xffu) << 23), sz = as_f32(((w[3] >> 16) & 0xffu) << 23);
-            float ax = sx * R.idir.x, ay = sy * R.idir.y, az = sz * R.idir.z;
-            float bx = (as_f32(w[0]) - R.o.x) * R.idir.x, by = (as_f32(w[1]) - R.o.y) * R.idir.y, bz = (as_f32(w[2]) - R.o.z) * R.idir.z;
-            bool nx = R.idir.x < 0.f, ny = R.idir.y < 0.f, nz = R.idir.z < 0.f;
-            uint32_t hitmask = 0;
-#if defined(__HIP_DEVICE_COMPILE__)
-#pragma unroll
-#endif
-            for (int i = 0; i < 8; ++i) {
-                const int wi = i >> 2, sh = (i & 3) * 8;
-                uint32_t meta = (w[6 + wi] >> sh) & 0xffu;
-                float qlx = (float) ((w[8 + wi] >> sh) & 0xffu),  qly = (float) ((w[10 + wi] >> sh) & 0xffu), qlz = (float) ((w[12 + wi] >> sh) & 0xffu);
-                float qhx = (float) ((w[14 + wi] >> sh) & 0xffu), qhy = (float) ((w[16 + wi] >> sh) & 0xffu), qhz = (float) ((w[18 + wi] >> sh) & 0xffu);
-                float t0x = fma_(nx ? qhx : qlx, ax, bx), t1x = fma_(nx ? qlx : qhx, ax, bx);
-                float t0y = fma_(ny ? qhy : qly, ay, by), t1y = fma_(ny ? qly : qhy, ay, by);
-                float t0z = fma_(nz ? qhz : qlz, az, bz), t1z = fma_(nz ? qlz : qhz, az, bz);
-                float tn = fmaxf(fmaxf(t0x, t0y), fmaxf(t0z, 0.f));
-                float tf = fminf(fminf(t1x, t1y), fminf(t1z, tmax));
-                bool isect = (meta != 0u) && (tn <= tf * 1.0000005f);
-                if (isect) {
-                    bool inner = (meta & 0x18u) == 0x18u;
-                    uint32_t bits = meta >> 5;
-                    uint32_t index = (meta ^ (inner ? R.octinv : 0u)) & 0x1fu;
-                    hitmask |= bits << index;
-                }
-            }
-            ng_x = w[4]; tg_x = w[5];
-            ng_y = (hitmask & 0xff000000u) | (w[3] >> 24);
-            tg_y = hitmask & 0x00ffffffu;
+            node_visit(A, R, tmax, child, ng_x, ng_y, tg_x, tg_y);
         } else {
             tg_x = ng_x; tg_y = ng_y; ng_x = 0; ng_y = 0;
         }
@@ -198,26 +243,15 @@ HAR_HD bool accel_trace(const Accel &A, Vec3 o_w, Vec3 d_w, float maxt, Hit &hit
                     if (sp >= Stack::Capacity) { status = HAR_STACK_OVERFLOW; return false; }
                     stack.push(sp++, tg_x, tg_y);
                 }
+                probe.inst();
                 const InstRec &I = A.insts[idx];
                 inst_sp = sp; cur_inst = I.inst_index; in_tlas = false;
                 if (!I.identity) R = ray_setup(xf_point(I.to_object, o_w), xf_vector(I.to_object, d_w));
                 ng_x = I.blas_root; ng_y = 0x80000000u; tg_y = 0;
                 break;
             } else {
-                const float *tp = reinterpret_cast<const float *>(A.tris + idx);
-#if defined(__HIP_DEVICE_COMPILE__)
-                const float4 a = reinterpret_cast<const float4 *>(tp)[0], b = reinterpret_cast<const float4 *>(tp)[1],
-                             c = reinterpret_cast<const float4 *>(tp)[2];
-                const float f[12] = { a.x, a.y, a.z, a.w, b.x, b.y, b.z, b.w, c.x, c.y, c.z, c.w };
-#else
-                float f[12]; for (int i = 0; i < 12; ++i) f[i] = tp[i];
-#endif
-                float t, u, v;
-                if (moeller_trumbore(R.o, R.d, tmax, Vec3(f[0], f[1], f[2]), Vec3(f[3], f[4], f[5]), Vec3(f[6], f[7], f[8]), t, u, v)) {
-                    if (AnyHit) return true;
-                    hit_update(hit, t, u, v, as_u32(f[9]), as_u32(f[10]), cur_inst);
-                    tmax = hit.t;
-                }
+                probe.tri();
+                if (tri_visit<AnyHit>(A, R, tmax, idx, cur_inst, hit)) return true;
             }
         }
 
@@ -232,6 +266,122 @@ HAR_HD bool accel_trace(const Accel &A, Vec3 o_w, Vec3 d_w, float maxt, Hit &hit
     }
     return hit.t != HAR_INF;
 }
+
+/*
+ * Resumable, DECOUPLED traversal for the persistent wavefront kernels.  One call of step() is one
+ * SIMT-friendly iteration with a fixed shape: at most ONE node visit, then at most ONE leaf item
+ * (one triangle test in a BLAS, one instance entry in the TLAS), then at most one stack pop -- so
+ * that the 64 lanes of a wave execute the same three blocks whatever their rays are doing (the
+ * reference loop above runs "all triangles of the node" inside every iteration, which costs a wave
+ * max-over-lanes triangle tests per iteration: measured 6 % lane utilisation in that block).
+ *
+ * POLICY 0: a node is only visited when no triangle is pending (same stack need as the reference loop);
+ * POLICY 1: nodes are visited every iteration, a still-pending triangle group is parked on the stack.
+ * Both visit the same set of candidate triangles with the exact Moeller-Trumbore test and the same
+ * tie rule, so the result is identical to accel_trace (order independent).
+ */
+template <int POLICY>
+struct Traversal {
+    Vec3 o_w, d_w;
+    RaySetup R;
+    float tmax;
+    Hit hit;
+    uint32_t ng_x, ng_y, tg_x, tg_y, cur_inst;
+    int sp, inst_sp;
+    bool in_tlas, found;
+
+    HAR_HD void begin(const Accel &A, Vec3 o, Vec3 d, float maxt) {
+        o_w = o; d_w = d; tmax = maxt;
+        hit.t = HAR_INF; hit.u = 0.f; hit.v = 0.f; hit.prim = 0; hit.shape = 0; hit.inst = 0xffffffffu;
+        R = ray_setup(o, d);
+        in_tlas = A.has_tlas != 0; cur_inst = 0xffffffffu; found = false;
+        ng_x = A.root; ng_y = 0x80000000u; tg_x = 0; tg_y = 0; sp = 0; inst_sp = -1;
+    }
+
+    /* ---- node phase: at most one node visit */
+    template <typename Stack, typename Probe>
+    HAR_HD bool phase_node(const Accel &A, Stack &stack, int &status, Probe &probe) {
+        if (ng_y > 0x00ffffffu && (POLICY == 1 || tg_y == 0u)) {
+            probe.node();
+            uint32_t child = ng_next_child(ng_x, ng_y, R.octinv);
+            if (ng_y > 0x00ffffffu) {
+                if (sp >= Stack::Capacity) return overflow(status);
+                stack.push(sp++, ng_x, ng_y);
+            }
+            uint32_t cx, cy;
+            node_visit(A, R, tmax, child, ng_x, ng_y, cx, cy);
+            if (POLICY == 1 && tg_y != 0u && cy != 0u) {          /* park the NEW group, finish the nearer old one first */
+                if (sp >= Stack::Capacity) return overflow(status);
+                stack.push(sp++, cx, cy);
+            } else if (cy != 0u) { tg_x = cx; tg_y = cy; }
+        }
+        return false;
+    }
+    /* ---- leaf phase: one triangle test (BLAS) or one instance entry (TLAS) */
+    template <bool AnyHit, typename Stack, typename Probe>
+    HAR_HD bool phase_leaf(const Accel &A, Stack &stack, int &status, Probe &probe) {
+        if (tg_y != 0u) {
+            uint32_t bit = 31u - clz32(tg_y);
+            tg_y &= ~(1u << bit);
+            uint32_t idx = tg_x + bit;
+            if (in_tlas) {
+                if (ng_y > 0x00ffffffu) {
+                    if (sp >= Stack::Capacity) return overflow(status);
+                    stack.push(sp++, ng_x, ng_y);
+                }
+                if (tg_y != 0u) {
+                    if (sp >= Stack::Capacity) return overflow(status);
+                    stack.push(sp++, tg_x, tg_y);
+                }
+                probe.inst();
+                const InstRec &I = A.insts[idx];
+                inst_sp = sp; cur_inst = I.inst_index; in_tlas = false;
+                if (!I.identity) R = ray_setup(xf_point(I.to_object, o_w), xf_vector(I.to_object, d_w));
+                ng_x = I.blas_root; ng_y = 0x80000000u; tg_y = 0;
+            } else {
+                probe.tri();
+                if (tri_visit<AnyHit>(A, R, tmax, idx, cur_inst, hit)) { found = true; return true; }
+            }
+        }
+        return false;
+    }
+    /* ---- pop phase: leave the instance / finish / take the next group from the stack */
+    template <typename Stack>
+    HAR_HD bool phase_pop(Stack &stack) {
+        if (ng_y <= 0x00ffffffu && tg_y == 0u) {
+            if (!in_tlas && sp == inst_sp) {
+                in_tlas = true; cur_inst = 0xffffffffu; inst_sp = -1;
+                R = ray_setup(o_w, d_w);
+            }
+            if (sp == 0) { found = hit.t != HAR_INF; return true; }
+            uint32_t x, y;
+            stack.pop(--sp, x, y);
+            if (y > 0x00ffffffu) { ng_x = x; ng_y = y; } else { tg_x = x; tg_y = y; ng_x = 0; ng_y = 0; }
+        }
+        return false;
+    }
+    HAR_HD bool overflow(int &status) { status = HAR_STACK_OVERFLOW; hit.t = HAR_INF; found = false; return true; }
+
+    /* one iteration; returns true when the ray is finished (`found` / `hit` hold the result).
+     * ORDER 0: node, leaf, pop   1: leaf, node, pop   2: leaf, pop, node */
+    template <bool AnyHit, typename Stack, typename Probe = NoProbe, int ORDER = 2>
+    HAR_HD bool step(const Accel &A, Stack &stack, int &status, Probe probe = Probe()) {
+        probe.iter();
+        if (ORDER == 0) {
+            if (phase_node(A, stack, status, probe)) return true;
+            if (phase_leaf<AnyHit>(A, stack, status, probe)) return true;
+            return phase_pop(stack);
+        } else if (ORDER == 1) {
+            if (phase_leaf<AnyHit>(A, stack, status, probe)) return true;
+            if (phase_node(A, stack, status, probe)) return true;
+            return phase_pop(stack);
+        } else {
+            if (phase_leaf<AnyHit>(A, stack, status, probe)) return true;
+            if (phase_pop(stack)) return true;
+            return phase_node(A, stack, status, probe);
+        }
+    }
+};
 
 /* Scene::ray_intersect_naive (scene.cpp:240-244): brute force over every triangle record */
 template <bool AnyHit>

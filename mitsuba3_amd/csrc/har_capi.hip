@@ -49,7 +49,7 @@ struct HarSceneImpl {
 
 struct HarIntegratorImpl {
     int type = HAR_INTEGRATOR_PATH;
-    uint32_t max_depth = 0, rr_depth = 5, chunk = 1u << 20;   /* lanes per wavefront chunk, multiple of 2048 */
+    uint32_t max_depth = 0, rr_depth = 5, chunk = 1u << 24;   /* lanes per wavefront chunk, multiple of 2048 */
     // workspace
     uint32_t ws_lanes = 0; bool ws_adjoint = false; uint32_t shard_cap = 0;
     std::vector<void *> owned;
@@ -94,7 +94,7 @@ int ensure_workspace(HarIntegratorImpl *I, uint32_t lanes, bool adjoint) {
     I->items.s3 = I->items.s4 = nullptr; I->dL = nullptr;
     if (adjoint && (ws_alloc(I, &I->items.s3, lanes) || ws_alloc(I, &I->items.s4, lanes) || ws_alloc(I, &I->dL, lanes))) return 1;
     if (ws_alloc(I, &I->result, lanes)) return 1;
-    if (ws_alloc(I, &I->counters, (size_t) 2 * HAR_MAX_BOUNCE_SLOTS * HAR_SHARDS * HAR_COUNTER_STRIDE) || ws_alloc(I, &I->totals, 4) || ws_alloc(I, &I->status, 1)) return 1;
+    if (ws_alloc(I, &I->counters, (size_t) 4 * HAR_MAX_BOUNCE_SLOTS * HAR_SHARDS * HAR_COUNTER_STRIDE) || ws_alloc(I, &I->totals, 4) || ws_alloc(I, &I->status, 1)) return 1;
     HIP_TRY(hipMemset(I->totals, 0, 4 * sizeof(unsigned long long)));
     HIP_TRY(hipMemset(I->status, 0, sizeof(int)));
     I->ws_lanes = lanes; I->ws_adjoint = adjoint; I->shard_cap = lanes / HAR_SHARDS;
@@ -117,6 +117,9 @@ uint32_t bounce_limit(const HarIntegratorImpl *I) { return std::min<uint32_t>(I-
 
 static inline uint32_t *cnt_alive(HarIntegratorImpl *I, uint32_t b) { return I->counters + (size_t) b * HAR_SHARDS * HAR_COUNTER_STRIDE; }
 static inline uint32_t *cnt_items(HarIntegratorImpl *I, uint32_t b) { return I->counters + (size_t) (HAR_MAX_BOUNCE_SLOTS + b) * HAR_SHARDS * HAR_COUNTER_STRIDE; }
+/* work cursors of the persistent traversal kernels (one per bounce and shard) */
+static inline uint32_t *cur_trace(HarIntegratorImpl *I, uint32_t b) { return I->counters + (size_t) (2 * HAR_MAX_BOUNCE_SLOTS + b) * HAR_SHARDS * HAR_COUNTER_STRIDE; }
+static inline uint32_t *cur_resolve(HarIntegratorImpl *I, uint32_t b) { return I->counters + (size_t) (3 * HAR_MAX_BOUNCE_SLOTS + b) * HAR_SHARDS * HAR_COUNTER_STRIDE; }
 
 /* one chunk: raygen + bounce loop.  `mode` selects path / prb primal / prb adjoint kernels */
 int run_chunk(HarSceneImpl *S, HarIntegratorImpl *I, const DSensor &C, int mode, uint32_t seed, uint32_t spp, uint32_t log_spp,
@@ -125,20 +128,24 @@ int run_chunk(HarSceneImpl *S, HarIntegratorImpl *I, const DSensor &C, int mode,
     const size_t used = (size_t) std::min<uint32_t>(nb + 2, HAR_MAX_BOUNCE_SLOTS) * HAR_SHARDS * HAR_COUNTER_STRIDE * sizeof(uint32_t);
     HIP_TRY(hipMemsetAsync(cnt_alive(I, 0), 0, used, s));
     HIP_TRY(hipMemsetAsync(cnt_items(I, 0), 0, used, s));
+    HIP_TRY(hipMemsetAsync(cur_trace(I, 0), 0, used, s));
+    HIP_TRY(hipMemsetAsync(cur_resolve(I, 0), 0, used, s));
     launch_raygen(mode, s, C, seed, spp, log_spp, lane_base, n, I->shard_cap, I->st[0], I->result, cnt_alive(I, 0), I->adj, I->dL);
     prof_mark(I, s, CLS_RAYGEN);
     ShadeParams P{ seed, I->max_depth, I->rr_depth };
     /* grid: a multiple of 8 so that block b serves shard b % 8; enough blocks to cover the chunk once */
     const uint32_t grid = std::max<uint32_t>(HAR_SHARDS, std::min<uint32_t>(((n + 255) / 256 + HAR_SHARDS - 1) / HAR_SHARDS * HAR_SHARDS, 4096u));
+    /* persistent traversal kernels: enough blocks to fill the chip (<= 8 blocks/CU), never more than the work */
+    const uint32_t tgrid = std::min<uint32_t>(grid, 2048u);
     const int small_stack = S->hs.stack_need() <= HAR_LDS_STACK_SMALL;   /* overflow is detected and reported */
     int cur = 0; uint32_t b = 0;
     for (; b < nb; ++b) {
-        launch_trace_closest(s, grid, small_stack, S->ds.accel, cnt_alive(I, b), I->shard_cap, I->st[cur], I->h0, I->h1, I->status);
+        launch_trace_closest(s, tgrid, small_stack, S->ds.accel, cnt_alive(I, b), cur_trace(I, b), I->shard_cap, I->st[cur], I->h0, I->h1, I->status);
         prof_mark(I, s, CLS_TRACE);
         launch_shade(mode, s, grid, S->ds, P, lane_base, I->shard_cap, cnt_alive(I, b), I->st[cur], I->h0, I->h1, I->st[cur ^ 1], cnt_alive(I, b + 1),
                      I->items, cnt_items(I, b), I->result);
         prof_mark(I, s, CLS_SHADE);
-        launch_resolve(mode, s, grid, small_stack, S->ds, cnt_items(I, b), I->shard_cap, I->items, I->result, I->dL, grad_refl, I->d_grad_tex, I->status);
+        launch_resolve(mode, s, tgrid, small_stack, S->ds, cnt_items(I, b), cur_resolve(I, b), I->shard_cap, I->items, I->result, I->dL, grad_refl, I->d_grad_tex, I->status);
         prof_mark(I, s, CLS_RESOLVE);
         cur ^= 1;
         if (b >= 15 && (b & 7) == 7) {           /* deep paths are rare: poll so that max_depth = -1 terminates */

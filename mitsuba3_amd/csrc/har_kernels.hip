@@ -160,24 +160,90 @@ __global__ __launch_bounds__(kBlock) void k_raygen(DSensor C, uint32_t seed, uin
     }
 }
 
+/* ------------------------------------------------- persistent traversal loop */
+/*
+ * The traversal kernels are VALU-issue bound (rocprofv3: SQ_ACTIVE_INST_VALU ~ 73 % of SIMD cycles)
+ * at ~30 % lane utilisation: incoherent rays need very different numbers of iterations (mean 13,
+ * wave maximum 39 on the 1M-triangle scene) and the reference loop runs max-over-lanes triangle
+ * tests per iteration.  Two changes fix that (tools/trace_stats.py models both on the CPU):
+ *   - Traversal<0>::step() has a fixed shape (<= 1 leaf item, <= 1 node visit, <= 1 pop);
+ *   - a wave is PERSISTENT: it draws rays in batches from its shard's cursor (one atomic per
+ *     HAR_FETCH_BATCH rays) and refills idle lanes whenever >= HAR_REFILL_IDLE lanes are idle, so
+ *     its lanes work on different rays at different stages ("persistent while-while", Aila & Laine,
+ *     adapted to 64-lane waves).
+ *   take(idx, T) -> bool : load work item idx into T (begin()); false = item has no ray to trace
+ *   done(idx, T)         : called by the lane when its ray finishes (divergent; plain stores only)
+ *   retire(pred, idx, T) : called by ALL lanes at refill time (wave-uniform; may use wave reductions),
+ *                          pred marks lanes whose item finished since the last refill
+ */
+#define HAR_FETCH_BATCH 128u
+#define HAR_REFILL_IDLE 12u
+
+template <bool ANY, bool RETIRE, int CAP, typename Take, typename Done, typename Retire>
+__device__ __forceinline__ void trace_persistent(const Accel &A, uint32_t *cursor, uint32_t n, LdsStack<CAP> &stack, int *status,
+                                                 Take take, Done done, Retire retire) {
+    const uint32_t lane = threadIdx.x & 63u;
+    uint32_t pool_next = 0, pool_end = 0;      /* wave-uniform */
+    bool exhausted = false;                    /* wave-uniform */
+    bool busy = false, has_result = false;
+    uint32_t idx = 0;
+    Traversal<0> T;
+    T.found = false; T.hit.t = HAR_INF;
+    for (;;) {
+        const uint64_t idle = __ballot(!busy);
+        const uint32_t n_idle = (uint32_t) __popcll(idle);
+        if (n_idle >= HAR_REFILL_IDLE) {
+            if (RETIRE) { retire(!busy && has_result, idx, T); has_result = false; }
+            if (pool_next == pool_end && !exhausted) {
+                uint32_t b = 0;
+                if (lane == 0) b = atomicAdd(cursor, HAR_FETCH_BATCH);
+                b = (uint32_t) __builtin_amdgcn_readfirstlane((int) b);
+                if (b >= n) exhausted = true;
+                else { pool_next = b; pool_end = min(b + HAR_FETCH_BATCH, n); }
+            }
+            const uint32_t avail = pool_end - pool_next;
+            if (avail) {
+                const uint32_t rank = wave_rank(idle);
+                if (!busy && rank < avail) {
+                    idx = pool_next + rank;
+                    if (take(idx, T)) busy = true;
+                    else if (RETIRE) { has_result = true; T.found = true; }     /* nothing to trace: retire next round */
+                }
+                pool_next += min(n_idle, avail);
+            } else if (n_idle == 64u) {
+                break;
+            }
+        }
+        if (busy) {
+            int st = 0;
+            if (T.template step<ANY, LdsStack<CAP>, NoProbe, 1>(A, stack, st)) {
+                busy = false;
+                if (RETIRE) has_result = true; else done(idx, T);
+            }
+            if (st) atomicMax(status, st);
+        }
+    }
+}
+
 /* ----------------------------------------------------------- trace_closest */
 template <int CAP>
-__global__ __launch_bounds__(kBlock) void k_trace_closest(Accel A, const uint32_t *count, uint32_t shard_cap, const float4 *a0, const float4 *a1,
-                                                          float4 *h0, uint2 *h1, int *status) {
+__global__ __launch_bounds__(kBlock) void k_trace_closest(Accel A, const uint32_t *count, uint32_t *cursor, uint32_t shard_cap, const float4 *a0,
+                                                          const float4 *a1, float4 *h0, uint2 *h1, int *status) {
     __shared__ uint2 lds[CAP * kBlock];
     LdsStack<CAP> stack{ lds + threadIdx.x };
-    const ShardLoop Q(count, shard_cap);
-    for (uint32_t tile = Q.first_tile(); tile * kBlock < Q.n; tile += Q.tile_step()) {
-        const uint32_t local = tile * kBlock + threadIdx.x;
-        if (local >= Q.n) continue;
-        const uint32_t i = Q.base + local;
-        float4 o = a0[i], d = a1[i];
-        Hit hit; int st = 0;
-        accel_trace<false>(A, Vec3(o.x, o.y, o.z), Vec3(d.x, d.y, d.z), o.w, hit, stack, st);
-        if (st) atomicMax(status, st);
-        h0[i] = make_float4(hit.t, hit.u, hit.v, __uint_as_float(hit.prim));
-        h1[i] = make_uint2(hit.shape, hit.inst);
-    }
+    const uint32_t shard = blockIdx.x & (HAR_SHARDS - 1), n = count[shard * HAR_COUNTER_STRIDE], base = shard * shard_cap;
+    if (n == 0) return;
+    trace_persistent<false, false, CAP>(A, cursor + shard * HAR_COUNTER_STRIDE, n, stack, status,
+        [&](uint32_t idx, Traversal<0> &T) {
+            float4 o = a0[base + idx], d = a1[base + idx];
+            T.begin(A, Vec3(o.x, o.y, o.z), Vec3(d.x, d.y, d.z), o.w);
+            return true;
+        },
+        [&](uint32_t idx, const Traversal<0> &T) {
+            h0[base + idx] = make_float4(T.hit.t, T.hit.u, T.hit.v, __uint_as_float(T.hit.prim));
+            h1[base + idx] = make_uint2(T.hit.shape, T.hit.inst);
+        },
+        [&](bool, uint32_t, const Traversal<0> &) { });
 }
 
 /* ------------------------------------------------------------------- shade */
@@ -227,49 +293,77 @@ __global__ __launch_bounds__(kBlock) void k_shade(DScene S, ShadeParams P, uint3
 
 /* ------------------------------------------------- resolve (shadow rays + NEE) */
 template <int MODE, int CAP>
-__global__ __launch_bounds__(kBlock) void k_resolve(DScene S, const uint32_t *item_count, uint32_t shard_cap, ItemArrays items, float4 *result,
+__global__ __launch_bounds__(kBlock) void k_resolve(DScene S, const uint32_t *item_count, uint32_t *cursor, uint32_t shard_cap, ItemArrays items, float4 *result,
                                                     const float4 *dL, float *grad_refl, float *const *grad_tex, int *status) {
     __shared__ uint2 lds[CAP * kBlock];
+    /* adjoint: per-block accumulators of the constant-albedo gradients.  Every path of the chip adds to the same
+     * few floats of grad_refl (one 64 B line): direct global atomics serialise at ~88 atomics/us per line, which
+     * made the adjoint 10x slower than the primal pass.  ds_add_f32 here, one global atomic per block and entry. */
+    __shared__ float gacc[MODE == MODE_PRB_ADJOINT ? 3 * HAR_LDS_GRAD_BSDFS : 1];
     LdsStack<CAP> stack{ lds + threadIdx.x };
-    const ShardLoop Q(item_count, shard_cap);
-    for (uint32_t tile = Q.first_tile(); tile * kBlock < Q.n; tile += Q.tile_step()) {
-        const uint32_t local = tile * kBlock + threadIdx.x;
-        const bool in_range = local < Q.n;
-        const uint32_t i = Q.base + (in_range ? local : 0u);
-        float4 s0 = items.s0[i], s1 = items.s1[i], s2 = items.s2[i];
-        const uint32_t lane = __float_as_uint(s1.w);
-        bool visible = false;
-        if (in_range && s0.w >= 0.f) {
-            Hit hit; int st = 0;
-            visible = !accel_trace<true>(S.accel, Vec3(s0.x, s0.y, s0.z), Vec3(s1.x, s1.y, s1.z), s0.w, hit, stack, st);
-            if (st) { atomicMax(status, st); visible = false; }
-        }
-        if (MODE == MODE_PATH || MODE == MODE_PRB_PRIMAL) {
-            if (visible) { float4 r = result[lane]; result[lane] = make_float4(r.x + s2.x, r.y + s2.y, r.z + s2.z, 0.f); }
-        } else {
-            /* L <- L - Lr_dir; g = dL * (dLr_dir/drho + [bsdf_val != 0] L / rho)  (prb.py:227,288-313) */
-            Vec3 g(0.f); float *dst = grad_refl; bool tex = false; TexTaps taps; float *tdst = nullptr;
-            if (in_range) {
-                float4 L = result[lane];
-                if (visible) { L = make_float4(L.x - s2.x, L.y - s2.y, L.z - s2.z, 0.f); result[lane] = L; }
-                float4 s3 = items.s3[i], s4 = items.s4[i], dl = dL[lane];
-                const uint32_t tag = __float_as_uint(s2.w), bsdf = tag & 0x7fffffffu;
-                g = visible ? Vec3(s3.x, s3.y, s3.z) : Vec3(0.f);
-                if (tag & 0x80000000u)
-                    g = g + Vec3(s4.x != 0.f ? L.x / s4.x : 0.f, s4.y != 0.f ? L.y / s4.y : 0.f, s4.z != 0.f ? L.z / s4.z : 0.f);
-                g = g * Vec3(dl.x, dl.y, dl.z);
-                const DBsdf B = S.bsdfs[bsdf];
-                dst = grad_refl + 3 * (size_t) bsdf;
-                if (B.texture >= 0) { tex = true; tex_taps(S.textures[B.texture], s3.w, s4.w, taps); tdst = grad_tex[B.texture]; }
-            }
-            const bool nz = in_range && (g.x != 0.f || g.y != 0.f || g.z != 0.f);
-            /* wave-uniform control flow: every lane takes part in the pre-reduction */
-            wave_aggregated_add3(dst, g, nz && !tex);
-            if (__ballot(nz && tex)) {
-                const float w[4] = { taps.w0x * taps.w0y, taps.w1x * taps.w0y, taps.w0x * taps.w1y, taps.w1x * taps.w1y };
-                for (int k = 0; k < 4; ++k)
-                    wave_aggregated_add3(nz && tex ? tdst + 3 * (size_t) taps.idx[k] : grad_refl, nz && tex ? g * w[k] : Vec3(0.f), nz && tex);
-            }
+    const uint32_t shard = blockIdx.x & (HAR_SHARDS - 1), n = item_count[shard * HAR_COUNTER_STRIDE], base = shard * shard_cap;
+    if (n == 0) return;
+    if (MODE == MODE_PRB_ADJOINT) {
+        for (uint32_t k = threadIdx.x; k < 3 * HAR_LDS_GRAD_BSDFS; k += kBlock) gacc[k] = 0.f;
+        __syncthreads();
+    }
+    auto take = [&](uint32_t idx, Traversal<0> &T) {
+        float4 s0 = items.s0[base + idx];
+        if (!(s0.w >= 0.f)) return false;
+        float4 s1 = items.s1[base + idx];
+        T.begin(S.accel, Vec3(s0.x, s0.y, s0.z), Vec3(s1.x, s1.y, s1.z), s0.w);
+        return true;
+    };
+    if (MODE == MODE_PATH || MODE == MODE_PRB_PRIMAL) {
+        /* forward: an unoccluded item adds its contribution to its lane's radiance (one item per lane and bounce: no race) */
+        trace_persistent<true, false, CAP>(S.accel, cursor + shard * HAR_COUNTER_STRIDE, n, stack, status, take,
+            [&](uint32_t idx, const Traversal<0> &T) {
+                if (!T.found) {
+                    const uint32_t i = base + idx, lane = __float_as_uint(items.s1[i].w);
+                    float4 s2 = items.s2[i], r = result[lane];
+                    result[lane] = make_float4(r.x + s2.x, r.y + s2.y, r.z + s2.z, 0.f);
+                }
+            },
+            [&](bool, uint32_t, const Traversal<0> &) { });
+    } else {
+        /* adjoint: L <- L - Lr_dir; g = dL * (dLr_dir/drho + [bsdf_val != 0] L / rho)  (prb.py:227,288-313);
+         * gradients are committed at refill time by ALL lanes so that the wave pre-reduction can run */
+        trace_persistent<true, true, CAP>(S.accel, cursor + shard * HAR_COUNTER_STRIDE, n, stack, status, take,
+            [&](uint32_t, const Traversal<0> &) { },
+            [&](bool pred, uint32_t idx, const Traversal<0> &T) {
+                const uint32_t i = base + (pred ? idx : 0u);
+                const bool visible = pred && !T.found;
+                Vec3 g(0.f); float *dst = grad_refl; bool tex = false; TexTaps taps; float *tdst = nullptr;
+                if (pred) {
+                    const uint32_t lane = __float_as_uint(items.s1[i].w);
+                    float4 s2 = items.s2[i], L = result[lane];
+                    if (visible) { L = make_float4(L.x - s2.x, L.y - s2.y, L.z - s2.z, 0.f); result[lane] = L; }
+                    float4 s3 = items.s3[i], s4 = items.s4[i], dl = dL[lane];
+                    const uint32_t tag = __float_as_uint(s2.w), bsdf = tag & 0x7fffffffu;
+                    g = visible ? Vec3(s3.x, s3.y, s3.z) : Vec3(0.f);
+                    if (tag & 0x80000000u)
+                        g = g + Vec3(s4.x != 0.f ? L.x / s4.x : 0.f, s4.y != 0.f ? L.y / s4.y : 0.f, s4.z != 0.f ? L.z / s4.z : 0.f);
+                    g = g * Vec3(dl.x, dl.y, dl.z);
+                    const DBsdf B = S.bsdfs[bsdf];
+                    dst = grad_refl + 3 * (size_t) bsdf;
+                    if (B.texture >= 0) { tex = true; tex_taps(S.textures[B.texture], s3.w, s4.w, taps); tdst = grad_tex[B.texture]; }
+                }
+                const bool nz = pred && (g.x != 0.f || g.y != 0.f || g.z != 0.f);
+                if (nz && !tex) {
+                    const uint32_t bsdf = (uint32_t) (dst - grad_refl) / 3u;
+                    if (bsdf < HAR_LDS_GRAD_BSDFS) { atomicAdd(&gacc[3 * bsdf], g.x); atomicAdd(&gacc[3 * bsdf + 1], g.y); atomicAdd(&gacc[3 * bsdf + 2], g.z); }
+                    else { atomicAdd(dst, g.x); atomicAdd(dst + 1, g.y); atomicAdd(dst + 2, g.z); }
+                }
+                if (__ballot(nz && tex)) {
+                    const float w[4] = { taps.w0x * taps.w0y, taps.w1x * taps.w0y, taps.w0x * taps.w1y, taps.w1x * taps.w1y };
+                    for (int k = 0; k < 4; ++k)
+                        wave_aggregated_add3(nz && tex ? tdst + 3 * (size_t) taps.idx[k] : grad_refl, nz && tex ? g * w[k] : Vec3(0.f), nz && tex);
+                }
+            });
+        __syncthreads();
+        for (uint32_t k = threadIdx.x; k < 3 * min(S.n_bsdfs, (uint32_t) HAR_LDS_GRAD_BSDFS); k += kBlock) {
+            const float v = gacc[k];
+            if (v != 0.f) atomicAdd(grad_refl + k, v);
         }
     }
 }
@@ -384,7 +478,11 @@ __global__ __launch_bounds__(kBlock) void k_api_intersect(DScene S, uint32_t n, 
     Vec3 O(o[i], o[n + i], o[2 * (size_t) n + i]), D(d[i], d[n + i], d[2 * (size_t) n + i]);
     Hit hit; int st = 0;
     if (NAIVE) accel_trace_naive<false>(S.accel, S.blas_tri_ranges, O, D, maxt[i], hit);
-    else accel_trace<false>(S.accel, O, D, maxt[i], hit, stack, st);
+    else {      /* the production traversal code (Traversal<0>::step), one ray per lane */
+        Traversal<0> T; T.begin(S.accel, O, D, maxt[i]);
+        while (!T.template step<false, LdsStack<HAR_LDS_STACK_DEPTH>, NoProbe, 1>(S.accel, stack, st)) { }
+        hit = T.hit;
+    }
     if (st) atomicMax(status, st);
     t[i] = hit.t; u[i] = hit.u; v[i] = hit.v; prim[i] = hit.prim; shape[i] = hit.shape; inst[i] = hit.inst;
 }
@@ -397,7 +495,11 @@ __global__ __launch_bounds__(kBlock) void k_api_ray_test(DScene S, uint32_t n, c
     Vec3 O(o[i], o[n + i], o[2 * (size_t) n + i]), D(d[i], d[n + i], d[2 * (size_t) n + i]);
     Hit hit; int st = 0; bool r;
     if (NAIVE) r = accel_trace_naive<true>(S.accel, S.blas_tri_ranges, O, D, maxt[i], hit);
-    else r = accel_trace<true>(S.accel, O, D, maxt[i], hit, stack, st);
+    else {
+        Traversal<0> T; T.begin(S.accel, O, D, maxt[i]);
+        while (!T.template step<true, LdsStack<HAR_LDS_STACK_DEPTH>, NoProbe, 1>(S.accel, stack, st)) { }
+        r = T.found;
+    }
     if (st) atomicMax(status, st);
     out[i] = r ? 1 : 0;
 }
@@ -474,10 +576,10 @@ void launch_raygen(int mode, hipStream_t s, const DSensor &C, uint32_t seed, uin
     if (mode == MODE_PRB_ADJOINT) hipLaunchKernelGGL(k_raygen<MODE_PRB_ADJOINT>, g, b, 0, s, C, seed, spp, log_spp, lane_base, n, shard_cap, out, result, count, adj, dL);
     else hipLaunchKernelGGL(k_raygen<MODE_PATH>, g, b, 0, s, C, seed, spp, log_spp, lane_base, n, shard_cap, out, result, count, adj, dL);
 }
-void launch_trace_closest(hipStream_t s, uint32_t grid, int small_stack, const Accel &A, const uint32_t *count, uint32_t shard_cap, const WaveState &in,
-                          float4 *h0, uint2 *h1, int *status) {
-    if (small_stack) hipLaunchKernelGGL(k_trace_closest<HAR_LDS_STACK_SMALL>, dim3(grid), dim3(kBlock), 0, s, A, count, shard_cap, in.a0, in.a1, h0, h1, status);
-    else hipLaunchKernelGGL(k_trace_closest<HAR_LDS_STACK_DEPTH>, dim3(grid), dim3(kBlock), 0, s, A, count, shard_cap, in.a0, in.a1, h0, h1, status);
+void launch_trace_closest(hipStream_t s, uint32_t grid, int small_stack, const Accel &A, const uint32_t *count, uint32_t *cursor, uint32_t shard_cap,
+                          const WaveState &in, float4 *h0, uint2 *h1, int *status) {
+    if (small_stack) hipLaunchKernelGGL(k_trace_closest<HAR_LDS_STACK_SMALL>, dim3(grid), dim3(kBlock), 0, s, A, count, cursor, shard_cap, in.a0, in.a1, h0, h1, status);
+    else hipLaunchKernelGGL(k_trace_closest<HAR_LDS_STACK_DEPTH>, dim3(grid), dim3(kBlock), 0, s, A, count, cursor, shard_cap, in.a0, in.a1, h0, h1, status);
 }
 void launch_shade(int mode, hipStream_t s, uint32_t grid, const DScene &S, const ShadeParams &P, uint32_t lane_base, uint32_t shard_cap, const uint32_t *count_in,
                   const WaveState &in, const float4 *h0, const uint2 *h1, const WaveState &out, uint32_t *count_out, const ItemArrays &items,
@@ -487,15 +589,15 @@ void launch_shade(int mode, hipStream_t s, uint32_t grid, const DScene &S, const
     else if (mode == MODE_PRB_PRIMAL) hipLaunchKernelGGL(k_shade<MODE_PRB_PRIMAL>, g, b, 0, s, S, P, lane_base, shard_cap, count_in, in, h0, h1, out, count_out, items, item_count, result);
     else hipLaunchKernelGGL(k_shade<MODE_PRB_ADJOINT>, g, b, 0, s, S, P, lane_base, shard_cap, count_in, in, h0, h1, out, count_out, items, item_count, result);
 }
-void launch_resolve(int mode, hipStream_t s, uint32_t grid, int small_stack, const DScene &S, const uint32_t *item_count, uint32_t shard_cap, const ItemArrays &items,
+void launch_resolve(int mode, hipStream_t s, uint32_t grid, int small_stack, const DScene &S, const uint32_t *item_count, uint32_t *cursor, uint32_t shard_cap, const ItemArrays &items,
                     float4 *result, const float4 *dL, float *grad_refl, float *const *grad_tex, int *status) {
     dim3 g(grid), b(kBlock);
     if (mode == MODE_PRB_ADJOINT) {
-        if (small_stack) hipLaunchKernelGGL((k_resolve<MODE_PRB_ADJOINT, HAR_LDS_STACK_SMALL>), g, b, 0, s, S, item_count, shard_cap, items, result, dL, grad_refl, grad_tex, status);
-        else hipLaunchKernelGGL((k_resolve<MODE_PRB_ADJOINT, HAR_LDS_STACK_DEPTH>), g, b, 0, s, S, item_count, shard_cap, items, result, dL, grad_refl, grad_tex, status);
+        if (small_stack) hipLaunchKernelGGL((k_resolve<MODE_PRB_ADJOINT, HAR_LDS_STACK_SMALL>), g, b, 0, s, S, item_count, cursor, shard_cap, items, result, dL, grad_refl, grad_tex, status);
+        else hipLaunchKernelGGL((k_resolve<MODE_PRB_ADJOINT, HAR_LDS_STACK_DEPTH>), g, b, 0, s, S, item_count, cursor, shard_cap, items, result, dL, grad_refl, grad_tex, status);
     } else {
-        if (small_stack) hipLaunchKernelGGL((k_resolve<MODE_PATH, HAR_LDS_STACK_SMALL>), g, b, 0, s, S, item_count, shard_cap, items, result, dL, grad_refl, grad_tex, status);
-        else hipLaunchKernelGGL((k_resolve<MODE_PATH, HAR_LDS_STACK_DEPTH>), g, b, 0, s, S, item_count, shard_cap, items, result, dL, grad_refl, grad_tex, status);
+        if (small_stack) hipLaunchKernelGGL((k_resolve<MODE_PATH, HAR_LDS_STACK_SMALL>), g, b, 0, s, S, item_count, cursor, shard_cap, items, result, dL, grad_refl, grad_tex, status);
+        else hipLaunchKernelGGL((k_resolve<MODE_PATH, HAR_LDS_STACK_DEPTH>), g, b, 0, s, S, item_count, cursor, shard_cap, items, result, dL, grad_refl, grad_tex, status);
     }
 }
 void launch_splat(hipStream_t s, const DSensor &C, uint32_t seed, uint32_t spp, uint32_t log_spp, uint32_t lane_base, uint32_t n,

@@ -10,6 +10,8 @@
 #include "../../mitsuba3_amd/csrc/har_path.h"
 #include "../../mitsuba3_amd/csrc/har_scene_host.h"
 #include <cstdio>
+#include <cstring>
+#include <algorithm>
 #include <string>
 #include <vector>
 
@@ -105,6 +107,137 @@ int hh_render(void *h, const HarSensor *sensor, int mode, uint32_t seed, uint32_
             uint32_t x = F.x0 + xs, y = F.y0 + ys;
             if (x < C.crop_w && y < C.crop_h) { float w = F.wx[xs] * F.wy[ys]; float *p = film + 4 * ((size_t) y * C.crop_w + x); for (int k = 0; k < 4; ++k) p[k] += val[k] * w; }
         }
+    }
+    return status;
+}
+
+/* --- traversal statistics (tools/trace_stats.py): per-ray event counts and a lock-step SIMT model of the
+ * static traversal kernel.  Rays of bounce b are the rays of all lanes alive at bounce b, in lane order
+ * (the order the compacting wavefront keeps), grouped into waves of 64. */
+struct EvProbe {
+    std::vector<uint32_t> *ev;     /* one entry per outer iteration: bit0 node, bit1 inst, bits 8.. triangle tests */
+    void iter() { ev->push_back(0u); }
+    void node() { ev->back() |= 1u; }
+    void inst() { ev->back() |= 2u; }
+    void tri()  { ev->back() += 256u; }
+};
+
+/* out[b*32 + ..]: closest rays in 0..15, shadow rays in 16..31:
+ * 0 rays, 1 iters, 2 nodes, 3 tris, 4 insts, 5 wave_steps, 6 wave_node_blocks, 7 wave_tri_blocks, 8 wave_inst_blocks, 9 waves, 10 mismatches
+ * policy: -1 reference loop (all triangles of a node per iteration), 0 / 1 = Traversal<POLICY>;
+ * refill: 0 = static waves of 64 consecutive rays, R > 0 = persistent wave that refills when >= R lanes are idle */
+} // extern "C"
+template <bool AnyHit, typename T, int ORDER>
+static void run_traversal_o(const Accel &A, Vec3 o, Vec3 d, float maxt, Hit &hit, bool &found, std::vector<uint32_t> &ev, int &status) {
+    T tr; HostStack stack; EvProbe pr{ &ev };
+    tr.begin(A, o, d, maxt);
+    while (!tr.template step<AnyHit, HostStack, EvProbe, ORDER>(A, stack, status, pr)) { }
+    hit = tr.hit; found = tr.found;
+}
+static int g_order = 2;
+template <bool AnyHit, typename T>
+static void run_traversal(const Accel &A, Vec3 o, Vec3 d, float maxt, Hit &hit, bool &found, std::vector<uint32_t> &ev, int &status) {
+    if (g_order == 0) run_traversal_o<AnyHit, T, 0>(A, o, d, maxt, hit, found, ev, status);
+    else if (g_order == 1) run_traversal_o<AnyHit, T, 1>(A, o, d, maxt, hit, found, ev, status);
+    else run_traversal_o<AnyHit, T, 2>(A, o, d, maxt, hit, found, ev, status);
+}
+extern "C" {
+
+void hh_set_order(int o) { g_order = o; }
+int hh_trace_stats(void *h, const HarSensor *sensor, uint32_t seed, uint32_t spp, int32_t max_depth, int32_t rr_depth,
+                   uint64_t lane_begin, uint64_t lane_end, uint32_t max_bounces, int policy, int refill, double *out) {
+    HScene *H = (HScene *) h; const DScene &S = H->ds;
+    DSensor C; std::string e; if (!lower_sensor(*sensor, C, e)) return -1;
+    uint32_t log_spp = 0xffffffffu; for (uint32_t k = 0; k < 32; ++k) if ((1u << k) == spp) log_spp = k;
+    ShadeParams P{ seed, (uint32_t) max_depth, (uint32_t) rr_depth };
+    std::vector<PathState> cur, next; LaneSample ls;
+    for (uint64_t lane = lane_begin; lane < lane_end; ++lane) cur.push_back(raygen_lane(C, seed, spp, log_spp, (uint32_t) lane, ls));
+    int status = 0;
+    for (uint32_t b = 0; b < max_bounces && !cur.empty(); ++b) {
+        double *o = out + 32 * b;
+        struct Sh { Vec3 o, d; float maxt; };
+        std::vector<Sh> shadow; next.clear();
+        auto account = [&](std::vector<std::vector<uint32_t>> &evs, double *q) {
+            size_t n = evs.size();
+            if (refill <= 0) {
+                for (size_t w = 0; w < n; w += 64) {
+                    size_t steps = 0;
+                    for (size_t i = w; i < std::min(n, w + 64); ++i) steps = std::max(steps, evs[i].size());
+                    q[5] += (double) steps; q[9] += 1;
+                    for (size_t k = 0; k < steps; ++k) {
+                        uint32_t anyn = 0, anyi = 0, mt = 0;
+                        for (size_t i = w; i < std::min(n, w + 64); ++i) if (k < evs[i].size()) { uint32_t v = evs[i][k]; anyn |= v & 1u; anyi |= (v >> 1) & 1u; mt = std::max(mt, v >> 8); }
+                        q[6] += anyn; q[7] += mt; q[8] += anyi;
+                    }
+                }
+            } else {
+                /* persistent waves: the bounce's rays are dealt to W concurrent waves in batches of 128 (like the kernel) */
+                const size_t W = std::max<size_t>(1, std::min<size_t>(n / 1024, 4096));
+                std::vector<size_t> cursor_of(W);
+                size_t next_batch = 0;
+                for (size_t w = 0; w < W; ++w) {
+                    size_t slot_ray[64], slot_pos[64]; bool busy[64];
+                    for (int l = 0; l < 64; ++l) busy[l] = false;
+                    size_t pool = 0, pool_end = 0; bool exhausted = false;
+                    q[9] += 1;
+                    for (;;) {
+                        int idle = 0; for (int l = 0; l < 64; ++l) idle += !busy[l];
+                        if (idle >= refill) {
+                            for (int l = 0; l < 64; ++l) {
+                                if (busy[l]) continue;
+                                if (pool == pool_end && !exhausted) {
+                                    /* round-robin batches across the waves: wave w takes batches w, w+W, ... */
+                                    size_t bidx = w + W * cursor_of[w]++;
+                                    if (bidx * 128 >= n) exhausted = true; else { pool = bidx * 128; pool_end = std::min(n, pool + 128); }
+                                }
+                                if (pool < pool_end) { busy[l] = true; slot_ray[l] = pool++; slot_pos[l] = 0; }
+                            }
+                            idle = 0; for (int l = 0; l < 64; ++l) idle += !busy[l];
+                            if (idle == 64) break;
+                        }
+                        uint32_t anyn = 0, anyi = 0, mt = 0;
+                        for (int l = 0; l < 64; ++l) if (busy[l]) {
+                            uint32_t v = evs[slot_ray[l]][slot_pos[l]++]; anyn |= v & 1u; anyi |= (v >> 1) & 1u; mt = std::max(mt, v >> 8);
+                            if (slot_pos[l] == evs[slot_ray[l]].size()) busy[l] = false;
+                        }
+                        q[5] += 1; q[6] += anyn; q[7] += mt; q[8] += anyi;
+                    }
+                }
+                (void) next_batch;
+            }
+            for (auto &v : evs) { q[0] += 1; q[1] += (double) v.size(); for (uint32_t x : v) { q[2] += x & 1u; q[4] += (x >> 1) & 1u; q[3] += x >> 8; } }
+        };
+        std::vector<std::vector<uint32_t>> evs(cur.size());
+        std::vector<Hit> hits(cur.size());
+        for (size_t i = 0; i < cur.size(); ++i) {
+            HostStack stack; EvProbe pr{ &evs[i] };
+            accel_trace<false>(S.accel, cur[i].o, cur[i].d, cur[i].maxt, hits[i], stack, status, pr);
+            if (policy >= 0) {
+                Hit h2; bool f2; evs[i].clear();
+                if (policy == 0) run_traversal<false, Traversal<0>>(S.accel, cur[i].o, cur[i].d, cur[i].maxt, h2, f2, evs[i], status);
+                else             run_traversal<false, Traversal<1>>(S.accel, cur[i].o, cur[i].d, cur[i].maxt, h2, f2, evs[i], status);
+                if (memcmp(&h2, &hits[i], sizeof(Hit)) != 0 || f2 != (hits[i].t != HAR_INF)) o[10] += 1;
+            }
+        }
+        account(evs, o);
+        for (size_t i = 0; i < cur.size(); ++i) {
+            ShadeResult R; shade_lane<MODE_PATH>(S, P, cur[i], hits[i], R);
+            if (R.item && R.item_ray) shadow.push_back(Sh{ R.sh_o, R.sh_d, R.sh_maxt });
+            if (R.alive) next.push_back(R.next);
+        }
+        std::vector<std::vector<uint32_t>> sev(shadow.size());
+        for (size_t i = 0; i < shadow.size(); ++i) {
+            HostStack stack; EvProbe pr{ &sev[i] }; Hit hh;
+            bool f1 = accel_trace<true>(S.accel, shadow[i].o, shadow[i].d, shadow[i].maxt, hh, stack, status, pr);
+            if (policy >= 0) {
+                Hit h2; bool f2; sev[i].clear();
+                if (policy == 0) run_traversal<true, Traversal<0>>(S.accel, shadow[i].o, shadow[i].d, shadow[i].maxt, h2, f2, sev[i], status);
+                else             run_traversal<true, Traversal<1>>(S.accel, shadow[i].o, shadow[i].d, shadow[i].maxt, h2, f2, sev[i], status);
+                if (f1 != f2) o[26] += 1;
+            }
+        }
+        account(sev, o + 16);
+        cur.swap(next);
     }
     return status;
 }

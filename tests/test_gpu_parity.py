@@ -216,7 +216,7 @@ def test_golden_ray_queries_bitexact(mi):
     scene = mi.load_dict(mi.cornell_box())
     n = fx["rays_o"].shape[1]
     ray = mi.Ray3f(fx["rays_o"], fx["rays_d"], np.full(n, 3.402823466e+38, np.float32))
-    for pi in (scene.ray_intersect_preliminary(ray), scene.ray_intersect_naive(ray)):
+    for pi in (scene.ray_intersect_preliminary(ray), scene._intersect(ray, True)):
         assert np.array_equal(pi.t.cpu().numpy(), fx["cornell_hit_t"])
         hit = np.isfinite(fx["cornell_hit_t"])
         assert np.array_equal(pi.prim_uv[0].cpu().numpy()[hit], fx["cornell_hit_u"][hit])

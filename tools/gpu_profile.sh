@@ -1,0 +1,25 @@
+#!/bin/bash
+# Runs on the GPU box (via gpurun): kernel trace + PMC passes of `python bench.py $BENCH_ARGS`,
+# summaries written to gpurun_out/prof/<tag>_*.txt (copy the ones to keep into profiles/).
+# usage: tools/gpu_profile.sh <tag> [kt] [sq] [mem] [tcc] -- <bench args>
+set -u
+TAG=$1; shift
+PASSES=()
+while [ $# -gt 0 ] && [ "$1" != "--" ]; do PASSES+=("$1"); shift; done
+[ $# -gt 0 ] && shift
+ARGS="$* --no-cpu-baseline --no-prb"
+cd "${GRAFT_REPO_ROOT:-.}"
+export TMPDIR=/tmp
+OUT=gpurun_out/prof; mkdir -p $OUT
+for P in "${PASSES[@]}"; do
+  D=/tmp/prof_${TAG}_$P; rm -rf $D
+  case $P in
+    kt)  rocprofv3 --kernel-trace --stats -d $D -o r -- python bench.py --steps 2 --warmup 1 $ARGS > $OUT/${TAG}_kt_bench.log 2>&1 ;;
+    sq)  rocprofv3 --pmc SQ_WAVES SQ_INSTS_VALU SQ_ACTIVE_INST_VALU SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_INSTS_VMEM_RD SQ_INSTS_LDS SQ_WAIT_INST_ANY -d $D -o r -- python bench.py --steps 1 --warmup 0 $ARGS > $OUT/${TAG}_sq_bench.log 2>&1 ;;
+    mem) rocprofv3 --pmc FETCH_SIZE -d ${D}f -o r -- python bench.py --steps 1 --warmup 0 $ARGS > /dev/null 2>&1
+         rocprofv3 --pmc WRITE_SIZE -d $D -o r -- python bench.py --steps 1 --warmup 0 $ARGS > /dev/null 2>&1
+         python tools/rocpd_summary.py $(find ${D}f -name '*.db') > $OUT/${TAG}_fetch.txt 2>&1 ;;
+    tcc) rocprofv3 --pmc TCC_HIT_sum TCC_MISS_sum -d $D -o r -- python bench.py --steps 1 --warmup 0 $ARGS > /dev/null 2>&1 ;;
+  esac
+  python tools/rocpd_summary.py $(find $D -name '*.db') > $OUT/${TAG}_$P.txt 2>&1
+done
