@@ -125,8 +125,22 @@ def main():
     achieved = alg_bytes / 1e9 / (kern_ms[dominant] / 1e3) if kern_ms[dominant] > 0 else 0.0
     kbar = stats["vertices"] / max(stats["paths"], 1)
     b_path = 152 + kbar * 505 + 16
+    # HBM traffic of the dominant kernel from the committed PMC passes (tools/gpu_profile.sh ... mem): bytes per launch
+    # = (FETCH_SIZE x 2 [gfx950 correction, MI355X_MICROARCH.md "HBM"] + WRITE_SIZE) KiB x 1024 / launches; null if the
+    # profile of this exact workload has not been collected
+    traffic = None
+    tpath = os.path.join(ROOT, "profiles", "r01_traffic_%s.json" % args.workload)
+    if os.path.exists(tpath) and args.res == 512 and args.spp == 256:
+        try:
+            with open(tpath) as f:
+                tj = json.load(f)
+            krec = next(v for k, v in tj.items() if ("k_" + dominant) in k and "counters" in v)
+            fetch = krec["counters"]["FETCH_SIZE"]; write = krec["counters"]["WRITE_SIZE"]
+            traffic = round((2.0 * fetch["sum"] / fetch["dispatches"] + write["sum"] / write["dispatches"]) * 1024.0)
+        except Exception:
+            traffic = None
     roofline = {"bound": "hbm", "kernel": dominant, "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": None,
+                "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": traffic, "algorithmic_bytes_per_launch": round(alg_bytes / launches),
                 "avg_launch_ms": round(kern_ms[dominant] / launches, 4), "launches": launches,
                 "kernel_ms": {k: round(v, 3) for k, v in kern_ms.items()},
                 "whole_path_model": {"K_bar": round(kbar, 3), "B_path": round(b_path, 1),
@@ -168,7 +182,7 @@ def main():
 
     if rank == 0:
         out = {
-            "metric": "Mpaths/s forward path, 1M-tri scene 512^2x256spp" if args.workload != "cornell" else "Mpaths/s forward path, Cornell box",
+            "metric": "Mpaths/s forward (PRB-adjoint in `prb_adjoint`), 1M-tri scene 512^2x256spp" if args.workload != "cornell" else "Mpaths/s forward path, Cornell box",
             "value": round(value, 2), "unit": "Mpaths/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": round(ms_per_step, 2), "higher_is_better": True, "scaling": "strong", "vs_baseline": None,
             "dtype": "f32", "data": "synthetic",

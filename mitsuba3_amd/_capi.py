@@ -8,7 +8,7 @@ import ctypes as C
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libhip_ad_rgb.so")
+LIB_PATH = os.environ.get("HAR_LIB_PATH", os.path.join(_HERE, "libhip_ad_rgb.so"))   # override: A/B builds in tools/
 
 f32p = C.POINTER(C.c_float)
 u32p = C.POINTER(C.c_uint32)

@@ -101,17 +101,27 @@ HAR_HD uint32_t popc32(uint32_t x) {
 }
 
 struct RaySetup { Vec3 o, d, idir; uint32_t octinv; };
+/* reciprocal for the (conservative) box tests only: v_rcp_f32 (1 ulp) on the device -- the slab test has a
+ * 5e-7 relative slack and leaf boxes are padded by 2e-5, the exact triangle test never uses it */
+HAR_HD float box_rcp(float x) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    return __builtin_amdgcn_rcpf(x);
+#else
+    return 1.f / x;
+#endif
+}
 HAR_HD RaySetup ray_setup(Vec3 o, Vec3 d) {
     RaySetup r; r.o = o; r.d = d;
     const float eps = 1e-30f;
-    r.idir = Vec3(1.f / (fabsf(d.x) > eps ? d.x : mulsign_(eps, d.x)),
-                  1.f / (fabsf(d.y) > eps ? d.y : mulsign_(eps, d.y)),
-                  1.f / (fabsf(d.z) > eps ? d.z : mulsign_(eps, d.z)));
+    r.idir = Vec3(box_rcp(fabsf(d.x) > eps ? d.x : mulsign_(eps, d.x)),
+                  box_rcp(fabsf(d.y) > eps ? d.y : mulsign_(eps, d.y)),
+                  box_rcp(fabsf(d.z) > eps ? d.z : mulsign_(eps, d.z)));
     r.octinv = (d.x < 0.f ? 0u : 4u) | (d.y < 0.f ? 0u : 2u) | (d.z < 0.f ? 0u : 1u);
     return r;
 }
 
 #define HAR_STACK_OVERFLOW 0x7fffffff
+#define HAR_MAX_PARKED 3          /* Traversal<2>: stack entries beyond the depth-first bound (HostScene::stack_need) */
 
 /* Probe: optional per-ray event counters (tools/ and the host harness); the default compiles to nothing */
 struct NoProbe { HAR_HD void node() {} HAR_HD void tri() {} HAR_HD void inst() {} HAR_HD void iter() {} };
@@ -142,25 +152,29 @@ HAR_HD void node_visit(const Accel &A, const RaySetup &R, float tmax, uint32_t i
     const uint32_t nxw[2] = { nx ? w[14] : w[8],  nx ? w[15] : w[9]  }, fxw[2] = { nx ? w[8]  : w[14], nx ? w[9]  : w[15] };
     const uint32_t nyw[2] = { ny ? w[16] : w[10], ny ? w[17] : w[11] }, fyw[2] = { ny ? w[10] : w[16], ny ? w[11] : w[17] };
     const uint32_t nzw[2] = { nz ? w[18] : w[12], nz ? w[19] : w[13] }, fzw[2] = { nz ? w[12] : w[18], nz ? w[13] : w[19] };
+    /* meta byte = bits(3) | index(5); inner children have index 24 + slot, which is remapped by the ray octant.
+     * Four children per dword are decoded at once: an empty child has bits == 0 and contributes nothing. */
+    const uint32_t oct4 = R.octinv * 0x01010101u;
+    uint32_t idx4[2], bits4[2];
+    for (int k = 0; k < 2; ++k) {
+        const uint32_t m = w[6 + k];
+        const uint32_t inner = ((m & (m << 1)) >> 4) & 0x01010101u;        /* bits 3 and 4 both set */
+        idx4[k] = (m ^ (oct4 & (inner * 0xffu))) & 0x1f1f1f1fu;
+        bits4[k] = (m >> 5) & 0x07070707u;
+    }
     uint32_t hitmask = 0;
 #if defined(__HIP_DEVICE_COMPILE__)
 #pragma unroll
 #endif
     for (int i = 0; i < 8; ++i) {
         const int wi = i >> 2, sh = (i & 3) * 8;
-        uint32_t meta = (w[6 + wi] >> sh) & 0xffu;
         float t0x = fma_((float) ((nxw[wi] >> sh) & 0xffu), ax, bx), t1x = fma_((float) ((fxw[wi] >> sh) & 0xffu), ax, bx);
         float t0y = fma_((float) ((nyw[wi] >> sh) & 0xffu), ay, by), t1y = fma_((float) ((fyw[wi] >> sh) & 0xffu), ay, by);
         float t0z = fma_((float) ((nzw[wi] >> sh) & 0xffu), az, bz), t1z = fma_((float) ((fzw[wi] >> sh) & 0xffu), az, bz);
         float tn = fmaxf(fmaxf(t0x, t0y), fmaxf(t0z, 0.f));
         float tf = fminf(fminf(t1x, t1y), fminf(t1z, tmax));
-        bool isect = (meta != 0u) && (tn <= tf * 1.0000005f);
-        if (isect) {
-            bool inner = (meta & 0x18u) == 0x18u;
-            uint32_t bits = meta >> 5;
-            uint32_t index = (meta ^ (inner ? R.octinv : 0u)) & 0x1fu;
-            hitmask |= bits << index;
-        }
+        const bool isect = tn <= tf * 1.0000005f;
+        hitmask |= (isect ? (bits4[wi] >> sh) & 0xffu : 0u) << ((idx4[wi] >> sh) & 0xffu);
     }
     ng_x = w[4]; tg_x = w[5];
     ng_y = (hitmask & 0xff000000u) | (w[3] >> 24);
@@ -288,6 +302,7 @@ struct Traversal {
     Hit hit;
     uint32_t ng_x, ng_y, tg_x, tg_y, cur_inst;
     int sp, inst_sp;
+    uint32_t parked;            /* POLICY 2: triangle groups currently parked on the stack (<= HAR_MAX_PARKED) */
     bool in_tlas, found;
 
     HAR_HD void begin(const Accel &A, Vec3 o, Vec3 d, float maxt) {
@@ -295,13 +310,13 @@ struct Traversal {
         hit.t = HAR_INF; hit.u = 0.f; hit.v = 0.f; hit.prim = 0; hit.shape = 0; hit.inst = 0xffffffffu;
         R = ray_setup(o, d);
         in_tlas = A.has_tlas != 0; cur_inst = 0xffffffffu; found = false;
-        ng_x = A.root; ng_y = 0x80000000u; tg_x = 0; tg_y = 0; sp = 0; inst_sp = -1;
+        ng_x = A.root; ng_y = 0x80000000u; tg_x = 0; tg_y = 0; sp = 0; inst_sp = -1; parked = 0;
     }
 
     /* ---- node phase: at most one node visit */
     template <typename Stack, typename Probe>
     HAR_HD bool phase_node(const Accel &A, Stack &stack, int &status, Probe &probe) {
-        if (ng_y > 0x00ffffffu && (POLICY == 1 || tg_y == 0u)) {
+        if (ng_y > 0x00ffffffu && (POLICY == 1 || tg_y == 0u || (POLICY == 2 && parked < HAR_MAX_PARKED))) {
             probe.node();
             uint32_t child = ng_next_child(ng_x, ng_y, R.octinv);
             if (ng_y > 0x00ffffffu) {
@@ -310,9 +325,10 @@ struct Traversal {
             }
             uint32_t cx, cy;
             node_visit(A, R, tmax, child, ng_x, ng_y, cx, cy);
-            if (POLICY == 1 && tg_y != 0u && cy != 0u) {          /* park the NEW group, finish the nearer old one first */
+            if (POLICY == 2 && ng_y <= 0x00ffffffu) ng_y = 0u;        /* no inner child hit: drop the leftover imask */
+            if (POLICY >= 1 && tg_y != 0u && cy != 0u) {          /* park the NEW group, finish the nearer old one first */
                 if (sp >= Stack::Capacity) return overflow(status);
-                stack.push(sp++, cx, cy);
+                stack.push(sp++, cx, cy); ++parked;
             } else if (cy != 0u) { tg_x = cx; tg_y = cy; }
         }
         return false;
@@ -320,12 +336,13 @@ struct Traversal {
     /* ---- leaf phase: one triangle test (BLAS) or one instance entry (TLAS) */
     template <bool AnyHit, typename Stack, typename Probe>
     HAR_HD bool phase_leaf(const Accel &A, Stack &stack, int &status, Probe &probe) {
+        if (POLICY == 2 && tg_y == 0u && ng_y <= 0x00ffffffu && ng_y != 0u) { tg_x = ng_x; tg_y = ng_y; ng_x = 0; ng_y = 0; }
         if (tg_y != 0u) {
             uint32_t bit = 31u - clz32(tg_y);
             tg_y &= ~(1u << bit);
             uint32_t idx = tg_x + bit;
             if (in_tlas) {
-                if (ng_y > 0x00ffffffu) {
+                if (POLICY == 2 ? ng_y != 0u : ng_y > 0x00ffffffu) {      /* POLICY 2: ng may hold a waiting instance list */
                     if (sp >= Stack::Capacity) return overflow(status);
                     stack.push(sp++, ng_x, ng_y);
                 }
@@ -348,6 +365,21 @@ struct Traversal {
     /* ---- pop phase: leave the instance / finish / take the next group from the stack */
     template <typename Stack>
     HAR_HD bool phase_pop(Stack &stack) {
+        if (POLICY == 2) {
+            /* pop as soon as no group is held in ng, even while triangles are pending (they are tested one per
+             * iteration in parallel with the node visits); a popped triangle group waits in ng until tg is empty */
+            if (ng_y == 0u) {
+                if (!in_tlas && sp == inst_sp) {
+                    if (tg_y != 0u) return false;                      /* drain the instance's triangles first */
+                    in_tlas = true; cur_inst = 0xffffffffu; inst_sp = -1;
+                    R = ray_setup(o_w, d_w);
+                }
+                if (sp == 0) { if (tg_y != 0u) return false; found = hit.t != HAR_INF; return true; }
+                stack.pop(--sp, ng_x, ng_y);
+                if (!in_tlas && ng_y <= 0x00ffffffu) --parked;         /* in a BLAS only parked triangle groups are non-node entries */
+            }
+            return false;
+        }
         if (ng_y <= 0x00ffffffu && tg_y == 0u) {
             if (!in_tlas && sp == inst_sp) {
                 in_tlas = true; cur_inst = 0xffffffffu; inst_sp = -1;

@@ -137,7 +137,7 @@ int run_chunk(HarSceneImpl *S, HarIntegratorImpl *I, const DSensor &C, int mode,
     const uint32_t grid = std::max<uint32_t>(HAR_SHARDS, std::min<uint32_t>(((n + 255) / 256 + HAR_SHARDS - 1) / HAR_SHARDS * HAR_SHARDS, 4096u));
     /* persistent traversal kernels: enough blocks to fill the chip (<= 8 blocks/CU), never more than the work */
     const uint32_t tgrid = std::min<uint32_t>(grid, 2048u);
-    const int small_stack = S->hs.stack_need() <= HAR_LDS_STACK_SMALL;   /* overflow is detected and reported */
+    const int small_stack = S->hs.stack_need() + HAR_STACK_MARGIN <= HAR_LDS_STACK_SMALL;   /* overflow is detected and reported */
     int cur = 0; uint32_t b = 0;
     for (; b < nb; ++b) {
         launch_trace_closest(s, tgrid, small_stack, S->ds.accel, cnt_alive(I, b), cur_trace(I, b), I->shard_cap, I->st[cur], I->h0, I->h1, I->status);
@@ -217,7 +217,7 @@ int har_scene_create(const HarSceneDesc *desc, HarScene *out) {
     D.accel.root = hs.root; D.accel.has_tlas = hs.has_tlas; D.accel.n_tris = (uint32_t) hs.tris.size(); D.accel.n_insts = (uint32_t) hs.inst_recs.size();
     D.n_emitters = (uint32_t) hs.emitters.size(); D.n_meshes = (uint32_t) hs.meshes.size();
     D.n_bsdfs = (uint32_t) hs.bsdfs.size(); D.n_textures = (uint32_t) hs.textures.size();
-    if (hs.stack_need() > HAR_LDS_STACK_DEPTH)
+    if (hs.stack_need() + HAR_STACK_MARGIN > HAR_LDS_STACK_DEPTH)
         fprintf(stderr, "[hip_ad_rgb] warning: BVH needs %u traversal stack entries, LDS stack holds %d (overflow is reported as an error)\n", hs.stack_need(), HAR_LDS_STACK_DEPTH);
     *out = S;
     return 0;

@@ -4,7 +4,15 @@
 #include "har_path.h"
 
 #define HAR_LDS_STACK_DEPTH 24      /* traversal stack entries per lane (deep scenes) */
-#define HAR_LDS_STACK_SMALL 12      /* used when the scene needs <= 12 entries: 24 KB LDS/block -> 6 blocks/CU */
+#ifndef HAR_LDS_STACK_SMALL         /* entries per lane of the small LDS stack: 12 x 8 B x 256 = 24 KB/block -> 6 blocks/CU.  Measured (tools/build_variant.sh A/B): 16 entries (5 blocks/CU) is 12 % slower */
+#define HAR_LDS_STACK_SMALL 12
+#endif
+#ifndef HAR_TRAV_POLICY
+#define HAR_TRAV_POLICY 0          /* Traversal<POLICY>, see har_accel.h; measured: POLICY 2 saves 7-15 % iterations in the model but nothing on the GPU */
+#endif
+#ifndef HAR_STACK_MARGIN            /* stack entries a scene needs beyond HostScene::stack_need() */
+#define HAR_STACK_MARGIN (HAR_TRAV_POLICY == 2 ? HAR_MAX_PARKED : 0)
+#endif
 #define HAR_LDS_GRAD_BSDFS 256     /* constant-albedo gradients accumulated per block in LDS (adjoint resolve) */
 #define HAR_SHARDS 8                /* XCD-private path queues */
 #define HAR_COUNTER_STRIDE 16       /* u32 stride between shard counters: one 64 B line each */

@@ -166,7 +166,7 @@ __global__ __launch_bounds__(kBlock) void k_raygen(DSensor C, uint32_t seed, uin
  * at ~30 % lane utilisation: incoherent rays need very different numbers of iterations (mean 13,
  * wave maximum 39 on the 1M-triangle scene) and the reference loop runs max-over-lanes triangle
  * tests per iteration.  Two changes fix that (tools/trace_stats.py models both on the CPU):
- *   - Traversal<0>::step() has a fixed shape (<= 1 leaf item, <= 1 node visit, <= 1 pop);
+ *   - Traversal<HAR_TRAV_POLICY>::step() has a fixed shape (<= 1 leaf item, <= 1 node visit, <= 1 pop);
  *   - a wave is PERSISTENT: it draws rays in batches from its shard's cursor (one atomic per
  *     HAR_FETCH_BATCH rays) and refills idle lanes whenever >= HAR_REFILL_IDLE lanes are idle, so
  *     its lanes work on different rays at different stages ("persistent while-while", Aila & Laine,
@@ -187,7 +187,7 @@ __device__ __forceinline__ void trace_persistent(const Accel &A, uint32_t *curso
     bool exhausted = false;                    /* wave-uniform */
     bool busy = false, has_result = false;
     uint32_t idx = 0;
-    Traversal<0> T;
+    Traversal<HAR_TRAV_POLICY> T;
     T.found = false; T.hit.t = HAR_INF;
     for (;;) {
         const uint64_t idle = __ballot(!busy);
@@ -234,16 +234,16 @@ __global__ __launch_bounds__(kBlock) void k_trace_closest(Accel A, const uint32_
     const uint32_t shard = blockIdx.x & (HAR_SHARDS - 1), n = count[shard * HAR_COUNTER_STRIDE], base = shard * shard_cap;
     if (n == 0) return;
     trace_persistent<false, false, CAP>(A, cursor + shard * HAR_COUNTER_STRIDE, n, stack, status,
-        [&](uint32_t idx, Traversal<0> &T) {
+        [&](uint32_t idx, Traversal<HAR_TRAV_POLICY> &T) {
             float4 o = a0[base + idx], d = a1[base + idx];
             T.begin(A, Vec3(o.x, o.y, o.z), Vec3(d.x, d.y, d.z), o.w);
             return true;
         },
-        [&](uint32_t idx, const Traversal<0> &T) {
+        [&](uint32_t idx, const Traversal<HAR_TRAV_POLICY> &T) {
             h0[base + idx] = make_float4(T.hit.t, T.hit.u, T.hit.v, __uint_as_float(T.hit.prim));
             h1[base + idx] = make_uint2(T.hit.shape, T.hit.inst);
         },
-        [&](bool, uint32_t, const Traversal<0> &) { });
+        [&](bool, uint32_t, const Traversal<HAR_TRAV_POLICY> &) { });
 }
 
 /* ------------------------------------------------------------------- shade */
@@ -307,7 +307,7 @@ __global__ __launch_bounds__(kBlock) void k_resolve(DScene S, const uint32_t *it
         for (uint32_t k = threadIdx.x; k < 3 * HAR_LDS_GRAD_BSDFS; k += kBlock) gacc[k] = 0.f;
         __syncthreads();
     }
-    auto take = [&](uint32_t idx, Traversal<0> &T) {
+    auto take = [&](uint32_t idx, Traversal<HAR_TRAV_POLICY> &T) {
         float4 s0 = items.s0[base + idx];
         if (!(s0.w >= 0.f)) return false;
         float4 s1 = items.s1[base + idx];
@@ -317,20 +317,20 @@ __global__ __launch_bounds__(kBlock) void k_resolve(DScene S, const uint32_t *it
     if (MODE == MODE_PATH || MODE == MODE_PRB_PRIMAL) {
         /* forward: an unoccluded item adds its contribution to its lane's radiance (one item per lane and bounce: no race) */
         trace_persistent<true, false, CAP>(S.accel, cursor + shard * HAR_COUNTER_STRIDE, n, stack, status, take,
-            [&](uint32_t idx, const Traversal<0> &T) {
+            [&](uint32_t idx, const Traversal<HAR_TRAV_POLICY> &T) {
                 if (!T.found) {
                     const uint32_t i = base + idx, lane = __float_as_uint(items.s1[i].w);
                     float4 s2 = items.s2[i], r = result[lane];
                     result[lane] = make_float4(r.x + s2.x, r.y + s2.y, r.z + s2.z, 0.f);
                 }
             },
-            [&](bool, uint32_t, const Traversal<0> &) { });
+            [&](bool, uint32_t, const Traversal<HAR_TRAV_POLICY> &) { });
     } else {
         /* adjoint: L <- L - Lr_dir; g = dL * (dLr_dir/drho + [bsdf_val != 0] L / rho)  (prb.py:227,288-313);
          * gradients are committed at refill time by ALL lanes so that the wave pre-reduction can run */
         trace_persistent<true, true, CAP>(S.accel, cursor + shard * HAR_COUNTER_STRIDE, n, stack, status, take,
-            [&](uint32_t, const Traversal<0> &) { },
-            [&](bool pred, uint32_t idx, const Traversal<0> &T) {
+            [&](uint32_t, const Traversal<HAR_TRAV_POLICY> &) { },
+            [&](bool pred, uint32_t idx, const Traversal<HAR_TRAV_POLICY> &T) {
                 const uint32_t i = base + (pred ? idx : 0u);
                 const bool visible = pred && !T.found;
                 Vec3 g(0.f); float *dst = grad_refl; bool tex = false; TexTaps taps; float *tdst = nullptr;
@@ -478,8 +478,8 @@ __global__ __launch_bounds__(kBlock) void k_api_intersect(DScene S, uint32_t n, 
     Vec3 O(o[i], o[n + i], o[2 * (size_t) n + i]), D(d[i], d[n + i], d[2 * (size_t) n + i]);
     Hit hit; int st = 0;
     if (NAIVE) accel_trace_naive<false>(S.accel, S.blas_tri_ranges, O, D, maxt[i], hit);
-    else {      /* the production traversal code (Traversal<0>::step), one ray per lane */
-        Traversal<0> T; T.begin(S.accel, O, D, maxt[i]);
+    else {      /* the production traversal code (Traversal<HAR_TRAV_POLICY>::step), one ray per lane */
+        Traversal<HAR_TRAV_POLICY> T; T.begin(S.accel, O, D, maxt[i]);
         while (!T.template step<false, LdsStack<HAR_LDS_STACK_DEPTH>, NoProbe, 1>(S.accel, stack, st)) { }
         hit = T.hit;
     }
@@ -496,7 +496,7 @@ __global__ __launch_bounds__(kBlock) void k_api_ray_test(DScene S, uint32_t n, c
     Hit hit; int st = 0; bool r;
     if (NAIVE) r = accel_trace_naive<true>(S.accel, S.blas_tri_ranges, O, D, maxt[i], hit);
     else {
-        Traversal<0> T; T.begin(S.accel, O, D, maxt[i]);
+        Traversal<HAR_TRAV_POLICY> T; T.begin(S.accel, O, D, maxt[i]);
         while (!T.template step<true, LdsStack<HAR_LDS_STACK_DEPTH>, NoProbe, 1>(S.accel, stack, st)) { }
         r = T.found;
     }

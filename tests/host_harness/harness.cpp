@@ -127,11 +127,12 @@ struct EvProbe {
  * policy: -1 reference loop (all triangles of a node per iteration), 0 / 1 = Traversal<POLICY>;
  * refill: 0 = static waves of 64 consecutive rays, R > 0 = persistent wave that refills when >= R lanes are idle */
 } // extern "C"
+static int g_max_sp = 0;
 template <bool AnyHit, typename T, int ORDER>
 static void run_traversal_o(const Accel &A, Vec3 o, Vec3 d, float maxt, Hit &hit, bool &found, std::vector<uint32_t> &ev, int &status) {
     T tr; HostStack stack; EvProbe pr{ &ev };
     tr.begin(A, o, d, maxt);
-    while (!tr.template step<AnyHit, HostStack, EvProbe, ORDER>(A, stack, status, pr)) { }
+    while (!tr.template step<AnyHit, HostStack, EvProbe, ORDER>(A, stack, status, pr)) { if (tr.sp > g_max_sp) g_max_sp = tr.sp; }
     hit = tr.hit; found = tr.found;
 }
 static int g_order = 2;
@@ -143,7 +144,8 @@ static void run_traversal(const Accel &A, Vec3 o, Vec3 d, float maxt, Hit &hit, 
 }
 extern "C" {
 
-void hh_set_order(int o) { g_order = o; }
+void hh_set_order(int o) { g_order = o; g_max_sp = 0; }
+int hh_max_sp() { return g_max_sp; }
 int hh_trace_stats(void *h, const HarSensor *sensor, uint32_t seed, uint32_t spp, int32_t max_depth, int32_t rr_depth,
                    uint64_t lane_begin, uint64_t lane_end, uint32_t max_bounces, int policy, int refill, double *out) {
     HScene *H = (HScene *) h; const DScene &S = H->ds;
@@ -215,7 +217,8 @@ int hh_trace_stats(void *h, const HarSensor *sensor, uint32_t seed, uint32_t spp
             if (policy >= 0) {
                 Hit h2; bool f2; evs[i].clear();
                 if (policy == 0) run_traversal<false, Traversal<0>>(S.accel, cur[i].o, cur[i].d, cur[i].maxt, h2, f2, evs[i], status);
-                else             run_traversal<false, Traversal<1>>(S.accel, cur[i].o, cur[i].d, cur[i].maxt, h2, f2, evs[i], status);
+                else if (policy == 1) run_traversal<false, Traversal<1>>(S.accel, cur[i].o, cur[i].d, cur[i].maxt, h2, f2, evs[i], status);
+                else             run_traversal<false, Traversal<2>>(S.accel, cur[i].o, cur[i].d, cur[i].maxt, h2, f2, evs[i], status);
                 if (memcmp(&h2, &hits[i], sizeof(Hit)) != 0 || f2 != (hits[i].t != HAR_INF)) o[10] += 1;
             }
         }
@@ -232,7 +235,8 @@ int hh_trace_stats(void *h, const HarSensor *sensor, uint32_t seed, uint32_t spp
             if (policy >= 0) {
                 Hit h2; bool f2; sev[i].clear();
                 if (policy == 0) run_traversal<true, Traversal<0>>(S.accel, shadow[i].o, shadow[i].d, shadow[i].maxt, h2, f2, sev[i], status);
-                else             run_traversal<true, Traversal<1>>(S.accel, shadow[i].o, shadow[i].d, shadow[i].maxt, h2, f2, sev[i], status);
+                else if (policy == 1) run_traversal<true, Traversal<1>>(S.accel, shadow[i].o, shadow[i].d, shadow[i].maxt, h2, f2, sev[i], status);
+                else             run_traversal<true, Traversal<2>>(S.accel, shadow[i].o, shadow[i].d, shadow[i].maxt, h2, f2, sev[i], status);
                 if (f1 != f2) o[26] += 1;
             }
         }

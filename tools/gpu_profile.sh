@@ -18,7 +18,7 @@ for P in "${PASSES[@]}"; do
     sq)  rocprofv3 --pmc SQ_WAVES SQ_INSTS_VALU SQ_ACTIVE_INST_VALU SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_INSTS_VMEM_RD SQ_INSTS_LDS SQ_WAIT_INST_ANY -d $D -o r -- python bench.py --steps 1 --warmup 0 $ARGS > $OUT/${TAG}_sq_bench.log 2>&1 ;;
     mem) rocprofv3 --pmc FETCH_SIZE -d ${D}f -o r -- python bench.py --steps 1 --warmup 0 $ARGS > /dev/null 2>&1
          rocprofv3 --pmc WRITE_SIZE -d $D -o r -- python bench.py --steps 1 --warmup 0 $ARGS > /dev/null 2>&1
-         python tools/rocpd_summary.py $(find ${D}f -name '*.db') > $OUT/${TAG}_fetch.txt 2>&1 ;;
+         python tools/rocpd_summary.py $(find ${D}f -name '*.db') $(find $D -name '*.db') --json $OUT/${TAG}_traffic.json > $OUT/${TAG}_fetch_write.txt 2>&1 ;;
     tcc) rocprofv3 --pmc TCC_HIT_sum TCC_MISS_sum -d $D -o r -- python bench.py --steps 1 --warmup 0 $ARGS > /dev/null 2>&1 ;;
   esac
   python tools/rocpd_summary.py $(find $D -name '*.db') > $OUT/${TAG}_$P.txt 2>&1

@@ -16,7 +16,13 @@ def short(name):
 
 
 def main():
-    for path in sys.argv[1:]:
+    import json
+    args = sys.argv[1:]
+    json_out = None
+    if "--json" in args:
+        k = args.index("--json"); json_out = args[k + 1]; args = args[:k] + args[k + 2:]
+    summary = {}
+    for path in args:
         db = sqlite3.connect(path)
         cur = db.cursor()
         print("== %s" % path)
@@ -26,6 +32,7 @@ def main():
         print("%-44s %8s %12s %12s %10s %10s %6s" % ("kernel", "calls", "total_ms", "avg_us", "min_us", "max_us", "%"))
         for n, c, s, a, mn, mx in rows:
             print("%-44s %8d %12.3f %12.2f %10.2f %10.2f %6.1f" % (short(n), c, s / 1e6, a / 1e3, mn / 1e3, mx / 1e3, 100.0 * s / tot))
+            summary.setdefault(short(n), {}).update({"calls": c, "total_ms": s / 1e6, "avg_us": a / 1e3})
         try:
             pm = cur.execute("select k.name, p.counter_name, sum(p.value), count(*) from counters_collection p join kernels k on 1=0").fetchall()
         except Exception:
@@ -40,8 +47,14 @@ def main():
                     print("-- PMC sums per kernel (sum over dispatches, dispatch count)")
                     for n, cn, v, c in rows:
                         print("%-44s %-24s %20.0f %8d" % (short(n), cn, v, c))
+                        summary.setdefault(short(n), {}).setdefault("counters", {})[cn] = {"sum": v, "dispatches": c}
         except Exception as e:
             print("(no counters: %s)" % e)
+
+
+    if json_out:
+        with open(json_out, "w") as f:
+            json.dump(summary, f, indent=1, sort_keys=True)
 
 
 if __name__ == "__main__":

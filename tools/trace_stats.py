@@ -51,6 +51,7 @@ def main():
             print("%-3d %-8s %9d | %15.2f %6.2f %6.2f %6.2f | %17.1f %8.1f %8.1f %8.1f | %5.2f %5.2f" %
                   (b, kind, r, q[1] / r, q[2] / r, q[3] / r, q[4] / r, q[5] / w, q[6] / w, q[7] / w, q[8] / w,
                    q[2] / (64 * q[6]) if q[6] else 0, q[3] / (64 * q[7]) if q[7] else 0))
+    print("max traversal stack entries used: %d (scene stack_need %d)" % (H.hh_max_sp(), scene.accel_info_host()["depth"] if hasattr(scene, "accel_info_host") else -1))
     tc = out[:, :16].sum(0); ts = out[:, 16:].sum(0)
     for kind, q in (("closest", tc), ("shadow", ts)):
         r, w = q[0], q[9]

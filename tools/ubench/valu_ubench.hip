@@ -1,0 +1,64 @@
+// VALU issue-rate micro-benchmark for gfx950: cycles per wave64 instruction per SIMD for the
+// instruction kinds the traversal kernel is made of.  8 waves per SIMD (2 blocks of 1024 threads per CU
+// would also do; here 256-thread blocks, 8 per CU), 4 independent chains per lane.
+#include <hip/hip_runtime.h>
+#include <cstdio>
+#include <cstdlib>
+#define CHECK(x) do { hipError_t e = (x); if (e != hipSuccess) { printf("%s: %s\n", #x, hipGetErrorString(e)); exit(1); } } while (0)
+
+#define REP8(x) x x x x x x x x
+#define REP64(x) REP8(REP8(x))
+
+template <int KIND>
+__global__ __launch_bounds__(256) void k(float *out, int iters, float seed) {
+    float a0 = threadIdx.x * seed, a1 = a0 + 1.f, a2 = a0 + 2.f, a3 = a0 + 3.f, b = seed * 1.0001f, c = seed * 0.5f;
+    uint32_t u0 = __float_as_uint(a0), u1 = u0 * 3u, u2 = u0 * 5u, u3 = u0 * 7u;
+    typedef float f2 __attribute__((ext_vector_type(2)));
+    f2 p0 = { a0, a1 }, p1 = { a2, a3 }, p2 = { a1, a2 }, p3 = { a3, a0 }, pb = { b, b }, pc = { c, c };
+    for (int i = 0; i < iters; ++i) {
+        if (KIND == 0) { REP64(asm volatile("v_fma_f32 %0, %0, %4, %5\n v_fma_f32 %1, %1, %4, %5\n v_fma_f32 %2, %2, %4, %5\n v_fma_f32 %3, %3, %4, %5" : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3) : "v"(b), "v"(c));) }
+        if (KIND == 1) { REP64(asm volatile("v_pk_fma_f32 %0, %0, %4, %5\n v_pk_fma_f32 %1, %1, %4, %5\n v_pk_fma_f32 %2, %2, %4, %5\n v_pk_fma_f32 %3, %3, %4, %5" : "+v"(p0), "+v"(p1), "+v"(p2), "+v"(p3) : "v"(pb), "v"(pc));) }
+        if (KIND == 2) { REP64(asm volatile("v_cvt_f32_ubyte1 %0, %4\n v_cvt_f32_ubyte2 %1, %5\n v_cvt_f32_ubyte3 %2, %6\n v_cvt_f32_ubyte0 %3, %7" : "=v"(a0), "=v"(a1), "=v"(a2), "=v"(a3) : "v"(u0), "v"(u1), "v"(u2), "v"(u3));) }
+        if (KIND == 3) { REP64(asm volatile("v_max3_f32 %0, %0, %4, %5\n v_min3_f32 %1, %1, %4, %5\n v_max3_f32 %2, %2, %4, %5\n v_min3_f32 %3, %3, %4, %5" : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3) : "v"(b), "v"(c));) }
+        if (KIND == 4) { REP64(asm volatile("v_mov_b32 %0, %4\n v_mov_b32 %1, %5\n v_mov_b32 %2, %6\n v_mov_b32 %3, %7" : "=v"(a0), "=v"(a1), "=v"(a2), "=v"(a3) : "v"(u0), "v"(u1), "v"(u2), "v"(u3));) }
+        if (KIND == 5) { REP64(asm volatile("v_and_b32 %0, %0, %4\n v_lshl_or_b32 %1, %1, %5, %4\n v_xor_b32 %2, %2, %4\n v_add_u32 %3, %3, %5" : "+v"(u0), "+v"(u1), "+v"(u2), "+v"(u3) : "v"(0x7fffffffu), "v"(1u));) }
+        if (KIND == 6) { REP64(asm volatile("v_cmp_le_f32 vcc, %0, %4\n v_cndmask_b32 %1, %1, %5, vcc\n v_cmp_gt_f32 vcc, %2, %4\n v_cndmask_b32 %3, %3, %5, vcc" : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3) : "v"(b), "v"(c) : "vcc");) }
+        if (KIND == 7) { REP64(asm volatile("v_mul_f32 %0, %0, %4\n v_add_f32 %1, %1, %5\n v_mul_f32 %2, %2, %4\n v_sub_f32 %3, %3, %5" : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3) : "v"(b), "v"(c));) }
+        if (KIND == 8) { REP64(asm volatile("v_rcp_f32 %0, %0\n v_rcp_f32 %1, %1\n v_rcp_f32 %2, %2\n v_rcp_f32 %3, %3" : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3));) }
+    }
+    out[blockIdx.x * 256 + threadIdx.x] = a0 + a1 + a2 + a3 + p0.x + p0.y + p1.x + p1.y + p2.x + p3.y + __uint_as_float(u0 ^ u1 ^ u2 ^ u3);
+}
+
+int main() {
+    hipDeviceProp_t prop; CHECK(hipGetDeviceProperties(&prop, 0));
+    int cus = prop.multiProcessorCount; double clk = prop.clockRate * 1e3;
+    float *out; CHECK(hipMalloc(&out, (size_t) cus * 8 * 256 * 4));
+    hipEvent_t e0, e1; CHECK(hipEventCreate(&e0)); CHECK(hipEventCreate(&e1));
+    const char *names[] = { "v_fma_f32", "v_pk_fma_f32", "v_cvt_f32_ubyteN", "v_max3/min3_f32", "v_mov_b32", "int and/lshl_or/xor/add", "v_cmp+v_cndmask", "v_mul/add/sub_f32", "v_rcp_f32" };
+    for (int waves_per_simd : { 1, 2, 8 }) {
+        int grid = cus * waves_per_simd;      // 256-thread block = 4 waves = 1 per SIMD
+        for (int kind = 0; kind < 9; ++kind) {
+            int iters = 200;
+            auto launch = [&]() {
+                switch (kind) {
+                    case 0: hipLaunchKernelGGL(k<0>, dim3(grid), dim3(256), 0, 0, out, iters, 1.0001f); break;
+                    case 1: hipLaunchKernelGGL(k<1>, dim3(grid), dim3(256), 0, 0, out, iters, 1.0001f); break;
+                    case 2: hipLaunchKernelGGL(k<2>, dim3(grid), dim3(256), 0, 0, out, iters, 1.0001f); break;
+                    case 3: hipLaunchKernelGGL(k<3>, dim3(grid), dim3(256), 0, 0, out, iters, 1.0001f); break;
+                    case 4: hipLaunchKernelGGL(k<4>, dim3(grid), dim3(256), 0, 0, out, iters, 1.0001f); break;
+                    case 5: hipLaunchKernelGGL(k<5>, dim3(grid), dim3(256), 0, 0, out, iters, 1.0001f); break;
+                    case 6: hipLaunchKernelGGL(k<6>, dim3(grid), dim3(256), 0, 0, out, iters, 1.0001f); break;
+                    case 7: hipLaunchKernelGGL(k<7>, dim3(grid), dim3(256), 0, 0, out, iters, 1.0001f); break;
+                    case 8: hipLaunchKernelGGL(k<8>, dim3(grid), dim3(256), 0, 0, out, iters, 1.0001f); break;
+                }
+            };
+            launch(); CHECK(hipDeviceSynchronize());
+            CHECK(hipEventRecord(e0)); launch(); CHECK(hipEventRecord(e1)); CHECK(hipEventSynchronize(e1));
+            float ms; CHECK(hipEventElapsedTime(&ms, e0, e1));
+            double instr_per_simd = (double) waves_per_simd * iters * 64 * 4;
+            printf("%d waves/SIMD  %-26s %8.3f ms  %6.2f cycles per wave-instruction per SIMD (at %.0f MHz)\n", waves_per_simd, names[kind], ms,
+                   ms * 1e-3 * clk / instr_per_simd, clk / 1e6);
+        }
+    }
+    return 0;
+}
