@@ -18,6 +18,7 @@
 #include <algorithm>
 #include <cmath>
 #include <cstring>
+#include <cstdlib>
 #include <limits>
 
 namespace har {
@@ -38,6 +39,7 @@ struct Builder {
     std::vector<uint32_t> order;
     std::vector<BNode> bn;
 
+    uint32_t max_leaf = 3;
     explicit Builder(const std::vector<PrimBox> &p) : prims(p), order(p.size()) { for (uint32_t i = 0; i < p.size(); ++i) order[i] = i; }
 
     Box prim_box(uint32_t i) const { Box b; std::memcpy(b.lo, prims[i].lo, 12); std::memcpy(b.hi, prims[i].hi, 12); return b; }
@@ -52,7 +54,7 @@ struct Builder {
         }
         bn[idx].box = box;
         uint32_t count = end - begin;
-        if (count <= 3) { bn[idx].first = begin; bn[idx].count = count; return idx; }
+        if (count <= max_leaf) { bn[idx].first = begin; bn[idx].count = count; return idx; }
         constexpr int NB = 16;
         float best = std::numeric_limits<float>::infinity(); int best_axis = -1, best_split = -1;
         for (int axis = 0; axis < 3; ++axis) {
@@ -115,7 +117,7 @@ void pad_prim_box(PrimBox &b) {
 }
 
 uint32_t build_bvh8(const std::vector<PrimBox> &prims, std::vector<Node8> &nodes, uint32_t leaf_base,
-                    std::vector<uint32_t> &leaf_order, Bvh8Stats *stats) {
+                    std::vector<uint32_t> &leaf_order, Bvh8Stats *stats, uint32_t max_leaf) {
     const uint32_t root_out = (uint32_t) nodes.size();
     nodes.emplace_back();
     std::memset(&nodes[root_out], 0, sizeof(Node8));
@@ -124,6 +126,7 @@ uint32_t build_bvh8(const std::vector<PrimBox> &prims, std::vector<Node8> &nodes
         return root_out;
     }
     Builder B(prims);
+    B.max_leaf = std::max(1u, std::min(3u, max_leaf));
     B.bn.reserve(prims.size());
     int broot = B.build(0, (uint32_t) prims.size());
 

@@ -13,8 +13,9 @@ void pad_prim_box(PrimBox &b);
 
 /* Appends a BVH8 over `prims` to `nodes`; leaves reference positions
  * leaf_base + k of the primitive sequence appended to `leaf_order` (indices into
- * `prims`).  Returns the index of the root node. */
+ * `prims`).  `max_leaf` (1..3) = primitives per leaf: every primitive of a hit leaf is processed without a box
+ * test of its own, so the TLAS (primitive = an instance entry, expensive) is built with 1.  Returns the root node index. */
 uint32_t build_bvh8(const std::vector<PrimBox> &prims, std::vector<Node8> &nodes, uint32_t leaf_base,
-                    std::vector<uint32_t> &leaf_order, Bvh8Stats *stats);
+                    std::vector<uint32_t> &leaf_order, Bvh8Stats *stats, uint32_t max_leaf = 3);
 
 } // namespace har

@@ -8,6 +8,7 @@
 #include <algorithm>
 #include <cmath>
 #include <cstring>
+#include <cstdlib>
 
 namespace har {
 
@@ -36,7 +37,8 @@ BlasInfo build_blas(HostScene &hs, const HarSceneDesc &d, uint32_t first_mesh, u
     BlasInfo info{};
     info.first_tri = (uint32_t) hs.tris.size(); info.tri_count = (uint32_t) recs.size(); info.empty = recs.empty();
     std::vector<uint32_t> order;
-    info.root = build_bvh8(prims, hs.nodes, info.first_tri, order, &hs.stats);
+    static const uint32_t blas_leaf = getenv("HAR_BLAS_MAX_LEAF") ? (uint32_t) atoi(getenv("HAR_BLAS_MAX_LEAF")) : 1u;   /* measured on MI355X: 1 beats 2 and 3 (fewer wasted triangle tests, esp. for any-hit rays) */
+    info.root = build_bvh8(prims, hs.nodes, info.first_tri, order, &hs.stats, blas_leaf);
     for (uint32_t i : order) hs.tris.push_back(recs[i]);
     for (int a = 0; a < 3; ++a) { info.lo[a] = INFINITY; info.hi[a] = -INFINITY; }
     for (const PrimBox &b : prims) for (int a = 0; a < 3; ++a) { info.lo[a] = std::min(info.lo[a], b.lo[a]); info.hi[a] = std::max(info.hi[a], b.hi[a]); }
@@ -114,10 +116,25 @@ bool lower_scene(const HarSceneDesc &d, HostScene &hs, std::string &err) {
         InstRec r{}; std::memcpy(r.to_world, d.instances[i].to_world, 48); std::memcpy(r.to_object, d.instances[i].to_object, 48);
         r.blas_root = g.root; r.inst_index = i; r.identity = 0;
         PrimBox b; for (int a = 0; a < 3; ++a) { b.lo[a] = INFINITY; b.hi[a] = -INFINITY; }
-        for (int c = 0; c < 8; ++c) {          // Instance::bbox, src/shapes/instance.cpp:93-103
-            Vec3 q = xf_point(r.to_world, Vec3(c & 1 ? g.hi[0] : g.lo[0], c & 2 ? g.hi[1] : g.lo[1], c & 4 ? g.hi[2] : g.lo[2]));
+        auto grow = [&](Vec3 q) {
             const float qq[3] = { q.x, q.y, q.z };
             for (int a = 0; a < 3; ++a) { b.lo[a] = std::min(b.lo[a], qq[a]); b.hi[a] = std::max(b.hi[a], qq[a]); }
+        };
+        /* Instance::bbox (src/shapes/instance.cpp:93-103) transforms the 8 corners of the group's box, which inflates
+         * the box of a rotated object by up to sqrt(3).  A TLAS leaf only has to bound the instance, so use the exact
+         * bound of the transformed vertices when that is cheap (it cuts instance entries per ray by ~1/4 on the
+         * 1M-triangle benchmark scene) and the reference's corner bound otherwise. */
+        const HarShapeGroup &sg = d.groups[d.instances[i].group];
+        uint64_t nverts = 0;
+        for (uint32_t s = sg.first_mesh; s < sg.first_mesh + sg.mesh_count; ++s) nverts += d.meshes[s].vertex_count;
+        if (nverts * (uint64_t) d.instance_count <= 200000000ull) {
+            for (uint32_t s = sg.first_mesh; s < sg.first_mesh + sg.mesh_count; ++s) {
+                const HarMesh &m = d.meshes[s];
+                for (uint32_t f = 0; f < m.face_count; ++f)          /* only referenced vertices */
+                    for (int k = 0; k < 3; ++k) { const float *v = m.vertex_ptr + 8 * (size_t) m.index_ptr[4 * (size_t) f + k]; grow(xf_point(r.to_world, Vec3(v[0], v[1], v[2]))); }
+            }
+        } else {
+            for (int c = 0; c < 8; ++c) grow(xf_point(r.to_world, Vec3(c & 1 ? g.hi[0] : g.lo[0], c & 2 ? g.hi[1] : g.lo[1], c & 4 ? g.hi[2] : g.lo[2])));
         }
         pad_prim_box(b);
         boxes.push_back(b); recs.push_back(r); ranges.push_back(g.first_tri); ranges.push_back(g.tri_count);
@@ -125,7 +142,8 @@ bool lower_scene(const HarSceneDesc &d, HostScene &hs, std::string &err) {
     hs.blas_depth = hs.stats.max_depth;
     std::vector<uint32_t> order;
     Bvh8Stats tstats;
-    hs.root = build_bvh8(boxes, hs.nodes, 0, order, &tstats);
+    static const uint32_t tlas_leaf = getenv("HAR_TLAS_MAX_LEAF") ? (uint32_t) atoi(getenv("HAR_TLAS_MAX_LEAF")) : 1u;
+    hs.root = build_bvh8(boxes, hs.nodes, 0, order, &tstats, tlas_leaf);
     hs.tlas_depth = tstats.max_depth; hs.stats.max_depth = std::max(hs.stats.max_depth, tstats.max_depth);
     hs.has_tlas = true;
     for (uint32_t k : order) { hs.inst_recs.push_back(recs[k]); hs.blas_tri_ranges.push_back(ranges[2 * k]); hs.blas_tri_ranges.push_back(ranges[2 * k + 1]); }
