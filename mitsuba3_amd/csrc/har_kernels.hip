@@ -176,8 +176,15 @@ __global__ __launch_bounds__(kBlock) void k_raygen(DSensor C, uint32_t seed, uin
  *   retire(pred, idx, T) : called by ALL lanes at refill time (wave-uniform; may use wave reductions),
  *                          pred marks lanes whose item finished since the last refill
  */
+#ifndef HAR_FETCH_BATCH
 #define HAR_FETCH_BATCH 128u
+#endif
+#ifndef HAR_REFILL_IDLE
 #define HAR_REFILL_IDLE 12u
+#endif
+#ifndef HAR_TRAV_ORDER
+#define HAR_TRAV_ORDER 0    /* measured: 0 (node, leaf, pop) 687, 2: 660, 1: 643 Mpaths/s on the 1M-tri scene */
+#endif
 
 template <bool ANY, bool RETIRE, int CAP, typename Take, typename Done, typename Retire>
 __device__ __forceinline__ void trace_persistent(const Accel &A, uint32_t *cursor, uint32_t n, LdsStack<CAP> &stack, int *status,
@@ -216,7 +223,7 @@ __device__ __forceinline__ void trace_persistent(const Accel &A, uint32_t *curso
         }
         if (busy) {
             int st = 0;
-            if (T.template step<ANY, LdsStack<CAP>, NoProbe, 1>(A, stack, st)) {
+            if (T.template step<ANY, LdsStack<CAP>, NoProbe, HAR_TRAV_ORDER>(A, stack, st)) {
                 busy = false;
                 if (RETIRE) has_result = true; else done(idx, T);
             }
