@@ -394,6 +394,16 @@ struct Traversal {
     }
     HAR_HD bool overflow(int &status) { status = HAR_STACK_OVERFLOW; hit.t = HAR_INF; found = false; return true; }
 
+    /* extra leaf round of the persistent kernels: one more leaf item + pop for a lane that still has one pending,
+     * so that it is ready for a node visit in the next iteration (the node block is the expensive one) */
+    template <bool AnyHit, typename Stack>
+    HAR_HD bool leaf_round(const Accel &A, Stack &stack, int &status) {
+        NoProbe probe;
+        if (phase_leaf<AnyHit>(A, stack, status, probe)) return true;
+        return phase_pop(stack);
+    }
+    HAR_HD bool leaf_pending() const { return tg_y != 0u; }
+
     /* one iteration; returns true when the ray is finished (`found` / `hit` hold the result).
      * ORDER 0: node, leaf, pop   1: leaf, node, pop   2: leaf, pop, node */
     template <bool AnyHit, typename Stack, typename Probe = NoProbe, int ORDER = 2>

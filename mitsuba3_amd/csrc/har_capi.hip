@@ -137,7 +137,9 @@ int run_chunk(HarSceneImpl *S, HarIntegratorImpl *I, const DSensor &C, int mode,
     const uint32_t grid = std::max<uint32_t>(HAR_SHARDS, std::min<uint32_t>(((n + 255) / 256 + HAR_SHARDS - 1) / HAR_SHARDS * HAR_SHARDS, 4096u));
     /* persistent traversal kernels: enough blocks to fill the chip (<= 8 blocks/CU), never more than the work */
     const uint32_t tgrid = std::min<uint32_t>(grid, 2048u);
-    const int small_stack = S->hs.stack_need() + HAR_STACK_MARGIN <= HAR_LDS_STACK_SMALL;   /* overflow is detected and reported */
+    /* LDS stack capacity class by the scene's depth-first bound (an overflow is still detected and reported) */
+    const uint32_t need = S->hs.stack_need() + HAR_STACK_MARGIN;
+    const int small_stack = need <= HAR_LDS_STACK_SMALL ? 0 : (need <= HAR_LDS_STACK_MEDIUM ? 1 : 2);
     int cur = 0; uint32_t b = 0;
     for (; b < nb; ++b) {
         launch_trace_closest(s, tgrid, small_stack, S->ds.accel, cnt_alive(I, b), cur_trace(I, b), I->shard_cap, I->st[cur], I->h0, I->h1, I->status);

@@ -3,7 +3,8 @@
 #include <hip/hip_runtime.h>
 #include "har_path.h"
 
-#define HAR_LDS_STACK_DEPTH 24      /* traversal stack entries per lane (deep scenes) */
+#define HAR_LDS_STACK_DEPTH 30      /* traversal stack entries per lane, deep scenes: 60 KB/block -> 2 blocks/CU */
+#define HAR_LDS_STACK_MEDIUM 18     /* 36 KB/block -> 4 blocks/CU */
 #ifndef HAR_LDS_STACK_SMALL         /* entries per lane of the small LDS stack: 12 x 8 B x 256 = 24 KB/block -> 6 blocks/CU.  Measured (tools/build_variant.sh A/B): 16 entries (5 blocks/CU) is 12 % slower */
 #define HAR_LDS_STACK_SMALL 12
 #endif
@@ -28,12 +29,12 @@ struct ItemArrays { float4 *s0, *s1, *s2, *s3, *s4; };
 
 void launch_raygen(int mode, hipStream_t s, const DSensor &C, uint32_t seed, uint32_t spp, uint32_t log_spp, uint32_t lane_base, uint32_t n,
                    uint32_t shard_cap, const WaveState &out, float4 *result, uint32_t *count, const float *adj, float4 *dL);
-void launch_trace_closest(hipStream_t s, uint32_t grid, int small_stack, const Accel &A, const uint32_t *count, uint32_t *cursor, uint32_t shard_cap,
+void launch_trace_closest(hipStream_t s, uint32_t grid, int stack_class, const Accel &A, const uint32_t *count, uint32_t *cursor, uint32_t shard_cap,
                           const WaveState &in, float4 *h0, uint2 *h1, int *status);
 void launch_shade(int mode, hipStream_t s, uint32_t grid, const DScene &S, const ShadeParams &P, uint32_t lane_base, uint32_t shard_cap, const uint32_t *count_in,
                   const WaveState &in, const float4 *h0, const uint2 *h1, const WaveState &out, uint32_t *count_out, const ItemArrays &items,
                   uint32_t *item_count, float4 *result);
-void launch_resolve(int mode, hipStream_t s, uint32_t grid, int small_stack, const DScene &S, const uint32_t *item_count, uint32_t *cursor, uint32_t shard_cap, const ItemArrays &items,
+void launch_resolve(int mode, hipStream_t s, uint32_t grid, int stack_class, const DScene &S, const uint32_t *item_count, uint32_t *cursor, uint32_t shard_cap, const ItemArrays &items,
                     float4 *result, const float4 *dL, float *grad_refl, float *const *grad_tex, int *status);
 void launch_splat(hipStream_t s, const DSensor &C, uint32_t seed, uint32_t spp, uint32_t log_spp, uint32_t lane_base, uint32_t n,
                   const float4 *result, int weights_only, float *film);

@@ -182,6 +182,12 @@ __global__ __launch_bounds__(kBlock) void k_raygen(DSensor C, uint32_t seed, uin
 #ifndef HAR_REFILL_IDLE
 #define HAR_REFILL_IDLE 12u
 #endif
+#ifndef HAR_EXTRA_ROUNDS
+#define HAR_EXTRA_ROUNDS 0
+#endif
+#ifndef HAR_EXTRA_MIN
+#define HAR_EXTRA_MIN 8u
+#endif
 #ifndef HAR_TRAV_ORDER
 #define HAR_TRAV_ORDER 0    /* measured: 0 (node, leaf, pop) 687, 2: 660, 1: 643 Mpaths/s on the 1M-tri scene */
 #endif
@@ -228,6 +234,20 @@ __device__ __forceinline__ void trace_persistent(const Accel &A, uint32_t *curso
                 if (RETIRE) has_result = true; else done(idx, T);
             }
             if (st) atomicMax(status, st);
+        }
+        /* extra leaf rounds: lanes with a pending triangle / instance catch up while the others wait (cheap block),
+         * so that more lanes take part in the next node visit (expensive block) */
+        for (int r = 0; r < HAR_EXTRA_ROUNDS; ++r) {
+            const bool want = busy && T.leaf_pending();
+            if ((uint32_t) __popcll(__ballot(want)) < HAR_EXTRA_MIN) break;
+            if (want) {
+                int st = 0;
+                if (T.template leaf_round<ANY>(A, stack, st)) {
+                    busy = false;
+                    if (RETIRE) has_result = true; else done(idx, T);
+                }
+                if (st) atomicMax(status, st);
+            }
         }
     }
 }
@@ -583,9 +603,10 @@ void launch_raygen(int mode, hipStream_t s, const DSensor &C, uint32_t seed, uin
     if (mode == MODE_PRB_ADJOINT) hipLaunchKernelGGL(k_raygen<MODE_PRB_ADJOINT>, g, b, 0, s, C, seed, spp, log_spp, lane_base, n, shard_cap, out, result, count, adj, dL);
     else hipLaunchKernelGGL(k_raygen<MODE_PATH>, g, b, 0, s, C, seed, spp, log_spp, lane_base, n, shard_cap, out, result, count, adj, dL);
 }
-void launch_trace_closest(hipStream_t s, uint32_t grid, int small_stack, const Accel &A, const uint32_t *count, uint32_t *cursor, uint32_t shard_cap,
+void launch_trace_closest(hipStream_t s, uint32_t grid, int stack_class, const Accel &A, const uint32_t *count, uint32_t *cursor, uint32_t shard_cap,
                           const WaveState &in, float4 *h0, uint2 *h1, int *status) {
-    if (small_stack) hipLaunchKernelGGL(k_trace_closest<HAR_LDS_STACK_SMALL>, dim3(grid), dim3(kBlock), 0, s, A, count, cursor, shard_cap, in.a0, in.a1, h0, h1, status);
+    if (stack_class == 0) hipLaunchKernelGGL(k_trace_closest<HAR_LDS_STACK_SMALL>, dim3(grid), dim3(kBlock), 0, s, A, count, cursor, shard_cap, in.a0, in.a1, h0, h1, status);
+    else if (stack_class == 1) hipLaunchKernelGGL(k_trace_closest<HAR_LDS_STACK_MEDIUM>, dim3(grid), dim3(kBlock), 0, s, A, count, cursor, shard_cap, in.a0, in.a1, h0, h1, status);
     else hipLaunchKernelGGL(k_trace_closest<HAR_LDS_STACK_DEPTH>, dim3(grid), dim3(kBlock), 0, s, A, count, cursor, shard_cap, in.a0, in.a1, h0, h1, status);
 }
 void launch_shade(int mode, hipStream_t s, uint32_t grid, const DScene &S, const ShadeParams &P, uint32_t lane_base, uint32_t shard_cap, const uint32_t *count_in,
@@ -596,14 +617,16 @@ void launch_shade(int mode, hipStream_t s, uint32_t grid, const DScene &S, const
     else if (mode == MODE_PRB_PRIMAL) hipLaunchKernelGGL(k_shade<MODE_PRB_PRIMAL>, g, b, 0, s, S, P, lane_base, shard_cap, count_in, in, h0, h1, out, count_out, items, item_count, result);
     else hipLaunchKernelGGL(k_shade<MODE_PRB_ADJOINT>, g, b, 0, s, S, P, lane_base, shard_cap, count_in, in, h0, h1, out, count_out, items, item_count, result);
 }
-void launch_resolve(int mode, hipStream_t s, uint32_t grid, int small_stack, const DScene &S, const uint32_t *item_count, uint32_t *cursor, uint32_t shard_cap, const ItemArrays &items,
+void launch_resolve(int mode, hipStream_t s, uint32_t grid, int stack_class, const DScene &S, const uint32_t *item_count, uint32_t *cursor, uint32_t shard_cap, const ItemArrays &items,
                     float4 *result, const float4 *dL, float *grad_refl, float *const *grad_tex, int *status) {
     dim3 g(grid), b(kBlock);
     if (mode == MODE_PRB_ADJOINT) {
-        if (small_stack) hipLaunchKernelGGL((k_resolve<MODE_PRB_ADJOINT, HAR_LDS_STACK_SMALL>), g, b, 0, s, S, item_count, cursor, shard_cap, items, result, dL, grad_refl, grad_tex, status);
+        if (stack_class == 0) hipLaunchKernelGGL((k_resolve<MODE_PRB_ADJOINT, HAR_LDS_STACK_SMALL>), g, b, 0, s, S, item_count, cursor, shard_cap, items, result, dL, grad_refl, grad_tex, status);
+        else if (stack_class == 1) hipLaunchKernelGGL((k_resolve<MODE_PRB_ADJOINT, HAR_LDS_STACK_MEDIUM>), g, b, 0, s, S, item_count, cursor, shard_cap, items, result, dL, grad_refl, grad_tex, status);
         else hipLaunchKernelGGL((k_resolve<MODE_PRB_ADJOINT, HAR_LDS_STACK_DEPTH>), g, b, 0, s, S, item_count, cursor, shard_cap, items, result, dL, grad_refl, grad_tex, status);
     } else {
-        if (small_stack) hipLaunchKernelGGL((k_resolve<MODE_PATH, HAR_LDS_STACK_SMALL>), g, b, 0, s, S, item_count, cursor, shard_cap, items, result, dL, grad_refl, grad_tex, status);
+        if (stack_class == 0) hipLaunchKernelGGL((k_resolve<MODE_PATH, HAR_LDS_STACK_SMALL>), g, b, 0, s, S, item_count, cursor, shard_cap, items, result, dL, grad_refl, grad_tex, status);
+        else if (stack_class == 1) hipLaunchKernelGGL((k_resolve<MODE_PATH, HAR_LDS_STACK_MEDIUM>), g, b, 0, s, S, item_count, cursor, shard_cap, items, result, dL, grad_refl, grad_tex, status);
         else hipLaunchKernelGGL((k_resolve<MODE_PATH, HAR_LDS_STACK_DEPTH>), g, b, 0, s, S, item_count, cursor, shard_cap, items, result, dL, grad_refl, grad_tex, status);
     }
 }

@@ -254,3 +254,66 @@ def test_golden_sampler_streams(mi):
     s = mi.Sampler({"sample_count": 4}); s.seed(7, 16)
     got = np.stack([s.next_1d().cpu().numpy() for _ in range(5)], axis=1)
     assert np.array_equal(got, fx["sampler_seed7"])
+
+
+# ---------------------------------------------------------------- edge cases and size-independent properties
+
+def test_lane_bands_union_equals_whole(mi, O):
+    """rendering lane bands [0,a), [a,b), [b,N) (whole pixel rows and ragged cuts) into one film equals
+    the single-call render (same per-lane streams; only the atomic summation order differs)."""
+    import torch
+    scene, _, _ = cbox(mi, O, 40)
+    integ = scene.integrator()
+    spp = 8; n = 40 * 40 * spp
+    whole = integ.render_film(scene, 0, 5, spp)
+    film = None
+    for lo, hi in ((0, 13 * 40 * spp), (13 * 40 * spp, 13 * 40 * spp + 777), (13 * 40 * spp + 777, n)):
+        film = integ.render_film(scene, 0, 5, spp, lanes=(lo, hi), film=film)
+    torch.cuda.synchronize()
+    assert rel_l2(film.cpu().numpy(), whole.cpu().numpy()) < 1e-6
+
+
+def test_depth_limits_and_rr(mi, O):
+    """max_depth 0 (weights only, path.cpp:102), 1 (emitters only), 2, and rr_depth = 1 against the oracle."""
+    scene, osc, sensor = cbox(mi, O, 32)
+    for md, rr in ((0, 5), (1, 5), (2, 5), (8, 1), (-1, 3)):
+        integ = mi.load_dict({"type": "path", "max_depth": md, "rr_depth": rr})
+        img = mi.render(scene, integrator=integ, spp=8, seed=2).cpu().numpy()
+        ref, _ = osc.render_path(sensor, seed=2, spp=8, max_depth=md, rr_depth=rr)
+        if md == 0:
+            assert not img.any() and not ref.any()
+        else:
+            assert rel_l2(img, ref) < 1e-4, (md, rr)
+
+
+def test_scene_without_emitters_and_all_miss(mi, O):
+    """n_emitters == 0 (scene.cpp:139 pmf guard) and a sensor that sees nothing: black images, no NaNs, finite stats."""
+    import torch
+    d = mi.cornell_box(); d.pop("light")
+    d["sensor"]["film"]["width"] = 24; d["sensor"]["film"]["height"] = 24
+    img = mi.render(mi.load_dict(d), spp=4, seed=0)
+    assert bool(torch.isfinite(img).all()) and float(img.abs().max()) == 0.0
+    d = mi.cornell_box()
+    d["sensor"]["film"]["width"] = 16; d["sensor"]["film"]["height"] = 16
+    d["sensor"]["to_world"] = mi.ScalarTransform4f().look_at(origin=[0, 0, 3.9], target=[0, 0, 10], up=[0, 1, 0])
+    scene = mi.load_dict(d)
+    img = mi.render(scene, spp=4, seed=0)
+    assert float(img.abs().max()) == 0.0
+    st = scene.integrator().stats()
+    assert st["paths"] == 16 * 16 * 4 and st["shadow_rays"] == 0
+
+
+def test_single_pixel_film_and_odd_spp(mi, O):
+    sd, sensor = O.cornell_box(1, 1)
+    d = mi.cornell_box(); d["sensor"]["film"]["width"] = 1; d["sensor"]["film"]["height"] = 1
+    img = mi.render(mi.load_dict(d), spp=37, seed=4).cpu().numpy()
+    ref, _ = O.OracleScene(sd).render_path(sensor, seed=4, spp=37, max_depth=8)
+    assert rel_l2(img, ref) < 1e-4
+
+
+def test_render_refuses_more_than_2_32_lanes(mi):
+    """integrator.cpp:276-294 / common.py:358-363: the wavefront index is 32 bit."""
+    d = mi.cornell_box(); d["sensor"]["film"]["width"] = 4096; d["sensor"]["film"]["height"] = 4096
+    scene = mi.load_dict(d)
+    with pytest.raises(Exception, match="2\\^32"):
+        mi.render(scene, spp=1024)

@@ -19,6 +19,7 @@ for P in "${PASSES[@]}"; do
     mem) rocprofv3 --pmc FETCH_SIZE -d ${D}f -o r -- python bench.py --steps 1 --warmup 0 $ARGS > /dev/null 2>&1
          rocprofv3 --pmc WRITE_SIZE -d $D -o r -- python bench.py --steps 1 --warmup 0 $ARGS > /dev/null 2>&1
          python tools/rocpd_summary.py $(find ${D}f -name '*.db') $(find $D -name '*.db') --json $OUT/${TAG}_traffic.json > $OUT/${TAG}_fetch_write.txt 2>&1 ;;
+    sq2) rocprofv3 --pmc SQ_INSTS_VALU SQ_THREAD_CYCLES_VALU SQ_ACTIVE_INST_VALU SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_WAVE_CYCLES SQ_INSTS_SALU -d $D -o r -- python bench.py --steps 1 --warmup 0 $ARGS > $OUT/${TAG}_sq2_bench.log 2>&1 ;;
     tcc) rocprofv3 --pmc TCC_HIT_sum TCC_MISS_sum -d $D -o r -- python bench.py --steps 1 --warmup 0 $ARGS > /dev/null 2>&1 ;;
   esac
   python tools/rocpd_summary.py $(find $D -name '*.db') > $OUT/${TAG}_$P.txt 2>&1
