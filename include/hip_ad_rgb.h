@@ -52,10 +52,32 @@ typedef struct HarInstance {
     float to_object[12];
 } HarInstance;
 
+/* BSDF record.  Colour parameters live in two "slots":
+ *   type 0 diffuse         (src/bsdfs/diffuse.cpp)         slot0 = reflectance
+ *   type 1 dielectric      (src/bsdfs/dielectric.cpp)      slot0 = specular_reflectance, slot1 = specular_transmittance, eta
+ *   type 2 roughconductor  (src/bsdfs/roughconductor.cpp)  slot0 = specular_reflectance, eta_c / k_c (RGB), alpha_u / alpha_v
+ *   type 3 roughplastic    (src/bsdfs/roughplastic.cpp)    slot0 = diffuse_reflectance, slot1 = specular_reflectance, eta, alpha_u
+ * slot0 may be a bitmap texture (`texture` >= 0), slot1 is constant.
+ * flags: bit0 twosided (src/bsdfs/twosided.cpp; `back` = record used for the back side, -1 = the same one),
+ *        bit1 GGX distribution (else Beckmann), bit2 sample_visible, bit3 roughplastic `nonlinear`. */
+#define HAR_BSDF_DIFFUSE        0
+#define HAR_BSDF_DIELECTRIC     1
+#define HAR_BSDF_ROUGHCONDUCTOR 2
+#define HAR_BSDF_ROUGHPLASTIC   3
+#define HAR_BSDF_TWOSIDED       1u
+#define HAR_BSDF_GGX            2u
+#define HAR_BSDF_SAMPLE_VISIBLE 4u
+#define HAR_BSDF_NONLINEAR      8u
 typedef struct HarBSDF {
-    uint32_t type;        /* 0 = diffuse (src/bsdfs/diffuse.cpp) */
-    int32_t  texture;     /* -1: constant `reflectance` (srgb), else bitmap index */
-    float    reflectance[3];
+    uint32_t type;
+    int32_t  texture;     /* -1: constant slot0 (srgb), else bitmap index */
+    float    reflectance[3];          /* slot0 */
+    uint32_t flags;
+    float    reflectance2[3];         /* slot1 */
+    float    alpha_u, alpha_v;
+    float    eta;                     /* int_ior / ext_ior */
+    float    eta_c[3], k_c[3];        /* conductor: real and imaginary part of the relative IOR */
+    int32_t  back;
 } HarBSDF;
 
 /* BitmapTexture, raw H x W x 3 f32, bilinear, repeat (src/textures/bitmap.cpp:175-206). HOST pointer. */
@@ -163,6 +185,10 @@ int har_bsdf_eval_pdf(HarScene scene, uint32_t bsdf, uint32_t n, const float *wi
 int har_bsdf_sample(HarScene scene, uint32_t bsdf, uint32_t n, const float *wi, const float *uv,
                     const float *sample1, const float *sample2 /*[2][n]*/, float *wo /*[3][n]*/,
                     float *pdf, float *weight /*[3][n]*/, void *stream);
+/* as har_bsdf_sample, additionally returns BSDFSample3f::eta and has_flag(sampled_type, Delta) in eta_delta[2][n] */
+int har_bsdf_sample_ex(HarScene scene, uint32_t bsdf, uint32_t n, const float *wi, const float *uv,
+                       const float *sample1, const float *sample2, float *wo, float *pdf, float *weight,
+                       float *eta_delta, void *stream);
 
 /* ------------------------------------------------------------------------
  *  Sensor / film

@@ -32,7 +32,9 @@ class HarInstance(C.Structure):
 
 
 class HarBSDF(C.Structure):
-    _fields_ = [("type", C.c_uint32), ("texture", C.c_int32), ("reflectance", C.c_float * 3)]
+    _fields_ = [("type", C.c_uint32), ("texture", C.c_int32), ("reflectance", C.c_float * 3), ("flags", C.c_uint32),
+                ("reflectance2", C.c_float * 3), ("alpha_u", C.c_float), ("alpha_v", C.c_float), ("eta", C.c_float),
+                ("eta_c", C.c_float * 3), ("k_c", C.c_float * 3), ("back", C.c_int32)]
 
 
 class HarTexture(C.Structure):
@@ -84,6 +86,7 @@ SIGNATURES = {
     "har_sampler_next_2d": (C.c_int, [C.c_uint32, vp, vp, vp, vp, vp]),
     "har_bsdf_eval_pdf": (C.c_int, [vp, C.c_uint32, C.c_uint32, vp, vp, vp, vp, vp, vp]),
     "har_bsdf_sample": (C.c_int, [vp, C.c_uint32, C.c_uint32, vp, vp, vp, vp, vp, vp, vp, vp]),
+    "har_bsdf_sample_ex": (C.c_int, [vp, C.c_uint32, C.c_uint32, vp, vp, vp, vp, vp, vp, vp, vp, vp]),
     "har_sensor_sample_ray": (C.c_int, [C.POINTER(HarSensor), C.c_uint32, vp, vp, vp, vp, vp, vp]),
     "har_film_put": (C.c_int, [C.POINTER(HarSensor), C.c_uint32, vp, vp, vp, vp, vp]),
     "har_film_develop": (C.c_int, [vp, C.c_uint32, C.c_uint32, vp, vp]),

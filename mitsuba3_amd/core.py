@@ -402,21 +402,60 @@ class Sensor:
         return Ray3f(o, d, mt), torch.ones(n, device=dev)
 
 
+# include/mitsuba/render/ior.h:24-48
+_IOR = {"vacuum": 1.0, "helium": 1.000036, "hydrogen": 1.000132, "air": 1.000277, "carbon dioxide": 1.00045, "water": 1.3330,
+        "acetone": 1.36, "ethanol": 1.361, "carbon tetrachloride": 1.461, "glycerol": 1.4729, "benzene": 1.501, "silicone oil": 1.52045,
+        "bromine": 1.661, "water ice": 1.31, "fused quartz": 1.458, "pyrex": 1.470, "acrylic glass": 1.49, "polypropylene": 1.49,
+        "bk7": 1.5046, "sodium chloride": 1.544, "amber": 1.55, "pet": 1.5750, "diamond": 2.419}
+
+
+def _lookup_ior(props, name, default):
+    v = props.get(name, default)
+    if isinstance(v, str):
+        if v.lower() not in _IOR:
+            raise RuntimeError("Could not find a material named \"%s\"" % v)
+        return float(_IOR[v.lower()])
+    return float(v)
+
+
+def _rgb_value(v, default, bounded=True):
+    """Properties colour value: float, list or {'type': 'rgb', 'value': ...} -> float32[3]"""
+    if v is None:
+        v = default
+    if isinstance(v, dict):
+        if v.get('type') != 'rgb':
+            raise RuntimeError("only `rgb` values are implemented for this parameter")
+        v = v['value']
+    out = _f32([v] * 3 if np.isscalar(v) else list(v))
+    if bounded and (np.any(out < 0) or np.any(out > 1)):
+        raise RuntimeError("Invalid RGB reflectance value %s, must be in the range [0, 1]!" % out)
+    return out
+
+
+BSDF_TYPES = {'diffuse': 0, 'dielectric': 1, 'roughconductor': 2, 'roughplastic': 3}
+# (parameter name of slot 0, default), (parameter name of slot 1, default)
+_BSDF_SLOTS = {'diffuse': (('reflectance', 0.5), None), 'dielectric': (('specular_reflectance', 1.0), ('specular_transmittance', 1.0)),
+               'roughconductor': (('specular_reflectance', 1.0), None), 'roughplastic': (('diffuse_reflectance', 0.5), ('specular_reflectance', 1.0))}
+
+
 class BSDF:
-    """SmoothDiffuse (src/bsdfs/diffuse.cpp) with an `rgb` or raw `bitmap` reflectance."""
+    """diffuse / dielectric / roughconductor / roughplastic (src/bsdfs/*.cpp), optionally wrapped by `twosided`.
+    Colour parameters live in two slots (include/hip_ad_rgb.h HarBSDF); slot 0 may be a raw `bitmap`."""
 
     def __init__(self, props=None, id=None):
         props = props or {}
         self.id = id
-        refl = props.get('reflectance', {'type': 'rgb', 'value': [0.5, 0.5, 0.5]})
+        self.kind = props.get('type', 'diffuse')
+        if self.kind not in BSDF_TYPES:
+            raise RuntimeError("Plugin \"%s\" not found for variant hip_ad_rgb" % self.kind)
+        (name0, def0), slot1 = _BSDF_SLOTS[self.kind]
+        self.slot0_name = name0; self.slot1_name = slot1[0] if slot1 else None
+        refl = props.get(name0, {'type': 'rgb', 'value': [def0] * 3})
         if isinstance(refl, (int, float)):
             refl = {'type': 'rgb', 'value': [refl] * 3}
         self.texture = None
         if refl['type'] == 'rgb':
-            v = refl['value']; v = [v] * 3 if np.isscalar(v) else list(v)
-            self.value = _f32(v)
-            if np.any(self.value < 0) or np.any(self.value > 1):
-                raise RuntimeError("Invalid RGB reflectance value %s, must be in the range [0, 1]!" % self.value)
+            self.value = _rgb_value(refl, def0)
         elif refl['type'] == 'bitmap':
             if 'data' not in refl:
                 raise RuntimeError("bitmap: hip_ad_rgb needs the texel array under 'data' (file loading is out of scope)")
@@ -431,6 +470,40 @@ class BSDF:
             self.value = _f32([0.5, 0.5, 0.5])
         else:
             raise RuntimeError("Plugin \"%s\" not found for variant hip_ad_rgb (textures: rgb, bitmap)" % refl['type'])
+        self.value2 = _rgb_value(props.get(slot1[0]), slot1[1]) if slot1 else _f32([0, 0, 0])
+        self.flags = 0; self.alpha_u = self.alpha_v = 0.1; self.eta = 1.0
+        self.eta_c = _f32([0, 0, 0]); self.k_c = _f32([1, 1, 1]); self.back = None
+        if self.kind in ('roughconductor', 'roughplastic'):          # MicrofacetDistribution(props), microfacet.h:103-144
+            distr = str(props.get('distribution', 'beckmann')).lower()
+            if distr not in ('beckmann', 'ggx'):
+                raise RuntimeError("Specified an invalid distribution \"%s\", must be \"beckmann\" or \"ggx\"!" % distr)
+            if distr == 'ggx':
+                self.flags |= 2
+            if props.get('sample_visible', True):
+                self.flags |= 4
+            if 'alpha_u' in props or 'alpha_v' in props:
+                if not ('alpha_u' in props and 'alpha_v' in props):
+                    raise RuntimeError("Microfacet model: both 'alpha_u' and 'alpha_v' must be specified.")
+                if 'alpha' in props:
+                    raise RuntimeError("Microfacet model: please specifyeither 'alpha' or 'alpha_u'/'alpha_v'.")
+                self.alpha_u = float(props['alpha_u']); self.alpha_v = float(props['alpha_v'])
+            else:
+                self.alpha_u = self.alpha_v = float(props.get('alpha', 0.1))
+        if self.kind == 'roughconductor':                            # roughconductor.cpp:163-172
+            if props.get('material', 'none') != 'none':
+                raise RuntimeError("roughconductor: `material` presets need the spectral IOR data files, give (eta, k) instead")
+            self.eta_c = _rgb_value(props.get('eta'), 0.0, bounded=False); self.k_c = _rgb_value(props.get('k'), 1.0, bounded=False)
+        if self.kind in ('dielectric', 'roughplastic'):
+            int_ior = _lookup_ior(props, 'int_ior', 'bk7' if self.kind == 'dielectric' else 'polypropylene')
+            ext_ior = _lookup_ior(props, 'ext_ior', 'air')
+            if int_ior < 0 or ext_ior < 0 or (self.kind == 'roughplastic' and int_ior == ext_ior):
+                raise RuntimeError("The interior and exterior indices of refraction must be positive" + (" and differ!" if self.kind == 'roughplastic' else "!"))
+            self.eta = float(np.float32(int_ior) / np.float32(ext_ior))
+            if self.kind == 'roughplastic':
+                if self.alpha_u != self.alpha_v:
+                    raise RuntimeError("The 'roughplastic' plugin currently does not support anisotropic microfacet distributions!")
+                if props.get('nonlinear', False):
+                    self.flags |= 8
         self.scene = None; self.index = None
 
     def _bind(self):
@@ -464,9 +537,36 @@ class BSDF:
         s2 = torch.as_tensor(sample2, dtype=torch.float32, device=dev).reshape(2, -1).contiguous(); n = s2.shape[1]
         wi, uv = self._prep(si.wi, getattr(si, 'uv', None), n)
         wo = torch.empty((3, n), dtype=torch.float32, device=dev); pdf = torch.empty(n, dtype=torch.float32, device=dev); w = torch.empty_like(wo)
-        check(lib().har_bsdf_sample(h, idx, n, _ptr(wi), _ptr(uv), C.c_void_p(0), _ptr(s2), _ptr(wo), _ptr(pdf), _ptr(w), _stream()))
-        bs = type("BSDFSample3f", (), dict(wo=wo, pdf=pdf, eta=torch.ones(n, device=dev), sampled_type=2, sampled_component=0))()
+        s1 = torch.as_tensor(sample1, dtype=torch.float32, device=dev).reshape(-1)
+        s1 = (s1.expand(n) if s1.numel() != n else s1).contiguous()
+        ed = torch.empty((2, n), dtype=torch.float32, device=dev)
+        check(lib().har_bsdf_sample_ex(h, idx, n, _ptr(wi), _ptr(uv), _ptr(s1), _ptr(s2), _ptr(wo), _ptr(pdf), _ptr(w), _ptr(ed), _stream()))
+        bs = type("BSDFSample3f", (), dict(wo=wo, pdf=pdf, eta=ed[0], delta=ed[1] > 0))()
         return bs, w
+
+
+def _mk_twosided(props, named, key):
+    """TwoSidedBRDF (src/bsdfs/twosided.cpp:70-110): one or two nested BSDFs without a transmission component."""
+    nested = []
+    for k, v in props.items():
+        if k == 'type':
+            continue
+        obj = _resolve(v, named, k) if isinstance(v, dict) else v
+        if isinstance(obj, BSDF):
+            nested.append(obj)
+    if not nested or len(nested) > 2:
+        raise RuntimeError("twosided: a maximum of two nested BSDFs can be specified (and at least one)!")
+    for b in nested:
+        if b.kind == 'dielectric':
+            raise RuntimeError("Only materials without a transmission component can be nested!")
+    front = nested[0]
+    if front.flags & 1:
+        raise RuntimeError("twosided: nested BSDF is already two-sided")
+    front.flags |= 1; front.id = front.id or key
+    front.back = nested[1] if len(nested) == 2 and nested[1] is not nested[0] else None
+    if key:
+        front.id = key
+    return front
 
 
 class ShapeGroup:
@@ -646,6 +746,8 @@ class Scene:
         if b.texture is not None:
             b.tex_index = len(self.textures); self.textures.append(b.texture)
         self.bsdf_objs.append(b)
+        if getattr(b, 'back', None) is not None:
+            self._add_bsdf(b.back)
         return b.index
 
     @property
@@ -682,8 +784,12 @@ class Scene:
             insts[i].to_world = (C.c_float * 12)(*[float(x) for x in tw]); insts[i].to_object = (C.c_float * 12)(*[float(x) for x in to])
         bsdfs = (M.HarBSDF * max(1, len(self.bsdf_objs)))()
         for i, b in enumerate(self.bsdf_objs):
-            bsdfs[i].type = 0; bsdfs[i].texture = b.tex_index if b.texture is not None else -1
+            bsdfs[i].type = BSDF_TYPES[b.kind]; bsdfs[i].texture = b.tex_index if b.texture is not None else -1
             bsdfs[i].reflectance = (C.c_float * 3)(*[float(x) for x in b.value])
+            bsdfs[i].flags = b.flags; bsdfs[i].reflectance2 = (C.c_float * 3)(*[float(x) for x in b.value2])
+            bsdfs[i].alpha_u = b.alpha_u; bsdfs[i].alpha_v = b.alpha_v; bsdfs[i].eta = b.eta
+            bsdfs[i].eta_c = (C.c_float * 3)(*[float(x) for x in b.eta_c]); bsdfs[i].k_c = (C.c_float * 3)(*[float(x) for x in b.k_c])
+            bsdfs[i].back = b.back.index if b.back is not None else -1
         texs = (M.HarTexture * max(1, len(self.textures)))()
         for i, t in enumerate(self.textures):
             texs[i].data = _fp(t); texs[i].height = t.shape[0]; texs[i].width = t.shape[1]
@@ -769,9 +875,9 @@ class Scene:
         for b in self.bsdf_objs:
             base = b.id if b.id else "bsdf%d" % b.index
             if b.texture is not None:
-                keys[base + ".reflectance.data"] = ("tex", b)
+                keys[base + "." + b.slot0_name + ".data"] = ("tex", b)
             else:
-                keys[base + ".reflectance.value"] = ("rgb", b)
+                keys[base + "." + b.slot0_name + ".value"] = ("rgb", b)
         return keys
 
     def _gradients(self, g_refl, g_tex):
@@ -817,6 +923,7 @@ def traverse(scene):
 # ---------------------------------------------------------------------------
 
 _REGISTRY = {}
+_BSDF_PLUGINS = ('diffuse', 'dielectric', 'roughconductor', 'roughplastic', 'twosided')
 
 
 def register_plugin(name, variant_name, instantiate):
@@ -844,7 +951,7 @@ def _create(props, named, key=None):
 
 def _shape_common(m, props, named):
     for k, v in props.items():
-        if isinstance(v, dict) and v.get('type') in ('ref',) or isinstance(v, dict) and v.get('type') in ('diffuse',):
+        if isinstance(v, dict) and v.get('type') in ('ref',) or isinstance(v, dict) and v.get('type') in _BSDF_PLUGINS:
             obj = _resolve(v, named, k)
             if isinstance(obj, BSDF):
                 m.bsdf = obj
@@ -865,7 +972,7 @@ def _mk_scene(props, named, key):
     for k, v in props.items():
         if k == 'type':
             continue
-        if isinstance(v, dict) and v.get('type') == 'diffuse':
+        if isinstance(v, dict) and v.get('type') in _BSDF_PLUGINS:
             named[k] = _create(v, named, k); children[k] = named[k]
     for k, v in props.items():
         if k == 'type' or k in children:
@@ -920,7 +1027,8 @@ for _name, _fn in {
     'perspective': lambda p, n, k: Sensor({kk: (_resolve(v, n, kk) if isinstance(v, dict) and v.get('type') in ('hdrfilm', 'independent') else v) for kk, v in p.items()}),
     'hdrfilm': lambda p, n, k: Film(p),
     'independent': lambda p, n, k: Sampler(p),
-    'diffuse': lambda p, n, k: BSDF(p, id=k),
+    'diffuse': lambda p, n, k: BSDF(p, id=k), 'dielectric': lambda p, n, k: BSDF(p, id=k), 'roughconductor': lambda p, n, k: BSDF(p, id=k),
+    'roughplastic': lambda p, n, k: BSDF(p, id=k), 'twosided': _mk_twosided,
     'rectangle': lambda p, n, k: _shape_common(_rectangle(p), p, n),
     'cube': lambda p, n, k: _shape_common(_cube(p), p, n),
     'mesh': _mk_mesh,

@@ -1,0 +1,319 @@
+/*
+ * har_bsdf.h -- BSDF models of the hip_ad_rgb path (HAR_HD: HIP kernels + host test harness).
+ *
+ *   type 0  diffuse          src/bsdfs/diffuse.cpp:100-179
+ *   type 1  dielectric       src/bsdfs/dielectric.cpp:245-353           (delta reflection / transmission)
+ *   type 2  roughconductor   src/bsdfs/roughconductor.cpp:226-520       (Beckmann / GGX microfacet, conductor Fresnel)
+ *   type 3  roughplastic     src/bsdfs/roughplastic.cpp:244-420         (rough dielectric coating over a diffuse base)
+ *   flag    twosided         src/bsdfs/twosided.cpp:112-270             (one nested BSDF, or a different one on the back)
+ *
+ * plus include/mitsuba/render/fresnel.h:35-91 (fresnel), :93-116 (fresnel_conductor), :276-313 (reflect / refract)
+ * and  include/mitsuba/render/microfacet.h:185-421 (MicrofacetDistribution eval / pdf / sample / smith_g1).
+ *
+ * Every model returns f * cos(theta_o) like the reference.  `d_slot0` / `d_slot1` of an evaluation are the
+ * per-channel derivatives of that value with respect to the BSDF's two colour parameters ("slots", see DBsdf),
+ * which is all the hand-derived PRB adjoint needs (SURVEY.md App. B generalised): delta lobes evaluate to zero,
+ * so -- exactly as in prb.py:288-297 -- they carry no parameter gradient.
+ */
+#pragma once
+#include "har_math.h"
+
+namespace har {
+
+enum { BSDF_DIFFUSE = 0, BSDF_DIELECTRIC = 1, BSDF_ROUGHCONDUCTOR = 2, BSDF_ROUGHPLASTIC = 3 };
+enum { BF_TWOSIDED = 1u, BF_GGX = 2u, BF_SAMPLE_VISIBLE = 4u, BF_NONLINEAR = 8u };
+#define HAR_ROUGH_TRANSMITTANCE_RES 64          /* MI_ROUGH_TRANSMITTANCE_RES, include/mitsuba/render/microfacet.h */
+
+/* colour parameter slots: slot 0 = diffuse.reflectance | roughconductor.specular_reflectance |
+ * roughplastic.diffuse_reflectance | dielectric.specular_reflectance (may be a bitmap texture);
+ * slot 1 = roughplastic.specular_reflectance | dielectric.specular_transmittance (constant) */
+struct DBsdf {
+    uint32_t type; int32_t texture; float r, g, b;
+    uint32_t flags;
+    float r2, g2, b2;
+    float alpha_u, alpha_v, eta;
+    float eta_c[3], k_c[3];
+    int32_t back;                 /* twosided: BSDF record of the back side (-1: the same record) */
+    int32_t table;                /* roughplastic: offset of its 64-entry external transmittance table, else -1 */
+    float inv_eta_2, internal_reflectance, spec_sampling_weight;
+    uint32_t pad;
+};
+static_assert(sizeof(DBsdf) == 96, "DBsdf layout");
+
+struct BsdfEval { Vec3 value; float pdf; Vec3 d_slot0, d_slot1; };
+struct BsdfSample { Vec3 wo; float pdf; Vec3 weight; float eta; bool delta; };
+
+HAR_HD float safe_sqrt_(float x) { return sqrtf(fmaxf(x, 0.f)); }
+HAR_HD float lerp_(float a, float b, float t) { return fma_(b, t, fnma_(a, t, a)); }        /* dr::lerp */
+
+/* fresnel(), fresnel.h:35-91 */
+HAR_HD void fresnel_dielectric(float cos_theta_i, float eta, float &r, float &cos_theta_t, float &eta_it, float &eta_ti) {
+    bool outside = cos_theta_i >= 0.f;
+    float rcp_eta = rcp_(eta);
+    eta_it = outside ? eta : rcp_eta; eta_ti = outside ? rcp_eta : eta;
+    float cos_theta_t_sqr = fnma_(fnma_(cos_theta_i, cos_theta_i, 1.f), eta_ti * eta_ti, 1.f);
+    float cos_theta_i_abs = fabsf(cos_theta_i), cos_theta_t_abs = safe_sqrt_(cos_theta_t_sqr);
+    bool index_matched = eta == 1.f, special_case = index_matched || cos_theta_i_abs == 0.f;
+    float r_sc = index_matched ? 0.f : 1.f;
+    float a_s = fnma_(eta_it, cos_theta_t_abs, cos_theta_i_abs) / fma_(eta_it, cos_theta_t_abs, cos_theta_i_abs);
+    float a_p = fnma_(eta_it, cos_theta_i_abs, cos_theta_t_abs) / fma_(eta_it, cos_theta_i_abs, cos_theta_t_abs);
+    r = 0.5f * (sqr_(a_s) + sqr_(a_p));
+    if (special_case) r = r_sc;
+    cos_theta_t = mulsign_neg_(cos_theta_t_abs, cos_theta_i);
+}
+
+/* fresnel_conductor(), fresnel.h:93-116 */
+HAR_HD float fresnel_conductor(float cos_theta_i, float eta_r, float eta_i) {
+    float cos_theta_i_2 = cos_theta_i * cos_theta_i, sin_theta_i_2 = 1.f - cos_theta_i_2, sin_theta_i_4 = sin_theta_i_2 * sin_theta_i_2;
+    float temp_1 = eta_r * eta_r - eta_i * eta_i - sin_theta_i_2;
+    float a_2_pb_2 = safe_sqrt_(temp_1 * temp_1 + 4.f * eta_i * eta_i * eta_r * eta_r);
+    float a = safe_sqrt_(.5f * (a_2_pb_2 + temp_1));
+    float term_1 = a_2_pb_2 + cos_theta_i_2, term_2 = 2.f * cos_theta_i * a;
+    float r_s = (term_1 - term_2) / (term_1 + term_2);
+    float term_3 = a_2_pb_2 * cos_theta_i_2 + sin_theta_i_4, term_4 = term_2 * sin_theta_i_2;
+    float r_p = r_s * (term_3 - term_4) / (term_3 + term_4);
+    return 0.5f * (r_s + r_p);
+}
+
+HAR_HD Vec3 reflect_local(Vec3 wi) { return Vec3(-wi.x, -wi.y, wi.z); }                                        /* fresnel.h:276 */
+HAR_HD Vec3 reflect_m(Vec3 wi, Vec3 m) { float k = 2.f * dot3(wi, m); return Vec3(fms_(m.x, k, wi.x), fms_(m.y, k, wi.y), fms_(m.z, k, wi.z)); }   /* :282 */
+HAR_HD Vec3 refract_local(Vec3 wi, float cos_theta_t, float eta_ti) { return Vec3(-eta_ti * wi.x, -eta_ti * wi.y, cos_theta_t); }                   /* :293 */
+HAR_HD Vec3 refract_m(Vec3 wi, Vec3 m, float cos_theta_t, float eta_ti) {                                                                            /* :311 */
+    float k = fma_(dot3(wi, m), eta_ti, cos_theta_t);
+    return Vec3(fms_(m.x, k, wi.x * eta_ti), fms_(m.y, k, wi.y * eta_ti), fms_(m.z, k, wi.z * eta_ti));
+}
+
+/* erfinv, single precision (M. Giles, "Approximating the erfinv function"); dr::erfinv is NOT IN TREE (parity unpinned) */
+HAR_HD float erfinv_(float x) {
+    float w = -logf((1.f - x) * (1.f + x)), p;
+    if (w < 5.f) {
+        w = w - 2.5f;
+        p = 2.81022636e-08f; p = fma_(p, w, 3.43273939e-07f); p = fma_(p, w, -3.5233877e-06f); p = fma_(p, w, -4.39150654e-06f);
+        p = fma_(p, w, 0.00021858087f); p = fma_(p, w, -0.00125372503f); p = fma_(p, w, -0.00417768164f); p = fma_(p, w, 0.246640727f);
+        p = fma_(p, w, 1.50140941f);
+    } else {
+        w = sqrtf(w) - 3.f;
+        p = -0.000200214257f; p = fma_(p, w, 0.000100950558f); p = fma_(p, w, 0.00134934322f); p = fma_(p, w, -0.00367342844f);
+        p = fma_(p, w, 0.00573950773f); p = fma_(p, w, -0.0076224613f); p = fma_(p, w, 0.00943887047f); p = fma_(p, w, 1.00167406f);
+        p = fma_(p, w, 2.83297682f);
+    }
+    return p * x;
+}
+
+/* MicrofacetDistribution, microfacet.h:64-447 */
+struct Microfacet {
+    bool ggx, sample_visible; float alpha_u, alpha_v;
+    HAR_HD Microfacet(bool g, float au, float av, bool sv) : ggx(g), sample_visible(sv), alpha_u(fmaxf(au, 1e-4f)), alpha_v(fmaxf(av, 1e-4f)) {}
+
+    HAR_HD float eval(Vec3 m) const {                                                  /* :185-207 */
+        float alpha_uv = alpha_u * alpha_v, cos_theta = m.z, cos_theta_2 = sqr_(cos_theta), result;
+        if (!ggx) result = expf(-(sqr_(m.x / alpha_u) + sqr_(m.y / alpha_v)) / cos_theta_2) / (HAR_PI * alpha_uv * sqr_(cos_theta_2));
+        else      result = rcp_(HAR_PI * alpha_uv * sqr_(sqr_(m.x / alpha_u) + sqr_(m.y / alpha_v) + sqr_(m.z)));
+        return result * cos_theta > 1e-20f ? result : 0.f;
+    }
+    HAR_HD float smith_g1(Vec3 v, Vec3 m) const {                                      /* :341-365 */
+        float xy_alpha_2 = sqr_(alpha_u * v.x) + sqr_(alpha_v * v.y), tan_theta_alpha_2 = xy_alpha_2 / sqr_(v.z), result;
+        if (!ggx) {
+            float a = rsqrt_(tan_theta_alpha_2), a_sqr = sqr_(a);
+            result = a >= 1.6f ? 1.f : (3.535f * a + 2.181f * a_sqr) / (1.f + 2.276f * a + 2.577f * a_sqr);
+        } else result = 2.f / (1.f + sqrtf(1.f + tan_theta_alpha_2));
+        if (xy_alpha_2 == 0.f) result = 1.f;
+        if (dot3(v, m) * v.z <= 0.f) result = 0.f;
+        return result;
+    }
+    HAR_HD float G(Vec3 wi, Vec3 wo, Vec3 m) const { return smith_g1(wi, m) * smith_g1(wo, m); }
+    HAR_HD float pdf(Vec3 wi, Vec3 m) const {                                          /* :219-228 */
+        float result = eval(m);
+        if (sample_visible) result *= smith_g1(wi, m) * fabsf(dot3(wi, m)) / wi.z; else result *= m.z;
+        return result;
+    }
+    HAR_HD void sample_visible_11(float cos_theta_i, float sx, float sy, float &slope_x, float &slope_y) const {   /* :368-421 */
+        if (!ggx) {
+            float tan_theta_i = safe_sqrt_(fnma_(cos_theta_i, cos_theta_i, 1.f)) / cos_theta_i, cot_theta_i = rcp_(tan_theta_i);
+            float maxval = erff(cot_theta_i);
+            sx = fmaxf(fminf(sx, 1.f - 1e-6f), 1e-6f); sy = fmaxf(fminf(sy, 1.f - 1e-6f), 1e-6f);
+            float x = maxval - (maxval + 1.f) * erff(sqrtf(-logf(sx)));
+            sx *= 1.f + maxval + 0.56418958354775628695f * tan_theta_i * expf(-sqr_(cot_theta_i));
+            for (int i = 0; i < 3; ++i) {
+                float slope = erfinv_(x), value = 1.f + x + 0.56418958354775628695f * tan_theta_i * expf(-sqr_(slope)) - sx, derivative = 1.f - slope * tan_theta_i;
+                x -= value / derivative;
+            }
+            slope_x = erfinv_(x); slope_y = erfinv_(fms_(2.f, sy, 1.f));
+        } else {
+            /* warp::square_to_uniform_disk_concentric, warp.h:54-90 */
+            float x = fms_(2.f, sx, 1.f), y = fms_(2.f, sy, 1.f);
+            bool is_zero = x == 0.f && y == 0.f, q13 = fabsf(x) < fabsf(y);
+            float r = q13 ? y : x, rp = q13 ? x : y, phi = 0.25f * HAR_PI * rp / r;
+            if (q13) phi = 0.5f * HAR_PI - phi;
+            if (is_zero) phi = 0.f;
+            float s, c; sincos_(phi, s, c);
+            float px = r * c, py = r * s;
+            float sc = 0.5f * (1.f + cos_theta_i);
+            py = lerp_(safe_sqrt_(1.f - sqr_(px)), py, sc);
+            float z = safe_sqrt_(1.f - fma_(py, py, px * px));
+            float sin_theta_i = safe_sqrt_(1.f - sqr_(cos_theta_i));
+            float norm = rcp_(fma_(sin_theta_i, py, cos_theta_i * z));
+            slope_x = fms_(cos_theta_i, py, sin_theta_i * z) * norm; slope_y = px * norm;
+        }
+    }
+    HAR_HD Vec3 sample(Vec3 wi, float sx, float sy, float &pdf_out) const {            /* :244-326 */
+        if (!sample_visible) {
+            float sin_phi, cos_phi, cos_theta, cos_theta_2, alpha_2;
+            if (alpha_u == alpha_v) { sincos_((2.f * HAR_PI) * sy, sin_phi, cos_phi); alpha_2 = alpha_u * alpha_u; }
+            else {
+                float ratio = alpha_v / alpha_u, tmp = ratio * tanf((2.f * HAR_PI) * sy);
+                cos_phi = rsqrt_(fma_(tmp, tmp, 1.f)); cos_phi = mulsign_(cos_phi, fabsf(sy - .5f) - .25f);
+                sin_phi = cos_phi * tmp;
+                alpha_2 = rcp_(sqr_(cos_phi / alpha_u) + sqr_(sin_phi / alpha_v));
+            }
+            if (!ggx) {
+                cos_theta = rsqrt_(fnma_(alpha_2, logf(1.f - sx), 1.f)); cos_theta_2 = sqr_(cos_theta);
+                float cos_theta_3 = fmaxf(cos_theta_2 * cos_theta, 1e-20f);
+                pdf_out = (1.f - sx) / (HAR_PI * alpha_u * alpha_v * cos_theta_3);
+            } else {
+                float tan_theta_m_2 = alpha_2 * sx / (1.f - sx);
+                cos_theta = rsqrt_(1.f + tan_theta_m_2); cos_theta_2 = sqr_(cos_theta);
+                float temp = 1.f + tan_theta_m_2 / alpha_2, cos_theta_3 = fmaxf(cos_theta_2 * cos_theta, 1e-20f);
+                pdf_out = rcp_(HAR_PI * alpha_u * alpha_v * cos_theta_3 * sqr_(temp));
+            }
+            float sin_theta = sqrtf(1.f - cos_theta_2);
+            return Vec3(cos_phi * sin_theta, sin_phi * sin_theta, cos_theta);
+        }
+        Vec3 wi_p = normalize3(Vec3(alpha_u * wi.x, alpha_v * wi.y, wi.z));
+        /* Frame3f::sincos_phi, frame.h:103-117 */
+        float sin_theta_2 = fma_(wi_p.x, wi_p.x, wi_p.y * wi_p.y), inv_sin_theta = rsqrt_(sin_theta_2);
+        float cos_phi = fminf(fmaxf(wi_p.x * inv_sin_theta, -1.f), 1.f), sin_phi = fminf(fmaxf(wi_p.y * inv_sin_theta, -1.f), 1.f);
+        if (fabsf(sin_theta_2) <= 4.f * 5.9604644775390625e-8f) { sin_phi = 0.f; cos_phi = 1.f; }
+        float slx, sly; sample_visible_11(wi_p.z, sx, sy, slx, sly);
+        float s0 = fms_(cos_phi, slx, sin_phi * sly) * alpha_u, s1 = fma_(sin_phi, slx, cos_phi * sly) * alpha_v;
+        Vec3 m = normalize3(Vec3(-s0, -s1, 1.f));
+        pdf_out = eval(m) * smith_g1(wi, m) * fabsf(dot3(wi, m)) / wi.z;
+        return m;
+    }
+};
+
+/* lerp_gather, roughplastic.cpp:338-349 */
+HAR_HD float lerp_gather(const float *data, float x, uint32_t size) {
+    x *= (float) (size - 1);
+    uint32_t index = (uint32_t) x; if (index > size - 2) index = size - 2;
+    float v0 = data[index], v1 = data[index + 1];
+    return lerp_(v0, v1, x - (float) index);
+}
+
+struct BsdfInputs { Vec3 slot0, slot1; const float *table; };       /* evaluated colour parameters + roughplastic table */
+
+HAR_HD bool bsdf_is_smooth(const DBsdf &B) { return B.type != BSDF_DIELECTRIC; }          /* BSDFFlags::Smooth */
+
+/* TYPES = bit mask of the BSDF types a scene contains (1 << type): the shading kernels are specialised for
+ * diffuse-only scenes, where the other models (and their registers) compile out */
+#define HAR_BSDF_ALL_TYPES 0xfu
+#define HAR_BSDF_ONLY_DIFFUSE 0x1u
+
+/* eval_pdf of one (not twosided) record: value = f * cos(theta_o) */
+template <uint32_t TYPES = HAR_BSDF_ALL_TYPES>
+HAR_HD void bsdf_eval_pdf_one(const DBsdf &B, const BsdfInputs &in, Vec3 wi, Vec3 wo, BsdfEval &e) {
+    e.value = Vec3(0.f); e.pdf = 0.f; e.d_slot0 = Vec3(0.f); e.d_slot1 = Vec3(0.f);
+    float cos_theta_i = wi.z, cos_theta_o = wo.z;
+    const uint32_t type = TYPES == HAR_BSDF_ONLY_DIFFUSE ? (uint32_t) BSDF_DIFFUSE : B.type;
+    switch (type) {
+    case BSDF_DIFFUSE: {                                                     /* diffuse.cpp:159-179 */
+        if (!(cos_theta_i > 0.f && cos_theta_o > 0.f)) return;
+        float k = HAR_INV_PI * cos_theta_o;
+        e.value = (in.slot0 * HAR_INV_PI) * cos_theta_o; e.pdf = k; e.d_slot0 = Vec3(k);
+    } break;
+    case BSDF_DIELECTRIC: break;                                             /* dielectric.cpp:340-348: delta lobes */
+    case BSDF_ROUGHCONDUCTOR: {                                              /* roughconductor.cpp:429-520 */
+        Vec3 H = normalize3(wo + wi);
+        if (!(cos_theta_i > 0.f && cos_theta_o > 0.f && dot3(wi, H) > 0.f && dot3(wo, H) > 0.f)) return;
+        Microfacet distr((B.flags & BF_GGX) != 0, B.alpha_u, B.alpha_v, (B.flags & BF_SAMPLE_VISIBLE) != 0);
+        float D = distr.eval(H);
+        bool active = D != 0.f;
+        float smith_g1_wi = distr.smith_g1(wi, H), G = smith_g1_wi * distr.smith_g1(wo, H);
+        float value = D * G / (4.f * cos_theta_i);
+        float c = dot3(wi, H);
+        Vec3 F(fresnel_conductor(c, B.eta_c[0], B.k_c[0]), fresnel_conductor(c, B.eta_c[1], B.k_c[1]), fresnel_conductor(c, B.eta_c[2], B.k_c[2]));
+        float pdf = distr.sample_visible ? D * smith_g1_wi / (4.f * cos_theta_i) : distr.pdf(wi, H) / (4.f * dot3(wo, H));
+        if (active) { e.d_slot0 = F * value; e.value = e.d_slot0 * in.slot0; }
+        e.pdf = pdf;
+    } break;
+    case BSDF_ROUGHPLASTIC: {                                                /* roughplastic.cpp:296-336 (eval), :351-395 (pdf) */
+        if (!(cos_theta_i > 0.f && cos_theta_o > 0.f)) return;
+        Microfacet distr((B.flags & BF_GGX) != 0, B.alpha_u, B.alpha_u, (B.flags & BF_SAMPLE_VISIBLE) != 0);
+        Vec3 H = normalize3(wo + wi);
+        float D = distr.eval(H);
+        float F, ct, eit, eti; fresnel_dielectric(dot3(wi, H), B.eta, F, ct, eit, eti);
+        float G = distr.G(wi, wo, H);
+        float spec = F * D * G / (4.f * cos_theta_i);
+        float t_i = lerp_gather(in.table, cos_theta_i, HAR_ROUGH_TRANSMITTANCE_RES), t_o = lerp_gather(in.table, cos_theta_o, HAR_ROUGH_TRANSMITTANCE_RES);
+        const bool nonlinear = (B.flags & BF_NONLINEAR) != 0;
+        Vec3 den = nonlinear ? Vec3(1.f) - in.slot0 * B.internal_reflectance : Vec3(1.f - B.internal_reflectance);
+        Vec3 diff(in.slot0.x / den.x, in.slot0.y / den.y, in.slot0.z / den.z);
+        float k = HAR_INV_PI * B.inv_eta_2 * cos_theta_o * t_i * t_o;
+        e.value = in.slot1 * spec + diff * k;
+        e.d_slot1 = Vec3(spec);
+        e.d_slot0 = nonlinear ? Vec3(k / (den.x * den.x), k / (den.y * den.y), k / (den.z * den.z)) : Vec3(k / den.x, k / den.y, k / den.z);
+        float prob_specular = (1.f - t_i) * B.spec_sampling_weight, prob_diffuse = t_i * (1.f - B.spec_sampling_weight);
+        prob_specular = prob_specular / (prob_specular + prob_diffuse); prob_diffuse = 1.f - prob_specular;
+        float result = distr.sample_visible ? D * distr.smith_g1(wi, H) / (4.f * cos_theta_i) : distr.pdf(wi, H) / (4.f * dot3(wo, H));
+        result *= prob_specular;
+        result += prob_diffuse * (HAR_INV_PI * cos_theta_o);
+        e.pdf = result;
+    } break;
+    }
+}
+
+/* sample of one (not twosided) record */
+template <uint32_t TYPES = HAR_BSDF_ALL_TYPES>
+HAR_HD void bsdf_sample_one(const DBsdf &B, const BsdfInputs &in, Vec3 wi, float sample1, float s2x, float s2y, BsdfSample &bs) {
+    bs.wo = Vec3(0.f); bs.pdf = 0.f; bs.weight = Vec3(0.f); bs.eta = 0.f; bs.delta = false;     /* dr::zeros<BSDFSample3f>() */
+    float cos_theta_i = wi.z;
+    const uint32_t type = TYPES == HAR_BSDF_ONLY_DIFFUSE ? (uint32_t) BSDF_DIFFUSE : B.type;
+    switch (type) {
+    case BSDF_DIFFUSE: {                                                     /* diffuse.cpp:100-124 */
+        bs.wo = square_to_cosine_hemisphere(s2x, s2y);
+        bs.pdf = HAR_INV_PI * bs.wo.z; bs.eta = 1.f;
+        bs.weight = (cos_theta_i > 0.f && bs.pdf > 0.f) ? in.slot0 : Vec3(0.f);
+    } break;
+    case BSDF_DIELECTRIC: {                                                  /* dielectric.cpp:245-338, TransportMode::Radiance */
+        float r_i, cos_theta_t, eta_it, eta_ti; fresnel_dielectric(cos_theta_i, B.eta, r_i, cos_theta_t, eta_it, eta_ti);
+        float t_i = 1.f - r_i;
+        bool selected_r = sample1 <= r_i;
+        bs.pdf = selected_r ? r_i : t_i;
+        bs.delta = true;
+        bs.wo = selected_r ? reflect_local(wi) : refract_local(wi, cos_theta_t, eta_ti);
+        bs.eta = selected_r ? 1.f : eta_it;
+        bs.weight = selected_r ? in.slot0 : in.slot1 * sqr_(eta_ti);
+    } break;
+    case BSDF_ROUGHCONDUCTOR: {                                              /* roughconductor.cpp:226-320 */
+        if (!(cos_theta_i > 0.f)) return;
+        Microfacet distr((B.flags & BF_GGX) != 0, B.alpha_u, B.alpha_v, (B.flags & BF_SAMPLE_VISIBLE) != 0);
+        float pdf; Vec3 m = distr.sample(wi, s2x, s2y, pdf);
+        bs.wo = reflect_m(wi, m); bs.eta = 1.f; bs.pdf = pdf;
+        bool active = pdf != 0.f && bs.wo.z > 0.f;
+        float weight = distr.sample_visible ? distr.smith_g1(bs.wo, m) : distr.G(wi, bs.wo, m) * dot3(wi, m) / (cos_theta_i * m.z);
+        bs.pdf /= 4.f * dot3(bs.wo, m);
+        float c = dot3(wi, m);
+        Vec3 F(fresnel_conductor(c, B.eta_c[0], B.k_c[0]), fresnel_conductor(c, B.eta_c[1], B.k_c[1]), fresnel_conductor(c, B.eta_c[2], B.k_c[2]));
+        bs.weight = active ? F * (in.slot0 * weight) : Vec3(0.f);
+    } break;
+    case BSDF_ROUGHPLASTIC: {                                                /* roughplastic.cpp:244-294 */
+        if (!(cos_theta_i > 0.f)) return;
+        float t_i = lerp_gather(in.table, cos_theta_i, HAR_ROUGH_TRANSMITTANCE_RES);
+        float prob_specular = (1.f - t_i) * B.spec_sampling_weight, prob_diffuse = t_i * (1.f - B.spec_sampling_weight);
+        prob_specular = prob_specular / (prob_specular + prob_diffuse);
+        bool sample_specular = sample1 < prob_specular;
+        bs.eta = 1.f;
+        if (sample_specular) {
+            Microfacet distr((B.flags & BF_GGX) != 0, B.alpha_u, B.alpha_u, (B.flags & BF_SAMPLE_VISIBLE) != 0);
+            float pdf_m; Vec3 m = distr.sample(wi, s2x, s2y, pdf_m);
+            bs.wo = reflect_m(wi, m);
+        } else bs.wo = square_to_cosine_hemisphere(s2x, s2y);
+        BsdfEval e; bsdf_eval_pdf_one<TYPES>(B, in, wi, bs.wo, e);
+        bs.pdf = e.pdf;
+        bool active = bs.pdf > 0.f;
+        bs.weight = active ? Vec3(e.value.x / bs.pdf, e.value.y / bs.pdf, e.value.z / bs.pdf) : Vec3(0.f);
+    } break;
+    }
+}
+
+} // namespace har

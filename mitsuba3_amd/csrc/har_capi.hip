@@ -214,11 +214,13 @@ int har_scene_create(const HarSceneDesc *desc, HarScene *out) {
         S->tex_dev.push_back(const_cast<float *>(p)); dt.push_back(DTexture{ p, t.w, t.h });
     }
     up(dt, &D.textures);
+    up(hs.bsdf_tables, &D.bsdf_tables);
     if (err != hipSuccess) { for (void *p : S->owned) (void) hipFree(p); delete S; return fail(std::string("scene upload: ") + hipGetErrorString(err)); }
     S->d_bsdfs = const_cast<DBsdf *>(D.bsdfs);
     D.accel.root = hs.root; D.accel.has_tlas = hs.has_tlas; D.accel.n_tris = (uint32_t) hs.tris.size(); D.accel.n_insts = (uint32_t) hs.inst_recs.size();
     D.n_emitters = (uint32_t) hs.emitters.size(); D.n_meshes = (uint32_t) hs.meshes.size();
     D.n_bsdfs = (uint32_t) hs.bsdfs.size(); D.n_textures = (uint32_t) hs.textures.size();
+    D.bsdf_types = 0; for (const DBsdf &b : hs.bsdfs) D.bsdf_types |= (1u << b.type) | ((b.flags & BF_TWOSIDED) ? 0x80000000u : 0u);
     if (hs.stack_need() + HAR_STACK_MARGIN > HAR_LDS_STACK_DEPTH)
         fprintf(stderr, "[hip_ad_rgb] warning: BVH needs %u traversal stack entries, LDS stack holds %d (overflow is reported as an error)\n", hs.stack_need(), HAR_LDS_STACK_DEPTH);
     *out = S;
@@ -236,6 +238,7 @@ int har_scene_destroy(HarScene S) {
 int har_scene_set_reflectance(HarScene S, uint32_t bsdf, const float rgb[3]) {
     if (!S || bsdf >= S->hs.bsdfs.size()) return fail("invalid bsdf index");
     DBsdf &b = S->hs.bsdfs[bsdf]; b.r = rgb[0]; b.g = rgb[1]; b.b = rgb[2];
+    if (b.type == BSDF_ROUGHPLASTIC) update_roughplastic_sampling_weight(S->hs, bsdf);     /* RoughPlastic::parameters_changed */
     HIP_TRY(hipMemcpy(S->d_bsdfs + bsdf, &b, sizeof(DBsdf), hipMemcpyHostToDevice));
     return 0;
 }
@@ -314,14 +317,17 @@ int har_bsdf_eval_pdf(HarScene S, uint32_t bsdf, uint32_t n, const float *wi, co
     HIP_TRY(hipGetLastError());
     return 0;
 }
-int har_bsdf_sample(HarScene S, uint32_t bsdf, uint32_t n, const float *wi, const float *uv, const float *sample1, const float *sample2,
-                    float *wo, float *pdf, float *weight, void *stream) {
-    (void) sample1;
+int har_bsdf_sample_ex(HarScene S, uint32_t bsdf, uint32_t n, const float *wi, const float *uv, const float *sample1, const float *sample2,
+                       float *wo, float *pdf, float *weight, float *eta_delta, void *stream) {
     if (!S || bsdf >= S->hs.bsdfs.size()) return fail("invalid bsdf index");
     if (n == 0) return 0;
-    launch_api_bsdf_sample((hipStream_t) stream, S->ds, bsdf, n, wi, uv, sample2, wo, pdf, weight);
+    launch_api_bsdf_sample((hipStream_t) stream, S->ds, bsdf, n, wi, uv, sample1, sample2, wo, pdf, weight, eta_delta);
     HIP_TRY(hipGetLastError());
     return 0;
+}
+int har_bsdf_sample(HarScene S, uint32_t bsdf, uint32_t n, const float *wi, const float *uv, const float *sample1, const float *sample2,
+                    float *wo, float *pdf, float *weight, void *stream) {
+    return har_bsdf_sample_ex(S, bsdf, n, wi, uv, sample1, sample2, wo, pdf, weight, nullptr, stream);
 }
 int har_sensor_sample_ray(const HarSensor *sensor, uint32_t n, const float *px, const float *py, float *o, float *d, float *maxt, void *stream) {
     DSensor C; std::string e;

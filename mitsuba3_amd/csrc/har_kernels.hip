@@ -102,7 +102,9 @@ __device__ __forceinline__ void wave_aggregated_add3(float *dst, Vec3 g, bool ac
 }
 
 __device__ __forceinline__ void store_state(const WaveState &W, uint32_t i, const PathState &s) {
-    W.a0[i] = make_float4(s.o.x, s.o.y, s.o.z, s.maxt);
+    /* a0.w: maxt of the camera ray (depth 0, eta == 1); bounce rays always have maxt = largest, so the slot carries
+     * -eta instead (negative = "unbounded ray", decoded by the traversal kernels and load_state) */
+    W.a0[i] = make_float4(s.o.x, s.o.y, s.o.z, (s.flags & 0xffffu) == 0u ? s.maxt : -s.eta);
     W.a1[i] = make_float4(s.d.x, s.d.y, s.d.z, s.prev_bsdf_pdf);
     W.a2[i] = make_float4(s.throughput.x, s.throughput.y, s.throughput.z, __uint_as_float(s.flags));
     W.a3[i] = make_float4(s.prev_p.x, s.prev_p.y, s.prev_p.z, __uint_as_float(s.lane));
@@ -111,7 +113,7 @@ __device__ __forceinline__ void store_state(const WaveState &W, uint32_t i, cons
 __device__ __forceinline__ PathState load_state(const WaveState &W, uint32_t i) {
     float4 a0 = W.a0[i], a1 = W.a1[i], a2 = W.a2[i], a3 = W.a3[i]; uint2 a4 = W.a4[i];
     PathState s;
-    s.o = Vec3(a0.x, a0.y, a0.z); s.maxt = a0.w;
+    s.o = Vec3(a0.x, a0.y, a0.z); s.maxt = a0.w < 0.f ? HAR_LARGEST : a0.w; s.eta = a0.w < 0.f ? -a0.w : 1.f;
     s.d = Vec3(a1.x, a1.y, a1.z); s.prev_bsdf_pdf = a1.w;
     s.throughput = Vec3(a2.x, a2.y, a2.z); s.flags = __float_as_uint(a2.w);
     s.prev_p = Vec3(a3.x, a3.y, a3.z); s.lane = __float_as_uint(a3.w);
@@ -263,7 +265,7 @@ __global__ __launch_bounds__(kBlock) void k_trace_closest(Accel A, const uint32_
     trace_persistent<false, false, CAP>(A, cursor + shard * HAR_COUNTER_STRIDE, n, stack, status,
         [&](uint32_t idx, Traversal<HAR_TRAV_POLICY> &T) {
             float4 o = a0[base + idx], d = a1[base + idx];
-            T.begin(A, Vec3(o.x, o.y, o.z), Vec3(d.x, d.y, d.z), o.w);
+            T.begin(A, Vec3(o.x, o.y, o.z), Vec3(d.x, d.y, d.z), o.w < 0.f ? HAR_LARGEST : o.w);
             return true;
         },
         [&](uint32_t idx, const Traversal<HAR_TRAV_POLICY> &T) {
@@ -274,7 +276,7 @@ __global__ __launch_bounds__(kBlock) void k_trace_closest(Accel A, const uint32_
 }
 
 /* ------------------------------------------------------------------- shade */
-template <int MODE>
+template <int MODE, uint32_t TYPES>
 __global__ __launch_bounds__(kBlock) void k_shade(DScene S, ShadeParams P, uint32_t lane_base, uint32_t shard_cap, const uint32_t *count_in, WaveState in,
                                                   const float4 *h0, const uint2 *h1, WaveState out, uint32_t *count_out,
                                                   ItemArrays items, uint32_t *item_count, float4 *result) {
@@ -291,7 +293,7 @@ __global__ __launch_bounds__(kBlock) void k_shade(DScene S, ShadeParams P, uint3
             PathState st = load_state(in, i);
             float4 hh = h0[i]; uint2 hs = h1[i];
             Hit hit; hit.t = hh.x; hit.u = hh.y; hit.v = hh.z; hit.prim = __float_as_uint(hh.w); hit.shape = hs.x; hit.inst = hs.y;
-            shade_lane<MODE>(S, P, st, hit, R);
+            shade_lane<MODE, TYPES>(S, P, st, hit, R);
             lane = st.lane - lane_base;
             if (R.add_emission) {
                 float4 r = result[lane];
@@ -312,7 +314,7 @@ __global__ __launch_bounds__(kBlock) void k_shade(DScene S, ShadeParams P, uint3
             items.s2[islot] = make_float4(R.contrib.x, R.contrib.y, R.contrib.z, __uint_as_float(MODE == MODE_PRB_ADJOINT ? (R.bsdf | (R.ind_active ? 0x80000000u : 0u)) : 0u));
             if (MODE == MODE_PRB_ADJOINT) {
                 items.s3[islot] = make_float4(R.dLr_drho.x, R.dLr_drho.y, R.dLr_drho.z, R.uv_x);
-                items.s4[islot] = make_float4(R.refl.x, R.refl.y, R.refl.z, R.uv_y);
+                items.s4[islot] = make_float4(R.rel_grad.x, R.rel_grad.y, R.rel_grad.z, R.uv_y);
             }
         }
     }
@@ -368,8 +370,7 @@ __global__ __launch_bounds__(kBlock) void k_resolve(DScene S, const uint32_t *it
                     float4 s3 = items.s3[i], s4 = items.s4[i], dl = dL[lane];
                     const uint32_t tag = __float_as_uint(s2.w), bsdf = tag & 0x7fffffffu;
                     g = visible ? Vec3(s3.x, s3.y, s3.z) : Vec3(0.f);
-                    if (tag & 0x80000000u)
-                        g = g + Vec3(s4.x != 0.f ? L.x / s4.x : 0.f, s4.y != 0.f ? L.y / s4.y : 0.f, s4.z != 0.f ? L.z / s4.z : 0.f);
+                    if (tag & 0x80000000u) g = g + Vec3(L.x * s4.x, L.y * s4.y, L.z * s4.z);
                     g = g * Vec3(dl.x, dl.y, dl.z);
                     const DBsdf B = S.bsdfs[bsdf];
                     dst = grad_refl + 3 * (size_t) bsdf;
@@ -556,19 +557,21 @@ __global__ void k_api_sampler_next(uint32_t n, uint64_t *state, const uint64_t *
 __global__ void k_api_bsdf_eval_pdf(DScene S, uint32_t bsdf, uint32_t n, const float *wi, const float *uv, const float *wo, float *value, float *pdf) {
     uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
-    TexTaps taps; Vec3 refl = bsdf_reflectance(S, S.bsdfs[bsdf], uv[i], uv[n + i], taps);
-    Vec3 val; float p;
-    diffuse_eval_pdf(refl, Vec3(wi[i], wi[n + i], wi[2 * (size_t) n + i]), Vec3(wo[i], wo[n + i], wo[2 * (size_t) n + i]), val, p);
-    value[i] = val.x; value[n + i] = val.y; value[2 * (size_t) n + i] = val.z; pdf[i] = p;
+    BsdfSide side; const bool ok = bsdf_side(S, bsdf, Vec3(wi[i], wi[n + i], wi[2 * (size_t) n + i]), side);
+    TexTaps taps; const BsdfInputs in = bsdf_inputs(S, S.bsdfs[side.index], uv[i], uv[n + i], taps);
+    BsdfEval e; bsdf_eval_pdf(S, side, in, ok, Vec3(wo[i], wo[n + i], wo[2 * (size_t) n + i]), e);
+    value[i] = e.value.x; value[n + i] = e.value.y; value[2 * (size_t) n + i] = e.value.z; pdf[i] = e.pdf;
 }
-__global__ void k_api_bsdf_sample(DScene S, uint32_t bsdf, uint32_t n, const float *wi, const float *uv, const float *s2, float *wo, float *pdf, float *weight) {
+__global__ void k_api_bsdf_sample(DScene S, uint32_t bsdf, uint32_t n, const float *wi, const float *uv, const float *s1, const float *s2, float *wo, float *pdf,
+                                  float *weight, float *eta_delta) {
     uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
-    TexTaps taps; Vec3 refl = bsdf_reflectance(S, S.bsdfs[bsdf], uv[i], uv[n + i], taps);
-    Vec3 w, wt; float p;
-    diffuse_sample(refl, Vec3(wi[i], wi[n + i], wi[2 * (size_t) n + i]), s2[i], s2[n + i], w, p, wt);
-    wo[i] = w.x; wo[n + i] = w.y; wo[2 * (size_t) n + i] = w.z; pdf[i] = p;
-    weight[i] = wt.x; weight[n + i] = wt.y; weight[2 * (size_t) n + i] = wt.z;
+    BsdfSide side; const bool ok = bsdf_side(S, bsdf, Vec3(wi[i], wi[n + i], wi[2 * (size_t) n + i]), side);
+    TexTaps taps; const BsdfInputs in = bsdf_inputs(S, S.bsdfs[side.index], uv[i], uv[n + i], taps);
+    BsdfSample b; bsdf_sample(S, side, in, ok, s1 ? s1[i] : 0.f, s2[i], s2[n + i], b);
+    wo[i] = b.wo.x; wo[n + i] = b.wo.y; wo[2 * (size_t) n + i] = b.wo.z; pdf[i] = b.pdf;
+    weight[i] = b.weight.x; weight[n + i] = b.weight.y; weight[2 * (size_t) n + i] = b.weight.z;
+    if (eta_delta) { eta_delta[i] = b.eta; eta_delta[n + i] = b.delta ? 1.f : 0.f; }
 }
 __global__ void k_api_sensor_ray(DSensor C, uint32_t n, const float *px, const float *py, float *o, float *d, float *maxt) {
     uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
@@ -613,9 +616,13 @@ void launch_shade(int mode, hipStream_t s, uint32_t grid, const DScene &S, const
                   const WaveState &in, const float4 *h0, const uint2 *h1, const WaveState &out, uint32_t *count_out, const ItemArrays &items,
                   uint32_t *item_count, float4 *result) {
     dim3 g(grid), b(kBlock);
-    if (mode == MODE_PATH) hipLaunchKernelGGL(k_shade<MODE_PATH>, g, b, 0, s, S, P, lane_base, shard_cap, count_in, in, h0, h1, out, count_out, items, item_count, result);
-    else if (mode == MODE_PRB_PRIMAL) hipLaunchKernelGGL(k_shade<MODE_PRB_PRIMAL>, g, b, 0, s, S, P, lane_base, shard_cap, count_in, in, h0, h1, out, count_out, items, item_count, result);
-    else hipLaunchKernelGGL(k_shade<MODE_PRB_ADJOINT>, g, b, 0, s, S, P, lane_base, shard_cap, count_in, in, h0, h1, out, count_out, items, item_count, result);
+    /* diffuse-only scenes (no twosided wrappers) run kernels in which the other BSDF models are compiled out */
+    const bool only_diffuse = S.bsdf_types == HAR_BSDF_ONLY_DIFFUSE;
+#define HAR_LAUNCH_SHADE(M, T) hipLaunchKernelGGL((k_shade<M, T>), g, b, 0, s, S, P, lane_base, shard_cap, count_in, in, h0, h1, out, count_out, items, item_count, result)
+    if (mode == MODE_PATH)            { if (only_diffuse) HAR_LAUNCH_SHADE(MODE_PATH, HAR_BSDF_ONLY_DIFFUSE); else HAR_LAUNCH_SHADE(MODE_PATH, HAR_BSDF_ALL_TYPES); }
+    else if (mode == MODE_PRB_PRIMAL) { if (only_diffuse) HAR_LAUNCH_SHADE(MODE_PRB_PRIMAL, HAR_BSDF_ONLY_DIFFUSE); else HAR_LAUNCH_SHADE(MODE_PRB_PRIMAL, HAR_BSDF_ALL_TYPES); }
+    else                              { if (only_diffuse) HAR_LAUNCH_SHADE(MODE_PRB_ADJOINT, HAR_BSDF_ONLY_DIFFUSE); else HAR_LAUNCH_SHADE(MODE_PRB_ADJOINT, HAR_BSDF_ALL_TYPES); }
+#undef HAR_LAUNCH_SHADE
 }
 void launch_resolve(int mode, hipStream_t s, uint32_t grid, int stack_class, const DScene &S, const uint32_t *item_count, uint32_t *cursor, uint32_t shard_cap, const ItemArrays &items,
                     float4 *result, const float4 *dL, float *grad_refl, float *const *grad_tex, int *status) {
@@ -667,8 +674,9 @@ void launch_api_sampler_next(hipStream_t s, uint32_t n, uint64_t *state, const u
 void launch_api_bsdf_eval_pdf(hipStream_t s, const DScene &S, uint32_t bsdf, uint32_t n, const float *wi, const float *uv, const float *wo, float *value, float *pdf) {
     hipLaunchKernelGGL(k_api_bsdf_eval_pdf, dim3(blocks_for(n)), dim3(kBlock), 0, s, S, bsdf, n, wi, uv, wo, value, pdf);
 }
-void launch_api_bsdf_sample(hipStream_t s, const DScene &S, uint32_t bsdf, uint32_t n, const float *wi, const float *uv, const float *s2, float *wo, float *pdf, float *weight) {
-    hipLaunchKernelGGL(k_api_bsdf_sample, dim3(blocks_for(n)), dim3(kBlock), 0, s, S, bsdf, n, wi, uv, s2, wo, pdf, weight);
+void launch_api_bsdf_sample(hipStream_t s, const DScene &S, uint32_t bsdf, uint32_t n, const float *wi, const float *uv, const float *s1, const float *s2, float *wo,
+                            float *pdf, float *weight, float *eta_delta) {
+    hipLaunchKernelGGL(k_api_bsdf_sample, dim3(blocks_for(n)), dim3(kBlock), 0, s, S, bsdf, n, wi, uv, s1, s2, wo, pdf, weight, eta_delta);
 }
 void launch_api_sensor_ray(hipStream_t s, const DSensor &C, uint32_t n, const float *px, const float *py, float *o, float *d, float *maxt) {
     hipLaunchKernelGGL(k_api_sensor_ray, dim3(blocks_for(n)), dim3(kBlock), 0, s, C, n, px, py, o, d, maxt);

@@ -27,6 +27,7 @@ struct PathState {
     uint32_t lane;
     Vec3 prev_p; float prev_bsdf_pdf;
     uint32_t flags;            /* bits 0..15 depth, bit 16 prev_bsdf_delta */
+    float eta;                 /* product of the sampled relative IORs (path.cpp:300, prb.py:229) */
 };
 
 struct ShadeParams {
@@ -41,8 +42,8 @@ struct ShadeResult {
     bool item_ray;                        /* item carries a shadow ray to test */
     Vec3 sh_o, sh_d; float sh_maxt;
     Vec3 contrib;                         /* PATH: throughput*bsdf*em*mis; PRB: Lr_dir */
-    /* MODE_PRB_ADJOINT only */
-    Vec3 dLr_drho, refl; bool ind_active; uint32_t bsdf; float uv_x, uv_y;
+    /* MODE_PRB_ADJOINT only: d Lr_dir / d slot0, and (d f / d slot0) / f at the sampled direction */
+    Vec3 dLr_drho, rel_grad; bool ind_active; uint32_t bsdf; float uv_x, uv_y;
 };
 
 /* raygen: SamplingIntegrator::render_sample up to the camera ray (integrator.cpp:448-483) */
@@ -53,7 +54,7 @@ HAR_HD PathState raygen_lane(const DSensor &C, uint32_t seed, uint32_t spp, uint
     float jx = pcg32_next_float(st.rng, inc), jy = pcg32_next_float(st.rng, inc);
     ls = lane_sample(C, lane, spp, log_spp, jx, jy);
     lane_camera_ray(C, ls, st.o, st.d, st.maxt);
-    st.throughput = Vec3(1.f); st.lane = lane; st.prev_p = Vec3(0.f); st.prev_bsdf_pdf = 1.f; st.flags = 1u << 16;
+    st.throughput = Vec3(1.f); st.lane = lane; st.prev_p = Vec3(0.f); st.prev_bsdf_pdf = 1.f; st.flags = 1u << 16; st.eta = 1.f;
     return st;
 }
 
@@ -85,7 +86,7 @@ HAR_HD void film_footprint(const DSensor &C, const LaneSample &L, Footprint &F) 
     }
 }
 
-template <int MODE>
+template <int MODE, uint32_t TYPES = HAR_BSDF_ALL_TYPES>
 HAR_HD void shade_lane(const DScene &S, const ShadeParams &P, const PathState &st, const Hit &hit, ShadeResult &R) {
     R.alive = false; R.add_emission = false; R.item = false; R.item_ray = false;
     uint64_t rng = st.rng;
@@ -121,15 +122,20 @@ HAR_HD void shade_lane(const DScene &S, const ShadeParams &P, const PathState &s
     if (MODE == MODE_PATH && !active_next) return;
     if (MODE != MODE_PATH && !valid) return;      /* prb: nothing below contributes for a miss */
 
-    const DBsdf B = S.bsdfs[M.bsdf];
+    /* BSDF record serving this side (twosided.cpp) and its evaluated colour parameters */
+    BsdfSide side; bool side_ok = true;
+    if (TYPES == HAR_BSDF_ONLY_DIFFUSE) { side.index = M.bsdf; side.wi = si.wi; side.wo_sign = 1.f; }      /* no twosided records either */
+    else side_ok = bsdf_side(S, M.bsdf, si.wi, side);
+    const DBsdf B = S.bsdfs[side.index];
     TexTaps taps;
-    Vec3 refl = bsdf_reflectance(S, B, si.uv_x, si.uv_y, taps);
+    const BsdfInputs bin = bsdf_inputs(S, B, si.uv_x, si.uv_y, taps);
 
-    /* ---- emitter sampling (path.cpp:238-258, prb.py:163-175; scene.cpp:316-366) */
+    /* ---- emitter sampling (path.cpp:238-258, prb.py:163-175; scene.cpp:316-366).  The two samples are drawn by
+     * every active lane; only BSDFs with a Smooth lobe use them (path.cpp:237, prb.py:169) */
     float ex = pcg32_next_float(rng, inc), ey = pcg32_next_float(rng, inc);
     DirSample ds; ds.pdf = 0.f; ds.d = Vec3(0.f); ds.p = Vec3(0.f); ds.n = Vec3(0.f); ds.dist = 0.f;
     Vec3 em_weight(0.f);
-    bool active_em = active_next && S.n_emitters > 0;
+    bool active_em = active_next && S.n_emitters > 0 && (TYPES == HAR_BSDF_ONLY_DIFFUSE || bsdf_is_smooth(B));
     if (active_em) {
         uint32_t index = 0; float wgt = 1.f;
         if (S.n_emitters > 1) {                                  /* sample_emitter, scene.cpp:248-271 */
@@ -144,22 +150,20 @@ HAR_HD void shade_lane(const DScene &S, const ShadeParams &P, const PathState &s
     Vec3 wo_em = active_em ? si.to_local(ds.d) : Vec3(0.f);
 
     /* ---- BSDF (bsdf.cpp:21-31 eval_pdf_sample) */
-    float s1 = pcg32_next_float(rng, inc); (void) s1;
+    float s1 = pcg32_next_float(rng, inc);
     float s2x = pcg32_next_float(rng, inc), s2y = pcg32_next_float(rng, inc);
-    Vec3 bsdf_val; float bsdf_pdf;
-    diffuse_eval_pdf(refl, si.wi, wo_em, bsdf_val, bsdf_pdf);
-    Vec3 bwo(0.f), bsdf_weight(0.f); float bs_pdf = 0.f, bs_eta = 0.f;
-    if (MODE == MODE_PATH || active_next) { diffuse_sample(refl, si.wi, s2x, s2y, bwo, bs_pdf, bsdf_weight); bs_eta = 1.f; }
+    BsdfEval ev; bsdf_eval_pdf<TYPES>(S, side, bin, side_ok, wo_em, ev);
+    BsdfSample bs; bs.wo = Vec3(0.f); bs.pdf = 0.f; bs.weight = Vec3(0.f); bs.eta = 0.f; bs.delta = false;
+    if (MODE == MODE_PATH || active_next) bsdf_sample<TYPES>(S, side, bin, side_ok, s1, s2x, s2y, bs);
 
     /* ---- NEE contribution (path.cpp:271-281, prb.py:210-216); visibility is resolved by the shadow kernel */
     R.contrib = Vec3(0.f); R.dLr_drho = Vec3(0.f);
     if (active_em) {
-        float mis_em = mis_weight(ds.pdf, bsdf_pdf);
-        if (MODE == MODE_PATH) R.contrib = st.throughput * ((bsdf_val * em_weight) * mis_em);
+        float mis_em = mis_weight(ds.pdf, ev.pdf);
+        if (MODE == MODE_PATH) R.contrib = st.throughput * ((ev.value * em_weight) * mis_em);
         else {
-            R.contrib = ((st.throughput * mis_em) * bsdf_val) * em_weight;
-            if (MODE == MODE_PRB_ADJOINT && si.wi.z > 0.f && wo_em.z > 0.f)
-                R.dLr_drho = ((st.throughput * mis_em) * (HAR_INV_PI * wo_em.z)) * em_weight;
+            R.contrib = ((st.throughput * mis_em) * ev.value) * em_weight;
+            if (MODE == MODE_PRB_ADJOINT) R.dLr_drho = ((st.throughput * mis_em) * ev.d_slot0) * em_weight;
         }
         if (R.contrib.x != 0.f || R.contrib.y != 0.f || R.contrib.z != 0.f) {
             R.item = true; R.item_ray = true;
@@ -169,13 +173,14 @@ HAR_HD void shade_lane(const DScene &S, const ShadeParams &P, const PathState &s
 
     /* ---- continue the path (path.cpp:287-331, prb.py:227-252) */
     PathState &N = R.next;
-    Vec3 wo_world = si.to_world(bwo);
+    Vec3 wo_world = si.to_world(bs.wo);
     N.o = offset_p(si, wo_world); N.d = wo_world; N.maxt = HAR_LARGEST;
-    N.throughput = st.throughput * bsdf_weight;
-    N.lane = st.lane; N.prev_p = si.p; N.prev_bsdf_pdf = bs_pdf;
+    N.throughput = st.throughput * bs.weight;
+    N.eta = st.eta * bs.eta;
+    N.lane = st.lane; N.prev_p = si.p; N.prev_bsdf_pdf = bs.pdf;
+    const uint32_t delta_bit = bs.delta ? 1u << 16 : 0u;
     float tmax = hmax3(N.throughput);
-    float eta = 1.f; (void) bs_eta;
-    float rr_prob = fminf(tmax * (eta * eta), .95f);
+    float rr_prob = fminf(tmax * (N.eta * N.eta), .95f);
     bool rr_active, alive;
     if (MODE == MODE_PATH) {
         uint32_t nd = depth + 1u;                                  /* path.cpp:317: depth++ BEFORE the test */
@@ -183,23 +188,26 @@ HAR_HD void shade_lane(const DScene &S, const ShadeParams &P, const PathState &s
         bool rr_continue = pcg32_next_float(rng, inc) < rr_prob;
         if (rr_active) N.throughput = N.throughput * rcp_(rr_prob);
         alive = active_next && (!rr_active || rr_continue) && (tmax != 0.f);
-        N.flags = nd;
+        N.flags = nd | delta_bit;
     } else {
         active_next = active_next && (tmax != 0.f);
         rr_active = depth >= P.rr_depth;                           /* prb.py:249: depth not yet incremented */
         if (rr_active) N.throughput = N.throughput * rcp_(rr_prob);
         bool rr_continue = pcg32_next_float(rng, inc) < rr_prob;
         alive = active_next && (!rr_active || rr_continue);
-        N.flags = depth + 1u;
+        N.flags = (depth + 1u) | delta_bit;
     }
     N.rng = rng;
     R.alive = alive;
 
     if (MODE == MODE_PRB_ADJOINT) {
-        /* Lr_ind = L * relative_grad(bsdf.eval(si, wo, active_next)) (prb.py:288-297) */
+        /* Lr_ind = L * relative_grad(bsdf.eval(si, wo, active_next)) (prb.py:288-297): d/d slot0 = L * (df/dslot0) / f */
         Vec3 wo = si.to_local(wo_world);
-        R.ind_active = alive && si.wi.z > 0.f && wo.z > 0.f;
-        R.refl = refl; R.bsdf = M.bsdf; R.uv_x = si.uv_x; R.uv_y = si.uv_y;
+        BsdfEval e2; bsdf_eval_pdf<TYPES>(S, side, bin, side_ok && alive, wo, e2);
+        R.rel_grad = Vec3(e2.value.x != 0.f ? e2.d_slot0.x / e2.value.x : 0.f, e2.value.y != 0.f ? e2.d_slot0.y / e2.value.y : 0.f,
+                          e2.value.z != 0.f ? e2.d_slot0.z / e2.value.z : 0.f);
+        R.ind_active = alive && (R.rel_grad.x != 0.f || R.rel_grad.y != 0.f || R.rel_grad.z != 0.f);
+        R.bsdf = side.index; R.uv_x = si.uv_x; R.uv_y = si.uv_y;
         R.item = R.item_ray || R.ind_active;   /* otherwise the vertex has a zero gradient */
     }
 }

@@ -7,11 +7,11 @@
  */
 #pragma once
 #include "har_accel.h"
+#include "har_bsdf.h"
 
 namespace har {
 
 struct DMesh    { uint32_t voff, foff, bsdf; int32_t emitter; uint32_t flags, face_count, pad0, pad1; };
-struct DBsdf    { uint32_t type; int32_t texture; float r, g, b; float pad0, pad1, pad2; };
 struct DTexture { const float *data; uint32_t w, h; };
 struct DEmitter { float radiance[3]; float inv_area; float to_world[12]; float normal[3]; uint32_t mesh; };
 struct DInst    { float to_world[12]; float to_object[12]; };
@@ -26,7 +26,9 @@ struct DScene {
     const DTexture *textures;
     const DEmitter *emitters;
     const DInst    *insts;
+    const float    *bsdf_tables;       /* roughplastic external transmittance tables, 64 floats each */
     uint32_t n_emitters, n_meshes, n_bsdfs, n_textures;
+    uint32_t bsdf_types;               /* bit mask (1 << type) of the BSDF types present (+ bit 31: some record is twosided) */
 };
 
 struct DSensor {
@@ -145,6 +147,41 @@ HAR_HD Vec3 bsdf_reflectance(const DScene &S, const DBsdf &B, float u, float v, 
     const DTexture T = S.textures[B.texture];
     tex_taps(T, u, v, taps);
     return tex_fetch(T, taps);
+}
+/* evaluated colour parameters of a BSDF record at (u, v) */
+HAR_HD BsdfInputs bsdf_inputs(const DScene &S, const DBsdf &B, float u, float v, TexTaps &taps) {
+    BsdfInputs in;
+    in.slot0 = bsdf_reflectance(S, B, u, v, taps);
+    in.slot1 = Vec3(B.r2, B.g2, B.b2);
+    in.table = B.table >= 0 ? S.bsdf_tables + B.table : nullptr;
+    return in;
+}
+
+/* TwoSidedBRDF (src/bsdfs/twosided.cpp:112-270): which record serves this side, and how wi / wo are mirrored.
+ * Returns false when the BSDF is zero on this side (two different nested BSDFs and wi.z == 0). */
+struct BsdfSide { uint32_t index; Vec3 wi; float wo_sign; };
+HAR_HD bool bsdf_side(const DScene &S, uint32_t index, Vec3 wi, BsdfSide &side) {
+    const DBsdf &B = S.bsdfs[index];
+    side.index = index; side.wi = wi; side.wo_sign = 1.f;
+    if (!(B.flags & BF_TWOSIDED)) return true;
+    if (B.back < 0) {                      /* m_brdf[0] == m_brdf[1]: wo.z = mulsign(wo.z, wi.z); wi.z = abs(wi.z) */
+        side.wo_sign = sign_(wi.z); side.wi.z = fabsf(wi.z);
+        return true;
+    }
+    if (wi.z > 0.f) return true;
+    if (wi.z < 0.f) { side.index = (uint32_t) B.back; side.wi.z = -wi.z; side.wo_sign = -1.f; return true; }
+    return false;
+}
+template <uint32_t TYPES = HAR_BSDF_ALL_TYPES>
+HAR_HD void bsdf_eval_pdf(const DScene &S, const BsdfSide &side, const BsdfInputs &in, bool side_ok, Vec3 wo, BsdfEval &e) {
+    if (!side_ok) { e.value = Vec3(0.f); e.pdf = 0.f; e.d_slot0 = Vec3(0.f); e.d_slot1 = Vec3(0.f); return; }
+    bsdf_eval_pdf_one<TYPES>(S.bsdfs[side.index], in, side.wi, Vec3(wo.x, wo.y, wo.z * side.wo_sign), e);
+}
+template <uint32_t TYPES = HAR_BSDF_ALL_TYPES>
+HAR_HD void bsdf_sample(const DScene &S, const BsdfSide &side, const BsdfInputs &in, bool side_ok, float s1, float s2x, float s2y, BsdfSample &bs) {
+    if (!side_ok) { bs.wo = Vec3(0.f); bs.pdf = 0.f; bs.weight = Vec3(0.f); bs.eta = 0.f; bs.delta = false; return; }
+    bsdf_sample_one<TYPES>(S.bsdfs[side.index], in, side.wi, s1, s2x, s2y, bs);
+    bs.wo.z *= side.wo_sign;
 }
 
 /* SmoothDiffuse::eval_pdf / sample (src/bsdfs/diffuse.cpp:159-179, 100-124) */

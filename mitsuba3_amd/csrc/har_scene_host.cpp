@@ -45,7 +45,90 @@ BlasInfo build_blas(HostScene &hs, const HarSceneDesc &d, uint32_t first_mesh, u
     return info;
 }
 
+/* quad::gauss_legendre (include/mitsuba/core/quad.h:27-90): nodes / weights on [-1, 1] */
+void gauss_legendre(int n, std::vector<float> &nodes, std::vector<float> &weights) {
+    nodes.assign(n, 0.f); weights.assign(n, 0.f);
+    auto legendre_pd = [](int l, double x, double &p, double &dp) {          /* math::legendre_pd */
+        double l_cur = x, l_p_pred = 1, d_cur = 1, d_p_pred = 0, k_cur = 1;
+        if (l == 0) { p = 1; dp = 0; return; }
+        for (int k = 1; k < l; ++k) {
+            double l_next = ((2 * k_cur + 1) * x * l_cur - k_cur * l_p_pred) / (k_cur + 1), d_next = d_p_pred + (2 * k_cur + 1) * l_cur;
+            l_p_pred = l_cur; l_cur = l_next; d_p_pred = d_cur; d_cur = d_next; k_cur += 1;
+        }
+        p = l_cur; dp = d_cur;
+    };
+    int N = n - 1, m = (N + 1) / 2;
+    for (int i = 0; i < m; ++i) {
+        double x = -std::cos((double) (2 * i + 1) / (double) (2 * N + 2) * 3.14159265358979323846);
+        for (int it = 0; it < 20; ++it) {
+            double p, dp; legendre_pd(N + 1, x, p, dp);
+            double step = p / dp; x -= step;
+            if (std::fabs(step) <= 4 * std::fabs(x) * 1.1102230246251565e-16) break;
+        }
+        double p, dp; legendre_pd(N + 1, x, p, dp);
+        weights[i] = weights[N - i] = (float) (2 / ((1 - x * x) * (dp * dp)));
+        nodes[i] = (float) x; nodes[N - i] = (float) -x;
+    }
+    if ((N % 2) == 0) {
+        double p, dp; legendre_pd(N + 1, 0.0, p, dp);
+        weights[N / 2] = (float) (2 / (dp * dp)); nodes[N / 2] = 0.f;
+    }
+}
+
+/* eval_transmittance / eval_reflectance (include/mitsuba/render/microfacet.h:465-567) for one direction */
+float rough_transmittance(const Microfacet &distr, Vec3 wi, float eta, bool reflectance) {
+    int res = eta > 1.f ? 32 : 128;
+    std::vector<float> nodes, weights; gauss_legendre(res, nodes, weights);
+    float result = 0.f;
+    for (int jy = 0; jy < res; ++jy)                     /* dr::meshgrid(nodes, nodes): x varies fastest */
+        for (int jx = 0; jx < res; ++jx) {
+            float nx = fma_(nodes[jx], 0.5f, 0.5f), ny = fma_(nodes[jy], 0.5f, 0.5f);
+            float pdf; Vec3 m = distr.sample(wi, nx, ny, pdf);
+            float f, cos_theta_t, eta_it, eta_ti; fresnel_dielectric(dot3(wi, m), eta, f, cos_theta_t, eta_it, eta_ti);
+            float smith;
+            if (reflectance) {
+                Vec3 wo = reflect_m(wi, m);
+                smith = distr.smith_g1(wo, m) * f;
+                if (wo.z <= 0.f || wi.z <= 0.f) smith = 0.f;
+            } else {
+                Vec3 wo = refract_m(wi, m, cos_theta_t, eta_ti);
+                smith = distr.smith_g1(wo, m) * (1.f - f);
+                if (wo.z * wi.z >= 0.f) smith = 0.f;
+            }
+            result += smith * (weights[jx] * weights[jy]) * 0.25f;
+        }
+    return result;
+}
+
+/* RoughPlastic::parameters_changed (src/bsdfs/roughplastic.cpp:204-242) */
+void build_roughplastic_tables(HostScene &hs, uint32_t index) {
+    DBsdf &b = hs.bsdfs[index];
+    b.inv_eta_2 = 1.f / (b.eta * b.eta);
+    Microfacet distr((b.flags & BF_GGX) != 0, b.alpha_u, b.alpha_u, true);
+    b.table = (int32_t) hs.bsdf_tables.size();
+    double mean = 0;
+    for (int i = 0; i < HAR_ROUGH_TRANSMITTANCE_RES; ++i) {
+        float mu = std::max(1e-6f, (float) i / (float) (HAR_ROUGH_TRANSMITTANCE_RES - 1));
+        Vec3 wi(std::sqrt(1.f - mu * mu), 0.f, mu);
+        hs.bsdf_tables.push_back(rough_transmittance(distr, wi, b.eta, false));
+        mean += (double) (rough_transmittance(distr, wi, 1.f / b.eta, true) * wi.z);
+    }
+    b.internal_reflectance = (float) (mean / HAR_ROUGH_TRANSMITTANCE_RES) * 2.f;
+}
+
 } // namespace
+
+void update_roughplastic_sampling_weight(HostScene &hs, uint32_t index) {
+    DBsdf &b = hs.bsdfs[index];
+    float d_mean;
+    if (b.texture >= 0) {                                /* BitmapTexture::mean */
+        const HostTexture &t = hs.textures[b.texture];
+        double acc = 0; for (float v : t.data) acc += v;
+        d_mean = (float) (acc / (double) t.data.size());
+    } else d_mean = (b.r + b.g + b.b) / 3.f;             /* SRGBReflectanceSpectrum::mean, srgb.cpp:117-122 */
+    float s_mean = (b.r2 + b.g2 + b.b2) / 3.f;
+    b.spec_sampling_weight = s_mean / (d_mean + s_mean);
+}
 
 bool lower_scene(const HarSceneDesc &d, HostScene &hs, std::string &err) {
     if (d.top_mesh_count > d.mesh_count) { err = "top_mesh_count exceeds mesh_count"; return false; }
@@ -64,18 +147,28 @@ bool lower_scene(const HarSceneDesc &d, HostScene &hs, std::string &err) {
         hs.faces.insert(hs.faces.end(), m.index_ptr, m.index_ptr + 4 * (size_t) m.face_count);
         hs.meshes.push_back(dm);
     }
-    for (uint32_t i = 0; i < d.bsdf_count; ++i) {
-        const HarBSDF &b = d.bsdfs[i];
-        if (b.type != 0) { err = "unsupported BSDF type (only `diffuse` is implemented in hip_ad_rgb)"; return false; }
-        if (b.texture >= (int32_t) d.texture_count) { err = "BSDF references a texture that does not exist"; return false; }
-        DBsdf db{}; db.type = b.type; db.texture = b.texture; db.r = b.reflectance[0]; db.g = b.reflectance[1]; db.b = b.reflectance[2];
-        hs.bsdfs.push_back(db);
-    }
     for (uint32_t i = 0; i < d.texture_count; ++i) {
         const HarTexture &t = d.textures[i];
         if (!t.data || !t.width || !t.height) { err = "empty texture"; return false; }
         HostTexture ht; ht.w = t.width; ht.h = t.height; ht.data.assign(t.data, t.data + 3 * (size_t) t.width * t.height);
         hs.textures.push_back(std::move(ht));
+    }
+    for (uint32_t i = 0; i < d.bsdf_count; ++i) {
+        const HarBSDF &b = d.bsdfs[i];
+        if (b.type > BSDF_ROUGHPLASTIC) { err = "unsupported BSDF type (diffuse, dielectric, roughconductor, roughplastic and twosided are implemented in hip_ad_rgb)"; return false; }
+        if (b.texture >= (int32_t) d.texture_count) { err = "BSDF references a texture that does not exist"; return false; }
+        if ((b.flags & BF_TWOSIDED) && b.back >= (int32_t) d.bsdf_count) { err = "twosided BSDF references a back-side BSDF that does not exist"; return false; }
+        if ((b.flags & BF_TWOSIDED) && b.type == BSDF_DIELECTRIC) { err = "Only materials without a transmission component can be nested!"; return false; }   /* twosided.cpp:79-83 */
+        if ((b.type == BSDF_DIELECTRIC || b.type == BSDF_ROUGHPLASTIC) && !(b.eta > 0.f)) { err = "The interior and exterior indices of refraction must be positive!"; return false; }
+        if (b.type == BSDF_ROUGHPLASTIC && b.eta == 1.f) { err = "The interior and exterior indices of refraction must be positive and differ!"; return false; }
+        if (b.type == BSDF_ROUGHPLASTIC && b.alpha_u != b.alpha_v) { err = "The 'roughplastic' plugin currently does not support anisotropic microfacet distributions!"; return false; }
+        DBsdf db{}; db.type = b.type; db.texture = b.texture; db.r = b.reflectance[0]; db.g = b.reflectance[1]; db.b = b.reflectance[2];
+        db.flags = b.flags; db.r2 = b.reflectance2[0]; db.g2 = b.reflectance2[1]; db.b2 = b.reflectance2[2];
+        db.alpha_u = b.alpha_u; db.alpha_v = b.alpha_v; db.eta = b.eta;
+        for (int k = 0; k < 3; ++k) { db.eta_c[k] = b.eta_c[k]; db.k_c[k] = b.k_c[k]; }
+        db.back = (b.flags & BF_TWOSIDED) ? b.back : -1; db.table = -1;
+        hs.bsdfs.push_back(db);
+        if (b.type == BSDF_ROUGHPLASTIC) { build_roughplastic_tables(hs, i); update_roughplastic_sampling_weight(hs, i); }
     }
     for (uint32_t i = 0; i < d.emitter_count; ++i) {
         const HarEmitter &e = d.emitters[i];

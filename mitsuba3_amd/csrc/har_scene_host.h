@@ -16,6 +16,7 @@ struct HostScene {
     std::vector<uint32_t> faces;
     std::vector<DMesh> meshes;
     std::vector<DBsdf> bsdfs;
+    std::vector<float> bsdf_tables;          /* roughplastic external transmittance, 64 floats per table */
     std::vector<HostTexture> textures;
     std::vector<DEmitter> emitters;
     std::vector<DInst> insts;
@@ -29,6 +30,9 @@ struct HostScene {
     uint32_t blas_depth = 0, tlas_depth = 0;   /* traversal stack need = blas_depth + (has_tlas ? tlas_depth + 1 : 0) */
     uint32_t stack_need() const { return blas_depth + (has_tlas ? tlas_depth + 1 : 0); }
 };
+
+/* RoughPlastic::parameters_changed (src/bsdfs/roughplastic.cpp:204-242): m_specular_sampling_weight from the means of the colour slots */
+void update_roughplastic_sampling_weight(HostScene &hs, uint32_t bsdf);
 
 /* returns false and fills `err` on invalid input */
 bool lower_scene(const HarSceneDesc &desc, HostScene &out, std::string &err);

@@ -7,6 +7,7 @@
  */
 #include "mi_oracle.h"
 #include "orc_math.h"
+#include "orc_bsdf.h"
 
 #include <algorithm>
 #include <atomic>
@@ -42,7 +43,7 @@ struct Scene {
     std::vector<Mesh> meshes; uint32_t top_count;
     std::vector<OrcShapeGroup> groups;
     std::vector<OrcInstance> instances;
-    std::vector<OrcBSDF> bsdfs;
+    std::vector<BsdfRecord> bsdfs;
     std::vector<Texture> textures;
     std::vector<OrcEmitter> emitters;
     Bvh top;                       // all top-level meshes
@@ -347,10 +348,39 @@ static inline V3 tex_eval(const Texture &t, const TexLookup &l) {
     }
     return V3(out[0], out[1], out[2]);
 }
-static inline V3 bsdf_reflectance(const Scene &sc, const OrcBSDF &b, const SI &si) {
+static inline V3 bsdf_reflectance(const Scene &sc, const OrcBSDF &b, const SI &si) {   /* (kept for the diffuse-only KAT entry points) */
     if (b.texture < 0) return V3(b.reflectance[0], b.reflectance[1], b.reflectance[2]);  // srgb.cpp: m_value
     TexLookup l; tex_lookup(sc.textures[b.texture], si.uv, l);
     return tex_eval(sc.textures[b.texture], l);
+}
+
+/* TwoSidedBRDF (src/bsdfs/twosided.cpp:112-270) around the nested plugins of orc_bsdf.h.
+ * `used` = record whose parameters are evaluated (front or back), for gradient book-keeping. */
+struct BsdfCtx { const BsdfRecord *rec; uint32_t used; V3 wi; float wo_sign; bool ok; V3 slot0, slot1; TexLookup tl; bool textured; };
+static inline BsdfCtx bsdf_prepare(const Scene &sc, uint32_t index, const SI &si) {
+    BsdfCtx c; c.used = index; c.wi = si.wi; c.wo_sign = 1.f; c.ok = true; c.textured = false;
+    const BsdfRecord *b = &sc.bsdfs[index];
+    if (b->p.flags & 1u) {
+        if (b->p.back < 0) { c.wo_sign = sign1(si.wi.z); c.wi.z = std::fabs(si.wi.z); }       // twosided.cpp:124-127
+        else if (si.wi.z > 0.f) { }
+        else if (si.wi.z < 0.f) { c.used = (uint32_t) b->p.back; b = &sc.bsdfs[c.used]; c.wi.z = -si.wi.z; c.wo_sign = -1.f; }
+        else c.ok = false;
+    }
+    c.rec = b;
+    if (b->p.texture >= 0) { c.textured = true; tex_lookup(sc.textures[b->p.texture], si.uv, c.tl); c.slot0 = tex_eval(sc.textures[b->p.texture], c.tl); }
+    else c.slot0 = V3(b->p.reflectance[0], b->p.reflectance[1], b->p.reflectance[2]);
+    c.slot1 = V3(b->p.reflectance2[0], b->p.reflectance2[1], b->p.reflectance2[2]);
+    return c;
+}
+static inline BSDFEval bsdf_eval_pdf(const BsdfCtx &c, V3 wo) {
+    if (!c.ok) return BSDFEval();
+    return plugin_eval_pdf(*c.rec, c.slot0, c.slot1, c.wi, V3(wo.x, wo.y, wo.z * c.wo_sign));
+}
+static inline BSDFSample bsdf_sample(const BsdfCtx &c, float s1, float s2x, float s2y, V3 &weight) {
+    if (!c.ok) { weight = V3(0.f); return BSDFSample(); }
+    BSDFSample bs = plugin_sample(*c.rec, c.slot0, c.slot1, c.wi, s1, s2x, s2y, weight);
+    bs.wo.z *= c.wo_sign;
+    return bs;
 }
 
 /* SmoothDiffuse::eval_pdf (src/bsdfs/diffuse.cpp:159-179) */
@@ -552,26 +582,25 @@ static V3 path_sample(const Scene &sc, Pcg32 &rng, Ray ray, uint32_t max_depth, 
         bool active_next = (depth + 1 < max_depth) && si.valid();
         valid_ray |= si.valid();                              // path.cpp:307-308 (JIT: evaluated every iteration)
         if (!active_next) break;                              // masked lane: state below is discarded
-        const OrcBSDF &bsdf = sc.bsdfs[sc.meshes[si.mesh].bsdf];
-        V3 refl = bsdf_reflectance(sc, bsdf, si);
-        // emitter sampling, path.cpp:238-258
+        BsdfCtx bsdf = bsdf_prepare(sc, sc.meshes[si.mesh].bsdf, si);          // si.bsdf(ray), path.cpp:232
+        // emitter sampling, path.cpp:236-258: the samples are drawn by every lane, used where the BSDF is Smooth
         float ex = rng.next_float32(), ey = rng.next_float32();
         DS ds; V3 em_weight(0.f), wo(0.f);
-        bool active_em = sample_emitter_direction(sc, si, ex, ey, ds, em_weight, st);
+        bool active_em = bsdf.rec->smooth();
+        if (active_em) active_em = sample_emitter_direction(sc, si, ex, ey, ds, em_weight, st);
         active_em &= ds.pdf != 0.f;
         if (active_em) wo = si.to_local(ds.d);
-        float s1 = rng.next_float32(); (void) s1;
+        float s1 = rng.next_float32();
         float s2x = rng.next_float32(), s2y = rng.next_float32();
-        V3 bsdf_val, bsdf_weight, bwo; float bsdf_pdf, bs_pdf;
-        diffuse_eval_pdf(refl, si.wi, wo, bsdf_val, bsdf_pdf);
-        diffuse_sample(refl, si.wi, s2x, s2y, bwo, bs_pdf, bsdf_weight);
+        BSDFEval ev = bsdf_eval_pdf(bsdf, wo);                                 // bsdf.cpp:21-31 eval_pdf_sample
+        V3 bsdf_weight; BSDFSample bs = bsdf_sample(bsdf, s1, s2x, s2y, bsdf_weight);
         if (active_em) {                                      // path.cpp:271-281
-            float mis_em = mis_weight(ds.pdf, bsdf_pdf);
-            result = fmadd(throughput, (bsdf_val * em_weight) * mis_em, result);
+            float mis_em = mis_weight(ds.pdf, ev.pdf);
+            result = fmadd(throughput, (ev.value * em_weight) * mis_em, result);
         }
-        ray = spawn_ray(si, si.to_world(bwo));                // path.cpp:287
-        throughput = throughput * bsdf_weight; eta *= 1.f;
-        prev_p = si.p; prev_bsdf_pdf = bs_pdf; prev_bsdf_delta = false;
+        ray = spawn_ray(si, si.to_world(bs.wo));              // path.cpp:287
+        throughput = throughput * bsdf_weight; eta *= bs.eta;
+        prev_p = si.p; prev_bsdf_pdf = bs.pdf; prev_bsdf_delta = bs.delta;
         depth += 1;                                           // path.cpp:317 (si valid here)
         float tmax = hmax(throughput);
         float rr_prob = std::fmin(tmax * sqr(eta), .95f);
@@ -619,36 +648,30 @@ static V3 prb_sample(const Scene &sc, Pcg32 &rng, Ray ray, uint32_t max_depth, u
             }
         }
         active_next &= (depth + 1 < max_depth) && si.valid();  // prb.py:166
-        bool active_em = active_next;                            // diffuse is Smooth
+        BsdfCtx bsdf{}; bsdf.ok = false; bsdf.rec = nullptr; bsdf.wo_sign = 1.f;
+        if (si.valid()) bsdf = bsdf_prepare(sc, sc.meshes[si.mesh].bsdf, si);
+        bool active_em = active_next && bsdf.rec && bsdf.rec->smooth();          // prb.py:169
         float ex = rng.next_float32(), ey = rng.next_float32();
         DS ds; V3 em_weight(0.f);
-        V3 refl(0.f); TexLookup tl{}; const OrcBSDF *bsdf = nullptr;
-        if (si.valid()) {
-            bsdf = &sc.bsdfs[sc.meshes[si.mesh].bsdf];
-            if (bsdf->texture >= 0) { tex_lookup(sc.textures[bsdf->texture], si.uv, tl); refl = tex_eval(sc.textures[bsdf->texture], tl); }
-            else refl = V3(bsdf->reflectance[0], bsdf->reflectance[1], bsdf->reflectance[2]);
-        }
         if (active_em) { sample_emitter_direction(sc, si, ex, ey, ds, em_weight, st); active_em &= ds.pdf != 0.f; }
         // prb.py:210-216
         V3 Lr_dir(0.f), dLr_dir_drho(0.f);
         if (active_em) {
             V3 wo = si.to_local(ds.d);
-            V3 bsdf_value_em; float bsdf_pdf_em;
-            diffuse_eval_pdf(refl, si.wi, wo, bsdf_value_em, bsdf_pdf_em);
-            float mis_em = mis_weight(ds.pdf, bsdf_pdf_em);
-            Lr_dir = ((beta * mis_em) * bsdf_value_em) * em_weight;
-            bool a = si.wi.z > 0.f && wo.z > 0.f;
-            if (a) dLr_dir_drho = ((beta * mis_em) * (InvPi * wo.z)) * em_weight;      // d/d rho of the line above
+            BSDFEval ev = bsdf_eval_pdf(bsdf, wo);
+            float mis_em = mis_weight(ds.pdf, ev.pdf);
+            Lr_dir = ((beta * mis_em) * ev.value) * em_weight;
+            dLr_dir_drho = ((beta * mis_em) * ev.d_slot0) * em_weight;           // d/d slot0 of the line above
         }
         // detached BSDF sampling, prb.py:220-223 (masked lanes return zeros)
-        float s1 = rng.next_float32(); (void) s1;
+        float s1 = rng.next_float32();
         float s2x = rng.next_float32(), s2y = rng.next_float32();
-        V3 bwo(0.f), bsdf_weight(0.f); float bs_pdf = 0.f, bs_eta = 0.f;
-        if (active_next) { diffuse_sample(refl, si.wi, s2x, s2y, bwo, bs_pdf, bsdf_weight); bs_eta = 1.f; }
+        V3 bwo(0.f), bsdf_weight(0.f); float bs_pdf = 0.f, bs_eta = 0.f; bool bs_delta = false;
+        if (active_next) { BSDFSample bs = bsdf_sample(bsdf, s1, s2x, s2y, bsdf_weight); bwo = bs.wo; bs_pdf = bs.pdf; bs_eta = bs.eta; bs_delta = bs.delta; }
         L = primal ? (L + Le) + Lr_dir : (L - Le) - Lr_dir;      // prb.py:227
         Ray ray_next = spawn_ray(si, si.to_world(bwo));
         eta *= bs_eta; beta = beta * bsdf_weight;
-        prev_p = si.p; bsdf_pdf_prev = bs_pdf; bsdf_delta_prev = false;
+        prev_p = si.p; bsdf_pdf_prev = bs_pdf; bsdf_delta_prev = bs_delta;
         float beta_max = hmax(beta);
         active_next &= beta_max != 0.f;
         float rr_prob = std::fmin(beta_max * (eta * eta), .95f);
@@ -658,17 +681,21 @@ static V3 prb_sample(const Scene &sc, Pcg32 &rng, Ray ray, uint32_t max_depth, u
         active_next &= !rr_active || rr_continue;
         PI pi_next;
         if (active_next) { st.closest_rays++; scene_trace<false>(sc, ray_next, pi_next, 0); }
-        if (!primal && grad && si.valid() && bsdf) {            // prb.py:263-313 specialised
+        if (!primal && grad && si.valid() && bsdf.rec) {        // prb.py:263-313 specialised to slot-0 colour parameters
             V3 wo = si.to_local(ray_next.d);
-            bool a = active_next && si.wi.z > 0.f && wo.z > 0.f; // bsdf.eval(si, wo, active_next) != 0
             V3 g = dLr_dir_drho;
-            if (a) g = g + V3(refl.x != 0.f ? L.x / refl.x : 0.f, refl.y != 0.f ? L.y / refl.y : 0.f, refl.z != 0.f ? L.z / refl.z : 0.f);
+            if (active_next) {                                   // Lr_ind = L * relative_grad(bsdf.eval(si, wo, active_next))
+                BSDFEval e2 = bsdf_eval_pdf(bsdf, wo);
+                g = g + V3(e2.value.x != 0.f ? L.x * (e2.d_slot0.x / e2.value.x) : 0.f, e2.value.y != 0.f ? L.y * (e2.d_slot0.y / e2.value.y) : 0.f,
+                           e2.value.z != 0.f ? L.z * (e2.d_slot0.z / e2.value.z) : 0.f);
+            }
             g = g * dL;
-            if (bsdf->texture < 0) {
-                float *dst = grad->refl + 3 * (size_t) sc.meshes[si.mesh].bsdf;
+            if (!bsdf.textured) {
+                float *dst = grad->refl + 3 * (size_t) bsdf.used;
                 dst[0] += g.x; dst[1] += g.y; dst[2] += g.z;
             } else {
-                float *dst = grad->tex[bsdf->texture];
+                const TexLookup &tl = bsdf.tl;
+                float *dst = grad->tex[bsdf.rec->p.texture];
                 const float wts[4] = { tl.w[0] * tl.w[2], tl.w[1] * tl.w[2], tl.w[0] * tl.w[3], tl.w[1] * tl.w[3] };
                 for (int k = 0; k < 4; ++k) { float *q = dst + 3 * (size_t) tl.idx[k]; q[0] += g.x * wts[k]; q[1] += g.y * wts[k]; q[2] += g.z * wts[k]; }
             }
@@ -747,6 +774,14 @@ static int render_forward(Scene &sc, const OrcSensor &s, uint32_t seed, uint32_t
 
 extern "C" {
 
+/* Texture::mean of slot 0: SRGBReflectanceSpectrum::mean (srgb.cpp:117-122) / BitmapTexture::mean (bitmap.cpp:730) */
+static float slot0_mean(const Scene &sc, uint32_t i) {
+    const OrcBSDF &p = sc.bsdfs[i].p;
+    if (p.texture < 0) return (p.reflectance[0] + p.reflectance[1] + p.reflectance[2]) / 3.f;
+    const Texture &t = sc.textures[p.texture]; double acc = 0; for (float v : t.data) acc += v;
+    return (float) (acc / (double) t.data.size());
+}
+
 void *orc_scene_create(const OrcSceneDesc *d) {
     Scene *sc = new Scene();
     sc->top_count = d->top_mesh_count;
@@ -759,13 +794,14 @@ void *orc_scene_create(const OrcSceneDesc *d) {
     }
     sc->groups.assign(d->groups, d->groups + d->group_count);
     sc->instances.assign(d->instances, d->instances + d->instance_count);
-    sc->bsdfs.assign(d->bsdfs, d->bsdfs + d->bsdf_count);
+    for (uint32_t i = 0; i < d->bsdf_count; ++i) { BsdfRecord r; r.p = d->bsdfs[i]; if (!(r.p.flags & 1u)) r.p.back = -1; sc->bsdfs.push_back(r); }
     for (uint32_t i = 0; i < d->texture_count; ++i) {
         Texture t; t.w = d->textures[i].width; t.h = d->textures[i].height;
         t.data.assign(d->textures[i].data, d->textures[i].data + 3 * (size_t) t.w * t.h);
         sc->textures.push_back(std::move(t));
     }
     sc->emitters.assign(d->emitters, d->emitters + d->emitter_count);
+    for (uint32_t i = 0; i < sc->bsdfs.size(); ++i) if (sc->bsdfs[i].p.type == 3) roughplastic_precompute(sc->bsdfs[i], slot0_mean(*sc, i));
     build_tri_bvh(sc->top, sc->meshes, 0, sc->top_count);
     sc->group_bvh.resize(sc->groups.size());
     for (size_t g = 0; g < sc->groups.size(); ++g) build_tri_bvh(sc->group_bvh[g], sc->meshes, sc->groups[g].first_mesh, sc->groups[g].mesh_count);
@@ -791,7 +827,10 @@ void *orc_scene_create(const OrcSceneDesc *d) {
     return sc;
 }
 void orc_scene_destroy(void *s) { delete (Scene *) s; }
-void orc_scene_set_reflectance(void *s, uint32_t b, const float rgb[3]) { for (int i = 0; i < 3; ++i) ((Scene *) s)->bsdfs[b].reflectance[i] = rgb[i]; }
+void orc_scene_set_reflectance(void *s, uint32_t b, const float rgb[3]) {
+    Scene *sc = (Scene *) s; for (int i = 0; i < 3; ++i) sc->bsdfs[b].p.reflectance[i] = rgb[i];
+    if (sc->bsdfs[b].p.type == 3) roughplastic_precompute(sc->bsdfs[b], slot0_mean(*sc, b));
+}
 void orc_scene_set_texture(void *s, uint32_t t, const float *data) { Texture &x = ((Scene *) s)->textures[t]; x.data.assign(data, data + 3 * (size_t) x.w * x.h); }
 
 void orc_ray_intersect(void *scene, uint32_t n, const float *o, const float *d, const float *maxt, int mode,
@@ -962,6 +1001,40 @@ void orc_surface_interaction(void *scene, const float o[3], const float d[3], fl
     const V3 vs[6] = { si.p, si.n, si.sn, si.ss, si.st, si.wi };
     for (int i = 0; i < 6; ++i) { out[3 * i] = vs[i].x; out[3 * i + 1] = vs[i].y; out[3 * i + 2] = vs[i].z; }
     out[18] = si.uv[0]; out[19] = si.uv[1]; out[20] = si.t; out[21] = out[22] = out[23] = 0.f;
+}
+
+
+void orc_microfacet_eval(int type, float alpha_u, float alpha_v, int sample_visible, const float wi[3], const float m[3], float out[3]) {
+    MicrofacetDistribution d(type ? MicrofacetType::GGX : MicrofacetType::Beckmann, alpha_u, alpha_v, sample_visible != 0);
+    V3 w(wi[0], wi[1], wi[2]), mm(m[0], m[1], m[2]);
+    out[0] = d.eval(mm); out[1] = d.pdf(w, mm); out[2] = d.smith_g1(w, mm);
+}
+void orc_microfacet_sample(int type, float alpha_u, float alpha_v, int sample_visible, const float wi[3], const float sample[2], float m[3], float *pdf) {
+    MicrofacetDistribution d(type ? MicrofacetType::GGX : MicrofacetType::Beckmann, alpha_u, alpha_v, sample_visible != 0);
+    V3 r = d.sample(V3(wi[0], wi[1], wi[2]), sample[0], sample[1], *pdf);
+    m[0] = r.x; m[1] = r.y; m[2] = r.z;
+}
+void orc_fresnel(float cos_theta_i, float eta, float out[4]) { FresnelResult f = fresnel(cos_theta_i, eta); out[0] = f.r; out[1] = f.cos_theta_t; out[2] = f.eta_it; out[3] = f.eta_ti; }
+float orc_fresnel_conductor(float cos_theta_i, float eta, float k) { return fresnel_conductor(cos_theta_i, eta, k); }
+void orc_bsdf_eval_pdf(void *scene, uint32_t bsdf, const float wi[3], const float uv[2], const float wo[3], float value[3], float *pdf) {
+    const Scene &sc = *(Scene *) scene;
+    SI si; si.wi = V3(wi[0], wi[1], wi[2]); si.uv[0] = uv[0]; si.uv[1] = uv[1];
+    BsdfCtx c = bsdf_prepare(sc, bsdf, si);
+    BSDFEval e = bsdf_eval_pdf(c, V3(wo[0], wo[1], wo[2]));
+    value[0] = e.value.x; value[1] = e.value.y; value[2] = e.value.z; *pdf = e.pdf;
+}
+void orc_bsdf_sample(void *scene, uint32_t bsdf, const float wi[3], const float uv[2], float sample1, const float sample2[2],
+                     float wo[3], float *pdf, float weight[3], float *eta, int *delta) {
+    const Scene &sc = *(Scene *) scene;
+    SI si; si.wi = V3(wi[0], wi[1], wi[2]); si.uv[0] = uv[0]; si.uv[1] = uv[1];
+    BsdfCtx c = bsdf_prepare(sc, bsdf, si);
+    V3 w; BSDFSample bs = bsdf_sample(c, sample1, sample2[0], sample2[1], w);
+    wo[0] = bs.wo.x; wo[1] = bs.wo.y; wo[2] = bs.wo.z; *pdf = bs.pdf; weight[0] = w.x; weight[1] = w.y; weight[2] = w.z; *eta = bs.eta; *delta = bs.delta ? 1 : 0;
+}
+void orc_roughplastic_tables(void *scene, uint32_t bsdf, float out[66]) {
+    const BsdfRecord &b = ((Scene *) scene)->bsdfs[bsdf];
+    for (int i = 0; i < 64; ++i) out[i] = i < (int) b.external_transmittance.size() ? b.external_transmittance[i] : 0.f;
+    out[64] = b.internal_reflectance; out[65] = b.specular_sampling_weight;
 }
 
 } // extern "C"

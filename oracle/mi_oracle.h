@@ -53,10 +53,20 @@ typedef struct OrcInstance {
     float to_object[12];
 } OrcInstance;
 
+/* type 0 diffuse, 1 dielectric, 2 roughconductor, 3 roughplastic (src/bsdfs); two colour slots
+ * (reflectance = slot 0, may be a bitmap; reflectance2 = slot 1); flags: bit0 twosided, bit1 GGX,
+ * bit2 sample_visible, bit3 roughplastic nonlinear; back = BSDF of the back side of a twosided pair or -1.
+ * Field for field the layout of HarBSDF (include/hip_ad_rgb.h). */
 typedef struct OrcBSDF {
-    uint32_t type;        /* 0 = diffuse (src/bsdfs/diffuse.cpp) */
-    int32_t  texture;     /* -1: constant `reflectance`, else index of bitmap */
+    uint32_t type;
+    int32_t  texture;     /* -1: constant slot 0, else index of bitmap */
     float    reflectance[3];
+    uint32_t flags;
+    float    reflectance2[3];
+    float    alpha_u, alpha_v;
+    float    eta;
+    float    eta_c[3], k_c[3];
+    int32_t  back;
 } OrcBSDF;
 
 /* bitmap texture, H x W x 3 f32, bilinear + repeat (src/textures/bitmap.cpp:175-206) */
@@ -105,6 +115,22 @@ void  orc_scene_destroy(void *scene);
 /* update a constant reflectance / a texture in place (for finite differences) */
 void  orc_scene_set_reflectance(void *scene, uint32_t bsdf, const float rgb[3]);
 void  orc_scene_set_texture(void *scene, uint32_t texture, const float *data);
+
+/* ---- BSDF / microfacet building blocks (golden-vector checks; src/render/tests/test_microfacet.py,
+ *      src/bsdfs/tests/test_dielectric.py, test_twosided.py) ---- */
+/* MicrofacetDistribution(type 0 beckmann / 1 ggx, alpha_u, alpha_v, sample_visible): out = {eval(m), pdf(wi, m), smith_g1(wi, m)} */
+void  orc_microfacet_eval(int type, float alpha_u, float alpha_v, int sample_visible, const float wi[3], const float m[3], float out[3]);
+/* sample(wi, sample) -> m[3], pdf */
+void  orc_microfacet_sample(int type, float alpha_u, float alpha_v, int sample_visible, const float wi[3], const float sample[2], float m[3], float *pdf);
+/* fresnel(cos_theta_i, eta) -> {r, cos_theta_t, eta_it, eta_ti};  fresnel_conductor(cos, eta, k) */
+void  orc_fresnel(float cos_theta_i, float eta, float out[4]);
+float orc_fresnel_conductor(float cos_theta_i, float eta, float k);
+/* BSDF::eval_pdf / BSDF::sample of scene BSDF `bsdf` (twosided handled): wi, wo local; uv[2] */
+void  orc_bsdf_eval_pdf(void *scene, uint32_t bsdf, const float wi[3], const float uv[2], const float wo[3], float value[3], float *pdf);
+void  orc_bsdf_sample(void *scene, uint32_t bsdf, const float wi[3], const float uv[2], float sample1, const float sample2[2],
+                      float wo[3], float *pdf, float weight[3], float *eta, int *delta);
+/* roughplastic precomputation of scene BSDF `bsdf`: out[0..63] external transmittance, out[64] internal reflectance, out[65] specular sampling weight */
+void  orc_roughplastic_tables(void *scene, uint32_t bsdf, float out[66]);
 
 /* ---- ray queries: Scene::ray_intersect_preliminary / ray_test / _naive ---- */
 /* mode: 0 = BVH, 1 = brute force.  rays SoA: o[3][n], d[3][n], maxt[n]. */

@@ -32,7 +32,9 @@ class Instance(C.Structure):
 
 
 class BSDF(C.Structure):
-    _fields_ = [("type", C.c_uint32), ("texture", C.c_int32), ("reflectance", C.c_float * 3)]
+    _fields_ = [("type", C.c_uint32), ("texture", C.c_int32), ("reflectance", C.c_float * 3), ("flags", C.c_uint32),
+                ("reflectance2", C.c_float * 3), ("alpha_u", C.c_float), ("alpha_v", C.c_float), ("eta", C.c_float),
+                ("eta_c", C.c_float * 3), ("k_c", C.c_float * 3), ("back", C.c_int32)]
 
 
 class Texture(C.Structure):
@@ -230,8 +232,16 @@ class SceneData:
             insts[i].to_world = (C.c_float * 12)(*[float(x) for x in tw])
             insts[i].to_object = (C.c_float * 12)(*[float(x) for x in to])
         bsdfs = (B * max(1, len(self.bsdfs)))()
-        for i, (t, tex, rgb) in enumerate(self.bsdfs):
-            bsdfs[i].type = t; bsdfs[i].texture = tex; bsdfs[i].reflectance = (C.c_float * 3)(*[float(x) for x in rgb])
+        for i, entry in enumerate(self.bsdfs):
+            # (type, texture, rgb) for diffuse, or (type, texture, rgb, extra) with extra = dict(flags=, reflectance2=, alpha_u=,
+            # alpha_v=, eta=, eta_c=, k_c=, back=) for the other plugins
+            t, tex, rgb = entry[0], entry[1], entry[2]
+            x = entry[3] if len(entry) > 3 else {}
+            bsdfs[i].type = t; bsdfs[i].texture = tex; bsdfs[i].reflectance = (C.c_float * 3)(*[float(v) for v in rgb])
+            bsdfs[i].flags = int(x.get("flags", 0)); bsdfs[i].reflectance2 = (C.c_float * 3)(*[float(v) for v in x.get("reflectance2", (0, 0, 0))])
+            bsdfs[i].alpha_u = float(x.get("alpha_u", 0.1)); bsdfs[i].alpha_v = float(x.get("alpha_v", 0.1)); bsdfs[i].eta = float(x.get("eta", 1.0))
+            bsdfs[i].eta_c = (C.c_float * 3)(*[float(v) for v in x.get("eta_c", (0, 0, 0))]); bsdfs[i].k_c = (C.c_float * 3)(*[float(v) for v in x.get("k_c", (1, 1, 1))])
+            bsdfs[i].back = int(x.get("back", -1))
         texs = (TX * max(1, len(self.textures)))()
         for i, t in enumerate(self.textures):
             texs[i].data = fp(t); texs[i].height = t.shape[0]; texs[i].width = t.shape[1]

@@ -82,6 +82,27 @@ def transcribe_kats():
         if 70 < no < 95:
             keys += [int(x, 16) for x in re.findall(r"0x[0-9a-fA-F]{8}", line)]
     out["tea_constants"] = {"values": keys, "src": "%s:76-90" % rel}
+    # --- dielectric sample KATs (src/bsdfs/tests/test_dielectric.py: example_bsdf + test02_sample / test03_sample_reverse, Radiance mode)
+    rel = "src/bsdfs/tests/test_dielectric.py"
+    L = _lines(rel); txt = "\n".join(L)
+    m = re.search(r"def example_bsdf\(reflectance=([0-9.]+), transmittance=([0-9.]+)\)", txt)
+    refl, trans = float(m.group(1)), float(m.group(2))
+    int_ior = float(re.search(r"'int_ior': ([0-9.]+)", txt).group(1)); ext_ior = float(re.search(r"'ext_ior': ([0-9.]+)", txt).group(1))
+    pdf_r = float(re.search(r"dr\.allclose\(bs\.pdf, ([0-9.]+)\)", txt).group(1))
+    line = next(i for i, l in enumerate(L, 1) if "def test02_sample" in l)
+    out["dielectric_sample"] = {
+        "bsdf": {"specular_reflectance": refl, "specular_transmittance": trans, "int_ior": int_ior, "ext_ior": ext_ior},
+        "cases": [
+            {"wi": [0, 0, 1], "sample1": 0.0, "weight": [refl] * 3, "pdf": pdf_r, "eta": 1.0, "wo": [0, 0, 1], "delta": True},
+            {"wi": [0, 0, 1], "sample1": 0.05, "weight": [trans / int_ior ** 2] * 3, "pdf": 1 - pdf_r, "eta": int_ior, "wo": [0, 0, -1], "delta": True},
+            {"wi": [0, 0, -1], "sample1": 0.0, "weight": [refl] * 3, "pdf": pdf_r, "eta": 1.0, "wo": [0, 0, -1], "delta": True},
+            {"wi": [0, 0, -1], "sample1": 0.05, "weight": [trans * int_ior ** 2] * 3, "pdf": 1 - pdf_r, "eta": 1 / int_ior, "wo": [0, 0, 1], "delta": True},
+        ],
+        "src": "%s:%d-%d (TransportMode.Radiance branch)" % (rel, line, line + 62)}
+    # --- twosided(diffuse) pdf (src/bsdfs/tests/test_twosided.py: test02_pdf)
+    rel = "src/bsdfs/tests/test_twosided.py"
+    line = next(i for i, l in enumerate(_lines(rel), 1) if "def test02_pdf" in l)
+    out["twosided_pdf"] = {"wi": [0, 0, 1], "cases": [{"wo": [0, 0, 1], "pdf": 1 / np.pi}, {"wo": [0, 0, -1], "pdf": 0.0}], "src": "%s:%d-%d" % (rel, line, line + 18)}
     # --- published PCG32 demo vector (pcg-random.org pcg32-demo, seed 42/54); drjit is NOT in the tree
     out["pcg32_published"] = {"initstate": 42, "initseq": 54,
                               "outputs": [0xa15c02b7, 0x7b47f409, 0xba1d3330, 0x83d2f293, 0xbfa4784b, 0xcbed606e],

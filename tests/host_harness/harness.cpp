@@ -39,9 +39,10 @@ static void bind(HScene &H) {
     S.accel.root = hs.root; S.accel.has_tlas = hs.has_tlas; S.accel.n_tris = (uint32_t) hs.tris.size(); S.accel.n_insts = (uint32_t) hs.inst_recs.size();
     S.blas_tri_ranges = hs.blas_tri_ranges.data();
     S.verts = hs.verts.data(); S.faces = hs.faces.data(); S.meshes = hs.meshes.data(); S.bsdfs = hs.bsdfs.data();
-    S.textures = H.dtex.data(); S.emitters = hs.emitters.data(); S.insts = hs.insts.data();
+    S.textures = H.dtex.data(); S.emitters = hs.emitters.data(); S.insts = hs.insts.data(); S.bsdf_tables = hs.bsdf_tables.data();
     S.n_emitters = (uint32_t) hs.emitters.size(); S.n_meshes = (uint32_t) hs.meshes.size();
     S.n_bsdfs = (uint32_t) hs.bsdfs.size(); S.n_textures = (uint32_t) hs.textures.size();
+    S.bsdf_types = 0; for (const DBsdf &b : hs.bsdfs) S.bsdf_types |= (1u << b.type) | ((b.flags & BF_TWOSIDED) ? 0x80000000u : 0u);
 }
 
 extern "C" {
@@ -56,6 +57,39 @@ void *hh_scene_create(const HarSceneDesc *d, char *err, int errlen) {
 void hh_scene_destroy(void *h) { delete (HScene *) h; }
 void hh_scene_info(void *h, uint64_t info[4]) {
     HScene *H = (HScene *) h; info[0] = H->hs.nodes.size(); info[1] = H->hs.tris.size(); info[2] = H->hs.stats.max_depth; info[3] = H->hs.inst_recs.size();
+}
+
+/* product BSDF code on the host: BSDF::eval_pdf / sample of scene BSDF `bsdf` (twosided handled) */
+void hh_bsdf_eval_pdf(void *h, uint32_t bsdf, const float wi[3], const float uv[2], const float wo[3], float value[3], float *pdf) {
+    HScene *H = (HScene *) h; const DScene &S = H->ds;
+    BsdfSide side; bool ok = bsdf_side(S, bsdf, Vec3(wi[0], wi[1], wi[2]), side);
+    TexTaps taps; BsdfInputs in = bsdf_inputs(S, S.bsdfs[side.index], uv[0], uv[1], taps);
+    BsdfEval e; bsdf_eval_pdf(S, side, in, ok, Vec3(wo[0], wo[1], wo[2]), e);
+    value[0] = e.value.x; value[1] = e.value.y; value[2] = e.value.z; *pdf = e.pdf;
+}
+void hh_bsdf_sample(void *h, uint32_t bsdf, const float wi[3], const float uv[2], float s1, const float s2[2], float wo[3], float *pdf, float weight[3], float *eta, int *delta) {
+    HScene *H = (HScene *) h; const DScene &S = H->ds;
+    BsdfSide side; bool ok = bsdf_side(S, bsdf, Vec3(wi[0], wi[1], wi[2]), side);
+    TexTaps taps; BsdfInputs in = bsdf_inputs(S, S.bsdfs[side.index], uv[0], uv[1], taps);
+    BsdfSample b; bsdf_sample(S, side, in, ok, s1, s2[0], s2[1], b);
+    wo[0] = b.wo.x; wo[1] = b.wo.y; wo[2] = b.wo.z; *pdf = b.pdf; weight[0] = b.weight.x; weight[1] = b.weight.y; weight[2] = b.weight.z; *eta = b.eta; *delta = b.delta;
+}
+void hh_microfacet_eval(int type, float alpha_u, float alpha_v, int sample_visible, const float wi[3], const float m[3], float out[3]) {
+    Microfacet d(type != 0, alpha_u, alpha_v, sample_visible != 0);
+    Vec3 w(wi[0], wi[1], wi[2]), mm(m[0], m[1], m[2]);
+    out[0] = d.eval(mm); out[1] = d.pdf(w, mm); out[2] = d.smith_g1(w, mm);
+}
+void hh_microfacet_sample(int type, float alpha_u, float alpha_v, int sample_visible, const float wi[3], const float sample[2], float m[3], float *pdf) {
+    Microfacet d(type != 0, alpha_u, alpha_v, sample_visible != 0);
+    Vec3 r = d.sample(Vec3(wi[0], wi[1], wi[2]), sample[0], sample[1], *pdf);
+    m[0] = r.x; m[1] = r.y; m[2] = r.z;
+}
+void hh_fresnel(float cos_theta_i, float eta, float out[4]) { fresnel_dielectric(cos_theta_i, eta, out[0], out[1], out[2], out[3]); }
+float hh_fresnel_conductor(float cos_theta_i, float eta, float k) { return fresnel_conductor(cos_theta_i, eta, k); }
+void hh_roughplastic_tables(void *h, uint32_t bsdf, float out[66]) {
+    HScene *H = (HScene *) h; const DBsdf &b = H->hs.bsdfs[bsdf];
+    for (int i = 0; i < 64; ++i) out[i] = b.table >= 0 ? H->hs.bsdf_tables[b.table + i] : 0.f;
+    out[64] = b.internal_reflectance; out[65] = b.spec_sampling_weight;
 }
 
 int hh_trace(void *h, uint32_t n, const float *o, const float *d, const float *maxt, int naive, int anyhit,

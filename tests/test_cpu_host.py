@@ -22,7 +22,10 @@ def oracle_scene_from(O, scene):
         sd.add_mesh(m["V"], m["F"], m["bsdf"], m["emitter"], m["flags"])
     sd.top_mesh_count = scene.top_mesh_count
     sd.groups = list(scene.groups); sd.instances = list(scene.instances)
-    sd.bsdfs = [(0, b.tex_index if b.texture is not None else -1, b.value) for b in scene.bsdf_objs]
+    types = {"diffuse": 0, "dielectric": 1, "roughconductor": 2, "roughplastic": 3}
+    sd.bsdfs = [(types[b.kind], b.tex_index if b.texture is not None else -1, b.value,
+                 dict(flags=b.flags, reflectance2=b.value2, alpha_u=b.alpha_u, alpha_v=b.alpha_v, eta=b.eta, eta_c=b.eta_c, k_c=b.k_c,
+                      back=b.back.index if b.back is not None else -1)) for b in scene.bsdf_objs]
     sd.textures = list(scene.textures); sd.emitters = list(scene.emitters)
     s = O.Sensor()
     C.memmove(C.byref(s), C.byref(scene.sensors()[0].har), C.sizeof(s))
@@ -176,7 +179,11 @@ def test_error_behaviour_without_side_effects(mi):
     with pytest.raises(ImportError):
         mi.set_variant("cuda_ad_rgb")
     with pytest.raises(RuntimeError):
-        mi.load_dict({"type": "roughconductor"})
+        mi.load_dict({"type": "principled"})                      # a plugin outside the scope of hip_ad_rgb
+    with pytest.raises(RuntimeError):
+        mi.load_dict({"type": "dielectric", "int_ior": -0.5})       # src/bsdfs/tests/test_dielectric.py:24-26
+    with pytest.raises(RuntimeError):
+        mi.load_dict({"type": "twosided", "b": {"type": "dielectric"}})   # twosided.cpp:79-83
     with pytest.raises(RuntimeError):
         mi.load_dict({"type": "path", "rr_depth": 0})
     with pytest.raises(RuntimeError):
