@@ -29,7 +29,7 @@ def parse():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=3)
     ap.add_argument("--warmup", type=int, default=1)
-    ap.add_argument("--workload", default="instanced1m", choices=["instanced1m", "flat1m", "cornell"])
+    ap.add_argument("--workload", default="instanced1m", choices=["instanced1m", "flat1m", "cornell", "materials1m"])
     ap.add_argument("--res", type=int, default=512)
     ap.add_argument("--spp", type=int, default=256)
     ap.add_argument("--max-depth", type=int, default=8)
@@ -47,7 +47,8 @@ def build_scene(mi, args, integrator_type):
         d["sensor"]["sampler"]["sample_count"] = args.spp
     else:
         d = mi.instanced_spheres_scene(width=args.res, height=args.res, spp=args.spp, grid=10, n_u=100, n_v=50,
-                                       flatten=(args.workload == "flat1m"), max_depth=args.max_depth)
+                                       flatten=(args.workload in ("flat1m", "materials1m")), max_depth=args.max_depth,
+                                       materials=(args.workload == "materials1m"))
     d["integrator"] = {"type": integrator_type, "max_depth": args.max_depth, "rr_depth": 5, "chunk_lanes": args.chunk}
     return mi.load_dict(d)
 

@@ -190,6 +190,12 @@ __global__ __launch_bounds__(kBlock) void k_raygen(DSensor C, uint32_t seed, uin
 #ifndef HAR_EXTRA_MIN
 #define HAR_EXTRA_MIN 8u
 #endif
+#ifndef HAR_SHADE_MIN_WAVES
+#define HAR_SHADE_MIN_WAVES 4     /* __launch_bounds__ waves/SIMD of the shading kernels: caps the generic (all-BSDF) kernel at 128 VGPRs; measured 28.4 -> 24.7 ms on the materials scene */
+#endif
+#ifndef HAR_MATERIAL_SORT
+#define HAR_MATERIAL_SORT 1
+#endif
 #ifndef HAR_TRAV_ORDER
 #define HAR_TRAV_ORDER 0    /* measured: 0 (node, leaf, pop) 687, 2: 660, 1: 643 Mpaths/s on the 1M-tri scene */
 #endif
@@ -277,14 +283,37 @@ __global__ __launch_bounds__(kBlock) void k_trace_closest(Accel A, const uint32_
 
 /* ------------------------------------------------------------------- shade */
 template <int MODE, uint32_t TYPES>
-__global__ __launch_bounds__(kBlock) void k_shade(DScene S, ShadeParams P, uint32_t lane_base, uint32_t shard_cap, const uint32_t *count_in, WaveState in,
+__global__ __launch_bounds__(kBlock, HAR_SHADE_MIN_WAVES) void k_shade(DScene S, ShadeParams P, uint32_t lane_base, uint32_t shard_cap, const uint32_t *count_in, WaveState in,
                                                   const float4 *h0, const uint2 *h1, WaveState out, uint32_t *count_out,
                                                   ItemArrays items, uint32_t *item_count, float4 *result) {
     __shared__ uint32_t lds_r[12];
+    __shared__ uint32_t sort_cnt[8], sort_perm[TYPES == HAR_BSDF_ONLY_DIFFUSE ? 1 : kBlock];
     const ShardLoop Q(count_in, shard_cap);
     uint32_t *cnt_alive = count_out + Q.shard * HAR_COUNTER_STRIDE, *cnt_item = item_count + Q.shard * HAR_COUNTER_STRIDE;
     for (uint32_t tile = Q.first_tile(); tile * kBlock < Q.n; tile += Q.tile_step()) {
-        const uint32_t local = tile * kBlock + threadIdx.x;
+        uint32_t local = tile * kBlock + threadIdx.x;
+        if (TYPES != HAR_BSDF_ONLY_DIFFUSE && HAR_MATERIAL_SORT) {
+            /* MATERIAL SORT: the 256 paths of this tile are re-dealt to the lanes by the BSDF type of the surface they hit
+             * (block-wide counting sort in LDS), so that a wave runs (mostly) ONE material model of the generic shading
+             * code instead of diverging over all of them.  The tile is a contiguous 4 KB window per state array, so the
+             * permuted loads still consume whole cache lines. */
+            uint32_t key = 5u;                                         /* 4 = miss, 5 = out of range */
+            if (local < Q.n) {
+                const uint2 hs = h1[Q.base + local];
+                const float t = h0[Q.base + local].x;
+                key = t == HAR_INF ? 4u : S.bsdfs[S.meshes[hs.x].bsdf].type;
+            }
+            if (threadIdx.x < 8) sort_cnt[threadIdx.x] = 0;
+            __syncthreads();
+            const uint32_t pos = atomicAdd(&sort_cnt[key], 1u);
+            __syncthreads();
+            uint32_t off = 0;
+            for (uint32_t k = 0; k < key; ++k) off += sort_cnt[k];
+            sort_perm[off + pos] = threadIdx.x;
+            __syncthreads();
+            local = tile * kBlock + sort_perm[threadIdx.x];
+            __syncthreads();
+        }
         const bool in_range = local < Q.n;
         const uint32_t i = Q.base + local;
         ShadeResult R; R.alive = false; R.item = false; R.add_emission = false;

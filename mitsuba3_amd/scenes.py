@@ -25,7 +25,7 @@ def bumpy_sphere(n_u=100, n_v=50, radius=0.08):
     return P.astype(np.float32), N.astype(np.float32), UV.astype(np.float32), np.asarray(F, np.uint32)
 
 
-def instanced_spheres_scene(width=512, height=512, spp=256, grid=10, n_u=100, n_v=50, flatten=False, max_depth=8):
+def instanced_spheres_scene(width=512, height=512, spp=256, grid=10, n_u=100, n_v=50, flatten=False, max_depth=8, materials=False):
     """C3 of SURVEY.md 8(d): Cornell box + grid x grid instances of a 2*n_u*n_v-triangle bumpy
     sphere (10 x 10 x 10 000 = 1.0 M effective triangles).  flatten=True bakes every instance
     into unique triangles (true BVH-size stress)."""
@@ -36,6 +36,10 @@ def instanced_spheres_scene(width=512, height=512, spp=256, grid=10, n_u=100, n_
     d['integrator']['max_depth'] = max_depth
     for k in ('small-box', 'large-box'):
         d.pop(k)
+    if materials:       # every BSDF plugin of the hot path: rough plastic walls, GGX conductor / diffuse / glass spheres
+        d['white'] = {'type': 'roughplastic', 'diffuse_reflectance': {'type': 'rgb', 'value': [0.885809, 0.698859, 0.666422]}, 'alpha': 0.2}
+        d['green'] = {'type': 'twosided', 'm': {'type': 'roughconductor', 'distribution': 'ggx', 'alpha': 0.15, 'eta': [0.2, 0.92, 1.1], 'k': [3.9, 2.45, 2.14]}}
+        d['glass'] = {'type': 'dielectric', 'int_ior': 1.5}
     P, N, UV, F = bumpy_sphere(n_u, n_v)
     mesh = {'type': 'mesh', 'positions': P, 'normals': N, 'texcoords': UV, 'faces': F, 'bsdf': {'type': 'ref', 'id': 'white'}}
     if not flatten:
@@ -47,7 +51,8 @@ def instanced_spheres_scene(width=512, height=512, spp=256, grid=10, n_u=100, n_
             z = -0.5 + 0.9 * ((gx * 7 + gy * 3) % grid) / max(grid - 1, 1)
             tf = T().translate([x, y, z]).rotate([0, 1, 0], 37.0 * k).scale(0.8 + 0.004 * k)
             if flatten:
-                m = dict(mesh); m['to_world'] = tf; m['bsdf'] = {'type': 'ref', 'id': ('white', 'green', 'red')[k % 3]}
+                ids = ('white', 'green', 'red', 'glass') if materials else ('white', 'green', 'red')
+                m = dict(mesh); m['to_world'] = tf; m['bsdf'] = {'type': 'ref', 'id': ids[k % len(ids)]}
                 d['ball%03d' % k] = m
             else:
                 d['inst%03d' % k] = {'type': 'instance', 'to_world': tf, 'group': {'type': 'ref', 'id': 'spheres'}}
