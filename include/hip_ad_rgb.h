@@ -83,9 +83,11 @@ typedef struct HarBSDF {
 /* BitmapTexture, raw H x W x 3 f32, bilinear, repeat (src/textures/bitmap.cpp:175-206). HOST pointer. */
 typedef struct HarTexture { const float *data; uint32_t width, height; } HarTexture;
 
-/* AreaLight on a Rectangle (src/emitters/area.cpp, src/shapes/rectangle.cpp:108-179) */
+/* type 0: AreaLight on a Rectangle (src/emitters/area.cpp, src/shapes/rectangle.cpp:108-179);
+ * type 1: ConstantBackgroundEmitter (src/emitters/constant.cpp): only `radiance` is read, at most one per scene.
+ * The order of the array is the order of Scene::emitters() (children in declaration order, scene.cpp:40-70). */
 typedef struct HarEmitter {
-    uint32_t type;        /* 0 = area */
+    uint32_t type;        /* 0 = area, 1 = constant */
     uint32_t mesh;
     float radiance[3];
     float to_world[12];   /* column-major 3x4 */

@@ -569,6 +569,14 @@ def _mk_twosided(props, named, key):
     return front
 
 
+class ConstantEmitter:
+    """ConstantBackgroundEmitter (src/emitters/constant.cpp): uniform environment radiance."""
+
+    def __init__(self, props):
+        rad = props.get('radiance', {'type': 'rgb', 'value': 1.0})
+        self.radiance = _rgb_value(rad, 1.0, bounded=False)
+
+
 class ShapeGroup:
     def __init__(self, shapes):
         self.shapes = shapes
@@ -704,6 +712,17 @@ class Scene:
         self._h = None; self._keep = []
         named = {}
         shapes = []; groups = []; insts = []
+        # Scene::emitters() order = declaration order of the children (scene.cpp:40-70): shapes with an area emitter and
+        # stand-alone emitters; the uniform emitter selection of sample_emitter() depends on it
+        self._emitter_order = [key for key, obj in children.items()
+                               if (isinstance(obj, Mesh) and obj.emitter is not None) or isinstance(obj, ConstantEmitter)]
+        self.emitters = [None] * len(self._emitter_order)
+        if sum(isinstance(o, ConstantEmitter) for o in children.values()) > 1:
+            raise RuntimeError("Only one environment emitter can be specified per scene.")
+        for key, obj in children.items():
+            if isinstance(obj, ConstantEmitter):
+                self.emitters[self._emitter_order.index(key)] = dict(type=1, mesh=0xffffffff, radiance=obj.radiance, to_world=[0.0] * 12,
+                                                                     normal=[0.0] * 3, inv_area=0.0)
         for key, obj in children.items():
             if isinstance(obj, BSDF):
                 named[key] = obj
@@ -762,8 +781,8 @@ class Scene:
         if m.emitter is not None:
             if not hasattr(m, 'rect'):
                 raise RuntimeError("area emitters are implemented for `rectangle` shapes only in hip_ad_rgb")
-            em = len(self.emitters)
-            self.emitters.append(dict(mesh=len(self.meshes), radiance=m.emitter, to_world=m.rect['to_world'].col_major_3x4(),
+            em = self._emitter_order.index(key)
+            self.emitters[em] = (dict(type=0, mesh=len(self.meshes), radiance=m.emitter, to_world=m.rect['to_world'].col_major_3x4(),
                                       normal=m.rect['normal'], inv_area=m.rect['inv_area']))
         self.meshes.append(dict(key=key, V=np.ascontiguousarray(m.V), F=np.ascontiguousarray(m.F), bsdf=bi, emitter=em, flags=m.flags))
 
@@ -795,7 +814,7 @@ class Scene:
             texs[i].data = _fp(t); texs[i].height = t.shape[0]; texs[i].width = t.shape[1]
         ems = (M.HarEmitter * max(1, len(self.emitters)))()
         for i, e in enumerate(self.emitters):
-            ems[i].type = 0; ems[i].mesh = e["mesh"]
+            ems[i].type = e.get("type", 0); ems[i].mesh = e["mesh"]
             ems[i].radiance = (C.c_float * 3)(*[float(x) for x in e["radiance"]])
             ems[i].to_world = (C.c_float * 12)(*[float(x) for x in e["to_world"]])
             ems[i].normal = (C.c_float * 3)(*[float(x) for x in e["normal"]]); ems[i].inv_area = float(e["inv_area"])
@@ -978,7 +997,7 @@ def _mk_scene(props, named, key):
         if k == 'type' or k in children:
             continue
         obj = _resolve(v, named, k) if isinstance(v, dict) else v
-        if isinstance(obj, (Mesh, Sensor, Integrator, BSDF, ShapeGroup, Instance)):
+        if isinstance(obj, (Mesh, Sensor, Integrator, BSDF, ShapeGroup, Instance, ConstantEmitter)):
             if isinstance(obj, ShapeGroup):
                 named[k] = obj
             children[k] = obj
@@ -1028,7 +1047,7 @@ for _name, _fn in {
     'hdrfilm': lambda p, n, k: Film(p),
     'independent': lambda p, n, k: Sampler(p),
     'diffuse': lambda p, n, k: BSDF(p, id=k), 'dielectric': lambda p, n, k: BSDF(p, id=k), 'roughconductor': lambda p, n, k: BSDF(p, id=k),
-    'roughplastic': lambda p, n, k: BSDF(p, id=k), 'twosided': _mk_twosided,
+    'roughplastic': lambda p, n, k: BSDF(p, id=k), 'twosided': _mk_twosided, 'constant': lambda p, n, k: ConstantEmitter(p),
     'rectangle': lambda p, n, k: _shape_common(_rectangle(p), p, n),
     'cube': lambda p, n, k: _shape_common(_cube(p), p, n),
     'mesh': _mk_mesh,

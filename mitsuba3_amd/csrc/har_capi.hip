@@ -220,6 +220,7 @@ int har_scene_create(const HarSceneDesc *desc, HarScene *out) {
     D.accel.root = hs.root; D.accel.has_tlas = hs.has_tlas; D.accel.n_tris = (uint32_t) hs.tris.size(); D.accel.n_insts = (uint32_t) hs.inst_recs.size();
     D.n_emitters = (uint32_t) hs.emitters.size(); D.n_meshes = (uint32_t) hs.meshes.size();
     D.n_bsdfs = (uint32_t) hs.bsdfs.size(); D.n_textures = (uint32_t) hs.textures.size();
+    D.env_emitter = hs.env_emitter;
     D.bsdf_types = 0; for (const DBsdf &b : hs.bsdfs) D.bsdf_types |= (1u << b.type) | ((b.flags & BF_TWOSIDED) ? 0x80000000u : 0u);
     if (hs.stack_need() + HAR_STACK_MARGIN > HAR_LDS_STACK_DEPTH)
         fprintf(stderr, "[hip_ad_rgb] warning: BVH needs %u traversal stack entries, LDS stack holds %d (overflow is reported as an error)\n", hs.stack_need(), HAR_LDS_STACK_DEPTH);

@@ -97,23 +97,26 @@ HAR_HD void shade_lane(const DScene &S, const ShadeParams &P, const PathState &s
     SurfInt si = compute_si(S, st.d, hit.t, hit.u, hit.v, hit.prim, hit.shape, hit.inst);
     const bool valid = si.valid();
     const DMesh M = valid ? S.meshes[si.mesh] : DMesh{};
-    const int emitter = valid ? M.emitter : -1;
+    const int emitter = valid ? M.emitter : S.env_emitter;          /* si.emitter(scene): the environment for a miss (scene.h:822-832) */
     const float pmf = S.n_emitters ? 1.f / (float) S.n_emitters : 0.f;   /* scene.cpp:139 */
 
     /* ---- direct emission + MIS with the previous BSDF sample (path.cpp:206-221, prb.py:148-161) */
     if (emitter >= 0) {
         const DEmitter E = S.emitters[emitter];
+        const bool env = E.type == 1u;
         Vec3 rel = si.p - st.prev_p;
         float dist = norm3(rel);
         Vec3 dd = div3(rel, dist);
-        float em_pdf = prev_delta ? 0.f : emitter_pdf_direction(E, dd, si.sn, dist) * pmf;
+        /* pdf_direction: area light (area.cpp:170-197) or uniform sphere (constant.cpp:155-160) */
+        float em_pdf = prev_delta ? 0.f : (env ? HAR_INV_FOUR_PI : emitter_pdf_direction(E, dd, si.sn, dist)) * pmf;
         float mis = mis_weight(st.prev_bsdf_pdf, em_pdf);
         Vec3 rad(E.radiance[0], E.radiance[1], E.radiance[2]);
+        const bool facing = env || si.wi.z > 0.f;                                      /* area.cpp:83-90 / constant.cpp:90-94 */
         if (MODE == MODE_PATH) {
-            Vec3 Le = (si.wi.z > 0.f && st.prev_bsdf_pdf > 0.f) ? rad : Vec3(0.f);   /* area.cpp:83-90 */
+            Vec3 Le = (facing && st.prev_bsdf_pdf > 0.f) ? rad : Vec3(0.f);
             R.add_emission = true; R.em_a = st.throughput; R.em_b = Le * mis;
         } else {
-            Vec3 ev = si.wi.z > 0.f ? rad : Vec3(0.f);
+            Vec3 ev = facing ? rad : Vec3(0.f);
             R.add_emission = true; R.em_a = Vec3(0.f); R.em_b = (st.throughput * mis) * ev;
         }
     }

@@ -13,7 +13,9 @@ namespace har {
 
 struct DMesh    { uint32_t voff, foff, bsdf; int32_t emitter; uint32_t flags, face_count, pad0, pad1; };
 struct DTexture { const float *data; uint32_t w, h; };
-struct DEmitter { float radiance[3]; float inv_area; float to_world[12]; float normal[3]; uint32_t mesh; };
+/* type 0: AreaLight on a rectangle (to_world, normal, inv_area, mesh); type 1: ConstantBackgroundEmitter
+ * (src/emitters/constant.cpp): to_world[0..2] = bounding sphere centre, to_world[3] = radius, mesh = 0xffffffff */
+struct DEmitter { float radiance[3]; float inv_area; float to_world[12]; float normal[3]; uint32_t mesh; uint32_t type; };
 struct DInst    { float to_world[12]; float to_object[12]; };
 
 struct DScene {
@@ -28,6 +30,7 @@ struct DScene {
     const DInst    *insts;
     const float    *bsdf_tables;       /* roughplastic external transmittance tables, 64 floats each */
     uint32_t n_emitters, n_meshes, n_bsdfs, n_textures;
+    int32_t  env_emitter;              /* index of the environment emitter (Scene::environment()), or -1 */
     uint32_t bsdf_types;               /* bit mask (1 << type) of the BSDF types present (+ bit 31: some record is twosided) */
 };
 
@@ -199,7 +202,22 @@ HAR_HD void diffuse_sample(Vec3 refl, Vec3 wi, float s2x, float s2y, Vec3 &wo, f
 /* AreaLight::sample_direction (src/emitters/area.cpp:118-168), Shape::sample_direction
  * (src/render/shape.cpp:93-110), Rectangle::sample_position (src/shapes/rectangle.cpp:159-173) */
 struct DirSample { Vec3 p, n, d; float dist, pdf; };
+#define HAR_INV_FOUR_PI 0.07957747154594766788f
+/* warp::square_to_uniform_sphere (include/mitsuba/core/warp.h:250-255) */
+HAR_HD Vec3 square_to_uniform_sphere(float sx, float sy) {
+    float z = fnma_(2.f, sy, 1.f), r = sqrtf(fmaxf(fnma_(z, z, 1.f), 0.f));
+    float s, c; sincos_(2.f * HAR_PI * sx, s, c);
+    return Vec3(r * c, r * s, z);
+}
 HAR_HD void emitter_sample_direction(const DEmitter &E, Vec3 ref_p, float sx, float sy, DirSample &ds, Vec3 &spec) {
+    if (E.type == 1u) {                                     /* ConstantBackgroundEmitter::sample_direction, constant.cpp:127-153 */
+        Vec3 d = square_to_uniform_sphere(sx, sy);
+        Vec3 c(E.to_world[0], E.to_world[1], E.to_world[2]);
+        float radius = fmaxf(E.to_world[3], norm3(ref_p - c)), dist = 2.f * radius;
+        ds.p = fma3(d, dist, ref_p); ds.n = -d; ds.pdf = HAR_INV_FOUR_PI; ds.d = d; ds.dist = dist;
+        spec = div3(Vec3(E.radiance[0], E.radiance[1], E.radiance[2]), ds.pdf);
+        return;
+    }
     ds.p = xf_point(E.to_world, Vec3(fma_(sx, 2.f, -1.f), fma_(sy, 2.f, -1.f), 0.f));
     ds.n = Vec3(E.normal[0], E.normal[1], E.normal[2]);
     ds.pdf = E.inv_area;

@@ -172,9 +172,11 @@ bool lower_scene(const HarSceneDesc &d, HostScene &hs, std::string &err) {
     }
     for (uint32_t i = 0; i < d.emitter_count; ++i) {
         const HarEmitter &e = d.emitters[i];
-        if (e.type != 0) { err = "unsupported emitter type (only `area` on a rectangle is implemented)"; return false; }
-        if (e.mesh >= d.top_mesh_count) { err = "area emitter must be attached to a top-level mesh"; return false; }
-        DEmitter de{};
+        if (e.type > 1) { err = "unsupported emitter type (`area` on a rectangle and `constant` are implemented)"; return false; }
+        if (e.type == 0 && e.mesh >= d.top_mesh_count) { err = "area emitter must be attached to a top-level mesh"; return false; }
+        if (e.type == 1 && hs.env_emitter >= 0) { err = "Only one environment emitter can be specified per scene."; return false; }   /* scene.cpp:64-65 */
+        if (e.type == 1) hs.env_emitter = (int32_t) i;
+        DEmitter de{}; de.type = e.type;
         std::memcpy(de.radiance, e.radiance, 12); de.inv_area = e.inv_area;
         std::memcpy(de.to_world, e.to_world, 48); std::memcpy(de.normal, e.normal, 12); de.mesh = e.mesh;
         hs.emitters.push_back(de);
@@ -185,6 +187,31 @@ bool lower_scene(const HarSceneDesc &d, HostScene &hs, std::string &err) {
         if (d.instances[i].group >= d.group_count) { err = "instance references a shapegroup that does not exist"; return false; }
         DInst di; std::memcpy(di.to_world, d.instances[i].to_world, 48); std::memcpy(di.to_object, d.instances[i].to_object, 48);
         hs.insts.push_back(di);
+    }
+
+    /* ConstantBackgroundEmitter::set_scene (constant.cpp:72-87): bounding sphere of Scene::bbox() (all shapes; an Instance
+     * contributes the 8 transformed corners of its group's box, instance.cpp:93-103), radius * (1 + RayEpsilon) */
+    if (hs.env_emitter >= 0) {
+        float lo[3] = { INFINITY, INFINITY, INFINITY }, hi[3] = { -INFINITY, -INFINITY, -INFINITY };
+        auto grow = [&](float x, float y, float z) { const float q[3] = { x, y, z }; for (int a = 0; a < 3; ++a) { lo[a] = std::min(lo[a], q[a]); hi[a] = std::max(hi[a], q[a]); } };
+        for (uint32_t s = 0; s < d.top_mesh_count; ++s)
+            for (uint32_t v = 0; v < d.meshes[s].vertex_count; ++v) { const float *p = d.meshes[s].vertex_ptr + 8 * (size_t) v; grow(p[0], p[1], p[2]); }
+        for (uint32_t i = 0; i < d.instance_count; ++i) {
+            const HarShapeGroup &sg = d.groups[d.instances[i].group];
+            float glo[3] = { INFINITY, INFINITY, INFINITY }, ghi[3] = { -INFINITY, -INFINITY, -INFINITY };
+            for (uint32_t s = sg.first_mesh; s < sg.first_mesh + sg.mesh_count; ++s)
+                for (uint32_t v = 0; v < d.meshes[s].vertex_count; ++v) { const float *p = d.meshes[s].vertex_ptr + 8 * (size_t) v; for (int a = 0; a < 3; ++a) { glo[a] = std::min(glo[a], p[a]); ghi[a] = std::max(ghi[a], p[a]); } }
+            if (!(glo[0] <= ghi[0])) continue;
+            for (int c = 0; c < 8; ++c) { Vec3 q = xf_point(d.instances[i].to_world, Vec3(c & 1 ? ghi[0] : glo[0], c & 2 ? ghi[1] : glo[1], c & 4 ? ghi[2] : glo[2])); grow(q.x, q.y, q.z); }
+        }
+        DEmitter &E = hs.emitters[hs.env_emitter];
+        if (lo[0] <= hi[0]) {
+            Vec3 c((hi[0] + lo[0]) * .5f, (hi[1] + lo[1]) * .5f, (hi[2] + lo[2]) * .5f);
+            float r = norm3(c - Vec3(hi[0], hi[1], hi[2]));
+            E.to_world[0] = c.x; E.to_world[1] = c.y; E.to_world[2] = c.z;
+            E.to_world[3] = std::max(HAR_RAY_EPS, r * (1.f + HAR_RAY_EPS));
+        } else { E.to_world[0] = E.to_world[1] = E.to_world[2] = 0.f; E.to_world[3] = HAR_RAY_EPS; }
+        E.mesh = 0xffffffffu;
     }
 
     BlasInfo top = build_blas(hs, d, 0, d.top_mesh_count);

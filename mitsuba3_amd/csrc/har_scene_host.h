@@ -24,6 +24,7 @@ struct HostScene {
     std::vector<TriRec> tris;
     std::vector<InstRec> inst_recs;
     std::vector<uint32_t> blas_tri_ranges;
+    int32_t env_emitter = -1;
     uint32_t root = 0;
     bool has_tlas = false;
     Bvh8Stats stats;

@@ -46,6 +46,7 @@ struct Scene {
     std::vector<BsdfRecord> bsdfs;
     std::vector<Texture> textures;
     std::vector<OrcEmitter> emitters;
+    int env = -1; float env_center[3] = { 0, 0, 0 }; float env_radius = 0.f;   // Scene::environment() + its bounding sphere
     Bvh top;                       // all top-level meshes
     std::vector<Bvh> group_bvh;    // one per shapegroup
     std::vector<BvhNode> inst_nodes; // BVH over instance world boxes
@@ -401,6 +402,20 @@ struct DS { V3 p, n, d; float dist = 0, pdf = 0; int emitter = -1; };
 /* AreaLight::sample_direction (src/emitters/area.cpp:118-168) over
  * Shape::sample_direction (src/render/shape.cpp:93-110) and
  * Rectangle::sample_position (src/shapes/rectangle.cpp:159-173) */
+/* ConstantBackgroundEmitter (src/emitters/constant.cpp): bounding sphere kept per scene */
+struct EnvSphere { V3 center; float radius = 0.f; };
+static inline V3 square_to_uniform_sphere(float sx, float sy) {          // warp.h:250-255
+    float z = fnmadd(2.f, sy, 1.f), r = std::sqrt(std::fmax(fnmadd(z, z, 1.f), 0.f));
+    float c, s = sincos(2.f * Pi * sx, &c);
+    return V3(r * c, r * s, z);
+}
+constexpr float InvFourPi = 0.07957747154594766788f;
+static inline void constant_sample_direction(const OrcEmitter &e, const EnvSphere &bs, V3 ref_p, float sx, float sy, DS &ds, V3 &spec) {   // constant.cpp:127-153
+    V3 d = square_to_uniform_sphere(sx, sy);
+    float radius = std::fmax(bs.radius, norm(ref_p - bs.center)), dist = 2.f * radius;
+    ds.p = fmadd(d, dist, ref_p); ds.n = -d; ds.pdf = InvFourPi; ds.d = d; ds.dist = dist;
+    spec = div(V3(e.radiance[0], e.radiance[1], e.radiance[2]), ds.pdf);
+}
 static inline void emitter_sample_direction(const OrcEmitter &e, V3 ref_p, float sx, float sy, DS &ds, V3 &spec) {
     ds.p = xf_point(e.to_world, V3(fmadd(sx, 2.f, -1.f), fmadd(sy, 2.f, -1.f), 0.f));
     ds.n = V3(e.normal[0], e.normal[1], e.normal[2]);
@@ -444,7 +459,8 @@ static inline bool sample_emitter_direction(const Scene &sc, const SI &si, float
         index = std::min((uint32_t) scaled, n - 1u);
         weight = (float) n; sx = scaled - (float) index;
     }
-    emitter_sample_direction(sc.emitters[index], si.p, sx, sy, ds, spec);
+    if (sc.emitters[index].type == 1) { EnvSphere bs; bs.center = V3(sc.env_center[0], sc.env_center[1], sc.env_center[2]); bs.radius = sc.env_radius; constant_sample_direction(sc.emitters[index], bs, si.p, sx, sy, ds, spec); }
+    else emitter_sample_direction(sc.emitters[index], si.p, sx, sy, ds, spec);
     ds.emitter = (int) index;
     ds.pdf *= pmf;
     spec = spec * weight;
@@ -560,7 +576,7 @@ static inline Lane make_lane(const OrcSensor &s, uint32_t seed, uint32_t spp, ui
 
 static V3 path_sample(const Scene &sc, Pcg32 &rng, Ray ray, uint32_t max_depth, uint32_t rr_depth, bool &valid_ray, OrcStats &st) {
     V3 throughput(1.f), result(0.f);
-    float eta = 1.f; uint32_t depth = 0; valid_ray = false;
+    float eta = 1.f; uint32_t depth = 0; valid_ray = sc.env >= 0;      // path.cpp:114: the environment is visible (hide_emitters = false)
     V3 prev_p(0.f); float prev_bsdf_pdf = 1.f; bool prev_bsdf_delta = true;
     if (max_depth == 0) return V3(0.f);
     PI pi; st.closest_rays++; scene_trace<false>(sc, ray, pi, 0);
@@ -568,15 +584,16 @@ static V3 path_sample(const Scene &sc, Pcg32 &rng, Ray ray, uint32_t max_depth, 
     while (active) {
         st.vertices++;
         SI si = compute_si(sc, ray, pi);
-        int emitter = si.valid() ? sc.meshes[si.mesh].emitter : -1;
+        int emitter = si.valid() ? sc.meshes[si.mesh].emitter : sc.env;     // si.emitter(scene), scene.h:822-832
         if (emitter >= 0) {                                   // path.cpp:206-221
             DS ds; ds.p = si.p; ds.n = si.sn;                 // records.h:77-79,173-180
-            V3 rel = si.p - prev_p; ds.dist = norm(rel); ds.d = div(rel, ds.dist);
-            float em_pdf = 0.f;
-            if (!prev_bsdf_delta) em_pdf = emitter_pdf_direction(sc.emitters[emitter], ds) * (1.f / (float) sc.emitters.size());
-            float mis_bsdf = mis_weight(prev_bsdf_pdf, em_pdf);
+            V3 rel = si.p - prev_p; ds.dist = norm(rel); ds.d = si.valid() ? div(rel, ds.dist) : -si.wi;
             const OrcEmitter &e = sc.emitters[emitter];
-            V3 Le = (si.wi.z > 0.f && prev_bsdf_pdf > 0.f) ? V3(e.radiance[0], e.radiance[1], e.radiance[2]) : V3(0.f);   // area.cpp:83-90
+            float em_pdf = 0.f;
+            if (!prev_bsdf_delta) em_pdf = (e.type == 1 ? InvFourPi : emitter_pdf_direction(e, ds)) * (1.f / (float) sc.emitters.size());
+            float mis_bsdf = mis_weight(prev_bsdf_pdf, em_pdf);
+            bool facing = e.type == 1 || si.wi.z > 0.f;                                                                   // area.cpp:83-90, constant.cpp:90-94
+            V3 Le = (facing && prev_bsdf_pdf > 0.f) ? V3(e.radiance[0], e.radiance[1], e.radiance[2]) : V3(0.f);
             result = fmadd(throughput, Le * mis_bsdf, result);
         }
         bool active_next = (depth + 1 < max_depth) && si.valid();
@@ -632,18 +649,18 @@ static V3 prb_sample(const Scene &sc, Pcg32 &rng, Ray ray, uint32_t max_depth, u
         ++iter; st.vertices++;
         bool active_next = true;
         SI si = compute_si(sc, ray, pi);
-        int emitter = si.valid() ? sc.meshes[si.mesh].emitter : -1;
+        int emitter = si.valid() ? sc.meshes[si.mesh].emitter : sc.env;
         // prb.py:153-161
         V3 Le(0.f);
         {
             float em_pdf = 0.f;
             DS ds; ds.p = si.p; ds.n = si.sn;
             V3 rel = si.p - prev_p; ds.dist = norm(rel); ds.d = si.valid() ? div(rel, ds.dist) : -si.wi;
-            if (emitter >= 0 && !bsdf_delta_prev) em_pdf = emitter_pdf_direction(sc.emitters[emitter], ds) * (1.f / (float) sc.emitters.size());
+            if (emitter >= 0 && !bsdf_delta_prev) em_pdf = (sc.emitters[emitter].type == 1 ? InvFourPi : emitter_pdf_direction(sc.emitters[emitter], ds)) * (1.f / (float) sc.emitters.size());
             float mis = mis_weight(bsdf_pdf_prev, em_pdf);
             if (emitter >= 0) {
                 const OrcEmitter &e = sc.emitters[emitter];
-                V3 ev = si.wi.z > 0.f ? V3(e.radiance[0], e.radiance[1], e.radiance[2]) : V3(0.f);
+                V3 ev = (e.type == 1 || si.wi.z > 0.f) ? V3(e.radiance[0], e.radiance[1], e.radiance[2]) : V3(0.f);
                 Le = (beta * mis) * ev;
             }
         }
@@ -801,6 +818,7 @@ void *orc_scene_create(const OrcSceneDesc *d) {
         sc->textures.push_back(std::move(t));
     }
     sc->emitters.assign(d->emitters, d->emitters + d->emitter_count);
+    for (uint32_t i = 0; i < sc->emitters.size(); ++i) if (sc->emitters[i].type == 1) sc->env = (int) i;
     for (uint32_t i = 0; i < sc->bsdfs.size(); ++i) if (sc->bsdfs[i].p.type == 3) roughplastic_precompute(sc->bsdfs[i], slot0_mean(*sc, i));
     build_tri_bvh(sc->top, sc->meshes, 0, sc->top_count);
     sc->group_bvh.resize(sc->groups.size());
@@ -823,6 +841,24 @@ void *orc_scene_create(const OrcSceneDesc *d) {
         sc->inst_nodes.emplace_back();
         build_rec(sc->inst_nodes, prims, 0, (uint32_t) prims.size(), 0, 2);
         for (auto &p : prims) sc->inst_order.push_back(p.id);
+    }
+    if (sc->env >= 0) {                                 // ConstantBackgroundEmitter::set_scene (constant.cpp:72-87)
+        float lo[3] = { Infinity, Infinity, Infinity }, hi[3] = { -Infinity, -Infinity, -Infinity };
+        for (uint32_t m = 0; m < sc->top_count; ++m)
+            for (uint32_t v = 0; v < sc->meshes[m].nv; ++v) for (int a = 0; a < 3; ++a) { float q = sc->meshes[m].V[8 * (size_t) v + a]; lo[a] = std::min(lo[a], q); hi[a] = std::max(hi[a], q); }
+        for (uint32_t i = 0; i < sc->instances.size(); ++i) {
+            const OrcShapeGroup &g = sc->groups[sc->instances[i].group];
+            float glo[3] = { Infinity, Infinity, Infinity }, ghi[3] = { -Infinity, -Infinity, -Infinity };
+            for (uint32_t m = g.first_mesh; m < g.first_mesh + g.mesh_count; ++m)
+                for (uint32_t v = 0; v < sc->meshes[m].nv; ++v) for (int a = 0; a < 3; ++a) { float q = sc->meshes[m].V[8 * (size_t) v + a]; glo[a] = std::min(glo[a], q); ghi[a] = std::max(ghi[a], q); }
+            if (!(glo[0] <= ghi[0])) continue;
+            for (int c = 0; c < 8; ++c) { V3 q = xf_point(sc->instances[i].to_world, V3(c & 1 ? ghi[0] : glo[0], c & 2 ? ghi[1] : glo[1], c & 4 ? ghi[2] : glo[2])); for (int a = 0; a < 3; ++a) { lo[a] = std::min(lo[a], q[a]); hi[a] = std::max(hi[a], q[a]); } }
+        }
+        if (lo[0] <= hi[0]) {
+            V3 c((hi[0] + lo[0]) * .5f, (hi[1] + lo[1]) * .5f, (hi[2] + lo[2]) * .5f);
+            sc->env_center[0] = c.x; sc->env_center[1] = c.y; sc->env_center[2] = c.z;
+            sc->env_radius = std::max(RayEpsilon, norm(c - V3(hi[0], hi[1], hi[2])) * (1.f + RayEpsilon));
+        } else sc->env_radius = RayEpsilon;
     }
     return sc;
 }

@@ -73,7 +73,7 @@ typedef struct OrcBSDF {
 typedef struct OrcTexture { const float *data; uint32_t width, height; } OrcTexture;
 
 typedef struct OrcEmitter {
-    uint32_t type;        /* 0 = area light on a rectangle */
+    uint32_t type;        /* 0 = area light on a rectangle, 1 = constant environment (src/emitters/constant.cpp; radiance only) */
     uint32_t mesh;        /* mesh that carries the emitter */
     float radiance[3];
     float to_world[12];   /* rectangle to_world, column-major 3x4 */

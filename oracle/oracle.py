@@ -247,7 +247,7 @@ class SceneData:
             texs[i].data = fp(t); texs[i].height = t.shape[0]; texs[i].width = t.shape[1]
         ems = (E * max(1, len(self.emitters)))()
         for i, e in enumerate(self.emitters):
-            ems[i].type = 0; ems[i].mesh = e["mesh"]
+            ems[i].type = int(e.get("type", 0)); ems[i].mesh = e["mesh"]
             ems[i].radiance = (C.c_float * 3)(*[float(x) for x in e["radiance"]])
             ems[i].to_world = (C.c_float * 12)(*[float(x) for x in e["to_world"]])
             ems[i].normal = (C.c_float * 3)(*[float(x) for x in e["normal"]])

@@ -398,3 +398,26 @@ def test_bsdf_plugins_device_vs_oracle(mi, O):
         assert close(bs.wo.cpu().numpy(), rwo, 0, 2e-5, 5e-3), name
         assert close(bs.pdf.cpu().numpy(), rsp, 2e-4, 1e-6, 5e-2), name
         assert close(w.cpu().numpy(), rw, 2e-4, 1e-6, 5e-2), name
+
+
+def test_constant_environment_emitter_parity(mi, O):
+    """`constant` emitter (src/emitters/constant.cpp) + area light in an opened Cornell box, and alone around a cube:
+    path / prb primal images and prb gradients vs the oracle"""
+    from tests.test_emitters_cpu import env_scene
+    from tests.test_cpu_host import oracle_scene_from
+    for with_area in (True, False):
+        scene = mi.load_dict(env_scene(mi, 40, with_area))
+        osc, sensor = oracle_scene_from(O, scene)
+        img = mi.render(scene, spp=16, seed=5).cpu().numpy()
+        ref, _ = osc.render_path(sensor, seed=5, spp=16, max_depth=8)
+        assert rel_l2(img, ref) < 1e-4
+        integ = mi.load_dict({"type": "prb", "max_depth": 6})
+        img = mi.render(scene, integrator=integ, spp=16, seed=5).cpu().numpy()
+        ref, _ = osc.render_prb(sensor, seed=5, spp=16, max_depth=6)
+        assert rel_l2(img, ref) < 1e-4
+        grad_in = np.random.default_rng(2).uniform(0.5, 1.5, (40, 40, 3)).astype(np.float32)
+        grads = integ.render_backward(scene, None, grad_in, seed=3, spp=8)
+        g_refl, _, _ = osc.render_prb_backward(sensor, grad_in, seed=3, spp=8, max_depth=6)
+        keys = scene._param_keys()
+        got = np.stack([grads[k].cpu().numpy() for k in keys]); want = np.stack([g_refl[b.index] for (_, b) in keys.values()])
+        assert rel_l2(got, want) < 1e-3
