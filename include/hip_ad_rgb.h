@@ -276,6 +276,17 @@ int har_shape_cube(const float to_world[32], float vertices[192], uint32_t faces
 int har_mesh_transform(const float to_world[32], uint32_t vertex_count, float *vertices,
                        uint32_t face_count, uint32_t *faces, int has_normals);
 
+/* ------------------------------------------------------------------------
+ *  Mesh files (host side).  PLYMesh ctor (src/shapes/ply.cpp:113-345): ASCII / binary little- / big-endian PLY with
+ *  triangle faces -> packed records (8 f32 per vertex, 4 u32 per face, mesh_utils.h:19-34) allocated with malloc;
+ *  flags bit0 = has vertex normals (stored or regenerated unless face_normals), bit1 = has texcoords.
+ *  har_mesh_compute_normals = Mesh::compute_normals (src/render/mesh.cpp:1218-1267), in place.
+ * ---------------------------------------------------------------------- */
+typedef struct HarMeshData { float *vertices; uint32_t *faces; uint32_t vertex_count, face_count, flags, reserved; } HarMeshData;
+int  har_mesh_load_ply(const char *filename, int face_normals, int flip_tex_coords, HarMeshData *out);
+int  har_mesh_compute_normals(uint32_t vertex_count, float *vertices, uint32_t face_count, const uint32_t *faces);
+void har_mesh_free(HarMeshData *mesh);
+
 #ifdef __cplusplus
 }
 #endif

@@ -46,6 +46,10 @@ class HarEmitter(C.Structure):
                 ("to_world", C.c_float * 12), ("normal", C.c_float * 3), ("inv_area", C.c_float)]
 
 
+class HarMeshData(C.Structure):
+    _fields_ = [("vertices", f32p), ("faces", u32p), ("vertex_count", C.c_uint32), ("face_count", C.c_uint32), ("flags", C.c_uint32), ("reserved", C.c_uint32)]
+
+
 class HarSceneDesc(C.Structure):
     _fields_ = [("meshes", C.POINTER(HarMesh)), ("mesh_count", C.c_uint32), ("top_mesh_count", C.c_uint32),
                 ("groups", C.POINTER(HarShapeGroup)), ("group_count", C.c_uint32), ("pad0", C.c_uint32),
@@ -86,6 +90,9 @@ SIGNATURES = {
     "har_sampler_next_2d": (C.c_int, [C.c_uint32, vp, vp, vp, vp, vp]),
     "har_bsdf_eval_pdf": (C.c_int, [vp, C.c_uint32, C.c_uint32, vp, vp, vp, vp, vp, vp]),
     "har_bsdf_sample": (C.c_int, [vp, C.c_uint32, C.c_uint32, vp, vp, vp, vp, vp, vp, vp, vp]),
+    "har_mesh_load_ply": (C.c_int, [C.c_char_p, C.c_int, C.c_int, vp]),
+    "har_mesh_compute_normals": (C.c_int, [C.c_uint32, vp, C.c_uint32, vp]),
+    "har_mesh_free": (None, [vp]),
     "har_bsdf_sample_ex": (C.c_int, [vp, C.c_uint32, C.c_uint32, vp, vp, vp, vp, vp, vp, vp, vp, vp]),
     "har_sensor_sample_ray": (C.c_int, [C.POINTER(HarSensor), C.c_uint32, vp, vp, vp, vp, vp, vp]),
     "har_film_put": (C.c_int, [C.POINTER(HarSensor), C.c_uint32, vp, vp, vp, vp, vp]),

@@ -224,6 +224,26 @@ class Mesh:
         self.V, self.F, self.flags = V, F, flags
         return self
 
+    def from_ply(self, filename, face_normals=False, flip_tex_coords=False):
+        """PLYMesh (src/shapes/ply.cpp): parsed by the C++ host library into the packed layout."""
+        md = _capi.HarMeshData()
+        check(lib().har_mesh_load_ply(str(filename).encode(), 1 if face_normals else 0, 1 if flip_tex_coords else 0, C.byref(md)))
+        try:
+            nv, nf = md.vertex_count, md.face_count
+            self.V = np.ctypeslib.as_array(md.vertices, shape=(max(nv, 1), 8))[:nv].copy() if nv else np.zeros((0, 8), np.float32)
+            self.F = np.ctypeslib.as_array(md.faces, shape=(max(nf, 1), 4))[:nf].copy() if nf else np.zeros((0, 4), np.uint32)
+            self.flags = int(md.flags)
+        finally:
+            lib().har_mesh_free(C.byref(md))
+        return self
+
+    def recompute_vertex_normals(self):
+        """Mesh::compute_normals (src/render/mesh.cpp:1218-1267)"""
+        self.V = np.ascontiguousarray(self.V); self.F = np.ascontiguousarray(self.F)
+        check(lib().har_mesh_compute_normals(self.V.shape[0], _fp(self.V), self.F.shape[0], _up(self.F)))
+        self.flags |= 1
+        return self
+
     def transform(self, to_world):
         self.V = np.ascontiguousarray(self.V); self.F = np.ascontiguousarray(self.F)
         check(lib().har_mesh_transform(_fp(to_world.data), self.V.shape[0], _fp(self.V), self.F.shape[0], _up(self.F), self.flags & 1))
@@ -1032,6 +1052,17 @@ def _mk_instance(props, named, key):
     return Instance(group, props.get('to_world', ScalarTransform4f()))
 
 
+def _mk_ply(props, named, key):
+    if 'filename' not in props:
+        raise RuntimeError("ply: the `filename` parameter is required")
+    m = Mesh(key or "ply").from_ply(props['filename'], props.get('face_normals', False), props.get('flip_tex_coords', False))
+    if props.get('flip_normals', False):        # Mesh::pack(flip_normals): reversed winding + negated normals (mesh.cpp:625-663)
+        m.F[:, [0, 2]] = m.F[:, [2, 0]]; m.V[:, 3:6] *= -1
+    if 'to_world' in props:
+        m.transform(props['to_world'])
+    return _shape_common(m, props, named)
+
+
 def _mk_mesh(props, named, key):
     m = Mesh(key or "mesh").from_fields(props['faces'], props['positions'], props.get('normals'), props.get('texcoords'))
     if 'to_world' in props:
@@ -1050,7 +1081,7 @@ for _name, _fn in {
     'roughplastic': lambda p, n, k: BSDF(p, id=k), 'twosided': _mk_twosided, 'constant': lambda p, n, k: ConstantEmitter(p),
     'rectangle': lambda p, n, k: _shape_common(_rectangle(p), p, n),
     'cube': lambda p, n, k: _shape_common(_cube(p), p, n),
-    'mesh': _mk_mesh,
+    'mesh': _mk_mesh, 'ply': _mk_ply,
     'shapegroup': _mk_shapegroup,
     'instance': _mk_instance,
     'gaussian': lambda p, n, k: p, 'box': lambda p, n, k: p, 'rgb': lambda p, n, k: p, 'bitmap': lambda p, n, k: p, 'area': lambda p, n, k: p,

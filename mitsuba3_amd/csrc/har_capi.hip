@@ -22,6 +22,7 @@ using namespace har;
 
 static thread_local std::string g_error;
 static int fail(const std::string &msg) { g_error = msg; return 1; }
+int har_set_error(const std::string &msg) { return fail(msg); }       /* used by har_mesh_io.cpp */
 
 #define HIP_TRY(expr)                                                                          \
     do { hipError_t _e = (expr); if (_e != hipSuccess) {                                       \

@@ -1,0 +1,215 @@
+/*
+ * har_mesh_io.cpp -- host-side mesh ingestion for the hip_ad_rgb path.
+ *
+ *   har_mesh_load_ply      PLYMesh ctor (src/shapes/ply.cpp:113-345) + parse_ply_header / parse_ascii (src/shapes/ply.h):
+ *                          ASCII, binary little- and big-endian; x/y/z [+ nx/ny/nz] [+ u/v | texture_u/texture_v | s/t] of any
+ *                          scalar type, converted to f32; triangle faces (`vertex_indices` / `vertex_index` lists of 3)
+ *   har_mesh_compute_normals  Mesh::compute_normals (src/render/mesh.cpp:1218-1267): angle-weighted vertex normals
+ *                          (Thuermer & Wuethrich 1998) for meshes without stored normals unless `face_normals`
+ * The result is the packed layout of include/mitsuba/render/mesh_utils.h:19-34 (8 f32 per vertex, 4 u32 per face) that
+ * har_scene_create ingests.  Extra per-vertex / per-face properties (colours, ...) are parsed and skipped.
+ */
+#include "../../include/hip_ad_rgb.h"
+#include "har_math.h"
+
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <fstream>
+#include <sstream>
+#include <string>
+#include <vector>
+
+using namespace har;
+
+extern int har_set_error(const std::string &msg);      /* har_capi.hip: thread-local message, returns 1 */
+
+namespace {
+
+enum PType { I8, U8, I16, U16, I32, U32, F32, F64, PInvalid };
+struct Prop { std::string name; PType type; bool is_list; PType count_type; };
+struct Element { std::string name; size_t count; std::vector<Prop> props; };
+
+PType parse_type(const std::string &t) {
+    if (t == "char" || t == "int8") return I8;      if (t == "uchar" || t == "uint8") return U8;
+    if (t == "short" || t == "int16") return I16;   if (t == "ushort" || t == "uint16") return U16;
+    if (t == "int" || t == "int32") return I32;     if (t == "uint" || t == "uint32") return U32;
+    if (t == "float" || t == "float32") return F32; if (t == "double" || t == "float64") return F64;
+    return PInvalid;
+}
+size_t type_size(PType t) { static const size_t s[] = { 1, 1, 2, 2, 4, 4, 4, 8, 0 }; return s[t]; }
+
+struct Reader {
+    const uint8_t *p, *end; bool ascii, swap;
+    std::istringstream text;
+    bool fail = false;
+    double read(PType t) {
+        if (ascii) {                                         /* strtod: accepts nan / inf like the reference's parser */
+            std::string tok; if (!(text >> tok)) { fail = true; return 0; }
+            char *endp = nullptr; double v = strtod(tok.c_str(), &endp);
+            if (endp == tok.c_str() || *endp != '\0') { fail = true; return 0; }
+            return v;
+        }
+        size_t n = type_size(t);
+        if ((size_t) (end - p) < n) { fail = true; return 0; }
+        uint8_t b[8]; memcpy(b, p, n); p += n;
+        if (swap) for (size_t i = 0; i < n / 2; ++i) std::swap(b[i], b[n - 1 - i]);
+        switch (t) {
+            case I8: { int8_t v; memcpy(&v, b, 1); return v; }     case U8: { uint8_t v; memcpy(&v, b, 1); return v; }
+            case I16: { int16_t v; memcpy(&v, b, 2); return v; }   case U16: { uint16_t v; memcpy(&v, b, 2); return v; }
+            case I32: { int32_t v; memcpy(&v, b, 4); return v; }   case U32: { uint32_t v; memcpy(&v, b, 4); return v; }
+            case F32: { float v; memcpy(&v, b, 4); return v; }     default: { double v; memcpy(&v, b, 8); return v; }
+        }
+    }
+};
+
+/* dr::unit_angle (Dr.Jit, NOT IN TREE -- restated from its published definition) */
+float unit_angle(Vec3 a, Vec3 b) {
+    float dot_uv = dot3(a, b);
+    Vec3 am(mulsign_(a.x, dot_uv), mulsign_(a.y, dot_uv), mulsign_(a.z, dot_uv));
+    float temp = 2.f * asinf(.5f * norm3(b - am));
+    return dot_uv >= 0.f ? temp : HAR_PI - temp;
+}
+
+} // namespace
+
+extern "C" {
+
+int har_mesh_compute_normals(uint32_t vertex_count, float *vertices, uint32_t face_count, const uint32_t *faces) {
+    if (!vertices || (!faces && face_count)) return har_set_error("null mesh buffers");
+    std::vector<float> acc(3 * (size_t) vertex_count, 0.f);
+    for (uint32_t f = 0; f < face_count; ++f) {
+        uint32_t fi[3] = { faces[4 * (size_t) f], faces[4 * (size_t) f + 1], faces[4 * (size_t) f + 2] };
+        Vec3 p[3];
+        for (int k = 0; k < 3; ++k) { if (fi[k] >= vertex_count) return har_set_error("face index out of bounds"); const float *v = vertices + 8 * (size_t) fi[k]; p[k] = Vec3(v[0], v[1], v[2]); }
+        Vec3 n = cross3(p[1] - p[0], p[2] - p[0]);
+        float length_sqr = dot3(n, n);
+        if (!(length_sqr > 0.f)) continue;
+        n = n * rsqrt_(length_sqr);
+        for (int k = 0; k < 3; ++k) {
+            float angle = unit_angle(normalize3(p[(k + 1) % 3] - p[k]), normalize3(p[(k + 2) % 3] - p[k]));
+            float *a = acc.data() + 3 * (size_t) fi[k];
+            a[0] += n.x * angle; a[1] += n.y * angle; a[2] += n.z * angle;
+        }
+    }
+    for (uint32_t v = 0; v < vertex_count; ++v) {
+        Vec3 n(acc[3 * (size_t) v], acc[3 * (size_t) v + 1], acc[3 * (size_t) v + 2]);
+        float length_sqr = dot3(n, n);
+        n = length_sqr > 0.f ? n * rsqrt_(length_sqr) : Vec3(1.f, 0.f, 0.f);
+        float *o = vertices + 8 * (size_t) v; o[3] = n.x; o[4] = n.y; o[5] = n.z;
+    }
+    return 0;
+}
+
+void har_mesh_free(HarMeshData *m) {
+    if (!m) return;
+    free(m->vertices); free(m->faces);
+    m->vertices = nullptr; m->faces = nullptr; m->vertex_count = m->face_count = 0;
+}
+
+int har_mesh_load_ply(const char *filename, int face_normals, int flip_tex_coords, HarMeshData *out) {
+    if (!filename || !out) return har_set_error("null argument");
+    memset(out, 0, sizeof(*out));
+    auto fail = [&](const std::string &d) { har_mesh_free(out); return har_set_error("Error while loading PLY file \"" + std::string(filename) + "\": " + d + "!"); };
+    std::ifstream f(filename, std::ios::binary);
+    if (!f) return fail("file not found");
+    std::string data((std::istreambuf_iterator<char>(f)), std::istreambuf_iterator<char>());
+    /* ---- header (parse_ply_header, src/shapes/ply.h) */
+    size_t pos = 0; std::string line; bool first = true, have_format = false, ascii = false, big = false, ended = false;
+    std::vector<Element> elements;
+    auto next_line = [&]() { size_t e = data.find('\n', pos); if (e == std::string::npos) return false; line = data.substr(pos, e - pos); pos = e + 1;
+                             if (!line.empty() && line.back() == '\r') line.pop_back(); return true; };
+    while (next_line()) {
+        std::istringstream ls(line); std::string tok; ls >> tok;
+        if (first) { if (tok != "ply") return fail("invalid PLY header"); first = false; continue; }
+        if (tok == "format") {
+            std::string fmt, ver; ls >> fmt >> ver;
+            if (fmt == "ascii") ascii = true; else if (fmt == "binary_little_endian") big = false; else if (fmt == "binary_big_endian") big = true;
+            else return fail("invalid PLY header: unknown format");
+            if (ver != "1.0") return fail("PLY file has unknown version number \"" + ver + "\"");
+            have_format = true;
+        } else if (tok == "comment" || tok == "obj_info" || tok.empty()) {
+        } else if (tok == "element") {
+            Element el; ls >> el.name >> el.count; if (!ls) return fail("invalid PLY header: \"element\" line");
+            elements.push_back(el);
+        } else if (tok == "property") {
+            if (elements.empty()) return fail("invalid PLY header: \"property\" before \"element\"");
+            Prop p; std::string t; ls >> t;
+            if (t == "list") { std::string ct, it; ls >> ct >> it >> p.name; p.is_list = true; p.count_type = parse_type(ct); p.type = parse_type(it); if (p.count_type == PInvalid) return fail("invalid PLY header: unknown list count type"); }
+            else { p.is_list = false; p.count_type = PInvalid; p.type = parse_type(t); ls >> p.name; }
+            if (p.type == PInvalid || p.name.empty()) return fail("invalid PLY header: unknown property type \"" + t + "\"");
+            elements.back().props.push_back(p);
+        } else if (tok == "end_header") { ended = true; break; }
+        else return fail("invalid PLY header: unknown token \"" + tok + "\"");
+    }
+    if (!ended || !have_format) return fail("invalid PLY header");
+    Reader R; R.p = (const uint8_t *) data.data() + pos; R.end = (const uint8_t *) data.data() + data.size(); R.ascii = ascii;
+    { uint16_t one = 1; bool host_little = *(uint8_t *) &one == 1; R.swap = !ascii && (big == host_little); }
+    if (ascii) R.text.str(data.substr(pos));
+    bool has_normals = false, has_uv = false;
+    std::vector<float> V; std::vector<uint32_t> F; size_t nv = 0, nf = 0;
+    for (const Element &el : elements) {
+        if (el.name == "vertex") {
+            int ix[8] = { -1, -1, -1, -1, -1, -1, -1, -1 };       /* x y z nx ny nz u v */
+            for (size_t k = 0; k < el.props.size(); ++k) {
+                const std::string &n = el.props[k].name;
+                if (el.props[k].is_list) return fail("incompatible contents -- vertex element with a list property");
+                if (n == "x") ix[0] = (int) k; else if (n == "y") ix[1] = (int) k; else if (n == "z") ix[2] = (int) k;
+                else if (n == "nx") ix[3] = (int) k; else if (n == "ny") ix[4] = (int) k; else if (n == "nz") ix[5] = (int) k;
+            }
+            auto find2 = [&](const char *a, const char *b) { int ia = -1, ib = -1; for (size_t k = 0; k < el.props.size(); ++k) { if (el.props[k].name == a) ia = (int) k; if (el.props[k].name == b) ib = (int) k; }
+                                                             if (ia >= 0 && ib >= 0 && ix[6] < 0) { ix[6] = ia; ix[7] = ib; } };
+            find2("u", "v"); find2("texture_u", "texture_v"); find2("s", "t");
+            if (ix[0] < 0 || ix[1] < 0 || ix[2] < 0) return fail("vertex positions (x, y, z) not found");
+            has_normals = !face_normals && ix[3] >= 0 && ix[4] >= 0 && ix[5] >= 0;
+            has_uv = ix[6] >= 0;
+            nv = el.count; V.assign(8 * nv, 0.f);
+            std::vector<double> rec(el.props.size());
+            for (size_t i = 0; i < nv; ++i) {
+                for (size_t k = 0; k < el.props.size(); ++k) rec[k] = R.read(el.props[k].type);
+                if (R.fail) return fail("unexpected end of file");
+                float *o = V.data() + 8 * i;
+                for (int c = 0; c < 3; ++c) { o[c] = (float) rec[ix[c]]; if (!finite_(o[c])) return fail("mesh contains invalid vertex position data"); }
+                if (has_normals) for (int c = 0; c < 3; ++c) o[3 + c] = (float) rec[ix[3 + c]];
+                if (has_uv) { o[6] = (float) rec[ix[6]]; o[7] = (float) rec[ix[7]]; if (flip_tex_coords) o[7] = 1.f - o[7]; }
+            }
+        } else if (el.name == "face") {
+            int il = -1;
+            for (size_t k = 0; k < el.props.size(); ++k) if (el.props[k].is_list && (el.props[k].name == "vertex_index" || el.props[k].name == "vertex_indices")) il = (int) k;
+            if (il < 0) return fail("vertex_index/vertex_indices property not found");
+            nf = el.count; F.assign(4 * nf, 0u);
+            for (size_t i = 0; i < nf; ++i) {
+                for (size_t k = 0; k < el.props.size(); ++k) {
+                    const Prop &p = el.props[k];
+                    if (!p.is_list) { (void) R.read(p.type); continue; }
+                    double cnt = R.read(p.count_type);
+                    if ((int) k == il) {
+                        if (R.fail || cnt != 3.0) return fail("incompatible contents -- is this a triangle mesh?");
+                        for (int c = 0; c < 3; ++c) { double v = R.read(p.type); if (v < 0 || v > 4294967295.0) return fail("invalid face index"); F[4 * i + c] = (uint32_t) v; }
+                    } else for (int c = 0; c < (int) cnt; ++c) (void) R.read(p.type);
+                }
+                if (R.fail) return fail("unexpected end of file");
+            }
+        } else {
+            for (const Prop &p : el.props) if (p.is_list) return fail("cannot skip unknown element \"" + el.name + "\" with list properties");
+            for (size_t i = 0; i < el.count; ++i) for (const Prop &p : el.props) (void) R.read(p.type);
+            if (R.fail) return fail("unexpected end of file");
+        }
+    }
+    if (!ascii && R.p != R.end) return fail("invalid file -- trailing content");
+    if (ascii) { std::string rest; if (R.text >> rest) return fail("invalid file -- trailing content"); }
+    for (size_t i = 0; i < nf; ++i) for (int c = 0; c < 3; ++c) if (F[4 * i + c] >= nv) return fail("face index out of bounds");
+    out->vertices = (float *) malloc(std::max<size_t>(V.size(), 1) * sizeof(float));
+    out->faces = (uint32_t *) malloc(std::max<size_t>(F.size(), 1) * sizeof(uint32_t));
+    if (!out->vertices || !out->faces) return fail("out of memory");
+    memcpy(out->vertices, V.data(), V.size() * sizeof(float)); memcpy(out->faces, F.data(), F.size() * sizeof(uint32_t));
+    out->vertex_count = (uint32_t) nv; out->face_count = (uint32_t) nf;
+    out->flags = (has_normals ? 1u : 0u) | (has_uv ? 2u : 0u);
+    if (!has_normals && !face_normals) {                   /* Mesh::from_packed -> pack(regenerate_normals = true), mesh.cpp:355-356 */
+        if (har_mesh_compute_normals(out->vertex_count, out->vertices, out->face_count, out->faces)) { har_mesh_free(out); return 1; }
+        out->flags |= 1u;
+    }
+    return 0;
+}
+
+} // extern "C"
