@@ -287,6 +287,13 @@ int  har_mesh_load_ply(const char *filename, int face_normals, int flip_tex_coor
 int  har_mesh_compute_normals(uint32_t vertex_count, float *vertices, uint32_t face_count, const uint32_t *faces);
 void har_mesh_free(HarMeshData *mesh);
 
+/* ------------------------------------------------------------------------
+ *  Image files (host side): HDRFilm::write (src/films/hdrfilm.cpp:414-560) -> Bitmap::write.  image = H x W x C float32.
+ *  EXR: OpenEXR 2 scanline, uncompressed, FLOAT channels R, G, B [, A]; PFM: "PF"/"Pf", little endian.
+ * ---------------------------------------------------------------------- */
+int  har_image_write_exr(const char *filename, const float *image, uint32_t width, uint32_t height, uint32_t channels);
+int  har_image_write_pfm(const char *filename, const float *image, uint32_t width, uint32_t height, uint32_t channels);
+
 #ifdef __cplusplus
 }
 #endif

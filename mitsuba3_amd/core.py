@@ -710,6 +710,41 @@ class Integrator:
         return scene._gradients(g_refl, g_tex)
 
 
+class Bitmap:
+    """Bitmap (src/core/bitmap.cpp) restricted to what HDRFilm::write needs: float32 H x W x {1,3,4}, write() to .exr / .pfm"""
+
+    def __init__(self, array):
+        if hasattr(array, 'detach'):
+            array = array.detach().cpu().numpy()
+        a = _f32(array)
+        if a.ndim == 2:
+            a = a[:, :, None]
+        if a.ndim != 3:
+            raise RuntimeError("Bitmap: expected an H x W x C array")
+        self.data = np.ascontiguousarray(a)
+
+    def size(self):
+        return (self.data.shape[1], self.data.shape[0])
+
+    def channel_count(self):
+        return self.data.shape[2]
+
+    def write(self, filename):
+        h, w, c = self.data.shape
+        ext = str(filename).lower().rsplit('.', 1)[-1]
+        if ext == 'exr':
+            check(lib().har_image_write_exr(str(filename).encode(), _fp(self.data), w, h, c))
+        elif ext == 'pfm':
+            check(lib().har_image_write_pfm(str(filename).encode(), _fp(self.data), w, h, c))
+        else:
+            raise RuntimeError("Bitmap.write(): unsupported file format \"%s\" (exr and pfm are implemented)" % ext)
+
+
+def write_bitmap(filename, data):
+    """mi.util.write_bitmap (src/python/python/util.py)"""
+    Bitmap(data).write(filename)
+
+
 def develop_film(film):
     torch = _torch()
     h, w, _ = film.shape
