@@ -244,6 +244,10 @@ int har_render_stats(HarIntegrator integrator, HarStats *out);
  * ms[0]=raygen ms[1]=trace_closest ms[2]=shade ms[3]=trace_shadow ms[4]=splat ms[5]=total
  * launches[i] = number of launches in that class. */
 int har_integrator_set_profiling(HarIntegrator integrator, int enable);
+/* `prb` only: keep the primal pass's ray-query results (24 B hit + 1 B visibility per lane and bounce, first 12 bounces) in
+ * HBM and reuse them in the adjoint replay of the same chunk instead of tracing every ray twice (default: enabled).
+ * The gradients are identical either way: the replayed rays are bit-identical to the primal ones. */
+int har_integrator_set_replay_cache(HarIntegrator integrator, int enable);
 int har_render_timing(HarIntegrator integrator, float ms[8], uint32_t launches[8]);
 
 

@@ -622,6 +622,7 @@ class Integrator:
         if self.rr_depth <= 0:
             raise RuntimeError("\"rr_depth\" must be set to a value greater than zero!")
         self.chunk_lanes = int(props.get('chunk_lanes', 0))
+        self.replay_cache = bool(props.get('replay_cache', True))      # hip_ad_rgb extension, see har_integrator_set_replay_cache
         self._h = None
 
     def _handle(self):
@@ -629,6 +630,8 @@ class Integrator:
             h = C.c_void_p()
             check(lib().har_integrator_create(0 if self.type == 'path' else 1, self.max_depth, self.rr_depth, self.chunk_lanes, C.byref(h)))
             self._h = h
+            if not self.replay_cache:
+                check(lib().har_integrator_set_replay_cache(h, 0))
         return self._h
 
     def __del__(self):

@@ -58,6 +58,8 @@ struct HarIntegratorImpl {
     float4 *h0 = nullptr; uint2 *h1 = nullptr;
     ItemArrays items{};
     float4 *result = nullptr, *dL = nullptr;
+    /* PRB replay cache (see ReplayCache): cache_bounces arrays of ws_lanes entries each */
+    float4 *rc_h0 = nullptr; uint2 *rc_h1 = nullptr; uint8_t *rc_vis = nullptr; uint32_t cache_bounces = 0; bool use_cache = true;
     float *adj = nullptr; size_t adj_floats = 0;
     uint32_t *counters = nullptr;
     unsigned long long *totals = nullptr;
@@ -82,6 +84,8 @@ template <typename T> int ws_alloc(HarIntegratorImpl *I, T **p, size_t count) {
     return 0;
 }
 
+uint32_t bounce_limit(const HarIntegratorImpl *I) { return std::min<uint32_t>(I->max_depth, HAR_MAX_BOUNCE_SLOTS - 2); }
+
 int ensure_workspace(HarIntegratorImpl *I, uint32_t lanes, bool adjoint) {
     if (I->ws_lanes >= lanes && (I->ws_adjoint || !adjoint)) return 0;
     I->free_ws();
@@ -94,6 +98,13 @@ int ensure_workspace(HarIntegratorImpl *I, uint32_t lanes, bool adjoint) {
     if (ws_alloc(I, &I->items.s0, lanes) || ws_alloc(I, &I->items.s1, lanes) || ws_alloc(I, &I->items.s2, lanes)) return 1;
     I->items.s3 = I->items.s4 = nullptr; I->dL = nullptr;
     if (adjoint && (ws_alloc(I, &I->items.s3, lanes) || ws_alloc(I, &I->items.s4, lanes) || ws_alloc(I, &I->dL, lanes))) return 1;
+    I->rc_h0 = nullptr; I->rc_h1 = nullptr; I->rc_vis = nullptr; I->cache_bounces = 0;
+    if (adjoint && I->use_cache) {
+        /* 25 B per lane and cached bounce; bounces beyond the cache are simply traced again */
+        const uint32_t nb = std::min<uint32_t>(bounce_limit(I), HAR_REPLAY_CACHE_BOUNCES);
+        if (nb && (ws_alloc(I, &I->rc_h0, (size_t) lanes * nb) || ws_alloc(I, &I->rc_h1, (size_t) lanes * nb) || ws_alloc(I, &I->rc_vis, (size_t) lanes * nb))) return 1;
+        I->cache_bounces = nb;
+    }
     if (ws_alloc(I, &I->result, lanes)) return 1;
     if (ws_alloc(I, &I->counters, (size_t) 4 * HAR_MAX_BOUNCE_SLOTS * HAR_SHARDS * HAR_COUNTER_STRIDE) || ws_alloc(I, &I->totals, 4) || ws_alloc(I, &I->status, 1)) return 1;
     HIP_TRY(hipMemset(I->totals, 0, 4 * sizeof(unsigned long long)));
@@ -114,7 +125,7 @@ void prof_mark(HarIntegratorImpl *I, hipStream_t s, int cls) {
 
 uint32_t log2_exact(uint32_t v) { for (uint32_t k = 0; k < 32; ++k) if ((1u << k) == v) return k; return 0xffffffffu; }
 
-uint32_t bounce_limit(const HarIntegratorImpl *I) { return std::min<uint32_t>(I->max_depth, HAR_MAX_BOUNCE_SLOTS - 2); }
+
 
 static inline uint32_t *cnt_alive(HarIntegratorImpl *I, uint32_t b) { return I->counters + (size_t) b * HAR_SHARDS * HAR_COUNTER_STRIDE; }
 static inline uint32_t *cnt_items(HarIntegratorImpl *I, uint32_t b) { return I->counters + (size_t) (HAR_MAX_BOUNCE_SLOTS + b) * HAR_SHARDS * HAR_COUNTER_STRIDE; }
@@ -124,7 +135,7 @@ static inline uint32_t *cur_resolve(HarIntegratorImpl *I, uint32_t b) { return I
 
 /* one chunk: raygen + bounce loop.  `mode` selects path / prb primal / prb adjoint kernels */
 int run_chunk(HarSceneImpl *S, HarIntegratorImpl *I, const DSensor &C, int mode, uint32_t seed, uint32_t spp, uint32_t log_spp,
-              uint32_t lane_base, uint32_t n, float *grad_refl, hipStream_t s) {
+              uint32_t lane_base, uint32_t n, float *grad_refl, hipStream_t s, int cache_mode = 0) {
     const uint32_t nb = bounce_limit(I);
     const size_t used = (size_t) std::min<uint32_t>(nb + 2, HAR_MAX_BOUNCE_SLOTS) * HAR_SHARDS * HAR_COUNTER_STRIDE * sizeof(uint32_t);
     HIP_TRY(hipMemsetAsync(cnt_alive(I, 0), 0, used, s));
@@ -143,12 +154,18 @@ int run_chunk(HarSceneImpl *S, HarIntegratorImpl *I, const DSensor &C, int mode,
     const int small_stack = need <= HAR_LDS_STACK_SMALL ? 0 : (need <= HAR_LDS_STACK_MEDIUM ? 1 : 2);
     int cur = 0; uint32_t b = 0;
     for (; b < nb; ++b) {
-        launch_trace_closest(s, tgrid, small_stack, S->ds.accel, cnt_alive(I, b), cur_trace(I, b), I->shard_cap, I->st[cur], I->h0, I->h1, I->status);
-        prof_mark(I, s, CLS_TRACE);
+        /* PRB replay cache: the primal pass of render_backward records this bounce's ray-query results per lane, the adjoint pass reads them */
+        ReplayCache rc{ nullptr, nullptr, nullptr, 0 };
+        if (cache_mode && b < I->cache_bounces)
+            rc = ReplayCache{ I->rc_h0 + (size_t) b * I->ws_lanes, I->rc_h1 + (size_t) b * I->ws_lanes, I->rc_vis + (size_t) b * I->ws_lanes, cache_mode };
+        if (rc.mode != 2) {
+            launch_trace_closest(s, tgrid, small_stack, S->ds.accel, cnt_alive(I, b), cur_trace(I, b), I->shard_cap, I->st[cur], I->h0, I->h1, I->status);
+            prof_mark(I, s, CLS_TRACE);
+        }
         launch_shade(mode, s, grid, S->ds, P, lane_base, I->shard_cap, cnt_alive(I, b), I->st[cur], I->h0, I->h1, I->st[cur ^ 1], cnt_alive(I, b + 1),
-                     I->items, cnt_items(I, b), I->result);
+                     I->items, cnt_items(I, b), I->result, rc);
         prof_mark(I, s, CLS_SHADE);
-        launch_resolve(mode, s, tgrid, small_stack, S->ds, cnt_items(I, b), cur_resolve(I, b), I->shard_cap, I->items, I->result, I->dL, grad_refl, I->d_grad_tex, I->status);
+        launch_resolve(mode, s, rc.mode == 2 ? grid : tgrid, small_stack, S->ds, cnt_items(I, b), cur_resolve(I, b), I->shard_cap, I->items, I->result, I->dL, grad_refl, I->d_grad_tex, I->status, rc);
         prof_mark(I, s, CLS_RESOLVE);
         cur ^= 1;
         if (b >= 15 && (b & 7) == 7) {           /* deep paths are rare: poll so that max_depth = -1 terminates */
@@ -453,9 +470,9 @@ int har_render_backward(HarScene S, HarIntegrator I, const HarSensor *sensor, co
     for (uint64_t base = lb; base < le; base += chunk) {
         uint32_t n = (uint32_t) std::min<uint64_t>(chunk, le - base);
         /* pass 1: primal, keeps L per lane in `result` (common.py:752-762) */
-        if (run_chunk(S, I, C, MODE_PRB_PRIMAL, seed, spp, log_spp, (uint32_t) base, n, nullptr, s)) return 1;
+        if (run_chunk(S, I, C, MODE_PRB_PRIMAL, seed, spp, log_spp, (uint32_t) base, n, nullptr, s, I->cache_bounces ? 1 : 0)) return 1;
         /* pass 2: adjoint replay with the identical sample stream (common.py:765-775) */
-        if (run_chunk(S, I, C, MODE_PRB_ADJOINT, seed, spp, log_spp, (uint32_t) base, n, grad_reflectance, s)) return 1;
+        if (run_chunk(S, I, C, MODE_PRB_ADJOINT, seed, spp, log_spp, (uint32_t) base, n, grad_reflectance, s, I->cache_bounces ? 2 : 0)) return 1;
     }
     HIP_TRY(hipGetLastError());
     return 0;
@@ -470,6 +487,12 @@ int har_render_stats(HarIntegrator I, HarStats *out) {
     HIP_TRY(hipMemcpyAsync(t, I->totals, sizeof(t), hipMemcpyDeviceToHost, s));
     if (read_status(I->status, s)) return 1;
     out->paths = t[0]; out->vertices = t[1]; out->closest_rays = t[2]; out->shadow_rays = t[3];
+    return 0;
+}
+
+int har_integrator_set_replay_cache(HarIntegrator I, int enable) {
+    if (!I) return fail("null integrator");
+    if (I->use_cache != (enable != 0)) { (void) hipDeviceSynchronize(); I->free_ws(); I->use_cache = enable != 0; }
     return 0;
 }
 

@@ -14,6 +14,7 @@
 #ifndef HAR_STACK_MARGIN            /* stack entries a scene needs beyond HostScene::stack_need() */
 #define HAR_STACK_MARGIN (HAR_TRAV_POLICY == 2 ? HAR_MAX_PARKED : 0)
 #endif
+#define HAR_REPLAY_CACHE_BOUNCES 12 /* PRB replay cache depth (25 B per lane and bounce); deeper bounces are traced twice */
 #define HAR_LDS_GRAD_BSDFS 256     /* constant-albedo gradients accumulated per block in LDS (adjoint resolve) */
 #define HAR_SHARDS 8                /* XCD-private path queues */
 #define HAR_COUNTER_STRIDE 16       /* u32 stride between shard counters: one 64 B line each */
@@ -26,6 +27,10 @@ namespace har {
 struct WaveState { float4 *a0, *a1, *a2, *a3; uint2 *a4; };
 /* NEE / gradient items written by `shade`, consumed by `resolve` */
 struct ItemArrays { float4 *s0, *s1, *s2, *s3, *s4; };
+/* PRB replay cache of ONE bounce, indexed by (lane - lane_base): the adjoint pass re-runs sampling and shading with the same random
+ * numbers, so its ray queries are bit-identical to the primal pass's; their results (24 B hit record, 1 B visibility) are kept in HBM
+ * between the two passes of a chunk instead of being traced twice.  mode 0 = unused, 1 = write (primal pass), 2 = read (adjoint pass) */
+struct ReplayCache { float4 *h0; uint2 *h1; uint8_t *vis; int mode; };
 
 void launch_raygen(int mode, hipStream_t s, const DSensor &C, uint32_t seed, uint32_t spp, uint32_t log_spp, uint32_t lane_base, uint32_t n,
                    uint32_t shard_cap, const WaveState &out, float4 *result, uint32_t *count, const float *adj, float4 *dL);
@@ -33,9 +38,9 @@ void launch_trace_closest(hipStream_t s, uint32_t grid, int stack_class, const A
                           const WaveState &in, float4 *h0, uint2 *h1, int *status);
 void launch_shade(int mode, hipStream_t s, uint32_t grid, const DScene &S, const ShadeParams &P, uint32_t lane_base, uint32_t shard_cap, const uint32_t *count_in,
                   const WaveState &in, const float4 *h0, const uint2 *h1, const WaveState &out, uint32_t *count_out, const ItemArrays &items,
-                  uint32_t *item_count, float4 *result);
+                  uint32_t *item_count, float4 *result, const ReplayCache &rc);
 void launch_resolve(int mode, hipStream_t s, uint32_t grid, int stack_class, const DScene &S, const uint32_t *item_count, uint32_t *cursor, uint32_t shard_cap, const ItemArrays &items,
-                    float4 *result, const float4 *dL, float *grad_refl, float *const *grad_tex, int *status);
+                    float4 *result, const float4 *dL, float *grad_refl, float *const *grad_tex, int *status, const ReplayCache &rc);
 void launch_splat(hipStream_t s, const DSensor &C, uint32_t seed, uint32_t spp, uint32_t log_spp, uint32_t lane_base, uint32_t n,
                   const float4 *result, int weights_only, float *film);
 void launch_develop(hipStream_t s, const float *film, uint32_t npx, float *image);

@@ -285,7 +285,7 @@ __global__ __launch_bounds__(kBlock) void k_trace_closest(Accel A, const uint32_
 template <int MODE, uint32_t TYPES>
 __global__ __launch_bounds__(kBlock, HAR_SHADE_MIN_WAVES) void k_shade(DScene S, ShadeParams P, uint32_t lane_base, uint32_t shard_cap, const uint32_t *count_in, WaveState in,
                                                   const float4 *h0, const uint2 *h1, WaveState out, uint32_t *count_out,
-                                                  ItemArrays items, uint32_t *item_count, float4 *result) {
+                                                  ItemArrays items, uint32_t *item_count, float4 *result, ReplayCache rc) {
     __shared__ uint32_t lds_r[12];
     __shared__ uint32_t sort_cnt[8], sort_perm[TYPES == HAR_BSDF_ONLY_DIFFUSE ? 1 : kBlock];
     const ShardLoop Q(count_in, shard_cap);
@@ -299,8 +299,11 @@ __global__ __launch_bounds__(kBlock, HAR_SHADE_MIN_WAVES) void k_shade(DScene S,
              * permuted loads still consume whole cache lines. */
             uint32_t key = 5u;                                         /* 4 = miss, 5 = out of range */
             if (local < Q.n) {
-                const uint2 hs = h1[Q.base + local];
-                const float t = h0[Q.base + local].x;
+                uint2 hs; float t;
+                if (MODE == MODE_PRB_ADJOINT && rc.mode == 2) {
+                    const uint32_t cl = __float_as_uint(in.a3[Q.base + local].w) - lane_base;
+                    hs = rc.h1[cl]; t = rc.h0[cl].x;
+                } else { hs = h1[Q.base + local]; t = h0[Q.base + local].x; }
                 key = t == HAR_INF ? 4u : S.bsdfs[S.meshes[hs.x].bsdf].type;
             }
             if (threadIdx.x < 8) sort_cnt[threadIdx.x] = 0;
@@ -320,7 +323,10 @@ __global__ __launch_bounds__(kBlock, HAR_SHADE_MIN_WAVES) void k_shade(DScene S,
         uint32_t lane = 0;
         if (in_range) {
             PathState st = load_state(in, i);
-            float4 hh = h0[i]; uint2 hs = h1[i];
+            float4 hh; uint2 hs;
+            if (MODE == MODE_PRB_ADJOINT && rc.mode == 2) { hh = rc.h0[st.lane - lane_base]; hs = rc.h1[st.lane - lane_base]; }      /* replay cache */
+            else { hh = h0[i]; hs = h1[i]; }
+            if (MODE == MODE_PRB_PRIMAL && rc.mode == 1) { rc.h0[st.lane - lane_base] = hh; rc.h1[st.lane - lane_base] = hs; }
             Hit hit; hit.t = hh.x; hit.u = hh.y; hit.v = hh.z; hit.prim = __float_as_uint(hh.w); hit.shape = hs.x; hit.inst = hs.y;
             shade_lane<MODE, TYPES>(S, P, st, hit, R);
             lane = st.lane - lane_base;
@@ -349,10 +355,63 @@ __global__ __launch_bounds__(kBlock, HAR_SHADE_MIN_WAVES) void k_shade(DScene S,
     }
 }
 
+/* adjoint of one NEE / vertex item (wave-uniform call: every lane takes part in the texel pre-reduction):
+ * L <- L - Lr_dir; g = dL * (dLr_dir/dslot0 + L * (df/dslot0)/f)  (prb.py:227,288-313) */
+__device__ __forceinline__ void adjoint_commit(const DScene &S, const ItemArrays &items, uint32_t i, bool pred, bool visible, float4 *result, const float4 *dL,
+                                               float *grad_refl, float *const *grad_tex, float *gacc) {
+    Vec3 g(0.f); float *dst = grad_refl; bool tex = false; TexTaps taps; float *tdst = nullptr;
+    if (pred) {
+        const uint32_t lane = __float_as_uint(items.s1[i].w);
+        float4 s2 = items.s2[i], L = result[lane];
+        if (visible) { L = make_float4(L.x - s2.x, L.y - s2.y, L.z - s2.z, 0.f); result[lane] = L; }
+        float4 s3 = items.s3[i], s4 = items.s4[i], dl = dL[lane];
+        const uint32_t tag = __float_as_uint(s2.w), bsdf = tag & 0x7fffffffu;
+        g = visible ? Vec3(s3.x, s3.y, s3.z) : Vec3(0.f);
+        if (tag & 0x80000000u) g = g + Vec3(L.x * s4.x, L.y * s4.y, L.z * s4.z);
+        g = g * Vec3(dl.x, dl.y, dl.z);
+        const DBsdf B = S.bsdfs[bsdf];
+        dst = grad_refl + 3 * (size_t) bsdf;
+        if (B.texture >= 0) { tex = true; tex_taps(S.textures[B.texture], s3.w, s4.w, taps); tdst = grad_tex[B.texture]; }
+    }
+    const bool nz = pred && (g.x != 0.f || g.y != 0.f || g.z != 0.f);
+    if (nz && !tex) {
+        const uint32_t bsdf = (uint32_t) (dst - grad_refl) / 3u;
+        if (bsdf < HAR_LDS_GRAD_BSDFS) { atomicAdd(&gacc[3 * bsdf], g.x); atomicAdd(&gacc[3 * bsdf + 1], g.y); atomicAdd(&gacc[3 * bsdf + 2], g.z); }
+        else { atomicAdd(dst, g.x); atomicAdd(dst + 1, g.y); atomicAdd(dst + 2, g.z); }
+    }
+    if (__ballot(nz && tex)) {
+        const float w[4] = { taps.w0x * taps.w0y, taps.w1x * taps.w0y, taps.w0x * taps.w1y, taps.w1x * taps.w1y };
+        for (int k = 0; k < 4; ++k)
+            wave_aggregated_add3(nz && tex ? tdst + 3 * (size_t) taps.idx[k] : grad_refl, nz && tex ? g * w[k] : Vec3(0.f), nz && tex);
+    }
+}
+
+/* adjoint resolve of a bounce whose shadow-ray results sit in the replay cache: no traversal, one item per thread */
+__global__ __launch_bounds__(kBlock) void k_resolve_adjoint_cached(DScene S, const uint32_t *item_count, uint32_t shard_cap, ItemArrays items, float4 *result,
+                                                                   const float4 *dL, float *grad_refl, float *const *grad_tex, ReplayCache rc) {
+    __shared__ float gacc[3 * HAR_LDS_GRAD_BSDFS];
+    for (uint32_t k = threadIdx.x; k < 3 * HAR_LDS_GRAD_BSDFS; k += kBlock) gacc[k] = 0.f;
+    __syncthreads();
+    const ShardLoop Q(item_count, shard_cap);
+    for (uint32_t tile = Q.first_tile(); tile * kBlock < Q.n; tile += Q.tile_step()) {
+        const uint32_t local = tile * kBlock + threadIdx.x;
+        const bool pred = local < Q.n;
+        const uint32_t i = Q.base + (pred ? local : 0u);
+        bool visible = false;
+        if (pred && items.s0[i].w >= 0.f) visible = rc.vis[__float_as_uint(items.s1[i].w)] != 0;
+        adjoint_commit(S, items, i, pred, visible, result, dL, grad_refl, grad_tex, gacc);
+    }
+    __syncthreads();
+    for (uint32_t k = threadIdx.x; k < 3 * min(S.n_bsdfs, (uint32_t) HAR_LDS_GRAD_BSDFS); k += kBlock) {
+        const float v = gacc[k];
+        if (v != 0.f) atomicAdd(grad_refl + k, v);
+    }
+}
+
 /* ------------------------------------------------- resolve (shadow rays + NEE) */
 template <int MODE, int CAP>
 __global__ __launch_bounds__(kBlock) void k_resolve(DScene S, const uint32_t *item_count, uint32_t *cursor, uint32_t shard_cap, ItemArrays items, float4 *result,
-                                                    const float4 *dL, float *grad_refl, float *const *grad_tex, int *status) {
+                                                    const float4 *dL, float *grad_refl, float *const *grad_tex, int *status, ReplayCache rc) {
     __shared__ uint2 lds[CAP * kBlock];
     /* adjoint: per-block accumulators of the constant-albedo gradients.  Every path of the chip adds to the same
      * few floats of grad_refl (one 64 B line): direct global atomics serialise at ~88 atomics/us per line, which
@@ -376,8 +435,10 @@ __global__ __launch_bounds__(kBlock) void k_resolve(DScene S, const uint32_t *it
         /* forward: an unoccluded item adds its contribution to its lane's radiance (one item per lane and bounce: no race) */
         trace_persistent<true, false, CAP>(S.accel, cursor + shard * HAR_COUNTER_STRIDE, n, stack, status, take,
             [&](uint32_t idx, const Traversal<HAR_TRAV_POLICY> &T) {
+                const uint32_t i = base + idx;
+                if (rc.mode == 1) rc.vis[__float_as_uint(items.s1[i].w)] = T.found ? 0 : 1;      /* replay cache */
                 if (!T.found) {
-                    const uint32_t i = base + idx, lane = __float_as_uint(items.s1[i].w);
+                    const uint32_t lane = __float_as_uint(items.s1[i].w);
                     float4 s2 = items.s2[i], r = result[lane];
                     result[lane] = make_float4(r.x + s2.x, r.y + s2.y, r.z + s2.z, 0.f);
                 }
@@ -389,33 +450,7 @@ __global__ __launch_bounds__(kBlock) void k_resolve(DScene S, const uint32_t *it
         trace_persistent<true, true, CAP>(S.accel, cursor + shard * HAR_COUNTER_STRIDE, n, stack, status, take,
             [&](uint32_t, const Traversal<HAR_TRAV_POLICY> &) { },
             [&](bool pred, uint32_t idx, const Traversal<HAR_TRAV_POLICY> &T) {
-                const uint32_t i = base + (pred ? idx : 0u);
-                const bool visible = pred && !T.found;
-                Vec3 g(0.f); float *dst = grad_refl; bool tex = false; TexTaps taps; float *tdst = nullptr;
-                if (pred) {
-                    const uint32_t lane = __float_as_uint(items.s1[i].w);
-                    float4 s2 = items.s2[i], L = result[lane];
-                    if (visible) { L = make_float4(L.x - s2.x, L.y - s2.y, L.z - s2.z, 0.f); result[lane] = L; }
-                    float4 s3 = items.s3[i], s4 = items.s4[i], dl = dL[lane];
-                    const uint32_t tag = __float_as_uint(s2.w), bsdf = tag & 0x7fffffffu;
-                    g = visible ? Vec3(s3.x, s3.y, s3.z) : Vec3(0.f);
-                    if (tag & 0x80000000u) g = g + Vec3(L.x * s4.x, L.y * s4.y, L.z * s4.z);
-                    g = g * Vec3(dl.x, dl.y, dl.z);
-                    const DBsdf B = S.bsdfs[bsdf];
-                    dst = grad_refl + 3 * (size_t) bsdf;
-                    if (B.texture >= 0) { tex = true; tex_taps(S.textures[B.texture], s3.w, s4.w, taps); tdst = grad_tex[B.texture]; }
-                }
-                const bool nz = pred && (g.x != 0.f || g.y != 0.f || g.z != 0.f);
-                if (nz && !tex) {
-                    const uint32_t bsdf = (uint32_t) (dst - grad_refl) / 3u;
-                    if (bsdf < HAR_LDS_GRAD_BSDFS) { atomicAdd(&gacc[3 * bsdf], g.x); atomicAdd(&gacc[3 * bsdf + 1], g.y); atomicAdd(&gacc[3 * bsdf + 2], g.z); }
-                    else { atomicAdd(dst, g.x); atomicAdd(dst + 1, g.y); atomicAdd(dst + 2, g.z); }
-                }
-                if (__ballot(nz && tex)) {
-                    const float w[4] = { taps.w0x * taps.w0y, taps.w1x * taps.w0y, taps.w0x * taps.w1y, taps.w1x * taps.w1y };
-                    for (int k = 0; k < 4; ++k)
-                        wave_aggregated_add3(nz && tex ? tdst + 3 * (size_t) taps.idx[k] : grad_refl, nz && tex ? g * w[k] : Vec3(0.f), nz && tex);
-                }
+                adjoint_commit(S, items, base + (pred ? idx : 0u), pred, pred && !T.found, result, dL, grad_refl, grad_tex, gacc);
             });
         __syncthreads();
         for (uint32_t k = threadIdx.x; k < 3 * min(S.n_bsdfs, (uint32_t) HAR_LDS_GRAD_BSDFS); k += kBlock) {
@@ -643,27 +678,31 @@ void launch_trace_closest(hipStream_t s, uint32_t grid, int stack_class, const A
 }
 void launch_shade(int mode, hipStream_t s, uint32_t grid, const DScene &S, const ShadeParams &P, uint32_t lane_base, uint32_t shard_cap, const uint32_t *count_in,
                   const WaveState &in, const float4 *h0, const uint2 *h1, const WaveState &out, uint32_t *count_out, const ItemArrays &items,
-                  uint32_t *item_count, float4 *result) {
+                  uint32_t *item_count, float4 *result, const ReplayCache &rc) {
     dim3 g(grid), b(kBlock);
     /* diffuse-only scenes (no twosided wrappers) run kernels in which the other BSDF models are compiled out */
     const bool only_diffuse = S.bsdf_types == HAR_BSDF_ONLY_DIFFUSE;
-#define HAR_LAUNCH_SHADE(M, T) hipLaunchKernelGGL((k_shade<M, T>), g, b, 0, s, S, P, lane_base, shard_cap, count_in, in, h0, h1, out, count_out, items, item_count, result)
+#define HAR_LAUNCH_SHADE(M, T) hipLaunchKernelGGL((k_shade<M, T>), g, b, 0, s, S, P, lane_base, shard_cap, count_in, in, h0, h1, out, count_out, items, item_count, result, rc)
     if (mode == MODE_PATH)            { if (only_diffuse) HAR_LAUNCH_SHADE(MODE_PATH, HAR_BSDF_ONLY_DIFFUSE); else HAR_LAUNCH_SHADE(MODE_PATH, HAR_BSDF_ALL_TYPES); }
     else if (mode == MODE_PRB_PRIMAL) { if (only_diffuse) HAR_LAUNCH_SHADE(MODE_PRB_PRIMAL, HAR_BSDF_ONLY_DIFFUSE); else HAR_LAUNCH_SHADE(MODE_PRB_PRIMAL, HAR_BSDF_ALL_TYPES); }
     else                              { if (only_diffuse) HAR_LAUNCH_SHADE(MODE_PRB_ADJOINT, HAR_BSDF_ONLY_DIFFUSE); else HAR_LAUNCH_SHADE(MODE_PRB_ADJOINT, HAR_BSDF_ALL_TYPES); }
 #undef HAR_LAUNCH_SHADE
 }
 void launch_resolve(int mode, hipStream_t s, uint32_t grid, int stack_class, const DScene &S, const uint32_t *item_count, uint32_t *cursor, uint32_t shard_cap, const ItemArrays &items,
-                    float4 *result, const float4 *dL, float *grad_refl, float *const *grad_tex, int *status) {
+                    float4 *result, const float4 *dL, float *grad_refl, float *const *grad_tex, int *status, const ReplayCache &rc) {
     dim3 g(grid), b(kBlock);
+    if (mode == MODE_PRB_ADJOINT && rc.mode == 2) {
+        hipLaunchKernelGGL(k_resolve_adjoint_cached, g, b, 0, s, S, item_count, shard_cap, items, result, dL, grad_refl, grad_tex, rc);
+        return;
+    }
     if (mode == MODE_PRB_ADJOINT) {
-        if (stack_class == 0) hipLaunchKernelGGL((k_resolve<MODE_PRB_ADJOINT, HAR_LDS_STACK_SMALL>), g, b, 0, s, S, item_count, cursor, shard_cap, items, result, dL, grad_refl, grad_tex, status);
-        else if (stack_class == 1) hipLaunchKernelGGL((k_resolve<MODE_PRB_ADJOINT, HAR_LDS_STACK_MEDIUM>), g, b, 0, s, S, item_count, cursor, shard_cap, items, result, dL, grad_refl, grad_tex, status);
-        else hipLaunchKernelGGL((k_resolve<MODE_PRB_ADJOINT, HAR_LDS_STACK_DEPTH>), g, b, 0, s, S, item_count, cursor, shard_cap, items, result, dL, grad_refl, grad_tex, status);
+        if (stack_class == 0) hipLaunchKernelGGL((k_resolve<MODE_PRB_ADJOINT, HAR_LDS_STACK_SMALL>), g, b, 0, s, S, item_count, cursor, shard_cap, items, result, dL, grad_refl, grad_tex, status, rc);
+        else if (stack_class == 1) hipLaunchKernelGGL((k_resolve<MODE_PRB_ADJOINT, HAR_LDS_STACK_MEDIUM>), g, b, 0, s, S, item_count, cursor, shard_cap, items, result, dL, grad_refl, grad_tex, status, rc);
+        else hipLaunchKernelGGL((k_resolve<MODE_PRB_ADJOINT, HAR_LDS_STACK_DEPTH>), g, b, 0, s, S, item_count, cursor, shard_cap, items, result, dL, grad_refl, grad_tex, status, rc);
     } else {
-        if (stack_class == 0) hipLaunchKernelGGL((k_resolve<MODE_PATH, HAR_LDS_STACK_SMALL>), g, b, 0, s, S, item_count, cursor, shard_cap, items, result, dL, grad_refl, grad_tex, status);
-        else if (stack_class == 1) hipLaunchKernelGGL((k_resolve<MODE_PATH, HAR_LDS_STACK_MEDIUM>), g, b, 0, s, S, item_count, cursor, shard_cap, items, result, dL, grad_refl, grad_tex, status);
-        else hipLaunchKernelGGL((k_resolve<MODE_PATH, HAR_LDS_STACK_DEPTH>), g, b, 0, s, S, item_count, cursor, shard_cap, items, result, dL, grad_refl, grad_tex, status);
+        if (stack_class == 0) hipLaunchKernelGGL((k_resolve<MODE_PATH, HAR_LDS_STACK_SMALL>), g, b, 0, s, S, item_count, cursor, shard_cap, items, result, dL, grad_refl, grad_tex, status, rc);
+        else if (stack_class == 1) hipLaunchKernelGGL((k_resolve<MODE_PATH, HAR_LDS_STACK_MEDIUM>), g, b, 0, s, S, item_count, cursor, shard_cap, items, result, dL, grad_refl, grad_tex, status, rc);
+        else hipLaunchKernelGGL((k_resolve<MODE_PATH, HAR_LDS_STACK_DEPTH>), g, b, 0, s, S, item_count, cursor, shard_cap, items, result, dL, grad_refl, grad_tex, status, rc);
     }
 }
 void launch_splat(hipStream_t s, const DSensor &C, uint32_t seed, uint32_t spp, uint32_t log_spp, uint32_t lane_base, uint32_t n,

@@ -421,3 +421,19 @@ def test_constant_environment_emitter_parity(mi, O):
         keys = scene._param_keys()
         got = np.stack([grads[k].cpu().numpy() for k in keys]); want = np.stack([g_refl[b.index] for (_, b) in keys.values()])
         assert rel_l2(got, want) < 1e-3
+
+
+def test_prb_replay_cache_is_transparent(mi, O):
+    """the adjoint pass with the replay cache (primal hit / visibility records reused) gives the gradients of a full re-trace,
+    for constant colours, textures and the all-materials scene, also when the path is deeper than the cache"""
+    scenes = [lambda: mi.textured_cornell_box(res=40, tex_res=16, spp=8), lambda: __import__("tests.test_bsdfs_cpu", fromlist=["x"])._material_cbox(mi, 40)]
+    for mk in scenes:
+        for md in (6, 20):
+            got = []
+            for cache in (True, False):
+                d = mk(); d["integrator"] = {"type": "prb", "max_depth": md, "rr_depth": 5, "replay_cache": cache}
+                scene = mi.load_dict(d)
+                grad_in = np.random.default_rng(4).uniform(0.5, 1.5, (40, 40, 3)).astype(np.float32)
+                grads = scene.integrator().render_backward(scene, None, grad_in, seed=2, spp=8)
+                got.append(np.concatenate([g.cpu().numpy().ravel() for g in grads.values()]))
+            assert np.abs(got[1]).max() > 0 and rel_l2(got[0], got[1]) < 1e-5
