@@ -574,7 +574,7 @@ static inline Lane make_lane(const OrcSensor &s, uint32_t seed, uint32_t spp, ui
 //  PathIntegrator::sample (src/integrators/path.cpp:94-346), JIT semantics
 // ---------------------------------------------------------------------------
 
-static V3 path_sample(const Scene &sc, Pcg32 &rng, Ray ray, uint32_t max_depth, uint32_t rr_depth, bool &valid_ray, OrcStats &st) {
+static V3 path_sample(const Scene &sc, Pcg32 &rng, Ray ray, uint32_t max_depth, uint32_t rr_depth, bool &valid_ray, OrcStats &st, bool scalar = false) {
     V3 throughput(1.f), result(0.f);
     float eta = 1.f; uint32_t depth = 0; valid_ray = sc.env >= 0;      // path.cpp:114: the environment is visible (hide_emitters = false)
     V3 prev_p(0.f); float prev_bsdf_pdf = 1.f; bool prev_bsdf_delta = true;
@@ -601,9 +601,12 @@ static V3 path_sample(const Scene &sc, Pcg32 &rng, Ray ray, uint32_t max_depth, 
         if (!active_next) break;                              // masked lane: state below is discarded
         BsdfCtx bsdf = bsdf_prepare(sc, sc.meshes[si.mesh].bsdf, si);          // si.bsdf(ray), path.cpp:232
         // emitter sampling, path.cpp:236-258: the samples are drawn by every lane, used where the BSDF is Smooth
-        float ex = rng.next_float32(), ey = rng.next_float32();
-        DS ds; V3 em_weight(0.f), wo(0.f);
         bool active_em = bsdf.rec->smooth();
+        /* JIT variants: `if (dr::any_or<true>(active_em))` is always taken, every lane draws the two samples;
+           scalar variants evaluate the real condition (path.cpp:244-249) */
+        float ex = 0.f, ey = 0.f;
+        if (!scalar || active_em) { ex = rng.next_float32(); ey = rng.next_float32(); }
+        DS ds; V3 em_weight(0.f), wo(0.f);
         if (active_em) active_em = sample_emitter_direction(sc, si, ex, ey, ds, em_weight, st);
         active_em &= ds.pdf != 0.f;
         if (active_em) wo = si.to_local(ds.d);
@@ -780,6 +783,126 @@ static int render_forward(Scene &sc, const OrcSensor &s, uint32_t seed, uint32_t
     });
     for (auto &f : films) if (!f.empty()) for (size_t i = 0; i < fsz; ++i) film[i] += f[i];
     merge_stats(stats, sts);
+    return 0;
+}
+
+
+// ---------------------------------------------------------------------------
+//  Scalar-variant driver (BASELINE config 1, `scalar_rgb`): SamplingIntegrator::render, CPU branch
+//  (src/render/integrator.cpp:190-274) -> Spiral::next_block (src/render/spiral.cpp:27-73) ->
+//  render_block (integrator.cpp:398-446: Morton pixel order, per-pixel reseed) -> render_sample ->
+//  ImageBlock::put, non-coalesced branch with the discretised filter (src/render/imageblock.cpp:283-375,
+//  include/mitsuba/core/rfilter.h:70-79, src/core/rfilter.cpp:11-26) -> HDRFilm::put_block
+// ---------------------------------------------------------------------------
+
+static inline void morton_decode2(uint32_t m, uint32_t &x, uint32_t &y) {     // dr::morton_decode<Point2u>: even bits -> x, odd bits -> y
+    auto compact = [](uint32_t v) { v &= 0x55555555u; v = (v ^ (v >> 1)) & 0x33333333u; v = (v ^ (v >> 2)) & 0x0f0f0f0fu;
+                                    v = (v ^ (v >> 4)) & 0x00ff00ffu; v = (v ^ (v >> 8)) & 0x0000ffffu; return v; };
+    x = compact(m); y = compact(m >> 1);
+}
+
+struct SpiralBlock { int32_t off_x, off_y; uint32_t size_x, size_y, id; };
+static std::vector<SpiralBlock> spiral_blocks(uint32_t size_x, uint32_t size_y, uint32_t off_x, uint32_t off_y, uint32_t block_size) {
+    std::vector<SpiralBlock> out;
+    int32_t bx = (int32_t) ((size_x + block_size - 1) / block_size), by = (int32_t) ((size_y + block_size - 1) / block_size);
+    uint32_t block_count = (uint32_t) (bx * by), counter = 0;
+    int direction = 0 /* Right, Down, Left, Up */; int32_t px = bx / 2, py = by / 2; uint32_t steps_left = 1, spiral_size = 1;
+    while (counter != block_count) {
+        SpiralBlock b; b.id = counter;                                  // single pass: block_id = m_block_counter
+        uint32_t ox = (uint32_t) px * block_size, oy = (uint32_t) py * block_size;
+        b.size_x = std::min(block_size, size_x - ox); b.size_y = std::min(block_size, size_y - oy);
+        b.off_x = (int32_t) (ox + off_x); b.off_y = (int32_t) (oy + off_y);
+        out.push_back(b);
+        ++counter;
+        if (counter != block_count) {
+            do {
+                switch (direction) { case 0: ++px; break; case 1: ++py; break; case 2: --px; break; default: --py; break; }
+                if (--steps_left == 0) {
+                    direction = (direction + 1) % 4;
+                    if (direction == 2 || direction == 0) ++spiral_size;
+                    steps_left = spiral_size;
+                }
+            } while (px < 0 || py < 0 || px >= bx || py >= by);
+        }
+    }
+    return out;
+}
+
+static int render_scalar(Scene &sc, const OrcSensor &s, uint32_t seed, uint32_t spp, int32_t max_depth, int32_t rr_depth,
+                         uint32_t n_threads, float *film, OrcStats *stats, uint32_t *block_size_out) {
+    const uint32_t W = s.crop_width, H = s.crop_height;
+    RFilter rf = make_rfilter(s.rfilter, s.rfilter_stddev);
+    // discretised filter (rfilter.cpp:11-26): MI_FILTER_RESOLUTION = 31
+    constexpr int RES = 31;
+    float values[RES + 1];
+    for (int i = 0; i < RES; ++i) values[i] = s.rfilter == 0 ? 1.f : rfilter_eval(rf, (rf.radius * (float) i) / (float) RES);
+    if (s.rfilter == 0) for (int i = 0; i < RES; ++i) values[i] = (rf.radius * (float) i) / (float) RES <= .5f ? 1.f : 0.f;
+    values[RES] = 0.f;
+    const float scale_factor = (float) RES / rf.radius;
+    const int border = (int) std::ceil(rf.radius - .5f - 2.f * RayEpsilon);
+    auto eval_discretized = [&](float x) { uint32_t index = std::min<uint32_t>((uint32_t) std::fabs(x * scale_factor), (uint32_t) RES); return values[index]; };
+    // block size (integrator.cpp:203-214)
+    uint32_t block_size = 32;
+    while (true) { if (block_size == 1 || ((W + block_size - 1) / block_size) * ((H + block_size - 1) / block_size) >= std::max(n_threads, 1u)) break; block_size /= 2; }
+    if (block_size_out) *block_size_out = block_size;
+    std::vector<SpiralBlock> blocks = spiral_blocks(W, H, s.crop_offset_x, s.crop_offset_y, block_size);
+    uint32_t md = max_depth < 0 ? 0xffffffffu : (uint32_t) max_depth;
+    seed *= W * H;                                                    // integrator.cpp:231 (dr::prod(film_size) of the crop window)
+    OrcStats st{};
+    const bool box = s.rfilter == 0;
+    for (const SpiralBlock &b : blocks) {
+        // ImageBlock(size, border = true): (size + 2 * border)^2 x 4, cleared per block (integrator.cpp:419)
+        const uint32_t bw = b.size_x + 2 * (uint32_t) border, bh = b.size_y + 2 * (uint32_t) border;
+        std::vector<float> blk((size_t) bw * bh * 4, 0.f);
+        uint32_t bseed = seed + b.id * block_size * block_size;       // integrator.cpp:412
+        for (uint32_t i = 0; i < block_size * block_size; ++i) {
+            uint32_t px, py; morton_decode2(i, px, py);
+            if (px >= b.size_x || py >= b.size_y) continue;
+            Pcg32 rng = sampler_seed(bseed + i, 0);                   // sampler->seed(seed + i): wavefront of size 1 (sampler.cpp:129-148)
+            float pos_fx = (float) ((int32_t) px + b.off_x), pos_fy = (float) ((int32_t) py + b.off_y);
+            for (uint32_t j = 0; j < spp; ++j) {                      // render_sample, integrator.cpp:448-520
+                float jx = rng.next_float32(), jy = rng.next_float32();
+                float sx = pos_fx + jx, sy = pos_fy + jy;
+                float isx = 1.f / (float) W, isy = 1.f / (float) H;
+                Ray ray = sensor_sample_ray(s, fmadd(sx, isx, -(float) s.crop_offset_x * isx), fmadd(sy, isy, -(float) s.crop_offset_y * isy));
+                bool valid; V3 rgb = path_sample(sc, rng, ray, md, (uint32_t) rr_depth, valid, st, /* scalar */ true);
+                st.paths++;
+                const float v[4] = { rgb.x, rgb.y, rgb.z, 1.f };
+                float ppx = box ? pos_fx : sx, ppy = box ? pos_fy : sy;
+                // ImageBlock::put, scalar branch (imageblock.cpp:283-375)
+                if (box) {                                            // no filter: nearest pixel (imageblock.cpp:225-243)
+                    int32_t x = (int32_t) std::floor(ppx) - b.off_x + border, y = (int32_t) std::floor(ppy) - b.off_y + border;
+                    if (x >= 0 && y >= 0 && (uint32_t) x < bw && (uint32_t) y < bh) { float *p = blk.data() + 4 * ((size_t) y * bw + x); for (int k = 0; k < 4; ++k) p[k] += v[k]; }
+                    continue;
+                }
+                float pfx = ppx + ((float) border - (float) b.off_x - .5f), pfy = ppy + ((float) border - (float) b.off_y - .5f);
+                int32_t x0 = std::max((int32_t) std::ceil(pfx - rf.radius), 0), y0 = std::max((int32_t) std::ceil(pfy - rf.radius), 0);
+                int32_t x1 = std::min((int32_t) std::floor(pfx + rf.radius), (int32_t) bw - 1), y1 = std::min((int32_t) std::floor(pfy + rf.radius), (int32_t) bh - 1);
+                if (x0 > x1 || y0 > y1) continue;
+                float wx[16], wy[16];
+                for (int32_t x = x0; x <= x1; ++x) wx[x - x0] = eval_discretized((float) x0 - pfx + (float) (x - x0));
+                for (int32_t y = y0; y <= y1; ++y) wy[y - y0] = eval_discretized((float) y0 - pfy + (float) (y - y0));
+                for (int32_t y = y0; y <= y1; ++y)
+                    for (int32_t x = x0; x <= x1; ++x) {
+                        float w = wx[x - x0] * wy[y - y0];
+                        float *p = blk.data() + 4 * ((size_t) y * bw + x);
+                        for (int k = 0; k < 4; ++k) p[k] = fmadd(v[k], w, p[k]);
+                    }
+            }
+        }
+        // HDRFilm::put_block -> ImageBlock::put_block (imageblock.cpp:152-185): accumulate the overlap with the film
+        for (uint32_t y = 0; y < bh; ++y) {
+            int32_t fy = (int32_t) y + b.off_y - border - (int32_t) s.crop_offset_y;
+            if (fy < 0 || fy >= (int32_t) H) continue;
+            for (uint32_t x = 0; x < bw; ++x) {
+                int32_t fx = (int32_t) x + b.off_x - border - (int32_t) s.crop_offset_x;
+                if (fx < 0 || fx >= (int32_t) W) continue;
+                const float *src = blk.data() + 4 * ((size_t) y * bw + x); float *dst = film + 4 * ((size_t) fy * W + fx);
+                for (int k = 0; k < 4; ++k) dst[k] += src[k];
+            }
+        }
+    }
+    if (stats) *stats = st;
     return 0;
 }
 
@@ -1071,6 +1194,18 @@ void orc_roughplastic_tables(void *scene, uint32_t bsdf, float out[66]) {
     const BsdfRecord &b = ((Scene *) scene)->bsdfs[bsdf];
     for (int i = 0; i < 64; ++i) out[i] = i < (int) b.external_transmittance.size() ? b.external_transmittance[i] : 0.f;
     out[64] = b.internal_reflectance; out[65] = b.specular_sampling_weight;
+}
+
+
+int orc_render_path_scalar(void *scene, const OrcSensor *s, uint32_t seed, uint32_t spp, int32_t max_depth, int32_t rr_depth,
+                           uint32_t n_threads, float *film, OrcStats *stats, uint32_t *block_size) {
+    return render_scalar(*(Scene *) scene, *s, seed, spp, max_depth, rr_depth, n_threads, film, stats, block_size);
+}
+void orc_morton_decode(uint32_t m, uint32_t out[2]) { morton_decode2(m, out[0], out[1]); }
+uint32_t orc_spiral(uint32_t size_x, uint32_t size_y, uint32_t block_size, uint32_t max_blocks, int32_t *out /* [n][5]: off_x, off_y, size_x, size_y, id */) {
+    std::vector<SpiralBlock> b = spiral_blocks(size_x, size_y, 0, 0, block_size);
+    for (uint32_t i = 0; i < std::min<uint32_t>((uint32_t) b.size(), max_blocks); ++i) { out[5 * i] = b[i].off_x; out[5 * i + 1] = b[i].off_y; out[5 * i + 2] = (int32_t) b[i].size_x; out[5 * i + 3] = (int32_t) b[i].size_y; out[5 * i + 4] = (int32_t) b[i].id; }
+    return (uint32_t) b.size();
 }
 
 } // extern "C"

@@ -116,6 +116,14 @@ void  orc_scene_destroy(void *scene);
 void  orc_scene_set_reflectance(void *scene, uint32_t bsdf, const float rgb[3]);
 void  orc_scene_set_texture(void *scene, uint32_t texture, const float *data);
 
+/* ---- scalar-variant driver (BASELINE config 1, `scalar_rgb`): SamplingIntegrator::render CPU branch
+ *      (integrator.cpp:190-274,398-446), Spiral (spiral.cpp:27-73), ImageBlock::put with the discretised filter.
+ *      n_threads = pool_size() + 1 of the emulated run (it decides the block size, integrator.cpp:203-214). ---- */
+int   orc_render_path_scalar(void *scene, const OrcSensor *sensor, uint32_t seed, uint32_t spp, int32_t max_depth, int32_t rr_depth,
+                             uint32_t n_threads, float *film /* H x W x 4, accumulated */, OrcStats *stats, uint32_t *block_size);
+void  orc_morton_decode(uint32_t m, uint32_t out[2]);
+uint32_t orc_spiral(uint32_t size_x, uint32_t size_y, uint32_t block_size, uint32_t max_blocks, int32_t *out);
+
 /* ---- BSDF / microfacet building blocks (golden-vector checks; src/render/tests/test_microfacet.py,
  *      src/bsdfs/tests/test_dielectric.py, test_twosided.py) ---- */
 /* MicrofacetDistribution(type 0 beckmann / 1 ggx, alpha_u, alpha_v, sample_visible): out = {eval(m), pdf(wi, m), smith_g1(wi, m)} */

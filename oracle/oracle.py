@@ -359,6 +359,14 @@ class OracleScene:
         film, st = self._render(lib().orc_render_path, sensor, seed, spp, max_depth, rr_depth, lanes, threads)
         return (film if raw else develop(film)), st
 
+    def render_path_scalar(self, sensor, seed=0, spp=4, max_depth=8, rr_depth=5, n_threads=1, raw=False):
+        """`scalar_rgb` driver (spiral blocks, Morton order, per-pixel reseed, discretised filter): BASELINE config 1"""
+        film = np.zeros((sensor.crop_height, sensor.crop_width, 4), np.float32)
+        st = Stats(); bs = C.c_uint32()
+        rc = lib().orc_render_path_scalar(self.handle, C.byref(sensor), seed, spp, max_depth, rr_depth, n_threads, fp(film), C.byref(st), C.byref(bs))
+        assert rc == 0
+        return (film if raw else develop(film)), st, bs.value
+
     def render_prb(self, sensor, seed=0, spp=4, max_depth=6, rr_depth=5, lanes=None, threads=0, raw=False):
         film, st = self._render(lib().orc_render_prb, sensor, seed, spp, max_depth, rr_depth, lanes, threads)
         return (film if raw else develop(film)), st

@@ -1,0 +1,58 @@
+"""BASELINE config 1 ("Cornell box, scalar_rgb path integrator, 64spp on CPU"): the oracle's restatement of the reference's
+scalar-variant driver -- spiral block order, Morton pixel order, per-pixel reseeding, discretised reconstruction filter,
+block borders (integrator.cpp:190-274,398-446; spiral.cpp:27-73; imageblock.cpp:283-375)."""
+import ctypes as C
+
+import numpy as np
+
+
+def test_morton_and_spiral(O):
+    L = O.lib(); out = (C.c_uint32 * 2)()
+    want = [(0, 0), (1, 0), (0, 1), (1, 1), (2, 0), (3, 0), (2, 1), (3, 1), (0, 2), (1, 2), (0, 3)]
+    for m, w in enumerate(want):
+        L.orc_morton_decode(m, out); assert (out[0], out[1]) == w
+    L.orc_morton_decode(0xffff, out); assert (out[0], out[1]) == (255, 255)
+    buf = (C.c_int32 * (5 * 64))()
+    n = L.orc_spiral(96, 96, 32, 64, buf)              # 3 x 3 blocks: centre, right, down, left, left, up, up, right, right
+    blocks = np.frombuffer(buf, np.int32).reshape(-1, 5)[:n]
+    assert n == 9 and [tuple(b[:2] // 32) for b in blocks] == [(1, 1), (2, 1), (2, 2), (1, 2), (0, 2), (0, 1), (0, 0), (1, 0), (2, 0)]
+    assert list(blocks[:, 4]) == list(range(9))
+    n = L.orc_spiral(100, 70, 32, 64, buf)             # ragged: 4 x 3 blocks, every pixel covered exactly once
+    blocks = np.frombuffer(buf, np.int32).reshape(-1, 5)[:n]
+    cover = np.zeros((70, 100), int)
+    for ox, oy, sx, sy, _ in blocks:
+        cover[oy:oy + sy, ox:ox + sx] += 1
+    assert n == 12 and (cover == 1).all()
+
+
+def test_config1_scalar_cornell(O):
+    """64 spp Cornell box through the scalar driver: same estimator as the JIT-order driver (different sample streams),
+    so the images agree statistically; every pixel receives exactly spp samples; block size follows the thread count."""
+    res, spp = 48, 64
+    sd, sensor = O.cornell_box(res, res)
+    osc = O.OracleScene(sd)
+    film_s, st, bs = osc.render_path_scalar(sensor, seed=0, spp=spp, max_depth=8, raw=True)
+    assert bs == 32 and st.paths == res * res * spp
+    _, _, bs8 = osc.render_path_scalar(sensor, seed=0, spp=1, max_depth=1, n_threads=8, raw=True)
+    assert bs8 == 16                                    # (48/32)^2 = 4 blocks < 8 threads -> 16 x 16 blocks
+    film_j, _ = osc.render_path(sensor, seed=0, spp=spp, max_depth=8, raw=True)
+    img_s, img_j = O.develop(film_s), O.develop(film_j)
+    assert np.isfinite(img_s).all() and img_s.min() >= 0
+    assert abs(img_s.mean() / img_j.mean() - 1) < 0.02
+    blur = lambda a: a.reshape(res // 8, 8, res // 8, 8, 3).mean(axis=(1, 3))
+    assert np.abs(blur(img_s) - blur(img_j)).max() / blur(img_j).max() < 0.08
+    # weights: eval_discretized() looks the filter up at the LEFT edge of 31 bins per radius (rfilter.h:70-79), which
+    # over-estimates a decreasing filter by ~5 % per axis -> ~10 % more accumulated weight; develop() divides it out
+    assert 1.07 < film_s[..., 3].sum() / film_j[..., 3].sum() < 1.13
+    # determinism + seed sensitivity
+    film_s2, _, _ = osc.render_path_scalar(sensor, seed=0, spp=spp, max_depth=8, raw=True)
+    assert np.array_equal(film_s, film_s2)
+    film_s3, _, _ = osc.render_path_scalar(sensor, seed=1, spp=spp, max_depth=8, raw=True)
+    assert not np.array_equal(film_s, film_s3)
+
+
+def test_scalar_directly_visible_emitter_kat(O):
+    """src/integrators/tests/test_integrators.py:28-53 runs under `variants_all_rgb`, i.e. also scalar_rgb: pixel (124, 36)"""
+    sd, sensor = O.cornell_box(256, 256, crop=(124, 36, 1, 1))
+    img, _, _ = O.OracleScene(sd).render_path_scalar(sensor, spp=64, max_depth=1)
+    assert np.allclose(img.reshape(3), [18.387, 13.9873, 6.75357], rtol=1e-5)
