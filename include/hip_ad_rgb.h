@@ -219,9 +219,18 @@ int har_integrator_destroy(HarIntegrator integrator);
  * ADIntegrator.render (common.py:46-110) restricted to lanes [lane_begin, lane_end)
  * of the W*H*spp wavefront (0,0 = all): splats into `film` (DEVICE, H x W x 4,
  * accumulated, not cleared, not developed) so that tiles rendered by several
- * GPUs can be summed with one reduce before har_film_develop. */
+ * GPUs can be summed with one reduce before har_film_develop.
+ * Multi-pass rendering (integrator.cpp:173-183,276-356; `path` only): when `samples_per_pass` is set, or W*H*spp exceeds
+ * 2^32 - 1, the job runs as n_passes wavefronts of W*H*spp_per_pass lanes whose sampler streams CONTINUE from pass to
+ * pass; lane_begin/lane_end then index the per-pass wavefront (har_render_pass_layout tells its size). */
 int har_render(HarScene scene, HarIntegrator integrator, const HarSensor *sensor, uint32_t seed,
                uint32_t spp, uint64_t lane_begin, uint64_t lane_end, float *film, void *stream);
+
+/* `samples_per_pass` property of SamplingIntegrator (integrator.cpp:140-147); 0 = unset */
+int har_integrator_set_samples_per_pass(HarIntegrator integrator, uint32_t samples_per_pass);
+/* the pass split har_render will use for `spp` samples per pixel of this sensor's crop window; fails like the reference
+ * when spp is not a multiple of the pass size (integrator.cpp:177-179, sampler.cpp:93-94) */
+int har_render_pass_layout(HarIntegrator integrator, const HarSensor *sensor, uint32_t spp, uint32_t *spp_per_pass, uint32_t *n_passes);
 
 /* RBIntegrator.render_backward (common.py:625-783), split so that the weight
  * image can be reduced across GPUs between the two calls:

@@ -103,6 +103,8 @@ SIGNATURES = {
     "har_integrator_create": (C.c_int, [C.c_int, C.c_int32, C.c_int32, C.c_uint32, C.POINTER(vp)]),
     "har_integrator_destroy": (C.c_int, [vp]),
     "har_render": (C.c_int, [vp, vp, C.POINTER(HarSensor), C.c_uint32, C.c_uint32, C.c_uint64, C.c_uint64, vp, vp]),
+    "har_integrator_set_samples_per_pass": (C.c_int, [vp, C.c_uint32]),
+    "har_render_pass_layout": (C.c_int, [vp, C.POINTER(HarSensor), C.c_uint32, u32p, u32p]),
     "har_render_weights": (C.c_int, [C.POINTER(HarSensor), C.c_uint32, C.c_uint32, C.c_uint64, C.c_uint64, vp, vp]),
     "har_render_backward": (C.c_int, [vp, vp, C.POINTER(HarSensor), vp, vp, C.c_uint32, C.c_uint32, C.c_uint64,
                                       C.c_uint64, vp, C.POINTER(vp), vp]),

@@ -623,6 +623,13 @@ class Integrator:
             raise RuntimeError("\"rr_depth\" must be set to a value greater than zero!")
         self.chunk_lanes = int(props.get('chunk_lanes', 0))
         self.replay_cache = bool(props.get('replay_cache', True))      # hip_ad_rgb extension, see har_integrator_set_replay_cache
+        # SamplingIntegrator property (integrator.cpp:140-147); the Python AD integrators do not query it, and an
+        # unqueried property is an error in the reference's plugin loader
+        self.samples_per_pass = props.get('samples_per_pass', None)
+        if self.samples_per_pass is not None:
+            if self.type != 'path':
+                raise RuntimeError("Unreferenced property \"samples_per_pass\" in plugin of type \"%s\"" % self.type)
+            self.samples_per_pass = int(self.samples_per_pass)
         self._h = None
 
     def _handle(self):
@@ -632,7 +639,16 @@ class Integrator:
             self._h = h
             if not self.replay_cache:
                 check(lib().har_integrator_set_replay_cache(h, 0))
+            if self.samples_per_pass is not None:
+                check(lib().har_integrator_set_samples_per_pass(h, self.samples_per_pass))
         return self._h
+
+    def pass_layout(self, sensor, spp=0):
+        """(spp_per_pass, n_passes) of a render() with `spp` samples (integrator.cpp:173-183,276-294)"""
+        spp = spp or sensor.sampler().sample_count()
+        a = C.c_uint32(); b = C.c_uint32()
+        check(lib().har_render_pass_layout(self._handle(), C.byref(sensor.har), spp, C.byref(a), C.byref(b)))
+        return a.value, b.value
 
     def __del__(self):
         try:

@@ -61,6 +61,9 @@ struct HarIntegratorImpl {
     /* PRB replay cache (see ReplayCache): cache_bounces arrays of ws_lanes entries each */
     float4 *rc_h0 = nullptr; uint2 *rc_h1 = nullptr; uint8_t *rc_vis = nullptr; uint32_t cache_bounces = 0; bool use_cache = true;
     float *adj = nullptr; size_t adj_floats = 0;
+    /* multi-pass rendering: sampler state per lane of the rendered lane range, pixel jitter per chunk lane (see PassState) */
+    uint32_t samples_per_pass = 0xffffffffu;
+    uint64_t *pass_rng = nullptr; size_t pass_rng_cap = 0; float2 *pass_jitter = nullptr; size_t pass_jitter_cap = 0;
     uint32_t *counters = nullptr;
     unsigned long long *totals = nullptr;
     int *status = nullptr;
@@ -90,6 +93,7 @@ int ensure_workspace(HarIntegratorImpl *I, uint32_t lanes, bool adjoint) {
     if (I->ws_lanes >= lanes && (I->ws_adjoint || !adjoint)) return 0;
     I->free_ws();
     I->counters = nullptr; I->totals = nullptr; I->status = nullptr; I->adj = nullptr; I->adj_floats = 0; I->d_grad_tex = nullptr; I->grad_tex_cap = 0;
+    I->pass_rng = nullptr; I->pass_rng_cap = 0; I->pass_jitter = nullptr; I->pass_jitter_cap = 0;
     for (int k = 0; k < 2; ++k) {
         if (ws_alloc(I, &I->st[k].a0, lanes) || ws_alloc(I, &I->st[k].a1, lanes) || ws_alloc(I, &I->st[k].a2, lanes) ||
             ws_alloc(I, &I->st[k].a3, lanes) || ws_alloc(I, &I->st[k].a4, lanes)) return 1;
@@ -135,14 +139,14 @@ static inline uint32_t *cur_resolve(HarIntegratorImpl *I, uint32_t b) { return I
 
 /* one chunk: raygen + bounce loop.  `mode` selects path / prb primal / prb adjoint kernels */
 int run_chunk(HarSceneImpl *S, HarIntegratorImpl *I, const DSensor &C, int mode, uint32_t seed, uint32_t spp, uint32_t log_spp,
-              uint32_t lane_base, uint32_t n, float *grad_refl, hipStream_t s, int cache_mode = 0) {
+              uint32_t lane_base, uint32_t n, float *grad_refl, hipStream_t s, int cache_mode = 0, const PassState &ps = PassState{ nullptr, nullptr, 0 }) {
     const uint32_t nb = bounce_limit(I);
     const size_t used = (size_t) std::min<uint32_t>(nb + 2, HAR_MAX_BOUNCE_SLOTS) * HAR_SHARDS * HAR_COUNTER_STRIDE * sizeof(uint32_t);
     HIP_TRY(hipMemsetAsync(cnt_alive(I, 0), 0, used, s));
     HIP_TRY(hipMemsetAsync(cnt_items(I, 0), 0, used, s));
     HIP_TRY(hipMemsetAsync(cur_trace(I, 0), 0, used, s));
     HIP_TRY(hipMemsetAsync(cur_resolve(I, 0), 0, used, s));
-    launch_raygen(mode, s, C, seed, spp, log_spp, lane_base, n, I->shard_cap, I->st[0], I->result, cnt_alive(I, 0), I->adj, I->dL);
+    launch_raygen(mode, s, C, seed, spp, log_spp, lane_base, n, I->shard_cap, I->st[0], I->result, cnt_alive(I, 0), I->adj, I->dL, ps);
     prof_mark(I, s, CLS_RAYGEN);
     ShadeParams P{ seed, I->max_depth, I->rr_depth };
     /* grid: a multiple of 8 so that block b serves shard b % 8; enough blocks to cover the chunk once */
@@ -163,7 +167,7 @@ int run_chunk(HarSceneImpl *S, HarIntegratorImpl *I, const DSensor &C, int mode,
             prof_mark(I, s, CLS_TRACE);
         }
         launch_shade(mode, s, grid, S->ds, P, lane_base, I->shard_cap, cnt_alive(I, b), I->st[cur], I->h0, I->h1, I->st[cur ^ 1], cnt_alive(I, b + 1),
-                     I->items, cnt_items(I, b), I->result, rc);
+                     I->items, cnt_items(I, b), I->result, rc, ps.rng);
         prof_mark(I, s, CLS_SHADE);
         launch_resolve(mode, s, rc.mode == 2 ? grid : tgrid, small_stack, S->ds, cnt_items(I, b), cur_resolve(I, b), I->shard_cap, I->items, I->result, I->dL, grad_refl, I->d_grad_tex, I->status, rc);
         prof_mark(I, s, CLS_RESOLVE);
@@ -181,6 +185,24 @@ int run_chunk(HarSceneImpl *S, HarIntegratorImpl *I, const DSensor &C, int mode,
         prof_mark(I, s, CLS_OTHER);
     }
     HIP_TRY(hipGetLastError());
+    return 0;
+}
+
+/* SamplingIntegrator::render, integrator.cpp:173-183,276-294 + Sampler::set_samples_per_wavefront, sampler.cpp:88-96 */
+int pass_layout(const HarIntegratorImpl *I, uint32_t crop_w, uint32_t crop_h, uint32_t spp, uint32_t &spp_per_pass, uint32_t &n_passes) {
+    if (spp == 0) return fail("spp must be > 0");
+    spp_per_pass = I->samples_per_pass == 0xffffffffu ? spp : std::min(I->samples_per_pass, spp);
+    if (spp_per_pass == 0 || spp % spp_per_pass != 0) return fail("sample_count (" + std::to_string(spp) + ") must be a multiple of spp_per_pass (" + std::to_string(spp_per_pass) + ").");
+    n_passes = spp / spp_per_pass;
+    const uint64_t limit = 0xffffffffull;
+    uint64_t wavefront = (uint64_t) crop_w * crop_h * spp_per_pass;
+    if (wavefront > limit) {
+        spp_per_pass /= (uint32_t) ((wavefront + limit - 1) / limit);
+        if (spp_per_pass == 0) return fail("the film alone exceeds the wavefront size limit of 2^32 - 1 lanes");
+        n_passes = spp / spp_per_pass;
+        /* the reference then calls sampler->set_samples_per_wavefront(spp_per_pass), which throws unless it divides the sample count */
+        if (spp % spp_per_pass != 0) return fail("sample_count should be a multiple of samples_per_wavefront! (" + std::to_string(spp) + " samples in passes of " + std::to_string(spp_per_pass) + "; set samples_per_pass)");
+    }
     return 0;
 }
 
@@ -394,33 +416,58 @@ int har_integrator_destroy(HarIntegrator I) {
 
 int har_render(HarScene S, HarIntegrator I, const HarSensor *sensor, uint32_t seed, uint32_t spp, uint64_t lb, uint64_t le, float *film, void *stream) {
     DSensor C; uint32_t log_spp;
-    if (check_common(S, I, sensor, spp, lb, le, C, log_spp)) return 1;
+    if (!S || !I || !sensor) return fail("null scene / integrator / sensor");
+    /* multi-pass layout; `path` only: the Python AD integrators render one wavefront or refuse (common.py:358-363) */
+    uint32_t spp_pass = spp, n_passes = 1;
+    if (I->type == HAR_INTEGRATOR_PATH && pass_layout(I, sensor->crop_width, sensor->crop_height, spp, spp_pass, n_passes)) return 1;
+    if (check_common(S, I, sensor, spp_pass, lb, le, C, log_spp)) return 1;
     if (!film) return fail("null film");
     hipStream_t s = (hipStream_t) stream;
     uint32_t chunk = (uint32_t) std::min<uint64_t>(I->chunk, (std::max<uint64_t>(le - lb, 2048) + 2047) / 2048 * 2048);
     if (ensure_workspace(I, chunk, false)) return 1;
+    const bool multi = n_passes > 1;
+    if (multi) {
+        if (I->pass_rng_cap < le - lb && I->max_depth != 0) { if (ws_alloc(I, &I->pass_rng, (size_t) (le - lb))) return 1; I->pass_rng_cap = (size_t) (le - lb); }
+        if (I->pass_jitter_cap < chunk) { if (ws_alloc(I, &I->pass_jitter, chunk)) return 1; I->pass_jitter_cap = chunk; }
+    }
     HIP_TRY(hipMemsetAsync(I->totals, 0, 4 * sizeof(unsigned long long), s));
     HIP_TRY(hipMemsetAsync(I->status, 0, sizeof(int), s));
     I->ev_used = 0; I->last_stream = s;
     prof_mark(I, s, CLS_START);
     const int mode = I->type == HAR_INTEGRATOR_PATH ? MODE_PATH : MODE_PRB_PRIMAL;
-    if (I->max_depth == 0) {      /* path.cpp:102-103: nothing but the weight channel */
+    for (uint32_t pass = 0; pass < n_passes; ++pass) {
+        if (I->max_depth == 0) {      /* path.cpp:102-103: nothing but the weight channel */
+            for (uint64_t base = lb; base < le; base += chunk) {
+                uint32_t n = (uint32_t) std::min<uint64_t>(chunk, le - base);
+                if (multi) launch_pass_jitter(s, seed, (uint32_t) base, n, pass, I->pass_jitter);
+                launch_splat(s, C, seed, spp_pass, log_spp, (uint32_t) base, n, nullptr, 1, film, multi ? I->pass_jitter : nullptr);
+            }
+            continue;
+        }
         for (uint64_t base = lb; base < le; base += chunk) {
             uint32_t n = (uint32_t) std::min<uint64_t>(chunk, le - base);
-            launch_splat(s, C, seed, spp, log_spp, (uint32_t) base, n, nullptr, 1, film);
+            const PassState ps{ multi ? I->pass_rng + (base - lb) : nullptr, multi ? I->pass_jitter : nullptr, pass };
+            if (run_chunk(S, I, C, mode, seed, spp_pass, log_spp, (uint32_t) base, n, nullptr, s, 0, ps)) return 1;
+            if (mode == MODE_PRB_PRIMAL) { launch_accumulate_stats(s, I->counters, bounce_limit(I), I->totals, n); prof_mark(I, s, CLS_OTHER); }
+            launch_splat(s, C, seed, spp_pass, log_spp, (uint32_t) base, n, I->result, 0, film, ps.jitter);
+            prof_mark(I, s, CLS_SPLAT);
         }
-        HIP_TRY(hipGetLastError());
-        return 0;
-    }
-    for (uint64_t base = lb; base < le; base += chunk) {
-        uint32_t n = (uint32_t) std::min<uint64_t>(chunk, le - base);
-        if (run_chunk(S, I, C, mode, seed, spp, log_spp, (uint32_t) base, n, nullptr, s)) return 1;
-        if (mode == MODE_PRB_PRIMAL) { launch_accumulate_stats(s, I->counters, bounce_limit(I), I->totals, n); prof_mark(I, s, CLS_OTHER); }
-        launch_splat(s, C, seed, spp, log_spp, (uint32_t) base, n, I->result, 0, film);
-        prof_mark(I, s, CLS_SPLAT);
     }
     HIP_TRY(hipGetLastError());
     return 0;
+}
+
+int har_integrator_set_samples_per_pass(HarIntegrator I, uint32_t samples_per_pass) {
+    if (!I) return fail("null integrator");
+    if (I->type != HAR_INTEGRATOR_PATH) return fail("samples_per_pass is a property of SamplingIntegrator (`path`); the AD integrators render a single wavefront");
+    I->samples_per_pass = samples_per_pass ? samples_per_pass : 0xffffffffu;
+    return 0;
+}
+int har_render_pass_layout(HarIntegrator I, const HarSensor *sensor, uint32_t spp, uint32_t *spp_per_pass, uint32_t *n_passes) {
+    if (!I || !sensor || !spp_per_pass || !n_passes) return fail("null argument");
+    *spp_per_pass = spp; *n_passes = 1;
+    if (I->type != HAR_INTEGRATOR_PATH) return spp ? 0 : fail("spp must be > 0");
+    return pass_layout(I, sensor->crop_width, sensor->crop_height, spp, *spp_per_pass, *n_passes);
 }
 
 int har_render_weights(const HarSensor *sensor, uint32_t seed, uint32_t spp, uint64_t lb, uint64_t le, float *film, void *stream) {

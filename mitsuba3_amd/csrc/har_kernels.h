@@ -31,18 +31,24 @@ struct ItemArrays { float4 *s0, *s1, *s2, *s3, *s4; };
  * numbers, so its ray queries are bit-identical to the primal pass's; their results (24 B hit record, 1 B visibility) are kept in HBM
  * between the two passes of a chunk instead of being traced twice.  mode 0 = unused, 1 = write (primal pass), 2 = read (adjoint pass) */
 struct ReplayCache { float4 *h0; uint2 *h1; uint8_t *vis; int mode; };
+/* Multi-pass rendering (integrator.cpp:280-356): the sampler of lane i keeps its PCG32 state from one pass to the next (sampler->advance()
+ * does not reseed).  `rng` holds that state per lane of the chunk (pre-offset to the chunk's first lane; nullptr = single pass, streams are
+ * seeded in raygen and dropped at path end); `jitter` receives the pass's pixel jitter per chunk lane for the splat kernel, which otherwise
+ * recomputes it from the seed; `pass` = 0 seeds the streams instead of reading `rng`. */
+struct PassState { uint64_t *rng; float2 *jitter; uint32_t pass; };
 
 void launch_raygen(int mode, hipStream_t s, const DSensor &C, uint32_t seed, uint32_t spp, uint32_t log_spp, uint32_t lane_base, uint32_t n,
-                   uint32_t shard_cap, const WaveState &out, float4 *result, uint32_t *count, const float *adj, float4 *dL);
+                   uint32_t shard_cap, const WaveState &out, float4 *result, uint32_t *count, const float *adj, float4 *dL, const PassState &ps = PassState{ nullptr, nullptr, 0 });
 void launch_trace_closest(hipStream_t s, uint32_t grid, int stack_class, const Accel &A, const uint32_t *count, uint32_t *cursor, uint32_t shard_cap,
                           const WaveState &in, float4 *h0, uint2 *h1, int *status);
 void launch_shade(int mode, hipStream_t s, uint32_t grid, const DScene &S, const ShadeParams &P, uint32_t lane_base, uint32_t shard_cap, const uint32_t *count_in,
                   const WaveState &in, const float4 *h0, const uint2 *h1, const WaveState &out, uint32_t *count_out, const ItemArrays &items,
-                  uint32_t *item_count, float4 *result, const ReplayCache &rc);
+                  uint32_t *item_count, float4 *result, const ReplayCache &rc, uint64_t *pass_rng = nullptr);
 void launch_resolve(int mode, hipStream_t s, uint32_t grid, int stack_class, const DScene &S, const uint32_t *item_count, uint32_t *cursor, uint32_t shard_cap, const ItemArrays &items,
                     float4 *result, const float4 *dL, float *grad_refl, float *const *grad_tex, int *status, const ReplayCache &rc);
 void launch_splat(hipStream_t s, const DSensor &C, uint32_t seed, uint32_t spp, uint32_t log_spp, uint32_t lane_base, uint32_t n,
-                  const float4 *result, int weights_only, float *film);
+                  const float4 *result, int weights_only, float *film, const float2 *jitter = nullptr);
+void launch_pass_jitter(hipStream_t s, uint32_t seed, uint32_t lane_base, uint32_t n, uint32_t pass, float2 *jitter);
 void launch_develop(hipStream_t s, const float *film, uint32_t npx, float *image);
 void launch_adjoint_image(hipStream_t s, const float *grad_in, const float *wfilm, uint32_t npx, float *adj);
 void launch_accumulate_stats(hipStream_t s, const uint32_t *counters, uint32_t n_bounces, unsigned long long *totals, uint32_t paths);

@@ -131,7 +131,7 @@ __device__ __forceinline__ uint32_t shard_slot(uint32_t i, uint32_t shard_cap) {
 template <int MODE>
 __global__ __launch_bounds__(kBlock) void k_raygen(DSensor C, uint32_t seed, uint32_t spp, uint32_t log_spp, uint32_t lane_base,
                                                    uint32_t n, uint32_t shard_cap, WaveState out, float4 *result, uint32_t *count,
-                                                   const float *adj, float4 *dL) {
+                                                   const float *adj, float4 *dL, PassState ps) {
     uint32_t i = blockIdx.x * kBlock + threadIdx.x;
     if (i < HAR_SHARDS) {            /* lanes dealt to shard i */
         const uint32_t tiles = (n + kBlock - 1) / kBlock, rem = n % kBlock;
@@ -142,7 +142,12 @@ __global__ __launch_bounds__(kBlock) void k_raygen(DSensor C, uint32_t seed, uin
     }
     if (i >= n) return;
     LaneSample ls;
-    PathState st = raygen_lane(C, seed, spp, log_spp, lane_base + i, ls);
+    PathState st;
+    if (ps.rng) {
+        float j[2];
+        st = raygen_lane(C, seed, spp, log_spp, lane_base + i, ls, ps.pass ? ps.rng + i : nullptr, j);
+        ps.jitter[i] = make_float2(j[0], j[1]);
+    } else st = raygen_lane(C, seed, spp, log_spp, lane_base + i, ls);
     store_state(out, shard_slot(i, shard_cap), st);
     if (MODE != MODE_PRB_ADJOINT) result[i] = make_float4(0.f, 0.f, 0.f, 0.f);
     if (MODE == MODE_PRB_ADJOINT) {
@@ -285,7 +290,7 @@ __global__ __launch_bounds__(kBlock) void k_trace_closest(Accel A, const uint32_
 template <int MODE, uint32_t TYPES>
 __global__ __launch_bounds__(kBlock, HAR_SHADE_MIN_WAVES) void k_shade(DScene S, ShadeParams P, uint32_t lane_base, uint32_t shard_cap, const uint32_t *count_in, WaveState in,
                                                   const float4 *h0, const uint2 *h1, WaveState out, uint32_t *count_out,
-                                                  ItemArrays items, uint32_t *item_count, float4 *result, ReplayCache rc) {
+                                                  ItemArrays items, uint32_t *item_count, float4 *result, ReplayCache rc, uint64_t *pass_rng) {
     __shared__ uint32_t lds_r[12];
     __shared__ uint32_t sort_cnt[8], sort_perm[TYPES == HAR_BSDF_ONLY_DIFFUSE ? 1 : kBlock];
     const ShardLoop Q(count_in, shard_cap);
@@ -330,6 +335,13 @@ __global__ __launch_bounds__(kBlock, HAR_SHADE_MIN_WAVES) void k_shade(DScene S,
             Hit hit; hit.t = hh.x; hit.u = hh.y; hit.v = hh.z; hit.prim = __float_as_uint(hh.w); hit.shape = hs.x; hit.inst = hs.y;
             shade_lane<MODE, TYPES>(S, P, st, hit, R);
             lane = st.lane - lane_base;
+            if (MODE == MODE_PATH && pass_rng && !R.alive) {
+                /* multi-pass render: the path ends here, its sampler lives on.  A lane that starts a loop iteration draws all six
+                 * numbers of that iteration whether or not it survives it (symbolic dr::while_loop: unmasked draws, path.cpp:247,263-264,323) */
+                uint64_t r = st.rng; const uint64_t inc = sampler_inc(P.seed, st.lane);
+                for (int k = 0; k < 6; ++k) r = r * HAR_PCG32_MULT + inc;
+                pass_rng[lane] = r;
+            }
             if (R.add_emission) {
                 float4 r = result[lane];
                 if (MODE == MODE_PATH)            r = make_float4(fma_(R.em_a.x, R.em_b.x, r.x), fma_(R.em_a.y, R.em_b.y, r.y), fma_(R.em_a.z, R.em_b.z, r.z), 0.f);
@@ -465,7 +477,7 @@ __global__ __launch_bounds__(kBlock) void k_resolve(DScene S, const uint32_t *it
  * adjacent lanes, so a wave normally shares ONE footprint: its 64 contributions are summed with DPP,
  * one lane adds the wave totals to an LDS tile, and each tile pixel costs one global atomic per block. */
 __global__ __launch_bounds__(kBlock) void k_splat(DSensor C, uint32_t seed, uint32_t spp, uint32_t log_spp, uint32_t lane_base, uint32_t n,
-                                                  const float4 *result, int weights_only, float *film) {
+                                                  const float4 *result, int weights_only, float *film, const float2 *jitter) {
     __shared__ float tile[HAR_SPLAT_TILE_FLOATS];
     __shared__ int tx0, ty0, tx1, ty1;
     const uint32_t i = blockIdx.x * kBlock + threadIdx.x;
@@ -476,7 +488,9 @@ __global__ __launch_bounds__(kBlock) void k_splat(DSensor C, uint32_t seed, uint
     for (int k = 0; k < HAR_MAX_FILTER_TAPS; ++k) { F.wx[k] = 0.f; F.wy[k] = 0.f; }
     float val[4] = { 0.f, 0.f, 0.f, 1.f };
     if (act) {
-        LaneSample ls = lane_film_pos(C, seed, spp, log_spp, lane_base + i);
+        LaneSample ls;
+        if (jitter) { const float2 j = jitter[i]; ls = lane_sample(C, lane_base + i, spp, log_spp, j.x, j.y); }
+        else ls = lane_film_pos(C, seed, spp, log_spp, lane_base + i);
         film_footprint(C, ls, F);
         if (!weights_only) { float4 r = result[i]; val[0] = r.x; val[1] = r.y; val[2] = r.z; }
         atomicMin(&tx0, (int) F.x0); atomicMin(&ty0, (int) F.y0);
@@ -532,6 +546,16 @@ __global__ __launch_bounds__(kBlock) void k_splat(DSensor C, uint32_t seed, uint
                 }
             }
     }
+}
+
+/* pixel jitter of pass `pass` for paths that draw nothing else (max_depth = 0, path.cpp:102-103): numbers 2*pass, 2*pass+1 of the stream */
+__global__ void k_pass_jitter(uint32_t seed, uint32_t lane_base, uint32_t n, uint32_t pass, float2 *jitter) {
+    uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    uint64_t rng, inc; sampler_seed(seed, lane_base + i, rng, inc);
+    for (uint32_t k = 0; k < 2 * pass; ++k) rng = rng * HAR_PCG32_MULT + inc;
+    float jx = pcg32_next_float(rng, inc), jy = pcg32_next_float(rng, inc);
+    jitter[i] = make_float2(jx, jy);
 }
 
 /* --------------------------------------------------------- small utilities */
@@ -665,10 +689,10 @@ __global__ void k_api_film_put(DSensor C, uint32_t n, const float *px, const flo
 static inline uint32_t blocks_for(uint32_t n) { return (n + kBlock - 1) / kBlock; }
 
 void launch_raygen(int mode, hipStream_t s, const DSensor &C, uint32_t seed, uint32_t spp, uint32_t log_spp, uint32_t lane_base, uint32_t n,
-                   uint32_t shard_cap, const WaveState &out, float4 *result, uint32_t *count, const float *adj, float4 *dL) {
+                   uint32_t shard_cap, const WaveState &out, float4 *result, uint32_t *count, const float *adj, float4 *dL, const PassState &ps) {
     dim3 g(blocks_for(n)), b(kBlock);
-    if (mode == MODE_PRB_ADJOINT) hipLaunchKernelGGL(k_raygen<MODE_PRB_ADJOINT>, g, b, 0, s, C, seed, spp, log_spp, lane_base, n, shard_cap, out, result, count, adj, dL);
-    else hipLaunchKernelGGL(k_raygen<MODE_PATH>, g, b, 0, s, C, seed, spp, log_spp, lane_base, n, shard_cap, out, result, count, adj, dL);
+    if (mode == MODE_PRB_ADJOINT) hipLaunchKernelGGL(k_raygen<MODE_PRB_ADJOINT>, g, b, 0, s, C, seed, spp, log_spp, lane_base, n, shard_cap, out, result, count, adj, dL, ps);
+    else hipLaunchKernelGGL(k_raygen<MODE_PATH>, g, b, 0, s, C, seed, spp, log_spp, lane_base, n, shard_cap, out, result, count, adj, dL, ps);
 }
 void launch_trace_closest(hipStream_t s, uint32_t grid, int stack_class, const Accel &A, const uint32_t *count, uint32_t *cursor, uint32_t shard_cap,
                           const WaveState &in, float4 *h0, uint2 *h1, int *status) {
@@ -678,11 +702,11 @@ void launch_trace_closest(hipStream_t s, uint32_t grid, int stack_class, const A
 }
 void launch_shade(int mode, hipStream_t s, uint32_t grid, const DScene &S, const ShadeParams &P, uint32_t lane_base, uint32_t shard_cap, const uint32_t *count_in,
                   const WaveState &in, const float4 *h0, const uint2 *h1, const WaveState &out, uint32_t *count_out, const ItemArrays &items,
-                  uint32_t *item_count, float4 *result, const ReplayCache &rc) {
+                  uint32_t *item_count, float4 *result, const ReplayCache &rc, uint64_t *pass_rng) {
     dim3 g(grid), b(kBlock);
     /* diffuse-only scenes (no twosided wrappers) run kernels in which the other BSDF models are compiled out */
     const bool only_diffuse = S.bsdf_types == HAR_BSDF_ONLY_DIFFUSE;
-#define HAR_LAUNCH_SHADE(M, T) hipLaunchKernelGGL((k_shade<M, T>), g, b, 0, s, S, P, lane_base, shard_cap, count_in, in, h0, h1, out, count_out, items, item_count, result, rc)
+#define HAR_LAUNCH_SHADE(M, T) hipLaunchKernelGGL((k_shade<M, T>), g, b, 0, s, S, P, lane_base, shard_cap, count_in, in, h0, h1, out, count_out, items, item_count, result, rc, pass_rng)
     if (mode == MODE_PATH)            { if (only_diffuse) HAR_LAUNCH_SHADE(MODE_PATH, HAR_BSDF_ONLY_DIFFUSE); else HAR_LAUNCH_SHADE(MODE_PATH, HAR_BSDF_ALL_TYPES); }
     else if (mode == MODE_PRB_PRIMAL) { if (only_diffuse) HAR_LAUNCH_SHADE(MODE_PRB_PRIMAL, HAR_BSDF_ONLY_DIFFUSE); else HAR_LAUNCH_SHADE(MODE_PRB_PRIMAL, HAR_BSDF_ALL_TYPES); }
     else                              { if (only_diffuse) HAR_LAUNCH_SHADE(MODE_PRB_ADJOINT, HAR_BSDF_ONLY_DIFFUSE); else HAR_LAUNCH_SHADE(MODE_PRB_ADJOINT, HAR_BSDF_ALL_TYPES); }
@@ -706,8 +730,11 @@ void launch_resolve(int mode, hipStream_t s, uint32_t grid, int stack_class, con
     }
 }
 void launch_splat(hipStream_t s, const DSensor &C, uint32_t seed, uint32_t spp, uint32_t log_spp, uint32_t lane_base, uint32_t n,
-                  const float4 *result, int weights_only, float *film) {
-    hipLaunchKernelGGL(k_splat, dim3(blocks_for(n)), dim3(kBlock), 0, s, C, seed, spp, log_spp, lane_base, n, result, weights_only, film);
+                  const float4 *result, int weights_only, float *film, const float2 *jitter) {
+    hipLaunchKernelGGL(k_splat, dim3(blocks_for(n)), dim3(kBlock), 0, s, C, seed, spp, log_spp, lane_base, n, result, weights_only, film, jitter);
+}
+void launch_pass_jitter(hipStream_t s, uint32_t seed, uint32_t lane_base, uint32_t n, uint32_t pass, float2 *jitter) {
+    hipLaunchKernelGGL(k_pass_jitter, dim3(blocks_for(n)), dim3(kBlock), 0, s, seed, lane_base, n, pass, jitter);
 }
 void launch_develop(hipStream_t s, const float *film, uint32_t npx, float *image) {
     hipLaunchKernelGGL(k_develop, dim3(blocks_for(npx)), dim3(kBlock), 0, s, film, npx, image);

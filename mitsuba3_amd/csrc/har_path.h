@@ -47,11 +47,14 @@ struct ShadeResult {
 };
 
 /* raygen: SamplingIntegrator::render_sample up to the camera ray (integrator.cpp:448-483) */
-HAR_HD PathState raygen_lane(const DSensor &C, uint32_t seed, uint32_t spp, uint32_t log_spp, uint32_t lane, LaneSample &ls) {
+HAR_HD PathState raygen_lane(const DSensor &C, uint32_t seed, uint32_t spp, uint32_t log_spp, uint32_t lane, LaneSample &ls,
+                             const uint64_t *resume = nullptr, float *jitter = nullptr) {
     PathState st;
     uint64_t inc;
     sampler_seed(seed, lane, st.rng, inc);
+    if (resume) st.rng = *resume;                 /* pass > 0 of a multi-pass render: the stream continues (integrator.cpp:349-356) */
     float jx = pcg32_next_float(st.rng, inc), jy = pcg32_next_float(st.rng, inc);
+    if (jitter) { jitter[0] = jx; jitter[1] = jy; }
     ls = lane_sample(C, lane, spp, log_spp, jx, jy);
     lane_camera_ray(C, ls, st.o, st.d, st.maxt);
     st.throughput = Vec3(1.f); st.lane = lane; st.prev_p = Vec3(0.f); st.prev_bsdf_pdf = 1.f; st.flags = 1u << 16; st.eta = 1.f;

@@ -39,7 +39,8 @@ def render_distributed(scene, integrator=None, sensor=0, seed=0, spp=0, develop=
     spp = s.sampler().sample_count()
     w, h = s.film().crop_size()
     rank, world = _world()
-    lanes = lane_range(w * h * spp, rank, world, granule=w * spp)
+    spp_pass, _ = integrator.pass_layout(s, spp)          # multi-pass jobs (> 2^32 - 1 samples): bands of the per-pass wavefront
+    lanes = lane_range(w * h * spp_pass, rank, world, granule=w * spp_pass)
     film = integrator.render_film(scene, s, seed, spp, lanes=lanes)
     if world > 1:
         dist.reduce(film, dst=dst, op=dist.ReduceOp.SUM)      # the single RCCL collective

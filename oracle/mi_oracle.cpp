@@ -598,7 +598,12 @@ static V3 path_sample(const Scene &sc, Pcg32 &rng, Ray ray, uint32_t max_depth, 
         }
         bool active_next = (depth + 1 < max_depth) && si.valid();
         valid_ray |= si.valid();                              // path.cpp:307-308 (JIT: evaluated every iteration)
-        if (!active_next) break;                              // masked lane: state below is discarded
+        if (!active_next) {
+            /* JIT: the lane still executes the rest of this iteration masked; its (unmasked) sampler draws advance the stream by 6,
+               which only matters when a later pass continues it (integrator.cpp:349-356).  Scalar: `break` at path.cpp:226-227. */
+            if (!scalar) for (int k = 0; k < 6; ++k) rng.next_uint32();
+            break;
+        }
         BsdfCtx bsdf = bsdf_prepare(sc, sc.meshes[si.mesh].bsdf, si);          // si.bsdf(ray), path.cpp:232
         // emitter sampling, path.cpp:236-258: the samples are drawn by every lane, used where the BSDF is Smooth
         bool active_em = bsdf.rec->smooth();
@@ -786,6 +791,43 @@ static int render_forward(Scene &sc, const OrcSensor &s, uint32_t seed, uint32_t
     return 0;
 }
 
+/* SamplingIntegrator::render, JIT branch with several passes (integrator.cpp:173-183,276-356): n_passes wavefronts of W*H*spp_per_pass
+ * lanes; lane i keeps its pixel and its sampler (seeded once, `sampler->advance()` does not reseed), the block accumulates all passes. */
+static int render_forward_passes(Scene &sc, const OrcSensor &s, uint32_t seed, uint32_t spp, uint32_t spp_per_pass, int32_t max_depth, int32_t rr_depth,
+                                 uint64_t lb, uint64_t le, float *film, OrcStats *stats, int threads) {
+    if (spp_per_pass == 0 || spp % spp_per_pass != 0) return -2;               // integrator.cpp:177-179
+    uint64_t total = (uint64_t) s.crop_width * s.crop_height * spp_per_pass;
+    if (lb == 0 && le == 0) le = total;
+    if (le > total || lb > le || total > 0xffffffffull) return -1;
+    const uint32_t n_passes = spp / spp_per_pass;
+    RFilter rf = make_rfilter(s.rfilter, s.rfilter_stddev);
+    threads = resolve_threads(threads);
+    size_t fsz = (size_t) s.crop_width * s.crop_height * 4;
+    std::vector<std::vector<float>> films(threads);
+    std::vector<OrcStats> sts(threads, OrcStats{});
+    uint32_t md = max_depth < 0 ? 0xffffffffu : (uint32_t) max_depth, rd = (uint32_t) rr_depth;
+    parallel_lanes(lb, le, threads, [&](int t, uint64_t b, uint64_t e) {
+        if (films[t].empty()) films[t].assign(fsz, 0.f);
+        for (uint64_t i = b; i < e; ++i) {
+            Lane L = make_lane(s, seed, spp_per_pass, i);                      // pass 0: seeded, jitter drawn
+            for (uint32_t pass = 0; pass < n_passes; ++pass) {
+                if (pass) {                                                    // render_sample again with the SAME `pos`, stream continues
+                    float jx = L.rng.next_float32(), jy = L.rng.next_float32();
+                    L.pos_x = L.ipos_x + jx; L.pos_y = L.ipos_y + jy;
+                    float sx = 1.f / (float) s.crop_width, sy = 1.f / (float) s.crop_height;
+                    L.ray = sensor_sample_ray(s, fmadd(L.pos_x, sx, -(float) s.crop_offset_x * sx), fmadd(L.pos_y, sy, -(float) s.crop_offset_y * sy));
+                }
+                bool valid; V3 rgb = path_sample(sc, L.rng, L.ray, md, rd, valid, sts[t]);
+                sts[t].paths++;
+                float v[4] = { rgb.x, rgb.y, rgb.z, 1.f };
+                film_put(s, rf, rf.type == 0 ? L.ipos_x : L.pos_x, rf.type == 0 ? L.ipos_y : L.pos_y, v, films[t].data());
+            }
+        }
+    });
+    for (auto &f : films) if (!f.empty()) for (size_t i = 0; i < fsz; ++i) film[i] += f[i];
+    merge_stats(stats, sts);
+    return 0;
+}
 
 // ---------------------------------------------------------------------------
 //  Scalar-variant driver (BASELINE config 1, `scalar_rgb`): SamplingIntegrator::render, CPU branch
@@ -1016,6 +1058,10 @@ void orc_ray_test(void *scene, uint32_t n, const float *o, const float *d, const
 int orc_render_path(void *scene, const OrcSensor *s, uint32_t seed, uint32_t spp, int32_t max_depth, int32_t rr_depth,
                     uint64_t lb, uint64_t le, float *film, OrcStats *stats, int threads) {
     return render_forward(*(Scene *) scene, *s, seed, spp, max_depth, rr_depth, lb, le, film, stats, threads, false);
+}
+int orc_render_path_passes(void *scene, const OrcSensor *s, uint32_t seed, uint32_t spp, uint32_t spp_per_pass, int32_t max_depth, int32_t rr_depth,
+                           uint64_t lb, uint64_t le, float *film, OrcStats *stats, int threads) {
+    return render_forward_passes(*(Scene *) scene, *s, seed, spp, spp_per_pass, max_depth, rr_depth, lb, le, film, stats, threads);
 }
 int orc_render_prb(void *scene, const OrcSensor *s, uint32_t seed, uint32_t spp, int32_t max_depth, int32_t rr_depth,
                    uint64_t lb, uint64_t le, float *film, OrcStats *stats, int threads) {

@@ -116,6 +116,11 @@ void  orc_scene_destroy(void *scene);
 void  orc_scene_set_reflectance(void *scene, uint32_t bsdf, const float rgb[3]);
 void  orc_scene_set_texture(void *scene, uint32_t texture, const float *data);
 
+/* ---- multi-pass JIT render (integrator.cpp:173-183,276-356): spp / spp_per_pass wavefronts of W*H*spp_per_pass lanes whose
+ *      sampler streams continue across passes; [lane_begin, lane_end) index the per-pass wavefront ---- */
+int   orc_render_path_passes(void *scene, const OrcSensor *sensor, uint32_t seed, uint32_t spp, uint32_t spp_per_pass, int32_t max_depth,
+                             int32_t rr_depth, uint64_t lane_begin, uint64_t lane_end, float *film, OrcStats *stats, int threads);
+
 /* ---- scalar-variant driver (BASELINE config 1, `scalar_rgb`): SamplingIntegrator::render CPU branch
  *      (integrator.cpp:190-274,398-446), Spiral (spiral.cpp:27-73), ImageBlock::put with the discretised filter.
  *      n_threads = pool_size() + 1 of the emulated run (it decides the block size, integrator.cpp:203-214). ---- */

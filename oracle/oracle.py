@@ -93,6 +93,12 @@ def lib():
             fn.restype = C.c_int
             fn.argtypes = [C.c_void_p, C.POINTER(Sensor), C.c_uint32, C.c_uint32, C.c_int32, C.c_int32,
                            C.c_uint64, C.c_uint64, c_f32p, C.POINTER(Stats), C.c_int]
+        L.orc_render_path_passes.restype = C.c_int
+        L.orc_render_path_passes.argtypes = [C.c_void_p, C.POINTER(Sensor), C.c_uint32, C.c_uint32, C.c_uint32, C.c_int32, C.c_int32,
+                                             C.c_uint64, C.c_uint64, c_f32p, C.POINTER(Stats), C.c_int]
+        L.orc_render_path_scalar.restype = C.c_int
+        L.orc_render_path_scalar.argtypes = [C.c_void_p, C.POINTER(Sensor), C.c_uint32, C.c_uint32, C.c_int32, C.c_int32, C.c_uint32,
+                                             c_f32p, C.POINTER(Stats), c_u32p]
         L.orc_render_prb_backward.restype = C.c_int
         L.orc_render_prb_backward.argtypes = [C.c_void_p, C.POINTER(Sensor), c_f32p, C.c_uint32, C.c_uint32,
                                               C.c_int32, C.c_int32, c_f32p, C.POINTER(c_f32p),
@@ -359,11 +365,19 @@ class OracleScene:
         film, st = self._render(lib().orc_render_path, sensor, seed, spp, max_depth, rr_depth, lanes, threads)
         return (film if raw else develop(film)), st
 
+    def render_path_passes(self, sensor, seed=0, spp=4, spp_per_pass=2, max_depth=8, rr_depth=5, lanes=None, threads=0, raw=False):
+        """multi-pass JIT render: `lanes` index the per-pass wavefront of W*H*spp_per_pass lanes"""
+        film = np.zeros((sensor.crop_height, sensor.crop_width, 4), np.float32)
+        st = Stats(); lb, le = lanes if lanes else (0, 0)
+        rc = lib().orc_render_path_passes(self.handle, C.byref(sensor), seed, spp, spp_per_pass, max_depth, rr_depth, lb, le, fp(film), C.byref(st), threads)
+        assert rc == 0, rc
+        return (film if raw else develop(film)), st
+
     def render_path_scalar(self, sensor, seed=0, spp=4, max_depth=8, rr_depth=5, n_threads=1, raw=False):
         """`scalar_rgb` driver (spiral blocks, Morton order, per-pixel reseed, discretised filter): BASELINE config 1"""
         film = np.zeros((sensor.crop_height, sensor.crop_width, 4), np.float32)
         st = Stats(); bs = C.c_uint32()
-        rc = lib().orc_render_path_scalar(self.handle, C.byref(sensor), seed, spp, max_depth, rr_depth, n_threads, fp(film), C.byref(st), C.byref(bs))
+        rc = lib().orc_render_path_scalar(self.handle, C.byref(sensor), seed, spp, max_depth, rr_depth, n_threads, fp(film), C.byref(st), C.cast(C.byref(bs), c_u32p))
         assert rc == 0
         return (film if raw else develop(film)), st, bs.value
 

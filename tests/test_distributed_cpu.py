@@ -23,10 +23,15 @@ from oracle import oracle as O
 
 class OracleIntegrator:
     """Test double with Integrator.render_film's signature; renders a lane band with the oracle."""
-    def __init__(self, osc, sensor):
-        self.osc, self.sensor = osc, sensor
+    def __init__(self, osc, sensor, samples_per_pass=None):
+        self.osc, self.sensor, self.per_pass = osc, sensor, samples_per_pass
+    def pass_layout(self, sensor, spp=0):
+        return (self.per_pass, spp // self.per_pass) if self.per_pass else (spp, 1)
     def render_film(self, scene, sensor=0, seed=0, spp=0, lanes=None, film=None):
-        raw, _ = self.osc.render_path(self.sensor, seed=seed, spp=spp, max_depth=8, lanes=lanes, raw=True)
+        if self.per_pass:
+            raw, _ = self.osc.render_path_passes(self.sensor, seed=seed, spp=spp, spp_per_pass=self.per_pass, max_depth=8, lanes=lanes, raw=True)
+        else:
+            raw, _ = self.osc.render_path(self.sensor, seed=seed, spp=spp, max_depth=8, lanes=lanes, raw=True)
         return torch.from_numpy(raw)
 
 dist.init_process_group(backend="gloo", rank=int(os.environ["RANK"]), world_size=int(os.environ["WORLD_SIZE"]))
@@ -47,7 +52,13 @@ if rank == 0:
     assert err < 1e-6, err
     # the weight channel is exactly the sum of the bands' weights: every lane rendered once
     assert abs(got[..., 3].sum() - whole[..., 3].sum()) / whole[..., 3].sum() < 1e-6
-    print("DIST_OK", err)
+# multi-pass job (the C5 shape of SURVEY.md 8e at test size): ranks own bands of the PER-PASS wavefront and run every pass on them
+film = mi.render_distributed(scene, integrator=OracleIntegrator(osc, osensor, samples_per_pass=2), seed=3, spp=8, develop=False)
+if rank == 0:
+    whole, _ = osc.render_path_passes(osensor, seed=3, spp=8, spp_per_pass=2, max_depth=8, raw=True)
+    err2 = np.abs(film.numpy() - whole).max() / np.abs(whole).max()
+    assert err2 < 1e-6, err2
+    print("DIST_OK", err, err2)
 dist.barrier()
 dist.destroy_process_group()
 '''

@@ -312,11 +312,53 @@ def test_single_pixel_film_and_odd_spp(mi, O):
 
 
 def test_render_refuses_more_than_2_32_lanes(mi):
-    """integrator.cpp:276-294 / common.py:358-363: the wavefront index is 32 bit."""
+    """integrator.cpp:276-294: a `path` job of 2^34 samples is split into passes of 1024 / 5 = 204 samples, which the sampler
+    refuses (1024 % 204 != 0, sampler.cpp:93-94); common.py:358-363: the AD integrators refuse outright."""
     d = mi.cornell_box(); d["sensor"]["film"]["width"] = 4096; d["sensor"]["film"]["height"] = 4096
     scene = mi.load_dict(d)
-    with pytest.raises(Exception, match="2\\^32"):
+    with pytest.raises(Exception, match="multiple of samples_per_wavefront"):
         mi.render(scene, spp=1024)
+    with pytest.raises(Exception, match="2\\^32"):
+        mi.render(scene, integrator=mi.load_dict({"type": "prb", "max_depth": 6}), spp=1024)
+    assert mi.load_dict({"type": "path", "max_depth": 8, "samples_per_pass": 128}).pass_layout(scene.sensors()[0], 1024) == (128, 8)
+
+
+def test_multipass_render_parity(mi, O):
+    """Multi-pass `path` render (integrator.cpp:173-183,276-356; SURVEY 8e: C5 runs as 8 passes of 128 spp): every lane keeps
+    its pixel and continues its sampler stream from pass to pass.  Compared with the oracle's multi-pass driver, with chunks
+    smaller than a pass, lane bands, max_depth 0 and the box filter."""
+    import torch
+    scene, osc, sensor = cbox(mi, O, 48)
+    for spp, per_pass, chunk in ((16, 4, 0), (12, 3, 4096), (8, 8, 0)):
+        integ = mi.load_dict({"type": "path", "max_depth": 8, "samples_per_pass": per_pass, "chunk_lanes": chunk})
+        img = mi.render(scene, integrator=integ, spp=spp, seed=2).cpu().numpy()
+        ref, st = osc.render_path_passes(sensor, seed=2, spp=spp, spp_per_pass=per_pass, max_depth=8)
+        assert rel_l2(img, ref) < 1e-4, (spp, per_pass, chunk)
+        gst = integ.stats()
+        assert gst["paths"] == st.paths and gst["vertices"] == st.vertices
+    single, _ = osc.render_path(sensor, seed=2, spp=16, max_depth=8)
+    multi = mi.render(scene, integrator=mi.load_dict({"type": "path", "max_depth": 8, "samples_per_pass": 4}), spp=16, seed=2).cpu().numpy()
+    assert rel_l2(multi, single) > 1e-2                                   # not the same samples as one wavefront of 16 spp
+    # lane bands of the per-pass wavefront (what each rank of render_distributed renders)
+    integ = mi.load_dict({"type": "path", "max_depth": 8, "samples_per_pass": 4})
+    n = 48 * 48 * 4
+    whole = integ.render_film(scene, 0, 2, 16)
+    film = None
+    for lo, hi in ((0, 20 * 48 * 4), (20 * 48 * 4, 20 * 48 * 4 + 501), (20 * 48 * 4 + 501, n)):
+        film = integ.render_film(scene, 0, 2, 16, lanes=(lo, hi), film=film)
+    torch.cuda.synchronize()
+    assert rel_l2(film.cpu().numpy(), whole.cpu().numpy()) < 1e-6
+    # max_depth = 0: only the weight channel, jitter = numbers 2p, 2p+1 of each stream
+    integ0 = mi.load_dict({"type": "path", "max_depth": 0, "samples_per_pass": 2})
+    f0 = integ0.render_film(scene, 0, 7, 6).cpu().numpy()
+    r0, _ = osc.render_path_passes(sensor, seed=7, spp=6, spp_per_pass=2, max_depth=0, raw=True)
+    assert rel_l2(f0, r0) < 1e-5
+    # box filter + crop window
+    scene, osc, sensor = cbox(mi, O, 64, crop=(8, 16, 40, 24), rfilter="box")
+    integ = mi.load_dict({"type": "path", "max_depth": 5, "samples_per_pass": 2})
+    img = mi.render(scene, integrator=integ, spp=8, seed=4).cpu().numpy()
+    ref, _ = osc.render_path_passes(sensor, seed=4, spp=8, spp_per_pass=2, max_depth=5)
+    assert rel_l2(img, ref) < 1e-4
 
 
 # ---------------------------------------------------------------- BSDF plugins beyond diffuse (SURVEY.md 8f rank 1)

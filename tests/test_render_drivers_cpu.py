@@ -56,3 +56,55 @@ def test_scalar_directly_visible_emitter_kat(O):
     sd, sensor = O.cornell_box(256, 256, crop=(124, 36, 1, 1))
     img, _, _ = O.OracleScene(sd).render_path_scalar(sensor, spp=64, max_depth=1)
     assert np.allclose(img.reshape(3), [18.387, 13.9873, 6.75357], rtol=1e-5)
+
+
+def test_multipass_oracle(O):
+    """JIT multi-pass render (integrator.cpp:173-183,276-356): lane i keeps its pixel and its sampler stream across passes"""
+    res = 16
+    sd, sensor = O.cornell_box(res, res)
+    osc = O.OracleScene(sd)
+    one, _ = osc.render_path(sensor, seed=5, spp=2, max_depth=6, raw=True)
+    same, _ = osc.render_path_passes(sensor, seed=5, spp=2, spp_per_pass=2, max_depth=6, raw=True)
+    assert np.array_equal(one, same)                                   # a single pass is the plain render
+    multi, st = osc.render_path_passes(sensor, seed=5, spp=8, spp_per_pass=2, max_depth=6, raw=True)
+    assert st.paths == res * res * 8
+    assert abs(multi[..., 3].sum() / one[..., 3].sum() - 4) < 1e-3      # four passes of the same wavefront size
+    assert np.abs(multi - 4 * one).max() > 1e-2                          # ... with fresh random numbers
+    # union of two lane bands of the per-pass wavefront == whole job
+    n = res * res * 2
+    a, _ = osc.render_path_passes(sensor, seed=5, spp=8, spp_per_pass=2, max_depth=6, lanes=(0, n // 2), raw=True)
+    b, _ = osc.render_path_passes(sensor, seed=5, spp=8, spp_per_pass=2, max_depth=6, lanes=(n // 2, n), raw=True)
+    assert np.abs(a + b - multi).max() <= 1e-5 * np.abs(multi).max()
+    # same estimator as one big wavefront
+    big, _ = osc.render_path(sensor, seed=5, spp=1024, max_depth=6)
+    mp, _ = osc.render_path_passes(sensor, seed=5, spp=1024, spp_per_pass=16, max_depth=6)
+    assert abs(mp.mean() / big.mean() - 1) < 0.03                        # (image-mean noise at this size: ~1 %)
+
+
+def test_pass_layout_host():
+    """har_render_pass_layout mirrors integrator.cpp:173-183,276-294 incl. the reference's C5 quirk"""
+    import ctypes as C
+    from mitsuba3_amd import _capi
+    L = _capi.lib()
+    sensor = _capi.HarSensor(); sensor.crop_width = 4096; sensor.crop_height = 4096
+    h = C.c_void_p(); _capi.check(L.har_integrator_create(0, 8, 5, 0, C.byref(h)))
+    a, b = C.c_uint32(), C.c_uint32()
+    # 4096^2 x 1024 = 2^34 lanes: 1024 / ceil(2^34 / (2^32 - 1)) = 204 samples per pass, which does not divide 1024 -> the reference throws
+    assert L.har_render_pass_layout(h, C.byref(sensor), 1024, C.byref(a), C.byref(b)) != 0
+    assert b"multiple" in L.har_last_error()
+    _capi.check(L.har_integrator_set_samples_per_pass(h, 128))
+    _capi.check(L.har_render_pass_layout(h, C.byref(sensor), 1024, C.byref(a), C.byref(b)))
+    assert (a.value, b.value) == (128, 8)
+    _capi.check(L.har_integrator_set_samples_per_pass(h, 256))       # 2^32 lanes > 2^32 - 1: halved again
+    _capi.check(L.har_render_pass_layout(h, C.byref(sensor), 1024, C.byref(a), C.byref(b)))
+    assert (a.value, b.value) == (128, 8)
+    _capi.check(L.har_integrator_set_samples_per_pass(h, 48))
+    assert L.har_render_pass_layout(h, C.byref(sensor), 1024, C.byref(a), C.byref(b)) != 0      # integrator.cpp:177-179
+    sensor.crop_width = sensor.crop_height = 512
+    _capi.check(L.har_integrator_set_samples_per_pass(h, 0))
+    _capi.check(L.har_render_pass_layout(h, C.byref(sensor), 256, C.byref(a), C.byref(b)))
+    assert (a.value, b.value) == (256, 1)
+    L.har_integrator_destroy(h)
+    hp = C.c_void_p(); _capi.check(L.har_integrator_create(1, 6, 5, 0, C.byref(hp)))
+    assert L.har_integrator_set_samples_per_pass(hp, 4) != 0         # AD integrators render one wavefront (common.py:358-363)
+    L.har_integrator_destroy(hp)

@@ -22,8 +22,26 @@ def timed(fn, steps=2, warmup=1):
     return (time.perf_counter() - t0) / steps
 
 
+def c5():
+    """config 5 on ONE GPU: Cornell 4096x4096x1024 spp = 2^34 paths as 8 passes of 128 spp (with N ranks each renders
+    1/N of the per-pass wavefront and the films are summed by one RCCL reduce).  16 GiB of sampler state lives across the passes."""
+    d = mi.cornell_box(); d["sensor"]["film"]["width"] = 4096; d["sensor"]["film"]["height"] = 4096
+    d["integrator"] = {"type": "path", "max_depth": 8, "samples_per_pass": 128}
+    scene = mi.load_dict(d)
+    mi.render(scene, spp=128, seed=0)                 # warm-up: one pass
+    torch.cuda.synchronize(); t0 = time.perf_counter()
+    img = mi.render(scene, spp=1024, seed=0)
+    torch.cuda.synchronize(); dt = time.perf_counter() - t0
+    st = scene.integrator().stats()
+    print(json.dumps({"config": "C5 cornell path 4096x4096x1024spp, 8 passes of 128 spp, 1 GPU", "seconds": dt, "Mpaths_per_s": 2.0 ** 34 / dt / 1e6,
+                      "paths": int(st["paths"]), "image_mean": float(img.mean()), "finite": bool(torch.isfinite(img).all()),
+                      "peak_mem_GiB": torch.cuda.max_memory_allocated() / 2 ** 30}))
+
+
 def main():
     mi.set_variant("hip_ad_rgb")
+    if "--c5" in sys.argv:
+        return c5()
     out = []
     # config 2: Cornell box, path, 512x512x256 spp
     d = mi.cornell_box(); d["sensor"]["film"]["width"] = 512; d["sensor"]["film"]["height"] = 512
