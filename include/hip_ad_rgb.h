@@ -293,10 +293,17 @@ int har_mesh_transform(const float to_world[32], uint32_t vertex_count, float *v
  *  Mesh files (host side).  PLYMesh ctor (src/shapes/ply.cpp:113-345): ASCII / binary little- / big-endian PLY with
  *  triangle faces -> packed records (8 f32 per vertex, 4 u32 per face, mesh_utils.h:19-34) allocated with malloc;
  *  flags bit0 = has vertex normals (stored or regenerated unless face_normals), bit1 = has texcoords.
+ *  Like the reference's loaders (PackedMesh::set_transform, src/render/mesh_utils.cpp:33-44,101-133) they bake `to_world`
+ *  (har_transform_* layout: matrix + inverse, NULL = identity) and `flip_normals` into the records BEFORE normals are regenerated.
  *  har_mesh_compute_normals = Mesh::compute_normals (src/render/mesh.cpp:1218-1267), in place.
  * ---------------------------------------------------------------------- */
 typedef struct HarMeshData { float *vertices; uint32_t *faces; uint32_t vertex_count, face_count, flags, reserved; } HarMeshData;
-int  har_mesh_load_ply(const char *filename, int face_normals, int flip_tex_coords, HarMeshData *out);
+int  har_mesh_load_ply(const char *filename, int face_normals, int flip_tex_coords, const float *to_world /*[32] or NULL*/, int flip_normals, HarMeshData *out);
+/* OBJMesh ctor (src/shapes/obj.cpp:98-296) + Mesh::from_corners (src/render/mesh_utils.cpp:210-560): polygons are fan-triangulated,
+ * corners of a point weld when normal / texcoord / UV-orientation agree; missing normals are regenerated per surface point */
+int  har_mesh_load_obj(const char *filename, int face_normals, int flip_tex_coords, const float *to_world, int flip_normals, HarMeshData *out);
+/* SerializedMesh ctor + load_legacy (src/shapes/serialized.cpp:225-370): container versions 3 and 4, sub-mesh `shape_index` */
+int  har_mesh_load_serialized(const char *filename, int shape_index, int face_normals, const float *to_world, int flip_normals, HarMeshData *out);
 int  har_mesh_compute_normals(uint32_t vertex_count, float *vertices, uint32_t face_count, const uint32_t *faces);
 void har_mesh_free(HarMeshData *mesh);
 

@@ -93,7 +93,9 @@ SIGNATURES = {
     "har_image_write_exr": (C.c_int, [C.c_char_p, vp, C.c_uint32, C.c_uint32, C.c_uint32]),
     "har_image_write_pfm": (C.c_int, [C.c_char_p, vp, C.c_uint32, C.c_uint32, C.c_uint32]),
     "har_integrator_set_replay_cache": (C.c_int, [vp, C.c_int]),
-    "har_mesh_load_ply": (C.c_int, [C.c_char_p, C.c_int, C.c_int, vp]),
+    "har_mesh_load_ply": (C.c_int, [C.c_char_p, C.c_int, C.c_int, f32p, C.c_int, vp]),
+    "har_mesh_load_obj": (C.c_int, [C.c_char_p, C.c_int, C.c_int, f32p, C.c_int, vp]),
+    "har_mesh_load_serialized": (C.c_int, [C.c_char_p, C.c_int, C.c_int, f32p, C.c_int, vp]),
     "har_mesh_compute_normals": (C.c_int, [C.c_uint32, vp, C.c_uint32, vp]),
     "har_mesh_free": (None, [vp]),
     "har_bsdf_sample_ex": (C.c_int, [vp, C.c_uint32, C.c_uint32, vp, vp, vp, vp, vp, vp, vp, vp, vp]),

@@ -224,10 +224,7 @@ class Mesh:
         self.V, self.F, self.flags = V, F, flags
         return self
 
-    def from_ply(self, filename, face_normals=False, flip_tex_coords=False):
-        """PLYMesh (src/shapes/ply.cpp): parsed by the C++ host library into the packed layout."""
-        md = _capi.HarMeshData()
-        check(lib().har_mesh_load_ply(str(filename).encode(), 1 if face_normals else 0, 1 if flip_tex_coords else 0, C.byref(md)))
+    def _adopt(self, md):
         try:
             nv, nf = md.vertex_count, md.face_count
             self.V = np.ctypeslib.as_array(md.vertices, shape=(max(nv, 1), 8))[:nv].copy() if nv else np.zeros((0, 8), np.float32)
@@ -236,6 +233,29 @@ class Mesh:
         finally:
             lib().har_mesh_free(C.byref(md))
         return self
+
+    @staticmethod
+    def _tw(to_world):
+        return _fp(to_world.data) if to_world is not None else None
+
+    def from_ply(self, filename, face_normals=False, flip_tex_coords=False, to_world=None, flip_normals=False):
+        """PLYMesh (src/shapes/ply.cpp): parsed by the C++ host library into the packed layout; `to_world` / `flip_normals` are
+        baked before missing normals are regenerated, as PackedMesh::set_transform does (mesh_utils.cpp:33-44)."""
+        md = _capi.HarMeshData()
+        check(lib().har_mesh_load_ply(str(filename).encode(), int(bool(face_normals)), int(bool(flip_tex_coords)), self._tw(to_world), int(bool(flip_normals)), C.byref(md)))
+        return self._adopt(md)
+
+    def from_obj(self, filename, face_normals=False, flip_tex_coords=True, to_world=None, flip_normals=False):
+        """OBJMesh (src/shapes/obj.cpp) + Mesh::from_corners (mesh_utils.cpp:210-560)"""
+        md = _capi.HarMeshData()
+        check(lib().har_mesh_load_obj(str(filename).encode(), int(bool(face_normals)), int(bool(flip_tex_coords)), self._tw(to_world), int(bool(flip_normals)), C.byref(md)))
+        return self._adopt(md)
+
+    def from_serialized(self, filename, shape_index=0, face_normals=False, to_world=None, flip_normals=False):
+        """SerializedMesh (src/shapes/serialized.cpp), container versions 3 and 4"""
+        md = _capi.HarMeshData()
+        check(lib().har_mesh_load_serialized(str(filename).encode(), int(shape_index), int(bool(face_normals)), self._tw(to_world), int(bool(flip_normals)), C.byref(md)))
+        return self._adopt(md)
 
     def recompute_vertex_normals(self):
         """Mesh::compute_normals (src/render/mesh.cpp:1218-1267)"""
@@ -1109,11 +1129,24 @@ def _mk_instance(props, named, key):
 def _mk_ply(props, named, key):
     if 'filename' not in props:
         raise RuntimeError("ply: the `filename` parameter is required")
-    m = Mesh(key or "ply").from_ply(props['filename'], props.get('face_normals', False), props.get('flip_tex_coords', False))
-    if props.get('flip_normals', False):        # Mesh::pack(flip_normals): reversed winding + negated normals (mesh.cpp:625-663)
-        m.F[:, [0, 2]] = m.F[:, [2, 0]]; m.V[:, 3:6] *= -1
-    if 'to_world' in props:
-        m.transform(props['to_world'])
+    m = Mesh(key or "ply").from_ply(props['filename'], props.get('face_normals', False), props.get('flip_tex_coords', False),
+                                    props.get('to_world'), props.get('flip_normals', False))
+    return _shape_common(m, props, named)
+
+
+def _mk_obj(props, named, key):
+    if 'filename' not in props:
+        raise RuntimeError("obj: the `filename` parameter is required")
+    m = Mesh(key or "obj").from_obj(props['filename'], props.get('face_normals', False), props.get('flip_tex_coords', True),
+                                    props.get('to_world'), props.get('flip_normals', False))
+    return _shape_common(m, props, named)
+
+
+def _mk_serialized(props, named, key):
+    if 'filename' not in props:
+        raise RuntimeError("serialized: the `filename` parameter is required")
+    m = Mesh(key or "serialized").from_serialized(props['filename'], props.get('shape_index', 0), props.get('face_normals', False),
+                                                  props.get('to_world'), props.get('flip_normals', False))
     return _shape_common(m, props, named)
 
 
@@ -1135,7 +1168,7 @@ for _name, _fn in {
     'roughplastic': lambda p, n, k: BSDF(p, id=k), 'twosided': _mk_twosided, 'constant': lambda p, n, k: ConstantEmitter(p),
     'rectangle': lambda p, n, k: _shape_common(_rectangle(p), p, n),
     'cube': lambda p, n, k: _shape_common(_cube(p), p, n),
-    'mesh': _mk_mesh, 'ply': _mk_ply,
+    'mesh': _mk_mesh, 'ply': _mk_ply, 'obj': _mk_obj, 'serialized': _mk_serialized,
     'shapegroup': _mk_shapegroup,
     'instance': _mk_instance,
     'gaussian': lambda p, n, k: p, 'box': lambda p, n, k: p, 'rgb': lambda p, n, k: p, 'bitmap': lambda p, n, k: p, 'area': lambda p, n, k: p,

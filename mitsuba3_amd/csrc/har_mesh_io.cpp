@@ -76,6 +76,7 @@ float unit_angle(Vec3 a, Vec3 b) {
 extern "C" {
 
 int har_mesh_compute_normals(uint32_t vertex_count, float *vertices, uint32_t face_count, const uint32_t *faces) {
+    if (vertex_count == 0 && face_count == 0) return 0;
     if (!vertices || (!faces && face_count)) return har_set_error("null mesh buffers");
     std::vector<float> acc(3 * (size_t) vertex_count, 0.f);
     for (uint32_t f = 0; f < face_count; ++f) {
@@ -107,7 +108,63 @@ void har_mesh_free(HarMeshData *m) {
     m->vertices = nullptr; m->faces = nullptr; m->vertex_count = m->face_count = 0;
 }
 
-int har_mesh_load_ply(const char *filename, int face_normals, int flip_tex_coords, HarMeshData *out) {
+} // extern "C"
+
+/* What the reference does between parsing a mesh file and Mesh::from_packed (PackedMesh::set_transform / set_vertex,
+ * src/render/mesh_utils.cpp:33-44,101-133): positions take `to_world`, stored normals its inverse transpose and are normalised
+ * (left alone when their length is 0 / not finite) and negated under `flip_normals`, the winding is reversed when
+ * det(to_world) < 0 XOR flip_normals; normals missing from the file are regenerated AFTERWARDS, from the transformed positions
+ * and the final winding (Mesh::pack, mesh.cpp:573-582,618-619), one per surface point when `position_index` splits vertices. */
+int har_mesh_finalize(std::vector<float> &V, std::vector<uint32_t> &F, bool stored_normals, bool regenerate, const float *to_world32,
+                      bool flip_normals, const std::vector<uint32_t> *position_index, uint32_t position_count) {
+    const size_t nv = V.size() / 8, nf = F.size() / 4;
+    float m[3][4] = { { 1, 0, 0, 0 }, { 0, 1, 0, 0 }, { 0, 0, 1, 0 } }, it[3][3] = { { 1, 0, 0 }, { 0, 1, 0 }, { 0, 0, 1 } };
+    bool transform = false;
+    if (to_world32) {            /* har_transform_* layout: matrix (row major 4 x 4) followed by its inverse transpose */
+        for (int r = 0; r < 3; ++r) for (int c = 0; c < 4; ++c) { m[r][c] = to_world32[4 * r + c]; transform |= m[r][c] != (r == c ? 1.f : 0.f); }
+        for (int r = 0; r < 3; ++r) for (int c = 0; c < 3; ++c) it[r][c] = to_world32[16 + 4 * r + c];
+    }
+    const float det = m[0][0] * (m[1][1] * m[2][2] - m[1][2] * m[2][1]) - m[0][1] * (m[1][0] * m[2][2] - m[1][2] * m[2][0]) +
+                      m[0][2] * (m[1][0] * m[2][1] - m[1][1] * m[2][0]);
+    for (size_t i = 0; i < nv; ++i) {
+        float *r = V.data() + 8 * i;
+        if (transform) {         /* same operation order as Transform4f::point / ::normal in har_host.cpp */
+            Vec3 p(r[0], r[1], r[2]), q(m[0][3], m[1][3], m[2][3]);
+            q = Vec3(fma_(m[0][0], p.x, q.x), fma_(m[1][0], p.x, q.y), fma_(m[2][0], p.x, q.z));
+            q = Vec3(fma_(m[0][1], p.y, q.x), fma_(m[1][1], p.y, q.y), fma_(m[2][1], p.y, q.z));
+            q = Vec3(fma_(m[0][2], p.z, q.x), fma_(m[1][2], p.z, q.y), fma_(m[2][2], p.z, q.z));
+            r[0] = q.x; r[1] = q.y; r[2] = q.z;
+        }
+        if (stored_normals) {
+            Vec3 n(r[3], r[4], r[5]);
+            if (transform) {
+                Vec3 q(it[0][0] * n.x, it[1][0] * n.x, it[2][0] * n.x);
+                q = Vec3(fma_(it[0][1], n.y, q.x), fma_(it[1][1], n.y, q.y), fma_(it[2][1], n.y, q.z));
+                n = Vec3(fma_(it[0][2], n.z, q.x), fma_(it[1][2], n.z, q.y), fma_(it[2][2], n.z, q.z));
+            }
+            float il = rsqrt_(dot3(n, n));
+            if (finite_(il)) n = n * il;
+            if (flip_normals) n = Vec3(-n.x, -n.y, -n.z);
+            r[3] = n.x; r[4] = n.y; r[5] = n.z;
+        }
+    }
+    if ((det < 0.f) != flip_normals)
+        for (size_t f = 0; f < nf; ++f) std::swap(F[4 * f], F[4 * f + 2]);
+    if (regenerate) {
+        if (position_index && position_count != nv) {
+            std::vector<float> P(8 * (size_t) position_count, 0.f); std::vector<uint32_t> G(F.size(), 0u);
+            for (size_t v = 0; v < nv; ++v) memcpy(P.data() + 8 * (size_t) (*position_index)[v], V.data() + 8 * v, 12);
+            for (size_t i = 0; i < F.size(); ++i) if ((i & 3) != 3) G[i] = (*position_index)[F[i]];
+            if (har_mesh_compute_normals(position_count, P.data(), (uint32_t) nf, G.data())) return 1;
+            for (size_t v = 0; v < nv; ++v) memcpy(V.data() + 8 * v + 3, P.data() + 8 * (size_t) (*position_index)[v] + 3, 12);
+        } else if (har_mesh_compute_normals((uint32_t) nv, V.data(), (uint32_t) nf, F.data())) return 1;
+    }
+    return 0;
+}
+
+extern "C" {
+
+int har_mesh_load_ply(const char *filename, int face_normals, int flip_tex_coords, const float *to_world, int flip_normals, HarMeshData *out) {
     if (!filename || !out) return har_set_error("null argument");
     memset(out, 0, sizeof(*out));
     auto fail = [&](const std::string &d) { har_mesh_free(out); return har_set_error("Error while loading PLY file \"" + std::string(filename) + "\": " + d + "!"); };
@@ -199,16 +256,14 @@ int har_mesh_load_ply(const char *filename, int face_normals, int flip_tex_coord
     if (!ascii && R.p != R.end) return fail("invalid file -- trailing content");
     if (ascii) { std::string rest; if (R.text >> rest) return fail("invalid file -- trailing content"); }
     for (size_t i = 0; i < nf; ++i) for (int c = 0; c < 3; ++c) if (F[4 * i + c] >= nv) return fail("face index out of bounds");
+    const bool regenerate = !has_normals && !face_normals;       /* Mesh::from_packed -> pack(regenerate_normals = true), mesh.cpp:355-356 */
+    if (har_mesh_finalize(V, F, has_normals, regenerate, to_world, flip_normals != 0, nullptr, 0)) return 1;
     out->vertices = (float *) malloc(std::max<size_t>(V.size(), 1) * sizeof(float));
     out->faces = (uint32_t *) malloc(std::max<size_t>(F.size(), 1) * sizeof(uint32_t));
     if (!out->vertices || !out->faces) return fail("out of memory");
     memcpy(out->vertices, V.data(), V.size() * sizeof(float)); memcpy(out->faces, F.data(), F.size() * sizeof(uint32_t));
     out->vertex_count = (uint32_t) nv; out->face_count = (uint32_t) nf;
-    out->flags = (has_normals ? 1u : 0u) | (has_uv ? 2u : 0u);
-    if (!has_normals && !face_normals) {                   /* Mesh::from_packed -> pack(regenerate_normals = true), mesh.cpp:355-356 */
-        if (har_mesh_compute_normals(out->vertex_count, out->vertices, out->face_count, out->faces)) { har_mesh_free(out); return 1; }
-        out->flags |= 1u;
-    }
+    out->flags = ((has_normals || regenerate) ? 1u : 0u) | (has_uv ? 2u : 0u);
     return 0;
 }
 

@@ -1,0 +1,273 @@
+"""OBJ (src/shapes/obj.cpp + Mesh::from_corners, src/render/mesh_utils.cpp:210-560) and `serialized` (src/shapes/serialized.cpp,
+container versions 3 / 4) ingestion by the C++ host library, against test-side writers and an independent restatement of the
+corner-welding rules.  Also the order of operations shared by all mesh loaders: to_world / flip_normals are baked BEFORE missing
+normals are regenerated (PackedMesh::set_transform, mesh_utils.cpp:33-44).  No GPU involved."""
+import os
+import struct
+import zlib
+
+import numpy as np
+import pytest
+
+from tests.test_mesh_io_cpu import grid_mesh, numpy_normals, write_ply
+
+
+# ----------------------------------------------------------------------------------------------------------------- OBJ
+
+def write_obj(path, P, faces, VT=None, VN=None, header="# test\no thing\ns off\n", crlf=False):
+    """faces: list of polygons, each a list of (p, t, n) 0-based index triples (t / n may be None)"""
+    nl = "\r\n" if crlf else "\n"
+    out = [header.rstrip("\n")]
+    out += ["v %.9g %.9g %.9g" % tuple(p) for p in P]
+    if VT is not None: out += ["vt %.9g %.9g" % tuple(t) for t in VT]
+    if VN is not None: out += ["vn %.9g %.9g %.9g" % tuple(n) for n in VN]
+    for poly in faces:
+        toks = []
+        for (p, t, n) in poly:
+            if t is None and n is None: toks.append("%d" % (p + 1))
+            elif n is None: toks.append("%d/%d" % (p + 1, t + 1))
+            elif t is None: toks.append("%d//%d" % (p + 1, n + 1))
+            else: toks.append("%d/%d/%d" % (p + 1, t + 1, n + 1))
+        out.append("f " + " ".join(toks))
+    with open(path, "wb") as f:
+        f.write((nl.join(out) + nl).encode())
+
+
+def weld_reference(P, faces, VT, VN, face_normals=False, flip_tex_coords=True):
+    """what from_corners must produce: (V [n x 8], F [m x 3], position_index)"""
+    P = np.asarray(P, np.float32)
+    VT = None if VT is None else np.asarray(VT, np.float32).copy()
+    if VT is not None and flip_tex_coords: VT[:, 1] = np.float32(1) - VT[:, 1]
+    VN = None if VN is None else np.asarray(VN, np.float32)
+    has_uv = any(t is not None for poly in faces for (_, t, _) in poly)
+    has_n = any(n is not None for poly in faces for (_, _, n) in poly) and not face_normals
+    tris = []
+    for poly in faces:
+        for i in range(1, len(poly) - 1):
+            tris.append((poly[0], poly[i], poly[i + 1]))
+    def uv_of(t): return (0.0, 0.0) if t is None else tuple(float(x) + 0.0 for x in VT[t])      # + 0.0 folds -0.0
+    def n_of(n): return (0.0, 0.0, 0.0) if n is None else tuple(float(x) + 0.0 for x in VN[n])
+    corner_keys = []
+    for tri in tris:
+        flipped = 0
+        if has_uv and not face_normals:
+            (a, b, c) = [np.float32(uv_of(t)) for (_, t, _) in tri]
+            area2 = np.float32(np.float32(b[0] - a[0]) * np.float32(c[1] - a[1])) - np.float32(np.float32(b[1] - a[1]) * np.float32(c[0] - a[0]))
+            flipped = 0 if area2 > 0 else 1
+        for (p, t, n) in tri:
+            corner_keys.append((p, (n_of(n) if has_n else ()) + (uv_of(t) if has_uv else ()) + ((flipped,) if has_uv and not face_normals else ())))
+    V, pidx, F = [], [], np.zeros((len(tris), 3), np.uint32)
+    for p in range(len(P)):
+        local = {}
+        for c, (cp, key) in enumerate(corner_keys):
+            if cp != p: continue
+            if key not in local:
+                local[key] = len(V)
+                rec = list(P[p]) + (list(key[0:3]) if has_n else [0, 0, 0]) + (list(key[3:5] if has_n else key[0:2]) if has_uv else [0, 0])
+                V.append(rec); pidx.append(p)
+            F[c // 3, c % 3] = local[key]
+    # position ids are dense over REFERENCED points
+    used = sorted(set(pidx)); remap = {p: i for i, p in enumerate(used)}
+    return np.asarray(V, np.float32).reshape(-1, 8), F, np.asarray([remap[p] for p in pidx], np.uint32), has_n, has_uv
+
+
+CUBE_P = [(-1, -1, -1), (1, -1, -1), (1, 1, -1), (-1, 1, -1), (-1, -1, 1), (1, -1, 1), (1, 1, 1), (-1, 1, 1), (5, 5, 5)]   # last: unreferenced
+CUBE_N = [(0, 0, -1), (0, 0, 1), (0, -1, 0), (1, 0, 0), (0, 1, 0), (-1, 0, 0)]
+CUBE_T = [(0, 0), (1, 0), (1, 1), (0, 1)]
+CUBE_Q = [(3, 2, 1, 0), (4, 5, 6, 7), (0, 1, 5, 4), (1, 2, 6, 5), (2, 3, 7, 6), (3, 0, 4, 7)]
+
+
+def cube_faces(with_t=True, with_n=True):
+    return [[(q[k], k if with_t else None, s if with_n else None) for k in range(4)] for s, q in enumerate(CUBE_Q)]
+
+
+def check_against_reference(m, ref, P_expected_normals=None):
+    V, F, pidx, has_n, has_uv = ref
+    assert m.V.shape == V.shape and m.F.shape[0] == F.shape[0]
+    assert np.array_equal(m.F[:, :3], F) and not m.F[:, 3].any()
+    assert np.allclose(m.V[:, :3], V[:, :3], rtol=1e-7)
+    assert np.allclose(m.V[:, 6:8], V[:, 6:8], rtol=1e-7)
+    if has_n:
+        n = V[:, 3:6] / np.maximum(np.linalg.norm(V[:, 3:6], axis=1, keepdims=True), 1e-30)
+        assert np.allclose(m.V[:, 3:6], n, atol=1e-6)
+    assert bool(m.flags & 2) == has_uv
+    return pidx
+
+
+def test_obj_cube_quads_weld_and_triangulate(mi, tmp_path):
+    path = os.path.join(tmp_path, "cube.obj")
+    for crlf in (False, True):
+        write_obj(path, CUBE_P, cube_faces(), CUBE_T, CUBE_N, crlf=crlf)
+        m = mi.core.Mesh("t").from_obj(path)
+        ref = weld_reference(CUBE_P, cube_faces(), CUBE_T, CUBE_N)
+        check_against_reference(m, ref)
+        assert m.V.shape[0] == 24 and m.F.shape[0] == 12 and m.flags == 3      # 8 points x 3 normals; the 9th point is dropped
+        # quads split along corners 0-2; vertex ids follow the source point order
+        assert np.array_equal(m.V[:3, :3], np.float32([CUBE_P[0]] * 3)) and np.array_equal(m.V[21:24, :3], np.float32([CUBE_P[7]] * 3))
+        assert np.array_equal(m.V[:, 7][m.V[:, 7] != 0], np.ones((m.V[:, 7] != 0).sum(), np.float32))   # v -> 1 - v
+
+
+def test_obj_corner_forms_and_missing_indices(mi, tmp_path):
+    path = os.path.join(tmp_path, "forms.obj")
+    P, Fi, _, UV = grid_mesh(4)
+    rng = np.random.default_rng(3)
+    N = rng.normal(size=(7, 3)).astype(np.float32)
+    polys = []
+    for k, f in enumerate(Fi):
+        mode = k % 4
+        polys.append([(int(p), (int(p) if mode in (1, 3) else None), (int((p + k) % 7) if mode in (2, 3) else None)) for p in f])
+    write_obj(path, P, polys, UV, N)
+    for fn in (False, True):
+        for flip in (True, False):
+            m = mi.core.Mesh("t").from_obj(path, face_normals=fn, flip_tex_coords=flip)
+            ref = weld_reference(P, polys, UV, N, face_normals=fn, flip_tex_coords=flip)
+            check_against_reference(m, ref)
+            assert bool(m.flags & 1) == (not fn)
+    # pentagon fan + triangle, positions only: normals regenerated, nothing splits
+    P5 = [(np.cos(a), np.sin(a), 0.1 * k) for k, a in enumerate(np.linspace(0, 2 * np.pi, 6)[:-1])] + [(0, 0, 1)]
+    polys = [[(k, None, None) for k in range(5)], [(0, None, None), (1, None, None), (5, None, None)]]
+    write_obj(path, P5, polys)
+    m = mi.core.Mesh("t").from_obj(path)
+    assert np.array_equal(m.F[:, :3], np.uint32([[0, 1, 2], [0, 2, 3], [0, 3, 4], [0, 1, 5]])) and m.flags == 1
+    assert np.allclose(m.V[:, 3:6], numpy_normals(np.float32(P5), m.F[:, :3]), atol=2e-6)
+
+
+def test_obj_regenerated_normals_are_per_surface_point(mi, tmp_path):
+    """a UV seam splits vertices but not the surface: the regenerated normal is shared (mesh.cpp:573-582)"""
+    P, Fi, _, UV = grid_mesh(5)
+    VT = np.concatenate([UV, UV + np.float32([0.5, 0.25])])          # second chart: the same points get other texcoords
+    polys = [[(int(p), int(p) + (len(P) if k % 2 else 0), None) for p in f] for k, f in enumerate(Fi)]
+    path = os.path.join(tmp_path, "seam.obj"); write_obj(path, P, polys, VT)
+    T = mi.ScalarTransform4f
+    for tw in (None, T().translate([0.5, 0, 1]).scale([1, 3, 0.5]), T().scale([-1, 1, 1])):
+        for flip in (False, True):
+            m = mi.core.Mesh("t").from_obj(path, to_world=tw, flip_normals=flip)
+            V, F, pidx, _, _ = weld_reference(P, polys, VT, None)
+            assert m.V.shape[0] == len(V) > len(P) and np.array_equal(np.sort(m.F[:, :3], axis=1), np.sort(F, axis=1))
+            M = np.eye(4, dtype=np.float32) if tw is None else np.asarray(tw.matrix, np.float32).reshape(4, 4)
+            Pw = (P @ M[:3, :3].T + M[:3, 3]).astype(np.float32)
+            assert np.allclose(m.V[:, :3], Pw[[sorted(set(range(len(P))))[i] for i in pidx]], atol=1e-6)
+            reverse = (np.linalg.det(M[:3, :3]) < 0) != flip
+            Fw = F[:, ::-1] if reverse else F
+            assert np.array_equal(m.F[:, :3], Fw)
+            # normals: computed on the TRANSFORMED surface points with the FINAL winding, shared across the seam
+            expect = numpy_normals(Pw, pidx[Fw])
+            assert np.allclose(m.V[:, 3:6], expect[pidx], atol=5e-6)
+
+
+def test_mesh_loaders_bake_transform_before_normals(mi, tmp_path):
+    """same rule for PLY: non-uniform scaling changes the angle weights, so the order matters"""
+    P, F, N, UV = grid_mesh(5)
+    path = os.path.join(tmp_path, "g.ply"); write_ply(path, "binary_little_endian", P, F)
+    T = mi.ScalarTransform4f
+    tw = T().rotate([0, 0, 1], 30).scale([1, 4, 0.25])
+    M = np.asarray(tw.matrix, np.float32).reshape(4, 4)
+    Pw = (P @ M[:3, :3].T + M[:3, 3]).astype(np.float32)
+    m = mi.core.Mesh("t").from_ply(path, to_world=tw)
+    assert np.allclose(m.V[:, :3], Pw, atol=1e-6) and np.allclose(m.V[:, 3:6], numpy_normals(Pw, F), atol=5e-6)
+    m2 = mi.core.Mesh("t").from_ply(path, to_world=tw, flip_normals=True)
+    assert np.array_equal(m2.F[:, :3], F[:, ::-1]) and np.allclose(m2.V[:, 3:6], -m.V[:, 3:6], atol=5e-6)
+    # stored normals: inverse transpose, normalised, negated by flip_normals; zero-length normals are left alone
+    Nn = (N * np.float32(2.5)); Nn[0] = 0
+    write_ply(path, "binary_little_endian", P, F, N=Nn)
+    m3 = mi.core.Mesh("t").from_ply(path, to_world=tw, flip_normals=True)
+    it = np.linalg.inv(M[:3, :3].astype(np.float64)).T
+    e = Nn.astype(np.float64) @ it.T; e[1:] /= np.linalg.norm(e[1:], axis=1, keepdims=True)
+    assert np.allclose(m3.V[1:, 3:6], -e[1:], atol=1e-5) and not m3.V[0, 3:6].any()
+
+
+def test_obj_errors(mi, tmp_path):
+    def load(text, **kw):
+        path = os.path.join(tmp_path, "e.obj")
+        with open(path, "wb") as f: f.write(text.encode())
+        return mi.core.Mesh("t").from_obj(path, **kw)
+    tri = "v 0 0 0\nv 1 0 0\nv 0 1 0\n"
+    assert load(tri + "f 1 2 3\n").F.shape[0] == 1
+    assert load(tri + "f 1 2\n").F.shape[0] == 0                                # degenerate polygon: no triangle
+    with pytest.raises(RuntimeError, match="invalid vertex 4"): load(tri + "f 1 2 4\n")
+    with pytest.raises(RuntimeError, match="invalid vertex 0"): load(tri + "f 0 1 2\n")
+    with pytest.raises(RuntimeError, match="invalid texture coordinate 2"): load(tri + "vt 0 0\nf 1/1 2/2 3/1\n")
+    with pytest.raises(RuntimeError, match="invalid normal 1"): load(tri + "f 1//1 2//1 3//1\n")
+    assert load(tri + "f 1//1 2//1 3//1\n", face_normals=True).F.shape[0] == 1   # normals are ignored entirely (obj.cpp:176,262)
+    with pytest.raises(RuntimeError, match="could not parse line"): load("v 0 0 abc\n")
+    with pytest.raises(RuntimeError, match="could not parse line"): load(tri + "f 1/1/1/1 2 3\n")
+    with pytest.raises(RuntimeError, match="invalid vertex position"): load("v 0 nan 0\n")
+    with pytest.raises(RuntimeError, match="excessively long line"): load("# " + "x" * 2000 + "\n" + tri)
+    with pytest.raises(RuntimeError, match="unreadable"): mi.core.Mesh("t").from_obj(os.path.join(tmp_path, "missing.obj"))
+
+
+# ---------------------------------------------------------------------------------------------------------- serialized
+
+def serialized_blob(version, P, F, N=None, UV=None, colors=None, double=False, name="mesh", face_normals_flag=False):
+    flags = (0x2000 if double else 0x1000) | (1 if N is not None else 0) | (2 if UV is not None else 0) | (8 if colors is not None else 0) | (0x10 if face_normals_flag else 0)
+    ft = "<f8" if double else "<f4"
+    payload = struct.pack("<I", flags)
+    if version == 4: payload += name.encode() + b"\0"
+    payload += struct.pack("<QQ", len(P), len(F)) + np.asarray(P).astype(ft).tobytes()
+    for a in (N, UV, colors):
+        if a is not None: payload += np.asarray(a).astype(ft).tobytes()
+    payload += np.asarray(F).astype("<u4").tobytes()
+    return struct.pack("<HH", 0x041C, version) + zlib.compress(payload)
+
+
+def write_serialized(path, version, blobs):
+    data, offsets = b"", []
+    for b in blobs:
+        offsets.append(len(data)); data += b
+    data += b"".join(struct.pack("<Q" if version == 4 else "<I", o) for o in offsets) + struct.pack("<I", len(blobs))
+    with open(path, "wb") as f: f.write(data)
+
+
+@pytest.mark.parametrize("version", [3, 4])
+def test_serialized_variants(mi, tmp_path, version):
+    P, F, N, UV = grid_mesh(6)
+    P2, F2, N2, UV2 = grid_mesh(3)
+    col = np.tile(np.float32([0.2, 0.4, 0.6]), (len(P), 1))
+    path = os.path.join(tmp_path, "m.serialized")
+    write_serialized(path, version, [serialized_blob(version, P, F, N, UV, col), serialized_blob(version, P2, F2, double=True),
+                                     serialized_blob(version, P2 * 2, F2, N=N2 * 3, double=True)])
+    m = mi.core.Mesh("t").from_serialized(path)
+    assert np.array_equal(m.V[:, :3], P) and np.array_equal(m.V[:, 3:6], N) and np.array_equal(m.V[:, 6:8], UV) and np.array_equal(m.F[:, :3], F) and m.flags == 3
+    m = mi.core.Mesh("t").from_serialized(path, shape_index=1)                 # doubles are narrowed; normals regenerated
+    assert np.array_equal(m.V[:, :3], P2) and np.allclose(m.V[:, 3:6], numpy_normals(P2, F2), atol=2e-6) and m.flags == 1
+    m = mi.core.Mesh("t").from_serialized(path, shape_index=2)                 # stored normals are normalised (mesh_utils.cpp:113-115)
+    assert np.array_equal(m.V[:, :3], P2 * 2) and np.allclose(m.V[:, 3:6], N2, atol=1e-6)
+    m = mi.core.Mesh("t").from_serialized(path, shape_index=0, face_normals=True)
+    assert m.flags == 2 and not m.V[:, 3:6].any()
+    with pytest.raises(RuntimeError, match="out of range"):
+        mi.core.Mesh("t").from_serialized(path, shape_index=3)
+    # scene plugin
+    d = mi.cornell_box()
+    d["blob"] = {"type": "serialized", "filename": path, "shape_index": 1, "to_world": mi.ScalarTransform4f().scale(0.2), "bsdf": {"type": "ref", "id": "red"}}
+    scene = mi.load_dict(d)
+    blob = [x for x in scene.meshes if x["key"] == "blob"][0]
+    assert blob["V"].shape[0] == len(P2) and np.allclose(blob["V"][:, :3], P2 * 0.2, atol=1e-7)
+
+
+def test_serialized_errors(mi, tmp_path):
+    P, F, N, UV = grid_mesh(3)
+    path = os.path.join(tmp_path, "e.serialized")
+    def load(data, **kw):
+        with open(path, "wb") as f: f.write(data)
+        return mi.core.Mesh("t").from_serialized(path, **kw)
+    good = serialized_blob(4, P, F) + struct.pack("<QI", 0, 1)
+    assert load(good).F.shape[0] == len(F)
+    with pytest.raises(RuntimeError, match="invalid file format"): load(b"\x1d\x04" + good[2:])
+    with pytest.raises(RuntimeError, match="incompatible file version"): load(good[:2] + struct.pack("<H", 2) + good[4:])
+    with pytest.raises(RuntimeError, match="version 5"): load(good[:2] + struct.pack("<H", 5) + good[4:])
+    with pytest.raises(RuntimeError, match="nonnegative"): load(good, shape_index=-1)
+    with pytest.raises(RuntimeError, match="inflate"): load(good[:4] + b"garbage-not-zlib" * 4)
+    short = struct.pack("<HH", 0x041C, 4) + zlib.compress(struct.pack("<I", 0x1000) + b"x\0" + struct.pack("<QQ", 100, 1))
+    with pytest.raises(RuntimeError, match="end of stream"): load(short)
+    bad = serialized_blob(4, P, np.uint32([[0, 1, 99]]))
+    with pytest.raises(RuntimeError, match="out of bounds"): load(bad)
+
+
+def test_obj_scene_plugin(mi, tmp_path):
+    path = os.path.join(tmp_path, "cube.obj"); write_obj(path, CUBE_P, cube_faces(), CUBE_T, CUBE_N)
+    d = mi.cornell_box()
+    d["thing"] = {"type": "obj", "filename": path, "to_world": mi.ScalarTransform4f().translate([0, 0.2, 0]).scale(0.1), "bsdf": {"type": "ref", "id": "green"}}
+    scene = mi.load_dict(d)
+    thing = [x for x in scene.meshes if x["key"] == "thing"][0]
+    assert thing["V"].shape[0] == 24 and thing["F"].shape[0] == 12 and thing["flags"] == 3
+    assert np.allclose(np.abs(thing["V"][:, :3] - np.float32([0, 0.2, 0])).max(axis=0), 0.1, atol=1e-6)
