@@ -8,6 +8,7 @@
 #include "mi_oracle.h"
 #include "orc_math.h"
 #include "orc_bsdf.h"
+#include "orc_envmap.h"
 
 #include <algorithm>
 #include <atomic>
@@ -47,6 +48,7 @@ struct Scene {
     std::vector<Texture> textures;
     std::vector<OrcEmitter> emitters;
     int env = -1; float env_center[3] = { 0, 0, 0 }; float env_radius = 0.f;   // Scene::environment() + its bounding sphere
+    EnvMap envmap;                 // when emitters[env].type == 2
     Bvh top;                       // all top-level meshes
     std::vector<Bvh> group_bvh;    // one per shapegroup
     std::vector<BvhNode> inst_nodes; // BVH over instance world boxes
@@ -460,6 +462,11 @@ static inline bool sample_emitter_direction(const Scene &sc, const SI &si, float
         weight = (float) n; sx = scaled - (float) index;
     }
     if (sc.emitters[index].type == 1) { EnvSphere bs; bs.center = V3(sc.env_center[0], sc.env_center[1], sc.env_center[2]); bs.radius = sc.env_radius; constant_sample_direction(sc.emitters[index], bs, si.p, sx, sy, ds, spec); }
+    else if (sc.emitters[index].type == 2) {       // EnvironmentMapEmitter::sample_direction (envmap.cpp:284-323)
+        float uv[2];
+        sc.envmap.sample_direction(si.p, sx, sy, ds.d, ds.dist, ds.pdf, spec, uv);
+        ds.p = fmadd(ds.d, ds.dist, si.p); ds.n = -ds.d;
+    }
     else emitter_sample_direction(sc.emitters[index], si.p, sx, sy, ds, spec);
     ds.emitter = (int) index;
     ds.pdf *= pmf;
@@ -590,10 +597,11 @@ static V3 path_sample(const Scene &sc, Pcg32 &rng, Ray ray, uint32_t max_depth, 
             V3 rel = si.p - prev_p; ds.dist = norm(rel); ds.d = si.valid() ? div(rel, ds.dist) : -si.wi;
             const OrcEmitter &e = sc.emitters[emitter];
             float em_pdf = 0.f;
-            if (!prev_bsdf_delta) em_pdf = (e.type == 1 ? InvFourPi : emitter_pdf_direction(e, ds)) * (1.f / (float) sc.emitters.size());
+            if (!prev_bsdf_delta) em_pdf = (e.type == 1 ? InvFourPi : e.type == 2 ? sc.envmap.pdf_direction(ds.d) : emitter_pdf_direction(e, ds)) * (1.f / (float) sc.emitters.size());
             float mis_bsdf = mis_weight(prev_bsdf_pdf, em_pdf);
-            bool facing = e.type == 1 || si.wi.z > 0.f;                                                                   // area.cpp:83-90, constant.cpp:90-94
-            V3 Le = (facing && prev_bsdf_pdf > 0.f) ? V3(e.radiance[0], e.radiance[1], e.radiance[2]) : V3(0.f);
+            bool facing = e.type != 0 || si.wi.z > 0.f;                                                                   // area.cpp:83-90, constant.cpp:90-94
+            V3 rad = e.type == 2 ? sc.envmap.eval(-si.wi) : V3(e.radiance[0], e.radiance[1], e.radiance[2]);             // envmap.cpp:228-236
+            V3 Le = (facing && prev_bsdf_pdf > 0.f) ? rad : V3(0.f);
             result = fmadd(throughput, Le * mis_bsdf, result);
         }
         bool active_next = (depth + 1 < max_depth) && si.valid();
@@ -664,11 +672,11 @@ static V3 prb_sample(const Scene &sc, Pcg32 &rng, Ray ray, uint32_t max_depth, u
             float em_pdf = 0.f;
             DS ds; ds.p = si.p; ds.n = si.sn;
             V3 rel = si.p - prev_p; ds.dist = norm(rel); ds.d = si.valid() ? div(rel, ds.dist) : -si.wi;
-            if (emitter >= 0 && !bsdf_delta_prev) em_pdf = (sc.emitters[emitter].type == 1 ? InvFourPi : emitter_pdf_direction(sc.emitters[emitter], ds)) * (1.f / (float) sc.emitters.size());
+            if (emitter >= 0 && !bsdf_delta_prev) em_pdf = (sc.emitters[emitter].type == 1 ? InvFourPi : sc.emitters[emitter].type == 2 ? sc.envmap.pdf_direction(ds.d) : emitter_pdf_direction(sc.emitters[emitter], ds)) * (1.f / (float) sc.emitters.size());
             float mis = mis_weight(bsdf_pdf_prev, em_pdf);
             if (emitter >= 0) {
                 const OrcEmitter &e = sc.emitters[emitter];
-                V3 ev = (e.type == 1 || si.wi.z > 0.f) ? V3(e.radiance[0], e.radiance[1], e.radiance[2]) : V3(0.f);
+                V3 ev = e.type == 2 ? sc.envmap.eval(-si.wi) : (e.type == 1 || si.wi.z > 0.f) ? V3(e.radiance[0], e.radiance[1], e.radiance[2]) : V3(0.f);
                 Le = (beta * mis) * ev;
             }
         }
@@ -983,7 +991,15 @@ void *orc_scene_create(const OrcSceneDesc *d) {
         sc->textures.push_back(std::move(t));
     }
     sc->emitters.assign(d->emitters, d->emitters + d->emitter_count);
-    for (uint32_t i = 0; i < sc->emitters.size(); ++i) if (sc->emitters[i].type == 1) sc->env = (int) i;
+    for (uint32_t i = 0; i < sc->emitters.size(); ++i) {
+        const OrcEmitter &e = sc->emitters[i];
+        if (e.type == 1 || e.type == 2) sc->env = (int) i;
+        if (e.type == 2) {
+            if (e.mesh >= sc->textures.size()) { delete sc; return nullptr; }
+            const Texture &t = sc->textures[e.mesh];
+            sc->envmap.init(t.data.data(), t.w, t.h, e.radiance[0], e.radiance[1] != 0.f, e.to_world, e.to_local);
+        }
+    }
     for (uint32_t i = 0; i < sc->bsdfs.size(); ++i) if (sc->bsdfs[i].p.type == 3) roughplastic_precompute(sc->bsdfs[i], slot0_mean(*sc, i));
     build_tri_bvh(sc->top, sc->meshes, 0, sc->top_count);
     sc->group_bvh.resize(sc->groups.size());
@@ -1024,6 +1040,8 @@ void *orc_scene_create(const OrcSceneDesc *d) {
             sc->env_center[0] = c.x; sc->env_center[1] = c.y; sc->env_center[2] = c.z;
             sc->env_radius = std::max(RayEpsilon, norm(c - V3(hi[0], hi[1], hi[2])) * (1.f + RayEpsilon));
         } else sc->env_radius = RayEpsilon;
+        for (int a = 0; a < 3; ++a) sc->envmap.center[a] = sc->env_center[a];          // EnvironmentMapEmitter::set_scene (envmap.cpp:214-226), same rule
+        sc->envmap.radius = sc->env_radius;
     }
     return sc;
 }
@@ -1253,5 +1271,31 @@ uint32_t orc_spiral(uint32_t size_x, uint32_t size_y, uint32_t block_size, uint3
     for (uint32_t i = 0; i < std::min<uint32_t>((uint32_t) b.size(), max_blocks); ++i) { out[5 * i] = b[i].off_x; out[5 * i + 1] = b[i].off_y; out[5 * i + 2] = (int32_t) b[i].size_x; out[5 * i + 3] = (int32_t) b[i].size_y; out[5 * i + 4] = (int32_t) b[i].id; }
     return (uint32_t) b.size();
 }
+
+
+void *orc_hier2d_create(const float *data, uint32_t w, uint32_t h, int normalize) { Hier2D *d = new Hier2D(); if (!d->build(data, w, h, normalize != 0)) { delete d; return nullptr; } return d; }
+void orc_hier2d_destroy(void *h) { delete (Hier2D *) h; }
+void orc_hier2d_sample(void *h, uint32_t n, const float *s, float *pos, float *pdf) { for (uint32_t i = 0; i < n; ++i) ((Hier2D *) h)->sample(s[2 * i], s[2 * i + 1], pos + 2 * i, pdf[i]); }
+void orc_hier2d_invert(void *h, uint32_t n, const float *pos, float *s, float *pdf) { for (uint32_t i = 0; i < n; ++i) ((Hier2D *) h)->invert(pos[2 * i], pos[2 * i + 1], s + 2 * i, pdf[i]); }
+void orc_hier2d_eval(void *h, uint32_t n, const float *pos, float *pdf) { for (uint32_t i = 0; i < n; ++i) pdf[i] = ((Hier2D *) h)->eval(pos[2 * i], pos[2 * i + 1]); }
+uint32_t orc_hier2d_data(void *h, float *out, uint32_t *table, uint32_t *n_levels) {
+    Hier2D *d = (Hier2D *) h;
+    if (out) std::copy(d->data.begin(), d->data.end(), out);
+    if (table) for (size_t l = 0; l < d->levels.size(); ++l) { table[3 * l] = d->levels[l].width; table[3 * l + 1] = d->levels[l].size; table[3 * l + 2] = d->levels[l].offset; }
+    if (n_levels) *n_levels = (uint32_t) d->levels.size();
+    return (uint32_t) d->data.size();
+}
+void *orc_envmap_create(const float *rgb, uint32_t w, uint32_t h, float scale, int mis, const float tw[12], const float tl[12]) { EnvMap *e = new EnvMap(); e->init(rgb, w, h, scale, mis != 0, tw, tl); return e; }
+void orc_envmap_destroy(void *e) { delete (EnvMap *) e; }
+void orc_envmap_set_bsphere(void *e, const float c[3], float r) { EnvMap *m = (EnvMap *) e; for (int a = 0; a < 3; ++a) m->center[a] = c[a]; m->radius = r; }
+void orc_envmap_eval(void *e, uint32_t n, const float *d, float *rgb) { for (uint32_t i = 0; i < n; ++i) { V3 v = ((EnvMap *) e)->eval(V3(d[3 * i], d[3 * i + 1], d[3 * i + 2])); rgb[3 * i] = v.x; rgb[3 * i + 1] = v.y; rgb[3 * i + 2] = v.z; } }
+void orc_envmap_sample_direction(void *e, uint32_t n, const float *p, const float *s, float *d, float *dist, float *pdf, float *weight) {
+    for (uint32_t i = 0; i < n; ++i) {
+        V3 dd, w; float uv[2];
+        ((EnvMap *) e)->sample_direction(V3(p[3 * i], p[3 * i + 1], p[3 * i + 2]), s[2 * i], s[2 * i + 1], dd, dist[i], pdf[i], w, uv);
+        d[3 * i] = dd.x; d[3 * i + 1] = dd.y; d[3 * i + 2] = dd.z; weight[3 * i] = w.x; weight[3 * i + 1] = w.y; weight[3 * i + 2] = w.z;
+    }
+}
+void orc_envmap_pdf_direction(void *e, uint32_t n, const float *d, float *pdf) { for (uint32_t i = 0; i < n; ++i) pdf[i] = ((EnvMap *) e)->pdf_direction(V3(d[3 * i], d[3 * i + 1], d[3 * i + 2])); }
 
 } // extern "C"

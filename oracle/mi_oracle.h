@@ -73,12 +73,15 @@ typedef struct OrcBSDF {
 typedef struct OrcTexture { const float *data; uint32_t width, height; } OrcTexture;
 
 typedef struct OrcEmitter {
-    uint32_t type;        /* 0 = area light on a rectangle, 1 = constant environment (src/emitters/constant.cpp; radiance only) */
+    uint32_t type;        /* 0 = area light on a rectangle, 1 = constant environment (src/emitters/constant.cpp; radiance only),
+                             2 = environment map (src/emitters/envmap.cpp): mesh = index of the H x W x 3 image in `textures`,
+                             radiance[0] = scale, radiance[1] = mis_compensation (0 / 1), to_world / to_local = emitter transform */
     uint32_t mesh;        /* mesh that carries the emitter */
     float radiance[3];
     float to_world[12];   /* rectangle to_world, column-major 3x4 */
     float normal[3];      /* m_frame.n (rectangle.cpp:118) */
     float inv_area;       /* m_inv_surface_area (rectangle.cpp:123) */
+    float to_local[12];   /* inverse of to_world as the reference's Transform tracks it (type 2 only) */
 } OrcEmitter;
 
 typedef struct OrcSceneDesc {
@@ -115,6 +118,20 @@ void  orc_scene_destroy(void *scene);
 /* update a constant reflectance / a texture in place (for finite differences) */
 void  orc_scene_set_reflectance(void *scene, uint32_t bsdf, const float rgb[3]);
 void  orc_scene_set_texture(void *scene, uint32_t texture, const float *data);
+
+/* ---- Hierarchical2D<Float, 0> (distr_2d.h:370-860) and the environment-map emitter (src/emitters/envmap.cpp) as free functions ---- */
+void *orc_hier2d_create(const float *data, uint32_t width, uint32_t height, int normalize);
+void  orc_hier2d_destroy(void *h);
+void  orc_hier2d_sample(void *h, uint32_t n, const float *sample /*[n][2]*/, float *pos /*[n][2]*/, float *pdf);
+void  orc_hier2d_invert(void *h, uint32_t n, const float *pos, float *sample, float *pdf);
+void  orc_hier2d_eval(void *h, uint32_t n, const float *pos, float *pdf);
+uint32_t orc_hier2d_data(void *h, float *out /* nullable */, uint32_t *level_table /* [n_levels][3]: width, size, offset; nullable */, uint32_t *n_levels);
+void *orc_envmap_create(const float *rgb, uint32_t width, uint32_t height, float scale, int mis_compensation, const float to_world[12], const float to_local[12]);
+void  orc_envmap_destroy(void *e);
+void  orc_envmap_set_bsphere(void *e, const float center[3], float radius);
+void  orc_envmap_eval(void *e, uint32_t n, const float *d_world /*[n][3]*/, float *rgb);
+void  orc_envmap_sample_direction(void *e, uint32_t n, const float *ref_p, const float *sample, float *d, float *dist, float *pdf, float *weight);
+void  orc_envmap_pdf_direction(void *e, uint32_t n, const float *d_world, float *pdf);
 
 /* ---- multi-pass JIT render (integrator.cpp:173-183,276-356): spp / spp_per_pass wavefronts of W*H*spp_per_pass lanes whose
  *      sampler streams continue across passes; [lane_begin, lane_end) index the per-pass wavefront ---- */

@@ -43,7 +43,7 @@ class Texture(C.Structure):
 
 class Emitter(C.Structure):
     _fields_ = [("type", C.c_uint32), ("mesh", C.c_uint32), ("radiance", C.c_float * 3),
-                ("to_world", C.c_float * 12), ("normal", C.c_float * 3), ("inv_area", C.c_float)]
+                ("to_world", C.c_float * 12), ("normal", C.c_float * 3), ("inv_area", C.c_float), ("to_local", C.c_float * 12)]
 
 
 class SceneDesc(C.Structure):
@@ -99,6 +99,21 @@ def lib():
         L.orc_render_path_scalar.restype = C.c_int
         L.orc_render_path_scalar.argtypes = [C.c_void_p, C.POINTER(Sensor), C.c_uint32, C.c_uint32, C.c_int32, C.c_int32, C.c_uint32,
                                              c_f32p, C.POINTER(Stats), c_u32p]
+        L.orc_hier2d_create.restype = C.c_void_p
+        L.orc_hier2d_create.argtypes = [c_f32p, C.c_uint32, C.c_uint32, C.c_int]
+        L.orc_hier2d_destroy.argtypes = [C.c_void_p]
+        for fn in (L.orc_hier2d_sample, L.orc_hier2d_invert):
+            fn.argtypes = [C.c_void_p, C.c_uint32, c_f32p, c_f32p, c_f32p]
+        L.orc_hier2d_eval.argtypes = [C.c_void_p, C.c_uint32, c_f32p, c_f32p]
+        L.orc_hier2d_data.restype = C.c_uint32
+        L.orc_hier2d_data.argtypes = [C.c_void_p, c_f32p, c_u32p, c_u32p]
+        L.orc_envmap_create.restype = C.c_void_p
+        L.orc_envmap_create.argtypes = [c_f32p, C.c_uint32, C.c_uint32, C.c_float, C.c_int, c_f32p, c_f32p]
+        L.orc_envmap_destroy.argtypes = [C.c_void_p]
+        L.orc_envmap_set_bsphere.argtypes = [C.c_void_p, c_f32p, C.c_float]
+        L.orc_envmap_eval.argtypes = [C.c_void_p, C.c_uint32, c_f32p, c_f32p]
+        L.orc_envmap_sample_direction.argtypes = [C.c_void_p, C.c_uint32, c_f32p, c_f32p, c_f32p, c_f32p, c_f32p, c_f32p]
+        L.orc_envmap_pdf_direction.argtypes = [C.c_void_p, C.c_uint32, c_f32p, c_f32p]
         L.orc_render_prb_backward.restype = C.c_int
         L.orc_render_prb_backward.argtypes = [C.c_void_p, C.POINTER(Sensor), c_f32p, C.c_uint32, C.c_uint32,
                                               C.c_int32, C.c_int32, c_f32p, C.POINTER(c_f32p),
@@ -201,6 +216,48 @@ class T:
 #  Scene container: owns numpy arrays + the ctypes description
 # --------------------------------------------------------------------------
 
+class Hier2D:
+    """Hierarchical2D<Float, 0> (distr_2d.h:370-860)"""
+    def __init__(self, data, normalize=True):
+        data = f32(data); assert data.ndim == 2
+        self.h = lib().orc_hier2d_create(fp(data), data.shape[1], data.shape[0], int(normalize))
+        assert self.h
+    def __del__(self):
+        if getattr(self, "h", None): lib().orc_hier2d_destroy(self.h)
+    def _run(self, fn, x):
+        x = f32(x).reshape(-1, 2); out = np.empty_like(x); pdf = np.empty(len(x), np.float32)
+        fn(self.h, len(x), fp(x), fp(out), fp(pdf)); return out, pdf
+    def sample(self, s): return self._run(lib().orc_hier2d_sample, s)
+    def invert(self, p): return self._run(lib().orc_hier2d_invert, p)
+    def eval(self, p):
+        p = f32(p).reshape(-1, 2); pdf = np.empty(len(p), np.float32); lib().orc_hier2d_eval(self.h, len(p), fp(p), fp(pdf)); return pdf
+    def storage(self):
+        n = C.c_uint32(); size = lib().orc_hier2d_data(self.h, None, None, C.byref(n))
+        data = np.empty(size, np.float32); table = np.empty((n.value, 3), np.uint32)
+        lib().orc_hier2d_data(self.h, fp(data), up(table), C.byref(n)); return data, table
+
+
+IDENTITY12 = [1, 0, 0, 0, 1, 0, 0, 0, 1, 0, 0, 0]
+
+
+class EnvMap:
+    """EnvironmentMapEmitter (src/emitters/envmap.cpp) on an H x W x 3 image"""
+    def __init__(self, rgb, scale=1.0, mis_compensation=False, to_world=IDENTITY12, to_local=IDENTITY12):
+        rgb = f32(rgb); assert rgb.ndim == 3 and rgb.shape[2] == 3
+        self.h = lib().orc_envmap_create(fp(rgb), rgb.shape[1], rgb.shape[0], scale, int(mis_compensation), fp(f32(to_world)), fp(f32(to_local)))
+    def __del__(self):
+        if getattr(self, "h", None): lib().orc_envmap_destroy(self.h)
+    def set_bsphere(self, center, radius): lib().orc_envmap_set_bsphere(self.h, fp(f32(center)), radius)
+    def eval(self, d):
+        d = f32(d).reshape(-1, 3); out = np.empty_like(d); lib().orc_envmap_eval(self.h, len(d), fp(d), fp(out)); return out
+    def pdf_direction(self, d):
+        d = f32(d).reshape(-1, 3); out = np.empty(len(d), np.float32); lib().orc_envmap_pdf_direction(self.h, len(d), fp(d), fp(out)); return out
+    def sample_direction(self, ref_p, sample):
+        sample = f32(sample).reshape(-1, 2); n = len(sample); p = f32(np.broadcast_to(f32(ref_p).reshape(-1, 3), (n, 3)))
+        d = np.empty((n, 3), np.float32); dist = np.empty(n, np.float32); pdf = np.empty(n, np.float32); w = np.empty((n, 3), np.float32)
+        lib().orc_envmap_sample_direction(self.h, n, fp(p), fp(sample), fp(d), fp(dist), fp(pdf), fp(w)); return d, dist, pdf, w
+
+
 class SceneData:
     """Flat scene description (numpy-backed) usable for BOTH the oracle and the
     product: `desc(cls)` re-emits it with the given ctypes struct classes."""
@@ -258,6 +315,7 @@ class SceneData:
             ems[i].to_world = (C.c_float * 12)(*[float(x) for x in e["to_world"]])
             ems[i].normal = (C.c_float * 3)(*[float(x) for x in e["normal"]])
             ems[i].inv_area = float(e["inv_area"])
+            ems[i].to_local = (C.c_float * 12)(*[float(x) for x in e.get("to_local", [1, 0, 0, 0, 1, 0, 0, 0, 1, 0, 0, 0])])
         d = SD()
         d.meshes = meshes; d.mesh_count = len(self.meshes); d.top_mesh_count = self.top_mesh_count
         d.groups = groups; d.group_count = len(self.groups)
