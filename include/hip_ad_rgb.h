@@ -87,12 +87,15 @@ typedef struct HarTexture { const float *data; uint32_t width, height; } HarText
  * type 1: ConstantBackgroundEmitter (src/emitters/constant.cpp): only `radiance` is read, at most one per scene.
  * The order of the array is the order of Scene::emitters() (children in declaration order, scene.cpp:40-70). */
 typedef struct HarEmitter {
-    uint32_t type;        /* 0 = area, 1 = constant */
+    uint32_t type;        /* 0 = area (src/emitters/area.cpp on a rectangle), 1 = constant (src/emitters/constant.cpp),
+                             2 = envmap (src/emitters/envmap.cpp): mesh = index of the H x W x 3 lat-long radiance image in `textures`,
+                             radiance[0] = scale, radiance[1] = mis_compensation (0 / 1), to_world / to_local = emitter transform */
     uint32_t mesh;
     float radiance[3];
     float to_world[12];   /* column-major 3x4 */
     float normal[3];
     float inv_area;
+    float to_local[12];   /* inverse of to_world as the reference's Transform tracks it (type 2 only) */
 } HarEmitter;
 
 typedef struct HarSceneDesc {
@@ -309,10 +312,15 @@ void har_mesh_free(HarMeshData *mesh);
 
 /* ------------------------------------------------------------------------
  *  Image files (host side): HDRFilm::write (src/films/hdrfilm.cpp:414-560) -> Bitmap::write.  image = H x W x C float32.
- *  EXR: OpenEXR 2 scanline, uncompressed, FLOAT channels R, G, B [, A]; PFM: "PF"/"Pf", little endian.
+ *  EXR: OpenEXR 2 scanline, uncompressed, FLOAT channels R, G, B [, A] or Y; PFM: "PF"/"Pf", little endian.
  * ---------------------------------------------------------------------- */
 int  har_image_write_exr(const char *filename, const float *image, uint32_t width, uint32_t height, uint32_t channels);
 int  har_image_write_pfm(const char *filename, const float *image, uint32_t width, uint32_t height, uint32_t channels);
+/* Bitmap(filename) (src/core/bitmap.cpp read_exr / read_pfm) for the environment-map emitter: scanline OpenEXR (NO / ZIPS / ZIP compression,
+ * HALF / FLOAT / UINT channels R G B [A] or Y) and PFM -> malloc'ed H x W x C float32, C = 1, 3 or 4 */
+typedef struct HarImage { float *data; uint32_t width, height, channels, reserved; } HarImage;
+int  har_image_read(const char *filename, HarImage *out);
+void har_image_free(HarImage *image);
 
 #ifdef __cplusplus
 }

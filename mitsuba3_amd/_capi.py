@@ -50,6 +50,10 @@ class HarMeshData(C.Structure):
     _fields_ = [("vertices", f32p), ("faces", u32p), ("vertex_count", C.c_uint32), ("face_count", C.c_uint32), ("flags", C.c_uint32), ("reserved", C.c_uint32)]
 
 
+class HarImage(C.Structure):
+    _fields_ = [("data", f32p), ("width", C.c_uint32), ("height", C.c_uint32), ("channels", C.c_uint32), ("reserved", C.c_uint32)]
+
+
 class HarSceneDesc(C.Structure):
     _fields_ = [("meshes", C.POINTER(HarMesh)), ("mesh_count", C.c_uint32), ("top_mesh_count", C.c_uint32),
                 ("groups", C.POINTER(HarShapeGroup)), ("group_count", C.c_uint32), ("pad0", C.c_uint32),
@@ -92,6 +96,8 @@ SIGNATURES = {
     "har_bsdf_sample": (C.c_int, [vp, C.c_uint32, C.c_uint32, vp, vp, vp, vp, vp, vp, vp, vp]),
     "har_image_write_exr": (C.c_int, [C.c_char_p, vp, C.c_uint32, C.c_uint32, C.c_uint32]),
     "har_image_write_pfm": (C.c_int, [C.c_char_p, vp, C.c_uint32, C.c_uint32, C.c_uint32]),
+    "har_image_read": (C.c_int, [C.c_char_p, vp]),
+    "har_image_free": (None, [vp]),
     "har_integrator_set_replay_cache": (C.c_int, [vp, C.c_int]),
     "har_mesh_load_ply": (C.c_int, [C.c_char_p, C.c_int, C.c_int, f32p, C.c_int, vp]),
     "har_mesh_load_obj": (C.c_int, [C.c_char_p, C.c_int, C.c_int, f32p, C.c_int, vp]),

@@ -9,6 +9,7 @@ used for device memory, streams and torch.distributed only.
 """
 import ctypes as C
 import math
+import os
 
 import numpy as np
 
@@ -617,6 +618,33 @@ class ConstantEmitter:
         self.radiance = _rgb_value(rad, 1.0, bounded=False)
 
 
+class EnvmapEmitter:
+    """EnvironmentMapEmitter (src/emitters/envmap.cpp): lat-long radiance image, importance sampled by luminance * sin(theta)."""
+
+    def __init__(self, props):
+        if 'bitmap' in props:
+            if 'filename' in props:
+                raise RuntimeError("Cannot specify both \"bitmap\" and \"filename\".")
+            b = props['bitmap']
+            if not isinstance(b, Bitmap):
+                raise RuntimeError("Property \"bitmap\" must be a Bitmap instance.")
+        elif 'filename' in props:
+            b = Bitmap(props['filename'])
+        else:
+            raise RuntimeError("envmap: one of \"filename\" / \"bitmap\" is required")
+        a = b.data
+        if a.shape[2] == 1:                                  # Bitmap::convert(PixelFormat::RGB): luminance is replicated
+            a = np.repeat(a, 3, axis=2)
+        elif a.shape[2] == 4:
+            a = a[:, :, :3]
+        elif a.shape[2] != 3:
+            raise RuntimeError("envmap: unsupported channel count %d" % a.shape[2])
+        self.data = np.ascontiguousarray(a, np.float32)
+        self.scale = float(props.get('scale', 1.0))
+        self.mis_compensation = bool(props.get('mis_compensation', False))
+        self.to_world = props.get('to_world', ScalarTransform4f())
+
+
 class ShapeGroup:
     def __init__(self, shapes):
         self.shapes = shapes
@@ -753,6 +781,13 @@ class Bitmap:
     """Bitmap (src/core/bitmap.cpp) restricted to what HDRFilm::write needs: float32 H x W x {1,3,4}, write() to .exr / .pfm"""
 
     def __init__(self, array):
+        if isinstance(array, (str, os.PathLike)):             # Bitmap(filename): OpenEXR (NO / ZIPS / ZIP) and PFM, read by the C++ host library
+            img = _capi.HarImage()
+            check(lib().har_image_read(str(array).encode(), C.byref(img)))
+            try:
+                array = np.ctypeslib.as_array(img.data, shape=(img.height, img.width, img.channels)).copy()
+            finally:
+                lib().har_image_free(C.byref(img))
         if hasattr(array, 'detach'):
             array = array.detach().cpu().numpy()
         a = _f32(array)
@@ -809,14 +844,19 @@ class Scene:
         # Scene::emitters() order = declaration order of the children (scene.cpp:40-70): shapes with an area emitter and
         # stand-alone emitters; the uniform emitter selection of sample_emitter() depends on it
         self._emitter_order = [key for key, obj in children.items()
-                               if (isinstance(obj, Mesh) and obj.emitter is not None) or isinstance(obj, ConstantEmitter)]
+                               if (isinstance(obj, Mesh) and obj.emitter is not None) or isinstance(obj, (ConstantEmitter, EnvmapEmitter))]
         self.emitters = [None] * len(self._emitter_order)
-        if sum(isinstance(o, ConstantEmitter) for o in children.values()) > 1:
+        if sum(isinstance(o, (ConstantEmitter, EnvmapEmitter)) for o in children.values()) > 1:
             raise RuntimeError("Only one environment emitter can be specified per scene.")
         for key, obj in children.items():
             if isinstance(obj, ConstantEmitter):
                 self.emitters[self._emitter_order.index(key)] = dict(type=1, mesh=0xffffffff, radiance=obj.radiance, to_world=[0.0] * 12,
                                                                      normal=[0.0] * 3, inv_area=0.0)
+            elif isinstance(obj, EnvmapEmitter):                # the radiance image travels in the texture table
+                self.emitters[self._emitter_order.index(key)] = dict(
+                    type=2, mesh=len(self.textures), radiance=[obj.scale, 1.0 if obj.mis_compensation else 0.0, 0.0],
+                    to_world=obj.to_world.col_major_3x4(), to_local=obj.to_world.inverse().col_major_3x4(), normal=[0.0] * 3, inv_area=0.0)
+                self.textures.append(obj.data)
         for key, obj in children.items():
             if isinstance(obj, BSDF):
                 named[key] = obj
@@ -912,6 +952,7 @@ class Scene:
             ems[i].radiance = (C.c_float * 3)(*[float(x) for x in e["radiance"]])
             ems[i].to_world = (C.c_float * 12)(*[float(x) for x in e["to_world"]])
             ems[i].normal = (C.c_float * 3)(*[float(x) for x in e["normal"]]); ems[i].inv_area = float(e["inv_area"])
+            ems[i].to_local = (C.c_float * 12)(*[float(x) for x in e.get("to_local", [1, 0, 0, 0, 1, 0, 0, 0, 1, 0, 0, 0])])
         d = M.HarSceneDesc()
         d.meshes = meshes; d.mesh_count = len(self.meshes); d.top_mesh_count = self.top_mesh_count
         d.groups = groups; d.group_count = len(self.groups)
@@ -1091,7 +1132,7 @@ def _mk_scene(props, named, key):
         if k == 'type' or k in children:
             continue
         obj = _resolve(v, named, k) if isinstance(v, dict) else v
-        if isinstance(obj, (Mesh, Sensor, Integrator, BSDF, ShapeGroup, Instance, ConstantEmitter)):
+        if isinstance(obj, (Mesh, Sensor, Integrator, BSDF, ShapeGroup, Instance, ConstantEmitter, EnvmapEmitter)):
             if isinstance(obj, ShapeGroup):
                 named[k] = obj
             children[k] = obj
@@ -1165,7 +1206,7 @@ for _name, _fn in {
     'hdrfilm': lambda p, n, k: Film(p),
     'independent': lambda p, n, k: Sampler(p),
     'diffuse': lambda p, n, k: BSDF(p, id=k), 'dielectric': lambda p, n, k: BSDF(p, id=k), 'roughconductor': lambda p, n, k: BSDF(p, id=k),
-    'roughplastic': lambda p, n, k: BSDF(p, id=k), 'twosided': _mk_twosided, 'constant': lambda p, n, k: ConstantEmitter(p),
+    'roughplastic': lambda p, n, k: BSDF(p, id=k), 'twosided': _mk_twosided, 'constant': lambda p, n, k: ConstantEmitter(p), 'envmap': lambda p, n, k: EnvmapEmitter(p),
     'rectangle': lambda p, n, k: _shape_common(_rectangle(p), p, n),
     'cube': lambda p, n, k: _shape_common(_cube(p), p, n),
     'mesh': _mk_mesh, 'ply': _mk_ply, 'obj': _mk_obj, 'serialized': _mk_serialized,

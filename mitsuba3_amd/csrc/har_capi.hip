@@ -255,6 +255,12 @@ int har_scene_create(const HarSceneDesc *desc, HarScene *out) {
     }
     up(dt, &D.textures);
     up(hs.bsdf_tables, &D.bsdf_tables);
+    D.envmap = nullptr;
+    if (hs.has_envmap) {
+        const float *tex = nullptr, *warp = nullptr; up(hs.env_tex, &tex); up(hs.env_warp, &warp);
+        hs.envmap.tex = tex; hs.envmap.warp = warp;
+        std::vector<DEnvmap> one(1, hs.envmap); up(one, &D.envmap);
+    }
     if (err != hipSuccess) { for (void *p : S->owned) (void) hipFree(p); delete S; return fail(std::string("scene upload: ") + hipGetErrorString(err)); }
     S->d_bsdfs = const_cast<DBsdf *>(D.bsdfs);
     D.accel.root = hs.root; D.accel.has_tlas = hs.has_tlas; D.accel.n_tris = (uint32_t) hs.tris.size(); D.accel.n_insts = (uint32_t) hs.inst_recs.size();
@@ -262,6 +268,7 @@ int har_scene_create(const HarSceneDesc *desc, HarScene *out) {
     D.n_bsdfs = (uint32_t) hs.bsdfs.size(); D.n_textures = (uint32_t) hs.textures.size();
     D.env_emitter = hs.env_emitter;
     D.bsdf_types = 0; for (const DBsdf &b : hs.bsdfs) D.bsdf_types |= (1u << b.type) | ((b.flags & BF_TWOSIDED) ? 0x80000000u : 0u);
+    if (hs.has_envmap) D.bsdf_types |= HAR_SCENE_ENVMAP;
     if (hs.stack_need() + HAR_STACK_MARGIN > HAR_LDS_STACK_DEPTH)
         fprintf(stderr, "[hip_ad_rgb] warning: BVH needs %u traversal stack entries, LDS stack holds %d (overflow is reported as an error)\n", hs.stack_need(), HAR_LDS_STACK_DEPTH);
     *out = S;

@@ -707,9 +707,12 @@ void launch_shade(int mode, hipStream_t s, uint32_t grid, const DScene &S, const
     /* diffuse-only scenes (no twosided wrappers) run kernels in which the other BSDF models are compiled out */
     const bool only_diffuse = S.bsdf_types == HAR_BSDF_ONLY_DIFFUSE;
 #define HAR_LAUNCH_SHADE(M, T) hipLaunchKernelGGL((k_shade<M, T>), g, b, 0, s, S, P, lane_base, shard_cap, count_in, in, h0, h1, out, count_out, items, item_count, result, rc, pass_rng)
-    if (mode == MODE_PATH)            { if (only_diffuse) HAR_LAUNCH_SHADE(MODE_PATH, HAR_BSDF_ONLY_DIFFUSE); else HAR_LAUNCH_SHADE(MODE_PATH, HAR_BSDF_ALL_TYPES); }
-    else if (mode == MODE_PRB_PRIMAL) { if (only_diffuse) HAR_LAUNCH_SHADE(MODE_PRB_PRIMAL, HAR_BSDF_ONLY_DIFFUSE); else HAR_LAUNCH_SHADE(MODE_PRB_PRIMAL, HAR_BSDF_ALL_TYPES); }
-    else                              { if (only_diffuse) HAR_LAUNCH_SHADE(MODE_PRB_ADJOINT, HAR_BSDF_ONLY_DIFFUSE); else HAR_LAUNCH_SHADE(MODE_PRB_ADJOINT, HAR_BSDF_ALL_TYPES); }
+    const bool envmap = (S.bsdf_types & HAR_SCENE_ENVMAP) != 0u;      /* generic BSDF code + environment-map sampling / lookup */
+#define HAR_LAUNCH_SHADE_MODE(M) do { if (envmap) HAR_LAUNCH_SHADE(M, HAR_BSDF_ALL_TYPES | HAR_SCENE_ENVMAP); else if (only_diffuse) HAR_LAUNCH_SHADE(M, HAR_BSDF_ONLY_DIFFUSE); else HAR_LAUNCH_SHADE(M, HAR_BSDF_ALL_TYPES); } while (0)
+    if (mode == MODE_PATH)            HAR_LAUNCH_SHADE_MODE(MODE_PATH);
+    else if (mode == MODE_PRB_PRIMAL) HAR_LAUNCH_SHADE_MODE(MODE_PRB_PRIMAL);
+    else                              HAR_LAUNCH_SHADE_MODE(MODE_PRB_ADJOINT);
+#undef HAR_LAUNCH_SHADE_MODE
 #undef HAR_LAUNCH_SHADE
 }
 void launch_resolve(int mode, hipStream_t s, uint32_t grid, int stack_class, const DScene &S, const uint32_t *item_count, uint32_t *cursor, uint32_t shard_cap, const ItemArrays &items,

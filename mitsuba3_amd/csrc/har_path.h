@@ -106,14 +106,16 @@ HAR_HD void shade_lane(const DScene &S, const ShadeParams &P, const PathState &s
     /* ---- direct emission + MIS with the previous BSDF sample (path.cpp:206-221, prb.py:148-161) */
     if (emitter >= 0) {
         const DEmitter E = S.emitters[emitter];
-        const bool env = E.type == 1u;
+        const bool env = E.type != 0u;
+        const bool envmap = (TYPES & HAR_SCENE_ENVMAP) != 0u && E.type == 2u;      /* kernels of scenes without an environment map compile this out */
         Vec3 rel = si.p - st.prev_p;
         float dist = norm3(rel);
         Vec3 dd = div3(rel, dist);
         /* pdf_direction: area light (area.cpp:170-197) or uniform sphere (constant.cpp:155-160) */
-        float em_pdf = prev_delta ? 0.f : (env ? HAR_INV_FOUR_PI : emitter_pdf_direction(E, dd, si.sn, dist)) * pmf;
+        float em_pdf = prev_delta ? 0.f : (envmap ? envmap_pdf_direction(*S.envmap, st.d) : env ? HAR_INV_FOUR_PI : emitter_pdf_direction(E, dd, si.sn, dist)) * pmf;
         float mis = mis_weight(st.prev_bsdf_pdf, em_pdf);
         Vec3 rad(E.radiance[0], E.radiance[1], E.radiance[2]);
+        if (envmap) rad = envmap_eval(*S.envmap, st.d);                              /* envmap.cpp:228-236: v = to_world^-1 * (-si.wi) */
         const bool facing = env || si.wi.z > 0.f;                                      /* area.cpp:83-90 / constant.cpp:90-94 */
         if (MODE == MODE_PATH) {
             Vec3 Le = (facing && st.prev_bsdf_pdf > 0.f) ? rad : Vec3(0.f);
@@ -149,7 +151,8 @@ HAR_HD void shade_lane(const DScene &S, const ShadeParams &P, const PathState &s
             index = (uint32_t) scaled; if (index > S.n_emitters - 1u) index = S.n_emitters - 1u;
             wgt = (float) S.n_emitters; ex = scaled - (float) index;
         }
-        emitter_sample_direction(S.emitters[index], si.p, ex, ey, ds, em_weight);
+        if ((TYPES & HAR_SCENE_ENVMAP) != 0u && S.emitters[index].type == 2u) envmap_sample_direction(*S.envmap, si.p, ex, ey, ds, em_weight);
+        else emitter_sample_direction(S.emitters[index], si.p, ex, ey, ds, em_weight);
         ds.pdf *= pmf; em_weight = em_weight * wgt;
         active_em = ds.pdf != 0.f;
     }

@@ -17,6 +17,17 @@ struct DTexture { const float *data; uint32_t w, h; };
  * (src/emitters/constant.cpp): to_world[0..2] = bounding sphere centre, to_world[3] = radius, mesh = 0xffffffff */
 struct DEmitter { float radiance[3]; float inv_area; float to_world[12]; float normal[3]; uint32_t mesh; uint32_t type; };
 struct DInst    { float to_world[12]; float to_object[12]; };
+/* EnvironmentMapEmitter (src/emitters/envmap.cpp), emitter type 2.  `tex` = H x (W + 2) x 3 radiance with one halo column on each side
+ * (:140-172), `warp` = storage of the Hierarchical2D<Float, 0> over the (W + 1) x H luminance * sin(theta) grid (distr_2d.h:405-560):
+ * level 0 row-major, levels >= 1 in 2 x 2 blocks; lvl_offset / lvl_width index it. */
+#define HAR_ENV_MAX_LEVELS 18
+struct DEnvmap {
+    const float *tex, *warp;
+    uint32_t w, h, n_levels; float scale;
+    float to_world[12], to_local[12];       /* column-major 3 x 4 */
+    float center[3], radius;                /* scene bounding sphere (set_scene, :214-226) */
+    uint32_t lvl_offset[HAR_ENV_MAX_LEVELS], lvl_width[HAR_ENV_MAX_LEVELS];
+};
 
 struct DScene {
     Accel accel;
@@ -32,6 +43,7 @@ struct DScene {
     uint32_t n_emitters, n_meshes, n_bsdfs, n_textures;
     int32_t  env_emitter;              /* index of the environment emitter (Scene::environment()), or -1 */
     uint32_t bsdf_types;               /* bit mask (1 << type) of the BSDF types present (+ bit 31: some record is twosided) */
+    const DEnvmap *envmap;             /* device record of the environment map when emitters[env_emitter].type == 2 */
 };
 
 struct DSensor {
@@ -209,6 +221,100 @@ HAR_HD Vec3 square_to_uniform_sphere(float sx, float sy) {
     float s, c; sincos_(2.f * HAR_PI * sx, s, c);
     return Vec3(r * c, r * s, z);
 }
+/* ---- environment map (src/emitters/envmap.cpp) ------------------------------------------------------------------------- */
+HAR_HD float clip01_(float x) { return fminf(fmaxf(x, 0.f), 1.f); }
+/* warp::interval_to_linear (include/mitsuba/core/warp.h:446-453) */
+HAR_HD float interval_to_linear(float v0, float v1, float sample) {
+    if (fabsf(v0 - v1) > 1e-4f * (v0 + v1))
+        return (v0 - sqrtf(fmaxf(lerp_(v0 * v0, v1 * v1, sample), 0.f))) / (v0 - v1);
+    return sample;
+}
+HAR_HD uint32_t hier_index(uint32_t x, uint32_t y, uint32_t width) { return ((x & 1u) | (((x & ~1u) | (y & 1u)) << 1)) + ((y & ~1u) * width); }
+/* Hierarchical2D<Float, 0>::sample (distr_2d.h:520-600) + warp::square_to_bilinear (warp.h:478-494) */
+HAR_HD void hier2d_sample(const DEnvmap &E, float sx, float sy, float &u, float &v, float &pdf) {
+    sx = clip01_(sx); sy = clip01_(sy);
+    uint32_t ox = 0, oy = 0;
+    for (int l = (int) E.n_levels - 1; l > 0; --l) {
+        ox <<= 1; oy <<= 1;
+        const float *q = E.warp + (((E.lvl_offset[l] + hier_index(ox, oy, E.lvl_width[l])) >> 2) << 2);
+        const float v00 = q[0], v10 = q[1], v01 = q[2], v11 = q[3];
+        sx = clip01_(sx); sy = clip01_(sy);
+        const float r0 = v00 + v10, r1 = v01 + v11;
+        sy *= r0 + r1;
+        const bool ym = sy > r0;
+        if (ym) { oy += 1u; sy -= r0; }
+        const float dy = ym ? r1 : r0, c0 = ym ? v01 : v00, c1 = ym ? v11 : v10;
+        sx *= dy;
+        const bool xm = sx > c0;
+        if (xm) { sx -= c0; ox += 1u; }
+        const float dx = xm ? c1 : c0;
+        const float inv = rcp_(dy * dx);
+        sy *= dx * inv; sx *= dy * inv;
+    }
+    const uint32_t W0 = E.lvl_width[0];
+    const float *d = E.warp + E.lvl_offset[0] + ox + oy * W0;
+    const float v00 = d[0], v10 = d[1], v01 = d[W0], v11 = d[W0 + 1];
+    const float r0 = v00 + v10, r1 = v01 + v11;
+    sy = interval_to_linear(r0, r1, sy);
+    const float c0 = lerp_(v00, v01, sy), c1 = lerp_(v10, v11, sy);
+    sx = interval_to_linear(c0, c1, sx);
+    pdf = lerp_(c0, c1, sx);
+    u = ((float) (int32_t) ox + sx) * (1.f / (float) E.w);                  /* m_patch_size = 1 / (size - 1), size = (W + 1, H) */
+    v = ((float) (int32_t) oy + sy) * (1.f / (float) (E.h - 1u));
+}
+/* Hierarchical2D::eval (distr_2d.h:700-725) */
+HAR_HD float hier2d_eval(const DEnvmap &E, float px, float py) {
+    px = clip01_(px) * (float) E.w; py = clip01_(py) * (float) (E.h - 1u);
+    uint32_t ox = (uint32_t) (int32_t) px, oy = (uint32_t) (int32_t) py;
+    if (ox > E.w - 1u) ox = E.w - 1u;
+    if (oy > E.h - 2u) oy = E.h - 2u;
+    px -= (float) (int32_t) ox; py -= (float) (int32_t) oy;
+    const uint32_t W0 = E.lvl_width[0];
+    const float *d = E.warp + E.lvl_offset[0] + ox + oy * W0;
+    return lerp_(lerp_(d[0], d[1], px), lerp_(d[W0], d[W0 + 1], px), py);
+}
+/* eval_spectrum, RGB branch (envmap.cpp:531-548,589-597): dr::Texture bilinear lookup with WrapMode::Clamp on the halo'ed storage */
+HAR_HD Vec3 envmap_eval_uv(const DEnvmap &E, float u_, float v_) {
+    const float rx = (float) E.w, ry = (float) E.h;
+    const float u = u_ - floorf(u_), v = clip01_(v_);
+    const float pos_x = fma_(u, rx, 1.f) / (rx + 2.f), pos_y = fma_(v, ry - 1.f, 0.5f) / ry;
+    const int32_t sw = (int32_t) E.w + 2, H = (int32_t) E.h;
+    const float px = fma_(pos_x, (float) sw, -0.5f), py = fma_(pos_y, ry, -0.5f);
+    const float fx = floorf(px), fy = floorf(py);
+    const int32_t ix = (int32_t) fx, iy = (int32_t) fy;
+    const float w1x = px - fx, w1y = py - fy, w0x = 1.f - w1x, w0y = 1.f - w1y;
+    const int32_t x0 = ix < 0 ? 0 : (ix > sw - 1 ? sw - 1 : ix), x1 = ix + 1 < 0 ? 0 : (ix + 1 > sw - 1 ? sw - 1 : ix + 1),
+                  y0 = iy < 0 ? 0 : (iy > H - 1 ? H - 1 : iy), y1 = iy + 1 < 0 ? 0 : (iy + 1 > H - 1 ? H - 1 : iy + 1);
+    const float *p00 = E.tex + 3 * ((size_t) y0 * sw + x0), *p10 = E.tex + 3 * ((size_t) y0 * sw + x1),
+                *p01 = E.tex + 3 * ((size_t) y1 * sw + x0), *p11 = E.tex + 3 * ((size_t) y1 * sw + x1);
+    float out[3];
+    for (int c = 0; c < 3; ++c) {
+        const float a = fma_(w0x, p00[c], w1x * p10[c]), b = fma_(w0x, p01[c], w1x * p11[c]);
+        out[c] = fma_(w0y, a, w1y * b) * E.scale;
+    }
+    return Vec3(out[0], out[1], out[2]);
+}
+HAR_HD void envmap_direction_to_uv(Vec3 d, float &u, float &v) {                                   /* envmap.cpp:454-459 */
+    u = atan2f(d.x, -d.z) * (0.5f * HAR_INV_PI);
+    v = acosf(fminf(fmaxf(d.y, -1.f), 1.f)) * HAR_INV_PI;
+}
+/* EnvironmentMapEmitter::eval (envmap.cpp:228-236): radiance arriving along world direction d (= -si.wi of the escaping ray) */
+HAR_HD Vec3 envmap_eval(const DEnvmap &E, Vec3 d_world) {
+    float u, v; envmap_direction_to_uv(xf_vector(E.to_local, d_world), u, v);
+    return envmap_eval_uv(E, u, v);
+}
+/* EnvironmentMapEmitter::pdf_direction (envmap.cpp:325-339) */
+HAR_HD float envmap_pdf_direction(const DEnvmap &E, Vec3 d_world) {
+    const Vec3 d = xf_vector(E.to_local, d_world);
+    float u, v; envmap_direction_to_uv(d, u, v);
+    u -= .5f / (float) E.w;
+    u -= floorf(u); v -= floorf(v);
+    const float inv_sin_theta = rsqrt_(fmaxf(d.x * d.x + d.z * d.z, 0x1p-24f * 0x1p-24f));
+    return hier2d_eval(E, u, v) * inv_sin_theta * (1.f / (2.f * (HAR_PI * HAR_PI)));
+}
+/* EnvironmentMapEmitter::sample_direction (envmap.cpp:284-323) */
+HAR_HD void envmap_sample_direction(const DEnvmap &E, Vec3 ref_p, float sx, float sy, struct DirSample &ds, Vec3 &spec);
+
 HAR_HD void emitter_sample_direction(const DEmitter &E, Vec3 ref_p, float sx, float sy, DirSample &ds, Vec3 &spec) {
     if (E.type == 1u) {                                     /* ConstantBackgroundEmitter::sample_direction, constant.cpp:127-153 */
         Vec3 d = square_to_uniform_sphere(sx, sy);
@@ -230,6 +336,20 @@ HAR_HD void emitter_sample_direction(const DEmitter &E, Vec3 ref_p, float sx, fl
     ds.pdf *= finite_(x) ? x : 0.f;
     bool active = dot3(ds.d, ds.n) < 0.f && ds.pdf != 0.f;
     spec = active ? div3(Vec3(E.radiance[0], E.radiance[1], E.radiance[2]), ds.pdf) : Vec3(0.f);
+}
+HAR_HD void envmap_sample_direction(const DEnvmap &E, Vec3 ref_p, float sx, float sy, DirSample &ds, Vec3 &spec) {
+    float u, v, pdf; hier2d_sample(E, sx, sy, u, v, pdf);
+    u += .5f / (float) E.w;
+    const bool active = pdf > 0.f;
+    float st, ct, sp, cp; sincos_(v * HAR_PI, st, ct); sincos_(u * (2.f * HAR_PI), sp, cp);
+    const float inv_sin_theta = rcp_(fmaxf(st, 0x1p-24f));
+    const Vec3 dl(sp * st, ct, -cp * st);
+    const Vec3 c(E.center[0], E.center[1], E.center[2]);
+    const float radius = fmaxf(E.radius, norm3(ref_p - c)), dist = 2.f * radius;
+    const Vec3 d = xf_vector(E.to_world, dl);
+    ds.p = fma3(d, dist, ref_p); ds.n = -d; ds.d = d; ds.dist = dist;
+    ds.pdf = active ? pdf * inv_sin_theta * (1.f / (2.f * (HAR_PI * HAR_PI))) : 0.f;
+    spec = active ? div3(envmap_eval_uv(E, u, v), ds.pdf) : Vec3(0.f);
 }
 /* AreaLight::pdf_direction (area.cpp:170-197) / Shape::pdf_direction (shape.cpp:112-124) */
 HAR_HD float emitter_pdf_direction(const DEmitter &E, Vec3 d, Vec3 n, float dist) {

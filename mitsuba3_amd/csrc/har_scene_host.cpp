@@ -130,6 +130,75 @@ void update_roughplastic_sampling_weight(HostScene &hs, uint32_t index) {
     b.spec_sampling_weight = s_mean / (d_mean + s_mean);
 }
 
+/* EnvironmentMapEmitter ctor (src/emitters/envmap.cpp:113-180) + rebuild_distribution (:476-529) + Hierarchical2D<Float, 0> ctor
+ * (include/mitsuba/core/distr_2d.h:405-515): the radiance image is padded to >= 2 x 3 (Bitmap::pad_to), stored with one halo column per side,
+ * and the (W + 1) x H grid of luminance * sin(theta) becomes a normalised bilinear interpolant with a MIP pyramid of 2 x 2-blocked sums. */
+static bool build_envmap(HostScene &hs, const HarTexture &img, const HarEmitter &e, std::string &err) {
+    if (!img.data || img.width == 0 || img.height == 0) { err = "envmap: empty bitmap"; return false; }
+    DEnvmap &E = hs.envmap;
+    const uint32_t W = std::max(img.width, 2u), H = std::max(img.height, 3u), sw = W + 2;
+    E.w = W; E.h = H; E.scale = e.radiance[0];
+    std::memcpy(E.to_world, e.to_world, 48); std::memcpy(E.to_local, e.to_local, 48);
+    E.center[0] = E.center[1] = E.center[2] = 0.f; E.radius = 1.f;
+    std::vector<float> &T = hs.env_tex; T.assign((size_t) H * sw * 3, 0.f);
+    for (uint32_t y = 0; y < H; ++y) {
+        float *row = T.data() + 3 * (size_t) y * sw;
+        for (uint32_t x = 0; x < W; ++x) std::memcpy(row + 3 * (x + 1), img.data + 3 * ((size_t) std::min(y, img.height - 1) * img.width + std::min(x, img.width - 1)), 12);
+        std::memcpy(row, row + 3 * W, 12); std::memcpy(row + 3 * (W + 1), row + 3, 12);          /* refresh_halo */
+    }
+    const uint32_t rx = W + 1, ry = H;
+    std::vector<float> lum((size_t) rx * ry);
+    for (uint32_t y = 0; y < ry; ++y)
+        for (uint32_t x = 0; x < rx; ++x) { const float *c = T.data() + 3 * ((size_t) y * sw + x + 1); lum[(size_t) y * rx + x] = c[0] * 0.212671f + c[1] * 0.715160f + c[2] * 0.072169f; }
+    float offset = 0.f;
+    if (e.radiance[1] != 0.f) {         /* mis_compensation (Karlik et al. 2019) */
+        float min_lum = INFINITY; double acc = 0.0;
+        for (uint32_t y = 0; y < ry; ++y) for (uint32_t x = 0; x + 1 < rx; ++x) { float l = lum[(size_t) y * rx + x]; min_lum = std::min(min_lum, l); acc += (double) l; }
+        offset = (float) (acc / (double) ((size_t) (rx - 1) * ry));
+        if (offset - min_lum <= 0.01f * offset) offset = 0.f;
+    }
+    const float theta_scale = 1.f / (float) (ry - 1) * HAR_PI;
+    for (uint32_t y = 0; y < ry; ++y) {
+        const float sin_theta = std::sin((float) y * theta_scale);
+        for (uint32_t x = 0; x < rx; ++x) { float &l = lum[(size_t) y * rx + x]; l = std::max(l - offset, 0.f) * sin_theta; }
+    }
+    /* hierarchy layout */
+    const uint32_t np[2] = { rx - 1, ry - 1 };
+    uint32_t max_level = 0; while ((1u << max_level) < std::max(np[0], np[1])) ++max_level;
+    if (max_level + 1 > HAR_ENV_MAX_LEVELS) { err = "envmap: resolution too large"; return false; }
+    std::vector<uint32_t> lw, lh; lw.push_back(rx); lh.push_back(ry);
+    { uint32_t a = np[0], b = np[1]; for (uint32_t l = 0; l < max_level; ++l) { a += a & 1u; b += b & 1u; lw.push_back(a); lh.push_back(b); a >>= 1; b >>= 1; } }
+    E.n_levels = (uint32_t) lw.size();
+    uint32_t total = 0;
+    for (uint32_t l = 0; l < E.n_levels; ++l) { total = (total + 3u) & ~3u; E.lvl_offset[l] = total; E.lvl_width[l] = lw[l]; total += lw[l] * lh[l]; }
+    total = (total + 3u) & ~3u;
+    std::vector<float> &Wd = hs.env_warp; Wd.assign(total, 0.f);
+    const bool has_mip = E.n_levels > 1;
+    double sum = 0.0;
+    for (uint32_t y = 0; y < np[1]; ++y)
+        for (uint32_t x = 0; x < np[0]; ++x) {
+            const float *q = lum.data() + (size_t) y * rx + x;
+            const float avg = .25f * (q[0] + q[1] + q[rx] + q[rx + 1]);
+            sum += (double) avg;
+            if (has_mip) Wd[E.lvl_offset[1] + hier_index(x, y, E.lvl_width[1])] = avg;
+        }
+    const float scale = (float) ((double) ((uint64_t) np[0] * np[1]) / sum);
+    for (size_t i = 0; i < lum.size(); ++i) Wd[E.lvl_offset[0] + i] = lum[i] * scale;
+    if (has_mip) for (uint32_t i = 0; i < lw[1] * lh[1]; ++i) Wd[E.lvl_offset[1] + i] *= scale;
+    uint32_t cur[2] = { np[0], np[1] };
+    for (uint32_t l = 2; l < E.n_levels; ++l) {
+        cur[0] = (cur[0] + 1u) >> 1; cur[1] = (cur[1] + 1u) >> 1;
+        for (uint32_t y = 0; y < cur[1]; ++y)
+            for (uint32_t x = 0; x < cur[0]; ++x) {
+                const float *d0 = Wd.data() + E.lvl_offset[l - 1] + hier_index(2 * x, 2 * y, E.lvl_width[l - 1]);
+                Wd[E.lvl_offset[l] + hier_index(x, y, E.lvl_width[l])] = d0[0] + d0[1] + d0[2] + d0[3];
+            }
+    }
+    E.tex = nullptr; E.warp = nullptr;
+    hs.has_envmap = true;
+    return true;
+}
+
 bool lower_scene(const HarSceneDesc &d, HostScene &hs, std::string &err) {
     if (d.top_mesh_count > d.mesh_count) { err = "top_mesh_count exceeds mesh_count"; return false; }
     for (uint32_t i = 0; i < d.mesh_count; ++i) {
@@ -172,10 +241,14 @@ bool lower_scene(const HarSceneDesc &d, HostScene &hs, std::string &err) {
     }
     for (uint32_t i = 0; i < d.emitter_count; ++i) {
         const HarEmitter &e = d.emitters[i];
-        if (e.type > 1) { err = "unsupported emitter type (`area` on a rectangle and `constant` are implemented)"; return false; }
+        if (e.type > 2) { err = "unsupported emitter type (`area` on a rectangle, `constant` and `envmap` are implemented)"; return false; }
         if (e.type == 0 && e.mesh >= d.top_mesh_count) { err = "area emitter must be attached to a top-level mesh"; return false; }
-        if (e.type == 1 && hs.env_emitter >= 0) { err = "Only one environment emitter can be specified per scene."; return false; }   /* scene.cpp:64-65 */
-        if (e.type == 1) hs.env_emitter = (int32_t) i;
+        if (e.type != 0 && hs.env_emitter >= 0) { err = "Only one environment emitter can be specified per scene."; return false; }   /* scene.cpp:64-65 */
+        if (e.type != 0) hs.env_emitter = (int32_t) i;
+        if (e.type == 2) {
+            if (e.mesh >= d.texture_count) { err = "envmap emitter references a bitmap that does not exist"; return false; }
+            if (!build_envmap(hs, d.textures[e.mesh], e, err)) return false;
+        }
         DEmitter de{}; de.type = e.type;
         std::memcpy(de.radiance, e.radiance, 12); de.inv_area = e.inv_area;
         std::memcpy(de.to_world, e.to_world, 48); std::memcpy(de.normal, e.normal, 12); de.mesh = e.mesh;
@@ -212,6 +285,10 @@ bool lower_scene(const HarSceneDesc &d, HostScene &hs, std::string &err) {
             E.to_world[3] = std::max(HAR_RAY_EPS, r * (1.f + HAR_RAY_EPS));
         } else { E.to_world[0] = E.to_world[1] = E.to_world[2] = 0.f; E.to_world[3] = HAR_RAY_EPS; }
         E.mesh = 0xffffffffu;
+        if (hs.has_envmap) {            /* EnvironmentMapEmitter::set_scene (envmap.cpp:214-226): the same rule */
+            for (int a = 0; a < 3; ++a) hs.envmap.center[a] = E.to_world[a];
+            hs.envmap.radius = E.to_world[3];
+        }
     }
 
     BlasInfo top = build_blas(hs, d, 0, d.top_mesh_count);

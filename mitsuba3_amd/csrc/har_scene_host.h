@@ -25,6 +25,8 @@ struct HostScene {
     std::vector<InstRec> inst_recs;
     std::vector<uint32_t> blas_tri_ranges;
     int32_t env_emitter = -1;
+    /* environment map (emitter type 2): halo'ed radiance storage, hierarchical warp storage, record without device pointers */
+    std::vector<float> env_tex, env_warp; DEnvmap envmap{}; bool has_envmap = false;
     uint32_t root = 0;
     bool has_tlas = false;
     Bvh8Stats stats;

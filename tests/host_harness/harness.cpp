@@ -44,6 +44,8 @@ static void bind(HScene &H) {
     S.n_bsdfs = (uint32_t) hs.bsdfs.size(); S.n_textures = (uint32_t) hs.textures.size();
     S.env_emitter = hs.env_emitter;
     S.bsdf_types = 0; for (const DBsdf &b : hs.bsdfs) S.bsdf_types |= (1u << b.type) | ((b.flags & BF_TWOSIDED) ? 0x80000000u : 0u);
+    S.envmap = nullptr;
+    if (hs.has_envmap) { hs.envmap.tex = hs.env_tex.data(); hs.envmap.warp = hs.env_warp.data(); S.envmap = &hs.envmap; S.bsdf_types |= HAR_SCENE_ENVMAP; }
 }
 
 extern "C" {
@@ -127,7 +129,9 @@ int hh_render(void *h, const HarSensor *sensor, int mode, uint32_t seed, uint32_
             Hit hit; HostStack stack;
             accel_trace<false>(S.accel, st.o, st.d, st.maxt, hit, stack, status);
             ShadeResult R;
-            if (mode == MODE_PATH) shade_lane<MODE_PATH>(S, P, st, hit, R); else shade_lane<MODE_PRB_PRIMAL>(S, P, st, hit, R);
+            constexpr uint32_t ENV = HAR_BSDF_ALL_TYPES | HAR_SCENE_ENVMAP;
+            if (S.envmap) { if (mode == MODE_PATH) shade_lane<MODE_PATH, ENV>(S, P, st, hit, R); else shade_lane<MODE_PRB_PRIMAL, ENV>(S, P, st, hit, R); }
+            else if (mode == MODE_PATH) shade_lane<MODE_PATH>(S, P, st, hit, R); else shade_lane<MODE_PRB_PRIMAL>(S, P, st, hit, R);
             if (R.add_emission) result = mode == MODE_PATH ? fma3(R.em_a, R.em_b, result) : result + R.em_b;
             if (R.item && R.item_ray) {
                 Hit sh; HostStack s2;
@@ -281,4 +285,29 @@ int hh_trace_stats(void *h, const HarSensor *sensor, uint32_t seed, uint32_t spp
     return status;
 }
 
+} // extern "C"
+
+extern "C" {
+/* environment map: the product's host lowering (build_envmap) + the HAR_HD lookup / sampling code */
+void hh_envmap_storage(void *h, uint32_t *info /* w, h, n_levels, warp size */, uint32_t *table /* [n_levels][2]: width, offset */, float *warp) {
+    HScene *H = (HScene *) h; const DEnvmap &E = H->hs.envmap;
+    info[0] = E.w; info[1] = E.h; info[2] = E.n_levels; info[3] = (uint32_t) H->hs.env_warp.size();
+    if (table) for (uint32_t l = 0; l < E.n_levels; ++l) { table[2 * l] = E.lvl_width[l]; table[2 * l + 1] = E.lvl_offset[l]; }
+    if (warp) std::copy(H->hs.env_warp.begin(), H->hs.env_warp.end(), warp);
+}
+void hh_envmap_eval(void *h, uint32_t n, const float *d, float *rgb, float *pdf) {
+    const DEnvmap &E = *((HScene *) h)->ds.envmap;
+    for (uint32_t i = 0; i < n; ++i) {
+        Vec3 dd(d[3 * i], d[3 * i + 1], d[3 * i + 2]); Vec3 v = envmap_eval(E, dd);
+        rgb[3 * i] = v.x; rgb[3 * i + 1] = v.y; rgb[3 * i + 2] = v.z; pdf[i] = envmap_pdf_direction(E, dd);
+    }
+}
+void hh_envmap_sample_direction(void *h, uint32_t n, const float *p, const float *s, float *d, float *dist, float *pdf, float *weight) {
+    const DEnvmap &E = *((HScene *) h)->ds.envmap;
+    for (uint32_t i = 0; i < n; ++i) {
+        DirSample ds; Vec3 w; envmap_sample_direction(E, Vec3(p[3 * i], p[3 * i + 1], p[3 * i + 2]), s[2 * i], s[2 * i + 1], ds, w);
+        d[3 * i] = ds.d.x; d[3 * i + 1] = ds.d.y; d[3 * i + 2] = ds.d.z; dist[i] = ds.dist; pdf[i] = ds.pdf;
+        weight[3 * i] = w.x; weight[3 * i + 1] = w.y; weight[3 * i + 2] = w.z;
+    }
+}
 } // extern "C"
