@@ -20,6 +20,7 @@
 #include <cstring>
 #include <cstdlib>
 #include <limits>
+#include <string>
 
 namespace har {
 
@@ -117,7 +118,7 @@ void pad_prim_box(PrimBox &b) {
 }
 
 uint32_t build_bvh8(const std::vector<PrimBox> &prims, std::vector<Node8> &nodes, uint32_t leaf_base,
-                    std::vector<uint32_t> &leaf_order, Bvh8Stats *stats, uint32_t max_leaf) {
+                    std::vector<uint32_t> &leaf_order, Bvh8Stats *stats, uint32_t max_leaf, float prim_cost, uint32_t dp_min_prims) {
     const uint32_t root_out = (uint32_t) nodes.size();
     nodes.emplace_back();
     std::memset(&nodes[root_out], 0, sizeof(Node8));
@@ -130,6 +131,50 @@ uint32_t build_bvh8(const std::vector<PrimBox> &prims, std::vector<Node8> &nodes
     B.bn.reserve(prims.size());
     int broot = B.build(0, (uint32_t) prims.size());
 
+    /* ---- optimal wide-BVH collapse by dynamic programming over the binary tree.
+     * C(n, i) = least SAH cost of representing the subtree of binary node n by at most i roots (child slots of the parent wide node):
+     *   C(n, 1) = min(leaf: A(n) * c_prim * count,  wide node: A(n) * c_node + min_k C(left, k) + C(right, 8 - k))
+     *   C(n, i) = min(C(n, i - 1), min_k C(left, k) + C(right, i - k))
+     * dp_split[n][i] = k of the best distribution, 0 = "use i - 1 roots"; dp_split[n][1] = k of the wide node made of n. */
+    /* measured on MI355X (tools/ab_collapse.sh): +5 % paths/s on the 1M-triangle instanced scene, +1 % on the flattened one, but -5 % on the 36-triangle
+     * Cornell box, where the greedy collapse's extra, tighter nodes pay off -> small primitive sets keep the greedy collapse */
+    static const bool dp_enabled = !(getenv("HAR_BVH_COLLAPSE") && std::string(getenv("HAR_BVH_COLLAPSE")) == "greedy");
+    const bool use_dp = dp_enabled && prims.size() >= (size_t) dp_min_prims;
+    static const float c_node = getenv("HAR_BVH_CNODE") ? (float) atof(getenv("HAR_BVH_CNODE")) : 1.f;
+    const float c_prim = prim_cost;
+    std::vector<float> dp_cost; std::vector<uint8_t> dp_split;
+    if (use_dp) {
+        const size_t nb = B.bn.size();
+        dp_cost.assign(nb * 9, 0.f); dp_split.assign(nb * 9, 0);
+        /* children have larger indices than their parent (pre-order construction): a reverse sweep is a post-order traversal */
+        for (size_t n = nb; n-- > 0; ) {
+            const BNode &b = B.bn[n];
+            float *Cn = dp_cost.data() + n * 9; uint8_t *Sn = dp_split.data() + n * 9;
+            const float A = b.box.area();
+            if (b.count) { for (int i = 1; i <= 8; ++i) Cn[i] = A * c_prim * (float) b.count; continue; }
+            const float *Cl = dp_cost.data() + (size_t) b.left * 9, *Cr = dp_cost.data() + (size_t) b.right * 9;
+            float best = std::numeric_limits<float>::infinity(); int bk = 1;
+            for (int k = 1; k < 8; ++k) { float c = Cl[k] + Cr[8 - k]; if (c < best) { best = c; bk = k; } }
+            Cn[1] = A * c_node + best; Sn[1] = (uint8_t) bk;
+            for (int i = 2; i <= 8; ++i) {
+                float bi = Cn[i - 1]; int ki = 0;
+                for (int k = 1; k < i; ++k) { float c = Cl[k] + Cr[i - k]; if (c < bi) { bi = c; ki = k; } }
+                Cn[i] = bi; Sn[i] = (uint8_t) ki;
+            }
+        }
+    }
+    /* roots chosen for subtree m when it may use up to i slots */
+    struct Collector {
+        const Builder &B; const std::vector<uint8_t> &split;
+        void operator()(int m, int i, int *child, int &nc) const {
+            const BNode &b = B.bn[m];
+            while (i > 1 && !b.count && split[(size_t) m * 9 + i] == 0) --i;
+            if (i == 1 || b.count) { child[nc++] = m; return; }
+            const int k = split[(size_t) m * 9 + i];
+            (*this)(b.left, k, child, nc); (*this)(b.right, i - k, child, nc);
+        }
+    } collect{ B, dp_split };
+
     struct Work { int b; uint32_t out; uint32_t depth; };
     std::vector<Work> queue; queue.push_back({ broot, root_out, 1 });
     uint32_t max_depth = 1;
@@ -139,15 +184,22 @@ uint32_t build_bvh8(const std::vector<PrimBox> &prims, std::vector<Node8> &nodes
         const BNode &bn = B.bn[w.b];
         int child[8]; int nc = 0;
         if (bn.count) child[nc++] = w.b;
-        else { child[nc++] = bn.left; child[nc++] = bn.right; }
-        // greedy collapse: open the internal child with the largest surface area
-        for (;;) {
-            if (nc >= 8) break;
-            int best = -1; float ba = -1.f;
-            for (int i = 0; i < nc; ++i) if (!B.bn[child[i]].count) { float a = B.bn[child[i]].box.area(); if (a > ba) { ba = a; best = i; } }
-            if (best < 0) break;
-            int c = child[best];
-            child[best] = B.bn[c].left; child[nc++] = B.bn[c].right;
+        else if (use_dp) {
+            /* SAH-optimal collapse for the given binary topology (Ylitie, Karras, Laine 2017, sec. 3.2): the children of this wide
+             * node are the <= 8 roots the dynamic program chose for the left and right binary subtrees */
+            const int k = dp_split[(size_t) w.b * 9 + 1];
+            collect(bn.left, k, child, nc); collect(bn.right, 8 - k, child, nc);
+        } else {
+            child[nc++] = bn.left; child[nc++] = bn.right;
+            // greedy collapse: open the internal child with the largest surface area
+            for (;;) {
+                if (nc >= 8) break;
+                int best = -1; float ba = -1.f;
+                for (int i = 0; i < nc; ++i) if (!B.bn[child[i]].count) { float a = B.bn[child[i]].box.area(); if (a > ba) { ba = a; best = i; } }
+                if (best < 0) break;
+                int c = child[best];
+                child[best] = B.bn[c].left; child[nc++] = B.bn[c].right;
+            }
         }
         // node box
         Box nb; nb.reset();

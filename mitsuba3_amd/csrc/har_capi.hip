@@ -61,6 +61,7 @@ struct HarIntegratorImpl {
     /* PRB replay cache (see ReplayCache): cache_bounces arrays of ws_lanes entries each */
     float4 *rc_h0 = nullptr; uint2 *rc_h1 = nullptr; uint8_t *rc_vis = nullptr; uint32_t cache_bounces = 0; bool use_cache = true;
     float *adj = nullptr; size_t adj_floats = 0;
+    uint2 *stack_spill = nullptr;         /* HBM part of the traversal stacks: HAR_STACK_SPILL entries per thread of the largest traversal grid */
     /* multi-pass rendering: sampler state per lane of the rendered lane range, pixel jitter per chunk lane (see PassState) */
     uint32_t samples_per_pass = 0xffffffffu;
     uint64_t *pass_rng = nullptr; size_t pass_rng_cap = 0; float2 *pass_jitter = nullptr; size_t pass_jitter_cap = 0;
@@ -110,6 +111,7 @@ int ensure_workspace(HarIntegratorImpl *I, uint32_t lanes, bool adjoint) {
         I->cache_bounces = nb;
     }
     if (ws_alloc(I, &I->result, lanes)) return 1;
+    if (ws_alloc(I, &I->stack_spill, (size_t) HAR_STACK_SPILL * HAR_MAX_TRAVERSAL_BLOCKS * 256)) return 1;
     if (ws_alloc(I, &I->counters, (size_t) 4 * HAR_MAX_BOUNCE_SLOTS * HAR_SHARDS * HAR_COUNTER_STRIDE) || ws_alloc(I, &I->totals, 4) || ws_alloc(I, &I->status, 1)) return 1;
     HIP_TRY(hipMemset(I->totals, 0, 4 * sizeof(unsigned long long)));
     HIP_TRY(hipMemset(I->status, 0, sizeof(int)));
@@ -152,10 +154,10 @@ int run_chunk(HarSceneImpl *S, HarIntegratorImpl *I, const DSensor &C, int mode,
     /* grid: a multiple of 8 so that block b serves shard b % 8; enough blocks to cover the chunk once */
     const uint32_t grid = std::max<uint32_t>(HAR_SHARDS, std::min<uint32_t>(((n + 255) / 256 + HAR_SHARDS - 1) / HAR_SHARDS * HAR_SHARDS, 4096u));
     /* persistent traversal kernels: enough blocks to fill the chip (<= 8 blocks/CU), never more than the work */
-    const uint32_t tgrid = std::min<uint32_t>(grid, 2048u);
-    /* LDS stack capacity class by the scene's depth-first bound (an overflow is still detected and reported) */
-    const uint32_t need = S->hs.stack_need() + HAR_STACK_MARGIN;
-    const int small_stack = need <= HAR_LDS_STACK_SMALL ? 0 : (need <= HAR_LDS_STACK_MEDIUM ? 1 : 2);
+    const uint32_t tgrid = std::min<uint32_t>(grid, (uint32_t) HAR_MAX_TRAVERSAL_BLOCKS);
+    /* scenes whose depth-first stack bound fits the LDS entries run the kernels without the HBM spill path */
+    static const bool force_spill = getenv("HAR_FORCE_STACK_SPILL") != nullptr;
+    uint2 *spill = (force_spill || S->hs.stack_need() + HAR_STACK_MARGIN > HAR_LDS_STACK_SMALL) ? I->stack_spill : nullptr;
     int cur = 0; uint32_t b = 0;
     for (; b < nb; ++b) {
         /* PRB replay cache: the primal pass of render_backward records this bounce's ray-query results per lane, the adjoint pass reads them */
@@ -163,13 +165,13 @@ int run_chunk(HarSceneImpl *S, HarIntegratorImpl *I, const DSensor &C, int mode,
         if (cache_mode && b < I->cache_bounces)
             rc = ReplayCache{ I->rc_h0 + (size_t) b * I->ws_lanes, I->rc_h1 + (size_t) b * I->ws_lanes, I->rc_vis + (size_t) b * I->ws_lanes, cache_mode };
         if (rc.mode != 2) {
-            launch_trace_closest(s, tgrid, small_stack, S->ds.accel, cnt_alive(I, b), cur_trace(I, b), I->shard_cap, I->st[cur], I->h0, I->h1, I->status);
+            launch_trace_closest(s, tgrid, spill, S->ds.accel, cnt_alive(I, b), cur_trace(I, b), I->shard_cap, I->st[cur], I->h0, I->h1, I->status);
             prof_mark(I, s, CLS_TRACE);
         }
         launch_shade(mode, s, grid, S->ds, P, lane_base, I->shard_cap, cnt_alive(I, b), I->st[cur], I->h0, I->h1, I->st[cur ^ 1], cnt_alive(I, b + 1),
                      I->items, cnt_items(I, b), I->result, rc, ps.rng);
         prof_mark(I, s, CLS_SHADE);
-        launch_resolve(mode, s, rc.mode == 2 ? grid : tgrid, small_stack, S->ds, cnt_items(I, b), cur_resolve(I, b), I->shard_cap, I->items, I->result, I->dL, grad_refl, I->d_grad_tex, I->status, rc);
+        launch_resolve(mode, s, rc.mode == 2 ? grid : tgrid, spill, S->ds, cnt_items(I, b), cur_resolve(I, b), I->shard_cap, I->items, I->result, I->dL, grad_refl, I->d_grad_tex, I->status, rc);
         prof_mark(I, s, CLS_RESOLVE);
         cur ^= 1;
         if (b >= 15 && (b & 7) == 7) {           /* deep paths are rare: poll so that max_depth = -1 terminates */
@@ -269,8 +271,9 @@ int har_scene_create(const HarSceneDesc *desc, HarScene *out) {
     D.env_emitter = hs.env_emitter;
     D.bsdf_types = 0; for (const DBsdf &b : hs.bsdfs) D.bsdf_types |= (1u << b.type) | ((b.flags & BF_TWOSIDED) ? 0x80000000u : 0u);
     if (hs.has_envmap) D.bsdf_types |= HAR_SCENE_ENVMAP;
-    if (hs.stack_need() + HAR_STACK_MARGIN > HAR_LDS_STACK_DEPTH)
-        fprintf(stderr, "[hip_ad_rgb] warning: BVH needs %u traversal stack entries, LDS stack holds %d (overflow is reported as an error)\n", hs.stack_need(), HAR_LDS_STACK_DEPTH);
+    if (hs.stack_need() + HAR_STACK_MARGIN > std::min(HAR_LDS_STACK_DEPTH, HAR_LDS_STACK_SMALL + HAR_STACK_SPILL))
+        fprintf(stderr, "[hip_ad_rgb] warning: BVH needs %u traversal stack entries, the traversal stack holds %d (overflow is reported as an error)\n", hs.stack_need(),
+                std::min(HAR_LDS_STACK_DEPTH, HAR_LDS_STACK_SMALL + HAR_STACK_SPILL));
     *out = S;
     return 0;
 }

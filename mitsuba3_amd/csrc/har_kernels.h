@@ -3,10 +3,13 @@
 #include <hip/hip_runtime.h>
 #include "har_path.h"
 
-#define HAR_LDS_STACK_DEPTH 30      /* traversal stack entries per lane, deep scenes: 60 KB/block -> 2 blocks/CU */
-#define HAR_LDS_STACK_MEDIUM 18     /* 36 KB/block -> 4 blocks/CU */
-#ifndef HAR_LDS_STACK_SMALL         /* entries per lane of the small LDS stack: 12 x 8 B x 256 = 24 KB/block -> 6 blocks/CU.  Measured (tools/build_variant.sh A/B): 16 entries (5 blocks/CU) is 12 % slower */
-#define HAR_LDS_STACK_SMALL 12
+#define HAR_LDS_STACK_DEPTH 30      /* traversal stack entries per lane of the stand-alone ray-query kernels (all in LDS): 60 KB/block */
+#ifndef HAR_LDS_STACK_SMALL         /* LDS entries per lane of the wavefront traversal kernels: 13 x 8 B x 256 = 26 KB/block -> still 6 blocks/CU (160 KB).  Measured (tools/build_variant.sh A/B): 16 entries (5 blocks/CU) is 12 % slower */
+#define HAR_LDS_STACK_SMALL 13
+#endif
+#ifndef HAR_STACK_SPILL             /* deeper entries of a lane's stack live in HBM (per-thread columns of the integrator workspace): LDS bytes set the occupancy of these
+                                       VALU-bound kernels, the depth-first bound of a BVH is rarely reached by a ray, and a spilled push/pop costs one 8-byte access */
+#define HAR_STACK_SPILL 20
 #endif
 #ifndef HAR_TRAV_POLICY
 #define HAR_TRAV_POLICY 0          /* Traversal<POLICY>, see har_accel.h; measured: POLICY 2 saves 7-15 % iterations in the model but nothing on the GPU */
@@ -17,6 +20,7 @@
 #define HAR_REPLAY_CACHE_BOUNCES 12 /* PRB replay cache depth (25 B per lane and bounce); deeper bounces are traced twice */
 #define HAR_LDS_GRAD_BSDFS 256     /* constant-albedo gradients accumulated per block in LDS (adjoint resolve) */
 #define HAR_SHARDS 8                /* XCD-private path queues */
+#define HAR_MAX_TRAVERSAL_BLOCKS 2048 /* persistent traversal kernels: enough blocks to fill the chip (<= 8 blocks/CU) */
 #define HAR_COUNTER_STRIDE 16       /* u32 stride between shard counters: one 64 B line each */
 #define HAR_SPLAT_TILE_FLOATS 8192
 #define HAR_MAX_BOUNCE_SLOTS 1026
@@ -39,12 +43,13 @@ struct PassState { uint64_t *rng; float2 *jitter; uint32_t pass; };
 
 void launch_raygen(int mode, hipStream_t s, const DSensor &C, uint32_t seed, uint32_t spp, uint32_t log_spp, uint32_t lane_base, uint32_t n,
                    uint32_t shard_cap, const WaveState &out, float4 *result, uint32_t *count, const float *adj, float4 *dL, const PassState &ps = PassState{ nullptr, nullptr, 0 });
-void launch_trace_closest(hipStream_t s, uint32_t grid, int stack_class, const Accel &A, const uint32_t *count, uint32_t *cursor, uint32_t shard_cap,
+/* `spill` = nullptr: the scene's depth-first bound fits the LDS stack and the kernels without the HBM spill path run (3 % faster) */
+void launch_trace_closest(hipStream_t s, uint32_t grid, uint2 *spill, const Accel &A, const uint32_t *count, uint32_t *cursor, uint32_t shard_cap,
                           const WaveState &in, float4 *h0, uint2 *h1, int *status);
 void launch_shade(int mode, hipStream_t s, uint32_t grid, const DScene &S, const ShadeParams &P, uint32_t lane_base, uint32_t shard_cap, const uint32_t *count_in,
                   const WaveState &in, const float4 *h0, const uint2 *h1, const WaveState &out, uint32_t *count_out, const ItemArrays &items,
                   uint32_t *item_count, float4 *result, const ReplayCache &rc, uint64_t *pass_rng = nullptr);
-void launch_resolve(int mode, hipStream_t s, uint32_t grid, int stack_class, const DScene &S, const uint32_t *item_count, uint32_t *cursor, uint32_t shard_cap, const ItemArrays &items,
+void launch_resolve(int mode, hipStream_t s, uint32_t grid, uint2 *spill, const DScene &S, const uint32_t *item_count, uint32_t *cursor, uint32_t shard_cap, const ItemArrays &items,
                     float4 *result, const float4 *dL, float *grad_refl, float *const *grad_tex, int *status, const ReplayCache &rc);
 void launch_splat(hipStream_t s, const DSensor &C, uint32_t seed, uint32_t spp, uint32_t log_spp, uint32_t lane_base, uint32_t n,
                   const float4 *result, int weights_only, float *film, const float2 *jitter = nullptr);

@@ -33,6 +33,27 @@ template <int CAP> struct LdsStack {
     __device__ __forceinline__ void push(int l, uint32_t x, uint32_t y) { col[l * kBlock] = make_uint2(x, y); }
     __device__ __forceinline__ void pop(int l, uint32_t &x, uint32_t &y) { uint2 v = col[l * kBlock]; x = v.x; y = v.y; }
 };
+/* first CAP entries in LDS, the next SPILL in a per-thread column of HBM (entry l of thread t at spill[(l - CAP) * stride + t]) */
+template <int CAP, int SPILL> struct HybridStack {
+    static constexpr int Capacity = CAP + SPILL;
+    uint2 *col, *spill; uint32_t stride;
+    __device__ __forceinline__ void push(int l, uint32_t x, uint32_t y) {
+        if (l < CAP) col[l * kBlock] = make_uint2(x, y); else spill[(size_t) (l - CAP) * stride] = make_uint2(x, y);
+    }
+    __device__ __forceinline__ void pop(int l, uint32_t &x, uint32_t &y) {
+        uint2 v; if (l < CAP) v = col[l * kBlock]; else v = spill[(size_t) (l - CAP) * stride];
+        x = v.x; y = v.y;
+    }
+};
+/* SPILL = false: scenes whose depth-first bound fits the LDS entries (no spill code in the loop) */
+template <bool SPILL> struct WaveStackOf { typedef HybridStack<HAR_LDS_STACK_SMALL, HAR_STACK_SPILL> type; };
+template <> struct WaveStackOf<false> { typedef LdsStack<HAR_LDS_STACK_SMALL> type; };
+template <bool SPILL> __device__ __forceinline__ typename WaveStackOf<SPILL>::type make_wave_stack(uint2 *lds, uint2 *spill);
+template <> __device__ __forceinline__ WaveStackOf<true>::type make_wave_stack<true>(uint2 *lds, uint2 *spill) {
+    const uint32_t stride = gridDim.x * kBlock;
+    return WaveStackOf<true>::type{ lds + threadIdx.x, spill + (size_t) blockIdx.x * kBlock + threadIdx.x, stride };
+}
+template <> __device__ __forceinline__ WaveStackOf<false>::type make_wave_stack<false>(uint2 *lds, uint2 *) { return WaveStackOf<false>::type{ lds + threadIdx.x }; }
 
 __device__ __forceinline__ uint32_t wave_rank(uint64_t mask) {
     return __builtin_amdgcn_mbcnt_hi((uint32_t) (mask >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t) mask, 0u));
@@ -205,8 +226,8 @@ __global__ __launch_bounds__(kBlock) void k_raygen(DSensor C, uint32_t seed, uin
 #define HAR_TRAV_ORDER 0    /* measured: 0 (node, leaf, pop) 687, 2: 660, 1: 643 Mpaths/s on the 1M-tri scene */
 #endif
 
-template <bool ANY, bool RETIRE, int CAP, typename Take, typename Done, typename Retire>
-__device__ __forceinline__ void trace_persistent(const Accel &A, uint32_t *cursor, uint32_t n, LdsStack<CAP> &stack, int *status,
+template <bool ANY, bool RETIRE, typename WaveStack, typename Take, typename Done, typename Retire>
+__device__ __forceinline__ void trace_persistent(const Accel &A, uint32_t *cursor, uint32_t n, WaveStack &stack, int *status,
                                                  Take take, Done done, Retire retire) {
     const uint32_t lane = threadIdx.x & 63u;
     uint32_t pool_next = 0, pool_end = 0;      /* wave-uniform */
@@ -242,7 +263,7 @@ __device__ __forceinline__ void trace_persistent(const Accel &A, uint32_t *curso
         }
         if (busy) {
             int st = 0;
-            if (T.template step<ANY, LdsStack<CAP>, NoProbe, HAR_TRAV_ORDER>(A, stack, st)) {
+            if (T.template step<ANY, WaveStack, NoProbe, HAR_TRAV_ORDER>(A, stack, st)) {
                 busy = false;
                 if (RETIRE) has_result = true; else done(idx, T);
             }
@@ -266,14 +287,15 @@ __device__ __forceinline__ void trace_persistent(const Accel &A, uint32_t *curso
 }
 
 /* ----------------------------------------------------------- trace_closest */
-template <int CAP>
+template <bool SPILL>
 __global__ __launch_bounds__(kBlock) void k_trace_closest(Accel A, const uint32_t *count, uint32_t *cursor, uint32_t shard_cap, const float4 *a0,
-                                                          const float4 *a1, float4 *h0, uint2 *h1, int *status) {
-    __shared__ uint2 lds[CAP * kBlock];
-    LdsStack<CAP> stack{ lds + threadIdx.x };
+                                                          const float4 *a1, float4 *h0, uint2 *h1, int *status, uint2 *spill) {
+    __shared__ uint2 lds[HAR_LDS_STACK_SMALL * kBlock];
+    typedef typename WaveStackOf<SPILL>::type WaveStack;
+    WaveStack stack = make_wave_stack<SPILL>(lds, spill);
     const uint32_t shard = blockIdx.x & (HAR_SHARDS - 1), n = count[shard * HAR_COUNTER_STRIDE], base = shard * shard_cap;
     if (n == 0) return;
-    trace_persistent<false, false, CAP>(A, cursor + shard * HAR_COUNTER_STRIDE, n, stack, status,
+    trace_persistent<false, false, WaveStack>(A, cursor + shard * HAR_COUNTER_STRIDE, n, stack, status,
         [&](uint32_t idx, Traversal<HAR_TRAV_POLICY> &T) {
             float4 o = a0[base + idx], d = a1[base + idx];
             T.begin(A, Vec3(o.x, o.y, o.z), Vec3(d.x, d.y, d.z), o.w < 0.f ? HAR_LARGEST : o.w);
@@ -421,15 +443,16 @@ __global__ __launch_bounds__(kBlock) void k_resolve_adjoint_cached(DScene S, con
 }
 
 /* ------------------------------------------------- resolve (shadow rays + NEE) */
-template <int MODE, int CAP>
+template <int MODE, bool SPILL>
 __global__ __launch_bounds__(kBlock) void k_resolve(DScene S, const uint32_t *item_count, uint32_t *cursor, uint32_t shard_cap, ItemArrays items, float4 *result,
-                                                    const float4 *dL, float *grad_refl, float *const *grad_tex, int *status, ReplayCache rc) {
-    __shared__ uint2 lds[CAP * kBlock];
+                                                    const float4 *dL, float *grad_refl, float *const *grad_tex, int *status, ReplayCache rc, uint2 *spill) {
+    __shared__ uint2 lds[HAR_LDS_STACK_SMALL * kBlock];
     /* adjoint: per-block accumulators of the constant-albedo gradients.  Every path of the chip adds to the same
      * few floats of grad_refl (one 64 B line): direct global atomics serialise at ~88 atomics/us per line, which
      * made the adjoint 10x slower than the primal pass.  ds_add_f32 here, one global atomic per block and entry. */
     __shared__ float gacc[MODE == MODE_PRB_ADJOINT ? 3 * HAR_LDS_GRAD_BSDFS : 1];
-    LdsStack<CAP> stack{ lds + threadIdx.x };
+    typedef typename WaveStackOf<SPILL>::type WaveStack;
+    WaveStack stack = make_wave_stack<SPILL>(lds, spill);
     const uint32_t shard = blockIdx.x & (HAR_SHARDS - 1), n = item_count[shard * HAR_COUNTER_STRIDE], base = shard * shard_cap;
     if (n == 0) return;
     if (MODE == MODE_PRB_ADJOINT) {
@@ -445,7 +468,7 @@ __global__ __launch_bounds__(kBlock) void k_resolve(DScene S, const uint32_t *it
     };
     if (MODE == MODE_PATH || MODE == MODE_PRB_PRIMAL) {
         /* forward: an unoccluded item adds its contribution to its lane's radiance (one item per lane and bounce: no race) */
-        trace_persistent<true, false, CAP>(S.accel, cursor + shard * HAR_COUNTER_STRIDE, n, stack, status, take,
+        trace_persistent<true, false, WaveStack>(S.accel, cursor + shard * HAR_COUNTER_STRIDE, n, stack, status, take,
             [&](uint32_t idx, const Traversal<HAR_TRAV_POLICY> &T) {
                 const uint32_t i = base + idx;
                 if (rc.mode == 1) rc.vis[__float_as_uint(items.s1[i].w)] = T.found ? 0 : 1;      /* replay cache */
@@ -459,7 +482,7 @@ __global__ __launch_bounds__(kBlock) void k_resolve(DScene S, const uint32_t *it
     } else {
         /* adjoint: L <- L - Lr_dir; g = dL * (dLr_dir/drho + [bsdf_val != 0] L / rho)  (prb.py:227,288-313);
          * gradients are committed at refill time by ALL lanes so that the wave pre-reduction can run */
-        trace_persistent<true, true, CAP>(S.accel, cursor + shard * HAR_COUNTER_STRIDE, n, stack, status, take,
+        trace_persistent<true, true, WaveStack>(S.accel, cursor + shard * HAR_COUNTER_STRIDE, n, stack, status, take,
             [&](uint32_t, const Traversal<HAR_TRAV_POLICY> &) { },
             [&](bool pred, uint32_t idx, const Traversal<HAR_TRAV_POLICY> &T) {
                 adjoint_commit(S, items, base + (pred ? idx : 0u), pred, pred && !T.found, result, dL, grad_refl, grad_tex, gacc);
@@ -694,11 +717,10 @@ void launch_raygen(int mode, hipStream_t s, const DSensor &C, uint32_t seed, uin
     if (mode == MODE_PRB_ADJOINT) hipLaunchKernelGGL(k_raygen<MODE_PRB_ADJOINT>, g, b, 0, s, C, seed, spp, log_spp, lane_base, n, shard_cap, out, result, count, adj, dL, ps);
     else hipLaunchKernelGGL(k_raygen<MODE_PATH>, g, b, 0, s, C, seed, spp, log_spp, lane_base, n, shard_cap, out, result, count, adj, dL, ps);
 }
-void launch_trace_closest(hipStream_t s, uint32_t grid, int stack_class, const Accel &A, const uint32_t *count, uint32_t *cursor, uint32_t shard_cap,
+void launch_trace_closest(hipStream_t s, uint32_t grid, uint2 *spill, const Accel &A, const uint32_t *count, uint32_t *cursor, uint32_t shard_cap,
                           const WaveState &in, float4 *h0, uint2 *h1, int *status) {
-    if (stack_class == 0) hipLaunchKernelGGL(k_trace_closest<HAR_LDS_STACK_SMALL>, dim3(grid), dim3(kBlock), 0, s, A, count, cursor, shard_cap, in.a0, in.a1, h0, h1, status);
-    else if (stack_class == 1) hipLaunchKernelGGL(k_trace_closest<HAR_LDS_STACK_MEDIUM>, dim3(grid), dim3(kBlock), 0, s, A, count, cursor, shard_cap, in.a0, in.a1, h0, h1, status);
-    else hipLaunchKernelGGL(k_trace_closest<HAR_LDS_STACK_DEPTH>, dim3(grid), dim3(kBlock), 0, s, A, count, cursor, shard_cap, in.a0, in.a1, h0, h1, status);
+    if (spill) hipLaunchKernelGGL(k_trace_closest<true>, dim3(grid), dim3(kBlock), 0, s, A, count, cursor, shard_cap, in.a0, in.a1, h0, h1, status, spill);
+    else hipLaunchKernelGGL(k_trace_closest<false>, dim3(grid), dim3(kBlock), 0, s, A, count, cursor, shard_cap, in.a0, in.a1, h0, h1, status, spill);
 }
 void launch_shade(int mode, hipStream_t s, uint32_t grid, const DScene &S, const ShadeParams &P, uint32_t lane_base, uint32_t shard_cap, const uint32_t *count_in,
                   const WaveState &in, const float4 *h0, const uint2 *h1, const WaveState &out, uint32_t *count_out, const ItemArrays &items,
@@ -715,22 +737,17 @@ void launch_shade(int mode, hipStream_t s, uint32_t grid, const DScene &S, const
 #undef HAR_LAUNCH_SHADE_MODE
 #undef HAR_LAUNCH_SHADE
 }
-void launch_resolve(int mode, hipStream_t s, uint32_t grid, int stack_class, const DScene &S, const uint32_t *item_count, uint32_t *cursor, uint32_t shard_cap, const ItemArrays &items,
+void launch_resolve(int mode, hipStream_t s, uint32_t grid, uint2 *spill, const DScene &S, const uint32_t *item_count, uint32_t *cursor, uint32_t shard_cap, const ItemArrays &items,
                     float4 *result, const float4 *dL, float *grad_refl, float *const *grad_tex, int *status, const ReplayCache &rc) {
     dim3 g(grid), b(kBlock);
     if (mode == MODE_PRB_ADJOINT && rc.mode == 2) {
         hipLaunchKernelGGL(k_resolve_adjoint_cached, g, b, 0, s, S, item_count, shard_cap, items, result, dL, grad_refl, grad_tex, rc);
         return;
     }
-    if (mode == MODE_PRB_ADJOINT) {
-        if (stack_class == 0) hipLaunchKernelGGL((k_resolve<MODE_PRB_ADJOINT, HAR_LDS_STACK_SMALL>), g, b, 0, s, S, item_count, cursor, shard_cap, items, result, dL, grad_refl, grad_tex, status, rc);
-        else if (stack_class == 1) hipLaunchKernelGGL((k_resolve<MODE_PRB_ADJOINT, HAR_LDS_STACK_MEDIUM>), g, b, 0, s, S, item_count, cursor, shard_cap, items, result, dL, grad_refl, grad_tex, status, rc);
-        else hipLaunchKernelGGL((k_resolve<MODE_PRB_ADJOINT, HAR_LDS_STACK_DEPTH>), g, b, 0, s, S, item_count, cursor, shard_cap, items, result, dL, grad_refl, grad_tex, status, rc);
-    } else {
-        if (stack_class == 0) hipLaunchKernelGGL((k_resolve<MODE_PATH, HAR_LDS_STACK_SMALL>), g, b, 0, s, S, item_count, cursor, shard_cap, items, result, dL, grad_refl, grad_tex, status, rc);
-        else if (stack_class == 1) hipLaunchKernelGGL((k_resolve<MODE_PATH, HAR_LDS_STACK_MEDIUM>), g, b, 0, s, S, item_count, cursor, shard_cap, items, result, dL, grad_refl, grad_tex, status, rc);
-        else hipLaunchKernelGGL((k_resolve<MODE_PATH, HAR_LDS_STACK_DEPTH>), g, b, 0, s, S, item_count, cursor, shard_cap, items, result, dL, grad_refl, grad_tex, status, rc);
-    }
+#define HAR_LAUNCH_RESOLVE(M, SP) hipLaunchKernelGGL((k_resolve<M, SP>), g, b, 0, s, S, item_count, cursor, shard_cap, items, result, dL, grad_refl, grad_tex, status, rc, spill)
+    if (mode == MODE_PRB_ADJOINT) { if (spill) HAR_LAUNCH_RESOLVE(MODE_PRB_ADJOINT, true); else HAR_LAUNCH_RESOLVE(MODE_PRB_ADJOINT, false); }
+    else { if (spill) HAR_LAUNCH_RESOLVE(MODE_PATH, true); else HAR_LAUNCH_RESOLVE(MODE_PATH, false); }
+#undef HAR_LAUNCH_RESOLVE
 }
 void launch_splat(hipStream_t s, const DSensor &C, uint32_t seed, uint32_t spp, uint32_t log_spp, uint32_t lane_base, uint32_t n,
                   const float4 *result, int weights_only, float *film, const float2 *jitter) {
