@@ -237,8 +237,18 @@ int hh_trace_stats(void *h, const HarSensor *sensor, uint32_t seed, uint32_t spp
                             if (idle == 64) break;
                         }
                         uint32_t anyn = 0, anyi = 0, mt = 0;
+                        /* what-if: lanes whose next step enters an instance wait until `defer` of them are pending (or nothing else can run) */
+                        static const int defer = getenv("HH_DEFER_INST") ? atoi(getenv("HH_DEFER_INST")) : 0;
+                        bool run_inst = true;
+                        if (defer > 0) {
+                            int pend = 0, other = 0;
+                            for (int l = 0; l < 64; ++l) if (busy[l]) { uint32_t v = evs[slot_ray[l]][slot_pos[l]]; if ((v >> 1) & 1u) ++pend; else ++other; }
+                            run_inst = pend >= defer || other == 0;
+                        }
                         for (int l = 0; l < 64; ++l) if (busy[l]) {
-                            uint32_t v = evs[slot_ray[l]][slot_pos[l]++]; anyn |= v & 1u; anyi |= (v >> 1) & 1u; mt = std::max(mt, v >> 8);
+                            uint32_t v = evs[slot_ray[l]][slot_pos[l]];
+                            if (!run_inst && ((v >> 1) & 1u)) continue;
+                            slot_pos[l]++; anyn |= v & 1u; anyi |= (v >> 1) & 1u; mt = std::max(mt, v >> 8);
                             if (slot_pos[l] == evs[slot_ray[l]].size()) busy[l] = false;
                         }
                         q[5] += 1; q[6] += anyn; q[7] += mt; q[8] += anyi;
