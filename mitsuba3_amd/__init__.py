@@ -19,3 +19,5 @@ from .core import (                                    # noqa: F401
 from . import core                                     # noqa: F401
 from .distributed import render_distributed, render_backward_distributed, lane_range   # noqa: F401
 from .scenes import instanced_spheres_scene, textured_cornell_box                       # noqa: F401
+from . import parser                                   # noqa: F401
+from .parser import load_file, load_string             # noqa: F401

@@ -377,7 +377,7 @@ class Film:
         pf = props.get('pixel_format', 'rgb')
         if pf != 'rgb':
             raise RuntimeError("hdrfilm: pixel_format \"%s\" is not supported by hip_ad_rgb (only 'rgb')" % pf)
-        rf = props.get('rfilter', {'type': 'gaussian'})
+        rf = next((v for v in props.values() if isinstance(v, dict) and 'type' in v), {'type': 'gaussian'})     # the film's only child object is its rfilter
         if rf['type'] == 'gaussian':
             self.rfilter = 1; self.stddev = float(rf.get('stddev', 0.5))
         elif rf['type'] == 'box':
@@ -397,8 +397,11 @@ class Sensor:
 
     def __init__(self, props):
         self.props = dict(props)
-        self.m_film = props['film'] if isinstance(props.get('film'), Film) else Film(props.get('film'))
-        self.m_sampler = props['sampler'] if isinstance(props.get('sampler'), Sampler) else Sampler(props.get('sampler'))
+        # child objects are recognised by their class, whatever the property is called (XML children are anonymous: `_arg_0`, ...)
+        film = next((v for v in props.values() if isinstance(v, Film)), props.get('film'))
+        sampler = next((v for v in props.values() if isinstance(v, Sampler)), props.get('sampler'))
+        self.m_film = film if isinstance(film, Film) else Film(film)
+        self.m_sampler = sampler if isinstance(sampler, Sampler) else Sampler(sampler)
         self.to_world = props.get('to_world', ScalarTransform4f())
         if self.to_world.has_scale():
             raise RuntimeError("Scale factors in the camera-to-world transformation are not allowed!")
