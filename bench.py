@@ -65,11 +65,18 @@ def main():
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU: the hip_ad_rgb path has no CPU fallback")
-    torch.cuda.set_device(local_rank)
+    # HAR_BENCH_SHARE_GPU=1 + HAR_BENCH_BACKEND=gloo: rehearsal of the N-rank code path on a box with fewer GPUs than ranks
+    # (ranks share devices, the film reduce goes through gloo); never used for reported numbers
+    device_index = local_rank % torch.cuda.device_count() if os.environ.get("HAR_BENCH_SHARE_GPU") else local_rank
+    torch.cuda.set_device(device_index)
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
-        dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
+        backend = os.environ.get("HAR_BENCH_BACKEND", "nccl")
+        if backend == "nccl":
+            dist.init_process_group(backend="nccl", device_id=torch.device("cuda", device_index))
+        else:
+            dist.init_process_group(backend=backend)
     mi.set_variant("hip_ad_rgb")
 
     def sync_barrier():
@@ -131,7 +138,7 @@ def main():
     # profile of this exact workload has not been collected
     traffic = None
     tpath = os.path.join(ROOT, "profiles", "r01_traffic_%s.json" % args.workload)
-    if os.path.exists(tpath) and args.res == 512 and args.spp == 256:
+    if os.path.exists(tpath) and args.res == 512 and args.spp == 256 and world == 1:      # the PMC passes were collected at N = 1 (launch sizes differ otherwise)
         try:
             with open(tpath) as f:
                 tj = json.load(f)

@@ -43,7 +43,10 @@ def render_distributed(scene, integrator=None, sensor=0, seed=0, spp=0, develop=
     lanes = lane_range(w * h * spp_pass, rank, world, granule=w * spp_pass)
     film = integrator.render_film(scene, s, seed, spp, lanes=lanes)
     if world > 1:
-        dist.reduce(film, dst=dst, op=dist.ReduceOp.SUM)      # the single RCCL collective
+        if dist.get_backend() == "gloo" and film.is_cuda:      # gloo has no device-tensor reduce (rehearsal runs only)
+            dist.all_reduce(film, op=dist.ReduceOp.SUM)
+        else:
+            dist.reduce(film, dst=dst, op=dist.ReduceOp.SUM)  # the single RCCL collective
     if not develop:
         return film
     return develop_film(film) if rank == dst or world == 1 else None
