@@ -502,6 +502,36 @@ def test_envmap_emitter_parity(mi, O):
     assert rel_l2(img, ref) < 1e-4
 
 
+def test_ztest_product_vs_oracle(mi, O):
+    """The reference's statistical render test (src/render/tests/test_renders.py:146-236; tests/ztest.py) with DIFFERENT seeds on both sides:
+    complements the same-seed parity tests (it would catch correlated sample streams across chunk / pass / band seams, which same-seed
+    comparisons cannot see).  Sample budget 2e6 per image as in the reference."""
+    from tests import ztest
+    from tests.test_cpu_host import oracle_scene_from
+    from tests.test_envmap_cpu import _env_scene
+    res = 32; spp = int(2e6) // (res * res)
+    spp = 1 << (spp.bit_length() - 1)                   # 1024
+    cases = []
+    scene, osc, sensor = cbox(mi, O, res, rfilter="box")
+    cases.append(("cornell", scene, osc, sensor, 8))
+    scene, _ = _env_scene(mi, res=res, to_world=mi.ScalarTransform4f().rotate([0, 1, 0], 70), with_area_light=True)
+    d = None
+    osc, sensor = oracle_scene_from(O, scene)
+    cases.append(("envmap", scene, osc, sensor, 8))
+    for name, scene, osc, sensor, md in cases:
+        if sensor.rfilter != 0:                           # pixels must be independent: rebuild the sensor with a box filter
+            scene.sensors()[0].film().rfilter = 0; scene.sensors()[0].update(); sensor.rfilter = 0
+        ref_mean, ref_var, n_ref = ztest.oracle_reference(osc, sensor, spp_b=8, batches=128, max_depth=md)     # many small batches: the variance estimate needs them
+        for integ in (mi.load_dict({"type": "path", "max_depth": md}),
+                      mi.load_dict({"type": "path", "max_depth": md, "chunk_lanes": 40000}),
+                      mi.load_dict({"type": "path", "max_depth": md, "samples_per_pass": spp // 8})):
+            img = mi.render(scene, integrator=integ, spp=spp, seed=4242).cpu().numpy()
+            ok, pmin, alpha = ztest.accept(img, spp, ref_mean, ref_var, n_ref)
+            assert ok, (name, pmin, alpha)
+        ok, _, _ = ztest.accept(img * 1.03, spp, ref_mean, ref_var, n_ref)
+        assert not ok, name                              # power: +3 % is rejected
+
+
 def test_prb_replay_cache_is_transparent(mi, O):
     """the adjoint pass with the replay cache (primal hit / visibility records reused) gives the gradients of a full re-trace,
     for constant colours, textures and the all-materials scene, also when the path is deeper than the cache"""

@@ -108,3 +108,22 @@ def test_pass_layout_host():
     hp = C.c_void_p(); _capi.check(L.har_integrator_create(1, 6, 5, 0, C.byref(hp)))
     assert L.har_integrator_set_samples_per_pass(hp, 4) != 0         # AD integrators render one wavefront (common.py:358-363)
     L.har_integrator_destroy(hp)
+
+
+def test_ztest_drivers_agree(O):
+    """the reference's Z-test (test_renders.py:146-236) between the oracle's drivers: scalar (spiral / Morton / discretised filter -- box filter
+    here so that pixels are independent), multi-pass and single-wavefront renders estimate the same image"""
+    from tests import ztest
+    res = 24
+    sd, sensor = O.cornell_box(res, res, rfilter="box")
+    osc = O.OracleScene(sd)
+    ref_mean, ref_var, n_ref = ztest.oracle_reference(osc, sensor, spp_b=8, batches=96, max_depth=6)
+    scalar, _, _ = osc.render_path_scalar(sensor, seed=77, spp=256, max_depth=6)
+    ok, pmin, alpha = ztest.accept(scalar, 256, ref_mean, ref_var, n_ref)
+    assert ok, (pmin, alpha)
+    multi, _ = osc.render_path_passes(sensor, seed=78, spp=256, spp_per_pass=32, max_depth=6)
+    ok, pmin, alpha = ztest.accept(multi, 256, ref_mean, ref_var, n_ref)
+    assert ok, (pmin, alpha)
+    # the test has power: a 5 % brighter image is rejected
+    ok, _, _ = ztest.accept(multi * 1.05, 256, ref_mean, ref_var, n_ref)
+    assert not ok
