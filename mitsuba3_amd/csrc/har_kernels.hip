@@ -175,10 +175,12 @@ __global__ __launch_bounds__(kBlock) void k_raygen(DSensor C, uint32_t seed, uin
         /* adjoint of ImageBlock::put + develop (common.py:696-746): gather grad_in / W over the footprint */
         Footprint F; film_footprint(C, ls, F);
         Vec3 g(0.f);
-        for (uint32_t ys = 0; ys < F.count; ++ys) {
-            uint32_t y = F.y0 + ys; if (!(y < C.crop_h)) continue;
-            for (uint32_t xs = 0; xs < F.count; ++xs) {
-                uint32_t x = F.x0 + xs; if (!(x < C.crop_w)) continue;
+#pragma unroll
+        for (uint32_t ys = 0; ys < HAR_MAX_FILTER_TAPS; ++ys) {        /* static tap indices keep the weights in registers (no scratch) */
+            uint32_t y = F.y0 + ys; if (!(ys < F.count && y < C.crop_h)) continue;
+#pragma unroll
+            for (uint32_t xs = 0; xs < HAR_MAX_FILTER_TAPS; ++xs) {
+                uint32_t x = F.x0 + xs; if (!(xs < F.count && x < C.crop_w)) continue;
                 float w = F.wx[xs] * F.wy[ys];
                 const float *a = adj + 3 * ((size_t) y * C.crop_w + x);
                 g = Vec3(fma_(a[0], w, g.x), fma_(a[1], w, g.y), fma_(a[2], w, g.z));
@@ -496,17 +498,27 @@ __global__ __launch_bounds__(kBlock) void k_resolve(DScene S, const uint32_t *it
 }
 
 /* ------------------------------------------------------------------- splat */
-/* ImageBlock::put (imageblock.cpp:444-540) for 256 consecutive lanes.  The spp samples of a pixel are
- * adjacent lanes, so a wave normally shares ONE footprint: its 64 contributions are summed with DPP,
- * one lane adds the wave totals to an LDS tile, and each tile pixel costs one global atomic per block. */
+/* ImageBlock::put (coalesced JIT branch, imageblock.cpp:444-520) for the 256 consecutive lanes of a block, as a GATHER in LDS.
+ * Lanes are ordered by pixel (lane = pixel * spp + sample), so a block covers a short run of pixels of one image row.  Every lane
+ * stages its value and its separable filter weights in LDS; then each thread owns one pixel of the block's tile and sums the lanes
+ * whose footprint covers it -- a contiguous lane range, found by binary search on the footprint origins -- with four fma per lane
+ * (short ranges are split over several threads).  No per-lane atomics: one LDS add per partial sum, one global atomic per tile
+ * float.  The previous formulation (a DPP wave reduction per tap and channel when a wave shares one footprint, per-lane LDS atomics
+ * otherwise) cost 5.8 ms per 67 M lanes at >= 64 spp and 45 ms below; this one is spp-independent.
+ * Blocks whose lanes span two image rows (only when width * spp is not a multiple of 256) or whose tile exceeds the LDS budget
+ * take the per-lane path. */
+#define HAR_SPLAT_GATHER_MAX_SPLIT 8
+#define HAR_SPLAT_TILE_PIXELS 512           /* LDS tile of the gather: 8 KB; wider tiles are processed in column slabs */
+template <int TAPS>
 __global__ __launch_bounds__(kBlock) void k_splat(DSensor C, uint32_t seed, uint32_t spp, uint32_t log_spp, uint32_t lane_base, uint32_t n,
                                                   const float4 *result, int weights_only, float *film, const float2 *jitter) {
-    __shared__ float tile[HAR_SPLAT_TILE_FLOATS];
-    __shared__ int tx0, ty0, tx1, ty1;
+    __shared__ float tile[4 * HAR_SPLAT_TILE_PIXELS];
+    __shared__ float4 s_val[kBlock];
+    __shared__ float s_wx[TAPS][kBlock + 1], s_wy[TAPS][kBlock + 1];        /* + 1: threads of a wave read different taps of the same lane -> different banks */
+    __shared__ int ext[6];                  /* footprint origin of the first / last active lane of the block, footprint size */
     const uint32_t i = blockIdx.x * kBlock + threadIdx.x;
     const bool act = i < n;
-    if (threadIdx.x == 0) { tx0 = 0x7fffffff; ty0 = 0x7fffffff; tx1 = -0x7fffffff; ty1 = -0x7fffffff; }
-    __syncthreads();
+    const uint32_t n_act_u = min((uint32_t) kBlock, n - blockIdx.x * kBlock);
     Footprint F; F.count = 0; F.x0 = 0; F.y0 = 0;
     for (int k = 0; k < HAR_MAX_FILTER_TAPS; ++k) { F.wx[k] = 0.f; F.wy[k] = 0.f; }
     float val[4] = { 0.f, 0.f, 0.f, 1.f };
@@ -516,53 +528,64 @@ __global__ __launch_bounds__(kBlock) void k_splat(DSensor C, uint32_t seed, uint
         else ls = lane_film_pos(C, seed, spp, log_spp, lane_base + i);
         film_footprint(C, ls, F);
         if (!weights_only) { float4 r = result[i]; val[0] = r.x; val[1] = r.y; val[2] = r.z; }
-        atomicMin(&tx0, (int) F.x0); atomicMin(&ty0, (int) F.y0);
-        atomicMax(&tx1, (int) F.x0 + (int) F.count); atomicMax(&ty1, (int) F.y0 + (int) F.count);
+        /* lanes are ordered by pixel: the block's extent follows from its first and last active lane (no LDS min / max atomics) */
+        if (threadIdx.x == 0) { ext[0] = (int) F.x0; ext[1] = (int) F.y0; ext[4] = (int) F.count; }
+        if (threadIdx.x == n_act_u - 1u) { ext[2] = (int) F.x0; ext[3] = (int) F.y0; }
     }
+    s_val[threadIdx.x] = act ? make_float4(val[0], val[1], val[2], val[3]) : make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+    for (int k = 0; k < TAPS; ++k) { s_wx[k][threadIdx.x] = F.wx[k]; s_wy[k][threadIdx.x] = F.wy[k]; }
     __syncthreads();
-    const int ox = tx0, oy = ty0, tw = tx1 - tx0, th = ty1 - ty0;
-    const bool use_tile = tw > 0 && th > 0 && (size_t) tw * th * 4 <= HAR_SPLAT_TILE_FLOATS;
-    if (use_tile) {
-        for (int k = threadIdx.x; k < tw * th * 4; k += kBlock) tile[k] = 0.f;
-        __syncthreads();
-        /* does the whole wave share one footprint? (inactive lanes carry zero weights) */
-        const uint32_t fx = __shfl(F.x0, 0, 64), fy = __shfl(F.y0, 0, 64), fc = __shfl(F.count, 0, 64);
-        const bool uniform = __all(!act || (F.x0 == fx && F.y0 == fy && F.count == fc)) && __shfl((int) act, 0, 64);
-        if (uniform) {
-            const bool last = (threadIdx.x & 63u) == 63u;
-            for (uint32_t ys = 0; ys < fc; ++ys)
-                for (uint32_t xs = 0; xs < fc; ++xs) {
-                    const float w = act ? F.wx[xs] * F.wy[ys] : 0.f;
-                    float *p = tile + 4 * (((int) fy + (int) ys - oy) * tw + ((int) fx + (int) xs - ox));
-                    if (!weights_only) {
-                        float a = wave_sum_to_last(val[0] * w), b = wave_sum_to_last(val[1] * w), c = wave_sum_to_last(val[2] * w);
-                        if (last) { atomicAdd(p, a); atomicAdd(p + 1, b); atomicAdd(p + 2, c); }
+    const int ox = ext[0], oy = ext[1], tw = ext[2] + ext[4] - ext[0], th = ext[4];
+    const bool one_row = tw > 0 && ext[1] == ext[3] && th <= TAPS;   /* all lanes in one image row (the footprint size is a constant of the filter) */
+    if (one_row) {
+        /* the lanes of pixel (x, y) are the global lanes [p * spp, (p + 1) * spp), p = y * crop_w + x (integrator.cpp:322-334), and their
+         * footprint starts at x - n: for the tile column `col`, tap t collects exactly the lanes of pixel x = col - t + n */
+        const int count = th, nhalf = (count - 1) / 2, y_pix = oy + nhalf;
+        const int64_t g0 = (int64_t) lane_base + (int64_t) blockIdx.x * kBlock;
+        const int n_act = (int) n_act_u;
+        const int slab_w = HAR_SPLAT_TILE_PIXELS / th;
+        for (int c0 = 0; c0 < tw; c0 += slab_w) {
+            const int sw = min(slab_w, tw - c0), E = sw * th;
+            int G = 1; while (G < HAR_SPLAT_GATHER_MAX_SPLIT && E * G * 2 <= kBlock) G *= 2;
+            for (int idx = threadIdx.x; idx < E * G; idx += kBlock) {
+                const int e = idx % E, g = idx / E, tx = e % sw, ty = e / sw, col = ox + c0 + tx;
+                float ax = 0.f, ay = 0.f, az = 0.f, aw = 0.f;
+                for (int t = 0; t < count; ++t) {
+                    const int x = col - t + nhalf;
+                    if (x < 0 || x >= (int) C.crop_w) continue;
+                    const int64_t first = ((int64_t) y_pix * C.crop_w + x) * spp - g0;
+                    int la = (int) max((int64_t) 0, first), lb = (int) min((int64_t) n_act, first + spp);
+                    if (la >= lb) continue;
+                    const int len = lb - la; lb = la + (len * (g + 1)) / G; la = la + (len * g) / G;
+                    const float *wxp = s_wx[t], *wyp = s_wy[ty];
+#pragma unroll 4
+                    for (int l = la; l < lb; ++l) {
+                        const float w = wxp[l] * wyp[l];
+                        const float4 v = s_val[l];
+                        ax += v.x * w; ay += v.y * w; az += v.z * w; aw += v.w * w;
                     }
-                    float d = wave_sum_to_last(val[3] * w);
-                    if (last) atomicAdd(p + 3, d);
                 }
-        } else if (act) {
-            for (uint32_t ys = 0; ys < F.count; ++ys)
-                for (uint32_t xs = 0; xs < F.count; ++xs) {
-                    float w = F.wx[xs] * F.wy[ys];
-                    float *p = tile + 4 * (((int) F.y0 + (int) ys - oy) * tw + ((int) F.x0 + (int) xs - ox));
-                    if (!weights_only) { atomicAdd(p, val[0] * w); atomicAdd(p + 1, val[1] * w); atomicAdd(p + 2, val[2] * w); }
-                    atomicAdd(p + 3, val[3] * w);
-                }
+                reinterpret_cast<float4 *>(tile)[idx] = make_float4(ax, ay, az, aw);      /* partial sum g of pixel e (E * G <= 512 slots) */
+            }
+            __syncthreads();
+            for (int k = threadIdx.x; k < E * 4; k += kBlock) {
+                float v = tile[k];
+                for (int g = 1; g < G; ++g) v += tile[k + 4 * E * g];
+                const int px = k >> 2, x = ox + c0 + px % sw, y = oy + px / sw;
+                if (v != 0.f && (uint32_t) x < C.crop_w && (uint32_t) y < C.crop_h)
+                    atomicAdd(film + 4 * ((size_t) y * C.crop_w + x) + (k & 3), v);
+            }
+            __syncthreads();
         }
-        __syncthreads();
-        for (int k = threadIdx.x; k < tw * th * 4; k += kBlock) {
-            float v = tile[k];
-            int px = k >> 2, x = ox + px % tw, y = oy + px / tw;
-            if (v != 0.f && (uint32_t) x < C.crop_w && (uint32_t) y < C.crop_h)
-                atomicAdd(film + 4 * ((size_t) y * C.crop_w + x) + (k & 3), v);
-        }
-    } else if (act) {
-        for (uint32_t ys = 0; ys < F.count; ++ys)
-            for (uint32_t xs = 0; xs < F.count; ++xs) {
-                uint32_t x = F.x0 + xs, y = F.y0 + ys;
-                if (x < C.crop_w && y < C.crop_h) {
-                    float w = F.wx[xs] * F.wy[ys];
+    } else if (act) {           /* lanes of two image rows in one block (width * spp not a multiple of 256): per-lane scatter */
+#pragma unroll
+        for (int ys = 0; ys < TAPS; ++ys)
+#pragma unroll
+            for (int xs = 0; xs < TAPS; ++xs) {
+                const uint32_t x = F.x0 + (uint32_t) xs, y = F.y0 + (uint32_t) ys;
+                if ((uint32_t) xs < F.count && (uint32_t) ys < F.count && x < C.crop_w && y < C.crop_h) {
+                    const float w = F.wx[xs] * F.wy[ys];
                     float *p = film + 4 * ((size_t) y * C.crop_w + x);
                     if (!weights_only) { atomicAdd(p, val[0] * w); atomicAdd(p + 1, val[1] * w); atomicAdd(p + 2, val[2] * w); }
                     atomicAdd(p + 3, val[3] * w);
@@ -751,7 +774,10 @@ void launch_resolve(int mode, hipStream_t s, uint32_t grid, uint2 *spill, const 
 }
 void launch_splat(hipStream_t s, const DSensor &C, uint32_t seed, uint32_t spp, uint32_t log_spp, uint32_t lane_base, uint32_t n,
                   const float4 *result, int weights_only, float *film, const float2 *jitter) {
-    hipLaunchKernelGGL(k_splat, dim3(blocks_for(n)), dim3(kBlock), 0, s, C, seed, spp, log_spp, lane_base, n, result, weights_only, film, jitter);
+    /* filter taps per axis: 2 * ceil(radius - 1/2) + 1 (5 for the default gaussian); the kernel is instantiated for <= 5 and <= 9 (LDS budget) */
+    const uint32_t taps = C.rfilter == 0 ? 1u : 2u * (uint32_t) ceilf(C.radius - .5f) + 1u;
+    if (taps <= 5) hipLaunchKernelGGL(k_splat<5>, dim3(blocks_for(n)), dim3(kBlock), 0, s, C, seed, spp, log_spp, lane_base, n, result, weights_only, film, jitter);
+    else hipLaunchKernelGGL(k_splat<HAR_MAX_FILTER_TAPS>, dim3(blocks_for(n)), dim3(kBlock), 0, s, C, seed, spp, log_spp, lane_base, n, result, weights_only, film, jitter);
 }
 void launch_pass_jitter(hipStream_t s, uint32_t seed, uint32_t lane_base, uint32_t n, uint32_t pass, float2 *jitter) {
     hipLaunchKernelGGL(k_pass_jitter, dim3(blocks_for(n)), dim3(kBlock), 0, s, seed, lane_base, n, pass, jitter);

@@ -84,7 +84,10 @@ HAR_HD void film_footprint(const DSensor &C, const LaneSample &L, Footprint &F) 
     int32_t ix = (int32_t) floorf(L.pos_x) - (int32_t) n, iy = (int32_t) floorf(L.pos_y) - (int32_t) n;
     F.x0 = (uint32_t) (ix - (int32_t) C.crop_x); F.y0 = (uint32_t) (iy - (int32_t) C.crop_y);
     float relx = ((float) ix + .5f) - L.pos_x, rely = ((float) iy + .5f) - L.pos_y;
-    for (uint32_t k = 0; k < HAR_MAX_FILTER_TAPS; ++k) {
+#if defined(__HIP_DEVICE_COMPILE__)
+#pragma unroll
+#endif
+    for (uint32_t k = 0; k < HAR_MAX_FILTER_TAPS; ++k) {      /* static indices: the weights stay in registers */
         if (k < F.count) { F.wx[k] = rfilter_eval(C, relx + (float) k); F.wy[k] = rfilter_eval(C, rely + (float) k); }
     }
 }
