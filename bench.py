@@ -50,6 +50,8 @@ def build_scene(mi, args, integrator_type):
                                        flatten=(args.workload in ("flat1m", "materials1m")), max_depth=args.max_depth,
                                        materials=(args.workload == "materials1m"))
     d["integrator"] = {"type": integrator_type, "max_depth": args.max_depth, "rr_depth": 5, "chunk_lanes": args.chunk}
+    if integrator_type == "prb":
+        d["integrator"]["emitter_gradients"] = False      # north_star: gradients w.r.t. BSDF / texture parameters
     return mi.load_dict(d)
 
 

@@ -146,6 +146,7 @@ int har_scene_destroy(HarScene scene);
 /* SceneParameters update of `<bsdf>.reflectance.value` / `<bsdf>.reflectance.data`
  * (mi.traverse + params.update(), src/python/python/util.py). HOST data. */
 int har_scene_set_reflectance(HarScene scene, uint32_t bsdf, const float rgb[3]);
+int har_scene_set_emitter_radiance(HarScene scene, uint32_t emitter, const float rgb[3]);   /* `area` / `constant` emitters */
 int har_scene_set_texture(HarScene scene, uint32_t texture, const float *data);
 /* accel statistics: node count, triangle count, bytes */
 int har_scene_accel_info(HarScene scene, uint64_t info[4]);
@@ -248,6 +249,10 @@ int har_render_backward(HarScene scene, HarIntegrator integrator, const HarSenso
                         const float *grad_in, const float *weight_film, uint32_t seed,
                         uint32_t spp, uint64_t lane_begin, uint64_t lane_end,
                         float *grad_reflectance, float *const *grad_textures, void *stream);
+
+/* Gradient w.r.t. the radiance of `area` / `constant` emitters (prb.py:160-161,198-206 with the emitter attached): when a DEVICE buffer of
+ * emitter_count x 3 floats is set, har_render_backward also accumulates into it; NULL switches it off again */
+int har_integrator_set_grad_emitters(HarIntegrator integrator, float *grad_emitters);
 
 /* counters of the last har_render / har_render_backward on this integrator (synchronises) */
 int har_render_stats(HarIntegrator integrator, HarStats *out);

@@ -674,6 +674,7 @@ class Integrator:
             raise RuntimeError("\"rr_depth\" must be set to a value greater than zero!")
         self.chunk_lanes = int(props.get('chunk_lanes', 0))
         self.replay_cache = bool(props.get('replay_cache', True))      # hip_ad_rgb extension, see har_integrator_set_replay_cache
+        self.emitter_gradients = bool(props.get('emitter_gradients', True))   # d / d radiance of area / constant emitters (har_integrator_set_grad_emitters)
         # SamplingIntegrator property (integrator.cpp:140-147); the Python AD integrators do not query it, and an
         # unqueried property is an error in the reference's plugin loader
         self.samples_per_pass = props.get('samples_per_pass', None)
@@ -775,9 +776,11 @@ class Integrator:
         g_refl = torch.zeros((len(scene.bsdfs), 3), dtype=torch.float32, device=dev)
         g_tex = [torch.zeros(tuple(t.shape), dtype=torch.float32, device=dev) for t in scene.textures]
         ptrs = (C.c_void_p * max(1, len(g_tex)))(*[t.data_ptr() for t in g_tex])
+        g_emit = torch.zeros((max(1, len(scene.emitters)), 3), dtype=torch.float32, device=dev)
+        check(lib().har_integrator_set_grad_emitters(self._handle(), _ptr(g_emit) if self.emitter_gradients else None))
         check(lib().har_render_backward(scene._handle(), self._handle(), C.byref(sensor.har), _ptr(grad_in), _ptr(weight_film), sd, spp,
                                         lb, le, _ptr(g_refl), ptrs, _stream()))
-        return scene._gradients(g_refl, g_tex)
+        return scene._gradients(g_refl, g_tex, g_emit if self.emitter_gradients else None)
 
 
 class Bitmap:
@@ -1035,12 +1038,23 @@ class Scene:
                 keys[base + "." + b.slot0_name + ".data"] = ("tex", b)
             else:
                 keys[base + "." + b.slot0_name + ".value"] = ("rgb", b)
+        # emitter radiances: `<shape>.emitter.radiance.value` for area lights, `<emitter>.radiance.value` for `constant` (type 2 = envmap: none)
+        for i, key in enumerate(self._emitter_order):
+            e = self.emitters[i]
+            if e.get("type", 0) == 0:
+                keys[key + ".emitter.radiance.value"] = ("emit", i)
+            elif e["type"] == 1:
+                keys[key + ".radiance.value"] = ("emit", i)
         return keys
 
-    def _gradients(self, g_refl, g_tex):
+    def _gradients(self, g_refl, g_tex, g_emit=None):
         out = {}
         for k, (kind, b) in self._param_keys().items():
-            out[k] = g_tex[b.tex_index] if kind == "tex" else g_refl[b.index]
+            if kind == "emit":
+                if g_emit is not None:
+                    out[k] = g_emit[b]
+            else:
+                out[k] = g_tex[b.tex_index] if kind == "tex" else g_refl[b.index]
         return out
 
 
@@ -1053,7 +1067,8 @@ class SceneParameters(dict):
         self.scene = scene
         dev = torch.device("cuda", torch.cuda.current_device()) if torch.cuda.is_available() else torch.device("cpu")
         for k, (kind, b) in scene._param_keys().items():
-            self[k] = torch.tensor(b.texture if kind == "tex" else b.value, dtype=torch.float32, device=dev)
+            value = scene.emitters[b]["radiance"] if kind == "emit" else (b.texture if kind == "tex" else b.value)
+            self[k] = torch.tensor(np.asarray(value, np.float32), dtype=torch.float32, device=dev)
 
     def update(self, values=None):
         if values:
@@ -1061,7 +1076,11 @@ class SceneParameters(dict):
                 self[k] = v
         for k, (kind, b) in self.scene._param_keys().items():
             v = self[k].detach().to("cpu", copy=True).numpy().astype(np.float32)
-            if kind == "tex":
+            if kind == "emit":
+                self.scene.emitters[b]["radiance"] = np.ascontiguousarray(v.reshape(3))
+                if self.scene._h is not None:
+                    check(lib().har_scene_set_emitter_radiance(self.scene._h, b, _fp(self.scene.emitters[b]["radiance"])))
+            elif kind == "tex":
                 b.texture = np.ascontiguousarray(v.reshape(b.texture.shape)); self.scene.textures[b.tex_index] = b.texture
                 if self.scene._h is not None:
                     check(lib().har_scene_set_texture(self.scene._h, b.tex_index, _fp(b.texture)))

@@ -61,6 +61,8 @@ struct HarIntegratorImpl {
     /* PRB replay cache (see ReplayCache): cache_bounces arrays of ws_lanes entries each */
     float4 *rc_h0 = nullptr; uint2 *rc_h1 = nullptr; uint8_t *rc_vis = nullptr; uint32_t cache_bounces = 0; bool use_cache = true;
     float *adj = nullptr; size_t adj_floats = 0;
+    float *grad_slots = nullptr; size_t grad_slots_cap = 0;   /* adjoint accumulators: (bsdf_count + emitter_count) x 3 */
+    float *grad_emitters = nullptr;       /* user buffer (DEVICE, emitter_count x 3) of har_integrator_set_grad_emitters, or null */
     uint2 *stack_spill = nullptr;         /* HBM part of the traversal stacks: HAR_STACK_SPILL entries per thread of the largest traversal grid */
     /* multi-pass rendering: sampler state per lane of the rendered lane range, pixel jitter per chunk lane (see PassState) */
     uint32_t samples_per_pass = 0xffffffffu;
@@ -95,6 +97,7 @@ int ensure_workspace(HarIntegratorImpl *I, uint32_t lanes, bool adjoint) {
     I->free_ws();
     I->counters = nullptr; I->totals = nullptr; I->status = nullptr; I->adj = nullptr; I->adj_floats = 0; I->d_grad_tex = nullptr; I->grad_tex_cap = 0;
     I->pass_rng = nullptr; I->pass_rng_cap = 0; I->pass_jitter = nullptr; I->pass_jitter_cap = 0;
+    I->grad_slots = nullptr; I->grad_slots_cap = 0;
     for (int k = 0; k < 2; ++k) {
         if (ws_alloc(I, &I->st[k].a0, lanes) || ws_alloc(I, &I->st[k].a1, lanes) || ws_alloc(I, &I->st[k].a2, lanes) ||
             ws_alloc(I, &I->st[k].a3, lanes) || ws_alloc(I, &I->st[k].a4, lanes)) return 1;
@@ -150,7 +153,7 @@ int run_chunk(HarSceneImpl *S, HarIntegratorImpl *I, const DSensor &C, int mode,
     HIP_TRY(hipMemsetAsync(cur_resolve(I, 0), 0, used, s));
     launch_raygen(mode, s, C, seed, spp, log_spp, lane_base, n, I->shard_cap, I->st[0], I->result, cnt_alive(I, 0), I->adj, I->dL, ps);
     prof_mark(I, s, CLS_RAYGEN);
-    ShadeParams P{ seed, I->max_depth, I->rr_depth };
+    ShadeParams P{ seed, I->max_depth, I->rr_depth, (mode == MODE_PRB_ADJOINT && I->grad_emitters) ? HAR_SHADE_EMITTER_GRADS : 0u };
     /* grid: a multiple of 8 so that block b serves shard b % 8; enough blocks to cover the chunk once */
     const uint32_t grid = std::max<uint32_t>(HAR_SHARDS, std::min<uint32_t>(((n + 255) / 256 + HAR_SHARDS - 1) / HAR_SHARDS * HAR_SHARDS, 4096u));
     /* persistent traversal kernels: enough blocks to fill the chip (<= 8 blocks/CU), never more than the work */
@@ -169,7 +172,7 @@ int run_chunk(HarSceneImpl *S, HarIntegratorImpl *I, const DSensor &C, int mode,
             prof_mark(I, s, CLS_TRACE);
         }
         launch_shade(mode, s, grid, S->ds, P, lane_base, I->shard_cap, cnt_alive(I, b), I->st[cur], I->h0, I->h1, I->st[cur ^ 1], cnt_alive(I, b + 1),
-                     I->items, cnt_items(I, b), I->result, rc, ps.rng);
+                     I->items, cnt_items(I, b), I->result, rc, ps.rng, I->dL, grad_refl);
         prof_mark(I, s, CLS_SHADE);
         launch_resolve(mode, s, rc.mode == 2 ? grid : tgrid, spill, S->ds, cnt_items(I, b), cur_resolve(I, b), I->shard_cap, I->items, I->result, I->dL, grad_refl, I->d_grad_tex, I->status, rc);
         prof_mark(I, s, CLS_RESOLVE);
@@ -291,6 +294,14 @@ int har_scene_set_reflectance(HarScene S, uint32_t bsdf, const float rgb[3]) {
     DBsdf &b = S->hs.bsdfs[bsdf]; b.r = rgb[0]; b.g = rgb[1]; b.b = rgb[2];
     if (b.type == BSDF_ROUGHPLASTIC) update_roughplastic_sampling_weight(S->hs, bsdf);     /* RoughPlastic::parameters_changed */
     HIP_TRY(hipMemcpy(S->d_bsdfs + bsdf, &b, sizeof(DBsdf), hipMemcpyHostToDevice));
+    return 0;
+}
+int har_scene_set_emitter_radiance(HarScene S, uint32_t emitter, const float rgb[3]) {
+    if (!S || emitter >= S->hs.emitters.size()) return fail("invalid emitter index");
+    DEmitter &e = S->hs.emitters[emitter];
+    if (e.type == 2u) return fail("an environment map has no constant radiance");
+    e.radiance[0] = rgb[0]; e.radiance[1] = rgb[1]; e.radiance[2] = rgb[2];
+    HIP_TRY(hipMemcpy(const_cast<DEmitter *>(S->ds.emitters) + emitter, &e, sizeof(DEmitter), hipMemcpyHostToDevice));
     return 0;
 }
 int har_scene_set_texture(HarScene S, uint32_t tex, const float *data) {
@@ -518,6 +529,10 @@ int har_render_backward(HarScene S, HarIntegrator I, const HarSensor *sensor, co
         HIP_TRY(hipMemcpyAsync(I->d_grad_tex, grad_textures, nt * sizeof(float *), hipMemcpyHostToDevice, s));
         HIP_TRY(hipStreamSynchronize(s));
     }
+    /* the kernels accumulate into (bsdf_count + emitter_count) x 3 slots; the two halves are added to the caller's buffers at the end */
+    const size_t nb3 = 3 * S->hs.bsdfs.size(), ne3 = 3 * S->hs.emitters.size();
+    if (I->grad_slots_cap < nb3 + ne3 + 3) { if (ws_alloc(I, &I->grad_slots, nb3 + ne3 + 3)) return 1; I->grad_slots_cap = nb3 + ne3 + 3; }
+    HIP_TRY(hipMemsetAsync(I->grad_slots, 0, (nb3 + ne3 + 3) * sizeof(float), s));
     HIP_TRY(hipMemsetAsync(I->totals, 0, 4 * sizeof(unsigned long long), s));
     HIP_TRY(hipMemsetAsync(I->status, 0, sizeof(int), s));
     I->ev_used = 0; I->last_stream = s;
@@ -529,9 +544,18 @@ int har_render_backward(HarScene S, HarIntegrator I, const HarSensor *sensor, co
         /* pass 1: primal, keeps L per lane in `result` (common.py:752-762) */
         if (run_chunk(S, I, C, MODE_PRB_PRIMAL, seed, spp, log_spp, (uint32_t) base, n, nullptr, s, I->cache_bounces ? 1 : 0)) return 1;
         /* pass 2: adjoint replay with the identical sample stream (common.py:765-775) */
-        if (run_chunk(S, I, C, MODE_PRB_ADJOINT, seed, spp, log_spp, (uint32_t) base, n, grad_reflectance, s, I->cache_bounces ? 2 : 0)) return 1;
+        if (run_chunk(S, I, C, MODE_PRB_ADJOINT, seed, spp, log_spp, (uint32_t) base, n, I->grad_slots, s, I->cache_bounces ? 2 : 0)) return 1;
     }
+    launch_add(s, I->grad_slots, grad_reflectance, (uint32_t) nb3);
+    if (I->grad_emitters && ne3) launch_add(s, I->grad_slots + nb3, I->grad_emitters, (uint32_t) ne3);
     HIP_TRY(hipGetLastError());
+    return 0;
+}
+
+int har_integrator_set_grad_emitters(HarIntegrator I, float *grad_emitters) {
+    if (!I) return fail("null integrator");
+    if (I->type != HAR_INTEGRATOR_PRB) return fail("emitter gradients are computed by the `prb` integrator");
+    I->grad_emitters = grad_emitters;
     return 0;
 }
 

@@ -18,7 +18,8 @@
 #define HAR_STACK_MARGIN (HAR_TRAV_POLICY == 2 ? HAR_MAX_PARKED : 0)
 #endif
 #define HAR_REPLAY_CACHE_BOUNCES 12 /* PRB replay cache depth (25 B per lane and bounce); deeper bounces are traced twice */
-#define HAR_LDS_GRAD_BSDFS 256     /* constant-albedo gradients accumulated per block in LDS (adjoint resolve) */
+#define HAR_LDS_GRAD_BSDFS 256     /* constant-albedo (and emitter-radiance) gradient slots accumulated per block in LDS (adjoint resolve) */
+#define HAR_LDS_GRAD_EMITTERS 32    /* emitter-radiance gradients of emission hits accumulated per block in LDS (adjoint shade) */
 #define HAR_SHARDS 8                /* XCD-private path queues */
 #define HAR_MAX_TRAVERSAL_BLOCKS 2048 /* persistent traversal kernels: enough blocks to fill the chip (<= 8 blocks/CU) */
 #define HAR_COUNTER_STRIDE 16       /* u32 stride between shard counters: one 64 B line each */
@@ -48,7 +49,7 @@ void launch_trace_closest(hipStream_t s, uint32_t grid, uint2 *spill, const Acce
                           const WaveState &in, float4 *h0, uint2 *h1, int *status);
 void launch_shade(int mode, hipStream_t s, uint32_t grid, const DScene &S, const ShadeParams &P, uint32_t lane_base, uint32_t shard_cap, const uint32_t *count_in,
                   const WaveState &in, const float4 *h0, const uint2 *h1, const WaveState &out, uint32_t *count_out, const ItemArrays &items,
-                  uint32_t *item_count, float4 *result, const ReplayCache &rc, uint64_t *pass_rng = nullptr);
+                  uint32_t *item_count, float4 *result, const ReplayCache &rc, uint64_t *pass_rng = nullptr, const float4 *dL = nullptr, float *grad_slots = nullptr);
 void launch_resolve(int mode, hipStream_t s, uint32_t grid, uint2 *spill, const DScene &S, const uint32_t *item_count, uint32_t *cursor, uint32_t shard_cap, const ItemArrays &items,
                     float4 *result, const float4 *dL, float *grad_refl, float *const *grad_tex, int *status, const ReplayCache &rc);
 void launch_splat(hipStream_t s, const DSensor &C, uint32_t seed, uint32_t spp, uint32_t log_spp, uint32_t lane_base, uint32_t n,
@@ -56,6 +57,7 @@ void launch_splat(hipStream_t s, const DSensor &C, uint32_t seed, uint32_t spp, 
 void launch_pass_jitter(hipStream_t s, uint32_t seed, uint32_t lane_base, uint32_t n, uint32_t pass, float2 *jitter);
 void launch_develop(hipStream_t s, const float *film, uint32_t npx, float *image);
 void launch_adjoint_image(hipStream_t s, const float *grad_in, const float *wfilm, uint32_t npx, float *adj);
+void launch_add(hipStream_t s, const float *src, float *dst, uint32_t n);      /* dst[i] += src[i] */
 void launch_accumulate_stats(hipStream_t s, const uint32_t *counters, uint32_t n_bounces, unsigned long long *totals, uint32_t paths);
 
 void launch_api_intersect(hipStream_t s, const DScene &S, uint32_t n, const float *o, const float *d, const float *maxt, int naive,

@@ -314,8 +314,13 @@ __global__ __launch_bounds__(kBlock) void k_trace_closest(Accel A, const uint32_
 template <int MODE, uint32_t TYPES>
 __global__ __launch_bounds__(kBlock, HAR_SHADE_MIN_WAVES) void k_shade(DScene S, ShadeParams P, uint32_t lane_base, uint32_t shard_cap, const uint32_t *count_in, WaveState in,
                                                   const float4 *h0, const uint2 *h1, WaveState out, uint32_t *count_out,
-                                                  ItemArrays items, uint32_t *item_count, float4 *result, ReplayCache rc, uint64_t *pass_rng) {
+                                                  ItemArrays items, uint32_t *item_count, float4 *result, ReplayCache rc, uint64_t *pass_rng,
+                                                  const float4 *dL, float *grad_slots) {
     __shared__ uint32_t lds_r[12];
+    /* adjoint with emitter gradients: per-block accumulators of d L / d radiance from emission hits (slots n_bsdfs + emitter of `grad_slots`) */
+    __shared__ float eacc[MODE == MODE_PRB_ADJOINT ? 3 * HAR_LDS_GRAD_EMITTERS : 1];
+    const bool emitter_grads = MODE == MODE_PRB_ADJOINT && (P.flags & HAR_SHADE_EMITTER_GRADS) != 0u;
+    if (emitter_grads) { for (uint32_t k = threadIdx.x; k < 3 * HAR_LDS_GRAD_EMITTERS; k += kBlock) eacc[k] = 0.f; __syncthreads(); }
     __shared__ uint32_t sort_cnt[8], sort_perm[TYPES == HAR_BSDF_ONLY_DIFFUSE ? 1 : kBlock];
     const ShardLoop Q(count_in, shard_cap);
     uint32_t *cnt_alive = count_out + Q.shard * HAR_COUNTER_STRIDE, *cnt_item = item_count + Q.shard * HAR_COUNTER_STRIDE;
@@ -372,6 +377,12 @@ __global__ __launch_bounds__(kBlock, HAR_SHADE_MIN_WAVES) void k_shade(DScene S,
                 else if (MODE == MODE_PRB_PRIMAL) r = make_float4(r.x + R.em_b.x, r.y + R.em_b.y, r.z + R.em_b.z, 0.f);
                 else                              r = make_float4(r.x - R.em_b.x, r.y - R.em_b.y, r.z - R.em_b.z, 0.f);
                 result[lane] = r;
+                if (MODE == MODE_PRB_ADJOINT && emitter_grads && R.em_index >= 0) {
+                    const float4 dl = dL[lane];
+                    const Vec3 g = R.em_unit * Vec3(dl.x, dl.y, dl.z);
+                    if ((uint32_t) R.em_index < HAR_LDS_GRAD_EMITTERS) { float *a = eacc + 3 * R.em_index; atomicAdd(a, g.x); atomicAdd(a + 1, g.y); atomicAdd(a + 2, g.z); }
+                    else { float *a = grad_slots + 3 * ((size_t) S.n_bsdfs + R.em_index); atomicAdd(a, g.x); atomicAdd(a + 1, g.y); atomicAdd(a + 2, g.z); }
+                }
             }
         }
         const bool alive = in_range && R.alive, item = in_range && R.item;
@@ -382,11 +393,24 @@ __global__ __launch_bounds__(kBlock, HAR_SHADE_MIN_WAVES) void k_shade(DScene S,
             islot += Q.base;
             items.s0[islot] = make_float4(R.sh_o.x, R.sh_o.y, R.sh_o.z, R.item_ray ? R.sh_maxt : -1.f);
             items.s1[islot] = make_float4(R.sh_d.x, R.sh_d.y, R.sh_d.z, __uint_as_float(lane));
-            items.s2[islot] = make_float4(R.contrib.x, R.contrib.y, R.contrib.z, __uint_as_float(MODE == MODE_PRB_ADJOINT ? (R.bsdf | (R.ind_active ? 0x80000000u : 0u)) : 0u));
+            if (MODE == MODE_PRB_ADJOINT) {
+                /* tag = bsdf (20 bits) | emitter (11 bits) | indirect-term flag; with an emitter the item carries the contribution for a unit radiance */
+                const bool fact = R.nee_emitter >= 0 && (uint32_t) R.nee_emitter < HAR_ITEM_NO_EMITTER;
+                const Vec3 c = fact ? R.contrib_unit : R.contrib;
+                const uint32_t tag = (R.bsdf & 0xfffffu) | ((fact ? (uint32_t) R.nee_emitter : HAR_ITEM_NO_EMITTER) << 20) | (R.ind_active ? 0x80000000u : 0u);
+                items.s2[islot] = make_float4(c.x, c.y, c.z, __uint_as_float(tag));
+            } else items.s2[islot] = make_float4(R.contrib.x, R.contrib.y, R.contrib.z, 0.f);
             if (MODE == MODE_PRB_ADJOINT) {
                 items.s3[islot] = make_float4(R.dLr_drho.x, R.dLr_drho.y, R.dLr_drho.z, R.uv_x);
                 items.s4[islot] = make_float4(R.rel_grad.x, R.rel_grad.y, R.rel_grad.z, R.uv_y);
             }
+        }
+    }
+    if (emitter_grads) {
+        __syncthreads();
+        for (uint32_t k = threadIdx.x; k < 3 * min(S.n_emitters, (uint32_t) HAR_LDS_GRAD_EMITTERS); k += kBlock) {
+            const float v = eacc[k];
+            if (v != 0.f) atomicAdd(grad_slots + 3 * (size_t) S.n_bsdfs + k, v);
         }
     }
 }
@@ -399,9 +423,20 @@ __device__ __forceinline__ void adjoint_commit(const DScene &S, const ItemArrays
     if (pred) {
         const uint32_t lane = __float_as_uint(items.s1[i].w);
         float4 s2 = items.s2[i], L = result[lane];
+        const float4 dl = dL[lane];
+        const uint32_t tag = __float_as_uint(s2.w), bsdf = tag & 0xfffffu, emitter = (tag >> 20) & 0x7ffu;
+        if (emitter != HAR_ITEM_NO_EMITTER) {       /* the item carries Lr_dir for a unit radiance: d Lr_dir / d radiance, and Lr_dir = unit * radiance */
+            const DEmitter E = S.emitters[emitter];
+            if (visible) {
+                const Vec3 ge = Vec3(s2.x, s2.y, s2.z) * Vec3(dl.x, dl.y, dl.z);
+                const uint32_t slot = S.n_bsdfs + emitter;
+                if (slot < HAR_LDS_GRAD_BSDFS) { atomicAdd(&gacc[3 * slot], ge.x); atomicAdd(&gacc[3 * slot + 1], ge.y); atomicAdd(&gacc[3 * slot + 2], ge.z); }
+                else { float *a = grad_refl + 3 * (size_t) slot; atomicAdd(a, ge.x); atomicAdd(a + 1, ge.y); atomicAdd(a + 2, ge.z); }
+            }
+            s2.x *= E.radiance[0]; s2.y *= E.radiance[1]; s2.z *= E.radiance[2];
+        }
         if (visible) { L = make_float4(L.x - s2.x, L.y - s2.y, L.z - s2.z, 0.f); result[lane] = L; }
-        float4 s3 = items.s3[i], s4 = items.s4[i], dl = dL[lane];
-        const uint32_t tag = __float_as_uint(s2.w), bsdf = tag & 0x7fffffffu;
+        float4 s3 = items.s3[i], s4 = items.s4[i];
         g = visible ? Vec3(s3.x, s3.y, s3.z) : Vec3(0.f);
         if (tag & 0x80000000u) g = g + Vec3(L.x * s4.x, L.y * s4.y, L.z * s4.z);
         g = g * Vec3(dl.x, dl.y, dl.z);
@@ -438,7 +473,7 @@ __global__ __launch_bounds__(kBlock) void k_resolve_adjoint_cached(DScene S, con
         adjoint_commit(S, items, i, pred, visible, result, dL, grad_refl, grad_tex, gacc);
     }
     __syncthreads();
-    for (uint32_t k = threadIdx.x; k < 3 * min(S.n_bsdfs, (uint32_t) HAR_LDS_GRAD_BSDFS); k += kBlock) {
+    for (uint32_t k = threadIdx.x; k < 3 * min(S.n_bsdfs + S.n_emitters, (uint32_t) HAR_LDS_GRAD_BSDFS); k += kBlock) {
         const float v = gacc[k];
         if (v != 0.f) atomicAdd(grad_refl + k, v);
     }
@@ -490,7 +525,7 @@ __global__ __launch_bounds__(kBlock) void k_resolve(DScene S, const uint32_t *it
                 adjoint_commit(S, items, base + (pred ? idx : 0u), pred, pred && !T.found, result, dL, grad_refl, grad_tex, gacc);
             });
         __syncthreads();
-        for (uint32_t k = threadIdx.x; k < 3 * min(S.n_bsdfs, (uint32_t) HAR_LDS_GRAD_BSDFS); k += kBlock) {
+        for (uint32_t k = threadIdx.x; k < 3 * min(S.n_bsdfs + S.n_emitters, (uint32_t) HAR_LDS_GRAD_BSDFS); k += kBlock) {
             const float v = gacc[k];
             if (v != 0.f) atomicAdd(grad_refl + k, v);
         }
@@ -617,6 +652,10 @@ __global__ void k_adjoint_image(const float *grad_in, const float *wfilm, uint32
     if (i >= npx) return;
     float w = wfilm[4 * (size_t) i + 3]; float iw = w == 0.f ? 1.f : w;
     for (int c = 0; c < 3; ++c) adj[3 * (size_t) i + c] = grad_in[3 * (size_t) i + c] / iw;
+}
+__global__ void k_add(const float *src, float *dst, uint32_t n) {
+    uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) dst[i] += src[i];
 }
 __global__ void k_accumulate_stats(const uint32_t *counters, uint32_t n_bounces, unsigned long long *totals, uint32_t paths) {
     if (threadIdx.x || blockIdx.x) return;
@@ -747,11 +786,11 @@ void launch_trace_closest(hipStream_t s, uint32_t grid, uint2 *spill, const Acce
 }
 void launch_shade(int mode, hipStream_t s, uint32_t grid, const DScene &S, const ShadeParams &P, uint32_t lane_base, uint32_t shard_cap, const uint32_t *count_in,
                   const WaveState &in, const float4 *h0, const uint2 *h1, const WaveState &out, uint32_t *count_out, const ItemArrays &items,
-                  uint32_t *item_count, float4 *result, const ReplayCache &rc, uint64_t *pass_rng) {
+                  uint32_t *item_count, float4 *result, const ReplayCache &rc, uint64_t *pass_rng, const float4 *dL, float *grad_slots) {
     dim3 g(grid), b(kBlock);
     /* diffuse-only scenes (no twosided wrappers) run kernels in which the other BSDF models are compiled out */
     const bool only_diffuse = S.bsdf_types == HAR_BSDF_ONLY_DIFFUSE;
-#define HAR_LAUNCH_SHADE(M, T) hipLaunchKernelGGL((k_shade<M, T>), g, b, 0, s, S, P, lane_base, shard_cap, count_in, in, h0, h1, out, count_out, items, item_count, result, rc, pass_rng)
+#define HAR_LAUNCH_SHADE(M, T) hipLaunchKernelGGL((k_shade<M, T>), g, b, 0, s, S, P, lane_base, shard_cap, count_in, in, h0, h1, out, count_out, items, item_count, result, rc, pass_rng, dL, grad_slots)
     const bool envmap = (S.bsdf_types & HAR_SCENE_ENVMAP) != 0u;      /* generic BSDF code + environment-map sampling / lookup */
 #define HAR_LAUNCH_SHADE_MODE(M) do { if (envmap) HAR_LAUNCH_SHADE(M, HAR_BSDF_ALL_TYPES | HAR_SCENE_ENVMAP); else if (only_diffuse) HAR_LAUNCH_SHADE(M, HAR_BSDF_ONLY_DIFFUSE); else HAR_LAUNCH_SHADE(M, HAR_BSDF_ALL_TYPES); } while (0)
     if (mode == MODE_PATH)            HAR_LAUNCH_SHADE_MODE(MODE_PATH);
@@ -787,6 +826,9 @@ void launch_develop(hipStream_t s, const float *film, uint32_t npx, float *image
 }
 void launch_adjoint_image(hipStream_t s, const float *grad_in, const float *wfilm, uint32_t npx, float *adj) {
     hipLaunchKernelGGL(k_adjoint_image, dim3(blocks_for(npx)), dim3(kBlock), 0, s, grad_in, wfilm, npx, adj);
+}
+void launch_add(hipStream_t s, const float *src, float *dst, uint32_t n) {
+    if (n) hipLaunchKernelGGL(k_add, dim3(blocks_for(n)), dim3(kBlock), 0, s, src, dst, n);
 }
 void launch_accumulate_stats(hipStream_t s, const uint32_t *counters, uint32_t n_bounces, unsigned long long *totals, uint32_t paths) {
     hipLaunchKernelGGL(k_accumulate_stats, dim3(1), dim3(1), 0, s, counters, n_bounces, totals, paths);

@@ -32,7 +32,10 @@ struct PathState {
 
 struct ShadeParams {
     uint32_t seed, max_depth, rr_depth;
+    uint32_t flags = 0;        /* bit 0 (adjoint): also accumulate the gradient w.r.t. the radiance of `area` / `constant` emitters */
 };
+#define HAR_SHADE_EMITTER_GRADS 1u
+#define HAR_ITEM_NO_EMITTER 0x7ffu   /* emitter field of an adjoint item's tag: contribution stored as is (no emitter gradient) */
 
 struct ShadeResult {
     bool alive;
@@ -44,6 +47,9 @@ struct ShadeResult {
     Vec3 contrib;                         /* PATH: throughput*bsdf*em*mis; PRB: Lr_dir */
     /* MODE_PRB_ADJOINT only: d Lr_dir / d slot0, and (d f / d slot0) / f at the sampled direction */
     Vec3 dLr_drho, rel_grad; bool ind_active; uint32_t bsdf; float uv_x, uv_y;
+    /* ... with HAR_SHADE_EMITTER_GRADS: d em_b / d radiance of emitter `em_index` (emission hit; -1 = none), and the NEE contribution for a UNIT
+     * radiance of emitter `nee_emitter` (contrib = contrib_unit * radiance; -1 = not factorable, e.g. an environment map) */
+    Vec3 em_unit; int32_t em_index; Vec3 contrib_unit; int32_t nee_emitter;
 };
 
 /* raygen: SamplingIntegrator::render_sample up to the camera ray (integrator.cpp:448-483) */
@@ -95,6 +101,7 @@ HAR_HD void film_footprint(const DSensor &C, const LaneSample &L, Footprint &F) 
 template <int MODE, uint32_t TYPES = HAR_BSDF_ALL_TYPES>
 HAR_HD void shade_lane(const DScene &S, const ShadeParams &P, const PathState &st, const Hit &hit, ShadeResult &R) {
     R.alive = false; R.add_emission = false; R.item = false; R.item_ray = false;
+    if (MODE == MODE_PRB_ADJOINT) { R.em_index = -1; R.nee_emitter = -1; R.em_unit = Vec3(0.f); R.contrib_unit = Vec3(0.f); }
     uint64_t rng = st.rng;
     const uint64_t inc = sampler_inc(P.seed, st.lane);
     const uint32_t depth = st.flags & 0xffffu;
@@ -126,6 +133,10 @@ HAR_HD void shade_lane(const DScene &S, const ShadeParams &P, const PathState &s
         } else {
             Vec3 ev = facing ? rad : Vec3(0.f);
             R.add_emission = true; R.em_a = Vec3(0.f); R.em_b = (st.throughput * mis) * ev;
+            if (MODE == MODE_PRB_ADJOINT) {          /* prb.py:160-161 with the emitter's eval attached: d Le / d radiance = beta * mis */
+                R.em_index = (E.type != 2u && facing) ? emitter : -1;
+                R.em_unit = st.throughput * mis;
+            }
         }
     }
 
@@ -145,7 +156,7 @@ HAR_HD void shade_lane(const DScene &S, const ShadeParams &P, const PathState &s
      * every active lane; only BSDFs with a Smooth lobe use them (path.cpp:237, prb.py:169) */
     float ex = pcg32_next_float(rng, inc), ey = pcg32_next_float(rng, inc);
     DirSample ds; ds.pdf = 0.f; ds.d = Vec3(0.f); ds.p = Vec3(0.f); ds.n = Vec3(0.f); ds.dist = 0.f;
-    Vec3 em_weight(0.f);
+    Vec3 em_weight(0.f); float em_unit = 0.f; uint32_t em_sampled = 0;
     bool active_em = active_next && S.n_emitters > 0 && (TYPES == HAR_BSDF_ONLY_DIFFUSE || bsdf_is_smooth(B));
     if (active_em) {
         uint32_t index = 0; float wgt = 1.f;
@@ -155,8 +166,8 @@ HAR_HD void shade_lane(const DScene &S, const ShadeParams &P, const PathState &s
             wgt = (float) S.n_emitters; ex = scaled - (float) index;
         }
         if ((TYPES & HAR_SCENE_ENVMAP) != 0u && S.emitters[index].type == 2u) envmap_sample_direction(*S.envmap, si.p, ex, ey, ds, em_weight);
-        else emitter_sample_direction(S.emitters[index], si.p, ex, ey, ds, em_weight);
-        ds.pdf *= pmf; em_weight = em_weight * wgt;
+        else emitter_sample_direction(S.emitters[index], si.p, ex, ey, ds, em_weight, MODE == MODE_PRB_ADJOINT ? &em_unit : nullptr);
+        ds.pdf *= pmf; em_weight = em_weight * wgt; em_unit *= wgt; em_sampled = index;
         active_em = ds.pdf != 0.f;
     }
     Vec3 wo_em = active_em ? si.to_local(ds.d) : Vec3(0.f);
@@ -175,7 +186,12 @@ HAR_HD void shade_lane(const DScene &S, const ShadeParams &P, const PathState &s
         if (MODE == MODE_PATH) R.contrib = st.throughput * ((ev.value * em_weight) * mis_em);
         else {
             R.contrib = ((st.throughput * mis_em) * ev.value) * em_weight;
-            if (MODE == MODE_PRB_ADJOINT) R.dLr_drho = ((st.throughput * mis_em) * ev.d_slot0) * em_weight;
+            if (MODE == MODE_PRB_ADJOINT) {
+                R.dLr_drho = ((st.throughput * mis_em) * ev.d_slot0) * em_weight;
+                /* em_weight = radiance * em_unit for `area` / `constant` emitters (prb.py:198-206, attached eval_emitter_direction) */
+                R.nee_emitter = ((P.flags & HAR_SHADE_EMITTER_GRADS) && S.emitters[em_sampled].type != 2u) ? (int32_t) em_sampled : -1;
+                R.contrib_unit = ((st.throughput * mis_em) * ev.value) * em_unit;
+            }
         }
         if (R.contrib.x != 0.f || R.contrib.y != 0.f || R.contrib.z != 0.f) {
             R.item = true; R.item_ray = true;

@@ -315,13 +315,15 @@ HAR_HD float envmap_pdf_direction(const DEnvmap &E, Vec3 d_world) {
 /* EnvironmentMapEmitter::sample_direction (envmap.cpp:284-323) */
 HAR_HD void envmap_sample_direction(const DEnvmap &E, Vec3 ref_p, float sx, float sy, struct DirSample &ds, Vec3 &spec);
 
-HAR_HD void emitter_sample_direction(const DEmitter &E, Vec3 ref_p, float sx, float sy, DirSample &ds, Vec3 &spec) {
+/* `unit` (optional): the weight the sample would carry for a unit radiance, i.e. d spec / d radiance */
+HAR_HD void emitter_sample_direction(const DEmitter &E, Vec3 ref_p, float sx, float sy, DirSample &ds, Vec3 &spec, float *unit = nullptr) {
     if (E.type == 1u) {                                     /* ConstantBackgroundEmitter::sample_direction, constant.cpp:127-153 */
         Vec3 d = square_to_uniform_sphere(sx, sy);
         Vec3 c(E.to_world[0], E.to_world[1], E.to_world[2]);
         float radius = fmaxf(E.to_world[3], norm3(ref_p - c)), dist = 2.f * radius;
         ds.p = fma3(d, dist, ref_p); ds.n = -d; ds.pdf = HAR_INV_FOUR_PI; ds.d = d; ds.dist = dist;
         spec = div3(Vec3(E.radiance[0], E.radiance[1], E.radiance[2]), ds.pdf);
+        if (unit) *unit = rcp_(ds.pdf);
         return;
     }
     ds.p = xf_point(E.to_world, Vec3(fma_(sx, 2.f, -1.f), fma_(sy, 2.f, -1.f), 0.f));
@@ -336,6 +338,7 @@ HAR_HD void emitter_sample_direction(const DEmitter &E, Vec3 ref_p, float sx, fl
     ds.pdf *= finite_(x) ? x : 0.f;
     bool active = dot3(ds.d, ds.n) < 0.f && ds.pdf != 0.f;
     spec = active ? div3(Vec3(E.radiance[0], E.radiance[1], E.radiance[2]), ds.pdf) : Vec3(0.f);
+    if (unit) *unit = active ? rcp_(ds.pdf) : 0.f;
 }
 HAR_HD void envmap_sample_direction(const DEnvmap &E, Vec3 ref_p, float sx, float sy, DirSample &ds, Vec3 &spec) {
     float u, v, pdf; hier2d_sample(E, sx, sy, u, v, pdf);

@@ -412,13 +412,15 @@ static inline V3 square_to_uniform_sphere(float sx, float sy) {          // warp
     return V3(r * c, r * s, z);
 }
 constexpr float InvFourPi = 0.07957747154594766788f;
-static inline void constant_sample_direction(const OrcEmitter &e, const EnvSphere &bs, V3 ref_p, float sx, float sy, DS &ds, V3 &spec) {   // constant.cpp:127-153
+/* `unit` (optional) = d spec / d radiance: the weight the sample would carry for a unit radiance (prb adjoint w.r.t. the emitter colour) */
+static inline void constant_sample_direction(const OrcEmitter &e, const EnvSphere &bs, V3 ref_p, float sx, float sy, DS &ds, V3 &spec, float *unit = nullptr) {   // constant.cpp:127-153
     V3 d = square_to_uniform_sphere(sx, sy);
     float radius = std::fmax(bs.radius, norm(ref_p - bs.center)), dist = 2.f * radius;
     ds.p = fmadd(d, dist, ref_p); ds.n = -d; ds.pdf = InvFourPi; ds.d = d; ds.dist = dist;
     spec = div(V3(e.radiance[0], e.radiance[1], e.radiance[2]), ds.pdf);
+    if (unit) *unit = rcp(ds.pdf);
 }
-static inline void emitter_sample_direction(const OrcEmitter &e, V3 ref_p, float sx, float sy, DS &ds, V3 &spec) {
+static inline void emitter_sample_direction(const OrcEmitter &e, V3 ref_p, float sx, float sy, DS &ds, V3 &spec, float *unit = nullptr) {
     ds.p = xf_point(e.to_world, V3(fmadd(sx, 2.f, -1.f), fmadd(sy, 2.f, -1.f), 0.f));
     ds.n = V3(e.normal[0], e.normal[1], e.normal[2]);
     ds.pdf = e.inv_area;
@@ -432,6 +434,7 @@ static inline void emitter_sample_direction(const OrcEmitter &e, V3 ref_p, float
     bool active = dot(ds.d, ds.n) < 0.f && ds.pdf != 0.f;
     V3 rad(e.radiance[0], e.radiance[1], e.radiance[2]);
     spec = active ? div(rad, ds.pdf) : V3(0.f);
+    if (unit) *unit = active ? rcp(ds.pdf) : 0.f;
 }
 /* AreaLight::pdf_direction (area.cpp:170-197) over Shape::pdf_direction (shape.cpp:112-124) */
 static inline float emitter_pdf_direction(const OrcEmitter &e, const DS &ds) {
@@ -452,7 +455,7 @@ static inline float mis_weight(float a, float b) {
 
 /* Scene::sample_emitter_direction (src/render/scene.cpp:316-366), JIT branch */
 static inline bool sample_emitter_direction(const Scene &sc, const SI &si, float sx, float sy, DS &ds, V3 &spec,
-                                            OrcStats &st, Ray *shadow_out = nullptr) {
+                                            OrcStats &st, Ray *shadow_out = nullptr, float *unit = nullptr) {
     uint32_t n = (uint32_t) sc.emitters.size();
     if (n == 0) { ds = DS(); spec = V3(0.f); return false; }
     uint32_t index = 0; float weight = 1.f, pmf = 1.f / (float) n;
@@ -461,21 +464,23 @@ static inline bool sample_emitter_direction(const Scene &sc, const SI &si, float
         index = std::min((uint32_t) scaled, n - 1u);
         weight = (float) n; sx = scaled - (float) index;
     }
-    if (sc.emitters[index].type == 1) { EnvSphere bs; bs.center = V3(sc.env_center[0], sc.env_center[1], sc.env_center[2]); bs.radius = sc.env_radius; constant_sample_direction(sc.emitters[index], bs, si.p, sx, sy, ds, spec); }
+    if (unit) *unit = 0.f;
+    if (sc.emitters[index].type == 1) { EnvSphere bs; bs.center = V3(sc.env_center[0], sc.env_center[1], sc.env_center[2]); bs.radius = sc.env_radius; constant_sample_direction(sc.emitters[index], bs, si.p, sx, sy, ds, spec, unit); }
     else if (sc.emitters[index].type == 2) {       // EnvironmentMapEmitter::sample_direction (envmap.cpp:284-323)
         float uv[2];
         sc.envmap.sample_direction(si.p, sx, sy, ds.d, ds.dist, ds.pdf, spec, uv);
         ds.p = fmadd(ds.d, ds.dist, si.p); ds.n = -ds.d;
     }
-    else emitter_sample_direction(sc.emitters[index], si.p, sx, sy, ds, spec);
+    else emitter_sample_direction(sc.emitters[index], si.p, sx, sy, ds, spec, unit);
     ds.emitter = (int) index;
     ds.pdf *= pmf;
     spec = spec * weight;
+    if (unit) *unit *= weight;
     if (ds.pdf != 0.f) {
         Ray r = spawn_ray_to(si, ds.p);
         if (shadow_out) *shadow_out = r;
         PI dummy; st.shadow_rays++;
-        if (scene_trace<true>(sc, r, dummy, 0)) { spec = V3(0.f); ds.pdf = 0.f; }
+        if (scene_trace<true>(sc, r, dummy, 0)) { spec = V3(0.f); ds.pdf = 0.f; if (unit) *unit = 0.f; }
     }
     return true;
 }
@@ -652,7 +657,7 @@ static V3 path_sample(const Scene &sc, Pcg32 &rng, Ray ray, uint32_t max_depth, 
 //  hand-derived gradients of SURVEY.md Appendix B into `grad`.
 // ---------------------------------------------------------------------------
 
-struct GradSink { float *refl; float *const *tex; };
+struct GradSink { float *refl; float *const *tex; float *emit; /* 3 per emitter (radiance of `area` / `constant`), may be null */ };
 
 static V3 prb_sample(const Scene &sc, Pcg32 &rng, Ray ray, uint32_t max_depth, uint32_t rr_depth, bool primal,
                      V3 L_in, V3 dL, const GradSink *grad, bool &valid, OrcStats &st) {
@@ -678,6 +683,10 @@ static V3 prb_sample(const Scene &sc, Pcg32 &rng, Ray ray, uint32_t max_depth, u
                 const OrcEmitter &e = sc.emitters[emitter];
                 V3 ev = e.type == 2 ? sc.envmap.eval(-si.wi) : (e.type == 1 || si.wi.z > 0.f) ? V3(e.radiance[0], e.radiance[1], e.radiance[2]) : V3(0.f);
                 Le = (beta * mis) * ev;
+                if (!primal && grad && grad->emit && e.type != 2 && (e.type == 1 || si.wi.z > 0.f)) {   // d Le / d radiance = beta * mis (prb.py:160-161, attached emitter.eval)
+                    V3 g = (beta * mis) * dL; float *dst = grad->emit + 3 * (size_t) emitter;
+                    dst[0] += g.x; dst[1] += g.y; dst[2] += g.z;
+                }
             }
         }
         active_next &= (depth + 1 < max_depth) && si.valid();  // prb.py:166
@@ -685,8 +694,8 @@ static V3 prb_sample(const Scene &sc, Pcg32 &rng, Ray ray, uint32_t max_depth, u
         if (si.valid()) bsdf = bsdf_prepare(sc, sc.meshes[si.mesh].bsdf, si);
         bool active_em = active_next && bsdf.rec && bsdf.rec->smooth();          // prb.py:169
         float ex = rng.next_float32(), ey = rng.next_float32();
-        DS ds; V3 em_weight(0.f);
-        if (active_em) { sample_emitter_direction(sc, si, ex, ey, ds, em_weight, st); active_em &= ds.pdf != 0.f; }
+        DS ds; V3 em_weight(0.f); float em_unit = 0.f;
+        if (active_em) { sample_emitter_direction(sc, si, ex, ey, ds, em_weight, st, nullptr, &em_unit); active_em &= ds.pdf != 0.f; }
         // prb.py:210-216
         V3 Lr_dir(0.f), dLr_dir_drho(0.f);
         if (active_em) {
@@ -695,6 +704,10 @@ static V3 prb_sample(const Scene &sc, Pcg32 &rng, Ray ray, uint32_t max_depth, u
             float mis_em = mis_weight(ds.pdf, ev.pdf);
             Lr_dir = ((beta * mis_em) * ev.value) * em_weight;
             dLr_dir_drho = ((beta * mis_em) * ev.d_slot0) * em_weight;           // d/d slot0 of the line above
+            if (!primal && grad && grad->emit && sc.emitters[ds.emitter].type != 2) {   // em_weight = radiance * em_unit (prb.py:198-206, attached eval_emitter_direction)
+                V3 g = (((beta * mis_em) * ev.value) * em_unit) * dL; float *dst = grad->emit + 3 * (size_t) ds.emitter;
+                dst[0] += g.x; dst[1] += g.y; dst[2] += g.z;
+            }
         }
         // detached BSDF sampling, prb.py:220-223 (masked lanes return zeros)
         float s1 = rng.next_float32();
@@ -1086,9 +1099,21 @@ int orc_render_prb(void *scene, const OrcSensor *s, uint32_t seed, uint32_t spp,
     return render_forward(*(Scene *) scene, *s, seed, spp, max_depth, rr_depth, lb, le, film, stats, threads, true);
 }
 
+int orc_render_prb_backward_ex(void *scene, const OrcSensor *sp, const float *grad_in, uint32_t seed, uint32_t spp,
+                               int32_t max_depth, int32_t rr_depth, float *grad_reflectance, float *const *grad_textures,
+                               float *grad_emitters, OrcStats *stats, int threads);
 int orc_render_prb_backward(void *scene, const OrcSensor *sp, const float *grad_in, uint32_t seed, uint32_t spp,
                             int32_t max_depth, int32_t rr_depth, float *grad_reflectance, float *const *grad_textures,
                             OrcStats *stats, int threads) {
+    return orc_render_prb_backward_ex(scene, sp, grad_in, seed, spp, max_depth, rr_depth, grad_reflectance, grad_textures, nullptr, stats, threads);
+}
+void orc_scene_set_emitter_radiance(void *scene, uint32_t emitter, const float rgb[3]) {
+    Scene &sc = *(Scene *) scene;
+    if (emitter < sc.emitters.size()) for (int c = 0; c < 3; ++c) sc.emitters[emitter].radiance[c] = rgb[c];
+}
+int orc_render_prb_backward_ex(void *scene, const OrcSensor *sp, const float *grad_in, uint32_t seed, uint32_t spp,
+                               int32_t max_depth, int32_t rr_depth, float *grad_reflectance, float *const *grad_textures,
+                               float *grad_emitters, OrcStats *stats, int threads) {
     Scene &sc = *(Scene *) scene; const OrcSensor &s = *sp;
     uint64_t total = (uint64_t) s.crop_width * s.crop_height * spp;
     if (total > 0xffffffffull) return -1;
@@ -1115,19 +1140,19 @@ int orc_render_prb_backward(void *scene, const OrcSensor *sp, const float *grad_
     for (size_t i = 0; i < npx; ++i) { float w = wfilm[4 * i + 3]; float iw = w == 0.f ? 1.f : w; for (int c = 0; c < 3; ++c) adj[3 * i + c] = grad_in[3 * i + c] / iw; }
     // per-thread gradient buffers
     size_t nb = sc.bsdfs.size();
-    std::vector<std::vector<float>> g_refl(threads);
+    std::vector<std::vector<float>> g_refl(threads), g_emit(threads);
     std::vector<std::vector<std::vector<float>>> g_tex(threads);
     std::vector<OrcStats> sts(threads, OrcStats{});
     uint32_t md = (uint32_t) max_depth, rd = (uint32_t) rr_depth;
     parallel_lanes(0, total, threads, [&](int t, uint64_t b, uint64_t e) {
         if (g_refl[t].empty()) {
-            g_refl[t].assign(3 * nb + 3, 0.f);
+            g_refl[t].assign(3 * nb + 3, 0.f); g_emit[t].assign(3 * sc.emitters.size() + 3, 0.f);
             g_tex[t].resize(sc.textures.size());
             for (size_t k = 0; k < sc.textures.size(); ++k) g_tex[t][k].assign(3 * (size_t) sc.textures[k].w * sc.textures[k].h, 0.f);
         }
         std::vector<float *> tp(sc.textures.size() + 1, nullptr);
         for (size_t k = 0; k < sc.textures.size(); ++k) tp[k] = g_tex[t][k].data();
-        GradSink sink{ g_refl[t].data(), tp.data() };
+        GradSink sink{ g_refl[t].data(), tp.data(), grad_emitters ? g_emit[t].data() : nullptr };
         for (uint64_t i = b; i < e; ++i) {
             Lane L = make_lane(s, seed, spp, i);
             // dL = adjoint of the splat (gather over the filter footprint)
@@ -1165,6 +1190,7 @@ int orc_render_prb_backward(void *scene, const OrcSensor *sp, const float *grad_
     for (int t = 0; t < threads; ++t) {
         if (g_refl[t].empty()) continue;
         if (grad_reflectance) for (size_t i = 0; i < 3 * nb; ++i) grad_reflectance[i] += g_refl[t][i];
+        if (grad_emitters) for (size_t i = 0; i < 3 * sc.emitters.size(); ++i) grad_emitters[i] += g_emit[t][i];
         for (size_t k = 0; k < sc.textures.size(); ++k)
             if (grad_textures && grad_textures[k]) { float *dst = grad_textures[k]; for (size_t i = 0; i < g_tex[t][k].size(); ++i) dst[i] += g_tex[t][k][i]; }
     }

@@ -188,6 +188,12 @@ int orc_render_prb_backward(void *scene, const OrcSensor *s, const float *grad_i
                             uint32_t seed, uint32_t spp, int32_t max_depth,
                             int32_t rr_depth, float *grad_reflectance,
                             float *const *grad_textures, OrcStats *stats, int threads);
+/* ... plus grad_emitters (emitter_count x 3, may be NULL): gradient w.r.t. the radiance of `area` / `constant` emitters
+ * (prb.py:160-161 attached emitter.eval, :198-206 attached eval_emitter_direction) */
+int orc_render_prb_backward_ex(void *scene, const OrcSensor *s, const float *grad_in, uint32_t seed, uint32_t spp, int32_t max_depth,
+                               int32_t rr_depth, float *grad_reflectance, float *const *grad_textures, float *grad_emitters,
+                               OrcStats *stats, int threads);
+void orc_scene_set_emitter_radiance(void *scene, uint32_t emitter, const float rgb[3]);
 /* HDRFilm::develop (hdrfilm.cpp:398-399): image[h][w][3] = RGB / (W==0?1:W) */
 void orc_film_develop(const float *film, uint32_t width, uint32_t height, float *image);
 

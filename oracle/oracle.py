@@ -114,6 +114,10 @@ def lib():
         L.orc_envmap_eval.argtypes = [C.c_void_p, C.c_uint32, c_f32p, c_f32p]
         L.orc_envmap_sample_direction.argtypes = [C.c_void_p, C.c_uint32, c_f32p, c_f32p, c_f32p, c_f32p, c_f32p, c_f32p]
         L.orc_envmap_pdf_direction.argtypes = [C.c_void_p, C.c_uint32, c_f32p, c_f32p]
+        L.orc_render_prb_backward_ex.restype = C.c_int
+        L.orc_render_prb_backward_ex.argtypes = [C.c_void_p, C.POINTER(Sensor), c_f32p, C.c_uint32, C.c_uint32, C.c_int32, C.c_int32, c_f32p,
+                                                 C.POINTER(c_f32p), c_f32p, C.POINTER(Stats), C.c_int]
+        L.orc_scene_set_emitter_radiance.argtypes = [C.c_void_p, C.c_uint32, c_f32p]
         L.orc_render_prb_backward.restype = C.c_int
         L.orc_render_prb_backward.argtypes = [C.c_void_p, C.POINTER(Sensor), c_f32p, C.c_uint32, C.c_uint32,
                                               C.c_int32, C.c_int32, c_f32p, C.POINTER(c_f32p),
@@ -453,6 +457,21 @@ class OracleScene:
                                            fp(g_refl), ptrs, C.byref(st), threads)
         assert rc == 0
         return g_refl, g_tex, st
+
+    def render_prb_backward_emitters(self, sensor, grad_in, seed=0, spp=4, max_depth=6, rr_depth=5, threads=0):
+        """as render_prb_backward, plus the gradient w.r.t. emitter radiances (emitter_count x 3)"""
+        grad_in = f32(grad_in)
+        g_refl = np.zeros((len(self.data.bsdfs), 3), np.float32); g_emit = np.zeros((max(1, len(self.data.emitters)), 3), np.float32)
+        g_tex = [np.zeros_like(t) for t in self.data.textures]
+        ptrs = (c_f32p * max(1, len(g_tex)))(*[fp(g) for g in g_tex])
+        st = Stats()
+        rc = lib().orc_render_prb_backward_ex(self.handle, C.byref(sensor), fp(grad_in), seed, spp, max_depth, rr_depth,
+                                              fp(g_refl), ptrs, fp(g_emit), C.byref(st), threads)
+        assert rc == 0
+        return g_refl, g_tex, g_emit[:len(self.data.emitters)], st
+
+    def set_emitter_radiance(self, emitter, rgb):
+        lib().orc_scene_set_emitter_radiance(self.handle, emitter, fp(f32(rgb)))
 
     def set_reflectance(self, bsdf, rgb):
         lib().orc_scene_set_reflectance(self.handle, bsdf, fp(f32(rgb)))

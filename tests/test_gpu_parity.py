@@ -395,7 +395,7 @@ def test_material_scene_prb_gradients(mi, O):
     grad_in = np.random.default_rng(1).uniform(0.5, 1.5, (40, 40, 3)).astype(np.float32)
     grads = integ.render_backward(scene, None, grad_in, seed=9, spp=16)
     g_refl, _, _ = osc.render_prb_backward(sensor, grad_in, seed=9, spp=16, max_depth=6)
-    keys = scene._param_keys()
+    keys = {k: v for k, v in scene._param_keys().items() if v[0] != "emit"}
     got = np.stack([grads[k].cpu().numpy() for k in keys]); want = np.stack([g_refl[b.index] for (_, b) in keys.values()])
     assert np.abs(want).max() > 0 and rel_l2(got, want) < 1e-3
     glass = [b for (_, b) in keys.values() if b.kind == "dielectric"]
@@ -460,7 +460,7 @@ def test_constant_environment_emitter_parity(mi, O):
         grad_in = np.random.default_rng(2).uniform(0.5, 1.5, (40, 40, 3)).astype(np.float32)
         grads = integ.render_backward(scene, None, grad_in, seed=3, spp=8)
         g_refl, _, _ = osc.render_prb_backward(sensor, grad_in, seed=3, spp=8, max_depth=6)
-        keys = scene._param_keys()
+        keys = {k: v for k, v in scene._param_keys().items() if v[0] != "emit"}
         got = np.stack([grads[k].cpu().numpy() for k in keys]); want = np.stack([g_refl[b.index] for (_, b) in keys.values()])
         assert rel_l2(got, want) < 1e-3
 
@@ -487,7 +487,7 @@ def test_envmap_emitter_parity(mi, O):
         grad_in = np.random.default_rng(2).uniform(0.5, 1.5, (48, 48, 3)).astype(np.float32)
         grads = integ.render_backward(scene, None, grad_in, seed=3, spp=8)
         g_refl, _, _ = osc.render_prb_backward(sensor, grad_in, seed=3, spp=8, max_depth=6)
-        keys = scene._param_keys()
+        keys = {k: v for k, v in scene._param_keys().items() if v[0] != "emit"}
         got = np.stack([grads[k].cpu().numpy() for k in keys]); want = np.stack([g_refl[b.index] for (_, b) in keys.values()])
         assert rel_l2(got, want) < 1e-3
     # glossy / dielectric materials under an environment map
@@ -530,6 +530,54 @@ def test_ztest_product_vs_oracle(mi, O):
             assert ok, (name, pmin, alpha)
         ok, _, _ = ztest.accept(img * 1.03, spp, ref_mean, ref_var, n_ref)
         assert not ok, name                              # power: +3 % is rejected
+
+
+def test_prb_emitter_radiance_gradients(mi, O):
+    """d loss / d radiance of `area` and `constant` emitters (prb.py:160-161 emission term, :198-206 emitter sampling term with the emitter
+    attached) vs the oracle, through render_backward and through mi.render + autograd; the BSDF gradients are unchanged by the extra outputs"""
+    import torch
+    from tests.test_emitters_cpu import env_scene
+    from tests.test_cpu_host import oracle_scene_from
+    for name, d in (("cornell", None), ("area+constant", env_scene(mi, 40, True)), ("constant", env_scene(mi, 40, False))):
+        if d is None:
+            d = mi.cornell_box(); d["sensor"]["film"]["width"] = 40; d["sensor"]["film"]["height"] = 40
+        scene = mi.load_dict(d)
+        osc, sensor = oracle_scene_from(O, scene)
+        integ = mi.load_dict({"type": "prb", "max_depth": 6})
+        grad_in = np.random.default_rng(4).uniform(0.5, 1.5, (40, 40, 3)).astype(np.float32)
+        grads = integ.render_backward(scene, None, grad_in, seed=3, spp=16)
+        g_refl, _, g_emit, _ = osc.render_prb_backward_emitters(sensor, grad_in, seed=3, spp=16, max_depth=6)
+        keys = scene._param_keys()
+        ek = {k: v[1] for k, v in keys.items() if v[0] == "emit"}
+        assert len(ek) == len(scene.emitters) >= 1, name
+        got = np.stack([grads[k].cpu().numpy() for k in ek]); want = np.stack([g_emit[i] for i in ek.values()])
+        assert np.abs(want).min() > 0 and rel_l2(got, want) < 1e-3, name
+        bk = {k: v for k, v in keys.items() if v[0] != "emit"}
+        got = np.stack([grads[k].cpu().numpy() for k in bk]); want = np.stack([g_refl[b.index] for (_, b) in bk.values()])
+        assert rel_l2(got, want) < 1e-3, name
+        # switching the emitter outputs off leaves the BSDF gradients as they were
+        integ2 = mi.load_dict({"type": "prb", "max_depth": 6, "emitter_gradients": False})
+        grads2 = integ2.render_backward(scene, None, grad_in, seed=3, spp=16)
+        assert not any(k in grads2 for k in ek)
+        assert rel_l2(np.stack([grads2[k].cpu().numpy() for k in bk]), got) < 1e-5
+    # autograd: the loss is linear in the radiance, so radiance . grad == loss of the emitted part; check against a finite difference
+    d = mi.cornell_box(); d["sensor"]["film"]["width"] = 32; d["sensor"]["film"]["height"] = 32
+    d["integrator"] = {"type": "prb", "max_depth": 6}
+    scene = mi.load_dict(d)
+    params = mi.traverse(scene); key = "light.emitter.radiance.value"
+    assert key in params
+    def loss_of(rad):
+        params[key] = torch.tensor(rad, dtype=torch.float32, device="cuda"); params.update()
+        return float((mi.render(scene, spp=64, seed=0) ** 2).mean())
+    base = params[key].detach().cpu().numpy().copy()
+    p = params[key].detach().clone().requires_grad_(); params[key] = p
+    img = mi.render(scene, params, spp=64, seed=0, seed_grad=11)
+    (img ** 2).mean().backward()
+    g = p.grad.cpu().numpy()
+    for c in range(3):
+        e = np.zeros(3, np.float32); e[c] = 0.05 * base[c]
+        fd = (loss_of(base + e) - loss_of(base - e)) / (2 * e[c])
+        assert abs(g[c] - fd) < 0.03 * abs(fd) + 1e-6, (c, g[c], fd)      # different sample sets in the primal / adjoint passes: statistical agreement
 
 
 def test_prb_replay_cache_is_transparent(mi, O):
