@@ -78,8 +78,16 @@ struct HarIntegratorImpl {
     bool profiling = false;
     std::vector<hipEvent_t> events; std::vector<int> ev_class; size_t ev_used = 0;
     hipStream_t last_stream = nullptr;
+    /* two-stream mode: a job of >= HAR_DUAL_MIN_LANES lanes is cut in two halves that run concurrently -- this integrator on the caller's stream, a
+     * private twin (own workspace) on `side_stream`.  Every persistent traversal launch ends with a tail of a few hundred microseconds in which
+     * the chip waits for the launch's longest rays (a chain of dependent node fetches); with two independent launch sequences in flight the blocks
+     * of one fill the CUs the other's tail leaves idle. */
+    HarIntegratorImpl *twin = nullptr; bool twin_used = false;
+    hipStream_t side_stream = nullptr; hipEvent_t ev_fork = nullptr, ev_join = nullptr;
     void free_ws() { for (void *p : owned) (void) hipFree(p); owned.clear(); ws_lanes = 0; }
 };
+#define HAR_DUAL_MIN_LANES (1u << 20)
+#define HAR_DUAL_MAX_LANES (1u << 24)
 
 namespace {
 
@@ -434,11 +442,15 @@ int har_integrator_destroy(HarIntegrator I) {
     (void) hipDeviceSynchronize();
     I->free_ws();
     for (hipEvent_t e : I->events) (void) hipEventDestroy(e);
+    if (I->twin) { I->twin->free_ws(); for (hipEvent_t e : I->twin->events) (void) hipEventDestroy(e); delete I->twin; }
+    if (I->ev_fork) (void) hipEventDestroy(I->ev_fork);
+    if (I->ev_join) (void) hipEventDestroy(I->ev_join);
+    if (I->side_stream) (void) hipStreamDestroy(I->side_stream);
     delete I;
     return 0;
 }
 
-int har_render(HarScene S, HarIntegrator I, const HarSensor *sensor, uint32_t seed, uint32_t spp, uint64_t lb, uint64_t le, float *film, void *stream) {
+static int render_range(HarScene S, HarIntegrator I, const HarSensor *sensor, uint32_t seed, uint32_t spp, uint64_t lb, uint64_t le, float *film, void *stream) {
     DSensor C; uint32_t log_spp;
     if (!S || !I || !sensor) return fail("null scene / integrator / sensor");
     /* multi-pass layout; `path` only: the Python AD integrators render one wavefront or refuse (common.py:358-363) */
@@ -481,6 +493,69 @@ int har_render(HarScene S, HarIntegrator I, const HarSensor *sensor, uint32_t se
     return 0;
 }
 
+static int backward_range(HarScene S, HarIntegrator I, const HarSensor *sensor, const float *grad_in, const float *weight_film, uint32_t seed,
+                          uint32_t spp, uint64_t lb, uint64_t le, float *grad_reflectance, float *const *grad_textures, void *stream);
+
+/* two-stream driver (see HarIntegratorImpl::twin): returns the split point, or `le` when the job runs on one stream */
+static uint64_t dual_split(HarIntegrator I, uint64_t lb, uint64_t le, hipStream_t s) {
+    /* measured on MI355X (1M-triangle scene): 2 M lanes 5.84 -> 5.40 ms, 8 M 13.6 -> 13.0, 16 M 24.0 -> 23.5, 32 M +-0, 67 M 85.4 -> 86.5 ms: the two
+     * launch sequences run in lock-step, so only part of the tails is hidden -- worth it for the small jobs a rank sees when N GPUs share a
+     * frame, not for a single large wavefront.  HAR_STREAMS = 1 / 2 forces one / two streams. */
+    static const int forced = getenv("HAR_STREAMS") ? atoi(getenv("HAR_STREAMS")) : 0;
+    I->twin_used = false;
+    if (forced == 1 || le - lb < HAR_DUAL_MIN_LANES || (forced != 2 && le - lb > HAR_DUAL_MAX_LANES)) return le;
+    if (!I->twin) {
+        if (hipStreamCreateWithFlags(&I->side_stream, hipStreamNonBlocking) != hipSuccess) return le;
+        if (hipEventCreateWithFlags(&I->ev_fork, hipEventDisableTiming) != hipSuccess || hipEventCreateWithFlags(&I->ev_join, hipEventDisableTiming) != hipSuccess) return le;
+        I->twin = new HarIntegratorImpl();
+    }
+    HarIntegratorImpl *T = I->twin;
+    T->type = I->type; T->max_depth = I->max_depth; T->rr_depth = I->rr_depth; T->chunk = I->chunk; T->samples_per_pass = I->samples_per_pass;
+    T->grad_emitters = I->grad_emitters; T->profiling = I->profiling;
+    if (T->use_cache != I->use_cache) { (void) hipDeviceSynchronize(); T->free_ws(); T->use_cache = I->use_cache; }
+    if (hipEventRecord(I->ev_fork, s) != hipSuccess || hipStreamWaitEvent(I->side_stream, I->ev_fork, 0) != hipSuccess) return le;
+    I->twin_used = true;
+    return lb + ((le - lb) / 2 + 2047) / 2048 * 2048;
+}
+static int dual_join(HarIntegrator I, hipStream_t s) {
+    HIP_TRY(hipEventRecord(I->ev_join, I->side_stream));
+    HIP_TRY(hipStreamWaitEvent(s, I->ev_join, 0));
+    return 0;
+}
+
+int har_render(HarScene S, HarIntegrator I, const HarSensor *sensor, uint32_t seed, uint32_t spp, uint64_t lb, uint64_t le, float *film, void *stream) {
+    if (!S || !I || !sensor) return fail("null scene / integrator / sensor");
+    uint64_t total_lb = lb, total_le = le;
+    if (lb == 0 && le == 0) {                           /* "all lanes": resolve the range here so that it can be cut */
+        uint32_t spp_pass = spp, n_passes = 1;
+        if (I->type == HAR_INTEGRATOR_PATH && pass_layout(I, sensor->crop_width, sensor->crop_height, spp, spp_pass, n_passes)) return 1;
+        total_le = (uint64_t) sensor->crop_width * sensor->crop_height * spp_pass;
+        if (total_le == 0 || total_le > 0xffffffffull) return render_range(S, I, sensor, seed, spp, lb, le, film, stream);      /* reports the error */
+    }
+    const uint64_t mid = total_le > total_lb ? dual_split(I, total_lb, total_le, (hipStream_t) stream) : total_le;
+    if (mid >= total_le) return render_range(S, I, sensor, seed, spp, lb, le, film, stream);
+    int rc = render_range(S, I, sensor, seed, spp, total_lb, mid, film, stream);
+    rc |= render_range(S, I->twin, sensor, seed, spp, mid, total_le, film, (void *) I->side_stream);
+    rc |= dual_join(I, (hipStream_t) stream);
+    return rc;
+}
+
+int har_render_backward(HarScene S, HarIntegrator I, const HarSensor *sensor, const float *grad_in, const float *weight_film, uint32_t seed,
+                        uint32_t spp, uint64_t lb, uint64_t le, float *grad_reflectance, float *const *grad_textures, void *stream) {
+    if (!S || !I || !sensor) return fail("null scene / integrator / sensor");
+    uint64_t total_lb = lb, total_le = le;
+    if (lb == 0 && le == 0) {
+        total_le = (uint64_t) sensor->crop_width * sensor->crop_height * spp;
+        if (total_le == 0 || total_le > 0xffffffffull) return backward_range(S, I, sensor, grad_in, weight_film, seed, spp, lb, le, grad_reflectance, grad_textures, stream);
+    }
+    const uint64_t mid = (total_le > total_lb && I->type == HAR_INTEGRATOR_PRB) ? dual_split(I, total_lb, total_le, (hipStream_t) stream) : total_le;
+    if (mid >= total_le) return backward_range(S, I, sensor, grad_in, weight_film, seed, spp, lb, le, grad_reflectance, grad_textures, stream);
+    int rc = backward_range(S, I, sensor, grad_in, weight_film, seed, spp, total_lb, mid, grad_reflectance, grad_textures, stream);
+    rc |= backward_range(S, I->twin, sensor, grad_in, weight_film, seed, spp, mid, total_le, grad_reflectance, grad_textures, (void *) I->side_stream);
+    rc |= dual_join(I, (hipStream_t) stream);
+    return rc;
+}
+
 int har_integrator_set_samples_per_pass(HarIntegrator I, uint32_t samples_per_pass) {
     if (!I) return fail("null integrator");
     if (I->type != HAR_INTEGRATOR_PATH) return fail("samples_per_pass is a property of SamplingIntegrator (`path`); the AD integrators render a single wavefront");
@@ -512,8 +587,8 @@ int har_render_weights(const HarSensor *sensor, uint32_t seed, uint32_t spp, uin
     return 0;
 }
 
-int har_render_backward(HarScene S, HarIntegrator I, const HarSensor *sensor, const float *grad_in, const float *weight_film, uint32_t seed,
-                        uint32_t spp, uint64_t lb, uint64_t le, float *grad_reflectance, float *const *grad_textures, void *stream) {
+static int backward_range(HarScene S, HarIntegrator I, const HarSensor *sensor, const float *grad_in, const float *weight_film, uint32_t seed,
+                          uint32_t spp, uint64_t lb, uint64_t le, float *grad_reflectance, float *const *grad_textures, void *stream) {
     DSensor C; uint32_t log_spp;
     if (check_common(S, I, sensor, spp, lb, le, C, log_spp)) return 1;
     if (I->type != HAR_INTEGRATOR_PRB) return fail("render_backward is implemented by the `prb` integrator");
@@ -571,6 +646,11 @@ int har_render_stats(HarIntegrator I, HarStats *out) {
     HIP_TRY(hipMemcpyAsync(t, I->totals, sizeof(t), hipMemcpyDeviceToHost, s));
     if (read_status(I->status, s)) return 1;
     out->paths = t[0]; out->vertices = t[1]; out->closest_rays = t[2]; out->shadow_rays = t[3];
+    if (I->twin_used && I->twin && I->twin->totals) {      /* the caller's stream has joined the side stream: one more copy on it sees the twin's counters */
+        HIP_TRY(hipMemcpyAsync(t, I->twin->totals, sizeof(t), hipMemcpyDeviceToHost, s));
+        if (read_status(I->twin->status, s)) return 1;
+        out->paths += t[0]; out->vertices += t[1]; out->closest_rays += t[2]; out->shadow_rays += t[3];
+    }
     return 0;
 }
 
@@ -586,9 +666,7 @@ int har_integrator_set_profiling(HarIntegrator I, int enable) {
     return 0;
 }
 
-int har_render_timing(HarIntegrator I, float ms[8], uint32_t launches[8]) {
-    if (!I) return fail("null integrator");
-    for (int k = 0; k < 8; ++k) { ms[k] = 0.f; launches[k] = 0; }
+static int add_timing(HarIntegratorImpl *I, float ms[8], uint32_t launches[8]) {
     if (I->ev_used < 2) return 0;
     HIP_TRY(hipEventSynchronize(I->events[I->ev_used - 1]));
     for (size_t k = 1; k < I->ev_used; ++k) {
@@ -597,6 +675,14 @@ int har_render_timing(HarIntegrator I, float ms[8], uint32_t launches[8]) {
         int c = I->ev_class[k]; if (c < 0 || c > 6) c = CLS_OTHER;
         ms[c] += dt; launches[c]++; ms[5] += dt;
     }
+    return 0;
+}
+/* in two-stream mode the launches of both halves are summed: kernels of the two streams overlap, so the class totals exceed the wall time */
+int har_render_timing(HarIntegrator I, float ms[8], uint32_t launches[8]) {
+    if (!I) return fail("null integrator");
+    for (int k = 0; k < 8; ++k) { ms[k] = 0.f; launches[k] = 0; }
+    if (add_timing(I, ms, launches)) return 1;
+    if (I->twin_used && I->twin && add_timing(I->twin, ms, launches)) return 1;
     return 0;
 }
 

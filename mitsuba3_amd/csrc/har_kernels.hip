@@ -232,6 +232,9 @@ template <bool ANY, bool RETIRE, typename WaveStack, typename Take, typename Don
 __device__ __forceinline__ void trace_persistent(const Accel &A, uint32_t *cursor, uint32_t n, WaveStack &stack, int *status,
                                                  Take take, Done done, Retire retire) {
     const uint32_t lane = threadIdx.x & 63u;
+    /* rays per fetch: 128 in the bulk; when the shard holds no more rays than its waves have lanes (late bounces, small jobs) every lane gets
+     * ONE ray -- such launches are latency chains of single rays, and two rays per lane would double them */
+    const uint32_t fetch = n <= (gridDim.x / HAR_SHARDS) * (kBlock / 64u) * 64u ? 64u : (uint32_t) HAR_FETCH_BATCH;
     uint32_t pool_next = 0, pool_end = 0;      /* wave-uniform */
     bool exhausted = false;                    /* wave-uniform */
     bool busy = false, has_result = false;
@@ -245,10 +248,10 @@ __device__ __forceinline__ void trace_persistent(const Accel &A, uint32_t *curso
             if (RETIRE) { retire(!busy && has_result, idx, T); has_result = false; }
             if (pool_next == pool_end && !exhausted) {
                 uint32_t b = 0;
-                if (lane == 0) b = atomicAdd(cursor, HAR_FETCH_BATCH);
+                if (lane == 0) b = atomicAdd(cursor, fetch);
                 b = (uint32_t) __builtin_amdgcn_readfirstlane((int) b);
                 if (b >= n) exhausted = true;
-                else { pool_next = b; pool_end = min(b + HAR_FETCH_BATCH, n); }
+                else { pool_next = b; pool_end = min(b + fetch, n); }
             }
             const uint32_t avail = pool_end - pool_next;
             if (avail) {
@@ -655,7 +658,7 @@ __global__ void k_adjoint_image(const float *grad_in, const float *wfilm, uint32
 }
 __global__ void k_add(const float *src, float *dst, uint32_t n) {
     uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i < n) dst[i] += src[i];
+    if (i < n && src[i] != 0.f) atomicAdd(dst + i, src[i]);      /* two streams may add to the same destination */
 }
 __global__ void k_accumulate_stats(const uint32_t *counters, uint32_t n_bounces, unsigned long long *totals, uint32_t paths) {
     if (threadIdx.x || blockIdx.x) return;
