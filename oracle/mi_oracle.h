@@ -220,6 +220,8 @@ void  orc_diffuse_eval_pdf(const float refl[3], const float wi[3], const float w
 void  orc_diffuse_sample(const float refl[3], const float wi[3], float s1,
                          const float s2[2], float wo[3], float *pdf, float weight[3]);
 void  orc_square_to_cosine_hemisphere(const float s[2], float out[3]);
+void  orc_square_to_uniform_sphere(const float s[2], float out[3]);              /* warp.h:250-255 */
+void  orc_square_to_uniform_disk_concentric(const float s[2], float out[2]);    /* warp.h:54-90 */
 void  orc_coordinate_system(const float n[3], float s[3], float t[3]);
 float orc_sincos(float x, float *c); /* returns sin */
 /* full SurfaceInteraction for one hit (tests of Mesh::compute_surface_interaction) */
