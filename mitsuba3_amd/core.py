@@ -501,16 +501,30 @@ class BSDF:
         if refl['type'] == 'rgb':
             self.value = _rgb_value(refl, def0)
         elif refl['type'] == 'bitmap':
-            if 'data' not in refl:
-                raise RuntimeError("bitmap: hip_ad_rgb needs the texel array under 'data' (file loading is out of scope)")
+            # BitmapTexture (src/textures/bitmap.cpp:175-260): texels from a tensor (`data`), a Bitmap object (`bitmap`) or a file (`filename`:
+            # OpenEXR / PFM, read by the C++ host library).  Float data is linear; in RGB variants `raw` only silences the [0, 1] range warning.
+            if sum(k in refl for k in ('data', 'bitmap', 'filename')) != 1:
+                raise RuntimeError("bitmap: exactly one of 'filename', 'bitmap' and 'data' must be specified")
             if refl.get('filter_type', 'bilinear') != 'bilinear' or refl.get('wrap_mode', 'repeat') != 'repeat':
                 raise RuntimeError("bitmap: only filter_type='bilinear' and wrap_mode='repeat' are implemented")
-            if not refl.get('raw', False):
-                raise RuntimeError("bitmap: only raw=True float data is implemented (no sRGB conversion)")
-            t = refl['data']
-            if hasattr(t, 'detach'):
-                t = t.detach().cpu().numpy()
-            self.texture = _f32(t).reshape(np.asarray(t).shape[0], np.asarray(t).shape[1], 3)
+            if 'to_uv' in refl:
+                raise RuntimeError("bitmap: 'to_uv' is not implemented by hip_ad_rgb")
+            if 'data' in refl:
+                t = refl['data']
+                if hasattr(t, 'detach'):
+                    t = t.detach().cpu().numpy()
+            else:
+                b = refl['bitmap'] if 'bitmap' in refl else Bitmap(refl['filename'])
+                if not isinstance(b, Bitmap):
+                    raise RuntimeError("Property \"bitmap\" must be a Bitmap instance.")
+                t = b.data
+            t = _f32(t)
+            if t.ndim == 2:
+                t = t[:, :, None]
+            if t.ndim != 3 or t.shape[2] not in (1, 3, 4):
+                raise RuntimeError("Bitmap raw tensor has dimension %d, expected 3 (H x W x {1, 3, 4})" % t.ndim)
+            t = np.repeat(t, 3, axis=2) if t.shape[2] == 1 else t[:, :, :3]
+            self.texture = np.ascontiguousarray(t, np.float32)
             self.value = _f32([0.5, 0.5, 0.5])
         else:
             raise RuntimeError("Plugin \"%s\" not found for variant hip_ad_rgb (textures: rgb, bitmap)" % refl['type'])

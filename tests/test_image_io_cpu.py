@@ -71,3 +71,24 @@ def test_pfm_roundtrip_and_errors(mi, tmp_path):
         mi.Bitmap(img[..., :2]).write(os.path.join(tmp_path, "b.exr"))
     with pytest.raises(RuntimeError):
         mi.Bitmap(img).write(os.path.join(tmp_path, "nodir", "b.exr"))
+
+
+def test_bitmap_texture_sources(mi, tmp_path):
+    """BitmapTexture (src/textures/bitmap.cpp:175-260): the same texels from `data`, a Bitmap object and an OpenEXR / PFM file; luminance
+    images are replicated, alpha is dropped; exactly one source may be given"""
+    import os
+    import pytest
+    tex = np.random.default_rng(0).random((8, 6, 3)).astype(np.float32)
+    ref = mi.load_dict({"type": "diffuse", "reflectance": {"type": "bitmap", "data": tex, "raw": True}}).texture
+    for ext in ("exr", "pfm"):
+        p = os.path.join(tmp_path, "t." + ext); mi.Bitmap(tex).write(p)
+        assert np.array_equal(mi.load_dict({"type": "diffuse", "reflectance": {"type": "bitmap", "filename": p}}).texture, ref)
+    assert np.array_equal(mi.load_dict({"type": "diffuse", "reflectance": {"type": "bitmap", "bitmap": mi.Bitmap(tex)}}).texture, ref)
+    grey = mi.load_dict({"type": "diffuse", "reflectance": {"type": "bitmap", "bitmap": mi.Bitmap(tex[:, :, :1])}}).texture
+    assert grey.shape == (8, 6, 3) and np.array_equal(grey[:, :, 2], tex[:, :, 0])
+    rgba = np.concatenate([tex, np.ones((8, 6, 1), np.float32)], 2)
+    assert np.array_equal(mi.load_dict({"type": "diffuse", "reflectance": {"type": "bitmap", "data": rgba}}).texture, ref)
+    with pytest.raises(RuntimeError, match="exactly one"):
+        mi.load_dict({"type": "diffuse", "reflectance": {"type": "bitmap", "data": tex, "bitmap": mi.Bitmap(tex)}})
+    with pytest.raises(RuntimeError, match="not found"):
+        mi.load_dict({"type": "diffuse", "reflectance": {"type": "bitmap", "filename": os.path.join(tmp_path, "missing.exr")}})
