@@ -933,11 +933,12 @@ class Scene:
         bi = self._add_bsdf(m.bsdf)
         em = -1
         if m.emitter is not None:
-            if not hasattr(m, 'rect'):
-                raise RuntimeError("area emitters are implemented for `rectangle` shapes only in hip_ad_rgb")
             em = self._emitter_order.index(key)
-            self.emitters[em] = (dict(type=0, mesh=len(self.meshes), radiance=m.emitter, to_world=m.rect['to_world'].col_major_3x4(),
-                                      normal=m.rect['normal'], inv_area=m.rect['inv_area']))
+            if hasattr(m, 'rect'):        # Rectangle::sample_position (analytic parameterisation)
+                self.emitters[em] = (dict(type=0, mesh=len(self.meshes), radiance=m.emitter, to_world=m.rect['to_world'].col_major_3x4(),
+                                          normal=m.rect['normal'], inv_area=m.rect['inv_area']))
+            else:                         # any other triangle mesh: Mesh::sample_position (area-weighted face selection)
+                self.emitters[em] = dict(type=3, mesh=len(self.meshes), radiance=m.emitter, to_world=[0.0] * 12, normal=[0.0] * 3, inv_area=0.0)
         self.meshes.append(dict(key=key, V=np.ascontiguousarray(m.V), F=np.ascontiguousarray(m.F), bsdf=bi, emitter=em, flags=m.flags))
 
     # -- C ABI description
@@ -1055,7 +1056,7 @@ class Scene:
         # emitter radiances: `<shape>.emitter.radiance.value` for area lights, `<emitter>.radiance.value` for `constant` (type 2 = envmap: none)
         for i, key in enumerate(self._emitter_order):
             e = self.emitters[i]
-            if e.get("type", 0) == 0:
+            if e.get("type", 0) in (0, 3):
                 keys[key + ".emitter.radiance.value"] = ("emit", i)
             elif e["type"] == 1:
                 keys[key + ".radiance.value"] = ("emit", i)

@@ -208,7 +208,7 @@ HAR_HD bool bsdf_is_smooth(const DBsdf &B) { return B.type != BSDF_DIELECTRIC; }
  * diffuse-only scenes, where the other models (and their registers) compile out */
 #define HAR_BSDF_ALL_TYPES 0xfu
 #define HAR_BSDF_ONLY_DIFFUSE 0x1u
-#define HAR_SCENE_ENVMAP 0x10u            /* the scene has an environment MAP (emitter type 2): kernels of other scenes compile its code out */
+#define HAR_SCENE_ENVMAP 0x10u            /* the scene has an environment MAP (emitter type 2) or a MESH area light (type 3): kernels of other scenes compile that code out */
 
 /* eval_pdf of one (not twosided) record: value = f * cos(theta_o) */
 template <uint32_t TYPES = HAR_BSDF_ALL_TYPES>

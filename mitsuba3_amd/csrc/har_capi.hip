@@ -284,7 +284,8 @@ int har_scene_create(const HarSceneDesc *desc, HarScene *out) {
     D.n_bsdfs = (uint32_t) hs.bsdfs.size(); D.n_textures = (uint32_t) hs.textures.size();
     D.env_emitter = hs.env_emitter;
     D.bsdf_types = 0; for (const DBsdf &b : hs.bsdfs) D.bsdf_types |= (1u << b.type) | ((b.flags & BF_TWOSIDED) ? 0x80000000u : 0u);
-    if (hs.has_envmap) D.bsdf_types |= HAR_SCENE_ENVMAP;
+    up(hs.emitter_cdf, &D.emitter_cdf);
+    if (hs.has_envmap || hs.has_mesh_emitters) D.bsdf_types |= HAR_SCENE_ENVMAP;
     if (hs.stack_need() + HAR_STACK_MARGIN > std::min(HAR_LDS_STACK_DEPTH, HAR_LDS_STACK_SMALL + HAR_STACK_SPILL))
         fprintf(stderr, "[hip_ad_rgb] warning: BVH needs %u traversal stack entries, the traversal stack holds %d (overflow is reported as an error)\n", hs.stack_need(),
                 std::min(HAR_LDS_STACK_DEPTH, HAR_LDS_STACK_SMALL + HAR_STACK_SPILL));

@@ -116,7 +116,7 @@ HAR_HD void shade_lane(const DScene &S, const ShadeParams &P, const PathState &s
     /* ---- direct emission + MIS with the previous BSDF sample (path.cpp:206-221, prb.py:148-161) */
     if (emitter >= 0) {
         const DEmitter E = S.emitters[emitter];
-        const bool env = E.type != 0u;
+        const bool env = E.type == 1u || E.type == 2u;
         const bool envmap = (TYPES & HAR_SCENE_ENVMAP) != 0u && E.type == 2u;      /* kernels of scenes without an environment map compile this out */
         Vec3 rel = si.p - st.prev_p;
         float dist = norm3(rel);
@@ -166,6 +166,8 @@ HAR_HD void shade_lane(const DScene &S, const ShadeParams &P, const PathState &s
             wgt = (float) S.n_emitters; ex = scaled - (float) index;
         }
         if ((TYPES & HAR_SCENE_ENVMAP) != 0u && S.emitters[index].type == 2u) envmap_sample_direction(*S.envmap, si.p, ex, ey, ds, em_weight);
+        else if ((TYPES & HAR_SCENE_ENVMAP) != 0u && S.emitters[index].type == 3u)
+            mesh_emitter_sample_direction(S, S.emitters[index], si.p, ex, ey, ds, em_weight, MODE == MODE_PRB_ADJOINT ? &em_unit : nullptr);
         else emitter_sample_direction(S.emitters[index], si.p, ex, ey, ds, em_weight, MODE == MODE_PRB_ADJOINT ? &em_unit : nullptr);
         ds.pdf *= pmf; em_weight = em_weight * wgt; em_unit *= wgt; em_sampled = index;
         active_em = ds.pdf != 0.f;

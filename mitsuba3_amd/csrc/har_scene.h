@@ -14,7 +14,9 @@ namespace har {
 struct DMesh    { uint32_t voff, foff, bsdf; int32_t emitter; uint32_t flags, face_count, pad0, pad1; };
 struct DTexture { const float *data; uint32_t w, h; };
 /* type 0: AreaLight on a rectangle (to_world, normal, inv_area, mesh); type 1: ConstantBackgroundEmitter
- * (src/emitters/constant.cpp): to_world[0..2] = bounding sphere centre, to_world[3] = radius, mesh = 0xffffffff */
+ * (src/emitters/constant.cpp): to_world[0..2] = bounding sphere centre, to_world[3] = radius, mesh = 0xffffffff; type 2: environment map
+ * (DEnvmap); type 3: AreaLight on a triangle mesh: mesh, inv_area = 1 / surface area, to_world[0] / [1] = bit patterns of the offset of its
+ * table in DScene::emitter_cdf and of its face count, to_world[2] = sum of the face areas */
 struct DEmitter { float radiance[3]; float inv_area; float to_world[12]; float normal[3]; uint32_t mesh; uint32_t type; };
 struct DInst    { float to_world[12]; float to_object[12]; };
 /* EnvironmentMapEmitter (src/emitters/envmap.cpp), emitter type 2.  `tex` = H x (W + 2) x 3 radiance with one halo column on each side
@@ -44,6 +46,7 @@ struct DScene {
     int32_t  env_emitter;              /* index of the environment emitter (Scene::environment()), or -1 */
     uint32_t bsdf_types;               /* bit mask (1 << type) of the BSDF types present (+ bit 31: some record is twosided) */
     const DEnvmap *envmap;             /* device record of the environment map when emitters[env_emitter].type == 2 */
+    const float   *emitter_cdf;        /* face-area tables of the mesh emitters (type 3): per emitter `count` unnormalised pmf values, then `count` cdf values */
 };
 
 struct DSensor {
@@ -353,6 +356,47 @@ HAR_HD void envmap_sample_direction(const DEnvmap &E, Vec3 ref_p, float sx, floa
     ds.p = fma3(d, dist, ref_p); ds.n = -d; ds.d = d; ds.dist = dist;
     ds.pdf = active ? pdf * inv_sin_theta * (1.f / (2.f * (HAR_PI * HAR_PI))) : 0.f;
     spec = active ? div3(envmap_eval_uv(E, u, v), ds.pdf) : Vec3(0.f);
+}
+/* AreaLight::sample_direction on a triangle mesh: Mesh::sample_position (src/render/mesh.cpp:1662-1712) -- DiscreteDistribution::sample_reuse over the
+ * face areas (distr_1d.h:117-183, JIT predicate, dr::binary_search over [0, n - 1]), warp::square_to_uniform_triangle (warp.h:153-156), interpolated
+ * vertex normals when the mesh has them -- then Shape::sample_direction (shape.cpp:93-110) and the one-sided test of area.cpp:118-168 */
+HAR_HD void mesh_emitter_sample_direction(const DScene &S, const DEmitter &E, Vec3 ref_p, float sx, float sy, DirSample &ds, Vec3 &spec, float *unit = nullptr) {
+    const uint32_t off = as_u32(E.to_world[0]), nf = as_u32(E.to_world[1]);
+    const float sum = E.to_world[2], normalization = E.inv_area;
+    const float *pmf = S.emitter_cdf + off, *cdf = pmf + nf;
+    const float value = sy * sum;
+    uint32_t start = 0, end = nf - 1u, iterations = 0;
+    if (start < end) { uint32_t span = end - start; iterations = 1; while (span >>= 1) ++iterations; }
+    for (uint32_t i = 0; i < iterations; ++i) {
+        const uint32_t middle = (start + end) >> 1;
+        const float c = cdf[middle];
+        const bool cond = ((c < value) || c == 0.f) && c != sum;
+        if (cond) start = middle + 1u < end ? middle + 1u : end; else end = middle;
+    }
+    const uint32_t idx = start;
+    const float pmf_n = pmf[idx] * normalization, cdf_n = idx > 0 ? cdf[idx - 1u] * normalization : 0.f;
+    sy = (sy - cdf_n) / pmf_n;
+    const DMesh M = S.meshes[E.mesh];
+    const uint32_t *f = S.faces + 4 * ((size_t) M.foff + idx);
+    const float *v0 = S.verts + 8 * ((size_t) M.voff + f[0]), *v1 = S.verts + 8 * ((size_t) M.voff + f[1]), *v2 = S.verts + 8 * ((size_t) M.voff + f[2]);
+    const Vec3 p0(v0[0], v0[1], v0[2]), e0 = Vec3(v1[0], v1[1], v1[2]) - p0, e1 = Vec3(v2[0], v2[1], v2[2]) - p0;
+    const float t = sqrtf(fmaxf(1.f - sx, 0.f)), bx = 1.f - t, by = t * sy;
+    ds.p = fma3(e0, bx, fma3(e1, by, p0));
+    Vec3 n;
+    if (M.flags & 1u) n = fma3(Vec3(v0[3], v0[4], v0[5]), 1.f - bx - by, fma3(Vec3(v1[3], v1[4], v1[5]), bx, Vec3(v2[3], v2[4], v2[5]) * by));
+    else n = cross3(e0, e1);
+    ds.n = normalize3(n);
+    ds.pdf = normalization;
+    ds.d = ds.p - ref_p;
+    const float dist2 = dot3(ds.d, ds.d);
+    ds.dist = sqrtf(dist2);
+    ds.d = div3(ds.d, ds.dist);
+    const float dp = fabsf(dot3(ds.d, ds.n));
+    const float x = dist2 / dp;
+    ds.pdf *= finite_(x) ? x : 0.f;
+    const bool active = dot3(ds.d, ds.n) < 0.f && ds.pdf != 0.f;
+    spec = active ? div3(Vec3(E.radiance[0], E.radiance[1], E.radiance[2]), ds.pdf) : Vec3(0.f);
+    if (unit) *unit = active ? rcp_(ds.pdf) : 0.f;
 }
 /* AreaLight::pdf_direction (area.cpp:170-197) / Shape::pdf_direction (shape.cpp:112-124) */
 HAR_HD float emitter_pdf_direction(const DEmitter &E, Vec3 d, Vec3 n, float dist) {

@@ -243,10 +243,11 @@ bool lower_scene(const HarSceneDesc &d, HostScene &hs, std::string &err) {
     }
     for (uint32_t i = 0; i < d.emitter_count; ++i) {
         const HarEmitter &e = d.emitters[i];
-        if (e.type > 2) { err = "unsupported emitter type (`area` on a rectangle, `constant` and `envmap` are implemented)"; return false; }
-        if (e.type == 0 && e.mesh >= d.top_mesh_count) { err = "area emitter must be attached to a top-level mesh"; return false; }
-        if (e.type != 0 && hs.env_emitter >= 0) { err = "Only one environment emitter can be specified per scene."; return false; }   /* scene.cpp:64-65 */
-        if (e.type != 0) hs.env_emitter = (int32_t) i;
+        if (e.type > 3) { err = "unsupported emitter type (`area`, `constant` and `envmap` are implemented)"; return false; }
+        const bool area = e.type == 0 || e.type == 3;
+        if (area && e.mesh >= d.top_mesh_count) { err = "area emitter must be attached to a top-level mesh"; return false; }
+        if (!area && hs.env_emitter >= 0) { err = "Only one environment emitter can be specified per scene."; return false; }   /* scene.cpp:64-65 */
+        if (!area) hs.env_emitter = (int32_t) i;
         if (e.type == 2) {
             if (e.mesh >= d.texture_count) { err = "envmap emitter references a bitmap that does not exist"; return false; }
             if (!build_envmap(hs, d.textures[e.mesh], e, err)) return false;
@@ -254,6 +255,24 @@ bool lower_scene(const HarSceneDesc &d, HostScene &hs, std::string &err) {
         DEmitter de{}; de.type = e.type;
         std::memcpy(de.radiance, e.radiance, 12); de.inv_area = e.inv_area;
         std::memcpy(de.to_world, e.to_world, 48); std::memcpy(de.normal, e.normal, 12); de.mesh = e.mesh;
+        if (e.type == 3) {            /* Mesh::build_pmf (mesh.cpp:1358-1372): face areas of the (world-space) mesh + their running sum */
+            const DMesh &M = hs.meshes[e.mesh];
+            if (M.face_count == 0) { err = "Cannot create sampling table for an empty mesh"; return false; }
+            const uint32_t off = (uint32_t) hs.emitter_cdf.size();
+            hs.emitter_cdf.resize(off + 2 * (size_t) M.face_count);
+            float acc = 0.f;
+            for (uint32_t f = 0; f < M.face_count; ++f) {
+                const uint32_t *fi = hs.faces.data() + 4 * ((size_t) M.foff + f);
+                auto P = [&](uint32_t v) { const float *q = hs.verts.data() + 8 * ((size_t) M.voff + v); return Vec3(q[0], q[1], q[2]); };
+                const Vec3 c = cross3(P(fi[1]) - P(fi[0]), P(fi[2]) - P(fi[0]));
+                const float a = .5f * sqrtf(dot3(c, c));
+                acc += a; hs.emitter_cdf[off + f] = a; hs.emitter_cdf[off + M.face_count + f] = acc;
+            }
+            uint32_t nf = M.face_count;
+            std::memcpy(&de.to_world[0], &off, 4); std::memcpy(&de.to_world[1], &nf, 4); de.to_world[2] = acc;
+            de.inv_area = rcp_(acc);
+            hs.has_mesh_emitters = true;
+        }
         hs.emitters.push_back(de);
     }
     for (uint32_t g = 0; g < d.group_count; ++g)

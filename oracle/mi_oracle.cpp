@@ -49,6 +49,9 @@ struct Scene {
     std::vector<OrcEmitter> emitters;
     int env = -1; float env_center[3] = { 0, 0, 0 }; float env_radius = 0.f;   // Scene::environment() + its bounding sphere
     EnvMap envmap;                 // when emitters[env].type == 2
+    /* AreaLight on a triangle mesh (emitter type 3): DiscreteDistribution over the face areas (Mesh::build_pmf, mesh.cpp:1358-1372) */
+    struct AreaPmf { std::vector<float> pmf, cdf; float sum = 0.f, normalization = 0.f; };
+    std::vector<AreaPmf> area_pmf;  // indexed by emitter
     Bvh top;                       // all top-level meshes
     std::vector<Bvh> group_bvh;    // one per shapegroup
     std::vector<BvhNode> inst_nodes; // BVH over instance world boxes
@@ -420,10 +423,43 @@ static inline void constant_sample_direction(const OrcEmitter &e, const EnvSpher
     spec = div(V3(e.radiance[0], e.radiance[1], e.radiance[2]), ds.pdf);
     if (unit) *unit = rcp(ds.pdf);
 }
-static inline void emitter_sample_direction(const OrcEmitter &e, V3 ref_p, float sx, float sy, DS &ds, V3 &spec, float *unit = nullptr) {
-    ds.p = xf_point(e.to_world, V3(fmadd(sx, 2.f, -1.f), fmadd(sy, 2.f, -1.f), 0.f));
-    ds.n = V3(e.normal[0], e.normal[1], e.normal[2]);
-    ds.pdf = e.inv_area;
+/* Mesh::sample_position (src/render/mesh.cpp:1662-1712) with DiscreteDistribution::sample_reuse (include/mitsuba/core/distr_1d.h:117-183; the JIT
+ * predicate of `sample`, dr::binary_search over [0, n - 1]) and warp::square_to_uniform_triangle (warp.h:153-156) */
+static inline void mesh_sample_position(const Mesh &m, const Scene::AreaPmf &d, float sx, float sy, V3 &p, V3 &n, float &pdf) {
+    const uint32_t nf = (uint32_t) d.pmf.size();
+    float value = sy * d.sum;
+    uint32_t start = 0, end = nf - 1, iterations = 0;
+    if (start < end) { uint32_t span = end - start; iterations = 1; while (span >>= 1) ++iterations; }
+    for (uint32_t i = 0; i < iterations; ++i) {
+        uint32_t middle = (start + end) >> 1;
+        float c = d.cdf[middle];
+        bool cond = ((c < value) || c == 0.f) && c != d.sum;
+        if (cond) start = std::min(middle + 1, end); else end = middle;
+    }
+    const uint32_t idx = start;
+    float pmf_n = d.pmf[idx] * d.normalization, cdf_n = idx > 0 ? d.cdf[idx - 1] * d.normalization : 0.f;
+    sy = (sy - cdf_n) / pmf_n;
+    const uint32_t *f = m.F.data() + 4 * (size_t) idx;
+    const float *v0 = m.V.data() + 8 * (size_t) f[0], *v1 = m.V.data() + 8 * (size_t) f[1], *v2 = m.V.data() + 8 * (size_t) f[2];
+    V3 p0(v0[0], v0[1], v0[2]), p1(v1[0], v1[1], v1[2]), p2(v2[0], v2[1], v2[2]);
+    V3 e0 = p1 - p0, e1 = p2 - p0;
+    float t = std::sqrt(std::fmax(1.f - sx, 0.f)), bx = 1.f - t, by = t * sy;
+    p = fmadd(e0, bx, fmadd(e1, by, p0));
+    if (m.flags & 1u) {
+        V3 n0(v0[3], v0[4], v0[5]), n1(v1[3], v1[4], v1[5]), n2(v2[3], v2[4], v2[5]);
+        n = fmadd(n0, 1.f - bx - by, fmadd(n1, bx, n2 * by));
+    } else n = cross(e0, e1);
+    n = normalize(n);
+    pdf = d.normalization;
+}
+static inline void emitter_sample_direction(const Scene &sc, uint32_t index, V3 ref_p, float sx, float sy, DS &ds, V3 &spec, float *unit = nullptr) {
+    const OrcEmitter &e = sc.emitters[index];
+    if (e.type == 3) mesh_sample_position(sc.meshes[e.mesh], sc.area_pmf[index], sx, sy, ds.p, ds.n, ds.pdf);
+    else {          // Rectangle::sample_position (rectangle.cpp:159-170)
+        ds.p = xf_point(e.to_world, V3(fmadd(sx, 2.f, -1.f), fmadd(sy, 2.f, -1.f), 0.f));
+        ds.n = V3(e.normal[0], e.normal[1], e.normal[2]);
+        ds.pdf = e.inv_area;
+    }
     ds.d = ds.p - ref_p;
     float dist2 = squared_norm(ds.d);
     ds.dist = std::sqrt(dist2);
@@ -471,7 +507,7 @@ static inline bool sample_emitter_direction(const Scene &sc, const SI &si, float
         sc.envmap.sample_direction(si.p, sx, sy, ds.d, ds.dist, ds.pdf, spec, uv);
         ds.p = fmadd(ds.d, ds.dist, si.p); ds.n = -ds.d;
     }
-    else emitter_sample_direction(sc.emitters[index], si.p, sx, sy, ds, spec, unit);
+    else emitter_sample_direction(sc, index, si.p, sx, sy, ds, spec, unit);
     ds.emitter = (int) index;
     ds.pdf *= pmf;
     spec = spec * weight;
@@ -604,7 +640,7 @@ static V3 path_sample(const Scene &sc, Pcg32 &rng, Ray ray, uint32_t max_depth, 
             float em_pdf = 0.f;
             if (!prev_bsdf_delta) em_pdf = (e.type == 1 ? InvFourPi : e.type == 2 ? sc.envmap.pdf_direction(ds.d) : emitter_pdf_direction(e, ds)) * (1.f / (float) sc.emitters.size());
             float mis_bsdf = mis_weight(prev_bsdf_pdf, em_pdf);
-            bool facing = e.type != 0 || si.wi.z > 0.f;                                                                   // area.cpp:83-90, constant.cpp:90-94
+            bool facing = (e.type != 0 && e.type != 3) || si.wi.z > 0.f;                                                                   // area.cpp:83-90, constant.cpp:90-94
             V3 rad = e.type == 2 ? sc.envmap.eval(-si.wi) : V3(e.radiance[0], e.radiance[1], e.radiance[2]);             // envmap.cpp:228-236
             V3 Le = (facing && prev_bsdf_pdf > 0.f) ? rad : V3(0.f);
             result = fmadd(throughput, Le * mis_bsdf, result);
@@ -1004,9 +1040,24 @@ void *orc_scene_create(const OrcSceneDesc *d) {
         sc->textures.push_back(std::move(t));
     }
     sc->emitters.assign(d->emitters, d->emitters + d->emitter_count);
+    sc->area_pmf.resize(sc->emitters.size());
     for (uint32_t i = 0; i < sc->emitters.size(); ++i) {
-        const OrcEmitter &e = sc->emitters[i];
+        const OrcEmitter e = sc->emitters[i];
         if (e.type == 1 || e.type == 2) sc->env = (int) i;
+        if (e.type == 3) {              // Mesh::build_pmf: face areas, sequential float prefix sum (dr::prefix_sum's summation order is not in the tree)
+            if (e.mesh >= sc->top_count || sc->meshes[e.mesh].nf == 0) { delete sc; return nullptr; }
+            const Mesh &m = sc->meshes[e.mesh];
+            Scene::AreaPmf &d = sc->area_pmf[i];
+            float acc = 0.f;
+            for (uint32_t f = 0; f < m.nf; ++f) {
+                const uint32_t *fi = m.F.data() + 4 * (size_t) f;
+                auto P = [&](uint32_t v) { const float *q = m.V.data() + 8 * (size_t) v; return V3(q[0], q[1], q[2]); };
+                float a = .5f * norm(cross(P(fi[1]) - P(fi[0]), P(fi[2]) - P(fi[0])));
+                d.pmf.push_back(a); acc += a; d.cdf.push_back(acc);
+            }
+            d.sum = acc; d.normalization = rcp(acc);
+            sc->emitters[i].inv_area = d.normalization;       // Mesh::pdf_position = m_area_pmf.normalization()
+        }
         if (e.type == 2) {
             if (e.mesh >= sc->textures.size()) { delete sc; return nullptr; }
             const Texture &t = sc->textures[e.mesh];

@@ -44,7 +44,8 @@ static void bind(HScene &H) {
     S.n_bsdfs = (uint32_t) hs.bsdfs.size(); S.n_textures = (uint32_t) hs.textures.size();
     S.env_emitter = hs.env_emitter;
     S.bsdf_types = 0; for (const DBsdf &b : hs.bsdfs) S.bsdf_types |= (1u << b.type) | ((b.flags & BF_TWOSIDED) ? 0x80000000u : 0u);
-    S.envmap = nullptr;
+    S.envmap = nullptr; S.emitter_cdf = hs.emitter_cdf.data();
+    if (hs.has_mesh_emitters) S.bsdf_types |= HAR_SCENE_ENVMAP;
     if (hs.has_envmap) { hs.envmap.tex = hs.env_tex.data(); hs.envmap.warp = hs.env_warp.data(); S.envmap = &hs.envmap; S.bsdf_types |= HAR_SCENE_ENVMAP; }
 }
 
@@ -130,7 +131,7 @@ int hh_render(void *h, const HarSensor *sensor, int mode, uint32_t seed, uint32_
             accel_trace<false>(S.accel, st.o, st.d, st.maxt, hit, stack, status);
             ShadeResult R;
             constexpr uint32_t ENV = HAR_BSDF_ALL_TYPES | HAR_SCENE_ENVMAP;
-            if (S.envmap) { if (mode == MODE_PATH) shade_lane<MODE_PATH, ENV>(S, P, st, hit, R); else shade_lane<MODE_PRB_PRIMAL, ENV>(S, P, st, hit, R); }
+            if (S.bsdf_types & HAR_SCENE_ENVMAP) { if (mode == MODE_PATH) shade_lane<MODE_PATH, ENV>(S, P, st, hit, R); else shade_lane<MODE_PRB_PRIMAL, ENV>(S, P, st, hit, R); }
             else if (mode == MODE_PATH) shade_lane<MODE_PATH>(S, P, st, hit, R); else shade_lane<MODE_PRB_PRIMAL>(S, P, st, hit, R);
             if (R.add_emission) result = mode == MODE_PATH ? fma3(R.em_a, R.em_b, result) : result + R.em_b;
             if (R.item && R.item_ray) {

@@ -532,6 +532,33 @@ def test_ztest_product_vs_oracle(mi, O):
         assert not ok, name                              # power: +3 % is rejected
 
 
+def test_mesh_area_emitters_parity(mi, O):
+    """area lights on arbitrary triangle meshes (Mesh::sample_position: face pmf + uniform triangle + interpolated normals) vs the oracle:
+    path / prb images, BSDF and emitter-radiance gradients"""
+    from tests.test_emitters_cpu import mesh_light_scene
+    from tests.test_cpu_host import oracle_scene_from
+    for normals in (True, False):
+        scene = mi.load_dict(mesh_light_scene(mi, 40, normals))
+        assert sorted(e["type"] for e in scene.emitters) == [3, 3]
+        osc, sensor = oracle_scene_from(O, scene)
+        img = mi.render(scene, spp=16, seed=5).cpu().numpy()
+        ref, st = osc.render_path(sensor, seed=5, spp=16, max_depth=8)
+        assert ref.mean() > 0.02 and rel_l2(img, ref) < 1e-4
+        gst = scene.integrator().stats()
+        assert gst["paths"] == st.paths and gst["vertices"] == st.vertices and gst["shadow_rays"] == st.shadow_rays
+        integ = mi.load_dict({"type": "prb", "max_depth": 6})
+        img = mi.render(scene, integrator=integ, spp=16, seed=5).cpu().numpy()
+        ref, _ = osc.render_prb(sensor, seed=5, spp=16, max_depth=6)
+        assert rel_l2(img, ref) < 1e-4
+        grad_in = np.random.default_rng(2).uniform(0.5, 1.5, (40, 40, 3)).astype(np.float32)
+        grads = integ.render_backward(scene, None, grad_in, seed=3, spp=8)
+        g_refl, _, g_emit, _ = osc.render_prb_backward_emitters(sensor, grad_in, seed=3, spp=8, max_depth=6)
+        keys = scene._param_keys()
+        bk = {k: v for k, v in keys.items() if v[0] != "emit"}; ek = {k: v[1] for k, v in keys.items() if v[0] == "emit"}
+        assert rel_l2(np.stack([grads[k].cpu().numpy() for k in bk]), np.stack([g_refl[b.index] for (_, b) in bk.values()])) < 1e-3
+        assert len(ek) == 2 and rel_l2(np.stack([grads[k].cpu().numpy() for k in ek]), np.stack([g_emit[i] for i in ek.values()])) < 1e-3
+
+
 def test_prb_emitter_radiance_gradients(mi, O):
     """d loss / d radiance of `area` and `constant` emitters (prb.py:160-161 emission term, :198-206 emitter sampling term with the emitter
     attached) vs the oracle, through render_backward and through mi.render + autograd; the BSDF gradients are unchanged by the extra outputs"""
