@@ -57,13 +57,17 @@ typedef struct HarInstance {
  *   type 1 dielectric      (src/bsdfs/dielectric.cpp)      slot0 = specular_reflectance, slot1 = specular_transmittance, eta
  *   type 2 roughconductor  (src/bsdfs/roughconductor.cpp)  slot0 = specular_reflectance, eta_c / k_c (RGB), alpha_u / alpha_v
  *   type 3 roughplastic    (src/bsdfs/roughplastic.cpp)    slot0 = diffuse_reflectance, slot1 = specular_reflectance, eta, alpha_u
+ *   type 4 conductor       (src/bsdfs/conductor.cpp)       slot0 = specular_reflectance, eta_c / k_c (RGB)
+ *   type 5 plastic         (src/bsdfs/plastic.cpp)         slot0 = diffuse_reflectance, slot1 = specular_reflectance, eta
  * slot0 may be a bitmap texture (`texture` >= 0), slot1 is constant.
  * flags: bit0 twosided (src/bsdfs/twosided.cpp; `back` = record used for the back side, -1 = the same one),
- *        bit1 GGX distribution (else Beckmann), bit2 sample_visible, bit3 roughplastic `nonlinear`. */
+ *        bit1 GGX distribution (else Beckmann), bit2 sample_visible, bit3 plastic / roughplastic `nonlinear`. */
 #define HAR_BSDF_DIFFUSE        0
 #define HAR_BSDF_DIELECTRIC     1
 #define HAR_BSDF_ROUGHCONDUCTOR 2
 #define HAR_BSDF_ROUGHPLASTIC   3
+#define HAR_BSDF_CONDUCTOR      4
+#define HAR_BSDF_PLASTIC        5
 #define HAR_BSDF_TWOSIDED       1u
 #define HAR_BSDF_GGX            2u
 #define HAR_BSDF_SAMPLE_VISIBLE 4u

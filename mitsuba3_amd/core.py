@@ -476,14 +476,15 @@ def _rgb_value(v, default, bounded=True):
     return out
 
 
-BSDF_TYPES = {'diffuse': 0, 'dielectric': 1, 'roughconductor': 2, 'roughplastic': 3}
+BSDF_TYPES = {'diffuse': 0, 'dielectric': 1, 'roughconductor': 2, 'roughplastic': 3, 'conductor': 4, 'plastic': 5}
 # (parameter name of slot 0, default), (parameter name of slot 1, default)
 _BSDF_SLOTS = {'diffuse': (('reflectance', 0.5), None), 'dielectric': (('specular_reflectance', 1.0), ('specular_transmittance', 1.0)),
-               'roughconductor': (('specular_reflectance', 1.0), None), 'roughplastic': (('diffuse_reflectance', 0.5), ('specular_reflectance', 1.0))}
+               'roughconductor': (('specular_reflectance', 1.0), None), 'roughplastic': (('diffuse_reflectance', 0.5), ('specular_reflectance', 1.0)),
+               'conductor': (('specular_reflectance', 1.0), None), 'plastic': (('diffuse_reflectance', 0.5), ('specular_reflectance', 1.0))}
 
 
 class BSDF:
-    """diffuse / dielectric / roughconductor / roughplastic (src/bsdfs/*.cpp), optionally wrapped by `twosided`.
+    """diffuse / dielectric / conductor / plastic / roughconductor / roughplastic (src/bsdfs/*.cpp), optionally wrapped by `twosided`.
     Colour parameters live in two slots (include/hip_ad_rgb.h HarBSDF); slot 0 may be a raw `bitmap`."""
 
     def __init__(self, props=None, id=None):
@@ -547,21 +548,22 @@ class BSDF:
                 self.alpha_u = float(props['alpha_u']); self.alpha_v = float(props['alpha_v'])
             else:
                 self.alpha_u = self.alpha_v = float(props.get('alpha', 0.1))
-        if self.kind == 'roughconductor':                            # roughconductor.cpp:163-172
+        if self.kind in ('roughconductor', 'conductor'):             # roughconductor.cpp:163-172, conductor.cpp:228-237
             if props.get('material', 'none') != 'none':
-                raise RuntimeError("roughconductor: `material` presets need the spectral IOR data files, give (eta, k) instead")
+                if 'eta' in props:
+                    raise RuntimeError("Should specify either (eta, k) or material, not both.")
+                raise RuntimeError("%s: `material` presets need the spectral IOR data files, give (eta, k) instead" % self.kind)
             self.eta_c = _rgb_value(props.get('eta'), 0.0, bounded=False); self.k_c = _rgb_value(props.get('k'), 1.0, bounded=False)
-        if self.kind in ('dielectric', 'roughplastic'):
+        if self.kind in ('dielectric', 'roughplastic', 'plastic'):
             int_ior = _lookup_ior(props, 'int_ior', 'bk7' if self.kind == 'dielectric' else 'polypropylene')
             ext_ior = _lookup_ior(props, 'ext_ior', 'air')
             if int_ior < 0 or ext_ior < 0 or (self.kind == 'roughplastic' and int_ior == ext_ior):
                 raise RuntimeError("The interior and exterior indices of refraction must be positive" + (" and differ!" if self.kind == 'roughplastic' else "!"))
             self.eta = float(np.float32(int_ior) / np.float32(ext_ior))
-            if self.kind == 'roughplastic':
-                if self.alpha_u != self.alpha_v:
-                    raise RuntimeError("The 'roughplastic' plugin currently does not support anisotropic microfacet distributions!")
-                if props.get('nonlinear', False):
-                    self.flags |= 8
+            if self.kind == 'roughplastic' and self.alpha_u != self.alpha_v:
+                raise RuntimeError("The 'roughplastic' plugin currently does not support anisotropic microfacet distributions!")
+            if self.kind in ('roughplastic', 'plastic') and props.get('nonlinear', False):
+                self.flags |= 8
         self.scene = None; self.index = None
 
     def _bind(self):
@@ -1114,7 +1116,7 @@ def traverse(scene):
 # ---------------------------------------------------------------------------
 
 _REGISTRY = {}
-_BSDF_PLUGINS = ('diffuse', 'dielectric', 'roughconductor', 'roughplastic', 'twosided')
+_BSDF_PLUGINS = ('diffuse', 'dielectric', 'conductor', 'plastic', 'roughconductor', 'roughplastic', 'twosided')
 
 
 def register_plugin(name, variant_name, instantiate):
@@ -1243,7 +1245,7 @@ for _name, _fn in {
     'hdrfilm': lambda p, n, k: Film(p),
     'independent': lambda p, n, k: Sampler(p),
     'diffuse': lambda p, n, k: BSDF(p, id=k), 'dielectric': lambda p, n, k: BSDF(p, id=k), 'roughconductor': lambda p, n, k: BSDF(p, id=k),
-    'roughplastic': lambda p, n, k: BSDF(p, id=k), 'twosided': _mk_twosided, 'constant': lambda p, n, k: ConstantEmitter(p), 'envmap': lambda p, n, k: EnvmapEmitter(p),
+    'roughplastic': lambda p, n, k: BSDF(p, id=k), 'conductor': lambda p, n, k: BSDF(p, id=k), 'plastic': lambda p, n, k: BSDF(p, id=k), 'twosided': _mk_twosided, 'constant': lambda p, n, k: ConstantEmitter(p), 'envmap': lambda p, n, k: EnvmapEmitter(p),
     'rectangle': lambda p, n, k: _shape_common(_rectangle(p), p, n),
     'cube': lambda p, n, k: _shape_common(_cube(p), p, n),
     'mesh': _mk_mesh, 'ply': _mk_ply, 'obj': _mk_obj, 'serialized': _mk_serialized,

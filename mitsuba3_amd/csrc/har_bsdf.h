@@ -20,7 +20,7 @@
 
 namespace har {
 
-enum { BSDF_DIFFUSE = 0, BSDF_DIELECTRIC = 1, BSDF_ROUGHCONDUCTOR = 2, BSDF_ROUGHPLASTIC = 3 };
+enum { BSDF_DIFFUSE = 0, BSDF_DIELECTRIC = 1, BSDF_ROUGHCONDUCTOR = 2, BSDF_ROUGHPLASTIC = 3, BSDF_CONDUCTOR = 4, BSDF_PLASTIC = 5, BSDF_TYPE_COUNT = 6 };
 enum { BF_TWOSIDED = 1u, BF_GGX = 2u, BF_SAMPLE_VISIBLE = 4u, BF_NONLINEAR = 8u };
 #define HAR_ROUGH_TRANSMITTANCE_RES 64          /* MI_ROUGH_TRANSMITTANCE_RES, include/mitsuba/render/microfacet.h */
 
@@ -202,13 +202,23 @@ HAR_HD float lerp_gather(const float *data, float x, uint32_t size) {
 
 struct BsdfInputs { Vec3 slot0, slot1; const float *table; };       /* evaluated colour parameters + roughplastic table */
 
-HAR_HD bool bsdf_is_smooth(const DBsdf &B) { return B.type != BSDF_DIELECTRIC; }          /* BSDFFlags::Smooth */
+HAR_HD bool bsdf_is_smooth(const DBsdf &B) { return B.type != BSDF_DIELECTRIC && B.type != BSDF_CONDUCTOR; }          /* BSDFFlags::Smooth */
 
 /* TYPES = bit mask of the BSDF types a scene contains (1 << type): the shading kernels are specialised for
  * diffuse-only scenes, where the other models (and their registers) compile out */
-#define HAR_BSDF_ALL_TYPES 0xfu
+#define HAR_BSDF_ALL_TYPES 0xffu
 #define HAR_BSDF_ONLY_DIFFUSE 0x1u
-#define HAR_SCENE_ENVMAP 0x10u            /* the scene has an environment MAP (emitter type 2) or a MESH area light (type 3): kernels of other scenes compile that code out */
+#define HAR_BSDF_CLASSIC_TYPES 0xfu       /* diffuse, dielectric, roughconductor, roughplastic: scenes without `conductor` / `plastic` run kernels without that code */
+#define HAR_BSDF_HAS(TYPES, T) (((TYPES) & (1u << (T))) != 0u)
+#define HAR_SCENE_ENVMAP 0x100u           /* the scene has an environment MAP (emitter type 2) or a MESH area light (type 3): kernels of other scenes compile that code out */
+
+/* fresnel_diffuse_reflectance (include/mitsuba/render/fresnel.h:327-355), evaluated on the host when a `plastic` record is (re)built */
+HAR_HD float fresnel_diffuse_reflectance(float eta) {
+    float inv_eta = 1.f / eta;
+    float approx_1 = fmaf(0.0636f, inv_eta, fmaf(eta, fmaf(eta, -1.4399f, 0.7099f), 0.6681f));
+    float approx_2 = fmaf(fmaf(fmaf(fmaf(fmaf(-1.36881f, inv_eta, 4.98554f), inv_eta, -7.80989f), inv_eta, 6.75335f), inv_eta, -3.4793f), inv_eta, 0.919317f);
+    return eta < 1.f ? approx_1 : approx_2;
+}
 
 /* eval_pdf of one (not twosided) record: value = f * cos(theta_o) */
 template <uint32_t TYPES = HAR_BSDF_ALL_TYPES>
@@ -259,6 +269,24 @@ HAR_HD void bsdf_eval_pdf_one(const DBsdf &B, const BsdfInputs &in, Vec3 wi, Vec
         result *= prob_specular;
         result += prob_diffuse * (HAR_INV_PI * cos_theta_o);
         e.pdf = result;
+    } break;
+    case BSDF_CONDUCTOR: break;                                              /* conductor.cpp:306-318: a delta lobe */
+    case BSDF_PLASTIC: {                                                     /* plastic.cpp:318-352 (the delta lobe evaluates to zero) */
+        if (!HAR_BSDF_HAS(TYPES, BSDF_PLASTIC)) return;
+        if (!(cos_theta_i > 0.f && cos_theta_o > 0.f)) return;
+        float f_i, f_o, ct, eit, eti;
+        fresnel_dielectric(cos_theta_i, B.eta, f_i, ct, eit, eti);
+        fresnel_dielectric(cos_theta_o, B.eta, f_o, ct, eit, eti);
+        const bool nonlinear = (B.flags & BF_NONLINEAR) != 0;
+        Vec3 den = nonlinear ? Vec3(1.f) - in.slot0 * B.internal_reflectance : Vec3(1.f - B.internal_reflectance);
+        Vec3 diff(in.slot0.x / den.x, in.slot0.y / den.y, in.slot0.z / den.z);
+        float hemi_pdf = HAR_INV_PI * cos_theta_o;
+        float k = hemi_pdf * B.inv_eta_2 * (1.f - f_i) * (1.f - f_o);
+        e.value = diff * k;
+        e.d_slot0 = nonlinear ? Vec3(k / (den.x * den.x), k / (den.y * den.y), k / (den.z * den.z)) : Vec3(k / den.x, k / den.y, k / den.z);
+        float prob_specular = f_i * B.spec_sampling_weight, prob_diffuse = (1.f - f_i) * (1.f - B.spec_sampling_weight);
+        prob_diffuse = prob_diffuse / (prob_specular + prob_diffuse);
+        e.pdf = hemi_pdf * prob_diffuse;
     } break;
     }
 }
@@ -313,6 +341,34 @@ HAR_HD void bsdf_sample_one(const DBsdf &B, const BsdfInputs &in, Vec3 wi, float
         bs.pdf = e.pdf;
         bool active = bs.pdf > 0.f;
         bs.weight = active ? Vec3(e.value.x / bs.pdf, e.value.y / bs.pdf, e.value.z / bs.pdf) : Vec3(0.f);
+    } break;
+    case BSDF_CONDUCTOR: {                                                   /* conductor.cpp:264-304 */
+        if (!HAR_BSDF_HAS(TYPES, BSDF_CONDUCTOR)) return;
+        if (!(cos_theta_i > 0.f)) return;
+        bs.wo = reflect_local(wi); bs.eta = 1.f; bs.pdf = 1.f; bs.delta = true;
+        Vec3 F(fresnel_conductor(cos_theta_i, B.eta_c[0], B.k_c[0]), fresnel_conductor(cos_theta_i, B.eta_c[1], B.k_c[1]), fresnel_conductor(cos_theta_i, B.eta_c[2], B.k_c[2]));
+        bs.weight = in.slot0 * F;
+    } break;
+    case BSDF_PLASTIC: {                                                     /* plastic.cpp:208-266 */
+        if (!HAR_BSDF_HAS(TYPES, BSDF_PLASTIC)) return;
+        if (!(cos_theta_i > 0.f)) return;
+        float f_i, ct, eit, eti; fresnel_dielectric(cos_theta_i, B.eta, f_i, ct, eit, eti);
+        float prob_specular = f_i * B.spec_sampling_weight, prob_diffuse = (1.f - f_i) * (1.f - B.spec_sampling_weight);
+        prob_specular = prob_specular / (prob_specular + prob_diffuse);
+        prob_diffuse = 1.f - prob_specular;
+        bs.eta = 1.f;
+        if (sample1 < prob_specular) {
+            bs.wo = reflect_local(wi); bs.pdf = prob_specular; bs.delta = true;
+            bs.weight = in.slot1 * (f_i / bs.pdf);
+        } else {
+            bs.wo = square_to_cosine_hemisphere(s2x, s2y);
+            bs.pdf = prob_diffuse * (HAR_INV_PI * bs.wo.z);
+            float f_o; fresnel_dielectric(bs.wo.z, B.eta, f_o, ct, eit, eti);
+            const bool nonlinear = (B.flags & BF_NONLINEAR) != 0;
+            Vec3 den = nonlinear ? Vec3(1.f) - in.slot0 * B.internal_reflectance : Vec3(1.f - B.internal_reflectance);
+            Vec3 value(in.slot0.x / den.x, in.slot0.y / den.y, in.slot0.z / den.z);
+            bs.weight = value * (B.inv_eta_2 * (1.f - f_i) * (1.f - f_o) / prob_diffuse);
+        }
     } break;
     }
 }

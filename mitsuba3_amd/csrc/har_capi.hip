@@ -304,7 +304,7 @@ int har_scene_destroy(HarScene S) {
 int har_scene_set_reflectance(HarScene S, uint32_t bsdf, const float rgb[3]) {
     if (!S || bsdf >= S->hs.bsdfs.size()) return fail("invalid bsdf index");
     DBsdf &b = S->hs.bsdfs[bsdf]; b.r = rgb[0]; b.g = rgb[1]; b.b = rgb[2];
-    if (b.type == BSDF_ROUGHPLASTIC) update_roughplastic_sampling_weight(S->hs, bsdf);     /* RoughPlastic::parameters_changed */
+    if (b.type == BSDF_ROUGHPLASTIC || b.type == BSDF_PLASTIC) update_roughplastic_sampling_weight(S->hs, bsdf);     /* RoughPlastic::parameters_changed */
     HIP_TRY(hipMemcpy(S->d_bsdfs + bsdf, &b, sizeof(DBsdf), hipMemcpyHostToDevice));
     return 0;
 }

@@ -795,7 +795,8 @@ void launch_shade(int mode, hipStream_t s, uint32_t grid, const DScene &S, const
     const bool only_diffuse = S.bsdf_types == HAR_BSDF_ONLY_DIFFUSE;
 #define HAR_LAUNCH_SHADE(M, T) hipLaunchKernelGGL((k_shade<M, T>), g, b, 0, s, S, P, lane_base, shard_cap, count_in, in, h0, h1, out, count_out, items, item_count, result, rc, pass_rng, dL, grad_slots)
     const bool envmap = (S.bsdf_types & HAR_SCENE_ENVMAP) != 0u;      /* generic BSDF code + environment-map sampling / lookup */
-#define HAR_LAUNCH_SHADE_MODE(M) do { if (envmap) HAR_LAUNCH_SHADE(M, HAR_BSDF_ALL_TYPES | HAR_SCENE_ENVMAP); else if (only_diffuse) HAR_LAUNCH_SHADE(M, HAR_BSDF_ONLY_DIFFUSE); else HAR_LAUNCH_SHADE(M, HAR_BSDF_ALL_TYPES); } while (0)
+    const bool classic = (S.bsdf_types & 0x7fffffffu & ~HAR_BSDF_CLASSIC_TYPES) == 0u;
+#define HAR_LAUNCH_SHADE_MODE(M) do { if (envmap) HAR_LAUNCH_SHADE(M, HAR_BSDF_ALL_TYPES | HAR_SCENE_ENVMAP); else if (only_diffuse) HAR_LAUNCH_SHADE(M, HAR_BSDF_ONLY_DIFFUSE); else if (classic) HAR_LAUNCH_SHADE(M, HAR_BSDF_CLASSIC_TYPES); else HAR_LAUNCH_SHADE(M, HAR_BSDF_ALL_TYPES); } while (0)
     if (mode == MODE_PATH)            HAR_LAUNCH_SHADE_MODE(MODE_PATH);
     else if (mode == MODE_PRB_PRIMAL) HAR_LAUNCH_SHADE_MODE(MODE_PRB_PRIMAL);
     else                              HAR_LAUNCH_SHADE_MODE(MODE_PRB_ADJOINT);

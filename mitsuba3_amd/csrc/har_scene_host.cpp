@@ -226,11 +226,11 @@ bool lower_scene(const HarSceneDesc &d, HostScene &hs, std::string &err) {
     }
     for (uint32_t i = 0; i < d.bsdf_count; ++i) {
         const HarBSDF &b = d.bsdfs[i];
-        if (b.type > BSDF_ROUGHPLASTIC) { err = "unsupported BSDF type (diffuse, dielectric, roughconductor, roughplastic and twosided are implemented in hip_ad_rgb)"; return false; }
+        if (b.type >= BSDF_TYPE_COUNT) { err = "unsupported BSDF type (diffuse, dielectric, conductor, plastic, roughconductor, roughplastic and twosided are implemented in hip_ad_rgb)"; return false; }
         if (b.texture >= (int32_t) d.texture_count) { err = "BSDF references a texture that does not exist"; return false; }
         if ((b.flags & BF_TWOSIDED) && b.back >= (int32_t) d.bsdf_count) { err = "twosided BSDF references a back-side BSDF that does not exist"; return false; }
         if ((b.flags & BF_TWOSIDED) && b.type == BSDF_DIELECTRIC) { err = "Only materials without a transmission component can be nested!"; return false; }   /* twosided.cpp:79-83 */
-        if ((b.type == BSDF_DIELECTRIC || b.type == BSDF_ROUGHPLASTIC) && !(b.eta > 0.f)) { err = "The interior and exterior indices of refraction must be positive!"; return false; }
+        if ((b.type == BSDF_DIELECTRIC || b.type == BSDF_ROUGHPLASTIC || b.type == BSDF_PLASTIC) && !(b.eta > 0.f)) { err = "The interior and exterior indices of refraction must be positive!"; return false; }
         if (b.type == BSDF_ROUGHPLASTIC && b.eta == 1.f) { err = "The interior and exterior indices of refraction must be positive and differ!"; return false; }
         if (b.type == BSDF_ROUGHPLASTIC && b.alpha_u != b.alpha_v) { err = "The 'roughplastic' plugin currently does not support anisotropic microfacet distributions!"; return false; }
         DBsdf db{}; db.type = b.type; db.texture = b.texture; db.r = b.reflectance[0]; db.g = b.reflectance[1]; db.b = b.reflectance[2];
@@ -240,6 +240,12 @@ bool lower_scene(const HarSceneDesc &d, HostScene &hs, std::string &err) {
         db.back = (b.flags & BF_TWOSIDED) ? b.back : -1; db.table = -1;
         hs.bsdfs.push_back(db);
         if (b.type == BSDF_ROUGHPLASTIC) { build_roughplastic_tables(hs, i); update_roughplastic_sampling_weight(hs, i); }
+        if (b.type == BSDF_PLASTIC) {                       /* SmoothPlastic::parameters_changed (plastic.cpp:188-205) */
+            DBsdf &p = hs.bsdfs[i];
+            p.inv_eta_2 = 1.f / (p.eta * p.eta);
+            p.internal_reflectance = fresnel_diffuse_reflectance(1.f / p.eta);
+            update_roughplastic_sampling_weight(hs, i);
+        }
     }
     for (uint32_t i = 0; i < d.emitter_count; ++i) {
         const HarEmitter &e = d.emitters[i];

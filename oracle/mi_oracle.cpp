@@ -1064,7 +1064,10 @@ void *orc_scene_create(const OrcSceneDesc *d) {
             sc->envmap.init(t.data.data(), t.w, t.h, e.radiance[0], e.radiance[1] != 0.f, e.to_world, e.to_local);
         }
     }
-    for (uint32_t i = 0; i < sc->bsdfs.size(); ++i) if (sc->bsdfs[i].p.type == 3) roughplastic_precompute(sc->bsdfs[i], slot0_mean(*sc, i));
+    for (uint32_t i = 0; i < sc->bsdfs.size(); ++i) {
+        if (sc->bsdfs[i].p.type == 3) roughplastic_precompute(sc->bsdfs[i], slot0_mean(*sc, i));
+        if (sc->bsdfs[i].p.type == 5) plastic_precompute(sc->bsdfs[i], slot0_mean(*sc, i));
+    }
     build_tri_bvh(sc->top, sc->meshes, 0, sc->top_count);
     sc->group_bvh.resize(sc->groups.size());
     for (size_t g = 0; g < sc->groups.size(); ++g) build_tri_bvh(sc->group_bvh[g], sc->meshes, sc->groups[g].first_mesh, sc->groups[g].mesh_count);
@@ -1113,6 +1116,7 @@ void orc_scene_destroy(void *s) { delete (Scene *) s; }
 void orc_scene_set_reflectance(void *s, uint32_t b, const float rgb[3]) {
     Scene *sc = (Scene *) s; for (int i = 0; i < 3; ++i) sc->bsdfs[b].p.reflectance[i] = rgb[i];
     if (sc->bsdfs[b].p.type == 3) roughplastic_precompute(sc->bsdfs[b], slot0_mean(*sc, b));
+    if (sc->bsdfs[b].p.type == 5) plastic_precompute(sc->bsdfs[b], slot0_mean(*sc, b));
 }
 void orc_scene_set_texture(void *s, uint32_t t, const float *data) { Texture &x = ((Scene *) s)->textures[t]; x.data.assign(data, data + 3 * (size_t) x.w * x.h); }
 

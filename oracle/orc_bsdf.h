@@ -266,7 +266,18 @@ static inline float eval_transmittance(const MicrofacetDistribution &distr, V3 w
     return result;
 }
 
-/* ------------------------------------------------------------------ plugins */
+/* fresnel_diffuse_reflectance (include/mitsuba/render/fresnel.h:327-355) */
+static inline float fresnel_diffuse_reflectance(float eta) {
+    float inv_eta = rcp(eta);
+    float approx_1 = fmadd(0.0636f, inv_eta, fmadd(eta, fmadd(eta, -1.4399f, 0.7099f), 0.6681f));
+    const float c[6] = { 0.919317f, -3.4793f, 6.75335f, -7.80989f, 4.98554f, -1.36881f };       // dr::horner
+    float approx_2 = c[5];
+    for (int i = 4; i >= 0; --i) approx_2 = fmadd(approx_2, inv_eta, c[i]);
+    return eta < 1.f ? approx_1 : approx_2;
+}
+
+/* ------------------------------------------------------------------ plugins
+ * types: 0 diffuse, 1 dielectric, 2 roughconductor, 3 roughplastic, 4 conductor (src/bsdfs/conductor.cpp:218-330), 5 plastic (src/bsdfs/plastic.cpp:150-360) */
 struct BSDFSample { V3 wo; float pdf = 0.f, eta = 0.f; bool delta = false; };
 /* value = f * cos, plus d value / d slot0 (for the hand-derived PRB adjoint of slot-0 colour parameters) */
 struct BSDFEval { V3 value, d_slot0; float pdf = 0.f; };
@@ -280,7 +291,7 @@ struct BsdfRecord {
     MicrofacetType mtype() const { return (p.flags & 2u) ? MicrofacetType::GGX : MicrofacetType::Beckmann; }
     bool sample_visible() const { return (p.flags & 4u) != 0; }
     bool nonlinear() const { return (p.flags & 8u) != 0; }
-    bool smooth() const { return p.type != 1; }
+    bool smooth() const { return p.type != 1 && p.type != 4; }      // BSDFFlags::Smooth: `dielectric` (1) and `conductor` (4) only have delta lobes
 };
 
 static inline float lerp_gather(const std::vector<float> &data, float x) {
@@ -331,7 +342,20 @@ static inline BSDFEval plugin_eval_pdf(const BsdfRecord &b, V3 slot0, V3 slot1, 
         result += prob_diffuse * (InvPi * cos_theta_o);     // warp::square_to_cosine_hemisphere_pdf
         e.pdf = result;
     }
-    return e;                                              // SmoothDielectric: eval = pdf = 0
+    else if (b.p.type == 5) {                              // SmoothPlastic::eval_pdf (plastic.cpp:318-352); the delta lobe evaluates to zero
+        if (!(cos_theta_i > 0.f && cos_theta_o > 0.f)) return e;
+        float f_i = fresnel(cos_theta_i, b.p.eta).r, f_o = fresnel(cos_theta_o, b.p.eta).r;
+        V3 den = b.nonlinear() ? V3(1.f) - slot0 * b.internal_reflectance : V3(1.f - b.internal_reflectance);
+        V3 diff(slot0.x / den.x, slot0.y / den.y, slot0.z / den.z);
+        float hemi_pdf = InvPi * cos_theta_o;
+        float k = hemi_pdf * b.inv_eta_2 * (1.f - f_i) * (1.f - f_o);
+        e.value = diff * k;
+        e.d_slot0 = b.nonlinear() ? V3(k / (den.x * den.x), k / (den.y * den.y), k / (den.z * den.z)) : V3(k / den.x, k / den.y, k / den.z);
+        float prob_specular = f_i * b.specular_sampling_weight, prob_diffuse = (1.f - f_i) * (1.f - b.specular_sampling_weight);
+        prob_diffuse = prob_diffuse / (prob_specular + prob_diffuse);
+        e.pdf = hemi_pdf * prob_diffuse;
+    }
+    return e;                                              // SmoothDielectric, SmoothConductor: eval = pdf = 0
 }
 
 static inline BSDFSample plugin_sample(const BsdfRecord &b, V3 slot0, V3 slot1, V3 wi, float sample1, float s2x, float s2y, V3 &weight) {
@@ -359,6 +383,29 @@ static inline BSDFSample plugin_sample(const BsdfRecord &b, V3 slot0, V3 slot1, 
         float c = dot(wi, m);
         V3 F(fresnel_conductor(c, b.p.eta_c[0], b.p.k_c[0]), fresnel_conductor(c, b.p.eta_c[1], b.p.k_c[1]), fresnel_conductor(c, b.p.eta_c[2], b.p.k_c[2]));
         if (active) weight = F * (slot0 * w);
+    } else if (b.p.type == 4) {                            // SmoothConductor::sample
+        if (!(cos_theta_i > 0.f)) return bs;
+        bs.wo = reflect(wi); bs.eta = 1.f; bs.pdf = 1.f; bs.delta = true;
+        V3 F(fresnel_conductor(cos_theta_i, b.p.eta_c[0], b.p.k_c[0]), fresnel_conductor(cos_theta_i, b.p.eta_c[1], b.p.k_c[1]), fresnel_conductor(cos_theta_i, b.p.eta_c[2], b.p.k_c[2]));
+        weight = slot0 * F;
+    } else if (b.p.type == 5) {                            // SmoothPlastic::sample (plastic.cpp:208-266), both components enabled
+        if (!(cos_theta_i > 0.f)) return bs;
+        float f_i = fresnel(cos_theta_i, b.p.eta).r;
+        float prob_specular = f_i * b.specular_sampling_weight, prob_diffuse = (1.f - f_i) * (1.f - b.specular_sampling_weight);
+        prob_specular = prob_specular / (prob_specular + prob_diffuse);
+        prob_diffuse = 1.f - prob_specular;
+        bs.eta = 1.f;
+        if (sample1 < prob_specular) {
+            bs.wo = reflect(wi); bs.pdf = prob_specular; bs.delta = true;
+            weight = slot1 * (f_i / bs.pdf);
+        } else {
+            bs.wo = square_to_cosine_hemisphere(s2x, s2y);
+            bs.pdf = prob_diffuse * (InvPi * bs.wo.z);
+            float f_o = fresnel(bs.wo.z, b.p.eta).r;
+            V3 den = b.nonlinear() ? V3(1.f) - slot0 * b.internal_reflectance : V3(1.f - b.internal_reflectance);
+            V3 value(slot0.x / den.x, slot0.y / den.y, slot0.z / den.z);
+            weight = value * (b.inv_eta_2 * (1.f - f_i) * (1.f - f_o) / prob_diffuse);
+        }
     } else {
         if (!(cos_theta_i > 0.f)) return bs;
         float t_i = lerp_gather(b.external_transmittance, cos_theta_i);
@@ -376,6 +423,14 @@ static inline BSDFSample plugin_sample(const BsdfRecord &b, V3 slot0, V3 slot1, 
         if (bs.pdf > 0.f) weight = V3(e.value.x / bs.pdf, e.value.y / bs.pdf, e.value.z / bs.pdf);
     }
     return bs;
+}
+
+/* SmoothPlastic::parameters_changed (plastic.cpp:188-205) */
+static inline void plastic_precompute(BsdfRecord &b, float d_mean) {
+    b.inv_eta_2 = 1.f / (b.p.eta * b.p.eta);
+    b.internal_reflectance = fresnel_diffuse_reflectance(1.f / b.p.eta);          // m_fdr_int
+    float s_mean = (b.p.reflectance2[0] + b.p.reflectance2[1] + b.p.reflectance2[2]) / 3.f;
+    b.specular_sampling_weight = s_mean / (d_mean + s_mean);
 }
 
 /* RoughPlastic::parameters_changed */

@@ -1,4 +1,4 @@
-"""BSDF models (diffuse, dielectric, roughconductor, roughplastic, twosided) on the CPU: the oracle against the
+"""BSDF models (diffuse, dielectric, conductor, plastic, roughconductor, roughplastic, twosided) on the CPU: the oracle against the
 reference's known answers, internal consistency in the style of the reference's own BSDF tests, the product's
 HAR_HD code (host harness) against the oracle, and PRB gradients against finite differences."""
 import ctypes as C
@@ -21,6 +21,12 @@ BSDF_DICTS = {
     "rp_beckmann": {"type": "roughplastic", "diffuse_reflectance": {"type": "rgb", "value": [0.7, 0.3, 0.1]}, "alpha": 0.15},
     "rp_ggx_nonlinear": {"type": "roughplastic", "distribution": "ggx", "alpha": 0.3, "nonlinear": True, "int_ior": 1.9,
                          "diffuse_reflectance": {"type": "rgb", "value": [0.4, 0.6, 0.2]}, "specular_reflectance": {"type": "rgb", "value": [0.9, 0.9, 0.5]}},
+    "conductor_mirror": {"type": "conductor"},
+    "conductor_gold": {"type": "conductor", "eta": [0.143, 0.375, 1.442], "k": [3.983, 2.386, 1.603], "specular_reflectance": {"type": "rgb", "value": [0.9, 0.8, 0.95]}},
+    "plastic": {"type": "plastic", "diffuse_reflectance": {"type": "rgb", "value": [0.1, 0.27, 0.36]}, "int_ior": 1.9},
+    "plastic_nonlinear": {"type": "plastic", "nonlinear": True, "diffuse_reflectance": {"type": "rgb", "value": [0.8, 0.6, 0.3]},
+                          "specular_reflectance": {"type": "rgb", "value": [0.7, 0.9, 0.5]}},
+    "twosided_plastic": {"type": "twosided", "m": {"type": "plastic"}},
     "twosided_diffuse": {"type": "twosided", "b": {"type": "diffuse", "reflectance": {"type": "rgb", "value": [0.1, 0.1, 0.1]}}},
     "twosided_pair": {"type": "twosided", "front": {"type": "roughconductor", "alpha": 0.2},
                       "back": {"type": "diffuse", "reflectance": {"type": "rgb", "value": [0.9, 0.9, 0.9]}}},
@@ -46,7 +52,7 @@ class Pair:
         self.scene = bsdf._bind and mi.core.Scene({'_bsdf': bsdf}) if bsdf.scene is None else bsdf.scene
         self.index = bsdf.index
         sd = O.SceneData()
-        types = {"diffuse": 0, "dielectric": 1, "roughconductor": 2, "roughplastic": 3}
+        types = {"diffuse": 0, "dielectric": 1, "roughconductor": 2, "roughplastic": 3, "conductor": 4, "plastic": 5}
         sd.bsdfs = [(types[b.kind], -1, b.value, dict(flags=b.flags, reflectance2=b.value2, alpha_u=b.alpha_u, alpha_v=b.alpha_v, eta=b.eta,
                                                      eta_c=b.eta_c, k_c=b.k_c, back=b.back.index if b.back is not None else -1)) for b in self.scene.bsdf_objs]
         self.osc = O.OracleScene(sd)
@@ -95,7 +101,10 @@ def test_reference_dielectric_and_twosided_kats(mi, O, H):
         assert np.allclose(v_front, v_back) and p_front == p_back and p_front > 0       # same BSDF on both sides (twosided.cpp:124-127)
 
 
-@pytest.mark.parametrize("name", [n for n in BSDF_DICTS if n != "dielectric"])
+DELTA_ONLY = ("dielectric", "conductor_mirror", "conductor_gold")
+
+
+@pytest.mark.parametrize("name", [n for n in BSDF_DICTS if n not in DELTA_ONLY])
 def test_sample_eval_pdf_consistency(mi, O, H, name):
     """src/bsdfs/tests/test_twosided.py:66-93 / test_rough_conductor.py:98-117 pattern: weight * pdf == eval, pdf == pdf, no NaNs"""
     P = Pair(mi, O, H, BSDF_DICTS[name])
@@ -109,6 +118,9 @@ def test_sample_eval_pdf_consistency(mi, O, H, name):
                         s2 = [(x + 0.37) / n, (y + 0.61) / n]
                         wo, pdf, w, eta, delta = P.sample(which, wi, 0.35, s2)
                         if not (w > 0).any():
+                            continue
+                        if name in ("plastic", "plastic_nonlinear", "twosided_plastic") and delta:       # plastic's delta lobe: the mirror direction
+                            assert np.allclose(wo, [-wi[0], -wi[1], wi[2]], atol=1e-6)
                             continue
                         val, p2 = P.eval_pdf(which, wi, wo)
                         assert np.isfinite(val).all() and np.isfinite(w).all() and not delta and eta == 1.0
@@ -130,6 +142,92 @@ def test_product_host_code_matches_oracle(mi, O, H, name):
         a, b = P.sample("oracle", wi, s1, s2), P.sample("product", wi, s1, s2)
         assert np.allclose(a[0], b[0], atol=2e-6) and np.isclose(a[1], b[1], rtol=5e-5, atol=1e-7) and np.allclose(a[2], b[2], rtol=5e-5, atol=1e-7)
         assert a[3] == b[3] and a[4] == b[4]
+
+
+def _fresnel_conductor_f64(c, eta, k):
+    """unpolarised reflectance of a conductor from the complex Fresnel equations, evaluated independently in complex128"""
+    n = eta + 1j * k
+    ct = np.sqrt(1 - (1 - c * c) / (n * n))
+    rs = (c - n * ct) / (c + n * ct); rp = (n * c - ct) / (n * c + ct)
+    return 0.5 * (abs(rs) ** 2 + abs(rp) ** 2)
+
+
+def _fresnel_dielectric_f64(c, eta):
+    s2 = (1 - c * c) / (eta * eta)
+    if s2 >= 1:
+        return 1.0
+    ct = np.sqrt(1 - s2)
+    rs = (c - eta * ct) / (c + eta * ct); rp = (eta * c - ct) / (eta * c + ct)
+    return 0.5 * (rs * rs + rp * rp)
+
+
+@pytest.mark.parametrize("name", ["conductor_mirror", "conductor_gold"])
+def test_conductor_is_a_fresnel_weighted_mirror(mi, O, H, name):
+    """SmoothConductor::sample (src/bsdfs/conductor.cpp:246-304): wo = reflect(wi), pdf = 1, weight = specular_reflectance * F(cos_i), eval = pdf = 0;
+    src/bsdfs/tests/test_conductor.py:57-60 checks the same Fresnel identity (through the Mueller matrix) at 45 degrees"""
+    d = BSDF_DICTS[name]; P = Pair(mi, O, H, d)
+    eta = np.array(d.get("eta", [0, 0, 0]), np.float64); k = np.array(d.get("k", [1, 1, 1]), np.float64)
+    refl = np.array(d.get("specular_reflectance", {"value": [1, 1, 1]})["value"], np.float64)
+    for which in ("oracle", "product"):
+        for theta in (0.0, 20.0, 45.0, 70.0, 89.0):
+            t = np.radians(theta); wi = [-np.sin(t), 0.0, np.cos(t)]
+            wo, pdf, w, e, delta = P.sample(which, wi, 0.3, [0.2, 0.9])
+            assert np.allclose(wo, [np.sin(t), 0, np.cos(t)], atol=1e-6) and pdf == 1.0 and e == 1.0 and delta
+            expect = refl * np.array([_fresnel_conductor_f64(np.cos(t), eta[c], k[c]) for c in range(3)])
+            assert np.allclose(w, expect, rtol=2e-5), (which, theta, w, expect)
+            val, p = P.eval_pdf(which, wi, wo); assert (val == 0).all() and p == 0.0
+        wo, pdf, w, e, delta = P.sample(which, [0.3, 0.2, -0.9], 0.3, [0.2, 0.9])          # back side: FrontSide only
+        assert pdf == 0.0 and (w == 0).all()
+    if name == "conductor_mirror":                  # (eta, k) = (0, 1): the "100% reflecting mirror" of the plugin documentation
+        assert np.allclose(P.sample("product", [0.6, 0, 0.8], 0.5, [0.5, 0.5])[2], 1.0, atol=1e-6)
+
+
+def test_fresnel_diffuse_reflectance_fit_vs_quadrature(mi, O, H):
+    """fresnel_diffuse_reflectance (include/mitsuba/render/fresnel.h:327-355) is a polynomial fit of 2 * int_0^1 F(mu, eta) mu dmu;
+    the plastic model stores it for 1 / eta (m_fdr_int).  The oracle's value must sit within the fit's accuracy of the quadrature."""
+    mu, wq = np.polynomial.legendre.leggauss(400); mu = 0.5 * (mu + 1); wq = 0.5 * wq
+    for name, eta in (("plastic", 1.9 / 1.000277), ("plastic_nonlinear", 1.49 / 1.000277)):
+        P = Pair(mi, O, H, BSDF_DICTS[name])
+        quad = 2.0 * sum(w * _fresnel_dielectric_f64(m, 1.0 / eta) * m for m, w in zip(mu, wq))
+        a = np.empty(66, np.float32); b = np.empty(66, np.float32)
+        O.lib().orc_roughplastic_tables(P.osc.handle, P.index, O.fp(a)); H.hh_roughplastic_tables(P.h, P.index, O.fp(b))
+        assert a[64] == b[64] and a[65] == b[65]                                 # internal_reflectance, specular_sampling_weight: bit-equal
+        assert abs(a[64] - quad) < 8e-3, (name, a[64], quad)
+
+
+@pytest.mark.parametrize("name", ["plastic", "plastic_nonlinear"])
+def test_plastic_lobes_and_energy(mi, O, H, name):
+    """SmoothPlastic (src/bsdfs/plastic.cpp:208-352): lobe selection probabilities, the delta lobe's weight, the diffuse lobe against
+    eval / pdf, pdf normalisation (integrates to the diffuse selection probability) and energy conservation"""
+    d = BSDF_DICTS[name]; P = Pair(mi, O, H, d)
+    eta = float(np.float32(d.get("int_ior", 1.49)) / np.float32(1.000277))
+    spec = np.array(d.get("specular_reflectance", {"value": [1, 1, 1]})["value"], np.float64)
+    rho = np.array(d["diffuse_reflectance"]["value"], np.float64)
+    ssw = spec.mean() / (rho.mean() + spec.mean())
+    rng = np.random.default_rng(5)
+    for which in ("oracle", "product"):
+        for theta in (0.0, 40.0, 75.0, 88.0):
+            t = np.radians(theta); wi = [np.sin(t), 0.0, np.cos(t)]
+            f_i = _fresnel_dielectric_f64(np.cos(t), eta)
+            ps = f_i * ssw / (f_i * ssw + (1 - f_i) * (1 - ssw))
+            wo, pdf, w, e, delta = P.sample(which, wi, ps * 0.999, [0.3, 0.3])              # just below the threshold: specular
+            assert delta and np.isclose(pdf, ps, rtol=1e-4) and np.allclose(wo, [-wi[0], 0, wi[2]], atol=1e-6) and e == 1.0
+            assert np.allclose(w, spec * f_i / ps, rtol=1e-4)
+            wo, pdf, w, e, delta = P.sample(which, wi, min(ps * 1.001 + 1e-6, 0.99999), [0.3, 0.3])   # just above: diffuse
+            assert not delta and wo[2] > 0 and e == 1.0
+            val, p2 = P.eval_pdf(which, wi, wo)
+            assert np.isclose(pdf, p2, rtol=1e-4) and np.allclose(w * pdf, val, rtol=1e-4, atol=1e-7)
+            # pdf integrates to the probability of the diffuse lobe; albedo = E[weight] <= 1
+            n = 4000; acc_pdf = 0.0; acc_w = np.zeros(3)
+            for _ in range(n):
+                u = rng.random(3)
+                wo_u = _sphere(u[0] * 0.5, u[1])                                           # uniform on the upper hemisphere, pdf 1 / (2 pi)
+                acc_pdf += P.eval_pdf(which, wi, wo_u)[1] * 2 * np.pi
+                acc_w += P.sample(which, wi, float(u[2]), rng.random(2))[2]
+            assert abs(acc_pdf / n - (1 - ps)) < 0.03, (which, theta, acc_pdf / n, 1 - ps)
+            assert (acc_w / n <= 1.0 + 1e-3).all(), (which, theta, acc_w / n)
+        assert P.sample(which, [0.1, 0.2, -0.9], 0.5, [0.5, 0.5])[1] == 0.0                  # FrontSide only
+        assert P.eval_pdf(which, [0.1, 0.2, 0.9], [0.1, 0.2, -0.9])[1] == 0.0
 
 
 def test_roughplastic_tables(mi, O, H):
@@ -154,11 +252,23 @@ def _material_cbox(mi, res):
     return d
 
 
-@pytest.mark.parametrize("mode,md", [(0, 8), (1, 6)])
-def test_material_scene_host_pipeline_matches_oracle(mi, O, mode, md):
+def _smooth_material_cbox(mi, res):
+    """the smooth counterparts: plastic walls, a gold `conductor` wall, a mirror box"""
+    d = mi.cornell_box()
+    d["sensor"]["film"]["width"] = res; d["sensor"]["film"]["height"] = res
+    d["white"] = dict(BSDF_DICTS["plastic"], diffuse_reflectance={"type": "rgb", "value": [0.7, 0.7, 0.65]})
+    d["green"] = {"type": "twosided", "m": dict(BSDF_DICTS["conductor_gold"])}
+    d["red"] = dict(BSDF_DICTS["plastic_nonlinear"])
+    d["mirror"] = dict(BSDF_DICTS["conductor_mirror"])
+    d["large-box"]["bsdf"] = {"type": "ref", "id": "mirror"}
+    return d
+
+
+@pytest.mark.parametrize("mode,md,which", [(0, 8, "rough"), (1, 6, "rough"), (0, 8, "smooth"), (1, 6, "smooth")])
+def test_material_scene_host_pipeline_matches_oracle(mi, O, mode, md, which):
     """path and prb primal on a Cornell box with every BSDF type (incl. transmission through the glass box)"""
     from tests.test_cpu_host import oracle_scene_from, rel_l2
-    scene = mi.load_dict(_material_cbox(mi, 32))
+    scene = mi.load_dict((_material_cbox if which == "rough" else _smooth_material_cbox)(mi, 32))
     osc, sensor = oracle_scene_from(O, scene)
     L = C.CDLL(os.path.join(ROOT, "tests", "host_harness", "libhost_harness.so")); L.hh_scene_create.restype = C.c_void_p
     L.hh_render.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_uint32, C.c_uint32, C.c_int32, C.c_int32, C.c_uint64, C.c_uint64, O.c_f32p]
@@ -167,6 +277,32 @@ def test_material_scene_host_pipeline_matches_oracle(mi, O, mode, md):
     assert L.hh_render(h, C.byref(sensor), mode, 3, 8, md, 5, 0, 0, O.fp(film)) == 0
     ref, st = (osc.render_path if mode == 0 else osc.render_prb)(sensor, seed=3, spp=8, max_depth=md, raw=True, threads=2)
     assert np.isfinite(film).all() and rel_l2(O.develop(film), O.develop(ref)) < 1e-4
+
+
+def test_oracle_prb_gradients_vs_finite_differences_plastic(mi, O):
+    """slot-0 (diffuse_reflectance) of `plastic`, linear and nonlinear.  With a specular lobe PRB is NOT the derivative of the estimator:
+    prb.py:288-297 takes relative_grad(bsdf.eval(si, wo)) at the sampled wo whatever lobe produced it, and SmoothPlastic::eval returns the
+    diffuse term at the mirror direction too (measured here: +14% on the white walls).  specular_reflectance = 0 never selects that lobe
+    (specular_sampling_weight = 0), which isolates the diffuse derivative, the part that has an exact answer."""
+    from tests.test_cpu_host import oracle_scene_from
+    d = _smooth_material_cbox(mi, 12)
+    for k in ("white", "red"):
+        d[k]["specular_reflectance"] = {"type": "rgb", "value": [0.0, 0.0, 0.0]}
+    scene = mi.load_dict(d)
+    osc, sensor = oracle_scene_from(O, scene)
+    seed, spp, md = 5, 2048, 4
+    grad_in = np.ones((12, 12, 3), np.float32)
+    g_refl, _, _ = osc.render_prb_backward(sensor, grad_in, seed=seed, spp=spp, max_depth=md)
+    names = [b.id for b in scene.bsdf_objs]
+    for key, chan in (("white", 0), ("red", 1)):
+        bsdf = names.index(key); base = scene.bsdf_objs[bsdf].value
+        eps = 2e-2; sums = []
+        for sgn in (+1, -1):
+            v = np.array(base, np.float32); v[chan] += sgn * eps; osc.set_reflectance(bsdf, v)
+            img, _ = osc.render_prb(sensor, seed=seed, spp=spp, max_depth=md); sums.append(img.astype(np.float64).sum())
+        osc.set_reflectance(bsdf, np.array(base, np.float32))
+        fd = (sums[0] - sums[1]) / (2 * eps)
+        assert abs(fd - g_refl[bsdf, chan]) / abs(fd) < 1.5e-2, (key, fd, g_refl[bsdf, chan])
 
 
 def test_oracle_prb_gradients_vs_finite_differences_materials(mi, O):

@@ -22,7 +22,7 @@ def oracle_scene_from(O, scene):
         sd.add_mesh(m["V"], m["F"], m["bsdf"], m["emitter"], m["flags"])
     sd.top_mesh_count = scene.top_mesh_count
     sd.groups = list(scene.groups); sd.instances = list(scene.instances)
-    types = {"diffuse": 0, "dielectric": 1, "roughconductor": 2, "roughplastic": 3}
+    types = {"diffuse": 0, "dielectric": 1, "roughconductor": 2, "roughplastic": 3, "conductor": 4, "plastic": 5}
     sd.bsdfs = [(types[b.kind], b.tex_index if b.texture is not None else -1, b.value,
                  dict(flags=b.flags, reflectance2=b.value2, alpha_u=b.alpha_u, alpha_v=b.alpha_v, eta=b.eta, eta_c=b.eta_c, k_c=b.k_c,
                       back=b.back.index if b.back is not None else -1)) for b in scene.bsdf_objs]

@@ -363,10 +363,10 @@ def test_multipass_render_parity(mi, O):
 
 # ---------------------------------------------------------------- BSDF plugins beyond diffuse
 
-def _material_scene(mi, O, res, integrator=None):
-    from tests.test_bsdfs_cpu import _material_cbox
+def _material_scene(mi, O, res, integrator=None, smooth=False):
+    from tests.test_bsdfs_cpu import _material_cbox, _smooth_material_cbox
     from tests.test_cpu_host import oracle_scene_from
-    d = _material_cbox(mi, res)
+    d = (_smooth_material_cbox if smooth else _material_cbox)(mi, res)
     if integrator:
         d["integrator"] = integrator
     scene = mi.load_dict(d)
@@ -402,6 +402,28 @@ def test_material_scene_prb_gradients(mi, O):
     assert glass and not grads[[k for k, (_, b) in keys.items() if b is glass[0]][0]].any()
 
 
+def test_smooth_material_scene_parity_and_gradients(mi, O):
+    """Cornell box with `plastic` walls (linear and nonlinear), a twosided gold `conductor` wall and a mirror box: `path`, `prb` primal and the
+    PRB adjoint (plastic.diffuse_reflectance; the conductors only have a delta lobe, hence no gradient) vs the oracle"""
+    scene, osc, sensor = _material_scene(mi, O, 48, smooth=True)
+    img = mi.render(scene, spp=16, seed=2).cpu().numpy()
+    ref, _ = osc.render_path(sensor, seed=2, spp=16, max_depth=8)
+    assert np.isfinite(img).all() and rel_l2(img, ref) < 1e-4
+    integ = mi.load_dict({"type": "prb", "max_depth": 6})
+    img = mi.render(scene, integrator=integ, spp=16, seed=2).cpu().numpy()
+    ref, _ = osc.render_prb(sensor, seed=2, spp=16, max_depth=6)
+    assert rel_l2(img, ref) < 1e-4
+    grad_in = np.random.default_rng(1).uniform(0.5, 1.5, (48, 48, 3)).astype(np.float32)
+    grads = integ.render_backward(scene, None, grad_in, seed=9, spp=16)
+    g_refl, _, _ = osc.render_prb_backward(sensor, grad_in, seed=9, spp=16, max_depth=6)
+    keys = {k: v for k, v in scene._param_keys().items() if v[0] != "emit"}
+    got = np.stack([grads[k].cpu().numpy() for k in keys]); want = np.stack([g_refl[b.index] for (_, b) in keys.values()])
+    assert np.abs(want).max() > 0 and rel_l2(got, want) < 1e-3
+    for k, (_, b) in keys.items():
+        if b.kind == "conductor":
+            assert not grads[k].any()
+
+
 def test_bsdf_plugins_device_vs_oracle(mi, O):
     """array-valued BSDF::eval_pdf / sample of every plugin on the GPU vs the oracle (same inputs)"""
     import ctypes as C
@@ -411,7 +433,7 @@ def test_bsdf_plugins_device_vs_oracle(mi, O):
     wi = np.stack([r[0] * np.cos(ph[0]), r[0] * np.sin(ph[0]), z[0]]).astype(np.float32)
     wo = np.stack([r[1] * np.cos(ph[1]), r[1] * np.sin(ph[1]), z[1]]).astype(np.float32)
     s1 = rng.random(n).astype(np.float32); s2 = rng.random((2, n)).astype(np.float32)
-    types = {"diffuse": 0, "dielectric": 1, "roughconductor": 2, "roughplastic": 3}
+    types = {"diffuse": 0, "dielectric": 1, "roughconductor": 2, "roughplastic": 3, "conductor": 4, "plastic": 5}
     for name, d in BSDF_DICTS.items():
         bsdf = mi.load_dict(d)
         si = type("SI", (), dict(wi=wi, uv=None))()
