@@ -9,6 +9,7 @@
 #include "orc_math.h"
 #include "orc_bsdf.h"
 #include "orc_envmap.h"
+#include "orc_dual.h"
 
 #include <algorithm>
 #include <atomic>
@@ -693,7 +694,90 @@ static V3 path_sample(const Scene &sc, Pcg32 &rng, Ray ray, uint32_t max_depth, 
 //  hand-derived gradients of SURVEY.md Appendix B into `grad`.
 // ---------------------------------------------------------------------------
 
-struct GradSink { float *refl; float *const *tex; float *emit; /* 3 per emitter (radiance of `area` / `constant`), may be null */ };
+// ---------------------------------------------------------------------------
+//  Geometry-attached part of PRBIntegrator.sample (prb.py:124-141, 176-216, 261-297) for `diffuse` BSDFs:
+//  derivatives w.r.t. the vertex positions of flat-shaded top-level meshes, by forward-mode duals (orc_dual.h).
+//  Slots 0..8 = coordinates of the three vertices of the triangle hit at the current vertex (the next interaction is detached).
+// ---------------------------------------------------------------------------
+
+constexpr int kShapeSlots = 9;
+typedef Dual<kShapeSlots> Dn;
+typedef Dual3<kShapeSlots> Dn3;
+static inline Dn3 dn3(V3 v) { return Dn3((double) v.x, (double) v.y, (double) v.z); }
+
+struct AttachedSI { Dn3 p, n, sn; Dn uv[2]; bool diff = false; uint32_t mesh = 0, vid[3] = { 0, 0, 0 }; };
+
+/* Mesh::compute_surface_interaction with AD-attached vertex positions (src/render/mesh.cpp:2286-2323) and
+ * SurfaceInteraction::attach_motion without FollowShape (include/mitsuba/render/interaction.h:525-545): the point stays on the
+ * (detached) ray and follows the moving tangent plane; the barycentric coordinates pick up the motion of that point relative to
+ * the triangle.  `shading` = false is RayFlags::Minimal (p, t, n only). */
+static AttachedSI attach_si(const Scene &sc, const Ray &ray, const PI &pi, const SI &si, const uint8_t *mask, int slot, bool shading) {
+    AttachedSI a; a.p = dn3(si.p); a.n = dn3(si.n); a.sn = dn3(si.sn); a.uv[0] = Dn((double) si.uv[0]); a.uv[1] = Dn((double) si.uv[1]);
+    if (!pi.valid() || pi.inst != 0xffffffffu || !mask || !mask[pi.shape]) return a;
+    const Mesh &m = sc.meshes[pi.shape];
+    const uint32_t *f = &m.F[4 * (size_t) pi.prim];
+    a.diff = true; a.mesh = pi.shape; a.vid[0] = f[0]; a.vid[1] = f[1]; a.vid[2] = f[2];
+    Dn3 P[3];
+    for (int k = 0; k < 3; ++k) {
+        const float *r = &m.V[8 * (size_t) f[k]];
+        P[k] = Dn3(Dn::param(r[0], slot + 3 * k), Dn::param(r[1], slot + 3 * k + 1), Dn::param(r[2], slot + 3 * k + 2));
+    }
+    double b1 = pi.u, b2 = pi.v, b0 = 1.0 - b1 - b2;
+    Dn3 e1 = P[1] - P[0], e2 = P[2] - P[0];
+    Dn3 p_att = P[0] * b0 + P[1] * b1 + P[2] * b2;
+    Dn3 n_geo = dnormalize(dcross(e1, e2));                       // face_normal
+    Dn3 nd = dn3(si.n);                                           // dr::detach(n)
+    Dn3 o = dn3(ray.o), d = dn3(ray.d);
+    Dn t_att = ddot(p_att - o, nd) / ddot(nd, d);
+    Dn3 p_ray = o + d * t_att;                                    // ray(t)
+    a.p = replace_grad3(si.p.x, si.p.y, si.p.z, p_ray);
+    a.n = replace_grad3(si.n.x, si.n.y, si.n.z, n_geo);
+    if (!shading) return a;
+    // mesh.cpp:2308-2321: rel = si.p - p_att has a zero value, only its derivative matters
+    Dn3 rel = replace_grad3(0.0, 0.0, 0.0, p_ray - p_att);
+    Dn a11 = ddot(e1, e1), a12 = ddot(e1, e2), a22 = ddot(e2, e2), inv_det = Dn(1.0) / (a11 * a22 - a12 * a12);
+    Dn r1 = ddot(e1, rel), r2 = ddot(e2, rel);
+    Dn b1d = replace_grad(b1, Dn(b1) + (a22 * r1 - a12 * r2) * inv_det);
+    Dn b2d = replace_grad(b2, Dn(b2) + (a11 * r2 - a12 * r1) * inv_det);
+    a.sn = a.n;                                                   // meshes without vertex normals: sh_frame.n = n (mesh.cpp:2367-2369)
+    if (m.flags & 2u) {
+        const float *r0 = &m.V[8 * (size_t) f[0]], *r1v = &m.V[8 * (size_t) f[1]], *r2v = &m.V[8 * (size_t) f[2]];
+        double u0 = r0[6], v0 = r0[7], du0 = r1v[6] - u0, dv0 = r1v[7] - v0, du1 = r2v[6] - u0, dv1 = r2v[7] - v0;
+        a.uv[0] = replace_grad((double) si.uv[0], b1d * du0 + b2d * du1 + Dn(u0));
+        a.uv[1] = replace_grad((double) si.uv[1], b1d * dv0 + b2d * dv1 + Dn(v0));
+    } else { a.uv[0] = b1d; a.uv[1] = b2d; }
+    return a;
+}
+
+/* bilinear, repeat-wrapped texture lookup (tex_lookup / tex_eval above) as a function of attached texture coordinates */
+static inline Dn3 tex_eval_dual(const Texture &t, const TexLookup &l, const Dn uv[2]) {
+    Dn px = uv[0] * (double) t.w - Dn(0.5), py = uv[1] * (double) t.h - Dn(0.5);
+    Dn w1x = replace_grad((double) l.w[1], px), w1y = replace_grad((double) l.w[3], py), w0x = Dn(1.0) - w1x, w0y = Dn(1.0) - w1y;
+    Dn out[3];
+    for (int c = 0; c < 3; ++c) {
+        double v00 = t.data[3 * (size_t) l.idx[0] + c], v10 = t.data[3 * (size_t) l.idx[1] + c],
+               v01 = t.data[3 * (size_t) l.idx[2] + c], v11 = t.data[3 * (size_t) l.idx[3] + c];
+        out[c] = w0y * (w0x * v00 + w1x * v10) + w1y * (w0x * v01 + w1x * v11);
+    }
+    return Dn3(out[0], out[1], out[2]);
+}
+
+/* solid_angle_to_area_jacobian (ad/integrators/common.py:1355-1384) and the direction it is evaluated along */
+static inline void dir_and_jacobian(const Dn3 &o, const Dn3 &p, const Dn3 &n, Dn3 &dir, Dn &J) {
+    Dn3 d = p - o; Dn d2 = ddot(d, d);
+    dir = dnormalize(d);
+    J = dabs(ddot(n, dir)) / d2;
+}
+
+struct ShapeSink { double *const *pos; const uint8_t *mask; };
+static inline void shape_scatter(const ShapeSink &sk, const AttachedSI &a, int slot, const double g[kShapeSlots]) {
+    if (!a.diff) return;
+    double *dst = sk.pos[a.mesh];
+    for (int k = 0; k < 3; ++k) for (int c = 0; c < 3; ++c) dst[3 * (size_t) a.vid[k] + c] += g[slot + 3 * k + c];
+}
+
+struct GradSink { float *refl; float *const *tex; float *emit; /* 3 per emitter (radiance of `area` / `constant`), may be null */
+                  const ShapeSink *shape = nullptr; /* vertex-position gradients of the meshes in its mask, may be null */ };
 
 static V3 prb_sample(const Scene &sc, Pcg32 &rng, Ray ray, uint32_t max_depth, uint32_t rr_depth, bool primal,
                      V3 L_in, V3 dL, const GradSink *grad, bool &valid, OrcStats &st) {
@@ -734,10 +818,11 @@ static V3 prb_sample(const Scene &sc, Pcg32 &rng, Ray ray, uint32_t max_depth, u
         if (active_em) { sample_emitter_direction(sc, si, ex, ey, ds, em_weight, st, nullptr, &em_unit); active_em &= ds.pdf != 0.f; }
         // prb.py:210-216
         V3 Lr_dir(0.f), dLr_dir_drho(0.f);
+        float mis_em = 0.f; V3 wo_em(0.f); const V3 beta_cur = beta;
         if (active_em) {
-            V3 wo = si.to_local(ds.d);
+            V3 wo = si.to_local(ds.d); wo_em = wo;
             BSDFEval ev = bsdf_eval_pdf(bsdf, wo);
-            float mis_em = mis_weight(ds.pdf, ev.pdf);
+            mis_em = mis_weight(ds.pdf, ev.pdf);
             Lr_dir = ((beta * mis_em) * ev.value) * em_weight;
             dLr_dir_drho = ((beta * mis_em) * ev.d_slot0) * em_weight;           // d/d slot0 of the line above
             if (!primal && grad && grad->emit && sc.emitters[ds.emitter].type != 2) {   // em_weight = radiance * em_unit (prb.py:198-206, attached eval_emitter_direction)
@@ -781,6 +866,54 @@ static V3 prb_sample(const Scene &sc, Pcg32 &rng, Ray ray, uint32_t max_depth, u
                 const float wts[4] = { tl.w[0] * tl.w[2], tl.w[1] * tl.w[2], tl.w[0] * tl.w[3], tl.w[1] * tl.w[3] };
                 for (int k = 0; k < 4; ++k) { float *q = dst + 3 * (size_t) tl.idx[k]; q[0] += g.x * wts[k]; q[1] += g.y * wts[k]; q[2] += g.z * wts[k]; }
             }
+        }
+        if (!primal && grad && grad->shape && si.valid() && bsdf.rec) {
+            /* prb.py:124-141 (attached si), :176-216 (emitter sampling with the attached shading point), :261-297 (attached wo, J):
+               d/d(vertex positions) of  Lr_dir + Lr_ind  for a `diffuse` BSDF, f * cos = rho(uv) / pi * cos_theta_o */
+            const ShapeSink &sk = *grad->shape;
+            AttachedSI a = attach_si(sc, ray, pi, si, sk.mask, 0, true);
+            Dn3 rho = bsdf.textured ? tex_eval_dual(sc.textures[bsdf.rec->p.texture], bsdf.tl, a.uv) : dn3(bsdf.slot0);
+            double g[kShapeSlots]; for (int k = 0; k < kShapeSlots; ++k) g[k] = 0.0;
+            const double dl[3] = { dL.x, dL.y, dL.z };
+            auto value_cos = [&](const Dn3 &wo_world, bool lit, Dn out[3]) {       // SmoothDiffuse::eval with wo = si.to_local(wo_world)
+                Dn cos_o = ddot(wo_world, a.sn);                                   // Frame3f::cos_theta(to_local(v)) = dot(v, n)
+                const Dn *r[3] = { &rho.x, &rho.y, &rho.z };
+                for (int c = 0; c < 3; ++c) out[c] = lit ? (*r[c]) * (double) InvPi * cos_o : Dn(0.0);
+            };
+            if (active_em && a.diff) {                                             // otherwise every input of Lr_dir is detached
+                const uint32_t et = sc.emitters[ds.emitter].type;
+                const bool is_surface = et == 0 || et == 3;
+                Dn3 dsd = dn3(ds.d); Dn J(1.0);
+                if (is_surface) {                                                  // prb.py:189-201: ds.d = normalize(ds.p - si.p), J(si.p, detach(ds.p), detach(ds.n))
+                    Dn3 dir; dir_and_jacobian(a.p, dn3(ds.p), dn3(ds.n), dir, J);
+                    dsd = replace_grad3(ds.d.x, ds.d.y, ds.d.z, dir);
+                }
+                Dn f[3]; value_cos(dsd, si.wi.z > 0.f && wo_em.z > 0.f, f);
+                const double w[3] = { (double) beta_cur.x * mis_em * em_weight.x, (double) beta_cur.y * mis_em * em_weight.y, (double) beta_cur.z * mis_em * em_weight.z };
+                for (int c = 0; c < 3; ++c) {
+                    if (w[c] == 0.0 || J.v == 0.0) continue;
+                    for (int k = 0; k < kShapeSlots; ++k) g[k] += dl[c] * w[c] * (f[c].d[k] + f[c].v * J.d[k] / J.v);      // em_weight *= relative_grad(J)
+                }
+            }
+            if (active_next && a.diff) {                                           // prb.py:261-297
+                /* si_next is computed OUTSIDE dr.resume_grad() (prb.py:263-266): its position and normal are detached, only the current
+                   point moves in wo and in the Jacobian */
+                SI si_next = compute_si(sc, ray_next, pi_next);
+                Dn3 wo_world = dn3(ray_next.d); Dn J(1.0);
+                if (pi_next.valid()) {
+                    Dn3 dir; dir_and_jacobian(a.p, dn3(si_next.p), dn3(si_next.n), dir, J);
+                    wo_world = replace_grad3(ray_next.d.x, ray_next.d.y, ray_next.d.z, dir);
+                }
+                V3 wo_l = si.to_local(ray_next.d);
+                Dn f[3]; value_cos(wo_world, si.wi.z > 0.f && wo_l.z > 0.f, f);
+                const double Lc[3] = { L.x, L.y, L.z };
+                for (int c = 0; c < 3; ++c) {
+                    if (Lc[c] == 0.0) continue;
+                    for (int k = 0; k < kShapeSlots; ++k)
+                        g[k] += dl[c] * Lc[c] * ((f[c].v != 0.0 ? f[c].d[k] / f[c].v : 0.0) + (J.v != 0.0 ? J.d[k] / J.v : 0.0));
+                }
+            }
+            shape_scatter(sk, a, 0, g);
         }
         if (si.valid()) depth += 1;                               // prb.py:326
         active = active_next; pi = pi_next; ray = ray_next;
@@ -1005,6 +1138,30 @@ static int render_scalar(Scene &sc, const OrcSensor &s, uint32_t seed, uint32_t 
     return 0;
 }
 
+/* bounding sphere of the scene for the environment emitters; recomputed when vertex positions change */
+static void scene_update_bounds(Scene &sc) {
+    if (sc.env >= 0) {                                 // ConstantBackgroundEmitter::set_scene (constant.cpp:72-87)
+        float lo[3] = { Infinity, Infinity, Infinity }, hi[3] = { -Infinity, -Infinity, -Infinity };
+        for (uint32_t m = 0; m < sc.top_count; ++m)
+            for (uint32_t v = 0; v < sc.meshes[m].nv; ++v) for (int a = 0; a < 3; ++a) { float q = sc.meshes[m].V[8 * (size_t) v + a]; lo[a] = std::min(lo[a], q); hi[a] = std::max(hi[a], q); }
+        for (uint32_t i = 0; i < sc.instances.size(); ++i) {
+            const OrcShapeGroup &g = sc.groups[sc.instances[i].group];
+            float glo[3] = { Infinity, Infinity, Infinity }, ghi[3] = { -Infinity, -Infinity, -Infinity };
+            for (uint32_t m = g.first_mesh; m < g.first_mesh + g.mesh_count; ++m)
+                for (uint32_t v = 0; v < sc.meshes[m].nv; ++v) for (int a = 0; a < 3; ++a) { float q = sc.meshes[m].V[8 * (size_t) v + a]; glo[a] = std::min(glo[a], q); ghi[a] = std::max(ghi[a], q); }
+            if (!(glo[0] <= ghi[0])) continue;
+            for (int c = 0; c < 8; ++c) { V3 q = xf_point(sc.instances[i].to_world, V3(c & 1 ? ghi[0] : glo[0], c & 2 ? ghi[1] : glo[1], c & 4 ? ghi[2] : glo[2])); for (int a = 0; a < 3; ++a) { lo[a] = std::min(lo[a], q[a]); hi[a] = std::max(hi[a], q[a]); } }
+        }
+        if (lo[0] <= hi[0]) {
+            V3 c((hi[0] + lo[0]) * .5f, (hi[1] + lo[1]) * .5f, (hi[2] + lo[2]) * .5f);
+            sc.env_center[0] = c.x; sc.env_center[1] = c.y; sc.env_center[2] = c.z;
+            sc.env_radius = std::max(RayEpsilon, norm(c - V3(hi[0], hi[1], hi[2])) * (1.f + RayEpsilon));
+        } else sc.env_radius = RayEpsilon;
+        for (int a = 0; a < 3; ++a) sc.envmap.center[a] = sc.env_center[a];          // EnvironmentMapEmitter::set_scene (envmap.cpp:214-226), same rule
+        sc.envmap.radius = sc.env_radius;
+    }
+}
+
 } // namespace
 
 // ===========================================================================
@@ -1090,26 +1247,7 @@ void *orc_scene_create(const OrcSceneDesc *d) {
         build_rec(sc->inst_nodes, prims, 0, (uint32_t) prims.size(), 0, 2);
         for (auto &p : prims) sc->inst_order.push_back(p.id);
     }
-    if (sc->env >= 0) {                                 // ConstantBackgroundEmitter::set_scene (constant.cpp:72-87)
-        float lo[3] = { Infinity, Infinity, Infinity }, hi[3] = { -Infinity, -Infinity, -Infinity };
-        for (uint32_t m = 0; m < sc->top_count; ++m)
-            for (uint32_t v = 0; v < sc->meshes[m].nv; ++v) for (int a = 0; a < 3; ++a) { float q = sc->meshes[m].V[8 * (size_t) v + a]; lo[a] = std::min(lo[a], q); hi[a] = std::max(hi[a], q); }
-        for (uint32_t i = 0; i < sc->instances.size(); ++i) {
-            const OrcShapeGroup &g = sc->groups[sc->instances[i].group];
-            float glo[3] = { Infinity, Infinity, Infinity }, ghi[3] = { -Infinity, -Infinity, -Infinity };
-            for (uint32_t m = g.first_mesh; m < g.first_mesh + g.mesh_count; ++m)
-                for (uint32_t v = 0; v < sc->meshes[m].nv; ++v) for (int a = 0; a < 3; ++a) { float q = sc->meshes[m].V[8 * (size_t) v + a]; glo[a] = std::min(glo[a], q); ghi[a] = std::max(ghi[a], q); }
-            if (!(glo[0] <= ghi[0])) continue;
-            for (int c = 0; c < 8; ++c) { V3 q = xf_point(sc->instances[i].to_world, V3(c & 1 ? ghi[0] : glo[0], c & 2 ? ghi[1] : glo[1], c & 4 ? ghi[2] : glo[2])); for (int a = 0; a < 3; ++a) { lo[a] = std::min(lo[a], q[a]); hi[a] = std::max(hi[a], q[a]); } }
-        }
-        if (lo[0] <= hi[0]) {
-            V3 c((hi[0] + lo[0]) * .5f, (hi[1] + lo[1]) * .5f, (hi[2] + lo[2]) * .5f);
-            sc->env_center[0] = c.x; sc->env_center[1] = c.y; sc->env_center[2] = c.z;
-            sc->env_radius = std::max(RayEpsilon, norm(c - V3(hi[0], hi[1], hi[2])) * (1.f + RayEpsilon));
-        } else sc->env_radius = RayEpsilon;
-        for (int a = 0; a < 3; ++a) sc->envmap.center[a] = sc->env_center[a];          // EnvironmentMapEmitter::set_scene (envmap.cpp:214-226), same rule
-        sc->envmap.radius = sc->env_radius;
-    }
+    scene_update_bounds(*sc);
     return sc;
 }
 void orc_scene_destroy(void *s) { delete (Scene *) s; }
@@ -1166,10 +1304,14 @@ void orc_scene_set_emitter_radiance(void *scene, uint32_t emitter, const float r
     Scene &sc = *(Scene *) scene;
     if (emitter < sc.emitters.size()) for (int c = 0; c < 3; ++c) sc.emitters[emitter].radiance[c] = rgb[c];
 }
-int orc_render_prb_backward_ex(void *scene, const OrcSensor *sp, const float *grad_in, uint32_t seed, uint32_t spp,
-                               int32_t max_depth, int32_t rr_depth, float *grad_reflectance, float *const *grad_textures,
-                               float *grad_emitters, OrcStats *stats, int threads) {
+static int prb_backward_impl(void *scene, const OrcSensor *sp, const float *grad_in, uint32_t seed, uint32_t spp,
+                             int32_t max_depth, int32_t rr_depth, float *grad_reflectance, float *const *grad_textures,
+                             float *grad_emitters, const uint8_t *pos_mask, double *const *grad_positions, OrcStats *stats, int threads) {
     Scene &sc = *(Scene *) scene; const OrcSensor &s = *sp;
+    if (pos_mask) {           /* the attached-geometry restatement covers `diffuse` BSDFs on flat-shaded top-level meshes */
+        for (const BsdfRecord &b : sc.bsdfs) if (b.p.type != 0 || (b.p.flags & 1u)) return -2;
+        for (size_t m = 0; m < sc.meshes.size(); ++m) if (pos_mask[m] && ((sc.meshes[m].flags & 1u) || m >= sc.top_count)) return -3;
+    }
     uint64_t total = (uint64_t) s.crop_width * s.crop_height * spp;
     if (total > 0xffffffffull) return -1;
     RFilter rf = make_rfilter(s.rfilter, s.rfilter_stddev);
@@ -1197,6 +1339,7 @@ int orc_render_prb_backward_ex(void *scene, const OrcSensor *sp, const float *gr
     size_t nb = sc.bsdfs.size();
     std::vector<std::vector<float>> g_refl(threads), g_emit(threads);
     std::vector<std::vector<std::vector<float>>> g_tex(threads);
+    std::vector<std::vector<std::vector<double>>> g_pos(threads);
     std::vector<OrcStats> sts(threads, OrcStats{});
     uint32_t md = (uint32_t) max_depth, rd = (uint32_t) rr_depth;
     parallel_lanes(0, total, threads, [&](int t, uint64_t b, uint64_t e) {
@@ -1208,6 +1351,12 @@ int orc_render_prb_backward_ex(void *scene, const OrcSensor *sp, const float *gr
         std::vector<float *> tp(sc.textures.size() + 1, nullptr);
         for (size_t k = 0; k < sc.textures.size(); ++k) tp[k] = g_tex[t][k].data();
         GradSink sink{ g_refl[t].data(), tp.data(), grad_emitters ? g_emit[t].data() : nullptr };
+        std::vector<double *> pp(sc.meshes.size() + 1, nullptr); ShapeSink shape{ pp.data(), pos_mask };
+        if (pos_mask) {
+            if (g_pos[t].empty()) { g_pos[t].resize(sc.meshes.size()); for (size_t m = 0; m < sc.meshes.size(); ++m) if (pos_mask[m]) g_pos[t][m].assign(3 * (size_t) sc.meshes[m].nv, 0.0); }
+            for (size_t m = 0; m < sc.meshes.size(); ++m) pp[m] = pos_mask[m] ? g_pos[t][m].data() : nullptr;
+            sink.shape = &shape;
+        }
         for (uint64_t i = b; i < e; ++i) {
             Lane L = make_lane(s, seed, spp, i);
             // dL = adjoint of the splat (gather over the filter footprint)
@@ -1248,9 +1397,31 @@ int orc_render_prb_backward_ex(void *scene, const OrcSensor *sp, const float *gr
         if (grad_emitters) for (size_t i = 0; i < 3 * sc.emitters.size(); ++i) grad_emitters[i] += g_emit[t][i];
         for (size_t k = 0; k < sc.textures.size(); ++k)
             if (grad_textures && grad_textures[k]) { float *dst = grad_textures[k]; for (size_t i = 0; i < g_tex[t][k].size(); ++i) dst[i] += g_tex[t][k][i]; }
+        if (pos_mask && !g_pos[t].empty())
+            for (size_t m = 0; m < sc.meshes.size(); ++m) if (pos_mask[m] && grad_positions[m]) for (size_t i = 0; i < g_pos[t][m].size(); ++i) grad_positions[m][i] += g_pos[t][m][i];
     }
     merge_stats(stats, sts);
     return 0;
+}
+int orc_render_prb_backward_ex(void *scene, const OrcSensor *sp, const float *grad_in, uint32_t seed, uint32_t spp,
+                               int32_t max_depth, int32_t rr_depth, float *grad_reflectance, float *const *grad_textures,
+                               float *grad_emitters, OrcStats *stats, int threads) {
+    return prb_backward_impl(scene, sp, grad_in, seed, spp, max_depth, rr_depth, grad_reflectance, grad_textures, grad_emitters, nullptr, nullptr, stats, threads);
+}
+/* + d/d(vertex positions) of the meshes with pos_mask[m] != 0: grad_positions[m] = 3 doubles per vertex (accumulated into).
+ * Returns -2 when the scene holds a BSDF other than plain `diffuse`, -3 for a mesh with vertex normals / inside a shape group. */
+int orc_render_prb_backward_shape(void *scene, const OrcSensor *sp, const float *grad_in, uint32_t seed, uint32_t spp,
+                                  int32_t max_depth, int32_t rr_depth, float *grad_reflectance, float *const *grad_textures,
+                                  const uint8_t *pos_mask, double *const *grad_positions, OrcStats *stats, int threads) {
+    return prb_backward_impl(scene, sp, grad_in, seed, spp, max_depth, rr_depth, grad_reflectance, grad_textures, nullptr, pos_mask, grad_positions, stats, threads);
+}
+void orc_scene_set_vertex_positions(void *scene, uint32_t mesh, const float *positions) {       /* + rebuild of the acceleration structure */
+    Scene &sc = *(Scene *) scene;
+    if (mesh >= sc.top_count) return;
+    Mesh &m = sc.meshes[mesh];
+    for (uint32_t i = 0; i < m.nv; ++i) for (int c = 0; c < 3; ++c) m.V[8 * (size_t) i + c] = positions[3 * (size_t) i + c];
+    build_tri_bvh(sc.top, sc.meshes, 0, sc.top_count);
+    scene_update_bounds(sc);
 }
 
 void orc_film_develop(const float *film, uint32_t width, uint32_t height, float *image) {

@@ -195,6 +195,16 @@ int orc_render_prb_backward_ex(void *scene, const OrcSensor *s, const float *gra
                                int32_t rr_depth, float *grad_reflectance, float *const *grad_textures, float *grad_emitters,
                                OrcStats *stats, int threads);
 void orc_scene_set_emitter_radiance(void *scene, uint32_t emitter, const float rgb[3]);
+/* ... plus the gradient w.r.t. the VERTEX POSITIONS of the meshes with pos_mask[m] != 0 (prb.py:124-141 attached surface interaction,
+ * :176-216 emitter sampling from the attached point, :261-297 attached wo and solid-angle-to-area Jacobian): grad_positions[m] holds 3
+ * doubles per vertex and is added to.  Restated over forward-mode dual numbers (orc_dual.h) for plain `diffuse` BSDFs and flat-shaded
+ * top-level meshes; returns -2 / -3 outside that domain.  PARITY UNPINNED: the reference's own shape-gradient tests
+ * (src/python/python/tests/test_ad_integrators.py) need Dr.Jit and are not runnable here. */
+int orc_render_prb_backward_shape(void *scene, const OrcSensor *s, const float *grad_in, uint32_t seed, uint32_t spp, int32_t max_depth,
+                                  int32_t rr_depth, float *grad_reflectance, float *const *grad_textures, const uint8_t *pos_mask,
+                                  double *const *grad_positions, OrcStats *stats, int threads);
+/* params['mesh.vertex_positions'] = ...; params.update(): new positions (3 floats per vertex) of a top-level mesh + acceleration rebuild */
+void orc_scene_set_vertex_positions(void *scene, uint32_t mesh, const float *positions);
 /* HDRFilm::develop (hdrfilm.cpp:398-399): image[h][w][3] = RGB / (W==0?1:W) */
 void orc_film_develop(const float *film, uint32_t width, uint32_t height, float *image);
 

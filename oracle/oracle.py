@@ -470,6 +470,33 @@ class OracleScene:
         assert rc == 0
         return g_refl, g_tex, g_emit[:len(self.data.emitters)], st
 
+    def render_prb_backward_shape(self, sensor, grad_in, meshes, seed=0, spp=4, max_depth=6, rr_depth=5, threads=0):
+        """as render_prb_backward, plus {mesh index: (vertex_count, 3) float64 gradient w.r.t. its vertex positions}"""
+        grad_in = f32(grad_in); nm = len(self.data.meshes)
+        g_refl = np.zeros((len(self.data.bsdfs), 3), np.float32)
+        g_tex = [np.zeros_like(t) for t in self.data.textures]
+        ptrs = (c_f32p * max(1, len(g_tex)))(*[fp(g) for g in g_tex])
+        mask = np.zeros(nm, np.uint8); mask[list(meshes)] = 1
+        g_pos = {m: np.zeros((self.data.meshes[m]["V"].shape[0], 3), np.float64) for m in meshes}
+        dp = C.POINTER(C.c_double)
+        pp = (dp * nm)(*[g_pos[m].ctypes.data_as(dp) if m in g_pos else dp() for m in range(nm)])
+        st = Stats()
+        L = lib(); L.orc_render_prb_backward_shape.restype = C.c_int
+        L.orc_render_prb_backward_shape.argtypes = [C.c_void_p, C.POINTER(Sensor), c_f32p, C.c_uint32, C.c_uint32, C.c_int32, C.c_int32, c_f32p,
+                                                    C.POINTER(c_f32p), C.c_void_p, C.POINTER(dp), C.POINTER(Stats), C.c_int]
+        rc = L.orc_render_prb_backward_shape(self.handle, C.byref(sensor), fp(grad_in), seed, spp, max_depth, rr_depth, fp(g_refl), ptrs,
+                                             mask.ctypes.data, pp, C.byref(st), threads)
+        if rc != 0:
+            raise RuntimeError("orc_render_prb_backward_shape: rc = %d" % rc)
+        return g_pos, g_refl, g_tex, st
+
+    def set_vertex_positions(self, mesh, positions):
+        p = f32(positions).reshape(-1, 3)
+        assert p.shape[0] == self.data.meshes[mesh]["V"].shape[0]
+        L = lib(); L.orc_scene_set_vertex_positions.restype = None; L.orc_scene_set_vertex_positions.argtypes = [C.c_void_p, C.c_uint32, c_f32p]
+        L.orc_scene_set_vertex_positions(self.handle, mesh, fp(p))
+        self.data.meshes[mesh]["V"][:, :3] = p
+
     def set_emitter_radiance(self, emitter, rgb):
         lib().orc_scene_set_emitter_radiance(self.handle, emitter, fp(f32(rgb)))
 

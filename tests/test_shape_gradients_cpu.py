@@ -1,0 +1,89 @@
+"""Vertex-position gradients of the PRB adjoint (attached surface interaction, solid-angle-to-area Jacobian;
+src/python/python/ad/integrators/prb.py:124-141, 176-216, 261-297) on the CPU:
+  * the oracle's dual-number restatement against finite differences of its own primal renders, on a scene without moving visibility
+    boundaries (PRB without reparameterisation has no boundary term, prb.py docstring);
+  * the product's hand-derived adjoint (HAR_HD code compiled for the host) against the oracle, vertex by vertex."""
+import ctypes as C
+import os
+
+import numpy as np
+import pytest
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(HERE)
+
+
+def slab_scene(mi, res=24, textured=False, env=False):
+    """two very large flat meshes (a floor and a ceiling, no vertex normals) lit by a small rectangle light just below the ceiling; nothing
+    casts a shadow edge onto anything else within reach of the camera, so moving the floor / ceiling only changes smooth terms"""
+    T = mi.ScalarTransform4f
+    S = 40.0
+    floor_p = np.array([[-S, 0, -S], [S, 0, -S], [S, 0, S], [-S, 0, S]], np.float32)
+    ceil_p = np.array([[-S, 3, -S], [-S, 3, S], [S, 3, S], [S, 3, -S]], np.float32)
+    faces = np.array([[0, 2, 1], [0, 3, 2]], np.uint32)           # floor: normal +y; the ceiling's vertex order gives -y
+    uv = np.array([[0, 0], [8, 0], [8, 8], [0, 8]], np.float32)
+    floor_bsdf = {"type": "diffuse", "reflectance": {"type": "rgb", "value": [0.7, 0.5, 0.3]}}
+    if textured:
+        rng = np.random.default_rng(3)
+        floor_bsdf = {"type": "diffuse", "reflectance": {"type": "bitmap", "data": rng.uniform(0.2, 0.9, (8, 8, 3)).astype(np.float32), "raw": True}}
+    d = {
+        "type": "scene",
+        "integrator": {"type": "prb", "max_depth": 4},
+        "sensor": {"type": "perspective", "fov": 50, "to_world": T().look_at(origin=[0.3, 2.0, 2.4], target=[0, 0, 0], up=[0, 1, 0]),
+                   "film": {"type": "hdrfilm", "width": res, "height": res, "rfilter": {"type": "gaussian"}, "pixel_format": "rgb"},
+                   "sampler": {"type": "independent", "sample_count": 16}},
+        "floor": {"type": "mesh", "positions": floor_p, "faces": faces, "texcoords": uv, "bsdf": floor_bsdf},
+        "ceiling": {"type": "mesh", "positions": ceil_p, "faces": faces, "bsdf": {"type": "diffuse", "reflectance": {"type": "rgb", "value": [0.4, 0.6, 0.8]}}},
+        "light": {"type": "rectangle", "to_world": T().translate([0.1, 2.9, 0.2]).rotate([1, 0, 0], 90).scale([0.04, 0.04, 0.04]),
+                  "bsdf": {"type": "diffuse", "reflectance": {"type": "rgb", "value": [0, 0, 0]}},
+                  "emitter": {"type": "area", "radiance": {"type": "rgb", "value": [4200.0, 3900.0, 3400.0]}}},
+    }
+    if env:
+        d.pop("ceiling")
+        d["sky"] = {"type": "constant", "radiance": {"type": "rgb", "value": [0.3, 0.4, 0.6]}}
+    return d
+
+
+def mesh_index(scene, key):
+    return [m["key"] for m in scene.meshes].index(key)
+
+
+def directional_fd(osc, sensor, mesh, base, direction, weights, eps, **kw):
+    sums = []
+    for sgn in (+1, -1):
+        osc.set_vertex_positions(mesh, base + sgn * eps * direction)
+        img, _ = osc.render_prb(sensor, **kw)
+        sums.append(float((img.astype(np.float64) * weights).sum()))
+    osc.set_vertex_positions(mesh, base)
+    return (sums[0] - sums[1]) / (2 * eps)
+
+
+@pytest.mark.parametrize("variant", ["plain", "textured", "env"])
+def test_oracle_shape_gradient_vs_finite_differences(mi, O, variant):
+    """d/d(theta) sum(w * image) for rigid and non-rigid motions of the floor and of the ceiling.  The two sides are different estimators
+    of the same derivative (PRB differentiates with the sampled directions held fixed in world space, a same-seed finite difference
+    lets them follow the surface), so they agree in expectation: 1024 spp, 3 % tolerance"""
+    from tests.test_cpu_host import oracle_scene_from
+    res = 12
+    scene = mi.load_dict(slab_scene(mi, res, textured=variant == "textured", env=variant == "env"))
+    osc, sensor = oracle_scene_from(O, scene)
+    kw = dict(seed=7, spp=1024, max_depth=4)
+    w = np.random.default_rng(2).uniform(0.5, 1.5, (res, res, 3)).astype(np.float32)
+    names = ["floor"] + ([] if variant == "env" else ["ceiling"])
+    ids = [mesh_index(scene, n) for n in names]
+    g_pos, _, _, _ = osc.render_prb_backward_shape(sensor, w, ids, **kw)
+    motions = {"lift": np.tile([0, 1, 0], (4, 1)), "tilt": np.array([[0, -1, 0], [0, 1, 0], [0, 1, 0], [0, -1, 0]]),
+               "shear": np.array([[1, 0, 0], [1, 0, 0], [-1, 0, 0.5], [-1, 0, 0.5]]) * 0.05}
+    for name, m in zip(names, ids):
+        base = scene.meshes[m]["V"][:, :3].astype(np.float32).copy()
+        assert np.abs(g_pos[m]).max() > 0
+        for label, direction in motions.items():
+            direction = direction.astype(np.float64)
+            fd = directional_fd(osc, sensor, m, base, direction.astype(np.float32), w, 2e-3 if label == "lift" else 2e-2, **kw)
+            ad = float((g_pos[m] * direction).sum())
+            lift = abs(float((g_pos[m] * motions["lift"]).sum()))
+            if label == "shear" and not (variant == "textured" and name == "floor"):
+                # sliding a flat, untextured, unbounded plane within itself changes nothing: both sides are ~ 0 relative to the lift
+                assert abs(ad) < 0.02 * lift + 1e-6, (name, label, ad)
+                continue
+            assert abs(fd - ad) <= 0.03 * abs(fd) + 0.005 * lift, (variant, name, label, fd, ad)
