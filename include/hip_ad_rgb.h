@@ -259,6 +259,17 @@ int har_render_backward(HarScene scene, HarIntegrator integrator, const HarSenso
  * emitter_count x 3 floats is set, har_render_backward also accumulates into it; NULL switches it off again */
 int har_integrator_set_grad_emitters(HarIntegrator integrator, float *grad_emitters);
 
+/* Gradient w.r.t. VERTEX POSITIONS (params['<mesh>.vertex_positions'] of mi.traverse): the geometry-attached part of PRBIntegrator.sample
+ * (src/python/python/ad/integrators/prb.py:124-141 attached surface interaction -- Mesh::compute_surface_interaction with AD-attached
+ * vertices, src/render/mesh.cpp:2286-2323, and SurfaceInteraction::attach_motion, include/mitsuba/render/interaction.h:525-545 --,
+ * :176-216 emitter sampling from the attached point, :261-297 attached outgoing direction and solid_angle_to_area_jacobian,
+ * ad/integrators/common.py:1355-1384).  `grad_positions` = HOST array of top_mesh_count DEVICE pointers; entry m (vertex_count x 3 floats)
+ * makes mesh m differentiable, NULL entries do not; har_render_backward then also accumulates into those buffers.  A NULL array switches the
+ * feature off.  Like `prb` itself this has no visibility-boundary term (that is prb_reparam / the projective integrators).
+ * Implemented for scenes whose BSDFs are all plain `diffuse` and for meshes without vertex normals; fails otherwise.
+ * New vertex positions are installed by creating a new scene (har_scene_create), which rebuilds the acceleration structure. */
+int har_integrator_set_grad_positions(HarIntegrator integrator, HarScene scene, float *const *grad_positions);
+
 /* counters of the last har_render / har_render_backward on this integrator (synchronises) */
 int har_render_stats(HarIntegrator integrator, HarStats *out);
 /* HIP-event timing of the last render call: per-kernel-class milliseconds, measured on

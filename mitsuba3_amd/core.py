@@ -691,6 +691,9 @@ class Integrator:
         self.chunk_lanes = int(props.get('chunk_lanes', 0))
         self.replay_cache = bool(props.get('replay_cache', True))      # hip_ad_rgb extension, see har_integrator_set_replay_cache
         self.emitter_gradients = bool(props.get('emitter_gradients', True))   # d / d radiance of area / constant emitters (har_integrator_set_grad_emitters)
+        # d / d vertex positions (har_integrator_set_grad_positions): False, True (every eligible mesh) or a list of '<shape>.vertex_positions' keys --
+        # the stand-in for dr.enable_grad(params[key]) of the reference
+        self.shape_gradients = props.get('shape_gradients', False)
         # SamplingIntegrator property (integrator.cpp:140-147); the Python AD integrators do not query it, and an
         # unqueried property is an error in the reference's plugin loader
         self.samples_per_pass = props.get('samples_per_pass', None)
@@ -794,9 +797,21 @@ class Integrator:
         ptrs = (C.c_void_p * max(1, len(g_tex)))(*[t.data_ptr() for t in g_tex])
         g_emit = torch.zeros((max(1, len(scene.emitters)), 3), dtype=torch.float32, device=dev)
         check(lib().har_integrator_set_grad_emitters(self._handle(), _ptr(g_emit) if self.emitter_gradients else None))
+        g_pos = {}
+        if self.shape_gradients:
+            keys = scene._position_keys()
+            wanted = keys if self.shape_gradients is True else {k: keys[k] for k in self.shape_gradients}    # KeyError: not a differentiable mesh
+            g_pos = {k: torch.zeros(3 * scene.meshes[m]["V"].shape[0], dtype=torch.float32, device=dev) for k, m in wanted.items()}
+            by_mesh = {wanted[k]: g for k, g in g_pos.items()}
+            pp = (C.c_void_p * max(1, scene.top_mesh_count))(*[by_mesh[m].data_ptr() if m in by_mesh else None for m in range(scene.top_mesh_count)])
+            check(lib().har_integrator_set_grad_positions(self._handle(), scene._handle(), pp if g_pos else None))
+        else:
+            check(lib().har_integrator_set_grad_positions(self._handle(), None, None))
         check(lib().har_render_backward(scene._handle(), self._handle(), C.byref(sensor.har), _ptr(grad_in), _ptr(weight_film), sd, spp,
                                         lb, le, _ptr(g_refl), ptrs, _stream()))
-        return scene._gradients(g_refl, g_tex, g_emit if self.emitter_gradients else None)
+        out = scene._gradients(g_refl, g_tex, g_emit if self.emitter_gradients else None)
+        out.update(g_pos)
+        return out
 
 
 class Bitmap:
@@ -1064,6 +1079,17 @@ class Scene:
                 keys[key + ".radiance.value"] = ("emit", i)
         return keys
 
+    def _position_keys(self):
+        """'<shape>.vertex_positions' (flat 3 N floats as in the reference's Mesh::traverse) of the top-level meshes without vertex normals"""
+        return {m["key"] + ".vertex_positions": i for i, m in enumerate(self.meshes[:self.top_mesh_count]) if not (m["flags"] & 1) and m["V"].shape[0]}
+
+    def _set_vertex_positions(self, mesh, positions):
+        """params['<shape>.vertex_positions'] = ...; params.update(): the acceleration structure is rebuilt with the next scene handle"""
+        V = self.meshes[mesh]["V"]
+        V[:, :3] = np.asarray(positions, np.float32).reshape(V.shape[0], 3)
+        if self._h is not None:
+            lib().har_scene_destroy(self._h); self._h = None
+
     def _gradients(self, g_refl, g_tex, g_emit=None):
         out = {}
         for k, (kind, b) in self._param_keys().items():
@@ -1086,11 +1112,17 @@ class SceneParameters(dict):
         for k, (kind, b) in scene._param_keys().items():
             value = scene.emitters[b]["radiance"] if kind == "emit" else (b.texture if kind == "tex" else b.value)
             self[k] = torch.tensor(np.asarray(value, np.float32), dtype=torch.float32, device=dev)
+        for k, m in scene._position_keys().items():
+            self[k] = torch.tensor(np.ascontiguousarray(scene.meshes[m]["V"][:, :3]).reshape(-1), dtype=torch.float32, device=dev)
 
     def update(self, values=None):
         if values:
             for k, v in values.items():
                 self[k] = v
+        for k, m in self.scene._position_keys().items():
+            v = self[k].detach().to("cpu", copy=True).numpy().astype(np.float32).reshape(-1, 3)
+            if not np.array_equal(v, self.scene.meshes[m]["V"][:, :3]):
+                self.scene._set_vertex_positions(m, v)
         for k, (kind, b) in self.scene._param_keys().items():
             v = self[k].detach().to("cpu", copy=True).numpy().astype(np.float32)
             if kind == "emit":

@@ -66,6 +66,9 @@ struct HarIntegratorImpl {
     float *adj = nullptr; size_t adj_floats = 0;
     float *grad_slots = nullptr; size_t grad_slots_cap = 0;   /* adjoint accumulators: (bsdf_count + emitter_count) x 3 */
     float *grad_emitters = nullptr;       /* user buffer (DEVICE, emitter_count x 3) of har_integrator_set_grad_emitters, or null */
+    /* vertex-position gradients (har_integrator_set_grad_positions): user buffers per top-level mesh, the flat accumulation buffer + offsets */
+    bool shape_on = false; std::vector<float *> pos_user; std::vector<int32_t> pos_offset; std::vector<uint32_t> pos_count;
+    int32_t *d_pos_offset = nullptr; float *grad_pos = nullptr; uint32_t pos_verts = 0; ShapeArrays geo{};
     uint2 *stack_spill = nullptr;         /* HBM part of the traversal stacks: HAR_STACK_SPILL entries per thread of the largest traversal grid */
     /* multi-pass rendering: sampler state per lane of the rendered lane range, pixel jitter per chunk lane (see PassState) */
     uint32_t samples_per_pass = 0xffffffffu;
@@ -117,6 +120,12 @@ int ensure_workspace(HarIntegratorImpl *I, uint32_t lanes, bool adjoint) {
     if (ws_alloc(I, &I->items.s0, lanes) || ws_alloc(I, &I->items.s1, lanes) || ws_alloc(I, &I->items.s2, lanes)) return 1;
     I->items.s3 = I->items.s4 = nullptr; I->dL = nullptr;
     if (adjoint && (ws_alloc(I, &I->items.s3, lanes) || ws_alloc(I, &I->items.s4, lanes) || ws_alloc(I, &I->dL, lanes))) return 1;
+    I->geo = ShapeArrays{ nullptr, nullptr, nullptr, nullptr, nullptr }; I->d_pos_offset = nullptr; I->grad_pos = nullptr;
+    if (adjoint && I->shape_on) {
+        if (ws_alloc(I, &I->geo.g0, lanes) || ws_alloc(I, &I->geo.g1, lanes) || ws_alloc(I, &I->geo.g2, lanes) || ws_alloc(I, &I->geo.g3, lanes) || ws_alloc(I, &I->geo.vis, lanes)) return 1;
+        if (ws_alloc(I, &I->d_pos_offset, I->pos_offset.size()) || ws_alloc(I, &I->grad_pos, (size_t) 3 * I->pos_verts)) return 1;
+        HIP_TRY(hipMemcpy(I->d_pos_offset, I->pos_offset.data(), I->pos_offset.size() * sizeof(int32_t), hipMemcpyHostToDevice));
+    }
     I->rc_h0 = nullptr; I->rc_h1 = nullptr; I->rc_vis = nullptr; I->cache_bounces = 0;
     if (adjoint && I->use_cache) {
         /* 25 B per lane and cached bounce; bounces beyond the cache are simply traced again */
@@ -172,6 +181,8 @@ int run_chunk(HarSceneImpl *S, HarIntegratorImpl *I, const DSensor &C, int mode,
     /* scenes whose depth-first stack bound fits the LDS entries run the kernels without the HBM spill path */
     static const bool force_spill = getenv("HAR_FORCE_STACK_SPILL") != nullptr;
     uint2 *spill = (force_spill || S->hs.stack_need() + HAR_STACK_MARGIN > HAR_LDS_STACK_SMALL) ? I->stack_spill : nullptr;
+    const bool shape = mode == MODE_PRB_ADJOINT && I->shape_on;
+    const ShapeTargets targets{ I->d_pos_offset, I->grad_pos, I->pos_verts };
     int cur = 0; uint32_t b = 0;
     for (; b < nb; ++b) {
         /* PRB replay cache: the primal pass of render_backward records this bounce's ray-query results per lane, the adjoint pass reads them */
@@ -182,10 +193,17 @@ int run_chunk(HarSceneImpl *S, HarIntegratorImpl *I, const DSensor &C, int mode,
             launch_trace_closest(s, tgrid, spill, S->ds.accel, cnt_alive(I, b), cur_trace(I, b), I->shard_cap, I->st[cur], I->h0, I->h1, I->status);
             prof_mark(I, s, CLS_TRACE);
         }
+        /* vertex-position gradients of the PREVIOUS bounce's vertices: its items are still in place, `result` holds its L, and this bounce's ray
+         * queries give the (detached) next interaction of every continued path */
+        if (shape && b > 0) {
+            launch_shape_adjoint(s, grid, S->ds, cnt_items(I, b - 1), I->shard_cap, I->items, I->geo, I->result, I->dL, 1, I->st[cur], I->h0, I->h1, rc, targets);
+            prof_mark(I, s, CLS_OTHER);
+        }
         launch_shade(mode, s, grid, S->ds, P, lane_base, I->shard_cap, cnt_alive(I, b), I->st[cur], I->h0, I->h1, I->st[cur ^ 1], cnt_alive(I, b + 1),
-                     I->items, cnt_items(I, b), I->result, rc, ps.rng, I->dL, grad_refl);
+                     I->items, cnt_items(I, b), I->result, rc, ps.rng, I->dL, grad_refl, shape ? &I->geo : nullptr);
         prof_mark(I, s, CLS_SHADE);
-        launch_resolve(mode, s, rc.mode == 2 ? grid : tgrid, spill, S->ds, cnt_items(I, b), cur_resolve(I, b), I->shard_cap, I->items, I->result, I->dL, grad_refl, I->d_grad_tex, I->status, rc);
+        launch_resolve(mode, s, rc.mode == 2 ? grid : tgrid, spill, S->ds, cnt_items(I, b), cur_resolve(I, b), I->shard_cap, I->items, I->result, I->dL, grad_refl, I->d_grad_tex, I->status, rc,
+                       shape ? I->geo.vis : nullptr);
         prof_mark(I, s, CLS_RESOLVE);
         cur ^= 1;
         if (b >= 15 && (b & 7) == 7) {           /* deep paths are rare: poll so that max_depth = -1 terminates */
@@ -195,6 +213,10 @@ int run_chunk(HarSceneImpl *S, HarIntegratorImpl *I, const DSensor &C, int mode,
             uint32_t total = 0; for (int k = 0; k < HAR_SHARDS; ++k) total += alive[k * HAR_COUNTER_STRIDE];
             if (total == 0) { ++b; break; }
         }
+    }
+    if (shape && b > 0) {            /* the last bounce: no path continues */
+        launch_shape_adjoint(s, grid, S->ds, cnt_items(I, b - 1), I->shard_cap, I->items, I->geo, I->result, I->dL, 0, I->st[cur], I->h0, I->h1, ReplayCache{ nullptr, nullptr, nullptr, 0 }, targets);
+        prof_mark(I, s, CLS_OTHER);
     }
     if (mode != MODE_PRB_PRIMAL) {
         launch_accumulate_stats(s, I->counters, std::min(b + 1, nb), I->totals, n);
@@ -549,7 +571,7 @@ int har_render_backward(HarScene S, HarIntegrator I, const HarSensor *sensor, co
         total_le = (uint64_t) sensor->crop_width * sensor->crop_height * spp;
         if (total_le == 0 || total_le > 0xffffffffull) return backward_range(S, I, sensor, grad_in, weight_film, seed, spp, lb, le, grad_reflectance, grad_textures, stream);
     }
-    const uint64_t mid = (total_le > total_lb && I->type == HAR_INTEGRATOR_PRB) ? dual_split(I, total_lb, total_le, (hipStream_t) stream) : total_le;
+    const uint64_t mid = (total_le > total_lb && I->type == HAR_INTEGRATOR_PRB && !I->shape_on) ? dual_split(I, total_lb, total_le, (hipStream_t) stream) : total_le;
     if (mid >= total_le) return backward_range(S, I, sensor, grad_in, weight_film, seed, spp, lb, le, grad_reflectance, grad_textures, stream);
     int rc = backward_range(S, I, sensor, grad_in, weight_film, seed, spp, total_lb, mid, grad_reflectance, grad_textures, stream);
     rc |= backward_range(S, I->twin, sensor, grad_in, weight_film, seed, spp, mid, total_le, grad_reflectance, grad_textures, (void *) I->side_stream);
@@ -612,6 +634,10 @@ static int backward_range(HarScene S, HarIntegrator I, const HarSensor *sensor, 
     const size_t nb3 = 3 * S->hs.bsdfs.size(), ne3 = 3 * S->hs.emitters.size();
     if (I->grad_slots_cap < nb3 + ne3 + 3) { if (ws_alloc(I, &I->grad_slots, nb3 + ne3 + 3)) return 1; I->grad_slots_cap = nb3 + ne3 + 3; }
     HIP_TRY(hipMemsetAsync(I->grad_slots, 0, (nb3 + ne3 + 3) * sizeof(float), s));
+    if (I->shape_on) {
+        if (I->pos_offset.size() != S->hs.meshes.size() || S->ds.bsdf_types != HAR_BSDF_ONLY_DIFFUSE) return fail("har_integrator_set_grad_positions was called for a different scene");
+        HIP_TRY(hipMemsetAsync(I->grad_pos, 0, (size_t) 3 * I->pos_verts * sizeof(float), s));
+    }
     HIP_TRY(hipMemsetAsync(I->totals, 0, 4 * sizeof(unsigned long long), s));
     HIP_TRY(hipMemsetAsync(I->status, 0, sizeof(int), s));
     I->ev_used = 0; I->last_stream = s;
@@ -627,7 +653,36 @@ static int backward_range(HarScene S, HarIntegrator I, const HarSensor *sensor, 
     }
     launch_add(s, I->grad_slots, grad_reflectance, (uint32_t) nb3);
     if (I->grad_emitters && ne3) launch_add(s, I->grad_slots + nb3, I->grad_emitters, (uint32_t) ne3);
+    if (I->shape_on)
+        for (size_t m = 0; m < I->pos_user.size(); ++m)
+            if (I->pos_user[m]) launch_add(s, I->grad_pos + 3 * (size_t) I->pos_offset[m], I->pos_user[m], 3 * I->pos_count[m]);
     HIP_TRY(hipGetLastError());
+    return 0;
+}
+
+int har_integrator_set_grad_positions(HarIntegrator I, HarScene S, float *const *grad_positions) {
+    if (!I) return fail("null integrator");
+    if (I->type != HAR_INTEGRATOR_PRB) return fail("vertex-position gradients are computed by the `prb` integrator");
+    std::vector<float *> user; std::vector<int32_t> offset; std::vector<uint32_t> count; uint32_t verts = 0;
+    if (grad_positions) {
+        if (!S) return fail("null scene");
+        /* the hand-derived adjoint of har_shape_grad.h covers plain `diffuse` BSDFs on flat-shaded top-level meshes */
+        if (S->ds.bsdf_types != HAR_BSDF_ONLY_DIFFUSE) return fail("vertex-position gradients are implemented for scenes whose BSDFs are all `diffuse` (no twosided wrappers)");
+        const size_t nm = S->hs.meshes.size();
+        offset.assign(nm, -1); user.assign(nm, nullptr); count.assign(nm, 0);
+        for (size_t m = 0; m < S->hs.top_mesh_count; ++m) {
+            if (!grad_positions[m]) continue;
+            const DMesh &M = S->hs.meshes[m];
+            if (M.flags & 1u) return fail("vertex-position gradients need a mesh without vertex normals (face_normals): a position update would regenerate them (mesh.cpp:876-878)");
+            offset[m] = (int32_t) verts; user[m] = grad_positions[m]; count[m] = M.vertex_count; verts += M.vertex_count;
+        }
+        if (verts == 0) { offset.clear(); user.clear(); count.clear(); }
+    }
+    if (offset != I->pos_offset || verts != I->pos_verts) {      /* the geometry records and the offset table are part of the adjoint workspace */
+        (void) hipDeviceSynchronize();
+        I->free_ws();
+    }
+    I->pos_user = user; I->pos_offset = offset; I->pos_count = count; I->pos_verts = verts; I->shape_on = verts != 0;
     return 0;
 }
 

@@ -41,6 +41,13 @@ struct ReplayCache { float4 *h0; uint2 *h1; uint8_t *vis; int mode; };
  * seeded in raygen and dropped at path end); `jitter` receives the pass's pixel jitter per chunk lane for the splat kernel, which otherwise
  * recomputes it from the seed; `pass` = 0 seeds the streams instead of reading `rng`. */
 struct PassState { uint64_t *rng; float2 *jitter; uint32_t pass; };
+/* Vertex-position gradients of the PRB adjoint (har_shape_grad.h).  `ShapeArrays`: per adjoint item, the geometry record written by `shade`
+ * (g0 = shape, prim, b1, b2; g1 = d_in, slot of the lane in the next wavefront; g2 = emitter sample point / direction, flags; g3 = its
+ * normal, cos theta_o) and the visibility `resolve` found for its shadow ray.  `ShapeTargets`: grad holds 3 floats per vertex of the
+ * differentiated meshes, mesh m starting at float3 offset[m] (-1 = not differentiated). */
+struct ShapeArrays { float4 *g0, *g1, *g2, *g3; uint8_t *vis; };
+struct ShapeTargets { const int32_t *offset; float *grad; uint32_t n_verts; };
+#define HAR_LDS_GRAD_VERTS 1024       /* up to this many differentiated vertices are accumulated in LDS (12 KB) before one global atomic per block and float */
 
 void launch_raygen(int mode, hipStream_t s, const DSensor &C, uint32_t seed, uint32_t spp, uint32_t log_spp, uint32_t lane_base, uint32_t n,
                    uint32_t shard_cap, const WaveState &out, float4 *result, uint32_t *count, const float *adj, float4 *dL, const PassState &ps = PassState{ nullptr, nullptr, 0 });
@@ -49,9 +56,15 @@ void launch_trace_closest(hipStream_t s, uint32_t grid, uint2 *spill, const Acce
                           const WaveState &in, float4 *h0, uint2 *h1, int *status);
 void launch_shade(int mode, hipStream_t s, uint32_t grid, const DScene &S, const ShadeParams &P, uint32_t lane_base, uint32_t shard_cap, const uint32_t *count_in,
                   const WaveState &in, const float4 *h0, const uint2 *h1, const WaveState &out, uint32_t *count_out, const ItemArrays &items,
-                  uint32_t *item_count, float4 *result, const ReplayCache &rc, uint64_t *pass_rng = nullptr, const float4 *dL = nullptr, float *grad_slots = nullptr);
+                  uint32_t *item_count, float4 *result, const ReplayCache &rc, uint64_t *pass_rng = nullptr, const float4 *dL = nullptr, float *grad_slots = nullptr,
+                  const ShapeArrays *geo = nullptr);
 void launch_resolve(int mode, hipStream_t s, uint32_t grid, uint2 *spill, const DScene &S, const uint32_t *item_count, uint32_t *cursor, uint32_t shard_cap, const ItemArrays &items,
-                    float4 *result, const float4 *dL, float *grad_refl, float *const *grad_tex, int *status, const ReplayCache &rc);
+                    float4 *result, const float4 *dL, float *grad_refl, float *const *grad_tex, int *status, const ReplayCache &rc, uint8_t *item_vis = nullptr);
+/* adjoint of the geometry-attached terms of the items of one bounce.  `next` / `h0` / `h1` / `rc_next`: wavefront and ray-query results of the
+ * FOLLOWING bounce (has_next = 0: the last bounce); runs after that bounce's trace and before its shade, while `result` still holds L of this one */
+void launch_shape_adjoint(hipStream_t s, uint32_t grid, const DScene &S, const uint32_t *item_count, uint32_t shard_cap, const ItemArrays &items, const ShapeArrays &geo,
+                          const float4 *result, const float4 *dL, int has_next, const WaveState &next, const float4 *h0, const uint2 *h1, const ReplayCache &rc_next,
+                          const ShapeTargets &T);
 void launch_splat(hipStream_t s, const DSensor &C, uint32_t seed, uint32_t spp, uint32_t log_spp, uint32_t lane_base, uint32_t n,
                   const float4 *result, int weights_only, float *film, const float2 *jitter = nullptr);
 void launch_pass_jitter(hipStream_t s, uint32_t seed, uint32_t lane_base, uint32_t n, uint32_t pass, float2 *jitter);

@@ -22,6 +22,7 @@
  * kernels only move data.  gfx950 only: 64-lane waves are assumed throughout.
  */
 #include "har_kernels.h"
+#include "har_shape_grad.h"
 
 namespace har {
 
@@ -314,11 +315,11 @@ __global__ __launch_bounds__(kBlock) void k_trace_closest(Accel A, const uint32_
 }
 
 /* ------------------------------------------------------------------- shade */
-template <int MODE, uint32_t TYPES>
+template <int MODE, uint32_t TYPES, bool SHAPE = false>
 __global__ __launch_bounds__(kBlock, HAR_SHADE_MIN_WAVES) void k_shade(DScene S, ShadeParams P, uint32_t lane_base, uint32_t shard_cap, const uint32_t *count_in, WaveState in,
                                                   const float4 *h0, const uint2 *h1, WaveState out, uint32_t *count_out,
                                                   ItemArrays items, uint32_t *item_count, float4 *result, ReplayCache rc, uint64_t *pass_rng,
-                                                  const float4 *dL, float *grad_slots) {
+                                                  const float4 *dL, float *grad_slots, ShapeArrays geo) {
     __shared__ uint32_t lds_r[12];
     /* adjoint with emitter gradients: per-block accumulators of d L / d radiance from emission hits (slots n_bsdfs + emitter of `grad_slots`) */
     __shared__ float eacc[MODE == MODE_PRB_ADJOINT ? 3 * HAR_LDS_GRAD_EMITTERS : 1];
@@ -358,9 +359,10 @@ __global__ __launch_bounds__(kBlock, HAR_SHADE_MIN_WAVES) void k_shade(DScene S,
         const uint32_t i = Q.base + local;
         ShadeResult R; R.alive = false; R.item = false; R.add_emission = false;
         uint32_t lane = 0;
+        float4 hh = make_float4(0.f, 0.f, 0.f, 0.f); uint2 hs = make_uint2(0u, 0u); Vec3 d_in(0.f);
         if (in_range) {
             PathState st = load_state(in, i);
-            float4 hh; uint2 hs;
+            d_in = st.d;
             if (MODE == MODE_PRB_ADJOINT && rc.mode == 2) { hh = rc.h0[st.lane - lane_base]; hs = rc.h1[st.lane - lane_base]; }      /* replay cache */
             else { hh = h0[i]; hs = h1[i]; }
             if (MODE == MODE_PRB_PRIMAL && rc.mode == 1) { rc.h0[st.lane - lane_base] = hh; rc.h1[st.lane - lane_base] = hs; }
@@ -407,6 +409,12 @@ __global__ __launch_bounds__(kBlock, HAR_SHADE_MIN_WAVES) void k_shade(DScene S,
                 items.s3[islot] = make_float4(R.dLr_drho.x, R.dLr_drho.y, R.dLr_drho.z, R.uv_x);
                 items.s4[islot] = make_float4(R.rel_grad.x, R.rel_grad.y, R.rel_grad.z, R.uv_y);
             }
+            if (SHAPE) {        /* geometry record of the vertex for k_shape_adjoint (vertex-position gradients) */
+                geo.g0[islot] = make_float4(__uint_as_float(hs.y == 0xffffffffu ? hs.x : 0xffffffffu), hh.w, hh.y, hh.z);      /* instanced geometry is not differentiated */
+                geo.g1[islot] = make_float4(d_in.x, d_in.y, d_in.z, __uint_as_float(alive ? Q.base + slot : HAR_SHAPE_NO_NEXT));
+                geo.g2[islot] = make_float4(R.nee_p.x, R.nee_p.y, R.nee_p.z, __uint_as_float(R.item_ray ? R.nee_flags : (R.nee_flags & HAR_SHAPE_LIT)));
+                geo.g3[islot] = make_float4(R.nee_n.x, R.nee_n.y, R.nee_n.z, R.cos_em);
+            }
         }
     }
     if (emitter_grads) {
@@ -421,8 +429,9 @@ __global__ __launch_bounds__(kBlock, HAR_SHADE_MIN_WAVES) void k_shade(DScene S,
 /* adjoint of one NEE / vertex item (wave-uniform call: every lane takes part in the texel pre-reduction):
  * L <- L - Lr_dir; g = dL * (dLr_dir/dslot0 + L * (df/dslot0)/f)  (prb.py:227,288-313) */
 __device__ __forceinline__ void adjoint_commit(const DScene &S, const ItemArrays &items, uint32_t i, bool pred, bool visible, float4 *result, const float4 *dL,
-                                               float *grad_refl, float *const *grad_tex, float *gacc) {
+                                               float *grad_refl, float *const *grad_tex, float *gacc, uint8_t *item_vis) {
     Vec3 g(0.f); float *dst = grad_refl; bool tex = false; TexTaps taps; float *tdst = nullptr;
+    if (pred && item_vis) item_vis[i] = visible ? 1 : 0;
     if (pred) {
         const uint32_t lane = __float_as_uint(items.s1[i].w);
         float4 s2 = items.s2[i], L = result[lane];
@@ -462,7 +471,7 @@ __device__ __forceinline__ void adjoint_commit(const DScene &S, const ItemArrays
 
 /* adjoint resolve of a bounce whose shadow-ray results sit in the replay cache: no traversal, one item per thread */
 __global__ __launch_bounds__(kBlock) void k_resolve_adjoint_cached(DScene S, const uint32_t *item_count, uint32_t shard_cap, ItemArrays items, float4 *result,
-                                                                   const float4 *dL, float *grad_refl, float *const *grad_tex, ReplayCache rc) {
+                                                                   const float4 *dL, float *grad_refl, float *const *grad_tex, ReplayCache rc, uint8_t *item_vis) {
     __shared__ float gacc[3 * HAR_LDS_GRAD_BSDFS];
     for (uint32_t k = threadIdx.x; k < 3 * HAR_LDS_GRAD_BSDFS; k += kBlock) gacc[k] = 0.f;
     __syncthreads();
@@ -473,7 +482,7 @@ __global__ __launch_bounds__(kBlock) void k_resolve_adjoint_cached(DScene S, con
         const uint32_t i = Q.base + (pred ? local : 0u);
         bool visible = false;
         if (pred && items.s0[i].w >= 0.f) visible = rc.vis[__float_as_uint(items.s1[i].w)] != 0;
-        adjoint_commit(S, items, i, pred, visible, result, dL, grad_refl, grad_tex, gacc);
+        adjoint_commit(S, items, i, pred, visible, result, dL, grad_refl, grad_tex, gacc, item_vis);
     }
     __syncthreads();
     for (uint32_t k = threadIdx.x; k < 3 * min(S.n_bsdfs + S.n_emitters, (uint32_t) HAR_LDS_GRAD_BSDFS); k += kBlock) {
@@ -485,7 +494,7 @@ __global__ __launch_bounds__(kBlock) void k_resolve_adjoint_cached(DScene S, con
 /* ------------------------------------------------- resolve (shadow rays + NEE) */
 template <int MODE, bool SPILL>
 __global__ __launch_bounds__(kBlock) void k_resolve(DScene S, const uint32_t *item_count, uint32_t *cursor, uint32_t shard_cap, ItemArrays items, float4 *result,
-                                                    const float4 *dL, float *grad_refl, float *const *grad_tex, int *status, ReplayCache rc, uint2 *spill) {
+                                                    const float4 *dL, float *grad_refl, float *const *grad_tex, int *status, ReplayCache rc, uint2 *spill, uint8_t *item_vis) {
     __shared__ uint2 lds[HAR_LDS_STACK_SMALL * kBlock];
     /* adjoint: per-block accumulators of the constant-albedo gradients.  Every path of the chip adds to the same
      * few floats of grad_refl (one 64 B line): direct global atomics serialise at ~88 atomics/us per line, which
@@ -525,13 +534,73 @@ __global__ __launch_bounds__(kBlock) void k_resolve(DScene S, const uint32_t *it
         trace_persistent<true, true, WaveStack>(S.accel, cursor + shard * HAR_COUNTER_STRIDE, n, stack, status, take,
             [&](uint32_t, const Traversal<HAR_TRAV_POLICY> &) { },
             [&](bool pred, uint32_t idx, const Traversal<HAR_TRAV_POLICY> &T) {
-                adjoint_commit(S, items, base + (pred ? idx : 0u), pred, pred && !T.found, result, dL, grad_refl, grad_tex, gacc);
+                adjoint_commit(S, items, base + (pred ? idx : 0u), pred, pred && !T.found, result, dL, grad_refl, grad_tex, gacc, item_vis);
             });
         __syncthreads();
         for (uint32_t k = threadIdx.x; k < 3 * min(S.n_bsdfs + S.n_emitters, (uint32_t) HAR_LDS_GRAD_BSDFS); k += kBlock) {
             const float v = gacc[k];
             if (v != 0.f) atomicAdd(grad_refl + k, v);
         }
+    }
+}
+
+/* ------------------------------------------------------- vertex-position gradients */
+/* One thread per adjoint item of a bounce: rebuild the vertex (triangle, barycentrics, incoming direction), look up the lane's next
+ * interaction (detached: prb.py:263-266 computes it outside dr.resume_grad) and apply har_shape_grad.h.  Scenes with few differentiated
+ * vertices (a Cornell box has a few dozen) would serialise on a handful of cache lines -- every path of the chip adds to the same
+ * vertices -- so those accumulate in LDS and flush once per block; large meshes scatter with global atomics. */
+__global__ __launch_bounds__(kBlock) void k_shape_adjoint(DScene S, const uint32_t *item_count, uint32_t shard_cap, ItemArrays items, ShapeArrays geo, const float4 *result,
+                                                          const float4 *dL, int has_next, WaveState next, const float4 *h0, const uint2 *h1, ReplayCache rc, ShapeTargets T) {
+    __shared__ float acc[3 * HAR_LDS_GRAD_VERTS];
+    const bool lds = T.n_verts <= HAR_LDS_GRAD_VERTS;
+    if (lds) { for (uint32_t k = threadIdx.x; k < 3 * T.n_verts; k += kBlock) acc[k] = 0.f; __syncthreads(); }
+    const ShardLoop Q(item_count, shard_cap);
+    for (uint32_t tile = Q.first_tile(); tile * kBlock < Q.n; tile += Q.tile_step()) {
+        const uint32_t local = tile * kBlock + threadIdx.x;
+        if (local >= Q.n) continue;
+        const uint32_t i = Q.base + local;
+        const float4 g0 = geo.g0[i];
+        const uint32_t shape = __float_as_uint(g0.x);
+        if (shape == 0xffffffffu) continue;
+        const int32_t off = T.offset[shape];
+        if (off < 0) continue;
+        const float4 g1 = geo.g1[i], g2 = geo.g2[i], g3 = geo.g3[i];
+        ShapeItem it;
+        it.shape = shape; it.prim = __float_as_uint(g0.y); it.b1 = g0.z; it.b2 = g0.w;
+        it.d_in = Vec3(g1.x, g1.y, g1.z); it.next_slot = __float_as_uint(g1.w);
+        it.q = Vec3(g2.x, g2.y, g2.z); it.nee_flags = __float_as_uint(g2.w);
+        it.n_e = Vec3(g3.x, g3.y, g3.z); it.cos_em = g3.w;
+        const uint32_t lane = __float_as_uint(items.s1[i].w);
+        const float4 L4 = result[lane], dl4 = dL[lane], s3 = items.s3[i];
+        bool nxt = has_next && it.next_slot != HAR_SHAPE_NO_NEXT, next_valid = false;
+        Vec3 np(0.f), nn(0.f), nd(0.f);
+        if (nxt) {
+            const float4 a1 = next.a1[it.next_slot];
+            nd = Vec3(a1.x, a1.y, a1.z);
+            float4 hh; uint2 hs;
+            if (rc.mode == 2) { hh = rc.h0[lane]; hs = rc.h1[lane]; } else { hh = h0[it.next_slot]; hs = h1[it.next_slot]; }
+            next_valid = hh.x != HAR_INF;
+            if (next_valid) { const SurfInt sn = compute_si(S, nd, hh.x, hh.y, hh.z, __float_as_uint(hh.w), hs.x, hs.y); np = sn.p; nn = sn.n; }
+        }
+        /* the emitter sample: w_em = ds.d (surface emitters: normalize(ds.p - si.p), recomputed from the interpolated point) */
+        {
+            const DMesh M = S.meshes[shape];
+            const uint32_t *f = S.faces + 4 * (size_t) (M.foff + it.prim);
+            const float *r0 = S.verts + 8 * (size_t) (M.voff + f[0]), *r1 = S.verts + 8 * (size_t) (M.voff + f[1]), *r2 = S.verts + 8 * (size_t) (M.voff + f[2]);
+            const Vec3 p = fma3(Vec3(r0[0], r0[1], r0[2]), 1.f - it.b1 - it.b2, fma3(Vec3(r1[0], r1[1], r1[2]), it.b1, Vec3(r2[0], r2[1], r2[2]) * it.b2));
+            it.w_em = (it.nee_flags & HAR_SHAPE_NEE_SURFACE) ? normalize3(it.q - p) : it.q;
+        }
+        Vec3 g[3] = { Vec3(0.f), Vec3(0.f), Vec3(0.f) }; uint32_t vid[3];
+        if (!shape_item_adjoint(S, it, geo.vis[i] != 0, Vec3(L4.x, L4.y, L4.z), Vec3(dl4.x, dl4.y, dl4.z), Vec3(s3.x, s3.y, s3.z), nxt, next_valid, np, nn, nd, g, vid)) continue;
+        for (int k = 0; k < 3; ++k) {
+            const uint32_t e = 3u * ((uint32_t) off + vid[k]);
+            if (lds) { atomicAdd(&acc[e], g[k].x); atomicAdd(&acc[e + 1], g[k].y); atomicAdd(&acc[e + 2], g[k].z); }
+            else { atomicAdd(T.grad + e, g[k].x); atomicAdd(T.grad + e + 1, g[k].y); atomicAdd(T.grad + e + 2, g[k].z); }
+        }
+    }
+    if (lds) {
+        __syncthreads();
+        for (uint32_t k = threadIdx.x; k < 3 * T.n_verts; k += kBlock) { const float v = acc[k]; if (v != 0.f) atomicAdd(T.grad + k, v); }
     }
 }
 
@@ -789,11 +858,17 @@ void launch_trace_closest(hipStream_t s, uint32_t grid, uint2 *spill, const Acce
 }
 void launch_shade(int mode, hipStream_t s, uint32_t grid, const DScene &S, const ShadeParams &P, uint32_t lane_base, uint32_t shard_cap, const uint32_t *count_in,
                   const WaveState &in, const float4 *h0, const uint2 *h1, const WaveState &out, uint32_t *count_out, const ItemArrays &items,
-                  uint32_t *item_count, float4 *result, const ReplayCache &rc, uint64_t *pass_rng, const float4 *dL, float *grad_slots) {
+                  uint32_t *item_count, float4 *result, const ReplayCache &rc, uint64_t *pass_rng, const float4 *dL, float *grad_slots, const ShapeArrays *geo) {
     dim3 g(grid), b(kBlock);
+    const ShapeArrays no_geo{ nullptr, nullptr, nullptr, nullptr, nullptr };
+    if (geo && mode == MODE_PRB_ADJOINT) {        /* vertex-position gradients: `diffuse`-only scenes (checked by har_integrator_set_grad_positions) */
+        hipLaunchKernelGGL((k_shade<MODE_PRB_ADJOINT, HAR_BSDF_ONLY_DIFFUSE, true>), g, b, 0, s, S, P, lane_base, shard_cap, count_in, in, h0, h1, out, count_out, items, item_count,
+                           result, rc, pass_rng, dL, grad_slots, *geo);
+        return;
+    }
     /* diffuse-only scenes (no twosided wrappers) run kernels in which the other BSDF models are compiled out */
     const bool only_diffuse = S.bsdf_types == HAR_BSDF_ONLY_DIFFUSE;
-#define HAR_LAUNCH_SHADE(M, T) hipLaunchKernelGGL((k_shade<M, T>), g, b, 0, s, S, P, lane_base, shard_cap, count_in, in, h0, h1, out, count_out, items, item_count, result, rc, pass_rng, dL, grad_slots)
+#define HAR_LAUNCH_SHADE(M, T) hipLaunchKernelGGL((k_shade<M, T>), g, b, 0, s, S, P, lane_base, shard_cap, count_in, in, h0, h1, out, count_out, items, item_count, result, rc, pass_rng, dL, grad_slots, no_geo)
     const bool envmap = (S.bsdf_types & HAR_SCENE_ENVMAP) != 0u;      /* generic BSDF code + environment-map sampling / lookup */
     const bool classic = (S.bsdf_types & 0x7fffffffu & ~HAR_BSDF_CLASSIC_TYPES) == 0u;
 #define HAR_LAUNCH_SHADE_MODE(M) do { if (envmap) HAR_LAUNCH_SHADE(M, HAR_BSDF_ALL_TYPES | HAR_SCENE_ENVMAP); else if (only_diffuse) HAR_LAUNCH_SHADE(M, HAR_BSDF_ONLY_DIFFUSE); else if (classic) HAR_LAUNCH_SHADE(M, HAR_BSDF_CLASSIC_TYPES); else HAR_LAUNCH_SHADE(M, HAR_BSDF_ALL_TYPES); } while (0)
@@ -804,16 +879,21 @@ void launch_shade(int mode, hipStream_t s, uint32_t grid, const DScene &S, const
 #undef HAR_LAUNCH_SHADE
 }
 void launch_resolve(int mode, hipStream_t s, uint32_t grid, uint2 *spill, const DScene &S, const uint32_t *item_count, uint32_t *cursor, uint32_t shard_cap, const ItemArrays &items,
-                    float4 *result, const float4 *dL, float *grad_refl, float *const *grad_tex, int *status, const ReplayCache &rc) {
+                    float4 *result, const float4 *dL, float *grad_refl, float *const *grad_tex, int *status, const ReplayCache &rc, uint8_t *item_vis) {
     dim3 g(grid), b(kBlock);
     if (mode == MODE_PRB_ADJOINT && rc.mode == 2) {
-        hipLaunchKernelGGL(k_resolve_adjoint_cached, g, b, 0, s, S, item_count, shard_cap, items, result, dL, grad_refl, grad_tex, rc);
+        hipLaunchKernelGGL(k_resolve_adjoint_cached, g, b, 0, s, S, item_count, shard_cap, items, result, dL, grad_refl, grad_tex, rc, item_vis);
         return;
     }
-#define HAR_LAUNCH_RESOLVE(M, SP) hipLaunchKernelGGL((k_resolve<M, SP>), g, b, 0, s, S, item_count, cursor, shard_cap, items, result, dL, grad_refl, grad_tex, status, rc, spill)
+#define HAR_LAUNCH_RESOLVE(M, SP) hipLaunchKernelGGL((k_resolve<M, SP>), g, b, 0, s, S, item_count, cursor, shard_cap, items, result, dL, grad_refl, grad_tex, status, rc, spill, item_vis)
     if (mode == MODE_PRB_ADJOINT) { if (spill) HAR_LAUNCH_RESOLVE(MODE_PRB_ADJOINT, true); else HAR_LAUNCH_RESOLVE(MODE_PRB_ADJOINT, false); }
     else { if (spill) HAR_LAUNCH_RESOLVE(MODE_PATH, true); else HAR_LAUNCH_RESOLVE(MODE_PATH, false); }
 #undef HAR_LAUNCH_RESOLVE
+}
+void launch_shape_adjoint(hipStream_t s, uint32_t grid, const DScene &S, const uint32_t *item_count, uint32_t shard_cap, const ItemArrays &items, const ShapeArrays &geo,
+                          const float4 *result, const float4 *dL, int has_next, const WaveState &next, const float4 *h0, const uint2 *h1, const ReplayCache &rc_next,
+                          const ShapeTargets &T) {
+    hipLaunchKernelGGL(k_shape_adjoint, dim3(grid), dim3(kBlock), 0, s, S, item_count, shard_cap, items, geo, result, dL, has_next, next, h0, h1, rc_next, T);
 }
 void launch_splat(hipStream_t s, const DSensor &C, uint32_t seed, uint32_t spp, uint32_t log_spp, uint32_t lane_base, uint32_t n,
                   const float4 *result, int weights_only, float *film, const float2 *jitter) {

@@ -50,6 +50,9 @@ struct ShadeResult {
     /* ... with HAR_SHADE_EMITTER_GRADS: d em_b / d radiance of emitter `em_index` (emission hit; -1 = none), and the NEE contribution for a UNIT
      * radiance of emitter `nee_emitter` (contrib = contrib_unit * radiance; -1 = not factorable, e.g. an environment map) */
     Vec3 em_unit; int32_t em_index; Vec3 contrib_unit; int32_t nee_emitter;
+    /* ... with vertex-position gradients (har_shape_grad.h): the detached emitter sample (position or, for an environment, direction; normal),
+     * cos(theta_o) towards it and the HAR_SHAPE_* flags of the vertex */
+    Vec3 nee_p, nee_n; float cos_em; uint32_t nee_flags;
 };
 
 /* raygen: SamplingIntegrator::render_sample up to the camera ray (integrator.cpp:448-483) */
@@ -101,7 +104,7 @@ HAR_HD void film_footprint(const DSensor &C, const LaneSample &L, Footprint &F) 
 template <int MODE, uint32_t TYPES = HAR_BSDF_ALL_TYPES>
 HAR_HD void shade_lane(const DScene &S, const ShadeParams &P, const PathState &st, const Hit &hit, ShadeResult &R) {
     R.alive = false; R.add_emission = false; R.item = false; R.item_ray = false;
-    if (MODE == MODE_PRB_ADJOINT) { R.em_index = -1; R.nee_emitter = -1; R.em_unit = Vec3(0.f); R.contrib_unit = Vec3(0.f); }
+    if (MODE == MODE_PRB_ADJOINT) { R.em_index = -1; R.nee_emitter = -1; R.em_unit = Vec3(0.f); R.contrib_unit = Vec3(0.f); R.nee_flags = 0u; R.cos_em = 0.f; R.nee_p = Vec3(0.f); R.nee_n = Vec3(0.f); }
     uint64_t rng = st.rng;
     const uint64_t inc = sampler_inc(P.seed, st.lane);
     const uint32_t depth = st.flags & 0xffffu;
@@ -198,8 +201,15 @@ HAR_HD void shade_lane(const DScene &S, const ShadeParams &P, const PathState &s
         if (R.contrib.x != 0.f || R.contrib.y != 0.f || R.contrib.z != 0.f) {
             R.item = true; R.item_ray = true;
             spawn_ray_to(si, ds.p, R.sh_o, R.sh_d, R.sh_maxt);
+            if (MODE == MODE_PRB_ADJOINT) {
+                const uint32_t et = S.emitters[em_sampled].type;
+                const bool surface = et == 0u || et == 3u;           /* EmitterFlags::Surface (prb.py:178) */
+                R.nee_flags = 1u | (surface ? 2u : 0u);
+                R.nee_p = surface ? ds.p : ds.d; R.nee_n = ds.n; R.cos_em = wo_em.z;
+            }
         }
     }
+    if (MODE == MODE_PRB_ADJOINT && si.wi.z > 0.f) R.nee_flags |= 4u;
 
     /* ---- continue the path (path.cpp:287-331, prb.py:227-252) */
     PathState &N = R.next;

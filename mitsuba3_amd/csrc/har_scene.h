@@ -11,7 +11,7 @@
 
 namespace har {
 
-struct DMesh    { uint32_t voff, foff, bsdf; int32_t emitter; uint32_t flags, face_count, pad0, pad1; };
+struct DMesh    { uint32_t voff, foff, bsdf; int32_t emitter; uint32_t flags, face_count, vertex_count, pad1; };
 struct DTexture { const float *data; uint32_t w, h; };
 /* type 0: AreaLight on a rectangle (to_world, normal, inv_area, mesh); type 1: ConstantBackgroundEmitter
  * (src/emitters/constant.cpp): to_world[0..2] = bounding sphere centre, to_world[3] = radius, mesh = 0xffffffff; type 2: environment map

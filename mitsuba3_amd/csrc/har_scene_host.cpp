@@ -211,9 +211,10 @@ bool lower_scene(const HarSceneDesc &d, HostScene &hs, std::string &err) {
         for (uint32_t f = 0; f < m.face_count; ++f)
             for (int k = 0; k < 3; ++k)
                 if (m.index_ptr[4 * (size_t) f + k] >= m.vertex_count) { err = "face index out of bounds"; return false; }
+        hs.top_mesh_count = d.top_mesh_count;
         DMesh dm{};
         dm.voff = (uint32_t) (hs.verts.size() / 8); dm.foff = (uint32_t) (hs.faces.size() / 4);
-        dm.bsdf = m.bsdf; dm.emitter = m.emitter; dm.flags = m.flags; dm.face_count = m.face_count;
+        dm.bsdf = m.bsdf; dm.emitter = m.emitter; dm.flags = m.flags; dm.face_count = m.face_count; dm.vertex_count = m.vertex_count;
         hs.verts.insert(hs.verts.end(), m.vertex_ptr, m.vertex_ptr + 8 * (size_t) m.vertex_count);
         hs.faces.insert(hs.faces.end(), m.index_ptr, m.index_ptr + 4 * (size_t) m.face_count);
         hs.meshes.push_back(dm);

@@ -14,7 +14,7 @@ struct HostTexture { std::vector<float> data; uint32_t w, h; };
 struct HostScene {
     std::vector<float> verts;
     std::vector<uint32_t> faces;
-    std::vector<DMesh> meshes;
+    std::vector<DMesh> meshes; uint32_t top_mesh_count = 0;      /* meshes [0, top_mesh_count) are the scene's own shapes, the rest belong to shape groups */
     std::vector<DBsdf> bsdfs;
     std::vector<float> bsdf_tables;          /* roughplastic external transmittance, 64 floats per table */
     std::vector<HostTexture> textures;

@@ -8,6 +8,7 @@
  * a GPU.  The shipped library (libhip_ad_rgb.so) never contains or calls this.
  */
 #include "../../mitsuba3_amd/csrc/har_path.h"
+#include "../../mitsuba3_amd/csrc/har_shape_grad.h"
 #include "../../mitsuba3_amd/csrc/har_scene_host.h"
 #include <cstdio>
 #include <cstring>
@@ -146,6 +147,70 @@ int hh_render(void *h, const HarSensor *sensor, int mode, uint32_t seed, uint32_
         for (uint32_t ys = 0; ys < F.count; ++ys) for (uint32_t xs = 0; xs < F.count; ++xs) {
             uint32_t x = F.x0 + xs, y = F.y0 + ys;
             if (x < C.crop_w && y < C.crop_h) { float w = F.wx[xs] * F.wy[ys]; float *p = film + 4 * ((size_t) y * C.crop_w + x); for (int k = 0; k < 4; ++k) p[k] += val[k] * w; }
+        }
+    }
+    return status;
+}
+
+/* vertex-position gradients: the lane-by-lane equivalent of (k_shade<ADJOINT, diffuse, SHAPE> -> k_resolve -> k_shape_adjoint), i.e. the product's
+ * hand-derived adjoint (har_shape_grad.h) driven exactly as the kernels drive it.  adj = grad_in / W (H x W x 3); grad[m] = 3 doubles per vertex
+ * of mesh m or NULL. */
+int hh_render_backward_shape(void *h, const HarSensor *sensor, const float *adj, uint32_t seed, uint32_t spp, int32_t max_depth, int32_t rr_depth,
+                             double *const *grad) {
+    HScene *H = (HScene *) h; const DScene &S = H->ds;
+    if (S.bsdf_types != HAR_BSDF_ONLY_DIFFUSE) return -2;
+    DSensor C; std::string e; if (!lower_sensor(*sensor, C, e)) return -1;
+    const uint64_t total = (uint64_t) C.crop_w * C.crop_h * spp;
+    uint32_t log_spp = 0xffffffffu; for (uint32_t k = 0; k < 32; ++k) if ((1u << k) == spp) log_spp = k;
+    ShadeParams P{ seed, (uint32_t) max_depth, (uint32_t) rr_depth };
+    int status = 0;
+    for (uint64_t lane = 0; lane < total; ++lane) {
+        LaneSample ls; const PathState st0 = raygen_lane(C, seed, spp, log_spp, (uint32_t) lane, ls);
+        Footprint F; film_footprint(C, ls, F);
+        Vec3 dl(0.f);
+        for (uint32_t ys = 0; ys < F.count; ++ys) for (uint32_t xs = 0; xs < F.count; ++xs) {
+            uint32_t x = F.x0 + xs, y = F.y0 + ys;
+            if (x < C.crop_w && y < C.crop_h) { float w = F.wx[xs] * F.wy[ys]; const float *a = adj + 3 * ((size_t) y * C.crop_w + x); dl = Vec3(fma_(a[0], w, dl.x), fma_(a[1], w, dl.y), fma_(a[2], w, dl.z)); }
+        }
+        /* primal pass: L */
+        Vec3 L(0.f);
+        {
+            PathState st = st0; bool alive = P.max_depth != 0;
+            while (alive) {
+                Hit hit; HostStack stack; accel_trace<false>(S.accel, st.o, st.d, st.maxt, hit, stack, status);
+                ShadeResult R; shade_lane<MODE_PRB_PRIMAL, HAR_BSDF_ONLY_DIFFUSE>(S, P, st, hit, R);
+                if (R.add_emission) L = L + R.em_b;
+                if (R.item && R.item_ray) { Hit sh; HostStack s2; if (!accel_trace<true>(S.accel, R.sh_o, R.sh_d, R.sh_maxt, sh, s2, status)) L = L + R.contrib; }
+                alive = R.alive; st = R.next;
+            }
+        }
+        /* adjoint replay */
+        PathState st = st0; bool alive = P.max_depth != 0;
+        Hit hit; { HostStack stack; if (alive) accel_trace<false>(S.accel, st.o, st.d, st.maxt, hit, stack, status); }
+        while (alive) {
+            ShadeResult R; shade_lane<MODE_PRB_ADJOINT, HAR_BSDF_ONLY_DIFFUSE>(S, P, st, hit, R);
+            if (R.add_emission) L = L - R.em_b;
+            bool visible = false;
+            if (R.item && R.item_ray) { Hit sh; HostStack s2; visible = !accel_trace<true>(S.accel, R.sh_o, R.sh_d, R.sh_maxt, sh, s2, status); if (visible) L = L - R.contrib; }
+            Hit next; bool next_valid = false; Vec3 np(0.f), nn(0.f);
+            if (R.alive) {
+                HostStack stack; accel_trace<false>(S.accel, R.next.o, R.next.d, R.next.maxt, next, stack, status);
+                next_valid = next.t != HAR_INF;
+                if (next_valid) { SurfInt sn = compute_si(S, R.next.d, next.t, next.u, next.v, next.prim, next.shape, next.inst); np = sn.p; nn = sn.n; }
+            }
+            if (R.item && hit.inst == 0xffffffffu && grad[hit.shape]) {
+                ShapeItem it; it.shape = hit.shape; it.prim = hit.prim; it.b1 = hit.u; it.b2 = hit.v; it.d_in = st.d;
+                it.next_slot = R.alive ? 0u : HAR_SHAPE_NO_NEXT;
+                it.q = R.nee_p; it.n_e = R.nee_n; it.cos_em = R.cos_em; it.nee_flags = R.item_ray ? R.nee_flags : (R.nee_flags & HAR_SHAPE_LIT);
+                const SurfInt si = compute_si(S, st.d, hit.t, hit.u, hit.v, hit.prim, hit.shape, hit.inst);
+                it.w_em = (it.nee_flags & HAR_SHAPE_NEE_SURFACE) ? normalize3(it.q - si.p) : it.q;
+                Vec3 g[3] = { Vec3(0.f), Vec3(0.f), Vec3(0.f) }; uint32_t vid[3];
+                if (shape_item_adjoint(S, it, visible, L, dl, R.dLr_drho, R.alive, next_valid, np, nn, R.next.d, g, vid)) {
+                    double *dst = grad[hit.shape];
+                    for (int k = 0; k < 3; ++k) { dst[3 * (size_t) vid[k]] += g[k].x; dst[3 * (size_t) vid[k] + 1] += g[k].y; dst[3 * (size_t) vid[k] + 2] += g[k].z; }
+                }
+            }
+            alive = R.alive; st = R.next; hit = next;
         }
     }
     return status;

@@ -643,3 +643,104 @@ def test_prb_replay_cache_is_transparent(mi, O):
                 grads = scene.integrator().render_backward(scene, None, grad_in, seed=2, spp=8)
                 got.append(np.concatenate([g.cpu().numpy().ravel() for g in grads.values()]))
             assert np.abs(got[1]).max() > 0 and rel_l2(got[0], got[1]) < 1e-5
+
+
+# ---------------------------------------------------------------- vertex-position gradients
+
+def _grid_floor(mi, d, n):
+    """replace the Cornell floor by an n x n vertex grid (flat, no normals): more differentiated vertices than the LDS accumulator holds"""
+    floor = mi.load_dict({"type": "rectangle", "to_world": mi.cornell_box()["floor"]["to_world"]})
+    P0 = floor.V[0, :3]
+    # corners of the rectangle lowering: find two edge vectors from vertex 0
+    e = [floor.V[k, :3] - P0 for k in range(1, 4)]
+    e.sort(key=lambda v: np.linalg.norm(v)); ex, ey = e[0], e[1]
+    nrm = np.cross(floor.V[floor.F[0, 1], :3] - floor.V[floor.F[0, 0], :3], floor.V[floor.F[0, 2], :3] - floor.V[floor.F[0, 0], :3])
+    if np.dot(np.cross(ex, ey), nrm) < 0:
+        ex, ey = ey, ex
+    s = np.linspace(0, 1, n, dtype=np.float32)
+    P = np.stack([P0 + a * ex + b * ey for b in s for a in s]).astype(np.float32)
+    F = []
+    for j in range(n - 1):
+        for i in range(n - 1):
+            a = j * n + i; F += [[a, a + 1, a + n + 1], [a, a + n + 1, a + n]]
+    d["floor"] = {"type": "mesh", "positions": P, "faces": np.asarray(F, np.uint32), "bsdf": {"type": "ref", "id": "white"}}
+    return d
+
+
+@pytest.mark.parametrize("which", ["slab", "slab_textured", "slab_env", "cbox", "cbox_grid", "cbox_nocache"])
+def test_prb_vertex_position_gradients(mi, O, which):
+    """har_integrator_set_grad_positions: the wavefront adjoint (k_shade<ADJOINT, SHAPE> geometry records, visibility from k_resolve,
+    k_shape_adjoint with the next bounce's detached interaction) vs the oracle's dual-number restatement, vertex by vertex; the colour
+    gradients of the same call must not change"""
+    from tests.test_cpu_host import oracle_scene_from
+    from tests.test_shape_gradients_cpu import slab_scene, cbox_mesh_scene, mesh_index
+    if which.startswith("cbox"):
+        res = 32; d = cbox_mesh_scene(mi, res); names = ["small-box", "large-box", "floor"]
+        if which == "cbox_grid":
+            d = _grid_floor(mi, d, 36)
+    else:
+        res = 24; d = slab_scene(mi, res, textured=which == "slab_textured", env=which == "slab_env"); names = ["floor"] + ([] if which == "slab_env" else ["ceiling"])
+    d["integrator"] = {"type": "prb", "max_depth": 5, "shape_gradients": [n + ".vertex_positions" for n in names]}
+    if which == "cbox_nocache":
+        d["integrator"]["replay_cache"] = False
+    scene = mi.load_dict(d)
+    osc, sensor = oracle_scene_from(O, scene)
+    ids = [mesh_index(scene, n) for n in names]
+    grad_in = np.random.default_rng(4).uniform(0.5, 1.5, (res, res, 3)).astype(np.float32)
+    integ = scene.integrator()
+    grads = integ.render_backward(scene, None, grad_in, seed=3, spp=16)
+    want, w_refl, w_tex, _ = osc.render_prb_backward_shape(sensor, grad_in, ids, seed=3, spp=16, max_depth=5)
+    for n, m in zip(names, ids):
+        got = grads[n + ".vertex_positions"].cpu().numpy().reshape(-1, 3)
+        scale = np.abs(want[m]).max()
+        assert scale > 0 and np.abs(got - want[m]).max() < 2e-3 * scale, (which, n, np.abs(got - want[m]).max() / scale)
+    keys = {k: v for k, v in scene._param_keys().items() if v[0] != "emit"}
+    for k, (kind, b) in keys.items():
+        ref = w_tex[b.tex_index] if kind == "tex" else w_refl[b.index]
+        if not ref.any():
+            assert not grads[k].any(), k                # e.g. the black BSDF of the light
+            continue
+        assert rel_l2(grads[k].cpu().numpy(), ref) < 1e-3, k
+    # switching the feature off again restores the plain adjoint
+    integ.shape_gradients = False
+    plain = integ.render_backward(scene, None, grad_in, seed=3, spp=16)
+    assert not any(k.endswith("vertex_positions") for k in plain)
+    for k in keys:
+        assert np.allclose(plain[k].cpu().numpy(), grads[k].cpu().numpy(), rtol=1e-4, atol=1e-7)
+
+
+def test_vertex_position_update_rebuilds_the_scene(mi, O):
+    """params['floor.vertex_positions'] = ...; params.update(): the next render sees the moved mesh (and matches the oracle's)"""
+    from tests.test_cpu_host import oracle_scene_from
+    from tests.test_shape_gradients_cpu import slab_scene, mesh_index
+    scene = mi.load_dict(slab_scene(mi, 24))
+    params = mi.traverse(scene)
+    key = "floor.vertex_positions"
+    assert key in params and params[key].numel() == 12
+    before = mi.render(scene, spp=8, seed=1).cpu().numpy()
+    p = params[key].clone().reshape(-1, 3); p[:, 1] += 0.4
+    params[key] = p.reshape(-1); params.update()
+    after = mi.render(scene, spp=8, seed=1).cpu().numpy()
+    osc, sensor = oracle_scene_from(O, scene)          # built from the updated arrays
+    ref, _ = osc.render_prb(sensor, seed=1, spp=8, max_depth=4)
+    assert rel_l2(after, ref) < 1e-4 and rel_l2(after, before) > 1e-2
+
+
+def test_vertex_position_gradients_refused_outside_their_domain(mi):
+    """non-diffuse BSDFs / meshes with vertex normals: an error, not a silently incomplete gradient"""
+    from tests.test_bsdfs_cpu import _material_cbox
+    d = _material_cbox(mi, 16); d["integrator"] = {"type": "prb", "max_depth": 3, "shape_gradients": True}
+    scene = mi.load_dict(d)
+    g = np.ones((16, 16, 3), np.float32)
+    assert scene._position_keys() == {}            # the Cornell shapes all carry vertex normals
+    d = mi.cornell_box(); d["sensor"]["film"]["width"] = 16; d["sensor"]["film"]["height"] = 16
+    d["integrator"] = {"type": "prb", "max_depth": 3, "shape_gradients": ["small-box.vertex_positions"]}
+    scene = mi.load_dict(d)
+    with pytest.raises(KeyError):
+        scene.integrator().render_backward(scene, None, g, seed=0, spp=4)
+    from tests.test_shape_gradients_cpu import slab_scene
+    d = slab_scene(mi, 16); d["ceiling"]["bsdf"] = {"type": "roughconductor", "alpha": 0.2}
+    d["integrator"] = {"type": "prb", "max_depth": 3, "shape_gradients": True}
+    scene = mi.load_dict(d)
+    with pytest.raises(RuntimeError, match="diffuse"):
+        scene.integrator().render_backward(scene, None, g, seed=0, spp=4)

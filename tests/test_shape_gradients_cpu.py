@@ -87,3 +87,57 @@ def test_oracle_shape_gradient_vs_finite_differences(mi, O, variant):
                 assert abs(ad) < 0.02 * lift + 1e-6, (name, label, ad)
                 continue
             assert abs(fd - ad) <= 0.03 * abs(fd) + 0.005 * lift, (variant, name, label, fd, ad)
+
+
+def cbox_mesh_scene(mi, res=20):
+    """Cornell box whose two boxes are flat-shaded `mesh` shapes (the cube's triangles without its vertex normals) and whose floor is a
+    textured flat mesh: occluders, shadows, interreflection, a rectangle light -- every branch of the attached computation"""
+    d = mi.cornell_box(); d["sensor"]["film"]["width"] = res; d["sensor"]["film"]["height"] = res
+    for key in ("small-box", "large-box"):
+        cube = mi.load_dict({"type": "cube", "to_world": d[key]["to_world"]})
+        d[key] = {"type": "mesh", "positions": cube.V[:, :3].copy(), "faces": cube.F[:, :3].copy(), "bsdf": {"type": "ref", "id": "white"}}
+    rng = np.random.default_rng(11)
+    floor = mi.load_dict({"type": "rectangle", "to_world": d["floor"]["to_world"]})
+    d["floor"] = {"type": "mesh", "positions": floor.V[:, :3].copy(), "faces": floor.F[:, :3].copy(), "texcoords": floor.V[:, 6:8].copy(),
+                  "bsdf": {"type": "diffuse", "reflectance": {"type": "bitmap", "data": rng.uniform(0.3, 0.9, (6, 6, 3)).astype(np.float32), "raw": True}}}
+    return d
+
+
+def harness(O):
+    L = C.CDLL(os.path.join(ROOT, "tests", "host_harness", "libhost_harness.so")); L.hh_scene_create.restype = C.c_void_p
+    L.hh_render.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_uint32, C.c_uint32, C.c_int32, C.c_int32, C.c_uint64, C.c_uint64, O.c_f32p]
+    L.hh_render_backward_shape.argtypes = [C.c_void_p, C.c_void_p, O.c_f32p, C.c_uint32, C.c_uint32, C.c_int32, C.c_int32, C.POINTER(C.POINTER(C.c_double))]
+    return L
+
+
+def product_host_gradients(O, L, scene, sensor, grad_in, meshes, seed, spp, max_depth):
+    desc = scene.desc(); err = C.create_string_buffer(256); h = C.c_void_p(L.hh_scene_create(C.byref(desc), err, 256)); assert h, err.value
+    H, W = grad_in.shape[:2]
+    film = np.zeros((H, W, 4), np.float32)
+    assert L.hh_render(h, C.byref(sensor), 1, seed, spp, max_depth, 5, 0, 0, O.fp(film)) == 0
+    w = film[:, :, 3:4]; adj = np.ascontiguousarray(grad_in / np.where(w == 0, 1, w), np.float32)
+    nm = len(scene.meshes); dp = C.POINTER(C.c_double)
+    g = {m: np.zeros((scene.meshes[m]["V"].shape[0], 3), np.float64) for m in meshes}
+    pp = (dp * nm)(*[g[m].ctypes.data_as(dp) if m in g else dp() for m in range(nm)])
+    assert L.hh_render_backward_shape(h, C.byref(sensor), O.fp(adj), seed, spp, max_depth, 5, pp) == 0
+    return g
+
+
+@pytest.mark.parametrize("which", ["slab", "slab_textured", "slab_env", "cbox"])
+def test_product_host_adjoint_matches_oracle(mi, O, which):
+    """har_shape_grad.h (hand-derived reverse mode, fp32) against the oracle's dual numbers (fp64), vertex by vertex, same seed"""
+    from tests.test_cpu_host import oracle_scene_from
+    if which == "cbox":
+        scene = mi.load_dict(cbox_mesh_scene(mi, 20)); names = ["small-box", "large-box", "floor"]; res = 20
+    else:
+        res = 16
+        scene = mi.load_dict(slab_scene(mi, res, textured=which == "slab_textured", env=which == "slab_env")); names = ["floor"] + ([] if which == "slab_env" else ["ceiling"])
+    osc, sensor = oracle_scene_from(O, scene)
+    ids = [mesh_index(scene, n) for n in names]
+    w = np.random.default_rng(4).uniform(0.5, 1.5, (res, res, 3)).astype(np.float32)
+    kw = dict(seed=3, spp=16, max_depth=5)
+    want, _, _, _ = osc.render_prb_backward_shape(sensor, w, ids, **kw)
+    got = product_host_gradients(O, harness(O), scene, sensor, w, ids, **kw)
+    for m in ids:
+        scale = np.abs(want[m]).max()
+        assert scale > 0 and np.abs(got[m] - want[m]).max() < 2e-3 * scale, (which, m, np.abs(got[m] - want[m]).max() / scale)
