@@ -324,6 +324,26 @@ int hh_trace_stats(void *h, const HarSensor *sensor, uint32_t seed, uint32_t spp
             }
             for (auto &v : evs) { q[0] += 1; q[1] += (double) v.size(); for (uint32_t x : v) { q[2] += x & 1u; q[4] += (x >> 1) & 1u; q[3] += x >> 8; } }
         };
+        /* what-if (HH_SORT=1 origin Morton, 2 = direction octant + origin Morton): the wavefront re-ordered before each trace launch */
+        static const int sort_mode = getenv("HH_SORT") ? atoi(getenv("HH_SORT")) : 0;
+        auto sort_key = [&](const Vec3 &o, const Vec3 &d, const float lo[3], const float hi[3]) {
+            uint32_t q[3]; const float oo[3] = { o.x, o.y, o.z };
+            for (int a = 0; a < 3; ++a) { float t = (oo[a] - lo[a]) / std::max(hi[a] - lo[a], 1e-20f); q[a] = (uint32_t) std::min(1023.f, std::max(0.f, t * 1024.f)); }
+            uint64_t m = 0; for (int bit = 9; bit >= 0; --bit) for (int a = 0; a < 3; ++a) m = (m << 1) | ((q[a] >> bit) & 1u);
+            uint64_t oct = (d.x < 0 ? 1u : 0u) | (d.y < 0 ? 2u : 0u) | (d.z < 0 ? 4u : 0u);
+            static const int bits = getenv("HH_SORT_BITS") ? atoi(getenv("HH_SORT_BITS")) : 30;
+            m >>= (30 - bits);
+            return sort_mode == 2 ? (oct << 30) | m : sort_mode == 3 ? (m << 3) | oct : m;
+        };
+        if (sort_mode && b > 0) {
+            float lo[3] = { 1e30f, 1e30f, 1e30f }, hi[3] = { -1e30f, -1e30f, -1e30f };
+            for (auto &c : cur) { const float oo[3] = { c.o.x, c.o.y, c.o.z }; for (int a = 0; a < 3; ++a) { lo[a] = std::min(lo[a], oo[a]); hi[a] = std::max(hi[a], oo[a]); } }
+            std::vector<std::pair<uint64_t, uint32_t>> keys(cur.size());
+            for (size_t i = 0; i < cur.size(); ++i) keys[i] = { sort_key(cur[i].o, cur[i].d, lo, hi), (uint32_t) i };
+            std::stable_sort(keys.begin(), keys.end());
+            std::vector<PathState> tmp(cur.size()); for (size_t i = 0; i < cur.size(); ++i) tmp[i] = cur[keys[i].second];
+            cur.swap(tmp);
+        }
         std::vector<std::vector<uint32_t>> evs(cur.size());
         std::vector<Hit> hits(cur.size());
         for (size_t i = 0; i < cur.size(); ++i) {
@@ -342,6 +362,15 @@ int hh_trace_stats(void *h, const HarSensor *sensor, uint32_t seed, uint32_t spp
             ShadeResult R; shade_lane<MODE_PATH>(S, P, cur[i], hits[i], R);
             if (R.item && R.item_ray) shadow.push_back(Sh{ R.sh_o, R.sh_d, R.sh_maxt });
             if (R.alive) next.push_back(R.next);
+        }
+        if (sort_mode && !shadow.empty()) {
+            float lo[3] = { 1e30f, 1e30f, 1e30f }, hi[3] = { -1e30f, -1e30f, -1e30f };
+            for (auto &c : shadow) { const float oo[3] = { c.o.x, c.o.y, c.o.z }; for (int a = 0; a < 3; ++a) { lo[a] = std::min(lo[a], oo[a]); hi[a] = std::max(hi[a], oo[a]); } }
+            std::vector<std::pair<uint64_t, uint32_t>> keys(shadow.size());
+            for (size_t i = 0; i < shadow.size(); ++i) keys[i] = { sort_key(shadow[i].o, shadow[i].d, lo, hi), (uint32_t) i };
+            std::stable_sort(keys.begin(), keys.end());
+            std::vector<Sh> tmp(shadow.size()); for (size_t i = 0; i < shadow.size(); ++i) tmp[i] = shadow[keys[i].second];
+            shadow.swap(tmp);
         }
         std::vector<std::vector<uint32_t>> sev(shadow.size());
         for (size_t i = 0; i < shadow.size(); ++i) {
