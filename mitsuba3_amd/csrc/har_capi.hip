@@ -182,6 +182,9 @@ int run_chunk(HarSceneImpl *S, HarIntegratorImpl *I, const DSensor &C, int mode,
     static const bool force_spill = getenv("HAR_FORCE_STACK_SPILL") != nullptr;
     uint2 *spill = (force_spill || S->hs.stack_need() + HAR_STACK_MARGIN > HAR_LDS_STACK_SMALL) ? I->stack_spill : nullptr;
     const bool shape = mode == MODE_PRB_ADJOINT && I->shape_on;
+    /* adjoint replay of a cached bounce: `shade` commits the vertex adjoint itself (the shadow-ray result is in the cache), no items, no resolve launch */
+    static const bool inline_env = getenv("HAR_ADJOINT_INLINE") ? atoi(getenv("HAR_ADJOINT_INLINE")) != 0 : true;
+    const bool inline_commit = inline_env && mode == MODE_PRB_ADJOINT && !shape;
     const ShapeTargets targets{ I->d_pos_offset, I->grad_pos, I->pos_verts };
     int cur = 0; uint32_t b = 0;
     for (; b < nb; ++b) {
@@ -200,9 +203,9 @@ int run_chunk(HarSceneImpl *S, HarIntegratorImpl *I, const DSensor &C, int mode,
             prof_mark(I, s, CLS_OTHER);
         }
         launch_shade(mode, s, grid, S->ds, P, lane_base, I->shard_cap, cnt_alive(I, b), I->st[cur], I->h0, I->h1, I->st[cur ^ 1], cnt_alive(I, b + 1),
-                     I->items, cnt_items(I, b), I->result, rc, ps.rng, I->dL, grad_refl, shape ? &I->geo : nullptr);
+                     I->items, cnt_items(I, b), I->result, rc, ps.rng, I->dL, grad_refl, shape ? &I->geo : nullptr, inline_commit && rc.mode == 2 ? I->d_grad_tex : nullptr);
         prof_mark(I, s, CLS_SHADE);
-        launch_resolve(mode, s, rc.mode == 2 ? grid : tgrid, spill, S->ds, cnt_items(I, b), cur_resolve(I, b), I->shard_cap, I->items, I->result, I->dL, grad_refl, I->d_grad_tex, I->status, rc,
+        if (!(inline_commit && rc.mode == 2)) launch_resolve(mode, s, rc.mode == 2 ? grid : tgrid, spill, S->ds, cnt_items(I, b), cur_resolve(I, b), I->shard_cap, I->items, I->result, I->dL, grad_refl, I->d_grad_tex, I->status, rc,
                        shape ? I->geo.vis : nullptr);
         prof_mark(I, s, CLS_RESOLVE);
         cur ^= 1;

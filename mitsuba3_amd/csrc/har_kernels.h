@@ -57,7 +57,7 @@ void launch_trace_closest(hipStream_t s, uint32_t grid, uint2 *spill, const Acce
 void launch_shade(int mode, hipStream_t s, uint32_t grid, const DScene &S, const ShadeParams &P, uint32_t lane_base, uint32_t shard_cap, const uint32_t *count_in,
                   const WaveState &in, const float4 *h0, const uint2 *h1, const WaveState &out, uint32_t *count_out, const ItemArrays &items,
                   uint32_t *item_count, float4 *result, const ReplayCache &rc, uint64_t *pass_rng = nullptr, const float4 *dL = nullptr, float *grad_slots = nullptr,
-                  const ShapeArrays *geo = nullptr);
+                  const ShapeArrays *geo = nullptr, float *const *grad_tex_inline = nullptr);      /* grad_tex_inline (adjoint, cached bounce): commit the vertex adjoint in place, no items */
 void launch_resolve(int mode, hipStream_t s, uint32_t grid, uint2 *spill, const DScene &S, const uint32_t *item_count, uint32_t *cursor, uint32_t shard_cap, const ItemArrays &items,
                     float4 *result, const float4 *dL, float *grad_refl, float *const *grad_tex, int *status, const ReplayCache &rc, uint8_t *item_vis = nullptr);
 /* adjoint of the geometry-attached terms of the items of one bounce.  `next` / `h0` / `h1` / `rc_next`: wavefront and ray-query results of the

@@ -314,13 +314,65 @@ __global__ __launch_bounds__(kBlock) void k_trace_closest(Accel A, const uint32_
         [&](bool, uint32_t, const Traversal<HAR_TRAV_POLICY> &) { });
 }
 
+/* adjoint of one NEE / vertex item (wave-uniform call: every lane takes part in the texel pre-reduction):
+ * L <- L - Lr_dir; g = dL * (dLr_dir/dslot0 + L * (df/dslot0)/f)  (prb.py:227,288-313).
+ * s2 = Lr_dir (or Lr_dir for a unit radiance) + tag, s3 = d Lr_dir / d slot0 + uv.x, s4 = (d f / d slot0) / f + uv.y -- the item layout of k_shade */
+__device__ __forceinline__ void adjoint_commit_values(const DScene &S, bool pred, bool visible, uint32_t lane, float4 s2, float4 s3, float4 s4, float4 *result, const float4 *dL,
+                                                      float *grad_refl, float *const *grad_tex, float *gacc) {
+    Vec3 g(0.f); float *dst = grad_refl; bool tex = false; TexTaps taps; float *tdst = nullptr;
+    if (pred) {
+        float4 L = result[lane];
+        const float4 dl = dL[lane];
+        const uint32_t tag = __float_as_uint(s2.w), bsdf = tag & 0xfffffu, emitter = (tag >> 20) & 0x7ffu;
+        if (emitter != HAR_ITEM_NO_EMITTER) {       /* the item carries Lr_dir for a unit radiance: d Lr_dir / d radiance, and Lr_dir = unit * radiance */
+            const DEmitter E = S.emitters[emitter];
+            if (visible) {
+                const Vec3 ge = Vec3(s2.x, s2.y, s2.z) * Vec3(dl.x, dl.y, dl.z);
+                const uint32_t slot = S.n_bsdfs + emitter;
+                if (slot < HAR_LDS_GRAD_BSDFS) { atomicAdd(&gacc[3 * slot], ge.x); atomicAdd(&gacc[3 * slot + 1], ge.y); atomicAdd(&gacc[3 * slot + 2], ge.z); }
+                else { float *a = grad_refl + 3 * (size_t) slot; atomicAdd(a, ge.x); atomicAdd(a + 1, ge.y); atomicAdd(a + 2, ge.z); }
+            }
+            s2.x *= E.radiance[0]; s2.y *= E.radiance[1]; s2.z *= E.radiance[2];
+        }
+        if (visible) { L = make_float4(L.x - s2.x, L.y - s2.y, L.z - s2.z, 0.f); result[lane] = L; }
+        g = visible ? Vec3(s3.x, s3.y, s3.z) : Vec3(0.f);
+        if (tag & 0x80000000u) g = g + Vec3(L.x * s4.x, L.y * s4.y, L.z * s4.z);
+        g = g * Vec3(dl.x, dl.y, dl.z);
+        const DBsdf B = S.bsdfs[bsdf];
+        dst = grad_refl + 3 * (size_t) bsdf;
+        if (B.texture >= 0) { tex = true; tex_taps(S.textures[B.texture], s3.w, s4.w, taps); tdst = grad_tex[B.texture]; }
+    }
+    const bool nz = pred && (g.x != 0.f || g.y != 0.f || g.z != 0.f);
+    if (nz && !tex) {
+        const uint32_t bsdf = (uint32_t) (dst - grad_refl) / 3u;
+        if (bsdf < HAR_LDS_GRAD_BSDFS) { atomicAdd(&gacc[3 * bsdf], g.x); atomicAdd(&gacc[3 * bsdf + 1], g.y); atomicAdd(&gacc[3 * bsdf + 2], g.z); }
+        else { atomicAdd(dst, g.x); atomicAdd(dst + 1, g.y); atomicAdd(dst + 2, g.z); }
+    }
+    if (__ballot(nz && tex)) {
+        const float w[4] = { taps.w0x * taps.w0y, taps.w1x * taps.w0y, taps.w0x * taps.w1y, taps.w1x * taps.w1y };
+        for (int k = 0; k < 4; ++k)
+            wave_aggregated_add3(nz && tex ? tdst + 3 * (size_t) taps.idx[k] : grad_refl, nz && tex ? g * w[k] : Vec3(0.f), nz && tex);
+    }
+}
+__device__ __forceinline__ void adjoint_commit(const DScene &S, const ItemArrays &items, uint32_t i, bool pred, bool visible, float4 *result, const float4 *dL,
+                                               float *grad_refl, float *const *grad_tex, float *gacc, uint8_t *item_vis) {
+    if (pred && item_vis) item_vis[i] = visible ? 1 : 0;
+    float4 s2 = make_float4(0.f, 0.f, 0.f, 0.f), s3 = s2, s4 = s2; uint32_t lane = 0;
+    if (pred) { lane = __float_as_uint(items.s1[i].w); s2 = items.s2[i]; s3 = items.s3[i]; s4 = items.s4[i]; }
+    adjoint_commit_values(S, pred, visible, lane, s2, s3, s4, result, dL, grad_refl, grad_tex, gacc);
+}
+
 /* ------------------------------------------------------------------- shade */
-template <int MODE, uint32_t TYPES, bool SHAPE = false>
+/* INLINE (adjoint replay of a bounce whose shadow-ray results sit in the replay cache): the visibility of the lane's emitter sample is known here,
+ * so the vertex's adjoint is committed on the spot instead of going through an item (80 B written + read) and k_resolve_adjoint_cached */
+template <int MODE, uint32_t TYPES, bool SHAPE = false, bool INLINE = false>
 __global__ __launch_bounds__(kBlock, HAR_SHADE_MIN_WAVES) void k_shade(DScene S, ShadeParams P, uint32_t lane_base, uint32_t shard_cap, const uint32_t *count_in, WaveState in,
                                                   const float4 *h0, const uint2 *h1, WaveState out, uint32_t *count_out,
                                                   ItemArrays items, uint32_t *item_count, float4 *result, ReplayCache rc, uint64_t *pass_rng,
-                                                  const float4 *dL, float *grad_slots, ShapeArrays geo) {
+                                                  const float4 *dL, float *grad_slots, ShapeArrays geo, float *const *grad_tex) {
     __shared__ uint32_t lds_r[12];
+    __shared__ float gacc[INLINE ? 3 * HAR_LDS_GRAD_BSDFS : 1];
+    if (INLINE) { for (uint32_t k = threadIdx.x; k < 3 * HAR_LDS_GRAD_BSDFS; k += kBlock) gacc[k] = 0.f; __syncthreads(); }
     /* adjoint with emitter gradients: per-block accumulators of d L / d radiance from emission hits (slots n_bsdfs + emitter of `grad_slots`) */
     __shared__ float eacc[MODE == MODE_PRB_ADJOINT ? 3 * HAR_LDS_GRAD_EMITTERS : 1];
     const bool emitter_grads = MODE == MODE_PRB_ADJOINT && (P.flags & HAR_SHADE_EMITTER_GRADS) != 0u;
@@ -390,7 +442,17 @@ __global__ __launch_bounds__(kBlock, HAR_SHADE_MIN_WAVES) void k_shade(DScene S,
                 }
             }
         }
-        const bool alive = in_range && R.alive, item = in_range && R.item;
+        bool item_pred = in_range && R.item;
+        if (INLINE) {
+            const bool fact = item_pred && R.nee_emitter >= 0 && (uint32_t) R.nee_emitter < HAR_ITEM_NO_EMITTER;
+            const Vec3 c = fact ? R.contrib_unit : R.contrib;
+            const uint32_t tag = (R.bsdf & 0xfffffu) | ((fact ? (uint32_t) R.nee_emitter : HAR_ITEM_NO_EMITTER) << 20) | (R.ind_active ? 0x80000000u : 0u);
+            const bool visible = item_pred && R.item_ray && rc.vis[lane] != 0;
+            adjoint_commit_values(S, item_pred, visible, lane, make_float4(c.x, c.y, c.z, __uint_as_float(tag)), make_float4(R.dLr_drho.x, R.dLr_drho.y, R.dLr_drho.z, R.uv_x),
+                                  make_float4(R.rel_grad.x, R.rel_grad.y, R.rel_grad.z, R.uv_y), result, dL, grad_slots, grad_tex, gacc);
+            item_pred = false;
+        }
+        const bool alive = in_range && R.alive, item = item_pred;
         uint32_t slot, islot;
         block_reserve2(cnt_alive, alive, cnt_item, item, lds_r, slot, islot);
         if (alive) store_state(out, Q.base + slot, R.next);
@@ -424,48 +486,12 @@ __global__ __launch_bounds__(kBlock, HAR_SHADE_MIN_WAVES) void k_shade(DScene S,
             if (v != 0.f) atomicAdd(grad_slots + 3 * (size_t) S.n_bsdfs + k, v);
         }
     }
-}
-
-/* adjoint of one NEE / vertex item (wave-uniform call: every lane takes part in the texel pre-reduction):
- * L <- L - Lr_dir; g = dL * (dLr_dir/dslot0 + L * (df/dslot0)/f)  (prb.py:227,288-313) */
-__device__ __forceinline__ void adjoint_commit(const DScene &S, const ItemArrays &items, uint32_t i, bool pred, bool visible, float4 *result, const float4 *dL,
-                                               float *grad_refl, float *const *grad_tex, float *gacc, uint8_t *item_vis) {
-    Vec3 g(0.f); float *dst = grad_refl; bool tex = false; TexTaps taps; float *tdst = nullptr;
-    if (pred && item_vis) item_vis[i] = visible ? 1 : 0;
-    if (pred) {
-        const uint32_t lane = __float_as_uint(items.s1[i].w);
-        float4 s2 = items.s2[i], L = result[lane];
-        const float4 dl = dL[lane];
-        const uint32_t tag = __float_as_uint(s2.w), bsdf = tag & 0xfffffu, emitter = (tag >> 20) & 0x7ffu;
-        if (emitter != HAR_ITEM_NO_EMITTER) {       /* the item carries Lr_dir for a unit radiance: d Lr_dir / d radiance, and Lr_dir = unit * radiance */
-            const DEmitter E = S.emitters[emitter];
-            if (visible) {
-                const Vec3 ge = Vec3(s2.x, s2.y, s2.z) * Vec3(dl.x, dl.y, dl.z);
-                const uint32_t slot = S.n_bsdfs + emitter;
-                if (slot < HAR_LDS_GRAD_BSDFS) { atomicAdd(&gacc[3 * slot], ge.x); atomicAdd(&gacc[3 * slot + 1], ge.y); atomicAdd(&gacc[3 * slot + 2], ge.z); }
-                else { float *a = grad_refl + 3 * (size_t) slot; atomicAdd(a, ge.x); atomicAdd(a + 1, ge.y); atomicAdd(a + 2, ge.z); }
-            }
-            s2.x *= E.radiance[0]; s2.y *= E.radiance[1]; s2.z *= E.radiance[2];
+    if (INLINE) {
+        __syncthreads();
+        for (uint32_t k = threadIdx.x; k < 3 * min(S.n_bsdfs + S.n_emitters, (uint32_t) HAR_LDS_GRAD_BSDFS); k += kBlock) {
+            const float v = gacc[k];
+            if (v != 0.f) atomicAdd(grad_slots + k, v);
         }
-        if (visible) { L = make_float4(L.x - s2.x, L.y - s2.y, L.z - s2.z, 0.f); result[lane] = L; }
-        float4 s3 = items.s3[i], s4 = items.s4[i];
-        g = visible ? Vec3(s3.x, s3.y, s3.z) : Vec3(0.f);
-        if (tag & 0x80000000u) g = g + Vec3(L.x * s4.x, L.y * s4.y, L.z * s4.z);
-        g = g * Vec3(dl.x, dl.y, dl.z);
-        const DBsdf B = S.bsdfs[bsdf];
-        dst = grad_refl + 3 * (size_t) bsdf;
-        if (B.texture >= 0) { tex = true; tex_taps(S.textures[B.texture], s3.w, s4.w, taps); tdst = grad_tex[B.texture]; }
-    }
-    const bool nz = pred && (g.x != 0.f || g.y != 0.f || g.z != 0.f);
-    if (nz && !tex) {
-        const uint32_t bsdf = (uint32_t) (dst - grad_refl) / 3u;
-        if (bsdf < HAR_LDS_GRAD_BSDFS) { atomicAdd(&gacc[3 * bsdf], g.x); atomicAdd(&gacc[3 * bsdf + 1], g.y); atomicAdd(&gacc[3 * bsdf + 2], g.z); }
-        else { atomicAdd(dst, g.x); atomicAdd(dst + 1, g.y); atomicAdd(dst + 2, g.z); }
-    }
-    if (__ballot(nz && tex)) {
-        const float w[4] = { taps.w0x * taps.w0y, taps.w1x * taps.w0y, taps.w0x * taps.w1y, taps.w1x * taps.w1y };
-        for (int k = 0; k < 4; ++k)
-            wave_aggregated_add3(nz && tex ? tdst + 3 * (size_t) taps.idx[k] : grad_refl, nz && tex ? g * w[k] : Vec3(0.f), nz && tex);
     }
 }
 
@@ -858,17 +884,26 @@ void launch_trace_closest(hipStream_t s, uint32_t grid, uint2 *spill, const Acce
 }
 void launch_shade(int mode, hipStream_t s, uint32_t grid, const DScene &S, const ShadeParams &P, uint32_t lane_base, uint32_t shard_cap, const uint32_t *count_in,
                   const WaveState &in, const float4 *h0, const uint2 *h1, const WaveState &out, uint32_t *count_out, const ItemArrays &items,
-                  uint32_t *item_count, float4 *result, const ReplayCache &rc, uint64_t *pass_rng, const float4 *dL, float *grad_slots, const ShapeArrays *geo) {
+                  uint32_t *item_count, float4 *result, const ReplayCache &rc, uint64_t *pass_rng, const float4 *dL, float *grad_slots, const ShapeArrays *geo,
+                  float *const *grad_tex) {
     dim3 g(grid), b(kBlock);
     const ShapeArrays no_geo{ nullptr, nullptr, nullptr, nullptr, nullptr };
     if (geo && mode == MODE_PRB_ADJOINT) {        /* vertex-position gradients: `diffuse`-only scenes (checked by har_integrator_set_grad_positions) */
         hipLaunchKernelGGL((k_shade<MODE_PRB_ADJOINT, HAR_BSDF_ONLY_DIFFUSE, true>), g, b, 0, s, S, P, lane_base, shard_cap, count_in, in, h0, h1, out, count_out, items, item_count,
-                           result, rc, pass_rng, dL, grad_slots, *geo);
+                           result, rc, pass_rng, dL, grad_slots, *geo, grad_tex);
+        return;
+    }
+    if (grad_tex && mode == MODE_PRB_ADJOINT && rc.mode == 2) {       /* cached bounce of the adjoint replay: commit in place (see k_shade) */
+        const bool env = (S.bsdf_types & HAR_SCENE_ENVMAP) != 0u, diffuse = S.bsdf_types == HAR_BSDF_ONLY_DIFFUSE, cls = (S.bsdf_types & 0x7fffffffu & ~HAR_BSDF_CLASSIC_TYPES) == 0u;
+#define HAR_LAUNCH_SHADE_INLINE(T) hipLaunchKernelGGL((k_shade<MODE_PRB_ADJOINT, T, false, true>), g, b, 0, s, S, P, lane_base, shard_cap, count_in, in, h0, h1, out, count_out, items, item_count, result, rc, pass_rng, dL, grad_slots, no_geo, grad_tex)
+        if (env) HAR_LAUNCH_SHADE_INLINE(HAR_BSDF_ALL_TYPES | HAR_SCENE_ENVMAP); else if (diffuse) HAR_LAUNCH_SHADE_INLINE(HAR_BSDF_ONLY_DIFFUSE);
+        else if (cls) HAR_LAUNCH_SHADE_INLINE(HAR_BSDF_CLASSIC_TYPES); else HAR_LAUNCH_SHADE_INLINE(HAR_BSDF_ALL_TYPES);
+#undef HAR_LAUNCH_SHADE_INLINE
         return;
     }
     /* diffuse-only scenes (no twosided wrappers) run kernels in which the other BSDF models are compiled out */
     const bool only_diffuse = S.bsdf_types == HAR_BSDF_ONLY_DIFFUSE;
-#define HAR_LAUNCH_SHADE(M, T) hipLaunchKernelGGL((k_shade<M, T>), g, b, 0, s, S, P, lane_base, shard_cap, count_in, in, h0, h1, out, count_out, items, item_count, result, rc, pass_rng, dL, grad_slots, no_geo)
+#define HAR_LAUNCH_SHADE(M, T) hipLaunchKernelGGL((k_shade<M, T>), g, b, 0, s, S, P, lane_base, shard_cap, count_in, in, h0, h1, out, count_out, items, item_count, result, rc, pass_rng, dL, grad_slots, no_geo, nullptr)
     const bool envmap = (S.bsdf_types & HAR_SCENE_ENVMAP) != 0u;      /* generic BSDF code + environment-map sampling / lookup */
     const bool classic = (S.bsdf_types & 0x7fffffffu & ~HAR_BSDF_CLASSIC_TYPES) == 0u;
 #define HAR_LAUNCH_SHADE_MODE(M) do { if (envmap) HAR_LAUNCH_SHADE(M, HAR_BSDF_ALL_TYPES | HAR_SCENE_ENVMAP); else if (only_diffuse) HAR_LAUNCH_SHADE(M, HAR_BSDF_ONLY_DIFFUSE); else if (classic) HAR_LAUNCH_SHADE(M, HAR_BSDF_CLASSIC_TYPES); else HAR_LAUNCH_SHADE(M, HAR_BSDF_ALL_TYPES); } while (0)
