@@ -7,7 +7,8 @@
 One "step" = one complete forward `path` render of the workload (all W*H*spp lanes:
 raygen -> [trace, shade, resolve]* -> splat -> film reduce -> develop), scene and BVH
 already resident in HBM.  value = W*H*spp / seconds / 1e6 (Mpaths/s), whole job over all
-ranks (weak scaling is NOT used: the image is fixed and sharded by pixel rows => "strong").
+ranks (weak scaling is NOT used: the image is fixed and sharded by pixel rows => "strong";
+the row bands are rebalanced by measured per-rank time over the first three frames).
 After the timed forward steps the PRB adjoint (RBIntegrator.render_backward equivalent:
 weight pass + primal pass + adjoint replay) is timed the same way and reported in
 `prb_adjoint`.  rank 0 prints ONE JSON line.
@@ -198,7 +199,9 @@ def main():
             "dtype": "f32", "data": "synthetic",
             "config": {"workload": "%s %dx%dx%dspp max_depth=%d rr_depth=5 seed=0" % (args.workload, args.res, args.res, args.spp, args.max_depth),
                        "triangles_effective": 100 * 10000 + 12 if args.workload != "cornell" else 36,
-                       "accel": accel, "parallelism": "pixel-row tiles x%d, one RCCL film reduce" % world},
+                       "accel": accel, "parallelism": "pixel-row tiles x%d, one RCCL film reduce" % world,
+                       # row bands of equal measured cost (mitsuba3_amd/distributed.py BandBalancer; adapts over the first 3 frames, then frozen)
+                       "row_bands": next(iter(getattr(integ, "_band_balancers", {}).values())).bounds if world > 1 and getattr(integ, "_band_balancers", None) else None},
             "prb_adjoint": prb, "roofline": roofline, "cpu_baseline": cpu,
             "stats": {k: int(v) for k, v in stats.items()},
         }

@@ -1,8 +1,8 @@
 """Multi-GPU sharding of the hot path: one process per GPU (torch.distributed, backend
 "nccl" = RCCL over xGMI).  Lanes are independent, so rank r renders the contiguous lane
-range [r*N/G, (r+1)*N/G) of the reference's own wavefront ordering -- i.e. a band of pixel
-rows with ALL their samples -- KEEPING the global lane index for RNG seeding, so the union
-of the bands is sample-identical to a single-GPU render.  Each rank splats into a private
+range of a band of pixel rows with ALL their samples (equal bands at first, then bands of
+equal measured cost, see BandBalancer) -- KEEPING the global lane index for RNG seeding, so the
+union of the bands is sample-identical to a single-GPU render.  Each rank splats into a private
 full-size film; the only collective is ONE sum-reduce of the H x W x 4 film (and, for prb,
 of the weight film and the gradient buffers).  The reference has no multi-GPU path
 (SURVEY.md 2.3); this is new design.
@@ -24,6 +24,91 @@ def lane_range(total_lanes, rank, world_size, granule=1):
     return lo, hi
 
 
+class BandBalancer:
+    """Row bands of equal COST instead of equal height.  Equal bands leave the ranks unequal work (on the 1M-triangle bench scene the cost per
+    pixel row varies by 2x from the top of the frame to the middle: 8 equal bands -> the slowest rank does 1.21x the mean, which caps strong
+    scaling at 82 %).  Every rank times its own band (device events), the times are all-gathered, and the next frame's boundaries equalise the
+    integral of the piecewise-constant cost-per-row estimate.  After `ADAPT_FRAMES` frames the bands are frozen, so a steady render loop pays
+    neither the extra synchronisation nor the all-gather.  Bands stay whole pixel rows with global lane indices: the union of the bands is still
+    sample-identical to a single-GPU render whatever the boundaries are."""
+
+    ADAPT_FRAMES = 3
+
+    def __init__(self, rows, world):
+        self.rows, self.world = rows, world
+        self.bounds = [rows * r // world for r in range(world + 1)]
+        self.frames = 0
+
+    def adapting(self):
+        return self.world > 1 and self.frames < self.ADAPT_FRAMES
+
+    def band(self, rank):
+        return self.bounds[rank], self.bounds[rank + 1]
+
+    def update(self, times):
+        """times[r] = seconds rank r spent on its current band (identical list on every rank)"""
+        self.frames += 1
+        b, n = self.bounds, self.world
+        if any(not (t > 0.0) for t in times) or self.rows < n:
+            return
+        dens = [times[r] / max(b[r + 1] - b[r], 1) for r in range(n)]            # cost per row, piecewise constant
+        total = sum(times)
+        new, r, acc = [0], 0, 0.0
+        for k in range(1, n):
+            target = total * k / n
+            while r < n - 1 and acc + times[r] < target:
+                acc += times[r]; r += 1
+            y = b[r] + (target - acc) / dens[r] if dens[r] > 0 else b[r + 1]
+            y = int(round(y))
+            new.append(min(max(y, new[-1] + 1), self.rows - (n - k)))                # every rank keeps at least one row
+        new.append(self.rows)
+        self.bounds = new
+
+
+def _balancer(integrator, key, rows, world):
+    table = integrator.__dict__.setdefault("_band_balancers", {})
+    bal = table.get(key)
+    if bal is None or bal.rows != rows or bal.world != world:
+        bal = table[key] = BandBalancer(rows, world)
+    return bal
+
+
+class _Timer:
+    """device time of the enclosed launches (HIP events on the current stream), or wall time for a host renderer (the CPU test double)"""
+
+    def __init__(self, enabled):
+        self.enabled = enabled; self.cuda = enabled and torch.cuda.is_available()
+
+    def __enter__(self):
+        if self.cuda:
+            self.e0 = torch.cuda.Event(enable_timing=True); self.e1 = torch.cuda.Event(enable_timing=True); self.e0.record()
+        elif self.enabled:
+            import time
+            self.t0 = time.perf_counter()
+        return self
+
+    def __exit__(self, *exc):
+        if self.cuda:
+            self.e1.record()
+        elif self.enabled:
+            import time
+            self.dt = time.perf_counter() - self.t0
+
+    def seconds(self):
+        if self.cuda:
+            self.e1.synchronize()
+            return self.e0.elapsed_time(self.e1) * 1e-3
+        return self.dt
+
+
+def _share_times(bal, timer, like):
+    """all-gather of the per-rank band times, then the new boundaries (same arithmetic on every rank)"""
+    t = torch.tensor([timer.seconds()], dtype=torch.float64, device=like.device if dist.get_backend() != "gloo" else "cpu")
+    out = [torch.zeros_like(t) for _ in range(bal.world)]
+    dist.all_gather(out, t)
+    bal.update([float(x.item()) for x in out])
+
+
 def _world():
     if dist.is_available() and dist.is_initialized():
         return dist.get_rank(), dist.get_world_size()
@@ -40,8 +125,14 @@ def render_distributed(scene, integrator=None, sensor=0, seed=0, spp=0, develop=
     w, h = s.film().crop_size()
     rank, world = _world()
     spp_pass, _ = integrator.pass_layout(s, spp)          # multi-pass jobs (> 2^32 - 1 samples): bands of the per-pass wavefront
-    lanes = lane_range(w * h * spp_pass, rank, world, granule=w * spp_pass)
-    film = integrator.render_film(scene, s, seed, spp, lanes=lanes)
+    bal = _balancer(integrator, ("path", id(scene), w, spp_pass), h, world)
+    y0, y1 = bal.band(rank)
+    lanes = (y0 * w * spp_pass, y1 * w * spp_pass)
+    adapt = bal.adapting()
+    with _Timer(adapt) as timer:
+        film = integrator.render_film(scene, s, seed, spp, lanes=lanes)
+    if adapt:
+        _share_times(bal, timer, film)
     if world > 1:
         if dist.get_backend() == "gloo" and film.is_cuda:      # gloo has no device-tensor reduce (rehearsal runs only)
             dist.all_reduce(film, op=dist.ReduceOp.SUM)
@@ -64,14 +155,20 @@ def render_backward_distributed(scene, grad_in, integrator=None, sensor=0, seed=
     spp = s.sampler().sample_count()
     w, h = s.film().crop_size()
     rank, world = _world()
-    lanes = lane_range(w * h * spp, rank, world, granule=w * spp)
+    bal = _balancer(integrator, ("prb", id(scene), w, spp), h, world)
+    y0, y1 = bal.band(rank)
+    lanes = (y0 * w * spp, y1 * w * spp)
+    adapt = bal.adapting()
     dev = core._device()
     wfilm = torch.zeros((h, w, 4), dtype=torch.float32, device=dev)
     sd = (s.sampler().m_base_seed + int(seed)) & 0xffffffff
     check(lib().har_render_weights(C.byref(s.har), sd, spp, lanes[0], lanes[1], core._ptr(wfilm), core._stream()))
     if world > 1:
         dist.all_reduce(wfilm, op=dist.ReduceOp.SUM)          # W[px] needs every rank's samples
-    grads = integrator.render_backward(scene, None, grad_in, s, seed, spp, lanes=lanes, weight_film=wfilm)
+    with _Timer(adapt) as timer:
+        grads = integrator.render_backward(scene, None, grad_in, s, seed, spp, lanes=lanes, weight_film=wfilm)
+    if adapt:
+        _share_times(bal, timer, wfilm)
     if world > 1:
         for g in grads.values():
             dist.all_reduce(g, op=dist.ReduceOp.SUM)

@@ -58,6 +58,21 @@ if rank == 0:
     whole, _ = osc.render_path_passes(osensor, seed=3, spp=8, spp_per_pass=2, max_depth=8, raw=True)
     err2 = np.abs(film.numpy() - whole).max() / np.abs(whole).max()
     assert err2 < 1e-6, err2
+# cost-balanced bands (BandBalancer): whatever boundaries the measured times produce, the union of the bands is the whole frame; after
+# ADAPT_FRAMES frames the bands are frozen and identical on every rank
+integ = OracleIntegrator(osc, osensor)
+whole, _ = osc.render_path(osensor, seed=3, spp=spp, max_depth=8, raw=True)
+for frame in range(5):
+    film = mi.render_distributed(scene, integrator=integ, seed=3, spp=spp, develop=False)
+    if rank == 0:
+        e3 = np.abs(film.numpy() - whole).max() / np.abs(whole).max()
+        assert e3 < 1e-6, (frame, e3)
+(bal,) = integ._band_balancers.values()
+assert bal.frames == 3 and not bal.adapting() and bal.bounds[0] == 0 and bal.bounds[-1] == res and all(b > a for a, b in zip(bal.bounds, bal.bounds[1:]))
+mine = torch.tensor(bal.bounds, dtype=torch.int64); both = [torch.zeros_like(mine) for _ in range(world)]
+dist.all_gather(both, mine)
+assert all(torch.equal(both[0], b) for b in both)
+if rank == 0:
     print("DIST_OK", err, err2)
 dist.barrier()
 dist.destroy_process_group()
@@ -80,6 +95,26 @@ def test_lane_range_partitions_whole_rows():
                 assert lo == prev and lo % (w * spp) == 0 and hi >= lo
                 prev = hi
             assert prev == total
+
+
+def test_band_balancer_equalises_cost():
+    """BandBalancer.update on a synthetic cost-per-row profile (the bench scene's shape: cheap sky rows, expensive middle): one update brings the
+    slowest rank from 1.2x to within 3 % of the mean, bands stay a partition of the rows, degenerate inputs are ignored"""
+    sys.path.insert(0, ROOT)
+    from mitsuba3_amd.distributed import BandBalancer
+    rows = 512
+    prof = np.interp(np.arange(rows), [0, 60, 200, 440, 512], [0.5, 0.8, 1.15, 1.25, 0.6])
+    for world in (2, 3, 4, 8):
+        b = BandBalancer(rows, world)
+        cost = lambda: [prof[b.bounds[r]:b.bounds[r + 1]].sum() for r in range(world)]
+        t0 = cost(); assert max(t0) / np.mean(t0) > 1.05
+        b.update(t0); t1 = cost()
+        assert max(t1) / np.mean(t1) < 1.03 and b.bounds[0] == 0 and b.bounds[-1] == rows and all(y > x for x, y in zip(b.bounds, b.bounds[1:]))
+        b.update(t1); b.update(cost())
+        assert not b.adapting() and max(cost()) / np.mean(cost()) < 1.02
+    b = BandBalancer(4, 4); b.update([1.0, 5.0, 1.0, 1.0]); assert b.bounds == [0, 1, 2, 3, 4]          # one row per rank: nothing to move
+    b = BandBalancer(64, 2); b.update([0.0, 1.0]); assert b.bounds == [0, 32, 64]                           # a missing measurement changes nothing
+    b = BandBalancer(64, 2); b.update([1.0, 1e-9]); assert b.bounds[1] <= 63 and b.bounds[1] >= 1
 
 
 def test_world_size_2_gloo_band_union_equals_whole():
