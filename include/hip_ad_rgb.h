@@ -237,6 +237,9 @@ int har_render(HarScene scene, HarIntegrator integrator, const HarSensor *sensor
 
 /* `samples_per_pass` property of SamplingIntegrator (integrator.cpp:140-147); 0 = unset */
 int har_integrator_set_samples_per_pass(HarIntegrator integrator, uint32_t samples_per_pass);
+/* Integrator property `hide_emitters` (src/render/integrator.cpp:29): camera rays pass through area emitters (Integrator::skip_area_emitters,
+ * integrator.cpp:96-124; path.cpp:177-190, prb.py:112-118) and do not see the environment (path.cpp:114-115, prb.py:146-148) */
+int har_integrator_set_hide_emitters(HarIntegrator integrator, int hide);
 /* the pass split har_render will use for `spp` samples per pixel of this sensor's crop window; fails like the reference
  * when spp is not a multiple of the pass size (integrator.cpp:177-179, sampler.cpp:93-94) */
 int har_render_pass_layout(HarIntegrator integrator, const HarSensor *sensor, uint32_t spp, uint32_t *spp_per_pass, uint32_t *n_passes);

@@ -682,8 +682,7 @@ class Integrator:
         default_depth = -1 if self.type == 'path' else 6        # integrator.cpp:539, common.py:31
         self.max_depth = int(props.get('max_depth', default_depth))
         self.rr_depth = int(props.get('rr_depth', 5))
-        if props.get('hide_emitters', False):
-            raise RuntimeError("hide_emitters=True is not implemented by hip_ad_rgb")
+        self.hide_emitters = bool(props.get('hide_emitters', False))      # integrator.cpp:29
         if self.max_depth < 0 and self.max_depth != -1:
             raise RuntimeError("\"max_depth\" must be set to -1 (infinite) or a value >= 0")
         if self.rr_depth <= 0:
@@ -710,6 +709,8 @@ class Integrator:
             self._h = h
             if not self.replay_cache:
                 check(lib().har_integrator_set_replay_cache(h, 0))
+            if self.hide_emitters:
+                check(lib().har_integrator_set_hide_emitters(h, 1))
             if self.samples_per_pass is not None:
                 check(lib().har_integrator_set_samples_per_pass(h, self.samples_per_pass))
         return self._h

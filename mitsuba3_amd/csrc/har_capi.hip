@@ -54,6 +54,8 @@ struct HarIntegratorImpl {
      * chunks are as large as HBM comfortably allows: 2^26 lanes = 15.6 GB of forward workspace, 32 GB with the adjoint items and the replay cache
      * (measured on the 1M-triangle scene, 67 M lanes: 16 M-lane chunks 708, 32 M 758, one 64 M chunk 783 Mpaths/s) */
     uint32_t max_depth = 0, rr_depth = 5, chunk = 1u << 26;
+    bool hide_emitters = false;           /* Integrator property (integrator.cpp:29) */
+    uint32_t *skip_counters = nullptr;    /* hide_emitters: count + cursor of the two continuation lists of skip_area_emitters */
     // workspace
     uint32_t ws_lanes = 0; bool ws_adjoint = false; uint32_t shard_cap = 0;
     std::vector<void *> owned;
@@ -135,6 +137,7 @@ int ensure_workspace(HarIntegratorImpl *I, uint32_t lanes, bool adjoint) {
     }
     if (ws_alloc(I, &I->result, lanes)) return 1;
     if (ws_alloc(I, &I->stack_spill, (size_t) HAR_STACK_SPILL * HAR_MAX_TRAVERSAL_BLOCKS * 256)) return 1;
+    if (ws_alloc(I, &I->skip_counters, (size_t) 4 * HAR_SHARDS * HAR_COUNTER_STRIDE)) return 1;
     if (ws_alloc(I, &I->counters, (size_t) 4 * HAR_MAX_BOUNCE_SLOTS * HAR_SHARDS * HAR_COUNTER_STRIDE) || ws_alloc(I, &I->totals, 4) || ws_alloc(I, &I->status, 1)) return 1;
     HIP_TRY(hipMemset(I->totals, 0, 4 * sizeof(unsigned long long)));
     HIP_TRY(hipMemset(I->status, 0, sizeof(int)));
@@ -173,7 +176,7 @@ int run_chunk(HarSceneImpl *S, HarIntegratorImpl *I, const DSensor &C, int mode,
     HIP_TRY(hipMemsetAsync(cur_resolve(I, 0), 0, used, s));
     launch_raygen(mode, s, C, seed, spp, log_spp, lane_base, n, I->shard_cap, I->st[0], I->result, cnt_alive(I, 0), I->adj, I->dL, ps);
     prof_mark(I, s, CLS_RAYGEN);
-    ShadeParams P{ seed, I->max_depth, I->rr_depth, (mode == MODE_PRB_ADJOINT && I->grad_emitters) ? HAR_SHADE_EMITTER_GRADS : 0u };
+    ShadeParams P{ seed, I->max_depth, I->rr_depth, ((mode == MODE_PRB_ADJOINT && I->grad_emitters) ? HAR_SHADE_EMITTER_GRADS : 0u) | (I->hide_emitters ? HAR_SHADE_HIDE_EMITTERS : 0u) };
     /* grid: a multiple of 8 so that block b serves shard b % 8; enough blocks to cover the chunk once */
     const uint32_t grid = std::max<uint32_t>(HAR_SHARDS, std::min<uint32_t>(((n + 255) / 256 + HAR_SHARDS - 1) / HAR_SHARDS * HAR_SHARDS, 4096u));
     /* persistent traversal kernels: enough blocks to fill the chip (<= 8 blocks/CU), never more than the work */
@@ -195,6 +198,30 @@ int run_chunk(HarSceneImpl *S, HarIntegratorImpl *I, const DSensor &C, int mode,
         if (rc.mode != 2) {
             launch_trace_closest(s, tgrid, spill, S->ds.accel, cnt_alive(I, b), cur_trace(I, b), I->shard_cap, I->st[cur], I->h0, I->h1, I->status);
             prof_mark(I, s, CLS_TRACE);
+        }
+        if (I->hide_emitters && b == 0 && rc.mode != 2) {
+            /* Integrator::skip_area_emitters (integrator.cpp:96-124) for the camera rays: continuation rays are gathered into a list, traced, and
+             * their hits replace the lanes' hits until no lane sits on an area emitter any more.  Scratch: the other wavefront buffer holds the two
+             * lists, the (still unused) item arrays the re-traced hits.  One host round trip per round -- `hide_emitters` is not a hot path. */
+            const size_t cs = (size_t) HAR_SHARDS * HAR_COUNTER_STRIDE;
+            uint32_t *cnt[2] = { I->skip_counters, I->skip_counters + 2 * cs }, *cursor[2] = { I->skip_counters + cs, I->skip_counters + 3 * cs };
+            float4 *lo[2] = { I->st[cur ^ 1].a0, I->st[cur ^ 1].a2 }, *ld[2] = { I->st[cur ^ 1].a1, I->st[cur ^ 1].a3 };
+            float4 *sh0 = I->items.s0; uint2 *sh1 = reinterpret_cast<uint2 *>(I->items.s1);
+            HIP_TRY(hipMemsetAsync(I->skip_counters, 0, 4 * cs * sizeof(uint32_t), s));
+            launch_skip_emitters(s, grid, S->ds, 1, I->shard_cap, cnt_alive(I, 0), I->st[cur].a0, I->st[cur].a1, nullptr, nullptr, I->h0, I->h1, lo[0], ld[0], cnt[0]);
+            for (int round = 0, a = 0; round < 256; ++round, a ^= 1) {
+                uint32_t host[HAR_SHARDS * HAR_COUNTER_STRIDE];
+                HIP_TRY(hipMemcpyAsync(host, cnt[a], sizeof(host), hipMemcpyDeviceToHost, s));
+                HIP_TRY(hipStreamSynchronize(s));
+                uint32_t total = 0; for (int k = 0; k < HAR_SHARDS; ++k) total += host[k * HAR_COUNTER_STRIDE];
+                if (total == 0) break;
+                WaveState list{ lo[a], ld[a], nullptr, nullptr, nullptr };
+                launch_trace_closest(s, tgrid, spill, S->ds.accel, cnt[a], cursor[a], I->shard_cap, list, sh0, sh1, I->status);
+                HIP_TRY(hipMemsetAsync(cnt[a ^ 1], 0, cs * sizeof(uint32_t), s));
+                HIP_TRY(hipMemsetAsync(cursor[a ^ 1], 0, cs * sizeof(uint32_t), s));
+                launch_skip_emitters(s, grid, S->ds, 0, I->shard_cap, cnt[a], lo[a], ld[a], sh0, sh1, I->h0, I->h1, lo[a ^ 1], ld[a ^ 1], cnt[a ^ 1]);
+            }
+            prof_mark(I, s, CLS_OTHER);
         }
         /* vertex-position gradients of the PREVIOUS bounce's vertices: its items are still in place, `result` holds its L, and this bounce's ray
          * queries give the (detached) next interaction of every continued path */
@@ -537,7 +564,7 @@ static uint64_t dual_split(HarIntegrator I, uint64_t lb, uint64_t le, hipStream_
     }
     HarIntegratorImpl *T = I->twin;
     T->type = I->type; T->max_depth = I->max_depth; T->rr_depth = I->rr_depth; T->chunk = I->chunk; T->samples_per_pass = I->samples_per_pass;
-    T->grad_emitters = I->grad_emitters; T->profiling = I->profiling;
+    T->grad_emitters = I->grad_emitters; T->profiling = I->profiling; T->hide_emitters = I->hide_emitters;
     if (T->use_cache != I->use_cache) { (void) hipDeviceSynchronize(); T->free_ws(); T->use_cache = I->use_cache; }
     if (hipEventRecord(I->ev_fork, s) != hipSuccess || hipStreamWaitEvent(I->side_stream, I->ev_fork, 0) != hipSuccess) return le;
     I->twin_used = true;
@@ -582,6 +609,11 @@ int har_render_backward(HarScene S, HarIntegrator I, const HarSensor *sensor, co
     return rc;
 }
 
+int har_integrator_set_hide_emitters(HarIntegrator I, int hide) {
+    if (!I) return fail("null integrator");
+    I->hide_emitters = hide != 0;
+    return 0;
+}
 int har_integrator_set_samples_per_pass(HarIntegrator I, uint32_t samples_per_pass) {
     if (!I) return fail("null integrator");
     if (I->type != HAR_INTEGRATOR_PATH) return fail("samples_per_pass is a property of SamplingIntegrator (`path`); the AD integrators render a single wavefront");

@@ -60,6 +60,10 @@ void launch_shade(int mode, hipStream_t s, uint32_t grid, const DScene &S, const
                   const ShapeArrays *geo = nullptr, float *const *grad_tex_inline = nullptr);      /* grad_tex_inline (adjoint, cached bounce): commit the vertex adjoint in place, no items */
 void launch_resolve(int mode, hipStream_t s, uint32_t grid, uint2 *spill, const DScene &S, const uint32_t *item_count, uint32_t *cursor, uint32_t shard_cap, const ItemArrays &items,
                     float4 *result, const float4 *dL, float *grad_refl, float *const *grad_tex, int *status, const ReplayCache &rc, uint8_t *item_vis = nullptr);
+/* hide_emitters: one round of Integrator::skip_area_emitters over the camera-ray hits (first = 1: scan h0 / h1 of the wavefront `ray_o / ray_d`;
+ * first = 0: commit the re-traced hits `hit0 / hit1` of the continuation list `ray_o / ray_d`); continuation rays are appended to `dst_*` */
+void launch_skip_emitters(hipStream_t s, uint32_t grid, const DScene &S, int first, uint32_t shard_cap, const uint32_t *count_in, const float4 *ray_o, const float4 *ray_d,
+                          const float4 *hit0, const uint2 *hit1, float4 *h0, uint2 *h1, float4 *dst_o, float4 *dst_d, uint32_t *dst_count);
 /* adjoint of the geometry-attached terms of the items of one bounce.  `next` / `h0` / `h1` / `rc_next`: wavefront and ray-query results of the
  * FOLLOWING bounce (has_next = 0: the last bounce); runs after that bounce's trace and before its shade, while `result` still holds L of this one */
 void launch_shape_adjoint(hipStream_t s, uint32_t grid, const DScene &S, const uint32_t *item_count, uint32_t shard_cap, const ItemArrays &items, const ShapeArrays &geo,

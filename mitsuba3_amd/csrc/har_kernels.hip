@@ -570,6 +570,42 @@ __global__ __launch_bounds__(kBlock) void k_resolve(DScene S, const uint32_t *it
     }
 }
 
+/* ------------------------------------------------------- hide_emitters */
+/* Integrator::skip_area_emitters (src/render/integrator.cpp:96-124; call sites path.cpp:177-190, prb.py:112-118): a CAMERA ray that hits an area
+ * emitter continues through all area emitters along it.  Only the preliminary intersection of the lane is replaced, its ray stays the camera ray.
+ * One round: (first = 1) scan the wavefront's camera-ray hits, (first = 0) take the re-traced hits of list `src`, store them as the lanes' hits;
+ * every hit that is an emitter again appends a continuation ray (origin offset along the geometric normal, same direction; .w of the direction =
+ * the lane's slot) to list `dst`.  The host loops trace(list) -> round until the list is empty. */
+__global__ __launch_bounds__(kBlock) void k_skip_emitters(DScene S, int first, uint32_t shard_cap, const uint32_t *count_in, const float4 *ray_d,
+                                                          const float4 *hit0, const uint2 *hit1, float4 *h0, uint2 *h1, float4 *dst_o, float4 *dst_d, uint32_t *dst_count) {
+    __shared__ uint32_t lds_r[12];
+    const ShardLoop Q(count_in, shard_cap);
+    uint32_t *cnt = dst_count + Q.shard * HAR_COUNTER_STRIDE;
+    for (uint32_t tile = Q.first_tile(); tile * kBlock < Q.n; tile += Q.tile_step()) {
+        const uint32_t local = tile * kBlock + threadIdx.x;
+        const bool in_range = local < Q.n;
+        const uint32_t i = Q.base + local;
+        bool again = false; float4 no = make_float4(0.f, 0.f, 0.f, 0.f), nd = no;
+        if (in_range) {
+            const float4 d = ray_d[i];
+            const float4 hh = first ? h0[i] : hit0[i]; const uint2 hs = first ? h1[i] : hit1[i];
+            const uint32_t slot = first ? i : __float_as_uint(d.w);
+            if (!first) { h0[slot] = hh; h1[slot] = hs; }
+            if (hh.x != HAR_INF && S.meshes[hs.x].emitter >= 0) {
+                const Vec3 dir(d.x, d.y, d.z);
+                const SurfInt si = compute_si(S, dir, hh.x, hh.y, hh.z, __float_as_uint(hh.w), hs.x, hs.y);
+                const Vec3 p = offset_p(si, dir);
+                no = make_float4(p.x, p.y, p.z, -1.f);                      /* .w < 0: unbounded ray (see store_state) */
+                nd = make_float4(d.x, d.y, d.z, __uint_as_float(slot));
+                again = true;
+            }
+        }
+        uint32_t slot_a, slot_b;
+        block_reserve2(cnt, again, cnt, false, lds_r, slot_a, slot_b);
+        if (again) { dst_o[Q.base + slot_a] = no; dst_d[Q.base + slot_a] = nd; }
+    }
+}
+
 /* ------------------------------------------------------- vertex-position gradients */
 /* One thread per adjoint item of a bounce: rebuild the vertex (triangle, barycentrics, incoming direction), look up the lane's next
  * interaction (detached: prb.py:263-266 computes it outside dr.resume_grad) and apply har_shape_grad.h.  Scenes with few differentiated
@@ -924,6 +960,11 @@ void launch_resolve(int mode, hipStream_t s, uint32_t grid, uint2 *spill, const 
     if (mode == MODE_PRB_ADJOINT) { if (spill) HAR_LAUNCH_RESOLVE(MODE_PRB_ADJOINT, true); else HAR_LAUNCH_RESOLVE(MODE_PRB_ADJOINT, false); }
     else { if (spill) HAR_LAUNCH_RESOLVE(MODE_PATH, true); else HAR_LAUNCH_RESOLVE(MODE_PATH, false); }
 #undef HAR_LAUNCH_RESOLVE
+}
+void launch_skip_emitters(hipStream_t s, uint32_t grid, const DScene &S, int first, uint32_t shard_cap, const uint32_t *count_in, const float4 *ray_o, const float4 *ray_d,
+                          const float4 *hit0, const uint2 *hit1, float4 *h0, uint2 *h1, float4 *dst_o, float4 *dst_d, uint32_t *dst_count) {
+    (void) ray_o;
+    hipLaunchKernelGGL(k_skip_emitters, dim3(grid), dim3(kBlock), 0, s, S, first, shard_cap, count_in, ray_d, hit0, hit1, h0, h1, dst_o, dst_d, dst_count);
 }
 void launch_shape_adjoint(hipStream_t s, uint32_t grid, const DScene &S, const uint32_t *item_count, uint32_t shard_cap, const ItemArrays &items, const ShapeArrays &geo,
                           const float4 *result, const float4 *dL, int has_next, const WaveState &next, const float4 *h0, const uint2 *h1, const ReplayCache &rc_next,

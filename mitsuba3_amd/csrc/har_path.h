@@ -32,9 +32,10 @@ struct PathState {
 
 struct ShadeParams {
     uint32_t seed, max_depth, rr_depth;
-    uint32_t flags = 0;        /* bit 0 (adjoint): also accumulate the gradient w.r.t. the radiance of `area` / `constant` emitters */
+    uint32_t flags = 0;        /* bit 0 (adjoint): also accumulate the gradient w.r.t. the radiance of `area` / `constant` emitters; bit 1: hide_emitters */
 };
 #define HAR_SHADE_EMITTER_GRADS 1u
+#define HAR_SHADE_HIDE_EMITTERS 2u   /* Integrator property `hide_emitters`: the environment is not seen by camera rays (path.cpp:114-115, prb.py:146-148) */
 #define HAR_ITEM_NO_EMITTER 0x7ffu   /* emitter field of an adjoint item's tag: contribution stored as is (no emitter gradient) */
 
 struct ShadeResult {
@@ -116,8 +117,9 @@ HAR_HD void shade_lane(const DScene &S, const ShadeParams &P, const PathState &s
     const int emitter = valid ? M.emitter : S.env_emitter;          /* si.emitter(scene): the environment for a miss (scene.h:822-832) */
     const float pmf = S.n_emitters ? 1.f / (float) S.n_emitters : 0.f;   /* scene.cpp:139 */
 
-    /* ---- direct emission + MIS with the previous BSDF sample (path.cpp:206-221, prb.py:148-161) */
-    if (emitter >= 0) {
+    /* ---- direct emission + MIS with the previous BSDF sample (path.cpp:206-221, prb.py:148-161).  hide_emitters: a camera ray that escapes does
+     * not see the environment (path.cpp:114-115 keeps valid_ray false, so the sample's result is dropped; prb.py:146-148 masks the eval) */
+    if (emitter >= 0 && !((P.flags & HAR_SHADE_HIDE_EMITTERS) && depth == 0u && !valid)) {
         const DEmitter E = S.emitters[emitter];
         const bool env = E.type == 1u || E.type == 2u;
         const bool envmap = (TYPES & HAR_SCENE_ENVMAP) != 0u && E.type == 2u;      /* kernels of scenes without an environment map compile this out */

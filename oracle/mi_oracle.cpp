@@ -49,6 +49,7 @@ struct Scene {
     std::vector<Texture> textures;
     std::vector<OrcEmitter> emitters;
     int env = -1; float env_center[3] = { 0, 0, 0 }; float env_radius = 0.f;   // Scene::environment() + its bounding sphere
+    bool hide_emitters = false;            // Integrator property `hide_emitters` (integrator.cpp:29), set by orc_scene_set_hide_emitters
     EnvMap envmap;                 // when emitters[env].type == 2
     /* AreaLight on a triangle mesh (emitter type 3): DiscreteDistribution over the face areas (Mesh::build_pmf, mesh.cpp:1358-1372) */
     struct AreaPmf { std::vector<float> pmf, cdf; float sum = 0.f, normalization = 0.f; };
@@ -623,12 +624,30 @@ static inline Lane make_lane(const OrcSensor &s, uint32_t seed, uint32_t spp, ui
 //  PathIntegrator::sample (src/integrators/path.cpp:94-346), JIT semantics
 // ---------------------------------------------------------------------------
 
+/* hide_emitters: a camera ray that hits an area emitter continues through ALL area emitters along it
+ * (path.cpp:177-190, prb.py:112-118; Integrator::skip_area_emitters, src/render/integrator.cpp:96-124).  Only the preliminary
+ * intersection is replaced: the loop keeps the camera ray (position and normal come from the barycentric coordinates,
+ * si.wi from the unchanged direction). */
+static void skip_area_emitters(const Scene &sc, const Ray &ray, PI &pi, OrcStats &st) {
+    if (!(pi.valid() && sc.meshes[pi.shape].emitter >= 0)) return;
+    SI si = compute_si(sc, ray, pi);
+    Ray r = spawn_ray(si, ray.d);
+    for (;;) {
+        PI q; st.closest_rays++; scene_trace<false>(sc, r, q, 0);
+        pi = q;
+        if (!(q.valid() && sc.meshes[q.shape].emitter >= 0)) return;
+        SI s2 = compute_si(sc, r, q);
+        r = spawn_ray(s2, r.d);
+    }
+}
+
 static V3 path_sample(const Scene &sc, Pcg32 &rng, Ray ray, uint32_t max_depth, uint32_t rr_depth, bool &valid_ray, OrcStats &st, bool scalar = false) {
     V3 throughput(1.f), result(0.f);
-    float eta = 1.f; uint32_t depth = 0; valid_ray = sc.env >= 0;      // path.cpp:114: the environment is visible (hide_emitters = false)
+    float eta = 1.f; uint32_t depth = 0; valid_ray = !sc.hide_emitters && sc.env >= 0;      // path.cpp:114-115
     V3 prev_p(0.f); float prev_bsdf_pdf = 1.f; bool prev_bsdf_delta = true;
     if (max_depth == 0) return V3(0.f);
     PI pi; st.closest_rays++; scene_trace<false>(sc, ray, pi, 0);
+    if (sc.hide_emitters) skip_area_emitters(sc, ray, pi, st);
     bool active = true;
     while (active) {
         st.vertices++;
@@ -784,6 +803,7 @@ static V3 prb_sample(const Scene &sc, Pcg32 &rng, Ray ray, uint32_t max_depth, u
     uint32_t depth = 0; V3 L = primal ? V3(0.f) : L_in; V3 beta(1.f); float eta = 1.f;
     bool active = true;
     PI pi; st.closest_rays++; scene_trace<false>(sc, ray, pi, 0);
+    if (sc.hide_emitters) skip_area_emitters(sc, ray, pi, st);             // prb.py:112-118
     V3 prev_p(0.f); float bsdf_pdf_prev = 1.f; bool bsdf_delta_prev = true;
     uint32_t iter = 0;
     while (active && iter < max_depth) {                      // prb.py:121-123 (max_iterations)
@@ -799,7 +819,7 @@ static V3 prb_sample(const Scene &sc, Pcg32 &rng, Ray ray, uint32_t max_depth, u
             V3 rel = si.p - prev_p; ds.dist = norm(rel); ds.d = si.valid() ? div(rel, ds.dist) : -si.wi;
             if (emitter >= 0 && !bsdf_delta_prev) em_pdf = (sc.emitters[emitter].type == 1 ? InvFourPi : sc.emitters[emitter].type == 2 ? sc.envmap.pdf_direction(ds.d) : emitter_pdf_direction(sc.emitters[emitter], ds)) * (1.f / (float) sc.emitters.size());
             float mis = mis_weight(bsdf_pdf_prev, em_pdf);
-            if (emitter >= 0) {
+            if (emitter >= 0 && !(sc.hide_emitters && depth == 0 && !si.valid())) {          // prb.py:146-148: active_next masks emitter.eval
                 const OrcEmitter &e = sc.emitters[emitter];
                 V3 ev = e.type == 2 ? sc.envmap.eval(-si.wi) : (e.type == 1 || si.wi.z > 0.f) ? V3(e.radiance[0], e.radiance[1], e.radiance[2]) : V3(0.f);
                 Le = (beta * mis) * ev;
@@ -1300,6 +1320,7 @@ int orc_render_prb_backward(void *scene, const OrcSensor *sp, const float *grad_
                             OrcStats *stats, int threads) {
     return orc_render_prb_backward_ex(scene, sp, grad_in, seed, spp, max_depth, rr_depth, grad_reflectance, grad_textures, nullptr, stats, threads);
 }
+void orc_scene_set_hide_emitters(void *scene, int hide) { ((Scene *) scene)->hide_emitters = hide != 0; }
 void orc_scene_set_emitter_radiance(void *scene, uint32_t emitter, const float rgb[3]) {
     Scene &sc = *(Scene *) scene;
     if (emitter < sc.emitters.size()) for (int c = 0; c < 3; ++c) sc.emitters[emitter].radiance[c] = rgb[c];

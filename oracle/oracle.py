@@ -118,6 +118,7 @@ def lib():
         L.orc_render_prb_backward_ex.argtypes = [C.c_void_p, C.POINTER(Sensor), c_f32p, C.c_uint32, C.c_uint32, C.c_int32, C.c_int32, c_f32p,
                                                  C.POINTER(c_f32p), c_f32p, C.POINTER(Stats), C.c_int]
         L.orc_scene_set_emitter_radiance.argtypes = [C.c_void_p, C.c_uint32, c_f32p]
+        L.orc_scene_set_hide_emitters.argtypes = [C.c_void_p, C.c_int]; L.orc_scene_set_hide_emitters.restype = None
         L.orc_render_prb_backward.restype = C.c_int
         L.orc_render_prb_backward.argtypes = [C.c_void_p, C.POINTER(Sensor), c_f32p, C.c_uint32, C.c_uint32,
                                               C.c_int32, C.c_int32, c_f32p, C.POINTER(c_f32p),
@@ -496,6 +497,9 @@ class OracleScene:
         L = lib(); L.orc_scene_set_vertex_positions.restype = None; L.orc_scene_set_vertex_positions.argtypes = [C.c_void_p, C.c_uint32, c_f32p]
         L.orc_scene_set_vertex_positions(self.handle, mesh, fp(p))
         self.data.meshes[mesh]["V"][:, :3] = p
+
+    def set_hide_emitters(self, hide):
+        lib().orc_scene_set_hide_emitters(self.handle, 1 if hide else 0)
 
     def set_emitter_radiance(self, emitter, rgb):
         lib().orc_scene_set_emitter_radiance(self.handle, emitter, fp(f32(rgb)))

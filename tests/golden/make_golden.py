@@ -158,12 +158,26 @@ def oracle_fixtures():
     g_refl, g_tex, _ = osc.render_prb_backward(sensor, grad_in, seed=0x1234, spp=8, max_depth=6)
     fx["c4_texture"] = tex; fx["c4_img"] = img; fx["c4_grad_in"] = grad_in
     fx["c4_grad_refl"] = g_refl; fx["c4_grad_tex"] = g_tex[0]
+    # vertex-position gradients of prb (slab scene of tests/test_shape_gradients_cpu.py: floor + ceiling, 16 x 16, 16 spp, seed 3, max_depth 5)
+    import mitsuba3_amd as mi
+    from tests.test_cpu_host import oracle_scene_from
+    from tests.test_shape_gradients_cpu import slab_scene, mesh_index
+    mi.set_variant("hip_ad_rgb")
+    scene = mi.load_dict(slab_scene(mi, 16, textured=True))
+    osc, sensor = oracle_scene_from(O, scene)
+    ids = [mesh_index(scene, n) for n in ("floor", "ceiling")]
+    w = np.random.default_rng(4).uniform(0.5, 1.5, (16, 16, 3)).astype(np.float32)
+    g_pos, _, _, _ = osc.render_prb_backward_shape(sensor, w, ids, seed=3, spp=16, max_depth=5)
+    fx["shape_grad_in"] = w; fx["shape_grad_floor"] = g_pos[ids[0]]; fx["shape_grad_ceiling"] = g_pos[ids[1]]
     np.savez_compressed(os.path.join(HERE, "oracle_fixtures.npz"), **fx)
     return fx
 
 
 if __name__ == "__main__":
+    old = dict(np.load(os.path.join(HERE, "oracle_fixtures.npz"))) if os.path.exists(os.path.join(HERE, "oracle_fixtures.npz")) else {}
     k = transcribe_kats()
     print("reference_kats.json:", sorted(k.keys()))
     f = oracle_fixtures()
     print("oracle_fixtures.npz:", {n: v.shape for n, v in f.items()})
+    changed = [n for n in old if n in f and not np.array_equal(old[n], f[n])]
+    print("fixtures that CHANGED w.r.t. the previous file (must be empty unless the oracle was changed on purpose):", changed)

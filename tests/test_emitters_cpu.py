@@ -161,3 +161,33 @@ def test_mesh_emitter_equals_rectangle_light(mi, O):
     img, _ = osb.render_path(sensor, seed=99, spp=512, max_depth=4)
     ok, pmin, alpha = ztest.accept(img, 512, ref_mean, ref_var, n_ref)
     assert ok, (pmin, alpha)
+
+
+def hide_emitters_scene(mi, res=32):
+    """the Cornell box seen by its own camera, with the back wall replaced by a constant sky: the ceiling light and the sky are in view"""
+    d = mi.cornell_box(); d["sensor"]["film"]["width"] = res; d["sensor"]["film"]["height"] = res
+    d.pop("back"); d["sky"] = {"type": "constant", "radiance": {"type": "rgb", "value": [0.2, 0.3, 0.5]}}
+    return d
+
+
+def test_oracle_hide_emitters(mi, O):
+    """Integrator property `hide_emitters` (path.cpp:114-115,177-190; prb.py:112-118,146-148): camera rays pass through area emitters and
+    do not see the environment; everything the emitters light stays lit"""
+    from tests.test_cpu_host import oracle_scene_from
+    scene = mi.load_dict(hide_emitters_scene(mi))
+    osc, sensor = oracle_scene_from(O, scene)
+    kw = dict(seed=1, spp=16, max_depth=4)
+    shown, _ = osc.render_path(sensor, **kw)
+    osc.set_hide_emitters(True)
+    hidden, _ = osc.render_path(sensor, **kw)
+    hidden_prb, _ = osc.render_prb(sensor, **kw)
+    osc.set_hide_emitters(False)
+    light = shown[:, :, 0] > 6.0
+    assert light.sum() >= 4 and hidden[light].max() < 4.0             # the light is in view ... and gone: those pixels show the ceiling behind it
+    sky = np.abs(shown - np.array([0.2, 0.3, 0.5], np.float32)).max(axis=2) < 1e-4
+    assert sky.sum() >= 16 and np.abs(hidden[sky]).max() < 0.05         # camera rays that escape see nothing (a little filter bleed from the walls)
+    # pixels whose 5 x 5 filter footprint holds neither: identical, sample for sample
+    same = np.abs(shown - hidden).max(axis=2) <= 1e-5 * np.maximum(np.abs(shown).max(axis=2), 1e-3)
+    assert same.mean() > 0.25
+    # prb: same estimator in expectation
+    assert abs(hidden_prb.mean() / hidden.mean() - 1) < 0.1

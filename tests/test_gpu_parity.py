@@ -249,6 +249,19 @@ def test_golden_prb_texture_gradient(mi):
     assert rel_l2(g, fx["c4_grad_tex"]) < 1e-3                             # north_star PRB tolerance
 
 
+def test_golden_shape_gradients(mi):
+    """vertex-position gradients of prb against the committed oracle fixture (no oracle call at run time)"""
+    from tests.test_shape_gradients_cpu import slab_scene
+    fx = _fx()
+    d = slab_scene(mi, 16, textured=True)
+    d["integrator"] = {"type": "prb", "max_depth": 5, "shape_gradients": True}
+    scene = mi.load_dict(d)
+    grads = scene.integrator().render_backward(scene, None, fx["shape_grad_in"], seed=3, spp=16)
+    for name in ("floor", "ceiling"):
+        got = grads[name + ".vertex_positions"].cpu().numpy().reshape(-1, 3); want = fx["shape_grad_" + name]
+        assert np.abs(got - want).max() < 2e-3 * np.abs(want).max(), name
+
+
 def test_golden_sampler_streams(mi):
     fx = _fx()
     s = mi.Sampler({"sample_count": 4}); s.seed(7, 16)
@@ -744,3 +757,33 @@ def test_vertex_position_gradients_refused_outside_their_domain(mi):
     scene = mi.load_dict(d)
     with pytest.raises(RuntimeError, match="diffuse"):
         scene.integrator().render_backward(scene, None, g, seed=0, spp=4)
+
+
+def test_hide_emitters_parity(mi, O):
+    """Integrator property `hide_emitters`: the device round trip of Integrator::skip_area_emitters (continuation lists, re-trace, hit replacement)
+    and the hidden environment, `path` / `prb` images and prb gradients vs the oracle; a stack of three emitters along the camera rays"""
+    from tests.test_cpu_host import oracle_scene_from
+    from tests.test_emitters_cpu import hide_emitters_scene
+    T = mi.ScalarTransform4f
+    for stacked in (False, True):
+        d = hide_emitters_scene(mi, 40)
+        if stacked:       # two more (small, dim) area lights in front of the camera: camera rays cross up to three emitters in a row
+            for k, z in enumerate((2.0, 1.2)):
+                d["panel%d" % k] = {"type": "rectangle", "to_world": T().translate([0.1 * k, 0.2, z]).scale([0.5, 0.4, 1.0]),
+                                    "bsdf": {"type": "ref", "id": "white"}, "emitter": {"type": "area", "radiance": {"type": "rgb", "value": [0.5, 0.4 + k, 0.3]}}}
+        for itype, md in (("path", 6), ("prb", 5)):
+            d["integrator"] = {"type": itype, "max_depth": md, "hide_emitters": True}
+            scene = mi.load_dict(d)
+            osc, sensor = oracle_scene_from(O, scene); osc.set_hide_emitters(True)
+            img = mi.render(scene, spp=16, seed=5).cpu().numpy()
+            ref, _ = (osc.render_path if itype == "path" else osc.render_prb)(sensor, seed=5, spp=16, max_depth=md)
+            assert np.isfinite(img).all() and rel_l2(img, ref) < 1e-4, (stacked, itype)
+            if itype == "prb":
+                grad_in = np.random.default_rng(1).uniform(0.5, 1.5, (40, 40, 3)).astype(np.float32)
+                grads = scene.integrator().render_backward(scene, None, grad_in, seed=9, spp=16)
+                g_refl, _, _ = osc.render_prb_backward(sensor, grad_in, seed=9, spp=16, max_depth=md)
+                keys = {k: v for k, v in scene._param_keys().items() if v[0] == "rgb"}
+                got = np.stack([grads[k].cpu().numpy() for k in keys]); want = np.stack([g_refl[b.index] for (_, b) in keys.values()])
+                assert rel_l2(got, want) < 1e-3, stacked
+        shown = mi.load_dict({**d, "integrator": {"type": "path", "max_depth": 6}})
+        assert rel_l2(mi.render(shown, spp=16, seed=5).cpu().numpy(), img) > 0.1           # the property does change the picture
