@@ -141,6 +141,8 @@ uint32_t build_bvh8(const std::vector<PrimBox> &prims, std::vector<Node8> &nodes
     static const bool dp_enabled = !(getenv("HAR_BVH_COLLAPSE") && std::string(getenv("HAR_BVH_COLLAPSE")) == "greedy");
     const bool use_dp = dp_enabled && prims.size() >= (size_t) dp_min_prims;
     static const float c_node = getenv("HAR_BVH_CNODE") ? (float) atof(getenv("HAR_BVH_CNODE")) : 1.f;
+    /* what-if: narrower nodes in the same 80-byte records (children packed into the first W storage positions, octant slots unchanged) */
+    static const int W = getenv("HAR_BVH_WIDTH") ? std::max(2, std::min(8, atoi(getenv("HAR_BVH_WIDTH")))) : 8;
     const float c_prim = prim_cost;
     std::vector<float> dp_cost; std::vector<uint8_t> dp_split;
     if (use_dp) {
@@ -151,12 +153,12 @@ uint32_t build_bvh8(const std::vector<PrimBox> &prims, std::vector<Node8> &nodes
             const BNode &b = B.bn[n];
             float *Cn = dp_cost.data() + n * 9; uint8_t *Sn = dp_split.data() + n * 9;
             const float A = b.box.area();
-            if (b.count) { for (int i = 1; i <= 8; ++i) Cn[i] = A * c_prim * (float) b.count; continue; }
+            if (b.count) { for (int i = 1; i <= W; ++i) Cn[i] = A * c_prim * (float) b.count; continue; }
             const float *Cl = dp_cost.data() + (size_t) b.left * 9, *Cr = dp_cost.data() + (size_t) b.right * 9;
             float best = std::numeric_limits<float>::infinity(); int bk = 1;
-            for (int k = 1; k < 8; ++k) { float c = Cl[k] + Cr[8 - k]; if (c < best) { best = c; bk = k; } }
+            for (int k = 1; k < W; ++k) { float c = Cl[k] + Cr[W - k]; if (c < best) { best = c; bk = k; } }
             Cn[1] = A * c_node + best; Sn[1] = (uint8_t) bk;
-            for (int i = 2; i <= 8; ++i) {
+            for (int i = 2; i <= W; ++i) {
                 float bi = Cn[i - 1]; int ki = 0;
                 for (int k = 1; k < i; ++k) { float c = Cl[k] + Cr[i - k]; if (c < bi) { bi = c; ki = k; } }
                 Cn[i] = bi; Sn[i] = (uint8_t) ki;
@@ -188,12 +190,12 @@ uint32_t build_bvh8(const std::vector<PrimBox> &prims, std::vector<Node8> &nodes
             /* SAH-optimal collapse for the given binary topology (Ylitie, Karras, Laine 2017, sec. 3.2): the children of this wide
              * node are the <= 8 roots the dynamic program chose for the left and right binary subtrees */
             const int k = dp_split[(size_t) w.b * 9 + 1];
-            collect(bn.left, k, child, nc); collect(bn.right, 8 - k, child, nc);
+            collect(bn.left, k, child, nc); collect(bn.right, W - k, child, nc);
         } else {
             child[nc++] = bn.left; child[nc++] = bn.right;
             // greedy collapse: open the internal child with the largest surface area
             for (;;) {
-                if (nc >= 8) break;
+                if (nc >= W) break;
                 int best = -1; float ba = -1.f;
                 for (int i = 0; i < nc; ++i) if (!B.bn[child[i]].count) { float a = B.bn[child[i]].box.area(); if (a > ba) { ba = a; best = i; } }
                 if (best < 0) break;
@@ -233,23 +235,24 @@ uint32_t build_bvh8(const std::vector<PrimBox> &prims, std::vector<Node8> &nodes
         const double org[3] = { n.px, n.py, n.pz };
         n.child_base = (uint32_t) nodes.size();
         n.tri_base = leaf_base + (uint32_t) leaf_order.size();
-        uint32_t n_internal = 0, tri_off = 0;
+        uint32_t n_internal = 0, tri_off = 0; int pos = 0;
         for (int s = 0; s < 8; ++s) {
             int c = child_in_slot[s];
             if (c < 0) continue;
             const BNode &cn = B.bn[c];
             uint8_t *q[6] = { n.qlox, n.qloy, n.qloz, n.qhix, n.qhiy, n.qhiz };
+            const int j = W == 8 ? s : pos++;              /* storage position of the child's box and meta byte */
             for (int a = 0; a < 3; ++a) {
                 double lo = std::floor(((double) cn.box.lo[a] - org[a]) / sc[a]), hi = std::ceil(((double) cn.box.hi[a] - org[a]) / sc[a]);
-                q[a][s] = (uint8_t) std::max(0.0, std::min(255.0, lo));
-                q[3 + a][s] = (uint8_t) std::max(0.0, std::min(255.0, hi));
+                q[a][j] = (uint8_t) std::max(0.0, std::min(255.0, lo));
+                q[3 + a][j] = (uint8_t) std::max(0.0, std::min(255.0, hi));
             }
             if (cn.count) {
-                n.meta[s] = (uint8_t) ((((1u << cn.count) - 1u) << 5) | tri_off);
+                n.meta[j] = (uint8_t) ((((1u << cn.count) - 1u) << 5) | tri_off);
                 for (uint32_t i = 0; i < cn.count; ++i) leaf_order.push_back(B.order[cn.first + i]);
                 tri_off += cn.count;
             } else {
-                n.meta[s] = (uint8_t) ((1u << 5) | (24u + (uint32_t) s));
+                n.meta[j] = (uint8_t) ((1u << 5) | (24u + (uint32_t) s));
                 n.imask |= (uint8_t) (1u << s);
                 ++n_internal;
             }
