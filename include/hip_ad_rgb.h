@@ -269,7 +269,7 @@ int har_integrator_set_grad_emitters(HarIntegrator integrator, float *grad_emitt
  * ad/integrators/common.py:1355-1384).  `grad_positions` = HOST array of top_mesh_count DEVICE pointers; entry m (vertex_count x 3 floats)
  * makes mesh m differentiable, NULL entries do not; har_render_backward then also accumulates into those buffers.  A NULL array switches the
  * feature off.  Like `prb` itself this has no visibility-boundary term (that is prb_reparam / the projective integrators).
- * Implemented for scenes whose BSDFs are all plain `diffuse` and for meshes without vertex normals; fails otherwise.
+ * Implemented for scenes whose BSDFs are all `diffuse` (plain or inside `twosided`) and for meshes without vertex normals; fails otherwise.
  * New vertex positions are installed by creating a new scene (har_scene_create), which rebuilds the acceleration structure. */
 int har_integrator_set_grad_positions(HarIntegrator integrator, HarScene scene, float *const *grad_positions);
 

@@ -670,7 +670,7 @@ static int backward_range(HarScene S, HarIntegrator I, const HarSensor *sensor, 
     if (I->grad_slots_cap < nb3 + ne3 + 3) { if (ws_alloc(I, &I->grad_slots, nb3 + ne3 + 3)) return 1; I->grad_slots_cap = nb3 + ne3 + 3; }
     HIP_TRY(hipMemsetAsync(I->grad_slots, 0, (nb3 + ne3 + 3) * sizeof(float), s));
     if (I->shape_on) {
-        if (I->pos_offset.size() != S->hs.meshes.size() || S->ds.bsdf_types != HAR_BSDF_ONLY_DIFFUSE) return fail("har_integrator_set_grad_positions was called for a different scene");
+        if (I->pos_offset.size() != S->hs.meshes.size() || (S->ds.bsdf_types & 0x7fffffffu) != HAR_BSDF_ONLY_DIFFUSE) return fail("har_integrator_set_grad_positions was called for a different scene");
         HIP_TRY(hipMemsetAsync(I->grad_pos, 0, (size_t) 3 * I->pos_verts * sizeof(float), s));
     }
     HIP_TRY(hipMemsetAsync(I->totals, 0, 4 * sizeof(unsigned long long), s));
@@ -702,7 +702,7 @@ int har_integrator_set_grad_positions(HarIntegrator I, HarScene S, float *const 
     if (grad_positions) {
         if (!S) return fail("null scene");
         /* the hand-derived adjoint of har_shape_grad.h covers plain `diffuse` BSDFs on flat-shaded top-level meshes */
-        if (S->ds.bsdf_types != HAR_BSDF_ONLY_DIFFUSE) return fail("vertex-position gradients are implemented for scenes whose BSDFs are all `diffuse` (no twosided wrappers)");
+        if ((S->ds.bsdf_types & 0x7fffffffu) != HAR_BSDF_ONLY_DIFFUSE) return fail("vertex-position gradients are implemented for scenes whose BSDFs are all `diffuse` (plain or inside `twosided`)");
         const size_t nm = S->hs.meshes.size();
         offset.assign(nm, -1); user.assign(nm, nullptr); count.assign(nm, 0);
         for (size_t m = 0; m < S->hs.top_mesh_count; ++m) {

@@ -653,7 +653,7 @@ __global__ __launch_bounds__(kBlock) void k_shape_adjoint(DScene S, const uint32
             it.w_em = (it.nee_flags & HAR_SHAPE_NEE_SURFACE) ? normalize3(it.q - p) : it.q;
         }
         Vec3 g[3] = { Vec3(0.f), Vec3(0.f), Vec3(0.f) }; uint32_t vid[3];
-        if (!shape_item_adjoint(S, it, geo.vis[i] != 0, Vec3(L4.x, L4.y, L4.z), Vec3(dl4.x, dl4.y, dl4.z), Vec3(s3.x, s3.y, s3.z), nxt, next_valid, np, nn, nd, g, vid)) continue;
+        if (!shape_item_adjoint(S, it, __float_as_uint(items.s2[i].w) & 0xfffffu, geo.vis[i] != 0, Vec3(L4.x, L4.y, L4.z), Vec3(dl4.x, dl4.y, dl4.z), Vec3(s3.x, s3.y, s3.z), nxt, next_valid, np, nn, nd, g, vid)) continue;
         for (int k = 0; k < 3; ++k) {
             const uint32_t e = 3u * ((uint32_t) off + vid[k]);
             if (lds) { atomicAdd(&acc[e], g[k].x); atomicAdd(&acc[e + 1], g[k].y); atomicAdd(&acc[e + 2], g[k].z); }
@@ -924,9 +924,13 @@ void launch_shade(int mode, hipStream_t s, uint32_t grid, const DScene &S, const
                   float *const *grad_tex) {
     dim3 g(grid), b(kBlock);
     const ShapeArrays no_geo{ nullptr, nullptr, nullptr, nullptr, nullptr };
-    if (geo && mode == MODE_PRB_ADJOINT) {        /* vertex-position gradients: `diffuse`-only scenes (checked by har_integrator_set_grad_positions) */
-        hipLaunchKernelGGL((k_shade<MODE_PRB_ADJOINT, HAR_BSDF_ONLY_DIFFUSE, true>), g, b, 0, s, S, P, lane_base, shard_cap, count_in, in, h0, h1, out, count_out, items, item_count,
-                           result, rc, pass_rng, dL, grad_slots, *geo, grad_tex);
+    if (geo && mode == MODE_PRB_ADJOINT) {        /* vertex-position gradients: scenes of `diffuse` BSDFs, plain or `twosided` (checked by har_integrator_set_grad_positions) */
+        if (S.bsdf_types == HAR_BSDF_ONLY_DIFFUSE)
+            hipLaunchKernelGGL((k_shade<MODE_PRB_ADJOINT, HAR_BSDF_ONLY_DIFFUSE, true>), g, b, 0, s, S, P, lane_base, shard_cap, count_in, in, h0, h1, out, count_out, items, item_count,
+                               result, rc, pass_rng, dL, grad_slots, *geo, grad_tex);
+        else
+            hipLaunchKernelGGL((k_shade<MODE_PRB_ADJOINT, HAR_BSDF_CLASSIC_TYPES, true>), g, b, 0, s, S, P, lane_base, shard_cap, count_in, in, h0, h1, out, count_out, items, item_count,
+                               result, rc, pass_rng, dL, grad_slots, *geo, grad_tex);
         return;
     }
     if (grad_tex && mode == MODE_PRB_ADJOINT && rc.mode == 2) {       /* cached bounce of the adjoint replay: commit in place (see k_shade) */

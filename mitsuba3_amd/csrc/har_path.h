@@ -207,11 +207,11 @@ HAR_HD void shade_lane(const DScene &S, const ShadeParams &P, const PathState &s
                 const uint32_t et = S.emitters[em_sampled].type;
                 const bool surface = et == 0u || et == 3u;           /* EmitterFlags::Surface (prb.py:178) */
                 R.nee_flags = 1u | (surface ? 2u : 0u);
-                R.nee_p = surface ? ds.p : ds.d; R.nee_n = ds.n; R.cos_em = wo_em.z;
+                R.nee_p = surface ? ds.p : ds.d; R.nee_n = ds.n; R.cos_em = wo_em.z * side.wo_sign;
             }
         }
     }
-    if (MODE == MODE_PRB_ADJOINT && si.wi.z > 0.f) R.nee_flags |= 4u;
+    if (MODE == MODE_PRB_ADJOINT && side_ok && side.wi.z > 0.f) R.nee_flags |= 4u | (side.wo_sign < 0.f ? 8u : 0u);      /* HAR_SHAPE_LIT, HAR_SHAPE_FLIPPED */
 
     /* ---- continue the path (path.cpp:287-331, prb.py:227-252) */
     PathState &N = R.next;

@@ -4,7 +4,7 @@
  * What the reference obtains by reverse-mode AD through the geometry-attached part of PRBIntegrator.sample
  * (src/python/python/ad/integrators/prb.py:124-141 attached surface interaction, :176-216 emitter sampling from the attached
  * point, :261-297 attached outgoing direction and solid-angle-to-area Jacobian) is written out here by hand for one path vertex
- * on a flat-shaded triangle with a `diffuse` BSDF.  Per vertex the differentiable quantities are
+ * on a flat-shaded triangle with a `diffuse` BSDF (plain or inside `twosided`).  Per vertex the differentiable quantities are
  *
  *   p_att = b0 P0 + b1 P1 + b2 P2                     (barycentrics detached, mesh.cpp:2296)
  *   n     = normalize((P1 - P0) x (P2 - P0))          (= shading normal of a mesh without vertex normals)
@@ -103,20 +103,21 @@ HAR_HD void tex_fetch_grad(const DTexture &T, const TexTaps &l, Vec3 &d_du, Vec3
 struct ShapeItem {
     uint32_t shape, prim; float b1, b2;
     Vec3 d_in; uint32_t next_slot;             /* 0xffffffff: the path ended at this vertex */
-    Vec3 q; uint32_t nee_flags;                /* bit 0: an emitter sample exists, bit 1: it lies on a surface, bit 2: the vertex is lit (cos_i > 0) */
+    Vec3 q; uint32_t nee_flags;                /* bit 0: an emitter sample exists, bit 1: it lies on a surface, bit 2: the vertex is lit (cos_i > 0), bit 3: flipped */
     Vec3 n_e; float cos_em;
     Vec3 w_em;
 };
 #define HAR_SHAPE_NEE         1u
 #define HAR_SHAPE_NEE_SURFACE 2u
 #define HAR_SHAPE_LIT         4u
+#define HAR_SHAPE_FLIPPED     8u          /* twosided BSDF seen from behind: wo is mirrored, cos = -<w, n> (twosided.cpp:124-127) */
 #define HAR_SHAPE_NO_NEXT     0xffffffffu
 
 /* One path vertex: the item's geometry record, the visibility of its emitter sample, the radiance accumulator L after this vertex's
  * subtraction (prb.py:227), the film adjoint dL, NEE's d Lr_dir / d rho (= beta mis em_weight cos / pi), and the next interaction
  * (position / geometric normal, `next_valid` = false for an escaped ray).  Adds to g[0..2]; returns false when the vertex's mesh is
  * not differentiated or nothing contributes. */
-HAR_HD bool shape_item_adjoint(const DScene &S, const ShapeItem &it, bool visible, Vec3 L, Vec3 dl, Vec3 dLr_drho,
+HAR_HD bool shape_item_adjoint(const DScene &S, const ShapeItem &it, uint32_t bsdf, bool visible, Vec3 L, Vec3 dl, Vec3 dLr_drho,
                                bool has_next, bool next_valid, Vec3 next_p, Vec3 next_n, Vec3 next_d, Vec3 g[3], uint32_t vid[3]) {
     const DMesh M = S.meshes[it.shape];
     const uint32_t *f = S.faces + 4 * (size_t) (M.foff + it.prim);
@@ -131,7 +132,8 @@ HAR_HD bool shape_item_adjoint(const DScene &S, const ShapeItem &it, bool visibl
         v.duv0[0] = r1[6] - r0[6]; v.duv0[1] = r1[7] - r0[7]; v.duv1[0] = r2[6] - r0[6]; v.duv1[1] = r2[7] - r0[7];
         uv_x = fma_(v.duv0[0], it.b1, fma_(v.duv1[0], it.b2, r0[6])); uv_y = fma_(v.duv0[1], it.b1, fma_(v.duv1[1], it.b2, r0[7]));
     }
-    const DBsdf B = S.bsdfs[M.bsdf];
+    const DBsdf B = S.bsdfs[bsdf];             /* the record serving this side (TwoSidedBRDF picks front / back) */
+    const float sign = (it.nee_flags & HAR_SHAPE_FLIPPED) ? -1.f : 1.f;
     TexTaps taps; const Vec3 rho = bsdf_reflectance(S, B, uv_x, uv_y, taps);
     Vec3 rho_du(0.f), rho_dv(0.f);
     if (B.texture >= 0) tex_fetch_grad(S.textures[B.texture], taps, rho_du, rho_dv);
@@ -145,7 +147,7 @@ HAR_HD bool shape_item_adjoint(const DScene &S, const ShapeItem &it, bool visibl
         v.nee.on = true; v.nee.attached = (it.nee_flags & HAR_SHAPE_NEE_SURFACE) != 0u;
         v.nee.target = it.q; v.nee.normal = it.n_e; v.nee.w = it.w_em;
         const float s = k.x * rho.x + k.y * rho.y + k.z * rho.z;
-        v.nee.cos_bar = s / it.cos_em; v.nee.a = v.nee.attached ? s : 0.f;
+        v.nee.cos_bar = sign * s / it.cos_em; v.nee.a = v.nee.attached ? s : 0.f;       /* cos_em = sign <w, n> */
         v.uv_bar[0] += k.x * rho_du.x + k.y * rho_du.y + k.z * rho_du.z;
         v.uv_bar[1] += k.x * rho_dv.x + k.y * rho_dv.y + k.z * rho_dv.z;
         any = true;
@@ -156,7 +158,7 @@ HAR_HD bool shape_item_adjoint(const DScene &S, const ShapeItem &it, bool visibl
         const Vec3 k = dl * L;
         const Vec3 e1 = v.p1 - v.p0, e2 = v.p2 - v.p0;
         const Vec3 n = normalize3(cross3(e1, e2));
-        const float cos_ind = dot3(next_d, n);
+        const float cos_ind = sign * dot3(next_d, n);
         const bool f_on = lit && cos_ind > 0.f;
         v.ind.on = true; v.ind.attached = next_valid;
         v.ind.target = next_p; v.ind.normal = next_n; v.ind.w = next_d;
@@ -166,7 +168,7 @@ HAR_HD bool shape_item_adjoint(const DScene &S, const ShapeItem &it, bool visibl
             if (rho.x != 0.f) { s += k.x; v.uv_bar[0] += k.x * rho_du.x / rho.x; v.uv_bar[1] += k.x * rho_dv.x / rho.x; }
             if (rho.y != 0.f) { s += k.y; v.uv_bar[0] += k.y * rho_du.y / rho.y; v.uv_bar[1] += k.y * rho_dv.y / rho.y; }
             if (rho.z != 0.f) { s += k.z; v.uv_bar[0] += k.z * rho_du.z / rho.z; v.uv_bar[1] += k.z * rho_dv.z / rho.z; }
-            v.ind.cos_bar = s / cos_ind;
+            v.ind.cos_bar = sign * s / cos_ind;
         }
         v.ind.a = next_valid ? k.x + k.y + k.z : 0.f;
         any = any || k.x != 0.f || k.y != 0.f || k.z != 0.f;

@@ -896,7 +896,7 @@ static V3 prb_sample(const Scene &sc, Pcg32 &rng, Ray ray, uint32_t max_depth, u
             double g[kShapeSlots]; for (int k = 0; k < kShapeSlots; ++k) g[k] = 0.0;
             const double dl[3] = { dL.x, dL.y, dL.z };
             auto value_cos = [&](const Dn3 &wo_world, bool lit, Dn out[3]) {       // SmoothDiffuse::eval with wo = si.to_local(wo_world)
-                Dn cos_o = ddot(wo_world, a.sn);                                   // Frame3f::cos_theta(to_local(v)) = dot(v, n)
+                Dn cos_o = ddot(wo_world, a.sn) * (double) bsdf.wo_sign;           // Frame3f::cos_theta(to_local(v)) = dot(v, n); twosided.cpp:124-127 mirrors wo
                 const Dn *r[3] = { &rho.x, &rho.y, &rho.z };
                 for (int c = 0; c < 3; ++c) out[c] = lit ? (*r[c]) * (double) InvPi * cos_o : Dn(0.0);
             };
@@ -908,7 +908,7 @@ static V3 prb_sample(const Scene &sc, Pcg32 &rng, Ray ray, uint32_t max_depth, u
                     Dn3 dir; dir_and_jacobian(a.p, dn3(ds.p), dn3(ds.n), dir, J);
                     dsd = replace_grad3(ds.d.x, ds.d.y, ds.d.z, dir);
                 }
-                Dn f[3]; value_cos(dsd, si.wi.z > 0.f && wo_em.z > 0.f, f);
+                Dn f[3]; value_cos(dsd, bsdf.ok && bsdf.wi.z > 0.f && wo_em.z * bsdf.wo_sign > 0.f, f);
                 const double w[3] = { (double) beta_cur.x * mis_em * em_weight.x, (double) beta_cur.y * mis_em * em_weight.y, (double) beta_cur.z * mis_em * em_weight.z };
                 for (int c = 0; c < 3; ++c) {
                     if (w[c] == 0.0 || J.v == 0.0) continue;
@@ -925,7 +925,7 @@ static V3 prb_sample(const Scene &sc, Pcg32 &rng, Ray ray, uint32_t max_depth, u
                     wo_world = replace_grad3(ray_next.d.x, ray_next.d.y, ray_next.d.z, dir);
                 }
                 V3 wo_l = si.to_local(ray_next.d);
-                Dn f[3]; value_cos(wo_world, si.wi.z > 0.f && wo_l.z > 0.f, f);
+                Dn f[3]; value_cos(wo_world, bsdf.ok && bsdf.wi.z > 0.f && wo_l.z * bsdf.wo_sign > 0.f, f);
                 const double Lc[3] = { L.x, L.y, L.z };
                 for (int c = 0; c < 3; ++c) {
                     if (Lc[c] == 0.0) continue;
@@ -1330,7 +1330,7 @@ static int prb_backward_impl(void *scene, const OrcSensor *sp, const float *grad
                              float *grad_emitters, const uint8_t *pos_mask, double *const *grad_positions, OrcStats *stats, int threads) {
     Scene &sc = *(Scene *) scene; const OrcSensor &s = *sp;
     if (pos_mask) {           /* the attached-geometry restatement covers `diffuse` BSDFs on flat-shaded top-level meshes */
-        for (const BsdfRecord &b : sc.bsdfs) if (b.p.type != 0 || (b.p.flags & 1u)) return -2;
+        for (const BsdfRecord &b : sc.bsdfs) if (b.p.type != 0) return -2;           /* `diffuse`, plain or inside `twosided` */
         for (size_t m = 0; m < sc.meshes.size(); ++m) if (pos_mask[m] && ((sc.meshes[m].flags & 1u) || m >= sc.top_count)) return -3;
     }
     uint64_t total = (uint64_t) s.crop_width * s.crop_height * spp;

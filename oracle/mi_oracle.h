@@ -199,7 +199,7 @@ void orc_scene_set_emitter_radiance(void *scene, uint32_t emitter, const float r
 void orc_scene_set_hide_emitters(void *scene, int hide);
 /* ... plus the gradient w.r.t. the VERTEX POSITIONS of the meshes with pos_mask[m] != 0 (prb.py:124-141 attached surface interaction,
  * :176-216 emitter sampling from the attached point, :261-297 attached wo and solid-angle-to-area Jacobian): grad_positions[m] holds 3
- * doubles per vertex and is added to.  Restated over forward-mode dual numbers (orc_dual.h) for plain `diffuse` BSDFs and flat-shaded
+ * doubles per vertex and is added to.  Restated over forward-mode dual numbers (orc_dual.h) for `diffuse` BSDFs (plain or inside `twosided`) and flat-shaded
  * top-level meshes; returns -2 / -3 outside that domain.  PARITY UNPINNED: the reference's own shape-gradient tests
  * (src/python/python/tests/test_ad_integrators.py) need Dr.Jit and are not runnable here. */
 int orc_render_prb_backward_shape(void *scene, const OrcSensor *s, const float *grad_in, uint32_t seed, uint32_t spp, int32_t max_depth,

@@ -158,7 +158,7 @@ int hh_render(void *h, const HarSensor *sensor, int mode, uint32_t seed, uint32_
 int hh_render_backward_shape(void *h, const HarSensor *sensor, const float *adj, uint32_t seed, uint32_t spp, int32_t max_depth, int32_t rr_depth,
                              double *const *grad) {
     HScene *H = (HScene *) h; const DScene &S = H->ds;
-    if (S.bsdf_types != HAR_BSDF_ONLY_DIFFUSE) return -2;
+    if ((S.bsdf_types & 0x7fffffffu) != HAR_BSDF_ONLY_DIFFUSE) return -2;
     DSensor C; std::string e; if (!lower_sensor(*sensor, C, e)) return -1;
     const uint64_t total = (uint64_t) C.crop_w * C.crop_h * spp;
     uint32_t log_spp = 0xffffffffu; for (uint32_t k = 0; k < 32; ++k) if ((1u << k) == spp) log_spp = k;
@@ -178,7 +178,7 @@ int hh_render_backward_shape(void *h, const HarSensor *sensor, const float *adj,
             PathState st = st0; bool alive = P.max_depth != 0;
             while (alive) {
                 Hit hit; HostStack stack; accel_trace<false>(S.accel, st.o, st.d, st.maxt, hit, stack, status);
-                ShadeResult R; shade_lane<MODE_PRB_PRIMAL, HAR_BSDF_ONLY_DIFFUSE>(S, P, st, hit, R);
+                ShadeResult R; shade_lane<MODE_PRB_PRIMAL, HAR_BSDF_CLASSIC_TYPES>(S, P, st, hit, R);
                 if (R.add_emission) L = L + R.em_b;
                 if (R.item && R.item_ray) { Hit sh; HostStack s2; if (!accel_trace<true>(S.accel, R.sh_o, R.sh_d, R.sh_maxt, sh, s2, status)) L = L + R.contrib; }
                 alive = R.alive; st = R.next;
@@ -188,7 +188,7 @@ int hh_render_backward_shape(void *h, const HarSensor *sensor, const float *adj,
         PathState st = st0; bool alive = P.max_depth != 0;
         Hit hit; { HostStack stack; if (alive) accel_trace<false>(S.accel, st.o, st.d, st.maxt, hit, stack, status); }
         while (alive) {
-            ShadeResult R; shade_lane<MODE_PRB_ADJOINT, HAR_BSDF_ONLY_DIFFUSE>(S, P, st, hit, R);
+            ShadeResult R; shade_lane<MODE_PRB_ADJOINT, HAR_BSDF_CLASSIC_TYPES>(S, P, st, hit, R);
             if (R.add_emission) L = L - R.em_b;
             bool visible = false;
             if (R.item && R.item_ray) { Hit sh; HostStack s2; visible = !accel_trace<true>(S.accel, R.sh_o, R.sh_d, R.sh_maxt, sh, s2, status); if (visible) L = L - R.contrib; }
@@ -205,7 +205,7 @@ int hh_render_backward_shape(void *h, const HarSensor *sensor, const float *adj,
                 const SurfInt si = compute_si(S, st.d, hit.t, hit.u, hit.v, hit.prim, hit.shape, hit.inst);
                 it.w_em = (it.nee_flags & HAR_SHAPE_NEE_SURFACE) ? normalize3(it.q - si.p) : it.q;
                 Vec3 g[3] = { Vec3(0.f), Vec3(0.f), Vec3(0.f) }; uint32_t vid[3];
-                if (shape_item_adjoint(S, it, visible, L, dl, R.dLr_drho, R.alive, next_valid, np, nn, R.next.d, g, vid)) {
+                if (shape_item_adjoint(S, it, R.bsdf, visible, L, dl, R.dLr_drho, R.alive, next_valid, np, nn, R.next.d, g, vid)) {
                     double *dst = grad[hit.shape];
                     for (int k = 0; k < 3; ++k) { dst[3 * (size_t) vid[k]] += g[k].x; dst[3 * (size_t) vid[k] + 1] += g[k].y; dst[3 * (size_t) vid[k] + 2] += g[k].z; }
                 }

@@ -680,14 +680,16 @@ def _grid_floor(mi, d, n):
     return d
 
 
-@pytest.mark.parametrize("which", ["slab", "slab_textured", "slab_env", "cbox", "cbox_grid", "cbox_nocache"])
+@pytest.mark.parametrize("which", ["slab", "slab_textured", "slab_env", "slab_twosided", "cbox", "cbox_grid", "cbox_nocache"])
 def test_prb_vertex_position_gradients(mi, O, which):
     """har_integrator_set_grad_positions: the wavefront adjoint (k_shade<ADJOINT, SHAPE> geometry records, visibility from k_resolve,
     k_shape_adjoint with the next bounce's detached interaction) vs the oracle's dual-number restatement, vertex by vertex; the colour
     gradients of the same call must not change"""
     from tests.test_cpu_host import oracle_scene_from
-    from tests.test_shape_gradients_cpu import slab_scene, cbox_mesh_scene, mesh_index
-    if which.startswith("cbox"):
+    from tests.test_shape_gradients_cpu import slab_scene, cbox_mesh_scene, twosided_slab_scene, mesh_index
+    if which == "slab_twosided":
+        res = 24; d = twosided_slab_scene(mi, res); names = ["floor", "ceiling", "sheet"]
+    elif which.startswith("cbox"):
         res = 32; d = cbox_mesh_scene(mi, res); names = ["small-box", "large-box", "floor"]
         if which == "cbox_grid":
             d = _grid_floor(mi, d, 36)

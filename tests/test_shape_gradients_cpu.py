@@ -44,6 +44,19 @@ def slab_scene(mi, res=24, textured=False, env=False):
     return d
 
 
+def twosided_slab_scene(mi, res=16):
+    """the slab scene with `twosided` diffuse BSDFs and a free-floating sheet whose geometric normal points away from the camera and the light:
+    the camera and the emitter samples meet its BACK side (TwoSidedBRDF mirrors wo, twosided.cpp:124-127)"""
+    d = slab_scene(mi, res)
+    for k in ("floor", "ceiling"):
+        d[k]["bsdf"] = {"type": "twosided", "m": d[k]["bsdf"]}
+    sheet = np.array([[-0.6, 0.9, -0.5], [0.5, 1.0, -0.6], [0.6, 1.1, 0.5], [-0.5, 0.95, 0.6]], np.float32)
+    d["sheet"] = {"type": "mesh", "positions": sheet, "faces": np.array([[0, 1, 2], [0, 2, 3]], np.uint32),           # normal ~ -y
+                  "bsdf": {"type": "twosided", "front": {"type": "diffuse", "reflectance": {"type": "rgb", "value": [0.2, 0.7, 0.4]}},
+                           "back": {"type": "diffuse", "reflectance": {"type": "rgb", "value": [0.8, 0.3, 0.6]}}}}
+    return d
+
+
 def mesh_index(scene, key):
     return [m["key"] for m in scene.meshes].index(key)
 
@@ -123,12 +136,14 @@ def product_host_gradients(O, L, scene, sensor, grad_in, meshes, seed, spp, max_
     return g
 
 
-@pytest.mark.parametrize("which", ["slab", "slab_textured", "slab_env", "cbox"])
+@pytest.mark.parametrize("which", ["slab", "slab_textured", "slab_env", "slab_twosided", "cbox"])
 def test_product_host_adjoint_matches_oracle(mi, O, which):
     """har_shape_grad.h (hand-derived reverse mode, fp32) against the oracle's dual numbers (fp64), vertex by vertex, same seed"""
     from tests.test_cpu_host import oracle_scene_from
     if which == "cbox":
         scene = mi.load_dict(cbox_mesh_scene(mi, 20)); names = ["small-box", "large-box", "floor"]; res = 20
+    elif which == "slab_twosided":
+        res = 16; scene = mi.load_dict(twosided_slab_scene(mi, res)); names = ["floor", "ceiling", "sheet"]
     else:
         res = 16
         scene = mi.load_dict(slab_scene(mi, res, textured=which == "slab_textured", env=which == "slab_env")); names = ["floor"] + ([] if which == "slab_env" else ["ceiling"])
