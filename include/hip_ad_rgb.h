@@ -120,8 +120,9 @@ typedef struct HarSensor {
     float near_clip, far_clip;
     uint32_t film_width, film_height;
     uint32_t crop_offset_x, crop_offset_y, crop_width, crop_height;
-    uint32_t rfilter;             /* 0 = box, 1 = gaussian (src/rfilters/gaussian.cpp) */
-    float    rfilter_stddev;
+    uint32_t rfilter;             /* 0 box, 1 gaussian, 2 tent, 3 mitchell, 4 catmullrom, 5 lanczos (src/rfilters/ *.cpp) */
+    float    rfilter_stddev;      /* parameter 0: gaussian `stddev`, tent `radius`, mitchell `B`, lanczos `lobes` */
+    float    rfilter_param1;      /* parameter 1: mitchell `C` */
 } HarSensor;
 
 /* counters of one render call (all lanes), read back with har_render_stats */
@@ -301,7 +302,7 @@ int har_transform_look_at(const float origin[3], const float target[3], const fl
 int har_transform_mul(const float a[32], const float b[32], float out[32]);
 int har_transform_inverse(const float a[32], float out[32]);
 /* PerspectiveCamera ctor + update_camera_transforms (src/sensors/perspective.cpp:137-198),
- * parse_fov (src/render/sensor.cpp:142-190), HDRFilm crop window, rfilter: 0 box / 1 gaussian */
+ * parse_fov (src/render/sensor.cpp:142-190), HDRFilm crop window, rfilter type + its first parameter (rfilter_param1 is set to 1/3, mitchell's default C) */
 int har_perspective_sensor(const float to_world[32], double fov, const char *fov_axis, float near_clip,
                            float far_clip, uint32_t width, uint32_t height, uint32_t crop_x,
                            uint32_t crop_y, uint32_t crop_w, uint32_t crop_h, uint32_t rfilter,

@@ -378,12 +378,21 @@ class Film:
         if pf != 'rgb':
             raise RuntimeError("hdrfilm: pixel_format \"%s\" is not supported by hip_ad_rgb (only 'rgb')" % pf)
         rf = next((v for v in props.values() if isinstance(v, dict) and 'type' in v), {'type': 'gaussian'})     # the film's only child object is its rfilter
-        if rf['type'] == 'gaussian':
+        self.rf_param1 = 1.0 / 3.0
+        if rf['type'] == 'gaussian':                     # src/rfilters/gaussian.cpp:48-55
             self.rfilter = 1; self.stddev = float(rf.get('stddev', 0.5))
         elif rf['type'] == 'box':
             self.rfilter = 0; self.stddev = 0.5
+        elif rf['type'] == 'tent':                       # tent.cpp:48-52
+            self.rfilter = 2; self.stddev = float(rf.get('radius', 1.0))
+        elif rf['type'] == 'mitchell':                   # mitchell.cpp:50-58
+            self.rfilter = 3; self.stddev = float(rf.get('B', 1.0 / 3.0)); self.rf_param1 = float(rf.get('C', 1.0 / 3.0))
+        elif rf['type'] == 'catmullrom':
+            self.rfilter = 4; self.stddev = 0.0
+        elif rf['type'] == 'lanczos':                    # lanczos.cpp:52-55
+            self.rfilter = 5; self.stddev = float(int(rf.get('lobes', 3)))
         else:
-            raise RuntimeError("Plugin \"%s\" not found for variant hip_ad_rgb (rfilters: box, gaussian)" % rf['type'])
+            raise RuntimeError("Plugin \"%s\" not found for variant hip_ad_rgb (rfilters: box, gaussian, tent, mitchell, catmullrom, lanczos)" % rf['type'])
 
     def size(self):
         return (self.width, self.height)
@@ -423,6 +432,7 @@ class Sensor:
         rc = lib().har_perspective_sensor(_fp(self.to_world.data), fov, fov_axis.encode(), self.near_clip, self.far_clip,
                                           f.width, f.height, f.crop_offset[0], f.crop_offset[1], f.crop_size_[0], f.crop_size_[1],
                                           f.rfilter, f.stddev, C.byref(s))
+        s.rfilter_param1 = f.rf_param1
         if rc == 2:
             raise RuntimeError("The 'fov_axis' parameter must be set to one of 'smaller', 'larger', 'diagonal', 'x', or 'y'!")
         if rc == 3:

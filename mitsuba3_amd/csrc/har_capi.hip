@@ -278,7 +278,7 @@ int check_common(HarSceneImpl *S, HarIntegratorImpl *I, const HarSensor *sensor,
     if (!S || !I || !sensor) return fail("null scene / integrator / sensor");
     std::string e;
     if (!lower_sensor(*sensor, C, e)) return fail(e);
-    if (C.rfilter == 1 && 2 * (uint32_t) ceilf(C.radius - .5f) + 1 > HAR_MAX_FILTER_TAPS) return fail("reconstruction filter radius too large (max 9 taps)");
+    if (C.rfilter != 0 && 2 * (uint32_t) ceilf(C.radius - .5f) + 1 > HAR_MAX_FILTER_TAPS) return fail("reconstruction filter radius too large (max 9 taps)");
     if (spp == 0) return fail("spp must be > 0");
     uint64_t total = (uint64_t) C.crop_w * C.crop_h * spp;
     /* 2^32 wavefront limit of JIT variants (integrator.cpp:276-294, common.py:358-363) */

@@ -52,6 +52,7 @@ HAR_HD float sign_(float x) { return as_f32(0x3f800000u | (as_u32(x) & 0x8000000
 HAR_HD bool  finite_(float x) { return (as_u32(x) & 0x7f800000u) != 0x7f800000u; }
 
 #define HAR_PI        3.14159265358979323846f
+#define HAR_EPSILON   5.9604644775390625e-8f      /* dr::Epsilon<float> = 2^-24 */
 #define HAR_INV_PI    0.31830988618379067154f
 #define HAR_INF       as_f32(0x7f800000u)
 #define HAR_LARGEST   3.402823466e+38f

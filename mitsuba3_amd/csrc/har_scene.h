@@ -54,7 +54,8 @@ struct DSensor {
     float to_world[16];
     float near_clip, far_clip;
     uint32_t crop_x, crop_y, crop_w, crop_h;
-    uint32_t rfilter;            /* 0 box, 1 gaussian */
+    uint32_t rfilter;            /* 0 box, 1 gaussian, 2 tent, 3 mitchell, 4 catmullrom, 5 lanczos */
+    float rf_p0, rf_p1;          /* filter parameters (HarSensor::rfilter_stddev / rfilter_param1) */
     float radius;
     float coeff[10];             /* GaussianFilter::m_coeff (LLVM branch) */
 };
@@ -436,7 +437,33 @@ HAR_HD float estrin10(float x, const float *c) {
     float c0 = fma_(x4, b1, b0);
     return fma_(x8, a4, c0);
 }
-HAR_HD float rfilter_eval(const DSensor &C, float x) { return fmaxf(estrin10(x * x, C.coeff), 0.f); }
+/* ... and the other reconstruction filters: tent.cpp:54-56, mitchell.cpp:60-79, catmullrom.cpp:39-54, lanczos.cpp:57-67 */
+HAR_HD float rfilter_eval(const DSensor &C, float x) {
+    switch (C.rfilter) {
+    case 2: return fmaxf(0.f, 1.f - fabsf(x * (1.f / C.radius)));
+    case 3: {
+        x = fabsf(x); const float x2 = x * x, x3 = x2 * x, B = C.rf_p0, Cc = C.rf_p1;
+        const float a3 = (12.f - 9.f * B - 6.f * Cc), a2 = (-18.f + 12.f * B + 6.f * Cc), a0 = (6.f - 2.f * B),
+                    b3 = (-B - 6.f * Cc), b2 = (6.f * B + 30.f * Cc), b1 = (-12.f * B - 48.f * Cc), b0 = (8.f * B + 24.f * Cc);
+        const float r = (1.f / 6.f) * (x < 1.f ? fma_(a3, x3, fma_(a2, x2, a0)) : fma_(b3, x3, fma_(b2, x2, fma_(b1, x, b0))));
+        return x < 2.f ? r : 0.f;
+    }
+    case 4: {
+        x = fabsf(x); const float x2 = x * x, x3 = x2 * x, B = 0.f, Cc = .5f;
+        const float r = (1.f / 6.f) * (x < 1.f ? (12.f - 9.f * B - 6.f * Cc) * x3 + (-18.f + 12.f * B + 6.f * Cc) * x2 + (6.f - 2.f * B)
+                                               : (-B - 6.f * Cc) * x3 + (6.f * B + 30.f * Cc) * x2 + (-12.f * B - 48.f * Cc) * x + (8.f * B + 24.f * Cc));
+        return x < 2.f ? r : 0.f;
+    }
+    case 5: {
+        x = fabsf(x);
+        const float x1 = HAR_PI * x, x2 = x1 / C.radius;
+        float s1, c1, s2, c2; sincos_(x1, s1, c1); sincos_(x2, s2, c2);
+        const float r = (s1 * s2) / (x1 * x2);
+        return x < HAR_EPSILON ? 1.f : (x > C.radius ? 0.f : r);
+    }
+    default: return fmaxf(estrin10(x * x, C.coeff), 0.f);
+    }
+}
 
 /* lane -> pixel/sample mapping of SamplingIntegrator::render (integrator.cpp:322-339) and
  * render_sample (:448-466): returns integer pixel (crop-relative) and jittered film position */

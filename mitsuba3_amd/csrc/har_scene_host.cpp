@@ -378,13 +378,19 @@ bool lower_scene(const HarSceneDesc &d, HostScene &hs, std::string &err) {
 
 bool lower_sensor(const HarSensor &in, DSensor &out, std::string &err) {
     if (in.crop_width == 0 || in.crop_height == 0) { err = "empty crop window"; return false; }
-    if (in.rfilter > 1) { err = "unsupported reconstruction filter (box and gaussian are implemented)"; return false; }
+    if (in.rfilter > 5) { err = "unsupported reconstruction filter (box, gaussian, tent, mitchell, catmullrom and lanczos are implemented)"; return false; }
     std::memcpy(out.s2c, in.sample_to_camera, 64); std::memcpy(out.to_world, in.to_world, 64);
     out.near_clip = in.near_clip; out.far_clip = in.far_clip;
     out.crop_x = in.crop_offset_x; out.crop_y = in.crop_offset_y; out.crop_w = in.crop_width; out.crop_h = in.crop_height;
     out.rfilter = in.rfilter;
     std::memset(out.coeff, 0, sizeof(out.coeff));
+    out.rf_p0 = in.rfilter_stddev; out.rf_p1 = in.rfilter_param1;
     if (in.rfilter == 0) { out.radius = 0.5f; return true; }
+    if (in.rfilter == 2 || in.rfilter == 5) {                  /* tent: radius; lanczos: radius = lobes */
+        if (!(in.rfilter_stddev > 0.f)) { err = "reconstruction filter: the radius / lobe count must be positive"; return false; }
+        out.radius = in.rfilter == 5 ? (float) (int) in.rfilter_stddev : in.rfilter_stddev; return true;
+    }
+    if (in.rfilter == 3 || in.rfilter == 4) { out.radius = 2.f; return true; }
     float stddev = in.rfilter_stddev;
     out.radius = 4 * stddev;
     // Remez fit of exp(-x/2), scaled by 1/stddev^(2i) and shifted to reach 0 at the radius

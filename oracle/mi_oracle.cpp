@@ -551,7 +551,7 @@ static inline Ray sensor_sample_ray(const OrcSensor &s, float px, float py) {
     return ray;
 }
 
-struct RFilter { uint32_t type; float radius; float coeff[10]; };
+struct RFilter { uint32_t type; float radius; float coeff[10]; float p0, p1; };
 /* GaussianFilter ctor + eval, LLVM branch (src/rfilters/gaussian.cpp:48-101) */
 static inline float estrin10(float x, const float *c) {
     float x2 = x * x, x4 = x2 * x2, x8 = x4 * x4;
@@ -560,9 +560,12 @@ static inline float estrin10(float x, const float *c) {
     float c0 = fmadd(x4, b1, b0), c1 = b2;
     return fmadd(x8, c1, c0);
 }
-static RFilter make_rfilter(uint32_t type, float stddev) {
-    RFilter f{}; f.type = type;
+static RFilter make_rfilter(uint32_t type, float stddev, float param1 = 0.f) {
+    RFilter f{}; f.type = type; f.p0 = stddev; f.p1 = param1;
     if (type == 0) { f.radius = 0.5f; return f; }
+    if (type == 2) { f.radius = stddev; return f; }                       // TentFilter (tent.cpp:48-52)
+    if (type == 3 || type == 4) { f.radius = 2.f; return f; }            // MitchellNetravaliFilter (mitchell.cpp:50-58), CatmullRomFilter
+    if (type == 5) { f.radius = stddev; return f; }                       // LanczosSincFilter (lanczos.cpp:52-55): radius = lobes
     f.radius = 4 * stddev;
     const double coeff[10] = { 9.992604880e-1, -4.977025247e-1, 1.222248550e-1, -1.932406282e-2, 2.136713061e-3,
                                -1.679873860e-4, 9.202145248e-6, -3.329417433e-7, 7.128382794e-9, -6.821193280e-11 };
@@ -571,7 +574,31 @@ static RFilter make_rfilter(uint32_t type, float stddev) {
     f.coeff[0] -= estrin10(f.radius * f.radius, f.coeff);
     return f;
 }
-static inline float rfilter_eval(const RFilter &f, float x) { return std::fmax(estrin10(x * x, f.coeff), 0.f); }
+static inline float rfilter_eval(const RFilter &f, float x) {
+    switch (f.type) {
+    case 2: return std::fmax(0.f, 1.f - std::fabs(x * (1.f / f.radius)));                        // tent.cpp:54-56
+    case 3: {                                                                                     // mitchell.cpp:60-79
+        x = std::fabs(x); float x2 = x * x, x3 = x2 * x; const float B = f.p0, Cc = f.p1;
+        float a3 = (12.f - 9.f * B - 6.f * Cc), a2 = (-18.f + 12.f * B + 6.f * Cc), a0 = (6.f - 2.f * B),
+              b3 = (-B - 6.f * Cc), b2 = (6.f * B + 30.f * Cc), b1 = (-12.f * B - 48.f * Cc), b0 = (8.f * B + 24.f * Cc);
+        float r = (1.f / 6.f) * (x < 1.f ? fmadd(a3, x3, fmadd(a2, x2, a0)) : fmadd(b3, x3, fmadd(b2, x2, fmadd(b1, x, b0))));
+        return x < 2.f ? r : 0.f;
+    }
+    case 4: {                                                                                     // catmullrom.cpp:39-54 (B = 0, C = 1/2, no fmadd)
+        x = std::fabs(x); float x2 = x * x, x3 = x2 * x; const float B = 0.f, Cc = .5f;
+        float r = (1.f / 6.f) * (x < 1.f ? (12.f - 9.f * B - 6.f * Cc) * x3 + (-18.f + 12.f * B + 6.f * Cc) * x2 + (6.f - 2.f * B)
+                                         : (-B - 6.f * Cc) * x3 + (6.f * B + 30.f * Cc) * x2 + (-12.f * B - 48.f * Cc) * x + (8.f * B + 24.f * Cc));
+        return x < 2.f ? r : 0.f;
+    }
+    case 5: {                                                                                     // lanczos.cpp:57-67
+        x = std::fabs(x);
+        float x1 = Pi * x, x2 = x1 / f.radius, c1, c2;
+        float r = (sincos(x1, &c1) * sincos(x2, &c2)) / (x1 * x2);
+        return x < Epsilon ? 1.f : (x > f.radius ? 0.f : r);
+    }
+    default: return std::fmax(estrin10(x * x, f.coeff), 0.f);
+    }
+}
 
 /* ImageBlock::put (src/render/imageblock.cpp:187-258 box, :444-540 coalesced JIT) */
 static inline void film_put(const OrcSensor &s, const RFilter &rf, float px, float py, const float v[4], float *film) {
@@ -978,7 +1005,7 @@ static int render_forward(Scene &sc, const OrcSensor &s, uint32_t seed, uint32_t
     uint64_t total = (uint64_t) s.crop_width * s.crop_height * spp;
     if (lb == 0 && le == 0) le = total;
     if (le > total || lb > le || total > 0xffffffffull) return -1;
-    RFilter rf = make_rfilter(s.rfilter, s.rfilter_stddev);
+    RFilter rf = make_rfilter(s.rfilter, s.rfilter_stddev, s.rfilter_param1);
     threads = resolve_threads(threads);
     size_t fsz = (size_t) s.crop_width * s.crop_height * 4;
     std::vector<std::vector<float>> films(threads);
@@ -1010,7 +1037,7 @@ static int render_forward_passes(Scene &sc, const OrcSensor &s, uint32_t seed, u
     if (lb == 0 && le == 0) le = total;
     if (le > total || lb > le || total > 0xffffffffull) return -1;
     const uint32_t n_passes = spp / spp_per_pass;
-    RFilter rf = make_rfilter(s.rfilter, s.rfilter_stddev);
+    RFilter rf = make_rfilter(s.rfilter, s.rfilter_stddev, s.rfilter_param1);
     threads = resolve_threads(threads);
     size_t fsz = (size_t) s.crop_width * s.crop_height * 4;
     std::vector<std::vector<float>> films(threads);
@@ -1083,7 +1110,7 @@ static std::vector<SpiralBlock> spiral_blocks(uint32_t size_x, uint32_t size_y, 
 static int render_scalar(Scene &sc, const OrcSensor &s, uint32_t seed, uint32_t spp, int32_t max_depth, int32_t rr_depth,
                          uint32_t n_threads, float *film, OrcStats *stats, uint32_t *block_size_out) {
     const uint32_t W = s.crop_width, H = s.crop_height;
-    RFilter rf = make_rfilter(s.rfilter, s.rfilter_stddev);
+    RFilter rf = make_rfilter(s.rfilter, s.rfilter_stddev, s.rfilter_param1);
     // discretised filter (rfilter.cpp:11-26): MI_FILTER_RESOLUTION = 31
     constexpr int RES = 31;
     float values[RES + 1];
@@ -1335,7 +1362,7 @@ static int prb_backward_impl(void *scene, const OrcSensor *sp, const float *grad
     }
     uint64_t total = (uint64_t) s.crop_width * s.crop_height * spp;
     if (total > 0xffffffffull) return -1;
-    RFilter rf = make_rfilter(s.rfilter, s.rfilter_stddev);
+    RFilter rf = make_rfilter(s.rfilter, s.rfilter_stddev, s.rfilter_param1);
     threads = resolve_threads(threads);
     uint32_t W = s.crop_width, H = s.crop_height;
     size_t npx = (size_t) W * H;
@@ -1465,9 +1492,10 @@ void orc_pcg32_seed(uint64_t initstate, uint64_t initseq, uint64_t si[2]) { Pcg3
 uint32_t orc_pcg32_next_uint32(uint64_t si[2]) { Pcg32 r; r.state = si[0]; r.inc = si[1]; uint32_t v = r.next_uint32(); si[0] = r.state; return v; }
 float orc_pcg32_next_float32(uint64_t si[2]) { Pcg32 r; r.state = si[0]; r.inc = si[1]; float v = r.next_float32(); si[0] = r.state; return v; }
 void orc_sampler_stream(uint32_t seed, uint32_t lane, uint32_t n, float *out) { Pcg32 r = sampler_seed(seed, lane); for (uint32_t i = 0; i < n; ++i) out[i] = r.next_float32(); }
+float orc_rfilter_eval2(uint32_t type, float p0, float p1, float x) { RFilter f = make_rfilter(type, p0, p1); return type == 0 ? (x >= -.5f && x < .5f ? 1.f : 0.f) : rfilter_eval(f, x); }
 float orc_rfilter_eval(uint32_t type, float stddev, float x) { RFilter f = make_rfilter(type, stddev); return type == 0 ? (std::fabs(x) <= .5f ? 1.f : 0.f) : rfilter_eval(f, x); }
 void orc_film_put(const OrcSensor *s, uint32_t n, const float *px, const float *py, const float *values4, float *film) {
-    RFilter rf = make_rfilter(s->rfilter, s->rfilter_stddev);
+    RFilter rf = make_rfilter(s->rfilter, s->rfilter_stddev, s->rfilter_param1);
     for (uint32_t i = 0; i < n; ++i) film_put(*s, rf, px[i], py[i], values4 + 4 * (size_t) i, film);
 }
 void orc_sensor_sample_ray(const OrcSensor *s, uint32_t n, const float *px, const float *py, float *o, float *d, float *maxt) {

@@ -102,8 +102,9 @@ typedef struct OrcSensor {
     float near_clip, far_clip;
     uint32_t film_width, film_height;
     uint32_t crop_offset_x, crop_offset_y, crop_width, crop_height;
-    uint32_t rfilter;             /* 0 = box, 1 = gaussian */
-    float    rfilter_stddev;
+    uint32_t rfilter;             /* 0 box, 1 gaussian, 2 tent, 3 mitchell, 4 catmullrom, 5 lanczos (src/rfilters/ *.cpp) */
+    float    rfilter_stddev;      /* parameter 0: gaussian stddev, tent radius, mitchell B, lanczos lobes */
+    float    rfilter_param1;      /* parameter 1: mitchell C */
 } OrcSensor;
 
 typedef struct OrcStats {
@@ -221,6 +222,7 @@ float    orc_pcg32_next_float32(uint64_t state_inc[2]);
  * (sampler.cpp:129-148 + independent.cpp:77-97) */
 void  orc_sampler_stream(uint32_t seed, uint32_t lane, uint32_t n, float *out);
 float orc_rfilter_eval(uint32_t rfilter, float stddev, float x);
+float orc_rfilter_eval2(uint32_t rfilter, float param0, float param1, float x);      /* any filter type, with its radius cut-off */
 /* ImageBlock::put, coalesced JIT branch (imageblock.cpp:444-540) */
 void  orc_film_put(const OrcSensor *s, uint32_t n, const float *pos_x,
                    const float *pos_y, const float *values4, float *film);

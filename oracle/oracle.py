@@ -61,7 +61,7 @@ class Sensor(C.Structure):
                 ("film_width", C.c_uint32), ("film_height", C.c_uint32),
                 ("crop_offset_x", C.c_uint32), ("crop_offset_y", C.c_uint32),
                 ("crop_width", C.c_uint32), ("crop_height", C.c_uint32),
-                ("rfilter", C.c_uint32), ("rfilter_stddev", C.c_float)]
+                ("rfilter", C.c_uint32), ("rfilter_stddev", C.c_float), ("rfilter_param1", C.c_float)]
 
 
 class Stats(C.Structure):
@@ -138,6 +138,8 @@ def lib():
         L.orc_sampler_stream.argtypes = [C.c_uint32, C.c_uint32, C.c_uint32, c_f32p]
         L.orc_rfilter_eval.restype = C.c_float
         L.orc_rfilter_eval.argtypes = [C.c_uint32, C.c_float, C.c_float]
+        L.orc_rfilter_eval2.restype = C.c_float
+        L.orc_rfilter_eval2.argtypes = [C.c_uint32, C.c_float, C.c_float, C.c_float]
         L.orc_film_put.argtypes = [C.POINTER(Sensor), C.c_uint32, c_f32p, c_f32p, c_f32p, c_f32p]
         L.orc_sensor_sample_ray.argtypes = [C.POINTER(Sensor), C.c_uint32, c_f32p, c_f32p, c_f32p, c_f32p, c_f32p]
         L.orc_diffuse_eval_pdf.argtypes = [c_f32p, c_f32p, c_f32p, c_f32p, c_f32p]

@@ -39,6 +39,7 @@ constexpr float InvPi    = 0.31830988618379067154f;
 constexpr float Infinity = std::numeric_limits<float>::infinity();
 constexpr float Largest  = std::numeric_limits<float>::max();
 /* include/mitsuba/core/math.h:17-22 with dr::Epsilon<float> = 2^-24 (unpinned) */
+constexpr float Epsilon       = 0x1p-24f;            /* dr::Epsilon<float> */
 constexpr float RayEpsilon    = 0x1p-24f * 1500.f;
 constexpr float ShadowEpsilon = RayEpsilon * 10.f;
 

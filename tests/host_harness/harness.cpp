@@ -152,6 +152,12 @@ int hh_render(void *h, const HarSensor *sensor, int mode, uint32_t seed, uint32_
     return status;
 }
 
+/* ReconstructionFilter::eval of the product's HAR_HD code (any filter type of HarSensor) */
+float hh_rfilter_eval(const HarSensor *sensor, float x) {
+    DSensor C; std::string e; if (!lower_sensor(*sensor, C, e)) return -1e30f;
+    return C.rfilter == 0 ? (x >= -.5f && x < .5f ? 1.f : 0.f) : rfilter_eval(C, x);
+}
+
 /* vertex-position gradients: the lane-by-lane equivalent of (k_shade<ADJOINT, diffuse, SHAPE> -> k_resolve -> k_shape_adjoint), i.e. the product's
  * hand-derived adjoint (har_shape_grad.h) driven exactly as the kernels drive it.  adj = grad_in / W (H x W x 3); grad[m] = 3 doubles per vertex
  * of mesh m or NULL. */

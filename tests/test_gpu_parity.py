@@ -789,3 +789,23 @@ def test_hide_emitters_parity(mi, O):
                 assert rel_l2(got, want) < 1e-3, stacked
         shown = mi.load_dict({**d, "integrator": {"type": "path", "max_depth": 6}})
         assert rel_l2(mi.render(shown, spp=16, seed=5).cpu().numpy(), img) > 0.1           # the property does change the picture
+
+
+@pytest.mark.parametrize("name", ["tent_wide", "mitchell_bc", "catmullrom", "lanczos", "lanczos2"])
+def test_reconstruction_filters_parity(mi, O, name):
+    """tent / mitchell / catmullrom / lanczos film filters (src/rfilters/*.cpp): the splat gather and the adjoint's footprint gather use the same
+    per-axis weights as the oracle, negative lobes included; `path` image, `prb` image and texture gradient"""
+    from tests.test_cpu_host import oracle_scene_from
+    from tests.test_rfilters_cpu import FILTERS
+    d = mi.textured_cornell_box(res=40, tex_res=8, spp=8)
+    d["sensor"]["film"]["rfilter"] = FILTERS[name][4]
+    scene = mi.load_dict(d)
+    osc, sensor = oracle_scene_from(O, scene)
+    img = mi.render(scene, integrator=mi.load_dict({"type": "path", "max_depth": 6}), spp=8, seed=2).cpu().numpy()
+    ref, _ = osc.render_path(sensor, seed=2, spp=8, max_depth=6)
+    assert np.isfinite(img).all() and rel_l2(img, ref) < 1e-4
+    integ = mi.load_dict({"type": "prb", "max_depth": 5})
+    grad_in = np.random.default_rng(1).uniform(0.5, 1.5, (40, 40, 3)).astype(np.float32)
+    grads = integ.render_backward(scene, None, grad_in, seed=9, spp=8)
+    g_refl, g_tex, _ = osc.render_prb_backward(sensor, grad_in, seed=9, spp=8, max_depth=5)
+    assert rel_l2(grads["white.reflectance.data"].cpu().numpy(), g_tex[0]) < 1e-3
