@@ -296,11 +296,27 @@ def _cube(props):
     return m
 
 
+def _check_props(plugin, props, known, unsupported=()):
+    """The reference's plugin loader rejects properties a plugin never queried ("Unreferenced property", src/core/plugin.cpp / properties.cpp)
+    -- a silently ignored property would be a silently different picture.  `unsupported`: (name, neutral value) pairs the reference knows
+    but hip_ad_rgb does not implement; anything but the neutral value is refused."""
+    for name, neutral in unsupported:
+        if name in props and props[name] != neutral:
+            raise RuntimeError("%s: property \"%s\" = %r is not implemented by hip_ad_rgb" % (plugin, name, props[name]))
+    for k, v in props.items():
+        if k in ('type', 'id') or k in known or any(k == u[0] for u in unsupported) or k.startswith('_arg_'):
+            continue
+        if isinstance(v, (dict, Film, Sampler)) or hasattr(v, 'har'):          # child objects: their key is free
+            continue
+        raise RuntimeError("Unreferenced property \"%s\" in plugin of type \"%s\"!" % (k, plugin))
+
+
 class Sampler:
     """IndependentSampler (src/samplers/independent.cpp) over PCG32Sampler (src/render/sampler.cpp)."""
 
     def __init__(self, props=None):
         props = props or {}
+        _check_props(props.get('type', 'independent'), props, ('sample_count', 'seed'))
         self.m_sample_count = int(props.get('sample_count', 4))
         self.m_base_seed = int(props.get('seed', 0))
         self.m_samples_per_wavefront = 1
@@ -371,6 +387,9 @@ class Film:
 
     def __init__(self, props=None):
         props = props or {}
+        # hdrfilm.cpp:146-208; file_format / component_format only concern Film::write (har_image_write_*: float32 / half channels)
+        _check_props('hdrfilm', props, ('width', 'height', 'crop_offset_x', 'crop_offset_y', 'crop_width', 'crop_height', 'pixel_format', 'file_format', 'component_format'),
+                     unsupported=(('sample_border', False), ('compensate', False)))
         self.width = int(props.get('width', 768)); self.height = int(props.get('height', 576))
         self.crop_offset = (int(props.get('crop_offset_x', 0)), int(props.get('crop_offset_y', 0)))
         self.crop_size_ = (int(props.get('crop_width', self.width)), int(props.get('crop_height', self.height)))
@@ -406,6 +425,9 @@ class Sensor:
 
     def __init__(self, props):
         self.props = dict(props)
+        # sensor.cpp:24-97, perspective.cpp:137-172
+        _check_props('perspective', props, ('to_world', 'fov', 'fov_axis', 'focal_length', 'near_clip', 'far_clip', 'film', 'sampler', 'shutter_open', 'shutter_close', 'focus_distance'),
+                     unsupported=(('principal_point_offset_x', 0.0), ('principal_point_offset_y', 0.0)))
         # child objects are recognised by their class, whatever the property is called (XML children are anonymous: `_arg_0`, ...)
         film = next((v for v in props.values() if isinstance(v, Film)), props.get('film'))
         sampler = next((v for v in props.values() if isinstance(v, Sampler)), props.get('sampler'))
@@ -689,6 +711,9 @@ class Integrator:
 
     def __init__(self, props):
         self.type = props['type']
+        # integrator.cpp:26-33,128-147,539-550; block_size only shapes the scalar / LLVM-parallel drivers; the last four are hip_ad_rgb extensions
+        _check_props(self.type, props, ('max_depth', 'rr_depth', 'hide_emitters', 'samples_per_pass', 'block_size', 'chunk_lanes', 'replay_cache', 'emitter_gradients', 'shape_gradients'),
+                     unsupported=(('timeout', -1.0),))
         default_depth = -1 if self.type == 'path' else 6        # integrator.cpp:539, common.py:31
         self.max_depth = int(props.get('max_depth', default_depth))
         self.rr_depth = int(props.get('rr_depth', 5))

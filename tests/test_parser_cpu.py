@@ -209,3 +209,21 @@ def test_cornell_box_xml_equals_dict(mi, tmp_path):
     with open(path, "w") as f:
         f.write(CBOX_XML.replace("</scene>", '<shape type="ply" id="blob"><string name="filename" value="g.ply"/><ref id="red"/></shape></scene>'))
     assert len(mi.load_file(path).meshes) == 9
+
+
+def test_unreferenced_and_unsupported_properties_are_errors(mi):
+    """the reference's loader rejects properties a plugin never queried; hip_ad_rgb does the same for its sensor / film / sampler / integrator
+    and refuses reference properties it does not implement instead of ignoring them"""
+    import pytest
+    base = mi.cornell_box()
+    for path, key, value, msg in [(("sensor", "film"), "sample_border", True, "not implemented"), (("sensor", "film"), "widht", 64, "Unreferenced"),
+                                  (("sensor",), "principal_point_offset_x", 0.1, "not implemented"), (("sensor", "sampler"), "samples", 4, "Unreferenced"),
+                                  (("integrator",), "maxdepth", 3, "Unreferenced"), (("integrator",), "timeout", 2.0, "not implemented")]:
+        d = mi.cornell_box(); node = d
+        for p in path:
+            node[p] = dict(node[p]); node = node[p]
+        node[key] = value
+        with pytest.raises(RuntimeError, match=msg):
+            mi.load_dict(d)
+    d = dict(base); d["sensor"] = dict(d["sensor"], shutter_open=0.0, focus_distance=5.0); d["integrator"] = dict(d["integrator"], block_size=32)
+    mi.load_dict(d)                              # known, inert properties pass
