@@ -809,3 +809,28 @@ def test_reconstruction_filters_parity(mi, O, name):
     grads = integ.render_backward(scene, None, grad_in, seed=9, spp=8)
     g_refl, g_tex, _ = osc.render_prb_backward(sensor, grad_in, seed=9, spp=8, max_depth=5)
     assert rel_l2(grads["white.reflectance.data"].cpu().numpy(), g_tex[0]) < 1e-3
+
+
+def test_vertex_position_optimisation_converges(mi):
+    """end to end: a floor displaced by 0.35 is pulled back to the height that produced the target image by gradient descent on
+    '<mesh>.vertex_positions' (render -> d loss / d image -> render_backward -> params.update(), which rebuilds the acceleration structure)"""
+    import torch
+    from tests.test_shape_gradients_cpu import slab_scene
+    res, spp = 32, 32
+    d = slab_scene(mi, res); d["integrator"] = {"type": "prb", "max_depth": 4, "shape_gradients": ["floor.vertex_positions"], "emitter_gradients": False}
+    scene = mi.load_dict(d); integ = scene.integrator()
+    target = mi.render(scene, integrator=integ, spp=256, seed=100)
+    params = mi.traverse(scene); key = "floor.vertex_positions"
+    base = params[key].clone().reshape(-1, 3)
+    height = torch.tensor(0.35, device=base.device)
+    losses, heights = [], []
+    for it in range(30):
+        p = base.clone(); p[:, 1] += height
+        params[key] = p.reshape(-1); params.update()
+        img = mi.render(scene, integrator=integ, spp=spp, seed=it)
+        diff = img - target
+        losses.append(float((diff ** 2).mean())); heights.append(float(height))
+        grads = integ.render_backward(scene, None, (2.0 * diff / diff.numel()).cpu().numpy(), seed=it, spp=spp)
+        g_h = grads[key].reshape(-1, 3)[:, 1].sum()                    # chain rule: every vertex moves with the height
+        height = height - torch.sign(g_h) * 0.06 * 0.9 ** it            # signed steps of decaying length: only the gradient's sign is trusted
+    assert abs(heights[-1]) < 0.03 and losses[-1] < 0.1 * losses[0], (heights, losses)
