@@ -678,11 +678,12 @@ __global__ __launch_bounds__(kBlock) void k_shape_adjoint(DScene S, const uint32
  * take the per-lane path. */
 #define HAR_SPLAT_GATHER_MAX_SPLIT 8
 #define HAR_SPLAT_TILE_PIXELS 512           /* LDS tile of the gather: 8 KB; wider tiles are processed in column slabs */
-template <int TAPS>
+/* WONLY: the weight pass of render_backward (har_render_weights) -- every lane's value is (0, 0, 0, 1), so the gather only multiplies weights */
+template <int TAPS, bool WONLY>
 __global__ __launch_bounds__(kBlock) void k_splat(DSensor C, uint32_t seed, uint32_t spp, uint32_t log_spp, uint32_t lane_base, uint32_t n,
                                                   const float4 *result, int weights_only, float *film, const float2 *jitter) {
     __shared__ float tile[4 * HAR_SPLAT_TILE_PIXELS];
-    __shared__ float4 s_val[kBlock];
+    __shared__ float4 s_val[WONLY ? 1 : kBlock];
     __shared__ float s_wx[TAPS][kBlock + 1], s_wy[TAPS][kBlock + 1];        /* + 1: threads of a wave read different taps of the same lane -> different banks */
     __shared__ int ext[6];                  /* footprint origin of the first / last active lane of the block, footprint size */
     const uint32_t i = blockIdx.x * kBlock + threadIdx.x;
@@ -701,7 +702,7 @@ __global__ __launch_bounds__(kBlock) void k_splat(DSensor C, uint32_t seed, uint
         if (threadIdx.x == 0) { ext[0] = (int) F.x0; ext[1] = (int) F.y0; ext[4] = (int) F.count; }
         if (threadIdx.x == n_act_u - 1u) { ext[2] = (int) F.x0; ext[3] = (int) F.y0; }
     }
-    s_val[threadIdx.x] = act ? make_float4(val[0], val[1], val[2], val[3]) : make_float4(0.f, 0.f, 0.f, 0.f);
+    if (!WONLY) s_val[threadIdx.x] = act ? make_float4(val[0], val[1], val[2], val[3]) : make_float4(0.f, 0.f, 0.f, 0.f);
 #pragma unroll
     for (int k = 0; k < TAPS; ++k) { s_wx[k][threadIdx.x] = F.wx[k]; s_wy[k][threadIdx.x] = F.wy[k]; }
     __syncthreads();
@@ -731,8 +732,8 @@ __global__ __launch_bounds__(kBlock) void k_splat(DSensor C, uint32_t seed, uint
 #pragma unroll 4
                     for (int l = la; l < lb; ++l) {
                         const float w = wxp[l] * wyp[l];
-                        const float4 v = s_val[l];
-                        ax += v.x * w; ay += v.y * w; az += v.z * w; aw += v.w * w;
+                        if (WONLY) aw += 1.f * w;
+                        else { const float4 v = s_val[l]; ax += v.x * w; ay += v.y * w; az += v.z * w; aw += v.w * w; }
                     }
                 }
                 reinterpret_cast<float4 *>(tile)[idx] = make_float4(ax, ay, az, aw);      /* partial sum g of pixel e (E * G <= 512 slots) */
@@ -979,8 +980,10 @@ void launch_splat(hipStream_t s, const DSensor &C, uint32_t seed, uint32_t spp, 
                   const float4 *result, int weights_only, float *film, const float2 *jitter) {
     /* filter taps per axis: 2 * ceil(radius - 1/2) + 1 (5 for the default gaussian); the kernel is instantiated for <= 5 and <= 9 (LDS budget) */
     const uint32_t taps = C.rfilter == 0 ? 1u : 2u * (uint32_t) ceilf(C.radius - .5f) + 1u;
-    if (taps <= 5) hipLaunchKernelGGL(k_splat<5>, dim3(blocks_for(n)), dim3(kBlock), 0, s, C, seed, spp, log_spp, lane_base, n, result, weights_only, film, jitter);
-    else hipLaunchKernelGGL(k_splat<HAR_MAX_FILTER_TAPS>, dim3(blocks_for(n)), dim3(kBlock), 0, s, C, seed, spp, log_spp, lane_base, n, result, weights_only, film, jitter);
+#define HAR_LAUNCH_SPLAT(T, W) hipLaunchKernelGGL((k_splat<T, W>), dim3(blocks_for(n)), dim3(kBlock), 0, s, C, seed, spp, log_spp, lane_base, n, result, weights_only, film, jitter)
+    if (taps <= 5) { if (weights_only) HAR_LAUNCH_SPLAT(5, true); else HAR_LAUNCH_SPLAT(5, false); }
+    else { if (weights_only) HAR_LAUNCH_SPLAT(HAR_MAX_FILTER_TAPS, true); else HAR_LAUNCH_SPLAT(HAR_MAX_FILTER_TAPS, false); }
+#undef HAR_LAUNCH_SPLAT
 }
 void launch_pass_jitter(hipStream_t s, uint32_t seed, uint32_t lane_base, uint32_t n, uint32_t pass, float2 *jitter) {
     hipLaunchKernelGGL(k_pass_jitter, dim3(blocks_for(n)), dim3(kBlock), 0, s, seed, lane_base, n, pass, jitter);
