@@ -680,7 +680,7 @@ def _grid_floor(mi, d, n):
     return d
 
 
-@pytest.mark.parametrize("which", ["slab", "slab_textured", "slab_env", "slab_twosided", "cbox", "cbox_grid", "cbox_nocache"])
+@pytest.mark.parametrize("which", ["slab", "slab_textured", "slab_env", "slab_twosided", "slab_crop_box", "cbox", "cbox_grid", "cbox_nocache"])
 def test_prb_vertex_position_gradients(mi, O, which):
     """har_integrator_set_grad_positions: the wavefront adjoint (k_shade<ADJOINT, SHAPE> geometry records, visibility from k_resolve,
     k_shape_adjoint with the next bounce's detached interaction) vs the oracle's dual-number restatement, vertex by vertex; the colour
@@ -694,7 +694,11 @@ def test_prb_vertex_position_gradients(mi, O, which):
         if which == "cbox_grid":
             d = _grid_floor(mi, d, 36)
     else:
-        res = 24; d = slab_scene(mi, res, textured=which == "slab_textured", env=which == "slab_env"); names = ["floor"] + ([] if which == "slab_env" else ["ceiling"])
+        res = 24; d = slab_scene(mi, res, textured=which in ("slab_textured", "slab_crop_box"), env=which == "slab_env"); names = ["floor"] + ([] if which == "slab_env" else ["ceiling"])
+    spp = 16
+    if which == "slab_crop_box":          # ragged case: crop window, box filter, sample count that is not a power of two
+        d["sensor"]["film"].update({"width": 40, "height": 30, "crop_offset_x": 9, "crop_offset_y": 4, "crop_width": res, "crop_height": res, "rfilter": {"type": "box"}})
+        spp = 12
     d["integrator"] = {"type": "prb", "max_depth": 5, "shape_gradients": [n + ".vertex_positions" for n in names]}
     if which == "cbox_nocache":
         d["integrator"]["replay_cache"] = False
@@ -703,8 +707,8 @@ def test_prb_vertex_position_gradients(mi, O, which):
     ids = [mesh_index(scene, n) for n in names]
     grad_in = np.random.default_rng(4).uniform(0.5, 1.5, (res, res, 3)).astype(np.float32)
     integ = scene.integrator()
-    grads = integ.render_backward(scene, None, grad_in, seed=3, spp=16)
-    want, w_refl, w_tex, _ = osc.render_prb_backward_shape(sensor, grad_in, ids, seed=3, spp=16, max_depth=5)
+    grads = integ.render_backward(scene, None, grad_in, seed=3, spp=spp)
+    want, w_refl, w_tex, _ = osc.render_prb_backward_shape(sensor, grad_in, ids, seed=3, spp=spp, max_depth=5)
     for n, m in zip(names, ids):
         got = grads[n + ".vertex_positions"].cpu().numpy().reshape(-1, 3)
         scale = np.abs(want[m]).max()
@@ -718,7 +722,7 @@ def test_prb_vertex_position_gradients(mi, O, which):
         assert rel_l2(grads[k].cpu().numpy(), ref) < 1e-3, k
     # switching the feature off again restores the plain adjoint
     integ.shape_gradients = False
-    plain = integ.render_backward(scene, None, grad_in, seed=3, spp=16)
+    plain = integ.render_backward(scene, None, grad_in, seed=3, spp=spp)
     assert not any(k.endswith("vertex_positions") for k in plain)
     for k in keys:
         assert np.allclose(plain[k].cpu().numpy(), grads[k].cpu().numpy(), rtol=1e-4, atol=1e-7)
