@@ -65,7 +65,10 @@ struct Builder {
         auto for_chunks = [&](auto &&body) {
             if (chunks <= 1) { body(0u, begin, end); return; }
             std::vector<std::thread> pool;
-            for (uint32_t c = 1; c < chunks; ++c) pool.emplace_back([&, c] { body(c, begin + (uint32_t) ((uint64_t) count * c / chunks), begin + (uint32_t) ((uint64_t) count * (c + 1) / chunks)); });
+            for (uint32_t c = 1; c < chunks; ++c) {
+                const uint32_t b0 = begin + (uint32_t) ((uint64_t) count * c / chunks), e0 = begin + (uint32_t) ((uint64_t) count * (c + 1) / chunks);
+                try { pool.emplace_back([&body, c, b0, e0] { body(c, b0, e0); }); } catch (...) { body(c, b0, e0); }
+            }
             body(0u, begin, begin + (uint32_t) ((uint64_t) count / chunks));
             for (auto &t : pool) t.join();
         };
@@ -131,9 +134,11 @@ struct Builder {
         static const uint32_t par_min = getenv("HAR_BUILD_PAR_MIN") ? (uint32_t) atol(getenv("HAR_BUILD_PAR_MIN")) : 16384u;
         if (count >= par_min && depth < 7) {
             std::vector<BNode> L, R;
-            std::thread t([&] { build_into(L, begin, mid, depth + 1); });
+            bool forked = false; std::thread t;
+            try { t = std::thread([&] { build_into(L, begin, mid, depth + 1); }); forked = true; } catch (...) { }      /* no thread to be had: this one does both */
+            if (!forked) build_into(L, begin, mid, depth + 1);
             build_into(R, mid, end, depth + 1);
-            t.join();
+            if (forked) t.join();
             auto splice = [&](const std::vector<BNode> &sub) {
                 const int base = (int) bn.size();
                 for (BNode n : sub) { if (n.left >= 0) { n.left += base; n.right += base; } bn.push_back(n); }
