@@ -241,6 +241,11 @@ int har_integrator_set_samples_per_pass(HarIntegrator integrator, uint32_t sampl
 /* Integrator property `hide_emitters` (src/render/integrator.cpp:29): camera rays pass through area emitters (Integrator::skip_area_emitters,
  * integrator.cpp:96-124; path.cpp:177-190, prb.py:112-118) and do not see the environment (path.cpp:114-115, prb.py:146-148) */
 int har_integrator_set_hide_emitters(HarIntegrator integrator, int hide);
+/* Alpha channel of `rgba` films (HDRFilm pixel_format, hdrfilm.cpp:135-160): when a DEVICE buffer of H x W x 4 floats (crop window) is set,
+ * har_render also accumulates  w * alpha  of every sample into its channel 3 -- alpha = 1 for a valid camera sample: PathIntegrator's valid_ray
+ * (path.cpp:114-115,307-308,341), `depth != 0` for prb (prb.py:332) -- with the same reconstruction-filter weights w as the radiance, so that
+ * A = channel 3 / W of the film (hdrfilm.cpp:398-399).  NULL switches it off. */
+int har_integrator_set_alpha_film(HarIntegrator integrator, float *alpha_film);
 /* the pass split har_render will use for `spp` samples per pixel of this sensor's crop window; fails like the reference
  * when spp is not a multiple of the pass size (integrator.cpp:177-179, sampler.cpp:93-94) */
 int har_render_pass_layout(HarIntegrator integrator, const HarSensor *sensor, uint32_t spp, uint32_t *spp_per_pass, uint32_t *n_passes);

@@ -393,9 +393,10 @@ class Film:
         self.width = int(props.get('width', 768)); self.height = int(props.get('height', 576))
         self.crop_offset = (int(props.get('crop_offset_x', 0)), int(props.get('crop_offset_y', 0)))
         self.crop_size_ = (int(props.get('crop_width', self.width)), int(props.get('crop_height', self.height)))
-        pf = props.get('pixel_format', 'rgb')
-        if pf != 'rgb':
-            raise RuntimeError("hdrfilm: pixel_format \"%s\" is not supported by hip_ad_rgb (only 'rgb')" % pf)
+        pf = str(props.get('pixel_format', 'rgb')).lower()          # hdrfilm.cpp:135-160
+        if pf not in ('rgb', 'rgba'):
+            raise RuntimeError("hdrfilm: pixel_format \"%s\" is not supported by hip_ad_rgb ('rgb', 'rgba')" % pf)
+        self.alpha = (pf == 'rgba')
         rf = next((v for v in props.values() if isinstance(v, dict) and 'type' in v), {'type': 'gaussian'})     # the film's only child object is its rfilter
         self.rf_param1 = 1.0 / 3.0
         if rf['type'] == 'gaussian':                     # src/rfilters/gaussian.cpp:48-55
@@ -781,8 +782,9 @@ class Integrator:
     def _sensor(self, scene, sensor):
         return scene.sensors()[sensor] if isinstance(sensor, int) else sensor
 
-    def render_film(self, scene, sensor=0, seed=0, spp=0, lanes=None, film=None):
-        """Raw {R,G,B,W} accumulation of lanes [begin, end) (all when None); no develop."""
+    def render_film(self, scene, sensor=0, seed=0, spp=0, lanes=None, film=None, alpha_film=None):
+        """Raw {R,G,B,W} accumulation of lanes [begin, end) (all when None); no develop.  `alpha_film` (H x W x 4 zeros): also accumulate
+        w * alpha into its channel 3 (`rgba` films, har_integrator_set_alpha_film)."""
         torch = _torch(); dev = _device()
         sensor = self._sensor(scene, sensor)
         if spp:
@@ -792,6 +794,7 @@ class Integrator:
         if film is None:
             film = torch.zeros((h, w, 4), dtype=torch.float32, device=dev)
         lb, le = lanes if lanes else (0, 0)
+        check(lib().har_integrator_set_alpha_film(self._handle(), _ptr(alpha_film) if alpha_film is not None else None))
         check(lib().har_render(scene._handle(), self._handle(), C.byref(sensor.har), (sensor.sampler().m_base_seed + int(seed)) & 0xffffffff,
                                spp, lb, le, _ptr(film), _stream()))
         return film
@@ -800,13 +803,17 @@ class Integrator:
         """SamplingIntegrator::render (integrator.cpp:151) / ADIntegrator.render (common.py:46)."""
         torch = _torch()
         sensor = self._sensor(scene, sensor)
-        film = self.render_film(scene, sensor, seed, spp)
+        alpha = None
+        if sensor.film().alpha and develop:
+            w, h = sensor.film().crop_size()
+            alpha = torch.zeros((h, w, 4), dtype=torch.float32, device=_device())
+        film = self.render_film(scene, sensor, seed, spp, alpha_film=alpha)
         if not develop:
             if self.type == 'prb':
                 raise Exception("develop=True must be specified when invoking AD integrators")
             out = film
         else:
-            out = develop_film(film)
+            out = develop_film(film, alpha)
         if evaluate:
             torch.cuda.current_stream().synchronize()
             self.stats()                 # surfaces device-side errors (traversal stack overflow)
@@ -827,7 +834,10 @@ class Integrator:
         if weight_film is None:
             weight_film = torch.zeros((h, w, 4), dtype=torch.float32, device=dev)
             check(lib().har_render_weights(C.byref(sensor.har), sd, spp, lb, le, _ptr(weight_film), _stream()))
-        grad_in = torch.as_tensor(grad_in, dtype=torch.float32, device=dev).reshape(h, w, 3).contiguous()
+        grad_in = torch.as_tensor(grad_in, dtype=torch.float32, device=dev)
+        if sensor.film().alpha and grad_in.numel() == h * w * 4:
+            grad_in = grad_in.reshape(h, w, 4)[:, :, :3]               # alpha is a mask of detached decisions: no gradient
+        grad_in = grad_in.reshape(h, w, 3).contiguous()
         g_refl = torch.zeros((len(scene.bsdfs), 3), dtype=torch.float32, device=dev)
         g_tex = [torch.zeros(tuple(t.shape), dtype=torch.float32, device=dev) for t in scene.textures]
         ptrs = (C.c_void_p * max(1, len(g_tex)))(*[t.data_ptr() for t in g_tex])
@@ -892,12 +902,17 @@ def write_bitmap(filename, data):
     Bitmap(data).write(filename)
 
 
-def develop_film(film):
+def develop_film(film, alpha_film=None):
+    """HDRFilm::develop (hdrfilm.cpp:301-404): RGB / W, and A / W for `rgba` films (alpha_film: channel 3 holds the accumulated w * alpha)"""
     torch = _torch()
     h, w, _ = film.shape
     img = torch.empty((h, w, 3), dtype=torch.float32, device=film.device)
     check(lib().har_film_develop(_ptr(film), w, h, _ptr(img), _stream()))
-    return img
+    if alpha_film is None:
+        return img
+    weight = film[:, :, 3:4]
+    a = alpha_film[:, :, 3:4] / torch.where(weight == 0, torch.ones_like(weight), weight)
+    return torch.cat([img, a], dim=2)
 
 
 # ---------------------------------------------------------------------------

@@ -55,6 +55,8 @@ struct HarIntegratorImpl {
      * (measured on the 1M-triangle scene, 67 M lanes: 16 M-lane chunks 708, 32 M 758, one 64 M chunk 783 Mpaths/s) */
     uint32_t max_depth = 0, rr_depth = 5, chunk = 1u << 26;
     bool hide_emitters = false;           /* Integrator property (integrator.cpp:29) */
+    float *alpha_film = nullptr;          /* user buffer (DEVICE, H x W x 4: channel 3 accumulates w * alpha) of har_integrator_set_alpha_film, or null */
+    float *alpha_lane = nullptr;          /* alpha value per lane of the chunk */
     uint32_t *skip_counters = nullptr;    /* hide_emitters: count + cursor of the two continuation lists of skip_area_emitters */
     // workspace
     uint32_t ws_lanes = 0; bool ws_adjoint = false; uint32_t shard_cap = 0;
@@ -138,6 +140,8 @@ int ensure_workspace(HarIntegratorImpl *I, uint32_t lanes, bool adjoint) {
     if (ws_alloc(I, &I->result, lanes)) return 1;
     if (ws_alloc(I, &I->stack_spill, (size_t) HAR_STACK_SPILL * HAR_MAX_TRAVERSAL_BLOCKS * 256)) return 1;
     if (ws_alloc(I, &I->skip_counters, (size_t) 4 * HAR_SHARDS * HAR_COUNTER_STRIDE)) return 1;
+    I->alpha_lane = nullptr;
+    if (I->alpha_film && ws_alloc(I, &I->alpha_lane, lanes)) return 1;
     if (ws_alloc(I, &I->counters, (size_t) 4 * HAR_MAX_BOUNCE_SLOTS * HAR_SHARDS * HAR_COUNTER_STRIDE) || ws_alloc(I, &I->totals, 4) || ws_alloc(I, &I->status, 1)) return 1;
     HIP_TRY(hipMemset(I->totals, 0, 4 * sizeof(unsigned long long)));
     HIP_TRY(hipMemset(I->status, 0, sizeof(int)));
@@ -222,6 +226,10 @@ int run_chunk(HarSceneImpl *S, HarIntegratorImpl *I, const DSensor &C, int mode,
                 launch_skip_emitters(s, grid, S->ds, 0, I->shard_cap, cnt[a], lo[a], ld[a], sh0, sh1, I->h0, I->h1, lo[a ^ 1], ld[a ^ 1], cnt[a ^ 1]);
             }
             prof_mark(I, s, CLS_OTHER);
+        }
+        if (I->alpha_lane && b == 0 && mode != MODE_PRB_ADJOINT) {        /* `rgba` films: is the camera sample valid?  (path.cpp:114-115,307-308; prb.py:332) */
+            const float miss = (mode == MODE_PATH && S->ds.env_emitter >= 0 && !I->hide_emitters) ? 1.f : 0.f;
+            launch_alpha_flags(s, grid, I->shard_cap, cnt_alive(I, 0), I->st[cur], I->h0, lane_base, miss, I->alpha_lane);
         }
         /* vertex-position gradients of the PREVIOUS bounce's vertices: its items are still in place, `result` holds its L, and this bounce's ray
          * queries give the (detached) next interaction of every continued path */
@@ -539,6 +547,7 @@ static int render_range(HarScene S, HarIntegrator I, const HarSensor *sensor, ui
             if (run_chunk(S, I, C, mode, seed, spp_pass, log_spp, (uint32_t) base, n, nullptr, s, 0, ps)) return 1;
             if (mode == MODE_PRB_PRIMAL) { launch_accumulate_stats(s, I->counters, bounce_limit(I), I->totals, n); prof_mark(I, s, CLS_OTHER); }
             launch_splat(s, C, seed, spp_pass, log_spp, (uint32_t) base, n, I->result, 0, film, ps.jitter);
+            if (I->alpha_lane) launch_splat(s, C, seed, spp_pass, log_spp, (uint32_t) base, n, nullptr, 1, I->alpha_film, ps.jitter, I->alpha_lane);
             prof_mark(I, s, CLS_SPLAT);
         }
     }
@@ -565,6 +574,8 @@ static uint64_t dual_split(HarIntegrator I, uint64_t lb, uint64_t le, hipStream_
     HarIntegratorImpl *T = I->twin;
     T->type = I->type; T->max_depth = I->max_depth; T->rr_depth = I->rr_depth; T->chunk = I->chunk; T->samples_per_pass = I->samples_per_pass;
     T->grad_emitters = I->grad_emitters; T->profiling = I->profiling; T->hide_emitters = I->hide_emitters;
+    if ((T->alpha_film != nullptr) != (I->alpha_film != nullptr)) { (void) hipDeviceSynchronize(); T->free_ws(); }
+    T->alpha_film = I->alpha_film;
     if (T->use_cache != I->use_cache) { (void) hipDeviceSynchronize(); T->free_ws(); T->use_cache = I->use_cache; }
     if (hipEventRecord(I->ev_fork, s) != hipSuccess || hipStreamWaitEvent(I->side_stream, I->ev_fork, 0) != hipSuccess) return le;
     I->twin_used = true;
@@ -609,6 +620,12 @@ int har_render_backward(HarScene S, HarIntegrator I, const HarSensor *sensor, co
     return rc;
 }
 
+int har_integrator_set_alpha_film(HarIntegrator I, float *alpha_film) {
+    if (!I) return fail("null integrator");
+    if ((alpha_film != nullptr) != (I->alpha_film != nullptr)) { (void) hipDeviceSynchronize(); I->free_ws(); }      /* the per-lane alpha values are workspace */
+    I->alpha_film = alpha_film;
+    return 0;
+}
 int har_integrator_set_hide_emitters(HarIntegrator I, int hide) {
     if (!I) return fail("null integrator");
     I->hide_emitters = hide != 0;

@@ -70,7 +70,9 @@ void launch_shape_adjoint(hipStream_t s, uint32_t grid, const DScene &S, const u
                           const float4 *result, const float4 *dL, int has_next, const WaveState &next, const float4 *h0, const uint2 *h1, const ReplayCache &rc_next,
                           const ShapeTargets &T);
 void launch_splat(hipStream_t s, const DSensor &C, uint32_t seed, uint32_t spp, uint32_t log_spp, uint32_t lane_base, uint32_t n,
-                  const float4 *result, int weights_only, float *film, const float2 *jitter = nullptr);
+                  const float4 *result, int weights_only, float *film, const float2 *jitter = nullptr, const float *scalar = nullptr);   /* weights_only + scalar: w * scalar[i] */
+/* alpha flags of the camera samples of a wavefront (1 = valid), see k_alpha_flags */
+void launch_alpha_flags(hipStream_t s, uint32_t grid, uint32_t shard_cap, const uint32_t *count_in, const WaveState &in, const float4 *h0, uint32_t lane_base, float miss_value, float *alpha);
 void launch_pass_jitter(hipStream_t s, uint32_t seed, uint32_t lane_base, uint32_t n, uint32_t pass, float2 *jitter);
 void launch_develop(hipStream_t s, const float *film, uint32_t npx, float *image);
 void launch_adjoint_image(hipStream_t s, const float *grad_in, const float *wfilm, uint32_t npx, float *adj);

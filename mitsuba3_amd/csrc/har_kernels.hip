@@ -570,6 +570,20 @@ __global__ __launch_bounds__(kBlock) void k_resolve(DScene S, const uint32_t *it
     }
 }
 
+/* alpha channel of `rgba` films: 1 for a valid camera sample.  PathIntegrator: valid_ray = the environment is visible or the path met a surface
+ * (path.cpp:114-115,307-308,341) -- the camera ray's intersection decides; prb: depth != 0 (prb.py:332).  Runs on the camera rays' hits (after
+ * hide_emitters' skipping), one float per lane of the chunk. */
+__global__ __launch_bounds__(kBlock) void k_alpha_flags(uint32_t shard_cap, const uint32_t *count_in, const float4 *state_a3, const float4 *h0, uint32_t lane_base,
+                                                        float miss_value, float *alpha) {
+    const ShardLoop Q(count_in, shard_cap);
+    for (uint32_t tile = Q.first_tile(); tile * kBlock < Q.n; tile += Q.tile_step()) {
+        const uint32_t local = tile * kBlock + threadIdx.x;
+        if (local >= Q.n) continue;
+        const uint32_t i = Q.base + local;
+        alpha[__float_as_uint(state_a3[i].w) - lane_base] = h0[i].x != HAR_INF ? 1.f : miss_value;
+    }
+}
+
 /* ------------------------------------------------------- hide_emitters */
 /* Integrator::skip_area_emitters (src/render/integrator.cpp:96-124; call sites path.cpp:177-190, prb.py:112-118): a CAMERA ray that hits an area
  * emitter continues through all area emitters along it.  Only the preliminary intersection of the lane is replaced, its ray stays the camera ray.
@@ -679,11 +693,13 @@ __global__ __launch_bounds__(kBlock) void k_shape_adjoint(DScene S, const uint32
 #define HAR_SPLAT_GATHER_MAX_SPLIT 8
 #define HAR_SPLAT_TILE_PIXELS 512           /* LDS tile of the gather: 8 KB; wider tiles are processed in column slabs */
 /* WONLY: the weight pass of render_backward (har_render_weights) -- every lane's value is (0, 0, 0, 1), so the gather only multiplies weights */
-template <int TAPS, bool WONLY>
+/* WONLY = 2: the alpha channel of an `rgba` film -- the lane's value is (0, 0, 0, scalar[i]) (har_integrator_set_alpha_film) */
+template <int TAPS, int WONLY>
 __global__ __launch_bounds__(kBlock) void k_splat(DSensor C, uint32_t seed, uint32_t spp, uint32_t log_spp, uint32_t lane_base, uint32_t n,
-                                                  const float4 *result, int weights_only, float *film, const float2 *jitter) {
+                                                  const float4 *result, int weights_only, float *film, const float2 *jitter, const float *scalar) {
     __shared__ float tile[4 * HAR_SPLAT_TILE_PIXELS];
     __shared__ float4 s_val[WONLY ? 1 : kBlock];
+    __shared__ float s_sv[WONLY == 2 ? kBlock : 1];
     __shared__ float s_wx[TAPS][kBlock + 1], s_wy[TAPS][kBlock + 1];        /* + 1: threads of a wave read different taps of the same lane -> different banks */
     __shared__ int ext[6];                  /* footprint origin of the first / last active lane of the block, footprint size */
     const uint32_t i = blockIdx.x * kBlock + threadIdx.x;
@@ -698,11 +714,13 @@ __global__ __launch_bounds__(kBlock) void k_splat(DSensor C, uint32_t seed, uint
         else ls = lane_film_pos(C, seed, spp, log_spp, lane_base + i);
         film_footprint(C, ls, F);
         if (!weights_only) { float4 r = result[i]; val[0] = r.x; val[1] = r.y; val[2] = r.z; }
+        if (WONLY == 2) val[3] = scalar[i];
         /* lanes are ordered by pixel: the block's extent follows from its first and last active lane (no LDS min / max atomics) */
         if (threadIdx.x == 0) { ext[0] = (int) F.x0; ext[1] = (int) F.y0; ext[4] = (int) F.count; }
         if (threadIdx.x == n_act_u - 1u) { ext[2] = (int) F.x0; ext[3] = (int) F.y0; }
     }
     if (!WONLY) s_val[threadIdx.x] = act ? make_float4(val[0], val[1], val[2], val[3]) : make_float4(0.f, 0.f, 0.f, 0.f);
+    if (WONLY == 2) s_sv[threadIdx.x] = act ? val[3] : 0.f;
 #pragma unroll
     for (int k = 0; k < TAPS; ++k) { s_wx[k][threadIdx.x] = F.wx[k]; s_wy[k][threadIdx.x] = F.wy[k]; }
     __syncthreads();
@@ -732,7 +750,8 @@ __global__ __launch_bounds__(kBlock) void k_splat(DSensor C, uint32_t seed, uint
 #pragma unroll 4
                     for (int l = la; l < lb; ++l) {
                         const float w = wxp[l] * wyp[l];
-                        if (WONLY) aw += 1.f * w;
+                        if (WONLY == 2) aw += s_sv[l] * w;
+                        else if (WONLY) aw += 1.f * w;
                         else { const float4 v = s_val[l]; ax += v.x * w; ay += v.y * w; az += v.z * w; aw += v.w * w; }
                     }
                 }
@@ -966,6 +985,9 @@ void launch_resolve(int mode, hipStream_t s, uint32_t grid, uint2 *spill, const 
     else { if (spill) HAR_LAUNCH_RESOLVE(MODE_PATH, true); else HAR_LAUNCH_RESOLVE(MODE_PATH, false); }
 #undef HAR_LAUNCH_RESOLVE
 }
+void launch_alpha_flags(hipStream_t s, uint32_t grid, uint32_t shard_cap, const uint32_t *count_in, const WaveState &in, const float4 *h0, uint32_t lane_base, float miss_value, float *alpha) {
+    hipLaunchKernelGGL(k_alpha_flags, dim3(grid), dim3(kBlock), 0, s, shard_cap, count_in, in.a3, h0, lane_base, miss_value, alpha);
+}
 void launch_skip_emitters(hipStream_t s, uint32_t grid, const DScene &S, int first, uint32_t shard_cap, const uint32_t *count_in, const float4 *ray_o, const float4 *ray_d,
                           const float4 *hit0, const uint2 *hit1, float4 *h0, uint2 *h1, float4 *dst_o, float4 *dst_d, uint32_t *dst_count) {
     (void) ray_o;
@@ -977,12 +999,13 @@ void launch_shape_adjoint(hipStream_t s, uint32_t grid, const DScene &S, const u
     hipLaunchKernelGGL(k_shape_adjoint, dim3(grid), dim3(kBlock), 0, s, S, item_count, shard_cap, items, geo, result, dL, has_next, next, h0, h1, rc_next, T);
 }
 void launch_splat(hipStream_t s, const DSensor &C, uint32_t seed, uint32_t spp, uint32_t log_spp, uint32_t lane_base, uint32_t n,
-                  const float4 *result, int weights_only, float *film, const float2 *jitter) {
+                  const float4 *result, int weights_only, float *film, const float2 *jitter, const float *scalar) {
     /* filter taps per axis: 2 * ceil(radius - 1/2) + 1 (5 for the default gaussian); the kernel is instantiated for <= 5 and <= 9 (LDS budget) */
     const uint32_t taps = C.rfilter == 0 ? 1u : 2u * (uint32_t) ceilf(C.radius - .5f) + 1u;
-#define HAR_LAUNCH_SPLAT(T, W) hipLaunchKernelGGL((k_splat<T, W>), dim3(blocks_for(n)), dim3(kBlock), 0, s, C, seed, spp, log_spp, lane_base, n, result, weights_only, film, jitter)
-    if (taps <= 5) { if (weights_only) HAR_LAUNCH_SPLAT(5, true); else HAR_LAUNCH_SPLAT(5, false); }
-    else { if (weights_only) HAR_LAUNCH_SPLAT(HAR_MAX_FILTER_TAPS, true); else HAR_LAUNCH_SPLAT(HAR_MAX_FILTER_TAPS, false); }
+#define HAR_LAUNCH_SPLAT(T, W) hipLaunchKernelGGL((k_splat<T, W>), dim3(blocks_for(n)), dim3(kBlock), 0, s, C, seed, spp, log_spp, lane_base, n, result, weights_only, film, jitter, scalar)
+    const int w = weights_only ? (scalar ? 2 : 1) : 0;
+    if (taps <= 5) { if (w == 2) HAR_LAUNCH_SPLAT(5, 2); else if (w == 1) HAR_LAUNCH_SPLAT(5, 1); else HAR_LAUNCH_SPLAT(5, 0); }
+    else { if (w == 2) HAR_LAUNCH_SPLAT(HAR_MAX_FILTER_TAPS, 2); else if (w == 1) HAR_LAUNCH_SPLAT(HAR_MAX_FILTER_TAPS, 1); else HAR_LAUNCH_SPLAT(HAR_MAX_FILTER_TAPS, 0); }
 #undef HAR_LAUNCH_SPLAT
 }
 void launch_pass_jitter(hipStream_t s, uint32_t seed, uint32_t lane_base, uint32_t n, uint32_t pass, float2 *jitter) {

@@ -129,18 +129,23 @@ def render_distributed(scene, integrator=None, sensor=0, seed=0, spp=0, develop=
     y0, y1 = bal.band(rank)
     lanes = (y0 * w * spp_pass, y1 * w * spp_pass)
     adapt = bal.adapting()
+    alpha = None
+    if getattr(s.film(), "alpha", False) and develop:             # `rgba` films: a second accumulator (w * alpha), reduced like the first
+        from . import core
+        alpha = torch.zeros((h, w, 4), dtype=torch.float32, device=core._device())
     with _Timer(adapt) as timer:
-        film = integrator.render_film(scene, s, seed, spp, lanes=lanes)
+        film = integrator.render_film(scene, s, seed, spp, lanes=lanes) if alpha is None else integrator.render_film(scene, s, seed, spp, lanes=lanes, alpha_film=alpha)
     if adapt:
         _share_times(bal, timer, film)
     if world > 1:
-        if dist.get_backend() == "gloo" and film.is_cuda:      # gloo has no device-tensor reduce (rehearsal runs only)
-            dist.all_reduce(film, op=dist.ReduceOp.SUM)
-        else:
-            dist.reduce(film, dst=dst, op=dist.ReduceOp.SUM)  # the single RCCL collective
+        for buf in ((film,) if alpha is None else (film, alpha)):
+            if dist.get_backend() == "gloo" and buf.is_cuda:      # gloo has no device-tensor reduce (rehearsal runs only)
+                dist.all_reduce(buf, op=dist.ReduceOp.SUM)
+            else:
+                dist.reduce(buf, dst=dst, op=dist.ReduceOp.SUM)  # the single RCCL collective (two for `rgba` films)
     if not develop:
         return film
-    return develop_film(film) if rank == dst or world == 1 else None
+    return develop_film(film, alpha) if rank == dst or world == 1 else None
 
 
 def render_backward_distributed(scene, grad_in, integrator=None, sensor=0, seed=0, spp=0):

@@ -50,6 +50,7 @@ struct Scene {
     std::vector<OrcEmitter> emitters;
     int env = -1; float env_center[3] = { 0, 0, 0 }; float env_radius = 0.f;   // Scene::environment() + its bounding sphere
     bool hide_emitters = false;            // Integrator property `hide_emitters` (integrator.cpp:29), set by orc_scene_set_hide_emitters
+    bool alpha_only = false;               // forward renders splat the alpha value (valid_ray ? 1 : 0) instead of the radiance (orc_scene_set_alpha_only)
     EnvMap envmap;                 // when emitters[env].type == 2
     /* AreaLight on a triangle mesh (emitter type 3): DiscreteDistribution over the face areas (Mesh::build_pmf, mesh.cpp:1358-1372) */
     struct AreaPmf { std::vector<float> pmf, cdf; float sum = 0.f, normalization = 0.f; };
@@ -1019,6 +1020,7 @@ static int render_forward(Scene &sc, const OrcSensor &s, uint32_t seed, uint32_t
             if (prb) rgb = prb_sample(sc, L.rng, L.ray, md, rd, true, V3(0.f), V3(0.f), nullptr, valid, sts[t]);
             else     rgb = path_sample(sc, L.rng, L.ray, md, rd, valid, sts[t]);
             sts[t].paths++;
+            if (sc.alpha_only) rgb = V3(valid ? 1.f : 0.f);             // the alpha channel of `rgba` films: integrator.cpp:497-504, common.py:150-152
             float v[4] = { rgb.x, rgb.y, rgb.z, 1.f };
             film_put(s, rf, rf.type == 0 ? L.ipos_x : L.pos_x, rf.type == 0 ? L.ipos_y : L.pos_y, v, films[t].data());
         }
@@ -1056,7 +1058,8 @@ static int render_forward_passes(Scene &sc, const OrcSensor &s, uint32_t seed, u
                 }
                 bool valid; V3 rgb = path_sample(sc, L.rng, L.ray, md, rd, valid, sts[t]);
                 sts[t].paths++;
-                float v[4] = { rgb.x, rgb.y, rgb.z, 1.f };
+                if (sc.alpha_only) rgb = V3(valid ? 1.f : 0.f);             // the alpha channel of `rgba` films: integrator.cpp:497-504, common.py:150-152
+            float v[4] = { rgb.x, rgb.y, rgb.z, 1.f };
                 film_put(s, rf, rf.type == 0 ? L.ipos_x : L.pos_x, rf.type == 0 ? L.ipos_y : L.pos_y, v, films[t].data());
             }
         }
@@ -1347,6 +1350,7 @@ int orc_render_prb_backward(void *scene, const OrcSensor *sp, const float *grad_
                             OrcStats *stats, int threads) {
     return orc_render_prb_backward_ex(scene, sp, grad_in, seed, spp, max_depth, rr_depth, grad_reflectance, grad_textures, nullptr, stats, threads);
 }
+void orc_scene_set_alpha_only(void *scene, int on) { ((Scene *) scene)->alpha_only = on != 0; }
 void orc_scene_set_hide_emitters(void *scene, int hide) { ((Scene *) scene)->hide_emitters = hide != 0; }
 void orc_scene_set_emitter_radiance(void *scene, uint32_t emitter, const float rgb[3]) {
     Scene &sc = *(Scene *) scene;

@@ -198,6 +198,9 @@ int orc_render_prb_backward_ex(void *scene, const OrcSensor *s, const float *gra
 void orc_scene_set_emitter_radiance(void *scene, uint32_t emitter, const float rgb[3]);
 /* Integrator property `hide_emitters` (src/render/integrator.cpp:29; path.cpp:114-115,177-190; prb.py:112-118,146-148) for every later render */
 void orc_scene_set_hide_emitters(void *scene, int hide);
+/* forward renders return the alpha channel of an `rgba` film in all three colour channels: 1 where the sample's ray is valid
+ * (path.cpp:114-115,307-308,341; prb.py:332 `depth != 0`), 0 elsewhere, filtered like the radiance */
+void orc_scene_set_alpha_only(void *scene, int on);
 /* ... plus the gradient w.r.t. the VERTEX POSITIONS of the meshes with pos_mask[m] != 0 (prb.py:124-141 attached surface interaction,
  * :176-216 emitter sampling from the attached point, :261-297 attached wo and solid-angle-to-area Jacobian): grad_positions[m] holds 3
  * doubles per vertex and is added to.  Restated over forward-mode dual numbers (orc_dual.h) for `diffuse` BSDFs (plain or inside `twosided`) and flat-shaded

@@ -500,6 +500,10 @@ class OracleScene:
         L.orc_scene_set_vertex_positions(self.handle, mesh, fp(p))
         self.data.meshes[mesh]["V"][:, :3] = p
 
+    def set_alpha_only(self, on):
+        L = lib(); L.orc_scene_set_alpha_only.argtypes = [C.c_void_p, C.c_int]; L.orc_scene_set_alpha_only.restype = None
+        L.orc_scene_set_alpha_only(self.handle, 1 if on else 0)
+
     def set_hide_emitters(self, hide):
         lib().orc_scene_set_hide_emitters(self.handle, 1 if hide else 0)
 

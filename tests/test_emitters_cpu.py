@@ -191,3 +191,21 @@ def test_oracle_hide_emitters(mi, O):
     assert same.mean() > 0.25
     # prb: same estimator in expectation
     assert abs(hidden_prb.mean() / hidden.mean() - 1) < 0.1
+
+
+def test_oracle_alpha_channel(mi, O):
+    """alpha of `rgba` films = filtered valid-sample mask: PathIntegrator counts a visible environment as valid (path.cpp:114-115), prb only
+    samples that met a surface (prb.py:332), hide_emitters takes the environment (and emitters in front of it) out"""
+    from tests.test_cpu_host import oracle_scene_from
+    scene = mi.load_dict(hide_emitters_scene(mi))            # no back wall: sky behind
+    osc, sensor = oracle_scene_from(O, scene)
+    kw = dict(seed=1, spp=8, max_depth=4)
+    osc.set_alpha_only(True)
+    a_path, _ = osc.render_path(sensor, **kw); a_prb, _ = osc.render_prb(sensor, **kw)
+    osc.set_hide_emitters(True)
+    a_hidden, _ = osc.render_path(sensor, **kw)
+    osc.set_hide_emitters(False); osc.set_alpha_only(False)
+    assert np.abs(a_path - 1.0).max() < 1e-5                                  # sky or surface everywhere
+    assert a_prb.min() < 0.05 and a_prb.max() > 0.999                         # the sky pixels are holes for prb
+    assert np.abs(a_prb - a_hidden).max() < 1e-5                              # ... and for path with hide_emitters (the light hides nothing valid here)
+    assert (a_path[..., 0] == a_path[..., 1]).all()

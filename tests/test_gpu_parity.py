@@ -838,3 +838,43 @@ def test_vertex_position_optimisation_converges(mi):
         g_h = grads[key].reshape(-1, 3)[:, 1].sum()                    # chain rule: every vertex moves with the height
         height = height - torch.sign(g_h) * 0.06 * 0.9 ** it            # signed steps of decaying length: only the gradient's sign is trusted
     assert abs(heights[-1]) < 0.03 and losses[-1] < 0.1 * losses[0], (heights, losses)
+
+
+@pytest.mark.parametrize("config", ["path", "prb", "path_hidden", "path_chunks", "path_passes"])
+def test_rgba_film_alpha_parity(mi, O, config):
+    """pixel_format = rgba (har_integrator_set_alpha_film): RGB as before, A = filtered valid-sample mask, vs the oracle"""
+    from tests.test_cpu_host import oracle_scene_from
+    from tests.test_emitters_cpu import hide_emitters_scene
+    d = hide_emitters_scene(mi, 40)
+    d["sensor"]["film"]["pixel_format"] = "rgba"
+    itype = "prb" if config == "prb" else "path"
+    d["integrator"] = {"type": itype, "max_depth": 5}
+    if config == "path_hidden":
+        d["integrator"]["hide_emitters"] = True
+    if config == "path_chunks":
+        d["integrator"]["chunk_lanes"] = 4096
+    if config == "path_passes":
+        d["integrator"]["samples_per_pass"] = 4
+    scene = mi.load_dict(d)
+    osc, sensor = oracle_scene_from(O, scene); osc.set_hide_emitters(config == "path_hidden")
+    img = mi.render(scene, spp=16, seed=3).cpu().numpy()
+    assert img.shape == (40, 40, 4)
+    if config == "path_passes":
+        ref, _ = osc.render_path_passes(sensor, seed=3, spp=16, spp_per_pass=4, max_depth=5)
+        osc.set_alpha_only(True); alpha, _ = osc.render_path_passes(sensor, seed=3, spp=16, spp_per_pass=4, max_depth=5)
+    else:
+        fn = osc.render_prb if itype == "prb" else osc.render_path
+        ref, _ = fn(sensor, seed=3, spp=16, max_depth=5)
+        osc.set_alpha_only(True); alpha, _ = fn(sensor, seed=3, spp=16, max_depth=5)
+    osc.set_alpha_only(False)
+    assert rel_l2(img[..., :3], ref) < 1e-4
+    assert np.abs(img[..., 3] - alpha[..., 0]).max() < 1e-5, config
+    if config in ("prb", "path_hidden"):
+        assert img[..., 3].min() < 0.05            # the sky is a hole
+    # the adjoint accepts an rgba-shaped gradient and ignores its alpha plane
+    if itype == "prb":
+        g4 = np.random.default_rng(1).uniform(0.5, 1.5, (40, 40, 4)).astype(np.float32)
+        a = scene.integrator().render_backward(scene, None, g4, seed=9, spp=8)
+        b = scene.integrator().render_backward(scene, None, g4[..., :3].copy(), seed=9, spp=8)
+        for k in a:
+            assert np.allclose(a[k].cpu().numpy(), b[k].cpu().numpy(), rtol=1e-5, atol=1e-8)
