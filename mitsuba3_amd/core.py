@@ -795,8 +795,12 @@ class Integrator:
             film = torch.zeros((h, w, 4), dtype=torch.float32, device=dev)
         lb, le = lanes if lanes else (0, 0)
         check(lib().har_integrator_set_alpha_film(self._handle(), _ptr(alpha_film) if alpha_film is not None else None))
-        check(lib().har_render(scene._handle(), self._handle(), C.byref(sensor.har), (sensor.sampler().m_base_seed + int(seed)) & 0xffffffff,
-                               spp, lb, le, _ptr(film), _stream()))
+        try:
+            check(lib().har_render(scene._handle(), self._handle(), C.byref(sensor.har), (sensor.sampler().m_base_seed + int(seed)) & 0xffffffff,
+                                   spp, lb, le, _ptr(film), _stream()))
+        finally:
+            if alpha_film is not None:        # the integrator must not keep a pointer into a tensor it does not own
+                check(lib().har_integrator_set_alpha_film(self._handle(), None))
         return film
 
     def render(self, scene, sensor=0, seed=0, spp=0, develop=True, evaluate=True):

@@ -111,7 +111,10 @@ template <typename T> int ws_alloc(HarIntegratorImpl *I, T **p, size_t count) {
 uint32_t bounce_limit(const HarIntegratorImpl *I) { return std::min<uint32_t>(I->max_depth, HAR_MAX_BOUNCE_SLOTS - 2); }
 
 int ensure_workspace(HarIntegratorImpl *I, uint32_t lanes, bool adjoint) {
-    if (I->ws_lanes >= lanes && (I->ws_adjoint || !adjoint)) return 0;
+    if (I->ws_lanes >= lanes && (I->ws_adjoint || !adjoint)) {
+        if (I->alpha_film && !I->alpha_lane) return ws_alloc(I, &I->alpha_lane, I->ws_lanes);      /* `rgba` film on an existing workspace */
+        return 0;
+    }
     I->free_ws();
     I->counters = nullptr; I->totals = nullptr; I->status = nullptr; I->adj = nullptr; I->adj_floats = 0; I->d_grad_tex = nullptr; I->grad_tex_cap = 0;
     I->pass_rng = nullptr; I->pass_rng_cap = 0; I->pass_jitter = nullptr; I->pass_jitter_cap = 0;
@@ -227,7 +230,7 @@ int run_chunk(HarSceneImpl *S, HarIntegratorImpl *I, const DSensor &C, int mode,
             }
             prof_mark(I, s, CLS_OTHER);
         }
-        if (I->alpha_lane && b == 0 && mode != MODE_PRB_ADJOINT) {        /* `rgba` films: is the camera sample valid?  (path.cpp:114-115,307-308; prb.py:332) */
+        if (I->alpha_film && I->alpha_lane && b == 0 && mode != MODE_PRB_ADJOINT) {        /* `rgba` films: is the camera sample valid?  (path.cpp:114-115,307-308; prb.py:332) */
             const float miss = (mode == MODE_PATH && S->ds.env_emitter >= 0 && !I->hide_emitters) ? 1.f : 0.f;
             launch_alpha_flags(s, grid, I->shard_cap, cnt_alive(I, 0), I->st[cur], I->h0, lane_base, miss, I->alpha_lane);
         }
@@ -547,7 +550,7 @@ static int render_range(HarScene S, HarIntegrator I, const HarSensor *sensor, ui
             if (run_chunk(S, I, C, mode, seed, spp_pass, log_spp, (uint32_t) base, n, nullptr, s, 0, ps)) return 1;
             if (mode == MODE_PRB_PRIMAL) { launch_accumulate_stats(s, I->counters, bounce_limit(I), I->totals, n); prof_mark(I, s, CLS_OTHER); }
             launch_splat(s, C, seed, spp_pass, log_spp, (uint32_t) base, n, I->result, 0, film, ps.jitter);
-            if (I->alpha_lane) launch_splat(s, C, seed, spp_pass, log_spp, (uint32_t) base, n, nullptr, 1, I->alpha_film, ps.jitter, I->alpha_lane);
+            if (I->alpha_film && I->alpha_lane) launch_splat(s, C, seed, spp_pass, log_spp, (uint32_t) base, n, nullptr, 1, I->alpha_film, ps.jitter, I->alpha_lane);
             prof_mark(I, s, CLS_SPLAT);
         }
     }
@@ -574,7 +577,6 @@ static uint64_t dual_split(HarIntegrator I, uint64_t lb, uint64_t le, hipStream_
     HarIntegratorImpl *T = I->twin;
     T->type = I->type; T->max_depth = I->max_depth; T->rr_depth = I->rr_depth; T->chunk = I->chunk; T->samples_per_pass = I->samples_per_pass;
     T->grad_emitters = I->grad_emitters; T->profiling = I->profiling; T->hide_emitters = I->hide_emitters;
-    if ((T->alpha_film != nullptr) != (I->alpha_film != nullptr)) { (void) hipDeviceSynchronize(); T->free_ws(); }
     T->alpha_film = I->alpha_film;
     if (T->use_cache != I->use_cache) { (void) hipDeviceSynchronize(); T->free_ws(); T->use_cache = I->use_cache; }
     if (hipEventRecord(I->ev_fork, s) != hipSuccess || hipStreamWaitEvent(I->side_stream, I->ev_fork, 0) != hipSuccess) return le;
@@ -622,8 +624,7 @@ int har_render_backward(HarScene S, HarIntegrator I, const HarSensor *sensor, co
 
 int har_integrator_set_alpha_film(HarIntegrator I, float *alpha_film) {
     if (!I) return fail("null integrator");
-    if ((alpha_film != nullptr) != (I->alpha_film != nullptr)) { (void) hipDeviceSynchronize(); I->free_ws(); }      /* the per-lane alpha values are workspace */
-    I->alpha_film = alpha_film;
+    I->alpha_film = alpha_film;          /* the per-lane alpha values are allocated with the next render's workspace and kept */
     return 0;
 }
 int har_integrator_set_hide_emitters(HarIntegrator I, int hide) {
