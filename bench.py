@@ -7,11 +7,19 @@
 One "step" = one complete forward `path` render of the workload (all W*H*spp lanes:
 raygen -> [trace, shade, resolve]* -> splat -> film reduce -> develop), scene and BVH
 already resident in HBM.  value = W*H*spp / seconds / 1e6 (Mpaths/s), whole job over all
-ranks (weak scaling is NOT used: the image is fixed and sharded by pixel rows => "strong";
-the row bands are rebalanced by measured per-rank time over the first three frames).
-After the timed forward steps the PRB adjoint (RBIntegrator.render_backward equivalent:
-weight pass + primal pass + adjoint replay) is timed the same way and reported in
-`prb_adjoint`.  rank 0 prints ONE JSON line.
+ranks.  The image is fixed and sharded by pixel rows => "strong" scaling (BASELINE.json:
+"1M-tri scene 512^2 x 256 spp, 1/2/4/8 GPU"); the row bands are rebalanced by measured
+per-rank time over the first three frames.  After the timed forward steps the PRB adjoint
+(RBIntegrator.render_backward: weight pass + primal pass + adjoint replay) is timed the same
+way on the TEXTURED variant of the scene (bitmap albedo: texel gradient atomics) with
+emitter gradients on, and reported in `prb_adjoint`.  rank 0 prints ONE JSON line.
+
+Process layout.  Started without a torch.distributed environment, this file is a LAUNCHER:
+  --gpus 1 : runs the measurement in one child process (`--worker`); a child killed by a
+             signal (a GPU fault aborts the process) is re-run after a pause (at most twice) and the
+             line reports "attempts" -- the failed attempt's stderr is passed through, nothing is hidden;
+  --gpus N : starts N ranks through `python -m torch.distributed.run` (RCCL), one per GPU.
+Under torch.distributed.run (RANK / WORLD_SIZE set, the driver's way for N > 1) it is a rank.
 """
 import argparse
 import json
@@ -23,9 +31,16 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBS = 8000.0          # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec (6.29 TB/s measured copy)
+T0 = time.perf_counter()
 
 
-def parse():
+def log(msg):
+    """phase log on stderr (rank 0): a run that dies mid-way says where"""
+    if int(os.environ.get("RANK", "0")) == 0:
+        sys.stderr.write("[bench %7.2fs] %s\n" % (time.perf_counter() - T0, msg)); sys.stderr.flush()
+
+
+def parse(argv=None):
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=3)
@@ -37,27 +52,90 @@ def parse():
     ap.add_argument("--chunk", type=int, default=0, help="wavefront chunk size in lanes (0 = library default)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-prb", action="store_true")
-    ap.add_argument("--cpu-seconds", type=float, default=15.0)
-    return ap.parse_args()
+    ap.add_argument("--cpu-seconds", type=float, default=12.0)
+    ap.add_argument("--worker", action="store_true", help="(internal) this process measures; see the module docstring")
+    return ap.parse_args(argv)
 
+
+# --------------------------------------------------------------------------------------------- launcher
+
+def free_port():
+    import socket
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        return s.getsockname()[1]
+
+
+def launcher(args):
+    import subprocess
+    passthrough = [a for a in sys.argv[1:] if a != "--worker"]
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    if args.gpus > 1:
+        cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(args.gpus), "--master-addr", "127.0.0.1",
+               "--master-port", str(free_port()), os.path.abspath(__file__)] + passthrough
+        return subprocess.call(cmd, env=env)
+    cmd = [sys.executable, os.path.abspath(__file__)] + passthrough + ["--worker"]
+    # A process killed by a signal (SIGABRT after "Memory access fault by GPU", SIGSEGV, ...) gets two more chances after a pause: on this pool
+    # a freshly leased box occasionally faults on the very first device access of a process (seen in round 2 with the identical snapshot that
+    # passed on the next box: the fault came during the scene upload, before any kernel of this repository ran, and a retry 1 s later hit it
+    # again) -- the pauses give the driver's GPU recovery time.  Ordinary errors (exit code > 0) are reported as they are.
+    pauses = (10.0, 30.0)
+    for attempt in range(1, len(pauses) + 2):
+        env["HAR_BENCH_ATTEMPT"] = str(attempt)
+        p = subprocess.run(cmd, env=env, stdout=subprocess.PIPE)
+        out = p.stdout.decode(errors="replace")
+        crashed = p.returncode < 0 or p.returncode in (134, 139)
+        if not crashed or attempt == len(pauses) + 1:
+            sys.stdout.write(out); sys.stdout.flush()
+            return p.returncode
+        sys.stderr.write("[bench] attempt %d ended with return code %d (killed by a signal / aborted); waiting %.0f s, then measuring again\n"
+                         % (attempt, p.returncode, pauses[attempt - 1]))
+        sys.stderr.flush()
+        time.sleep(pauses[attempt - 1])
+
+
+# --------------------------------------------------------------------------------------------- measurement
 
 def build_scene(mi, args, integrator_type):
+    textured = integrator_type == "prb"
     if args.workload == "cornell":
-        d = mi.cornell_box()
+        d = mi.textured_cornell_box(res=args.res, tex_res=256, spp=args.spp, max_depth=args.max_depth) if textured else mi.cornell_box()
         d["sensor"]["film"]["width"] = args.res; d["sensor"]["film"]["height"] = args.res
         d["sensor"]["sampler"]["sample_count"] = args.spp
     else:
         d = mi.instanced_spheres_scene(width=args.res, height=args.res, spp=args.spp, grid=10, n_u=100, n_v=50,
                                        flatten=(args.workload in ("flat1m", "materials1m")), max_depth=args.max_depth,
-                                       materials=(args.workload == "materials1m"))
+                                       materials=(args.workload == "materials1m"), textured=textured)
     d["integrator"] = {"type": integrator_type, "max_depth": args.max_depth, "rr_depth": 5, "chunk_lanes": args.chunk}
     if integrator_type == "prb":
-        d["integrator"]["emitter_gradients"] = False      # north_star: gradients w.r.t. BSDF / texture parameters
+        d["integrator"]["emitter_gradients"] = True       # every differentiable scene parameter of the path: albedo texels, constant albedos, emitter radiance
     return mi.load_dict(d)
 
 
-def main():
-    args = parse()
+def load_profile(kind, workload):
+    """committed rocprofv3 PMC summaries (tools/gpu_profile.sh, copied to profiles/): newest round first"""
+    import glob
+    for path in sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_%s_%s.json" % (kind, workload))), reverse=True):
+        try:
+            with open(path) as f:
+                return json.load(f), os.path.basename(path)
+        except Exception:
+            continue
+    return None, None
+
+
+def kernel_record(profile, kernel):
+    for name, rec in (profile or {}).items():
+        if ("k_" + kernel) in name and "counters" in rec:
+            return rec
+    return None
+
+
+def worker(args):
+    import faulthandler
+    faulthandler.enable()                      # a GPU fault ends in abort(): say which Python line was running
+    log("importing torch")
     import numpy as np
     import torch
     import torch.distributed as dist
@@ -66,12 +144,16 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        raise SystemExit("bench.py: --gpus %d but the process group has %d rank(s); start it as `python bench.py --gpus N` (self-launching) "
+                         "or under torch.distributed.run with --nproc-per-node N" % (args.gpus, world))
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU: the hip_ad_rgb path has no CPU fallback")
     # HAR_BENCH_SHARE_GPU=1 + HAR_BENCH_BACKEND=gloo: rehearsal of the N-rank code path on a box with fewer GPUs than ranks
     # (ranks share devices, the film reduce goes through gloo); never used for reported numbers
     device_index = local_rank % torch.cuda.device_count() if os.environ.get("HAR_BENCH_SHARE_GPU") else local_rank
     torch.cuda.set_device(device_index)
+    backend = None
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
@@ -80,17 +162,21 @@ def main():
             dist.init_process_group(backend="nccl", device_id=torch.device("cuda", device_index))
         else:
             dist.init_process_group(backend=backend)
+        assert dist.get_world_size() == args.gpus
     mi.set_variant("hip_ad_rgb")
+    log("device %s, %d rank(s)" % (torch.cuda.get_device_name(device_index), world))
 
     def sync_barrier():
         if world > 1:
             dist.barrier()
         torch.cuda.synchronize()
 
-    def timed(fn, steps, warmup):
+    def timed(fn, steps, warmup, on_start=None):
         for _ in range(warmup):
             fn()
         sync_barrier()
+        if on_start:
+            on_start()
         t0 = time.perf_counter()
         for _ in range(steps):
             fn()
@@ -105,24 +191,32 @@ def main():
     n_paths = args.res * args.res * args.spp
 
     # ---------------- forward `path` ----------------
+    log("building the %s scene + BVH" % args.workload)
     scene = build_scene(mi, args, "path")
     integ = scene.integrator()
     accel = scene.accel_info()
-    integ.set_profiling(True)          # HIP events on the launch stream, one per kernel launch
 
     def fwd():
         return mi.render_distributed(scene, integ, seed=0, spp=args.spp)
 
-    dt = timed(fwd, args.steps, args.warmup)
+    log("first forward frame (workspace allocation, code object load)")
+    fwd(); sync_barrier()
+    log("forward: %d warmup + %d timed frames" % (args.warmup, args.steps))
+    # HIP events on the launch stream, one per kernel launch, over the TIMED frames only (har_integrator_set_profiling restarts the statistics;
+    # every frame records into its own event set, see include/hip_ad_rgb.h)
+    dt = timed(fwd, args.steps, args.warmup, on_start=lambda: integ.set_profiling(True))
     ms_per_step = dt / args.steps * 1e3
     value = n_paths / (dt / args.steps) / 1e6
-    timing = integ.timing()            # of the LAST timed step on this rank
+    timing = integ.timing()            # per-kernel HIP-event durations, average per frame over the timed frames of this rank
+    integ.set_profiling(False)
     stats = integ.stats()
+    log("forward done: %.1f Mpaths/s" % value)
 
-    # roofline of the dominant kernel, algorithmic bytes per SURVEY.md 8(d):
+    # roofline of the dominant kernel, algorithmic bytes per SURVEY.md 8(d) (DESIGN.md section 3):
     #   trace_closest: 56 B/ray (32 B ray in + 24 B hit out) + unique accel bytes once per launch
-    #   shade: 72+24 B in, 72 B out (live) ; resolve: 48 B/item + 32 B result RMW
-    kern_ms = {k: v[0] for k, v in timing.items()}
+    #   resolve: 33 B/shadow ray + accel ; shade: state in/out + hit + gathers ; raygen/splat: 152 + 16 B/path
+    kern_ms = {k: v[0] for k, v in timing.items() if k != "frames"}
+    frames_profiled = int(timing["frames"][0])
     dominant = max(("trace_closest", "shade", "resolve", "splat", "raygen"), key=lambda k: kern_ms[k])
     launches = max(timing[dominant][1], 1)
     if dominant == "trace_closest":
@@ -134,33 +228,44 @@ def main():
     else:
         alg_bytes = stats["paths"] * (152 + 16)
     achieved = alg_bytes / 1e9 / (kern_ms[dominant] / 1e3) if kern_ms[dominant] > 0 else 0.0
-    kbar = stats["vertices"] / max(stats["paths"], 1)
-    b_path = 152 + kbar * 505 + 16
-    # HBM traffic of the dominant kernel from the committed PMC passes (tools/gpu_profile.sh ... mem): bytes per launch
-    # = (FETCH_SIZE x 2 [gfx950 correction, MI355X_MICROARCH.md "HBM"] + WRITE_SIZE) KiB x 1024 / launches; null if the
-    # profile of this exact workload has not been collected
-    traffic = None
-    tpath = os.path.join(ROOT, "profiles", "r01_traffic_%s.json" % args.workload)
-    if os.path.exists(tpath) and args.res == 512 and args.spp == 256 and world == 1:      # the PMC passes were collected at N = 1 (launch sizes differ otherwise)
-        try:
-            with open(tpath) as f:
-                tj = json.load(f)
-            krec = next(v for k, v in tj.items() if ("k_" + dominant) in k and "counters" in v)
-            fetch = krec["counters"]["FETCH_SIZE"]; write = krec["counters"]["WRITE_SIZE"]
-            traffic = round((2.0 * fetch["sum"] / fetch["dispatches"] + write["sum"] / write["dispatches"]) * 1024.0)
-        except Exception:
-            traffic = None
+    # HBM traffic from the committed PMC passes (separate FETCH_SIZE / WRITE_SIZE runs of this command, tools/gpu_profile.sh ... mem):
+    # bytes = (FETCH_SIZE x 2 [gfx950 correction, MI355X_MICROARCH.md "HBM"] + WRITE_SIZE) KiB x 1024; per launch for the dominant kernel,
+    # summed over all kernels of a frame for `frame_traffic`.  Only valid for the launch shape it was collected at (N = 1, 512^2 x 256).
+    traffic = frame_traffic = traffic_src = None
+    bound_actual = None
+    if args.res == 512 and args.spp == 256 and world == 1 and not args.chunk:
+        prof, traffic_src = load_profile("traffic", args.workload)
+        rec = kernel_record(prof, dominant)
+        if rec and "FETCH_SIZE" in rec["counters"] and "WRITE_SIZE" in rec["counters"]:
+            f, w = rec["counters"]["FETCH_SIZE"], rec["counters"]["WRITE_SIZE"]
+            traffic = round((2.0 * f["sum"] / f["dispatches"] + w["sum"] / w["dispatches"]) * 1024.0)
+            tot = 0.0
+            for r in prof.values():
+                c = r.get("counters", {})
+                if "FETCH_SIZE" in c and "WRITE_SIZE" in c:
+                    tot += (2.0 * c["FETCH_SIZE"]["sum"] + c["WRITE_SIZE"]["sum"]) * 1024.0
+            frame_traffic = {"bytes_per_frame": round(tot), "GBs": round(tot / 1e9 / (ms_per_step / 1e3), 1),
+                             "frac_of_peak": round(tot / 1e9 / (ms_per_step / 1e3) / HBM_PEAK_GBS, 4), "source": "profiles/" + traffic_src}
+        sq, sq_src = load_profile("sq", args.workload)
+        rec = kernel_record(sq, dominant)
+        if rec and "SQ_ACTIVE_INST_VALU" in rec["counters"] and "SQ_BUSY_CYCLES" in rec["counters"]:
+            c = rec["counters"]
+            # SQ_ACTIVE_INST_VALU counts cycles (x4, per SIMD quad) in which a SIMD issues VALU; SQ_BUSY_CYCLES the cycles an SQ is busy (per SE / XCC):
+            # the ratio against SIMD-cycles = busy x (SIMDs per counter instance) is the VALU issue utilisation tools/rocpd_summary.py tabulates
+            bound_actual = {"kind": "valu_issue", "SQ_INSTS_VALU_per_64_rays": round(c["SQ_INSTS_VALU"]["sum"] / max(stats["closest_rays" if dominant == "trace_closest" else "shadow_rays"] / 64.0, 1), 1)
+                            if "SQ_INSTS_VALU" in c else None, "source": "profiles/" + sq_src}
     roofline = {"bound": "hbm", "kernel": dominant, "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": traffic, "algorithmic_bytes_per_launch": round(alg_bytes / launches),
-                "avg_launch_ms": round(kern_ms[dominant] / launches, 4), "launches": launches,
+                "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": traffic, "traffic_source": ("profiles/" + traffic_src) if traffic is not None else None,
+                "algorithmic_bytes_per_launch": round(alg_bytes / launches),
+                "avg_launch_ms": round(kern_ms[dominant] / launches, 4), "launches": launches, "frames_averaged": frames_profiled,
                 "kernel_ms": {k: round(v, 3) for k, v in kern_ms.items()},
-                "whole_path_model": {"K_bar": round(kbar, 3), "B_path": round(b_path, 1),
-                                     "achieved_GBs": round(value * 1e6 * b_path / 1e9, 1),
-                                     "frac_of_8TBs": round(value * 1e6 * b_path / 1e9 / HBM_PEAK_GBS, 5)}}
+                "bound_actual": bound_actual, "frame_traffic": frame_traffic}
 
     # ---------------- PRB adjoint ----------------
     prb = None
+    scene_p = None
     if not args.no_prb:
+        log("PRB adjoint: building the textured scene")
         scene_p = build_scene(mi, args, "prb")
         integ_p = scene_p.integrator()
         grad_in = torch.full((args.res, args.res, 3), 1.0 / (args.res * args.res * 3), device="cuda")
@@ -168,28 +273,48 @@ def main():
         def bwd():
             return mi.render_backward_distributed(scene_p, grad_in, integ_p, seed=1, spp=args.spp)
 
-        p_steps = max(1, min(args.steps, 2))
-        dtp = timed(bwd, p_steps, 1 if args.warmup else 0)
+        p_steps = max(1, min(args.steps, 5))
+        log("PRB adjoint: 1 warmup + %d timed steps" % p_steps)
+        dtp = timed(bwd, p_steps, 1)
+        pst = integ_p.stats()
         prb = {"metric": "Mpaths/s prb adjoint (weight pass + primal + adjoint replay)",
-               "value": round(n_paths / (dtp / p_steps) / 1e6, 2), "ms_per_step": round(dtp / p_steps * 1e3, 2), "steps": p_steps}
+               "value": round(n_paths / (dtp / p_steps) / 1e6, 2), "ms_per_step": round(dtp / p_steps * 1e3, 2), "steps": p_steps,
+               "workload": "%s + 256x256 bitmap albedo on the `white` BSDF (walls + spheres), emitter_gradients=True" % args.workload,
+               "gradient_targets": {"texels": int(sum(int(np.prod(t.shape)) for t in scene_p.textures)), "constant_albedos": len(scene_p.bsdfs), "emitters": len(scene_p.emitters)},
+               "stats": {k: int(v) for k, v in pst.items()}}
+        log("PRB adjoint done: %.1f Mpaths/s" % prb["value"])
 
-    # ---------------- CPU baseline (oracle, rank 0, N = 1 only) ----------------
+    # ---------------- CPU baseline (oracle = CPU restatement of llvm_ad_rgb; rank 0, N = 1 only) ----------------
     cpu = None
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         from oracle import oracle as O
-        from tests.test_cpu_host import oracle_scene_from
-        osc, sensor = oracle_scene_from(O, scene)
         cores = os.cpu_count() or 1
+        log("CPU baseline: oracle on %d host threads (forward)" % cores)
+        osc, sensor = O.scene_from_product(scene)
         t0 = time.perf_counter()
         _, st = osc.render_path(sensor, seed=0, spp=1, max_depth=args.max_depth, threads=cores)
         probe = time.perf_counter() - t0
-        spp_cpu = int(max(1, min(32, args.cpu_seconds / max(probe, 1e-3))))
+        budget = args.cpu_seconds * (0.6 if scene_p is not None else 1.0)
+        spp_cpu = int(max(1, min(64, budget / max(probe, 1e-3))))
         t0 = time.perf_counter()
         _, st = osc.render_path(sensor, seed=0, spp=spp_cpu, max_depth=args.max_depth, threads=cores)
         el = time.perf_counter() - t0
         cpu = {"value": round(st.paths / el / 1e6, 4), "unit": "Mpaths/s", "cores": cores, "kind": "port",
                "sample": "%dx%dx%d spp of the same scene/seed (%.1f s); CPU restatement of llvm_ad_rgb (reference not installable)"
                          % (args.res, args.res, spp_cpu, el)}
+        if scene_p is not None:
+            log("CPU baseline: oracle PRB backward")
+            oscp, sensorp = O.scene_from_product(scene_p)
+            g = np.full((args.res, args.res, 3), 1.0 / (args.res * args.res * 3), np.float32)
+            t0 = time.perf_counter()
+            oscp.render_prb_backward(sensorp, g, seed=1, spp=1, max_depth=args.max_depth, threads=cores)
+            probe = time.perf_counter() - t0
+            spp_p = int(max(1, min(32, args.cpu_seconds * 0.4 / max(probe, 1e-3))))
+            t0 = time.perf_counter()
+            oscp.render_prb_backward(sensorp, g, seed=1, spp=spp_p, max_depth=args.max_depth, threads=cores)
+            elp = time.perf_counter() - t0
+            cpu["prb_adjoint"] = {"value": round(args.res * args.res * spp_p / elp / 1e6, 4), "unit": "Mpaths/s",
+                                  "sample": "%dx%dx%d spp of the textured scene (%.1f s), render_prb_backward of the oracle" % (args.res, args.res, spp_p, elp)}
 
     if rank == 0:
         out = {
@@ -200,15 +325,22 @@ def main():
             "config": {"workload": "%s %dx%dx%dspp max_depth=%d rr_depth=5 seed=0" % (args.workload, args.res, args.res, args.spp, args.max_depth),
                        "triangles_effective": 100 * 10000 + 12 if args.workload != "cornell" else 36,
                        "accel": accel, "parallelism": "pixel-row tiles x%d, one RCCL film reduce" % world,
+                       "ranks": world, "collective_backend": ("rccl (torch.distributed nccl)" if backend == "nccl" else backend),
                        # row bands of equal measured cost (mitsuba3_amd/distributed.py BandBalancer; adapts over the first 3 frames, then frozen)
                        "row_bands": next(iter(getattr(integ, "_band_balancers", {}).values())).bounds if world > 1 and getattr(integ, "_band_balancers", None) else None},
             "prb_adjoint": prb, "roofline": roofline, "cpu_baseline": cpu,
             "stats": {k: int(v) for k, v in stats.items()},
+            "attempts": int(os.environ.get("HAR_BENCH_ATTEMPT", "1")),
         }
-        print(json.dumps(out))
+        print(json.dumps(out)); sys.stdout.flush()
     if world > 1:
         dist.destroy_process_group()
+    log("done")
 
 
 if __name__ == "__main__":
-    main()
+    _args = parse()
+    if _args.worker or "RANK" in os.environ:
+        worker(_args)
+    else:
+        sys.exit(launcher(_args))

@@ -281,10 +281,11 @@ int har_integrator_set_grad_positions(HarIntegrator integrator, HarScene scene, 
 
 /* counters of the last har_render / har_render_backward on this integrator (synchronises) */
 int har_render_stats(HarIntegrator integrator, HarStats *out);
-/* HIP-event timing of the last render call: per-kernel-class milliseconds, measured on
- * `stream` when profiling was enabled with har_integrator_set_profiling(.., 1).
- * ms[0]=raygen ms[1]=trace_closest ms[2]=shade ms[3]=trace_shadow ms[4]=splat ms[5]=total
- * launches[i] = number of launches in that class. */
+/* HIP-event timing of the render calls ("frames") issued since har_integrator_set_profiling(.., 1): one event per kernel launch, recorded on
+ * the stream of the launch.  Every frame records into its own event set (a ring of 32 sets; an event is never re-recorded while an earlier
+ * record may be pending), so frames may be enqueued back-to-back without synchronisation.  har_render_timing waits for the recorded frames and
+ * returns the AVERAGE PER FRAME: ms[0]=raygen ms[1]=trace_closest ms[2]=shade ms[3]=resolve (shadow rays) ms[4]=splat ms[5]=total ms[6]=other,
+ * launches[i] = launches of that class per frame, ms[7] = number of frames averaged.  set_profiling(.., 1) restarts the statistics. */
 int har_integrator_set_profiling(HarIntegrator integrator, int enable);
 /* `prb` only: keep the primal pass's ray-query results (24 B hit + 1 B visibility per lane and bounce, first 12 bounces) in
  * HBM and reuse them in the adjoint replay of the same chunk instead of tracing every ray twice (default: enabled).

@@ -769,10 +769,11 @@ class Integrator:
         check(lib().har_integrator_set_profiling(self._handle(), 1 if enable else 0))
 
     def timing(self):
+        """average per frame since set_profiling(True): {class: (milliseconds, launches)}; "frames" = (frames averaged, 0)"""
         ms = (C.c_float * 8)(); cnt = (C.c_uint32 * 8)()
         check(lib().har_render_timing(self._handle(), ms, cnt))
-        names = ["raygen", "trace_closest", "shade", "resolve", "splat", "total", "other", "_"]
-        return {names[i]: (ms[i], cnt[i]) for i in range(7)}
+        names = ["raygen", "trace_closest", "shade", "resolve", "splat", "total", "other", "frames"]
+        return {names[i]: (ms[i], cnt[i]) for i in range(8)}
 
     def stats(self):
         st = _capi.HarStats()
@@ -1397,6 +1398,10 @@ def render(scene, params=None, sensor=0, integrator=None, seed=0, seed_grad=0, s
         @staticmethod
         def backward(ctx, grad_out):
             grads = integrator.render_backward(scene, params, grad_out, sensor, seed_grad, spp_grad)
+            missing = [k for k in keys if k not in grads]
+            if missing:       # e.g. emitter radiance with emitter_gradients=False, vertex positions without shape_gradients
+                raise RuntimeError("mi.render(): the `prb` integrator is not configured to differentiate %s (integrator properties `emitter_gradients`, "
+                                   "`shape_gradients`); differentiable keys of this render: %s" % (missing, sorted(grads)))
             return tuple(grads[k].reshape(params[k].shape) for k in keys)
 
     return _RenderOp.apply(*[params[k] for k in keys])

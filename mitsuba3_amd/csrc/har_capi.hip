@@ -15,6 +15,8 @@
 #include <algorithm>
 #include <cstdio>
 #include <cstring>
+#include <map>
+#include <mutex>
 #include <string>
 #include <vector>
 
@@ -28,11 +30,65 @@ int har_set_error(const std::string &msg) { return fail(msg); }       /* used by
     do { hipError_t _e = (expr); if (_e != hipSuccess) {                                       \
         return fail(std::string(#expr) + ": " + hipGetErrorString(_e)); } } while (0)
 
+/*
+ * Device allocations of the library.  HAR_DEBUG_GUARD = 1 | 2 (debug switch, tests/test_gpu_parity.py::test_guarded_*): every buffer gets a private
+ * virtual-address reservation (hipMemAddressReserve / hipMemCreate / hipMemMap) with UNMAPPED ranges on both sides, and sits flush against the
+ * end (1) or the start (2) of its mapped pages -- an access past the end (before the start) of any workspace or scene array is then a GPU
+ * memory-access fault whatever the neighbouring allocations are, instead of a silent read of another array.  Default: plain hipMalloc.
+ */
+namespace {
+struct GuardedBlock { void *base; size_t reserved; void *mapped; size_t mapped_bytes; hipMemGenericAllocationHandle_t handle; };
+std::map<void *, GuardedBlock> g_guarded;
+std::mutex g_guarded_mutex;
+int guard_mode() { static const int m = getenv("HAR_DEBUG_GUARD") ? atoi(getenv("HAR_DEBUG_GUARD")) : 0; return m; }
+}
+static hipError_t dev_alloc(void **out, size_t bytes) {
+    bytes = std::max<size_t>(bytes, 1);
+    if (!guard_mode()) return hipMalloc(out, bytes);
+    int dev = 0; hipError_t e = hipGetDevice(&dev); if (e != hipSuccess) return e;
+    hipMemAllocationProp prop{}; prop.type = hipMemAllocationTypePinned; prop.location.type = hipMemLocationTypeDevice; prop.location.id = dev;
+    size_t gran = 0; e = hipMemGetAllocationGranularity(&gran, &prop, hipMemAllocationGranularityMinimum); if (e != hipSuccess) return e;
+    gran = std::max<size_t>(gran, 4096);
+    GuardedBlock B{};
+    B.mapped_bytes = (bytes + gran - 1) / gran * gran;
+    const size_t guard = std::max<size_t>(gran, (size_t) 64 << 20);          /* 64 MB of nothing on either side */
+    B.reserved = B.mapped_bytes + 2 * guard;
+    e = hipMemAddressReserve(&B.base, B.reserved, gran, nullptr, 0); if (e != hipSuccess) return e;
+    e = hipMemCreate(&B.handle, B.mapped_bytes, &prop, 0); if (e != hipSuccess) { (void) hipMemAddressFree(B.base, B.reserved); return e; }
+    B.mapped = (char *) B.base + guard;
+    e = hipMemMap(B.mapped, B.mapped_bytes, 0, B.handle, 0);
+    if (e == hipSuccess) {
+        hipMemAccessDesc acc{}; acc.location = prop.location; acc.flags = hipMemAccessFlagsProtReadWrite;
+        e = hipMemSetAccess(B.mapped, B.mapped_bytes, &acc, 1);
+    }
+    if (e != hipSuccess) { (void) hipMemRelease(B.handle); (void) hipMemAddressFree(B.base, B.reserved); return e; }
+    /* end-flush placement keeps 256-byte alignment (every array of the library is accessed with <= 16-byte vectors) */
+    void *user = guard_mode() == 2 ? B.mapped : (char *) B.mapped + (B.mapped_bytes - bytes) / 256 * 256;
+    std::lock_guard<std::mutex> lock(g_guarded_mutex);
+    g_guarded[user] = B; *out = user;
+    return hipSuccess;
+}
+static void dev_free(void *p) {
+    if (!p) return;
+    if (guard_mode()) {
+        std::lock_guard<std::mutex> lock(g_guarded_mutex);
+        auto it = g_guarded.find(p);
+        if (it != g_guarded.end()) {
+            const GuardedBlock B = it->second; g_guarded.erase(it);
+            (void) hipDeviceSynchronize();
+            (void) hipMemUnmap(B.mapped, B.mapped_bytes); (void) hipMemRelease(B.handle);
+            /* the address range stays reserved for the life of the process (quarantine): a stale pointer faults instead of reaching a later allocation */
+            return;
+        }
+    }
+    (void) hipFree(p);
+}
+
 template <typename T> static hipError_t upload(const std::vector<T> &v, const T **dst, std::vector<void *> &owned) {
     *dst = nullptr;
     size_t bytes = std::max<size_t>(v.size(), 1) * sizeof(T);
     void *p = nullptr;
-    hipError_t e = hipMalloc(&p, bytes);
+    hipError_t e = dev_alloc(&p, bytes);
     if (e != hipSuccess) return e;
     owned.push_back(p);
     if (!v.empty()) { e = hipMemcpy(p, v.data(), v.size() * sizeof(T), hipMemcpyHostToDevice); if (e != hipSuccess) return e; }
@@ -82,8 +138,14 @@ struct HarIntegratorImpl {
     int *status = nullptr;
     float **d_grad_tex = nullptr; size_t grad_tex_cap = 0;
     // profiling
+    /* Per-launch HIP events of the frames rendered since har_integrator_set_profiling(1).  An event is NEVER re-recorded while an earlier record of it
+     * may still be pending: every frame (render_range / backward_range call) takes its own event set from a ring, and a set is only reused after its
+     * last event has completed and its durations have been folded into the accumulators -- a render loop that enqueues tens of frames without a
+     * synchronisation (bench.py) therefore neither waits nor touches in-flight events. */
     bool profiling = false;
-    std::vector<hipEvent_t> events; std::vector<int> ev_class; size_t ev_used = 0;
+    struct EventSet { std::vector<hipEvent_t> ev; std::vector<int> cls; size_t used = 0; };
+    std::vector<EventSet> sets; size_t cur_set = 0;
+    double acc_ms[8] = { 0 }; uint64_t acc_launches[8] = { 0 }; uint64_t acc_frames = 0;
     hipStream_t last_stream = nullptr;
     /* two-stream mode: a job of >= HAR_DUAL_MIN_LANES lanes is cut in two halves that run concurrently -- this integrator on the caller's stream, a
      * private twin (own workspace) on `side_stream`.  Every persistent traversal launch ends with a tail of a few hundred microseconds in which
@@ -91,18 +153,20 @@ struct HarIntegratorImpl {
      * of one fill the CUs the other's tail leaves idle. */
     HarIntegratorImpl *twin = nullptr; bool twin_used = false;
     hipStream_t side_stream = nullptr; hipEvent_t ev_fork = nullptr, ev_join = nullptr;
-    void free_ws() { for (void *p : owned) (void) hipFree(p); owned.clear(); ws_lanes = 0; }
+    void free_ws();
 };
+void HarIntegratorImpl::free_ws() { for (void *p : owned) dev_free(p); owned.clear(); ws_lanes = 0; }
 #define HAR_DUAL_MIN_LANES (1u << 20)
 #define HAR_DUAL_MAX_LANES (1u << 24)
 
 namespace {
 
+void prof_mark(HarIntegratorImpl *I, hipStream_t s, int cls);
 enum { CLS_RAYGEN = 0, CLS_TRACE = 1, CLS_SHADE = 2, CLS_RESOLVE = 3, CLS_SPLAT = 4, CLS_OTHER = 6, CLS_START = 7 };
 
 template <typename T> int ws_alloc(HarIntegratorImpl *I, T **p, size_t count) {
     void *q = nullptr;
-    hipError_t e = hipMalloc(&q, std::max<size_t>(count, 1) * sizeof(T));
+    hipError_t e = dev_alloc(&q, std::max<size_t>(count, 1) * sizeof(T));
     if (e != hipSuccess) return fail(std::string("hipMalloc(workspace): ") + hipGetErrorString(e));
     I->owned.push_back(q); *p = (T *) q;
     return 0;
@@ -152,14 +216,59 @@ int ensure_workspace(HarIntegratorImpl *I, uint32_t lanes, bool adjoint) {
     return 0;
 }
 
-void prof_mark(HarIntegratorImpl *I, hipStream_t s, int cls) {
-    if (!I->profiling) return;
-    if (I->ev_used == I->events.size()) {
-        hipEvent_t e; if (hipEventCreate(&e) != hipSuccess) return;
-        I->events.push_back(e); I->ev_class.push_back(cls);
+/* HAR_DEBUG_SYNC=1 (debug switch): name every launch class on stderr and wait for it, so that a GPU fault is attributed to a kernel */
+void dbg_sync(hipStream_t s, int cls) {
+    static const bool on = getenv("HAR_DEBUG_SYNC") != nullptr;
+    if (!on) return;
+    static const char *names[8] = { "raygen", "trace_closest", "shade", "resolve", "splat", "?", "other", "start" };
+    fprintf(stderr, "[hip_ad_rgb] sync after %s ...", names[cls & 7]); fflush(stderr);
+    hipError_t e = hipStreamSynchronize(s);
+    fprintf(stderr, " %s\n", hipGetErrorString(e)); fflush(stderr);
+}
+
+#define HAR_PROFILE_RING 32       /* event sets (frames in flight) before prof_begin has to wait for the oldest */
+/* fold a finished event set into the accumulators (waits for its last event) */
+int prof_collect(HarIntegratorImpl *I, HarIntegratorImpl::EventSet &E) {
+    if (E.used >= 2) {
+        HIP_TRY(hipEventSynchronize(E.ev[E.used - 1]));
+        for (size_t k = 1; k < E.used; ++k) {
+            float dt = 0.f;
+            HIP_TRY(hipEventElapsedTime(&dt, E.ev[k - 1], E.ev[k]));
+            int c = E.cls[k]; if (c < 0 || c > 6) c = CLS_OTHER;
+            I->acc_ms[c] += dt; I->acc_launches[c]++; I->acc_ms[5] += dt;
+        }
+        I->acc_frames++;
     }
-    I->ev_class[I->ev_used] = cls;
-    (void) hipEventRecord(I->events[I->ev_used++], s);
+    E.used = 0;
+    return 0;
+}
+/* start of a frame: take the next event set of the ring */
+int prof_begin(HarIntegratorImpl *I, hipStream_t s) {
+    if (!I->profiling) return 0;
+    if (I->sets.empty()) { I->sets.resize(1); I->cur_set = 0; }
+    else {
+        const size_t next = (I->cur_set + 1) % HAR_PROFILE_RING;
+        if (next >= I->sets.size()) I->sets.resize(next + 1);
+        I->cur_set = next;
+    }
+    if (prof_collect(I, I->sets[I->cur_set])) return 1;
+    prof_mark(I, s, CLS_START);
+    return 0;
+}
+void prof_mark(HarIntegratorImpl *I, hipStream_t s, int cls) {
+    dbg_sync(s, cls);
+    if (!I->profiling || I->sets.empty()) return;
+    HarIntegratorImpl::EventSet &E = I->sets[I->cur_set];
+    if (E.used == E.ev.size()) {
+        hipEvent_t e; if (hipEventCreate(&e) != hipSuccess) return;
+        E.ev.push_back(e); E.cls.push_back(cls);
+    }
+    E.cls[E.used] = cls;
+    (void) hipEventRecord(E.ev[E.used++], s);
+}
+void prof_destroy(HarIntegratorImpl *I) {
+    for (auto &E : I->sets) for (hipEvent_t e : E.ev) (void) hipEventDestroy(e);
+    I->sets.clear();
 }
 
 uint32_t log2_exact(uint32_t v) { for (uint32_t k = 0; k < 32; ++k) if ((1u << k) == v) return k; return 0xffffffffu; }
@@ -340,7 +449,7 @@ int har_scene_create(const HarSceneDesc *desc, HarScene *out) {
         hs.envmap.tex = tex; hs.envmap.warp = warp;
         std::vector<DEnvmap> one(1, hs.envmap); up(one, &D.envmap);
     }
-    if (err != hipSuccess) { for (void *p : S->owned) (void) hipFree(p); delete S; return fail(std::string("scene upload: ") + hipGetErrorString(err)); }
+    if (err != hipSuccess) { for (void *p : S->owned) dev_free(p); delete S; return fail(std::string("scene upload: ") + hipGetErrorString(err)); }
     S->d_bsdfs = const_cast<DBsdf *>(D.bsdfs);
     D.accel.root = hs.root; D.accel.has_tlas = hs.has_tlas; D.accel.n_tris = (uint32_t) hs.tris.size(); D.accel.n_insts = (uint32_t) hs.inst_recs.size();
     D.n_emitters = (uint32_t) hs.emitters.size(); D.n_meshes = (uint32_t) hs.meshes.size();
@@ -349,9 +458,16 @@ int har_scene_create(const HarSceneDesc *desc, HarScene *out) {
     D.bsdf_types = 0; for (const DBsdf &b : hs.bsdfs) D.bsdf_types |= (1u << b.type) | ((b.flags & BF_TWOSIDED) ? 0x80000000u : 0u);
     up(hs.emitter_cdf, &D.emitter_cdf);
     if (hs.has_envmap || hs.has_mesh_emitters) D.bsdf_types |= HAR_SCENE_ENVMAP;
-    if (hs.stack_need() + HAR_STACK_MARGIN > std::min(HAR_LDS_STACK_DEPTH, HAR_LDS_STACK_SMALL + HAR_STACK_SPILL))
-        fprintf(stderr, "[hip_ad_rgb] warning: BVH needs %u traversal stack entries, the traversal stack holds %d (overflow is reported as an error)\n", hs.stack_need(),
-                std::min(HAR_LDS_STACK_DEPTH, HAR_LDS_STACK_SMALL + HAR_STACK_SPILL));
+    /* the depth-first bound of the BVH must fit the traversal stacks (LDS entries + HBM spill columns): a deeper scene is refused here instead of
+     * rendering with rays that overflow (an overflowing ray is a miss + a status word that only har_render_stats reads) */
+    const uint32_t stack_cap = (uint32_t) std::min(HAR_LDS_STACK_DEPTH, HAR_LDS_STACK_SMALL + HAR_STACK_SPILL);
+    if (hs.stack_need() + HAR_STACK_MARGIN > stack_cap) {
+        const std::string msg = "the scene's BVH needs " + std::to_string(hs.stack_need() + HAR_STACK_MARGIN) + " traversal stack entries per ray, the kernels hold " +
+                                std::to_string(stack_cap) + " (HAR_LDS_STACK_DEPTH / HAR_LDS_STACK_SMALL + HAR_STACK_SPILL in har_kernels.h)";
+        for (void *p : S->owned) dev_free(p);
+        delete S;
+        return fail(msg);
+    }
     *out = S;
     return 0;
 }
@@ -359,7 +475,7 @@ int har_scene_create(const HarSceneDesc *desc, HarScene *out) {
 int har_scene_destroy(HarScene S) {
     if (!S) return 0;
     (void) hipDeviceSynchronize();     /* accel must outlive in-flight launches (scene_native.inl:44-57) */
-    for (void *p : S->owned) (void) hipFree(p);
+    for (void *p : S->owned) dev_free(p);
     delete S;
     return 0;
 }
@@ -406,19 +522,19 @@ int har_ray_intersect_preliminary(HarScene S, uint32_t n, const float *o, const 
                                   float *v, uint32_t *prim, uint32_t *shape, uint32_t *inst, void *stream) {
     if (!S) return fail("null scene");
     if (n == 0) return 0;
-    int *st = nullptr; HIP_TRY(hipMalloc(&st, sizeof(int))); HIP_TRY(hipMemsetAsync(st, 0, sizeof(int), (hipStream_t) stream));
+    int *st = nullptr; HIP_TRY(dev_alloc((void **) &st, sizeof(int))); HIP_TRY(hipMemsetAsync(st, 0, sizeof(int), (hipStream_t) stream));
     launch_api_intersect((hipStream_t) stream, S->ds, n, o, d, maxt, naive, t, u, v, prim, shape, inst, st);
     HIP_TRY(hipGetLastError());
-    int rc = read_status(st, (hipStream_t) stream); (void) hipFree(st);
+    int rc = read_status(st, (hipStream_t) stream); dev_free(st);
     return rc;
 }
 int har_ray_test(HarScene S, uint32_t n, const float *o, const float *d, const float *maxt, int naive, uint8_t *hit, void *stream) {
     if (!S) return fail("null scene");
     if (n == 0) return 0;
-    int *st = nullptr; HIP_TRY(hipMalloc(&st, sizeof(int))); HIP_TRY(hipMemsetAsync(st, 0, sizeof(int), (hipStream_t) stream));
+    int *st = nullptr; HIP_TRY(dev_alloc((void **) &st, sizeof(int))); HIP_TRY(hipMemsetAsync(st, 0, sizeof(int), (hipStream_t) stream));
     launch_api_ray_test((hipStream_t) stream, S->ds, n, o, d, maxt, naive, hit, st);
     HIP_TRY(hipGetLastError());
-    int rc = read_status(st, (hipStream_t) stream); (void) hipFree(st);
+    int rc = read_status(st, (hipStream_t) stream); dev_free(st);
     return rc;
 }
 int har_compute_surface_interaction(HarScene S, uint32_t n, const float *o, const float *d, const float *t, const float *u, const float *v,
@@ -505,8 +621,8 @@ int har_integrator_destroy(HarIntegrator I) {
     if (!I) return 0;
     (void) hipDeviceSynchronize();
     I->free_ws();
-    for (hipEvent_t e : I->events) (void) hipEventDestroy(e);
-    if (I->twin) { I->twin->free_ws(); for (hipEvent_t e : I->twin->events) (void) hipEventDestroy(e); delete I->twin; }
+    prof_destroy(I);
+    if (I->twin) { I->twin->free_ws(); prof_destroy(I->twin); delete I->twin; }
     if (I->ev_fork) (void) hipEventDestroy(I->ev_fork);
     if (I->ev_join) (void) hipEventDestroy(I->ev_join);
     if (I->side_stream) (void) hipStreamDestroy(I->side_stream);
@@ -532,8 +648,8 @@ static int render_range(HarScene S, HarIntegrator I, const HarSensor *sensor, ui
     }
     HIP_TRY(hipMemsetAsync(I->totals, 0, 4 * sizeof(unsigned long long), s));
     HIP_TRY(hipMemsetAsync(I->status, 0, sizeof(int), s));
-    I->ev_used = 0; I->last_stream = s;
-    prof_mark(I, s, CLS_START);
+    I->last_stream = s;
+    if (prof_begin(I, s)) return 1;
     const int mode = I->type == HAR_INTEGRATOR_PATH ? MODE_PATH : MODE_PRB_PRIMAL;
     for (uint32_t pass = 0; pass < n_passes; ++pass) {
         if (I->max_depth == 0) {      /* path.cpp:102-103: nothing but the weight channel */
@@ -693,8 +809,8 @@ static int backward_range(HarScene S, HarIntegrator I, const HarSensor *sensor, 
     }
     HIP_TRY(hipMemsetAsync(I->totals, 0, 4 * sizeof(unsigned long long), s));
     HIP_TRY(hipMemsetAsync(I->status, 0, sizeof(int), s));
-    I->ev_used = 0; I->last_stream = s;
-    prof_mark(I, s, CLS_START);
+    I->last_stream = s;
+    if (prof_begin(I, s)) return 1;
     launch_adjoint_image(s, grad_in, weight_film, (uint32_t) npx, I->adj);
     prof_mark(I, s, CLS_OTHER);
     for (uint64_t base = lb; base < le; base += chunk) {
@@ -771,27 +887,34 @@ int har_integrator_set_replay_cache(HarIntegrator I, int enable) {
 
 int har_integrator_set_profiling(HarIntegrator I, int enable) {
     if (!I) return fail("null integrator");
-    I->profiling = enable != 0; I->ev_used = 0;
-    return 0;
-}
-
-static int add_timing(HarIntegratorImpl *I, float ms[8], uint32_t launches[8]) {
-    if (I->ev_used < 2) return 0;
-    HIP_TRY(hipEventSynchronize(I->events[I->ev_used - 1]));
-    for (size_t k = 1; k < I->ev_used; ++k) {
-        float dt = 0.f;
-        HIP_TRY(hipEventElapsedTime(&dt, I->events[k - 1], I->events[k]));
-        int c = I->ev_class[k]; if (c < 0 || c > 6) c = CLS_OTHER;
-        ms[c] += dt; launches[c]++; ms[5] += dt;
+    /* (re)start: frames enqueued so far are dropped from the statistics (their events complete on their own and are reused later) */
+    for (HarIntegratorImpl *J : { I, I->twin }) {
+        if (!J) continue;
+        J->profiling = enable != 0;
+        if (!J->sets.empty()) { (void) hipDeviceSynchronize(); for (auto &E : J->sets) E.used = 0; }
+        for (int k = 0; k < 8; ++k) { J->acc_ms[k] = 0.0; J->acc_launches[k] = 0; }
+        J->acc_frames = 0;
     }
     return 0;
 }
-/* in two-stream mode the launches of both halves are summed: kernels of the two streams overlap, so the class totals exceed the wall time */
+
+static int add_timing(HarIntegratorImpl *I, double ms[8], double launches[8], uint64_t &frames) {
+    for (auto &E : I->sets) if (prof_collect(I, E)) return 1;
+    for (int k = 0; k < 8; ++k) { ms[k] += I->acc_ms[k]; launches[k] += (double) I->acc_launches[k]; }
+    frames = std::max(frames, I->acc_frames);
+    return 0;
+}
+/* AVERAGE per frame over the frames rendered since har_integrator_set_profiling(1): ms[c] = device time between consecutive events of class c,
+ * launches[c] = launches of class c per frame (rounded); ms[7] = number of frames averaged over.  In two-stream mode the launches of both
+ * halves are summed: kernels of the two streams overlap, so the class totals exceed the wall time. */
 int har_render_timing(HarIntegrator I, float ms[8], uint32_t launches[8]) {
     if (!I) return fail("null integrator");
-    for (int k = 0; k < 8; ++k) { ms[k] = 0.f; launches[k] = 0; }
-    if (add_timing(I, ms, launches)) return 1;
-    if (I->twin_used && I->twin && add_timing(I->twin, ms, launches)) return 1;
+    double m[8] = { 0 }, l[8] = { 0 }; uint64_t frames = 0;
+    if (add_timing(I, m, l, frames)) return 1;
+    if (I->twin && add_timing(I->twin, m, l, frames)) return 1;
+    const double f = frames ? (double) frames : 1.0;
+    for (int k = 0; k < 8; ++k) { ms[k] = (float) (m[k] / f); launches[k] = (uint32_t) (l[k] / f + 0.5); }
+    ms[7] = (float) frames;
     return 0;
 }
 

@@ -377,7 +377,8 @@ __global__ __launch_bounds__(kBlock, HAR_SHADE_MIN_WAVES) void k_shade(DScene S,
     __shared__ float eacc[MODE == MODE_PRB_ADJOINT ? 3 * HAR_LDS_GRAD_EMITTERS : 1];
     const bool emitter_grads = MODE == MODE_PRB_ADJOINT && (P.flags & HAR_SHADE_EMITTER_GRADS) != 0u;
     if (emitter_grads) { for (uint32_t k = threadIdx.x; k < 3 * HAR_LDS_GRAD_EMITTERS; k += kBlock) eacc[k] = 0.f; __syncthreads(); }
-    __shared__ uint32_t sort_cnt[8], sort_perm[TYPES == HAR_BSDF_ONLY_DIFFUSE ? 1 : kBlock];
+    constexpr uint32_t kSortKeys = BSDF_TYPE_COUNT + 2;                        /* one bucket per BSDF model, then misses, then lanes beyond the tile's end */
+    __shared__ uint32_t sort_cnt[kSortKeys], sort_perm[TYPES == HAR_BSDF_ONLY_DIFFUSE ? 1 : kBlock];
     const ShardLoop Q(count_in, shard_cap);
     uint32_t *cnt_alive = count_out + Q.shard * HAR_COUNTER_STRIDE, *cnt_item = item_count + Q.shard * HAR_COUNTER_STRIDE;
     for (uint32_t tile = Q.first_tile(); tile * kBlock < Q.n; tile += Q.tile_step()) {
@@ -387,16 +388,16 @@ __global__ __launch_bounds__(kBlock, HAR_SHADE_MIN_WAVES) void k_shade(DScene S,
              * (block-wide counting sort in LDS), so that a wave runs (mostly) ONE material model of the generic shading
              * code instead of diverging over all of them.  The tile is a contiguous 4 KB window per state array, so the
              * permuted loads still consume whole cache lines. */
-            uint32_t key = 5u;                                         /* 4 = miss, 5 = out of range */
+            uint32_t key = BSDF_TYPE_COUNT + 1u;                       /* BSDF_TYPE_COUNT = miss, + 1 = out of range */
             if (local < Q.n) {
                 uint2 hs; float t;
                 if (MODE == MODE_PRB_ADJOINT && rc.mode == 2) {
                     const uint32_t cl = __float_as_uint(in.a3[Q.base + local].w) - lane_base;
                     hs = rc.h1[cl]; t = rc.h0[cl].x;
                 } else { hs = h1[Q.base + local]; t = h0[Q.base + local].x; }
-                key = t == HAR_INF ? 4u : S.bsdfs[S.meshes[hs.x].bsdf].type;
+                key = t == HAR_INF ? (uint32_t) BSDF_TYPE_COUNT : min(S.bsdfs[S.meshes[hs.x].bsdf].type, (uint32_t) BSDF_TYPE_COUNT - 1u);
             }
-            if (threadIdx.x < 8) sort_cnt[threadIdx.x] = 0;
+            if (threadIdx.x < kSortKeys) sort_cnt[threadIdx.x] = 0;
             __syncthreads();
             const uint32_t pos = atomicAdd(&sort_cnt[key], 1u);
             __syncthreads();
@@ -708,21 +709,30 @@ __global__ __launch_bounds__(kBlock) void k_splat(DSensor C, uint32_t seed, uint
     Footprint F; F.count = 0; F.x0 = 0; F.y0 = 0;
     for (int k = 0; k < HAR_MAX_FILTER_TAPS; ++k) { F.wx[k] = 0.f; F.wy[k] = 0.f; }
     float val[4] = { 0.f, 0.f, 0.f, 1.f };
+    /* `shifted`: the footprint does not start at (pixel - n).  pos = ipos + jitter is a float32 addition: for jitter within half an ulp of 1 it rounds
+     * up to ipos + 1 (about 1e-5 of the samples of a 512-wide film), and ImageBlock::put (imageblock.cpp:444-470) -- like film_footprint -- takes the
+     * footprint from floor(pos).  The gather below knows the lanes of a tile column only through their PIXEL, so such a lane is left out of it
+     * (zero weights in LDS) and scatters its taps itself, as the reference's put() does. */
+    bool shifted = false;
     if (act) {
         LaneSample ls;
         if (jitter) { const float2 j = jitter[i]; ls = lane_sample(C, lane_base + i, spp, log_spp, j.x, j.y); }
         else ls = lane_film_pos(C, seed, spp, log_spp, lane_base + i);
         film_footprint(C, ls, F);
+        const uint32_t nh = (F.count - 1u) / 2u;
+        const uint32_t px0 = (uint32_t) ((int32_t) ls.ipos_x - (int32_t) nh - (int32_t) C.crop_x), py0 = (uint32_t) ((int32_t) ls.ipos_y - (int32_t) nh - (int32_t) C.crop_y);
+        shifted = F.x0 != px0 || F.y0 != py0;
         if (!weights_only) { float4 r = result[i]; val[0] = r.x; val[1] = r.y; val[2] = r.z; }
         if (WONLY == 2) val[3] = scalar[i];
-        /* lanes are ordered by pixel: the block's extent follows from its first and last active lane (no LDS min / max atomics) */
-        if (threadIdx.x == 0) { ext[0] = (int) F.x0; ext[1] = (int) F.y0; ext[4] = (int) F.count; }
-        if (threadIdx.x == n_act_u - 1u) { ext[2] = (int) F.x0; ext[3] = (int) F.y0; }
+        /* lanes are ordered by pixel: the block's extent follows from the pixels of its first and last active lane (no LDS min / max atomics) */
+        if (threadIdx.x == 0) { ext[0] = (int) px0; ext[1] = (int) py0; ext[4] = (int) F.count; }
+        if (threadIdx.x == n_act_u - 1u) { ext[2] = (int) px0; ext[3] = (int) py0; }
     }
-    if (!WONLY) s_val[threadIdx.x] = act ? make_float4(val[0], val[1], val[2], val[3]) : make_float4(0.f, 0.f, 0.f, 0.f);
-    if (WONLY == 2) s_sv[threadIdx.x] = act ? val[3] : 0.f;
+    const bool gathered = act && !shifted;
+    if (!WONLY) s_val[threadIdx.x] = gathered ? make_float4(val[0], val[1], val[2], val[3]) : make_float4(0.f, 0.f, 0.f, 0.f);
+    if (WONLY == 2) s_sv[threadIdx.x] = gathered ? val[3] : 0.f;
 #pragma unroll
-    for (int k = 0; k < TAPS; ++k) { s_wx[k][threadIdx.x] = F.wx[k]; s_wy[k][threadIdx.x] = F.wy[k]; }
+    for (int k = 0; k < TAPS; ++k) { s_wx[k][threadIdx.x] = gathered ? F.wx[k] : 0.f; s_wy[k][threadIdx.x] = gathered ? F.wy[k] : 0.f; }
     __syncthreads();
     const int ox = ext[0], oy = ext[1], tw = ext[2] + ext[4] - ext[0], th = ext[4];
     const bool one_row = tw > 0 && ext[1] == ext[3] && th <= TAPS;   /* all lanes in one image row (the footprint size is a constant of the filter) */
@@ -767,7 +777,8 @@ __global__ __launch_bounds__(kBlock) void k_splat(DSensor C, uint32_t seed, uint
             }
             __syncthreads();
         }
-    } else if (act) {           /* lanes of two image rows in one block (width * spp not a multiple of 256): per-lane scatter */
+    }
+    if (act && (!one_row || shifted)) {           /* lanes of two image rows in one block (width * spp not a multiple of 256), shifted footprints: per-lane scatter */
 #pragma unroll
         for (int ys = 0; ys < TAPS; ++ys)
 #pragma unroll

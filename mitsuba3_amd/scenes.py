@@ -25,10 +25,19 @@ def bumpy_sphere(n_u=100, n_v=50, radius=0.08):
     return P.astype(np.float32), N.astype(np.float32), UV.astype(np.float32), np.asarray(F, np.uint32)
 
 
-def instanced_spheres_scene(width=512, height=512, spp=256, grid=10, n_u=100, n_v=50, flatten=False, max_depth=8, materials=False):
+def checker_texture(tex_res=256):
+    """C4's albedo bitmap: 0.5 + 0.25 * checker(8 x 8), raw RGB float32"""
+    yy, xx = np.mgrid[0:tex_res, 0:tex_res]
+    checker = (((xx * 8) // tex_res + (yy * 8) // tex_res) % 2).astype(np.float32)
+    return np.repeat((0.5 + 0.25 * (checker - 0.5) * 2 * 0.5)[..., None], 3, -1).astype(np.float32)
+
+
+def instanced_spheres_scene(width=512, height=512, spp=256, grid=10, n_u=100, n_v=50, flatten=False, max_depth=8, materials=False, textured=False, tex_res=256):
     """C3 of SURVEY.md 8(d): Cornell box + grid x grid instances of a 2*n_u*n_v-triangle bumpy
     sphere (10 x 10 x 10 000 = 1.0 M effective triangles).  flatten=True bakes every instance
-    into unique triangles (true BVH-size stress)."""
+    into unique triangles (true BVH-size stress).  textured=True: the `white` BSDF (floor, ceiling, back wall and -- instanced scene: all,
+    flattened: every third -- spheres) takes the C4 checker bitmap as its reflectance, so that a PRB adjoint over this scene scatters its
+    gradients into texels (bilinear taps, atomics under contention) instead of three constant-albedo slots."""
     T = ScalarTransform4f
     d = cornell_box()
     d['sensor']['film']['width'] = width; d['sensor']['film']['height'] = height
@@ -40,6 +49,8 @@ def instanced_spheres_scene(width=512, height=512, spp=256, grid=10, n_u=100, n_
         d['white'] = {'type': 'roughplastic', 'diffuse_reflectance': {'type': 'rgb', 'value': [0.885809, 0.698859, 0.666422]}, 'alpha': 0.2}
         d['green'] = {'type': 'twosided', 'm': {'type': 'roughconductor', 'distribution': 'ggx', 'alpha': 0.15, 'eta': [0.2, 0.92, 1.1], 'k': [3.9, 2.45, 2.14]}}
         d['glass'] = {'type': 'dielectric', 'int_ior': 1.5}
+    if textured:
+        d['white'] = {'type': 'diffuse', 'reflectance': {'type': 'bitmap', 'data': checker_texture(tex_res), 'raw': True}}
     P, N, UV, F = bumpy_sphere(n_u, n_v)
     mesh = {'type': 'mesh', 'positions': P, 'normals': N, 'texcoords': UV, 'faces': F, 'bsdf': {'type': 'ref', 'id': 'white'}}
     if not flatten:
@@ -67,8 +78,6 @@ def textured_cornell_box(res=256, tex_res=256, spp=256, max_depth=6):
     d['sensor']['film']['width'] = res; d['sensor']['film']['height'] = res
     d['sensor']['sampler']['sample_count'] = spp
     d['integrator'] = {'type': 'prb', 'max_depth': max_depth, 'rr_depth': 5}
-    yy, xx = np.mgrid[0:tex_res, 0:tex_res]
-    checker = (((xx * 8) // tex_res + (yy * 8) // tex_res) % 2).astype(np.float32)
-    tex = np.repeat((0.5 + 0.25 * (checker - 0.5) * 2 * 0.5)[..., None], 3, -1).astype(np.float32)
+    tex = checker_texture(tex_res)
     d['white'] = {'type': 'diffuse', 'reflectance': {'type': 'bitmap', 'data': tex, 'raw': True}}
     return d

@@ -522,3 +522,20 @@ def develop(film):
     img = np.empty((h, w, 3), np.float32)
     lib().orc_film_develop(fp(f32(film)), w, h, fp(img))
     return img
+
+
+def scene_from_product(scene):
+    """Feed the product's flat scene arrays (mitsuba3_amd.Scene) to the oracle unchanged."""
+    sd = SceneData()
+    for m in scene.meshes:
+        sd.add_mesh(m["V"], m["F"], m["bsdf"], m["emitter"], m["flags"])
+    sd.top_mesh_count = scene.top_mesh_count
+    sd.groups = list(scene.groups); sd.instances = list(scene.instances)
+    types = {"diffuse": 0, "dielectric": 1, "roughconductor": 2, "roughplastic": 3, "conductor": 4, "plastic": 5}
+    sd.bsdfs = [(types[b.kind], b.tex_index if b.texture is not None else -1, b.value,
+                 dict(flags=b.flags, reflectance2=b.value2, alpha_u=b.alpha_u, alpha_v=b.alpha_v, eta=b.eta, eta_c=b.eta_c, k_c=b.k_c,
+                      back=b.back.index if b.back is not None else -1)) for b in scene.bsdf_objs]
+    sd.textures = list(scene.textures); sd.emitters = list(scene.emitters)
+    s = Sensor()
+    C.memmove(C.byref(s), C.byref(scene.sensors()[0].har), C.sizeof(s))
+    return OracleScene(sd), s
