@@ -824,6 +824,20 @@ class Integrator:
             self.stats()                 # surfaces device-side errors (traversal stack overflow)
         return out
 
+    def render_weights(self, scene, sensor=0, seed=0, spp=0, lanes=None):
+        """the weight-only splat of RBIntegrator.render_backward (common.py:716-746: a dummy L = 1 film) for lanes [begin, end) (all when None):
+        raw H x W x 4 film whose channel 3 is the accumulated filter weight W[px]"""
+        torch = _torch(); dev = _device()
+        sensor = self._sensor(scene, sensor)
+        if spp:
+            sensor.sampler().set_sample_count(spp)
+        spp = sensor.sampler().sample_count()
+        w, h = sensor.film().crop_size()
+        film = torch.zeros((h, w, 4), dtype=torch.float32, device=dev)
+        lb, le = lanes if lanes else (0, 0)
+        check(lib().har_render_weights(C.byref(sensor.har), (sensor.sampler().m_base_seed + int(seed)) & 0xffffffff, spp, lb, le, _ptr(film), _stream()))
+        return film
+
     def render_backward(self, scene, params, grad_in, sensor=0, seed=0, spp=0, lanes=None, weight_film=None):
         """RBIntegrator.render_backward (common.py:625-783): returns {key: gradient tensor}."""
         if self.type != 'prb':

@@ -149,10 +149,9 @@ def render_distributed(scene, integrator=None, sensor=0, seed=0, spp=0, develop=
 
 
 def render_backward_distributed(scene, grad_in, integrator=None, sensor=0, seed=0, spp=0):
-    """RBIntegrator.render_backward across all ranks; gradients are all-reduced."""
-    import ctypes as C
-    from . import core
-    from ._capi import lib, check
+    """RBIntegrator.render_backward across all ranks (common.py:625-783): every rank splats the filter weights of its lane band, ONE all-reduce
+    makes W[px] complete everywhere (the adjoint of develop needs every rank's samples), every rank replays its band, and the gradient
+    buffers are all-reduced.  Returns {key: gradient tensor}, identical on every rank."""
     integrator = integrator or scene.integrator()
     s = scene.sensors()[sensor] if isinstance(sensor, int) else sensor
     if spp:
@@ -164,10 +163,7 @@ def render_backward_distributed(scene, grad_in, integrator=None, sensor=0, seed=
     y0, y1 = bal.band(rank)
     lanes = (y0 * w * spp, y1 * w * spp)
     adapt = bal.adapting()
-    dev = core._device()
-    wfilm = torch.zeros((h, w, 4), dtype=torch.float32, device=dev)
-    sd = (s.sampler().m_base_seed + int(seed)) & 0xffffffff
-    check(lib().har_render_weights(C.byref(s.har), sd, spp, lanes[0], lanes[1], core._ptr(wfilm), core._stream()))
+    wfilm = integrator.render_weights(scene, s, seed, spp, lanes=lanes)
     if world > 1:
         dist.all_reduce(wfilm, op=dist.ReduceOp.SUM)          # W[px] needs every rank's samples
     with _Timer(adapt) as timer:

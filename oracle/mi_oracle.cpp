@@ -1356,9 +1356,35 @@ void orc_scene_set_emitter_radiance(void *scene, uint32_t emitter, const float r
     Scene &sc = *(Scene *) scene;
     if (emitter < sc.emitters.size()) for (int c = 0; c < 3; ++c) sc.emitters[emitter].radiance[c] = rgb[c];
 }
+/* weight-only splat of lanes [lb, le): W[px] of the dummy L = 1 film (common.py:716-746) */
+static void render_weights_impl(const OrcSensor &s, uint32_t seed, uint32_t spp, uint64_t lb, uint64_t le, float *film, int threads) {
+    RFilter rf = make_rfilter(s.rfilter, s.rfilter_stddev, s.rfilter_param1);
+    const size_t npx = (size_t) s.crop_width * s.crop_height;
+    std::vector<std::vector<float>> films(threads);
+    parallel_lanes(lb, le, threads, [&](int t, uint64_t b, uint64_t e) {
+        if (films[t].empty()) films[t].assign(npx * 4, 0.f);
+        for (uint64_t i = b; i < e; ++i) {
+            Lane L = make_lane(s, seed, spp, i);
+            float v[4] = { 0.f, 0.f, 0.f, 1.f };
+            film_put(s, rf, rf.type == 0 ? L.ipos_x : L.pos_x, rf.type == 0 ? L.ipos_y : L.pos_y, v, films[t].data());
+        }
+    });
+    for (auto &f : films) if (!f.empty()) for (size_t i = 0; i < npx * 4; ++i) film[i] += f[i];
+}
+int orc_render_weights(const OrcSensor *s, uint32_t seed, uint32_t spp, uint64_t lb, uint64_t le, float *film, int threads) {
+    uint64_t total = (uint64_t) s->crop_width * s->crop_height * spp;
+    if (total > 0xffffffffull) return -1;
+    if (lb == 0 && le == 0) le = total;
+    if (lb > le || le > total) return -1;
+    render_weights_impl(*s, seed, spp, lb, le, film, resolve_threads(threads));
+    return 0;
+}
+/* lanes [lb, le) only (0, 0 = all); weight_film != NULL: the accumulated weights of ALL lanes come from the caller (a rank of a multi-GPU job
+ * holds the all-reduced weight film), otherwise they are computed here over the whole wavefront */
 static int prb_backward_impl(void *scene, const OrcSensor *sp, const float *grad_in, uint32_t seed, uint32_t spp,
                              int32_t max_depth, int32_t rr_depth, float *grad_reflectance, float *const *grad_textures,
-                             float *grad_emitters, const uint8_t *pos_mask, double *const *grad_positions, OrcStats *stats, int threads) {
+                             float *grad_emitters, const uint8_t *pos_mask, double *const *grad_positions, OrcStats *stats, int threads,
+                             uint64_t lb = 0, uint64_t le = 0, const float *weight_film = nullptr) {
     Scene &sc = *(Scene *) scene; const OrcSensor &s = *sp;
     if (pos_mask) {           /* the attached-geometry restatement covers `diffuse` BSDFs on flat-shaded top-level meshes */
         for (const BsdfRecord &b : sc.bsdfs) if (b.p.type != 0) return -2;           /* `diffuse`, plain or inside `twosided` */
@@ -1370,20 +1396,12 @@ static int prb_backward_impl(void *scene, const OrcSensor *sp, const float *grad
     threads = resolve_threads(threads);
     uint32_t W = s.crop_width, H = s.crop_height;
     size_t npx = (size_t) W * H;
+    if (lb == 0 && le == 0) le = total;
+    if (lb > le || le > total) return -1;
     // (1) weight-only splat: W[px] of the dummy L=1 film (common.py:716-746)
     std::vector<float> wfilm(npx * 4, 0.f);
-    {
-        std::vector<std::vector<float>> films(threads);
-        parallel_lanes(0, total, threads, [&](int t, uint64_t b, uint64_t e) {
-            if (films[t].empty()) films[t].assign(npx * 4, 0.f);
-            for (uint64_t i = b; i < e; ++i) {
-                Lane L = make_lane(s, seed, spp, i);
-                float v[4] = { 0.f, 0.f, 0.f, 1.f };
-                film_put(s, rf, rf.type == 0 ? L.ipos_x : L.pos_x, rf.type == 0 ? L.ipos_y : L.pos_y, v, films[t].data());
-            }
-        });
-        for (auto &f : films) if (!f.empty()) for (size_t i = 0; i < npx * 4; ++i) wfilm[i] += f[i];
-    }
+    if (weight_film) std::copy(weight_film, weight_film + npx * 4, wfilm.begin());
+    else render_weights_impl(s, seed, spp, 0, total, wfilm.data(), threads);
     // adjoint image: grad_in / W  (adjoint of hdrfilm.cpp:398-399)
     std::vector<float> adj(npx * 3);
     for (size_t i = 0; i < npx; ++i) { float w = wfilm[4 * i + 3]; float iw = w == 0.f ? 1.f : w; for (int c = 0; c < 3; ++c) adj[3 * i + c] = grad_in[3 * i + c] / iw; }
@@ -1394,7 +1412,7 @@ static int prb_backward_impl(void *scene, const OrcSensor *sp, const float *grad
     std::vector<std::vector<std::vector<double>>> g_pos(threads);
     std::vector<OrcStats> sts(threads, OrcStats{});
     uint32_t md = (uint32_t) max_depth, rd = (uint32_t) rr_depth;
-    parallel_lanes(0, total, threads, [&](int t, uint64_t b, uint64_t e) {
+    parallel_lanes(lb, le, threads, [&](int t, uint64_t b, uint64_t e) {
         if (g_refl[t].empty()) {
             g_refl[t].assign(3 * nb + 3, 0.f); g_emit[t].assign(3 * sc.emitters.size() + 3, 0.f);
             g_tex[t].resize(sc.textures.size());
@@ -1459,6 +1477,12 @@ int orc_render_prb_backward_ex(void *scene, const OrcSensor *sp, const float *gr
                                int32_t max_depth, int32_t rr_depth, float *grad_reflectance, float *const *grad_textures,
                                float *grad_emitters, OrcStats *stats, int threads) {
     return prb_backward_impl(scene, sp, grad_in, seed, spp, max_depth, rr_depth, grad_reflectance, grad_textures, grad_emitters, nullptr, nullptr, stats, threads);
+}
+int orc_render_prb_backward_lanes(void *scene, const OrcSensor *sp, const float *grad_in, const float *weight_film, uint32_t seed, uint32_t spp,
+                                  int32_t max_depth, int32_t rr_depth, uint64_t lane_begin, uint64_t lane_end, float *grad_reflectance,
+                                  float *const *grad_textures, float *grad_emitters, OrcStats *stats, int threads) {
+    return prb_backward_impl(scene, sp, grad_in, seed, spp, max_depth, rr_depth, grad_reflectance, grad_textures, grad_emitters, nullptr, nullptr, stats, threads,
+                             lane_begin, lane_end, weight_film);
 }
 /* + d/d(vertex positions) of the meshes with pos_mask[m] != 0: grad_positions[m] = 3 doubles per vertex (accumulated into).
  * Returns -2 when the scene holds a BSDF other than plain `diffuse`, -3 for a mesh with vertex normals / inside a shape group. */

@@ -195,6 +195,13 @@ int orc_render_prb_backward(void *scene, const OrcSensor *s, const float *grad_i
 int orc_render_prb_backward_ex(void *scene, const OrcSensor *s, const float *grad_in, uint32_t seed, uint32_t spp, int32_t max_depth,
                                int32_t rr_depth, float *grad_reflectance, float *const *grad_textures, float *grad_emitters,
                                OrcStats *stats, int threads);
+/* the two pieces a rank of a multi-GPU job runs (mitsuba3_amd/distributed.py render_backward_distributed): the weight-only splat of its lane
+ * band (film H x W x 4, added to), and the backward pass of lanes [lane_begin, lane_end) (0, 0 = all) against the all-reduced weight film
+ * (NULL: computed here over the whole wavefront) */
+int orc_render_weights(const OrcSensor *s, uint32_t seed, uint32_t spp, uint64_t lane_begin, uint64_t lane_end, float *film, int threads);
+int orc_render_prb_backward_lanes(void *scene, const OrcSensor *s, const float *grad_in, const float *weight_film, uint32_t seed, uint32_t spp,
+                                  int32_t max_depth, int32_t rr_depth, uint64_t lane_begin, uint64_t lane_end, float *grad_reflectance,
+                                  float *const *grad_textures, float *grad_emitters, OrcStats *stats, int threads);
 void orc_scene_set_emitter_radiance(void *scene, uint32_t emitter, const float rgb[3]);
 /* Integrator property `hide_emitters` (src/render/integrator.cpp:29; path.cpp:114-115,177-190; prb.py:112-118,146-148) for every later render */
 void orc_scene_set_hide_emitters(void *scene, int hide);

@@ -473,6 +473,22 @@ class OracleScene:
         assert rc == 0
         return g_refl, g_tex, g_emit[:len(self.data.emitters)], st
 
+    def render_prb_backward_lanes(self, sensor, grad_in, weight_film, lanes, seed=0, spp=4, max_depth=6, rr_depth=5, threads=0):
+        """one rank's share of a multi-GPU render_backward: lanes [lo, hi) against the all-reduced weight film (H x W x 4).
+        Returns (g_refl, g_tex, g_emit, stats); sums over disjoint lane bands equal render_prb_backward_emitters of the whole frame."""
+        grad_in = f32(grad_in); weight_film = f32(weight_film)
+        g_refl = np.zeros((len(self.data.bsdfs), 3), np.float32); g_emit = np.zeros((max(1, len(self.data.emitters)), 3), np.float32)
+        g_tex = [np.zeros_like(t) for t in self.data.textures]
+        ptrs = (c_f32p * max(1, len(g_tex)))(*[fp(g) for g in g_tex])
+        st = Stats()
+        L = lib(); L.orc_render_prb_backward_lanes.restype = C.c_int
+        L.orc_render_prb_backward_lanes.argtypes = [C.c_void_p, C.POINTER(Sensor), c_f32p, c_f32p, C.c_uint32, C.c_uint32, C.c_int32, C.c_int32, C.c_uint64, C.c_uint64,
+                                                    c_f32p, C.POINTER(c_f32p), c_f32p, C.POINTER(Stats), C.c_int]
+        rc = L.orc_render_prb_backward_lanes(self.handle, C.byref(sensor), fp(grad_in), fp(weight_film), seed, spp, max_depth, rr_depth, lanes[0], lanes[1],
+                                             fp(g_refl), ptrs, fp(g_emit), C.byref(st), threads)
+        assert rc == 0
+        return g_refl, g_tex, g_emit[:len(self.data.emitters)], st
+
     def render_prb_backward_shape(self, sensor, grad_in, meshes, seed=0, spp=4, max_depth=6, rr_depth=5, threads=0):
         """as render_prb_backward, plus {mesh index: (vertex_count, 3) float64 gradient w.r.t. its vertex positions}"""
         grad_in = f32(grad_in); nm = len(self.data.meshes)
@@ -522,6 +538,16 @@ def develop(film):
     img = np.empty((h, w, 3), np.float32)
     lib().orc_film_develop(fp(f32(film)), w, h, fp(img))
     return img
+
+
+def render_weights(sensor, seed, spp, lanes=None, threads=0):
+    """weight-only splat (common.py:716-746) of lanes [lo, hi) (None = all): raw film H x W x 4 with the accumulated weights in channel 3"""
+    film = np.zeros((sensor.crop_height, sensor.crop_width, 4), np.float32)
+    L = lib(); L.orc_render_weights.restype = C.c_int
+    L.orc_render_weights.argtypes = [C.POINTER(Sensor), C.c_uint32, C.c_uint32, C.c_uint64, C.c_uint64, c_f32p, C.c_int]
+    lo, hi = lanes if lanes else (0, 0)
+    assert L.orc_render_weights(C.byref(sensor), seed, spp, lo, hi, fp(film), threads) == 0
+    return film
 
 
 def scene_from_product(scene):

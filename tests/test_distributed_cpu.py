@@ -79,6 +79,62 @@ dist.destroy_process_group()
 '''
 
 
+WORKER_PRB = r'''
+import os, sys
+import numpy as np
+import torch
+import torch.distributed as dist
+sys.path.insert(0, os.environ["HAR_ROOT"])
+import mitsuba3_amd as mi
+from oracle import oracle as O
+
+class OracleIntegrator:
+    """Test double with Integrator.render_film / render_weights / render_backward signatures; the oracle renders the rank's lane band."""
+    def __init__(self, osc, sensor, keys):
+        self.osc, self.sensor, self.keys = osc, sensor, keys
+    def pass_layout(self, sensor, spp=0):
+        return spp, 1
+    def render_film(self, scene, sensor=0, seed=0, spp=0, lanes=None, film=None):
+        raw, _ = self.osc.render_path(self.sensor, seed=seed, spp=spp, max_depth=6, lanes=lanes, raw=True)
+        return torch.from_numpy(raw)
+    def render_weights(self, scene, sensor=0, seed=0, spp=0, lanes=None):
+        return torch.from_numpy(O.render_weights(self.sensor, seed, spp, lanes))
+    def render_backward(self, scene, params, grad_in, sensor=0, seed=0, spp=0, lanes=None, weight_film=None):
+        g_refl, g_tex, g_emit, _ = self.osc.render_prb_backward_lanes(self.sensor, np.asarray(grad_in), weight_film.numpy(), lanes, seed=seed, spp=spp, max_depth=6)
+        return {"refl": torch.from_numpy(g_refl), "tex": torch.from_numpy(g_tex[0]), "emit": torch.from_numpy(g_emit)}
+
+dist.init_process_group(backend="gloo", rank=int(os.environ["RANK"]), world_size=int(os.environ["WORLD_SIZE"]))
+rank, world = dist.get_rank(), dist.get_world_size()
+mi.set_variant("hip_ad_rgb")
+res, spp = 25, 4                                       # 25 rows: three ranks get ragged bands (8, 8, 9)
+d = mi.textured_cornell_box(res=res, tex_res=8, spp=spp)
+scene = mi.load_dict(d)                                # host-side scene only; no device handle is created
+sd, osensor = O.cornell_box(res, res, white_texture=d["white"]["reflectance"]["data"])
+osc = O.OracleScene(sd)
+integ = OracleIntegrator(osc, osensor, None)
+grad_in = np.random.default_rng(1).uniform(0.5, 1.5, (res, res, 3)).astype(np.float32)
+whole = osc.render_prb_backward_emitters(osensor, grad_in, seed=9, spp=spp, max_depth=6)
+ref = {"refl": whole[0], "tex": whole[1][0], "emit": whole[2]}
+rel = lambda a, b: float(np.linalg.norm(a.astype(np.float64) - b.astype(np.float64)) / np.linalg.norm(b.astype(np.float64)))
+for frame in range(4):                                 # bands move over the first three frames (BandBalancer), the sum must not
+    grads = mi.render_backward_distributed(scene, grad_in, integ, seed=9, spp=spp)
+    (bal,) = [b for k, b in integ._band_balancers.items() if k[0] == "prb"]
+    assert bal.bounds[0] == 0 and bal.bounds[-1] == res and all(y > x for x, y in zip(bal.bounds, bal.bounds[1:]))
+    for k in ref:                                      # all-reduced: every rank holds the whole-frame gradients
+        e = rel(grads[k].numpy(), ref[k])
+        assert e < 2e-5, (frame, k, e)
+# the weight film every rank used is the whole frame's
+y0, y1 = bal.band(rank)
+wf = torch.from_numpy(O.render_weights(osensor, 9, spp, (y0 * res * spp, y1 * res * spp)))
+dist.all_reduce(wf)
+assert rel(wf.numpy(), O.render_weights(osensor, 9, spp)) < 1e-6
+if rank == 0:
+    print("DIST_PRB_OK", world, bal.bounds)
+dist.barrier()
+dist.destroy_process_group()
+'''
+
+
 def _free_port():
     s = socket.socket(); s.bind(("127.0.0.1", 0)); p = s.getsockname()[1]; s.close(); return p
 
@@ -117,13 +173,13 @@ def test_band_balancer_equalises_cost():
     b = BandBalancer(64, 2); b.update([1.0, 1e-9]); assert b.bounds[1] <= 63 and b.bounds[1] >= 1
 
 
-def test_world_size_2_gloo_band_union_equals_whole():
+def _run_ranks(worker, world):
     port = _free_port()
     procs = []
-    for rank in range(2):
-        env = dict(os.environ, RANK=str(rank), WORLD_SIZE="2", MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), HAR_ROOT=ROOT,
+    for rank in range(world):
+        env = dict(os.environ, RANK=str(rank), WORLD_SIZE=str(world), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), HAR_ROOT=ROOT,
                    OMP_NUM_THREADS="2")
-        procs.append(subprocess.Popen([sys.executable, "-c", WORKER], env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True))
+        procs.append(subprocess.Popen([sys.executable, "-c", worker], env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True))
     outs = []
     for p in procs:
         try:
@@ -132,4 +188,15 @@ def test_world_size_2_gloo_band_union_equals_whole():
             p.kill(); out, _ = p.communicate()
         outs.append(out)
     assert all(p.returncode == 0 for p in procs), "\n".join(outs)
-    assert "DIST_OK" in outs[0]
+    return outs
+
+
+def test_world_size_2_gloo_band_union_equals_whole():
+    assert "DIST_OK" in _run_ranks(WORKER, 2)[0]
+
+
+@pytest.mark.parametrize("world", [2, 3])
+def test_gloo_render_backward_distributed_equals_single_rank(world):
+    """render_backward_distributed (weight-film all-reduce + gradient all-reduce) with 2 ranks and with 3 ranks over 25 rows (ragged bands):
+    texel, constant-albedo and emitter gradients equal the single-rank oracle's whatever the band boundaries are"""
+    assert "DIST_PRB_OK %d" % world in _run_ranks(WORKER_PRB, world)[0]
