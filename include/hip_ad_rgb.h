@@ -279,6 +279,24 @@ int har_integrator_set_grad_emitters(HarIntegrator integrator, float *grad_emitt
  * New vertex positions are installed by creating a new scene (har_scene_create), which rebuilds the acceleration structure. */
 int har_integrator_set_grad_positions(HarIntegrator integrator, HarScene scene, float *const *grad_positions);
 
+/* SamplingIntegrator::sample(scene, sampler, ray, medium, aovs, active) -> (Spectrum, Mask), array-valued
+ * (include/mitsuba/render/integrator.h:432-437; PathIntegrator::sample src/integrators/path.cpp:94-346, PRBIntegrator.sample(mode=Primal)
+ * src/python/python/ad/integrators/prb.py:68-339): n rays in (DEVICE, SoA: o, d = 3 x n floats, maxt = n floats), radiance out (rgb = 3 x n) and
+ * the returned mask (valid, n bytes, may be NULL).  The `sampler` argument is the PCG32 wavefront sampler of Sampler::seed(seed, .) restricted to
+ * lanes [lane_offset, lane_offset + n): `state` = NULL starts the freshly seeded streams, otherwise ray i continues from state[i] (as produced
+ * by har_sampler_seed / har_sampler_next_* for the same seed and lane); `state_out` (may be NULL, `path` only) receives the states after the
+ * call -- a lane that starts a loop iteration draws all of that iteration's numbers (JIT loop semantics, path.cpp:247,263-264,323).
+ * `path` returns select(valid, L, 0) (path.cpp:341-345), `prb` returns L and valid = depth != 0 (prb.py:332).  No medium, no AOVs. */
+int har_integrator_sample(HarScene scene, HarIntegrator integrator, uint32_t seed, uint32_t lane_offset, uint32_t n, const float *o, const float *d,
+                          const float *maxt, const uint64_t *state, float *rgb, uint8_t *valid, uint64_t *state_out, void *stream);
+/* Sampler::clone (include/mitsuba/render/sampler.h:89-99): copies the n PCG32 streams (DEVICE arrays) -- both samplers then produce the same
+ * numbers (RBIntegrator.render_backward's `sampler.clone()`, common.py:755).  Sampler::fork (sampler.h:78-87) has no device state: a forked
+ * sampler is a new host object that is seeded later.  Sampler::advance (sampler.h:109-115; independent.cpp:69-72) only moves the host-side
+ * sample / dimension indices of the independent sampler: har_sampler_advance leaves the streams as they are and exists so that a binding can
+ * forward the virtual call. */
+int har_sampler_clone(uint32_t n, const uint64_t *state, const uint64_t *inc, uint64_t *state_dst, uint64_t *inc_dst, void *stream);
+int har_sampler_advance(uint32_t n, uint64_t *state, const uint64_t *inc, void *stream);
+
 /* counters of the last har_render / har_render_backward on this integrator (synchronises) */
 int har_render_stats(HarIntegrator integrator, HarStats *out);
 /* HIP-event timing of the render calls ("frames") issued since har_integrator_set_profiling(.., 1): one event per kernel launch, recorded on

@@ -341,10 +341,22 @@ class Sampler:
         return self.state is not None
 
     def clone(self):
+        """Sampler::clone (sampler.h:89-99): same configuration and the same streams (har_sampler_clone)"""
         s = Sampler(); s.__dict__.update(self.__dict__)
         if self.state is not None:
-            s.state = self.state.clone(); s.inc = self.inc.clone()
+            torch = _torch()
+            s.state = torch.empty_like(self.state); s.inc = torch.empty_like(self.inc)
+            check(lib().har_sampler_clone(self.m_wavefront_size, _ptr(self.state), _ptr(self.inc), _ptr(s.state), _ptr(s.inc), _stream()))
         return s
+
+    def advance(self):
+        """Sampler::advance (sampler.h:109-115, independent.cpp:69-72): next sample, dimension index 0; the PCG32 streams are not reseeded"""
+        self.m_sample_index = getattr(self, "m_sample_index", 0) + 1
+        if self.state is not None:
+            check(lib().har_sampler_advance(self.m_wavefront_size, _ptr(self.state), _ptr(self.inc), _stream()))
+
+    def schedule_state(self):
+        """Sampler::schedule_state (sampler.h:127): nothing to schedule -- there is no tracing JIT on this path"""
 
     def fork(self):
         s = Sampler(); s.m_sample_count = self.m_sample_count; s.m_base_seed = self.m_base_seed
@@ -359,7 +371,8 @@ class Sampler:
             self.m_wavefront_size = int(wavefront_size)
         n = self.m_wavefront_size
         self.state = torch.empty(n, dtype=torch.int64, device=dev); self.inc = torch.empty(n, dtype=torch.int64, device=dev)
-        check(lib().har_sampler_seed((self.m_base_seed + int(seed)) & 0xffffffff, 0, n, _ptr(self.state), _ptr(self.inc), _stream()))
+        self.m_seed_value = (self.m_base_seed + int(seed)) & 0xffffffff          # the streams' increments are a function of (seed value, lane)
+        check(lib().har_sampler_seed(self.m_seed_value, 0, n, _ptr(self.state), _ptr(self.inc), _stream()))
 
     def _active(self, active):
         if active is None:
@@ -823,6 +836,27 @@ class Integrator:
             torch.cuda.current_stream().synchronize()
             self.stats()                 # surfaces device-side errors (traversal stack overflow)
         return out
+
+    def sample(self, scene, sampler, ray, medium=None, active=True, seed=None):
+        """SamplingIntegrator::sample (integrator.h:432-437): (spec 3 x n, valid n) for the rays `ray` (mi.Ray3f) with the sampler's streams.
+        `sampler` is a seeded mi.Sampler whose wavefront size equals the number of rays; its state is advanced (`path`) as the call draws from it."""
+        torch = _torch(); dev = _device()
+        if medium is not None:
+            raise RuntimeError("Integrator.sample(): participating media are not part of the hip_ad_rgb path")
+        n = len(ray)
+        if not sampler.seeded() or sampler.wavefront_size() != n:
+            raise RuntimeError("Integrator.sample(): the sampler must be seeded with wavefront_size == number of rays")
+        rgb = torch.empty((3, n), dtype=torch.float32, device=dev); valid = torch.empty(n, dtype=torch.uint8, device=dev)
+        state_out = torch.empty_like(sampler.state) if self.type == 'path' else None
+        sd = sampler.m_seed_value if seed is None else (sampler.m_base_seed + int(seed)) & 0xffffffff
+        check(lib().har_integrator_sample(scene._handle(), self._handle(), sd, 0, n, _ptr(ray.o), _ptr(ray.d), _ptr(ray.maxt), _ptr(sampler.state),
+                                          _ptr(rgb), _ptr(valid), _ptr(state_out), _stream()))
+        if state_out is not None:
+            sampler.state = state_out
+        if active is not True:
+            a = torch.as_tensor(active, device=dev).to(torch.bool)
+            rgb = rgb * a; valid = valid * a.to(torch.uint8)
+        return rgb, valid.to(torch.bool)
 
     def render_weights(self, scene, sensor=0, seed=0, spp=0, lanes=None):
         """the weight-only splat of RBIntegrator.render_backward (common.py:716-746: a dummy L = 1 film) for lanes [begin, end) (all when None):

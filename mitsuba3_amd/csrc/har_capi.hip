@@ -281,16 +281,22 @@ static inline uint32_t *cnt_items(HarIntegratorImpl *I, uint32_t b) { return I->
 static inline uint32_t *cur_trace(HarIntegratorImpl *I, uint32_t b) { return I->counters + (size_t) (2 * HAR_MAX_BOUNCE_SLOTS + b) * HAR_SHARDS * HAR_COUNTER_STRIDE; }
 static inline uint32_t *cur_resolve(HarIntegratorImpl *I, uint32_t b) { return I->counters + (size_t) (3 * HAR_MAX_BOUNCE_SLOTS + b) * HAR_SHARDS * HAR_COUNTER_STRIDE; }
 
-/* one chunk: raygen + bounce loop.  `mode` selects path / prb primal / prb adjoint kernels */
+/* rays of har_integrator_sample: SoA arrays of n_total rays, the chunk covers [first, first + n) */
+struct RaySource { const float *o, *d, *maxt; const uint64_t *state; uint32_t n_total, first; };
+
+/* one chunk: raygen + bounce loop.  `mode` selects path / prb primal / prb adjoint kernels; `rays` != nullptr: the wavefront starts from
+ * caller-supplied rays (SamplingIntegrator::sample) instead of the sensor; `valid_lane` != nullptr receives the samples' masks */
 int run_chunk(HarSceneImpl *S, HarIntegratorImpl *I, const DSensor &C, int mode, uint32_t seed, uint32_t spp, uint32_t log_spp,
-              uint32_t lane_base, uint32_t n, float *grad_refl, hipStream_t s, int cache_mode = 0, const PassState &ps = PassState{ nullptr, nullptr, 0 }) {
+              uint32_t lane_base, uint32_t n, float *grad_refl, hipStream_t s, int cache_mode = 0, const PassState &ps = PassState{ nullptr, nullptr, 0 },
+              const RaySource *rays = nullptr, float *valid_lane = nullptr) {
     const uint32_t nb = bounce_limit(I);
     const size_t used = (size_t) std::min<uint32_t>(nb + 2, HAR_MAX_BOUNCE_SLOTS) * HAR_SHARDS * HAR_COUNTER_STRIDE * sizeof(uint32_t);
     HIP_TRY(hipMemsetAsync(cnt_alive(I, 0), 0, used, s));
     HIP_TRY(hipMemsetAsync(cnt_items(I, 0), 0, used, s));
     HIP_TRY(hipMemsetAsync(cur_trace(I, 0), 0, used, s));
     HIP_TRY(hipMemsetAsync(cur_resolve(I, 0), 0, used, s));
-    launch_raygen(mode, s, C, seed, spp, log_spp, lane_base, n, I->shard_cap, I->st[0], I->result, cnt_alive(I, 0), I->adj, I->dL, ps);
+    if (rays) launch_raygen_rays(s, seed, lane_base, n, rays->n_total, rays->first, rays->o, rays->d, rays->maxt, rays->state, I->shard_cap, I->st[0], I->result, cnt_alive(I, 0));
+    else launch_raygen(mode, s, C, seed, spp, log_spp, lane_base, n, I->shard_cap, I->st[0], I->result, cnt_alive(I, 0), I->adj, I->dL, ps);
     prof_mark(I, s, CLS_RAYGEN);
     ShadeParams P{ seed, I->max_depth, I->rr_depth, ((mode == MODE_PRB_ADJOINT && I->grad_emitters) ? HAR_SHADE_EMITTER_GRADS : 0u) | (I->hide_emitters ? HAR_SHADE_HIDE_EMITTERS : 0u) };
     /* grid: a multiple of 8 so that block b serves shard b % 8; enough blocks to cover the chunk once */
@@ -339,9 +345,9 @@ int run_chunk(HarSceneImpl *S, HarIntegratorImpl *I, const DSensor &C, int mode,
             }
             prof_mark(I, s, CLS_OTHER);
         }
-        if (I->alpha_film && I->alpha_lane && b == 0 && mode != MODE_PRB_ADJOINT) {        /* `rgba` films: is the camera sample valid?  (path.cpp:114-115,307-308; prb.py:332) */
+        if (((I->alpha_film && I->alpha_lane) || valid_lane) && b == 0 && mode != MODE_PRB_ADJOINT) {        /* `rgba` films: is the camera sample valid?  (path.cpp:114-115,307-308; prb.py:332) */
             const float miss = (mode == MODE_PATH && S->ds.env_emitter >= 0 && !I->hide_emitters) ? 1.f : 0.f;
-            launch_alpha_flags(s, grid, I->shard_cap, cnt_alive(I, 0), I->st[cur], I->h0, lane_base, miss, I->alpha_lane);
+            launch_alpha_flags(s, grid, I->shard_cap, cnt_alive(I, 0), I->st[cur], I->h0, lane_base, miss, valid_lane ? valid_lane : I->alpha_lane);
         }
         /* vertex-position gradients of the PREVIOUS bounce's vertices: its items are still in place, `result` holds its L, and this bounce's ray
          * queries give the (detached) next interaction of every continued path */
@@ -736,6 +742,57 @@ int har_render_backward(HarScene S, HarIntegrator I, const HarSensor *sensor, co
     rc |= backward_range(S, I->twin, sensor, grad_in, weight_film, seed, spp, mid, total_le, grad_reflectance, grad_textures, (void *) I->side_stream);
     rc |= dual_join(I, (hipStream_t) stream);
     return rc;
+}
+
+int har_integrator_sample(HarScene S, HarIntegrator I, uint32_t seed, uint32_t lane_offset, uint32_t n, const float *o, const float *d, const float *maxt,
+                          const uint64_t *state, float *rgb, uint8_t *valid, uint64_t *state_out, void *stream) {
+    if (!S || !I) return fail("null scene / integrator");
+    if (n == 0) return 0;
+    if (!o || !d || !maxt || !rgb) return fail("null ray / output arrays");
+    if ((uint64_t) lane_offset + n > 0xffffffffull) return fail("lane_offset + n exceeds the 2^32 - 1 lanes of a wavefront");
+    if (state_out && I->type != HAR_INTEGRATOR_PATH) return fail("state_out: only `path` reports the sampler state after sample()");
+    hipStream_t s = (hipStream_t) stream;
+    const uint32_t chunk = (uint32_t) std::min<uint64_t>(I->chunk, ((uint64_t) std::max<uint32_t>(n, 2048) + 2047) / 2048 * 2048);
+    if (ensure_workspace(I, chunk, false)) return 1;
+    if (!I->alpha_lane && ws_alloc(I, &I->alpha_lane, I->ws_lanes)) return 1;      /* the samples' masks use the per-lane alpha array of `rgba` films */
+    HIP_TRY(hipMemsetAsync(I->totals, 0, 4 * sizeof(unsigned long long), s));
+    HIP_TRY(hipMemsetAsync(I->status, 0, sizeof(int), s));
+    I->last_stream = s; I->twin_used = false;
+    if (prof_begin(I, s)) return 1;
+    const int mode = I->type == HAR_INTEGRATOR_PATH ? MODE_PATH : MODE_PRB_PRIMAL;
+    const DSensor C{};                                     /* no sensor on this entry point */
+    for (uint64_t base = 0; base < n; base += chunk) {
+        const uint32_t m = (uint32_t) std::min<uint64_t>(chunk, n - base);
+        const RaySource rays{ o, d, maxt, state, n, (uint32_t) base };
+        if (I->max_depth == 0) {                           /* path.cpp:102-103 / prb.py: no interaction at all */
+            HIP_TRY(hipMemsetAsync(I->result, 0, (size_t) m * sizeof(float4), s));
+            HIP_TRY(hipMemsetAsync(I->alpha_lane, 0, (size_t) m * sizeof(float), s));
+            if (state_out) { if (!state) return fail("state_out with max_depth = 0 needs `state` (the sampler is not touched, path.cpp:102-103)"); HIP_TRY(hipMemcpyAsync(state_out + base, state + base, (size_t) m * sizeof(uint64_t), hipMemcpyDeviceToDevice, s)); }
+        } else {
+            /* the lanes' final sampler states come back through the multi-pass mechanism (PassState::rng is indexed by lane - lane_base) */
+            const PassState ps{ state_out ? state_out + base : nullptr, nullptr, 1u };
+            if (run_chunk(S, I, C, mode, seed, 1, 0, lane_offset + (uint32_t) base, m, nullptr, s, 0, ps, &rays, I->alpha_lane)) return 1;
+            if (mode == MODE_PRB_PRIMAL) launch_accumulate_stats(s, I->counters, bounce_limit(I), I->totals, m);
+        }
+        launch_sample_out(s, m, n, (uint32_t) base, I->result, I->alpha_lane, mode == MODE_PATH ? 1 : 0, rgb, valid);
+        prof_mark(I, s, CLS_OTHER);
+    }
+    HIP_TRY(hipGetLastError());
+    return 0;
+}
+
+int har_sampler_clone(uint32_t n, const uint64_t *state, const uint64_t *inc, uint64_t *state_dst, uint64_t *inc_dst, void *stream) {
+    if (n == 0) return 0;
+    if (!state || !inc || !state_dst || !inc_dst) return fail("null sampler state");
+    HIP_TRY(hipMemcpyAsync(state_dst, state, (size_t) n * sizeof(uint64_t), hipMemcpyDeviceToDevice, (hipStream_t) stream));
+    HIP_TRY(hipMemcpyAsync(inc_dst, inc, (size_t) n * sizeof(uint64_t), hipMemcpyDeviceToDevice, (hipStream_t) stream));
+    return 0;
+}
+int har_sampler_advance(uint32_t n, uint64_t *state, const uint64_t *inc, void *stream) {
+    /* IndependentSampler::advance (src/samplers/independent.cpp:69-72 -> Sampler::advance, src/render/sampler.cpp:69-72) moves the sample index and
+     * resets the dimension index; the PCG32 streams are untouched (no reseed), so the device state does not change */
+    (void) n; (void) state; (void) inc; (void) stream;
+    return 0;
 }
 
 int har_integrator_set_alpha_film(HarIntegrator I, float *alpha_film) {

@@ -51,6 +51,10 @@ struct ShapeTargets { const int32_t *offset; float *grad; uint32_t n_verts; };
 
 void launch_raygen(int mode, hipStream_t s, const DSensor &C, uint32_t seed, uint32_t spp, uint32_t log_spp, uint32_t lane_base, uint32_t n,
                    uint32_t shard_cap, const WaveState &out, float4 *result, uint32_t *count, const float *adj, float4 *dL, const PassState &ps = PassState{ nullptr, nullptr, 0 });
+/* har_integrator_sample: the wavefront of n caller-supplied rays (SoA arrays of n_total rays, this chunk starts at `first`), see k_raygen_rays */
+void launch_raygen_rays(hipStream_t s, uint32_t seed, uint32_t lane_base, uint32_t n, uint32_t n_total, uint32_t first, const float *o, const float *d, const float *maxt,
+                        const uint64_t *state, uint32_t shard_cap, const WaveState &out, float4 *result, uint32_t *count);
+void launch_sample_out(hipStream_t s, uint32_t n, uint32_t n_total, uint32_t first, const float4 *result, const float *valid_lane, int zero_invalid, float *rgb, uint8_t *valid);
 /* `spill` = nullptr: the scene's depth-first bound fits the LDS stack and the kernels without the HBM spill path run (3 % faster) */
 void launch_trace_closest(hipStream_t s, uint32_t grid, uint2 *spill, const Accel &A, const uint32_t *count, uint32_t *cursor, uint32_t shard_cap,
                           const WaveState &in, float4 *h0, uint2 *h1, int *status);

@@ -191,6 +191,43 @@ __global__ __launch_bounds__(kBlock) void k_raygen(DSensor C, uint32_t seed, uin
     }
 }
 
+/* SamplingIntegrator::sample over caller-supplied rays (include/mitsuba/render/integrator.h:432-437): the wavefront starts from the rays
+ * instead of the sensor.  Ray i is wavefront lane lane_base + i: its sampler is Sampler::seed's stream of that lane (sampler.cpp:129-148),
+ * continued from state[i] when the caller passes its PCG32 states; the loop state is PathIntegrator::sample's initial one (path.cpp:129-147:
+ * throughput 1, eta 1, depth 0, prev_bsdf_pdf 1, prev_bsdf_delta true). */
+__global__ __launch_bounds__(kBlock) void k_raygen_rays(uint32_t seed, uint32_t lane_base, uint32_t n, uint32_t n_total, uint32_t first, const float *o, const float *d,
+                                                        const float *maxt, const uint64_t *state, uint32_t shard_cap, WaveState out, float4 *result, uint32_t *count) {
+    uint32_t i = blockIdx.x * kBlock + threadIdx.x;
+    if (i < HAR_SHARDS) {
+        const uint32_t tiles = (n + kBlock - 1) / kBlock, rem = n % kBlock;
+        uint32_t t = tiles > i ? (tiles - i + HAR_SHARDS - 1) / HAR_SHARDS : 0u;
+        uint32_t c = t * kBlock;
+        if (rem && tiles && (tiles - 1) % HAR_SHARDS == i) c -= kBlock - rem;
+        count[i * HAR_COUNTER_STRIDE] = c;
+    }
+    if (i >= n) return;
+    const size_t g = (size_t) first + i;                   /* index into the caller's arrays (SoA, stride n_total) */
+    PathState st;
+    uint64_t inc;
+    sampler_seed(seed, lane_base + i, st.rng, inc);
+    if (state) st.rng = state[g];
+    st.o = Vec3(o[g], o[n_total + g], o[2 * (size_t) n_total + g]); st.d = Vec3(d[g], d[n_total + g], d[2 * (size_t) n_total + g]); st.maxt = maxt[g];
+    st.throughput = Vec3(1.f); st.lane = lane_base + i; st.prev_p = Vec3(0.f); st.prev_bsdf_pdf = 1.f; st.flags = 1u << 16; st.eta = 1.f;
+    store_state(out, shard_slot(i, shard_cap), st);
+    result[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+}
+/* radiance + mask of har_integrator_sample: PathIntegrator returns select(valid_ray, result, 0) (path.cpp:341-345), prb returns L and depth != 0 (prb.py:332) */
+__global__ void k_sample_out(uint32_t n, uint32_t n_total, uint32_t first, const float4 *result, const float *valid_lane, int zero_invalid, float *rgb, uint8_t *valid) {
+    uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const size_t g = (size_t) first + i;
+    const bool v = valid_lane[i] != 0.f;
+    float4 r = result[i];
+    if (zero_invalid && !v) r = make_float4(0.f, 0.f, 0.f, 0.f);
+    rgb[g] = r.x; rgb[n_total + g] = r.y; rgb[2 * (size_t) n_total + g] = r.z;
+    if (valid) valid[g] = v ? 1 : 0;
+}
+
 /* ------------------------------------------------- persistent traversal loop */
 /*
  * The traversal kernels are VALU-issue bound (rocprofv3: SQ_ACTIVE_INST_VALU ~ 73 % of SIMD cycles)
@@ -943,6 +980,13 @@ void launch_raygen(int mode, hipStream_t s, const DSensor &C, uint32_t seed, uin
     dim3 g(blocks_for(n)), b(kBlock);
     if (mode == MODE_PRB_ADJOINT) hipLaunchKernelGGL(k_raygen<MODE_PRB_ADJOINT>, g, b, 0, s, C, seed, spp, log_spp, lane_base, n, shard_cap, out, result, count, adj, dL, ps);
     else hipLaunchKernelGGL(k_raygen<MODE_PATH>, g, b, 0, s, C, seed, spp, log_spp, lane_base, n, shard_cap, out, result, count, adj, dL, ps);
+}
+void launch_raygen_rays(hipStream_t s, uint32_t seed, uint32_t lane_base, uint32_t n, uint32_t n_total, uint32_t first, const float *o, const float *d, const float *maxt,
+                        const uint64_t *state, uint32_t shard_cap, const WaveState &out, float4 *result, uint32_t *count) {
+    hipLaunchKernelGGL(k_raygen_rays, dim3(blocks_for(n)), dim3(kBlock), 0, s, seed, lane_base, n, n_total, first, o, d, maxt, state, shard_cap, out, result, count);
+}
+void launch_sample_out(hipStream_t s, uint32_t n, uint32_t n_total, uint32_t first, const float4 *result, const float *valid_lane, int zero_invalid, float *rgb, uint8_t *valid) {
+    hipLaunchKernelGGL(k_sample_out, dim3(blocks_for(n)), dim3(kBlock), 0, s, n, n_total, first, result, valid_lane, zero_invalid, rgb, valid);
 }
 void launch_trace_closest(hipStream_t s, uint32_t grid, uint2 *spill, const Accel &A, const uint32_t *count, uint32_t *cursor, uint32_t shard_cap,
                           const WaveState &in, float4 *h0, uint2 *h1, int *status) {

@@ -1342,6 +1342,32 @@ int orc_render_prb(void *scene, const OrcSensor *s, uint32_t seed, uint32_t spp,
     return render_forward(*(Scene *) scene, *s, seed, spp, max_depth, rr_depth, lb, le, film, stats, threads, true);
 }
 
+/* SamplingIntegrator::sample (include/mitsuba/render/integrator.h:432-437; PathIntegrator::sample path.cpp:94-346, PRBIntegrator.sample primal
+ * prb.py:68-339) for n caller-supplied rays: ray i uses the sampler stream of wavefront lane lane_offset + i (Sampler::seed, sampler.cpp:129-148),
+ * continued from state[i] when `state` is given.  rgb is 3 x n (SoA), valid[i] = the returned mask, state_out[i] (nullable) = the stream's
+ * state after the call. */
+int orc_integrator_sample(void *scene, int prb, uint32_t n, const float *o, const float *d, const float *maxt, uint32_t seed, uint32_t lane_offset,
+                          const uint64_t *state, int32_t max_depth, int32_t rr_depth, float *rgb, uint8_t *valid, uint64_t *state_out, int threads) {
+    Scene &sc = *(Scene *) scene;
+    threads = resolve_threads(threads);
+    std::vector<OrcStats> sts(threads, OrcStats{});
+    const uint32_t md = max_depth < 0 ? 0xffffffffu : (uint32_t) max_depth, rd = (uint32_t) rr_depth;
+    parallel_lanes(0, n, threads, [&](int t, uint64_t b, uint64_t e) {
+        for (uint64_t i = b; i < e; ++i) {
+            Pcg32 rng = sampler_seed(seed, lane_offset + (uint32_t) i);
+            if (state) rng.state = state[i];
+            Ray ray; ray.o = V3(o[i], o[n + i], o[2 * (size_t) n + i]); ray.d = V3(d[i], d[n + i], d[2 * (size_t) n + i]); ray.maxt = maxt[i];
+            bool v = false; V3 L;
+            if (prb) L = prb_sample(sc, rng, ray, md, rd, true, V3(0.f), V3(0.f), nullptr, v, sts[t]);
+            else     L = path_sample(sc, rng, ray, md, rd, v, sts[t]);
+            rgb[i] = L.x; rgb[n + i] = L.y; rgb[2 * (size_t) n + i] = L.z;
+            if (valid) valid[i] = v ? 1 : 0;
+            if (state_out) state_out[i] = rng.state;
+        }
+    });
+    return 0;
+}
+
 int orc_render_prb_backward_ex(void *scene, const OrcSensor *sp, const float *grad_in, uint32_t seed, uint32_t spp,
                                int32_t max_depth, int32_t rr_depth, float *grad_reflectance, float *const *grad_textures,
                                float *grad_emitters, OrcStats *stats, int threads);

@@ -195,6 +195,10 @@ int orc_render_prb_backward(void *scene, const OrcSensor *s, const float *grad_i
 int orc_render_prb_backward_ex(void *scene, const OrcSensor *s, const float *grad_in, uint32_t seed, uint32_t spp, int32_t max_depth,
                                int32_t rr_depth, float *grad_reflectance, float *const *grad_textures, float *grad_emitters,
                                OrcStats *stats, int threads);
+/* SamplingIntegrator::sample (integrator.h:432-437) over n caller-supplied rays (SoA 3 x n): path (prb = 0) or the primal prb sample (prb = 1);
+ * ray i draws from the stream of wavefront lane lane_offset + i, continued from state[i] if given; rgb 3 x n, valid n, state_out n (nullable) */
+int orc_integrator_sample(void *scene, int prb, uint32_t n, const float *o, const float *d, const float *maxt, uint32_t seed, uint32_t lane_offset,
+                          const uint64_t *state, int32_t max_depth, int32_t rr_depth, float *rgb, uint8_t *valid, uint64_t *state_out, int threads);
 /* the two pieces a rank of a multi-GPU job runs (mitsuba3_amd/distributed.py render_backward_distributed): the weight-only splat of its lane
  * band (film H x W x 4, added to), and the backward pass of lanes [lane_begin, lane_end) (0, 0 = all) against the all-reduced weight film
  * (NULL: computed here over the whole wavefront) */

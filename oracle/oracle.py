@@ -473,6 +473,20 @@ class OracleScene:
         assert rc == 0
         return g_refl, g_tex, g_emit[:len(self.data.emitters)], st
 
+    def integrator_sample(self, o, d, maxt, seed=0, lane_offset=0, state=None, max_depth=8, rr_depth=5, prb=False, threads=0):
+        """SamplingIntegrator::sample over n rays (3 x n origins / directions): (rgb 3 x n, valid n uint8, state_out n uint64)"""
+        o = f32(o); d = f32(d); maxt = f32(maxt); n = maxt.shape[0]
+        rgb = np.empty((3, n), np.float32); valid = np.empty(n, np.uint8); so = np.empty(n, np.uint64)
+        st = None if state is None else np.ascontiguousarray(state, np.uint64)
+        L = lib(); L.orc_integrator_sample.restype = C.c_int
+        u64p = C.POINTER(C.c_uint64)
+        L.orc_integrator_sample.argtypes = [C.c_void_p, C.c_int, C.c_uint32, c_f32p, c_f32p, c_f32p, C.c_uint32, C.c_uint32, u64p, C.c_int32, C.c_int32, c_f32p,
+                                            C.POINTER(C.c_uint8), u64p, C.c_int]
+        rc = L.orc_integrator_sample(self.handle, 1 if prb else 0, n, fp(o), fp(d), fp(maxt), seed, lane_offset, st.ctypes.data_as(u64p) if st is not None else None,
+                                     max_depth, rr_depth, fp(rgb), valid.ctypes.data_as(C.POINTER(C.c_uint8)), so.ctypes.data_as(u64p), threads)
+        assert rc == 0
+        return rgb, valid, so
+
     def render_prb_backward_lanes(self, sensor, grad_in, weight_film, lanes, seed=0, spp=4, max_depth=6, rr_depth=5, threads=0):
         """one rank's share of a multi-GPU render_backward: lanes [lo, hi) against the all-reduced weight film (H x W x 4).
         Returns (g_refl, g_tex, g_emit, stats); sums over disjoint lane bands equal render_prb_backward_emitters of the whole frame."""
