@@ -279,6 +279,17 @@ int har_integrator_set_grad_emitters(HarIntegrator integrator, float *grad_emitt
  * New vertex positions are installed by creating a new scene (har_scene_create), which rebuilds the acceleration structure. */
 int har_integrator_set_grad_positions(HarIntegrator integrator, HarScene scene, float *const *grad_positions);
 
+/* RBIntegrator.render_forward (src/python/python/ad/integrators/common.py:497-623): the forward-mode derivative image of the `prb` integrator.
+ * tangent_reflectance (DEVICE, bsdf_count x 3), tangent_textures (HOST array of texture_count DEVICE pointers, H_i x W_i x 3 each; NULL when the
+ * scene has no bitmaps) and tangent_emitters (DEVICE, emitter_count x 3, may be NULL) are the dr.set_grad() values of the scene parameters, in
+ * the layout of har_render_backward's gradient buffers.  Lanes [lane_begin, lane_end) (0, 0 = all) splat their differential radiance
+ * dL = sum over vertices <d Lo / d theta, tangent> (prb.py:313) into `film` (DEVICE, H x W x 4, accumulated like har_render's);
+ * har_film_develop(film) is the gradient image.  Parameters: colour slot 0 of every BSDF (constant or bitmap), radiance of `area` / `constant`
+ * emitters.  Vertex positions: use har_render_backward. */
+int har_render_forward(HarScene scene, HarIntegrator integrator, const HarSensor *sensor, uint32_t seed, uint32_t spp, uint64_t lane_begin,
+                       uint64_t lane_end, const float *tangent_reflectance, const float *const *tangent_textures, const float *tangent_emitters,
+                       float *film, void *stream);
+
 /* SamplingIntegrator::sample(scene, sampler, ray, medium, aovs, active) -> (Spectrum, Mask), array-valued
  * (include/mitsuba/render/integrator.h:432-437; PathIntegrator::sample src/integrators/path.cpp:94-346, PRBIntegrator.sample(mode=Primal)
  * src/python/python/ad/integrators/prb.py:68-339): n rays in (DEVICE, SoA: o, d = 3 x n floats, maxt = n floats), radiance out (rgb = 3 x n) and

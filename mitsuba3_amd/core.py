@@ -913,6 +913,48 @@ class Integrator:
         return out
 
 
+def _render_forward(self, scene, params=None, sensor=0, seed=0, spp=0, tangents=None, lanes=None, develop=True):
+    """RBIntegrator.render_forward (common.py:497-623): the forward-mode derivative image for the parameter tangents.
+    `tangents` = {key: tensor} (the values dr.set_grad() would carry); without it, the `.grad` fields of the `params` entries that have
+    requires_grad are used.  Keys are those of mi.traverse(scene); missing keys have a zero tangent.  Returns the gradient image H x W x 3."""
+    if self.type != 'prb':
+        raise RuntimeError("render_forward(): only the `prb` integrator implements the differential pass in hip_ad_rgb")
+    torch = _torch(); dev = _device()
+    sensor = self._sensor(scene, sensor)
+    if spp:
+        sensor.sampler().set_sample_count(spp)
+    spp = sensor.sampler().sample_count()
+    w, h = sensor.film().crop_size()
+    if tangents is None:
+        tangents = {k: v.grad for k, v in (params or {}).items() if getattr(v, 'requires_grad', False) and getattr(v, 'grad', None) is not None}
+    keys = scene._param_keys()
+    unknown = [k for k in tangents if k not in keys]
+    if unknown:
+        raise RuntimeError("render_forward(): %s are not differentiable parameters of the `prb` forward mode (available: %s)" % (unknown, sorted(keys)))
+    t_refl = torch.zeros((max(1, len(scene.bsdfs)), 3), dtype=torch.float32, device=dev)
+    t_tex = [torch.zeros(tuple(t.shape), dtype=torch.float32, device=dev) for t in scene.textures]
+    t_emit = torch.zeros((max(1, len(scene.emitters)), 3), dtype=torch.float32, device=dev)
+    any_emit = False
+    for k, v in tangents.items():
+        kind, b = keys[k]
+        v = torch.as_tensor(v, dtype=torch.float32, device=dev)
+        if kind == "tex":
+            t_tex[b.tex_index].copy_(v.reshape(t_tex[b.tex_index].shape))
+        elif kind == "emit":
+            t_emit[b].copy_(v.reshape(3)); any_emit = True
+        else:
+            t_refl[b.index].copy_(v.reshape(3))
+    ptrs = (C.c_void_p * max(1, len(t_tex)))(*[t.data_ptr() for t in t_tex])
+    film = torch.zeros((h, w, 4), dtype=torch.float32, device=dev)
+    lb, le = lanes if lanes else (0, 0)
+    check(lib().har_render_forward(scene._handle(), self._handle(), C.byref(sensor.har), (sensor.sampler().m_base_seed + int(seed)) & 0xffffffff, spp, lb, le,
+                                   _ptr(t_refl), ptrs if t_tex else None, _ptr(t_emit) if any_emit else None, _ptr(film), _stream()))
+    return develop_film(film) if develop else film
+
+
+Integrator.render_forward = _render_forward
+
+
 class Bitmap:
     """Bitmap (src/core/bitmap.cpp) restricted to what HDRFilm::write needs: float32 H x W x {1,3,4}, write() to .exr / .pfm"""
 

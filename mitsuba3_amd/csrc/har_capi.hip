@@ -111,6 +111,7 @@ struct HarIntegratorImpl {
      * (measured on the 1M-triangle scene, 67 M lanes: 16 M-lane chunks 708, 32 M 758, one 64 M chunk 783 Mpaths/s) */
     uint32_t max_depth = 0, rr_depth = 5, chunk = 1u << 26;
     bool hide_emitters = false;           /* Integrator property (integrator.cpp:29) */
+    bool forward_mode = false;            /* har_render_forward in progress: the adjoint kernels read tangents and accumulate differential radiance */
     float *alpha_film = nullptr;          /* user buffer (DEVICE, H x W x 4: channel 3 accumulates w * alpha) of har_integrator_set_alpha_film, or null */
     float *alpha_lane = nullptr;          /* alpha value per lane of the chunk */
     uint32_t *skip_counters = nullptr;    /* hide_emitters: count + cursor of the two continuation lists of skip_area_emitters */
@@ -298,7 +299,9 @@ int run_chunk(HarSceneImpl *S, HarIntegratorImpl *I, const DSensor &C, int mode,
     if (rays) launch_raygen_rays(s, seed, lane_base, n, rays->n_total, rays->first, rays->o, rays->d, rays->maxt, rays->state, I->shard_cap, I->st[0], I->result, cnt_alive(I, 0));
     else launch_raygen(mode, s, C, seed, spp, log_spp, lane_base, n, I->shard_cap, I->st[0], I->result, cnt_alive(I, 0), I->adj, I->dL, ps);
     prof_mark(I, s, CLS_RAYGEN);
-    ShadeParams P{ seed, I->max_depth, I->rr_depth, ((mode == MODE_PRB_ADJOINT && I->grad_emitters) ? HAR_SHADE_EMITTER_GRADS : 0u) | (I->hide_emitters ? HAR_SHADE_HIDE_EMITTERS : 0u) };
+    const bool fwd = mode == MODE_PRB_ADJOINT && I->forward_mode;
+    ShadeParams P{ seed, I->max_depth, I->rr_depth, ((mode == MODE_PRB_ADJOINT && I->grad_emitters) ? HAR_SHADE_EMITTER_GRADS : 0u) | (I->hide_emitters ? HAR_SHADE_HIDE_EMITTERS : 0u) |
+                   (fwd ? HAR_SHADE_FORWARD_MODE : 0u) };
     /* grid: a multiple of 8 so that block b serves shard b % 8; enough blocks to cover the chunk once */
     const uint32_t grid = std::max<uint32_t>(HAR_SHARDS, std::min<uint32_t>(((n + 255) / 256 + HAR_SHARDS - 1) / HAR_SHARDS * HAR_SHARDS, 4096u));
     /* persistent traversal kernels: enough blocks to fill the chip (<= 8 blocks/CU), never more than the work */
@@ -359,7 +362,7 @@ int run_chunk(HarSceneImpl *S, HarIntegratorImpl *I, const DSensor &C, int mode,
                      I->items, cnt_items(I, b), I->result, rc, ps.rng, I->dL, grad_refl, shape ? &I->geo : nullptr, inline_commit && rc.mode == 2 ? I->d_grad_tex : nullptr);
         prof_mark(I, s, CLS_SHADE);
         if (!(inline_commit && rc.mode == 2)) launch_resolve(mode, s, rc.mode == 2 ? grid : tgrid, spill, S->ds, cnt_items(I, b), cur_resolve(I, b), I->shard_cap, I->items, I->result, I->dL, grad_refl, I->d_grad_tex, I->status, rc,
-                       shape ? I->geo.vis : nullptr);
+                       shape ? I->geo.vis : nullptr, fwd ? 1 : 0);
         prof_mark(I, s, CLS_RESOLVE);
         cur ^= 1;
         if (b >= 15 && (b & 7) == 7) {           /* deep paths are rare: poll so that max_depth = -1 terminates */
@@ -882,6 +885,57 @@ static int backward_range(HarScene S, HarIntegrator I, const HarSensor *sensor, 
     if (I->shape_on)
         for (size_t m = 0; m < I->pos_user.size(); ++m)
             if (I->pos_user[m]) launch_add(s, I->grad_pos + 3 * (size_t) I->pos_offset[m], I->pos_user[m], 3 * I->pos_count[m]);
+    HIP_TRY(hipGetLastError());
+    return 0;
+}
+
+/* RBIntegrator.render_forward (src/python/python/ad/integrators/common.py:497-623): primal pass (L per lane), then the differential pass in
+ * FORWARD mode -- the adjoint kernels read the parameters' tangents where render_backward accumulates gradients, and every lane sums
+ * <d Lo / d theta, tangent> over its vertices (prb.py:313) -- then the lanes' differential radiance is splatted like an image. */
+int har_render_forward(HarScene S, HarIntegrator I, const HarSensor *sensor, uint32_t seed, uint32_t spp, uint64_t lb, uint64_t le,
+                       const float *tangent_reflectance, const float *const *tangent_textures, const float *tangent_emitters, float *film, void *stream) {
+    DSensor C; uint32_t log_spp;
+    if (check_common(S, I, sensor, spp, lb, le, C, log_spp)) return 1;
+    if (I->type != HAR_INTEGRATOR_PRB) return fail("render_forward is implemented by the `prb` integrator");
+    if (!film || !tangent_reflectance) return fail("null film / tangent buffers");
+    if (I->shape_on) return fail("render_forward: tangents of vertex positions are not implemented (use render_backward for shape gradients)");
+    hipStream_t s = (hipStream_t) stream;
+    if (I->max_depth == 0) {        /* no interaction, no derivative: a zero image with the filter weights */
+        return har_render_weights(sensor, seed, spp, lb, le, film, stream);
+    }
+    uint32_t chunk = (uint32_t) std::min<uint64_t>(I->chunk, (std::max<uint64_t>(le - lb, 2048) + 2047) / 2048 * 2048);
+    if (ensure_workspace(I, chunk, true)) return 1;
+    const size_t nt = S->hs.textures.size();
+    if (I->grad_tex_cap < std::max<size_t>(nt, 1)) { if (ws_alloc(I, &I->d_grad_tex, std::max<size_t>(nt, 1))) return 1; I->grad_tex_cap = std::max<size_t>(nt, 1); }
+    if (nt) {
+        if (!tangent_textures) return fail("tangent_textures is null but the scene has bitmap textures");
+        for (size_t k = 0; k < nt; ++k) if (!tangent_textures[k]) return fail("null texture tangent buffer");
+        HIP_TRY(hipMemcpyAsync(I->d_grad_tex, tangent_textures, nt * sizeof(float *), hipMemcpyHostToDevice, s));
+        HIP_TRY(hipStreamSynchronize(s));
+    }
+    /* tangent slots in the layout of the gradient slots: (bsdf_count + emitter_count) x 3 */
+    const size_t nb3 = 3 * S->hs.bsdfs.size(), ne3 = 3 * S->hs.emitters.size();
+    if (I->grad_slots_cap < nb3 + ne3 + 3) { if (ws_alloc(I, &I->grad_slots, nb3 + ne3 + 3)) return 1; I->grad_slots_cap = nb3 + ne3 + 3; }
+    HIP_TRY(hipMemsetAsync(I->grad_slots, 0, (nb3 + ne3 + 3) * sizeof(float), s));
+    if (nb3) HIP_TRY(hipMemcpyAsync(I->grad_slots, tangent_reflectance, nb3 * sizeof(float), hipMemcpyDeviceToDevice, s));
+    if (tangent_emitters && ne3) HIP_TRY(hipMemcpyAsync(I->grad_slots + nb3, tangent_emitters, ne3 * sizeof(float), hipMemcpyDeviceToDevice, s));
+    HIP_TRY(hipMemsetAsync(I->totals, 0, 4 * sizeof(unsigned long long), s));
+    HIP_TRY(hipMemsetAsync(I->status, 0, sizeof(int), s));
+    I->last_stream = s; I->twin_used = false;
+    if (prof_begin(I, s)) return 1;
+    float *saved_emitters = I->grad_emitters;
+    I->grad_emitters = tangent_emitters ? I->grad_slots + nb3 : nullptr;       /* only its non-null-ness is read (HAR_SHADE_EMITTER_GRADS) */
+    int rc = 0;
+    for (uint64_t base = lb; base < le && !rc; base += chunk) {
+        uint32_t n = (uint32_t) std::min<uint64_t>(chunk, le - base);
+        rc = run_chunk(S, I, C, MODE_PRB_PRIMAL, seed, spp, log_spp, (uint32_t) base, n, nullptr, s, I->cache_bounces ? 1 : 0);
+        I->forward_mode = true;
+        if (!rc) rc = run_chunk(S, I, C, MODE_PRB_ADJOINT, seed, spp, log_spp, (uint32_t) base, n, I->grad_slots, s, I->cache_bounces ? 2 : 0);
+        I->forward_mode = false;
+        if (!rc) { launch_splat(s, C, seed, spp, log_spp, (uint32_t) base, n, I->dL, 0, film); prof_mark(I, s, CLS_SPLAT); }
+    }
+    I->grad_emitters = saved_emitters;
+    if (rc) return rc;
     HIP_TRY(hipGetLastError());
     return 0;
 }

@@ -174,6 +174,7 @@ __global__ __launch_bounds__(kBlock) void k_raygen(DSensor C, uint32_t seed, uin
     if (MODE != MODE_PRB_ADJOINT) result[i] = make_float4(0.f, 0.f, 0.f, 0.f);
     if (MODE == MODE_PRB_ADJOINT) {
         /* adjoint of ImageBlock::put + develop (common.py:696-746): gather grad_in / W over the footprint */
+        if (!adj) { dL[i] = make_float4(0.f, 0.f, 0.f, 0.f); return; }      /* forward mode: dL accumulates the lane's differential radiance */
         Footprint F; film_footprint(C, ls, F);
         Vec3 g(0.f);
 #pragma unroll
@@ -355,7 +356,39 @@ __global__ __launch_bounds__(kBlock) void k_trace_closest(Accel A, const uint32_
  * L <- L - Lr_dir; g = dL * (dLr_dir/dslot0 + L * (df/dslot0)/f)  (prb.py:227,288-313).
  * s2 = Lr_dir (or Lr_dir for a unit radiance) + tag, s3 = d Lr_dir / d slot0 + uv.x, s4 = (d f / d slot0) / f + uv.y -- the item layout of k_shade */
 __device__ __forceinline__ void adjoint_commit_values(const DScene &S, bool pred, bool visible, uint32_t lane, float4 s2, float4 s3, float4 s4, float4 *result, const float4 *dL,
-                                                      float *grad_refl, float *const *grad_tex, float *gacc) {
+                                                      float *grad_refl, float *const *grad_tex, float *gacc, bool fwd = false) {
+    if (fwd) {
+        /* FORWARD mode (RBIntegrator.render_forward, common.py:497-623; prb.py:313 `dL += dr.forward_to(Lo)`): `grad_refl` / `grad_tex` hold the
+         * TANGENTS of the parameters (same layout as the gradient buffers: slots of the BSDFs, then of the emitters; one array per bitmap) and are
+         * only read; the lane's differential radiance accumulates in dL[lane] (one item per lane and bounce: no race), which raygen zeroed */
+        if (pred) {
+            float4 L = result[lane];
+            const uint32_t tag = __float_as_uint(s2.w), bsdf = tag & 0xfffffu, emitter = (tag >> 20) & 0x7ffu;
+            Vec3 acc(0.f);
+            if (emitter != HAR_ITEM_NO_EMITTER) {
+                const DEmitter E = S.emitters[emitter];
+                if (visible) { const float *te = grad_refl + 3 * ((size_t) S.n_bsdfs + emitter); acc = Vec3(s2.x * te[0], s2.y * te[1], s2.z * te[2]); }
+                s2.x *= E.radiance[0]; s2.y *= E.radiance[1]; s2.z *= E.radiance[2];
+            }
+            if (visible) { L = make_float4(L.x - s2.x, L.y - s2.y, L.z - s2.z, 0.f); result[lane] = L; }
+            Vec3 g = visible ? Vec3(s3.x, s3.y, s3.z) : Vec3(0.f);
+            if (tag & 0x80000000u) g = g + Vec3(L.x * s4.x, L.y * s4.y, L.z * s4.z);
+            const DBsdf B = S.bsdfs[bsdf];
+            Vec3 tan;
+            if (B.texture >= 0) {
+                TexTaps taps; tex_taps(S.textures[B.texture], s3.w, s4.w, taps);
+                const float *tt = grad_tex[B.texture];
+                const float w[4] = { taps.w0x * taps.w0y, taps.w1x * taps.w0y, taps.w0x * taps.w1y, taps.w1x * taps.w1y };
+                tan = Vec3(0.f);
+                for (int k = 0; k < 4; ++k) { const float *q = tt + 3 * (size_t) taps.idx[k]; tan = Vec3(fma_(q[0], w[k], tan.x), fma_(q[1], w[k], tan.y), fma_(q[2], w[k], tan.z)); }
+            } else { const float *q = grad_refl + 3 * (size_t) bsdf; tan = Vec3(q[0], q[1], q[2]); }
+            acc = acc + g * tan;
+            float4 *acc_out = const_cast<float4 *>(dL);
+            const float4 d = acc_out[lane];
+            acc_out[lane] = make_float4(d.x + acc.x, d.y + acc.y, d.z + acc.z, 0.f);
+        }
+        return;
+    }
     Vec3 g(0.f); float *dst = grad_refl; bool tex = false; TexTaps taps; float *tdst = nullptr;
     if (pred) {
         float4 L = result[lane];
@@ -392,11 +425,11 @@ __device__ __forceinline__ void adjoint_commit_values(const DScene &S, bool pred
     }
 }
 __device__ __forceinline__ void adjoint_commit(const DScene &S, const ItemArrays &items, uint32_t i, bool pred, bool visible, float4 *result, const float4 *dL,
-                                               float *grad_refl, float *const *grad_tex, float *gacc, uint8_t *item_vis) {
+                                               float *grad_refl, float *const *grad_tex, float *gacc, uint8_t *item_vis, bool fwd = false) {
     if (pred && item_vis) item_vis[i] = visible ? 1 : 0;
     float4 s2 = make_float4(0.f, 0.f, 0.f, 0.f), s3 = s2, s4 = s2; uint32_t lane = 0;
     if (pred) { lane = __float_as_uint(items.s1[i].w); s2 = items.s2[i]; s3 = items.s3[i]; s4 = items.s4[i]; }
-    adjoint_commit_values(S, pred, visible, lane, s2, s3, s4, result, dL, grad_refl, grad_tex, gacc);
+    adjoint_commit_values(S, pred, visible, lane, s2, s3, s4, result, dL, grad_refl, grad_tex, gacc, fwd);
 }
 
 /* ------------------------------------------------------------------- shade */
@@ -412,6 +445,7 @@ __global__ __launch_bounds__(kBlock, HAR_SHADE_MIN_WAVES) void k_shade(DScene S,
     if (INLINE) { for (uint32_t k = threadIdx.x; k < 3 * HAR_LDS_GRAD_BSDFS; k += kBlock) gacc[k] = 0.f; __syncthreads(); }
     /* adjoint with emitter gradients: per-block accumulators of d L / d radiance from emission hits (slots n_bsdfs + emitter of `grad_slots`) */
     __shared__ float eacc[MODE == MODE_PRB_ADJOINT ? 3 * HAR_LDS_GRAD_EMITTERS : 1];
+    const bool fwd = MODE == MODE_PRB_ADJOINT && (P.flags & HAR_SHADE_FORWARD_MODE) != 0u;      /* render_forward: tangents in, dL accumulates (see adjoint_commit_values) */
     const bool emitter_grads = MODE == MODE_PRB_ADJOINT && (P.flags & HAR_SHADE_EMITTER_GRADS) != 0u;
     if (emitter_grads) { for (uint32_t k = threadIdx.x; k < 3 * HAR_LDS_GRAD_EMITTERS; k += kBlock) eacc[k] = 0.f; __syncthreads(); }
     constexpr uint32_t kSortKeys = BSDF_TYPE_COUNT + 2;                        /* one bucket per BSDF model, then misses, then lanes beyond the tile's end */
@@ -472,7 +506,12 @@ __global__ __launch_bounds__(kBlock, HAR_SHADE_MIN_WAVES) void k_shade(DScene S,
                 else if (MODE == MODE_PRB_PRIMAL) r = make_float4(r.x + R.em_b.x, r.y + R.em_b.y, r.z + R.em_b.z, 0.f);
                 else                              r = make_float4(r.x - R.em_b.x, r.y - R.em_b.y, r.z - R.em_b.z, 0.f);
                 result[lane] = r;
-                if (MODE == MODE_PRB_ADJOINT && emitter_grads && R.em_index >= 0) {
+                if (MODE == MODE_PRB_ADJOINT && emitter_grads && R.em_index >= 0 && fwd) {
+                    const float *te = grad_slots + 3 * ((size_t) S.n_bsdfs + R.em_index);        /* tangent of the emitter's radiance */
+                    float4 *acc_out = const_cast<float4 *>(dL);
+                    const float4 d = acc_out[lane];
+                    acc_out[lane] = make_float4(fma_(R.em_unit.x, te[0], d.x), fma_(R.em_unit.y, te[1], d.y), fma_(R.em_unit.z, te[2], d.z), 0.f);
+                } else if (MODE == MODE_PRB_ADJOINT && emitter_grads && R.em_index >= 0) {
                     const float4 dl = dL[lane];
                     const Vec3 g = R.em_unit * Vec3(dl.x, dl.y, dl.z);
                     if ((uint32_t) R.em_index < HAR_LDS_GRAD_EMITTERS) { float *a = eacc + 3 * R.em_index; atomicAdd(a, g.x); atomicAdd(a + 1, g.y); atomicAdd(a + 2, g.z); }
@@ -487,7 +526,7 @@ __global__ __launch_bounds__(kBlock, HAR_SHADE_MIN_WAVES) void k_shade(DScene S,
             const uint32_t tag = (R.bsdf & 0xfffffu) | ((fact ? (uint32_t) R.nee_emitter : HAR_ITEM_NO_EMITTER) << 20) | (R.ind_active ? 0x80000000u : 0u);
             const bool visible = item_pred && R.item_ray && rc.vis[lane] != 0;
             adjoint_commit_values(S, item_pred, visible, lane, make_float4(c.x, c.y, c.z, __uint_as_float(tag)), make_float4(R.dLr_drho.x, R.dLr_drho.y, R.dLr_drho.z, R.uv_x),
-                                  make_float4(R.rel_grad.x, R.rel_grad.y, R.rel_grad.z, R.uv_y), result, dL, grad_slots, grad_tex, gacc);
+                                  make_float4(R.rel_grad.x, R.rel_grad.y, R.rel_grad.z, R.uv_y), result, dL, grad_slots, grad_tex, gacc, fwd);
             item_pred = false;
         }
         const bool alive = in_range && R.alive, item = item_pred;
@@ -517,14 +556,14 @@ __global__ __launch_bounds__(kBlock, HAR_SHADE_MIN_WAVES) void k_shade(DScene S,
             }
         }
     }
-    if (emitter_grads) {
+    if (emitter_grads && !fwd) {
         __syncthreads();
         for (uint32_t k = threadIdx.x; k < 3 * min(S.n_emitters, (uint32_t) HAR_LDS_GRAD_EMITTERS); k += kBlock) {
             const float v = eacc[k];
             if (v != 0.f) atomicAdd(grad_slots + 3 * (size_t) S.n_bsdfs + k, v);
         }
     }
-    if (INLINE) {
+    if (INLINE && !fwd) {
         __syncthreads();
         for (uint32_t k = threadIdx.x; k < 3 * min(S.n_bsdfs + S.n_emitters, (uint32_t) HAR_LDS_GRAD_BSDFS); k += kBlock) {
             const float v = gacc[k];
@@ -535,7 +574,7 @@ __global__ __launch_bounds__(kBlock, HAR_SHADE_MIN_WAVES) void k_shade(DScene S,
 
 /* adjoint resolve of a bounce whose shadow-ray results sit in the replay cache: no traversal, one item per thread */
 __global__ __launch_bounds__(kBlock) void k_resolve_adjoint_cached(DScene S, const uint32_t *item_count, uint32_t shard_cap, ItemArrays items, float4 *result,
-                                                                   const float4 *dL, float *grad_refl, float *const *grad_tex, ReplayCache rc, uint8_t *item_vis) {
+                                                                   const float4 *dL, float *grad_refl, float *const *grad_tex, ReplayCache rc, uint8_t *item_vis, int fwd) {
     __shared__ float gacc[3 * HAR_LDS_GRAD_BSDFS];
     for (uint32_t k = threadIdx.x; k < 3 * HAR_LDS_GRAD_BSDFS; k += kBlock) gacc[k] = 0.f;
     __syncthreads();
@@ -546,9 +585,10 @@ __global__ __launch_bounds__(kBlock) void k_resolve_adjoint_cached(DScene S, con
         const uint32_t i = Q.base + (pred ? local : 0u);
         bool visible = false;
         if (pred && items.s0[i].w >= 0.f) visible = rc.vis[__float_as_uint(items.s1[i].w)] != 0;
-        adjoint_commit(S, items, i, pred, visible, result, dL, grad_refl, grad_tex, gacc, item_vis);
+        adjoint_commit(S, items, i, pred, visible, result, dL, grad_refl, grad_tex, gacc, item_vis, fwd != 0);
     }
     __syncthreads();
+    if (fwd) return;
     for (uint32_t k = threadIdx.x; k < 3 * min(S.n_bsdfs + S.n_emitters, (uint32_t) HAR_LDS_GRAD_BSDFS); k += kBlock) {
         const float v = gacc[k];
         if (v != 0.f) atomicAdd(grad_refl + k, v);
@@ -558,7 +598,7 @@ __global__ __launch_bounds__(kBlock) void k_resolve_adjoint_cached(DScene S, con
 /* ------------------------------------------------- resolve (shadow rays + NEE) */
 template <int MODE, bool SPILL>
 __global__ __launch_bounds__(kBlock) void k_resolve(DScene S, const uint32_t *item_count, uint32_t *cursor, uint32_t shard_cap, ItemArrays items, float4 *result,
-                                                    const float4 *dL, float *grad_refl, float *const *grad_tex, int *status, ReplayCache rc, uint2 *spill, uint8_t *item_vis) {
+                                                    const float4 *dL, float *grad_refl, float *const *grad_tex, int *status, ReplayCache rc, uint2 *spill, uint8_t *item_vis, int fwd) {
     __shared__ uint2 lds[HAR_LDS_STACK_SMALL * kBlock];
     /* adjoint: per-block accumulators of the constant-albedo gradients.  Every path of the chip adds to the same
      * few floats of grad_refl (one 64 B line): direct global atomics serialise at ~88 atomics/us per line, which
@@ -598,9 +638,10 @@ __global__ __launch_bounds__(kBlock) void k_resolve(DScene S, const uint32_t *it
         trace_persistent<true, true, WaveStack>(S.accel, cursor + shard * HAR_COUNTER_STRIDE, n, stack, status, take,
             [&](uint32_t, const Traversal<HAR_TRAV_POLICY> &) { },
             [&](bool pred, uint32_t idx, const Traversal<HAR_TRAV_POLICY> &T) {
-                adjoint_commit(S, items, base + (pred ? idx : 0u), pred, pred && !T.found, result, dL, grad_refl, grad_tex, gacc, item_vis);
+                adjoint_commit(S, items, base + (pred ? idx : 0u), pred, pred && !T.found, result, dL, grad_refl, grad_tex, gacc, item_vis, fwd != 0);
             });
         __syncthreads();
+        if (fwd) return;
         for (uint32_t k = threadIdx.x; k < 3 * min(S.n_bsdfs + S.n_emitters, (uint32_t) HAR_LDS_GRAD_BSDFS); k += kBlock) {
             const float v = gacc[k];
             if (v != 0.f) atomicAdd(grad_refl + k, v);
@@ -1029,13 +1070,13 @@ void launch_shade(int mode, hipStream_t s, uint32_t grid, const DScene &S, const
 #undef HAR_LAUNCH_SHADE
 }
 void launch_resolve(int mode, hipStream_t s, uint32_t grid, uint2 *spill, const DScene &S, const uint32_t *item_count, uint32_t *cursor, uint32_t shard_cap, const ItemArrays &items,
-                    float4 *result, const float4 *dL, float *grad_refl, float *const *grad_tex, int *status, const ReplayCache &rc, uint8_t *item_vis) {
+                    float4 *result, const float4 *dL, float *grad_refl, float *const *grad_tex, int *status, const ReplayCache &rc, uint8_t *item_vis, int fwd) {
     dim3 g(grid), b(kBlock);
     if (mode == MODE_PRB_ADJOINT && rc.mode == 2) {
-        hipLaunchKernelGGL(k_resolve_adjoint_cached, g, b, 0, s, S, item_count, shard_cap, items, result, dL, grad_refl, grad_tex, rc, item_vis);
+        hipLaunchKernelGGL(k_resolve_adjoint_cached, g, b, 0, s, S, item_count, shard_cap, items, result, dL, grad_refl, grad_tex, rc, item_vis, fwd);
         return;
     }
-#define HAR_LAUNCH_RESOLVE(M, SP) hipLaunchKernelGGL((k_resolve<M, SP>), g, b, 0, s, S, item_count, cursor, shard_cap, items, result, dL, grad_refl, grad_tex, status, rc, spill, item_vis)
+#define HAR_LAUNCH_RESOLVE(M, SP) hipLaunchKernelGGL((k_resolve<M, SP>), g, b, 0, s, S, item_count, cursor, shard_cap, items, result, dL, grad_refl, grad_tex, status, rc, spill, item_vis, fwd)
     if (mode == MODE_PRB_ADJOINT) { if (spill) HAR_LAUNCH_RESOLVE(MODE_PRB_ADJOINT, true); else HAR_LAUNCH_RESOLVE(MODE_PRB_ADJOINT, false); }
     else { if (spill) HAR_LAUNCH_RESOLVE(MODE_PATH, true); else HAR_LAUNCH_RESOLVE(MODE_PATH, false); }
 #undef HAR_LAUNCH_RESOLVE

@@ -35,6 +35,7 @@ struct ShadeParams {
     uint32_t flags = 0;        /* bit 0 (adjoint): also accumulate the gradient w.r.t. the radiance of `area` / `constant` emitters; bit 1: hide_emitters */
 };
 #define HAR_SHADE_EMITTER_GRADS 1u
+#define HAR_SHADE_FORWARD_MODE 4u    /* adjoint kernels in FORWARD mode (RBIntegrator.render_forward): parameter tangents in, differential radiance out */
 #define HAR_SHADE_HIDE_EMITTERS 2u   /* Integrator property `hide_emitters`: the environment is not seen by camera rays (path.cpp:114-115, prb.py:146-148) */
 #define HAR_ITEM_NO_EMITTER 0x7ffu   /* emitter field of an adjoint item's tag: contribution stored as is (no emitter gradient) */
 

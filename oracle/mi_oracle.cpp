@@ -824,7 +824,15 @@ static inline void shape_scatter(const ShapeSink &sk, const AttachedSI &a, int s
 }
 
 struct GradSink { float *refl; float *const *tex; float *emit; /* 3 per emitter (radiance of `area` / `constant`), may be null */
-                  const ShapeSink *shape = nullptr; /* vertex-position gradients of the meshes in its mask, may be null */ };
+                  const ShapeSink *shape = nullptr; /* vertex-position gradients of the meshes in its mask, may be null */
+                  /* FORWARD mode (RBIntegrator.render_forward, common.py:497-623; prb.py:313 `dL += dr.forward_to(Lo)`): refl / tex / emit hold the
+                   * parameters' tangents (read only) and every derivative term is contracted with them into *fwd; the caller passes dL = 1 */
+                  V3 *fwd = nullptr; };
+/* one derivative term: backward adds w * g to the parameter's gradient slot, forward adds w * g * tangent to the lane's differential radiance */
+static inline void grad_commit(const GradSink *grad, float *slot, V3 g, float w = 1.f) {
+    if (grad->fwd) { grad->fwd->x += g.x * w * slot[0]; grad->fwd->y += g.y * w * slot[1]; grad->fwd->z += g.z * w * slot[2]; }
+    else { slot[0] += g.x * w; slot[1] += g.y * w; slot[2] += g.z * w; }
+}
 
 static V3 prb_sample(const Scene &sc, Pcg32 &rng, Ray ray, uint32_t max_depth, uint32_t rr_depth, bool primal,
                      V3 L_in, V3 dL, const GradSink *grad, bool &valid, OrcStats &st) {
@@ -852,8 +860,7 @@ static V3 prb_sample(const Scene &sc, Pcg32 &rng, Ray ray, uint32_t max_depth, u
                 V3 ev = e.type == 2 ? sc.envmap.eval(-si.wi) : (e.type == 1 || si.wi.z > 0.f) ? V3(e.radiance[0], e.radiance[1], e.radiance[2]) : V3(0.f);
                 Le = (beta * mis) * ev;
                 if (!primal && grad && grad->emit && e.type != 2 && (e.type == 1 || si.wi.z > 0.f)) {   // d Le / d radiance = beta * mis (prb.py:160-161, attached emitter.eval)
-                    V3 g = (beta * mis) * dL; float *dst = grad->emit + 3 * (size_t) emitter;
-                    dst[0] += g.x; dst[1] += g.y; dst[2] += g.z;
+                    grad_commit(grad, grad->emit + 3 * (size_t) emitter, (beta * mis) * dL);
                 }
             }
         }
@@ -874,8 +881,7 @@ static V3 prb_sample(const Scene &sc, Pcg32 &rng, Ray ray, uint32_t max_depth, u
             Lr_dir = ((beta * mis_em) * ev.value) * em_weight;
             dLr_dir_drho = ((beta * mis_em) * ev.d_slot0) * em_weight;           // d/d slot0 of the line above
             if (!primal && grad && grad->emit && sc.emitters[ds.emitter].type != 2) {   // em_weight = radiance * em_unit (prb.py:198-206, attached eval_emitter_direction)
-                V3 g = (((beta * mis_em) * ev.value) * em_unit) * dL; float *dst = grad->emit + 3 * (size_t) ds.emitter;
-                dst[0] += g.x; dst[1] += g.y; dst[2] += g.z;
+                grad_commit(grad, grad->emit + 3 * (size_t) ds.emitter, (((beta * mis_em) * ev.value) * em_unit) * dL);
             }
         }
         // detached BSDF sampling, prb.py:220-223 (masked lanes return zeros)
@@ -905,14 +911,12 @@ static V3 prb_sample(const Scene &sc, Pcg32 &rng, Ray ray, uint32_t max_depth, u
                            e2.value.z != 0.f ? L.z * (e2.d_slot0.z / e2.value.z) : 0.f);
             }
             g = g * dL;
-            if (!bsdf.textured) {
-                float *dst = grad->refl + 3 * (size_t) bsdf.used;
-                dst[0] += g.x; dst[1] += g.y; dst[2] += g.z;
-            } else {
+            if (!bsdf.textured) grad_commit(grad, grad->refl + 3 * (size_t) bsdf.used, g);
+            else {
                 const TexLookup &tl = bsdf.tl;
                 float *dst = grad->tex[bsdf.rec->p.texture];
                 const float wts[4] = { tl.w[0] * tl.w[2], tl.w[1] * tl.w[2], tl.w[0] * tl.w[3], tl.w[1] * tl.w[3] };
-                for (int k = 0; k < 4; ++k) { float *q = dst + 3 * (size_t) tl.idx[k]; q[0] += g.x * wts[k]; q[1] += g.y * wts[k]; q[2] += g.z * wts[k]; }
+                for (int k = 0; k < 4; ++k) grad_commit(grad, dst + 3 * (size_t) tl.idx[k], g, wts[k]);
             }
         }
         if (!primal && grad && grad->shape && si.valid() && bsdf.rec) {
@@ -1503,6 +1507,37 @@ int orc_render_prb_backward_ex(void *scene, const OrcSensor *sp, const float *gr
                                int32_t max_depth, int32_t rr_depth, float *grad_reflectance, float *const *grad_textures,
                                float *grad_emitters, OrcStats *stats, int threads) {
     return prb_backward_impl(scene, sp, grad_in, seed, spp, max_depth, rr_depth, grad_reflectance, grad_textures, grad_emitters, nullptr, nullptr, stats, threads);
+}
+/* RBIntegrator.render_forward (common.py:497-623): raw film (H x W x 4) of the lanes' differential radiance for the given parameter tangents
+ * (layout of the gradient buffers of orc_render_prb_backward_ex; tangent_emitters may be NULL) */
+int orc_render_prb_forward(void *scene, const OrcSensor *sp, uint32_t seed, uint32_t spp, int32_t max_depth, int32_t rr_depth, const float *tangent_reflectance,
+                           const float *const *tangent_textures, const float *tangent_emitters, float *film, int threads) {
+    Scene &sc = *(Scene *) scene; const OrcSensor &s = *sp;
+    uint64_t total = (uint64_t) s.crop_width * s.crop_height * spp;
+    if (total > 0xffffffffull) return -1;
+    RFilter rf = make_rfilter(s.rfilter, s.rfilter_stddev, s.rfilter_param1);
+    threads = resolve_threads(threads);
+    size_t fsz = (size_t) s.crop_width * s.crop_height * 4;
+    std::vector<std::vector<float>> films(threads);
+    uint32_t md = (uint32_t) max_depth, rd = (uint32_t) rr_depth;
+    std::vector<float> zero_emit(3 * sc.emitters.size() + 3, 0.f);
+    parallel_lanes(0, total, threads, [&](int t, uint64_t b, uint64_t e) {
+        if (films[t].empty()) films[t].assign(fsz, 0.f);
+        for (uint64_t i = b; i < e; ++i) {
+            Lane L = make_lane(s, seed, spp, i);
+            bool valid; OrcStats dummy{};
+            Pcg32 rng2 = L.rng;                               // sampler.clone() for the primal pass (common.py:569-578)
+            V3 Lp = prb_sample(sc, rng2, L.ray, md, rd, true, V3(0.f), V3(0.f), nullptr, valid, dummy);
+            V3 acc(0.f);
+            GradSink sink{ const_cast<float *>(tangent_reflectance), const_cast<float *const *>(tangent_textures),
+                           const_cast<float *>(tangent_emitters ? tangent_emitters : zero_emit.data()), nullptr, &acc };
+            prb_sample(sc, L.rng, L.ray, md, rd, false, Lp, V3(1.f), &sink, valid, dummy);
+            float v[4] = { acc.x, acc.y, acc.z, 1.f };
+            film_put(s, rf, rf.type == 0 ? L.ipos_x : L.pos_x, rf.type == 0 ? L.ipos_y : L.pos_y, v, films[t].data());
+        }
+    });
+    for (auto &f : films) if (!f.empty()) for (size_t i = 0; i < fsz; ++i) film[i] += f[i];
+    return 0;
 }
 int orc_render_prb_backward_lanes(void *scene, const OrcSensor *sp, const float *grad_in, const float *weight_film, uint32_t seed, uint32_t spp,
                                   int32_t max_depth, int32_t rr_depth, uint64_t lane_begin, uint64_t lane_end, float *grad_reflectance,

@@ -199,6 +199,11 @@ int orc_render_prb_backward_ex(void *scene, const OrcSensor *s, const float *gra
  * ray i draws from the stream of wavefront lane lane_offset + i, continued from state[i] if given; rgb 3 x n, valid n, state_out n (nullable) */
 int orc_integrator_sample(void *scene, int prb, uint32_t n, const float *o, const float *d, const float *maxt, uint32_t seed, uint32_t lane_offset,
                           const uint64_t *state, int32_t max_depth, int32_t rr_depth, float *rgb, uint8_t *valid, uint64_t *state_out, int threads);
+/* RBIntegrator.render_forward (src/python/python/ad/integrators/common.py:497-623): the forward-mode derivative image of `prb`.  Tangents in
+ * the layout of orc_render_prb_backward_ex's gradient buffers (tangent_emitters may be NULL); film = raw H x W x 4 accumulation of the lanes'
+ * differential radiance dL = sum over vertices <d Lo / d theta, tangent> (prb.py:313), orc_film_develop(film) is the gradient image */
+int orc_render_prb_forward(void *scene, const OrcSensor *s, uint32_t seed, uint32_t spp, int32_t max_depth, int32_t rr_depth, const float *tangent_reflectance,
+                           const float *const *tangent_textures, const float *tangent_emitters, float *film, int threads);
 /* the two pieces a rank of a multi-GPU job runs (mitsuba3_amd/distributed.py render_backward_distributed): the weight-only splat of its lane
  * band (film H x W x 4, added to), and the backward pass of lanes [lane_begin, lane_end) (0, 0 = all) against the all-reduced weight film
  * (NULL: computed here over the whole wavefront) */

@@ -473,6 +473,19 @@ class OracleScene:
         assert rc == 0
         return g_refl, g_tex, g_emit[:len(self.data.emitters)], st
 
+    def render_prb_forward(self, sensor, t_refl, t_tex=(), t_emit=None, seed=0, spp=4, max_depth=6, rr_depth=5, threads=0, raw=False):
+        """RBIntegrator.render_forward: gradient image (H x W x 3) for the parameter tangents t_refl (bsdf_count x 3), t_tex (one array per bitmap),
+        t_emit (emitter_count x 3 or None)"""
+        t_refl = f32(t_refl); t_tex = [f32(t) for t in t_tex]
+        ptrs = (c_f32p * max(1, len(t_tex)))(*[fp(t) for t in t_tex])
+        te = None if t_emit is None else f32(t_emit)
+        film = np.zeros((sensor.crop_height, sensor.crop_width, 4), np.float32)
+        L = lib(); L.orc_render_prb_forward.restype = C.c_int
+        L.orc_render_prb_forward.argtypes = [C.c_void_p, C.POINTER(Sensor), C.c_uint32, C.c_uint32, C.c_int32, C.c_int32, c_f32p, C.POINTER(c_f32p), c_f32p, c_f32p, C.c_int]
+        rc = L.orc_render_prb_forward(self.handle, C.byref(sensor), seed, spp, max_depth, rr_depth, fp(t_refl), ptrs, fp(te) if te is not None else None, fp(film), threads)
+        assert rc == 0
+        return film if raw else develop(film)
+
     def integrator_sample(self, o, d, maxt, seed=0, lane_offset=0, state=None, max_depth=8, rr_depth=5, prb=False, threads=0):
         """SamplingIntegrator::sample over n rays (3 x n origins / directions): (rgb 3 x n, valid n uint8, state_out n uint64)"""
         o = f32(o); d = f32(d); maxt = f32(maxt); n = maxt.shape[0]

@@ -143,3 +143,78 @@ def test_film_put_vs_oracle(mi, O, rfilter):
     ref = np.zeros((23, 37, 4), np.float32)
     O.lib().orc_film_put(C.byref(sensor), n, O.fp(px), O.fp(py), O.fp(vals), O.fp(ref))
     assert rel_l2(film.cpu().numpy(), ref) < 1e-5
+
+
+# ------------------------------------------------------------------ RBIntegrator.render_forward (common.py:497-623)
+
+def test_render_forward_vs_oracle_textured_cornell(mi, O):
+    """forward-mode derivative image of `prb` for tangents on the albedo bitmap, the constant albedos and the emitter radiance, vs the oracle
+    (pinned by finite differences and the adjoint identity in tests/test_render_forward_cpu.py); north_star's gradient tolerance 1e-3"""
+    res, spp = 64, 32
+    d = mi.textured_cornell_box(res=res, tex_res=16, spp=spp)
+    scene = mi.load_dict(d)
+    sd, sensor = O.cornell_box(res, res, white_texture=d["white"]["reflectance"]["data"])
+    osc = O.OracleScene(sd)
+    rng = np.random.default_rng(3)
+    keys = scene._param_keys()
+    tangents, t_refl, t_emit, t_tex = {}, np.zeros((len(scene.bsdfs), 3), np.float32), np.zeros((len(scene.emitters), 3), np.float32), None
+    for k, (kind, b) in keys.items():
+        if kind == "tex":
+            t_tex = rng.uniform(-1, 1, tuple(scene.textures[b.tex_index].shape)).astype(np.float32); tangents[k] = t_tex
+        elif kind == "emit":
+            t_emit[b] = rng.uniform(-1, 1, 3); tangents[k] = t_emit[b]
+        else:
+            t_refl[b.index] = rng.uniform(-1, 1, 3); tangents[k] = t_refl[b.index]
+    img = scene.integrator().render_forward(scene, None, seed=5, spp=spp, tangents=tangents).cpu().numpy()
+    ref = osc.render_prb_forward(sensor, t_refl, [t_tex], t_emit, seed=5, spp=spp, max_depth=6)
+    assert rel_l2(img, ref) < 1e-3
+    # each parameter group on its own (the others' tangents are zero), and linearity of the sum (src/render/tests/test_ad.py:6-134)
+    parts = [scene.integrator().render_forward(scene, None, seed=5, spp=spp, tangents={k: v}).cpu().numpy() for k, v in tangents.items()]
+    assert rel_l2(sum(parts), img) < 1e-5
+    only_tex = osc.render_prb_forward(sensor, 0 * t_refl, [t_tex], None, seed=5, spp=spp, max_depth=6)
+    k_tex = next(k for k, (kind, _) in keys.items() if kind == "tex")
+    assert rel_l2(parts[list(tangents).index(k_tex)], only_tex) < 1e-3
+
+
+def test_render_forward_is_transpose_of_render_backward(mi):
+    """<J t, g> == <t, J^T g> between har_render_forward and har_render_backward on the textured instanced scene (bitmap shared by 9 instances,
+    generic materials off): both passes replay the same sample streams, so the identity holds per sample up to float rounding"""
+    import torch
+    res, spp = 96, 8
+    d = mi.instanced_spheres_scene(width=res, height=res, spp=spp, grid=3, n_u=16, n_v=8, textured=True, tex_res=32)
+    d["integrator"] = {"type": "prb", "max_depth": 6, "rr_depth": 5, "emitter_gradients": True}
+    scene = mi.load_dict(d)
+    integ = scene.integrator()
+    rng = np.random.default_rng(8)
+    keys = scene._param_keys()
+    tangents = {}
+    for k, (kind, b) in keys.items():
+        shape = tuple(scene.textures[b.tex_index].shape) if kind == "tex" else (3,)
+        tangents[k] = rng.uniform(-1, 1, shape).astype(np.float32)
+    g = rng.uniform(-1, 1, (res, res, 3)).astype(np.float32)
+    fwd = integ.render_forward(scene, None, seed=2, spp=spp, tangents=tangents).cpu().numpy().astype(np.float64)
+    grads = integ.render_backward(scene, None, g, seed=2, spp=spp)
+    lhs = float((fwd * g).sum())
+    rhs = float(sum((grads[k].cpu().numpy().astype(np.float64).reshape(-1) * tangents[k].reshape(-1)).sum() for k in tangents))
+    assert abs(lhs - rhs) < 2e-4 * max(abs(lhs), abs(rhs)), (lhs, rhs)
+
+
+def test_render_forward_materials_vs_oracle(mi, O):
+    """forward mode through the generic (all-BSDF) kernels: rough plastic / rough conductor / dielectric scene, tangents on every colour slot 0"""
+    res, spp = 48, 16
+    d = mi.instanced_spheres_scene(width=res, height=res, spp=spp, grid=3, n_u=12, n_v=6, flatten=True, materials=True)
+    d["integrator"] = {"type": "prb", "max_depth": 6, "rr_depth": 5, "emitter_gradients": True}
+    scene = mi.load_dict(d)
+    osc, sensor = O.scene_from_product(scene)
+    rng = np.random.default_rng(4)
+    keys = scene._param_keys()
+    tangents, t_refl, t_emit = {}, np.zeros((len(scene.bsdfs), 3), np.float32), np.zeros((len(scene.emitters), 3), np.float32)
+    for k, (kind, b) in keys.items():
+        v = rng.uniform(-1, 1, 3).astype(np.float32); tangents[k] = v
+        if kind == "emit":
+            t_emit[b] = v
+        else:
+            t_refl[b.index] = v
+    img = scene.integrator().render_forward(scene, None, seed=1, spp=spp, tangents=tangents).cpu().numpy()
+    ref = osc.render_prb_forward(sensor, t_refl, [], t_emit, seed=1, spp=spp, max_depth=6)
+    assert rel_l2(img, ref) < 1e-3
