@@ -52,7 +52,13 @@ struct Accel {
     uint32_t root;             /* TLAS root if has_tlas, else BLAS root of the top-level geometry */
     uint32_t has_tlas;
     uint32_t n_tris, n_insts;
+    /* two-level scenes: the top-level (non-instanced) geometry is NOT an entry of the TLAS.  A ray walks its BLAS first -- no instance entry, no
+     * ray transform, and every lane of a wave does so at the same time -- and then starts at the TLAS root with the closest hit found so far
+     * as tmax.  (As a TLAS entry its box spans the scene, so every ray entered it anyway: one instance-entry block per ray for nothing.)
+     * top_root = 0xffffffff: no top-level geometry.  top_first / top_count: its triangle records (brute-force kernel). */
+    uint32_t top_root, top_first, top_count;
 };
+#define HAR_NO_NODE 0xffffffffu
 
 struct Hit {
     float t, u, v;
@@ -228,6 +234,8 @@ HAR_HD bool accel_trace(const Accel &A, Vec3 o_w, Vec3 d_w, float maxt, Hit &hit
     uint32_t cur_inst = 0xffffffffu;
     uint32_t ng_x = A.root, ng_y = 0x80000000u, tg_x = 0, tg_y = 0;
     int sp = 0, inst_sp = -1;
+    bool tlas_pending = false;
+    if (A.has_tlas && A.top_root != HAR_NO_NODE) { in_tlas = false; inst_sp = 0; ng_x = A.top_root; tlas_pending = true; }      /* top-level geometry first */
     for (;;) {
         probe.iter();
         if (ng_y > 0x00ffffffu) {
@@ -272,6 +280,7 @@ HAR_HD bool accel_trace(const Accel &A, Vec3 o_w, Vec3 d_w, float maxt, Hit &hit
         if (ng_y <= 0x00ffffffu) {
             if (!in_tlas && sp == inst_sp) {
                 in_tlas = true; cur_inst = 0xffffffffu; inst_sp = -1;
+                if (tlas_pending) { tlas_pending = false; ng_x = A.root; ng_y = 0x80000000u; continue; }      /* the ray is still the world-space one */
                 R = ray_setup(o_w, d_w);
             }
             if (sp == 0) break;
@@ -311,6 +320,9 @@ struct Traversal {
         R = ray_setup(o, d);
         in_tlas = A.has_tlas != 0; cur_inst = 0xffffffffu; found = false;
         ng_x = A.root; ng_y = 0x80000000u; tg_x = 0; tg_y = 0; sp = 0; inst_sp = -1; parked = 0;
+        /* top-level geometry first (see Accel): the state "in a BLAS, no instance" (in_tlas false, cur_inst none) only exists in this phase of a
+         * two-level scene -- TLAS entries always carry an instance index -- so no extra flag is kept */
+        if (A.has_tlas && A.top_root != HAR_NO_NODE) { in_tlas = false; inst_sp = 0; ng_x = A.top_root; }
     }
 
     /* ---- node phase: at most one node visit */
@@ -364,14 +376,16 @@ struct Traversal {
     }
     /* ---- pop phase: leave the instance / finish / take the next group from the stack */
     template <typename Stack>
-    HAR_HD bool phase_pop(Stack &stack) {
+    HAR_HD bool phase_pop(const Accel &A, Stack &stack) {
         if (POLICY == 2) {
             /* pop as soon as no group is held in ng, even while triangles are pending (they are tested one per
              * iteration in parallel with the node visits); a popped triangle group waits in ng until tg is empty */
             if (ng_y == 0u) {
                 if (!in_tlas && sp == inst_sp) {
                     if (tg_y != 0u) return false;                      /* drain the instance's triangles first */
+                    const bool top_phase = cur_inst == 0xffffffffu;
                     in_tlas = true; cur_inst = 0xffffffffu; inst_sp = -1;
+                    if (top_phase) { ng_x = A.root; ng_y = 0x80000000u; return false; }
                     R = ray_setup(o_w, d_w);
                 }
                 if (sp == 0) { if (tg_y != 0u) return false; found = hit.t != HAR_INF; return true; }
@@ -382,7 +396,10 @@ struct Traversal {
         }
         if (ng_y <= 0x00ffffffu && tg_y == 0u) {
             if (!in_tlas && sp == inst_sp) {
-                in_tlas = true; cur_inst = 0xffffffffu; inst_sp = -1;
+                const bool top_phase = cur_inst == 0xffffffffu;
+                in_tlas = true; inst_sp = -1;
+                if (top_phase) { ng_x = A.root; ng_y = 0x80000000u; return false; }      /* top-level BLAS done: on to the TLAS with the same (world-space) ray */
+                cur_inst = 0xffffffffu;
                 R = ray_setup(o_w, d_w);
             }
             if (sp == 0) { found = hit.t != HAR_INF; return true; }
@@ -400,7 +417,7 @@ struct Traversal {
     HAR_HD bool leaf_round(const Accel &A, Stack &stack, int &status) {
         NoProbe probe;
         if (phase_leaf<AnyHit>(A, stack, status, probe)) return true;
-        return phase_pop(stack);
+        return phase_pop(A, stack);
     }
     HAR_HD bool leaf_pending() const { return tg_y != 0u; }
 
@@ -412,14 +429,14 @@ struct Traversal {
         if (ORDER == 0) {
             if (phase_node(A, stack, status, probe)) return true;
             if (phase_leaf<AnyHit>(A, stack, status, probe)) return true;
-            return phase_pop(stack);
+            return phase_pop(A, stack);
         } else if (ORDER == 1) {
             if (phase_leaf<AnyHit>(A, stack, status, probe)) return true;
             if (phase_node(A, stack, status, probe)) return true;
-            return phase_pop(stack);
+            return phase_pop(A, stack);
         } else {
             if (phase_leaf<AnyHit>(A, stack, status, probe)) return true;
-            if (phase_pop(stack)) return true;
+            if (phase_pop(A, stack)) return true;
             return phase_node(A, stack, status, probe);
         }
     }
@@ -430,15 +447,20 @@ template <bool AnyHit>
 HAR_HD bool accel_trace_naive(const Accel &A, const uint32_t *blas_tri_ranges, Vec3 o_w, Vec3 d_w, float maxt, Hit &hit) {
     hit.t = HAR_INF; hit.u = 0.f; hit.v = 0.f; hit.prim = 0; hit.shape = 0; hit.inst = 0xffffffffu;
     float tmax = maxt;
-    uint32_t n = A.has_tlas ? A.n_insts : 1u;
-    for (uint32_t k = 0; k < n; ++k) {
+    const uint32_t n_top = (A.has_tlas && A.top_root != HAR_NO_NODE) ? 1u : 0u;
+    uint32_t n = A.has_tlas ? A.n_insts + n_top : 1u;
+    for (uint32_t kk = 0; kk < n; ++kk) {
         Vec3 o = o_w, d = d_w; uint32_t inst = 0xffffffffu, first, count;
-        if (A.has_tlas) {
-            const InstRec &I = A.insts[k];
-            if (!I.identity) { o = xf_point(I.to_object, o_w); d = xf_vector(I.to_object, d_w); }
-            inst = I.inst_index;
+        if (kk < n_top) { first = A.top_first; count = A.top_count; }          /* the top-level geometry of a two-level scene */
+        else {
+            const uint32_t k = kk - n_top;
+            if (A.has_tlas) {
+                const InstRec &I = A.insts[k];
+                if (!I.identity) { o = xf_point(I.to_object, o_w); d = xf_vector(I.to_object, d_w); }
+                inst = I.inst_index;
+            }
+            first = blas_tri_ranges[2 * k]; count = blas_tri_ranges[2 * k + 1];
         }
-        first = blas_tri_ranges[2 * k]; count = blas_tri_ranges[2 * k + 1];
         for (uint32_t i = first; i < first + count; ++i) {
             const TriRec &T = A.tris[i];
             float t, u, v;

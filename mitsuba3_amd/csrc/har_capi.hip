@@ -119,7 +119,7 @@ struct HarIntegratorImpl {
     uint32_t ws_lanes = 0; bool ws_adjoint = false; uint32_t shard_cap = 0;
     std::vector<void *> owned;
     WaveState st[2]{};
-    float4 *h0 = nullptr; uint2 *h1 = nullptr;
+    float4 *h0 = nullptr; uint2 *h1 = nullptr; float4 *hit_scratch = nullptr;      /* hit records (32 B per lane, two views); scratch records of hide_emitters */
     ItemArrays items{};
     float4 *result = nullptr, *dL = nullptr;
     /* PRB replay cache (see ReplayCache): cache_bounces arrays of ws_lanes entries each */
@@ -188,7 +188,9 @@ int ensure_workspace(HarIntegratorImpl *I, uint32_t lanes, bool adjoint) {
         if (ws_alloc(I, &I->st[k].a0, lanes) || ws_alloc(I, &I->st[k].a1, lanes) || ws_alloc(I, &I->st[k].a2, lanes) ||
             ws_alloc(I, &I->st[k].a3, lanes) || ws_alloc(I, &I->st[k].a4, lanes)) return 1;
     }
-    if (ws_alloc(I, &I->h0, lanes) || ws_alloc(I, &I->h1, lanes)) return 1;
+    /* closest-hit records: one 32-byte record per lane, viewed as h0 (float4, stride 2) and h1 (uint2, stride 4) -- see HIT0 / HIT1 in har_kernels.hip */
+    if (ws_alloc(I, &I->h0, (size_t) 2 * lanes)) return 1;
+    I->h1 = HAR_HIT_INTERLEAVED ? reinterpret_cast<uint2 *>(I->h0 + 1) : reinterpret_cast<uint2 *>(I->h0 + lanes); I->hit_scratch = nullptr;
     if (ws_alloc(I, &I->items.s0, lanes) || ws_alloc(I, &I->items.s1, lanes) || ws_alloc(I, &I->items.s2, lanes)) return 1;
     I->items.s3 = I->items.s4 = nullptr; I->dL = nullptr;
     if (adjoint && (ws_alloc(I, &I->items.s3, lanes) || ws_alloc(I, &I->items.s4, lanes) || ws_alloc(I, &I->dL, lanes))) return 1;
@@ -312,7 +314,7 @@ int run_chunk(HarSceneImpl *S, HarIntegratorImpl *I, const DSensor &C, int mode,
     const bool shape = mode == MODE_PRB_ADJOINT && I->shape_on;
     /* adjoint replay of a cached bounce: `shade` commits the vertex adjoint itself (the shadow-ray result is in the cache), no items, no resolve launch */
     static const bool inline_env = getenv("HAR_ADJOINT_INLINE") ? atoi(getenv("HAR_ADJOINT_INLINE")) != 0 : true;
-    const bool inline_commit = inline_env && mode == MODE_PRB_ADJOINT && !shape;
+    const bool inline_commit = inline_env && mode == MODE_PRB_ADJOINT && !shape && !I->forward_mode;      /* forward mode commits in the resolve kernels (own instantiation) */
     const ShapeTargets targets{ I->d_pos_offset, I->grad_pos, I->pos_verts };
     int cur = 0; uint32_t b = 0;
     for (; b < nb; ++b) {
@@ -331,7 +333,8 @@ int run_chunk(HarSceneImpl *S, HarIntegratorImpl *I, const DSensor &C, int mode,
             const size_t cs = (size_t) HAR_SHARDS * HAR_COUNTER_STRIDE;
             uint32_t *cnt[2] = { I->skip_counters, I->skip_counters + 2 * cs }, *cursor[2] = { I->skip_counters + cs, I->skip_counters + 3 * cs };
             float4 *lo[2] = { I->st[cur ^ 1].a0, I->st[cur ^ 1].a2 }, *ld[2] = { I->st[cur ^ 1].a1, I->st[cur ^ 1].a3 };
-            float4 *sh0 = I->items.s0; uint2 *sh1 = reinterpret_cast<uint2 *>(I->items.s1);
+            if (!I->hit_scratch && ws_alloc(I, &I->hit_scratch, (size_t) 2 * I->ws_lanes)) return 1;       /* re-traced hits: records in the layout of h0 / h1 */
+            float4 *sh0 = I->hit_scratch; uint2 *sh1 = HAR_HIT_INTERLEAVED ? reinterpret_cast<uint2 *>(I->hit_scratch + 1) : reinterpret_cast<uint2 *>(I->hit_scratch + I->ws_lanes);
             HIP_TRY(hipMemsetAsync(I->skip_counters, 0, 4 * cs * sizeof(uint32_t), s));
             launch_skip_emitters(s, grid, S->ds, 1, I->shard_cap, cnt_alive(I, 0), I->st[cur].a0, I->st[cur].a1, nullptr, nullptr, I->h0, I->h1, lo[0], ld[0], cnt[0]);
             for (int round = 0, a = 0; round < 256; ++round, a ^= 1) {
@@ -461,6 +464,7 @@ int har_scene_create(const HarSceneDesc *desc, HarScene *out) {
     if (err != hipSuccess) { for (void *p : S->owned) dev_free(p); delete S; return fail(std::string("scene upload: ") + hipGetErrorString(err)); }
     S->d_bsdfs = const_cast<DBsdf *>(D.bsdfs);
     D.accel.root = hs.root; D.accel.has_tlas = hs.has_tlas; D.accel.n_tris = (uint32_t) hs.tris.size(); D.accel.n_insts = (uint32_t) hs.inst_recs.size();
+    D.accel.top_root = hs.top_root; D.accel.top_first = hs.top_first; D.accel.top_count = hs.top_count;
     D.n_emitters = (uint32_t) hs.emitters.size(); D.n_meshes = (uint32_t) hs.meshes.size();
     D.n_bsdfs = (uint32_t) hs.bsdfs.size(); D.n_textures = (uint32_t) hs.textures.size();
     D.env_emitter = hs.env_emitter;

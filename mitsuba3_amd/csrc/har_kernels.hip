@@ -28,6 +28,7 @@ namespace har {
 
 static constexpr int kBlock = 256;
 
+
 template <int CAP> struct LdsStack {
     static constexpr int Capacity = CAP;
     uint2 *col;   /* &lds[threadIdx.x]; entry l lives at col[l * kBlock] */
@@ -339,25 +340,34 @@ __global__ __launch_bounds__(kBlock) void k_trace_closest(Accel A, const uint32_
     WaveStack stack = make_wave_stack<SPILL>(lds, spill);
     const uint32_t shard = blockIdx.x & (HAR_SHARDS - 1), n = count[shard * HAR_COUNTER_STRIDE], base = shard * shard_cap;
     if (n == 0) return;
-    trace_persistent<false, false, WaveStack>(A, cursor + shard * HAR_COUNTER_STRIDE, n, stack, status,
-        [&](uint32_t idx, Traversal<HAR_TRAV_POLICY> &T) {
-            float4 o = a0[base + idx], d = a1[base + idx];
-            T.begin(A, Vec3(o.x, o.y, o.z), Vec3(d.x, d.y, d.z), o.w < 0.f ? HAR_LARGEST : o.w);
-            return true;
-        },
-        [&](uint32_t idx, const Traversal<HAR_TRAV_POLICY> &T) {
-            h0[base + idx] = make_float4(T.hit.t, T.hit.u, T.hit.v, __uint_as_float(T.hit.prim));
-            h1[base + idx] = make_uint2(T.hit.shape, T.hit.inst);
-        },
+    auto take = [&](uint32_t idx, Traversal<HAR_TRAV_POLICY> &T) {
+        float4 o = a0[base + idx], d = a1[base + idx];
+        T.begin(A, Vec3(o.x, o.y, o.z), Vec3(d.x, d.y, d.z), o.w < 0.f ? HAR_LARGEST : o.w);
+        return true;
+    };
+    auto store = [&](uint32_t idx, const Traversal<HAR_TRAV_POLICY> &T) {
+        h0[HIT0(base + idx)] = make_float4(T.hit.t, T.hit.u, T.hit.v, __uint_as_float(T.hit.prim));
+        h1[HIT1(base + idx)] = make_uint2(T.hit.shape, T.hit.inst);
+    };
+#if HAR_CLOSEST_RETIRE
+    /* hits are committed at refill time by all lanes that finished since the last refill (one store instruction for >= HAR_REFILL_IDLE lanes)
+     * instead of by each lane in the iteration it finishes in (a store instruction + address arithmetic issued for one or two lanes) */
+    trace_persistent<false, true, WaveStack>(A, cursor + shard * HAR_COUNTER_STRIDE, n, stack, status, take,
+        [&](uint32_t, const Traversal<HAR_TRAV_POLICY> &) { },
+        [&](bool pred, uint32_t idx, const Traversal<HAR_TRAV_POLICY> &T) { if (pred) store(idx, T); });
+#else
+    trace_persistent<false, false, WaveStack>(A, cursor + shard * HAR_COUNTER_STRIDE, n, stack, status, take, store,
         [&](bool, uint32_t, const Traversal<HAR_TRAV_POLICY> &) { });
+#endif
 }
 
 /* adjoint of one NEE / vertex item (wave-uniform call: every lane takes part in the texel pre-reduction):
  * L <- L - Lr_dir; g = dL * (dLr_dir/dslot0 + L * (df/dslot0)/f)  (prb.py:227,288-313).
  * s2 = Lr_dir (or Lr_dir for a unit radiance) + tag, s3 = d Lr_dir / d slot0 + uv.x, s4 = (d f / d slot0) / f + uv.y -- the item layout of k_shade */
+template <bool FWD = false>
 __device__ __forceinline__ void adjoint_commit_values(const DScene &S, bool pred, bool visible, uint32_t lane, float4 s2, float4 s3, float4 s4, float4 *result, const float4 *dL,
-                                                      float *grad_refl, float *const *grad_tex, float *gacc, bool fwd = false) {
-    if (fwd) {
+                                                      float *grad_refl, float *const *grad_tex, float *gacc) {
+    if (FWD) {
         /* FORWARD mode (RBIntegrator.render_forward, common.py:497-623; prb.py:313 `dL += dr.forward_to(Lo)`): `grad_refl` / `grad_tex` hold the
          * TANGENTS of the parameters (same layout as the gradient buffers: slots of the BSDFs, then of the emitters; one array per bitmap) and are
          * only read; the lane's differential radiance accumulates in dL[lane] (one item per lane and bounce: no race), which raygen zeroed */
@@ -424,12 +434,13 @@ __device__ __forceinline__ void adjoint_commit_values(const DScene &S, bool pred
             wave_aggregated_add3(nz && tex ? tdst + 3 * (size_t) taps.idx[k] : grad_refl, nz && tex ? g * w[k] : Vec3(0.f), nz && tex);
     }
 }
+template <bool FWD = false>
 __device__ __forceinline__ void adjoint_commit(const DScene &S, const ItemArrays &items, uint32_t i, bool pred, bool visible, float4 *result, const float4 *dL,
-                                               float *grad_refl, float *const *grad_tex, float *gacc, uint8_t *item_vis, bool fwd = false) {
+                                               float *grad_refl, float *const *grad_tex, float *gacc, uint8_t *item_vis) {
     if (pred && item_vis) item_vis[i] = visible ? 1 : 0;
     float4 s2 = make_float4(0.f, 0.f, 0.f, 0.f), s3 = s2, s4 = s2; uint32_t lane = 0;
     if (pred) { lane = __float_as_uint(items.s1[i].w); s2 = items.s2[i]; s3 = items.s3[i]; s4 = items.s4[i]; }
-    adjoint_commit_values(S, pred, visible, lane, s2, s3, s4, result, dL, grad_refl, grad_tex, gacc, fwd);
+    adjoint_commit_values<FWD>(S, pred, visible, lane, s2, s3, s4, result, dL, grad_refl, grad_tex, gacc);
 }
 
 /* ------------------------------------------------------------------- shade */
@@ -465,7 +476,7 @@ __global__ __launch_bounds__(kBlock, HAR_SHADE_MIN_WAVES) void k_shade(DScene S,
                 if (MODE == MODE_PRB_ADJOINT && rc.mode == 2) {
                     const uint32_t cl = __float_as_uint(in.a3[Q.base + local].w) - lane_base;
                     hs = rc.h1[cl]; t = rc.h0[cl].x;
-                } else { hs = h1[Q.base + local]; t = h0[Q.base + local].x; }
+                } else { hs = h1[HIT1(Q.base + local)]; t = h0[HIT0(Q.base + local)].x; }
                 key = t == HAR_INF ? (uint32_t) BSDF_TYPE_COUNT : min(S.bsdfs[S.meshes[hs.x].bsdf].type, (uint32_t) BSDF_TYPE_COUNT - 1u);
             }
             if (threadIdx.x < kSortKeys) sort_cnt[threadIdx.x] = 0;
@@ -488,7 +499,7 @@ __global__ __launch_bounds__(kBlock, HAR_SHADE_MIN_WAVES) void k_shade(DScene S,
             PathState st = load_state(in, i);
             d_in = st.d;
             if (MODE == MODE_PRB_ADJOINT && rc.mode == 2) { hh = rc.h0[st.lane - lane_base]; hs = rc.h1[st.lane - lane_base]; }      /* replay cache */
-            else { hh = h0[i]; hs = h1[i]; }
+            else { hh = h0[HIT0(i)]; hs = h1[HIT1(i)]; }
             if (MODE == MODE_PRB_PRIMAL && rc.mode == 1) { rc.h0[st.lane - lane_base] = hh; rc.h1[st.lane - lane_base] = hs; }
             Hit hit; hit.t = hh.x; hit.u = hh.y; hit.v = hh.z; hit.prim = __float_as_uint(hh.w); hit.shape = hs.x; hit.inst = hs.y;
             shade_lane<MODE, TYPES>(S, P, st, hit, R);
@@ -526,7 +537,7 @@ __global__ __launch_bounds__(kBlock, HAR_SHADE_MIN_WAVES) void k_shade(DScene S,
             const uint32_t tag = (R.bsdf & 0xfffffu) | ((fact ? (uint32_t) R.nee_emitter : HAR_ITEM_NO_EMITTER) << 20) | (R.ind_active ? 0x80000000u : 0u);
             const bool visible = item_pred && R.item_ray && rc.vis[lane] != 0;
             adjoint_commit_values(S, item_pred, visible, lane, make_float4(c.x, c.y, c.z, __uint_as_float(tag)), make_float4(R.dLr_drho.x, R.dLr_drho.y, R.dLr_drho.z, R.uv_x),
-                                  make_float4(R.rel_grad.x, R.rel_grad.y, R.rel_grad.z, R.uv_y), result, dL, grad_slots, grad_tex, gacc, fwd);
+                                  make_float4(R.rel_grad.x, R.rel_grad.y, R.rel_grad.z, R.uv_y), result, dL, grad_slots, grad_tex, gacc);      /* forward mode never commits in place (host) */
             item_pred = false;
         }
         const bool alive = in_range && R.alive, item = item_pred;
@@ -563,7 +574,7 @@ __global__ __launch_bounds__(kBlock, HAR_SHADE_MIN_WAVES) void k_shade(DScene S,
             if (v != 0.f) atomicAdd(grad_slots + 3 * (size_t) S.n_bsdfs + k, v);
         }
     }
-    if (INLINE && !fwd) {
+    if (INLINE) {
         __syncthreads();
         for (uint32_t k = threadIdx.x; k < 3 * min(S.n_bsdfs + S.n_emitters, (uint32_t) HAR_LDS_GRAD_BSDFS); k += kBlock) {
             const float v = gacc[k];
@@ -573,8 +584,9 @@ __global__ __launch_bounds__(kBlock, HAR_SHADE_MIN_WAVES) void k_shade(DScene S,
 }
 
 /* adjoint resolve of a bounce whose shadow-ray results sit in the replay cache: no traversal, one item per thread */
+template <bool FWD>
 __global__ __launch_bounds__(kBlock) void k_resolve_adjoint_cached(DScene S, const uint32_t *item_count, uint32_t shard_cap, ItemArrays items, float4 *result,
-                                                                   const float4 *dL, float *grad_refl, float *const *grad_tex, ReplayCache rc, uint8_t *item_vis, int fwd) {
+                                                                   const float4 *dL, float *grad_refl, float *const *grad_tex, ReplayCache rc, uint8_t *item_vis) {
     __shared__ float gacc[3 * HAR_LDS_GRAD_BSDFS];
     for (uint32_t k = threadIdx.x; k < 3 * HAR_LDS_GRAD_BSDFS; k += kBlock) gacc[k] = 0.f;
     __syncthreads();
@@ -585,10 +597,10 @@ __global__ __launch_bounds__(kBlock) void k_resolve_adjoint_cached(DScene S, con
         const uint32_t i = Q.base + (pred ? local : 0u);
         bool visible = false;
         if (pred && items.s0[i].w >= 0.f) visible = rc.vis[__float_as_uint(items.s1[i].w)] != 0;
-        adjoint_commit(S, items, i, pred, visible, result, dL, grad_refl, grad_tex, gacc, item_vis, fwd != 0);
+        adjoint_commit<FWD>(S, items, i, pred, visible, result, dL, grad_refl, grad_tex, gacc, item_vis);
     }
     __syncthreads();
-    if (fwd) return;
+    if (FWD) return;
     for (uint32_t k = threadIdx.x; k < 3 * min(S.n_bsdfs + S.n_emitters, (uint32_t) HAR_LDS_GRAD_BSDFS); k += kBlock) {
         const float v = gacc[k];
         if (v != 0.f) atomicAdd(grad_refl + k, v);
@@ -596,9 +608,9 @@ __global__ __launch_bounds__(kBlock) void k_resolve_adjoint_cached(DScene S, con
 }
 
 /* ------------------------------------------------- resolve (shadow rays + NEE) */
-template <int MODE, bool SPILL>
+template <int MODE, bool SPILL, bool FWD = false>
 __global__ __launch_bounds__(kBlock) void k_resolve(DScene S, const uint32_t *item_count, uint32_t *cursor, uint32_t shard_cap, ItemArrays items, float4 *result,
-                                                    const float4 *dL, float *grad_refl, float *const *grad_tex, int *status, ReplayCache rc, uint2 *spill, uint8_t *item_vis, int fwd) {
+                                                    const float4 *dL, float *grad_refl, float *const *grad_tex, int *status, ReplayCache rc, uint2 *spill, uint8_t *item_vis) {
     __shared__ uint2 lds[HAR_LDS_STACK_SMALL * kBlock];
     /* adjoint: per-block accumulators of the constant-albedo gradients.  Every path of the chip adds to the same
      * few floats of grad_refl (one 64 B line): direct global atomics serialise at ~88 atomics/us per line, which
@@ -638,10 +650,10 @@ __global__ __launch_bounds__(kBlock) void k_resolve(DScene S, const uint32_t *it
         trace_persistent<true, true, WaveStack>(S.accel, cursor + shard * HAR_COUNTER_STRIDE, n, stack, status, take,
             [&](uint32_t, const Traversal<HAR_TRAV_POLICY> &) { },
             [&](bool pred, uint32_t idx, const Traversal<HAR_TRAV_POLICY> &T) {
-                adjoint_commit(S, items, base + (pred ? idx : 0u), pred, pred && !T.found, result, dL, grad_refl, grad_tex, gacc, item_vis, fwd != 0);
+                adjoint_commit<FWD>(S, items, base + (pred ? idx : 0u), pred, pred && !T.found, result, dL, grad_refl, grad_tex, gacc, item_vis);
             });
         __syncthreads();
-        if (fwd) return;
+        if (FWD) return;
         for (uint32_t k = threadIdx.x; k < 3 * min(S.n_bsdfs + S.n_emitters, (uint32_t) HAR_LDS_GRAD_BSDFS); k += kBlock) {
             const float v = gacc[k];
             if (v != 0.f) atomicAdd(grad_refl + k, v);
@@ -659,7 +671,7 @@ __global__ __launch_bounds__(kBlock) void k_alpha_flags(uint32_t shard_cap, cons
         const uint32_t local = tile * kBlock + threadIdx.x;
         if (local >= Q.n) continue;
         const uint32_t i = Q.base + local;
-        alpha[__float_as_uint(state_a3[i].w) - lane_base] = h0[i].x != HAR_INF ? 1.f : miss_value;
+        alpha[__float_as_uint(state_a3[i].w) - lane_base] = h0[HIT0(i)].x != HAR_INF ? 1.f : miss_value;
     }
 }
 
@@ -681,9 +693,9 @@ __global__ __launch_bounds__(kBlock) void k_skip_emitters(DScene S, int first, u
         bool again = false; float4 no = make_float4(0.f, 0.f, 0.f, 0.f), nd = no;
         if (in_range) {
             const float4 d = ray_d[i];
-            const float4 hh = first ? h0[i] : hit0[i]; const uint2 hs = first ? h1[i] : hit1[i];
+            const float4 hh = first ? h0[HIT0(i)] : hit0[HIT0(i)]; const uint2 hs = first ? h1[HIT1(i)] : hit1[HIT1(i)];
             const uint32_t slot = first ? i : __float_as_uint(d.w);
-            if (!first) { h0[slot] = hh; h1[slot] = hs; }
+            if (!first) { h0[HIT0(slot)] = hh; h1[HIT1(slot)] = hs; }
             if (hh.x != HAR_INF && S.meshes[hs.x].emitter >= 0) {
                 const Vec3 dir(d.x, d.y, d.z);
                 const SurfInt si = compute_si(S, dir, hh.x, hh.y, hh.z, __float_as_uint(hh.w), hs.x, hs.y);
@@ -733,7 +745,7 @@ __global__ __launch_bounds__(kBlock) void k_shape_adjoint(DScene S, const uint32
             const float4 a1 = next.a1[it.next_slot];
             nd = Vec3(a1.x, a1.y, a1.z);
             float4 hh; uint2 hs;
-            if (rc.mode == 2) { hh = rc.h0[lane]; hs = rc.h1[lane]; } else { hh = h0[it.next_slot]; hs = h1[it.next_slot]; }
+            if (rc.mode == 2) { hh = rc.h0[lane]; hs = rc.h1[lane]; } else { hh = h0[HIT0(it.next_slot)]; hs = h1[HIT1(it.next_slot)]; }
             next_valid = hh.x != HAR_INF;
             if (next_valid) { const SurfInt sn = compute_si(S, nd, hh.x, hh.y, hh.z, __float_as_uint(hh.w), hs.x, hs.y); np = sn.p; nn = sn.n; }
         }
@@ -1073,13 +1085,17 @@ void launch_resolve(int mode, hipStream_t s, uint32_t grid, uint2 *spill, const 
                     float4 *result, const float4 *dL, float *grad_refl, float *const *grad_tex, int *status, const ReplayCache &rc, uint8_t *item_vis, int fwd) {
     dim3 g(grid), b(kBlock);
     if (mode == MODE_PRB_ADJOINT && rc.mode == 2) {
-        hipLaunchKernelGGL(k_resolve_adjoint_cached, g, b, 0, s, S, item_count, shard_cap, items, result, dL, grad_refl, grad_tex, rc, item_vis, fwd);
+        if (fwd) hipLaunchKernelGGL(k_resolve_adjoint_cached<true>, g, b, 0, s, S, item_count, shard_cap, items, result, dL, grad_refl, grad_tex, rc, item_vis);
+        else hipLaunchKernelGGL(k_resolve_adjoint_cached<false>, g, b, 0, s, S, item_count, shard_cap, items, result, dL, grad_refl, grad_tex, rc, item_vis);
         return;
     }
-#define HAR_LAUNCH_RESOLVE(M, SP) hipLaunchKernelGGL((k_resolve<M, SP>), g, b, 0, s, S, item_count, cursor, shard_cap, items, result, dL, grad_refl, grad_tex, status, rc, spill, item_vis, fwd)
-    if (mode == MODE_PRB_ADJOINT) { if (spill) HAR_LAUNCH_RESOLVE(MODE_PRB_ADJOINT, true); else HAR_LAUNCH_RESOLVE(MODE_PRB_ADJOINT, false); }
+#define HAR_LAUNCH_RESOLVE(M, SP) hipLaunchKernelGGL((k_resolve<M, SP>), g, b, 0, s, S, item_count, cursor, shard_cap, items, result, dL, grad_refl, grad_tex, status, rc, spill, item_vis)
+#define HAR_LAUNCH_RESOLVE_FWD(SP) hipLaunchKernelGGL((k_resolve<MODE_PRB_ADJOINT, SP, true>), g, b, 0, s, S, item_count, cursor, shard_cap, items, result, dL, grad_refl, grad_tex, status, rc, spill, item_vis)
+    if (mode == MODE_PRB_ADJOINT && fwd) { if (spill) HAR_LAUNCH_RESOLVE_FWD(true); else HAR_LAUNCH_RESOLVE_FWD(false); }
+    else if (mode == MODE_PRB_ADJOINT) { if (spill) HAR_LAUNCH_RESOLVE(MODE_PRB_ADJOINT, true); else HAR_LAUNCH_RESOLVE(MODE_PRB_ADJOINT, false); }
     else { if (spill) HAR_LAUNCH_RESOLVE(MODE_PATH, true); else HAR_LAUNCH_RESOLVE(MODE_PATH, false); }
 #undef HAR_LAUNCH_RESOLVE
+#undef HAR_LAUNCH_RESOLVE_FWD
 }
 void launch_alpha_flags(hipStream_t s, uint32_t grid, uint32_t shard_cap, const uint32_t *count_in, const WaveState &in, const float4 *h0, uint32_t lane_base, float miss_value, float *alpha) {
     hipLaunchKernelGGL(k_alpha_flags, dim3(grid), dim3(kBlock), 0, s, shard_cap, count_in, in.a3, h0, lane_base, miss_value, alpha);

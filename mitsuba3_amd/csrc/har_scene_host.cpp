@@ -329,12 +329,8 @@ bool lower_scene(const HarSceneDesc &d, HostScene &hs, std::string &err) {
     std::vector<BlasInfo> groups;
     for (uint32_t g = 0; g < d.group_count; ++g) groups.push_back(build_blas(hs, d, d.groups[g].first_mesh, d.groups[g].mesh_count));
     std::vector<PrimBox> boxes; std::vector<InstRec> recs; std::vector<uint32_t> ranges;
-    auto identity = [](float *m) { std::memset(m, 0, 48); m[0] = m[4] = m[8] = 1.f; };
-    if (!top.empty) {
-        InstRec r{}; identity(r.to_world); identity(r.to_object); r.blas_root = top.root; r.inst_index = 0xffffffffu; r.identity = 1;
-        PrimBox b; std::memcpy(b.lo, top.lo, 12); std::memcpy(b.hi, top.hi, 12);
-        boxes.push_back(b); recs.push_back(r); ranges.push_back(top.first_tri); ranges.push_back(top.tri_count);
-    }
+    /* the top-level geometry is not a TLAS entry: rays walk its BLAS first and then the TLAS (Accel::top_root, har_accel.h) */
+    if (!top.empty) { hs.top_root = top.root; hs.top_first = top.first_tri; hs.top_count = top.tri_count; }
     for (uint32_t i = 0; i < d.instance_count; ++i) {
         const BlasInfo &g = groups[d.instances[i].group];
         if (g.empty) continue;
