@@ -10,6 +10,8 @@
 #include <cstdio>
 #include <cstring>
 #include <string>
+#include <new>
+#include <stdexcept>
 #include <vector>
 #include <cstdlib>
 #include <cmath>
@@ -94,7 +96,15 @@ static float half_to_float(uint16_t h) {
     float f; memcpy(&f, &bits, 4); return f;
 }
 
+static int image_read_impl(const char *filename, HarImage *out);
+/* the file's contents are untrusted: every size taken from it is checked against the bytes that are there (and against 2^31 pixels), allocations
+ * are checked, and no C++ exception crosses the C boundary */
 int har_image_read(const char *filename, HarImage *out) {
+    try { return image_read_impl(filename, out); }
+    catch (const std::bad_alloc &) { if (out) { free(out->data); out->data = nullptr; } return har_set_error(std::string("Error while loading \"") + (filename ? filename : "") + "\": out of memory"); }
+    catch (const std::exception &e) { if (out) { free(out->data); out->data = nullptr; } return har_set_error(std::string("Error while loading \"") + (filename ? filename : "") + "\": " + e.what()); }
+}
+static int image_read_impl(const char *filename, HarImage *out) {
     if (!filename || !out) return har_set_error("null argument");
     out->data = nullptr; out->width = out->height = out->channels = 0;
     FILE *f = fopen(filename, "rb");
@@ -110,9 +120,12 @@ int har_image_read(const char *filename, HarImage *out) {
         }
         ++pos;                                                                               /* the single whitespace after the scale */
         const uint32_t c = tok[0] == "PF" ? 3u : 1u; const long w = atol(tok[1].c_str()), h = atol(tok[2].c_str()); const double scale = atof(tok[3].c_str());
-        if (nt < 4 || w <= 0 || h <= 0 || scale == 0.0) return fail("invalid PFM header");
-        if (pos + (size_t) w * h * c * 4 > d.size()) return fail("unexpected end of file");
-        out->data = (float *) malloc((size_t) w * h * c * 4); out->width = (uint32_t) w; out->height = (uint32_t) h; out->channels = c;
+        if (nt < 4 || w <= 0 || h <= 0 || scale == 0.0 || !(scale == scale)) return fail("invalid PFM header");
+        if (w > 0x7fffffffl || h > 0x7fffffffl || (uint64_t) w * (uint64_t) h > 0x7fffffffull) return fail("image too large");
+        if (pos > d.size() || (uint64_t) w * h * c * 4 > d.size() - pos) return fail("unexpected end of file");
+        out->data = (float *) malloc((size_t) w * h * c * 4);
+        if (!out->data) return fail("out of memory");
+        out->width = (uint32_t) w; out->height = (uint32_t) h; out->channels = c;
         const bool big = scale > 0.0;
         for (long y = 0; y < h; ++y)
             for (size_t i = 0; i < (size_t) w * c; ++i) {
@@ -125,7 +138,7 @@ int har_image_read(const char *filename, HarImage *out) {
     /* ---- OpenEXR */
     size_t pos = 0;
     auto need = [&](size_t n) { return pos + n <= d.size(); };
-    auto rd32 = [&]() { int32_t v = 0; if (need(4)) { memcpy(&v, d.data() + pos, 4); } pos += 4; return v; };
+    auto rd32 = [&]() { int32_t v = 0; if (need(4)) { memcpy(&v, d.data() + pos, 4); pos += 4; } else pos = d.size(); return v; };
     auto rdstr = [&]() { std::string r; while (pos < d.size() && d[pos]) r += (char) d[pos++]; ++pos; return r; };
     if (d.size() < 8 || rd32() != 20000630) return fail("unknown file format (OpenEXR and PFM are implemented)");
     const int32_t version = rd32();
@@ -137,20 +150,25 @@ int har_image_read(const char *filename, HarImage *out) {
         if (size < 0 || !need((size_t) size)) return fail("corrupt header");
         if (name == "channels") {
             while (pos < start + (size_t) size && d[pos]) {
-                Chan c; c.name = rdstr(); c.type = rd32(); pos += 4; int32_t xs = rd32(), ys = rd32();
+                Chan c; c.name = rdstr(); c.type = rd32(); if (!need(12)) return fail("corrupt channel list"); pos += 4; int32_t xs = rd32(), ys = rd32();
                 if (xs != 1 || ys != 1) return fail("subsampled channels are not supported");
+                if (c.type < 0 || c.type > 2) return fail("unknown channel type");
+                if (pos > start + (size_t) size) return fail("corrupt channel list");
                 chans.push_back(c);
+                if (chans.size() > 1024) return fail("too many channels");
             }
-        } else if (name == "compression") comp = d[pos];
-        else if (name == "dataWindow") memcpy(win, d.data() + pos, 16);
-        else if (name == "lineOrder") line_order = d[pos];
+        } else if (name == "compression") { if (size < 1) return fail("corrupt header"); comp = d[pos]; }
+        else if (name == "dataWindow") { if (size != 16) return fail("corrupt dataWindow attribute"); memcpy(win, d.data() + pos, 16); }
+        else if (name == "lineOrder") { if (size < 1) return fail("corrupt header"); line_order = d[pos]; }
         pos = start + (size_t) size;
     }
     ++pos;
     if (chans.empty() || comp < 0 || win[2] < win[0] || win[3] < win[1]) return fail("incomplete header");
     if (comp != 0 && comp != 2 && comp != 3) return fail("unsupported compression (NO_COMPRESSION, ZIPS and ZIP are implemented)");
     (void) line_order;                                          /* chunks carry their y coordinate */
-    const uint32_t W = (uint32_t) (win[2] - win[0] + 1), H = (uint32_t) (win[3] - win[1] + 1);
+    const int64_t W64 = (int64_t) win[2] - (int64_t) win[0] + 1, H64 = (int64_t) win[3] - (int64_t) win[1] + 1;       /* no int32 overflow in the subtraction */
+    if (W64 <= 0 || H64 <= 0 || W64 > 0x7fffffffll || H64 > 0x7fffffffll || W64 * H64 > 0x7fffffffll) return fail("invalid data window");
+    const uint32_t W = (uint32_t) W64, H = (uint32_t) H64;
     /* map file channels to output channels */
     int map_[4] = { -1, -1, -1, -1 }; bool lum = false;
     for (size_t k = 0; k < chans.size(); ++k) {
@@ -165,13 +183,18 @@ int har_image_read(const char *filename, HarImage *out) {
     for (size_t k = 0; k < chans.size(); ++k) { ch_off[k] = line_bytes; line_bytes += (size_t) W * (chans[k].type == 1 ? 2 : 4); }
     const uint32_t lines_per_chunk = comp == 3 ? 16u : 1u, n_chunks = (H + lines_per_chunk - 1) / lines_per_chunk;
     if (!need(8ull * n_chunks)) return fail("unexpected end of file");
-    out->data = (float *) malloc((size_t) W * H * C * 4); out->width = W; out->height = H; out->channels = C;
+    /* the pixel data cannot be smaller than ~1/1000 of the decoded size (zlib's best ratio): refuse windows the file cannot possibly fill */
+    if ((uint64_t) W * H * C * 4 / 1100 > d.size() + 1024) return fail("data window larger than the file can hold");
+    out->data = (float *) malloc((size_t) W * H * C * 4);
+    if (!out->data) return fail("out of memory");
+    memset(out->data, 0, (size_t) W * H * C * 4);
+    out->width = W; out->height = H; out->channels = C;
     std::vector<uint8_t> raw, tmp;
     for (uint32_t c = 0; c < n_chunks; ++c) {
         uint64_t off; memcpy(&off, d.data() + pos + 8ull * c, 8);
-        if (off + 8 > d.size()) return fail("corrupt chunk table");
+        if (off > d.size() || d.size() - off < 8) return fail("corrupt chunk table");
         int32_t y0, sz; memcpy(&y0, d.data() + off, 4); memcpy(&sz, d.data() + off + 4, 4);
-        if (sz < 0 || off + 8 + (uint64_t) sz > d.size() || y0 < win[1] || y0 > win[3]) return fail("corrupt chunk");
+        if (sz < 0 || (uint64_t) sz > d.size() - off - 8 || y0 < win[1] || y0 > win[3]) return fail("corrupt chunk");
         const uint32_t nl = std::min<uint32_t>(lines_per_chunk, (uint32_t) (win[3] - y0 + 1));
         const size_t expect = line_bytes * nl;
         const uint8_t *src = d.data() + off + 8;

@@ -347,7 +347,11 @@ __global__ __launch_bounds__(kBlock) void k_trace_closest(Accel A, const uint32_
     };
     auto store = [&](uint32_t idx, const Traversal<HAR_TRAV_POLICY> &T) {
         h0[HIT0(base + idx)] = make_float4(T.hit.t, T.hit.u, T.hit.v, __uint_as_float(T.hit.prim));
+#if HAR_HIT_INTERLEAVED      /* the second half as ONE 16-byte store: the ray's 32-byte sector is written completely (no byte-masked partial write) */
+        *reinterpret_cast<uint4 *>(h1 + HIT1(base + idx)) = make_uint4(T.hit.shape, T.hit.inst, 0u, 0u);
+#else
         h1[HIT1(base + idx)] = make_uint2(T.hit.shape, T.hit.inst);
+#endif
     };
 #if HAR_CLOSEST_RETIRE
     /* hits are committed at refill time by all lanes that finished since the last refill (one store instruction for >= HAR_REFILL_IDLE lanes)

@@ -21,6 +21,8 @@
 #include <cstring>
 #include <fstream>
 #include <string>
+#include <new>
+#include <stdexcept>
 #include <vector>
 
 using namespace har;
@@ -35,6 +37,7 @@ bool read_file(const char *filename, std::string &data) {
     std::ifstream f(filename, std::ios::binary);
     if (!f) return false;
     f.seekg(0, std::ios::end); std::streamoff n = f.tellg(); f.seekg(0);
+    if (n < 0) return false;
     data.resize((size_t) n);
     if (n) f.read(&data[0], n);
     return (bool) f;
@@ -62,7 +65,21 @@ void fetch_key(const std::vector<float> &pool, uint32_t index, int dim, uint32_t
 
 extern "C" {
 
+static int mesh_load_obj_impl(const char *filename, int face_normals, int flip_tex_coords, const float *to_world, int flip_normals, HarMeshData *out);
+static int mesh_load_serialized_impl(const char *filename, int shape_index, int face_normals, const float *to_world, int flip_normals, HarMeshData *out);
+static void mesh_reset(HarMeshData *out) { if (out) { free(out->vertices); free(out->faces); out->vertices = nullptr; out->faces = nullptr; out->vertex_count = out->face_count = out->flags = out->reserved = 0; } }
+/* no C++ exception (std::bad_alloc of a file-controlled size, ...) crosses the C boundary */
 int har_mesh_load_obj(const char *filename, int face_normals, int flip_tex_coords, const float *to_world, int flip_normals, HarMeshData *out) {
+    try { return mesh_load_obj_impl(filename, face_normals, flip_tex_coords, to_world, flip_normals, out); }
+    catch (const std::bad_alloc &) { mesh_reset(out); return har_set_error(std::string("Error while loading OBJ file \"") + (filename ? filename : "") + "\": out of memory"); }
+    catch (const std::exception &e) { mesh_reset(out); return har_set_error(std::string("Error while loading OBJ file \"") + (filename ? filename : "") + "\": " + e.what()); }
+}
+int har_mesh_load_serialized(const char *filename, int shape_index, int face_normals, const float *to_world, int flip_normals, HarMeshData *out) {
+    try { return mesh_load_serialized_impl(filename, shape_index, face_normals, to_world, flip_normals, out); }
+    catch (const std::bad_alloc &) { mesh_reset(out); return har_set_error(std::string("Error while loading serialized file \"") + (filename ? filename : "") + "\": out of memory!"); }
+    catch (const std::exception &e) { mesh_reset(out); return har_set_error(std::string("Error while loading serialized file \"") + (filename ? filename : "") + "\": " + e.what() + "!"); }
+}
+static int mesh_load_obj_impl(const char *filename, int face_normals, int flip_tex_coords, const float *to_world, int flip_normals, HarMeshData *out) {
     if (!filename || !out) return har_set_error("null argument");
     out->vertices = nullptr; out->faces = nullptr; out->vertex_count = out->face_count = out->flags = out->reserved = 0;
     auto fail = [&](const std::string &d) { return har_set_error("Error while loading OBJ file \"" + std::string(filename) + "\": " + d); };
@@ -191,14 +208,14 @@ int har_mesh_load_obj(const char *filename, int face_normals, int flip_tex_coord
     return emit(V, F, ((has_normals || regenerate) ? 1u : 0u) | (has_uv ? 2u : 0u), out);
 }
 
-int har_mesh_load_serialized(const char *filename, int shape_index, int face_normals, const float *to_world, int flip_normals, HarMeshData *out) {
+static int mesh_load_serialized_impl(const char *filename, int shape_index, int face_normals, const float *to_world, int flip_normals, HarMeshData *out) {
     if (!filename || !out) return har_set_error("null argument");
     out->vertices = nullptr; out->faces = nullptr; out->vertex_count = out->face_count = out->flags = out->reserved = 0;
     auto fail = [&](const std::string &d) { return har_set_error("Error while loading serialized file \"" + std::string(filename) + "\": " + d + "!"); };
     if (shape_index < 0) return fail("shape index must be nonnegative");
     std::string data;
     if (!read_file(filename, data)) return fail("file not found / unreadable");
-    auto rd = [&](size_t off, void *dst, size_t n) { if (off + n > data.size()) return false; memcpy(dst, data.data() + off, n); return true; };
+    auto rd = [&](size_t off, void *dst, size_t n) { if (off > data.size() || n > data.size() - off) return false; memcpy(dst, data.data() + off, n); return true; };
     uint16_t format = 0, version = 0;
     if (!rd(0, &format, 2) || !rd(2, &version, 2)) return fail("unexpected end of file");
     if (format != 0x041C) return fail("encountered an invalid file format");
@@ -226,6 +243,7 @@ int har_mesh_load_serialized(const char *filename, int shape_index, int face_nor
             rc = inflate(&zs, Z_NO_FLUSH);
             if (rc != Z_OK && rc != Z_STREAM_END) { inflateEnd(&zs); return fail("inflate(): stream error"); }
             raw.insert(raw.end(), chunk, chunk + (sizeof(chunk) - zs.avail_out));
+            if (raw.size() > ((size_t) 1 << 36)) { inflateEnd(&zs); return fail("inflate(): stream larger than 64 GiB"); }
             if (rc == Z_OK && zs.avail_in == 0 && zs.avail_out != 0) { inflateEnd(&zs); return fail("inflate(): unexpected end of file"); }
         }
         inflateEnd(&zs);
@@ -238,6 +256,8 @@ int har_mesh_load_serialized(const char *filename, int shape_index, int face_nor
     uint64_t vertex_count = 0, face_count = 0;
     if (!take(&vertex_count, 8) || !take(&face_count, 8)) return fail("unexpected end of stream");
     if (vertex_count > 0xffffffffull || face_count > 0xffffffffull) return fail("mesh too large");
+    /* the counts are bounded by what the inflated stream holds (positions: >= 12 bytes per vertex, indices: >= 12 bytes per face) before anything is allocated */
+    if (vertex_count > (raw.size() - pos) / 12 || face_count > (raw.size() - pos) / 12) return fail("unexpected end of stream");
     const bool dp = flags & 0x2000u, has_normals = flags & 0x0001u, has_texcoords = flags & 0x0002u, has_colors = flags & 0x0008u;
     const bool store_normals = has_normals && !face_normals;
     auto read_array = [&](float *dst, size_t dim, size_t stride) {           /* read_helper: doubles are narrowed, null dst = skip */

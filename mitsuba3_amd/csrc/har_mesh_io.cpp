@@ -18,6 +18,8 @@
 #include <fstream>
 #include <sstream>
 #include <string>
+#include <new>
+#include <stdexcept>
 #include <vector>
 
 using namespace har;
@@ -164,7 +166,15 @@ int har_mesh_finalize(std::vector<float> &V, std::vector<uint32_t> &F, bool stor
 
 extern "C" {
 
+static int mesh_load_ply_impl(const char *filename, int face_normals, int flip_tex_coords, const float *to_world, int flip_normals, HarMeshData *out);
+/* file contents are untrusted: element counts are bounded by the bytes that are left in the file and by the 2^32 - 1 indices of the packed layout,
+ * and no C++ exception (std::bad_alloc of a header-controlled vector size, ...) crosses the C boundary */
 int har_mesh_load_ply(const char *filename, int face_normals, int flip_tex_coords, const float *to_world, int flip_normals, HarMeshData *out) {
+    try { return mesh_load_ply_impl(filename, face_normals, flip_tex_coords, to_world, flip_normals, out); }
+    catch (const std::bad_alloc &) { if (out) har_mesh_free(out); return har_set_error(std::string("Error while loading PLY file \"") + (filename ? filename : "") + "\": out of memory!"); }
+    catch (const std::exception &e) { if (out) har_mesh_free(out); return har_set_error(std::string("Error while loading PLY file \"") + (filename ? filename : "") + "\": " + e.what() + "!"); }
+}
+static int mesh_load_ply_impl(const char *filename, int face_normals, int flip_tex_coords, const float *to_world, int flip_normals, HarMeshData *out) {
     if (!filename || !out) return har_set_error("null argument");
     memset(out, 0, sizeof(*out));
     auto fail = [&](const std::string &d) { har_mesh_free(out); return har_set_error("Error while loading PLY file \"" + std::string(filename) + "\": " + d + "!"); };
@@ -206,6 +216,9 @@ int har_mesh_load_ply(const char *filename, int face_normals, int flip_tex_coord
     bool has_normals = false, has_uv = false;
     std::vector<float> V; std::vector<uint32_t> F; size_t nv = 0, nf = 0;
     for (const Element &el : elements) {
+        /* every element occupies at least one byte (binary) / two characters (ascii) per property value */
+        const size_t bytes_left = ascii ? data.size() - pos : (size_t) (R.end - R.p);
+        if (el.count > 0xffffffffull || (!el.props.empty() && el.count > bytes_left)) return fail("element count exceeds the file size");
         if (el.name == "vertex") {
             int ix[8] = { -1, -1, -1, -1, -1, -1, -1, -1 };       /* x y z nx ny nz u v */
             for (size_t k = 0; k < el.props.size(); ++k) {

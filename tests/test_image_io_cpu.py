@@ -92,3 +92,44 @@ def test_bitmap_texture_sources(mi, tmp_path):
         mi.load_dict({"type": "diffuse", "reflectance": {"type": "bitmap", "data": tex, "bitmap": mi.Bitmap(tex)}})
     with pytest.raises(RuntimeError, match="not found"):
         mi.load_dict({"type": "diffuse", "reflectance": {"type": "bitmap", "filename": os.path.join(tmp_path, "missing.exr")}})
+
+
+def test_corrupt_files_are_errors_not_crashes(tmp_path):
+    """the loaders must not trust file contents -- truncated / oversized headers give an error message, never a crash or a huge allocation"""
+    import ctypes as C, struct
+    import mitsuba3_amd as mi
+    from mitsuba3_amd import _capi
+    L = mi.lib()
+
+    def read(path):
+        img = _capi.HarImage() if hasattr(_capi, "HarImage") else None
+        class Img(C.Structure):
+            _fields_ = [("data", C.POINTER(C.c_float)), ("width", C.c_uint32), ("height", C.c_uint32), ("channels", C.c_uint32)]
+        img = img or Img()
+        rc = L.har_image_read(str(path).encode(), C.byref(img))
+        msg = L.har_last_error().decode()
+        if rc == 0:
+            L.har_image_free(C.byref(img))
+        return rc, msg
+
+    good = tmp_path / "ok.exr"
+    arr = np.random.default_rng(0).uniform(0, 1, (5, 7, 3)).astype(np.float32)
+    mi.write_bitmap(str(good), arr) if hasattr(mi, "write_bitmap") else mi.Bitmap(arr).write(str(good))
+    blob = good.read_bytes()
+    assert read(good)[0] == 0
+    # dataWindow attribute with a wrong size / an absurd window / int32 overflow in max - min
+    i = blob.index(b"dataWindow\x00box2i\x00")
+    j = i + len(b"dataWindow\x00box2i\x00")
+    bad = [blob[:j] + struct.pack("<i", 4) + blob[j + 4:],                                                    # size 4 instead of 16
+           blob[:j + 4] + struct.pack("<4i", 0, 0, 2 ** 31 - 1, 2 ** 31 - 1) + blob[j + 20:],                 # 2^31 x 2^31 pixels
+           blob[:j + 4] + struct.pack("<4i", -2 ** 31, -2 ** 31, 2 ** 31 - 1, 2 ** 31 - 1) + blob[j + 20:],   # overflowing subtraction
+           blob[:40], blob[: len(blob) // 2]]                                                                # truncated
+    for k, b in enumerate(bad):
+        f = tmp_path / ("bad%d.exr" % k); f.write_bytes(b)
+        rc, msg = read(f)
+        assert rc != 0 and "Error while loading" in msg, (k, rc, msg)
+    # PFM: absurd dimensions, truncated payload
+    for k, b in enumerate([b"PF\n999999999 999999999\n-1.0\n" + b"\x00" * 64, b"PF\n4 4\n-1.0\n" + b"\x00" * 16, b"PF\n-4 4\n-1.0\n"]):
+        f = tmp_path / ("bad%d.pfm" % k); f.write_bytes(b)
+        rc, msg = read(f)
+        assert rc != 0, (k, msg)

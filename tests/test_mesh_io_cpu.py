@@ -157,3 +157,15 @@ def test_ply_errors(mi, tmp_path):
         load("e.ply", quad.replace(b"4 0 1 2 3", b"3 0 1 9"))
     with pytest.raises(RuntimeError, match="invalid vertex position"):
         load("f.ply", quad.replace(b"1 1 0", b"nan 1 0").replace(b"4 0 1 2 3", b"3 0 1 2"))
+
+
+def test_ply_header_counts_are_bounded_by_the_file(tmp_path):
+    """ADVICE r1: a header-controlled element count must not drive an allocation (std::bad_alloc through the C boundary aborts the process)"""
+    import mitsuba3_amd as mi
+    hdr = ("ply\nformat binary_little_endian 1.0\nelement vertex %d\nproperty float x\nproperty float y\nproperty float z\n"
+           "element face 1\nproperty list uchar int vertex_indices\nend_header\n")
+    for n in (2 ** 40, 2 ** 62, 10 ** 9):
+        f = tmp_path / ("huge%d.ply" % n); f.write_bytes((hdr % n).encode() + b"\x00" * 64)
+        with pytest.raises(Exception) as e:
+            mi.load_dict({"type": "ply", "filename": str(f)})
+        assert "PLY" in str(e.value)

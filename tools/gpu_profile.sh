@@ -7,7 +7,7 @@ TAG=$1; shift
 PASSES=()
 while [ $# -gt 0 ] && [ "$1" != "--" ]; do PASSES+=("$1"); shift; done
 [ $# -gt 0 ] && shift
-ARGS="$* --no-cpu-baseline --no-prb"
+ARGS="$* --no-cpu-baseline --no-prb --worker"      # --worker: measure in THIS process (bench.py without it is a launcher; rocprofv3 must see the kernels)
 cd "${GRAFT_REPO_ROOT:-.}"
 export TMPDIR=/tmp
 OUT=gpurun_out/prof; mkdir -p $OUT
@@ -22,5 +22,6 @@ for P in "${PASSES[@]}"; do
     sq2) rocprofv3 --pmc SQ_INSTS_VALU SQ_THREAD_CYCLES_VALU SQ_ACTIVE_INST_VALU SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_WAVE_CYCLES SQ_INSTS_SALU -d $D -o r -- python bench.py --steps 1 --warmup 0 $ARGS > $OUT/${TAG}_sq2_bench.log 2>&1 ;;
     tcc) rocprofv3 --pmc TCC_HIT_sum TCC_MISS_sum -d $D -o r -- python bench.py --steps 1 --warmup 0 $ARGS > /dev/null 2>&1 ;;
   esac
-  python tools/rocpd_summary.py $(find $D -name '*.db') > $OUT/${TAG}_$P.txt 2>&1
+  python tools/rocpd_summary.py $(find $D -name '*.db') --json $OUT/${TAG}_$P.json > $OUT/${TAG}_$P.txt 2>&1
+  [ "$P" = kt ] && find $D -name '*kernel_stats.csv' -exec cp {} $OUT/${TAG}_kernel_stats.csv \;
 done
