@@ -96,7 +96,9 @@ template <typename T> static hipError_t upload(const std::vector<T> &v, const T 
     return hipSuccess;
 }
 
+static uint64_t g_scene_serial = 0;
 struct HarSceneImpl {
+    uint64_t serial = ++g_scene_serial;       /* identifies the scene in per-integrator caches (a freed scene's address may be reused) */
     HostScene hs;
     DScene ds{};
     std::vector<void *> owned;
@@ -138,6 +140,8 @@ struct HarIntegratorImpl {
     unsigned long long *totals = nullptr;
     int *status = nullptr;
     float **d_grad_tex = nullptr; size_t grad_tex_cap = 0;
+    /* texel-gradient queues of the adjoint pass (TexelQueues, har_kernels.h): records, counters, band tables; built for `tq_scene` */
+    TexelQueues tq{ nullptr, nullptr, nullptr, nullptr, 0u, 0u }; uint64_t tq_scene = 0; uint32_t tq_lanes = 0, tq_lds = 0;
     // profiling
     /* Per-launch HIP events of the frames rendered since har_integrator_set_profiling(1).  An event is NEVER re-recorded while an earlier record of it
      * may still be pending: every frame (render_range / backward_range call) takes its own event set from a ring, and a set is only reused after its
@@ -182,6 +186,7 @@ int ensure_workspace(HarIntegratorImpl *I, uint32_t lanes, bool adjoint) {
     }
     I->free_ws();
     I->counters = nullptr; I->totals = nullptr; I->status = nullptr; I->adj = nullptr; I->adj_floats = 0; I->d_grad_tex = nullptr; I->grad_tex_cap = 0;
+    I->tq = TexelQueues{ nullptr, nullptr, nullptr, nullptr, 0u, 0u }; I->tq_scene = 0; I->tq_lanes = 0;
     I->pass_rng = nullptr; I->pass_rng_cap = 0; I->pass_jitter = nullptr; I->pass_jitter_cap = 0;
     I->grad_slots = nullptr; I->grad_slots_cap = 0;
     for (int k = 0; k < 2; ++k) {
@@ -213,8 +218,10 @@ int ensure_workspace(HarIntegratorImpl *I, uint32_t lanes, bool adjoint) {
     I->alpha_lane = nullptr;
     if (I->alpha_film && ws_alloc(I, &I->alpha_lane, lanes)) return 1;
     if (ws_alloc(I, &I->counters, (size_t) 4 * HAR_MAX_BOUNCE_SLOTS * HAR_SHARDS * HAR_COUNTER_STRIDE) || ws_alloc(I, &I->totals, 4) || ws_alloc(I, &I->status, 1)) return 1;
-    HIP_TRY(hipMemset(I->totals, 0, 4 * sizeof(unsigned long long)));
-    HIP_TRY(hipMemset(I->status, 0, sizeof(int)));
+    /* totals / status are cleared by every render call ON ITS STREAM before use.  (Round 1 also cleared them here with hipMemset: that memset is
+     * enqueued on the NULL stream and runs after whatever is queued there -- in two-stream mode after the first half of the frame -- while the twin
+     * renders on its non-blocking stream; when the twin finished first, the late memset wiped its counters: half the paths in har_render_stats,
+     * seen as an intermittent test failure when scenes of different cost alternate.) */
     I->ws_lanes = lanes; I->ws_adjoint = adjoint; I->shard_cap = lanes / HAR_SHARDS;
     return 0;
 }
@@ -283,6 +290,49 @@ static inline uint32_t *cnt_items(HarIntegratorImpl *I, uint32_t b) { return I->
 /* work cursors of the persistent traversal kernels (one per bounce and shard) */
 static inline uint32_t *cur_trace(HarIntegratorImpl *I, uint32_t b) { return I->counters + (size_t) (2 * HAR_MAX_BOUNCE_SLOTS + b) * HAR_SHARDS * HAR_COUNTER_STRIDE; }
 static inline uint32_t *cur_resolve(HarIntegratorImpl *I, uint32_t b) { return I->counters + (size_t) (3 * HAR_MAX_BOUNCE_SLOTS + b) * HAR_SHARDS * HAR_COUNTER_STRIDE; }
+
+/* texel-gradient queues for the bitmap textures of scene S (see TexelQueues): row bands whose LDS copy fits HAR_TQ_LDS_BYTES, at most HAR_TQ_MAX of
+ * them; textures that do not fit keep the direct atomics.  HAR_TEXEL_QUEUES=0 switches the queues off (A/B). */
+int ensure_texel_queues(HarSceneImpl *S, HarIntegratorImpl *I) {
+    static const bool enabled = !(getenv("HAR_TEXEL_QUEUES") && atoi(getenv("HAR_TEXEL_QUEUES")) == 0);
+    if (I->tq_scene == S->serial && I->tq_lanes == I->ws_lanes) return 0;
+    I->tq = TexelQueues{ nullptr, nullptr, nullptr, nullptr, 0u, 0u }; I->tq_scene = S->serial; I->tq_lanes = I->ws_lanes;
+    const size_t nt = S->hs.textures.size();
+    if (!enabled || nt == 0) return 0;
+    /* LDS copy of a band: 24 KB by default (measured on the textured 1M-triangle scene, PRB step: 64 KB 127.7 ms, 48 KB 130.4, 24 KB 125.9, 16 KB 126.2 --
+     * LDS float atomics retire about one lane per cycle and CU, so what matters is that every CU holds several blocks); larger copies only where a
+     * texture would otherwise need more than the HAR_TQ_MAX queues.  HAR_TQ_LDS forces one size (A/B). */
+    static const size_t lds_forced = getenv("HAR_TQ_LDS") ? (size_t) atol(getenv("HAR_TQ_LDS")) : 0;
+    std::vector<uint2> band(nt); std::vector<uint4> qinfo, heights; uint32_t nq = 0; size_t lds_used = 0;
+    for (size_t t = 0; t < nt; ++t) {
+        const uint32_t W = S->hs.textures[t].w, H = S->hs.textures[t].h;
+        band[t] = make_uint2(0xffffffffu, 1u);
+        if (W == 0 || H == 0 || W > 65535u || H > 65535u) continue;
+        const size_t sizes[4] = { (size_t) HAR_TQ_LDS_BYTES, 32768, 49152, 65536 };
+        for (int k = 0; k < 4; ++k) {
+            const size_t lds = lds_forced ? lds_forced : sizes[k];
+            if ((size_t) W * 12 * 2 > lds) { if (lds_forced) break; continue; }
+            /* the LDS copy of a band holds its rows + the row after it (k_texel_accumulate) */
+            const uint32_t rows = std::min<uint32_t>(H, (uint32_t) (lds / ((size_t) W * 12)) - 1u), nb = (H + rows - 1) / rows;
+            if (nq + nb > HAR_TQ_MAX) { if (lds_forced) break; continue; }
+            band[t] = make_uint2(nq, rows);
+            for (uint32_t b = 0; b < nb; ++b) { qinfo.push_back(make_uint4((uint32_t) t, b * rows, std::min(rows, H - b * rows), W)); heights.push_back(make_uint4(H, 0u, 0u, 0u)); }
+            nq += nb; lds_used = std::max(lds_used, lds);
+            break;
+        }
+    }
+    if (nq == 0) return 0;
+    qinfo.insert(qinfo.end(), heights.begin(), heights.end());
+    uint2 *d_band = nullptr; uint4 *d_qinfo = nullptr; float4 *rec = nullptr; uint32_t *count = nullptr;
+    /* every (shard, band) queue holds twice its mean share of a shard's lanes: 2 x lanes records of 32 bytes in total */
+    const uint32_t cap = std::max<uint32_t>(1024u, (uint32_t) (2ull * I->shard_cap / nq));
+    if (ws_alloc(I, &d_band, nt) || ws_alloc(I, &d_qinfo, qinfo.size()) || ws_alloc(I, &rec, (size_t) 2 * HAR_SHARDS * nq * cap) ||
+        ws_alloc(I, &count, (size_t) HAR_SHARDS * nq * HAR_COUNTER_STRIDE)) return 1;
+    HIP_TRY(hipMemcpy(d_band, band.data(), nt * sizeof(uint2), hipMemcpyHostToDevice));
+    HIP_TRY(hipMemcpy(d_qinfo, qinfo.data(), qinfo.size() * sizeof(uint4), hipMemcpyHostToDevice));
+    I->tq = TexelQueues{ rec, count, d_band, d_qinfo, nq, cap }; I->tq_lds = (uint32_t) lds_used;
+    return 0;
+}
 
 /* rays of har_integrator_sample: SoA arrays of n_total rays, the chunk covers [first, first + n) */
 struct RaySource { const float *o, *d, *maxt; const uint64_t *state; uint32_t n_total, first; };
@@ -361,9 +411,16 @@ int run_chunk(HarSceneImpl *S, HarIntegratorImpl *I, const DSensor &C, int mode,
             launch_shape_adjoint(s, grid, S->ds, cnt_items(I, b - 1), I->shard_cap, I->items, I->geo, I->result, I->dL, 1, I->st[cur], I->h0, I->h1, rc, targets);
             prof_mark(I, s, CLS_OTHER);
         }
+        const bool queued = inline_commit && rc.mode == 2 && I->tq.nq != 0;          /* texel gradients of this bounce go through the band queues */
+        if (queued) HIP_TRY(hipMemsetAsync(I->tq.count, 0, (size_t) HAR_SHARDS * I->tq.nq * HAR_COUNTER_STRIDE * sizeof(uint32_t), s));
         launch_shade(mode, s, grid, S->ds, P, lane_base, I->shard_cap, cnt_alive(I, b), I->st[cur], I->h0, I->h1, I->st[cur ^ 1], cnt_alive(I, b + 1),
-                     I->items, cnt_items(I, b), I->result, rc, ps.rng, I->dL, grad_refl, shape ? &I->geo : nullptr, inline_commit && rc.mode == 2 ? I->d_grad_tex : nullptr);
+                     I->items, cnt_items(I, b), I->result, rc, ps.rng, I->dL, grad_refl, shape ? &I->geo : nullptr, inline_commit && rc.mode == 2 ? I->d_grad_tex : nullptr,
+                     queued ? &I->tq : nullptr);
         prof_mark(I, s, CLS_SHADE);
+        if (queued) {
+            static const uint32_t bpq_env = getenv("HAR_TQ_BPQ") ? (uint32_t) atoi(getenv("HAR_TQ_BPQ")) : 0u;
+            launch_texel_accumulate(s, I->tq, I->d_grad_tex, bpq_env ? bpq_env : (n > (1u << 22) ? 4u : 1u), I->tq_lds); prof_mark(I, s, CLS_OTHER);
+        }
         if (!(inline_commit && rc.mode == 2)) launch_resolve(mode, s, rc.mode == 2 ? grid : tgrid, spill, S->ds, cnt_items(I, b), cur_resolve(I, b), I->shard_cap, I->items, I->result, I->dL, grad_refl, I->d_grad_tex, I->status, rc,
                        shape ? I->geo.vis : nullptr, fwd ? 1 : 0);
         prof_mark(I, s, CLS_RESOLVE);
@@ -863,6 +920,7 @@ static int backward_range(HarScene S, HarIntegrator I, const HarSensor *sensor, 
         HIP_TRY(hipMemcpyAsync(I->d_grad_tex, grad_textures, nt * sizeof(float *), hipMemcpyHostToDevice, s));
         HIP_TRY(hipStreamSynchronize(s));
     }
+    if (ensure_texel_queues(S, I)) return 1;
     /* the kernels accumulate into (bsdf_count + emitter_count) x 3 slots; the two halves are added to the caller's buffers at the end */
     const size_t nb3 = 3 * S->hs.bsdfs.size(), ne3 = 3 * S->hs.emitters.size();
     if (I->grad_slots_cap < nb3 + ne3 + 3) { if (ws_alloc(I, &I->grad_slots, nb3 + ne3 + 3)) return 1; I->grad_slots_cap = nb3 + ne3 + 3; }

@@ -64,6 +64,19 @@ struct PassState { uint64_t *rng; float2 *jitter; uint32_t pass; };
  * normal, cos theta_o) and the visibility `resolve` found for its shadow ray.  `ShapeTargets`: grad holds 3 floats per vertex of the
  * differentiated meshes, mesh m starting at float3 offset[m] (-1 = not differentiated). */
 struct ShapeArrays { float4 *g0, *g1, *g2, *g3; uint8_t *vis; };
+/* Texel-gradient queues of the PRB adjoint.  Global float atomics run at the memory side of the chip at a fixed rate (measured: ~57 G atomics/s
+ * whatever the address distribution -- a 64^2 and a 4096^2 gradient texture cost the same), and a bitmap albedo needs 12 of them per path vertex
+ * (4 bilinear taps x RGB): 44 of the 156 ms of a PRB step on the textured 1M-triangle scene.  Instead, the shading kernel APPENDS one 32-byte
+ * record per vertex -- {texel cell, bilinear fractions, gradient} -- to the queue of the texture ROW BAND its cell lies in (one queue per band
+ * and XCD shard; slots are reserved per 256-thread block with one atomic per non-empty band, like the path compaction), and k_texel_accumulate
+ * gives every (band, shard) queue to a few blocks that add the records' taps into an LDS copy of the band (ds_add_f32) and flush it with one
+ * global atomic per texel and channel.  ~10x fewer global atomics; the records cost 64 B of HBM traffic per vertex.
+ * Queues are bounded (2x the mean band load): a record that finds its queue full is committed with direct atomics by its lane.
+ *   band[tex]  = { first queue of the texture (0xffffffff: not queued -- direct atomics), rows per band }
+ *   qinfo[q]   = { texture, first row, rows, width } */
+#define HAR_TQ_MAX 64                 /* queues (row bands of all queued textures) */
+#define HAR_TQ_LDS_BYTES 24576        /* default LDS copy of a band: (rows + 1) x width x 3 floats (6 blocks per CU) */
+struct TexelQueues { float4 *rec; uint32_t *count; const uint2 *band; const uint4 *qinfo; uint32_t nq, cap; };
 struct ShapeTargets { const int32_t *offset; float *grad; uint32_t n_verts; };
 #define HAR_LDS_GRAD_VERTS 1024       /* up to this many differentiated vertices are accumulated in LDS (12 KB) before one global atomic per block and float */
 
@@ -79,7 +92,10 @@ void launch_trace_closest(hipStream_t s, uint32_t grid, uint2 *spill, const Acce
 void launch_shade(int mode, hipStream_t s, uint32_t grid, const DScene &S, const ShadeParams &P, uint32_t lane_base, uint32_t shard_cap, const uint32_t *count_in,
                   const WaveState &in, const float4 *h0, const uint2 *h1, const WaveState &out, uint32_t *count_out, const ItemArrays &items,
                   uint32_t *item_count, float4 *result, const ReplayCache &rc, uint64_t *pass_rng = nullptr, const float4 *dL = nullptr, float *grad_slots = nullptr,
-                  const ShapeArrays *geo = nullptr, float *const *grad_tex_inline = nullptr);      /* grad_tex_inline (adjoint, cached bounce): commit the vertex adjoint in place, no items */
+                  const ShapeArrays *geo = nullptr, float *const *grad_tex_inline = nullptr,       /* grad_tex_inline (adjoint, cached bounce): commit the vertex adjoint in place, no items */
+                  const TexelQueues *tq = nullptr);                                                /* ... with the texel gradients going through the queues */
+/* the records of one bounce -> LDS band copies -> grad_tex (see TexelQueues); blocks_per_queue blocks share a queue */
+void launch_texel_accumulate(hipStream_t s, const TexelQueues &tq, float *const *grad_tex, uint32_t blocks_per_queue, uint32_t lds_bytes);
 void launch_resolve(int mode, hipStream_t s, uint32_t grid, uint2 *spill, const DScene &S, const uint32_t *item_count, uint32_t *cursor, uint32_t shard_cap, const ItemArrays &items,
                     float4 *result, const float4 *dL, float *grad_refl, float *const *grad_tex, int *status, const ReplayCache &rc, uint8_t *item_vis = nullptr,
                     int fwd = 0);      /* fwd: forward mode (render_forward) -- grad_refl / grad_tex are the parameters' tangents, dL accumulates */

@@ -107,8 +107,11 @@ __device__ __forceinline__ float wave_sum_to_last(float v) {
 
 /* gradient scatter with wave-level pre-reduction: lanes that target the same address are summed
  * (DPP) and committed by one lane, so a constant albedo costs 3 atomics per wave instead of 192 */
+#ifndef HAR_TEXEL_ROUNDS
+#define HAR_TEXEL_ROUNDS 6
+#endif
 __device__ __forceinline__ void wave_aggregated_add3(float *dst, Vec3 g, bool active) {
-    for (int round = 0; round < 6; ++round) {
+    for (int round = 0; round < HAR_TEXEL_ROUNDS; ++round) {
         uint64_t m = __ballot(active);
         if (m == 0) return;
         const int leader = __ffsll((long long) m) - 1;
@@ -368,9 +371,12 @@ __global__ __launch_bounds__(kBlock) void k_trace_closest(Accel A, const uint32_
 /* adjoint of one NEE / vertex item (wave-uniform call: every lane takes part in the texel pre-reduction):
  * L <- L - Lr_dir; g = dL * (dLr_dir/dslot0 + L * (df/dslot0)/f)  (prb.py:227,288-313).
  * s2 = Lr_dir (or Lr_dir for a unit radiance) + tag, s3 = d Lr_dir / d slot0 + uv.x, s4 = (d f / d slot0) / f + uv.y -- the item layout of k_shade */
+/* a texel-gradient record on its way to a queue (see TexelQueues): the bilinear cell, the fractions and the gradient of the interpolated colour */
+struct TexelRecord { bool has; uint32_t q, cell, tex; float w1x, w1y; Vec3 g; };
+
 template <bool FWD = false>
 __device__ __forceinline__ void adjoint_commit_values(const DScene &S, bool pred, bool visible, uint32_t lane, float4 s2, float4 s3, float4 s4, float4 *result, const float4 *dL,
-                                                      float *grad_refl, float *const *grad_tex, float *gacc) {
+                                                      float *grad_refl, float *const *grad_tex, float *gacc, const TexelQueues *tq = nullptr, TexelRecord *rec = nullptr) {
     if (FWD) {
         /* FORWARD mode (RBIntegrator.render_forward, common.py:497-623; prb.py:313 `dL += dr.forward_to(Lo)`): `grad_refl` / `grad_tex` hold the
          * TANGENTS of the parameters (same layout as the gradient buffers: slots of the BSDFs, then of the emitters; one array per bitmap) and are
@@ -427,16 +433,42 @@ __device__ __forceinline__ void adjoint_commit_values(const DScene &S, bool pred
         if (B.texture >= 0) { tex = true; tex_taps(S.textures[B.texture], s3.w, s4.w, taps); tdst = grad_tex[B.texture]; }
     }
     const bool nz = pred && (g.x != 0.f || g.y != 0.f || g.z != 0.f);
-    if (nz && !tex) {
+    if (rec) {          /* queued textures: hand the record to the caller (block-wide append), no atomics here */
+        rec->has = false;
+        if (nz && tex) {
+            const uint32_t t = (uint32_t) S.bsdfs[(uint32_t) (dst - grad_refl) / 3u].texture;
+            const uint2 band = tq->band[t];
+            if (band.x != 0xffffffffu) {
+                const uint32_t W = S.textures[t].w, y0 = taps.idx[0] / W, x0 = taps.idx[0] - y0 * W;
+                rec->has = true; rec->q = band.x + y0 / band.y; rec->cell = x0 | (y0 << 16); rec->tex = t; rec->w1x = taps.w1x; rec->w1y = taps.w1y; rec->g = g;
+                tex = false; g = Vec3(0.f);
+            }
+        }
+    }
+    const bool nz_direct = nz && (g.x != 0.f || g.y != 0.f || g.z != 0.f || tex);
+    if (nz_direct && !tex) {
         const uint32_t bsdf = (uint32_t) (dst - grad_refl) / 3u;
         if (bsdf < HAR_LDS_GRAD_BSDFS) { atomicAdd(&gacc[3 * bsdf], g.x); atomicAdd(&gacc[3 * bsdf + 1], g.y); atomicAdd(&gacc[3 * bsdf + 2], g.z); }
         else { atomicAdd(dst, g.x); atomicAdd(dst + 1, g.y); atomicAdd(dst + 2, g.z); }
     }
-    if (__ballot(nz && tex)) {
+    if (__ballot(nz_direct && tex)) {
         const float w[4] = { taps.w0x * taps.w0y, taps.w1x * taps.w0y, taps.w0x * taps.w1y, taps.w1x * taps.w1y };
         for (int k = 0; k < 4; ++k)
-            wave_aggregated_add3(nz && tex ? tdst + 3 * (size_t) taps.idx[k] : grad_refl, nz && tex ? g * w[k] : Vec3(0.f), nz && tex);
+            wave_aggregated_add3(nz_direct && tex ? tdst + 3 * (size_t) taps.idx[k] : grad_refl, nz_direct && tex ? g * w[k] : Vec3(0.f), nz_direct && tex);
     }
+}
+/* the four taps of a record committed with direct atomics (queue overflow); wave-uniform call */
+__device__ __forceinline__ void texel_record_direct(const DScene &S, float *const *grad_tex, float *dummy, const TexelRecord &r, bool active) {
+    if (!__ballot(active)) return;
+    uint32_t idx[4] = { 0, 0, 0, 0 }; float w[4] = { 0.f, 0.f, 0.f, 0.f }; float *dst = dummy;
+    if (active) {
+        const uint32_t W = S.textures[r.tex].w, H = S.textures[r.tex].h, x0 = r.cell & 0xffffu, y0 = r.cell >> 16, x1 = x0 + 1 == W ? 0u : x0 + 1, y1 = y0 + 1 == H ? 0u : y0 + 1;
+        idx[0] = y0 * W + x0; idx[1] = y0 * W + x1; idx[2] = y1 * W + x0; idx[3] = y1 * W + x1;
+        const float w0x = 1.f - r.w1x, w0y = 1.f - r.w1y;
+        w[0] = w0x * w0y; w[1] = r.w1x * w0y; w[2] = w0x * r.w1y; w[3] = r.w1x * r.w1y;
+        dst = grad_tex[r.tex];
+    }
+    for (int k = 0; k < 4; ++k) wave_aggregated_add3(active ? dst + 3 * (size_t) idx[k] : dummy, active ? r.g * w[k] : Vec3(0.f), active);
 }
 template <bool FWD = false>
 __device__ __forceinline__ void adjoint_commit(const DScene &S, const ItemArrays &items, uint32_t i, bool pred, bool visible, float4 *result, const float4 *dL,
@@ -454,8 +486,9 @@ template <int MODE, uint32_t TYPES, bool SHAPE = false, bool INLINE = false>
 __global__ __launch_bounds__(kBlock, HAR_SHADE_MIN_WAVES) void k_shade(DScene S, ShadeParams P, uint32_t lane_base, uint32_t shard_cap, const uint32_t *count_in, WaveState in,
                                                   const float4 *h0, const uint2 *h1, WaveState out, uint32_t *count_out,
                                                   ItemArrays items, uint32_t *item_count, float4 *result, ReplayCache rc, uint64_t *pass_rng,
-                                                  const float4 *dL, float *grad_slots, ShapeArrays geo, float *const *grad_tex) {
+                                                  const float4 *dL, float *grad_slots, ShapeArrays geo, float *const *grad_tex, TexelQueues tq) {
     __shared__ uint32_t lds_r[12];
+    __shared__ uint32_t tq_hist[INLINE ? HAR_TQ_MAX : 1], tq_base[INLINE ? HAR_TQ_MAX : 1];
     __shared__ float gacc[INLINE ? 3 * HAR_LDS_GRAD_BSDFS : 1];
     if (INLINE) { for (uint32_t k = threadIdx.x; k < 3 * HAR_LDS_GRAD_BSDFS; k += kBlock) gacc[k] = 0.f; __syncthreads(); }
     /* adjoint with emitter gradients: per-block accumulators of d L / d radiance from emission hits (slots n_bsdfs + emitter of `grad_slots`) */
@@ -540,9 +573,30 @@ __global__ __launch_bounds__(kBlock, HAR_SHADE_MIN_WAVES) void k_shade(DScene S,
             const Vec3 c = fact ? R.contrib_unit : R.contrib;
             const uint32_t tag = (R.bsdf & 0xfffffu) | ((fact ? (uint32_t) R.nee_emitter : HAR_ITEM_NO_EMITTER) << 20) | (R.ind_active ? 0x80000000u : 0u);
             const bool visible = item_pred && R.item_ray && rc.vis[lane] != 0;
+            TexelRecord rec; rec.has = false;
             adjoint_commit_values(S, item_pred, visible, lane, make_float4(c.x, c.y, c.z, __uint_as_float(tag)), make_float4(R.dLr_drho.x, R.dLr_drho.y, R.dLr_drho.z, R.uv_x),
-                                  make_float4(R.rel_grad.x, R.rel_grad.y, R.rel_grad.z, R.uv_y), result, dL, grad_slots, grad_tex, gacc);      /* forward mode never commits in place (host) */
+                                  make_float4(R.rel_grad.x, R.rel_grad.y, R.rel_grad.z, R.uv_y), result, dL, grad_slots, grad_tex, gacc,      /* forward mode never commits in place (host) */
+                                  tq.nq ? &tq : nullptr, tq.nq ? &rec : nullptr);
             item_pred = false;
+            if (tq.nq) {
+                /* append the block's texel records to their band queues (TexelQueues): LDS histogram -> one global atomic per non-empty band -> scattered 32-byte records */
+                if (threadIdx.x < tq.nq) tq_hist[threadIdx.x] = 0u;
+                __syncthreads();
+                const uint32_t rank = rec.has ? atomicAdd(&tq_hist[rec.q], 1u) : 0u;
+                __syncthreads();
+                if (threadIdx.x < tq.nq) { const uint32_t c = tq_hist[threadIdx.x]; tq_base[threadIdx.x] = c ? atomicAdd(tq.count + (size_t) (Q.shard * tq.nq + threadIdx.x) * HAR_COUNTER_STRIDE, c) : 0u; }
+                __syncthreads();
+                bool overflow = false;
+                if (rec.has) {
+                    const uint32_t slot = tq_base[rec.q] + rank;
+                    if (slot < tq.cap) {
+                        float4 *dst = tq.rec + 2 * ((size_t) (Q.shard * tq.nq + rec.q) * tq.cap + slot);
+                        dst[0] = make_float4(__uint_as_float(rec.cell), __uint_as_float(rec.tex), rec.w1x, rec.w1y);
+                        dst[1] = make_float4(rec.g.x, rec.g.y, rec.g.z, 0.f);
+                    } else overflow = true;
+                }
+                texel_record_direct(S, grad_tex, grad_slots, rec, overflow);
+            }
         }
         const bool alive = in_range && R.alive, item = item_pred;
         uint32_t slot, islot;
@@ -584,6 +638,44 @@ __global__ __launch_bounds__(kBlock, HAR_SHADE_MIN_WAVES) void k_shade(DScene S,
             const float v = gacc[k];
             if (v != 0.f) atomicAdd(grad_slots + k, v);
         }
+    }
+}
+
+/* texel-gradient queues -> gradient textures (see TexelQueues): blockIdx / bpq = shard * nq + band queue; the queue's records are shared by bpq blocks */
+__global__ __launch_bounds__(kBlock) void k_texel_accumulate(TexelQueues tq, float *const *grad_tex, uint32_t bpq) {
+    extern __shared__ float band[];
+    const uint32_t qid = blockIdx.x / bpq, part = blockIdx.x - qid * bpq, q = qid % tq.nq;
+    const uint32_t n = min(tq.count[(size_t) qid * HAR_COUNTER_STRIDE], tq.cap);
+    if (n == 0) return;
+    const uint4 info = tq.qinfo[q];                        /* texture, first row, rows, width */
+    const uint32_t W = info.w, row0 = info.y, rows = info.z, H = tq.qinfo[q + tq.nq].x;
+    /* the LDS copy holds the band's rows PLUS the row after it (the second bilinear row of cells in the band's last row; row 0 after the
+     * texture's last row: repeat wrap), so that every tap of every record is an LDS atomic -- a global atomic in this loop would make each
+     * iteration wait for a memory-side round trip */
+    const uint32_t nfl = (rows + 1u) * W * 3u;
+    float *dst = grad_tex[info.x];
+    for (uint32_t k = threadIdx.x; k < nfl; k += kBlock) band[k] = 0.f;
+    __syncthreads();
+    const uint32_t b = (uint32_t) ((uint64_t) n * part / bpq), e = (uint32_t) ((uint64_t) n * (part + 1) / bpq);
+    const float4 *rec = tq.rec + 2 * (size_t) qid * tq.cap;
+    for (uint32_t i = b + threadIdx.x; i < e; i += kBlock) {
+        const float4 r0 = rec[2 * (size_t) i], r1 = rec[2 * (size_t) i + 1];
+        const uint32_t cell = __float_as_uint(r0.x), x0 = cell & 0xffffu, ry = (cell >> 16) - row0, x1 = x0 + 1 == W ? 0u : x0 + 1;
+        const float w0x = 1.f - r0.z, w0y = 1.f - r0.w;
+        float *a0 = band + 3u * (ry * W + x0), *a1 = band + 3u * (ry * W + x1), *a2 = a0 + 3u * W, *a3 = a1 + 3u * W;
+        const float w00 = w0x * w0y, w10 = r0.z * w0y, w01 = w0x * r0.w, w11 = r0.z * r0.w;
+        atomicAdd(a0, r1.x * w00); atomicAdd(a0 + 1, r1.y * w00); atomicAdd(a0 + 2, r1.z * w00);
+        atomicAdd(a1, r1.x * w10); atomicAdd(a1 + 1, r1.y * w10); atomicAdd(a1 + 2, r1.z * w10);
+        atomicAdd(a2, r1.x * w01); atomicAdd(a2 + 1, r1.y * w01); atomicAdd(a2 + 2, r1.z * w01);
+        atomicAdd(a3, r1.x * w11); atomicAdd(a3 + 1, r1.y * w11); atomicAdd(a3 + 2, r1.z * w11);
+    }
+    __syncthreads();
+    for (uint32_t k = threadIdx.x; k < nfl; k += kBlock) {
+        const float v = band[k];
+        if (v == 0.f) continue;
+        const uint32_t r = k / (3u * W), c = k - r * 3u * W;
+        uint32_t y = row0 + r; if (y >= H) y -= H;
+        atomicAdd(dst + 3 * (size_t) y * W + c, v);
     }
 }
 
@@ -1053,21 +1145,23 @@ void launch_trace_closest(hipStream_t s, uint32_t grid, uint2 *spill, const Acce
 void launch_shade(int mode, hipStream_t s, uint32_t grid, const DScene &S, const ShadeParams &P, uint32_t lane_base, uint32_t shard_cap, const uint32_t *count_in,
                   const WaveState &in, const float4 *h0, const uint2 *h1, const WaveState &out, uint32_t *count_out, const ItemArrays &items,
                   uint32_t *item_count, float4 *result, const ReplayCache &rc, uint64_t *pass_rng, const float4 *dL, float *grad_slots, const ShapeArrays *geo,
-                  float *const *grad_tex) {
+                  float *const *grad_tex, const TexelQueues *tq_in) {
     dim3 g(grid), b(kBlock);
     const ShapeArrays no_geo{ nullptr, nullptr, nullptr, nullptr, nullptr };
+    const TexelQueues no_tq{ nullptr, nullptr, nullptr, nullptr, 0u, 0u };
+    const TexelQueues tq = tq_in ? *tq_in : no_tq;
     if (geo && mode == MODE_PRB_ADJOINT) {        /* vertex-position gradients: scenes of `diffuse` BSDFs, plain or `twosided` (checked by har_integrator_set_grad_positions) */
         if (S.bsdf_types == HAR_BSDF_ONLY_DIFFUSE)
             hipLaunchKernelGGL((k_shade<MODE_PRB_ADJOINT, HAR_BSDF_ONLY_DIFFUSE, true>), g, b, 0, s, S, P, lane_base, shard_cap, count_in, in, h0, h1, out, count_out, items, item_count,
-                               result, rc, pass_rng, dL, grad_slots, *geo, grad_tex);
+                               result, rc, pass_rng, dL, grad_slots, *geo, grad_tex, no_tq);
         else
             hipLaunchKernelGGL((k_shade<MODE_PRB_ADJOINT, HAR_BSDF_CLASSIC_TYPES, true>), g, b, 0, s, S, P, lane_base, shard_cap, count_in, in, h0, h1, out, count_out, items, item_count,
-                               result, rc, pass_rng, dL, grad_slots, *geo, grad_tex);
+                               result, rc, pass_rng, dL, grad_slots, *geo, grad_tex, no_tq);
         return;
     }
     if (grad_tex && mode == MODE_PRB_ADJOINT && rc.mode == 2) {       /* cached bounce of the adjoint replay: commit in place (see k_shade) */
         const bool env = (S.bsdf_types & HAR_SCENE_ENVMAP) != 0u, diffuse = S.bsdf_types == HAR_BSDF_ONLY_DIFFUSE, cls = (S.bsdf_types & 0x7fffffffu & ~HAR_BSDF_CLASSIC_TYPES) == 0u;
-#define HAR_LAUNCH_SHADE_INLINE(T) hipLaunchKernelGGL((k_shade<MODE_PRB_ADJOINT, T, false, true>), g, b, 0, s, S, P, lane_base, shard_cap, count_in, in, h0, h1, out, count_out, items, item_count, result, rc, pass_rng, dL, grad_slots, no_geo, grad_tex)
+#define HAR_LAUNCH_SHADE_INLINE(T) hipLaunchKernelGGL((k_shade<MODE_PRB_ADJOINT, T, false, true>), g, b, 0, s, S, P, lane_base, shard_cap, count_in, in, h0, h1, out, count_out, items, item_count, result, rc, pass_rng, dL, grad_slots, no_geo, grad_tex, tq)
         if (env) HAR_LAUNCH_SHADE_INLINE(HAR_BSDF_ALL_TYPES | HAR_SCENE_ENVMAP); else if (diffuse) HAR_LAUNCH_SHADE_INLINE(HAR_BSDF_ONLY_DIFFUSE);
         else if (cls) HAR_LAUNCH_SHADE_INLINE(HAR_BSDF_CLASSIC_TYPES); else HAR_LAUNCH_SHADE_INLINE(HAR_BSDF_ALL_TYPES);
 #undef HAR_LAUNCH_SHADE_INLINE
@@ -1075,7 +1169,7 @@ void launch_shade(int mode, hipStream_t s, uint32_t grid, const DScene &S, const
     }
     /* diffuse-only scenes (no twosided wrappers) run kernels in which the other BSDF models are compiled out */
     const bool only_diffuse = S.bsdf_types == HAR_BSDF_ONLY_DIFFUSE;
-#define HAR_LAUNCH_SHADE(M, T) hipLaunchKernelGGL((k_shade<M, T>), g, b, 0, s, S, P, lane_base, shard_cap, count_in, in, h0, h1, out, count_out, items, item_count, result, rc, pass_rng, dL, grad_slots, no_geo, nullptr)
+#define HAR_LAUNCH_SHADE(M, T) hipLaunchKernelGGL((k_shade<M, T>), g, b, 0, s, S, P, lane_base, shard_cap, count_in, in, h0, h1, out, count_out, items, item_count, result, rc, pass_rng, dL, grad_slots, no_geo, nullptr, no_tq)
     const bool envmap = (S.bsdf_types & HAR_SCENE_ENVMAP) != 0u;      /* generic BSDF code + environment-map sampling / lookup */
     const bool classic = (S.bsdf_types & 0x7fffffffu & ~HAR_BSDF_CLASSIC_TYPES) == 0u;
 #define HAR_LAUNCH_SHADE_MODE(M) do { if (envmap) HAR_LAUNCH_SHADE(M, HAR_BSDF_ALL_TYPES | HAR_SCENE_ENVMAP); else if (only_diffuse) HAR_LAUNCH_SHADE(M, HAR_BSDF_ONLY_DIFFUSE); else if (classic) HAR_LAUNCH_SHADE(M, HAR_BSDF_CLASSIC_TYPES); else HAR_LAUNCH_SHADE(M, HAR_BSDF_ALL_TYPES); } while (0)
@@ -1084,6 +1178,9 @@ void launch_shade(int mode, hipStream_t s, uint32_t grid, const DScene &S, const
     else                              HAR_LAUNCH_SHADE_MODE(MODE_PRB_ADJOINT);
 #undef HAR_LAUNCH_SHADE_MODE
 #undef HAR_LAUNCH_SHADE
+}
+void launch_texel_accumulate(hipStream_t s, const TexelQueues &tq, float *const *grad_tex, uint32_t bpq, uint32_t lds_bytes) {
+    hipLaunchKernelGGL(k_texel_accumulate, dim3(HAR_SHARDS * tq.nq * bpq), dim3(kBlock), lds_bytes, s, tq, grad_tex, bpq);
 }
 void launch_resolve(int mode, hipStream_t s, uint32_t grid, uint2 *spill, const DScene &S, const uint32_t *item_count, uint32_t *cursor, uint32_t shard_cap, const ItemArrays &items,
                     float4 *result, const float4 *dL, float *grad_refl, float *const *grad_tex, int *status, const ReplayCache &rc, uint8_t *item_vis, int fwd) {

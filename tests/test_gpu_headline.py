@@ -80,7 +80,7 @@ def test_forward_parity_1m_scene_512(mi, O, flatten):
     ref, st = osc.render_path(sensor, seed=0, spp=spp, max_depth=8)
     assert rel_l2(img, ref) < 1e-4
     gst = scene.integrator().stats()
-    assert gst["paths"] == st.paths == res * res * spp and gst["vertices"] == st.vertices
+    assert gst["paths"] == st.paths == res * res * spp and gst["vertices"] == st.vertices, (gst, st.paths, st.vertices)
 
 
 # ------------------------------------------------------------------ N1 (ii): PRB gradients on the instanced scene with a bitmap albedo
@@ -147,3 +147,26 @@ def test_config2_cornell_512_full_parity(mi, O):
     assert rel_l2(img, ref) < 1e-4
     gst = scene.integrator().stats()
     assert gst["paths"] == st.paths and gst["vertices"] == st.vertices
+
+
+# ------------------------------------------------------------------ texel-gradient queues (TexelQueues, har_kernels.h)
+
+@pytest.mark.parametrize("tex_res", [2, 7, 64, 512])
+def test_texel_queue_gradients_all_texture_sizes(mi, O, tex_res):
+    """the band-queue path of the PRB adjoint for textures from 2 x 2 (every path of the chip adds to the same four texels; bilinear wrap in both
+    directions on every tap) over a non-power-of-two size to 512 x 512 (57 bands of 64 KB): texel gradients vs the oracle, and the queued path
+    vs the direct atomics (HAR_TEXEL_QUEUES=0 is read once per process, so the comparison uses the replay cache switch, which disables the
+    in-place commit and with it the queues)"""
+    res, spp = 128, 16
+    d = mi.instanced_spheres_scene(width=res, height=res, spp=spp, grid=3, n_u=16, n_v=8, textured=True, tex_res=tex_res)
+    d["integrator"] = {"type": "prb", "max_depth": 6, "rr_depth": 5}
+    scene = mi.load_dict(d)
+    osc, sensor = O.scene_from_product(scene)
+    grad_in = np.random.default_rng(tex_res).uniform(0.5, 1.5, (res, res, 3)).astype(np.float32) / (res * res)
+    g = scene.integrator().render_backward(scene, None, grad_in, seed=3, spp=spp)["white.reflectance.data"].cpu().numpy()
+    _, g_tex, _ = osc.render_prb_backward(sensor, grad_in, seed=3, spp=spp, max_depth=6)
+    assert rel_l2(g, g_tex[0]) < 1e-3
+    d["integrator"]["replay_cache"] = False
+    scene2 = mi.load_dict(d)
+    g2 = scene2.integrator().render_backward(scene2, None, grad_in, seed=3, spp=spp)["white.reflectance.data"].cpu().numpy()
+    assert rel_l2(g, g2) < 5e-4           # two float32 summation orders of up to ~10^6 terms per texel (2 x 2 texture)

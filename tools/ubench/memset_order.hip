@@ -26,13 +26,13 @@ static void *vmm_alloc(size_t bytes) {
     return p;
 }
 int main() {
-    const uint32_t n = 1280;                     // 5120 bytes, the size run_chunk clears
-    for (int vmm = 0; vmm < 2; ++vmm) for (int own_stream = 0; own_stream < 2; ++own_stream) for (int offset = 0; offset < 2; ++offset) {
+    for (uint32_t n : { 1280u, 8u, 1u })         // 5120 bytes (the counters run_chunk clears), 32 bytes (totals), 4 bytes (status)
+    for (int vmm = 0; vmm < 2; ++vmm) for (int own_stream = 0; own_stream < 3; ++own_stream) for (int offset = 0; offset < 2; ++offset) {
         uint32_t *base = nullptr, *bad = nullptr;
         if (vmm) base = (uint32_t *) vmm_alloc(1 << 22); else CK(hipMalloc(&base, 1 << 22));
         CK(hipMalloc(&bad, 4)); CK(hipMemset(bad, 0, 4));
         uint32_t *buf = base + (offset ? 131328 : 0);     // an interior pointer, as cnt_items / cur_trace are
-        hipStream_t s = nullptr; if (own_stream) CK(hipStreamCreate(&s));
+        hipStream_t s = nullptr; if (own_stream == 1) CK(hipStreamCreate(&s)); if (own_stream == 2) CK(hipStreamCreateWithFlags(&s, hipStreamNonBlocking));
         for (int it = 0; it < 2000; ++it) {
             hipLaunchKernelGGL(k_dirty, dim3(2048), dim3(256), 0, s, buf, n, (uint32_t) it, 2000);
             CK(hipMemsetAsync(buf, 0, n * 4, s));
@@ -40,8 +40,8 @@ int main() {
         }
         CK(hipStreamSynchronize(s));
         uint32_t h = 0; CK(hipMemcpy(&h, bad, 4, hipMemcpyDeviceToHost));
-        printf("memory=%s stream=%s pointer=%s : %u non-zero words seen after hipMemsetAsync in 2000 rounds\n", vmm ? "vmm" : "hipMalloc", own_stream ? "created" : "null",
-               offset ? "interior" : "base", h);
+        printf("bytes=%u memory=%s stream=%s pointer=%s : %u non-zero words seen after hipMemsetAsync in 2000 rounds\n", n * 4, vmm ? "vmm" : "hipMalloc",
+               own_stream == 0 ? "null" : own_stream == 1 ? "created" : "non-blocking", offset ? "interior" : "base", h);
     }
     return 0;
 }
