@@ -239,21 +239,29 @@ def worker(args):
         if rec and "FETCH_SIZE" in rec["counters"] and "WRITE_SIZE" in rec["counters"]:
             f, w = rec["counters"]["FETCH_SIZE"], rec["counters"]["WRITE_SIZE"]
             traffic = round((2.0 * f["sum"] / f["dispatches"] + w["sum"] / w["dispatches"]) * 1024.0)
+            # whole frame: every kernel's FETCH x 2 + WRITE of the profiled run, divided by the frames that run rendered (= raygen dispatches)
+            rg = kernel_record(prof, "raygen")
+            frames_prof = max(1, int(rg["counters"]["FETCH_SIZE"]["dispatches"])) if rg else 1
             tot = 0.0
             for r in prof.values():
                 c = r.get("counters", {})
                 if "FETCH_SIZE" in c and "WRITE_SIZE" in c:
                     tot += (2.0 * c["FETCH_SIZE"]["sum"] + c["WRITE_SIZE"]["sum"]) * 1024.0
+            tot /= frames_prof
             frame_traffic = {"bytes_per_frame": round(tot), "GBs": round(tot / 1e9 / (ms_per_step / 1e3), 1),
                              "frac_of_peak": round(tot / 1e9 / (ms_per_step / 1e3) / HBM_PEAK_GBS, 4), "source": "profiles/" + traffic_src}
         sq, sq_src = load_profile("sq", args.workload)
         rec = kernel_record(sq, dominant)
-        if rec and "SQ_ACTIVE_INST_VALU" in rec["counters"] and "SQ_BUSY_CYCLES" in rec["counters"]:
+        if rec and "SQ_INSTS_VALU" in rec["counters"] and rec.get("total_ms"):
             c = rec["counters"]
-            # SQ_ACTIVE_INST_VALU counts cycles (x4, per SIMD quad) in which a SIMD issues VALU; SQ_BUSY_CYCLES the cycles an SQ is busy (per SE / XCC):
-            # the ratio against SIMD-cycles = busy x (SIMDs per counter instance) is the VALU issue utilisation tools/rocpd_summary.py tabulates
-            bound_actual = {"kind": "valu_issue", "SQ_INSTS_VALU_per_64_rays": round(c["SQ_INSTS_VALU"]["sum"] / max(stats["closest_rays" if dominant == "trace_closest" else "shadow_rays"] / 64.0, 1), 1)
-                            if "SQ_INSTS_VALU" in c else None, "source": "profiles/" + sq_src}
+            rays = stats["closest_rays"] if dominant == "trace_closest" else stats["shadow_rays"] if dominant == "resolve" else stats["vertices"]
+            frames_sq = max(1, int(c["SQ_INSTS_VALU"]["dispatches"]) // max(launches, 1))
+            # what the kernel is really bound by: wave64 VALU instructions issued (SQ_INSTS_VALU) x ~2.7 cycles per instruction (tools/ubench/valu_ubench,
+            # the fma / mul / add rate; conversions and min3 / max3 are slower) over the SIMD cycles of its launches (1024 SIMDs x 2.4 GHz x duration)
+            bound_actual = {"kind": "valu_issue",
+                            "valu_insts_per_64_rays": round(c["SQ_INSTS_VALU"]["sum"] / frames_sq / max(rays / 64.0, 1.0), 1),
+                            "valu_issue_frac_of_simd_cycles": round(c["SQ_INSTS_VALU"]["sum"] * 2.7 / (1024 * rec["total_ms"] * 1e-3 * 2.4e9), 3),
+                            "source": "profiles/" + sq_src}
     roofline = {"bound": "hbm", "kernel": dominant, "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                 "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": traffic, "traffic_source": ("profiles/" + traffic_src) if traffic is not None else None,
                 "algorithmic_bytes_per_launch": round(alg_bytes / launches),
