@@ -290,6 +290,17 @@ int har_render_forward(HarScene scene, HarIntegrator integrator, const HarSensor
                        uint64_t lane_end, const float *tangent_reflectance, const float *const *tangent_textures, const float *tangent_emitters,
                        float *film, void *stream);
 
+/* BASELINE config 1 (`scalar_rgb`, "plumbing, no GPU"): SamplingIntegrator::render's NON-JIT branch on the host
+ * (src/render/integrator.cpp:190-274 block size + seed scaling, src/render/spiral.cpp:27-73, integrator.cpp:398-446 render_block: Morton pixel
+ * order, per-pixel reseed; :448-520 render_sample; ImageBlock::put's scalar branch with the discretised filter, src/render/imageblock.cpp:228-375,
+ * include/mitsuba/core/rfilter.h:70-79; put_block :160-186) for the `path` integrator.  A separate, explicitly named CPU entry point that runs the
+ * same path code as the kernels (host compilation of the HAR_HD headers) with the scalar variants' sampler semantics; the hip_ad_rgb entry points
+ * never call it and never fall back to it.  desc / sensor as for har_scene_create / har_render; film = HOST memory, H x W x 4 {R, G, B, W},
+ * accumulated; block_size 0 = the reference's choice for n_threads workers (0 = all host cores), returned in *block_size_used (may be NULL).
+ * `hide_emitters`, `rgba` films and multi-pass rendering are not part of this entry point. */
+int har_render_scalar(const HarSceneDesc *desc, const HarSensor *sensor, uint32_t seed, uint32_t spp, int32_t max_depth, int32_t rr_depth,
+                      uint32_t block_size, uint32_t n_threads, float *film, uint32_t *block_size_used);
+
 /* SamplingIntegrator::sample(scene, sampler, ray, medium, aovs, active) -> (Spectrum, Mask), array-valued
  * (include/mitsuba/render/integrator.h:432-437; PathIntegrator::sample src/integrators/path.cpp:94-346, PRBIntegrator.sample(mode=Primal)
  * src/python/python/ad/integrators/prb.py:68-339): n rays in (DEVICE, SoA: o, d = 3 x n floats, maxt = n floats), radiance out (rgb = 3 x n) and

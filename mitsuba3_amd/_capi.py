@@ -121,6 +121,7 @@ SIGNATURES = {
     "har_render_weights": (C.c_int, [C.POINTER(HarSensor), C.c_uint32, C.c_uint32, C.c_uint64, C.c_uint64, vp, vp]),
     "har_render_backward": (C.c_int, [vp, vp, C.POINTER(HarSensor), vp, vp, C.c_uint32, C.c_uint32, C.c_uint64,
                                       C.c_uint64, vp, C.POINTER(vp), vp]),
+    "har_render_scalar": (C.c_int, [C.POINTER(HarSceneDesc), C.POINTER(HarSensor), C.c_uint32, C.c_uint32, C.c_int32, C.c_int32, C.c_uint32, C.c_uint32, vp, u32p]),
     "har_render_forward": (C.c_int, [vp, vp, C.POINTER(HarSensor), C.c_uint32, C.c_uint32, C.c_uint64, C.c_uint64, vp, vp, vp, vp, vp]),
     "har_integrator_sample": (C.c_int, [vp, vp, C.c_uint32, C.c_uint32, C.c_uint32, vp, vp, vp, vp, vp, vp, vp, vp]),
     "har_sampler_clone": (C.c_int, [C.c_uint32, vp, vp, vp, vp, vp]),

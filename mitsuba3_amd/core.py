@@ -17,14 +17,16 @@ from . import _capi
 from ._capi import lib, check, HarError
 
 VARIANT = "hip_ad_rgb"
+SCALAR_VARIANT = "scalar_rgb"        # BASELINE config 1: the reference's CPU plumbing path (har_render_scalar), forward `path` renders only
 _variant = None
 
 
 def set_variant(name):
-    """mi.set_variant: only `hip_ad_rgb` is provided by this package."""
+    """mi.set_variant: `hip_ad_rgb` (the HIP hot path; needs a GPU, no fallback) or `scalar_rgb` (config 1: the scalar branch of
+    SamplingIntegrator::render on the host, forward `path` only -- an explicit choice, never a fallback of the former)."""
     global _variant
-    if name != VARIANT:
-        raise ImportError("Requested an unsupported variant \"%s\". The following variants are available: %s." % (name, VARIANT))
+    if name not in (VARIANT, SCALAR_VARIANT):
+        raise ImportError("Requested an unsupported variant \"%s\". The following variants are available: %s, %s." % (name, VARIANT, SCALAR_VARIANT))
     _variant = name
 
 
@@ -33,7 +35,27 @@ def variant():
 
 
 def variants():
-    return [VARIANT]
+    return [VARIANT, SCALAR_VARIANT]
+
+
+def _render_scalar(scene, integrator, sensor, seed, spp, threads=0, block_size=0):
+    """SamplingIntegrator::render, non-JIT branch (integrator.cpp:190-274) through har_render_scalar: developed image as a numpy array"""
+    if integrator.type != 'path':
+        raise RuntimeError("scalar_rgb: only the `path` integrator is part of the config-1 plumbing path")
+    if integrator.hide_emitters or sensor.film().alpha or integrator.samples_per_pass is not None:
+        raise RuntimeError("scalar_rgb: hide_emitters, rgba films and samples_per_pass are not part of the config-1 plumbing path")
+    if spp:
+        sensor.sampler().set_sample_count(spp)
+    spp = sensor.sampler().sample_count()
+    w, h = sensor.film().crop_size()
+    film = np.zeros((h, w, 4), np.float32)
+    d = scene.desc()
+    used = C.c_uint32(0)
+    # the scalar driver passes `seed` through Sampler::seed, which adds the sampler's own `seed` property (sampler.cpp:129-131)
+    check(lib().har_render_scalar(C.byref(d), C.byref(sensor.har), int(seed) & 0xffffffff, spp, integrator.max_depth, integrator.rr_depth, block_size, threads,
+                                   film.ctypes.data_as(C.c_void_p), C.byref(used)))
+    wgt = film[..., 3:4]
+    return film[..., :3] / np.where(wgt == 0, 1.0, wgt).astype(np.float32)
 
 
 def _f32(x):
@@ -1475,6 +1497,10 @@ def render(scene, params=None, sensor=0, integrator=None, seed=0, seed_grad=0, s
         seed_grad = sample_tea_32(seed, 1)[0]
     elif seed_grad == seed:
         raise Exception('The primal and differential seed should be different to ensure unbiased gradient computation!')
+    if _variant == SCALAR_VARIANT:
+        if any(getattr(v, 'requires_grad', False) for v in (params or {}).values()):
+            raise RuntimeError("scalar_rgb renders are not differentiable (the reference's scalar variants have no AD either); use hip_ad_rgb")
+        return _render_scalar(scene, integrator, sensor, seed, spp)
     keys = [k for k, v in (params or {}).items() if getattr(v, 'requires_grad', False)]
     if not keys:
         return integrator.render(scene, sensor, seed, spp)

@@ -36,6 +36,7 @@ struct ShadeParams {
 };
 #define HAR_SHADE_EMITTER_GRADS 1u
 #define HAR_SHADE_FORWARD_MODE 4u    /* adjoint kernels in FORWARD mode (RBIntegrator.render_forward): parameter tangents in, differential radiance out */
+#define HAR_SHADE_SCALAR_DRAWS 8u    /* scalar variants: the two emitter samples are only drawn where the BSDF has a smooth lobe (path.cpp:244-249); JIT variants draw them on every lane */
 #define HAR_SHADE_HIDE_EMITTERS 2u   /* Integrator property `hide_emitters`: the environment is not seen by camera rays (path.cpp:114-115, prb.py:146-148) */
 #define HAR_ITEM_NO_EMITTER 0x7ffu   /* emitter field of an adjoint item's tag: contribution stored as is (no emitter gradient) */
 
@@ -160,7 +161,8 @@ HAR_HD void shade_lane(const DScene &S, const ShadeParams &P, const PathState &s
 
     /* ---- emitter sampling (path.cpp:238-258, prb.py:163-175; scene.cpp:316-366).  The two samples are drawn by
      * every active lane; only BSDFs with a Smooth lobe use them (path.cpp:237, prb.py:169) */
-    float ex = pcg32_next_float(rng, inc), ey = pcg32_next_float(rng, inc);
+    float ex = 0.f, ey = 0.f;
+    if (!(P.flags & HAR_SHADE_SCALAR_DRAWS) || TYPES == HAR_BSDF_ONLY_DIFFUSE || bsdf_is_smooth(B)) { ex = pcg32_next_float(rng, inc); ey = pcg32_next_float(rng, inc); }
     DirSample ds; ds.pdf = 0.f; ds.d = Vec3(0.f); ds.p = Vec3(0.f); ds.n = Vec3(0.f); ds.dist = 0.f;
     Vec3 em_weight(0.f); float em_unit = 0.f; uint32_t em_sampled = 0;
     bool active_em = active_next && S.n_emitters > 0 && (TYPES == HAR_BSDF_ONLY_DIFFUSE || bsdf_is_smooth(B));

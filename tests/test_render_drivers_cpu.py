@@ -4,6 +4,7 @@ block borders (integrator.cpp:190-274,398-446; spiral.cpp:27-73; imageblock.cpp:
 import ctypes as C
 
 import numpy as np
+import pytest
 
 
 def test_morton_and_spiral(O):
@@ -127,3 +128,59 @@ def test_ztest_drivers_agree(O):
     # the test has power: a 5 % brighter image is rejected
     ok, _, _ = ztest.accept(multi * 1.05, 256, ref_mean, ref_var, n_ref)
     assert not ok
+
+
+# ------------------------------------------------------------------ the PRODUCT's scalar path (har_render_scalar, variant 'scalar_rgb')
+
+def _rel_l2(a, b):
+    return float(np.linalg.norm(a.astype(np.float64) - b.astype(np.float64)) / np.linalg.norm(b.astype(np.float64)))
+
+
+def test_product_scalar_path_matches_the_oracle_scalar_driver(O):
+    """config 1 in the product: har_render_scalar (Spiral, Morton order, per-pixel reseed, discretised filter, bordered blocks, put_block; the
+    path code is the host compilation of the kernels' headers with scalar draw semantics) against the oracle's restatement of the same
+    reference code -- same sample streams, so the films agree to rounding; no GPU involved"""
+    import mitsuba3_amd as mi
+    from mitsuba3_amd import core
+    mi.set_variant("scalar_rgb")
+    try:
+        for res, spp, crop, rf in ((48, 16, None, "gaussian"), (40, 8, (7, 5, 21, 30), "gaussian"), (32, 8, None, "box"), (32, 4, None, "tent")):
+            d = mi.cornell_box(); f = d["sensor"]["film"]; f["width"] = res; f["height"] = res; f["rfilter"] = {"type": rf}
+            if crop:
+                f["crop_offset_x"], f["crop_offset_y"], f["crop_width"], f["crop_height"] = crop
+            scene = mi.load_dict(d)
+            osc, sensor = O.scene_from_product(scene)
+            ref, st, bs = osc.render_path_scalar(sensor, seed=3, spp=spp, max_depth=8)
+            img = core._render_scalar(scene, scene.integrator(), scene.sensors()[0], 3, spp, threads=1)
+            assert _rel_l2(img, ref) < 1e-5, (res, spp, crop, rf)
+            img4 = core._render_scalar(scene, scene.integrator(), scene.sensors()[0], 3, spp, threads=8)       # other block size, other put_block order
+            ref4, _, bs4 = osc.render_path_scalar(sensor, seed=3, spp=spp, max_depth=8, n_threads=8)
+            assert _rel_l2(img4, ref4) < 1e-5 and (bs4 != bs or res * res <= 32 * 32 * 8)
+        # mi.render goes through the same entry point under the scalar variant; the KAT of test_integrators.py:28-53 (runs under scalar_rgb too)
+        d = mi.cornell_box(); f = d["sensor"]["film"]; f["width"] = 256; f["height"] = 256
+        f["crop_offset_x"], f["crop_offset_y"], f["crop_width"], f["crop_height"] = 124, 36, 1, 1
+        d["integrator"] = {"type": "path", "max_depth": 1}
+        img = mi.render(mi.load_dict(d), spp=64)
+        assert np.allclose(np.asarray(img).reshape(3), [18.387, 13.9873, 6.75357], rtol=1e-5)
+        # materials (conditional emitter draws where the BSDF has no smooth lobe: dielectric / conductor)
+        d = mi.instanced_spheres_scene(width=24, height=24, spp=8, grid=2, n_u=8, n_v=4, flatten=True, materials=True)
+        scene = mi.load_dict(d)
+        osc, sensor = O.scene_from_product(scene)
+        ref, _, _ = osc.render_path_scalar(sensor, seed=1, spp=8, max_depth=8)
+        img = core._render_scalar(scene, scene.integrator(), scene.sensors()[0], 1, 8, threads=1)
+        assert _rel_l2(img, ref) < 1e-4
+    finally:
+        mi.set_variant("hip_ad_rgb")
+
+
+def test_hip_variant_never_falls_back_to_the_scalar_path():
+    """the scalar entry point is an explicit choice: under `hip_ad_rgb` a render without a GPU is an error, not a CPU render"""
+    import torch
+    import mitsuba3_amd as mi
+    if torch.cuda.is_available():
+        pytest.skip("needs a machine without a GPU")
+    mi.set_variant("hip_ad_rgb")
+    d = mi.cornell_box(); d["sensor"]["film"]["width"] = 8; d["sensor"]["film"]["height"] = 8
+    with pytest.raises(Exception) as e:
+        mi.render(mi.load_dict(d), spp=1)
+    assert "HIP device" in str(e.value) or "no CPU fallback" in str(e.value)
