@@ -335,8 +335,11 @@ __device__ __forceinline__ void trace_persistent(const Accel &A, uint32_t *curso
 }
 
 /* ----------------------------------------------------------- trace_closest */
+#ifndef HAR_TRACE_MIN_WAVES
+#define HAR_TRACE_MIN_WAVES 1     /* __launch_bounds__ waves per SIMD of the traversal kernels (A/B: 7 with an 11-entry LDS stack) */
+#endif
 template <bool SPILL>
-__global__ __launch_bounds__(kBlock) void k_trace_closest(Accel A, const uint32_t *count, uint32_t *cursor, uint32_t shard_cap, const float4 *a0,
+__global__ __launch_bounds__(kBlock, HAR_TRACE_MIN_WAVES) void k_trace_closest(Accel A, const uint32_t *count, uint32_t *cursor, uint32_t shard_cap, const float4 *a0,
                                                           const float4 *a1, float4 *h0, uint2 *h1, int *status, uint2 *spill) {
     __shared__ uint2 lds[HAR_LDS_STACK_SMALL * kBlock];
     typedef typename WaveStackOf<SPILL>::type WaveStack;
@@ -705,7 +708,7 @@ __global__ __launch_bounds__(kBlock) void k_resolve_adjoint_cached(DScene S, con
 
 /* ------------------------------------------------- resolve (shadow rays + NEE) */
 template <int MODE, bool SPILL, bool FWD = false>
-__global__ __launch_bounds__(kBlock) void k_resolve(DScene S, const uint32_t *item_count, uint32_t *cursor, uint32_t shard_cap, ItemArrays items, float4 *result,
+__global__ __launch_bounds__(kBlock, HAR_TRACE_MIN_WAVES) void k_resolve(DScene S, const uint32_t *item_count, uint32_t *cursor, uint32_t shard_cap, ItemArrays items, float4 *result,
                                                     const float4 *dL, float *grad_refl, float *const *grad_tex, int *status, ReplayCache rc, uint2 *spill, uint8_t *item_vis) {
     __shared__ uint2 lds[HAR_LDS_STACK_SMALL * kBlock];
     /* adjoint: per-block accumulators of the constant-albedo gradients.  Every path of the chip adds to the same
