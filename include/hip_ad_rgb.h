@@ -319,6 +319,13 @@ int har_integrator_sample(HarScene scene, HarIntegrator integrator, uint32_t see
 int har_sampler_clone(uint32_t n, const uint64_t *state, const uint64_t *inc, uint64_t *state_dst, uint64_t *inc_dst, void *stream);
 int har_sampler_advance(uint32_t n, uint64_t *state, const uint64_t *inc, void *stream);
 
+/* `prb`: gradients of the NON-colour-slot-0 parameters of the rough BSDF models (src/bsdfs/roughconductor.cpp:226-520 `alpha` / `alpha_u` /
+ * `alpha_v`, `eta`, `k`; src/bsdfs/roughplastic.cpp:244-420 `alpha`, `specular_reflectance`) for the following har_render_backward calls.
+ * grad = DEVICE buffer of bsdf_count x 15 floats, ACCUMULATED into: per BSDF record five groups of three channel contributions --
+ * [0..2] alpha_u (sum the three for the scalar; roughplastic's single `alpha` is reported here), [3..5] alpha_v, [6..8] eta (RGB), [9..11] k (RGB),
+ * [12..14] colour slot 1 (roughplastic.specular_reflectance).  NULL switches it off (default).  Needs the replay cache (default) and
+ * max_depth <= 12; delta lobes and the `eta` of plastic / rough plastic carry no gradient (as in the reference). */
+int har_integrator_set_grad_bsdf_params(HarIntegrator integrator, float *grad);
 /* counters of the last har_render / har_render_backward on this integrator (synchronises) */
 int har_render_stats(HarIntegrator integrator, HarStats *out);
 /* HIP-event timing of the render calls ("frames") issued since har_integrator_set_profiling(.., 1): one event per kernel launch, recorded on

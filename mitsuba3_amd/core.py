@@ -598,7 +598,7 @@ class BSDF:
         else:
             raise RuntimeError("Plugin \"%s\" not found for variant hip_ad_rgb (textures: rgb, bitmap)" % refl['type'])
         self.value2 = _rgb_value(props.get(slot1[0]), slot1[1]) if slot1 else _f32([0, 0, 0])
-        self.flags = 0; self.alpha_u = self.alpha_v = 0.1; self.eta = 1.0
+        self.flags = 0; self.alpha_u = self.alpha_v = 0.1; self.eta = 1.0; self.anisotropic = False
         self.eta_c = _f32([0, 0, 0]); self.k_c = _f32([1, 1, 1]); self.back = None
         if self.kind in ('roughconductor', 'roughplastic'):          # MicrofacetDistribution(props), microfacet.h:103-144
             distr = str(props.get('distribution', 'beckmann')).lower()
@@ -613,7 +613,7 @@ class BSDF:
                     raise RuntimeError("Microfacet model: both 'alpha_u' and 'alpha_v' must be specified.")
                 if 'alpha' in props:
                     raise RuntimeError("Microfacet model: please specifyeither 'alpha' or 'alpha_u'/'alpha_v'.")
-                self.alpha_u = float(props['alpha_u']); self.alpha_v = float(props['alpha_v'])
+                self.alpha_u = float(props['alpha_u']); self.alpha_v = float(props['alpha_v']); self.anisotropic = True
             else:
                 self.alpha_u = self.alpha_v = float(props.get('alpha', 0.1))
         if self.kind in ('roughconductor', 'conductor'):             # roughconductor.cpp:163-172, conductor.cpp:228-237
@@ -748,7 +748,7 @@ class Integrator:
     def __init__(self, props):
         self.type = props['type']
         # integrator.cpp:26-33,128-147,539-550; block_size only shapes the scalar / LLVM-parallel drivers; the last four are hip_ad_rgb extensions
-        _check_props(self.type, props, ('max_depth', 'rr_depth', 'hide_emitters', 'samples_per_pass', 'block_size', 'chunk_lanes', 'replay_cache', 'emitter_gradients', 'shape_gradients'),
+        _check_props(self.type, props, ('max_depth', 'rr_depth', 'hide_emitters', 'samples_per_pass', 'block_size', 'chunk_lanes', 'replay_cache', 'emitter_gradients', 'shape_gradients', 'bsdf_parameter_gradients'),
                      unsupported=(('timeout', -1.0),))
         default_depth = -1 if self.type == 'path' else 6        # integrator.cpp:539, common.py:31
         self.max_depth = int(props.get('max_depth', default_depth))
@@ -764,6 +764,8 @@ class Integrator:
         # d / d vertex positions (har_integrator_set_grad_positions): False, True (every eligible mesh) or a list of '<shape>.vertex_positions' keys --
         # the stand-in for dr.enable_grad(params[key]) of the reference
         self.shape_gradients = props.get('shape_gradients', False)
+        # gradients of `alpha` / `alpha_u` / `alpha_v`, `eta`, `k` (roughconductor) and `alpha`, `specular_reflectance` (roughplastic): har_integrator_set_grad_bsdf_params
+        self.bsdf_parameter_gradients = bool(props.get('bsdf_parameter_gradients', False))
         # SamplingIntegrator property (integrator.cpp:140-147); the Python AD integrators do not query it, and an
         # unqueried property is an error in the reference's plugin loader
         self.samples_per_pass = props.get('samples_per_pass', None)
@@ -928,9 +930,16 @@ class Integrator:
             check(lib().har_integrator_set_grad_positions(self._handle(), scene._handle(), pp if g_pos else None))
         else:
             check(lib().har_integrator_set_grad_positions(self._handle(), None, None))
+        g_extra = torch.zeros((max(1, len(scene.bsdfs)), 15), dtype=torch.float32, device=dev) if self.bsdf_parameter_gradients else None
+        check(lib().har_integrator_set_grad_bsdf_params(self._handle(), _ptr(g_extra) if g_extra is not None else None))
         check(lib().har_render_backward(scene._handle(), self._handle(), C.byref(sensor.har), _ptr(grad_in), _ptr(weight_film), sd, spp,
                                         lb, le, _ptr(g_refl), ptrs, _stream()))
         out = scene._gradients(g_refl, g_tex, g_emit if self.emitter_gradients else None)
+        if g_extra is not None:
+            for k, (what, b) in scene._bsdf_param_keys().items():
+                rec = g_extra[b.index]
+                out[k] = {"alpha": rec[0:6].sum().reshape(1), "alpha_u": rec[0:3].sum().reshape(1), "alpha_v": rec[3:6].sum().reshape(1),
+                          "eta": rec[6:9], "k": rec[9:12], "slot1": rec[12:15]}[what]
         out.update(g_pos)
         return out
 
@@ -1247,6 +1256,45 @@ class Scene:
                 keys[key + ".radiance.value"] = ("emit", i)
         return keys
 
+    def _bsdf_param_keys(self):
+        """the non-slot-0 parameters of the rough models: '<bsdf>.alpha.value' (or alpha_u / alpha_v), '<bsdf>.eta.value', '<bsdf>.k.value' of
+        roughconductor (roughconductor.cpp:226-250 traverse), '<bsdf>.alpha.value' and '<bsdf>.specular_reflectance.value' of roughplastic"""
+        keys = {}
+        for b in self.bsdf_objs:
+            base = b.id if b.id else "bsdf%d" % b.index
+            if b.kind in ('roughconductor', 'roughplastic'):
+                if b.anisotropic:
+                    keys[base + ".alpha_u.value"] = ("alpha_u", b); keys[base + ".alpha_v.value"] = ("alpha_v", b)
+                else:
+                    keys[base + ".alpha.value"] = ("alpha", b)
+            if b.kind == 'roughconductor':
+                keys[base + ".eta.value"] = ("eta", b); keys[base + ".k.value"] = ("k", b)
+            if b.kind == 'roughplastic' and b.slot1_name:
+                keys[base + "." + b.slot1_name + ".value"] = ("slot1", b)
+        return keys
+
+    def _bsdf_param_value(self, what, b):
+        return {"alpha": [b.alpha_u], "alpha_u": [b.alpha_u], "alpha_v": [b.alpha_v], "eta": b.eta_c, "k": b.k_c, "slot1": b.value2}[what]
+
+    def _set_bsdf_param(self, what, b, v):
+        """params.update() of a non-slot-0 BSDF parameter: the record is re-lowered with the next scene handle (roughplastic's sampling weights and
+        transmittance tables depend on alpha / the colours: RoughPlastic::parameters_changed, roughplastic.cpp:204-242)"""
+        v = np.asarray(v, np.float32).reshape(-1)
+        if what == "alpha":
+            b.alpha_u = b.alpha_v = float(v[0])
+        elif what == "alpha_u":
+            b.alpha_u = float(v[0])
+        elif what == "alpha_v":
+            b.alpha_v = float(v[0])
+        elif what == "eta":
+            b.eta_c = _f32(v[:3])
+        elif what == "k":
+            b.k_c = _f32(v[:3])
+        else:
+            b.value2 = _f32(v[:3])
+        if self._h is not None:
+            lib().har_scene_destroy(self._h); self._h = None
+
     def _position_keys(self):
         """'<shape>.vertex_positions' (flat 3 N floats as in the reference's Mesh::traverse) of the top-level meshes without vertex normals"""
         return {m["key"] + ".vertex_positions": i for i, m in enumerate(self.meshes[:self.top_mesh_count]) if not (m["flags"] & 1) and m["V"].shape[0]}
@@ -1280,6 +1328,8 @@ class SceneParameters(dict):
         for k, (kind, b) in scene._param_keys().items():
             value = scene.emitters[b]["radiance"] if kind == "emit" else (b.texture if kind == "tex" else b.value)
             self[k] = torch.tensor(np.asarray(value, np.float32), dtype=torch.float32, device=dev)
+        for k, (what, b) in scene._bsdf_param_keys().items():
+            self[k] = torch.tensor(np.asarray(scene._bsdf_param_value(what, b), np.float32), dtype=torch.float32, device=dev)
         for k, m in scene._position_keys().items():
             self[k] = torch.tensor(np.ascontiguousarray(scene.meshes[m]["V"][:, :3]).reshape(-1), dtype=torch.float32, device=dev)
 
@@ -1291,6 +1341,10 @@ class SceneParameters(dict):
             v = self[k].detach().to("cpu", copy=True).numpy().astype(np.float32).reshape(-1, 3)
             if not np.array_equal(v, self.scene.meshes[m]["V"][:, :3]):
                 self.scene._set_vertex_positions(m, v)
+        for k, (what, b) in self.scene._bsdf_param_keys().items():
+            v = self[k].detach().to("cpu", copy=True).numpy().astype(np.float32).reshape(-1)
+            if not np.array_equal(v, np.asarray(self.scene._bsdf_param_value(what, b), np.float32).reshape(-1)):
+                self.scene._set_bsdf_param(what, b, v)
         for k, (kind, b) in self.scene._param_keys().items():
             v = self[k].detach().to("cpu", copy=True).numpy().astype(np.float32)
             if kind == "emit":

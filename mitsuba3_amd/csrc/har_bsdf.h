@@ -75,6 +75,33 @@ HAR_HD float fresnel_conductor(float cos_theta_i, float eta_r, float eta_i) {
     return 0.5f * (r_s + r_p);
 }
 
+/* fresnel_conductor and its derivatives w.r.t. eta (real part) and k (imaginary part): forward-mode chain rule through the function above */
+HAR_HD float fresnel_conductor_grad(float cos_theta_i, float eta_r, float eta_i, float &dF_deta, float &dF_dk) {
+    const float c2 = cos_theta_i * cos_theta_i, s2 = 1.f - c2, s4 = s2 * s2;
+    const float temp_1 = eta_r * eta_r - eta_i * eta_i - s2;
+    const float rad = temp_1 * temp_1 + 4.f * eta_i * eta_i * eta_r * eta_r;
+    const float ab = safe_sqrt_(rad);                                   /* a^2 + b^2 */
+    const float a = safe_sqrt_(.5f * (ab + temp_1));
+    const float term_1 = ab + c2, term_2 = 2.f * cos_theta_i * a;
+    const float r_s = (term_1 - term_2) / (term_1 + term_2);
+    const float term_3 = ab * c2 + s4, term_4 = term_2 * s2;
+    const float q = (term_3 - term_4) / (term_3 + term_4), r_p = r_s * q;
+    float out[2];
+    for (int k = 0; k < 2; ++k) {                                       /* k = 0: d / d eta_r, 1: d / d eta_i */
+        const float d_temp_1 = k == 0 ? 2.f * eta_r : -2.f * eta_i;
+        const float d_rad = 2.f * temp_1 * d_temp_1 + (k == 0 ? 8.f * eta_i * eta_i * eta_r : 8.f * eta_i * eta_r * eta_r);
+        const float d_ab = ab > 0.f ? .5f * d_rad / ab : 0.f;
+        const float d_a = a > 0.f ? .25f * (d_ab + d_temp_1) / a : 0.f;
+        const float d_t1 = d_ab, d_t2 = 2.f * cos_theta_i * d_a;
+        const float d_rs = ((d_t1 - d_t2) * (term_1 + term_2) - (term_1 - term_2) * (d_t1 + d_t2)) / sqr_(term_1 + term_2);
+        const float d_t3 = d_ab * c2, d_t4 = d_t2 * s2;
+        const float d_q = ((d_t3 - d_t4) * (term_3 + term_4) - (term_3 - term_4) * (d_t3 + d_t4)) / sqr_(term_3 + term_4);
+        out[k] = .5f * (d_rs + d_rs * q + r_s * d_q);
+    }
+    dF_deta = out[0]; dF_dk = out[1];
+    return .5f * (r_s + r_p);
+}
+
 HAR_HD Vec3 reflect_local(Vec3 wi) { return Vec3(-wi.x, -wi.y, wi.z); }                                        /* fresnel.h:276 */
 HAR_HD Vec3 reflect_m(Vec3 wi, Vec3 m) { float k = 2.f * dot3(wi, m); return Vec3(fms_(m.x, k, wi.x), fms_(m.y, k, wi.y), fms_(m.z, k, wi.z)); }   /* :282 */
 HAR_HD Vec3 refract_local(Vec3 wi, float cos_theta_t, float eta_ti) { return Vec3(-eta_ti * wi.x, -eta_ti * wi.y, cos_theta_t); }                   /* :293 */
@@ -122,6 +149,36 @@ struct Microfacet {
         return result;
     }
     HAR_HD float G(Vec3 wi, Vec3 wo, Vec3 m) const { return smith_g1(wi, m) * smith_g1(wo, m); }
+    /* d ln D(m) / d alpha_u, d alpha_v (hand-derived from eval() above; zero where eval() clamps D to zero or alpha to 1e-4):
+     *   Beckmann: ln D = -(x^2/au^2 + y^2/av^2)/c^2 - ln(pi au av c^4);   GGX: ln D = -ln(pi au av) - 2 ln(x^2/au^2 + y^2/av^2 + z^2) */
+    HAR_HD void dlog_eval(Vec3 m, float &du, float &dv) const {
+        const float c2 = sqr_(m.z);
+        if (!ggx) { du = 2.f * sqr_(m.x) / (alpha_u * alpha_u * alpha_u * c2) - 1.f / alpha_u; dv = 2.f * sqr_(m.y) / (alpha_v * alpha_v * alpha_v * c2) - 1.f / alpha_v; }
+        else {
+            const float S = sqr_(m.x / alpha_u) + sqr_(m.y / alpha_v) + c2;
+            du = 4.f * sqr_(m.x) / (alpha_u * alpha_u * alpha_u * S) - 1.f / alpha_u; dv = 4.f * sqr_(m.y) / (alpha_v * alpha_v * alpha_v * S) - 1.f / alpha_v;
+        }
+    }
+    /* d ln G1(v, m) / d alpha_u, d alpha_v: G1 is a function of t = (au^2 vx^2 + av^2 vy^2) / vz^2 */
+    HAR_HD void dlog_smith_g1(Vec3 v, Vec3 m, float &du, float &dv) const {
+        du = 0.f; dv = 0.f;
+        const float xy_alpha_2 = sqr_(alpha_u * v.x) + sqr_(alpha_v * v.y), inv_z2 = 1.f / sqr_(v.z), t = xy_alpha_2 * inv_z2;
+        if (xy_alpha_2 == 0.f || dot3(v, m) * v.z <= 0.f) return;
+        float dG_dt, G1;
+        if (!ggx) {
+            const float a = rsqrt_(t), a2 = a * a;
+            if (a >= 1.6f) return;                                                     /* the rational fit is cut off at 1 */
+            const float num = 3.535f * a + 2.181f * a2, den = 1.f + 2.276f * a + 2.577f * a2;
+            G1 = num / den;
+            const float dG_da = ((3.535f + 4.362f * a) * den - num * (2.276f + 5.154f * a)) / (den * den);
+            dG_dt = dG_da * (-.5f * a / t);                                            /* a = t^(-1/2) */
+        } else {
+            const float sq = sqrtf(1.f + t);
+            G1 = 2.f / (1.f + sq); dG_dt = -1.f / (sq * sqr_(1.f + sq));
+        }
+        const float k = dG_dt / G1;
+        du = k * 2.f * alpha_u * sqr_(v.x) * inv_z2; dv = k * 2.f * alpha_v * sqr_(v.y) * inv_z2;
+    }
     HAR_HD float pdf(Vec3 wi, Vec3 m) const {                                          /* :219-228 */
         float result = eval(m);
         if (sample_visible) result *= smith_g1(wi, m) * fabsf(dot3(wi, m)) / wi.z; else result *= m.z;
@@ -288,6 +345,42 @@ HAR_HD void bsdf_eval_pdf_one(const DBsdf &B, const BsdfInputs &in, Vec3 wi, Vec
         prob_diffuse = prob_diffuse / (prob_specular + prob_diffuse);
         e.pdf = hemi_pdf * prob_diffuse;
     } break;
+    }
+}
+
+/* Derivatives of eval()'s value (f * cos theta_o, per channel) with respect to the NON-colour parameters of the rough models -- what the PRB adjoint
+ * needs beyond d_slot0 / d_slot1 (prb.py:288-313 with `alpha`, `eta`, `k` attached; roughconductor.cpp:429-520, roughplastic.cpp:296-336):
+ *   d_alpha_u / d_alpha_v : every channel scales with D * G, so d value_c = value_spec_c * d ln(D G)
+ *   d_eta / d_k           : roughconductor's complex IOR, channel-diagonal through the conductor Fresnel term
+ * (roughplastic's `eta` and its transmittance tables are not differentiable in the reference either: ScalarFloat members.) */
+struct BsdfEvalExtra { Vec3 d_alpha_u, d_alpha_v, d_eta, d_k; };
+HAR_HD void bsdf_eval_extra_one(const DBsdf &B, const BsdfInputs &in, Vec3 wi, Vec3 wo, BsdfEvalExtra &x) {
+    x.d_alpha_u = Vec3(0.f); x.d_alpha_v = Vec3(0.f); x.d_eta = Vec3(0.f); x.d_k = Vec3(0.f);
+    const float cos_theta_i = wi.z, cos_theta_o = wo.z;
+    if (!(cos_theta_i > 0.f && cos_theta_o > 0.f)) return;
+    if (B.type == BSDF_ROUGHCONDUCTOR) {
+        const Vec3 H = normalize3(wo + wi);
+        if (!(dot3(wi, H) > 0.f && dot3(wo, H) > 0.f)) return;
+        Microfacet distr((B.flags & BF_GGX) != 0, B.alpha_u, B.alpha_v, (B.flags & BF_SAMPLE_VISIBLE) != 0);
+        const float D = distr.eval(H);
+        if (D == 0.f) return;
+        const float V = D * distr.G(wi, wo, H) / (4.f * cos_theta_i), c = dot3(wi, H);
+        float du, dv, gu, gv, hu, hv; distr.dlog_eval(H, du, dv); distr.dlog_smith_g1(wi, H, gu, gv); distr.dlog_smith_g1(wo, H, hu, hv);
+        float Fc[3], dE[3], dK[3];
+        for (int k = 0; k < 3; ++k) Fc[k] = fresnel_conductor_grad(c, B.eta_c[k], B.k_c[k], dE[k], dK[k]);
+        const Vec3 F(Fc[0], Fc[1], Fc[2]), value = (F * V) * in.slot0;
+        x.d_alpha_u = value * (du + gu + hu); x.d_alpha_v = value * (dv + gv + hv);
+        x.d_eta = (Vec3(dE[0], dE[1], dE[2]) * V) * in.slot0; x.d_k = (Vec3(dK[0], dK[1], dK[2]) * V) * in.slot0;
+    } else if (B.type == BSDF_ROUGHPLASTIC) {
+        Microfacet distr((B.flags & BF_GGX) != 0, B.alpha_u, B.alpha_u, (B.flags & BF_SAMPLE_VISIBLE) != 0);
+        const Vec3 H = normalize3(wo + wi);
+        const float D = distr.eval(H);
+        if (D == 0.f) return;
+        float F, ct, eit, eti; fresnel_dielectric(dot3(wi, H), B.eta, F, ct, eit, eti);
+        const float spec = F * D * distr.G(wi, wo, H) / (4.f * cos_theta_i);
+        float du, dv, gu, gv, hu, hv; distr.dlog_eval(H, du, dv); distr.dlog_smith_g1(wi, H, gu, gv); distr.dlog_smith_g1(wo, H, hu, hv);
+        /* one `alpha` for both axes: d / d alpha = d / d alpha_u + d / d alpha_v, reported in d_alpha_u */
+        x.d_alpha_u = (in.slot1 * spec) * ((du + gu + hu) + (dv + gv + hv));
     }
 }
 

@@ -129,6 +129,7 @@ struct HarIntegratorImpl {
     float *adj = nullptr; size_t adj_floats = 0;
     float *grad_slots = nullptr; size_t grad_slots_cap = 0;   /* adjoint accumulators: (bsdf_count + emitter_count) x 3 */
     float *grad_emitters = nullptr;       /* user buffer (DEVICE, emitter_count x 3) of har_integrator_set_grad_emitters, or null */
+    float *grad_bsdf_params = nullptr;    /* user buffer (DEVICE, bsdf_count x 15) of har_integrator_set_grad_bsdf_params, or null */
     /* vertex-position gradients (har_integrator_set_grad_positions): user buffers per top-level mesh, the flat accumulation buffer + offsets */
     bool shape_on = false; std::vector<float *> pos_user; std::vector<int32_t> pos_offset; std::vector<uint32_t> pos_count;
     int32_t *d_pos_offset = nullptr; float *grad_pos = nullptr; uint32_t pos_verts = 0; ShapeArrays geo{};
@@ -353,7 +354,7 @@ int run_chunk(HarSceneImpl *S, HarIntegratorImpl *I, const DSensor &C, int mode,
     prof_mark(I, s, CLS_RAYGEN);
     const bool fwd = mode == MODE_PRB_ADJOINT && I->forward_mode;
     ShadeParams P{ seed, I->max_depth, I->rr_depth, ((mode == MODE_PRB_ADJOINT && I->grad_emitters) ? HAR_SHADE_EMITTER_GRADS : 0u) | (I->hide_emitters ? HAR_SHADE_HIDE_EMITTERS : 0u) |
-                   (fwd ? HAR_SHADE_FORWARD_MODE : 0u) };
+                   (fwd ? HAR_SHADE_FORWARD_MODE : 0u) | ((mode == MODE_PRB_ADJOINT && I->grad_bsdf_params && !fwd) ? HAR_SHADE_EXTRA_GRADS : 0u) };
     /* grid: a multiple of 8 so that block b serves shard b % 8; enough blocks to cover the chunk once */
     const uint32_t grid = std::max<uint32_t>(HAR_SHARDS, std::min<uint32_t>(((n + 255) / 256 + HAR_SHARDS - 1) / HAR_SHARDS * HAR_SHARDS, 4096u));
     /* persistent traversal kernels: enough blocks to fill the chip (<= 8 blocks/CU), never more than the work */
@@ -415,7 +416,7 @@ int run_chunk(HarSceneImpl *S, HarIntegratorImpl *I, const DSensor &C, int mode,
         if (queued) HIP_TRY(hipMemsetAsync(I->tq.count, 0, (size_t) HAR_SHARDS * I->tq.nq * HAR_COUNTER_STRIDE * sizeof(uint32_t), s));
         launch_shade(mode, s, grid, S->ds, P, lane_base, I->shard_cap, cnt_alive(I, b), I->st[cur], I->h0, I->h1, I->st[cur ^ 1], cnt_alive(I, b + 1),
                      I->items, cnt_items(I, b), I->result, rc, ps.rng, I->dL, grad_refl, shape ? &I->geo : nullptr, inline_commit && rc.mode == 2 ? I->d_grad_tex : nullptr,
-                     queued ? &I->tq : nullptr);
+                     queued ? &I->tq : nullptr, (inline_commit && rc.mode == 2) ? I->grad_bsdf_params : nullptr);
         prof_mark(I, s, CLS_SHADE);
         if (queued) {
             static const uint32_t bpq_env = getenv("HAR_TQ_BPQ") ? (uint32_t) atoi(getenv("HAR_TQ_BPQ")) : 0u;
@@ -762,7 +763,7 @@ static uint64_t dual_split(HarIntegrator I, uint64_t lb, uint64_t le, hipStream_
     }
     HarIntegratorImpl *T = I->twin;
     T->type = I->type; T->max_depth = I->max_depth; T->rr_depth = I->rr_depth; T->chunk = I->chunk; T->samples_per_pass = I->samples_per_pass;
-    T->grad_emitters = I->grad_emitters; T->profiling = I->profiling; T->hide_emitters = I->hide_emitters;
+    T->grad_emitters = I->grad_emitters; T->grad_bsdf_params = I->grad_bsdf_params; T->profiling = I->profiling; T->hide_emitters = I->hide_emitters;
     T->alpha_film = I->alpha_film;
     if (T->use_cache != I->use_cache) { (void) hipDeviceSynchronize(); T->free_ws(); T->use_cache = I->use_cache; }
     if (hipEventRecord(I->ev_fork, s) != hipSuccess || hipStreamWaitEvent(I->side_stream, I->ev_fork, 0) != hipSuccess) return le;
@@ -920,6 +921,13 @@ static int backward_range(HarScene S, HarIntegrator I, const HarSensor *sensor, 
         HIP_TRY(hipMemcpyAsync(I->d_grad_tex, grad_textures, nt * sizeof(float *), hipMemcpyHostToDevice, s));
         HIP_TRY(hipStreamSynchronize(s));
     }
+    if (I->grad_bsdf_params) {
+        /* the alpha / eta / k / slot-1 terms are committed in place by the cached-bounce shading kernel only */
+        if (!I->use_cache || I->shape_on) return fail("gradients of alpha / eta / k / specular colours need the replay cache and cannot be combined with vertex-position gradients");
+        if (bounce_limit(I) > HAR_REPLAY_CACHE_BOUNCES) return fail("gradients of alpha / eta / k / specular colours: max_depth must not exceed " + std::to_string(HAR_REPLAY_CACHE_BOUNCES) + " (the cached bounces)");
+        static const bool inline_env = getenv("HAR_ADJOINT_INLINE") ? atoi(getenv("HAR_ADJOINT_INLINE")) != 0 : true;
+        if (!inline_env) return fail("gradients of alpha / eta / k / specular colours need the in-place commit (HAR_ADJOINT_INLINE=0 is set)");
+    }
     if (ensure_texel_queues(S, I)) return 1;
     /* the kernels accumulate into (bsdf_count + emitter_count) x 3 slots; the two halves are added to the caller's buffers at the end */
     const size_t nb3 = 3 * S->hs.bsdfs.size(), ne3 = 3 * S->hs.emitters.size();
@@ -1025,6 +1033,13 @@ int har_integrator_set_grad_positions(HarIntegrator I, HarScene S, float *const 
         I->free_ws();
     }
     I->pos_user = user; I->pos_offset = offset; I->pos_count = count; I->pos_verts = verts; I->shape_on = verts != 0;
+    return 0;
+}
+
+int har_integrator_set_grad_bsdf_params(HarIntegrator I, float *grad) {
+    if (!I) return fail("null integrator");
+    if (I->type != HAR_INTEGRATOR_PRB) return fail("BSDF parameter gradients are computed by the `prb` integrator");
+    I->grad_bsdf_params = grad;
     return 0;
 }
 

@@ -19,6 +19,7 @@
 #endif
 #define HAR_REPLAY_CACHE_BOUNCES 12 /* PRB replay cache depth (25 B per lane and bounce); deeper bounces are traced twice */
 #define HAR_LDS_GRAD_BSDFS 256     /* constant-albedo (and emitter-radiance) gradient slots accumulated per block in LDS (adjoint resolve) */
+#define HAR_LDS_EXTRA_BSDFS 16      /* BSDF records whose alpha / eta / k / slot-1 gradients (15 floats each) are accumulated per block in LDS */
 #define HAR_LDS_GRAD_EMITTERS 32    /* emitter-radiance gradients of emission hits accumulated per block in LDS (adjoint shade) */
 #define HAR_SHARDS 8                /* XCD-private path queues */
 #define HAR_MAX_TRAVERSAL_BLOCKS 2048 /* persistent traversal kernels: enough blocks to fill the chip (<= 8 blocks/CU) */
@@ -93,7 +94,8 @@ void launch_shade(int mode, hipStream_t s, uint32_t grid, const DScene &S, const
                   const WaveState &in, const float4 *h0, const uint2 *h1, const WaveState &out, uint32_t *count_out, const ItemArrays &items,
                   uint32_t *item_count, float4 *result, const ReplayCache &rc, uint64_t *pass_rng = nullptr, const float4 *dL = nullptr, float *grad_slots = nullptr,
                   const ShapeArrays *geo = nullptr, float *const *grad_tex_inline = nullptr,       /* grad_tex_inline (adjoint, cached bounce): commit the vertex adjoint in place, no items */
-                  const TexelQueues *tq = nullptr);                                                /* ... with the texel gradients going through the queues */
+                  const TexelQueues *tq = nullptr,                                                 /* ... with the texel gradients going through the queues */
+                  float *grad_extra = nullptr);                                                    /* ... plus 15 floats per BSDF record: d / d {alpha_u, alpha_v, eta, k, slot 1} */
 /* the records of one bounce -> LDS band copies -> grad_tex (see TexelQueues); blocks_per_queue blocks share a queue */
 void launch_texel_accumulate(hipStream_t s, const TexelQueues &tq, float *const *grad_tex, uint32_t blocks_per_queue, uint32_t lds_bytes);
 void launch_resolve(int mode, hipStream_t s, uint32_t grid, uint2 *spill, const DScene &S, const uint32_t *item_count, uint32_t *cursor, uint32_t shard_cap, const ItemArrays &items,

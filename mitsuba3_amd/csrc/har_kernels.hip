@@ -485,12 +485,16 @@ __device__ __forceinline__ void adjoint_commit(const DScene &S, const ItemArrays
 /* ------------------------------------------------------------------- shade */
 /* INLINE (adjoint replay of a bounce whose shadow-ray results sit in the replay cache): the visibility of the lane's emitter sample is known here,
  * so the vertex's adjoint is committed on the spot instead of going through an item (80 B written + read) and k_resolve_adjoint_cached */
-template <int MODE, uint32_t TYPES, bool SHAPE = false, bool INLINE = false>
+template <int MODE, uint32_t TYPES, bool SHAPE = false, bool INLINE = false, bool EXTRA = false>
 __global__ __launch_bounds__(kBlock, HAR_SHADE_MIN_WAVES) void k_shade(DScene S, ShadeParams P, uint32_t lane_base, uint32_t shard_cap, const uint32_t *count_in, WaveState in,
                                                   const float4 *h0, const uint2 *h1, WaveState out, uint32_t *count_out,
                                                   ItemArrays items, uint32_t *item_count, float4 *result, ReplayCache rc, uint64_t *pass_rng,
-                                                  const float4 *dL, float *grad_slots, ShapeArrays geo, float *const *grad_tex, TexelQueues tq) {
+                                                  const float4 *dL, float *grad_slots, ShapeArrays geo, float *const *grad_tex, TexelQueues tq, float *grad_extra) {
     __shared__ uint32_t lds_r[12];
+    /* EXTRA: gradients w.r.t. alpha_u, alpha_v, eta, k, colour slot 1 of the rough BSDF records (15 floats per record): per-block accumulators for
+     * the first HAR_LDS_EXTRA_BSDFS records, global atomics beyond */
+    __shared__ float xacc[EXTRA ? 15 * HAR_LDS_EXTRA_BSDFS : 1];
+    if (EXTRA) { for (uint32_t k = threadIdx.x; k < 15 * HAR_LDS_EXTRA_BSDFS; k += kBlock) xacc[k] = 0.f; __syncthreads(); }
     __shared__ uint32_t tq_hist[INLINE ? HAR_TQ_MAX : 1], tq_base[INLINE ? HAR_TQ_MAX : 1];
     __shared__ float gacc[INLINE ? 3 * HAR_LDS_GRAD_BSDFS : 1];
     if (INLINE) { for (uint32_t k = threadIdx.x; k < 3 * HAR_LDS_GRAD_BSDFS; k += kBlock) gacc[k] = 0.f; __syncthreads(); }
@@ -542,7 +546,7 @@ __global__ __launch_bounds__(kBlock, HAR_SHADE_MIN_WAVES) void k_shade(DScene S,
             else { hh = h0[HIT0(i)]; hs = h1[HIT1(i)]; }
             if (MODE == MODE_PRB_PRIMAL && rc.mode == 1) { rc.h0[st.lane - lane_base] = hh; rc.h1[st.lane - lane_base] = hs; }
             Hit hit; hit.t = hh.x; hit.u = hh.y; hit.v = hh.z; hit.prim = __float_as_uint(hh.w); hit.shape = hs.x; hit.inst = hs.y;
-            shade_lane<MODE, TYPES>(S, P, st, hit, R);
+            shade_lane<MODE, TYPES, EXTRA>(S, P, st, hit, R);
             lane = st.lane - lane_base;
             if (MODE == MODE_PATH && pass_rng && !R.alive) {
                 /* multi-pass render: the path ends here, its sampler lives on.  A lane that starts a loop iteration draws all six
@@ -580,6 +584,19 @@ __global__ __launch_bounds__(kBlock, HAR_SHADE_MIN_WAVES) void k_shade(DScene S,
             adjoint_commit_values(S, item_pred, visible, lane, make_float4(c.x, c.y, c.z, __uint_as_float(tag)), make_float4(R.dLr_drho.x, R.dLr_drho.y, R.dLr_drho.z, R.uv_x),
                                   make_float4(R.rel_grad.x, R.rel_grad.y, R.rel_grad.z, R.uv_y), result, dL, grad_slots, grad_tex, gacc,      /* forward mode never commits in place (host) */
                                   tq.nq ? &tq : nullptr, tq.nq ? &rec : nullptr);
+            if (EXTRA && item_pred) {
+                /* the same two terms as for slot 0 (adjoint_commit_values), for the five other parameter groups: g = dL * ([visible] d Lr_dir / d theta
+                 * + [path continues] L * (d f / d theta) / f), with L already reduced by this vertex's Lr_dir */
+                const float4 L = result[lane], dl = dL[lane];
+                for (int g = 0; g < HAR_EXTRA_GROUPS; ++g) {
+                    Vec3 v = visible ? R.x_dir[g] : Vec3(0.f);
+                    if (R.x_ind) v = v + Vec3(L.x * R.x_rel[g].x, L.y * R.x_rel[g].y, L.z * R.x_rel[g].z);
+                    v = v * Vec3(dl.x, dl.y, dl.z);
+                    if (v.x == 0.f && v.y == 0.f && v.z == 0.f) continue;
+                    if (R.bsdf < HAR_LDS_EXTRA_BSDFS) { float *a = xacc + 15 * R.bsdf + 3 * g; atomicAdd(a, v.x); atomicAdd(a + 1, v.y); atomicAdd(a + 2, v.z); }
+                    else { float *a = grad_extra + 15 * (size_t) R.bsdf + 3 * g; atomicAdd(a, v.x); atomicAdd(a + 1, v.y); atomicAdd(a + 2, v.z); }
+                }
+            }
             item_pred = false;
             if (tq.nq) {
                 /* append the block's texel records to their band queues (TexelQueues): LDS histogram -> one global atomic per non-empty band -> scattered 32-byte records */
@@ -641,6 +658,11 @@ __global__ __launch_bounds__(kBlock, HAR_SHADE_MIN_WAVES) void k_shade(DScene S,
             const float v = gacc[k];
             if (v != 0.f) atomicAdd(grad_slots + k, v);
         }
+        if (EXTRA)
+            for (uint32_t k = threadIdx.x; k < 15 * min(S.n_bsdfs, (uint32_t) HAR_LDS_EXTRA_BSDFS); k += kBlock) {
+                const float v = xacc[k];
+                if (v != 0.f) atomicAdd(grad_extra + k, v);
+            }
     }
 }
 
@@ -1148,7 +1170,7 @@ void launch_trace_closest(hipStream_t s, uint32_t grid, uint2 *spill, const Acce
 void launch_shade(int mode, hipStream_t s, uint32_t grid, const DScene &S, const ShadeParams &P, uint32_t lane_base, uint32_t shard_cap, const uint32_t *count_in,
                   const WaveState &in, const float4 *h0, const uint2 *h1, const WaveState &out, uint32_t *count_out, const ItemArrays &items,
                   uint32_t *item_count, float4 *result, const ReplayCache &rc, uint64_t *pass_rng, const float4 *dL, float *grad_slots, const ShapeArrays *geo,
-                  float *const *grad_tex, const TexelQueues *tq_in) {
+                  float *const *grad_tex, const TexelQueues *tq_in, float *grad_extra) {
     dim3 g(grid), b(kBlock);
     const ShapeArrays no_geo{ nullptr, nullptr, nullptr, nullptr, nullptr };
     const TexelQueues no_tq{ nullptr, nullptr, nullptr, nullptr, 0u, 0u };
@@ -1156,23 +1178,29 @@ void launch_shade(int mode, hipStream_t s, uint32_t grid, const DScene &S, const
     if (geo && mode == MODE_PRB_ADJOINT) {        /* vertex-position gradients: scenes of `diffuse` BSDFs, plain or `twosided` (checked by har_integrator_set_grad_positions) */
         if (S.bsdf_types == HAR_BSDF_ONLY_DIFFUSE)
             hipLaunchKernelGGL((k_shade<MODE_PRB_ADJOINT, HAR_BSDF_ONLY_DIFFUSE, true>), g, b, 0, s, S, P, lane_base, shard_cap, count_in, in, h0, h1, out, count_out, items, item_count,
-                               result, rc, pass_rng, dL, grad_slots, *geo, grad_tex, no_tq);
+                               result, rc, pass_rng, dL, grad_slots, *geo, grad_tex, no_tq, nullptr);
         else
             hipLaunchKernelGGL((k_shade<MODE_PRB_ADJOINT, HAR_BSDF_CLASSIC_TYPES, true>), g, b, 0, s, S, P, lane_base, shard_cap, count_in, in, h0, h1, out, count_out, items, item_count,
-                               result, rc, pass_rng, dL, grad_slots, *geo, grad_tex, no_tq);
+                               result, rc, pass_rng, dL, grad_slots, *geo, grad_tex, no_tq, nullptr);
         return;
     }
     if (grad_tex && mode == MODE_PRB_ADJOINT && rc.mode == 2) {       /* cached bounce of the adjoint replay: commit in place (see k_shade) */
         const bool env = (S.bsdf_types & HAR_SCENE_ENVMAP) != 0u, diffuse = S.bsdf_types == HAR_BSDF_ONLY_DIFFUSE, cls = (S.bsdf_types & 0x7fffffffu & ~HAR_BSDF_CLASSIC_TYPES) == 0u;
-#define HAR_LAUNCH_SHADE_INLINE(T) hipLaunchKernelGGL((k_shade<MODE_PRB_ADJOINT, T, false, true>), g, b, 0, s, S, P, lane_base, shard_cap, count_in, in, h0, h1, out, count_out, items, item_count, result, rc, pass_rng, dL, grad_slots, no_geo, grad_tex, tq)
+#define HAR_LAUNCH_SHADE_INLINE(T) hipLaunchKernelGGL((k_shade<MODE_PRB_ADJOINT, T, false, true>), g, b, 0, s, S, P, lane_base, shard_cap, count_in, in, h0, h1, out, count_out, items, item_count, result, rc, pass_rng, dL, grad_slots, no_geo, grad_tex, tq, nullptr)
+#define HAR_LAUNCH_SHADE_EXTRA(T) hipLaunchKernelGGL((k_shade<MODE_PRB_ADJOINT, T, false, true, true>), g, b, 0, s, S, P, lane_base, shard_cap, count_in, in, h0, h1, out, count_out, items, item_count, result, rc, pass_rng, dL, grad_slots, no_geo, grad_tex, tq, grad_extra)
+        if (grad_extra && !diffuse) {         /* gradients w.r.t. alpha / eta / k / slot 1: the generic shading code with the extra derivative terms */
+            if (env) HAR_LAUNCH_SHADE_EXTRA(HAR_BSDF_ALL_TYPES | HAR_SCENE_ENVMAP); else HAR_LAUNCH_SHADE_EXTRA(HAR_BSDF_ALL_TYPES);
+            return;
+        }
         if (env) HAR_LAUNCH_SHADE_INLINE(HAR_BSDF_ALL_TYPES | HAR_SCENE_ENVMAP); else if (diffuse) HAR_LAUNCH_SHADE_INLINE(HAR_BSDF_ONLY_DIFFUSE);
         else if (cls) HAR_LAUNCH_SHADE_INLINE(HAR_BSDF_CLASSIC_TYPES); else HAR_LAUNCH_SHADE_INLINE(HAR_BSDF_ALL_TYPES);
 #undef HAR_LAUNCH_SHADE_INLINE
+#undef HAR_LAUNCH_SHADE_EXTRA
         return;
     }
     /* diffuse-only scenes (no twosided wrappers) run kernels in which the other BSDF models are compiled out */
     const bool only_diffuse = S.bsdf_types == HAR_BSDF_ONLY_DIFFUSE;
-#define HAR_LAUNCH_SHADE(M, T) hipLaunchKernelGGL((k_shade<M, T>), g, b, 0, s, S, P, lane_base, shard_cap, count_in, in, h0, h1, out, count_out, items, item_count, result, rc, pass_rng, dL, grad_slots, no_geo, nullptr, no_tq)
+#define HAR_LAUNCH_SHADE(M, T) hipLaunchKernelGGL((k_shade<M, T>), g, b, 0, s, S, P, lane_base, shard_cap, count_in, in, h0, h1, out, count_out, items, item_count, result, rc, pass_rng, dL, grad_slots, no_geo, nullptr, no_tq, nullptr)
     const bool envmap = (S.bsdf_types & HAR_SCENE_ENVMAP) != 0u;      /* generic BSDF code + environment-map sampling / lookup */
     const bool classic = (S.bsdf_types & 0x7fffffffu & ~HAR_BSDF_CLASSIC_TYPES) == 0u;
 #define HAR_LAUNCH_SHADE_MODE(M) do { if (envmap) HAR_LAUNCH_SHADE(M, HAR_BSDF_ALL_TYPES | HAR_SCENE_ENVMAP); else if (only_diffuse) HAR_LAUNCH_SHADE(M, HAR_BSDF_ONLY_DIFFUSE); else if (classic) HAR_LAUNCH_SHADE(M, HAR_BSDF_CLASSIC_TYPES); else HAR_LAUNCH_SHADE(M, HAR_BSDF_ALL_TYPES); } while (0)

@@ -36,6 +36,7 @@ struct ShadeParams {
 };
 #define HAR_SHADE_EMITTER_GRADS 1u
 #define HAR_SHADE_FORWARD_MODE 4u    /* adjoint kernels in FORWARD mode (RBIntegrator.render_forward): parameter tangents in, differential radiance out */
+#define HAR_SHADE_EXTRA_GRADS 16u    /* adjoint: also differentiate w.r.t. alpha / eta / k / colour slot 1 of the rough BSDF models (ShadeResult::x_dir / x_rel) */
 #define HAR_SHADE_SCALAR_DRAWS 8u    /* scalar variants: the two emitter samples are only drawn where the BSDF has a smooth lobe (path.cpp:244-249); JIT variants draw them on every lane */
 #define HAR_SHADE_HIDE_EMITTERS 2u   /* Integrator property `hide_emitters`: the environment is not seen by camera rays (path.cpp:114-115, prb.py:146-148) */
 #define HAR_ITEM_NO_EMITTER 0x7ffu   /* emitter field of an adjoint item's tag: contribution stored as is (no emitter gradient) */
@@ -56,7 +57,12 @@ struct ShadeResult {
     /* ... with vertex-position gradients (har_shape_grad.h): the detached emitter sample (position or, for an environment, direction; normal),
      * cos(theta_o) towards it and the HAR_SHAPE_* flags of the vertex */
     Vec3 nee_p, nee_n; float cos_em; uint32_t nee_flags;
+    /* ... with HAR_SHADE_EXTRA_GRADS: the non-slot-0 parameters of the vertex's BSDF record, groups 0 alpha_u, 1 alpha_v, 2 eta, 3 k (roughconductor's
+     * complex IOR, per channel), 4 colour slot 1: x_dir[g] = d Lr_dir / d theta_g (per channel), x_rel[g] = (d f / d theta_g) / f at the sampled
+     * direction -- what dLr_drho / rel_grad are for slot 0 (prb.py:288-313) */
+    Vec3 x_dir[5], x_rel[5]; bool x_ind;
 };
+#define HAR_EXTRA_GROUPS 5
 
 /* raygen: SamplingIntegrator::render_sample up to the camera ray (integrator.cpp:448-483) */
 HAR_HD PathState raygen_lane(const DSensor &C, uint32_t seed, uint32_t spp, uint32_t log_spp, uint32_t lane, LaneSample &ls,
@@ -104,9 +110,10 @@ HAR_HD void film_footprint(const DSensor &C, const LaneSample &L, Footprint &F) 
     }
 }
 
-template <int MODE, uint32_t TYPES = HAR_BSDF_ALL_TYPES>
+template <int MODE, uint32_t TYPES = HAR_BSDF_ALL_TYPES, bool EXTRA = false>
 HAR_HD void shade_lane(const DScene &S, const ShadeParams &P, const PathState &st, const Hit &hit, ShadeResult &R) {
     R.alive = false; R.add_emission = false; R.item = false; R.item_ray = false;
+    if (MODE == MODE_PRB_ADJOINT && EXTRA) { for (int g = 0; g < 5; ++g) { R.x_dir[g] = Vec3(0.f); R.x_rel[g] = Vec3(0.f); } R.x_ind = false; }
     if (MODE == MODE_PRB_ADJOINT) { R.em_index = -1; R.nee_emitter = -1; R.em_unit = Vec3(0.f); R.contrib_unit = Vec3(0.f); R.nee_flags = 0u; R.cos_em = 0.f; R.nee_p = Vec3(0.f); R.nee_n = Vec3(0.f); }
     uint64_t rng = st.rng;
     const uint64_t inc = sampler_inc(P.seed, st.lane);
@@ -201,6 +208,11 @@ HAR_HD void shade_lane(const DScene &S, const ShadeParams &P, const PathState &s
                 /* em_weight = radiance * em_unit for `area` / `constant` emitters (prb.py:198-206, attached eval_emitter_direction) */
                 R.nee_emitter = ((P.flags & HAR_SHADE_EMITTER_GRADS) && S.emitters[em_sampled].type != 2u) ? (int32_t) em_sampled : -1;
                 R.contrib_unit = ((st.throughput * mis_em) * ev.value) * em_unit;
+                if (EXTRA && TYPES != HAR_BSDF_ONLY_DIFFUSE) {
+                    BsdfEvalExtra x; bsdf_eval_extra(S, side, bin, side_ok, wo_em, x);
+                    const Vec3 w = (st.throughput * mis_em) * em_weight;
+                    R.x_dir[0] = w * x.d_alpha_u; R.x_dir[1] = w * x.d_alpha_v; R.x_dir[2] = w * x.d_eta; R.x_dir[3] = w * x.d_k; R.x_dir[4] = w * ev.d_slot1;
+                }
             }
         }
         if (R.contrib.x != 0.f || R.contrib.y != 0.f || R.contrib.z != 0.f) {
@@ -253,7 +265,16 @@ HAR_HD void shade_lane(const DScene &S, const ShadeParams &P, const PathState &s
                           e2.value.z != 0.f ? e2.d_slot0.z / e2.value.z : 0.f);
         R.ind_active = alive && (R.rel_grad.x != 0.f || R.rel_grad.y != 0.f || R.rel_grad.z != 0.f);
         R.bsdf = side.index; R.uv_x = si.uv_x; R.uv_y = si.uv_y;
-        R.item = R.item_ray || R.ind_active;   /* otherwise the vertex has a zero gradient */
+        if (EXTRA && TYPES != HAR_BSDF_ONLY_DIFFUSE) {
+            BsdfEvalExtra x; bsdf_eval_extra(S, side, bin, side_ok && alive, wo, x);
+            const Vec3 dv[5] = { x.d_alpha_u, x.d_alpha_v, x.d_eta, x.d_k, e2.d_slot1 };
+            R.x_ind = false;
+            for (int g = 0; g < 5; ++g) {
+                R.x_rel[g] = Vec3(e2.value.x != 0.f ? dv[g].x / e2.value.x : 0.f, e2.value.y != 0.f ? dv[g].y / e2.value.y : 0.f, e2.value.z != 0.f ? dv[g].z / e2.value.z : 0.f);
+                R.x_ind = R.x_ind || (alive && (R.x_rel[g].x != 0.f || R.x_rel[g].y != 0.f || R.x_rel[g].z != 0.f));
+            }
+        }
+        R.item = R.item_ray || R.ind_active || (EXTRA && TYPES != HAR_BSDF_ONLY_DIFFUSE && R.x_ind);   /* otherwise the vertex has a zero gradient */
     }
 }
 

@@ -196,6 +196,11 @@ HAR_HD void bsdf_eval_pdf(const DScene &S, const BsdfSide &side, const BsdfInput
     if (!side_ok) { e.value = Vec3(0.f); e.pdf = 0.f; e.d_slot0 = Vec3(0.f); e.d_slot1 = Vec3(0.f); return; }
     bsdf_eval_pdf_one<TYPES>(S.bsdfs[side.index], in, side.wi, Vec3(wo.x, wo.y, wo.z * side.wo_sign), e);
 }
+/* d value / d {alpha, eta, k} of the record serving this side (see bsdf_eval_extra_one) */
+HAR_HD void bsdf_eval_extra(const DScene &S, const BsdfSide &side, const BsdfInputs &in, bool side_ok, Vec3 wo, BsdfEvalExtra &x) {
+    if (!side_ok) { x.d_alpha_u = Vec3(0.f); x.d_alpha_v = Vec3(0.f); x.d_eta = Vec3(0.f); x.d_k = Vec3(0.f); return; }
+    bsdf_eval_extra_one(S.bsdfs[side.index], in, side.wi, Vec3(wo.x, wo.y, wo.z * side.wo_sign), x);
+}
 template <uint32_t TYPES = HAR_BSDF_ALL_TYPES>
 HAR_HD void bsdf_sample(const DScene &S, const BsdfSide &side, const BsdfInputs &in, bool side_ok, float s1, float s2x, float s2y, BsdfSample &bs) {
     if (!side_ok) { bs.wo = Vec3(0.f); bs.pdf = 0.f; bs.weight = Vec3(0.f); bs.eta = 0.f; bs.delta = false; return; }

@@ -827,7 +827,86 @@ struct GradSink { float *refl; float *const *tex; float *emit; /* 3 per emitter 
                   const ShapeSink *shape = nullptr; /* vertex-position gradients of the meshes in its mask, may be null */
                   /* FORWARD mode (RBIntegrator.render_forward, common.py:497-623; prb.py:313 `dL += dr.forward_to(Lo)`): refl / tex / emit hold the
                    * parameters' tangents (read only) and every derivative term is contracted with them into *fwd; the caller passes dL = 1 */
-                  V3 *fwd = nullptr; };
+                  V3 *fwd = nullptr;
+                  /* gradients w.r.t. alpha_u, alpha_v, eta (RGB), k (RGB), colour slot 1 of the rough models: 15 floats per BSDF record, may be null */
+                  float *extra = nullptr; };
+
+/* The specular part of RoughConductor::eval / RoughPlastic::eval (roughconductor.cpp:429-520, roughplastic.cpp:296-336, microfacet.h:185-207,341-365,
+ * fresnel.h:93-116) in DOUBLE precision as a function of the parameters the adjoint differentiates: value_c(alpha_u, alpha_v, eta_c, k_c, slot1_c).
+ * The oracle differentiates it NUMERICALLY (central differences, relative step 1e-6: ~1e-9 accurate in double) -- no hand-derived formula, so it is
+ * an independent check of the product's analytic derivatives (har_bsdf.h). */
+static void rough_spec_value_d(const BsdfRecord &b, V3 slot0, double au, double av, const double ec[3], const double kc[3], const double s1[3], V3 wi_f, V3 wo_f, double out[3]) {
+    out[0] = out[1] = out[2] = 0.0;
+    const double wi[3] = { wi_f.x, wi_f.y, wi_f.z }, wo[3] = { wo_f.x, wo_f.y, wo_f.z };
+    if (!(wi[2] > 0.0 && wo[2] > 0.0)) return;
+    double H[3] = { wi[0] + wo[0], wi[1] + wo[1], wi[2] + wo[2] }; const double hl = std::sqrt(H[0] * H[0] + H[1] * H[1] + H[2] * H[2]);
+    for (double &h : H) h /= hl;
+    const double wih = wi[0] * H[0] + wi[1] * H[1] + wi[2] * H[2], woh = wo[0] * H[0] + wo[1] * H[1] + wo[2] * H[2];
+    const bool ggx = b.mtype() == MicrofacetType::GGX;
+    au = std::max(au, 1e-4); av = std::max(av, 1e-4);
+    const double au0 = std::max((double) b.p.alpha_u, 1e-4), av0 = b.p.type == 3 ? au0 : std::max((double) b.p.alpha_v, 1e-4);
+    auto D = [&]() {
+        const double c2 = H[2] * H[2], q = (H[0] / au) * (H[0] / au) + (H[1] / av) * (H[1] / av);
+        const double r = ggx ? 1.0 / (M_PI * au * av * (q + c2) * (q + c2)) : std::exp(-q / c2) / (M_PI * au * av * c2 * c2);
+        return r * H[2] > 1e-20 ? r : 0.0;
+    };
+    auto G1 = [&](const double v[3]) {
+        const double xy = (au * v[0]) * (au * v[0]) + (av * v[1]) * (av * v[1]), t = xy / (v[2] * v[2]);
+        double r;
+        if (!ggx) {
+            /* the rational fit is not exactly 1 at its cut-off (1.000057 at a = 1.6): the branch is the one the UNPERTURBED parameters take, as in
+               the reference's AD of dr::select (microfacet.h:352-357) -- differencing across it would add jump / step to lanes that sit on it */
+            const double t0 = ((au0 * v[0]) * (au0 * v[0]) + (av0 * v[1]) * (av0 * v[1])) / (v[2] * v[2]);
+            const double a = 1.0 / std::sqrt(t); r = 1.0 / std::sqrt(t0) >= 1.6 ? 1.0 : (3.535 * a + 2.181 * a * a) / (1.0 + 2.276 * a + 2.577 * a * a);
+        }
+        else r = 2.0 / (1.0 + std::sqrt(1.0 + t));
+        if (xy == 0.0) r = 1.0;
+        if ((v[0] * H[0] + v[1] * H[1] + v[2] * H[2]) * v[2] <= 0.0) r = 0.0;
+        return r;
+    };
+    auto Fc = [&](double c, double er, double ei) {
+        const double c2 = c * c, s2 = 1.0 - c2, s4 = s2 * s2, t1 = er * er - ei * ei - s2, ab = std::sqrt(std::max(t1 * t1 + 4.0 * ei * ei * er * er, 0.0));
+        const double a = std::sqrt(std::max(0.5 * (ab + t1), 0.0)), T1 = ab + c2, T2 = 2.0 * c * a, rs = (T1 - T2) / (T1 + T2), T3 = ab * c2 + s4, T4 = T2 * s2;
+        return 0.5 * (rs + rs * (T3 - T4) / (T3 + T4));
+    };
+    if (b.p.type == 2) {
+        if (!(wih > 0.0 && woh > 0.0)) return;
+        const double d = D(); if (d == 0.0) return;
+        const double V = d * G1(wi) * G1(wo) / (4.0 * wi[2]);
+        const double s0[3] = { slot0.x, slot0.y, slot0.z };
+        for (int c = 0; c < 3; ++c) out[c] = s0[c] * Fc(wih, ec[c], kc[c]) * V;
+    } else if (b.p.type == 3) {
+        av = au;
+        const double d = D();
+        const double F = (double) fresnel((float) wih, b.p.eta).r;                 /* not a function of the differentiated parameters */
+        const double spec = F * d * G1(wi) * G1(wo) / (4.0 * wi[2]);
+        for (int c = 0; c < 3; ++c) out[c] = s1[c] * spec;
+    }
+}
+/* d value_c / d theta for the five parameter groups (alpha_u, alpha_v, eta, k, slot 1) at (wi, wo): out[g][c] */
+static void rough_spec_grad_fd(const BsdfRecord &b, V3 slot0, V3 slot1, V3 wi, V3 wo, double out[5][3]) {
+    for (int g = 0; g < 5; ++g) for (int c = 0; c < 3; ++c) out[g][c] = 0.0;
+    if (b.p.type != 2 && b.p.type != 3) return;
+    const double au = b.p.alpha_u, av = b.p.type == 3 ? b.p.alpha_u : b.p.alpha_v;
+    double ec[3], kc[3], s1[3] = { slot1.x, slot1.y, slot1.z };
+    for (int c = 0; c < 3; ++c) { ec[c] = b.p.eta_c[c]; kc[c] = b.p.k_c[c]; }
+    auto diff = [&](int g, int c) {
+        double p[2][3];
+        for (int sgn = 0; sgn < 2; ++sgn) {
+            double a1 = au, a2 = av, e[3] = { ec[0], ec[1], ec[2] }, k[3] = { kc[0], kc[1], kc[2] }, t[3] = { s1[0], s1[1], s1[2] };
+            const double f = sgn ? 1.0 - 1e-6 : 1.0 + 1e-6;
+            if (g == 0) { a1 *= f; if (b.p.type == 3) a2 = a1; } else if (g == 1) a2 *= f; else if (g == 2) e[c] *= f; else if (g == 3) k[c] *= f; else t[c] = t[c] * f + (sgn ? -1e-9 : 1e-9);
+            rough_spec_value_d(b, slot0, a1, a2, e, k, t, wi, wo, p[sgn]);
+        }
+        const double base = g == 0 ? au : g == 1 ? av : g == 2 ? ec[c] : g == 3 ? kc[c] : s1[c];
+        const double h = g == 4 ? 2.0 * (base * 1e-6 + 1e-9) : 2e-6 * base;
+        if (g <= 1) { for (int cc = 0; cc < 3; ++cc) out[g][cc] = h != 0.0 ? (p[0][cc] - p[1][cc]) / h : 0.0; }
+        else out[g][c] = h != 0.0 ? (p[0][c] - p[1][c]) / h : 0.0;
+    };
+    diff(0, 0);
+    if (b.p.type == 2) { diff(1, 0); for (int c = 0; c < 3; ++c) { diff(2, c); diff(3, c); } }
+    else for (int c = 0; c < 3; ++c) diff(4, c);
+}
 /* one derivative term: backward adds w * g to the parameter's gradient slot, forward adds w * g * tangent to the lane's differential radiance */
 static inline void grad_commit(const GradSink *grad, float *slot, V3 g, float w = 1.f) {
     if (grad->fwd) { grad->fwd->x += g.x * w * slot[0]; grad->fwd->y += g.y * w * slot[1]; grad->fwd->z += g.z * w * slot[2]; }
@@ -917,6 +996,28 @@ static V3 prb_sample(const Scene &sc, Pcg32 &rng, Ray ray, uint32_t max_depth, u
                 float *dst = grad->tex[bsdf.rec->p.texture];
                 const float wts[4] = { tl.w[0] * tl.w[2], tl.w[1] * tl.w[2], tl.w[0] * tl.w[3], tl.w[1] * tl.w[3] };
                 for (int k = 0; k < 4; ++k) grad_commit(grad, dst + 3 * (size_t) tl.idx[k], g, wts[k]);
+            }
+        }
+        if (!primal && grad && grad->extra && si.valid() && bsdf.rec && bsdf.ok && (bsdf.rec->p.type == 2 || bsdf.rec->p.type == 3)) {
+            /* the same two terms for alpha / eta / k / colour slot 1 (prb.py:288-313 with those parameters attached): dL * (d Lr_dir / d theta + L * (d f / d theta) / f) */
+            double dem[5][3], dwo[5][3];
+            float *dst = grad->extra + 15 * (size_t) bsdf.used;
+            if (active_em) {
+                rough_spec_grad_fd(*bsdf.rec, bsdf.slot0, bsdf.slot1, bsdf.wi, V3(wo_em.x, wo_em.y, wo_em.z * bsdf.wo_sign), dem);
+                const double w[3] = { (double) beta_cur.x * mis_em * em_weight.x, (double) beta_cur.y * mis_em * em_weight.y, (double) beta_cur.z * mis_em * em_weight.z };
+                const double dl[3] = { dL.x, dL.y, dL.z };
+                for (int g = 0; g < 5; ++g) for (int c = 0; c < 3; ++c) dst[3 * g + c] += (float) (dl[c] * w[c] * dem[g][c]);
+                if (getenv("ORC_DEBUG_EXTRA") && dl[0] != 0.0 && bsdf.rec->p.type == 3) fprintf(stderr, "EM depth %u bsdf %d wi %.9g %.9g %.9g wo %.9g %.9g %.9g dalpha %.9g w %.9g dl %.9g\n", depth, (int) bsdf.used, bsdf.wi.x, bsdf.wi.y, bsdf.wi.z,
+                                                       wo_em.x, wo_em.y, wo_em.z * bsdf.wo_sign, dem[0][0], w[0], dl[0]);
+            }
+            if (active_next) {
+                V3 wo = si.to_local(ray_next.d); const V3 wol(wo.x, wo.y, wo.z * bsdf.wo_sign);
+                rough_spec_grad_fd(*bsdf.rec, bsdf.slot0, bsdf.slot1, bsdf.wi, wol, dwo);
+                BSDFEval e2 = bsdf_eval_pdf(bsdf, wo);
+                const double f[3] = { e2.value.x, e2.value.y, e2.value.z }, Lc[3] = { L.x, L.y, L.z }, dl[3] = { dL.x, dL.y, dL.z };
+                for (int g = 0; g < 5; ++g) for (int c = 0; c < 3; ++c) if (f[c] != 0.0) dst[3 * g + c] += (float) (dl[c] * Lc[c] * dwo[g][c] / f[c]);
+                if (getenv("ORC_DEBUG_EXTRA") && dl[0] != 0.0 && bsdf.rec->p.type == 3) fprintf(stderr, "REL depth %u bsdf %d wi %.9g %.9g %.9g wo %.9g %.9g %.9g dalpha %.9g f %.9g L %.9g dl %.9g\n", depth, (int) bsdf.used, bsdf.wi.x, bsdf.wi.y, bsdf.wi.z,
+                                                       wol.x, wol.y, wol.z, dwo[0][0], f[0], Lc[0], dl[0]);
             }
         }
         if (!primal && grad && grad->shape && si.valid() && bsdf.rec) {
@@ -1414,7 +1515,7 @@ int orc_render_weights(const OrcSensor *s, uint32_t seed, uint32_t spp, uint64_t
 static int prb_backward_impl(void *scene, const OrcSensor *sp, const float *grad_in, uint32_t seed, uint32_t spp,
                              int32_t max_depth, int32_t rr_depth, float *grad_reflectance, float *const *grad_textures,
                              float *grad_emitters, const uint8_t *pos_mask, double *const *grad_positions, OrcStats *stats, int threads,
-                             uint64_t lb = 0, uint64_t le = 0, const float *weight_film = nullptr) {
+                             uint64_t lb = 0, uint64_t le = 0, const float *weight_film = nullptr, float *grad_bsdf_params = nullptr) {
     Scene &sc = *(Scene *) scene; const OrcSensor &s = *sp;
     if (pos_mask) {           /* the attached-geometry restatement covers `diffuse` BSDFs on flat-shaded top-level meshes */
         for (const BsdfRecord &b : sc.bsdfs) if (b.p.type != 0) return -2;           /* `diffuse`, plain or inside `twosided` */
@@ -1437,20 +1538,21 @@ static int prb_backward_impl(void *scene, const OrcSensor *sp, const float *grad
     for (size_t i = 0; i < npx; ++i) { float w = wfilm[4 * i + 3]; float iw = w == 0.f ? 1.f : w; for (int c = 0; c < 3; ++c) adj[3 * i + c] = grad_in[3 * i + c] / iw; }
     // per-thread gradient buffers
     size_t nb = sc.bsdfs.size();
-    std::vector<std::vector<float>> g_refl(threads), g_emit(threads);
+    std::vector<std::vector<float>> g_refl(threads), g_emit(threads), g_extra(threads);
     std::vector<std::vector<std::vector<float>>> g_tex(threads);
     std::vector<std::vector<std::vector<double>>> g_pos(threads);
     std::vector<OrcStats> sts(threads, OrcStats{});
     uint32_t md = (uint32_t) max_depth, rd = (uint32_t) rr_depth;
     parallel_lanes(lb, le, threads, [&](int t, uint64_t b, uint64_t e) {
         if (g_refl[t].empty()) {
-            g_refl[t].assign(3 * nb + 3, 0.f); g_emit[t].assign(3 * sc.emitters.size() + 3, 0.f);
+            g_refl[t].assign(3 * nb + 3, 0.f); g_emit[t].assign(3 * sc.emitters.size() + 3, 0.f); g_extra[t].assign(15 * nb + 15, 0.f);
             g_tex[t].resize(sc.textures.size());
             for (size_t k = 0; k < sc.textures.size(); ++k) g_tex[t][k].assign(3 * (size_t) sc.textures[k].w * sc.textures[k].h, 0.f);
         }
         std::vector<float *> tp(sc.textures.size() + 1, nullptr);
         for (size_t k = 0; k < sc.textures.size(); ++k) tp[k] = g_tex[t][k].data();
         GradSink sink{ g_refl[t].data(), tp.data(), grad_emitters ? g_emit[t].data() : nullptr };
+        sink.extra = grad_bsdf_params ? g_extra[t].data() : nullptr;
         std::vector<double *> pp(sc.meshes.size() + 1, nullptr); ShapeSink shape{ pp.data(), pos_mask };
         if (pos_mask) {
             if (g_pos[t].empty()) { g_pos[t].resize(sc.meshes.size()); for (size_t m = 0; m < sc.meshes.size(); ++m) if (pos_mask[m]) g_pos[t][m].assign(3 * (size_t) sc.meshes[m].nv, 0.0); }
@@ -1495,6 +1597,7 @@ static int prb_backward_impl(void *scene, const OrcSensor *sp, const float *grad
         if (g_refl[t].empty()) continue;
         if (grad_reflectance) for (size_t i = 0; i < 3 * nb; ++i) grad_reflectance[i] += g_refl[t][i];
         if (grad_emitters) for (size_t i = 0; i < 3 * sc.emitters.size(); ++i) grad_emitters[i] += g_emit[t][i];
+        if (grad_bsdf_params) for (size_t i = 0; i < 15 * nb; ++i) grad_bsdf_params[i] += g_extra[t][i];
         for (size_t k = 0; k < sc.textures.size(); ++k)
             if (grad_textures && grad_textures[k]) { float *dst = grad_textures[k]; for (size_t i = 0; i < g_tex[t][k].size(); ++i) dst[i] += g_tex[t][k][i]; }
         if (pos_mask && !g_pos[t].empty())
@@ -1538,6 +1641,11 @@ int orc_render_prb_forward(void *scene, const OrcSensor *sp, uint32_t seed, uint
     });
     for (auto &f : films) if (!f.empty()) for (size_t i = 0; i < fsz; ++i) film[i] += f[i];
     return 0;
+}
+/* ... plus the gradients w.r.t. alpha_u, alpha_v, eta, k, colour slot 1 of the rough BSDF records: grad_bsdf_params = bsdf_count x 15, added to */
+int orc_render_prb_backward_bsdf_params(void *scene, const OrcSensor *sp, const float *grad_in, uint32_t seed, uint32_t spp, int32_t max_depth, int32_t rr_depth,
+                                        float *grad_reflectance, float *const *grad_textures, float *grad_bsdf_params, OrcStats *stats, int threads) {
+    return prb_backward_impl(scene, sp, grad_in, seed, spp, max_depth, rr_depth, grad_reflectance, grad_textures, nullptr, nullptr, nullptr, stats, threads, 0, 0, nullptr, grad_bsdf_params);
 }
 int orc_render_prb_backward_lanes(void *scene, const OrcSensor *sp, const float *grad_in, const float *weight_film, uint32_t seed, uint32_t spp,
                                   int32_t max_depth, int32_t rr_depth, uint64_t lane_begin, uint64_t lane_end, float *grad_reflectance,

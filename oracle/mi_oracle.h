@@ -199,6 +199,12 @@ int orc_render_prb_backward_ex(void *scene, const OrcSensor *s, const float *gra
  * ray i draws from the stream of wavefront lane lane_offset + i, continued from state[i] if given; rgb 3 x n, valid n, state_out n (nullable) */
 int orc_integrator_sample(void *scene, int prb, uint32_t n, const float *o, const float *d, const float *maxt, uint32_t seed, uint32_t lane_offset,
                           const uint64_t *state, int32_t max_depth, int32_t rr_depth, float *rgb, uint8_t *valid, uint64_t *state_out, int threads);
+/* render_backward plus the gradients of the rough models' `alpha` / `alpha_u` / `alpha_v`, `eta`, `k` (roughconductor.cpp:226-520) and `alpha`,
+ * `specular_reflectance` (roughplastic.cpp:244-420): grad_bsdf_params = bsdf_count x 15 floats {alpha_u[3], alpha_v[3], eta[3], k[3], slot1[3]} (per-channel
+ * contributions; sum the three for a scalar alpha), added to.  The derivatives of the BSDF value are central differences of a double-precision
+ * restatement of the models -- PARITY UNPINNED against the reference (its AD is Dr.Jit's). */
+int orc_render_prb_backward_bsdf_params(void *scene, const OrcSensor *s, const float *grad_in, uint32_t seed, uint32_t spp, int32_t max_depth, int32_t rr_depth,
+                                        float *grad_reflectance, float *const *grad_textures, float *grad_bsdf_params, OrcStats *stats, int threads);
 /* RBIntegrator.render_forward (src/python/python/ad/integrators/common.py:497-623): the forward-mode derivative image of `prb`.  Tangents in
  * the layout of orc_render_prb_backward_ex's gradient buffers (tangent_emitters may be NULL); film = raw H x W x 4 accumulation of the lanes'
  * differential radiance dL = sum over vertices <d Lo / d theta, tangent> (prb.py:313), orc_film_develop(film) is the gradient image */

@@ -473,6 +473,20 @@ class OracleScene:
         assert rc == 0
         return g_refl, g_tex, g_emit[:len(self.data.emitters)], st
 
+    def render_prb_backward_bsdf_params(self, sensor, grad_in, seed=0, spp=4, max_depth=6, rr_depth=5, threads=0):
+        """gradients w.r.t. alpha_u, alpha_v, eta, k, colour slot 1 of every BSDF record: array (bsdf_count, 5, 3) of per-channel contributions"""
+        grad_in = f32(grad_in)
+        g_refl = np.zeros((len(self.data.bsdfs), 3), np.float32); g_x = np.zeros((len(self.data.bsdfs), 15), np.float32)
+        g_tex = [np.zeros_like(t) for t in self.data.textures]
+        ptrs = (c_f32p * max(1, len(g_tex)))(*[fp(g) for g in g_tex])
+        st = Stats()
+        L = lib(); L.orc_render_prb_backward_bsdf_params.restype = C.c_int
+        L.orc_render_prb_backward_bsdf_params.argtypes = [C.c_void_p, C.POINTER(Sensor), c_f32p, C.c_uint32, C.c_uint32, C.c_int32, C.c_int32, c_f32p, C.POINTER(c_f32p), c_f32p,
+                                                          C.POINTER(Stats), C.c_int]
+        rc = L.orc_render_prb_backward_bsdf_params(self.handle, C.byref(sensor), fp(grad_in), seed, spp, max_depth, rr_depth, fp(g_refl), ptrs, fp(g_x), C.byref(st), threads)
+        assert rc == 0
+        return g_x.reshape(-1, 5, 3), g_refl
+
     def render_prb_forward(self, sensor, t_refl, t_tex=(), t_emit=None, seed=0, spp=4, max_depth=6, rr_depth=5, threads=0, raw=False):
         """RBIntegrator.render_forward: gradient image (H x W x 3) for the parameter tangents t_refl (bsdf_count x 3), t_tex (one array per bitmap),
         t_emit (emitter_count x 3 or None)"""

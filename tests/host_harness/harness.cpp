@@ -90,6 +90,22 @@ void hh_microfacet_sample(int type, float alpha_u, float alpha_v, int sample_vis
     Vec3 r = d.sample(Vec3(wi[0], wi[1], wi[2]), sample[0], sample[1], *pdf);
     m[0] = r.x; m[1] = r.y; m[2] = r.z;
 }
+/* product's hand-derived d value / d {alpha_u, alpha_v, eta, k} of a rough BSDF record built from the arguments (har_bsdf.h bsdf_eval_extra_one) next to
+ * the value itself, so that the test can difference the value in its parameters */
+void hh_bsdf_eval_extra(int type, int ggx, int sample_visible, float alpha_u, float alpha_v, float eta, const float eta_c[3], const float k_c[3], const float slot0[3],
+                        const float slot1[3], const float wi[3], const float wo[3], float value[3], float out[12]) {
+    DBsdf B{}; B.type = (uint32_t) type; B.texture = -1; B.flags = (ggx ? BF_GGX : 0u) | (sample_visible ? BF_SAMPLE_VISIBLE : 0u);
+    B.alpha_u = alpha_u; B.alpha_v = alpha_v; B.eta = eta; B.back = -1; B.table = -1;
+    for (int k = 0; k < 3; ++k) { B.eta_c[k] = eta_c[k]; B.k_c[k] = k_c[k]; }
+    B.inv_eta_2 = 1.f / (eta * eta); B.internal_reflectance = 0.f; B.spec_sampling_weight = .5f;
+    static float table[64]; for (int i = 0; i < 64; ++i) table[i] = 1.f;          /* the (detached) transmittance table does not matter for the derivatives */
+    BsdfInputs in; in.slot0 = Vec3(slot0[0], slot0[1], slot0[2]); in.slot1 = Vec3(slot1[0], slot1[1], slot1[2]); in.table = table;
+    BsdfEval e; bsdf_eval_pdf_one(B, in, Vec3(wi[0], wi[1], wi[2]), Vec3(wo[0], wo[1], wo[2]), e);
+    value[0] = e.value.x; value[1] = e.value.y; value[2] = e.value.z;
+    BsdfEvalExtra x; bsdf_eval_extra_one(B, in, Vec3(wi[0], wi[1], wi[2]), Vec3(wo[0], wo[1], wo[2]), x);
+    const Vec3 g[4] = { x.d_alpha_u, x.d_alpha_v, x.d_eta, x.d_k };
+    for (int k = 0; k < 4; ++k) { out[3 * k] = g[k].x; out[3 * k + 1] = g[k].y; out[3 * k + 2] = g[k].z; }
+}
 void hh_fresnel(float cos_theta_i, float eta, float out[4]) { fresnel_dielectric(cos_theta_i, eta, out[0], out[1], out[2], out[3]); }
 float hh_fresnel_conductor(float cos_theta_i, float eta, float k) { return fresnel_conductor(cos_theta_i, eta, k); }
 void hh_roughplastic_tables(void *h, uint32_t bsdf, float out[66]) {
