@@ -279,6 +279,15 @@ int har_integrator_set_grad_emitters(HarIntegrator integrator, float *grad_emitt
  * New vertex positions are installed by creating a new scene (har_scene_create), which rebuilds the acceleration structure. */
 int har_integrator_set_grad_positions(HarIntegrator integrator, HarScene scene, float *const *grad_positions);
 
+/* Gradient w.r.t. the `to_world` of INSTANCES (params['<instance>.to_world']): Instance::compute_surface_interaction with an attached transform
+ * (src/shapes/instance.cpp:150-266) inside PRBIntegrator.sample -- the nested interaction is detached (:181-189), the hit point follows
+ * to_world (:191-193) and is put back onto the ray through the moving tangent plane (:240-249); normals and uv stay detached (:194-224, 250-251).
+ * `grad_to_world` = DEVICE buffer of instance_count x 12 floats (column-major 3x4 like HarInstance::to_world; the reference's 4x4 has a constant
+ * fourth row); har_render_backward then also accumulates into it.  NULL switches the feature off.  Can be combined with
+ * har_integrator_set_grad_positions (as in the reference, NOT for the meshes of the instanced shape groups themselves, instance.cpp:162-166).
+ * Like `prb` itself: no visibility-boundary term.  Scenes whose BSDFs are all `diffuse` (plain or inside `twosided`); fails otherwise. */
+int har_integrator_set_grad_instances(HarIntegrator integrator, HarScene scene, float *grad_to_world);
+
 /* RBIntegrator.render_forward (src/python/python/ad/integrators/common.py:497-623): the forward-mode derivative image of the `prb` integrator.
  * tangent_reflectance (DEVICE, bsdf_count x 3), tangent_textures (HOST array of texture_count DEVICE pointers, H_i x W_i x 3 each; NULL when the
  * scene has no bitmaps) and tangent_emitters (DEVICE, emitter_count x 3, may be NULL) are the dr.set_grad() values of the scene parameters, in

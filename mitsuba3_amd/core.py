@@ -920,16 +920,24 @@ class Integrator:
         ptrs = (C.c_void_p * max(1, len(g_tex)))(*[t.data_ptr() for t in g_tex])
         g_emit = torch.zeros((max(1, len(scene.emitters)), 3), dtype=torch.float32, device=dev)
         check(lib().har_integrator_set_grad_emitters(self._handle(), _ptr(g_emit) if self.emitter_gradients else None))
-        g_pos = {}
+        g_pos = {}; g_inst = None; inst_wanted = {}
         if self.shape_gradients:
-            keys = scene._position_keys()
-            wanted = keys if self.shape_gradients is True else {k: keys[k] for k in self.shape_gradients}    # KeyError: not a differentiable mesh
+            keys = scene._position_keys(); ikeys = scene._instance_keys()
+            if self.shape_gradients is True:
+                wanted, inst_wanted = keys, ikeys
+            else:
+                inst_wanted = {k: ikeys[k] for k in self.shape_gradients if k in ikeys}
+                wanted = {k: keys[k] for k in self.shape_gradients if k not in ikeys}    # KeyError: not a differentiable mesh / instance
             g_pos = {k: torch.zeros(3 * scene.meshes[m]["V"].shape[0], dtype=torch.float32, device=dev) for k, m in wanted.items()}
             by_mesh = {wanted[k]: g for k, g in g_pos.items()}
             pp = (C.c_void_p * max(1, scene.top_mesh_count))(*[by_mesh[m].data_ptr() if m in by_mesh else None for m in range(scene.top_mesh_count)])
             check(lib().har_integrator_set_grad_positions(self._handle(), scene._handle(), pp if g_pos else None))
+            if inst_wanted:
+                g_inst = torch.zeros((len(scene.instances), 12), dtype=torch.float32, device=dev)
+            check(lib().har_integrator_set_grad_instances(self._handle(), scene._handle() if inst_wanted else None, _ptr(g_inst) if inst_wanted else None))
         else:
             check(lib().har_integrator_set_grad_positions(self._handle(), None, None))
+            check(lib().har_integrator_set_grad_instances(self._handle(), None, None))
         g_extra = torch.zeros((max(1, len(scene.bsdfs)), 15), dtype=torch.float32, device=dev) if self.bsdf_parameter_gradients else None
         check(lib().har_integrator_set_grad_bsdf_params(self._handle(), _ptr(g_extra) if g_extra is not None else None))
         check(lib().har_render_backward(scene._handle(), self._handle(), C.byref(sensor.har), _ptr(grad_in), _ptr(weight_film), sd, spp,
@@ -941,6 +949,9 @@ class Integrator:
                 out[k] = {"alpha": rec[0:6].sum().reshape(1), "alpha_u": rec[0:3].sum().reshape(1), "alpha_v": rec[3:6].sum().reshape(1),
                           "eta": rec[6:9], "k": rec[9:12], "slot1": rec[12:15]}[what]
         out.update(g_pos)
+        for k, i in inst_wanted.items():                      # column-major 3x4 -> the reference's 4x4 (constant fourth row: zero gradient)
+            m = torch.zeros((4, 4), dtype=torch.float32, device=dev); m[:3, :] = g_inst[i].reshape(4, 3).T
+            out[k] = m
         return out
 
 
@@ -1050,7 +1061,7 @@ class Scene:
 
     def __init__(self, children):
         self.bsdf_objs = []; self.meshes = []; self.top_mesh_count = 0
-        self.groups = []; self.instances = []; self.emitters = []
+        self.groups = []; self.instances = []; self.instance_keys = []; self.emitters = []
         self.m_sensors = []; self.m_integrator = None; self.textures = []
         self._h = None; self._keep = []
         named = {}
@@ -1104,6 +1115,7 @@ class Scene:
             if id(it.group) not in gindex:
                 raise RuntimeError("A reference to a 'shapegroup' must be specified!")
             self.instances.append((gindex[id(it.group)], it.to_world.col_major_3x4(), it.to_world.inverse().col_major_3x4()))
+            self.instance_keys.append(key)
 
     # -- construction helpers
     def _add_bsdf(self, b):
@@ -1299,6 +1311,21 @@ class Scene:
         """'<shape>.vertex_positions' (flat 3 N floats as in the reference's Mesh::traverse) of the top-level meshes without vertex normals"""
         return {m["key"] + ".vertex_positions": i for i, m in enumerate(self.meshes[:self.top_mesh_count]) if not (m["flags"] & 1) and m["V"].shape[0]}
 
+    def _instance_keys(self):
+        """'<instance>.to_world' (4 x 4, Instance::traverse, instance.cpp:79-85)"""
+        return {k + ".to_world": i for i, k in enumerate(self.instance_keys)}
+
+    def _instance_matrix(self, i):
+        m = np.eye(4, dtype=np.float32); m[:3, :] = np.asarray(self.instances[i][1], np.float32).reshape(4, 3).T
+        return m
+
+    def _set_instance_matrix(self, i, m4):
+        """params['<instance>.to_world'] = ...; params.update(): the instance-level acceleration structure is rebuilt with the next scene handle"""
+        m = np.asarray(m4, np.float64).reshape(4, 4); inv = np.linalg.inv(m)
+        self.instances[i] = (self.instances[i][0], [float(x) for x in m[:3, :].T.reshape(-1)], [float(x) for x in inv[:3, :].T.reshape(-1)])
+        if self._h is not None:
+            lib().har_scene_destroy(self._h); self._h = None
+
     def _set_vertex_positions(self, mesh, positions):
         """params['<shape>.vertex_positions'] = ...; params.update(): the acceleration structure is rebuilt with the next scene handle"""
         V = self.meshes[mesh]["V"]
@@ -1332,6 +1359,8 @@ class SceneParameters(dict):
             self[k] = torch.tensor(np.asarray(scene._bsdf_param_value(what, b), np.float32), dtype=torch.float32, device=dev)
         for k, m in scene._position_keys().items():
             self[k] = torch.tensor(np.ascontiguousarray(scene.meshes[m]["V"][:, :3]).reshape(-1), dtype=torch.float32, device=dev)
+        for k, i in scene._instance_keys().items():
+            self[k] = torch.tensor(scene._instance_matrix(i), dtype=torch.float32, device=dev)
 
     def update(self, values=None):
         if values:
@@ -1341,6 +1370,10 @@ class SceneParameters(dict):
             v = self[k].detach().to("cpu", copy=True).numpy().astype(np.float32).reshape(-1, 3)
             if not np.array_equal(v, self.scene.meshes[m]["V"][:, :3]):
                 self.scene._set_vertex_positions(m, v)
+        for k, i in self.scene._instance_keys().items():
+            v = self[k].detach().to("cpu", copy=True).numpy().astype(np.float32).reshape(4, 4)
+            if not np.array_equal(v, self.scene._instance_matrix(i)):
+                self.scene._set_instance_matrix(i, v)
         for k, (what, b) in self.scene._bsdf_param_keys().items():
             v = self[k].detach().to("cpu", copy=True).numpy().astype(np.float32).reshape(-1)
             if not np.array_equal(v, np.asarray(self.scene._bsdf_param_value(what, b), np.float32).reshape(-1)):

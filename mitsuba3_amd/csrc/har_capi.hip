@@ -133,6 +133,8 @@ struct HarIntegratorImpl {
     /* vertex-position gradients (har_integrator_set_grad_positions): user buffers per top-level mesh, the flat accumulation buffer + offsets */
     bool shape_on = false; std::vector<float *> pos_user; std::vector<int32_t> pos_offset; std::vector<uint32_t> pos_count;
     int32_t *d_pos_offset = nullptr; float *grad_pos = nullptr; uint32_t pos_verts = 0; ShapeArrays geo{};
+    /* instance to_world gradients (har_integrator_set_grad_instances): user buffer (DEVICE, instance_count x 12), per-instance slot table, accumulation buffer */
+    float *inst_user = nullptr; uint32_t inst_count = 0; int32_t *d_inst_slot = nullptr; float *grad_inst = nullptr;
     uint2 *stack_spill = nullptr;         /* HBM part of the traversal stacks: HAR_STACK_SPILL entries per thread of the largest traversal grid */
     /* multi-pass rendering: sampler state per lane of the rendered lane range, pixel jitter per chunk lane (see PassState) */
     uint32_t samples_per_pass = 0xffffffffu;
@@ -200,11 +202,18 @@ int ensure_workspace(HarIntegratorImpl *I, uint32_t lanes, bool adjoint) {
     if (ws_alloc(I, &I->items.s0, lanes) || ws_alloc(I, &I->items.s1, lanes) || ws_alloc(I, &I->items.s2, lanes)) return 1;
     I->items.s3 = I->items.s4 = nullptr; I->dL = nullptr;
     if (adjoint && (ws_alloc(I, &I->items.s3, lanes) || ws_alloc(I, &I->items.s4, lanes) || ws_alloc(I, &I->dL, lanes))) return 1;
-    I->geo = ShapeArrays{ nullptr, nullptr, nullptr, nullptr, nullptr }; I->d_pos_offset = nullptr; I->grad_pos = nullptr;
+    I->geo = ShapeArrays{ nullptr, nullptr, nullptr, nullptr, nullptr }; I->d_pos_offset = nullptr; I->grad_pos = nullptr; I->d_inst_slot = nullptr; I->grad_inst = nullptr;
     if (adjoint && I->shape_on) {
         if (ws_alloc(I, &I->geo.g0, lanes) || ws_alloc(I, &I->geo.g1, lanes) || ws_alloc(I, &I->geo.g2, lanes) || ws_alloc(I, &I->geo.g3, lanes) || ws_alloc(I, &I->geo.vis, lanes)) return 1;
-        if (ws_alloc(I, &I->d_pos_offset, I->pos_offset.size()) || ws_alloc(I, &I->grad_pos, (size_t) 3 * I->pos_verts)) return 1;
-        HIP_TRY(hipMemcpy(I->d_pos_offset, I->pos_offset.data(), I->pos_offset.size() * sizeof(int32_t), hipMemcpyHostToDevice));
+        if (I->pos_verts) {
+            if (ws_alloc(I, &I->d_pos_offset, I->pos_offset.size()) || ws_alloc(I, &I->grad_pos, (size_t) 3 * I->pos_verts)) return 1;
+            HIP_TRY(hipMemcpy(I->d_pos_offset, I->pos_offset.data(), I->pos_offset.size() * sizeof(int32_t), hipMemcpyHostToDevice));
+        }
+        if (I->inst_count) {
+            std::vector<int32_t> slots(I->inst_count); for (uint32_t k = 0; k < I->inst_count; ++k) slots[k] = (int32_t) k;
+            if (ws_alloc(I, &I->d_inst_slot, I->inst_count) || ws_alloc(I, &I->grad_inst, (size_t) 12 * I->inst_count)) return 1;
+            HIP_TRY(hipMemcpy(I->d_inst_slot, slots.data(), slots.size() * sizeof(int32_t), hipMemcpyHostToDevice));
+        }
     }
     I->rc_h0 = nullptr; I->rc_h1 = nullptr; I->rc_vis = nullptr; I->cache_bounces = 0;
     if (adjoint && I->use_cache) {
@@ -366,7 +375,7 @@ int run_chunk(HarSceneImpl *S, HarIntegratorImpl *I, const DSensor &C, int mode,
     /* adjoint replay of a cached bounce: `shade` commits the vertex adjoint itself (the shadow-ray result is in the cache), no items, no resolve launch */
     static const bool inline_env = getenv("HAR_ADJOINT_INLINE") ? atoi(getenv("HAR_ADJOINT_INLINE")) != 0 : true;
     const bool inline_commit = inline_env && mode == MODE_PRB_ADJOINT && !shape && !I->forward_mode;      /* forward mode commits in the resolve kernels (own instantiation) */
-    const ShapeTargets targets{ I->d_pos_offset, I->grad_pos, I->pos_verts };
+    const ShapeTargets targets{ I->d_pos_offset, I->grad_pos, I->pos_verts, I->d_inst_slot, I->grad_inst };
     int cur = 0; uint32_t b = 0;
     for (; b < nb; ++b) {
         /* PRB replay cache: the primal pass of render_backward records this bounce's ray-query results per lane, the adjoint pass reads them */
@@ -934,8 +943,10 @@ static int backward_range(HarScene S, HarIntegrator I, const HarSensor *sensor, 
     if (I->grad_slots_cap < nb3 + ne3 + 3) { if (ws_alloc(I, &I->grad_slots, nb3 + ne3 + 3)) return 1; I->grad_slots_cap = nb3 + ne3 + 3; }
     HIP_TRY(hipMemsetAsync(I->grad_slots, 0, (nb3 + ne3 + 3) * sizeof(float), s));
     if (I->shape_on) {
-        if (I->pos_offset.size() != S->hs.meshes.size() || (S->ds.bsdf_types & 0x7fffffffu) != HAR_BSDF_ONLY_DIFFUSE) return fail("har_integrator_set_grad_positions was called for a different scene");
-        HIP_TRY(hipMemsetAsync(I->grad_pos, 0, (size_t) 3 * I->pos_verts * sizeof(float), s));
+        if ((I->pos_verts && I->pos_offset.size() != S->hs.meshes.size()) || (I->inst_count && I->inst_count != S->hs.insts.size()) || (S->ds.bsdf_types & 0x7fffffffu) != HAR_BSDF_ONLY_DIFFUSE)
+            return fail("har_integrator_set_grad_positions / har_integrator_set_grad_instances was called for a different scene");
+        if (I->pos_verts) HIP_TRY(hipMemsetAsync(I->grad_pos, 0, (size_t) 3 * I->pos_verts * sizeof(float), s));
+        if (I->inst_count) HIP_TRY(hipMemsetAsync(I->grad_inst, 0, (size_t) 12 * I->inst_count * sizeof(float), s));
     }
     HIP_TRY(hipMemsetAsync(I->totals, 0, 4 * sizeof(unsigned long long), s));
     HIP_TRY(hipMemsetAsync(I->status, 0, sizeof(int), s));
@@ -955,6 +966,7 @@ static int backward_range(HarScene S, HarIntegrator I, const HarSensor *sensor, 
     if (I->shape_on)
         for (size_t m = 0; m < I->pos_user.size(); ++m)
             if (I->pos_user[m]) launch_add(s, I->grad_pos + 3 * (size_t) I->pos_offset[m], I->pos_user[m], 3 * I->pos_count[m]);
+    if (I->shape_on && I->inst_count) launch_add(s, I->grad_inst, I->inst_user, 12 * I->inst_count);
     HIP_TRY(hipGetLastError());
     return 0;
 }
@@ -1032,7 +1044,23 @@ int har_integrator_set_grad_positions(HarIntegrator I, HarScene S, float *const 
         (void) hipDeviceSynchronize();
         I->free_ws();
     }
-    I->pos_user = user; I->pos_offset = offset; I->pos_count = count; I->pos_verts = verts; I->shape_on = verts != 0;
+    I->pos_user = user; I->pos_offset = offset; I->pos_count = count; I->pos_verts = verts; I->shape_on = verts != 0 || I->inst_count != 0;
+    return 0;
+}
+
+int har_integrator_set_grad_instances(HarIntegrator I, HarScene S, float *grad_to_world) {
+    if (!I) return fail("null integrator");
+    if (I->type != HAR_INTEGRATOR_PRB) return fail("instance to_world gradients are computed by the `prb` integrator");
+    uint32_t n = 0;
+    if (grad_to_world) {
+        if (!S) return fail("null scene");
+        if ((S->ds.bsdf_types & 0x7fffffffu) != HAR_BSDF_ONLY_DIFFUSE) return fail("instance to_world gradients are implemented for scenes whose BSDFs are all `diffuse` (plain or inside `twosided`)");
+        n = (uint32_t) S->hs.insts.size();
+        if (n == 0) return fail("the scene has no instances");
+        if (n >= (1u << (32 - HAR_SHAPE_INST_SHIFT)) - 1u) return fail("too many instances for the adjoint's geometry records");
+    }
+    if (n != I->inst_count) { (void) hipDeviceSynchronize(); I->free_ws(); }      /* the geometry records and the slot table are part of the adjoint workspace */
+    I->inst_user = n ? grad_to_world : nullptr; I->inst_count = n; I->shape_on = I->pos_verts != 0 || n != 0;
     return 0;
 }
 

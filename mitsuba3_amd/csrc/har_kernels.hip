@@ -638,9 +638,11 @@ __global__ __launch_bounds__(kBlock, HAR_SHADE_MIN_WAVES) void k_shade(DScene S,
                 items.s4[islot] = make_float4(R.rel_grad.x, R.rel_grad.y, R.rel_grad.z, R.uv_y);
             }
             if (SHAPE) {        /* geometry record of the vertex for k_shape_adjoint (vertex-position gradients) */
-                geo.g0[islot] = make_float4(__uint_as_float(hs.y == 0xffffffffu ? hs.x : 0xffffffffu), hh.w, hh.y, hh.z);      /* instanced geometry is not differentiated */
+                /* top-level geometry: its vertex positions are differentiated; instanced geometry: the instance's to_world (index + 1 in bits 8.. of the flags) */
+                const uint32_t inst_bits = hs.y == 0xffffffffu ? 0u : (hs.y + 1u) << HAR_SHAPE_INST_SHIFT;
+                geo.g0[islot] = make_float4(__uint_as_float(hs.x), hh.w, hh.y, hh.z);
                 geo.g1[islot] = make_float4(d_in.x, d_in.y, d_in.z, __uint_as_float(alive ? Q.base + slot : HAR_SHAPE_NO_NEXT));
-                geo.g2[islot] = make_float4(R.nee_p.x, R.nee_p.y, R.nee_p.z, __uint_as_float(R.item_ray ? R.nee_flags : (R.nee_flags & HAR_SHAPE_LIT)));
+                geo.g2[islot] = make_float4(R.nee_p.x, R.nee_p.y, R.nee_p.z, __uint_as_float((R.item_ray ? R.nee_flags : (R.nee_flags & HAR_SHAPE_LIT)) | inst_bits));
                 geo.g3[islot] = make_float4(R.nee_n.x, R.nee_n.y, R.nee_n.z, R.cos_em);
             }
         }
@@ -840,7 +842,7 @@ __global__ __launch_bounds__(kBlock) void k_skip_emitters(DScene S, int first, u
 __global__ __launch_bounds__(kBlock) void k_shape_adjoint(DScene S, const uint32_t *item_count, uint32_t shard_cap, ItemArrays items, ShapeArrays geo, const float4 *result,
                                                           const float4 *dL, int has_next, WaveState next, const float4 *h0, const uint2 *h1, ReplayCache rc, ShapeTargets T) {
     __shared__ float acc[3 * HAR_LDS_GRAD_VERTS];
-    const bool lds = T.n_verts <= HAR_LDS_GRAD_VERTS;
+    const bool lds = T.n_verts != 0 && T.n_verts <= HAR_LDS_GRAD_VERTS;
     if (lds) { for (uint32_t k = threadIdx.x; k < 3 * T.n_verts; k += kBlock) acc[k] = 0.f; __syncthreads(); }
     const ShardLoop Q(item_count, shard_cap);
     for (uint32_t tile = Q.first_tile(); tile * kBlock < Q.n; tile += Q.tile_step()) {
@@ -850,9 +852,11 @@ __global__ __launch_bounds__(kBlock) void k_shape_adjoint(DScene S, const uint32
         const float4 g0 = geo.g0[i];
         const uint32_t shape = __float_as_uint(g0.x);
         if (shape == 0xffffffffu) continue;
-        const int32_t off = T.offset[shape];
+        const float4 g2 = geo.g2[i];
+        const uint32_t inst = (__float_as_uint(g2.w) >> HAR_SHAPE_INST_SHIFT) - 1u;       /* 0xffffffff: top-level geometry */
+        const int32_t off = inst == 0xffffffffu ? (T.offset ? T.offset[shape] : -1) : (T.inst_slot ? T.inst_slot[inst] : -1);
         if (off < 0) continue;
-        const float4 g1 = geo.g1[i], g2 = geo.g2[i], g3 = geo.g3[i];
+        const float4 g1 = geo.g1[i], g3 = geo.g3[i];
         ShapeItem it;
         it.shape = shape; it.prim = __float_as_uint(g0.y); it.b1 = g0.z; it.b2 = g0.w;
         it.d_in = Vec3(g1.x, g1.y, g1.z); it.next_slot = __float_as_uint(g1.w);
@@ -869,6 +873,14 @@ __global__ __launch_bounds__(kBlock) void k_shape_adjoint(DScene S, const uint32
             if (rc.mode == 2) { hh = rc.h0[lane]; hs = rc.h1[lane]; } else { hh = h0[HIT0(it.next_slot)]; hs = h1[HIT1(it.next_slot)]; }
             next_valid = hh.x != HAR_INF;
             if (next_valid) { const SurfInt sn = compute_si(S, nd, hh.x, hh.y, hh.z, __float_as_uint(hh.w), hs.x, hs.y); np = sn.p; nn = sn.n; }
+        }
+        if (inst != 0xffffffffu) {          /* d / d to_world of the instance: 12 floats, few distinct targets -> global atomics after a wave-level pre-reduction would be the next step */
+            float gM[12];
+            it.w_em = Vec3(0.f);
+            if (!instance_item_adjoint(S, it, inst, __float_as_uint(items.s2[i].w) & 0xfffffu, geo.vis[i] != 0, Vec3(L4.x, L4.y, L4.z), Vec3(dl4.x, dl4.y, dl4.z), Vec3(s3.x, s3.y, s3.z), nxt, next_valid, np, nn, nd, gM)) continue;
+            float *dst = T.inst_grad + 12 * (size_t) off;
+            for (int k = 0; k < 12; ++k) if (gM[k] != 0.f) atomicAdd(dst + k, gM[k]);
+            continue;
         }
         /* the emitter sample: w_em = ds.d (surface emitters: normalize(ds.p - si.p), recomputed from the interpolated point) */
         {

@@ -42,6 +42,21 @@ struct ShapeVertex {
     ShapeDirTerm nee, ind;
 };
 
+/* adjoint of the point p a direction block starts from: w = normalize(y - p) enters cos = <w, n> (n = the normal the BSDF's cosine uses) and
+ * log J = log |<m, w>| - 2 log |y - p|.  Zero for a detached direction (w given, J = 1). */
+HAR_HD Vec3 dir_term_point_adjoint(const ShapeDirTerm &T, Vec3 p, Vec3 n) {
+    if (!T.on || !T.attached) return Vec3(0.f);
+    const Vec3 D = T.target - p;
+    const float r2 = dot3(D, D), r = sqrtf(r2);
+    const Vec3 u = D * rcp_(r);
+    const float c = dot3(T.normal, u);
+    Vec3 u_bar = n * T.cos_bar;                            /* d cos / d w */
+    if (c != 0.f) u_bar = u_bar + T.normal * (T.a / c);    /* d log |<m, u>| / d u */
+    /* u = D / |D|, D = y - p:  du = -(dp - u <u, dp>) / r;  log J also holds -2 log r, dr = -<u, dp> */
+    const Vec3 proj = u_bar - u * dot3(u, u_bar);
+    return u * (2.f * T.a / r) - proj * rcp_(r);
+}
+
 /* adds d objective / d P_k to g[k] */
 HAR_HD void shape_vertex_adjoint(const ShapeVertex &v, Vec3 g[3]) {
     const float b0 = 1.f - v.b1 - v.b2;
@@ -56,16 +71,7 @@ HAR_HD void shape_vertex_adjoint(const ShapeVertex &v, Vec3 g[3]) {
         const ShapeDirTerm &T = *terms[k];
         if (!T.on) continue;
         n_bar = n_bar + T.w * T.cos_bar;                       /* cos = <w, n> */
-        if (!T.attached) continue;
-        const Vec3 D = T.target - p;
-        const float r2 = dot3(D, D), r = sqrtf(r2);
-        const Vec3 u = D * rcp_(r);
-        const float c = dot3(T.normal, u);
-        Vec3 u_bar = n * T.cos_bar;                            /* d cos / d w */
-        if (c != 0.f) u_bar = u_bar + T.normal * (T.a / c);    /* d log |<m, u>| / d u */
-        /* u = D / |D|, D = y - p:  du = -(dp - u <u, dp>) / r;  log J also holds -2 log r, dr = -<u, dp> */
-        const Vec3 proj = u_bar - u * dot3(u, u_bar);
-        p_bar = p_bar - proj * rcp_(r) + u * (2.f * T.a / r);
+        p_bar = p_bar + dir_term_point_adjoint(T, p, n);
     }
     /* texture coordinates -> barycentric coordinates -> (p - p_att) */
     float b1_bar, b2_bar;
@@ -175,6 +181,44 @@ HAR_HD bool shape_item_adjoint(const DScene &S, const ShapeItem &it, uint32_t bs
     }
     if (!any) return false;
     shape_vertex_adjoint(v, g);
+    return true;
+}
+
+/* The same vertex on INSTANCED geometry, differentiated w.r.t. the instance's `to_world` (Instance::compute_surface_interaction with an attached
+ * transform, src/shapes/instance.cpp:150-266): the nested interaction is detached, `si.p = to_world * p_obj` carries the motion (:191-193), the
+ * normals use dr::detach(to_world) and uv is not attached (:250-251), and without FollowShape the point is put back onto the ray,
+ *   t = (<n, p_att> - <n, o>) / <n, d>,  p = ray(t)   (:240-249)   =>   p_att_bar = n <p_bar, d> / <n, d>,   to_world_bar = p_att_bar (x) (p_obj, 1).
+ * Any vertex normals / texcoords of the nested mesh are fine (they are values here).  gM: 12 floats, column-major 3x4 like DInst::to_world. */
+HAR_HD bool instance_item_adjoint(const DScene &S, const ShapeItem &it, uint32_t inst, uint32_t bsdf, bool visible, Vec3 L, Vec3 dl, Vec3 dLr_drho,
+                                  bool has_next, bool next_valid, Vec3 next_p, Vec3 next_n, Vec3 next_d, float gM[12]) {
+    const DMesh M = S.meshes[it.shape];
+    const uint32_t *f = S.faces + 4 * (size_t) (M.foff + it.prim);
+    const float *r0 = S.verts + 8 * (size_t) (M.voff + f[0]), *r1 = S.verts + 8 * (size_t) (M.voff + f[1]), *r2 = S.verts + 8 * (size_t) (M.voff + f[2]);
+    const Vec3 p_obj = fma3(Vec3(r0[0], r0[1], r0[2]), 1.f - it.b1 - it.b2, fma3(Vec3(r1[0], r1[1], r1[2]), it.b1, Vec3(r2[0], r2[1], r2[2]) * it.b2));
+    const SurfInt si = compute_si(S, it.d_in, 0.f, it.b1, it.b2, it.prim, it.shape, inst);      /* world-space p, geometric normal n, shading normal sn, uv */
+    const DBsdf B = S.bsdfs[bsdf];
+    const float sign = (it.nee_flags & HAR_SHAPE_FLIPPED) ? -1.f : 1.f;
+    TexTaps taps; const Vec3 rho = bsdf_reflectance(S, B, si.uv_x, si.uv_y, taps);
+    const bool lit = (it.nee_flags & HAR_SHAPE_LIT) != 0u;
+    Vec3 p_bar(0.f);
+    if ((it.nee_flags & HAR_SHAPE_NEE) && (it.nee_flags & HAR_SHAPE_NEE_SURFACE) && visible && lit && it.cos_em > 0.f) {
+        const Vec3 k = dl * dLr_drho;
+        const float s = k.x * rho.x + k.y * rho.y + k.z * rho.z;
+        ShapeDirTerm T; T.on = true; T.attached = true; T.target = it.q; T.normal = it.n_e; T.w = it.w_em; T.cos_bar = sign * s / it.cos_em; T.a = s;
+        p_bar = p_bar + dir_term_point_adjoint(T, si.p, si.sn);
+    }
+    if (has_next && next_valid) {
+        const Vec3 k = dl * L;
+        const float cos_ind = sign * dot3(next_d, si.sn);
+        ShapeDirTerm T; T.on = true; T.attached = true; T.target = next_p; T.normal = next_n; T.w = next_d; T.cos_bar = 0.f;
+        if (lit && cos_ind > 0.f) T.cos_bar = sign * ((rho.x != 0.f ? k.x : 0.f) + (rho.y != 0.f ? k.y : 0.f) + (rho.z != 0.f ? k.z : 0.f)) / cos_ind;
+        T.a = k.x + k.y + k.z;
+        p_bar = p_bar + dir_term_point_adjoint(T, si.p, si.sn);
+    }
+    if (p_bar.x == 0.f && p_bar.y == 0.f && p_bar.z == 0.f) return false;
+    const Vec3 patt_bar = si.n * (dot3(p_bar, it.d_in) / dot3(si.n, it.d_in));
+    const float ph[4] = { p_obj.x, p_obj.y, p_obj.z, 1.f };
+    for (int c = 0; c < 4; ++c) { gM[3 * c] = patt_bar.x * ph[c]; gM[3 * c + 1] = patt_bar.y * ph[c]; gM[3 * c + 2] = patt_bar.z * ph[c]; }
     return true;
 }
 

@@ -747,19 +747,38 @@ static V3 path_sample(const Scene &sc, Pcg32 &rng, Ray ray, uint32_t max_depth, 
 //  Slots 0..8 = coordinates of the three vertices of the triangle hit at the current vertex (the next interaction is detached).
 // ---------------------------------------------------------------------------
 
-constexpr int kShapeSlots = 9;
+constexpr int kShapeSlots = 12;      /* 9 vertex coordinates of a top-level triangle, or the 12 entries of an instance's to_world */
 typedef Dual<kShapeSlots> Dn;
 typedef Dual3<kShapeSlots> Dn3;
 static inline Dn3 dn3(V3 v) { return Dn3((double) v.x, (double) v.y, (double) v.z); }
 
-struct AttachedSI { Dn3 p, n, sn; Dn uv[2]; bool diff = false; uint32_t mesh = 0, vid[3] = { 0, 0, 0 }; };
+struct AttachedSI { Dn3 p, n, sn; Dn uv[2]; bool diff = false; uint32_t mesh = 0, vid[3] = { 0, 0, 0 }; uint32_t inst = 0xffffffffu; /* != none: the slots are to_world[0..11] of this instance */ };
 
 /* Mesh::compute_surface_interaction with AD-attached vertex positions (src/render/mesh.cpp:2286-2323) and
  * SurfaceInteraction::attach_motion without FollowShape (include/mitsuba/render/interaction.h:525-545): the point stays on the
  * (detached) ray and follows the moving tangent plane; the barycentric coordinates pick up the motion of that point relative to
  * the triangle.  `shading` = false is RayFlags::Minimal (p, t, n only). */
-static AttachedSI attach_si(const Scene &sc, const Ray &ray, const PI &pi, const SI &si, const uint8_t *mask, int slot, bool shading) {
+static AttachedSI attach_si(const Scene &sc, const Ray &ray, const PI &pi, const SI &si, const uint8_t *mask, int slot, bool shading, const uint8_t *inst_mask = nullptr) {
     AttachedSI a; a.p = dn3(si.p); a.n = dn3(si.n); a.sn = dn3(si.sn); a.uv[0] = Dn((double) si.uv[0]); a.uv[1] = Dn((double) si.uv[1]);
+    if (pi.valid() && pi.inst != 0xffffffffu && inst_mask && inst_mask[pi.inst]) {
+        /* Instance::compute_surface_interaction with an attached `to_world` (src/shapes/instance.cpp:150-266): the nested interaction is computed
+         * with gradients suspended (:181-189), "hit point si.p is only attached to the surface motion" (:191-193: si.p = to_world * si.p, the normals
+         * use dr::detach(to_world)), and without FollowShape the point is re-intersected with the moving tangent plane (:240-249):
+         * si.t = (<n, p> - <n, o>) / <n, d>, si.p = ray(si.t).  uv and both normals stay detached (the TODOs at :250-251). */
+        const OrcInstance &in = sc.instances[pi.inst];
+        const Mesh &m = sc.meshes[pi.shape];
+        const uint32_t *f = &m.F[4 * (size_t) pi.prim];
+        const float *r0 = &m.V[8 * (size_t) f[0]], *r1 = &m.V[8 * (size_t) f[1]], *r2 = &m.V[8 * (size_t) f[2]];
+        const double b1 = pi.u, b2 = pi.v, b0 = 1.0 - b1 - b2;
+        const double po[3] = { r0[0] * b0 + r1[0] * b1 + r2[0] * b2, r0[1] * b0 + r1[1] * b1 + r2[1] * b2, r0[2] * b0 + r1[2] * b1 + r2[2] * b2 };   /* object-space hit point */
+        Dn M[12]; for (int k = 0; k < 12; ++k) M[k] = Dn::param(in.to_world[k], slot + k);
+        Dn3 p_att(M[0] * po[0] + M[3] * po[1] + M[6] * po[2] + M[9], M[1] * po[0] + M[4] * po[1] + M[7] * po[2] + M[10], M[2] * po[0] + M[5] * po[1] + M[8] * po[2] + M[11]);
+        Dn3 nd = dn3(si.n), o = dn3(ray.o), d = dn3(ray.d);
+        Dn t_att = ddot(p_att - o, nd) / ddot(nd, d);
+        a.p = replace_grad3(si.p.x, si.p.y, si.p.z, o + d * t_att);
+        a.diff = true; a.inst = pi.inst; a.mesh = pi.shape;
+        return a;
+    }
     if (!pi.valid() || pi.inst != 0xffffffffu || !mask || !mask[pi.shape]) return a;
     const Mesh &m = sc.meshes[pi.shape];
     const uint32_t *f = &m.F[4 * (size_t) pi.prim];
@@ -816,9 +835,10 @@ static inline void dir_and_jacobian(const Dn3 &o, const Dn3 &p, const Dn3 &n, Dn
     J = dabs(ddot(n, dir)) / d2;
 }
 
-struct ShapeSink { double *const *pos; const uint8_t *mask; };
+struct ShapeSink { double *const *pos; const uint8_t *mask; double *inst = nullptr; const uint8_t *inst_mask = nullptr; /* 12 per instance: d / d to_world (column-major 3x4) */ };
 static inline void shape_scatter(const ShapeSink &sk, const AttachedSI &a, int slot, const double g[kShapeSlots]) {
     if (!a.diff) return;
+    if (a.inst != 0xffffffffu) { for (int k = 0; k < 12; ++k) sk.inst[12 * (size_t) a.inst + k] += g[slot + k]; return; }
     double *dst = sk.pos[a.mesh];
     for (int k = 0; k < 3; ++k) for (int c = 0; c < 3; ++c) dst[3 * (size_t) a.vid[k] + c] += g[slot + 3 * k + c];
 }
@@ -1024,7 +1044,7 @@ static V3 prb_sample(const Scene &sc, Pcg32 &rng, Ray ray, uint32_t max_depth, u
             /* prb.py:124-141 (attached si), :176-216 (emitter sampling with the attached shading point), :261-297 (attached wo, J):
                d/d(vertex positions) of  Lr_dir + Lr_ind  for a `diffuse` BSDF, f * cos = rho(uv) / pi * cos_theta_o */
             const ShapeSink &sk = *grad->shape;
-            AttachedSI a = attach_si(sc, ray, pi, si, sk.mask, 0, true);
+            AttachedSI a = attach_si(sc, ray, pi, si, sk.mask, 0, true, sk.inst_mask);
             Dn3 rho = bsdf.textured ? tex_eval_dual(sc.textures[bsdf.rec->p.texture], bsdf.tl, a.uv) : dn3(bsdf.slot0);
             double g[kShapeSlots]; for (int k = 0; k < kShapeSlots; ++k) g[k] = 0.0;
             const double dl[3] = { dL.x, dL.y, dL.z };
@@ -1515,8 +1535,10 @@ int orc_render_weights(const OrcSensor *s, uint32_t seed, uint32_t spp, uint64_t
 static int prb_backward_impl(void *scene, const OrcSensor *sp, const float *grad_in, uint32_t seed, uint32_t spp,
                              int32_t max_depth, int32_t rr_depth, float *grad_reflectance, float *const *grad_textures,
                              float *grad_emitters, const uint8_t *pos_mask, double *const *grad_positions, OrcStats *stats, int threads,
-                             uint64_t lb = 0, uint64_t le = 0, const float *weight_film = nullptr, float *grad_bsdf_params = nullptr) {
+                             uint64_t lb = 0, uint64_t le = 0, const float *weight_film = nullptr, float *grad_bsdf_params = nullptr,
+                             const uint8_t *inst_mask = nullptr, double *grad_to_world = nullptr) {
     Scene &sc = *(Scene *) scene; const OrcSensor &s = *sp;
+    if (inst_mask) for (const BsdfRecord &b : sc.bsdfs) if (b.p.type != 0) return -2;
     if (pos_mask) {           /* the attached-geometry restatement covers `diffuse` BSDFs on flat-shaded top-level meshes */
         for (const BsdfRecord &b : sc.bsdfs) if (b.p.type != 0) return -2;           /* `diffuse`, plain or inside `twosided` */
         for (size_t m = 0; m < sc.meshes.size(); ++m) if (pos_mask[m] && ((sc.meshes[m].flags & 1u) || m >= sc.top_count)) return -3;
@@ -1541,6 +1563,7 @@ static int prb_backward_impl(void *scene, const OrcSensor *sp, const float *grad
     std::vector<std::vector<float>> g_refl(threads), g_emit(threads), g_extra(threads);
     std::vector<std::vector<std::vector<float>>> g_tex(threads);
     std::vector<std::vector<std::vector<double>>> g_pos(threads);
+    std::vector<std::vector<double>> g_inst(threads);
     std::vector<OrcStats> sts(threads, OrcStats{});
     uint32_t md = (uint32_t) max_depth, rd = (uint32_t) rr_depth;
     parallel_lanes(lb, le, threads, [&](int t, uint64_t b, uint64_t e) {
@@ -1558,6 +1581,10 @@ static int prb_backward_impl(void *scene, const OrcSensor *sp, const float *grad
             if (g_pos[t].empty()) { g_pos[t].resize(sc.meshes.size()); for (size_t m = 0; m < sc.meshes.size(); ++m) if (pos_mask[m]) g_pos[t][m].assign(3 * (size_t) sc.meshes[m].nv, 0.0); }
             for (size_t m = 0; m < sc.meshes.size(); ++m) pp[m] = pos_mask[m] ? g_pos[t][m].data() : nullptr;
             sink.shape = &shape;
+        }
+        if (inst_mask) {
+            if (g_inst[t].empty()) g_inst[t].assign(12 * sc.instances.size() + 12, 0.0);
+            shape.inst = g_inst[t].data(); shape.inst_mask = inst_mask; sink.shape = &shape;
         }
         for (uint64_t i = b; i < e; ++i) {
             Lane L = make_lane(s, seed, spp, i);
@@ -1600,6 +1627,7 @@ static int prb_backward_impl(void *scene, const OrcSensor *sp, const float *grad
         if (grad_bsdf_params) for (size_t i = 0; i < 15 * nb; ++i) grad_bsdf_params[i] += g_extra[t][i];
         for (size_t k = 0; k < sc.textures.size(); ++k)
             if (grad_textures && grad_textures[k]) { float *dst = grad_textures[k]; for (size_t i = 0; i < g_tex[t][k].size(); ++i) dst[i] += g_tex[t][k][i]; }
+        if (inst_mask && grad_to_world && !g_inst[t].empty()) for (size_t i = 0; i < 12 * sc.instances.size(); ++i) grad_to_world[i] += g_inst[t][i];
         if (pos_mask && !g_pos[t].empty())
             for (size_t m = 0; m < sc.meshes.size(); ++m) if (pos_mask[m] && grad_positions[m]) for (size_t i = 0; i < g_pos[t][m].size(); ++i) grad_positions[m][i] += g_pos[t][m][i];
     }
@@ -1659,6 +1687,14 @@ int orc_render_prb_backward_shape(void *scene, const OrcSensor *sp, const float 
                                   int32_t max_depth, int32_t rr_depth, float *grad_reflectance, float *const *grad_textures,
                                   const uint8_t *pos_mask, double *const *grad_positions, OrcStats *stats, int threads) {
     return prb_backward_impl(scene, sp, grad_in, seed, spp, max_depth, rr_depth, grad_reflectance, grad_textures, nullptr, pos_mask, grad_positions, stats, threads);
+}
+/* + d/d(to_world) of the instances with inst_mask[i] != 0 (Instance::compute_surface_interaction, instance.cpp:150-266, with an attached transform):
+ * grad_to_world = 12 doubles per instance, column-major 3x4 like OrcInstance::to_world (accumulated into).  -2: a BSDF other than `diffuse`. */
+int orc_render_prb_backward_instances(void *scene, const OrcSensor *sp, const float *grad_in, uint32_t seed, uint32_t spp,
+                                      int32_t max_depth, int32_t rr_depth, float *grad_reflectance, float *const *grad_textures,
+                                      const uint8_t *inst_mask, double *grad_to_world, OrcStats *stats, int threads) {
+    return prb_backward_impl(scene, sp, grad_in, seed, spp, max_depth, rr_depth, grad_reflectance, grad_textures, nullptr, nullptr, nullptr, stats, threads,
+                             0, 0, nullptr, nullptr, inst_mask, grad_to_world);
 }
 void orc_scene_set_vertex_positions(void *scene, uint32_t mesh, const float *positions) {       /* + rebuild of the acceleration structure */
     Scene &sc = *(Scene *) scene;

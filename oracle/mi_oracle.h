@@ -231,6 +231,12 @@ void orc_scene_set_alpha_only(void *scene, int on);
 int orc_render_prb_backward_shape(void *scene, const OrcSensor *s, const float *grad_in, uint32_t seed, uint32_t spp, int32_t max_depth,
                                   int32_t rr_depth, float *grad_reflectance, float *const *grad_textures, const uint8_t *pos_mask,
                                   double *const *grad_positions, OrcStats *stats, int threads);
+/* + gradients w.r.t. the `to_world` of instances (Instance::compute_surface_interaction with an attached transform, src/shapes/instance.cpp:150-266:
+ * the hit point follows to_world and is re-intersected with the moving tangent plane, normals and uv stay detached): 12 doubles per instance,
+ * column-major 3x4, accumulated into; instances with inst_mask[i] == 0 are not differentiated.  `diffuse` BSDFs only (-2 otherwise). */
+int orc_render_prb_backward_instances(void *scene, const OrcSensor *s, const float *grad_in, uint32_t seed, uint32_t spp, int32_t max_depth,
+                                      int32_t rr_depth, float *grad_reflectance, float *const *grad_textures, const uint8_t *inst_mask,
+                                      double *grad_to_world, OrcStats *stats, int threads);
 /* params['mesh.vertex_positions'] = ...; params.update(): new positions (3 floats per vertex) of a top-level mesh + acceleration rebuild */
 void orc_scene_set_vertex_positions(void *scene, uint32_t mesh, const float *positions);
 /* HDRFilm::develop (hdrfilm.cpp:398-399): image[h][w][3] = RGB / (W==0?1:W) */

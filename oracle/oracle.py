@@ -550,6 +550,31 @@ class OracleScene:
             raise RuntimeError("orc_render_prb_backward_shape: rc = %d" % rc)
         return g_pos, g_refl, g_tex, st
 
+    def render_prb_backward_instances(self, sensor, grad_in, instances=None, seed=0, spp=4, max_depth=6, rr_depth=5, threads=0):
+        """as render_prb_backward, plus (instance_count, 3, 4) float64: d loss / d to_world (row r, column c; the 4th row of the 4x4 is constant)"""
+        grad_in = f32(grad_in); ni = len(self.data.instances)
+        g_refl = np.zeros((len(self.data.bsdfs), 3), np.float32)
+        g_tex = [np.zeros_like(t) for t in self.data.textures]
+        ptrs = (c_f32p * max(1, len(g_tex)))(*[fp(g) for g in g_tex])
+        mask = np.zeros(max(1, ni), np.uint8); mask[list(range(ni)) if instances is None else list(instances)] = 1
+        g = np.zeros((max(1, ni), 12), np.float64)
+        st = Stats()
+        L = lib(); L.orc_render_prb_backward_instances.restype = C.c_int
+        L.orc_render_prb_backward_instances.argtypes = [C.c_void_p, C.POINTER(Sensor), c_f32p, C.c_uint32, C.c_uint32, C.c_int32, C.c_int32, c_f32p,
+                                                        C.POINTER(c_f32p), C.c_void_p, C.c_void_p, C.POINTER(Stats), C.c_int]
+        rc = L.orc_render_prb_backward_instances(self.handle, C.byref(sensor), fp(grad_in), seed, spp, max_depth, rr_depth, fp(g_refl), ptrs,
+                                                 mask.ctypes.data, g.ctypes.data, C.byref(st), threads)
+        if rc != 0:
+            raise RuntimeError("orc_render_prb_backward_instances: rc = %d" % rc)
+        return g[:ni].reshape(ni, 4, 3).transpose(0, 2, 1).copy(), g_refl, g_tex, st       # column-major 3x4 -> [row][col]
+
+    def set_instance_to_world(self, inst, m4):
+        """new to_world (4x4, affine) of an instance + rebuild of the instance-level acceleration structure"""
+        m = np.asarray(m4, np.float64).reshape(4, 4); inv = np.linalg.inv(m)
+        tw = f32(m[:3, :].T.reshape(-1)); to = f32(inv[:3, :].T.reshape(-1))
+        L = lib(); L.orc_scene_set_instance_transform.restype = None; L.orc_scene_set_instance_transform.argtypes = [C.c_void_p, C.c_uint32, c_f32p, c_f32p]
+        L.orc_scene_set_instance_transform(self.handle, inst, fp(tw), fp(to))
+
     def set_vertex_positions(self, mesh, positions):
         p = f32(positions).reshape(-1, 3)
         assert p.shape[0] == self.data.meshes[mesh]["V"].shape[0]

@@ -178,8 +178,8 @@ float hh_rfilter_eval(const HarSensor *sensor, float x) {
 /* vertex-position gradients: the lane-by-lane equivalent of (k_shade<ADJOINT, diffuse, SHAPE> -> k_resolve -> k_shape_adjoint), i.e. the product's
  * hand-derived adjoint (har_shape_grad.h) driven exactly as the kernels drive it.  adj = grad_in / W (H x W x 3); grad[m] = 3 doubles per vertex
  * of mesh m or NULL. */
-int hh_render_backward_shape(void *h, const HarSensor *sensor, const float *adj, uint32_t seed, uint32_t spp, int32_t max_depth, int32_t rr_depth,
-                             double *const *grad) {
+static int backward_shape_impl(void *h, const HarSensor *sensor, const float *adj, uint32_t seed, uint32_t spp, int32_t max_depth, int32_t rr_depth,
+                               double *const *grad, double *inst_grad) {
     HScene *H = (HScene *) h; const DScene &S = H->ds;
     if ((S.bsdf_types & 0x7fffffffu) != HAR_BSDF_ONLY_DIFFUSE) return -2;
     DSensor C; std::string e; if (!lower_sensor(*sensor, C, e)) return -1;
@@ -221,7 +221,15 @@ int hh_render_backward_shape(void *h, const HarSensor *sensor, const float *adj,
                 next_valid = next.t != HAR_INF;
                 if (next_valid) { SurfInt sn = compute_si(S, R.next.d, next.t, next.u, next.v, next.prim, next.shape, next.inst); np = sn.p; nn = sn.n; }
             }
-            if (R.item && hit.inst == 0xffffffffu && grad[hit.shape]) {
+            if (R.item && hit.inst != 0xffffffffu && inst_grad) {       /* d / d to_world of the instance (instance_item_adjoint), as k_shape_adjoint drives it */
+                ShapeItem it; it.shape = hit.shape; it.prim = hit.prim; it.b1 = hit.u; it.b2 = hit.v; it.d_in = st.d;
+                it.next_slot = R.alive ? 0u : HAR_SHAPE_NO_NEXT;
+                it.q = R.nee_p; it.n_e = R.nee_n; it.cos_em = R.cos_em; it.nee_flags = R.item_ray ? R.nee_flags : (R.nee_flags & HAR_SHAPE_LIT); it.w_em = Vec3(0.f);
+                float gM[12];
+                if (instance_item_adjoint(S, it, hit.inst, R.bsdf, visible, L, dl, R.dLr_drho, R.alive, next_valid, np, nn, R.next.d, gM))
+                    for (int k = 0; k < 12; ++k) inst_grad[12 * (size_t) hit.inst + k] += gM[k];
+            }
+            if (R.item && hit.inst == 0xffffffffu && grad && grad[hit.shape]) {
                 ShapeItem it; it.shape = hit.shape; it.prim = hit.prim; it.b1 = hit.u; it.b2 = hit.v; it.d_in = st.d;
                 it.next_slot = R.alive ? 0u : HAR_SHAPE_NO_NEXT;
                 it.q = R.nee_p; it.n_e = R.nee_n; it.cos_em = R.cos_em; it.nee_flags = R.item_ray ? R.nee_flags : (R.nee_flags & HAR_SHAPE_LIT);
@@ -237,6 +245,16 @@ int hh_render_backward_shape(void *h, const HarSensor *sensor, const float *adj,
         }
     }
     return status;
+}
+
+int hh_render_backward_shape(void *h, const HarSensor *sensor, const float *adj, uint32_t seed, uint32_t spp, int32_t max_depth, int32_t rr_depth,
+                             double *const *grad) {
+    return backward_shape_impl(h, sensor, adj, seed, spp, max_depth, rr_depth, grad, nullptr);
+}
+/* instance to_world gradients: inst_grad = 12 doubles per instance (column-major 3x4) */
+int hh_render_backward_instances(void *h, const HarSensor *sensor, const float *adj, uint32_t seed, uint32_t spp, int32_t max_depth, int32_t rr_depth,
+                                 double *inst_grad) {
+    return backward_shape_impl(h, sensor, adj, seed, spp, max_depth, rr_depth, nullptr, inst_grad);
 }
 
 /* --- traversal statistics (tools/trace_stats.py): per-ray event counts and a lock-step SIMT model of the

@@ -156,3 +156,117 @@ def test_product_host_adjoint_matches_oracle(mi, O, which):
     for m in ids:
         scale = np.abs(want[m]).max()
         assert scale > 0 and np.abs(got[m] - want[m]).max() < 2e-3 * scale, (which, m, np.abs(got[m] - want[m]).max() / scale)
+
+
+# ------------------------------------------------------------------ instance to_world gradients (instance.cpp:150-266)
+
+def instanced_slab_scene(mi, res=24, env=False):
+    """the slab scene with the floor and the ceiling as INSTANCES of one shape group (a unit quad with vertex normals and texcoords), each with a
+    rotating / scaling / translating to_world; still no visibility boundary within reach of the camera"""
+    T = mi.ScalarTransform4f
+    d = slab_scene(mi, res, env=env)
+    quad_p = np.array([[-1, 0, -1], [1, 0, -1], [1, 0, 1], [-1, 0, 1]], np.float32)
+    quad = {"type": "mesh", "positions": quad_p, "normals": np.tile([0, 1, 0], (4, 1)).astype(np.float32), "texcoords": np.array([[0, 0], [8, 0], [8, 8], [0, 8]], np.float32),
+            "faces": np.array([[0, 2, 1], [0, 3, 2]], np.uint32), "bsdf": d["floor"]["bsdf"]}
+    d.pop("floor"); d.pop("ceiling", None)
+    d["group"] = {"type": "shapegroup", "quad": quad}
+    d["floor"] = {"type": "instance", "to_world": T().translate([0.2, 0.0, -0.1]).rotate([0, 1, 0], 25.0).scale([40, 1, 40]), "group": {"type": "ref", "id": "group"}}
+    if not env:
+        d["ceiling"] = {"type": "instance", "to_world": T().translate([0, 3.0, 0]).rotate([1, 0, 0], 180.0).rotate([0, 1, 0], -10.0).scale([40, 1, 40]), "group": {"type": "ref", "id": "group"}}
+    return d
+
+
+def set_instance_matrix(scene, i, m4):
+    """host-side scene description only: (group, to_world, to_object) column-major 3x4"""
+    m = np.asarray(m4, np.float64).reshape(4, 4); inv = np.linalg.inv(m)
+    g = scene.instances[i][0]
+    scene.instances[i] = (g, [float(x) for x in m[:3, :].T.reshape(-1)], [float(x) for x in inv[:3, :].T.reshape(-1)])
+
+
+def instance_matrix(scene, i):
+    m = np.eye(4); m[:3, :] = np.asarray(scene.instances[i][1], np.float64).reshape(4, 3).T
+    return m
+
+
+@pytest.mark.parametrize("variant", ["plain", "env"])
+def test_oracle_instance_gradient_vs_finite_differences(mi, O, variant):
+    """d/d(to_world) sum(w * image) for motions of the instanced floor / ceiling that keep visibility smooth: lift, tilt about x, in-plane rotation
+    and in-plane scale (the last two only move the hit point within the plane: with detached uv and normals -- instance.cpp:250-251 --
+    the attached computation sees nothing, and on an untextured unbounded plane neither does the image)."""
+    res = 12
+    scene = mi.load_dict(instanced_slab_scene(mi, res, env=variant == "env"))
+    osc, sensor = O.scene_from_product(scene)
+    kw = dict(seed=7, spp=1024, max_depth=4)
+    w = np.random.default_rng(2).uniform(0.5, 1.5, (res, res, 3)).astype(np.float32)
+    g, _, _, _ = osc.render_prb_backward_instances(sensor, w, None, **kw)
+    assert g.shape == (len(scene.instances), 3, 4)
+
+    def loss():
+        sc2, _ = O.scene_from_product(scene)
+        img, _ = sc2.render_prb(sensor, **kw)
+        return float((img.astype(np.float64) * w).sum())
+
+    def rot_x(a):
+        c, s = np.cos(a), np.sin(a); return np.array([[1, 0, 0, 0], [0, c, -s, 0], [0, s, c, 0], [0, 0, 0, 1.0]])
+
+    def rot_y(a):
+        c, s = np.cos(a), np.sin(a); return np.array([[c, 0, s, 0], [0, 1, 0, 0], [-s, 0, c, 0], [0, 0, 0, 1.0]])
+
+    for i in range(len(scene.instances)):
+        base = instance_matrix(scene, i)
+        assert np.abs(g[i]).max() > 0
+        motions = {"lift": lambda e: np.array([[1, 0, 0, 0], [0, 1, 0, e], [0, 0, 1, 0], [0, 0, 0, 1.0]]) @ base,
+                   "tilt": lambda e: base @ rot_x(e), "spin": lambda e: base @ rot_y(e)}
+        lift = None
+        for label, eps in (("lift", 2e-3), ("tilt", 2e-4), ("spin", 1e-2)):
+            f = motions[label]
+            set_instance_matrix(scene, i, f(eps)); lp = loss()
+            set_instance_matrix(scene, i, f(-eps)); lm = loss()
+            set_instance_matrix(scene, i, base)
+            fd = (lp - lm) / (2 * eps)
+            dM = (f(eps) - f(-eps))[:3, :] / (2 * eps)
+            ad = float((g[i] * dM).sum())
+            if label == "lift": lift = abs(ad)
+            if label == "spin":
+                assert abs(ad) < 0.02 * lift + 1e-6 and abs(fd) < 0.05 * lift, (variant, i, label, fd, ad)
+                continue
+            assert abs(fd - ad) <= 0.03 * abs(fd) + 0.005 * lift, (variant, i, label, fd, ad)
+
+
+def instanced_cbox_scene(mi, res=20, grid=2):
+    """Cornell box (diffuse) + grid x grid rotated / scaled instances of a smooth-shaded, textured bumpy sphere and one instanced box: occluders,
+    shadows, interreflection between instances, vertex normals and texcoords on the nested meshes, a twosided record"""
+    d = mi.instanced_spheres_scene(width=res, height=res, spp=16, grid=grid, n_u=10, n_v=6)
+    d["integrator"] = {"type": "prb", "max_depth": 5, "rr_depth": 5}
+    d["green"] = {"type": "twosided", "m": d["green"]}
+    T = mi.ScalarTransform4f
+    cube = mi.load_dict({"type": "cube"})
+    d["boxes"] = {"type": "shapegroup", "b": {"type": "mesh", "positions": cube.V[:, :3].copy(), "faces": cube.F[:, :3].copy(), "bsdf": {"type": "ref", "id": "green"}}}
+    d["box0"] = {"type": "instance", "to_world": T().translate([0.3, -0.7, 0.3]).rotate([0, 1, 0], -17).scale(0.25), "group": {"type": "ref", "id": "boxes"}}
+    return d
+
+
+@pytest.mark.parametrize("which", ["slab", "slab_env", "cbox"])
+def test_product_host_instance_adjoint_matches_oracle(mi, O, which):
+    """instance_item_adjoint (har_shape_grad.h, fp32, hand-derived) against the oracle's dual numbers (fp64), instance by instance, same seed"""
+    if which == "cbox":
+        res = 20; scene = mi.load_dict(instanced_cbox_scene(mi, res))
+    else:
+        res = 16; scene = mi.load_dict(instanced_slab_scene(mi, res, env=which == "slab_env"))
+    osc, sensor = O.scene_from_product(scene)
+    w = np.random.default_rng(4).uniform(0.5, 1.5, (res, res, 3)).astype(np.float32)
+    kw = dict(seed=3, spp=16, max_depth=5)
+    want, _, _, _ = osc.render_prb_backward_instances(sensor, w, None, **kw)
+    L = harness(O)
+    L.hh_render_backward_instances.argtypes = [C.c_void_p, C.c_void_p, O.c_f32p, C.c_uint32, C.c_uint32, C.c_int32, C.c_int32, C.c_void_p]
+    desc = scene.desc(); err = C.create_string_buffer(256); h = C.c_void_p(L.hh_scene_create(C.byref(desc), err, 256)); assert h, err.value
+    film = np.zeros((res, res, 4), np.float32)
+    assert L.hh_render(h, C.byref(sensor), 1, kw["seed"], kw["spp"], kw["max_depth"], 5, 0, 0, O.fp(film)) == 0
+    wt = film[:, :, 3:4]; adj = np.ascontiguousarray(w / np.where(wt == 0, 1, wt), np.float32)
+    g = np.zeros((len(scene.instances), 12), np.float64)
+    assert L.hh_render_backward_instances(h, C.byref(sensor), O.fp(adj), kw["seed"], kw["spp"], kw["max_depth"], 5, g.ctypes.data) == 0
+    got = g.reshape(-1, 4, 3).transpose(0, 2, 1)
+    assert want.shape == got.shape and len(scene.instances) >= 1
+    for i in range(len(scene.instances)):
+        scale = np.abs(want[i]).max()
+        assert scale > 0 and np.abs(got[i] - want[i]).max() < 2e-3 * scale, (which, i, np.abs(got[i] - want[i]).max() / scale, got[i], want[i])
