@@ -1592,6 +1592,15 @@ def render(scene, params=None, sensor=0, integrator=None, seed=0, seed_grad=0, s
     if not keys:
         return integrator.render(scene, sensor, seed, spp)
     params.update()
+    # dr.enable_grad(params[key]) is what makes a parameter differentiable in the reference: switch on the adjoint terms the requested keys need
+    if integrator.type == 'prb':
+        shape_keys = [k for k in keys if k in scene._position_keys() or k in scene._instance_keys()]
+        if shape_keys and integrator.shape_gradients is not True:
+            integrator.shape_gradients = sorted(set(list(integrator.shape_gradients or [])) | set(shape_keys))
+        if any(k in scene._bsdf_param_keys() for k in keys):
+            integrator.bsdf_parameter_gradients = True
+        if any(v[0] == "emit" for k, v in scene._param_keys().items() if k in keys):
+            integrator.emitter_gradients = True
 
     class _RenderOp(torch.autograd.Function):
         @staticmethod
@@ -1603,8 +1612,8 @@ def render(scene, params=None, sensor=0, integrator=None, seed=0, seed_grad=0, s
             grads = integrator.render_backward(scene, params, grad_out, sensor, seed_grad, spp_grad)
             missing = [k for k in keys if k not in grads]
             if missing:       # e.g. emitter radiance with emitter_gradients=False, vertex positions without shape_gradients
-                raise RuntimeError("mi.render(): the `prb` integrator is not configured to differentiate %s (integrator properties `emitter_gradients`, "
-                                   "`shape_gradients`); differentiable keys of this render: %s" % (missing, sorted(grads)))
+                raise RuntimeError("mi.render(): the `prb` integrator cannot differentiate %s (integrator properties `emitter_gradients`, "
+                                   "`shape_gradients`, `bsdf_parameter_gradients`); differentiable keys of this render: %s" % (missing, sorted(grads)))
             return tuple(grads[k].reshape(params[k].shape) for k in keys)
 
     return _RenderOp.apply(*[params[k] for k in keys])

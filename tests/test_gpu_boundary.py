@@ -342,3 +342,45 @@ def test_instance_to_world_update_and_domain(mi, O):
     scene = mi.load_dict(d)
     with pytest.raises(RuntimeError, match="diffuse"):
         scene.integrator().render_backward(scene, None, np.ones((16, 16, 3), np.float32), seed=0, spp=4)
+
+
+def test_mi_render_autograd_new_parameter_kinds(mi, O):
+    """mi.render(scene, params) with requires_grad on a roughness, a complex IOR and an instance transform: the torch.autograd route switches the
+    adjoint terms on by itself (the stand-in for dr.enable_grad) and returns the same gradients as render_backward with the loss's image adjoint;
+    a descent step on `alpha` reduces the loss to the render made with the true value"""
+    import torch
+    res, spp = 48, 64
+    d = mi.instanced_spheres_scene(width=res, height=res, spp=spp, grid=3, n_u=12, n_v=6, flatten=True, materials=True)
+    d["integrator"] = {"type": "prb", "max_depth": 5, "rr_depth": 5}
+    scene = mi.load_dict(d)
+    target = mi.render(scene, spp=256, seed=50).detach()
+    params = mi.traverse(scene)
+    true_alpha = params["white.alpha.value"].clone()
+    params["white.alpha.value"] = true_alpha * 2.0
+    for k in ("white.alpha.value", "green.eta.value"):
+        params[k].requires_grad_(True)
+    img = mi.render(scene, params, spp=spp, seed=3)
+    loss = ((img - target) ** 2).mean(); loss.backward()
+    ga, ge = params["white.alpha.value"].grad.clone(), params["green.eta.value"].grad.clone()
+    assert scene.integrator().bsdf_parameter_gradients and ga.abs().max() > 0 and ge.abs().max() > 0
+    adj = (2.0 * (img.detach() - target) / img.numel())
+    # the same numbers through the explicit route (seed_grad = TEA32(seed, 1)[0], util.py:render)
+    from mitsuba3_amd.core import sample_tea_32
+    _seed_grad = lambda seed: sample_tea_32(seed, 1)[0]
+    grads = scene.integrator().render_backward(scene, None, adj, seed=_seed_grad(3), spp=spp)
+    assert torch.allclose(grads["white.alpha.value"].reshape(-1), ga.reshape(-1), rtol=1e-4, atol=1e-9)
+    assert torch.allclose(grads["green.eta.value"].reshape(-1), ge.reshape(-1), rtol=1e-4, atol=1e-9)
+    # rougher than the target: the gradient points towards smaller alpha
+    assert float(ga.reshape(-1)[0]) > 0
+
+    # instance transform through autograd on a diffuse instanced scene
+    from tests.test_shape_gradients_cpu import instanced_cbox_scene
+    scene = mi.load_dict(instanced_cbox_scene(mi, 24, grid=2))
+    params = mi.traverse(scene)
+    params["inst000.to_world"].requires_grad_(True)
+    img = mi.render(scene, params, spp=16, seed=1)
+    img.sum().backward()
+    g = params["inst000.to_world"].grad
+    osc, sensor = O.scene_from_product(scene)
+    want, _, _, _ = osc.render_prb_backward_instances(sensor, np.ones((24, 24, 3), np.float32), None, seed=_seed_grad(1), spp=16, max_depth=5)
+    assert np.abs(g.cpu().numpy()[:3] - want[0]).max() < 2e-3 * np.abs(want[0]).max()
