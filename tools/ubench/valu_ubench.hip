@@ -30,6 +30,9 @@ __global__ __launch_bounds__(256) void k(float *out, int iters, float seed) {
         if (KIND == 12) { REP64(asm volatile("v_max_f32 %0, %0, %4\n v_min_f32 %1, %1, %5\n v_max_f32 %2, %2, %4\n v_min_f32 %3, %3, %5" : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3) : "v"(b), "v"(c));) }
         if (KIND == 13) { REP64(asm volatile("v_cvt_f32_u32 %0, %4\n v_cvt_f32_u32 %1, %5\n v_cvt_f32_u32 %2, %6\n v_cvt_f32_u32 %3, %7" : "=v"(a0), "=v"(a1), "=v"(a2), "=v"(a3) : "v"(u0), "v"(u1), "v"(u2), "v"(u3));) }
         if (KIND == 14) { REP64(asm volatile("v_lshl_or_b32 %0, %4, %5, %0\n v_lshl_or_b32 %1, %4, %5, %1\n v_lshl_or_b32 %2, %4, %5, %2\n v_lshl_or_b32 %3, %4, %5, %3" : "+v"(u0), "+v"(u1), "+v"(u2), "+v"(u3) : "v"(3u), "v"(5u));) }
+        if (KIND == 15) { REP64(asm volatile("v_fma_mix_f32 %0, %4, %5, %0 op_sel_hi:[1,0,0]\n v_fma_mix_f32 %1, %4, %5, %1 op_sel:[1,0,0] op_sel_hi:[1,0,0]\n v_fma_mix_f32 %2, %6, %5, %2 op_sel_hi:[1,0,0]\n v_fma_mix_f32 %3, %6, %5, %3 op_sel:[1,0,0] op_sel_hi:[1,0,0]" : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3) : "v"(0x3c003800u), "v"(b), "v"(0x40003a00u));) }
+        if (KIND == 16) { REP64(asm volatile("v_cvt_f32_f16 %0, %4\n v_cvt_f32_f16 %1, %5\n v_cvt_f32_f16 %2, %4\n v_cvt_f32_f16 %3, %5" : "=v"(a0), "=v"(a1), "=v"(a2), "=v"(a3) : "v"(0x3c003800u), "v"(0x40003a00u));) }
+        if (KIND == 17) { REP64(asm volatile("v_fma_f32 %0, %4, %5, %0\n v_fma_f32 %1, %4, %5, %1\n v_fma_f32 %2, %6, %5, %2\n v_fma_f32 %3, %6, %5, %3" : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3) : "v"(c), "v"(b), "v"(seed));) }
         if (KIND == 8) { REP64(asm volatile("v_rcp_f32 %0, %0\n v_rcp_f32 %1, %1\n v_rcp_f32 %2, %2\n v_rcp_f32 %3, %3" : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3));) }
     }
     out[blockIdx.x * 256 + threadIdx.x] = a0 + a1 + a2 + a3 + p0.x + p0.y + p1.x + p1.y + p2.x + p3.y + __uint_as_float(u0 ^ u1 ^ u2 ^ u3);
@@ -40,10 +43,10 @@ int main() {
     int cus = prop.multiProcessorCount; double clk = prop.clockRate * 1e3;
     float *out; CHECK(hipMalloc(&out, (size_t) cus * 8 * 256 * 4));
     hipEvent_t e0, e1; CHECK(hipEventCreate(&e0)); CHECK(hipEventCreate(&e1));
-    const char *names[] = { "v_fma_f32", "v_pk_fma_f32", "v_cvt_f32_ubyteN", "v_max3/min3_f32", "v_mov_b32", "int and/lshl_or/xor/add", "v_cmp+v_cndmask", "v_mul/add/sub_f32", "v_rcp_f32", "v_perm_b32", "v_bfe_u32", "v_and_or_b32", "v_max/min_f32", "v_cvt_f32_u32", "v_lshl_or_b32" };
+    const char *names[] = { "v_fma_f32", "v_pk_fma_f32", "v_cvt_f32_ubyteN", "v_max3/min3_f32", "v_mov_b32", "int and/lshl_or/xor/add", "v_cmp+v_cndmask", "v_mul/add/sub_f32", "v_rcp_f32", "v_perm_b32", "v_bfe_u32", "v_and_or_b32", "v_max/min_f32", "v_cvt_f32_u32", "v_lshl_or_b32", "v_fma_mix_f32 (f16 src0)", "v_cvt_f32_f16", "v_fma_f32 acc (c += a*b)" };
     for (int waves_per_simd : { 2, 8 }) {
         int grid = cus * waves_per_simd;      // 256-thread block = 4 waves = 1 per SIMD
-        for (int kind = 0; kind < 15; ++kind) {
+        for (int kind = 0; kind < 18; ++kind) {
             int iters = 200;
             auto launch = [&]() {
                 switch (kind) {
@@ -62,6 +65,9 @@ int main() {
                     case 12: hipLaunchKernelGGL(k<12>, dim3(grid), dim3(256), 0, 0, out, iters, 1.0001f); break;
                     case 13: hipLaunchKernelGGL(k<13>, dim3(grid), dim3(256), 0, 0, out, iters, 1.0001f); break;
                     case 14: hipLaunchKernelGGL(k<14>, dim3(grid), dim3(256), 0, 0, out, iters, 1.0001f); break;
+                    case 15: hipLaunchKernelGGL(k<15>, dim3(grid), dim3(256), 0, 0, out, iters, 1.0001f); break;
+                    case 16: hipLaunchKernelGGL(k<16>, dim3(grid), dim3(256), 0, 0, out, iters, 1.0001f); break;
+                    case 17: hipLaunchKernelGGL(k<17>, dim3(grid), dim3(256), 0, 0, out, iters, 1.0001f); break;
                 }
             };
             launch(); CHECK(hipDeviceSynchronize());
