@@ -1,7 +1,7 @@
 /*
  * harness.cpp -- HOST TEST HARNESS (test tool, not a product path).
  *
- * Compiles the product's HAR_HD device functions (mitsuba3_amd/csrc/*.h: BVH8
+ * Compiles the product's HAR_HD device functions (headers of mitsuba3_amd/csrc: BVH8
  * traversal, surface interaction, shading stages, film footprint) and its host
  * scene lowering with g++ and drives them lane by lane, so that the logic the
  * HIP kernels execute can be checked against the oracle on a machine without
