@@ -196,7 +196,7 @@ def test_oracle_instance_gradient_vs_finite_differences(mi, O, variant):
     res = 12
     scene = mi.load_dict(instanced_slab_scene(mi, res, env=variant == "env"))
     osc, sensor = O.scene_from_product(scene)
-    kw = dict(seed=7, spp=1024, max_depth=4)
+    kw = dict(seed=7, spp=1024, max_depth=4, threads=1)      # one thread: the float32 film sums are then reproducible, the differences below are of 1e-4 steps
     w = np.random.default_rng(2).uniform(0.5, 1.5, (res, res, 3)).astype(np.float32)
     g, _, _, _ = osc.render_prb_backward_instances(sensor, w, None, **kw)
     assert g.shape == (len(scene.instances), 3, 4)
@@ -218,7 +218,7 @@ def test_oracle_instance_gradient_vs_finite_differences(mi, O, variant):
         motions = {"lift": lambda e: np.array([[1, 0, 0, 0], [0, 1, 0, e], [0, 0, 1, 0], [0, 0, 0, 1.0]]) @ base,
                    "tilt": lambda e: base @ rot_x(e), "spin": lambda e: base @ rot_y(e)}
         lift = None
-        for label, eps in (("lift", 2e-3), ("tilt", 2e-4), ("spin", 1e-2)):
+        for label, eps in (("lift", 2e-3), ("tilt", 1e-3), ("spin", 1e-2)):
             f = motions[label]
             set_instance_matrix(scene, i, f(eps)); lp = loss()
             set_instance_matrix(scene, i, f(-eps)); lm = loss()
