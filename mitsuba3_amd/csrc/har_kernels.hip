@@ -972,7 +972,11 @@ __global__ __launch_bounds__(kBlock) void k_splat(DSensor C, uint32_t seed, uint
             for (int idx = threadIdx.x; idx < E * G; idx += kBlock) {
                 const int e = idx % E, g = idx / E, tx = e % sw, ty = e / sw, col = ox + c0 + tx;
                 float ax = 0.f, ay = 0.f, az = 0.f, aw = 0.f;
-                for (int t = 0; t < count; ++t) {
+                /* only the taps whose pixel x = col - t + nhalf is one of the block's pixels [x_first, x_last] have lanes here: at spp >= 256 that is ONE tap per
+                 * thread (a wave used to walk all `count` taps with mostly idle lanes: 5x the LDS reads) */
+                const int x_first = ox + nhalf, x_last = ext[2] + nhalf;
+                const int t_lo = max(0, col + nhalf - x_last), t_hi = min(count - 1, col + nhalf - x_first);
+                for (int t = t_lo; t <= t_hi; ++t) {
                     const int x = col - t + nhalf;
                     if (x < 0 || x >= (int) C.crop_w) continue;
                     const int64_t first = ((int64_t) y_pix * C.crop_w + x) * spp - g0;
