@@ -149,6 +149,22 @@ def test_config2_cornell_512_full_parity(mi, O):
     assert gst["paths"] == st.paths and gst["vertices"] == st.vertices
 
 
+@pytest.mark.parametrize("res,spp,rfilter", [(48, 256, "gaussian"), (40, 512, "gaussian"), (56, 64, "gaussian"), (33, 96, "gaussian"), (40, 256, "tent"), (40, 256, "box")])
+def test_splat_gather_at_high_sample_counts(mi, O, res, spp, rfilter):
+    """k_splat's LDS gather at the bench's samples per pixel: a 256-lane block holds exactly one pixel (256 spp), half a pixel (512), four
+    pixels (64) or a ragged 2.67 (96, width x spp not a multiple of 256 -> some blocks span two rows and scatter) -- the tap loop of a tile column
+    only visits the taps whose pixel has lanes in the block.  Film (RGB and the accumulated weights) vs the oracle's ImageBlock::put"""
+    d = mi.cornell_box(); d["sensor"]["film"]["width"] = res; d["sensor"]["film"]["height"] = res
+    d["sensor"]["film"]["rfilter"] = {"type": rfilter}
+    d["integrator"]["max_depth"] = 3
+    scene = mi.load_dict(d)
+    osc, sensor = O.scene_from_product(scene)
+    film = scene.integrator().render_film(scene, seed=2, spp=spp).cpu().numpy()
+    raw, _ = osc.render_path(sensor, seed=2, spp=spp, max_depth=3, raw=True)
+    assert rel_l2(film[..., 3], raw[..., 3]) < 2e-6            # the weight channel: pure filter arithmetic
+    assert rel_l2(film[..., :3], raw[..., :3]) < 1e-4
+
+
 # ------------------------------------------------------------------ texel-gradient queues (TexelQueues, har_kernels.h)
 
 @pytest.mark.parametrize("tex_res", [2, 7, 64, 512])
