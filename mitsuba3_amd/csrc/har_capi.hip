@@ -375,7 +375,7 @@ int run_chunk(HarSceneImpl *S, HarIntegratorImpl *I, const DSensor &C, int mode,
     /* adjoint replay of a cached bounce: `shade` commits the vertex adjoint itself (the shadow-ray result is in the cache), no items, no resolve launch */
     static const bool inline_env = getenv("HAR_ADJOINT_INLINE") ? atoi(getenv("HAR_ADJOINT_INLINE")) != 0 : true;
     const bool inline_commit = inline_env && mode == MODE_PRB_ADJOINT && !shape && !I->forward_mode;      /* forward mode commits in the resolve kernels (own instantiation) */
-    const ShapeTargets targets{ I->d_pos_offset, I->grad_pos, I->pos_verts, I->d_inst_slot, I->grad_inst };
+    const ShapeTargets targets{ I->d_pos_offset, I->grad_pos, I->pos_verts, I->d_inst_slot, I->grad_inst, I->inst_count };
     int cur = 0; uint32_t b = 0;
     for (; b < nb; ++b) {
         /* PRB replay cache: the primal pass of render_backward records this bounce's ray-query results per lane, the adjoint pass reads them */

@@ -79,7 +79,8 @@ struct ShapeArrays { float4 *g0, *g1, *g2, *g3; uint8_t *vis; };
 #define HAR_TQ_LDS_BYTES 24576        /* default LDS copy of a band: (rows + 1) x width x 3 floats (6 blocks per CU) */
 struct TexelQueues { float4 *rec; uint32_t *count; const uint2 *band; const uint4 *qinfo; uint32_t nq, cap; };
 #define HAR_SHAPE_INST_SHIFT 8           /* geometry records: bits 8..31 of the flags word = instance index + 1 of a vertex on instanced geometry (0: top-level) */
-struct ShapeTargets { const int32_t *offset; float *grad; uint32_t n_verts; const int32_t *inst_slot; float *inst_grad; /* per instance: slot (12 floats each in inst_grad) or -1; null = no instance is differentiated */ };
+struct ShapeTargets { const int32_t *offset; float *grad; uint32_t n_verts; const int32_t *inst_slot; float *inst_grad; uint32_t n_insts; /* per instance: slot (12 floats each in inst_grad) or -1; null = no instance is differentiated */ };
+#define HAR_LDS_GRAD_INSTS 128        /* instance-transform gradients accumulated per block in LDS (6 KB) */
 #define HAR_LDS_GRAD_VERTS 1024       /* up to this many differentiated vertices are accumulated in LDS (12 KB) before one global atomic per block and float */
 
 void launch_raygen(int mode, hipStream_t s, const DSensor &C, uint32_t seed, uint32_t spp, uint32_t log_spp, uint32_t lane_base, uint32_t n,

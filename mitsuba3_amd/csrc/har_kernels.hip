@@ -842,8 +842,13 @@ __global__ __launch_bounds__(kBlock) void k_skip_emitters(DScene S, int first, u
 __global__ __launch_bounds__(kBlock) void k_shape_adjoint(DScene S, const uint32_t *item_count, uint32_t shard_cap, ItemArrays items, ShapeArrays geo, const float4 *result,
                                                           const float4 *dL, int has_next, WaveState next, const float4 *h0, const uint2 *h1, ReplayCache rc, ShapeTargets T) {
     __shared__ float acc[3 * HAR_LDS_GRAD_VERTS];
+    /* instance transforms: every path of the chip that meets instance i adds to the same 12 floats -- per-block accumulators for the first
+     * HAR_LDS_GRAD_INSTS slots (same-line global atomics serialise at ~88 per microsecond), global atomics beyond */
+    __shared__ float iacc[12 * HAR_LDS_GRAD_INSTS];
     const bool lds = T.n_verts != 0 && T.n_verts <= HAR_LDS_GRAD_VERTS;
-    if (lds) { for (uint32_t k = threadIdx.x; k < 3 * T.n_verts; k += kBlock) acc[k] = 0.f; __syncthreads(); }
+    if (lds) { for (uint32_t k = threadIdx.x; k < 3 * T.n_verts; k += kBlock) acc[k] = 0.f; }
+    if (T.inst_grad) { for (uint32_t k = threadIdx.x; k < 12 * HAR_LDS_GRAD_INSTS; k += kBlock) iacc[k] = 0.f; }
+    __syncthreads();
     const ShardLoop Q(item_count, shard_cap);
     for (uint32_t tile = Q.first_tile(); tile * kBlock < Q.n; tile += Q.tile_step()) {
         const uint32_t local = tile * kBlock + threadIdx.x;
@@ -878,7 +883,7 @@ __global__ __launch_bounds__(kBlock) void k_shape_adjoint(DScene S, const uint32
             float gM[12];
             it.w_em = Vec3(0.f);
             if (!instance_item_adjoint(S, it, inst, __float_as_uint(items.s2[i].w) & 0xfffffu, geo.vis[i] != 0, Vec3(L4.x, L4.y, L4.z), Vec3(dl4.x, dl4.y, dl4.z), Vec3(s3.x, s3.y, s3.z), nxt, next_valid, np, nn, nd, gM)) continue;
-            float *dst = T.inst_grad + 12 * (size_t) off;
+            float *dst = (uint32_t) off < HAR_LDS_GRAD_INSTS ? iacc + 12 * off : T.inst_grad + 12 * (size_t) off;
             for (int k = 0; k < 12; ++k) if (gM[k] != 0.f) atomicAdd(dst + k, gM[k]);
             continue;
         }
@@ -898,10 +903,9 @@ __global__ __launch_bounds__(kBlock) void k_shape_adjoint(DScene S, const uint32
             else { atomicAdd(T.grad + e, g[k].x); atomicAdd(T.grad + e + 1, g[k].y); atomicAdd(T.grad + e + 2, g[k].z); }
         }
     }
-    if (lds) {
-        __syncthreads();
-        for (uint32_t k = threadIdx.x; k < 3 * T.n_verts; k += kBlock) { const float v = acc[k]; if (v != 0.f) atomicAdd(T.grad + k, v); }
-    }
+    __syncthreads();
+    if (lds) for (uint32_t k = threadIdx.x; k < 3 * T.n_verts; k += kBlock) { const float v = acc[k]; if (v != 0.f) atomicAdd(T.grad + k, v); }
+    if (T.inst_grad) for (uint32_t k = threadIdx.x; k < 12 * min(T.n_insts, (uint32_t) HAR_LDS_GRAD_INSTS); k += kBlock) { const float v = iacc[k]; if (v != 0.f) atomicAdd(T.inst_grad + k, v); }
 }
 
 /* ------------------------------------------------------------------- splat */
