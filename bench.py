@@ -163,8 +163,18 @@ def worker(args):
         else:
             dist.init_process_group(backend=backend)
         assert dist.get_world_size() == args.gpus
-    mi.set_variant("hip_ad_rgb")
     log("device %s, %d rank(s)" % (torch.cuda.get_device_name(device_index), world))
+    # preflight WITHOUT this repository's library: a pageable host-to-device copy and a reduction through PyTorch.  Twice in ~70 leases of this
+    # round a box faulted ("Memory access fault by GPU") inside the HIP runtime's own copy of the first upload, for every process started on it,
+    # with builds that run clean everywhere else; if that happens here the traceback points at this line, not at
+    # libhip_ad_rgb.so, and the launcher's retry / the reader can tell the two apart
+    pre = torch.ones(1 << 22, dtype=torch.float32).to("cuda")
+    if float(pre.sum().item()) != float(1 << 22):
+        raise SystemExit("bench.py: the GPU preflight (torch copy + sum) returned a wrong value -- this box's GPU is not usable")
+    del pre
+    torch.cuda.synchronize()
+    log("preflight ok (torch H2D copy + reduction, before libhip_ad_rgb.so is loaded)")
+    mi.set_variant("hip_ad_rgb")
 
     def sync_barrier():
         if world > 1:
