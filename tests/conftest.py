@@ -14,26 +14,13 @@ def pytest_configure(config):
 
 
 def _gpu_preflight(config):
-    """`-m gpu` sessions only, before this process touches the HIP runtime: a PyTorch-only host-to-device copy + reduction in a CHILD process.
-    Twice in ~70 leases of round 2 every process started on a box died with "Memory access fault by GPU" inside the runtime's copy of its first
-    upload -- with builds that are clean on every other box.  If the child dies that way, this session takes the
-    runtime's other copy path (shader blits instead of the SDMA engines; the variable is read when the runtime initialises, i.e. after this
-    point) and says so; the tests themselves are unchanged.  No GPU / no torch: nothing happens here, the tests report that themselves."""
+    """`-m gpu` sessions only, before this process touches the HIP runtime: see __graft_entry__.gpu_preflight (a box whose first upload faults
+    gets the runtime's other copy path; the tests themselves are unchanged)."""
     expr = (config.getoption("-m", default="") or "").strip()
-    if "gpu" not in expr or "not gpu" in expr or os.environ.get("HAR_TEST_PREFLIGHT", "1") == "0":
+    if "gpu" not in expr or "not gpu" in expr:
         return
-    import subprocess
-    code = ("import sys, torch\n"
-            "if not torch.cuda.is_available(): sys.exit(3)\n"
-            "x = torch.ones(1 << 22, dtype=torch.float32).to('cuda'); assert float(x.sum().item()) == float(1 << 22)\n")
-    try:
-        p = subprocess.run([sys.executable, "-c", code], stdout=subprocess.DEVNULL, stderr=subprocess.PIPE, timeout=600)
-    except Exception:
-        return
-    if p.returncode < 0 or p.returncode in (134, 139):
-        os.environ["HSA_ENABLE_SDMA"] = "0"
-        sys.stderr.write("[conftest] the PyTorch-only GPU preflight died (return code %d): %s\n[conftest] continuing with HSA_ENABLE_SDMA=0\n"
-                         % (p.returncode, p.stderr.decode(errors="replace").strip().splitlines()[-1:] or ""))
+    import __graft_entry__ as g
+    g.gpu_preflight()
 
 
 @pytest.fixture(scope="session", autouse=True)
