@@ -384,3 +384,73 @@ def test_mi_render_autograd_new_parameter_kinds(mi, O):
     osc, sensor = O.scene_from_product(scene)
     want, _, _, _ = osc.render_prb_backward_instances(sensor, np.ones((24, 24, 3), np.float32), None, seed=_seed_grad(1), spp=16, max_depth=5)
     assert np.abs(g.cpu().numpy()[:3] - want[0]).max() < 2e-3 * np.abs(want[0]).max()
+
+
+# ------------------------------------------------------------------ ray queries on adversarial triangle soups
+
+def _soup(rng, n, degenerate=True):
+    """n random triangles in [-1, 1]^3 of mixed sizes; every 7th duplicated exactly (ties: the later primitive wins, kdtree.h:2433-2460), every 11th
+    degenerate (zero area), every 5th axis-aligned (flat boxes), a few sharing edges exactly"""
+    c = rng.uniform(-1, 1, (n, 1, 3)); s = 10 ** rng.uniform(-2.5, -0.2, (n, 1, 1))
+    if n < 10:
+        c *= 0.2; s = np.full((n, 1, 1), 0.9)                      # a handful of large triangles around the origin
+    P = (c + s * rng.normal(size=(n, 3, 3))).astype(np.float32)
+    P[::5, :, 2] = P[::5, :1, 2]                                   # axis-aligned: zero-thickness boxes
+    if degenerate:
+        P[10::11, 2] = P[10::11, 1]                                # zero area
+    for k in range(7, n, 7):
+        P[k] = P[k - 1]                                            # exact duplicates
+    for k in range(13, n, 13):
+        P[k, 0] = P[k - 1, 1]; P[k, 1] = P[k - 1, 0]               # shared edge, opposite winding
+    V = P.reshape(-1, 3); F = np.arange(3 * n, dtype=np.uint32).reshape(n, 3)
+    return V, F
+
+
+@pytest.mark.parametrize("n_tris,instanced", [(1, False), (3, False), (200, False), (20000, False), (300, True)])
+def test_ray_queries_bitexact_on_triangle_soups(mi, O, n_tris, instanced):
+    """accelerated == brute force == oracle, bit for bit (t, u, v, prim, shape, instance) and any-hit, on soups built to hit the builder's and the
+    traversal's edge cases: single-triangle scenes, duplicates and shared edges (ties), degenerate and zero-thickness primitives, four orders of
+    magnitude of sizes; instanced: overlapping instances of two shape groups incl. a mirroring (negative determinant) and a strongly
+    non-uniform transform, next to top-level geometry"""
+    from tests.test_gpu_parity import random_rays
+    rng = np.random.default_rng(100 + n_tris)
+    T = mi.ScalarTransform4f
+    d = {"type": "scene", "integrator": {"type": "path", "max_depth": 3},
+         "sensor": {"type": "perspective", "fov": 45, "to_world": T().look_at(origin=[0, 0, 4], target=[0, 0, 0], up=[0, 1, 0]),
+                    "film": {"type": "hdrfilm", "width": 16, "height": 16, "rfilter": {"type": "box"}, "pixel_format": "rgb"}, "sampler": {"type": "independent", "sample_count": 4}},
+         "white": {"type": "diffuse", "reflectance": {"type": "rgb", "value": [0.5, 0.5, 0.5]}}}
+    V, F = _soup(rng, n_tris)
+    d["soup"] = {"type": "mesh", "positions": V, "faces": F, "bsdf": {"type": "ref", "id": "white"}}
+    if instanced:
+        for g in range(2):
+            Vg, Fg = _soup(rng, 150 + 50 * g, degenerate=False)
+            d["group%d" % g] = {"type": "shapegroup", "m": {"type": "mesh", "positions": (0.4 * Vg).astype(np.float32), "faces": Fg, "bsdf": {"type": "ref", "id": "white"}}}
+        xf = [T().translate([0.3, 0.1, -0.2]).rotate([1, 1, 0], 33.0).scale([1.0, 0.2, 2.5]),            # strongly non-uniform
+              T().translate([-0.2, 0.0, 0.1]).scale([-1.0, 1.0, 1.0]),                                   # mirroring
+              T().translate([0.25, 0.12, -0.15]).rotate([0, 0, 1], 80.0).scale(0.7),                     # overlaps the first
+              T().scale(1.3), T().translate([0.0, -0.4, 0.0]).rotate([0, 1, 0], 170.0)]
+        for k, t in enumerate(xf):
+            d["inst%d" % k] = {"type": "instance", "to_world": t, "group": {"type": "ref", "id": "group%d" % (k % 2)}}
+    scene = mi.load_dict(d)
+    osc, _ = O.scene_from_product(scene)
+    n = 200000
+    o, dd = random_rays(n, seed=n_tris)
+    o = (1.4 * o).astype(np.float32)
+    maxt = np.full(n, 3.402823466e+38, np.float32)
+    ref = osc.ray_intersect(o, dd, maxt, naive=True)
+    hit = np.isfinite(ref[0])
+    assert hit.mean() > (0.001 if n_tris < 10 else 0.05)
+    for naive in (False, True):
+        pi = scene._intersect(mi.Ray3f(o, dd, maxt), naive)
+        assert np.array_equal(pi.t.cpu().numpy(), ref[0])
+        assert np.array_equal(pi.prim_uv[0].cpu().numpy()[hit], ref[1][hit]) and np.array_equal(pi.prim_uv[1].cpu().numpy()[hit], ref[2][hit])
+        assert np.array_equal(pi.prim_index.cpu().numpy().astype(np.uint32)[hit], ref[3][hit])
+        assert np.array_equal(pi.shape_index.cpu().numpy().astype(np.uint32)[hit], ref[4][hit])
+        assert np.array_equal(pi.instance.cpu().numpy().astype(np.uint32)[hit], ref[5][hit])
+    maxt2 = np.random.default_rng(3).uniform(0.01, 3.0, n).astype(np.float32)
+    want = osc.ray_test(o, dd, maxt2)
+    for naive in (False, True):
+        assert np.array_equal(scene.ray_test(mi.Ray3f(o, dd, maxt2), naive=naive).cpu().numpy(), want)
+    # and a small render through the same structures
+    img = mi.render(scene, spp=4, seed=1).cpu().numpy()
+    assert np.isfinite(img).all()
