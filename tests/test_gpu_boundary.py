@@ -451,6 +451,13 @@ def test_ray_queries_bitexact_on_triangle_soups(mi, O, n_tris, instanced):
     want = osc.ray_test(o, dd, maxt2)
     for naive in (False, True):
         assert np.array_equal(scene.ray_test(mi.Ray3f(o, dd, maxt2), naive=naive).cpu().numpy(), want)
-    # and a small render through the same structures
-    img = mi.render(scene, spp=4, seed=1).cpu().numpy()
-    assert np.isfinite(img).all()
+    # and a render through the same structures under a constant sky (normals of mirrored / sheared instances, one-sided BSDF)
+    d["sky"] = {"type": "constant", "radiance": {"type": "rgb", "value": [0.9, 1.0, 1.1]}}
+    d["sensor"]["film"]["width"] = 48; d["sensor"]["film"]["height"] = 48
+    scene = mi.load_dict(d)
+    osc, sensor = O.scene_from_product(scene)
+    img = mi.render(scene, spp=8, seed=1).cpu().numpy()
+    ref, st = osc.render_path(sensor, seed=1, spp=8, max_depth=3)
+    assert rel_l2(img, ref) < 1e-4
+    gst = scene.integrator().stats()
+    assert gst["paths"] == st.paths and gst["vertices"] == st.vertices
