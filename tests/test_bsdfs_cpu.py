@@ -325,3 +325,38 @@ def test_oracle_prb_gradients_vs_finite_differences_materials(mi, O):
         osc.set_reflectance(bsdf, np.array(base, np.float32))
         fd = (sums[0] - sums[1]) / (2 * eps)
         assert abs(fd - g_refl[bsdf, chan]) / abs(fd) < 1.5e-2, (bsdf, fd, g_refl[bsdf, chan])
+
+
+def test_bitmap_bilinear_repeat_vs_numpy(mi, O, H):
+    """BitmapTexture::eval for a raw RGB bitmap (bitmap.cpp:834-850 -> dr::Texture<Float, 2>::eval, bilinear + repeat; texel centres at (i + 0.5) / res):
+    the diffuse BSDF's value * pi / cos(theta_o) at uv is the interpolated texel.  NON-square 7 x 3 bitmap, uv far outside [0, 1] (negative, > 2) and
+    exactly on texel centres / seams -- oracle and host-compiled product against an independent NumPy lookup"""
+    rng = np.random.default_rng(21)
+    Hh, Ww = 3, 7
+    tex = rng.uniform(0.1, 0.9, (Hh, Ww, 3)).astype(np.float32)
+    P = Pair(mi, O, H, {"type": "diffuse", "reflectance": {"type": "bitmap", "data": tex, "raw": True}})
+    # Pair builds the oracle scene without textures: give it the bitmap
+    sd = O.SceneData(); b = P.scene.bsdf_objs[P.index]
+    sd.bsdfs = [(0, 0, b.value, dict(flags=b.flags, reflectance2=b.value2, alpha_u=b.alpha_u, alpha_v=b.alpha_v, eta=b.eta, eta_c=b.eta_c, k_c=b.k_c, back=-1))]
+    sd.textures = [tex]
+    osc = O.OracleScene(sd)
+
+    def numpy_lookup(u, v):
+        px, py = np.float32(u) * Ww - np.float32(0.5), np.float32(v) * Hh - np.float32(0.5)
+        x0, y0 = int(np.floor(px)), int(np.floor(py)); fx, fy = float(px - x0), float(py - y0)
+        t = lambda x, y: tex[y % Hh, x % Ww].astype(np.float64)
+        return (1 - fy) * ((1 - fx) * t(x0, y0) + fx * t(x0 + 1, y0)) + fy * ((1 - fx) * t(x0, y0 + 1) + fx * t(x0 + 1, y0 + 1))
+
+    wi = O.f32([0.2, -0.1, 0.9]); wo = O.f32([-0.3, 0.2, 0.8]); wo /= np.linalg.norm(wo)
+    uvs = [(0.5 / Ww, 0.5 / Hh), (0.0, 0.0), (1.0, 1.0), (-0.25, 2.75), (3.9, -1.4), (1.0 - 1e-7, 0.5), ((Ww - 0.5) / Ww, (Hh - 0.5) / Hh)]
+    uvs += [tuple(rng.uniform(-3, 4, 2)) for _ in range(200)]
+    for u, v in uvs:
+        uv = O.f32([u, v]); want = numpy_lookup(u, v)
+        for which in ("oracle", "product"):
+            val = np.empty(3, np.float32); pdf = C.c_float()
+            if which == "oracle":
+                O.lib().orc_bsdf_eval_pdf(osc.handle, 0, O.fp(wi), O.fp(uv), O.fp(wo), O.fp(val), C.byref(pdf))
+            else:
+                H.hh_bsdf_eval_pdf(P.h, P.index, O.fp(wi), O.fp(uv), O.fp(wo), O.fp(val), C.byref(pdf))
+            got = val.astype(np.float64) * np.pi / float(wo[2])
+            assert np.allclose(got, want, rtol=2e-5, atol=2e-6), (which, u, v, got, want)
