@@ -1,5 +1,6 @@
 """The reference's AD integrator tests re-hosted on the product (src/integrators/tests/test_ad_integrators.py): the dict-only configurations
-DiffuseAlbedoConfig, DiffuseAlbedoGIConfig and AreaLightRadianceConfig (:227-314), the forward-mode check of test02_rendering_forward (:1318-1356)
+DiffuseAlbedoConfig, DiffuseAlbedoGIConfig, AreaLightRadianceConfig, DirectlyVisibleAreaLightRadianceConfig, ConstantEmitterRadianceConfig and
+CropWindowConfig (:227-424; of BASIC_CONFIGS_LIST the point light and the OBJ-normals configs are outside the path), the forward-mode check of test02_rendering_forward (:1318-1356)
 and the backward check of test03_rendering_backward (:1359-1396), with the error measures of check_image_error / check_gradient_error (:41-130).
 
 The reference compares against finite-difference images it ships as EXR files (tests/integrators/*.exr: absent here) which its
@@ -39,13 +40,26 @@ def config(mi, name):
                        "to_world": T().translate([1.25, 0.0, 1.0]) @ T().rotate([0, 1, 0], -90)},
              "light": {"type": "constant", "radiance": 3.0}}
         return d, sensor, "green.bsdf.reflectance.value", 3, dict(mean=0.04, max=0.4, bwd=0.0005)
+    if name == "directly_visible_area_light_radiance":
+        d = {"type": "scene", "light": {"type": "rectangle", "emitter": {"type": "area", "radiance": {"type": "rgb", "value": [1.0, 1.0, 1.0]}}}}
+        return d, sensor, "light.emitter.radiance.value", 2, dict(mean=0.02, max=0.2, bwd=0.02)
+    if name == "constant_emitter_radiance":
+        d = {"type": "scene", "plane": {"type": "rectangle", "bsdf": {"type": "diffuse"}}, "sphere": uv_sphere(), "light": {"type": "constant"}}
+        return d, sensor, "light.radiance.value", 2, dict(mean=0.02, max=0.1, bwd=0.02)
+    if name == "crop_window":
+        d = {"type": "scene", "plane": {"type": "rectangle", "bsdf": {"type": "diffuse"}}, "light": {"type": "constant"}}
+        sensor = {"type": "perspective", "to_world": T().look_at(origin=[0, 0, 4], target=[0, 0, 0], up=[0, 1, 0]),
+                  "film": {"type": "hdrfilm", "rfilter": {"type": "gaussian", "stddev": 0.5}, "width": 64, "height": 64,
+                           "crop_width": 32, "crop_height": 32, "crop_offset_x": 32, "crop_offset_y": 20}}
+        return d, sensor, "plane.bsdf.reflectance.value", 2, dict(mean=0.01, max=0.2, bwd=0.002)
     d = {"type": "scene", "plane": {"type": "rectangle", "bsdf": {"type": "diffuse", "reflectance": {"type": "rgb", "value": [1.0, 1.0, 1.0]}}}, "sphere": uv_sphere(),
          "light": {"type": "rectangle", "to_world": T().translate([1.25, 0.0, 1.0]) @ T().rotate([0, 1, 0], -90),
                    "emitter": {"type": "area", "radiance": {"type": "rgb", "value": [3.0, 3.0, 3.0]}}}}
     return d, sensor, "light.emitter.radiance.value", 2, dict(mean=0.02, max=0.4, bwd=0.0005)
 
 
-@pytest.mark.parametrize("name", ["diffuse_albedo", "diffuse_albedo_gi", "area_light_radiance"])
+@pytest.mark.parametrize("name", ["diffuse_albedo", "diffuse_albedo_gi", "area_light_radiance", "directly_visible_area_light_radiance",
+                                  "constant_emitter_radiance", "crop_window"])
 def test_reference_ad_config_forward_and_backward(mi, name):
     import torch
     d, sensor, key, max_depth, thr = config(mi, name)
@@ -77,7 +91,7 @@ def test_reference_ad_config_forward_and_backward(mi, name):
     grad = float(grads[key].double().sum().item()) / fwd_ref.size
     grad_ref = float(fwd_ref.mean()) * grad_in
     error = abs(grad - grad_ref) / max(abs(grad_ref), 1e-3)
-    # the reference's threshold is 5e-4 for its own sampler / seed; three times that here (a 128-spp estimate of the image mean has a relative
-    # standard deviation of ~1e-3 on these scenes)
+    # measured 5e-5 ... 3e-4 on all six configurations; the 5e-4 thresholds are for the reference's own sampler stream and seed, so 1.5e-3 is the
+    # floor here (a 128-spp estimate of the image mean has a relative standard deviation of ~1e-3 on these scenes)
     print("reference AD config %s: forward error mean %.4f (<= %.3f) max %.3f (<= %.2f); backward error %.2e (reference threshold %.1e)" % (name, err.mean(), thr["mean"], err.max(), thr["max"], error, thr["bwd"]))
-    assert error <= 3 * thr["bwd"], (name, grad, grad_ref, error)
+    assert error <= max(thr["bwd"], 1.5e-3), (name, grad, grad_ref, error)
