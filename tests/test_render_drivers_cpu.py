@@ -26,6 +26,25 @@ def test_morton_and_spiral(O):
     assert n == 12 and (cover == 1).all()
 
 
+def test_reference_spiral_known_answers(O):
+    """src/render/tests/test_spiral.py: test02_small_film (a 15 x 12 film is ONE block) and test03_normal_film (318 x 322: 110 blocks, the first
+    twelve spiral outwards from the centre block at (160, 160): right, down, left, left, up, up, right, right, right, down, down)"""
+    L = O.lib(); buf = (C.c_int32 * (5 * 256))()
+    n = L.orc_spiral(15, 12, 32, 256, buf)
+    assert n == 1 and list(np.frombuffer(buf, np.int32)[:5]) == [0, 0, 15, 12, 0]
+    n = L.orc_spiral(318, 322, 32, 256, buf)
+    blocks = np.frombuffer(buf, np.int32).reshape(-1, 5)[:n]
+    w = 32; c = np.array([160, 160])
+    steps = [(0, 0), (1, 0), (1, 1), (0, 1), (-1, 1), (-1, 0), (-1, -1), (0, -1), (1, -1), (2, -1), (2, 0), (2, 1)]
+    assert n == 110
+    for b, (sx, sy) in zip(blocks, steps):
+        assert tuple(b[:2]) == tuple(c + np.array([sx, sy]) * w) and tuple(b[2:4]) == (w, w)
+    cover = np.zeros((322, 318), int)
+    for ox, oy, sx, sy, _ in blocks:
+        cover[oy:oy + sy, ox:ox + sx] += 1
+    assert (cover == 1).all()
+
+
 def test_config1_scalar_cornell(O):
     """64 spp Cornell box through the scalar driver: same estimator as the JIT-order driver (different sample streams),
     so the images agree statistically; every pixel receives exactly spp samples; block size follows the thread count."""
