@@ -120,6 +120,8 @@ void build_roughplastic_tables(HostScene &hs, uint32_t index) {
 
 } // namespace
 
+void quad_gauss_legendre(int n, std::vector<float> &nodes, std::vector<float> &weights) { gauss_legendre(n, nodes, weights); }
+
 void update_roughplastic_sampling_weight(HostScene &hs, uint32_t index) {
     DBsdf &b = hs.bsdfs[index];
     float d_mean;

@@ -38,6 +38,8 @@ struct HostScene {
 
 /* RoughPlastic::parameters_changed (src/bsdfs/roughplastic.cpp:204-242): m_specular_sampling_weight from the means of the colour slots */
 void update_roughplastic_sampling_weight(HostScene &hs, uint32_t bsdf);
+/* quad::gauss_legendre (include/mitsuba/core/quad.h:27-90): nodes / weights on [-1, 1] */
+void quad_gauss_legendre(int n, std::vector<float> &nodes, std::vector<float> &weights);
 
 /* returns false and fills `err` on invalid input */
 bool lower_scene(const HarSceneDesc &desc, HostScene &out, std::string &err);

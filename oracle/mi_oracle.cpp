@@ -1790,6 +1790,11 @@ void orc_bsdf_sample(void *scene, uint32_t bsdf, const float wi[3], const float 
     V3 w; BSDFSample bs = bsdf_sample(c, sample1, sample2[0], sample2[1], w);
     wo[0] = bs.wo.x; wo[1] = bs.wo.y; wo[2] = bs.wo.z; *pdf = bs.pdf; weight[0] = w.x; weight[1] = w.y; weight[2] = w.z; *eta = bs.eta; *delta = bs.delta ? 1 : 0;
 }
+/* quad::gauss_legendre (include/mitsuba/core/quad.h:27-90): n nodes and n weights on [-1, 1] (known answers: src/core/tests/test_quad.py:16-22) */
+void orc_gauss_legendre(int n, float *nodes, float *weights) {
+    std::vector<float> a, b; gauss_legendre(n, a, b);
+    for (int i = 0; i < n; ++i) { nodes[i] = a[i]; weights[i] = b[i]; }
+}
 void orc_roughplastic_tables(void *scene, uint32_t bsdf, float out[66]) {
     const BsdfRecord &b = ((Scene *) scene)->bsdfs[bsdf];
     for (int i = 0; i < 64; ++i) out[i] = i < (int) b.external_transmittance.size() ? b.external_transmittance[i] : 0.f;

@@ -162,6 +162,7 @@ void  orc_bsdf_eval_pdf(void *scene, uint32_t bsdf, const float wi[3], const flo
 void  orc_bsdf_sample(void *scene, uint32_t bsdf, const float wi[3], const float uv[2], float sample1, const float sample2[2],
                       float wo[3], float *pdf, float weight[3], float *eta, int *delta);
 /* roughplastic precomputation of scene BSDF `bsdf`: out[0..63] external transmittance, out[64] internal reflectance, out[65] specular sampling weight */
+void  orc_gauss_legendre(int n, float *nodes, float *weights);      /* quad.h:27-90 */
 void  orc_roughplastic_tables(void *scene, uint32_t bsdf, float out[66]);
 
 /* ---- ray queries: Scene::ray_intersect_preliminary / ray_test / _naive ---- */

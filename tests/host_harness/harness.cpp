@@ -108,6 +108,10 @@ void hh_bsdf_eval_extra(int type, int ggx, int sample_visible, float alpha_u, fl
 }
 void hh_fresnel(float cos_theta_i, float eta, float out[4]) { fresnel_dielectric(cos_theta_i, eta, out[0], out[1], out[2], out[3]); }
 float hh_fresnel_conductor(float cos_theta_i, float eta, float k) { return fresnel_conductor(cos_theta_i, eta, k); }
+void hh_gauss_legendre(int n, float *nodes, float *weights) {       /* the product's host-side quadrature rule (har_scene_host.cpp) */
+    std::vector<float> a, b; quad_gauss_legendre(n, a, b);
+    for (int i = 0; i < n; ++i) { nodes[i] = a[i]; weights[i] = b[i]; }
+}
 void hh_roughplastic_tables(void *h, uint32_t bsdf, float out[66]) {
     HScene *H = (HScene *) h; const DBsdf &b = H->hs.bsdfs[bsdf];
     for (int i = 0; i < 64; ++i) out[i] = b.table >= 0 ? H->hs.bsdf_tables[b.table + i] : 0.f;

@@ -360,3 +360,22 @@ def test_bitmap_bilinear_repeat_vs_numpy(mi, O, H):
                 H.hh_bsdf_eval_pdf(P.h, P.index, O.fp(wi), O.fp(uv), O.fp(wo), O.fp(val), C.byref(pdf))
             got = val.astype(np.float64) * np.pi / float(wo[2])
             assert np.allclose(got, want, rtol=2e-5, atol=2e-6), (which, u, v, got, want)
+
+
+def test_reference_gauss_legendre_known_answers(O, H):
+    """src/core/tests/test_quad.py:16-22 (test02_gauss_legendre) for the rule behind rough plastic's transmittance tables (quad.h:27-90), oracle and
+    product host code; plus NumPy's leggauss at the table resolution"""
+    s = np.sqrt
+    kats = {1: ([0.0], [2.0]), 2: ([-s(1 / 3), s(1 / 3)], [1.0, 1.0]), 3: ([-s(3 / 5), 0.0, s(3 / 5)], [5 / 9, 8 / 9, 5 / 9]),
+            4: ([-0.861136, -0.339981, 0.339981, 0.861136], [0.347855, 0.652145, 0.652145, 0.347855])}
+    H.hh_gauss_legendre.restype = None
+    for fn in (O.lib().orc_gauss_legendre, H.hh_gauss_legendre):
+        for n, (nodes, weights) in kats.items():
+            a = np.zeros(n, np.float32); b = np.zeros(n, np.float32)
+            fn(n, O.fp(a), O.fp(b))
+            assert np.allclose(a, nodes, atol=2e-6) and np.allclose(b, weights, atol=2e-6), (n, a, b)
+        for n in (32, 100):
+            a = np.zeros(n, np.float32); b = np.zeros(n, np.float32)
+            fn(n, O.fp(a), O.fp(b))
+            x, w = np.polynomial.legendre.leggauss(n)
+            assert np.allclose(a, x, atol=3e-6) and np.allclose(b, w, atol=3e-6)
