@@ -227,3 +227,33 @@ def test_unreferenced_and_unsupported_properties_are_errors(mi):
             mi.load_dict(d)
     d = dict(base); d["sensor"] = dict(d["sensor"], shutter_open=0.0, focus_distance=5.0); d["integrator"] = dict(d["integrator"], block_size=32)
     mi.load_dict(d)                              # known, inert properties pass
+
+
+def test_reference_transform_known_answers(mi):
+    """src/core/tests/test_transform.py: test02_inverse (scale / translate matrices, their inverses, point transforms, random affine matrices against
+    numpy.linalg.inv), test07_transform_has_scale -- for the product's ScalarTransform4f (har_transform_*; transform.h:132-203,364-400)"""
+    T = mi.ScalarTransform4f
+    p = np.array([1.0, 2.0, 3.0, 1.0])
+    def apply(t, q): return (t.matrix.astype(np.float64) @ q)[:3]
+    t = T().scale([1.0, 10.0, 500.0])
+    assert np.allclose(t.matrix, np.diag([1, 10, 500, 1])) and np.allclose(apply(t, p), [1, 20, 1500])
+    assert np.allclose(t.inverse().matrix, np.diag([1, 1 / 10.0, 1 / 500.0, 1]))
+    t = T().translate([1, 0, 1.5])
+    want = np.eye(4); want[:3, 3] = [1, 0, 1.5]
+    assert np.allclose(t.matrix, want) and np.allclose(apply(t, p), [2, 2, 4.5])
+    want[:3, 3] = [-1, 0, -1.5]
+    assert np.allclose(t.inverse().matrix, want)
+    rng = np.random.default_rng(0)
+    for _ in range(10):
+        m = rng.random((4, 4)); m[3] = [0, 0, 0, 1]
+        data = np.concatenate([m.ravel(), np.linalg.inv(m).T.ravel()]).astype(np.float32)   # (matrix, inverse_transpose) as Transform stores them (transform.h:47-50)
+        t = T(data)
+        inv = t.inverse().matrix.astype(np.float64)
+        assert np.linalg.norm(np.linalg.inv(m) - inv) / np.linalg.norm(inv) < 5e-4
+        q = np.append(rng.random(3), 1.0)
+        assert np.linalg.norm(apply(t.inverse(), np.append(apply(t, q), 1.0)) - q[:3]) < 5e-3
+        c = (t @ t.inverse()).matrix                       # composition keeps the pair consistent
+        assert np.allclose(c, np.eye(4), atol=2e-4)
+    assert not T().rotate([1, 0, 0], 0.5).has_scale() and not T().rotate([0, 1, 0], 50).has_scale() and not T().rotate([0, 0, 1], 1e3).has_scale()
+    assert not T().translate([41, 1e3, 0]).has_scale() and not T().scale([1, 1, 1]).has_scale() and T().scale([1, 1, 1.1]).has_scale()
+    assert not T().look_at(origin=[10, -1, 3], target=[1, 1, 2], up=[0, 1, 0]).has_scale() and not T().has_scale()
