@@ -423,11 +423,17 @@ class Film:
     def __init__(self, props=None):
         props = props or {}
         # hdrfilm.cpp:146-208; file_format / component_format only concern Film::write (har_image_write_*: float32 / half channels)
-        _check_props('hdrfilm', props, ('width', 'height', 'crop_offset_x', 'crop_offset_y', 'crop_width', 'crop_height', 'pixel_format', 'file_format', 'component_format'),
-                     unsupported=(('sample_border', False), ('compensate', False)))
+        _check_props('hdrfilm', props, ('width', 'height', 'crop_offset_x', 'crop_offset_y', 'crop_width', 'crop_height', 'pixel_format', 'file_format', 'component_format',
+                                        'sample_border'), unsupported=(('compensate', False),))
         self.width = int(props.get('width', 768)); self.height = int(props.get('height', 576))
-        self.crop_offset = (int(props.get('crop_offset_x', 0)), int(props.get('crop_offset_y', 0)))
+        self.crop_offset_ = (int(props.get('crop_offset_x', 0)), int(props.get('crop_offset_y', 0)))
         self.crop_size_ = (int(props.get('crop_width', self.width)), int(props.get('crop_height', self.height)))
+        if min(self.width, self.height, *self.crop_offset_, *self.crop_size_) < 0:
+            raise RuntimeError("hdrfilm: sizes and offsets are unsigned")
+        # Film::set_crop_window (src/render/film.cpp:90-99)
+        if self.crop_offset_[0] + self.crop_size_[0] > self.width or self.crop_offset_[1] + self.crop_size_[1] > self.height:
+            raise RuntimeError("Invalid crop window specification: crop_offset(%u, %u) + crop_size(%u, %u) > size(%u, %u)"
+                               % (self.crop_offset_ + self.crop_size_ + (self.width, self.height)))
         pf = str(props.get('pixel_format', 'rgb')).lower()          # hdrfilm.cpp:135-160
         if pf not in ('rgb', 'rgba'):
             raise RuntimeError("hdrfilm: pixel_format \"%s\" is not supported by hip_ad_rgb ('rgb', 'rgba')" % pf)
@@ -449,11 +455,24 @@ class Film:
         else:
             raise RuntimeError("Plugin \"%s\" not found for variant hip_ad_rgb (rfilters: box, gaussian, tent, mitchell, catmullrom, lanczos)" % rf['type'])
 
+        # Film::sample_border (film.cpp:29-32): samples are also drawn in a border of ceil(radius - 1/2) pixels (rfilter.h border_size) around the crop
+        # window -- nothing for the box filter, not implemented otherwise
+        radius = {0: 0.5, 1: 4.0 * self.stddev, 2: self.stddev, 3: 2.0, 4: 2.0, 5: self.stddev}[self.rfilter]
+        self.sample_border_ = bool(props.get('sample_border', False))
+        if self.sample_border_ and math.ceil(radius - 0.5) > 0:
+            raise RuntimeError("hdrfilm: property \"sample_border\" = True is not implemented by hip_ad_rgb for filters with a border (radius > 0.5)")
+
+    def sample_border(self):
+        return self.sample_border_
+
     def size(self):
         return (self.width, self.height)
 
     def crop_size(self):
         return self.crop_size_
+
+    def crop_offset(self):
+        return self.crop_offset_
 
 
 class Sensor:
@@ -488,7 +507,7 @@ class Sensor:
             fov = 2.0 * math.degrees(math.atan(math.sqrt(36 * 36 + 24 * 24) / (2.0 * value))); fov_axis = 'diagonal'
         s = _capi.HarSensor()
         rc = lib().har_perspective_sensor(_fp(self.to_world.data), fov, fov_axis.encode(), self.near_clip, self.far_clip,
-                                          f.width, f.height, f.crop_offset[0], f.crop_offset[1], f.crop_size_[0], f.crop_size_[1],
+                                          f.width, f.height, f.crop_offset_[0], f.crop_offset_[1], f.crop_size_[0], f.crop_size_[1],
                                           f.rfilter, f.stddev, C.byref(s))
         s.rfilter_param1 = f.rf_param1
         if rc == 2:

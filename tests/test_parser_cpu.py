@@ -257,3 +257,21 @@ def test_reference_transform_known_answers(mi):
     assert not T().rotate([1, 0, 0], 0.5).has_scale() and not T().rotate([0, 1, 0], 50).has_scale() and not T().rotate([0, 0, 1], 1e3).has_scale()
     assert not T().translate([41, 1e3, 0]).has_scale() and not T().scale([1, 1, 1]).has_scale() and T().scale([1, 1, 1.1]).has_scale()
     assert not T().look_at(origin=[10, -1, 3], target=[1, 1, 2], up=[0, 1, 0]).has_scale() and not T().has_scale()
+
+
+def test_reference_film_crop_window(mi):
+    """src/films/tests/test_hdrfilm.py:36-72 (test02_crops) and Film::set_crop_window (src/render/film.cpp:90-99): accessors, and a crop window that
+    leaves the film is an error -- from a dict and from XML"""
+    film = mi.load_dict({'type': 'hdrfilm', 'width': 32, 'height': 21, 'crop_width': 11, 'crop_height': 5, 'crop_offset_x': 2, 'crop_offset_y': 3,
+                         'pixel_format': 'rgba', 'rfilter': {'type': 'box'}, 'sample_border': True})
+    assert film.size() == (32, 21) and film.crop_size() == (11, 5) and film.crop_offset() == (2, 3) and film.sample_border()
+    incomplete = '<film version="3.0.0" type="hdrfilm"><integer name="width" value="32"/><integer name="height" value="21"/>' \
+                 '<integer name="crop_offset_x" value="30"/><integer name="crop_offset_y" value="20"/>'
+    with pytest.raises(RuntimeError, match="Invalid crop window"):
+        mi.load_string(incomplete + "</film>")
+    film = mi.load_string(incomplete + '<integer name="crop_width" value="2"/><integer name="crop_height" value="1"/></film>')
+    assert film.size() == (32, 21) and film.crop_size() == (2, 1) and film.crop_offset() == (30, 20)
+    with pytest.raises(RuntimeError, match="Invalid crop window"):
+        mi.load_dict({'type': 'hdrfilm', 'width': 8, 'height': 8, 'crop_width': 8, 'crop_offset_x': 1})
+    with pytest.raises(RuntimeError, match="sample_border"):        # a border of filter radius would have to be sampled: not built
+        mi.load_dict({'type': 'hdrfilm', 'width': 8, 'height': 8, 'sample_border': True})
