@@ -277,3 +277,51 @@ def test_bitmap_read_roundtrip_and_envmap_from_file(mi, O, tmp_path):
     with pytest.raises(RuntimeError, match="both"): mi.load_dict({"type": "envmap", "filename": p, "bitmap": mi.Bitmap(one)})
     d = mi.cornell_box(); d["e1"] = {"type": "envmap", "bitmap": mi.Bitmap(one)}; d["e2"] = {"type": "constant"}
     with pytest.raises(RuntimeError, match="Only one environment emitter"): mi.load_dict(d)
+
+
+def _eval_uv(em, u, v):
+    """radiance at lat-long coordinates (u, v) in the convention of the reference's test helper (test_envmap.py:176-197)"""
+    u = np.atleast_1d(np.asarray(u, np.float64)); v = np.atleast_1d(np.asarray(v, np.float64))
+    phi, theta = u * 2 * np.pi, v * np.pi
+    st, ct = np.sin(theta), np.cos(theta)
+    d = np.stack([np.sin(phi) * st, ct, -np.cos(phi) * st], axis=1).astype(np.float32)
+    return em.eval(d)
+
+
+@pytest.mark.parametrize("which", ["oracle", "product"])
+def test_reference_envmap_pixel_shift_seam_and_poles(mi, O, H, which):
+    """src/emitters/tests/test_envmap.py: test06_pixel_shift (a ramp reads back the texel-centre coordinate u W - 1/2 along phi and the
+    align-corners coordinate v (H - 1) along theta), test07_phi_seam_continuity (a periodic cosine is continuous across u = 0) and
+    test08_theta_pole_clamp (the poles clamp, they do not wrap) -- with the reference's non-hardware-texture tolerances; the oracle's EnvMap and the
+    product's host-built tables + host-compiled device lookup"""
+    if which == "oracle":
+        make = lambda img: O.EnvMap(np.asarray(img, np.float32))
+    else:
+        class Prod:
+            def __init__(self, img):
+                d = {"type": "scene", "integrator": {"type": "path", "max_depth": 2}, "sensor": mi.cornell_box()["sensor"],
+                     "env": {"type": "envmap", "bitmap": mi.Bitmap(np.asarray(img, np.float32))}}
+                self.scene = mi.load_dict(d); desc = self.scene.desc(); err = C.create_string_buffer(256)
+                self.h = C.c_void_p(H.hh_scene_create(C.byref(desc), err, 256)); assert self.h, err.value
+            def eval(self, dirs):
+                dirs = np.ascontiguousarray(dirs, np.float32); n = dirs.shape[0]; out = np.zeros((n, 3), np.float32); pdf = np.zeros(n, np.float32)
+                H.hh_envmap_eval(self.h, n, O.fp(dirs), O.fp(out), O.fp(pdf)); return out
+        make = Prod
+    W, Hh = 16, 8
+    img = np.broadcast_to(np.arange(W, dtype=np.float32)[None, :, None], (Hh, W, 3)).copy()
+    t = np.linspace(1.0 / W, 1.0 - 1.0 / W, 50)
+    assert np.abs(_eval_uv(make(img), t, np.full_like(t, 0.5))[:, 0] - (t * W - 0.5)).max() < 1e-4
+    W, Hh = 8, 16
+    img = np.broadcast_to(np.arange(Hh, dtype=np.float32)[:, None, None], (Hh, W, 3)).copy()
+    t = np.linspace(1.0 / Hh, 1.0 - 1.0 / Hh, 50)
+    assert np.abs(_eval_uv(make(img), np.zeros_like(t), t)[:, 0] - t * (Hh - 1)).max() < 1e-4
+    W, Hh = 64, 8
+    col = np.cos(2 * np.pi * np.arange(W) / W).astype(np.float32)
+    img = np.broadcast_to(col[None, :, None], (Hh, W, 3)).copy()
+    u = np.linspace(-0.1, 0.1, 201); uw = u - np.floor(u)
+    got = _eval_uv(make(img), u, np.full_like(u, 0.5))[:, 0]
+    assert np.abs(got - np.cos(2 * np.pi * (uw * W - 0.5) / W)).max() < 5e-3
+    W, Hh = 8, 16
+    img = np.zeros((Hh, W, 3), np.float32); img[0] = 10.0; img[Hh - 1] = 20.0
+    em = make(img)
+    assert abs(_eval_uv(em, 0.0, 0.0)[0, 0] - 10.0) < 1e-3 and abs(_eval_uv(em, 0.0, 1.0)[0, 0] - 20.0) < 1e-3
