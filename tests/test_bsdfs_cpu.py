@@ -379,3 +379,53 @@ def test_reference_gauss_legendre_known_answers(O, H):
             fn(n, O.fp(a), O.fp(b))
             x, w = np.polynomial.legendre.leggauss(n)
             assert np.allclose(a, x, atol=3e-6) and np.allclose(b, w, atol=3e-6)
+
+
+@pytest.mark.parametrize("name", ["diffuse", "rc_beckmann", "rc_ggx_aniso", "rc_ggx_all", "rc_beckmann_all", "rp_beckmann", "rp_ggx_nonlinear", "twosided_pair"])
+@pytest.mark.parametrize("which", ["oracle", "product"])
+def test_sampling_density_chi2(mi, O, H, name, which):
+    """The reference's chi^2 test of BSDF sampling (mitsuba.chi2.ChiSquareTest with BSDFAdapter: src/bsdfs/tests/test_rough_conductor.py:8-95,
+    test_rough_plastic.py:6-37, test_diffuse.py:42-52) re-hosted: the histogram of sampled directions over a (cos theta, phi) grid against the
+    integral of pdf() over each cell, cells with fewer than 5 expected samples pooled, significance 0.01 as in the reference.  `weight * pdf == eval`
+    (test above) cannot see a sampler whose samples are not distributed like the pdf it reports; this can."""
+    from scipy import stats
+    P = Pair(mi, O, H, BSDF_DICTS[name])
+    import zlib
+    rng = np.random.default_rng(zlib.crc32(name.encode()) + int(os.environ.get('CHI2_SEED_OFFSET', '0')))
+    n_samples, R, Cc, sub = 40000, 24, 48, 6
+    for wi in ([0.0, 0.0, 1.0], [0.6, -0.3, 0.74]):
+        wi = np.float32(wi) / np.linalg.norm(wi)
+        hist = np.zeros((R, Cc))
+        for _ in range(n_samples):
+            s = rng.random(3)
+            wo, pdf, w, eta, delta = P.sample(which, wi, float(s[0]), [float(s[1]), float(s[2])])
+            if not (w > 0).any() or delta:         # invalid samples (e.g. a reflection below the horizon: weight 0) do not count, as in BSDFAdapter (chi2.py)
+                continue
+            z = min(max(float(wo[2]), -1.0), 1.0); phi = np.arctan2(float(wo[1]), float(wo[0])) % (2 * np.pi)
+            hist[min(int((z + 1) / 2 * R), R - 1), min(int(phi / (2 * np.pi) * Cc), Cc - 1)] += 1
+        # expected counts: midpoint rule on a sub x sub grid per cell (uniform measure dz dphi on the sphere)
+        expected = np.zeros((R, Cc)); cell = (2.0 / R) * (2 * np.pi / Cc)
+        for i in range(R):
+            for j in range(Cc):
+                acc = 0.0
+                for a in range(sub):
+                    for b in range(sub):
+                        z = -1 + 2 * (i + (a + 0.5) / sub) / R; phi = 2 * np.pi * (j + (b + 0.5) / sub) / Cc
+                        r = np.sqrt(max(0.0, 1 - z * z))
+                        acc += P.eval_pdf(which, wi, [r * np.cos(phi), r * np.sin(phi), z])[1]
+                expected[i, j] = acc / (sub * sub) * cell * n_samples
+        assert abs(expected.sum() / n_samples - hist.sum() / n_samples) < 0.02          # the pdf's mass == the fraction of valid samples
+        o, e = hist.ravel(), expected.ravel()
+        order = np.argsort(e); o, e = o[order], e[order]
+        pooled_o, pooled_e, chi2, dof = 0.0, 0.0, 0.0, 0
+        for oo, ee in zip(o, e):
+            if ee < 5:
+                pooled_o += oo; pooled_e += ee
+                continue
+            chi2 += (oo - ee) ** 2 / ee; dof += 1
+        if pooled_e > 0:
+            chi2 += (pooled_o - pooled_e) ** 2 / max(pooled_e, 1e-9); dof += 1
+        p = stats.chi2.sf(chi2, dof - 1)
+        # 16 tests per implementation (8 models x 2 incident directions): Sidak-corrected level, like ChiSquareTest.run(significance_level, test_count)
+        assert p > 1.0 - (1.0 - 0.01) ** (1.0 / 16.0), (name, which, wi, chi2, dof, p)
+        print('chi2 %s %s wi.z=%.2f: p = %.3f' % (name, which, wi[2], p))
