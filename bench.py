@@ -303,7 +303,8 @@ def worker(args):
                "value": round(n_paths / (dtp / p_steps) / 1e6, 2), "ms_per_step": round(dtp / p_steps * 1e3, 2), "steps": p_steps,
                "workload": "%s + 256x256 bitmap albedo on the `white` BSDF (walls + spheres), emitter_gradients=True" % args.workload,
                "gradient_targets": {"texels": int(sum(int(np.prod(t.shape)) for t in scene_p.textures)), "constant_albedos": len(scene_p.bsdfs), "emitters": len(scene_p.emitters)},
-               "stats": {k: int(v) for k, v in pst.items()}}
+               "stats": {k: int(v) for k, v in pst.items()},
+               "stats_note": "counters of the adjoint replay: its ray queries are served by the replay cache (shadow_rays = 0 traced); the primal pass of the same step traces the rays"}
         log("PRB adjoint done: %.1f Mpaths/s" % prb["value"])
 
     # ---------------- CPU baseline (oracle = CPU restatement of llvm_ad_rgb; rank 0, N = 1 only) ----------------
