@@ -1613,15 +1613,18 @@ def render(scene, params=None, sensor=0, integrator=None, seed=0, seed_grad=0, s
     if not keys:
         return integrator.render(scene, sensor, seed, spp)
     params.update()
-    # dr.enable_grad(params[key]) is what makes a parameter differentiable in the reference: switch on the adjoint terms the requested keys need
+    # dr.enable_grad(params[key]) is what makes a parameter differentiable in the reference: the adjoint terms the requested keys need are switched
+    # on for THIS call's backward pass only -- the caller's integrator keeps its own properties (optimising vertex positions first and alpha
+    # second with one integrator must not leave `shape_gradients` on for the second render)
+    overrides = {}
     if integrator.type == 'prb':
         shape_keys = [k for k in keys if k in scene._position_keys() or k in scene._instance_keys()]
         if shape_keys and integrator.shape_gradients is not True:
-            integrator.shape_gradients = sorted(set(list(integrator.shape_gradients or [])) | set(shape_keys))
-        if any(k in scene._bsdf_param_keys() for k in keys):
-            integrator.bsdf_parameter_gradients = True
-        if any(v[0] == "emit" for k, v in scene._param_keys().items() if k in keys):
-            integrator.emitter_gradients = True
+            overrides['shape_gradients'] = sorted(set(list(integrator.shape_gradients or [])) | set(shape_keys))
+        if any(k in scene._bsdf_param_keys() for k in keys) and not integrator.bsdf_parameter_gradients:
+            overrides['bsdf_parameter_gradients'] = True
+        if any(v[0] == "emit" for k, v in scene._param_keys().items() if k in keys) and not integrator.emitter_gradients:
+            overrides['emitter_gradients'] = True
 
     class _RenderOp(torch.autograd.Function):
         @staticmethod
@@ -1630,7 +1633,14 @@ def render(scene, params=None, sensor=0, integrator=None, seed=0, seed_grad=0, s
 
         @staticmethod
         def backward(ctx, grad_out):
-            grads = integrator.render_backward(scene, params, grad_out, sensor, seed_grad, spp_grad)
+            saved = {k: getattr(integrator, k) for k in overrides}
+            try:
+                for k, v in overrides.items():
+                    setattr(integrator, k, v)
+                grads = integrator.render_backward(scene, params, grad_out, sensor, seed_grad, spp_grad)
+            finally:
+                for k, v in saved.items():
+                    setattr(integrator, k, v)
             missing = [k for k in keys if k not in grads]
             if missing:       # e.g. emitter radiance with emitter_gradients=False, vertex positions without shape_gradients
                 raise RuntimeError("mi.render(): the `prb` integrator cannot differentiate %s (integrator properties `emitter_gradients`, "

@@ -188,9 +188,15 @@ HAR_HD void node_visit(const Accel &A, const RaySetup &R, float tmax, uint32_t i
 }
 
 /* pick the next child of a node group (front-to-back = highest bit); returns its node index */
+#if !defined(__HIP_DEVICE_COMPILE__)
+static int g_host_child_order = 0;      /* host what-if models only (tools/trace_stats.py): 1 = back-to-front */
+#endif
 HAR_HD uint32_t ng_next_child(uint32_t ng_x, uint32_t &ng_y, uint32_t octinv) {
     uint32_t imask = ng_y & 0xffu;
     uint32_t bit = 31u - clz32(ng_y);
+#if !defined(__HIP_DEVICE_COMPILE__)
+    if (g_host_child_order == 1) bit = (uint32_t) __builtin_ctz(ng_y & 0xff000000u);
+#endif
     ng_y &= ~(1u << bit);
     uint32_t slot = (bit - 24u) ^ octinv;
     return ng_x + popc32(imask & ~(0xffffffffu << slot));

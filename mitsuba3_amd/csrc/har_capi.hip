@@ -306,6 +306,16 @@ static inline uint32_t *cur_resolve(HarIntegratorImpl *I, uint32_t b) { return I
 int ensure_texel_queues(HarSceneImpl *S, HarIntegratorImpl *I) {
     static const bool enabled = !(getenv("HAR_TEXEL_QUEUES") && atoi(getenv("HAR_TEXEL_QUEUES")) == 0);
     if (I->tq_scene == S->serial && I->tq_lanes == I->ws_lanes) return 0;
+    /* queues of another scene (params.update() re-creates the scene handle; one integrator may alternate between scenes): give their buffers back
+     * first -- the record buffer alone is 64 B per workspace lane */
+    {
+        void *old[4] = { I->tq.rec, I->tq.count, const_cast<uint2 *>(I->tq.band), const_cast<uint4 *>(I->tq.qinfo) };
+        for (void *q : old) {
+            if (!q) continue;
+            auto it = std::find(I->owned.begin(), I->owned.end(), q);
+            if (it != I->owned.end()) { I->owned.erase(it); dev_free(q); }
+        }
+    }
     I->tq = TexelQueues{ nullptr, nullptr, nullptr, nullptr, 0u, 0u }; I->tq_scene = S->serial; I->tq_lanes = I->ws_lanes;
     const size_t nt = S->hs.textures.size();
     if (!enabled || nt == 0) return 0;
@@ -359,7 +369,9 @@ int run_chunk(HarSceneImpl *S, HarIntegratorImpl *I, const DSensor &C, int mode,
     HIP_TRY(hipMemsetAsync(cur_trace(I, 0), 0, used, s));
     HIP_TRY(hipMemsetAsync(cur_resolve(I, 0), 0, used, s));
     if (rays) launch_raygen_rays(s, seed, lane_base, n, rays->n_total, rays->first, rays->o, rays->d, rays->maxt, rays->state, I->shard_cap, I->st[0], I->result, cnt_alive(I, 0));
-    else launch_raygen(mode, s, C, seed, spp, log_spp, lane_base, n, I->shard_cap, I->st[0], I->result, cnt_alive(I, 0), I->adj, I->dL, ps);
+    /* forward mode: k_raygen<ADJOINT> takes `adj == nullptr` as "zero dL" -- a workspace that served render_backward before still holds that call's adjoint
+     * image in I->adj (possibly of a smaller film), which must not be gathered here */
+    else launch_raygen(mode, s, C, seed, spp, log_spp, lane_base, n, I->shard_cap, I->st[0], I->result, cnt_alive(I, 0), I->forward_mode ? nullptr : I->adj, I->dL, ps);
     prof_mark(I, s, CLS_RAYGEN);
     const bool fwd = mode == MODE_PRB_ADJOINT && I->forward_mode;
     ShadeParams P{ seed, I->max_depth, I->rr_depth, ((mode == MODE_PRB_ADJOINT && I->grad_emitters) ? HAR_SHADE_EMITTER_GRADS : 0u) | (I->hide_emitters ? HAR_SHADE_HIDE_EMITTERS : 0u) |

@@ -2,10 +2,9 @@
  * har_mesh_formats.cpp -- OBJ and `serialized` mesh files for the hip_ad_rgb path (SURVEY.md 8f rank 2, next to har_mesh_io.cpp's PLY).
  *
  *   har_mesh_load_obj         OBJMesh ctor (src/shapes/obj.cpp:98-296): v / vn / vt / f records, 1-based `p`, `p/t`, `p//n`, `p/t/n`
- *                             corners, polygons of any size; then Mesh::from_corners -> corner_to_packed_mesh
- *                             (src/render/mesh_utils.cpp:210-560): fan triangulation around corner 0, corners of one source point
- *                             weld when normal, texcoord and the sign of the triangle's UV area agree, vertex ids follow the source
- *                             point order, unreferenced points are dropped.  Missing normals are regenerated per SURFACE POINT
+ *                             corners, polygons of any size, with the welding rules of Mesh::from_corners
+ *                             (src/render/mesh_utils.cpp:210-560) -- see the contract stated above mesh_load_obj_impl; the implementation
+ *                             is this repository's own (scanner + hash table + prefix sum).  Missing normals are regenerated per SURFACE POINT
  *                             (Mesh::pack: normal_index = position_index, src/render/mesh.cpp:573-582), i.e. UV seams stay smooth.
  *   har_mesh_load_serialized  SerializedMesh ctor + load_legacy (src/shapes/serialized.cpp:225-370): Mitsuba 0.x / 2 / 3 `.serialized`
  *                             container versions 3 and 4 (zlib stream per sub-mesh, offset table at the end of the file).
@@ -16,6 +15,7 @@
 
 #include <zlib.h>
 
+#include <algorithm>
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
@@ -54,11 +54,14 @@ int emit(const std::vector<float> &V, const std::vector<uint32_t> &F, uint32_t f
 
 const uint32_t kMissing = 0xffffffffu;
 
-/* bit pattern of one attribute record, -0.0 folded to +0.0 so that equal values compare equal (mesh_utils.cpp:185-207) */
+/* the words a corner attribute contributes to a welding key: the record's IEEE bit patterns with the sign of a zero cleared (so -0 welds with +0);
+ * a corner without that attribute contributes zeros */
 void fetch_key(const std::vector<float> &pool, uint32_t index, int dim, uint32_t *out) {
-    if (index == kMissing) memset(out, 0, dim * sizeof(uint32_t));
-    else memcpy(out, pool.data() + (size_t) index * dim, dim * sizeof(float));
-    for (int k = 0; k < dim; ++k) if (out[k] == 0x80000000u) out[k] = 0;
+    for (int k = 0; k < dim; ++k) {
+        uint32_t word = 0;
+        if (index != kMissing) memcpy(&word, &pool[(size_t) index * dim + k], sizeof(word));
+        out[k] = (word << 1) == 0u ? 0u : word;
+    }
 }
 
 } // namespace
@@ -79,133 +82,218 @@ int har_mesh_load_serialized(const char *filename, int shape_index, int face_nor
     catch (const std::bad_alloc &) { mesh_reset(out); return har_set_error(std::string("Error while loading serialized file \"") + (filename ? filename : "") + "\": out of memory!"); }
     catch (const std::exception &e) { mesh_reset(out); return har_set_error(std::string("Error while loading serialized file \"") + (filename ? filename : "") + "\": " + e.what() + "!"); }
 }
+/* ---------------------------------------------------------------------------------------------------------------- Wavefront OBJ
+ *
+ * Written from the observable contract of the reference's loader (what a file produces, which files are refused and with which message),
+ * not from its text:
+ *   records    `v x y z`, `vn x y z`, `vt u v`, `f c c c ...` with corners `p`, `p/t`, `p//n`, `p/t/n` (1-based); everything else is skipped;
+ *              `vn` is ignored with face_normals, `vt`'s v is mirrored with flip_tex_coords; a line of 1024+ characters is refused;
+ *   topology   a polygon c0 c1 ... c(n-1) becomes the fan (c0, ci, ci+1); corners of ONE source point stay one vertex when their normal,
+ *              texcoord and the orientation of their triangle in UV space agree bit for bit (-0 == +0, a missing attribute == zeros);
+ *   numbering  vertices are numbered point by point in `v` order and, within a point, in the order its variants first occur in the triangle
+ *              list; points no face refers to do not exist in the output.
+ * Structure here: a character scanner per line, one open-addressing hash table keyed on (point, attribute words) that hands out a variant
+ * rank per point, and a prefix sum over the points' variant counts that turns (point, rank) into the final vertex id.
+ */
+namespace {
+
+struct LineScanner {
+    const char *p, *end;
+    static bool blank(char c) { return c == ' ' || c == '\t' || c == '\r'; }
+    void skip_blanks() { while (p < end && blank(*p)) ++p; }
+    bool at_end() { skip_blanks(); return p >= end; }
+    /* `word` followed by a blank: a record tag */
+    bool tag(const char *word) {
+        const size_t n = strlen(word);
+        if ((size_t) (end - p) <= n || memcmp(p, word, n) != 0 || !(p[n] == ' ' || p[n] == '\t')) return false;
+        p += n + 1; return true;
+    }
+    /* one real number; the buffer behind the line is NUL-terminated, the line itself ends at `end` (strtof would walk over the newline) */
+    bool real(float &v) {
+        skip_blanks();
+        if (p >= end) return false;
+        char *stop = nullptr; v = strtof(p, &stop);
+        if (stop == p || stop > end) return false;
+        p = stop; return true;
+    }
+    /* a decimal integer; a sign is read like C's strtoul reads it (the value wraps: `-1` is 4294967295, which no pool can satisfy, so relative
+     * OBJ indices end in the "invalid vertex -1" message exactly like in the reference) */
+    bool index(uint32_t &v) {
+        const char *q = p; bool negative = false;
+        if (q < end && (*q == '-' || *q == '+')) { negative = *q == '-'; ++q; }
+        if (q >= end || *q < '0' || *q > '9') return false;
+        uint64_t acc = 0;
+        while (q < end && *q >= '0' && *q <= '9') { acc = std::min<uint64_t>(acc * 10u + (uint64_t) (*q - '0'), 0xffffffffull); ++q; }
+        v = negative ? (uint32_t) (0u - (uint32_t) acc) : (uint32_t) acc; p = q; return true;
+    }
+};
+
+struct ObjSoup {
+    std::vector<float> xyz, nrm, uv;                        /* the three attribute pools as read */
+    std::vector<uint32_t> c_point, c_uv, c_nrm;            /* per face corner: 0-based pool indices, kMissing = not given */
+    std::vector<uint32_t> poly_first;                       /* first corner of every polygon + one past the last */
+    bool any_uv = false, any_nrm = false;
+};
+
+/* parse one `f` record: a corner is up to three slash-separated indices, corners are separated by blanks */
+enum CornerStatus { CORNER_OK, CORNER_NONE, CORNER_MALFORMED };
+CornerStatus scan_corner(LineScanner &L, uint32_t ref[3]) {
+    ref[0] = ref[1] = ref[2] = 0;
+    L.skip_blanks();
+    if (L.p >= L.end) return CORNER_NONE;
+    int field = 0; bool got_any = false;
+    for (;;) {
+        uint32_t v;
+        if (L.index(v)) { ref[field] = v; got_any = true; }
+        if (L.p < L.end && *L.p == '/') { if (++field > 2) return CORNER_MALFORMED; ++L.p; continue; }
+        break;
+    }
+    if (!got_any) return CORNER_NONE;                        /* not a number: the record ends here (trailing junk is ignored like the reference does) */
+    if (L.p < L.end && !LineScanner::blank(*L.p)) return CORNER_MALFORMED;
+    return CORNER_OK;
+}
+
+/* hash table (point, words...) -> rank of that attribute variant within its point */
+struct VariantTable {
+    size_t words; std::vector<uint32_t> slots;              /* per slot: point, rank, words...; point == kMissing: empty */
+    size_t mask = 0, used = 0, stride = 0;
+    explicit VariantTable(size_t words_, size_t expected) : words(words_) {
+        stride = 2 + words; size_t cap = 16; while (cap < 2 * expected + 8) cap <<= 1;
+        mask = cap - 1; slots.assign(cap * stride, kMissing);
+    }
+    static uint64_t mix(uint64_t h, uint32_t v) { h ^= v; h *= 0x9E3779B97F4A7C15ull; return h ^ (h >> 29); }
+    /* returns the rank; `fresh` tells whether the variant is new (its rank is then next_rank) */
+    uint32_t find_or_add(uint32_t point, const uint32_t *w, uint32_t next_rank, bool &fresh) {
+        uint64_t h = mix(0x243F6A8885A308D3ull, point);
+        for (size_t k = 0; k < words; ++k) h = mix(h, w[k]);
+        for (size_t i = (size_t) h & mask;; i = (i + 1) & mask) {
+            uint32_t *s = slots.data() + i * stride;
+            if (s[0] == kMissing) { s[0] = point; s[1] = next_rank; memcpy(s + 2, w, words * sizeof(uint32_t)); ++used; fresh = true; return next_rank; }
+            if (s[0] == point && memcmp(s + 2, w, words * sizeof(uint32_t)) == 0) { fresh = false; return s[1]; }
+        }
+    }
+};
+
+} // namespace
+
 static int mesh_load_obj_impl(const char *filename, int face_normals, int flip_tex_coords, const float *to_world, int flip_normals, HarMeshData *out) {
     if (!filename || !out) return har_set_error("null argument");
     out->vertices = nullptr; out->faces = nullptr; out->vertex_count = out->face_count = out->flags = out->reserved = 0;
     auto fail = [&](const std::string &d) { return har_set_error("Error while loading OBJ file \"" + std::string(filename) + "\": " + d); };
-    std::string data;
-    if (!read_file(filename, data)) return fail("file not found / unreadable");
+    std::string text;
+    if (!read_file(filename, text)) return fail("file not found / unreadable");
 
-    std::vector<float> positions, normals, texcoords;
-    std::vector<uint32_t> corner_vertex, corner_uv, corner_normal, face_offsets(1, 0u);
-    bool has_uv_indices = false, has_normal_indices = false;
-    const char *ptr = data.data(), *eof = ptr + data.size();
-    char buf[1025];
-    auto is_ws = [](char c) { return c == ' ' || c == '\t'; };
-    while (ptr < eof) {
-        const char *next = ptr; while (next != eof && *next != '\n') ++next;
-        size_t size = (size_t) (next - ptr);
-        if (size >= sizeof(buf) - 1) return fail("file contains an excessively long line! (" + std::to_string(size) + " characters)");
-        memcpy(buf, ptr, size); buf[size] = '\0';
-        const char *cur = buf; while (*cur == ' ' || *cur == '\t' || *cur == '\r') ++cur;
-        bool parse_error = false;
-        auto floats = [&](int n, float *dst) { for (int i = 0; i < n; ++i) { char *e = nullptr; dst[i] = strtof(cur, &e); parse_error |= e == cur; cur = e; } };
-        if (cur[0] == 'v' && is_ws(cur[1])) {
-            cur += 2; float p[3]; floats(3, p);
-            if (!(finite_(p[0]) && finite_(p[1]) && finite_(p[2]))) return fail("mesh contains invalid vertex position data");
-            positions.insert(positions.end(), p, p + 3);
-        } else if (cur[0] == 'v' && cur[1] == 'n' && is_ws(cur[2])) {
+    /* ---- pass 1: records */
+    ObjSoup soup; soup.poly_first.push_back(0u);
+    const char *cursor = text.data(), *const file_end = cursor + text.size();
+    while (cursor < file_end) {
+        const char *eol = (const char *) memchr(cursor, '\n', (size_t) (file_end - cursor));
+        if (!eol) eol = file_end;
+        const size_t length = (size_t) (eol - cursor);
+        if (length >= 1024) return fail("file contains an excessively long line! (" + std::to_string(length) + " characters)");
+        LineScanner L{ cursor, eol };
+        auto bad_line = [&]() { return fail("could not parse line \"" + std::string(cursor, length) + "\""); };
+        L.skip_blanks();
+        if (L.tag("v")) {
+            float q[3];
+            if (!L.real(q[0]) || !L.real(q[1]) || !L.real(q[2])) return bad_line();
+            if (!finite_(q[0]) || !finite_(q[1]) || !finite_(q[2])) return fail("mesh contains invalid vertex position data");
+            soup.xyz.insert(soup.xyz.end(), q, q + 3);
+        } else if (L.tag("vn")) {
             if (!face_normals) {
-                cur += 3; float n[3]; floats(3, n);
-                if (!(finite_(n[0]) && finite_(n[1]) && finite_(n[2]))) return fail("mesh contains invalid vertex normal data");
-                normals.insert(normals.end(), n, n + 3);
+                float q[3];
+                if (!L.real(q[0]) || !L.real(q[1]) || !L.real(q[2])) return bad_line();
+                if (!finite_(q[0]) || !finite_(q[1]) || !finite_(q[2])) return fail("mesh contains invalid vertex normal data");
+                soup.nrm.insert(soup.nrm.end(), q, q + 3);
             }
-        } else if (cur[0] == 'v' && cur[1] == 't' && is_ws(cur[2])) {
-            cur += 3; float uv[2]; floats(2, uv);
-            if (flip_tex_coords) uv[1] = 1.f - uv[1];
-            texcoords.insert(texcoords.end(), uv, uv + 2);
-        } else if (cur[0] == 'f' && is_ws(cur[1])) {
-            cur += 2;
-            size_t type_index = 0; uint32_t key[3] = { 0, 0, 0 };
-            while (true) {
-                char *next2 = nullptr;
-                uint32_t value = (uint32_t) strtoul(cur, &next2, 10);
-                if (cur == next2) break;
-                if (type_index < 3) key[type_index] = value; else { parse_error = true; break; }
-                while (*next2 == '/') { type_index++; next2++; }
-                if (*next2 == ' ' || *next2 == '\t' || *next2 == '\0' || *next2 == '\r') {
-                    type_index = 0;
-                    if (key[0] == 0 || (size_t) (key[0] - 1) * 3 >= positions.size()) return fail("reference to invalid vertex " + std::to_string(key[0]) + "!");
-                    if (key[1] != 0 && (size_t) (key[1] - 1) * 2 >= texcoords.size()) return fail("reference to invalid texture coordinate " + std::to_string(key[1]) + "!");
-                    if (key[2] != 0 && !face_normals && (size_t) (key[2] - 1) * 3 >= normals.size()) return fail("reference to invalid normal " + std::to_string(key[2]) + "!");
-                    corner_vertex.push_back(key[0] - 1);
-                    corner_uv.push_back(key[1] ? key[1] - 1 : kMissing);
-                    corner_normal.push_back(key[2] ? key[2] - 1 : kMissing);
-                    has_uv_indices |= key[1] != 0; has_normal_indices |= key[2] != 0;
-                    key[1] = key[2] = 0;
-                }
-                cur = next2;
+        } else if (L.tag("vt")) {
+            float q[2];
+            if (!L.real(q[0]) || !L.real(q[1])) return bad_line();
+            soup.uv.push_back(q[0]); soup.uv.push_back(flip_tex_coords ? 1.f - q[1] : q[1]);
+        } else if (L.tag("f")) {
+            for (;;) {
+                uint32_t ref[3];
+                const CornerStatus st = scan_corner(L, ref);
+                if (st == CORNER_NONE) break;
+                if (st == CORNER_MALFORMED) return bad_line();
+                if (ref[0] == 0 || (size_t) ref[0] > soup.xyz.size() / 3) return fail("reference to invalid vertex " + std::to_string((int32_t) ref[0]) + "!");
+                if (ref[1] != 0 && (size_t) ref[1] > soup.uv.size() / 2) return fail("reference to invalid texture coordinate " + std::to_string((int32_t) ref[1]) + "!");
+                if (ref[2] != 0 && !face_normals && (size_t) ref[2] > soup.nrm.size() / 3) return fail("reference to invalid normal " + std::to_string((int32_t) ref[2]) + "!");
+                soup.c_point.push_back(ref[0] - 1u);
+                soup.c_uv.push_back(ref[1] ? ref[1] - 1u : kMissing);
+                soup.c_nrm.push_back(ref[2] ? ref[2] - 1u : kMissing);
+                soup.any_uv = soup.any_uv || ref[1] != 0; soup.any_nrm = soup.any_nrm || ref[2] != 0;
             }
-            face_offsets.push_back((uint32_t) corner_vertex.size());
+            soup.poly_first.push_back((uint32_t) soup.c_point.size());
         }
-        if (parse_error) return fail("could not parse line \"" + std::string(buf) + "\"");
-        ptr = next + 1;
+        cursor = eol + 1;
     }
 
-    /* ---- Mesh::from_corners (mesh_utils.cpp:210-560) */
-    const bool has_normals = has_normal_indices && !face_normals, has_uv = has_uv_indices, split_uv_sign = has_uv && !face_normals;
-    const size_t n_points = positions.size() / 3;
-    std::vector<uint32_t> tri_corner;                        /* triangle corner -> face corner: fan around corner 0 */
-    for (size_t f = 0; f + 1 < face_offsets.size(); ++f) {
-        uint32_t begin = face_offsets[f], n = face_offsets[f + 1] - begin;
-        for (uint32_t i = 1; i + 1 < n; ++i) { tri_corner.push_back(begin); tri_corner.push_back(begin + i); tri_corner.push_back(begin + i + 1); }
+    /* ---- pass 2: fans.  tri[3t + j] = the face corner serving corner j of triangle t */
+    const bool keep_normals = soup.any_nrm && !face_normals, keep_uv = soup.any_uv, orient_uv = keep_uv && !face_normals;
+    std::vector<uint32_t> tri;
+    for (size_t f = 0; f + 1 < soup.poly_first.size(); ++f) {
+        const uint32_t c0 = soup.poly_first[f], sides = soup.poly_first[f + 1] - c0;
+        for (uint32_t k = 2; k < sides; ++k) { tri.push_back(c0); tri.push_back(c0 + k - 1u); tri.push_back(c0 + k); }
     }
-    const size_t n_tris = tri_corner.size() / 3, n_tc = tri_corner.size();
-    std::vector<uint8_t> uv_flipped;
-    if (split_uv_sign) {
-        uv_flipped.resize(n_tris);
-        for (size_t t = 0; t < n_tris; ++t) {
-            uint32_t bits[6]; float uv[6];
-            for (int j = 0; j < 3; ++j) fetch_key(texcoords, corner_uv[tri_corner[3 * t + j]], 2, bits + 2 * j);
-            memcpy(uv, bits, sizeof(uv));
-            float area2 = (uv[2] - uv[0]) * (uv[5] - uv[1]) - (uv[3] - uv[1]) * (uv[4] - uv[0]);
-            uv_flipped[t] = !(area2 > 0.f);
+    const size_t n_tri = tri.size() / 3, n_points = soup.xyz.size() / 3;
+
+    /* ---- pass 3: variants.  A variant's words: [normal bits x3][uv bits x2][uv orientation]; at least one word so that the table has a key */
+    const size_t words = std::max<size_t>(1, (keep_normals ? 3 : 0) + (keep_uv ? 2 : 0) + (orient_uv ? 1 : 0));
+    VariantTable table(words, tri.size());
+    std::vector<uint32_t> variants_of(n_points, 0u);        /* distinct variants seen per point so far */
+    std::vector<uint32_t> rank_of(tri.size());              /* per triangle corner */
+    struct Variant { uint32_t point, rank; uint32_t w[6]; };
+    std::vector<Variant> fresh_variants;
+    for (size_t t = 0; t < n_tri; ++t) {
+        uint32_t mirrored = 0;
+        if (orient_uv) {
+            float a[2], b[2], c[2]; uint32_t bits[2];
+            fetch_key(soup.uv, soup.c_uv[tri[3 * t]], 2, bits);     memcpy(a, bits, 8);
+            fetch_key(soup.uv, soup.c_uv[tri[3 * t + 1]], 2, bits); memcpy(b, bits, 8);
+            fetch_key(soup.uv, soup.c_uv[tri[3 * t + 2]], 2, bits); memcpy(c, bits, 8);
+            const float signed_area = (b[0] - a[0]) * (c[1] - a[1]) - (b[1] - a[1]) * (c[0] - a[0]);
+            mirrored = signed_area > 0.f ? 0u : 1u;
+        }
+        for (int j = 0; j < 3; ++j) {
+            const uint32_t fc = tri[3 * t + j], point = soup.c_point[fc];
+            uint32_t w[6] = { 0, 0, 0, 0, 0, 0 }; size_t n = 0;
+            if (keep_normals) { fetch_key(soup.nrm, soup.c_nrm[fc], 3, w + n); n += 3; }
+            if (keep_uv) { fetch_key(soup.uv, soup.c_uv[fc], 2, w + n); n += 2; }
+            if (orient_uv) w[n++] = mirrored;
+            bool fresh = false;
+            const uint32_t rank = table.find_or_add(point, w, variants_of[point], fresh);
+            if (fresh) { Variant v; v.point = point; v.rank = rank; memcpy(v.w, w, sizeof(w)); fresh_variants.push_back(v); variants_of[point]++; }
+            rank_of[3 * t + j] = rank;
         }
     }
-    size_t vert_dim = (has_normals ? 3 : 0) + (has_uv ? 2 : 0) + (split_uv_sign ? 1 : 0);
-    if (vert_dim == 0) vert_dim = 1;
-    std::vector<uint32_t> key(vert_dim, 0u);
-    auto build_key = [&](uint32_t c) {
-        uint32_t sc = tri_corner[c], *k = key.data();
-        if (has_normals) { fetch_key(normals, corner_normal[sc], 3, k); k += 3; }
-        if (has_uv) { fetch_key(texcoords, corner_uv[sc], 2, k); k += 2; }
-        if (split_uv_sign) *k++ = uv_flipped[c / 3];
-    };
-    /* stable counting sort of the triangle corners by source point */
-    std::vector<uint32_t> point_offsets(n_points + 1, 0u), corner_order(n_tc);
-    for (size_t c = 0; c < n_tc; ++c) point_offsets[corner_vertex[tri_corner[c]]]++;
-    for (size_t p = 1; p <= n_points; ++p) point_offsets[p] += point_offsets[p - 1];
-    for (size_t c = n_tc; c-- > 0; ) corner_order[--point_offsets[corner_vertex[tri_corner[c]]]] = (uint32_t) c;
 
-    std::vector<float> V; std::vector<uint32_t> F(4 * n_tris, 0u), position_index, vert_keys;
-    uint32_t vertex_count = 0, position_count = 0;
+    /* ---- pass 4: numbering.  first_vertex[point] = vertices of all earlier points; compact ids for the points that are in use */
+    std::vector<uint32_t> first_vertex(n_points + 1, 0u), compact_point(n_points, kMissing);
+    uint32_t points_in_use = 0;
     for (size_t p = 0; p < n_points; ++p) {
-        uint32_t begin = point_offsets[p], end = point_offsets[p + 1];
-        if (begin == end) continue;                          /* unreferenced source vertices are dropped */
-        uint32_t point_id = position_count++, vert_base = vertex_count;
-        vert_keys.clear();
-        for (uint32_t i = begin; i != end; ++i) {
-            uint32_t c = corner_order[i];
-            build_key(c);
-            uint32_t n_local = vertex_count - vert_base, j = 0;
-            while (j < n_local && memcmp(vert_keys.data() + (size_t) j * vert_dim, key.data(), vert_dim * sizeof(uint32_t)) != 0) ++j;
-            uint32_t vid = vert_base + j;
-            if (vid == vertex_count) {
-                vertex_count++;
-                position_index.push_back(point_id);
-                vert_keys.insert(vert_keys.end(), key.begin(), key.end());
-                float rec[8] = { positions[3 * p], positions[3 * p + 1], positions[3 * p + 2], 0.f, 0.f, 0.f, 0.f, 0.f };
-                const uint32_t *k = key.data();
-                if (has_normals) { memcpy(rec + 3, k, 12); k += 3; }
-                if (has_uv) { memcpy(rec + 6, k, 8); k += 2; }
-                V.insert(V.end(), rec, rec + 8);
-            }
-            F[(size_t) (c / 3) * 4 + c % 3] = vid;
-        }
+        first_vertex[p + 1] = first_vertex[p] + variants_of[p];
+        if (variants_of[p]) compact_point[p] = points_in_use++;
     }
-    const bool regenerate = !has_normals && !face_normals;
-    if (har_mesh_finalize(V, F, has_normals, regenerate, to_world, flip_normals != 0, &position_index, position_count)) return 1;
-    return emit(V, F, ((has_normals || regenerate) ? 1u : 0u) | (has_uv ? 2u : 0u), out);
+    const uint32_t n_vertices = first_vertex[n_points];
+    std::vector<float> V((size_t) n_vertices * 8, 0.f);
+    std::vector<uint32_t> surface_point(n_vertices, 0u);
+    for (const Variant &v : fresh_variants) {
+        const uint32_t id = first_vertex[v.point] + v.rank;
+        float *rec = V.data() + (size_t) id * 8;
+        memcpy(rec, soup.xyz.data() + (size_t) v.point * 3, 12);
+        size_t n = 0;
+        if (keep_normals) { memcpy(rec + 3, v.w + n, 12); n += 3; }
+        if (keep_uv) { memcpy(rec + 6, v.w + n, 8); n += 2; }
+        surface_point[id] = compact_point[v.point];
+    }
+    std::vector<uint32_t> F(4 * n_tri, 0u);
+    for (size_t t = 0; t < n_tri; ++t)
+        for (int j = 0; j < 3; ++j) F[4 * t + j] = first_vertex[soup.c_point[tri[3 * t + j]]] + rank_of[3 * t + j];
+
+    const bool regenerate = !keep_normals && !face_normals;
+    if (har_mesh_finalize(V, F, keep_normals, regenerate, to_world, flip_normals != 0, &surface_point, points_in_use)) return 1;
+    return emit(V, F, ((keep_normals || regenerate) ? 1u : 0u) | (keep_uv ? 2u : 0u), out);
 }
 
 static int mesh_load_serialized_impl(const char *filename, int shape_index, int face_normals, const float *to_world, int flip_normals, HarMeshData *out) {

@@ -25,6 +25,7 @@
 #include <new>
 #include <stdexcept>
 #include <string>
+#include <exception>
 #include <thread>
 #include <vector>
 
@@ -162,9 +163,11 @@ extern "C" int har_render_scalar(const HarSceneDesc *desc, const HarSensor *sens
         const ShadeParams P0{ 0u, (uint32_t) max_depth, (uint32_t) rr_depth, HAR_SHADE_SCALAR_DRAWS };
 
         std::mutex film_mutex; std::atomic<uint32_t> next(0); std::atomic<int> status_all(0);
-        auto worker = [&]() {
+        std::exception_ptr worker_error; std::mutex error_mutex;
+        auto worker_body = [&]() {
             std::vector<float> blk; ShadeParams P = P0;            /* per worker: P.seed names the current pixel's stream */
             for (;;) {
+                if (status_all.load()) break;                     /* an overflow reported by any worker ends the render early */
                 const uint32_t bi = next.fetch_add(1);
                 if (bi >= blocks.size()) break;
                 const Block &b = blocks[bi];
@@ -230,10 +233,21 @@ extern "C" int har_render_scalar(const HarSceneDesc *desc, const HarSensor *sens
                 }
             }
         };
+        /* an exception in a pool thread (std::bad_alloc of a block buffer) must not reach std::terminate: it is kept, the other workers stop at
+         * their next block, and the calling thread rethrows it after the join (into the catch clauses below) */
+        auto worker = [&]() {
+            try { worker_body(); }
+            catch (...) {
+                std::lock_guard<std::mutex> lock(error_mutex);
+                if (!worker_error) worker_error = std::current_exception();
+                next.store((uint32_t) blocks.size());
+            }
+        };
         std::vector<std::thread> pool;
         for (uint32_t t = 1; t < n_threads; ++t) { try { pool.emplace_back(worker); } catch (...) { break; } }
         worker();
         for (auto &t : pool) t.join();
+        if (worker_error) std::rethrow_exception(worker_error);
         if (status_all.load()) return har_set_error("scalar render: traversal stack / filter footprint overflow");
         return 0;
     } catch (const std::bad_alloc &) { return har_set_error("har_render_scalar: out of memory"); }

@@ -422,6 +422,8 @@ int hh_trace_stats(void *h, const HarSensor *sensor, uint32_t seed, uint32_t spp
             shadow.swap(tmp);
         }
         std::vector<std::vector<uint32_t>> sev(shadow.size());
+        static const int shadow_order = getenv("HH_SHADOW_ORDER") ? atoi(getenv("HH_SHADOW_ORDER")) : 0;
+        g_host_child_order = shadow_order;
         for (size_t i = 0; i < shadow.size(); ++i) {
             HostStack stack; EvProbe pr{ &sev[i] }; Hit hh;
             bool f1 = accel_trace<true>(S.accel, shadow[i].o, shadow[i].d, shadow[i].maxt, hh, stack, status, pr);
@@ -432,7 +434,10 @@ int hh_trace_stats(void *h, const HarSensor *sensor, uint32_t seed, uint32_t spp
                 else             run_traversal<true, Traversal<2>>(S.accel, shadow[i].o, shadow[i].d, shadow[i].maxt, h2, f2, sev[i], status);
                 if (f1 != f2) o[26] += 1;
             }
+            /* occluded vs unoccluded shadow rays: count and node visits of the occluded ones (slots 27 / 28) */
+            if (f1) { o[27] += 1; for (uint32_t x : sev[i]) o[28] += x & 1u; }
         }
+        g_host_child_order = 0;
         account(sev, o + 16);
         cur.swap(next);
     }

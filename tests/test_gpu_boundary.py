@@ -192,11 +192,24 @@ def test_render_forward_is_transpose_of_render_backward(mi):
         shape = tuple(scene.textures[b.tex_index].shape) if kind == "tex" else (3,)
         tangents[k] = rng.uniform(-1, 1, shape).astype(np.float32)
     g = rng.uniform(-1, 1, (res, res, 3)).astype(np.float32)
-    fwd = integ.render_forward(scene, None, seed=2, spp=spp, tangents=tangents).cpu().numpy().astype(np.float64)
+    def identity(fwd, grads):
+        lhs = float((fwd * g).sum())
+        rhs = float(sum((grads[k].cpu().numpy().astype(np.float64).reshape(-1) * tangents[k].reshape(-1)).sum() for k in tangents))
+        assert abs(lhs - rhs) < 2e-4 * max(abs(lhs), abs(rhs)), (lhs, rhs)
+    # backward FIRST: the integrator's workspace then holds that call's adjoint image, which forward mode must not gather (round-2 advisor finding:
+    # k_raygen took `adj != nullptr` as "adjoint mode", so a render_forward after a render_backward started from a stale dL)
     grads = integ.render_backward(scene, None, g, seed=2, spp=spp)
-    lhs = float((fwd * g).sum())
-    rhs = float(sum((grads[k].cpu().numpy().astype(np.float64).reshape(-1) * tangents[k].reshape(-1)).sum() for k in tangents))
-    assert abs(lhs - rhs) < 2e-4 * max(abs(lhs), abs(rhs)), (lhs, rhs)
+    fwd = integ.render_forward(scene, None, seed=2, spp=spp, tangents=tangents).cpu().numpy().astype(np.float64)
+    identity(fwd, grads)
+    # ... and the pair once more on the same integrator, forward first this time
+    fwd2 = integ.render_forward(scene, None, seed=2, spp=spp, tangents=tangents).cpu().numpy().astype(np.float64)
+    grads2 = integ.render_backward(scene, None, g, seed=2, spp=spp)
+    assert np.array_equal(fwd, fwd2)
+    identity(fwd2, grads2)
+    # a fresh integrator that never ran a backward pass gives the same derivative image
+    d2 = dict(d); scene_b = mi.load_dict(d2)
+    fwd3 = scene_b.integrator().render_forward(scene_b, None, seed=2, spp=spp, tangents=tangents).cpu().numpy().astype(np.float64)
+    assert rel_l2(fwd3, fwd) < 1e-6
 
 
 def test_render_forward_materials_vs_oracle(mi, O):

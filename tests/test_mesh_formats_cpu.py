@@ -176,6 +176,28 @@ def test_mesh_loaders_bake_transform_before_normals(mi, tmp_path):
     assert np.allclose(m3.V[1:, 3:6], -e[1:], atol=1e-5) and not m3.V[0, 3:6].any()
 
 
+def test_obj_random_polygon_soup_welds_like_the_contract(mi, tmp_path):
+    """stress of the hash-table welding: 600 points, 1500 polygons of 3..7 sides, few distinct normals / texcoords (many repeats, -0.0 vs +0.0
+    texcoords, mirrored UV triangles, missing indices in some corners, a third of the points never referenced)"""
+    rng = np.random.default_rng(11)
+    P = rng.uniform(-1, 1, (600, 3)).astype(np.float32)
+    VT = rng.integers(-2, 3, (9, 2)).astype(np.float32) * np.float32(0.5); VT[3] = (-0.0, 0.0); VT[4] = (0.0, -0.0)
+    VN = rng.normal(size=(5, 3)).astype(np.float32); VN[2] = (0.0, -0.0, 1.0)
+    polys = []
+    for _ in range(1500):
+        sides = int(rng.integers(3, 8))
+        pts = rng.choice(400, sides, replace=False)              # points 400..599 stay unreferenced
+        mode = int(rng.integers(0, 4))
+        polys.append([(int(q), int(rng.integers(0, 9)) if mode in (1, 3) else None, int(rng.integers(0, 5)) if mode in (2, 3) else None) for q in pts])
+    path = os.path.join(tmp_path, "soup.obj")
+    write_obj(path, P, polys, VT, VN)
+    for fn in (False, True):
+        m = mi.core.Mesh("t").from_obj(path, face_normals=fn)
+        ref = weld_reference(P, polys, VT, VN, face_normals=fn)
+        check_against_reference(m, ref)
+        assert m.F.shape[0] == sum(len(q) - 2 for q in polys)
+
+
 def test_obj_errors(mi, tmp_path):
     def load(text, **kw):
         path = os.path.join(tmp_path, "e.obj")
@@ -186,6 +208,7 @@ def test_obj_errors(mi, tmp_path):
     assert load(tri + "f 1 2\n").F.shape[0] == 0                                # degenerate polygon: no triangle
     with pytest.raises(RuntimeError, match="invalid vertex 4"): load(tri + "f 1 2 4\n")
     with pytest.raises(RuntimeError, match="invalid vertex 0"): load(tri + "f 0 1 2\n")
+    with pytest.raises(RuntimeError, match="invalid vertex -1"): load(tri + "f -1 -2 -3\n")      # relative indices: refused like the reference (strtoul wraps)
     with pytest.raises(RuntimeError, match="invalid texture coordinate 2"): load(tri + "vt 0 0\nf 1/1 2/2 3/1\n")
     with pytest.raises(RuntimeError, match="invalid normal 1"): load(tri + "f 1//1 2//1 3//1\n")
     assert load(tri + "f 1//1 2//1 3//1\n", face_normals=True).F.shape[0] == 1   # normals are ignored entirely (obj.cpp:176,262)
