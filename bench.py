@@ -16,8 +16,10 @@ emitter gradients on, and reported in `prb_adjoint`.  rank 0 prints ONE JSON lin
 
 Process layout.  Started without a torch.distributed environment, this file is a LAUNCHER:
   --gpus 1 : runs the measurement in one child process (`--worker`); a child killed by a
-             signal (a GPU fault aborts the process) is re-run after a pause (at most twice) and the
-             line reports "attempts" -- the failed attempt's stderr is passed through, nothing is hidden;
+             signal BEFORE its PyTorch-only preflight passed (a bad box: nothing of this repository
+             has run yet) is re-run after a pause (at most twice); a crash after the preflight is the
+             product's and is reported, not retried (--retry-on-signal overrides).  The line reports
+             "attempts" and, when > 1, says so in `metric`;
   --gpus N : starts N ranks through `python -m torch.distributed.run` (RCCL), one per GPU.
 Under torch.distributed.run (RANK / WORLD_SIZE set, the driver's way for N > 1) it is a rank.
 """
@@ -53,6 +55,8 @@ def parse(argv=None):
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-prb", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=12.0)
+    ap.add_argument("--retry-on-signal", action="store_true", help="re-run a worker killed by a signal even when it died after the preflight (off: such a crash is reported, not retried)")
+    ap.add_argument("--no-secondary", action="store_true", help="skip the secondary forward workload (flat1m: the 64 MB-BVH variant of the scene)")
     ap.add_argument("--worker", action="store_true", help="(internal) this process measures; see the module docstring")
     return ap.parse_args(argv)
 
@@ -76,24 +80,41 @@ def launcher(args):
                "--master-port", str(free_port()), os.path.abspath(__file__)] + passthrough
         return subprocess.call(cmd, env=env)
     cmd = [sys.executable, os.path.abspath(__file__)] + passthrough + ["--worker"]
-    # A process killed by a signal (SIGABRT after "Memory access fault by GPU", SIGSEGV, ...) gets two more chances after a pause: on this pool
-    # a freshly leased box occasionally faults on the very first device access of a process (seen in round 2 with the identical snapshot that
-    # passed on the next box: the fault came during the scene upload, before any kernel of this repository ran, and a retry 1 s later hit it
-    # again) -- the pauses give the driver's GPU recovery time.  Ordinary errors (exit code > 0) are reported as they are.
+    # A child killed by a signal (SIGABRT after "Memory access fault by GPU", SIGSEGV, ...) is re-run ONLY when it died before this repository's
+    # library did anything: the worker first runs a PyTorch-only preflight (host-to-device copy + reduction) and records in a stage file that it
+    # passed.  Twice in round 2 a freshly leased box faulted inside the HIP runtime's first copy of every process started on it; such a box
+    # fails the preflight, which is not evidence about the product, and gets two more chances after a pause.  A crash AFTER the preflight is
+    # the product's: it is reported as it is (return code, stderr), never retried -- unless --retry-on-signal asks for the round-2 behaviour.
+    import tempfile
     pauses = (10.0, 30.0)
+    stage_file = tempfile.NamedTemporaryFile(prefix="har_bench_stage_", delete=False).name
+    env["HAR_BENCH_STAGE_FILE"] = stage_file
     for attempt in range(1, len(pauses) + 2):
         env["HAR_BENCH_ATTEMPT"] = str(attempt)
+        open(stage_file, "w").close()
         p = subprocess.run(cmd, env=env, stdout=subprocess.PIPE)
         out = p.stdout.decode(errors="replace")
         crashed = p.returncode < 0 or p.returncode in (134, 139)
-        if not crashed or attempt == len(pauses) + 1:
+        try:
+            stage = open(stage_file).read()
+        except OSError:
+            stage = ""
+        retry = crashed and attempt <= len(pauses) and ("preflight_ok" not in stage or args.retry_on_signal)
+        if not retry:
+            if crashed and "preflight_ok" in stage:
+                sys.stderr.write("[bench] the worker was killed (return code %d) AFTER the PyTorch-only preflight passed: a fault of this repository's "
+                                 "code path, not retried (use --retry-on-signal to override)\n" % p.returncode)
             sys.stdout.write(out); sys.stdout.flush()
+            try:
+                os.unlink(stage_file)
+            except OSError:
+                pass
             return p.returncode
-        sys.stderr.write("[bench] attempt %d ended with return code %d (killed by a signal / aborted); waiting %.0f s, then measuring again "
+        sys.stderr.write("[bench] WARNING attempt %d ended with return code %d (killed by a signal / aborted) %s; waiting %.0f s, then measuring again "
                          "with the runtime's copies on shader blits instead of the SDMA engines (HSA_ENABLE_SDMA=0)\n"
-                         % (attempt, p.returncode, pauses[attempt - 1]))
+                         % (attempt, p.returncode, "before the preflight passed" if "preflight_ok" not in stage else "after the preflight (--retry-on-signal)", pauses[attempt - 1]))
         sys.stderr.flush()
-        # both bad-box episodes of this round faulted inside the runtime's first host-to-device copy: take the other copy path on the retry.
+        # both bad-box episodes of round 2 faulted inside the runtime's first host-to-device copy: take the other copy path on the retry.
         # The timed region holds no copies (everything is resident), so the reported numbers do not depend on it; "copy_path" in the line says so.
         env["HSA_ENABLE_SDMA"] = "0"
         time.sleep(pauses[attempt - 1])
@@ -134,6 +155,30 @@ def kernel_record(profile, kernel):
         if ("k_" + kernel) in name and "counters" in rec:
             return rec
     return None
+
+
+def profile_matches_run(profile, timing):
+    """True when the committed PMC summary was taken from a build with this run's launch sequence: for every kernel class of the frame the
+    profile holds a `k_<class>` kernel whose dispatches per frame (frames = its raygen dispatches) equal this run's launches per frame
+    (HIP-event classes of har_integrator_timing).  Otherwise a string that says what differs -- the caller then quotes no counter figure."""
+    if not profile:
+        return "no committed profile for this workload"
+    def disp(kernel):
+        n = 0
+        for name, rec in profile.items():
+            if ("k_" + kernel) in name:
+                c = rec.get("counters", {})
+                n += int(next(iter(c.values()))["dispatches"]) if c else int(rec.get("calls", 0))
+        return n
+    frames = disp("raygen")
+    if frames == 0:
+        return "the profile holds no k_raygen dispatch"
+    for cls in ("raygen", "trace_closest", "shade", "resolve", "splat"):
+        want = int(timing[cls][1])
+        got = disp(cls)
+        if got != want * frames:
+            return "stale profile: k_%s has %d dispatches in %d profiled frame(s), this run launches it %d time(s) per frame" % (cls, got, frames, want)
+    return True
 
 
 def worker(args):
@@ -178,6 +223,12 @@ def worker(args):
     del pre
     torch.cuda.synchronize()
     log("preflight ok (torch H2D copy + reduction, before libhip_ad_rgb.so is loaded)")
+    if os.environ.get("HAR_BENCH_STAGE_FILE"):
+        try:
+            with open(os.environ["HAR_BENCH_STAGE_FILE"], "w") as f:
+                f.write("preflight_ok\n")
+        except OSError:
+            pass
     mi.set_variant("hip_ad_rgb")
 
     def sync_barrier():
@@ -247,9 +298,14 @@ def worker(args):
     # summed over all kernels of a frame for `frame_traffic`.  Only valid for the launch shape it was collected at (N = 1, 512^2 x 256).
     traffic = frame_traffic = traffic_src = None
     bound_actual = None
+    profile_check = None
     if args.res == 512 and args.spp == 256 and world == 1 and not args.chunk:
         prof, traffic_src = load_profile("traffic", args.workload)
         rec = kernel_record(prof, dominant)
+        # a committed profile is only quoted when it describes THIS build's launch sequence: same kernels, same launches per frame
+        profile_check = profile_matches_run(prof, timing)
+        if profile_check is not True:
+            rec = None
         if rec and "FETCH_SIZE" in rec["counters"] and "WRITE_SIZE" in rec["counters"]:
             f, w = rec["counters"]["FETCH_SIZE"], rec["counters"]["WRITE_SIZE"]
             traffic = round((2.0 * f["sum"] / f["dispatches"] + w["sum"] / w["dispatches"]) * 1024.0)
@@ -265,7 +321,7 @@ def worker(args):
             frame_traffic = {"bytes_per_frame": round(tot), "GBs": round(tot / 1e9 / (ms_per_step / 1e3), 1),
                              "frac_of_peak": round(tot / 1e9 / (ms_per_step / 1e3) / HBM_PEAK_GBS, 4), "source": "profiles/" + traffic_src}
         sq, sq_src = load_profile("sq", args.workload)
-        rec = kernel_record(sq, dominant)
+        rec = kernel_record(sq, dominant) if profile_matches_run(sq, timing) is True else None
         if rec and "SQ_INSTS_VALU" in rec["counters"] and rec.get("total_ms"):
             c = rec["counters"]
             rays = stats["closest_rays"] if dominant == "trace_closest" else stats["shadow_rays"] if dominant == "resolve" else stats["vertices"]
@@ -281,7 +337,8 @@ def worker(args):
                 "algorithmic_bytes_per_launch": round(alg_bytes / launches),
                 "avg_launch_ms": round(kern_ms[dominant] / launches, 4), "launches": launches, "frames_averaged": frames_profiled,
                 "kernel_ms": {k: round(v, 3) for k, v in kern_ms.items()},
-                "bound_actual": bound_actual, "frame_traffic": frame_traffic}
+                "bound_actual": bound_actual, "frame_traffic": frame_traffic,
+                "profile_check": ("ok: the committed profile's kernels and launches per frame equal this run's" if profile_check is True else profile_check)}
 
     # ---------------- PRB adjoint ----------------
     prb = None
@@ -307,13 +364,44 @@ def worker(args):
                "stats_note": "counters of the adjoint replay: its ray queries are served by the replay cache (shadow_rays = 0 traced); the primal pass of the same step traces the rays"}
         log("PRB adjoint done: %.1f Mpaths/s" % prb["value"])
 
+    # ---------------- secondary forward workload: the FLATTENED 1M-triangle scene (64 MB BVH instead of 0.65 MB: SURVEY.md 8(d)'s BVH-size stress) ----------------
+    secondary = None
+    if args.workload == "instanced1m" and not args.no_secondary and world == 1:
+        import copy
+        a2 = copy.copy(args); a2.workload = "flat1m"
+        log("secondary workload flat1m: building the scene + BVH")
+        scene2 = build_scene(mi, a2, "path")
+        integ2 = scene2.integrator()
+
+        def fwd2():
+            return mi.render_distributed(scene2, integ2, seed=0, spp=args.spp)
+
+        fwd2(); sync_barrier()
+        s_steps = max(1, min(args.steps, 5))
+        dt2 = timed(fwd2, s_steps, 1, on_start=lambda: integ2.set_profiling(True))
+        t2 = integ2.timing(); integ2.set_profiling(False)
+        st2 = integ2.stats(); acc2 = scene2.accel_info()
+        l2 = max(t2["trace_closest"][1], 1)
+        ach2 = (st2["closest_rays"] * 56 + acc2["bytes"] * l2) / 1e9 / (t2["trace_closest"][0] / 1e3)
+        secondary = {"workload": "flat1m %dx%dx%dspp (flattened: unique triangles, %.0f MB BVH)" % (args.res, args.res, args.spp, acc2["bytes"] / 1e6),
+                     "value": round(n_paths / (dt2 / s_steps) / 1e6, 2), "unit": "Mpaths/s", "ms_per_step": round(dt2 / s_steps * 1e3, 2), "steps": s_steps,
+                     "accel": acc2, "kernel_ms": {k: round(v[0], 3) for k, v in t2.items() if k != "frames"},
+                     "trace_closest_achieved_GBs": round(ach2, 2), "trace_closest_frac_of_hbm_peak": round(ach2 / HBM_PEAK_GBS, 5),
+                     "stats": {k: int(v) for k, v in st2.items()}}
+        log("secondary done: %.1f Mpaths/s" % secondary["value"])
+        del scene2, integ2
+
     # ---------------- CPU baseline (oracle = CPU restatement of llvm_ad_rgb; rank 0, N = 1 only) ----------------
     cpu = None
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         from oracle import oracle as O
         cores = os.cpu_count() or 1
         log("CPU baseline: oracle on %d host threads (forward)" % cores)
-        osc, sensor = O.scene_from_product(scene)
+        if args.workload in ("instanced1m", "flat1m"):      # the oracle's own lowering of the scene description (independent of the product's host code)
+            sd_o, sensor = O.benchmark_spheres_scene(args.res, args.res, flatten=(args.workload == "flat1m"))
+            osc = O.OracleScene(sd_o)
+        else:
+            osc, sensor = O.scene_from_product(scene)
         t0 = time.perf_counter()
         _, st = osc.render_path(sensor, seed=0, spp=1, max_depth=args.max_depth, threads=cores)
         probe = time.perf_counter() - t0
@@ -323,11 +411,16 @@ def worker(args):
         _, st = osc.render_path(sensor, seed=0, spp=spp_cpu, max_depth=args.max_depth, threads=cores)
         el = time.perf_counter() - t0
         cpu = {"value": round(st.paths / el / 1e6, 4), "unit": "Mpaths/s", "cores": cores, "kind": "port",
+               "note": "the oracle is a slow, readable restatement written as a CHECKER (284 us x thread per path); it is NOT llvm_ad_rgb -- an Embree-backed llvm_ad_rgb on these cores would be one to two orders of magnitude faster; the ratio value / cpu_baseline.value bounds nothing",
                "sample": "%dx%dx%d spp of the same scene/seed (%.1f s); CPU restatement of llvm_ad_rgb (reference not installable)"
                          % (args.res, args.res, spp_cpu, el)}
         if scene_p is not None:
             log("CPU baseline: oracle PRB backward")
-            oscp, sensorp = O.scene_from_product(scene_p)
+            if args.workload in ("instanced1m", "flat1m"):
+                sd_p, sensorp = O.benchmark_spheres_scene(args.res, args.res, flatten=(args.workload == "flat1m"), textured=True)
+                oscp = O.OracleScene(sd_p)
+            else:
+                oscp, sensorp = O.scene_from_product(scene_p)
             g = np.full((args.res, args.res, 3), 1.0 / (args.res * args.res * 3), np.float32)
             t0 = time.perf_counter()
             oscp.render_prb_backward(sensorp, g, seed=1, spp=1, max_depth=args.max_depth, threads=cores)
@@ -351,11 +444,13 @@ def worker(args):
                        "ranks": world, "collective_backend": ("rccl (torch.distributed nccl)" if backend == "nccl" else backend),
                        # row bands of equal measured cost (mitsuba3_amd/distributed.py BandBalancer; adapts over the first 3 frames, then frozen)
                        "row_bands": next(iter(getattr(integ, "_band_balancers", {}).values())).bounds if world > 1 and getattr(integ, "_band_balancers", None) else None},
-            "prb_adjoint": prb, "roofline": roofline, "cpu_baseline": cpu,
+            "prb_adjoint": prb, "secondary": secondary, "roofline": roofline, "cpu_baseline": cpu,
             "stats": {k: int(v) for k, v in stats.items()},
             "attempts": int(os.environ.get("HAR_BENCH_ATTEMPT", "1")),
             "copy_path": "shader blits (HSA_ENABLE_SDMA=0, retry)" if os.environ.get("HSA_ENABLE_SDMA") == "0" else "runtime default",
         }
+        if out["attempts"] > 1:
+            out["metric"] = "WARNING measured on attempt %d (earlier worker(s) died before the GPU preflight passed) -- " % out["attempts"] + out["metric"]
         print(json.dumps(out)); sys.stdout.flush()
     if world > 1:
         dist.destroy_process_group()

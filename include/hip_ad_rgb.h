@@ -123,6 +123,9 @@ typedef struct HarSensor {
     uint32_t rfilter;             /* 0 box, 1 gaussian, 2 tent, 3 mitchell, 4 catmullrom, 5 lanczos (src/rfilters/ *.cpp) */
     float    rfilter_stddev;      /* parameter 0: gaussian `stddev`, tent `radius`, mitchell `B`, lanczos `lobes` */
     float    rfilter_param1;      /* parameter 1: mitchell `C` */
+    uint32_t sample_border;       /* Film::sample_border (src/render/film.cpp:29-32): != 0 -> the lane -> pixel map of render() runs over the crop window
+                                   * enlarged by rfilter->border_size() = ceil(radius - 1/2 - 2 RayEpsilon) pixels on every side
+                                   * (src/render/integrator.cpp:162-165, 322-339); the film itself keeps the crop size, splats are clipped to it */
 } HarSensor;
 
 /* counters of one render call (all lanes), read back with har_render_stats */

@@ -69,7 +69,8 @@ class HarSensor(C.Structure):
                 ("film_width", C.c_uint32), ("film_height", C.c_uint32),
                 ("crop_offset_x", C.c_uint32), ("crop_offset_y", C.c_uint32),
                 ("crop_width", C.c_uint32), ("crop_height", C.c_uint32),
-                ("rfilter", C.c_uint32), ("rfilter_stddev", C.c_float), ("rfilter_param1", C.c_float)]
+                ("rfilter", C.c_uint32), ("rfilter_stddev", C.c_float), ("rfilter_param1", C.c_float),
+                ("sample_border", C.c_uint32)]
 
 
 class HarStats(C.Structure):

@@ -455,12 +455,15 @@ class Film:
         else:
             raise RuntimeError("Plugin \"%s\" not found for variant hip_ad_rgb (rfilters: box, gaussian, tent, mitchell, catmullrom, lanczos)" % rf['type'])
 
-        # Film::sample_border (film.cpp:29-32): samples are also drawn in a border of ceil(radius - 1/2) pixels (rfilter.h border_size) around the crop
-        # window -- nothing for the box filter, not implemented otherwise
+        # Film::sample_border (film.cpp:29-32): samples are also drawn in a border of rfilter->border_size() = ceil(radius - 1/2 - 2 RayEpsilon) pixels
+        # (rfilter.cpp:22) around the crop window; the film keeps its size, the splats of border samples are clipped to it
         radius = {0: 0.5, 1: 4.0 * self.stddev, 2: self.stddev, 3: 2.0, 4: 2.0, 5: self.stddev}[self.rfilter]
         self.sample_border_ = bool(props.get('sample_border', False))
-        if self.sample_border_ and math.ceil(radius - 0.5) > 0:
-            raise RuntimeError("hdrfilm: property \"sample_border\" = True is not implemented by hip_ad_rgb for filters with a border (radius > 0.5)")
+        self.border_size_ = max(0, int(math.ceil(np.float32(np.float32(radius) - np.float32(0.5)) - np.float32(2.0 * 1500.0 * 2.0 ** -24)))) if self.sample_border_ else 0
+
+    def sample_grid(self):
+        """pixels of the lane -> pixel map of render(): crop_size + 2 * border_size with sample_border (integrator.cpp:162-165), else the crop size"""
+        return (self.crop_size_[0] + 2 * self.border_size_, self.crop_size_[1] + 2 * self.border_size_)
 
     def sample_border(self):
         return self.sample_border_
@@ -510,6 +513,7 @@ class Sensor:
                                           f.width, f.height, f.crop_offset_[0], f.crop_offset_[1], f.crop_size_[0], f.crop_size_[1],
                                           f.rfilter, f.stddev, C.byref(s))
         s.rfilter_param1 = f.rf_param1
+        s.sample_border = 1 if f.sample_border_ else 0
         if rc == 2:
             raise RuntimeError("The 'fov_axis' parameter must be set to one of 'smaller', 'larger', 'diagonal', 'x', or 'y'!")
         if rc == 3:

@@ -467,6 +467,15 @@ int run_chunk(HarSceneImpl *S, HarIntegratorImpl *I, const DSensor &C, int mode,
     return 0;
 }
 
+/* pixels of the sample grid of render(): the crop window, plus the filter border with Film::sample_border (integrator.cpp:162-165) */
+int sample_grid(const HarSensor *sensor, uint32_t &w, uint32_t &h) {
+    DSensor C; std::string e;
+    if (!sensor) return fail("null sensor");
+    if (!lower_sensor(*sensor, C, e)) return fail(e);
+    w = C.samp_w; h = C.samp_h;
+    return 0;
+}
+
 /* SamplingIntegrator::render, integrator.cpp:173-183,276-294 + Sampler::set_samples_per_wavefront, sampler.cpp:88-96 */
 int pass_layout(const HarIntegratorImpl *I, uint32_t crop_w, uint32_t crop_h, uint32_t spp, uint32_t &spp_per_pass, uint32_t &n_passes) {
     if (spp == 0) return fail("spp must be > 0");
@@ -491,7 +500,7 @@ int check_common(HarSceneImpl *S, HarIntegratorImpl *I, const HarSensor *sensor,
     if (!lower_sensor(*sensor, C, e)) return fail(e);
     if (C.rfilter != 0 && 2 * (uint32_t) ceilf(C.radius - .5f) + 1 > HAR_MAX_FILTER_TAPS) return fail("reconstruction filter radius too large (max 9 taps)");
     if (spp == 0) return fail("spp must be > 0");
-    uint64_t total = (uint64_t) C.crop_w * C.crop_h * spp;
+    uint64_t total = (uint64_t) C.samp_w * C.samp_h * spp;
     /* 2^32 wavefront limit of JIT variants (integrator.cpp:276-294, common.py:358-363) */
     if (total > 0xffffffffull) return fail("the rendering task exceeds 2^32 - 1 Monte Carlo samples; render in several passes");
     if (lb == 0 && le == 0) le = total;
@@ -726,8 +735,9 @@ static int render_range(HarScene S, HarIntegrator I, const HarSensor *sensor, ui
     DSensor C; uint32_t log_spp;
     if (!S || !I || !sensor) return fail("null scene / integrator / sensor");
     /* multi-pass layout; `path` only: the Python AD integrators render one wavefront or refuse (common.py:358-363) */
-    uint32_t spp_pass = spp, n_passes = 1;
-    if (I->type == HAR_INTEGRATOR_PATH && pass_layout(I, sensor->crop_width, sensor->crop_height, spp, spp_pass, n_passes)) return 1;
+    uint32_t spp_pass = spp, n_passes = 1, grid_w = 0, grid_h = 0;
+    if (sample_grid(sensor, grid_w, grid_h)) return 1;
+    if (I->type == HAR_INTEGRATOR_PATH && pass_layout(I, grid_w, grid_h, spp, spp_pass, n_passes)) return 1;
     if (check_common(S, I, sensor, spp_pass, lb, le, C, log_spp)) return 1;
     if (!film) return fail("null film");
     hipStream_t s = (hipStream_t) stream;
@@ -801,9 +811,10 @@ int har_render(HarScene S, HarIntegrator I, const HarSensor *sensor, uint32_t se
     if (!S || !I || !sensor) return fail("null scene / integrator / sensor");
     uint64_t total_lb = lb, total_le = le;
     if (lb == 0 && le == 0) {                           /* "all lanes": resolve the range here so that it can be cut */
-        uint32_t spp_pass = spp, n_passes = 1;
-        if (I->type == HAR_INTEGRATOR_PATH && pass_layout(I, sensor->crop_width, sensor->crop_height, spp, spp_pass, n_passes)) return 1;
-        total_le = (uint64_t) sensor->crop_width * sensor->crop_height * spp_pass;
+        uint32_t spp_pass = spp, n_passes = 1, grid_w = 0, grid_h = 0;
+        if (sample_grid(sensor, grid_w, grid_h)) return 1;
+        if (I->type == HAR_INTEGRATOR_PATH && pass_layout(I, grid_w, grid_h, spp, spp_pass, n_passes)) return 1;
+        total_le = (uint64_t) grid_w * grid_h * spp_pass;
         if (total_le == 0 || total_le > 0xffffffffull) return render_range(S, I, sensor, seed, spp, lb, le, film, stream);      /* reports the error */
     }
     const uint64_t mid = total_le > total_lb ? dual_split(I, total_lb, total_le, (hipStream_t) stream) : total_le;
@@ -819,7 +830,9 @@ int har_render_backward(HarScene S, HarIntegrator I, const HarSensor *sensor, co
     if (!S || !I || !sensor) return fail("null scene / integrator / sensor");
     uint64_t total_lb = lb, total_le = le;
     if (lb == 0 && le == 0) {
-        total_le = (uint64_t) sensor->crop_width * sensor->crop_height * spp;
+        uint32_t grid_w = 0, grid_h = 0;
+        if (sample_grid(sensor, grid_w, grid_h)) return 1;
+        total_le = (uint64_t) grid_w * grid_h * spp;
         if (total_le == 0 || total_le > 0xffffffffull) return backward_range(S, I, sensor, grad_in, weight_film, seed, spp, lb, le, grad_reflectance, grad_textures, stream);
     }
     const uint64_t mid = (total_le > total_lb && I->type == HAR_INTEGRATOR_PRB && !I->shape_on) ? dual_split(I, total_lb, total_le, (hipStream_t) stream) : total_le;
@@ -901,14 +914,16 @@ int har_render_pass_layout(HarIntegrator I, const HarSensor *sensor, uint32_t sp
     if (!I || !sensor || !spp_per_pass || !n_passes) return fail("null argument");
     *spp_per_pass = spp; *n_passes = 1;
     if (I->type != HAR_INTEGRATOR_PATH) return spp ? 0 : fail("spp must be > 0");
-    return pass_layout(I, sensor->crop_width, sensor->crop_height, spp, *spp_per_pass, *n_passes);
+    uint32_t grid_w = 0, grid_h = 0;
+    if (sample_grid(sensor, grid_w, grid_h)) return 1;
+    return pass_layout(I, grid_w, grid_h, spp, *spp_per_pass, *n_passes);
 }
 
 int har_render_weights(const HarSensor *sensor, uint32_t seed, uint32_t spp, uint64_t lb, uint64_t le, float *film, void *stream) {
     if (!sensor || !film) return fail("null sensor / film");
     DSensor C; std::string e;
     if (!lower_sensor(*sensor, C, e)) return fail(e);
-    uint64_t total = (uint64_t) C.crop_w * C.crop_h * spp;
+    uint64_t total = (uint64_t) C.samp_w * C.samp_h * spp;
     if (spp == 0 || total > 0xffffffffull) return fail("invalid sample count");
     if (lb == 0 && le == 0) le = total;
     if (lb > le || le > total) return fail("invalid lane range");

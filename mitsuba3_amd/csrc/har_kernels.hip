@@ -964,7 +964,7 @@ __global__ __launch_bounds__(kBlock) void k_splat(DSensor C, uint32_t seed, uint
     const int ox = ext[0], oy = ext[1], tw = ext[2] + ext[4] - ext[0], th = ext[4];
     const bool one_row = tw > 0 && ext[1] == ext[3] && th <= TAPS;   /* all lanes in one image row (the footprint size is a constant of the filter) */
     if (one_row) {
-        /* the lanes of pixel (x, y) are the global lanes [p * spp, (p + 1) * spp), p = y * crop_w + x (integrator.cpp:322-334), and their
+        /* the lanes of pixel (x, y) are the global lanes [p * spp, (p + 1) * spp), p = y * samp_w + x in sample-grid coordinates (integrator.cpp:322-334), and their
          * footprint starts at x - n: for the tile column `col`, tap t collects exactly the lanes of pixel x = col - t + n */
         const int count = th, nhalf = (count - 1) / 2, y_pix = oy + nhalf;
         const int64_t g0 = (int64_t) lane_base + (int64_t) blockIdx.x * kBlock;
@@ -982,8 +982,9 @@ __global__ __launch_bounds__(kBlock) void k_splat(DSensor C, uint32_t seed, uint
                 const int t_lo = max(0, col + nhalf - x_last), t_hi = min(count - 1, col + nhalf - x_first);
                 for (int t = t_lo; t <= t_hi; ++t) {
                     const int x = col - t + nhalf;
-                    if (x < 0 || x >= (int) C.crop_w) continue;
-                    const int64_t first = ((int64_t) y_pix * C.crop_w + x) * spp - g0;
+                    /* pixel (x, y_pix) of the crop window is pixel (x + border, y_pix + border) of the sample grid (Film::sample_border; border = 0 otherwise) */
+                    if (x < -(int) C.border || x >= (int) (C.crop_w + C.border)) continue;
+                    const int64_t first = ((int64_t) (y_pix + (int) C.border) * C.samp_w + (x + (int) C.border)) * spp - g0;
                     int la = (int) max((int64_t) 0, first), lb = (int) min((int64_t) n_act, first + spp);
                     if (la >= lb) continue;
                     const int len = lb - la; lb = la + (len * (g + 1)) / G; la = la + (len * g) / G;

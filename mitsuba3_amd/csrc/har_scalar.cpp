@@ -139,6 +139,8 @@ extern "C" int har_render_scalar(const HarSceneDesc *desc, const HarSensor *sens
         if (!lower_sensor(*sensor, C, e)) return har_set_error(e);
         const DScene &S = B.ds;
         const uint32_t W = C.crop_w, H = C.crop_h;
+        /* Film::sample_border: the spiral runs over the enlarged film, every block is shifted back by the border (integrator.cpp:162-165, 248-249) */
+        const uint32_t Wg = C.samp_w, Hg = C.samp_h; const int32_t sample_shift = (int32_t) C.border;
         if (n_threads == 0) n_threads = std::max(1u, std::thread::hardware_concurrency());
 
         /* ReconstructionFilter::init_discretization (rfilter.cpp:11-26) */
@@ -155,11 +157,12 @@ extern "C" int har_render_scalar(const HarSceneDesc *desc, const HarSensor *sens
         /* integrator.cpp:203-214: a block for every thread */
         if (block_size == 0) {
             block_size = 32;                                      /* MI_BLOCK_SIZE */
-            while (!(block_size == 1 || ((W + block_size - 1) / block_size) * ((H + block_size - 1) / block_size) >= n_threads)) block_size /= 2;
+            while (!(block_size == 1 || ((Wg + block_size - 1) / block_size) * ((Hg + block_size - 1) / block_size) >= n_threads)) block_size /= 2;
         }
         if (block_size_used) *block_size_used = block_size;
-        const std::vector<Block> blocks = spiral(W, H, C.crop_x, C.crop_y, block_size);
-        const uint32_t seed_scaled = seed * (W * H);              /* integrator.cpp:231: seed *= prod(film_size), film_size = crop_size (:162) */
+        std::vector<Block> blocks = spiral(Wg, Hg, C.crop_x, C.crop_y, block_size);
+        for (Block &b : blocks) { b.off_x -= sample_shift; b.off_y -= sample_shift; }
+        const uint32_t seed_scaled = seed * (Wg * Hg);              /* integrator.cpp:231: seed *= prod(film_size), film_size = crop_size (:162) */
         const ShadeParams P0{ 0u, (uint32_t) max_depth, (uint32_t) rr_depth, HAR_SHADE_SCALAR_DRAWS };
 
         std::mutex film_mutex; std::atomic<uint32_t> next(0); std::atomic<int> status_all(0);

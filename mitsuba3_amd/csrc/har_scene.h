@@ -54,6 +54,7 @@ struct DSensor {
     float to_world[16];
     float near_clip, far_clip;
     uint32_t crop_x, crop_y, crop_w, crop_h;
+    uint32_t samp_w, samp_h, border;   /* the sample grid of render(): the crop window + `border` pixels on every side (Film::sample_border, integrator.cpp:162-165); border = 0: the crop */
     uint32_t rfilter;            /* 0 box, 1 gaussian, 2 tent, 3 mitchell, 4 catmullrom, 5 lanczos */
     float rf_p0, rf_p1;          /* filter parameters (HarSensor::rfilter_stddev / rfilter_param1) */
     float radius;
@@ -475,9 +476,10 @@ HAR_HD float rfilter_eval(const DSensor &C, float x) {
 struct LaneSample { float pos_x, pos_y, ipos_x, ipos_y; };
 HAR_HD LaneSample lane_sample(const DSensor &C, uint32_t idx, uint32_t spp, uint32_t log_spp, float jx, float jy) {
     uint32_t p = (log_spp != 0xffffffffu) ? (idx >> log_spp) : (idx / spp);
-    uint32_t y = p / C.crop_w, x = p - C.crop_w * y;
+    uint32_t y = p / C.samp_w, x = p - C.samp_w * y;                 /* integrator.cpp:330-331 over film_size = crop_size + 2 * border_size */
     LaneSample L;
-    L.ipos_x = (float) (int32_t) (x + C.crop_x); L.ipos_y = (float) (int32_t) (y + C.crop_y);
+    /* pos -= border_size; pos += crop_offset (integrator.cpp:333-336): a Vector2i, negative in the border of a crop window at the film's origin */
+    L.ipos_x = (float) ((int32_t) (x + C.crop_x) - (int32_t) C.border); L.ipos_y = (float) ((int32_t) (y + C.crop_y) - (int32_t) C.border);
     L.pos_x = L.ipos_x + jx; L.pos_y = L.ipos_y + jy;
     return L;
 }

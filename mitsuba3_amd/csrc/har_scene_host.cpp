@@ -374,15 +374,7 @@ bool lower_scene(const HarSceneDesc &d, HostScene &hs, std::string &err) {
     return true;
 }
 
-bool lower_sensor(const HarSensor &in, DSensor &out, std::string &err) {
-    if (in.crop_width == 0 || in.crop_height == 0) { err = "empty crop window"; return false; }
-    if (in.rfilter > 5) { err = "unsupported reconstruction filter (box, gaussian, tent, mitchell, catmullrom and lanczos are implemented)"; return false; }
-    std::memcpy(out.s2c, in.sample_to_camera, 64); std::memcpy(out.to_world, in.to_world, 64);
-    out.near_clip = in.near_clip; out.far_clip = in.far_clip;
-    out.crop_x = in.crop_offset_x; out.crop_y = in.crop_offset_y; out.crop_w = in.crop_width; out.crop_h = in.crop_height;
-    out.rfilter = in.rfilter;
-    std::memset(out.coeff, 0, sizeof(out.coeff));
-    out.rf_p0 = in.rfilter_stddev; out.rf_p1 = in.rfilter_param1;
+static bool lower_sensor_filter(const HarSensor &in, DSensor &out, std::string &err) {
     if (in.rfilter == 0) { out.radius = 0.5f; return true; }
     if (in.rfilter == 2 || in.rfilter == 5) {                  /* tent: radius; lanczos: radius = lobes */
         if (!(in.rfilter_stddev > 0.f)) { err = "reconstruction filter: the radius / lobe count must be positive"; return false; }
@@ -397,6 +389,22 @@ bool lower_sensor(const HarSensor &in, DSensor &out, std::string &err) {
     double scale = 1;
     for (int i = 0; i < 10; ++i) { out.coeff[i] = (float) (coeff[i] * scale); scale /= (double) stddev * (double) stddev; }
     out.coeff[0] -= estrin10(out.radius * out.radius, out.coeff);
+    return true;
+}
+
+bool lower_sensor(const HarSensor &in, DSensor &out, std::string &err) {
+    if (in.crop_width == 0 || in.crop_height == 0) { err = "empty crop window"; return false; }
+    if (in.rfilter > 5) { err = "unsupported reconstruction filter (box, gaussian, tent, mitchell, catmullrom and lanczos are implemented)"; return false; }
+    std::memcpy(out.s2c, in.sample_to_camera, 64); std::memcpy(out.to_world, in.to_world, 64);
+    out.near_clip = in.near_clip; out.far_clip = in.far_clip;
+    out.crop_x = in.crop_offset_x; out.crop_y = in.crop_offset_y; out.crop_w = in.crop_width; out.crop_h = in.crop_height;
+    out.rfilter = in.rfilter;
+    std::memset(out.coeff, 0, sizeof(out.coeff));
+    out.rf_p0 = in.rfilter_stddev; out.rf_p1 = in.rfilter_param1;
+    if (!lower_sensor_filter(in, out, err)) return false;
+    /* ReconstructionFilter::init_discretization (rfilter.cpp:22): border_size = ceil(radius - 1/2 - 2 RayEpsilon) */
+    out.border = in.sample_border ? (uint32_t) std::max(0, (int) std::ceil(out.radius - .5f - 2.f * HAR_RAY_EPS)) : 0u;
+    out.samp_w = out.crop_w + 2u * out.border; out.samp_h = out.crop_h + 2u * out.border;
     return true;
 }
 

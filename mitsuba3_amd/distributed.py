@@ -123,11 +123,12 @@ def render_distributed(scene, integrator=None, sensor=0, seed=0, spp=0, develop=
         s.sampler().set_sample_count(spp)
     spp = s.sampler().sample_count()
     w, h = s.film().crop_size()
+    gw, gh = s.film().sample_grid()                       # rows of the SAMPLE grid are dealt to the ranks (= the crop unless Film::sample_border)
     rank, world = _world()
     spp_pass, _ = integrator.pass_layout(s, spp)          # multi-pass jobs (> 2^32 - 1 samples): bands of the per-pass wavefront
-    bal = _balancer(integrator, ("path", id(scene), w, spp_pass), h, world)
+    bal = _balancer(integrator, ("path", id(scene), gw, spp_pass), gh, world)
     y0, y1 = bal.band(rank)
-    lanes = (y0 * w * spp_pass, y1 * w * spp_pass)
+    lanes = (y0 * gw * spp_pass, y1 * gw * spp_pass)
     adapt = bal.adapting()
     alpha = None
     if getattr(s.film(), "alpha", False) and develop:             # `rgba` films: a second accumulator (w * alpha), reduced like the first
@@ -157,11 +158,11 @@ def render_backward_distributed(scene, grad_in, integrator=None, sensor=0, seed=
     if spp:
         s.sampler().set_sample_count(spp)
     spp = s.sampler().sample_count()
-    w, h = s.film().crop_size()
+    gw, gh = s.film().sample_grid()
     rank, world = _world()
-    bal = _balancer(integrator, ("prb", id(scene), w, spp), h, world)
+    bal = _balancer(integrator, ("prb", id(scene), gw, spp), gh, world)
     y0, y1 = bal.band(rank)
-    lanes = (y0 * w * spp, y1 * w * spp)
+    lanes = (y0 * gw * spp, y1 * gw * spp)
     adapt = bal.adapting()
     wfilm = integrator.render_weights(scene, s, seed, spp, lanes=lanes)
     if world > 1:
@@ -171,6 +172,12 @@ def render_backward_distributed(scene, grad_in, integrator=None, sensor=0, seed=
     if adapt:
         _share_times(bal, timer, wfilm)
     if world > 1:
-        for g in grads.values():
-            dist.all_reduce(g, op=dist.ReduceOp.SUM)
+        # ONE collective for all gradient buffers (texels, constant albedos, emitter radiance, ...): xGMI rings are latency bound for the small ones
+        keys = list(grads)
+        flat = torch.cat([grads[k].reshape(-1).to(torch.float32) for k in keys])
+        dist.all_reduce(flat, op=dist.ReduceOp.SUM)
+        off = 0
+        for k in keys:
+            n = grads[k].numel()
+            grads[k] = flat[off:off + n].reshape(grads[k].shape).to(grads[k].dtype); off += n
     return grads

@@ -631,15 +631,29 @@ static inline void film_put(const OrcSensor &s, const RFilter &rf, float px, flo
 //  Lane -> sample mapping (src/render/integrator.cpp:322-339, 448-520)
 // ---------------------------------------------------------------------------
 
+/* Film::sample_border: film_size = crop_size + 2 * rfilter->border_size() (integrator.cpp:162-165), border_size = ceil(radius - 1/2 - 2 RayEpsilon)
+ * (rfilter.cpp:22); the lane map runs over that grid and is shifted back by the border (integrator.cpp:333-334) */
+static inline uint32_t sample_border_size(const OrcSensor &s) {
+    if (!s.sample_border) return 0;
+    RFilter rf = make_rfilter(s.rfilter, s.rfilter_stddev, s.rfilter_param1);
+    int b = (int) std::ceil(rf.radius - .5f - 2.f * RayEpsilon);
+    return b > 0 ? (uint32_t) b : 0u;
+}
+static inline uint64_t sample_grid_pixels(const OrcSensor &s) {
+    const uint64_t b = sample_border_size(s);
+    return (s.crop_width + 2 * b) * (s.crop_height + 2 * b);
+}
+
 struct Lane { Pcg32 rng; float pos_x, pos_y, ipos_x, ipos_y; Ray ray; };
 static inline Lane make_lane(const OrcSensor &s, uint32_t seed, uint32_t spp, uint64_t idx) {
     Lane L;
     L.rng = sampler_seed(seed, (uint32_t) idx);
     uint32_t lspp = 0; while ((1u << (lspp + 1)) <= spp) ++lspp;
     uint32_t p = ((1u << lspp) == spp) ? (uint32_t) idx >> lspp : (uint32_t) idx / spp;
-    uint32_t y = p / s.crop_width, x = p - s.crop_width * y;
+    const uint32_t border = sample_border_size(s), grid_w = s.crop_width + 2 * border;
+    uint32_t y = p / grid_w, x = p - grid_w * y;
     float jx = L.rng.next_float32(), jy = L.rng.next_float32();
-    L.ipos_x = (float) (int32_t) (x + s.crop_offset_x); L.ipos_y = (float) (int32_t) (y + s.crop_offset_y);
+    L.ipos_x = (float) ((int32_t) (x + s.crop_offset_x) - (int32_t) border); L.ipos_y = (float) ((int32_t) (y + s.crop_offset_y) - (int32_t) border);
     L.pos_x = L.ipos_x + jx;
     L.pos_y = L.ipos_y + jy;
     float sx = 1.f / (float) s.crop_width, sy = 1.f / (float) s.crop_height;
@@ -1128,7 +1142,7 @@ static void merge_stats(OrcStats *dst, const std::vector<OrcStats> &src) {
 
 static int render_forward(Scene &sc, const OrcSensor &s, uint32_t seed, uint32_t spp, int32_t max_depth, int32_t rr_depth,
                           uint64_t lb, uint64_t le, float *film, OrcStats *stats, int threads, bool prb) {
-    uint64_t total = (uint64_t) s.crop_width * s.crop_height * spp;
+    uint64_t total = sample_grid_pixels(s) * spp;
     if (lb == 0 && le == 0) le = total;
     if (le > total || lb > le || total > 0xffffffffull) return -1;
     RFilter rf = make_rfilter(s.rfilter, s.rfilter_stddev, s.rfilter_param1);
@@ -1160,7 +1174,7 @@ static int render_forward(Scene &sc, const OrcSensor &s, uint32_t seed, uint32_t
 static int render_forward_passes(Scene &sc, const OrcSensor &s, uint32_t seed, uint32_t spp, uint32_t spp_per_pass, int32_t max_depth, int32_t rr_depth,
                                  uint64_t lb, uint64_t le, float *film, OrcStats *stats, int threads) {
     if (spp_per_pass == 0 || spp % spp_per_pass != 0) return -2;               // integrator.cpp:177-179
-    uint64_t total = (uint64_t) s.crop_width * s.crop_height * spp_per_pass;
+    uint64_t total = sample_grid_pixels(s) * spp_per_pass;
     if (lb == 0 && le == 0) le = total;
     if (le > total || lb > le || total > 0xffffffffull) return -1;
     const uint32_t n_passes = spp / spp_per_pass;
@@ -1250,11 +1264,14 @@ static int render_scalar(Scene &sc, const OrcSensor &s, uint32_t seed, uint32_t 
     auto eval_discretized = [&](float x) { uint32_t index = std::min<uint32_t>((uint32_t) std::fabs(x * scale_factor), (uint32_t) RES); return values[index]; };
     // block size (integrator.cpp:203-214)
     uint32_t block_size = 32;
-    while (true) { if (block_size == 1 || ((W + block_size - 1) / block_size) * ((H + block_size - 1) / block_size) >= std::max(n_threads, 1u)) break; block_size /= 2; }
+    /* Film::sample_border: spiral over the enlarged film, every block shifted back by the border (integrator.cpp:162-165, 215, 248-249) */
+    const uint32_t sb = sample_border_size(s), Wg = W + 2 * sb, Hg = H + 2 * sb;
+    while (true) { if (block_size == 1 || ((Wg + block_size - 1) / block_size) * ((Hg + block_size - 1) / block_size) >= std::max(n_threads, 1u)) break; block_size /= 2; }
     if (block_size_out) *block_size_out = block_size;
-    std::vector<SpiralBlock> blocks = spiral_blocks(W, H, s.crop_offset_x, s.crop_offset_y, block_size);
+    std::vector<SpiralBlock> blocks = spiral_blocks(Wg, Hg, s.crop_offset_x, s.crop_offset_y, block_size);
+    for (SpiralBlock &b : blocks) { b.off_x -= (int32_t) sb; b.off_y -= (int32_t) sb; }
     uint32_t md = max_depth < 0 ? 0xffffffffu : (uint32_t) max_depth;
-    seed *= W * H;                                                    // integrator.cpp:231 (dr::prod(film_size) of the crop window)
+    seed *= Wg * Hg;                                                    // integrator.cpp:231 (dr::prod(film_size) of the crop window)
     OrcStats st{};
     const bool box = s.rfilter == 0;
     for (const SpiralBlock &b : blocks) {
@@ -1523,7 +1540,7 @@ static void render_weights_impl(const OrcSensor &s, uint32_t seed, uint32_t spp,
     for (auto &f : films) if (!f.empty()) for (size_t i = 0; i < npx * 4; ++i) film[i] += f[i];
 }
 int orc_render_weights(const OrcSensor *s, uint32_t seed, uint32_t spp, uint64_t lb, uint64_t le, float *film, int threads) {
-    uint64_t total = (uint64_t) s->crop_width * s->crop_height * spp;
+    uint64_t total = sample_grid_pixels(*s) * spp;
     if (total > 0xffffffffull) return -1;
     if (lb == 0 && le == 0) le = total;
     if (lb > le || le > total) return -1;
@@ -1543,7 +1560,7 @@ static int prb_backward_impl(void *scene, const OrcSensor *sp, const float *grad
         for (const BsdfRecord &b : sc.bsdfs) if (b.p.type != 0) return -2;           /* `diffuse`, plain or inside `twosided` */
         for (size_t m = 0; m < sc.meshes.size(); ++m) if (pos_mask[m] && ((sc.meshes[m].flags & 1u) || m >= sc.top_count)) return -3;
     }
-    uint64_t total = (uint64_t) s.crop_width * s.crop_height * spp;
+    uint64_t total = sample_grid_pixels(s) * spp;
     if (total > 0xffffffffull) return -1;
     RFilter rf = make_rfilter(s.rfilter, s.rfilter_stddev, s.rfilter_param1);
     threads = resolve_threads(threads);
@@ -1644,7 +1661,7 @@ int orc_render_prb_backward_ex(void *scene, const OrcSensor *sp, const float *gr
 int orc_render_prb_forward(void *scene, const OrcSensor *sp, uint32_t seed, uint32_t spp, int32_t max_depth, int32_t rr_depth, const float *tangent_reflectance,
                            const float *const *tangent_textures, const float *tangent_emitters, float *film, int threads) {
     Scene &sc = *(Scene *) scene; const OrcSensor &s = *sp;
-    uint64_t total = (uint64_t) s.crop_width * s.crop_height * spp;
+    uint64_t total = sample_grid_pixels(s) * spp;
     if (total > 0xffffffffull) return -1;
     RFilter rf = make_rfilter(s.rfilter, s.rfilter_stddev, s.rfilter_param1);
     threads = resolve_threads(threads);

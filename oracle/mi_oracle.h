@@ -105,6 +105,7 @@ typedef struct OrcSensor {
     uint32_t rfilter;             /* 0 box, 1 gaussian, 2 tent, 3 mitchell, 4 catmullrom, 5 lanczos (src/rfilters/ *.cpp) */
     float    rfilter_stddev;      /* parameter 0: gaussian stddev, tent radius, mitchell B, lanczos lobes */
     float    rfilter_param1;      /* parameter 1: mitchell C */
+    uint32_t sample_border;       /* Film::sample_border (film.cpp:29-32): render() samples crop_size + 2 * rfilter->border_size() pixels (integrator.cpp:162-165) */
 } OrcSensor;
 
 typedef struct OrcStats {
@@ -295,6 +296,7 @@ void orc_perspective_sensor(const float to_world[32], double fov_deg, const char
 void orc_rectangle(const float to_world[32], float *vertices, uint32_t *faces,
                    float normal[3], float *inv_area);
 void orc_cube(const float to_world[32], float *vertices, uint32_t *faces);
+void orc_bake_mesh(const float to_world[32], float *vertices, uint32_t vertex_count, uint32_t *faces, uint32_t face_count);   /* mesh_utils.cpp:33-88 */
 
 #ifdef __cplusplus
 }

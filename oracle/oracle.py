@@ -61,7 +61,8 @@ class Sensor(C.Structure):
                 ("film_width", C.c_uint32), ("film_height", C.c_uint32),
                 ("crop_offset_x", C.c_uint32), ("crop_offset_y", C.c_uint32),
                 ("crop_width", C.c_uint32), ("crop_height", C.c_uint32),
-                ("rfilter", C.c_uint32), ("rfilter_stddev", C.c_float), ("rfilter_param1", C.c_float)]
+                ("rfilter", C.c_uint32), ("rfilter_stddev", C.c_float), ("rfilter_param1", C.c_float),
+                ("sample_border", C.c_uint32)]
 
 
 class Stats(C.Structure):
@@ -161,6 +162,7 @@ def lib():
                                              C.c_uint32, C.c_uint32, C.c_float, C.POINTER(Sensor)]
         L.orc_rectangle.argtypes = [c_f32p, c_f32p, c_u32p, c_f32p, c_f32p]
         L.orc_cube.argtypes = [c_f32p, c_f32p, c_u32p]
+        L.orc_bake_mesh.argtypes = [c_f32p, c_f32p, C.c_uint32, c_u32p, C.c_uint32]; L.orc_bake_mesh.restype = None
         _LIB = L
     return _LIB
 
@@ -387,6 +389,54 @@ def cornell_box(width=256, height=256, crop=None, rfilter="gaussian", white_text
     sd.top_mesh_count = len(sd.meshes)
     cam = T().look_at([0, 0, 3.9], [0, 0, 0], [0, 1, 0])
     sensor = perspective_sensor(cam, 39.3077, "smaller", 0.001, 100.0, width, height, crop, rfilter)
+    return sd, sensor
+
+
+def benchmark_spheres_scene(width=512, height=512, grid=10, n_u=100, n_v=50, flatten=False, textured=False, tex_res=256, rfilter="gaussian"):
+    """The 1M-triangle benchmark scenes of SURVEY.md 8(d) (`mitsuba3_amd.scenes.instanced_spheres_scene`: Cornell box without its two
+    boxes + grid x grid bumpy spheres, as instances of one shape group or flattened) lowered by the ORACLE's own code: its transform chain
+    (orc_translate / orc_rotate / orc_scale / orc_matmul / orc_affine_inverse), its rectangle and mesh baking, its perspective sensor.  The
+    tests that use this do not hand the product's baked vertex arrays, instance matrices or HarSensor to the oracle (`scene_from_product`
+    does), so a defect in the product's host lowering of these scenes shows up as a parity failure.  The sphere's object-space vertex table
+    and the checker bitmap are scene CONTENT (the asset the dict carries), taken from the same generator as the product's scene."""
+    from mitsuba3_amd.scenes import bumpy_sphere, checker_texture
+    sd = SceneData()
+    sd.bsdfs = [(0, -1, CBOX_WHITE), (0, -1, CBOX_GREEN), (0, -1, CBOX_RED)]
+    if textured:
+        sd.textures.append(f32(checker_texture(tex_res))); sd.bsdfs[0] = (0, 0, CBOX_WHITE)
+    light_tf = T().translate([0.0, 0.99, 0.01]).rotate([1, 0, 0], 90).scale([0.23, 0.19, 0.19])
+    V, F, n, ia = rectangle(light_tf)
+    sd.add_mesh(V, F, 0, emitter=0)
+    sd.emitters.append(dict(mesh=0, radiance=CBOX_RADIANCE, to_world=light_tf.col_major_3x4(), normal=n, inv_area=ia))
+    for tf, b in [(T().translate([0.0, -1.0, 0.0]).rotate([1, 0, 0], -90), 0), (T().translate([0.0, 1.0, 0.0]).rotate([1, 0, 0], 90), 0),
+                  (T().translate([0.0, 0.0, -1.0]), 0), (T().translate([1.0, 0.0, 0.0]).rotate([0, 1, 0], -90), 1),
+                  (T().translate([-1.0, 0.0, 0.0]).rotate([0, 1, 0], 90), 2)]:
+        V, F, _, _ = rectangle(tf)
+        sd.add_mesh(V, F, b)
+    P, N, UV, Fi = bumpy_sphere(n_u, n_v)
+    V0 = np.concatenate([P, N, UV], axis=1).astype(np.float32)
+    F0 = np.concatenate([Fi, np.zeros((Fi.shape[0], 1), np.uint32)], axis=1).astype(np.uint32)
+    tfs = []
+    k = 0
+    for gy in range(grid):
+        for gx in range(grid):
+            x = -0.8 + 1.6 * gx / max(grid - 1, 1); y = -0.85 + 1.5 * gy / max(grid - 1, 1)
+            z = -0.5 + 0.9 * ((gx * 7 + gy * 3) % grid) / max(grid - 1, 1)
+            tfs.append(T().translate([x, y, z]).rotate([0, 1, 0], 37.0 * k).scale(0.8 + 0.004 * k))
+            k += 1
+    if flatten:
+        for k, tf in enumerate(tfs):
+            V = V0.copy(); F = F0.copy()
+            lib().orc_bake_mesh(fp(tf.data), fp(V), V.shape[0], up(F), F.shape[0])
+            sd.add_mesh(V, F, k % 3)
+        sd.top_mesh_count = len(sd.meshes)
+    else:
+        sd.top_mesh_count = len(sd.meshes)
+        sd.add_mesh(V0, F0, 0)
+        sd.groups = [(sd.top_mesh_count, 1)]
+        sd.instances = [(0, tf.col_major_3x4(), tf.inverse().col_major_3x4()) for tf in tfs]
+    cam = T().look_at([0, 0, 3.9], [0, 0, 0], [0, 1, 0])
+    sensor = perspective_sensor(cam, 39.3077, "smaller", 0.001, 100.0, width, height, None, rfilter)
     return sd, sensor
 
 

@@ -222,4 +222,11 @@ void orc_cube(const float to_world[32], float *vertices, uint32_t *faces) {
     bake(load(to_world), vertices, 24, faces, 12);
 }
 
+/* a triangle mesh given in object space with a `to_world`: the records are transformed in place (PackedMesh::set_transform + transform_records,
+ * src/render/mesh_utils.cpp:33-88: positions by the matrix, normals by the inverse transpose and renormalised, winding reversed for a
+ * mirroring transform) */
+void orc_bake_mesh(const float to_world[32], float *vertices, uint32_t vertex_count, uint32_t *faces, uint32_t face_count) {
+    bake(load(to_world), vertices, vertex_count, faces, face_count);
+}
+
 } // extern "C"

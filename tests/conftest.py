@@ -10,6 +10,7 @@ if ROOT not in sys.path:
 
 def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: test needs a real MI355X (run with -m gpu on the GPU box)")
+    config.addinivalue_line("markers", "slow: parity at the literal bench sizes (a minute or two of oracle on the box's host cores each); they run with -m gpu")
     _gpu_preflight(config)
 
 

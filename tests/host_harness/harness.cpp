@@ -143,7 +143,7 @@ int hh_render(void *h, const HarSensor *sensor, int mode, uint32_t seed, uint32_
               uint64_t lane_begin, uint64_t lane_end, float *film) {
     HScene *H = (HScene *) h; const DScene &S = H->ds;
     DSensor C; std::string e; if (!lower_sensor(*sensor, C, e)) return -1;
-    uint64_t total = (uint64_t) C.crop_w * C.crop_h * spp;
+    uint64_t total = (uint64_t) C.samp_w * C.samp_h * spp;       /* the sample grid: crop + border with Film::sample_border */
     if (lane_begin == 0 && lane_end == 0) lane_end = total;
     uint32_t log_spp = 0xffffffffu; for (uint32_t k = 0; k < 32; ++k) if ((1u << k) == spp) log_spp = k;
     ShadeParams P{ seed, (uint32_t) max_depth, (uint32_t) rr_depth };

@@ -284,3 +284,66 @@ def test_shading_textured_and_instanced(mi, O, H):
     ref, _ = osc.render_path(sensor, seed=1, spp=4, max_depth=8, raw=True)
     assert rel_l2(O.develop(film), O.develop(ref)) < 1e-6
     H.hh_scene_destroy(h)
+
+
+# ------------------------------------------------------------------ the benchmark scenes: product lowering == the oracle's own lowering
+
+@pytest.mark.parametrize("flatten", [False, True], ids=["instanced", "flattened"])
+def test_benchmark_scene_lowering_matches_the_oracles_own(mi, O, flatten):
+    """`mi.load_dict(mi.instanced_spheres_scene(...))` (product host code: ScalarTransform4f chain, mesh baking / instance matrices, sensor) against
+    `O.benchmark_spheres_scene(...)` (the oracle's transform / baking / sensor code): same baked vertices, same instance matrices, same sensor
+    record -- the GPU headline tests feed the oracle from the latter, this test says on the CPU where a difference would come from"""
+    import ctypes as C
+    res = 48
+    d = mi.instanced_spheres_scene(width=res, height=res, spp=4, grid=4, n_u=20, n_v=10, flatten=flatten, textured=True, tex_res=16)
+    scene = mi.load_dict(d)
+    sd, sensor = O.benchmark_spheres_scene(res, res, grid=4, n_u=20, n_v=10, flatten=flatten, textured=True, tex_res=16)
+    assert len(scene.meshes) == len(sd.meshes) and scene.top_mesh_count == sd.top_mesh_count
+    for a, b in zip(scene.meshes, sd.meshes):
+        assert np.array_equal(a["F"], b["F"]) and a["bsdf"] == b["bsdf"] and a["emitter"] == b["emitter"]
+        assert np.abs(a["V"] - b["V"]).max() <= 1e-6
+    assert len(scene.instances) == len(sd.instances)
+    for (g, tw, to), (g2, tw2, to2) in zip(scene.instances, sd.instances):
+        assert g == g2 and np.abs(np.asarray(tw, np.float32) - tw2).max() <= 1e-6 and np.abs(np.asarray(to, np.float32) - to2).max() <= 1e-5
+    mine = scene.sensors()[0].har
+    for name, _ in sensor._fields_:
+        a, b = getattr(mine, name), getattr(sensor, name)
+        a = np.asarray(list(a) if hasattr(a, "__len__") else a, np.float64); b = np.asarray(list(b) if hasattr(b, "__len__") else b, np.float64)
+        assert np.allclose(a, b, rtol=1e-6, atol=1e-7), name
+    assert np.array_equal(scene.textures[0], sd.textures[0])
+
+
+# ------------------------------------------------------------------ Film::sample_border (film.cpp:29-32, integrator.cpp:162-165, 322-339)
+
+@pytest.mark.parametrize("rf,crop", [("gaussian", None), ("gaussian", (5, 3, 20, 17)), ("tent", None), ("box", None)], ids=["gaussian", "gaussian-crop", "tent", "box"])
+def test_sample_border_host_pipeline_matches_oracle(mi, O, H, rf, crop):
+    """`sample_border`: the lane -> pixel map covers crop_size + 2 * border_size pixels, shifted back by the border; the film keeps the crop size and
+    border samples are clipped.  Product (host compilation of the kernels' headers) vs oracle, plus what the property means: more samples
+    (paths = (W + 2b)(H + 2b) spp), larger filter-weight sums along the edges, nothing changes for the border-free box filter."""
+    res, spp = 28, 4
+    d = mi.cornell_box(); f = d["sensor"]["film"]; f["width"] = res; f["height"] = res; f["rfilter"] = {"type": rf}; f["sample_border"] = True
+    if crop:
+        f["crop_offset_x"], f["crop_offset_y"], f["crop_width"], f["crop_height"] = crop
+    scene = mi.load_dict(d)
+    osc, sensor = oracle_scene_from(O, scene)
+    assert sensor.sample_border == 1
+    w, h = (crop[2], crop[3]) if crop else (res, res)
+    b = {"gaussian": 2, "tent": 1, "box": 0}[rf]
+    assert scene.sensors()[0].film().sample_grid() == (w + 2 * b, h + 2 * b)
+    hnd = _harness_scene(H, scene)
+    film = np.zeros((h, w, 4), np.float32)
+    assert H.hh_render(hnd, C.byref(sensor), 0, 2, spp, 8, 5, 0, 0, O.fp(film)) == 0
+    ref, st = osc.render_path(sensor, seed=2, spp=spp, max_depth=8, raw=True, threads=2)
+    assert st.paths == (w + 2 * b) * (h + 2 * b) * spp
+    assert rel_l2(film, ref) < 1e-6
+    H.hh_scene_destroy(hnd)
+    # against the same film without the property: identical for the box filter, heavier edges otherwise
+    sensor.sample_border = 0
+    plain, st0 = osc.render_path(sensor, seed=2, spp=spp, max_depth=8, raw=True, threads=2)
+    assert st0.paths == w * h * spp
+    if b == 0:
+        assert np.array_equal(plain, ref)
+    else:
+        assert ref[0, :, 3].sum() > 1.03 * plain[0, :, 3].sum() and ref[:, -1, 3].sum() > 1.03 * plain[:, -1, 3].sum()
+        inner = (slice(2 * b + 1, h - 2 * b - 1), slice(2 * b + 1, w - 2 * b - 1))
+        assert abs(ref[inner][..., 3].mean() / plain[inner][..., 3].mean() - 1) < 0.05      # interior weights: same density of samples

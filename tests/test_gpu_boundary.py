@@ -204,7 +204,7 @@ def test_render_forward_is_transpose_of_render_backward(mi):
     # ... and the pair once more on the same integrator, forward first this time
     fwd2 = integ.render_forward(scene, None, seed=2, spp=spp, tangents=tangents).cpu().numpy().astype(np.float64)
     grads2 = integ.render_backward(scene, None, g, seed=2, spp=spp)
-    assert np.array_equal(fwd, fwd2)
+    assert rel_l2(fwd2, fwd) < 1e-6                                     # float atomics: not bit-reproducible run to run
     identity(fwd2, grads2)
     # a fresh integrator that never ran a backward pass gives the same derivative image
     d2 = dict(d); scene_b = mi.load_dict(d2)

@@ -16,12 +16,35 @@ def rel_l2(a, b):
 
 
 def _scene_1m(mi, O, res, spp, flatten=False, textured=False, integrator=None, grid=10, n_u=100, n_v=50):
+    """product scene from the dict; ORACLE scene from the oracle's own lowering of the same description (its transform chain, mesh baking,
+    instance matrices and sensor: `O.benchmark_spheres_scene`) -- not `scene_from_product`, which would hand the oracle the product's baked
+    arrays and hide a defect of the product's host lowering (round-2 verdict, "shared lowering")"""
     d = mi.instanced_spheres_scene(width=res, height=res, spp=spp, grid=grid, n_u=n_u, n_v=n_v, flatten=flatten, textured=textured)
     if integrator:
         d["integrator"] = integrator
     scene = mi.load_dict(d)
-    osc, sensor = O.scene_from_product(scene)
-    return scene, osc, sensor
+    sd, sensor = O.benchmark_spheres_scene(res, res, grid=grid, n_u=n_u, n_v=n_v, flatten=flatten, textured=textured)
+    return scene, O.OracleScene(sd), sensor
+
+
+# oracle BSDF / emitter indices of the benchmark scenes (O.benchmark_spheres_scene: white, green, red; one emitter) by the product's parameter keys
+_ORACLE_SLOT = {"green.reflectance.value": ("refl", 1), "red.reflectance.value": ("refl", 2), "white.reflectance.value": ("refl", 0),
+                "light.emitter.radiance.value": ("emit", 0)}
+
+
+def _check_prb_gradients(grads, g_refl, g_tex, g_emit, tol=1e-3):
+    g = grads["white.reflectance.data"].cpu().numpy()
+    assert g.shape == g_tex[0].shape and np.count_nonzero(g_tex[0]) > 0.5 * g.size
+    assert rel_l2(g, g_tex[0]) < tol                                       # north_star PRB tolerance
+    checked = 0
+    for key, (kind, idx) in _ORACLE_SLOT.items():                          # constant albedos (green, red walls) and the emitter's radiance
+        if key not in grads:
+            continue
+        ref = g_emit[idx] if kind == "emit" else g_refl[idx]
+        assert np.abs(np.asarray(ref)).max() > 0
+        assert rel_l2(grads[key].cpu().numpy().reshape(-1), np.asarray(ref).reshape(-1)) < tol, key
+        checked += 1
+    assert checked >= 3
 
 
 # ------------------------------------------------------------------ the bench's launch pattern (BENCH_r01: GPU memory access fault)
@@ -126,17 +149,58 @@ def test_prb_gradients_instanced_textured(mi, O):
     grad_in = rng.uniform(0.5, 1.5, (res, res, 3)).astype(np.float32) / (res * res * 3)
     grads = scene.integrator().render_backward(scene, None, grad_in, seed=7, spp=spp)
     g_refl, g_tex, g_emit, _ = osc.render_prb_backward_emitters(sensor, grad_in, seed=7, spp=spp, max_depth=8)
-    g = grads["white.reflectance.data"].cpu().numpy()
-    assert g.shape == g_tex[0].shape and np.count_nonzero(g_tex[0]) > 0.5 * g.size
-    assert rel_l2(g, g_tex[0]) < 1e-3                                       # north_star PRB tolerance
-    checked = 0
-    for key, (kind, b) in scene._param_keys().items():                      # constant albedos (green, red walls) and the emitter's radiance
-        if kind == "tex":
-            continue
-        ref = g_emit[b] if kind == "emit" else g_refl[b.index]
-        assert rel_l2(grads[key].cpu().numpy().reshape(-1), np.asarray(ref).reshape(-1)) < 1e-3, key
-        checked += 1
-    assert checked >= 3
+    _check_prb_gradients(grads, g_refl, g_tex, g_emit)
+
+
+def test_prb_gradients_flat1m_textured(mi, O):
+    """the FLATTENED 1M-triangle scene (64 MB BVH) with the bitmap albedo on every third sphere and the walls: texel, constant-albedo and
+    emitter-radiance gradients vs the oracle at 256 x 256 x 16 spp (round-2 verdict: flat1m had no PRB-gradient test)"""
+    res, spp = 256, 16
+    scene, osc, sensor = _scene_1m(mi, O, res, spp, flatten=True, textured=True, integrator={"type": "prb", "max_depth": 8, "rr_depth": 5, "emitter_gradients": True})
+    grad_in = np.random.default_rng(15).uniform(0.5, 1.5, (res, res, 3)).astype(np.float32) / (res * res * 3)
+    grads = scene.integrator().render_backward(scene, None, grad_in, seed=3, spp=spp)
+    g_refl, g_tex, g_emit, _ = osc.render_prb_backward_emitters(sensor, grad_in, seed=3, spp=spp, max_depth=8)
+    _check_prb_gradients(grads, g_refl, g_tex, g_emit)
+
+
+def test_forward_parity_c3_1024(mi, O):
+    """BASELINE config 3 at its own film size: the instanced 1M-triangle scene, 1024 x 1024, 2 spp (2 M paths for the oracle): image <= 1e-4,
+    path and vertex counts equal"""
+    res, spp = 1024, 2
+    scene, osc, sensor = _scene_1m(mi, O, res, spp)
+    img = mi.render(scene, spp=spp, seed=0).cpu().numpy()
+    ref, st = osc.render_path(sensor, seed=0, spp=spp, max_depth=8)
+    assert rel_l2(img, ref) < 1e-4
+    gst = scene.integrator().stats()
+    assert gst["paths"] == st.paths == res * res * spp and gst["vertices"] == st.vertices, (gst, st.paths, st.vertices)
+
+
+# ------------------------------------------------------------------ the literal bench configuration (slow: ~2 minutes of oracle on the box's host cores)
+
+@pytest.mark.slow
+def test_bench_configuration_forward_parity_full_size(mi, O):
+    """`bench.py`'s forward workload, literally: instanced 1M-triangle scene, 512 x 512 x 256 spp, max_depth 8, rr_depth 5, seed 0 -- one 2^26-lane
+    wavefront, the size at which `k_splat` runs its one-pixel-per-block path and every bounce's queue is 10^7..10^8 entries.  Image <= 1e-4 and
+    the per-frame integer counters (paths, path vertices) EQUAL to the oracle's; the oracle scene comes from the oracle's own lowering"""
+    res, spp = 512, 256
+    scene, osc, sensor = _scene_1m(mi, O, res, spp)
+    img = mi.render(scene, spp=spp, seed=0).cpu().numpy()
+    gst = scene.integrator().stats()
+    ref, st = osc.render_path(sensor, seed=0, spp=spp, max_depth=8)
+    assert rel_l2(img, ref) < 1e-4
+    assert gst["paths"] == st.paths == res * res * spp and gst["vertices"] == st.vertices, (gst, st.paths, st.vertices)
+
+
+@pytest.mark.slow
+def test_bench_configuration_prb_parity_full_film(mi, O):
+    """`bench.py`'s PRB workload at the bench's film size: textured instanced 1M-triangle scene, 512 x 512, 64 spp (16.8 M paths; the bench's 256 spp
+    would be 2 minutes of oracle), emitter gradients on: texel / constant-albedo / radiance gradients <= 1e-3"""
+    res, spp = 512, 64
+    scene, osc, sensor = _scene_1m(mi, O, res, spp, textured=True, integrator={"type": "prb", "max_depth": 8, "rr_depth": 5, "emitter_gradients": True})
+    grad_in = np.random.default_rng(21).uniform(0.5, 1.5, (res, res, 3)).astype(np.float32) / (res * res * 3)
+    grads = scene.integrator().render_backward(scene, None, grad_in, seed=9, spp=spp)
+    g_refl, g_tex, g_emit, _ = osc.render_prb_backward_emitters(sensor, grad_in, seed=9, spp=spp, max_depth=8)
+    _check_prb_gradients(grads, g_refl, g_tex, g_emit)
 
 
 # ------------------------------------------------------------------ N1 (iii): BASELINE config 4 at its own size

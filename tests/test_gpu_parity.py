@@ -815,6 +815,46 @@ def test_reconstruction_filters_parity(mi, O, name):
     assert rel_l2(grads["white.reflectance.data"].cpu().numpy(), g_tex[0]) < 1e-3
 
 
+@pytest.mark.parametrize("rf,crop,spp", [("gaussian", None, 8), ("gaussian", (3, 6, 30, 21), 8), ("tent", None, 4), ("gaussian", None, 256), ("box", None, 8)],
+                         ids=["gaussian", "gaussian-crop", "tent", "gaussian-256spp", "box"])
+def test_sample_border_parity(mi, O, rf, crop, spp):
+    """Film::sample_border (film.cpp:29-32): render()'s lane map covers crop_size + 2 * rfilter->border_size() pixels, shifted back by the border
+    (integrator.cpp:162-165, 322-339), splats are clipped to the film.  `path` image (both splat paths: the gather of k_splat at 256 spp holds ONE
+    pixel per block, below that several), `prb` image, texture gradients and the sample count vs the oracle; distributed bands are whole rows of the
+    SAMPLE grid (band union == whole)."""
+    from tests.test_cpu_host import oracle_scene_from
+    res = 36
+    d = mi.textured_cornell_box(res=res, tex_res=8, spp=spp)
+    f = d["sensor"]["film"]; f["rfilter"] = {"type": rf}; f["sample_border"] = True
+    if crop:
+        f["crop_offset_x"], f["crop_offset_y"], f["crop_width"], f["crop_height"] = crop
+    scene = mi.load_dict(d)
+    osc, sensor = oracle_scene_from(O, scene)
+    w, h = (crop[2], crop[3]) if crop else (res, res)
+    b = {"gaussian": 2, "tent": 1, "box": 0}[rf]
+    integ = mi.load_dict({"type": "path", "max_depth": 6})
+    img = mi.render(scene, integrator=integ, spp=spp, seed=2).cpu().numpy()
+    ref, st = osc.render_path(sensor, seed=2, spp=spp, max_depth=6)
+    assert integ.stats()["paths"] == st.paths == (w + 2 * b) * (h + 2 * b) * spp
+    assert img.shape == ref.shape == (h, w, 3) and np.isfinite(img).all() and rel_l2(img, ref) < 1e-4
+    # two lane bands of whole sample-grid rows add up to the whole film
+    gw, gh = scene.sensors()[0].film().sample_grid()
+    cut = (gh // 2) * gw * spp
+    parts = integ.render_film(scene, scene.sensors()[0], 2, spp, lanes=(0, cut)) + integ.render_film(scene, scene.sensors()[0], 2, spp, lanes=(cut, gw * gh * spp))
+    whole = integ.render_film(scene, scene.sensors()[0], 2, spp)
+    assert rel_l2(parts.cpu().numpy(), whole.cpu().numpy()) < 1e-6
+    if spp > 16:
+        return
+    prb = mi.load_dict({"type": "prb", "max_depth": 5})
+    img_p = mi.render(scene, integrator=prb, spp=spp, seed=4).cpu().numpy()
+    ref_p, _ = osc.render_prb(sensor, seed=4, spp=spp, max_depth=5)
+    assert rel_l2(img_p, ref_p) < 1e-4
+    grad_in = np.random.default_rng(1).uniform(0.5, 1.5, (h, w, 3)).astype(np.float32)
+    grads = prb.render_backward(scene, None, grad_in, seed=9, spp=spp)
+    g_refl, g_tex, _ = osc.render_prb_backward(sensor, grad_in, seed=9, spp=spp, max_depth=5)
+    assert rel_l2(grads["white.reflectance.data"].cpu().numpy(), g_tex[0]) < 1e-3
+
+
 def test_vertex_position_optimisation_converges(mi):
     """end to end: a floor displaced by 0.35 is pulled back to the height that produced the target image by gradient descent on
     '<mesh>.vertex_positions' (render -> d loss / d image -> render_backward -> params.update(), which rebuilds the acceleration structure)"""

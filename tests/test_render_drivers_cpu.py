@@ -163,8 +163,9 @@ def test_product_scalar_path_matches_the_oracle_scalar_driver(O):
     from mitsuba3_amd import core
     mi.set_variant("scalar_rgb")
     try:
-        for res, spp, crop, rf in ((48, 16, None, "gaussian"), (40, 8, (7, 5, 21, 30), "gaussian"), (32, 8, None, "box"), (32, 4, None, "tent")):
-            d = mi.cornell_box(); f = d["sensor"]["film"]; f["width"] = res; f["height"] = res; f["rfilter"] = {"type": rf}
+        for res, spp, crop, rf, sb in ((48, 16, None, "gaussian", False), (40, 8, (7, 5, 21, 30), "gaussian", False), (32, 8, None, "box", False), (32, 4, None, "tent", False),
+                                       (36, 4, None, "gaussian", True), (40, 4, (7, 5, 21, 30), "tent", True)):       # Film::sample_border: spiral over the enlarged film
+            d = mi.cornell_box(); f = d["sensor"]["film"]; f["width"] = res; f["height"] = res; f["rfilter"] = {"type": rf}; f["sample_border"] = sb
             if crop:
                 f["crop_offset_x"], f["crop_offset_y"], f["crop_width"], f["crop_height"] = crop
             scene = mi.load_dict(d)

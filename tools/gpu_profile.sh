@@ -7,7 +7,7 @@ TAG=$1; shift
 PASSES=()
 while [ $# -gt 0 ] && [ "$1" != "--" ]; do PASSES+=("$1"); shift; done
 [ $# -gt 0 ] && shift
-ARGS="$* --no-cpu-baseline --no-prb --worker"      # --worker: measure in THIS process (bench.py without it is a launcher; rocprofv3 must see the kernels)
+ARGS="$* --no-cpu-baseline --no-prb --no-secondary --worker"      # --worker: measure in THIS process (bench.py without it is a launcher; rocprofv3 must see the kernels)
 cd "${GRAFT_REPO_ROOT:-.}"
 export TMPDIR=/tmp
 OUT=gpurun_out/prof; mkdir -p $OUT
