@@ -350,6 +350,11 @@ int har_integrator_set_profiling(HarIntegrator integrator, int enable);
  * HBM and reuse them in the adjoint replay of the same chunk instead of tracing every ray twice (default: enabled).
  * The gradients are identical either way: the replayed rays are bit-identical to the primal ones. */
 int har_integrator_set_replay_cache(HarIntegrator integrator, int enable);
+/* Per-material shading queues for `path` and the primal pass of `prb` (the reference dispatches per BSDF through the virtual calls of
+ * src/integrators/path.cpp:233,266-267): after the closest-hit launch of a bounce the paths are dealt to one index list per BSDF model and every
+ * model is shaded by its own kernel.  Results are identical to the default (one kernel with a block-local material sort).  Default: OFF -- measured
+ * slower on MI355X (the class kernels gather path state through sparse index lists). */
+int har_integrator_set_material_queues(HarIntegrator integrator, int enable);
 int har_render_timing(HarIntegrator integrator, float ms[8], uint32_t launches[8]);
 
 

@@ -771,7 +771,7 @@ class Integrator:
     def __init__(self, props):
         self.type = props['type']
         # integrator.cpp:26-33,128-147,539-550; block_size only shapes the scalar / LLVM-parallel drivers; the last four are hip_ad_rgb extensions
-        _check_props(self.type, props, ('max_depth', 'rr_depth', 'hide_emitters', 'samples_per_pass', 'block_size', 'chunk_lanes', 'replay_cache', 'emitter_gradients', 'shape_gradients', 'bsdf_parameter_gradients'),
+        _check_props(self.type, props, ('max_depth', 'rr_depth', 'hide_emitters', 'samples_per_pass', 'block_size', 'chunk_lanes', 'replay_cache', 'material_queues', 'emitter_gradients', 'shape_gradients', 'bsdf_parameter_gradients'),
                      unsupported=(('timeout', -1.0),))
         default_depth = -1 if self.type == 'path' else 6        # integrator.cpp:539, common.py:31
         self.max_depth = int(props.get('max_depth', default_depth))
@@ -783,6 +783,7 @@ class Integrator:
             raise RuntimeError("\"rr_depth\" must be set to a value greater than zero!")
         self.chunk_lanes = int(props.get('chunk_lanes', 0))
         self.replay_cache = bool(props.get('replay_cache', True))      # hip_ad_rgb extension, see har_integrator_set_replay_cache
+        self.material_queues = bool(props.get('material_queues', False))   # hip_ad_rgb extension, see har_integrator_set_material_queues
         self.emitter_gradients = bool(props.get('emitter_gradients', True))   # d / d radiance of area / constant emitters (har_integrator_set_grad_emitters)
         # d / d vertex positions (har_integrator_set_grad_positions): False, True (every eligible mesh) or a list of '<shape>.vertex_positions' keys --
         # the stand-in for dr.enable_grad(params[key]) of the reference
@@ -805,6 +806,8 @@ class Integrator:
             self._h = h
             if not self.replay_cache:
                 check(lib().har_integrator_set_replay_cache(h, 0))
+            if self.material_queues:
+                check(lib().har_integrator_set_material_queues(h, 1))
             if self.hide_emitters:
                 check(lib().har_integrator_set_hide_emitters(h, 1))
             if self.samples_per_pass is not None:
@@ -946,8 +949,9 @@ class Integrator:
         g_pos = {}; g_inst = None; inst_wanted = {}
         if self.shape_gradients:
             keys = scene._position_keys(); ikeys = scene._instance_keys()
-            if self.shape_gradients is True:
-                wanted, inst_wanted = keys, ikeys
+            if self.shape_gradients is True:         # "every eligible mesh / instance": the meshes the adjoint can differentiate, instances if the instanced meshes are diffuse
+                wanted = scene._differentiable_position_keys()
+                inst_wanted = ikeys if all(scene._bsdf_is_diffuse(m["bsdf"]) for m in scene.meshes[scene.top_mesh_count:]) else {}
             else:
                 inst_wanted = {k: ikeys[k] for k in self.shape_gradients if k in ikeys}
                 wanted = {k: keys[k] for k in self.shape_gradients if k not in ikeys}    # KeyError: not a differentiable mesh / instance
@@ -1335,6 +1339,15 @@ class Scene:
     def _position_keys(self):
         """'<shape>.vertex_positions' (flat 3 N floats as in the reference's Mesh::traverse) of the top-level meshes without vertex normals"""
         return {m["key"] + ".vertex_positions": i for i, m in enumerate(self.meshes[:self.top_mesh_count]) if not (m["flags"] & 1) and m["V"].shape[0]}
+
+    def _bsdf_is_diffuse(self, index):
+        b = self.bsdf_objs[index]
+        return b.kind == "diffuse" and (b.back is None or b.back.kind == "diffuse")
+
+    def _differentiable_position_keys(self):
+        """the subset of _position_keys() the `prb` adjoint can differentiate: flat-shaded top-level meshes whose BSDF is `diffuse` (plain or inside
+        `twosided`); the other meshes of the scene may carry any BSDF (har_integrator_set_grad_positions)"""
+        return {k: i for k, i in self._position_keys().items() if self._bsdf_is_diffuse(self.meshes[i]["bsdf"])}
 
     def _instance_keys(self):
         """'<instance>.to_world' (4 x 4, Instance::traverse, instance.cpp:79-85)"""

@@ -260,6 +260,10 @@ HAR_HD float lerp_gather(const float *data, float x, uint32_t size) {
 struct BsdfInputs { Vec3 slot0, slot1; const float *table; };       /* evaluated colour parameters + roughplastic table */
 
 HAR_HD bool bsdf_is_smooth(const DBsdf &B) { return B.type != BSDF_DIELECTRIC && B.type != BSDF_CONDUCTOR; }          /* BSDFFlags::Smooth */
+/* material class of a BSDF record for the per-material shading queues: its model when both sides of the surface evaluate the same model (plain records,
+ * `twosided` with one nested BSDF or a same-model pair), HAR_MAT_GENERIC for a `twosided` pair of two different models (the generic kernel serves it) */
+#define HAR_MAT_GENERIC 6u
+#define HAR_MAT_CLASSES 7u
 
 /* TYPES = bit mask of the BSDF types a scene contains (1 << type): the shading kernels are specialised for
  * diffuse-only scenes, where the other models (and their registers) compile out */
@@ -267,6 +271,12 @@ HAR_HD bool bsdf_is_smooth(const DBsdf &B) { return B.type != BSDF_DIELECTRIC &&
 #define HAR_BSDF_ONLY_DIFFUSE 0x1u
 #define HAR_BSDF_CLASSIC_TYPES 0xfu       /* diffuse, dielectric, roughconductor, roughplastic: scenes without `conductor` / `plastic` run kernels without that code */
 #define HAR_BSDF_HAS(TYPES, T) (((TYPES) & (1u << (T))) != 0u)
+/* per-material shading queues (k_classify + one k_shade launch per BSDF model, har_kernels.hip): TYPES = (1 << type) | HAR_BSDF_QUEUED.  With ONE model
+ * bit set the `switch (B.type)` of the eval / sample code folds to that model at compile time; the QUEUED bit keeps such a mask distinct from
+ * HAR_BSDF_ONLY_DIFFUSE, which additionally promises "no twosided record in the scene" */
+#define HAR_BSDF_QUEUED 0x200u
+#define HAR_BSDF_SINGLE(TYPES) ((((TYPES) & 0xffu) != 0u) && ((((TYPES) & 0xffu) & (((TYPES) & 0xffu) - 1u)) == 0u))
+#define HAR_BSDF_SINGLE_TYPE(TYPES) ((((TYPES) & 0xffu) == 1u) ? 0u : (((TYPES) & 0xffu) == 2u) ? 1u : (((TYPES) & 0xffu) == 4u) ? 2u : (((TYPES) & 0xffu) == 8u) ? 3u : (((TYPES) & 0xffu) == 16u) ? 4u : 5u)
 #define HAR_SCENE_ENVMAP 0x100u           /* the scene has an environment MAP (emitter type 2) or a MESH area light (type 3): kernels of other scenes compile that code out */
 
 /* fresnel_diffuse_reflectance (include/mitsuba/render/fresnel.h:327-355), evaluated on the host when a `plastic` record is (re)built */
@@ -282,7 +292,7 @@ template <uint32_t TYPES = HAR_BSDF_ALL_TYPES>
 HAR_HD void bsdf_eval_pdf_one(const DBsdf &B, const BsdfInputs &in, Vec3 wi, Vec3 wo, BsdfEval &e) {
     e.value = Vec3(0.f); e.pdf = 0.f; e.d_slot0 = Vec3(0.f); e.d_slot1 = Vec3(0.f);
     float cos_theta_i = wi.z, cos_theta_o = wo.z;
-    const uint32_t type = TYPES == HAR_BSDF_ONLY_DIFFUSE ? (uint32_t) BSDF_DIFFUSE : B.type;
+    const uint32_t type = HAR_BSDF_SINGLE(TYPES) ? (uint32_t) HAR_BSDF_SINGLE_TYPE(TYPES) : B.type;
     switch (type) {
     case BSDF_DIFFUSE: {                                                     /* diffuse.cpp:159-179 */
         if (!(cos_theta_i > 0.f && cos_theta_o > 0.f)) return;
@@ -389,7 +399,7 @@ template <uint32_t TYPES = HAR_BSDF_ALL_TYPES>
 HAR_HD void bsdf_sample_one(const DBsdf &B, const BsdfInputs &in, Vec3 wi, float sample1, float s2x, float s2y, BsdfSample &bs) {
     bs.wo = Vec3(0.f); bs.pdf = 0.f; bs.weight = Vec3(0.f); bs.eta = 0.f; bs.delta = false;     /* dr::zeros<BSDFSample3f>() */
     float cos_theta_i = wi.z;
-    const uint32_t type = TYPES == HAR_BSDF_ONLY_DIFFUSE ? (uint32_t) BSDF_DIFFUSE : B.type;
+    const uint32_t type = HAR_BSDF_SINGLE(TYPES) ? (uint32_t) HAR_BSDF_SINGLE_TYPE(TYPES) : B.type;
     switch (type) {
     case BSDF_DIFFUSE: {                                                     /* diffuse.cpp:100-124 */
         bs.wo = square_to_cosine_hemisphere(s2x, s2y);

@@ -99,6 +99,7 @@ template <typename T> static hipError_t upload(const std::vector<T> &v, const T 
 static uint64_t g_scene_serial = 0;
 struct HarSceneImpl {
     uint64_t serial = ++g_scene_serial;       /* identifies the scene in per-integrator caches (a freed scene's address may be reused) */
+    uint32_t mat_classes = 0, mat_miss_class = 0;   /* material classes (MaterialQueues) the scene's BSDF records fall into: bit mask, and the class escaped paths ride in */
     HostScene hs;
     DScene ds{};
     std::vector<void *> owned;
@@ -126,6 +127,11 @@ struct HarIntegratorImpl {
     float4 *result = nullptr, *dL = nullptr;
     /* PRB replay cache (see ReplayCache): cache_bounces arrays of ws_lanes entries each */
     float4 *rc_h0 = nullptr; uint2 *rc_h1 = nullptr; uint8_t *rc_vis = nullptr; uint32_t cache_bounces = 0; bool use_cache = true;
+    /* PRB replay tape (TapeArrays, har_kernels.h): per bounce the wavefront's path state, its hit records, a visibility byte and the next-slot word per
+     * vertex slot; two slot-ordered (L, dL) array pairs that alternate from bounce to bounce */
+    bool ws_tape = false; uint32_t tape_bounces = 0;
+    WaveState tape_st[HAR_REPLAY_CACHE_BOUNCES + 1]{}; float4 *tape_h0 = nullptr; uint8_t *tape_vis = nullptr; uint32_t *tape_next = nullptr;
+    float4 *tape_la[2] = { nullptr, nullptr }; float2 *tape_lb[2] = { nullptr, nullptr };
     float *adj = nullptr; size_t adj_floats = 0;
     float *grad_slots = nullptr; size_t grad_slots_cap = 0;   /* adjoint accumulators: (bsdf_count + emitter_count) x 3 */
     float *grad_emitters = nullptr;       /* user buffer (DEVICE, emitter_count x 3) of har_integrator_set_grad_emitters, or null */
@@ -135,6 +141,8 @@ struct HarIntegratorImpl {
     int32_t *d_pos_offset = nullptr; float *grad_pos = nullptr; uint32_t pos_verts = 0; ShapeArrays geo{};
     /* instance to_world gradients (har_integrator_set_grad_instances): user buffer (DEVICE, instance_count x 12), per-instance slot table, accumulation buffer */
     float *inst_user = nullptr; uint32_t inst_count = 0; int32_t *d_inst_slot = nullptr; float *grad_inst = nullptr;
+    bool material_queues = false;         /* har_integrator_set_material_queues */
+    uint32_t *mq_idx = nullptr, *mq_count = nullptr;      /* per-material shading queues (MaterialQueues): HAR_MAT_CLASSES index lists of ws_lanes entries, their counters */
     uint2 *stack_spill = nullptr;         /* HBM part of the traversal stacks: HAR_STACK_SPILL entries per thread of the largest traversal grid */
     /* multi-pass rendering: sampler state per lane of the rendered lane range, pixel jitter per chunk lane (see PassState) */
     uint32_t samples_per_pass = 0xffffffffu;
@@ -182,8 +190,8 @@ template <typename T> int ws_alloc(HarIntegratorImpl *I, T **p, size_t count) {
 
 uint32_t bounce_limit(const HarIntegratorImpl *I) { return std::min<uint32_t>(I->max_depth, HAR_MAX_BOUNCE_SLOTS - 2); }
 
-int ensure_workspace(HarIntegratorImpl *I, uint32_t lanes, bool adjoint) {
-    if (I->ws_lanes >= lanes && (I->ws_adjoint || !adjoint)) {
+int ensure_workspace(HarIntegratorImpl *I, uint32_t lanes, bool adjoint, bool tape = false) {
+    if (I->ws_lanes >= lanes && (I->ws_adjoint || !adjoint) && (!adjoint || I->ws_tape == tape)) {
         if (I->alpha_film && !I->alpha_lane) return ws_alloc(I, &I->alpha_lane, I->ws_lanes);      /* `rgba` film on an existing workspace */
         return 0;
     }
@@ -191,7 +199,7 @@ int ensure_workspace(HarIntegratorImpl *I, uint32_t lanes, bool adjoint) {
     I->counters = nullptr; I->totals = nullptr; I->status = nullptr; I->adj = nullptr; I->adj_floats = 0; I->d_grad_tex = nullptr; I->grad_tex_cap = 0;
     I->tq = TexelQueues{ nullptr, nullptr, nullptr, nullptr, 0u, 0u }; I->tq_scene = 0; I->tq_lanes = 0;
     I->pass_rng = nullptr; I->pass_rng_cap = 0; I->pass_jitter = nullptr; I->pass_jitter_cap = 0;
-    I->grad_slots = nullptr; I->grad_slots_cap = 0;
+    I->grad_slots = nullptr; I->grad_slots_cap = 0; I->mq_idx = nullptr; I->mq_count = nullptr;
     for (int k = 0; k < 2; ++k) {
         if (ws_alloc(I, &I->st[k].a0, lanes) || ws_alloc(I, &I->st[k].a1, lanes) || ws_alloc(I, &I->st[k].a2, lanes) ||
             ws_alloc(I, &I->st[k].a3, lanes) || ws_alloc(I, &I->st[k].a4, lanes)) return 1;
@@ -216,6 +224,19 @@ int ensure_workspace(HarIntegratorImpl *I, uint32_t lanes, bool adjoint) {
         }
     }
     I->rc_h0 = nullptr; I->rc_h1 = nullptr; I->rc_vis = nullptr; I->cache_bounces = 0;
+    I->ws_tape = false; I->tape_bounces = 0; I->tape_h0 = nullptr; I->tape_vis = nullptr; I->tape_next = nullptr;
+    for (int k = 0; k < 2; ++k) { I->tape_la[k] = nullptr; I->tape_lb[k] = nullptr; }
+    if (adjoint && tape) {
+        /* the tape instead of the lane-indexed cache: (nb + 1) x 72 B of path state + nb x (32 B hit + 1 B visibility + 4 B next slot) per lane, 2 x 24 B for
+         * L / dL: 62 GB for a 2^26-lane chunk at max_depth = 8 -- what 288 GB of HBM are for (the adjoint shading pass moves 40 % fewer bytes) */
+        const uint32_t nb = bounce_limit(I);
+        for (uint32_t b = 0; b <= nb; ++b)
+            if (ws_alloc(I, &I->tape_st[b].a0, lanes) || ws_alloc(I, &I->tape_st[b].a1, lanes) || ws_alloc(I, &I->tape_st[b].a2, lanes) ||
+                ws_alloc(I, &I->tape_st[b].a3, lanes) || ws_alloc(I, &I->tape_st[b].a4, lanes)) return 1;
+        if (ws_alloc(I, &I->tape_h0, (size_t) 2 * lanes * nb) || ws_alloc(I, &I->tape_vis, (size_t) lanes * nb) || ws_alloc(I, &I->tape_next, (size_t) lanes * nb)) return 1;
+        for (int k = 0; k < 2; ++k) if (ws_alloc(I, &I->tape_la[k], lanes) || ws_alloc(I, &I->tape_lb[k], lanes)) return 1;
+        I->ws_tape = true; I->tape_bounces = nb;
+    } else
     if (adjoint && I->use_cache) {
         /* 25 B per lane and cached bounce; bounces beyond the cache are simply traced again */
         const uint32_t nb = std::min<uint32_t>(bounce_limit(I), HAR_REPLAY_CACHE_BOUNCES);
@@ -364,14 +385,18 @@ int run_chunk(HarSceneImpl *S, HarIntegratorImpl *I, const DSensor &C, int mode,
               const RaySource *rays = nullptr, float *valid_lane = nullptr) {
     const uint32_t nb = bounce_limit(I);
     const size_t used = (size_t) std::min<uint32_t>(nb + 2, HAR_MAX_BOUNCE_SLOTS) * HAR_SHARDS * HAR_COUNTER_STRIDE * sizeof(uint32_t);
-    HIP_TRY(hipMemsetAsync(cnt_alive(I, 0), 0, used, s));
+    /* replay tape (cache_mode 3: the primal pass records, 4: the adjoint pass replays; TapeArrays in har_kernels.h) */
+    const bool tape_w = cache_mode == 3, tape_r = cache_mode == 4, tape = tape_w || tape_r;
+    if (tape && (!I->ws_tape || nb > I->tape_bounces || rays)) return fail("internal: tape mode without a tape workspace");
+    if (!tape_r) HIP_TRY(hipMemsetAsync(cnt_alive(I, 0), 0, used, s));      /* the replay reads the primal pass's wavefront sizes */
     HIP_TRY(hipMemsetAsync(cnt_items(I, 0), 0, used, s));
     HIP_TRY(hipMemsetAsync(cur_trace(I, 0), 0, used, s));
     HIP_TRY(hipMemsetAsync(cur_resolve(I, 0), 0, used, s));
-    if (rays) launch_raygen_rays(s, seed, lane_base, n, rays->n_total, rays->first, rays->o, rays->d, rays->maxt, rays->state, I->shard_cap, I->st[0], I->result, cnt_alive(I, 0));
+    if (tape_r) launch_tape_begin(s, C, seed, spp, log_spp, lane_base, n, I->shard_cap, I->result, I->adj, I->tape_la[0], I->tape_lb[0]);
+    else if (rays) launch_raygen_rays(s, seed, lane_base, n, rays->n_total, rays->first, rays->o, rays->d, rays->maxt, rays->state, I->shard_cap, I->st[0], I->result, cnt_alive(I, 0));
     /* forward mode: k_raygen<ADJOINT> takes `adj == nullptr` as "zero dL" -- a workspace that served render_backward before still holds that call's adjoint
      * image in I->adj (possibly of a smaller film), which must not be gathered here */
-    else launch_raygen(mode, s, C, seed, spp, log_spp, lane_base, n, I->shard_cap, I->st[0], I->result, cnt_alive(I, 0), I->forward_mode ? nullptr : I->adj, I->dL, ps);
+    else launch_raygen(mode, s, C, seed, spp, log_spp, lane_base, n, I->shard_cap, tape_w ? I->tape_st[0] : I->st[0], I->result, cnt_alive(I, 0), I->forward_mode ? nullptr : I->adj, I->dL, ps);
     prof_mark(I, s, CLS_RAYGEN);
     const bool fwd = mode == MODE_PRB_ADJOINT && I->forward_mode;
     ShadeParams P{ seed, I->max_depth, I->rr_depth, ((mode == MODE_PRB_ADJOINT && I->grad_emitters) ? HAR_SHADE_EMITTER_GRADS : 0u) | (I->hide_emitters ? HAR_SHADE_HIDE_EMITTERS : 0u) |
@@ -388,27 +413,39 @@ int run_chunk(HarSceneImpl *S, HarIntegratorImpl *I, const DSensor &C, int mode,
     static const bool inline_env = getenv("HAR_ADJOINT_INLINE") ? atoi(getenv("HAR_ADJOINT_INLINE")) != 0 : true;
     const bool inline_commit = inline_env && mode == MODE_PRB_ADJOINT && !shape && !I->forward_mode;      /* forward mode commits in the resolve kernels (own instantiation) */
     const ShapeTargets targets{ I->d_pos_offset, I->grad_pos, I->pos_verts, I->d_inst_slot, I->grad_inst, I->inst_count };
+    /* per-material shading queues: scenes with more than one BSDF model, `path` and the primal pass of `prb` (the adjoint kernels keep the generic code:
+     * their in-place commit is bound by memory traffic, not by the model code).  HAR_MATERIAL_QUEUES=0: the generic kernel with its block-local sort (A/B) */
+    static const int mq_env = getenv("HAR_MATERIAL_QUEUES") ? atoi(getenv("HAR_MATERIAL_QUEUES")) : -1;      /* -1: the integrator's setting; 0 / 1 force (A/B) */
+    const bool use_mq = (mq_env < 0 ? I->material_queues : mq_env != 0) && mode != MODE_PRB_ADJOINT && __builtin_popcount(S->mat_classes) >= 2 && !(S->ds.bsdf_types & HAR_SCENE_ENVMAP);
+    if (use_mq && !I->mq_idx && (ws_alloc(I, &I->mq_idx, (size_t) HAR_MAT_CLASSES * I->ws_lanes) || ws_alloc(I, &I->mq_count, (size_t) HAR_MAT_CLASSES * HAR_SHARDS * HAR_COUNTER_STRIDE))) return 1;
+    const MaterialQueues mq{ I->mq_idx, I->mq_count, I->ws_lanes, S->mat_miss_class };
     int cur = 0; uint32_t b = 0;
     for (; b < nb; ++b) {
         /* PRB replay cache: the primal pass of render_backward records this bounce's ray-query results per lane, the adjoint pass reads them */
         ReplayCache rc{ nullptr, nullptr, nullptr, 0 };
-        if (cache_mode && b < I->cache_bounces)
+        if (tape) rc = ReplayCache{ nullptr, nullptr, I->tape_vis + (size_t) b * I->ws_lanes, cache_mode };
+        else if (cache_mode && b < I->cache_bounces)
             rc = ReplayCache{ I->rc_h0 + (size_t) b * I->ws_lanes, I->rc_h1 + (size_t) b * I->ws_lanes, I->rc_vis + (size_t) b * I->ws_lanes, cache_mode };
-        if (rc.mode != 2) {
-            launch_trace_closest(s, tgrid, spill, S->ds.accel, cnt_alive(I, b), cur_trace(I, b), I->shard_cap, I->st[cur], I->h0, I->h1, I->status);
+        /* the wavefront buffers of this bounce: the ping-pong pair, or the tape's per-bounce buffers (path state in / out, hit records) */
+        const WaveState st_in = tape ? I->tape_st[b] : I->st[cur], st_out = tape ? I->tape_st[b + 1] : I->st[cur ^ 1];
+        float4 *const h0 = tape ? I->tape_h0 + (size_t) 2 * I->ws_lanes * b : I->h0;
+        uint2 *const h1 = tape ? (HAR_HIT_INTERLEAVED ? reinterpret_cast<uint2 *>(h0 + 1) : reinterpret_cast<uint2 *>(h0 + I->ws_lanes)) : I->h1;
+        const TapeArrays tp{ tape ? I->tape_next + (size_t) b * I->ws_lanes : nullptr, I->tape_la[b & 1], I->tape_lb[b & 1], I->tape_la[(b & 1) ^ 1], I->tape_lb[(b & 1) ^ 1] };
+        if (rc.mode != 2 && rc.mode != 4) {
+            launch_trace_closest(s, tgrid, spill, S->ds.accel, cnt_alive(I, b), cur_trace(I, b), I->shard_cap, st_in, h0, h1, I->status);
             prof_mark(I, s, CLS_TRACE);
         }
-        if (I->hide_emitters && b == 0 && rc.mode != 2) {
+        if (I->hide_emitters && b == 0 && rc.mode != 2 && rc.mode != 4) {
             /* Integrator::skip_area_emitters (integrator.cpp:96-124) for the camera rays: continuation rays are gathered into a list, traced, and
              * their hits replace the lanes' hits until no lane sits on an area emitter any more.  Scratch: the other wavefront buffer holds the two
              * lists, the (still unused) item arrays the re-traced hits.  One host round trip per round -- `hide_emitters` is not a hot path. */
             const size_t cs = (size_t) HAR_SHARDS * HAR_COUNTER_STRIDE;
             uint32_t *cnt[2] = { I->skip_counters, I->skip_counters + 2 * cs }, *cursor[2] = { I->skip_counters + cs, I->skip_counters + 3 * cs };
-            float4 *lo[2] = { I->st[cur ^ 1].a0, I->st[cur ^ 1].a2 }, *ld[2] = { I->st[cur ^ 1].a1, I->st[cur ^ 1].a3 };
+            float4 *lo[2] = { st_out.a0, st_out.a2 }, *ld[2] = { st_out.a1, st_out.a3 };
             if (!I->hit_scratch && ws_alloc(I, &I->hit_scratch, (size_t) 2 * I->ws_lanes)) return 1;       /* re-traced hits: records in the layout of h0 / h1 */
             float4 *sh0 = I->hit_scratch; uint2 *sh1 = HAR_HIT_INTERLEAVED ? reinterpret_cast<uint2 *>(I->hit_scratch + 1) : reinterpret_cast<uint2 *>(I->hit_scratch + I->ws_lanes);
             HIP_TRY(hipMemsetAsync(I->skip_counters, 0, 4 * cs * sizeof(uint32_t), s));
-            launch_skip_emitters(s, grid, S->ds, 1, I->shard_cap, cnt_alive(I, 0), I->st[cur].a0, I->st[cur].a1, nullptr, nullptr, I->h0, I->h1, lo[0], ld[0], cnt[0]);
+            launch_skip_emitters(s, grid, S->ds, 1, I->shard_cap, cnt_alive(I, 0), st_in.a0, st_in.a1, nullptr, nullptr, h0, h1, lo[0], ld[0], cnt[0]);
             for (int round = 0, a = 0; round < 256; ++round, a ^= 1) {
                 uint32_t host[HAR_SHARDS * HAR_COUNTER_STRIDE];
                 HIP_TRY(hipMemcpyAsync(host, cnt[a], sizeof(host), hipMemcpyDeviceToHost, s));
@@ -419,31 +456,42 @@ int run_chunk(HarSceneImpl *S, HarIntegratorImpl *I, const DSensor &C, int mode,
                 launch_trace_closest(s, tgrid, spill, S->ds.accel, cnt[a], cursor[a], I->shard_cap, list, sh0, sh1, I->status);
                 HIP_TRY(hipMemsetAsync(cnt[a ^ 1], 0, cs * sizeof(uint32_t), s));
                 HIP_TRY(hipMemsetAsync(cursor[a ^ 1], 0, cs * sizeof(uint32_t), s));
-                launch_skip_emitters(s, grid, S->ds, 0, I->shard_cap, cnt[a], lo[a], ld[a], sh0, sh1, I->h0, I->h1, lo[a ^ 1], ld[a ^ 1], cnt[a ^ 1]);
+                launch_skip_emitters(s, grid, S->ds, 0, I->shard_cap, cnt[a], lo[a], ld[a], sh0, sh1, h0, h1, lo[a ^ 1], ld[a ^ 1], cnt[a ^ 1]);
             }
             prof_mark(I, s, CLS_OTHER);
         }
         if (((I->alpha_film && I->alpha_lane) || valid_lane) && b == 0 && mode != MODE_PRB_ADJOINT) {        /* `rgba` films: is the camera sample valid?  (path.cpp:114-115,307-308; prb.py:332) */
             const float miss = (mode == MODE_PATH && S->ds.env_emitter >= 0 && !I->hide_emitters) ? 1.f : 0.f;
-            launch_alpha_flags(s, grid, I->shard_cap, cnt_alive(I, 0), I->st[cur], I->h0, lane_base, miss, valid_lane ? valid_lane : I->alpha_lane);
+            launch_alpha_flags(s, grid, I->shard_cap, cnt_alive(I, 0), st_in, h0, lane_base, miss, valid_lane ? valid_lane : I->alpha_lane);
         }
         /* vertex-position gradients of the PREVIOUS bounce's vertices: its items are still in place, `result` holds its L, and this bounce's ray
          * queries give the (detached) next interaction of every continued path */
         if (shape && b > 0) {
-            launch_shape_adjoint(s, grid, S->ds, cnt_items(I, b - 1), I->shard_cap, I->items, I->geo, I->result, I->dL, 1, I->st[cur], I->h0, I->h1, rc, targets);
+            launch_shape_adjoint(s, grid, S->ds, cnt_items(I, b - 1), I->shard_cap, I->items, I->geo, I->result, I->dL, 1, st_in, h0, h1, rc, targets);
             prof_mark(I, s, CLS_OTHER);
         }
-        const bool queued = inline_commit && rc.mode == 2 && I->tq.nq != 0;          /* texel gradients of this bounce go through the band queues */
+        const bool cached = rc.mode == 2 || rc.mode == 4;                             /* adjoint replay of a cached / taped bounce */
+        const bool queued = inline_commit && cached && I->tq.nq != 0;                 /* texel gradients of this bounce go through the band queues */
         if (queued) HIP_TRY(hipMemsetAsync(I->tq.count, 0, (size_t) HAR_SHARDS * I->tq.nq * HAR_COUNTER_STRIDE * sizeof(uint32_t), s));
-        launch_shade(mode, s, grid, S->ds, P, lane_base, I->shard_cap, cnt_alive(I, b), I->st[cur], I->h0, I->h1, I->st[cur ^ 1], cnt_alive(I, b + 1),
-                     I->items, cnt_items(I, b), I->result, rc, ps.rng, I->dL, grad_refl, shape ? &I->geo : nullptr, inline_commit && rc.mode == 2 ? I->d_grad_tex : nullptr,
-                     queued ? &I->tq : nullptr, (inline_commit && rc.mode == 2) ? I->grad_bsdf_params : nullptr);
+        if (use_mq) {
+            /* classify the bounce's hits, then one specialised launch per material class of the scene; the launches append their survivors / items to the
+             * same compacted queues (slot reservation is per block, so the order of the classes does not matter to any path) */
+            HIP_TRY(hipMemsetAsync(I->mq_count, 0, (size_t) HAR_MAT_CLASSES * HAR_SHARDS * HAR_COUNTER_STRIDE * sizeof(uint32_t), s));
+            launch_classify(s, grid, S->ds, I->shard_cap, cnt_alive(I, b), h0, h1, mq);
+            for (uint32_t c = 0; c < HAR_MAT_CLASSES; ++c)
+                if (S->mat_classes & (1u << c))
+                    launch_shade(mode, s, grid, S->ds, P, lane_base, I->shard_cap, cnt_alive(I, b), st_in, h0, h1, st_out, cnt_alive(I, b + 1),
+                                 I->items, cnt_items(I, b), I->result, rc, ps.rng, I->dL, grad_refl, nullptr, nullptr, nullptr, nullptr, &mq, c, tape ? &tp : nullptr);
+        } else
+        launch_shade(mode, s, grid, S->ds, P, lane_base, I->shard_cap, cnt_alive(I, b), st_in, h0, h1, st_out, cnt_alive(I, b + 1),
+                     I->items, cnt_items(I, b), I->result, rc, ps.rng, I->dL, grad_refl, shape ? &I->geo : nullptr, inline_commit && cached ? I->d_grad_tex : nullptr,
+                     queued ? &I->tq : nullptr, (inline_commit && (rc.mode == 2 || rc.mode == 4)) ? I->grad_bsdf_params : nullptr, nullptr, 0, tape ? &tp : nullptr);
         prof_mark(I, s, CLS_SHADE);
         if (queued) {
             static const uint32_t bpq_env = getenv("HAR_TQ_BPQ") ? (uint32_t) atoi(getenv("HAR_TQ_BPQ")) : 0u;
             launch_texel_accumulate(s, I->tq, I->d_grad_tex, bpq_env ? bpq_env : (n > (1u << 22) ? 4u : 1u), I->tq_lds); prof_mark(I, s, CLS_OTHER);
         }
-        if (!(inline_commit && rc.mode == 2)) launch_resolve(mode, s, rc.mode == 2 ? grid : tgrid, spill, S->ds, cnt_items(I, b), cur_resolve(I, b), I->shard_cap, I->items, I->result, I->dL, grad_refl, I->d_grad_tex, I->status, rc,
+        if (!(inline_commit && cached)) launch_resolve(mode, s, rc.mode == 2 ? grid : tgrid, spill, S->ds, cnt_items(I, b), cur_resolve(I, b), I->shard_cap, I->items, I->result, I->dL, grad_refl, I->d_grad_tex, I->status, rc,
                        shape ? I->geo.vis : nullptr, fwd ? 1 : 0);
         prof_mark(I, s, CLS_RESOLVE);
         cur ^= 1;
@@ -535,6 +583,19 @@ int har_scene_create(const HarSceneDesc *desc, HarScene *out) {
     auto up = [&](auto &vec, auto **dst) { if (err == hipSuccess) err = upload(vec, dst, S->owned); };
     up(hs.nodes, &D.accel.nodes); up(hs.tris, &D.accel.tris); up(hs.inst_recs, &D.accel.insts);
     up(hs.blas_tri_ranges, &D.blas_tri_ranges); up(hs.verts, &D.verts); up(hs.faces, &D.faces);
+    /* material class of every BSDF record and mesh (MaterialQueues; the mesh's class rides in DMesh::pad1 so that k_classify needs ONE dependent load) */
+    S->mat_classes = 0;
+    {
+        std::vector<uint32_t> cls(hs.bsdfs.size());
+        for (size_t k = 0; k < hs.bsdfs.size(); ++k) {
+            const DBsdf &b = hs.bsdfs[k];
+            uint32_t c = std::min<uint32_t>(b.type, BSDF_TYPE_COUNT - 1u);
+            if ((b.flags & BF_TWOSIDED) && b.back >= 0 && hs.bsdfs[(size_t) b.back].type != b.type) c = HAR_MAT_GENERIC;
+            cls[k] = c;
+        }
+        for (DMesh &m : hs.meshes) { m.pad1 = m.bsdf < cls.size() ? cls[m.bsdf] : 0u; S->mat_classes |= 1u << m.pad1; }
+    }
+    S->mat_miss_class = 0; while (S->mat_miss_class < HAR_MAT_CLASSES && !(S->mat_classes & (1u << S->mat_miss_class))) ++S->mat_miss_class;
     up(hs.meshes, &D.meshes); up(hs.bsdfs, &D.bsdfs); up(hs.emitters, &D.emitters); up(hs.insts, &D.insts);
     std::vector<DTexture> dt;
     for (auto &t : hs.textures) {
@@ -946,7 +1007,13 @@ static int backward_range(HarScene S, HarIntegrator I, const HarSensor *sensor, 
     if (I->max_depth == 0) return 0;
     hipStream_t s = (hipStream_t) stream;
     uint32_t chunk = (uint32_t) std::min<uint64_t>(I->chunk, (std::max<uint64_t>(le - lb, 2048) + 2047) / 2048 * 2048);
-    if (ensure_workspace(I, chunk, true)) return 1;
+    /* replay TAPE instead of the lane-indexed replay cache (TapeArrays, har_kernels.h) whenever the adjoint commits in place: the default.  Not with
+     * vertex-position / instance gradients (their adjoint goes through items), hide_emitters (its device round trip re-traces into the ping-pong
+     * buffers), the replay cache switched off, or more bounces than the tape holds.  HAR_PRB_TAPE=0: the round-2 cache (A/B). */
+    static const bool tape_env = getenv("HAR_PRB_TAPE") ? atoi(getenv("HAR_PRB_TAPE")) != 0 : true;
+    static const bool inline_env0 = getenv("HAR_ADJOINT_INLINE") ? atoi(getenv("HAR_ADJOINT_INLINE")) != 0 : true;
+    const bool tape = tape_env && inline_env0 && I->use_cache && !I->shape_on && !I->hide_emitters && bounce_limit(I) <= HAR_REPLAY_CACHE_BOUNCES;
+    if (ensure_workspace(I, chunk, true, tape)) return 1;
     size_t npx = (size_t) C.crop_w * C.crop_h;
     if (I->adj_floats < 3 * npx) { if (ws_alloc(I, &I->adj, 3 * npx)) return 1; I->adj_floats = 3 * npx; }
     size_t nt = S->hs.textures.size();
@@ -970,7 +1037,7 @@ static int backward_range(HarScene S, HarIntegrator I, const HarSensor *sensor, 
     if (I->grad_slots_cap < nb3 + ne3 + 3) { if (ws_alloc(I, &I->grad_slots, nb3 + ne3 + 3)) return 1; I->grad_slots_cap = nb3 + ne3 + 3; }
     HIP_TRY(hipMemsetAsync(I->grad_slots, 0, (nb3 + ne3 + 3) * sizeof(float), s));
     if (I->shape_on) {
-        if ((I->pos_verts && I->pos_offset.size() != S->hs.meshes.size()) || (I->inst_count && I->inst_count != S->hs.insts.size()) || (S->ds.bsdf_types & 0x7fffffffu) != HAR_BSDF_ONLY_DIFFUSE)
+        if ((I->pos_verts && I->pos_offset.size() != S->hs.meshes.size()) || (I->inst_count && I->inst_count != S->hs.insts.size()))
             return fail("har_integrator_set_grad_positions / har_integrator_set_grad_instances was called for a different scene");
         if (I->pos_verts) HIP_TRY(hipMemsetAsync(I->grad_pos, 0, (size_t) 3 * I->pos_verts * sizeof(float), s));
         if (I->inst_count) HIP_TRY(hipMemsetAsync(I->grad_inst, 0, (size_t) 12 * I->inst_count * sizeof(float), s));
@@ -984,9 +1051,9 @@ static int backward_range(HarScene S, HarIntegrator I, const HarSensor *sensor, 
     for (uint64_t base = lb; base < le; base += chunk) {
         uint32_t n = (uint32_t) std::min<uint64_t>(chunk, le - base);
         /* pass 1: primal, keeps L per lane in `result` (common.py:752-762) */
-        if (run_chunk(S, I, C, MODE_PRB_PRIMAL, seed, spp, log_spp, (uint32_t) base, n, nullptr, s, I->cache_bounces ? 1 : 0)) return 1;
+        if (run_chunk(S, I, C, MODE_PRB_PRIMAL, seed, spp, log_spp, (uint32_t) base, n, nullptr, s, tape ? 3 : I->cache_bounces ? 1 : 0)) return 1;
         /* pass 2: adjoint replay with the identical sample stream (common.py:765-775) */
-        if (run_chunk(S, I, C, MODE_PRB_ADJOINT, seed, spp, log_spp, (uint32_t) base, n, I->grad_slots, s, I->cache_bounces ? 2 : 0)) return 1;
+        if (run_chunk(S, I, C, MODE_PRB_ADJOINT, seed, spp, log_spp, (uint32_t) base, n, I->grad_slots, s, tape ? 4 : I->cache_bounces ? 2 : 0)) return 1;
     }
     launch_add(s, I->grad_slots, grad_reflectance, (uint32_t) nb3);
     if (I->grad_emitters && ne3) launch_add(s, I->grad_slots + nb3, I->grad_emitters, (uint32_t) ne3);
@@ -1049,20 +1116,29 @@ int har_render_forward(HarScene S, HarIntegrator I, const HarSensor *sensor, uin
     return 0;
 }
 
+static bool record_is_diffuse(const HostScene &hs, int32_t index) {
+    if (index < 0 || (size_t) index >= hs.bsdfs.size()) return false;
+    const DBsdf &b = hs.bsdfs[(size_t) index];
+    return b.type == BSDF_DIFFUSE && (b.back < 0 || hs.bsdfs[(size_t) b.back].type == BSDF_DIFFUSE);
+}
+
 int har_integrator_set_grad_positions(HarIntegrator I, HarScene S, float *const *grad_positions) {
     if (!I) return fail("null integrator");
     if (I->type != HAR_INTEGRATOR_PRB) return fail("vertex-position gradients are computed by the `prb` integrator");
     std::vector<float *> user; std::vector<int32_t> offset; std::vector<uint32_t> count; uint32_t verts = 0;
     if (grad_positions) {
         if (!S) return fail("null scene");
-        /* the hand-derived adjoint of har_shape_grad.h covers plain `diffuse` BSDFs on flat-shaded top-level meshes */
-        if ((S->ds.bsdf_types & 0x7fffffffu) != HAR_BSDF_ONLY_DIFFUSE) return fail("vertex-position gradients are implemented for scenes whose BSDFs are all `diffuse` (plain or inside `twosided`)");
+        /* the hand-derived adjoint of har_shape_grad.h covers `diffuse` BSDFs (plain or inside `twosided`) on flat-shaded top-level meshes.  Only the
+         * DIFFERENTIATED meshes have to be diffuse: the shape terms of prb.py:124-141,176-216,261-297 live at vertices whose own triangle moves, so the
+         * rest of the scene may carry any BSDF model -- its vertices are shaded by the generic adjoint kernels and contribute no shape term */
+        if (S->ds.bsdf_types & HAR_SCENE_ENVMAP) return fail("vertex-position gradients are not implemented for scenes with an environment map or a mesh area light");
         const size_t nm = S->hs.meshes.size();
         offset.assign(nm, -1); user.assign(nm, nullptr); count.assign(nm, 0);
         for (size_t m = 0; m < S->hs.top_mesh_count; ++m) {
             if (!grad_positions[m]) continue;
             const DMesh &M = S->hs.meshes[m];
             if (M.flags & 1u) return fail("vertex-position gradients need a mesh without vertex normals (face_normals): a position update would regenerate them (mesh.cpp:876-878)");
+            if (!record_is_diffuse(S->hs, M.bsdf)) return fail("vertex-position gradients: the BSDF of a differentiated mesh must be `diffuse` (plain or inside `twosided`); other meshes of the scene may carry any BSDF");
             offset[m] = (int32_t) verts; user[m] = grad_positions[m]; count[m] = M.vertex_count; verts += M.vertex_count;
         }
         if (verts == 0) { offset.clear(); user.clear(); count.clear(); }
@@ -1081,7 +1157,10 @@ int har_integrator_set_grad_instances(HarIntegrator I, HarScene S, float *grad_t
     uint32_t n = 0;
     if (grad_to_world) {
         if (!S) return fail("null scene");
-        if ((S->ds.bsdf_types & 0x7fffffffu) != HAR_BSDF_ONLY_DIFFUSE) return fail("instance to_world gradients are implemented for scenes whose BSDFs are all `diffuse` (plain or inside `twosided`)");
+        /* as for the vertex positions: the shape terms live on the moving geometry, i.e. on the meshes of the shape groups -- those have to be diffuse */
+        if (S->ds.bsdf_types & HAR_SCENE_ENVMAP) return fail("instance to_world gradients are not implemented for scenes with an environment map or a mesh area light");
+        for (size_t m = S->hs.top_mesh_count; m < S->hs.meshes.size(); ++m)
+            if (!record_is_diffuse(S->hs, S->hs.meshes[m].bsdf)) return fail("instance to_world gradients: the BSDFs of the instanced meshes must be `diffuse` (plain or inside `twosided`); top-level meshes may carry any BSDF");
         n = (uint32_t) S->hs.insts.size();
         if (n == 0) return fail("the scene has no instances");
         if (n >= (1u << (32 - HAR_SHAPE_INST_SHIFT)) - 1u) return fail("too many instances for the adjoint's geometry records");
@@ -1119,6 +1198,13 @@ int har_render_stats(HarIntegrator I, HarStats *out) {
         if (read_status(I->twin->status, s)) return 1;
         out->paths += t[0]; out->vertices += t[1]; out->closest_rays += t[2]; out->shadow_rays += t[3];
     }
+    return 0;
+}
+
+int har_integrator_set_material_queues(HarIntegrator I, int enable) {
+    if (!I) return fail("null integrator");
+    I->material_queues = enable != 0;
+    if (I->twin) I->twin->material_queues = I->material_queues;
     return 0;
 }
 

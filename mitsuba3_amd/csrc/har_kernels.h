@@ -55,6 +55,14 @@ struct ItemArrays { float4 *s0, *s1, *s2, *s3, *s4; };
  * numbers, so its ray queries are bit-identical to the primal pass's; their results (24 B hit record, 1 B visibility) are kept in HBM
  * between the two passes of a chunk instead of being traced twice.  mode 0 = unused, 1 = write (primal pass), 2 = read (adjoint pass) */
 struct ReplayCache { float4 *h0; uint2 *h1; uint8_t *vis; int mode; };
+/* PRB replay TAPE (modes 3 = record in the primal pass, 4 = replay in the adjoint pass; the default when the adjoint commits in place).  The lane-
+ * indexed cache above makes the adjoint pass read hit records, visibility, L and dL through an ever sparser survivor list (1.6x the algorithmic
+ * bytes, round-2 PMC passes) and write the path state a second time.  The tape keeps the primal pass's WAVEFRONTS instead: bounce b's compacted
+ * path state (72 B per path, written anyway -- each bounce gets its own buffer instead of a ping-pong pair), its hit records (the closest-hit kernel
+ * writes them straight into the tape), one visibility byte per vertex slot, and `next` = the slot the survivor took in bounce b + 1.  The adjoint
+ * pass then streams every bounce in the primal's slot order: dense reads, NO compaction (no slot reservation, no state store), and L / dL travel in
+ * two slot-ordered arrays (la = L.xyz, dL.x; lb = dL.yz) from slot i to slot next[i].  ReplayCache::vis = the bounce's visibility bytes. */
+struct TapeArrays { uint32_t *next; float4 *la_in; float2 *lb_in; float4 *la_out; float2 *lb_out; };
 /* Multi-pass rendering (integrator.cpp:280-356): the sampler of lane i keeps its PCG32 state from one pass to the next (sampler->advance()
  * does not reseed).  `rng` holds that state per lane of the chunk (pre-offset to the chunk's first lane; nullptr = single pass, streams are
  * seeded in raygen and dropped at path end); `jitter` receives the pass's pixel jitter per chunk lane for the splat kernel, which otherwise
@@ -78,6 +86,12 @@ struct ShapeArrays { float4 *g0, *g1, *g2, *g3; uint8_t *vis; };
 #define HAR_TQ_MAX 64                 /* queues (row bands of all queued textures) */
 #define HAR_TQ_LDS_BYTES 24576        /* default LDS copy of a band: (rows + 1) x width x 3 floats (6 blocks per CU) */
 struct TexelQueues { float4 *rec; uint32_t *count; const uint2 *band; const uint4 *qinfo; uint32_t nq, cap; };
+/* Per-material shading queues (north_star: "material-sorted BSDF megakernels"; the reference's dispatch point is the BSDF virtual call of
+ * path.cpp:233,266-267).  After the closest-hit launch of a bounce, k_classify deals the shard's paths to HAR_MAT_CLASSES index lists by the BSDF MODEL
+ * of the surface they hit (har_bsdf.h: six models + "twosided pair of two models"; escaped paths ride in `miss_class`), in slot order within a
+ * 256-path tile, and ONE k_shade launch per non-empty class -- a kernel in which only that model's code exists (registers, no scratch, no divergence
+ * over models) -- shades its list.  idx: class c, shard s -> idx[c * lanes + s * shard_cap + k] = slot of the k-th path; count: (c * HAR_SHARDS + s) * stride. */
+struct MaterialQueues { uint32_t *idx; uint32_t *count; uint32_t lanes, miss_class; };
 #define HAR_SHAPE_INST_SHIFT 8           /* geometry records: bits 8..31 of the flags word = instance index + 1 of a vertex on instanced geometry (0: top-level) */
 struct ShapeTargets { const int32_t *offset; float *grad; uint32_t n_verts; const int32_t *inst_slot; float *inst_grad; uint32_t n_insts; /* per instance: slot (12 floats each in inst_grad) or -1; null = no instance is differentiated */ };
 #define HAR_LDS_GRAD_INSTS 128        /* instance-transform gradients accumulated per block in LDS (6 KB) */
@@ -97,7 +111,13 @@ void launch_shade(int mode, hipStream_t s, uint32_t grid, const DScene &S, const
                   uint32_t *item_count, float4 *result, const ReplayCache &rc, uint64_t *pass_rng = nullptr, const float4 *dL = nullptr, float *grad_slots = nullptr,
                   const ShapeArrays *geo = nullptr, float *const *grad_tex_inline = nullptr,       /* grad_tex_inline (adjoint, cached bounce): commit the vertex adjoint in place, no items */
                   const TexelQueues *tq = nullptr,                                                 /* ... with the texel gradients going through the queues */
-                  float *grad_extra = nullptr);                                                    /* ... plus 15 floats per BSDF record: d / d {alpha_u, alpha_v, eta, k, slot 1} */
+                  float *grad_extra = nullptr,                                                     /* ... plus 15 floats per BSDF record: d / d {alpha_u, alpha_v, eta, k, slot 1} */
+                  const MaterialQueues *mq = nullptr, uint32_t mat_class = 0,                      /* shade the paths of ONE material class (path / prb primal), see MaterialQueues */
+                  const TapeArrays *tape = nullptr);                                               /* rc.mode 3 / 4: the bounce's tape arrays */
+/* adjoint pass in tape mode: L (the primal pass's result) and dL (gathered from the adjoint image over the lane's footprint) into bounce 0's slot order */
+void launch_tape_begin(hipStream_t s, const DSensor &C, uint32_t seed, uint32_t spp, uint32_t log_spp, uint32_t lane_base, uint32_t n, uint32_t shard_cap,
+                       const float4 *result, const float *adj, float4 *la, float2 *lb);
+void launch_classify(hipStream_t s, uint32_t grid, const DScene &S, uint32_t shard_cap, const uint32_t *count_in, const float4 *h0, const uint2 *h1, const MaterialQueues &mq);
 /* the records of one bounce -> LDS band copies -> grad_tex (see TexelQueues); blocks_per_queue blocks share a queue */
 void launch_texel_accumulate(hipStream_t s, const TexelQueues &tq, float *const *grad_tex, uint32_t blocks_per_queue, uint32_t lds_bytes);
 void launch_resolve(int mode, hipStream_t s, uint32_t grid, uint2 *spill, const DScene &S, const uint32_t *item_count, uint32_t *cursor, uint32_t shard_cap, const ItemArrays &items,

@@ -196,6 +196,32 @@ __global__ __launch_bounds__(kBlock) void k_raygen(DSensor C, uint32_t seed, uin
     }
 }
 
+/* start of the adjoint pass in tape mode (TapeArrays): lane i of the chunk sits in slot shard_slot(i) of bounce 0's wavefront; its L is the primal pass's
+ * result, its dL the adjoint image gathered over its film footprint (the adjoint of ImageBlock::put + develop, common.py:696-746 -- the same gather as
+ * k_raygen<MODE_PRB_ADJOINT>, whose path state the tape already holds) */
+__global__ __launch_bounds__(kBlock) void k_tape_begin(DSensor C, uint32_t seed, uint32_t spp, uint32_t log_spp, uint32_t lane_base, uint32_t n, uint32_t shard_cap,
+                                                       const float4 *result, const float *adj, float4 *la, float2 *lb) {
+    const uint32_t i = blockIdx.x * kBlock + threadIdx.x;
+    if (i >= n) return;
+    const LaneSample ls = lane_film_pos(C, seed, spp, log_spp, lane_base + i);
+    Footprint F; film_footprint(C, ls, F);
+    Vec3 g(0.f);
+#pragma unroll
+    for (uint32_t ys = 0; ys < HAR_MAX_FILTER_TAPS; ++ys) {
+        uint32_t y = F.y0 + ys; if (!(ys < F.count && y < C.crop_h)) continue;
+#pragma unroll
+        for (uint32_t xs = 0; xs < HAR_MAX_FILTER_TAPS; ++xs) {
+            uint32_t x = F.x0 + xs; if (!(xs < F.count && x < C.crop_w)) continue;
+            float w = F.wx[xs] * F.wy[ys];
+            const float *a = adj + 3 * ((size_t) y * C.crop_w + x);
+            g = Vec3(fma_(a[0], w, g.x), fma_(a[1], w, g.y), fma_(a[2], w, g.z));
+        }
+    }
+    const float4 r = result[i];
+    const uint32_t slot = shard_slot(i, shard_cap);
+    la[slot] = make_float4(r.x, r.y, r.z, g.x); lb[slot] = make_float2(g.y, g.z);
+}
+
 /* SamplingIntegrator::sample over caller-supplied rays (include/mitsuba/render/integrator.h:432-437): the wavefront starts from the rays
  * instead of the sensor.  Ray i is wavefront lane lane_base + i: its sampler is Sampler::seed's stream of that lane (sampler.cpp:129-148),
  * continued from state[i] when the caller passes its PCG32 states; the loop state is PathIntegrator::sample's initial one (path.cpp:129-147:
@@ -377,6 +403,56 @@ __global__ __launch_bounds__(kBlock, HAR_TRACE_MIN_WAVES) void k_trace_closest(A
 /* a texel-gradient record on its way to a queue (see TexelQueues): the bilinear cell, the fractions and the gradient of the interpolated colour */
 struct TexelRecord { bool has; uint32_t q, cell, tex; float w1x, w1y; Vec3 g; };
 
+/* the reverse-mode commit of one vertex with the lane's L and dL in REGISTERS (the in-place commit of k_shade keeps them there across the emission
+ * term, this commit and the extra-parameter terms; the tape hands them from slot to slot): L <- L - [visible] Lr_dir, `dirty` says whether L changed */
+__device__ __forceinline__ void adjoint_commit_regs(const DScene &S, bool pred, bool visible, float4 s2, float4 s3, float4 s4, Vec3 &L, bool &dirty, Vec3 dl,
+                                                    float *grad_refl, float *const *grad_tex, float *gacc, const TexelQueues *tq = nullptr, TexelRecord *rec = nullptr) {
+    Vec3 g(0.f); float *dst = grad_refl; bool tex = false; TexTaps taps; float *tdst = nullptr;
+    if (pred) {
+        const uint32_t tag = __float_as_uint(s2.w), bsdf = tag & 0xfffffu, emitter = (tag >> 20) & 0x7ffu;
+        if (emitter != HAR_ITEM_NO_EMITTER) {       /* the item carries Lr_dir for a unit radiance: d Lr_dir / d radiance, and Lr_dir = unit * radiance */
+            const DEmitter E = S.emitters[emitter];
+            if (visible) {
+                const Vec3 ge = Vec3(s2.x, s2.y, s2.z) * dl;
+                const uint32_t slot = S.n_bsdfs + emitter;
+                if (slot < HAR_LDS_GRAD_BSDFS) { atomicAdd(&gacc[3 * slot], ge.x); atomicAdd(&gacc[3 * slot + 1], ge.y); atomicAdd(&gacc[3 * slot + 2], ge.z); }
+                else { float *a = grad_refl + 3 * (size_t) slot; atomicAdd(a, ge.x); atomicAdd(a + 1, ge.y); atomicAdd(a + 2, ge.z); }
+            }
+            s2.x *= E.radiance[0]; s2.y *= E.radiance[1]; s2.z *= E.radiance[2];
+        }
+        if (visible) { L = Vec3(L.x - s2.x, L.y - s2.y, L.z - s2.z); dirty = true; }
+        g = visible ? Vec3(s3.x, s3.y, s3.z) : Vec3(0.f);
+        if (tag & 0x80000000u) g = g + Vec3(L.x * s4.x, L.y * s4.y, L.z * s4.z);
+        g = g * dl;
+        const DBsdf B = S.bsdfs[bsdf];
+        dst = grad_refl + 3 * (size_t) bsdf;
+        if (B.texture >= 0) { tex = true; tex_taps(S.textures[B.texture], s3.w, s4.w, taps); tdst = grad_tex[B.texture]; }
+    }
+    const bool nz = pred && (g.x != 0.f || g.y != 0.f || g.z != 0.f);
+    if (rec) {          /* queued textures: hand the record to the caller (block-wide append), no atomics here */
+        rec->has = false;
+        if (nz && tex) {
+            const uint32_t t = (uint32_t) S.bsdfs[(uint32_t) (dst - grad_refl) / 3u].texture;
+            const uint2 band = tq->band[t];
+            if (band.x != 0xffffffffu) {
+                const uint32_t W = S.textures[t].w, y0 = taps.idx[0] / W, x0 = taps.idx[0] - y0 * W;
+                rec->has = true; rec->q = band.x + y0 / band.y; rec->cell = x0 | (y0 << 16); rec->tex = t; rec->w1x = taps.w1x; rec->w1y = taps.w1y; rec->g = g;
+                tex = false; g = Vec3(0.f);
+            }
+        }
+    }
+    const bool nz_direct = nz && (g.x != 0.f || g.y != 0.f || g.z != 0.f || tex);
+    if (nz_direct && !tex) {
+        const uint32_t bsdf = (uint32_t) (dst - grad_refl) / 3u;
+        if (bsdf < HAR_LDS_GRAD_BSDFS) { atomicAdd(&gacc[3 * bsdf], g.x); atomicAdd(&gacc[3 * bsdf + 1], g.y); atomicAdd(&gacc[3 * bsdf + 2], g.z); }
+        else { atomicAdd(dst, g.x); atomicAdd(dst + 1, g.y); atomicAdd(dst + 2, g.z); }
+    }
+    if (__ballot(nz_direct && tex)) {
+        const float w[4] = { taps.w0x * taps.w0y, taps.w1x * taps.w0y, taps.w0x * taps.w1y, taps.w1x * taps.w1y };
+        for (int k = 0; k < 4; ++k)
+            wave_aggregated_add3(nz_direct && tex ? tdst + 3 * (size_t) taps.idx[k] : grad_refl, nz_direct && tex ? g * w[k] : Vec3(0.f), nz_direct && tex);
+    }
+}
 template <bool FWD = false>
 __device__ __forceinline__ void adjoint_commit_values(const DScene &S, bool pred, bool visible, uint32_t lane, float4 s2, float4 s3, float4 s4, float4 *result, const float4 *dL,
                                                       float *grad_refl, float *const *grad_tex, float *gacc, const TexelQueues *tq = nullptr, TexelRecord *rec = nullptr) {
@@ -412,53 +488,10 @@ __device__ __forceinline__ void adjoint_commit_values(const DScene &S, bool pred
         }
         return;
     }
-    Vec3 g(0.f); float *dst = grad_refl; bool tex = false; TexTaps taps; float *tdst = nullptr;
-    if (pred) {
-        float4 L = result[lane];
-        const float4 dl = dL[lane];
-        const uint32_t tag = __float_as_uint(s2.w), bsdf = tag & 0xfffffu, emitter = (tag >> 20) & 0x7ffu;
-        if (emitter != HAR_ITEM_NO_EMITTER) {       /* the item carries Lr_dir for a unit radiance: d Lr_dir / d radiance, and Lr_dir = unit * radiance */
-            const DEmitter E = S.emitters[emitter];
-            if (visible) {
-                const Vec3 ge = Vec3(s2.x, s2.y, s2.z) * Vec3(dl.x, dl.y, dl.z);
-                const uint32_t slot = S.n_bsdfs + emitter;
-                if (slot < HAR_LDS_GRAD_BSDFS) { atomicAdd(&gacc[3 * slot], ge.x); atomicAdd(&gacc[3 * slot + 1], ge.y); atomicAdd(&gacc[3 * slot + 2], ge.z); }
-                else { float *a = grad_refl + 3 * (size_t) slot; atomicAdd(a, ge.x); atomicAdd(a + 1, ge.y); atomicAdd(a + 2, ge.z); }
-            }
-            s2.x *= E.radiance[0]; s2.y *= E.radiance[1]; s2.z *= E.radiance[2];
-        }
-        if (visible) { L = make_float4(L.x - s2.x, L.y - s2.y, L.z - s2.z, 0.f); result[lane] = L; }
-        g = visible ? Vec3(s3.x, s3.y, s3.z) : Vec3(0.f);
-        if (tag & 0x80000000u) g = g + Vec3(L.x * s4.x, L.y * s4.y, L.z * s4.z);
-        g = g * Vec3(dl.x, dl.y, dl.z);
-        const DBsdf B = S.bsdfs[bsdf];
-        dst = grad_refl + 3 * (size_t) bsdf;
-        if (B.texture >= 0) { tex = true; tex_taps(S.textures[B.texture], s3.w, s4.w, taps); tdst = grad_tex[B.texture]; }
-    }
-    const bool nz = pred && (g.x != 0.f || g.y != 0.f || g.z != 0.f);
-    if (rec) {          /* queued textures: hand the record to the caller (block-wide append), no atomics here */
-        rec->has = false;
-        if (nz && tex) {
-            const uint32_t t = (uint32_t) S.bsdfs[(uint32_t) (dst - grad_refl) / 3u].texture;
-            const uint2 band = tq->band[t];
-            if (band.x != 0xffffffffu) {
-                const uint32_t W = S.textures[t].w, y0 = taps.idx[0] / W, x0 = taps.idx[0] - y0 * W;
-                rec->has = true; rec->q = band.x + y0 / band.y; rec->cell = x0 | (y0 << 16); rec->tex = t; rec->w1x = taps.w1x; rec->w1y = taps.w1y; rec->g = g;
-                tex = false; g = Vec3(0.f);
-            }
-        }
-    }
-    const bool nz_direct = nz && (g.x != 0.f || g.y != 0.f || g.z != 0.f || tex);
-    if (nz_direct && !tex) {
-        const uint32_t bsdf = (uint32_t) (dst - grad_refl) / 3u;
-        if (bsdf < HAR_LDS_GRAD_BSDFS) { atomicAdd(&gacc[3 * bsdf], g.x); atomicAdd(&gacc[3 * bsdf + 1], g.y); atomicAdd(&gacc[3 * bsdf + 2], g.z); }
-        else { atomicAdd(dst, g.x); atomicAdd(dst + 1, g.y); atomicAdd(dst + 2, g.z); }
-    }
-    if (__ballot(nz_direct && tex)) {
-        const float w[4] = { taps.w0x * taps.w0y, taps.w1x * taps.w0y, taps.w0x * taps.w1y, taps.w1x * taps.w1y };
-        for (int k = 0; k < 4; ++k)
-            wave_aggregated_add3(nz_direct && tex ? tdst + 3 * (size_t) taps.idx[k] : grad_refl, nz_direct && tex ? g * w[k] : Vec3(0.f), nz_direct && tex);
-    }
+    Vec3 L(0.f), dl(0.f); bool dirty = false;
+    if (pred) { const float4 r = result[lane], d4 = dL[lane]; L = Vec3(r.x, r.y, r.z); dl = Vec3(d4.x, d4.y, d4.z); }
+    adjoint_commit_regs(S, pred, visible, s2, s3, s4, L, dirty, dl, grad_refl, grad_tex, gacc, tq, rec);
+    if (pred && dirty) result[lane] = make_float4(L.x, L.y, L.z, 0.f);
 }
 /* the four taps of a record committed with direct atomics (queue overflow); wave-uniform call */
 __device__ __forceinline__ void texel_record_direct(const DScene &S, float *const *grad_tex, float *dummy, const TexelRecord &r, bool active) {
@@ -482,14 +515,53 @@ __device__ __forceinline__ void adjoint_commit(const DScene &S, const ItemArrays
     adjoint_commit_values<FWD>(S, pred, visible, lane, s2, s3, s4, result, dL, grad_refl, grad_tex, gacc);
 }
 
+/* ---------------------------------------------------------------- classify */
+/* Material classification of a bounce's closest hits (MaterialQueues): every 256-path tile of a shard is dealt to the class lists in SLOT ORDER (wave
+ * ballots give each path its rank within its class; one atomic per class and tile reserves the list range), so a class kernel reads its tile's path
+ * state from one 4 KB window per array in increasing order. */
+__global__ __launch_bounds__(kBlock) void k_classify(DScene S, uint32_t shard_cap, const uint32_t *count_in, const float4 *h0, const uint2 *h1, MaterialQueues mq) {
+    __shared__ uint32_t wave_cnt[kBlock / 64][HAR_MAT_CLASSES + 1], cls_base[HAR_MAT_CLASSES + 1];
+    const ShardLoop Q(count_in, shard_cap);
+    const uint32_t wave = threadIdx.x >> 6;
+    for (uint32_t tile = Q.first_tile(); tile * kBlock < Q.n; tile += Q.tile_step()) {
+        const uint32_t local = tile * kBlock + threadIdx.x;
+        uint32_t key = HAR_MAT_CLASSES;                                  /* beyond the shard's end */
+        if (local < Q.n) {
+            const float t = h0[HIT0(Q.base + local)].x;
+            if (t == HAR_INF) key = mq.miss_class;
+            else key = min(S.meshes[h1[HIT1(Q.base + local)].x].pad1, (uint32_t) HAR_MAT_GENERIC);        /* the mesh's material class (har_scene_create) */
+        }
+        uint32_t rank = 0;
+#pragma unroll
+        for (uint32_t c = 0; c < HAR_MAT_CLASSES; ++c) {
+            const uint64_t m = __ballot(key == c);
+            if (key == c) rank = wave_rank(m);
+            if ((threadIdx.x & 63u) == 0u) wave_cnt[wave][c] = (uint32_t) __popcll(m);
+        }
+        __syncthreads();
+        if (threadIdx.x < HAR_MAT_CLASSES) {
+            uint32_t total = 0; for (uint32_t w = 0; w < kBlock / 64; ++w) total += wave_cnt[w][threadIdx.x];
+            cls_base[threadIdx.x] = total ? atomicAdd(mq.count + (size_t) (threadIdx.x * HAR_SHARDS + Q.shard) * HAR_COUNTER_STRIDE, total) : 0u;
+        }
+        __syncthreads();
+        if (key < HAR_MAT_CLASSES) {
+            uint32_t pos = cls_base[key] + rank;
+            for (uint32_t w = 0; w < wave; ++w) pos += wave_cnt[w][key];
+            mq.idx[(size_t) key * mq.lanes + Q.base + pos] = local;
+        }
+        __syncthreads();
+    }
+}
+
 /* ------------------------------------------------------------------- shade */
 /* INLINE (adjoint replay of a bounce whose shadow-ray results sit in the replay cache): the visibility of the lane's emitter sample is known here,
  * so the vertex's adjoint is committed on the spot instead of going through an item (80 B written + read) and k_resolve_adjoint_cached */
-template <int MODE, uint32_t TYPES, bool SHAPE = false, bool INLINE = false, bool EXTRA = false>
+template <int MODE, uint32_t TYPES, bool SHAPE = false, bool INLINE = false, bool EXTRA = false, bool QUEUED = false>
 __global__ __launch_bounds__(kBlock, HAR_SHADE_MIN_WAVES) void k_shade(DScene S, ShadeParams P, uint32_t lane_base, uint32_t shard_cap, const uint32_t *count_in, WaveState in,
                                                   const float4 *h0, const uint2 *h1, WaveState out, uint32_t *count_out,
                                                   ItemArrays items, uint32_t *item_count, float4 *result, ReplayCache rc, uint64_t *pass_rng,
-                                                  const float4 *dL, float *grad_slots, ShapeArrays geo, float *const *grad_tex, TexelQueues tq, float *grad_extra) {
+                                                  const float4 *dL, float *grad_slots, ShapeArrays geo, float *const *grad_tex, TexelQueues tq, float *grad_extra,
+                                                  MaterialQueues mq, uint32_t mat_class, TapeArrays tape) {
     __shared__ uint32_t lds_r[12];
     /* EXTRA: gradients w.r.t. alpha_u, alpha_v, eta, k, colour slot 1 of the rough BSDF records (15 floats per record): per-block accumulators for
      * the first HAR_LDS_EXTRA_BSDFS records, global atomics beyond */
@@ -505,11 +577,15 @@ __global__ __launch_bounds__(kBlock, HAR_SHADE_MIN_WAVES) void k_shade(DScene S,
     if (emitter_grads) { for (uint32_t k = threadIdx.x; k < 3 * HAR_LDS_GRAD_EMITTERS; k += kBlock) eacc[k] = 0.f; __syncthreads(); }
     constexpr uint32_t kSortKeys = BSDF_TYPE_COUNT + 2;                        /* one bucket per BSDF model, then misses, then lanes beyond the tile's end */
     __shared__ uint32_t sort_cnt[kSortKeys], sort_perm[TYPES == HAR_BSDF_ONLY_DIFFUSE ? 1 : kBlock];
-    const ShardLoop Q(count_in, shard_cap);
+    ShardLoop Q(count_in, shard_cap);
+    /* QUEUED: the paths of ONE material class of this shard, through the index list k_classify built (MaterialQueues) */
+    const uint32_t *q_idx = QUEUED ? mq.idx + (size_t) mat_class * mq.lanes + Q.base : nullptr;
+    if (QUEUED) Q.n = mq.count[(size_t) (mat_class * HAR_SHARDS + Q.shard) * HAR_COUNTER_STRIDE];
     uint32_t *cnt_alive = count_out + Q.shard * HAR_COUNTER_STRIDE, *cnt_item = item_count + Q.shard * HAR_COUNTER_STRIDE;
     for (uint32_t tile = Q.first_tile(); tile * kBlock < Q.n; tile += Q.tile_step()) {
         uint32_t local = tile * kBlock + threadIdx.x;
-        if (TYPES != HAR_BSDF_ONLY_DIFFUSE && HAR_MATERIAL_SORT) {
+        if (QUEUED) local = local < Q.n ? q_idx[local] : 0xffffffffu;
+        if (!QUEUED && TYPES != HAR_BSDF_ONLY_DIFFUSE && HAR_MATERIAL_SORT) {
             /* MATERIAL SORT: the 256 paths of this tile are re-dealt to the lanes by the BSDF type of the surface they hit
              * (block-wide counting sort in LDS), so that a wave runs (mostly) ONE material model of the generic shading
              * code instead of diverging over all of them.  The tile is a contiguous 4 KB window per state array, so the
@@ -534,11 +610,15 @@ __global__ __launch_bounds__(kBlock, HAR_SHADE_MIN_WAVES) void k_shade(DScene S,
             local = tile * kBlock + sort_perm[threadIdx.x];
             __syncthreads();
         }
-        const bool in_range = local < Q.n;
+        const bool in_range = QUEUED ? local != 0xffffffffu : local < Q.n;
         const uint32_t i = Q.base + local;
         ShadeResult R; R.alive = false; R.item = false; R.add_emission = false;
         uint32_t lane = 0;
         float4 hh = make_float4(0.f, 0.f, 0.f, 0.f); uint2 hs = make_uint2(0u, 0u); Vec3 d_in(0.f);
+        /* in-place adjoint commit: the lane's L and dL stay in registers from the emission term to the write-back; tape replay (rc.mode == 4): they come
+         * from / go to the slot-ordered tape arrays and nothing is compacted (TapeArrays) */
+        Vec3 Lr(0.f), dlr(0.f); bool L_dirty = false;
+        const bool tape_read = MODE == MODE_PRB_ADJOINT && INLINE && rc.mode == 4;
         if (in_range) {
             PathState st = load_state(in, i);
             d_in = st.d;
@@ -548,6 +628,10 @@ __global__ __launch_bounds__(kBlock, HAR_SHADE_MIN_WAVES) void k_shade(DScene S,
             Hit hit; hit.t = hh.x; hit.u = hh.y; hit.v = hh.z; hit.prim = __float_as_uint(hh.w); hit.shape = hs.x; hit.inst = hs.y;
             shade_lane<MODE, TYPES, EXTRA>(S, P, st, hit, R);
             lane = st.lane - lane_base;
+            if (MODE == MODE_PRB_ADJOINT && INLINE) {
+                if (tape_read) { const float4 a = tape.la_in[i]; const float2 c2 = tape.lb_in[i]; Lr = Vec3(a.x, a.y, a.z); dlr = Vec3(a.w, c2.x, c2.y); }
+                else { const float4 r = result[lane], d4 = dL[lane]; Lr = Vec3(r.x, r.y, r.z); dlr = Vec3(d4.x, d4.y, d4.z); }
+            }
             if (MODE == MODE_PATH && pass_rng && !R.alive) {
                 /* multi-pass render: the path ends here, its sampler lives on.  A lane that starts a loop iteration draws all six
                  * numbers of that iteration whether or not it survives it (symbolic dr::while_loop: unmasked draws, path.cpp:247,263-264,323) */
@@ -555,7 +639,14 @@ __global__ __launch_bounds__(kBlock, HAR_SHADE_MIN_WAVES) void k_shade(DScene S,
                 for (int k = 0; k < 6; ++k) r = r * HAR_PCG32_MULT + inc;
                 pass_rng[lane] = r;
             }
-            if (R.add_emission) {
+            if (R.add_emission && MODE == MODE_PRB_ADJOINT && INLINE) {
+                Lr = Vec3(Lr.x - R.em_b.x, Lr.y - R.em_b.y, Lr.z - R.em_b.z); L_dirty = true;
+                if (emitter_grads && R.em_index >= 0) {
+                    const Vec3 g = R.em_unit * dlr;
+                    if ((uint32_t) R.em_index < HAR_LDS_GRAD_EMITTERS) { float *a = eacc + 3 * R.em_index; atomicAdd(a, g.x); atomicAdd(a + 1, g.y); atomicAdd(a + 2, g.z); }
+                    else { float *a = grad_slots + 3 * ((size_t) S.n_bsdfs + R.em_index); atomicAdd(a, g.x); atomicAdd(a + 1, g.y); atomicAdd(a + 2, g.z); }
+                }
+            } else if (R.add_emission) {
                 float4 r = result[lane];
                 if (MODE == MODE_PATH)            r = make_float4(fma_(R.em_a.x, R.em_b.x, r.x), fma_(R.em_a.y, R.em_b.y, r.y), fma_(R.em_a.z, R.em_b.z, r.z), 0.f);
                 else if (MODE == MODE_PRB_PRIMAL) r = make_float4(r.x + R.em_b.x, r.y + R.em_b.y, r.z + R.em_b.z, 0.f);
@@ -579,15 +670,15 @@ __global__ __launch_bounds__(kBlock, HAR_SHADE_MIN_WAVES) void k_shade(DScene S,
             const bool fact = item_pred && R.nee_emitter >= 0 && (uint32_t) R.nee_emitter < HAR_ITEM_NO_EMITTER;
             const Vec3 c = fact ? R.contrib_unit : R.contrib;
             const uint32_t tag = (R.bsdf & 0xfffffu) | ((fact ? (uint32_t) R.nee_emitter : HAR_ITEM_NO_EMITTER) << 20) | (R.ind_active ? 0x80000000u : 0u);
-            const bool visible = item_pred && R.item_ray && rc.vis[lane] != 0;
+            const bool visible = item_pred && R.item_ray && rc.vis[tape_read ? i : lane] != 0;      /* the tape's visibility bytes are per vertex slot */
             TexelRecord rec; rec.has = false;
-            adjoint_commit_values(S, item_pred, visible, lane, make_float4(c.x, c.y, c.z, __uint_as_float(tag)), make_float4(R.dLr_drho.x, R.dLr_drho.y, R.dLr_drho.z, R.uv_x),
-                                  make_float4(R.rel_grad.x, R.rel_grad.y, R.rel_grad.z, R.uv_y), result, dL, grad_slots, grad_tex, gacc,      /* forward mode never commits in place (host) */
-                                  tq.nq ? &tq : nullptr, tq.nq ? &rec : nullptr);
+            adjoint_commit_regs(S, item_pred, visible, make_float4(c.x, c.y, c.z, __uint_as_float(tag)), make_float4(R.dLr_drho.x, R.dLr_drho.y, R.dLr_drho.z, R.uv_x),
+                                make_float4(R.rel_grad.x, R.rel_grad.y, R.rel_grad.z, R.uv_y), Lr, L_dirty, dlr, grad_slots, grad_tex, gacc,      /* forward mode never commits in place (host) */
+                                tq.nq ? &tq : nullptr, tq.nq ? &rec : nullptr);
             if (EXTRA && item_pred) {
-                /* the same two terms as for slot 0 (adjoint_commit_values), for the five other parameter groups: g = dL * ([visible] d Lr_dir / d theta
+                /* the same two terms as for slot 0 (adjoint_commit_regs), for the five other parameter groups: g = dL * ([visible] d Lr_dir / d theta
                  * + [path continues] L * (d f / d theta) / f), with L already reduced by this vertex's Lr_dir */
-                const float4 L = result[lane], dl = dL[lane];
+                const Vec3 L = Lr, dl = dlr;
                 for (int g = 0; g < HAR_EXTRA_GROUPS; ++g) {
                     Vec3 v = visible ? R.x_dir[g] : Vec3(0.f);
                     if (R.x_ind) v = v + Vec3(L.x * R.x_rel[g].x, L.y * R.x_rel[g].y, L.z * R.x_rel[g].z);
@@ -596,6 +687,13 @@ __global__ __launch_bounds__(kBlock, HAR_SHADE_MIN_WAVES) void k_shade(DScene S,
                     if (R.bsdf < HAR_LDS_EXTRA_BSDFS) { float *a = xacc + 15 * R.bsdf + 3 * g; atomicAdd(a, v.x); atomicAdd(a + 1, v.y); atomicAdd(a + 2, v.z); }
                     else { float *a = grad_extra + 15 * (size_t) R.bsdf + 3 * g; atomicAdd(a, v.x); atomicAdd(a + 1, v.y); atomicAdd(a + 2, v.z); }
                 }
+            }
+            /* write-back: replay -> the survivor's slot of the next bounce (the primal pass's compaction, TapeArrays::next); otherwise the lane's result */
+            if (in_range) {
+                if (tape_read) {
+                    const uint32_t nx = R.alive ? tape.next[i] : 0xffffffffu;
+                    if (nx != 0xffffffffu) { tape.la_out[nx] = make_float4(Lr.x, Lr.y, Lr.z, dlr.x); tape.lb_out[nx] = make_float2(dlr.y, dlr.z); }
+                } else if (L_dirty) result[lane] = make_float4(Lr.x, Lr.y, Lr.z, 0.f);
             }
             item_pred = false;
             if (tq.nq) {
@@ -619,9 +717,10 @@ __global__ __launch_bounds__(kBlock, HAR_SHADE_MIN_WAVES) void k_shade(DScene S,
             }
         }
         const bool alive = in_range && R.alive, item = item_pred;
-        uint32_t slot, islot;
-        block_reserve2(cnt_alive, alive, cnt_item, item, lds_r, slot, islot);
-        if (alive) store_state(out, Q.base + slot, R.next);
+        uint32_t slot = 0, islot = 0;
+        if (!tape_read) block_reserve2(cnt_alive, alive, cnt_item, item, lds_r, slot, islot);      /* tape replay: the primal pass's slots stand, nothing is stored */
+        if (alive && !tape_read) store_state(out, Q.base + slot, R.next);
+        if (MODE == MODE_PRB_PRIMAL && rc.mode == 3 && in_range) tape.next[i] = alive ? Q.base + slot : 0xffffffffu;
         if (item) {
             islot += Q.base;
             items.s0[islot] = make_float4(R.sh_o.x, R.sh_o.y, R.sh_o.z, R.item_ray ? R.sh_maxt : -1.f);
@@ -632,7 +731,7 @@ __global__ __launch_bounds__(kBlock, HAR_SHADE_MIN_WAVES) void k_shade(DScene S,
                 const Vec3 c = fact ? R.contrib_unit : R.contrib;
                 const uint32_t tag = (R.bsdf & 0xfffffu) | ((fact ? (uint32_t) R.nee_emitter : HAR_ITEM_NO_EMITTER) << 20) | (R.ind_active ? 0x80000000u : 0u);
                 items.s2[islot] = make_float4(c.x, c.y, c.z, __uint_as_float(tag));
-            } else items.s2[islot] = make_float4(R.contrib.x, R.contrib.y, R.contrib.z, 0.f);
+            } else items.s2[islot] = make_float4(R.contrib.x, R.contrib.y, R.contrib.z, __uint_as_float(i));      /* .w: the vertex slot (tape: where k_resolve files the visibility) */
             if (MODE == MODE_PRB_ADJOINT) {
                 items.s3[islot] = make_float4(R.dLr_drho.x, R.dLr_drho.y, R.dLr_drho.z, R.uv_x);
                 items.s4[islot] = make_float4(R.rel_grad.x, R.rel_grad.y, R.rel_grad.z, R.uv_y);
@@ -759,7 +858,8 @@ __global__ __launch_bounds__(kBlock, HAR_TRACE_MIN_WAVES) void k_resolve(DScene 
         trace_persistent<true, false, WaveStack>(S.accel, cursor + shard * HAR_COUNTER_STRIDE, n, stack, status, take,
             [&](uint32_t idx, const Traversal<HAR_TRAV_POLICY> &T) {
                 const uint32_t i = base + idx;
-                if (rc.mode == 1) rc.vis[__float_as_uint(items.s1[i].w)] = T.found ? 0 : 1;      /* replay cache */
+                if (rc.mode == 1) rc.vis[__float_as_uint(items.s1[i].w)] = T.found ? 0 : 1;      /* replay cache: per lane */
+                else if (rc.mode == 3) rc.vis[__float_as_uint(items.s2[i].w)] = T.found ? 0 : 1; /* replay tape: per vertex slot */
                 if (!T.found) {
                     const uint32_t lane = __float_as_uint(items.s1[i].w);
                     float4 s2 = items.s2[i], r = result[lane];
@@ -1191,24 +1291,47 @@ void launch_trace_closest(hipStream_t s, uint32_t grid, uint2 *spill, const Acce
 void launch_shade(int mode, hipStream_t s, uint32_t grid, const DScene &S, const ShadeParams &P, uint32_t lane_base, uint32_t shard_cap, const uint32_t *count_in,
                   const WaveState &in, const float4 *h0, const uint2 *h1, const WaveState &out, uint32_t *count_out, const ItemArrays &items,
                   uint32_t *item_count, float4 *result, const ReplayCache &rc, uint64_t *pass_rng, const float4 *dL, float *grad_slots, const ShapeArrays *geo,
-                  float *const *grad_tex, const TexelQueues *tq_in, float *grad_extra) {
+                  float *const *grad_tex, const TexelQueues *tq_in, float *grad_extra, const MaterialQueues *mq_in, uint32_t mat_class, const TapeArrays *tape_in) {
     dim3 g(grid), b(kBlock);
     const ShapeArrays no_geo{ nullptr, nullptr, nullptr, nullptr, nullptr };
     const TexelQueues no_tq{ nullptr, nullptr, nullptr, nullptr, 0u, 0u };
     const TexelQueues tq = tq_in ? *tq_in : no_tq;
+    const MaterialQueues no_mq{ nullptr, nullptr, 0u, 0u };
+    const TapeArrays tape = tape_in ? *tape_in : TapeArrays{ nullptr, nullptr, nullptr, nullptr, nullptr };
+    if (mq_in && mode != MODE_PRB_ADJOINT) {
+        /* one material class: the kernel of that BSDF model (TYPES = its bit | HAR_BSDF_QUEUED), the generic classic / all-model kernel for twosided pairs of two models */
+        const MaterialQueues mq = *mq_in;
+        const bool classic = (S.bsdf_types & 0x7fffffffu & ~HAR_BSDF_CLASSIC_TYPES) == 0u;
+#define HAR_LAUNCH_SHADE_Q(M, T) hipLaunchKernelGGL((k_shade<M, T, false, false, false, true>), g, b, 0, s, S, P, lane_base, shard_cap, count_in, in, h0, h1, out, count_out, items, item_count, result, rc, pass_rng, dL, grad_slots, no_geo, nullptr, no_tq, nullptr, mq, mat_class, tape)
+#define HAR_LAUNCH_SHADE_Q_MODE(M) do { switch (mat_class) { \
+            case BSDF_DIFFUSE:        HAR_LAUNCH_SHADE_Q(M, (1u << BSDF_DIFFUSE) | HAR_BSDF_QUEUED); break; \
+            case BSDF_DIELECTRIC:     HAR_LAUNCH_SHADE_Q(M, (1u << BSDF_DIELECTRIC) | HAR_BSDF_QUEUED); break; \
+            case BSDF_ROUGHCONDUCTOR: HAR_LAUNCH_SHADE_Q(M, (1u << BSDF_ROUGHCONDUCTOR) | HAR_BSDF_QUEUED); break; \
+            case BSDF_ROUGHPLASTIC:   HAR_LAUNCH_SHADE_Q(M, (1u << BSDF_ROUGHPLASTIC) | HAR_BSDF_QUEUED); break; \
+            case BSDF_CONDUCTOR:      HAR_LAUNCH_SHADE_Q(M, (1u << BSDF_CONDUCTOR) | HAR_BSDF_QUEUED); break; \
+            case BSDF_PLASTIC:        HAR_LAUNCH_SHADE_Q(M, (1u << BSDF_PLASTIC) | HAR_BSDF_QUEUED); break; \
+            default: if (classic) HAR_LAUNCH_SHADE_Q(M, HAR_BSDF_CLASSIC_TYPES | HAR_BSDF_QUEUED); else HAR_LAUNCH_SHADE_Q(M, HAR_BSDF_ALL_TYPES | HAR_BSDF_QUEUED); break; } } while (0)
+        if (mode == MODE_PATH) HAR_LAUNCH_SHADE_Q_MODE(MODE_PATH); else HAR_LAUNCH_SHADE_Q_MODE(MODE_PRB_PRIMAL);
+#undef HAR_LAUNCH_SHADE_Q_MODE
+#undef HAR_LAUNCH_SHADE_Q
+        return;
+    }
     if (geo && mode == MODE_PRB_ADJOINT) {        /* vertex-position gradients: scenes of `diffuse` BSDFs, plain or `twosided` (checked by har_integrator_set_grad_positions) */
         if (S.bsdf_types == HAR_BSDF_ONLY_DIFFUSE)
             hipLaunchKernelGGL((k_shade<MODE_PRB_ADJOINT, HAR_BSDF_ONLY_DIFFUSE, true>), g, b, 0, s, S, P, lane_base, shard_cap, count_in, in, h0, h1, out, count_out, items, item_count,
-                               result, rc, pass_rng, dL, grad_slots, *geo, grad_tex, no_tq, nullptr);
+                               result, rc, pass_rng, dL, grad_slots, *geo, grad_tex, no_tq, nullptr, no_mq, 0u, tape);
+        else if ((S.bsdf_types & 0x7fffffffu & ~HAR_BSDF_CLASSIC_TYPES) != 0u)      /* `conductor` / `plastic` records somewhere in the scene */
+            hipLaunchKernelGGL((k_shade<MODE_PRB_ADJOINT, HAR_BSDF_ALL_TYPES, true>), g, b, 0, s, S, P, lane_base, shard_cap, count_in, in, h0, h1, out, count_out, items, item_count,
+                               result, rc, pass_rng, dL, grad_slots, *geo, grad_tex, no_tq, nullptr, no_mq, 0u, tape);
         else
             hipLaunchKernelGGL((k_shade<MODE_PRB_ADJOINT, HAR_BSDF_CLASSIC_TYPES, true>), g, b, 0, s, S, P, lane_base, shard_cap, count_in, in, h0, h1, out, count_out, items, item_count,
-                               result, rc, pass_rng, dL, grad_slots, *geo, grad_tex, no_tq, nullptr);
+                               result, rc, pass_rng, dL, grad_slots, *geo, grad_tex, no_tq, nullptr, no_mq, 0u, tape);
         return;
     }
-    if (grad_tex && mode == MODE_PRB_ADJOINT && rc.mode == 2) {       /* cached bounce of the adjoint replay: commit in place (see k_shade) */
+    if (grad_tex && mode == MODE_PRB_ADJOINT && (rc.mode == 2 || rc.mode == 4)) {       /* cached / taped bounce of the adjoint replay: commit in place (see k_shade) */
         const bool env = (S.bsdf_types & HAR_SCENE_ENVMAP) != 0u, diffuse = S.bsdf_types == HAR_BSDF_ONLY_DIFFUSE, cls = (S.bsdf_types & 0x7fffffffu & ~HAR_BSDF_CLASSIC_TYPES) == 0u;
-#define HAR_LAUNCH_SHADE_INLINE(T) hipLaunchKernelGGL((k_shade<MODE_PRB_ADJOINT, T, false, true>), g, b, 0, s, S, P, lane_base, shard_cap, count_in, in, h0, h1, out, count_out, items, item_count, result, rc, pass_rng, dL, grad_slots, no_geo, grad_tex, tq, nullptr)
-#define HAR_LAUNCH_SHADE_EXTRA(T) hipLaunchKernelGGL((k_shade<MODE_PRB_ADJOINT, T, false, true, true>), g, b, 0, s, S, P, lane_base, shard_cap, count_in, in, h0, h1, out, count_out, items, item_count, result, rc, pass_rng, dL, grad_slots, no_geo, grad_tex, tq, grad_extra)
+#define HAR_LAUNCH_SHADE_INLINE(T) hipLaunchKernelGGL((k_shade<MODE_PRB_ADJOINT, T, false, true>), g, b, 0, s, S, P, lane_base, shard_cap, count_in, in, h0, h1, out, count_out, items, item_count, result, rc, pass_rng, dL, grad_slots, no_geo, grad_tex, tq, nullptr, no_mq, 0u, tape)
+#define HAR_LAUNCH_SHADE_EXTRA(T) hipLaunchKernelGGL((k_shade<MODE_PRB_ADJOINT, T, false, true, true>), g, b, 0, s, S, P, lane_base, shard_cap, count_in, in, h0, h1, out, count_out, items, item_count, result, rc, pass_rng, dL, grad_slots, no_geo, grad_tex, tq, grad_extra, no_mq, 0u, tape)
         if (grad_extra && !diffuse) {         /* gradients w.r.t. alpha / eta / k / slot 1: the generic shading code with the extra derivative terms */
             if (env) HAR_LAUNCH_SHADE_EXTRA(HAR_BSDF_ALL_TYPES | HAR_SCENE_ENVMAP); else HAR_LAUNCH_SHADE_EXTRA(HAR_BSDF_ALL_TYPES);
             return;
@@ -1221,7 +1344,7 @@ void launch_shade(int mode, hipStream_t s, uint32_t grid, const DScene &S, const
     }
     /* diffuse-only scenes (no twosided wrappers) run kernels in which the other BSDF models are compiled out */
     const bool only_diffuse = S.bsdf_types == HAR_BSDF_ONLY_DIFFUSE;
-#define HAR_LAUNCH_SHADE(M, T) hipLaunchKernelGGL((k_shade<M, T>), g, b, 0, s, S, P, lane_base, shard_cap, count_in, in, h0, h1, out, count_out, items, item_count, result, rc, pass_rng, dL, grad_slots, no_geo, nullptr, no_tq, nullptr)
+#define HAR_LAUNCH_SHADE(M, T) hipLaunchKernelGGL((k_shade<M, T>), g, b, 0, s, S, P, lane_base, shard_cap, count_in, in, h0, h1, out, count_out, items, item_count, result, rc, pass_rng, dL, grad_slots, no_geo, nullptr, no_tq, nullptr, no_mq, 0u, tape)
     const bool envmap = (S.bsdf_types & HAR_SCENE_ENVMAP) != 0u;      /* generic BSDF code + environment-map sampling / lookup */
     const bool classic = (S.bsdf_types & 0x7fffffffu & ~HAR_BSDF_CLASSIC_TYPES) == 0u;
 #define HAR_LAUNCH_SHADE_MODE(M) do { if (envmap) HAR_LAUNCH_SHADE(M, HAR_BSDF_ALL_TYPES | HAR_SCENE_ENVMAP); else if (only_diffuse) HAR_LAUNCH_SHADE(M, HAR_BSDF_ONLY_DIFFUSE); else if (classic) HAR_LAUNCH_SHADE(M, HAR_BSDF_CLASSIC_TYPES); else HAR_LAUNCH_SHADE(M, HAR_BSDF_ALL_TYPES); } while (0)
@@ -1230,6 +1353,13 @@ void launch_shade(int mode, hipStream_t s, uint32_t grid, const DScene &S, const
     else                              HAR_LAUNCH_SHADE_MODE(MODE_PRB_ADJOINT);
 #undef HAR_LAUNCH_SHADE_MODE
 #undef HAR_LAUNCH_SHADE
+}
+void launch_tape_begin(hipStream_t s, const DSensor &C, uint32_t seed, uint32_t spp, uint32_t log_spp, uint32_t lane_base, uint32_t n, uint32_t shard_cap,
+                       const float4 *result, const float *adj, float4 *la, float2 *lb) {
+    hipLaunchKernelGGL(k_tape_begin, dim3(blocks_for(n)), dim3(kBlock), 0, s, C, seed, spp, log_spp, lane_base, n, shard_cap, result, adj, la, lb);
+}
+void launch_classify(hipStream_t s, uint32_t grid, const DScene &S, uint32_t shard_cap, const uint32_t *count_in, const float4 *h0, const uint2 *h1, const MaterialQueues &mq) {
+    hipLaunchKernelGGL(k_classify, dim3(grid), dim3(kBlock), 0, s, S, shard_cap, count_in, h0, h1, mq);
 }
 void launch_texel_accumulate(hipStream_t s, const TexelQueues &tq, float *const *grad_tex, uint32_t bpq, uint32_t lds_bytes) {
     hipLaunchKernelGGL(k_texel_accumulate, dim3(HAR_SHARDS * tq.nq * bpq), dim3(kBlock), lds_bytes, s, tq, grad_tex, bpq);

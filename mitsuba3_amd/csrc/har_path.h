@@ -169,10 +169,12 @@ HAR_HD void shade_lane(const DScene &S, const ShadeParams &P, const PathState &s
     /* ---- emitter sampling (path.cpp:238-258, prb.py:163-175; scene.cpp:316-366).  The two samples are drawn by
      * every active lane; only BSDFs with a Smooth lobe use them (path.cpp:237, prb.py:169) */
     float ex = 0.f, ey = 0.f;
-    if (!(P.flags & HAR_SHADE_SCALAR_DRAWS) || TYPES == HAR_BSDF_ONLY_DIFFUSE || bsdf_is_smooth(B)) { ex = pcg32_next_float(rng, inc); ey = pcg32_next_float(rng, inc); }
+    /* BSDFFlags::Smooth of the record: a compile-time constant in the kernels of a single-model material queue */
+    const bool smooth = HAR_BSDF_SINGLE(TYPES) ? (HAR_BSDF_SINGLE_TYPE(TYPES) != (uint32_t) BSDF_DIELECTRIC && HAR_BSDF_SINGLE_TYPE(TYPES) != (uint32_t) BSDF_CONDUCTOR) : bsdf_is_smooth(B);
+    if (!(P.flags & HAR_SHADE_SCALAR_DRAWS) || smooth) { ex = pcg32_next_float(rng, inc); ey = pcg32_next_float(rng, inc); }
     DirSample ds; ds.pdf = 0.f; ds.d = Vec3(0.f); ds.p = Vec3(0.f); ds.n = Vec3(0.f); ds.dist = 0.f;
     Vec3 em_weight(0.f); float em_unit = 0.f; uint32_t em_sampled = 0;
-    bool active_em = active_next && S.n_emitters > 0 && (TYPES == HAR_BSDF_ONLY_DIFFUSE || bsdf_is_smooth(B));
+    bool active_em = active_next && S.n_emitters > 0 && smooth;
     if (active_em) {
         uint32_t index = 0; float wgt = 1.f;
         if (S.n_emitters > 1) {                                  /* sample_emitter, scene.cpp:248-271 */

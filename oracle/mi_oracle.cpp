@@ -1054,9 +1054,11 @@ static V3 prb_sample(const Scene &sc, Pcg32 &rng, Ray ray, uint32_t max_depth, u
                                                        wol.x, wol.y, wol.z, dwo[0][0], f[0], Lc[0], dl[0]);
             }
         }
-        if (!primal && grad && grad->shape && si.valid() && bsdf.rec) {
+        if (!primal && grad && grad->shape && si.valid() && bsdf.rec && bsdf.rec->p.type == 0) {
             /* prb.py:124-141 (attached si), :176-216 (emitter sampling with the attached shading point), :261-297 (attached wo, J):
-               d/d(vertex positions) of  Lr_dir + Lr_ind  for a `diffuse` BSDF, f * cos = rho(uv) / pi * cos_theta_o */
+               d/d(vertex positions) of  Lr_dir + Lr_ind  for a `diffuse` BSDF, f * cos = rho(uv) / pi * cos_theta_o.
+               The shape terms exist only at vertices whose own triangle is attached (attach_si: a.diff), so the restriction to `diffuse` concerns the
+               DIFFERENTIATED meshes (checked by the driver); vertices on other meshes, whatever their BSDF, contribute nothing here */
             const ShapeSink &sk = *grad->shape;
             AttachedSI a = attach_si(sc, ray, pi, si, sk.mask, 0, true, sk.inst_mask);
             Dn3 rho = bsdf.textured ? tex_eval_dual(sc.textures[bsdf.rec->p.texture], bsdf.tl, a.uv) : dn3(bsdf.slot0);
@@ -1555,10 +1557,20 @@ static int prb_backward_impl(void *scene, const OrcSensor *sp, const float *grad
                              uint64_t lb = 0, uint64_t le = 0, const float *weight_film = nullptr, float *grad_bsdf_params = nullptr,
                              const uint8_t *inst_mask = nullptr, double *grad_to_world = nullptr) {
     Scene &sc = *(Scene *) scene; const OrcSensor &s = *sp;
-    if (inst_mask) for (const BsdfRecord &b : sc.bsdfs) if (b.p.type != 0) return -2;
-    if (pos_mask) {           /* the attached-geometry restatement covers `diffuse` BSDFs on flat-shaded top-level meshes */
-        for (const BsdfRecord &b : sc.bsdfs) if (b.p.type != 0) return -2;           /* `diffuse`, plain or inside `twosided` */
-        for (size_t m = 0; m < sc.meshes.size(); ++m) if (pos_mask[m] && ((sc.meshes[m].flags & 1u) || m >= sc.top_count)) return -3;
+    /* the attached-geometry restatement evaluates the `diffuse` model at attached vertices: the MOVING meshes (the masked ones; the meshes of the
+     * shape groups for instance transforms) must carry `diffuse` BSDFs, plain or inside `twosided`; every other mesh may carry any model */
+    auto diffuse_record = [&](int32_t k) {
+        if (k < 0 || (size_t) k >= sc.bsdfs.size()) return false;
+        const BsdfRecord &b = sc.bsdfs[(size_t) k];
+        return b.p.type == 0 && (b.p.back < 0 || sc.bsdfs[(size_t) b.p.back].p.type == 0);
+    };
+    if (inst_mask) for (size_t m = sc.top_count; m < sc.meshes.size(); ++m) if (!diffuse_record((int32_t) sc.meshes[m].bsdf)) return -2;
+    if (pos_mask) {           /* flat-shaded top-level meshes */
+        for (size_t m = 0; m < sc.meshes.size(); ++m) {
+            if (!pos_mask[m]) continue;
+            if (!diffuse_record((int32_t) sc.meshes[m].bsdf)) return -2;
+            if ((sc.meshes[m].flags & 1u) || m >= sc.top_count) return -3;
+        }
     }
     uint64_t total = sample_grid_pixels(s) * spp;
     if (total > 0xffffffffull) return -1;

@@ -189,9 +189,9 @@ float hh_rfilter_eval(const HarSensor *sensor, float x) {
 static int backward_shape_impl(void *h, const HarSensor *sensor, const float *adj, uint32_t seed, uint32_t spp, int32_t max_depth, int32_t rr_depth,
                                double *const *grad, double *inst_grad) {
     HScene *H = (HScene *) h; const DScene &S = H->ds;
-    if ((S.bsdf_types & 0x7fffffffu) != HAR_BSDF_ONLY_DIFFUSE) return -2;
+    /* the moving meshes must be diffuse (checked by the callers / the C entry points); the rest of the scene is shaded by the generic code */
     DSensor C; std::string e; if (!lower_sensor(*sensor, C, e)) return -1;
-    const uint64_t total = (uint64_t) C.crop_w * C.crop_h * spp;
+    const uint64_t total = (uint64_t) C.samp_w * C.samp_h * spp;
     uint32_t log_spp = 0xffffffffu; for (uint32_t k = 0; k < 32; ++k) if ((1u << k) == spp) log_spp = k;
     ShadeParams P{ seed, (uint32_t) max_depth, (uint32_t) rr_depth };
     int status = 0;
@@ -209,7 +209,7 @@ static int backward_shape_impl(void *h, const HarSensor *sensor, const float *ad
             PathState st = st0; bool alive = P.max_depth != 0;
             while (alive) {
                 Hit hit; HostStack stack; accel_trace<false>(S.accel, st.o, st.d, st.maxt, hit, stack, status);
-                ShadeResult R; shade_lane<MODE_PRB_PRIMAL, HAR_BSDF_CLASSIC_TYPES>(S, P, st, hit, R);
+                ShadeResult R; shade_lane<MODE_PRB_PRIMAL, HAR_BSDF_ALL_TYPES>(S, P, st, hit, R);
                 if (R.add_emission) L = L + R.em_b;
                 if (R.item && R.item_ray) { Hit sh; HostStack s2; if (!accel_trace<true>(S.accel, R.sh_o, R.sh_d, R.sh_maxt, sh, s2, status)) L = L + R.contrib; }
                 alive = R.alive; st = R.next;
@@ -219,7 +219,7 @@ static int backward_shape_impl(void *h, const HarSensor *sensor, const float *ad
         PathState st = st0; bool alive = P.max_depth != 0;
         Hit hit; { HostStack stack; if (alive) accel_trace<false>(S.accel, st.o, st.d, st.maxt, hit, stack, status); }
         while (alive) {
-            ShadeResult R; shade_lane<MODE_PRB_ADJOINT, HAR_BSDF_CLASSIC_TYPES>(S, P, st, hit, R);
+            ShadeResult R; shade_lane<MODE_PRB_ADJOINT, HAR_BSDF_ALL_TYPES>(S, P, st, hit, R);
             if (R.add_emission) L = L - R.em_b;
             bool visible = false;
             if (R.item && R.item_ray) { Hit sh; HostStack s2; visible = !accel_trace<true>(S.accel, R.sh_o, R.sh_d, R.sh_maxt, sh, s2, status); if (visible) L = L - R.contrib; }
@@ -311,7 +311,7 @@ int hh_trace_stats(void *h, const HarSensor *sensor, uint32_t seed, uint32_t spp
     int status = 0;
     for (uint32_t b = 0; b < max_bounces && !cur.empty(); ++b) {
         double *o = out + 32 * b;
-        struct Sh { Vec3 o, d; float maxt; };
+        struct Sh { Vec3 o, d; float maxt; uint32_t pixel; };
         std::vector<Sh> shadow; next.clear();
         auto account = [&](std::vector<std::vector<uint32_t>> &evs, double *q) {
             size_t n = evs.size();
@@ -409,7 +409,7 @@ int hh_trace_stats(void *h, const HarSensor *sensor, uint32_t seed, uint32_t spp
         account(evs, o);
         for (size_t i = 0; i < cur.size(); ++i) {
             ShadeResult R; shade_lane<MODE_PATH>(S, P, cur[i], hits[i], R);
-            if (R.item && R.item_ray) shadow.push_back(Sh{ R.sh_o, R.sh_d, R.sh_maxt });
+            if (R.item && R.item_ray) shadow.push_back(Sh{ R.sh_o, R.sh_d, R.sh_maxt, cur[i].lane / spp });
             if (R.alive) next.push_back(R.next);
         }
         if (sort_mode && !shadow.empty()) {
@@ -436,6 +436,17 @@ int hh_trace_stats(void *h, const HarSensor *sensor, uint32_t seed, uint32_t spp
             }
             /* occluded vs unoccluded shadow rays: count and node visits of the occluded ones (slots 27 / 28) */
             if (f1) { o[27] += 1; for (uint32_t x : sev[i]) o[28] += x & 1u; }
+            /* occluder-cache what-if: is the occluder of this ray the one that occluded the pixel's previous occluded shadow ray of this bounce?
+             * slot 29: same instance (upper bound of a cache's hit rate), slot 30: same triangle (lower bound) */
+            if (f1) {
+                static std::vector<Hit> last; static uint32_t last_bounce = 0xffffffffu;
+                if (last_bounce != b) { last.assign((size_t) C.samp_w * C.samp_h, Hit{ HAR_INF, 0.f, 0.f, 0u, 0u, 0u }); last_bounce = b; }
+                Hit occ; { HostStack s3; int st3 = 0; accel_trace<false>(S.accel, shadow[i].o, shadow[i].d, shadow[i].maxt, occ, s3, st3); }      /* any-hit reports no identity: take the nearest occluder */
+                hh = occ;
+                Hit &L = last[shadow[i].pixel];
+                if (L.t != HAR_INF) { if (L.inst == hh.inst && L.shape == hh.shape) { o[29] += 1; if (L.prim == hh.prim) o[30] += 1; } }
+                L = hh; L.t = 1.f;
+            }
         }
         g_host_child_order = 0;
         account(sev, o + 16);

@@ -375,14 +375,18 @@ def test_mi_render_autograd_new_parameter_kinds(mi, O):
     img = mi.render(scene, params, spp=spp, seed=3)
     loss = ((img - target) ** 2).mean(); loss.backward()
     ga, ge = params["white.alpha.value"].grad.clone(), params["green.eta.value"].grad.clone()
-    assert scene.integrator().bsdf_parameter_gradients and ga.abs().max() > 0 and ge.abs().max() > 0
+    assert ga.abs().max() > 0 and ge.abs().max() > 0
+    # the adjoint terms were switched on for THAT backward pass only: the caller's integrator keeps its properties (round-2 advisor finding)
+    assert not scene.integrator().bsdf_parameter_gradients and not scene.integrator().shape_gradients
     adj = (2.0 * (img.detach() - target) / img.numel())
+    scene.integrator().bsdf_parameter_gradients = True                  # the explicit route asks for them itself
     # the same numbers through the explicit route (seed_grad = TEA32(seed, 1)[0], util.py:render)
     from mitsuba3_amd.core import sample_tea_32
     _seed_grad = lambda seed: sample_tea_32(seed, 1)[0]
     grads = scene.integrator().render_backward(scene, None, adj, seed=_seed_grad(3), spp=spp)
     assert torch.allclose(grads["white.alpha.value"].reshape(-1), ga.reshape(-1), rtol=1e-4, atol=1e-9)
     assert torch.allclose(grads["green.eta.value"].reshape(-1), ge.reshape(-1), rtol=1e-4, atol=1e-9)
+    scene.integrator().bsdf_parameter_gradients = False
     # rougher than the target: the gradient points towards smaller alpha
     assert float(ga.reshape(-1)[0]) > 0
 
@@ -397,6 +401,13 @@ def test_mi_render_autograd_new_parameter_kinds(mi, O):
     osc, sensor = O.scene_from_product(scene)
     want, _, _, _ = osc.render_prb_backward_instances(sensor, np.ones((24, 24, 3), np.float32), None, seed=_seed_grad(1), spp=16, max_depth=5)
     assert np.abs(g.cpu().numpy()[:3] - want[0]).max() < 2e-3 * np.abs(want[0]).max()
+    # ... and with the SAME integrator a colour afterwards: the transform's adjoint terms are not left switched on
+    assert not scene.integrator().shape_gradients
+    params["inst000.to_world"].requires_grad_(False)
+    ckey = next(k for k, v in scene._param_keys().items() if v[0] == "rgb")
+    params[ckey].requires_grad_(True)
+    mi.render(scene, params, spp=16, seed=1).sum().backward()
+    assert params[ckey].grad.abs().max() > 0
 
 
 # ------------------------------------------------------------------ ray queries on adversarial triangle soups

@@ -138,6 +138,36 @@ def test_materials_1m_scene_512_forward_and_gradients(mi, O):
             assert rel_l2(grads[key].cpu().numpy().reshape(-1), g_refl[b.index]) < 1e-3, key
 
 
+def test_material_queues_equal_the_generic_kernel(mi, O):
+    """per-material shading queues (har_integrator_set_material_queues: k_classify + one k_shade launch per BSDF model) against the default generic
+    kernel and the oracle: same paths, same vertex count, images equal up to the order of the film's float atomics; `path` and the primal pass of
+    `prb` (whose hits feed the replay cache), on a scene with four models + a twosided conductor + escaping rays"""
+    res, spp = 192, 8
+    d = mi.instanced_spheres_scene(width=res, height=res, spp=spp, flatten=True, materials=True, grid=6, n_u=24, n_v=12)
+    d["sky"] = {"type": "constant", "radiance": {"type": "rgb", "value": [0.2, 0.3, 0.5]}}
+    d.pop("ceiling", None)                                                   # let paths escape: the miss class
+    scene = mi.load_dict(d)
+    osc, sensor = O.scene_from_product(scene)
+    ref, st = osc.render_path(sensor, seed=3, spp=spp, max_depth=8)
+    imgs = {}
+    for on in (False, True):
+        integ = mi.load_dict({"type": "path", "max_depth": 8, "material_queues": on})
+        imgs[on] = mi.render(scene, integrator=integ, spp=spp, seed=3).cpu().numpy()
+        gst = integ.stats()
+        assert gst["paths"] == st.paths and abs(gst["vertices"] - st.vertices) <= 1e-5 * st.vertices
+        assert rel_l2(imgs[on], ref) < 1e-4
+    assert rel_l2(imgs[True], imgs[False]) < 1e-6
+    grad_in = np.random.default_rng(2).uniform(0.5, 1.5, (res, res, 3)).astype(np.float32) / (res * res * 3)
+    g = {}
+    for on in (False, True):
+        integ = mi.load_dict({"type": "prb", "max_depth": 6, "material_queues": on})
+        g[on] = integ.render_backward(scene, None, grad_in, seed=5, spp=spp)
+    for k in g[False]:
+        a, b = g[False][k].cpu().numpy(), g[True][k].cpu().numpy()
+        if np.abs(a).max() > 0:
+            assert rel_l2(b, a) < 1e-4, k
+
+
 # ------------------------------------------------------------------ N1 (ii): PRB gradients on the instanced scene with a bitmap albedo
 
 def test_prb_gradients_instanced_textured(mi, O):

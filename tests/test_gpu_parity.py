@@ -680,15 +680,17 @@ def _grid_floor(mi, d, n):
     return d
 
 
-@pytest.mark.parametrize("which", ["slab", "slab_textured", "slab_env", "slab_twosided", "slab_crop_box", "cbox", "cbox_grid", "cbox_nocache"])
+@pytest.mark.parametrize("which", ["slab", "slab_textured", "slab_env", "slab_twosided", "slab_crop_box", "cbox", "cbox_grid", "cbox_nocache", "slab_rough_conductor", "slab_rough_plastic"])
 def test_prb_vertex_position_gradients(mi, O, which):
     """har_integrator_set_grad_positions: the wavefront adjoint (k_shade<ADJOINT, SHAPE> geometry records, visibility from k_resolve,
     k_shape_adjoint with the next bounce's detached interaction) vs the oracle's dual-number restatement, vertex by vertex; the colour
     gradients of the same call must not change"""
     from tests.test_cpu_host import oracle_scene_from
-    from tests.test_shape_gradients_cpu import slab_scene, cbox_mesh_scene, twosided_slab_scene, mesh_index
+    from tests.test_shape_gradients_cpu import slab_scene, cbox_mesh_scene, twosided_slab_scene, rough_slab_scene, mesh_index
     if which == "slab_twosided":
         res = 24; d = twosided_slab_scene(mi, res); names = ["floor", "ceiling", "sheet"]
+    elif which.startswith("slab_rough"):      # a rough (not differentiated) ceiling: generic adjoint kernels around the diffuse floor's shape terms
+        res = 24; d = rough_slab_scene(mi, res, "roughconductor" if which.endswith("conductor") else "roughplastic"); names = ["floor"]
     elif which.startswith("cbox"):
         res = 32; d = cbox_mesh_scene(mi, res); names = ["small-box", "large-box", "floor"]
         if which == "cbox_grid":
@@ -758,11 +760,15 @@ def test_vertex_position_gradients_refused_outside_their_domain(mi):
     with pytest.raises(KeyError):
         scene.integrator().render_backward(scene, None, g, seed=0, spp=4)
     from tests.test_shape_gradients_cpu import slab_scene
+    # a rough mesh may be PART of the scene; asking for ITS vertex positions is refused, `True` selects the meshes the adjoint can differentiate
     d = slab_scene(mi, 16); d["ceiling"]["bsdf"] = {"type": "roughconductor", "alpha": 0.2}
-    d["integrator"] = {"type": "prb", "max_depth": 3, "shape_gradients": True}
+    d["integrator"] = {"type": "prb", "max_depth": 3, "shape_gradients": ["ceiling.vertex_positions"]}
     scene = mi.load_dict(d)
     with pytest.raises(RuntimeError, match="diffuse"):
         scene.integrator().render_backward(scene, None, g, seed=0, spp=4)
+    scene.integrator().shape_gradients = True
+    out = scene.integrator().render_backward(scene, None, g, seed=0, spp=4)
+    assert "floor.vertex_positions" in out and "ceiling.vertex_positions" not in out
 
 
 def test_hide_emitters_parity(mi, O):

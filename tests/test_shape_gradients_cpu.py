@@ -44,6 +44,17 @@ def slab_scene(mi, res=24, textured=False, env=False):
     return d
 
 
+def rough_slab_scene(mi, res=24, model="roughconductor"):
+    """the slab scene with a ROUGH ceiling (GGX conductor or rough plastic) that is not differentiated: the floor's vertex-position gradient has to
+    flow through paths that bounce off a non-diffuse surface (generic adjoint kernels) -- the shape terms themselves still live on the diffuse floor"""
+    d = slab_scene(mi, res)
+    if model == "roughconductor":
+        d["ceiling"]["bsdf"] = {"type": "roughconductor", "distribution": "ggx", "alpha": 0.35, "eta": [0.2, 0.92, 1.1], "k": [3.9, 2.45, 2.14]}
+    else:
+        d["ceiling"]["bsdf"] = {"type": "roughplastic", "alpha": 0.3, "diffuse_reflectance": {"type": "rgb", "value": [0.4, 0.6, 0.8]}}
+    return d
+
+
 def twosided_slab_scene(mi, res=16):
     """the slab scene with `twosided` diffuse BSDFs and a free-floating sheet whose geometric normal points away from the camera and the light:
     the camera and the emitter samples meet its BACK side (TwoSidedBRDF mirrors wo, twosided.cpp:124-127)"""
@@ -71,18 +82,18 @@ def directional_fd(osc, sensor, mesh, base, direction, weights, eps, **kw):
     return (sums[0] - sums[1]) / (2 * eps)
 
 
-@pytest.mark.parametrize("variant", ["plain", "textured", "env"])
+@pytest.mark.parametrize("variant", ["plain", "textured", "env", "rough_ceiling"])
 def test_oracle_shape_gradient_vs_finite_differences(mi, O, variant):
     """d/d(theta) sum(w * image) for rigid and non-rigid motions of the floor and of the ceiling.  The two sides are different estimators
     of the same derivative (PRB differentiates with the sampled directions held fixed in world space, a same-seed finite difference
     lets them follow the surface), so they agree in expectation: 1024 spp, 3 % tolerance"""
     from tests.test_cpu_host import oracle_scene_from
     res = 12
-    scene = mi.load_dict(slab_scene(mi, res, textured=variant == "textured", env=variant == "env"))
+    scene = mi.load_dict(rough_slab_scene(mi, res) if variant == "rough_ceiling" else slab_scene(mi, res, textured=variant == "textured", env=variant == "env"))
     osc, sensor = oracle_scene_from(O, scene)
     kw = dict(seed=7, spp=1024, max_depth=4)
     w = np.random.default_rng(2).uniform(0.5, 1.5, (res, res, 3)).astype(np.float32)
-    names = ["floor"] + ([] if variant == "env" else ["ceiling"])
+    names = ["floor"] + ([] if variant in ("env", "rough_ceiling") else ["ceiling"])       # a rough ceiling is part of the scene but not differentiated
     ids = [mesh_index(scene, n) for n in names]
     g_pos, _, _, _ = osc.render_prb_backward_shape(sensor, w, ids, **kw)
     motions = {"lift": np.tile([0, 1, 0], (4, 1)), "tilt": np.array([[0, -1, 0], [0, 1, 0], [0, 1, 0], [0, -1, 0]]),
@@ -136,7 +147,7 @@ def product_host_gradients(O, L, scene, sensor, grad_in, meshes, seed, spp, max_
     return g
 
 
-@pytest.mark.parametrize("which", ["slab", "slab_textured", "slab_env", "slab_twosided", "cbox"])
+@pytest.mark.parametrize("which", ["slab", "slab_textured", "slab_env", "slab_twosided", "cbox", "slab_rough_conductor", "slab_rough_plastic"])
 def test_product_host_adjoint_matches_oracle(mi, O, which):
     """har_shape_grad.h (hand-derived reverse mode, fp32) against the oracle's dual numbers (fp64), vertex by vertex, same seed"""
     from tests.test_cpu_host import oracle_scene_from
@@ -144,6 +155,8 @@ def test_product_host_adjoint_matches_oracle(mi, O, which):
         scene = mi.load_dict(cbox_mesh_scene(mi, 20)); names = ["small-box", "large-box", "floor"]; res = 20
     elif which == "slab_twosided":
         res = 16; scene = mi.load_dict(twosided_slab_scene(mi, res)); names = ["floor", "ceiling", "sheet"]
+    elif which.startswith("slab_rough"):
+        res = 16; scene = mi.load_dict(rough_slab_scene(mi, res, "roughconductor" if which.endswith("conductor") else "roughplastic")); names = ["floor"]
     else:
         res = 16
         scene = mi.load_dict(slab_scene(mi, res, textured=which == "slab_textured", env=which == "slab_env")); names = ["floor"] + ([] if which == "slab_env" else ["ceiling"])

@@ -9,7 +9,7 @@ import sys
 def short(name):
     m = re.search(r"har\d*(k_[a-z_]+)", name)
     base = m.group(1) if m else name.split("(")[0][:60]
-    t = re.search(r"ILi(\d+)(?:ELi(\d+))?", name)
+    t = re.search(r"ILi(\d+)(?:EL[ij](\d+))?", name)
     if m and t:
         base += "<" + ",".join(x for x in t.groups() if x) + ">"
     return base

@@ -60,6 +60,7 @@ def main():
         # VALU cost model (instructions issued per 64 rays): node block 250, triangle block 60, instance block 100, loop overhead 30 per step
         if kind == "shadow" and q[11]:
             print("    occluded shadow rays: %.1f %%, node visits per occluded ray %.2f, per unoccluded ray %.2f" % (100 * q[11] / r, q[12] / q[11], (q[2] - q[12]) / max(r - q[11], 1)))
+            print("    occluder-cache what-if (per pixel and bounce, previous occluded shadow ray): same instance / mesh %.1f %% of the occluded rays, same triangle %.1f %%" % (100 * q[13] / q[11], 100 * q[14] / q[11]))
         cost = (250 * q[6] + 60 * q[7] + 100 * q[8] + 30 * q[5]) / (r / 64)
         print("    modelled VALU instructions per 64 rays: %.0f  (blocks per 64 rays: steps %.1f node %.1f tri %.1f inst %.1f)" %
               (cost, q[5] / (r / 64), q[6] / (r / 64), q[7] / (r / 64), q[8] / (r / 64)))
