@@ -57,6 +57,12 @@ struct Accel {
      * as tmax.  (As a TLAS entry its box spans the scene, so every ray entered it anyway: one instance-entry block per ray for nothing.)
      * top_root = 0xffffffff: no top-level geometry.  top_first / top_count: its triangle records (brute-force kernel). */
     uint32_t top_root, top_first, top_count;
+    /* order of the two phases of a two-level scene (Traversal::begin; round 3).  A FEW top-level triangles around instanced content -- the walls of a box
+     * scene -- are better walked AFTER the TLAS: half of the benchmark scene's shadow rays are occluded by an instance and then never pay the walls' node
+     * visits (k_resolve 29.9 -> 26.5 ms), and a closest-hit ray that met an instance reaches the walls with tmax in front of them.  Many top-level
+     * triangles (terrain under instanced trees) keep the top-level-first order, which enters the TLAS with tmax at the nearest top-level hit.
+     * bit 0: any-hit rays walk the TLAS first, bit 1: closest-hit rays do. */
+    uint32_t top_last;
 };
 #define HAR_NO_NODE 0xffffffffu
 
@@ -190,6 +196,7 @@ HAR_HD void node_visit(const Accel &A, const RaySetup &R, float tmax, uint32_t i
 /* pick the next child of a node group (front-to-back = highest bit); returns its node index */
 #if !defined(__HIP_DEVICE_COMPILE__)
 static int g_host_child_order = 0;      /* host what-if models only (tools/trace_stats.py): 1 = back-to-front */
+static unsigned long long g_host_top_nodes = 0, g_host_top_tris = 0, g_host_rays = 0;      /* host statistics: node visits / triangle tests spent in the top-level BLAS phase */
 #endif
 HAR_HD uint32_t ng_next_child(uint32_t ng_x, uint32_t &ng_y, uint32_t octinv) {
     uint32_t imask = ng_y & 0xffu;
@@ -202,10 +209,9 @@ HAR_HD uint32_t ng_next_child(uint32_t ng_x, uint32_t &ng_y, uint32_t octinv) {
     return ng_x + popc32(imask & ~(0xffffffffu << slot));
 }
 
-/* one triangle record against the (object-space) ray; closest-hit bookkeeping */
+/* one triangle record against the (object-space) ray; closest-hit bookkeeping.  `tp`: a TriRec (12 words) */
 template <bool AnyHit>
-HAR_HD bool tri_visit(const Accel &A, const RaySetup &R, float &tmax, uint32_t idx, uint32_t cur_inst, Hit &hit) {
-    const float *tp = reinterpret_cast<const float *>(A.tris + idx);
+HAR_HD bool tri_visit_at(const float *tp, const RaySetup &R, float &tmax, uint32_t cur_inst, Hit &hit) {
 #if defined(__HIP_DEVICE_COMPILE__)
     const float4 a = reinterpret_cast<const float4 *>(tp)[0], b = reinterpret_cast<const float4 *>(tp)[1],
                  c = reinterpret_cast<const float4 *>(tp)[2];
@@ -220,6 +226,10 @@ HAR_HD bool tri_visit(const Accel &A, const RaySetup &R, float &tmax, uint32_t i
         tmax = hit.t;
     }
     return false;
+}
+template <bool AnyHit>
+HAR_HD bool tri_visit(const Accel &A, const RaySetup &R, float &tmax, uint32_t idx, uint32_t cur_inst, Hit &hit) {
+    return tri_visit_at<AnyHit>(reinterpret_cast<const float *>(A.tris + idx), R, tmax, cur_inst, hit);
 }
 
 /*
@@ -242,10 +252,16 @@ HAR_HD bool accel_trace(const Accel &A, Vec3 o_w, Vec3 d_w, float maxt, Hit &hit
     int sp = 0, inst_sp = -1;
     bool tlas_pending = false;
     if (A.has_tlas && A.top_root != HAR_NO_NODE) { in_tlas = false; inst_sp = 0; ng_x = A.top_root; tlas_pending = true; }      /* top-level geometry first */
+#if !defined(__HIP_DEVICE_COMPILE__)
+    ++g_host_rays;
+#endif
     for (;;) {
         probe.iter();
         if (ng_y > 0x00ffffffu) {
             probe.node();
+#if !defined(__HIP_DEVICE_COMPILE__)
+            if (tlas_pending) ++g_host_top_nodes;
+#endif
             uint32_t px = ng_x, py = ng_y;
             uint32_t child = ng_next_child(px, py, R.octinv);
             if (py > 0x00ffffffu) {
@@ -279,6 +295,9 @@ HAR_HD bool accel_trace(const Accel &A, Vec3 o_w, Vec3 d_w, float maxt, Hit &hit
                 break;
             } else {
                 probe.tri();
+#if !defined(__HIP_DEVICE_COMPILE__)
+                if (tlas_pending) ++g_host_top_tris;
+#endif
                 if (tri_visit<AnyHit>(A, R, tmax, idx, cur_inst, hit)) return true;
             }
         }
@@ -319,16 +338,23 @@ struct Traversal {
     int sp, inst_sp;
     uint32_t parked;            /* POLICY 2: triangle groups currently parked on the stack (<= HAR_MAX_PARKED) */
     bool in_tlas, found;
+    bool top_last, top_pending; /* any-hit rays: TLAS first, then the top-level BLAS (begin); top_pending: it is still to be walked once the TLAS is exhausted */
 
-    HAR_HD void begin(const Accel &A, Vec3 o, Vec3 d, float maxt) {
-        o_w = o; d_w = d; tmax = maxt;
+    /* top_last (any-hit queries only; pair it with step<AnyHit = true>): walk the TLAS FIRST and the top-level BLAS afterwards.  For a closest-hit ray
+     * the top-level geometry goes first so that the TLAS is entered with tmax at the nearest wall; an occlusion query has no use for that, and on a
+     * "box around instanced content" scene half of the shadow rays are occluded by an instance -- they never pay the 2.5 node visits of the walls */
+    HAR_HD void begin(const Accel &A, Vec3 o, Vec3 d, float maxt, bool top_last = false) {
+        o_w = o; d_w = d; tmax = maxt; top_pending = false; this->top_last = top_last && POLICY != 2;
         hit.t = HAR_INF; hit.u = 0.f; hit.v = 0.f; hit.prim = 0; hit.shape = 0; hit.inst = 0xffffffffu;
         R = ray_setup(o, d);
         in_tlas = A.has_tlas != 0; cur_inst = 0xffffffffu; found = false;
         ng_x = A.root; ng_y = 0x80000000u; tg_x = 0; tg_y = 0; sp = 0; inst_sp = -1; parked = 0;
         /* top-level geometry first (see Accel): the state "in a BLAS, no instance" (in_tlas false, cur_inst none) only exists in this phase of a
          * two-level scene -- TLAS entries always carry an instance index -- so no extra flag is kept */
-        if (A.has_tlas && A.top_root != HAR_NO_NODE) { in_tlas = false; inst_sp = 0; ng_x = A.top_root; }
+        if (A.has_tlas && A.top_root != HAR_NO_NODE) {
+            if (this->top_last) top_pending = true;                   /* start at the TLAS root (set above) */
+            else { in_tlas = false; inst_sp = 0; ng_x = A.top_root; }
+        }
     }
 
     /* ---- node phase: at most one node visit */
@@ -381,7 +407,7 @@ struct Traversal {
         return false;
     }
     /* ---- pop phase: leave the instance / finish / take the next group from the stack */
-    template <typename Stack>
+    template <typename Stack, bool TOP_LAST = false>
     HAR_HD bool phase_pop(const Accel &A, Stack &stack) {
         if (POLICY == 2) {
             /* pop as soon as no group is held in ng, even while triangles are pending (they are tested one per
@@ -404,11 +430,20 @@ struct Traversal {
             if (!in_tlas && sp == inst_sp) {
                 const bool top_phase = cur_inst == 0xffffffffu;
                 in_tlas = true; inst_sp = -1;
-                if (top_phase) { ng_x = A.root; ng_y = 0x80000000u; return false; }      /* top-level BLAS done: on to the TLAS with the same (world-space) ray */
+                if (top_phase) {
+                    if (TOP_LAST && top_last) { found = hit.t != HAR_INF; return true; } /* any-hit order: the top-level BLAS was the last thing to walk */
+                    ng_x = A.root; ng_y = 0x80000000u; return false;                      /* top-level BLAS done: on to the TLAS with the same (world-space) ray */
+                }
                 cur_inst = 0xffffffffu;
                 R = ray_setup(o_w, d_w);
             }
-            if (sp == 0) { found = hit.t != HAR_INF; return true; }
+            if (sp == 0) {
+                if (TOP_LAST && top_pending) {        /* TLAS exhausted without an occluder: now the top-level geometry (world-space ray, no instance) */
+                    top_pending = false; in_tlas = false; inst_sp = 0; ng_x = A.top_root; ng_y = 0x80000000u;
+                    return false;
+                }
+                found = hit.t != HAR_INF; return true;
+            }
             uint32_t x, y;
             stack.pop(--sp, x, y);
             if (y > 0x00ffffffu) { ng_x = x; ng_y = y; } else { tg_x = x; tg_y = y; ng_x = 0; ng_y = 0; }
@@ -423,7 +458,7 @@ struct Traversal {
     HAR_HD bool leaf_round(const Accel &A, Stack &stack, int &status) {
         NoProbe probe;
         if (phase_leaf<AnyHit>(A, stack, status, probe)) return true;
-        return phase_pop(A, stack);
+        return phase_pop<Stack, true>(A, stack);
     }
     HAR_HD bool leaf_pending() const { return tg_y != 0u; }
 
@@ -432,17 +467,18 @@ struct Traversal {
     template <bool AnyHit, typename Stack, typename Probe = NoProbe, int ORDER = 2>
     HAR_HD bool step(const Accel &A, Stack &stack, int &status, Probe probe = Probe()) {
         probe.iter();
+        /* the TLAS-first order is switched on per ray by begin(..., top_last) from Accel::top_last */
         if (ORDER == 0) {
             if (phase_node(A, stack, status, probe)) return true;
             if (phase_leaf<AnyHit>(A, stack, status, probe)) return true;
-            return phase_pop(A, stack);
+            return phase_pop<Stack, true>(A, stack);
         } else if (ORDER == 1) {
             if (phase_leaf<AnyHit>(A, stack, status, probe)) return true;
             if (phase_node(A, stack, status, probe)) return true;
-            return phase_pop(A, stack);
+            return phase_pop<Stack, true>(A, stack);
         } else {
             if (phase_leaf<AnyHit>(A, stack, status, probe)) return true;
-            if (phase_pop(A, stack)) return true;
+            if (phase_pop<Stack, true>(A, stack)) return true;
             return phase_node(A, stack, status, probe);
         }
     }

@@ -613,7 +613,7 @@ int har_scene_create(const HarSceneDesc *desc, HarScene *out) {
     if (err != hipSuccess) { for (void *p : S->owned) dev_free(p); delete S; return fail(std::string("scene upload: ") + hipGetErrorString(err)); }
     S->d_bsdfs = const_cast<DBsdf *>(D.bsdfs);
     D.accel.root = hs.root; D.accel.has_tlas = hs.has_tlas; D.accel.n_tris = (uint32_t) hs.tris.size(); D.accel.n_insts = (uint32_t) hs.inst_recs.size();
-    D.accel.top_root = hs.top_root; D.accel.top_first = hs.top_first; D.accel.top_count = hs.top_count;
+    D.accel.top_root = hs.top_root; D.accel.top_first = hs.top_first; D.accel.top_count = hs.top_count; D.accel.top_last = hs.top_last;
     D.n_emitters = (uint32_t) hs.emitters.size(); D.n_meshes = (uint32_t) hs.meshes.size();
     D.n_bsdfs = (uint32_t) hs.bsdfs.size(); D.n_textures = (uint32_t) hs.textures.size();
     D.env_emitter = hs.env_emitter;

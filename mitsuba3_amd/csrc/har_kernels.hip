@@ -374,7 +374,7 @@ __global__ __launch_bounds__(kBlock, HAR_TRACE_MIN_WAVES) void k_trace_closest(A
     if (n == 0) return;
     auto take = [&](uint32_t idx, Traversal<HAR_TRAV_POLICY> &T) {
         float4 o = a0[base + idx], d = a1[base + idx];
-        T.begin(A, Vec3(o.x, o.y, o.z), Vec3(d.x, d.y, d.z), o.w < 0.f ? HAR_LARGEST : o.w);
+        T.begin(A, Vec3(o.x, o.y, o.z), Vec3(d.x, d.y, d.z), o.w < 0.f ? HAR_LARGEST : o.w, (A.top_last & 2u) != 0u);
         return true;
     };
     auto store = [&](uint32_t idx, const Traversal<HAR_TRAV_POLICY> &T) {
@@ -850,7 +850,7 @@ __global__ __launch_bounds__(kBlock, HAR_TRACE_MIN_WAVES) void k_resolve(DScene 
         float4 s0 = items.s0[base + idx];
         if (!(s0.w >= 0.f)) return false;
         float4 s1 = items.s1[base + idx];
-        T.begin(S.accel, Vec3(s0.x, s0.y, s0.z), Vec3(s1.x, s1.y, s1.z), s0.w);
+        T.begin(S.accel, Vec3(s0.x, s0.y, s0.z), Vec3(s1.x, s1.y, s1.z), s0.w, (S.accel.top_last & 1u) != 0u);
         return true;
     };
     if (MODE == MODE_PATH || MODE == MODE_PRB_PRIMAL) {
@@ -1177,7 +1177,7 @@ __global__ __launch_bounds__(kBlock) void k_api_intersect(DScene S, uint32_t n, 
     Hit hit; int st = 0;
     if (NAIVE) accel_trace_naive<false>(S.accel, S.blas_tri_ranges, O, D, maxt[i], hit);
     else {      /* the production traversal code (Traversal<HAR_TRAV_POLICY>::step), one ray per lane */
-        Traversal<HAR_TRAV_POLICY> T; T.begin(S.accel, O, D, maxt[i]);
+        Traversal<HAR_TRAV_POLICY> T; T.begin(S.accel, O, D, maxt[i], (S.accel.top_last & 2u) != 0u);
         while (!T.template step<false, LdsStack<HAR_LDS_STACK_DEPTH>, NoProbe, 1>(S.accel, stack, st)) { }
         hit = T.hit;
     }
@@ -1194,7 +1194,7 @@ __global__ __launch_bounds__(kBlock) void k_api_ray_test(DScene S, uint32_t n, c
     Hit hit; int st = 0; bool r;
     if (NAIVE) r = accel_trace_naive<true>(S.accel, S.blas_tri_ranges, O, D, maxt[i], hit);
     else {
-        Traversal<HAR_TRAV_POLICY> T; T.begin(S.accel, O, D, maxt[i]);
+        Traversal<HAR_TRAV_POLICY> T; T.begin(S.accel, O, D, maxt[i], (S.accel.top_last & 1u) != 0u);
         while (!T.template step<true, LdsStack<HAR_LDS_STACK_DEPTH>, NoProbe, 1>(S.accel, stack, st)) { }
         r = T.found;
     }

@@ -16,7 +16,7 @@ namespace {
 
 struct BlasInfo { uint32_t root, first_tri, tri_count; float lo[3], hi[3]; bool empty; };
 
-BlasInfo build_blas(HostScene &hs, const HarSceneDesc &d, uint32_t first_mesh, uint32_t mesh_count) {
+BlasInfo build_blas(HostScene &hs, const HarSceneDesc &d, uint32_t first_mesh, uint32_t mesh_count, bool optimal_collapse = false) {
     std::vector<PrimBox> prims; std::vector<TriRec> recs;
     for (uint32_t s = first_mesh; s < first_mesh + mesh_count; ++s) {
         const HarMesh &m = d.meshes[s];
@@ -40,7 +40,9 @@ BlasInfo build_blas(HostScene &hs, const HarSceneDesc &d, uint32_t first_mesh, u
     static const uint32_t blas_leaf = getenv("HAR_BLAS_MAX_LEAF") ? (uint32_t) atoi(getenv("HAR_BLAS_MAX_LEAF")) : 1u;   /* measured on MI355X: 1 beats 2 and 3 (fewer wasted triangle tests, esp. for any-hit rays) */
     static const uint32_t blas_dp_min = getenv("HAR_BVH_DP_MIN") ? (uint32_t) atol(getenv("HAR_BVH_DP_MIN")) : 128u;    /* measured: the 36-triangle Cornell box is 5 % faster with the greedy collapse */
     static const float tri_cost = getenv("HAR_BVH_CTRI") ? (float) atof(getenv("HAR_BVH_CTRI")) : 0.3f;     /* triangle test vs node visit (VALU instructions) */
-    info.root = build_bvh8(prims, hs.nodes, info.first_tri, order, &hs.stats, blas_leaf, tri_cost, blas_dp_min);
+    /* optimal_collapse: the top-level BLAS of a two-level scene, which EVERY ray walks -- the SAH-optimal collapse whatever its size (round 3, host model:
+     * 2.55 -> 1.85 node visits per ray for the 12 wall triangles of the benchmark scene; the small-scene exception above is about stand-alone scenes) */
+    info.root = build_bvh8(prims, hs.nodes, info.first_tri, order, &hs.stats, blas_leaf, tri_cost, optimal_collapse ? 0u : blas_dp_min);
     for (uint32_t i : order) hs.tris.push_back(recs[i]);
     for (int a = 0; a < 3; ++a) { info.lo[a] = INFINITY; info.hi[a] = -INFINITY; }
     for (const PrimBox &b : prims) for (int a = 0; a < 3; ++a) { info.lo[a] = std::min(info.lo[a], b.lo[a]); info.hi[a] = std::max(info.hi[a], b.hi[a]); }
@@ -321,7 +323,7 @@ bool lower_scene(const HarSceneDesc &d, HostScene &hs, std::string &err) {
         }
     }
 
-    BlasInfo top = build_blas(hs, d, 0, d.top_mesh_count);
+    BlasInfo top = build_blas(hs, d, 0, d.top_mesh_count, d.instance_count != 0);
     hs.blas_depth = hs.stats.max_depth;
     if (d.instance_count == 0) {
         hs.root = top.root; hs.has_tlas = false;
@@ -333,6 +335,11 @@ bool lower_scene(const HarSceneDesc &d, HostScene &hs, std::string &err) {
     std::vector<PrimBox> boxes; std::vector<InstRec> recs; std::vector<uint32_t> ranges;
     /* the top-level geometry is not a TLAS entry: rays walk its BLAS first and then the TLAS (Accel::top_root, har_accel.h) */
     if (!top.empty) { hs.top_root = top.root; hs.top_first = top.first_tri; hs.top_count = top.tri_count; }
+    /* Accel::top_last: TLAS-first order when the top-level geometry is a handful of triangles around the instanced content.  HAR_TOP_LAST_MAX: the
+     * threshold (triangles), HAR_TOP_LAST: force the bit mask (A/B: 0 = round-2 order, 1 = any-hit only, 3 = both) */
+    static const uint32_t top_last_max = getenv("HAR_TOP_LAST_MAX") ? (uint32_t) atoi(getenv("HAR_TOP_LAST_MAX")) : 256u;
+    static const int top_last_forced = getenv("HAR_TOP_LAST") ? atoi(getenv("HAR_TOP_LAST")) : -1;
+    hs.top_last = top_last_forced >= 0 ? (uint32_t) top_last_forced : (!top.empty && top.tri_count <= top_last_max ? 3u : 0u);
     for (uint32_t i = 0; i < d.instance_count; ++i) {
         const BlasInfo &g = groups[d.instances[i].group];
         if (g.empty) continue;

@@ -32,6 +32,7 @@ struct HostScene {
     bool has_tlas = false;
     Bvh8Stats stats;
     uint32_t blas_depth = 0, tlas_depth = 0;   /* traversal stack need = blas_depth + (has_tlas ? tlas_depth + 1 : 0) */
+    uint32_t top_last = 0;     /* Accel::top_last */
     uint32_t top_root = 0xffffffffu, top_first = 0, top_count = 0;   /* two-level scenes: BLAS of the top-level geometry (Accel::top_root) */
     uint32_t stack_need() const { return blas_depth + (has_tlas ? tlas_depth + 1 : 0); }
 };

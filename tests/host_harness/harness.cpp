@@ -38,7 +38,7 @@ static void bind(HScene &H) {
     DScene &S = H.ds;
     S.accel.nodes = hs.nodes.data(); S.accel.tris = hs.tris.data(); S.accel.insts = hs.inst_recs.data();
     S.accel.root = hs.root; S.accel.has_tlas = hs.has_tlas; S.accel.n_tris = (uint32_t) hs.tris.size(); S.accel.n_insts = (uint32_t) hs.inst_recs.size();
-    S.accel.top_root = hs.top_root; S.accel.top_first = hs.top_first; S.accel.top_count = hs.top_count;
+    S.accel.top_root = hs.top_root; S.accel.top_first = hs.top_first; S.accel.top_count = hs.top_count; S.accel.top_last = hs.top_last;
     S.blas_tri_ranges = hs.blas_tri_ranges.data();
     S.verts = hs.verts.data(); S.faces = hs.faces.data(); S.meshes = hs.meshes.data(); S.bsdfs = hs.bsdfs.data();
     S.textures = H.dtex.data(); S.emitters = hs.emitters.data(); S.insts = hs.insts.data(); S.bsdf_tables = hs.bsdf_tables.data();
@@ -285,7 +285,7 @@ static int g_max_sp = 0;
 template <bool AnyHit, typename T, int ORDER>
 static void run_traversal_o(const Accel &A, Vec3 o, Vec3 d, float maxt, Hit &hit, bool &found, std::vector<uint32_t> &ev, int &status) {
     T tr; HostStack stack; EvProbe pr{ &ev };
-    tr.begin(A, o, d, maxt);
+    tr.begin(A, o, d, maxt, (A.top_last & (AnyHit ? 1u : 2u)) != 0u);      /* HAR_TOP_LAST=0..3 selects the order (har_scene_host.cpp) */
     while (!tr.template step<AnyHit, HostStack, EvProbe, ORDER>(A, stack, status, pr)) { if (tr.sp > g_max_sp) g_max_sp = tr.sp; }
     hit = tr.hit; found = tr.found;
 }
@@ -299,6 +299,7 @@ static void run_traversal(const Accel &A, Vec3 o, Vec3 d, float maxt, Hit &hit, 
 extern "C" {
 
 void hh_set_order(int o) { g_order = o; g_max_sp = 0; }
+void hh_top_phase_stats(double out[3]) { out[0] = (double) g_host_rays; out[1] = (double) g_host_top_nodes; out[2] = (double) g_host_top_tris; }
 int hh_max_sp() { return g_max_sp; }
 int hh_trace_stats(void *h, const HarSensor *sensor, uint32_t seed, uint32_t spp, int32_t max_depth, int32_t rr_depth,
                    uint64_t lane_begin, uint64_t lane_end, uint32_t max_bounces, int policy, int refill, double *out) {
