@@ -197,6 +197,8 @@ HAR_HD void node_visit(const Accel &A, const RaySetup &R, float tmax, uint32_t i
 #if !defined(__HIP_DEVICE_COMPILE__)
 static int g_host_child_order = 0;      /* host what-if models only (tools/trace_stats.py): 1 = back-to-front */
 static unsigned long long g_host_top_nodes = 0, g_host_top_tris = 0, g_host_rays = 0;      /* host statistics: node visits / triangle tests spent in the top-level BLAS phase */
+static unsigned long long g_host_empty_nodes = 0, g_host_stale_nodes = 0;
+static unsigned long long g_host_tlas_nodes = 0, g_host_inst_nodes = 0, g_host_inst_tris = 0, g_host_inst_entries = 0;      /* ... in the TLAS, inside instances */
 #endif
 HAR_HD uint32_t ng_next_child(uint32_t ng_x, uint32_t &ng_y, uint32_t octinv) {
     uint32_t imask = ng_y & 0xffu;
@@ -260,7 +262,7 @@ HAR_HD bool accel_trace(const Accel &A, Vec3 o_w, Vec3 d_w, float maxt, Hit &hit
         if (ng_y > 0x00ffffffu) {
             probe.node();
 #if !defined(__HIP_DEVICE_COMPILE__)
-            if (tlas_pending) ++g_host_top_nodes;
+            if (tlas_pending) ++g_host_top_nodes; else if (in_tlas) ++g_host_tlas_nodes; else ++g_host_inst_nodes;
 #endif
             uint32_t px = ng_x, py = ng_y;
             uint32_t child = ng_next_child(px, py, R.octinv);
@@ -269,6 +271,17 @@ HAR_HD bool accel_trace(const Accel &A, Vec3 o_w, Vec3 d_w, float maxt, Hit &hit
                 stack.push(sp++, px, py);
             }
             node_visit(A, R, tmax, child, ng_x, ng_y, tg_x, tg_y);
+#if !defined(__HIP_DEVICE_COMPILE__)
+            {       /* is the node's own (quantisation-frame) box beyond the current tmax, i.e. was it queued under an older tmax? */
+                const Node8 &N = A.nodes[child];
+                const float lo[3] = { N.px, N.py, N.pz }, sc[3] = { as_f32((uint32_t) N.ex << 23), as_f32((uint32_t) N.ey << 23), as_f32((uint32_t) N.ez << 23) };
+                const float oo[3] = { R.o.x, R.o.y, R.o.z }, id[3] = { R.idir.x, R.idir.y, R.idir.z };
+                float tn = 0.f, tf = tmax;
+                for (int a = 0; a < 3; ++a) { float t0 = (lo[a] - oo[a]) * id[a], t1 = (lo[a] + 255.f * sc[a] - oo[a]) * id[a]; if (t0 > t1) { float q = t0; t0 = t1; t1 = q; } tn = fmaxf(tn, t0); tf = fminf(tf, t1); }
+                if (tn > tf) ++g_host_stale_nodes;
+            }
+            if (ng_y <= 0x00ffffffu && tg_y == 0u) ++g_host_empty_nodes;        /* a visit that hit none of the node's children (the node was queued under an older, larger tmax, or grazed) */
+#endif
         } else {
             tg_x = ng_x; tg_y = ng_y; ng_x = 0; ng_y = 0;
         }
@@ -288,6 +301,9 @@ HAR_HD bool accel_trace(const Accel &A, Vec3 o_w, Vec3 d_w, float maxt, Hit &hit
                     stack.push(sp++, tg_x, tg_y);
                 }
                 probe.inst();
+#if !defined(__HIP_DEVICE_COMPILE__)
+                ++g_host_inst_entries;
+#endif
                 const InstRec &I = A.insts[idx];
                 inst_sp = sp; cur_inst = I.inst_index; in_tlas = false;
                 if (!I.identity) R = ray_setup(xf_point(I.to_object, o_w), xf_vector(I.to_object, d_w));
@@ -296,7 +312,7 @@ HAR_HD bool accel_trace(const Accel &A, Vec3 o_w, Vec3 d_w, float maxt, Hit &hit
             } else {
                 probe.tri();
 #if !defined(__HIP_DEVICE_COMPILE__)
-                if (tlas_pending) ++g_host_top_tris;
+                if (tlas_pending) ++g_host_top_tris; else ++g_host_inst_tris;
 #endif
                 if (tri_visit<AnyHit>(A, R, tmax, idx, cur_inst, hit)) return true;
             }
