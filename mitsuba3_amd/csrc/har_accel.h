@@ -395,9 +395,11 @@ struct Traversal {
     }
     /* ---- leaf phase: one triangle test (BLAS) or one instance entry (TLAS) */
     template <bool AnyHit, typename Stack, typename Probe>
-    HAR_HD bool phase_leaf(const Accel &A, Stack &stack, int &status, Probe &probe) {
+    HAR_HD bool phase_leaf(const Accel &A, Stack &stack, int &status, Probe &probe, bool allow_inst = true) {
         if (POLICY == 2 && tg_y == 0u && ng_y <= 0x00ffffffu && ng_y != 0u) { tg_x = ng_x; tg_y = ng_y; ng_x = 0; ng_y = 0; }
-        if (tg_y != 0u) {
+        /* allow_inst = false (persistent kernels, deferred instance entry): a lane whose next leaf item is an instance entry waits this step out -- the
+         * entry block (ray transform, reciprocals, two pushes: ~100 instructions) then runs when several lanes of the wave need it, not for one */
+        if (tg_y != 0u && (allow_inst || !in_tlas)) {
             uint32_t bit = 31u - clz32(tg_y);
             tg_y &= ~(1u << bit);
             uint32_t idx = tg_x + bit;
@@ -480,20 +482,21 @@ struct Traversal {
 
     /* one iteration; returns true when the ray is finished (`found` / `hit` hold the result).
      * ORDER 0: node, leaf, pop   1: leaf, node, pop   2: leaf, pop, node */
+    HAR_HD bool wants_instance_entry() const { return in_tlas && tg_y != 0u; }
     template <bool AnyHit, typename Stack, typename Probe = NoProbe, int ORDER = 2>
-    HAR_HD bool step(const Accel &A, Stack &stack, int &status, Probe probe = Probe()) {
+    HAR_HD bool step(const Accel &A, Stack &stack, int &status, Probe probe = Probe(), bool allow_inst = true) {
         probe.iter();
         /* the TLAS-first order is switched on per ray by begin(..., top_last) from Accel::top_last */
         if (ORDER == 0) {
             if (phase_node(A, stack, status, probe)) return true;
-            if (phase_leaf<AnyHit>(A, stack, status, probe)) return true;
+            if (phase_leaf<AnyHit>(A, stack, status, probe, allow_inst)) return true;
             return phase_pop<Stack, true>(A, stack);
         } else if (ORDER == 1) {
-            if (phase_leaf<AnyHit>(A, stack, status, probe)) return true;
+            if (phase_leaf<AnyHit>(A, stack, status, probe, allow_inst)) return true;
             if (phase_node(A, stack, status, probe)) return true;
             return phase_pop<Stack, true>(A, stack);
         } else {
-            if (phase_leaf<AnyHit>(A, stack, status, probe)) return true;
+            if (phase_leaf<AnyHit>(A, stack, status, probe, allow_inst)) return true;
             if (phase_pop<Stack, true>(A, stack)) return true;
             return phase_node(A, stack, status, probe);
         }

@@ -293,6 +293,9 @@ __global__ void k_sample_out(uint32_t n, uint32_t n_total, uint32_t first, const
 #ifndef HAR_MATERIAL_SORT
 #define HAR_MATERIAL_SORT 1
 #endif
+#ifndef HAR_DEFER_INST
+#define HAR_DEFER_INST 4      /* persistent traversal: instance entries wait for this many lanes (0 = enter at once; host model tools/trace_stats.py HH_DEFER_INST: -3 %; measured 4 / 6 / 8: k_resolve 26.83 -> 26.27 / 26.31 / 26.43 ms, k_trace_closest +-0) */
+#endif
 #ifndef HAR_TRAV_ORDER
 #define HAR_TRAV_ORDER 0    /* measured: 0 (node, leaf, pop) 687, 2: 660, 1: 643 Mpaths/s on the 1M-tri scene */
 #endif
@@ -335,9 +338,16 @@ __device__ __forceinline__ void trace_persistent(const Accel &A, uint32_t *curso
                 break;
             }
         }
+#if HAR_DEFER_INST
+        /* deferred instance entry: lanes whose next leaf item enters an instance wait until HAR_DEFER_INST of them do (or no other lane can use the step) */
+        const uint64_t m_inst = __ballot(busy && T.wants_instance_entry());
+        const bool allow_inst = (uint32_t) __popcll(m_inst) >= (uint32_t) HAR_DEFER_INST || __ballot(busy) == m_inst;
+#else
+        const bool allow_inst = true;
+#endif
         if (busy) {
             int st = 0;
-            if (T.template step<ANY, WaveStack, NoProbe, HAR_TRAV_ORDER>(A, stack, st)) {
+            if (T.template step<ANY, WaveStack, NoProbe, HAR_TRAV_ORDER>(A, stack, st, NoProbe(), allow_inst)) {
                 busy = false;
                 if (RETIRE) has_result = true; else done(idx, T);
             }
