@@ -196,9 +196,10 @@ HAR_HD void node_visit(const Accel &A, const RaySetup &R, float tmax, uint32_t i
 /* pick the next child of a node group (front-to-back = highest bit); returns its node index */
 #if !defined(__HIP_DEVICE_COMPILE__)
 static int g_host_child_order = 0;      /* host what-if models only (tools/trace_stats.py): 1 = back-to-front */
-static unsigned long long g_host_top_nodes = 0, g_host_top_tris = 0, g_host_rays = 0;      /* host statistics: node visits / triangle tests spent in the top-level BLAS phase */
-static unsigned long long g_host_empty_nodes = 0, g_host_stale_nodes = 0;
-static unsigned long long g_host_tlas_nodes = 0, g_host_inst_nodes = 0, g_host_inst_tris = 0, g_host_inst_entries = 0;      /* ... in the TLAS, inside instances */
+/* host statistics of the reference loop, [0] closest-hit / [1] any-hit queries: rays, node visits / triangle tests of the top-level BLAS phase, node visits in the
+ * TLAS and inside instances, triangle tests and entries of instances, node visits that hit no child, ... whose own box lies beyond the current tmax */
+static unsigned long long g_host_stat[2][9] = { { 0 }, { 0 } };
+enum { HS_RAYS = 0, HS_TOP_NODES, HS_TOP_TRIS, HS_TLAS_NODES, HS_INST_NODES, HS_INST_TRIS, HS_INST_ENTRIES, HS_EMPTY_NODES, HS_STALE_NODES };
 #endif
 HAR_HD uint32_t ng_next_child(uint32_t ng_x, uint32_t &ng_y, uint32_t octinv) {
     uint32_t imask = ng_y & 0xffu;
@@ -255,14 +256,14 @@ HAR_HD bool accel_trace(const Accel &A, Vec3 o_w, Vec3 d_w, float maxt, Hit &hit
     bool tlas_pending = false;
     if (A.has_tlas && A.top_root != HAR_NO_NODE) { in_tlas = false; inst_sp = 0; ng_x = A.top_root; tlas_pending = true; }      /* top-level geometry first */
 #if !defined(__HIP_DEVICE_COMPILE__)
-    ++g_host_rays;
+    ++g_host_stat[AnyHit][HS_RAYS];
 #endif
     for (;;) {
         probe.iter();
         if (ng_y > 0x00ffffffu) {
             probe.node();
 #if !defined(__HIP_DEVICE_COMPILE__)
-            if (tlas_pending) ++g_host_top_nodes; else if (in_tlas) ++g_host_tlas_nodes; else ++g_host_inst_nodes;
+            ++g_host_stat[AnyHit][tlas_pending ? HS_TOP_NODES : in_tlas ? HS_TLAS_NODES : HS_INST_NODES];
 #endif
             uint32_t px = ng_x, py = ng_y;
             uint32_t child = ng_next_child(px, py, R.octinv);
@@ -278,9 +279,9 @@ HAR_HD bool accel_trace(const Accel &A, Vec3 o_w, Vec3 d_w, float maxt, Hit &hit
                 const float oo[3] = { R.o.x, R.o.y, R.o.z }, id[3] = { R.idir.x, R.idir.y, R.idir.z };
                 float tn = 0.f, tf = tmax;
                 for (int a = 0; a < 3; ++a) { float t0 = (lo[a] - oo[a]) * id[a], t1 = (lo[a] + 255.f * sc[a] - oo[a]) * id[a]; if (t0 > t1) { float q = t0; t0 = t1; t1 = q; } tn = fmaxf(tn, t0); tf = fminf(tf, t1); }
-                if (tn > tf) ++g_host_stale_nodes;
+                if (tn > tf) ++g_host_stat[AnyHit][HS_STALE_NODES];
             }
-            if (ng_y <= 0x00ffffffu && tg_y == 0u) ++g_host_empty_nodes;        /* a visit that hit none of the node's children (the node was queued under an older, larger tmax, or grazed) */
+            if (ng_y <= 0x00ffffffu && tg_y == 0u) ++g_host_stat[AnyHit][HS_EMPTY_NODES];        /* a visit that hit none of the node's children (the node was queued under an older, larger tmax, or grazed) */
 #endif
         } else {
             tg_x = ng_x; tg_y = ng_y; ng_x = 0; ng_y = 0;
@@ -302,7 +303,7 @@ HAR_HD bool accel_trace(const Accel &A, Vec3 o_w, Vec3 d_w, float maxt, Hit &hit
                 }
                 probe.inst();
 #if !defined(__HIP_DEVICE_COMPILE__)
-                ++g_host_inst_entries;
+                ++g_host_stat[AnyHit][HS_INST_ENTRIES];
 #endif
                 const InstRec &I = A.insts[idx];
                 inst_sp = sp; cur_inst = I.inst_index; in_tlas = false;
@@ -312,7 +313,7 @@ HAR_HD bool accel_trace(const Accel &A, Vec3 o_w, Vec3 d_w, float maxt, Hit &hit
             } else {
                 probe.tri();
 #if !defined(__HIP_DEVICE_COMPILE__)
-                if (tlas_pending) ++g_host_top_tris; else ++g_host_inst_tris;
+                ++g_host_stat[AnyHit][tlas_pending ? HS_TOP_TRIS : HS_INST_TRIS];
 #endif
                 if (tri_visit<AnyHit>(A, R, tmax, idx, cur_inst, hit)) return true;
             }
