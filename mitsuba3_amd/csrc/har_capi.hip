@@ -129,7 +129,8 @@ struct HarIntegratorImpl {
     float4 *rc_h0 = nullptr; uint2 *rc_h1 = nullptr; uint8_t *rc_vis = nullptr; uint32_t cache_bounces = 0; bool use_cache = true;
     /* PRB replay tape (TapeArrays, har_kernels.h): per bounce the wavefront's path state, its hit records, a visibility byte and the next-slot word per
      * vertex slot; two slot-ordered (L, dL) array pairs that alternate from bounce to bounce */
-    bool ws_tape = false; uint32_t tape_bounces = 0;
+    int ws_tape = 0 /* 0 none, 1 state tape, 2 record tape */; uint32_t tape_bounces = 0;
+    float4 *tape_rec[4] = { nullptr, nullptr, nullptr, nullptr };      /* record tape: rec0, rec1, rec2, rec_em (lanes x bounces each) */
     WaveState tape_st[HAR_REPLAY_CACHE_BOUNCES + 1]{}; float4 *tape_h0 = nullptr; uint8_t *tape_vis = nullptr; uint32_t *tape_next = nullptr;
     float4 *tape_la[2] = { nullptr, nullptr }; float2 *tape_lb[2] = { nullptr, nullptr };
     float *adj = nullptr; size_t adj_floats = 0;
@@ -190,7 +191,7 @@ template <typename T> int ws_alloc(HarIntegratorImpl *I, T **p, size_t count) {
 
 uint32_t bounce_limit(const HarIntegratorImpl *I) { return std::min<uint32_t>(I->max_depth, HAR_MAX_BOUNCE_SLOTS - 2); }
 
-int ensure_workspace(HarIntegratorImpl *I, uint32_t lanes, bool adjoint, bool tape = false) {
+int ensure_workspace(HarIntegratorImpl *I, uint32_t lanes, bool adjoint, int tape = 0) {
     if (I->ws_lanes >= lanes && (I->ws_adjoint || !adjoint) && (!adjoint || I->ws_tape == tape)) {
         if (I->alpha_film && !I->alpha_lane) return ws_alloc(I, &I->alpha_lane, I->ws_lanes);      /* `rgba` film on an existing workspace */
         return 0;
@@ -224,9 +225,20 @@ int ensure_workspace(HarIntegratorImpl *I, uint32_t lanes, bool adjoint, bool ta
         }
     }
     I->rc_h0 = nullptr; I->rc_h1 = nullptr; I->rc_vis = nullptr; I->cache_bounces = 0;
-    I->ws_tape = false; I->tape_bounces = 0; I->tape_h0 = nullptr; I->tape_vis = nullptr; I->tape_next = nullptr;
+    I->ws_tape = 0; I->tape_bounces = 0; I->tape_h0 = nullptr; I->tape_vis = nullptr; I->tape_next = nullptr;
     for (int k = 0; k < 2; ++k) { I->tape_la[k] = nullptr; I->tape_lb[k] = nullptr; }
-    if (adjoint && tape) {
+    for (int k = 0; k < 4; ++k) I->tape_rec[k] = nullptr;
+    for (auto &w : I->tape_st) w = WaveState{};
+    if (adjoint && tape == 2) {
+        /* record tape (TapeArrays): 3 x 16 B of adjoint record + 16 B of emission + 1 B visibility + 4 B next slot per lane and bounce, 2 x 24 B for L / dL:
+         * 37 GB for a 2^26-lane chunk at max_depth = 8 */
+        const uint32_t nb = bounce_limit(I);
+        for (int k = 0; k < 4; ++k) if (ws_alloc(I, &I->tape_rec[k], (size_t) lanes * nb)) return 1;
+        if (ws_alloc(I, &I->tape_vis, (size_t) lanes * nb) || ws_alloc(I, &I->tape_next, (size_t) lanes * nb)) return 1;
+        for (int k = 0; k < 2; ++k) if (ws_alloc(I, &I->tape_la[k], lanes) || ws_alloc(I, &I->tape_lb[k], lanes)) return 1;
+        I->ws_tape = 2; I->tape_bounces = nb;
+    } else
+    if (adjoint && tape == 1) {
         /* the tape instead of the lane-indexed cache: (nb + 1) x 72 B of path state + nb x (32 B hit + 1 B visibility + 4 B next slot) per lane, 2 x 24 B for
          * L / dL: 62 GB for a 2^26-lane chunk at max_depth = 8 -- what 288 GB of HBM are for (the adjoint shading pass moves 40 % fewer bytes) */
         const uint32_t nb = bounce_limit(I);
@@ -235,7 +247,7 @@ int ensure_workspace(HarIntegratorImpl *I, uint32_t lanes, bool adjoint, bool ta
                 ws_alloc(I, &I->tape_st[b].a3, lanes) || ws_alloc(I, &I->tape_st[b].a4, lanes)) return 1;
         if (ws_alloc(I, &I->tape_h0, (size_t) 2 * lanes * nb) || ws_alloc(I, &I->tape_vis, (size_t) lanes * nb) || ws_alloc(I, &I->tape_next, (size_t) lanes * nb)) return 1;
         for (int k = 0; k < 2; ++k) if (ws_alloc(I, &I->tape_la[k], lanes) || ws_alloc(I, &I->tape_lb[k], lanes)) return 1;
-        I->ws_tape = true; I->tape_bounces = nb;
+        I->ws_tape = 1; I->tape_bounces = nb;
     } else
     if (adjoint && I->use_cache) {
         /* 25 B per lane and cached bounce; bounces beyond the cache are simply traced again */
@@ -387,11 +399,38 @@ int run_chunk(HarSceneImpl *S, HarIntegratorImpl *I, const DSensor &C, int mode,
     const size_t used = (size_t) std::min<uint32_t>(nb + 2, HAR_MAX_BOUNCE_SLOTS) * HAR_SHARDS * HAR_COUNTER_STRIDE * sizeof(uint32_t);
     /* replay tape (cache_mode 3: the primal pass records, 4: the adjoint pass replays; TapeArrays in har_kernels.h) */
     const bool tape_w = cache_mode == 3, tape_r = cache_mode == 4, tape = tape_w || tape_r;
-    if (tape && (!I->ws_tape || nb > I->tape_bounces || rays)) return fail("internal: tape mode without a tape workspace");
+    /* record tape (cache_mode 5: the primal pass shades with the adjoint flavour and writes one record per vertex, 6: the adjoint pass is k_commit) */
+    const bool rec_w = cache_mode == 5, rec_r = cache_mode == 6;
+    if (tape && (I->ws_tape != 1 || nb > I->tape_bounces || rays)) return fail("internal: tape mode without a tape workspace");
+    if ((rec_w || rec_r) && (I->ws_tape != 2 || nb > I->tape_bounces || rays)) return fail("internal: record-tape mode without its workspace");
+    if (rec_r) {
+        /* the whole adjoint pass: L / dL into bounce 0's slot order, then one streaming commit per bounce (+ the texel queues' accumulation) */
+        launch_tape_begin(s, C, seed, spp, log_spp, lane_base, n, I->shard_cap, I->result, nullptr, I->tape_la[0], I->tape_lb[0], nullptr, I->dL);
+        prof_mark(I, s, CLS_RAYGEN);
+        const uint32_t cgrid = std::max<uint32_t>(HAR_SHARDS, std::min<uint32_t>(((n + 255) / 256 + HAR_SHARDS - 1) / HAR_SHARDS * HAR_SHARDS, 4096u));
+        for (uint32_t b = 0; b < nb; ++b) {
+            const size_t off = (size_t) b * I->ws_lanes;
+            const TapeArrays tp{ I->tape_next + off, I->tape_la[b & 1], I->tape_lb[b & 1], I->tape_la[(b & 1) ^ 1], I->tape_lb[(b & 1) ^ 1],
+                                 I->tape_rec[0] + off, I->tape_rec[1] + off, I->tape_rec[2] + off, I->tape_rec[3] + off };
+            const bool queued = I->tq.nq != 0;
+            if (queued) HIP_TRY(hipMemsetAsync(I->tq.count, 0, (size_t) HAR_SHARDS * I->tq.nq * HAR_COUNTER_STRIDE * sizeof(uint32_t), s));
+            launch_commit(s, cgrid, S->ds, I->shard_cap, cnt_alive(I, b), tp, I->tape_vis + off, grad_refl, I->d_grad_tex, queued ? &I->tq : nullptr);
+            prof_mark(I, s, CLS_SHADE);
+            if (queued) {
+                static const uint32_t bpq_env = getenv("HAR_TQ_BPQ") ? (uint32_t) atoi(getenv("HAR_TQ_BPQ")) : 0u;
+                launch_texel_accumulate(s, I->tq, I->d_grad_tex, bpq_env ? bpq_env : (n > (1u << 22) ? 4u : 1u), I->tq_lds); prof_mark(I, s, CLS_OTHER);
+            }
+        }
+        launch_accumulate_stats(s, I->counters, nb, I->totals, n);
+        prof_mark(I, s, CLS_OTHER);
+        HIP_TRY(hipGetLastError());
+        return 0;
+    }
     if (!tape_r) HIP_TRY(hipMemsetAsync(cnt_alive(I, 0), 0, used, s));      /* the replay reads the primal pass's wavefront sizes */
     HIP_TRY(hipMemsetAsync(cnt_items(I, 0), 0, used, s));
     HIP_TRY(hipMemsetAsync(cur_trace(I, 0), 0, used, s));
     HIP_TRY(hipMemsetAsync(cur_resolve(I, 0), 0, used, s));
+    if (rec_w) launch_tape_begin(s, C, seed, spp, log_spp, lane_base, n, I->shard_cap, nullptr, I->adj, nullptr, nullptr, I->dL, nullptr);      /* dL per lane, for the emission terms of the primal pass */
     if (tape_r) launch_tape_begin(s, C, seed, spp, log_spp, lane_base, n, I->shard_cap, I->result, I->adj, I->tape_la[0], I->tape_lb[0]);
     else if (rays) launch_raygen_rays(s, seed, lane_base, n, rays->n_total, rays->first, rays->o, rays->d, rays->maxt, rays->state, I->shard_cap, I->st[0], I->result, cnt_alive(I, 0));
     /* forward mode: k_raygen<ADJOINT> takes `adj == nullptr` as "zero dL" -- a workspace that served render_backward before still holds that call's adjoint
@@ -399,7 +438,7 @@ int run_chunk(HarSceneImpl *S, HarIntegratorImpl *I, const DSensor &C, int mode,
     else launch_raygen(mode, s, C, seed, spp, log_spp, lane_base, n, I->shard_cap, tape_w ? I->tape_st[0] : I->st[0], I->result, cnt_alive(I, 0), I->forward_mode ? nullptr : I->adj, I->dL, ps);
     prof_mark(I, s, CLS_RAYGEN);
     const bool fwd = mode == MODE_PRB_ADJOINT && I->forward_mode;
-    ShadeParams P{ seed, I->max_depth, I->rr_depth, ((mode == MODE_PRB_ADJOINT && I->grad_emitters) ? HAR_SHADE_EMITTER_GRADS : 0u) | (I->hide_emitters ? HAR_SHADE_HIDE_EMITTERS : 0u) |
+    ShadeParams P{ seed, I->max_depth, I->rr_depth, (((mode == MODE_PRB_ADJOINT || rec_w) && I->grad_emitters) ? HAR_SHADE_EMITTER_GRADS : 0u) | (I->hide_emitters ? HAR_SHADE_HIDE_EMITTERS : 0u) |
                    (fwd ? HAR_SHADE_FORWARD_MODE : 0u) | ((mode == MODE_PRB_ADJOINT && I->grad_bsdf_params && !fwd) ? HAR_SHADE_EXTRA_GRADS : 0u) };
     /* grid: a multiple of 8 so that block b serves shard b % 8; enough blocks to cover the chunk once */
     const uint32_t grid = std::max<uint32_t>(HAR_SHARDS, std::min<uint32_t>(((n + 255) / 256 + HAR_SHARDS - 1) / HAR_SHARDS * HAR_SHARDS, 4096u));
@@ -416,21 +455,23 @@ int run_chunk(HarSceneImpl *S, HarIntegratorImpl *I, const DSensor &C, int mode,
     /* per-material shading queues: scenes with more than one BSDF model, `path` and the primal pass of `prb` (the adjoint kernels keep the generic code:
      * their in-place commit is bound by memory traffic, not by the model code).  HAR_MATERIAL_QUEUES=0: the generic kernel with its block-local sort (A/B) */
     static const int mq_env = getenv("HAR_MATERIAL_QUEUES") ? atoi(getenv("HAR_MATERIAL_QUEUES")) : -1;      /* -1: the integrator's setting; 0 / 1 force (A/B) */
-    const bool use_mq = (mq_env < 0 ? I->material_queues : mq_env != 0) && mode != MODE_PRB_ADJOINT && __builtin_popcount(S->mat_classes) >= 2 && !(S->ds.bsdf_types & HAR_SCENE_ENVMAP);
+    const bool use_mq = (mq_env < 0 ? I->material_queues : mq_env != 0) && mode != MODE_PRB_ADJOINT && cache_mode != 5 && __builtin_popcount(S->mat_classes) >= 2 && !(S->ds.bsdf_types & HAR_SCENE_ENVMAP);
     if (use_mq && !I->mq_idx && (ws_alloc(I, &I->mq_idx, (size_t) HAR_MAT_CLASSES * I->ws_lanes) || ws_alloc(I, &I->mq_count, (size_t) HAR_MAT_CLASSES * HAR_SHARDS * HAR_COUNTER_STRIDE))) return 1;
     const MaterialQueues mq{ I->mq_idx, I->mq_count, I->ws_lanes, S->mat_miss_class };
     int cur = 0; uint32_t b = 0;
     for (; b < nb; ++b) {
         /* PRB replay cache: the primal pass of render_backward records this bounce's ray-query results per lane, the adjoint pass reads them */
         ReplayCache rc{ nullptr, nullptr, nullptr, 0 };
-        if (tape) rc = ReplayCache{ nullptr, nullptr, I->tape_vis + (size_t) b * I->ws_lanes, cache_mode };
+        if (tape || rec_w) rc = ReplayCache{ nullptr, nullptr, I->tape_vis + (size_t) b * I->ws_lanes, cache_mode };
         else if (cache_mode && b < I->cache_bounces)
             rc = ReplayCache{ I->rc_h0 + (size_t) b * I->ws_lanes, I->rc_h1 + (size_t) b * I->ws_lanes, I->rc_vis + (size_t) b * I->ws_lanes, cache_mode };
         /* the wavefront buffers of this bounce: the ping-pong pair, or the tape's per-bounce buffers (path state in / out, hit records) */
         const WaveState st_in = tape ? I->tape_st[b] : I->st[cur], st_out = tape ? I->tape_st[b + 1] : I->st[cur ^ 1];
         float4 *const h0 = tape ? I->tape_h0 + (size_t) 2 * I->ws_lanes * b : I->h0;
         uint2 *const h1 = tape ? (HAR_HIT_INTERLEAVED ? reinterpret_cast<uint2 *>(h0 + 1) : reinterpret_cast<uint2 *>(h0 + I->ws_lanes)) : I->h1;
-        const TapeArrays tp{ tape ? I->tape_next + (size_t) b * I->ws_lanes : nullptr, I->tape_la[b & 1], I->tape_lb[b & 1], I->tape_la[(b & 1) ^ 1], I->tape_lb[(b & 1) ^ 1] };
+        const size_t toff = (size_t) b * I->ws_lanes;
+        const TapeArrays tp{ (tape || rec_w) ? I->tape_next + toff : nullptr, I->tape_la[b & 1], I->tape_lb[b & 1], I->tape_la[(b & 1) ^ 1], I->tape_lb[(b & 1) ^ 1],
+                             rec_w ? I->tape_rec[0] + toff : nullptr, rec_w ? I->tape_rec[1] + toff : nullptr, rec_w ? I->tape_rec[2] + toff : nullptr, rec_w ? I->tape_rec[3] + toff : nullptr };
         if (rc.mode != 2 && rc.mode != 4) {
             launch_trace_closest(s, tgrid, spill, S->ds.accel, cnt_alive(I, b), cur_trace(I, b), I->shard_cap, st_in, h0, h1, I->status);
             prof_mark(I, s, CLS_TRACE);
@@ -485,7 +526,7 @@ int run_chunk(HarSceneImpl *S, HarIntegratorImpl *I, const DSensor &C, int mode,
         } else
         launch_shade(mode, s, grid, S->ds, P, lane_base, I->shard_cap, cnt_alive(I, b), st_in, h0, h1, st_out, cnt_alive(I, b + 1),
                      I->items, cnt_items(I, b), I->result, rc, ps.rng, I->dL, grad_refl, shape ? &I->geo : nullptr, inline_commit && cached ? I->d_grad_tex : nullptr,
-                     queued ? &I->tq : nullptr, (inline_commit && (rc.mode == 2 || rc.mode == 4)) ? I->grad_bsdf_params : nullptr, nullptr, 0, tape ? &tp : nullptr);
+                     queued ? &I->tq : nullptr, (inline_commit && (rc.mode == 2 || rc.mode == 4)) ? I->grad_bsdf_params : nullptr, nullptr, 0, (tape || rec_w) ? &tp : nullptr);
         prof_mark(I, s, CLS_SHADE);
         if (queued) {
             static const uint32_t bpq_env = getenv("HAR_TQ_BPQ") ? (uint32_t) atoi(getenv("HAR_TQ_BPQ")) : 0u;
@@ -1012,7 +1053,11 @@ static int backward_range(HarScene S, HarIntegrator I, const HarSensor *sensor, 
      * buffers), the replay cache switched off, or more bounces than the tape holds.  HAR_PRB_TAPE=0: the round-2 cache (A/B). */
     static const bool tape_env = getenv("HAR_PRB_TAPE") ? atoi(getenv("HAR_PRB_TAPE")) != 0 : true;
     static const bool inline_env0 = getenv("HAR_ADJOINT_INLINE") ? atoi(getenv("HAR_ADJOINT_INLINE")) != 0 : true;
-    const bool tape = tape_env && inline_env0 && I->use_cache && !I->shape_on && !I->hide_emitters && bounce_limit(I) <= HAR_REPLAY_CACHE_BOUNCES;
+    /* ... and the RECORD tape (primal pass writes one adjoint record per vertex, the adjoint pass is a streaming commit) unless alpha / eta / k gradients are
+     * asked for (their fifteen extra vectors per vertex stay with the re-shading replay).  HAR_PRB_TAPE=1: the state tape (A/B) */
+    static const int tape_kind_env = getenv("HAR_PRB_TAPE") ? atoi(getenv("HAR_PRB_TAPE")) : 2;
+    const bool tape_ok = tape_env && inline_env0 && I->use_cache && !I->shape_on && !I->hide_emitters && bounce_limit(I) <= HAR_REPLAY_CACHE_BOUNCES;
+    const int tape = !tape_ok ? 0 : (tape_kind_env >= 2 && !I->grad_bsdf_params && chunk <= (1u << 29)) ? 2 : 1;
     if (ensure_workspace(I, chunk, true, tape)) return 1;
     size_t npx = (size_t) C.crop_w * C.crop_h;
     if (I->adj_floats < 3 * npx) { if (ws_alloc(I, &I->adj, 3 * npx)) return 1; I->adj_floats = 3 * npx; }
@@ -1051,9 +1096,9 @@ static int backward_range(HarScene S, HarIntegrator I, const HarSensor *sensor, 
     for (uint64_t base = lb; base < le; base += chunk) {
         uint32_t n = (uint32_t) std::min<uint64_t>(chunk, le - base);
         /* pass 1: primal, keeps L per lane in `result` (common.py:752-762) */
-        if (run_chunk(S, I, C, MODE_PRB_PRIMAL, seed, spp, log_spp, (uint32_t) base, n, nullptr, s, tape ? 3 : I->cache_bounces ? 1 : 0)) return 1;
+        if (run_chunk(S, I, C, MODE_PRB_PRIMAL, seed, spp, log_spp, (uint32_t) base, n, I->grad_slots, s, tape == 2 ? 5 : tape == 1 ? 3 : I->cache_bounces ? 1 : 0)) return 1;
         /* pass 2: adjoint replay with the identical sample stream (common.py:765-775) */
-        if (run_chunk(S, I, C, MODE_PRB_ADJOINT, seed, spp, log_spp, (uint32_t) base, n, I->grad_slots, s, tape ? 4 : I->cache_bounces ? 2 : 0)) return 1;
+        if (run_chunk(S, I, C, MODE_PRB_ADJOINT, seed, spp, log_spp, (uint32_t) base, n, I->grad_slots, s, tape == 2 ? 6 : tape == 1 ? 4 : I->cache_bounces ? 2 : 0)) return 1;
     }
     launch_add(s, I->grad_slots, grad_reflectance, (uint32_t) nb3);
     if (I->grad_emitters && ne3) launch_add(s, I->grad_slots + nb3, I->grad_emitters, (uint32_t) ne3);

@@ -62,7 +62,18 @@ struct ReplayCache { float4 *h0; uint2 *h1; uint8_t *vis; int mode; };
  * writes them straight into the tape), one visibility byte per vertex slot, and `next` = the slot the survivor took in bounce b + 1.  The adjoint
  * pass then streams every bounce in the primal's slot order: dense reads, NO compaction (no slot reservation, no state store), and L / dL travel in
  * two slot-ordered arrays (la = L.xyz, dL.x; lb = dL.yz) from slot i to slot next[i].  ReplayCache::vis = the bounce's visibility bytes. */
-struct TapeArrays { uint32_t *next; float4 *la_in; float2 *lb_in; float4 *la_out; float2 *lb_out; };
+struct TapeArrays { uint32_t *next; float4 *la_in; float2 *lb_in; float4 *la_out; float2 *lb_out; float4 *rec0, *rec1, *rec2, *rec_em; };
+/* RECORD tape (modes 5 = record, 6 = commit; the default without alpha / eta / k gradients).  The state tape above still re-runs the whole shading of every
+ * vertex in the adjoint pass (surface interaction, emitter sample, two BSDF evaluations) only to rebuild three small vectors: the vertex's direct radiance,
+ * its derivative w.r.t. the colour slot and the relative derivative of the BSDF value.  Here the PRIMAL pass shades with the adjoint flavour of shade_lane once
+ * and writes those vectors per vertex slot -- rec0 = {Lr_dir (per unit radiance when the emitter is differentiated), tag}, rec1 = {dLr_dir / d slot0, u},
+ * rec2 = {(df / d slot0) / f, v}, rec_em = {emitted radiance met at the vertex} -- and the adjoint pass is k_commit: a streaming kernel that walks the
+ * wavefronts in slot order, subtracts, multiplies by dL and files the gradients; it touches no geometry.  `next` word of a slot: bits 0..28 the survivor's slot
+ * in the next bounce (HAR_TAPE_DEAD: none), bit 29 the vertex has a shadow ray (its visibility byte is valid), bit 30 it has a record, bit 31 an emission record. */
+#define HAR_TAPE_DEAD 0x1fffffffu
+#define HAR_TAPE_HAS_RAY 0x20000000u
+#define HAR_TAPE_HAS_REC 0x40000000u
+#define HAR_TAPE_HAS_EM 0x80000000u
 /* Multi-pass rendering (integrator.cpp:280-356): the sampler of lane i keeps its PCG32 state from one pass to the next (sampler->advance()
  * does not reseed).  `rng` holds that state per lane of the chunk (pre-offset to the chunk's first lane; nullptr = single pass, streams are
  * seeded in raygen and dropped at path end); `jitter` receives the pass's pixel jitter per chunk lane for the splat kernel, which otherwise
@@ -116,7 +127,10 @@ void launch_shade(int mode, hipStream_t s, uint32_t grid, const DScene &S, const
                   const TapeArrays *tape = nullptr);                                               /* rc.mode 3 / 4: the bounce's tape arrays */
 /* adjoint pass in tape mode: L (the primal pass's result) and dL (gathered from the adjoint image over the lane's footprint) into bounce 0's slot order */
 void launch_tape_begin(hipStream_t s, const DSensor &C, uint32_t seed, uint32_t spp, uint32_t log_spp, uint32_t lane_base, uint32_t n, uint32_t shard_cap,
-                       const float4 *result, const float *adj, float4 *la, float2 *lb);
+                       const float4 *result, const float *adj, float4 *la, float2 *lb, float4 *dL_out = nullptr, const float4 *dL_in = nullptr);
+/* adjoint pass of the record tape: one bounce's vertices, in slot order (see TapeArrays) */
+void launch_commit(hipStream_t s, uint32_t grid, const DScene &S, uint32_t shard_cap, const uint32_t *count_in, const TapeArrays &tape, const uint8_t *vis,
+                   float *grad_slots, float *const *grad_tex, const TexelQueues *tq);
 void launch_classify(hipStream_t s, uint32_t grid, const DScene &S, uint32_t shard_cap, const uint32_t *count_in, const float4 *h0, const uint2 *h1, const MaterialQueues &mq);
 /* the records of one bounce -> LDS band copies -> grad_tex (see TexelQueues); blocks_per_queue blocks share a queue */
 void launch_texel_accumulate(hipStream_t s, const TexelQueues &tq, float *const *grad_tex, uint32_t blocks_per_queue, uint32_t lds_bytes);

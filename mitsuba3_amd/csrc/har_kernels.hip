@@ -200,12 +200,19 @@ __global__ __launch_bounds__(kBlock) void k_raygen(DSensor C, uint32_t seed, uin
  * result, its dL the adjoint image gathered over its film footprint (the adjoint of ImageBlock::put + develop, common.py:696-746 -- the same gather as
  * k_raygen<MODE_PRB_ADJOINT>, whose path state the tape already holds) */
 __global__ __launch_bounds__(kBlock) void k_tape_begin(DSensor C, uint32_t seed, uint32_t spp, uint32_t log_spp, uint32_t lane_base, uint32_t n, uint32_t shard_cap,
-                                                       const float4 *result, const float *adj, float4 *la, float2 *lb) {
+                                                       const float4 *result, const float *adj, float4 *la, float2 *lb, float4 *dL_out, const float4 *dL_in) {
     const uint32_t i = blockIdx.x * kBlock + threadIdx.x;
     if (i >= n) return;
+    Vec3 g(0.f);
+    if (dL_in) {            /* record tape, start of the commit pass: dL was gathered before the primal pass (dL_out call), only the slot order is new */
+        const float4 d = dL_in[i]; g = Vec3(d.x, d.y, d.z);
+        const float4 r = result[i];
+        const uint32_t slot = shard_slot(i, shard_cap);
+        la[slot] = make_float4(r.x, r.y, r.z, g.x); lb[slot] = make_float2(g.y, g.z);
+        return;
+    }
     const LaneSample ls = lane_film_pos(C, seed, spp, log_spp, lane_base + i);
     Footprint F; film_footprint(C, ls, F);
-    Vec3 g(0.f);
 #pragma unroll
     for (uint32_t ys = 0; ys < HAR_MAX_FILTER_TAPS; ++ys) {
         uint32_t y = F.y0 + ys; if (!(ys < F.count && y < C.crop_h)) continue;
@@ -217,6 +224,7 @@ __global__ __launch_bounds__(kBlock) void k_tape_begin(DSensor C, uint32_t seed,
             g = Vec3(fma_(a[0], w, g.x), fma_(a[1], w, g.y), fma_(a[2], w, g.z));
         }
     }
+    if (dL_out) { dL_out[i] = make_float4(g.x, g.y, g.z, 0.f); return; }      /* record tape, before the primal pass: per-lane dL for the emission terms */
     const float4 r = result[i];
     const uint32_t slot = shard_slot(i, shard_cap);
     la[slot] = make_float4(r.x, r.y, r.z, g.x); lb[slot] = make_float2(g.y, g.z);
@@ -566,7 +574,7 @@ __global__ __launch_bounds__(kBlock) void k_classify(DScene S, uint32_t shard_ca
 /* ------------------------------------------------------------------- shade */
 /* INLINE (adjoint replay of a bounce whose shadow-ray results sit in the replay cache): the visibility of the lane's emitter sample is known here,
  * so the vertex's adjoint is committed on the spot instead of going through an item (80 B written + read) and k_resolve_adjoint_cached */
-template <int MODE, uint32_t TYPES, bool SHAPE = false, bool INLINE = false, bool EXTRA = false, bool QUEUED = false>
+template <int MODE, uint32_t TYPES, bool SHAPE = false, bool INLINE = false, bool EXTRA = false, bool QUEUED = false, bool RECORD = false>
 __global__ __launch_bounds__(kBlock, HAR_SHADE_MIN_WAVES) void k_shade(DScene S, ShadeParams P, uint32_t lane_base, uint32_t shard_cap, const uint32_t *count_in, WaveState in,
                                                   const float4 *h0, const uint2 *h1, WaveState out, uint32_t *count_out,
                                                   ItemArrays items, uint32_t *item_count, float4 *result, ReplayCache rc, uint64_t *pass_rng,
@@ -659,9 +667,10 @@ __global__ __launch_bounds__(kBlock, HAR_SHADE_MIN_WAVES) void k_shade(DScene S,
             } else if (R.add_emission) {
                 float4 r = result[lane];
                 if (MODE == MODE_PATH)            r = make_float4(fma_(R.em_a.x, R.em_b.x, r.x), fma_(R.em_a.y, R.em_b.y, r.y), fma_(R.em_a.z, R.em_b.z, r.z), 0.f);
-                else if (MODE == MODE_PRB_PRIMAL) r = make_float4(r.x + R.em_b.x, r.y + R.em_b.y, r.z + R.em_b.z, 0.f);
+                else if (MODE == MODE_PRB_PRIMAL || RECORD) r = make_float4(r.x + R.em_b.x, r.y + R.em_b.y, r.z + R.em_b.z, 0.f);      /* RECORD: this IS the primal pass */
                 else                              r = make_float4(r.x - R.em_b.x, r.y - R.em_b.y, r.z - R.em_b.z, 0.f);
                 result[lane] = r;
+                if (RECORD) tape.rec_em[i] = make_float4(R.em_b.x, R.em_b.y, R.em_b.z, 0.f);
                 if (MODE == MODE_PRB_ADJOINT && emitter_grads && R.em_index >= 0 && fwd) {
                     const float *te = grad_slots + 3 * ((size_t) S.n_bsdfs + R.em_index);        /* tangent of the emitter's radiance */
                     float4 *acc_out = const_cast<float4 *>(dL);
@@ -726,23 +735,35 @@ __global__ __launch_bounds__(kBlock, HAR_SHADE_MIN_WAVES) void k_shade(DScene S,
                 texel_record_direct(S, grad_tex, grad_slots, rec, overflow);
             }
         }
+        if (RECORD && item_pred) {
+            /* record tape: what the commit kernel needs of this vertex (the item layout of the adjoint kernels, filed per VERTEX SLOT) */
+            const bool fact = R.nee_emitter >= 0 && (uint32_t) R.nee_emitter < HAR_ITEM_NO_EMITTER;
+            const Vec3 c = fact ? R.contrib_unit : R.contrib;
+            const uint32_t tag = (R.bsdf & 0xfffffu) | ((fact ? (uint32_t) R.nee_emitter : HAR_ITEM_NO_EMITTER) << 20) | (R.ind_active ? 0x80000000u : 0u);
+            tape.rec0[i] = make_float4(c.x, c.y, c.z, __uint_as_float(tag));
+            tape.rec1[i] = make_float4(R.dLr_drho.x, R.dLr_drho.y, R.dLr_drho.z, R.uv_x);
+            tape.rec2[i] = make_float4(R.rel_grad.x, R.rel_grad.y, R.rel_grad.z, R.uv_y);
+        }
+        const bool has_rec = RECORD && item_pred;
+        if (RECORD) item_pred = item_pred && R.item_ray;            /* the queue of the primal pass holds shadow rays only */
         const bool alive = in_range && R.alive, item = item_pred;
         uint32_t slot = 0, islot = 0;
         if (!tape_read) block_reserve2(cnt_alive, alive, cnt_item, item, lds_r, slot, islot);      /* tape replay: the primal pass's slots stand, nothing is stored */
         if (alive && !tape_read) store_state(out, Q.base + slot, R.next);
         if (MODE == MODE_PRB_PRIMAL && rc.mode == 3 && in_range) tape.next[i] = alive ? Q.base + slot : 0xffffffffu;
+        if (RECORD && in_range) tape.next[i] = (alive ? Q.base + slot : HAR_TAPE_DEAD) | (item ? HAR_TAPE_HAS_RAY : 0u) | (has_rec ? HAR_TAPE_HAS_REC : 0u) | (R.add_emission ? HAR_TAPE_HAS_EM : 0u);
         if (item) {
             islot += Q.base;
             items.s0[islot] = make_float4(R.sh_o.x, R.sh_o.y, R.sh_o.z, R.item_ray ? R.sh_maxt : -1.f);
             items.s1[islot] = make_float4(R.sh_d.x, R.sh_d.y, R.sh_d.z, __uint_as_float(lane));
-            if (MODE == MODE_PRB_ADJOINT) {
+            if (MODE == MODE_PRB_ADJOINT && !RECORD) {
                 /* tag = bsdf (20 bits) | emitter (11 bits) | indirect-term flag; with an emitter the item carries the contribution for a unit radiance */
                 const bool fact = R.nee_emitter >= 0 && (uint32_t) R.nee_emitter < HAR_ITEM_NO_EMITTER;
                 const Vec3 c = fact ? R.contrib_unit : R.contrib;
                 const uint32_t tag = (R.bsdf & 0xfffffu) | ((fact ? (uint32_t) R.nee_emitter : HAR_ITEM_NO_EMITTER) << 20) | (R.ind_active ? 0x80000000u : 0u);
                 items.s2[islot] = make_float4(c.x, c.y, c.z, __uint_as_float(tag));
             } else items.s2[islot] = make_float4(R.contrib.x, R.contrib.y, R.contrib.z, __uint_as_float(i));      /* .w: the vertex slot (tape: where k_resolve files the visibility) */
-            if (MODE == MODE_PRB_ADJOINT) {
+            if (MODE == MODE_PRB_ADJOINT && !RECORD) {
                 items.s3[islot] = make_float4(R.dLr_drho.x, R.dLr_drho.y, R.dLr_drho.z, R.uv_x);
                 items.s4[islot] = make_float4(R.rel_grad.x, R.rel_grad.y, R.rel_grad.z, R.uv_y);
             }
@@ -774,6 +795,64 @@ __global__ __launch_bounds__(kBlock, HAR_SHADE_MIN_WAVES) void k_shade(DScene S,
                 const float v = xacc[k];
                 if (v != 0.f) atomicAdd(grad_extra + k, v);
             }
+    }
+}
+
+/* ------------------------------------------------------------------ commit */
+/* Adjoint pass of the RECORD tape (TapeArrays): bounce b's vertices in the primal pass's slot order.  Per vertex: L <- L - emission met here - [visible] Lr_dir,
+ * g = dL * ([visible] dLr_dir / d slot0 + L * (df / d slot0) / f) (prb.py:227,288-313) into the colour slot / the texel-gradient queues / the emitter's slot, then
+ * L and dL move on to the survivor's slot of the next bounce.  No geometry, no sampling, no BSDF code: 133 B per vertex streamed. */
+__global__ __launch_bounds__(kBlock) void k_commit(DScene S, uint32_t shard_cap, const uint32_t *count_in, TapeArrays tape, const uint8_t *vis,
+                                                   float *grad_slots, float *const *grad_tex, TexelQueues tq) {
+    __shared__ uint32_t tq_hist[HAR_TQ_MAX], tq_base[HAR_TQ_MAX];
+    __shared__ float gacc[3 * HAR_LDS_GRAD_BSDFS];
+    for (uint32_t k = threadIdx.x; k < 3 * HAR_LDS_GRAD_BSDFS; k += kBlock) gacc[k] = 0.f;
+    __syncthreads();
+    const ShardLoop Q(count_in, shard_cap);
+    for (uint32_t tile = Q.first_tile(); tile * kBlock < Q.n; tile += Q.tile_step()) {
+        const uint32_t local = tile * kBlock + threadIdx.x;
+        const bool in_range = local < Q.n;
+        const uint32_t i = Q.base + local;
+        TexelRecord rec; rec.has = false;
+        bool pred = false, visible = false, dirty = false;
+        float4 s2 = make_float4(0.f, 0.f, 0.f, 0.f), s3 = s2, s4 = s2;
+        Vec3 L(0.f), dl(0.f); uint32_t nx = HAR_TAPE_DEAD;
+        if (in_range) {
+            nx = tape.next[i];
+            const float4 a = tape.la_in[i]; const float2 c2 = tape.lb_in[i];
+            L = Vec3(a.x, a.y, a.z); dl = Vec3(a.w, c2.x, c2.y);
+            if (nx & HAR_TAPE_HAS_EM) { const float4 e = tape.rec_em[i]; L = Vec3(L.x - e.x, L.y - e.y, L.z - e.z); }
+            pred = (nx & HAR_TAPE_HAS_REC) != 0u;
+            if (pred) { s2 = tape.rec0[i]; s3 = tape.rec1[i]; s4 = tape.rec2[i]; visible = (nx & HAR_TAPE_HAS_RAY) != 0u && vis[i] != 0; }
+        }
+        adjoint_commit_regs(S, pred, visible, s2, s3, s4, L, dirty, dl, grad_slots, grad_tex, gacc, tq.nq ? &tq : nullptr, tq.nq ? &rec : nullptr);
+        if (in_range && (nx & HAR_TAPE_DEAD) != HAR_TAPE_DEAD) {
+            const uint32_t nslot = nx & HAR_TAPE_DEAD;
+            tape.la_out[nslot] = make_float4(L.x, L.y, L.z, dl.x); tape.lb_out[nslot] = make_float2(dl.y, dl.z);
+        }
+        if (tq.nq) {        /* the block's texel records -> their band queues (as in k_shade's in-place commit) */
+            if (threadIdx.x < tq.nq) tq_hist[threadIdx.x] = 0u;
+            __syncthreads();
+            const uint32_t rank = rec.has ? atomicAdd(&tq_hist[rec.q], 1u) : 0u;
+            __syncthreads();
+            if (threadIdx.x < tq.nq) { const uint32_t c = tq_hist[threadIdx.x]; tq_base[threadIdx.x] = c ? atomicAdd(tq.count + (size_t) (Q.shard * tq.nq + threadIdx.x) * HAR_COUNTER_STRIDE, c) : 0u; }
+            __syncthreads();
+            bool overflow = false;
+            if (rec.has) {
+                const uint32_t slot = tq_base[rec.q] + rank;
+                if (slot < tq.cap) {
+                    float4 *dst = tq.rec + 2 * ((size_t) (Q.shard * tq.nq + rec.q) * tq.cap + slot);
+                    dst[0] = make_float4(__uint_as_float(rec.cell), __uint_as_float(rec.tex), rec.w1x, rec.w1y);
+                    dst[1] = make_float4(rec.g.x, rec.g.y, rec.g.z, 0.f);
+                } else overflow = true;
+            }
+            texel_record_direct(S, grad_tex, grad_slots, rec, overflow);
+        }
+    }
+    __syncthreads();
+    for (uint32_t k = threadIdx.x; k < 3 * min(S.n_bsdfs + S.n_emitters, (uint32_t) HAR_LDS_GRAD_BSDFS); k += kBlock) {
+        const float v = gacc[k];
+        if (v != 0.f) atomicAdd(grad_slots + k, v);
     }
 }
 
@@ -869,7 +948,7 @@ __global__ __launch_bounds__(kBlock, HAR_TRACE_MIN_WAVES) void k_resolve(DScene 
             [&](uint32_t idx, const Traversal<HAR_TRAV_POLICY> &T) {
                 const uint32_t i = base + idx;
                 if (rc.mode == 1) rc.vis[__float_as_uint(items.s1[i].w)] = T.found ? 0 : 1;      /* replay cache: per lane */
-                else if (rc.mode == 3) rc.vis[__float_as_uint(items.s2[i].w)] = T.found ? 0 : 1; /* replay tape: per vertex slot */
+                else if (rc.mode == 3 || rc.mode == 5) rc.vis[__float_as_uint(items.s2[i].w)] = T.found ? 0 : 1; /* replay / record tape: per vertex slot */
                 if (!T.found) {
                     const uint32_t lane = __float_as_uint(items.s1[i].w);
                     float4 s2 = items.s2[i], r = result[lane];
@@ -1307,7 +1386,15 @@ void launch_shade(int mode, hipStream_t s, uint32_t grid, const DScene &S, const
     const TexelQueues no_tq{ nullptr, nullptr, nullptr, nullptr, 0u, 0u };
     const TexelQueues tq = tq_in ? *tq_in : no_tq;
     const MaterialQueues no_mq{ nullptr, nullptr, 0u, 0u };
-    const TapeArrays tape = tape_in ? *tape_in : TapeArrays{ nullptr, nullptr, nullptr, nullptr, nullptr };
+    const TapeArrays tape = tape_in ? *tape_in : TapeArrays{ nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr };
+    if (rc.mode == 5) {       /* record tape, primal pass: the adjoint flavour of the shading code, primal bookkeeping, one record per vertex (k_shade<.., RECORD>) */
+        const bool env = (S.bsdf_types & HAR_SCENE_ENVMAP) != 0u, diffuse = S.bsdf_types == HAR_BSDF_ONLY_DIFFUSE, cls = (S.bsdf_types & 0x7fffffffu & ~HAR_BSDF_CLASSIC_TYPES) == 0u;
+#define HAR_LAUNCH_SHADE_RECORD(T) hipLaunchKernelGGL((k_shade<MODE_PRB_ADJOINT, T, false, false, false, false, true>), g, b, 0, s, S, P, lane_base, shard_cap, count_in, in, h0, h1, out, count_out, items, item_count, result, rc, pass_rng, dL, grad_slots, no_geo, nullptr, no_tq, nullptr, no_mq, 0u, tape)
+        if (env) HAR_LAUNCH_SHADE_RECORD(HAR_BSDF_ALL_TYPES | HAR_SCENE_ENVMAP); else if (diffuse) HAR_LAUNCH_SHADE_RECORD(HAR_BSDF_ONLY_DIFFUSE);
+        else if (cls) HAR_LAUNCH_SHADE_RECORD(HAR_BSDF_CLASSIC_TYPES); else HAR_LAUNCH_SHADE_RECORD(HAR_BSDF_ALL_TYPES);
+#undef HAR_LAUNCH_SHADE_RECORD
+        return;
+    }
     if (mq_in && mode != MODE_PRB_ADJOINT) {
         /* one material class: the kernel of that BSDF model (TYPES = its bit | HAR_BSDF_QUEUED), the generic classic / all-model kernel for twosided pairs of two models */
         const MaterialQueues mq = *mq_in;
@@ -1365,8 +1452,13 @@ void launch_shade(int mode, hipStream_t s, uint32_t grid, const DScene &S, const
 #undef HAR_LAUNCH_SHADE
 }
 void launch_tape_begin(hipStream_t s, const DSensor &C, uint32_t seed, uint32_t spp, uint32_t log_spp, uint32_t lane_base, uint32_t n, uint32_t shard_cap,
-                       const float4 *result, const float *adj, float4 *la, float2 *lb) {
-    hipLaunchKernelGGL(k_tape_begin, dim3(blocks_for(n)), dim3(kBlock), 0, s, C, seed, spp, log_spp, lane_base, n, shard_cap, result, adj, la, lb);
+                       const float4 *result, const float *adj, float4 *la, float2 *lb, float4 *dL_out, const float4 *dL_in) {
+    hipLaunchKernelGGL(k_tape_begin, dim3(blocks_for(n)), dim3(kBlock), 0, s, C, seed, spp, log_spp, lane_base, n, shard_cap, result, adj, la, lb, dL_out, dL_in);
+}
+void launch_commit(hipStream_t s, uint32_t grid, const DScene &S, uint32_t shard_cap, const uint32_t *count_in, const TapeArrays &tape, const uint8_t *vis,
+                   float *grad_slots, float *const *grad_tex, const TexelQueues *tq) {
+    const TexelQueues no_tq{ nullptr, nullptr, nullptr, nullptr, 0u, 0u };
+    hipLaunchKernelGGL(k_commit, dim3(grid), dim3(kBlock), 0, s, S, shard_cap, count_in, tape, vis, grad_slots, grad_tex, tq ? *tq : no_tq);
 }
 void launch_classify(hipStream_t s, uint32_t grid, const DScene &S, uint32_t shard_cap, const uint32_t *count_in, const float4 *h0, const uint2 *h1, const MaterialQueues &mq) {
     hipLaunchKernelGGL(k_classify, dim3(grid), dim3(kBlock), 0, s, S, shard_cap, count_in, h0, h1, mq);
