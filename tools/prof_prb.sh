@@ -14,9 +14,9 @@ for _ in range(3):
     mi.render_backward_distributed(scene, g, integ, seed=1, spp=256)
 torch.cuda.synchronize()
 PY
-for t in 1 0; do
+for t in 2 1 0; do
   D=/tmp/prof_prb_t$t; rm -rf $D
   HAR_PRB_TAPE=$t rocprofv3 --kernel-trace --stats -d $D -o r -- python /tmp/prb_only.py > gpurun_out/prof/r03_prb_tape${t}_kt.log 2>&1
   python tools/rocpd_summary.py $(find $D -name '*.db') > gpurun_out/prof/r03_prb_tape${t}_kt.txt 2>&1
 done
-head -14 gpurun_out/prof/r03_prb_tape1_kt.txt; head -14 gpurun_out/prof/r03_prb_tape0_kt.txt
+head -14 gpurun_out/prof/r03_prb_tape2_kt.txt; head -12 gpurun_out/prof/r03_prb_tape1_kt.txt
