@@ -346,13 +346,14 @@ __device__ __forceinline__ void trace_persistent(const Accel &A, uint32_t *curso
                 break;
             }
         }
-#if HAR_DEFER_INST
-        /* deferred instance entry: lanes whose next leaf item enters an instance wait until HAR_DEFER_INST of them do (or no other lane can use the step) */
-        const uint64_t m_inst = __ballot(busy && T.wants_instance_entry());
-        const bool allow_inst = (uint32_t) __popcll(m_inst) >= (uint32_t) HAR_DEFER_INST || __ballot(busy) == m_inst;
-#else
-        const bool allow_inst = true;
-#endif
+        /* deferred instance entry (shadow rays only): lanes whose next leaf item enters an instance wait until HAR_DEFER_INST of them do (or no other lane can
+         * use the step).  Closest-hit launches do not defer: on a rank's 8.4 M-lane band the waiting lengthens the last rays' chains (k_trace_closest 12.85 ->
+         * 13.99 ms) while a full 67 M-lane frame gains nothing; k_resolve gains on both (7.67 -> 7.37 ms, 26.83 -> 26.27 ms) */
+        bool allow_inst = true;
+        if (ANY && HAR_DEFER_INST) {
+            const uint64_t m_inst = __ballot(busy && T.wants_instance_entry());
+            allow_inst = (uint32_t) __popcll(m_inst) >= (uint32_t) HAR_DEFER_INST || __ballot(busy) == m_inst;
+        }
         if (busy) {
             int st = 0;
             if (T.template step<ANY, WaveStack, NoProbe, HAR_TRAV_ORDER>(A, stack, st, NoProbe(), allow_inst)) {
