@@ -405,8 +405,7 @@ int run_chunk(HarSceneImpl *S, HarIntegratorImpl *I, const DSensor &C, int mode,
     if ((rec_w || rec_r) && (I->ws_tape != 2 || nb > I->tape_bounces || rays)) return fail("internal: record-tape mode without its workspace");
     if (rec_r) {
         /* the whole adjoint pass: L / dL into bounce 0's slot order, then one streaming commit per bounce (+ the texel queues' accumulation) */
-        launch_tape_begin(s, C, seed, spp, log_spp, lane_base, n, I->shard_cap, I->result, nullptr, I->tape_la[0], I->tape_lb[0], nullptr, I->dL);
-        prof_mark(I, s, CLS_RAYGEN);
+
         const uint32_t cgrid = std::max<uint32_t>(HAR_SHARDS, std::min<uint32_t>(((n + 255) / 256 + HAR_SHARDS - 1) / HAR_SHARDS * HAR_SHARDS, 4096u));
         for (uint32_t b = 0; b < nb; ++b) {
             const size_t off = (size_t) b * I->ws_lanes;
@@ -414,7 +413,8 @@ int run_chunk(HarSceneImpl *S, HarIntegratorImpl *I, const DSensor &C, int mode,
                                  I->tape_rec[0] + off, I->tape_rec[1] + off, I->tape_rec[2] + off, I->tape_rec[3] + off };
             const bool queued = I->tq.nq != 0;
             if (queued) HIP_TRY(hipMemsetAsync(I->tq.count, 0, (size_t) HAR_SHARDS * I->tq.nq * HAR_COUNTER_STRIDE * sizeof(uint32_t), s));
-            launch_commit(s, cgrid, S->ds, I->shard_cap, cnt_alive(I, b), tp, I->tape_vis + off, grad_refl, I->d_grad_tex, queued ? &I->tq : nullptr);
+            launch_commit(s, cgrid, S->ds, I->shard_cap, cnt_alive(I, b), tp, I->tape_vis + off, grad_refl, I->d_grad_tex, queued ? &I->tq : nullptr,
+                          b == 0 ? I->result : nullptr, b == 0 ? I->dL : nullptr);
             prof_mark(I, s, CLS_SHADE);
             if (queued) {
                 static const uint32_t bpq_env = getenv("HAR_TQ_BPQ") ? (uint32_t) atoi(getenv("HAR_TQ_BPQ")) : 0u;
@@ -430,12 +430,13 @@ int run_chunk(HarSceneImpl *S, HarIntegratorImpl *I, const DSensor &C, int mode,
     HIP_TRY(hipMemsetAsync(cnt_items(I, 0), 0, used, s));
     HIP_TRY(hipMemsetAsync(cur_trace(I, 0), 0, used, s));
     HIP_TRY(hipMemsetAsync(cur_resolve(I, 0), 0, used, s));
-    if (rec_w) launch_tape_begin(s, C, seed, spp, log_spp, lane_base, n, I->shard_cap, nullptr, I->adj, nullptr, nullptr, I->dL, nullptr);      /* dL per lane, for the emission terms of the primal pass */
     if (tape_r) launch_tape_begin(s, C, seed, spp, log_spp, lane_base, n, I->shard_cap, I->result, I->adj, I->tape_la[0], I->tape_lb[0]);
     else if (rays) launch_raygen_rays(s, seed, lane_base, n, rays->n_total, rays->first, rays->o, rays->d, rays->maxt, rays->state, I->shard_cap, I->st[0], I->result, cnt_alive(I, 0));
     /* forward mode: k_raygen<ADJOINT> takes `adj == nullptr` as "zero dL" -- a workspace that served render_backward before still holds that call's adjoint
      * image in I->adj (possibly of a smaller film), which must not be gathered here */
-    else launch_raygen(mode, s, C, seed, spp, log_spp, lane_base, n, I->shard_cap, tape_w ? I->tape_st[0] : I->st[0], I->result, cnt_alive(I, 0), I->forward_mode ? nullptr : I->adj, I->dL, ps);
+    /* the adjoint image goes to the adjoint raygen (dL per lane; not in forward mode: dL accumulates there) and to the primal raygen of the record tape (dL for its emission terms) */
+    else launch_raygen(mode, s, C, seed, spp, log_spp, lane_base, n, I->shard_cap, tape_w ? I->tape_st[0] : I->st[0], I->result, cnt_alive(I, 0),
+                       (I->forward_mode || (mode == MODE_PRB_PRIMAL && !rec_w)) ? nullptr : I->adj, I->dL, ps);
     prof_mark(I, s, CLS_RAYGEN);
     const bool fwd = mode == MODE_PRB_ADJOINT && I->forward_mode;
     ShadeParams P{ seed, I->max_depth, I->rr_depth, (((mode == MODE_PRB_ADJOINT || rec_w) && I->grad_emitters) ? HAR_SHADE_EMITTER_GRADS : 0u) | (I->hide_emitters ? HAR_SHADE_HIDE_EMITTERS : 0u) |

@@ -130,7 +130,8 @@ void launch_tape_begin(hipStream_t s, const DSensor &C, uint32_t seed, uint32_t 
                        const float4 *result, const float *adj, float4 *la, float2 *lb, float4 *dL_out = nullptr, const float4 *dL_in = nullptr);
 /* adjoint pass of the record tape: one bounce's vertices, in slot order (see TapeArrays) */
 void launch_commit(hipStream_t s, uint32_t grid, const DScene &S, uint32_t shard_cap, const uint32_t *count_in, const TapeArrays &tape, const uint8_t *vis,
-                   float *grad_slots, float *const *grad_tex, const TexelQueues *tq);
+                   float *grad_slots, float *const *grad_tex, const TexelQueues *tq,
+                   const float4 *result = nullptr, const float4 *dL = nullptr);       /* bounce 0: L / dL straight from the per-lane arrays (the slot <-> lane map is arithmetic) */
 void launch_classify(hipStream_t s, uint32_t grid, const DScene &S, uint32_t shard_cap, const uint32_t *count_in, const float4 *h0, const uint2 *h1, const MaterialQueues &mq);
 /* the records of one bounce -> LDS band copies -> grad_tex (see TexelQueues); blocks_per_queue blocks share a queue */
 void launch_texel_accumulate(hipStream_t s, const TexelQueues &tq, float *const *grad_tex, uint32_t blocks_per_queue, uint32_t lds_bytes);

@@ -176,7 +176,7 @@ __global__ __launch_bounds__(kBlock) void k_raygen(DSensor C, uint32_t seed, uin
     } else st = raygen_lane(C, seed, spp, log_spp, lane_base + i, ls);
     store_state(out, shard_slot(i, shard_cap), st);
     if (MODE != MODE_PRB_ADJOINT) result[i] = make_float4(0.f, 0.f, 0.f, 0.f);
-    if (MODE == MODE_PRB_ADJOINT) {
+    if (MODE == MODE_PRB_ADJOINT || (MODE == MODE_PRB_PRIMAL && adj)) {      /* PRB_PRIMAL + adj: the primal pass of the record tape needs dL per lane for its emission terms */
         /* adjoint of ImageBlock::put + develop (common.py:696-746): gather grad_in / W over the footprint */
         if (!adj) { dL[i] = make_float4(0.f, 0.f, 0.f, 0.f); return; }      /* forward mode: dL accumulates the lane's differential radiance */
         Footprint F; film_footprint(C, ls, F);
@@ -803,8 +803,9 @@ __global__ __launch_bounds__(kBlock, HAR_SHADE_MIN_WAVES) void k_shade(DScene S,
 /* Adjoint pass of the RECORD tape (TapeArrays): bounce b's vertices in the primal pass's slot order.  Per vertex: L <- L - emission met here - [visible] Lr_dir,
  * g = dL * ([visible] dLr_dir / d slot0 + L * (df / d slot0) / f) (prb.py:227,288-313) into the colour slot / the texel-gradient queues / the emitter's slot, then
  * L and dL move on to the survivor's slot of the next bounce.  No geometry, no sampling, no BSDF code: 133 B per vertex streamed. */
+template <bool FIRST>
 __global__ __launch_bounds__(kBlock) void k_commit(DScene S, uint32_t shard_cap, const uint32_t *count_in, TapeArrays tape, const uint8_t *vis,
-                                                   float *grad_slots, float *const *grad_tex, TexelQueues tq) {
+                                                   float *grad_slots, float *const *grad_tex, TexelQueues tq, const float4 *result, const float4 *dL) {
     __shared__ uint32_t tq_hist[HAR_TQ_MAX], tq_base[HAR_TQ_MAX];
     __shared__ float gacc[3 * HAR_LDS_GRAD_BSDFS];
     for (uint32_t k = threadIdx.x; k < 3 * HAR_LDS_GRAD_BSDFS; k += kBlock) gacc[k] = 0.f;
@@ -820,8 +821,14 @@ __global__ __launch_bounds__(kBlock) void k_commit(DScene S, uint32_t shard_cap,
         Vec3 L(0.f), dl(0.f); uint32_t nx = HAR_TAPE_DEAD;
         if (in_range) {
             nx = tape.next[i];
-            const float4 a = tape.la_in[i]; const float2 c2 = tape.lb_in[i];
-            L = Vec3(a.x, a.y, a.z); dl = Vec3(a.w, c2.x, c2.y);
+            if (FIRST) {        /* bounce 0: slot i of shard s holds lane ((i / 256) * HAR_SHARDS + s) * 256 + i % 256 of the chunk (shard_slot); L = the primal result */
+                const uint32_t lane = ((local / kBlock) * HAR_SHARDS + Q.shard) * kBlock + (local % kBlock);
+                const float4 r = result[lane], d4 = dL[lane];
+                L = Vec3(r.x, r.y, r.z); dl = Vec3(d4.x, d4.y, d4.z);
+            } else {
+                const float4 a = tape.la_in[i]; const float2 c2 = tape.lb_in[i];
+                L = Vec3(a.x, a.y, a.z); dl = Vec3(a.w, c2.x, c2.y);
+            }
             if (nx & HAR_TAPE_HAS_EM) { const float4 e = tape.rec_em[i]; L = Vec3(L.x - e.x, L.y - e.y, L.z - e.z); }
             pred = (nx & HAR_TAPE_HAS_REC) != 0u;
             if (pred) { s2 = tape.rec0[i]; s3 = tape.rec1[i]; s4 = tape.rec2[i]; visible = (nx & HAR_TAPE_HAS_RAY) != 0u && vis[i] != 0; }
@@ -1364,6 +1371,7 @@ void launch_raygen(int mode, hipStream_t s, const DSensor &C, uint32_t seed, uin
                    uint32_t shard_cap, const WaveState &out, float4 *result, uint32_t *count, const float *adj, float4 *dL, const PassState &ps) {
     dim3 g(blocks_for(n)), b(kBlock);
     if (mode == MODE_PRB_ADJOINT) hipLaunchKernelGGL(k_raygen<MODE_PRB_ADJOINT>, g, b, 0, s, C, seed, spp, log_spp, lane_base, n, shard_cap, out, result, count, adj, dL, ps);
+    else if (mode == MODE_PRB_PRIMAL && adj) hipLaunchKernelGGL(k_raygen<MODE_PRB_PRIMAL>, g, b, 0, s, C, seed, spp, log_spp, lane_base, n, shard_cap, out, result, count, adj, dL, ps);
     else hipLaunchKernelGGL(k_raygen<MODE_PATH>, g, b, 0, s, C, seed, spp, log_spp, lane_base, n, shard_cap, out, result, count, adj, dL, ps);
 }
 void launch_raygen_rays(hipStream_t s, uint32_t seed, uint32_t lane_base, uint32_t n, uint32_t n_total, uint32_t first, const float *o, const float *d, const float *maxt,
@@ -1457,9 +1465,10 @@ void launch_tape_begin(hipStream_t s, const DSensor &C, uint32_t seed, uint32_t 
     hipLaunchKernelGGL(k_tape_begin, dim3(blocks_for(n)), dim3(kBlock), 0, s, C, seed, spp, log_spp, lane_base, n, shard_cap, result, adj, la, lb, dL_out, dL_in);
 }
 void launch_commit(hipStream_t s, uint32_t grid, const DScene &S, uint32_t shard_cap, const uint32_t *count_in, const TapeArrays &tape, const uint8_t *vis,
-                   float *grad_slots, float *const *grad_tex, const TexelQueues *tq) {
+                   float *grad_slots, float *const *grad_tex, const TexelQueues *tq, const float4 *result, const float4 *dL) {
     const TexelQueues no_tq{ nullptr, nullptr, nullptr, nullptr, 0u, 0u };
-    hipLaunchKernelGGL(k_commit, dim3(grid), dim3(kBlock), 0, s, S, shard_cap, count_in, tape, vis, grad_slots, grad_tex, tq ? *tq : no_tq);
+    if (result) hipLaunchKernelGGL(k_commit<true>, dim3(grid), dim3(kBlock), 0, s, S, shard_cap, count_in, tape, vis, grad_slots, grad_tex, tq ? *tq : no_tq, result, dL);
+    else hipLaunchKernelGGL(k_commit<false>, dim3(grid), dim3(kBlock), 0, s, S, shard_cap, count_in, tape, vis, grad_slots, grad_tex, tq ? *tq : no_tq, result, dL);
 }
 void launch_classify(hipStream_t s, uint32_t grid, const DScene &S, uint32_t shard_cap, const uint32_t *count_in, const float4 *h0, const uint2 *h1, const MaterialQueues &mq) {
     hipLaunchKernelGGL(k_classify, dim3(grid), dim3(kBlock), 0, s, S, shard_cap, count_in, h0, h1, mq);
