@@ -299,7 +299,7 @@ static void run_traversal(const Accel &A, Vec3 o, Vec3 d, float maxt, Hit &hit, 
 extern "C" {
 
 void hh_set_order(int o) { g_order = o; g_max_sp = 0; }
-void hh_top_phase_stats(double out[18]) { for (int q = 0; q < 2; ++q) for (int k = 0; k < 9; ++k) out[9 * q + k] = (double) g_host_stat[q][k]; }
+void hh_top_phase_stats(double out[24]) { for (int q = 0; q < 2; ++q) for (int k = 0; k < 12; ++k) out[12 * q + k] = (double) g_host_stat[q][k]; }
 int hh_max_sp() { return g_max_sp; }
 int hh_trace_stats(void *h, const HarSensor *sensor, uint32_t seed, uint32_t spp, int32_t max_depth, int32_t rr_depth,
                    uint64_t lane_begin, uint64_t lane_end, uint32_t max_bounces, int policy, int refill, double *out) {

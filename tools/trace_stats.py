@@ -52,13 +52,15 @@ def main():
                   (b, kind, r, q[1] / r, q[2] / r, q[3] / r, q[4] / r, q[5] / w, q[6] / w, q[7] / w, q[8] / w,
                    q[2] / (64 * q[6]) if q[6] else 0, q[3] / (64 * q[7]) if q[7] else 0))
     print("max traversal stack entries used: %d (scene stack_need %d)" % (H.hh_max_sp(), scene.accel_info_host()["depth"] if hasattr(scene, "accel_info_host") else -1))
-    tp = (C.c_double * 18)(); H.hh_top_phase_stats(tp)
+    tp = (C.c_double * 24)(); H.hh_top_phase_stats(tp)
     for q, kind in ((0, "closest-hit"), (1, "any-hit")):
-        r, top_n, top_t, tlas_n, inst_n, inst_t, ent, empty, stale = tp[9 * q:9 * q + 9]
+        r, top_n, top_t, tlas_n, inst_n, inst_t, ent, empty, stale, fent, fnodes, _ = tp[12 * q:12 * q + 12]
         if r:
             print("reference loop (top-level first), %s queries: top-level BLAS %.2f node visits + %.2f triangle tests per ray, TLAS %.2f node visits, %.2f instance entries per ray "
                   "with %.2f node visits + %.2f triangle tests per ENTRY; %.2f node visits per ray (%.0f %%) hit none of the node's children, %.2f of them lie beyond the current tmax"
                   % (kind, top_n / r, top_t / r, tlas_n / r, ent / r, inst_n / max(ent, 1), inst_t / max(ent, 1), empty / r, 100 * empty / max(top_n + tlas_n + inst_n, 1), stale / r))
+            if q == 0:
+                print("    instance entries that gave the ray no closer hit: %.0f %% of the entries, %.2f node visits each (%.2f per ray)" % (100 * fent / max(ent, 1), fnodes / max(fent, 1), fnodes / r))
     tc = out[:, :16].sum(0); ts = out[:, 16:].sum(0)
     for kind, q in (("closest", tc), ("shadow", ts)):
         r, w = q[0], q[9]
