@@ -198,8 +198,8 @@ HAR_HD void node_visit(const Accel &A, const RaySetup &R, float tmax, uint32_t i
 static int g_host_child_order = 0;      /* host what-if models only (tools/trace_stats.py): 1 = back-to-front */
 /* host statistics of the reference loop, [0] closest-hit / [1] any-hit queries: rays, node visits / triangle tests of the top-level BLAS phase, node visits in the
  * TLAS and inside instances, triangle tests and entries of instances, node visits that hit no child, ... whose own box lies beyond the current tmax */
-static unsigned long long g_host_stat[2][9] = { { 0 }, { 0 } };
-enum { HS_RAYS = 0, HS_TOP_NODES, HS_TOP_TRIS, HS_TLAS_NODES, HS_INST_NODES, HS_INST_TRIS, HS_INST_ENTRIES, HS_EMPTY_NODES, HS_STALE_NODES };
+static unsigned long long g_host_stat[2][12] = { { 0 }, { 0 } };
+enum { HS_RAYS = 0, HS_TOP_NODES, HS_TOP_TRIS, HS_TLAS_NODES, HS_INST_NODES, HS_INST_TRIS, HS_INST_ENTRIES, HS_EMPTY_NODES, HS_STALE_NODES, HS_FALSE_ENTRIES, HS_FALSE_ENTRY_NODES, HS_ENTRY_MARK };
 #endif
 HAR_HD uint32_t ng_next_child(uint32_t ng_x, uint32_t &ng_y, uint32_t octinv) {
     uint32_t imask = ng_y & 0xffu;
@@ -304,6 +304,7 @@ HAR_HD bool accel_trace(const Accel &A, Vec3 o_w, Vec3 d_w, float maxt, Hit &hit
                 probe.inst();
 #if !defined(__HIP_DEVICE_COMPILE__)
                 ++g_host_stat[AnyHit][HS_INST_ENTRIES];
+                g_host_stat[AnyHit][HS_ENTRY_MARK] = g_host_stat[AnyHit][HS_INST_NODES];      /* node-visit counter at entry */
 #endif
                 const InstRec &I = A.insts[idx];
                 inst_sp = sp; cur_inst = I.inst_index; in_tlas = false;
@@ -321,6 +322,12 @@ HAR_HD bool accel_trace(const Accel &A, Vec3 o_w, Vec3 d_w, float maxt, Hit &hit
 
         if (ng_y <= 0x00ffffffu) {
             if (!in_tlas && sp == inst_sp) {
+#if !defined(__HIP_DEVICE_COMPILE__)
+                if (!tlas_pending && hit.inst != cur_inst) {      /* the instance was entered for nothing: no hit of it became the closest one */
+                    ++g_host_stat[AnyHit][HS_FALSE_ENTRIES];
+                    g_host_stat[AnyHit][HS_FALSE_ENTRY_NODES] += g_host_stat[AnyHit][HS_INST_NODES] - g_host_stat[AnyHit][HS_ENTRY_MARK];
+                }
+#endif
                 in_tlas = true; cur_inst = 0xffffffffu; inst_sp = -1;
                 if (tlas_pending) { tlas_pending = false; ng_x = A.root; ng_y = 0x80000000u; continue; }      /* the ray is still the world-space one */
                 R = ray_setup(o_w, d_w);
