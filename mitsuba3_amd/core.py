@@ -949,9 +949,9 @@ class Integrator:
         g_pos = {}; g_inst = None; inst_wanted = {}
         if self.shape_gradients:
             keys = scene._position_keys(); ikeys = scene._instance_keys()
-            if self.shape_gradients is True:         # "every eligible mesh / instance": the meshes the adjoint can differentiate, instances if the instanced meshes are diffuse
+            if self.shape_gradients is True:         # "every eligible mesh / instance": the meshes the adjoint can differentiate, instances if no instanced mesh is purely specular
                 wanted = scene._differentiable_position_keys()
-                inst_wanted = ikeys if all(scene._bsdf_is_diffuse(m["bsdf"]) for m in scene.meshes[scene.top_mesh_count:]) else {}
+                inst_wanted = ikeys if all(scene._bsdf_has_smooth_lobe(m["bsdf"]) for m in scene.meshes[scene.top_mesh_count:]) else {}
             else:
                 inst_wanted = {k: ikeys[k] for k in self.shape_gradients if k in ikeys}
                 wanted = {k: keys[k] for k in self.shape_gradients if k not in ikeys}    # KeyError: not a differentiable mesh / instance
@@ -1340,14 +1340,17 @@ class Scene:
         """'<shape>.vertex_positions' (flat 3 N floats as in the reference's Mesh::traverse) of the top-level meshes without vertex normals"""
         return {m["key"] + ".vertex_positions": i for i, m in enumerate(self.meshes[:self.top_mesh_count]) if not (m["flags"] & 1) and m["V"].shape[0]}
 
-    def _bsdf_is_diffuse(self, index):
+    def _bsdf_has_smooth_lobe(self, index):
+        """BSDFFlags::Smooth on every side: models made of delta lobes only (`dielectric`, `conductor`) cannot sit on MOVING geometry -- their eval() is zero,
+        so prb.py:288 would form relative_grad(0) (har_integrator_set_grad_positions)"""
         b = self.bsdf_objs[index]
-        return b.kind == "diffuse" and (b.back is None or b.back.kind == "diffuse")
+        delta = ("dielectric", "conductor")
+        return b.kind not in delta and (b.back is None or b.back.kind not in delta)
 
     def _differentiable_position_keys(self):
-        """the subset of _position_keys() the `prb` adjoint can differentiate: flat-shaded top-level meshes whose BSDF is `diffuse` (plain or inside
-        `twosided`); the other meshes of the scene may carry any BSDF (har_integrator_set_grad_positions)"""
-        return {k: i for k, i in self._position_keys().items() if self._bsdf_is_diffuse(self.meshes[i]["bsdf"])}
+        """the subset of _position_keys() the `prb` adjoint can differentiate: flat-shaded top-level meshes whose BSDF has a non-delta lobe (any of diffuse,
+        roughconductor, roughplastic, plastic, plain or inside `twosided`); the other meshes of the scene may carry any BSDF"""
+        return {k: i for k, i in self._position_keys().items() if self._bsdf_has_smooth_lobe(self.meshes[i]["bsdf"])}
 
     def _instance_keys(self):
         """'<instance>.to_world' (4 x 4, Instance::traverse, instance.cpp:79-85)"""

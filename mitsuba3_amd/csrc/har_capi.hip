@@ -211,9 +211,10 @@ int ensure_workspace(HarIntegratorImpl *I, uint32_t lanes, bool adjoint, int tap
     if (ws_alloc(I, &I->items.s0, lanes) || ws_alloc(I, &I->items.s1, lanes) || ws_alloc(I, &I->items.s2, lanes)) return 1;
     I->items.s3 = I->items.s4 = nullptr; I->dL = nullptr;
     if (adjoint && (ws_alloc(I, &I->items.s3, lanes) || ws_alloc(I, &I->items.s4, lanes) || ws_alloc(I, &I->dL, lanes))) return 1;
-    I->geo = ShapeArrays{ nullptr, nullptr, nullptr, nullptr, nullptr }; I->d_pos_offset = nullptr; I->grad_pos = nullptr; I->d_inst_slot = nullptr; I->grad_inst = nullptr;
+    I->geo = ShapeArrays{}; I->d_pos_offset = nullptr; I->grad_pos = nullptr; I->d_inst_slot = nullptr; I->grad_inst = nullptr;
     if (adjoint && I->shape_on) {
-        if (ws_alloc(I, &I->geo.g0, lanes) || ws_alloc(I, &I->geo.g1, lanes) || ws_alloc(I, &I->geo.g2, lanes) || ws_alloc(I, &I->geo.g3, lanes) || ws_alloc(I, &I->geo.vis, lanes)) return 1;
+        if (ws_alloc(I, &I->geo.g0, lanes) || ws_alloc(I, &I->geo.g1, lanes) || ws_alloc(I, &I->geo.g2, lanes) || ws_alloc(I, &I->geo.g3, lanes) || ws_alloc(I, &I->geo.g4, lanes) ||
+            ws_alloc(I, &I->geo.g5, lanes) || ws_alloc(I, &I->geo.g6, lanes) || ws_alloc(I, &I->geo.pv0, lanes) || ws_alloc(I, &I->geo.pv1, lanes) || ws_alloc(I, &I->geo.vis, lanes)) return 1;
         if (I->pos_verts) {
             if (ws_alloc(I, &I->d_pos_offset, I->pos_offset.size()) || ws_alloc(I, &I->grad_pos, (size_t) 3 * I->pos_verts)) return 1;
             HIP_TRY(hipMemcpy(I->d_pos_offset, I->pos_offset.data(), I->pos_offset.size() * sizeof(int32_t), hipMemcpyHostToDevice));
@@ -1162,10 +1163,12 @@ int har_render_forward(HarScene S, HarIntegrator I, const HarSensor *sensor, uin
     return 0;
 }
 
-static bool record_is_diffuse(const HostScene &hs, int32_t index) {
+/* BSDFs with only delta lobes on MOVING geometry: bsdf.eval() is zero there, so prb.py:288 forms relative_grad(0) -- a 0 / 0 whose value the tree does not
+ * pin -- and the sampled direction is a reflection / refraction of wi, not a direction the solid-angle-to-area Jacobian could hold fixed.  Refused. */
+static bool record_has_smooth_lobe(const HostScene &hs, int32_t index) {
     if (index < 0 || (size_t) index >= hs.bsdfs.size()) return false;
     const DBsdf &b = hs.bsdfs[(size_t) index];
-    return b.type == BSDF_DIFFUSE && (b.back < 0 || hs.bsdfs[(size_t) b.back].type == BSDF_DIFFUSE);
+    return bsdf_is_smooth(b) && (b.back < 0 || bsdf_is_smooth(hs.bsdfs[(size_t) b.back]));
 }
 
 int har_integrator_set_grad_positions(HarIntegrator I, HarScene S, float *const *grad_positions) {
@@ -1174,9 +1177,9 @@ int har_integrator_set_grad_positions(HarIntegrator I, HarScene S, float *const 
     std::vector<float *> user; std::vector<int32_t> offset; std::vector<uint32_t> count; uint32_t verts = 0;
     if (grad_positions) {
         if (!S) return fail("null scene");
-        /* the hand-derived adjoint of har_shape_grad.h covers `diffuse` BSDFs (plain or inside `twosided`) on flat-shaded top-level meshes.  Only the
-         * DIFFERENTIATED meshes have to be diffuse: the shape terms of prb.py:124-141,176-216,261-297 live at vertices whose own triangle moves, so the
-         * rest of the scene may carry any BSDF model -- its vertices are shaded by the generic adjoint kernels and contribute no shape term */
+        /* the hand-derived adjoint of har_shape_grad.h covers flat-shaded top-level meshes carrying any BSDF with a non-delta lobe (the directional derivatives
+         * of the models come from har_bsdf_dir.h); the rest of the scene may carry any model -- a vertex next to moving geometry contributes through its
+         * attached si.wi (prb.py:128-140) */
         if (S->ds.bsdf_types & HAR_SCENE_ENVMAP) return fail("vertex-position gradients are not implemented for scenes with an environment map or a mesh area light");
         const size_t nm = S->hs.meshes.size();
         offset.assign(nm, -1); user.assign(nm, nullptr); count.assign(nm, 0);
@@ -1184,7 +1187,7 @@ int har_integrator_set_grad_positions(HarIntegrator I, HarScene S, float *const 
             if (!grad_positions[m]) continue;
             const DMesh &M = S->hs.meshes[m];
             if (M.flags & 1u) return fail("vertex-position gradients need a mesh without vertex normals (face_normals): a position update would regenerate them (mesh.cpp:876-878)");
-            if (!record_is_diffuse(S->hs, M.bsdf)) return fail("vertex-position gradients: the BSDF of a differentiated mesh must be `diffuse` (plain or inside `twosided`); other meshes of the scene may carry any BSDF");
+            if (!record_has_smooth_lobe(S->hs, M.bsdf)) return fail("vertex-position gradients: a differentiated mesh cannot carry a BSDF made of delta lobes only (`dielectric`, `conductor`); other meshes of the scene may");
             offset[m] = (int32_t) verts; user[m] = grad_positions[m]; count[m] = M.vertex_count; verts += M.vertex_count;
         }
         if (verts == 0) { offset.clear(); user.clear(); count.clear(); }
@@ -1203,10 +1206,10 @@ int har_integrator_set_grad_instances(HarIntegrator I, HarScene S, float *grad_t
     uint32_t n = 0;
     if (grad_to_world) {
         if (!S) return fail("null scene");
-        /* as for the vertex positions: the shape terms live on the moving geometry, i.e. on the meshes of the shape groups -- those have to be diffuse */
+        /* as for the vertex positions: any BSDF with a non-delta lobe on the moving geometry, i.e. on the meshes of the shape groups */
         if (S->ds.bsdf_types & HAR_SCENE_ENVMAP) return fail("instance to_world gradients are not implemented for scenes with an environment map or a mesh area light");
         for (size_t m = S->hs.top_mesh_count; m < S->hs.meshes.size(); ++m)
-            if (!record_is_diffuse(S->hs, S->hs.meshes[m].bsdf)) return fail("instance to_world gradients: the BSDFs of the instanced meshes must be `diffuse` (plain or inside `twosided`); top-level meshes may carry any BSDF");
+            if (!record_has_smooth_lobe(S->hs, S->hs.meshes[m].bsdf)) return fail("instance to_world gradients: an instanced mesh cannot carry a BSDF made of delta lobes only (`dielectric`, `conductor`); top-level meshes may");
         n = (uint32_t) S->hs.insts.size();
         if (n == 0) return fail("the scene has no instances");
         if (n >= (1u << (32 - HAR_SHAPE_INST_SHIFT)) - 1u) return fail("too many instances for the adjoint's geometry records");

@@ -83,7 +83,10 @@ struct PassState { uint64_t *rng; float2 *jitter; uint32_t pass; };
  * (g0 = shape, prim, b1, b2; g1 = d_in, slot of the lane in the next wavefront; g2 = emitter sample point / direction, flags; g3 = its
  * normal, cos theta_o) and the visibility `resolve` found for its shadow ray.  `ShapeTargets`: grad holds 3 floats per vertex of the
  * differentiated meshes, mesh m starting at float3 offset[m] (-1 = not differentiated). */
-struct ShapeArrays { float4 *g0, *g1, *g2, *g3; uint8_t *vis; };
+/* g0..g6: per adjoint item -- {mesh, prim, b1, b2}, {d_in, next slot}, {emitter sample, flags | instance}, {its normal, -}, {beta mis em_weight, -},
+ * {previous vertex: mesh, prim, b1, b2}, {the ray the previous vertex lies on, its instance};  pv0 / pv1: per LANE, the last vertex the path met (what the next
+ * vertex files as g5 / g6);  vis: the item's shadow-ray result */
+struct ShapeArrays { float4 *g0, *g1, *g2, *g3, *g4, *g5, *g6, *pv0, *pv1; uint8_t *vis; };
 /* Texel-gradient queues of the PRB adjoint.  Global float atomics run at the memory side of the chip at a fixed rate (measured: ~57 G atomics/s
  * whatever the address distribution -- a 64^2 and a 4096^2 gradient texture cost the same), and a bitmap albedo needs 12 of them per path vertex
  * (4 bilinear taps x RGB): 44 of the 156 ms of a PRB step on the textured 1M-triangle scene.  Instead, the shading kernel APPENDS one 32-byte

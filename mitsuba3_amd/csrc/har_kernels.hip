@@ -633,14 +633,14 @@ __global__ __launch_bounds__(kBlock, HAR_SHADE_MIN_WAVES) void k_shade(DScene S,
         const uint32_t i = Q.base + local;
         ShadeResult R; R.alive = false; R.item = false; R.add_emission = false;
         uint32_t lane = 0;
-        float4 hh = make_float4(0.f, 0.f, 0.f, 0.f); uint2 hs = make_uint2(0u, 0u); Vec3 d_in(0.f);
+        float4 hh = make_float4(0.f, 0.f, 0.f, 0.f); uint2 hs = make_uint2(0u, 0u); Vec3 d_in(0.f); bool first_vertex = true;
         /* in-place adjoint commit: the lane's L and dL stay in registers from the emission term to the write-back; tape replay (rc.mode == 4): they come
          * from / go to the slot-ordered tape arrays and nothing is compacted (TapeArrays) */
         Vec3 Lr(0.f), dlr(0.f); bool L_dirty = false;
         const bool tape_read = MODE == MODE_PRB_ADJOINT && INLINE && rc.mode == 4;
         if (in_range) {
             PathState st = load_state(in, i);
-            d_in = st.d;
+            d_in = st.d; first_vertex = (st.flags & 0xffffu) == 0u;
             if (MODE == MODE_PRB_ADJOINT && rc.mode == 2) { hh = rc.h0[st.lane - lane_base]; hs = rc.h1[st.lane - lane_base]; }      /* replay cache */
             else { hh = h0[HIT0(i)]; hs = h1[HIT1(i)]; }
             if (MODE == MODE_PRB_PRIMAL && rc.mode == 1) { rc.h0[st.lane - lane_base] = hh; rc.h1[st.lane - lane_base] = hs; }
@@ -686,6 +686,7 @@ __global__ __launch_bounds__(kBlock, HAR_SHADE_MIN_WAVES) void k_shade(DScene S,
             }
         }
         bool item_pred = in_range && R.item;
+        if (SHAPE) item_pred = in_range && (R.item || R.alive);       /* the solid-angle-to-area Jacobian of a continued path moves with the vertex whatever the BSDF value */
         if (INLINE) {
             const bool fact = item_pred && R.nee_emitter >= 0 && (uint32_t) R.nee_emitter < HAR_ITEM_NO_EMITTER;
             const Vec3 c = fact ? R.contrib_unit : R.contrib;
@@ -775,7 +776,15 @@ __global__ __launch_bounds__(kBlock, HAR_SHADE_MIN_WAVES) void k_shade(DScene S,
                 geo.g1[islot] = make_float4(d_in.x, d_in.y, d_in.z, __uint_as_float(alive ? Q.base + slot : HAR_SHAPE_NO_NEXT));
                 geo.g2[islot] = make_float4(R.nee_p.x, R.nee_p.y, R.nee_p.z, __uint_as_float((R.item_ray ? R.nee_flags : (R.nee_flags & HAR_SHAPE_LIT)) | inst_bits));
                 geo.g3[islot] = make_float4(R.nee_n.x, R.nee_n.y, R.nee_n.z, R.cos_em);
+                geo.g4[islot] = make_float4(R.nee_w.x, R.nee_w.y, R.nee_w.z, 0.f);
+                /* the previous vertex of the path (si.wi follows its motion, prb.py:128-140); none for the camera vertex */
+                geo.g5[islot] = first_vertex ? make_float4(__uint_as_float(0xffffffffu), 0.f, 0.f, 0.f) : geo.pv0[lane];
+                geo.g6[islot] = first_vertex ? make_float4(0.f, 0.f, 0.f, __uint_as_float(0xffffffffu)) : geo.pv1[lane];
             }
+        }
+        if (SHAPE && in_range && hh.x != HAR_INF) {
+            geo.pv0[lane] = make_float4(__uint_as_float(hs.x), hh.w, hh.y, hh.z);
+            geo.pv1[lane] = make_float4(d_in.x, d_in.y, d_in.z, __uint_as_float(hs.y));
         }
     }
     if (emitter_grads && !fwd) {
@@ -1032,10 +1041,11 @@ __global__ __launch_bounds__(kBlock) void k_skip_emitters(DScene S, int first, u
 }
 
 /* ------------------------------------------------------- vertex-position gradients */
-/* One thread per adjoint item of a bounce: rebuild the vertex (triangle, barycentrics, incoming direction), look up the lane's next
- * interaction (detached: prb.py:263-266 computes it outside dr.resume_grad) and apply har_shape_grad.h.  Scenes with few differentiated
- * vertices (a Cornell box has a few dozen) would serialise on a handful of cache lines -- every path of the chip adds to the same
- * vertices -- so those accumulate in LDS and flush once per block; large meshes scatter with global atomics. */
+/* One thread per adjoint item of a bounce: rebuild the vertex (triangle, barycentrics, incoming direction, the previous vertex), look up the lane's next
+ * interaction (detached: prb.py:263-266 computes it outside dr.resume_grad) and apply har_shape_grad.h.  A vertex adds to its own triangle / instance and,
+ * through the attached si.wi, to the previous vertex's.  Scenes with few differentiated vertices (a Cornell box has a few dozen) would serialise on a
+ * handful of cache lines -- every path of the chip adds to the same vertices -- so those accumulate in LDS and flush once per block; large meshes scatter
+ * with global atomics. */
 __global__ __launch_bounds__(kBlock) void k_shape_adjoint(DScene S, const uint32_t *item_count, uint32_t shard_cap, ItemArrays items, ShapeArrays geo, const float4 *result,
                                                           const float4 *dL, int has_next, WaveState next, const float4 *h0, const uint2 *h1, ReplayCache rc, ShapeTargets T) {
     __shared__ float acc[3 * HAR_LDS_GRAD_VERTS];
@@ -1046,6 +1056,22 @@ __global__ __launch_bounds__(kBlock) void k_shape_adjoint(DScene S, const uint32
     if (lds) { for (uint32_t k = threadIdx.x; k < 3 * T.n_verts; k += kBlock) acc[k] = 0.f; }
     if (T.inst_grad) { for (uint32_t k = threadIdx.x; k < 12 * HAR_LDS_GRAD_INSTS; k += kBlock) iacc[k] = 0.f; }
     __syncthreads();
+    /* slot of a vertex's geometry in the gradient buffers, or -1: top-level mesh -> first vertex, instance -> its 12 floats */
+    auto target = [&](uint32_t shape, uint32_t inst) -> int32_t {
+        if (shape == 0xffffffffu) return -1;
+        return inst == 0xffffffffu ? (T.offset ? T.offset[shape] : -1) : (T.inst_slot ? T.inst_slot[inst] : -1);
+    };
+    auto add_verts = [&](int32_t off, const uint32_t vid[3], const Vec3 g[3]) {
+        for (int k = 0; k < 3; ++k) {
+            const uint32_t e = 3u * ((uint32_t) off + vid[k]);
+            if (lds) { atomicAdd(&acc[e], g[k].x); atomicAdd(&acc[e + 1], g[k].y); atomicAdd(&acc[e + 2], g[k].z); }
+            else { atomicAdd(T.grad + e, g[k].x); atomicAdd(T.grad + e + 1, g[k].y); atomicAdd(T.grad + e + 2, g[k].z); }
+        }
+    };
+    auto add_inst = [&](int32_t off, const float gM[12]) {
+        float *dst = (uint32_t) off < HAR_LDS_GRAD_INSTS ? iacc + 12 * off : T.inst_grad + 12 * (size_t) off;
+        for (int k = 0; k < 12; ++k) if (gM[k] != 0.f) atomicAdd(dst + k, gM[k]);
+    };
     const ShardLoop Q(item_count, shard_cap);
     for (uint32_t tile = Q.first_tile(); tile * kBlock < Q.n; tile += Q.tile_step()) {
         const uint32_t local = tile * kBlock + threadIdx.x;
@@ -1054,18 +1080,20 @@ __global__ __launch_bounds__(kBlock) void k_shape_adjoint(DScene S, const uint32
         const float4 g0 = geo.g0[i];
         const uint32_t shape = __float_as_uint(g0.x);
         if (shape == 0xffffffffu) continue;
-        const float4 g2 = geo.g2[i];
-        const uint32_t inst = (__float_as_uint(g2.w) >> HAR_SHAPE_INST_SHIFT) - 1u;       /* 0xffffffff: top-level geometry */
-        const int32_t off = inst == 0xffffffffu ? (T.offset ? T.offset[shape] : -1) : (T.inst_slot ? T.inst_slot[inst] : -1);
-        if (off < 0) continue;
-        const float4 g1 = geo.g1[i], g3 = geo.g3[i];
+        const float4 g2 = geo.g2[i], g5 = geo.g5[i], g6 = geo.g6[i];
         ShapeItem it;
         it.shape = shape; it.prim = __float_as_uint(g0.y); it.b1 = g0.z; it.b2 = g0.w;
+        it.inst = (__float_as_uint(g2.w) >> HAR_SHAPE_INST_SHIFT) - 1u;       /* 0xffffffff: top-level geometry */
+        it.prev_shape = __float_as_uint(g5.x); it.prev_prim = __float_as_uint(g5.y); it.prev_b1 = g5.z; it.prev_b2 = g5.w;
+        it.prev_d = Vec3(g6.x, g6.y, g6.z); it.prev_inst = __float_as_uint(g6.w);
+        const int32_t off = target(it.shape, it.inst), poff = target(it.prev_shape, it.prev_inst);
+        if (off < 0 && poff < 0) continue;
+        const float4 g1 = geo.g1[i], g3 = geo.g3[i], g4 = geo.g4[i];
         it.d_in = Vec3(g1.x, g1.y, g1.z); it.next_slot = __float_as_uint(g1.w);
-        it.q = Vec3(g2.x, g2.y, g2.z); it.nee_flags = __float_as_uint(g2.w);
-        it.n_e = Vec3(g3.x, g3.y, g3.z); it.cos_em = g3.w;
+        it.q = Vec3(g2.x, g2.y, g2.z); it.nee_flags = __float_as_uint(g2.w) & ((1u << HAR_SHAPE_INST_SHIFT) - 1u);
+        it.n_e = Vec3(g3.x, g3.y, g3.z); it.W = Vec3(g4.x, g4.y, g4.z);
         const uint32_t lane = __float_as_uint(items.s1[i].w);
-        const float4 L4 = result[lane], dl4 = dL[lane], s3 = items.s3[i];
+        const float4 L4 = result[lane], dl4 = dL[lane];
         bool nxt = has_next && it.next_slot != HAR_SHAPE_NO_NEXT, next_valid = false;
         Vec3 np(0.f), nn(0.f), nd(0.f);
         if (nxt) {
@@ -1076,29 +1104,15 @@ __global__ __launch_bounds__(kBlock) void k_shape_adjoint(DScene S, const uint32
             next_valid = hh.x != HAR_INF;
             if (next_valid) { const SurfInt sn = compute_si(S, nd, hh.x, hh.y, hh.z, __float_as_uint(hh.w), hs.x, hs.y); np = sn.p; nn = sn.n; }
         }
-        if (inst != 0xffffffffu) {          /* d / d to_world of the instance: 12 floats, few distinct targets -> global atomics after a wave-level pre-reduction would be the next step */
-            float gM[12];
-            it.w_em = Vec3(0.f);
-            if (!instance_item_adjoint(S, it, inst, __float_as_uint(items.s2[i].w) & 0xfffffu, geo.vis[i] != 0, Vec3(L4.x, L4.y, L4.z), Vec3(dl4.x, dl4.y, dl4.z), Vec3(s3.x, s3.y, s3.z), nxt, next_valid, np, nn, nd, gM)) continue;
-            float *dst = (uint32_t) off < HAR_LDS_GRAD_INSTS ? iacc + 12 * off : T.inst_grad + 12 * (size_t) off;
-            for (int k = 0; k < 12; ++k) if (gM[k] != 0.f) atomicAdd(dst + k, gM[k]);
-            continue;
-        }
         /* the emitter sample: w_em = ds.d (surface emitters: normalize(ds.p - si.p), recomputed from the interpolated point) */
-        {
-            const DMesh M = S.meshes[shape];
-            const uint32_t *f = S.faces + 4 * (size_t) (M.foff + it.prim);
-            const float *r0 = S.verts + 8 * (size_t) (M.voff + f[0]), *r1 = S.verts + 8 * (size_t) (M.voff + f[1]), *r2 = S.verts + 8 * (size_t) (M.voff + f[2]);
-            const Vec3 p = fma3(Vec3(r0[0], r0[1], r0[2]), 1.f - it.b1 - it.b2, fma3(Vec3(r1[0], r1[1], r1[2]), it.b1, Vec3(r2[0], r2[1], r2[2]) * it.b2));
-            it.w_em = (it.nee_flags & HAR_SHAPE_NEE_SURFACE) ? normalize3(it.q - p) : it.q;
-        }
-        Vec3 g[3] = { Vec3(0.f), Vec3(0.f), Vec3(0.f) }; uint32_t vid[3];
-        if (!shape_item_adjoint(S, it, __float_as_uint(items.s2[i].w) & 0xfffffu, geo.vis[i] != 0, Vec3(L4.x, L4.y, L4.z), Vec3(dl4.x, dl4.y, dl4.z), Vec3(s3.x, s3.y, s3.z), nxt, next_valid, np, nn, nd, g, vid)) continue;
-        for (int k = 0; k < 3; ++k) {
-            const uint32_t e = 3u * ((uint32_t) off + vid[k]);
-            if (lds) { atomicAdd(&acc[e], g[k].x); atomicAdd(&acc[e + 1], g[k].y); atomicAdd(&acc[e + 2], g[k].z); }
-            else { atomicAdd(T.grad + e, g[k].x); atomicAdd(T.grad + e + 1, g[k].y); atomicAdd(T.grad + e + 2, g[k].z); }
-        }
+        it.w_em = it.q;
+        if (it.nee_flags & HAR_SHAPE_NEE_SURFACE) { const SurfInt si = compute_si(S, it.d_in, 0.f, it.b1, it.b2, it.prim, it.shape, it.inst); it.w_em = normalize3(it.q - si.p); }
+        ShapeGrad G;
+        if (!shape_item_adjoint(S, it, off >= 0, poff >= 0, geo.vis[i] != 0, Vec3(L4.x, L4.y, L4.z), Vec3(dl4.x, dl4.y, dl4.z), nxt, next_valid, np, nn, nd, G)) continue;
+        if (G.self_mesh) add_verts(off, G.vid, G.g);
+        if (G.self_inst) add_inst(off, G.gM);
+        if (G.prev_mesh) add_verts(poff, G.pvid, G.gp);
+        if (G.prev_inst) add_inst(poff, G.gpM);
     }
     __syncthreads();
     if (lds) for (uint32_t k = threadIdx.x; k < 3 * T.n_verts; k += kBlock) { const float v = acc[k]; if (v != 0.f) atomicAdd(T.grad + k, v); }

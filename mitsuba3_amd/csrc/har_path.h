@@ -57,6 +57,7 @@ struct ShadeResult {
     /* ... with vertex-position gradients (har_shape_grad.h): the detached emitter sample (position or, for an environment, direction; normal),
      * cos(theta_o) towards it and the HAR_SHAPE_* flags of the vertex */
     Vec3 nee_p, nee_n; float cos_em; uint32_t nee_flags;
+    Vec3 nee_w;                           /* beta * mis * em_weight: Lr_dir = nee_w * f(wi, wo_em) */
     /* ... with HAR_SHADE_EXTRA_GRADS: the non-slot-0 parameters of the vertex's BSDF record, groups 0 alpha_u, 1 alpha_v, 2 eta, 3 k (roughconductor's
      * complex IOR, per channel), 4 colour slot 1: x_dir[g] = d Lr_dir / d theta_g (per channel), x_rel[g] = (d f / d theta_g) / f at the sampled
      * direction -- what dLr_drho / rel_grad are for slot 0 (prb.py:288-313) */
@@ -114,7 +115,7 @@ template <int MODE, uint32_t TYPES = HAR_BSDF_ALL_TYPES, bool EXTRA = false>
 HAR_HD void shade_lane(const DScene &S, const ShadeParams &P, const PathState &st, const Hit &hit, ShadeResult &R) {
     R.alive = false; R.add_emission = false; R.item = false; R.item_ray = false;
     if (MODE == MODE_PRB_ADJOINT && EXTRA) { for (int g = 0; g < 5; ++g) { R.x_dir[g] = Vec3(0.f); R.x_rel[g] = Vec3(0.f); } R.x_ind = false; }
-    if (MODE == MODE_PRB_ADJOINT) { R.em_index = -1; R.nee_emitter = -1; R.em_unit = Vec3(0.f); R.contrib_unit = Vec3(0.f); R.nee_flags = 0u; R.cos_em = 0.f; R.nee_p = Vec3(0.f); R.nee_n = Vec3(0.f); }
+    if (MODE == MODE_PRB_ADJOINT) { R.em_index = -1; R.nee_emitter = -1; R.em_unit = Vec3(0.f); R.contrib_unit = Vec3(0.f); R.nee_flags = 0u; R.cos_em = 0.f; R.nee_p = Vec3(0.f); R.nee_n = Vec3(0.f); R.nee_w = Vec3(0.f); }
     uint64_t rng = st.rng;
     const uint64_t inc = sampler_inc(P.seed, st.lane);
     const uint32_t depth = st.flags & 0xffffu;
@@ -225,6 +226,7 @@ HAR_HD void shade_lane(const DScene &S, const ShadeParams &P, const PathState &s
                 const bool surface = et == 0u || et == 3u;           /* EmitterFlags::Surface (prb.py:178) */
                 R.nee_flags = 1u | (surface ? 2u : 0u);
                 R.nee_p = surface ? ds.p : ds.d; R.nee_n = ds.n; R.cos_em = wo_em.z * side.wo_sign;
+                R.nee_w = (st.throughput * mis_em) * em_weight;
             }
         }
     }

@@ -1,78 +1,73 @@
 /*
- * har_shape_grad.h -- vertex-position gradients of the PRB adjoint (HAR_HD: device kernel + host test harness).
+ * har_shape_grad.h -- vertex-position / instance-transform gradients of the PRB adjoint (HAR_HD: device kernel + host test harness).
  *
  * What the reference obtains by reverse-mode AD through the geometry-attached part of PRBIntegrator.sample
- * (src/python/python/ad/integrators/prb.py:124-141 attached surface interaction, :176-216 emitter sampling from the attached
- * point, :261-297 attached outgoing direction and solid-angle-to-area Jacobian) is written out here by hand for one path vertex
- * on a flat-shaded triangle with a `diffuse` BSDF (plain or inside `twosided`).  Per vertex the differentiable quantities are
+ * (src/python/python/ad/integrators/prb.py:124-141 attached surface interaction and si.wi, :176-216 emitter sampling from the attached
+ * point, :261-297 attached outgoing direction and solid-angle-to-area Jacobian) is written out here by hand for one path vertex.
+ * On a flat-shaded top-level triangle the differentiable quantities are
  *
  *   p_att = b0 P0 + b1 P1 + b2 P2                     (barycentrics detached, mesh.cpp:2296)
  *   n     = normalize((P1 - P0) x (P2 - P0))          (= shading normal of a mesh without vertex normals)
+ *   s, t  = coordinate_system(n)                      (finalize_surface_interaction, interaction.h:570-600: no packed tangents)
  *   p     = o + d * <p_att - o, n_det> / <n_det, d>   (attach_motion without FollowShape, interaction.h:536-544: the point stays on the ray)
- *   b_i  += barycentric coordinates of (p - p_att)    (mesh.cpp:2308-2321) -> uv -> rho(uv)
+ *   b_i  += barycentric coordinates of (p - p_att)    (mesh.cpp:2308-2321) -> uv -> colour slot 0 (uv)
+ *   wi    = to_local(-d) in the attached frame at the camera vertex; at later vertices the DETACHED frame applied to
+ *           normalize(p_prev - p_det), p_prev = the previous vertex attached to ITS triangle with RayFlags::Minimal (prb.py:128-140)
  *
  * and two "direction blocks" use them, one for emitter sampling (target = the detached emitter sample) and one for the sampled
- * continuation (target = the detached next interaction): w = normalize(y - p), cos = <w, n>, J = |<m, w>| / |y - p|^2 with
+ * continuation (target = the detached next interaction): w = normalize(y - p), wo = to_local(w), J = |<m, w>| / |y - p|^2 with
  *
- *   Lr_dir = beta mis em_weight * rho/pi cos * relative_grad(J),   Lr_ind = L * relative_grad(rho/pi cos) * relative_grad(J).
+ *   Lr_dir = beta mis em_weight * f(wi, wo) * relative_grad(J),   Lr_ind = L * relative_grad(f(wi, wo)) * relative_grad(J),   f = BSDF value x cos.
  *
- * The caller reduces the colour channels to scalar adjoints (cos_bar = d objective / d cos, a = d objective / d log J, uv_bar); this
- * file turns them into the gradient w.r.t. P0, P1, P2.  The oracle (oracle/mi_oracle.cpp attach_si, over dual numbers) computes the
- * same thing without any of the formulas below.
+ * f may be any model (har_bsdf_dir.h supplies d f / d wi, d f / d wo); on an instance only p is attached (instance.cpp:191-193,240-251).  A vertex whose own
+ * geometry does not move still contributes through wi when the PREVIOUS vertex's does.  The oracle (oracle/mi_oracle.cpp attach_si / attach_frame over dual
+ * numbers, BSDF directions by finite differences) computes the same thing without any of the formulas below.
  */
 #pragma once
 #include "har_scene.h"
+#include "har_bsdf_dir.h"
 
 namespace har {
-
-struct ShapeDirTerm {
-    bool on;            /* the term exists (visible emitter sample / the path continued) */
-    bool attached;      /* w = normalize(target - p) and J exist (surface emitter, valid next interaction); otherwise w is a detached direction and J = 1 */
-    Vec3 target, normal;/* y, m: detached */
-    Vec3 w;             /* value of the direction (ds.d / ray_next.d) */
-    float cos_bar, a;   /* adjoints of <w, n> and of log J */
-};
 
 struct ShapeVertex {
     Vec3 p0, p1, p2;
     float b1, b2;
     Vec3 d_in;                      /* direction of the (detached) ray the vertex lies on */
     bool has_uv; float duv0[2], duv1[2];   /* texcoord differences (P1 - P0, P2 - P0) of the triangle; without texcoords uv = (b1, b2) */
-    float uv_bar[2];                /* adjoint of the texture coordinates (both terms) */
-    ShapeDirTerm nee, ind;
+    float uv_bar[2];                /* adjoint of the texture coordinates */
+    Vec3 p_bar, n_bar;              /* adjoints of the attached point and of the attached (unit) normal */
 };
 
-/* adjoint of the point p a direction block starts from: w = normalize(y - p) enters cos = <w, n> (n = the normal the BSDF's cosine uses) and
- * log J = log |<m, w>| - 2 log |y - p|.  Zero for a detached direction (w given, J = 1). */
-HAR_HD Vec3 dir_term_point_adjoint(const ShapeDirTerm &T, Vec3 p, Vec3 n) {
-    if (!T.on || !T.attached) return Vec3(0.f);
-    const Vec3 D = T.target - p;
+/* adjoint of the point p a direction block starts from: w = normalize(y - p) carries the adjoint `w_bar` (from wo = to_local(w)) and
+ * log J = log |<m, w>| - 2 log |y - p| carries `a`. */
+HAR_HD Vec3 dir_point_adjoint(Vec3 target, Vec3 normal, Vec3 p, Vec3 w_bar, float a) {
+    const Vec3 D = target - p;
     const float r2 = dot3(D, D), r = sqrtf(r2);
     const Vec3 u = D * rcp_(r);
-    const float c = dot3(T.normal, u);
-    Vec3 u_bar = n * T.cos_bar;                            /* d cos / d w */
-    if (c != 0.f) u_bar = u_bar + T.normal * (T.a / c);    /* d log |<m, u>| / d u */
+    const float c = dot3(normal, u);
+    Vec3 u_bar = w_bar;
+    if (c != 0.f) u_bar = u_bar + normal * (a / c);        /* d log |<m, u>| / d u */
     /* u = D / |D|, D = y - p:  du = -(dp - u <u, dp>) / r;  log J also holds -2 log r, dr = -<u, dp> */
     const Vec3 proj = u_bar - u * dot3(u, u_bar);
-    return u * (2.f * T.a / r) - proj * rcp_(r);
+    return u * (2.f * a / r) - proj * rcp_(r);
+}
+/* adjoint of coordinate_system(n) (vector.h:118-138): s = (sg nx^2 a + 1, sg b, -sg nx), t = (b, ny^2 a + sg, -ny), a = -1 / (sg + nz), b = nx ny a */
+HAR_HD Vec3 coordinate_system_adjoint(Vec3 n, Vec3 s_bar, Vec3 t_bar) {
+    const float sg = n.z >= 0.f ? 1.f : -1.f, a = -1.f / (sg + n.z);
+    float a_bar = sg * n.x * n.x * s_bar.x + n.y * n.y * t_bar.y;
+    const float b_bar = sg * s_bar.y + t_bar.x;
+    a_bar += b_bar * n.x * n.y;
+    return Vec3(2.f * sg * n.x * a * s_bar.x - sg * s_bar.z + b_bar * n.y * a, 2.f * n.y * a * t_bar.y - t_bar.z + b_bar * n.x * a, a_bar * a * a);
 }
 
 /* adds d objective / d P_k to g[k] */
 HAR_HD void shape_vertex_adjoint(const ShapeVertex &v, Vec3 g[3]) {
     const float b0 = 1.f - v.b1 - v.b2;
     const Vec3 e1 = v.p1 - v.p0, e2 = v.p2 - v.p0;
-    const Vec3 p = fma3(v.p0, b0, fma3(v.p1, v.b1, v.p2 * v.b2));
     const Vec3 N = cross3(e1, e2);
     const float len = norm3(N);
     const Vec3 n = N * rcp_(len);
-    Vec3 p_bar(0.f), n_bar(0.f);
-    const ShapeDirTerm *terms[2] = { &v.nee, &v.ind };
-    for (int k = 0; k < 2; ++k) {
-        const ShapeDirTerm &T = *terms[k];
-        if (!T.on) continue;
-        n_bar = n_bar + T.w * T.cos_bar;                       /* cos = <w, n> */
-        p_bar = p_bar + dir_term_point_adjoint(T, p, n);
-    }
+    Vec3 p_bar = v.p_bar; const Vec3 n_bar = v.n_bar;
     /* texture coordinates -> barycentric coordinates -> (p - p_att) */
     float b1_bar, b2_bar;
     if (v.has_uv) { b1_bar = v.uv_bar[0] * v.duv0[0] + v.uv_bar[1] * v.duv0[1]; b2_bar = v.uv_bar[0] * v.duv1[0] + v.uv_bar[1] * v.duv1[1]; }
@@ -107,119 +102,131 @@ HAR_HD void tex_fetch_grad(const DTexture &T, const TexTaps &l, Vec3 &d_du, Vec3
 
 /* geometry record of one adjoint item, written by the shading stage when vertex-position gradients are requested */
 struct ShapeItem {
-    uint32_t shape, prim; float b1, b2;
+    uint32_t shape, prim, inst; float b1, b2;  /* the vertex: mesh, triangle, instance (0xffffffff: top-level geometry), barycentrics */
     Vec3 d_in; uint32_t next_slot;             /* 0xffffffff: the path ended at this vertex */
-    Vec3 q; uint32_t nee_flags;                /* bit 0: an emitter sample exists, bit 1: it lies on a surface, bit 2: the vertex is lit (cos_i > 0), bit 3: flipped */
-    Vec3 n_e; float cos_em;
-    Vec3 w_em;
+    Vec3 q; uint32_t nee_flags;                /* bit 0: an emitter sample exists, bit 1: it lies on a surface */
+    Vec3 n_e;
+    Vec3 w_em;                                 /* ds.d */
+    Vec3 W;                                    /* beta * mis * em_weight: Lr_dir = W * f(wi, wo_em) */
+    uint32_t prev_shape, prev_prim, prev_inst; float prev_b1, prev_b2; Vec3 prev_d;     /* the previous vertex and the ray IT lies on (prev_shape = 0xffffffff: this is the camera vertex) */
 };
 #define HAR_SHAPE_NEE         1u
 #define HAR_SHAPE_NEE_SURFACE 2u
-#define HAR_SHAPE_LIT         4u
-#define HAR_SHAPE_FLIPPED     8u          /* twosided BSDF seen from behind: wo is mirrored, cos = -<w, n> (twosided.cpp:124-127) */
+#define HAR_SHAPE_LIT         4u          /* (kept in the records for diagnostics; the side is recomputed from the geometry) */
+#define HAR_SHAPE_FLIPPED     8u
 #define HAR_SHAPE_NO_NEXT     0xffffffffu
+#define HAR_SHAPE_NONE        0xffffffffu
 
-/* One path vertex: the item's geometry record, the visibility of its emitter sample, the radiance accumulator L after this vertex's
- * subtraction (prb.py:227), the film adjoint dL, NEE's d Lr_dir / d rho (= beta mis em_weight cos / pi), and the next interaction
- * (position / geometric normal, `next_valid` = false for an escaped ray).  Adds to g[0..2]; returns false when the vertex's mesh is
- * not differentiated or nothing contributes. */
-HAR_HD bool shape_item_adjoint(const DScene &S, const ShapeItem &it, uint32_t bsdf, bool visible, Vec3 L, Vec3 dl, Vec3 dLr_drho,
-                               bool has_next, bool next_valid, Vec3 next_p, Vec3 next_n, Vec3 next_d, Vec3 g[3], uint32_t vid[3]) {
-    const DMesh M = S.meshes[it.shape];
-    const uint32_t *f = S.faces + 4 * (size_t) (M.foff + it.prim);
-    vid[0] = f[0]; vid[1] = f[1]; vid[2] = f[2];
-    const float *r0 = S.verts + 8 * (size_t) (M.voff + f[0]), *r1 = S.verts + 8 * (size_t) (M.voff + f[1]), *r2 = S.verts + 8 * (size_t) (M.voff + f[2]);
-    ShapeVertex v;
-    v.p0 = Vec3(r0[0], r0[1], r0[2]); v.p1 = Vec3(r1[0], r1[1], r1[2]); v.p2 = Vec3(r2[0], r2[1], r2[2]);
-    v.b1 = it.b1; v.b2 = it.b2; v.d_in = it.d_in;
-    v.has_uv = (M.flags & 2u) != 0u;
-    float uv_x = it.b1, uv_y = it.b2;
-    if (v.has_uv) {
-        v.duv0[0] = r1[6] - r0[6]; v.duv0[1] = r1[7] - r0[7]; v.duv1[0] = r2[6] - r0[6]; v.duv1[1] = r2[7] - r0[7];
-        uv_x = fma_(v.duv0[0], it.b1, fma_(v.duv1[0], it.b2, r0[6])); uv_y = fma_(v.duv0[1], it.b1, fma_(v.duv1[1], it.b2, r0[7]));
-    }
-    const DBsdf B = S.bsdfs[bsdf];             /* the record serving this side (TwoSidedBRDF picks front / back) */
-    const float sign = (it.nee_flags & HAR_SHAPE_FLIPPED) ? -1.f : 1.f;
-    TexTaps taps; const Vec3 rho = bsdf_reflectance(S, B, uv_x, uv_y, taps);
-    Vec3 rho_du(0.f), rho_dv(0.f);
-    if (B.texture >= 0) tex_fetch_grad(S.textures[B.texture], taps, rho_du, rho_dv);
-    v.uv_bar[0] = 0.f; v.uv_bar[1] = 0.f;
-    const bool lit = (it.nee_flags & HAR_SHAPE_LIT) != 0u;
-    bool any = false;
-    /* emitter sampling: sum_c dl_c W_c d(rho_c / pi cos) + sum_c dl_c W_c rho_c / pi cos dlogJ, with W_c cos / pi = dLr_drho_c */
-    v.nee.on = false;
-    if ((it.nee_flags & HAR_SHAPE_NEE) && visible && lit && it.cos_em > 0.f) {
-        const Vec3 k = dl * dLr_drho;
-        v.nee.on = true; v.nee.attached = (it.nee_flags & HAR_SHAPE_NEE_SURFACE) != 0u;
-        v.nee.target = it.q; v.nee.normal = it.n_e; v.nee.w = it.w_em;
-        const float s = k.x * rho.x + k.y * rho.y + k.z * rho.z;
-        v.nee.cos_bar = sign * s / it.cos_em; v.nee.a = v.nee.attached ? s : 0.f;       /* cos_em = sign <w, n> */
-        v.uv_bar[0] += k.x * rho_du.x + k.y * rho_du.y + k.z * rho_du.z;
-        v.uv_bar[1] += k.x * rho_dv.x + k.y * rho_dv.y + k.z * rho_dv.z;
-        any = true;
-    }
-    /* continuation: sum_c dl_c L_c (d(rho_c cos) / (rho_c cos) + dlogJ) */
-    v.ind.on = false;
-    if (has_next) {
-        const Vec3 k = dl * L;
-        const Vec3 e1 = v.p1 - v.p0, e2 = v.p2 - v.p0;
-        const Vec3 n = normalize3(cross3(e1, e2));
-        const float cos_ind = sign * dot3(next_d, n);
-        const bool f_on = lit && cos_ind > 0.f;
-        v.ind.on = true; v.ind.attached = next_valid;
-        v.ind.target = next_p; v.ind.normal = next_n; v.ind.w = next_d;
-        v.ind.cos_bar = 0.f;
-        if (f_on) {
-            float s = 0.f;
-            if (rho.x != 0.f) { s += k.x; v.uv_bar[0] += k.x * rho_du.x / rho.x; v.uv_bar[1] += k.x * rho_dv.x / rho.x; }
-            if (rho.y != 0.f) { s += k.y; v.uv_bar[0] += k.y * rho_du.y / rho.y; v.uv_bar[1] += k.y * rho_dv.y / rho.y; }
-            if (rho.z != 0.f) { s += k.z; v.uv_bar[0] += k.z * rho_du.z / rho.z; v.uv_bar[1] += k.z * rho_dv.z / rho.z; }
-            v.ind.cos_bar = sign * s / cos_ind;
-        }
-        v.ind.a = next_valid ? k.x + k.y + k.z : 0.f;
-        any = any || k.x != 0.f || k.y != 0.f || k.z != 0.f;
-    }
-    if (!any) return false;
-    shape_vertex_adjoint(v, g);
-    return true;
+/* what one vertex adds: to the three vertices of its own triangle (`self_mesh`) or to its instance's to_world (`self_inst`, 12 floats column-major 3x4
+ * like DInst::to_world), and the same for the PREVIOUS vertex, which the attached si.wi follows */
+struct ShapeGrad {
+    bool self_mesh, self_inst, prev_mesh, prev_inst;
+    Vec3 g[3]; uint32_t vid[3]; float gM[12];
+    Vec3 gp[3]; uint32_t pvid[3]; float gpM[12];
+};
+
+HAR_HD void shape_triangle(const DScene &S, uint32_t shape, uint32_t prim, uint32_t vid[3], const float *r[3]) {
+    const DMesh M = S.meshes[shape];
+    const uint32_t *f = S.faces + 4 * (size_t) (M.foff + prim);
+    for (int k = 0; k < 3; ++k) { vid[k] = f[k]; r[k] = S.verts + 8 * (size_t) (M.voff + f[k]); }
 }
 
-/* The same vertex on INSTANCED geometry, differentiated w.r.t. the instance's `to_world` (Instance::compute_surface_interaction with an attached
- * transform, src/shapes/instance.cpp:150-266): the nested interaction is detached, `si.p = to_world * p_obj` carries the motion (:191-193), the
- * normals use dr::detach(to_world) and uv is not attached (:250-251), and without FollowShape the point is put back onto the ray,
- *   t = (<n, p_att> - <n, o>) / <n, d>,  p = ray(t)   (:240-249)   =>   p_att_bar = n <p_bar, d> / <n, d>,   to_world_bar = p_att_bar (x) (p_obj, 1).
- * Any vertex normals / texcoords of the nested mesh are fine (they are values here).  gM: 12 floats, column-major 3x4 like DInst::to_world. */
-HAR_HD bool instance_item_adjoint(const DScene &S, const ShapeItem &it, uint32_t inst, uint32_t bsdf, bool visible, Vec3 L, Vec3 dl, Vec3 dLr_drho,
-                                  bool has_next, bool next_valid, Vec3 next_p, Vec3 next_n, Vec3 next_d, float gM[12]) {
+/* One path vertex.  self_on / prev_on: the vertex's own geometry / the previous vertex's geometry is differentiated.  `visible` = the emitter sample is not
+ * occluded; L = the radiance accumulator after this vertex's subtraction (prb.py:227); dl = the film adjoint; the next interaction (position / geometric
+ * normal; next_valid = false for an escaped ray) is detached (prb.py:263-266).  Returns false when nothing contributes. */
+HAR_HD bool shape_item_adjoint(const DScene &S, const ShapeItem &it, bool self_on, bool prev_on, bool visible, Vec3 L, Vec3 dl,
+                               bool has_next, bool next_valid, Vec3 next_p, Vec3 next_n, Vec3 next_d, ShapeGrad &out) {
+    out.self_mesh = out.self_inst = out.prev_mesh = out.prev_inst = false;
+    const bool depth0 = it.prev_shape == HAR_SHAPE_NONE;
+    prev_on = prev_on && !depth0;
+    if (!self_on && !prev_on) return false;
+    const SurfInt si = compute_si(S, it.d_in, 0.f, it.b1, it.b2, it.prim, it.shape, it.inst);     /* detached values: p, n, frame, wi, uv */
     const DMesh M = S.meshes[it.shape];
-    const uint32_t *f = S.faces + 4 * (size_t) (M.foff + it.prim);
-    const float *r0 = S.verts + 8 * (size_t) (M.voff + f[0]), *r1 = S.verts + 8 * (size_t) (M.voff + f[1]), *r2 = S.verts + 8 * (size_t) (M.voff + f[2]);
-    const Vec3 p_obj = fma3(Vec3(r0[0], r0[1], r0[2]), 1.f - it.b1 - it.b2, fma3(Vec3(r1[0], r1[1], r1[2]), it.b1, Vec3(r2[0], r2[1], r2[2]) * it.b2));
-    const SurfInt si = compute_si(S, it.d_in, 0.f, it.b1, it.b2, it.prim, it.shape, inst);      /* world-space p, geometric normal n, shading normal sn, uv */
-    const DBsdf B = S.bsdfs[bsdf];
-    const float sign = (it.nee_flags & HAR_SHAPE_FLIPPED) ? -1.f : 1.f;
-    TexTaps taps; const Vec3 rho = bsdf_reflectance(S, B, si.uv_x, si.uv_y, taps);
-    const bool lit = (it.nee_flags & HAR_SHAPE_LIT) != 0u;
-    Vec3 p_bar(0.f);
-    if ((it.nee_flags & HAR_SHAPE_NEE) && (it.nee_flags & HAR_SHAPE_NEE_SURFACE) && visible && lit && it.cos_em > 0.f) {
-        const Vec3 k = dl * dLr_drho;
-        const float s = k.x * rho.x + k.y * rho.y + k.z * rho.z;
-        ShapeDirTerm T; T.on = true; T.attached = true; T.target = it.q; T.normal = it.n_e; T.w = it.w_em; T.cos_bar = sign * s / it.cos_em; T.a = s;
-        p_bar = p_bar + dir_term_point_adjoint(T, si.p, si.sn);
+    BsdfSide side; const bool side_ok = bsdf_side(S, M.bsdf, si.wi, side);
+    const DBsdf B = S.bsdfs[side.index];
+    TexTaps taps; const BsdfInputs bin = bsdf_inputs(S, B, si.uv_x, si.uv_y, taps);
+    const bool self_mesh = self_on && it.inst == HAR_SHAPE_NONE;       /* attached triangle: p, n, frame, uv; an attached instance moves p only */
+    Vec3 rho_du(0.f), rho_dv(0.f);
+    if (self_mesh && B.texture >= 0) tex_fetch_grad(S.textures[B.texture], taps, rho_du, rho_dv);
+    SurfInt sp; Vec3 u_prev(0.f); float r_prev = 1.f;
+    if (prev_on) {
+        sp = compute_si(S, it.prev_d, 0.f, it.prev_b1, it.prev_b2, it.prev_prim, it.prev_shape, it.prev_inst);
+        const Vec3 D = sp.p - si.p; r_prev = norm3(D); u_prev = D * rcp_(r_prev);
     }
-    if (has_next && next_valid) {
-        const Vec3 k = dl * L;
-        const float cos_ind = sign * dot3(next_d, si.sn);
-        ShapeDirTerm T; T.on = true; T.attached = true; T.target = next_p; T.normal = next_n; T.w = next_d; T.cos_bar = 0.f;
-        if (lit && cos_ind > 0.f) T.cos_bar = sign * ((rho.x != 0.f ? k.x : 0.f) + (rho.y != 0.f ? k.y : 0.f) + (rho.z != 0.f ? k.z : 0.f)) / cos_ind;
-        T.a = k.x + k.y + k.z;
-        p_bar = p_bar + dir_term_point_adjoint(T, si.p, si.sn);
+    Vec3 p_bar(0.f), n_bar(0.f), s_bar(0.f), t_bar(0.f), pprev_bar(0.f); float uv_bar[2] = { 0.f, 0.f };
+    bool any = false;
+    for (int term = 0; term < 2; ++term) {
+        bool attached; Vec3 w, target, normal, A; float a = 0.f;
+        BsdfEval e; e.value = Vec3(0.f); e.d_slot0 = Vec3(0.f);
+        if (term == 0) {              /* emitter sampling: sum_c dl_c W_c (d f_c + f_c dlogJ) */
+            if (!((it.nee_flags & HAR_SHAPE_NEE) && visible)) continue;
+            w = it.w_em; attached = (it.nee_flags & HAR_SHAPE_NEE_SURFACE) != 0u; target = it.q; normal = it.n_e;
+        } else {                      /* continuation: sum_c dl_c L_c (d f_c / f_c + dlogJ) */
+            if (!has_next) continue;
+            w = next_d; attached = next_valid; target = next_p; normal = next_n;
+        }
+        const Vec3 wo_l = si.to_local(w), wo_side(wo_l.x, wo_l.y, wo_l.z * side.wo_sign);
+        if (side_ok) bsdf_eval_pdf_one(B, bin, side.wi, wo_side, e);
+        if (term == 0) { A = dl * it.W; a = A.x * e.value.x + A.y * e.value.y + A.z * e.value.z; }
+        else {
+            const Vec3 k = dl * L;
+            A = Vec3(e.value.x != 0.f ? k.x / e.value.x : 0.f, e.value.y != 0.f ? k.y / e.value.y : 0.f, e.value.z != 0.f ? k.z / e.value.z : 0.f);
+            a = k.x + k.y + k.z;
+        }
+        if (!attached || !self_on) a = 0.f;
+        float g6[6] = { 0.f, 0.f, 0.f, 0.f, 0.f, 0.f };
+        if (side_ok && (A.x != 0.f || A.y != 0.f || A.z != 0.f)) { bsdf_weighted_value_dir(B, bin, side.wi, wo_side, A, g6); g6[2] *= side.wo_sign; g6[5] *= side.wo_sign; }
+        const Vec3 gwi(g6[0], g6[1], g6[2]), gwo(g6[3], g6[4], g6[5]);
+        /* wo = to_local(w) */
+        if (self_mesh) {
+            s_bar = s_bar + w * gwo.x; t_bar = t_bar + w * gwo.y; n_bar = n_bar + w * gwo.z;
+            const Vec3 c = A * e.d_slot0;                        /* colour slot 0 (uv) */
+            uv_bar[0] += c.x * rho_du.x + c.y * rho_du.y + c.z * rho_du.z; uv_bar[1] += c.x * rho_dv.x + c.y * rho_dv.y + c.z * rho_dv.z;
+        }
+        if (self_on && attached) p_bar = p_bar + dir_point_adjoint(target, normal, si.p, si.ss * gwo.x + si.st * gwo.y + si.sn * gwo.z, a);
+        /* wi */
+        if (depth0) { if (self_mesh) { const Vec3 wv = -it.d_in; s_bar = s_bar + wv * gwi.x; t_bar = t_bar + wv * gwi.y; n_bar = n_bar + wv * gwi.z; } }
+        else if (prev_on) { const Vec3 u_bar = si.ss * gwi.x + si.st * gwi.y + si.sn * gwi.z; pprev_bar = pprev_bar + (u_bar - u_prev * dot3(u_prev, u_bar)) * rcp_(r_prev); }
+        any = true;
     }
-    if (p_bar.x == 0.f && p_bar.y == 0.f && p_bar.z == 0.f) return false;
-    const Vec3 patt_bar = si.n * (dot3(p_bar, it.d_in) / dot3(si.n, it.d_in));
-    const float ph[4] = { p_obj.x, p_obj.y, p_obj.z, 1.f };
-    for (int c = 0; c < 4; ++c) { gM[3 * c] = patt_bar.x * ph[c]; gM[3 * c + 1] = patt_bar.y * ph[c]; gM[3 * c + 2] = patt_bar.z * ph[c]; }
-    return true;
+    if (!any) return false;
+    bool some = false;
+    if (self_mesh) {
+        const float *r[3]; shape_triangle(S, it.shape, it.prim, out.vid, r);
+        ShapeVertex v;
+        v.p0 = Vec3(r[0][0], r[0][1], r[0][2]); v.p1 = Vec3(r[1][0], r[1][1], r[1][2]); v.p2 = Vec3(r[2][0], r[2][1], r[2][2]);
+        v.b1 = it.b1; v.b2 = it.b2; v.d_in = it.d_in;
+        v.has_uv = (M.flags & 2u) != 0u;
+        if (v.has_uv) { v.duv0[0] = r[1][6] - r[0][6]; v.duv0[1] = r[1][7] - r[0][7]; v.duv1[0] = r[2][6] - r[0][6]; v.duv1[1] = r[2][7] - r[0][7]; }
+        v.uv_bar[0] = uv_bar[0]; v.uv_bar[1] = uv_bar[1];
+        v.p_bar = p_bar; v.n_bar = n_bar + coordinate_system_adjoint(si.sn, s_bar, t_bar);
+        out.g[0] = out.g[1] = out.g[2] = Vec3(0.f);
+        shape_vertex_adjoint(v, out.g);
+        out.self_mesh = true; some = true;
+    } else if (self_on && (p_bar.x != 0.f || p_bar.y != 0.f || p_bar.z != 0.f)) {
+        /* Instance::compute_surface_interaction with an attached transform (instance.cpp:150-266): si.p = to_world * p_obj carries the motion (:191-193), and
+         * without FollowShape the point is put back onto the ray, t = (<n, p_att> - <n, o>) / <n, d>, p = ray(t) (:240-249) */
+        uint32_t vid[3]; const float *r[3]; shape_triangle(S, it.shape, it.prim, vid, r);
+        const float b0 = 1.f - it.b1 - it.b2;
+        const float ph[4] = { r[0][0] * b0 + r[1][0] * it.b1 + r[2][0] * it.b2, r[0][1] * b0 + r[1][1] * it.b1 + r[2][1] * it.b2, r[0][2] * b0 + r[1][2] * it.b1 + r[2][2] * it.b2, 1.f };
+        const Vec3 patt_bar = si.n * (dot3(p_bar, it.d_in) / dot3(si.n, it.d_in));
+        for (int c = 0; c < 4; ++c) { out.gM[3 * c] = patt_bar.x * ph[c]; out.gM[3 * c + 1] = patt_bar.y * ph[c]; out.gM[3 * c + 2] = patt_bar.z * ph[c]; }
+        out.self_inst = true; some = true;
+    }
+    if (prev_on && (pprev_bar.x != 0.f || pprev_bar.y != 0.f || pprev_bar.z != 0.f)) {
+        /* pi_prev.compute_surface_interaction(ray_prev, RayFlags::Minimal): only the point is attached -- p = ray_prev(t), t = <p_att - o, n_det> / <n_det, d> */
+        const float *r[3]; shape_triangle(S, it.prev_shape, it.prev_prim, out.pvid, r);
+        const float b0 = 1.f - it.prev_b1 - it.prev_b2;
+        const Vec3 patt_bar = sp.n * (dot3(pprev_bar, it.prev_d) / dot3(sp.n, it.prev_d));
+        if (it.prev_inst == HAR_SHAPE_NONE) { out.gp[0] = patt_bar * b0; out.gp[1] = patt_bar * it.prev_b1; out.gp[2] = patt_bar * it.prev_b2; out.prev_mesh = true; }
+        else {
+            const float ph[4] = { r[0][0] * b0 + r[1][0] * it.prev_b1 + r[2][0] * it.prev_b2, r[0][1] * b0 + r[1][1] * it.prev_b1 + r[2][1] * it.prev_b2, r[0][2] * b0 + r[1][2] * it.prev_b1 + r[2][2] * it.prev_b2, 1.f };
+            for (int c = 0; c < 4; ++c) { out.gpM[3 * c] = patt_bar.x * ph[c]; out.gpM[3 * c + 1] = patt_bar.y * ph[c]; out.gpM[3 * c + 2] = patt_bar.z * ph[c]; }
+            out.prev_inst = true;
+        }
+        some = true;
+    }
+    return some;
 }
 
 } // namespace har

@@ -761,7 +761,10 @@ static V3 path_sample(const Scene &sc, Pcg32 &rng, Ray ray, uint32_t max_depth, 
 //  Slots 0..8 = coordinates of the three vertices of the triangle hit at the current vertex (the next interaction is detached).
 // ---------------------------------------------------------------------------
 
-constexpr int kShapeSlots = 12;      /* 9 vertex coordinates of a top-level triangle, or the 12 entries of an instance's to_world */
+/* slots 0..11: the CURRENT vertex (9 vertex coordinates of a top-level triangle, or the 12 entries of an instance's to_world);
+ * slots 12..23: the same for the PREVIOUS vertex, whose motion the attached si.wi follows (prb.py:128-140) */
+constexpr int kShapeSlots = 24;
+constexpr int kPrevSlot = 12;
 typedef Dual<kShapeSlots> Dn;
 typedef Dual3<kShapeSlots> Dn3;
 static inline Dn3 dn3(V3 v) { return Dn3((double) v.x, (double) v.y, (double) v.z); }
@@ -847,6 +850,102 @@ static inline void dir_and_jacobian(const Dn3 &o, const Dn3 &p, const Dn3 &n, Dn
     Dn3 d = p - o; Dn d2 = ddot(d, d);
     dir = dnormalize(d);
     J = dabs(ddot(n, dir)) / d2;
+}
+
+/* finalize_surface_interaction (interaction.h:570-600) with an attached shading normal: meshes pack no tangents here, sh_frame.s stays zero and the
+ * frame is coordinate_system(sh_frame.n) (vector.h:118-138) -- written over duals, so the tangents follow the normal exactly as the reference's AD sees it */
+struct AttachedFrame { Dn3 s, t, n; };
+static AttachedFrame attach_frame(const AttachedSI &a, const SI &si) {
+    AttachedFrame f; const Dn3 &n = a.sn;
+    const double sign = n.z.v >= 0.0 ? 1.0 : -1.0;                 /* dr::sign / mulsign: constants under differentiation */
+    Dn av = Dn(-1.0) / (Dn(sign) + n.z), b = n.x * n.y * av;
+    Dn3 s((n.x * n.x * av) * sign + Dn(1.0), b * sign, n.x * (-sign)), t(b, n.y * n.y * av + Dn(sign), -n.y);
+    f.s = replace_grad3(si.ss.x, si.ss.y, si.ss.z, s); f.t = replace_grad3(si.st.x, si.st.y, si.st.z, t); f.n = replace_grad3(si.sn.x, si.sn.y, si.sn.z, n);
+    return f;
+}
+static inline Dn3 frame_to_local(const AttachedFrame &f, const Dn3 &v) { return Dn3(ddot(v, f.s), ddot(v, f.t), ddot(v, f.n)); }
+
+/* BSDF::eval (value = f * cos theta_o) of the plugins with a non-delta lobe -- diffuse.cpp:159-179, roughconductor.cpp:429-520, roughplastic.cpp:296-336,
+ * plastic.cpp:318-352 over microfacet.h:185-207,341-365 and fresnel.h:35-116 -- in DOUBLE precision as a function of the two LOCAL directions.  The oracle
+ * differentiates it numerically (central differences): the attached `si.wi` / `wo` of prb.py:128-140,276-288 reach the BSDF through these six numbers.
+ * (wi0, wo0) = the unperturbed directions: every dr::select of the plugin takes the branch THEY take, as the reference's AD does. */
+static double fresnel_r_d(double cos_i, double eta) {
+    const bool outside = cos_i >= 0.0; const double eta_it = outside ? eta : 1.0 / eta, eta_ti = outside ? 1.0 / eta : eta;
+    const double ct2 = 1.0 - (1.0 - cos_i * cos_i) * eta_ti * eta_ti, ci = std::fabs(cos_i), ct = std::sqrt(std::max(ct2, 0.0));
+    if (eta == 1.0) return 0.0;
+    if (ci == 0.0) return 1.0;
+    const double a_s = (ci - eta_it * ct) / (ci + eta_it * ct), a_p = (ct - eta_it * ci) / (ct + eta_it * ci);
+    return 0.5 * (a_s * a_s + a_p * a_p);
+}
+static void bsdf_value_dir_d(const BsdfRecord &b, const double s0[3], const double s1[3], const double wi[3], const double wo[3], const double wi0[3], const double wo0[3], double out[3]) {
+    out[0] = out[1] = out[2] = 0.0;
+    const uint32_t type = b.p.type;
+    if (!(wi0[2] > 0.0 && wo0[2] > 0.0)) return;                      /* every model here is one-sided */
+    if (type == 0) { for (int c = 0; c < 3; ++c) out[c] = s0[c] * (double) InvPi * wo[2]; return; }
+    auto diffuse_base = [&](double k) {                               /* value / (1 - fdr_int * value) or value / (1 - fdr_int) */
+        for (int c = 0; c < 3; ++c) { const double den = b.nonlinear() ? 1.0 - s0[c] * (double) b.internal_reflectance : 1.0 - (double) b.internal_reflectance; out[c] += s0[c] / den * k; }
+    };
+    if (type == 5) {
+        diffuse_base((double) InvPi * wo[2] * (double) b.inv_eta_2 * (1.0 - fresnel_r_d(wi[2], b.p.eta)) * (1.0 - fresnel_r_d(wo[2], b.p.eta)));
+        return;
+    }
+    if (type != 2 && type != 3) return;
+    auto half = [](const double a[3], const double c[3], double H[3]) { for (int k = 0; k < 3; ++k) H[k] = a[k] + c[k]; const double l = std::sqrt(H[0] * H[0] + H[1] * H[1] + H[2] * H[2]); for (int k = 0; k < 3; ++k) H[k] /= l; };
+    auto dot = [](const double a[3], const double c[3]) { return a[0] * c[0] + a[1] * c[1] + a[2] * c[2]; };
+    double H[3], H0[3]; half(wi, wo, H); half(wi0, wo0, H0);
+    const bool ggx = b.mtype() == MicrofacetType::GGX;
+    const double au = std::max((double) b.p.alpha_u, 1e-4), av = type == 3 ? au : std::max((double) b.p.alpha_v, 1e-4);
+    auto Dm = [&](const double m[3]) {
+        const double c2 = m[2] * m[2], q = (m[0] / au) * (m[0] / au) + (m[1] / av) * (m[1] / av);
+        return ggx ? 1.0 / (M_PI * au * av * (q + c2) * (q + c2)) : std::exp(-q / c2) / (M_PI * au * av * c2 * c2);
+    };
+    auto G1 = [&](const double v[3], const double v0[3]) {
+        const double xy = (au * v[0]) * (au * v[0]) + (av * v[1]) * (av * v[1]), t = xy / (v[2] * v[2]);
+        const double xy0 = (au * v0[0]) * (au * v0[0]) + (av * v0[1]) * (av * v0[1]), t0 = xy0 / (v0[2] * v0[2]);
+        double r;
+        if (!ggx) { const double a = 1.0 / std::sqrt(t); r = 1.0 / std::sqrt(t0) >= 1.6 ? 1.0 : (3.535 * a + 2.181 * a * a) / (1.0 + 2.276 * a + 2.577 * a * a); }
+        else r = 2.0 / (1.0 + std::sqrt(1.0 + t));
+        if (xy0 == 0.0) r = 1.0;
+        if (dot(v0, H0) * v0[2] <= 0.0) r = 0.0;
+        return r;
+    };
+    const double D = Dm(H0) * H0[2] > 1e-20 ? Dm(H) : 0.0;
+    const double wih = dot(wi, H);
+    if (type == 2) {
+        if (!(dot(wi0, H0) > 0.0 && dot(wo0, H0) > 0.0) || D == 0.0) return;
+        const double V = D * G1(wi, wi0) * G1(wo, wo0) / (4.0 * wi[2]);
+        auto Fc = [&](double c, double er, double ei) {
+            const double c2 = c * c, s2 = 1.0 - c2, s4 = s2 * s2, t1 = er * er - ei * ei - s2, ab = std::sqrt(std::max(t1 * t1 + 4.0 * ei * ei * er * er, 0.0));
+            const double a = std::sqrt(std::max(0.5 * (ab + t1), 0.0)), T1 = ab + c2, T2 = 2.0 * c * a, rs = (T1 - T2) / (T1 + T2), T3 = ab * c2 + s4, T4 = T2 * s2;
+            return 0.5 * (rs + rs * (T3 - T4) / (T3 + T4));
+        };
+        for (int c = 0; c < 3; ++c) out[c] = s0[c] * Fc(wih, b.p.eta_c[c], b.p.k_c[c]) * V;
+        return;
+    }
+    const double spec = fresnel_r_d(wih, b.p.eta) * D * G1(wi, wi0) * G1(wo, wo0) / (4.0 * wi[2]);
+    auto table = [&](double x, double x0) {                           /* lerp_gather: the cell is the one the unperturbed argument falls into */
+        const std::vector<float> &d = b.external_transmittance; const size_t n = d.size();
+        x *= (double) (n - 1); x0 *= (double) (n - 1);
+        const uint32_t i = std::min<uint32_t>((uint32_t) x0, (uint32_t) (n - 2));
+        return (double) d[i] + ((double) d[i + 1] - (double) d[i]) * (x - (double) i);
+    };
+    for (int c = 0; c < 3; ++c) out[c] = s1[c] * spec;
+    diffuse_base((double) InvPi * (double) b.inv_eta_2 * wo[2] * table(wi[2], wi0[2]) * table(wo[2], wo0[2]));
+}
+/* value and its six directional partials: d[c][j] = d value_c / d wi_j (j < 3), d wo_(j-3) (j >= 3) */
+struct DirGrad { double d[3][6]; };
+static void bsdf_dir_grad_fd(const BsdfRecord &b, V3 slot0, V3 slot1, V3 wi, V3 wo, DirGrad &g) {
+    const double s0[3] = { slot0.x, slot0.y, slot0.z }, s1[3] = { slot1.x, slot1.y, slot1.z };
+    const double x0[6] = { wi.x, wi.y, wi.z, wo.x, wo.y, wo.z };
+    const double h = 1e-6;
+    for (int j = 0; j < 6; ++j) {
+        double xp[6], xm[6], fp[3], fm[3];
+        for (int k = 0; k < 6; ++k) { xp[k] = x0[k]; xm[k] = x0[k]; }
+        xp[j] += h; xm[j] -= h;
+        bsdf_value_dir_d(b, s0, s1, xp, xp + 3, x0, x0 + 3, fp);
+        bsdf_value_dir_d(b, s0, s1, xm, xm + 3, x0, x0 + 3, fm);
+        for (int c = 0; c < 3; ++c) g.d[c][j] = (fp[c] - fm[c]) / (2.0 * h);
+    }
 }
 
 struct ShapeSink { double *const *pos; const uint8_t *mask; double *inst = nullptr; const uint8_t *inst_mask = nullptr; /* 12 per instance: d / d to_world (column-major 3x4) */ };
@@ -954,6 +1053,7 @@ static V3 prb_sample(const Scene &sc, Pcg32 &rng, Ray ray, uint32_t max_depth, u
     PI pi; st.closest_rays++; scene_trace<false>(sc, ray, pi, 0);
     if (sc.hide_emitters) skip_area_emitters(sc, ray, pi, st);             // prb.py:112-118
     V3 prev_p(0.f); float bsdf_pdf_prev = 1.f; bool bsdf_delta_prev = true;
+    Ray ray_prev = ray; PI pi_prev; SI si_prev;                 // prb.py:105-109: the previous vertex, for the attached si.wi
     uint32_t iter = 0;
     while (active && iter < max_depth) {                      // prb.py:121-123 (max_iterations)
         ++iter; st.vertices++;
@@ -1054,56 +1154,86 @@ static V3 prb_sample(const Scene &sc, Pcg32 &rng, Ray ray, uint32_t max_depth, u
                                                        wol.x, wol.y, wol.z, dwo[0][0], f[0], Lc[0], dl[0]);
             }
         }
-        if (!primal && grad && grad->shape && si.valid() && bsdf.rec && bsdf.rec->p.type == 0) {
-            /* prb.py:124-141 (attached si), :176-216 (emitter sampling with the attached shading point), :261-297 (attached wo, J):
-               d/d(vertex positions) of  Lr_dir + Lr_ind  for a `diffuse` BSDF, f * cos = rho(uv) / pi * cos_theta_o.
-               The shape terms exist only at vertices whose own triangle is attached (attach_si: a.diff), so the restriction to `diffuse` concerns the
-               DIFFERENTIATED meshes (checked by the driver); vertices on other meshes, whatever their BSDF, contribute nothing here */
+        if (!primal && grad && grad->shape && si.valid() && bsdf.rec) {
+            /* prb.py:124-141 (attached si, si.wi re-attached to the motion of the PREVIOUS vertex), :176-216 (emitter sampling with the attached shading
+               point), :261-297 (attached wo, J): d/d(vertex positions, instance transforms) of  Lr_dir + Lr_ind  for whatever BSDF the vertex carries.
+               The BSDF value is a function of (si.wi, wo, si.uv); the oracle differentiates it numerically in the two directions (bsdf_dir_grad_fd) and
+               chains the result with the duals of the attached geometry.  A vertex contributes when its own triangle is attached (a.diff) or when the
+               previous vertex's is (ap.diff: only si.wi moves, so only BSDFs that depend on wi see it).  relative_grad(0) is taken as "no derivative". */
             const ShapeSink &sk = *grad->shape;
             AttachedSI a = attach_si(sc, ray, pi, si, sk.mask, 0, true, sk.inst_mask);
-            Dn3 rho = bsdf.textured ? tex_eval_dual(sc.textures[bsdf.rec->p.texture], bsdf.tl, a.uv) : dn3(bsdf.slot0);
-            double g[kShapeSlots]; for (int k = 0; k < kShapeSlots; ++k) g[k] = 0.0;
-            const double dl[3] = { dL.x, dL.y, dL.z };
-            auto value_cos = [&](const Dn3 &wo_world, bool lit, Dn out[3]) {       // SmoothDiffuse::eval with wo = si.to_local(wo_world)
-                Dn cos_o = ddot(wo_world, a.sn) * (double) bsdf.wo_sign;           // Frame3f::cos_theta(to_local(v)) = dot(v, n); twosided.cpp:124-127 mirrors wo
-                const Dn *r[3] = { &rho.x, &rho.y, &rho.z };
-                for (int c = 0; c < 3; ++c) out[c] = lit ? (*r[c]) * (double) InvPi * cos_o : Dn(0.0);
-            };
-            if (active_em && a.diff) {                                             // otherwise every input of Lr_dir is detached
-                const uint32_t et = sc.emitters[ds.emitter].type;
-                const bool is_surface = et == 0 || et == 3;
-                Dn3 dsd = dn3(ds.d); Dn J(1.0);
-                if (is_surface) {                                                  // prb.py:189-201: ds.d = normalize(ds.p - si.p), J(si.p, detach(ds.p), detach(ds.n))
-                    Dn3 dir; dir_and_jacobian(a.p, dn3(ds.p), dn3(ds.n), dir, J);
-                    dsd = replace_grad3(ds.d.x, ds.d.y, ds.d.z, dir);
+            AttachedSI ap;
+            if (depth >= 1) ap = attach_si(sc, ray_prev, pi_prev, si_prev, sk.mask, kPrevSlot, false, sk.inst_mask);     /* pi_prev.compute_surface_interaction(ray_prev, Minimal) */
+            if (a.diff || ap.diff) {
+                const AttachedFrame fr = attach_frame(a, si);
+                Dn3 wi_l;
+                if (depth == 0) wi_l = frame_to_local(fr, dn3(-ray.d));            /* compute_surface_interaction: wi = to_local(-ray.d) in the attached frame */
+                else {                                                             /* prb.py:137-140: si_detached.to_local(normalize(si_prev.p - si_detached.p)) */
+                    AttachedFrame fd; fd.s = dn3(si.ss); fd.t = dn3(si.st); fd.n = dn3(si.sn);
+                    wi_l = frame_to_local(fd, dnormalize(ap.p - dn3(si.p)));
                 }
-                Dn f[3]; value_cos(dsd, bsdf.ok && bsdf.wi.z > 0.f && wo_em.z * bsdf.wo_sign > 0.f, f);
-                const double w[3] = { (double) beta_cur.x * mis_em * em_weight.x, (double) beta_cur.y * mis_em * em_weight.y, (double) beta_cur.z * mis_em * em_weight.z };
-                for (int c = 0; c < 3; ++c) {
-                    if (w[c] == 0.0 || J.v == 0.0) continue;
-                    for (int k = 0; k < kShapeSlots; ++k) g[k] += dl[c] * w[c] * (f[c].d[k] + f[c].v * J.d[k] / J.v);      // em_weight *= relative_grad(J)
+                wi_l = replace_grad3(si.wi.x, si.wi.y, si.wi.z, wi_l);
+                Dn3 rho = bsdf.textured ? tex_eval_dual(sc.textures[bsdf.rec->p.texture], bsdf.tl, a.uv) : dn3(bsdf.slot0);
+                double g[kShapeSlots]; for (int k = 0; k < kShapeSlots; ++k) g[k] = 0.0;
+                const double dl[3] = { dL.x, dL.y, dL.z };
+                /* bsdf.eval(ctx, si, si.to_local(wo_world)) with everything attached; TwoSidedBRDF mirrors both directions for the back side (twosided.cpp:124-127) */
+                auto value_cos = [&](const Dn3 &wo_world, V3 wo_value, Dn out[3]) {
+                    Dn3 wo_l = replace_grad3(wo_value.x, wo_value.y, wo_value.z, frame_to_local(fr, wo_world));
+                    const double sg = bsdf.wo_sign;
+                    const V3 wo_side(wo_value.x, wo_value.y, wo_value.z * bsdf.wo_sign);
+                    BSDFEval ev; if (bsdf.ok) ev = plugin_eval_pdf(*bsdf.rec, bsdf.slot0, bsdf.slot1, bsdf.wi, wo_side);
+                    DirGrad dg; for (int c = 0; c < 3; ++c) for (int j = 0; j < 6; ++j) dg.d[c][j] = 0.0;
+                    if (bsdf.ok) bsdf_dir_grad_fd(*bsdf.rec, bsdf.slot0, bsdf.slot1, bsdf.wi, wo_side, dg);
+                    const Dn *in[6] = { &wi_l.x, &wi_l.y, &wi_l.z, &wo_l.x, &wo_l.y, &wo_l.z };
+                    const Dn *r[3] = { &rho.x, &rho.y, &rho.z };
+                    const float val[3] = { ev.value.x, ev.value.y, ev.value.z }, ds0[3] = { ev.d_slot0.x, ev.d_slot0.y, ev.d_slot0.z };
+                    for (int c = 0; c < 3; ++c) {
+                        Dn f((double) val[c]);
+                        for (int k = 0; k < kShapeSlots; ++k) {
+                            double acc = (double) ds0[c] * r[c]->d[k];
+                            for (int j = 0; j < 6; ++j) acc += dg.d[c][j] * in[j]->d[k] * ((j == 2 || j == 5) ? sg : 1.0);
+                            f.d[k] = acc;
+                        }
+                        out[c] = f;
+                    }
+                };
+                if (active_em) {
+                    const uint32_t et = sc.emitters[ds.emitter].type;
+                    const bool is_surface = et == 0 || et == 3;
+                    Dn3 dsd = dn3(ds.d); Dn J(1.0);
+                    if (is_surface) {                                              // prb.py:189-201: ds.d = normalize(ds.p - si.p), J(si.p, detach(ds.p), detach(ds.n))
+                        Dn3 dir; dir_and_jacobian(a.p, dn3(ds.p), dn3(ds.n), dir, J);
+                        dsd = replace_grad3(ds.d.x, ds.d.y, ds.d.z, dir);
+                    }
+                    Dn f[3]; value_cos(dsd, wo_em, f);
+                    const double w[3] = { (double) beta_cur.x * mis_em * em_weight.x, (double) beta_cur.y * mis_em * em_weight.y, (double) beta_cur.z * mis_em * em_weight.z };
+                    for (int c = 0; c < 3; ++c) {
+                        if (w[c] == 0.0 || J.v == 0.0) continue;
+                        for (int k = 0; k < kShapeSlots; ++k) g[k] += dl[c] * w[c] * (f[c].d[k] + f[c].v * J.d[k] / J.v);      // em_weight *= relative_grad(J)
+                    }
                 }
+                if (active_next) {                                                 // prb.py:261-297
+                    /* si_next is computed OUTSIDE dr.resume_grad() (prb.py:263-266): its position and normal are detached, only the current
+                       point moves in wo and in the Jacobian */
+                    SI si_next = compute_si(sc, ray_next, pi_next);
+                    Dn3 wo_world = dn3(ray_next.d); Dn J(1.0);
+                    if (pi_next.valid()) {
+                        Dn3 dir; dir_and_jacobian(a.p, dn3(si_next.p), dn3(si_next.n), dir, J);
+                        wo_world = replace_grad3(ray_next.d.x, ray_next.d.y, ray_next.d.z, dir);
+                    }
+                    Dn f[3]; value_cos(wo_world, si.to_local(ray_next.d), f);
+                    const double Lc[3] = { L.x, L.y, L.z };
+                    for (int c = 0; c < 3; ++c) {
+                        if (Lc[c] == 0.0) continue;
+                        for (int k = 0; k < kShapeSlots; ++k)
+                            g[k] += dl[c] * Lc[c] * ((f[c].v != 0.0 ? f[c].d[k] / f[c].v : 0.0) + (J.v != 0.0 ? J.d[k] / J.v : 0.0));
+                    }
+                }
+                shape_scatter(sk, a, 0, g);
+                shape_scatter(sk, ap, kPrevSlot, g);
             }
-            if (active_next && a.diff) {                                           // prb.py:261-297
-                /* si_next is computed OUTSIDE dr.resume_grad() (prb.py:263-266): its position and normal are detached, only the current
-                   point moves in wo and in the Jacobian */
-                SI si_next = compute_si(sc, ray_next, pi_next);
-                Dn3 wo_world = dn3(ray_next.d); Dn J(1.0);
-                if (pi_next.valid()) {
-                    Dn3 dir; dir_and_jacobian(a.p, dn3(si_next.p), dn3(si_next.n), dir, J);
-                    wo_world = replace_grad3(ray_next.d.x, ray_next.d.y, ray_next.d.z, dir);
-                }
-                V3 wo_l = si.to_local(ray_next.d);
-                Dn f[3]; value_cos(wo_world, bsdf.ok && bsdf.wi.z > 0.f && wo_l.z * bsdf.wo_sign > 0.f, f);
-                const double Lc[3] = { L.x, L.y, L.z };
-                for (int c = 0; c < 3; ++c) {
-                    if (Lc[c] == 0.0) continue;
-                    for (int k = 0; k < kShapeSlots; ++k)
-                        g[k] += dl[c] * Lc[c] * ((f[c].v != 0.0 ? f[c].d[k] / f[c].v : 0.0) + (J.v != 0.0 ? J.d[k] / J.v : 0.0));
-                }
-            }
-            shape_scatter(sk, a, 0, g);
         }
+        if (si.valid()) { ray_prev = ray; pi_prev = pi; si_prev = si; }          // prb.py:327-330 (only lanes that met a surface continue)
         if (si.valid()) depth += 1;                               // prb.py:326
         active = active_next; pi = pi_next; ray = ray_next;
     }
@@ -1557,18 +1687,10 @@ static int prb_backward_impl(void *scene, const OrcSensor *sp, const float *grad
                              uint64_t lb = 0, uint64_t le = 0, const float *weight_film = nullptr, float *grad_bsdf_params = nullptr,
                              const uint8_t *inst_mask = nullptr, double *grad_to_world = nullptr) {
     Scene &sc = *(Scene *) scene; const OrcSensor &s = *sp;
-    /* the attached-geometry restatement evaluates the `diffuse` model at attached vertices: the MOVING meshes (the masked ones; the meshes of the
-     * shape groups for instance transforms) must carry `diffuse` BSDFs, plain or inside `twosided`; every other mesh may carry any model */
-    auto diffuse_record = [&](int32_t k) {
-        if (k < 0 || (size_t) k >= sc.bsdfs.size()) return false;
-        const BsdfRecord &b = sc.bsdfs[(size_t) k];
-        return b.p.type == 0 && (b.p.back < 0 || sc.bsdfs[(size_t) b.p.back].p.type == 0);
-    };
-    if (inst_mask) for (size_t m = sc.top_count; m < sc.meshes.size(); ++m) if (!diffuse_record((int32_t) sc.meshes[m].bsdf)) return -2;
+    /* any BSDF model may sit on (or next to) the moving geometry: the attached BSDF value is differentiated in si.wi / wo numerically (bsdf_dir_grad_fd) */
     if (pos_mask) {           /* flat-shaded top-level meshes */
         for (size_t m = 0; m < sc.meshes.size(); ++m) {
             if (!pos_mask[m]) continue;
-            if (!diffuse_record((int32_t) sc.meshes[m].bsdf)) return -2;
             if ((sc.meshes[m].flags & 1u) || m >= sc.top_count) return -3;
         }
     }

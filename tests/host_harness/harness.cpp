@@ -189,7 +189,6 @@ float hh_rfilter_eval(const HarSensor *sensor, float x) {
 static int backward_shape_impl(void *h, const HarSensor *sensor, const float *adj, uint32_t seed, uint32_t spp, int32_t max_depth, int32_t rr_depth,
                                double *const *grad, double *inst_grad) {
     HScene *H = (HScene *) h; const DScene &S = H->ds;
-    /* the moving meshes must be diffuse (checked by the callers / the C entry points); the rest of the scene is shaded by the generic code */
     DSensor C; std::string e; if (!lower_sensor(*sensor, C, e)) return -1;
     const uint64_t total = (uint64_t) C.samp_w * C.samp_h * spp;
     uint32_t log_spp = 0xffffffffu; for (uint32_t k = 0; k < 32; ++k) if ((1u << k) == spp) log_spp = k;
@@ -218,6 +217,8 @@ static int backward_shape_impl(void *h, const HarSensor *sensor, const float *ad
         /* adjoint replay */
         PathState st = st0; bool alive = P.max_depth != 0;
         Hit hit; { HostStack stack; if (alive) accel_trace<false>(S.accel, st.o, st.d, st.maxt, hit, stack, status); }
+        Hit prev; prev.t = HAR_INF; prev.shape = HAR_SHAPE_NONE; prev.prim = 0; prev.inst = HAR_SHAPE_NONE; prev.u = prev.v = 0.f; Vec3 prev_d(0.f);
+        auto moving = [&](uint32_t shape, uint32_t inst) { return shape != HAR_SHAPE_NONE && (inst == HAR_SHAPE_NONE ? (grad && grad[shape]) : inst_grad != nullptr); };
         while (alive) {
             ShadeResult R; shade_lane<MODE_PRB_ADJOINT, HAR_BSDF_ALL_TYPES>(S, P, st, hit, R);
             if (R.add_emission) L = L - R.em_b;
@@ -229,26 +230,23 @@ static int backward_shape_impl(void *h, const HarSensor *sensor, const float *ad
                 next_valid = next.t != HAR_INF;
                 if (next_valid) { SurfInt sn = compute_si(S, R.next.d, next.t, next.u, next.v, next.prim, next.shape, next.inst); np = sn.p; nn = sn.n; }
             }
-            if (R.item && hit.inst != 0xffffffffu && inst_grad) {       /* d / d to_world of the instance (instance_item_adjoint), as k_shape_adjoint drives it */
-                ShapeItem it; it.shape = hit.shape; it.prim = hit.prim; it.b1 = hit.u; it.b2 = hit.v; it.d_in = st.d;
+            const bool self_on = hit.t != HAR_INF && moving(hit.shape, hit.inst), prev_on = moving(prev.shape, prev.inst);
+            if ((R.item || R.alive) && hit.t != HAR_INF && (self_on || prev_on)) {       /* the record k_shade<SHAPE> writes, the call k_shape_adjoint makes */
+                ShapeItem it; it.shape = hit.shape; it.prim = hit.prim; it.inst = hit.inst; it.b1 = hit.u; it.b2 = hit.v; it.d_in = st.d;
                 it.next_slot = R.alive ? 0u : HAR_SHAPE_NO_NEXT;
-                it.q = R.nee_p; it.n_e = R.nee_n; it.cos_em = R.cos_em; it.nee_flags = R.item_ray ? R.nee_flags : (R.nee_flags & HAR_SHAPE_LIT); it.w_em = Vec3(0.f);
-                float gM[12];
-                if (instance_item_adjoint(S, it, hit.inst, R.bsdf, visible, L, dl, R.dLr_drho, R.alive, next_valid, np, nn, R.next.d, gM))
-                    for (int k = 0; k < 12; ++k) inst_grad[12 * (size_t) hit.inst + k] += gM[k];
-            }
-            if (R.item && hit.inst == 0xffffffffu && grad && grad[hit.shape]) {
-                ShapeItem it; it.shape = hit.shape; it.prim = hit.prim; it.b1 = hit.u; it.b2 = hit.v; it.d_in = st.d;
-                it.next_slot = R.alive ? 0u : HAR_SHAPE_NO_NEXT;
-                it.q = R.nee_p; it.n_e = R.nee_n; it.cos_em = R.cos_em; it.nee_flags = R.item_ray ? R.nee_flags : (R.nee_flags & HAR_SHAPE_LIT);
+                it.q = R.nee_p; it.n_e = R.nee_n; it.nee_flags = R.item_ray ? R.nee_flags : (R.nee_flags & HAR_SHAPE_LIT); it.W = R.nee_w;
+                it.prev_shape = prev.shape; it.prev_prim = prev.prim; it.prev_inst = prev.inst; it.prev_b1 = prev.u; it.prev_b2 = prev.v; it.prev_d = prev_d;
                 const SurfInt si = compute_si(S, st.d, hit.t, hit.u, hit.v, hit.prim, hit.shape, hit.inst);
                 it.w_em = (it.nee_flags & HAR_SHAPE_NEE_SURFACE) ? normalize3(it.q - si.p) : it.q;
-                Vec3 g[3] = { Vec3(0.f), Vec3(0.f), Vec3(0.f) }; uint32_t vid[3];
-                if (shape_item_adjoint(S, it, R.bsdf, visible, L, dl, R.dLr_drho, R.alive, next_valid, np, nn, R.next.d, g, vid)) {
-                    double *dst = grad[hit.shape];
-                    for (int k = 0; k < 3; ++k) { dst[3 * (size_t) vid[k]] += g[k].x; dst[3 * (size_t) vid[k] + 1] += g[k].y; dst[3 * (size_t) vid[k] + 2] += g[k].z; }
+                ShapeGrad G;
+                if (shape_item_adjoint(S, it, self_on, prev_on, visible, L, dl, R.alive, next_valid, np, nn, R.next.d, G)) {
+                    if (G.self_mesh) { double *dst = grad[hit.shape]; for (int k = 0; k < 3; ++k) { dst[3 * (size_t) G.vid[k]] += G.g[k].x; dst[3 * (size_t) G.vid[k] + 1] += G.g[k].y; dst[3 * (size_t) G.vid[k] + 2] += G.g[k].z; } }
+                    if (G.self_inst) for (int k = 0; k < 12; ++k) inst_grad[12 * (size_t) hit.inst + k] += G.gM[k];
+                    if (G.prev_mesh) { double *dst = grad[prev.shape]; for (int k = 0; k < 3; ++k) { dst[3 * (size_t) G.pvid[k]] += G.gp[k].x; dst[3 * (size_t) G.pvid[k] + 1] += G.gp[k].y; dst[3 * (size_t) G.pvid[k] + 2] += G.gp[k].z; } }
+                    if (G.prev_inst) for (int k = 0; k < 12; ++k) inst_grad[12 * (size_t) prev.inst + k] += G.gpM[k];
                 }
             }
+            if (hit.t != HAR_INF) { prev = hit; prev_d = st.d; }
             alive = R.alive; st = R.next; hit = next;
         }
     }

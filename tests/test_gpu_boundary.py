@@ -281,7 +281,7 @@ def test_bsdf_parameter_update_rebuilds_records(mi):
 
 # ------------------------------------------------------------------ PRB gradients of an instance's to_world (instance.cpp:150-266)
 
-@pytest.mark.parametrize("which", ["slab", "slab_env", "cbox", "cbox_nocache", "cbox_with_positions"])
+@pytest.mark.parametrize("which", ["slab", "slab_env", "cbox", "cbox_nocache", "cbox_with_positions", "slab_roughplastic", "slab_roughconductor"])
 def test_prb_instance_to_world_gradients(mi, O, which):
     """har_integrator_set_grad_instances: the wavefront adjoint (geometry records of k_shade<ADJOINT, SHAPE> carrying the instance index,
     k_shape_adjoint -> instance_item_adjoint) vs the oracle's dual-number restatement of Instance::compute_surface_interaction with an attached
@@ -291,7 +291,7 @@ def test_prb_instance_to_world_gradients(mi, O, which):
     if which.startswith("cbox"):
         res = 32; d = instanced_cbox_scene(mi, res, grid=3)
     else:
-        res = 24; d = instanced_slab_scene(mi, res, env=which == "slab_env")
+        res = 24; d = instanced_slab_scene(mi, res, env=which == "slab_env", model=which[5:] if which.startswith("slab_rough") else None)
     spp = 16
     keys = [k for k, v in d.items() if isinstance(v, dict) and v.get("type") == "instance"]
     wanted = [k + ".to_world" for k in keys]
@@ -335,7 +335,7 @@ def test_prb_instance_to_world_gradients(mi, O, which):
 
 def test_instance_to_world_update_and_domain(mi, O):
     """params['<instance>.to_world'] = ...; params.update(): the next render sees the moved instance (== the oracle on the updated scene);
-    non-diffuse scenes are refused"""
+    purely specular instanced meshes are refused"""
     import torch
     from tests.test_shape_gradients_cpu import instanced_cbox_scene
     d = instanced_cbox_scene(mi, 24, grid=2)
@@ -352,8 +352,12 @@ def test_instance_to_world_update_and_domain(mi, O):
     assert rel_l2(after, ref) < 1e-4 and rel_l2(after, before) > 1e-3
     d = mi.instanced_spheres_scene(width=16, height=16, spp=4, grid=2, n_u=8, n_v=4, materials=True)
     d["integrator"] = {"type": "prb", "max_depth": 3, "shape_gradients": ["inst000.to_world"]}
+    scene = mi.load_dict(d)                             # rough-plastic spheres: inside the domain
+    out = scene.integrator().render_backward(scene, None, np.ones((16, 16, 3), np.float32), seed=0, spp=4)
+    assert out["inst000.to_world"].abs().max() > 0
+    d["spheres"]["ball"]["bsdf"] = {"type": "ref", "id": "glass"}      # delta lobes only on the moving geometry: eval() = 0, relative_grad(0) -- refused
     scene = mi.load_dict(d)
-    with pytest.raises(RuntimeError, match="diffuse"):
+    with pytest.raises(RuntimeError, match="delta lobes"):
         scene.integrator().render_backward(scene, None, np.ones((16, 16, 3), np.float32), seed=0, spp=4)
 
 

@@ -680,7 +680,8 @@ def _grid_floor(mi, d, n):
     return d
 
 
-@pytest.mark.parametrize("which", ["slab", "slab_textured", "slab_env", "slab_twosided", "slab_crop_box", "cbox", "cbox_grid", "cbox_nocache", "slab_rough_conductor", "slab_rough_plastic"])
+@pytest.mark.parametrize("which", ["slab", "slab_textured", "slab_env", "slab_twosided", "slab_crop_box", "cbox", "cbox_grid", "cbox_nocache", "slab_rough_conductor", "slab_rough_plastic",
+                                   "floor_roughconductor", "floor_roughconductor_beckmann", "floor_roughplastic", "floor_plastic", "both_roughconductor", "cbox_rough"])
 def test_prb_vertex_position_gradients(mi, O, which):
     """har_integrator_set_grad_positions: the wavefront adjoint (k_shade<ADJOINT, SHAPE> geometry records, visibility from k_resolve,
     k_shape_adjoint with the next bounce's detached interaction) vs the oracle's dual-number restatement, vertex by vertex; the colour
@@ -689,12 +690,20 @@ def test_prb_vertex_position_gradients(mi, O, which):
     from tests.test_shape_gradients_cpu import slab_scene, cbox_mesh_scene, twosided_slab_scene, rough_slab_scene, mesh_index
     if which == "slab_twosided":
         res = 24; d = twosided_slab_scene(mi, res); names = ["floor", "ceiling", "sheet"]
-    elif which.startswith("slab_rough"):      # a rough (not differentiated) ceiling: generic adjoint kernels around the diffuse floor's shape terms
+    elif which.startswith("slab_rough"):      # a rough (not differentiated) ceiling: its vertices follow the floor through the attached si.wi (prb.py:128-140)
         res = 24; d = rough_slab_scene(mi, res, "roughconductor" if which.endswith("conductor") else "roughplastic"); names = ["floor"]
+    elif which.startswith("floor_") or which.startswith("both_"):      # the MOVING meshes carry the non-diffuse models: d f / d wi, d f / d wo (har_bsdf_dir.h)
+        where, model = which.split("_", 1)
+        res = 24; d = rough_slab_scene(mi, res, model, where); names = ["floor", "ceiling"]
     elif which.startswith("cbox"):
         res = 32; d = cbox_mesh_scene(mi, res); names = ["small-box", "large-box", "floor"]
         if which == "cbox_grid":
             d = _grid_floor(mi, d, 36)
+        if which == "cbox_rough":              # every model on moving geometry at once: a textured rough-plastic floor, a twosided conductor box, a plastic box
+            from tests.test_shape_gradients_cpu import ROUGH_BSDFS
+            d["floor"]["bsdf"] = {"type": "roughplastic", "alpha": 0.25, "diffuse_reflectance": d["floor"]["bsdf"]["reflectance"]}
+            d["small-box"]["bsdf"] = {"type": "twosided", "bsdf": dict(ROUGH_BSDFS["roughconductor"])}
+            d["large-box"]["bsdf"] = dict(ROUGH_BSDFS["plastic"])
     else:
         res = 24; d = slab_scene(mi, res, textured=which in ("slab_textured", "slab_crop_box"), env=which == "slab_env"); names = ["floor"] + ([] if which == "slab_env" else ["ceiling"])
     spp = 16
@@ -748,7 +757,7 @@ def test_vertex_position_update_rebuilds_the_scene(mi, O):
 
 
 def test_vertex_position_gradients_refused_outside_their_domain(mi):
-    """non-diffuse BSDFs / meshes with vertex normals: an error, not a silently incomplete gradient"""
+    """purely specular BSDFs on moving geometry / meshes with vertex normals: an error, not a silently incomplete gradient"""
     from tests.test_bsdfs_cpu import _material_cbox
     d = _material_cbox(mi, 16); d["integrator"] = {"type": "prb", "max_depth": 3, "shape_gradients": True}
     scene = mi.load_dict(d)
@@ -760,15 +769,20 @@ def test_vertex_position_gradients_refused_outside_their_domain(mi):
     with pytest.raises(KeyError):
         scene.integrator().render_backward(scene, None, g, seed=0, spp=4)
     from tests.test_shape_gradients_cpu import slab_scene
-    # a rough mesh may be PART of the scene; asking for ITS vertex positions is refused, `True` selects the meshes the adjoint can differentiate
-    d = slab_scene(mi, 16); d["ceiling"]["bsdf"] = {"type": "roughconductor", "alpha": 0.2}
+    # a mesh with only delta lobes may be PART of the scene; asking for ITS vertex positions is refused (eval() is zero: prb.py:288 would form relative_grad(0)),
+    # `True` selects the meshes the adjoint can differentiate -- rough models included
+    d = slab_scene(mi, 16); d["ceiling"]["bsdf"] = {"type": "conductor", "eta": [0.2, 0.92, 1.1], "k": [3.9, 2.45, 2.14]}
     d["integrator"] = {"type": "prb", "max_depth": 3, "shape_gradients": ["ceiling.vertex_positions"]}
     scene = mi.load_dict(d)
-    with pytest.raises(RuntimeError, match="diffuse"):
+    with pytest.raises(RuntimeError, match="delta lobes"):
         scene.integrator().render_backward(scene, None, g, seed=0, spp=4)
     scene.integrator().shape_gradients = True
     out = scene.integrator().render_backward(scene, None, g, seed=0, spp=4)
     assert "floor.vertex_positions" in out and "ceiling.vertex_positions" not in out
+    d["ceiling"]["bsdf"] = {"type": "roughconductor", "alpha": 0.2}
+    scene = mi.load_dict(d); scene.integrator().shape_gradients = True
+    out = scene.integrator().render_backward(scene, None, g, seed=0, spp=4)
+    assert "floor.vertex_positions" in out and "ceiling.vertex_positions" in out
 
 
 def test_hide_emitters_parity(mi, O):

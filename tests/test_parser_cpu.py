@@ -216,7 +216,7 @@ def test_unreferenced_and_unsupported_properties_are_errors(mi):
     and refuses reference properties it does not implement instead of ignoring them"""
     import pytest
     base = mi.cornell_box()
-    for path, key, value, msg in [(("sensor", "film"), "sample_border", True, "not implemented"), (("sensor", "film"), "widht", 64, "Unreferenced"),
+    for path, key, value, msg in [(("sensor", "film"), "compensate", True, "not implemented"), (("sensor", "film"), "widht", 64, "Unreferenced"),
                                   (("sensor",), "principal_point_offset_x", 0.1, "not implemented"), (("sensor", "sampler"), "samples", 4, "Unreferenced"),
                                   (("integrator",), "maxdepth", 3, "Unreferenced"), (("integrator",), "timeout", 2.0, "not implemented")]:
         d = mi.cornell_box(); node = d
@@ -273,5 +273,9 @@ def test_reference_film_crop_window(mi):
     assert film.size() == (32, 21) and film.crop_size() == (2, 1) and film.crop_offset() == (30, 20)
     with pytest.raises(RuntimeError, match="Invalid crop window"):
         mi.load_dict({'type': 'hdrfilm', 'width': 8, 'height': 8, 'crop_width': 8, 'crop_offset_x': 1})
-    with pytest.raises(RuntimeError, match="sample_border"):        # a border of filter radius would have to be sampled: not built
-        mi.load_dict({'type': 'hdrfilm', 'width': 8, 'height': 8, 'sample_border': True})
+    # sample_border with a bordered filter (round 3): the sample grid grows by rfilter->border_size() = ceil(radius - 1/2 - 2 RayEpsilon) on every side
+    f = mi.load_dict({'type': 'hdrfilm', 'width': 8, 'height': 8, 'sample_border': True})
+    assert f.sample_border() and f.sample_grid() == (12, 12)          # gaussian, stddev 0.5: radius 2 -> border 2
+    assert mi.load_dict({'type': 'hdrfilm', 'width': 8, 'height': 6, 'sample_border': True, 'rfilter': {'type': 'tent'}}).sample_grid() == (10, 8)
+    assert mi.load_dict({'type': 'hdrfilm', 'width': 8, 'height': 6, 'sample_border': True, 'rfilter': {'type': 'box'}}).sample_grid() == (8, 6)
+    assert mi.load_dict({'type': 'hdrfilm', 'width': 8, 'height': 6}).sample_grid() == (8, 6)
