@@ -153,7 +153,7 @@ struct HarIntegratorImpl {
     int *status = nullptr;
     float **d_grad_tex = nullptr; size_t grad_tex_cap = 0;
     /* texel-gradient queues of the adjoint pass (TexelQueues, har_kernels.h): records, counters, band tables; built for `tq_scene` */
-    TexelQueues tq{ nullptr, nullptr, nullptr, nullptr, 0u, 0u }; uint64_t tq_scene = 0; uint32_t tq_lanes = 0, tq_lds = 0;
+    TexelQueues tq{ nullptr, nullptr, nullptr, nullptr, 0u, 0u, nullptr }; uint64_t tq_scene = 0; uint32_t tq_lanes = 0, tq_lds = 0;
     // profiling
     /* Per-launch HIP events of the frames rendered since har_integrator_set_profiling(1).  An event is NEVER re-recorded while an earlier record of it
      * may still be pending: every frame (render_range / backward_range call) takes its own event set from a ring, and a set is only reused after its
@@ -198,7 +198,7 @@ int ensure_workspace(HarIntegratorImpl *I, uint32_t lanes, bool adjoint, int tap
     }
     I->free_ws();
     I->counters = nullptr; I->totals = nullptr; I->status = nullptr; I->adj = nullptr; I->adj_floats = 0; I->d_grad_tex = nullptr; I->grad_tex_cap = 0;
-    I->tq = TexelQueues{ nullptr, nullptr, nullptr, nullptr, 0u, 0u }; I->tq_scene = 0; I->tq_lanes = 0;
+    I->tq = TexelQueues{ nullptr, nullptr, nullptr, nullptr, 0u, 0u, nullptr }; I->tq_scene = 0; I->tq_lanes = 0;
     I->pass_rng = nullptr; I->pass_rng_cap = 0; I->pass_jitter = nullptr; I->pass_jitter_cap = 0;
     I->grad_slots = nullptr; I->grad_slots_cap = 0; I->mq_idx = nullptr; I->mq_count = nullptr;
     for (int k = 0; k < 2; ++k) {
@@ -350,12 +350,12 @@ int ensure_texel_queues(HarSceneImpl *S, HarIntegratorImpl *I) {
             if (it != I->owned.end()) { I->owned.erase(it); dev_free(q); }
         }
     }
-    I->tq = TexelQueues{ nullptr, nullptr, nullptr, nullptr, 0u, 0u }; I->tq_scene = S->serial; I->tq_lanes = I->ws_lanes;
+    I->tq = TexelQueues{ nullptr, nullptr, nullptr, nullptr, 0u, 0u, nullptr }; I->tq_scene = S->serial; I->tq_lanes = I->ws_lanes;
     const size_t nt = S->hs.textures.size();
     if (!enabled || nt == 0) return 0;
-    /* LDS copy of a band: 24 KB by default (measured on the textured 1M-triangle scene, PRB step: 64 KB 127.7 ms, 48 KB 130.4, 24 KB 125.9, 16 KB 126.2 --
-     * LDS float atomics retire about one lane per cycle and CU, so what matters is that every CU holds several blocks); larger copies only where a
-     * texture would otherwise need more than the HAR_TQ_MAX queues.  HAR_TQ_LDS forces one size (A/B). */
+    /* LDS copy of a band: the smallest of 24 / 32 / 48 / 64 KB that keeps the texture within HAR_TQ_MAX queues (three 64-bit accumulators per texel: a 256-wide
+     * texture gets 4-row bands in 32 KB, five blocks per CU).  Round 2 measured the float version at 24 / 48 / 64 KB: 125.9 / 130.4 / 127.7 ms per PRB step --
+     * what matters is that every CU holds several blocks.  HAR_TQ_LDS forces one size (A/B). */
     static const size_t lds_forced = getenv("HAR_TQ_LDS") ? (size_t) atol(getenv("HAR_TQ_LDS")) : 0;
     std::vector<uint2> band(nt); std::vector<uint4> qinfo, heights; uint32_t nq = 0; size_t lds_used = 0;
     for (size_t t = 0; t < nt; ++t) {
@@ -365,9 +365,10 @@ int ensure_texel_queues(HarSceneImpl *S, HarIntegratorImpl *I) {
         const size_t sizes[4] = { (size_t) HAR_TQ_LDS_BYTES, 32768, 49152, 65536 };
         for (int k = 0; k < 4; ++k) {
             const size_t lds = lds_forced ? lds_forced : sizes[k];
-            if ((size_t) W * 12 * 2 > lds) { if (lds_forced) break; continue; }
+            const size_t row_bytes = (size_t) W * 3 * HAR_TQ_ACC_BYTES;                /* three 64-bit fixed-point accumulators per texel */
+            if (row_bytes * 2 > lds) { if (lds_forced) break; continue; }
             /* the LDS copy of a band holds its rows + the row after it (k_texel_accumulate) */
-            const uint32_t rows = std::min<uint32_t>(H, (uint32_t) (lds / ((size_t) W * 12)) - 1u), nb = (H + rows - 1) / rows;
+            const uint32_t rows = std::min<uint32_t>(H, (uint32_t) (lds / row_bytes) - 1u), nb = (H + rows - 1) / rows;
             if (nq + nb > HAR_TQ_MAX) { if (lds_forced) break; continue; }
             band[t] = make_uint2(nq, rows);
             for (uint32_t b = 0; b < nb; ++b) { qinfo.push_back(make_uint4((uint32_t) t, b * rows, std::min(rows, H - b * rows), W)); heights.push_back(make_uint4(H, 0u, 0u, 0u)); }
@@ -381,10 +382,10 @@ int ensure_texel_queues(HarSceneImpl *S, HarIntegratorImpl *I) {
     /* every (shard, band) queue holds twice its mean share of a shard's lanes: 2 x lanes records of 32 bytes in total */
     const uint32_t cap = std::max<uint32_t>(1024u, (uint32_t) (2ull * I->shard_cap / nq));
     if (ws_alloc(I, &d_band, nt) || ws_alloc(I, &d_qinfo, qinfo.size()) || ws_alloc(I, &rec, (size_t) 2 * HAR_SHARDS * nq * cap) ||
-        ws_alloc(I, &count, (size_t) HAR_SHARDS * nq * HAR_COUNTER_STRIDE)) return 1;
+        ws_alloc(I, &count, (size_t) (HAR_SHARDS * nq + 1) * HAR_COUNTER_STRIDE)) return 1;          /* + the launch's gmax word (cleared with the counters) */
     HIP_TRY(hipMemcpy(d_band, band.data(), nt * sizeof(uint2), hipMemcpyHostToDevice));
     HIP_TRY(hipMemcpy(d_qinfo, qinfo.data(), qinfo.size() * sizeof(uint4), hipMemcpyHostToDevice));
-    I->tq = TexelQueues{ rec, count, d_band, d_qinfo, nq, cap }; I->tq_lds = (uint32_t) lds_used;
+    I->tq = TexelQueues{ rec, count, d_band, d_qinfo, nq, cap, count + (size_t) HAR_SHARDS * nq * HAR_COUNTER_STRIDE }; I->tq_lds = (uint32_t) lds_used;
     return 0;
 }
 
@@ -413,7 +414,7 @@ int run_chunk(HarSceneImpl *S, HarIntegratorImpl *I, const DSensor &C, int mode,
             const TapeArrays tp{ I->tape_next + off, I->tape_la[b & 1], I->tape_lb[b & 1], I->tape_la[(b & 1) ^ 1], I->tape_lb[(b & 1) ^ 1],
                                  I->tape_rec[0] + off, I->tape_rec[1] + off, I->tape_rec[2] + off, I->tape_rec[3] + off };
             const bool queued = I->tq.nq != 0;
-            if (queued) HIP_TRY(hipMemsetAsync(I->tq.count, 0, (size_t) HAR_SHARDS * I->tq.nq * HAR_COUNTER_STRIDE * sizeof(uint32_t), s));
+            if (queued) HIP_TRY(hipMemsetAsync(I->tq.count, 0, (size_t) (HAR_SHARDS * I->tq.nq + 1) * HAR_COUNTER_STRIDE * sizeof(uint32_t), s));
             launch_commit(s, cgrid, S->ds, I->shard_cap, cnt_alive(I, b), tp, I->tape_vis + off, grad_refl, I->d_grad_tex, queued ? &I->tq : nullptr,
                           b == 0 ? I->result : nullptr, b == 0 ? I->dL : nullptr);
             prof_mark(I, s, CLS_SHADE);
@@ -515,7 +516,7 @@ int run_chunk(HarSceneImpl *S, HarIntegratorImpl *I, const DSensor &C, int mode,
         }
         const bool cached = rc.mode == 2 || rc.mode == 4;                             /* adjoint replay of a cached / taped bounce */
         const bool queued = inline_commit && cached && I->tq.nq != 0;                 /* texel gradients of this bounce go through the band queues */
-        if (queued) HIP_TRY(hipMemsetAsync(I->tq.count, 0, (size_t) HAR_SHARDS * I->tq.nq * HAR_COUNTER_STRIDE * sizeof(uint32_t), s));
+        if (queued) HIP_TRY(hipMemsetAsync(I->tq.count, 0, (size_t) (HAR_SHARDS * I->tq.nq + 1) * HAR_COUNTER_STRIDE * sizeof(uint32_t), s));
         if (use_mq) {
             /* classify the bounce's hits, then one specialised launch per material class of the scene; the launches append their survivors / items to the
              * same compacted queues (slot reservation is per block, so the order of the classes does not matter to any path) */

@@ -98,8 +98,14 @@ struct ShapeArrays { float4 *g0, *g1, *g2, *g3, *g4, *g5, *g6, *pv0, *pv1; uint8
  *   band[tex]  = { first queue of the texture (0xffffffff: not queued -- direct atomics), rows per band }
  *   qinfo[q]   = { texture, first row, rows, width } */
 #define HAR_TQ_MAX 64                 /* queues (row bands of all queued textures) */
-#define HAR_TQ_LDS_BYTES 24576        /* default LDS copy of a band: (rows + 1) x width x 3 floats (6 blocks per CU) */
-struct TexelQueues { float4 *rec; uint32_t *count; const uint2 *band; const uint4 *qinfo; uint32_t nq, cap; };
+#define HAR_TQ_LDS_BYTES 24576        /* smallest LDS copy of a band: (rows + 1) x width x 3 accumulators of HAR_TQ_ACC_BYTES */
+/* The LDS copy of a band accumulates in 64-bit FIXED POINT: on gfx950 a ds_add_f32 wave instruction takes ~193 cycles of the CU's LDS pipeline whatever its
+ * addresses (the float atomic unit retires one lane per 3 cycles), ds_add_u64 takes 12 (profiles/r03_lds_atomic_ubench.txt).  `gmax` = the largest |gradient
+ * component| of the records of this launch (float bits, atomicMax by the appending kernels, cleared with the counters): the accumulating block scales its
+ * share so that n records of that size cannot overflow 2^62.  Integer sums are also order-independent: the queued texture gradients are bit-reproducible.
+ * A non-finite gradient sets gmax to +inf and the launch falls back to float atomics (NaN / inf reach the texture as before). */
+#define HAR_TQ_ACC_BYTES 8
+struct TexelQueues { float4 *rec; uint32_t *count; const uint2 *band; const uint4 *qinfo; uint32_t nq, cap; uint32_t *gmax; };
 /* Per-material shading queues (north_star: "material-sorted BSDF megakernels"; the reference's dispatch point is the BSDF virtual call of
  * path.cpp:233,266-267).  After the closest-hit launch of a bounce, k_classify deals the shard's paths to HAR_MAT_CLASSES index lists by the BSDF MODEL
  * of the surface they hit (har_bsdf.h: six models + "twosided pair of two models"; escaped paths ride in `miss_class`), in slot order within a

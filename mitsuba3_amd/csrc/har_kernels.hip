@@ -105,6 +105,26 @@ __device__ __forceinline__ float wave_sum_to_last(float v) {
     return v;
 }
 
+/* wave-wide maximum of NON-NEGATIVE floats with DPP: result valid in lane 63 */
+__device__ __forceinline__ float wave_max_to_last(float v) {
+    v = fmaxf(v, __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0xB1, 0xF, 0xF, true)));
+    v = fmaxf(v, __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x4E, 0xF, 0xF, true)));
+    v = fmaxf(v, __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x141, 0xF, 0xF, true)));
+    v = fmaxf(v, __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x140, 0xF, 0xF, true)));
+    v = fmaxf(v, __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x142, 0xA, 0xF, false)));
+    v = fmaxf(v, __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x143, 0xC, 0xF, false)));
+    return v;
+}
+/* TexelQueues::gmax: the block's largest |gradient component| among the records it appends (float bits in LDS word `lds_max`; +inf for a non-finite one).
+ * All lanes call; the caller publishes lds_max with one global atomicMax per block at the end. */
+__device__ __forceinline__ void texel_record_track_max(uint32_t *lds_max, bool has, Vec3 g) {
+    if (!__ballot(has)) return;
+    float m = has ? fmaxf(fabsf(g.x), fmaxf(fabsf(g.y), fabsf(g.z))) : 0.f;
+    if (has && !(m <= 3.4028234e38f)) m = __uint_as_float(0x7f800000u);        /* NaN or inf */
+    m = wave_max_to_last(m);
+    if ((threadIdx.x & 63u) == 63u && m > 0.f) atomicMax(lds_max, __float_as_uint(m));
+}
+
 /* gradient scatter with wave-level pre-reduction: lanes that target the same address are summed
  * (DPP) and committed by one lane, so a constant albedo costs 3 atomics per wave instead of 192 */
 #ifndef HAR_TEXEL_ROUNDS
@@ -125,6 +145,51 @@ __device__ __forceinline__ void wave_aggregated_add3(float *dst, Vec3 g, bool ac
         active = active && !match;
     }
     if (active) { atomicAdd(dst, g.x); atomicAdd(dst + 1, g.y); atomicAdd(dst + 2, g.z); }
+}
+
+/* the same for a per-block LDS accumulator indexed by a small slot number (BSDF / emitter records: 3 floats per slot).  The lanes of a wave mostly share ONE slot,
+ * and 64 same-address ds_add_f32 serialise in the CU's single LDS pipeline (>= 64 cycles each, three per vertex); the DPP sum runs on the SIMD instead.  Must be
+ * called by all lanes of the wave.  HAR_LDS_PREREDUCE=0: plain LDS atomics (A/B). */
+#ifndef HAR_LDS_PREREDUCE
+#define HAR_LDS_PREREDUCE 1
+#endif
+__device__ __forceinline__ void wave_slot_add3(float *acc, uint32_t slot, Vec3 g, bool active) {
+#if HAR_LDS_PREREDUCE
+    for (int round = 0; round < 3; ++round) {
+        const uint64_t m = __ballot(active);
+        if (m == 0) return;
+        const uint32_t key = __shfl(slot, __ffsll((long long) m) - 1, 64);
+        const bool match = active && slot == key;
+        const float sx = wave_sum_to_last(match ? g.x : 0.f), sy = wave_sum_to_last(match ? g.y : 0.f), sz = wave_sum_to_last(match ? g.z : 0.f);
+        if ((threadIdx.x & 63u) == 63u) { float *q = acc + 3u * key; atomicAdd(q, sx); atomicAdd(q + 1, sy); atomicAdd(q + 2, sz); }
+        active = active && !match;
+    }
+#endif
+    if (active) { float *q = acc + 3u * slot; atomicAdd(q, g.x); atomicAdd(q + 1, g.y); atomicAdd(q + 2, g.z); }
+}
+
+/* rank of a lane among the block's lanes that append to the same queue: hist[q] += (lanes of this wave with queue q), one LDS atomic per wave and distinct queue
+ * instead of one per lane (a wave's vertices mostly fall into one or two texture row bands, and same-address returning atomics serialise).  All lanes call. */
+__device__ __forceinline__ uint32_t wave_ranked_count(uint32_t *hist, uint32_t q, bool active) {
+    uint32_t rank = 0;
+#if HAR_LDS_PREREDUCE
+    const uint32_t lane = threadIdx.x & 63u;
+    for (int round = 0; round < 4; ++round) {
+        const uint64_t m = __ballot(active);
+        if (m == 0) return rank;
+        const int leader = __ffsll((long long) m) - 1;
+        const uint32_t key = __shfl(q, leader, 64);
+        const bool match = active && q == key;
+        const uint64_t mm = __ballot(match);
+        uint32_t base = 0;
+        if (lane == (uint32_t) leader) base = atomicAdd(&hist[key], (uint32_t) __popcll(mm));
+        base = __shfl(base, leader, 64);
+        if (match) rank = base + (uint32_t) __popcll(mm & ((1ull << lane) - 1ull));
+        active = active && !match;
+    }
+#endif
+    if (active) rank = atomicAdd(&hist[q], 1u);
+    return rank;
 }
 
 __device__ __forceinline__ void store_state(const WaveState &W, uint32_t i, const PathState &s) {
@@ -427,15 +492,16 @@ struct TexelRecord { bool has; uint32_t q, cell, tex; float w1x, w1y; Vec3 g; };
 __device__ __forceinline__ void adjoint_commit_regs(const DScene &S, bool pred, bool visible, float4 s2, float4 s3, float4 s4, Vec3 &L, bool &dirty, Vec3 dl,
                                                     float *grad_refl, float *const *grad_tex, float *gacc, const TexelQueues *tq = nullptr, TexelRecord *rec = nullptr) {
     Vec3 g(0.f); float *dst = grad_refl; bool tex = false; TexTaps taps; float *tdst = nullptr;
+    bool em_lds = false; uint32_t em_slot = 0; Vec3 ge(0.f);
     if (pred) {
         const uint32_t tag = __float_as_uint(s2.w), bsdf = tag & 0xfffffu, emitter = (tag >> 20) & 0x7ffu;
         if (emitter != HAR_ITEM_NO_EMITTER) {       /* the item carries Lr_dir for a unit radiance: d Lr_dir / d radiance, and Lr_dir = unit * radiance */
             const DEmitter E = S.emitters[emitter];
             if (visible) {
-                const Vec3 ge = Vec3(s2.x, s2.y, s2.z) * dl;
-                const uint32_t slot = S.n_bsdfs + emitter;
-                if (slot < HAR_LDS_GRAD_BSDFS) { atomicAdd(&gacc[3 * slot], ge.x); atomicAdd(&gacc[3 * slot + 1], ge.y); atomicAdd(&gacc[3 * slot + 2], ge.z); }
-                else { float *a = grad_refl + 3 * (size_t) slot; atomicAdd(a, ge.x); atomicAdd(a + 1, ge.y); atomicAdd(a + 2, ge.z); }
+                ge = Vec3(s2.x, s2.y, s2.z) * dl;
+                em_slot = S.n_bsdfs + emitter;
+                if (em_slot < HAR_LDS_GRAD_BSDFS) em_lds = true;        /* committed below by the whole wave (pre-reduced) */
+                else { float *a = grad_refl + 3 * (size_t) em_slot; atomicAdd(a, ge.x); atomicAdd(a + 1, ge.y); atomicAdd(a + 2, ge.z); }
             }
             s2.x *= E.radiance[0]; s2.y *= E.radiance[1]; s2.z *= E.radiance[2];
         }
@@ -447,6 +513,7 @@ __device__ __forceinline__ void adjoint_commit_regs(const DScene &S, bool pred, 
         dst = grad_refl + 3 * (size_t) bsdf;
         if (B.texture >= 0) { tex = true; tex_taps(S.textures[B.texture], s3.w, s4.w, taps); tdst = grad_tex[B.texture]; }
     }
+    if (__ballot(em_lds)) wave_slot_add3(gacc, em_slot, ge, em_lds);
     const bool nz = pred && (g.x != 0.f || g.y != 0.f || g.z != 0.f);
     if (rec) {          /* queued textures: hand the record to the caller (block-wide append), no atomics here */
         rec->has = false;
@@ -461,10 +528,11 @@ __device__ __forceinline__ void adjoint_commit_regs(const DScene &S, bool pred, 
         }
     }
     const bool nz_direct = nz && (g.x != 0.f || g.y != 0.f || g.z != 0.f || tex);
-    if (nz_direct && !tex) {
+    {
         const uint32_t bsdf = (uint32_t) (dst - grad_refl) / 3u;
-        if (bsdf < HAR_LDS_GRAD_BSDFS) { atomicAdd(&gacc[3 * bsdf], g.x); atomicAdd(&gacc[3 * bsdf + 1], g.y); atomicAdd(&gacc[3 * bsdf + 2], g.z); }
-        else { atomicAdd(dst, g.x); atomicAdd(dst + 1, g.y); atomicAdd(dst + 2, g.z); }
+        const bool flat = nz_direct && !tex, lds = flat && bsdf < HAR_LDS_GRAD_BSDFS;
+        if (__ballot(lds)) wave_slot_add3(gacc, bsdf, g, lds);
+        if (flat && !lds) { atomicAdd(dst, g.x); atomicAdd(dst + 1, g.y); atomicAdd(dst + 2, g.z); }
     }
     if (__ballot(nz_direct && tex)) {
         const float w[4] = { taps.w0x * taps.w0y, taps.w1x * taps.w0y, taps.w0x * taps.w1y, taps.w1x * taps.w1y };
@@ -586,9 +654,9 @@ __global__ __launch_bounds__(kBlock, HAR_SHADE_MIN_WAVES) void k_shade(DScene S,
      * the first HAR_LDS_EXTRA_BSDFS records, global atomics beyond */
     __shared__ float xacc[EXTRA ? 15 * HAR_LDS_EXTRA_BSDFS : 1];
     if (EXTRA) { for (uint32_t k = threadIdx.x; k < 15 * HAR_LDS_EXTRA_BSDFS; k += kBlock) xacc[k] = 0.f; __syncthreads(); }
-    __shared__ uint32_t tq_hist[INLINE ? HAR_TQ_MAX : 1], tq_base[INLINE ? HAR_TQ_MAX : 1];
+    __shared__ uint32_t tq_hist[INLINE ? HAR_TQ_MAX : 1], tq_base[INLINE ? HAR_TQ_MAX : 1], tq_gmax;
     __shared__ float gacc[INLINE ? 3 * HAR_LDS_GRAD_BSDFS : 1];
-    if (INLINE) { for (uint32_t k = threadIdx.x; k < 3 * HAR_LDS_GRAD_BSDFS; k += kBlock) gacc[k] = 0.f; __syncthreads(); }
+    if (INLINE) { for (uint32_t k = threadIdx.x; k < 3 * HAR_LDS_GRAD_BSDFS; k += kBlock) gacc[k] = 0.f; if (threadIdx.x == 0) tq_gmax = 0u; __syncthreads(); }
     /* adjoint with emitter gradients: per-block accumulators of d L / d radiance from emission hits (slots n_bsdfs + emitter of `grad_slots`) */
     __shared__ float eacc[MODE == MODE_PRB_ADJOINT ? 3 * HAR_LDS_GRAD_EMITTERS : 1];
     const bool fwd = MODE == MODE_PRB_ADJOINT && (P.flags & HAR_SHADE_FORWARD_MODE) != 0u;      /* render_forward: tangents in, dL accumulates (see adjoint_commit_values) */
@@ -638,6 +706,7 @@ __global__ __launch_bounds__(kBlock, HAR_SHADE_MIN_WAVES) void k_shade(DScene S,
          * from / go to the slot-ordered tape arrays and nothing is compacted (TapeArrays) */
         Vec3 Lr(0.f), dlr(0.f); bool L_dirty = false;
         const bool tape_read = MODE == MODE_PRB_ADJOINT && INLINE && rc.mode == 4;
+        bool eg_lds = false; uint32_t eg_slot = 0; Vec3 eg(0.f);          /* d L / d radiance of the emitter met by this lane (emission hit) */
         if (in_range) {
             PathState st = load_state(in, i);
             d_in = st.d; first_vertex = (st.flags & 0xffffu) == 0u;
@@ -662,7 +731,7 @@ __global__ __launch_bounds__(kBlock, HAR_SHADE_MIN_WAVES) void k_shade(DScene S,
                 Lr = Vec3(Lr.x - R.em_b.x, Lr.y - R.em_b.y, Lr.z - R.em_b.z); L_dirty = true;
                 if (emitter_grads && R.em_index >= 0) {
                     const Vec3 g = R.em_unit * dlr;
-                    if ((uint32_t) R.em_index < HAR_LDS_GRAD_EMITTERS) { float *a = eacc + 3 * R.em_index; atomicAdd(a, g.x); atomicAdd(a + 1, g.y); atomicAdd(a + 2, g.z); }
+                    if ((uint32_t) R.em_index < HAR_LDS_GRAD_EMITTERS) { eg_lds = true; eg_slot = (uint32_t) R.em_index; eg = g; }      /* committed below by the whole wave */
                     else { float *a = grad_slots + 3 * ((size_t) S.n_bsdfs + R.em_index); atomicAdd(a, g.x); atomicAdd(a + 1, g.y); atomicAdd(a + 2, g.z); }
                 }
             } else if (R.add_emission) {
@@ -680,11 +749,12 @@ __global__ __launch_bounds__(kBlock, HAR_SHADE_MIN_WAVES) void k_shade(DScene S,
                 } else if (MODE == MODE_PRB_ADJOINT && emitter_grads && R.em_index >= 0) {
                     const float4 dl = dL[lane];
                     const Vec3 g = R.em_unit * Vec3(dl.x, dl.y, dl.z);
-                    if ((uint32_t) R.em_index < HAR_LDS_GRAD_EMITTERS) { float *a = eacc + 3 * R.em_index; atomicAdd(a, g.x); atomicAdd(a + 1, g.y); atomicAdd(a + 2, g.z); }
+                    if ((uint32_t) R.em_index < HAR_LDS_GRAD_EMITTERS) { eg_lds = true; eg_slot = (uint32_t) R.em_index; eg = g; }
                     else { float *a = grad_slots + 3 * ((size_t) S.n_bsdfs + R.em_index); atomicAdd(a, g.x); atomicAdd(a + 1, g.y); atomicAdd(a + 2, g.z); }
                 }
             }
         }
+        if (MODE == MODE_PRB_ADJOINT && emitter_grads && __ballot(eg_lds)) wave_slot_add3(eacc, eg_slot, eg, eg_lds);
         bool item_pred = in_range && R.item;
         if (SHAPE) item_pred = in_range && (R.item || R.alive);       /* the solid-angle-to-area Jacobian of a continued path moves with the vertex whatever the BSDF value */
         if (INLINE) {
@@ -721,7 +791,8 @@ __global__ __launch_bounds__(kBlock, HAR_SHADE_MIN_WAVES) void k_shade(DScene S,
                 /* append the block's texel records to their band queues (TexelQueues): LDS histogram -> one global atomic per non-empty band -> scattered 32-byte records */
                 if (threadIdx.x < tq.nq) tq_hist[threadIdx.x] = 0u;
                 __syncthreads();
-                const uint32_t rank = rec.has ? atomicAdd(&tq_hist[rec.q], 1u) : 0u;
+                texel_record_track_max(&tq_gmax, rec.has, rec.g);
+                const uint32_t rank = wave_ranked_count(tq_hist, rec.q, rec.has);
                 __syncthreads();
                 if (threadIdx.x < tq.nq) { const uint32_t c = tq_hist[threadIdx.x]; tq_base[threadIdx.x] = c ? atomicAdd(tq.count + (size_t) (Q.shard * tq.nq + threadIdx.x) * HAR_COUNTER_STRIDE, c) : 0u; }
                 __syncthreads();
@@ -796,6 +867,7 @@ __global__ __launch_bounds__(kBlock, HAR_SHADE_MIN_WAVES) void k_shade(DScene S,
     }
     if (INLINE) {
         __syncthreads();
+        if (threadIdx.x == 0 && tq.nq && tq_gmax) atomicMax(tq.gmax, tq_gmax);
         for (uint32_t k = threadIdx.x; k < 3 * min(S.n_bsdfs + S.n_emitters, (uint32_t) HAR_LDS_GRAD_BSDFS); k += kBlock) {
             const float v = gacc[k];
             if (v != 0.f) atomicAdd(grad_slots + k, v);
@@ -815,9 +887,10 @@ __global__ __launch_bounds__(kBlock, HAR_SHADE_MIN_WAVES) void k_shade(DScene S,
 template <bool FIRST>
 __global__ __launch_bounds__(kBlock) void k_commit(DScene S, uint32_t shard_cap, const uint32_t *count_in, TapeArrays tape, const uint8_t *vis,
                                                    float *grad_slots, float *const *grad_tex, TexelQueues tq, const float4 *result, const float4 *dL) {
-    __shared__ uint32_t tq_hist[HAR_TQ_MAX], tq_base[HAR_TQ_MAX];
+    __shared__ uint32_t tq_hist[HAR_TQ_MAX], tq_base[HAR_TQ_MAX], tq_gmax;
     __shared__ float gacc[3 * HAR_LDS_GRAD_BSDFS];
     for (uint32_t k = threadIdx.x; k < 3 * HAR_LDS_GRAD_BSDFS; k += kBlock) gacc[k] = 0.f;
+    if (threadIdx.x == 0) tq_gmax = 0u;
     __syncthreads();
     const ShardLoop Q(count_in, shard_cap);
     for (uint32_t tile = Q.first_tile(); tile * kBlock < Q.n; tile += Q.tile_step()) {
@@ -850,7 +923,8 @@ __global__ __launch_bounds__(kBlock) void k_commit(DScene S, uint32_t shard_cap,
         if (tq.nq) {        /* the block's texel records -> their band queues (as in k_shade's in-place commit) */
             if (threadIdx.x < tq.nq) tq_hist[threadIdx.x] = 0u;
             __syncthreads();
-            const uint32_t rank = rec.has ? atomicAdd(&tq_hist[rec.q], 1u) : 0u;
+            texel_record_track_max(&tq_gmax, rec.has, rec.g);
+            const uint32_t rank = wave_ranked_count(tq_hist, rec.q, rec.has);
             __syncthreads();
             if (threadIdx.x < tq.nq) { const uint32_t c = tq_hist[threadIdx.x]; tq_base[threadIdx.x] = c ? atomicAdd(tq.count + (size_t) (Q.shard * tq.nq + threadIdx.x) * HAR_COUNTER_STRIDE, c) : 0u; }
             __syncthreads();
@@ -867,18 +941,24 @@ __global__ __launch_bounds__(kBlock) void k_commit(DScene S, uint32_t shard_cap,
         }
     }
     __syncthreads();
+    if (threadIdx.x == 0 && tq.nq && tq_gmax) atomicMax(tq.gmax, tq_gmax);
     for (uint32_t k = threadIdx.x; k < 3 * min(S.n_bsdfs + S.n_emitters, (uint32_t) HAR_LDS_GRAD_BSDFS); k += kBlock) {
         const float v = gacc[k];
         if (v != 0.f) atomicAdd(grad_slots + k, v);
     }
 }
 
-/* texel-gradient queues -> gradient textures (see TexelQueues): blockIdx / bpq = shard * nq + band queue; the queue's records are shared by bpq blocks */
-__global__ __launch_bounds__(kBlock) void k_texel_accumulate(TexelQueues tq, float *const *grad_tex, uint32_t bpq) {
-    extern __shared__ float band[];
+/* texel-gradient queues -> gradient textures (see TexelQueues): blockIdx / bpq = shard * nq + band queue; the queue's records are shared by bpq blocks.
+ * FIXED = false: the float-atomic version (fallback for launches with a non-finite gradient, and HAR_TQ_FIXED=0 for A/B); its LDS copy has the same footprint. */
+template <bool FIXED>
+__global__ __launch_bounds__(kBlock) void k_texel_accumulate(TexelQueues tq, float *const *grad_tex, uint32_t bpq, uint32_t spread, uint32_t force_float) {
+    extern __shared__ unsigned long long band64[];
+    float *band = reinterpret_cast<float *>(band64);
+    const uint32_t gbits = *tq.gmax;
+    if (FIXED != (!force_float && gbits < 0x7f800000u)) return;            /* both instantiations are launched; exactly one of them runs (no host round trip for gmax) */
     const uint32_t qid = blockIdx.x / bpq, part = blockIdx.x - qid * bpq, q = qid % tq.nq;
     const uint32_t n = min(tq.count[(size_t) qid * HAR_COUNTER_STRIDE], tq.cap);
-    if (n == 0) return;
+    if (n == 0 || gbits == 0u) return;
     const uint4 info = tq.qinfo[q];                        /* texture, first row, rows, width */
     const uint32_t W = info.w, row0 = info.y, rows = info.z, H = tq.qinfo[q + tq.nq].x;
     /* the LDS copy holds the band's rows PLUS the row after it (the second bilinear row of cells in the band's last row; row 0 after the
@@ -886,25 +966,61 @@ __global__ __launch_bounds__(kBlock) void k_texel_accumulate(TexelQueues tq, flo
      * iteration wait for a memory-side round trip */
     const uint32_t nfl = (rows + 1u) * W * 3u;
     float *dst = grad_tex[info.x];
-    for (uint32_t k = threadIdx.x; k < nfl; k += kBlock) band[k] = 0.f;
+    for (uint32_t k = threadIdx.x; k < nfl; k += kBlock) { if (FIXED) band64[k] = 0ull; else band[k] = 0.f; }
     __syncthreads();
     const uint32_t b = (uint32_t) ((uint64_t) n * part / bpq), e = (uint32_t) ((uint64_t) n * (part + 1) / bpq);
     const float4 *rec = tq.rec + 2 * (size_t) qid * tq.cap;
-    for (uint32_t i = b + threadIdx.x; i < e; i += kBlock) {
-        const float4 r0 = rec[2 * (size_t) i], r1 = rec[2 * (size_t) i + 1];
-        const uint32_t cell = __float_as_uint(r0.x), x0 = cell & 0xffffu, ry = (cell >> 16) - row0, x1 = x0 + 1 == W ? 0u : x0 + 1;
+    /* fixed point: |sum of any accumulator| <= (e - b) * gmax < 2^(en + eg), scaled to stay below 2^62 */
+    int eg = 0; (void) frexpf(__uint_as_float(gbits), &eg);
+    const int en = 32 - __clz((int) max(e - b, 1u));
+    const double scale = FIXED ? ldexp(1.0, 62 - en - eg) : 1.0;
+    auto fixed = [&](float v) { return (unsigned long long) __double2ll_rn((double) v * scale); };
+    /* spread = 1: every group of four lanes walks its own contiguous segment of the block's share (one 128-byte line per group and step) instead of the wave
+     * walking 64 consecutive records; measured neutral for the float atomics (they cost 193 cycles whatever the addresses), kept as a switch (HAR_TQ_SPREAD) */
+    const uint32_t len = e - b, per = spread ? (((len + kBlock / 4u - 1u) / (kBlock / 4u) + 3u) & ~3u) : 0u;
+    const uint32_t first = spread ? b + (threadIdx.x >> 2) * per + (threadIdx.x & 3u) : b + threadIdx.x;
+    const uint32_t last = spread ? min(e, b + ((threadIdx.x >> 2) + 1u) * per) : e, step = spread ? 4u : kBlock;
+    const uint32_t trips = spread ? (per + 3u) / 4u : (len + kBlock - 1u) / kBlock;           /* uniform trip count: the wave-level steps below need every lane */
+    uint32_t i = first;
+    for (uint32_t trip = 0; trip < trips; ++trip, i += step) {
+        bool active = i < last;
+        float4 r0 = make_float4(0.f, 0.f, 0.f, 0.f), r1 = r0;
+        if (active) { r0 = rec[2 * (size_t) i]; r1 = rec[2 * (size_t) i + 1]; }
+        const uint32_t cell = __float_as_uint(r0.x);
         const float w0x = 1.f - r0.z, w0y = 1.f - r0.w;
-        float *a0 = band + 3u * (ry * W + x0), *a1 = band + 3u * (ry * W + x1), *a2 = a0 + 3u * W, *a3 = a1 + 3u * W;
-        const float w00 = w0x * w0y, w10 = r0.z * w0y, w01 = w0x * r0.w, w11 = r0.z * r0.w;
-        atomicAdd(a0, r1.x * w00); atomicAdd(a0 + 1, r1.y * w00); atomicAdd(a0 + 2, r1.z * w00);
-        atomicAdd(a1, r1.x * w10); atomicAdd(a1 + 1, r1.y * w10); atomicAdd(a1 + 2, r1.z * w10);
-        atomicAdd(a2, r1.x * w01); atomicAdd(a2 + 1, r1.y * w01); atomicAdd(a2 + 2, r1.z * w01);
-        atomicAdd(a3, r1.x * w11); atomicAdd(a3 + 1, r1.y * w11); atomicAdd(a3 + 2, r1.z * w11);
+        const float w[4] = { w0x * w0y, r0.z * w0y, w0x * r0.w, r0.z * r0.w };
+        float p[12];
+        for (int t = 0; t < 4; ++t) { p[3 * t] = r1.x * w[t]; p[3 * t + 1] = r1.y * w[t]; p[3 * t + 2] = r1.z * w[t]; }
+        auto commit = [&](uint32_t c, const float *v) {
+            const uint32_t x0 = c & 0xffffu, ry = (c >> 16) - row0, x1 = x0 + 1 == W ? 0u : x0 + 1;
+            const uint32_t a[4] = { 3u * (ry * W + x0), 3u * (ry * W + x1), 3u * (ry * W + x0) + 3u * W, 3u * (ry * W + x1) + 3u * W };
+            for (int t = 0; t < 4; ++t)
+                for (int ch = 0; ch < 3; ++ch) {
+                    if (FIXED) atomicAdd(&band64[a[t] + ch], fixed(v[3 * t + ch]));
+                    else atomicAdd(&band[a[t] + ch], v[3 * t + ch]);
+                }
+        };
+        /* the samples of one pixel sit side by side in the queue and fall into the same cell: sum such a run on the SIMD (DPP) and let one lane commit it --
+         * 64 same-address LDS atomics serialise (2 cycles per lane even for integers) */
+        for (int round = 0; round < 2; ++round) {
+            const uint64_t m = __ballot(active);
+            if (m == 0) break;
+            const uint32_t key = __shfl(cell, __ffsll((long long) m) - 1, 64);
+            const bool match = active && cell == key;
+            if (__popcll(__ballot(match)) < 16) break;
+            float sum[12];
+            for (int k = 0; k < 12; ++k) sum[k] = wave_sum_to_last(match ? p[k] : 0.f);
+            if ((threadIdx.x & 63u) == 63u) commit(key, sum);
+            active = active && !match;
+        }
+        if (active) commit(cell, p);
     }
     __syncthreads();
+    const double inv = 1.0 / scale;
     for (uint32_t k = threadIdx.x; k < nfl; k += kBlock) {
-        const float v = band[k];
-        if (v == 0.f) continue;
+        float v;
+        if (FIXED) { const long long acc = (long long) band64[k]; if (acc == 0) continue; v = (float) ((double) acc * inv); }
+        else { v = band[k]; if (v == 0.f) continue; }
         const uint32_t r = k / (3u * W), c = k - r * 3u * W;
         uint32_t y = row0 + r; if (y >= H) y -= H;
         atomicAdd(dst + 3 * (size_t) y * W + c, v);
@@ -1488,7 +1604,11 @@ void launch_classify(hipStream_t s, uint32_t grid, const DScene &S, uint32_t sha
     hipLaunchKernelGGL(k_classify, dim3(grid), dim3(kBlock), 0, s, S, shard_cap, count_in, h0, h1, mq);
 }
 void launch_texel_accumulate(hipStream_t s, const TexelQueues &tq, float *const *grad_tex, uint32_t bpq, uint32_t lds_bytes) {
-    hipLaunchKernelGGL(k_texel_accumulate, dim3(HAR_SHARDS * tq.nq * bpq), dim3(kBlock), lds_bytes, s, tq, grad_tex, bpq);
+    static const uint32_t spread = getenv("HAR_TQ_SPREAD") ? (uint32_t) atoi(getenv("HAR_TQ_SPREAD")) : 0u;      /* 1: groups of four lanes walk separate segments (A/B, see the kernel) */
+    static const bool fixed = !(getenv("HAR_TQ_FIXED") && atoi(getenv("HAR_TQ_FIXED")) == 0);       /* 0: float LDS atomics always (A/B) */
+    if (fixed) hipLaunchKernelGGL(k_texel_accumulate<true>, dim3(HAR_SHARDS * tq.nq * bpq), dim3(kBlock), lds_bytes, s, tq, grad_tex, bpq, spread, 0u);
+    /* launches whose records hold a non-finite gradient (gmax = +inf): the float version, so that NaN / inf reach the texture; an empty launch otherwise */
+    hipLaunchKernelGGL(k_texel_accumulate<false>, dim3(HAR_SHARDS * tq.nq * bpq), dim3(kBlock), lds_bytes, s, tq, grad_tex, bpq, spread, fixed ? 0u : 1u);
 }
 void launch_resolve(int mode, hipStream_t s, uint32_t grid, uint2 *spill, const DScene &S, const uint32_t *item_count, uint32_t *cursor, uint32_t shard_cap, const ItemArrays &items,
                     float4 *result, const float4 *dL, float *grad_refl, float *const *grad_tex, int *status, const ReplayCache &rc, uint8_t *item_vis, int fwd) {
