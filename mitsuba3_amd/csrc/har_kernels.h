@@ -102,7 +102,8 @@ struct ShapeArrays { float4 *g0, *g1, *g2, *g3, *g4, *g5, *g6, *pv0, *pv1; uint8
 /* The LDS copy of a band accumulates in 64-bit FIXED POINT: on gfx950 a ds_add_f32 wave instruction takes ~193 cycles of the CU's LDS pipeline whatever its
  * addresses (the float atomic unit retires one lane per 3 cycles), ds_add_u64 takes 12 (profiles/r03_lds_atomic_ubench.txt).  `gmax` = the largest |gradient
  * component| of the records of this launch (float bits, atomicMax by the appending kernels, cleared with the counters): the accumulating block scales its
- * share so that n records of that size cannot overflow 2^62.  Integer sums are also order-independent: the queued texture gradients are bit-reproducible.
+ * share so that n records of that size cannot overflow 2^62.  (Integer sums are order-independent within a block; the blocks' flushes and the overflow
+ * records still meet in global float atomics, so the texture gradient as a whole is not bit-reproducible.)
  * A non-finite gradient sets gmax to +inf and the launch falls back to float atomics (NaN / inf reach the texture as before). */
 #define HAR_TQ_ACC_BYTES 8
 struct TexelQueues { float4 *rec; uint32_t *count; const uint2 *band; const uint4 *qinfo; uint32_t nq, cap; uint32_t *gmax; };

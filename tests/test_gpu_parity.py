@@ -130,6 +130,32 @@ def test_prb_backward_texture_gradient(mi, O):
     assert rel_l2(g, g_tex[0]) < 1e-3
 
 
+def test_texel_gradient_fixed_point_accumulation_edge_cases(mi, O):
+    """k_texel_accumulate adds the queued texel gradients in 64-bit fixed point scaled by the launch's largest gradient component: (a) an adjoint image whose
+    pixels span 24 orders of magnitude still matches the oracle's float sums to 1e-3; (b) a
+    tiny and a huge uniform scale give the same gradient up to that scale (no overflow, no underflow); (c) an infinite pixel adjoint takes the float fallback
+    and reaches the texture as a non-finite value instead of being dropped"""
+    res, spp = 48, 16
+    scene, osc, sensor = _textured(mi, O, res, 16, spp)
+    integ = mi.load_dict({"type": "prb", "max_depth": 6})
+    rng = np.random.default_rng(5)
+    base = rng.uniform(0.5, 1.5, (res, res, 3)).astype(np.float32)
+    key = "white.reflectance.data"
+    g1 = integ.render_backward(scene, None, base, seed=11, spp=spp)[key].cpu().numpy()
+    _, ref, _ = osc.render_prb_backward(sensor, base, seed=11, spp=spp, max_depth=6)
+    assert rel_l2(g1, ref[0]) < 1e-3
+    for scale in (1e-30, 1e+30):
+        gs = integ.render_backward(scene, None, (base * np.float32(scale)).astype(np.float32), seed=11, spp=spp)[key].cpu().numpy()
+        assert np.isfinite(gs).all() and rel_l2(gs / np.float32(scale), g1) < 1e-5, scale
+    wide = base.copy(); wide[: res // 2] *= np.float32(1e-12); wide[res // 2:] *= np.float32(1e+12)      # two halves of the film, 24 decades apart
+    gw = integ.render_backward(scene, None, wide, seed=11, spp=spp)[key].cpu().numpy()
+    _, rw, _ = osc.render_prb_backward(sensor, wide, seed=11, spp=spp, max_depth=6)
+    assert rel_l2(gw, rw[0]) < 1e-3
+    bad = base.copy(); bad[res // 2, res // 2, 0] = np.inf
+    gb = integ.render_backward(scene, None, bad, seed=11, spp=spp)[key].cpu().numpy()
+    assert not np.isfinite(gb).all()
+
+
 def test_prb_backward_constant_albedo(mi, O):
     scene, osc, sensor = cbox(mi, O, 40)
     integ = mi.load_dict({"type": "prb", "max_depth": 6})
