@@ -237,7 +237,13 @@ def worker(args):
         torch.cuda.synchronize()
 
     def timed(fn, steps, warmup, on_start=None):
-        for _ in range(warmup):
+        # N > 1: the row-band balancer adapts (and synchronises) over its first frames; with fewer warm-up frames than that, run the rest untimed here so
+        # that no adaptation frame -- with its event synchronisation and all-gather -- lands inside the timed region
+        settle = 0
+        if world > 1:
+            from mitsuba3_amd.distributed import BandBalancer
+            settle = max(0, BandBalancer.ADAPT_FRAMES - warmup)
+        for _ in range(warmup + settle):
             fn()
         sync_barrier()
         if on_start:

@@ -904,7 +904,9 @@ static uint64_t dual_split(HarIntegrator I, uint64_t lb, uint64_t le, hipStream_
     if (T->use_cache != I->use_cache) { (void) hipDeviceSynchronize(); T->free_ws(); T->use_cache = I->use_cache; }
     if (hipEventRecord(I->ev_fork, s) != hipSuccess || hipStreamWaitEvent(I->side_stream, I->ev_fork, 0) != hipSuccess) return le;
     I->twin_used = true;
-    return lb + ((le - lb) / 2 + 2047) / 2048 * 2048;
+    /* HAR_DUAL_FRAC (percent, default 50): the share of the first half -- an uneven cut de-synchronises the two launch sequences (A/B) */
+    static const uint64_t frac = getenv("HAR_DUAL_FRAC") ? (uint64_t) std::min(90, std::max(10, atoi(getenv("HAR_DUAL_FRAC")))) : 50u;
+    return lb + ((le - lb) * frac / 100 + 2047) / 2048 * 2048;
 }
 static int dual_join(HarIntegrator I, hipStream_t s) {
     HIP_TRY(hipEventRecord(I->ev_join, I->side_stream));
