@@ -290,7 +290,12 @@ def worker(args):
     frames_profiled = int(timing["frames"][0])
     dominant = max(("trace_closest", "shade", "resolve", "splat", "raygen"), key=lambda k: kern_ms[k])
     launches = max(timing[dominant][1], 1)
-    if dominant == "trace_closest":
+    # jobs of at most 2^25 lanes per rank (N > 1) run bounce b's shadow rays on a second stream NEXT TO bounce b + 1's closest-hit rays (har_capi.hip overlap_applies):
+    # the interval the trace class times then holds both traversal kernels, so its bytes are the bytes of both
+    overlapped = stats["shadow_rays"] > 0 and kern_ms["resolve"] < 0.05 * kern_ms["trace_closest"]
+    if dominant == "trace_closest" and overlapped:
+        alg_bytes = stats["closest_rays"] * 56 + stats["shadow_rays"] * 33 + 2 * accel["bytes"] * launches
+    elif dominant == "trace_closest":
         alg_bytes = stats["closest_rays"] * 56 + accel["bytes"] * launches
     elif dominant == "resolve":
         alg_bytes = stats["shadow_rays"] * 33 + accel["bytes"] * launches
@@ -338,7 +343,7 @@ def worker(args):
                             "valu_insts_per_64_rays": round(c["SQ_INSTS_VALU"]["sum"] / frames_sq / max(rays / 64.0, 1.0), 1),
                             "valu_issue_frac_of_simd_cycles": round(c["SQ_INSTS_VALU"]["sum"] * 2.7 / (1024 * rec["total_ms"] * 1e-3 * 2.4e9), 3),
                             "source": "profiles/" + sq_src}
-    roofline = {"bound": "hbm", "kernel": dominant, "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+    roofline = {"bound": "hbm", "kernel": dominant + ("+resolve (concurrent on two streams)" if dominant == "trace_closest" and overlapped else ""), "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                 "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": traffic, "traffic_source": ("profiles/" + traffic_src) if traffic is not None else None,
                 "algorithmic_bytes_per_launch": round(alg_bytes / launches),
                 "avg_launch_ms": round(kern_ms[dominant] / launches, 4), "launches": launches, "frames_averaged": frames_profiled,

@@ -170,11 +170,16 @@ struct HarIntegratorImpl {
      * of one fill the CUs the other's tail leaves idle. */
     HarIntegratorImpl *twin = nullptr; bool twin_used = false;
     hipStream_t side_stream = nullptr; hipEvent_t ev_fork = nullptr, ev_join = nullptr;
+    /* shadow-ray overlap (small jobs): bounce b's shadow rays (k_resolve) do not depend on bounce b + 1's closest-hit rays (k_trace_closest) -- both only need
+     * bounce b's shading -- so k_resolve runs on `aux_stream` next to the trace launch and the two meet again before bounce b + 1 is shaded.  One traversal
+     * tail per bounce instead of two (see run_chunk). */
+    hipStream_t aux_stream = nullptr; hipEvent_t ev_shaded = nullptr, ev_resolved = nullptr;
     void free_ws();
 };
 void HarIntegratorImpl::free_ws() { for (void *p : owned) dev_free(p); owned.clear(); ws_lanes = 0; }
 #define HAR_DUAL_MIN_LANES (1u << 20)
 #define HAR_DUAL_MAX_LANES (1u << 24)
+#define HAR_OVERLAP_MAX_LANES (1u << 25)
 
 namespace {
 
@@ -389,6 +394,19 @@ int ensure_texel_queues(HarSceneImpl *S, HarIntegratorImpl *I) {
     return 0;
 }
 
+/* shadow-ray overlap (HarIntegratorImpl::aux_stream) for a job of n lanes?  `path` and the primal passes of `prb`, at most HAR_OVERLAP_MAX_LANES lanes -- the share
+ * of a rank when several GPUs split a frame, where a launch is short and its tail (the chip waiting for the launch's longest rays) is a sizeable part of it:
+ * measured on the middle bands of the headline frame (tools/band_bench.py, profiles/r03_ab_shadow_overlap.txt), one stream without / with overlap | two streams
+ * without / with: 2 M lanes 5.46 / 4.67 | 5.11 / 4.60 ms, 4 M 8.56 / 7.64 | 8.09 / 7.68, 8 M 13.89 / 13.03 | 13.47 / 13.16, 16 M 24.58 / 23.76 | 24.42 / 24.36,
+ * 33 M 42.50 / 41.90, 67 M 77.07 / 77.30.  A single large wavefront keeps one stream and sequential launches (its kernels are timed one by one for the bench
+ * line).  Not with the HBM stack spill (both traversal kernels would share it) nor with hide_emitters.  HAR_OVERLAP = 0 / 1 forces it off / on (A/B). */
+static bool overlap_applies(const HarSceneImpl *S, const HarIntegratorImpl *I, uint64_t n) {
+    static const int overlap_env = getenv("HAR_OVERLAP") ? atoi(getenv("HAR_OVERLAP")) : -1;
+    static const bool force_spill = getenv("HAR_FORCE_STACK_SPILL") != nullptr;
+    if (force_spill || S->hs.stack_need() + HAR_STACK_MARGIN > HAR_LDS_STACK_SMALL || I->hide_emitters) return false;
+    return overlap_env < 0 ? n <= HAR_OVERLAP_MAX_LANES : overlap_env != 0;
+}
+
 /* rays of har_integrator_sample: SoA arrays of n_total rays, the chunk covers [first, first + n) */
 struct RaySource { const float *o, *d, *maxt; const uint64_t *state; uint32_t n_total, first; };
 
@@ -461,6 +479,12 @@ int run_chunk(HarSceneImpl *S, HarIntegratorImpl *I, const DSensor &C, int mode,
     const bool use_mq = (mq_env < 0 ? I->material_queues : mq_env != 0) && mode != MODE_PRB_ADJOINT && cache_mode != 5 && __builtin_popcount(S->mat_classes) >= 2 && !(S->ds.bsdf_types & HAR_SCENE_ENVMAP);
     if (use_mq && !I->mq_idx && (ws_alloc(I, &I->mq_idx, (size_t) HAR_MAT_CLASSES * I->ws_lanes) || ws_alloc(I, &I->mq_count, (size_t) HAR_MAT_CLASSES * HAR_SHARDS * HAR_COUNTER_STRIDE))) return 1;
     const MaterialQueues mq{ I->mq_idx, I->mq_count, I->ws_lanes, S->mat_miss_class };
+    bool overlap = mode != MODE_PRB_ADJOINT && !rays && overlap_applies(S, I, n);
+    if (overlap && !I->aux_stream) {
+        if (hipStreamCreateWithFlags(&I->aux_stream, hipStreamNonBlocking) != hipSuccess || hipEventCreateWithFlags(&I->ev_shaded, hipEventDisableTiming) != hipSuccess ||
+            hipEventCreateWithFlags(&I->ev_resolved, hipEventDisableTiming) != hipSuccess) { I->aux_stream = nullptr; overlap = false; }
+    }
+    bool resolve_pending = false;
     int cur = 0; uint32_t b = 0;
     for (; b < nb; ++b) {
         /* PRB replay cache: the primal pass of render_backward records this bounce's ray-query results per lane, the adjoint pass reads them */
@@ -514,6 +538,7 @@ int run_chunk(HarSceneImpl *S, HarIntegratorImpl *I, const DSensor &C, int mode,
             launch_shape_adjoint(s, grid, S->ds, cnt_items(I, b - 1), I->shard_cap, I->items, I->geo, I->result, I->dL, 1, st_in, h0, h1, rc, targets);
             prof_mark(I, s, CLS_OTHER);
         }
+        if (resolve_pending) { HIP_TRY(hipStreamWaitEvent(s, I->ev_resolved, 0)); resolve_pending = false; }      /* bounce b - 1's shadow rays have updated `result`; the item arrays are free again */
         const bool cached = rc.mode == 2 || rc.mode == 4;                             /* adjoint replay of a cached / taped bounce */
         const bool queued = inline_commit && cached && I->tq.nq != 0;                 /* texel gradients of this bounce go through the band queues */
         if (queued) HIP_TRY(hipMemsetAsync(I->tq.count, 0, (size_t) (HAR_SHARDS * I->tq.nq + 1) * HAR_COUNTER_STRIDE * sizeof(uint32_t), s));
@@ -535,7 +560,13 @@ int run_chunk(HarSceneImpl *S, HarIntegratorImpl *I, const DSensor &C, int mode,
             static const uint32_t bpq_env = getenv("HAR_TQ_BPQ") ? (uint32_t) atoi(getenv("HAR_TQ_BPQ")) : 0u;
             launch_texel_accumulate(s, I->tq, I->d_grad_tex, bpq_env ? bpq_env : (n > (1u << 22) ? 4u : 1u), I->tq_lds); prof_mark(I, s, CLS_OTHER);
         }
-        if (!(inline_commit && cached)) launch_resolve(mode, s, rc.mode == 2 ? grid : tgrid, spill, S->ds, cnt_items(I, b), cur_resolve(I, b), I->shard_cap, I->items, I->result, I->dL, grad_refl, I->d_grad_tex, I->status, rc,
+        if (overlap) {
+            HIP_TRY(hipEventRecord(I->ev_shaded, s));
+            HIP_TRY(hipStreamWaitEvent(I->aux_stream, I->ev_shaded, 0));
+            launch_resolve(mode, I->aux_stream, tgrid, spill, S->ds, cnt_items(I, b), cur_resolve(I, b), I->shard_cap, I->items, I->result, I->dL, grad_refl, I->d_grad_tex, I->status, rc, nullptr, 0);
+            HIP_TRY(hipEventRecord(I->ev_resolved, I->aux_stream));
+            resolve_pending = true;
+        } else if (!(inline_commit && cached)) launch_resolve(mode, s, rc.mode == 2 ? grid : tgrid, spill, S->ds, cnt_items(I, b), cur_resolve(I, b), I->shard_cap, I->items, I->result, I->dL, grad_refl, I->d_grad_tex, I->status, rc,
                        shape ? I->geo.vis : nullptr, fwd ? 1 : 0);
         prof_mark(I, s, CLS_RESOLVE);
         cur ^= 1;
@@ -547,6 +578,7 @@ int run_chunk(HarSceneImpl *S, HarIntegratorImpl *I, const DSensor &C, int mode,
             if (total == 0) { ++b; break; }
         }
     }
+    if (resolve_pending) HIP_TRY(hipStreamWaitEvent(s, I->ev_resolved, 0));
     if (shape && b > 0) {            /* the last bounce: no path continues */
         launch_shape_adjoint(s, grid, S->ds, cnt_items(I, b - 1), I->shard_cap, I->items, I->geo, I->result, I->dL, 0, I->st[cur], I->h0, I->h1, ReplayCache{ nullptr, nullptr, nullptr, 0 }, targets);
         prof_mark(I, s, CLS_OTHER);
@@ -828,10 +860,17 @@ int har_integrator_destroy(HarIntegrator I) {
     (void) hipDeviceSynchronize();
     I->free_ws();
     prof_destroy(I);
-    if (I->twin) { I->twin->free_ws(); prof_destroy(I->twin); delete I->twin; }
+    if (I->twin) { I->twin->free_ws(); prof_destroy(I->twin); }
     if (I->ev_fork) (void) hipEventDestroy(I->ev_fork);
     if (I->ev_join) (void) hipEventDestroy(I->ev_join);
     if (I->side_stream) (void) hipStreamDestroy(I->side_stream);
+    for (HarIntegratorImpl *J : { I->twin, I })
+        if (J) {
+            if (J->ev_shaded) (void) hipEventDestroy(J->ev_shaded);
+            if (J->ev_resolved) (void) hipEventDestroy(J->ev_resolved);
+            if (J->aux_stream) (void) hipStreamDestroy(J->aux_stream);
+        }
+    if (I->twin) delete I->twin;
     delete I;
     return 0;
 }
@@ -924,8 +963,11 @@ int har_render(HarScene S, HarIntegrator I, const HarSensor *sensor, uint32_t se
         total_le = (uint64_t) grid_w * grid_h * spp_pass;
         if (total_le == 0 || total_le > 0xffffffffull) return render_range(S, I, sensor, seed, spp, lb, le, film, stream);      /* reports the error */
     }
-    const uint64_t mid = total_le > total_lb ? dual_split(I, total_lb, total_le, (hipStream_t) stream) : total_le;
-    if (mid >= total_le) return render_range(S, I, sensor, seed, spp, lb, le, film, stream);
+    /* jobs small enough for the shadow-ray overlap run on one stream: that beats two half-jobs with or without overlap (overlap_applies) */
+    static const int streams_env = getenv("HAR_STREAMS") ? atoi(getenv("HAR_STREAMS")) : 0;
+    const bool single = streams_env != 2 && overlap_applies(S, I, std::min<uint64_t>(total_le - total_lb, I->chunk));
+    const uint64_t mid = (total_le > total_lb && !single) ? dual_split(I, total_lb, total_le, (hipStream_t) stream) : total_le;
+    if (mid >= total_le) { I->twin_used = false; return render_range(S, I, sensor, seed, spp, lb, le, film, stream); }
     int rc = render_range(S, I, sensor, seed, spp, total_lb, mid, film, stream);
     rc |= render_range(S, I->twin, sensor, seed, spp, mid, total_le, film, (void *) I->side_stream);
     rc |= dual_join(I, (hipStream_t) stream);
@@ -942,7 +984,12 @@ int har_render_backward(HarScene S, HarIntegrator I, const HarSensor *sensor, co
         total_le = (uint64_t) grid_w * grid_h * spp;
         if (total_le == 0 || total_le > 0xffffffffull) return backward_range(S, I, sensor, grad_in, weight_film, seed, spp, lb, le, grad_reflectance, grad_textures, stream);
     }
-    const uint64_t mid = (total_le > total_lb && I->type == HAR_INTEGRATOR_PRB && !I->shape_on) ? dual_split(I, total_lb, total_le, (hipStream_t) stream) : total_le;
+    /* as in har_render: one stream when the primal pass overlaps its shadow rays (PRB bands of 8 / 16 / 33 M lanes: 16.46 / 30.19 / 54.32 ms against 17.01 / 30.90 /
+     * 55.34 ms on two streams, profiles/r03_ab_shadow_overlap.txt) */
+    static const int streams_env = getenv("HAR_STREAMS") ? atoi(getenv("HAR_STREAMS")) : 0;
+    const bool single = streams_env != 2 && overlap_applies(S, I, std::min<uint64_t>(total_le - total_lb, I->chunk));
+    const uint64_t mid = (total_le > total_lb && I->type == HAR_INTEGRATOR_PRB && !I->shape_on && !single) ? dual_split(I, total_lb, total_le, (hipStream_t) stream) : total_le;
+    if (mid >= total_le) I->twin_used = false;
     if (mid >= total_le) return backward_range(S, I, sensor, grad_in, weight_film, seed, spp, lb, le, grad_reflectance, grad_textures, stream);
     int rc = backward_range(S, I, sensor, grad_in, weight_film, seed, spp, total_lb, mid, grad_reflectance, grad_textures, stream);
     rc |= backward_range(S, I->twin, sensor, grad_in, weight_film, seed, spp, mid, total_le, grad_reflectance, grad_textures, (void *) I->side_stream);
