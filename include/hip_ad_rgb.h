@@ -278,7 +278,8 @@ int har_integrator_set_grad_emitters(HarIntegrator integrator, float *grad_emitt
  * ad/integrators/common.py:1355-1384).  `grad_positions` = HOST array of top_mesh_count DEVICE pointers; entry m (vertex_count x 3 floats)
  * makes mesh m differentiable, NULL entries do not; har_render_backward then also accumulates into those buffers.  A NULL array switches the
  * feature off.  Like `prb` itself this has no visibility-boundary term (that is prb_reparam / the projective integrators).
- * Implemented for scenes whose BSDFs are all `diffuse` (plain or inside `twosided`) and for meshes without vertex normals; fails otherwise.
+ * The differentiated meshes are top-level, without vertex normals, and carry a BSDF with a non-delta lobe (diffuse, roughconductor, roughplastic, plastic; plain
+ * or inside `twosided`) -- the attached si.wi / wo reach the BSDF value (prb.py:128-140, 276-288); the other meshes of the scene may carry any BSDF.  Fails otherwise.
  * New vertex positions are installed by creating a new scene (har_scene_create), which rebuilds the acceleration structure. */
 int har_integrator_set_grad_positions(HarIntegrator integrator, HarScene scene, float *const *grad_positions);
 
@@ -288,7 +289,7 @@ int har_integrator_set_grad_positions(HarIntegrator integrator, HarScene scene, 
  * `grad_to_world` = DEVICE buffer of instance_count x 12 floats (column-major 3x4 like HarInstance::to_world; the reference's 4x4 has a constant
  * fourth row); har_render_backward then also accumulates into it.  NULL switches the feature off.  Can be combined with
  * har_integrator_set_grad_positions (as in the reference, NOT for the meshes of the instanced shape groups themselves, instance.cpp:162-166).
- * Like `prb` itself: no visibility-boundary term.  Scenes whose BSDFs are all `diffuse` (plain or inside `twosided`); fails otherwise. */
+ * Like `prb` itself: no visibility-boundary term.  The instanced meshes carry BSDFs with a non-delta lobe (as above); fails otherwise. */
 int har_integrator_set_grad_instances(HarIntegrator integrator, HarScene scene, float *grad_to_world);
 
 /* RBIntegrator.render_forward (src/python/python/ad/integrators/common.py:497-623): the forward-mode derivative image of the `prb` integrator.
