@@ -216,6 +216,14 @@ int har_film_put(const HarSensor *sensor, uint32_t n, const float *pos_x, const 
                  const float *values4 /*[n][4]*/, float *film, void *stream);
 /* HDRFilm::develop (src/films/hdrfilm.cpp:301-404): image H x W x 3 = RGB / (W==0 ? 1 : W) */
 int har_film_develop(const float *film, uint32_t width, uint32_t height, float *image, void *stream);
+/* ... with the film's `pixel_format` (hdrfilm.cpp:149-176, develop :326-395): HAR_PIXEL_RGB -> H x W x 3; HAR_PIXEL_Y -> H x W x 1, luminance(rgb)
+ * (include/mitsuba/core/spectrum.h:439-442); HAR_PIXEL_XYZ -> H x W x 3, srgb_to_xyz(rgb) (spectrum.h:402-410).  The conversion is applied to the weighted
+ * sums, the division by the weight comes last, as in the reference.  The alpha channel of `rgba` / `luminance_alpha` / `xyza` films is a second film
+ * (har_integrator_set_alpha_film) developed as A / W by the caller. */
+#define HAR_PIXEL_RGB 0
+#define HAR_PIXEL_Y   1
+#define HAR_PIXEL_XYZ 2
+int har_film_develop_format(const float *film, uint32_t width, uint32_t height, int pixel_format, float *image, void *stream);
 
 /* ------------------------------------------------------------------------
  *  Integrators

@@ -117,6 +117,7 @@ SIGNATURES = {
     "har_sensor_sample_ray": (C.c_int, [C.POINTER(HarSensor), C.c_uint32, vp, vp, vp, vp, vp, vp]),
     "har_film_put": (C.c_int, [C.POINTER(HarSensor), C.c_uint32, vp, vp, vp, vp, vp]),
     "har_film_develop": (C.c_int, [vp, C.c_uint32, C.c_uint32, vp, vp]),
+    "har_film_develop_format": (C.c_int, [vp, C.c_uint32, C.c_uint32, C.c_int, vp, vp]),
     "har_integrator_create": (C.c_int, [C.c_int, C.c_int32, C.c_int32, C.c_uint32, C.POINTER(vp)]),
     "har_integrator_destroy": (C.c_int, [vp]),
     "har_render": (C.c_int, [vp, vp, C.POINTER(HarSensor), C.c_uint32, C.c_uint32, C.c_uint64, C.c_uint64, vp, vp]),

@@ -55,7 +55,11 @@ def _render_scalar(scene, integrator, sensor, seed, spp, threads=0, block_size=0
     check(lib().har_render_scalar(C.byref(d), C.byref(sensor.har), int(seed) & 0xffffffff, spp, integrator.max_depth, integrator.rr_depth, block_size, threads,
                                    film.ctypes.data_as(C.c_void_p), C.byref(used)))
     wgt = film[..., 3:4]
-    return film[..., :3] / np.where(wgt == 0, 1.0, wgt).astype(np.float32)
+    rgb = film[..., :3]
+    rows = _COLOUR_ROWS[sensor.film().colour]           # `luminance` / `xyz` films: the colour transform of HDRFilm::develop on the weighted sums, then / W
+    if rows is not None:
+        rgb = rgb @ np.asarray(rows, np.float32).T
+    return rgb / np.where(wgt == 0, 1.0, wgt).astype(np.float32)
 
 
 def _f32(x):
@@ -434,10 +438,12 @@ class Film:
         if self.crop_offset_[0] + self.crop_size_[0] > self.width or self.crop_offset_[1] + self.crop_size_[1] > self.height:
             raise RuntimeError("Invalid crop window specification: crop_offset(%u, %u) + crop_size(%u, %u) > size(%u, %u)"
                                % (self.crop_offset_ + self.crop_size_ + (self.width, self.height)))
-        pf = str(props.get('pixel_format', 'rgb')).lower()          # hdrfilm.cpp:135-160
-        if pf not in ('rgb', 'rgba'):
-            raise RuntimeError("hdrfilm: pixel_format \"%s\" is not supported by hip_ad_rgb ('rgb', 'rgba')" % pf)
-        self.alpha = (pf == 'rgba')
+        pf = str(props.get('pixel_format', 'rgb')).lower()          # hdrfilm.cpp:149-176
+        formats = {'rgb': (0, False), 'rgba': (0, True), 'luminance': (1, False), 'luminance_alpha': (1, True), 'xyz': (2, False), 'xyza': (2, True)}
+        if pf not in formats:
+            raise RuntimeError("The \"pixel_format\" parameter must either be equal to \"luminance\", \"luminance_alpha\", \"rgb\", \"rgba\",  \"xyz\", \"xyza\". Found %s." % pf)
+        self.pixel_format = pf
+        self.colour, self.alpha = formats[pf]        # colour: HAR_PIXEL_RGB / _Y / _XYZ of har_film_develop_format; alpha: FilmFlags::Alpha
         rf = next((v for v in props.values() if isinstance(v, dict) and 'type' in v), {'type': 'gaussian'})     # the film's only child object is its rfilter
         self.rf_param1 = 1.0 / 3.0
         if rf['type'] == 'gaussian':                     # src/rfilters/gaussian.cpp:48-55
@@ -881,7 +887,7 @@ class Integrator:
                 raise Exception("develop=True must be specified when invoking AD integrators")
             out = film
         else:
-            out = develop_film(film, alpha)
+            out = develop_film(film, alpha, sensor.film().colour)
         if evaluate:
             torch.cuda.current_stream().synchronize()
             self.stats()                 # surfaces device-side errors (traversal stack overflow)
@@ -938,9 +944,15 @@ class Integrator:
             weight_film = torch.zeros((h, w, 4), dtype=torch.float32, device=dev)
             check(lib().har_render_weights(C.byref(sensor.har), sd, spp, lb, le, _ptr(weight_film), _stream()))
         grad_in = torch.as_tensor(grad_in, dtype=torch.float32, device=dev)
-        if sensor.film().alpha and grad_in.numel() == h * w * 4:
-            grad_in = grad_in.reshape(h, w, 4)[:, :, :3]               # alpha is a mask of detached decisions: no gradient
-        grad_in = grad_in.reshape(h, w, 3).contiguous()
+        colour = sensor.film().colour
+        nc = 1 if colour == 1 else 3
+        if sensor.film().alpha and grad_in.numel() == h * w * (nc + 1):
+            grad_in = grad_in.reshape(h, w, nc + 1)[:, :, :nc]           # alpha is a mask of detached decisions: no gradient
+        grad_in = grad_in.reshape(h, w, nc)
+        if colour:            # adjoint of develop's colour transform (linear: rows of luminance() / srgb_to_xyz()): d loss / d rgb = M^T d loss / d colour
+            m = torch.tensor(_COLOUR_ROWS[colour], dtype=torch.float32, device=dev)
+            grad_in = grad_in @ m
+        grad_in = grad_in.contiguous()
         g_refl = torch.zeros((len(scene.bsdfs), 3), dtype=torch.float32, device=dev)
         g_tex = [torch.zeros(tuple(t.shape), dtype=torch.float32, device=dev) for t in scene.textures]
         ptrs = (C.c_void_p * max(1, len(g_tex)))(*[t.data_ptr() for t in g_tex])
@@ -1018,7 +1030,7 @@ def _render_forward(self, scene, params=None, sensor=0, seed=0, spp=0, tangents=
     lb, le = lanes if lanes else (0, 0)
     check(lib().har_render_forward(scene._handle(), self._handle(), C.byref(sensor.har), (sensor.sampler().m_base_seed + int(seed)) & 0xffffffff, spp, lb, le,
                                    _ptr(t_refl), ptrs if t_tex else None, _ptr(t_emit) if any_emit else None, _ptr(film), _stream()))
-    return develop_film(film) if develop else film
+    return develop_film(film, None, sensor.film().colour) if develop else film
 
 
 Integrator.render_forward = _render_forward
@@ -1066,12 +1078,18 @@ def write_bitmap(filename, data):
     Bitmap(data).write(filename)
 
 
-def develop_film(film, alpha_film=None):
-    """HDRFilm::develop (hdrfilm.cpp:301-404): RGB / W, and A / W for `rgba` films (alpha_film: channel 3 holds the accumulated w * alpha)"""
+# luminance() and srgb_to_xyz() (include/mitsuba/core/spectrum.h:439-442, 402-410): rows of the colour transform HDRFilm::develop applies for `luminance*` / `xyz*` films
+_COLOUR_ROWS = {0: None, 1: ((0.212671, 0.715160, 0.072169),),
+                2: ((0.412453, 0.357580, 0.180423), (0.212671, 0.715160, 0.072169), (0.019334, 0.119193, 0.950227))}
+
+
+def develop_film(film, alpha_film=None, colour=0):
+    """HDRFilm::develop (hdrfilm.cpp:301-404): colour / W -- RGB, Y = luminance(rgb) or XYZ = srgb_to_xyz(rgb) by the film's pixel format -- and A / W for films with
+    an alpha channel (alpha_film: channel 3 holds the accumulated w * alpha)"""
     torch = _torch()
     h, w, _ = film.shape
-    img = torch.empty((h, w, 3), dtype=torch.float32, device=film.device)
-    check(lib().har_film_develop(_ptr(film), w, h, _ptr(img), _stream()))
+    img = torch.empty((h, w, 1 if colour == 1 else 3), dtype=torch.float32, device=film.device)
+    check(lib().har_film_develop_format(_ptr(film), w, h, int(colour), _ptr(img), _stream()))
     if alpha_film is None:
         return img
     weight = film[:, :, 3:4]

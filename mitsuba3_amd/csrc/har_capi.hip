@@ -837,8 +837,12 @@ int har_film_put(const HarSensor *sensor, uint32_t n, const float *px, const flo
     return 0;
 }
 int har_film_develop(const float *film, uint32_t width, uint32_t height, float *image, void *stream) {
+    return har_film_develop_format(film, width, height, HAR_PIXEL_RGB, image, stream);
+}
+int har_film_develop_format(const float *film, uint32_t width, uint32_t height, int pixel_format, float *image, void *stream) {
     if (!film || !image) return fail("null film / image");
-    launch_develop((hipStream_t) stream, film, width * height, image);
+    if (pixel_format != HAR_PIXEL_RGB && pixel_format != HAR_PIXEL_Y && pixel_format != HAR_PIXEL_XYZ) return fail("har_film_develop_format: pixel_format must be HAR_PIXEL_RGB, _Y or _XYZ");
+    launch_develop((hipStream_t) stream, film, width * height, image, pixel_format);
     HIP_TRY(hipGetLastError());
     return 0;
 }

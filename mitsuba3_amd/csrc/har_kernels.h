@@ -162,7 +162,7 @@ void launch_splat(hipStream_t s, const DSensor &C, uint32_t seed, uint32_t spp, 
 /* alpha flags of the camera samples of a wavefront (1 = valid), see k_alpha_flags */
 void launch_alpha_flags(hipStream_t s, uint32_t grid, uint32_t shard_cap, const uint32_t *count_in, const WaveState &in, const float4 *h0, uint32_t lane_base, float miss_value, float *alpha);
 void launch_pass_jitter(hipStream_t s, uint32_t seed, uint32_t lane_base, uint32_t n, uint32_t pass, float2 *jitter);
-void launch_develop(hipStream_t s, const float *film, uint32_t npx, float *image);
+void launch_develop(hipStream_t s, const float *film, uint32_t npx, float *image, int colour = 0);
 void launch_adjoint_image(hipStream_t s, const float *grad_in, const float *wfilm, uint32_t npx, float *adj);
 void launch_add(hipStream_t s, const float *src, float *dst, uint32_t n);      /* dst[i] += src[i] */
 void launch_accumulate_stats(hipStream_t s, const uint32_t *counters, uint32_t n_bounces, unsigned long long *totals, uint32_t paths);

@@ -1364,11 +1364,18 @@ __global__ void k_pass_jitter(uint32_t seed, uint32_t lane_base, uint32_t n, uin
 }
 
 /* --------------------------------------------------------- small utilities */
-__global__ void k_develop(const float *film, uint32_t npx, float *image) {
+/* HDRFilm::develop, JIT branch (hdrfilm.cpp:310-395): colour 0 = RGB, 1 = Y (`luminance(rgb)`, spectrum.h:439-442), 2 = XYZ (`srgb_to_xyz`, spectrum.h:402-410: M * rgb
+ * as the sum of the matrix columns scaled by the components).  The conversion runs on the WEIGHTED sums, the division by the weight comes last (:390). */
+__global__ void k_develop(const float *film, uint32_t npx, float *image, int colour) {
     uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= npx) return;
     float4 f = reinterpret_cast<const float4 *>(film)[i];
     float w = f.w == 0.f ? 1.f : f.w;
+    if (colour == 1) { image[i] = fma_(f.z, 0.072169f, fma_(f.y, 0.715160f, f.x * 0.212671f)) / w; return; }
+    if (colour == 2) {
+        f = make_float4(fma_(f.z, 0.180423f, fma_(f.y, 0.357580f, f.x * 0.412453f)), fma_(f.z, 0.072169f, fma_(f.y, 0.715160f, f.x * 0.212671f)),
+                        fma_(f.z, 0.950227f, fma_(f.y, 0.119193f, f.x * 0.019334f)), f.w);
+    }
     image[3 * (size_t) i] = f.x / w; image[3 * (size_t) i + 1] = f.y / w; image[3 * (size_t) i + 2] = f.z / w;
 }
 __global__ void k_adjoint_image(const float *grad_in, const float *wfilm, uint32_t npx, float *adj) {
@@ -1652,8 +1659,8 @@ void launch_splat(hipStream_t s, const DSensor &C, uint32_t seed, uint32_t spp, 
 void launch_pass_jitter(hipStream_t s, uint32_t seed, uint32_t lane_base, uint32_t n, uint32_t pass, float2 *jitter) {
     hipLaunchKernelGGL(k_pass_jitter, dim3(blocks_for(n)), dim3(kBlock), 0, s, seed, lane_base, n, pass, jitter);
 }
-void launch_develop(hipStream_t s, const float *film, uint32_t npx, float *image) {
-    hipLaunchKernelGGL(k_develop, dim3(blocks_for(npx)), dim3(kBlock), 0, s, film, npx, image);
+void launch_develop(hipStream_t s, const float *film, uint32_t npx, float *image, int colour) {
+    hipLaunchKernelGGL(k_develop, dim3(blocks_for(npx)), dim3(kBlock), 0, s, film, npx, image, colour);
 }
 void launch_adjoint_image(hipStream_t s, const float *grad_in, const float *wfilm, uint32_t npx, float *adj) {
     hipLaunchKernelGGL(k_adjoint_image, dim3(blocks_for(npx)), dim3(kBlock), 0, s, grad_in, wfilm, npx, adj);

@@ -146,7 +146,7 @@ def render_distributed(scene, integrator=None, sensor=0, seed=0, spp=0, develop=
                 dist.reduce(buf, dst=dst, op=dist.ReduceOp.SUM)  # the single RCCL collective (two for `rgba` films)
     if not develop:
         return film
-    return develop_film(film, alpha) if rank == dst or world == 1 else None
+    return develop_film(film, alpha, getattr(s.film(), "colour", 0)) if rank == dst or world == 1 else None
 
 
 def render_backward_distributed(scene, grad_in, integrator=None, sensor=0, seed=0, spp=0):

@@ -926,6 +926,41 @@ def test_vertex_position_optimisation_converges(mi):
     assert abs(heights[-1]) < 0.03 and losses[-1] < 0.1 * losses[0], (heights, losses)
 
 
+@pytest.mark.parametrize("fmt", ["luminance", "luminance_alpha", "xyz", "xyza"])
+def test_film_pixel_formats(mi, O, fmt):
+    """HDRFilm pixel formats (hdrfilm.cpp:149-176, develop :326-395): Y = luminance(rgb), XYZ = srgb_to_xyz(rgb) (spectrum.h:402-442) of the ORACLE's image, the
+    alpha plane as for rgba; the `prb` adjoint takes a gradient in the film's own channels (the transform is linear: its transpose reaches the RGB adjoint)"""
+    from tests.test_cpu_host import oracle_scene_from
+    from tests.test_emitters_cpu import hide_emitters_scene
+    d = hide_emitters_scene(mi, 32)
+    d["sensor"]["film"]["pixel_format"] = fmt
+    d["integrator"] = {"type": "prb", "max_depth": 4}
+    scene = mi.load_dict(d)
+    osc, sensor = oracle_scene_from(O, scene)
+    img = mi.render(scene, spp=16, seed=3).cpu().numpy()
+    ref, _ = osc.render_prb(sensor, seed=3, spp=16, max_depth=4)
+    y = np.float32(0.212671) * ref[..., 0] + np.float32(0.715160) * ref[..., 1] + np.float32(0.072169) * ref[..., 2]
+    M = np.array([[0.412453, 0.357580, 0.180423], [0.212671, 0.715160, 0.072169], [0.019334, 0.119193, 0.950227]], np.float32)
+    want = y[..., None] if fmt.startswith("luminance") else ref @ M.T
+    nc = want.shape[2]
+    assert img.shape == (32, 32, nc + (1 if fmt.endswith("a") else 0))
+    assert rel_l2(img[..., :nc], want) < 1e-4
+    if fmt.endswith("a"):
+        osc.set_alpha_only(True); alpha, _ = osc.render_prb(sensor, seed=3, spp=16, max_depth=4); osc.set_alpha_only(False)
+        assert np.abs(img[..., nc] - alpha[..., 0]).max() < 1e-5
+    # gradients: sum(w * colour) = sum((M^T w) * rgb)
+    w = np.random.default_rng(1).uniform(0.5, 1.5, img.shape).astype(np.float32)
+    grads = scene.integrator().render_backward(scene, None, w, seed=5, spp=8)
+    w_rgb = (w[..., :nc] * np.array([0.212671, 0.715160, 0.072169], np.float32)) if nc == 1 else w[..., :nc] @ M
+    g_refl, _, _ = osc.render_prb_backward(sensor, np.ascontiguousarray(w_rgb, np.float32), seed=5, spp=8, max_depth=4)
+    keys = [k for k in grads if k.endswith("reflectance.value")]
+    assert keys
+    for k in keys:
+        b = scene._param_keys()[k][1]
+        if g_refl[b.index].any():
+            assert rel_l2(grads[k].cpu().numpy(), g_refl[b.index]) < 1e-3, k
+
+
 @pytest.mark.parametrize("config", ["path", "prb", "path_hidden", "path_chunks", "path_passes"])
 def test_rgba_film_alpha_parity(mi, O, config):
     """pixel_format = rgba (har_integrator_set_alpha_film): RGB as before, A = filtered valid-sample mask, vs the oracle"""

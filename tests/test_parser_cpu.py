@@ -259,6 +259,15 @@ def test_reference_transform_known_answers(mi):
     assert not T().look_at(origin=[10, -1, 3], target=[1, 1, 2], up=[0, 1, 0]).has_scale() and not T().has_scale()
 
 
+def test_film_pixel_formats_are_parsed_like_the_reference(mi):
+    """hdrfilm.cpp:149-176: the six pixel formats, their FilmFlags::Alpha, and the reference's message for anything else"""
+    for pf, colour, alpha in (("rgb", 0, False), ("rgba", 0, True), ("luminance", 1, False), ("luminance_alpha", 1, True), ("xyz", 2, False), ("XYZA", 2, True)):
+        f = mi.load_dict({'type': 'hdrfilm', 'width': 4, 'height': 4, 'pixel_format': pf})
+        assert (f.colour, f.alpha) == (colour, alpha)
+    with pytest.raises(RuntimeError, match='"pixel_format" parameter must either be equal to'):
+        mi.load_dict({'type': 'hdrfilm', 'width': 4, 'height': 4, 'pixel_format': 'yuv'})
+
+
 def test_reference_film_crop_window(mi):
     """src/films/tests/test_hdrfilm.py:36-72 (test02_crops) and Film::set_crop_window (src/render/film.cpp:90-99): accessors, and a crop window that
     leaves the film is an error -- from a dict and from XML"""

@@ -182,6 +182,16 @@ def test_product_scalar_path_matches_the_oracle_scalar_driver(O):
         d["integrator"] = {"type": "path", "max_depth": 1}
         img = mi.render(mi.load_dict(d), spp=64)
         assert np.allclose(np.asarray(img).reshape(3), [18.387, 13.9873, 6.75357], rtol=1e-5)
+        # luminance / xyz films (hdrfilm.cpp:149-176): the develop step's colour transform of the same film (spectrum.h:402-442)
+        for pf in ("luminance", "xyz"):
+            d = mi.cornell_box(); f = d["sensor"]["film"]; f["width"] = 24; f["height"] = 24; f["pixel_format"] = pf
+            scene = mi.load_dict(d)
+            osc, sensor = O.scene_from_product(scene)
+            ref, _, _ = osc.render_path_scalar(sensor, seed=3, spp=4, max_depth=8)
+            M = np.array([[0.412453, 0.357580, 0.180423], [0.212671, 0.715160, 0.072169], [0.019334, 0.119193, 0.950227]], np.float32)
+            want = (ref @ M[1])[..., None] if pf == "luminance" else ref @ M.T
+            img = core._render_scalar(scene, scene.integrator(), scene.sensors()[0], 3, 4, threads=1)
+            assert img.shape == want.shape and _rel_l2(img, want) < 1e-5, pf
         # materials (conditional emitter draws where the BSDF has no smooth lobe: dielectric / conductor)
         d = mi.instanced_spheres_scene(width=24, height=24, spp=8, grid=2, n_u=8, n_v=4, flatten=True, materials=True)
         scene = mi.load_dict(d)
