@@ -19,6 +19,7 @@
  * shape_index[n], inst_index[n] (include/mitsuba/render/interaction.h:717-836).
  */
 #pragma once
+#include <stddef.h>
 #include <stdint.h>
 
 #ifdef __cplusplus
@@ -142,6 +143,17 @@ typedef struct HarIntegratorImpl *HarIntegrator;
 const char *har_last_error(void);
 /* returns the gfx arch string of the current device ("gfx950"), or NULL without a GPU */
 const char *har_device_arch(void);
+
+/* ------------------------------------------------------------------------
+ *  Device memory (the reference allocates through Dr.Jit's caching allocator, jit_malloc: every array of the renderer lives in the process's one pool).
+ *  By default the library calls hipMalloc / hipFree.  A host that owns a device allocator installs it here: alloc_fn(bytes, user) returns device memory
+ *  usable on any stream of the current device (NULL = out of memory), free_fn(ptr, user) releases a block alloc_fn returned.  Blocks remember the
+ *  function that frees them, so the hook may change while blocks are alive; NULL, NULL restores hipMalloc.  The library synchronises the device before it
+ *  frees a workspace.  (mitsuba3_amd installs PyTorch's caching allocator: torch.cuda.caching_allocator_alloc / _delete.)
+ * ------------------------------------------------------------------------ */
+typedef void *(*HarAllocFn)(size_t bytes, void *user);
+typedef void (*HarFreeFn)(void *ptr, void *user);
+int har_set_allocator(HarAllocFn alloc_fn, HarFreeFn free_fn, void *user);
 
 /* ------------------------------------------------------------------------
  *  Scene + acceleration structure

@@ -118,6 +118,7 @@ SIGNATURES = {
     "har_film_put": (C.c_int, [C.POINTER(HarSensor), C.c_uint32, vp, vp, vp, vp, vp]),
     "har_film_develop": (C.c_int, [vp, C.c_uint32, C.c_uint32, vp, vp]),
     "har_film_develop_format": (C.c_int, [vp, C.c_uint32, C.c_uint32, C.c_int, vp, vp]),
+    "har_set_allocator": (C.c_int, [vp, vp, vp]),
     "har_integrator_create": (C.c_int, [C.c_int, C.c_int32, C.c_int32, C.c_uint32, C.POINTER(vp)]),
     "har_integrator_destroy": (C.c_int, [vp]),
     "har_render": (C.c_int, [vp, vp, C.POINTER(HarSensor), C.c_uint32, C.c_uint32, C.c_uint64, C.c_uint64, vp, vp]),
@@ -169,6 +170,42 @@ def lib():
             fn.argtypes = args
         _LIB = L
     return _LIB
+
+
+# --- device memory through PyTorch's caching allocator (har_set_allocator): the library's workspaces (tens of GB for a 2^26-lane wavefront) and scene arrays then
+# live in the process's one pool -- visible in torch.cuda.memory_allocated(), returned to it when an integrator goes away, never competing with it for the
+# device.  HAR_TORCH_ALLOCATOR=0: plain hipMalloc / hipFree.
+_ALLOC_CB = None; _FREE_CB = None; _ALLOC_STATE = {"installed": False, "closing": False}
+
+
+def install_torch_allocator():
+    global _ALLOC_CB, _FREE_CB
+    if _ALLOC_STATE["installed"] or os.environ.get("HAR_TORCH_ALLOCATOR", "1") == "0" or os.environ.get("HAR_DEBUG_GUARD"):
+        return
+    import atexit
+    import torch
+    if not torch.cuda.is_available():
+        return
+
+    def _alloc(nbytes, user):
+        try:
+            return torch.cuda.caching_allocator_alloc(int(nbytes), torch.cuda.current_device(), torch.cuda.current_stream())
+        except Exception:           # torch.cuda.OutOfMemoryError etc.: the library reports "out of memory" through its own error path
+            return None
+
+    def _free(ptr, user):
+        if ptr and not _ALLOC_STATE["closing"]:
+            try:
+                torch.cuda.caching_allocator_delete(ptr)
+            except Exception:
+                pass
+
+    _ALLOC_CB = C.CFUNCTYPE(C.c_void_p, C.c_size_t, C.c_void_p)(_alloc)
+    _FREE_CB = C.CFUNCTYPE(None, C.c_void_p, C.c_void_p)(_free)
+    check(lib().har_set_allocator(C.cast(_ALLOC_CB, C.c_void_p), C.cast(_FREE_CB, C.c_void_p), None))
+    _ALLOC_STATE["installed"] = True
+    # objects that outlive the interpreter's orderly phase free their blocks while torch is being torn down: leave those to the process exit
+    atexit.register(lambda: _ALLOC_STATE.__setitem__("closing", True))
 
 
 def check(rc):

@@ -83,6 +83,7 @@ def _device():
     torch = _torch()
     if not torch.cuda.is_available():
         raise HarError("hip_ad_rgb requires a HIP device (torch.cuda.is_available() is False); there is no CPU fallback")
+    _capi.install_torch_allocator()         # once: the library allocates through PyTorch's caching allocator (har_set_allocator)
     return torch.device("cuda", torch.cuda.current_device())
 
 

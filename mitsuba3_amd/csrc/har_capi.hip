@@ -41,10 +41,31 @@ struct GuardedBlock { void *base; size_t reserved; void *mapped; size_t mapped_b
 std::map<void *, GuardedBlock> g_guarded;
 std::mutex g_guarded_mutex;
 int guard_mode() { static const int m = getenv("HAR_DEBUG_GUARD") ? atoi(getenv("HAR_DEBUG_GUARD")) : 0; return m; }
+/* har_set_allocator: the host's device allocator (the Python host installs PyTorch's caching allocator, so that workspaces and scene arrays show up in -- and are
+ * reused through -- the process's one memory pool).  Every block remembers who has to free it, so the hook can be changed while blocks are alive. */
+HarAllocFn g_alloc_fn = nullptr; HarFreeFn g_free_fn = nullptr; void *g_alloc_user = nullptr;
+struct HostBlock { HarFreeFn free_fn; void *user; };
+std::map<void *, HostBlock> g_host_blocks;
+std::mutex g_alloc_mutex;
+}
+int har_set_allocator(HarAllocFn alloc_fn, HarFreeFn free_fn, void *user) {
+    if ((alloc_fn == nullptr) != (free_fn == nullptr)) return fail("har_set_allocator: give both functions, or neither (hipMalloc / hipFree)");
+    std::lock_guard<std::mutex> lock(g_alloc_mutex);
+    g_alloc_fn = alloc_fn; g_free_fn = free_fn; g_alloc_user = user;
+    return 0;
 }
 static hipError_t dev_alloc(void **out, size_t bytes) {
     bytes = std::max<size_t>(bytes, 1);
-    if (!guard_mode()) return hipMalloc(out, bytes);
+    if (!guard_mode()) {
+        HarAllocFn fn; HarFreeFn ffn; void *user;
+        { std::lock_guard<std::mutex> lock(g_alloc_mutex); fn = g_alloc_fn; ffn = g_free_fn; user = g_alloc_user; }
+        if (!fn) return hipMalloc(out, bytes);
+        void *p = fn(bytes, user);
+        if (!p) return hipErrorOutOfMemory;
+        std::lock_guard<std::mutex> lock(g_alloc_mutex);
+        g_host_blocks[p] = HostBlock{ ffn, user }; *out = p;
+        return hipSuccess;
+    }
     int dev = 0; hipError_t e = hipGetDevice(&dev); if (e != hipSuccess) return e;
     hipMemAllocationProp prop{}; prop.type = hipMemAllocationTypePinned; prop.location.type = hipMemLocationTypeDevice; prop.location.id = dev;
     size_t gran = 0; e = hipMemGetAllocationGranularity(&gran, &prop, hipMemAllocationGranularityMinimum); if (e != hipSuccess) return e;
@@ -80,6 +101,17 @@ static void dev_free(void *p) {
             /* the address range stays reserved for the life of the process (quarantine): a stale pointer faults instead of reaching a later allocation */
             return;
         }
+    }
+    {
+        HostBlock B{ nullptr, nullptr };
+        {
+            std::lock_guard<std::mutex> lock(g_alloc_mutex);
+            auto it = g_host_blocks.find(p);
+            if (it != g_host_blocks.end()) { B = it->second; g_host_blocks.erase(it); }
+        }
+        /* hipFree synchronises the device before it releases a block; a pooling allocator hands the block to its next user at once, so do the same here
+         * (the library's private streams may still be reading it) */
+        if (B.free_fn) { (void) hipDeviceSynchronize(); B.free_fn(p, B.user); return; }
     }
     (void) hipFree(p);
 }

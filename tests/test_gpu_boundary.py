@@ -489,3 +489,23 @@ def test_ray_queries_bitexact_on_triangle_soups(mi, O, n_tris, instanced):
     assert rel_l2(img, ref) < 1e-4
     gst = scene.integrator().stats()
     assert gst["paths"] == st.paths and gst["vertices"] == st.vertices
+
+
+def test_library_memory_lives_in_the_torch_pool(mi):
+    """har_set_allocator: the Python host installs PyTorch's caching allocator, so the library's scene arrays and wavefront workspaces are part of
+    torch.cuda.memory_allocated() while they live and go back to the pool when the objects die (the reference allocates through Dr.Jit's jit_malloc pool)"""
+    import gc
+    import torch
+    gc.collect(); torch.cuda.synchronize()
+    base = torch.cuda.memory_allocated()
+    d = mi.cornell_box(); d["sensor"]["film"]["width"] = 64; d["sensor"]["film"]["height"] = 64
+    scene = mi.load_dict(d)
+    img = mi.render(scene, spp=16, seed=0)
+    held = torch.cuda.memory_allocated() - base
+    assert held > 4 * 64 * 64 * 16 * 100, held            # >= 100 B of path state per lane, far more than the 48 KB image
+    ref = img.cpu().numpy()
+    del scene, img
+    gc.collect(); torch.cuda.synchronize()
+    assert torch.cuda.memory_allocated() - base < 1 << 20, torch.cuda.memory_allocated() - base
+    scene = mi.load_dict(d)                                # the pool's blocks are reused: same image
+    assert np.array_equal(mi.render(scene, spp=16, seed=0).cpu().numpy() > 0, ref > 0) and rel_l2(mi.render(scene, spp=16, seed=0).cpu().numpy(), ref) < 1e-6
