@@ -201,6 +201,10 @@ def worker(args):
     # HAR_BENCH_SHARE_GPU=1 + HAR_BENCH_BACKEND=gloo: rehearsal of the N-rank code path on a box with fewer GPUs than ranks
     # (ranks share devices, the film reduce goes through gloo); never used for reported numbers
     device_index = local_rank % torch.cuda.device_count() if os.environ.get("HAR_BENCH_SHARE_GPU") else local_rank
+    if os.environ.get("HAR_BENCH_SHARE_GPU") and world > 1:
+        # ranks that SHARE a GPU are time-sliced process by process: the per-rank auxiliary stream of the shadow-ray overlap then only adds queue switches
+        # (measured: PRB 636 -> 271 Mpaths/s with two ranks on one GPU; on a GPU of its own a rank gains 3-6 %, profiles/r03_ab_shadow_overlap.txt)
+        os.environ.setdefault("HAR_OVERLAP", "0")
     torch.cuda.set_device(device_index)
     backend = None
     if world > 1:
