@@ -707,7 +707,7 @@ def _grid_floor(mi, d, n):
 
 
 @pytest.mark.parametrize("which", ["slab", "slab_textured", "slab_env", "slab_twosided", "slab_crop_box", "cbox", "cbox_grid", "cbox_nocache", "slab_rough_conductor", "slab_rough_plastic",
-                                   "floor_roughconductor", "floor_roughconductor_beckmann", "floor_roughplastic", "floor_plastic", "both_roughconductor", "cbox_rough"])
+                                   "floor_roughconductor", "floor_roughconductor_beckmann", "floor_roughplastic", "floor_plastic", "both_roughconductor", "floor_roughconductor_aniso", "cbox_rough"])
 def test_prb_vertex_position_gradients(mi, O, which):
     """har_integrator_set_grad_positions: the wavefront adjoint (k_shade<ADJOINT, SHAPE> geometry records, visibility from k_resolve,
     k_shape_adjoint with the next bounce's detached interaction) vs the oracle's dual-number restatement, vertex by vertex; the colour

@@ -49,6 +49,8 @@ ROUGH_BSDFS = {
     "roughconductor_beckmann": {"type": "roughconductor", "distribution": "beckmann", "alpha": 0.3, "eta": [0.2, 0.92, 1.1], "k": [3.9, 2.45, 2.14]},
     "roughplastic": {"type": "roughplastic", "alpha": 0.3, "diffuse_reflectance": {"type": "rgb", "value": [0.4, 0.6, 0.8]}},
     "plastic": {"type": "plastic", "diffuse_reflectance": {"type": "rgb", "value": [0.5, 0.6, 0.4]}},
+    # anisotropic: the BSDF sees the tangent frame, which follows the moving normal through coordinate_system() (no packed tangents)
+    "roughconductor_aniso": {"type": "roughconductor", "distribution": "ggx", "alpha_u": 0.15, "alpha_v": 0.45, "eta": [0.2, 0.92, 1.1], "k": [3.9, 2.45, 2.14]},
 }
 
 
@@ -91,7 +93,7 @@ def directional_fd(osc, sensor, mesh, base, direction, weights, eps, **kw):
     return (sums[0] - sums[1]) / (2 * eps)
 
 
-@pytest.mark.parametrize("variant", ["plain", "textured", "env", "rough_ceiling", "rough_floor_conductor", "rough_floor_plastic", "rough_both", "beckmann_floor"])
+@pytest.mark.parametrize("variant", ["plain", "textured", "env", "rough_ceiling", "rough_floor_conductor", "rough_floor_plastic", "rough_both", "beckmann_floor", "aniso_floor"])
 def test_oracle_shape_gradient_vs_finite_differences(mi, O, variant):
     """d/d(theta) sum(w * image) for rigid and non-rigid motions of the floor and of the ceiling.  The two sides are different estimators
     of the same derivative (PRB differentiates with the sampled directions held fixed in world space, a same-seed finite difference
@@ -99,7 +101,7 @@ def test_oracle_shape_gradient_vs_finite_differences(mi, O, variant):
     from tests.test_cpu_host import oracle_scene_from
     res = 12
     rough = {"rough_ceiling": ("roughconductor", "ceiling"), "rough_floor_conductor": ("roughconductor", "floor"), "rough_floor_plastic": ("roughplastic", "floor"),
-             "rough_both": ("roughconductor", "both"), "beckmann_floor": ("roughconductor_beckmann", "floor")}
+             "rough_both": ("roughconductor", "both"), "beckmann_floor": ("roughconductor_beckmann", "floor"), "aniso_floor": ("roughconductor_aniso", "floor")}
     # (`plastic` is left out on purpose: its delta lobe is sampled by reflection, and the detached estimator with the solid-angle-to-area Jacobian is not a
     # derivative for such a vertex -- in the reference either; the product is compared with the oracle on it below, not with finite differences)
     scene = mi.load_dict(rough_slab_scene(mi, res, *rough[variant]) if variant in rough else slab_scene(mi, res, textured=variant == "textured", env=variant == "env"))
@@ -162,7 +164,7 @@ def product_host_gradients(O, L, scene, sensor, grad_in, meshes, seed, spp, max_
 
 @pytest.mark.parametrize("which", ["slab", "slab_textured", "slab_env", "slab_twosided", "cbox", "slab_rough_conductor", "slab_rough_plastic",
                                    "floor_roughconductor", "floor_roughconductor_beckmann", "floor_roughplastic", "floor_plastic", "both_roughconductor", "both_roughplastic",
-                                   "cbox_rough"])
+                                   "floor_roughconductor_aniso", "cbox_rough"])
 def test_product_host_adjoint_matches_oracle(mi, O, which):
     """har_shape_grad.h (hand-derived reverse mode, fp32) against the oracle's dual numbers (fp64), vertex by vertex, same seed"""
     from tests.test_cpu_host import oracle_scene_from
