@@ -763,13 +763,18 @@ static V3 path_sample(const Scene &sc, Pcg32 &rng, Ray ray, uint32_t max_depth, 
 
 /* slots 0..11: the CURRENT vertex (9 vertex coordinates of a top-level triangle, or the 12 entries of an instance's to_world);
  * slots 12..23: the same for the PREVIOUS vertex, whose motion the attached si.wi follows (prb.py:128-140) */
-constexpr int kShapeSlots = 24;
+constexpr int kShapeSlots = 33;
 constexpr int kPrevSlot = 12;
+/* slots 24..32: the three VERTEX NORMALS of the current triangle on a mesh with vertex normals.  The reference regenerates them from the positions whenever
+ * the positions are written (mesh.cpp:876-878 -> pack(regenerate_normals) -> compute_normals, :1216-1267), so they are differentiable functions of the whole
+ * one-ring; the oracle takes the derivative in two stages like reverse mode would: per path vertex w.r.t. the three normals (accumulated per mesh vertex),
+ * then once per face through compute_normals (normals_backward below). */
+constexpr int kNormalSlot = 24;
 typedef Dual<kShapeSlots> Dn;
 typedef Dual3<kShapeSlots> Dn3;
 static inline Dn3 dn3(V3 v) { return Dn3((double) v.x, (double) v.y, (double) v.z); }
 
-struct AttachedSI { Dn3 p, n, sn; Dn uv[2]; bool diff = false; uint32_t mesh = 0, vid[3] = { 0, 0, 0 }; uint32_t inst = 0xffffffffu; /* != none: the slots are to_world[0..11] of this instance */ };
+struct AttachedSI { Dn3 p, n, sn; Dn uv[2]; bool diff = false, smooth = false; uint32_t mesh = 0, vid[3] = { 0, 0, 0 }; uint32_t inst = 0xffffffffu; /* != none: the slots are to_world[0..11] of this instance */ };
 
 /* Mesh::compute_surface_interaction with AD-attached vertex positions (src/render/mesh.cpp:2286-2323) and
  * SurfaceInteraction::attach_motion without FollowShape (include/mitsuba/render/interaction.h:525-545): the point stays on the
@@ -823,6 +828,17 @@ static AttachedSI attach_si(const Scene &sc, const Ray &ray, const PI &pi, const
     Dn b1d = replace_grad(b1, Dn(b1) + (a22 * r1 - a12 * r2) * inv_det);
     Dn b2d = replace_grad(b2, Dn(b2) + (a11 * r2 - a12 * r1) * inv_det);
     a.sn = a.n;                                                   // meshes without vertex normals: sh_frame.n = n (mesh.cpp:2367-2369)
+    if (m.flags & 1u) {
+        /* mesh.cpp:2346-2356: n = normalize(n0 + (n1 - n0) b1 + (n2 - n0) b2) with the attached barycentrics and the attached (regenerated) vertex normals */
+        Dn3 N[3];
+        for (int k = 0; k < 3; ++k) {
+            const float *r = &m.V[8 * (size_t) f[k]];
+            N[k] = Dn3(Dn::param(r[3], kNormalSlot + 3 * k), Dn::param(r[4], kNormalSlot + 3 * k + 1), Dn::param(r[5], kNormalSlot + 3 * k + 2));
+        }
+        Dn3 nn = N[0] + (N[1] - N[0]) * b1d + (N[2] - N[0]) * b2d;
+        a.sn = replace_grad3(si.sn.x, si.sn.y, si.sn.z, dnormalize(nn));
+        a.smooth = true;
+    }
     if (m.flags & 2u) {
         const float *r0 = &m.V[8 * (size_t) f[0]], *r1v = &m.V[8 * (size_t) f[1]], *r2v = &m.V[8 * (size_t) f[2]];
         double u0 = r0[6], v0 = r0[7], du0 = r1v[6] - u0, dv0 = r1v[7] - v0, du1 = r2v[6] - u0, dv1 = r2v[7] - v0;
@@ -948,12 +964,94 @@ static void bsdf_dir_grad_fd(const BsdfRecord &b, V3 slot0, V3 slot1, V3 wi, V3 
     }
 }
 
-struct ShapeSink { double *const *pos; const uint8_t *mask; double *inst = nullptr; const uint8_t *inst_mask = nullptr; /* 12 per instance: d / d to_world (column-major 3x4) */ };
+struct ShapeSink { double *const *pos; const uint8_t *mask; double *inst = nullptr; const uint8_t *inst_mask = nullptr; /* 12 per instance: d / d to_world (column-major 3x4) */
+                   double *const *nrm = nullptr; /* per mesh with vertex normals: d / d (vertex normal), 3 per vertex (first stage of the two-stage derivative) */ };
 static inline void shape_scatter(const ShapeSink &sk, const AttachedSI &a, int slot, const double g[kShapeSlots]) {
     if (!a.diff) return;
     if (a.inst != 0xffffffffu) { for (int k = 0; k < 12; ++k) sk.inst[12 * (size_t) a.inst + k] += g[slot + k]; return; }
     double *dst = sk.pos[a.mesh];
     for (int k = 0; k < 3; ++k) for (int c = 0; c < 3; ++c) dst[3 * (size_t) a.vid[k] + c] += g[slot + 3 * k + c];
+    if (slot == 0 && a.smooth && sk.nrm && sk.nrm[a.mesh]) {
+        double *dn = sk.nrm[a.mesh];
+        for (int k = 0; k < 3; ++k) for (int c = 0; c < 3; ++c) dn[3 * (size_t) a.vid[k] + c] += g[kNormalSlot + 3 * k + c];
+    }
+}
+
+/* Mesh::compute_normals (src/render/mesh.cpp:1216-1267): angle-weighted vertex normals (Thuermer & Wuethrich 1998), written over a scalar type so that the
+ * same text regenerates the normals (T = double values) and differentiates one face's contributions (T = Dual<9>: the nine coordinates of the face).
+ * corner[k] = unit face normal x interior angle at corner k; returns false for a face without area. */
+template <typename T> struct T3 { T x, y, z; };
+template <typename T> static inline T tsqrt(const T &a);
+template <> inline double tsqrt<double>(const double &a) { return std::sqrt(a); }
+template <> inline Dual<9> tsqrt<Dual<9>>(const Dual<9> &a) { return dsqrt(a); }
+static inline double tasin(double x) { return std::asin(x); }
+static inline Dual<9> tasin(const Dual<9> &x) { Dual<9> r; r.v = std::asin(x.v); const double k = 1.0 / std::sqrt(1.0 - x.v * x.v); for (int i = 0; i < 9; ++i) r.d[i] = x.d[i] * k; return r; }
+static inline double tval(double x) { return x; }
+static inline double tval(const Dual<9> &x) { return x.v; }
+template <typename T> static bool face_corner_normals(const T P[3][3], T3<T> corner[3]) {
+    auto sub = [](const T a[3], const T b[3], T o[3]) { for (int c = 0; c < 3; ++c) o[c] = a[c] - b[c]; };
+    auto dot = [](const T a[3], const T b[3]) { return a[0] * b[0] + a[1] * b[1] + a[2] * b[2]; };
+    T e1[3], e2[3]; sub(P[1], P[0], e1); sub(P[2], P[0], e2);
+    T n[3] = { e1[1] * e2[2] - e1[2] * e2[1], e1[2] * e2[0] - e1[0] * e2[2], e1[0] * e2[1] - e1[1] * e2[0] };
+    T l2 = dot(n, n);
+    if (!(tval(l2) > 0.0)) return false;
+    T il = T(1.0) / tsqrt(l2);
+    for (int c = 0; c < 3; ++c) n[c] = n[c] * il;
+    for (int k = 0; k < 3; ++k) {
+        T u[3], v[3]; sub(P[(k + 1) % 3], P[k], u); sub(P[(k + 2) % 3], P[k], v);
+        T iu = T(1.0) / tsqrt(dot(u, u)), iv = T(1.0) / tsqrt(dot(v, v));
+        for (int c = 0; c < 3; ++c) { u[c] = u[c] * iu; v[c] = v[c] * iv; }
+        /* dr::unit_angle: 2 asin(|v - u| / 2), or pi - 2 asin(|v + u| / 2) for an obtuse angle */
+        T d = dot(u, v); const bool acute = tval(d) >= 0.0;
+        T w[3]; for (int c = 0; c < 3; ++c) w[c] = acute ? v[c] - u[c] : v[c] + u[c];
+        T t = tasin(tsqrt(dot(w, w)) * T(0.5)) * T(2.0);
+        T angle = acute ? t : T(M_PI) - t;
+        corner[k].x = n[0] * angle; corner[k].y = n[1] * angle; corner[k].z = n[2] * angle;
+    }
+    return true;
+}
+/* accumulated (un-normalised) vertex normals in double */
+static void mesh_normal_sums(const Mesh &m, std::vector<double> &acc) {
+    acc.assign(3 * (size_t) m.nv, 0.0);
+    for (uint32_t f = 0; f < m.nf; ++f) {
+        const uint32_t *fi = &m.F[4 * (size_t) f];
+        double P[3][3]; for (int k = 0; k < 3; ++k) for (int c = 0; c < 3; ++c) P[k][c] = m.V[8 * (size_t) fi[k] + c];
+        T3<double> cn[3];
+        if (!face_corner_normals<double>(P, cn)) continue;
+        for (int k = 0; k < 3; ++k) { acc[3 * (size_t) fi[k]] += cn[k].x; acc[3 * (size_t) fi[k] + 1] += cn[k].y; acc[3 * (size_t) fi[k] + 2] += cn[k].z; }
+    }
+}
+/* regenerate the vertex normals of a mesh from its positions (what Mesh::parameters_changed does when the positions are written, mesh.cpp:876-878) */
+static void mesh_regenerate_normals(Mesh &m) {
+    std::vector<double> acc; mesh_normal_sums(m, acc);
+    for (uint32_t v = 0; v < m.nv; ++v) {
+        const double *a = &acc[3 * (size_t) v]; const double l2 = a[0] * a[0] + a[1] * a[1] + a[2] * a[2];
+        float *o = &m.V[8 * (size_t) v + 3];
+        if (l2 > 0.0) { const double il = 1.0 / std::sqrt(l2); o[0] = (float) (a[0] * il); o[1] = (float) (a[1] * il); o[2] = (float) (a[2] * il); }
+        else { o[0] = 1.f; o[1] = 0.f; o[2] = 0.f; }
+    }
+}
+/* second stage: nbar[v] = d objective / d (unit vertex normal v)  ->  gpos += d objective / d positions, through normalize(sum over the vertex's corners) */
+static void normals_backward(const Mesh &m, const double *nbar, double *gpos) {
+    std::vector<double> acc; mesh_normal_sums(m, acc);
+    std::vector<double> abar(3 * (size_t) m.nv, 0.0);           /* adjoint of the accumulated sums: (nbar - n <n, nbar>) / |acc| */
+    for (uint32_t v = 0; v < m.nv; ++v) {
+        const double *a = &acc[3 * (size_t) v]; const double l2 = a[0] * a[0] + a[1] * a[1] + a[2] * a[2];
+        if (!(l2 > 0.0)) continue;
+        const double il = 1.0 / std::sqrt(l2), n[3] = { a[0] * il, a[1] * il, a[2] * il }, *b = &nbar[3 * (size_t) v];
+        const double nb = n[0] * b[0] + n[1] * b[1] + n[2] * b[2];
+        for (int c = 0; c < 3; ++c) abar[3 * (size_t) v + c] = (b[c] - n[c] * nb) * il;
+    }
+    for (uint32_t f = 0; f < m.nf; ++f) {
+        const uint32_t *fi = &m.F[4 * (size_t) f];
+        Dual<9> P[3][3]; for (int k = 0; k < 3; ++k) for (int c = 0; c < 3; ++c) P[k][c] = Dual<9>::param(m.V[8 * (size_t) fi[k] + c], 3 * k + c);
+        T3<Dual<9>> cn[3];
+        if (!face_corner_normals<Dual<9>>(P, cn)) continue;
+        for (int k = 0; k < 3; ++k) {
+            const double *ab = &abar[3 * (size_t) fi[k]];
+            for (int s = 0; s < 9; ++s) gpos[3 * (size_t) fi[s / 3] + s % 3] += ab[0] * cn[k].x.d[s] + ab[1] * cn[k].y.d[s] + ab[2] * cn[k].z.d[s];
+        }
+    }
 }
 
 struct GradSink { float *refl; float *const *tex; float *emit; /* 3 per emitter (radiance of `area` / `constant`), may be null */
@@ -1691,7 +1789,7 @@ static int prb_backward_impl(void *scene, const OrcSensor *sp, const float *grad
     if (pos_mask) {           /* flat-shaded top-level meshes */
         for (size_t m = 0; m < sc.meshes.size(); ++m) {
             if (!pos_mask[m]) continue;
-            if ((sc.meshes[m].flags & 1u) || m >= sc.top_count) return -3;
+            if (m >= sc.top_count) return -3;
         }
     }
     uint64_t total = sample_grid_pixels(s) * spp;
@@ -1713,7 +1811,7 @@ static int prb_backward_impl(void *scene, const OrcSensor *sp, const float *grad
     size_t nb = sc.bsdfs.size();
     std::vector<std::vector<float>> g_refl(threads), g_emit(threads), g_extra(threads);
     std::vector<std::vector<std::vector<float>>> g_tex(threads);
-    std::vector<std::vector<std::vector<double>>> g_pos(threads);
+    std::vector<std::vector<std::vector<double>>> g_pos(threads), g_nrm(threads);
     std::vector<std::vector<double>> g_inst(threads);
     std::vector<OrcStats> sts(threads, OrcStats{});
     uint32_t md = (uint32_t) max_depth, rd = (uint32_t) rr_depth;
@@ -1727,10 +1825,14 @@ static int prb_backward_impl(void *scene, const OrcSensor *sp, const float *grad
         for (size_t k = 0; k < sc.textures.size(); ++k) tp[k] = g_tex[t][k].data();
         GradSink sink{ g_refl[t].data(), tp.data(), grad_emitters ? g_emit[t].data() : nullptr };
         sink.extra = grad_bsdf_params ? g_extra[t].data() : nullptr;
-        std::vector<double *> pp(sc.meshes.size() + 1, nullptr); ShapeSink shape{ pp.data(), pos_mask };
+        std::vector<double *> pp(sc.meshes.size() + 1, nullptr), pn(sc.meshes.size() + 1, nullptr); ShapeSink shape{ pp.data(), pos_mask };
         if (pos_mask) {
-            if (g_pos[t].empty()) { g_pos[t].resize(sc.meshes.size()); for (size_t m = 0; m < sc.meshes.size(); ++m) if (pos_mask[m]) g_pos[t][m].assign(3 * (size_t) sc.meshes[m].nv, 0.0); }
-            for (size_t m = 0; m < sc.meshes.size(); ++m) pp[m] = pos_mask[m] ? g_pos[t][m].data() : nullptr;
+            if (g_pos[t].empty()) {
+                g_pos[t].resize(sc.meshes.size()); g_nrm[t].resize(sc.meshes.size());
+                for (size_t m = 0; m < sc.meshes.size(); ++m) if (pos_mask[m]) { g_pos[t][m].assign(3 * (size_t) sc.meshes[m].nv, 0.0); if (sc.meshes[m].flags & 1u) g_nrm[t][m].assign(3 * (size_t) sc.meshes[m].nv, 0.0); }
+            }
+            for (size_t m = 0; m < sc.meshes.size(); ++m) { pp[m] = pos_mask[m] ? g_pos[t][m].data() : nullptr; pn[m] = (pos_mask[m] && !g_nrm[t][m].empty()) ? g_nrm[t][m].data() : nullptr; }
+            shape.nrm = pn.data();
             sink.shape = &shape;
         }
         if (inst_mask) {
@@ -1782,6 +1884,13 @@ static int prb_backward_impl(void *scene, const OrcSensor *sp, const float *grad
         if (pos_mask && !g_pos[t].empty())
             for (size_t m = 0; m < sc.meshes.size(); ++m) if (pos_mask[m] && grad_positions[m]) for (size_t i = 0; i < g_pos[t][m].size(); ++i) grad_positions[m][i] += g_pos[t][m][i];
     }
+    if (pos_mask)           /* second stage of the vertex-normal derivative: the summed normal adjoints through compute_normals, once per face */
+        for (size_t m = 0; m < sc.meshes.size(); ++m) {
+            if (!pos_mask[m] || !grad_positions[m] || !(sc.meshes[m].flags & 1u)) continue;
+            std::vector<double> nbar(3 * (size_t) sc.meshes[m].nv, 0.0);
+            for (int t = 0; t < threads; ++t) if (!g_nrm[t].empty() && !g_nrm[t][m].empty()) for (size_t i = 0; i < nbar.size(); ++i) nbar[i] += g_nrm[t][m][i];
+            normals_backward(sc.meshes[m], nbar.data(), grad_positions[m]);
+        }
     merge_stats(stats, sts);
     return 0;
 }
@@ -1852,6 +1961,7 @@ void orc_scene_set_vertex_positions(void *scene, uint32_t mesh, const float *pos
     if (mesh >= sc.top_count) return;
     Mesh &m = sc.meshes[mesh];
     for (uint32_t i = 0; i < m.nv; ++i) for (int c = 0; c < 3; ++c) m.V[8 * (size_t) i + c] = positions[3 * (size_t) i + c];
+    if (m.flags & 1u) mesh_regenerate_normals(m);             /* mesh.cpp:876-878: writing the positions regenerates the vertex normals */
     build_tri_bvh(sc.top, sc.meshes, 0, sc.top_count);
     scene_update_bounds(sc);
 }

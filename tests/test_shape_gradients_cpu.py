@@ -66,6 +66,31 @@ def rough_slab_scene(mi, res=24, model="roughconductor", where="ceiling"):
     return d
 
 
+def smooth_slab_scene(mi, res=24, n=13, model=None):
+    """the slab scene with a SMOOTH-SHADED floor: one grid over the whole floor (cells concentrated in the middle) with a gentle bump field and VERTEX NORMALS,
+    which the reference regenerates from the positions whenever those are written (mesh.cpp:876-878, compute_normals :1216-1267) -- the shading normal of a hit
+    then depends on the whole one-ring of its triangle.  The bumps are shallow (slope < 0.15): no self-shadowing, no silhouette inside the view"""
+    d = slab_scene(mi, res)
+    S = 40.0
+    t = np.linspace(-1.0, 1.0, n)
+    ax = S * np.sign(t) * np.abs(t) ** 3
+    X, Z = np.meshgrid(ax, ax, indexing="xy")
+    Y = 0.08 * np.exp(-(X ** 2 + Z ** 2) / 4.0) * np.cos(1.5 * X) * np.cos(1.5 * Z)
+    P = np.stack([X, Y, Z], -1).reshape(-1, 3).astype(np.float32)
+    F = []
+    for j in range(n - 1):
+        for i in range(n - 1):
+            a = j * n + i
+            F += [[a, a + n + 1, a + 1], [a, a + n, a + n + 1]]          # normal +y
+    uv = np.stack([(X / S + 1) * 4, (Z / S + 1) * 4], -1).reshape(-1, 2).astype(np.float32)
+    mesh = mi.load_dict({"type": "mesh", "positions": P, "faces": np.asarray(F, np.uint32), "normals": np.tile([0, 1, 0], (n * n, 1)).astype(np.float32), "texcoords": uv})
+    mesh.recompute_vertex_normals()
+    d["floor"] = {"type": "mesh", "positions": P, "faces": np.asarray(F, np.uint32), "normals": mesh.V[:, 3:6].copy(), "texcoords": uv, "bsdf": d["floor"]["bsdf"]}
+    if model:
+        d["floor"]["bsdf"] = dict(ROUGH_BSDFS[model])
+    return d
+
+
 def twosided_slab_scene(mi, res=16):
     """the slab scene with `twosided` diffuse BSDFs and a free-floating sheet whose geometric normal points away from the camera and the light:
     the camera and the emitter samples meet its BACK side (TwoSidedBRDF mirrors wo, twosided.cpp:124-127)"""
@@ -126,6 +151,34 @@ def test_oracle_shape_gradient_vs_finite_differences(mi, O, variant):
                 assert abs(ad) < 0.02 * lift + 1e-6, (name, label, ad)
                 continue
             assert abs(fd - ad) <= 0.03 * abs(fd) + 0.005 * lift, (variant, name, label, fd, ad)
+
+
+@pytest.mark.parametrize("variant", ["diffuse", "roughplastic"])
+def test_oracle_smooth_mesh_gradient_vs_finite_differences(mi, O, variant):
+    """vertex normals regenerated from the positions (mesh.cpp:876-878): the oracle's two-stage derivative (per path vertex w.r.t. the three vertex normals, then once per
+    face through compute_normals) against same-seed finite differences of renders whose normals are regenerated after every move -- rigid lift, tilt, and a smooth
+    NON-RIGID bump that changes the normals of the lit region"""
+    from tests.test_cpu_host import oracle_scene_from
+    res = 12
+    scene = mi.load_dict(smooth_slab_scene(mi, res, model=None if variant == "diffuse" else variant))
+    osc, sensor = oracle_scene_from(O, scene)
+    m = mesh_index(scene, "floor")
+    assert scene.meshes[m]["flags"] & 1
+    base = scene.meshes[m]["V"][:, :3].astype(np.float32).copy()
+    osc.set_vertex_positions(m, base)                       # normals = compute_normals(positions), as after any position update
+    kw = dict(seed=7, spp=4096, max_depth=4)
+    w = np.random.default_rng(2).uniform(0.5, 1.5, (res, res, 3)).astype(np.float32)
+    g_pos, _, _, _ = osc.render_prb_backward_shape(sensor, w, [m], **kw)
+    r2 = base[:, 0] ** 2 + base[:, 2] ** 2
+    motions = {"lift": (np.tile([0, 1, 0], (len(base), 1)), 2e-3),
+               "tilt": (np.stack([np.zeros(len(base)), np.clip(base[:, 0], -3, 3) / 3.0, np.zeros(len(base))], -1), 5e-3),
+               "bump": (np.stack([np.zeros(len(base)), np.exp(-r2 / 2.0), np.zeros(len(base))], -1), 5e-3),
+               "dent": (np.stack([np.zeros(len(base)), np.exp(-((base[:, 0] - 0.8) ** 2 + (base[:, 2] + 0.5) ** 2) / 0.8), np.zeros(len(base))], -1), 5e-3)}
+    lift = abs(float((g_pos[m] * motions["lift"][0]).sum()))
+    for label, (direction, eps) in motions.items():
+        fd = directional_fd(osc, sensor, m, base, direction.astype(np.float32), w, eps, **kw)
+        ad = float((g_pos[m] * direction).sum())
+        assert abs(fd - ad) <= 0.03 * abs(fd) + 0.005 * lift, (variant, label, fd, ad)
 
 
 def cbox_mesh_scene(mi, res=20):
