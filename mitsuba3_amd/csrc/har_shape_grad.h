@@ -35,7 +35,8 @@ struct ShapeVertex {
     Vec3 d_in;                      /* direction of the (detached) ray the vertex lies on */
     bool has_uv; float duv0[2], duv1[2];   /* texcoord differences (P1 - P0, P2 - P0) of the triangle; without texcoords uv = (b1, b2) */
     float uv_bar[2];                /* adjoint of the texture coordinates */
-    Vec3 p_bar, n_bar;              /* adjoints of the attached point and of the attached (unit) normal */
+    float b_bar[2];                 /* direct adjoint of the attached barycentrics (b1, b2): interpolated vertex normals */
+    Vec3 p_bar, n_bar;              /* adjoints of the attached point and of the attached (unit) GEOMETRIC normal */
 };
 
 /* adjoint of the point p a direction block starts from: w = normalize(y - p) carries the adjoint `w_bar` (from wo = to_local(w)) and
@@ -72,6 +73,7 @@ HAR_HD void shape_vertex_adjoint(const ShapeVertex &v, Vec3 g[3]) {
     float b1_bar, b2_bar;
     if (v.has_uv) { b1_bar = v.uv_bar[0] * v.duv0[0] + v.uv_bar[1] * v.duv0[1]; b2_bar = v.uv_bar[0] * v.duv1[0] + v.uv_bar[1] * v.duv1[1]; }
     else { b1_bar = v.uv_bar[0]; b2_bar = v.uv_bar[1]; }
+    b1_bar += v.b_bar[0]; b2_bar += v.b_bar[1];
     Vec3 patt_bar(0.f);
     if (b1_bar != 0.f || b2_bar != 0.f) {
         const float a11 = dot3(e1, e1), a12 = dot3(e1, e2), a22 = dot3(e2, e2), inv_det = rcp_(a11 * a22 - a12 * a12);
@@ -123,6 +125,9 @@ struct ShapeGrad {
     bool self_mesh, self_inst, prev_mesh, prev_inst;
     Vec3 g[3]; uint32_t vid[3]; float gM[12];
     Vec3 gp[3]; uint32_t pvid[3]; float gpM[12];
+    /* meshes with vertex normals: d objective / d (the three vertex normals of the triangle) -- the FIRST stage of the derivative through the regenerated normals
+     * (mesh.cpp:876-878, compute_normals :1216-1267); face_normals_adjoint below is the second, run once per face after all path vertices have been added up */
+    bool self_normals; Vec3 gn[3];
 };
 
 HAR_HD void shape_triangle(const DScene &S, uint32_t shape, uint32_t prim, uint32_t vid[3], const float *r[3]) {
@@ -136,7 +141,7 @@ HAR_HD void shape_triangle(const DScene &S, uint32_t shape, uint32_t prim, uint3
  * normal; next_valid = false for an escaped ray) is detached (prb.py:263-266).  Returns false when nothing contributes. */
 HAR_HD bool shape_item_adjoint(const DScene &S, const ShapeItem &it, bool self_on, bool prev_on, bool visible, Vec3 L, Vec3 dl,
                                bool has_next, bool next_valid, Vec3 next_p, Vec3 next_n, Vec3 next_d, ShapeGrad &out) {
-    out.self_mesh = out.self_inst = out.prev_mesh = out.prev_inst = false;
+    out.self_mesh = out.self_inst = out.prev_mesh = out.prev_inst = out.self_normals = false;
     const bool depth0 = it.prev_shape == HAR_SHAPE_NONE;
     prev_on = prev_on && !depth0;
     if (!self_on && !prev_on) return false;
@@ -198,8 +203,20 @@ HAR_HD bool shape_item_adjoint(const DScene &S, const ShapeItem &it, bool self_o
         v.b1 = it.b1; v.b2 = it.b2; v.d_in = it.d_in;
         v.has_uv = (M.flags & 2u) != 0u;
         if (v.has_uv) { v.duv0[0] = r[1][6] - r[0][6]; v.duv0[1] = r[1][7] - r[0][7]; v.duv1[0] = r[2][6] - r[0][6]; v.duv1[1] = r[2][7] - r[0][7]; }
-        v.uv_bar[0] = uv_bar[0]; v.uv_bar[1] = uv_bar[1];
-        v.p_bar = p_bar; v.n_bar = n_bar + coordinate_system_adjoint(si.sn, s_bar, t_bar);
+        v.uv_bar[0] = uv_bar[0]; v.uv_bar[1] = uv_bar[1]; v.b_bar[0] = 0.f; v.b_bar[1] = 0.f;
+        const Vec3 sn_bar = n_bar + coordinate_system_adjoint(si.sn, s_bar, t_bar);          /* adjoint of the (unit) SHADING normal */
+        v.p_bar = p_bar; v.n_bar = sn_bar;
+        if (M.flags & 1u) {
+            /* mesh.cpp:2346-2356: sn = normalize(m), m = n0 + (n1 - n0) b1 + (n2 - n0) b2 over the attached barycentrics and the attached (regenerated) vertex
+             * normals; the geometric normal no longer reaches any term */
+            const Vec3 n0(r[0][3], r[0][4], r[0][5]), n1(r[1][3], r[1][4], r[1][5]), n2(r[2][3], r[2][4], r[2][5]);
+            const Vec3 m = fma3(n1 - n0, it.b1, fma3(n2 - n0, it.b2, n0));
+            const Vec3 m_bar = (sn_bar - si.sn * dot3(si.sn, sn_bar)) * rcp_(norm3(m));
+            out.gn[0] = m_bar * (1.f - it.b1 - it.b2); out.gn[1] = m_bar * it.b1; out.gn[2] = m_bar * it.b2;
+            out.self_normals = true;
+            v.b_bar[0] = dot3(m_bar, n1 - n0); v.b_bar[1] = dot3(m_bar, n2 - n0);
+            v.n_bar = Vec3(0.f);
+        }
         out.g[0] = out.g[1] = out.g[2] = Vec3(0.f);
         shape_vertex_adjoint(v, out.g);
         out.self_mesh = true; some = true;
@@ -227,6 +244,54 @@ HAR_HD bool shape_item_adjoint(const DScene &S, const ShapeItem &it, bool self_o
         some = true;
     }
     return some;
+}
+
+/* dr::unit_angle(u, v) of two unit vectors: 2 asin(|v - u| / 2), or pi - 2 asin(|v + u| / 2) for an obtuse angle (restated from its published definition) */
+HAR_HD float unit_angle3(Vec3 u, Vec3 v) {
+    const bool acute = dot3(u, v) >= 0.f;
+    const float t = 2.f * asinf(.5f * norm3(acute ? v - u : v + u));
+    return acute ? t : HAR_PI - t;
+}
+/* Second stage of the vertex-normal derivative, one FACE: Mesh::compute_normals (mesh.cpp:1216-1267) adds  c_k = n_face * angle_k  to the sum of the face's k-th
+ * vertex; given the adjoints a_bar[k] of those three sums this adds d objective / d P_j to g[j].  (n_face = N / |N|, N = (P1 - P0) x (P2 - P0);
+ * angle_k = unit_angle(normalize(P_{k+1} - P_k), normalize(P_{k+2} - P_k)).)  Faces without area contribute nothing, as in the forward pass. */
+HAR_HD void face_normals_adjoint(const Vec3 P[3], const Vec3 a_bar[3], Vec3 g[3]) {
+    const Vec3 e1 = P[1] - P[0], e2 = P[2] - P[0], N = cross3(e1, e2);
+    const float l2 = dot3(N, N);
+    if (!(l2 > 0.f)) return;
+    const float len = sqrtf(l2);
+    const Vec3 n = N * rcp_(len);
+    Vec3 n_bar(0.f);
+    for (int k = 0; k < 3; ++k) {
+        const int k1 = (k + 1) % 3, k2 = (k + 2) % 3;
+        const Vec3 a = P[k1] - P[k], b = P[k2] - P[k];
+        const float la = norm3(a), lb = norm3(b);
+        const Vec3 u = a * rcp_(la), v = b * rcp_(lb);
+        const bool acute = dot3(u, v) >= 0.f;
+        const Vec3 w = acute ? v - u : v + u;
+        const float r = norm3(w), s = .5f * r, t = 2.f * asinf(s), angle = acute ? t : HAR_PI - t;
+        n_bar = n_bar + a_bar[k] * angle;
+        const float angle_bar = dot3(n, a_bar[k]);
+        if (!(r > 0.f)) continue;
+        /* angle = +-2 asin(r / 2) (+ pi): d angle / d r = +-1 / sqrt(1 - r^2 / 4) */
+        const float r_bar = (acute ? angle_bar : -angle_bar) * rsqrt_(fmaxf(1.f - s * s, 1e-12f));
+        const Vec3 w_bar = w * (r_bar / r);
+        const Vec3 v_bar = w_bar, u_bar = acute ? -w_bar : w_bar;
+        const Vec3 ab = (u_bar - u * dot3(u, u_bar)) * rcp_(la), bb = (v_bar - v * dot3(v, v_bar)) * rcp_(lb);
+        g[k1] = g[k1] + ab; g[k2] = g[k2] + bb; g[k] = g[k] - (ab + bb);
+    }
+    const Vec3 N_bar = (n_bar - n * dot3(n, n_bar)) * rcp_(len);
+    const Vec3 e1_bar = cross3(e2, N_bar), e2_bar = cross3(N_bar, e1);
+    g[1] = g[1] + e1_bar; g[2] = g[2] + e2_bar; g[0] = g[0] - (e1_bar + e2_bar);
+}
+/* the three corner contributions c_k of a face (forward pass of the above; false for a face without area) */
+HAR_HD bool face_corner_normals(const Vec3 P[3], Vec3 c[3]) {
+    const Vec3 N = cross3(P[1] - P[0], P[2] - P[0]);
+    const float l2 = dot3(N, N);
+    if (!(l2 > 0.f)) return false;
+    const Vec3 n = N * rsqrt_(l2);
+    for (int k = 0; k < 3; ++k) c[k] = n * unit_angle3(normalize3(P[(k + 1) % 3] - P[k]), normalize3(P[(k + 2) % 3] - P[k]));
+    return true;
 }
 
 } // namespace har

@@ -194,6 +194,9 @@ static int backward_shape_impl(void *h, const HarSensor *sensor, const float *ad
     uint32_t log_spp = 0xffffffffu; for (uint32_t k = 0; k < 32; ++k) if ((1u << k) == spp) log_spp = k;
     ShadeParams P{ seed, (uint32_t) max_depth, (uint32_t) rr_depth };
     int status = 0;
+    /* meshes with vertex normals: first-stage adjoints of the vertex normals (3 per vertex), pushed through compute_normals after the lane loop */
+    std::vector<std::vector<double>> nbar(H->hs.meshes.size());
+    if (grad) for (size_t m = 0; m < H->hs.top_mesh_count; ++m) if (grad[m] && (H->hs.meshes[m].flags & 1u)) nbar[m].assign(3 * (size_t) H->hs.meshes[m].vertex_count, 0.0);
     for (uint64_t lane = 0; lane < total; ++lane) {
         LaneSample ls; const PathState st0 = raygen_lane(C, seed, spp, log_spp, (uint32_t) lane, ls);
         Footprint F; film_footprint(C, ls, F);
@@ -241,6 +244,7 @@ static int backward_shape_impl(void *h, const HarSensor *sensor, const float *ad
                 ShapeGrad G;
                 if (shape_item_adjoint(S, it, self_on, prev_on, visible, L, dl, R.alive, next_valid, np, nn, R.next.d, G)) {
                     if (G.self_mesh) { double *dst = grad[hit.shape]; for (int k = 0; k < 3; ++k) { dst[3 * (size_t) G.vid[k]] += G.g[k].x; dst[3 * (size_t) G.vid[k] + 1] += G.g[k].y; dst[3 * (size_t) G.vid[k] + 2] += G.g[k].z; } }
+                    if (G.self_normals && !nbar[hit.shape].empty()) { double *dst = nbar[hit.shape].data(); for (int k = 0; k < 3; ++k) { dst[3 * (size_t) G.vid[k]] += G.gn[k].x; dst[3 * (size_t) G.vid[k] + 1] += G.gn[k].y; dst[3 * (size_t) G.vid[k] + 2] += G.gn[k].z; } }
                     if (G.self_inst) for (int k = 0; k < 12; ++k) inst_grad[12 * (size_t) hit.inst + k] += G.gM[k];
                     if (G.prev_mesh) { double *dst = grad[prev.shape]; for (int k = 0; k < 3; ++k) { dst[3 * (size_t) G.pvid[k]] += G.gp[k].x; dst[3 * (size_t) G.pvid[k] + 1] += G.gp[k].y; dst[3 * (size_t) G.pvid[k] + 2] += G.gp[k].z; } }
                     if (G.prev_inst) for (int k = 0; k < 12; ++k) inst_grad[12 * (size_t) prev.inst + k] += G.gpM[k];
@@ -248,6 +252,30 @@ static int backward_shape_impl(void *h, const HarSensor *sensor, const float *ad
             }
             if (hit.t != HAR_INF) { prev = hit; prev_d = st.d; }
             alive = R.alive; st = R.next; hit = next;
+        }
+    }
+    /* second stage (k_normals_sums + k_normals_adjoint on the device): n_v = normalize(sum of the corner contributions), face by face */
+    for (size_t m = 0; m < nbar.size(); ++m) {
+        if (nbar[m].empty()) continue;
+        const DMesh &M = S.meshes[m];
+        std::vector<Vec3> acc(M.vertex_count, Vec3(0.f));
+        auto tri = [&](uint32_t f, uint32_t vid[3], Vec3 Pt[3]) {
+            const uint32_t *fi = S.faces + 4 * (size_t) (M.foff + f);
+            for (int k = 0; k < 3; ++k) { vid[k] = fi[k]; const float *r = S.verts + 8 * (size_t) (M.voff + fi[k]); Pt[k] = Vec3(r[0], r[1], r[2]); }
+        };
+        for (uint32_t f = 0; f < M.face_count; ++f) { uint32_t vid[3]; Vec3 Pt[3], c[3]; tri(f, vid, Pt); if (face_corner_normals(Pt, c)) for (int k = 0; k < 3; ++k) acc[vid[k]] = acc[vid[k]] + c[k]; }
+        for (uint32_t f = 0; f < M.face_count; ++f) {
+            uint32_t vid[3]; Vec3 Pt[3], ab[3]; tri(f, vid, Pt);
+            for (int k = 0; k < 3; ++k) {
+                const Vec3 a = acc[vid[k]]; const float l2 = dot3(a, a);
+                const double *b = &nbar[m][3 * (size_t) vid[k]]; const Vec3 nb((float) b[0], (float) b[1], (float) b[2]);
+                if (!(l2 > 0.f)) { ab[k] = Vec3(0.f); continue; }
+                const float il = rsqrt_(l2); const Vec3 n = a * il;
+                ab[k] = (nb - n * dot3(n, nb)) * il;
+            }
+            Vec3 g[3] = { Vec3(0.f), Vec3(0.f), Vec3(0.f) };
+            face_normals_adjoint(Pt, ab, g);
+            for (int k = 0; k < 3; ++k) { double *dst = grad[m] + 3 * (size_t) vid[k]; dst[0] += g[k].x; dst[1] += g[k].y; dst[2] += g[k].z; }
         }
     }
     return status;

@@ -217,7 +217,7 @@ def product_host_gradients(O, L, scene, sensor, grad_in, meshes, seed, spp, max_
 
 @pytest.mark.parametrize("which", ["slab", "slab_textured", "slab_env", "slab_twosided", "cbox", "slab_rough_conductor", "slab_rough_plastic",
                                    "floor_roughconductor", "floor_roughconductor_beckmann", "floor_roughplastic", "floor_plastic", "both_roughconductor", "both_roughplastic",
-                                   "floor_roughconductor_aniso", "cbox_rough"])
+                                   "floor_roughconductor_aniso", "cbox_rough", "smooth_floor", "smooth_floor_roughplastic", "smooth_floor_roughconductor_aniso"])
 def test_product_host_adjoint_matches_oracle(mi, O, which):
     """har_shape_grad.h (hand-derived reverse mode, fp32) against the oracle's dual numbers (fp64), vertex by vertex, same seed"""
     from tests.test_cpu_host import oracle_scene_from
@@ -231,6 +231,8 @@ def test_product_host_adjoint_matches_oracle(mi, O, which):
     elif which.startswith("floor_") or which.startswith("both_"):
         where, model = which.split("_", 1)
         res = 16; scene = mi.load_dict(rough_slab_scene(mi, res, model, where)); names = ["floor", "ceiling"]
+    elif which.startswith("smooth_floor"):         # vertex normals regenerated from the positions: both stages of the derivative (har_shape_grad.h face_normals_adjoint)
+        res = 16; scene = mi.load_dict(smooth_slab_scene(mi, res, model=which[13:] or None)); names = ["floor", "ceiling"]
     elif which == "slab_twosided":
         res = 16; scene = mi.load_dict(twosided_slab_scene(mi, res)); names = ["floor", "ceiling", "sheet"]
     elif which.startswith("slab_rough"):
