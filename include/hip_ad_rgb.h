@@ -298,7 +298,8 @@ int har_integrator_set_grad_emitters(HarIntegrator integrator, float *grad_emitt
  * ad/integrators/common.py:1355-1384).  `grad_positions` = HOST array of top_mesh_count DEVICE pointers; entry m (vertex_count x 3 floats)
  * makes mesh m differentiable, NULL entries do not; har_render_backward then also accumulates into those buffers.  A NULL array switches the
  * feature off.  Like `prb` itself this has no visibility-boundary term (that is prb_reparam / the projective integrators).
- * The differentiated meshes are top-level, without vertex normals, and carry a BSDF with a non-delta lobe (diffuse, roughconductor, roughplastic, plastic; plain
+ * The differentiated meshes are top-level -- flat-shaded, or with the vertex normals a position update regenerates (Mesh::compute_normals, mesh.cpp:876-878,
+ * 1216-1267: the gradient then runs through the interpolated normal and the angle-weighted normal sums of the whole one-ring) -- and carry a BSDF with a non-delta lobe (diffuse, roughconductor, roughplastic, plastic; plain
  * or inside `twosided`) -- the attached si.wi / wo reach the BSDF value (prb.py:128-140, 276-288); the other meshes of the scene may carry any BSDF.  Fails otherwise.
  * New vertex positions are installed by creating a new scene (har_scene_create), which rebuilds the acceleration structure. */
 int har_integrator_set_grad_positions(HarIntegrator integrator, HarScene scene, float *const *grad_positions);

@@ -1356,8 +1356,9 @@ class Scene:
             lib().har_scene_destroy(self._h); self._h = None
 
     def _position_keys(self):
-        """'<shape>.vertex_positions' (flat 3 N floats as in the reference's Mesh::traverse) of the top-level meshes without vertex normals"""
-        return {m["key"] + ".vertex_positions": i for i, m in enumerate(self.meshes[:self.top_mesh_count]) if not (m["flags"] & 1) and m["V"].shape[0]}
+        """'<shape>.vertex_positions' (flat 3 N floats as in the reference's Mesh::traverse) of the top-level meshes; writing them regenerates the vertex normals of
+        a smooth-shaded mesh (mesh.cpp:876-878), see _set_vertex_positions"""
+        return {m["key"] + ".vertex_positions": i for i, m in enumerate(self.meshes[:self.top_mesh_count]) if m["V"].shape[0]}
 
     def _bsdf_has_smooth_lobe(self, index):
         """BSDFFlags::Smooth on every side: models made of delta lobes only (`dielectric`, `conductor`) cannot sit on MOVING geometry -- their eval() is zero,
@@ -1367,9 +1368,22 @@ class Scene:
         return b.kind not in delta and (b.back is None or b.back.kind not in delta)
 
     def _differentiable_position_keys(self):
-        """the subset of _position_keys() the `prb` adjoint can differentiate: flat-shaded top-level meshes whose BSDF has a non-delta lobe (any of diffuse,
-        roughconductor, roughplastic, plastic, plain or inside `twosided`); the other meshes of the scene may carry any BSDF"""
-        return {k: i for k, i in self._position_keys().items() if self._bsdf_has_smooth_lobe(self.meshes[i]["bsdf"])}
+        """the subset of _position_keys() the `prb` adjoint can differentiate with `shape_gradients=True`: top-level meshes whose BSDF has a non-delta lobe (any of
+        diffuse, roughconductor, roughplastic, plastic, plain or inside `twosided`) and, if they carry vertex normals, carry the REGENERATED ones (Mesh::compute_normals:
+        what a position update produces, mesh.cpp:876-878) -- a mesh with normals of another origin is left out here and refused when named explicitly; the other
+        meshes of the scene may carry any BSDF"""
+        out = {}
+        for k, i in self._position_keys().items():
+            m = self.meshes[i]
+            if not self._bsdf_has_smooth_lobe(m["bsdf"]):
+                continue
+            if m["flags"] & 1:
+                V = np.ascontiguousarray(m["V"]).copy(); F = np.ascontiguousarray(m["F"])
+                check(lib().har_mesh_compute_normals(V.shape[0], _fp(V), F.shape[0], _up(F)))
+                if np.abs(V[:, 3:6] - m["V"][:, 3:6]).max() > 1e-4:
+                    continue
+            out[k] = i
+        return out
 
     def _instance_keys(self):
         """'<instance>.to_world' (4 x 4, Instance::traverse, instance.cpp:79-85)"""
@@ -1390,6 +1404,12 @@ class Scene:
         """params['<shape>.vertex_positions'] = ...; params.update(): the acceleration structure is rebuilt with the next scene handle"""
         V = self.meshes[mesh]["V"]
         V[:, :3] = np.asarray(positions, np.float32).reshape(V.shape[0], 3)
+        if self.meshes[mesh]["flags"] & 1:
+            # Mesh::parameters_changed (mesh.cpp:876-878): pack(regenerate_normals = positions written and normals not) -> compute_normals (:1216-1267)
+            F = np.ascontiguousarray(self.meshes[mesh]["F"])
+            if not V.flags["C_CONTIGUOUS"]:
+                V = self.meshes[mesh]["V"] = np.ascontiguousarray(V)
+            check(lib().har_mesh_compute_normals(V.shape[0], _fp(V), F.shape[0], _up(F)))
         if self._h is not None:
             lib().har_scene_destroy(self._h); self._h = None
 

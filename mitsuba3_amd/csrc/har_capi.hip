@@ -172,6 +172,8 @@ struct HarIntegratorImpl {
     /* vertex-position gradients (har_integrator_set_grad_positions): user buffers per top-level mesh, the flat accumulation buffer + offsets */
     bool shape_on = false; std::vector<float *> pos_user; std::vector<int32_t> pos_offset; std::vector<uint32_t> pos_count;
     int32_t *d_pos_offset = nullptr; float *grad_pos = nullptr; uint32_t pos_verts = 0; ShapeArrays geo{};
+    /* differentiated meshes WITH vertex normals: adjoints of the vertex normals and scratch for the normal sums, laid out like grad_pos (har_shape_grad.h) */
+    bool pos_smooth = false; float *grad_nrm = nullptr, *nrm_acc = nullptr;
     /* instance to_world gradients (har_integrator_set_grad_instances): user buffer (DEVICE, instance_count x 12), per-instance slot table, accumulation buffer */
     float *inst_user = nullptr; uint32_t inst_count = 0; int32_t *d_inst_slot = nullptr; float *grad_inst = nullptr;
     bool material_queues = false;         /* har_integrator_set_material_queues */
@@ -248,12 +250,13 @@ int ensure_workspace(HarIntegratorImpl *I, uint32_t lanes, bool adjoint, int tap
     if (ws_alloc(I, &I->items.s0, lanes) || ws_alloc(I, &I->items.s1, lanes) || ws_alloc(I, &I->items.s2, lanes)) return 1;
     I->items.s3 = I->items.s4 = nullptr; I->dL = nullptr;
     if (adjoint && (ws_alloc(I, &I->items.s3, lanes) || ws_alloc(I, &I->items.s4, lanes) || ws_alloc(I, &I->dL, lanes))) return 1;
-    I->geo = ShapeArrays{}; I->d_pos_offset = nullptr; I->grad_pos = nullptr; I->d_inst_slot = nullptr; I->grad_inst = nullptr;
+    I->geo = ShapeArrays{}; I->d_pos_offset = nullptr; I->grad_pos = nullptr; I->d_inst_slot = nullptr; I->grad_inst = nullptr; I->grad_nrm = nullptr; I->nrm_acc = nullptr;
     if (adjoint && I->shape_on) {
         if (ws_alloc(I, &I->geo.g0, lanes) || ws_alloc(I, &I->geo.g1, lanes) || ws_alloc(I, &I->geo.g2, lanes) || ws_alloc(I, &I->geo.g3, lanes) || ws_alloc(I, &I->geo.g4, lanes) ||
             ws_alloc(I, &I->geo.g5, lanes) || ws_alloc(I, &I->geo.g6, lanes) || ws_alloc(I, &I->geo.pv0, lanes) || ws_alloc(I, &I->geo.pv1, lanes) || ws_alloc(I, &I->geo.vis, lanes)) return 1;
         if (I->pos_verts) {
             if (ws_alloc(I, &I->d_pos_offset, I->pos_offset.size()) || ws_alloc(I, &I->grad_pos, (size_t) 3 * I->pos_verts)) return 1;
+            if (I->pos_smooth && (ws_alloc(I, &I->grad_nrm, (size_t) 3 * I->pos_verts) || ws_alloc(I, &I->nrm_acc, (size_t) 3 * I->pos_verts))) return 1;
             HIP_TRY(hipMemcpy(I->d_pos_offset, I->pos_offset.data(), I->pos_offset.size() * sizeof(int32_t), hipMemcpyHostToDevice));
         }
         if (I->inst_count) {
@@ -504,7 +507,7 @@ int run_chunk(HarSceneImpl *S, HarIntegratorImpl *I, const DSensor &C, int mode,
     /* adjoint replay of a cached bounce: `shade` commits the vertex adjoint itself (the shadow-ray result is in the cache), no items, no resolve launch */
     static const bool inline_env = getenv("HAR_ADJOINT_INLINE") ? atoi(getenv("HAR_ADJOINT_INLINE")) != 0 : true;
     const bool inline_commit = inline_env && mode == MODE_PRB_ADJOINT && !shape && !I->forward_mode;      /* forward mode commits in the resolve kernels (own instantiation) */
-    const ShapeTargets targets{ I->d_pos_offset, I->grad_pos, I->pos_verts, I->d_inst_slot, I->grad_inst, I->inst_count };
+    const ShapeTargets targets{ I->d_pos_offset, I->grad_pos, I->pos_verts, I->d_inst_slot, I->grad_inst, I->inst_count, I->grad_nrm };
     /* per-material shading queues: scenes with more than one BSDF model, `path` and the primal pass of `prb` (the adjoint kernels keep the generic code:
      * their in-place commit is bound by memory traffic, not by the model code).  HAR_MATERIAL_QUEUES=0: the generic kernel with its block-local sort (A/B) */
     static const int mq_env = getenv("HAR_MATERIAL_QUEUES") ? atoi(getenv("HAR_MATERIAL_QUEUES")) : -1;      /* -1: the integrator's setting; 0 / 1 force (A/B) */
@@ -1173,6 +1176,7 @@ static int backward_range(HarScene S, HarIntegrator I, const HarSensor *sensor, 
         if ((I->pos_verts && I->pos_offset.size() != S->hs.meshes.size()) || (I->inst_count && I->inst_count != S->hs.insts.size()))
             return fail("har_integrator_set_grad_positions / har_integrator_set_grad_instances was called for a different scene");
         if (I->pos_verts) HIP_TRY(hipMemsetAsync(I->grad_pos, 0, (size_t) 3 * I->pos_verts * sizeof(float), s));
+        if (I->pos_verts && I->grad_nrm) HIP_TRY(hipMemsetAsync(I->grad_nrm, 0, (size_t) 3 * I->pos_verts * sizeof(float), s));
         if (I->inst_count) HIP_TRY(hipMemsetAsync(I->grad_inst, 0, (size_t) 12 * I->inst_count * sizeof(float), s));
     }
     HIP_TRY(hipMemsetAsync(I->totals, 0, 4 * sizeof(unsigned long long), s));
@@ -1191,8 +1195,14 @@ static int backward_range(HarScene S, HarIntegrator I, const HarSensor *sensor, 
     launch_add(s, I->grad_slots, grad_reflectance, (uint32_t) nb3);
     if (I->grad_emitters && ne3) launch_add(s, I->grad_slots + nb3, I->grad_emitters, (uint32_t) ne3);
     if (I->shape_on)
-        for (size_t m = 0; m < I->pos_user.size(); ++m)
-            if (I->pos_user[m]) launch_add(s, I->grad_pos + 3 * (size_t) I->pos_offset[m], I->pos_user[m], 3 * I->pos_count[m]);
+        for (size_t m = 0; m < I->pos_user.size(); ++m) {
+            if (!I->pos_user[m]) continue;
+            /* meshes with vertex normals: the summed adjoints of the vertex normals go through compute_normals once per face (second stage) */
+            if (I->grad_nrm && (S->hs.meshes[m].flags & 1u))
+                launch_normals_adjoint(s, S->ds, (uint32_t) m, S->hs.meshes[m].face_count, S->hs.meshes[m].vertex_count, I->nrm_acc + 3 * (size_t) I->pos_offset[m],
+                                       I->grad_nrm + 3 * (size_t) I->pos_offset[m], I->grad_pos + 3 * (size_t) I->pos_offset[m]);
+            launch_add(s, I->grad_pos + 3 * (size_t) I->pos_offset[m], I->pos_user[m], 3 * I->pos_count[m]);
+        }
     if (I->shape_on && I->inst_count) launch_add(s, I->grad_inst, I->inst_user, 12 * I->inst_count);
     HIP_TRY(hipGetLastError());
     return 0;
@@ -1260,10 +1270,10 @@ static bool record_has_smooth_lobe(const HostScene &hs, int32_t index) {
 int har_integrator_set_grad_positions(HarIntegrator I, HarScene S, float *const *grad_positions) {
     if (!I) return fail("null integrator");
     if (I->type != HAR_INTEGRATOR_PRB) return fail("vertex-position gradients are computed by the `prb` integrator");
-    std::vector<float *> user; std::vector<int32_t> offset; std::vector<uint32_t> count; uint32_t verts = 0;
+    std::vector<float *> user; std::vector<int32_t> offset; std::vector<uint32_t> count; uint32_t verts = 0; bool smooth = false;
     if (grad_positions) {
         if (!S) return fail("null scene");
-        /* the hand-derived adjoint of har_shape_grad.h covers flat-shaded top-level meshes carrying any BSDF with a non-delta lobe (the directional derivatives
+        /* the hand-derived adjoint of har_shape_grad.h covers top-level meshes, flat-shaded or with (regenerated) vertex normals, carrying any BSDF with a non-delta lobe (the directional derivatives
          * of the models come from har_bsdf_dir.h); the rest of the scene may carry any model -- a vertex next to moving geometry contributes through its
          * attached si.wi (prb.py:128-140) */
         if (S->ds.bsdf_types & HAR_SCENE_ENVMAP) return fail("vertex-position gradients are not implemented for scenes with an environment map or a mesh area light");
@@ -1272,17 +1282,26 @@ int har_integrator_set_grad_positions(HarIntegrator I, HarScene S, float *const 
         for (size_t m = 0; m < S->hs.top_mesh_count; ++m) {
             if (!grad_positions[m]) continue;
             const DMesh &M = S->hs.meshes[m];
-            if (M.flags & 1u) return fail("vertex-position gradients need a mesh without vertex normals (face_normals): a position update would regenerate them (mesh.cpp:876-878)");
+            if (M.flags & 1u) {
+                /* a position update regenerates the vertex normals (mesh.cpp:876-878 -> compute_normals): the gradient is that of the REGENERATED normals, so the
+                 * mesh must carry them -- stored normals of another origin (file, analytic) would render one surface and differentiate another */
+                std::vector<float> copy(S->hs.verts.begin() + 8 * (size_t) M.voff, S->hs.verts.begin() + 8 * (size_t) (M.voff + M.vertex_count));
+                if (har_mesh_compute_normals(M.vertex_count, copy.data(), M.face_count, S->hs.faces.data() + 4 * (size_t) M.foff)) return 1;
+                float worst = 0.f;
+                for (size_t v = 0; v < M.vertex_count; ++v) for (int c = 3; c < 6; ++c) worst = std::max(worst, std::fabs(copy[8 * v + c] - S->hs.verts[8 * ((size_t) M.voff + v) + c]));
+                if (worst > 1e-4f) return fail("vertex-position gradients of a mesh with vertex normals: its normals are not the ones a position update regenerates (Mesh::compute_normals, mesh.cpp:876-878); write the positions once (params.update()) or regenerate the normals first");
+                smooth = true;
+            }
             if (!record_has_smooth_lobe(S->hs, M.bsdf)) return fail("vertex-position gradients: a differentiated mesh cannot carry a BSDF made of delta lobes only (`dielectric`, `conductor`); other meshes of the scene may");
             offset[m] = (int32_t) verts; user[m] = grad_positions[m]; count[m] = M.vertex_count; verts += M.vertex_count;
         }
         if (verts == 0) { offset.clear(); user.clear(); count.clear(); }
     }
-    if (offset != I->pos_offset || verts != I->pos_verts) {      /* the geometry records and the offset table are part of the adjoint workspace */
+    if (offset != I->pos_offset || verts != I->pos_verts || smooth != I->pos_smooth) {      /* the geometry records and the offset table are part of the adjoint workspace */
         (void) hipDeviceSynchronize();
         I->free_ws();
     }
-    I->pos_user = user; I->pos_offset = offset; I->pos_count = count; I->pos_verts = verts; I->shape_on = verts != 0 || I->inst_count != 0;
+    I->pos_user = user; I->pos_offset = offset; I->pos_count = count; I->pos_verts = verts; I->pos_smooth = smooth; I->shape_on = verts != 0 || I->inst_count != 0;
     return 0;
 }
 

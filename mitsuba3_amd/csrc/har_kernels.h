@@ -114,7 +114,8 @@ struct TexelQueues { float4 *rec; uint32_t *count; const uint2 *band; const uint
  * over models) -- shades its list.  idx: class c, shard s -> idx[c * lanes + s * shard_cap + k] = slot of the k-th path; count: (c * HAR_SHARDS + s) * stride. */
 struct MaterialQueues { uint32_t *idx; uint32_t *count; uint32_t lanes, miss_class; };
 #define HAR_SHAPE_INST_SHIFT 8           /* geometry records: bits 8..31 of the flags word = instance index + 1 of a vertex on instanced geometry (0: top-level) */
-struct ShapeTargets { const int32_t *offset; float *grad; uint32_t n_verts; const int32_t *inst_slot; float *inst_grad; uint32_t n_insts; /* per instance: slot (12 floats each in inst_grad) or -1; null = no instance is differentiated */ };
+struct ShapeTargets { const int32_t *offset; float *grad; uint32_t n_verts; const int32_t *inst_slot; float *inst_grad; uint32_t n_insts;
+                      float *grad_nrm = nullptr;       /* meshes with vertex normals: adjoints of the vertex normals, laid out like `grad` (first stage, see launch_normals_adjoint) */ /* per instance: slot (12 floats each in inst_grad) or -1; null = no instance is differentiated */ };
 #define HAR_LDS_GRAD_INSTS 128        /* instance-transform gradients accumulated per block in LDS (6 KB) */
 #define HAR_LDS_GRAD_VERTS 1024       /* up to this many differentiated vertices are accumulated in LDS (12 KB) before one global atomic per block and float */
 
@@ -157,6 +158,9 @@ void launch_skip_emitters(hipStream_t s, uint32_t grid, const DScene &S, int fir
 void launch_shape_adjoint(hipStream_t s, uint32_t grid, const DScene &S, const uint32_t *item_count, uint32_t shard_cap, const ItemArrays &items, const ShapeArrays &geo,
                           const float4 *result, const float4 *dL, int has_next, const WaveState &next, const float4 *h0, const uint2 *h1, const ReplayCache &rc_next,
                           const ShapeTargets &T);
+/* second stage of the derivative through regenerated vertex normals (Mesh::compute_normals, mesh.cpp:1216-1267) for mesh `mesh`: acc (3 floats per vertex of the mesh,
+ * scratch) <- the angle-weighted normal sums, then every face pushes the adjoints of its three vertices' normals (nbar) to its three positions (grad += ...) */
+void launch_normals_adjoint(hipStream_t s, const DScene &S, uint32_t mesh, uint32_t face_count, uint32_t vertex_count, float *acc, const float *nbar, float *grad);
 void launch_splat(hipStream_t s, const DSensor &C, uint32_t seed, uint32_t spp, uint32_t log_spp, uint32_t lane_base, uint32_t n,
                   const float4 *result, int weights_only, float *film, const float2 *jitter = nullptr, const float *scalar = nullptr);   /* weights_only + scalar: w * scalar[i] */
 /* alpha flags of the camera samples of a wavefront (1 = valid), see k_alpha_flags */

@@ -1226,6 +1226,8 @@ __global__ __launch_bounds__(kBlock) void k_shape_adjoint(DScene S, const uint32
         ShapeGrad G;
         if (!shape_item_adjoint(S, it, off >= 0, poff >= 0, geo.vis[i] != 0, Vec3(L4.x, L4.y, L4.z), Vec3(dl4.x, dl4.y, dl4.z), nxt, next_valid, np, nn, nd, G)) continue;
         if (G.self_mesh) add_verts(off, G.vid, G.g);
+        if (G.self_normals && T.grad_nrm)
+            for (int k = 0; k < 3; ++k) { float *q = T.grad_nrm + 3u * ((uint32_t) off + G.vid[k]); atomicAdd(q, G.gn[k].x); atomicAdd(q + 1, G.gn[k].y); atomicAdd(q + 2, G.gn[k].z); }
         if (G.self_inst) add_inst(off, G.gM);
         if (G.prev_mesh) add_verts(poff, G.pvid, G.gp);
         if (G.prev_inst) add_inst(poff, G.gpM);
@@ -1233,6 +1235,41 @@ __global__ __launch_bounds__(kBlock) void k_shape_adjoint(DScene S, const uint32
     __syncthreads();
     if (lds) for (uint32_t k = threadIdx.x; k < 3 * T.n_verts; k += kBlock) { const float v = acc[k]; if (v != 0.f) atomicAdd(T.grad + k, v); }
     if (T.inst_grad) for (uint32_t k = threadIdx.x; k < 12 * min(T.n_insts, (uint32_t) HAR_LDS_GRAD_INSTS); k += kBlock) { const float v = iacc[k]; if (v != 0.f) atomicAdd(T.inst_grad + k, v); }
+}
+
+/* regenerated vertex normals, second stage (har_shape_grad.h face_normals_adjoint): one thread per face of the mesh */
+__device__ __forceinline__ void normals_face(const DScene &S, const DMesh &M, uint32_t f, uint32_t vid[3], Vec3 P[3]) {
+    const uint32_t *fi = S.faces + 4 * (size_t) (M.foff + f);
+    for (int k = 0; k < 3; ++k) { vid[k] = fi[k]; const float *r = S.verts + 8 * (size_t) (M.voff + fi[k]); P[k] = Vec3(r[0], r[1], r[2]); }
+}
+__global__ void k_normals_sums(DScene S, uint32_t mesh, float *acc) {
+    const DMesh M = S.meshes[mesh];
+    const uint32_t f = blockIdx.x * blockDim.x + threadIdx.x;
+    if (f >= M.face_count) return;
+    uint32_t vid[3]; Vec3 P[3], c[3]; normals_face(S, M, f, vid, P);
+    if (!face_corner_normals(P, c)) return;
+    for (int k = 0; k < 3; ++k) { float *q = acc + 3 * (size_t) vid[k]; atomicAdd(q, c[k].x); atomicAdd(q + 1, c[k].y); atomicAdd(q + 2, c[k].z); }
+}
+__global__ void k_normals_adjoint(DScene S, uint32_t mesh, const float *acc, const float *nbar, float *grad) {
+    const DMesh M = S.meshes[mesh];
+    const uint32_t f = blockIdx.x * blockDim.x + threadIdx.x;
+    if (f >= M.face_count) return;
+    uint32_t vid[3]; Vec3 P[3], ab[3]; normals_face(S, M, f, vid, P);
+    bool any = false;
+    for (int k = 0; k < 3; ++k) {
+        const float *a = acc + 3 * (size_t) vid[k], *b = nbar + 3 * (size_t) vid[k];
+        const Vec3 av(a[0], a[1], a[2]), nb(b[0], b[1], b[2]);
+        const float l2 = dot3(av, av);
+        ab[k] = Vec3(0.f);
+        if (!(l2 > 0.f)) continue;
+        const float il = rsqrt_(l2); const Vec3 n = av * il;
+        ab[k] = (nb - n * dot3(n, nb)) * il;               /* n_v = acc_v / |acc_v| */
+        any = any || nb.x != 0.f || nb.y != 0.f || nb.z != 0.f;
+    }
+    if (!any) return;
+    Vec3 g[3] = { Vec3(0.f), Vec3(0.f), Vec3(0.f) };
+    face_normals_adjoint(P, ab, g);
+    for (int k = 0; k < 3; ++k) { float *q = grad + 3 * (size_t) vid[k]; atomicAdd(q, g[k].x); atomicAdd(q + 1, g[k].y); atomicAdd(q + 2, g[k].z); }
 }
 
 /* ------------------------------------------------------------------- splat */
@@ -1645,6 +1682,12 @@ void launch_shape_adjoint(hipStream_t s, uint32_t grid, const DScene &S, const u
                           const float4 *result, const float4 *dL, int has_next, const WaveState &next, const float4 *h0, const uint2 *h1, const ReplayCache &rc_next,
                           const ShapeTargets &T) {
     hipLaunchKernelGGL(k_shape_adjoint, dim3(grid), dim3(kBlock), 0, s, S, item_count, shard_cap, items, geo, result, dL, has_next, next, h0, h1, rc_next, T);
+}
+void launch_normals_adjoint(hipStream_t s, const DScene &S, uint32_t mesh, uint32_t face_count, uint32_t vertex_count, float *acc, const float *nbar, float *grad) {
+    if (face_count == 0) return;
+    (void) hipMemsetAsync(acc, 0, (size_t) 3 * vertex_count * sizeof(float), s);
+    hipLaunchKernelGGL(k_normals_sums, dim3(blocks_for(face_count)), dim3(kBlock), 0, s, S, mesh, acc);
+    hipLaunchKernelGGL(k_normals_adjoint, dim3(blocks_for(face_count)), dim3(kBlock), 0, s, S, mesh, acc, nbar, grad);
 }
 void launch_splat(hipStream_t s, const DSensor &C, uint32_t seed, uint32_t spp, uint32_t log_spp, uint32_t lane_base, uint32_t n,
                   const float4 *result, int weights_only, float *film, const float2 *jitter, const float *scalar) {

@@ -707,14 +707,19 @@ def _grid_floor(mi, d, n):
 
 
 @pytest.mark.parametrize("which", ["slab", "slab_textured", "slab_env", "slab_twosided", "slab_crop_box", "cbox", "cbox_grid", "cbox_nocache", "slab_rough_conductor", "slab_rough_plastic",
-                                   "floor_roughconductor", "floor_roughconductor_beckmann", "floor_roughplastic", "floor_plastic", "both_roughconductor", "floor_roughconductor_aniso", "cbox_rough"])
+                                   "floor_roughconductor", "floor_roughconductor_beckmann", "floor_roughplastic", "floor_plastic", "both_roughconductor", "floor_roughconductor_aniso", "cbox_rough",
+                                   "smooth_floor", "smooth_floor_roughplastic", "cbox_shapes"])
 def test_prb_vertex_position_gradients(mi, O, which):
     """har_integrator_set_grad_positions: the wavefront adjoint (k_shade<ADJOINT, SHAPE> geometry records, visibility from k_resolve,
     k_shape_adjoint with the next bounce's detached interaction) vs the oracle's dual-number restatement, vertex by vertex; the colour
     gradients of the same call must not change"""
     from tests.test_cpu_host import oracle_scene_from
-    from tests.test_shape_gradients_cpu import slab_scene, cbox_mesh_scene, twosided_slab_scene, rough_slab_scene, mesh_index
-    if which == "slab_twosided":
+    from tests.test_shape_gradients_cpu import slab_scene, cbox_mesh_scene, twosided_slab_scene, rough_slab_scene, smooth_slab_scene, mesh_index
+    if which.startswith("smooth_floor"):      # vertex normals regenerated from the positions (mesh.cpp:876-878): k_shape_adjoint's normal adjoints + k_normals_adjoint
+        res = 24; d = smooth_slab_scene(mi, res, model=which[13:] or None); names = ["floor", "ceiling"]
+    elif which == "cbox_shapes":              # the Cornell box's own rectangles and cubes: meshes WITH vertex normals (equal to the regenerated ones on flat faces)
+        res = 32; d = mi.cornell_box(); d["sensor"]["film"]["width"] = res; d["sensor"]["film"]["height"] = res; names = ["small-box", "large-box", "floor", "back"]
+    elif which == "slab_twosided":
         res = 24; d = twosided_slab_scene(mi, res); names = ["floor", "ceiling", "sheet"]
     elif which.startswith("slab_rough"):      # a rough (not differentiated) ceiling: its vertices follow the floor through the attached si.wi (prb.py:128-140)
         res = 24; d = rough_slab_scene(mi, res, "roughconductor" if which.endswith("conductor") else "roughplastic"); names = ["floor"]
@@ -785,14 +790,22 @@ def test_vertex_position_update_rebuilds_the_scene(mi, O):
 def test_vertex_position_gradients_refused_outside_their_domain(mi):
     """purely specular BSDFs on moving geometry / meshes with vertex normals: an error, not a silently incomplete gradient"""
     from tests.test_bsdfs_cpu import _material_cbox
-    d = _material_cbox(mi, 16); d["integrator"] = {"type": "prb", "max_depth": 3, "shape_gradients": True}
-    scene = mi.load_dict(d)
     g = np.ones((16, 16, 3), np.float32)
-    assert scene._position_keys() == {}            # the Cornell shapes all carry vertex normals
-    d = mi.cornell_box(); d["sensor"]["film"]["width"] = 16; d["sensor"]["film"]["height"] = 16
-    d["integrator"] = {"type": "prb", "max_depth": 3, "shape_gradients": ["small-box.vertex_positions"]}
+    # a mesh whose vertex normals are NOT the ones a position update regenerates (analytic normals of the bumpy sphere): refused when named, left out by `True`,
+    # accepted once its positions have been written (params.update() regenerates the normals, mesh.cpp:876-878)
+    d = mi.instanced_spheres_scene(width=16, height=16, spp=4, grid=1, n_u=12, n_v=6, flatten=True)
+    d["integrator"] = {"type": "prb", "max_depth": 3, "shape_gradients": ["ball000.vertex_positions"]}
     scene = mi.load_dict(d)
+    with pytest.raises(RuntimeError, match="regenerates"):
+        scene.integrator().render_backward(scene, None, g, seed=0, spp=4)
+    scene.integrator().shape_gradients = True
+    out = scene.integrator().render_backward(scene, None, g, seed=0, spp=4)
+    assert "ball000.vertex_positions" not in out and "floor.vertex_positions" in out          # the box's rectangles: flat faces, regenerated == stored
+    params = mi.traverse(scene); params["ball000.vertex_positions"] = params["ball000.vertex_positions"].clone(); params.update()
+    out = scene.integrator().render_backward(scene, None, g, seed=0, spp=4)
+    assert "ball000.vertex_positions" in out and out["ball000.vertex_positions"].abs().max() > 0
     with pytest.raises(KeyError):
+        scene.integrator().shape_gradients = ["nonexistent.vertex_positions"]
         scene.integrator().render_backward(scene, None, g, seed=0, spp=4)
     from tests.test_shape_gradients_cpu import slab_scene
     # a mesh with only delta lobes may be PART of the scene; asking for ITS vertex positions is refused (eval() is zero: prb.py:288 would form relative_grad(0)),
