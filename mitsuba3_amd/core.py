@@ -1441,14 +1441,22 @@ class SceneParameters(dict):
             self[k] = torch.tensor(np.ascontiguousarray(scene.meshes[m]["V"][:, :3]).reshape(-1), dtype=torch.float32, device=dev)
         for k, i in scene._instance_keys().items():
             self[k] = torch.tensor(scene._instance_matrix(i), dtype=torch.float32, device=dev)
+        self._written = set()           # keys assigned since the last update() (SceneParameters.__setitem__ flags them in the reference, util.py)
+
+    def __setitem__(self, key, value):
+        super().__setitem__(key, value)
+        if hasattr(self, "_written"):
+            self._written.add(key)
 
     def update(self, values=None):
         if values:
             for k, v in values.items():
                 self[k] = v
+        written, self._written = self._written, set()
         for k, m in self.scene._position_keys().items():
             v = self[k].detach().to("cpu", copy=True).numpy().astype(np.float32).reshape(-1, 3)
-            if not np.array_equal(v, self.scene.meshes[m]["V"][:, :3]):
+            # a WRITTEN key notifies the mesh even when the values are the old ones: the vertex normals are regenerated (mesh.cpp:876-878)
+            if k in written or not np.array_equal(v, self.scene.meshes[m]["V"][:, :3]):
                 self.scene._set_vertex_positions(m, v)
         for k, i in self.scene._instance_keys().items():
             v = self[k].detach().to("cpu", copy=True).numpy().astype(np.float32).reshape(4, 4)
