@@ -793,7 +793,7 @@ def test_vertex_position_gradients_refused_outside_their_domain(mi):
     g = np.ones((16, 16, 3), np.float32)
     # a mesh whose vertex normals are NOT the ones a position update regenerates (analytic normals of the bumpy sphere): refused when named, left out by `True`,
     # accepted once its positions have been written (params.update() regenerates the normals, mesh.cpp:876-878)
-    d = mi.instanced_spheres_scene(width=16, height=16, spp=4, grid=1, n_u=12, n_v=6, flatten=True)
+    d = mi.instanced_spheres_scene(width=16, height=16, spp=4, grid=2, n_u=12, n_v=6, flatten=True)
     d["integrator"] = {"type": "prb", "max_depth": 3, "shape_gradients": ["ball000.vertex_positions"]}
     scene = mi.load_dict(d)
     with pytest.raises(RuntimeError, match="regenerates"):
@@ -801,9 +801,12 @@ def test_vertex_position_gradients_refused_outside_their_domain(mi):
     scene.integrator().shape_gradients = True
     out = scene.integrator().render_backward(scene, None, g, seed=0, spp=4)
     assert "ball000.vertex_positions" not in out and "floor.vertex_positions" in out          # the box's rectangles: flat faces, regenerated == stored
-    params = mi.traverse(scene); params["ball000.vertex_positions"] = params["ball000.vertex_positions"].clone(); params.update()
-    out = scene.integrator().render_backward(scene, None, g, seed=0, spp=4)
-    assert "ball000.vertex_positions" in out and out["ball000.vertex_positions"].abs().max() > 0
+    params = mi.traverse(scene)
+    for k in range(4):
+        params["ball%03d.vertex_positions" % k] = params["ball%03d.vertex_positions" % k].clone()
+    params.update()
+    out = scene.integrator().render_backward(scene, None, g, seed=0, spp=16)
+    assert all("ball%03d.vertex_positions" % k in out for k in range(4)) and max(float(out["ball%03d.vertex_positions" % k].abs().max()) for k in range(4)) > 0
     with pytest.raises(KeyError):
         scene.integrator().shape_gradients = ["nonexistent.vertex_positions"]
         scene.integrator().render_backward(scene, None, g, seed=0, spp=4)
