@@ -708,7 +708,7 @@ def _grid_floor(mi, d, n):
 
 @pytest.mark.parametrize("which", ["slab", "slab_textured", "slab_env", "slab_twosided", "slab_crop_box", "cbox", "cbox_grid", "cbox_nocache", "slab_rough_conductor", "slab_rough_plastic",
                                    "floor_roughconductor", "floor_roughconductor_beckmann", "floor_roughplastic", "floor_plastic", "both_roughconductor", "floor_roughconductor_aniso", "cbox_rough",
-                                   "smooth_floor", "smooth_floor_roughplastic", "cbox_shapes"])
+                                   "smooth_floor", "smooth_floor_roughplastic", "cbox_shapes", "smooth_spheres"])
 def test_prb_vertex_position_gradients(mi, O, which):
     """har_integrator_set_grad_positions: the wavefront adjoint (k_shade<ADJOINT, SHAPE> geometry records, visibility from k_resolve,
     k_shape_adjoint with the next bounce's detached interaction) vs the oracle's dual-number restatement, vertex by vertex; the colour
@@ -717,6 +717,8 @@ def test_prb_vertex_position_gradients(mi, O, which):
     from tests.test_shape_gradients_cpu import slab_scene, cbox_mesh_scene, twosided_slab_scene, rough_slab_scene, smooth_slab_scene, mesh_index
     if which.startswith("smooth_floor"):      # vertex normals regenerated from the positions (mesh.cpp:876-878): k_shape_adjoint's normal adjoints + k_normals_adjoint
         res = 24; d = smooth_slab_scene(mi, res, model=which[13:] or None); names = ["floor", "ceiling"]
+    elif which == "smooth_spheres":           # closed smooth meshes (UV spheres with seam and pole vertices) inside the Cornell box; normals regenerated below
+        res = 32; d = mi.instanced_spheres_scene(width=res, height=res, spp=16, grid=2, n_u=16, n_v=8, flatten=True); names = ["ball000", "ball001", "ball002", "ball003", "floor"]
     elif which == "cbox_shapes":              # the Cornell box's own rectangles and cubes: meshes WITH vertex normals (equal to the regenerated ones on flat faces)
         res = 32; d = mi.cornell_box(); d["sensor"]["film"]["width"] = res; d["sensor"]["film"]["height"] = res; names = ["small-box", "large-box", "floor", "back"]
     elif which == "slab_twosided":
@@ -745,6 +747,11 @@ def test_prb_vertex_position_gradients(mi, O, which):
     if which == "cbox_nocache":
         d["integrator"]["replay_cache"] = False
     scene = mi.load_dict(d)
+    if which == "smooth_spheres":             # writing the positions regenerates the vertex normals (mesh.cpp:876-878): the analytic normals of the scene give way
+        params = mi.traverse(scene)
+        for n in names[:4]:
+            params[n + ".vertex_positions"] = params[n + ".vertex_positions"].clone()
+        params.update()
     osc, sensor = oracle_scene_from(O, scene)
     ids = [mesh_index(scene, n) for n in names]
     grad_in = np.random.default_rng(4).uniform(0.5, 1.5, (res, res, 3)).astype(np.float32)
