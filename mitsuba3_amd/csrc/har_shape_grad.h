@@ -246,52 +246,70 @@ HAR_HD bool shape_item_adjoint(const DScene &S, const ShapeItem &it, bool self_o
     return some;
 }
 
+/* ---- second stage of the vertex-normal derivative.  Written in DOUBLE precision: real meshes hold slivers (the last ring of a UV sphere has triangles whose pole
+ * edge is 1e-17 long) whose corner terms have derivatives of 1 / edge that cancel or meet a zero adjoint only in exact arithmetic -- in fp32 they come out as
+ * inf - inf.  One thread per face, once per render: the fp64 rate is irrelevant. */
+struct D3 { double x, y, z; };
+HAR_HD D3 d3(Vec3 v) { return D3{ (double) v.x, (double) v.y, (double) v.z }; }
+HAR_HD D3 operator+(D3 a, D3 b) { return D3{ a.x + b.x, a.y + b.y, a.z + b.z }; }
+HAR_HD D3 operator-(D3 a, D3 b) { return D3{ a.x - b.x, a.y - b.y, a.z - b.z }; }
+HAR_HD D3 operator-(D3 a) { return D3{ -a.x, -a.y, -a.z }; }
+HAR_HD D3 operator*(D3 a, double s) { return D3{ a.x * s, a.y * s, a.z * s }; }
+HAR_HD double ddot3(D3 a, D3 b) { return a.x * b.x + a.y * b.y + a.z * b.z; }
+HAR_HD D3 dcross3(D3 a, D3 b) { return D3{ a.y * b.z - a.z * b.y, a.z * b.x - a.x * b.z, a.x * b.y - a.y * b.x }; }
 /* dr::unit_angle(u, v) of two unit vectors: 2 asin(|v - u| / 2), or pi - 2 asin(|v + u| / 2) for an obtuse angle (restated from its published definition) */
-HAR_HD float unit_angle3(Vec3 u, Vec3 v) {
-    const bool acute = dot3(u, v) >= 0.f;
-    const float t = 2.f * asinf(.5f * norm3(acute ? v - u : v + u));
-    return acute ? t : HAR_PI - t;
+HAR_HD double unit_angle_d(D3 u, D3 v) {
+    const bool acute = ddot3(u, v) >= 0.0;
+    const D3 w = acute ? v - u : v + u;
+    const double t = 2.0 * asin(fmin(0.5 * sqrt(ddot3(w, w)), 1.0));
+    return acute ? t : 3.14159265358979323846 - t;
 }
-/* Second stage of the vertex-normal derivative, one FACE: Mesh::compute_normals (mesh.cpp:1216-1267) adds  c_k = n_face * angle_k  to the sum of the face's k-th
- * vertex; given the adjoints a_bar[k] of those three sums this adds d objective / d P_j to g[j].  (n_face = N / |N|, N = (P1 - P0) x (P2 - P0);
- * angle_k = unit_angle(normalize(P_{k+1} - P_k), normalize(P_{k+2} - P_k)).)  Faces without area contribute nothing, as in the forward pass. */
-HAR_HD void face_normals_adjoint(const Vec3 P[3], const Vec3 a_bar[3], Vec3 g[3]) {
-    const Vec3 e1 = P[1] - P[0], e2 = P[2] - P[0], N = cross3(e1, e2);
-    const float l2 = dot3(N, N);
-    if (!(l2 > 0.f)) return;
-    const float len = sqrtf(l2);
-    const Vec3 n = N * rcp_(len);
-    Vec3 n_bar(0.f);
+/* Mesh::compute_normals (mesh.cpp:1216-1267) adds  c_k = n_face * angle_k  to the sum of the face's k-th vertex (n_face = N / |N|, N = (P1 - P0) x (P2 - P0);
+ * angle_k = unit_angle(normalize(P_{k+1} - P_k), normalize(P_{k+2} - P_k))); false for a face without area, which contributes nothing */
+HAR_HD bool face_corner_normals(const Vec3 Pf[3], Vec3 c[3]) {
+    const D3 P[3] = { d3(Pf[0]), d3(Pf[1]), d3(Pf[2]) };
+    const D3 N = dcross3(P[1] - P[0], P[2] - P[0]);
+    const double l2 = ddot3(N, N);
+    if (!(l2 > 0.0)) return false;
+    const D3 n = N * (1.0 / sqrt(l2));
+    for (int k = 0; k < 3; ++k) {
+        const D3 a = P[(k + 1) % 3] - P[k], b = P[(k + 2) % 3] - P[k];
+        const double angle = unit_angle_d(a * (1.0 / sqrt(ddot3(a, a))), b * (1.0 / sqrt(ddot3(b, b))));
+        c[k] = Vec3((float) (n.x * angle), (float) (n.y * angle), (float) (n.z * angle));
+    }
+    return true;
+}
+/* ... and its reverse: given the adjoints a_bar[k] of the three sums the face adds to, g[j] += d objective / d P_j */
+HAR_HD void face_normals_adjoint(const Vec3 Pf[3], const Vec3 a_bar_f[3], Vec3 g[3]) {
+    const D3 P[3] = { d3(Pf[0]), d3(Pf[1]), d3(Pf[2]) }, a_bar[3] = { d3(a_bar_f[0]), d3(a_bar_f[1]), d3(a_bar_f[2]) };
+    const D3 e1 = P[1] - P[0], e2 = P[2] - P[0], N = dcross3(e1, e2);
+    const double l2 = ddot3(N, N);
+    if (!(l2 > 0.0)) return;
+    const double len = sqrt(l2);
+    const D3 n = N * (1.0 / len);
+    D3 n_bar{ 0.0, 0.0, 0.0 }, gd[3] = { D3{ 0.0, 0.0, 0.0 }, D3{ 0.0, 0.0, 0.0 }, D3{ 0.0, 0.0, 0.0 } };
     for (int k = 0; k < 3; ++k) {
         const int k1 = (k + 1) % 3, k2 = (k + 2) % 3;
-        const Vec3 a = P[k1] - P[k], b = P[k2] - P[k];
-        const float la = norm3(a), lb = norm3(b);
-        const Vec3 u = a * rcp_(la), v = b * rcp_(lb);
-        const bool acute = dot3(u, v) >= 0.f;
-        const Vec3 w = acute ? v - u : v + u;
-        const float r = norm3(w), s = .5f * r, t = 2.f * asinf(s), angle = acute ? t : HAR_PI - t;
+        const D3 a = P[k1] - P[k], b = P[k2] - P[k];
+        const double la = sqrt(ddot3(a, a)), lb = sqrt(ddot3(b, b));
+        const D3 u = a * (1.0 / la), v = b * (1.0 / lb);
+        const bool acute = ddot3(u, v) >= 0.0;
+        const D3 w = acute ? v - u : v + u;
+        const double r = sqrt(ddot3(w, w)), s = fmin(0.5 * r, 1.0), t = 2.0 * asin(s), angle = acute ? t : 3.14159265358979323846 - t;
         n_bar = n_bar + a_bar[k] * angle;
-        const float angle_bar = dot3(n, a_bar[k]);
-        if (!(r > 0.f)) continue;
+        const double angle_bar = ddot3(n, a_bar[k]);
+        if (!(r > 0.0) || angle_bar == 0.0) continue;
         /* angle = +-2 asin(r / 2) (+ pi): d angle / d r = +-1 / sqrt(1 - r^2 / 4) */
-        const float r_bar = (acute ? angle_bar : -angle_bar) * rsqrt_(fmaxf(1.f - s * s, 1e-12f));
-        const Vec3 w_bar = w * (r_bar / r);
-        const Vec3 v_bar = w_bar, u_bar = acute ? -w_bar : w_bar;
-        const Vec3 ab = (u_bar - u * dot3(u, u_bar)) * rcp_(la), bb = (v_bar - v * dot3(v, v_bar)) * rcp_(lb);
-        g[k1] = g[k1] + ab; g[k2] = g[k2] + bb; g[k] = g[k] - (ab + bb);
+        const double r_bar = (acute ? angle_bar : -angle_bar) / sqrt(fmax(1.0 - s * s, 1e-300));
+        const D3 w_bar = w * (r_bar / r);
+        const D3 v_bar = w_bar, u_bar = acute ? -w_bar : w_bar;
+        const D3 ab = (u_bar - u * ddot3(u, u_bar)) * (1.0 / la), bb = (v_bar - v * ddot3(v, v_bar)) * (1.0 / lb);
+        gd[k1] = gd[k1] + ab; gd[k2] = gd[k2] + bb; gd[k] = gd[k] - (ab + bb);
     }
-    const Vec3 N_bar = (n_bar - n * dot3(n, n_bar)) * rcp_(len);
-    const Vec3 e1_bar = cross3(e2, N_bar), e2_bar = cross3(N_bar, e1);
-    g[1] = g[1] + e1_bar; g[2] = g[2] + e2_bar; g[0] = g[0] - (e1_bar + e2_bar);
-}
-/* the three corner contributions c_k of a face (forward pass of the above; false for a face without area) */
-HAR_HD bool face_corner_normals(const Vec3 P[3], Vec3 c[3]) {
-    const Vec3 N = cross3(P[1] - P[0], P[2] - P[0]);
-    const float l2 = dot3(N, N);
-    if (!(l2 > 0.f)) return false;
-    const Vec3 n = N * rsqrt_(l2);
-    for (int k = 0; k < 3; ++k) c[k] = n * unit_angle3(normalize3(P[(k + 1) % 3] - P[k]), normalize3(P[(k + 2) % 3] - P[k]));
-    return true;
+    const D3 N_bar = (n_bar - n * ddot3(n, n_bar)) * (1.0 / len);
+    const D3 e1_bar = dcross3(e2, N_bar), e2_bar = dcross3(N_bar, e1);
+    gd[1] = gd[1] + e1_bar; gd[2] = gd[2] + e2_bar; gd[0] = gd[0] - (e1_bar + e2_bar);
+    for (int k = 0; k < 3; ++k) g[k] = g[k] + Vec3((float) gd[k].x, (float) gd[k].y, (float) gd[k].z);
 }
 
 } // namespace har

@@ -718,7 +718,7 @@ def test_prb_vertex_position_gradients(mi, O, which):
     if which.startswith("smooth_floor"):      # vertex normals regenerated from the positions (mesh.cpp:876-878): k_shape_adjoint's normal adjoints + k_normals_adjoint
         res = 24; d = smooth_slab_scene(mi, res, model=which[13:] or None); names = ["floor", "ceiling"]
     elif which == "smooth_spheres":           # closed smooth meshes (UV spheres with seam and pole vertices) inside the Cornell box; normals regenerated below
-        res = 32; d = mi.instanced_spheres_scene(width=res, height=res, spp=16, grid=2, n_u=16, n_v=8, flatten=True); names = ["ball000", "ball001", "ball002", "ball003", "floor"]
+        res = 32; d = mi.instanced_spheres_scene(width=res, height=res, spp=16, grid=2, n_u=16, n_v=8, flatten=True); names = ["ball000", "ball001", "ball003", "floor"]      # (ball002 is out of every path's reach at this size)
     elif which == "cbox_shapes":              # the Cornell box's own rectangles and cubes: meshes WITH vertex normals (equal to the regenerated ones on flat faces)
         res = 32; d = mi.cornell_box(); d["sensor"]["film"]["width"] = res; d["sensor"]["film"]["height"] = res; names = ["small-box", "large-box", "floor", "back"]
     elif which == "slab_twosided":
@@ -749,7 +749,7 @@ def test_prb_vertex_position_gradients(mi, O, which):
     scene = mi.load_dict(d)
     if which == "smooth_spheres":             # writing the positions regenerates the vertex normals (mesh.cpp:876-878): the analytic normals of the scene give way
         params = mi.traverse(scene)
-        for n in names[:4]:
+        for n in names[:3]:
             params[n + ".vertex_positions"] = params[n + ".vertex_positions"].clone()
         params.update()
     osc, sensor = oracle_scene_from(O, scene)
@@ -800,7 +800,8 @@ def test_vertex_position_gradients_refused_outside_their_domain(mi):
     g = np.ones((16, 16, 3), np.float32)
     # a mesh whose vertex normals are NOT the ones a position update regenerates (analytic normals of the bumpy sphere): refused when named, left out by `True`,
     # accepted once its positions have been written (params.update() regenerates the normals, mesh.cpp:876-878)
-    d = mi.instanced_spheres_scene(width=16, height=16, spp=4, grid=2, n_u=12, n_v=6, flatten=True)
+    g = np.ones((32, 32, 3), np.float32)
+    d = mi.instanced_spheres_scene(width=32, height=32, spp=4, grid=2, n_u=12, n_v=6, flatten=True)
     d["integrator"] = {"type": "prb", "max_depth": 3, "shape_gradients": ["ball000.vertex_positions"]}
     scene = mi.load_dict(d)
     with pytest.raises(RuntimeError, match="regenerates"):
@@ -818,6 +819,7 @@ def test_vertex_position_gradients_refused_outside_their_domain(mi):
         scene.integrator().shape_gradients = ["nonexistent.vertex_positions"]
         scene.integrator().render_backward(scene, None, g, seed=0, spp=4)
     from tests.test_shape_gradients_cpu import slab_scene
+    g = np.ones((16, 16, 3), np.float32)
     # a mesh with only delta lobes may be PART of the scene; asking for ITS vertex positions is refused (eval() is zero: prb.py:288 would form relative_grad(0)),
     # `True` selects the meshes the adjoint can differentiate -- rough models included
     d = slab_scene(mi, 16); d["ceiling"]["bsdf"] = {"type": "conductor", "eta": [0.2, 0.92, 1.1], "k": [3.9, 2.45, 2.14]}
