@@ -801,7 +801,7 @@ static AttachedSI attach_si(const Scene &sc, const Ray &ray, const PI &pi, const
         a.diff = true; a.inst = pi.inst; a.mesh = pi.shape;
         return a;
     }
-    if (!pi.valid() || pi.inst != 0xffffffffu || !mask || !mask[pi.shape]) return a;
+    if (!pi.valid() || !mask || !mask[pi.shape]) return a;
     const Mesh &m = sc.meshes[pi.shape];
     const uint32_t *f = &m.F[4 * (size_t) pi.prim];
     a.diff = true; a.mesh = pi.shape; a.vid[0] = f[0]; a.vid[1] = f[1]; a.vid[2] = f[2];
@@ -814,12 +814,25 @@ static AttachedSI attach_si(const Scene &sc, const Ray &ray, const PI &pi, const
     Dn3 e1 = P[1] - P[0], e2 = P[2] - P[0];
     Dn3 p_att = P[0] * b0 + P[1] * b1 + P[2] * b2;
     Dn3 n_geo = dnormalize(dcross(e1, e2));                       // face_normal
-    Dn3 nd = dn3(si.n);                                           // dr::detach(n)
-    Dn3 o = dn3(ray.o), d = dn3(ray.d);
+    /* A mesh INSIDE a shape group (differentiated vertex positions shared by all instances; the instance's to_world is detached -- the reference refuses both at
+     * once, instance.cpp:162-166): the nested Mesh::compute_surface_interaction runs in OBJECT space on to_object * ray (instance.cpp:181-189), then
+     * si.p = to_world * si.p, si.n = normalize(to_world * si.n), sh_frame.n likewise (:191-204).  `wp` / `wn` apply the detached transforms to attached values. */
+    const bool nested = pi.inst != 0xffffffffu;
+    const OrcInstance *in = nested ? &sc.instances[pi.inst] : nullptr;
+    auto wp = [&](const Dn3 &q) { if (!nested) return q; const float *M = in->to_world;
+        return Dn3(q.x * (double) M[0] + q.y * (double) M[3] + q.z * (double) M[6] + Dn((double) M[9]), q.x * (double) M[1] + q.y * (double) M[4] + q.z * (double) M[7] + Dn((double) M[10]),
+                   q.x * (double) M[2] + q.y * (double) M[5] + q.z * (double) M[8] + Dn((double) M[11])); };
+    auto wn = [&](const Dn3 &q) { if (!nested) return q; const float *T = in->to_object;          /* inverse transpose, then normalize */
+        return dnormalize(Dn3(q.x * (double) T[0] + q.y * (double) T[1] + q.z * (double) T[2], q.x * (double) T[3] + q.y * (double) T[4] + q.z * (double) T[5],
+                              q.x * (double) T[6] + q.y * (double) T[7] + q.z * (double) T[8])); };
+    V3 ro = ray.o, rd = ray.d;
+    if (nested) { ro = xf_point(in->to_object, ray.o); rd = xf_vector(in->to_object, ray.d); }
+    Dn3 nd = dvalue(n_geo);                                       // dr::detach(n) (object space for a nested mesh)
+    Dn3 o = dn3(ro), d = dn3(rd);
     Dn t_att = ddot(p_att - o, nd) / ddot(nd, d);
     Dn3 p_ray = o + d * t_att;                                    // ray(t)
-    a.p = replace_grad3(si.p.x, si.p.y, si.p.z, p_ray);
-    a.n = replace_grad3(si.n.x, si.n.y, si.n.z, n_geo);
+    a.p = replace_grad3(si.p.x, si.p.y, si.p.z, wp(p_ray));
+    a.n = replace_grad3(si.n.x, si.n.y, si.n.z, wn(n_geo));
     if (!shading) return a;
     // mesh.cpp:2308-2321: rel = si.p - p_att has a zero value, only its derivative matters
     Dn3 rel = replace_grad3(0.0, 0.0, 0.0, p_ray - p_att);
@@ -836,7 +849,7 @@ static AttachedSI attach_si(const Scene &sc, const Ray &ray, const PI &pi, const
             N[k] = Dn3(Dn::param(r[3], kNormalSlot + 3 * k), Dn::param(r[4], kNormalSlot + 3 * k + 1), Dn::param(r[5], kNormalSlot + 3 * k + 2));
         }
         Dn3 nn = N[0] + (N[1] - N[0]) * b1d + (N[2] - N[0]) * b2d;
-        a.sn = replace_grad3(si.sn.x, si.sn.y, si.sn.z, dnormalize(nn));
+        a.sn = replace_grad3(si.sn.x, si.sn.y, si.sn.z, nested ? wn(dnormalize(nn)) : dnormalize(nn));
         a.smooth = true;
     }
     if (m.flags & 2u) {
@@ -1560,6 +1573,30 @@ static int render_scalar(Scene &sc, const OrcSensor &s, uint32_t seed, uint32_t 
     return 0;
 }
 
+/* the BVH over the instances' world-space boxes (Instance::bbox, instance.cpp:93-103); rebuilt when a nested mesh or a transform changes */
+static void build_instance_bvh(Scene *sc) {
+    sc->inst_nodes.clear(); sc->inst_order.clear();
+    if (!sc->instances.empty()) {
+        std::vector<BuildPrim> prims;
+        for (uint32_t i = 0; i < sc->instances.size(); ++i) {
+            const Bvh &b = sc->group_bvh[sc->instances[i].group];
+            BuildPrim p; p.id = i;
+            for (int a = 0; a < 3; ++a) { p.lo[a] = Infinity; p.hi[a] = -Infinity; }
+            if (!b.empty())
+                for (int c = 0; c < 8; ++c) {
+                    V3 q = xf_point(sc->instances[i].to_world, V3(c & 1 ? b.hi[0] : b.lo[0], c & 2 ? b.hi[1] : b.lo[1], c & 4 ? b.hi[2] : b.lo[2]));
+                    for (int a = 0; a < 3; ++a) { p.lo[a] = std::min(p.lo[a], q[a]); p.hi[a] = std::max(p.hi[a], q[a]); }
+                }
+            pad_box(p.lo, p.hi);
+            for (int a = 0; a < 3; ++a) p.c[a] = 0.5f * (p.lo[a] + p.hi[a]);
+            prims.push_back(p);
+        }
+        sc->inst_nodes.emplace_back();
+        build_rec(sc->inst_nodes, prims, 0, (uint32_t) prims.size(), 0, 2);
+        for (auto &p : prims) sc->inst_order.push_back(p.id);
+    }
+}
+
 /* bounding sphere of the scene for the environment emitters; recomputed when vertex positions change */
 static void scene_update_bounds(Scene &sc) {
     if (sc.env >= 0) {                                 // ConstantBackgroundEmitter::set_scene (constant.cpp:72-87)
@@ -1650,25 +1687,7 @@ void *orc_scene_create(const OrcSceneDesc *d) {
     build_tri_bvh(sc->top, sc->meshes, 0, sc->top_count);
     sc->group_bvh.resize(sc->groups.size());
     for (size_t g = 0; g < sc->groups.size(); ++g) build_tri_bvh(sc->group_bvh[g], sc->meshes, sc->groups[g].first_mesh, sc->groups[g].mesh_count);
-    if (!sc->instances.empty()) {                      // Instance::bbox (instance.cpp:93-103)
-        std::vector<BuildPrim> prims;
-        for (uint32_t i = 0; i < sc->instances.size(); ++i) {
-            const Bvh &b = sc->group_bvh[sc->instances[i].group];
-            BuildPrim p; p.id = i;
-            for (int a = 0; a < 3; ++a) { p.lo[a] = Infinity; p.hi[a] = -Infinity; }
-            if (!b.empty())
-                for (int c = 0; c < 8; ++c) {
-                    V3 q = xf_point(sc->instances[i].to_world, V3(c & 1 ? b.hi[0] : b.lo[0], c & 2 ? b.hi[1] : b.lo[1], c & 4 ? b.hi[2] : b.lo[2]));
-                    for (int a = 0; a < 3; ++a) { p.lo[a] = std::min(p.lo[a], q[a]); p.hi[a] = std::max(p.hi[a], q[a]); }
-                }
-            pad_box(p.lo, p.hi);
-            for (int a = 0; a < 3; ++a) p.c[a] = 0.5f * (p.lo[a] + p.hi[a]);
-            prims.push_back(p);
-        }
-        sc->inst_nodes.emplace_back();
-        build_rec(sc->inst_nodes, prims, 0, (uint32_t) prims.size(), 0, 2);
-        for (auto &p : prims) sc->inst_order.push_back(p.id);
-    }
+    build_instance_bvh(sc);
     scene_update_bounds(*sc);
     return sc;
 }
@@ -1789,7 +1808,7 @@ static int prb_backward_impl(void *scene, const OrcSensor *sp, const float *grad
     if (pos_mask) {           /* flat-shaded top-level meshes */
         for (size_t m = 0; m < sc.meshes.size(); ++m) {
             if (!pos_mask[m]) continue;
-            if (m >= sc.top_count) return -3;
+            if (m >= sc.top_count && inst_mask) return -3;       /* instance.cpp:162-166: "Cannot differentiate instance parameters and shapegroup internal parameters at the same time!" */
         }
     }
     uint64_t total = sample_grid_pixels(s) * spp;
@@ -1958,11 +1977,16 @@ int orc_render_prb_backward_instances(void *scene, const OrcSensor *sp, const fl
 }
 void orc_scene_set_vertex_positions(void *scene, uint32_t mesh, const float *positions) {       /* + rebuild of the acceleration structure */
     Scene &sc = *(Scene *) scene;
-    if (mesh >= sc.top_count) return;
+    if (mesh >= sc.meshes.size()) return;
     Mesh &m = sc.meshes[mesh];
     for (uint32_t i = 0; i < m.nv; ++i) for (int c = 0; c < 3; ++c) m.V[8 * (size_t) i + c] = positions[3 * (size_t) i + c];
     if (m.flags & 1u) mesh_regenerate_normals(m);             /* mesh.cpp:876-878: writing the positions regenerates the vertex normals */
-    build_tri_bvh(sc.top, sc.meshes, 0, sc.top_count);
+    if (mesh < sc.top_count) build_tri_bvh(sc.top, sc.meshes, 0, sc.top_count);
+    else {                                                    /* a mesh inside a shape group: that group's BVH and the boxes of its instances */
+        for (size_t g = 0; g < sc.groups.size(); ++g)
+            if (mesh >= sc.groups[g].first_mesh && mesh < sc.groups[g].first_mesh + sc.groups[g].mesh_count) build_tri_bvh(sc.group_bvh[g], sc.meshes, sc.groups[g].first_mesh, sc.groups[g].mesh_count);
+        build_instance_bvh(&sc);
+    }
     scene_update_bounds(sc);
 }
 

@@ -332,6 +332,31 @@ def test_oracle_instance_gradient_vs_finite_differences(mi, O, variant):
             assert abs(fd - ad) <= 0.03 * abs(fd) + 0.005 * lift, (variant, i, label, fd, ad)
 
 
+@pytest.mark.parametrize("variant", ["plain", "roughplastic"])
+def test_oracle_nested_mesh_gradient_vs_finite_differences(mi, O, variant):
+    """vertex positions of a mesh INSIDE a shape group (shared by all its instances; the instances' to_world detached, instance.cpp:150-204): the nested surface
+    interaction is attached in object space and carried to the world by the detached transforms.  One quad instanced as floor and (turned over) as ceiling: lifting
+    its vertices raises the floor and lowers the ceiling at once; `bend` moves one corner only (both planes tilt and their normals change)"""
+    res = 12
+    scene = mi.load_dict(instanced_slab_scene(mi, res, model=None if variant == "plain" else variant))
+    osc, sensor = O.scene_from_product(scene)
+    m = scene.top_mesh_count                       # the shape group's only mesh
+    assert scene.meshes[m]["flags"] & 1 and len(scene.instances) == 2
+    base = scene.meshes[m]["V"][:, :3].astype(np.float32).copy()
+    osc.set_vertex_positions(m, base)              # (its stored normals are already the regenerated ones: a planar quad)
+    kw = dict(seed=7, spp=8192 if variant != "plain" else 2048, max_depth=4)
+    w = np.random.default_rng(2).uniform(0.5, 1.5, (res, res, 3)).astype(np.float32)
+    g_pos, _, _, _ = osc.render_prb_backward_shape(sensor, w, [m], **kw)
+    motions = {"lift": (np.tile([0, 1, 0], (4, 1)), 2e-3), "tilt": (np.array([[0, -1, 0], [0, 1, 0], [0, 1, 0], [0, -1, 0]]), 1e-3),
+               "bend": (np.array([[0, 1, 0], [0, 0, 0], [0, 0, 0], [0, 0, 0]]), 2e-3)}
+    lift = abs(float((g_pos[m] * motions["lift"][0]).sum()))
+    assert lift > 0
+    for label, (direction, eps) in motions.items():
+        fd = directional_fd(osc, sensor, m, base, direction.astype(np.float32), w, eps, **kw)
+        ad = float((g_pos[m] * direction).sum())
+        assert abs(fd - ad) <= 0.03 * abs(fd) + 0.01 * lift, (variant, label, fd, ad)
+
+
 def instanced_cbox_scene(mi, res=20, grid=2):
     """Cornell box (diffuse) + grid x grid rotated / scaled instances of a smooth-shaded, textured bumpy sphere and one instanced box: occluders,
     shadows, interreflection between instances, vertex normals and texcoords on the nested meshes, a twosided record"""
