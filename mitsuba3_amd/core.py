@@ -763,8 +763,9 @@ class EnvmapEmitter:
 
 
 class ShapeGroup:
-    def __init__(self, shapes):
+    def __init__(self, shapes, keys=None):
         self.shapes = shapes
+        self.keys = list(keys) if keys else [str(i) for i in range(len(shapes))]      # the children's names: '<group>.<child>' in mi.traverse, as in the reference
 
 
 class Instance:
@@ -1154,7 +1155,7 @@ class Scene:
             for i, m in enumerate(g.shapes):
                 if m.emitter is not None:
                     raise RuntimeError("Instancing of emitters is not supported")
-                self._add_mesh("%s.%d" % (key, i), m)
+                self._add_mesh("%s.%s" % (key, g.keys[i]), m)
             gindex[id(g)] = len(self.groups)
             self.groups.append((first, len(self.meshes) - first))
         for key, it in insts:
@@ -1554,15 +1555,15 @@ def _mk_scene(props, named, key):
 
 
 def _mk_shapegroup(props, named, key):
-    shapes = []
+    shapes = []; keys = []
     for k, v in props.items():
         if isinstance(v, dict) and 'type' in v:
             obj = _resolve(v, named, k)
             if isinstance(obj, Mesh):
-                shapes.append(obj)
+                shapes.append(obj); keys.append(k)
         elif isinstance(v, Mesh):
-            shapes.append(v)
-    g = ShapeGroup(shapes)
+            shapes.append(v); keys.append(k)
+    g = ShapeGroup(shapes, keys)
     if key:
         named[key] = g
     return g

@@ -140,7 +140,10 @@ HAR_HD void shape_triangle(const DScene &S, uint32_t shape, uint32_t prim, uint3
  * occluded; L = the radiance accumulator after this vertex's subtraction (prb.py:227); dl = the film adjoint; the next interaction (position / geometric
  * normal; next_valid = false for an escaped ray) is detached (prb.py:263-266).  Returns false when nothing contributes. */
 HAR_HD bool shape_item_adjoint(const DScene &S, const ShapeItem &it, bool self_on, bool prev_on, bool visible, Vec3 L, Vec3 dl,
-                               bool has_next, bool next_valid, Vec3 next_p, Vec3 next_n, Vec3 next_d, ShapeGrad &out) {
+                               bool has_next, bool next_valid, Vec3 next_p, Vec3 next_n, Vec3 next_d, ShapeGrad &out, bool self_nested = false, bool prev_nested = false) {
+    /* self_nested / prev_nested: the vertex lies on an INSTANCE and what moves is the nested mesh of its shape group (vertex positions shared by all instances,
+     * the instance's to_world detached -- instance.cpp:162-166 refuses both at once): the nested Mesh::compute_surface_interaction is attached in OBJECT space on
+     * to_object * ray (:181-189), then si.p = to_world * si.p, si.n / sh_frame.n = normalize(to_world * n) (:191-204) */
     out.self_mesh = out.self_inst = out.prev_mesh = out.prev_inst = out.self_normals = false;
     const bool depth0 = it.prev_shape == HAR_SHAPE_NONE;
     prev_on = prev_on && !depth0;
@@ -150,7 +153,8 @@ HAR_HD bool shape_item_adjoint(const DScene &S, const ShapeItem &it, bool self_o
     BsdfSide side; const bool side_ok = bsdf_side(S, M.bsdf, si.wi, side);
     const DBsdf B = S.bsdfs[side.index];
     TexTaps taps; const BsdfInputs bin = bsdf_inputs(S, B, si.uv_x, si.uv_y, taps);
-    const bool self_mesh = self_on && it.inst == HAR_SHAPE_NONE;       /* attached triangle: p, n, frame, uv; an attached instance moves p only */
+    const bool nested = self_on && self_nested && it.inst != HAR_SHAPE_NONE;
+    const bool self_mesh = self_on && (it.inst == HAR_SHAPE_NONE || nested);       /* attached triangle: p, n, frame, uv; an attached instance TRANSFORM moves p only */
     Vec3 rho_du(0.f), rho_dv(0.f);
     if (self_mesh && B.texture >= 0) tex_fetch_grad(S.textures[B.texture], taps, rho_du, rho_dv);
     SurfInt sp; Vec3 u_prev(0.f); float r_prev = 1.f;
@@ -204,14 +208,26 @@ HAR_HD bool shape_item_adjoint(const DScene &S, const ShapeItem &it, bool self_o
         v.has_uv = (M.flags & 2u) != 0u;
         if (v.has_uv) { v.duv0[0] = r[1][6] - r[0][6]; v.duv0[1] = r[1][7] - r[0][7]; v.duv1[0] = r[2][6] - r[0][6]; v.duv1[1] = r[2][7] - r[0][7]; }
         v.uv_bar[0] = uv_bar[0]; v.uv_bar[1] = uv_bar[1]; v.b_bar[0] = 0.f; v.b_bar[1] = 0.f;
-        const Vec3 sn_bar = n_bar + coordinate_system_adjoint(si.sn, s_bar, t_bar);          /* adjoint of the (unit) SHADING normal */
-        v.p_bar = p_bar; v.n_bar = sn_bar;
+        Vec3 sn_bar = n_bar + coordinate_system_adjoint(si.sn, s_bar, t_bar);          /* adjoint of the (unit) SHADING normal */
+        /* the unit shading normal in the MESH's space: the interpolated vertex normals, or the face normal */
+        const Vec3 n0(r[0][3], r[0][4], r[0][5]), n1(r[1][3], r[1][4], r[1][5]), n2(r[2][3], r[2][4], r[2][5]);
+        const Vec3 m = (M.flags & 1u) ? fma3(n1 - n0, it.b1, fma3(n2 - n0, it.b2, n0)) : cross3(v.p1 - v.p0, v.p2 - v.p0);
+        Vec3 sn_mesh = si.sn;
+        v.p_bar = p_bar;
+        if (nested) {
+            /* world <- object: p_w = A_w p_o + t, sn_w = normalize(A_o^T sn_o), d_o = A_o d_w  (A_w / A_o: linear parts of to_world / to_object) */
+            const DInst &I = S.insts[it.inst];
+            sn_mesh = normalize3(m);
+            const float scale = norm3(xf_normal(I.to_object, sn_mesh));
+            sn_bar = xf_vector(I.to_object, (sn_bar - si.sn * dot3(si.sn, sn_bar)) * rcp_(scale));
+            v.p_bar = xf_normal(I.to_world, p_bar);
+            v.d_in = xf_vector(I.to_object, it.d_in);
+        }
+        v.n_bar = sn_bar;
         if (M.flags & 1u) {
             /* mesh.cpp:2346-2356: sn = normalize(m), m = n0 + (n1 - n0) b1 + (n2 - n0) b2 over the attached barycentrics and the attached (regenerated) vertex
              * normals; the geometric normal no longer reaches any term */
-            const Vec3 n0(r[0][3], r[0][4], r[0][5]), n1(r[1][3], r[1][4], r[1][5]), n2(r[2][3], r[2][4], r[2][5]);
-            const Vec3 m = fma3(n1 - n0, it.b1, fma3(n2 - n0, it.b2, n0));
-            const Vec3 m_bar = (sn_bar - si.sn * dot3(si.sn, sn_bar)) * rcp_(norm3(m));
+            const Vec3 m_bar = (sn_bar - sn_mesh * dot3(sn_mesh, sn_bar)) * rcp_(norm3(m));
             out.gn[0] = m_bar * (1.f - it.b1 - it.b2); out.gn[1] = m_bar * it.b1; out.gn[2] = m_bar * it.b2;
             out.self_normals = true;
             v.b_bar[0] = dot3(m_bar, n1 - n0); v.b_bar[1] = dot3(m_bar, n2 - n0);
@@ -236,7 +252,14 @@ HAR_HD bool shape_item_adjoint(const DScene &S, const ShapeItem &it, bool self_o
         const float b0 = 1.f - it.prev_b1 - it.prev_b2;
         const Vec3 patt_bar = sp.n * (dot3(pprev_bar, it.prev_d) / dot3(sp.n, it.prev_d));
         if (it.prev_inst == HAR_SHAPE_NONE) { out.gp[0] = patt_bar * b0; out.gp[1] = patt_bar * it.prev_b1; out.gp[2] = patt_bar * it.prev_b2; out.prev_mesh = true; }
-        else {
+        else if (prev_nested) {
+            /* the nested mesh of the previous vertex's instance moves: p_w = to_world * ray_obj(t), t = <p_att - o, n_o> / <n_o, d_o> in object space */
+            const DInst &I = S.insts[it.prev_inst];
+            const Vec3 q0(r[0][0], r[0][1], r[0][2]), q1(r[1][0], r[1][1], r[1][2]), q2(r[2][0], r[2][1], r[2][2]);
+            const Vec3 n_o = cross3(q1 - q0, q2 - q0), d_o = xf_vector(I.to_object, it.prev_d);
+            const Vec3 po = n_o * (dot3(pprev_bar, it.prev_d) / dot3(n_o, d_o));
+            out.gp[0] = po * b0; out.gp[1] = po * it.prev_b1; out.gp[2] = po * it.prev_b2; out.prev_mesh = true;
+        } else {
             const float ph[4] = { r[0][0] * b0 + r[1][0] * it.prev_b1 + r[2][0] * it.prev_b2, r[0][1] * b0 + r[1][1] * it.prev_b1 + r[2][1] * it.prev_b2, r[0][2] * b0 + r[1][2] * it.prev_b1 + r[2][2] * it.prev_b2, 1.f };
             for (int c = 0; c < 4; ++c) { out.gpM[3 * c] = patt_bar.x * ph[c]; out.gpM[3 * c + 1] = patt_bar.y * ph[c]; out.gpM[3 * c + 2] = patt_bar.z * ph[c]; }
             out.prev_inst = true;

@@ -196,7 +196,7 @@ static int backward_shape_impl(void *h, const HarSensor *sensor, const float *ad
     int status = 0;
     /* meshes with vertex normals: first-stage adjoints of the vertex normals (3 per vertex), pushed through compute_normals after the lane loop */
     std::vector<std::vector<double>> nbar(H->hs.meshes.size());
-    if (grad) for (size_t m = 0; m < H->hs.top_mesh_count; ++m) if (grad[m] && (H->hs.meshes[m].flags & 1u)) nbar[m].assign(3 * (size_t) H->hs.meshes[m].vertex_count, 0.0);
+    if (grad) for (size_t m = 0; m < H->hs.meshes.size(); ++m) if (grad[m] && (H->hs.meshes[m].flags & 1u)) nbar[m].assign(3 * (size_t) H->hs.meshes[m].vertex_count, 0.0);
     for (uint64_t lane = 0; lane < total; ++lane) {
         LaneSample ls; const PathState st0 = raygen_lane(C, seed, spp, log_spp, (uint32_t) lane, ls);
         Footprint F; film_footprint(C, ls, F);
@@ -221,7 +221,9 @@ static int backward_shape_impl(void *h, const HarSensor *sensor, const float *ad
         PathState st = st0; bool alive = P.max_depth != 0;
         Hit hit; { HostStack stack; if (alive) accel_trace<false>(S.accel, st.o, st.d, st.maxt, hit, stack, status); }
         Hit prev; prev.t = HAR_INF; prev.shape = HAR_SHAPE_NONE; prev.prim = 0; prev.inst = HAR_SHAPE_NONE; prev.u = prev.v = 0.f; Vec3 prev_d(0.f);
-        auto moving = [&](uint32_t shape, uint32_t inst) { return shape != HAR_SHAPE_NONE && (inst == HAR_SHAPE_NONE ? (grad && grad[shape]) : inst_grad != nullptr); };
+        /* a vertex on an instance moves with the instance's to_world (inst_grad) or with the nested mesh of its shape group (grad[nested mesh]) */
+        auto nested_on = [&](uint32_t shape, uint32_t inst) { return shape != HAR_SHAPE_NONE && inst != HAR_SHAPE_NONE && grad && grad[shape]; };
+        auto moving = [&](uint32_t shape, uint32_t inst) { return shape != HAR_SHAPE_NONE && (inst == HAR_SHAPE_NONE ? (grad && grad[shape]) : (inst_grad != nullptr || nested_on(shape, inst))); };
         while (alive) {
             ShadeResult R; shade_lane<MODE_PRB_ADJOINT, HAR_BSDF_ALL_TYPES>(S, P, st, hit, R);
             if (R.add_emission) L = L - R.em_b;
@@ -242,7 +244,7 @@ static int backward_shape_impl(void *h, const HarSensor *sensor, const float *ad
                 const SurfInt si = compute_si(S, st.d, hit.t, hit.u, hit.v, hit.prim, hit.shape, hit.inst);
                 it.w_em = (it.nee_flags & HAR_SHAPE_NEE_SURFACE) ? normalize3(it.q - si.p) : it.q;
                 ShapeGrad G;
-                if (shape_item_adjoint(S, it, self_on, prev_on, visible, L, dl, R.alive, next_valid, np, nn, R.next.d, G)) {
+                if (shape_item_adjoint(S, it, self_on, prev_on, visible, L, dl, R.alive, next_valid, np, nn, R.next.d, G, nested_on(hit.shape, hit.inst), nested_on(prev.shape, prev.inst))) {
                     if (G.self_mesh) { double *dst = grad[hit.shape]; for (int k = 0; k < 3; ++k) { dst[3 * (size_t) G.vid[k]] += G.g[k].x; dst[3 * (size_t) G.vid[k] + 1] += G.g[k].y; dst[3 * (size_t) G.vid[k] + 2] += G.g[k].z; } }
                     if (G.self_normals && !nbar[hit.shape].empty()) { double *dst = nbar[hit.shape].data(); for (int k = 0; k < 3; ++k) { dst[3 * (size_t) G.vid[k]] += G.gn[k].x; dst[3 * (size_t) G.vid[k] + 1] += G.gn[k].y; dst[3 * (size_t) G.vid[k] + 2] += G.gn[k].z; } }
                     if (G.self_inst) for (int k = 0; k < 12; ++k) inst_grad[12 * (size_t) hit.inst + k] += G.gM[k];

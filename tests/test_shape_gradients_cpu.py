@@ -271,6 +271,18 @@ def instanced_slab_scene(mi, res=24, env=False, model=None):
     return d
 
 
+def instanced_smooth_scene(mi, res=24, model=None):
+    """the smooth-shaded bumpy floor of smooth_slab_scene as the mesh of a SHAPE GROUP, instanced once as the floor (rotated about y, slightly anisotropic scale) and
+    once, turned over and lifted, as the ceiling: nested vertex normals, texcoords, a non-rigid instance transform"""
+    T = mi.ScalarTransform4f
+    d = smooth_slab_scene(mi, res, model=model)
+    mesh = d.pop("floor"); d.pop("ceiling", None)
+    d["group"] = {"type": "shapegroup", "grid": mesh}
+    d["floor"] = {"type": "instance", "to_world": T().translate([0.1, 0.0, -0.1]).rotate([0, 1, 0], 20.0).scale([1.0, 1.2, 0.9]), "group": {"type": "ref", "id": "group"}}
+    d["ceiling"] = {"type": "instance", "to_world": T().translate([0, 3.0, 0]).rotate([1, 0, 0], 180.0).rotate([0, 1, 0], -10.0), "group": {"type": "ref", "id": "group"}}
+    return d
+
+
 def set_instance_matrix(scene, i, m4):
     """host-side scene description only: (group, to_world, to_object) column-major 3x4"""
     m = np.asarray(m4, np.float64).reshape(4, 4); inv = np.linalg.inv(m)
@@ -332,23 +344,27 @@ def test_oracle_instance_gradient_vs_finite_differences(mi, O, variant):
             assert abs(fd - ad) <= 0.03 * abs(fd) + 0.005 * lift, (variant, i, label, fd, ad)
 
 
-@pytest.mark.parametrize("variant", ["plain", "roughplastic"])
+@pytest.mark.parametrize("variant", ["plain", "roughplastic", "smooth"])
 def test_oracle_nested_mesh_gradient_vs_finite_differences(mi, O, variant):
     """vertex positions of a mesh INSIDE a shape group (shared by all its instances; the instances' to_world detached, instance.cpp:150-204): the nested surface
     interaction is attached in object space and carried to the world by the detached transforms.  One quad instanced as floor and (turned over) as ceiling: lifting
     its vertices raises the floor and lowers the ceiling at once; `bend` moves one corner only (both planes tilt and their normals change)"""
     res = 12
-    scene = mi.load_dict(instanced_slab_scene(mi, res, model=None if variant == "plain" else variant))
+    scene = mi.load_dict(instanced_smooth_scene(mi, res) if variant == "smooth" else instanced_slab_scene(mi, res, model=None if variant == "plain" else variant))
     osc, sensor = O.scene_from_product(scene)
     m = scene.top_mesh_count                       # the shape group's only mesh
     assert scene.meshes[m]["flags"] & 1 and len(scene.instances) == 2
     base = scene.meshes[m]["V"][:, :3].astype(np.float32).copy()
-    osc.set_vertex_positions(m, base)              # (its stored normals are already the regenerated ones: a planar quad)
-    kw = dict(seed=7, spp=8192 if variant != "plain" else 2048, max_depth=4)
+    osc.set_vertex_positions(m, base)              # (the planar quad's stored normals are already the regenerated ones)
+    kw = dict(seed=7, spp=2048 if variant == "plain" else 8192, max_depth=4)
     w = np.random.default_rng(2).uniform(0.5, 1.5, (res, res, 3)).astype(np.float32)
     g_pos, _, _, _ = osc.render_prb_backward_shape(sensor, w, [m], **kw)
-    motions = {"lift": (np.tile([0, 1, 0], (4, 1)), 2e-3), "tilt": (np.array([[0, -1, 0], [0, 1, 0], [0, 1, 0], [0, -1, 0]]), 1e-3),
-               "bend": (np.array([[0, 1, 0], [0, 0, 0], [0, 0, 0], [0, 0, 0]]), 2e-3)}
+    if variant == "smooth":                        # the bumpy grid: rigid lift (object space) and a smooth non-rigid bump that changes the nested vertex normals
+        r2 = base[:, 0] ** 2 + base[:, 2] ** 2
+        motions = {"lift": (np.tile([0, 1, 0], (len(base), 1)), 2e-3), "bump": (np.stack([np.zeros(len(base)), np.exp(-r2 / 2.0), np.zeros(len(base))], -1), 5e-3)}
+    else:
+        motions = {"lift": (np.tile([0, 1, 0], (4, 1)), 2e-3), "tilt": (np.array([[0, -1, 0], [0, 1, 0], [0, 1, 0], [0, -1, 0]]), 1e-3),
+                   "bend": (np.array([[0, 1, 0], [0, 0, 0], [0, 0, 0], [0, 0, 0]]), 2e-3)}
     lift = abs(float((g_pos[m] * motions["lift"][0]).sum()))
     assert lift > 0
     for label, (direction, eps) in motions.items():
@@ -368,6 +384,31 @@ def instanced_cbox_scene(mi, res=20, grid=2):
     d["boxes"] = {"type": "shapegroup", "b": {"type": "mesh", "positions": cube.V[:, :3].copy(), "faces": cube.F[:, :3].copy(), "bsdf": {"type": "ref", "id": "green"}}}
     d["box0"] = {"type": "instance", "to_world": T().translate([0.3, -0.7, 0.3]).rotate([0, 1, 0], -17).scale(0.25), "group": {"type": "ref", "id": "boxes"}}
     return d
+
+
+@pytest.mark.parametrize("which", ["slab", "slab_roughplastic", "cbox_boxes", "smooth", "smooth_roughplastic"])
+def test_product_host_nested_mesh_adjoint_matches_oracle(mi, O, which):
+    """vertex positions of meshes INSIDE shape groups (har_shape_grad.h `self_nested` / `prev_nested`): the host build of the product's adjoint against the oracle, vertex
+    by vertex -- a planar quad instanced twice, the instanced box of the Cornell scene (flat-shaded nested mesh, twosided), and a smooth-shaded bumpy grid instanced
+    twice under non-rigid transforms (nested vertex normals: both stages of the normal derivative run in object space)"""
+    if which.startswith("cbox"):
+        res = 20; scene = mi.load_dict(instanced_cbox_scene(mi, res)); key = "boxes.b"
+    elif which.startswith("smooth"):
+        res = 16; scene = mi.load_dict(instanced_smooth_scene(mi, res, model=which[7:] or None)); key = "group.grid"
+    else:
+        res = 16; scene = mi.load_dict(instanced_slab_scene(mi, res, model=which[5:] or None)); key = "group.quad"
+    m = [i for i, x in enumerate(scene.meshes) if x["key"] == key]
+    assert len(m) == 1 and m[0] >= scene.top_mesh_count, [x["key"] for x in scene.meshes]
+    m = m[0]
+    if scene.meshes[m]["flags"] & 1:
+        scene._set_vertex_positions(m, scene.meshes[m]["V"][:, :3].copy())          # regenerated normals (the spheres come with analytic ones)
+    osc, sensor = O.scene_from_product(scene)
+    w = np.random.default_rng(4).uniform(0.5, 1.5, (res, res, 3)).astype(np.float32)
+    kw = dict(seed=3, spp=16, max_depth=5)
+    want, _, _, _ = osc.render_prb_backward_shape(sensor, w, [m], **kw)
+    got = product_host_gradients(O, harness(O), scene, sensor, w, [m], **kw)
+    scale = np.abs(want[m]).max()
+    assert scale > 0 and np.abs(got[m] - want[m]).max() < 2e-3 * scale, (which, np.abs(got[m] - want[m]).max() / scale)
 
 
 @pytest.mark.parametrize("which", ["slab", "slab_env", "cbox", "slab_roughplastic", "slab_roughconductor", "slab_plastic"])
