@@ -295,10 +295,12 @@ int har_integrator_set_grad_emitters(HarIntegrator integrator, float *grad_emitt
  * (src/python/python/ad/integrators/prb.py:124-141 attached surface interaction -- Mesh::compute_surface_interaction with AD-attached
  * vertices, src/render/mesh.cpp:2286-2323, and SurfaceInteraction::attach_motion, include/mitsuba/render/interaction.h:525-545 --,
  * :176-216 emitter sampling from the attached point, :261-297 attached outgoing direction and solid_angle_to_area_jacobian,
- * ad/integrators/common.py:1355-1384).  `grad_positions` = HOST array of top_mesh_count DEVICE pointers; entry m (vertex_count x 3 floats)
- * makes mesh m differentiable, NULL entries do not; har_render_backward then also accumulates into those buffers.  A NULL array switches the
+ * ad/integrators/common.py:1355-1384).  `grad_positions` = HOST array of mesh_count DEVICE pointers (HarSceneDesc::meshes: the top-level meshes,
+ * then the meshes of the shape groups); entry m (vertex_count x 3 floats) makes mesh m differentiable, NULL entries do not; har_render_backward then also accumulates into those buffers.  A NULL array switches the
  * feature off.  Like `prb` itself this has no visibility-boundary term (that is prb_reparam / the projective integrators).
- * The differentiated meshes are top-level -- flat-shaded, or with the vertex normals a position update regenerates (Mesh::compute_normals, mesh.cpp:876-878,
+ * A mesh INSIDE a shape group moves all its instances at once (object-space positions; Instance::compute_surface_interaction with a detached to_world,
+ * src/shapes/instance.cpp:150-204); like the reference (:162-166) this cannot be combined with har_integrator_set_grad_instances.
+ * The differentiated meshes are flat-shaded, or carry the vertex normals a position update regenerates (Mesh::compute_normals, mesh.cpp:876-878,
  * 1216-1267: the gradient then runs through the interpolated normal and the angle-weighted normal sums of the whole one-ring) -- and carry a BSDF with a non-delta lobe (diffuse, roughconductor, roughplastic, plastic; plain
  * or inside `twosided`) -- the attached si.wi / wo reach the BSDF value (prb.py:128-140, 276-288); the other meshes of the scene may carry any BSDF.  Fails otherwise.
  * New vertex positions are installed by creating a new scene (har_scene_create), which rebuilds the acceleration structure. */

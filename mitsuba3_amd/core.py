@@ -971,7 +971,11 @@ class Integrator:
                 wanted = {k: keys[k] for k in self.shape_gradients if k not in ikeys}    # KeyError: not a differentiable mesh / instance
             g_pos = {k: torch.zeros(3 * scene.meshes[m]["V"].shape[0], dtype=torch.float32, device=dev) for k, m in wanted.items()}
             by_mesh = {wanted[k]: g for k, g in g_pos.items()}
-            pp = (C.c_void_p * max(1, scene.top_mesh_count))(*[by_mesh[m].data_ptr() if m in by_mesh else None for m in range(scene.top_mesh_count)])
+            pp = (C.c_void_p * max(1, len(scene.meshes)))(*[by_mesh[m].data_ptr() if m in by_mesh else None for m in range(len(scene.meshes))])
+            # what the previous call left on must not veto this call's selection (nested vertex positions and instance transforms exclude each other)
+            check(lib().har_integrator_set_grad_positions(self._handle(), None, None))
+            if not inst_wanted:
+                check(lib().har_integrator_set_grad_instances(self._handle(), None, None))
             check(lib().har_integrator_set_grad_positions(self._handle(), scene._handle(), pp if g_pos else None))
             if inst_wanted:
                 g_inst = torch.zeros((len(scene.instances), 12), dtype=torch.float32, device=dev)
@@ -1357,9 +1361,10 @@ class Scene:
             lib().har_scene_destroy(self._h); self._h = None
 
     def _position_keys(self):
-        """'<shape>.vertex_positions' (flat 3 N floats as in the reference's Mesh::traverse) of the top-level meshes; writing them regenerates the vertex normals of
-        a smooth-shaded mesh (mesh.cpp:876-878), see _set_vertex_positions"""
-        return {m["key"] + ".vertex_positions": i for i, m in enumerate(self.meshes[:self.top_mesh_count]) if m["V"].shape[0]}
+        """'<shape>.vertex_positions' (flat 3 N floats as in the reference's Mesh::traverse) of the top-level meshes and, as '<group>.<child>.vertex_positions', of the
+        meshes inside shape groups (object space, shared by all instances); writing them regenerates the vertex normals of a smooth-shaded mesh (mesh.cpp:876-878),
+        see _set_vertex_positions"""
+        return {m["key"] + ".vertex_positions": i for i, m in enumerate(self.meshes) if m["V"].shape[0]}
 
     def _bsdf_has_smooth_lobe(self, index):
         """BSDFFlags::Smooth on every side: models made of delta lobes only (`dielectric`, `conductor`) cannot sit on MOVING geometry -- their eval() is zero,
@@ -1376,6 +1381,8 @@ class Scene:
         out = {}
         for k, i in self._position_keys().items():
             m = self.meshes[i]
+            if i >= self.top_mesh_count:         # nested meshes exclude the instances' to_world (instance.cpp:162-166): only when named explicitly
+                continue
             if not self._bsdf_has_smooth_lobe(m["bsdf"]):
                 continue
             if m["flags"] & 1:

@@ -1279,9 +1279,10 @@ int har_integrator_set_grad_positions(HarIntegrator I, HarScene S, float *const 
         if (S->ds.bsdf_types & HAR_SCENE_ENVMAP) return fail("vertex-position gradients are not implemented for scenes with an environment map or a mesh area light");
         const size_t nm = S->hs.meshes.size();
         offset.assign(nm, -1); user.assign(nm, nullptr); count.assign(nm, 0);
-        for (size_t m = 0; m < S->hs.top_mesh_count; ++m) {
+        for (size_t m = 0; m < nm; ++m) {          /* top-level meshes, then the meshes of the shape groups (vertex positions shared by all their instances) */
             if (!grad_positions[m]) continue;
             const DMesh &M = S->hs.meshes[m];
+            if (m >= S->hs.top_mesh_count && I->inst_count) return fail("Cannot differentiate instance parameters and shapegroup internal parameters at the same time!");      /* instance.cpp:162-166 */
             if (M.flags & 1u) {
                 /* a position update regenerates the vertex normals (mesh.cpp:876-878 -> compute_normals): the gradient is that of the REGENERATED normals, so the
                  * mesh must carry them -- stored normals of another origin (file, analytic) would render one surface and differentiate another */
@@ -1317,6 +1318,8 @@ int har_integrator_set_grad_instances(HarIntegrator I, HarScene S, float *grad_t
             if (!record_has_smooth_lobe(S->hs, S->hs.meshes[m].bsdf)) return fail("instance to_world gradients: an instanced mesh cannot carry a BSDF made of delta lobes only (`dielectric`, `conductor`); top-level meshes may");
         n = (uint32_t) S->hs.insts.size();
         if (n == 0) return fail("the scene has no instances");
+        for (size_t m = S->hs.top_mesh_count; m < I->pos_offset.size(); ++m)
+            if (I->pos_offset[m] >= 0) return fail("Cannot differentiate instance parameters and shapegroup internal parameters at the same time!");      /* instance.cpp:162-166 */
         if (n >= (1u << (32 - HAR_SHAPE_INST_SHIFT)) - 1u) return fail("too many instances for the adjoint's geometry records");
     }
     if (n != I->inst_count) { (void) hipDeviceSynchronize(); I->free_ws(); }      /* the geometry records and the slot table are part of the adjoint workspace */

@@ -1202,7 +1202,11 @@ __global__ __launch_bounds__(kBlock) void k_shape_adjoint(DScene S, const uint32
         it.inst = (__float_as_uint(g2.w) >> HAR_SHAPE_INST_SHIFT) - 1u;       /* 0xffffffff: top-level geometry */
         it.prev_shape = __float_as_uint(g5.x); it.prev_prim = __float_as_uint(g5.y); it.prev_b1 = g5.z; it.prev_b2 = g5.w;
         it.prev_d = Vec3(g6.x, g6.y, g6.z); it.prev_inst = __float_as_uint(g6.w);
-        const int32_t off = target(it.shape, it.inst), poff = target(it.prev_shape, it.prev_inst);
+        /* a vertex on an instance moves with the instance's to_world (inst_slot) or with the NESTED MESH of its shape group (offset[nested mesh]); never both
+         * (har_integrator_set_grad_positions / _instances refuse the combination, as instance.cpp:162-166 does) */
+        auto nested = [&](uint32_t shape, uint32_t inst) -> int32_t { return (shape != 0xffffffffu && inst != 0xffffffffu && T.offset) ? T.offset[shape] : -1; };
+        const int32_t noff = nested(it.shape, it.inst), npoff = nested(it.prev_shape, it.prev_inst);
+        const int32_t off = noff >= 0 ? noff : target(it.shape, it.inst), poff = npoff >= 0 ? npoff : target(it.prev_shape, it.prev_inst);
         if (off < 0 && poff < 0) continue;
         const float4 g1 = geo.g1[i], g3 = geo.g3[i], g4 = geo.g4[i];
         it.d_in = Vec3(g1.x, g1.y, g1.z); it.next_slot = __float_as_uint(g1.w);
@@ -1224,7 +1228,7 @@ __global__ __launch_bounds__(kBlock) void k_shape_adjoint(DScene S, const uint32
         it.w_em = it.q;
         if (it.nee_flags & HAR_SHAPE_NEE_SURFACE) { const SurfInt si = compute_si(S, it.d_in, 0.f, it.b1, it.b2, it.prim, it.shape, it.inst); it.w_em = normalize3(it.q - si.p); }
         ShapeGrad G;
-        if (!shape_item_adjoint(S, it, off >= 0, poff >= 0, geo.vis[i] != 0, Vec3(L4.x, L4.y, L4.z), Vec3(dl4.x, dl4.y, dl4.z), nxt, next_valid, np, nn, nd, G)) continue;
+        if (!shape_item_adjoint(S, it, off >= 0, poff >= 0, geo.vis[i] != 0, Vec3(L4.x, L4.y, L4.z), Vec3(dl4.x, dl4.y, dl4.z), nxt, next_valid, np, nn, nd, G, noff >= 0, npoff >= 0)) continue;
         if (G.self_mesh) add_verts(off, G.vid, G.g);
         if (G.self_normals && T.grad_nrm)
             for (int k = 0; k < 3; ++k) { float *q = T.grad_nrm + 3u * ((uint32_t) off + G.vid[k]); atomicAdd(q, G.gn[k].x); atomicAdd(q + 1, G.gn[k].y); atomicAdd(q + 2, G.gn[k].z); }

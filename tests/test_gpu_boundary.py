@@ -333,6 +333,49 @@ def test_prb_instance_to_world_gradients(mi, O, which):
     assert not any(k.endswith("to_world") for k in plain)
 
 
+@pytest.mark.parametrize("which", ["slab", "slab_roughplastic", "cbox_boxes", "smooth", "smooth_roughplastic"])
+def test_prb_nested_mesh_vertex_position_gradients(mi, O, which):
+    """'<group>.<child>.vertex_positions': vertex positions of a mesh INSIDE a shape group, shared by all its instances (Instance::compute_surface_interaction with a
+    detached to_world, instance.cpp:150-204): the kernels (geometry records carrying the instance, k_shape_adjoint in object space, k_normals_adjoint for nested vertex
+    normals) vs the oracle, vertex by vertex; combining them with instance transforms is refused like in the reference (:162-166); an update moves every instance"""
+    from tests.test_shape_gradients_cpu import instanced_slab_scene, instanced_cbox_scene, instanced_smooth_scene
+    if which.startswith("cbox"):
+        res = 32; d = instanced_cbox_scene(mi, res); key = "boxes.b"
+    elif which.startswith("smooth"):
+        res = 24; d = instanced_smooth_scene(mi, res, model=which[7:] or None); key = "group.grid"
+    else:
+        res = 24; d = instanced_slab_scene(mi, res, model=which[5:] or None); key = "group.quad"
+    d["integrator"] = {"type": "prb", "max_depth": 5, "shape_gradients": [key + ".vertex_positions"]}
+    scene = mi.load_dict(d)
+    m = [i for i, x in enumerate(scene.meshes) if x["key"] == key][0]
+    assert m >= scene.top_mesh_count
+    params = mi.traverse(scene)
+    if scene.meshes[m]["flags"] & 1:
+        params[key + ".vertex_positions"] = params[key + ".vertex_positions"].clone(); params.update()
+    osc, sensor = O.scene_from_product(scene)
+    grad_in = np.random.default_rng(4).uniform(0.5, 1.5, (res, res, 3)).astype(np.float32)
+    integ = scene.integrator()
+    grads = integ.render_backward(scene, None, grad_in, seed=3, spp=16)
+    want, w_refl, _, _ = osc.render_prb_backward_shape(sensor, grad_in, [m], seed=3, spp=16, max_depth=5)
+    got = grads[key + ".vertex_positions"].cpu().numpy().reshape(-1, 3)
+    scale = np.abs(want[m]).max()
+    assert scale > 0 and np.abs(got - want[m]).max() < 2e-3 * scale, (which, np.abs(got - want[m]).max() / scale)
+    inst_key = [k for k in params.keys() if k.endswith(".to_world")][0]
+    integ.shape_gradients = [key + ".vertex_positions", inst_key]
+    with pytest.raises(RuntimeError, match="at the same time"):
+        integ.render_backward(scene, None, grad_in, seed=3, spp=16)
+    integ.shape_gradients = [inst_key]                  # and the other way round on the same integrator: the earlier selection does not linger
+    assert inst_key in integ.render_backward(scene, None, grad_in, seed=3, spp=16)
+    integ.shape_gradients = False
+    before = mi.render(scene, spp=8, seed=1).cpu().numpy()
+    p = params[key + ".vertex_positions"].clone().reshape(-1, 3); p[:, 1] += 0.15
+    params[key + ".vertex_positions"] = p.reshape(-1); params.update()
+    after = mi.render(scene, spp=8, seed=1).cpu().numpy()
+    osc2, sensor2 = O.scene_from_product(scene)
+    ref, _ = osc2.render_prb(sensor2, seed=1, spp=8, max_depth=5)
+    assert rel_l2(after, ref) < 1e-4 and rel_l2(after, before) > 1e-3
+
+
 def test_instance_to_world_update_and_domain(mi, O):
     """params['<instance>.to_world'] = ...; params.update(): the next render sees the moved instance (== the oracle on the updated scene);
     purely specular instanced meshes are refused"""
