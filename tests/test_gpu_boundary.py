@@ -368,7 +368,7 @@ def test_prb_nested_mesh_vertex_position_gradients(mi, O, which):
     assert inst_key in integ.render_backward(scene, None, grad_in, seed=3, spp=16)
     integ.shape_gradients = False
     before = mi.render(scene, spp=8, seed=1).cpu().numpy()
-    p = params[key + ".vertex_positions"].clone().reshape(-1, 3); p[:, 1] += 0.04           # (the ceiling instance is turned over: it comes DOWN by the same amount and must stay above the light)
+    p = params[key + ".vertex_positions"].clone().reshape(-1, 3); p[:, 1] -= 0.04           # (object space: the floor sinks, the turned-over ceiling instance RISES by the same amount and stays above the light)
     params[key + ".vertex_positions"] = p.reshape(-1); params.update()
     after = mi.render(scene, spp=8, seed=1).cpu().numpy()
     osc2, sensor2 = O.scene_from_product(scene)
