@@ -174,6 +174,7 @@ struct HarIntegratorImpl {
     int32_t *d_pos_offset = nullptr; float *grad_pos = nullptr; uint32_t pos_verts = 0; ShapeArrays geo{};
     /* differentiated meshes WITH vertex normals: adjoints of the vertex normals and scratch for the normal sums, laid out like grad_pos (har_shape_grad.h) */
     bool pos_smooth = false; float *grad_nrm = nullptr, *nrm_acc = nullptr;
+    uint64_t pos_checked_scene = 0; std::vector<uint8_t> pos_checked;      /* meshes of scene `pos_checked_scene` whose normals were found to be the regenerated ones */
     /* instance to_world gradients (har_integrator_set_grad_instances): user buffer (DEVICE, instance_count x 12), per-instance slot table, accumulation buffer */
     float *inst_user = nullptr; uint32_t inst_count = 0; int32_t *d_inst_slot = nullptr; float *grad_inst = nullptr;
     bool material_queues = false;         /* har_integrator_set_material_queues */
@@ -1283,7 +1284,9 @@ int har_integrator_set_grad_positions(HarIntegrator I, HarScene S, float *const 
             if (!grad_positions[m]) continue;
             const DMesh &M = S->hs.meshes[m];
             if (m >= S->hs.top_mesh_count && I->inst_count) return fail("Cannot differentiate instance parameters and shapegroup internal parameters at the same time!");      /* instance.cpp:162-166 */
-            if (M.flags & 1u) {
+            const bool known = I->pos_checked_scene == S->serial && m < I->pos_checked.size() && I->pos_checked[m];      /* an optimisation loop calls this every step */
+            if ((M.flags & 1u) && known) smooth = true;
+            else if (M.flags & 1u) {
                 /* a position update regenerates the vertex normals (mesh.cpp:876-878 -> compute_normals): the gradient is that of the REGENERATED normals, so the
                  * mesh must carry them -- stored normals of another origin (file, analytic) would render one surface and differentiate another */
                 std::vector<float> copy(S->hs.verts.begin() + 8 * (size_t) M.voff, S->hs.verts.begin() + 8 * (size_t) (M.voff + M.vertex_count));
@@ -1292,6 +1295,8 @@ int har_integrator_set_grad_positions(HarIntegrator I, HarScene S, float *const 
                 for (size_t v = 0; v < M.vertex_count; ++v) for (int c = 3; c < 6; ++c) worst = std::max(worst, std::fabs(copy[8 * v + c] - S->hs.verts[8 * ((size_t) M.voff + v) + c]));
                 if (worst > 1e-4f) return fail("vertex-position gradients of a mesh with vertex normals: its normals are not the ones a position update regenerates (Mesh::compute_normals, mesh.cpp:876-878); write the positions once (params.update()) or regenerate the normals first");
                 smooth = true;
+                if (I->pos_checked_scene != S->serial) { I->pos_checked_scene = S->serial; I->pos_checked.assign(nm, 0); }
+                I->pos_checked[m] = 1;
             }
             if (!record_has_smooth_lobe(S->hs, M.bsdf)) return fail("vertex-position gradients: a differentiated mesh cannot carry a BSDF made of delta lobes only (`dielectric`, `conductor`); other meshes of the scene may");
             offset[m] = (int32_t) verts; user[m] = grad_positions[m]; count[m] = M.vertex_count; verts += M.vertex_count;
