@@ -303,7 +303,9 @@ def test_oracle_instance_gradient_vs_finite_differences(mi, O, variant):
     res = 12
     scene = mi.load_dict(instanced_slab_scene(mi, res, env=variant == "env", model=variant if variant.startswith("rough") else None))
     osc, sensor = O.scene_from_product(scene)
-    kw = dict(seed=7, spp=4096 if variant.startswith("rough") else 1024, max_depth=4, threads=1)      # one thread: the float32 film sums are then reproducible, the differences below are of 1e-4 steps
+    # plain / env: one thread -- the float32 film sums are then reproducible, and the tilt below is a difference of 1e-3 steps.  The glossy variants only check lift and
+    # spin (2e-3 / 1e-2 steps): the summation-order noise of a threaded render (~1e-6 of the loss) is far below their tolerance
+    kw = dict(seed=7, spp=4096 if variant.startswith("rough") else 1024, max_depth=4, threads=0 if variant.startswith("rough") else 1)
     w = np.random.default_rng(2).uniform(0.5, 1.5, (res, res, 3)).astype(np.float32)
     g, _, _, _ = osc.render_prb_backward_instances(sensor, w, None, **kw)
     assert g.shape == (len(scene.instances), 3, 4)
