@@ -602,8 +602,17 @@ int run_chunk(HarSceneImpl *S, HarIntegratorImpl *I, const DSensor &C, int mode,
             launch_resolve(mode, I->aux_stream, tgrid, spill, S->ds, cnt_items(I, b), cur_resolve(I, b), I->shard_cap, I->items, I->result, I->dL, grad_refl, I->d_grad_tex, I->status, rc, nullptr, 0);
             HIP_TRY(hipEventRecord(I->ev_resolved, I->aux_stream));
             resolve_pending = true;
-        } else if (!(inline_commit && cached)) launch_resolve(mode, s, rc.mode == 2 ? grid : tgrid, spill, S->ds, cnt_items(I, b), cur_resolve(I, b), I->shard_cap, I->items, I->result, I->dL, grad_refl, I->d_grad_tex, I->status, rc,
-                       shape ? I->geo.vis : nullptr, fwd ? 1 : 0);
+        } else if (!(inline_commit && cached)) {
+            /* adjoint items of a cached bounce (the path vertex-position gradients take): texel gradients through the band queues, as in the in-place commit */
+            const bool item_queued = mode == MODE_PRB_ADJOINT && rc.mode == 2 && !fwd && I->tq.nq != 0;
+            if (item_queued) HIP_TRY(hipMemsetAsync(I->tq.count, 0, (size_t) (HAR_SHARDS * I->tq.nq + 1) * HAR_COUNTER_STRIDE * sizeof(uint32_t), s));
+            launch_resolve(mode, s, rc.mode == 2 ? grid : tgrid, spill, S->ds, cnt_items(I, b), cur_resolve(I, b), I->shard_cap, I->items, I->result, I->dL, grad_refl, I->d_grad_tex, I->status, rc,
+                           shape ? I->geo.vis : nullptr, fwd ? 1 : 0, item_queued ? &I->tq : nullptr);
+            if (item_queued) {
+                static const uint32_t bpq_env2 = getenv("HAR_TQ_BPQ") ? (uint32_t) atoi(getenv("HAR_TQ_BPQ")) : 0u;
+                launch_texel_accumulate(s, I->tq, I->d_grad_tex, bpq_env2 ? bpq_env2 : (n > (1u << 22) ? 4u : 1u), I->tq_lds);
+            }
+        }
         prof_mark(I, s, CLS_RESOLVE);
         cur ^= 1;
         if (b >= 15 && (b & 7) == 7) {           /* deep paths are rare: poll so that max_depth = -1 terminates */

@@ -148,7 +148,7 @@ void launch_classify(hipStream_t s, uint32_t grid, const DScene &S, uint32_t sha
 void launch_texel_accumulate(hipStream_t s, const TexelQueues &tq, float *const *grad_tex, uint32_t blocks_per_queue, uint32_t lds_bytes);
 void launch_resolve(int mode, hipStream_t s, uint32_t grid, uint2 *spill, const DScene &S, const uint32_t *item_count, uint32_t *cursor, uint32_t shard_cap, const ItemArrays &items,
                     float4 *result, const float4 *dL, float *grad_refl, float *const *grad_tex, int *status, const ReplayCache &rc, uint8_t *item_vis = nullptr,
-                    int fwd = 0);      /* fwd: forward mode (render_forward) -- grad_refl / grad_tex are the parameters' tangents, dL accumulates */
+                    int fwd = 0, const TexelQueues *tq = nullptr);      /* tq: the cached adjoint resolve files texel gradients in the band queues; fwd: forward mode (render_forward) -- grad_refl / grad_tex are the parameters' tangents, dL accumulates */
 /* hide_emitters: one round of Integrator::skip_area_emitters over the camera-ray hits (first = 1: scan h0 / h1 of the wavefront `ray_o / ray_d`;
  * first = 0: commit the re-traced hits `hit0 / hit1` of the continuation list `ray_o / ray_d`); continuation rays are appended to `dst_*` */
 void launch_skip_emitters(hipStream_t s, uint32_t grid, const DScene &S, int first, uint32_t shard_cap, const uint32_t *count_in, const float4 *ray_o, const float4 *ray_d,

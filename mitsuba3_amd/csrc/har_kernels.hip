@@ -593,13 +593,35 @@ __device__ __forceinline__ void texel_record_direct(const DScene &S, float *cons
     }
     for (int k = 0; k < 4; ++k) wave_aggregated_add3(active ? dst + 3 * (size_t) idx[k] : dummy, active ? r.g * w[k] : Vec3(0.f), active);
 }
+/* append the block's texel records to their band queues (TexelQueues): LDS histogram -> one global atomic per non-empty band -> scattered 32-byte records; a record
+ * that finds its queue full is committed with direct atomics by its lane.  Block-wide (three barriers); hist / base: HAR_TQ_MAX words each, gmax: one word of LDS. */
+__device__ __forceinline__ void texel_queue_append(const DScene &S, const TexelQueues &tq, uint32_t shard, const TexelRecord &rec, uint32_t *hist, uint32_t *base, uint32_t *gmax,
+                                                   float *const *grad_tex, float *grad_slots) {
+    if (threadIdx.x < tq.nq) hist[threadIdx.x] = 0u;
+    __syncthreads();
+    texel_record_track_max(gmax, rec.has, rec.g);
+    const uint32_t rank = wave_ranked_count(hist, rec.q, rec.has);
+    __syncthreads();
+    if (threadIdx.x < tq.nq) { const uint32_t c = hist[threadIdx.x]; base[threadIdx.x] = c ? atomicAdd(tq.count + (size_t) (shard * tq.nq + threadIdx.x) * HAR_COUNTER_STRIDE, c) : 0u; }
+    __syncthreads();
+    bool overflow = false;
+    if (rec.has) {
+        const uint32_t slot = base[rec.q] + rank;
+        if (slot < tq.cap) {
+            float4 *dst = tq.rec + 2 * ((size_t) (shard * tq.nq + rec.q) * tq.cap + slot);
+            dst[0] = make_float4(__uint_as_float(rec.cell), __uint_as_float(rec.tex), rec.w1x, rec.w1y);
+            dst[1] = make_float4(rec.g.x, rec.g.y, rec.g.z, 0.f);
+        } else overflow = true;
+    }
+    texel_record_direct(S, grad_tex, grad_slots, rec, overflow);
+}
 template <bool FWD = false>
 __device__ __forceinline__ void adjoint_commit(const DScene &S, const ItemArrays &items, uint32_t i, bool pred, bool visible, float4 *result, const float4 *dL,
-                                               float *grad_refl, float *const *grad_tex, float *gacc, uint8_t *item_vis) {
+                                               float *grad_refl, float *const *grad_tex, float *gacc, uint8_t *item_vis, const TexelQueues *tq = nullptr, TexelRecord *rec = nullptr) {
     if (pred && item_vis) item_vis[i] = visible ? 1 : 0;
     float4 s2 = make_float4(0.f, 0.f, 0.f, 0.f), s3 = s2, s4 = s2; uint32_t lane = 0;
     if (pred) { lane = __float_as_uint(items.s1[i].w); s2 = items.s2[i]; s3 = items.s3[i]; s4 = items.s4[i]; }
-    adjoint_commit_values<FWD>(S, pred, visible, lane, s2, s3, s4, result, dL, grad_refl, grad_tex, gacc);
+    adjoint_commit_values<FWD>(S, pred, visible, lane, s2, s3, s4, result, dL, grad_refl, grad_tex, gacc, tq, rec);
 }
 
 /* ---------------------------------------------------------------- classify */
@@ -788,24 +810,7 @@ __global__ __launch_bounds__(kBlock, HAR_SHADE_MIN_WAVES) void k_shade(DScene S,
             }
             item_pred = false;
             if (tq.nq) {
-                /* append the block's texel records to their band queues (TexelQueues): LDS histogram -> one global atomic per non-empty band -> scattered 32-byte records */
-                if (threadIdx.x < tq.nq) tq_hist[threadIdx.x] = 0u;
-                __syncthreads();
-                texel_record_track_max(&tq_gmax, rec.has, rec.g);
-                const uint32_t rank = wave_ranked_count(tq_hist, rec.q, rec.has);
-                __syncthreads();
-                if (threadIdx.x < tq.nq) { const uint32_t c = tq_hist[threadIdx.x]; tq_base[threadIdx.x] = c ? atomicAdd(tq.count + (size_t) (Q.shard * tq.nq + threadIdx.x) * HAR_COUNTER_STRIDE, c) : 0u; }
-                __syncthreads();
-                bool overflow = false;
-                if (rec.has) {
-                    const uint32_t slot = tq_base[rec.q] + rank;
-                    if (slot < tq.cap) {
-                        float4 *dst = tq.rec + 2 * ((size_t) (Q.shard * tq.nq + rec.q) * tq.cap + slot);
-                        dst[0] = make_float4(__uint_as_float(rec.cell), __uint_as_float(rec.tex), rec.w1x, rec.w1y);
-                        dst[1] = make_float4(rec.g.x, rec.g.y, rec.g.z, 0.f);
-                    } else overflow = true;
-                }
-                texel_record_direct(S, grad_tex, grad_slots, rec, overflow);
+                texel_queue_append(S, tq, Q.shard, rec, tq_hist, tq_base, &tq_gmax, grad_tex, grad_slots);
             }
         }
         if (RECORD && item_pred) {
@@ -920,25 +925,7 @@ __global__ __launch_bounds__(kBlock) void k_commit(DScene S, uint32_t shard_cap,
             const uint32_t nslot = nx & HAR_TAPE_DEAD;
             tape.la_out[nslot] = make_float4(L.x, L.y, L.z, dl.x); tape.lb_out[nslot] = make_float2(dl.y, dl.z);
         }
-        if (tq.nq) {        /* the block's texel records -> their band queues (as in k_shade's in-place commit) */
-            if (threadIdx.x < tq.nq) tq_hist[threadIdx.x] = 0u;
-            __syncthreads();
-            texel_record_track_max(&tq_gmax, rec.has, rec.g);
-            const uint32_t rank = wave_ranked_count(tq_hist, rec.q, rec.has);
-            __syncthreads();
-            if (threadIdx.x < tq.nq) { const uint32_t c = tq_hist[threadIdx.x]; tq_base[threadIdx.x] = c ? atomicAdd(tq.count + (size_t) (Q.shard * tq.nq + threadIdx.x) * HAR_COUNTER_STRIDE, c) : 0u; }
-            __syncthreads();
-            bool overflow = false;
-            if (rec.has) {
-                const uint32_t slot = tq_base[rec.q] + rank;
-                if (slot < tq.cap) {
-                    float4 *dst = tq.rec + 2 * ((size_t) (Q.shard * tq.nq + rec.q) * tq.cap + slot);
-                    dst[0] = make_float4(__uint_as_float(rec.cell), __uint_as_float(rec.tex), rec.w1x, rec.w1y);
-                    dst[1] = make_float4(rec.g.x, rec.g.y, rec.g.z, 0.f);
-                } else overflow = true;
-            }
-            texel_record_direct(S, grad_tex, grad_slots, rec, overflow);
-        }
+        if (tq.nq) texel_queue_append(S, tq, Q.shard, rec, tq_hist, tq_base, &tq_gmax, grad_tex, grad_slots);      /* the block's texel records -> their band queues */
     }
     __syncthreads();
     if (threadIdx.x == 0 && tq.nq && tq_gmax) atomicMax(tq.gmax, tq_gmax);
@@ -1030,9 +1017,13 @@ __global__ __launch_bounds__(kBlock) void k_texel_accumulate(TexelQueues tq, flo
 /* adjoint resolve of a bounce whose shadow-ray results sit in the replay cache: no traversal, one item per thread */
 template <bool FWD>
 __global__ __launch_bounds__(kBlock) void k_resolve_adjoint_cached(DScene S, const uint32_t *item_count, uint32_t shard_cap, ItemArrays items, float4 *result,
-                                                                   const float4 *dL, float *grad_refl, float *const *grad_tex, ReplayCache rc, uint8_t *item_vis) {
+                                                                   const float4 *dL, float *grad_refl, float *const *grad_tex, ReplayCache rc, uint8_t *item_vis, TexelQueues tq) {
     __shared__ float gacc[3 * HAR_LDS_GRAD_BSDFS];
+    /* tq.nq != 0 (reverse mode): the texel gradients go through the band queues like in the in-place commit -- the item path is what vertex-position gradients
+     * run on, and with direct atomics a small albedo texture (every path of the chip adds to the same few texels) made this kernel 80 % of such a step */
+    __shared__ uint32_t tq_hist[FWD ? 1 : HAR_TQ_MAX], tq_base[FWD ? 1 : HAR_TQ_MAX], tq_gmax;
     for (uint32_t k = threadIdx.x; k < 3 * HAR_LDS_GRAD_BSDFS; k += kBlock) gacc[k] = 0.f;
+    if (threadIdx.x == 0) tq_gmax = 0u;
     __syncthreads();
     const ShardLoop Q(item_count, shard_cap);
     for (uint32_t tile = Q.first_tile(); tile * kBlock < Q.n; tile += Q.tile_step()) {
@@ -1041,10 +1032,14 @@ __global__ __launch_bounds__(kBlock) void k_resolve_adjoint_cached(DScene S, con
         const uint32_t i = Q.base + (pred ? local : 0u);
         bool visible = false;
         if (pred && items.s0[i].w >= 0.f) visible = rc.vis[__float_as_uint(items.s1[i].w)] != 0;
-        adjoint_commit<FWD>(S, items, i, pred, visible, result, dL, grad_refl, grad_tex, gacc, item_vis);
+        TexelRecord rec; rec.has = false;
+        const bool queued = !FWD && tq.nq != 0;
+        adjoint_commit<FWD>(S, items, i, pred, visible, result, dL, grad_refl, grad_tex, gacc, item_vis, queued ? &tq : nullptr, queued ? &rec : nullptr);
+        if (queued) texel_queue_append(S, tq, Q.shard, rec, tq_hist, tq_base, &tq_gmax, grad_tex, grad_refl);
     }
     __syncthreads();
     if (FWD) return;
+    if (threadIdx.x == 0 && tq.nq && tq_gmax) atomicMax(tq.gmax, tq_gmax);
     for (uint32_t k = threadIdx.x; k < 3 * min(S.n_bsdfs + S.n_emitters, (uint32_t) HAR_LDS_GRAD_BSDFS); k += kBlock) {
         const float v = gacc[k];
         if (v != 0.f) atomicAdd(grad_refl + k, v);
@@ -1659,11 +1654,12 @@ void launch_texel_accumulate(hipStream_t s, const TexelQueues &tq, float *const 
     hipLaunchKernelGGL(k_texel_accumulate<false>, dim3(HAR_SHARDS * tq.nq * bpq), dim3(kBlock), lds_bytes, s, tq, grad_tex, bpq, spread, fixed ? 0u : 1u);
 }
 void launch_resolve(int mode, hipStream_t s, uint32_t grid, uint2 *spill, const DScene &S, const uint32_t *item_count, uint32_t *cursor, uint32_t shard_cap, const ItemArrays &items,
-                    float4 *result, const float4 *dL, float *grad_refl, float *const *grad_tex, int *status, const ReplayCache &rc, uint8_t *item_vis, int fwd) {
+                    float4 *result, const float4 *dL, float *grad_refl, float *const *grad_tex, int *status, const ReplayCache &rc, uint8_t *item_vis, int fwd, const TexelQueues *tq) {
     dim3 g(grid), b(kBlock);
     if (mode == MODE_PRB_ADJOINT && rc.mode == 2) {
-        if (fwd) hipLaunchKernelGGL(k_resolve_adjoint_cached<true>, g, b, 0, s, S, item_count, shard_cap, items, result, dL, grad_refl, grad_tex, rc, item_vis);
-        else hipLaunchKernelGGL(k_resolve_adjoint_cached<false>, g, b, 0, s, S, item_count, shard_cap, items, result, dL, grad_refl, grad_tex, rc, item_vis);
+        const TexelQueues no_tq{ nullptr, nullptr, nullptr, nullptr, 0u, 0u, nullptr };
+        if (fwd) hipLaunchKernelGGL(k_resolve_adjoint_cached<true>, g, b, 0, s, S, item_count, shard_cap, items, result, dL, grad_refl, grad_tex, rc, item_vis, no_tq);
+        else hipLaunchKernelGGL(k_resolve_adjoint_cached<false>, g, b, 0, s, S, item_count, shard_cap, items, result, dL, grad_refl, grad_tex, rc, item_vis, tq ? *tq : no_tq);
         return;
     }
 #define HAR_LAUNCH_RESOLVE(M, SP) hipLaunchKernelGGL((k_resolve<M, SP>), g, b, 0, s, S, item_count, cursor, shard_cap, items, result, dL, grad_refl, grad_tex, status, rc, spill, item_vis)
