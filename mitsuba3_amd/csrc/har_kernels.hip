@@ -1172,64 +1172,77 @@ __global__ __launch_bounds__(kBlock) void k_shape_adjoint(DScene S, const uint32
         if (shape == 0xffffffffu) return -1;
         return inst == 0xffffffffu ? (T.offset ? T.offset[shape] : -1) : (T.inst_slot ? T.inst_slot[inst] : -1);
     };
-    auto add_verts = [&](int32_t off, const uint32_t vid[3], const Vec3 g[3]) {
+    /* The scatters below are reached by ALL lanes of a wave (a lane without work passes on = false), because they pre-reduce: the 64 samples of a pixel meet
+     * the same triangle at the camera vertex, i.e. the same three vertices -- 64 same-address atomics per float serialise (global: ~88 per microsecond on one line,
+     * LDS: one lane per 3 cycles), and a smooth floor seen from above made this kernel 85 % of a shape-gradient step.  Lanes that target the same vertex are summed
+     * with DPP and one of them adds (wave_slot_add3 for the block's LDS copy, wave_aggregated_add3 for global memory). */
+    auto add_verts = [&](bool on, int32_t off, const uint32_t vid[3], const Vec3 g[3], float *global) {
+        if (!__ballot(on)) return;
         for (int k = 0; k < 3; ++k) {
-            const uint32_t e = 3u * ((uint32_t) off + vid[k]);
-            if (lds) { atomicAdd(&acc[e], g[k].x); atomicAdd(&acc[e + 1], g[k].y); atomicAdd(&acc[e + 2], g[k].z); }
-            else { atomicAdd(T.grad + e, g[k].x); atomicAdd(T.grad + e + 1, g[k].y); atomicAdd(T.grad + e + 2, g[k].z); }
+            const uint32_t v = on ? (uint32_t) off + vid[k] : 0u;
+            if (lds && global == T.grad) wave_slot_add3(acc, v, on ? g[k] : Vec3(0.f), on);
+            else wave_aggregated_add3(global + 3u * (size_t) v, on ? g[k] : Vec3(0.f), on);
         }
     };
-    auto add_inst = [&](int32_t off, const float gM[12]) {
-        float *dst = (uint32_t) off < HAR_LDS_GRAD_INSTS ? iacc + 12 * off : T.inst_grad + 12 * (size_t) off;
-        for (int k = 0; k < 12; ++k) if (gM[k] != 0.f) atomicAdd(dst + k, gM[k]);
+    auto add_inst = [&](bool on, int32_t off, const float gM[12]) {
+        if (!__ballot(on)) return;
+        const bool in_lds = on && (uint32_t) off < HAR_LDS_GRAD_INSTS;
+        for (int c = 0; c < 4; ++c) {
+            const Vec3 col = on ? Vec3(gM[3 * c], gM[3 * c + 1], gM[3 * c + 2]) : Vec3(0.f);
+            if (__ballot(in_lds)) wave_slot_add3(iacc, in_lds ? 4u * (uint32_t) off + (uint32_t) c : 0u, col, in_lds);
+            if (__ballot(on && !in_lds)) wave_aggregated_add3(T.inst_grad + (on ? 12 * (size_t) off + 3 * c : 0), col, on && !in_lds);
+        }
     };
     const ShardLoop Q(item_count, shard_cap);
     for (uint32_t tile = Q.first_tile(); tile * kBlock < Q.n; tile += Q.tile_step()) {
         const uint32_t local = tile * kBlock + threadIdx.x;
-        if (local >= Q.n) continue;
-        const uint32_t i = Q.base + local;
-        const float4 g0 = geo.g0[i];
-        const uint32_t shape = __float_as_uint(g0.x);
-        if (shape == 0xffffffffu) continue;
-        const float4 g2 = geo.g2[i], g5 = geo.g5[i], g6 = geo.g6[i];
-        ShapeItem it;
-        it.shape = shape; it.prim = __float_as_uint(g0.y); it.b1 = g0.z; it.b2 = g0.w;
-        it.inst = (__float_as_uint(g2.w) >> HAR_SHAPE_INST_SHIFT) - 1u;       /* 0xffffffff: top-level geometry */
-        it.prev_shape = __float_as_uint(g5.x); it.prev_prim = __float_as_uint(g5.y); it.prev_b1 = g5.z; it.prev_b2 = g5.w;
-        it.prev_d = Vec3(g6.x, g6.y, g6.z); it.prev_inst = __float_as_uint(g6.w);
-        /* a vertex on an instance moves with the instance's to_world (inst_slot) or with the NESTED MESH of its shape group (offset[nested mesh]); never both
-         * (har_integrator_set_grad_positions / _instances refuse the combination, as instance.cpp:162-166 does) */
-        auto nested = [&](uint32_t shape, uint32_t inst) -> int32_t { return (shape != 0xffffffffu && inst != 0xffffffffu && T.offset) ? T.offset[shape] : -1; };
-        const int32_t noff = nested(it.shape, it.inst), npoff = nested(it.prev_shape, it.prev_inst);
-        const int32_t off = noff >= 0 ? noff : target(it.shape, it.inst), poff = npoff >= 0 ? npoff : target(it.prev_shape, it.prev_inst);
-        if (off < 0 && poff < 0) continue;
-        const float4 g1 = geo.g1[i], g3 = geo.g3[i], g4 = geo.g4[i];
-        it.d_in = Vec3(g1.x, g1.y, g1.z); it.next_slot = __float_as_uint(g1.w);
-        it.q = Vec3(g2.x, g2.y, g2.z); it.nee_flags = __float_as_uint(g2.w) & ((1u << HAR_SHAPE_INST_SHIFT) - 1u);
-        it.n_e = Vec3(g3.x, g3.y, g3.z); it.W = Vec3(g4.x, g4.y, g4.z);
-        const uint32_t lane = __float_as_uint(items.s1[i].w);
-        const float4 L4 = result[lane], dl4 = dL[lane];
-        bool nxt = has_next && it.next_slot != HAR_SHAPE_NO_NEXT, next_valid = false;
-        Vec3 np(0.f), nn(0.f), nd(0.f);
-        if (nxt) {
-            const float4 a1 = next.a1[it.next_slot];
-            nd = Vec3(a1.x, a1.y, a1.z);
-            float4 hh; uint2 hs;
-            if (rc.mode == 2) { hh = rc.h0[lane]; hs = rc.h1[lane]; } else { hh = h0[HIT0(it.next_slot)]; hs = h1[HIT1(it.next_slot)]; }
-            next_valid = hh.x != HAR_INF;
-            if (next_valid) { const SurfInt sn = compute_si(S, nd, hh.x, hh.y, hh.z, __float_as_uint(hh.w), hs.x, hs.y); np = sn.p; nn = sn.n; }
+        ShapeGrad G; G.self_mesh = G.self_inst = G.prev_mesh = G.prev_inst = G.self_normals = false;
+        int32_t off = -1, poff = -1;
+        if (local < Q.n) {
+            const uint32_t i = Q.base + local;
+            const float4 g0 = geo.g0[i];
+            const uint32_t shape = __float_as_uint(g0.x);
+            if (shape != 0xffffffffu) {
+                const float4 g2 = geo.g2[i], g5 = geo.g5[i], g6 = geo.g6[i];
+                ShapeItem it;
+                it.shape = shape; it.prim = __float_as_uint(g0.y); it.b1 = g0.z; it.b2 = g0.w;
+                it.inst = (__float_as_uint(g2.w) >> HAR_SHAPE_INST_SHIFT) - 1u;       /* 0xffffffff: top-level geometry */
+                it.prev_shape = __float_as_uint(g5.x); it.prev_prim = __float_as_uint(g5.y); it.prev_b1 = g5.z; it.prev_b2 = g5.w;
+                it.prev_d = Vec3(g6.x, g6.y, g6.z); it.prev_inst = __float_as_uint(g6.w);
+                /* a vertex on an instance moves with the instance's to_world (inst_slot) or with the NESTED MESH of its shape group (offset[nested mesh]); never both
+                 * (har_integrator_set_grad_positions / _instances refuse the combination, as instance.cpp:162-166 does) */
+                auto nested = [&](uint32_t shp, uint32_t inst) -> int32_t { return (shp != 0xffffffffu && inst != 0xffffffffu && T.offset) ? T.offset[shp] : -1; };
+                const int32_t noff = nested(it.shape, it.inst), npoff = nested(it.prev_shape, it.prev_inst);
+                off = noff >= 0 ? noff : target(it.shape, it.inst); poff = npoff >= 0 ? npoff : target(it.prev_shape, it.prev_inst);
+                if (off >= 0 || poff >= 0) {
+                    const float4 g1 = geo.g1[i], g3 = geo.g3[i], g4 = geo.g4[i];
+                    it.d_in = Vec3(g1.x, g1.y, g1.z); it.next_slot = __float_as_uint(g1.w);
+                    it.q = Vec3(g2.x, g2.y, g2.z); it.nee_flags = __float_as_uint(g2.w) & ((1u << HAR_SHAPE_INST_SHIFT) - 1u);
+                    it.n_e = Vec3(g3.x, g3.y, g3.z); it.W = Vec3(g4.x, g4.y, g4.z);
+                    const uint32_t lane = __float_as_uint(items.s1[i].w);
+                    const float4 L4 = result[lane], dl4 = dL[lane];
+                    bool nxt = has_next && it.next_slot != HAR_SHAPE_NO_NEXT, next_valid = false;
+                    Vec3 np(0.f), nn(0.f), nd(0.f);
+                    if (nxt) {
+                        const float4 a1 = next.a1[it.next_slot];
+                        nd = Vec3(a1.x, a1.y, a1.z);
+                        float4 hh; uint2 hs;
+                        if (rc.mode == 2) { hh = rc.h0[lane]; hs = rc.h1[lane]; } else { hh = h0[HIT0(it.next_slot)]; hs = h1[HIT1(it.next_slot)]; }
+                        next_valid = hh.x != HAR_INF;
+                        if (next_valid) { const SurfInt sn = compute_si(S, nd, hh.x, hh.y, hh.z, __float_as_uint(hh.w), hs.x, hs.y); np = sn.p; nn = sn.n; }
+                    }
+                    /* the emitter sample: w_em = ds.d (surface emitters: normalize(ds.p - si.p), recomputed from the interpolated point) */
+                    it.w_em = it.q;
+                    if (it.nee_flags & HAR_SHAPE_NEE_SURFACE) { const SurfInt si = compute_si(S, it.d_in, 0.f, it.b1, it.b2, it.prim, it.shape, it.inst); it.w_em = normalize3(it.q - si.p); }
+                    if (!shape_item_adjoint(S, it, off >= 0, poff >= 0, geo.vis[i] != 0, Vec3(L4.x, L4.y, L4.z), Vec3(dl4.x, dl4.y, dl4.z), nxt, next_valid, np, nn, nd, G, noff >= 0, npoff >= 0))
+                        G.self_mesh = G.self_inst = G.prev_mesh = G.prev_inst = G.self_normals = false;
+                }
+            }
         }
-        /* the emitter sample: w_em = ds.d (surface emitters: normalize(ds.p - si.p), recomputed from the interpolated point) */
-        it.w_em = it.q;
-        if (it.nee_flags & HAR_SHAPE_NEE_SURFACE) { const SurfInt si = compute_si(S, it.d_in, 0.f, it.b1, it.b2, it.prim, it.shape, it.inst); it.w_em = normalize3(it.q - si.p); }
-        ShapeGrad G;
-        if (!shape_item_adjoint(S, it, off >= 0, poff >= 0, geo.vis[i] != 0, Vec3(L4.x, L4.y, L4.z), Vec3(dl4.x, dl4.y, dl4.z), nxt, next_valid, np, nn, nd, G, noff >= 0, npoff >= 0)) continue;
-        if (G.self_mesh) add_verts(off, G.vid, G.g);
-        if (G.self_normals && T.grad_nrm)
-            for (int k = 0; k < 3; ++k) { float *q = T.grad_nrm + 3u * ((uint32_t) off + G.vid[k]); atomicAdd(q, G.gn[k].x); atomicAdd(q + 1, G.gn[k].y); atomicAdd(q + 2, G.gn[k].z); }
-        if (G.self_inst) add_inst(off, G.gM);
-        if (G.prev_mesh) add_verts(poff, G.pvid, G.gp);
-        if (G.prev_inst) add_inst(poff, G.gpM);
+        add_verts(G.self_mesh, off, G.vid, G.g, T.grad);
+        if (T.grad_nrm) add_verts(G.self_normals, off, G.vid, G.gn, T.grad_nrm);
+        add_verts(G.prev_mesh, poff, G.pvid, G.gp, T.grad);
+        if (T.inst_grad) { add_inst(G.self_inst, off, G.gM); add_inst(G.prev_inst, poff, G.gpM); }
     }
     __syncthreads();
     if (lds) for (uint32_t k = threadIdx.x; k < 3 * T.n_verts; k += kBlock) { const float v = acc[k]; if (v != 0.f) atomicAdd(T.grad + k, v); }
