@@ -117,7 +117,7 @@ struct MaterialQueues { uint32_t *idx; uint32_t *count; uint32_t lanes, miss_cla
 struct ShapeTargets { const int32_t *offset; float *grad; uint32_t n_verts; const int32_t *inst_slot; float *inst_grad; uint32_t n_insts;
                       float *grad_nrm = nullptr;       /* meshes with vertex normals: adjoints of the vertex normals, laid out like `grad` (first stage, see launch_normals_adjoint) */ /* per instance: slot (12 floats each in inst_grad) or -1; null = no instance is differentiated */ };
 #define HAR_LDS_GRAD_INSTS 128        /* instance-transform gradients accumulated per block in LDS (6 KB) */
-#define HAR_LDS_GRAD_VERTS 1024       /* up to this many differentiated vertices are accumulated in LDS (12 KB) before one global atomic per block and float */
+#define HAR_LDS_GRAD_VERTS 1024       /* entries of the per-block direct-mapped LDS cache of vertex gradients (k_shape_adjoint; power of two) */
 
 void launch_raygen(int mode, hipStream_t s, const DSensor &C, uint32_t seed, uint32_t spp, uint32_t log_spp, uint32_t lane_base, uint32_t n,
                    uint32_t shard_cap, const WaveState &out, float4 *result, uint32_t *count, const float *adj, float4 *dL, const PassState &ps = PassState{ nullptr, nullptr, 0 });

@@ -168,6 +168,35 @@ __device__ __forceinline__ void wave_slot_add3(float *acc, uint32_t slot, Vec3 g
     if (active) { float *q = acc + 3u * slot; atomicAdd(q, g.x); atomicAdd(q + 1, g.y); atomicAdd(q + 2, g.z); }
 }
 
+/* ... and for accumulators too many to keep one LDS slot each (the vertices of a mesh): a direct-mapped CACHE of `slots` (power of two) entries -- tags[slot] = the
+ * key that owns the slot (0xffffffff: free), claimed with an integer compare-and-swap; a key that finds its slot taken by another goes to global memory.  The hot
+ * keys of a block (the few hundred vertices in view) therefore meet in LDS whatever the size of the mesh.  acc2 / global2: an optional second accumulator under the
+ * same keys (vertex normals); pass g2 = 0 / global2 = nullptr without.  All lanes call. */
+__device__ __forceinline__ void wave_cached_add3(float *acc, float *acc2, uint32_t *tags, uint32_t slots, uint32_t key, Vec3 g, Vec3 g2, bool active, float *global, float *global2) {
+    auto commit = [&](uint32_t k, Vec3 a, Vec3 b) {
+        const uint32_t slot = k & (slots - 1u), old = atomicCAS(&tags[slot], 0xffffffffu, k);
+        if (old == 0xffffffffu || old == k) {
+            float *q = acc + 3u * slot; atomicAdd(q, a.x); atomicAdd(q + 1, a.y); atomicAdd(q + 2, a.z);
+            if (acc2) { float *r = acc2 + 3u * slot; atomicAdd(r, b.x); atomicAdd(r + 1, b.y); atomicAdd(r + 2, b.z); }
+        } else {
+            float *q = global + 3 * (size_t) k; atomicAdd(q, a.x); atomicAdd(q + 1, a.y); atomicAdd(q + 2, a.z);
+            if (global2) { float *r = global2 + 3 * (size_t) k; atomicAdd(r, b.x); atomicAdd(r + 1, b.y); atomicAdd(r + 2, b.z); }
+        }
+    };
+    for (int round = 0; round < 4; ++round) {
+        const uint64_t m = __ballot(active);
+        if (m == 0) return;
+        const uint32_t lead = __shfl(key, __ffsll((long long) m) - 1, 64);
+        const bool match = active && key == lead;
+        const float sx = wave_sum_to_last(match ? g.x : 0.f), sy = wave_sum_to_last(match ? g.y : 0.f), sz = wave_sum_to_last(match ? g.z : 0.f);
+        float tx = 0.f, ty = 0.f, tz = 0.f;
+        if (acc2) { tx = wave_sum_to_last(match ? g2.x : 0.f); ty = wave_sum_to_last(match ? g2.y : 0.f); tz = wave_sum_to_last(match ? g2.z : 0.f); }
+        if ((threadIdx.x & 63u) == 63u) commit(lead, Vec3(sx, sy, sz), Vec3(tx, ty, tz));
+        active = active && !match;
+    }
+    if (active) commit(key, g, g2);
+}
+
 /* rank of a lane among the block's lanes that append to the same queue: hist[q] += (lanes of this wave with queue q), one LDS atomic per wave and distinct queue
  * instead of one per lane (a wave's vertices mostly fall into one or two texture row bands, and same-address returning atomics serialise).  All lanes call. */
 __device__ __forceinline__ uint32_t wave_ranked_count(uint32_t *hist, uint32_t q, bool active) {
@@ -1159,12 +1188,15 @@ __global__ __launch_bounds__(kBlock) void k_skip_emitters(DScene S, int first, u
  * with global atomics. */
 __global__ __launch_bounds__(kBlock) void k_shape_adjoint(DScene S, const uint32_t *item_count, uint32_t shard_cap, ItemArrays items, ShapeArrays geo, const float4 *result,
                                                           const float4 *dL, int has_next, WaveState next, const float4 *h0, const uint2 *h1, ReplayCache rc, ShapeTargets T) {
-    __shared__ float acc[3 * HAR_LDS_GRAD_VERTS];
+    /* vertex gradients: a direct-mapped LDS cache of HAR_LDS_GRAD_VERTS vertices per block (wave_cached_add3) -- every path of the chip adds to the few hundred
+     * vertices in view, whatever the size of the mesh; `nacc`: the adjoints of their vertex normals (meshes with vertex normals), under the same tags */
+    __shared__ float acc[3 * HAR_LDS_GRAD_VERTS], nacc[3 * HAR_LDS_GRAD_VERTS];
+    __shared__ uint32_t vtag[HAR_LDS_GRAD_VERTS];
     /* instance transforms: every path of the chip that meets instance i adds to the same 12 floats -- per-block accumulators for the first
      * HAR_LDS_GRAD_INSTS slots (same-line global atomics serialise at ~88 per microsecond), global atomics beyond */
     __shared__ float iacc[12 * HAR_LDS_GRAD_INSTS];
-    const bool lds = T.n_verts != 0 && T.n_verts <= HAR_LDS_GRAD_VERTS;
-    if (lds) { for (uint32_t k = threadIdx.x; k < 3 * T.n_verts; k += kBlock) acc[k] = 0.f; }
+    const bool lds = T.n_verts != 0;
+    if (lds) { for (uint32_t k = threadIdx.x; k < 3 * HAR_LDS_GRAD_VERTS; k += kBlock) { acc[k] = 0.f; nacc[k] = 0.f; } for (uint32_t k = threadIdx.x; k < HAR_LDS_GRAD_VERTS; k += kBlock) vtag[k] = 0xffffffffu; }
     if (T.inst_grad) { for (uint32_t k = threadIdx.x; k < 12 * HAR_LDS_GRAD_INSTS; k += kBlock) iacc[k] = 0.f; }
     __syncthreads();
     /* slot of a vertex's geometry in the gradient buffers, or -1: top-level mesh -> first vertex, instance -> its 12 floats */
@@ -1176,12 +1208,12 @@ __global__ __launch_bounds__(kBlock) void k_shape_adjoint(DScene S, const uint32
      * the same triangle at the camera vertex, i.e. the same three vertices -- 64 same-address atomics per float serialise (global: ~88 per microsecond on one line,
      * LDS: one lane per 3 cycles), and a smooth floor seen from above made this kernel 85 % of a shape-gradient step.  Lanes that target the same vertex are summed
      * with DPP and one of them adds (wave_slot_add3 for the block's LDS copy, wave_aggregated_add3 for global memory). */
-    auto add_verts = [&](bool on, int32_t off, const uint32_t vid[3], const Vec3 g[3], float *global) {
+    auto add_verts = [&](bool on, int32_t off, const uint32_t vid[3], const Vec3 g[3], const Vec3 *gn) {
         if (!__ballot(on)) return;
+        const bool normals = T.grad_nrm != nullptr;
         for (int k = 0; k < 3; ++k) {
             const uint32_t v = on ? (uint32_t) off + vid[k] : 0u;
-            if (lds && global == T.grad) wave_slot_add3(acc, v, on ? g[k] : Vec3(0.f), on);
-            else wave_aggregated_add3(global + 3u * (size_t) v, on ? g[k] : Vec3(0.f), on);
+            wave_cached_add3(acc, normals ? nacc : nullptr, vtag, HAR_LDS_GRAD_VERTS, v, on ? g[k] : Vec3(0.f), (on && gn) ? gn[k] : Vec3(0.f), on, T.grad, normals ? T.grad_nrm : nullptr);
         }
     };
     auto add_inst = [&](bool on, int32_t off, const float gM[12]) {
@@ -1239,13 +1271,19 @@ __global__ __launch_bounds__(kBlock) void k_shape_adjoint(DScene S, const uint32
                 }
             }
         }
-        add_verts(G.self_mesh, off, G.vid, G.g, T.grad);
-        if (T.grad_nrm) add_verts(G.self_normals, off, G.vid, G.gn, T.grad_nrm);
-        add_verts(G.prev_mesh, poff, G.pvid, G.gp, T.grad);
+        add_verts(G.self_mesh, off, G.vid, G.g, G.self_normals ? G.gn : nullptr);
+        add_verts(G.prev_mesh, poff, G.pvid, G.gp, nullptr);
         if (T.inst_grad) { add_inst(G.self_inst, off, G.gM); add_inst(G.prev_inst, poff, G.gpM); }
     }
     __syncthreads();
-    if (lds) for (uint32_t k = threadIdx.x; k < 3 * T.n_verts; k += kBlock) { const float v = acc[k]; if (v != 0.f) atomicAdd(T.grad + k, v); }
+    if (lds)
+        for (uint32_t k = threadIdx.x; k < 3 * HAR_LDS_GRAD_VERTS; k += kBlock) {
+            const uint32_t tag = vtag[k / 3u];
+            if (tag == 0xffffffffu) continue;
+            const float v = acc[k], w = nacc[k];
+            if (v != 0.f) atomicAdd(T.grad + 3 * (size_t) tag + k % 3u, v);
+            if (w != 0.f && T.grad_nrm) atomicAdd(T.grad_nrm + 3 * (size_t) tag + k % 3u, w);
+        }
     if (T.inst_grad) for (uint32_t k = threadIdx.x; k < 12 * min(T.n_insts, (uint32_t) HAR_LDS_GRAD_INSTS); k += kBlock) { const float v = iacc[k]; if (v != 0.f) atomicAdd(T.inst_grad + k, v); }
 }
 
