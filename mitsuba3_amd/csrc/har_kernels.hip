@@ -380,6 +380,10 @@ __global__ void k_sample_out(uint32_t n, uint32_t n_total, uint32_t first, const
 #ifndef HAR_FETCH_BATCH
 #define HAR_FETCH_BATCH 128u
 #endif
+#ifndef HAR_FETCH_SMALL_FACTOR
+#define HAR_FETCH_SMALL_FACTOR 16u    /* shards with at most this many rays per lane of their waves draw 64 rays per fetch instead of HAR_FETCH_BATCH: a shorter ragged end for the small
+                                       * launches of late bounces and of a rank's band (1 / 4 / 16: 2 M-lane band 4.69 / 4.55 / 4.56 ms, 8 M 13.06 / 13.04 / 12.90, full frame 77.11 / 77.20 / 77.37) */
+#endif
 #ifndef HAR_REFILL_IDLE
 #define HAR_REFILL_IDLE 12u
 #endif
@@ -408,7 +412,7 @@ __device__ __forceinline__ void trace_persistent(const Accel &A, uint32_t *curso
     const uint32_t lane = threadIdx.x & 63u;
     /* rays per fetch: 128 in the bulk; when the shard holds no more rays than its waves have lanes (late bounces, small jobs) every lane gets
      * ONE ray -- such launches are latency chains of single rays, and two rays per lane would double them */
-    const uint32_t fetch = n <= (gridDim.x / HAR_SHARDS) * (kBlock / 64u) * 64u ? 64u : (uint32_t) HAR_FETCH_BATCH;
+    const uint32_t fetch = n <= (uint32_t) HAR_FETCH_SMALL_FACTOR * (gridDim.x / HAR_SHARDS) * (kBlock / 64u) * 64u ? 64u : (uint32_t) HAR_FETCH_BATCH;
     uint32_t pool_next = 0, pool_end = 0;      /* wave-uniform */
     bool exhausted = false;                    /* wave-uniform */
     bool busy = false, has_result = false;
