@@ -208,7 +208,10 @@ struct HarIntegratorImpl {
     /* shadow-ray overlap (small jobs): bounce b's shadow rays (k_resolve) do not depend on bounce b + 1's closest-hit rays (k_trace_closest) -- both only need
      * bounce b's shading -- so k_resolve runs on `aux_stream` next to the trace launch and the two meet again before bounce b + 1 is shaded.  One traversal
      * tail per bounce instead of two (see run_chunk). */
-    hipStream_t aux_stream = nullptr; hipEvent_t ev_shaded = nullptr, ev_resolved = nullptr;
+    hipStream_t aux_stream = nullptr; hipEvent_t ev_shaded = nullptr, ev_resolved = nullptr, ev_resolved2 = nullptr;
+    /* ... with a second set of item arrays and a second radiance accumulator the shadow rays of bounce b only have to be done before bounce b + 2 is SHADED (the item
+     * set is free again); `result2` collects what they add and is folded into `result` at the end of the chunk */
+    ItemArrays items2{}; float4 *result2 = nullptr;
     void free_ws();
 };
 void HarIntegratorImpl::free_ws() { for (void *p : owned) dev_free(p); owned.clear(); ws_lanes = 0; }
@@ -249,7 +252,7 @@ int ensure_workspace(HarIntegratorImpl *I, uint32_t lanes, bool adjoint, int tap
     if (ws_alloc(I, &I->h0, (size_t) 2 * lanes)) return 1;
     I->h1 = HAR_HIT_INTERLEAVED ? reinterpret_cast<uint2 *>(I->h0 + 1) : reinterpret_cast<uint2 *>(I->h0 + lanes); I->hit_scratch = nullptr;
     if (ws_alloc(I, &I->items.s0, lanes) || ws_alloc(I, &I->items.s1, lanes) || ws_alloc(I, &I->items.s2, lanes)) return 1;
-    I->items.s3 = I->items.s4 = nullptr; I->dL = nullptr;
+    I->items.s3 = I->items.s4 = nullptr; I->dL = nullptr; I->items2 = ItemArrays{}; I->result2 = nullptr;
     if (adjoint && (ws_alloc(I, &I->items.s3, lanes) || ws_alloc(I, &I->items.s4, lanes) || ws_alloc(I, &I->dL, lanes))) return 1;
     I->geo = ShapeArrays{}; I->d_pos_offset = nullptr; I->grad_pos = nullptr; I->d_inst_slot = nullptr; I->grad_inst = nullptr; I->grad_nrm = nullptr; I->nrm_acc = nullptr;
     if (adjoint && I->shape_on) {
@@ -518,9 +521,12 @@ int run_chunk(HarSceneImpl *S, HarIntegratorImpl *I, const DSensor &C, int mode,
     bool overlap = mode != MODE_PRB_ADJOINT && !rays && overlap_applies(S, I, n);
     if (overlap && !I->aux_stream) {
         if (hipStreamCreateWithFlags(&I->aux_stream, hipStreamNonBlocking) != hipSuccess || hipEventCreateWithFlags(&I->ev_shaded, hipEventDisableTiming) != hipSuccess ||
-            hipEventCreateWithFlags(&I->ev_resolved, hipEventDisableTiming) != hipSuccess) { I->aux_stream = nullptr; overlap = false; }
+            hipEventCreateWithFlags(&I->ev_resolved, hipEventDisableTiming) != hipSuccess || hipEventCreateWithFlags(&I->ev_resolved2, hipEventDisableTiming) != hipSuccess) { I->aux_stream = nullptr; overlap = false; }
     }
-    bool resolve_pending = false;
+    if (overlap && !I->result2 && (ws_alloc(I, &I->items2.s0, I->ws_lanes) || ws_alloc(I, &I->items2.s1, I->ws_lanes) || ws_alloc(I, &I->items2.s2, I->ws_lanes) || ws_alloc(I, &I->result2, I->ws_lanes))) return 1;
+    if (overlap) HIP_TRY(hipMemsetAsync(I->result2, 0, (size_t) n * sizeof(float4), s));
+    hipEvent_t ev_res[2] = { I->ev_resolved, I->ev_resolved2 };
+    bool resolve_pending[2] = { false, false };
     int cur = 0; uint32_t b = 0;
     for (; b < nb; ++b) {
         /* PRB replay cache: the primal pass of render_backward records this bounce's ray-query results per lane, the adjoint pass reads them */
@@ -574,7 +580,9 @@ int run_chunk(HarSceneImpl *S, HarIntegratorImpl *I, const DSensor &C, int mode,
             launch_shape_adjoint(s, grid, S->ds, cnt_items(I, b - 1), I->shard_cap, I->items, I->geo, I->result, I->dL, 1, st_in, h0, h1, rc, targets);
             prof_mark(I, s, CLS_OTHER);
         }
-        if (resolve_pending) { HIP_TRY(hipStreamWaitEvent(s, I->ev_resolved, 0)); resolve_pending = false; }      /* bounce b - 1's shadow rays have updated `result`; the item arrays are free again */
+        /* bounce b - 2's shadow rays used the item set this bounce's shading is about to fill */
+        if (resolve_pending[b & 1]) { HIP_TRY(hipStreamWaitEvent(s, ev_res[b & 1], 0)); resolve_pending[b & 1] = false; }
+        const ItemArrays &items_b = (overlap && (b & 1)) ? I->items2 : I->items;
         const bool cached = rc.mode == 2 || rc.mode == 4;                             /* adjoint replay of a cached / taped bounce */
         const bool queued = inline_commit && cached && I->tq.nq != 0;                 /* texel gradients of this bounce go through the band queues */
         if (queued) HIP_TRY(hipMemsetAsync(I->tq.count, 0, (size_t) (HAR_SHARDS * I->tq.nq + 1) * HAR_COUNTER_STRIDE * sizeof(uint32_t), s));
@@ -586,10 +594,10 @@ int run_chunk(HarSceneImpl *S, HarIntegratorImpl *I, const DSensor &C, int mode,
             for (uint32_t c = 0; c < HAR_MAT_CLASSES; ++c)
                 if (S->mat_classes & (1u << c))
                     launch_shade(mode, s, grid, S->ds, P, lane_base, I->shard_cap, cnt_alive(I, b), st_in, h0, h1, st_out, cnt_alive(I, b + 1),
-                                 I->items, cnt_items(I, b), I->result, rc, ps.rng, I->dL, grad_refl, nullptr, nullptr, nullptr, nullptr, &mq, c, tape ? &tp : nullptr);
+                                 items_b, cnt_items(I, b), I->result, rc, ps.rng, I->dL, grad_refl, nullptr, nullptr, nullptr, nullptr, &mq, c, tape ? &tp : nullptr);
         } else
         launch_shade(mode, s, grid, S->ds, P, lane_base, I->shard_cap, cnt_alive(I, b), st_in, h0, h1, st_out, cnt_alive(I, b + 1),
-                     I->items, cnt_items(I, b), I->result, rc, ps.rng, I->dL, grad_refl, shape ? &I->geo : nullptr, inline_commit && cached ? I->d_grad_tex : nullptr,
+                     items_b, cnt_items(I, b), I->result, rc, ps.rng, I->dL, grad_refl, shape ? &I->geo : nullptr, inline_commit && cached ? I->d_grad_tex : nullptr,
                      queued ? &I->tq : nullptr, (inline_commit && (rc.mode == 2 || rc.mode == 4)) ? I->grad_bsdf_params : nullptr, nullptr, 0, (tape || rec_w) ? &tp : nullptr);
         prof_mark(I, s, CLS_SHADE);
         if (queued) {
@@ -599,9 +607,9 @@ int run_chunk(HarSceneImpl *S, HarIntegratorImpl *I, const DSensor &C, int mode,
         if (overlap) {
             HIP_TRY(hipEventRecord(I->ev_shaded, s));
             HIP_TRY(hipStreamWaitEvent(I->aux_stream, I->ev_shaded, 0));
-            launch_resolve(mode, I->aux_stream, tgrid, spill, S->ds, cnt_items(I, b), cur_resolve(I, b), I->shard_cap, I->items, I->result, I->dL, grad_refl, I->d_grad_tex, I->status, rc, nullptr, 0);
-            HIP_TRY(hipEventRecord(I->ev_resolved, I->aux_stream));
-            resolve_pending = true;
+            launch_resolve(mode, I->aux_stream, tgrid, spill, S->ds, cnt_items(I, b), cur_resolve(I, b), I->shard_cap, items_b, I->result2, I->dL, grad_refl, I->d_grad_tex, I->status, rc, nullptr, 0);
+            HIP_TRY(hipEventRecord(ev_res[b & 1], I->aux_stream));
+            resolve_pending[b & 1] = true;
         } else if (!(inline_commit && cached)) {
             /* adjoint items of a cached bounce (the path vertex-position gradients take): texel gradients through the band queues, as in the in-place commit */
             const bool item_queued = mode == MODE_PRB_ADJOINT && rc.mode == 2 && !fwd && I->tq.nq != 0;
@@ -623,7 +631,8 @@ int run_chunk(HarSceneImpl *S, HarIntegratorImpl *I, const DSensor &C, int mode,
             if (total == 0) { ++b; break; }
         }
     }
-    if (resolve_pending) HIP_TRY(hipStreamWaitEvent(s, I->ev_resolved, 0));
+    for (int k = 0; k < 2; ++k) if (resolve_pending[k]) HIP_TRY(hipStreamWaitEvent(s, ev_res[k], 0));
+    if (overlap) launch_add(s, reinterpret_cast<const float *>(I->result2), reinterpret_cast<float *>(I->result), 4u * n);      /* the shadow rays' share of the radiance */
     if (shape && b > 0) {            /* the last bounce: no path continues */
         launch_shape_adjoint(s, grid, S->ds, cnt_items(I, b - 1), I->shard_cap, I->items, I->geo, I->result, I->dL, 0, I->st[cur], I->h0, I->h1, ReplayCache{ nullptr, nullptr, nullptr, 0 }, targets);
         prof_mark(I, s, CLS_OTHER);
@@ -917,6 +926,7 @@ int har_integrator_destroy(HarIntegrator I) {
         if (J) {
             if (J->ev_shaded) (void) hipEventDestroy(J->ev_shaded);
             if (J->ev_resolved) (void) hipEventDestroy(J->ev_resolved);
+            if (J->ev_resolved2) (void) hipEventDestroy(J->ev_resolved2);
             if (J->aux_stream) (void) hipStreamDestroy(J->aux_stream);
         }
     if (I->twin) delete I->twin;
