@@ -206,7 +206,7 @@ struct HarIntegratorImpl {
     HarIntegratorImpl *twin = nullptr; bool twin_used = false;
     hipStream_t side_stream = nullptr; hipEvent_t ev_fork = nullptr, ev_join = nullptr;
     /* shadow-ray overlap (small jobs): bounce b's shadow rays (k_resolve) do not depend on bounce b + 1's closest-hit rays (k_trace_closest) -- both only need
-     * bounce b's shading -- so k_resolve runs on `aux_stream` next to the trace launch and the two meet again before bounce b + 1 is shaded.  One traversal
+     * bounce b's shading -- so k_resolve runs on `aux_stream` next to the trace launch (and, with the second item set below, next to bounce b + 1's shading too).  One traversal
      * tail per bounce instead of two (see run_chunk). */
     hipStream_t aux_stream = nullptr; hipEvent_t ev_shaded = nullptr, ev_resolved = nullptr, ev_resolved2 = nullptr;
     /* ... with a second set of item arrays and a second radiance accumulator the shadow rays of bounce b only have to be done before bounce b + 2 is SHADED (the item
@@ -437,7 +437,8 @@ int ensure_texel_queues(HarSceneImpl *S, HarIntegratorImpl *I) {
  * of a rank when several GPUs split a frame, where a launch is short and its tail (the chip waiting for the launch's longest rays) is a sizeable part of it:
  * measured on the middle bands of the headline frame (tools/band_bench.py, profiles/r03_ab_shadow_overlap.txt), one stream without / with overlap | two streams
  * without / with: 2 M lanes 5.46 / 4.67 | 5.11 / 4.60 ms, 4 M 8.56 / 7.64 | 8.09 / 7.68, 8 M 13.89 / 13.03 | 13.47 / 13.16, 16 M 24.58 / 23.76 | 24.42 / 24.36,
- * 33 M 42.50 / 41.90, 67 M 77.07 / 77.30.  A single large wavefront keeps one stream and sequential launches (its kernels are timed one by one for the bench
+ * 33 M 42.50 / 41.90, 67 M 77.07 / 77.30; with the asynchronous join (second item set + `result2`) and 64-ray fetches 2 M 4.11, 8 M 12.60, 16 M 23.66, 33 M 42.06, 67 M still
+ * neutral (78.05 / 78.37).  A single large wavefront keeps one stream and sequential launches (its kernels are timed one by one for the bench
  * line).  Not with the HBM stack spill (both traversal kernels would share it) nor with hide_emitters.  HAR_OVERLAP = 0 / 1 forces it off / on (A/B). */
 static bool overlap_applies(const HarSceneImpl *S, const HarIntegratorImpl *I, uint64_t n) {
     static const int overlap_env = getenv("HAR_OVERLAP") ? atoi(getenv("HAR_OVERLAP")) : -1;
