@@ -27,5 +27,5 @@ python bench.py --gpus 1 --steps 20 --warmup 5 --no-cpu-baseline > gpurun_out/r0
 python -c "
 import json
 for f in ('gpurun_out/r03/bench_final.json','gpurun_out/r03/bench_final2.json'):
-    d=json.load(open(f)); print(d['value'], d['ms_per_step'], d['roofline']['frac'], d['roofline']['profile_check'], d.get('prb_adjoint',{}).get('value'), d.get('secondary',{}).get('value'), d.get('cpu_baseline',{}).get('value'))
+    d=json.load(open(f)); print(d["value"], d["ms_per_step"], d["roofline"]["frac"], d["roofline"]["profile_check"], (d.get("prb_adjoint") or {}).get("value"), (d.get("secondary") or {}).get("value"), (d.get("cpu_baseline") or {}).get("value"))
 "
