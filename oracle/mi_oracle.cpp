@@ -2034,6 +2034,12 @@ void orc_diffuse_sample(const float refl[3], const float wi[3], float, const flo
 void orc_square_to_cosine_hemisphere(const float s[2], float out[3]) { V3 v = square_to_cosine_hemisphere(s[0], s[1]); out[0] = v.x; out[1] = v.y; out[2] = v.z; }
 void orc_square_to_uniform_sphere(const float s[2], float out[3]) { V3 v = square_to_uniform_sphere(s[0], s[1]); out[0] = v.x; out[1] = v.y; out[2] = v.z; }
 void orc_square_to_uniform_disk_concentric(const float s[2], float out[2]) { square_to_uniform_disk_concentric(s[0], s[1], out[0], out[1]); }
+/* Mesh::compute_normals (mesh.cpp:1216-1267) on packed vertices (8 floats each; the normals at offset 3 are overwritten), faces of 4 u32 */
+void orc_mesh_compute_normals(uint32_t nv, float *vertices, uint32_t nf, const uint32_t *faces) {
+    Mesh m; m.nv = nv; m.nf = nf; m.V.assign(vertices, vertices + 8 * (size_t) nv); m.F.assign(faces, faces + 4 * (size_t) nf); m.bsdf = 0; m.emitter = -1; m.flags = 1u;
+    mesh_regenerate_normals(m);
+    std::copy(m.V.begin(), m.V.end(), vertices);
+}
 void orc_coordinate_system(const float n[3], float s[3], float t[3]) { V3 a, b; coordinate_system(V3(n[0], n[1], n[2]), a, b); s[0] = a.x; s[1] = a.y; s[2] = a.z; t[0] = b.x; t[1] = b.y; t[2] = b.z; }
 float orc_sincos(float x, float *c) { return sincos(x, c); }
 void orc_surface_interaction(void *scene, const float o[3], const float d[3], float t, float u, float v, uint32_t prim,

@@ -271,6 +271,7 @@ void  orc_square_to_cosine_hemisphere(const float s[2], float out[3]);
 void  orc_square_to_uniform_sphere(const float s[2], float out[3]);              /* warp.h:250-255 */
 void  orc_square_to_uniform_disk_concentric(const float s[2], float out[2]);    /* warp.h:54-90 */
 void  orc_coordinate_system(const float n[3], float s[3], float t[3]);
+void  orc_mesh_compute_normals(uint32_t nv, float *vertices, uint32_t nf, const uint32_t *faces);
 float orc_sincos(float x, float *c); /* returns sin */
 /* full SurfaceInteraction for one hit (tests of Mesh::compute_surface_interaction) */
 void  orc_surface_interaction(void *scene, const float o[3], const float d[3],

@@ -294,3 +294,36 @@ def test_obj_scene_plugin(mi, tmp_path):
     thing = [x for x in scene.meshes if x["key"] == "thing"][0]
     assert thing["V"].shape[0] == 24 and thing["F"].shape[0] == 12 and thing["flags"] == 3
     assert np.allclose(np.abs(thing["V"][:, :3] - np.float32([0, 0.2, 0])).max(axis=0), 0.1, atol=1e-6)
+
+
+def test_reference_normal_weighting_and_regeneration_kats(mi, O):
+    """src/render/tests/test_mesh_state.py:30-48 (test01_normal_weighting_scheme) and :51-77 (test02_normal_regeneration_rules, the position-write part): generated
+    normals average the unit face normals weighted by the interior angle at each vertex (Thuermer & Wuethrich); a batch that writes positions without normals
+    regenerates them.  Both the product (har_mesh_compute_normals, Scene._set_vertex_positions) and the oracle's own restatement (the one its shape-gradient
+    derivative differentiates) are held to the reference's numbers"""
+    import ctypes as C
+    a, b = 1.0, 0.5
+    P = np.array([[0, 0, 0], [-a, 1, 0], [a, 1, 0], [-b, 0, 1], [b, 0, 1]], np.float32)
+    F = np.array([[0, 1, 2], [0, 3, 4]], np.uint32)
+    n0 = np.array([0.0, 0.0, -1.0]); n1 = np.array([0.0, 1.0, 0.0])
+    n2 = n0 * (np.pi / 2.0) + n1 * np.arccos(3.0 / 5.0); n2 /= np.linalg.norm(n2)
+    want = np.vstack([n2, n0, n0, n1, n1])
+    m = mi.load_dict({"type": "mesh", "positions": P, "faces": F, "normals": np.tile([1, 0, 0], (5, 1)).astype(np.float32)})
+    m.recompute_vertex_normals()
+    assert np.allclose(m.V[:, 3:6], want, atol=5e-4)
+    V = np.zeros((5, 8), np.float32); V[:, :3] = P
+    F4 = np.zeros((2, 4), np.uint32); F4[:, :3] = F
+    L = O.lib(); L.orc_mesh_compute_normals.restype = None
+    L.orc_mesh_compute_normals.argtypes = [C.c_uint32, C.c_void_p, C.c_uint32, C.c_void_p]
+    L.orc_mesh_compute_normals(5, V.ctypes.data, 2, F4.ctypes.data)
+    assert np.allclose(V[:, 3:6], want, atol=5e-4) and np.abs(V[:, 3:6] - m.V[:, 3:6]).max() < 1e-6
+    # test02: a unit quad; tilting it through its 'vertex_positions' regenerates the normals
+    quad = {"type": "mesh", "positions": np.float32([[0, 0, 0], [1, 0, 0], [1, 1, 0], [0, 1, 0]]), "faces": np.uint32([[0, 1, 2], [0, 2, 3]]),
+            "normals": np.tile([0, 0, 1], (4, 1)).astype(np.float32)}
+    d = mi.cornell_box(); d["quad"] = quad
+    scene = mi.load_dict(d)
+    i = scene._position_keys()["quad.vertex_positions"]
+    assert np.allclose(scene.meshes[i]["V"][:, 3:6], [0, 0, 1])
+    p = scene.meshes[i]["V"][:, :3].copy(); p[:, 2] = p[:, 0]
+    scene._set_vertex_positions(i, p)
+    assert np.allclose(scene.meshes[i]["V"][:, 3:6], [-np.sqrt(0.5), 0, np.sqrt(0.5)], atol=1e-6)
