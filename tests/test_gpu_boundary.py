@@ -552,3 +552,25 @@ def test_library_memory_lives_in_the_torch_pool(mi):
     assert torch.cuda.memory_allocated() - base < 1 << 20, torch.cuda.memory_allocated() - base
     scene = mi.load_dict(d)                                # the pool's blocks are reused: same image
     assert np.array_equal(mi.render(scene, spp=16, seed=0).cpu().numpy() > 0, ref > 0) and rel_l2(mi.render(scene, spp=16, seed=0).cpu().numpy(), ref) < 1e-6
+
+
+def test_reference_position_edits_reach_the_accel(mi):
+    """src/render/tests/test_mesh_state.py:196-237 (test07_update_geometry_accel, the translation part): position edits through the parameter interface propagate to
+    the ray-tracing acceleration structure -- after translating the mesh and the ray origins alike, the hit distances are the ones measured before"""
+    P = np.float32([[-1, 0, -1], [1, 0, -1], [1, 0, 1], [-1, 0, 1]])
+    d = {"type": "scene", "rect": {"type": "mesh", "positions": P, "faces": np.uint32([[0, 2, 1], [0, 3, 2]]), "normals": np.tile([0, 1, 0], (4, 1)).astype(np.float32),
+                                   "texcoords": np.float32([[0, 0], [1, 0], [1, 1], [0, 1]])}}
+    scene = mi.load_dict(d)
+    params = mi.traverse(scene)
+    init = params["rect.vertex_positions"].clone().reshape(-1, 3)
+    g = np.arange(16)
+    px = 1.9 * ((g % 4) / 3.0 - 0.5); pz = 1.9 * ((g // 4) / 3.0 - 0.5)
+    o = np.stack([px, np.full(16, -5.0), pz]).astype(np.float32); dd = np.tile(np.float32([[0], [1], [0]]), (1, 16)); maxt = np.full(16, 3.402823466e+38, np.float32)
+    t0 = scene.ray_intersect_preliminary(mi.Ray3f(o, dd, maxt)).t.cpu().numpy()
+    assert np.allclose(t0, 5.0)
+    import torch
+    for v in ([0, 0, 10], [-5, 0, 10]):
+        params["rect.vertex_positions"] = (init + torch.tensor(v, dtype=init.dtype, device=init.device)).reshape(-1); params.update()
+        t = scene.ray_intersect_preliminary(mi.Ray3f(o + np.float32(v)[:, None], dd, maxt)).t.cpu().numpy()
+        assert np.allclose(t, t0)
+        assert not np.isfinite(scene.ray_intersect_preliminary(mi.Ray3f(o, dd, maxt)).t.cpu().numpy()).any()      # nothing is left at the old place
