@@ -112,7 +112,7 @@ HAR_HD Vec3 refract_m(Vec3 wi, Vec3 m, float cos_theta_t, float eta_ti) {       
 
 /* erfinv, single precision (M. Giles, "Approximating the erfinv function"); dr::erfinv is NOT IN TREE (parity unpinned) */
 HAR_HD float erfinv_(float x) {
-    float w = -logf((1.f - x) * (1.f + x)), p;
+    float w = -log_((1.f - x) * (1.f + x)), p;
     if (w < 5.f) {
         w = w - 2.5f;
         p = 2.81022636e-08f; p = fma_(p, w, 3.43273939e-07f); p = fma_(p, w, -3.5233877e-06f); p = fma_(p, w, -4.39150654e-06f);
@@ -134,7 +134,7 @@ struct Microfacet {
 
     HAR_HD float eval(Vec3 m) const {                                                  /* :185-207 */
         float alpha_uv = alpha_u * alpha_v, cos_theta = m.z, cos_theta_2 = sqr_(cos_theta), result;
-        if (!ggx) result = expf(-(sqr_(m.x / alpha_u) + sqr_(m.y / alpha_v)) / cos_theta_2) / (HAR_PI * alpha_uv * sqr_(cos_theta_2));
+        if (!ggx) result = exp_(-(sqr_(m.x / alpha_u) + sqr_(m.y / alpha_v)) / cos_theta_2) / (HAR_PI * alpha_uv * sqr_(cos_theta_2));
         else      result = rcp_(HAR_PI * alpha_uv * sqr_(sqr_(m.x / alpha_u) + sqr_(m.y / alpha_v) + sqr_(m.z)));
         return result * cos_theta > 1e-20f ? result : 0.f;
     }
@@ -187,12 +187,12 @@ struct Microfacet {
     HAR_HD void sample_visible_11(float cos_theta_i, float sx, float sy, float &slope_x, float &slope_y) const {   /* :368-421 */
         if (!ggx) {
             float tan_theta_i = safe_sqrt_(fnma_(cos_theta_i, cos_theta_i, 1.f)) / cos_theta_i, cot_theta_i = rcp_(tan_theta_i);
-            float maxval = erff(cot_theta_i);
+            float maxval = erf_(cot_theta_i);
             sx = fmaxf(fminf(sx, 1.f - 1e-6f), 1e-6f); sy = fmaxf(fminf(sy, 1.f - 1e-6f), 1e-6f);
-            float x = maxval - (maxval + 1.f) * erff(sqrtf(-logf(sx)));
-            sx *= 1.f + maxval + 0.56418958354775628695f * tan_theta_i * expf(-sqr_(cot_theta_i));
+            float x = maxval - (maxval + 1.f) * erf_(sqrtf(-log_(sx)));
+            sx *= 1.f + maxval + 0.56418958354775628695f * tan_theta_i * exp_(-sqr_(cot_theta_i));
             for (int i = 0; i < 3; ++i) {
-                float slope = erfinv_(x), value = 1.f + x + 0.56418958354775628695f * tan_theta_i * expf(-sqr_(slope)) - sx, derivative = 1.f - slope * tan_theta_i;
+                float slope = erfinv_(x), value = 1.f + x + 0.56418958354775628695f * tan_theta_i * exp_(-sqr_(slope)) - sx, derivative = 1.f - slope * tan_theta_i;
                 x -= value / derivative;
             }
             slope_x = erfinv_(x); slope_y = erfinv_(fms_(2.f, sy, 1.f));
@@ -218,13 +218,13 @@ struct Microfacet {
             float sin_phi, cos_phi, cos_theta, cos_theta_2, alpha_2;
             if (alpha_u == alpha_v) { sincos_((2.f * HAR_PI) * sy, sin_phi, cos_phi); alpha_2 = alpha_u * alpha_u; }
             else {
-                float ratio = alpha_v / alpha_u, tmp = ratio * tanf((2.f * HAR_PI) * sy);
+                float ratio = alpha_v / alpha_u, tmp = ratio * tan_((2.f * HAR_PI) * sy);
                 cos_phi = rsqrt_(fma_(tmp, tmp, 1.f)); cos_phi = mulsign_(cos_phi, fabsf(sy - .5f) - .25f);
                 sin_phi = cos_phi * tmp;
                 alpha_2 = rcp_(sqr_(cos_phi / alpha_u) + sqr_(sin_phi / alpha_v));
             }
             if (!ggx) {
-                cos_theta = rsqrt_(fnma_(alpha_2, logf(1.f - sx), 1.f)); cos_theta_2 = sqr_(cos_theta);
+                cos_theta = rsqrt_(fnma_(alpha_2, log_(1.f - sx), 1.f)); cos_theta_2 = sqr_(cos_theta);
                 float cos_theta_3 = fmaxf(cos_theta_2 * cos_theta, 1e-20f);
                 pdf_out = (1.f - sx) / (HAR_PI * alpha_u * alpha_v * cos_theta_3);
             } else {

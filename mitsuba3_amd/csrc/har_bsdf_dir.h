@@ -36,7 +36,7 @@ HAR_HD D6 d6_safe_sqrt(const D6 &a) {
     for (int i = 0; i < 6; ++i) r.d[i] = a.d[i] * k;
     return r;
 }
-HAR_HD D6 d6_exp(const D6 &a) { D6 r; r.v = expf(a.v); for (int i = 0; i < 6; ++i) r.d[i] = a.d[i] * r.v; return r; }
+HAR_HD D6 d6_exp(const D6 &a) { D6 r; r.v = exp_(a.v); for (int i = 0; i < 6; ++i) r.d[i] = a.d[i] * r.v; return r; }
 HAR_HD D6 d6_abs(const D6 &a) { return a.v < 0.f ? -a : a; }
 
 struct D6Vec { D6 x, y, z; };

@@ -305,8 +305,8 @@ HAR_HD Vec3 envmap_eval_uv(const DEnvmap &E, float u_, float v_) {
     return Vec3(out[0], out[1], out[2]);
 }
 HAR_HD void envmap_direction_to_uv(Vec3 d, float &u, float &v) {                                   /* envmap.cpp:454-459 */
-    u = atan2f(d.x, -d.z) * (0.5f * HAR_INV_PI);
-    v = acosf(fminf(fmaxf(d.y, -1.f), 1.f)) * HAR_INV_PI;
+    u = atan2_(d.x, -d.z) * (0.5f * HAR_INV_PI);
+    v = acos_(fminf(fmaxf(d.y, -1.f), 1.f)) * HAR_INV_PI;
 }
 /* EnvironmentMapEmitter::eval (envmap.cpp:228-236): radiance arriving along world direction d (= -si.wi of the escaping ray) */
 HAR_HD Vec3 envmap_eval(const DEnvmap &E, Vec3 d_world) {

@@ -2042,6 +2042,14 @@ void orc_mesh_compute_normals(uint32_t nv, float *vertices, uint32_t nf, const u
 }
 void orc_coordinate_system(const float n[3], float s[3], float t[3]) { V3 a, b; coordinate_system(V3(n[0], n[1], n[2]), a, b); s[0] = a.x; s[1] = a.y; s[2] = a.z; t[0] = b.x; t[1] = b.y; t[2] = b.z; }
 float orc_sincos(float x, float *c) { return sincos(x, c); }
+/* the restated Dr.Jit elementary functions of orc_math.h: 0 exp, 1 log, 2 erf, 3 atan2(x, y), 4 acos, 5 tan, 6 erfinv */
+float orc_math_fn(int fn, float x, float y) {
+    switch (fn) {
+        case 0: return exp32(x);   case 1: return log32(x);  case 2: return erf32(x); case 3: return atan2_32(x, y);
+        case 4: return acos32(x);  case 5: return tan32(x);  case 6: return erfinv(x);
+    }
+    return std::numeric_limits<float>::quiet_NaN();
+}
 void orc_surface_interaction(void *scene, const float o[3], const float d[3], float t, float u, float v, uint32_t prim,
                              uint32_t shape, uint32_t inst, float out[24]) {
     const Scene &sc = *(Scene *) scene;

@@ -13,8 +13,8 @@
  *
  * Pinned by the golden vectors of src/render/tests/test_microfacet.py, src/bsdfs/tests/test_dielectric.py and
  * src/bsdfs/tests/test_twosided.py (tests/golden/reference_kats.json).  Parity unpinned: dr::erf / dr::erfinv /
- * dr::exp / dr::log / dr::tan are Dr.Jit polynomials that are not in the tree; libm versions and Giles' erfinv
- * approximation are used here.
+ * dr::exp / dr::log / dr::tan are Dr.Jit polynomials that are not in the tree; Cephes-style restatements (orc_math.h)
+ * and Giles' erfinv approximation are used here.
  */
 #pragma once
 #include "orc_math.h"
@@ -67,7 +67,7 @@ static inline V3 refract(V3 wi, V3 m, float cos_theta_t, float eta_ti) {
 
 /* erfinv (Giles 2010, single precision).  dr::erfinv: NOT IN TREE, parity unpinned */
 static inline float erfinv(float x) {
-    float w = -std::log((1.f - x) * (1.f + x)), p;
+    float w = -log32((1.f - x) * (1.f + x)), p;
     if (w < 5.f) {
         w -= 2.5f;
         const float c[9] = { 2.81022636e-08f, 3.43273939e-07f, -3.5233877e-06f, -4.39150654e-06f, 0.00021858087f, -0.00125372503f, -0.00417768164f, 0.246640727f, 1.50140941f };
@@ -92,7 +92,7 @@ public:
     float eval(V3 m) const {
         float alpha_uv = m_alpha_u * m_alpha_v, cos_theta = m.z, cos_theta_2 = sqr(cos_theta), result;
         if (m_type == MicrofacetType::Beckmann)
-            result = std::exp(-(sqr(m.x / m_alpha_u) + sqr(m.y / m_alpha_v)) / cos_theta_2) / (Pi * alpha_uv * sqr(cos_theta_2));
+            result = exp32(-(sqr(m.x / m_alpha_u) + sqr(m.y / m_alpha_v)) / cos_theta_2) / (Pi * alpha_uv * sqr(cos_theta_2));
         else
             result = rcp(Pi * alpha_uv * sqr(sqr(m.x / m_alpha_u) + sqr(m.y / m_alpha_v) + sqr(m.z)));
         return (result * cos_theta > 1e-20f) ? result : 0.f;
@@ -122,12 +122,12 @@ public:
         if (m_type == MicrofacetType::Beckmann) {
             float tan_theta_i = safe_sqrt(fnmadd(cos_theta_i, cos_theta_i, 1.f)) / cos_theta_i;
             float cot_theta_i = rcp(tan_theta_i);
-            float maxval = std::erf(cot_theta_i);
+            float maxval = erf32(cot_theta_i);
             sx = std::fmax(std::fmin(sx, 1.f - 1e-6f), 1e-6f); sy = std::fmax(std::fmin(sy, 1.f - 1e-6f), 1e-6f);
-            float x = maxval - (maxval + 1.f) * std::erf(std::sqrt(-std::log(sx)));
-            sx *= 1.f + maxval + InvSqrtPi * tan_theta_i * std::exp(-sqr(cot_theta_i));
+            float x = maxval - (maxval + 1.f) * erf32(std::sqrt(-log32(sx)));
+            sx *= 1.f + maxval + InvSqrtPi * tan_theta_i * exp32(-sqr(cot_theta_i));
             for (int i = 0; i < 3; ++i) {
-                float slope = erfinv(x), value = 1.f + x + InvSqrtPi * tan_theta_i * std::exp(-sqr(slope)) - sx, derivative = 1.f - slope * tan_theta_i;
+                float slope = erfinv(x), value = 1.f + x + InvSqrtPi * tan_theta_i * exp32(-sqr(slope)) - sx, derivative = 1.f - slope * tan_theta_i;
                 x -= value / derivative;
             }
             out_x = erfinv(x); out_y = erfinv(fmsub(2.f, sy, 1.f));
@@ -157,14 +157,14 @@ public:
                 sin_phi = sincos((2.f * Pi) * sy, &cos_phi);
                 alpha_2 = m_alpha_u * m_alpha_u;
             } else {
-                float ratio = m_alpha_v / m_alpha_u, tmp = ratio * std::tan((2.f * Pi) * sy);
+                float ratio = m_alpha_v / m_alpha_u, tmp = ratio * tan32((2.f * Pi) * sy);
                 cos_phi = rsqrt(fmadd(tmp, tmp, 1.f));
                 cos_phi = mulsign(cos_phi, std::fabs(sy - .5f) - .25f);
                 sin_phi = cos_phi * tmp;
                 alpha_2 = rcp(sqr(cos_phi / m_alpha_u) + sqr(sin_phi / m_alpha_v));
             }
             if (m_type == MicrofacetType::Beckmann) {
-                cos_theta = rsqrt(fnmadd(alpha_2, std::log(1.f - sx), 1.f));
+                cos_theta = rsqrt(fnmadd(alpha_2, log32(1.f - sx), 1.f));
                 cos_theta_2 = sqr(cos_theta);
                 float cos_theta_3 = std::fmax(cos_theta_2 * cos_theta, 1e-20f);
                 pdf_out = (1.f - sx) / (Pi * m_alpha_u * m_alpha_v * cos_theta_3);

@@ -9,7 +9,7 @@
  *
  * Pinned by the Mathematica spot checks of src/core/tests/test_distr_2d.py:7-50 and the weight bounds of
  * src/emitters/tests/test_envmap.py:45-95 (tests/test_envmap_cpu.py).  Parity unpinned: dr::Texture bilinear/clamp lookup,
- * dr::sincos / atan2 / acos lowering (libm here).
+ * dr::sincos / atan2 / acos lowering (Cephes-style restatements in orc_math.h).
  */
 #pragma once
 #include "orc_math.h"
@@ -222,8 +222,8 @@ public:
         return V3(sp * st, ct, -cp * st);
     }
     static void direction_to_uv(V3 d, float uv[2]) {
-        uv[0] = std::atan2(d.x, -d.z) * (0.5f * InvPi);
-        uv[1] = std::acos(std::fmin(std::fmax(d.y, -1.f), 1.f)) * InvPi;
+        uv[0] = atan2_32(d.x, -d.z) * (0.5f * InvPi);
+        uv[1] = acos32(std::fmin(std::fmax(d.y, -1.f), 1.f)) * InvPi;
     }
 
     /* eval_spectrum, RGB branch: dr::Texture<Float, 2>::eval, Linear + Clamp, on the halo'ed storage */

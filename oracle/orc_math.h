@@ -19,6 +19,7 @@
 #include <cstdint>
 #include <cstring>
 #include <limits>
+#include <initializer_list>
 
 namespace orc {
 
@@ -90,6 +91,76 @@ static inline float sincos(float x, float *c_out) {
     *c_out = mulsign(poly ? c : s, u2f(sign_cos));
     return mulsign(poly ? s : c, u2f(sign_sin));
 }
+
+/*
+ * drjit/math.h exp / log / erf / atan2 / acos / tan, single precision (NOT IN TREE: parity unpinned).  Dr.Jit evaluates these as Cephes-derived range
+ * reductions followed by a polynomial in Horner / Estrin form with fused operations; libm rounds differently in the last place.  Restated here the Cephes way
+ * (S. Moshier's single-precision routines; erf: one polynomial below 0.93, 1 - exp(polynomial) above), every contraction explicit, so that a result is a
+ * function of the algorithm and not of the C library the checker happens to be linked with.
+ */
+template <size_t N> static inline float horner(float x, const float (&c)[N]) {      /* c[0] is the leading coefficient */
+    float acc = c[0];
+    for (size_t i = 1; i < N; ++i) acc = fmadd(acc, x, c[i]);
+    return acc;
+}
+static inline float exp32(float x) {
+    if (std::isnan(x)) return x;
+    if (x <= -86.6f) return 0.f;                      /* below 2^-125: flushed */
+    if (x > 88.72283f) return Infinity;
+    static const float P[] = { 1.9875691500e-4f, 1.3981999507e-3f, 8.3334519073e-3f, 4.1665795894e-2f, 1.6666665459e-1f, 5.0000001201e-1f };
+    const float n = std::floor(fmadd(x, 1.44269504088896341f, 0.5f));
+    float r = fnmadd(n, 0.693359375f, x);             /* ln 2 in two pieces */
+    r = fnmadd(n, -2.12194440e-4f, r);
+    const float y = fmadd(horner(r, P), r * r, r) + 1.f;
+    const int e = (int) n, half = e >> 1;
+    return std::ldexp(std::ldexp(y, half), e - half);
+}
+static inline float log32(float x) {
+    if (std::isnan(x) || x < 0.f) return std::numeric_limits<float>::quiet_NaN();
+    if (x == 0.f) return -Infinity;
+    if (std::isinf(x)) return x;
+    static const float P[] = { 7.0376836292e-2f, -1.1514610310e-1f, 1.1676998740e-1f, -1.2420140846e-1f, 1.4249322787e-1f,
+                               -1.6668057665e-1f, 2.0000714765e-1f, -2.4999993993e-1f, 3.3333331174e-1f };
+    int e; float m = std::frexp(x, &e);               /* x = m 2^e, m in [0.5, 1) */
+    if (m < 0.707106781186547524f) { --e; m = m + m - 1.f; } else m = m - 1.f;
+    const float fe = (float) e, z = m * m;
+    float y = fmadd(fe, -2.12194440e-4f, horner(m, P) * m * z);
+    y = fmadd(z, -0.5f, y);
+    return fmadd(fe, 0.693359375f, m + y);
+}
+static inline float erf32(float a) {
+    const float t = std::fabs(a), s = a * a;
+    if (t > 0.927734375f) {
+        float r = fmadd(fmadd(-1.72853470e-5f, t, 3.83197126e-4f), s, fmadd(-3.88396438e-3f, t, 2.42546219e-2f));
+        for (float q : { -1.06777877e-1f, -6.34846687e-1f, -1.28717512e-1f }) r = fmadd(r, t, q);
+        return std::copysign(1.f - exp32(fmadd(r, t, -t)), a);
+    }
+    static const float P[] = { -5.96761703e-4f, 4.99119423e-3f, -2.67681349e-2f, 1.12819925e-1f, -3.76125336e-1f, 1.28379166e-1f };
+    return fmadd(horner(s, P), a, a);
+}
+static inline float atan2_32(float y, float x) {
+    const float HalfPi = 0.5f * Pi, QuarterPi = 0.25f * Pi;
+    if (x == 0.f) return y == 0.f ? 0.f : std::copysign(HalfPi, y);
+    if (y == 0.f) return x < 0.f ? Pi : 0.f;
+    static const float P[] = { 8.05374449538e-2f, -1.38776856032e-1f, 1.99777106478e-1f, -3.33329491539e-1f };
+    const float q = y / x;
+    float a = std::fabs(q), offset = 0.f;
+    if (a > 2.414213562373095f)       { offset = HalfPi;    a = -(1.f / a); }             /* tan(3 pi / 8) */
+    else if (a > 0.4142135623730950f) { offset = QuarterPi; a = (a - 1.f) / (a + 1.f); }  /* tan(pi / 8) */
+    const float z = a * a, at = std::copysign(offset + fmadd(horner(z, P) * z, a, a), q);
+    return (x < 0.f ? std::copysign(Pi, y) : 0.f) + at;
+}
+static inline float asin_small(float a) {             /* 0 <= a <= 0.5 */
+    static const float P[] = { 4.2163199048e-2f, 2.4181311049e-2f, 4.5470025998e-2f, 7.4953002686e-2f, 1.6666752422e-1f };
+    const float z = a * a;
+    return fmadd(horner(z, P) * z, a, a);
+}
+static inline float acos32(float x) {
+    if (x < -0.5f) return Pi - 2.f * asin_small(std::sqrt(0.5f * (1.f + x)));
+    if (x > 0.5f)  return 2.f * asin_small(std::sqrt(0.5f * (1.f - x)));
+    return 0.5f * Pi - std::copysign(asin_small(std::fabs(x)), x);
+}
+static inline float tan32(float x) { float c, s = sincos(x, &c); return s / c; }
 
 /* include/mitsuba/core/random.h:76-90 */
 static inline void sample_tea_32(uint32_t v0, uint32_t v1, int rounds, uint32_t &o0, uint32_t &o1) {

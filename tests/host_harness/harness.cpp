@@ -108,6 +108,14 @@ void hh_bsdf_eval_extra(int type, int ggx, int sample_visible, float alpha_u, fl
 }
 void hh_fresnel(float cos_theta_i, float eta, float out[4]) { fresnel_dielectric(cos_theta_i, eta, out[0], out[1], out[2], out[3]); }
 float hh_fresnel_conductor(float cos_theta_i, float eta, float k) { return fresnel_conductor(cos_theta_i, eta, k); }
+/* elementary functions of har_math.h / har_bsdf.h, same numbering as orc_math_fn */
+float hh_math_fn(int fn, float x, float y) {
+    switch (fn) {
+        case 0: return exp_(x);   case 1: return log_(x);  case 2: return erf_(x); case 3: return atan2_(x, y);
+        case 4: return acos_(x);  case 5: return tan_(x);  case 6: return erfinv_(x);
+    }
+    return 0.f;
+}
 void hh_coordinate_system(const float n[3], float s[3], float t[3]) {      /* coordinate_system of har_math.h (vector.h:118-138) */
     Vec3 a, b; coordinate_system(Vec3(n[0], n[1], n[2]), a, b);
     s[0] = a.x; s[1] = a.y; s[2] = a.z; t[0] = b.x; t[1] = b.y; t[2] = b.z;

@@ -347,3 +347,40 @@ def test_sample_border_host_pipeline_matches_oracle(mi, O, H, rf, crop):
         assert ref[0, :, 3].sum() > 1.03 * plain[0, :, 3].sum() and ref[:, -1, 3].sum() > 1.03 * plain[:, -1, 3].sum()
         inner = (slice(2 * b + 1, h - 2 * b - 1), slice(2 * b + 1, w - 2 * b - 1))
         assert abs(ref[inner][..., 3].mean() / plain[inner][..., 3].mean() - 1) < 0.05      # interior weights: same density of samples
+
+
+def test_elementary_functions_accuracy_and_host_device_agreement(O):
+    """dr::exp / log / erf / atan2 / acos / tan (Dr.Jit, NOT IN TREE): the oracle's Cephes-style restatements (orc_math.h) against double
+    precision, and the product's own versions (har_math.h, compiled for the host) against the oracle's BIT FOR BIT -- they are written
+    independently but must describe the same arithmetic, which is what makes paths through rough BSDFs identical on the device."""
+    import math
+    L = O.lib()
+    H = C.CDLL(os.path.join(ROOT, "tests", "host_harness", "libhost_harness.so"))
+    H.hh_math_fn.restype = C.c_float; H.hh_math_fn.argtypes = [C.c_int, C.c_float, C.c_float]
+    rng = np.random.default_rng(7)
+    n = 20000
+    cases = {
+        0: (rng.uniform(-86, 88, n), None, math.exp, 1.5),
+        1: (np.exp(rng.uniform(-87, 88, n)), None, math.log, 1.5),
+        2: (rng.uniform(-4.5, 4.5, n), None, math.erf, 1.5),
+        3: (rng.uniform(-1, 1, n), rng.uniform(-1, 1, n), math.atan2, 4.0),
+        4: (rng.uniform(-1, 1, n), None, math.acos, 2.0),
+        5: (rng.uniform(-1.5, 1.5, n), None, math.tan, 3.0),
+    }
+    for fn, (xs, ys, ref, ulps) in cases.items():
+        xs = xs.astype(np.float32); ys = np.zeros_like(xs) if ys is None else ys.astype(np.float32)
+        worst = 0.0
+        for x, y in zip(xs, ys):
+            a = L.orc_math_fn(fn, float(x), float(y)); b = H.hh_math_fn(fn, float(x), float(y))
+            assert np.float32(a).tobytes() == np.float32(b).tobytes(), (fn, x, y, a, b)
+            r = ref(float(x), float(y)) if fn == 3 else ref(float(x))
+            worst = max(worst, abs(a - r) / float(np.spacing(np.float32(abs(r)) if r else np.float32(1e-30))))
+        assert worst <= ulps, (fn, worst)
+    # special values, and erfinv (Giles) through the restated log
+    for fn, x, want in [(0, -200.0, 0.0), (0, 0.0, 1.0), (0, 100.0, math.inf), (1, 1.0, 0.0), (1, 0.0, -math.inf), (1, math.inf, math.inf), (2, 10.0, 1.0), (2, -10.0, -1.0),
+                        (4, 1.0, 0.0), (4, -1.0, math.pi), (6, 0.0, 0.0)]:
+        a = L.orc_math_fn(fn, x, 0.0); b = H.hh_math_fn(fn, x, 0.0)
+        assert a == b and abs(a - want) <= 1e-6 * max(1.0, abs(want)) if math.isfinite(want) else (a == want and b == want), (fn, x, a, b)
+    assert abs(L.orc_math_fn(1, 1e-40, 0.0) - math.log(1e-40)) < 1e-4 and L.orc_math_fn(1, 1e-40, 0.0) == H.hh_math_fn(1, 1e-40, 0.0)
+    for x in rng.uniform(-0.999, 0.999, 2000).astype(np.float32):
+        a = L.orc_math_fn(6, float(x), 0.0); assert a == H.hh_math_fn(6, float(x), 0.0) and abs(math.erf(a) - float(x)) < 2e-6

@@ -118,9 +118,9 @@ def test_materials_1m_scene_512_forward_and_gradients(mi, O):
     ref, st = osc.render_path(sensor, seed=0, spp=spp, max_depth=8)
     assert rel_l2(img, ref) < 1e-4
     gst = scene.integrator().stats()
-    # the rough models sample through erf / erfinv / exp / sincos: the device's and the host's libm differ in the last ulp, which flips a discrete
-    # decision (lobe choice, Russian roulette, a grazing hit) for about one path in a million -- the diffuse 1M scenes above match to the vertex
-    assert gst["paths"] == st.paths and abs(gst["vertices"] - st.vertices) <= 1e-5 * st.vertices, (gst, st.vertices)
+    # the rough models sample through erf / erfinv / exp / log / sincos: the product and the oracle each restate Dr.Jit's polynomial versions (har_math.h,
+    # orc_math.h), so these are the SAME paths on the device as in the oracle, to the vertex, like the diffuse 1M scenes above
+    assert gst["paths"] == st.paths and gst["vertices"] == st.vertices, (gst, st.vertices)
     res, spp = 256, 8
     d = mi.instanced_spheres_scene(width=res, height=res, spp=spp, flatten=True, materials=True)
     d["integrator"] = {"type": "prb", "max_depth": 8, "rr_depth": 5, "bsdf_parameter_gradients": True}
@@ -154,7 +154,7 @@ def test_material_queues_equal_the_generic_kernel(mi, O):
         integ = mi.load_dict({"type": "path", "max_depth": 8, "material_queues": on})
         imgs[on] = mi.render(scene, integrator=integ, spp=spp, seed=3).cpu().numpy()
         gst = integ.stats()
-        assert gst["paths"] == st.paths and abs(gst["vertices"] - st.vertices) <= 1e-5 * st.vertices
+        assert gst["paths"] == st.paths and gst["vertices"] == st.vertices
         assert rel_l2(imgs[on], ref) < 1e-4
     assert rel_l2(imgs[True], imgs[False]) < 1e-6
     grad_in = np.random.default_rng(2).uniform(0.5, 1.5, (res, res, 3)).astype(np.float32) / (res * res * 3)
