@@ -426,7 +426,7 @@ def worker(args):
         _, st = osc.render_path(sensor, seed=0, spp=spp_cpu, max_depth=args.max_depth, threads=cores)
         el = time.perf_counter() - t0
         cpu = {"value": round(st.paths / el / 1e6, 4), "unit": "Mpaths/s", "cores": cores, "kind": "port",
-               "note": "the oracle is a slow, readable restatement written as a CHECKER (284 us x thread per path); it is NOT llvm_ad_rgb -- an Embree-backed llvm_ad_rgb on these cores would be one to two orders of magnitude faster; the ratio value / cpu_baseline.value bounds nothing",
+               "note": "the oracle is a slow, readable restatement written as a CHECKER (%.0f us x thread per path in this run); it is NOT llvm_ad_rgb -- an Embree-backed llvm_ad_rgb on these cores would be one to two orders of magnitude faster; the ratio value / cpu_baseline.value bounds nothing" % (el * cores / max(st.paths, 1) * 1e6),
                "sample": "%dx%dx%d spp of the same scene/seed (%.1f s); CPU restatement of llvm_ad_rgb (reference not installable)"
                          % (args.res, args.res, spp_cpu, el)}
         if scene_p is not None:

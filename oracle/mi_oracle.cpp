@@ -1365,7 +1365,7 @@ static void parallel_lanes(uint64_t begin, uint64_t end, int threads, Fn fn) {
     if (n < 4096 || threads == 1) { fn(0, begin, end); return; }
     std::vector<std::thread> pool;
     std::atomic<uint64_t> next(begin);
-    const uint64_t chunk = 16384;
+    const uint64_t chunk = std::min<uint64_t>(16384, std::max<uint64_t>(512, n / ((uint64_t) threads * 8)));   /* >= 8 chunks per worker: balanced tails on 256 threads too */
     for (int t = 0; t < threads; ++t)
         pool.emplace_back([&, t]() {
             for (;;) { uint64_t b = next.fetch_add(chunk); if (b >= end) break; fn(t, b, std::min(end, b + chunk)); }
@@ -1378,7 +1378,10 @@ static int resolve_threads(int threads) {
     return threads < 1 ? 1 : threads;
 }
 
-static void merge_stats(OrcStats *dst, const std::vector<OrcStats> &src) {
+/* one counter block per worker thread, each on its own cache line: the workers bump `vertices` at every path vertex, and neighbouring 32-byte blocks
+ * made them fight over lines (the 256-thread CPU baseline of bench.py ran at a thirteenth of the single-thread rate per thread) */
+struct alignas(64) ThreadStats : OrcStats { ThreadStats() : OrcStats{} {} };
+static void merge_stats(OrcStats *dst, const std::vector<ThreadStats> &src) {
     if (!dst) return;
     for (const auto &s : src) { dst->paths += s.paths; dst->vertices += s.vertices; dst->closest_rays += s.closest_rays; dst->shadow_rays += s.shadow_rays; }
 }
@@ -1392,7 +1395,7 @@ static int render_forward(Scene &sc, const OrcSensor &s, uint32_t seed, uint32_t
     threads = resolve_threads(threads);
     size_t fsz = (size_t) s.crop_width * s.crop_height * 4;
     std::vector<std::vector<float>> films(threads);
-    std::vector<OrcStats> sts(threads, OrcStats{});
+    std::vector<ThreadStats> sts(threads);
     uint32_t md = (uint32_t) max_depth, rd = (uint32_t) rr_depth;
     parallel_lanes(lb, le, threads, [&](int t, uint64_t b, uint64_t e) {
         if (films[t].empty()) films[t].assign(fsz, 0.f);
@@ -1425,7 +1428,7 @@ static int render_forward_passes(Scene &sc, const OrcSensor &s, uint32_t seed, u
     threads = resolve_threads(threads);
     size_t fsz = (size_t) s.crop_width * s.crop_height * 4;
     std::vector<std::vector<float>> films(threads);
-    std::vector<OrcStats> sts(threads, OrcStats{});
+    std::vector<ThreadStats> sts(threads);
     uint32_t md = max_depth < 0 ? 0xffffffffu : (uint32_t) max_depth, rd = (uint32_t) rr_depth;
     parallel_lanes(lb, le, threads, [&](int t, uint64_t b, uint64_t e) {
         if (films[t].empty()) films[t].assign(fsz, 0.f);
@@ -1741,7 +1744,7 @@ int orc_integrator_sample(void *scene, int prb, uint32_t n, const float *o, cons
                           const uint64_t *state, int32_t max_depth, int32_t rr_depth, float *rgb, uint8_t *valid, uint64_t *state_out, int threads) {
     Scene &sc = *(Scene *) scene;
     threads = resolve_threads(threads);
-    std::vector<OrcStats> sts(threads, OrcStats{});
+    std::vector<ThreadStats> sts(threads);
     const uint32_t md = max_depth < 0 ? 0xffffffffu : (uint32_t) max_depth, rd = (uint32_t) rr_depth;
     parallel_lanes(0, n, threads, [&](int t, uint64_t b, uint64_t e) {
         for (uint64_t i = b; i < e; ++i) {
@@ -1832,7 +1835,7 @@ static int prb_backward_impl(void *scene, const OrcSensor *sp, const float *grad
     std::vector<std::vector<std::vector<float>>> g_tex(threads);
     std::vector<std::vector<std::vector<double>>> g_pos(threads), g_nrm(threads);
     std::vector<std::vector<double>> g_inst(threads);
-    std::vector<OrcStats> sts(threads, OrcStats{});
+    std::vector<ThreadStats> sts(threads);
     uint32_t md = (uint32_t) max_depth, rd = (uint32_t) rr_depth;
     parallel_lanes(lb, le, threads, [&](int t, uint64_t b, uint64_t e) {
         if (g_refl[t].empty()) {
