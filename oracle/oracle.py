@@ -394,7 +394,7 @@ def cornell_box(width=256, height=256, crop=None, rfilter="gaussian", white_text
     return sd, sensor
 
 
-def benchmark_spheres_scene(width=512, height=512, grid=10, n_u=100, n_v=50, flatten=False, textured=False, tex_res=256, rfilter="gaussian"):
+def benchmark_spheres_scene(width=512, height=512, grid=10, n_u=100, n_v=50, flatten=False, textured=False, tex_res=256, rfilter="gaussian", materials=False):
     """The 1M-triangle benchmark scenes of SURVEY.md 8(d) (`mitsuba3_amd.scenes.instanced_spheres_scene`: Cornell box without its two
     boxes + grid x grid bumpy spheres, as instances of one shape group or flattened) lowered by the ORACLE's own code: its transform chain
     (orc_translate / orc_rotate / orc_scale / orc_matmul / orc_affine_inverse), its rectangle and mesh baking, its perspective sensor.  The
@@ -406,6 +406,19 @@ def benchmark_spheres_scene(width=512, height=512, grid=10, n_u=100, n_v=50, fla
     sd.bsdfs = [(0, -1, CBOX_WHITE), (0, -1, CBOX_GREEN), (0, -1, CBOX_RED)]
     if textured:
         sd.textures.append(f32(checker_texture(tex_res))); sd.bsdfs[0] = (0, 0, CBOX_WHITE)
+    n_ids = 3
+    if materials:
+        # the `materials=True` variant of the scene: `white` = roughplastic (src/bsdfs/roughplastic.cpp:151-195: Beckmann, visible normals, alpha 0.2, int_ior
+        # "polypropylene" 1.49 over ext_ior "air" 1.000277 (src/bsdfs/ior.h), eta = int / ext in single precision, specular_reflectance 1), `green` = twosided GGX
+        # roughconductor (roughconductor.cpp:155-205, twosided.cpp:70-110), `red` stays diffuse, fourth sphere material `glass` = dielectric with int_ior 1.5
+        # (dielectric.cpp:160-185).  Written from the plugins' documented defaults, not read from the product's BSDF objects.
+        assert flatten and not textured
+        air = np.float32(1.000277)
+        sd.bsdfs = [(3, -1, CBOX_WHITE, dict(flags=4, reflectance2=(1, 1, 1), alpha_u=0.2, alpha_v=0.2, eta=float(np.float32(1.49) / air))),
+                    (2, -1, (1, 1, 1), dict(flags=1 | 2 | 4, alpha_u=0.15, alpha_v=0.15, eta_c=(0.2, 0.92, 1.1), k_c=(3.9, 2.45, 2.14))),
+                    (0, -1, CBOX_RED),
+                    (1, -1, (1, 1, 1), dict(reflectance2=(1, 1, 1), eta=float(np.float32(1.5) / air)))]
+        n_ids = 4
     light_tf = T().translate([0.0, 0.99, 0.01]).rotate([1, 0, 0], 90).scale([0.23, 0.19, 0.19])
     V, F, n, ia = rectangle(light_tf)
     sd.add_mesh(V, F, 0, emitter=0)
@@ -430,7 +443,7 @@ def benchmark_spheres_scene(width=512, height=512, grid=10, n_u=100, n_v=50, fla
         for k, tf in enumerate(tfs):
             V = V0.copy(); F = F0.copy()
             lib().orc_bake_mesh(fp(tf.data), fp(V), V.shape[0], up(F), F.shape[0])
-            sd.add_mesh(V, F, k % 3)
+            sd.add_mesh(V, F, k % n_ids)
         sd.top_mesh_count = len(sd.meshes)
     else:
         sd.top_mesh_count = len(sd.meshes)

@@ -313,6 +313,30 @@ def test_benchmark_scene_lowering_matches_the_oracles_own(mi, O, flatten):
     assert np.array_equal(scene.textures[0], sd.textures[0])
 
 
+def test_materials_scene_lowering_matches_the_oracles_own(mi, O):
+    """the `materials=True` variant (rough plastic walls; twosided GGX conductor, diffuse and glass spheres): the BSDF records the product parses from the
+    dict against the records `O.benchmark_spheres_scene(materials=True)` writes down from the plugins' documented defaults (distribution, visible
+    normals, named IORs, eta in single precision, slot defaults), and the two oracle scenes render the same paths"""
+    res, spp = 40, 4
+    d = mi.instanced_spheres_scene(width=res, height=res, spp=spp, grid=3, n_u=16, n_v=8, flatten=True, materials=True)
+    scene = mi.load_dict(d)
+    sd, sensor = O.benchmark_spheres_scene(res, res, grid=3, n_u=16, n_v=8, flatten=True, materials=True)
+    types = {"diffuse": 0, "dielectric": 1, "roughconductor": 2, "roughplastic": 3, "conductor": 4, "plastic": 5}
+    assert len(scene.bsdf_objs) == len(sd.bsdfs) == 4
+    for b, rec in zip(scene.bsdf_objs, sd.bsdfs):
+        x = rec[3] if len(rec) > 3 else {}
+        assert types[b.kind] == rec[0] and rec[1] == -1 and np.array_equal(np.asarray(b.value, np.float32), np.asarray(rec[2], np.float32)) and b.flags == x.get("flags", 0), (b.kind, rec)
+        if b.kind != "diffuse":
+            assert np.array_equal(np.asarray(b.value2, np.float32), np.asarray(x.get("reflectance2", (0, 0, 0)), np.float32))
+            assert np.float32(b.eta) == np.float32(x.get("eta", 1.0)) and np.float32(b.alpha_u) == np.float32(x.get("alpha_u", 0.1)) and np.float32(b.alpha_v) == np.float32(x.get("alpha_v", 0.1))
+            assert np.array_equal(np.asarray(b.eta_c, np.float32), np.asarray(x.get("eta_c", (0, 0, 0)), np.float32)) and np.array_equal(np.asarray(b.k_c, np.float32), np.asarray(x.get("k_c", (1, 1, 1)), np.float32))
+    assert [m["bsdf"] for m in scene.meshes] == [m["bsdf"] for m in sd.meshes]
+    oa, sa = O.scene_from_product(scene)
+    ia, sta = oa.render_path(sa, seed=0, spp=spp, max_depth=8)
+    ib, stb = O.OracleScene(sd).render_path(sensor, seed=0, spp=spp, max_depth=8)
+    assert sta.vertices == stb.vertices and np.abs(ia - ib).max() <= 1e-5 * np.abs(ia).max()
+
+
 # ------------------------------------------------------------------ Film::sample_border (film.cpp:29-32, integrator.cpp:162-165, 322-339)
 
 @pytest.mark.parametrize("rf,crop", [("gaussian", None), ("gaussian", (5, 3, 20, 17)), ("tent", None), ("box", None)], ids=["gaussian", "gaussian-crop", "tent", "box"])

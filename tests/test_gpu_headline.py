@@ -15,15 +15,15 @@ def rel_l2(a, b):
     return float(np.linalg.norm(a.astype(np.float64) - b.astype(np.float64)) / np.linalg.norm(b.astype(np.float64)))
 
 
-def _scene_1m(mi, O, res, spp, flatten=False, textured=False, integrator=None, grid=10, n_u=100, n_v=50):
+def _scene_1m(mi, O, res, spp, flatten=False, textured=False, integrator=None, grid=10, n_u=100, n_v=50, materials=False):
     """product scene from the dict; ORACLE scene from the oracle's own lowering of the same description (its transform chain, mesh baking,
     instance matrices and sensor: `O.benchmark_spheres_scene`) -- not `scene_from_product`, which would hand the oracle the product's baked
     arrays and hide a defect of the product's host lowering (round-2 verdict, "shared lowering")"""
-    d = mi.instanced_spheres_scene(width=res, height=res, spp=spp, grid=grid, n_u=n_u, n_v=n_v, flatten=flatten, textured=textured)
+    d = mi.instanced_spheres_scene(width=res, height=res, spp=spp, grid=grid, n_u=n_u, n_v=n_v, flatten=flatten, textured=textured, materials=materials)
     if integrator:
         d["integrator"] = integrator
     scene = mi.load_dict(d)
-    sd, sensor = O.benchmark_spheres_scene(res, res, grid=grid, n_u=n_u, n_v=n_v, flatten=flatten, textured=textured)
+    sd, sensor = O.benchmark_spheres_scene(res, res, grid=grid, n_u=n_u, n_v=n_v, flatten=flatten, textured=textured, materials=materials)
     return scene, O.OracleScene(sd), sensor
 
 
@@ -111,9 +111,7 @@ def test_materials_1m_scene_512_forward_and_gradients(mi, O):
     bench's film size: forward image <= 1e-4 with equal path / vertex counts (the material-sorted generic shading kernel at 1 M lanes), and
     the PRB gradients of the colours AND of alpha / eta / k / specular_reflectance <= 1e-3 at 256 x 256 x 8 spp"""
     res, spp = 512, 4
-    d = mi.instanced_spheres_scene(width=res, height=res, spp=spp, flatten=True, materials=True)
-    scene = mi.load_dict(d)
-    osc, sensor = O.scene_from_product(scene)
+    scene, osc, sensor = _scene_1m(mi, O, res, spp, flatten=True, materials=True)      # the oracle's own lowering, BSDF records from the plugins' documented defaults
     img = mi.render(scene, spp=spp, seed=0).cpu().numpy()
     ref, st = osc.render_path(sensor, seed=0, spp=spp, max_depth=8)
     assert rel_l2(img, ref) < 1e-4
