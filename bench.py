@@ -410,8 +410,10 @@ def worker(args):
     cpu = None
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         from oracle import oracle as O
-        cores = os.cpu_count() or 1
-        log("CPU baseline: oracle on %d host threads (forward)" % cores)
+        # threads = the cores this container may really use (affinity mask capped by its cgroup CPU quota: the GPU boxes show 256 logical CPUs behind a quota of
+        # 16, and 256 threads run at HALF the rate of 16 there -- profiles/r03_cpu_scaling.txt); `cores` in the line is this count
+        cores = max(1, int(O.lib().orc_default_threads()))
+        log("CPU baseline: oracle on %d host threads of %d logical CPUs (forward)" % (cores, os.cpu_count() or 1))
         if args.workload in ("instanced1m", "flat1m"):      # the oracle's own lowering of the scene description (independent of the product's host code)
             sd_o, sensor = O.benchmark_spheres_scene(args.res, args.res, flatten=(args.workload == "flat1m"))
             osc = O.OracleScene(sd_o)
@@ -425,7 +427,7 @@ def worker(args):
         t0 = time.perf_counter()
         _, st = osc.render_path(sensor, seed=0, spp=spp_cpu, max_depth=args.max_depth, threads=cores)
         el = time.perf_counter() - t0
-        cpu = {"value": round(st.paths / el / 1e6, 4), "unit": "Mpaths/s", "cores": cores, "kind": "port",
+        cpu = {"value": round(st.paths / el / 1e6, 4), "unit": "Mpaths/s", "cores": cores, "logical_cpus": os.cpu_count() or 1, "kind": "port",
                "note": "the oracle is a slow, readable restatement written as a CHECKER (%.0f us x thread per path in this run); it is NOT llvm_ad_rgb -- an Embree-backed llvm_ad_rgb on these cores would be one to two orders of magnitude faster; the ratio value / cpu_baseline.value bounds nothing" % (el * cores / max(st.paths, 1) * 1e6),
                "sample": "%dx%dx%d spp of the same scene/seed (%.1f s); CPU restatement of llvm_ad_rgb (reference not installable)"
                          % (args.res, args.res, spp_cpu, el)}

@@ -14,6 +14,7 @@
  * 8-bit quantisation of the child boxes against the (padded) parent box.
  */
 #include "har_accel_build.h"
+#include "har_cpu.h"
 
 #include <algorithm>
 #include <cmath>
@@ -60,7 +61,7 @@ struct Builder {
         constexpr int NB = 16;
         const uint32_t count = end - begin;
         static const uint32_t sweep_par_min = getenv("HAR_BUILD_SWEEP_MIN") ? (uint32_t) atol(getenv("HAR_BUILD_SWEEP_MIN")) : 131072u;
-        static const uint32_t hw = std::max(1u, std::thread::hardware_concurrency());      /* a system call: once */
+        static const uint32_t hw = har_usable_cores();      /* affinity mask and container quota, looked up once */
         const uint32_t chunks = count >= sweep_par_min ? std::min<uint32_t>(std::min(hw, 32u), count / 32768u) : 1u;
         auto for_chunks = [&](auto &&body) {
             if (chunks <= 1) { body(0u, begin, end); return; }

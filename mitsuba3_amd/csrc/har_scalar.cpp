@@ -14,6 +14,7 @@
  * the scalar variants' draw semantics (path.cpp:226-227 `break`, :244-249 conditional emitter samples).
  */
 #include "../../include/hip_ad_rgb.h"
+#include "har_cpu.h"
 #include "har_path.h"
 #include "har_scene_host.h"
 
@@ -141,7 +142,7 @@ extern "C" int har_render_scalar(const HarSceneDesc *desc, const HarSensor *sens
         const uint32_t W = C.crop_w, H = C.crop_h;
         /* Film::sample_border: the spiral runs over the enlarged film, every block is shifted back by the border (integrator.cpp:162-165, 248-249) */
         const uint32_t Wg = C.samp_w, Hg = C.samp_h; const int32_t sample_shift = (int32_t) C.border;
-        if (n_threads == 0) n_threads = std::max(1u, std::thread::hardware_concurrency());
+        if (n_threads == 0) n_threads = har_usable_cores();         /* affinity mask and container quota, not the machine's CPU count */
 
         /* ReconstructionFilter::init_discretization (rfilter.cpp:11-26) */
         constexpr int RES = 31;                                   /* MI_FILTER_RESOLUTION */

@@ -13,6 +13,8 @@
 
 #include <algorithm>
 #include <atomic>
+#include <fstream>
+#include <sched.h>
 #include <cstdio>
 #include <cstdlib>
 #include <thread>
@@ -1357,9 +1359,29 @@ static V3 prb_sample(const Scene &sc, Pcg32 &rng, Ray ray, uint32_t max_depth, u
 //  ADIntegrator.render / RBIntegrator.render_backward, common.py:46-110,625-783)
 // ---------------------------------------------------------------------------
 
+/* worker threads when the caller asks for "all": the CPUs of the affinity mask, capped by the container's bandwidth quota (cgroup v2 cpu.max or the v1
+ * cfs files) -- the GPU boxes show 256 logical CPUs behind a quota of 16, and 256 threads then run at an eighth of the rate of 16 (tools/cpu_scaling.py) */
+static int default_threads() {
+    static const int cached = [] {
+        int n = (int) std::thread::hardware_concurrency();
+        cpu_set_t mask;
+        if (sched_getaffinity(0, sizeof(mask), &mask) == 0 && CPU_COUNT(&mask) > 0) n = std::min(n, CPU_COUNT(&mask));
+        double quota = 0.0, period = 0.0;
+        std::ifstream v2("/sys/fs/cgroup/cpu.max");
+        std::string q;
+        if (v2 && (v2 >> q >> period)) { if (q != "max") quota = std::strtod(q.c_str(), nullptr); }
+        else {
+            std::ifstream fq("/sys/fs/cgroup/cpu/cpu.cfs_quota_us"), fp("/sys/fs/cgroup/cpu/cpu.cfs_period_us");
+            if (!(fq >> quota) || !(fp >> period)) quota = period = 0.0;
+        }
+        if (quota > 0.0 && period > 0.0) n = std::min(n, (int) std::ceil(quota / period));
+        return std::max(n, 1);
+    }();
+    return cached;
+}
 template <typename Fn>
 static void parallel_lanes(uint64_t begin, uint64_t end, int threads, Fn fn) {
-    if (threads <= 0) threads = (int) std::thread::hardware_concurrency();
+    if (threads <= 0) threads = default_threads();
     if (threads < 1) threads = 1;
     uint64_t n = end - begin;
     if (n < 4096 || threads == 1) { fn(0, begin, end); return; }
@@ -1374,7 +1396,7 @@ static void parallel_lanes(uint64_t begin, uint64_t end, int threads, Fn fn) {
 }
 
 static int resolve_threads(int threads) {
-    if (threads <= 0) threads = (int) std::thread::hardware_concurrency();
+    if (threads <= 0) threads = default_threads();
     return threads < 1 ? 1 : threads;
 }
 
@@ -2045,6 +2067,7 @@ void orc_mesh_compute_normals(uint32_t nv, float *vertices, uint32_t nf, const u
 }
 void orc_coordinate_system(const float n[3], float s[3], float t[3]) { V3 a, b; coordinate_system(V3(n[0], n[1], n[2]), a, b); s[0] = a.x; s[1] = a.y; s[2] = a.z; t[0] = b.x; t[1] = b.y; t[2] = b.z; }
 float orc_sincos(float x, float *c) { return sincos(x, c); }
+int orc_default_threads(void) { return default_threads(); }
 /* the restated Dr.Jit elementary functions of orc_math.h: 0 exp, 1 log, 2 erf, 3 atan2(x, y), 4 acos, 5 tan, 6 erfinv */
 float orc_math_fn(int fn, float x, float y) {
     switch (fn) {

@@ -149,6 +149,8 @@ def lib():
         L.orc_coordinate_system.argtypes = [c_f32p, c_f32p, c_f32p]
         L.orc_sincos.restype = C.c_float
         L.orc_sincos.argtypes = [C.c_float, c_f32p]
+        L.orc_default_threads.restype = C.c_int
+        L.orc_default_threads.argtypes = []
         L.orc_math_fn.restype = C.c_float
         L.orc_math_fn.argtypes = [C.c_int, C.c_float, C.c_float]
         L.orc_surface_interaction.argtypes = [C.c_void_p, c_f32p, c_f32p, C.c_float, C.c_float, C.c_float,
