@@ -1853,7 +1853,10 @@ static int prb_backward_impl(void *scene, const OrcSensor *sp, const float *grad
     for (size_t i = 0; i < npx; ++i) { float w = wfilm[4 * i + 3]; float iw = w == 0.f ? 1.f : w; for (int c = 0; c < 3; ++c) adj[3 * i + c] = grad_in[3 * i + c] / iw; }
     // per-thread gradient buffers
     size_t nb = sc.bsdfs.size();
-    std::vector<std::vector<float>> g_refl(threads), g_emit(threads), g_extra(threads);
+    /* the scalar slots (constant albedos, emitter radiance, alpha / eta / k) receive a term from every vertex of every path: they are summed in float -- like the
+     * scatter_reduce of the reference -- over blocks of at most 8192 lanes and the block sums in double, so that the total does not depend on how many lanes a
+     * worker happens to process (a single float accumulator per worker stagnates: 0.3 % low after 10^6 paths, which 256 workers hid and 16 did not) */
+    std::vector<std::vector<double>> g_refl(threads), g_emit(threads), g_extra(threads);
     std::vector<std::vector<std::vector<float>>> g_tex(threads);
     std::vector<std::vector<std::vector<double>>> g_pos(threads), g_nrm(threads);
     std::vector<std::vector<double>> g_inst(threads);
@@ -1861,14 +1864,20 @@ static int prb_backward_impl(void *scene, const OrcSensor *sp, const float *grad
     uint32_t md = (uint32_t) max_depth, rd = (uint32_t) rr_depth;
     parallel_lanes(lb, le, threads, [&](int t, uint64_t b, uint64_t e) {
         if (g_refl[t].empty()) {
-            g_refl[t].assign(3 * nb + 3, 0.f); g_emit[t].assign(3 * sc.emitters.size() + 3, 0.f); g_extra[t].assign(15 * nb + 15, 0.f);
+            g_refl[t].assign(3 * nb + 3, 0.0); g_emit[t].assign(3 * sc.emitters.size() + 3, 0.0); g_extra[t].assign(15 * nb + 15, 0.0);
             g_tex[t].resize(sc.textures.size());
             for (size_t k = 0; k < sc.textures.size(); ++k) g_tex[t][k].assign(3 * (size_t) sc.textures[k].w * sc.textures[k].h, 0.f);
         }
         std::vector<float *> tp(sc.textures.size() + 1, nullptr);
         for (size_t k = 0; k < sc.textures.size(); ++k) tp[k] = g_tex[t][k].data();
-        GradSink sink{ g_refl[t].data(), tp.data(), grad_emitters ? g_emit[t].data() : nullptr };
-        sink.extra = grad_bsdf_params ? g_extra[t].data() : nullptr;
+        std::vector<float> b_refl(g_refl[t].size()), b_emit(g_emit[t].size()), b_extra(g_extra[t].size());     /* sums of the current block of lanes */
+        GradSink sink{ b_refl.data(), tp.data(), grad_emitters ? b_emit.data() : nullptr };
+        sink.extra = grad_bsdf_params ? b_extra.data() : nullptr;
+        auto flush_block = [&]() {
+            for (size_t k = 0; k < b_refl.size(); ++k) { g_refl[t][k] += (double) b_refl[k]; b_refl[k] = 0.f; }
+            for (size_t k = 0; k < b_emit.size(); ++k) { g_emit[t][k] += (double) b_emit[k]; b_emit[k] = 0.f; }
+            for (size_t k = 0; k < b_extra.size(); ++k) { g_extra[t][k] += (double) b_extra[k]; b_extra[k] = 0.f; }
+        };
         std::vector<double *> pp(sc.meshes.size() + 1, nullptr), pn(sc.meshes.size() + 1, nullptr); ShapeSink shape{ pp.data(), pos_mask };
         if (pos_mask) {
             if (g_pos[t].empty()) {
@@ -1915,13 +1924,22 @@ static int prb_backward_impl(void *scene, const OrcSensor *sp, const float *grad
             V3 Lp = prb_sample(sc, rng2, L.ray, md, rd, true, V3(0.f), V3(0.f), nullptr, valid, dummy);
             prb_sample(sc, L.rng, L.ray, md, rd, false, Lp, dL, &sink, valid, sts[t]);
             sts[t].paths++;
+            if (((i - b) & 8191u) == 8191u) flush_block();
         }
+        flush_block();
     });
+    std::vector<double> t_refl(3 * nb + 3, 0.0), t_emit(3 * sc.emitters.size() + 3, 0.0), t_extra(15 * nb + 15, 0.0);
     for (int t = 0; t < threads; ++t) {
         if (g_refl[t].empty()) continue;
-        if (grad_reflectance) for (size_t i = 0; i < 3 * nb; ++i) grad_reflectance[i] += g_refl[t][i];
-        if (grad_emitters) for (size_t i = 0; i < 3 * sc.emitters.size(); ++i) grad_emitters[i] += g_emit[t][i];
-        if (grad_bsdf_params) for (size_t i = 0; i < 15 * nb; ++i) grad_bsdf_params[i] += g_extra[t][i];
+        for (size_t i = 0; i < 3 * nb; ++i) t_refl[i] += g_refl[t][i];
+        for (size_t i = 0; i < 3 * sc.emitters.size(); ++i) t_emit[i] += g_emit[t][i];
+        for (size_t i = 0; i < 15 * nb; ++i) t_extra[i] += g_extra[t][i];
+    }
+    if (grad_reflectance) for (size_t i = 0; i < 3 * nb; ++i) grad_reflectance[i] += (float) t_refl[i];
+    if (grad_emitters) for (size_t i = 0; i < 3 * sc.emitters.size(); ++i) grad_emitters[i] += (float) t_emit[i];
+    if (grad_bsdf_params) for (size_t i = 0; i < 15 * nb; ++i) grad_bsdf_params[i] += (float) t_extra[i];
+    for (int t = 0; t < threads; ++t) {
+        if (g_refl[t].empty()) continue;
         for (size_t k = 0; k < sc.textures.size(); ++k)
             if (grad_textures && grad_textures[k]) { float *dst = grad_textures[k]; for (size_t i = 0; i < g_tex[t][k].size(); ++i) dst[i] += g_tex[t][k][i]; }
         if (inst_mask && grad_to_world && !g_inst[t].empty()) for (size_t i = 0; i < 12 * sc.instances.size(); ++i) grad_to_world[i] += g_inst[t][i];

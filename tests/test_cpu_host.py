@@ -408,3 +408,19 @@ def test_elementary_functions_accuracy_and_host_device_agreement(O):
     assert abs(L.orc_math_fn(1, 1e-40, 0.0) - math.log(1e-40)) < 1e-4 and L.orc_math_fn(1, 1e-40, 0.0) == H.hh_math_fn(1, 1e-40, 0.0)
     for x in rng.uniform(-0.999, 0.999, 2000).astype(np.float32):
         a = L.orc_math_fn(6, float(x), 0.0); assert a == H.hh_math_fn(6, float(x), 0.0) and abs(math.erf(a) - float(x)) < 2e-6
+
+
+def test_scalar_gradient_sums_do_not_depend_on_the_worker_count(O):
+    """render_prb_backward adds a term to the emitter / constant-albedo slots for every vertex of every path.  A float accumulator per worker loses the small
+    terms once its sum has grown (6e-4 low after 3e5 paths on one thread, 3e-3 after 1e6 -- which is how the 16-core GPU boxes failed the full-film PRB test the
+    256-thread runs passed); block sums in float, totals in double: the result is the same for 1 and 8 workers."""
+    res, spp = 48, 96
+    sd, sensor = O.cornell_box(res, res)
+    osc = O.OracleScene(sd)
+    g = np.full((res, res, 3), 1.0 / (res * res * 3), np.float32)
+    out = {}
+    for th in (1, 8):
+        g_refl, _, g_emit, _ = osc.render_prb_backward_emitters(sensor, g, seed=3, spp=spp, max_depth=6, threads=th)
+        out[th] = np.concatenate([np.asarray(g_refl, np.float64).reshape(-1), np.asarray(g_emit, np.float64).reshape(-1)])
+    m = np.abs(out[8]) > 0
+    assert m.sum() >= 6 and np.abs(out[1][m] / out[8][m] - 1).max() < 1e-5
