@@ -352,7 +352,11 @@ HAR_HD bool accel_trace(const Accel &A, Vec3 o_w, Vec3 d_w, float maxt, Hit &hit
  * Both visit the same set of candidate triangles with the exact Moeller-Trumbore test and the same
  * tie rule, so the result is identical to accel_trace (order independent).
  */
-template <int POLICY>
+/* FLAT = true: the specialisation for scenes WITHOUT a TLAS (Accel::has_tlas == 0: one BLAS over the top-level meshes -- the Cornell boxes, the flattened
+ * 1M-triangle scene).  `in_tlas` is constantly false there, so the instance-entry block, the instance exit with its second ray_setup, the world-space copy
+ * of the ray and the instance / phase flags all fold away at compile time; the persistent kernels are instantiated for both (launch_trace_closest /
+ * launch_resolve pick by has_tlas).  Same visits, same tests, same result as the generic code on such a scene. */
+template <int POLICY, bool FLAT = false>
 struct Traversal {
     Vec3 o_w, d_w;
     RaySetup R;
@@ -371,8 +375,9 @@ struct Traversal {
         o_w = o; d_w = d; tmax = maxt; top_pending = false; this->top_last = top_last && POLICY != 2;
         hit.t = HAR_INF; hit.u = 0.f; hit.v = 0.f; hit.prim = 0; hit.shape = 0; hit.inst = 0xffffffffu;
         R = ray_setup(o, d);
-        in_tlas = A.has_tlas != 0; cur_inst = 0xffffffffu; found = false;
+        in_tlas = !FLAT && A.has_tlas != 0; cur_inst = 0xffffffffu; found = false;
         ng_x = A.root; ng_y = 0x80000000u; tg_x = 0; tg_y = 0; sp = 0; inst_sp = -1; parked = 0;
+        if (FLAT) { this->top_last = false; return; }
         /* top-level geometry first (see Accel): the state "in a BLAS, no instance" (in_tlas false, cur_inst none) only exists in this phase of a
          * two-level scene -- TLAS entries always carry an instance index -- so no extra flag is kept */
         if (A.has_tlas && A.top_root != HAR_NO_NODE) {
@@ -407,11 +412,11 @@ struct Traversal {
         if (POLICY == 2 && tg_y == 0u && ng_y <= 0x00ffffffu && ng_y != 0u) { tg_x = ng_x; tg_y = ng_y; ng_x = 0; ng_y = 0; }
         /* allow_inst = false (persistent kernels, deferred instance entry): a lane whose next leaf item is an instance entry waits this step out -- the
          * entry block (ray transform, reciprocals, two pushes: ~100 instructions) then runs when several lanes of the wave need it, not for one */
-        if (tg_y != 0u && (allow_inst || !in_tlas)) {
+        if (tg_y != 0u && (FLAT || allow_inst || !in_tlas)) {
             uint32_t bit = 31u - clz32(tg_y);
             tg_y &= ~(1u << bit);
             uint32_t idx = tg_x + bit;
-            if (in_tlas) {
+            if (!FLAT && in_tlas) {
                 if (POLICY == 2 ? ng_y != 0u : ng_y > 0x00ffffffu) {      /* POLICY 2: ng may hold a waiting instance list */
                     if (sp >= Stack::Capacity) return overflow(status);
                     stack.push(sp++, ng_x, ng_y);
@@ -427,7 +432,7 @@ struct Traversal {
                 ng_x = I.blas_root; ng_y = 0x80000000u; tg_y = 0;
             } else {
                 probe.tri();
-                if (tri_visit<AnyHit>(A, R, tmax, idx, cur_inst, hit)) { found = true; return true; }
+                if (tri_visit<AnyHit>(A, R, tmax, idx, FLAT ? 0xffffffffu : cur_inst, hit)) { found = true; return true; }
             }
         }
         return false;
@@ -439,7 +444,7 @@ struct Traversal {
             /* pop as soon as no group is held in ng, even while triangles are pending (they are tested one per
              * iteration in parallel with the node visits); a popped triangle group waits in ng until tg is empty */
             if (ng_y == 0u) {
-                if (!in_tlas && sp == inst_sp) {
+                if (!FLAT && !in_tlas && sp == inst_sp) {
                     if (tg_y != 0u) return false;                      /* drain the instance's triangles first */
                     const bool top_phase = cur_inst == 0xffffffffu;
                     in_tlas = true; cur_inst = 0xffffffffu; inst_sp = -1;
@@ -448,12 +453,12 @@ struct Traversal {
                 }
                 if (sp == 0) { if (tg_y != 0u) return false; found = hit.t != HAR_INF; return true; }
                 stack.pop(--sp, ng_x, ng_y);
-                if (!in_tlas && ng_y <= 0x00ffffffu) --parked;         /* in a BLAS only parked triangle groups are non-node entries */
+                if ((FLAT || !in_tlas) && ng_y <= 0x00ffffffu) --parked;         /* in a BLAS only parked triangle groups are non-node entries */
             }
             return false;
         }
         if (ng_y <= 0x00ffffffu && tg_y == 0u) {
-            if (!in_tlas && sp == inst_sp) {
+            if (!FLAT && !in_tlas && sp == inst_sp) {
                 const bool top_phase = cur_inst == 0xffffffffu;
                 in_tlas = true; inst_sp = -1;
                 if (top_phase) {
@@ -464,7 +469,7 @@ struct Traversal {
                 R = ray_setup(o_w, d_w);
             }
             if (sp == 0) {
-                if (TOP_LAST && top_pending) {        /* TLAS exhausted without an occluder: now the top-level geometry (world-space ray, no instance) */
+                if (!FLAT && TOP_LAST && top_pending) {        /* TLAS exhausted without an occluder: now the top-level geometry (world-space ray, no instance) */
                     top_pending = false; in_tlas = false; inst_sp = 0; ng_x = A.top_root; ng_y = 0x80000000u;
                     return false;
                 }
@@ -490,7 +495,7 @@ struct Traversal {
 
     /* one iteration; returns true when the ray is finished (`found` / `hit` hold the result).
      * ORDER 0: node, leaf, pop   1: leaf, node, pop   2: leaf, pop, node */
-    HAR_HD bool wants_instance_entry() const { return in_tlas && tg_y != 0u; }
+    HAR_HD bool wants_instance_entry() const { return !FLAT && in_tlas && tg_y != 0u; }
     template <bool AnyHit, typename Stack, typename Probe = NoProbe, int ORDER = 2>
     HAR_HD bool step(const Accel &A, Stack &stack, int &status, Probe probe = Probe(), bool allow_inst = true) {
         probe.iter();

@@ -406,7 +406,7 @@ __global__ void k_sample_out(uint32_t n, uint32_t n_total, uint32_t first, const
 #define HAR_TRAV_ORDER 0    /* measured: 0 (node, leaf, pop) 687, 2: 660, 1: 643 Mpaths/s on the 1M-tri scene */
 #endif
 
-template <bool ANY, bool RETIRE, typename WaveStack, typename Take, typename Done, typename Retire>
+template <bool ANY, bool RETIRE, typename WaveStack, bool FLAT, typename Take, typename Done, typename Retire>
 __device__ __forceinline__ void trace_persistent(const Accel &A, uint32_t *cursor, uint32_t n, WaveStack &stack, int *status,
                                                  Take take, Done done, Retire retire) {
     const uint32_t lane = threadIdx.x & 63u;
@@ -417,7 +417,7 @@ __device__ __forceinline__ void trace_persistent(const Accel &A, uint32_t *curso
     bool exhausted = false;                    /* wave-uniform */
     bool busy = false, has_result = false;
     uint32_t idx = 0;
-    Traversal<HAR_TRAV_POLICY> T;
+    Traversal<HAR_TRAV_POLICY, FLAT> T;
     T.found = false; T.hit.t = HAR_INF;
     for (;;) {
         const uint64_t idle = __ballot(!busy);
@@ -448,7 +448,7 @@ __device__ __forceinline__ void trace_persistent(const Accel &A, uint32_t *curso
          * use the step).  Closest-hit launches do not defer: on a rank's 8.4 M-lane band the waiting lengthens the last rays' chains (k_trace_closest 12.85 ->
          * 13.99 ms) while a full 67 M-lane frame gains nothing; k_resolve gains on both (7.67 -> 7.37 ms, 26.83 -> 26.27 ms) */
         bool allow_inst = true;
-        if (ANY && HAR_DEFER_INST) {
+        if (ANY && HAR_DEFER_INST && !FLAT) {
             const uint64_t m_inst = __ballot(busy && T.wants_instance_entry());
             allow_inst = (uint32_t) __popcll(m_inst) >= (uint32_t) HAR_DEFER_INST || __ballot(busy) == m_inst;
         }
@@ -481,20 +481,21 @@ __device__ __forceinline__ void trace_persistent(const Accel &A, uint32_t *curso
 #ifndef HAR_TRACE_MIN_WAVES
 #define HAR_TRACE_MIN_WAVES 1     /* __launch_bounds__ waves per SIMD of the traversal kernels (A/B: 7 with an 11-entry LDS stack) */
 #endif
-template <bool SPILL>
+template <bool SPILL, bool FLAT = false>
 __global__ __launch_bounds__(kBlock, HAR_TRACE_MIN_WAVES) void k_trace_closest(Accel A, const uint32_t *count, uint32_t *cursor, uint32_t shard_cap, const float4 *a0,
                                                           const float4 *a1, float4 *h0, uint2 *h1, int *status, uint2 *spill) {
     __shared__ uint2 lds[HAR_LDS_STACK_SMALL * kBlock];
     typedef typename WaveStackOf<SPILL>::type WaveStack;
+    typedef Traversal<HAR_TRAV_POLICY, FLAT> Trav;
     WaveStack stack = make_wave_stack<SPILL>(lds, spill);
     const uint32_t shard = blockIdx.x & (HAR_SHARDS - 1), n = count[shard * HAR_COUNTER_STRIDE], base = shard * shard_cap;
     if (n == 0) return;
-    auto take = [&](uint32_t idx, Traversal<HAR_TRAV_POLICY> &T) {
+    auto take = [&](uint32_t idx, Trav &T) {
         float4 o = a0[base + idx], d = a1[base + idx];
         T.begin(A, Vec3(o.x, o.y, o.z), Vec3(d.x, d.y, d.z), o.w < 0.f ? HAR_LARGEST : o.w, (A.top_last & 2u) != 0u);
         return true;
     };
-    auto store = [&](uint32_t idx, const Traversal<HAR_TRAV_POLICY> &T) {
+    auto store = [&](uint32_t idx, const Trav &T) {
         h0[HIT0(base + idx)] = make_float4(T.hit.t, T.hit.u, T.hit.v, __uint_as_float(T.hit.prim));
 #if HAR_HIT_INTERLEAVED      /* the second half as ONE 16-byte store: the ray's 32-byte sector is written completely (no byte-masked partial write) */
         *reinterpret_cast<uint4 *>(h1 + HIT1(base + idx)) = make_uint4(T.hit.shape, T.hit.inst, 0u, 0u);
@@ -505,12 +506,12 @@ __global__ __launch_bounds__(kBlock, HAR_TRACE_MIN_WAVES) void k_trace_closest(A
 #if HAR_CLOSEST_RETIRE
     /* hits are committed at refill time by all lanes that finished since the last refill (one store instruction for >= HAR_REFILL_IDLE lanes)
      * instead of by each lane in the iteration it finishes in (a store instruction + address arithmetic issued for one or two lanes) */
-    trace_persistent<false, true, WaveStack>(A, cursor + shard * HAR_COUNTER_STRIDE, n, stack, status, take,
-        [&](uint32_t, const Traversal<HAR_TRAV_POLICY> &) { },
-        [&](bool pred, uint32_t idx, const Traversal<HAR_TRAV_POLICY> &T) { if (pred) store(idx, T); });
+    trace_persistent<false, true, WaveStack, FLAT>(A, cursor + shard * HAR_COUNTER_STRIDE, n, stack, status, take,
+        [&](uint32_t, const Trav &) { },
+        [&](bool pred, uint32_t idx, const Trav &T) { if (pred) store(idx, T); });
 #else
-    trace_persistent<false, false, WaveStack>(A, cursor + shard * HAR_COUNTER_STRIDE, n, stack, status, take, store,
-        [&](bool, uint32_t, const Traversal<HAR_TRAV_POLICY> &) { });
+    trace_persistent<false, false, WaveStack, FLAT>(A, cursor + shard * HAR_COUNTER_STRIDE, n, stack, status, take, store,
+        [&](bool, uint32_t, const Trav &) { });
 #endif
 }
 
@@ -1080,7 +1081,7 @@ __global__ __launch_bounds__(kBlock) void k_resolve_adjoint_cached(DScene S, con
 }
 
 /* ------------------------------------------------- resolve (shadow rays + NEE) */
-template <int MODE, bool SPILL, bool FWD = false>
+template <int MODE, bool SPILL, bool FWD = false, bool FLAT = false>
 __global__ __launch_bounds__(kBlock, HAR_TRACE_MIN_WAVES) void k_resolve(DScene S, const uint32_t *item_count, uint32_t *cursor, uint32_t shard_cap, ItemArrays items, float4 *result,
                                                     const float4 *dL, float *grad_refl, float *const *grad_tex, int *status, ReplayCache rc, uint2 *spill, uint8_t *item_vis) {
     __shared__ uint2 lds[HAR_LDS_STACK_SMALL * kBlock];
@@ -1089,6 +1090,7 @@ __global__ __launch_bounds__(kBlock, HAR_TRACE_MIN_WAVES) void k_resolve(DScene 
      * made the adjoint 10x slower than the primal pass.  ds_add_f32 here, one global atomic per block and entry. */
     __shared__ float gacc[MODE == MODE_PRB_ADJOINT ? 3 * HAR_LDS_GRAD_BSDFS : 1];
     typedef typename WaveStackOf<SPILL>::type WaveStack;
+    typedef Traversal<HAR_TRAV_POLICY, FLAT> Trav;
     WaveStack stack = make_wave_stack<SPILL>(lds, spill);
     const uint32_t shard = blockIdx.x & (HAR_SHARDS - 1), n = item_count[shard * HAR_COUNTER_STRIDE], base = shard * shard_cap;
     if (n == 0) return;
@@ -1096,7 +1098,7 @@ __global__ __launch_bounds__(kBlock, HAR_TRACE_MIN_WAVES) void k_resolve(DScene 
         for (uint32_t k = threadIdx.x; k < 3 * HAR_LDS_GRAD_BSDFS; k += kBlock) gacc[k] = 0.f;
         __syncthreads();
     }
-    auto take = [&](uint32_t idx, Traversal<HAR_TRAV_POLICY> &T) {
+    auto take = [&](uint32_t idx, Trav &T) {
         float4 s0 = items.s0[base + idx];
         if (!(s0.w >= 0.f)) return false;
         float4 s1 = items.s1[base + idx];
@@ -1105,8 +1107,8 @@ __global__ __launch_bounds__(kBlock, HAR_TRACE_MIN_WAVES) void k_resolve(DScene 
     };
     if (MODE == MODE_PATH || MODE == MODE_PRB_PRIMAL) {
         /* forward: an unoccluded item adds its contribution to its lane's radiance (one item per lane and bounce: no race) */
-        trace_persistent<true, false, WaveStack>(S.accel, cursor + shard * HAR_COUNTER_STRIDE, n, stack, status, take,
-            [&](uint32_t idx, const Traversal<HAR_TRAV_POLICY> &T) {
+        trace_persistent<true, false, WaveStack, FLAT>(S.accel, cursor + shard * HAR_COUNTER_STRIDE, n, stack, status, take,
+            [&](uint32_t idx, const Trav &T) {
                 const uint32_t i = base + idx;
                 if (rc.mode == 1) rc.vis[__float_as_uint(items.s1[i].w)] = T.found ? 0 : 1;      /* replay cache: per lane */
                 else if (rc.mode == 3 || rc.mode == 5) rc.vis[__float_as_uint(items.s2[i].w)] = T.found ? 0 : 1; /* replay / record tape: per vertex slot */
@@ -1116,13 +1118,13 @@ __global__ __launch_bounds__(kBlock, HAR_TRACE_MIN_WAVES) void k_resolve(DScene 
                     result[lane] = make_float4(r.x + s2.x, r.y + s2.y, r.z + s2.z, 0.f);
                 }
             },
-            [&](bool, uint32_t, const Traversal<HAR_TRAV_POLICY> &) { });
+            [&](bool, uint32_t, const Trav &) { });
     } else {
         /* adjoint: L <- L - Lr_dir; g = dL * (dLr_dir/drho + [bsdf_val != 0] L / rho)  (prb.py:227,288-313);
          * gradients are committed at refill time by ALL lanes so that the wave pre-reduction can run */
-        trace_persistent<true, true, WaveStack>(S.accel, cursor + shard * HAR_COUNTER_STRIDE, n, stack, status, take,
-            [&](uint32_t, const Traversal<HAR_TRAV_POLICY> &) { },
-            [&](bool pred, uint32_t idx, const Traversal<HAR_TRAV_POLICY> &T) {
+        trace_persistent<true, true, WaveStack, FLAT>(S.accel, cursor + shard * HAR_COUNTER_STRIDE, n, stack, status, take,
+            [&](uint32_t, const Trav &) { },
+            [&](bool pred, uint32_t idx, const Trav &T) {
                 adjoint_commit<FWD>(S, items, base + (pred ? idx : 0u), pred, pred && !T.found, result, dL, grad_refl, grad_tex, gacc, item_vis);
             });
         __syncthreads();
@@ -1609,9 +1611,13 @@ void launch_raygen_rays(hipStream_t s, uint32_t seed, uint32_t lane_base, uint32
 void launch_sample_out(hipStream_t s, uint32_t n, uint32_t n_total, uint32_t first, const float4 *result, const float *valid_lane, int zero_invalid, float *rgb, uint8_t *valid) {
     hipLaunchKernelGGL(k_sample_out, dim3(blocks_for(n)), dim3(kBlock), 0, s, n, n_total, first, result, valid_lane, zero_invalid, rgb, valid);
 }
+/* HAR_FLAT_KERNELS=0: scenes without a TLAS run the generic traversal kernels (A/B switch) */
+static bool flat_kernels() { static const bool on = !(getenv("HAR_FLAT_KERNELS") && atoi(getenv("HAR_FLAT_KERNELS")) == 0); return on; }
 void launch_trace_closest(hipStream_t s, uint32_t grid, uint2 *spill, const Accel &A, const uint32_t *count, uint32_t *cursor, uint32_t shard_cap,
                           const WaveState &in, float4 *h0, uint2 *h1, int *status) {
+    /* scenes without a TLAS run the FLAT instantiation of the traversal (har_accel.h): no instance blocks, no world-space ray copy */
     if (spill) hipLaunchKernelGGL(k_trace_closest<true>, dim3(grid), dim3(kBlock), 0, s, A, count, cursor, shard_cap, in.a0, in.a1, h0, h1, status, spill);
+    else if (!A.has_tlas && flat_kernels()) hipLaunchKernelGGL((k_trace_closest<false, true>), dim3(grid), dim3(kBlock), 0, s, A, count, cursor, shard_cap, in.a0, in.a1, h0, h1, status, spill);
     else hipLaunchKernelGGL(k_trace_closest<false>, dim3(grid), dim3(kBlock), 0, s, A, count, cursor, shard_cap, in.a0, in.a1, h0, h1, status, spill);
 }
 void launch_shade(int mode, hipStream_t s, uint32_t grid, const DScene &S, const ShadeParams &P, uint32_t lane_base, uint32_t shard_cap, const uint32_t *count_in,
@@ -1717,11 +1723,12 @@ void launch_resolve(int mode, hipStream_t s, uint32_t grid, uint2 *spill, const 
         else hipLaunchKernelGGL(k_resolve_adjoint_cached<false>, g, b, 0, s, S, item_count, shard_cap, items, result, dL, grad_refl, grad_tex, rc, item_vis, tq ? *tq : no_tq);
         return;
     }
-#define HAR_LAUNCH_RESOLVE(M, SP) hipLaunchKernelGGL((k_resolve<M, SP>), g, b, 0, s, S, item_count, cursor, shard_cap, items, result, dL, grad_refl, grad_tex, status, rc, spill, item_vis)
+#define HAR_LAUNCH_RESOLVE(M, SP, FL) hipLaunchKernelGGL((k_resolve<M, SP, false, FL>), g, b, 0, s, S, item_count, cursor, shard_cap, items, result, dL, grad_refl, grad_tex, status, rc, spill, item_vis)
 #define HAR_LAUNCH_RESOLVE_FWD(SP) hipLaunchKernelGGL((k_resolve<MODE_PRB_ADJOINT, SP, true>), g, b, 0, s, S, item_count, cursor, shard_cap, items, result, dL, grad_refl, grad_tex, status, rc, spill, item_vis)
+    const bool flat = !spill && !S.accel.has_tlas && flat_kernels();
     if (mode == MODE_PRB_ADJOINT && fwd) { if (spill) HAR_LAUNCH_RESOLVE_FWD(true); else HAR_LAUNCH_RESOLVE_FWD(false); }
-    else if (mode == MODE_PRB_ADJOINT) { if (spill) HAR_LAUNCH_RESOLVE(MODE_PRB_ADJOINT, true); else HAR_LAUNCH_RESOLVE(MODE_PRB_ADJOINT, false); }
-    else { if (spill) HAR_LAUNCH_RESOLVE(MODE_PATH, true); else HAR_LAUNCH_RESOLVE(MODE_PATH, false); }
+    else if (mode == MODE_PRB_ADJOINT) { if (spill) HAR_LAUNCH_RESOLVE(MODE_PRB_ADJOINT, true, false); else if (flat) HAR_LAUNCH_RESOLVE(MODE_PRB_ADJOINT, false, true); else HAR_LAUNCH_RESOLVE(MODE_PRB_ADJOINT, false, false); }
+    else { if (spill) HAR_LAUNCH_RESOLVE(MODE_PATH, true, false); else if (flat) HAR_LAUNCH_RESOLVE(MODE_PATH, false, true); else HAR_LAUNCH_RESOLVE(MODE_PATH, false, false); }
 #undef HAR_LAUNCH_RESOLVE
 #undef HAR_LAUNCH_RESOLVE_FWD
 }

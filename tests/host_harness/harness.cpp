@@ -136,7 +136,19 @@ int hh_trace(void *h, uint32_t n, const float *o, const float *d, const float *m
     for (uint32_t i = 0; i < n; ++i) {
         Vec3 O(o[i], o[n + i], o[2 * (size_t) n + i]), D(d[i], d[n + i], d[2 * (size_t) n + i]);
         Hit hit; HostStack st; bool r;
-        if (naive) r = anyhit ? accel_trace_naive<true>(H->ds.accel, H->ds.blas_tri_ranges, O, D, maxt[i], hit)
+        if (naive >= 2) {
+            /* the persistent kernels' resumable traversal, stepped to the end: 2 = the instantiation the launchers pick (FLAT for a scene without a TLAS),
+             * 3 = always the generic one */
+            const Accel &A = H->ds.accel; const bool tl = (A.top_last & (anyhit ? 1u : 2u)) != 0u;
+            auto run = [&](auto &T) {
+                T.begin(A, O, D, maxt[i], tl);
+                if (anyhit) { while (!T.template step<true, HostStack, NoProbe, 0>(A, st, status)) { } }
+                else        { while (!T.template step<false, HostStack, NoProbe, 0>(A, st, status)) { } }
+                hit = T.hit; return T.found;
+            };
+            if (naive == 2 && !A.has_tlas) { Traversal<0, true> T; r = run(T); } else { Traversal<0, false> T; r = run(T); }
+        }
+        else if (naive) r = anyhit ? accel_trace_naive<true>(H->ds.accel, H->ds.blas_tri_ranges, O, D, maxt[i], hit)
                               : accel_trace_naive<false>(H->ds.accel, H->ds.blas_tri_ranges, O, D, maxt[i], hit);
         else       r = anyhit ? accel_trace<true>(H->ds.accel, O, D, maxt[i], hit, st, status)
                               : accel_trace<false>(H->ds.accel, O, D, maxt[i], hit, st, status);

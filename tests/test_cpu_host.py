@@ -224,14 +224,16 @@ def _trace_both(H, O, scene, osc, n, seed):
     t = np.empty(n, np.float32); u = np.empty(n, np.float32); v = np.empty(n, np.float32)
     p = np.empty(n, np.uint32); s = np.empty(n, np.uint32); i = np.empty(n, np.uint32); hf = np.empty(n, np.uint8)
     hfp = hf.ctypes.data_as(C.POINTER(C.c_uint8))
-    for naive in (0, 1):
+    for naive in (0, 1, 2, 3):      # reference loop, brute force, the persistent kernels' resumable traversal (2: the instantiation the launchers pick -- FLAT without a TLAS; 3: generic)
         assert H.hh_trace(h, n, O.fp(o), O.fp(d), O.fp(maxt), naive, 0, O.fp(t), O.fp(u), O.fp(v), O.up(p), O.up(s), O.up(i), hfp) == 0
         hit = np.isfinite(ref[0])
         assert np.array_equal(t, ref[0]) and np.array_equal(u[hit], ref[1][hit]) and np.array_equal(v[hit], ref[2][hit])
         assert np.array_equal(p[hit], ref[3][hit]) and np.array_equal(s[hit], ref[4][hit]) and np.array_equal(i[hit], ref[5][hit])
     maxt2 = rng.uniform(0.05, 2.5, n).astype(np.float32)
-    H.hh_trace(h, n, O.fp(o), O.fp(d), O.fp(maxt2), 0, 1, O.fp(t), O.fp(u), O.fp(v), O.up(p), O.up(s), O.up(i), hfp)
-    assert np.array_equal(hf.astype(bool), osc.ray_test(o, d, maxt2))
+    occluded = osc.ray_test(o, d, maxt2)
+    for naive in (0, 2, 3):
+        H.hh_trace(h, n, O.fp(o), O.fp(d), O.fp(maxt2), naive, 1, O.fp(t), O.fp(u), O.fp(v), O.up(p), O.up(s), O.up(i), hfp)
+        assert np.array_equal(hf.astype(bool), occluded)
     H.hh_scene_destroy(h)
 
 
