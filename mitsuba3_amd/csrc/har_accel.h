@@ -356,6 +356,12 @@ HAR_HD bool accel_trace(const Accel &A, Vec3 o_w, Vec3 d_w, float maxt, Hit &hit
  * 1M-triangle scene).  `in_tlas` is constantly false there, so the instance-entry block, the instance exit with its second ray_setup, the world-space copy
  * of the ray and the instance / phase flags all fold away at compile time; the persistent kernels are instantiated for both (launch_trace_closest /
  * launch_resolve pick by has_tlas).  Same visits, same tests, same result as the generic code on such a scene. */
+#define HAR_INST_LEAVING  0xfffffffeu
+#define HAR_INST_ENTERING 0xfffffffdu
+#ifndef HAR_DEFER_XFORM
+#define HAR_DEFER_XFORM 1     /* instance entry / exit only NOTE the transition; the object-space ray, cur_inst and the BLAS root are set at ONE place, the top of
+                               * the next step (apply_pending) -- see Traversal::pend.  0: they are set where the transition happens (round-2 form) */
+#endif
 template <int POLICY, bool FLAT = false>
 struct Traversal {
     Vec3 o_w, d_w;
@@ -367,6 +373,9 @@ struct Traversal {
     uint32_t parked;            /* POLICY 2: triangle groups currently parked on the stack (<= HAR_MAX_PARKED) */
     bool in_tlas, found;
     bool top_last, top_pending; /* any-hit rays: TLAS first, then the top-level BLAS (begin); top_pending: it is still to be walked once the TLAS is exhausted */
+    /* pending ray transition (HAR_DEFER_XFORM), kept in cur_inst: HAR_INST_LEAVING = leave the instance (world-space ray again), HAR_INST_ENTERING = enter the
+     * instance record whose index waits in ng_x.  Why: `R`, `cur_inst` and `ng_x` re-defined inside the leaf and pop phases made the compiler keep TWO copies of
+     * that state (15 registers) and shuffle them with v_mov every wave step (ISA audit). */
 
     /* top_last (any-hit queries only; pair it with step<AnyHit = true>): walk the TLAS FIRST and the top-level BLAS afterwards.  For a closest-hit ray
      * the top-level geometry goes first so that the TLAS is entered with tmax at the nearest wall; an occlusion query has no use for that, and on a
@@ -426,10 +435,16 @@ struct Traversal {
                     stack.push(sp++, tg_x, tg_y);
                 }
                 probe.inst();
+                inst_sp = sp; in_tlas = false;
+#if HAR_DEFER_XFORM
+                cur_inst = HAR_INST_ENTERING; ng_x = idx;
+#else
                 const InstRec &I = A.insts[idx];
-                inst_sp = sp; cur_inst = I.inst_index; in_tlas = false;
+                cur_inst = I.inst_index;
                 if (!I.identity) R = ray_setup(xf_point(I.to_object, o_w), xf_vector(I.to_object, d_w));
-                ng_x = I.blas_root; ng_y = 0x80000000u; tg_y = 0;
+                ng_x = I.blas_root;
+#endif
+                ng_y = 0x80000000u; tg_y = 0;
             } else {
                 probe.tri();
                 if (tri_visit<AnyHit>(A, R, tmax, idx, FLAT ? 0xffffffffu : cur_inst, hit)) { found = true; return true; }
@@ -447,9 +462,9 @@ struct Traversal {
                 if (!FLAT && !in_tlas && sp == inst_sp) {
                     if (tg_y != 0u) return false;                      /* drain the instance's triangles first */
                     const bool top_phase = cur_inst == 0xffffffffu;
-                    in_tlas = true; cur_inst = 0xffffffffu; inst_sp = -1;
+                    in_tlas = true; inst_sp = -1;
                     if (top_phase) { ng_x = A.root; ng_y = 0x80000000u; return false; }
-                    R = ray_setup(o_w, d_w);
+                    leave_instance();
                 }
                 if (sp == 0) { if (tg_y != 0u) return false; found = hit.t != HAR_INF; return true; }
                 stack.pop(--sp, ng_x, ng_y);
@@ -465,8 +480,7 @@ struct Traversal {
                     if (TOP_LAST && top_last) { found = hit.t != HAR_INF; return true; } /* any-hit order: the top-level BLAS was the last thing to walk */
                     ng_x = A.root; ng_y = 0x80000000u; return false;                      /* top-level BLAS done: on to the TLAS with the same (world-space) ray */
                 }
-                cur_inst = 0xffffffffu;
-                R = ray_setup(o_w, d_w);
+                leave_instance();
             }
             if (sp == 0) {
                 if (!FLAT && TOP_LAST && top_pending) {        /* TLAS exhausted without an occluder: now the top-level geometry (world-space ray, no instance) */
@@ -482,6 +496,28 @@ struct Traversal {
         return false;
     }
     HAR_HD bool overflow(int &status) { status = HAR_STACK_OVERFLOW; hit.t = HAR_INF; found = false; return true; }
+    HAR_HD void leave_instance() {
+#if HAR_DEFER_XFORM
+        cur_inst = HAR_INST_LEAVING;
+#else
+        cur_inst = 0xffffffffu; R = ray_setup(o_w, d_w);
+#endif
+    }
+    /* the one place where the ray changes its space (HAR_DEFER_XFORM): called at the top of every step */
+    HAR_HD void apply_pending(const Accel &A) {
+#if HAR_DEFER_XFORM
+        if (!FLAT && (cur_inst == HAR_INST_LEAVING || cur_inst == HAR_INST_ENTERING)) {
+            if (cur_inst == HAR_INST_LEAVING) { cur_inst = 0xffffffffu; R = ray_setup(o_w, d_w); }
+            else {
+                const InstRec &I = A.insts[ng_x];
+                cur_inst = I.inst_index; ng_x = I.blas_root;
+                if (!I.identity) R = ray_setup(xf_point(I.to_object, o_w), xf_vector(I.to_object, d_w));
+            }
+        }
+#else
+        (void) A;
+#endif
+    }
 
     /* extra leaf round of the persistent kernels: one more leaf item + pop for a lane that still has one pending,
      * so that it is ready for a node visit in the next iteration (the node block is the expensive one) */
@@ -499,6 +535,7 @@ struct Traversal {
     template <bool AnyHit, typename Stack, typename Probe = NoProbe, int ORDER = 2>
     HAR_HD bool step(const Accel &A, Stack &stack, int &status, Probe probe = Probe(), bool allow_inst = true) {
         probe.iter();
+        apply_pending(A);
         /* the TLAS-first order is switched on per ray by begin(..., top_last) from Accel::top_last */
         if (ORDER == 0) {
             if (phase_node(A, stack, status, probe)) return true;
@@ -506,11 +543,13 @@ struct Traversal {
             return phase_pop<Stack, true>(A, stack);
         } else if (ORDER == 1) {
             if (phase_leaf<AnyHit>(A, stack, status, probe, allow_inst)) return true;
+            apply_pending(A);                       /* the node phase of THIS step already walks the instance just entered */
             if (phase_node(A, stack, status, probe)) return true;
             return phase_pop<Stack, true>(A, stack);
         } else {
             if (phase_leaf<AnyHit>(A, stack, status, probe, allow_inst)) return true;
             if (phase_pop<Stack, true>(A, stack)) return true;
+            apply_pending(A);
             return phase_node(A, stack, status, probe);
         }
     }

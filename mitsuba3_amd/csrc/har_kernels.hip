@@ -479,7 +479,8 @@ __device__ __forceinline__ void trace_persistent(const Accel &A, uint32_t *curso
 
 /* ----------------------------------------------------------- trace_closest */
 #ifndef HAR_TRACE_MIN_WAVES
-#define HAR_TRACE_MIN_WAVES 1     /* __launch_bounds__ waves per SIMD of the traversal kernels (A/B: 7 with an 11-entry LDS stack) */
+#define HAR_TRACE_MIN_WAVES 6     /* __launch_bounds__ waves per SIMD of the traversal kernels: the LDS stacks allow 6 blocks per CU, so the registers must too (<= 80; the
+                                   * two-level k_trace_closest would take 82 on its own and lose its sixth wave: 871 vs 899 Mpaths/s, profiles/r03_ab_defer_xform.txt).  A/B: 7 with an 11-entry LDS stack */
 #endif
 template <bool SPILL, bool FLAT = false>
 __global__ __launch_bounds__(kBlock, HAR_TRACE_MIN_WAVES) void k_trace_closest(Accel A, const uint32_t *count, uint32_t *cursor, uint32_t shard_cap, const float4 *a0,
@@ -1082,7 +1083,8 @@ __global__ __launch_bounds__(kBlock) void k_resolve_adjoint_cached(DScene S, con
 
 /* ------------------------------------------------- resolve (shadow rays + NEE) */
 template <int MODE, bool SPILL, bool FWD = false, bool FLAT = false>
-__global__ __launch_bounds__(kBlock, HAR_TRACE_MIN_WAVES) void k_resolve(DScene S, const uint32_t *item_count, uint32_t *cursor, uint32_t shard_cap, ItemArrays items, float4 *result,
+__global__ __launch_bounds__(kBlock, (MODE == MODE_PRB_ADJOINT ? 1 : HAR_TRACE_MIN_WAVES)) void k_resolve(    /* the adjoint flavour keeps gradient accumulators in LDS: 5 blocks per CU */
+                                                    DScene S, const uint32_t *item_count, uint32_t *cursor, uint32_t shard_cap, ItemArrays items, float4 *result,
                                                     const float4 *dL, float *grad_refl, float *const *grad_tex, int *status, ReplayCache rc, uint2 *spill, uint8_t *item_vis) {
     __shared__ uint2 lds[HAR_LDS_STACK_SMALL * kBlock];
     /* adjoint: per-block accumulators of the constant-albedo gradients.  Every path of the chip adds to the same
