@@ -7,6 +7,7 @@
  * HIP kernels execute can be checked against the oracle on a machine without
  * a GPU.  The shipped library (libhip_ad_rgb.so) never contains or calls this.
  */
+#include "../../mitsuba3_amd/csrc/har_cpu.h"
 #include "../../mitsuba3_amd/csrc/har_path.h"
 #include "../../mitsuba3_amd/csrc/har_shape_grad.h"
 #include "../../mitsuba3_amd/csrc/har_scene_host.h"
@@ -108,6 +109,8 @@ void hh_bsdf_eval_extra(int type, int ggx, int sample_visible, float alpha_u, fl
 }
 void hh_fresnel(float cos_theta_i, float eta, float out[4]) { fresnel_dielectric(cos_theta_i, eta, out[0], out[1], out[2], out[3]); }
 float hh_fresnel_conductor(float cos_theta_i, float eta, float k) { return fresnel_conductor(cos_theta_i, eta, k); }
+/* har_cpu.h: the worker-thread count the product's host code uses for "all cores" */
+unsigned hh_usable_cores() { return har_usable_cores(); }
 /* elementary functions of har_math.h / har_bsdf.h, same numbering as orc_math_fn */
 float hh_math_fn(int fn, float x, float y) {
     switch (fn) {

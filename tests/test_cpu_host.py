@@ -426,3 +426,24 @@ def test_scalar_gradient_sums_do_not_depend_on_the_worker_count(O):
         out[th] = np.concatenate([np.asarray(g_refl, np.float64).reshape(-1), np.asarray(g_emit, np.float64).reshape(-1)])
     m = np.abs(out[8]) > 0
     assert m.sum() >= 6 and np.abs(out[1][m] / out[8][m] - 1).max() < 1e-5
+
+
+def test_usable_core_count_follows_affinity_and_container_quota(O):
+    """the product's host code (har_cpu.h) and the oracle (default_threads) each work out how many cores the process may really use -- the affinity mask
+    capped by the cgroup CPU quota (16 of 256 logical CPUs on the GPU boxes) -- and must agree with each other and with a reading of the same files here"""
+    import math
+    H = C.CDLL(os.path.join(ROOT, "tests", "host_harness", "libhost_harness.so"))
+    H.hh_usable_cores.restype = C.c_uint
+    want = len(os.sched_getaffinity(0))
+    try:
+        q, p = open("/sys/fs/cgroup/cpu.max").read().split()
+        if q != "max":
+            want = min(want, max(1, math.ceil(float(q) / float(p))))
+    except OSError:
+        try:
+            q = int(open("/sys/fs/cgroup/cpu/cpu.cfs_quota_us").read()); p = int(open("/sys/fs/cgroup/cpu/cpu.cfs_period_us").read())
+            if q > 0 and p > 0:
+                want = min(want, max(1, math.ceil(q / p)))
+        except OSError:
+            pass
+    assert H.hh_usable_cores() == O.lib().orc_default_threads() == want >= 1
