@@ -172,22 +172,43 @@ int har_scene_set_texture(HarScene scene, uint32_t texture, const float *data);
 /* accel statistics: node count, triangle count, bytes */
 int har_scene_accel_info(HarScene scene, uint64_t info[4]);
 
+/* Every array-valued call below takes the reference's `Mask active` as `const uint8_t *active` (DEVICE, n bytes; NULL = all lanes active).
+ * A masked lane does no work and returns what the reference's masked lane returns: "no intersection" (t = inf) / false / zero value and weight;
+ * it never advances a sampler stream. */
+
 /* Scene::ray_intersect_preliminary (src/render/scene.cpp:216-230) /
- * Scene::ray_intersect_naive (:240-244, naive != 0: brute-force kernel).  DEVICE arrays. */
+ * Scene::ray_intersect_naive (:240-244, naive != 0: brute-force kernel).  DEVICE arrays.
+ * (`coherent`, `reorder`, `reorder_hint`, `reorder_hint_bits` of the reference are scheduling hints for its backends, DRJIT_MARK_USED only.) */
 int har_ray_intersect_preliminary(HarScene scene, uint32_t n, const float *o, const float *d,
-                                  const float *maxt, int naive, float *t, float *u, float *v,
+                                  const float *maxt, const uint8_t *active, int naive, float *t, float *u, float *v,
                                   uint32_t *prim_index, uint32_t *shape_index,
                                   uint32_t *inst_index, void *stream);
 /* Scene::ray_test (src/render/scene.cpp:232-238).  hit: u8[n]. DEVICE arrays. */
 int har_ray_test(HarScene scene, uint32_t n, const float *o, const float *d, const float *maxt,
-                 int naive, uint8_t *hit, void *stream);
-/* PreliminaryIntersection::compute_surface_interaction (interaction.h:804-829,
- * src/render/mesh.cpp:2255-2437).  out: 21 x f32 SoA [21][n] =
- * {p, n, sh_frame.n, sh_frame.s, sh_frame.t, wi, uv.x, uv.y, t}. DEVICE arrays. */
+                 const uint8_t *active, int naive, uint8_t *hit, void *stream);
+/* RayFlags (include/mitsuba/render/interaction.h:19-87).  Minimal: t, p, n only; Shading (= Default): + uv, dp_du, dp_dv, sh_frame, wi;
+ * NormalPartials (needs Shading): + dn_du, dn_dv.  FollowShape / DetachShape choose which AD dependence the reference attaches to the hit
+ * ("no effect in non-differentiable variants"): accepted, the values are the same; both at once are refused like every unknown bit. */
+#define HAR_RAY_MINIMAL         0u
+#define HAR_RAY_SHADING         1u
+#define HAR_RAY_NORMAL_PARTIALS 2u
+#define HAR_RAY_FOLLOW_SHAPE    4u
+#define HAR_RAY_DETACH_SHAPE    8u
+#define HAR_RAY_DEFAULT         HAR_RAY_SHADING
+/* rows of a SurfaceInteraction3f wavefront (SoA, n floats per row; interaction.h:345-420) */
+#define HAR_SI_ROWS 33   /* p 0-2, n 3-5, sh_frame.n 6-8, sh_frame.s 9-11, sh_frame.t 12-14, wi 15-17, uv 18-19, t 20, dp_du 21-23, dp_dv 24-26, dn_du 27-29, dn_dv 30-32 */
+/* PreliminaryIntersection::compute_surface_interaction(ray, ray_flags, active) (interaction.h:804-829,
+ * src/render/mesh.cpp:2255-2437, src/shapes/instance.cpp:150-266, finalize_surface_interaction interaction.h:559-605).
+ * out: HAR_SI_ROWS x f32 SoA [33][n]; fields the flags do not ask for are zero.  A lane that is masked or holds no
+ * intersection: t = inf, zero fields, wi = -d (with Shading).  DEVICE arrays. */
 int har_compute_surface_interaction(HarScene scene, uint32_t n, const float *o, const float *d,
                                     const float *t, const float *u, const float *v,
                                     const uint32_t *prim_index, const uint32_t *shape_index,
-                                    const uint32_t *inst_index, float *out, void *stream);
+                                    const uint32_t *inst_index, uint32_t ray_flags, const uint8_t *active, float *out, void *stream);
+/* Scene::ray_intersect(ray, ray_flags, coherent, ..., active) (src/render/scene.cpp:197-214): the preliminary intersection (t .. inst_index, also
+ * outputs) expanded into the SurfaceInteraction `si` ([33][n]); naive != 0: Scene::ray_intersect_naive (:240-244) */
+int har_ray_intersect(HarScene scene, uint32_t n, const float *o, const float *d, const float *maxt, uint32_t ray_flags, const uint8_t *active, int naive,
+                      float *t, float *u, float *v, uint32_t *prim_index, uint32_t *shape_index, uint32_t *inst_index, float *si, void *stream);
 
 /* ------------------------------------------------------------------------
  *  Sampler  (src/render/sampler.cpp:129-148, src/samplers/independent.cpp:77-97)
@@ -204,18 +225,33 @@ int har_sampler_next_2d(uint32_t n, uint64_t *state, const uint64_t *inc, const 
                         float *out, void *stream);
 
 /* ------------------------------------------------------------------------
- *  BSDF  (include/mitsuba/render/bsdf.h:322-465, src/bsdfs/diffuse.cpp:100-179)
+ *  BSDF  (include/mitsuba/render/bsdf.h:322-465, src/bsdfs/ *.cpp)
  *  wi/wo in the local shading frame, SoA [3][n]; uv [2][n]; DEVICE arrays.
  * ---------------------------------------------------------------------- */
-int har_bsdf_eval_pdf(HarScene scene, uint32_t bsdf, uint32_t n, const float *wi, const float *uv,
-                      const float *wo, float *value /*[3][n]*/, float *pdf, void *stream);
-int har_bsdf_sample(HarScene scene, uint32_t bsdf, uint32_t n, const float *wi, const float *uv,
-                    const float *sample1, const float *sample2 /*[2][n]*/, float *wo /*[3][n]*/,
-                    float *pdf, float *weight /*[3][n]*/, void *stream);
-/* as har_bsdf_sample, additionally returns BSDFSample3f::eta and has_flag(sampled_type, Delta) in eta_delta[2][n] */
-int har_bsdf_sample_ex(HarScene scene, uint32_t bsdf, uint32_t n, const float *wi, const float *uv,
-                       const float *sample1, const float *sample2, float *wo, float *pdf, float *weight,
-                       float *eta_delta, void *stream);
+/* BSDFContext (include/mitsuba/render/bsdf.h:140-186).  NULL = BSDFContext(): Radiance, every lobe type, every component.
+ * mode: dielectric's transmitted weight carries eta_ti^2 only under Radiance (dielectric.cpp:362-367); type_mask / component select lobes through
+ * BSDFContext::is_enabled (:177-181) -- component indices: dielectric 0 reflection, 1 transmission; roughplastic 0 glossy, 1 diffuse; plastic 0 delta
+ * reflection, 1 diffuse; the one-lobe models 0; `twosided` lists the front BSDF's components first, then the back's (twosided.cpp:86-99,129-146). */
+#define HAR_TRANSPORT_RADIANCE   0u
+#define HAR_TRANSPORT_IMPORTANCE 1u
+#define HAR_LOBE_DIFFUSE_REFLECTION 0x02u   /* BSDFFlags (bsdf.h:31-80) */
+#define HAR_LOBE_GLOSSY_REFLECTION  0x08u
+#define HAR_LOBE_DELTA_REFLECTION   0x20u
+#define HAR_LOBE_DELTA_TRANSMISSION 0x40u
+#define HAR_LOBE_ALL                0x1ffu
+typedef struct HarBSDFContext { uint32_t mode, type_mask, component; } HarBSDFContext;
+/* BSDF::eval_pdf / eval / pdf(ctx, si, wo, active) (bsdf.h:375-465) */
+int har_bsdf_eval_pdf(HarScene scene, uint32_t bsdf, const HarBSDFContext *ctx, uint32_t n, const float *wi, const float *uv,
+                      const float *wo, const uint8_t *active, float *value /*[3][n]*/, float *pdf, void *stream);
+int har_bsdf_eval(HarScene scene, uint32_t bsdf, const HarBSDFContext *ctx, uint32_t n, const float *wi, const float *uv,
+                  const float *wo, const uint8_t *active, float *value /*[3][n]*/, void *stream);
+int har_bsdf_pdf(HarScene scene, uint32_t bsdf, const HarBSDFContext *ctx, uint32_t n, const float *wi, const float *uv,
+                 const float *wo, const uint8_t *active, float *pdf, void *stream);
+/* BSDF::sample(ctx, si, sample1, sample2, active) -> (BSDFSample3f, weight) (bsdf.h:322-373): wo, pdf, weight, and -- each may be NULL --
+ * BSDFSample3f::eta, ::sampled_type (a BSDFFlags lobe bit; Delta lobes are HAR_LOBE_DELTA_*), ::sampled_component.  sample1 may be NULL (zeros). */
+int har_bsdf_sample(HarScene scene, uint32_t bsdf, const HarBSDFContext *ctx, uint32_t n, const float *wi, const float *uv,
+                    const float *sample1, const float *sample2 /*[2][n]*/, const uint8_t *active, float *wo /*[3][n]*/,
+                    float *pdf, float *weight /*[3][n]*/, float *eta, uint32_t *sampled_type, uint32_t *sampled_component, void *stream);
 
 /* ------------------------------------------------------------------------
  *  Sensor / film
@@ -344,9 +380,10 @@ int har_render_scalar(const HarSceneDesc *desc, const HarSensor *sensor, uint32_
  * lanes [lane_offset, lane_offset + n): `state` = NULL starts the freshly seeded streams, otherwise ray i continues from state[i] (as produced
  * by har_sampler_seed / har_sampler_next_* for the same seed and lane); `state_out` (may be NULL, `path` only) receives the states after the
  * call -- a lane that starts a loop iteration draws all of that iteration's numbers (JIT loop semantics, path.cpp:247,263-264,323).
- * `path` returns select(valid, L, 0) (path.cpp:341-345), `prb` returns L and valid = depth != 0 (prb.py:332).  No medium, no AOVs. */
+ * `path` returns select(valid, L, 0) (path.cpp:341-345), `prb` returns L and valid = depth != 0 (prb.py:332).  No medium, no AOVs.
+ * `active` (n bytes, NULL = all): a masked ray never enters the loop -- zero radiance, valid = 0, and state_out = the state it came in with. */
 int har_integrator_sample(HarScene scene, HarIntegrator integrator, uint32_t seed, uint32_t lane_offset, uint32_t n, const float *o, const float *d,
-                          const float *maxt, const uint64_t *state, float *rgb, uint8_t *valid, uint64_t *state_out, void *stream);
+                          const float *maxt, const uint64_t *state, const uint8_t *active, float *rgb, uint8_t *valid, uint64_t *state_out, void *stream);
 /* Sampler::clone (include/mitsuba/render/sampler.h:89-99): copies the n PCG32 streams (DEVICE arrays) -- both samplers then produce the same
  * numbers (RBIntegrator.render_backward's `sampler.clone()`, common.py:755).  Sampler::fork (sampler.h:78-87) has no device state: a forked
  * sampler is a new host object that is seeded later.  Sampler::advance (sampler.h:109-115; independent.cpp:69-72) only moves the host-side

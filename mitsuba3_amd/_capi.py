@@ -73,6 +73,10 @@ class HarSensor(C.Structure):
                 ("sample_border", C.c_uint32)]
 
 
+class HarBSDFContext(C.Structure):
+    _fields_ = [("mode", C.c_uint32), ("type_mask", C.c_uint32), ("component", C.c_uint32)]
+
+
 class HarStats(C.Structure):
     _fields_ = [("paths", C.c_uint64), ("vertices", C.c_uint64), ("closest_rays", C.c_uint64),
                 ("shadow_rays", C.c_uint64)]
@@ -94,14 +98,17 @@ SIGNATURES = {
     "har_integrator_set_alpha_film": (C.c_int, [vp, vp]),
     "har_scene_set_texture": (C.c_int, [vp, C.c_uint32, f32p]),
     "har_scene_accel_info": (C.c_int, [vp, u64p]),
-    "har_ray_intersect_preliminary": (C.c_int, [vp, C.c_uint32, vp, vp, vp, C.c_int, vp, vp, vp, vp, vp, vp, vp]),
-    "har_ray_test": (C.c_int, [vp, C.c_uint32, vp, vp, vp, C.c_int, vp, vp]),
-    "har_compute_surface_interaction": (C.c_int, [vp, C.c_uint32, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp]),
+    "har_ray_intersect_preliminary": (C.c_int, [vp, C.c_uint32, vp, vp, vp, vp, C.c_int, vp, vp, vp, vp, vp, vp, vp]),
+    "har_ray_test": (C.c_int, [vp, C.c_uint32, vp, vp, vp, vp, C.c_int, vp, vp]),
+    "har_compute_surface_interaction": (C.c_int, [vp, C.c_uint32, vp, vp, vp, vp, vp, vp, vp, vp, C.c_uint32, vp, vp, vp]),
+    "har_ray_intersect": (C.c_int, [vp, C.c_uint32, vp, vp, vp, C.c_uint32, vp, C.c_int, vp, vp, vp, vp, vp, vp, vp, vp]),
     "har_sampler_seed": (C.c_int, [C.c_uint32, C.c_uint32, C.c_uint32, vp, vp, vp]),
     "har_sampler_next_1d": (C.c_int, [C.c_uint32, vp, vp, vp, vp, vp]),
     "har_sampler_next_2d": (C.c_int, [C.c_uint32, vp, vp, vp, vp, vp]),
-    "har_bsdf_eval_pdf": (C.c_int, [vp, C.c_uint32, C.c_uint32, vp, vp, vp, vp, vp, vp]),
-    "har_bsdf_sample": (C.c_int, [vp, C.c_uint32, C.c_uint32, vp, vp, vp, vp, vp, vp, vp, vp]),
+    "har_bsdf_eval_pdf": (C.c_int, [vp, C.c_uint32, C.POINTER(HarBSDFContext), C.c_uint32, vp, vp, vp, vp, vp, vp, vp]),
+    "har_bsdf_eval": (C.c_int, [vp, C.c_uint32, C.POINTER(HarBSDFContext), C.c_uint32, vp, vp, vp, vp, vp, vp]),
+    "har_bsdf_pdf": (C.c_int, [vp, C.c_uint32, C.POINTER(HarBSDFContext), C.c_uint32, vp, vp, vp, vp, vp, vp]),
+    "har_bsdf_sample": (C.c_int, [vp, C.c_uint32, C.POINTER(HarBSDFContext), C.c_uint32, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp]),
     "har_image_write_exr": (C.c_int, [C.c_char_p, vp, C.c_uint32, C.c_uint32, C.c_uint32]),
     "har_image_write_pfm": (C.c_int, [C.c_char_p, vp, C.c_uint32, C.c_uint32, C.c_uint32]),
     "har_image_read": (C.c_int, [C.c_char_p, vp]),
@@ -113,7 +120,6 @@ SIGNATURES = {
     "har_mesh_load_serialized": (C.c_int, [C.c_char_p, C.c_int, C.c_int, f32p, C.c_int, vp]),
     "har_mesh_compute_normals": (C.c_int, [C.c_uint32, vp, C.c_uint32, vp]),
     "har_mesh_free": (None, [vp]),
-    "har_bsdf_sample_ex": (C.c_int, [vp, C.c_uint32, C.c_uint32, vp, vp, vp, vp, vp, vp, vp, vp, vp]),
     "har_sensor_sample_ray": (C.c_int, [C.POINTER(HarSensor), C.c_uint32, vp, vp, vp, vp, vp, vp]),
     "har_film_put": (C.c_int, [C.POINTER(HarSensor), C.c_uint32, vp, vp, vp, vp, vp]),
     "har_film_develop": (C.c_int, [vp, C.c_uint32, C.c_uint32, vp, vp]),
@@ -129,7 +135,7 @@ SIGNATURES = {
                                       C.c_uint64, vp, C.POINTER(vp), vp]),
     "har_render_scalar": (C.c_int, [C.POINTER(HarSceneDesc), C.POINTER(HarSensor), C.c_uint32, C.c_uint32, C.c_int32, C.c_int32, C.c_uint32, C.c_uint32, vp, u32p]),
     "har_render_forward": (C.c_int, [vp, vp, C.POINTER(HarSensor), C.c_uint32, C.c_uint32, C.c_uint64, C.c_uint64, vp, vp, vp, vp, vp]),
-    "har_integrator_sample": (C.c_int, [vp, vp, C.c_uint32, C.c_uint32, C.c_uint32, vp, vp, vp, vp, vp, vp, vp, vp]),
+    "har_integrator_sample": (C.c_int, [vp, vp, C.c_uint32, C.c_uint32, C.c_uint32, vp, vp, vp, vp, vp, vp, vp, vp, vp]),
     "har_sampler_clone": (C.c_int, [C.c_uint32, vp, vp, vp, vp, vp]),
     "har_sampler_advance": (C.c_int, [C.c_uint32, vp, vp, vp]),
     "har_render_stats": (C.c_int, [vp, C.POINTER(HarStats)]),

@@ -209,22 +209,84 @@ class PreliminaryIntersection3f:
     def is_valid(self):
         return ~_torch().isinf(self.t)
 
-    def compute_surface_interaction(self, ray):
-        return self.scene._compute_si(ray, self)
+    def compute_surface_interaction(self, ray, ray_flags=None, active=True):
+        """PreliminaryIntersection::compute_surface_interaction(ray, ray_flags = RayFlags::Default, active) (interaction.h:804-829)"""
+        return self.scene._compute_si(ray, self, RayFlags.Default if ray_flags is None else ray_flags, active)
 
 
 class SurfaceInteraction3f:
+    """rows of har_compute_surface_interaction's output (include/hip_ad_rgb.h HAR_SI_ROWS; interaction.h:345-420)"""
+
     def __init__(self, raw):
         self.p = raw[0:3]; self.n = raw[3:6]
         self.sh_frame = type("Frame3f", (), dict(n=raw[6:9], s=raw[9:12], t=raw[12:15]))()
         self.wi = raw[15:18]; self.uv = raw[18:20]; self.t = raw[20]
+        self.dp_du = raw[21:24]; self.dp_dv = raw[24:27]; self.dn_du = raw[27:30]; self.dn_dv = raw[30:33]
 
     def is_valid(self):
         return ~_torch().isinf(self.t)
 
 
+class RayFlags:
+    """include/mitsuba/render/interaction.h:19-87"""
+    Minimal = 0x0; Shading = 0x1; NormalPartials = 0x2; Default = 0x1; All = 0x1; FollowShape = 0x4; DetachShape = 0x8
+
+
+class TransportMode:
+    """include/mitsuba/render/fwd.h / bsdf.h: Radiance = 0, Importance = 1"""
+    Radiance = 0; Importance = 1
+
+
+class BSDFFlags:
+    """include/mitsuba/render/bsdf.h:31-125 (the lobe types and their unions)"""
+    Empty = 0x0; Null = 0x1; DiffuseReflection = 0x2; DiffuseTransmission = 0x4; GlossyReflection = 0x8; GlossyTransmission = 0x10
+    DeltaReflection = 0x20; DeltaTransmission = 0x40; Delta1DReflection = 0x80; Delta1DTransmission = 0x100
+    Reflection = 0x2 | 0x20 | 0x80 | 0x8; Transmission = 0x4 | 0x40 | 0x100 | 0x10 | 0x1
+    Diffuse = 0x2 | 0x4; Glossy = 0x8 | 0x10; Smooth = 0x2 | 0x4 | 0x8 | 0x10; Delta = 0x1 | 0x20 | 0x40; Delta1D = 0x80 | 0x100; All = 0x1ff
+
+
 class BSDFContext:
-    pass
+    """include/mitsuba/render/bsdf.h:140-186: transport mode, lobe type mask, component index; every BSDF call honours all three (har_bsdf_*)"""
+
+    def __init__(self, mode=TransportMode.Radiance, type_mask=0x1ff, component=0xffffffff):
+        self.mode = int(mode); self.type_mask = int(type_mask) & 0xffffffff; self.component = int(component) & 0xffffffff
+
+    def reverse(self):
+        self.mode = 1 - self.mode
+
+    def is_enabled(self, type_, component_=0):
+        t = int(type_)
+        return (self.type_mask == 0xffffffff or (self.type_mask & t) == t) and (self.component == 0xffffffff or self.component == component_)
+
+    def _c(self):
+        from ._capi import HarBSDFContext
+        if self.mode not in (0, 1):
+            raise RuntimeError("BSDFContext.mode must be TransportMode.Radiance or TransportMode.Importance")
+        return C.byref(HarBSDFContext(self.mode, self.type_mask, self.component))
+
+
+def _mask(active, n):
+    """the reference's `Mask active` argument -> device uint8[n] (None when every lane is active: the C ABI's NULL)"""
+    if active is True or active is None:
+        return None
+    torch = _torch()
+    if active is False:
+        return torch.zeros(n, dtype=torch.uint8, device=_device())
+    a = torch.as_tensor(active, device=_device()).reshape(-1)
+    a = (a != 0).to(torch.uint8)
+    if a.numel() == 1 and n != 1:
+        a = a.expand(n)
+    if a.numel() != n:
+        raise RuntimeError("active: mask of %d entries for a wavefront of %d lanes" % (a.numel(), n))
+    return a.contiguous()
+
+
+def _ctx(ctx):
+    if ctx is None:
+        return None
+    if not isinstance(ctx, BSDFContext):
+        raise RuntimeError("ctx must be a BSDFContext (or None for the default context)")
+    return ctx._c()
 
 
 # ---------------------------------------------------------------------------
@@ -676,31 +738,53 @@ class BSDF:
         uv = torch.zeros((2, n), dtype=torch.float32, device=dev) if si_uv is None else torch.as_tensor(si_uv, dtype=torch.float32, device=dev).reshape(2, -1).contiguous()
         return wi, uv
 
-    def eval_pdf(self, ctx, si, wo, active=True):
+    def _eval(self, which, ctx, si, wo, active):
         torch = _torch(); dev = _device(); h, idx = self._bind()
         wo = torch.as_tensor(wo, dtype=torch.float32, device=dev).reshape(3, -1).contiguous(); n = wo.shape[1]
         wi, uv = self._prep(si.wi, getattr(si, 'uv', None), n)
-        val = torch.empty((3, n), dtype=torch.float32, device=dev); pdf = torch.empty(n, dtype=torch.float32, device=dev)
-        check(lib().har_bsdf_eval_pdf(h, idx, n, _ptr(wi), _ptr(uv), _ptr(wo), _ptr(val), _ptr(pdf), _stream()))
+        a = _mask(active, n); c = _ctx(ctx)
+        val = torch.empty((3, n), dtype=torch.float32, device=dev) if which != 'pdf' else None
+        pdf = torch.empty(n, dtype=torch.float32, device=dev) if which != 'eval' else None
+        if which == 'eval_pdf':
+            check(lib().har_bsdf_eval_pdf(h, idx, c, n, _ptr(wi), _ptr(uv), _ptr(wo), _ptr(a), _ptr(val), _ptr(pdf), _stream()))
+        elif which == 'eval':
+            check(lib().har_bsdf_eval(h, idx, c, n, _ptr(wi), _ptr(uv), _ptr(wo), _ptr(a), _ptr(val), _stream()))
+        else:
+            check(lib().har_bsdf_pdf(h, idx, c, n, _ptr(wi), _ptr(uv), _ptr(wo), _ptr(a), _ptr(pdf), _stream()))
         return val, pdf
 
+    def eval_pdf(self, ctx, si, wo, active=True):
+        """BSDF::eval_pdf(ctx, si, wo, active) (bsdf.h:431-465)"""
+        return self._eval('eval_pdf', ctx, si, wo, active)
+
     def eval(self, ctx, si, wo, active=True):
-        return self.eval_pdf(ctx, si, wo, active)[0]
+        return self._eval('eval', ctx, si, wo, active)[0]
 
     def pdf(self, ctx, si, wo, active=True):
-        return self.eval_pdf(ctx, si, wo, active)[1]
+        return self._eval('pdf', ctx, si, wo, active)[1]
 
     def sample(self, ctx, si, sample1, sample2, active=True):
+        """BSDF::sample(ctx, si, sample1, sample2, active) -> (BSDFSample3f, weight) (bsdf.h:322-373)"""
         torch = _torch(); dev = _device(); h, idx = self._bind()
         s2 = torch.as_tensor(sample2, dtype=torch.float32, device=dev).reshape(2, -1).contiguous(); n = s2.shape[1]
         wi, uv = self._prep(si.wi, getattr(si, 'uv', None), n)
         wo = torch.empty((3, n), dtype=torch.float32, device=dev); pdf = torch.empty(n, dtype=torch.float32, device=dev); w = torch.empty_like(wo)
         s1 = torch.as_tensor(sample1, dtype=torch.float32, device=dev).reshape(-1)
         s1 = (s1.expand(n) if s1.numel() != n else s1).contiguous()
-        ed = torch.empty((2, n), dtype=torch.float32, device=dev)
-        check(lib().har_bsdf_sample_ex(h, idx, n, _ptr(wi), _ptr(uv), _ptr(s1), _ptr(s2), _ptr(wo), _ptr(pdf), _ptr(w), _ptr(ed), _stream()))
-        bs = type("BSDFSample3f", (), dict(wo=wo, pdf=pdf, eta=ed[0], delta=ed[1] > 0))()
+        eta = torch.empty(n, dtype=torch.float32, device=dev)
+        st = torch.empty(n, dtype=torch.int32, device=dev); sc = torch.empty(n, dtype=torch.int32, device=dev)
+        a = _mask(active, n)
+        check(lib().har_bsdf_sample(h, idx, _ctx(ctx), n, _ptr(wi), _ptr(uv), _ptr(s1), _ptr(s2), _ptr(a), _ptr(wo), _ptr(pdf), _ptr(w), _ptr(eta), _ptr(st), _ptr(sc), _stream()))
+        bs = type("BSDFSample3f", (), dict(wo=wo, pdf=pdf, eta=eta, sampled_type=st, sampled_component=sc, delta=(st & BSDFFlags.Delta) != 0))()
         return bs, w
+
+    def component_count(self):
+        """BSDF::component_count(): the lobes of this plugin (twosided: the front BSDF's, then the back's, twosided.cpp:86-99)"""
+        own = {'dielectric': 2, 'roughplastic': 2, 'plastic': 2}
+        n = own.get(self.kind, 1)
+        if self.flags & 1:
+            return n + (own.get(self.back.kind, 1) if self.back is not None else n)
+        return n
 
 
 def _mk_twosided(props, named, key):
@@ -907,13 +991,11 @@ class Integrator:
         rgb = torch.empty((3, n), dtype=torch.float32, device=dev); valid = torch.empty(n, dtype=torch.uint8, device=dev)
         state_out = torch.empty_like(sampler.state) if self.type == 'path' else None
         sd = sampler.m_seed_value if seed is None else (sampler.m_base_seed + int(seed)) & 0xffffffff
+        # `active`: a masked ray never enters the loop -- zero radiance, invalid, and its sampler stream is not advanced (handled inside the call)
         check(lib().har_integrator_sample(scene._handle(), self._handle(), sd, 0, n, _ptr(ray.o), _ptr(ray.d), _ptr(ray.maxt), _ptr(sampler.state),
-                                          _ptr(rgb), _ptr(valid), _ptr(state_out), _stream()))
+                                          _ptr(_mask(active, n)), _ptr(rgb), _ptr(valid), _ptr(state_out), _stream()))
         if state_out is not None:
             sampler.state = state_out
-        if active is not True:
-            a = torch.as_tensor(active, device=dev).to(torch.bool)
-            rgb = rgb * a; valid = valid * a.to(torch.uint8)
         return rgb, valid.to(torch.bool)
 
     def render_weights(self, scene, sensor=0, seed=0, spp=0, lanes=None):
@@ -1273,34 +1355,49 @@ class Scene:
         check(lib().har_scene_accel_info(self._handle(), info))
         return dict(nodes=info[0], triangles=info[1], bytes=info[2], depth=info[3])
 
-    def _intersect(self, ray, naive):
+    def _intersect(self, ray, naive, active=True):
         torch = _torch(); dev = _device(); n = len(ray)
         t = torch.empty(n, dtype=torch.float32, device=dev); u = torch.empty_like(t); v = torch.empty_like(t)
         prim = torch.empty(n, dtype=torch.int32, device=dev); shape = torch.empty_like(prim); inst = torch.empty_like(prim)
-        check(lib().har_ray_intersect_preliminary(self._handle(), n, _ptr(ray.o), _ptr(ray.d), _ptr(ray.maxt), 1 if naive else 0,
+        check(lib().har_ray_intersect_preliminary(self._handle(), n, _ptr(ray.o), _ptr(ray.d), _ptr(ray.maxt), _ptr(_mask(active, n)), 1 if naive else 0,
                                                   _ptr(t), _ptr(u), _ptr(v), _ptr(prim), _ptr(shape), _ptr(inst), _stream()))
         return PreliminaryIntersection3f(self, t, u, v, prim, shape, inst)
 
     def ray_intersect_preliminary(self, ray, coherent=False, reorder=False, reorder_hint=0, reorder_hint_bits=0, active=True):
-        return self._intersect(ray, False)
+        """Scene::ray_intersect_preliminary (scene.cpp:216-230).  coherent / reorder* are scheduling hints of the reference's backends (DRJIT_MARK_USED)."""
+        return self._intersect(ray, False, active)
 
-    def ray_intersect(self, ray, ray_flags=None, coherent=False, active=True):
-        return self._intersect(ray, False).compute_surface_interaction(ray)
+    def _intersect_si(self, ray, ray_flags, active, naive):
+        torch = _torch(); dev = _device(); n = len(ray)
+        t = torch.empty(n, dtype=torch.float32, device=dev); u = torch.empty_like(t); v = torch.empty_like(t)
+        prim = torch.empty(n, dtype=torch.int32, device=dev); shape = torch.empty_like(prim); inst = torch.empty_like(prim)
+        out = torch.empty((33, n), dtype=torch.float32, device=dev)
+        flags = RayFlags.Default if ray_flags is None else int(ray_flags)
+        check(lib().har_ray_intersect(self._handle(), n, _ptr(ray.o), _ptr(ray.d), _ptr(ray.maxt), flags, _ptr(_mask(active, n)), 1 if naive else 0,
+                                      _ptr(t), _ptr(u), _ptr(v), _ptr(prim), _ptr(shape), _ptr(inst), _ptr(out), _stream()))
+        si = SurfaceInteraction3f(out)
+        si.prim_index = prim; si.shape_index = shape; si.instance = inst
+        return si
+
+    def ray_intersect(self, ray, ray_flags=None, coherent=False, reorder=False, reorder_hint=0, reorder_hint_bits=0, active=True):
+        """Scene::ray_intersect(ray, ray_flags, coherent, ..., active) (scene.cpp:197-214)"""
+        return self._intersect_si(ray, ray_flags, active, False)
 
     def ray_intersect_naive(self, ray, active=True):
-        return self._intersect(ray, True).compute_surface_interaction(ray)
+        return self._intersect_si(ray, None, active, True)
 
     def ray_test(self, ray, coherent=False, active=True, naive=False):
         torch = _torch(); dev = _device(); n = len(ray)
         hit = torch.empty(n, dtype=torch.uint8, device=dev)
-        check(lib().har_ray_test(self._handle(), n, _ptr(ray.o), _ptr(ray.d), _ptr(ray.maxt), 1 if naive else 0, _ptr(hit), _stream()))
+        check(lib().har_ray_test(self._handle(), n, _ptr(ray.o), _ptr(ray.d), _ptr(ray.maxt), _ptr(_mask(active, n)), 1 if naive else 0, _ptr(hit), _stream()))
         return hit.bool()
 
-    def _compute_si(self, ray, pi):
+    def _compute_si(self, ray, pi, ray_flags=1, active=True):
         torch = _torch(); dev = _device(); n = len(ray)
-        out = torch.empty((21, n), dtype=torch.float32, device=dev)
+        out = torch.empty((33, n), dtype=torch.float32, device=dev)
         check(lib().har_compute_surface_interaction(self._handle(), n, _ptr(ray.o), _ptr(ray.d), _ptr(pi.t), _ptr(pi.prim_uv[0]), _ptr(pi.prim_uv[1]),
-                                                    _ptr(pi.prim_index), _ptr(pi.shape_index), _ptr(pi.instance), _ptr(out), _stream()))
+                                                    _ptr(pi.prim_index), _ptr(pi.shape_index), _ptr(pi.instance), int(ray_flags), _ptr(_mask(active, n)),
+                                                    _ptr(out), _stream()))
         return SurfaceInteraction3f(out)
 
     # -- parameters (mi.traverse)

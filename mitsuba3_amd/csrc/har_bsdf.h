@@ -41,7 +41,22 @@ struct DBsdf {
 static_assert(sizeof(DBsdf) == 96, "DBsdf layout");
 
 struct BsdfEval { Vec3 value; float pdf; Vec3 d_slot0, d_slot1; };
-struct BsdfSample { Vec3 wo; float pdf; Vec3 weight; float eta; bool delta; };
+struct BsdfSample { Vec3 wo; float pdf; Vec3 weight; float eta; bool delta; uint32_t type, comp; };     /* type / comp: BSDFSample3f::sampled_type / sampled_component (bsdf.h:212-216) */
+
+/* BSDFFlags of the lobes these models have (include/mitsuba/render/bsdf.h:31-80) */
+enum { LOBE_DIFFUSE_REFLECTION = 0x2u, LOBE_GLOSSY_REFLECTION = 0x8u, LOBE_DELTA_REFLECTION = 0x20u, LOBE_DELTA_TRANSMISSION = 0x40u };
+/* BSDFContext (include/mitsuba/render/bsdf.h:140-186): transport mode (0 = Radiance, 1 = Importance), type mask, component index.  The wavefront kernels
+ * run the default context -- the `CTX = false` instantiations below, in which every test of it folds away; the array-valued plugin surface
+ * (har_bsdf_eval / _pdf / _eval_pdf / _sample) passes the caller's. */
+struct BsdfCtx {
+    uint32_t mode = 0u, type_mask = 0x1ffu, component = 0xffffffffu;
+    HAR_HD bool is_enabled(uint32_t type, uint32_t comp = 0u) const {                   /* bsdf.h:177-181 */
+        return (type_mask == 0xffffffffu || (type_mask & type) == type) && (component == 0xffffffffu || component == comp);
+    }
+};
+/* BSDF::component_count() of a (not twosided) record: diffuse 1, dielectric 2 (reflection, transmission), roughconductor 1, roughplastic 2 (glossy, diffuse),
+ * conductor 1, plastic 2 (delta reflection, diffuse) */
+HAR_HD uint32_t bsdf_component_count(uint32_t type) { return (type == 1u || type == 3u || type == 5u) ? 2u : 1u; }
 
 HAR_HD float safe_sqrt_(float x) { return sqrtf(fmaxf(x, 0.f)); }
 HAR_HD float lerp_(float a, float b, float t) { return fma_(b, t, fnma_(a, t, a)); }        /* dr::lerp */
@@ -288,19 +303,21 @@ HAR_HD float fresnel_diffuse_reflectance(float eta) {
 }
 
 /* eval_pdf of one (not twosided) record: value = f * cos(theta_o) */
-template <uint32_t TYPES = HAR_BSDF_ALL_TYPES>
-HAR_HD void bsdf_eval_pdf_one(const DBsdf &B, const BsdfInputs &in, Vec3 wi, Vec3 wo, BsdfEval &e) {
+template <uint32_t TYPES = HAR_BSDF_ALL_TYPES, bool CTX = false>
+HAR_HD void bsdf_eval_pdf_one(const DBsdf &B, const BsdfInputs &in, Vec3 wi, Vec3 wo, BsdfEval &e, const BsdfCtx &ctx = BsdfCtx()) {
     e.value = Vec3(0.f); e.pdf = 0.f; e.d_slot0 = Vec3(0.f); e.d_slot1 = Vec3(0.f);
     float cos_theta_i = wi.z, cos_theta_o = wo.z;
     const uint32_t type = HAR_BSDF_SINGLE(TYPES) ? (uint32_t) HAR_BSDF_SINGLE_TYPE(TYPES) : B.type;
     switch (type) {
     case BSDF_DIFFUSE: {                                                     /* diffuse.cpp:159-179 */
+        if (CTX && !ctx.is_enabled(LOBE_DIFFUSE_REFLECTION)) return;
         if (!(cos_theta_i > 0.f && cos_theta_o > 0.f)) return;
         float k = HAR_INV_PI * cos_theta_o;
         e.value = (in.slot0 * HAR_INV_PI) * cos_theta_o; e.pdf = k; e.d_slot0 = Vec3(k);
     } break;
     case BSDF_DIELECTRIC: break;                                             /* dielectric.cpp:340-348: delta lobes */
     case BSDF_ROUGHCONDUCTOR: {                                              /* roughconductor.cpp:429-520 */
+        if (CTX && !ctx.is_enabled(LOBE_GLOSSY_REFLECTION)) return;
         Vec3 H = normalize3(wo + wi);
         if (!(cos_theta_i > 0.f && cos_theta_o > 0.f && dot3(wi, H) > 0.f && dot3(wo, H) > 0.f)) return;
         Microfacet distr((B.flags & BF_GGX) != 0, B.alpha_u, B.alpha_v, (B.flags & BF_SAMPLE_VISIBLE) != 0);
@@ -311,10 +328,13 @@ HAR_HD void bsdf_eval_pdf_one(const DBsdf &B, const BsdfInputs &in, Vec3 wi, Vec
         float c = dot3(wi, H);
         Vec3 F(fresnel_conductor(c, B.eta_c[0], B.k_c[0]), fresnel_conductor(c, B.eta_c[1], B.k_c[1]), fresnel_conductor(c, B.eta_c[2], B.k_c[2]));
         float pdf = distr.sample_visible ? D * smith_g1_wi / (4.f * cos_theta_i) : distr.pdf(wi, H) / (4.f * dot3(wo, H));
-        if (active) { e.d_slot0 = F * value; e.value = e.d_slot0 * in.slot0; }
+        if (active) { e.d_slot0 = F * value; e.value = F * (in.slot0 * value); }       /* roughconductor.cpp:386-389: (F * (result * reflectance)) */
         e.pdf = pdf;
     } break;
     case BSDF_ROUGHPLASTIC: {                                                /* roughplastic.cpp:296-336 (eval), :351-395 (pdf) */
+        /* component 0 = the glossy coating, 1 = the diffuse base (roughplastic.cpp:301-302) */
+        const bool has_specular = !CTX || ctx.is_enabled(LOBE_GLOSSY_REFLECTION, 0u), has_diffuse = !CTX || ctx.is_enabled(LOBE_DIFFUSE_REFLECTION, 1u);
+        if (CTX && !has_specular && !has_diffuse) return;
         if (!(cos_theta_i > 0.f && cos_theta_o > 0.f)) return;
         Microfacet distr((B.flags & BF_GGX) != 0, B.alpha_u, B.alpha_u, (B.flags & BF_SAMPLE_VISIBLE) != 0);
         Vec3 H = normalize3(wo + wi);
@@ -330,8 +350,12 @@ HAR_HD void bsdf_eval_pdf_one(const DBsdf &B, const BsdfInputs &in, Vec3 wi, Vec
         e.value = in.slot1 * spec + diff * k;
         e.d_slot1 = Vec3(spec);
         e.d_slot0 = nonlinear ? Vec3(k / (den.x * den.x), k / (den.y * den.y), k / (den.z * den.z)) : Vec3(k / den.x, k / den.y, k / den.z);
+        if (CTX && !has_specular) { e.value = diff * k; e.d_slot1 = Vec3(0.f); }                  /* :305-327: the disabled lobe adds nothing */
+        if (CTX && !has_diffuse) { e.value = in.slot1 * spec; e.d_slot0 = Vec3(0.f); }
         float prob_specular = (1.f - t_i) * B.spec_sampling_weight, prob_diffuse = t_i * (1.f - B.spec_sampling_weight);
-        prob_specular = prob_specular / (prob_specular + prob_diffuse); prob_diffuse = 1.f - prob_specular;
+        if (CTX && has_specular != has_diffuse) prob_specular = has_specular ? 1.f : 0.f;         /* :372-375 */
+        else prob_specular = prob_specular / (prob_specular + prob_diffuse);
+        prob_diffuse = 1.f - prob_specular;
         float result = distr.sample_visible ? D * distr.smith_g1(wi, H) / (4.f * cos_theta_i) : distr.pdf(wi, H) / (4.f * dot3(wo, H));
         result *= prob_specular;
         result += prob_diffuse * (HAR_INV_PI * cos_theta_o);
@@ -340,6 +364,7 @@ HAR_HD void bsdf_eval_pdf_one(const DBsdf &B, const BsdfInputs &in, Vec3 wi, Vec
     case BSDF_CONDUCTOR: break;                                              /* conductor.cpp:306-318: a delta lobe */
     case BSDF_PLASTIC: {                                                     /* plastic.cpp:318-352 (the delta lobe evaluates to zero) */
         if (!HAR_BSDF_HAS(TYPES, BSDF_PLASTIC)) return;
+        if (CTX && !ctx.is_enabled(LOBE_DIFFUSE_REFLECTION, 1u)) return;        /* component 1 = the diffuse base, 0 = the delta coating (plastic.cpp:270,322) */
         if (!(cos_theta_i > 0.f && cos_theta_o > 0.f)) return;
         float f_i, f_o, ct, eit, eti;
         fresnel_dielectric(cos_theta_i, B.eta, f_i, ct, eit, eti);
@@ -353,6 +378,7 @@ HAR_HD void bsdf_eval_pdf_one(const DBsdf &B, const BsdfInputs &in, Vec3 wi, Vec
         e.d_slot0 = nonlinear ? Vec3(k / (den.x * den.x), k / (den.y * den.y), k / (den.z * den.z)) : Vec3(k / den.x, k / den.y, k / den.z);
         float prob_specular = f_i * B.spec_sampling_weight, prob_diffuse = (1.f - f_i) * (1.f - B.spec_sampling_weight);
         prob_diffuse = prob_diffuse / (prob_specular + prob_diffuse);
+        if (CTX && !ctx.is_enabled(LOBE_DELTA_REFLECTION, 0u)) prob_diffuse = 1.f;               /* :339-346 */
         e.pdf = hemi_pdf * prob_diffuse;
     } break;
     }
@@ -395,32 +421,41 @@ HAR_HD void bsdf_eval_extra_one(const DBsdf &B, const BsdfInputs &in, Vec3 wi, V
 }
 
 /* sample of one (not twosided) record */
-template <uint32_t TYPES = HAR_BSDF_ALL_TYPES>
-HAR_HD void bsdf_sample_one(const DBsdf &B, const BsdfInputs &in, Vec3 wi, float sample1, float s2x, float s2y, BsdfSample &bs) {
-    bs.wo = Vec3(0.f); bs.pdf = 0.f; bs.weight = Vec3(0.f); bs.eta = 0.f; bs.delta = false;     /* dr::zeros<BSDFSample3f>() */
+template <uint32_t TYPES = HAR_BSDF_ALL_TYPES, bool CTX = false>
+HAR_HD void bsdf_sample_one(const DBsdf &B, const BsdfInputs &in, Vec3 wi, float sample1, float s2x, float s2y, BsdfSample &bs, const BsdfCtx &ctx = BsdfCtx()) {
+    bs.wo = Vec3(0.f); bs.pdf = 0.f; bs.weight = Vec3(0.f); bs.eta = 0.f; bs.delta = false; bs.type = 0u; bs.comp = 0u;     /* dr::zeros<BSDFSample3f>() */
     float cos_theta_i = wi.z;
     const uint32_t type = HAR_BSDF_SINGLE(TYPES) ? (uint32_t) HAR_BSDF_SINGLE_TYPE(TYPES) : B.type;
     switch (type) {
     case BSDF_DIFFUSE: {                                                     /* diffuse.cpp:100-124 */
+        if (CTX && !ctx.is_enabled(LOBE_DIFFUSE_REFLECTION)) return;
         bs.wo = square_to_cosine_hemisphere(s2x, s2y);
-        bs.pdf = HAR_INV_PI * bs.wo.z; bs.eta = 1.f;
+        bs.pdf = HAR_INV_PI * bs.wo.z; bs.eta = 1.f; bs.type = LOBE_DIFFUSE_REFLECTION;
         bs.weight = (cos_theta_i > 0.f && bs.pdf > 0.f) ? in.slot0 : Vec3(0.f);
     } break;
-    case BSDF_DIELECTRIC: {                                                  /* dielectric.cpp:245-338, TransportMode::Radiance */
+    case BSDF_DIELECTRIC: {                                                  /* dielectric.cpp:245-370 */
+        /* component 0 = reflection, 1 = transmission; with one of them disabled the other is taken with probability 1 and carries the Fresnel
+         * term in its weight (:262-272, 348-350); TransportMode::Importance drops the eta_ti^2 radiance scaling of the transmitted lobe (:362-367) */
+        const bool has_reflection = !CTX || ctx.is_enabled(LOBE_DELTA_REFLECTION, 0u), has_transmission = !CTX || ctx.is_enabled(LOBE_DELTA_TRANSMISSION, 1u);
+        if (CTX && !has_reflection && !has_transmission) return;
         float r_i, cos_theta_t, eta_it, eta_ti; fresnel_dielectric(cos_theta_i, B.eta, r_i, cos_theta_t, eta_it, eta_ti);
         float t_i = 1.f - r_i;
-        bool selected_r = sample1 <= r_i;
-        bs.pdf = selected_r ? r_i : t_i;
-        bs.delta = true;
+        const bool both = has_reflection && has_transmission;
+        bool selected_r = both ? sample1 <= r_i : has_reflection;
+        bs.pdf = both ? (selected_r ? r_i : t_i) : 1.f;
+        bs.delta = true; bs.type = selected_r ? LOBE_DELTA_REFLECTION : LOBE_DELTA_TRANSMISSION; bs.comp = selected_r ? 0u : 1u;
         bs.wo = selected_r ? reflect_local(wi) : refract_local(wi, cos_theta_t, eta_ti);
         bs.eta = selected_r ? 1.f : eta_it;
-        bs.weight = selected_r ? in.slot0 : in.slot1 * sqr_(eta_ti);
+        const float factor = (CTX && ctx.mode != 0u) ? 1.f : eta_ti;
+        bs.weight = selected_r ? in.slot0 : in.slot1 * sqr_(factor);
+        if (CTX && !both) bs.weight = selected_r ? in.slot0 * r_i : (in.slot1 * t_i) * sqr_(factor);
     } break;
     case BSDF_ROUGHCONDUCTOR: {                                              /* roughconductor.cpp:226-320 */
+        if (CTX && !ctx.is_enabled(LOBE_GLOSSY_REFLECTION)) return;
         if (!(cos_theta_i > 0.f)) return;
         Microfacet distr((B.flags & BF_GGX) != 0, B.alpha_u, B.alpha_v, (B.flags & BF_SAMPLE_VISIBLE) != 0);
         float pdf; Vec3 m = distr.sample(wi, s2x, s2y, pdf);
-        bs.wo = reflect_m(wi, m); bs.eta = 1.f; bs.pdf = pdf;
+        bs.wo = reflect_m(wi, m); bs.eta = 1.f; bs.pdf = pdf; bs.type = LOBE_GLOSSY_REFLECTION;
         bool active = pdf != 0.f && bs.wo.z > 0.f;
         float weight = distr.sample_visible ? distr.smith_g1(bs.wo, m) : distr.G(wi, bs.wo, m) * dot3(wi, m) / (cos_theta_i * m.z);
         bs.pdf /= 4.f * dot3(bs.wo, m);
@@ -429,42 +464,49 @@ HAR_HD void bsdf_sample_one(const DBsdf &B, const BsdfInputs &in, Vec3 wi, float
         bs.weight = active ? F * (in.slot0 * weight) : Vec3(0.f);
     } break;
     case BSDF_ROUGHPLASTIC: {                                                /* roughplastic.cpp:244-294 */
+        const bool has_specular = !CTX || ctx.is_enabled(LOBE_GLOSSY_REFLECTION, 0u), has_diffuse = !CTX || ctx.is_enabled(LOBE_DIFFUSE_REFLECTION, 1u);
+        if (CTX && !has_specular && !has_diffuse) return;
         if (!(cos_theta_i > 0.f)) return;
         float t_i = lerp_gather(in.table, cos_theta_i, HAR_ROUGH_TRANSMITTANCE_RES);
         float prob_specular = (1.f - t_i) * B.spec_sampling_weight, prob_diffuse = t_i * (1.f - B.spec_sampling_weight);
-        prob_specular = prob_specular / (prob_specular + prob_diffuse);
+        if (CTX && has_specular != has_diffuse) prob_specular = has_specular ? 1.f : 0.f;         /* :261-264 */
+        else prob_specular = prob_specular / (prob_specular + prob_diffuse);
         bool sample_specular = sample1 < prob_specular;
         bs.eta = 1.f;
         if (sample_specular) {
             Microfacet distr((B.flags & BF_GGX) != 0, B.alpha_u, B.alpha_u, (B.flags & BF_SAMPLE_VISIBLE) != 0);
             float pdf_m; Vec3 m = distr.sample(wi, s2x, s2y, pdf_m);
-            bs.wo = reflect_m(wi, m);
-        } else bs.wo = square_to_cosine_hemisphere(s2x, s2y);
-        BsdfEval e; bsdf_eval_pdf_one<TYPES>(B, in, wi, bs.wo, e);
+            bs.wo = reflect_m(wi, m); bs.type = LOBE_GLOSSY_REFLECTION; bs.comp = 0u;
+        } else { bs.wo = square_to_cosine_hemisphere(s2x, s2y); bs.type = LOBE_DIFFUSE_REFLECTION; bs.comp = 1u; }
+        BsdfEval e; bsdf_eval_pdf_one<TYPES, CTX>(B, in, wi, bs.wo, e, ctx);
         bs.pdf = e.pdf;
         bool active = bs.pdf > 0.f;
         bs.weight = active ? Vec3(e.value.x / bs.pdf, e.value.y / bs.pdf, e.value.z / bs.pdf) : Vec3(0.f);
     } break;
     case BSDF_CONDUCTOR: {                                                   /* conductor.cpp:264-304 */
         if (!HAR_BSDF_HAS(TYPES, BSDF_CONDUCTOR)) return;
+        if (CTX && !ctx.is_enabled(LOBE_DELTA_REFLECTION)) return;
         if (!(cos_theta_i > 0.f)) return;
-        bs.wo = reflect_local(wi); bs.eta = 1.f; bs.pdf = 1.f; bs.delta = true;
+        bs.wo = reflect_local(wi); bs.eta = 1.f; bs.pdf = 1.f; bs.delta = true; bs.type = LOBE_DELTA_REFLECTION;
         Vec3 F(fresnel_conductor(cos_theta_i, B.eta_c[0], B.k_c[0]), fresnel_conductor(cos_theta_i, B.eta_c[1], B.k_c[1]), fresnel_conductor(cos_theta_i, B.eta_c[2], B.k_c[2]));
         bs.weight = in.slot0 * F;
     } break;
     case BSDF_PLASTIC: {                                                     /* plastic.cpp:208-266 */
         if (!HAR_BSDF_HAS(TYPES, BSDF_PLASTIC)) return;
+        const bool has_specular = !CTX || ctx.is_enabled(LOBE_DELTA_REFLECTION, 0u), has_diffuse = !CTX || ctx.is_enabled(LOBE_DIFFUSE_REFLECTION, 1u);
+        if (CTX && !has_specular && !has_diffuse) return;
         if (!(cos_theta_i > 0.f)) return;
         float f_i, ct, eit, eti; fresnel_dielectric(cos_theta_i, B.eta, f_i, ct, eit, eti);
         float prob_specular = f_i * B.spec_sampling_weight, prob_diffuse = (1.f - f_i) * (1.f - B.spec_sampling_weight);
-        prob_specular = prob_specular / (prob_specular + prob_diffuse);
+        if (CTX && has_specular != has_diffuse) prob_specular = has_specular ? 1.f : 0.f;         /* :231-234 */
+        else prob_specular = prob_specular / (prob_specular + prob_diffuse);
         prob_diffuse = 1.f - prob_specular;
         bs.eta = 1.f;
         if (sample1 < prob_specular) {
-            bs.wo = reflect_local(wi); bs.pdf = prob_specular; bs.delta = true;
+            bs.wo = reflect_local(wi); bs.pdf = prob_specular; bs.delta = true; bs.type = LOBE_DELTA_REFLECTION; bs.comp = 0u;
             bs.weight = in.slot1 * (f_i / bs.pdf);
         } else {
-            bs.wo = square_to_cosine_hemisphere(s2x, s2y);
+            bs.wo = square_to_cosine_hemisphere(s2x, s2y); bs.type = LOBE_DIFFUSE_REFLECTION; bs.comp = 1u;
             bs.pdf = prob_diffuse * (HAR_INV_PI * bs.wo.z);
             float f_o; fresnel_dielectric(bs.wo.z, B.eta, f_o, ct, eit, eti);
             const bool nonlinear = (B.flags & BF_NONLINEAR) != 0;

@@ -448,7 +448,7 @@ static bool overlap_applies(const HarSceneImpl *S, const HarIntegratorImpl *I, u
 }
 
 /* rays of har_integrator_sample: SoA arrays of n_total rays, the chunk covers [first, first + n) */
-struct RaySource { const float *o, *d, *maxt; const uint64_t *state; uint32_t n_total, first; };
+struct RaySource { const float *o, *d, *maxt; const uint64_t *state; const uint8_t *active; uint32_t n_total, first; };
 
 /* one chunk: raygen + bounce loop.  `mode` selects path / prb primal / prb adjoint kernels; `rays` != nullptr: the wavefront starts from
  * caller-supplied rays (SamplingIntegrator::sample) instead of the sensor; `valid_lane` != nullptr receives the samples' masks */
@@ -491,7 +491,7 @@ int run_chunk(HarSceneImpl *S, HarIntegratorImpl *I, const DSensor &C, int mode,
     HIP_TRY(hipMemsetAsync(cur_trace(I, 0), 0, used, s));
     HIP_TRY(hipMemsetAsync(cur_resolve(I, 0), 0, used, s));
     if (tape_r) launch_tape_begin(s, C, seed, spp, log_spp, lane_base, n, I->shard_cap, I->result, I->adj, I->tape_la[0], I->tape_lb[0]);
-    else if (rays) launch_raygen_rays(s, seed, lane_base, n, rays->n_total, rays->first, rays->o, rays->d, rays->maxt, rays->state, I->shard_cap, I->st[0], I->result, cnt_alive(I, 0));
+    else if (rays) launch_raygen_rays(s, seed, lane_base, n, rays->n_total, rays->first, rays->o, rays->d, rays->maxt, rays->state, rays->active, I->shard_cap, I->st[0], I->result, cnt_alive(I, 0));
     /* forward mode: k_raygen<ADJOINT> takes `adj == nullptr` as "zero dL" -- a workspace that served render_backward before still holds that call's adjoint
      * image in I->adj (possibly of a smaller film), which must not be gathered here */
     /* the adjoint image goes to the adjoint raygen (dL per lane; not in forward mode: dL accumulates there) and to the primal raygen of the record tape (dL for its emission terms) */
@@ -811,32 +811,46 @@ static int read_status(int *d_status, hipStream_t s) {
     return 0;
 }
 
-int har_ray_intersect_preliminary(HarScene S, uint32_t n, const float *o, const float *d, const float *maxt, int naive, float *t, float *u,
+int har_ray_intersect_preliminary(HarScene S, uint32_t n, const float *o, const float *d, const float *maxt, const uint8_t *active, int naive, float *t, float *u,
                                   float *v, uint32_t *prim, uint32_t *shape, uint32_t *inst, void *stream) {
     if (!S) return fail("null scene");
     if (n == 0) return 0;
     int *st = nullptr; HIP_TRY(dev_alloc((void **) &st, sizeof(int))); HIP_TRY(hipMemsetAsync(st, 0, sizeof(int), (hipStream_t) stream));
-    launch_api_intersect((hipStream_t) stream, S->ds, n, o, d, maxt, naive, t, u, v, prim, shape, inst, st);
+    launch_api_intersect((hipStream_t) stream, S->ds, n, o, d, maxt, active, naive, t, u, v, prim, shape, inst, st);
     HIP_TRY(hipGetLastError());
     int rc = read_status(st, (hipStream_t) stream); dev_free(st);
     return rc;
 }
-int har_ray_test(HarScene S, uint32_t n, const float *o, const float *d, const float *maxt, int naive, uint8_t *hit, void *stream) {
+int har_ray_test(HarScene S, uint32_t n, const float *o, const float *d, const float *maxt, const uint8_t *active, int naive, uint8_t *hit, void *stream) {
     if (!S) return fail("null scene");
     if (n == 0) return 0;
     int *st = nullptr; HIP_TRY(dev_alloc((void **) &st, sizeof(int))); HIP_TRY(hipMemsetAsync(st, 0, sizeof(int), (hipStream_t) stream));
-    launch_api_ray_test((hipStream_t) stream, S->ds, n, o, d, maxt, naive, hit, st);
+    launch_api_ray_test((hipStream_t) stream, S->ds, n, o, d, maxt, active, naive, hit, st);
     HIP_TRY(hipGetLastError());
     int rc = read_status(st, (hipStream_t) stream); dev_free(st);
     return rc;
 }
+/* RayFlags the entry points accept (interaction.h:19-87): unknown bits and FollowShape together with DetachShape are refused, never ignored */
+static int check_ray_flags(uint32_t ray_flags) {
+    if (ray_flags & ~(uint32_t) RAY_KNOWN_FLAGS) return fail("ray_flags: unknown RayFlags bits (known: Minimal 0, Shading 1, NormalPartials 2, FollowShape 4, DetachShape 8)");
+    if ((ray_flags & RAY_FOLLOW_SHAPE) && (ray_flags & RAY_DETACH_SHAPE)) return fail("ray_flags: at most one of FollowShape and DetachShape can be specified");
+    return 0;
+}
 int har_compute_surface_interaction(HarScene S, uint32_t n, const float *o, const float *d, const float *t, const float *u, const float *v,
-                                    const uint32_t *prim, const uint32_t *shape, const uint32_t *inst, float *out, void *stream) {
+                                    const uint32_t *prim, const uint32_t *shape, const uint32_t *inst, uint32_t ray_flags, const uint8_t *active, float *out, void *stream) {
     if (!S) return fail("null scene");
+    if (check_ray_flags(ray_flags)) return 1;
     if (n == 0) return 0;
-    launch_api_si((hipStream_t) stream, S->ds, n, o, d, t, u, v, prim, shape, inst, out);
+    launch_api_si((hipStream_t) stream, S->ds, n, o, d, t, u, v, prim, shape, inst, ray_flags, active, out);
     HIP_TRY(hipGetLastError());
     return 0;
+}
+int har_ray_intersect(HarScene S, uint32_t n, const float *o, const float *d, const float *maxt, uint32_t ray_flags, const uint8_t *active, int naive, float *t, float *u,
+                      float *v, uint32_t *prim, uint32_t *shape, uint32_t *inst, float *si, void *stream) {
+    if (!S) return fail("null scene");
+    if (check_ray_flags(ray_flags)) return 1;
+    if (har_ray_intersect_preliminary(S, n, o, d, maxt, active, naive, t, u, v, prim, shape, inst, stream)) return 1;
+    return har_compute_surface_interaction(S, n, o, d, t, u, v, prim, shape, inst, ray_flags, active, si, stream);
 }
 int har_sampler_seed(uint32_t seed, uint32_t lane_offset, uint32_t n, uint64_t *state, uint64_t *inc, void *stream) {
     if (n == 0) return 0;
@@ -856,24 +870,46 @@ int har_sampler_next_2d(uint32_t n, uint64_t *state, const uint64_t *inc, const 
     HIP_TRY(hipGetLastError());
     return 0;
 }
-int har_bsdf_eval_pdf(HarScene S, uint32_t bsdf, uint32_t n, const float *wi, const float *uv, const float *wo, float *value, float *pdf, void *stream) {
+/* HarBSDFContext -> BsdfCtx; NULL = BSDFContext() (Radiance, all lobes, all components) */
+static int lower_ctx(const HarBSDFContext *ctx, BsdfCtx &out) {
+    out = BsdfCtx();
+    if (!ctx) return 0;
+    if (ctx->mode > 1u) return fail("HarBSDFContext::mode must be 0 (TransportMode::Radiance) or 1 (TransportMode::Importance)");
+    out.mode = ctx->mode; out.type_mask = ctx->type_mask; out.component = ctx->component;
+    return 0;
+}
+static int bsdf_eval_common(HarScene S, uint32_t bsdf, const HarBSDFContext *ctx, uint32_t n, const float *wi, const float *uv, const float *wo, const uint8_t *active,
+                            float *value, float *pdf, void *stream) {
     if (!S || bsdf >= S->hs.bsdfs.size()) return fail("invalid bsdf index");
+    BsdfCtx c; if (lower_ctx(ctx, c)) return 1;
     if (n == 0) return 0;
-    launch_api_bsdf_eval_pdf((hipStream_t) stream, S->ds, bsdf, n, wi, uv, wo, value, pdf);
+    if (!wi || !uv || !wo) return fail("null wi / uv / wo");
+    launch_api_bsdf_eval_pdf((hipStream_t) stream, S->ds, bsdf, c, n, wi, uv, wo, active, value, pdf);
     HIP_TRY(hipGetLastError());
     return 0;
 }
-int har_bsdf_sample_ex(HarScene S, uint32_t bsdf, uint32_t n, const float *wi, const float *uv, const float *sample1, const float *sample2,
-                       float *wo, float *pdf, float *weight, float *eta_delta, void *stream) {
+int har_bsdf_eval_pdf(HarScene S, uint32_t bsdf, const HarBSDFContext *ctx, uint32_t n, const float *wi, const float *uv, const float *wo, const uint8_t *active,
+                      float *value, float *pdf, void *stream) {
+    if (!value || !pdf) return fail("null value / pdf");
+    return bsdf_eval_common(S, bsdf, ctx, n, wi, uv, wo, active, value, pdf, stream);
+}
+int har_bsdf_eval(HarScene S, uint32_t bsdf, const HarBSDFContext *ctx, uint32_t n, const float *wi, const float *uv, const float *wo, const uint8_t *active, float *value, void *stream) {
+    if (!value) return fail("null value");
+    return bsdf_eval_common(S, bsdf, ctx, n, wi, uv, wo, active, value, nullptr, stream);
+}
+int har_bsdf_pdf(HarScene S, uint32_t bsdf, const HarBSDFContext *ctx, uint32_t n, const float *wi, const float *uv, const float *wo, const uint8_t *active, float *pdf, void *stream) {
+    if (!pdf) return fail("null pdf");
+    return bsdf_eval_common(S, bsdf, ctx, n, wi, uv, wo, active, nullptr, pdf, stream);
+}
+int har_bsdf_sample(HarScene S, uint32_t bsdf, const HarBSDFContext *ctx, uint32_t n, const float *wi, const float *uv, const float *sample1, const float *sample2,
+                    const uint8_t *active, float *wo, float *pdf, float *weight, float *eta, uint32_t *sampled_type, uint32_t *sampled_component, void *stream) {
     if (!S || bsdf >= S->hs.bsdfs.size()) return fail("invalid bsdf index");
+    BsdfCtx c; if (lower_ctx(ctx, c)) return 1;
     if (n == 0) return 0;
-    launch_api_bsdf_sample((hipStream_t) stream, S->ds, bsdf, n, wi, uv, sample1, sample2, wo, pdf, weight, eta_delta);
+    if (!wi || !uv || !sample2 || !wo || !pdf || !weight) return fail("null input / output arrays");
+    launch_api_bsdf_sample((hipStream_t) stream, S->ds, bsdf, c, n, wi, uv, sample1, sample2, active, wo, pdf, weight, eta, sampled_type, sampled_component);
     HIP_TRY(hipGetLastError());
     return 0;
-}
-int har_bsdf_sample(HarScene S, uint32_t bsdf, uint32_t n, const float *wi, const float *uv, const float *sample1, const float *sample2,
-                    float *wo, float *pdf, float *weight, void *stream) {
-    return har_bsdf_sample_ex(S, bsdf, n, wi, uv, sample1, sample2, wo, pdf, weight, nullptr, stream);
 }
 int har_sensor_sample_ray(const HarSensor *sensor, uint32_t n, const float *px, const float *py, float *o, float *d, float *maxt, void *stream) {
     DSensor C; std::string e;
@@ -1058,7 +1094,7 @@ int har_render_backward(HarScene S, HarIntegrator I, const HarSensor *sensor, co
 }
 
 int har_integrator_sample(HarScene S, HarIntegrator I, uint32_t seed, uint32_t lane_offset, uint32_t n, const float *o, const float *d, const float *maxt,
-                          const uint64_t *state, float *rgb, uint8_t *valid, uint64_t *state_out, void *stream) {
+                          const uint64_t *state, const uint8_t *active, float *rgb, uint8_t *valid, uint64_t *state_out, void *stream) {
     if (!S || !I) return fail("null scene / integrator");
     if (n == 0) return 0;
     if (!o || !d || !maxt || !rgb) return fail("null ray / output arrays");
@@ -1076,7 +1112,7 @@ int har_integrator_sample(HarScene S, HarIntegrator I, uint32_t seed, uint32_t l
     const DSensor C{};                                     /* no sensor on this entry point */
     for (uint64_t base = 0; base < n; base += chunk) {
         const uint32_t m = (uint32_t) std::min<uint64_t>(chunk, n - base);
-        const RaySource rays{ o, d, maxt, state, n, (uint32_t) base };
+        const RaySource rays{ o, d, maxt, state, active, n, (uint32_t) base };
         if (I->max_depth == 0) {                           /* path.cpp:102-103 / prb.py: no interaction at all */
             HIP_TRY(hipMemsetAsync(I->result, 0, (size_t) m * sizeof(float4), s));
             HIP_TRY(hipMemsetAsync(I->alpha_lane, 0, (size_t) m * sizeof(float), s));
@@ -1087,7 +1123,7 @@ int har_integrator_sample(HarScene S, HarIntegrator I, uint32_t seed, uint32_t l
             if (run_chunk(S, I, C, mode, seed, 1, 0, lane_offset + (uint32_t) base, m, nullptr, s, 0, ps, &rays, I->alpha_lane)) return 1;
             if (mode == MODE_PRB_PRIMAL) launch_accumulate_stats(s, I->counters, bounce_limit(I), I->totals, m);
         }
-        launch_sample_out(s, m, n, (uint32_t) base, I->result, I->alpha_lane, mode == MODE_PATH ? 1 : 0, rgb, valid);
+        launch_sample_out(s, m, n, (uint32_t) base, I->result, I->alpha_lane, mode == MODE_PATH ? 1 : 0, rgb, valid, active, seed, lane_offset + (uint32_t) base, state, state_out);
         prof_mark(I, s, CLS_OTHER);
     }
     HIP_TRY(hipGetLastError());

@@ -123,8 +123,9 @@ void launch_raygen(int mode, hipStream_t s, const DSensor &C, uint32_t seed, uin
                    uint32_t shard_cap, const WaveState &out, float4 *result, uint32_t *count, const float *adj, float4 *dL, const PassState &ps = PassState{ nullptr, nullptr, 0 });
 /* har_integrator_sample: the wavefront of n caller-supplied rays (SoA arrays of n_total rays, this chunk starts at `first`), see k_raygen_rays */
 void launch_raygen_rays(hipStream_t s, uint32_t seed, uint32_t lane_base, uint32_t n, uint32_t n_total, uint32_t first, const float *o, const float *d, const float *maxt,
-                        const uint64_t *state, uint32_t shard_cap, const WaveState &out, float4 *result, uint32_t *count);
-void launch_sample_out(hipStream_t s, uint32_t n, uint32_t n_total, uint32_t first, const float4 *result, const float *valid_lane, int zero_invalid, float *rgb, uint8_t *valid);
+                        const uint64_t *state, const uint8_t *active, uint32_t shard_cap, const WaveState &out, float4 *result, uint32_t *count);
+void launch_sample_out(hipStream_t s, uint32_t n, uint32_t n_total, uint32_t first, const float4 *result, const float *valid_lane, int zero_invalid, float *rgb, uint8_t *valid,
+                       const uint8_t *active, uint32_t seed, uint32_t lane_base, const uint64_t *state_in, uint64_t *state_out);
 /* `spill` = nullptr: the scene's depth-first bound fits the LDS stack and the kernels without the HBM spill path run (3 % faster) */
 void launch_trace_closest(hipStream_t s, uint32_t grid, uint2 *spill, const Accel &A, const uint32_t *count, uint32_t *cursor, uint32_t shard_cap,
                           const WaveState &in, float4 *h0, uint2 *h1, int *status);
@@ -171,16 +172,18 @@ void launch_adjoint_image(hipStream_t s, const float *grad_in, const float *wfil
 void launch_add(hipStream_t s, const float *src, float *dst, uint32_t n);      /* dst[i] += src[i] */
 void launch_accumulate_stats(hipStream_t s, const uint32_t *counters, uint32_t n_bounces, unsigned long long *totals, uint32_t paths);
 
-void launch_api_intersect(hipStream_t s, const DScene &S, uint32_t n, const float *o, const float *d, const float *maxt, int naive,
+/* array-valued plugin surface: `active` = the reference's Mask argument (NULL = all lanes) */
+void launch_api_intersect(hipStream_t s, const DScene &S, uint32_t n, const float *o, const float *d, const float *maxt, const uint8_t *active, int naive,
                           float *t, float *u, float *v, uint32_t *prim, uint32_t *shape, uint32_t *inst, int *status);
-void launch_api_ray_test(hipStream_t s, const DScene &S, uint32_t n, const float *o, const float *d, const float *maxt, int naive, uint8_t *out, int *status);
+void launch_api_ray_test(hipStream_t s, const DScene &S, uint32_t n, const float *o, const float *d, const float *maxt, const uint8_t *active, int naive, uint8_t *out, int *status);
 void launch_api_si(hipStream_t s, const DScene &S, uint32_t n, const float *o, const float *d, const float *t, const float *u, const float *v,
-                   const uint32_t *prim, const uint32_t *shape, const uint32_t *inst, float *out);
+                   const uint32_t *prim, const uint32_t *shape, const uint32_t *inst, uint32_t ray_flags, const uint8_t *active, float *out);
 void launch_api_sampler_seed(hipStream_t s, uint32_t seed, uint32_t lane_offset, uint32_t n, uint64_t *state, uint64_t *inc);
 void launch_api_sampler_next(hipStream_t s, uint32_t n, uint64_t *state, const uint64_t *inc, const uint8_t *active, float *out, int dims);
-void launch_api_bsdf_eval_pdf(hipStream_t s, const DScene &S, uint32_t bsdf, uint32_t n, const float *wi, const float *uv, const float *wo, float *value, float *pdf);
-void launch_api_bsdf_sample(hipStream_t s, const DScene &S, uint32_t bsdf, uint32_t n, const float *wi, const float *uv, const float *s1, const float *s2,
-                            float *wo, float *pdf, float *weight, float *eta_delta);
+void launch_api_bsdf_eval_pdf(hipStream_t s, const DScene &S, uint32_t bsdf, const BsdfCtx &ctx, uint32_t n, const float *wi, const float *uv, const float *wo, const uint8_t *active,
+                              float *value, float *pdf);
+void launch_api_bsdf_sample(hipStream_t s, const DScene &S, uint32_t bsdf, const BsdfCtx &ctx, uint32_t n, const float *wi, const float *uv, const float *s1, const float *s2,
+                            const uint8_t *active, float *wo, float *pdf, float *weight, float *eta, uint32_t *stype, uint32_t *scomp);
 void launch_api_sensor_ray(hipStream_t s, const DSensor &C, uint32_t n, const float *px, const float *py, float *o, float *d, float *maxt);
 void launch_api_film_put(hipStream_t s, const DSensor &C, uint32_t n, const float *px, const float *py, const float *values4, float *film);
 

@@ -329,7 +329,7 @@ __global__ __launch_bounds__(kBlock) void k_tape_begin(DSensor C, uint32_t seed,
  * continued from state[i] when the caller passes its PCG32 states; the loop state is PathIntegrator::sample's initial one (path.cpp:129-147:
  * throughput 1, eta 1, depth 0, prev_bsdf_pdf 1, prev_bsdf_delta true). */
 __global__ __launch_bounds__(kBlock) void k_raygen_rays(uint32_t seed, uint32_t lane_base, uint32_t n, uint32_t n_total, uint32_t first, const float *o, const float *d,
-                                                        const float *maxt, const uint64_t *state, uint32_t shard_cap, WaveState out, float4 *result, uint32_t *count) {
+                                                        const float *maxt, const uint64_t *state, const uint8_t *active, uint32_t shard_cap, WaveState out, float4 *result, uint32_t *count) {
     uint32_t i = blockIdx.x * kBlock + threadIdx.x;
     if (i < HAR_SHARDS) {
         const uint32_t tiles = (n + kBlock - 1) / kBlock, rem = n % kBlock;
@@ -345,18 +345,28 @@ __global__ __launch_bounds__(kBlock) void k_raygen_rays(uint32_t seed, uint32_t 
     sampler_seed(seed, lane_base + i, st.rng, inc);
     if (state) st.rng = state[g];
     st.o = Vec3(o[g], o[n_total + g], o[2 * (size_t) n_total + g]); st.d = Vec3(d[g], d[n_total + g], d[2 * (size_t) n_total + g]); st.maxt = maxt[g];
+    /* a masked lane keeps its slot in the dense wavefront but carries a ray of zero length: it ends at once, and k_sample_out discards whatever it gathered
+     * and restores its sampler stream (the reference's masked lane never enters the loop) */
+    if (active && !active[g]) st.maxt = 0.f;
     st.throughput = Vec3(1.f); st.lane = lane_base + i; st.prev_p = Vec3(0.f); st.prev_bsdf_pdf = 1.f; st.flags = 1u << 16; st.eta = 1.f;
     store_state(out, shard_slot(i, shard_cap), st);
     result[i] = make_float4(0.f, 0.f, 0.f, 0.f);
 }
-/* radiance + mask of har_integrator_sample: PathIntegrator returns select(valid_ray, result, 0) (path.cpp:341-345), prb returns L and depth != 0 (prb.py:332) */
-__global__ void k_sample_out(uint32_t n, uint32_t n_total, uint32_t first, const float4 *result, const float *valid_lane, int zero_invalid, float *rgb, uint8_t *valid) {
+/* radiance + mask of har_integrator_sample: PathIntegrator returns select(valid_ray, result, 0) (path.cpp:341-345), prb returns L and depth != 0 (prb.py:332).
+ * A lane the caller masked out (`active`, the Mask argument of integrator.h:432-437) never enters the loop: zero radiance, valid = false, and its sampler stream
+ * stays where it was (state_out = the state it came in with). */
+__global__ void k_sample_out(uint32_t n, uint32_t n_total, uint32_t first, const float4 *result, const float *valid_lane, int zero_invalid, float *rgb, uint8_t *valid,
+                             const uint8_t *active, uint32_t seed, uint32_t lane_base, const uint64_t *state_in, uint64_t *state_out) {
     uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
     const size_t g = (size_t) first + i;
-    const bool v = valid_lane[i] != 0.f;
+    bool v = valid_lane[i] != 0.f;
     float4 r = result[i];
     if (zero_invalid && !v) r = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (active && !active[g]) {
+        r = make_float4(0.f, 0.f, 0.f, 0.f); v = false;
+        if (state_out) { uint64_t st, inc; sampler_seed(seed, lane_base + i, st, inc); state_out[g] = state_in ? state_in[g] : st; }
+    }
     rgb[g] = r.x; rgb[n_total + g] = r.y; rgb[2 * (size_t) n_total + g] = r.z;
     if (valid) valid[g] = v ? 1 : 0;
 }
@@ -1496,7 +1506,7 @@ __global__ void k_accumulate_stats(const uint32_t *counters, uint32_t n_bounces,
 
 /* --- array-valued plugin surface (Scene::ray_intersect*, Sampler, BSDF, Sensor, ImageBlock) --- */
 template <bool NAIVE>
-__global__ __launch_bounds__(kBlock) void k_api_intersect(DScene S, uint32_t n, const float *o, const float *d, const float *maxt,
+__global__ __launch_bounds__(kBlock) void k_api_intersect(DScene S, uint32_t n, const float *o, const float *d, const float *maxt, const uint8_t *active,
                                                           float *t, float *u, float *v, uint32_t *prim, uint32_t *shape, uint32_t *inst, int *status) {
     __shared__ uint2 lds[HAR_LDS_STACK_DEPTH * kBlock];
     LdsStack<HAR_LDS_STACK_DEPTH> stack{ lds + threadIdx.x };
@@ -1504,7 +1514,9 @@ __global__ __launch_bounds__(kBlock) void k_api_intersect(DScene S, uint32_t n, 
     if (i >= n) return;
     Vec3 O(o[i], o[n + i], o[2 * (size_t) n + i]), D(d[i], d[n + i], d[2 * (size_t) n + i]);
     Hit hit; int st = 0;
-    if (NAIVE) accel_trace_naive<false>(S.accel, S.blas_tri_ranges, O, D, maxt[i], hit);
+    /* a masked lane traces nothing and reports "no intersection": t = inf, zero-initialised indices (the `active` argument of scene.cpp:216-230) */
+    if (active && !active[i]) { hit.t = HAR_INF; hit.u = 0.f; hit.v = 0.f; hit.prim = 0; hit.shape = 0; hit.inst = 0xffffffffu; }
+    else if (NAIVE) accel_trace_naive<false>(S.accel, S.blas_tri_ranges, O, D, maxt[i], hit);
     else {      /* the production traversal code (Traversal<HAR_TRAV_POLICY>::step), one ray per lane */
         Traversal<HAR_TRAV_POLICY> T; T.begin(S.accel, O, D, maxt[i], (S.accel.top_last & 2u) != 0u);
         while (!T.template step<false, LdsStack<HAR_LDS_STACK_DEPTH>, NoProbe, 1>(S.accel, stack, st)) { }
@@ -1514,14 +1526,15 @@ __global__ __launch_bounds__(kBlock) void k_api_intersect(DScene S, uint32_t n, 
     t[i] = hit.t; u[i] = hit.u; v[i] = hit.v; prim[i] = hit.prim; shape[i] = hit.shape; inst[i] = hit.inst;
 }
 template <bool NAIVE>
-__global__ __launch_bounds__(kBlock) void k_api_ray_test(DScene S, uint32_t n, const float *o, const float *d, const float *maxt, uint8_t *out, int *status) {
+__global__ __launch_bounds__(kBlock) void k_api_ray_test(DScene S, uint32_t n, const float *o, const float *d, const float *maxt, const uint8_t *active, uint8_t *out, int *status) {
     __shared__ uint2 lds[HAR_LDS_STACK_DEPTH * kBlock];
     LdsStack<HAR_LDS_STACK_DEPTH> stack{ lds + threadIdx.x };
     uint32_t i = blockIdx.x * kBlock + threadIdx.x;
     if (i >= n) return;
     Vec3 O(o[i], o[n + i], o[2 * (size_t) n + i]), D(d[i], d[n + i], d[2 * (size_t) n + i]);
     Hit hit; int st = 0; bool r;
-    if (NAIVE) r = accel_trace_naive<true>(S.accel, S.blas_tri_ranges, O, D, maxt[i], hit);
+    if (active && !active[i]) r = false;                  /* masked lane: `false` (scene.cpp:232-238) */
+    else if (NAIVE) r = accel_trace_naive<true>(S.accel, S.blas_tri_ranges, O, D, maxt[i], hit);
     else {
         Traversal<HAR_TRAV_POLICY> T; T.begin(S.accel, O, D, maxt[i], (S.accel.top_last & 1u) != 0u);
         while (!T.template step<true, LdsStack<HAR_LDS_STACK_DEPTH>, NoProbe, 1>(S.accel, stack, st)) { }
@@ -1530,15 +1543,31 @@ __global__ __launch_bounds__(kBlock) void k_api_ray_test(DScene S, uint32_t n, c
     if (st) atomicMax(status, st);
     out[i] = r ? 1 : 0;
 }
+/* out = 33 rows of n floats: p 0-2, n 3-5, sh_frame.n 6-8, sh_frame.s 9-11, sh_frame.t 12-14, wi 15-17, uv 18-19, t 20, dp_du 21-23, dp_dv 24-26, dn_du 27-29,
+ * dn_dv 30-32 (SurfaceInteraction3f, interaction.h:345-420).  A lane that is masked or holds no intersection gets what the reference's masked vcall + finalize leave
+ * (interaction.h:559-605,804-829): t = inf, zero-initialised fields, the frame coordinate_system builds around a zero normal, wi = -ray.d. */
 __global__ void k_api_si(DScene S, uint32_t n, const float *o, const float *d, const float *t, const float *u, const float *v,
-                         const uint32_t *prim, const uint32_t *shape, const uint32_t *inst, float *out) {
+                         const uint32_t *prim, const uint32_t *shape, const uint32_t *inst, uint32_t ray_flags, const uint8_t *active, float *out) {
     uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
     (void) o;
-    SurfInt si = compute_si(S, Vec3(d[i], d[n + i], d[2 * (size_t) n + i]), t[i], u[i], v[i], prim[i], shape[i], inst[i]);
-    const Vec3 vs[6] = { si.p, si.n, si.sn, si.ss, si.st, si.wi };
+    const Vec3 D(d[i], d[n + i], d[2 * (size_t) n + i]);
+    const bool shading = (ray_flags & RAY_SHADING) != 0u, valid = !(active && !active[i]) && t[i] != HAR_INF;
+    Vec3 vs[6] = { Vec3(0.f), Vec3(0.f), Vec3(0.f), Vec3(0.f), Vec3(0.f), Vec3(0.f) };
+    float uvx = 0.f, uvy = 0.f;
+    SurfPartials P; P.dp_du = Vec3(0.f); P.dp_dv = Vec3(0.f); P.dn_du = Vec3(0.f); P.dn_dv = Vec3(0.f);
+    if (valid) {
+        const SurfInt si = compute_si(S, D, t[i], u[i], v[i], prim[i], shape[i], inst[i]);
+        vs[0] = si.p; vs[1] = si.n;
+        if (shading) {
+            vs[2] = si.sn; vs[3] = si.ss; vs[4] = si.st; vs[5] = si.wi; uvx = si.uv_x; uvy = si.uv_y;
+            compute_si_partials(S, u[i], v[i], prim[i], shape[i], inst[i], (ray_flags & RAY_NORMAL_PARTIALS) != 0u, P);
+        }
+    } else if (shading) { coordinate_system(Vec3(0.f), vs[3], vs[4]); vs[5] = -D; }
     for (int k = 0; k < 6; ++k) { out[(3 * k) * (size_t) n + i] = vs[k].x; out[(3 * k + 1) * (size_t) n + i] = vs[k].y; out[(3 * k + 2) * (size_t) n + i] = vs[k].z; }
-    out[18 * (size_t) n + i] = si.uv_x; out[19 * (size_t) n + i] = si.uv_y; out[20 * (size_t) n + i] = si.t;
+    out[18 * (size_t) n + i] = uvx; out[19 * (size_t) n + i] = uvy; out[20 * (size_t) n + i] = valid ? t[i] : HAR_INF;
+    const Vec3 ps[4] = { P.dp_du, P.dp_dv, P.dn_du, P.dn_dv };
+    for (int k = 0; k < 4; ++k) { out[(21 + 3 * k) * (size_t) n + i] = ps[k].x; out[(22 + 3 * k) * (size_t) n + i] = ps[k].y; out[(23 + 3 * k) * (size_t) n + i] = ps[k].z; }
 }
 __global__ void k_api_sampler_seed(uint32_t seed, uint32_t lane_offset, uint32_t n, uint64_t *state, uint64_t *inc) {
     uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
@@ -1553,24 +1582,36 @@ __global__ void k_api_sampler_next(uint32_t n, uint64_t *state, const uint64_t *
     for (int k = 0; k < dims; ++k) out[k * (size_t) n + i] = pcg32_next_float(s, inc[i]);
     state[i] = s;
 }
-__global__ void k_api_bsdf_eval_pdf(DScene S, uint32_t bsdf, uint32_t n, const float *wi, const float *uv, const float *wo, float *value, float *pdf) {
+/* BSDF::eval_pdf / eval / pdf (bsdf.h:375-465) of scene BSDF `bsdf` under the caller's BSDFContext; `value` / `pdf` may be NULL (eval / pdf alone: for the
+ * models of har_bsdf.h the pair is computed in one pass and BSDF::eval, ::pdf return its halves).  A masked lane evaluates to zero. */
+__global__ void k_api_bsdf_eval_pdf(DScene S, uint32_t bsdf, BsdfCtx ctx, uint32_t n, const float *wi, const float *uv, const float *wo, const uint8_t *active, float *value, float *pdf) {
     uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
-    BsdfSide side; const bool ok = bsdf_side(S, bsdf, Vec3(wi[i], wi[n + i], wi[2 * (size_t) n + i]), side);
-    TexTaps taps; const BsdfInputs in = bsdf_inputs(S, S.bsdfs[side.index], uv[i], uv[n + i], taps);
-    BsdfEval e; bsdf_eval_pdf(S, side, in, ok, Vec3(wo[i], wo[n + i], wo[2 * (size_t) n + i]), e);
-    value[i] = e.value.x; value[n + i] = e.value.y; value[2 * (size_t) n + i] = e.value.z; pdf[i] = e.pdf;
+    BsdfEval e; e.value = Vec3(0.f); e.pdf = 0.f;
+    if (!(active && !active[i])) {
+        BsdfSide side; const bool ok = bsdf_side(S, bsdf, Vec3(wi[i], wi[n + i], wi[2 * (size_t) n + i]), side);
+        TexTaps taps; const BsdfInputs in = bsdf_inputs(S, S.bsdfs[side.index], uv[i], uv[n + i], taps);
+        bsdf_eval_pdf<HAR_BSDF_ALL_TYPES, true>(S, side, in, ok, Vec3(wo[i], wo[n + i], wo[2 * (size_t) n + i]), e, bsdf_side_ctx(S, bsdf, side, ctx));
+    }
+    if (value) { value[i] = e.value.x; value[n + i] = e.value.y; value[2 * (size_t) n + i] = e.value.z; }
+    if (pdf) pdf[i] = e.pdf;
 }
-__global__ void k_api_bsdf_sample(DScene S, uint32_t bsdf, uint32_t n, const float *wi, const float *uv, const float *s1, const float *s2, float *wo, float *pdf,
-                                  float *weight, float *eta_delta) {
+/* BSDF::sample (bsdf.h:322-373): BSDFSample3f {wo, pdf, eta, sampled_type, sampled_component} + the weight.  A masked lane returns dr::zeros. */
+__global__ void k_api_bsdf_sample(DScene S, uint32_t bsdf, BsdfCtx ctx, uint32_t n, const float *wi, const float *uv, const float *s1, const float *s2, const uint8_t *active,
+                                  float *wo, float *pdf, float *weight, float *eta, uint32_t *stype, uint32_t *scomp) {
     uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
-    BsdfSide side; const bool ok = bsdf_side(S, bsdf, Vec3(wi[i], wi[n + i], wi[2 * (size_t) n + i]), side);
-    TexTaps taps; const BsdfInputs in = bsdf_inputs(S, S.bsdfs[side.index], uv[i], uv[n + i], taps);
-    BsdfSample b; bsdf_sample(S, side, in, ok, s1 ? s1[i] : 0.f, s2[i], s2[n + i], b);
+    BsdfSample b; b.wo = Vec3(0.f); b.pdf = 0.f; b.weight = Vec3(0.f); b.eta = 0.f; b.delta = false; b.type = 0u; b.comp = 0u;
+    if (!(active && !active[i])) {
+        BsdfSide side; const bool ok = bsdf_side(S, bsdf, Vec3(wi[i], wi[n + i], wi[2 * (size_t) n + i]), side);
+        TexTaps taps; const BsdfInputs in = bsdf_inputs(S, S.bsdfs[side.index], uv[i], uv[n + i], taps);
+        bsdf_sample<HAR_BSDF_ALL_TYPES, true>(S, side, in, ok, s1 ? s1[i] : 0.f, s2[i], s2[n + i], b, bsdf_side_ctx(S, bsdf, side, ctx));
+    }
     wo[i] = b.wo.x; wo[n + i] = b.wo.y; wo[2 * (size_t) n + i] = b.wo.z; pdf[i] = b.pdf;
     weight[i] = b.weight.x; weight[n + i] = b.weight.y; weight[2 * (size_t) n + i] = b.weight.z;
-    if (eta_delta) { eta_delta[i] = b.eta; eta_delta[n + i] = b.delta ? 1.f : 0.f; }
+    if (eta) eta[i] = b.eta;
+    if (stype) stype[i] = b.type;
+    if (scomp) scomp[i] = b.comp;
 }
 __global__ void k_api_sensor_ray(DSensor C, uint32_t n, const float *px, const float *py, float *o, float *d, float *maxt) {
     uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
@@ -1607,11 +1648,12 @@ void launch_raygen(int mode, hipStream_t s, const DSensor &C, uint32_t seed, uin
     else hipLaunchKernelGGL(k_raygen<MODE_PATH>, g, b, 0, s, C, seed, spp, log_spp, lane_base, n, shard_cap, out, result, count, adj, dL, ps);
 }
 void launch_raygen_rays(hipStream_t s, uint32_t seed, uint32_t lane_base, uint32_t n, uint32_t n_total, uint32_t first, const float *o, const float *d, const float *maxt,
-                        const uint64_t *state, uint32_t shard_cap, const WaveState &out, float4 *result, uint32_t *count) {
-    hipLaunchKernelGGL(k_raygen_rays, dim3(blocks_for(n)), dim3(kBlock), 0, s, seed, lane_base, n, n_total, first, o, d, maxt, state, shard_cap, out, result, count);
+                        const uint64_t *state, const uint8_t *active, uint32_t shard_cap, const WaveState &out, float4 *result, uint32_t *count) {
+    hipLaunchKernelGGL(k_raygen_rays, dim3(blocks_for(n)), dim3(kBlock), 0, s, seed, lane_base, n, n_total, first, o, d, maxt, state, active, shard_cap, out, result, count);
 }
-void launch_sample_out(hipStream_t s, uint32_t n, uint32_t n_total, uint32_t first, const float4 *result, const float *valid_lane, int zero_invalid, float *rgb, uint8_t *valid) {
-    hipLaunchKernelGGL(k_sample_out, dim3(blocks_for(n)), dim3(kBlock), 0, s, n, n_total, first, result, valid_lane, zero_invalid, rgb, valid);
+void launch_sample_out(hipStream_t s, uint32_t n, uint32_t n_total, uint32_t first, const float4 *result, const float *valid_lane, int zero_invalid, float *rgb, uint8_t *valid,
+                       const uint8_t *active, uint32_t seed, uint32_t lane_base, const uint64_t *state_in, uint64_t *state_out) {
+    hipLaunchKernelGGL(k_sample_out, dim3(blocks_for(n)), dim3(kBlock), 0, s, n, n_total, first, result, valid_lane, zero_invalid, rgb, valid, active, seed, lane_base, state_in, state_out);
 }
 /* HAR_FLAT_KERNELS=0: scenes without a TLAS run the generic traversal kernels (A/B switch) */
 static bool flat_kernels() { static const bool on = !(getenv("HAR_FLAT_KERNELS") && atoi(getenv("HAR_FLAT_KERNELS")) == 0); return on; }
@@ -1778,20 +1820,20 @@ void launch_add(hipStream_t s, const float *src, float *dst, uint32_t n) {
 void launch_accumulate_stats(hipStream_t s, const uint32_t *counters, uint32_t n_bounces, unsigned long long *totals, uint32_t paths) {
     hipLaunchKernelGGL(k_accumulate_stats, dim3(1), dim3(1), 0, s, counters, n_bounces, totals, paths);
 }
-void launch_api_intersect(hipStream_t s, const DScene &S, uint32_t n, const float *o, const float *d, const float *maxt, int naive,
+void launch_api_intersect(hipStream_t s, const DScene &S, uint32_t n, const float *o, const float *d, const float *maxt, const uint8_t *active, int naive,
                           float *t, float *u, float *v, uint32_t *prim, uint32_t *shape, uint32_t *inst, int *status) {
     dim3 g(blocks_for(n)), b(kBlock);
-    if (naive) hipLaunchKernelGGL(k_api_intersect<true>, g, b, 0, s, S, n, o, d, maxt, t, u, v, prim, shape, inst, status);
-    else hipLaunchKernelGGL(k_api_intersect<false>, g, b, 0, s, S, n, o, d, maxt, t, u, v, prim, shape, inst, status);
+    if (naive) hipLaunchKernelGGL(k_api_intersect<true>, g, b, 0, s, S, n, o, d, maxt, active, t, u, v, prim, shape, inst, status);
+    else hipLaunchKernelGGL(k_api_intersect<false>, g, b, 0, s, S, n, o, d, maxt, active, t, u, v, prim, shape, inst, status);
 }
-void launch_api_ray_test(hipStream_t s, const DScene &S, uint32_t n, const float *o, const float *d, const float *maxt, int naive, uint8_t *out, int *status) {
+void launch_api_ray_test(hipStream_t s, const DScene &S, uint32_t n, const float *o, const float *d, const float *maxt, const uint8_t *active, int naive, uint8_t *out, int *status) {
     dim3 g(blocks_for(n)), b(kBlock);
-    if (naive) hipLaunchKernelGGL(k_api_ray_test<true>, g, b, 0, s, S, n, o, d, maxt, out, status);
-    else hipLaunchKernelGGL(k_api_ray_test<false>, g, b, 0, s, S, n, o, d, maxt, out, status);
+    if (naive) hipLaunchKernelGGL(k_api_ray_test<true>, g, b, 0, s, S, n, o, d, maxt, active, out, status);
+    else hipLaunchKernelGGL(k_api_ray_test<false>, g, b, 0, s, S, n, o, d, maxt, active, out, status);
 }
 void launch_api_si(hipStream_t s, const DScene &S, uint32_t n, const float *o, const float *d, const float *t, const float *u, const float *v,
-                   const uint32_t *prim, const uint32_t *shape, const uint32_t *inst, float *out) {
-    hipLaunchKernelGGL(k_api_si, dim3(blocks_for(n)), dim3(kBlock), 0, s, S, n, o, d, t, u, v, prim, shape, inst, out);
+                   const uint32_t *prim, const uint32_t *shape, const uint32_t *inst, uint32_t ray_flags, const uint8_t *active, float *out) {
+    hipLaunchKernelGGL(k_api_si, dim3(blocks_for(n)), dim3(kBlock), 0, s, S, n, o, d, t, u, v, prim, shape, inst, ray_flags, active, out);
 }
 void launch_api_sampler_seed(hipStream_t s, uint32_t seed, uint32_t lane_offset, uint32_t n, uint64_t *state, uint64_t *inc) {
     hipLaunchKernelGGL(k_api_sampler_seed, dim3(blocks_for(n)), dim3(kBlock), 0, s, seed, lane_offset, n, state, inc);
@@ -1799,12 +1841,13 @@ void launch_api_sampler_seed(hipStream_t s, uint32_t seed, uint32_t lane_offset,
 void launch_api_sampler_next(hipStream_t s, uint32_t n, uint64_t *state, const uint64_t *inc, const uint8_t *active, float *out, int dims) {
     hipLaunchKernelGGL(k_api_sampler_next, dim3(blocks_for(n)), dim3(kBlock), 0, s, n, state, inc, active, out, dims);
 }
-void launch_api_bsdf_eval_pdf(hipStream_t s, const DScene &S, uint32_t bsdf, uint32_t n, const float *wi, const float *uv, const float *wo, float *value, float *pdf) {
-    hipLaunchKernelGGL(k_api_bsdf_eval_pdf, dim3(blocks_for(n)), dim3(kBlock), 0, s, S, bsdf, n, wi, uv, wo, value, pdf);
+void launch_api_bsdf_eval_pdf(hipStream_t s, const DScene &S, uint32_t bsdf, const BsdfCtx &ctx, uint32_t n, const float *wi, const float *uv, const float *wo, const uint8_t *active,
+                              float *value, float *pdf) {
+    hipLaunchKernelGGL(k_api_bsdf_eval_pdf, dim3(blocks_for(n)), dim3(kBlock), 0, s, S, bsdf, ctx, n, wi, uv, wo, active, value, pdf);
 }
-void launch_api_bsdf_sample(hipStream_t s, const DScene &S, uint32_t bsdf, uint32_t n, const float *wi, const float *uv, const float *s1, const float *s2, float *wo,
-                            float *pdf, float *weight, float *eta_delta) {
-    hipLaunchKernelGGL(k_api_bsdf_sample, dim3(blocks_for(n)), dim3(kBlock), 0, s, S, bsdf, n, wi, uv, s1, s2, wo, pdf, weight, eta_delta);
+void launch_api_bsdf_sample(hipStream_t s, const DScene &S, uint32_t bsdf, const BsdfCtx &ctx, uint32_t n, const float *wi, const float *uv, const float *s1, const float *s2,
+                            const uint8_t *active, float *wo, float *pdf, float *weight, float *eta, uint32_t *stype, uint32_t *scomp) {
+    hipLaunchKernelGGL(k_api_bsdf_sample, dim3(blocks_for(n)), dim3(kBlock), 0, s, S, bsdf, ctx, n, wi, uv, s1, s2, active, wo, pdf, weight, eta, stype, scomp);
 }
 void launch_api_sensor_ray(hipStream_t s, const DSensor &C, uint32_t n, const float *px, const float *py, float *o, float *d, float *maxt) {
     hipLaunchKernelGGL(k_api_sensor_ray, dim3(blocks_for(n)), dim3(kBlock), 0, s, C, n, px, py, o, d, maxt);

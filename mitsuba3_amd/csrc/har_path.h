@@ -196,7 +196,7 @@ HAR_HD void shade_lane(const DScene &S, const ShadeParams &P, const PathState &s
     float s1 = pcg32_next_float(rng, inc);
     float s2x = pcg32_next_float(rng, inc), s2y = pcg32_next_float(rng, inc);
     BsdfEval ev; bsdf_eval_pdf<TYPES>(S, side, bin, side_ok, wo_em, ev);
-    BsdfSample bs; bs.wo = Vec3(0.f); bs.pdf = 0.f; bs.weight = Vec3(0.f); bs.eta = 0.f; bs.delta = false;
+    BsdfSample bs; bs.wo = Vec3(0.f); bs.pdf = 0.f; bs.weight = Vec3(0.f); bs.eta = 0.f; bs.delta = false; bs.type = 0u; bs.comp = 0u;
     if (MODE == MODE_PATH || active_next) bsdf_sample<TYPES>(S, side, bin, side_ok, s1, s2x, s2y, bs);
 
     /* ---- NEE contribution (path.cpp:271-281, prb.py:210-216); visibility is resolved by the shadow kernel */

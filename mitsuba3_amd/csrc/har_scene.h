@@ -123,6 +123,59 @@ HAR_HD SurfInt compute_si(const DScene &S, Vec3 ray_d, float t, float bu, float 
     return si;
 }
 
+/* RayFlags (include/mitsuba/render/interaction.h:19-87).  The wavefront kernels compute what RayFlags::Default asks for (compute_si above); the array-valued
+ * Scene::ray_intersect / PreliminaryIntersection::compute_surface_interaction entry points honour the caller's flags through compute_si_flags.  FollowShape /
+ * DetachShape only choose which AD dependence the reference tracks through the hit; the primal values are the same (the C ABI carries no AD graph). */
+enum { RAY_MINIMAL = 0u, RAY_SHADING = 1u, RAY_NORMAL_PARTIALS = 2u, RAY_FOLLOW_SHAPE = 4u, RAY_DETACH_SHAPE = 8u, RAY_KNOWN_FLAGS = 15u };
+struct SurfPartials { Vec3 dp_du, dp_dv, dn_du, dn_dv; };
+/* Position / normal partials of Mesh::compute_surface_interaction (src/render/mesh.cpp:2334-2395: dn / d barycentric of the normalised interpolated normal,
+ * change of variables to the texture parameterisation) and their transport through an instance (src/shapes/instance.cpp:206-212,250-253) */
+HAR_HD void compute_si_partials(const DScene &S, float bu, float bv, uint32_t prim, uint32_t shape, uint32_t inst, bool normal_partials, SurfPartials &P) {
+    const DMesh M = S.meshes[shape];
+    const uint32_t *f = S.faces + 4 * (size_t) (M.foff + prim);
+    const float *v0 = S.verts + 8 * (size_t) (M.voff + f[0]), *v1 = S.verts + 8 * (size_t) (M.voff + f[1]), *v2 = S.verts + 8 * (size_t) (M.voff + f[2]);
+    const Vec3 p0(v0[0], v0[1], v0[2]), e1 = Vec3(v1[0], v1[1], v1[2]) - p0, e2 = Vec3(v2[0], v2[1], v2[2]) - p0;
+    const float b1 = bu, b2 = bv;
+    const bool need_dn = (M.flags & 1u) && normal_partials;
+    Vec3 dn_db1(0.f), dn_db2(0.f), sn(0.f);
+    if (M.flags & 1u) {
+        Vec3 n0(v0[3], v0[4], v0[5]), dn1 = Vec3(v1[3], v1[4], v1[5]) - n0, dn2 = Vec3(v2[3], v2[4], v2[5]) - n0;
+        Vec3 n = fma3(dn1, b1, fma3(dn2, b2, n0));
+        const float il = rsqrt_(dot3(n, n));
+        n = n * il; sn = n;
+        if (need_dn) {
+            dn1 = dn1 * il; dn2 = dn2 * il;
+            dn_db1 = fma3(n, -dot3(n, dn1), dn1); dn_db2 = fma3(n, -dot3(n, dn2), dn2);        /* dr::fnmadd(n, dot(n, dn), dn) */
+        }
+    }
+    P.dn_du = Vec3(0.f); P.dn_dv = Vec3(0.f);
+    if (M.flags & 2u) {
+        const float u0 = v0[6], w0 = v0[7], du0x = v1[6] - u0, du0y = v1[7] - w0, du1x = v2[6] - u0, du1y = v2[7] - w0;
+        const float det = fms_(du0x, du1y, du0y * du1x), inv_det = det != 0.f ? rcp_(det) : 0.f;
+        /* to_uv_basis(d1, d2) = ( fmsub(duv1.y, d1, duv0.y * d2), fnmadd(duv1.x, d1, duv0.x * d2) ) * inv_det */
+        P.dp_du = Vec3(fms_(du1y, e1.x, du0y * e2.x), fms_(du1y, e1.y, du0y * e2.y), fms_(du1y, e1.z, du0y * e2.z)) * inv_det;
+        P.dp_dv = Vec3(fnma_(du1x, e1.x, du0x * e2.x), fnma_(du1x, e1.y, du0x * e2.y), fnma_(du1x, e1.z, du0x * e2.z)) * inv_det;
+        if (need_dn) {
+            P.dn_du = Vec3(fms_(du1y, dn_db1.x, du0y * dn_db2.x), fms_(du1y, dn_db1.y, du0y * dn_db2.y), fms_(du1y, dn_db1.z, du0y * dn_db2.z)) * inv_det;
+            P.dn_dv = Vec3(fnma_(du1x, dn_db1.x, du0x * dn_db2.x), fnma_(du1x, dn_db1.y, du0x * dn_db2.y), fnma_(du1x, dn_db1.z, du0x * dn_db2.z)) * inv_det;
+        }
+    } else {
+        P.dp_du = e1; P.dp_dv = e2;
+        if (need_dn) { P.dn_du = dn_db1; P.dn_dv = dn_db2; }
+    }
+    if (inst != 0xffffffffu) {
+        const DInst &I = S.insts[inst];
+        if (need_dn) {                  /* instance.cpp:206-212 (meshes without vertex normals: the partials are zero and stay zero) */
+            Vec3 n = xf_normal(I.to_object, sn);
+            const float inv_len = rcp_(norm3(n));
+            n = n * inv_len;
+            const Vec3 du = xf_normal(I.to_object, P.dn_du) * inv_len, dv = xf_normal(I.to_object, P.dn_dv) * inv_len;
+            P.dn_du = fma3(n, -dot3(n, du), du); P.dn_dv = fma3(n, -dot3(n, dv), dv);
+        }
+        P.dp_du = xf_vector(I.to_world, P.dp_du); P.dp_dv = xf_vector(I.to_world, P.dp_dv);
+    }
+}
+
 /* Interaction::offset_p / spawn_ray / spawn_ray_to (interaction.h:161-191) */
 HAR_HD Vec3 offset_p(const SurfInt &si, Vec3 d) {
     float mag = (1.f + hmax3(abs3(si.p))) * HAR_RAY_EPS;
@@ -192,20 +245,27 @@ HAR_HD bool bsdf_side(const DScene &S, uint32_t index, Vec3 wi, BsdfSide &side) 
     if (wi.z < 0.f) { side.index = (uint32_t) B.back; side.wi.z = -wi.z; side.wo_sign = -1.f; return true; }
     return false;
 }
-template <uint32_t TYPES = HAR_BSDF_ALL_TYPES>
-HAR_HD void bsdf_eval_pdf(const DScene &S, const BsdfSide &side, const BsdfInputs &in, bool side_ok, Vec3 wo, BsdfEval &e) {
+/* The context a nested BSDF of a `twosided` record sees (twosided.cpp:129-146, 164-180): the front side and a one-BSDF `twosided` get the caller's context as it
+ * is; the back side of a two-BSDF pair gets `component - component_count(front)` (uint32 arithmetic, as in the reference) unless the component is "all" */
+HAR_HD BsdfCtx bsdf_side_ctx(const DScene &S, uint32_t index, const BsdfSide &side, BsdfCtx ctx) {
+    const DBsdf &B = S.bsdfs[index];
+    if ((B.flags & BF_TWOSIDED) && B.back >= 0 && side.wo_sign < 0.f && ctx.component != 0xffffffffu) ctx.component -= bsdf_component_count(B.type);
+    return ctx;
+}
+template <uint32_t TYPES = HAR_BSDF_ALL_TYPES, bool CTX = false>
+HAR_HD void bsdf_eval_pdf(const DScene &S, const BsdfSide &side, const BsdfInputs &in, bool side_ok, Vec3 wo, BsdfEval &e, const BsdfCtx &ctx = BsdfCtx()) {
     if (!side_ok) { e.value = Vec3(0.f); e.pdf = 0.f; e.d_slot0 = Vec3(0.f); e.d_slot1 = Vec3(0.f); return; }
-    bsdf_eval_pdf_one<TYPES>(S.bsdfs[side.index], in, side.wi, Vec3(wo.x, wo.y, wo.z * side.wo_sign), e);
+    bsdf_eval_pdf_one<TYPES, CTX>(S.bsdfs[side.index], in, side.wi, Vec3(wo.x, wo.y, wo.z * side.wo_sign), e, ctx);
 }
 /* d value / d {alpha, eta, k} of the record serving this side (see bsdf_eval_extra_one) */
 HAR_HD void bsdf_eval_extra(const DScene &S, const BsdfSide &side, const BsdfInputs &in, bool side_ok, Vec3 wo, BsdfEvalExtra &x) {
     if (!side_ok) { x.d_alpha_u = Vec3(0.f); x.d_alpha_v = Vec3(0.f); x.d_eta = Vec3(0.f); x.d_k = Vec3(0.f); return; }
     bsdf_eval_extra_one(S.bsdfs[side.index], in, side.wi, Vec3(wo.x, wo.y, wo.z * side.wo_sign), x);
 }
-template <uint32_t TYPES = HAR_BSDF_ALL_TYPES>
-HAR_HD void bsdf_sample(const DScene &S, const BsdfSide &side, const BsdfInputs &in, bool side_ok, float s1, float s2x, float s2y, BsdfSample &bs) {
-    if (!side_ok) { bs.wo = Vec3(0.f); bs.pdf = 0.f; bs.weight = Vec3(0.f); bs.eta = 0.f; bs.delta = false; return; }
-    bsdf_sample_one<TYPES>(S.bsdfs[side.index], in, side.wi, s1, s2x, s2y, bs);
+template <uint32_t TYPES = HAR_BSDF_ALL_TYPES, bool CTX = false>
+HAR_HD void bsdf_sample(const DScene &S, const BsdfSide &side, const BsdfInputs &in, bool side_ok, float s1, float s2x, float s2y, BsdfSample &bs, const BsdfCtx &ctx = BsdfCtx()) {
+    if (!side_ok) { bs.wo = Vec3(0.f); bs.pdf = 0.f; bs.weight = Vec3(0.f); bs.eta = 0.f; bs.delta = false; bs.type = 0u; bs.comp = 0u; return; }
+    bsdf_sample_one<TYPES, CTX>(S.bsdfs[side.index], in, side.wi, s1, s2x, s2y, bs, ctx);
     bs.wo.z *= side.wo_sign;
 }
 

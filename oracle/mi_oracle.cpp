@@ -8,10 +8,12 @@
 #include "mi_oracle.h"
 #include "orc_math.h"
 #include "orc_bsdf.h"
+#include "orc_bsdf_ctx.h"
 #include "orc_envmap.h"
 #include "orc_dual.h"
 
 #include <algorithm>
+#include <memory>
 #include <atomic>
 #include <fstream>
 #include <sched.h>
@@ -1724,26 +1726,33 @@ void orc_scene_set_reflectance(void *s, uint32_t b, const float rgb[3]) {
 }
 void orc_scene_set_texture(void *s, uint32_t t, const float *data) { Texture &x = ((Scene *) s)->textures[t]; x.data.assign(data, data + 3 * (size_t) x.w * x.h); }
 
-void orc_ray_intersect(void *scene, uint32_t n, const float *o, const float *d, const float *maxt, int mode,
-                       float *t, float *u, float *v, uint32_t *prim, uint32_t *shape, uint32_t *inst) {
+/* `active` (nullable): the Mask argument of Scene::ray_intersect_preliminary / ray_test (scene.cpp:216-238) -- a masked lane is not traced and reports
+ * dr::zeros<PreliminaryIntersection3f>() (t = inf) / false */
+void orc_ray_intersect_masked(void *scene, uint32_t n, const float *o, const float *d, const float *maxt, const uint8_t *active, int mode,
+                              float *t, float *u, float *v, uint32_t *prim, uint32_t *shape, uint32_t *inst) {
     const Scene &sc = *(Scene *) scene;
     parallel_lanes(0, n, 0, [&](int, uint64_t b, uint64_t e) {
         for (uint64_t i = b; i < e; ++i) {
             Ray r; r.o = V3(o[i], o[n + i], o[2 * (size_t) n + i]); r.d = V3(d[i], d[n + i], d[2 * (size_t) n + i]); r.maxt = maxt[i];
-            PI pi; scene_trace<false>(sc, r, pi, mode);
+            PI pi; if (!active || active[i]) scene_trace<false>(sc, r, pi, mode);
             t[i] = pi.t; u[i] = pi.u; v[i] = pi.v; prim[i] = pi.prim; shape[i] = pi.shape; inst[i] = pi.inst;
         }
     });
 }
-void orc_ray_test(void *scene, uint32_t n, const float *o, const float *d, const float *maxt, int mode, uint8_t *hit) {
+void orc_ray_intersect(void *scene, uint32_t n, const float *o, const float *d, const float *maxt, int mode,
+                       float *t, float *u, float *v, uint32_t *prim, uint32_t *shape, uint32_t *inst) {
+    orc_ray_intersect_masked(scene, n, o, d, maxt, nullptr, mode, t, u, v, prim, shape, inst);
+}
+void orc_ray_test_masked(void *scene, uint32_t n, const float *o, const float *d, const float *maxt, const uint8_t *active, int mode, uint8_t *hit) {
     const Scene &sc = *(Scene *) scene;
     parallel_lanes(0, n, 0, [&](int, uint64_t b, uint64_t e) {
         for (uint64_t i = b; i < e; ++i) {
             Ray r; r.o = V3(o[i], o[n + i], o[2 * (size_t) n + i]); r.d = V3(d[i], d[n + i], d[2 * (size_t) n + i]); r.maxt = maxt[i];
-            PI pi; hit[i] = scene_trace<true>(sc, r, pi, mode) ? 1 : 0;
+            PI pi; hit[i] = (!active || active[i]) && scene_trace<true>(sc, r, pi, mode) ? 1 : 0;
         }
     });
 }
+void orc_ray_test(void *scene, uint32_t n, const float *o, const float *d, const float *maxt, int mode, uint8_t *hit) { orc_ray_test_masked(scene, n, o, d, maxt, nullptr, mode, hit); }
 
 int orc_render_path(void *scene, const OrcSensor *s, uint32_t seed, uint32_t spp, int32_t max_depth, int32_t rr_depth,
                     uint64_t lb, uint64_t le, float *film, OrcStats *stats, int threads) {
@@ -1762,8 +1771,16 @@ int orc_render_prb(void *scene, const OrcSensor *s, uint32_t seed, uint32_t spp,
  * prb.py:68-339) for n caller-supplied rays: ray i uses the sampler stream of wavefront lane lane_offset + i (Sampler::seed, sampler.cpp:129-148),
  * continued from state[i] when `state` is given.  rgb is 3 x n (SoA), valid[i] = the returned mask, state_out[i] (nullable) = the stream's
  * state after the call. */
+int orc_integrator_sample_masked(void *scene, int prb, uint32_t n, const float *o, const float *d, const float *maxt, uint32_t seed, uint32_t lane_offset,
+                                 const uint64_t *state, const uint8_t *active, int32_t max_depth, int32_t rr_depth, float *rgb, uint8_t *valid, uint64_t *state_out, int threads);
 int orc_integrator_sample(void *scene, int prb, uint32_t n, const float *o, const float *d, const float *maxt, uint32_t seed, uint32_t lane_offset,
                           const uint64_t *state, int32_t max_depth, int32_t rr_depth, float *rgb, uint8_t *valid, uint64_t *state_out, int threads) {
+    return orc_integrator_sample_masked(scene, prb, n, o, d, maxt, seed, lane_offset, state, nullptr, max_depth, rr_depth, rgb, valid, state_out, threads);
+}
+/* ... with the Mask argument of SamplingIntegrator::sample (integrator.h:432-437): the loop condition of a masked lane is false from the start (path.cpp:161-166
+ * `active` enters the loop state; prb.py:97), so it draws nothing, returns zero radiance and valid = false */
+int orc_integrator_sample_masked(void *scene, int prb, uint32_t n, const float *o, const float *d, const float *maxt, uint32_t seed, uint32_t lane_offset,
+                                 const uint64_t *state, const uint8_t *active, int32_t max_depth, int32_t rr_depth, float *rgb, uint8_t *valid, uint64_t *state_out, int threads) {
     Scene &sc = *(Scene *) scene;
     threads = resolve_threads(threads);
     std::vector<ThreadStats> sts(threads);
@@ -1773,9 +1790,10 @@ int orc_integrator_sample(void *scene, int prb, uint32_t n, const float *o, cons
             Pcg32 rng = sampler_seed(seed, lane_offset + (uint32_t) i);
             if (state) rng.state = state[i];
             Ray ray; ray.o = V3(o[i], o[n + i], o[2 * (size_t) n + i]); ray.d = V3(d[i], d[n + i], d[2 * (size_t) n + i]); ray.maxt = maxt[i];
-            bool v = false; V3 L;
-            if (prb) L = prb_sample(sc, rng, ray, md, rd, true, V3(0.f), V3(0.f), nullptr, v, sts[t]);
-            else     L = path_sample(sc, rng, ray, md, rd, v, sts[t]);
+            bool v = false; V3 L(0.f);
+            if (active && !active[i]) { }
+            else if (prb) L = prb_sample(sc, rng, ray, md, rd, true, V3(0.f), V3(0.f), nullptr, v, sts[t]);
+            else          L = path_sample(sc, rng, ray, md, rd, v, sts[t]);
             rgb[i] = L.x; rgb[n + i] = L.y; rgb[2 * (size_t) n + i] = L.z;
             if (valid) valid[i] = v ? 1 : 0;
             if (state_out) state_out[i] = rng.state;
@@ -2094,6 +2112,90 @@ float orc_math_fn(int fn, float x, float y) {
     }
     return std::numeric_limits<float>::quiet_NaN();
 }
+/* PreliminaryIntersection::compute_surface_interaction(ray, ray_flags, active) (interaction.h:804-829) WITH its flags and mask, written out once more from
+ * Mesh::compute_surface_interaction (src/render/mesh.cpp:2255-2437), Instance::compute_surface_interaction (src/shapes/instance.cpp:150-266) and
+ * finalize_surface_interaction (interaction.h:559-605) -- independently of compute_si() above, which only knows RayFlags::Default.
+ * out[33] = p, n, sh_frame.n, sh_frame.s, sh_frame.t, wi, uv, t, dp_du, dp_dv, dn_du, dn_dv.  ray_flags: Shading 1, NormalPartials 2 (FollowShape 4 / DetachShape 8
+ * change nothing in a primal evaluation). */
+void orc_surface_interaction_flags(void *scene, const float o[3], const float d[3], float t, float u, float v, uint32_t prim, uint32_t shape, uint32_t inst,
+                                   uint32_t ray_flags, int active_, float out[33]) {
+    const Scene &sc = *(Scene *) scene;
+    (void) o;
+    const bool shading = (ray_flags & 1u) != 0;
+    bool active = active_ != 0 && t != Infinity;                                  // interaction.h:811 active &= is_valid()
+    V3 si_p(0.f), si_n(0.f), sh_n(0.f), sh_s(0.f), sh_t(0.f), wi(0.f), dp_du(0.f), dp_dv(0.f), dn_du(0.f), dn_dv(0.f);
+    float uv0 = 0.f, uv1 = 0.f, si_t = Infinity;
+    const V3 ray_d(d[0], d[1], d[2]);
+    if (active) {                                                                 // the masked vcall returns dr::zeros<SurfaceInteraction3f>()
+        const Mesh &m = sc.meshes[shape];
+        const uint32_t *f = &m.F[4 * (size_t) prim];
+        const float *rec0 = &m.V[8 * (size_t) f[0]], *rec1 = &m.V[8 * (size_t) f[1]], *rec2 = &m.V[8 * (size_t) f[2]];
+        const V3 p0(rec0[0], rec0[1], rec0[2]), p1(rec1[0], rec1[1], rec1[2]), p2(rec2[0], rec2[1], rec2[2]);
+        float b1 = u, b2 = v, b0 = 1.f - b1 - b2;
+        V3 e1 = p1 - p0, e2 = p2 - p0;
+        si_p = fmadd(p0, b0, fmadd(p1, b1, p2 * b2));
+        si_n = normalize(cross(e1, e2));
+        si_t = t;
+        const bool has_normals = (m.flags & 1u) != 0, has_texcoords = (m.flags & 2u) != 0;
+        if (shading) {
+            bool need_dn = has_normals && (ray_flags & 2u) != 0;
+            V3 dn_db1(0.f), dn_db2(0.f);
+            if (has_normals) {
+                V3 n0(rec0[3], rec0[4], rec0[5]), dn1 = V3(rec1[3], rec1[4], rec1[5]) - n0, dn2 = V3(rec2[3], rec2[4], rec2[5]) - n0;
+                V3 n = fmadd(dn1, b1, fmadd(dn2, b2, n0));
+                float il = rsqrt(squared_norm(n));
+                n = n * il;
+                sh_n = n;
+                if (need_dn) {
+                    dn1 = dn1 * il; dn2 = dn2 * il;
+                    dn_db1 = fmadd(n, -dot(n, dn1), dn1);                         // dr::fnmadd(n, dot(n, dn1), dn1)
+                    dn_db2 = fmadd(n, -dot(n, dn2), dn2);
+                }
+            } else sh_n = si_n;
+            if (has_texcoords) {
+                float uvx0 = rec0[6], uvy0 = rec0[7];
+                float duv0x = rec1[6] - uvx0, duv0y = rec1[7] - uvy0, duv1x = rec2[6] - uvx0, duv1y = rec2[7] - uvy0;
+                uv0 = fmadd(duv0x, b1, fmadd(duv1x, b2, uvx0)); uv1 = fmadd(duv0y, b1, fmadd(duv1y, b2, uvy0));
+                float det = fmsub(duv0x, duv1y, duv0y * duv1x), inv_det = det != 0.f ? rcp(det) : 0.f;
+                auto to_uv_basis = [&](V3 d1, V3 d2, V3 &a, V3 &b) {
+                    a = V3(fmsub(duv1y, d1.x, duv0y * d2.x), fmsub(duv1y, d1.y, duv0y * d2.y), fmsub(duv1y, d1.z, duv0y * d2.z)) * inv_det;
+                    b = V3(fnmadd(duv1x, d1.x, duv0x * d2.x), fnmadd(duv1x, d1.y, duv0x * d2.y), fnmadd(duv1x, d1.z, duv0x * d2.z)) * inv_det;
+                };
+                to_uv_basis(e1, e2, dp_du, dp_dv);
+                if (need_dn) to_uv_basis(dn_db1, dn_db2, dn_du, dn_dv);
+            } else {
+                uv0 = b1; uv1 = b2; dp_du = e1; dp_dv = e2;
+                if (need_dn) { dn_du = dn_db1; dn_dv = dn_db2; }
+            }
+        }
+        if (inst != 0xffffffffu) {                                                // instance.cpp:190-253
+            const OrcInstance &in = sc.instances[inst];
+            si_p = xf_point(in.to_world, si_p);
+            si_n = normalize(xf_normal(in.to_object, si_n));
+            if (shading) {
+                V3 n = xf_normal(in.to_object, sh_n);
+                float inv_len = rcp(norm(n));
+                n = n * inv_len;
+                sh_n = n;
+                if (ray_flags & 2u) {
+                    V3 a = xf_normal(in.to_object, dn_du) * inv_len, b = xf_normal(in.to_object, dn_dv) * inv_len;
+                    dn_du = fmadd(n, -dot(n, a), a); dn_dv = fmadd(n, -dot(n, b), b);
+                }
+                dp_du = xf_vector(in.to_world, dp_du); dp_dv = xf_vector(in.to_world, dp_dv);
+            }
+        }
+    }
+    if (shading) {                                                                // finalize_surface_interaction: no packed tangents, sh_frame.s == 0 -> coordinate_system(n)
+        coordinate_system(sh_n, sh_s, sh_t);
+        V3 md = -ray_d;
+        wi = active ? V3(dot(md, sh_s), dot(md, sh_t), dot(md, sh_n)) : md;
+    }
+    const V3 vs[6] = { si_p, si_n, sh_n, sh_s, sh_t, wi };
+    for (int i = 0; i < 6; ++i) { out[3 * i] = vs[i].x; out[3 * i + 1] = vs[i].y; out[3 * i + 2] = vs[i].z; }
+    out[18] = uv0; out[19] = uv1; out[20] = si_t;
+    const V3 ps[4] = { dp_du, dp_dv, dn_du, dn_dv };
+    for (int i = 0; i < 4; ++i) { out[21 + 3 * i] = ps[i].x; out[22 + 3 * i] = ps[i].y; out[23 + 3 * i] = ps[i].z; }
+}
 void orc_surface_interaction(void *scene, const float o[3], const float d[3], float t, float u, float v, uint32_t prim,
                              uint32_t shape, uint32_t inst, float out[24]) {
     const Scene &sc = *(Scene *) scene;
@@ -2132,6 +2234,44 @@ void orc_bsdf_sample(void *scene, uint32_t bsdf, const float wi[3], const float 
     BsdfCtx c = bsdf_prepare(sc, bsdf, si);
     V3 w; BSDFSample bs = bsdf_sample(c, sample1, sample2[0], sample2[1], w);
     wo[0] = bs.wo.x; wo[1] = bs.wo.y; wo[2] = bs.wo.z; *pdf = bs.pdf; weight[0] = w.x; weight[1] = w.y; weight[2] = w.z; *eta = bs.eta; *delta = bs.delta ? 1 : 0;
+}
+/* BSDF::eval / pdf / eval_pdf / sample WITH the BSDFContext and Mask arguments (orc_bsdf_ctx.h): scene BSDF `bsdf`, twosided handled as twosided.cpp does */
+static void ctx_setup(const Scene &sc, uint32_t bsdf, const float wi[3], const float uv[2], ctxapi::TwoSided &ts, ctxapi::Si &front, ctxapi::Si &back,
+                      std::unique_ptr<ctxapi::Plugin> &p0, std::unique_ptr<ctxapi::Plugin> &p1, bool &twosided) {
+    const BsdfRecord &r0 = sc.bsdfs[bsdf];
+    twosided = (r0.p.flags & 1u) != 0;
+    const BsdfRecord &r1 = (twosided && r0.p.back >= 0) ? sc.bsdfs[(uint32_t) r0.p.back] : r0;
+    p0.reset(ctxapi::make_plugin(r0));
+    if (&r1 != &r0) p1.reset(ctxapi::make_plugin(r1));
+    ts.brdf[0] = p0.get(); ts.brdf[1] = p1 ? p1.get() : p0.get();
+    SI si; si.wi = V3(wi[0], wi[1], wi[2]); si.uv[0] = uv[0]; si.uv[1] = uv[1];
+    auto fill = [&](const BsdfRecord &r, ctxapi::Si &o) { o.wi = si.wi; o.slot0 = bsdf_reflectance(sc, r.p, si); o.slot1 = V3(r.p.reflectance2[0], r.p.reflectance2[1], r.p.reflectance2[2]); };
+    fill(r0, front); fill(r1, back);
+}
+void orc_bsdf_evaluate_ctx(void *scene, uint32_t bsdf, uint32_t mode, uint32_t type_mask, uint32_t component, int which, int active, const float wi[3], const float uv[2],
+                           const float wo[3], float value[3], float *pdf) {
+    const Scene &sc = *(Scene *) scene;
+    ctxapi::TwoSided ts; ctxapi::Si front, back; std::unique_ptr<ctxapi::Plugin> p0, p1; bool twosided;
+    ctx_setup(sc, bsdf, wi, uv, ts, front, back, p0, p1, twosided);
+    ctxapi::Context ctx; ctx.mode = mode; ctx.type_mask = type_mask; ctx.component = component;
+    V3 v(0.f), w(wo[0], wo[1], wo[2]); float p = 0.f;
+    if (twosided) ts.evaluate(which, ctx, front, back, w, active != 0, v, p);
+    else if (which == 0) v = p0->eval(ctx, front, w, active != 0);
+    else if (which == 1) p = p0->pdf(ctx, front, w, active != 0);
+    else p0->eval_pdf(ctx, front, w, active != 0, v, p);
+    value[0] = v.x; value[1] = v.y; value[2] = v.z; *pdf = p;
+}
+void orc_bsdf_sample_ctx(void *scene, uint32_t bsdf, uint32_t mode, uint32_t type_mask, uint32_t component, int active, const float wi[3], const float uv[2], float sample1,
+                         const float sample2[2], float wo[3], float *pdf, float weight[3], float *eta, uint32_t *sampled_type, uint32_t *sampled_component) {
+    const Scene &sc = *(Scene *) scene;
+    ctxapi::TwoSided ts; ctxapi::Si front, back; std::unique_ptr<ctxapi::Plugin> p0, p1; bool twosided;
+    ctx_setup(sc, bsdf, wi, uv, ts, front, back, p0, p1, twosided);
+    ctxapi::Context ctx; ctx.mode = mode; ctx.type_mask = type_mask; ctx.component = component;
+    V3 w(0.f);
+    ctxapi::Sample bs = twosided ? ts.sample(ctx, front, back, sample1, sample2[0], sample2[1], active != 0, w)
+                                 : p0->sample(ctx, front, sample1, sample2[0], sample2[1], active != 0, w);
+    wo[0] = bs.wo.x; wo[1] = bs.wo.y; wo[2] = bs.wo.z; *pdf = bs.pdf; weight[0] = w.x; weight[1] = w.y; weight[2] = w.z; *eta = bs.eta;
+    *sampled_type = bs.sampled_type; *sampled_component = bs.sampled_component;
 }
 /* quad::gauss_legendre (include/mitsuba/core/quad.h:27-90): n nodes and n weights on [-1, 1] (known answers: src/core/tests/test_quad.py:16-22) */
 void orc_gauss_legendre(int n, float *nodes, float *weights) {

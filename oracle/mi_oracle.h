@@ -162,6 +162,12 @@ float orc_fresnel_conductor(float cos_theta_i, float eta, float k);
 void  orc_bsdf_eval_pdf(void *scene, uint32_t bsdf, const float wi[3], const float uv[2], const float wo[3], float value[3], float *pdf);
 void  orc_bsdf_sample(void *scene, uint32_t bsdf, const float wi[3], const float uv[2], float sample1, const float sample2[2],
                       float wo[3], float *pdf, float weight[3], float *eta, int *delta);
+/* ... with the BSDFContext (mode 0 Radiance / 1 Importance, type_mask, component; include/mitsuba/render/bsdf.h:140-186) and the Mask argument (`active`) of
+ * BSDF::eval (which = 0) / pdf (1) / eval_pdf (2) and BSDF::sample, restated per plugin in orc_bsdf_ctx.h.  sampled_type is the BSDFFlags lobe bit. */
+void  orc_bsdf_evaluate_ctx(void *scene, uint32_t bsdf, uint32_t mode, uint32_t type_mask, uint32_t component, int which, int active, const float wi[3], const float uv[2],
+                            const float wo[3], float value[3], float *pdf);
+void  orc_bsdf_sample_ctx(void *scene, uint32_t bsdf, uint32_t mode, uint32_t type_mask, uint32_t component, int active, const float wi[3], const float uv[2], float sample1,
+                          const float sample2[2], float wo[3], float *pdf, float weight[3], float *eta, uint32_t *sampled_type, uint32_t *sampled_component);
 /* roughplastic precomputation of scene BSDF `bsdf`: out[0..63] external transmittance, out[64] internal reflectance, out[65] specular sampling weight */
 void  orc_gauss_legendre(int n, float *nodes, float *weights);      /* quad.h:27-90 */
 void  orc_roughplastic_tables(void *scene, uint32_t bsdf, float out[66]);
@@ -173,6 +179,11 @@ void orc_ray_intersect(void *scene, uint32_t n, const float *o, const float *d,
                        uint32_t *prim, uint32_t *shape, uint32_t *inst);
 void orc_ray_test(void *scene, uint32_t n, const float *o, const float *d,
                   const float *maxt, int mode, uint8_t *hit);
+
+/* ... with the Mask argument (`active`, n bytes, nullable): masked lanes report t = inf / hit = 0 */
+void orc_ray_intersect_masked(void *scene, uint32_t n, const float *o, const float *d, const float *maxt, const uint8_t *active, int mode,
+                              float *t, float *u, float *v, uint32_t *prim, uint32_t *shape, uint32_t *inst);
+void orc_ray_test_masked(void *scene, uint32_t n, const float *o, const float *d, const float *maxt, const uint8_t *active, int mode, uint8_t *hit);
 
 /* ---- integrators ----
  * lanes [lane_begin, lane_end) of the reference's wavefront ordering are
@@ -201,6 +212,8 @@ int orc_render_prb_backward_ex(void *scene, const OrcSensor *s, const float *gra
  * ray i draws from the stream of wavefront lane lane_offset + i, continued from state[i] if given; rgb 3 x n, valid n, state_out n (nullable) */
 int orc_integrator_sample(void *scene, int prb, uint32_t n, const float *o, const float *d, const float *maxt, uint32_t seed, uint32_t lane_offset,
                           const uint64_t *state, int32_t max_depth, int32_t rr_depth, float *rgb, uint8_t *valid, uint64_t *state_out, int threads);
+int orc_integrator_sample_masked(void *scene, int prb, uint32_t n, const float *o, const float *d, const float *maxt, uint32_t seed, uint32_t lane_offset,
+                                 const uint64_t *state, const uint8_t *active, int32_t max_depth, int32_t rr_depth, float *rgb, uint8_t *valid, uint64_t *state_out, int threads);
 /* render_backward plus the gradients of the rough models' `alpha` / `alpha_u` / `alpha_v`, `eta`, `k` (roughconductor.cpp:226-520) and `alpha`,
  * `specular_reflectance` (roughplastic.cpp:244-420): grad_bsdf_params = bsdf_count x 15 floats {alpha_u[3], alpha_v[3], eta[3], k[3], slot1[3]} (per-channel
  * contributions; sum the three for a scalar alpha), added to.  The derivatives of the BSDF value are central differences of a double-precision
@@ -279,6 +292,10 @@ float orc_math_fn(int fn, float x, float y); /* 0 exp, 1 log, 2 erf, 3 atan2(x, 
 void  orc_surface_interaction(void *scene, const float o[3], const float d[3],
                               float t, float u, float v, uint32_t prim, uint32_t shape,
                               uint32_t inst, float out[24]);
+
+/* ... with RayFlags (Shading 1, NormalPartials 2, FollowShape 4, DetachShape 8) and the mask: out[33] = p, n, sh_frame.n, .s, .t, wi, uv, t, dp_du, dp_dv, dn_du, dn_dv */
+void  orc_surface_interaction_flags(void *scene, const float o[3], const float d[3], float t, float u, float v, uint32_t prim, uint32_t shape, uint32_t inst,
+                                    uint32_t ray_flags, int active, float out[33]);
 
 /* ---- independent scene builders (restating util.py:569-703 etc.) ---- */
 /* A transform is 32 floats: row-major 4x4 `matrix` followed by the row-major

@@ -485,6 +485,65 @@ class OracleScene:
                            hit.ctypes.data_as(C.POINTER(C.c_uint8)))
         return hit.astype(bool)
 
+    def ray_intersect_masked(self, o, d, maxt, active, naive=False):
+        o = f32(o); d = f32(d); maxt = f32(maxt); n = maxt.shape[0]
+        a = np.ascontiguousarray(active, np.uint8)
+        t = np.empty(n, np.float32); u = np.empty(n, np.float32); v = np.empty(n, np.float32)
+        prim = np.empty(n, np.uint32); shape = np.empty(n, np.uint32); inst = np.empty(n, np.uint32)
+        L = lib(); L.orc_ray_intersect_masked.restype = None
+        L.orc_ray_intersect_masked.argtypes = [C.c_void_p, C.c_uint32, c_f32p, c_f32p, c_f32p, C.POINTER(C.c_uint8), C.c_int, c_f32p, c_f32p, c_f32p, c_u32p, c_u32p, c_u32p]
+        L.orc_ray_intersect_masked(self.handle, n, fp(o), fp(d), fp(maxt), a.ctypes.data_as(C.POINTER(C.c_uint8)), 1 if naive else 0, fp(t), fp(u), fp(v), up(prim), up(shape), up(inst))
+        return t, u, v, prim, shape, inst
+
+    def ray_test_masked(self, o, d, maxt, active, naive=False):
+        o = f32(o); d = f32(d); maxt = f32(maxt); n = maxt.shape[0]
+        a = np.ascontiguousarray(active, np.uint8); hit = np.empty(n, np.uint8)
+        L = lib(); L.orc_ray_test_masked.restype = None
+        L.orc_ray_test_masked.argtypes = [C.c_void_p, C.c_uint32, c_f32p, c_f32p, c_f32p, C.POINTER(C.c_uint8), C.c_int, C.POINTER(C.c_uint8)]
+        L.orc_ray_test_masked(self.handle, n, fp(o), fp(d), fp(maxt), a.ctypes.data_as(C.POINTER(C.c_uint8)), 1 if naive else 0, hit.ctypes.data_as(C.POINTER(C.c_uint8)))
+        return hit.astype(bool)
+
+    def surface_interaction_flags(self, o, d, t, u, v, prim, shape, inst, ray_flags=1, active=None):
+        """compute_surface_interaction(ray, ray_flags, active) per lane: (33, n) rows p, n, sh_frame.n/.s/.t, wi, uv, t, dp_du, dp_dv, dn_du, dn_dv"""
+        o = f32(o); d = f32(d); n = len(t)
+        out = np.empty((33, n), np.float32); row = np.empty(33, np.float32)
+        L = lib(); L.orc_surface_interaction_flags.restype = None
+        L.orc_surface_interaction_flags.argtypes = [C.c_void_p, c_f32p, c_f32p, C.c_float, C.c_float, C.c_float, C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32, C.c_int, c_f32p]
+        for i in range(n):
+            oo = f32(o[:, i]); dd = f32(d[:, i])
+            L.orc_surface_interaction_flags(self.handle, fp(oo), fp(dd), float(t[i]), float(u[i]), float(v[i]), int(prim[i]), int(shape[i]), int(inst[i]) & 0xffffffff,
+                                            int(ray_flags), 1 if (active is None or active[i]) else 0, fp(row))
+            out[:, i] = row
+        return out
+
+    def bsdf_evaluate_ctx(self, bsdf, ctx, which, wi, uv, wo, active=None):
+        """BSDF::eval (which 0) / pdf (1) / eval_pdf (2) with ctx = (mode, type_mask, component) and a mask: (value 3 x n, pdf n)"""
+        wi = f32(wi); uv = f32(uv); wo = f32(wo); n = wo.shape[1]
+        val = np.zeros((3, n), np.float32); pdf = np.zeros(n, np.float32); v3 = np.empty(3, np.float32); p1 = C.c_float()
+        L = lib(); L.orc_bsdf_evaluate_ctx.restype = None
+        L.orc_bsdf_evaluate_ctx.argtypes = [C.c_void_p, C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32, C.c_int, C.c_int, c_f32p, c_f32p, c_f32p, c_f32p, C.POINTER(C.c_float)]
+        for i in range(n):
+            a = f32(wi[:, i]); b = f32(uv[:, i]); c = f32(wo[:, i])
+            L.orc_bsdf_evaluate_ctx(self.handle, bsdf, ctx[0], ctx[1] & 0xffffffff, ctx[2] & 0xffffffff, which, 1 if (active is None or active[i]) else 0, fp(a), fp(b), fp(c), fp(v3), C.byref(p1))
+            val[:, i] = v3; pdf[i] = p1.value
+        return val, pdf
+
+    def bsdf_sample_ctx(self, bsdf, ctx, wi, uv, s1, s2, active=None):
+        """BSDF::sample with ctx and a mask: dict(wo 3 x n, pdf, weight 3 x n, eta, sampled_type, sampled_component)"""
+        wi = f32(wi); uv = f32(uv); s1 = f32(s1); s2 = f32(s2); n = s2.shape[1]
+        wo = np.zeros((3, n), np.float32); w = np.zeros((3, n), np.float32); pdf = np.zeros(n, np.float32); eta = np.zeros(n, np.float32)
+        st = np.zeros(n, np.uint32); sc = np.zeros(n, np.uint32)
+        a3 = np.empty(3, np.float32); w3 = np.empty(3, np.float32); p1 = C.c_float(); e1 = C.c_float(); t1 = C.c_uint32(); c1 = C.c_uint32()
+        L = lib(); L.orc_bsdf_sample_ctx.restype = None
+        L.orc_bsdf_sample_ctx.argtypes = [C.c_void_p, C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32, C.c_int, c_f32p, c_f32p, C.c_float, c_f32p, c_f32p, C.POINTER(C.c_float), c_f32p,
+                                          C.POINTER(C.c_float), C.POINTER(C.c_uint32), C.POINTER(C.c_uint32)]
+        for i in range(n):
+            a = f32(wi[:, i]); b = f32(uv[:, i]); c = f32(s2[:, i])
+            L.orc_bsdf_sample_ctx(self.handle, bsdf, ctx[0], ctx[1] & 0xffffffff, ctx[2] & 0xffffffff, 1 if (active is None or active[i]) else 0, fp(a), fp(b), float(s1[i]), fp(c),
+                                  fp(a3), C.byref(p1), fp(w3), C.byref(e1), C.byref(t1), C.byref(c1))
+            wo[:, i] = a3; w[:, i] = w3; pdf[i] = p1.value; eta[i] = e1.value; st[i] = t1.value; sc[i] = c1.value
+        return dict(wo=wo, pdf=pdf, weight=w, eta=eta, sampled_type=st, sampled_component=sc)
+
     def _render(self, fn, sensor, seed, spp, max_depth, rr_depth, lanes, threads):
         film = np.zeros((sensor.crop_height, sensor.crop_width, 4), np.float32)
         st = Stats()
@@ -567,17 +626,19 @@ class OracleScene:
         assert rc == 0
         return film if raw else develop(film)
 
-    def integrator_sample(self, o, d, maxt, seed=0, lane_offset=0, state=None, max_depth=8, rr_depth=5, prb=False, threads=0):
-        """SamplingIntegrator::sample over n rays (3 x n origins / directions): (rgb 3 x n, valid n uint8, state_out n uint64)"""
+    def integrator_sample(self, o, d, maxt, seed=0, lane_offset=0, state=None, max_depth=8, rr_depth=5, prb=False, threads=0, active=None):
+        """SamplingIntegrator::sample over n rays (3 x n origins / directions): (rgb 3 x n, valid n uint8, state_out n uint64); active: the Mask argument"""
         o = f32(o); d = f32(d); maxt = f32(maxt); n = maxt.shape[0]
         rgb = np.empty((3, n), np.float32); valid = np.empty(n, np.uint8); so = np.empty(n, np.uint64)
         st = None if state is None else np.ascontiguousarray(state, np.uint64)
-        L = lib(); L.orc_integrator_sample.restype = C.c_int
+        am = None if active is None else np.ascontiguousarray(active, np.uint8)
+        L = lib(); L.orc_integrator_sample_masked.restype = C.c_int
         u64p = C.POINTER(C.c_uint64)
-        L.orc_integrator_sample.argtypes = [C.c_void_p, C.c_int, C.c_uint32, c_f32p, c_f32p, c_f32p, C.c_uint32, C.c_uint32, u64p, C.c_int32, C.c_int32, c_f32p,
-                                            C.POINTER(C.c_uint8), u64p, C.c_int]
-        rc = L.orc_integrator_sample(self.handle, 1 if prb else 0, n, fp(o), fp(d), fp(maxt), seed, lane_offset, st.ctypes.data_as(u64p) if st is not None else None,
-                                     max_depth, rr_depth, fp(rgb), valid.ctypes.data_as(C.POINTER(C.c_uint8)), so.ctypes.data_as(u64p), threads)
+        L.orc_integrator_sample_masked.argtypes = [C.c_void_p, C.c_int, C.c_uint32, c_f32p, c_f32p, c_f32p, C.c_uint32, C.c_uint32, u64p, C.POINTER(C.c_uint8), C.c_int32, C.c_int32, c_f32p,
+                                                   C.POINTER(C.c_uint8), u64p, C.c_int]
+        rc = L.orc_integrator_sample_masked(self.handle, 1 if prb else 0, n, fp(o), fp(d), fp(maxt), seed, lane_offset, st.ctypes.data_as(u64p) if st is not None else None,
+                                            am.ctypes.data_as(C.POINTER(C.c_uint8)) if am is not None else None,
+                                            max_depth, rr_depth, fp(rgb), valid.ctypes.data_as(C.POINTER(C.c_uint8)), so.ctypes.data_as(u64p), threads)
         assert rc == 0
         return rgb, valid, so
 

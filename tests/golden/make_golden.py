@@ -99,6 +99,29 @@ def transcribe_kats():
             {"wi": [0, 0, -1], "sample1": 0.05, "weight": [trans * int_ior ** 2] * 3, "pdf": 1 - pdf_r, "eta": 1 / int_ior, "wo": [0, 0, 1], "delta": True},
         ],
         "src": "%s:%d-%d (TransportMode.Radiance branch)" % (rel, line, line + 62)}
+    # --- dielectric under a BSDFContext (same file: test02/test03 Importance branch, test04_sample_specific_component): mode 0 Radiance / 1 Importance,
+    #     type_mask / component select a lobe -- then pdf = 1 and the weight carries the Fresnel term (0.3 * 0.04, 0.6 * (1 - 0.04) [/ 1.5^2 under Radiance])
+    l4 = next(i for i, l in enumerate(L, 1) if "def test04_sample_specific_component" in l)
+    assert "0.3 * 0.04" in txt and "0.6 * (1 - 0.04) / 1.5**2" in txt and "ctx.component = 3" in txt
+    DR, DT, ALL, NONE = 0x20, 0x40, 0x1ff, 0xffffffff
+    ctx_cases = []
+    for mode in (1, 0):                                          # i == 0: Importance, i == 1: Radiance
+        t_w = trans if mode == 1 else trans / int_ior ** 2
+        ctx_cases += [   # test02_sample (both lobes): wi = +z
+            {"ctx": [mode, ALL, NONE], "wi": [0, 0, 1], "sample1": 0.0, "weight": [refl] * 3, "pdf": pdf_r, "eta": 1.0, "wo": [0, 0, 1], "type": DR, "component": 0},
+            {"ctx": [mode, ALL, NONE], "wi": [0, 0, 1], "sample1": 0.05, "weight": [t_w] * 3, "pdf": 1 - pdf_r, "eta": int_ior, "wo": [0, 0, -1], "type": DT, "component": 1},
+            # test03_sample_reverse: wi = -z
+            {"ctx": [mode, ALL, NONE], "wi": [0, 0, -1], "sample1": 0.0, "weight": [refl] * 3, "pdf": pdf_r, "eta": 1.0, "wo": [0, 0, -1], "type": DR, "component": 0},
+            {"ctx": [mode, ALL, NONE], "wi": [0, 0, -1], "sample1": 0.05, "weight": [trans if mode == 1 else trans * int_ior ** 2] * 3, "pdf": 1 - pdf_r,
+             "eta": 1 / int_ior, "wo": [0, 0, 1], "type": DT, "component": 1}]
+        for sample in (0.0, 0.5, 1.0):                           # test04_sample_specific_component
+            for sel in (0, 1):
+                ctx_cases.append({"ctx": [mode, DR, NONE] if sel == 0 else [mode, ALL, 0], "wi": [0, 0, 1], "sample1": sample, "weight": [refl * pdf_r] * 3, "pdf": 1.0,
+                                  "eta": 1.0, "wo": [0, 0, 1], "type": DR, "component": 0})
+                ctx_cases.append({"ctx": [mode, DT, NONE] if sel == 0 else [mode, ALL, 1], "wi": [0, 0, 1], "sample1": sample,
+                                  "weight": [trans * (1 - pdf_r) * (1.0 if mode == 1 else 1 / int_ior ** 2)] * 3, "pdf": 1.0, "eta": int_ior, "wo": [0, 0, -1], "type": DT, "component": 1})
+    ctx_cases.append({"ctx": [0, ALL, 3], "wi": [0, 0, 1], "sample1": 0.0, "weight": [0.0] * 3, "zero_only": True})      # ctx.component = 3: nothing enabled
+    out["dielectric_context"] = {"bsdf": out["dielectric_sample"]["bsdf"], "cases": ctx_cases, "src": "%s:%d-%d and :%d-%d" % (rel, line, line + 62, l4, l4 + 44)}
     # --- twosided(diffuse) pdf (src/bsdfs/tests/test_twosided.py: test02_pdf)
     rel = "src/bsdfs/tests/test_twosided.py"
     line = next(i for i, l in enumerate(_lines(rel), 1) if "def test02_pdf" in l)

@@ -81,6 +81,49 @@ void hh_bsdf_sample(void *h, uint32_t bsdf, const float wi[3], const float uv[2]
     BsdfSample b; bsdf_sample(S, side, in, ok, s1, s2[0], s2[1], b);
     wo[0] = b.wo.x; wo[1] = b.wo.y; wo[2] = b.wo.z; *pdf = b.pdf; weight[0] = b.weight.x; weight[1] = b.weight.y; weight[2] = b.weight.z; *eta = b.eta; *delta = b.delta;
 }
+/* ... with the BSDFContext (mode, type_mask, component) and the Mask argument, exactly as k_api_bsdf_eval_pdf / k_api_bsdf_sample (har_kernels.hip) do it */
+void hh_bsdf_eval_pdf_ctx(void *h, uint32_t bsdf, uint32_t mode, uint32_t type_mask, uint32_t component, int active, const float wi[3], const float uv[2], const float wo[3],
+                          float value[3], float *pdf) {
+    HScene *H = (HScene *) h; const DScene &S = H->ds;
+    BsdfCtx ctx; ctx.mode = mode; ctx.type_mask = type_mask; ctx.component = component;
+    BsdfEval e; e.value = Vec3(0.f); e.pdf = 0.f;
+    if (active) {
+        BsdfSide side; bool ok = bsdf_side(S, bsdf, Vec3(wi[0], wi[1], wi[2]), side);
+        TexTaps taps; BsdfInputs in = bsdf_inputs(S, S.bsdfs[side.index], uv[0], uv[1], taps);
+        bsdf_eval_pdf<HAR_BSDF_ALL_TYPES, true>(S, side, in, ok, Vec3(wo[0], wo[1], wo[2]), e, bsdf_side_ctx(S, bsdf, side, ctx));
+    }
+    value[0] = e.value.x; value[1] = e.value.y; value[2] = e.value.z; *pdf = e.pdf;
+}
+void hh_bsdf_sample_ctx(void *h, uint32_t bsdf, uint32_t mode, uint32_t type_mask, uint32_t component, int active, const float wi[3], const float uv[2], float s1, const float s2[2],
+                        float wo[3], float *pdf, float weight[3], float *eta, uint32_t *stype, uint32_t *scomp) {
+    HScene *H = (HScene *) h; const DScene &S = H->ds;
+    BsdfCtx ctx; ctx.mode = mode; ctx.type_mask = type_mask; ctx.component = component;
+    BsdfSample b; b.wo = Vec3(0.f); b.pdf = 0.f; b.weight = Vec3(0.f); b.eta = 0.f; b.delta = false; b.type = 0u; b.comp = 0u;
+    if (active) {
+        BsdfSide side; bool ok = bsdf_side(S, bsdf, Vec3(wi[0], wi[1], wi[2]), side);
+        TexTaps taps; BsdfInputs in = bsdf_inputs(S, S.bsdfs[side.index], uv[0], uv[1], taps);
+        bsdf_sample<HAR_BSDF_ALL_TYPES, true>(S, side, in, ok, s1, s2[0], s2[1], b, bsdf_side_ctx(S, bsdf, side, ctx));
+    }
+    wo[0] = b.wo.x; wo[1] = b.wo.y; wo[2] = b.wo.z; *pdf = b.pdf; weight[0] = b.weight.x; weight[1] = b.weight.y; weight[2] = b.weight.z; *eta = b.eta; *stype = b.type; *scomp = b.comp;
+}
+/* compute_si + compute_si_partials under RayFlags and a mask, exactly as k_api_si (har_kernels.hip): out[33] */
+void hh_surface_interaction_flags(void *h, const float d[3], float t, float u, float v, uint32_t prim, uint32_t shape, uint32_t inst, uint32_t ray_flags, int active, float out[33]) {
+    HScene *H = (HScene *) h; const DScene &S = H->ds;
+    const Vec3 D(d[0], d[1], d[2]);
+    const bool shading = (ray_flags & RAY_SHADING) != 0u, valid = active && t != HAR_INF;
+    Vec3 vs[6] = { Vec3(0.f), Vec3(0.f), Vec3(0.f), Vec3(0.f), Vec3(0.f), Vec3(0.f) };
+    float uvx = 0.f, uvy = 0.f;
+    SurfPartials P; P.dp_du = Vec3(0.f); P.dp_dv = Vec3(0.f); P.dn_du = Vec3(0.f); P.dn_dv = Vec3(0.f);
+    if (valid) {
+        const SurfInt si = compute_si(S, D, t, u, v, prim, shape, inst);
+        vs[0] = si.p; vs[1] = si.n;
+        if (shading) { vs[2] = si.sn; vs[3] = si.ss; vs[4] = si.st; vs[5] = si.wi; uvx = si.uv_x; uvy = si.uv_y; compute_si_partials(S, u, v, prim, shape, inst, (ray_flags & RAY_NORMAL_PARTIALS) != 0u, P); }
+    } else if (shading) { coordinate_system(Vec3(0.f), vs[3], vs[4]); vs[5] = -D; }
+    for (int k = 0; k < 6; ++k) { out[3 * k] = vs[k].x; out[3 * k + 1] = vs[k].y; out[3 * k + 2] = vs[k].z; }
+    out[18] = uvx; out[19] = uvy; out[20] = valid ? t : HAR_INF;
+    const Vec3 ps[4] = { P.dp_du, P.dp_dv, P.dn_du, P.dn_dv };
+    for (int k = 0; k < 4; ++k) { out[21 + 3 * k] = ps[k].x; out[22 + 3 * k] = ps[k].y; out[23 + 3 * k] = ps[k].z; }
+}
 void hh_microfacet_eval(int type, float alpha_u, float alpha_v, int sample_visible, const float wi[3], const float m[3], float out[3]) {
     Microfacet d(type != 0, alpha_u, alpha_v, sample_visible != 0);
     Vec3 w(wi[0], wi[1], wi[2]), mm(m[0], m[1], m[2]);
