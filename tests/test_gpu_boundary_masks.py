@@ -106,6 +106,7 @@ def test_bsdf_context_and_mask_device_vs_oracle(mi, O):
     nonzero = 0
     for name, d in BSDF_DICTS.items():
         bsdf = mi.load_dict(d)
+        bsdf._bind()                                          # a stand-alone plugin lives in a private scene
         si = type("SI", (), dict(wi=wi, uv=None))()
         sd = O.SceneData()
         sd.bsdfs = [(types[b.kind], -1, b.value, dict(flags=b.flags, reflectance2=b.value2, alpha_u=b.alpha_u, alpha_v=b.alpha_v, eta=b.eta, eta_c=b.eta_c,
