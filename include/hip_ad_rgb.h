@@ -416,6 +416,12 @@ int har_integrator_set_replay_cache(HarIntegrator integrator, int enable);
  * model is shaded by its own kernel.  Results are identical to the default (one kernel with a block-local material sort).  Default: OFF -- measured
  * slower on MI355X (the class kernels gather path state through sparse index lists). */
 int har_integrator_set_material_queues(HarIntegrator integrator, int enable);
+/* Wave-shared BVH descent for the FIRST closest-hit launch of a render (the camera rays): at >= 64 samples per pixel the 64 lanes of a wave are samples of one
+ * pixel (lane = pixel * spp + sample, integrator.cpp:322-334) and walk the acceleration structure together -- one conservative box test per child for the whole
+ * wave, exact per-ray triangle tests at the leaves (mesh.h:1130-1155), so the intersections are those of the per-ray kernels bit for bit; packets that turn out
+ * incoherent fall back to the per-ray kernel.  mode -1 (default): automatic (renders with spp a multiple of 64); 0: off; 1: on for every first launch, also for
+ * the rays of har_integrator_sample (testing). */
+int har_integrator_set_packet_tracing(HarIntegrator integrator, int mode);
 int har_render_timing(HarIntegrator integrator, float ms[8], uint32_t launches[8]);
 
 

@@ -115,6 +115,7 @@ SIGNATURES = {
     "har_image_free": (None, [vp]),
     "har_integrator_set_replay_cache": (C.c_int, [vp, C.c_int]),
     "har_integrator_set_material_queues": (C.c_int, [vp, C.c_int]),
+    "har_integrator_set_packet_tracing": (C.c_int, [vp, C.c_int]),
     "har_mesh_load_ply": (C.c_int, [C.c_char_p, C.c_int, C.c_int, f32p, C.c_int, vp]),
     "har_mesh_load_obj": (C.c_int, [C.c_char_p, C.c_int, C.c_int, f32p, C.c_int, vp]),
     "har_mesh_load_serialized": (C.c_int, [C.c_char_p, C.c_int, C.c_int, f32p, C.c_int, vp]),

@@ -863,7 +863,7 @@ class Integrator:
     def __init__(self, props):
         self.type = props['type']
         # integrator.cpp:26-33,128-147,539-550; block_size only shapes the scalar / LLVM-parallel drivers; the last four are hip_ad_rgb extensions
-        _check_props(self.type, props, ('max_depth', 'rr_depth', 'hide_emitters', 'samples_per_pass', 'block_size', 'chunk_lanes', 'replay_cache', 'material_queues', 'emitter_gradients', 'shape_gradients', 'bsdf_parameter_gradients'),
+        _check_props(self.type, props, ('max_depth', 'rr_depth', 'hide_emitters', 'samples_per_pass', 'block_size', 'chunk_lanes', 'replay_cache', 'material_queues', 'packet_tracing', 'emitter_gradients', 'shape_gradients', 'bsdf_parameter_gradients'),
                      unsupported=(('timeout', -1.0),))
         default_depth = -1 if self.type == 'path' else 6        # integrator.cpp:539, common.py:31
         self.max_depth = int(props.get('max_depth', default_depth))
@@ -876,6 +876,8 @@ class Integrator:
         self.chunk_lanes = int(props.get('chunk_lanes', 0))
         self.replay_cache = bool(props.get('replay_cache', True))      # hip_ad_rgb extension, see har_integrator_set_replay_cache
         self.material_queues = bool(props.get('material_queues', False))   # hip_ad_rgb extension, see har_integrator_set_material_queues
+        # hip_ad_rgb extension, see har_integrator_set_packet_tracing: None = automatic, False / True force the wave-shared descent of the camera rays off / on
+        self.packet_tracing = props.get('packet_tracing', None)
         self.emitter_gradients = bool(props.get('emitter_gradients', True))   # d / d radiance of area / constant emitters (har_integrator_set_grad_emitters)
         # d / d vertex positions (har_integrator_set_grad_positions): False, True (every eligible mesh) or a list of '<shape>.vertex_positions' keys --
         # the stand-in for dr.enable_grad(params[key]) of the reference
@@ -900,6 +902,8 @@ class Integrator:
                 check(lib().har_integrator_set_replay_cache(h, 0))
             if self.material_queues:
                 check(lib().har_integrator_set_material_queues(h, 1))
+            if self.packet_tracing is not None:
+                check(lib().har_integrator_set_packet_tracing(h, 1 if self.packet_tracing else 0))
             if self.hide_emitters:
                 check(lib().har_integrator_set_hide_emitters(h, 1))
             if self.samples_per_pass is not None:

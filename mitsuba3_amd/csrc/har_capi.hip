@@ -150,6 +150,7 @@ struct HarIntegratorImpl {
     float *alpha_film = nullptr;          /* user buffer (DEVICE, H x W x 4: channel 3 accumulates w * alpha) of har_integrator_set_alpha_film, or null */
     float *alpha_lane = nullptr;          /* alpha value per lane of the chunk */
     uint32_t *skip_counters = nullptr;    /* hide_emitters: count + cursor of the two continuation lists of skip_area_emitters */
+    uint32_t *pk_list = nullptr, *pk_counters = nullptr;      /* wave-shared descent of the camera rays (k_trace_packet): the packets left to the per-lane kernel, their count + cursor */
     // workspace
     uint32_t ws_lanes = 0; bool ws_adjoint = false; uint32_t shard_cap = 0;
     std::vector<void *> owned;
@@ -178,6 +179,7 @@ struct HarIntegratorImpl {
     /* instance to_world gradients (har_integrator_set_grad_instances): user buffer (DEVICE, instance_count x 12), per-instance slot table, accumulation buffer */
     float *inst_user = nullptr; uint32_t inst_count = 0; int32_t *d_inst_slot = nullptr; float *grad_inst = nullptr;
     bool material_queues = false;         /* har_integrator_set_material_queues */
+    int packet_tracing = -1;              /* har_integrator_set_packet_tracing: -1 automatic, 0 off, 1 every first closest-hit launch */
     uint32_t *mq_idx = nullptr, *mq_count = nullptr;      /* per-material shading queues (MaterialQueues): HAR_MAT_CLASSES index lists of ws_lanes entries, their counters */
     uint2 *stack_spill = nullptr;         /* HBM part of the traversal stacks: HAR_STACK_SPILL entries per thread of the largest traversal grid */
     /* multi-pass rendering: sampler state per lane of the rendered lane range, pixel jitter per chunk lane (see PassState) */
@@ -303,6 +305,7 @@ int ensure_workspace(HarIntegratorImpl *I, uint32_t lanes, bool adjoint, int tap
     if (ws_alloc(I, &I->result, lanes)) return 1;
     if (ws_alloc(I, &I->stack_spill, (size_t) HAR_STACK_SPILL * HAR_MAX_TRAVERSAL_BLOCKS * 256)) return 1;
     if (ws_alloc(I, &I->skip_counters, (size_t) 4 * HAR_SHARDS * HAR_COUNTER_STRIDE)) return 1;
+    if (ws_alloc(I, &I->pk_list, (size_t) lanes / 64 + HAR_SHARDS) || ws_alloc(I, &I->pk_counters, (size_t) 2 * HAR_SHARDS * HAR_COUNTER_STRIDE)) return 1;
     I->alpha_lane = nullptr;
     if (I->alpha_film && ws_alloc(I, &I->alpha_lane, lanes)) return 1;
     if (ws_alloc(I, &I->counters, (size_t) 4 * HAR_MAX_BOUNCE_SLOTS * HAR_SHARDS * HAR_COUNTER_STRIDE) || ws_alloc(I, &I->totals, 4) || ws_alloc(I, &I->status, 1)) return 1;
@@ -543,6 +546,19 @@ int run_chunk(HarSceneImpl *S, HarIntegratorImpl *I, const DSensor &C, int mode,
         const TapeArrays tp{ (tape || rec_w) ? I->tape_next + toff : nullptr, I->tape_la[b & 1], I->tape_lb[b & 1], I->tape_la[(b & 1) ^ 1], I->tape_lb[(b & 1) ^ 1],
                              rec_w ? I->tape_rec[0] + toff : nullptr, rec_w ? I->tape_rec[1] + toff : nullptr, rec_w ? I->tape_rec[2] + toff : nullptr, rec_w ? I->tape_rec[3] + toff : nullptr };
         if (rc.mode != 2 && rc.mode != 4) {
+            /* camera rays at >= 64 samples per pixel: a wave is one pixel, its 64 rays walk the BVH together (k_trace_packet); what that kernel gives up on
+             * -- incoherent packets -- goes to the per-lane kernel through a list.  Same hit records either way.  HAR_PACKET=0 / 1 forces it off / on (A/B). */
+            static const int packet_env = getenv("HAR_PACKET") ? atoi(getenv("HAR_PACKET")) : -1;
+            static const uint32_t packet_budget = getenv("HAR_PACKET_BUDGET") ? (uint32_t) atoi(getenv("HAR_PACKET_BUDGET")) : 160u;
+            const int packet_mode = packet_env >= 0 ? packet_env : I->packet_tracing;
+            const bool packet = b == 0 && !tape_r && (packet_mode < 0 ? (!rays && spp >= 64 && spp % 64 == 0 && lane_base % 64 == 0) : packet_mode != 0);
+            if (packet) {
+                const size_t cs = (size_t) HAR_SHARDS * HAR_COUNTER_STRIDE;
+                const PacketList pl{ I->pk_list, I->pk_counters, I->pk_counters + cs, cnt_alive(I, b), I->shard_cap / 64u + 1u };
+                HIP_TRY(hipMemsetAsync(I->pk_counters, 0, 2 * cs * sizeof(uint32_t), s));
+                launch_trace_packet(s, tgrid, S->ds.accel, cnt_alive(I, b), cur_trace(I, b), I->shard_cap, st_in, h0, h1, pl, packet_budget);
+                launch_trace_closest(s, tgrid, spill, S->ds.accel, pl.count, pl.cursor, I->shard_cap, st_in, h0, h1, I->status, &pl);
+            } else
             launch_trace_closest(s, tgrid, spill, S->ds.accel, cnt_alive(I, b), cur_trace(I, b), I->shard_cap, st_in, h0, h1, I->status);
             prof_mark(I, s, CLS_TRACE);
         }
@@ -1416,6 +1432,14 @@ int har_render_stats(HarIntegrator I, HarStats *out) {
         if (read_status(I->twin->status, s)) return 1;
         out->paths += t[0]; out->vertices += t[1]; out->closest_rays += t[2]; out->shadow_rays += t[3];
     }
+    return 0;
+}
+
+int har_integrator_set_packet_tracing(HarIntegrator I, int mode) {
+    if (!I) return fail("null integrator");
+    if (mode < -1 || mode > 1) return fail("har_integrator_set_packet_tracing: mode must be -1 (automatic), 0 (off) or 1 (on)");
+    I->packet_tracing = mode;
+    if (I->twin) I->twin->packet_tracing = mode;
     return 0;
 }
 

@@ -127,8 +127,14 @@ void launch_raygen_rays(hipStream_t s, uint32_t seed, uint32_t lane_base, uint32
 void launch_sample_out(hipStream_t s, uint32_t n, uint32_t n_total, uint32_t first, const float4 *result, const float *valid_lane, int zero_invalid, float *rgb, uint8_t *valid,
                        const uint8_t *active, uint32_t seed, uint32_t lane_base, const uint64_t *state_in, uint64_t *state_out);
 /* `spill` = nullptr: the scene's depth-first bound fits the LDS stack and the kernels without the HBM spill path run (3 % faster) */
+/* Packets (64 consecutive rays of a shard) the wave-shared descent gave up on: list[shard * stride + k] = first ray of the k-th one, count[shard * HAR_COUNTER_STRIDE]
+ * their number, cursor = the work cursor of the per-lane launch that serves them, shard_count = the wavefront's rays per shard (the last packet may be partial) */
+struct PacketList { uint32_t *list, *count, *cursor; const uint32_t *shard_count; uint32_t stride; };
+/* pl != nullptr: only the rays of the listed packets (count / cursor are then pl->count / pl->cursor) */
 void launch_trace_closest(hipStream_t s, uint32_t grid, uint2 *spill, const Accel &A, const uint32_t *count, uint32_t *cursor, uint32_t shard_cap,
-                          const WaveState &in, float4 *h0, uint2 *h1, int *status);
+                          const WaveState &in, float4 *h0, uint2 *h1, int *status, const PacketList *pl = nullptr);
+void launch_trace_packet(hipStream_t s, uint32_t grid, const Accel &A, const uint32_t *count, uint32_t *cursor, uint32_t shard_cap, const WaveState &in, float4 *h0, uint2 *h1,
+                         const PacketList &pl, uint32_t budget);
 void launch_shade(int mode, hipStream_t s, uint32_t grid, const DScene &S, const ShadeParams &P, uint32_t lane_base, uint32_t shard_cap, const uint32_t *count_in,
                   const WaveState &in, const float4 *h0, const uint2 *h1, const WaveState &out, uint32_t *count_out, const ItemArrays &items,
                   uint32_t *item_count, float4 *result, const ReplayCache &rc, uint64_t *pass_rng = nullptr, const float4 *dL = nullptr, float *grad_slots = nullptr,

@@ -492,26 +492,36 @@ __device__ __forceinline__ void trace_persistent(const Accel &A, uint32_t *curso
 #define HAR_TRACE_MIN_WAVES 6     /* __launch_bounds__ waves per SIMD of the traversal kernels: the LDS stacks allow 6 blocks per CU, so the registers must too (<= 80; the
                                    * two-level k_trace_closest would take 82 on its own and lose its sixth wave: 871 vs 899 Mpaths/s, profiles/r03_ab_defer_xform.txt).  A/B: 7 with an 11-entry LDS stack */
 #endif
-template <bool SPILL, bool FLAT = false>
+/* LIST: the launch walks the rays of the 64-ray packets named in `list` (per shard: list[shard * list_stride + k] = first ray of the packet within the shard) --
+ * the packets k_trace_packet gave up on -- instead of the whole wavefront: work item idx is ray list[idx / 64] + idx % 64, `count` holds the number of PACKETS */
+template <bool SPILL, bool FLAT = false, bool LIST = false>
 __global__ __launch_bounds__(kBlock, HAR_TRACE_MIN_WAVES) void k_trace_closest(Accel A, const uint32_t *count, uint32_t *cursor, uint32_t shard_cap, const float4 *a0,
-                                                          const float4 *a1, float4 *h0, uint2 *h1, int *status, uint2 *spill) {
+                                                          const float4 *a1, float4 *h0, uint2 *h1, int *status, uint2 *spill, const uint32_t *list, uint32_t list_stride,
+                                                          const uint32_t *shard_count) {
     __shared__ uint2 lds[HAR_LDS_STACK_SMALL * kBlock];
     typedef typename WaveStackOf<SPILL>::type WaveStack;
     typedef Traversal<HAR_TRAV_POLICY, FLAT> Trav;
     WaveStack stack = make_wave_stack<SPILL>(lds, spill);
-    const uint32_t shard = blockIdx.x & (HAR_SHARDS - 1), n = count[shard * HAR_COUNTER_STRIDE], base = shard * shard_cap;
+    const uint32_t shard = blockIdx.x & (HAR_SHARDS - 1), base = shard * shard_cap;
+    const uint32_t n = LIST ? 64u * count[shard * HAR_COUNTER_STRIDE] : count[shard * HAR_COUNTER_STRIDE];
+    const uint32_t n_rays = LIST ? shard_count[shard * HAR_COUNTER_STRIDE] : n;      /* rays of the shard (the last packet may be partial) */
     if (n == 0) return;
+    auto ray_of = [&](uint32_t idx) { return LIST ? list[(size_t) shard * list_stride + (idx >> 6)] + (idx & 63u) : idx; };
     auto take = [&](uint32_t idx, Trav &T) {
-        float4 o = a0[base + idx], d = a1[base + idx];
+        const uint32_t r = ray_of(idx);
+        if (LIST && r >= n_rays) return false;
+        float4 o = a0[base + r], d = a1[base + r];
         T.begin(A, Vec3(o.x, o.y, o.z), Vec3(d.x, d.y, d.z), o.w < 0.f ? HAR_LARGEST : o.w, (A.top_last & 2u) != 0u);
         return true;
     };
     auto store = [&](uint32_t idx, const Trav &T) {
-        h0[HIT0(base + idx)] = make_float4(T.hit.t, T.hit.u, T.hit.v, __uint_as_float(T.hit.prim));
+        const uint32_t r = ray_of(idx);
+        if (LIST && r >= n_rays) return;
+        h0[HIT0(base + r)] = make_float4(T.hit.t, T.hit.u, T.hit.v, __uint_as_float(T.hit.prim));
 #if HAR_HIT_INTERLEAVED      /* the second half as ONE 16-byte store: the ray's 32-byte sector is written completely (no byte-masked partial write) */
-        *reinterpret_cast<uint4 *>(h1 + HIT1(base + idx)) = make_uint4(T.hit.shape, T.hit.inst, 0u, 0u);
+        *reinterpret_cast<uint4 *>(h1 + HIT1(base + r)) = make_uint4(T.hit.shape, T.hit.inst, 0u, 0u);
 #else
-        h1[HIT1(base + idx)] = make_uint2(T.hit.shape, T.hit.inst);
+        h1[HIT1(base + r)] = make_uint2(T.hit.shape, T.hit.inst);
 #endif
     };
 #if HAR_CLOSEST_RETIRE
@@ -524,6 +534,194 @@ __global__ __launch_bounds__(kBlock, HAR_TRACE_MIN_WAVES) void k_trace_closest(A
     trace_persistent<false, false, WaveStack, FLAT>(A, cursor + shard * HAR_COUNTER_STRIDE, n, stack, status, take, store,
         [&](bool, uint32_t, const Trav &) { });
 #endif
+}
+
+/* ------------------------------------------------------------- trace_packet */
+/*
+ * Wave-shared descent for COHERENT closest-hit launches: the camera rays of a render at >= 64 spp, where the 64 lanes of a wave are 64 samples of ONE pixel
+ * (lane = pixel * spp + sample, integrator.cpp:322-334).  The wave walks the BVH once for all its rays: a child box is tested against the PACKET -- interval
+ * arithmetic over the rays' origins and reciprocal directions, one child per lane, ~70 instructions per node visit for the wave instead of the 246-instruction
+ * per-lane test of eight boxes -- with one traversal stack per wave and wave-uniform control flow.  At the leaves every lane runs the exact Moeller-Trumbore
+ * test of its own ray (tri_visit), with the tie rule of the per-lane kernels; the BVH only prunes, and the packet test only keeps MORE boxes than any single
+ * ray's test would, so the hit records are those of k_trace_closest (and of the brute-force kernel) bit for bit.
+ * A packet that turns out incoherent (a pixel that covers hundreds of triangles, a ray set whose directions straddle an axis and prune little) would cost more
+ * than 64 independent walks: after `budget` steps -- or when the wave's stack is full -- the wave drops it and files it in `list`, which a
+ * k_trace_closest<.., LIST> launch serves afterwards.  Host model: tools/packet_stats.py (camera rays of the 1M-triangle scene at 512^2: 13.7 node visits +
+ * 11.5 leaf tests per packet, ~2 150 VALU instructions per 64 rays against ~6 200 for the per-lane kernel; shadow rays and later bounces are NOT coherent at the
+ * scale of the geometry -- a first-bounce shadow packet would visit 9 400 nodes -- and stay with the per-lane kernels).
+ */
+#ifndef HAR_PACKET_STACK
+#define HAR_PACKET_STACK 48        /* stack entries per wave (8 B each, LDS) */
+#endif
+template <typename F> __device__ __forceinline__ float wave_reduce_f32(float v, F op) {      /* all 64 lanes take part; the result comes back wave-uniform */
+#define HAR_DPP_STEP(ctrl, rm) v = op(v, __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(__builtin_bit_cast(int, v), __builtin_bit_cast(int, v), ctrl, rm, 0xF, false)))
+    HAR_DPP_STEP(0xB1, 0xF); HAR_DPP_STEP(0x4E, 0xF); HAR_DPP_STEP(0x141, 0xF); HAR_DPP_STEP(0x140, 0xF); HAR_DPP_STEP(0x142, 0xA); HAR_DPP_STEP(0x143, 0xC);
+#undef HAR_DPP_STEP
+    return __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), 63));
+}
+__device__ __forceinline__ float wave_min_f32(float v) { return wave_reduce_f32(v, [](float a, float b) { return fminf(a, b); }); }
+__device__ __forceinline__ float wave_max_f32(float v) { return wave_reduce_f32(v, [](float a, float b) { return fmaxf(a, b); }); }
+/* what a packet knows about its rays: per axis, in the orientation of the rays' travel (an axis the rays run down is mirrored, so that every kept axis has
+ * positive directions): on = farthest-back origin bound used for the NEAR plane, of = the one for the FAR plane, id_lo / id_hi the reciprocal directions' range.
+ * mixed: the rays' directions have both signs on that axis -- no constraint from its slab. */
+struct PacketBounds { float on[3], of[3], id_lo[3], id_hi[3]; uint32_t neg, mixed, octinv; };      /* neg / mixed: bit a = axis a */
+__device__ __forceinline__ float uniform_f32(float v) { return __builtin_bit_cast(float, __builtin_amdgcn_readfirstlane(__builtin_bit_cast(int, v))); }
+__device__ __forceinline__ PacketBounds packet_bounds(const RaySetup &R) {
+    PacketBounds B;
+    const float o[3] = { R.o.x, R.o.y, R.o.z }, id[3] = { R.idir.x, R.idir.y, R.idir.z };
+    B.octinv = 0u; B.neg = 0u; B.mixed = 0u;
+#pragma unroll
+    for (int a = 0; a < 3; ++a) {
+        const float o_lo = wave_min_f32(o[a]), o_hi = wave_max_f32(o[a]), i_lo = wave_min_f32(id[a]), i_hi = wave_max_f32(id[a]);
+        const bool neg = i_hi < 0.f, mixed = !(i_lo > 0.f || i_hi < 0.f);
+        if (neg) B.neg |= 1u << a; else B.octinv |= 4u >> a;
+        if (mixed) B.mixed |= 1u << a;
+        /* mirrored axis: plane' = -plane, o' = -o, idir' = -idir; the values are wave-uniform and are kept in scalar registers */
+        B.on[a] = uniform_f32(neg ? -o_lo : o_hi); B.of[a] = uniform_f32(neg ? -o_hi : o_lo);
+        B.id_lo[a] = uniform_f32(neg ? -i_hi : i_lo); B.id_hi[a] = uniform_f32(neg ? -i_lo : i_hi);
+    }
+    return B;
+}
+/* the packet's test of the eight children of node `index` (wave-uniform): lane l tests child l % 8; returns the node group / triangle group of node_visit */
+__device__ __forceinline__ void packet_node_visit(const Accel &A, const PacketBounds &B, float tmax_wave, uint32_t index, uint32_t &ng_x, uint32_t &ng_y, uint32_t &tg_x, uint32_t &tg_y) {
+    const uint32_t *np = reinterpret_cast<const uint32_t *>(A.nodes + index);
+    const uint4 n0 = reinterpret_cast<const uint4 *>(np)[0];
+    const uint2 n1 = reinterpret_cast<const uint2 *>(np)[2];
+    const uint32_t c = threadIdx.x & 7u;
+    const uint8_t *nb = reinterpret_cast<const uint8_t *>(np);
+    const uint32_t meta = nb[24 + c];
+    const float q[6] = { (float) nb[32 + c], (float) nb[40 + c], (float) nb[48 + c], (float) nb[56 + c], (float) nb[64 + c], (float) nb[72 + c] };      /* qlo x y z, qhi x y z */
+    const float p[3] = { __uint_as_float(n0.x), __uint_as_float(n0.y), __uint_as_float(n0.z) };
+    const float sc[3] = { __uint_as_float((n0.w & 0xffu) << 23), __uint_as_float(((n0.w >> 8) & 0xffu) << 23), __uint_as_float(((n0.w >> 16) & 0xffu) << 23) };
+    float lb = 0.f, ub = tmax_wave;
+#pragma unroll
+    for (int a = 0; a < 3; ++a) {
+        const float lo = fma_(q[a], sc[a], p[a]), hi = fma_(q[3 + a], sc[a], p[a]);
+        const bool neg = (B.neg >> a) & 1u;
+        const float pn = neg ? -hi : lo, pf = neg ? -lo : hi;                        /* near / far plane along the rays' travel */
+        const float dn = pn - B.on[a], df = pf - B.of[a];
+        float tn = dn * (dn >= 0.f ? B.id_lo[a] : B.id_hi[a]), tf = df * (df >= 0.f ? B.id_hi[a] : B.id_lo[a]);
+        if ((B.mixed >> a) & 1u) { tn = -HAR_INF; tf = HAR_INF; }
+        lb = fmaxf(lb, tn); ub = fminf(ub, tf);
+    }
+    const uint32_t bits = meta >> 5;
+    uint32_t idx = meta & 31u;
+    if ((meta & 0x18u) == 0x18u) idx ^= B.octinv;                                    /* inner child: slot by the rays' octant (node_visit) */
+    uint32_t m = (lb <= ub * 1.000002f) ? bits << idx : 0u;
+    /* OR over the eight children = over each aligned group of eight lanes */
+    m |= (uint32_t) __builtin_amdgcn_update_dpp((int) m, (int) m, 0xB1, 0xF, 0xF, false);
+    m |= (uint32_t) __builtin_amdgcn_update_dpp((int) m, (int) m, 0x4E, 0xF, 0xF, false);
+    m |= (uint32_t) __builtin_amdgcn_update_dpp((int) m, (int) m, 0x141, 0xF, 0xF, false);
+    const uint32_t hitmask = (uint32_t) __builtin_amdgcn_readfirstlane((int) m);
+    ng_x = n1.x; tg_x = n1.y;
+    ng_y = (hitmask & 0xff000000u) | (n0.w >> 24);
+    tg_y = hitmask & 0x00ffffffu;
+}
+#ifndef HAR_PACKET_MIN_WAVES
+#define HAR_PACKET_MIN_WAVES 8
+#endif
+template <bool FLAT>
+__global__ __launch_bounds__(kBlock, HAR_PACKET_MIN_WAVES) void k_trace_packet(Accel A, const uint32_t *count, uint32_t *cursor, uint32_t shard_cap, const float4 *a0, const float4 *a1,
+                                                         float4 *h0, uint2 *h1, uint32_t *list, uint32_t list_stride, uint32_t *list_count, uint32_t budget) {
+    __shared__ uint2 lds[(kBlock / 64) * HAR_PACKET_STACK];
+    const uint32_t lane = threadIdx.x & 63u;
+    uint2 *stack = lds + (threadIdx.x >> 6) * HAR_PACKET_STACK;
+    const uint32_t shard = blockIdx.x & (HAR_SHARDS - 1), n = count[shard * HAR_COUNTER_STRIDE], base = shard * shard_cap;
+    if (n == 0) return;
+    for (;;) {
+        uint32_t pk = 0;
+        if (lane == 0) pk = atomicAdd(cursor + shard * HAR_COUNTER_STRIDE, 64u);
+        pk = (uint32_t) __builtin_amdgcn_readfirstlane((int) pk);
+        if (pk >= n) break;
+        const uint32_t idx = min(pk + lane, n - 1u);                    /* the lanes past the end of the last packet walk a copy of its last ray; their result is dropped */
+        const float4 fo = a0[base + idx], fd = a1[base + idx];
+        const Vec3 o_w(fo.x, fo.y, fo.z), d_w(fd.x, fd.y, fd.z);
+        float tmax = fo.w < 0.f ? HAR_LARGEST : fo.w;
+        Hit hit; hit.t = HAR_INF; hit.u = 0.f; hit.v = 0.f; hit.prim = 0; hit.shape = 0; hit.inst = 0xffffffffu;
+        RaySetup R = ray_setup(o_w, d_w);
+        const PacketBounds Bw = packet_bounds(R);
+        PacketBounds B = Bw;
+        float tmax_wave = wave_max_f32(tmax);
+        uint32_t cur_inst = 0xffffffffu, steps = 0;
+        bool in_tlas = false;
+        /* the levels of a two-level scene in the per-lane kernels' order (Traversal::begin): phase 0 / 1; FLAT: one phase over A.root.
+         * Control flow is wave-uniform throughout (every condition below is computed from scalars); it is written without `break` / `continue` out of nested
+         * conditionals so that the structurised loops keep all 64 lanes together.  state: 0 walking, 1 this phase is done, 2 given up */
+        const bool top_last = !FLAT && (A.top_last & 2u) != 0u, has_top = !FLAT && A.has_tlas && A.top_root != HAR_NO_NODE;
+        const int n_phases = (!FLAT && A.has_tlas) ? 2 : 1;
+        int state = 0;
+        for (int phase = 0; phase < n_phases; ++phase) {
+            uint32_t ng_x = A.root, ng_y = 0x80000000u, tg_x = 0u, tg_y = 0u;
+            bool skip = state == 2;
+            if (FLAT || !A.has_tlas) in_tlas = false;
+            else if ((phase == 0) != top_last) { ng_x = A.top_root; in_tlas = false; skip = skip || !has_top; }      /* the top-level meshes' BLAS, world space */
+            else in_tlas = true;
+            int sp = 0, inst_sp = -1;
+            state = skip ? state : 0;
+            /* the reference loop of har_accel.h (accel_trace) with wave-uniform state: visit the nearest pending child, run ALL leaf items of the visited node, pop */
+            while (!skip && state == 0) {
+                ++steps;
+                if (steps > budget) state = 2;
+                else if (ng_y > 0x00ffffffu) {
+                    uint32_t px = ng_x, py = ng_y;
+                    const uint32_t child = ng_next_child(px, py, B.octinv);
+                    if (py > 0x00ffffffu) {
+                        if (sp >= HAR_PACKET_STACK) state = 2;
+                        else { if (lane == 0) stack[sp] = make_uint2(px, py); ++sp; }
+                    }
+                    if (state == 0) packet_node_visit(A, B, tmax_wave, child, ng_x, ng_y, tg_x, tg_y);
+                } else { tg_x = ng_x; tg_y = ng_y; ng_x = 0u; ng_y = 0u; }
+                bool entered = false;
+                while (state == 0 && !entered && tg_y != 0u) {
+                    const uint32_t bit = 31u - clz32(tg_y);
+                    tg_y &= ~(1u << bit);
+                    const uint32_t leaf = tg_x + bit;
+                    ++steps;
+                    if (!FLAT && in_tlas) {
+                        /* instance entry: the rest of the TLAS node waits on the stack, every lane takes its ray to object space (as Traversal::apply_pending does),
+                         * the packet's bounds are rebuilt there; the instance is left when the stack is back at this depth */
+                        if (sp + 2 > HAR_PACKET_STACK) state = 2;
+                        else {
+                            if (ng_y > 0x00ffffffu) { if (lane == 0) stack[sp] = make_uint2(ng_x, ng_y); ++sp; }
+                            if (tg_y != 0u) { if (lane == 0) stack[sp] = make_uint2(tg_x, tg_y); ++sp; }
+                            const InstRec &I = A.insts[leaf];
+                            inst_sp = sp; cur_inst = I.inst_index; in_tlas = false;
+                            if (!I.identity) { R = ray_setup(xf_point(I.to_object, o_w), xf_vector(I.to_object, d_w)); B = packet_bounds(R); }
+                            ng_x = I.blas_root; ng_y = 0x80000000u; tg_y = 0u;
+                            entered = true;
+                        }
+                    } else {
+                        const float t_old = tmax;
+                        tri_visit<false>(A, R, tmax, leaf, FLAT ? 0xffffffffu : cur_inst, hit);
+                        if (__ballot(tmax != t_old)) tmax_wave = wave_max_f32(tmax);
+                    }
+                }
+                if (state == 0 && ng_y <= 0x00ffffffu) {
+                    if (!FLAT && !in_tlas && sp == inst_sp) { R = ray_setup(o_w, d_w); B = Bw; cur_inst = 0xffffffffu; in_tlas = true; inst_sp = -1; }      /* the instance is done: world space again */
+                    if (sp == 0) state = 1;
+                    else {
+                        --sp;
+                        const uint2 e = stack[sp];
+                        ng_x = (uint32_t) __builtin_amdgcn_readfirstlane((int) e.x); ng_y = (uint32_t) __builtin_amdgcn_readfirstlane((int) e.y);
+                    }
+                }
+            }
+        }
+        if (state == 2) {
+            if (lane == 0) { const uint32_t k = atomicAdd(list_count + shard * HAR_COUNTER_STRIDE, 1u); list[(size_t) shard * list_stride + k] = pk; }
+        } else if (pk + lane < n) {
+            h0[HIT0(base + idx)] = make_float4(hit.t, hit.u, hit.v, __uint_as_float(hit.prim));
+#if HAR_HIT_INTERLEAVED
+            *reinterpret_cast<uint4 *>(h1 + HIT1(base + idx)) = make_uint4(hit.shape, hit.inst, 0u, 0u);
+#else
+            h1[HIT1(base + idx)] = make_uint2(hit.shape, hit.inst);
+#endif
+        }
+        /* ONE latch for this loop.  Without a convergent operation here LLVM threads the `state == 2 && lane != 0` path straight to the loop header, which makes two
+         * back edges = a nested loop in which lanes 1..63 spin on packet 0 (their copy of `pk`) while lane 0 is parked at the list append: the kernel never ends
+         * (seen on the GPU: every launch with a failing packet hung).  A wave barrier may not be duplicated into the two paths, so all lanes meet here. */
+        __builtin_amdgcn_wave_barrier();
+    }
 }
 
 /* adjoint of one NEE / vertex item (wave-uniform call: every lane takes part in the texel pre-reduction):
@@ -1658,11 +1856,20 @@ void launch_sample_out(hipStream_t s, uint32_t n, uint32_t n_total, uint32_t fir
 /* HAR_FLAT_KERNELS=0: scenes without a TLAS run the generic traversal kernels (A/B switch) */
 static bool flat_kernels() { static const bool on = !(getenv("HAR_FLAT_KERNELS") && atoi(getenv("HAR_FLAT_KERNELS")) == 0); return on; }
 void launch_trace_closest(hipStream_t s, uint32_t grid, uint2 *spill, const Accel &A, const uint32_t *count, uint32_t *cursor, uint32_t shard_cap,
-                          const WaveState &in, float4 *h0, uint2 *h1, int *status) {
+                          const WaveState &in, float4 *h0, uint2 *h1, int *status, const PacketList *pl) {
+    const uint32_t *list = pl ? pl->list : nullptr, *shard_count = pl ? pl->shard_count : nullptr; const uint32_t stride = pl ? pl->stride : 0u;
     /* scenes without a TLAS run the FLAT instantiation of the traversal (har_accel.h): no instance blocks, no world-space ray copy */
-    if (spill) hipLaunchKernelGGL(k_trace_closest<true>, dim3(grid), dim3(kBlock), 0, s, A, count, cursor, shard_cap, in.a0, in.a1, h0, h1, status, spill);
-    else if (!A.has_tlas && flat_kernels()) hipLaunchKernelGGL((k_trace_closest<false, true>), dim3(grid), dim3(kBlock), 0, s, A, count, cursor, shard_cap, in.a0, in.a1, h0, h1, status, spill);
-    else hipLaunchKernelGGL(k_trace_closest<false>, dim3(grid), dim3(kBlock), 0, s, A, count, cursor, shard_cap, in.a0, in.a1, h0, h1, status, spill);
+#define HAR_LAUNCH_TC(SP, FL, LI) hipLaunchKernelGGL((k_trace_closest<SP, FL, LI>), dim3(grid), dim3(kBlock), 0, s, A, count, cursor, shard_cap, in.a0, in.a1, h0, h1, status, spill, list, stride, shard_count)
+    const bool flat = !A.has_tlas && flat_kernels();
+    if (pl) { if (spill) HAR_LAUNCH_TC(true, false, true); else if (flat) HAR_LAUNCH_TC(false, true, true); else HAR_LAUNCH_TC(false, false, true); }
+    else    { if (spill) HAR_LAUNCH_TC(true, false, false); else if (flat) HAR_LAUNCH_TC(false, true, false); else HAR_LAUNCH_TC(false, false, false); }
+#undef HAR_LAUNCH_TC
+}
+/* the wave-shared descent of a coherent closest-hit launch (k_trace_packet); the packets it gives up on are filed in `pl` for launch_trace_closest(.., &pl) */
+void launch_trace_packet(hipStream_t s, uint32_t grid, const Accel &A, const uint32_t *count, uint32_t *cursor, uint32_t shard_cap, const WaveState &in, float4 *h0, uint2 *h1,
+                         const PacketList &pl, uint32_t budget) {
+    if (!A.has_tlas) hipLaunchKernelGGL(k_trace_packet<true>, dim3(grid), dim3(kBlock), 0, s, A, count, cursor, shard_cap, in.a0, in.a1, h0, h1, pl.list, pl.stride, pl.count, budget);
+    else hipLaunchKernelGGL(k_trace_packet<false>, dim3(grid), dim3(kBlock), 0, s, A, count, cursor, shard_cap, in.a0, in.a1, h0, h1, pl.list, pl.stride, pl.count, budget);
 }
 void launch_shade(int mode, hipStream_t s, uint32_t grid, const DScene &S, const ShadeParams &P, uint32_t lane_base, uint32_t shard_cap, const uint32_t *count_in,
                   const WaveState &in, const float4 *h0, const uint2 *h1, const WaveState &out, uint32_t *count_out, const ItemArrays &items,

@@ -552,6 +552,173 @@ int hh_trace_stats(void *h, const HarSensor *sensor, uint32_t seed, uint32_t spp
 
 } // extern "C"
 
+/* --- wave-shared ("packet") descent model (tools/packet_stats.py): the 64 rays of a wave walk the BVH TOGETHER -- one conservative interval test per child box for the
+ * whole packet, exact per-lane Moeller-Trumbore tests at the leaves (so the hits stay those of the brute-force kernel: the BVH only prunes), one shared stack.  This is a
+ * MODEL of the candidate kernel for coherent launches (camera rays / first shadow rays at >= 64 spp: a wave is one pixel); it counts the blocks such a wave would issue. */
+namespace {
+struct PkBounds { float o_lo[3], o_hi[3], id_lo[3], id_hi[3]; bool mixed[3]; uint32_t octinv; };
+struct PkCount { double packets = 0, rays = 0, nodes = 0, tris = 0, insts = 0, mismatches = 0, lane_nodes = 0, lane_tris = 0, lane_insts = 0, coherent = 0; };
+static PkBounds pk_bounds(const RaySetup *R, const bool *act, int n) {
+    PkBounds B; for (int a = 0; a < 3; ++a) { B.o_lo[a] = HAR_INF; B.o_hi[a] = -HAR_INF; B.id_lo[a] = HAR_INF; B.id_hi[a] = -HAR_INF; }
+    for (int l = 0; l < n; ++l) if (act[l]) {
+        const float o[3] = { R[l].o.x, R[l].o.y, R[l].o.z }, id[3] = { R[l].idir.x, R[l].idir.y, R[l].idir.z };
+        for (int a = 0; a < 3; ++a) { B.o_lo[a] = fminf(B.o_lo[a], o[a]); B.o_hi[a] = fmaxf(B.o_hi[a], o[a]); B.id_lo[a] = fminf(B.id_lo[a], id[a]); B.id_hi[a] = fmaxf(B.id_hi[a], id[a]); }
+    }
+    B.octinv = 0;
+    for (int a = 0; a < 3; ++a) { B.mixed[a] = !(B.id_lo[a] > 0.f || B.id_hi[a] < 0.f); if (!(B.id_hi[a] < 0.f)) B.octinv |= 4u >> a; }      /* octinv bit set = non-negative direction (ray_setup) */
+    return B;
+}
+/* conservative version of node_visit: same outputs (child group / triangle group), a child is kept unless NO ray of the packet can meet its box */
+static void pk_node_visit(const Accel &A, const PkBounds &B, float tmax_wave, uint32_t index, uint32_t &ng_x, uint32_t &ng_y, uint32_t &tg_x, uint32_t &tg_y) {
+    const Node8 &N = A.nodes[index];
+    const float p[3] = { N.px, N.py, N.pz }, sc[3] = { as_f32((uint32_t) N.ex << 23), as_f32((uint32_t) N.ey << 23), as_f32((uint32_t) N.ez << 23) };
+    const uint8_t *qlo[3] = { N.qlox, N.qloy, N.qloz }, *qhi[3] = { N.qhix, N.qhiy, N.qhiz };
+    uint32_t hitmask = 0;
+    for (int i = 0; i < 8; ++i) {
+        const uint32_t m = N.meta[i], bits = m >> 5; uint32_t idx = m & 31u;
+        if (bits == 0) continue;
+        if ((m & 0x18u) == 0x18u) idx ^= B.octinv;                          /* inner child: slot remapped by the octant (node_visit) */
+        float lb = 0.f, ub = tmax_wave;
+        for (int a = 0; a < 3; ++a) {
+            if (B.mixed[a]) continue;                                        /* directions of both signs on this axis: no constraint from its slab */
+            const float lo = fma_((float) qlo[a][i], sc[a], p[a]), hi = fma_((float) qhi[a][i], sc[a], p[a]);
+            float tn, tf;
+            if (B.id_lo[a] > 0.f) {                                          /* t = (plane - o) * idir, idir in [id_lo, id_hi] > 0 */
+                const float dn = lo - B.o_hi[a], df = hi - B.o_lo[a];
+                tn = dn * (dn >= 0.f ? B.id_lo[a] : B.id_hi[a]); tf = df * (df >= 0.f ? B.id_hi[a] : B.id_lo[a]);
+            } else {                                                         /* idir in [id_lo, id_hi] < 0: near plane = hi */
+                const float dn = hi - B.o_lo[a], df = lo - B.o_hi[a];      /* dn <= ... : (hi - o) largest at o_lo; t = dn * idir, idir negative */
+                tn = dn * (dn >= 0.f ? B.id_lo[a] : B.id_hi[a]);            /* lower bound: most negative product */
+                tf = df * (df >= 0.f ? B.id_hi[a] : B.id_lo[a]);
+                /* with negative idir: t_near = (hi - o) * idir is smallest for the LARGEST (hi - o) times the most negative idir when hi - o >= 0 */
+            }
+            lb = fmaxf(lb, tn); ub = fminf(ub, tf);
+        }
+        if (lb <= ub * 1.000002f) hitmask |= bits << idx;
+    }
+    ng_x = N.child_base; tg_x = N.tri_base;
+    ng_y = (hitmask & 0xff000000u) | N.imask; tg_y = hitmask & 0x00ffffffu;
+}
+/* one BLAS (or the TLAS) walked by the packet; R / act / tmax / hit are per lane */
+template <bool AnyHit>
+static void pk_walk(const Accel &A, uint32_t root, bool tlas, const Vec3 *o_w, const Vec3 *d_w, RaySetup *R, bool *act, float *tmax, Hit *hit, bool *found, int n, uint32_t cur_inst, PkCount &C) {
+    PkBounds B = pk_bounds(R, act, n);
+    uint32_t sx[64], sy[64]; int sp = 0;
+    uint32_t ng_x = root, ng_y = 0x80000000u, tg_x = 0, tg_y = 0;
+    for (;;) {
+        bool any = false; for (int l = 0; l < n; ++l) any = any || act[l];
+        if (!any) return;
+        if (ng_y > 0x00ffffffu) {
+            uint32_t px = ng_x, py = ng_y;
+            const uint32_t child = ng_next_child(px, py, B.octinv);
+            if (py > 0x00ffffffu) { sx[sp] = px; sy[sp] = py; ++sp; }
+            float tw = 0.f; for (int l = 0; l < n; ++l) if (act[l]) tw = fmaxf(tw, tmax[l]);
+            pk_node_visit(A, B, tw, child, ng_x, ng_y, tg_x, tg_y); C.nodes += 1;
+        } else { tg_x = ng_x; tg_y = ng_y; ng_x = 0; ng_y = 0; }
+        while (tg_y != 0u) {
+            const uint32_t bit = 31u - clz32(tg_y); tg_y &= ~(1u << bit);
+            const uint32_t idx = tg_x + bit;
+            if (tlas) {
+                const InstRec &I = A.insts[idx];
+                RaySetup Ro[64];
+                for (int l = 0; l < n; ++l) if (act[l]) Ro[l] = I.identity ? R[l] : ray_setup(xf_point(I.to_object, o_w[l]), xf_vector(I.to_object, d_w[l]));
+                C.insts += 1;
+                pk_walk<AnyHit>(A, I.blas_root, false, o_w, d_w, Ro, act, tmax, hit, found, n, I.inst_index, C);
+            } else {
+                C.tris += 1;
+                for (int l = 0; l < n; ++l) if (act[l]) {
+                    if (tri_visit<AnyHit>(A, R[l], tmax[l], idx, cur_inst, hit[l])) { found[l] = true; act[l] = false; }
+                }
+            }
+        }
+        if (ng_y <= 0x00ffffffu) {
+            if (sp == 0) return;
+            --sp; ng_x = sx[sp]; ng_y = sy[sp];
+        }
+    }
+}
+template <bool AnyHit>
+static void pk_trace(const Accel &A, const Vec3 *o, const Vec3 *d, const float *maxt, int n, Hit *hit, bool *found, PkCount &C) {
+    RaySetup R[64]; bool act[64]; float tmax[64];
+    for (int l = 0; l < n; ++l) { R[l] = ray_setup(o[l], d[l]); act[l] = true; tmax[l] = maxt[l]; found[l] = false; hit[l].t = HAR_INF; hit[l].u = 0.f; hit[l].v = 0.f; hit[l].prim = 0; hit[l].shape = 0; hit[l].inst = 0xffffffffu; }
+    C.packets += 1; C.rays += n;
+    const bool two_level = A.has_tlas != 0;
+    const bool top_last = (A.top_last & (AnyHit ? 1u : 2u)) != 0u;
+    if (!two_level) { pk_walk<AnyHit>(A, A.root, false, o, d, R, act, tmax, hit, found, n, 0xffffffffu, C); }
+    else {
+        for (int phase = 0; phase < 2; ++phase) {
+            const bool top = (phase == 0) != top_last;
+            if (top) { if (A.top_root != HAR_NO_NODE) pk_walk<AnyHit>(A, A.top_root, false, o, d, R, act, tmax, hit, found, n, 0xffffffffu, C); }
+            else pk_walk<AnyHit>(A, A.root, true, o, d, R, act, tmax, hit, found, n, 0xffffffffu, C);
+        }
+    }
+    if (!AnyHit) for (int l = 0; l < n; ++l) found[l] = hit[l].t != HAR_INF;
+}
+struct CountProbe { double *nodes, *tris, *insts; void iter() {} void node() { *nodes += 1; } void tri() { *tris += 1; } void inst() { *insts += 1; } };
+}
+
+extern "C" {
+/* out[bounce][2][12]: per bounce, closest (0) and shadow (1) launches: packets, rays, packet node visits, packet leaf (triangle) blocks, packet instance entries, mismatches
+ * against the per-ray reference loop, and the per-ray loop's node visits / triangle tests / instance entries summed over the same rays; slots 9.. : histogram helper (unused) */
+int hh_packet_stats(void *h, const HarSensor *sensor, uint32_t seed, uint32_t spp, int32_t max_depth, int32_t rr_depth, uint64_t lane_begin, uint64_t lane_end,
+                    uint32_t max_bounces, double *out, double *per_packet /* nullable: [bounce 0 closest | bounce 0 shadow] x (nodes, tris, insts, lane nodes) per packet, 4 doubles each, cap in out */,
+                    uint64_t per_packet_cap) {
+    HScene *H = (HScene *) h; const DScene &S = H->ds;
+    DSensor C; std::string e; if (!lower_sensor(*sensor, C, e)) return -1;
+    uint32_t log_spp = 0xffffffffu; for (uint32_t k = 0; k < 32; ++k) if ((1u << k) == spp) log_spp = k;
+    ShadeParams P{ seed, (uint32_t) max_depth, (uint32_t) rr_depth };
+    std::vector<PathState> cur, next; LaneSample ls;
+    for (uint64_t lane = lane_begin; lane < lane_end; ++lane) cur.push_back(raygen_lane(C, seed, spp, log_spp, (uint32_t) lane, ls));
+    int status = 0; uint64_t pp = 0;
+    for (uint32_t b = 0; b < max_bounces && !cur.empty(); ++b) {
+        struct Sh { Vec3 o, d; float maxt; };
+        std::vector<Sh> shadow; next.clear();
+        std::vector<Hit> hits(cur.size());
+        PkCount cc;
+        for (size_t w = 0; w < cur.size(); w += 64) {
+            const int n = (int) std::min<size_t>(64, cur.size() - w);
+            Vec3 o[64], d[64]; float mt[64]; Hit ph[64]; bool pf[64];
+            for (int l = 0; l < n; ++l) { o[l] = cur[w + l].o; d[l] = cur[w + l].d; mt[l] = cur[w + l].maxt; }
+            const double n0 = cc.nodes, t0 = cc.tris, i0 = cc.insts, ln0 = cc.lane_nodes;
+            pk_trace<false>(S.accel, o, d, mt, n, ph, pf, cc);
+            for (int l = 0; l < n; ++l) {
+                HostStack stack; CountProbe pr{ &cc.lane_nodes, &cc.lane_tris, &cc.lane_insts };
+                accel_trace<false>(S.accel, o[l], d[l], mt[l], hits[w + l], stack, status, pr);
+                if (memcmp(&hits[w + l], &ph[l], sizeof(Hit)) != 0) cc.mismatches += 1;
+            }
+            if (per_packet && b == 0 && pp < per_packet_cap) { double *q = per_packet + 8 * pp; q[0] = cc.nodes - n0; q[1] = cc.tris - t0; q[2] = cc.insts - i0; q[3] = cc.lane_nodes - ln0; }
+            if (b == 0) ++pp;
+        }
+        double *q = out + 24 * b;
+        q[0] = cc.packets; q[1] = cc.rays; q[2] = cc.nodes; q[3] = cc.tris; q[4] = cc.insts; q[5] = cc.mismatches; q[6] = cc.lane_nodes; q[7] = cc.lane_tris; q[8] = cc.lane_insts;
+        for (size_t i = 0; i < cur.size(); ++i) {
+            ShadeResult R; shade_lane<MODE_PATH>(S, P, cur[i], hits[i], R);
+            if (R.item && R.item_ray) shadow.push_back(Sh{ R.sh_o, R.sh_d, R.sh_maxt });
+            if (R.alive) next.push_back(R.next);
+        }
+        PkCount sc; uint64_t sp2 = 0;
+        for (size_t w = 0; w < shadow.size(); w += 64) {
+            const int n = (int) std::min<size_t>(64, shadow.size() - w);
+            Vec3 o[64], d[64]; float mt[64]; Hit ph[64]; bool pf[64];
+            for (int l = 0; l < n; ++l) { o[l] = shadow[w + l].o; d[l] = shadow[w + l].d; mt[l] = shadow[w + l].maxt; }
+            const double n0 = sc.nodes, t0 = sc.tris, i0 = sc.insts, ln0 = sc.lane_nodes;
+            pk_trace<true>(S.accel, o, d, mt, n, ph, pf, sc);
+            for (int l = 0; l < n; ++l) {
+                HostStack stack; CountProbe pr{ &sc.lane_nodes, &sc.lane_tris, &sc.lane_insts }; Hit hh;
+                const bool f = accel_trace<true>(S.accel, o[l], d[l], mt[l], hh, stack, status, pr);
+                if (f != pf[l]) sc.mismatches += 1;
+            }
+            if (per_packet && b == 0 && sp2 < per_packet_cap) { double *qq = per_packet + 8 * sp2 + 4; qq[0] = sc.nodes - n0; qq[1] = sc.tris - t0; qq[2] = sc.insts - i0; qq[3] = sc.lane_nodes - ln0; }
+            if (b == 0) ++sp2;
+        }
+        q += 12;
+        q[0] = sc.packets; q[1] = sc.rays; q[2] = sc.nodes; q[3] = sc.tris; q[4] = sc.insts; q[5] = sc.mismatches; q[6] = sc.lane_nodes; q[7] = sc.lane_tris; q[8] = sc.lane_insts;
+        cur.swap(next);
+    }
+    return status;
+}
+}
+
 extern "C" {
 /* environment map: the product's host lowering (build_envmap) + the HAR_HD lookup / sampling code */
 void hh_envmap_storage(void *h, uint32_t *info /* w, h, n_levels, warp size */, uint32_t *table /* [n_levels][2]: width, offset */, float *warp) {
