@@ -85,8 +85,14 @@ typedef struct HarBSDF {
     int32_t  back;
 } HarBSDF;
 
-/* BitmapTexture, raw H x W x 3 f32, bilinear, repeat (src/textures/bitmap.cpp:175-206). HOST pointer. */
-typedef struct HarTexture { const float *data; uint32_t width, height; } HarTexture;
+/* BitmapTexture, raw H x W x 3 f32 (src/textures/bitmap.cpp:175-206). HOST pointer.  mode = filter_type | wrap_mode (bitmap.cpp:182-206):
+ * HAR_TEX_BILINEAR / HAR_TEX_NEAREST, HAR_TEX_REPEAT / HAR_TEX_MIRROR / HAR_TEX_CLAMP; 0 = the reference's defaults (bilinear, repeat). */
+#define HAR_TEX_BILINEAR 0u
+#define HAR_TEX_NEAREST  1u
+#define HAR_TEX_REPEAT   0u
+#define HAR_TEX_MIRROR   2u
+#define HAR_TEX_CLAMP    4u
+typedef struct HarTexture { const float *data; uint32_t width, height; uint32_t mode, reserved; } HarTexture;
 
 /* type 0: AreaLight on a Rectangle (src/emitters/area.cpp, src/shapes/rectangle.cpp:108-179);
  * type 1: ConstantBackgroundEmitter (src/emitters/constant.cpp): only `radiance` is read, at most one per scene.
@@ -127,6 +133,8 @@ typedef struct HarSensor {
     uint32_t sample_border;       /* Film::sample_border (src/render/film.cpp:29-32): != 0 -> the lane -> pixel map of render() runs over the crop window
                                    * enlarged by rfilter->border_size() = ceil(radius - 1/2 - 2 RayEpsilon) pixels on every side
                                    * (src/render/integrator.cpp:162-165, 322-339); the film itself keeps the crop size, splats are clipped to it */
+    float    principal_point_offset_x, principal_point_offset_y;   /* PerspectiveCamera `principal_point_offset_x / _y` (src/sensors/perspective.cpp:147-150): sample_ray adds
+                                   * film_size * offset / crop_size to the film position before it is taken to the near plane (:213-221) */
 } HarSensor;
 
 /* counters of one render call (all lanes), read back with har_render_stats */
@@ -467,7 +475,8 @@ int  har_mesh_load_ply(const char *filename, int face_normals, int flip_tex_coor
 /* OBJMesh ctor (src/shapes/obj.cpp:98-296) + Mesh::from_corners (src/render/mesh_utils.cpp:210-560): polygons are fan-triangulated,
  * corners of a point weld when normal / texcoord / UV-orientation agree; missing normals are regenerated per surface point */
 int  har_mesh_load_obj(const char *filename, int face_normals, int flip_tex_coords, const float *to_world, int flip_normals, HarMeshData *out);
-/* SerializedMesh ctor + load_legacy (src/shapes/serialized.cpp:225-370): container versions 3 and 4, sub-mesh `shape_index` */
+/* SerializedMesh ctor + load_legacy / load_v5 (src/shapes/serialized.cpp:225-450): container versions 3, 4 and 5 (the packed records as the reference writes them
+ * today, Mesh::write_serialized), sub-mesh `shape_index`.  face_normals: 0 / 1, or -1 = the property is unset (a version-5 file's stored FaceNormals flag then applies) */
 int  har_mesh_load_serialized(const char *filename, int shape_index, int face_normals, const float *to_world, int flip_normals, HarMeshData *out);
 int  har_mesh_compute_normals(uint32_t vertex_count, float *vertices, uint32_t face_count, const uint32_t *faces);
 void har_mesh_free(HarMeshData *mesh);

@@ -38,7 +38,7 @@ class HarBSDF(C.Structure):
 
 
 class HarTexture(C.Structure):
-    _fields_ = [("data", f32p), ("width", C.c_uint32), ("height", C.c_uint32)]
+    _fields_ = [("data", f32p), ("width", C.c_uint32), ("height", C.c_uint32), ("mode", C.c_uint32), ("reserved", C.c_uint32)]
 
 
 class HarEmitter(C.Structure):
@@ -70,7 +70,7 @@ class HarSensor(C.Structure):
                 ("crop_offset_x", C.c_uint32), ("crop_offset_y", C.c_uint32),
                 ("crop_width", C.c_uint32), ("crop_height", C.c_uint32),
                 ("rfilter", C.c_uint32), ("rfilter_stddev", C.c_float), ("rfilter_param1", C.c_float),
-                ("sample_border", C.c_uint32)]
+                ("sample_border", C.c_uint32), ("principal_point_offset_x", C.c_float), ("principal_point_offset_y", C.c_float)]
 
 
 class HarBSDFContext(C.Structure):

@@ -341,10 +341,11 @@ class Mesh:
         check(lib().har_mesh_load_obj(str(filename).encode(), int(bool(face_normals)), int(bool(flip_tex_coords)), self._tw(to_world), int(bool(flip_normals)), C.byref(md)))
         return self._adopt(md)
 
-    def from_serialized(self, filename, shape_index=0, face_normals=False, to_world=None, flip_normals=False):
-        """SerializedMesh (src/shapes/serialized.cpp), container versions 3 and 4"""
+    def from_serialized(self, filename, shape_index=0, face_normals=None, to_world=None, flip_normals=False):
+        """SerializedMesh (src/shapes/serialized.cpp), container versions 3, 4 and 5; face_normals=None: the property is unset (a v5 file's own flag applies)"""
         md = _capi.HarMeshData()
-        check(lib().har_mesh_load_serialized(str(filename).encode(), int(shape_index), int(bool(face_normals)), self._tw(to_world), int(bool(flip_normals)), C.byref(md)))
+        fn = -1 if face_normals is None else int(bool(face_normals))
+        check(lib().har_mesh_load_serialized(str(filename).encode(), int(shape_index), fn, self._tw(to_world), int(bool(flip_normals)), C.byref(md)))
         return self._adopt(md)
 
     def recompute_vertex_normals(self):
@@ -491,7 +492,10 @@ class Film:
         props = props or {}
         # hdrfilm.cpp:146-208; file_format / component_format only concern Film::write (har_image_write_*: float32 / half channels)
         _check_props('hdrfilm', props, ('width', 'height', 'crop_offset_x', 'crop_offset_y', 'crop_width', 'crop_height', 'pixel_format', 'file_format', 'component_format',
-                                        'sample_border'), unsupported=(('compensate', False),))
+                                        'sample_border', 'compensate', 'banner'))
+        if 'compensate' in props:          # hdrfilm.cpp:218-225: marked as queried, warned about, ignored
+            import warnings
+            warnings.warn("The \"compensate\" (Kahan-style error-compensated accumulation) parameter has been removed and is now ignored.")
         self.width = int(props.get('width', 768)); self.height = int(props.get('height', 576))
         self.crop_offset_ = (int(props.get('crop_offset_x', 0)), int(props.get('crop_offset_y', 0)))
         self.crop_size_ = (int(props.get('crop_width', self.width)), int(props.get('crop_height', self.height)))
@@ -553,8 +557,8 @@ class Sensor:
     def __init__(self, props):
         self.props = dict(props)
         # sensor.cpp:24-97, perspective.cpp:137-172
-        _check_props('perspective', props, ('to_world', 'fov', 'fov_axis', 'focal_length', 'near_clip', 'far_clip', 'film', 'sampler', 'shutter_open', 'shutter_close', 'focus_distance'),
-                     unsupported=(('principal_point_offset_x', 0.0), ('principal_point_offset_y', 0.0)))
+        _check_props('perspective', props, ('to_world', 'fov', 'fov_axis', 'focal_length', 'near_clip', 'far_clip', 'film', 'sampler', 'shutter_open', 'shutter_close', 'focus_distance',
+                                            'principal_point_offset_x', 'principal_point_offset_y'))
         # child objects are recognised by their class, whatever the property is called (XML children are anonymous: `_arg_0`, ...)
         film = next((v for v in props.values() if isinstance(v, Film)), props.get('film'))
         sampler = next((v for v in props.values() if isinstance(v, Sampler)), props.get('sampler'))
@@ -583,6 +587,8 @@ class Sensor:
                                           f.rfilter, f.stddev, C.byref(s))
         s.rfilter_param1 = f.rf_param1
         s.sample_border = 1 if f.sample_border_ else 0
+        # perspective.cpp:147-150: the principal point, as a fraction of the film size
+        s.principal_point_offset_x = float(self.props.get('principal_point_offset_x', 0.0)); s.principal_point_offset_y = float(self.props.get('principal_point_offset_y', 0.0))
         if rc == 2:
             raise RuntimeError("The 'fov_axis' parameter must be set to one of 'smaller', 'larger', 'diagonal', 'x', or 'y'!")
         if rc == 3:
@@ -658,7 +664,7 @@ class BSDF:
         refl = props.get(name0, {'type': 'rgb', 'value': [def0] * 3})
         if isinstance(refl, (int, float)):
             refl = {'type': 'rgb', 'value': [refl] * 3}
-        self.texture = None
+        self.texture = None; self.tex_mode = 0
         if refl['type'] == 'rgb':
             self.value = _rgb_value(refl, def0)
         elif refl['type'] == 'bitmap':
@@ -666,8 +672,13 @@ class BSDF:
             # OpenEXR / PFM, read by the C++ host library).  Float data is linear; in RGB variants `raw` only silences the [0, 1] range warning.
             if sum(k in refl for k in ('data', 'bitmap', 'filename')) != 1:
                 raise RuntimeError("bitmap: exactly one of 'filename', 'bitmap' and 'data' must be specified")
-            if refl.get('filter_type', 'bilinear') != 'bilinear' or refl.get('wrap_mode', 'repeat') != 'repeat':
-                raise RuntimeError("bitmap: only filter_type='bilinear' and wrap_mode='repeat' are implemented")
+            # filter_type / wrap_mode (bitmap.cpp:182-206) -> HarTexture::mode
+            ft = str(refl.get('filter_type', 'bilinear')); wm = str(refl.get('wrap_mode', 'repeat'))
+            if ft not in ('nearest', 'bilinear'):
+                raise RuntimeError("Invalid filter type \"%s\", must be one of: \"nearest\", or \"bilinear\"!" % ft)
+            if wm not in ('repeat', 'mirror', 'clamp'):
+                raise RuntimeError("Invalid wrap mode \"%s\", must be one of: \"repeat\", \"mirror\", or \"clamp\"!" % wm)
+            self.tex_mode = (1 if ft == 'nearest' else 0) | {'repeat': 0, 'mirror': 2, 'clamp': 4}[wm]
             if 'to_uv' in refl:
                 raise RuntimeError("bitmap: 'to_uv' is not implemented by hip_ad_rgb")
             if 'data' in refl:
@@ -1199,7 +1210,7 @@ class Scene:
     def __init__(self, children):
         self.bsdf_objs = []; self.meshes = []; self.top_mesh_count = 0
         self.groups = []; self.instances = []; self.instance_keys = []; self.emitters = []
-        self.m_sensors = []; self.m_integrator = None; self.textures = []
+        self.m_sensors = []; self.m_integrator = None; self.textures = []; self.texture_modes = []
         self._h = None; self._keep = []
         named = {}
         shapes = []; groups = []; insts = []
@@ -1218,7 +1229,7 @@ class Scene:
                 self.emitters[self._emitter_order.index(key)] = dict(
                     type=2, mesh=len(self.textures), radiance=[obj.scale, 1.0 if obj.mis_compensation else 0.0, 0.0],
                     to_world=obj.to_world.col_major_3x4(), to_local=obj.to_world.inverse().col_major_3x4(), normal=[0.0] * 3, inv_area=0.0)
-                self.textures.append(obj.data)
+                self.textures.append(obj.data); self.texture_modes.append(0)
         for key, obj in children.items():
             if isinstance(obj, BSDF):
                 named[key] = obj
@@ -1260,7 +1271,7 @@ class Scene:
             return b.index
         b.scene = self; b.index = len(self.bsdf_objs)
         if b.texture is not None:
-            b.tex_index = len(self.textures); self.textures.append(b.texture)
+            b.tex_index = len(self.textures); self.textures.append(b.texture); self.texture_modes.append(b.tex_mode)
         self.bsdf_objs.append(b)
         if getattr(b, 'back', None) is not None:
             self._add_bsdf(b.back)
@@ -1311,7 +1322,7 @@ class Scene:
             bsdfs[i].back = b.back.index if b.back is not None else -1
         texs = (M.HarTexture * max(1, len(self.textures)))()
         for i, t in enumerate(self.textures):
-            texs[i].data = _fp(t); texs[i].height = t.shape[0]; texs[i].width = t.shape[1]
+            texs[i].data = _fp(t); texs[i].height = t.shape[0]; texs[i].width = t.shape[1]; texs[i].mode = self.texture_modes[i] if i < len(self.texture_modes) else 0
         ems = (M.HarEmitter * max(1, len(self.emitters)))()
         for i, e in enumerate(self.emitters):
             ems[i].type = e.get("type", 0); ems[i].mesh = e["mesh"]
@@ -1709,7 +1720,7 @@ def _mk_obj(props, named, key):
 def _mk_serialized(props, named, key):
     if 'filename' not in props:
         raise RuntimeError("serialized: the `filename` parameter is required")
-    m = Mesh(key or "serialized").from_serialized(props['filename'], props.get('shape_index', 0), props.get('face_normals', False),
+    m = Mesh(key or "serialized").from_serialized(props['filename'], props.get('shape_index', 0), props.get('face_normals', None),
                                                   props.get('to_world'), props.get('flip_normals', False))
     return _shape_common(m, props, named)
 

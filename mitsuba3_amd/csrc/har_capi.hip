@@ -409,6 +409,7 @@ int ensure_texel_queues(HarSceneImpl *S, HarIntegratorImpl *I) {
         const uint32_t W = S->hs.textures[t].w, H = S->hs.textures[t].h;
         band[t] = make_uint2(0xffffffffu, 1u);
         if (W == 0 || H == 0 || W > 65535u || H > 65535u) continue;
+        if (S->hs.textures[t].mode != 0u) continue;          /* the queue records assume the bilinear + repeat neighbourhood (x0 + 1, y0 + 1 wrapped): other modes keep the direct atomics */
         const size_t sizes[4] = { (size_t) HAR_TQ_LDS_BYTES, 32768, 49152, 65536 };
         for (int k = 0; k < 4; ++k) {
             const size_t lds = lds_forced ? lds_forced : sizes[k];
@@ -747,7 +748,7 @@ int har_scene_create(const HarSceneDesc *desc, HarScene *out) {
     std::vector<DTexture> dt;
     for (auto &t : hs.textures) {
         const float *p = nullptr; up(t.data, &p);
-        S->tex_dev.push_back(const_cast<float *>(p)); dt.push_back(DTexture{ p, t.w, t.h });
+        S->tex_dev.push_back(const_cast<float *>(p)); dt.push_back(DTexture{ p, t.w, t.h, t.mode, 0u });
     }
     up(dt, &D.textures);
     up(hs.bsdf_tables, &D.bsdf_tables);

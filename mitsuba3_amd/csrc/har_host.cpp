@@ -205,6 +205,7 @@ int har_perspective_sensor(const float to_world[32], double fov, const char *fov
     out->near_clip = near_clip; out->far_clip = far_clip; out->film_width = width; out->film_height = height;
     out->crop_offset_x = cx; out->crop_offset_y = cy; out->crop_width = cw; out->crop_height = ch;
     out->rfilter = rfilter; out->rfilter_stddev = stddev; out->rfilter_param1 = 1.f / 3.f;
+    out->principal_point_offset_x = 0.f; out->principal_point_offset_y = 0.f;
     return 0;
 }
 

@@ -29,7 +29,7 @@ using namespace har;
 
 extern int har_set_error(const std::string &msg);
 extern int har_mesh_finalize(std::vector<float> &V, std::vector<uint32_t> &F, bool stored_normals, bool regenerate, const float *to_world32,
-                             bool flip_normals, const std::vector<uint32_t> *position_index, uint32_t position_count);     /* har_mesh_io.cpp */
+                             bool flip_normals, const std::vector<uint32_t> *position_index, uint32_t position_count, bool packed_records = false);     /* har_mesh_io.cpp */
 
 namespace {
 
@@ -307,8 +307,7 @@ static int mesh_load_serialized_impl(const char *filename, int shape_index, int 
     uint16_t format = 0, version = 0;
     if (!rd(0, &format, 2) || !rd(2, &version, 2)) return fail("unexpected end of file");
     if (format != 0x041C) return fail("encountered an invalid file format");
-    if (version == 5) return fail("version 5 (packed-record) files are not supported by hip_ad_rgb yet; re-export as version 4");
-    if (version != 3 && version != 4) return fail("encountered an incompatible file version");
+    if (version != 3 && version != 4 && version != 5) return fail("encountered an incompatible file version");
     size_t offset = 0;
     if (shape_index != 0) {                                  /* sub-mesh directory at the end of the file (serialized.cpp:264-297) */
         uint32_t count = 0;
@@ -337,9 +336,57 @@ static int mesh_load_serialized_impl(const char *filename, int shape_index, int 
         inflateEnd(&zs);
     }
     size_t pos = 0;
-    auto take = [&](void *dst, size_t n) { if (pos + n > raw.size()) return false; if (dst) memcpy(dst, raw.data() + pos, n); pos += n; return true; };
+    auto take = [&](void *dst, size_t n) { if (n > raw.size() - std::min(pos, raw.size()) || pos > raw.size()) return false; if (dst) memcpy(dst, raw.data() + pos, n); pos += n; return true; };
     uint32_t flags = 0;
     if (!take(&flags, 4)) return fail("unexpected end of stream");
+    if (version == 5) {
+        /* SerializedMesh::load_v5 (serialized.cpp:393-450; writer Mesh::write_serialized, mesh.cpp:1091-1148): the packed representation verbatim -- flag word
+         * (low bits = Layout: 1 normals, 2 tangents, 4 texcoords, 8 per-face BSDFs; 0x10 face normals; 0x1000 single precision), length-prefixed name, four
+         * 64-bit counts, then the 8-float vertex records and 4-word face records AS THEY ARE, the optional vertex -> surface point / normal group maps and the
+         * custom attributes; `to_world` / `flip_normals` are applied afterwards (PackedMesh::transform_records, mesh_utils.cpp:46-99). */
+        auto take_string = [&](std::string &out) { uint32_t len = 0; if (!take(&len, 4) || len > raw.size() - pos) return false; out.assign((const char *) raw.data() + pos, len); pos += len; return true; };
+        std::string name;
+        if (!take_string(name)) return fail("unexpected end of stream");
+        auto fail5 = [&](const std::string &d) { return har_set_error("\"" + name + "\": " + d); };
+        if (!(flags & 0x1000u)) return fail5("version 5 serialized meshes are stored in single precision.");
+        const uint32_t layout = flags & 0xfu;
+        const bool l_normals = layout & 1u, l_tangents = layout & 2u, l_texcoords = layout & 4u;
+        uint64_t vc = 0, fc = 0, pc = 0, nc = 0;
+        if (!take(&vc, 8) || !take(&fc, 8) || !take(&pc, 8) || !take(&nc, 8)) return fail("unexpected end of stream");
+        if (pc > vc || nc > vc || (l_tangents && !l_normals)) return fail5("invalid serialized mesh header.");
+        if (layout & 8u) return fail5("per-face BSDF indices (Layout::FaceBSDFs) are not implemented by hip_ad_rgb");
+        if (vc > 0xffffffffull || fc > 0xffffffffull) return fail("mesh too large");
+        if (vc > (raw.size() - pos) / 32 || fc > (raw.size() - pos) / 16) return fail("unexpected end of stream");
+        std::vector<float> V(8 * (size_t) vc); std::vector<uint32_t> F(4 * (size_t) fc), pidx;
+        if (!take(V.data(), V.size() * 4) || !take(F.data(), F.size() * 4)) return fail("unexpected end of stream");
+        if (pc) { pidx.resize((size_t) vc); if (!take(pidx.data(), pidx.size() * 4)) return fail("unexpected end of stream"); for (uint32_t g : pidx) if (g >= pc) return fail5("invalid serialized mesh header."); }
+        if (nc && !take(nullptr, (size_t) vc * 4)) return fail("unexpected end of stream");
+        uint32_t attr_count = 0;
+        if (!take(&attr_count, 4)) return fail("unexpected end of stream");
+        for (uint32_t a = 0; a < attr_count; ++a) {          /* custom attributes are read past: nothing on the hip_ad_rgb path looks them up */
+            std::string an; uint8_t aflags = 0; uint32_t dim = 0;
+            if (!take_string(an) || !take(&aflags, 1) || !take(&dim, 4)) return fail("unexpected end of stream");
+            const uint64_t rows = an.compare(0, 5, "face_") == 0 ? fc : vc;
+            if (dim != 0 && rows > (raw.size() - pos) / 4 / dim) return fail("unexpected end of stream");
+            pos += (size_t) (rows * dim * 4);
+        }
+        for (size_t i = 0; i < (size_t) fc; ++i) for (int k = 0; k < 3; ++k) if (F[4 * i + k] >= vc) return fail("face index out of bounds");
+        /* the stored FaceNormals flag applies when the scene description leaves the property unset (face_normals < 0) */
+        const bool fn = face_normals < 0 ? (flags & 0x10u) != 0 : face_normals != 0;
+        const bool store_normals = l_normals && !fn;
+        if (l_tangents && store_normals)         /* frame_decode (mesh_utils.h:92-117): the normal of the packed (normal, tangent) frame; hip_ad_rgb keeps no tangents */
+            for (size_t v = 0; v < (size_t) vc; ++v) {
+                float *r = V.data() + 8 * v; const float px = r[3], py = r[4], pz = r[5];
+                const float a = 1.f / (1.f + fmaf(pz, pz, fmaf(py, py, px * px))), A = 8.f * (a * a), B = fmaf(-4.f, a, A), X = A * px, Y = A * py, Z = A * pz, yy = py * Y, xz = px * Z, yz = py * Z, u = 1.f - yy;
+                r[3] = fmaf(B, py, xz); r[4] = fmaf(-B, px, yz); r[5] = fmaf(-px, X, u);
+            }
+        if (!store_normals) for (size_t v = 0; v < (size_t) vc; ++v) { float *r = V.data() + 8 * v; r[3] = r[4] = r[5] = 0.f; }
+        if (!l_texcoords) for (size_t v = 0; v < (size_t) vc; ++v) { float *r = V.data() + 8 * v; r[6] = r[7] = 0.f; }
+        const bool regenerate = !store_normals && !fn;
+        if (har_mesh_finalize(V, F, store_normals, regenerate, to_world, flip_normals != 0, pc ? &pidx : nullptr, (uint32_t) (pc ? pc : vc), true)) return 1;
+        return emit(V, F, ((store_normals || regenerate) ? 1u : 0u) | (l_texcoords ? 2u : 0u), out);
+    }
+    if (face_normals < 0) face_normals = 0;
     if (version == 4) { while (true) { char ch; if (!take(&ch, 1)) return fail("unexpected end of stream"); if (!ch) break; } }
     uint64_t vertex_count = 0, face_count = 0;
     if (!take(&vertex_count, 8) || !take(&face_count, 8)) return fail("unexpected end of stream");

@@ -118,7 +118,7 @@ void har_mesh_free(HarMeshData *m) {
  * det(to_world) < 0 XOR flip_normals; normals missing from the file are regenerated AFTERWARDS, from the transformed positions
  * and the final winding (Mesh::pack, mesh.cpp:573-582,618-619), one per surface point when `position_index` splits vertices. */
 int har_mesh_finalize(std::vector<float> &V, std::vector<uint32_t> &F, bool stored_normals, bool regenerate, const float *to_world32,
-                      bool flip_normals, const std::vector<uint32_t> *position_index, uint32_t position_count) {
+                      bool flip_normals, const std::vector<uint32_t> *position_index, uint32_t position_count, bool packed_records) {
     const size_t nv = V.size() / 8, nf = F.size() / 4;
     float m[3][4] = { { 1, 0, 0, 0 }, { 0, 1, 0, 0 }, { 0, 0, 1, 0 } }, it[3][3] = { { 1, 0, 0 }, { 0, 1, 0 }, { 0, 0, 1 } };
     bool transform = false;
@@ -144,8 +144,10 @@ int har_mesh_finalize(std::vector<float> &V, std::vector<uint32_t> &F, bool stor
                 q = Vec3(fma_(it[0][1], n.y, q.x), fma_(it[1][1], n.y, q.y), fma_(it[2][1], n.y, q.z));
                 n = Vec3(fma_(it[0][2], n.z, q.x), fma_(it[1][2], n.z, q.y), fma_(it[2][2], n.z, q.z));
             }
-            float il = rsqrt_(dot3(n, n));
-            if (finite_(il)) n = n * il;
+            /* packed_records (serialized v5, PackedMesh::transform_records, mesh_utils.cpp:71-76): the stored normal is kept as it is unless a transform is applied,
+             * and then dr::normalize()d without a guard; parsed files (set_vertex, :113-115) always normalise and leave zero / non-finite lengths alone */
+            if (packed_records) { if (transform) n = n * rsqrt_(dot3(n, n)); }
+            else { float il = rsqrt_(dot3(n, n)); if (finite_(il)) n = n * il; }
             if (flip_normals) n = Vec3(-n.x, -n.y, -n.z);
             r[3] = n.x; r[4] = n.y; r[5] = n.z;
         }
@@ -270,7 +272,7 @@ static int mesh_load_ply_impl(const char *filename, int face_normals, int flip_t
     if (ascii) { std::string rest; if (R.text >> rest) return fail("invalid file -- trailing content"); }
     for (size_t i = 0; i < nf; ++i) for (int c = 0; c < 3; ++c) if (F[4 * i + c] >= nv) return fail("face index out of bounds");
     const bool regenerate = !has_normals && !face_normals;       /* Mesh::from_packed -> pack(regenerate_normals = true), mesh.cpp:355-356 */
-    if (har_mesh_finalize(V, F, has_normals, regenerate, to_world, flip_normals != 0, nullptr, 0)) return 1;
+    if (har_mesh_finalize(V, F, has_normals, regenerate, to_world, flip_normals != 0, nullptr, 0, false)) return 1;
     out->vertices = (float *) malloc(std::max<size_t>(V.size(), 1) * sizeof(float));
     out->faces = (uint32_t *) malloc(std::max<size_t>(F.size(), 1) * sizeof(uint32_t));
     if (!out->vertices || !out->faces) return fail("out of memory");

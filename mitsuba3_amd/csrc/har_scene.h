@@ -12,7 +12,7 @@
 namespace har {
 
 struct DMesh    { uint32_t voff, foff, bsdf; int32_t emitter; uint32_t flags, face_count, vertex_count, pad1; };
-struct DTexture { const float *data; uint32_t w, h; };
+struct DTexture { const float *data; uint32_t w, h; uint32_t mode, pad; };      /* mode: HarTexture::mode (bit 0 nearest, bit 1 mirror, bit 2 clamp) */
 /* type 0: AreaLight on a rectangle (to_world, normal, inv_area, mesh); type 1: ConstantBackgroundEmitter
  * (src/emitters/constant.cpp): to_world[0..2] = bounding sphere centre, to_world[3] = radius, mesh = 0xffffffff; type 2: environment map
  * (DEnvmap); type 3: AreaLight on a triangle mesh: mesh, inv_area = 1 / surface area, to_world[0] / [1] = bit patterns of the offset of its
@@ -59,6 +59,7 @@ struct DSensor {
     float rf_p0, rf_p1;          /* filter parameters (HarSensor::rfilter_stddev / rfilter_param1) */
     float radius;
     float coeff[10];             /* GaussianFilter::m_coeff (LLVM branch) */
+    float ppo_x, ppo_y;          /* scaled principal point offset: film size * principal_point_offset / crop size (perspective.cpp:213-214) */
 };
 
 struct SurfInt {
@@ -190,22 +191,43 @@ HAR_HD void spawn_ray_to(const SurfInt &si, Vec3 target, Vec3 &o, Vec3 &d, float
     maxt = dist * (1.f - HAR_SHADOW_EPS);
 }
 
-/* dr::Texture<Float, 2>::eval, bilinear + repeat (call site bitmap.cpp:842-850) */
+/* dr::Texture<Float, 2>::eval (call site bitmap.cpp:842-850; Dr.Jit's texture.h is NOT IN TREE -- parity unpinned): texel centres at (i + 1/2) / res; the integer
+ * texel index is wrapped by WrapMode Repeat (i mod res), Clamp (clip to [0, res - 1]) or Mirror (the image flipped every other repetition, so that index -1 is
+ * texel 0 and index res is texel res - 1); FilterMode::Nearest takes the texel under floor(uv * res), Linear blends the four around uv * res - 1/2. */
 struct TexTaps { uint32_t idx[4]; float w0x, w1x, w0y, w1y; };
+HAR_HD int32_t tex_wrap(int32_t i, int32_t n, uint32_t mode) {
+    if (mode & 4u) return i < 0 ? 0 : (i > n - 1 ? n - 1 : i);                       /* clamp */
+    const int32_t shifted = i < 0 ? i + 1 : i, div = shifted / n;                     /* truncating division, as the reference's integer divisor */
+    int32_t mod = i - div * n;
+    if (mod < 0) mod += n;
+    if ((mode & 2u) && (((div & 1) == 0) == (i < 0))) mod = n - 1 - mod;              /* mirror: flip unless (even repetition) xor (negative side) */
+    return mod;
+}
 HAR_HD void tex_taps(const DTexture &T, float u, float v, TexTaps &l) {
+    const int32_t W = (int32_t) T.w, H = (int32_t) T.h;
+    if (T.mode & 1u) {                                                                 /* nearest: one texel, written as four coincident taps of weight (1, 0) */
+        const int32_t x = tex_wrap((int32_t) floorf(u * (float) T.w), W, T.mode), y = tex_wrap((int32_t) floorf(v * (float) T.h), H, T.mode);
+        l.w1x = 0.f; l.w1y = 0.f; l.w0x = 1.f; l.w0y = 1.f;
+        l.idx[0] = l.idx[1] = l.idx[2] = l.idx[3] = (uint32_t) (y * W + x);
+        return;
+    }
     float px = fma_(u, (float) T.w, -0.5f), py = fma_(v, (float) T.h, -0.5f);
     float fx = floorf(px), fy = floorf(py);
-    int32_t ix = (int32_t) fx, iy = (int32_t) fy, W = (int32_t) T.w, H = (int32_t) T.h;
+    int32_t ix = (int32_t) fx, iy = (int32_t) fy;
     l.w1x = px - fx; l.w1y = py - fy; l.w0x = 1.f - l.w1x; l.w0y = 1.f - l.w1y;
-    int32_t x0 = ix % W; if (x0 < 0) x0 += W;
-    int32_t x1 = (ix + 1) % W; if (x1 < 0) x1 += W;
-    int32_t y0 = iy % H; if (y0 < 0) y0 += H;
-    int32_t y1 = (iy + 1) % H; if (y1 < 0) y1 += H;
+    int32_t x0, x1, y0, y1;
+    if (T.mode == 0u) {                                                                /* bilinear + repeat, the defaults: the round-1 code path */
+        x0 = ix % W; if (x0 < 0) x0 += W;
+        x1 = (ix + 1) % W; if (x1 < 0) x1 += W;
+        y0 = iy % H; if (y0 < 0) y0 += H;
+        y1 = (iy + 1) % H; if (y1 < 0) y1 += H;
+    } else { x0 = tex_wrap(ix, W, T.mode); x1 = tex_wrap(ix + 1, W, T.mode); y0 = tex_wrap(iy, H, T.mode); y1 = tex_wrap(iy + 1, H, T.mode); }
     l.idx[0] = (uint32_t) (y0 * W + x0); l.idx[1] = (uint32_t) (y0 * W + x1);
     l.idx[2] = (uint32_t) (y1 * W + x0); l.idx[3] = (uint32_t) (y1 * W + x1);
 }
 HAR_HD Vec3 tex_fetch(const DTexture &T, const TexTaps &l) {
     float out[3];
+    if (T.mode & 1u) { for (int c = 0; c < 3; ++c) out[c] = T.data[3 * (size_t) l.idx[0] + c]; return Vec3(out[0], out[1], out[2]); }
     for (int c = 0; c < 3; ++c) {
         float v00 = T.data[3 * (size_t) l.idx[0] + c], v10 = T.data[3 * (size_t) l.idx[1] + c];
         float v01 = T.data[3 * (size_t) l.idx[2] + c], v11 = T.data[3 * (size_t) l.idx[3] + c];
@@ -479,6 +501,7 @@ HAR_HD float emitter_pdf_direction(const DEmitter &E, Vec3 d, Vec3 n, float dist
 HAR_HD void sensor_sample_ray(const DSensor &C, float px, float py, Vec3 &o, Vec3 &d, float &maxt) {
     const float *M = C.s2c;
     float r0 = M[3], r1 = M[7], r2 = M[11], r3 = M[15];
+    px = px + C.ppo_x; py = py + C.ppo_y;                              /* perspective.cpp:216-221 */
     r0 = fma_(M[0], px, r0); r1 = fma_(M[4], px, r1); r2 = fma_(M[8], px, r2);  r3 = fma_(M[12], px, r3);
     r0 = fma_(M[1], py, r0); r1 = fma_(M[5], py, r1); r2 = fma_(M[9], py, r2);  r3 = fma_(M[13], py, r3);
     r0 = fma_(M[2], 0.f, r0); r1 = fma_(M[6], 0.f, r1); r2 = fma_(M[10], 0.f, r2); r3 = fma_(M[14], 0.f, r3);

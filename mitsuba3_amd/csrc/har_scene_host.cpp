@@ -226,7 +226,8 @@ bool lower_scene(const HarSceneDesc &d, HostScene &hs, std::string &err) {
     for (uint32_t i = 0; i < d.texture_count; ++i) {
         const HarTexture &t = d.textures[i];
         if (!t.data || !t.width || !t.height) { err = "empty texture"; return false; }
-        HostTexture ht; ht.w = t.width; ht.h = t.height; ht.data.assign(t.data, t.data + 3 * (size_t) t.width * t.height);
+        if ((t.mode & ~7u) != 0u || (t.mode & 6u) == 6u) { err = "HarTexture::mode: HAR_TEX_BILINEAR / _NEAREST combined with HAR_TEX_REPEAT / _MIRROR / _CLAMP"; return false; }
+        HostTexture ht; ht.w = t.width; ht.h = t.height; ht.mode = t.mode; ht.data.assign(t.data, t.data + 3 * (size_t) t.width * t.height);
         hs.textures.push_back(std::move(ht));
     }
     for (uint32_t i = 0; i < d.bsdf_count; ++i) {
@@ -408,6 +409,8 @@ bool lower_sensor(const HarSensor &in, DSensor &out, std::string &err) {
     out.rfilter = in.rfilter;
     std::memset(out.coeff, 0, sizeof(out.coeff));
     out.rf_p0 = in.rfilter_stddev; out.rf_p1 = in.rfilter_param1;
+    out.ppo_x = (float) in.film_width * in.principal_point_offset_x / (float) in.crop_width;
+    out.ppo_y = (float) in.film_height * in.principal_point_offset_y / (float) in.crop_height;
     if (!lower_sensor_filter(in, out, err)) return false;
     /* ReconstructionFilter::init_discretization (rfilter.cpp:22): border_size = ceil(radius - 1/2 - 2 RayEpsilon) */
     out.border = in.sample_border ? (uint32_t) std::max(0, (int) std::ceil(out.radius - .5f - 2.f * HAR_RAY_EPS)) : 0u;

@@ -9,7 +9,7 @@
 
 namespace har {
 
-struct HostTexture { std::vector<float> data; uint32_t w, h; };
+struct HostTexture { std::vector<float> data; uint32_t w, h, mode = 0; };
 
 struct HostScene {
     std::vector<float> verts;

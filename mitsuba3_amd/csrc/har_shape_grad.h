@@ -93,6 +93,7 @@ HAR_HD void shape_vertex_adjoint(const ShapeVertex &v, Vec3 g[3]) {
 /* d rho_c / d (u, v) of the bilinear lookup whose taps are `l` */
 HAR_HD void tex_fetch_grad(const DTexture &T, const TexTaps &l, Vec3 &d_du, Vec3 &d_dv) {
     float du[3], dv[3];
+    if (T.mode & 1u) { d_du = Vec3(0.f); d_dv = Vec3(0.f); return; }       /* FilterMode::Nearest: piecewise constant in uv */
     for (int c = 0; c < 3; ++c) {
         const float v00 = T.data[3 * (size_t) l.idx[0] + c], v10 = T.data[3 * (size_t) l.idx[1] + c];
         const float v01 = T.data[3 * (size_t) l.idx[2] + c], v11 = T.data[3 * (size_t) l.idx[3] + c];

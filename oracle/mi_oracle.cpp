@@ -43,7 +43,7 @@ struct Bvh {
     float lo[3], hi[3];
     bool empty() const { return tris.empty(); }
 };
-struct Texture { std::vector<float> data; uint32_t w, h; };
+struct Texture { std::vector<float> data; uint32_t w, h, mode = 0; };
 
 struct Scene {
     std::vector<Mesh> meshes; uint32_t top_count;
@@ -338,21 +338,36 @@ static inline Ray spawn_ray_to(const SI &si, V3 t) {
 // ---------------------------------------------------------------------------
 
 struct TexLookup { uint32_t idx[4]; float w[4]; };
-/* dr::Texture<Float,2>::eval, bilinear + repeat (ext/drjit texture.h, NOT IN TREE,
- * parity unpinned; call site src/textures/bitmap.cpp:842-850) */
+/* dr::Texture<Float,2>::eval (ext/drjit texture.h, NOT IN TREE, parity unpinned; call site src/textures/bitmap.cpp:842-850).  Restated from Dr.Jit's published
+ * behaviour: WrapMode::Repeat / Mirror / Clamp act on the INTEGER texel position -- repeat: pos mod res; mirror: the texture is flipped in every other
+ * repetition (counting repetitions of negative positions from -1); clamp: clip to [0, res - 1] -- and FilterMode::Nearest reads the texel under floor(uv * res),
+ * Linear interpolates the four texels around uv * res - 1/2. */
+static inline uint32_t tex_wrap_pos(int64_t pos, int64_t res, uint32_t mode) {
+    if (mode & 4u) return (uint32_t) std::min<int64_t>(std::max<int64_t>(pos, 0), res - 1);
+    /* repetition index r (floor division) and offset m in [0, res) */
+    int64_t r = pos >= 0 ? pos / res : -((-pos - 1) / res) - 1, m = pos - r * res;
+    if ((mode & 2u) && (r & 1)) m = res - 1 - m;                                   /* odd repetitions (.. -3, -1, 1, 3 ..) run backwards */
+    return (uint32_t) m;
+}
 static inline void tex_lookup(const Texture &t, const float uv[2], TexLookup &l) {
+    if (t.mode & 1u) {
+        int64_t x = (int64_t) std::floor(uv[0] * (float) t.w), y = (int64_t) std::floor(uv[1] * (float) t.h);
+        uint32_t i = tex_wrap_pos(y, t.h, t.mode) * t.w + tex_wrap_pos(x, t.w, t.mode);
+        l.idx[0] = l.idx[1] = l.idx[2] = l.idx[3] = i; l.w[0] = 1.f; l.w[1] = 0.f; l.w[2] = 1.f; l.w[3] = 0.f;
+        return;
+    }
     float px = fmadd(uv[0], (float) t.w, -0.5f), py = fmadd(uv[1], (float) t.h, -0.5f);
     float fx = std::floor(px), fy = std::floor(py);
-    int32_t ix = (int32_t) fx, iy = (int32_t) fy;
+    int64_t ix = (int64_t) fx, iy = (int64_t) fy;
     float w1x = px - fx, w1y = py - fy, w0x = 1.f - w1x, w0y = 1.f - w1y;
-    auto wrap = [](int32_t i, int32_t n) { int32_t r = i % n; return (uint32_t) (r < 0 ? r + n : r); };
-    uint32_t x0 = wrap(ix, (int32_t) t.w), x1 = wrap(ix + 1, (int32_t) t.w);
-    uint32_t y0 = wrap(iy, (int32_t) t.h), y1 = wrap(iy + 1, (int32_t) t.h);
+    uint32_t x0 = tex_wrap_pos(ix, t.w, t.mode), x1 = tex_wrap_pos(ix + 1, t.w, t.mode);
+    uint32_t y0 = tex_wrap_pos(iy, t.h, t.mode), y1 = tex_wrap_pos(iy + 1, t.h, t.mode);
     l.idx[0] = y0 * t.w + x0; l.idx[1] = y0 * t.w + x1; l.idx[2] = y1 * t.w + x0; l.idx[3] = y1 * t.w + x1;
     l.w[0] = w0x; l.w[1] = w1x; l.w[2] = w0y; l.w[3] = w1y;
 }
 static inline V3 tex_eval(const Texture &t, const TexLookup &l) {
     float out[3];
+    if (t.mode & 1u) return V3(t.data[3 * (size_t) l.idx[0]], t.data[3 * (size_t) l.idx[0] + 1], t.data[3 * (size_t) l.idx[0] + 2]);
     for (int c = 0; c < 3; ++c) {
         float v00 = t.data[3 * (size_t) l.idx[0] + c], v10 = t.data[3 * (size_t) l.idx[1] + c],
               v01 = t.data[3 * (size_t) l.idx[2] + c], v11 = t.data[3 * (size_t) l.idx[3] + c];
@@ -537,7 +552,9 @@ static inline Ray sensor_sample_ray(const OrcSensor &s, float px, float py) {
     const float *M = s.sample_to_camera;
     float r[4];
     for (int i = 0; i < 4; ++i) r[i] = M[4 * i + 3];
-    float arg[3] = { px, py, 0.f };
+    /* scaled_principal_point_offset = film size * offset / crop size, added to the position sample (perspective.cpp:213-221) */
+    const float sppx = (float) s.film_width * s.principal_point_offset_x / (float) s.crop_width, sppy = (float) s.film_height * s.principal_point_offset_y / (float) s.crop_height;
+    float arg[3] = { px + sppx, py + sppy, 0.f };
     for (int j = 0; j < 3; ++j) for (int i = 0; i < 4; ++i) r[i] = fmadd(M[4 * i + j], arg[j], r[i]);   // transform.h:337-345
     float iw = rcp(r[3]);
     V3 near_p(r[0] * iw, r[1] * iw, r[2] * iw);
@@ -867,6 +884,7 @@ static AttachedSI attach_si(const Scene &sc, const Ray &ray, const PI &pi, const
 
 /* bilinear, repeat-wrapped texture lookup (tex_lookup / tex_eval above) as a function of attached texture coordinates */
 static inline Dn3 tex_eval_dual(const Texture &t, const TexLookup &l, const Dn uv[2]) {
+    if (t.mode & 1u) return Dn3(Dn((double) t.data[3 * (size_t) l.idx[0]]), Dn((double) t.data[3 * (size_t) l.idx[0] + 1]), Dn((double) t.data[3 * (size_t) l.idx[0] + 2]));     /* nearest: constant in uv */
     Dn px = uv[0] * (double) t.w - Dn(0.5), py = uv[1] * (double) t.h - Dn(0.5);
     Dn w1x = replace_grad((double) l.w[1], px), w1y = replace_grad((double) l.w[3], py), w0x = Dn(1.0) - w1x, w0y = Dn(1.0) - w1y;
     Dn out[3];
@@ -1678,7 +1696,7 @@ void *orc_scene_create(const OrcSceneDesc *d) {
     sc->instances.assign(d->instances, d->instances + d->instance_count);
     for (uint32_t i = 0; i < d->bsdf_count; ++i) { BsdfRecord r; r.p = d->bsdfs[i]; if (!(r.p.flags & 1u)) r.p.back = -1; sc->bsdfs.push_back(r); }
     for (uint32_t i = 0; i < d->texture_count; ++i) {
-        Texture t; t.w = d->textures[i].width; t.h = d->textures[i].height;
+        Texture t; t.w = d->textures[i].width; t.h = d->textures[i].height; t.mode = d->textures[i].mode;
         t.data.assign(d->textures[i].data, d->textures[i].data + 3 * (size_t) t.w * t.h);
         sc->textures.push_back(std::move(t));
     }

@@ -69,8 +69,9 @@ typedef struct OrcBSDF {
     int32_t  back;
 } OrcBSDF;
 
-/* bitmap texture, H x W x 3 f32, bilinear + repeat (src/textures/bitmap.cpp:175-206) */
-typedef struct OrcTexture { const float *data; uint32_t width, height; } OrcTexture;
+/* bitmap texture, H x W x 3 f32 (src/textures/bitmap.cpp:175-206); mode: bit 0 filter_type nearest (else bilinear), bits 1-2 wrap_mode 0 repeat / 2 mirror / 4 clamp
+ * (field for field HarTexture) */
+typedef struct OrcTexture { const float *data; uint32_t width, height; uint32_t mode, reserved; } OrcTexture;
 
 typedef struct OrcEmitter {
     uint32_t type;        /* 0 = area light on a rectangle, 1 = constant environment (src/emitters/constant.cpp; radiance only),
@@ -106,6 +107,7 @@ typedef struct OrcSensor {
     float    rfilter_stddev;      /* parameter 0: gaussian stddev, tent radius, mitchell B, lanczos lobes */
     float    rfilter_param1;      /* parameter 1: mitchell C */
     uint32_t sample_border;       /* Film::sample_border (film.cpp:29-32): render() samples crop_size + 2 * rfilter->border_size() pixels (integrator.cpp:162-165) */
+    float    principal_point_offset_x, principal_point_offset_y;   /* perspective.cpp:147-150,213-221 */
 } OrcSensor;
 
 typedef struct OrcStats {

@@ -38,7 +38,7 @@ class BSDF(C.Structure):
 
 
 class Texture(C.Structure):
-    _fields_ = [("data", c_f32p), ("width", C.c_uint32), ("height", C.c_uint32)]
+    _fields_ = [("data", c_f32p), ("width", C.c_uint32), ("height", C.c_uint32), ("mode", C.c_uint32), ("reserved", C.c_uint32)]
 
 
 class Emitter(C.Structure):
@@ -62,7 +62,7 @@ class Sensor(C.Structure):
                 ("crop_offset_x", C.c_uint32), ("crop_offset_y", C.c_uint32),
                 ("crop_width", C.c_uint32), ("crop_height", C.c_uint32),
                 ("rfilter", C.c_uint32), ("rfilter_stddev", C.c_float), ("rfilter_param1", C.c_float),
-                ("sample_border", C.c_uint32)]
+                ("sample_border", C.c_uint32), ("principal_point_offset_x", C.c_float), ("principal_point_offset_y", C.c_float)]
 
 
 class Stats(C.Structure):
@@ -282,6 +282,7 @@ class SceneData:
         self.instances = []  # (group, to_world12, to_object12)
         self.bsdfs = []      # (type, texture, rgb)
         self.textures = []   # HxWx3 float32
+        self.texture_modes = []   # per texture: filter_type | wrap_mode (OrcTexture::mode), default 0 = bilinear + repeat
         self.emitters = []   # dict(mesh, radiance, to_world12, normal, inv_area)
         self._keep = []
 
@@ -320,7 +321,7 @@ class SceneData:
             bsdfs[i].back = int(x.get("back", -1))
         texs = (TX * max(1, len(self.textures)))()
         for i, t in enumerate(self.textures):
-            texs[i].data = fp(t); texs[i].height = t.shape[0]; texs[i].width = t.shape[1]
+            texs[i].data = fp(t); texs[i].height = t.shape[0]; texs[i].width = t.shape[1]; texs[i].mode = self.texture_modes[i] if i < len(self.texture_modes) else 0
         ems = (E * max(1, len(self.emitters)))()
         for i, e in enumerate(self.emitters):
             ems[i].type = int(e.get("type", 0)); ems[i].mesh = e["mesh"]
@@ -755,7 +756,7 @@ def scene_from_product(scene):
     sd.bsdfs = [(types[b.kind], b.tex_index if b.texture is not None else -1, b.value,
                  dict(flags=b.flags, reflectance2=b.value2, alpha_u=b.alpha_u, alpha_v=b.alpha_v, eta=b.eta, eta_c=b.eta_c, k_c=b.k_c,
                       back=b.back.index if b.back is not None else -1)) for b in scene.bsdf_objs]
-    sd.textures = list(scene.textures); sd.emitters = list(scene.emitters)
+    sd.textures = list(scene.textures); sd.texture_modes = list(getattr(scene, 'texture_modes', [])); sd.emitters = list(scene.emitters)
     s = Sensor()
     C.memmove(C.byref(s), C.byref(scene.sensors()[0].har), C.sizeof(s))
     return OracleScene(sd), s

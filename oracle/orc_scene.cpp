@@ -185,6 +185,7 @@ void orc_perspective_sensor(const float to_world[32], double fov, const char *fo
     out->film_width = width; out->film_height = height;
     out->crop_offset_x = cx; out->crop_offset_y = cy; out->crop_width = cw; out->crop_height = ch;
     out->rfilter = rfilter; out->rfilter_stddev = stddev; out->rfilter_param1 = 1.f / 3.f;
+    out->principal_point_offset_x = 0.f; out->principal_point_offset_y = 0.f;
 }
 
 void orc_rectangle(const float to_world[32], float *vertices, uint32_t *faces, float normal[3], float *inv_area) {

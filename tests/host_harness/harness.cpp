@@ -35,7 +35,7 @@ struct HScene {
 static void bind(HScene &H) {
     HostScene &hs = H.hs;
     H.dtex.clear();
-    for (auto &t : hs.textures) H.dtex.push_back(DTexture{ t.data.data(), t.w, t.h });
+    for (auto &t : hs.textures) H.dtex.push_back(DTexture{ t.data.data(), t.w, t.h, t.mode, 0u });
     DScene &S = H.ds;
     S.accel.nodes = hs.nodes.data(); S.accel.tris = hs.tris.data(); S.accel.insts = hs.inst_recs.data();
     S.accel.root = hs.root; S.accel.has_tlas = hs.has_tlas; S.accel.n_tris = (uint32_t) hs.tris.size(); S.accel.n_insts = (uint32_t) hs.inst_recs.size();

@@ -362,6 +362,48 @@ def test_bitmap_bilinear_repeat_vs_numpy(mi, O, H):
             assert np.allclose(got, want, rtol=2e-5, atol=2e-6), (which, u, v, got, want)
 
 
+@pytest.mark.parametrize("filter_type", ["bilinear", "nearest"])
+@pytest.mark.parametrize("wrap_mode", ["repeat", "mirror", "clamp"])
+def test_bitmap_filter_and_wrap_modes_vs_numpy(mi, O, H, filter_type, wrap_mode):
+    """BitmapTexture `filter_type` / `wrap_mode` (src/textures/bitmap.cpp:182-206 -> dr::FilterMode / dr::WrapMode): oracle and host-compiled product against an
+    independent NumPy lookup built on np.pad ('wrap' = repeat, 'symmetric' = mirror: the edge texel repeats, 'edge' = clamp), uv far outside [0, 1]"""
+    rng = np.random.default_rng(31)
+    Hh, Ww, R = 4, 5, 6                         # R repetitions of padding on every side
+    tex = rng.uniform(0.1, 0.9, (Hh, Ww, 3)).astype(np.float32)
+    P = Pair(mi, O, H, {"type": "diffuse", "reflectance": {"type": "bitmap", "data": tex, "raw": True, "filter_type": filter_type, "wrap_mode": wrap_mode}})
+    assert P.scene.texture_modes == [(1 if filter_type == "nearest" else 0) | {"repeat": 0, "mirror": 2, "clamp": 4}[wrap_mode]]
+    sd = O.SceneData(); b = P.scene.bsdf_objs[P.index]
+    sd.bsdfs = [(0, 0, b.value, dict(flags=b.flags, reflectance2=b.value2, alpha_u=b.alpha_u, alpha_v=b.alpha_v, eta=b.eta, eta_c=b.eta_c, k_c=b.k_c, back=-1))]
+    sd.textures = [tex]; sd.texture_modes = list(P.scene.texture_modes)
+    osc = O.OracleScene(sd)
+    big = np.pad(tex, ((R * Hh, R * Hh), (R * Ww, R * Ww), (0, 0)), mode={"repeat": "wrap", "mirror": "symmetric", "clamp": "edge"}[wrap_mode]).astype(np.float64)
+
+    def numpy_lookup(u, v):
+        t = lambda x, y: big[y + R * Hh, x + R * Ww]
+        if filter_type == "nearest":
+            return t(int(np.floor(np.float32(u) * np.float32(Ww))), int(np.floor(np.float32(v) * np.float32(Hh))))
+        px, py = np.float32(u) * Ww - np.float32(0.5), np.float32(v) * Hh - np.float32(0.5)
+        x0, y0 = int(np.floor(px)), int(np.floor(py)); fx, fy = float(px - x0), float(py - y0)
+        return (1 - fy) * ((1 - fx) * t(x0, y0) + fx * t(x0 + 1, y0)) + fy * ((1 - fx) * t(x0, y0 + 1) + fx * t(x0 + 1, y0 + 1))
+
+    wi = O.f32([0.2, -0.1, 0.9]); wo = O.f32([-0.3, 0.2, 0.8]); wo /= np.linalg.norm(wo)
+    uvs = [(0.5 / Ww, 0.5 / Hh), (0.0, 0.0), (1.0, 1.0), (-0.001, 1.001), (-1.0, 2.0), (-0.25, 2.75), (3.9, -1.4), (-4.99, 4.99), ((Ww - 0.5) / Ww, (Hh - 0.5) / Hh)]
+    uvs += [tuple(rng.uniform(-5, 6, 2)) for _ in range(300)]
+    for u, v in uvs:
+        uv = O.f32([u, v]); want = numpy_lookup(u, v)
+        for which in ("oracle", "product"):
+            val = np.empty(3, np.float32); pdf = C.c_float()
+            if which == "oracle":
+                O.lib().orc_bsdf_eval_pdf(osc.handle, 0, O.fp(wi), O.fp(uv), O.fp(wo), O.fp(val), C.byref(pdf))
+            else:
+                H.hh_bsdf_eval_pdf(P.h, P.index, O.fp(wi), O.fp(uv), O.fp(wo), O.fp(val), C.byref(pdf))
+            got = val.astype(np.float64) * np.pi / float(wo[2])
+            assert np.allclose(got, want, rtol=2e-5, atol=2e-6), (which, filter_type, wrap_mode, u, v, got, want)
+    for bad in ({"filter_type": "trilinear"}, {"wrap_mode": "border"}):
+        with pytest.raises(RuntimeError, match="Invalid"):
+            mi.load_dict({"type": "diffuse", "reflectance": {"type": "bitmap", "data": tex, **bad}})
+
+
 def test_reference_gauss_legendre_known_answers(O, H):
     """src/core/tests/test_quad.py:16-22 (test02_gauss_legendre) for the rule behind rough plastic's transmittance tables (quad.h:27-90), oracle and
     product host code; plus NumPy's leggauss at the table resolution"""

@@ -375,6 +375,43 @@ def test_sample_border_host_pipeline_matches_oracle(mi, O, H, rf, crop):
         assert abs(ref[inner][..., 3].mean() / plain[inner][..., 3].mean() - 1) < 0.05      # interior weights: same density of samples
 
 
+def test_principal_point_offset_host_pipeline_and_meaning(mi, O, H):
+    """PerspectiveCamera `principal_point_offset_x / _y` (src/sensors/perspective.cpp:147-150, 213-221): sample_ray adds film_size * offset / crop_size to the film
+    position.  Product (host build of the kernels' headers) vs oracle on a render; and what the property means: an offset of k / film_width is the picture of
+    the crop window moved by k pixels"""
+    res, spp = 32, 4
+    def scene_with(ppo, crop):
+        d = mi.cornell_box(); f = d["sensor"]["film"]; f["width"] = res; f["height"] = res; f["rfilter"] = {"type": "box"}
+        f["crop_offset_x"], f["crop_offset_y"], f["crop_width"], f["crop_height"] = crop
+        d["sensor"]["principal_point_offset_x"], d["sensor"]["principal_point_offset_y"] = ppo
+        return mi.load_dict(d)
+    scene = scene_with((3 / res, -2 / res), (6, 8, 16, 12))
+    osc, sensor = oracle_scene_from(O, scene)
+    assert np.isclose(sensor.principal_point_offset_x, 3 / res) and np.isclose(sensor.principal_point_offset_y, -2 / res)
+    hnd = _harness_scene(H, scene)
+    film = np.zeros((12, 16, 4), np.float32)
+    assert H.hh_render(hnd, C.byref(sensor), 0, 5, spp, 8, 5, 0, 0, O.fp(film)) == 0
+    ref, _ = osc.render_path(sensor, seed=5, spp=spp, max_depth=8, raw=True, threads=2)
+    assert rel_l2(film, ref) < 1e-6
+    H.hh_scene_destroy(hnd)
+    # the same rays as the window moved by (+3, -2) pixels without an offset
+    n = 4000
+    p = np.random.default_rng(3).uniform(0, 1, (2, n)).astype(np.float32)
+    moved = scene_with((0.0, 0.0), (9, 6, 16, 12))
+    _, s2 = oracle_scene_from(O, moved)
+    rays = []
+    for sn in (sensor, s2):
+        o = np.empty((3, n), np.float32); dd = np.empty((3, n), np.float32); mt = np.empty(n, np.float32)
+        O.lib().orc_sensor_sample_ray(C.byref(sn), n, O.fp(np.ascontiguousarray(p[0])), O.fp(np.ascontiguousarray(p[1])), O.fp(o), O.fp(dd), O.fp(mt))
+        rays.append((o, dd, mt))
+    assert np.allclose(rays[0][1], rays[1][1], atol=2e-6) and np.allclose(rays[0][0], rays[1][0], atol=2e-6) and np.allclose(rays[0][2], rays[1][2], rtol=1e-5)
+    plain = scene_with((0.0, 0.0), (6, 8, 16, 12))
+    _, s3 = oracle_scene_from(O, plain)
+    o3 = np.empty((3, n), np.float32); d3 = np.empty((3, n), np.float32); m3 = np.empty(n, np.float32)
+    O.lib().orc_sensor_sample_ray(C.byref(s3), n, O.fp(np.ascontiguousarray(p[0])), O.fp(np.ascontiguousarray(p[1])), O.fp(o3), O.fp(d3), O.fp(m3))
+    assert np.abs(d3 - rays[0][1]).max() > 1e-2                      # the offset does something
+
+
 def test_elementary_functions_accuracy_and_host_device_agreement(O):
     """dr::exp / log / erf / atan2 / acos / tan (Dr.Jit, NOT IN TREE): the oracle's Cephes-style restatements (orc_math.h) against double
     precision, and the product's own versions (har_math.h, compiled for the host) against the oracle's BIT FOR BIT -- they are written

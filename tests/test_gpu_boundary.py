@@ -110,10 +110,12 @@ def test_compute_surface_interaction_vs_oracle(mi, O):
 
 def test_sensor_sample_ray_vs_oracle(mi, O):
     """PerspectiveCamera::sample_ray (src/sensors/perspective.cpp:194-245) through har_sensor_sample_ray, full and cropped films"""
-    for crop in (None, (5, 9, 20, 17)):
+    for crop, ppo in ((None, None), ((5, 9, 20, 17), None), ((5, 9, 20, 17), (0.1, -0.05)), (None, (-0.2, 0.3))):
         d = mi.cornell_box(); f = d["sensor"]["film"]; f["width"] = 40; f["height"] = 30
         if crop:
             f["crop_offset_x"], f["crop_offset_y"], f["crop_width"], f["crop_height"] = crop
+        if ppo:                                            # principal_point_offset_x / _y (perspective.cpp:147-150, 213-221)
+            d["sensor"]["principal_point_offset_x"], d["sensor"]["principal_point_offset_y"] = ppo
         scene = mi.load_dict(d)
         _, sensor = O.scene_from_product(scene)
         n = 5000

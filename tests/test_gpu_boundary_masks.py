@@ -178,3 +178,29 @@ def test_integrator_sample_mask_vs_oracle(mi, O, kind):
         s2 = mi.Sampler({"sample_count": 4, "seed": 2}); s2.seed(1, n)
         full, _ = scene.integrator().sample(scene, s2, mi.Ray3f(o, dd, maxt))
         assert np.array_equal(full.cpu().numpy()[:, active], spec[:, active]), name
+
+
+@pytest.mark.parametrize("mode", [("nearest", "repeat"), ("bilinear", "clamp"), ("bilinear", "mirror"), ("nearest", "mirror")])
+def test_bitmap_filter_and_wrap_modes_render_and_gradient(mi, O, mode):
+    """BitmapTexture filter_type / wrap_mode (src/textures/bitmap.cpp:182-206) in the kernels: a textured Cornell box whose `white` texture is looked up far outside
+    [0, 1] (uv scaled by the mesh's texcoords are in [0, 1]; the texture's own `to_uv` is not part of this path, so the test scales the texcoords of the floor) --
+    forward image and PRB texel gradients (direct atomics: the band queues serve bilinear + repeat only) vs the oracle"""
+    d = mi.textured_cornell_box(res=40, tex_res=8, spp=16)
+    tex = np.random.default_rng(6).uniform(0.2, 0.9, (8, 6, 3)).astype(np.float32)
+    d["white"]["reflectance"] = {"type": "bitmap", "data": tex, "raw": True, "filter_type": mode[0], "wrap_mode": mode[1]}
+    scene = mi.load_dict(d)
+    # stretch the texture coordinates of every mesh that carries `white` to [-1.5, 2.5]^2 so that the wrap mode matters
+    for m in scene.meshes:
+        if scene.bsdf_objs[m["bsdf"]].id == "white":
+            m["V"][:, 6:8] = m["V"][:, 6:8] * 4.0 - 1.5
+    scene._h = None                                     # re-lower with the edited records
+    osc, sensor = O.scene_from_product(scene)
+    img = mi.render(scene, spp=16, seed=3).cpu().numpy()
+    ref, _ = osc.render_prb(sensor, seed=3, spp=16, max_depth=6)
+    assert rel_l2(img, ref) < 1e-4, mode
+    grad_in = np.random.default_rng(2).uniform(0.5, 1.5, (40, 40, 3)).astype(np.float32)
+    grads = scene.integrator().render_backward(scene, None, grad_in, seed=9, spp=16)
+    g_refl, g_tex, _ = osc.render_prb_backward(sensor, grad_in, seed=9, spp=16, max_depth=6)
+    got = grads["white.reflectance.data"].cpu().numpy()
+    assert got.shape == tex.shape and np.abs(g_tex[0]).max() > 0
+    assert rel_l2(got, g_tex[0]) < 1e-3, mode

@@ -267,6 +267,85 @@ def test_serialized_variants(mi, tmp_path, version):
     assert blob["V"].shape[0] == len(P2) and np.allclose(blob["V"][:, :3], P2 * 0.2, atol=1e-7)
 
 
+def serialized_v5_blob(V, F, layout, name="mesh", face_normals_flag=False, pidx=None, pcount=0, nidx=None, ncount=0, attrs=(), single=True):
+    """Mesh::write_serialized (src/render/mesh.cpp:1091-1148): magic, version 5, then ONE zlib stream: flags, length-prefixed name, four u64 counts, the packed
+    vertex (8 x f32) and face (4 x u32) records verbatim, the optional index maps, the attributes"""
+    flags = (0x1000 if single else 0) | layout | (0x10 if face_normals_flag else 0)
+    payload = struct.pack("<I", flags) + struct.pack("<I", len(name)) + name.encode()
+    payload += struct.pack("<QQQQ", len(V), len(F), pcount, ncount) + np.asarray(V, "<f4").tobytes() + np.asarray(F, "<u4").tobytes()
+    if pcount: payload += np.asarray(pidx, "<u4").tobytes()
+    if ncount: payload += np.asarray(nidx, "<u4").tobytes()
+    payload += struct.pack("<I", len(attrs))
+    for an, dim, data in attrs:
+        payload += struct.pack("<I", len(an)) + an.encode() + struct.pack("<BI", 0, dim) + np.asarray(data, "<f4").tobytes()
+    return struct.pack("<HH", 0x041C, 5) + zlib.compress(payload)
+
+
+def test_serialized_version_5(mi, tmp_path):
+    """SerializedMesh::load_v5 (src/shapes/serialized.cpp:393-450): the packed records go in as they are; to_world / flip_normals are applied afterwards
+    (PackedMesh::transform_records, mesh_utils.cpp:46-99); index maps and attributes are read past; the stored FaceNormals flag applies when the property is unset"""
+    P, F, N, UV = grid_mesh(5)
+    V = np.zeros((len(P), 8), np.float32); V[:, :3] = P; V[:, 3:6] = N * 1.5; V[:, 6:8] = UV           # un-normalised normals: records are NOT renormalised without a transform
+    F4 = np.zeros((len(F), 4), np.uint32); F4[:, :3] = F; F4[:, 3] = 7
+    path = os.path.join(tmp_path, "v5.serialized")
+    attrs = [("vertex_color", 3, np.ones((len(P), 3), np.float32)), ("face_id", 1, np.arange(len(F), dtype=np.float32))]
+    pidx = np.arange(len(P), dtype=np.uint32)
+    blobs = [serialized_v5_blob(V, F4, 1 | 4, attrs=attrs),                                           # normals + texcoords + attributes
+             serialized_v5_blob(V, F4, 4, pidx=pidx // 2 * 0 + np.minimum(pidx, len(P) - 1), pcount=len(P)),   # no normals: regenerated; an (identity) position map
+             serialized_v5_blob(V, F4, 1 | 4, face_normals_flag=True)]                                 # stored face_normals flag
+    write_serialized(path, 4, blobs)          # the sub-mesh directory of a v5 file has the 64-bit offsets of v4 (serialized.cpp:283-290)
+    m = mi.core.Mesh("t").from_serialized(path)
+    assert np.array_equal(m.V, V) and np.array_equal(m.F, F4) and m.flags == 3
+    m = mi.core.Mesh("t").from_serialized(path, shape_index=1)
+    assert np.array_equal(m.V[:, :3], P) and np.allclose(m.V[:, 3:6], numpy_normals(P, F), atol=2e-6) and m.flags == 3 and np.array_equal(m.V[:, 6:8], UV)
+    m = mi.core.Mesh("t").from_serialized(path, shape_index=2)                                      # property unset: the file's flag decides
+    assert m.flags == 2 and not m.V[:, 3:6].any()
+    m = mi.core.Mesh("t").from_serialized(path, shape_index=2, face_normals=False)                  # ... an explicit property wins
+    assert m.flags == 3 and np.array_equal(m.V[:, 3:6], V[:, 3:6])
+    m = mi.core.Mesh("t").from_serialized(path, shape_index=0, face_normals=True)
+    assert m.flags == 2 and not m.V[:, 3:6].any()
+    # to_world with a negative determinant + flip_normals: positions M p, normals -normalize(M^-T n), winding reversed iff (det < 0) != flip
+    T = mi.ScalarTransform4f().translate([0.5, -1, 2]).scale([2, -1, 0.5])
+    m = mi.core.Mesh("t").from_serialized(path, to_world=T, flip_normals=True)
+    M = np.asarray(T.matrix if not callable(getattr(T, "matrix", None)) else T.matrix(), np.float64).reshape(4, 4)
+    assert np.allclose(m.V[:, :3], P @ M[:3, :3].T + M[:3, 3], atol=1e-6)
+    n = (N * 1.5) @ np.linalg.inv(M[:3, :3]); n /= np.linalg.norm(n, axis=1, keepdims=True)
+    assert np.allclose(m.V[:, 3:6], -n, atol=1e-6) and np.array_equal(m.F[:, :3], F4[:, :3])          # det < 0 and flip: no reversal
+    m = mi.core.Mesh("t").from_serialized(path, to_world=T)
+    assert np.array_equal(m.F[:, :3], F4[:, [2, 1, 0]]) and np.allclose(m.V[:, 3:6], n, atol=1e-6)
+    # a Tangents layout stores the frame as modified Rodrigues parameters (mesh_utils.h:59-117): the product keeps its normal
+    def frame_encode(nn, ss):
+        tt = np.cross(nn, ss); R = np.stack([ss, tt, nn], axis=1)
+        from scipy.spatial.transform import Rotation
+        q = Rotation.from_matrix(R).as_quat()            # x, y, z, w
+        w = q[3]; return q[:3] / (1 + abs(w)) * (1 if w >= 0 else -1)
+    Vt = V.copy(); rng = np.random.default_rng(1)
+    nn = rng.normal(size=(len(P), 3)); nn /= np.linalg.norm(nn, axis=1, keepdims=True)
+    ss = np.cross(nn, rng.normal(size=(len(P), 3))); ss /= np.linalg.norm(ss, axis=1, keepdims=True)
+    Vt[:, 3:6] = np.stack([frame_encode(a, b) for a, b in zip(nn, ss)])
+    with open(path, "wb") as f: f.write(serialized_v5_blob(Vt, F4, 1 | 2 | 4))
+    m = mi.core.Mesh("t").from_serialized(path)
+    assert np.allclose(m.V[:, 3:6], nn, atol=2e-6)
+    # errors of load_v5
+    def load(blob, **kw):
+        with open(path, "wb") as f: f.write(blob)
+        return mi.core.Mesh("t").from_serialized(path, **kw)
+    with pytest.raises(RuntimeError, match="single precision"): load(serialized_v5_blob(V, F4, 1, single=False))
+    with pytest.raises(RuntimeError, match="invalid serialized mesh header"): load(serialized_v5_blob(V, F4, 2 | 4))                   # tangents without normals
+    with pytest.raises(RuntimeError, match="invalid serialized mesh header"): load(serialized_v5_blob(V, F4, 1, pidx=pidx, pcount=len(P) + 1))
+    with pytest.raises(RuntimeError, match="FaceBSDFs"): load(serialized_v5_blob(V, F4, 1 | 8))
+    bad = F4.copy(); bad[0, 1] = 10 ** 6
+    with pytest.raises(RuntimeError, match="out of bounds"): load(serialized_v5_blob(V, bad, 1))
+    with pytest.raises(RuntimeError, match="end of stream"): load(struct.pack("<HH", 0x041C, 5) + zlib.compress(struct.pack("<II", 0x1001, 1) + b"x" + struct.pack("<QQQQ", 50, 1, 0, 0)))
+    # scene plugin
+    d = mi.cornell_box()
+    with open(path, "wb") as f: f.write(serialized_v5_blob(V, F4, 1 | 4))
+    d["blob"] = {"type": "serialized", "filename": path, "to_world": mi.ScalarTransform4f().scale(0.2), "bsdf": {"type": "ref", "id": "red"}}
+    scene = mi.load_dict(d)
+    blob = [x for x in scene.meshes if x["key"] == "blob"][0]
+    assert blob["V"].shape[0] == len(P) and np.allclose(blob["V"][:, :3], P * 0.2, atol=1e-7)
+
+
 def test_serialized_errors(mi, tmp_path):
     P, F, N, UV = grid_mesh(3)
     path = os.path.join(tmp_path, "e.serialized")
@@ -277,7 +356,7 @@ def test_serialized_errors(mi, tmp_path):
     assert load(good).F.shape[0] == len(F)
     with pytest.raises(RuntimeError, match="invalid file format"): load(b"\x1d\x04" + good[2:])
     with pytest.raises(RuntimeError, match="incompatible file version"): load(good[:2] + struct.pack("<H", 2) + good[4:])
-    with pytest.raises(RuntimeError, match="version 5"): load(good[:2] + struct.pack("<H", 5) + good[4:])
+    with pytest.raises(RuntimeError, match="incompatible file version"): load(good[:2] + struct.pack("<H", 6) + good[4:])
     with pytest.raises(RuntimeError, match="nonnegative"): load(good, shape_index=-1)
     with pytest.raises(RuntimeError, match="inflate"): load(good[:4] + b"garbage-not-zlib" * 4)
     short = struct.pack("<HH", 0x041C, 4) + zlib.compress(struct.pack("<I", 0x1000) + b"x\0" + struct.pack("<QQ", 100, 1))
