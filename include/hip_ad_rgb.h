@@ -156,8 +156,10 @@ const char *har_device_arch(void);
  *  Device memory (the reference allocates through Dr.Jit's caching allocator, jit_malloc: every array of the renderer lives in the process's one pool).
  *  By default the library calls hipMalloc / hipFree.  A host that owns a device allocator installs it here: alloc_fn(bytes, user) returns device memory
  *  usable on any stream of the current device (NULL = out of memory), free_fn(ptr, user) releases a block alloc_fn returned.  Blocks remember the
- *  function that frees them, so the hook may change while blocks are alive; NULL, NULL restores hipMalloc.  The library synchronises the device before it
- *  frees a workspace.  (mitsuba3_amd installs PyTorch's caching allocator: torch.cuda.caching_allocator_alloc / _delete.)
+ *  function that frees them, so the hook may change while blocks are alive; NULL, NULL restores hipMalloc.  INVARIANT: no block is freed while the device runs --
+ *  the library synchronises the device before it frees (once per workspace), because a pooling allocator hands a freed block to its next user at once and blocks are
+ *  not bound to a stream here.  alloc_fn returning NULL means "out of memory": har_render_backward then steps down to a smaller workspace (record tape -> lane-indexed
+ *  replay cache -> smaller chunks) instead of failing.  (mitsuba3_amd installs PyTorch's caching allocator: torch.cuda.caching_allocator_alloc / _delete.)
  * ------------------------------------------------------------------------ */
 typedef void *(*HarAllocFn)(size_t bytes, void *user);
 typedef void (*HarFreeFn)(void *ptr, void *user);

@@ -1069,10 +1069,13 @@ class Integrator:
             g_pos = {k: torch.zeros(3 * scene.meshes[m]["V"].shape[0], dtype=torch.float32, device=dev) for k, m in wanted.items()}
             by_mesh = {wanted[k]: g for k, g in g_pos.items()}
             pp = (C.c_void_p * max(1, len(scene.meshes)))(*[by_mesh[m].data_ptr() if m in by_mesh else None for m in range(len(scene.meshes))])
-            # what the previous call left on must not veto this call's selection (nested vertex positions and instance transforms exclude each other)
-            check(lib().har_integrator_set_grad_positions(self._handle(), None, None))
+            # what the previous call left on must not veto this call's selection (nested vertex positions and instance transforms exclude each other): instances
+            # that are no longer wanted go first, then the positions REPLACE the previous selection.  An unchanged selection changes nothing in the library, so an
+            # optimisation loop keeps its adjoint workspace from step to step (both setters only rebuild it when the offset table / instance count differs).
             if not inst_wanted:
                 check(lib().har_integrator_set_grad_instances(self._handle(), None, None))
+            elif any(m >= scene.top_mesh_count for m in by_mesh):
+                raise RuntimeError("Cannot differentiate instance parameters and shapegroup internal parameters at the same time!")     # instance.cpp:162-166
             check(lib().har_integrator_set_grad_positions(self._handle(), scene._handle(), pp if g_pos else None))
             if inst_wanted:
                 g_inst = torch.zeros((len(scene.instances), 12), dtype=torch.float32, device=dev)

@@ -135,8 +135,20 @@ HAR_HD RaySetup ray_setup(Vec3 o, Vec3 d) {
 #define HAR_STACK_OVERFLOW 0x7fffffff
 #define HAR_MAX_PARKED 3          /* Traversal<2>: stack entries beyond the depth-first bound (HostScene::stack_need) */
 
-/* Probe: optional per-ray event counters (tools/ and the host harness); the default compiles to nothing */
-struct NoProbe { HAR_HD void node() {} HAR_HD void tri() {} HAR_HD void inst() {} HAR_HD void iter() {} };
+/* Probe: optional per-ray instrumentation of the traversal loops (tools/ and the host test harness implement it; tests/host_harness/harness.cpp).  The default
+ * compiles to nothing, and nothing of the instrumentation lives in this header:
+ *   iter / node / tri / inst        one outer iteration / node visit / triangle test / instance entry
+ *   ray(any_hit)                    a reference-loop query starts
+ *   visited(A, R, tmax, node, ng_y, tg_y, phase)   after a node visit of the reference loop: phase 0 = top-level BLAS of a two-level scene, 1 = TLAS, 2 = inside an instance
+ *   leaf(phase) / entered()         a triangle test in that phase / an instance was entered
+ *   left(top_phase, useful)         an instance (or the top-level phase) is done; useful = it gave the ray its closest hit
+ *   back_to_front()                 what-if: take the FARTHEST pending child first */
+struct Accel; struct RaySetup;
+struct NoProbe {
+    HAR_HD void node() {} HAR_HD void tri() {} HAR_HD void inst() {} HAR_HD void iter() {}
+    HAR_HD void ray(bool) {} HAR_HD void visited(const Accel &, const RaySetup &, float, uint32_t, uint32_t, uint32_t, int) {} HAR_HD void leaf(int) {} HAR_HD void entered() {}
+    HAR_HD void left(bool, bool) {} HAR_HD bool back_to_front() const { return false; }
+};
 
 /*
  * One node visit: fetch the 80-byte node `index`, intersect the ray with its 8 quantised child
@@ -193,19 +205,14 @@ HAR_HD void node_visit(const Accel &A, const RaySetup &R, float tmax, uint32_t i
     tg_y = hitmask & 0x00ffffffu;
 }
 
-/* pick the next child of a node group (front-to-back = highest bit); returns its node index */
-#if !defined(__HIP_DEVICE_COMPILE__)
-static int g_host_child_order = 0;      /* host what-if models only (tools/trace_stats.py): 1 = back-to-front */
-/* host statistics of the reference loop, [0] closest-hit / [1] any-hit queries: rays, node visits / triangle tests of the top-level BLAS phase, node visits in the
- * TLAS and inside instances, triangle tests and entries of instances, node visits that hit no child, ... whose own box lies beyond the current tmax */
-static unsigned long long g_host_stat[2][12] = { { 0 }, { 0 } };
-enum { HS_RAYS = 0, HS_TOP_NODES, HS_TOP_TRIS, HS_TLAS_NODES, HS_INST_NODES, HS_INST_TRIS, HS_INST_ENTRIES, HS_EMPTY_NODES, HS_STALE_NODES, HS_FALSE_ENTRIES, HS_FALSE_ENTRY_NODES, HS_ENTRY_MARK };
-#endif
-HAR_HD uint32_t ng_next_child(uint32_t ng_x, uint32_t &ng_y, uint32_t octinv) {
+/* pick the next child of a node group (front-to-back = highest bit); returns its node index.  back_to_front: a Probe's what-if (host models only) */
+HAR_HD uint32_t ng_next_child(uint32_t ng_x, uint32_t &ng_y, uint32_t octinv, bool back_to_front = false) {
     uint32_t imask = ng_y & 0xffu;
     uint32_t bit = 31u - clz32(ng_y);
 #if !defined(__HIP_DEVICE_COMPILE__)
-    if (g_host_child_order == 1) bit = (uint32_t) __builtin_ctz(ng_y & 0xff000000u);
+    if (back_to_front) bit = (uint32_t) __builtin_ctz(ng_y & 0xff000000u);
+#else
+    (void) back_to_front;
 #endif
     ng_y &= ~(1u << bit);
     uint32_t slot = (bit - 24u) ^ octinv;
@@ -255,34 +262,19 @@ HAR_HD bool accel_trace(const Accel &A, Vec3 o_w, Vec3 d_w, float maxt, Hit &hit
     int sp = 0, inst_sp = -1;
     bool tlas_pending = false;
     if (A.has_tlas && A.top_root != HAR_NO_NODE) { in_tlas = false; inst_sp = 0; ng_x = A.top_root; tlas_pending = true; }      /* top-level geometry first */
-#if !defined(__HIP_DEVICE_COMPILE__)
-    ++g_host_stat[AnyHit][HS_RAYS];
-#endif
+    probe.ray(AnyHit);
     for (;;) {
         probe.iter();
         if (ng_y > 0x00ffffffu) {
             probe.node();
-#if !defined(__HIP_DEVICE_COMPILE__)
-            ++g_host_stat[AnyHit][tlas_pending ? HS_TOP_NODES : in_tlas ? HS_TLAS_NODES : HS_INST_NODES];
-#endif
             uint32_t px = ng_x, py = ng_y;
-            uint32_t child = ng_next_child(px, py, R.octinv);
+            uint32_t child = ng_next_child(px, py, R.octinv, probe.back_to_front());
             if (py > 0x00ffffffu) {
                 if (sp >= Stack::Capacity) { status = HAR_STACK_OVERFLOW; return false; }
                 stack.push(sp++, px, py);
             }
             node_visit(A, R, tmax, child, ng_x, ng_y, tg_x, tg_y);
-#if !defined(__HIP_DEVICE_COMPILE__)
-            {       /* is the node's own (quantisation-frame) box beyond the current tmax, i.e. was it queued under an older tmax? */
-                const Node8 &N = A.nodes[child];
-                const float lo[3] = { N.px, N.py, N.pz }, sc[3] = { as_f32((uint32_t) N.ex << 23), as_f32((uint32_t) N.ey << 23), as_f32((uint32_t) N.ez << 23) };
-                const float oo[3] = { R.o.x, R.o.y, R.o.z }, id[3] = { R.idir.x, R.idir.y, R.idir.z };
-                float tn = 0.f, tf = tmax;
-                for (int a = 0; a < 3; ++a) { float t0 = (lo[a] - oo[a]) * id[a], t1 = (lo[a] + 255.f * sc[a] - oo[a]) * id[a]; if (t0 > t1) { float q = t0; t0 = t1; t1 = q; } tn = fmaxf(tn, t0); tf = fminf(tf, t1); }
-                if (tn > tf) ++g_host_stat[AnyHit][HS_STALE_NODES];
-            }
-            if (ng_y <= 0x00ffffffu && tg_y == 0u) ++g_host_stat[AnyHit][HS_EMPTY_NODES];        /* a visit that hit none of the node's children (the node was queued under an older, larger tmax, or grazed) */
-#endif
+            probe.visited(A, R, tmax, child, ng_y, tg_y, tlas_pending ? 0 : in_tlas ? 1 : 2);
         } else {
             tg_x = ng_x; tg_y = ng_y; ng_x = 0; ng_y = 0;
         }
@@ -301,33 +293,21 @@ HAR_HD bool accel_trace(const Accel &A, Vec3 o_w, Vec3 d_w, float maxt, Hit &hit
                     if (sp >= Stack::Capacity) { status = HAR_STACK_OVERFLOW; return false; }
                     stack.push(sp++, tg_x, tg_y);
                 }
-                probe.inst();
-#if !defined(__HIP_DEVICE_COMPILE__)
-                ++g_host_stat[AnyHit][HS_INST_ENTRIES];
-                g_host_stat[AnyHit][HS_ENTRY_MARK] = g_host_stat[AnyHit][HS_INST_NODES];      /* node-visit counter at entry */
-#endif
+                probe.inst(); probe.entered();
                 const InstRec &I = A.insts[idx];
                 inst_sp = sp; cur_inst = I.inst_index; in_tlas = false;
                 if (!I.identity) R = ray_setup(xf_point(I.to_object, o_w), xf_vector(I.to_object, d_w));
                 ng_x = I.blas_root; ng_y = 0x80000000u; tg_y = 0;
                 break;
             } else {
-                probe.tri();
-#if !defined(__HIP_DEVICE_COMPILE__)
-                ++g_host_stat[AnyHit][tlas_pending ? HS_TOP_TRIS : HS_INST_TRIS];
-#endif
+                probe.tri(); probe.leaf(tlas_pending ? 0 : 2);
                 if (tri_visit<AnyHit>(A, R, tmax, idx, cur_inst, hit)) return true;
             }
         }
 
         if (ng_y <= 0x00ffffffu) {
             if (!in_tlas && sp == inst_sp) {
-#if !defined(__HIP_DEVICE_COMPILE__)
-                if (!tlas_pending && hit.inst != cur_inst) {      /* the instance was entered for nothing: no hit of it became the closest one */
-                    ++g_host_stat[AnyHit][HS_FALSE_ENTRIES];
-                    g_host_stat[AnyHit][HS_FALSE_ENTRY_NODES] += g_host_stat[AnyHit][HS_INST_NODES] - g_host_stat[AnyHit][HS_ENTRY_MARK];
-                }
-#endif
+                probe.left(tlas_pending, hit.inst == cur_inst);
                 in_tlas = true; cur_inst = 0xffffffffu; inst_sp = -1;
                 if (tlas_pending) { tlas_pending = false; ng_x = A.root; ng_y = 0x80000000u; continue; }      /* the ray is still the world-space one */
                 R = ray_setup(o_w, d_w);
@@ -511,7 +491,9 @@ struct Traversal {
             else {
                 const InstRec &I = A.insts[ng_x];
                 cur_inst = I.inst_index; ng_x = I.blas_root;
-                if (!I.identity) R = ray_setup(xf_point(I.to_object, o_w), xf_vector(I.to_object, d_w));
+                /* always from the WORLD-space ray (an identity record transforms to the same bits): a pending LEAVING that this ENTERING overwrote -- possible
+                 * once leaf_round() runs between two steps -- must not leave the previous instance's object-space ray in R */
+                R = ray_setup(xf_point(I.to_object, o_w), xf_vector(I.to_object, d_w));
             }
         }
 #else

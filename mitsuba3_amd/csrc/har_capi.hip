@@ -89,7 +89,7 @@ static hipError_t dev_alloc(void **out, size_t bytes) {
     g_guarded[user] = B; *out = user;
     return hipSuccess;
 }
-static void dev_free(void *p) {
+static void dev_free(void *p, bool device_is_idle = false) {      /* device_is_idle: the caller has synchronised the device (free_ws: once for all its blocks) */
     if (!p) return;
     if (guard_mode()) {
         std::lock_guard<std::mutex> lock(g_guarded_mutex);
@@ -111,7 +111,7 @@ static void dev_free(void *p) {
         }
         /* hipFree synchronises the device before it releases a block; a pooling allocator hands the block to its next user at once, so do the same here
          * (the library's private streams may still be reading it) */
-        if (B.free_fn) { (void) hipDeviceSynchronize(); B.free_fn(p, B.user); return; }
+        if (B.free_fn) { if (!device_is_idle) (void) hipDeviceSynchronize(); B.free_fn(p, B.user); return; }
     }
     (void) hipFree(p);
 }
@@ -180,6 +180,7 @@ struct HarIntegratorImpl {
     float *inst_user = nullptr; uint32_t inst_count = 0; int32_t *d_inst_slot = nullptr; float *grad_inst = nullptr;
     bool material_queues = false;         /* har_integrator_set_material_queues */
     int packet_tracing = -1;              /* har_integrator_set_packet_tracing: -1 automatic, 0 off, 1 every first closest-hit launch */
+    int bw_tape_max = 2; uint32_t bw_chunk_max = 0xffffffffu;      /* render_backward: what the last out-of-memory fallback settled on (tape kind, chunk lanes) */
     uint32_t *mq_idx = nullptr, *mq_count = nullptr;      /* per-material shading queues (MaterialQueues): HAR_MAT_CLASSES index lists of ws_lanes entries, their counters */
     uint2 *stack_spill = nullptr;         /* HBM part of the traversal stacks: HAR_STACK_SPILL entries per thread of the largest traversal grid */
     /* multi-pass rendering: sampler state per lane of the rendered lane range, pixel jitter per chunk lane (see PassState) */
@@ -216,7 +217,9 @@ struct HarIntegratorImpl {
     ItemArrays items2{}; float4 *result2 = nullptr;
     void free_ws();
 };
-void HarIntegratorImpl::free_ws() { for (void *p : owned) dev_free(p); owned.clear(); ws_lanes = 0; }
+/* One device synchronisation for the whole workspace: blocks handed back to a pooling allocator (har_set_allocator) are reused at once, and the library's private
+ * streams may still be reading them -- the invariant is "no block of this library is freed while the device runs"; dev_free keeps it per block for single frees. */
+void HarIntegratorImpl::free_ws() { if (!owned.empty()) (void) hipDeviceSynchronize(); for (void *p : owned) dev_free(p, true); owned.clear(); ws_lanes = 0; }
 #define HAR_DUAL_MIN_LANES (1u << 20)
 #define HAR_DUAL_MAX_LANES (1u << 24)
 #define HAR_OVERLAP_MAX_LANES (1u << 25)
@@ -1222,8 +1225,22 @@ static int backward_range(HarScene S, HarIntegrator I, const HarSensor *sensor, 
      * asked for (their fifteen extra vectors per vertex stay with the re-shading replay).  HAR_PRB_TAPE=1: the state tape (A/B) */
     static const int tape_kind_env = getenv("HAR_PRB_TAPE") ? atoi(getenv("HAR_PRB_TAPE")) : 2;
     const bool tape_ok = tape_env && inline_env0 && I->use_cache && !I->shape_on && !I->hide_emitters && bounce_limit(I) <= HAR_REPLAY_CACHE_BOUNCES;
-    const int tape = !tape_ok ? 0 : (tape_kind_env >= 2 && !I->grad_bsdf_params && chunk <= (1u << 29)) ? 2 : 1;
-    if (ensure_workspace(I, chunk, true, tape)) return 1;
+    chunk = std::min(chunk, I->bw_chunk_max);
+    int tape = !tape_ok ? 0 : (tape_kind_env >= 2 && !I->grad_bsdf_params && chunk <= (1u << 29)) ? 2 : 1;
+    tape = std::min(tape, I->bw_tape_max);
+    /* The tapes are the large workspaces (record tape 69 B, state tape 115 B per lane and bounce against 25 B for the lane-indexed cache: 28 - 90 GB for a 2^26-lane chunk
+     * at max_depth 6 - 12).  When the device -- or the host's allocator pool, shared with the caller's tensors -- cannot hold one, step down instead of failing: record
+     * tape -> lane-indexed replay cache (same gradients, more traffic), then halve the chunk (more launch tails) down to 2^20 lanes. */
+    for (;;) {
+        if (ensure_workspace(I, chunk, true, tape) == 0) break;
+        const std::string why = g_error;
+        (void) hipDeviceSynchronize(); I->free_ws(); (void) hipGetLastError();
+        if (tape != 0) { tape = 0; I->bw_tape_max = 0; }
+        else if (chunk > (1u << 20)) { chunk = std::max<uint32_t>(1u << 20, (chunk / 2 + 2047) / 2048 * 2048); I->bw_chunk_max = chunk; }
+        else return fail("render_backward: no workspace fits the device (" + why + ")");
+        static const bool verbose = getenv("HAR_VERBOSE") != nullptr;
+        if (verbose) fprintf(stderr, "[hip_ad_rgb] render_backward: %s -- retrying with tape %d, chunk %u lanes\n", why.c_str(), tape, chunk);
+    }
     size_t npx = (size_t) C.crop_w * C.crop_h;
     if (I->adj_floats < 3 * npx) { if (ws_alloc(I, &I->adj, 3 * npx)) return 1; I->adj_floats = 3 * npx; }
     size_t nt = S->hs.textures.size();

@@ -171,7 +171,7 @@ def render_backward_distributed(scene, grad_in, integrator=None, sensor=0, seed=
         grads = integrator.render_backward(scene, None, grad_in, s, seed, spp, lanes=lanes, weight_film=wfilm)
     if adapt:
         _share_times(bal, timer, wfilm)
-    if world > 1:
+    if world > 1 and grads:            # (an empty dict -- no differentiable key -- needs no collective; every rank sees the same key set)
         # ONE collective for all gradient buffers (texels, constant albedos, emitter radiance, ...): xGMI rings are latency bound for the small ones
         keys = list(grads)
         flat = torch.cat([grads[k].reshape(-1).to(torch.float32) for k in keys])

@@ -2127,9 +2127,11 @@ float orc_math_fn(int fn, float x, float y) {
     switch (fn) {
         case 0: return exp32(x);   case 1: return log32(x);  case 2: return erf32(x); case 3: return atan2_32(x, y);
         case 4: return acos32(x);  case 5: return tan32(x);  case 6: return erfinv(x);
+        case 7: { float c; return sincos(x, &c); }  case 8: { float c; (void) sincos(x, &c); return c; }
     }
     return std::numeric_limits<float>::quiet_NaN();
 }
+void orc_math_fn_array(int fn, uint32_t n, const float *x, const float *y, float *out) { for (uint32_t i = 0; i < n; ++i) out[i] = orc_math_fn(fn, x[i], y ? y[i] : 0.f); }
 /* PreliminaryIntersection::compute_surface_interaction(ray, ray_flags, active) (interaction.h:804-829) WITH its flags and mask, written out once more from
  * Mesh::compute_surface_interaction (src/render/mesh.cpp:2255-2437), Instance::compute_surface_interaction (src/shapes/instance.cpp:150-266) and
  * finalize_surface_interaction (interaction.h:559-605) -- independently of compute_si() above, which only knows RayFlags::Default.

@@ -289,7 +289,8 @@ void  orc_coordinate_system(const float n[3], float s[3], float t[3]);
 void  orc_mesh_compute_normals(uint32_t nv, float *vertices, uint32_t nf, const uint32_t *faces);
 float orc_sincos(float x, float *c); /* returns sin */
 int orc_default_threads(void);        /* worker threads used for `threads <= 0`: affinity mask capped by the container's CPU quota */
-float orc_math_fn(int fn, float x, float y); /* 0 exp, 1 log, 2 erf, 3 atan2(x, y), 4 acos, 5 tan, 6 erfinv (orc_math.h / orc_bsdf.h) */
+float orc_math_fn(int fn, float x, float y); /* 0 exp, 1 log, 2 erf, 3 atan2(x, y), 4 acos, 5 tan, 6 erfinv, 7 sin, 8 cos (orc_math.h / orc_bsdf.h) */
+void  orc_math_fn_array(int fn, uint32_t n, const float *x, const float *y /* nullable */, float *out);
 /* full SurfaceInteraction for one hit (tests of Mesh::compute_surface_interaction) */
 void  orc_surface_interaction(void *scene, const float o[3], const float d[3],
                               float t, float u, float v, uint32_t prim, uint32_t shape,

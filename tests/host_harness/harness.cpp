@@ -159,9 +159,11 @@ float hh_math_fn(int fn, float x, float y) {
     switch (fn) {
         case 0: return exp_(x);   case 1: return log_(x);  case 2: return erf_(x); case 3: return atan2_(x, y);
         case 4: return acos_(x);  case 5: return tan_(x);  case 6: return erfinv_(x);
+        case 7: { float sn, cs; sincos_(x, sn, cs); return sn; }  case 8: { float sn, cs; sincos_(x, sn, cs); return cs; }
     }
     return 0.f;
 }
+void hh_math_fn_array(int fn, uint32_t n, const float *x, const float *y, float *out) { for (uint32_t i = 0; i < n; ++i) out[i] = hh_math_fn(fn, x[i], y ? y[i] : 0.f); }
 void hh_coordinate_system(const float n[3], float s[3], float t[3]) {      /* coordinate_system of har_math.h (vector.h:118-138) */
     Vec3 a, b; coordinate_system(Vec3(n[0], n[1], n[2]), a, b);
     s[0] = a.x; s[1] = a.y; s[2] = a.z; t[0] = b.x; t[1] = b.y; t[2] = b.z;
@@ -362,8 +364,36 @@ int hh_render_backward_instances(void *h, const HarSensor *sensor, const float *
 /* --- traversal statistics (tools/trace_stats.py): per-ray event counts and a lock-step SIMT model of the
  * static traversal kernel.  Rays of bounce b are the rays of all lanes alive at bounce b, in lane order
  * (the order the compacting wavefront keeps), grouped into waves of 64. */
-struct EvProbe {
+/* statistics of the reference loop (accel_trace), [0] closest-hit / [1] any-hit queries: rays, node visits / triangle tests of the top-level BLAS phase, node visits in the
+ * TLAS and inside instances, triangle tests and entries of instances, node visits that hit no child, ... whose own box lies beyond the current tmax, instance entries that
+ * gave the ray nothing and their node visits.  Filled through the Probe interface of har_accel.h (this used to sit inside the product header). */
+enum { HS_RAYS = 0, HS_TOP_NODES, HS_TOP_TRIS, HS_TLAS_NODES, HS_INST_NODES, HS_INST_TRIS, HS_INST_ENTRIES, HS_EMPTY_NODES, HS_STALE_NODES, HS_FALSE_ENTRIES, HS_FALSE_ENTRY_NODES, HS_ENTRY_MARK };
+static unsigned long long g_host_stat[2][12] = { { 0 }, { 0 } };
+static int g_host_child_order = 0;      /* what-if: 1 = back-to-front */
+struct StatHooks {
+    int q = 0;
+    void ray(bool any_hit) { q = any_hit ? 1 : 0; ++g_host_stat[q][HS_RAYS]; }
+    void visited(const Accel &A, const RaySetup &R, float tmax, uint32_t child, uint32_t ng_y, uint32_t tg_y, int phase) {
+        ++g_host_stat[q][phase == 0 ? HS_TOP_NODES : phase == 1 ? HS_TLAS_NODES : HS_INST_NODES];
+        /* is the node's own (quantisation-frame) box beyond the current tmax, i.e. was it queued under an older tmax? */
+        const Node8 &N = A.nodes[child];
+        const float lo[3] = { N.px, N.py, N.pz }, sc[3] = { as_f32((uint32_t) N.ex << 23), as_f32((uint32_t) N.ey << 23), as_f32((uint32_t) N.ez << 23) };
+        const float oo[3] = { R.o.x, R.o.y, R.o.z }, id[3] = { R.idir.x, R.idir.y, R.idir.z };
+        float tn = 0.f, tf = tmax;
+        for (int a = 0; a < 3; ++a) { float t0 = (lo[a] - oo[a]) * id[a], t1 = (lo[a] + 255.f * sc[a] - oo[a]) * id[a]; if (t0 > t1) { float w = t0; t0 = t1; t1 = w; } tn = fmaxf(tn, t0); tf = fminf(tf, t1); }
+        if (tn > tf) ++g_host_stat[q][HS_STALE_NODES];
+        if (ng_y <= 0x00ffffffu && tg_y == 0u) ++g_host_stat[q][HS_EMPTY_NODES];        /* a visit that hit none of the node's children */
+    }
+    void leaf(int phase) { ++g_host_stat[q][phase == 0 ? HS_TOP_TRIS : HS_INST_TRIS]; }
+    void entered() { ++g_host_stat[q][HS_INST_ENTRIES]; g_host_stat[q][HS_ENTRY_MARK] = g_host_stat[q][HS_INST_NODES]; }
+    void left(bool top_phase, bool useful) {
+        if (!top_phase && !useful) { ++g_host_stat[q][HS_FALSE_ENTRIES]; g_host_stat[q][HS_FALSE_ENTRY_NODES] += g_host_stat[q][HS_INST_NODES] - g_host_stat[q][HS_ENTRY_MARK]; }
+    }
+    bool back_to_front() const { return g_host_child_order == 1; }
+};
+struct EvProbe : StatHooks {
     std::vector<uint32_t> *ev;     /* one entry per outer iteration: bit0 node, bit1 inst, bits 8.. triangle tests */
+    explicit EvProbe(std::vector<uint32_t> *e) : ev(e) {}
     void iter() { ev->push_back(0u); }
     void node() { ev->back() |= 1u; }
     void inst() { ev->back() |= 2u; }
@@ -654,7 +684,7 @@ static void pk_trace(const Accel &A, const Vec3 *o, const Vec3 *d, const float *
     }
     if (!AnyHit) for (int l = 0; l < n; ++l) found[l] = hit[l].t != HAR_INF;
 }
-struct CountProbe { double *nodes, *tris, *insts; void iter() {} void node() { *nodes += 1; } void tri() { *tris += 1; } void inst() { *insts += 1; } };
+struct CountProbe : NoProbe { double *nodes, *tris, *insts; CountProbe(double *a, double *b, double *c) : nodes(a), tris(b), insts(c) {} void iter() {} void node() { *nodes += 1; } void tri() { *tris += 1; } void inst() { *insts += 1; } };
 }
 
 extern "C" {
