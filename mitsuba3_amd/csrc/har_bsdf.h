@@ -285,6 +285,8 @@ HAR_HD bool bsdf_is_smooth(const DBsdf &B) { return B.type != BSDF_DIELECTRIC &&
 #define HAR_BSDF_ALL_TYPES 0xffu
 #define HAR_BSDF_ONLY_DIFFUSE 0x1u
 #define HAR_BSDF_CLASSIC_TYPES 0xfu       /* diffuse, dielectric, roughconductor, roughplastic: scenes without `conductor` / `plastic` run kernels without that code */
+/* models without microfacet code (diffuse, dielectric, conductor, plastic): the cheap half of a split shading pass (k_shade, SPLIT) */
+#define HAR_BSDF_CHEAP_TYPES ((1u << BSDF_DIFFUSE) | (1u << BSDF_DIELECTRIC) | (1u << BSDF_CONDUCTOR) | (1u << BSDF_PLASTIC))
 #define HAR_BSDF_HAS(TYPES, T) (((TYPES) & (1u << (T))) != 0u)
 /* per-material shading queues (k_classify + one k_shade launch per BSDF model, har_kernels.hip): TYPES = (1 << type) | HAR_BSDF_QUEUED.  With ONE model
  * bit set the `switch (B.type)` of the eval / sample code folds to that model at compile time; the QUEUED bit keeps such a mask distinct from
@@ -317,6 +319,7 @@ HAR_HD void bsdf_eval_pdf_one(const DBsdf &B, const BsdfInputs &in, Vec3 wi, Vec
     } break;
     case BSDF_DIELECTRIC: break;                                             /* dielectric.cpp:340-348: delta lobes */
     case BSDF_ROUGHCONDUCTOR: {                                              /* roughconductor.cpp:429-520 */
+        if (!HAR_BSDF_HAS(TYPES, BSDF_ROUGHCONDUCTOR)) return;
         if (CTX && !ctx.is_enabled(LOBE_GLOSSY_REFLECTION)) return;
         Vec3 H = normalize3(wo + wi);
         if (!(cos_theta_i > 0.f && cos_theta_o > 0.f && dot3(wi, H) > 0.f && dot3(wo, H) > 0.f)) return;
@@ -332,6 +335,7 @@ HAR_HD void bsdf_eval_pdf_one(const DBsdf &B, const BsdfInputs &in, Vec3 wi, Vec
         e.pdf = pdf;
     } break;
     case BSDF_ROUGHPLASTIC: {                                                /* roughplastic.cpp:296-336 (eval), :351-395 (pdf) */
+        if (!HAR_BSDF_HAS(TYPES, BSDF_ROUGHPLASTIC)) return;
         /* component 0 = the glossy coating, 1 = the diffuse base (roughplastic.cpp:301-302) */
         const bool has_specular = !CTX || ctx.is_enabled(LOBE_GLOSSY_REFLECTION, 0u), has_diffuse = !CTX || ctx.is_enabled(LOBE_DIFFUSE_REFLECTION, 1u);
         if (CTX && !has_specular && !has_diffuse) return;
@@ -451,6 +455,7 @@ HAR_HD void bsdf_sample_one(const DBsdf &B, const BsdfInputs &in, Vec3 wi, float
         if (CTX && !both) bs.weight = selected_r ? in.slot0 * r_i : (in.slot1 * t_i) * sqr_(factor);
     } break;
     case BSDF_ROUGHCONDUCTOR: {                                              /* roughconductor.cpp:226-320 */
+        if (!HAR_BSDF_HAS(TYPES, BSDF_ROUGHCONDUCTOR)) return;
         if (CTX && !ctx.is_enabled(LOBE_GLOSSY_REFLECTION)) return;
         if (!(cos_theta_i > 0.f)) return;
         Microfacet distr((B.flags & BF_GGX) != 0, B.alpha_u, B.alpha_v, (B.flags & BF_SAMPLE_VISIBLE) != 0);
@@ -464,6 +469,7 @@ HAR_HD void bsdf_sample_one(const DBsdf &B, const BsdfInputs &in, Vec3 wi, float
         bs.weight = active ? F * (in.slot0 * weight) : Vec3(0.f);
     } break;
     case BSDF_ROUGHPLASTIC: {                                                /* roughplastic.cpp:244-294 */
+        if (!HAR_BSDF_HAS(TYPES, BSDF_ROUGHPLASTIC)) return;
         const bool has_specular = !CTX || ctx.is_enabled(LOBE_GLOSSY_REFLECTION, 0u), has_diffuse = !CTX || ctx.is_enabled(LOBE_DIFFUSE_REFLECTION, 1u);
         if (CTX && !has_specular && !has_diffuse) return;
         if (!(cos_theta_i > 0.f)) return;

@@ -508,6 +508,9 @@ int run_chunk(HarSceneImpl *S, HarIntegratorImpl *I, const DSensor &C, int mode,
     const bool fwd = mode == MODE_PRB_ADJOINT && I->forward_mode;
     ShadeParams P{ seed, I->max_depth, I->rr_depth, (((mode == MODE_PRB_ADJOINT || rec_w) && I->grad_emitters) ? HAR_SHADE_EMITTER_GRADS : 0u) | (I->hide_emitters ? HAR_SHADE_HIDE_EMITTERS : 0u) |
                    (fwd ? HAR_SHADE_FORWARD_MODE : 0u) | ((mode == MODE_PRB_ADJOINT && I->grad_bsdf_params && !fwd) ? HAR_SHADE_EXTRA_GRADS : 0u) };
+    /* generic shading kernels: material-sort window in tiles of 256 paths (k_shade; HAR_SORT_WINDOW=1 is the round-3 kernel, A/B) */
+    static const uint32_t sort_window_env = getenv("HAR_SORT_WINDOW") ? (uint32_t) std::max(1, atoi(getenv("HAR_SORT_WINDOW"))) : 8u;
+    P.sort_window = sort_window_env;
     /* grid: a multiple of 8 so that block b serves shard b % 8; enough blocks to cover the chunk once */
     const uint32_t grid = std::max<uint32_t>(HAR_SHARDS, std::min<uint32_t>(((n + 255) / 256 + HAR_SHARDS - 1) / HAR_SHARDS * HAR_SHARDS, 4096u));
     /* persistent traversal kernels: enough blocks to fill the chip (<= 8 blocks/CU), never more than the work */
@@ -531,7 +534,9 @@ int run_chunk(HarSceneImpl *S, HarIntegratorImpl *I, const DSensor &C, int mode,
         if (hipStreamCreateWithFlags(&I->aux_stream, hipStreamNonBlocking) != hipSuccess || hipEventCreateWithFlags(&I->ev_shaded, hipEventDisableTiming) != hipSuccess ||
             hipEventCreateWithFlags(&I->ev_resolved, hipEventDisableTiming) != hipSuccess || hipEventCreateWithFlags(&I->ev_resolved2, hipEventDisableTiming) != hipSuccess) { I->aux_stream = nullptr; overlap = false; }
     }
-    if (overlap && !I->result2 && (ws_alloc(I, &I->items2.s0, I->ws_lanes) || ws_alloc(I, &I->items2.s1, I->ws_lanes) || ws_alloc(I, &I->items2.s2, I->ws_lanes) || ws_alloc(I, &I->result2, I->ws_lanes))) return 1;
+    if (overlap && !I->result2 && (ws_alloc(I, &I->items2.s0, I->ws_lanes) || ws_alloc(I, &I->items2.s1, I->ws_lanes) || ws_alloc(I, &I->items2.s2, I->ws_lanes) || ws_alloc(I, &I->result2, I->ws_lanes))) {
+        I->result2 = nullptr; overlap = false; (void) hipGetLastError();      /* no room for the second item set: one stream (an optimisation, not a requirement) */
+    }
     if (overlap) HIP_TRY(hipMemsetAsync(I->result2, 0, (size_t) n * sizeof(float4), s));
     hipEvent_t ev_res[2] = { I->ev_resolved, I->ev_resolved2 };
     bool resolve_pending[2] = { false, false };
@@ -1231,9 +1236,22 @@ static int backward_range(HarScene S, HarIntegrator I, const HarSensor *sensor, 
     /* The tapes are the large workspaces (record tape 69 B, state tape 115 B per lane and bounce against 25 B for the lane-indexed cache: 28 - 90 GB for a 2^26-lane chunk
      * at max_depth 6 - 12).  When the device -- or the host's allocator pool, shared with the caller's tensors -- cannot hold one, step down instead of failing: record
      * tape -> lane-indexed replay cache (same gradients, more traffic), then halve the chunk (more launch tails) down to 2^20 lanes. */
+    const size_t npx = (size_t) C.crop_w * C.crop_h, nt = S->hs.textures.size();
+    /* the kernels accumulate into (bsdf_count + emitter_count) x 3 slots; the two halves are added to the caller's buffers at the end */
+    const size_t nb3 = 3 * S->hs.bsdfs.size(), ne3 = 3 * S->hs.emitters.size();
+    /* everything render_backward allocates, so that the step-down below sees every refusal (the texel queues are sized by the workspace's lanes) */
+    auto allocate = [&]() -> int {
+        if (ensure_workspace(I, chunk, true, tape)) return 1;
+        if (I->adj_floats < 3 * npx) { if (ws_alloc(I, &I->adj, 3 * npx)) return 1; I->adj_floats = 3 * npx; }
+        if (I->grad_tex_cap < std::max<size_t>(nt, 1)) { if (ws_alloc(I, &I->d_grad_tex, std::max<size_t>(nt, 1))) return 1; I->grad_tex_cap = std::max<size_t>(nt, 1); }
+        if (ensure_texel_queues(S, I)) return 1;
+        if (I->grad_slots_cap < nb3 + ne3 + 3) { if (ws_alloc(I, &I->grad_slots, nb3 + ne3 + 3)) return 1; I->grad_slots_cap = nb3 + ne3 + 3; }
+        return 0;
+    };
     for (;;) {
-        if (ensure_workspace(I, chunk, true, tape) == 0) break;
+        if (allocate() == 0) break;
         const std::string why = g_error;
+        if (why.find("hipMalloc") == std::string::npos) return 1;             /* not an allocation failure: the error stands */
         (void) hipDeviceSynchronize(); I->free_ws(); (void) hipGetLastError();
         if (tape != 0) { tape = 0; I->bw_tape_max = 0; }
         else if (chunk > (1u << 20)) { chunk = std::max<uint32_t>(1u << 20, (chunk / 2 + 2047) / 2048 * 2048); I->bw_chunk_max = chunk; }
@@ -1241,10 +1259,6 @@ static int backward_range(HarScene S, HarIntegrator I, const HarSensor *sensor, 
         static const bool verbose = getenv("HAR_VERBOSE") != nullptr;
         if (verbose) fprintf(stderr, "[hip_ad_rgb] render_backward: %s -- retrying with tape %d, chunk %u lanes\n", why.c_str(), tape, chunk);
     }
-    size_t npx = (size_t) C.crop_w * C.crop_h;
-    if (I->adj_floats < 3 * npx) { if (ws_alloc(I, &I->adj, 3 * npx)) return 1; I->adj_floats = 3 * npx; }
-    size_t nt = S->hs.textures.size();
-    if (I->grad_tex_cap < std::max<size_t>(nt, 1)) { if (ws_alloc(I, &I->d_grad_tex, std::max<size_t>(nt, 1))) return 1; I->grad_tex_cap = std::max<size_t>(nt, 1); }
     if (nt) {
         if (!grad_textures) return fail("grad_textures is null but the scene has bitmap textures");
         for (size_t k = 0; k < nt; ++k) if (!grad_textures[k]) return fail("null texture gradient buffer");
@@ -1258,10 +1272,6 @@ static int backward_range(HarScene S, HarIntegrator I, const HarSensor *sensor, 
         static const bool inline_env = getenv("HAR_ADJOINT_INLINE") ? atoi(getenv("HAR_ADJOINT_INLINE")) != 0 : true;
         if (!inline_env) return fail("gradients of alpha / eta / k / specular colours need the in-place commit (HAR_ADJOINT_INLINE=0 is set)");
     }
-    if (ensure_texel_queues(S, I)) return 1;
-    /* the kernels accumulate into (bsdf_count + emitter_count) x 3 slots; the two halves are added to the caller's buffers at the end */
-    const size_t nb3 = 3 * S->hs.bsdfs.size(), ne3 = 3 * S->hs.emitters.size();
-    if (I->grad_slots_cap < nb3 + ne3 + 3) { if (ws_alloc(I, &I->grad_slots, nb3 + ne3 + 3)) return 1; I->grad_slots_cap = nb3 + ne3 + 3; }
     HIP_TRY(hipMemsetAsync(I->grad_slots, 0, (nb3 + ne3 + 3) * sizeof(float), s));
     if (I->shape_on) {
         if ((I->pos_verts && I->pos_offset.size() != S->hs.meshes.size()) || (I->inst_count && I->inst_count != S->hs.insts.size()))

@@ -409,6 +409,9 @@ __global__ void k_sample_out(uint32_t n, uint32_t n_total, uint32_t first, const
 #ifndef HAR_MATERIAL_SORT
 #define HAR_MATERIAL_SORT 1
 #endif
+#ifndef HAR_SORT_WINDOW_MAX
+#define HAR_SORT_WINDOW_MAX 8          /* tiles of 256 paths per material-sort window of the generic shading kernels (LDS: 1 KB per tile) */
+#endif
 #ifndef HAR_DEFER_INST
 #define HAR_DEFER_INST 4      /* persistent traversal: instance entries wait for this many lanes (0 = enter at once; host model tools/trace_stats.py HH_DEFER_INST: -3 %; measured 4 / 6 / 8: k_resolve 26.83 -> 26.27 / 26.31 / 26.43 ms, k_trace_closest +-0) */
 #endif
@@ -927,41 +930,57 @@ __global__ __launch_bounds__(kBlock, HAR_SHADE_MIN_WAVES) void k_shade(DScene S,
     const bool fwd = MODE == MODE_PRB_ADJOINT && (P.flags & HAR_SHADE_FORWARD_MODE) != 0u;      /* render_forward: tangents in, dL accumulates (see adjoint_commit_values) */
     const bool emitter_grads = MODE == MODE_PRB_ADJOINT && (P.flags & HAR_SHADE_EMITTER_GRADS) != 0u;
     if (emitter_grads) { for (uint32_t k = threadIdx.x; k < 3 * HAR_LDS_GRAD_EMITTERS; k += kBlock) eacc[k] = 0.f; __syncthreads(); }
-    constexpr uint32_t kSortKeys = BSDF_TYPE_COUNT + 2;                        /* one bucket per BSDF model, then misses, then lanes beyond the tile's end */
-    __shared__ uint32_t sort_cnt[kSortKeys], sort_perm[TYPES == HAR_BSDF_ONLY_DIFFUSE ? 1 : kBlock];
+    /* sort buckets: the models without microfacet code, escaped paths, the rough models, two-model pairs (HAR_MAT_GENERIC), lanes beyond the wavefront's end */
+    constexpr uint32_t kSortKeys = HAR_MAT_CLASSES + 2;
+    constexpr bool kSorted = !QUEUED && TYPES != HAR_BSDF_ONLY_DIFFUSE && HAR_MATERIAL_SORT;
+    __shared__ uint32_t sort_cnt[kSortKeys];
+    __shared__ uint16_t sort_perm[kSorted ? kBlock * HAR_SORT_WINDOW_MAX : 1], sort_tmp[kSorted ? kBlock * HAR_SORT_WINDOW_MAX : 1];
     ShardLoop Q(count_in, shard_cap);
     /* QUEUED: the paths of ONE material class of this shard, through the index list k_classify built (MaterialQueues) */
     const uint32_t *q_idx = QUEUED ? mq.idx + (size_t) mat_class * mq.lanes + Q.base : nullptr;
     if (QUEUED) Q.n = mq.count[(size_t) (mat_class * HAR_SHARDS + Q.shard) * HAR_COUNTER_STRIDE];
     uint32_t *cnt_alive = count_out + Q.shard * HAR_COUNTER_STRIDE, *cnt_item = item_count + Q.shard * HAR_COUNTER_STRIDE;
-    for (uint32_t tile = Q.first_tile(); tile * kBlock < Q.n; tile += Q.tile_step()) {
-        uint32_t local = tile * kBlock + threadIdx.x;
-        if (QUEUED) local = local < Q.n ? q_idx[local] : 0xffffffffu;
-        if (!QUEUED && TYPES != HAR_BSDF_ONLY_DIFFUSE && HAR_MATERIAL_SORT) {
-            /* MATERIAL SORT: the 256 paths of this tile are re-dealt to the lanes by the BSDF type of the surface they hit
-             * (block-wide counting sort in LDS), so that a wave runs (mostly) ONE material model of the generic shading
-             * code instead of diverging over all of them.  The tile is a contiguous 4 KB window per state array, so the
-             * permuted loads still consume whole cache lines. */
-            uint32_t key = BSDF_TYPE_COUNT + 1u;                       /* BSDF_TYPE_COUNT = miss, + 1 = out of range */
-            if (local < Q.n) {
-                uint2 hs; float t;
-                if (MODE == MODE_PRB_ADJOINT && rc.mode == 2) {
-                    const uint32_t cl = __float_as_uint(in.a3[Q.base + local].w) - lane_base;
-                    hs = rc.h1[cl]; t = rc.h0[cl].x;
-                } else { hs = h1[HIT1(Q.base + local)]; t = h0[HIT0(Q.base + local)].x; }
-                key = t == HAR_INF ? (uint32_t) BSDF_TYPE_COUNT : min(S.bsdfs[S.meshes[hs.x].bsdf].type, (uint32_t) BSDF_TYPE_COUNT - 1u);
-            }
+    /* MATERIAL SORT over a WINDOW of `win` tiles (generic kernels): the window's 256 * win paths are re-dealt to the lanes by the BSDF model of the surface they hit
+     * (block-wide counting sort in LDS), then shaded in `win` rounds of 256, so that a wave runs (mostly) ONE material model of the generic shading code instead of
+     * diverging over all of them.  With four models a 256-path window leaves three of four waves with two models (modelled cost 3.2 against 1.7 for perfectly sorted
+     * waves, 7.2 unsorted); 2048 paths bring that to 1.9.  The window is a contiguous 4 KB * win range per state array, so the permuted loads still consume whole cache
+     * lines (across rounds).  win = 1 for wavefronts too small to give every block a whole window (ShadeParams::sort_window caps it; 1 = the round-3 kernel). */
+    const uint32_t win = kSorted ? max(1u, min(min(P.sort_window, (uint32_t) HAR_SORT_WINDOW_MAX), Q.n / (Q.tile_step() * kBlock))) : 1u;
+    for (uint32_t tile0 = Q.first_tile() * win; tile0 * kBlock < Q.n; tile0 += Q.tile_step() * win) {
+        if (kSorted) {
+            __syncthreads();                                             /* the previous window's bucket counts have been read by everyone */
             if (threadIdx.x < kSortKeys) sort_cnt[threadIdx.x] = 0;
             __syncthreads();
-            const uint32_t pos = atomicAdd(&sort_cnt[key], 1u);
+            for (uint32_t r = 0; r < win; ++r) {
+                const uint32_t l = (tile0 + r) * kBlock + threadIdx.x;
+                uint32_t key = kSortKeys - 1u;                             /* out of range */
+                if (l < Q.n) {
+                    uint2 hs; float t;
+                    if (MODE == MODE_PRB_ADJOINT && rc.mode == 2) {
+                        const uint32_t cl = __float_as_uint(in.a3[Q.base + l].w) - lane_base;
+                        hs = rc.h1[cl]; t = rc.h0[cl].x;
+                    } else { hs = h1[HIT1(Q.base + l)]; t = h0[HIT0(Q.base + l)].x; }
+                    /* the mesh's material class (DMesh::pad1, har_scene_create): diffuse 0, dielectric 1, rough conductor 2, rough plastic 3, conductor 4, plastic 5, generic 6 */
+                    const uint32_t cls = t == HAR_INF ? 7u : min(S.meshes[hs.x].pad1, (uint32_t) HAR_MAT_GENERIC);
+                    key = (0x47326510u >> (4u * cls)) & 0xfu;               /* buckets: diffuse, dielectric, conductor, plastic, escaped | rough conductor, rough plastic, generic */
+                }
+                sort_tmp[r * kBlock + threadIdx.x] = (uint16_t) ((key << 12) | atomicAdd(&sort_cnt[key], 1u));      /* rank within the bucket (< 4096) */
+            }
             __syncthreads();
-            uint32_t off = 0;
-            for (uint32_t k = 0; k < key; ++k) off += sort_cnt[k];
-            sort_perm[off + pos] = threadIdx.x;
-            __syncthreads();
-            local = tile * kBlock + sort_perm[threadIdx.x];
+            for (uint32_t r = 0; r < win; ++r) {
+                const uint32_t kp = sort_tmp[r * kBlock + threadIdx.x], key = kp >> 12;
+                uint32_t off = 0;
+                for (uint32_t k = 0; k < key; ++k) off += sort_cnt[k];
+                sort_perm[off + (kp & 0xfffu)] = (uint16_t) (r * kBlock + threadIdx.x);
+            }
             __syncthreads();
         }
+        /* the sorted window is shaded in rounds of 256 (the tail of the last round holds the out-of-range lanes) */
+        const uint32_t rounds = kSorted ? win : 1u;
+      for (uint32_t round = 0; round < rounds; ++round) {
+        const uint32_t pos = round * kBlock + threadIdx.x;
+        uint32_t local = kSorted ? tile0 * kBlock + sort_perm[pos] : tile0 * kBlock + threadIdx.x;
+        if (QUEUED) local = local < Q.n ? q_idx[local] : 0xffffffffu;
         const bool in_range = QUEUED ? local != 0xffffffffu : local < Q.n;
         const uint32_t i = Q.base + local;
         ShadeResult R; R.alive = false; R.item = false; R.add_emission = false;
@@ -1105,6 +1124,7 @@ __global__ __launch_bounds__(kBlock, HAR_SHADE_MIN_WAVES) void k_shade(DScene S,
             geo.pv0[lane] = make_float4(__uint_as_float(hs.x), hh.w, hh.y, hh.z);
             geo.pv1[lane] = make_float4(d_in.x, d_in.y, d_in.z, __uint_as_float(hs.y));
         }
+      }       /* rounds of the window */
     }
     if (emitter_grads && !fwd) {
         __syncthreads();

@@ -33,6 +33,7 @@ struct PathState {
 struct ShadeParams {
     uint32_t seed, max_depth, rr_depth;
     uint32_t flags = 0;        /* bit 0 (adjoint): also accumulate the gradient w.r.t. the radiance of `area` / `constant` emitters; bit 1: hide_emitters */
+    uint32_t sort_window = 1;  /* generic shading kernels: tiles of 256 paths per material-sort window (k_shade) */
 };
 #define HAR_SHADE_EMITTER_GRADS 1u
 #define HAR_SHADE_FORWARD_MODE 4u    /* adjoint kernels in FORWARD mode (RBIntegrator.render_forward): parameter tangents in, differential radiance out */

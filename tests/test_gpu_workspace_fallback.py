@@ -12,7 +12,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 pytestmark = pytest.mark.gpu
 
 WORKER = r'''
-import ctypes as C, os, sys
+import ctypes as C, gc, os, sys
 import numpy as np
 import torch
 sys.path.insert(0, os.environ["HAR_ROOT"])
@@ -40,6 +40,7 @@ grad_in = torch.from_numpy(np.random.default_rng(2).uniform(0.5, 1.5, (res, res,
 rel = lambda a, b: float(torch.linalg.norm(a.double() - b.double()) / torch.linalg.norm(b.double()))
 
 def run(budget):
+    gc.collect()                                   # integrators of earlier runs give their workspaces back before the budget is set
     scene = mi.load_dict(d); integ = scene.integrator()
     base = state["total"]                          # scene arrays are allocated; the budget applies to what render_backward adds
     state["budget"] = None if budget is None else base + budget
@@ -67,6 +68,7 @@ for frac in (0.6, 0.25):                           # first: the tape does not fi
             assert rel(g2[k], full[k]) < 2e-4, (frac, k)
     results.append((frac, peak, refused))
 # a budget nothing fits in is an error with the allocator's reason, not a crash
+gc.collect()
 scene = mi.load_dict(d); integ = scene.integrator()
 state["budget"] = state["total"] + (1 << 20)
 try:

@@ -1,7 +1,7 @@
 #!/bin/bash
 # Runs on the GPU box (via gpurun): kernel trace + PMC passes of `python bench.py $BENCH_ARGS`,
 # summaries written to gpurun_out/prof/<tag>_*.txt (copy the ones to keep into profiles/).
-# usage: tools/gpu_profile.sh <tag> [kt] [sq] [mem] [tcc] -- <bench args>
+# usage: tools/gpu_profile.sh <tag> [kt] [sq] [sq2] [ic] [mem] [tcc] -- <bench args>
 set -u
 TAG=$1; shift
 PASSES=()
@@ -20,6 +20,7 @@ for P in "${PASSES[@]}"; do
          rocprofv3 --pmc WRITE_SIZE -d $D -o r -- python bench.py --steps 1 --warmup 0 $ARGS > /dev/null 2>&1
          python tools/rocpd_summary.py $(find ${D}f -name '*.db') $(find $D -name '*.db') --json $OUT/${TAG}_traffic.json > $OUT/${TAG}_fetch_write.txt 2>&1 ;;
     sq2) rocprofv3 --pmc SQ_INSTS_VALU SQ_THREAD_CYCLES_VALU SQ_ACTIVE_INST_VALU SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_WAVE_CYCLES SQ_INSTS_SALU -d $D -o r -- python bench.py --steps 1 --warmup 0 $ARGS > $OUT/${TAG}_sq2_bench.log 2>&1 ;;
+    ic)  rocprofv3 --pmc SQC_ICACHE_REQ SQC_ICACHE_HITS SQC_ICACHE_MISSES SQ_IFETCH SQ_WAIT_INST_LDS SQ_WAVE_CYCLES SQ_WAIT_INST_ANY SQ_INSTS_LDS -d $D -o r -- python bench.py --steps 1 --warmup 0 $ARGS > $OUT/${TAG}_ic_bench.log 2>&1 ;;
     tcc) rocprofv3 --pmc TCC_HIT_sum TCC_MISS_sum -d $D -o r -- python bench.py --steps 1 --warmup 0 $ARGS > /dev/null 2>&1 ;;
   esac
   python tools/rocpd_summary.py $(find $D -name '*.db') --json $OUT/${TAG}_$P.json > $OUT/${TAG}_$P.txt 2>&1
