@@ -409,6 +409,9 @@ __global__ void k_sample_out(uint32_t n, uint32_t n_total, uint32_t first, const
 #ifndef HAR_MATERIAL_SORT
 #define HAR_MATERIAL_SORT 1
 #endif
+#ifndef HAR_SHAPE_MIN_WAVES
+#define HAR_SHAPE_MIN_WAVES 2           /* k_shape_adjoint: 2 = 256 registers per lane + 848 B of scratch, 1 = 438 (accumulation registers as spill space) */
+#endif
 #ifndef HAR_SORT_WINDOW_MAX
 #define HAR_SORT_WINDOW_MAX 8          /* tiles of 256 paths per material-sort window of the generic shading kernels (LDS: 1 KB per tile) */
 #endif
@@ -621,7 +624,7 @@ __device__ __forceinline__ void packet_node_visit(const Accel &A, const PacketBo
     tg_y = hitmask & 0x00ffffffu;
 }
 #ifndef HAR_PACKET_MIN_WAVES
-#define HAR_PACKET_MIN_WAVES 8
+#define HAR_PACKET_MIN_WAVES 4      /* 86 registers, no scratch (8: 64 + 60 B of scratch; 4 / 6 / 8 waves measured within 0.5 % of each other, profiles/r04_ab_prb_commit.txt) */
 #endif
 template <bool FLAT>
 __global__ __launch_bounds__(kBlock, HAR_PACKET_MIN_WAVES) void k_trace_packet(Accel A, const uint32_t *count, uint32_t *cursor, uint32_t shard_cap, const float4 *a0, const float4 *a1,
@@ -761,7 +764,8 @@ __device__ __forceinline__ void adjoint_commit_regs(const DScene &S, bool pred, 
     }
     if (__ballot(em_lds)) wave_slot_add3(gacc, em_slot, ge, em_lds);
     const bool nz = pred && (g.x != 0.f || g.y != 0.f || g.z != 0.f);
-    if (rec) {          /* queued textures: hand the record to the caller (block-wide append), no atomics here */
+    if (tq) {           /* queued textures: hand the record to the caller (its append), no atomics here.  `rec` is always the caller's local (a pointer that
+                         * is null on one path keeps the record in scratch memory: 40 B per lane of k_commit until round 4) */
         rec->has = false;
         if (nz && tex) {
             const uint32_t t = (uint32_t) S.bsdfs[(uint32_t) (dst - grad_refl) / 3u].texture;
@@ -829,15 +833,17 @@ __device__ __forceinline__ void adjoint_commit_values(const DScene &S, bool pred
 /* the four taps of a record committed with direct atomics (queue overflow); wave-uniform call */
 __device__ __forceinline__ void texel_record_direct(const DScene &S, float *const *grad_tex, float *dummy, const TexelRecord &r, bool active) {
     if (!__ballot(active)) return;
-    uint32_t idx[4] = { 0, 0, 0, 0 }; float w[4] = { 0.f, 0.f, 0.f, 0.f }; float *dst = dummy;
+    uint32_t W = 1u, x0 = 0u, y0 = 0u, x1 = 0u, y1 = 0u; float *dst = dummy;
     if (active) {
-        const uint32_t W = S.textures[r.tex].w, H = S.textures[r.tex].h, x0 = r.cell & 0xffffu, y0 = r.cell >> 16, x1 = x0 + 1 == W ? 0u : x0 + 1, y1 = y0 + 1 == H ? 0u : y0 + 1;
-        idx[0] = y0 * W + x0; idx[1] = y0 * W + x1; idx[2] = y1 * W + x0; idx[3] = y1 * W + x1;
-        const float w0x = 1.f - r.w1x, w0y = 1.f - r.w1y;
-        w[0] = w0x * w0y; w[1] = r.w1x * w0y; w[2] = w0x * r.w1y; w[3] = r.w1x * r.w1y;
+        W = S.textures[r.tex].w; const uint32_t H = S.textures[r.tex].h;
+        x0 = r.cell & 0xffffu; y0 = r.cell >> 16; x1 = x0 + 1 == W ? 0u : x0 + 1; y1 = y0 + 1 == H ? 0u : y0 + 1;
         dst = grad_tex[r.tex];
     }
-    for (int k = 0; k < 4; ++k) wave_aggregated_add3(active ? dst + 3 * (size_t) idx[k] : dummy, active ? r.g * w[k] : Vec3(0.f), active);
+    for (int k = 0; k < 4; ++k) {        /* the four bilinear taps (no indexed arrays: they would live in scratch) */
+        const uint32_t idx = ((k & 2) ? y1 : y0) * W + ((k & 1) ? x1 : x0);
+        const float w = ((k & 1) ? r.w1x : 1.f - r.w1x) * ((k & 2) ? r.w1y : 1.f - r.w1y);
+        wave_aggregated_add3(active ? dst + 3 * (size_t) idx : dummy, active ? r.g * w : Vec3(0.f), active);
+    }
 }
 /* append the block's texel records to their band queues (TexelQueues): LDS histogram -> one global atomic per non-empty band -> scattered 32-byte records; a record
  * that finds its queue full is committed with direct atomics by its lane.  Block-wide (three barriers); hist / base: HAR_TQ_MAX words each, gmax: one word of LDS. */
@@ -1049,7 +1055,7 @@ __global__ __launch_bounds__(kBlock, HAR_SHADE_MIN_WAVES) void k_shade(DScene S,
             TexelRecord rec; rec.has = false;
             adjoint_commit_regs(S, item_pred, visible, make_float4(c.x, c.y, c.z, __uint_as_float(tag)), make_float4(R.dLr_drho.x, R.dLr_drho.y, R.dLr_drho.z, R.uv_x),
                                 make_float4(R.rel_grad.x, R.rel_grad.y, R.rel_grad.z, R.uv_y), Lr, L_dirty, dlr, grad_slots, grad_tex, gacc,      /* forward mode never commits in place (host) */
-                                tq.nq ? &tq : nullptr, tq.nq ? &rec : nullptr);
+                                tq.nq ? &tq : nullptr, &rec);
             if (EXTRA && item_pred) {
                 /* the same two terms as for slot 0 (adjoint_commit_regs), for the five other parameter groups: g = dL * ([visible] d Lr_dir / d theta
                  * + [path continues] L * (d f / d theta) / f), with L already reduced by this vertex's Lr_dir */
@@ -1183,12 +1189,14 @@ __global__ __launch_bounds__(kBlock) void k_commit(DScene S, uint32_t shard_cap,
             pred = (nx & HAR_TAPE_HAS_REC) != 0u;
             if (pred) { s2 = tape.rec0[i]; s3 = tape.rec1[i]; s4 = tape.rec2[i]; visible = (nx & HAR_TAPE_HAS_RAY) != 0u && vis[i] != 0; }
         }
-        adjoint_commit_regs(S, pred, visible, s2, s3, s4, L, dirty, dl, grad_slots, grad_tex, gacc, tq.nq ? &tq : nullptr, tq.nq ? &rec : nullptr);
+        adjoint_commit_regs(S, pred, visible, s2, s3, s4, L, dirty, dl, grad_slots, grad_tex, gacc, tq.nq ? &tq : nullptr, &rec);
         if (in_range && (nx & HAR_TAPE_DEAD) != HAR_TAPE_DEAD) {
             const uint32_t nslot = nx & HAR_TAPE_DEAD;
             tape.la_out[nslot] = make_float4(L.x, L.y, L.z, dl.x); tape.lb_out[nslot] = make_float2(dl.y, dl.z);
         }
-        if (tq.nq) texel_queue_append(S, tq, Q.shard, rec, tq_hist, tq_base, &tq_gmax, grad_tex, grad_slots);      /* the block's texel records -> their band queues */
+        /* the block's texel records -> their band queues (a per-WAVE append -- ballot ranks, one global atomic per wave and band, no barriers -- was measured 3 % slower
+         * on the whole PRB step: four times the returning global atomics; profiles/r04_ab_prb_commit.txt) */
+        if (tq.nq) texel_queue_append(S, tq, Q.shard, rec, tq_hist, tq_base, &tq_gmax, grad_tex, grad_slots);
     }
     __syncthreads();
     if (threadIdx.x == 0 && tq.nq && tq_gmax) atomicMax(tq.gmax, tq_gmax);
@@ -1297,7 +1305,7 @@ __global__ __launch_bounds__(kBlock) void k_resolve_adjoint_cached(DScene S, con
         if (pred && items.s0[i].w >= 0.f) visible = rc.vis[__float_as_uint(items.s1[i].w)] != 0;
         TexelRecord rec; rec.has = false;
         const bool queued = !FWD && tq.nq != 0;
-        adjoint_commit<FWD>(S, items, i, pred, visible, result, dL, grad_refl, grad_tex, gacc, item_vis, queued ? &tq : nullptr, queued ? &rec : nullptr);
+        adjoint_commit<FWD>(S, items, i, pred, visible, result, dL, grad_refl, grad_tex, gacc, item_vis, queued ? &tq : nullptr, &rec);
         if (queued) texel_queue_append(S, tq, Q.shard, rec, tq_hist, tq_base, &tq_gmax, grad_tex, grad_refl);
     }
     __syncthreads();
@@ -1422,7 +1430,7 @@ __global__ __launch_bounds__(kBlock) void k_skip_emitters(DScene S, int first, u
  * through the attached si.wi, to the previous vertex's.  Scenes with few differentiated vertices (a Cornell box has a few dozen) would serialise on a
  * handful of cache lines -- every path of the chip adds to the same vertices -- so those accumulate in LDS and flush once per block; large meshes scatter
  * with global atomics. */
-__global__ __launch_bounds__(kBlock) void k_shape_adjoint(DScene S, const uint32_t *item_count, uint32_t shard_cap, ItemArrays items, ShapeArrays geo, const float4 *result,
+__global__ __launch_bounds__(kBlock, HAR_SHAPE_MIN_WAVES) void k_shape_adjoint(DScene S, const uint32_t *item_count, uint32_t shard_cap, ItemArrays items, ShapeArrays geo, const float4 *result,
                                                           const float4 *dL, int has_next, WaveState next, const float4 *h0, const uint2 *h1, ReplayCache rc, ShapeTargets T) {
     /* vertex gradients: a direct-mapped LDS cache of HAR_LDS_GRAD_VERTS vertices per block (wave_cached_add3) -- every path of the chip adds to the few hundred
      * vertices in view, whatever the size of the mesh; `nacc`: the adjoints of their vertex normals (meshes with vertex normals), under the same tags */
