@@ -150,11 +150,27 @@ def load_profile(kind, workload):
     return None, None
 
 
+# kernels of a HIP-event class of har_integrator_timing: the closest-hit class holds the per-lane kernel (whole wavefront or the packets' left-overs) AND the
+# wave-shared camera-ray descent of bounce 0 (k_trace_packet) -- one family, one set of rays
+CLASS_KERNELS = {"trace_closest": ("k_trace_closest", "k_trace_packet")}
+
+
+def class_kernels(cls):
+    return CLASS_KERNELS.get(cls, ("k_" + cls,))
+
+
 def kernel_record(profile, kernel):
+    """the class's kernels of a committed PMC summary merged into one record (counter sums, dispatches, total_ms)"""
+    out = None
     for name, rec in (profile or {}).items():
-        if ("k_" + kernel) in name and "counters" in rec:
-            return rec
-    return None
+        if any(k in name for k in class_kernels(kernel)) and "counters" in rec:
+            if out is None:
+                out = {"counters": {}, "total_ms": 0.0, "calls": 0}
+            out["total_ms"] += float(rec.get("total_ms", 0.0)); out["calls"] += int(rec.get("calls", 0))
+            for cname, c in rec["counters"].items():
+                acc = out["counters"].setdefault(cname, {"sum": 0.0, "dispatches": 0})
+                acc["sum"] += float(c["sum"]); acc["dispatches"] += int(c["dispatches"])
+    return out
 
 
 def profile_matches_run(profile, timing):
@@ -166,7 +182,7 @@ def profile_matches_run(profile, timing):
     def disp(kernel):
         n = 0
         for name, rec in profile.items():
-            if ("k_" + kernel) in name:
+            if any(k in name for k in class_kernels(kernel)):
                 c = rec.get("counters", {})
                 n += int(next(iter(c.values()))["dispatches"]) if c else int(rec.get("calls", 0))
         return n

@@ -566,6 +566,7 @@ int run_chunk(HarSceneImpl *S, HarIntegratorImpl *I, const DSensor &C, int mode,
                 const PacketList pl{ I->pk_list, I->pk_counters, I->pk_counters + cs, cnt_alive(I, b), I->shard_cap / 64u + 1u };
                 HIP_TRY(hipMemsetAsync(I->pk_counters, 0, 2 * cs * sizeof(uint32_t), s));
                 launch_trace_packet(s, tgrid, S->ds.accel, cnt_alive(I, b), cur_trace(I, b), I->shard_cap, st_in, h0, h1, pl, packet_budget);
+                prof_mark(I, s, CLS_TRACE);             /* two launches of the closest-hit class: the packets, then the rays of the packets that gave up */
                 launch_trace_closest(s, tgrid, spill, S->ds.accel, pl.count, pl.cursor, I->shard_cap, st_in, h0, h1, I->status, &pl);
             } else
             launch_trace_closest(s, tgrid, spill, S->ds.accel, cnt_alive(I, b), cur_trace(I, b), I->shard_cap, st_in, h0, h1, I->status);

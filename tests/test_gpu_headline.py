@@ -69,7 +69,7 @@ def test_unsynchronised_profiled_frames_instanced1m(mi):
     torch.cuda.synchronize()
     assert integ.stats() == st0
     t = integ.timing()
-    assert int(t["frames"][0]) == frames and t["trace_closest"][1] == 8 and t["total"][0] > 0
+    assert int(t["frames"][0]) == frames and t["trace_closest"][1] == 9 and t["total"][0] > 0        # 8 bounces; the camera rays take two launches (packets, then the rays of the packets that gave up)
     integ.set_profiling(False)
     assert bool(torch.isfinite(last).all())
     assert rel_l2(last.cpu().numpy(), first.cpu().numpy()) < 1e-6             # float atomics of the film splat commute up to rounding
