@@ -28,7 +28,7 @@ struct alignas(16) Node8 {
     float px, py, pz;
     uint8_t ex, ey, ez, imask;
     uint32_t child_base, tri_base;
-    uint8_t meta[8];
+    uint8_t lmask, pad[7];          /* lmask: the child slots that are LEAVES (one primitive each: record tri_base + rank of the slot among the leaf slots); imask: the inner ones */
     uint8_t qlox[8], qloy[8], qloz[8], qhix[8], qhiy[8], qhiz[8];
 };
 static_assert(sizeof(Node8) == 80, "Node8 must be 80 bytes");
@@ -150,10 +150,34 @@ struct NoProbe {
     HAR_HD void left(bool, bool) {} HAR_HD bool back_to_front() const { return false; }
 };
 
+/* (m << 1) | sign bit of x: v_alignbit_b32 on the device */
+HAR_HD uint32_t shift_in_sign(uint32_t m, float x) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    return __builtin_amdgcn_alignbit(m, as_u32(x), 31u);
+#else
+    return (m << 1) | (as_u32(x) >> 31);
+#endif
+}
+/* bit i of x moves to bit i ^ c (x: 8 bits, c: 3 bits) */
+HAR_HD uint32_t xor_permute8(uint32_t x, uint32_t c) {
+    const uint32_t k1 = c & 1u, k2 = c & 2u, k4 = c & 4u;
+    x = ((x << k1) & 0xaau) | ((x >> k1) & ~0xaau);          /* (a & m) | (b & ~m): one v_bfi_b32 per stage */
+    x = ((x << k2) & 0xccu) | ((x >> k2) & ~0xccu);
+    x = ((x << k4) & 0xf0u) | ((x >> k4) & ~0xf0u);
+    return x;
+}
+/* next leaf of a leaf group (tg_y = hit leaf slots | the node's leaf slots << 8; 0 when no leaf is pending): returns its record index and clears it */
+HAR_HD uint32_t tg_next_leaf(uint32_t tg_x, uint32_t &tg_y) {
+    const uint32_t hl = tg_y & 0xffu, bit = 31u - clz32(hl);
+    const uint32_t idx = tg_x + popc32((tg_y >> 8) & ~(0xffffffffu << bit));
+    tg_y = (hl & ~(1u << bit)) ? (tg_y & ~(1u << bit)) : 0u;
+    return idx;
+}
+
 /*
  * One node visit: fetch the 80-byte node `index`, intersect the ray with its 8 quantised child
- * boxes and return the hits as a node group (child_base | hit-children bits in traversal order |
- * imask) and a triangle group (tri_base | 24-bit triangle mask) -- Ylitie et al.'s encoding.
+ * boxes and return the hits as a node group (child_base | hit inner children in traversal order << 24 |
+ * imask) and a leaf group (tri_base | hit leaf slots | lmask << 8) -- after Ylitie et al.'s encoding.
  */
 HAR_HD void node_visit(const Accel &A, const RaySetup &R, float tmax, uint32_t index, uint32_t &ng_x, uint32_t &ng_y, uint32_t &tg_x, uint32_t &tg_y) {
     const uint32_t *np = reinterpret_cast<const uint32_t *>(A.nodes + index);
@@ -166,8 +190,8 @@ HAR_HD void node_visit(const Accel &A, const RaySetup &R, float tmax, uint32_t i
 #else
     uint32_t w[20]; for (int i = 0; i < 20; ++i) w[i] = np[i];
 #endif
-    // w[0..2] origin, w[3] = ex | ey<<8 | ez<<16 | imask<<24, w[4] child_base, w[5] tri_base,
-    // w[6..7] meta, w[8..9] qlox, w[10..11] qloy, w[12..13] qloz, w[14..15] qhix, w[16..17] qhiy, w[18..19] qhiz
+    // w[0..2] origin, w[3] = ex | ey<<8 | ez<<16 | imask<<24, w[4] child_base, w[5] tri_base, w[6] & 0xff = lmask,
+    // w[8..9] qlox, w[10..11] qloy, w[12..13] qloz, w[14..15] qhix, w[16..17] qhiy, w[18..19] qhiz
     float sx = as_f32((w[3] & 0xffu) << 23), sy = as_f32(((w[3] >> 8) & 0xffu) << 23), sz = as_f32(((w[3] >> 16) & 0xffu) << 23);
     float ax = sx * R.idir.x, ay = sy * R.idir.y, az = sz * R.idir.z;
     float bx = (as_f32(w[0]) - R.o.x) * R.idir.x, by = (as_f32(w[1]) - R.o.y) * R.idir.y, bz = (as_f32(w[2]) - R.o.z) * R.idir.z;
@@ -176,33 +200,29 @@ HAR_HD void node_visit(const Accel &A, const RaySetup &R, float tmax, uint32_t i
     const uint32_t nxw[2] = { nx ? w[14] : w[8],  nx ? w[15] : w[9]  }, fxw[2] = { nx ? w[8]  : w[14], nx ? w[9]  : w[15] };
     const uint32_t nyw[2] = { ny ? w[16] : w[10], ny ? w[17] : w[11] }, fyw[2] = { ny ? w[10] : w[16], ny ? w[11] : w[17] };
     const uint32_t nzw[2] = { nz ? w[18] : w[12], nz ? w[19] : w[13] }, fzw[2] = { nz ? w[12] : w[18], nz ? w[13] : w[19] };
-    /* meta byte = bits(3) | index(5); inner children have index 24 + slot, which is remapped by the ray octant.
-     * Four children per dword are decoded at once: an empty child has bits == 0 and contributes nothing. */
-    const uint32_t oct4 = R.octinv * 0x01010101u;
-    uint32_t idx4[2], bits4[2];
-    for (int k = 0; k < 2; ++k) {
-        const uint32_t m = w[6 + k];
-        const uint32_t inner = ((m & (m << 1)) >> 4) & 0x01010101u;        /* bits 3 and 4 both set */
-        idx4[k] = (m ^ (oct4 & (inner * 0xffu))) & 0x1f1f1f1fu;
-        bits4[k] = (m >> 5) & 0x07070707u;
-    }
-    uint32_t hitmask = 0;
+    /* ONE BIT PER CHILD SLOT (round 4): slot i is hit when  tf * (1 + 5e-7) - tn >= 0; the sign of that (fused) difference is shifted into `miss`, slot 7 first, so
+     * that slot i ends at bit i -- an fma and a funnel shift per child where a multiply, a compare, a select and a shift-or (plus two byte extractions of a per-child
+     * meta byte) used to assemble the mask.  Leaves hold one primitive each, so a slot needs no count. */
+    uint32_t miss = 0u;
 #if defined(__HIP_DEVICE_COMPILE__)
 #pragma unroll
 #endif
-    for (int i = 0; i < 8; ++i) {
+    for (int i = 7; i >= 0; --i) {
         const int wi = i >> 2, sh = (i & 3) * 8;
         float t0x = fma_((float) ((nxw[wi] >> sh) & 0xffu), ax, bx), t1x = fma_((float) ((fxw[wi] >> sh) & 0xffu), ax, bx);
         float t0y = fma_((float) ((nyw[wi] >> sh) & 0xffu), ay, by), t1y = fma_((float) ((fyw[wi] >> sh) & 0xffu), ay, by);
         float t0z = fma_((float) ((nzw[wi] >> sh) & 0xffu), az, bz), t1z = fma_((float) ((fzw[wi] >> sh) & 0xffu), az, bz);
         float tn = fmaxf(fmaxf(t0x, t0y), fmaxf(t0z, 0.f));
         float tf = fminf(fminf(t1x, t1y), fminf(t1z, tmax));
-        const bool isect = tn <= tf * 1.0000005f;
-        hitmask |= (isect ? (bits4[wi] >> sh) & 0xffu : 0u) << ((idx4[wi] >> sh) & 0xffu);
+        miss = shift_in_sign(miss, fma_(tf, 1.0000005f, -tn));
     }
+    const uint32_t imask = w[3] >> 24, lmask = w[6] & 0xffu;
+    const uint32_t inner = ~miss & imask, leaf = ~miss & lmask;
     ng_x = w[4]; tg_x = w[5];
-    ng_y = (hitmask & 0xff000000u) | (w[3] >> 24);
-    tg_y = hitmask & 0x00ffffffu;
+    /* inner children are taken front to back along the ray: the child in slot s at position s ^ octinv (the builder stores them in octant order) -- a permutation of the
+     * eight bits by XOR on their index = three conditional swaps of neighbouring bits / pairs / nibbles, written as shifts by 0 or by the stage's distance */
+    ng_y = (xor_permute8(inner, R.octinv) << 24) | imask;
+    tg_y = leaf ? (leaf | (lmask << 8)) : 0u;                  /* leaf group: hit leaf slots | the node's leaf slots (for the rank of a slot: tg_next_leaf) */
 }
 
 /* pick the next child of a node group (front-to-back = highest bit); returns its node index.  back_to_front: a Probe's what-if (host models only) */
@@ -280,9 +300,7 @@ HAR_HD bool accel_trace(const Accel &A, Vec3 o_w, Vec3 d_w, float maxt, Hit &hit
         }
 
         while (tg_y != 0u) {
-            uint32_t bit = 31u - clz32(tg_y);
-            tg_y &= ~(1u << bit);
-            uint32_t idx = tg_x + bit;
+            uint32_t idx = tg_next_leaf(tg_x, tg_y);
             if (in_tlas) {
                 // InstanceEntry leaf: save the TLAS continuation, switch to object space
                 if (ng_y > 0x00ffffffu) {
@@ -402,9 +420,7 @@ struct Traversal {
         /* allow_inst = false (persistent kernels, deferred instance entry): a lane whose next leaf item is an instance entry waits this step out -- the
          * entry block (ray transform, reciprocals, two pushes: ~100 instructions) then runs when several lanes of the wave need it, not for one */
         if (tg_y != 0u && (FLAT || allow_inst || !in_tlas)) {
-            uint32_t bit = 31u - clz32(tg_y);
-            tg_y &= ~(1u << bit);
-            uint32_t idx = tg_x + bit;
+            uint32_t idx = tg_next_leaf(tg_x, tg_y);
             if (!FLAT && in_tlas) {
                 if (POLICY == 2 ? ng_y != 0u : ng_y > 0x00ffffffu) {      /* POLICY 2: ng may hold a waiting instance list */
                     if (sp >= Stack::Capacity) return overflow(status);

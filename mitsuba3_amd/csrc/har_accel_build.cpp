@@ -189,7 +189,8 @@ uint32_t build_bvh8(const std::vector<PrimBox> &prims, std::vector<Node8> &nodes
     auto now = [] { return std::chrono::steady_clock::now(); };
     auto t0 = now();
     Builder B(prims);
-    B.max_leaf = std::max(1u, std::min(3u, max_leaf));
+    (void) max_leaf;
+    B.max_leaf = 1;                /* one primitive per leaf: the node format holds one bit per child slot (Node8::lmask); 2 and 3 were measured slower in round 1 */
     B.bn.reserve(prims.size());
     int broot = B.build(0, (uint32_t) prims.size());
     auto t1 = now();
@@ -298,24 +299,22 @@ uint32_t build_bvh8(const std::vector<PrimBox> &prims, std::vector<Node8> &nodes
         const double org[3] = { n.px, n.py, n.pz };
         n.child_base = (uint32_t) nodes.size();
         n.tri_base = leaf_base + (uint32_t) leaf_order.size();
-        uint32_t n_internal = 0, tri_off = 0; int pos = 0;
+        uint32_t n_internal = 0;
         for (int s = 0; s < 8; ++s) {
             int c = child_in_slot[s];
             if (c < 0) continue;
             const BNode &cn = B.bn[c];
             uint8_t *q[6] = { n.qlox, n.qloy, n.qloz, n.qhix, n.qhiy, n.qhiz };
-            const int j = W == 8 ? s : pos++;              /* storage position of the child's box and meta byte */
             for (int a = 0; a < 3; ++a) {
                 double lo = std::floor(((double) cn.box.lo[a] - org[a]) / sc[a]), hi = std::ceil(((double) cn.box.hi[a] - org[a]) / sc[a]);
-                q[a][j] = (uint8_t) std::max(0.0, std::min(255.0, lo));
-                q[3 + a][j] = (uint8_t) std::max(0.0, std::min(255.0, hi));
+                q[a][s] = (uint8_t) std::max(0.0, std::min(255.0, lo));
+                q[3 + a][s] = (uint8_t) std::max(0.0, std::min(255.0, hi));
             }
             if (cn.count) {
-                n.meta[j] = (uint8_t) ((((1u << cn.count) - 1u) << 5) | tri_off);
-                for (uint32_t i = 0; i < cn.count; ++i) leaf_order.push_back(B.order[cn.first + i]);
-                tri_off += cn.count;
+                /* leaf slot: its record is tri_base + (number of leaf slots below s) -- the records are appended in slot order */
+                n.lmask |= (uint8_t) (1u << s);
+                leaf_order.push_back(B.order[cn.first]);
             } else {
-                n.meta[j] = (uint8_t) ((1u << 5) | (24u + (uint32_t) s));
                 n.imask |= (uint8_t) (1u << s);
                 ++n_internal;
             }

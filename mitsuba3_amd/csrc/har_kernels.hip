@@ -595,7 +595,7 @@ __device__ __forceinline__ void packet_node_visit(const Accel &A, const PacketBo
     const uint2 n1 = reinterpret_cast<const uint2 *>(np)[2];
     const uint32_t c = threadIdx.x & 7u;
     const uint8_t *nb = reinterpret_cast<const uint8_t *>(np);
-    const uint32_t meta = nb[24 + c];
+    const uint32_t imask = n0.w >> 24, lmask = nb[24];            /* the node's inner / leaf child slots (Node8) */
     const float q[6] = { (float) nb[32 + c], (float) nb[40 + c], (float) nb[48 + c], (float) nb[56 + c], (float) nb[64 + c], (float) nb[72 + c] };      /* qlo x y z, qhi x y z */
     const float p[3] = { __uint_as_float(n0.x), __uint_as_float(n0.y), __uint_as_float(n0.z) };
     const float sc[3] = { __uint_as_float((n0.w & 0xffu) << 23), __uint_as_float(((n0.w >> 8) & 0xffu) << 23), __uint_as_float(((n0.w >> 16) & 0xffu) << 23) };
@@ -610,18 +610,17 @@ __device__ __forceinline__ void packet_node_visit(const Accel &A, const PacketBo
         if ((B.mixed >> a) & 1u) { tn = -HAR_INF; tf = HAR_INF; }
         lb = fmaxf(lb, tn); ub = fminf(ub, tf);
     }
-    const uint32_t bits = meta >> 5;
-    uint32_t idx = meta & 31u;
-    if ((meta & 0x18u) == 0x18u) idx ^= B.octinv;                                    /* inner child: slot by the rays' octant (node_visit) */
-    uint32_t m = (lb <= ub * 1.000002f) ? bits << idx : 0u;
+    /* this lane's child: an inner one goes to position slot ^ octinv of the node group (node_visit), a leaf to its slot of the leaf group, an empty slot nowhere */
+    const uint32_t pos = ((imask >> c) & 1u) ? 1u << (24u + (c ^ B.octinv)) : ((lmask >> c) & 1u) ? 1u << c : 0u;
+    uint32_t m = (lb <= ub * 1.000002f) ? pos : 0u;
     /* OR over the eight children = over each aligned group of eight lanes */
     m |= (uint32_t) __builtin_amdgcn_update_dpp((int) m, (int) m, 0xB1, 0xF, 0xF, false);
     m |= (uint32_t) __builtin_amdgcn_update_dpp((int) m, (int) m, 0x4E, 0xF, 0xF, false);
     m |= (uint32_t) __builtin_amdgcn_update_dpp((int) m, (int) m, 0x141, 0xF, 0xF, false);
     const uint32_t hitmask = (uint32_t) __builtin_amdgcn_readfirstlane((int) m);
     ng_x = n1.x; tg_x = n1.y;
-    ng_y = (hitmask & 0xff000000u) | (n0.w >> 24);
-    tg_y = hitmask & 0x00ffffffu;
+    ng_y = (hitmask & 0xff000000u) | imask;
+    tg_y = (hitmask & 0xffu) ? ((hitmask & 0xffu) | (lmask << 8)) : 0u;
 }
 #ifndef HAR_PACKET_MIN_WAVES
 #define HAR_PACKET_MIN_WAVES 4      /* 86 registers, no scratch (8: 64 + 60 B of scratch; 4 / 6 / 8 waves measured within 0.5 % of each other, profiles/r04_ab_prb_commit.txt) */
@@ -679,9 +678,7 @@ __global__ __launch_bounds__(kBlock, HAR_PACKET_MIN_WAVES) void k_trace_packet(A
                 } else { tg_x = ng_x; tg_y = ng_y; ng_x = 0u; ng_y = 0u; }
                 bool entered = false;
                 while (state == 0 && !entered && tg_y != 0u) {
-                    const uint32_t bit = 31u - clz32(tg_y);
-                    tg_y &= ~(1u << bit);
-                    const uint32_t leaf = tg_x + bit;
+                    const uint32_t leaf = tg_next_leaf(tg_x, tg_y);
                     ++steps;
                     if (!FLAT && in_tlas) {
                         /* instance entry: the rest of the TLAS node waits on the stack, every lane takes its ray to object space (as Traversal::apply_pending does),

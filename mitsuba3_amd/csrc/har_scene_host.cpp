@@ -37,7 +37,7 @@ BlasInfo build_blas(HostScene &hs, const HarSceneDesc &d, uint32_t first_mesh, u
     BlasInfo info{};
     info.first_tri = (uint32_t) hs.tris.size(); info.tri_count = (uint32_t) recs.size(); info.empty = recs.empty();
     std::vector<uint32_t> order;
-    static const uint32_t blas_leaf = getenv("HAR_BLAS_MAX_LEAF") ? (uint32_t) atoi(getenv("HAR_BLAS_MAX_LEAF")) : 1u;   /* measured on MI355X: 1 beats 2 and 3 (fewer wasted triangle tests, esp. for any-hit rays) */
+    const uint32_t blas_leaf = 1u;           /* one primitive per leaf (Node8::lmask): 1 beat 2 and 3 in round 1 (fewer wasted triangle tests, esp. for any-hit rays) */
     static const uint32_t blas_dp_min = getenv("HAR_BVH_DP_MIN") ? (uint32_t) atol(getenv("HAR_BVH_DP_MIN")) : 128u;    /* measured: the 36-triangle Cornell box is 5 % faster with the greedy collapse */
     static const float tri_cost = getenv("HAR_BVH_CTRI") ? (float) atof(getenv("HAR_BVH_CTRI")) : 0.3f;     /* triangle test vs node visit (VALU instructions) */
     /* optimal_collapse: the top-level BLAS of a two-level scene, which EVERY ray walks -- the SAH-optimal collapse whatever its size (round 3, host model:
@@ -373,7 +373,7 @@ bool lower_scene(const HarSceneDesc &d, HostScene &hs, std::string &err) {
     hs.blas_depth = hs.stats.max_depth;
     std::vector<uint32_t> order;
     Bvh8Stats tstats;
-    static const uint32_t tlas_leaf = getenv("HAR_TLAS_MAX_LEAF") ? (uint32_t) atoi(getenv("HAR_TLAS_MAX_LEAF")) : 1u;
+    const uint32_t tlas_leaf = 1u;
     static const float inst_cost = getenv("HAR_BVH_CINST") ? (float) atof(getenv("HAR_BVH_CINST")) : 1.5f;  /* instance entry = ray transform + a BLAS root visit */
     hs.root = build_bvh8(boxes, hs.nodes, 0, order, &tstats, tlas_leaf, inst_cost, 0);
     hs.tlas_depth = tstats.max_depth; hs.stats.max_depth = std::max(hs.stats.max_depth, tstats.max_depth);

@@ -167,7 +167,9 @@ HAR_HD bool shape_item_adjoint(const DScene &S, const ShapeItem &it, bool self_o
     bool any = false;
     /* ONE copy of the directional-derivative code for both terms: unrolled, the two copies of bsdf_weighted_value_dir (every BSDF model) took the kernel to 438
      * registers (accumulation registers as spill space), one wave per SIMD */
+#if defined(__clang__)
 #pragma clang loop unroll(disable)
+#endif
     for (int term = 0; term < 2; ++term) {
         bool attached; Vec3 w, target, normal, A; float a = 0.f;
         BsdfEval e; e.value = Vec3(0.f); e.d_slot0 = Vec3(0.f);

@@ -605,9 +605,9 @@ static void pk_node_visit(const Accel &A, const PkBounds &B, float tmax_wave, ui
     const uint8_t *qlo[3] = { N.qlox, N.qloy, N.qloz }, *qhi[3] = { N.qhix, N.qhiy, N.qhiz };
     uint32_t hitmask = 0;
     for (int i = 0; i < 8; ++i) {
-        const uint32_t m = N.meta[i], bits = m >> 5; uint32_t idx = m & 31u;
-        if (bits == 0) continue;
-        if ((m & 0x18u) == 0x18u) idx ^= B.octinv;                          /* inner child: slot remapped by the octant (node_visit) */
+        const bool inner = (N.imask >> i) & 1u, leaf = (N.lmask >> i) & 1u;
+        if (!inner && !leaf) continue;
+        const uint32_t bits = 1u, idx = inner ? 24u + ((uint32_t) i ^ B.octinv) : (uint32_t) i;      /* inner child: position by the octant (node_visit); leaf: its slot */
         float lb = 0.f, ub = tmax_wave;
         for (int a = 0; a < 3; ++a) {
             if (B.mixed[a]) continue;                                        /* directions of both signs on this axis: no constraint from its slab */
@@ -627,7 +627,7 @@ static void pk_node_visit(const Accel &A, const PkBounds &B, float tmax_wave, ui
         if (lb <= ub * 1.000002f) hitmask |= bits << idx;
     }
     ng_x = N.child_base; tg_x = N.tri_base;
-    ng_y = (hitmask & 0xff000000u) | N.imask; tg_y = hitmask & 0x00ffffffu;
+    ng_y = (hitmask & 0xff000000u) | N.imask; tg_y = (hitmask & 0xffu) ? ((hitmask & 0xffu) | ((uint32_t) N.lmask << 8)) : 0u;
 }
 /* one BLAS (or the TLAS) walked by the packet; R / act / tmax / hit are per lane */
 template <bool AnyHit>
@@ -646,8 +646,7 @@ static void pk_walk(const Accel &A, uint32_t root, bool tlas, const Vec3 *o_w, c
             pk_node_visit(A, B, tw, child, ng_x, ng_y, tg_x, tg_y); C.nodes += 1;
         } else { tg_x = ng_x; tg_y = ng_y; ng_x = 0; ng_y = 0; }
         while (tg_y != 0u) {
-            const uint32_t bit = 31u - clz32(tg_y); tg_y &= ~(1u << bit);
-            const uint32_t idx = tg_x + bit;
+            const uint32_t idx = tg_next_leaf(tg_x, tg_y);
             if (tlas) {
                 const InstRec &I = A.insts[idx];
                 RaySetup Ro[64];
