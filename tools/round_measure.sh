@@ -9,6 +9,6 @@ timeout 600 python3 bench.py --gpus 1 --steps 20 --warmup 5 > gpurun_out/bench/$
 bash tools/gpu_profile.sh ${TAG} kt sq mem -- --workload instanced1m
 for wl in flat1m cornell materials1m; do timeout 300 python3 bench.py --workload $wl --steps 5 --warmup 2 --no-cpu-baseline > gpurun_out/bench/${TAG}_$wl.json 2> gpurun_out/bench/${TAG}_$wl.err; cut -c1-200 gpurun_out/bench/${TAG}_$wl.json; done
 HAR_BENCH_SHARE_GPU=1 HAR_BENCH_BACKEND=gloo timeout 300 python3 bench.py --gpus 2 --steps 3 --warmup 1 --no-cpu-baseline > gpurun_out/bench/${TAG}_n2_rehearsal.json 2> gpurun_out/bench/${TAG}_n2_rehearsal.err; echo "n2 rehearsal rc=$?"
-rocprofv3 --kernel-trace --stats -d /tmp/prof_${TAG}_prb -o r -- python3 tools/prb_breakdown.py instanced1m textured > gpurun_out/prof/${TAG}_prb_bench.log 2>&1
+timeout -k 5 240 rocprofv3 --kernel-trace --stats -d /tmp/prof_${TAG}_prb -o r -- python3 tools/prb_breakdown.py instanced1m textured > gpurun_out/prof/${TAG}_prb_bench.log 2>&1
 python3 tools/rocpd_summary.py $(find /tmp/prof_${TAG}_prb -name '*.db') --json gpurun_out/prof/${TAG}_prb_kt.json > gpurun_out/prof/${TAG}_prb_kt.txt 2>&1
 ls gpurun_out/prof | grep ${TAG}
