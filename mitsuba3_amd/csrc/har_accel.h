@@ -491,6 +491,17 @@ struct Traversal {
         }
         return false;
     }
+    /* field-wise select: this = c ? n : this (the persistent kernels' refill) */
+    HAR_HD void merge(bool c, const Traversal &n) {
+#define HAR_SEL(f) f = c ? n.f : f
+        HAR_SEL(o_w.x); HAR_SEL(o_w.y); HAR_SEL(o_w.z); HAR_SEL(d_w.x); HAR_SEL(d_w.y); HAR_SEL(d_w.z);
+        HAR_SEL(R.o.x); HAR_SEL(R.o.y); HAR_SEL(R.o.z); HAR_SEL(R.d.x); HAR_SEL(R.d.y); HAR_SEL(R.d.z);
+        HAR_SEL(R.idir.x); HAR_SEL(R.idir.y); HAR_SEL(R.idir.z); HAR_SEL(R.octinv);
+        HAR_SEL(tmax); HAR_SEL(hit.t); HAR_SEL(hit.u); HAR_SEL(hit.v); HAR_SEL(hit.prim); HAR_SEL(hit.shape); HAR_SEL(hit.inst);
+        HAR_SEL(ng_x); HAR_SEL(ng_y); HAR_SEL(tg_x); HAR_SEL(tg_y); HAR_SEL(cur_inst); HAR_SEL(sp); HAR_SEL(inst_sp); HAR_SEL(parked);
+        HAR_SEL(in_tlas); HAR_SEL(found); HAR_SEL(top_last); HAR_SEL(top_pending);
+#undef HAR_SEL
+    }
     HAR_HD bool overflow(int &status) { status = HAR_STACK_OVERFLOW; hit.t = HAR_INF; found = false; return true; }
     HAR_HD void leave_instance() {
 #if HAR_DEFER_XFORM

@@ -31,6 +31,7 @@ static constexpr int kBlock = 256;
 
 template <int CAP> struct LdsStack {
     static constexpr int Capacity = CAP;
+    static constexpr bool kSelectRefill = true;
     uint2 *col;   /* &lds[threadIdx.x]; entry l lives at col[l * kBlock] */
     __device__ __forceinline__ void push(int l, uint32_t x, uint32_t y) { col[l * kBlock] = make_uint2(x, y); }
     __device__ __forceinline__ void pop(int l, uint32_t &x, uint32_t &y) { uint2 v = col[l * kBlock]; x = v.x; y = v.y; }
@@ -38,6 +39,7 @@ template <int CAP> struct LdsStack {
 /* first CAP entries in LDS, the next SPILL in a per-thread column of HBM (entry l of thread t at spill[(l - CAP) * stride + t]) */
 template <int CAP, int SPILL> struct HybridStack {
     static constexpr int Capacity = CAP + SPILL;
+    static constexpr bool kSelectRefill = false;        /* the branch-free refill lets LLVM fold push()'s two stores into one store through a selected (LDS-or-global) pointer, which its gfx950 back end cannot select */
     uint2 *col, *spill; uint32_t stride;
     __device__ __forceinline__ void push(int l, uint32_t x, uint32_t y) {
         if (l < CAP) col[l * kBlock] = make_uint2(x, y); else spill[(size_t) (l - CAP) * stride] = make_uint2(x, y);
@@ -418,6 +420,9 @@ __global__ void k_sample_out(uint32_t n, uint32_t n_total, uint32_t first, const
 #ifndef HAR_DEFER_INST
 #define HAR_DEFER_INST 4      /* persistent traversal: instance entries wait for this many lanes (0 = enter at once; host model tools/trace_stats.py HH_DEFER_INST: -3 %; measured 4 / 6 / 8: k_resolve 26.83 -> 26.27 / 26.31 / 26.43 ms, k_trace_closest +-0) */
 #endif
+#ifndef HAR_REFILL_SELECT
+#define HAR_REFILL_SELECT 1     /* branch-free refill of the persistent traversal loop (trace_persistent); 0: the divergent `take` of rounds 1-4 */
+#endif
 #ifndef HAR_TRAV_ORDER
 #define HAR_TRAV_ORDER 0    /* measured: 0 (node, leaf, pop) 687, 2: 660, 1: 643 Mpaths/s on the 1M-tri scene */
 #endif
@@ -435,6 +440,60 @@ __device__ __forceinline__ void trace_persistent(const Accel &A, uint32_t *curso
     uint32_t idx = 0;
     Traversal<HAR_TRAV_POLICY, FLAT> T;
     T.found = false; T.hit.t = HAR_INF;
+#if HAR_REFILL_SELECT && !HAR_EXTRA_ROUNDS
+    /* BRANCH-FREE REFILL.  The same sequence of operations as the single loop below -- [refill when >= HAR_REFILL_IDLE lanes are idle] [step] ... -- written as two
+     * nested loops (refill / step until enough lanes are idle), and in the refill EVERY lane builds a fresh traversal state (the idle ones for their new ray, the
+     * others for a ray they drop again: a broadcast load) that is merged into the lane's state field by field with selects.  Written as a divergent
+     * `if (idle) take(idx, T)` inside the stepping loop, the compiler keeps the loop-carried state in a SECOND register set around the refill and copies it over,
+     * over again and back: 3 x 31 v_mov per refill, ~8 % of the instructions a wave issues (profiles/r04_isa_blocks.txt; 141 -> 63 VALU instructions per refill).
+     * Once the shard has no rays left the wave only comes back here when all its lanes are done (the old loop ran `retire` in every step of that phase). */
+    if constexpr (WaveStack::kSelectRefill) {
+        for (;;) {
+            const uint64_t idle = __ballot(!busy);
+            const uint32_t n_idle = (uint32_t) __popcll(idle);
+            if (RETIRE) { retire(!busy && has_result, idx, T); has_result = false; }
+            if (pool_next == pool_end && !exhausted) {
+                uint32_t b = 0;
+                if (lane == 0) b = atomicAdd(cursor, fetch);
+                b = (uint32_t) __builtin_amdgcn_readfirstlane((int) b);
+                if (b >= n) exhausted = true;
+                else { pool_next = b; pool_end = min(b + fetch, n); }
+            }
+            const uint32_t avail = pool_end - pool_next;
+            if (avail == 0u && n_idle == 64u) break;
+            const uint32_t rank = wave_rank(idle);
+            const bool want = !busy && rank < avail;
+            const uint32_t idx_new = min(pool_next + (want ? rank : 0u), n - 1u);      /* a lane that takes nothing still loads a ray that exists */
+            Traversal<HAR_TRAV_POLICY, FLAT> Tn;
+            const bool ok = take(idx_new, Tn);                                         /* take() is branch-free: it always begins Tn */
+            if (RETIRE) Tn.found = !ok;                                                /* nothing to trace: retire next round */
+            T.merge(want, Tn);
+            idx = want ? idx_new : idx;
+            busy = busy || (want && ok);
+            if (RETIRE) has_result = has_result || (want && !ok);
+            pool_next += min(n_idle, avail);
+            const uint32_t refill_at = (exhausted && pool_next == pool_end) ? 64u : (uint32_t) HAR_REFILL_IDLE;
+            uint32_t n_idle_now;
+            do {
+                bool allow_inst = true;
+                if (ANY && HAR_DEFER_INST && !FLAT) {
+                    const uint64_t m_inst = __ballot(busy && T.wants_instance_entry());
+                    allow_inst = (uint32_t) __popcll(m_inst) >= (uint32_t) HAR_DEFER_INST || __ballot(busy) == m_inst;
+                }
+                if (busy) {
+                    int st = 0;
+                    if (T.template step<ANY, WaveStack, NoProbe, HAR_TRAV_ORDER>(A, stack, st, NoProbe(), allow_inst)) {
+                        busy = false;
+                        if (RETIRE) has_result = true; else done(idx, T);
+                    }
+                    if (st) atomicMax(status, st);
+                }
+                n_idle_now = (uint32_t) __popcll(__ballot(!busy));
+            } while (n_idle_now < refill_at);
+        }
+        return;
+    }
+#endif
     for (;;) {
         const uint64_t idle = __ballot(!busy);
         const uint32_t n_idle = (uint32_t) __popcll(idle);
@@ -514,11 +573,11 @@ __global__ __launch_bounds__(kBlock, HAR_TRACE_MIN_WAVES) void k_trace_closest(A
     if (n == 0) return;
     auto ray_of = [&](uint32_t idx) { return LIST ? list[(size_t) shard * list_stride + (idx >> 6)] + (idx & 63u) : idx; };
     auto take = [&](uint32_t idx, Trav &T) {
-        const uint32_t r = ray_of(idx);
-        if (LIST && r >= n_rays) return false;
+        /* branch-free (trace_persistent's refill merges the state with selects): a work item past the shard's last ray begins a copy of that ray and says `false` */
+        const uint32_t r0 = ray_of(idx), r = LIST ? min(r0, n_rays - 1u) : r0;
         float4 o = a0[base + r], d = a1[base + r];
         T.begin(A, Vec3(o.x, o.y, o.z), Vec3(d.x, d.y, d.z), o.w < 0.f ? HAR_LARGEST : o.w, (A.top_last & 2u) != 0u);
-        return true;
+        return !LIST || r0 < n_rays;
     };
     auto store = [&](uint32_t idx, const Trav &T) {
         const uint32_t r = ray_of(idx);
@@ -1334,11 +1393,10 @@ __global__ __launch_bounds__(kBlock, (MODE == MODE_PRB_ADJOINT ? 1 : HAR_TRACE_M
         __syncthreads();
     }
     auto take = [&](uint32_t idx, Trav &T) {
-        float4 s0 = items.s0[base + idx];
-        if (!(s0.w >= 0.f)) return false;
-        float4 s1 = items.s1[base + idx];
+        /* branch-free (trace_persistent's refill merges the state with selects): an item without a shadow ray (maxt < 0) begins a state nobody steps */
+        const float4 s0 = items.s0[base + idx], s1 = items.s1[base + idx];
         T.begin(S.accel, Vec3(s0.x, s0.y, s0.z), Vec3(s1.x, s1.y, s1.z), s0.w, (S.accel.top_last & 1u) != 0u);
-        return true;
+        return s0.w >= 0.f;
     };
     if (MODE == MODE_PATH || MODE == MODE_PRB_PRIMAL) {
         /* forward: an unoccluded item adds its contribution to its lane's radiance (one item per lane and bounce: no race) */
