@@ -485,9 +485,18 @@ int hh_trace_stats(void *h, const HarSensor *sensor, uint32_t seed, uint32_t spp
                             for (int l = 0; l < 64; ++l) if (busy[l]) { uint32_t v = evs[slot_ray[l]][slot_pos[l]]; if ((v >> 1) & 1u) ++pend; else ++other; }
                             run_inst = pend >= defer || other == 0;
                         }
+                        /* what-if: lanes whose next step tests a triangle wait until `defer_tri` of them do (or nothing else can run) */
+                        static const int defer_tri = getenv("HH_DEFER_TRI") ? atoi(getenv("HH_DEFER_TRI")) : 0;
+                        bool run_tri = true;
+                        if (defer_tri > 0) {
+                            int pend = 0, other = 0;
+                            for (int l = 0; l < 64; ++l) if (busy[l]) { uint32_t v = evs[slot_ray[l]][slot_pos[l]]; if (v >> 8) ++pend; else ++other; }
+                            run_tri = pend >= defer_tri || other == 0;
+                        }
                         for (int l = 0; l < 64; ++l) if (busy[l]) {
                             uint32_t v = evs[slot_ray[l]][slot_pos[l]];
                             if (!run_inst && ((v >> 1) & 1u)) continue;
+                            if (!run_tri && (v >> 8)) continue;
                             slot_pos[l]++; anyn |= v & 1u; anyi |= (v >> 1) & 1u; mt = std::max(mt, v >> 8);
                             if (slot_pos[l] == evs[slot_ray[l]].size()) busy[l] = false;
                         }

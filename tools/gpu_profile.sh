@@ -25,6 +25,7 @@ for P in "${PASSES[@]}"; do
     ta)  timeout -k 5 ${PROF_TIMEOUT:-240} rocprofv3 --pmc TA_TA_BUSY_sum TA_FLAT_READ_WAVEFRONTS_sum -d $D -o r -- python bench.py --steps 1 --warmup 0 $ARGS > $OUT/${TAG}_ta_bench.log 2>&1 ;;      # more TA counters in one pass exceed the hardware: rocprofv3 aborts, then hangs in its finaliser
     tcc) timeout -k 5 ${PROF_TIMEOUT:-240} rocprofv3 --pmc TCC_HIT_sum TCC_MISS_sum -d $D -o r -- python bench.py --steps 1 --warmup 0 $ARGS > /dev/null 2>&1 ;;
   esac
-  python tools/rocpd_summary.py $(find $D -name '*.db') --json $OUT/${TAG}_$P.json > $OUT/${TAG}_$P.txt 2>&1
+  LAUNCHES=""; [ "$P" = kt ] && LAUNCHES="--launches $OUT/${TAG}_launches.txt"
+  python tools/rocpd_summary.py $(find $D -name '*.db') --json $OUT/${TAG}_$P.json $LAUNCHES > $OUT/${TAG}_$P.txt 2>&1
   [ "$P" = kt ] && find $D -name '*kernel_stats.csv' -exec cp {} $OUT/${TAG}_kernel_stats.csv \;
 done

@@ -21,6 +21,9 @@ def main():
     json_out = None
     if "--json" in args:
         k = args.index("--json"); json_out = args[k + 1]; args = args[:k] + args[k + 2:]
+    launches_out = None
+    if "--launches" in args:
+        k = args.index("--launches"); launches_out = args[k + 1]; args = args[:k] + args[k + 2:]
     summary = {}
     for path in args:
         db = sqlite3.connect(path)
@@ -52,6 +55,18 @@ def main():
             print("(no counters: %s)" % e)
 
 
+    if launches_out:
+        # per-launch table of the LAST frame (dispatch order): one line per kernel launch from the last k_raygen on
+        db = sqlite3.connect(args[0])
+        rows = db.execute("select name, start, end from kernels order by start").fetchall()
+        last = max((i for i, r in enumerate(rows) if "k_raygen" in r[0]), default=0)
+        with open(launches_out, "w") as f:
+            f.write("# kernel launches of the last frame in dispatch order: start offset (us), duration (us), gap to the previous launch's end (us)\n")
+            t0, prev_end = rows[last][1], rows[last][1]
+            for n, st, en in rows[last:]:
+                f.write("%-40s %10.1f %10.1f %8.1f\n" % (short(n), (st - t0) / 1e3, (en - st) / 1e3, (st - prev_end) / 1e3))
+                prev_end = en
+            f.write("# frame: %.1f us from the first launch's start to the last launch's end\n" % ((prev_end - t0) / 1e3))
     if json_out:
         with open(json_out, "w") as f:
             json.dump(summary, f, indent=1, sort_keys=True)
