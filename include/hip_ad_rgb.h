@@ -101,7 +101,9 @@ typedef struct HarEmitter {
     uint32_t type;        /* 0 = area (src/emitters/area.cpp on a rectangle), 1 = constant (src/emitters/constant.cpp),
                              2 = envmap (src/emitters/envmap.cpp): mesh = index of the H x W x 3 lat-long radiance image in `textures`,
                              radiance[0] = scale, radiance[1] = mis_compensation (0 / 1), to_world / to_local = emitter transform,
-                             3 = area on any top-level triangle mesh `mesh` (Mesh::sample_position, src/render/mesh.cpp:1662-1712): radiance only */
+                             3 = area on any top-level triangle mesh `mesh` (Mesh::sample_position, src/render/mesh.cpp:1662-1712): radiance only,
+                             4 = point (src/emitters/point.cpp): radiance = the radiant intensity, to_world[9..11] = the position (m_position,
+                             point.cpp:62-77: `position` or the translation of `to_world`); a delta emitter -- sampled with MIS weight 1, never hit */
     uint32_t mesh;
     float radiance[3];
     float to_world[12];   /* column-major 3x4 */

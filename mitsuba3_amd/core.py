@@ -830,6 +830,21 @@ class ConstantEmitter:
         self.radiance = _rgb_value(rad, 1.0, bounded=False)
 
 
+class PointLight:
+    """PointLight (src/emitters/point.cpp): isotropic point source of radiant `intensity` at `position` (or the translation of `to_world`);
+    EmitterFlags::DeltaPosition -- only emitter sampling finds it, with MIS weight 1 (path.cpp:274, prb.py:211)."""
+
+    def __init__(self, props):
+        _check_props("point", props, ('position', 'to_world', 'intensity'), unsupported=(('sampling_weight', 1.0),))
+        if 'position' in props:
+            if 'to_world' in props:                                  # point.cpp:65-68
+                raise RuntimeError("Only one of the parameters 'position' and 'to_world' can be specified at the same time!'")
+            self.position = _f32(list(props['position'])).reshape(3)
+        else:
+            self.position = _f32(props.get('to_world', ScalarTransform4f()).col_major_3x4()[9:12])      # m_to_world.translation(), point.cpp:72
+        self.intensity = _rgb_value(props.get('intensity', {'type': 'rgb', 'value': 1.0}), 1.0, bounded=False)   # get_emissive_texture("intensity", 1.f), :77
+
+
 class EnvmapEmitter:
     """EnvironmentMapEmitter (src/emitters/envmap.cpp): lat-long radiance image, importance sampled by luminance * sin(theta)."""
 
@@ -1220,13 +1235,17 @@ class Scene:
         # Scene::emitters() order = declaration order of the children (scene.cpp:40-70): shapes with an area emitter and
         # stand-alone emitters; the uniform emitter selection of sample_emitter() depends on it
         self._emitter_order = [key for key, obj in children.items()
-                               if (isinstance(obj, Mesh) and obj.emitter is not None) or isinstance(obj, (ConstantEmitter, EnvmapEmitter))]
+                               if (isinstance(obj, Mesh) and obj.emitter is not None) or isinstance(obj, (ConstantEmitter, EnvmapEmitter, PointLight))]
         self.emitters = [None] * len(self._emitter_order)
         if sum(isinstance(o, (ConstantEmitter, EnvmapEmitter)) for o in children.values()) > 1:
             raise RuntimeError("Only one environment emitter can be specified per scene.")
         for key, obj in children.items():
             if isinstance(obj, ConstantEmitter):
                 self.emitters[self._emitter_order.index(key)] = dict(type=1, mesh=0xffffffff, radiance=obj.radiance, to_world=[0.0] * 12,
+                                                                     normal=[0.0] * 3, inv_area=0.0)
+            elif isinstance(obj, PointLight):                   # HarEmitter type 4: `radiance` = intensity, to_world[9..11] = position
+                self.emitters[self._emitter_order.index(key)] = dict(type=4, mesh=0xffffffff, radiance=obj.intensity,
+                                                                     to_world=[1.0, 0.0, 0.0, 0.0, 1.0, 0.0, 0.0, 0.0, 1.0] + [float(x) for x in obj.position],
                                                                      normal=[0.0] * 3, inv_area=0.0)
             elif isinstance(obj, EnvmapEmitter):                # the radiance image travels in the texture table
                 self.emitters[self._emitter_order.index(key)] = dict(
@@ -1434,6 +1453,8 @@ class Scene:
                 keys[key + ".emitter.radiance.value"] = ("emit", i)
             elif e["type"] == 1:
                 keys[key + ".radiance.value"] = ("emit", i)
+            elif e["type"] == 4:                                  # PointLight::traverse (point.cpp:84-88): `intensity` is the differentiable one
+                keys[key + ".intensity.value"] = ("emit", i)
         return keys
 
     def _bsdf_param_keys(self):
@@ -1669,7 +1690,7 @@ def _mk_scene(props, named, key):
         if k == 'type' or k in children:
             continue
         obj = _resolve(v, named, k) if isinstance(v, dict) else v
-        if isinstance(obj, (Mesh, Sensor, Integrator, BSDF, ShapeGroup, Instance, ConstantEmitter, EnvmapEmitter)):
+        if isinstance(obj, (Mesh, Sensor, Integrator, BSDF, ShapeGroup, Instance, ConstantEmitter, EnvmapEmitter, PointLight)):
             if isinstance(obj, ShapeGroup):
                 named[k] = obj
             children[k] = obj
@@ -1743,7 +1764,7 @@ for _name, _fn in {
     'hdrfilm': lambda p, n, k: Film(p),
     'independent': lambda p, n, k: Sampler(p),
     'diffuse': lambda p, n, k: BSDF(p, id=k), 'dielectric': lambda p, n, k: BSDF(p, id=k), 'roughconductor': lambda p, n, k: BSDF(p, id=k),
-    'roughplastic': lambda p, n, k: BSDF(p, id=k), 'conductor': lambda p, n, k: BSDF(p, id=k), 'plastic': lambda p, n, k: BSDF(p, id=k), 'twosided': _mk_twosided, 'constant': lambda p, n, k: ConstantEmitter(p), 'envmap': lambda p, n, k: EnvmapEmitter(p),
+    'roughplastic': lambda p, n, k: BSDF(p, id=k), 'conductor': lambda p, n, k: BSDF(p, id=k), 'plastic': lambda p, n, k: BSDF(p, id=k), 'twosided': _mk_twosided, 'constant': lambda p, n, k: ConstantEmitter(p), 'envmap': lambda p, n, k: EnvmapEmitter(p), 'point': lambda p, n, k: PointLight(p),
     'rectangle': lambda p, n, k: _shape_common(_rectangle(p), p, n),
     'cube': lambda p, n, k: _shape_common(_cube(p), p, n),
     'mesh': _mk_mesh, 'ply': _mk_ply, 'obj': _mk_obj, 'serialized': _mk_serialized,

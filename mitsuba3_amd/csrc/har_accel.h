@@ -493,6 +493,7 @@ struct Traversal {
     }
     /* field-wise select: this = c ? n : this (the persistent kernels' refill) */
     HAR_HD void merge(bool c, const Traversal &n) {
+        static_assert(sizeof(Traversal) == 128, "Traversal gained or lost a member: bring merge() up to date");
 #define HAR_SEL(f) f = c ? n.f : f
         HAR_SEL(o_w.x); HAR_SEL(o_w.y); HAR_SEL(o_w.z); HAR_SEL(d_w.x); HAR_SEL(d_w.y); HAR_SEL(d_w.z);
         HAR_SEL(R.o.x); HAR_SEL(R.o.y); HAR_SEL(R.o.z); HAR_SEL(R.d.x); HAR_SEL(R.d.y); HAR_SEL(R.d.z);

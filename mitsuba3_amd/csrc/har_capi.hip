@@ -776,7 +776,7 @@ int har_scene_create(const HarSceneDesc *desc, HarScene *out) {
     D.env_emitter = hs.env_emitter;
     D.bsdf_types = 0; for (const DBsdf &b : hs.bsdfs) D.bsdf_types |= (1u << b.type) | ((b.flags & BF_TWOSIDED) ? 0x80000000u : 0u);
     up(hs.emitter_cdf, &D.emitter_cdf);
-    if (hs.has_envmap || hs.has_mesh_emitters) D.bsdf_types |= HAR_SCENE_ENVMAP;
+    if (hs.has_envmap || hs.has_mesh_emitters || hs.has_point_emitters) D.bsdf_types |= HAR_SCENE_ENVMAP;
     /* the depth-first bound of the BVH must fit the traversal stacks (LDS entries + HBM spill columns): a deeper scene is refused here instead of
      * rendering with rays that overflow (an overflowing ray is a miss + a status word that only har_render_stats reads) */
     const uint32_t stack_cap = (uint32_t) std::min(HAR_LDS_STACK_DEPTH, HAR_LDS_STACK_SMALL + HAR_STACK_SPILL);
@@ -1378,7 +1378,7 @@ int har_integrator_set_grad_positions(HarIntegrator I, HarScene S, float *const 
         /* the hand-derived adjoint of har_shape_grad.h covers top-level meshes, flat-shaded or with (regenerated) vertex normals, carrying any BSDF with a non-delta lobe (the directional derivatives
          * of the models come from har_bsdf_dir.h); the rest of the scene may carry any model -- a vertex next to moving geometry contributes through its
          * attached si.wi (prb.py:128-140) */
-        if (S->ds.bsdf_types & HAR_SCENE_ENVMAP) return fail("vertex-position gradients are not implemented for scenes with an environment map or a mesh area light");
+        if (S->ds.bsdf_types & HAR_SCENE_ENVMAP) return fail("vertex-position gradients are not implemented for scenes with an environment map, a mesh area light or a point light");
         const size_t nm = S->hs.meshes.size();
         offset.assign(nm, -1); user.assign(nm, nullptr); count.assign(nm, 0);
         for (size_t m = 0; m < nm; ++m) {          /* top-level meshes, then the meshes of the shape groups (vertex positions shared by all their instances) */
@@ -1419,7 +1419,7 @@ int har_integrator_set_grad_instances(HarIntegrator I, HarScene S, float *grad_t
     if (grad_to_world) {
         if (!S) return fail("null scene");
         /* as for the vertex positions: any BSDF with a non-delta lobe on the moving geometry, i.e. on the meshes of the shape groups */
-        if (S->ds.bsdf_types & HAR_SCENE_ENVMAP) return fail("instance to_world gradients are not implemented for scenes with an environment map or a mesh area light");
+        if (S->ds.bsdf_types & HAR_SCENE_ENVMAP) return fail("instance to_world gradients are not implemented for scenes with an environment map, a mesh area light or a point light");
         for (size_t m = S->hs.top_mesh_count; m < S->hs.meshes.size(); ++m)
             if (!record_has_smooth_lobe(S->hs, S->hs.meshes[m].bsdf)) return fail("instance to_world gradients: an instanced mesh cannot carry a BSDF made of delta lobes only (`dielectric`, `conductor`); top-level meshes may");
         n = (uint32_t) S->hs.insts.size();

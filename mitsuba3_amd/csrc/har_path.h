@@ -176,6 +176,7 @@ HAR_HD void shade_lane(const DScene &S, const ShadeParams &P, const PathState &s
     if (!(P.flags & HAR_SHADE_SCALAR_DRAWS) || smooth) { ex = pcg32_next_float(rng, inc); ey = pcg32_next_float(rng, inc); }
     DirSample ds; ds.pdf = 0.f; ds.d = Vec3(0.f); ds.p = Vec3(0.f); ds.n = Vec3(0.f); ds.dist = 0.f;
     Vec3 em_weight(0.f); float em_unit = 0.f; uint32_t em_sampled = 0;
+    bool em_delta = false;                                       /* DirectionSample::delta: a point light's sample carries MIS weight 1 (path.cpp:274, prb.py:211) */
     bool active_em = active_next && S.n_emitters > 0 && smooth;
     if (active_em) {
         uint32_t index = 0; float wgt = 1.f;
@@ -187,6 +188,9 @@ HAR_HD void shade_lane(const DScene &S, const ShadeParams &P, const PathState &s
         if ((TYPES & HAR_SCENE_ENVMAP) != 0u && S.emitters[index].type == 2u) envmap_sample_direction(*S.envmap, si.p, ex, ey, ds, em_weight);
         else if ((TYPES & HAR_SCENE_ENVMAP) != 0u && S.emitters[index].type == 3u)
             mesh_emitter_sample_direction(S, S.emitters[index], si.p, ex, ey, ds, em_weight, MODE == MODE_PRB_ADJOINT ? &em_unit : nullptr);
+        else if ((TYPES & HAR_SCENE_ENVMAP) != 0u && S.emitters[index].type == 4u) {
+            point_sample_direction(S.emitters[index], si.p, ds, em_weight, MODE == MODE_PRB_ADJOINT ? &em_unit : nullptr); em_delta = true;
+        }
         else emitter_sample_direction(S.emitters[index], si.p, ex, ey, ds, em_weight, MODE == MODE_PRB_ADJOINT ? &em_unit : nullptr);
         ds.pdf *= pmf; em_weight = em_weight * wgt; em_unit *= wgt; em_sampled = index;
         active_em = ds.pdf != 0.f;
@@ -203,7 +207,7 @@ HAR_HD void shade_lane(const DScene &S, const ShadeParams &P, const PathState &s
     /* ---- NEE contribution (path.cpp:271-281, prb.py:210-216); visibility is resolved by the shadow kernel */
     R.contrib = Vec3(0.f); R.dLr_drho = Vec3(0.f);
     if (active_em) {
-        float mis_em = mis_weight(ds.pdf, ev.pdf);
+        float mis_em = ((TYPES & HAR_SCENE_ENVMAP) != 0u && em_delta) ? 1.f : mis_weight(ds.pdf, ev.pdf);
         if (MODE == MODE_PATH) R.contrib = st.throughput * ((ev.value * em_weight) * mis_em);
         else {
             R.contrib = ((st.throughput * mis_em) * ev.value) * em_weight;

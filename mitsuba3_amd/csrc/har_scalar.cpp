@@ -61,7 +61,7 @@ struct BoundScene {
         S.env_emitter = hs.env_emitter;
         S.bsdf_types = 0; for (const DBsdf &b : hs.bsdfs) S.bsdf_types |= (1u << b.type) | ((b.flags & BF_TWOSIDED) ? 0x80000000u : 0u);
         S.envmap = nullptr; S.emitter_cdf = hs.emitter_cdf.data();
-        if (hs.has_mesh_emitters) S.bsdf_types |= HAR_SCENE_ENVMAP;
+        if (hs.has_mesh_emitters || hs.has_point_emitters) S.bsdf_types |= HAR_SCENE_ENVMAP;
         if (hs.has_envmap) { hs.envmap.tex = hs.env_tex.data(); hs.envmap.warp = hs.env_warp.data(); S.envmap = &hs.envmap; S.bsdf_types |= HAR_SCENE_ENVMAP; }
     }
 };

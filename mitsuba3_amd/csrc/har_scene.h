@@ -407,6 +407,17 @@ HAR_HD float envmap_pdf_direction(const DEnvmap &E, Vec3 d_world) {
 /* EnvironmentMapEmitter::sample_direction (envmap.cpp:284-323) */
 HAR_HD void envmap_sample_direction(const DEnvmap &E, Vec3 ref_p, float sx, float sy, struct DirSample &ds, Vec3 &spec);
 
+/* PointLight::sample_direction (src/emitters/point.cpp:119-148): emitter type 4, position in to_world[9..11], `radiance` = radiant intensity; pdf 1, delta */
+HAR_HD void point_sample_direction(const DEmitter &E, Vec3 ref_p, DirSample &ds, Vec3 &spec, float *unit = nullptr) {
+    ds.p = Vec3(E.to_world[9], E.to_world[10], E.to_world[11]); ds.n = Vec3(0.f); ds.pdf = 1.f;
+    ds.d = ds.p - ref_p;
+    const float dist2 = dot3(ds.d, ds.d), inv_dist = rsqrt_(dist2);
+    ds.dist = sqrtf(dist2);
+    ds.d = ds.d * inv_dist;
+    const float w = inv_dist * inv_dist;
+    spec = Vec3(E.radiance[0], E.radiance[1], E.radiance[2]) * w;
+    if (unit) *unit = w;
+}
 /* `unit` (optional): the weight the sample would carry for a unit radiance, i.e. d spec / d radiance */
 HAR_HD void emitter_sample_direction(const DEmitter &E, Vec3 ref_p, float sx, float sy, DirSample &ds, Vec3 &spec, float *unit = nullptr) {
     if (E.type == 1u) {                                     /* ConstantBackgroundEmitter::sample_direction, constant.cpp:127-153 */

@@ -255,11 +255,12 @@ bool lower_scene(const HarSceneDesc &d, HostScene &hs, std::string &err) {
     }
     for (uint32_t i = 0; i < d.emitter_count; ++i) {
         const HarEmitter &e = d.emitters[i];
-        if (e.type > 3) { err = "unsupported emitter type (`area`, `constant` and `envmap` are implemented)"; return false; }
-        const bool area = e.type == 0 || e.type == 3;
+        if (e.type > 4) { err = "unsupported emitter type (`area`, `constant`, `envmap` and `point` are implemented)"; return false; }
+        const bool area = e.type == 0 || e.type == 3, point = e.type == 4;
         if (area && e.mesh >= d.top_mesh_count) { err = "area emitter must be attached to a top-level mesh"; return false; }
-        if (!area && hs.env_emitter >= 0) { err = "Only one environment emitter can be specified per scene."; return false; }   /* scene.cpp:64-65 */
-        if (!area) hs.env_emitter = (int32_t) i;
+        if (!area && !point && hs.env_emitter >= 0) { err = "Only one environment emitter can be specified per scene."; return false; }   /* scene.cpp:64-65 */
+        if (!area && !point) hs.env_emitter = (int32_t) i;
+        if (point) hs.has_point_emitters = true;
         if (e.type == 2) {
             if (e.mesh >= d.texture_count) { err = "envmap emitter references a bitmap that does not exist"; return false; }
             if (!build_envmap(hs, d.textures[e.mesh], e, err)) return false;

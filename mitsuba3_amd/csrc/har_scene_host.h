@@ -28,6 +28,7 @@ struct HostScene {
     /* environment map (emitter type 2): halo'ed radiance storage, hierarchical warp storage, record without device pointers */
     std::vector<float> env_tex, env_warp; DEnvmap envmap{}; bool has_envmap = false;
     std::vector<float> emitter_cdf; bool has_mesh_emitters = false;      /* face-area tables of the mesh area lights (emitter type 3) */
+    bool has_point_emitters = false;                                     /* emitter type 4 (delta position): shaded by the kernels with the generic emitter code */
     uint32_t root = 0;
     bool has_tlas = false;
     Bvh8Stats stats;

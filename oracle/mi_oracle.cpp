@@ -424,7 +424,7 @@ static inline void diffuse_sample(V3 refl, V3 wi, float s2x, float s2y, V3 &wo, 
     weight = (wi.z > 0.f && pdf > 0.f) ? refl : V3(0.f);
 }
 
-struct DS { V3 p, n, d; float dist = 0, pdf = 0; int emitter = -1; };
+struct DS { V3 p, n, d; float dist = 0, pdf = 0; int emitter = -1; bool delta = false; };
 
 /* AreaLight::sample_direction (src/emitters/area.cpp:118-168) over
  * Shape::sample_direction (src/render/shape.cpp:93-110) and
@@ -474,8 +474,20 @@ static inline void mesh_sample_position(const Mesh &m, const Scene::AreaPmf &d, 
     n = normalize(n);
     pdf = d.normalization;
 }
+/* PointLight::sample_direction (src/emitters/point.cpp:119-148): the position is to_world[9..11], `radiance` holds the radiant intensity */
+static inline void point_sample_direction(const OrcEmitter &e, V3 ref_p, DS &ds, V3 &spec, float *unit) {
+    ds.p = V3(e.to_world[9], e.to_world[10], e.to_world[11]); ds.n = V3(0.f); ds.pdf = 1.f; ds.delta = true;
+    ds.d = ds.p - ref_p;
+    const float dist2 = squared_norm(ds.d), inv_dist = rsqrt(dist2);
+    ds.dist = std::sqrt(dist2);
+    ds.d = ds.d * inv_dist;
+    const float w = sqr(inv_dist);
+    spec = V3(e.radiance[0], e.radiance[1], e.radiance[2]) * w;
+    if (unit) *unit = w;
+}
 static inline void emitter_sample_direction(const Scene &sc, uint32_t index, V3 ref_p, float sx, float sy, DS &ds, V3 &spec, float *unit = nullptr) {
     const OrcEmitter &e = sc.emitters[index];
+    if (e.type == 4) { point_sample_direction(e, ref_p, ds, spec, unit); return; }
     if (e.type == 3) mesh_sample_position(sc.meshes[e.mesh], sc.area_pmf[index], sx, sy, ds.p, ds.n, ds.pdf);
     else {          // Rectangle::sample_position (rectangle.cpp:159-170)
         ds.p = xf_point(e.to_world, V3(fmadd(sx, 2.f, -1.f), fmadd(sy, 2.f, -1.f), 0.f));
@@ -752,7 +764,7 @@ static V3 path_sample(const Scene &sc, Pcg32 &rng, Ray ray, uint32_t max_depth, 
         BSDFEval ev = bsdf_eval_pdf(bsdf, wo);                                 // bsdf.cpp:21-31 eval_pdf_sample
         V3 bsdf_weight; BSDFSample bs = bsdf_sample(bsdf, s1, s2x, s2y, bsdf_weight);
         if (active_em) {                                      // path.cpp:271-281
-            float mis_em = mis_weight(ds.pdf, ev.pdf);
+            float mis_em = ds.delta ? 1.f : mis_weight(ds.pdf, ev.pdf);              // path.cpp:274: dr::select(ds.delta, 1.f, mis_weight(ds.pdf, bsdf_pdf))
             result = fmadd(throughput, (ev.value * em_weight) * mis_em, result);
         }
         ray = spawn_ray(si, si.to_world(bs.wo));              // path.cpp:287
@@ -1223,7 +1235,7 @@ static V3 prb_sample(const Scene &sc, Pcg32 &rng, Ray ray, uint32_t max_depth, u
         if (active_em) {
             V3 wo = si.to_local(ds.d); wo_em = wo;
             BSDFEval ev = bsdf_eval_pdf(bsdf, wo);
-            mis_em = mis_weight(ds.pdf, ev.pdf);
+            mis_em = ds.delta ? 1.f : mis_weight(ds.pdf, ev.pdf);                   // prb.py:211
             Lr_dir = ((beta * mis_em) * ev.value) * em_weight;
             dLr_dir_drho = ((beta * mis_em) * ev.d_slot0) * em_weight;           // d/d slot0 of the line above
             if (!primal && grad && grad->emit && sc.emitters[ds.emitter].type != 2) {   // em_weight = radiance * em_unit (prb.py:198-206, attached eval_emitter_direction)
@@ -2041,9 +2053,11 @@ int orc_render_prb_backward_lanes(void *scene, const OrcSensor *sp, const float 
 }
 /* + d/d(vertex positions) of the meshes with pos_mask[m] != 0: grad_positions[m] = 3 doubles per vertex (accumulated into).
  * Returns -2 when the scene holds a BSDF other than plain `diffuse`, -3 for a mesh with vertex normals / inside a shape group. */
+static bool has_point_emitter(void *scene) { for (const OrcEmitter &e : ((Scene *) scene)->emitters) if (e.type == 4) return true; return false; }
 int orc_render_prb_backward_shape(void *scene, const OrcSensor *sp, const float *grad_in, uint32_t seed, uint32_t spp,
                                   int32_t max_depth, int32_t rr_depth, float *grad_reflectance, float *const *grad_textures,
                                   const uint8_t *pos_mask, double *const *grad_positions, OrcStats *stats, int threads) {
+    if (has_point_emitter(scene)) return -3;       /* the geometry-attached emitter terms are restated for surface and environment emitters only */
     return prb_backward_impl(scene, sp, grad_in, seed, spp, max_depth, rr_depth, grad_reflectance, grad_textures, nullptr, pos_mask, grad_positions, stats, threads);
 }
 /* + d/d(to_world) of the instances with inst_mask[i] != 0 (Instance::compute_surface_interaction, instance.cpp:150-266, with an attached transform):
@@ -2051,6 +2065,7 @@ int orc_render_prb_backward_shape(void *scene, const OrcSensor *sp, const float 
 int orc_render_prb_backward_instances(void *scene, const OrcSensor *sp, const float *grad_in, uint32_t seed, uint32_t spp,
                                       int32_t max_depth, int32_t rr_depth, float *grad_reflectance, float *const *grad_textures,
                                       const uint8_t *inst_mask, double *grad_to_world, OrcStats *stats, int threads) {
+    if (has_point_emitter(scene)) return -3;
     return prb_backward_impl(scene, sp, grad_in, seed, spp, max_depth, rr_depth, grad_reflectance, grad_textures, nullptr, nullptr, nullptr, stats, threads,
                              0, 0, nullptr, nullptr, inst_mask, grad_to_world);
 }

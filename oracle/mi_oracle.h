@@ -77,7 +77,8 @@ typedef struct OrcEmitter {
     uint32_t type;        /* 0 = area light on a rectangle, 1 = constant environment (src/emitters/constant.cpp; radiance only),
                              2 = environment map (src/emitters/envmap.cpp): mesh = index of the H x W x 3 image in `textures`,
                              radiance[0] = scale, radiance[1] = mis_compensation (0 / 1), to_world / to_local = emitter transform,
-                             3 = area light on a top-level triangle mesh (`mesh`; Mesh::sample_position, src/render/mesh.cpp:1662-1712) */
+                             3 = area light on a top-level triangle mesh (`mesh`; Mesh::sample_position, src/render/mesh.cpp:1662-1712),
+                             4 = point light (src/emitters/point.cpp): radiance = radiant intensity, to_world[9..11] = position */
     uint32_t mesh;        /* mesh that carries the emitter */
     float radiance[3];
     float to_world[12];   /* rectangle to_world, column-major 3x4 */

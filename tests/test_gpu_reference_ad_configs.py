@@ -1,6 +1,6 @@
 """The reference's AD integrator tests re-hosted on the product (src/integrators/tests/test_ad_integrators.py): the dict-only configurations
-DiffuseAlbedoConfig, DiffuseAlbedoGIConfig, AreaLightRadianceConfig, DirectlyVisibleAreaLightRadianceConfig, ConstantEmitterRadianceConfig and
-CropWindowConfig (:227-424; of BASIC_CONFIGS_LIST the point light and the OBJ-normals configs are outside the path), the forward-mode check of test02_rendering_forward (:1318-1356)
+DiffuseAlbedoConfig, DiffuseAlbedoGIConfig, AreaLightRadianceConfig, DirectlyVisibleAreaLightRadianceConfig, PointLightIntensityConfig,
+ConstantEmitterRadianceConfig and CropWindowConfig (:227-424; of BASIC_CONFIGS_LIST the OBJ-normals configs are outside the path), the forward-mode check of test02_rendering_forward (:1318-1356)
 and the backward check of test03_rendering_backward (:1359-1396), with the error measures of check_image_error / check_gradient_error (:41-130).
 
 The reference compares against finite-difference images it ships as EXR files (tests/integrators/*.exr: absent here) which its
@@ -43,6 +43,10 @@ def config(mi, name):
     if name == "directly_visible_area_light_radiance":
         d = {"type": "scene", "light": {"type": "rectangle", "emitter": {"type": "area", "radiance": {"type": "rgb", "value": [1.0, 1.0, 1.0]}}}}
         return d, sensor, "light.emitter.radiance.value", 2, dict(mean=0.02, max=0.2, bwd=0.02)
+    if name == "point_light_intensity":           # PointLightIntensityConfig (:348-367): off-camera point light over a white plane
+        d = {"type": "scene", "plane": {"type": "rectangle", "bsdf": {"type": "diffuse", "reflectance": {"type": "rgb", "value": [1.0, 1.0, 1.0]}}}, "sphere": uv_sphere(),
+             "light": {"type": "point", "position": [1.25, 0.0, 1.0], "intensity": {"type": "rgb", "value": [5.0, 5.0, 5.0]}}}
+        return d, sensor, "light.intensity.value", 2, dict(mean=0.02, max=0.2, bwd=0.002)
     if name == "constant_emitter_radiance":
         d = {"type": "scene", "plane": {"type": "rectangle", "bsdf": {"type": "diffuse"}}, "sphere": uv_sphere(), "light": {"type": "constant"}}
         return d, sensor, "light.radiance.value", 2, dict(mean=0.02, max=0.1, bwd=0.02)
@@ -59,7 +63,7 @@ def config(mi, name):
 
 
 @pytest.mark.parametrize("name", ["diffuse_albedo", "diffuse_albedo_gi", "area_light_radiance", "directly_visible_area_light_radiance",
-                                  "constant_emitter_radiance", "crop_window"])
+                                  "point_light_intensity", "constant_emitter_radiance", "crop_window"])
 def test_reference_ad_config_forward_and_backward(mi, name):
     import torch
     d, sensor, key, max_depth, thr = config(mi, name)
