@@ -62,6 +62,14 @@ void *hh_scene_create(const HarSceneDesc *d, char *err, int errlen) {
     return H;
 }
 void hh_scene_destroy(void *h) { delete (HScene *) h; }
+/* FNV-1a over the bytes of the node array, the triangle records and the instance records: the builder's output, for tests that compare builds */
+void hh_accel_hash(void *h, uint64_t out[3]) {
+    HScene *H = (HScene *) h;
+    auto fnv = [](const void *p, size_t n) { uint64_t x = 1469598103934665603ull; const unsigned char *b = (const unsigned char *) p; for (size_t i = 0; i < n; ++i) { x ^= b[i]; x *= 1099511628211ull; } return x; };
+    out[0] = fnv(H->hs.nodes.data(), H->hs.nodes.size() * sizeof(Node8));
+    out[1] = fnv(H->hs.tris.data(), H->hs.tris.size() * sizeof(TriRec));
+    out[2] = fnv(H->hs.inst_recs.data(), H->hs.inst_recs.size() * sizeof(InstRec));
+}
 void hh_scene_info(void *h, uint64_t info[4]) {
     HScene *H = (HScene *) h; info[0] = H->hs.nodes.size(); info[1] = H->hs.tris.size(); info[2] = H->hs.stats.max_depth; info[3] = H->hs.inst_recs.size();
 }

@@ -520,3 +520,23 @@ def test_usable_core_count_follows_affinity_and_container_quota(O):
         except OSError:
             pass
     assert H.hh_usable_cores() == O.lib().orc_default_threads() == want >= 1
+
+
+def test_builder_threads_do_not_change_the_tree():
+    """har_accel_build.cpp: the collapse (dynamic program) and the node emission run on several threads for large primitive sets -- subtrees are swept / emitted
+    concurrently into ranges known from a counting pass.  The arrays must be the sequential walk's byte for byte: same node order, same records, whatever the
+    thread count (HAR_BUILD_EMIT_THREADS is read once per process, hence the subprocesses)."""
+    import subprocess, sys
+    code = ("import sys, ctypes as C; sys.path.insert(0, %r)\n"
+            "import mitsuba3_amd as mi; mi.set_variant('hip_ad_rgb')\n"
+            "H = C.CDLL(%r); H.hh_scene_create.restype = C.c_void_p\n"
+            "for d in (mi.instanced_spheres_scene(width=16, height=16, spp=1, grid=3, n_u=100, n_v=50, flatten=True), mi.instanced_spheres_scene(width=16, height=16, spp=1, grid=4, n_u=40, n_v=20), mi.cornell_box()):\n"
+            "    s = mi.load_dict(d); desc = s.desc(); err = C.create_string_buffer(256); h = C.c_void_p(H.hh_scene_create(C.byref(desc), err, 256)); assert h, err.value\n"
+            "    out = (C.c_uint64 * 3)(); H.hh_accel_hash(h, out); info = (C.c_uint64 * 4)(); H.hh_scene_info(h, info); print(list(out), list(info))\n"
+            % (ROOT, os.path.join(ROOT, "tests", "host_harness", "libhost_harness.so")))
+    outs = []
+    for threads in ("1", "3", "8"):
+        env = dict(os.environ); env["HAR_BUILD_EMIT_THREADS"] = threads
+        outs.append(subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, check=True).stdout)
+    assert outs[0].count("\n") == 3 and "[" in outs[0]
+    assert outs[0] == outs[1] == outs[2]
