@@ -447,20 +447,31 @@ static inline void constant_sample_direction(const OrcEmitter &e, const EnvSpher
 }
 /* Mesh::sample_position (src/render/mesh.cpp:1662-1712) with DiscreteDistribution::sample_reuse (include/mitsuba/core/distr_1d.h:117-183; the JIT
  * predicate of `sample`, dr::binary_search over [0, n - 1]) and warp::square_to_uniform_triangle (warp.h:153-156) */
-static inline void mesh_sample_position(const Mesh &m, const Scene::AreaPmf &d, float sx, float sy, V3 &p, V3 &n, float &pdf) {
-    const uint32_t nf = (uint32_t) d.pmf.size();
-    float value = sy * d.sum;
-    uint32_t start = 0, end = nf - 1, iterations = 0;
+/* DiscreteDistribution::sample (distr_1d.h:117-140, JIT branch): value *= sum; dr::binary_search over [0, n - 1] with the predicate
+ * (cdf[i] < value || cdf[i] == 0) && cdf[i] != sum -- the first bucket whose running sum reaches the value, skipping empty buckets at either end */
+static inline uint32_t discrete_sample(const float *cdf, uint32_t n, float sum, float value01) {
+    const float value = value01 * sum;
+    uint32_t start = 0, end = n - 1, iterations = 0;
     if (start < end) { uint32_t span = end - start; iterations = 1; while (span >>= 1) ++iterations; }
     for (uint32_t i = 0; i < iterations; ++i) {
         uint32_t middle = (start + end) >> 1;
-        float c = d.cdf[middle];
-        bool cond = ((c < value) || c == 0.f) && c != d.sum;
+        float c = cdf[middle];
+        bool cond = ((c < value) || c == 0.f) && c != sum;
         if (cond) start = std::min(middle + 1, end); else end = middle;
     }
-    const uint32_t idx = start;
-    float pmf_n = d.pmf[idx] * d.normalization, cdf_n = idx > 0 ? d.cdf[idx - 1] * d.normalization : 0.f;
-    sy = (sy - cdf_n) / pmf_n;
+    return start;
+}
+/* DiscreteDistribution::sample_reuse_pmf (distr_1d.h:159-183): the index, the re-used sample (value - cdf_normalized[index - 1]) / pmf_normalized[index] and the pmf */
+static inline uint32_t discrete_sample_reuse(const float *pmf, const float *cdf, uint32_t n, float sum, float normalization, float value01, float &reused, float &pmf_out) {
+    const uint32_t idx = discrete_sample(cdf, n, sum, value01);
+    const float pmf_n = pmf[idx] * normalization, cdf_n = idx > 0 ? cdf[idx - 1] * normalization : 0.f;
+    reused = (value01 - cdf_n) / pmf_n; pmf_out = pmf_n;
+    return idx;
+}
+static inline void mesh_sample_position(const Mesh &m, const Scene::AreaPmf &d, float sx, float sy, V3 &p, V3 &n, float &pdf) {
+    const uint32_t nf = (uint32_t) d.pmf.size();
+    float pmf_n;
+    const uint32_t idx = discrete_sample_reuse(d.pmf.data(), d.cdf.data(), nf, d.sum, d.normalization, sy, sy, pmf_n);
     const uint32_t *f = m.F.data() + 4 * (size_t) idx;
     const float *v0 = m.V.data() + 8 * (size_t) f[0], *v1 = m.V.data() + 8 * (size_t) f[1], *v2 = m.V.data() + 8 * (size_t) f[2];
     V3 p0(v0[0], v0[1], v0[2]), p1(v1[0], v1[1], v1[2]), p2(v2[0], v2[1], v2[2]);
@@ -2124,6 +2135,14 @@ void orc_diffuse_eval_pdf(const float refl[3], const float wi[3], const float wo
 void orc_diffuse_sample(const float refl[3], const float wi[3], float, const float s2[2], float wo[3], float *pdf, float weight[3]) {
     V3 w, wt; diffuse_sample(V3(refl[0], refl[1], refl[2]), V3(wi[0], wi[1], wi[2]), s2[0], s2[1], w, *pdf, wt);
     wo[0] = w.x; wo[1] = w.y; wo[2] = w.z; weight[0] = wt.x; weight[1] = wt.y; weight[2] = wt.z;
+}
+/* mi.DiscreteDistribution([pmf...]) as the emitters' face tables build it (Mesh::build_pmf / DiscreteDistribution::update: running float sum, normalization = 1 / sum):
+ * sample_reuse_pmf of `n_samples` values -> index, re-used sample, normalised pmf */
+void orc_discrete_sample_reuse(const float *pmf, uint32_t n, uint32_t n_samples, const float *values, uint32_t *index, float *reused, float *pmf_out) {
+    std::vector<float> cdf(n); float acc = 0.f;
+    for (uint32_t i = 0; i < n; ++i) { acc += pmf[i]; cdf[i] = acc; }
+    const float normalization = rcp(acc);
+    for (uint32_t k = 0; k < n_samples; ++k) index[k] = discrete_sample_reuse(pmf, cdf.data(), n, acc, normalization, values[k], reused[k], pmf_out[k]);
 }
 void orc_square_to_cosine_hemisphere(const float s[2], float out[3]) { V3 v = square_to_cosine_hemisphere(s[0], s[1]); out[0] = v.x; out[1] = v.y; out[2] = v.z; }
 void orc_square_to_uniform_sphere(const float s[2], float out[3]) { V3 v = square_to_uniform_sphere(s[0], s[1]); out[0] = v.x; out[1] = v.y; out[2] = v.z; }

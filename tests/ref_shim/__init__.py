@@ -16,7 +16,10 @@ def make_modules(backend, O=None, H=None):
     dr.cos = lambda x: np.cos(np.asarray(x, np.float32)).astype(np.float32)
     dr.sin = lambda x: np.sin(np.asarray(x, np.float32)).astype(np.float32)
     dr.full = lambda t, v, n: np.full(n, v, np.float32)
-    dr.linspace = lambda t, a, b, n, endpoint=True: np.linspace(a, b, n, endpoint=endpoint, dtype=np.float64).astype(np.float32)
+    # drjit.linspace: fma(arange(n), step, start) in float32 -- one rounding per element, so 20 steps to float32(pi / 2) end BELOW pi / 2 (np.linspace's end point
+    # lies above it: its cosine is negative, i.e. a ray from the other side of the interface; src/render/tests/test_fresnel.py:70-75 depends on the difference)
+    dr.linspace = lambda t, a, b, n, endpoint=True: (np.arange(n, dtype=np.float64) * float(np.float32((float(b) - float(a)) / (n - 1 if endpoint else n)))
+                                                       + float(np.float32(a))).astype(np.float32)
 
     def meshgrid(a, b):
         x, y = np.meshgrid(a, b)
@@ -28,6 +31,10 @@ def make_modules(backend, O=None, H=None):
         return bool(np.allclose(a, b, rtol=rtol, atol=atol))
     dr.allclose = allclose
     dr.abs = np.abs
+    dr.sqrt = lambda x: np.sqrt(np.asarray(x, np.float64))
+    dr.acos = lambda x: np.arccos(np.clip(np.asarray(x, np.float64), -1.0, 1.0))
+    dr.all = lambda x, axis=None: bool(np.all(x))
+    dr.zeros = lambda t, n=1: np.zeros(n, np.float32)
 
     mi = types.ModuleType("mitsuba")
     mi.Float = lambda x: np.asarray(x, np.float32)
@@ -83,6 +90,49 @@ def make_modules(backend, O=None, H=None):
                 ms[i] = m; pdfs[i] = p.value
             return [ms[:, 0], ms[:, 1], ms[:, 2]], pdfs
     mi.MicrofacetDistribution = MicrofacetDistribution
+
+    # fresnel(cos_theta_i, eta) -> (F, cos_theta_t, eta_it, eta_ti) and fresnel_conductor(cos_theta_i, eta [complex]) (include/mitsuba/render/fresnel.h:38-116)
+    def fresnel(cos_theta_i, eta):
+        c = np.asarray(cos_theta_i, np.float32).reshape(-1); out = np.empty((c.size, 4), np.float32)
+        for i in range(c.size):
+            o = np.empty(4, np.float32)
+            if backend == "oracle":
+                O.lib().orc_fresnel.argtypes = [C.c_float, C.c_float, O.c_f32p]; O.lib().orc_fresnel(C.c_float(c[i]), C.c_float(eta), O.fp(o))
+            else:
+                H.hh_fresnel.argtypes = [C.c_float, C.c_float, O.c_f32p]; H.hh_fresnel(C.c_float(c[i]), C.c_float(eta), O.fp(o))
+            out[i] = o
+        if np.ndim(cos_theta_i) == 0:
+            return tuple(float(v) for v in out[0])
+        return out[:, 0], out[:, 1], out[:, 2], out[:, 3]
+    mi.fresnel = fresnel
+
+    def fresnel_conductor(cos_theta_i, eta):
+        c = np.asarray(cos_theta_i, np.float32).reshape(-1); e = complex(eta); out = np.empty(c.size, np.float32)
+        fn = O.lib().orc_fresnel_conductor if backend == "oracle" else H.hh_fresnel_conductor
+        fn.restype = C.c_float; fn.argtypes = [C.c_float, C.c_float, C.c_float]
+        for i in range(c.size):
+            out[i] = fn(C.c_float(c[i]), C.c_float(e.real), C.c_float(e.imag))
+        return float(out[0]) if np.ndim(cos_theta_i) == 0 else out
+    mi.fresnel_conductor = fresnel_conductor
+
+    # DiscreteDistribution (include/mitsuba/core/distr_1d.h:27-215) as the mesh area lights use it (face choice with sample re-use); oracle only
+    class DiscreteDistribution:
+        def __init__(self, pmf):
+            self.pmf = np.asarray(pmf, np.float32)
+
+        def _run(self, values):
+            v = np.ascontiguousarray(np.asarray(values, np.float32).reshape(-1)); n = v.size
+            idx = np.zeros(n, np.uint32); reused = np.zeros(n, np.float32); pmf = np.zeros(n, np.float32)
+            L = O.lib()
+            L.orc_discrete_sample_reuse.argtypes = [O.c_f32p, C.c_uint32, C.c_uint32, O.c_f32p, C.POINTER(C.c_uint32), O.c_f32p, O.c_f32p]
+            L.orc_discrete_sample_reuse(O.fp(np.ascontiguousarray(self.pmf)), self.pmf.size, n, O.fp(v), idx.ctypes.data_as(C.POINTER(C.c_uint32)), O.fp(reused), O.fp(pmf))
+            return idx.astype(np.int64), reused, pmf
+
+        def sample(self, values): return self._run(values)[0]
+        def sample_pmf(self, values): i, _, p = self._run(values); return i, p
+        def sample_reuse(self, values): i, r, _ = self._run(values); return i, r
+        def sample_reuse_pmf(self, values): return self._run(values)
+    mi.DiscreteDistribution = DiscreteDistribution
     return mi, dr
 
 
