@@ -142,3 +142,12 @@ def test_oracle_intensity_gradient_is_the_finite_difference(mi, O):
     b, _ = osc.render_prb(sensor, seed=2, spp=16, max_depth=4)
     fd = (b.astype(np.float64).sum() - a.astype(np.float64).sum()) / 1.0
     assert g_emit[k, 0] > 0 and np.isclose(g_emit[k, 0], fd, rtol=2e-4)
+
+
+def test_point_light_from_xml(mi):
+    """the XML form of the plugin's documentation (point.cpp:40-47): <point name="position"/> + <rgb name="intensity"/>"""
+    s = mi.load_string('<scene version="3.0.0"><shape type="rectangle" id="rect"><bsdf type="diffuse"/></shape>'
+                       '<emitter type="point" id="bulb"><point name="position" value="0.0, 5.0, 0.0"/><rgb name="intensity" value="1.0, 2.0, 3.0"/></emitter></scene>')
+    e = s.emitters[0]
+    assert e["type"] == 4 and list(e["to_world"][9:12]) == [0.0, 5.0, 0.0] and np.allclose(e["radiance"], [1.0, 2.0, 3.0])
+    assert "bulb.intensity.value" in s._param_keys()
