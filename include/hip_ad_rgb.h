@@ -103,7 +103,12 @@ typedef struct HarEmitter {
                              radiance[0] = scale, radiance[1] = mis_compensation (0 / 1), to_world / to_local = emitter transform,
                              3 = area on any top-level triangle mesh `mesh` (Mesh::sample_position, src/render/mesh.cpp:1662-1712): radiance only,
                              4 = point (src/emitters/point.cpp): radiance = the radiant intensity, to_world[9..11] = the position (m_position,
-                             point.cpp:62-77: `position` or the translation of `to_world`); a delta emitter -- sampled with MIS weight 1, never hit */
+                             point.cpp:62-77: `position` or the translation of `to_world`); a delta emitter -- sampled with MIS weight 1, never hit,
+                             5 = spot (src/emitters/spot.cpp, without `texture`): radiance = the intensity along the axis, to_world / to_local = the emitter's
+                             transform and its inverse, normal[0] = cutoff_angle, normal[1] = beam_width in degrees (update(), spot.cpp:300-312),
+                             6 = directional (src/emitters/directional.cpp): radiance = the irradiance, to_world = the emitter's transform -- light travels along
+                             its +z axis (`direction` is lowered to look_at(0, direction, up) by the host, directional.cpp:69-78); delta direction, infinite,
+                             not an environment emitter (escaping rays do not see it) */
     uint32_t mesh;
     float radiance[3];
     float to_world[12];   /* column-major 3x4 */

@@ -845,6 +845,42 @@ class PointLight:
         self.intensity = _rgb_value(props.get('intensity', {'type': 'rgb', 'value': 1.0}), 1.0, bounded=False)   # get_emissive_texture("intensity", 1.f), :77
 
 
+class SpotLight:
+    """SpotLight (src/emitters/spot.cpp) without a `texture`: a point source at the origin of `to_world` that radiates `intensity` along the local +z axis inside
+    `beam_width` degrees, falling off linearly in the angle to zero at `cutoff_angle` (falloff_curve, :143-151); EmitterFlags::DeltaPosition."""
+
+    def __init__(self, props):
+        _check_props("spot", props, ('to_world', 'intensity', 'cutoff_angle', 'beam_width'), unsupported=(('sampling_weight', 1.0),))
+        if 'texture' in props:
+            raise RuntimeError("spot: property \"texture\" is not implemented by hip_ad_rgb")
+        self.to_world = props.get('to_world', ScalarTransform4f())
+        self.intensity = _rgb_value(props.get('intensity', {'type': 'rgb', 'value': 1.0}), 1.0, bounded=False)      # get_emissive_texture("intensity", 1.f), :93
+        self.cutoff_angle = float(np.float32(props.get('cutoff_angle', 20.0)))                                        # :105-107
+        self.beam_width = float(np.float32(props.get('beam_width', np.float32(self.cutoff_angle) * np.float32(3.0) / np.float32(4.0))))
+        if not (self.cutoff_angle >= self.beam_width and self.cutoff_angle > 0):
+            raise RuntimeError("spot: cutoff_angle must be positive and not smaller than beam_width")
+
+
+class DirectionalEmitter:
+    """DirectionalEmitter (src/emitters/directional.cpp): a distant source that delivers `irradiance` onto surfaces perpendicular to its direction of travel,
+    the +z axis of `to_world` (or `direction`, lowered to look_at(0, direction, up) as in :69-78); EmitterFlags::Infinite | DeltaDirection -- sampled with
+    MIS weight 1, invisible to escaping rays."""
+
+    def __init__(self, props):
+        _check_props("directional", props, ('to_world', 'direction', 'irradiance'), unsupported=(('sampling_weight', 1.0),))
+        if 'direction' in props:
+            if 'to_world' in props:                                   # directional.cpp:70-72
+                raise RuntimeError("Only one of the parameters 'direction' and 'to_world' can be specified at the same time!'")
+            d = _f32(list(props['direction'])).reshape(3); d = (d / np.sqrt(np.float32((d * d).sum()))).astype(np.float32)
+            # coordinate_system(direction).first (vector.h:118-138, Duff et al.) in float32
+            sign = np.float32(np.copysign(1.0, d[2])); a = np.float32(-1.0) / (sign + d[2]); b = d[0] * d[1] * a
+            up = _f32([np.copysign(1.0, d[2]) * (d[0] * d[0] * a) + 1.0, np.copysign(1.0, d[2]) * b, -np.copysign(1.0, d[2]) * d[0]])
+            self.to_world = ScalarTransform4f().look_at(origin=[0.0, 0.0, 0.0], target=[float(x) for x in d], up=[float(x) for x in up])
+        else:
+            self.to_world = props.get('to_world', ScalarTransform4f())
+        self.irradiance = _rgb_value(props.get('irradiance', {'type': 'rgb', 'value': 1.0}), 1.0, bounded=False)      # get_emissive_texture("irradiance", 1.f), :80
+
+
 class EnvmapEmitter:
     """EnvironmentMapEmitter (src/emitters/envmap.cpp): lat-long radiance image, importance sampled by luminance * sin(theta)."""
 
@@ -1235,7 +1271,7 @@ class Scene:
         # Scene::emitters() order = declaration order of the children (scene.cpp:40-70): shapes with an area emitter and
         # stand-alone emitters; the uniform emitter selection of sample_emitter() depends on it
         self._emitter_order = [key for key, obj in children.items()
-                               if (isinstance(obj, Mesh) and obj.emitter is not None) or isinstance(obj, (ConstantEmitter, EnvmapEmitter, PointLight))]
+                               if (isinstance(obj, Mesh) and obj.emitter is not None) or isinstance(obj, (ConstantEmitter, EnvmapEmitter, PointLight, SpotLight, DirectionalEmitter))]
         self.emitters = [None] * len(self._emitter_order)
         if sum(isinstance(o, (ConstantEmitter, EnvmapEmitter)) for o in children.values()) > 1:
             raise RuntimeError("Only one environment emitter can be specified per scene.")
@@ -1247,6 +1283,13 @@ class Scene:
                 self.emitters[self._emitter_order.index(key)] = dict(type=4, mesh=0xffffffff, radiance=obj.intensity,
                                                                      to_world=[1.0, 0.0, 0.0, 0.0, 1.0, 0.0, 0.0, 0.0, 1.0] + [float(x) for x in obj.position],
                                                                      normal=[0.0] * 3, inv_area=0.0)
+            elif isinstance(obj, SpotLight):                    # HarEmitter type 5: transform + inverse, normal = (cutoff_angle, beam_width, -) in degrees
+                self.emitters[self._emitter_order.index(key)] = dict(type=5, mesh=0xffffffff, radiance=obj.intensity, to_world=obj.to_world.col_major_3x4(),
+                                                                     to_local=obj.to_world.inverse().col_major_3x4(),
+                                                                     normal=[obj.cutoff_angle, obj.beam_width, 0.0], inv_area=0.0)
+            elif isinstance(obj, DirectionalEmitter):           # HarEmitter type 6: `radiance` = irradiance, the transform (light travels along its +z)
+                self.emitters[self._emitter_order.index(key)] = dict(type=6, mesh=0xffffffff, radiance=obj.irradiance, to_world=obj.to_world.col_major_3x4(),
+                                                                     to_local=obj.to_world.inverse().col_major_3x4(), normal=[0.0] * 3, inv_area=0.0)
             elif isinstance(obj, EnvmapEmitter):                # the radiance image travels in the texture table
                 self.emitters[self._emitter_order.index(key)] = dict(
                     type=2, mesh=len(self.textures), radiance=[obj.scale, 1.0 if obj.mis_compensation else 0.0, 0.0],
@@ -1453,8 +1496,10 @@ class Scene:
                 keys[key + ".emitter.radiance.value"] = ("emit", i)
             elif e["type"] == 1:
                 keys[key + ".radiance.value"] = ("emit", i)
-            elif e["type"] == 4:                                  # PointLight::traverse (point.cpp:84-88): `intensity` is the differentiable one
+            elif e["type"] in (4, 5):                             # PointLight::traverse (point.cpp:84-88), SpotLight::traverse (spot.cpp:111-118): `intensity`
                 keys[key + ".intensity.value"] = ("emit", i)
+            elif e["type"] == 6:                                  # DirectionalEmitter::traverse (directional.cpp:93-97)
+                keys[key + ".irradiance.value"] = ("emit", i)
         return keys
 
     def _bsdf_param_keys(self):
@@ -1690,7 +1735,7 @@ def _mk_scene(props, named, key):
         if k == 'type' or k in children:
             continue
         obj = _resolve(v, named, k) if isinstance(v, dict) else v
-        if isinstance(obj, (Mesh, Sensor, Integrator, BSDF, ShapeGroup, Instance, ConstantEmitter, EnvmapEmitter, PointLight)):
+        if isinstance(obj, (Mesh, Sensor, Integrator, BSDF, ShapeGroup, Instance, ConstantEmitter, EnvmapEmitter, PointLight, SpotLight, DirectionalEmitter)):
             if isinstance(obj, ShapeGroup):
                 named[k] = obj
             children[k] = obj
@@ -1764,7 +1809,7 @@ for _name, _fn in {
     'hdrfilm': lambda p, n, k: Film(p),
     'independent': lambda p, n, k: Sampler(p),
     'diffuse': lambda p, n, k: BSDF(p, id=k), 'dielectric': lambda p, n, k: BSDF(p, id=k), 'roughconductor': lambda p, n, k: BSDF(p, id=k),
-    'roughplastic': lambda p, n, k: BSDF(p, id=k), 'conductor': lambda p, n, k: BSDF(p, id=k), 'plastic': lambda p, n, k: BSDF(p, id=k), 'twosided': _mk_twosided, 'constant': lambda p, n, k: ConstantEmitter(p), 'envmap': lambda p, n, k: EnvmapEmitter(p), 'point': lambda p, n, k: PointLight(p),
+    'roughplastic': lambda p, n, k: BSDF(p, id=k), 'conductor': lambda p, n, k: BSDF(p, id=k), 'plastic': lambda p, n, k: BSDF(p, id=k), 'twosided': _mk_twosided, 'constant': lambda p, n, k: ConstantEmitter(p), 'envmap': lambda p, n, k: EnvmapEmitter(p), 'point': lambda p, n, k: PointLight(p), 'spot': lambda p, n, k: SpotLight(p), 'directional': lambda p, n, k: DirectionalEmitter(p),
     'rectangle': lambda p, n, k: _shape_common(_rectangle(p), p, n),
     'cube': lambda p, n, k: _shape_common(_cube(p), p, n),
     'mesh': _mk_mesh, 'ply': _mk_ply, 'obj': _mk_obj, 'serialized': _mk_serialized,

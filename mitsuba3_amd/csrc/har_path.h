@@ -190,6 +190,10 @@ HAR_HD void shade_lane(const DScene &S, const ShadeParams &P, const PathState &s
             mesh_emitter_sample_direction(S, S.emitters[index], si.p, ex, ey, ds, em_weight, MODE == MODE_PRB_ADJOINT ? &em_unit : nullptr);
         else if ((TYPES & HAR_SCENE_ENVMAP) != 0u && S.emitters[index].type == 4u) {
             point_sample_direction(S.emitters[index], si.p, ds, em_weight, MODE == MODE_PRB_ADJOINT ? &em_unit : nullptr); em_delta = true;
+        } else if ((TYPES & HAR_SCENE_ENVMAP) != 0u && S.emitters[index].type == 5u) {
+            spot_sample_direction(S.emitters[index], si.p, ds, em_weight, MODE == MODE_PRB_ADJOINT ? &em_unit : nullptr); em_delta = true;
+        } else if ((TYPES & HAR_SCENE_ENVMAP) != 0u && S.emitters[index].type == 6u) {
+            directional_sample_direction(S.emitters[index], si.p, ds, em_weight, MODE == MODE_PRB_ADJOINT ? &em_unit : nullptr); em_delta = true;
         }
         else emitter_sample_direction(S.emitters[index], si.p, ex, ey, ds, em_weight, MODE == MODE_PRB_ADJOINT ? &em_unit : nullptr);
         ds.pdf *= pmf; em_weight = em_weight * wgt; em_unit *= wgt; em_sampled = index;

@@ -418,6 +418,33 @@ HAR_HD void point_sample_direction(const DEmitter &E, Vec3 ref_p, DirSample &ds,
     spec = Vec3(E.radiance[0], E.radiance[1], E.radiance[2]) * w;
     if (unit) *unit = w;
 }
+/* SpotLight::sample_direction (src/emitters/spot.cpp:177-211) with falloff_curve (:143-151): emitter type 5; the record holds the linear part of to_world^-1 in
+ * to_world[0..8], the position in [9..11], normal = (cutoff angle in radians, its cosine, the beam width's cosine), inv_area = 1 / transition width */
+HAR_HD void spot_sample_direction(const DEmitter &E, Vec3 ref_p, DirSample &ds, Vec3 &spec, float *unit = nullptr) {
+    ds.p = Vec3(E.to_world[9], E.to_world[10], E.to_world[11]); ds.n = Vec3(0.f); ds.pdf = 1.f;
+    ds.d = ds.p - ref_p;
+    ds.dist = norm3(ds.d);
+    const float inv_dist = rcp_(ds.dist);
+    ds.d = ds.d * inv_dist;
+    const Vec3 local_dir = normalize3(xf_vector(E.to_world, -ds.d));            /* to_world[0..8] = the inverse's linear part: a vector needs no more */
+    const float cos_theta = local_dir.z;
+    const float beam_res = cos_theta >= E.normal[2] ? 1.f : (E.normal[0] - acos_(cos_theta)) * E.inv_area;
+    const float falloff = cos_theta > E.normal[1] ? beam_res : 0.f;
+    const bool active = falloff > 0.f;
+    const float w = falloff * (inv_dist * inv_dist);
+    spec = active ? Vec3(E.radiance[0], E.radiance[1], E.radiance[2]) * w : Vec3(0.f);
+    if (unit) *unit = active ? w : 0.f;
+}
+/* DirectionalEmitter::sample_direction (src/emitters/directional.cpp:149-176): emitter type 6; the record holds the direction of travel in to_world[0..2], the scene's
+ * bounding sphere (set_scene, :99-109) in [3..5] (centre) and [6] (radius); `radiance` = the irradiance */
+HAR_HD void directional_sample_direction(const DEmitter &E, Vec3 ref_p, DirSample &ds, Vec3 &spec, float *unit = nullptr) {
+    const Vec3 d(E.to_world[0], E.to_world[1], E.to_world[2]);
+    const float radius = fmaxf(E.to_world[6], norm3(ref_p - Vec3(E.to_world[3], E.to_world[4], E.to_world[5])));
+    const float dist = 2.f * radius;
+    ds.p = ref_p - d * dist; ds.n = d; ds.pdf = 1.f; ds.d = -d; ds.dist = dist;
+    spec = Vec3(E.radiance[0], E.radiance[1], E.radiance[2]);
+    if (unit) *unit = 1.f;
+}
 /* `unit` (optional): the weight the sample would carry for a unit radiance, i.e. d spec / d radiance */
 HAR_HD void emitter_sample_direction(const DEmitter &E, Vec3 ref_p, float sx, float sy, DirSample &ds, Vec3 &spec, float *unit = nullptr) {
     if (E.type == 1u) {                                     /* ConstantBackgroundEmitter::sample_direction, constant.cpp:127-153 */

@@ -255,8 +255,8 @@ bool lower_scene(const HarSceneDesc &d, HostScene &hs, std::string &err) {
     }
     for (uint32_t i = 0; i < d.emitter_count; ++i) {
         const HarEmitter &e = d.emitters[i];
-        if (e.type > 4) { err = "unsupported emitter type (`area`, `constant`, `envmap` and `point` are implemented)"; return false; }
-        const bool area = e.type == 0 || e.type == 3, point = e.type == 4;
+        if (e.type > 6) { err = "unsupported emitter type (`area`, `constant`, `envmap`, `point`, `spot` and `directional` are implemented)"; return false; }
+        const bool area = e.type == 0 || e.type == 3, point = e.type >= 4;      /* the delta emitters */
         if (area && e.mesh >= d.top_mesh_count) { err = "area emitter must be attached to a top-level mesh"; return false; }
         if (!area && !point && hs.env_emitter >= 0) { err = "Only one environment emitter can be specified per scene."; return false; }   /* scene.cpp:64-65 */
         if (!area && !point) hs.env_emitter = (int32_t) i;
@@ -268,6 +268,14 @@ bool lower_scene(const HarSceneDesc &d, HostScene &hs, std::string &err) {
         DEmitter de{}; de.type = e.type;
         std::memcpy(de.radiance, e.radiance, 12); de.inv_area = e.inv_area;
         std::memcpy(de.to_world, e.to_world, 48); std::memcpy(de.normal, e.normal, 12); de.mesh = e.mesh;
+        if (e.type == 5) {            /* SpotLight::update (spot.cpp:300-312); the record keeps what sample_direction reads: the inverse's linear part, the position, the cone */
+            const float deg = 0.017453292519943295f, cutoff_rad = e.normal[0] * deg, beam_rad = e.normal[1] * deg;
+            if (!(cutoff_rad >= beam_rad) || !(cutoff_rad > 0.f)) { err = "spot: cutoff_angle must be positive and not smaller than beam_width"; return false; }
+            float s_, cos_cutoff, cos_beam; sincos_(cutoff_rad, s_, cos_cutoff); sincos_(beam_rad, s_, cos_beam);
+            for (int k = 0; k < 9; ++k) de.to_world[k] = e.to_local[k];
+            de.to_world[9] = e.to_world[9]; de.to_world[10] = e.to_world[10]; de.to_world[11] = e.to_world[11];
+            de.normal[0] = cutoff_rad; de.normal[1] = cos_cutoff; de.normal[2] = cos_beam; de.inv_area = 1.0f / (cutoff_rad - beam_rad);
+        }
         if (e.type == 3) {            /* Mesh::build_pmf (mesh.cpp:1358-1372): face areas of the (world-space) mesh + their running sum */
             const DMesh &M = hs.meshes[e.mesh];
             if (M.face_count == 0) { err = "Cannot create sampling table for an empty mesh"; return false; }
@@ -298,7 +306,9 @@ bool lower_scene(const HarSceneDesc &d, HostScene &hs, std::string &err) {
 
     /* ConstantBackgroundEmitter::set_scene (constant.cpp:72-87): bounding sphere of Scene::bbox() (all shapes; an Instance
      * contributes the 8 transformed corners of its group's box, instance.cpp:93-103), radius * (1 + RayEpsilon) */
-    if (hs.env_emitter >= 0) {
+    bool needs_bounds = hs.env_emitter >= 0;
+    for (const DEmitter &E : hs.emitters) needs_bounds = needs_bounds || E.type == 6u;      /* DirectionalEmitter::set_scene (directional.cpp:99-109): the same sphere */
+    if (needs_bounds) {
         float lo[3] = { INFINITY, INFINITY, INFINITY }, hi[3] = { -INFINITY, -INFINITY, -INFINITY };
         auto grow = [&](float x, float y, float z) { const float q[3] = { x, y, z }; for (int a = 0; a < 3; ++a) { lo[a] = std::min(lo[a], q[a]); hi[a] = std::max(hi[a], q[a]); } };
         for (uint32_t s = 0; s < d.top_mesh_count; ++s)
@@ -311,15 +321,25 @@ bool lower_scene(const HarSceneDesc &d, HostScene &hs, std::string &err) {
             if (!(glo[0] <= ghi[0])) continue;
             for (int c = 0; c < 8; ++c) { Vec3 q = xf_point(d.instances[i].to_world, Vec3(c & 1 ? ghi[0] : glo[0], c & 2 ? ghi[1] : glo[1], c & 4 ? ghi[2] : glo[2])); grow(q.x, q.y, q.z); }
         }
-        DEmitter &E = hs.emitters[hs.env_emitter];
+        float bs[4] = { 0.f, 0.f, 0.f, HAR_RAY_EPS };        /* centre, radius */
         if (lo[0] <= hi[0]) {
             Vec3 c((hi[0] + lo[0]) * .5f, (hi[1] + lo[1]) * .5f, (hi[2] + lo[2]) * .5f);
             float r = norm3(c - Vec3(hi[0], hi[1], hi[2]));
-            E.to_world[0] = c.x; E.to_world[1] = c.y; E.to_world[2] = c.z;
-            E.to_world[3] = std::max(HAR_RAY_EPS, r * (1.f + HAR_RAY_EPS));
-        } else { E.to_world[0] = E.to_world[1] = E.to_world[2] = 0.f; E.to_world[3] = HAR_RAY_EPS; }
+            bs[0] = c.x; bs[1] = c.y; bs[2] = c.z; bs[3] = std::max(HAR_RAY_EPS, r * (1.f + HAR_RAY_EPS));
+        }
+        for (DEmitter &D : hs.emitters)
+            if (D.type == 6u) {          /* the record of a directional light: its direction (third column of to_world), then the sphere */
+                const float dx = D.to_world[6], dy = D.to_world[7], dz = D.to_world[8];
+                D.to_world[0] = dx; D.to_world[1] = dy; D.to_world[2] = dz;
+                D.to_world[3] = bs[0]; D.to_world[4] = bs[1]; D.to_world[5] = bs[2]; D.to_world[6] = bs[3];
+            }
+        if (hs.env_emitter >= 0) {
+        DEmitter &E = hs.emitters[hs.env_emitter];
+        E.to_world[0] = bs[0]; E.to_world[1] = bs[1]; E.to_world[2] = bs[2]; E.to_world[3] = bs[3];
         E.mesh = 0xffffffffu;
-        if (hs.has_envmap) {            /* EnvironmentMapEmitter::set_scene (envmap.cpp:214-226): the same rule */
+        }
+        if (hs.env_emitter >= 0 && hs.has_envmap) {
+            DEmitter &E = hs.emitters[hs.env_emitter];            /* EnvironmentMapEmitter::set_scene (envmap.cpp:214-226): the same rule */
             for (int a = 0; a < 3; ++a) hs.envmap.center[a] = E.to_world[a];
             hs.envmap.radius = E.to_world[3];
         }

@@ -496,9 +496,40 @@ static inline void point_sample_direction(const OrcEmitter &e, V3 ref_p, DS &ds,
     spec = V3(e.radiance[0], e.radiance[1], e.radiance[2]) * w;
     if (unit) *unit = w;
 }
+/* SpotLight (src/emitters/spot.cpp): update() (:300-312), falloff_curve (:143-151), sample_direction (:177-211).  to_world / to_local = the emitter's transform and
+ * its inverse, normal[0] = cutoff_angle, normal[1] = beam_width (degrees); `radiance` = the radiant intensity along the axis.  No `texture`. */
+static inline void spot_sample_direction(const OrcEmitter &e, V3 ref_p, DS &ds, V3 &spec, float *unit) {
+    const float deg = 0.017453292519943295f;                                  // dr::deg_to_rad: value * (Pi / 180)
+    const float cutoff_rad = e.normal[0] * deg, beam_rad = e.normal[1] * deg;
+    const float inv_transition_width = 1.0f / (cutoff_rad - beam_rad);
+    float cos_cutoff, cos_beam; sincos(cutoff_rad, &cos_cutoff); sincos(beam_rad, &cos_beam);
+    ds.p = V3(e.to_world[9], e.to_world[10], e.to_world[11]); ds.n = V3(0.f); ds.pdf = 1.f; ds.delta = true;
+    ds.d = ds.p - ref_p;
+    ds.dist = norm(ds.d);
+    const float inv_dist = rcp(ds.dist);
+    ds.d = ds.d * inv_dist;
+    const V3 local_dir = normalize(xf_vector(e.to_local, -ds.d));              // falloff_curve: dr::normalize(to_world.inverse() * -ds.d)
+    const float cos_theta = local_dir.z;
+    const float beam_res = cos_theta >= cos_beam ? 1.f : (cutoff_rad - acos32(cos_theta)) * inv_transition_width;
+    const float falloff = cos_theta > cos_cutoff ? beam_res : 0.f;
+    const bool active = falloff > 0.f;
+    const float w = falloff * sqr(inv_dist);
+    spec = active ? V3(e.radiance[0], e.radiance[1], e.radiance[2]) * w : V3(0.f);
+    if (unit) *unit = active ? w : 0.f;
+}
 static inline void emitter_sample_direction(const Scene &sc, uint32_t index, V3 ref_p, float sx, float sy, DS &ds, V3 &spec, float *unit = nullptr) {
     const OrcEmitter &e = sc.emitters[index];
     if (e.type == 4) { point_sample_direction(e, ref_p, ds, spec, unit); return; }
+    if (e.type == 5) { spot_sample_direction(e, ref_p, ds, spec, unit); return; }
+    if (e.type == 6) {          // DirectionalEmitter::sample_direction (directional.cpp:149-176): d = to_world * (0, 0, 1) = the third column; `radiance` = the irradiance
+        const V3 d(e.to_world[6], e.to_world[7], e.to_world[8]);
+        const float radius = std::fmax(sc.env_radius, norm(ref_p - V3(sc.env_center[0], sc.env_center[1], sc.env_center[2])));
+        const float dist = 2.f * radius;
+        ds.p = ref_p - d * dist; ds.n = d; ds.pdf = 1.f; ds.delta = true; ds.d = -d; ds.dist = dist;
+        spec = V3(e.radiance[0], e.radiance[1], e.radiance[2]);
+        if (unit) *unit = 1.f;
+        return;
+    }
     if (e.type == 3) mesh_sample_position(sc.meshes[e.mesh], sc.area_pmf[index], sx, sy, ds.p, ds.n, ds.pdf);
     else {          // Rectangle::sample_position (rectangle.cpp:159-170)
         ds.p = xf_point(e.to_world, V3(fmadd(sx, 2.f, -1.f), fmadd(sy, 2.f, -1.f), 0.f));
@@ -1667,7 +1698,9 @@ static void build_instance_bvh(Scene *sc) {
 
 /* bounding sphere of the scene for the environment emitters; recomputed when vertex positions change */
 static void scene_update_bounds(Scene &sc) {
-    if (sc.env >= 0) {                                 // ConstantBackgroundEmitter::set_scene (constant.cpp:72-87)
+    bool needs_bounds = sc.env >= 0;
+    for (const OrcEmitter &e : sc.emitters) needs_bounds |= e.type == 6;      // DirectionalEmitter::set_scene (directional.cpp:99-109): the same sphere
+    if (needs_bounds) {                                // ConstantBackgroundEmitter::set_scene (constant.cpp:72-87)
         float lo[3] = { Infinity, Infinity, Infinity }, hi[3] = { -Infinity, -Infinity, -Infinity };
         for (uint32_t m = 0; m < sc.top_count; ++m)
             for (uint32_t v = 0; v < sc.meshes[m].nv; ++v) for (int a = 0; a < 3; ++a) { float q = sc.meshes[m].V[8 * (size_t) v + a]; lo[a] = std::min(lo[a], q); hi[a] = std::max(hi[a], q); }
@@ -2064,7 +2097,7 @@ int orc_render_prb_backward_lanes(void *scene, const OrcSensor *sp, const float 
 }
 /* + d/d(vertex positions) of the meshes with pos_mask[m] != 0: grad_positions[m] = 3 doubles per vertex (accumulated into).
  * Returns -2 when the scene holds a BSDF other than plain `diffuse`, -3 for a mesh with vertex normals / inside a shape group. */
-static bool has_point_emitter(void *scene) { for (const OrcEmitter &e : ((Scene *) scene)->emitters) if (e.type == 4) return true; return false; }
+static bool has_point_emitter(void *scene) { for (const OrcEmitter &e : ((Scene *) scene)->emitters) if (e.type >= 4) return true; return false; }
 int orc_render_prb_backward_shape(void *scene, const OrcSensor *sp, const float *grad_in, uint32_t seed, uint32_t spp,
                                   int32_t max_depth, int32_t rr_depth, float *grad_reflectance, float *const *grad_textures,
                                   const uint8_t *pos_mask, double *const *grad_positions, OrcStats *stats, int threads) {
@@ -2135,6 +2168,21 @@ void orc_diffuse_eval_pdf(const float refl[3], const float wi[3], const float wo
 void orc_diffuse_sample(const float refl[3], const float wi[3], float, const float s2[2], float wo[3], float *pdf, float weight[3]) {
     V3 w, wt; diffuse_sample(V3(refl[0], refl[1], refl[2]), V3(wi[0], wi[1], wi[2]), s2[0], s2[1], w, *pdf, wt);
     wo[0] = w.x; wo[1] = w.y; wo[2] = w.z; weight[0] = wt.x; weight[1] = wt.y; weight[2] = wt.z;
+}
+/* Emitter::sample_direction of emitter `index` alone (no emitter choice, no visibility test) from the reference points p[n][3] with samples s[n][2]:
+ * d[n][3], dist[n], pdf[n], delta[n], weight[n][3] -- the quantities the reference's emitter tests look at (src/emitters/tests/test_*.py) */
+void orc_emitter_sample_direction(void *scene, uint32_t index, uint32_t n, const float *p, const float *s, float *d, float *dist, float *pdf, uint8_t *delta, float *weight) {
+    const Scene &sc = *(const Scene *) scene;
+    for (uint32_t i = 0; i < n; ++i) {
+        DS ds; V3 spec(0.f);
+        const V3 ref(p[3 * i], p[3 * i + 1], p[3 * i + 2]);
+        const OrcEmitter &e = sc.emitters[index];
+        if (e.type == 1) { EnvSphere bs; bs.center = V3(sc.env_center[0], sc.env_center[1], sc.env_center[2]); bs.radius = sc.env_radius; constant_sample_direction(e, bs, ref, s[2 * i], s[2 * i + 1], ds, spec, nullptr); }
+        else if (e.type == 2) { float uv[2]; sc.envmap.sample_direction(ref, s[2 * i], s[2 * i + 1], ds.d, ds.dist, ds.pdf, spec, uv); }
+        else emitter_sample_direction(sc, index, ref, s[2 * i], s[2 * i + 1], ds, spec, nullptr);
+        d[3 * i] = ds.d.x; d[3 * i + 1] = ds.d.y; d[3 * i + 2] = ds.d.z; dist[i] = ds.dist; pdf[i] = ds.pdf; delta[i] = ds.delta ? 1 : 0;
+        weight[3 * i] = spec.x; weight[3 * i + 1] = spec.y; weight[3 * i + 2] = spec.z;
+    }
 }
 /* mi.DiscreteDistribution([pmf...]) as the emitters' face tables build it (Mesh::build_pmf / DiscreteDistribution::update: running float sum, normalization = 1 / sum):
  * sample_reuse_pmf of `n_samples` values -> index, re-used sample, normalised pmf */

@@ -78,7 +78,10 @@ typedef struct OrcEmitter {
                              2 = environment map (src/emitters/envmap.cpp): mesh = index of the H x W x 3 image in `textures`,
                              radiance[0] = scale, radiance[1] = mis_compensation (0 / 1), to_world / to_local = emitter transform,
                              3 = area light on a top-level triangle mesh (`mesh`; Mesh::sample_position, src/render/mesh.cpp:1662-1712),
-                             4 = point light (src/emitters/point.cpp): radiance = radiant intensity, to_world[9..11] = position */
+                             4 = point light (src/emitters/point.cpp): radiance = radiant intensity, to_world[9..11] = position,
+                             5 = spot light (src/emitters/spot.cpp): radiance = intensity, to_world / to_local = transform and inverse,
+                             normal[0] = cutoff_angle, normal[1] = beam_width in degrees (no `texture`),
+                             6 = directional light (src/emitters/directional.cpp): radiance = irradiance, to_world = the emitter's transform (light travels along its +z) */
     uint32_t mesh;        /* mesh that carries the emitter */
     float radiance[3];
     float to_world[12];   /* rectangle to_world, column-major 3x4 */

@@ -62,6 +62,25 @@ void *hh_scene_create(const HarSceneDesc *d, char *err, int errlen) {
     return H;
 }
 void hh_scene_destroy(void *h) { delete (HScene *) h; }
+/* Emitter::sample_direction of emitter `index` alone through the product's shading headers (the dispatch of shade_lane, har_path.h): reference points p[n][3], samples
+ * s[n][2] -> d[n][3], dist[n], pdf[n], delta[n], weight[n][3] (the counterpart of orc_emitter_sample_direction) */
+void hh_emitter_sample_direction(void *h, uint32_t index, uint32_t n, const float *p, const float *s, float *d, float *dist, float *pdf, uint8_t *delta, float *weight) {
+    HScene *H = (HScene *) h; const DScene &S = H->ds;
+    for (uint32_t i = 0; i < n; ++i) {
+        DirSample ds; ds.pdf = 0.f; ds.d = Vec3(0.f); ds.p = Vec3(0.f); ds.n = Vec3(0.f); ds.dist = 0.f;
+        Vec3 w(0.f); bool dl = false;
+        const Vec3 ref(p[3 * i], p[3 * i + 1], p[3 * i + 2]);
+        const DEmitter &E = S.emitters[index];
+        if (E.type == 2u) envmap_sample_direction(*S.envmap, ref, s[2 * i], s[2 * i + 1], ds, w);
+        else if (E.type == 3u) mesh_emitter_sample_direction(S, E, ref, s[2 * i], s[2 * i + 1], ds, w, nullptr);
+        else if (E.type == 4u) { point_sample_direction(E, ref, ds, w, nullptr); dl = true; }
+        else if (E.type == 5u) { spot_sample_direction(E, ref, ds, w, nullptr); dl = true; }
+        else if (E.type == 6u) { directional_sample_direction(E, ref, ds, w, nullptr); dl = true; }
+        else emitter_sample_direction(E, ref, s[2 * i], s[2 * i + 1], ds, w, nullptr);
+        d[3 * i] = ds.d.x; d[3 * i + 1] = ds.d.y; d[3 * i + 2] = ds.d.z; dist[i] = ds.dist; pdf[i] = ds.pdf; delta[i] = dl ? 1 : 0;
+        weight[3 * i] = w.x; weight[3 * i + 1] = w.y; weight[3 * i + 2] = w.z;
+    }
+}
 /* FNV-1a over the bytes of the node array, the triangle records and the instance records: the builder's output, for tests that compare builds */
 void hh_accel_hash(void *h, uint64_t out[3]) {
     HScene *H = (HScene *) h;

@@ -1,4 +1,4 @@
-"""`point` emitter (src/emitters/point.cpp; HarEmitter type 4) on the device, through the C ABI, against the oracle:
+"""`point`, `spot` and `directional` emitters (src/emitters/point.cpp, spot.cpp, directional.cpp; HarEmitter types 4 / 5 / 6) on the device, through the C ABI, against the oracle:
 forward images (1e-4) with equal path / vertex / ray counters, prb gradients (1e-3) w.r.t. albedos, a bitmap albedo and the light's intensity,
 har_integrator_sample, and src/render/tests/test_ad.py:55-134 literally through mi.render + autograd (backward and forward mode)."""
 import numpy as np
@@ -88,6 +88,93 @@ def test_integrator_sample_with_a_point_light(mi, O):
         ref, rvalid, _ = osc.integrator_sample(o, d, maxt, seed=5 + 3, max_depth=5, rr_depth=3, prb=(kind == "prb"))
         assert np.array_equal(valid.cpu().numpy().astype(np.uint8), rvalid), kind
         assert np.abs(ref).max() > 0 and rel_l2(spec.cpu().numpy(), ref) < 1e-4, kind
+
+
+def spot_box(mi, res, textured=False):
+    d = mi.textured_cornell_box(res=res, tex_res=16, spp=4) if textured else mi.cornell_box()
+    d["sensor"]["film"]["width"] = res; d["sensor"]["film"]["height"] = res
+    d["spot"] = {"type": "spot", "cutoff_angle": 40.0, "beam_width": 25.0, "intensity": {"type": "rgb", "value": [3.0, 2.0, 1.0]},
+                 "to_world": mi.ScalarTransform4f().look_at(origin=[0.3, 0.9, 0.2], target=[-0.2, -1.0, 0.1], up=[0, 0, 1])}
+    return d
+
+
+def test_forward_parity_with_a_spot_light(mi, O):
+    """SpotLight::sample_direction (spot.cpp:177-211): falloff between beam width and cut-off, the inverse transform, MIS weight 1"""
+    res, spp = 64, 16
+    scene = mi.load_dict(spot_box(mi, res))
+    assert [e.get("type", 0) for e in scene.emitters].count(5) == 1
+    osc, sensor = O.scene_from_product(scene)
+    img = mi.render(scene, spp=spp, seed=5).cpu().numpy()
+    st = scene.integrator().stats()
+    ref, ost = osc.render_path(sensor, seed=5, spp=spp, max_depth=scene.integrator().max_depth, rr_depth=scene.integrator().rr_depth)
+    assert np.abs(ref).max() > 0 and rel_l2(img, ref) < 1e-4, rel_l2(img, ref)
+    assert st["paths"] == res * res * spp and st["vertices"] == ost.vertices
+    d2 = mi.cornell_box(); d2["sensor"]["film"]["width"] = res; d2["sensor"]["film"]["height"] = res
+    plain = mi.render(mi.load_dict(d2), spp=spp, seed=5).cpu().numpy()
+    assert rel_l2(plain, ref) > 0.02                              # the spot light is in the picture
+
+
+def test_prb_gradients_with_a_spot_light(mi, O):
+    res, spp, md = 48, 16, 6
+    d = spot_box(mi, res, textured=True); d["integrator"] = {"type": "prb", "max_depth": md}
+    scene = mi.load_dict(d)
+    osc, sensor = O.scene_from_product(scene)
+    keys = scene._param_keys()
+    assert "spot.intensity.value" in keys
+    grad_in = np.random.default_rng(8).uniform(0.5, 1.5, (res, res, 3)).astype(np.float32)
+    grads = scene.integrator().render_backward(scene, None, grad_in, seed=3, spp=spp)
+    g_refl, g_tex, g_emit, _ = osc.render_prb_backward_emitters(sensor, grad_in, seed=3, spp=spp, max_depth=md)
+    ek = {k: v[1] for k, v in keys.items() if v[0] == "emit"}
+    got = np.stack([grads[k].cpu().numpy() for k in ek]); want = np.stack([g_emit[i] for i in ek.values()])
+    assert len(ek) == 2 and np.abs(want).min() > 0 and rel_l2(got, want) < 1e-3, (got, want)
+    for k, (kind, b) in keys.items():
+        if kind == "tex":
+            assert rel_l2(grads[k].cpu().numpy(), g_tex[b.tex_index]) < 1e-3, k
+        elif kind == "rgb":
+            assert rel_l2(grads[k].cpu().numpy(), g_refl[b.index]) < 1e-3, k
+
+
+def sun_box(mi, res, textured=False):
+    d = mi.textured_cornell_box(res=res, tex_res=16, spp=4) if textured else mi.cornell_box()
+    d["sensor"]["film"]["width"] = res; d["sensor"]["film"]["height"] = res
+    d["sun"] = {"type": "directional", "direction": [0.3, -0.2, -1.0], "irradiance": {"type": "rgb", "value": [2.0, 1.5, 1.0]}}      # through the open front of the box
+    return d
+
+
+def test_forward_parity_with_a_directional_light(mi, O):
+    """DirectionalEmitter::sample_direction (directional.cpp:149-176): shadow rays of twice the bounding sphere's radius, MIS weight 1, no attenuation"""
+    res, spp = 64, 16
+    scene = mi.load_dict(sun_box(mi, res))
+    assert [e.get("type", 0) for e in scene.emitters].count(6) == 1
+    osc, sensor = O.scene_from_product(scene)
+    img = mi.render(scene, spp=spp, seed=5).cpu().numpy()
+    st = scene.integrator().stats()
+    ref, ost = osc.render_path(sensor, seed=5, spp=spp, max_depth=scene.integrator().max_depth, rr_depth=scene.integrator().rr_depth)
+    assert np.abs(ref).max() > 0 and rel_l2(img, ref) < 1e-4, rel_l2(img, ref)
+    assert st["paths"] == res * res * spp and st["vertices"] == ost.vertices
+    d2 = mi.cornell_box(); d2["sensor"]["film"]["width"] = res; d2["sensor"]["film"]["height"] = res
+    plain = mi.render(mi.load_dict(d2), spp=spp, seed=5).cpu().numpy()
+    assert rel_l2(plain, ref) > 0.02
+
+
+def test_prb_gradients_with_a_directional_light(mi, O):
+    res, spp, md = 48, 16, 6
+    d = sun_box(mi, res, textured=True); d["integrator"] = {"type": "prb", "max_depth": md}
+    scene = mi.load_dict(d)
+    osc, sensor = O.scene_from_product(scene)
+    keys = scene._param_keys()
+    assert "sun.irradiance.value" in keys
+    grad_in = np.random.default_rng(9).uniform(0.5, 1.5, (res, res, 3)).astype(np.float32)
+    grads = scene.integrator().render_backward(scene, None, grad_in, seed=3, spp=spp)
+    g_refl, g_tex, g_emit, _ = osc.render_prb_backward_emitters(sensor, grad_in, seed=3, spp=spp, max_depth=md)
+    ek = {k: v[1] for k, v in keys.items() if v[0] == "emit"}
+    got = np.stack([grads[k].cpu().numpy() for k in ek]); want = np.stack([g_emit[i] for i in ek.values()])
+    assert len(ek) == 2 and np.abs(want).min() > 0 and rel_l2(got, want) < 1e-3, (got, want)
+    for k, (kind, b) in keys.items():
+        if kind == "tex":
+            assert rel_l2(grads[k].cpu().numpy(), g_tex[b.tex_index]) < 1e-3, k
+        elif kind == "rgb":
+            assert rel_l2(grads[k].cpu().numpy(), g_refl[b.index]) < 1e-3, k
 
 
 def simple_scene(mi, res=1, integrator="prb"):
