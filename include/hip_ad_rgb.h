@@ -142,6 +142,8 @@ typedef struct HarSensor {
                                    * (src/render/integrator.cpp:162-165, 322-339); the film itself keeps the crop size, splats are clipped to it */
     float    principal_point_offset_x, principal_point_offset_y;   /* PerspectiveCamera `principal_point_offset_x / _y` (src/sensors/perspective.cpp:147-150): sample_ray adds
                                    * film_size * offset / crop_size to the film position before it is taken to the near plane (:213-221) */
+    uint32_t projection;          /* 0 = PerspectiveCamera (src/sensors/perspective.cpp), 1 = OrthographicCamera (src/sensors/orthographic.cpp:131-157): sample_to_camera is
+                                   * the inverse of orthographic_projection (sensor.h:272-307), an affine map; rays start on the near plane and run along to_world's +z */
 } HarSensor;
 
 /* counters of one render call (all lanes), read back with har_render_stats */
@@ -457,6 +459,11 @@ int har_transform_mul(const float a[32], const float b[32], float out[32]);
 int har_transform_inverse(const float a[32], float out[32]);
 /* PerspectiveCamera ctor + update_camera_transforms (src/sensors/perspective.cpp:137-198),
  * parse_fov (src/render/sensor.cpp:142-190), HDRFilm crop window, rfilter type + its first parameter (rfilter_param1 is set to 1/3, mitchell's default C) */
+/* OrthographicCamera (src/sensors/orthographic.cpp:104-121 update_camera_transforms; sensor.h:272-307 orthographic_projection): fills `out` like
+ * har_perspective_sensor (to_world may carry a scale -- it sets the size of the view) */
+int har_orthographic_sensor(const float to_world[32], float near_clip, float far_clip, uint32_t width, uint32_t height,
+                            uint32_t crop_offset_x, uint32_t crop_offset_y, uint32_t crop_width, uint32_t crop_height,
+                            uint32_t rfilter, float rfilter_stddev, HarSensor *out);
 int har_perspective_sensor(const float to_world[32], double fov, const char *fov_axis, float near_clip,
                            float far_clip, uint32_t width, uint32_t height, uint32_t crop_x,
                            uint32_t crop_y, uint32_t crop_w, uint32_t crop_h, uint32_t rfilter,

@@ -70,7 +70,8 @@ class HarSensor(C.Structure):
                 ("crop_offset_x", C.c_uint32), ("crop_offset_y", C.c_uint32),
                 ("crop_width", C.c_uint32), ("crop_height", C.c_uint32),
                 ("rfilter", C.c_uint32), ("rfilter_stddev", C.c_float), ("rfilter_param1", C.c_float),
-                ("sample_border", C.c_uint32), ("principal_point_offset_x", C.c_float), ("principal_point_offset_y", C.c_float)]
+                ("sample_border", C.c_uint32), ("principal_point_offset_x", C.c_float), ("principal_point_offset_y", C.c_float),
+                ("projection", C.c_uint32)]
 
 
 class HarBSDFContext(C.Structure):
@@ -148,6 +149,8 @@ SIGNATURES = {
     "har_transform_look_at": (C.c_int, [f32p, f32p, f32p, f32p]),
     "har_transform_mul": (C.c_int, [f32p, f32p, f32p]),
     "har_transform_inverse": (C.c_int, [f32p, f32p]),
+    "har_orthographic_sensor": (C.c_int, [f32p, C.c_float, C.c_float, C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32, C.c_float,
+                                          C.POINTER(HarSensor)]),
     "har_perspective_sensor": (C.c_int, [f32p, C.c_double, C.c_char_p, C.c_float, C.c_float, C.c_uint32, C.c_uint32,
                                          C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32, C.c_float,
                                          C.POINTER(HarSensor)]),

@@ -552,20 +552,24 @@ class Film:
 
 
 class Sensor:
-    """PerspectiveCamera (src/sensors/perspective.cpp)."""
+    """PerspectiveCamera (src/sensors/perspective.cpp) and OrthographicCamera (src/sensors/orthographic.cpp)."""
 
     def __init__(self, props):
         self.props = dict(props)
-        # sensor.cpp:24-97, perspective.cpp:137-172
-        _check_props('perspective', props, ('to_world', 'fov', 'fov_axis', 'focal_length', 'near_clip', 'far_clip', 'film', 'sampler', 'shutter_open', 'shutter_close', 'focus_distance',
-                                            'principal_point_offset_x', 'principal_point_offset_y'))
+        self.kind = props.get('type', 'perspective')
+        # sensor.cpp:24-97, perspective.cpp:137-172, orthographic.cpp:93-97
+        if self.kind == 'orthographic':
+            _check_props('orthographic', props, ('to_world', 'near_clip', 'far_clip', 'film', 'sampler', 'shutter_open', 'shutter_close'))
+        else:
+            _check_props('perspective', props, ('to_world', 'fov', 'fov_axis', 'focal_length', 'near_clip', 'far_clip', 'film', 'sampler', 'shutter_open', 'shutter_close', 'focus_distance',
+                                                'principal_point_offset_x', 'principal_point_offset_y'))
         # child objects are recognised by their class, whatever the property is called (XML children are anonymous: `_arg_0`, ...)
         film = next((v for v in props.values() if isinstance(v, Film)), props.get('film'))
         sampler = next((v for v in props.values() if isinstance(v, Sampler)), props.get('sampler'))
         self.m_film = film if isinstance(film, Film) else Film(film)
         self.m_sampler = sampler if isinstance(sampler, Sampler) else Sampler(sampler)
         self.to_world = props.get('to_world', ScalarTransform4f())
-        if self.to_world.has_scale():
+        if self.kind != 'orthographic' and self.to_world.has_scale():            # perspective.cpp:143-146; an orthographic camera's scale sets the size of its view
             raise RuntimeError("Scale factors in the camera-to-world transformation are not allowed!")
         if 'fov' in props and 'focal_length' in props:
             raise RuntimeError("Please specify either a focal length ('focal_length') or a field of view ('fov')!")
@@ -574,6 +578,15 @@ class Sensor:
 
     def update(self):
         f = self.m_film
+        if self.kind == 'orthographic':            # OrthographicCamera::update_camera_transforms (orthographic.cpp:104-121)
+            s = _capi.HarSensor()
+            if lib().har_orthographic_sensor(_fp(self.to_world.data), self.near_clip, self.far_clip, f.width, f.height, f.crop_offset_[0], f.crop_offset_[1],
+                                             f.crop_size_[0], f.crop_size_[1], f.rfilter, f.stddev, C.byref(s)):
+                raise RuntimeError("invalid sensor parameters")
+            s.rfilter_param1 = f.rf_param1
+            s.sample_border = 1 if f.sample_border_ else 0
+            self.har = s
+            return
         fov_axis = self.props.get('fov_axis', 'x')
         if 'fov' in self.props:
             fov = float(self.props['fov'])
@@ -1806,6 +1819,7 @@ for _name, _fn in {
     'path': lambda p, n, k: Integrator(p),
     'prb': lambda p, n, k: Integrator(p),
     'perspective': lambda p, n, k: Sensor({kk: (_resolve(v, n, kk) if isinstance(v, dict) and v.get('type') in ('hdrfilm', 'independent') else v) for kk, v in p.items()}),
+    'orthographic': lambda p, n, k: Sensor({kk: (_resolve(v, n, kk) if isinstance(v, dict) and v.get('type') in ('hdrfilm', 'independent') else v) for kk, v in p.items()}),
     'hdrfilm': lambda p, n, k: Film(p),
     'independent': lambda p, n, k: Sampler(p),
     'diffuse': lambda p, n, k: BSDF(p, id=k), 'dielectric': lambda p, n, k: BSDF(p, id=k), 'roughconductor': lambda p, n, k: BSDF(p, id=k),

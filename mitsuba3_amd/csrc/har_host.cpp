@@ -205,7 +205,30 @@ int har_perspective_sensor(const float to_world[32], double fov, const char *fov
     out->near_clip = near_clip; out->far_clip = far_clip; out->film_width = width; out->film_height = height;
     out->crop_offset_x = cx; out->crop_offset_y = cy; out->crop_width = cw; out->crop_height = ch;
     out->rfilter = rfilter; out->rfilter_stddev = stddev; out->rfilter_param1 = 1.f / 3.f;
-    out->principal_point_offset_x = 0.f; out->principal_point_offset_y = 0.f;
+    out->principal_point_offset_x = 0.f; out->principal_point_offset_y = 0.f; out->projection = 0u;
+    return 0;
+}
+
+int har_orthographic_sensor(const float to_world[32], float near_clip, float far_clip, uint32_t width, uint32_t height, uint32_t cx, uint32_t cy, uint32_t cw, uint32_t ch,
+                            uint32_t rfilter, float stddev, HarSensor *out) {
+    if (!out || !to_world || width == 0 || height == 0) return 1;
+    /* orthographic_projection (sensor.h:272-307): scale(1 / rel_size) * translate(-rel_offset) * scale(-1/2, -aspect/2, 1) * translate(-1, -1/aspect, 0) *
+     * orthographic(near, far), the last being scale(1, 1, 1 / (far - near)) * translate(0, 0, -near) (transform.h:162-166) */
+    const float fsx = (float) (int) width, fsy = (float) (int) height;
+    const float rel_size[2] = { (float) (int) cw / fsx, (float) (int) ch / fsy }, rel_off[2] = { (float) (int) cx / fsx, (float) (int) cy / fsy };
+    const float asp = fsx / fsy;
+    const float s1[3] = { 1.f / rel_size[0], 1.f / rel_size[1], 1.f }, t1[3] = { -rel_off[0], -rel_off[1], 0.f };
+    const float s2[3] = { -0.5f, -0.5f * asp, 1.f }, t2[3] = { -1.f, -1.f / asp, 0.f };
+    const float s3[3] = { 1.f, 1.f, 1.f / (far_clip - near_clip) }, t3[3] = { 0.f, 0.f, -near_clip };
+    Transform4f proj = Transform4f::scale(s1) * (Transform4f::translate(t1) * (Transform4f::scale(s2) * (Transform4f::translate(t2) * (Transform4f::scale(s3) * Transform4f::translate(t3)))));
+    Transform4f s2c = proj.inverse();
+    std::memset(out, 0, sizeof(*out));
+    std::memcpy(out->sample_to_camera, s2c.matrix.v, 64);
+    std::memcpy(out->to_world, to_world, 64);
+    out->near_clip = near_clip; out->far_clip = far_clip; out->film_width = width; out->film_height = height;
+    out->crop_offset_x = cx; out->crop_offset_y = cy; out->crop_width = cw; out->crop_height = ch;
+    out->rfilter = rfilter; out->rfilter_stddev = stddev; out->rfilter_param1 = 1.f / 3.f;
+    out->projection = 1u;
     return 0;
 }
 

@@ -60,6 +60,7 @@ struct DSensor {
     float radius;
     float coeff[10];             /* GaussianFilter::m_coeff (LLVM branch) */
     float ppo_x, ppo_y;          /* scaled principal point offset: film size * principal_point_offset / crop size (perspective.cpp:213-214) */
+    uint32_t projection;         /* 0 perspective, 1 orthographic (HarSensor::projection) */
 };
 
 struct SurfInt {
@@ -543,6 +544,15 @@ HAR_HD void sensor_sample_ray(const DSensor &C, float px, float py, Vec3 &o, Vec
     r0 = fma_(M[0], px, r0); r1 = fma_(M[4], px, r1); r2 = fma_(M[8], px, r2);  r3 = fma_(M[12], px, r3);
     r0 = fma_(M[1], py, r0); r1 = fma_(M[5], py, r1); r2 = fma_(M[9], py, r2);  r3 = fma_(M[13], py, r3);
     r0 = fma_(M[2], 0.f, r0); r1 = fma_(M[6], 0.f, r1); r2 = fma_(M[10], 0.f, r2); r3 = fma_(M[14], 0.f, r3);
+    if (C.projection == 1u) {            /* OrthographicCamera::sample_ray (orthographic.cpp:131-157): near_p = sample_to_camera * p (affine), o = to_world * near_p, d = normalize(to_world * +z) */
+        const float *T = C.to_world;
+        Vec3 ow(fma_(T[0], r0, T[3]), fma_(T[4], r0, T[7]), fma_(T[8], r0, T[11]));
+        ow = Vec3(fma_(T[1], r1, ow.x), fma_(T[5], r1, ow.y), fma_(T[9], r1, ow.z));
+        o = Vec3(fma_(T[2], r2, ow.x), fma_(T[6], r2, ow.y), fma_(T[10], r2, ow.z));
+        d = normalize3(Vec3(T[2], T[6], T[10]));
+        maxt = C.far_clip - C.near_clip;
+        return;
+    }
     float iw = rcp_(r3);
     Vec3 dl = normalize3(Vec3(r0 * iw, r1 * iw, r2 * iw));
     const float *T = C.to_world;

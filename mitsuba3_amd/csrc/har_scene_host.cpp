@@ -424,6 +424,8 @@ static bool lower_sensor_filter(const HarSensor &in, DSensor &out, std::string &
 bool lower_sensor(const HarSensor &in, DSensor &out, std::string &err) {
     if (in.crop_width == 0 || in.crop_height == 0) { err = "empty crop window"; return false; }
     if (in.rfilter > 5) { err = "unsupported reconstruction filter (box, gaussian, tent, mitchell, catmullrom and lanczos are implemented)"; return false; }
+    if (in.projection > 1) { err = "unsupported sensor projection (0 = perspective, 1 = orthographic)"; return false; }
+    out.projection = in.projection;
     std::memcpy(out.s2c, in.sample_to_camera, 64); std::memcpy(out.to_world, in.to_world, 64);
     out.near_clip = in.near_clip; out.far_clip = in.far_clip;
     out.crop_x = in.crop_offset_x; out.crop_y = in.crop_offset_y; out.crop_w = in.crop_width; out.crop_h = in.crop_height;

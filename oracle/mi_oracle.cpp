@@ -610,6 +610,16 @@ static inline Ray sensor_sample_ray(const OrcSensor &s, float px, float py) {
     const float sppx = (float) s.film_width * s.principal_point_offset_x / (float) s.crop_width, sppy = (float) s.film_height * s.principal_point_offset_y / (float) s.crop_height;
     float arg[3] = { px + sppx, py + sppy, 0.f };
     for (int j = 0; j < 3; ++j) for (int i = 0; i < 4; ++i) r[i] = fmadd(M[4 * i + j], arg[j], r[i]);   // transform.h:337-345
+    if (s.projection == 1) {      // OrthographicCamera::sample_ray (orthographic.cpp:131-157): an affine sample_to_camera, rays from the near plane along to_world's +z
+        const float *T = s.to_world;
+        Ray ray;
+        V3 o(T[3], T[7], T[11]);
+        for (int j = 0; j < 3; ++j) o = V3(fmadd(T[j], r[j], o.x), fmadd(T[4 + j], r[j], o.y), fmadd(T[8 + j], r[j], o.z));      // to_world * near_p (a point)
+        ray.o = o;
+        ray.d = normalize(V3(T[2], T[6], T[10]));                                                                           // to_world * (0, 0, 1)
+        ray.maxt = s.far_clip - s.near_clip;
+        return ray;
+    }
     float iw = rcp(r[3]);
     V3 near_p(r[0] * iw, r[1] * iw, r[2] * iw);
     V3 d = normalize(near_p);

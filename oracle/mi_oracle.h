@@ -112,6 +112,7 @@ typedef struct OrcSensor {
     float    rfilter_param1;      /* parameter 1: mitchell C */
     uint32_t sample_border;       /* Film::sample_border (film.cpp:29-32): render() samples crop_size + 2 * rfilter->border_size() pixels (integrator.cpp:162-165) */
     float    principal_point_offset_x, principal_point_offset_y;   /* perspective.cpp:147-150,213-221 */
+    uint32_t projection;          /* 0 = PerspectiveCamera, 1 = OrthographicCamera (src/sensors/orthographic.cpp): sample_to_camera = orthographic_projection(...)^-1 */
 } OrcSensor;
 
 typedef struct OrcStats {

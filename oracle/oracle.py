@@ -62,7 +62,8 @@ class Sensor(C.Structure):
                 ("crop_offset_x", C.c_uint32), ("crop_offset_y", C.c_uint32),
                 ("crop_width", C.c_uint32), ("crop_height", C.c_uint32),
                 ("rfilter", C.c_uint32), ("rfilter_stddev", C.c_float), ("rfilter_param1", C.c_float),
-                ("sample_border", C.c_uint32), ("principal_point_offset_x", C.c_float), ("principal_point_offset_y", C.c_float)]
+                ("sample_border", C.c_uint32), ("principal_point_offset_x", C.c_float), ("principal_point_offset_y", C.c_float),
+                ("projection", C.c_uint32)]
 
 
 class Stats(C.Structure):
