@@ -740,6 +740,9 @@ int har_scene_create(const HarSceneDesc *desc, HarScene *out) {
     auto up = [&](auto &vec, auto **dst) { if (err == hipSuccess) err = upload(vec, dst, S->owned); };
     up(hs.nodes, &D.accel.nodes); up(hs.tris, &D.accel.tris); up(hs.inst_recs, &D.accel.insts);
     up(hs.blas_tri_ranges, &D.blas_tri_ranges); up(hs.verts, &D.verts); up(hs.faces, &D.faces);
+#if HAR_SHADING_TRIS
+    up(hs.shade_tris, &D.shade_tris);
+#endif
     /* material class of every BSDF record and mesh (MaterialQueues; the mesh's class rides in DMesh::pad1 so that k_classify needs ONE dependent load) */
     S->mat_classes = 0;
     {

@@ -54,6 +54,9 @@ struct BoundScene {
         S.accel.root = hs.root; S.accel.has_tlas = hs.has_tlas; S.accel.n_tris = (uint32_t) hs.tris.size(); S.accel.n_insts = (uint32_t) hs.inst_recs.size();
         S.accel.top_root = hs.top_root; S.accel.top_first = hs.top_first; S.accel.top_count = hs.top_count; S.accel.top_last = hs.top_last;
         S.blas_tri_ranges = hs.blas_tri_ranges.data();
+#if HAR_SHADING_TRIS
+        S.shade_tris = hs.shade_tris.data();
+#endif
         S.verts = hs.verts.data(); S.faces = hs.faces.data(); S.meshes = hs.meshes.data(); S.bsdfs = hs.bsdfs.data();
         S.textures = dtex.data(); S.emitters = hs.emitters.data(); S.insts = hs.insts.data(); S.bsdf_tables = hs.bsdf_tables.data();
         S.n_emitters = (uint32_t) hs.emitters.size(); S.n_meshes = (uint32_t) hs.meshes.size();

@@ -17,6 +17,9 @@ struct DTexture { const float *data; uint32_t w, h; uint32_t mode, pad; };      
  * (src/emitters/constant.cpp): to_world[0..2] = bounding sphere centre, to_world[3] = radius, mesh = 0xffffffff; type 2: environment map
  * (DEnvmap); type 3: AreaLight on a triangle mesh: mesh, inv_area = 1 / surface area, to_world[0] / [1] = bit patterns of the offset of its
  * table in DScene::emitter_cdf and of its face count, to_world[2] = sum of the face areas */
+#ifndef HAR_SHADING_TRIS
+#define HAR_SHADING_TRIS 0      /* 1: compute_si reads pre-gathered per-face vertex records (what-if build, not measured yet) */
+#endif
 struct DEmitter { float radiance[3]; float inv_area; float to_world[12]; float normal[3]; uint32_t mesh; uint32_t type; };
 struct DInst    { float to_world[12]; float to_object[12]; };
 /* EnvironmentMapEmitter (src/emitters/envmap.cpp), emitter type 2.  `tex` = H x (W + 2) x 3 radiance with one halo column on each side
@@ -35,6 +38,9 @@ struct DScene {
     Accel accel;
     const uint32_t *blas_tri_ranges;   /* per TLAS record: first, count (brute-force kernel) */
     const float    *verts;             /* packed vertices, 8 f32 each (mesh_utils.h:19-34) */
+#if HAR_SHADING_TRIS
+    const float    *shade_tris;        /* what-if build: the three vertex records of every face, 24 f32 per face in face order (see compute_si) */
+#endif
     const uint32_t *faces;             /* packed faces, 4 u32 each */
     const DMesh    *meshes;
     const DBsdf    *bsdfs;
@@ -83,10 +89,16 @@ HAR_HD SurfInt compute_si(const DScene &S, Vec3 ray_d, float t, float bu, float 
     si.t = t; si.uv_x = 0.f; si.uv_y = 0.f; si.mesh = 0;
     if (t == HAR_INF) { si.wi = -ray_d; return si; }
     const DMesh M = S.meshes[shape];
+#if HAR_SHADING_TRIS
+    /* what-if (A/B builds; docs/rounds/r05_plan.md item 1): the face's three vertex records pre-gathered into ONE 96-byte block -- hit -> mesh record -> block instead
+     * of hit -> mesh record -> face -> three scattered vertices: one level of dependent loads less, one or two cache lines instead of three or four */
+    const float *r0 = S.shade_tris + 24 * (size_t) (M.foff + prim), *r1 = r0 + 8, *r2 = r0 + 16;
+#else
     const uint32_t *f = S.faces + 4 * (size_t) (M.foff + prim);
     const float *r0 = S.verts + 8 * (size_t) (M.voff + f[0]);
     const float *r1 = S.verts + 8 * (size_t) (M.voff + f[1]);
     const float *r2 = S.verts + 8 * (size_t) (M.voff + f[2]);
+#endif
 #if defined(__HIP_DEVICE_COMPILE__)
     const float4 qa0 = reinterpret_cast<const float4 *>(r0)[0], qa1 = reinterpret_cast<const float4 *>(r0)[1];
     const float4 qb0 = reinterpret_cast<const float4 *>(r1)[0], qb1 = reinterpret_cast<const float4 *>(r1)[1];

@@ -221,6 +221,10 @@ bool lower_scene(const HarSceneDesc &d, HostScene &hs, std::string &err) {
         dm.bsdf = m.bsdf; dm.emitter = m.emitter; dm.flags = m.flags; dm.face_count = m.face_count; dm.vertex_count = m.vertex_count;
         hs.verts.insert(hs.verts.end(), m.vertex_ptr, m.vertex_ptr + 8 * (size_t) m.vertex_count);
         hs.faces.insert(hs.faces.end(), m.index_ptr, m.index_ptr + 4 * (size_t) m.face_count);
+#if HAR_SHADING_TRIS
+        for (uint32_t f = 0; f < m.face_count; ++f)
+            for (int k = 0; k < 3; ++k) { const float *v = m.vertex_ptr + 8 * (size_t) m.index_ptr[4 * (size_t) f + k]; hs.shade_tris.insert(hs.shade_tris.end(), v, v + 8); }
+#endif
         hs.meshes.push_back(dm);
     }
     for (uint32_t i = 0; i < d.texture_count; ++i) {

@@ -13,6 +13,7 @@ struct HostTexture { std::vector<float> data; uint32_t w, h, mode = 0; };
 
 struct HostScene {
     std::vector<float> verts;
+    std::vector<float> shade_tris;      /* HAR_SHADING_TRIS builds: three vertex records per face (empty otherwise) */
     std::vector<uint32_t> faces;
     std::vector<DMesh> meshes; uint32_t top_mesh_count = 0;      /* meshes [0, top_mesh_count) are the scene's own shapes, the rest belong to shape groups */
     std::vector<DBsdf> bsdfs;
