@@ -288,6 +288,28 @@ def test_golden_shape_gradients(mi):
         assert np.abs(got - want).max() < 2e-3 * np.abs(want).max(), name
 
 
+def test_golden_round4_plugins(mi):
+    """`point` / `spot` / `directional` emitters and the `orthographic` sensor in one scene against the committed oracle arrays (no oracle call at run time):
+    forward image, prb image, gradients w.r.t. the four emitters' parameters and the constant albedos"""
+    from tests.test_golden_cpu import round4_scene
+    fx = _fx()
+    scene = mi.load_dict(round4_scene(mi))
+    img = mi.render(scene, spp=8, seed=2).cpu().numpy()
+    assert rel_l2(img, fx["r4_path"]) < 1e-4                               # north_star forward tolerance
+    integ = mi.load_dict({"type": "prb", "max_depth": 6})
+    img = mi.render(scene, integrator=integ, spp=8, seed=2).cpu().numpy()
+    assert rel_l2(img, fx["r4_prb"]) < 1e-4
+    grads = integ.render_backward(scene, None, fx["r4_grad_in"], seed=5, spp=8)
+    keys = scene._param_keys()
+    ek = {k: v[1] for k, v in keys.items() if v[0] == "emit"}
+    assert len(ek) == 4
+    got = np.stack([grads[k].cpu().numpy() for k in ek]); want = np.stack([fx["r4_grad_emit"][i] for i in ek.values()])
+    assert rel_l2(got, want) < 1e-3                                        # north_star PRB tolerance
+    for k, (kind, b) in keys.items():
+        if kind == "rgb":
+            assert rel_l2(grads[k].cpu().numpy(), fx["r4_grad_refl"][b.index]) < 1e-3, k
+
+
 def test_golden_sampler_streams(mi):
     fx = _fx()
     s = mi.Sampler({"sample_count": 4}); s.seed(7, 16)
