@@ -199,6 +199,13 @@ def test_product_scalar_path_matches_the_oracle_scalar_driver(O):
         ref, _, _ = osc.render_path_scalar(sensor, seed=1, spp=8, max_depth=8)
         img = core._render_scalar(scene, scene.integrator(), scene.sensors()[0], 1, 8, threads=1)
         assert _rel_l2(img, ref) < 1e-4
+        # the plugins round 4 added, under the scalar variant too: point / spot / directional emitters behind an orthographic camera (tests/test_golden_cpu.py: round4_scene)
+        from tests.test_golden_cpu import round4_scene
+        scene = mi.load_dict(round4_scene(mi))
+        osc, sensor = O.scene_from_product(scene)
+        ref, _, _ = osc.render_path_scalar(sensor, seed=2, spp=8, max_depth=8)
+        img = core._render_scalar(scene, scene.integrator(), scene.sensors()[0], 2, 8, threads=1)
+        assert np.abs(ref).max() > 0 and _rel_l2(img, ref) < 1e-5
     finally:
         mi.set_variant("hip_ad_rgb")
 
