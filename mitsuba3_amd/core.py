@@ -1277,7 +1277,7 @@ class Scene:
     def __init__(self, children):
         self.bsdf_objs = []; self.meshes = []; self.top_mesh_count = 0
         self.groups = []; self.instances = []; self.instance_keys = []; self.emitters = []
-        self.m_sensors = []; self.m_integrator = None; self.textures = []; self.texture_modes = []
+        self.m_sensors = []; self.sensor_keys = []; self.m_integrator = None; self.textures = []; self.texture_modes = []
         self._h = None; self._keep = []
         named = {}
         shapes = []; groups = []; insts = []
@@ -1316,7 +1316,7 @@ class Scene:
                 self._add_bsdf(obj)
         for key, obj in children.items():
             if isinstance(obj, Sensor):
-                self.m_sensors.append(obj)
+                self.m_sensors.append(obj); self.sensor_keys.append(key)
             elif isinstance(obj, Integrator):
                 self.m_integrator = obj
             elif isinstance(obj, Mesh):
@@ -1615,6 +1615,47 @@ class Scene:
         if self._h is not None:
             lib().har_scene_destroy(self._h); self._h = None
 
+    def _pose_keys(self):
+        """the NON-differentiable placement parameters the reference's traverse() exposes (ParamFlags::NonDifferentiable): '<sensor>.to_world' (perspective.cpp:177,
+        orthographic.cpp:95), '<emitter>.position' of a point light (point.cpp:86), '<emitter>.to_world' of spot and directional lights (spot.cpp:117,
+        directional.cpp:96) -- 4 x 4 matrices / a 3-vector; params.update() re-lowers the sensor or the scene"""
+        keys = {}
+        for k, s in zip(self.sensor_keys, self.m_sensors):
+            keys[k + ".to_world"] = ("sensor", s)
+        for i, key in enumerate(self._emitter_order):
+            t = self.emitters[i].get("type", 0)
+            if t == 4:
+                keys[key + ".position"] = ("position", i)
+            elif t in (5, 6):
+                keys[key + ".to_world"] = ("emitter_to_world", i)
+        return keys
+
+    def _pose_value(self, kind, b):
+        if kind == "sensor":
+            return np.asarray(b.to_world.matrix, np.float32).reshape(4, 4).copy()
+        if kind == "position":
+            return np.asarray(self.emitters[b]["to_world"][9:12], np.float32).copy()
+        m = np.eye(4, dtype=np.float32); m[:3, :] = np.asarray(self.emitters[b]["to_world"], np.float32).reshape(4, 3).T
+        return m
+
+    def _set_pose(self, kind, b, value):
+        if kind == "sensor":
+            m = np.asarray(value, np.float64).reshape(4, 4)
+            b.to_world = ScalarTransform4f(np.concatenate([m.astype(np.float32).ravel(), np.linalg.inv(m).astype(np.float32).ravel()]))
+            if b.kind != 'orthographic' and b.to_world.has_scale():
+                raise RuntimeError("Scale factors in the camera-to-world transformation are not allowed!")
+            b.update()                                           # the sensor record travels with every render call: no scene handle involved
+            return
+        e = dict(self.emitters[b])
+        if kind == "position":
+            e["to_world"] = list(e["to_world"][:9]) + [float(x) for x in np.asarray(value, np.float32).reshape(3)]
+        else:
+            m = np.asarray(value, np.float64).reshape(4, 4); inv = np.linalg.inv(m)
+            e["to_world"] = [float(x) for x in m[:3, :].T.reshape(-1)]; e["to_local"] = [float(x) for x in inv[:3, :].T.reshape(-1)]
+        self.emitters[b] = e
+        if self._h is not None:                                  # the emitter records are part of the scene handle: rebuilt with the next one
+            lib().har_scene_destroy(self._h); self._h = None
+
     def _gradients(self, g_refl, g_tex, g_emit=None):
         out = {}
         for k, (kind, b) in self._param_keys().items():
@@ -1643,6 +1684,8 @@ class SceneParameters(dict):
             self[k] = torch.tensor(np.ascontiguousarray(scene.meshes[m]["V"][:, :3]).reshape(-1), dtype=torch.float32, device=dev)
         for k, i in scene._instance_keys().items():
             self[k] = torch.tensor(scene._instance_matrix(i), dtype=torch.float32, device=dev)
+        for k, (kind, b) in scene._pose_keys().items():
+            self[k] = torch.tensor(scene._pose_value(kind, b), dtype=torch.float32, device=dev)
         self._written = set()           # keys assigned since the last update() (SceneParameters.__setitem__ flags them in the reference, util.py)
 
     def __setitem__(self, key, value):
@@ -1664,6 +1707,10 @@ class SceneParameters(dict):
             v = self[k].detach().to("cpu", copy=True).numpy().astype(np.float32).reshape(4, 4)
             if not np.array_equal(v, self.scene._instance_matrix(i)):
                 self.scene._set_instance_matrix(i, v)
+        for k, (kind, b) in self.scene._pose_keys().items():
+            v = self[k].detach().to("cpu", copy=True).numpy().astype(np.float32)
+            if not np.array_equal(v.reshape(-1), self.scene._pose_value(kind, b).reshape(-1)):
+                self.scene._set_pose(kind, b, v)
         for k, (what, b) in self.scene._bsdf_param_keys().items():
             v = self[k].detach().to("cpu", copy=True).numpy().astype(np.float32).reshape(-1)
             if not np.array_equal(v, np.asarray(self.scene._bsdf_param_value(what, b), np.float32).reshape(-1)):
@@ -1880,6 +1927,9 @@ def render(scene, params=None, sensor=0, integrator=None, seed=0, seed_grad=0, s
             raise RuntimeError("scalar_rgb renders are not differentiable (the reference's scalar variants have no AD either); use hip_ad_rgb")
         return _render_scalar(scene, integrator, sensor, seed, spp)
     keys = [k for k, v in (params or {}).items() if getattr(v, 'requires_grad', False)]
+    fixed = [k for k in keys if k in scene._pose_keys()]
+    if fixed:       # ParamFlags::NonDifferentiable in the reference's traverse(): dr.enable_grad on them has no effect there; here it is said
+        raise RuntimeError("%s are not differentiable parameters (placement of sensors and delta emitters: ParamFlags::NonDifferentiable)" % fixed)
     if not keys:
         return integrator.render(scene, sensor, seed, spp)
     params.update()

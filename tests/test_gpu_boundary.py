@@ -362,7 +362,7 @@ def test_prb_nested_mesh_vertex_position_gradients(mi, O, which):
     got = grads[key + ".vertex_positions"].cpu().numpy().reshape(-1, 3)
     scale = np.abs(want[m]).max()
     assert scale > 0 and np.abs(got - want[m]).max() < 2e-3 * scale, (which, np.abs(got - want[m]).max() / scale)
-    inst_key = [k for k in params.keys() if k.endswith(".to_world")][0]
+    inst_key = next(iter(scene._instance_keys()))          # '<instance>.to_world' (the sensor's and the delta emitters' placement keys end in .to_world too)
     integ.shape_gradients = [key + ".vertex_positions", inst_key]
     with pytest.raises(RuntimeError, match="at the same time"):
         integ.render_backward(scene, None, grad_in, seed=3, spp=16)
