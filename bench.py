@@ -47,7 +47,7 @@ def parse(argv=None):
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=3)
     ap.add_argument("--warmup", type=int, default=1)
-    ap.add_argument("--workload", default="instanced1m", choices=["instanced1m", "flat1m", "cornell", "materials1m"])
+    ap.add_argument("--workload", default="instanced1m", choices=["instanced1m", "flat1m", "cornell", "materials1m", "c4_loop", "vertex_loop"])
     ap.add_argument("--res", type=int, default=512)
     ap.add_argument("--spp", type=int, default=256)
     ap.add_argument("--max-depth", type=int, default=8)
@@ -197,6 +197,96 @@ def profile_matches_run(profile, timing):
     return True
 
 
+def optimisation_loop(args, mi, torch, timed, sync_barrier, world, rank):
+    """BASELINE config 4 as it is used: the inverse-rendering LOOP (src/python/python/util.py:344-528 mi.render + SceneParameters.update):
+        c4_loop     render(prb, 256^2 x 256 spp, Cornell box, 256^2 albedo bitmap) -> mean(img^2) -> backward -> Adam step -> params.update()
+        vertex_loop the same loop over the vertex positions of a >= 100 k-triangle mesh in the Cornell box (shape gradients; the accel follows by a device refit)
+    one step = all of that; value = steps / s; `outside_kernels` = the share of a step's wall time in which none of the library's kernels runs
+    (HIP events of every launch of the profiled steps, har_integrator_set_profiling), i.e. host work + torch's own small kernels."""
+    import numpy as np
+    if world != 1:
+        raise SystemExit("bench.py --workload %s is a single-GPU measurement" % args.workload)
+    res = args.res if args.res != 512 else 256          # config 4's film (BASELINE.json: Cornell resolution); --res overrides
+    spp = args.spp
+    if args.workload == "c4_loop":
+        d = mi.textured_cornell_box(res=res, tex_res=256, spp=spp, max_depth=args.max_depth)
+        key = "white.reflectance.data"
+        what = "Cornell box %dx%dx%dspp prb max_depth=%d, 256x256x3 albedo bitmap on the white walls" % (res, res, spp, args.max_depth)
+    else:
+        d = mi.cornell_box(); d["sensor"]["film"]["width"] = res; d["sensor"]["film"]["height"] = res
+        d["sensor"]["sampler"]["sample_count"] = spp
+        d["integrator"] = {"type": "prb", "max_depth": args.max_depth, "rr_depth": 5}
+        from mitsuba3_amd.scenes import bumpy_sphere
+        P, N, UV, F = bumpy_sphere(n_u=320, n_v=160, radius=0.35)            # 102 400 triangles
+        d.pop("small-box"); d.pop("large-box")
+        d["blob"] = {"type": "mesh", "positions": P + np.array([0.0, -0.45, 0.0], np.float32), "faces": F, "bsdf": {"type": "ref", "id": "white"}}
+        key = "blob.vertex_positions"
+        what = "Cornell box + a %d-triangle mesh, %dx%dx%dspp prb max_depth=%d, gradients w.r.t. its %d vertex positions" % (F.shape[0], res, res, spp, args.max_depth, P.shape[0])
+    log("optimisation loop: building the scene")
+    scene = mi.load_dict(d)
+    integ = scene.integrator()
+    params = mi.traverse(scene)
+    params[key] = params[key].clone().requires_grad_(True)
+    params.update()
+    opt = torch.optim.Adam([params[key]], lr=(0.01 if args.workload == "c4_loop" else 1e-4))
+    it = [0]
+
+    def step():
+        opt.zero_grad(set_to_none=True)
+        img = mi.render(scene, params, spp=spp, seed=it[0])
+        loss = (img ** 2).mean()
+        loss.backward()
+        opt.step()
+        params.update()
+        it[0] += 1
+
+    log("first step (workspace allocation, code object load)")
+    step(); sync_barrier()
+    log("loop: %d warmup + %d timed steps" % (args.warmup, args.steps))
+    dt = timed(step, args.steps, args.warmup)
+    ms = dt / args.steps * 1e3
+    # kernel time of the library per step: HIP events around every launch (forward render = 1 frame, backward = 1 frame)
+    integ.set_profiling(True)
+    n_prof = max(2, min(args.steps, 5))
+    for _ in range(n_prof):
+        step()
+    sync_barrier()
+    timing = integ.timing(); integ.set_profiling(False)
+    frames = max(1, int(timing["frames"][0]))
+    kernel_ms = float(timing["total"][0]) * frames / n_prof            # timing() averages per frame; a step holds frames / n_prof of them
+    # host-only cost of the step's non-render parts, measured alone: params.update() and the optimiser step with the GPU idle
+    torch.cuda.synchronize(); t0 = time.perf_counter()
+    for _ in range(20):
+        params.update()
+    torch.cuda.synchronize(); update_ms = (time.perf_counter() - t0) / 20 * 1e3
+    # plain PRB step of the same scene without the loop around it (render_backward with a fixed adjoint): what the loop adds
+    grad_in = torch.full((res, res, 3), 1.0 / (res * res * 3), device="cuda")
+    saved = integ.shape_gradients
+    if args.workload == "vertex_loop":
+        integ.shape_gradients = [key]
+
+    def plain():
+        integ.render(scene, seed=1, spp=spp, evaluate=False)
+        integ.render_backward(scene, None, grad_in, seed=2, spp=spp)
+
+    plain(); sync_barrier()
+    dt_plain = timed(plain, max(2, min(args.steps, 5)), 1)
+    integ.shape_gradients = saved
+    plain_ms = dt_plain / max(2, min(args.steps, 5)) * 1e3
+    out = {"metric": "optimisation steps/s: render -> loss -> backward -> Adam -> params.update() (BASELINE config 4 loop)" if args.workload == "c4_loop"
+                     else "optimisation steps/s over vertex positions (device accel refit per step)",
+           "value": round(args.steps / dt, 3), "unit": "steps/s", "n_gpus": 1, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(ms, 3),
+           "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+           "config": {"workload": what, "parameter": key, "parameter_values": int(params[key].numel()), "optimizer": "torch.optim.Adam"},
+           "loop": {"library_kernel_ms_per_step": round(kernel_ms, 3), "outside_kernels_ms_per_step": round(ms - kernel_ms, 3),
+                    "outside_kernels_share": round((ms - kernel_ms) / ms, 4), "params_update_ms": round(update_ms, 4),
+                    "plain_primal_plus_backward_ms": round(plain_ms, 3), "loop_over_plain": round(ms / plain_ms, 3),
+                    "mpaths_per_s_primal_plus_adjoint": round(res * res * spp / (ms / 1e3) / 1e6, 2),
+                    "kernel_ms_per_frame": {k: round(v[0], 3) for k, v in timing.items() if k != "frames"}, "frames_per_step": frames / n_prof}}
+    print(json.dumps(out)); sys.stdout.flush()
+    log("done")
+
+
 def worker(args):
     import faulthandler
     faulthandler.enable()                      # a GPU fault ends in abort(): say which Python line was running
@@ -278,6 +368,9 @@ def worker(args):
             dist.all_reduce(t, op=dist.ReduceOp.MAX)
             dt = float(t.item())
         return dt
+
+    if args.workload in ("c4_loop", "vertex_loop"):
+        return optimisation_loop(args, mi, torch, timed, sync_barrier, world, rank)
 
     n_paths = args.res * args.res * args.spp
 

@@ -92,7 +92,10 @@ typedef struct HarBSDF {
 #define HAR_TEX_REPEAT   0u
 #define HAR_TEX_MIRROR   2u
 #define HAR_TEX_CLAMP    4u
-typedef struct HarTexture { const float *data; uint32_t width, height; uint32_t mode, reserved; } HarTexture;
+/* to_uv: the `to_uv` property of BitmapTexture (bitmap.cpp:175), a 2-D affine map applied to the surface's uv before every lookup (`uv = m_transform * si.uv`,
+ * bitmap.cpp:565,792,831,847): row-major 2 x 3, { m00, m01, m02, m10, m11, m12 } -> u' = fma(m01, v, fma(m00, u, m02)), v' likewise (AffineTransform * Point,
+ * include/mitsuba/core/transform.h:322-335).  Six zeros (a zero-initialised record) mean the identity. */
+typedef struct HarTexture { const float *data; uint32_t width, height; uint32_t mode, reserved; float to_uv[6]; } HarTexture;
 
 /* type 0: AreaLight on a Rectangle (src/emitters/area.cpp, src/shapes/rectangle.cpp:108-179);
  * type 1: ConstantBackgroundEmitter (src/emitters/constant.cpp): only `radiance` is read, at most one per scene.
@@ -115,6 +118,10 @@ typedef struct HarEmitter {
     float normal[3];
     float inv_area;
     float to_local[12];   /* inverse of to_world as the reference's Transform tracks it (type 2 only) */
+    float sampling_weight; /* Emitter property `sampling_weight` (src/render/emitter.cpp:9; default 1 -- set it, a zero-initialised record has weight 0): as soon as one emitter's
+                            * weight differs from 1 the scene picks emitters from a DiscreteDistribution over the weights instead of uniformly
+                            * (Scene::update_emitter_sampling_distribution, src/render/scene.cpp:120-141; sample_emitter :248-271, pdf_emitter :273-279,
+                            * pdf_emitter_direction :378-388).  Weights are non-negative and not all zero. */
 } HarEmitter;
 
 typedef struct HarSceneDesc {
@@ -188,6 +195,14 @@ int har_scene_destroy(HarScene scene);
 int har_scene_set_reflectance(HarScene scene, uint32_t bsdf, const float rgb[3]);
 int har_scene_set_emitter_radiance(HarScene scene, uint32_t emitter, const float rgb[3]);   /* `area` / `constant` emitters */
 int har_scene_set_texture(HarScene scene, uint32_t texture, const float *data);
+/* The same updates from DEVICE memory, ordered on `stream` (NULL = default stream), with no host round trip and no synchronisation: the optimisation loop of
+ * BASELINE config 4 (render -> loss -> backward -> optimiser step -> params.update(), src/python/python/util.py:344-528; in the reference the scene parameters ARE
+ * device arrays).  data / rgb: DEVICE pointers (H x W x 3 floats / 3 floats) that must stay valid until the copy has run on `stream`.  Exception: the colour or bitmap
+ * of a `plastic` / `roughplastic` record also sets its lobe-selection weight (the MEAN of the reflectance, RoughPlastic::parameters_changed,
+ * roughplastic.cpp:204-242), which is computed on the host: those records take one synchronous device-to-host copy. */
+int har_scene_set_texture_device(HarScene scene, uint32_t texture, const float *data, void *stream);
+int har_scene_set_reflectance_device(HarScene scene, uint32_t bsdf, const float *rgb, void *stream);
+int har_scene_set_emitter_radiance_device(HarScene scene, uint32_t emitter, const float *rgb, void *stream);
 /* accel statistics: node count, triangle count, bytes */
 int har_scene_accel_info(HarScene scene, uint64_t info[4]);
 

@@ -11,7 +11,7 @@ layer that mirrors the reference's `mitsuba` module for this path:
 """
 from ._capi import HarError, lib, LIB_PATH            # noqa: F401
 from .core import (                                    # noqa: F401
-    set_variant, variant, variants, ScalarTransform4f, Transform4f, cornell_box, load_dict, render, traverse,
+    set_variant, variant, variants, ScalarTransform4f, Transform4f, ScalarTransform3f, Transform3f, AreaLight, cornell_box, load_dict, render, traverse,
     register_plugin, register_integrator, Scene, Sensor, Film, Sampler, BSDF, BSDFContext, BSDFFlags, TransportMode, RayFlags, Mesh, ShapeGroup, Instance,
     Integrator, Ray3f, PreliminaryIntersection3f, SurfaceInteraction3f, SceneParameters, develop_film, sample_tea_32,
     Bitmap, write_bitmap, ConstantEmitter, EnvmapEmitter, PointLight, SpotLight, DirectionalEmitter,

@@ -38,12 +38,12 @@ class HarBSDF(C.Structure):
 
 
 class HarTexture(C.Structure):
-    _fields_ = [("data", f32p), ("width", C.c_uint32), ("height", C.c_uint32), ("mode", C.c_uint32), ("reserved", C.c_uint32)]
+    _fields_ = [("data", f32p), ("width", C.c_uint32), ("height", C.c_uint32), ("mode", C.c_uint32), ("reserved", C.c_uint32), ("to_uv", C.c_float * 6)]
 
 
 class HarEmitter(C.Structure):
     _fields_ = [("type", C.c_uint32), ("mesh", C.c_uint32), ("radiance", C.c_float * 3),
-                ("to_world", C.c_float * 12), ("normal", C.c_float * 3), ("inv_area", C.c_float), ("to_local", C.c_float * 12)]
+                ("to_world", C.c_float * 12), ("normal", C.c_float * 3), ("inv_area", C.c_float), ("to_local", C.c_float * 12), ("sampling_weight", C.c_float)]
 
 
 class HarMeshData(C.Structure):
@@ -99,6 +99,9 @@ SIGNATURES = {
     "har_integrator_set_alpha_film": (C.c_int, [vp, vp]),
     "har_scene_set_texture": (C.c_int, [vp, C.c_uint32, f32p]),
     "har_scene_accel_info": (C.c_int, [vp, u64p]),
+    "har_scene_set_texture_device": (C.c_int, [vp, C.c_uint32, vp, vp]),
+    "har_scene_set_reflectance_device": (C.c_int, [vp, C.c_uint32, vp, vp]),
+    "har_scene_set_emitter_radiance_device": (C.c_int, [vp, C.c_uint32, vp, vp]),
     "har_ray_intersect_preliminary": (C.c_int, [vp, C.c_uint32, vp, vp, vp, vp, C.c_int, vp, vp, vp, vp, vp, vp, vp]),
     "har_ray_test": (C.c_int, [vp, C.c_uint32, vp, vp, vp, vp, C.c_int, vp, vp]),
     "har_compute_surface_interaction": (C.c_int, [vp, C.c_uint32, vp, vp, vp, vp, vp, vp, vp, vp, C.c_uint32, vp, vp, vp]),

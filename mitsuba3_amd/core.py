@@ -145,6 +145,42 @@ class ScalarTransform4f:
 Transform4f = ScalarTransform4f
 
 
+class ScalarTransform3f:
+    """ScalarAffineTransform3f (include/mitsuba/core/transform.h): 2-D affine maps, the type of BitmapTexture's `to_uv`.  Chained like the reference's Python API:
+    T().translate(v).rotate(deg).scale(v) = translate * rotate * scale (the last call acts first on a point)."""
+
+    def __init__(self, matrix=None):
+        self.matrix = np.eye(3, dtype=np.float32) if matrix is None else np.asarray(matrix, np.float32).reshape(3, 3).copy()
+
+    def _chain(self, m):
+        # Transform::operator*, affine branch (transform.h:364-400): sums of fmadd in float32 -- float64 accumulation rounded once is the same value for these 2-term sums
+        # except in the last bit; `to_uv` is consumed as six float32 numbers, so the stored matrix IS the parameter
+        return ScalarTransform3f((self.matrix.astype(np.float64) @ np.asarray(m, np.float64)).astype(np.float32))
+
+    def translate(self, v):
+        m = np.eye(3, dtype=np.float32); m[0, 2] = v[0]; m[1, 2] = v[1]; return self._chain(m)
+
+    def scale(self, v):
+        v = [v, v] if np.isscalar(v) else v
+        m = np.eye(3, dtype=np.float32); m[0, 0] = v[0]; m[1, 1] = v[1]; return self._chain(m)
+
+    def rotate(self, angle):
+        a = math.radians(float(angle)); c, sn = math.cos(a), math.sin(a)
+        m = np.eye(3, dtype=np.float32); m[0, 0] = c; m[0, 1] = -sn; m[1, 0] = sn; m[1, 1] = c; return self._chain(m)
+
+    def inverse(self):
+        return ScalarTransform3f(np.linalg.inv(self.matrix.astype(np.float64)).astype(np.float32))
+
+    def __matmul__(self, other):
+        return self._chain(other.matrix)
+
+    def rows_2x3(self):
+        return [float(x) for x in self.matrix[:2, :].reshape(-1)]
+
+
+Transform3f = ScalarTransform3f
+
+
 def cornell_box():
     """mi.cornell_box() (src/python/python/util.py:569-703)."""
     T = ScalarTransform4f
@@ -367,7 +403,13 @@ class Mesh:
         return self.V.shape[0]
 
 
+# Shape(props) (src/render/shape.cpp:17-60) + Mesh(props) (src/render/mesh.cpp:160-175): rectangle and cube are Mesh plugins in this tree.
+# `silhouette_sampling_weight` only feeds the projective integrators' boundary sampling: queried, no effect on `path` / `prb`.
+_SHAPE_PROPS = ('to_world', 'flip_normals', 'face_normals', 'silhouette_sampling_weight')
+
+
 def _rectangle(props):
+    _check_props('rectangle', props, _SHAPE_PROPS, unsupported=(('face_normals', False),))
     tw = props.get('to_world', ScalarTransform4f())
     m = Mesh("rectangle")
     V = np.empty((4, 8), np.float32); F = np.empty((2, 4), np.uint32); n = np.empty(3, np.float32); ia = C.c_float()
@@ -378,6 +420,7 @@ def _rectangle(props):
 
 
 def _cube(props):
+    _check_props('cube', props, _SHAPE_PROPS, unsupported=(('face_normals', False), ('flip_normals', False)))
     tw = props.get('to_world', ScalarTransform4f())
     m = Mesh("cube")
     V = np.empty((24, 8), np.float32); F = np.empty((12, 4), np.uint32)
@@ -386,7 +429,7 @@ def _cube(props):
     return m
 
 
-def _check_props(plugin, props, known, unsupported=()):
+def _check_props(plugin, props, known, unsupported=(), free_children=True):
     """The reference's plugin loader rejects properties a plugin never queried ("Unreferenced property", src/core/plugin.cpp / properties.cpp)
     -- a silently ignored property would be a silently different picture.  `unsupported`: (name, neutral value) pairs the reference knows
     but hip_ad_rgb does not implement; anything but the neutral value is refused."""
@@ -396,7 +439,9 @@ def _check_props(plugin, props, known, unsupported=()):
     for k, v in props.items():
         if k in ('type', 'id') or k in known or any(k == u[0] for u in unsupported) or k.startswith('_arg_'):
             continue
-        if isinstance(v, (dict, Film, Sampler)) or hasattr(v, 'har'):          # child objects: their key is free
+        # child objects: plugins that walk props.objects() (shapes, sensors, the scene, twosided) take them under any name; the others (BSDFs, emitters,
+        # textures) only mark the names they query (Properties::try_get marks a child queried only when the cast succeeds, properties.h:700-725)
+        if free_children and (isinstance(v, (dict, Film, Sampler, BSDF, Mesh)) or hasattr(v, 'har')):
             continue
         raise RuntimeError("Unreferenced property \"%s\" in plugin of type \"%s\"!" % (k, plugin))
 
@@ -655,6 +700,16 @@ def _rgb_value(v, default, bounded=True):
     return out
 
 
+# the properties each BSDF plugin queries (src/bsdfs/*.cpp constructors; MicrofacetDistribution(props), microfacet.h:103-144)
+_BSDF_PROPS = {'diffuse': ('reflectance',),
+               'dielectric': ('int_ior', 'ext_ior', 'specular_reflectance', 'specular_transmittance'),
+               'conductor': ('material', 'eta', 'k', 'specular_reflectance'),
+               'plastic': ('int_ior', 'ext_ior', 'diffuse_reflectance', 'specular_reflectance', 'nonlinear'),
+               'roughconductor': ('material', 'eta', 'k', 'distribution', 'sample_visible', 'alpha', 'alpha_u', 'alpha_v', 'specular_reflectance'),
+               'roughplastic': ('distribution', 'sample_visible', 'alpha', 'alpha_u', 'alpha_v', 'int_ior', 'ext_ior', 'diffuse_reflectance', 'specular_reflectance', 'nonlinear')}
+# BitmapTexture(props) (src/textures/bitmap.cpp:175-260); `raw` only silences a range warning for float data in RGB variants, `accel` picks Dr.Jit's texture
+# hardware path on CUDA (no effect on values), `format` = the storage type of the texels ("auto" / "variant" / "fp16": this path keeps float32)
+_BITMAP_PROPS = ('filename', 'bitmap', 'data', 'to_uv', 'raw', 'accel', 'filter_type', 'wrap_mode', 'format')
 BSDF_TYPES = {'diffuse': 0, 'dielectric': 1, 'roughconductor': 2, 'roughplastic': 3, 'conductor': 4, 'plastic': 5}
 # (parameter name of slot 0, default), (parameter name of slot 1, default)
 _BSDF_SLOTS = {'diffuse': (('reflectance', 0.5), None), 'dielectric': (('specular_reflectance', 1.0), ('specular_transmittance', 1.0)),
@@ -672,12 +727,13 @@ class BSDF:
         self.kind = props.get('type', 'diffuse')
         if self.kind not in BSDF_TYPES:
             raise RuntimeError("Plugin \"%s\" not found for variant hip_ad_rgb" % self.kind)
+        _check_props(self.kind, props, _BSDF_PROPS[self.kind], free_children=False)
         (name0, def0), slot1 = _BSDF_SLOTS[self.kind]
         self.slot0_name = name0; self.slot1_name = slot1[0] if slot1 else None
         refl = props.get(name0, {'type': 'rgb', 'value': [def0] * 3})
         if isinstance(refl, (int, float)):
             refl = {'type': 'rgb', 'value': [refl] * 3}
-        self.texture = None; self.tex_mode = 0
+        self.texture = None; self.tex_mode = 0; self.tex_to_uv = None
         if refl['type'] == 'rgb':
             self.value = _rgb_value(refl, def0)
         elif refl['type'] == 'bitmap':
@@ -692,8 +748,18 @@ class BSDF:
             if wm not in ('repeat', 'mirror', 'clamp'):
                 raise RuntimeError("Invalid wrap mode \"%s\", must be one of: \"repeat\", \"mirror\", or \"clamp\"!" % wm)
             self.tex_mode = (1 if ft == 'nearest' else 0) | {'repeat': 0, 'mirror': 2, 'clamp': 4}[wm]
+            _check_props('bitmap', refl, _BITMAP_PROPS, unsupported=(('format', 'auto'),), free_children=False)
+            # to_uv (bitmap.cpp:175): uv = m_transform * si.uv before every lookup (:565,792,831,847) -> HarTexture::to_uv, row-major 2 x 3
+            self.tex_to_uv = None
             if 'to_uv' in refl:
-                raise RuntimeError("bitmap: 'to_uv' is not implemented by hip_ad_rgb")
+                tuv = refl['to_uv']
+                if isinstance(tuv, ScalarTransform4f):        # Properties::get<AffineTransform3f> of a stored 4 x 4 (an XML <transform>): Transform::extract (transform.h:441-456)
+                    m4 = tuv.matrix; tuv = ScalarTransform3f([[m4[0, 0], m4[0, 1], m4[0, 3]], [m4[1, 0], m4[1, 1], m4[1, 3]], [0.0, 0.0, 1.0]])
+                if not isinstance(tuv, ScalarTransform3f):
+                    raise RuntimeError("bitmap: 'to_uv' must be a ScalarTransform3f")
+                if abs(float(np.linalg.det(tuv.matrix[:2, :2].astype(np.float64)))) == 0.0:
+                    raise RuntimeError("bitmap: 'to_uv' is singular")
+                self.tex_to_uv = tuv.rows_2x3()
             if 'data' in refl:
                 t = refl['data']
                 if hasattr(t, 'detach'):
@@ -813,9 +879,10 @@ class BSDF:
 
 def _mk_twosided(props, named, key):
     """TwoSidedBRDF (src/bsdfs/twosided.cpp:70-110): one or two nested BSDFs without a transmission component."""
+    _check_props('twosided', props, ('allow_transmission',), unsupported=(('allow_transmission', False),))      # twosided.cpp:76-104: nested BSDFs under any name
     nested = []
     for k, v in props.items():
-        if k == 'type':
+        if k in ('type', 'id', 'allow_transmission'):
             continue
         obj = _resolve(v, named, k) if isinstance(v, dict) else v
         if isinstance(obj, BSDF):
@@ -835,12 +902,42 @@ def _mk_twosided(props, named, key):
     return front
 
 
+def _sampling_weight(props):
+    """Emitter(props) (src/render/emitter.cpp:9): `sampling_weight`, default 1 -- Scene::update_emitter_sampling_distribution (scene.cpp:120-141) switches from the
+    uniform emitter choice to a DiscreteDistribution over the weights as soon as one of them is not 1"""
+    w = float(np.float32(props.get('sampling_weight', 1.0)))
+    if not (w >= 0.0) or not math.isfinite(w):
+        raise RuntimeError("DiscreteDistribution: entries must be non-negative!")
+    return w
+
+
+def _emissive_rgb(plugin, name, v):
+    """Properties::get_emissive_texture in RGB variants: a float, an `rgb` colour (unbounded) -- spatially varying textures are refused where the path needs the
+    texture-importance-sampling branch (area.cpp:133-165) or is not written for them"""
+    if isinstance(v, dict) and v.get('type') not in (None, 'rgb'):
+        raise RuntimeError("%s: a spatially varying \"%s\" (texture plugin \"%s\") is not implemented by hip_ad_rgb -- the reference then importance-samples the "
+                           "texture and maps the sample through Shape::eval_parameterization (src/emitters/area.cpp:133-165); use an `rgb` value" % (plugin, name, v.get('type')))
+    return _rgb_value(v, 1.0, bounded=False)
+
+
+class AreaLight:
+    """AreaLight (src/emitters/area.cpp) with a uniform `radiance`; it inherits the placement of its parent shape (a `to_world` is an error, :66-69)."""
+
+    def __init__(self, props):
+        if 'to_world' in props:
+            raise RuntimeError("Found a 'to_world' transformation -- this is not allowed. The area light inherits this transformation from its parent shape.")
+        _check_props('area', props, ('radiance', 'sampling_weight'), free_children=False)
+        self.radiance = _emissive_rgb('area', 'radiance', props.get('radiance', {'type': 'rgb', 'value': 1.0}))       # get_emissive_texture("radiance", 1.f), :71
+        self.sampling_weight = _sampling_weight(props)
+
+
 class ConstantEmitter:
     """ConstantBackgroundEmitter (src/emitters/constant.cpp): uniform environment radiance."""
 
     def __init__(self, props):
-        rad = props.get('radiance', {'type': 'rgb', 'value': 1.0})
-        self.radiance = _rgb_value(rad, 1.0, bounded=False)
+        _check_props('constant', props, ('radiance', 'sampling_weight', 'to_world'), free_children=False)      # Endpoint(props) queries to_world (endpoint.cpp:12); a uniform environment does not depend on it
+        self.radiance = _emissive_rgb('constant', 'radiance', props.get('radiance', {'type': 'rgb', 'value': 1.0}))
+        self.sampling_weight = _sampling_weight(props)
 
 
 class PointLight:
@@ -848,7 +945,8 @@ class PointLight:
     EmitterFlags::DeltaPosition -- only emitter sampling finds it, with MIS weight 1 (path.cpp:274, prb.py:211)."""
 
     def __init__(self, props):
-        _check_props("point", props, ('position', 'to_world', 'intensity'), unsupported=(('sampling_weight', 1.0),))
+        _check_props("point", props, ('position', 'to_world', 'intensity', 'sampling_weight'), free_children=False)
+        self.sampling_weight = _sampling_weight(props)
         if 'position' in props:
             if 'to_world' in props:                                  # point.cpp:65-68
                 raise RuntimeError("Only one of the parameters 'position' and 'to_world' can be specified at the same time!'")
@@ -863,7 +961,8 @@ class SpotLight:
     `beam_width` degrees, falling off linearly in the angle to zero at `cutoff_angle` (falloff_curve, :143-151); EmitterFlags::DeltaPosition."""
 
     def __init__(self, props):
-        _check_props("spot", props, ('to_world', 'intensity', 'cutoff_angle', 'beam_width'), unsupported=(('sampling_weight', 1.0),))
+        _check_props("spot", props, ('to_world', 'intensity', 'cutoff_angle', 'beam_width', 'texture', 'sampling_weight'), free_children=False)
+        self.sampling_weight = _sampling_weight(props)
         if 'texture' in props:
             raise RuntimeError("spot: property \"texture\" is not implemented by hip_ad_rgb")
         self.to_world = props.get('to_world', ScalarTransform4f())
@@ -880,7 +979,8 @@ class DirectionalEmitter:
     MIS weight 1, invisible to escaping rays."""
 
     def __init__(self, props):
-        _check_props("directional", props, ('to_world', 'direction', 'irradiance'), unsupported=(('sampling_weight', 1.0),))
+        _check_props("directional", props, ('to_world', 'direction', 'irradiance', 'sampling_weight'), free_children=False)
+        self.sampling_weight = _sampling_weight(props)
         if 'direction' in props:
             if 'to_world' in props:                                   # directional.cpp:70-72
                 raise RuntimeError("Only one of the parameters 'direction' and 'to_world' can be specified at the same time!'")
@@ -898,6 +998,8 @@ class EnvmapEmitter:
     """EnvironmentMapEmitter (src/emitters/envmap.cpp): lat-long radiance image, importance sampled by luminance * sin(theta)."""
 
     def __init__(self, props):
+        _check_props('envmap', props, ('filename', 'bitmap', 'scale', 'mis_compensation', 'to_world', 'sampling_weight'), free_children=False)      # envmap.cpp:118-200
+        self.sampling_weight = _sampling_weight(props)
         if 'bitmap' in props:
             if 'filename' in props:
                 raise RuntimeError("Cannot specify both \"bitmap\" and \"filename\".")
@@ -1271,14 +1373,28 @@ def develop_film(film, alpha_film=None, colour=0):
 #  Scene
 # ---------------------------------------------------------------------------
 
+def _static_table(fn):
+    """the key tables of a scene (which parameters exist, under which names) are fixed at construction: built once (an optimisation loop asks every step)"""
+    name = "_memo" + fn.__name__
+
+    def get(self):
+        t = self.__dict__.get(name)
+        if t is None:
+            t = self.__dict__[name] = fn(self)
+        return t
+    get.__name__ = fn.__name__; get.__doc__ = fn.__doc__
+    return get
+
+
 class Scene:
     """Scene (src/render/scene.cpp): owns the flat SceneIR arrays and the device accel."""
 
     def __init__(self, children):
         self.bsdf_objs = []; self.meshes = []; self.top_mesh_count = 0
         self.groups = []; self.instances = []; self.instance_keys = []; self.emitters = []
-        self.m_sensors = []; self.sensor_keys = []; self.m_integrator = None; self.textures = []; self.texture_modes = []
+        self.m_sensors = []; self.sensor_keys = []; self.m_integrator = None; self.textures = []; self.texture_modes = []; self.texture_to_uv = []
         self._h = None; self._keep = []
+        self._device_values = {}      # (kind, index) -> (device tensor, record): values params.update() pushed device-to-device; the numpy mirrors are refreshed by sync_host()
         named = {}
         shapes = []; groups = []; insts = []
         # Scene::emitters() order = declaration order of the children (scene.cpp:40-70): shapes with an area emitter and
@@ -1291,23 +1407,23 @@ class Scene:
         for key, obj in children.items():
             if isinstance(obj, ConstantEmitter):
                 self.emitters[self._emitter_order.index(key)] = dict(type=1, mesh=0xffffffff, radiance=obj.radiance, to_world=[0.0] * 12,
-                                                                     normal=[0.0] * 3, inv_area=0.0)
+                                                                     normal=[0.0] * 3, inv_area=0.0, sampling_weight=obj.sampling_weight)
             elif isinstance(obj, PointLight):                   # HarEmitter type 4: `radiance` = intensity, to_world[9..11] = position
                 self.emitters[self._emitter_order.index(key)] = dict(type=4, mesh=0xffffffff, radiance=obj.intensity,
                                                                      to_world=[1.0, 0.0, 0.0, 0.0, 1.0, 0.0, 0.0, 0.0, 1.0] + [float(x) for x in obj.position],
-                                                                     normal=[0.0] * 3, inv_area=0.0)
+                                                                     normal=[0.0] * 3, inv_area=0.0, sampling_weight=obj.sampling_weight)
             elif isinstance(obj, SpotLight):                    # HarEmitter type 5: transform + inverse, normal = (cutoff_angle, beam_width, -) in degrees
                 self.emitters[self._emitter_order.index(key)] = dict(type=5, mesh=0xffffffff, radiance=obj.intensity, to_world=obj.to_world.col_major_3x4(),
                                                                      to_local=obj.to_world.inverse().col_major_3x4(),
-                                                                     normal=[obj.cutoff_angle, obj.beam_width, 0.0], inv_area=0.0)
+                                                                     normal=[obj.cutoff_angle, obj.beam_width, 0.0], inv_area=0.0, sampling_weight=obj.sampling_weight)
             elif isinstance(obj, DirectionalEmitter):           # HarEmitter type 6: `radiance` = irradiance, the transform (light travels along its +z)
                 self.emitters[self._emitter_order.index(key)] = dict(type=6, mesh=0xffffffff, radiance=obj.irradiance, to_world=obj.to_world.col_major_3x4(),
-                                                                     to_local=obj.to_world.inverse().col_major_3x4(), normal=[0.0] * 3, inv_area=0.0)
+                                                                     to_local=obj.to_world.inverse().col_major_3x4(), normal=[0.0] * 3, inv_area=0.0, sampling_weight=obj.sampling_weight)
             elif isinstance(obj, EnvmapEmitter):                # the radiance image travels in the texture table
                 self.emitters[self._emitter_order.index(key)] = dict(
                     type=2, mesh=len(self.textures), radiance=[obj.scale, 1.0 if obj.mis_compensation else 0.0, 0.0],
-                    to_world=obj.to_world.col_major_3x4(), to_local=obj.to_world.inverse().col_major_3x4(), normal=[0.0] * 3, inv_area=0.0)
-                self.textures.append(obj.data); self.texture_modes.append(0)
+                    to_world=obj.to_world.col_major_3x4(), to_local=obj.to_world.inverse().col_major_3x4(), normal=[0.0] * 3, inv_area=0.0, sampling_weight=obj.sampling_weight)
+                self.textures.append(obj.data); self.texture_modes.append(0); self.texture_to_uv.append(None)
         for key, obj in children.items():
             if isinstance(obj, BSDF):
                 named[key] = obj
@@ -1349,7 +1465,7 @@ class Scene:
             return b.index
         b.scene = self; b.index = len(self.bsdf_objs)
         if b.texture is not None:
-            b.tex_index = len(self.textures); self.textures.append(b.texture); self.texture_modes.append(b.tex_mode)
+            b.tex_index = len(self.textures); self.textures.append(b.texture); self.texture_modes.append(b.tex_mode); self.texture_to_uv.append(b.tex_to_uv)
         self.bsdf_objs.append(b)
         if getattr(b, 'back', None) is not None:
             self._add_bsdf(b.back)
@@ -1360,8 +1476,8 @@ class Scene:
         return self.bsdf_objs
 
     def _add_mesh(self, key, m):
-        if m.bsdf is None:
-            m.bsdf = BSDF()
+        if m.bsdf is None:          # Shape(props), shape.cpp:50-57: a default diffuse BSDF -- black when the shape carries an emitter
+            m.bsdf = BSDF({'type': 'diffuse', 'reflectance': {'type': 'rgb', 'value': [0.0, 0.0, 0.0]}} if m.emitter is not None else None)
         if m.bsdf.scene is None:
             m.bsdf.id = key + ".bsdf"             # a BSDF nested in a shape (not a scene-level object): '<shape>.bsdf.reflectance.value' as in mi.traverse() (Shape::traverse registers it as "bsdf")
         bi = self._add_bsdf(m.bsdf)
@@ -1370,13 +1486,27 @@ class Scene:
             em = self._emitter_order.index(key)
             if hasattr(m, 'rect'):        # Rectangle::sample_position (analytic parameterisation)
                 self.emitters[em] = (dict(type=0, mesh=len(self.meshes), radiance=m.emitter, to_world=m.rect['to_world'].col_major_3x4(),
-                                          normal=m.rect['normal'], inv_area=m.rect['inv_area']))
+                                          normal=m.rect['normal'], inv_area=m.rect['inv_area'], sampling_weight=getattr(m, 'emitter_weight', 1.0)))
             else:                         # any other triangle mesh: Mesh::sample_position (area-weighted face selection)
-                self.emitters[em] = dict(type=3, mesh=len(self.meshes), radiance=m.emitter, to_world=[0.0] * 12, normal=[0.0] * 3, inv_area=0.0)
+                self.emitters[em] = dict(type=3, mesh=len(self.meshes), radiance=m.emitter, to_world=[0.0] * 12, normal=[0.0] * 3, inv_area=0.0,
+                                         sampling_weight=getattr(m, 'emitter_weight', 1.0))
         self.meshes.append(dict(key=key, V=np.ascontiguousarray(m.V), F=np.ascontiguousarray(m.F), bsdf=bi, emitter=em, flags=m.flags))
+
+    def sync_host(self):
+        """refresh the host mirrors (Scene.textures, BSDF.value / .texture, emitters[i]['radiance']) from the values params.update() pushed device-to-device"""
+        for (kind, idx), (t, b) in list(self._device_values.items()):
+            v = t.detach().to("cpu").numpy().astype(np.float32)
+            if kind == "emit":
+                self.emitters[idx]["radiance"] = np.ascontiguousarray(v.reshape(3))
+            elif kind == "tex":
+                b.texture = np.ascontiguousarray(v.reshape(b.texture.shape)); self.textures[idx] = b.texture
+            else:
+                b.value = np.ascontiguousarray(v.reshape(3))
+        self._device_values.clear()
 
     # -- C ABI description
     def desc(self):
+        self.sync_host()
         M = _capi
         meshes = (M.HarMesh * max(1, len(self.meshes)))()
         for i, m in enumerate(self.meshes):
@@ -1401,6 +1531,8 @@ class Scene:
         texs = (M.HarTexture * max(1, len(self.textures)))()
         for i, t in enumerate(self.textures):
             texs[i].data = _fp(t); texs[i].height = t.shape[0]; texs[i].width = t.shape[1]; texs[i].mode = self.texture_modes[i] if i < len(self.texture_modes) else 0
+            if i < len(self.texture_to_uv) and self.texture_to_uv[i] is not None:
+                texs[i].to_uv = (C.c_float * 6)(*self.texture_to_uv[i])
         ems = (M.HarEmitter * max(1, len(self.emitters)))()
         for i, e in enumerate(self.emitters):
             ems[i].type = e.get("type", 0); ems[i].mesh = e["mesh"]
@@ -1408,6 +1540,7 @@ class Scene:
             ems[i].to_world = (C.c_float * 12)(*[float(x) for x in e["to_world"]])
             ems[i].normal = (C.c_float * 3)(*[float(x) for x in e["normal"]]); ems[i].inv_area = float(e["inv_area"])
             ems[i].to_local = (C.c_float * 12)(*[float(x) for x in e.get("to_local", [1, 0, 0, 0, 1, 0, 0, 0, 1, 0, 0, 0])])
+            ems[i].sampling_weight = float(e.get("sampling_weight", 1.0))
         d = M.HarSceneDesc()
         d.meshes = meshes; d.mesh_count = len(self.meshes); d.top_mesh_count = self.top_mesh_count
         d.groups = groups; d.group_count = len(self.groups)
@@ -1494,6 +1627,7 @@ class Scene:
         return SurfaceInteraction3f(out)
 
     # -- parameters (mi.traverse)
+    @_static_table
     def _param_keys(self):
         keys = {}
         for b in self.bsdf_objs:
@@ -1515,6 +1649,7 @@ class Scene:
                 keys[key + ".irradiance.value"] = ("emit", i)
         return keys
 
+    @_static_table
     def _bsdf_param_keys(self):
         """the non-slot-0 parameters of the rough models: '<bsdf>.alpha.value' (or alpha_u / alpha_v), '<bsdf>.eta.value', '<bsdf>.k.value' of
         roughconductor (roughconductor.cpp:226-250 traverse), '<bsdf>.alpha.value' and '<bsdf>.specular_reflectance.value' of roughplastic"""
@@ -1554,6 +1689,7 @@ class Scene:
         if self._h is not None:
             lib().har_scene_destroy(self._h); self._h = None
 
+    @_static_table
     def _position_keys(self):
         """'<shape>.vertex_positions' (flat 3 N floats as in the reference's Mesh::traverse) of the top-level meshes and, as '<group>.<child>.vertex_positions', of the
         meshes inside shape groups (object space, shared by all instances); writing them regenerates the vertex normals of a smooth-shaded mesh (mesh.cpp:876-878),
@@ -1587,6 +1723,7 @@ class Scene:
             out[k] = i
         return out
 
+    @_static_table
     def _instance_keys(self):
         """'<instance>.to_world' (4 x 4, Instance::traverse, instance.cpp:79-85)"""
         return {k + ".to_world": i for i, k in enumerate(self.instance_keys)}
@@ -1615,6 +1752,7 @@ class Scene:
         if self._h is not None:
             lib().har_scene_destroy(self._h); self._h = None
 
+    @_static_table
     def _pose_keys(self):
         """the NON-differentiable placement parameters the reference's traverse() exposes (ParamFlags::NonDifferentiable): '<sensor>.to_world' (perspective.cpp:177,
         orthographic.cpp:95), '<emitter>.position' of a point light (point.cpp:86), '<emitter>.to_world' of spot and directional lights (spot.cpp:117,
@@ -1674,6 +1812,7 @@ class SceneParameters(dict):
         super().__init__()
         torch = _torch()
         self.scene = scene
+        scene.sync_host()
         dev = torch.device("cuda", torch.cuda.current_device()) if torch.cuda.is_available() else torch.device("cpu")
         for k, (kind, b) in scene._param_keys().items():
             value = scene.emitters[b]["radiance"] if kind == "emit" else (b.texture if kind == "tex" else b.value)
@@ -1693,42 +1832,122 @@ class SceneParameters(dict):
         if hasattr(self, "_written"):
             self._written.add(key)
 
+    def _host_kinds(self):
+        """(key, setter) of the parameters whose update runs on the host (geometry: accel update; poses; the non-colour BSDF parameters, whose records are
+        re-lowered): the key tables are those of the scene at traverse() time -- the set of parameters of a scene does not change"""
+        if getattr(self, "_host_table", None) is None:
+            sc = self.scene; t = []
+            for k, m in sc._position_keys().items():
+                t.append((k, "pos", m))
+            for k, i in sc._instance_keys().items():
+                t.append((k, "inst", i))
+            for k, (kind, b) in sc._pose_keys().items():
+                t.append((k, "pose", (kind, b)))
+            for k, (what, b) in sc._bsdf_param_keys().items():
+                t.append((k, "bsdf", (what, b)))
+            self._host_table = t
+            self._colour_table = list(sc._param_keys().items())
+        return self._host_table
+
+    def _changed_keys(self, written):
+        """which host-updated keys hold other values than at the last update(): WRITTEN keys (SceneParameters.__setitem__ flags them, util.py) and tensors modified
+        in place (an optimiser step) -- found by comparing with the snapshot of the last update() ON THE TENSOR'S DEVICE, one flag per key, ONE read-back for all
+        of them (round 4 copied every parameter to the host, every step)"""
+        torch = _torch()
+        table = self._host_kinds()
+        snap = self.__dict__.setdefault("_snapshot", {})
+        changed = set(k for k, _, _ in table if k in written or k not in snap)
+        flags = []; names = []
+        for k, _, _ in table:
+            if k in changed:
+                continue
+            t = self[k]
+            if not hasattr(t, "detach"):
+                changed.add(k); continue
+            t = t.detach(); old = snap[k]
+            if old.shape != t.shape or old.device != t.device or old.dtype != t.dtype:
+                changed.add(k); continue
+            flags.append((t != old).any()); names.append(k)
+        if flags:
+            by_dev = {}
+            for f, k in zip(flags, names):
+                by_dev.setdefault(f.device, []).append((f, k))
+            for dev, items in by_dev.items():
+                got = torch.stack([f for f, _ in items]).tolist()          # one synchronisation per device
+                changed.update(k for (_, k), g in zip(items, got) if g)
+        for k in changed:
+            t = self[k]
+            snap[k] = t.detach().clone() if hasattr(t, "detach") else torch.as_tensor(np.asarray(t, np.float32))
+        return changed
+
     def update(self, values=None):
+        """SceneParameters.update (src/python/python/util.py): push the values to the scene.  Colours, bitmaps and emitter radiances that live on the GPU go to the
+        scene's device arrays directly (har_scene_set_*_device: a device-to-device copy on the current stream, no host round trip, no synchronisation); geometry,
+        poses and the non-colour BSDF parameters are compared on their device and only the ones that changed travel to the host (accel update / re-lowering)."""
         if values:
             for k, v in values.items():
                 self[k] = v
+        torch = _torch()
         written, self._written = self._written, set()
-        for k, m in self.scene._position_keys().items():
-            v = self[k].detach().to("cpu", copy=True).numpy().astype(np.float32).reshape(-1, 3)
-            # a WRITTEN key notifies the mesh even when the values are the old ones: the vertex normals are regenerated (mesh.cpp:876-878)
-            if k in written or not np.array_equal(v, self.scene.meshes[m]["V"][:, :3]):
-                self.scene._set_vertex_positions(m, v)
-        for k, i in self.scene._instance_keys().items():
-            v = self[k].detach().to("cpu", copy=True).numpy().astype(np.float32).reshape(4, 4)
-            if not np.array_equal(v, self.scene._instance_matrix(i)):
-                self.scene._set_instance_matrix(i, v)
-        for k, (kind, b) in self.scene._pose_keys().items():
-            v = self[k].detach().to("cpu", copy=True).numpy().astype(np.float32)
-            if not np.array_equal(v.reshape(-1), self.scene._pose_value(kind, b).reshape(-1)):
-                self.scene._set_pose(kind, b, v)
-        for k, (what, b) in self.scene._bsdf_param_keys().items():
-            v = self[k].detach().to("cpu", copy=True).numpy().astype(np.float32).reshape(-1)
-            if not np.array_equal(v, np.asarray(self.scene._bsdf_param_value(what, b), np.float32).reshape(-1)):
-                self.scene._set_bsdf_param(what, b, v)
-        for k, (kind, b) in self.scene._param_keys().items():
-            v = self[k].detach().to("cpu", copy=True).numpy().astype(np.float32)
-            if kind == "emit":
-                self.scene.emitters[b]["radiance"] = np.ascontiguousarray(v.reshape(3))
-                if self.scene._h is not None:
-                    check(lib().har_scene_set_emitter_radiance(self.scene._h, b, _fp(self.scene.emitters[b]["radiance"])))
-            elif kind == "tex":
-                b.texture = np.ascontiguousarray(v.reshape(b.texture.shape)); self.scene.textures[b.tex_index] = b.texture
-                if self.scene._h is not None:
-                    check(lib().har_scene_set_texture(self.scene._h, b.tex_index, _fp(b.texture)))
+        sc = self.scene
+        changed = self._changed_keys(written)
+        for k, what, ref in self._host_kinds():
+            if k not in changed:
+                continue
+            v = self[k]
+            v = v.detach().to("cpu").numpy().astype(np.float32) if hasattr(v, "detach") else np.asarray(v, np.float32)
+            if what == "pos":
+                v = v.reshape(-1, 3)
+                # a WRITTEN key notifies the mesh even when the values are the old ones: the vertex normals are regenerated (mesh.cpp:876-878)
+                if k in written or not np.array_equal(v, sc.meshes[ref]["V"][:, :3]):
+                    sc._set_vertex_positions(ref, v)
+            elif what == "inst":
+                if not np.array_equal(v.reshape(4, 4), sc._instance_matrix(ref)):
+                    sc._set_instance_matrix(ref, v.reshape(4, 4))
+            elif what == "pose":
+                if not np.array_equal(v.reshape(-1), sc._pose_value(*ref).reshape(-1)):
+                    sc._set_pose(ref[0], ref[1], v)
             else:
+                if not np.array_equal(v.reshape(-1), np.asarray(sc._bsdf_param_value(*ref), np.float32).reshape(-1)):
+                    sc._set_bsdf_param(ref[0], ref[1], v.reshape(-1))
+        stream = None
+        for k, (kind, b) in self._colour_table:
+            t = self[k]
+            on_gpu = hasattr(t, "is_cuda") and t.is_cuda and sc._h is not None
+            if on_gpu:
+                # the scene's copy is the value AT update(): snapshot on the device (a later in-place edit of the tensor is not an update), host mirror refreshed lazily
+                v = t.detach().to(torch.float32).contiguous()
+                stream = stream or _stream()
+                if kind == "emit":
+                    if v.numel() != 3:
+                        raise RuntimeError("%s: expected 3 values" % k)
+                    check(lib().har_scene_set_emitter_radiance_device(sc._h, b, _ptr(v), stream))
+                elif kind == "tex":
+                    if v.numel() != b.texture.size:
+                        raise RuntimeError("%s: expected a tensor of shape %s" % (k, b.texture.shape))
+                    check(lib().har_scene_set_texture_device(sc._h, b.tex_index, _ptr(v), stream))
+                else:
+                    if v.numel() != 3:
+                        raise RuntimeError("%s: expected 3 values" % k)
+                    check(lib().har_scene_set_reflectance_device(sc._h, b.index, _ptr(v), stream))
+                sc._device_values[(kind, b if kind == "emit" else (b.tex_index if kind == "tex" else b.index))] = (v if v.data_ptr() != t.data_ptr() else v.clone(), b)
+                continue
+            v = t.detach().to("cpu").numpy().astype(np.float32) if hasattr(t, "detach") else np.asarray(t, np.float32)
+            if kind == "emit":
+                sc._device_values.pop(("emit", b), None)
+                sc.emitters[b]["radiance"] = np.ascontiguousarray(v.reshape(3))
+                if sc._h is not None:
+                    check(lib().har_scene_set_emitter_radiance(sc._h, b, _fp(sc.emitters[b]["radiance"])))
+            elif kind == "tex":
+                sc._device_values.pop(("tex", b.tex_index), None)
+                b.texture = np.ascontiguousarray(v.reshape(b.texture.shape)); sc.textures[b.tex_index] = b.texture
+                if sc._h is not None:
+                    check(lib().har_scene_set_texture(sc._h, b.tex_index, _fp(b.texture)))
+            else:
+                sc._device_values.pop(("rgb", b.index), None)
                 b.value = np.ascontiguousarray(v.reshape(3))
-                if self.scene._h is not None:
-                    check(lib().har_scene_set_reflectance(self.scene._h, b.index, _fp(b.value)))
+                if sc._h is not None:
+                    check(lib().har_scene_set_reflectance(sc._h, b.index, _fp(b.value)))
 
 
 def traverse(scene):
@@ -1775,9 +1994,10 @@ def _shape_common(m, props, named):
         elif isinstance(v, BSDF):
             m.bsdf = v
         elif isinstance(v, dict) and v.get('type') == 'area':
-            rad = v.get('radiance', {'type': 'rgb', 'value': 1.0})
-            val = rad['value'] if isinstance(rad, dict) else rad
-            m.emitter = _f32([val] * 3 if np.isscalar(val) else val)
+            if m.emitter is not None:
+                raise RuntimeError("Only a single Emitter child object can be specified per shape.")       # shape.cpp:25-27
+            a = AreaLight(v)
+            m.emitter = a.radiance; m.emitter_weight = a.sampling_weight
         elif isinstance(v, dict) and 'type' in v and k not in ('to_world',):
             if (v['type'], VARIANT) not in _REGISTRY:
                 raise RuntimeError("Plugin \"%s\" not found for variant \"%s\"" % (v['type'], VARIANT))
@@ -1785,6 +2005,7 @@ def _shape_common(m, props, named):
 
 
 def _mk_scene(props, named, key):
+    _check_props('scene', props, ())                 # Scene(props) (scene.cpp:26-70) walks props.objects(): children under any name, no other property
     children = {}
     for k, v in props.items():
         if k == 'type':
@@ -1803,6 +2024,7 @@ def _mk_scene(props, named, key):
 
 
 def _mk_shapegroup(props, named, key):
+    _check_props('shapegroup', props, ())            # ShapeGroup(props) (src/shapes/shapegroup.cpp): the child shapes, nothing else
     shapes = []; keys = []
     for k, v in props.items():
         if isinstance(v, dict) and 'type' in v:
@@ -1818,6 +2040,7 @@ def _mk_shapegroup(props, named, key):
 
 
 def _mk_instance(props, named, key):
+    _check_props('instance', props, ('to_world',))   # Instance(props) (src/shapes/instance.cpp:60-77)
     group = None
     for k, v in props.items():
         obj = _resolve(v, named, k) if isinstance(v, dict) else v
@@ -1831,6 +2054,7 @@ def _mk_instance(props, named, key):
 
 
 def _mk_ply(props, named, key):
+    _check_props('ply', props, _SHAPE_PROPS + ('filename', 'flip_tex_coords'))      # ply.cpp:113-118 over Mesh(props)
     if 'filename' not in props:
         raise RuntimeError("ply: the `filename` parameter is required")
     m = Mesh(key or "ply").from_ply(props['filename'], props.get('face_normals', False), props.get('flip_tex_coords', False),
@@ -1839,6 +2063,7 @@ def _mk_ply(props, named, key):
 
 
 def _mk_obj(props, named, key):
+    _check_props('obj', props, _SHAPE_PROPS + ('filename', 'flip_tex_coords'))      # obj.cpp:98-113
     if 'filename' not in props:
         raise RuntimeError("obj: the `filename` parameter is required")
     m = Mesh(key or "obj").from_obj(props['filename'], props.get('face_normals', False), props.get('flip_tex_coords', True),
@@ -1847,6 +2072,7 @@ def _mk_obj(props, named, key):
 
 
 def _mk_serialized(props, named, key):
+    _check_props('serialized', props, _SHAPE_PROPS + ('filename', 'shape_index'))   # serialized.cpp:225-244
     if 'filename' not in props:
         raise RuntimeError("serialized: the `filename` parameter is required")
     m = Mesh(key or "serialized").from_serialized(props['filename'], props.get('shape_index', 0), props.get('face_normals', None),
@@ -1855,6 +2081,8 @@ def _mk_serialized(props, named, key):
 
 
 def _mk_mesh(props, named, key):
+    # not a reference plugin: the dict form of mi.Mesh(...) + params (faces / positions / normals / texcoords arrays)
+    _check_props('mesh', props, ('faces', 'positions', 'normals', 'texcoords', 'to_world', 'silhouette_sampling_weight'))
     m = Mesh(key or "mesh").from_fields(props['faces'], props['positions'], props.get('normals'), props.get('texcoords'))
     if 'to_world' in props:
         m.transform(props['to_world'])
@@ -1949,7 +2177,9 @@ def render(scene, params=None, sensor=0, integrator=None, seed=0, seed_grad=0, s
     class _RenderOp(torch.autograd.Function):
         @staticmethod
         def forward(ctx, *tensors):
-            return integrator.render(scene, sensor, seed, spp)
+            # no synchronisation: the frame is enqueued on the current stream like any torch op (a scene whose BVH is too deep for the traversal stacks is refused
+            # at creation, so there is no device-side error left to wait for); Integrator.render() called directly still evaluates
+            return integrator.render(scene, sensor, seed, spp, evaluate=False)
 
         @staticmethod
         def backward(ctx, grad_out):

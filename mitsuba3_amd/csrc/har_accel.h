@@ -45,6 +45,44 @@ struct alignas(16) InstRec {
     uint32_t pad;
 };
 
+/* ---- node emission, shared by the host builder (har_accel_build.cpp) and the refit of har_refit.h (device + host): the frame of a node (origin + one power-of-two
+ * scale per axis, after Ylitie et al. 2017) and the quantisation of a child box against it.  One implementation, so that a refit of geometry that did not move
+ * reproduces the built nodes bit for bit (double arithmetic, exact on both sides). */
+HAR_HD uint8_t node_exp_byte(double extent) {
+    /* smallest e with extent / 2^e <= 255 */
+    int e = -126;
+    if (extent > 0.0) {
+        e = (int) ceil(log2(extent / 255.0));
+        while (extent / ldexp(1.0, e) > 255.0) ++e;
+        while (e > -126 && extent / ldexp(1.0, e - 1) <= 255.0) --e;
+    }
+    e = e < -126 ? -126 : (e > 127 ? 127 : e);
+    return (uint8_t) (e + 127);
+}
+HAR_HD void node_set_frame(Node8 &n, const float lo[3], const float hi[3]) {
+    n.px = lo[0]; n.py = lo[1]; n.pz = lo[2];
+    n.ex = node_exp_byte((double) hi[0] - (double) n.px);
+    n.ey = node_exp_byte((double) hi[1] - (double) n.py);
+    n.ez = node_exp_byte((double) hi[2] - (double) n.pz);
+}
+HAR_HD void node_quantise_child(Node8 &n, int s, const float clo[3], const float chi[3]) {
+    const double sc[3] = { ldexp(1.0, (int) n.ex - 127), ldexp(1.0, (int) n.ey - 127), ldexp(1.0, (int) n.ez - 127) };
+    const double org[3] = { n.px, n.py, n.pz };
+    uint8_t *q[6] = { n.qlox, n.qloy, n.qloz, n.qhix, n.qhiy, n.qhiz };
+    for (int a = 0; a < 3; ++a) {
+        double lo = floor(((double) clo[a] - org[a]) / sc[a]), hi = ceil(((double) chi[a] - org[a]) / sc[a]);
+        lo = lo < 0.0 ? 0.0 : (lo > 255.0 ? 255.0 : lo); hi = hi < 0.0 ? 0.0 : (hi > 255.0 ? 255.0 : hi);
+        q[a][s] = (uint8_t) lo; q[3 + a][s] = (uint8_t) hi;
+    }
+}
+/* conservative padding of a primitive box before it enters a node (builder and refit) */
+HAR_HD void pad_box(float lo[3], float hi[3]) {
+    float m = 1.f;
+    for (int a = 0; a < 3; ++a) m = fmaxf(m, fmaxf(fabsf(lo[a]), fabsf(hi[a])));
+    const float pad = 2e-5f * m;
+    for (int a = 0; a < 3; ++a) { lo[a] -= pad; hi[a] += pad; }
+}
+
 struct Accel {
     const Node8   *nodes;
     const TriRec  *tris;

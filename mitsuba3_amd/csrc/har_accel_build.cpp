@@ -191,26 +191,9 @@ template <typename F> static void run_parallel(unsigned threads, size_t n, F &&f
     for (auto &t : pool) t.join();
 }
 
-static inline uint8_t exp_byte(double extent) {
-    // smallest e with extent / 2^e <= 255
-    int e = -126;
-    if (extent > 0.0) {
-        e = (int) std::ceil(std::log2(extent / 255.0));
-        while (extent / std::ldexp(1.0, e) > 255.0) ++e;
-        while (e > -126 && extent / std::ldexp(1.0, e - 1) <= 255.0) --e;
-    }
-    e = std::max(-126, std::min(127, e));
-    return (uint8_t) (e + 127);
-}
-
 } // namespace
 
-void pad_prim_box(PrimBox &b) {
-    float m = 1.f;
-    for (int a = 0; a < 3; ++a) m = std::max(m, std::max(std::fabs(b.lo[a]), std::fabs(b.hi[a])));
-    float pad = 2e-5f * m;
-    for (int a = 0; a < 3; ++a) { b.lo[a] -= pad; b.hi[a] += pad; }
-}
+void pad_prim_box(PrimBox &b) { pad_box(b.lo, b.hi); }
 
 uint32_t build_bvh8(const std::vector<PrimBox> &prims, std::vector<Node8> &nodes, uint32_t leaf_base,
                     std::vector<uint32_t> &leaf_order, Bvh8Stats *stats, uint32_t max_leaf, float prim_cost, uint32_t dp_min_prims) {
@@ -391,12 +374,7 @@ uint32_t build_bvh8(const std::vector<PrimBox> &prims, std::vector<Node8> &nodes
             for (int i = 0; i < nc; ++i) child_in_slot[slot_of[i]] = child[i];
 
             Node8 n; std::memset(&n, 0, sizeof(n));
-            n.px = nb.lo[0]; n.py = nb.lo[1]; n.pz = nb.lo[2];
-            n.ex = exp_byte((double) nb.hi[0] - (double) n.px);
-            n.ey = exp_byte((double) nb.hi[1] - (double) n.py);
-            n.ez = exp_byte((double) nb.hi[2] - (double) n.pz);
-            const double sc[3] = { std::ldexp(1.0, (int) n.ex - 127), std::ldexp(1.0, (int) n.ey - 127), std::ldexp(1.0, (int) n.ez - 127) };
-            const double org[3] = { n.px, n.py, n.pz };
+            node_set_frame(n, nb.lo, nb.hi);
             n.child_base = node_cursor;
             n.tri_base = leaf_base + leaf_cursor;
             uint32_t n_internal = 0;
@@ -404,12 +382,7 @@ uint32_t build_bvh8(const std::vector<PrimBox> &prims, std::vector<Node8> &nodes
                 int c = child_in_slot[s];
                 if (c < 0) continue;
                 const BNode &cn = B.bn[c];
-                uint8_t *q[6] = { n.qlox, n.qloy, n.qloz, n.qhix, n.qhiy, n.qhiz };
-                for (int a = 0; a < 3; ++a) {
-                    double lo = std::floor(((double) cn.box.lo[a] - org[a]) / sc[a]), hi = std::ceil(((double) cn.box.hi[a] - org[a]) / sc[a]);
-                    q[a][s] = (uint8_t) std::max(0.0, std::min(255.0, lo));
-                    q[3 + a][s] = (uint8_t) std::max(0.0, std::min(255.0, hi));
-                }
+                node_quantise_child(n, s, cn.box.lo, cn.box.hi);
                 if (cn.count) {
                     /* leaf slot: its record is tri_base + (number of leaf slots below s) -- the records are appended in slot order */
                     n.lmask |= (uint8_t) (1u << s);

@@ -13,6 +13,7 @@
 #include "har_scene_host.h"
 
 #include <algorithm>
+#include <cstddef>
 #include <cstdio>
 #include <cstring>
 #include <map>
@@ -137,6 +138,8 @@ struct HarSceneImpl {
     std::vector<void *> owned;
     std::vector<float *> tex_dev;
     DBsdf *d_bsdfs = nullptr;
+    /* har_scene_set_*_device: the host mirrors (hs.textures[k].data, hs.bsdfs, hs.emitters) that no longer hold the device's values */
+    std::vector<uint8_t> tex_host_stale; bool bsdf_host_stale = false, emitter_host_stale = false;
 };
 
 struct HarIntegratorImpl {
@@ -190,6 +193,8 @@ struct HarIntegratorImpl {
     unsigned long long *totals = nullptr;
     int *status = nullptr;
     float **d_grad_tex = nullptr; size_t grad_tex_cap = 0;
+    /* staging of the per-call pointer table (upload_pointer_table): a ring of pinned slots with one event each */
+    void **ptr_ring = nullptr; size_t ptr_ring_cap = 0; hipEvent_t ptr_ring_ev[8]{}; bool ptr_ring_used[8]{}; uint32_t ptr_ring_next = 0;
     /* texel-gradient queues of the adjoint pass (TexelQueues, har_kernels.h): records, counters, band tables; built for `tq_scene` */
     TexelQueues tq{ nullptr, nullptr, nullptr, nullptr, 0u, 0u, nullptr }; uint64_t tq_scene = 0; uint32_t tq_lanes = 0, tq_lds = 0;
     // profiling
@@ -760,8 +765,9 @@ int har_scene_create(const HarSceneDesc *desc, HarScene *out) {
     std::vector<DTexture> dt;
     for (auto &t : hs.textures) {
         const float *p = nullptr; up(t.data, &p);
-        S->tex_dev.push_back(const_cast<float *>(p)); dt.push_back(DTexture{ p, t.w, t.h, t.mode, 0u });
+        S->tex_dev.push_back(const_cast<float *>(p)); dt.push_back(hs.device_texture(dt.size(), p));
     }
+    S->tex_host_stale.assign(hs.textures.size(), 0);
     up(dt, &D.textures);
     up(hs.bsdf_tables, &D.bsdf_tables);
     D.envmap = nullptr;
@@ -770,6 +776,8 @@ int har_scene_create(const HarSceneDesc *desc, HarScene *out) {
         hs.envmap.tex = tex; hs.envmap.warp = warp;
         std::vector<DEnvmap> one(1, hs.envmap); up(one, &D.envmap);
     }
+    up(hs.emitter_cdf, &D.emitter_cdf);
+    { const float *distr = nullptr; up(hs.emitter_distr, &distr); hs.bind_tables(D, distr); }
     if (err != hipSuccess) { for (void *p : S->owned) dev_free(p); delete S; return fail(std::string("scene upload: ") + hipGetErrorString(err)); }
     S->d_bsdfs = const_cast<DBsdf *>(D.bsdfs);
     D.accel.root = hs.root; D.accel.has_tlas = hs.has_tlas; D.accel.n_tris = (uint32_t) hs.tris.size(); D.accel.n_insts = (uint32_t) hs.inst_recs.size();
@@ -778,8 +786,7 @@ int har_scene_create(const HarSceneDesc *desc, HarScene *out) {
     D.n_bsdfs = (uint32_t) hs.bsdfs.size(); D.n_textures = (uint32_t) hs.textures.size();
     D.env_emitter = hs.env_emitter;
     D.bsdf_types = 0; for (const DBsdf &b : hs.bsdfs) D.bsdf_types |= (1u << b.type) | ((b.flags & BF_TWOSIDED) ? 0x80000000u : 0u);
-    up(hs.emitter_cdf, &D.emitter_cdf);
-    if (hs.has_envmap || hs.has_mesh_emitters || hs.has_point_emitters) D.bsdf_types |= HAR_SCENE_ENVMAP;
+    if (hs.has_envmap || hs.has_mesh_emitters || hs.has_point_emitters || !hs.emitter_distr.empty()) D.bsdf_types |= HAR_SCENE_ENVMAP;
     /* the depth-first bound of the BVH must fit the traversal stacks (LDS entries + HBM spill columns): a deeper scene is refused here instead of
      * rendering with rays that overflow (an overflowing ray is a miss + a status word that only har_render_stats reads) */
     const uint32_t stack_cap = (uint32_t) std::min(HAR_LDS_STACK_DEPTH, HAR_LDS_STACK_SMALL + HAR_STACK_SPILL);
@@ -802,8 +809,15 @@ int har_scene_destroy(HarScene S) {
     return 0;
 }
 
+/* device -> host refresh of the mirrors that har_scene_set_*_device left stale (the host setters below rewrite whole records from the mirror) */
+static int sync_host_records(HarSceneImpl *S) {
+    if (S->bsdf_host_stale) { HIP_TRY(hipMemcpy(S->hs.bsdfs.data(), S->d_bsdfs, S->hs.bsdfs.size() * sizeof(DBsdf), hipMemcpyDeviceToHost)); S->bsdf_host_stale = false; }
+    if (S->emitter_host_stale) { HIP_TRY(hipMemcpy(S->hs.emitters.data(), S->ds.emitters, S->hs.emitters.size() * sizeof(DEmitter), hipMemcpyDeviceToHost)); S->emitter_host_stale = false; }
+    return 0;
+}
 int har_scene_set_reflectance(HarScene S, uint32_t bsdf, const float rgb[3]) {
     if (!S || bsdf >= S->hs.bsdfs.size()) return fail("invalid bsdf index");
+    if (sync_host_records(S)) return 1;
     DBsdf &b = S->hs.bsdfs[bsdf]; b.r = rgb[0]; b.g = rgb[1]; b.b = rgb[2];
     if (b.type == BSDF_ROUGHPLASTIC || b.type == BSDF_PLASTIC) update_roughplastic_sampling_weight(S->hs, bsdf);     /* RoughPlastic::parameters_changed */
     HIP_TRY(hipMemcpy(S->d_bsdfs + bsdf, &b, sizeof(DBsdf), hipMemcpyHostToDevice));
@@ -811,10 +825,26 @@ int har_scene_set_reflectance(HarScene S, uint32_t bsdf, const float rgb[3]) {
 }
 int har_scene_set_emitter_radiance(HarScene S, uint32_t emitter, const float rgb[3]) {
     if (!S || emitter >= S->hs.emitters.size()) return fail("invalid emitter index");
+    if (sync_host_records(S)) return 1;
     DEmitter &e = S->hs.emitters[emitter];
     if (e.type == 2u) return fail("an environment map has no constant radiance");
     e.radiance[0] = rgb[0]; e.radiance[1] = rgb[1]; e.radiance[2] = rgb[2];
     HIP_TRY(hipMemcpy(const_cast<DEmitter *>(S->ds.emitters) + emitter, &e, sizeof(DEmitter), hipMemcpyHostToDevice));
+    return 0;
+}
+/* the records whose lobe-selection weight depends on the MEAN of texture `tex` (RoughPlastic / SmoothPlastic::parameters_changed, roughplastic.cpp:204-242,
+ * plastic.cpp:188-205: m_specular_sampling_weight from the means of the two reflectances) */
+static bool texture_feeds_sampling_weight(const HostScene &hs, uint32_t tex) {
+    for (const DBsdf &b : hs.bsdfs) if (b.texture == (int32_t) tex && (b.type == BSDF_ROUGHPLASTIC || b.type == BSDF_PLASTIC)) return true;
+    return false;
+}
+static int refresh_sampling_weights(HarSceneImpl *S, uint32_t tex) {
+    for (uint32_t k = 0; k < S->hs.bsdfs.size(); ++k) {
+        DBsdf &b = S->hs.bsdfs[k];
+        if (b.texture != (int32_t) tex || !(b.type == BSDF_ROUGHPLASTIC || b.type == BSDF_PLASTIC)) continue;
+        update_roughplastic_sampling_weight(S->hs, k);
+        HIP_TRY(hipMemcpy(S->d_bsdfs + k, &b, sizeof(DBsdf), hipMemcpyHostToDevice));
+    }
     return 0;
 }
 int har_scene_set_texture(HarScene S, uint32_t tex, const float *data) {
@@ -822,6 +852,53 @@ int har_scene_set_texture(HarScene S, uint32_t tex, const float *data) {
     HostTexture &t = S->hs.textures[tex];
     t.data.assign(data, data + t.data.size());
     HIP_TRY(hipMemcpy(S->tex_dev[tex], data, t.data.size() * sizeof(float), hipMemcpyHostToDevice));
+    S->tex_host_stale[tex] = 0;
+    return refresh_sampling_weights(S, tex);
+}
+/* The same three updates from DEVICE memory, ordered on `stream`, without a host round trip: what an optimisation loop calls every step (mi.traverse +
+ * params.update(), src/python/python/util.py:344-528 -- in the reference the parameters ARE device arrays and update() copies nothing).  The library's host
+ * mirror of the value goes stale and is refreshed from the device only when something needs it (har_scene_set_* from the host overwrite it anyway).
+ * Exception: a bitmap / colour that feeds the lobe-selection weight of a `plastic` / `roughplastic` record (the mean of the reflectance) -- that weight is
+ * computed on the host, so these records take one synchronous device-to-host copy. */
+int har_scene_set_texture_device(HarScene S, uint32_t tex, const float *dev, void *stream) {
+    if (!S || tex >= S->hs.textures.size()) return fail("invalid texture index");
+    if (!dev) return fail("null device pointer");
+    HostTexture &t = S->hs.textures[tex];
+    hipStream_t s = (hipStream_t) stream;
+    if (texture_feeds_sampling_weight(S->hs, tex)) {
+        HIP_TRY(hipMemcpyAsync(t.data.data(), dev, t.data.size() * sizeof(float), hipMemcpyDeviceToHost, s));
+        if (dev != S->tex_dev[tex]) HIP_TRY(hipMemcpyAsync(S->tex_dev[tex], dev, t.data.size() * sizeof(float), hipMemcpyDeviceToDevice, s));
+        HIP_TRY(hipStreamSynchronize(s));
+        S->tex_host_stale[tex] = 0;
+        return refresh_sampling_weights(S, tex);
+    }
+    if (dev != S->tex_dev[tex]) HIP_TRY(hipMemcpyAsync(S->tex_dev[tex], dev, t.data.size() * sizeof(float), hipMemcpyDeviceToDevice, s));
+    S->tex_host_stale[tex] = 1;
+    return 0;
+}
+int har_scene_set_reflectance_device(HarScene S, uint32_t bsdf, const float *dev_rgb, void *stream) {
+    if (!S || bsdf >= S->hs.bsdfs.size()) return fail("invalid bsdf index");
+    if (!dev_rgb) return fail("null device pointer");
+    DBsdf &b = S->hs.bsdfs[bsdf];
+    hipStream_t s = (hipStream_t) stream;
+    if (b.type == BSDF_ROUGHPLASTIC || b.type == BSDF_PLASTIC) {           /* its sampling weight depends on the colour: through the host */
+        float rgb[3];
+        HIP_TRY(hipMemcpyAsync(rgb, dev_rgb, sizeof(rgb), hipMemcpyDeviceToHost, s));
+        HIP_TRY(hipStreamSynchronize(s));
+        return har_scene_set_reflectance(S, bsdf, rgb);
+    }
+    static_assert(offsetof(DBsdf, g) == offsetof(DBsdf, r) + 4 && offsetof(DBsdf, b) == offsetof(DBsdf, r) + 8, "slot 0 is three consecutive floats");
+    HIP_TRY(hipMemcpyAsync(&S->d_bsdfs[bsdf].r, dev_rgb, 3 * sizeof(float), hipMemcpyDeviceToDevice, s));
+    S->bsdf_host_stale = true;
+    return 0;
+}
+int har_scene_set_emitter_radiance_device(HarScene S, uint32_t emitter, const float *dev_rgb, void *stream) {
+    if (!S || emitter >= S->hs.emitters.size()) return fail("invalid emitter index");
+    if (!dev_rgb) return fail("null device pointer");
+    if (S->hs.emitters[emitter].type == 2u) return fail("an environment map has no constant radiance");
+    HIP_TRY(hipMemcpyAsync(const_cast<float *>(S->ds.emitters[0].radiance) + (size_t) emitter * (sizeof(DEmitter) / sizeof(float)), dev_rgb, 3 * sizeof(float),
+                           hipMemcpyDeviceToDevice, (hipStream_t) stream));
+    S->emitter_host_stale = true;
     return 0;
 }
 int har_scene_accel_info(HarScene S, uint64_t info[4]) {
@@ -990,6 +1067,8 @@ int har_integrator_destroy(HarIntegrator I) {
     if (I->side_stream) (void) hipStreamDestroy(I->side_stream);
     for (HarIntegratorImpl *J : { I->twin, I })
         if (J) {
+            if (J->ptr_ring) (void) hipHostFree(J->ptr_ring);
+            for (int k = 0; k < 8; ++k) if (J->ptr_ring_ev[k]) (void) hipEventDestroy(J->ptr_ring_ev[k]);
             if (J->ev_shaded) (void) hipEventDestroy(J->ev_shaded);
             if (J->ev_resolved) (void) hipEventDestroy(J->ev_resolved);
             if (J->ev_resolved2) (void) hipEventDestroy(J->ev_resolved2);
@@ -1042,6 +1121,28 @@ static int render_range(HarScene S, HarIntegrator I, const HarSensor *sensor, ui
         }
     }
     HIP_TRY(hipGetLastError());
+    return 0;
+}
+
+/* The table of texture gradient (tangent) buffers is a HOST array of the caller that only lives for the call, while the kernels read it from the device.  It is
+ * staged through a ring of eight PINNED slots, so that the copy is asynchronous and the call returns without waiting for the stream (round 4 synchronised the
+ * stream here, once per optimisation step: the GPU then idled while the host enqueued the whole adjoint pass).  A slot is reused only after the copy that read it
+ * has run (its event); the device table itself is rewritten in stream order. */
+static int upload_pointer_table(HarIntegratorImpl *I, const void *const *host, size_t n, hipStream_t s) {
+    if (I->ptr_ring_cap < n) {
+        (void) hipDeviceSynchronize();
+        if (I->ptr_ring) (void) hipHostFree(I->ptr_ring);
+        I->ptr_ring = nullptr; I->ptr_ring_cap = 0;
+        HIP_TRY(hipHostMalloc((void **) &I->ptr_ring, 8 * n * sizeof(void *), hipHostMallocDefault));
+        I->ptr_ring_cap = n;
+        for (int k = 0; k < 8; ++k) { if (!I->ptr_ring_ev[k]) HIP_TRY(hipEventCreateWithFlags(&I->ptr_ring_ev[k], hipEventDisableTiming)); I->ptr_ring_used[k] = false; }
+    }
+    const uint32_t k = I->ptr_ring_next; I->ptr_ring_next = (k + 1u) & 7u;
+    if (I->ptr_ring_used[k]) HIP_TRY(hipEventSynchronize(I->ptr_ring_ev[k]));
+    void **slot = I->ptr_ring + (size_t) k * I->ptr_ring_cap;
+    std::memcpy(slot, host, n * sizeof(void *));
+    HIP_TRY(hipMemcpyAsync(I->d_grad_tex, slot, n * sizeof(void *), hipMemcpyHostToDevice, s));
+    HIP_TRY(hipEventRecord(I->ptr_ring_ev[k], s)); I->ptr_ring_used[k] = true;
     return 0;
 }
 
@@ -1266,8 +1367,7 @@ static int backward_range(HarScene S, HarIntegrator I, const HarSensor *sensor, 
     if (nt) {
         if (!grad_textures) return fail("grad_textures is null but the scene has bitmap textures");
         for (size_t k = 0; k < nt; ++k) if (!grad_textures[k]) return fail("null texture gradient buffer");
-        HIP_TRY(hipMemcpyAsync(I->d_grad_tex, grad_textures, nt * sizeof(float *), hipMemcpyHostToDevice, s));
-        HIP_TRY(hipStreamSynchronize(s));
+        if (upload_pointer_table(I, (const void *const *) grad_textures, nt, s)) return 1;
     }
     if (I->grad_bsdf_params) {
         /* the alpha / eta / k / slot-1 terms are committed in place by the cached-bounce shading kernel only */
@@ -1334,8 +1434,7 @@ int har_render_forward(HarScene S, HarIntegrator I, const HarSensor *sensor, uin
     if (nt) {
         if (!tangent_textures) return fail("tangent_textures is null but the scene has bitmap textures");
         for (size_t k = 0; k < nt; ++k) if (!tangent_textures[k]) return fail("null texture tangent buffer");
-        HIP_TRY(hipMemcpyAsync(I->d_grad_tex, tangent_textures, nt * sizeof(float *), hipMemcpyHostToDevice, s));
-        HIP_TRY(hipStreamSynchronize(s));
+        if (upload_pointer_table(I, (const void *const *) tangent_textures, nt, s)) return 1;
     }
     /* tangent slots in the layout of the gradient slots: (bsdf_count + emitter_count) x 3 */
     const size_t nb3 = 3 * S->hs.bsdfs.size(), ne3 = 3 * S->hs.emitters.size();

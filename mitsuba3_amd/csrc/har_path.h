@@ -127,6 +127,8 @@ HAR_HD void shade_lane(const DScene &S, const ShadeParams &P, const PathState &s
     const DMesh M = valid ? S.meshes[si.mesh] : DMesh{};
     const int emitter = valid ? M.emitter : S.env_emitter;          /* si.emitter(scene): the environment for a miss (scene.h:822-832) */
     const float pmf = S.n_emitters ? 1.f / (float) S.n_emitters : 0.f;   /* scene.cpp:139 */
+    /* Scene::m_emitter_distr (scene.cpp:120-141): non-uniform emitter selection; only in the kernels of scenes that carry the generic emitter code */
+    const bool distr = (TYPES & HAR_SCENE_ENVMAP) != 0u && S.emitter_distr != nullptr;
 
     /* ---- direct emission + MIS with the previous BSDF sample (path.cpp:206-221, prb.py:148-161).  hide_emitters: a camera ray that escapes does
      * not see the environment (path.cpp:114-115 keeps valid_ray false, so the sample's result is dropped; prb.py:146-148 masks the eval) */
@@ -138,7 +140,9 @@ HAR_HD void shade_lane(const DScene &S, const ShadeParams &P, const PathState &s
         float dist = norm3(rel);
         Vec3 dd = div3(rel, dist);
         /* pdf_direction: area light (area.cpp:170-197) or uniform sphere (constant.cpp:155-160) */
-        float em_pdf = prev_delta ? 0.f : (envmap ? envmap_pdf_direction(*S.envmap, st.d) : env ? HAR_INV_FOUR_PI : emitter_pdf_direction(E, dd, si.sn, dist)) * pmf;
+        /* Scene::pdf_emitter_direction (scene.cpp:378-388): emitter_pmf = m_emitter_pmf, or sampling_weight * normalization with a distribution */
+        const float hit_pmf = distr ? S.emitter_distr[emitter] * S.emitter_norm : pmf;
+        float em_pdf = prev_delta ? 0.f : (envmap ? envmap_pdf_direction(*S.envmap, st.d) : env ? HAR_INV_FOUR_PI : emitter_pdf_direction(E, dd, si.sn, dist)) * hit_pmf;
         float mis = mis_weight(st.prev_bsdf_pdf, em_pdf);
         Vec3 rad(E.radiance[0], E.radiance[1], E.radiance[2]);
         if (envmap) rad = envmap_eval(*S.envmap, st.d);                              /* envmap.cpp:228-236: v = to_world^-1 * (-si.wi) */
@@ -179,12 +183,21 @@ HAR_HD void shade_lane(const DScene &S, const ShadeParams &P, const PathState &s
     bool em_delta = false;                                       /* DirectionSample::delta: a point light's sample carries MIS weight 1 (path.cpp:274, prb.py:211) */
     bool active_em = active_next && S.n_emitters > 0 && smooth;
     if (active_em) {
-        uint32_t index = 0; float wgt = 1.f;
-        if (S.n_emitters > 1) {                                  /* sample_emitter, scene.cpp:248-271 */
+        uint32_t index = 0; float wgt = 1.f, sel_pmf = pmf;
+        if (S.n_emitters > 1 && distr) {                         /* sample_emitter with m_emitter_distr (scene.cpp:258-261): sample_reuse_pmf, weight = rcp(pmf) */
+            float reused, p;
+            index = discrete_sample_reuse_pmf(S.emitter_distr, S.emitter_distr + S.n_emitters, S.emitter_valid_lo, S.emitter_valid_hi, S.emitter_sum, S.emitter_norm, ex,
+                                              !(P.flags & HAR_SHADE_SCALAR_DRAWS), reused, p);
+            wgt = rcp_(p); ex = reused;
+        } else if (S.n_emitters > 1) {                           /* sample_emitter, scene.cpp:248-271 */
             float scaled = ex * (float) S.n_emitters;
             index = (uint32_t) scaled; if (index > S.n_emitters - 1u) index = S.n_emitters - 1u;
             wgt = (float) S.n_emitters; ex = scaled - (float) index;
         }
+        /* pdf_emitter(index) = eval_pmf_normalized (scene.cpp:273-279, applied at :338).  JIT variants take that branch for a single emitter too (:326); the scalar
+         * variants sample their only emitter directly (:351-354) and never multiply by its pmf */
+        if (distr && (S.n_emitters > 1 || !(P.flags & HAR_SHADE_SCALAR_DRAWS))) sel_pmf = S.emitter_distr[index] * S.emitter_norm;
+        else if (distr) sel_pmf = 1.f;
         if ((TYPES & HAR_SCENE_ENVMAP) != 0u && S.emitters[index].type == 2u) envmap_sample_direction(*S.envmap, si.p, ex, ey, ds, em_weight);
         else if ((TYPES & HAR_SCENE_ENVMAP) != 0u && S.emitters[index].type == 3u)
             mesh_emitter_sample_direction(S, S.emitters[index], si.p, ex, ey, ds, em_weight, MODE == MODE_PRB_ADJOINT ? &em_unit : nullptr);
@@ -196,7 +209,7 @@ HAR_HD void shade_lane(const DScene &S, const ShadeParams &P, const PathState &s
             directional_sample_direction(S.emitters[index], si.p, ds, em_weight, MODE == MODE_PRB_ADJOINT ? &em_unit : nullptr); em_delta = true;
         }
         else emitter_sample_direction(S.emitters[index], si.p, ex, ey, ds, em_weight, MODE == MODE_PRB_ADJOINT ? &em_unit : nullptr);
-        ds.pdf *= pmf; em_weight = em_weight * wgt; em_unit *= wgt; em_sampled = index;
+        ds.pdf *= sel_pmf; em_weight = em_weight * wgt; em_unit *= wgt; em_sampled = index;
         active_em = ds.pdf != 0.f;
     }
     Vec3 wo_em = active_em ? si.to_local(ds.d) : Vec3(0.f);

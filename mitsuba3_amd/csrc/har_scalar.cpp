@@ -48,7 +48,7 @@ struct BoundScene {
     HostScene hs; std::vector<DTexture> dtex; DScene ds{};
     void bind() {
         dtex.clear();
-        for (auto &t : hs.textures) dtex.push_back(DTexture{ t.data.data(), t.w, t.h, t.mode, 0u });
+        for (size_t k = 0; k < hs.textures.size(); ++k) dtex.push_back(hs.device_texture(k, hs.textures[k].data.data()));
         DScene &S = ds;
         S.accel.nodes = hs.nodes.data(); S.accel.tris = hs.tris.data(); S.accel.insts = hs.inst_recs.data();
         S.accel.root = hs.root; S.accel.has_tlas = hs.has_tlas; S.accel.n_tris = (uint32_t) hs.tris.size(); S.accel.n_insts = (uint32_t) hs.inst_recs.size();
@@ -64,7 +64,8 @@ struct BoundScene {
         S.env_emitter = hs.env_emitter;
         S.bsdf_types = 0; for (const DBsdf &b : hs.bsdfs) S.bsdf_types |= (1u << b.type) | ((b.flags & BF_TWOSIDED) ? 0x80000000u : 0u);
         S.envmap = nullptr; S.emitter_cdf = hs.emitter_cdf.data();
-        if (hs.has_mesh_emitters || hs.has_point_emitters) S.bsdf_types |= HAR_SCENE_ENVMAP;
+        hs.bind_tables(S, hs.emitter_distr.data());
+        if (hs.has_mesh_emitters || hs.has_point_emitters || !hs.emitter_distr.empty()) S.bsdf_types |= HAR_SCENE_ENVMAP;
         if (hs.has_envmap) { hs.envmap.tex = hs.env_tex.data(); hs.envmap.warp = hs.env_warp.data(); S.envmap = &hs.envmap; S.bsdf_types |= HAR_SCENE_ENVMAP; }
     }
 };

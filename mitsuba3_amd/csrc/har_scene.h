@@ -12,7 +12,10 @@
 namespace har {
 
 struct DMesh    { uint32_t voff, foff, bsdf; int32_t emitter; uint32_t flags, face_count, vertex_count, pad1; };
-struct DTexture { const float *data; uint32_t w, h; uint32_t mode, pad; };      /* mode: HarTexture::mode (bit 0 nearest, bit 1 mirror, bit 2 clamp) */
+/* mode: HarTexture::mode (bit 0 nearest, bit 1 mirror, bit 2 clamp), bit 31 (HAR_TEX_HAS_UV_XF): `uvm` is not the identity; uvm = BitmapTexture's `to_uv`
+ * (bitmap.cpp:175), row-major 2 x 3 -- tex_taps applies it to the surface's uv before the lookup (bitmap.cpp:565,792,831,847) */
+#define HAR_TEX_HAS_UV_XF 0x80000000u
+struct DTexture { const float *data; uint32_t w, h; uint32_t mode, pad; float uvm[6]; };
 /* type 0: AreaLight on a rectangle (to_world, normal, inv_area, mesh); type 1: ConstantBackgroundEmitter
  * (src/emitters/constant.cpp): to_world[0..2] = bounding sphere centre, to_world[3] = radius, mesh = 0xffffffff; type 2: environment map
  * (DEnvmap); type 3: AreaLight on a triangle mesh: mesh, inv_area = 1 / surface area, to_world[0] / [1] = bit patterns of the offset of its
@@ -53,6 +56,11 @@ struct DScene {
     uint32_t bsdf_types;               /* bit mask (1 << type) of the BSDF types present (+ bit 31: some record is twosided) */
     const DEnvmap *envmap;             /* device record of the environment map when emitters[env_emitter].type == 2 */
     const float   *emitter_cdf;        /* face-area tables of the mesh emitters (type 3): per emitter `count` unnormalised pmf values, then `count` cdf values */
+    /* Scene::m_emitter_distr (scene.cpp:120-141): NULL = uniform emitter selection (every sampling_weight is 1); otherwise n_emitters unnormalised pmf values (the
+     * weights), then n_emitters cdf values (running sums accumulated in double, distr_1d.h:236-266), with their sum, 1 / sum and the first / last bin of non-zero weight */
+    const float   *emitter_distr;
+    float    emitter_sum, emitter_norm;
+    uint32_t emitter_valid_lo, emitter_valid_hi;
 };
 
 struct DSensor {
@@ -218,6 +226,10 @@ HAR_HD int32_t tex_wrap(int32_t i, int32_t n, uint32_t mode) {
 }
 HAR_HD void tex_taps(const DTexture &T, float u, float v, TexTaps &l) {
     const int32_t W = (int32_t) T.w, H = (int32_t) T.h;
+    if (T.mode & HAR_TEX_HAS_UV_XF) {                                                    /* uv = m_transform * si.uv (bitmap.cpp:847; AffineTransform * Point, transform.h:322-335) */
+        const float tu = fma_(T.uvm[1], v, fma_(T.uvm[0], u, T.uvm[2])), tv = fma_(T.uvm[4], v, fma_(T.uvm[3], u, T.uvm[5]));
+        u = tu; v = tv;
+    }
     if (T.mode & 1u) {                                                                 /* nearest: one texel, written as four coincident taps of weight (1, 0) */
         const int32_t x = tex_wrap((int32_t) floorf(u * (float) T.w), W, T.mode), y = tex_wrap((int32_t) floorf(v * (float) T.h), H, T.mode);
         l.w1x = 0.f; l.w1y = 0.f; l.w0x = 1.f; l.w0y = 1.f;
@@ -229,7 +241,7 @@ HAR_HD void tex_taps(const DTexture &T, float u, float v, TexTaps &l) {
     int32_t ix = (int32_t) fx, iy = (int32_t) fy;
     l.w1x = px - fx; l.w1y = py - fy; l.w0x = 1.f - l.w1x; l.w0y = 1.f - l.w1y;
     int32_t x0, x1, y0, y1;
-    if (T.mode == 0u) {                                                                /* bilinear + repeat, the defaults: the round-1 code path */
+    if ((T.mode & 7u) == 0u) {                                                         /* bilinear + repeat, the defaults: the round-1 code path */
         x0 = ix % W; if (x0 < 0) x0 += W;
         x1 = (ix + 1) % W; if (x1 < 0) x1 += W;
         y0 = iy % H; if (y0 < 0) y0 += H;
@@ -496,6 +508,24 @@ HAR_HD void envmap_sample_direction(const DEnvmap &E, Vec3 ref_p, float sx, floa
     ds.p = fma3(d, dist, ref_p); ds.n = -d; ds.d = d; ds.dist = dist;
     ds.pdf = active ? pdf * inv_sin_theta * (1.f / (2.f * (HAR_PI * HAR_PI))) : 0.f;
     spec = active ? div3(envmap_eval_uv(E, u, v), ds.pdf) : Vec3(0.f);
+}
+/* DiscreteDistribution::sample / sample_reuse_pmf (include/mitsuba/core/distr_1d.h:117-140,205-219): value *= sum; dr::binary_search over [lo, hi] (m_valid) with the
+ * predicate of the variant -- JIT: (cdf[i] < value || cdf[i] == 0) && cdf[i] != sum, scalar: cdf[i] < value -- then the index, the re-used sample
+ * (value - cdf_normalized[index - 1]) / pmf_normalized[index] and the normalised pmf */
+HAR_HD uint32_t discrete_sample_reuse_pmf(const float *pmf, const float *cdf, uint32_t lo, uint32_t hi, float sum, float normalization, float value01, bool jit,
+                                          float &reused, float &pmf_out) {
+    const float value = value01 * sum;
+    uint32_t start = lo, end = hi, iterations = 0;
+    if (start < end) { uint32_t span = end - start; iterations = 1; while (span >>= 1) ++iterations; }
+    for (uint32_t i = 0; i < iterations; ++i) {
+        const uint32_t middle = (start + end) >> 1;
+        const float c = cdf[middle];
+        const bool cond = jit ? (((c < value) || c == 0.f) && c != sum) : (c < value);
+        if (cond) start = middle + 1u < end ? middle + 1u : end; else end = middle;
+    }
+    const float pmf_n = pmf[start] * normalization, cdf_n = start > 0u ? cdf[start - 1u] * normalization : 0.f;
+    reused = (value01 - cdf_n) / pmf_n; pmf_out = pmf_n;
+    return start;
 }
 /* AreaLight::sample_direction on a triangle mesh: Mesh::sample_position (src/render/mesh.cpp:1662-1712) -- DiscreteDistribution::sample_reuse over the
  * face areas (distr_1d.h:117-183, JIT predicate, dr::binary_search over [0, n - 1]), warp::square_to_uniform_triangle (warp.h:153-156), interpolated

@@ -14,15 +14,33 @@ namespace har {
 
 namespace {
 
-struct BlasInfo { uint32_t root, first_tri, tri_count; float lo[3], hi[3]; bool empty; };
+/* depth of every node of a BLAS (children sit behind their parents, so one forward sweep does it) -> its nodes sorted deepest first */
+void blas_refit_order(HostScene &hs, BlasInfo &B) {
+    B.order_first = (uint32_t) hs.refit_order.size(); B.level_begin.clear();
+    if (B.empty || B.node_count == 0) return;
+    std::vector<uint32_t> depth(B.node_count, 0u); uint32_t deepest = 0;
+    for (uint32_t i = 0; i < B.node_count; ++i) {
+        const Node8 &n = hs.nodes[B.root + i];
+        uint32_t k = 0;
+        for (int s = 0; s < 8; ++s) if (n.imask & (1u << s)) { depth[n.child_base + k - B.root] = depth[i] + 1u; deepest = std::max(deepest, depth[i] + 1u); ++k; }
+    }
+    std::vector<uint32_t> count(deepest + 2, 0u);
+    for (uint32_t d : depth) count[deepest - d + 1]++;
+    for (uint32_t l = 0; l <= deepest; ++l) count[l + 1] += count[l];
+    B.level_begin.assign(count.begin(), count.end());
+    hs.refit_order.resize((size_t) B.order_first + B.node_count);
+    std::vector<uint32_t> cursor(count.begin(), count.end() - 1);
+    for (uint32_t i = 0; i < B.node_count; ++i) hs.refit_order[B.order_first + cursor[deepest - depth[i]]++] = B.root + i;
+}
 
-BlasInfo build_blas(HostScene &hs, const HarSceneDesc &d, uint32_t first_mesh, uint32_t mesh_count, bool optimal_collapse = false) {
+BlasInfo build_blas(HostScene &hs, uint32_t first_mesh, uint32_t mesh_count, bool optimal_collapse = false) {
     std::vector<PrimBox> prims; std::vector<TriRec> recs;
     for (uint32_t s = first_mesh; s < first_mesh + mesh_count; ++s) {
-        const HarMesh &m = d.meshes[s];
+        const DMesh &m = hs.meshes[s];
+        const float *vertex_ptr = hs.verts.data() + 8 * (size_t) m.voff; const uint32_t *index_ptr = hs.faces.data() + 4 * (size_t) m.foff;
         for (uint32_t f = 0; f < m.face_count; ++f) {
             float p[3][3];
-            for (int k = 0; k < 3; ++k) { const float *v = m.vertex_ptr + 8 * (size_t) m.index_ptr[4 * (size_t) f + k]; p[k][0] = v[0]; p[k][1] = v[1]; p[k][2] = v[2]; }
+            for (int k = 0; k < 3; ++k) { const float *v = vertex_ptr + 8 * (size_t) index_ptr[4 * (size_t) f + k]; p[k][0] = v[0]; p[k][1] = v[1]; p[k][2] = v[2]; }
             TriRec t;
             t.p0x = p[0][0]; t.p0y = p[0][1]; t.p0z = p[0][2];
             t.e1x = p[1][0] - p[0][0]; t.e1y = p[1][1] - p[0][1]; t.e1z = p[1][2] - p[0][2];
@@ -42,10 +60,13 @@ BlasInfo build_blas(HostScene &hs, const HarSceneDesc &d, uint32_t first_mesh, u
     static const float tri_cost = getenv("HAR_BVH_CTRI") ? (float) atof(getenv("HAR_BVH_CTRI")) : 0.3f;     /* triangle test vs node visit (VALU instructions) */
     /* optimal_collapse: the top-level BLAS of a two-level scene, which EVERY ray walks -- the SAH-optimal collapse whatever its size (round 3, host model:
      * 2.55 -> 1.85 node visits per ray for the 12 wall triangles of the benchmark scene; the small-scene exception above is about stand-alone scenes) */
+    const uint32_t before = (uint32_t) hs.nodes.size();
     info.root = build_bvh8(prims, hs.nodes, info.first_tri, order, &hs.stats, blas_leaf, tri_cost, optimal_collapse ? 0u : blas_dp_min);
+    info.node_count = (uint32_t) hs.nodes.size() - before;
     for (uint32_t i : order) hs.tris.push_back(recs[i]);
     for (int a = 0; a < 3; ++a) { info.lo[a] = INFINITY; info.hi[a] = -INFINITY; }
     for (const PrimBox &b : prims) for (int a = 0; a < 3; ++a) { info.lo[a] = std::min(info.lo[a], b.lo[a]); info.hi[a] = std::max(info.hi[a], b.hi[a]); }
+    blas_refit_order(hs, info);
     return info;
 }
 
@@ -232,6 +253,14 @@ bool lower_scene(const HarSceneDesc &d, HostScene &hs, std::string &err) {
         if (!t.data || !t.width || !t.height) { err = "empty texture"; return false; }
         if ((t.mode & ~7u) != 0u || (t.mode & 6u) == 6u) { err = "HarTexture::mode: HAR_TEX_BILINEAR / _NEAREST combined with HAR_TEX_REPEAT / _MIRROR / _CLAMP"; return false; }
         HostTexture ht; ht.w = t.width; ht.h = t.height; ht.mode = t.mode; ht.data.assign(t.data, t.data + 3 * (size_t) t.width * t.height);
+        bool zero = true, ident = true;          /* to_uv (bitmap.cpp:175): six zeros = the identity of a zero-initialised record */
+        const float id6[6] = { 1.f, 0.f, 0.f, 0.f, 1.f, 0.f };
+        for (int k = 0; k < 6; ++k) { if (!std::isfinite(t.to_uv[k])) { err = "HarTexture::to_uv must be finite"; return false; } zero = zero && t.to_uv[k] == 0.f; ident = ident && t.to_uv[k] == id6[k]; }
+        if (!zero && !ident) {
+            if (t.to_uv[0] * t.to_uv[4] - t.to_uv[1] * t.to_uv[3] == 0.f) { err = "HarTexture::to_uv is singular"; return false; }
+            for (int k = 0; k < 6; ++k) ht.uvm[k] = t.to_uv[k];
+            ht.mode |= HAR_TEX_HAS_UV_XF;
+        }
         hs.textures.push_back(std::move(ht));
     }
     for (uint32_t i = 0; i < d.bsdf_count; ++i) {
@@ -260,6 +289,7 @@ bool lower_scene(const HarSceneDesc &d, HostScene &hs, std::string &err) {
     for (uint32_t i = 0; i < d.emitter_count; ++i) {
         const HarEmitter &e = d.emitters[i];
         if (e.type > 6) { err = "unsupported emitter type (`area`, `constant`, `envmap`, `point`, `spot` and `directional` are implemented)"; return false; }
+        if (!(e.sampling_weight >= 0.f) || !std::isfinite(e.sampling_weight)) { err = "DiscreteDistribution: entries must be non-negative!"; return false; }      /* distr_1d.h:247-248 */
         const bool area = e.type == 0 || e.type == 3, point = e.type >= 4;      /* the delta emitters */
         if (area && e.mesh >= d.top_mesh_count) { err = "area emitter must be attached to a top-level mesh"; return false; }
         if (!area && !point && hs.env_emitter >= 0) { err = "Only one environment emitter can be specified per scene."; return false; }   /* scene.cpp:64-65 */
@@ -279,6 +309,9 @@ bool lower_scene(const HarSceneDesc &d, HostScene &hs, std::string &err) {
             for (int k = 0; k < 9; ++k) de.to_world[k] = e.to_local[k];
             de.to_world[9] = e.to_world[9]; de.to_world[10] = e.to_world[10]; de.to_world[11] = e.to_world[11];
             de.normal[0] = cutoff_rad; de.normal[1] = cos_cutoff; de.normal[2] = cos_beam; de.inv_area = 1.0f / (cutoff_rad - beam_rad);
+        }
+        if (e.type == 6) {            /* the record of a directional light keeps its direction of travel (third column of to_world) in [0..2]; [3..6] = the scene's bounding sphere (update_scene_bounds) */
+            de.to_world[0] = e.to_world[6]; de.to_world[1] = e.to_world[7]; de.to_world[2] = e.to_world[8];
         }
         if (e.type == 3) {            /* Mesh::build_pmf (mesh.cpp:1358-1372): face areas of the (world-space) mesh + their running sum */
             const DMesh &M = hs.meshes[e.mesh];
@@ -300,6 +333,24 @@ bool lower_scene(const HarSceneDesc &d, HostScene &hs, std::string &err) {
         }
         hs.emitters.push_back(de);
     }
+    /* Scene::update_emitter_sampling_distribution (scene.cpp:120-141): a DiscreteDistribution over the weights as soon as one differs from 1; its tables are built by
+     * compute_cdf_scalar (distr_1d.h:236-266: running sums in double, rounded to float per entry; first / last bin with mass) in every variant, because the
+     * constructor taking a ScalarFloat array is the one used */
+    bool non_uniform = false;
+    for (uint32_t i = 0; i < d.emitter_count; ++i) non_uniform = non_uniform || d.emitters[i].sampling_weight != 1.f;
+    if (non_uniform) {
+        const uint32_t n = d.emitter_count;
+        hs.emitter_distr.assign(2 * (size_t) n, 0.f);
+        double sum = 0.0; uint32_t lo = 0xffffffffu, hi = 0xffffffffu;
+        for (uint32_t i = 0; i < n; ++i) {
+            const double v = (double) d.emitters[i].sampling_weight;
+            sum += v; hs.emitter_distr[i] = d.emitters[i].sampling_weight; hs.emitter_distr[n + i] = (float) sum;
+            if (v > 0.0) { if (lo == 0xffffffffu) lo = i; hi = i; }
+        }
+        if (lo == 0xffffffffu) { err = "DiscreteDistribution: no probability mass found!"; return false; }
+        hs.emitter_valid_lo = lo; hs.emitter_valid_hi = hi;
+        hs.emitter_sum = hs.emitter_distr[n + hi]; hs.emitter_norm = rcp_(hs.emitter_sum);
+    }
     for (uint32_t g = 0; g < d.group_count; ++g)
         if (d.groups[g].first_mesh < d.top_mesh_count || d.groups[g].first_mesh + d.groups[g].mesh_count > d.mesh_count) { err = "shapegroup mesh range invalid"; return false; }
     for (uint32_t i = 0; i < d.instance_count; ++i) {
@@ -308,56 +359,71 @@ bool lower_scene(const HarSceneDesc &d, HostScene &hs, std::string &err) {
         hs.insts.push_back(di);
     }
 
-    /* ConstantBackgroundEmitter::set_scene (constant.cpp:72-87): bounding sphere of Scene::bbox() (all shapes; an Instance
-     * contributes the 8 transformed corners of its group's box, instance.cpp:93-103), radius * (1 + RayEpsilon) */
+    hs.groups.assign(d.groups, d.groups + d.group_count);
+    hs.inst_group.resize(d.instance_count);
+    for (uint32_t i = 0; i < d.instance_count; ++i) hs.inst_group[i] = d.instances[i].group;
+    update_scene_bounds(hs);
+
+    hs.blas_top = build_blas(hs, 0, d.top_mesh_count, d.instance_count != 0);
+    hs.blas_depth = hs.stats.max_depth;
+    if (d.instance_count == 0) {
+        hs.root = hs.blas_top.root; hs.has_tlas = false; hs.tlas_first = (uint32_t) hs.nodes.size();
+        hs.blas_tri_ranges = { hs.blas_top.first_tri, hs.blas_top.tri_count };
+        return true;
+    }
+    for (uint32_t g = 0; g < d.group_count; ++g) hs.blas_groups.push_back(build_blas(hs, d.groups[g].first_mesh, d.groups[g].mesh_count));
+    hs.blas_depth = hs.stats.max_depth;
+    hs.tlas_first = (uint32_t) hs.nodes.size();
+    hs.inst_boxes.resize(d.instance_count); hs.inst_box_valid.assign(d.instance_count, 0);
+    return build_tlas(hs, err);
+}
+
+/* ConstantBackgroundEmitter::set_scene (constant.cpp:72-87): bounding sphere of Scene::bbox() (all shapes; an Instance
+ * contributes the 8 transformed corners of its group's box, instance.cpp:93-103), radius * (1 + RayEpsilon) */
+void update_scene_bounds(HostScene &hs) {
     bool needs_bounds = hs.env_emitter >= 0;
     for (const DEmitter &E : hs.emitters) needs_bounds = needs_bounds || E.type == 6u;      /* DirectionalEmitter::set_scene (directional.cpp:99-109): the same sphere */
-    if (needs_bounds) {
-        float lo[3] = { INFINITY, INFINITY, INFINITY }, hi[3] = { -INFINITY, -INFINITY, -INFINITY };
-        auto grow = [&](float x, float y, float z) { const float q[3] = { x, y, z }; for (int a = 0; a < 3; ++a) { lo[a] = std::min(lo[a], q[a]); hi[a] = std::max(hi[a], q[a]); } };
-        for (uint32_t s = 0; s < d.top_mesh_count; ++s)
-            for (uint32_t v = 0; v < d.meshes[s].vertex_count; ++v) { const float *p = d.meshes[s].vertex_ptr + 8 * (size_t) v; grow(p[0], p[1], p[2]); }
-        for (uint32_t i = 0; i < d.instance_count; ++i) {
-            const HarShapeGroup &sg = d.groups[d.instances[i].group];
-            float glo[3] = { INFINITY, INFINITY, INFINITY }, ghi[3] = { -INFINITY, -INFINITY, -INFINITY };
-            for (uint32_t s = sg.first_mesh; s < sg.first_mesh + sg.mesh_count; ++s)
-                for (uint32_t v = 0; v < d.meshes[s].vertex_count; ++v) { const float *p = d.meshes[s].vertex_ptr + 8 * (size_t) v; for (int a = 0; a < 3; ++a) { glo[a] = std::min(glo[a], p[a]); ghi[a] = std::max(ghi[a], p[a]); } }
-            if (!(glo[0] <= ghi[0])) continue;
-            for (int c = 0; c < 8; ++c) { Vec3 q = xf_point(d.instances[i].to_world, Vec3(c & 1 ? ghi[0] : glo[0], c & 2 ? ghi[1] : glo[1], c & 4 ? ghi[2] : glo[2])); grow(q.x, q.y, q.z); }
+    if (!needs_bounds) return;
+    float lo[3] = { INFINITY, INFINITY, INFINITY }, hi[3] = { -INFINITY, -INFINITY, -INFINITY };
+    auto grow = [&](float x, float y, float z) { const float q[3] = { x, y, z }; for (int a = 0; a < 3; ++a) { lo[a] = std::min(lo[a], q[a]); hi[a] = std::max(hi[a], q[a]); } };
+    auto vertex = [&](const DMesh &m, uint32_t v) { return hs.verts.data() + 8 * ((size_t) m.voff + v); };
+    for (uint32_t s = 0; s < hs.top_mesh_count; ++s)
+        for (uint32_t v = 0; v < hs.meshes[s].vertex_count; ++v) { const float *p = vertex(hs.meshes[s], v); grow(p[0], p[1], p[2]); }
+    for (uint32_t i = 0; i < hs.insts.size(); ++i) {
+        const HarShapeGroup &sg = hs.groups[hs.inst_group[i]];
+        float glo[3] = { INFINITY, INFINITY, INFINITY }, ghi[3] = { -INFINITY, -INFINITY, -INFINITY };
+        for (uint32_t s = sg.first_mesh; s < sg.first_mesh + sg.mesh_count; ++s)
+            for (uint32_t v = 0; v < hs.meshes[s].vertex_count; ++v) { const float *p = vertex(hs.meshes[s], v); for (int a = 0; a < 3; ++a) { glo[a] = std::min(glo[a], p[a]); ghi[a] = std::max(ghi[a], p[a]); } }
+        if (!(glo[0] <= ghi[0])) continue;
+        for (int c = 0; c < 8; ++c) { Vec3 q = xf_point(hs.insts[i].to_world, Vec3(c & 1 ? ghi[0] : glo[0], c & 2 ? ghi[1] : glo[1], c & 4 ? ghi[2] : glo[2])); grow(q.x, q.y, q.z); }
+    }
+    float bs[4] = { 0.f, 0.f, 0.f, HAR_RAY_EPS };        /* centre, radius */
+    if (lo[0] <= hi[0]) {
+        Vec3 c((hi[0] + lo[0]) * .5f, (hi[1] + lo[1]) * .5f, (hi[2] + lo[2]) * .5f);
+        float r = norm3(c - Vec3(hi[0], hi[1], hi[2]));
+        bs[0] = c.x; bs[1] = c.y; bs[2] = c.z; bs[3] = std::max(HAR_RAY_EPS, r * (1.f + HAR_RAY_EPS));
+    }
+    for (DEmitter &D : hs.emitters)
+        if (D.type == 6u) {          /* the record of a directional light: its direction in [0..2] (set when the record was lowered), then the sphere */
+            D.to_world[3] = bs[0]; D.to_world[4] = bs[1]; D.to_world[5] = bs[2]; D.to_world[6] = bs[3];
         }
-        float bs[4] = { 0.f, 0.f, 0.f, HAR_RAY_EPS };        /* centre, radius */
-        if (lo[0] <= hi[0]) {
-            Vec3 c((hi[0] + lo[0]) * .5f, (hi[1] + lo[1]) * .5f, (hi[2] + lo[2]) * .5f);
-            float r = norm3(c - Vec3(hi[0], hi[1], hi[2]));
-            bs[0] = c.x; bs[1] = c.y; bs[2] = c.z; bs[3] = std::max(HAR_RAY_EPS, r * (1.f + HAR_RAY_EPS));
-        }
-        for (DEmitter &D : hs.emitters)
-            if (D.type == 6u) {          /* the record of a directional light: its direction (third column of to_world), then the sphere */
-                const float dx = D.to_world[6], dy = D.to_world[7], dz = D.to_world[8];
-                D.to_world[0] = dx; D.to_world[1] = dy; D.to_world[2] = dz;
-                D.to_world[3] = bs[0]; D.to_world[4] = bs[1]; D.to_world[5] = bs[2]; D.to_world[6] = bs[3];
-            }
-        if (hs.env_emitter >= 0) {
+    if (hs.env_emitter >= 0) {
         DEmitter &E = hs.emitters[hs.env_emitter];
         E.to_world[0] = bs[0]; E.to_world[1] = bs[1]; E.to_world[2] = bs[2]; E.to_world[3] = bs[3];
         E.mesh = 0xffffffffu;
-        }
-        if (hs.env_emitter >= 0 && hs.has_envmap) {
-            DEmitter &E = hs.emitters[hs.env_emitter];            /* EnvironmentMapEmitter::set_scene (envmap.cpp:214-226): the same rule */
-            for (int a = 0; a < 3; ++a) hs.envmap.center[a] = E.to_world[a];
-            hs.envmap.radius = E.to_world[3];
-        }
     }
+    if (hs.env_emitter >= 0 && hs.has_envmap) {
+        DEmitter &E = hs.emitters[hs.env_emitter];            /* EnvironmentMapEmitter::set_scene (envmap.cpp:214-226): the same rule */
+        for (int a = 0; a < 3; ++a) hs.envmap.center[a] = E.to_world[a];
+        hs.envmap.radius = E.to_world[3];
+    }
+}
 
-    BlasInfo top = build_blas(hs, d, 0, d.top_mesh_count, d.instance_count != 0);
-    hs.blas_depth = hs.stats.max_depth;
-    if (d.instance_count == 0) {
-        hs.root = top.root; hs.has_tlas = false;
-        hs.blas_tri_ranges = { top.first_tri, top.tri_count };
-        return true;
-    }
-    std::vector<BlasInfo> groups;
-    for (uint32_t g = 0; g < d.group_count; ++g) groups.push_back(build_blas(hs, d, d.groups[g].first_mesh, d.groups[g].mesh_count));
+/* The instance level: one TLAS leaf per Instance whose group is not empty, over the world-space box of the instance; hs.nodes is cut back to tlas_first and the new
+ * TLAS appended, hs.inst_recs / hs.blas_tri_ranges rewritten in leaf order.  Boxes are recomputed for the instances marked invalid (all of them at creation). */
+bool build_tlas(HostScene &hs, std::string &err) {
+    const uint32_t n_inst = (uint32_t) hs.insts.size();
+    const BlasInfo &top = hs.blas_top;
     std::vector<PrimBox> boxes; std::vector<InstRec> recs; std::vector<uint32_t> ranges;
     /* the top-level geometry is not a TLAS entry: rays walk its BLAS first and then the TLAS (Accel::top_root, har_accel.h) */
     if (!top.empty) { hs.top_root = top.root; hs.top_first = top.first_tri; hs.top_count = top.tri_count; }
@@ -366,44 +432,50 @@ bool lower_scene(const HarSceneDesc &d, HostScene &hs, std::string &err) {
     static const uint32_t top_last_max = getenv("HAR_TOP_LAST_MAX") ? (uint32_t) atoi(getenv("HAR_TOP_LAST_MAX")) : 256u;
     static const int top_last_forced = getenv("HAR_TOP_LAST") ? atoi(getenv("HAR_TOP_LAST")) : -1;
     hs.top_last = top_last_forced >= 0 ? (uint32_t) top_last_forced : (!top.empty && top.tri_count <= top_last_max ? 3u : 0u);
-    for (uint32_t i = 0; i < d.instance_count; ++i) {
-        const BlasInfo &g = groups[d.instances[i].group];
+    for (uint32_t i = 0; i < n_inst; ++i) {
+        const BlasInfo &g = hs.blas_groups[hs.inst_group[i]];
         if (g.empty) continue;
-        InstRec r{}; std::memcpy(r.to_world, d.instances[i].to_world, 48); std::memcpy(r.to_object, d.instances[i].to_object, 48);
+        InstRec r{}; std::memcpy(r.to_world, hs.insts[i].to_world, 48); std::memcpy(r.to_object, hs.insts[i].to_object, 48);
         r.blas_root = g.root; r.inst_index = i; r.identity = 0;
-        PrimBox b; for (int a = 0; a < 3; ++a) { b.lo[a] = INFINITY; b.hi[a] = -INFINITY; }
-        auto grow = [&](Vec3 q) {
-            const float qq[3] = { q.x, q.y, q.z };
-            for (int a = 0; a < 3; ++a) { b.lo[a] = std::min(b.lo[a], qq[a]); b.hi[a] = std::max(b.hi[a], qq[a]); }
-        };
-        /* Instance::bbox (src/shapes/instance.cpp:93-103) transforms the 8 corners of the group's box, which inflates
-         * the box of a rotated object by up to sqrt(3).  A TLAS leaf only has to bound the instance, so use the exact
-         * bound of the transformed vertices when that is cheap (it cuts instance entries per ray by ~1/4 on the
-         * 1M-triangle benchmark scene) and the reference's corner bound otherwise. */
-        const HarShapeGroup &sg = d.groups[d.instances[i].group];
-        uint64_t nverts = 0;
-        for (uint32_t s = sg.first_mesh; s < sg.first_mesh + sg.mesh_count; ++s) nverts += d.meshes[s].vertex_count;
-        if (nverts * (uint64_t) d.instance_count <= 200000000ull) {
-            for (uint32_t s = sg.first_mesh; s < sg.first_mesh + sg.mesh_count; ++s) {
-                const HarMesh &m = d.meshes[s];
-                for (uint32_t f = 0; f < m.face_count; ++f)          /* only referenced vertices */
-                    for (int k = 0; k < 3; ++k) { const float *v = m.vertex_ptr + 8 * (size_t) m.index_ptr[4 * (size_t) f + k]; grow(xf_point(r.to_world, Vec3(v[0], v[1], v[2]))); }
+        if (!hs.inst_box_valid[i]) {
+            PrimBox b; for (int a = 0; a < 3; ++a) { b.lo[a] = INFINITY; b.hi[a] = -INFINITY; }
+            auto grow = [&](Vec3 q) {
+                const float qq[3] = { q.x, q.y, q.z };
+                for (int a = 0; a < 3; ++a) { b.lo[a] = std::min(b.lo[a], qq[a]); b.hi[a] = std::max(b.hi[a], qq[a]); }
+            };
+            /* Instance::bbox (src/shapes/instance.cpp:93-103) transforms the 8 corners of the group's box, which inflates
+             * the box of a rotated object by up to sqrt(3).  A TLAS leaf only has to bound the instance, so use the exact
+             * bound of the transformed vertices when that is cheap (it cuts instance entries per ray by ~1/4 on the
+             * 1M-triangle benchmark scene) and the reference's corner bound otherwise. */
+            const HarShapeGroup &sg = hs.groups[hs.inst_group[i]];
+            uint64_t nverts = 0;
+            for (uint32_t s = sg.first_mesh; s < sg.first_mesh + sg.mesh_count; ++s) nverts += hs.meshes[s].vertex_count;
+            if (nverts * (uint64_t) n_inst <= 200000000ull) {
+                for (uint32_t s = sg.first_mesh; s < sg.first_mesh + sg.mesh_count; ++s) {
+                    const DMesh &m = hs.meshes[s];
+                    const float *vertex_ptr = hs.verts.data() + 8 * (size_t) m.voff; const uint32_t *index_ptr = hs.faces.data() + 4 * (size_t) m.foff;
+                    for (uint32_t f = 0; f < m.face_count; ++f)          /* only referenced vertices */
+                        for (int k = 0; k < 3; ++k) { const float *v = vertex_ptr + 8 * (size_t) index_ptr[4 * (size_t) f + k]; grow(xf_point(r.to_world, Vec3(v[0], v[1], v[2]))); }
+                }
+            } else {
+                for (int c = 0; c < 8; ++c) grow(xf_point(r.to_world, Vec3(c & 1 ? g.hi[0] : g.lo[0], c & 2 ? g.hi[1] : g.lo[1], c & 4 ? g.hi[2] : g.lo[2])));
             }
-        } else {
-            for (int c = 0; c < 8; ++c) grow(xf_point(r.to_world, Vec3(c & 1 ? g.hi[0] : g.lo[0], c & 2 ? g.hi[1] : g.lo[1], c & 4 ? g.hi[2] : g.lo[2])));
+            pad_prim_box(b);
+            hs.inst_boxes[i] = b; hs.inst_box_valid[i] = 1;
         }
-        pad_prim_box(b);
-        boxes.push_back(b); recs.push_back(r); ranges.push_back(g.first_tri); ranges.push_back(g.tri_count);
+        boxes.push_back(hs.inst_boxes[i]); recs.push_back(r); ranges.push_back(g.first_tri); ranges.push_back(g.tri_count);
     }
-    hs.blas_depth = hs.stats.max_depth;
     std::vector<uint32_t> order;
     Bvh8Stats tstats;
     const uint32_t tlas_leaf = 1u;
     static const float inst_cost = getenv("HAR_BVH_CINST") ? (float) atof(getenv("HAR_BVH_CINST")) : 1.5f;  /* instance entry = ray transform + a BLAS root visit */
+    hs.nodes.resize(hs.tlas_first);
     hs.root = build_bvh8(boxes, hs.nodes, 0, order, &tstats, tlas_leaf, inst_cost, 0);
-    hs.tlas_depth = tstats.max_depth; hs.stats.max_depth = std::max(hs.stats.max_depth, tstats.max_depth);
+    hs.tlas_depth = tstats.max_depth; hs.stats.max_depth = std::max(hs.blas_depth, tstats.max_depth);
     hs.has_tlas = true;
+    hs.inst_recs.clear(); hs.blas_tri_ranges.clear();
     for (uint32_t k : order) { hs.inst_recs.push_back(recs[k]); hs.blas_tri_ranges.push_back(ranges[2 * k]); hs.blas_tri_ranges.push_back(ranges[2 * k + 1]); }
+    (void) err;
     return true;
 }
 

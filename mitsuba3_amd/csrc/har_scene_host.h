@@ -9,7 +9,15 @@
 
 namespace har {
 
-struct HostTexture { std::vector<float> data; uint32_t w, h, mode = 0; };
+struct HostTexture { std::vector<float> data; uint32_t w, h, mode = 0; float uvm[6] = { 1.f, 0.f, 0.f, 0.f, 1.f, 0.f }; };      /* mode carries HAR_TEX_HAS_UV_XF when uvm is not the identity */
+
+/* one bottom-level BVH: its nodes are the range [root, root + node_count) of HostScene::nodes (the root first, children behind their parents), its triangle records
+ * [first_tri, first_tri + tri_count); refit order = its nodes sorted by depth, deepest first (level_begin[l] .. level_begin[l + 1] of HostScene::refit_order) */
+struct BlasInfo {
+    uint32_t root = 0, node_count = 0, first_tri = 0, tri_count = 0; float lo[3], hi[3]; bool empty = true;
+    uint32_t order_first = 0; std::vector<uint32_t> level_begin;      /* into refit_order, relative to order_first; levels from the deepest to the root */
+    uint32_t refits = 0; double built_area = 0.0;                     /* refits since the last build; sum of the node surface areas right after the build (0 = not measured yet) */
+};
 
 struct HostScene {
     std::vector<float> verts;
@@ -30,6 +38,17 @@ struct HostScene {
     std::vector<float> env_tex, env_warp; DEnvmap envmap{}; bool has_envmap = false;
     std::vector<float> emitter_cdf; bool has_mesh_emitters = false;      /* face-area tables of the mesh area lights (emitter type 3) */
     bool has_point_emitters = false;                                     /* emitter type 4 (delta position): shaded by the kernels with the generic emitter code */
+    /* Scene::m_emitter_distr (scene.cpp:120-141): empty when every sampling_weight is 1; else pmf[n] then cdf[n] (DScene::emitter_distr) */
+    std::vector<float> emitter_distr; float emitter_sum = 0.f, emitter_norm = 0.f; uint32_t emitter_valid_lo = 0, emitter_valid_hi = 0;
+    /* fills the texture / emitter-distribution fields of a DScene whose array pointers the caller has set (device or host copies) */
+    void bind_tables(DScene &D, const float *distr_ptr) const {
+        D.emitter_distr = emitter_distr.empty() ? nullptr : distr_ptr; D.emitter_sum = emitter_sum; D.emitter_norm = emitter_norm;
+        D.emitter_valid_lo = emitter_valid_lo; D.emitter_valid_hi = emitter_valid_hi;
+    }
+    DTexture device_texture(size_t i, const float *data_ptr) const {
+        const HostTexture &t = textures[i]; DTexture d{ data_ptr, t.w, t.h, t.mode, 0u, { t.uvm[0], t.uvm[1], t.uvm[2], t.uvm[3], t.uvm[4], t.uvm[5] } };
+        return d;
+    }
     uint32_t root = 0;
     bool has_tlas = false;
     Bvh8Stats stats;
@@ -37,6 +56,13 @@ struct HostScene {
     uint32_t top_last = 0;     /* Accel::top_last */
     uint32_t top_root = 0xffffffffu, top_first = 0, top_count = 0;   /* two-level scenes: BLAS of the top-level geometry (Accel::top_root) */
     uint32_t stack_need() const { return blas_depth + (has_tlas ? tlas_depth + 1 : 0); }
+    /* ---- what the incremental updates need (har_scene_update_instances / _vertices; Scene::parameters_changed -> m_accel.rebuild for the dirty shapes only,
+     * src/render/scene.cpp:517-540, scene_optix.inl:351-372) */
+    std::vector<HarShapeGroup> groups; std::vector<uint32_t> inst_group;      /* the SceneIR split: shape groups, the group of every instance */
+    BlasInfo blas_top; std::vector<BlasInfo> blas_groups;                     /* the bottom-level BVHs */
+    std::vector<uint32_t> refit_order;                                        /* node indices of every BLAS by depth (BlasInfo::level_begin) */
+    std::vector<PrimBox> inst_boxes; std::vector<uint8_t> inst_box_valid;     /* world-space box of every instance (TLAS leaves), recomputed for the instances that moved */
+    uint32_t tlas_first = 0;                                                  /* the TLAS nodes are the tail [tlas_first, nodes.size()) of `nodes` */
 };
 
 /* RoughPlastic::parameters_changed (src/bsdfs/roughplastic.cpp:204-242): m_specular_sampling_weight from the means of the colour slots */
@@ -46,6 +72,10 @@ void quad_gauss_legendre(int n, std::vector<float> &nodes, std::vector<float> &w
 
 /* returns false and fills `err` on invalid input */
 bool lower_scene(const HarSceneDesc &desc, HostScene &out, std::string &err);
+/* the pieces of lower_scene an update re-runs: bounding sphere of the scene for the environment / directional emitters (constant.cpp:72-87), world boxes of the
+ * instances that are not valid + TLAS over them (the BLAS arrays are untouched: hs.nodes is cut back to tlas_first and the new TLAS appended) */
+void update_scene_bounds(HostScene &hs);
+bool build_tlas(HostScene &hs, std::string &err);
 
 /* GaussianFilter ctor (src/rfilters/gaussian.cpp:48-93) + sensor repack */
 bool lower_sensor(const HarSensor &in, DSensor &out, std::string &err);

@@ -101,6 +101,10 @@ HAR_HD void tex_fetch_grad(const DTexture &T, const TexTaps &l, Vec3 &d_du, Vec3
         dv[c] = (float) T.h * (l.w0x * (v01 - v00) + l.w1x * (v11 - v10));
     }
     d_du = Vec3(du[0], du[1], du[2]); d_dv = Vec3(dv[0], dv[1], dv[2]);
+    if (T.mode & HAR_TEX_HAS_UV_XF) {          /* the lookup ran at to_uv * (u, v): back to the surface's (u, v) by the transpose of the linear part (bitmap.cpp:591-598) */
+        const Vec3 a = d_du, b = d_dv;
+        d_du = a * T.uvm[0] + b * T.uvm[3]; d_dv = a * T.uvm[1] + b * T.uvm[4];
+    }
 }
 
 /* geometry record of one adjoint item, written by the shading stage when vertex-position gradients are requested */

@@ -43,7 +43,20 @@ struct Bvh {
     float lo[3], hi[3];
     bool empty() const { return tris.empty(); }
 };
-struct Texture { std::vector<float> data; uint32_t w, h, mode = 0; };
+/* `xf`: the bitmap's m_transform (to_uv, bitmap.cpp:175) as the 3 x 3 matrix of the ScalarAffineTransform3f; `moved` = it is not the identity */
+struct Texture {
+    std::vector<float> data; uint32_t w, h, mode = 0;
+    float xf[3][3] = { { 1.f, 0.f, 0.f }, { 0.f, 1.f, 0.f }, { 0.f, 0.f, 1.f } }; bool moved = false;
+    /* m_transform * Point2f, affine branch of Transform::operator*(Point) (transform.h:322-335): start from the translation column, then one fmadd per input coordinate */
+    void to_texture_space(const float uv_in[2], float uv_out[2]) const {
+        if (!moved) { uv_out[0] = uv_in[0]; uv_out[1] = uv_in[1]; return; }
+        for (int row = 0; row < 2; ++row) {
+            float acc = xf[row][2];
+            for (int col = 0; col < 2; ++col) acc = fmadd(xf[row][col], uv_in[col], acc);
+            uv_out[row] = acc;
+        }
+    }
+};
 
 struct Scene {
     std::vector<Mesh> meshes; uint32_t top_count;
@@ -59,6 +72,8 @@ struct Scene {
     /* AreaLight on a triangle mesh (emitter type 3): DiscreteDistribution over the face areas (Mesh::build_pmf, mesh.cpp:1358-1372) */
     struct AreaPmf { std::vector<float> pmf, cdf; float sum = 0.f, normalization = 0.f; };
     std::vector<AreaPmf> area_pmf;  // indexed by emitter
+    /* Scene::m_emitter_distr (scene.cpp:120-141): set up when some emitter's sampling_weight is not 1; `first` / `last` = DiscreteDistribution::m_valid */
+    struct EmitterChoice { bool weighted = false; AreaPmf table; uint32_t first = 0, last = 0; } choice;
     Bvh top;                       // all top-level meshes
     std::vector<Bvh> group_bvh;    // one per shapegroup
     std::vector<BvhNode> inst_nodes; // BVH over instance world boxes
@@ -349,7 +364,8 @@ static inline uint32_t tex_wrap_pos(int64_t pos, int64_t res, uint32_t mode) {
     if ((mode & 2u) && (r & 1)) m = res - 1 - m;                                   /* odd repetitions (.. -3, -1, 1, 3 ..) run backwards */
     return (uint32_t) m;
 }
-static inline void tex_lookup(const Texture &t, const float uv[2], TexLookup &l) {
+static inline void tex_lookup(const Texture &t, const float uv_surface[2], TexLookup &l) {
+    float uv[2]; t.to_texture_space(uv_surface, uv);                   /* uv = m_transform * si.uv (bitmap.cpp:565,792,831,847) */
     if (t.mode & 1u) {
         int64_t x = (int64_t) std::floor(uv[0] * (float) t.w), y = (int64_t) std::floor(uv[1] * (float) t.h);
         uint32_t i = tex_wrap_pos(y, t.h, t.mode) * t.w + tex_wrap_pos(x, t.w, t.mode);
@@ -449,21 +465,23 @@ static inline void constant_sample_direction(const OrcEmitter &e, const EnvSpher
  * predicate of `sample`, dr::binary_search over [0, n - 1]) and warp::square_to_uniform_triangle (warp.h:153-156) */
 /* DiscreteDistribution::sample (distr_1d.h:117-140, JIT branch): value *= sum; dr::binary_search over [0, n - 1] with the predicate
  * (cdf[i] < value || cdf[i] == 0) && cdf[i] != sum -- the first bucket whose running sum reaches the value, skipping empty buckets at either end */
-static inline uint32_t discrete_sample(const float *cdf, uint32_t n, float sum, float value01) {
+static inline uint32_t discrete_sample(const float *cdf, uint32_t n, float sum, float value01, uint32_t first = 0, uint32_t last = 0xffffffffu, bool scalar_variant = false) {
     const float value = value01 * sum;
-    uint32_t start = 0, end = n - 1, iterations = 0;
+    uint32_t start = first, end = last == 0xffffffffu ? n - 1 : last, iterations = 0;      /* m_valid: [0, n - 1] for tables built on the device (compute_cdf), first / last bin with mass for compute_cdf_scalar */
     if (start < end) { uint32_t span = end - start; iterations = 1; while (span >>= 1) ++iterations; }
     for (uint32_t i = 0; i < iterations; ++i) {
         uint32_t middle = (start + end) >> 1;
         float c = cdf[middle];
-        bool cond = ((c < value) || c == 0.f) && c != sum;
+        bool cond = scalar_variant ? c < value                                   /* distr_1d.h:126-127: the non-JIT predicate */
+                                   : ((c < value) || c == 0.f) && c != sum;
         if (cond) start = std::min(middle + 1, end); else end = middle;
     }
     return start;
 }
 /* DiscreteDistribution::sample_reuse_pmf (distr_1d.h:159-183): the index, the re-used sample (value - cdf_normalized[index - 1]) / pmf_normalized[index] and the pmf */
-static inline uint32_t discrete_sample_reuse(const float *pmf, const float *cdf, uint32_t n, float sum, float normalization, float value01, float &reused, float &pmf_out) {
-    const uint32_t idx = discrete_sample(cdf, n, sum, value01);
+static inline uint32_t discrete_sample_reuse(const float *pmf, const float *cdf, uint32_t n, float sum, float normalization, float value01, float &reused, float &pmf_out,
+                                             uint32_t first = 0, uint32_t last = 0xffffffffu, bool scalar_variant = false) {
+    const uint32_t idx = discrete_sample(cdf, n, sum, value01, first, last, scalar_variant);
     const float pmf_n = pmf[idx] * normalization, cdf_n = idx > 0 ? cdf[idx - 1] * normalization : 0.f;
     reused = (value01 - cdf_n) / pmf_n; pmf_out = pmf_n;
     return idx;
@@ -565,17 +583,31 @@ static inline float mis_weight(float a, float b) {
     return std::isfinite(w) ? w : 0.f;
 }
 
+/* Scene::pdf_emitter (scene.cpp:273-279) / the emitter_pmf of pdf_emitter_direction (:378-388): m_emitter_pmf = 1 / n, or weight * normalization of the distribution */
+static inline float emitter_choice_pmf(const Scene &sc, uint32_t index) {
+    if (!sc.choice.weighted) return 1.f / (float) sc.emitters.size();
+    return sc.choice.table.pmf[index] * sc.choice.table.normalization;
+}
+
 /* Scene::sample_emitter_direction (src/render/scene.cpp:316-366), JIT branch */
 static inline bool sample_emitter_direction(const Scene &sc, const SI &si, float sx, float sy, DS &ds, V3 &spec,
-                                            OrcStats &st, Ray *shadow_out = nullptr, float *unit = nullptr) {
+                                            OrcStats &st, Ray *shadow_out = nullptr, float *unit = nullptr, bool scalar_variant = false) {
     uint32_t n = (uint32_t) sc.emitters.size();
     if (n == 0) { ds = DS(); spec = V3(0.f); return false; }
     uint32_t index = 0; float weight = 1.f, pmf = 1.f / (float) n;
-    if (n > 1) {                                   // sample_emitter, scene.cpp:248-271
+    const Scene::EmitterChoice &ch = sc.choice;
+    if (n > 1 && ch.weighted) {                    // sample_emitter with m_emitter_distr (scene.cpp:258-261): sample_reuse_pmf, emitter_weight = rcp(pmf)
+        float chosen_pmf;
+        index = discrete_sample_reuse(ch.table.pmf.data(), ch.table.cdf.data(), n, ch.table.sum, ch.table.normalization, sx, sx, chosen_pmf, ch.first, ch.last, scalar_variant);
+        weight = rcp(chosen_pmf);
+    } else if (n > 1) {                            // sample_emitter, scene.cpp:248-271
         float scaled = sx * (float) n;
         index = std::min((uint32_t) scaled, n - 1u);
         weight = (float) n; sx = scaled - (float) index;
     }
+    /* pdf_emitter (scene.cpp:273-279): eval_pmf_normalized -- in JIT variants also when there is one emitter (:326); scalar variants with one emitter take the
+       branch at :351-354, which samples it directly and applies no selection probability */
+    if (ch.weighted) pmf = (scalar_variant && n == 1) ? 1.f : emitter_choice_pmf(sc, index);
     if (unit) *unit = 0.f;
     if (sc.emitters[index].type == 1) { EnvSphere bs; bs.center = V3(sc.env_center[0], sc.env_center[1], sc.env_center[2]); bs.radius = sc.env_radius; constant_sample_direction(sc.emitters[index], bs, si.p, sx, sy, ds, spec, unit); }
     else if (sc.emitters[index].type == 2) {       // EnvironmentMapEmitter::sample_direction (envmap.cpp:284-323)
@@ -785,7 +817,7 @@ static V3 path_sample(const Scene &sc, Pcg32 &rng, Ray ray, uint32_t max_depth, 
             V3 rel = si.p - prev_p; ds.dist = norm(rel); ds.d = si.valid() ? div(rel, ds.dist) : -si.wi;
             const OrcEmitter &e = sc.emitters[emitter];
             float em_pdf = 0.f;
-            if (!prev_bsdf_delta) em_pdf = (e.type == 1 ? InvFourPi : e.type == 2 ? sc.envmap.pdf_direction(ds.d) : emitter_pdf_direction(e, ds)) * (1.f / (float) sc.emitters.size());
+            if (!prev_bsdf_delta) em_pdf = (e.type == 1 ? InvFourPi : e.type == 2 ? sc.envmap.pdf_direction(ds.d) : emitter_pdf_direction(e, ds)) * emitter_choice_pmf(sc, (uint32_t) emitter);
             float mis_bsdf = mis_weight(prev_bsdf_pdf, em_pdf);
             bool facing = (e.type != 0 && e.type != 3) || si.wi.z > 0.f;                                                                   // area.cpp:83-90, constant.cpp:90-94
             V3 rad = e.type == 2 ? sc.envmap.eval(-si.wi) : V3(e.radiance[0], e.radiance[1], e.radiance[2]);             // envmap.cpp:228-236
@@ -808,7 +840,7 @@ static V3 path_sample(const Scene &sc, Pcg32 &rng, Ray ray, uint32_t max_depth, 
         float ex = 0.f, ey = 0.f;
         if (!scalar || active_em) { ex = rng.next_float32(); ey = rng.next_float32(); }
         DS ds; V3 em_weight(0.f), wo(0.f);
-        if (active_em) active_em = sample_emitter_direction(sc, si, ex, ey, ds, em_weight, st);
+        if (active_em) active_em = sample_emitter_direction(sc, si, ex, ey, ds, em_weight, st, nullptr, nullptr, scalar);
         active_em &= ds.pdf != 0.f;
         if (active_em) wo = si.to_local(ds.d);
         float s1 = rng.next_float32();
@@ -949,7 +981,9 @@ static AttachedSI attach_si(const Scene &sc, const Ray &ray, const PI &pi, const
 /* bilinear, repeat-wrapped texture lookup (tex_lookup / tex_eval above) as a function of attached texture coordinates */
 static inline Dn3 tex_eval_dual(const Texture &t, const TexLookup &l, const Dn uv[2]) {
     if (t.mode & 1u) return Dn3(Dn((double) t.data[3 * (size_t) l.idx[0]]), Dn((double) t.data[3 * (size_t) l.idx[0] + 1]), Dn((double) t.data[3 * (size_t) l.idx[0] + 2]));     /* nearest: constant in uv */
-    Dn px = uv[0] * (double) t.w - Dn(0.5), py = uv[1] * (double) t.h - Dn(0.5);
+    /* the lookup position in texture space: m_transform * uv, carried with its derivative (an affine map: the duals go through the linear part) */
+    const Dn tu = uv[0] * (double) t.xf[0][0] + uv[1] * (double) t.xf[0][1] + Dn((double) t.xf[0][2]), tv = uv[0] * (double) t.xf[1][0] + uv[1] * (double) t.xf[1][1] + Dn((double) t.xf[1][2]);
+    Dn px = tu * (double) t.w - Dn(0.5), py = tv * (double) t.h - Dn(0.5);
     Dn w1x = replace_grad((double) l.w[1], px), w1y = replace_grad((double) l.w[3], py), w0x = Dn(1.0) - w1x, w0y = Dn(1.0) - w1y;
     Dn out[3];
     for (int c = 0; c < 3; ++c) {
@@ -1263,7 +1297,7 @@ static V3 prb_sample(const Scene &sc, Pcg32 &rng, Ray ray, uint32_t max_depth, u
             float em_pdf = 0.f;
             DS ds; ds.p = si.p; ds.n = si.sn;
             V3 rel = si.p - prev_p; ds.dist = norm(rel); ds.d = si.valid() ? div(rel, ds.dist) : -si.wi;
-            if (emitter >= 0 && !bsdf_delta_prev) em_pdf = (sc.emitters[emitter].type == 1 ? InvFourPi : sc.emitters[emitter].type == 2 ? sc.envmap.pdf_direction(ds.d) : emitter_pdf_direction(sc.emitters[emitter], ds)) * (1.f / (float) sc.emitters.size());
+            if (emitter >= 0 && !bsdf_delta_prev) em_pdf = (sc.emitters[emitter].type == 1 ? InvFourPi : sc.emitters[emitter].type == 2 ? sc.envmap.pdf_direction(ds.d) : emitter_pdf_direction(sc.emitters[emitter], ds)) * emitter_choice_pmf(sc, (uint32_t) emitter);
             float mis = mis_weight(bsdf_pdf_prev, em_pdf);
             if (emitter >= 0 && !(sc.hide_emitters && depth == 0 && !si.valid())) {          // prb.py:146-148: active_next masks emitter.eval
                 const OrcEmitter &e = sc.emitters[emitter];
@@ -1764,10 +1798,27 @@ void *orc_scene_create(const OrcSceneDesc *d) {
     for (uint32_t i = 0; i < d->texture_count; ++i) {
         Texture t; t.w = d->textures[i].width; t.h = d->textures[i].height; t.mode = d->textures[i].mode;
         t.data.assign(d->textures[i].data, d->textures[i].data + 3 * (size_t) t.w * t.h);
+        const float *m = d->textures[i].to_uv; bool unset = true;
+        for (int k = 0; k < 6; ++k) unset = unset && m[k] == 0.f;
+        if (!unset) { for (int r = 0; r < 2; ++r) for (int c = 0; c < 3; ++c) { t.xf[r][c] = m[3 * r + c]; t.moved = t.moved || m[3 * r + c] != (r == c ? 1.f : 0.f); } }
         sc->textures.push_back(std::move(t));
     }
     sc->emitters.assign(d->emitters, d->emitters + d->emitter_count);
     sc->area_pmf.resize(sc->emitters.size());
+    {   /* Scene::update_emitter_sampling_distribution (scene.cpp:120-141) -> DiscreteDistribution(const ScalarFloat *, size) -> compute_cdf_scalar (distr_1d.h:236-266) */
+        Scene::EmitterChoice &ch = sc->choice;
+        for (const OrcEmitter &e : sc->emitters) { if (!(e.sampling_weight >= 0.f)) { delete sc; return nullptr; } ch.weighted = ch.weighted || e.sampling_weight != 1.f; }
+        if (ch.weighted) {
+            double running = 0.0; bool seen = false;
+            for (uint32_t i = 0; i < sc->emitters.size(); ++i) {
+                const float w = sc->emitters[i].sampling_weight;
+                running += (double) w; ch.table.pmf.push_back(w); ch.table.cdf.push_back((float) running);
+                if (w > 0.f) { if (!seen) ch.first = i; ch.last = i; seen = true; }
+            }
+            if (!seen) { delete sc; return nullptr; }                       /* "no probability mass found!" */
+            ch.table.sum = ch.table.cdf[ch.last]; ch.table.normalization = rcp(ch.table.sum);
+        }
+    }
     for (uint32_t i = 0; i < sc->emitters.size(); ++i) {
         const OrcEmitter e = sc->emitters[i];
         if (e.type == 1 || e.type == 2) sc->env = (int) i;

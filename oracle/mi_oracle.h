@@ -71,7 +71,9 @@ typedef struct OrcBSDF {
 
 /* bitmap texture, H x W x 3 f32 (src/textures/bitmap.cpp:175-206); mode: bit 0 filter_type nearest (else bilinear), bits 1-2 wrap_mode 0 repeat / 2 mirror / 4 clamp
  * (field for field HarTexture) */
-typedef struct OrcTexture { const float *data; uint32_t width, height; uint32_t mode, reserved; } OrcTexture;
+/* to_uv: BitmapTexture's `to_uv` (src/textures/bitmap.cpp:175), the top two rows of the 3 x 3 homogeneous matrix of a ScalarAffineTransform3f, row-major;
+ * all zero = unset (identity) */
+typedef struct OrcTexture { const float *data; uint32_t width, height; uint32_t mode, reserved; float to_uv[6]; } OrcTexture;
 
 typedef struct OrcEmitter {
     uint32_t type;        /* 0 = area light on a rectangle, 1 = constant environment (src/emitters/constant.cpp; radiance only),
@@ -88,6 +90,7 @@ typedef struct OrcEmitter {
     float normal[3];      /* m_frame.n (rectangle.cpp:118) */
     float inv_area;       /* m_inv_surface_area (rectangle.cpp:123) */
     float to_local[12];   /* inverse of to_world as the reference's Transform tracks it (type 2 only) */
+    float sampling_weight; /* Emitter::m_sampling_weight (src/render/emitter.cpp:9) */
 } OrcEmitter;
 
 typedef struct OrcSceneDesc {

@@ -38,12 +38,12 @@ class BSDF(C.Structure):
 
 
 class Texture(C.Structure):
-    _fields_ = [("data", c_f32p), ("width", C.c_uint32), ("height", C.c_uint32), ("mode", C.c_uint32), ("reserved", C.c_uint32)]
+    _fields_ = [("data", c_f32p), ("width", C.c_uint32), ("height", C.c_uint32), ("mode", C.c_uint32), ("reserved", C.c_uint32), ("to_uv", C.c_float * 6)]
 
 
 class Emitter(C.Structure):
     _fields_ = [("type", C.c_uint32), ("mesh", C.c_uint32), ("radiance", C.c_float * 3),
-                ("to_world", C.c_float * 12), ("normal", C.c_float * 3), ("inv_area", C.c_float), ("to_local", C.c_float * 12)]
+                ("to_world", C.c_float * 12), ("normal", C.c_float * 3), ("inv_area", C.c_float), ("to_local", C.c_float * 12), ("sampling_weight", C.c_float)]
 
 
 class SceneDesc(C.Structure):
@@ -284,6 +284,7 @@ class SceneData:
         self.bsdfs = []      # (type, texture, rgb)
         self.textures = []   # HxWx3 float32
         self.texture_modes = []   # per texture: filter_type | wrap_mode (OrcTexture::mode), default 0 = bilinear + repeat
+        self.texture_to_uv = []   # per texture: None or the six floats of the bitmap's `to_uv` (row-major 2 x 3)
         self.emitters = []   # dict(mesh, radiance, to_world12, normal, inv_area)
         self._keep = []
 
@@ -323,6 +324,9 @@ class SceneData:
         texs = (TX * max(1, len(self.textures)))()
         for i, t in enumerate(self.textures):
             texs[i].data = fp(t); texs[i].height = t.shape[0]; texs[i].width = t.shape[1]; texs[i].mode = self.texture_modes[i] if i < len(self.texture_modes) else 0
+            uvm = self.texture_to_uv[i] if i < len(self.texture_to_uv) else None
+            if uvm is not None:
+                texs[i].to_uv = (C.c_float * 6)(*[float(x) for x in uvm])
         ems = (E * max(1, len(self.emitters)))()
         for i, e in enumerate(self.emitters):
             ems[i].type = int(e.get("type", 0)); ems[i].mesh = e["mesh"]
@@ -331,6 +335,7 @@ class SceneData:
             ems[i].normal = (C.c_float * 3)(*[float(x) for x in e["normal"]])
             ems[i].inv_area = float(e["inv_area"])
             ems[i].to_local = (C.c_float * 12)(*[float(x) for x in e.get("to_local", [1, 0, 0, 0, 1, 0, 0, 0, 1, 0, 0, 0])])
+            ems[i].sampling_weight = float(e.get("sampling_weight", 1.0))
         d = SD()
         d.meshes = meshes; d.mesh_count = len(self.meshes); d.top_mesh_count = self.top_mesh_count
         d.groups = groups; d.group_count = len(self.groups)
@@ -749,6 +754,8 @@ def render_weights(sensor, seed, spp, lanes=None, threads=0):
 def scene_from_product(scene):
     """Feed the product's flat scene arrays (mitsuba3_amd.Scene) to the oracle unchanged."""
     sd = SceneData()
+    if hasattr(scene, "sync_host"):
+        scene.sync_host()          # values params.update() pushed device-to-device -> the numpy mirrors read below
     for m in scene.meshes:
         sd.add_mesh(m["V"], m["F"], m["bsdf"], m["emitter"], m["flags"])
     sd.top_mesh_count = scene.top_mesh_count
@@ -758,6 +765,7 @@ def scene_from_product(scene):
                  dict(flags=b.flags, reflectance2=b.value2, alpha_u=b.alpha_u, alpha_v=b.alpha_v, eta=b.eta, eta_c=b.eta_c, k_c=b.k_c,
                       back=b.back.index if b.back is not None else -1)) for b in scene.bsdf_objs]
     sd.textures = list(scene.textures); sd.texture_modes = list(getattr(scene, 'texture_modes', [])); sd.emitters = list(scene.emitters)
+    sd.texture_to_uv = list(getattr(scene, 'texture_to_uv', []))
     s = Sensor()
     C.memmove(C.byref(s), C.byref(scene.sensors()[0].har), C.sizeof(s))
     return OracleScene(sd), s

@@ -1,0 +1,141 @@
+"""Round-5 rows a10 / a13 on the device, through the C ABI, against the oracle:
+ * emitters with `sampling_weight` (Scene::m_emitter_distr, src/render/scene.cpp:120-141, 248-279, 378-388): forward 1e-4 with equal vertex counts, prb
+   gradients 1e-3 (albedos, bitmap texels, emitter radiances), weights that include an environment emitter and a never-sampled emitter;
+ * bitmap `to_uv` (src/textures/bitmap.cpp:175, 565, 847): forward, texel gradients through the transformed taps, vertex-position gradients through the
+   transformed lookup (bitmap.cpp:591-598)."""
+import numpy as np
+import pytest
+
+from tests.test_scene_properties_cpu import two_light_scene, textured_scene
+
+pytestmark = pytest.mark.gpu
+
+
+def rel_l2(a, b):
+    return float(np.linalg.norm(a.astype(np.float64) - b.astype(np.float64)) / np.linalg.norm(b.astype(np.float64)))
+
+
+@pytest.mark.parametrize("weights", [(1.0, 3.0, None), (0.25, 1.0, None), (2.0, 2.0, None), (1.0, 3.0, 0.5), (1.0, 0.0, None)])
+def test_forward_parity_with_weighted_emitters(mi, O, weights):
+    res, spp = 64, 32
+    scene = mi.load_dict(two_light_scene(mi, weights[0], weights[1], res=res, sky=weights[2]))
+    osc, sensor = O.scene_from_product(scene)
+    img = mi.render(scene, spp=spp, seed=5).cpu().numpy()
+    st = scene.integrator().stats()
+    ref, ost = osc.render_path(sensor, seed=5, spp=spp, max_depth=scene.integrator().max_depth, rr_depth=scene.integrator().rr_depth)
+    assert np.abs(ref).max() > 0 and rel_l2(img, ref) < 1e-4, (weights, rel_l2(img, ref))            # north_star forward tolerance
+    assert st["paths"] == res * res * spp and st["vertices"] == ost.vertices, (weights, st, ost.vertices)
+    if weights[:2] != (2.0, 2.0):
+        # ... and it is not the uniform-selection picture: ignoring the property would be seen
+        uni = mi.render(mi.load_dict(two_light_scene(mi, 1.0, 1.0, res=res, sky=None if weights[2] is None else 1.0)), spp=spp, seed=5).cpu().numpy()
+        assert rel_l2(uni, ref) > 1e-3
+
+
+def test_single_weighted_emitter_and_materials(mi, O):
+    """one emitter of weight 3 (pdf_emitter = 3 * (1 / 3), scene.cpp:326-338) on the materials scene: the generic shading kernel with a distribution"""
+    res, spp = 48, 16
+    d = mi.instanced_spheres_scene(width=res, height=res, spp=spp, grid=3, n_u=16, n_v=8, materials=True)
+    lights = [k for k, v in d.items() if isinstance(v, dict) and isinstance(v.get("emitter"), dict)]
+    assert lights
+    for k in lights:
+        d[k]["emitter"]["sampling_weight"] = 3.0
+    scene = mi.load_dict(d)
+    osc, sensor = O.scene_from_product(scene)
+    img = mi.render(scene, spp=spp, seed=2).cpu().numpy()
+    ref, ost = osc.render_path(sensor, seed=2, spp=spp, max_depth=scene.integrator().max_depth, rr_depth=scene.integrator().rr_depth)
+    assert rel_l2(img, ref) < 1e-4 and scene.integrator().stats()["vertices"] == ost.vertices
+
+
+def test_prb_gradients_with_weighted_emitters(mi, O):
+    res, spp, md = 48, 32, 6
+    d = two_light_scene(mi, 1.0, 3.0, res=res, sky=0.5)
+    tex = np.random.default_rng(2).uniform(0.2, 0.9, (16, 16, 3)).astype(np.float32)
+    d["white"] = {"type": "diffuse", "reflectance": {"type": "bitmap", "data": tex}}
+    d["integrator"] = {"type": "prb", "max_depth": md}
+    scene = mi.load_dict(d)
+    osc, sensor = O.scene_from_product(scene)
+    keys = scene._param_keys()
+    grad_in = np.random.default_rng(7).uniform(0.5, 1.5, (res, res, 3)).astype(np.float32)
+    grads = scene.integrator().render_backward(scene, None, grad_in, seed=3, spp=spp)
+    g_refl, g_tex, g_emit, _ = osc.render_prb_backward_emitters(sensor, grad_in, seed=3, spp=spp, max_depth=md)
+    ek = {k: v[1] for k, v in keys.items() if v[0] == "emit"}
+    assert len(ek) == 3
+    got = np.stack([grads[k].cpu().numpy() for k in ek]); want = np.stack([g_emit[i] for i in ek.values()])
+    assert np.abs(want).min() > 0 and rel_l2(got, want) < 1e-3, (got, want)                          # north_star PRB tolerance
+    n_tex = 0
+    for k, (kind, b) in keys.items():
+        if kind == "tex":
+            assert rel_l2(grads[k].cpu().numpy(), g_tex[b.tex_index]) < 1e-3, k; n_tex += 1
+        elif kind == "rgb":
+            assert rel_l2(grads[k].cpu().numpy(), g_refl[b.index]) < 1e-3, k
+    assert n_tex == 1
+    # the primal image of the prb integrator
+    img = scene.integrator().render(scene, seed=3, spp=spp).cpu().numpy()
+    ref, _ = osc.render_prb(sensor, seed=3, spp=spp, max_depth=md)
+    assert rel_l2(img, ref) < 1e-4
+
+
+@pytest.mark.parametrize("filter_type,wrap_mode", [("bilinear", "repeat"), ("nearest", "mirror"), ("bilinear", "clamp")])
+def test_to_uv_forward_and_texel_gradients(mi, O, filter_type, wrap_mode):
+    res, spp, md = 48, 32, 6
+    T = mi.ScalarTransform3f
+    d, tex = textured_scene(mi, T().translate([0.1, 0.3]).rotate(-20.0).scale([3.0, 2.0]), res=res, filter_type=filter_type, wrap_mode=wrap_mode, tex_res=16)
+    scene = mi.load_dict(d)
+    osc, sensor = O.scene_from_product(scene)
+    img = mi.render(scene, spp=spp, seed=9).cpu().numpy()
+    ref, ost = osc.render_path(sensor, seed=9, spp=spp, max_depth=scene.integrator().max_depth, rr_depth=scene.integrator().rr_depth)
+    assert rel_l2(img, ref) < 1e-4 and scene.integrator().stats()["vertices"] == ost.vertices
+    d0, _ = textured_scene(mi, None, res=res, filter_type=filter_type, wrap_mode=wrap_mode, tex_res=16)
+    plain = mi.render(mi.load_dict(d0), spp=spp, seed=9).cpu().numpy()
+    assert rel_l2(plain, ref) > 1e-2                                     # the transform is in the picture
+    d["integrator"] = {"type": "prb", "max_depth": md}
+    scene = mi.load_dict(d)
+    osc, sensor = O.scene_from_product(scene)
+    grad_in = np.random.default_rng(4).uniform(0.5, 1.5, (res, res, 3)).astype(np.float32)
+    grads = scene.integrator().render_backward(scene, None, grad_in, seed=3, spp=spp)
+    g_refl, g_tex, _ = osc.render_prb_backward(sensor, grad_in, seed=3, spp=spp, max_depth=md)
+    k = [k for k, v in scene._param_keys().items() if v[0] == "tex"][0]
+    ti = scene._param_keys()[k][1].tex_index
+    assert np.abs(g_tex[ti]).max() > 0 and rel_l2(grads[k].cpu().numpy(), g_tex[ti]) < 1e-3
+
+
+def test_to_uv_through_mi_render_autograd_and_update(mi, O):
+    """the public route: mi.traverse -> requires_grad -> mi.render -> backward, then params.update() with new texels: the updated scene renders like a fresh one"""
+    import torch
+    T = mi.ScalarTransform3f
+    d, tex = textured_scene(mi, T().rotate(40.0).scale([2.0, 2.0]), res=32, tex_res=8)
+    d["integrator"] = {"type": "prb", "max_depth": 5}
+    scene = mi.load_dict(d)
+    params = mi.traverse(scene)
+    key = [k for k in params if k.endswith(".data")][0]
+    params[key].requires_grad_()
+    out = mi.render(scene, params, spp=16, seed=1)
+    (out ** 2).mean().backward()
+    g = params[key].grad.cpu().numpy()
+    assert np.isfinite(g).all() and np.abs(g).max() > 0
+    new = (tex * 0.5 + 0.25).astype(np.float32)
+    params[key] = torch.tensor(new, device="cuda"); params.update()
+    a = mi.render(scene, spp=16, seed=1).detach().cpu().numpy()
+    d2, _ = textured_scene(mi, T().rotate(40.0).scale([2.0, 2.0]), res=32, tex_res=8)
+    d2["white"]["reflectance"]["data"] = new; d2["integrator"] = {"type": "prb", "max_depth": 5}
+    b = mi.render(mi.load_dict(d2), spp=16, seed=1).cpu().numpy()
+    assert rel_l2(a, b) < 1e-6                 # the film is summed with float atomics: equal up to the order of the additions
+
+
+def test_vertex_position_gradients_through_a_transformed_texture(mi, O):
+    """shape gradients of a mesh whose albedo is a bitmap with `to_uv`: d rho / d uv runs through the transpose of the transform's linear part (bitmap.cpp:591-598)"""
+    res, spp, md = 32, 64, 4
+    T = mi.ScalarTransform3f
+    d, tex = textured_scene(mi, T().rotate(30.0).scale([1.5, 2.5]), res=res, tex_res=8)
+    d["integrator"] = {"type": "prb", "max_depth": md, "shape_gradients": ["floor.vertex_positions"]}
+    scene = mi.load_dict(d)
+    osc, sensor = O.scene_from_product(scene)
+    grad_in = np.random.default_rng(8).uniform(0.5, 1.5, (res, res, 3)).astype(np.float32)
+    grads = scene.integrator().render_backward(scene, None, grad_in, seed=3, spp=spp)
+    mesh = scene._position_keys()["floor.vertex_positions"]
+    want, _, w_tex, _ = osc.render_prb_backward_shape(sensor, grad_in, [mesh], seed=3, spp=spp, max_depth=md)
+    got = grads["floor.vertex_positions"].cpu().numpy().reshape(-1, 3)
+    scale = np.abs(want[mesh]).max()
+    assert scale > 0 and np.abs(got - want[mesh]).max() < 2e-3 * scale, np.abs(got - want[mesh]).max() / scale
+    k = [k for k, v in scene._param_keys().items() if v[0] == "tex"][0]
+    assert rel_l2(grads[k].cpu().numpy(), w_tex[scene._param_keys()[k][1].tex_index]) < 1e-3
