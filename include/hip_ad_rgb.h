@@ -203,6 +203,28 @@ int har_scene_set_texture(HarScene scene, uint32_t texture, const float *data);
 int har_scene_set_texture_device(HarScene scene, uint32_t texture, const float *data, void *stream);
 int har_scene_set_reflectance_device(HarScene scene, uint32_t bsdf, const float *rgb, void *stream);
 int har_scene_set_emitter_radiance_device(HarScene scene, uint32_t emitter, const float *rgb, void *stream);
+/* ------------------------------------------------------------------------
+ *  Incremental updates of the acceleration data.  The reference rebuilds what a changed shape needs, not the scene: Scene::parameters_changed calls
+ *  m_accel.rebuild only when a shape is dirty (src/render/scene.cpp:517-540); the OptiX backend re-builds the dirty geometry and refreshes the instance level
+ *  with stable handles (src/render/scene_optix.inl:351-372).  Both calls keep the HarScene handle, every device array and every integrator workspace.
+ *   - har_scene_update_instances: new `to_world` / `to_object` (column-major 3 x 4 each, HOST) for instances [first, first + count): the instance level (TLAS,
+ *     a host build over <= instance_count boxes) is rebuilt and rewritten in place, the bottom-level BVHs are not touched;
+ *   - har_scene_update_vertices: new packed vertex records (HOST, vertex_count x 8 floats as in HarMesh::vertex_ptr; the caller has regenerated the normals,
+ *     Mesh::parameters_changed, mesh.cpp:876-878) of mesh `mesh`: the BLAS that holds it is REFITTED on the device -- triangle records rewritten, node boxes
+ *     re-quantised bottom-up with the builder's own arithmetic -- and the instance level rebuilt if the mesh is instanced.  Ray queries stay exact (the boxes
+ *     only prune); what a refit cannot do is re-sort triangles that moved far, so the call watches the tree's cost (sum of node areas / root area):
+ *       0                           done
+ *       HAR_UPDATE_REBUILD_ADVISED  done -- the scene is valid -- but the cost has grown by more than HAR_REFIT_MAX_INFLATION (default 1.5x) against the tree as built at the last
+ *                                   build (or HAR_REFIT_MAX_STEPS refits have passed): a new scene would trace faster
+ *       HAR_UPDATE_NEEDS_NEW_SCENE  not done: the mesh carries an area emitter (har_last_error says so); create a new scene
+ *       1                           error
+ *  Both synchronise `stream` before they return (their sources are pageable host memory). */
+#define HAR_UPDATE_NEEDS_NEW_SCENE 2
+#define HAR_UPDATE_REBUILD_ADVISED 3
+int har_scene_update_instances(HarScene scene, uint32_t first, uint32_t count, const float *to_world, const float *to_object, void *stream);
+int har_scene_update_vertices(HarScene scene, uint32_t mesh, const float *vertices, void *stream);
+/* info[0] = refits since the scene was created, info[1] = cost figure of the last refitted BLAS, info[2] = its ratio to the figure at the first refit, info[3] = nodes */
+int har_scene_refit_info(HarScene scene, double info[4]);
 /* accel statistics: node count, triangle count, bytes */
 int har_scene_accel_info(HarScene scene, uint64_t info[4]);
 

@@ -1173,8 +1173,13 @@ class Integrator:
         state_out = torch.empty_like(sampler.state) if self.type == 'path' else None
         sd = sampler.m_seed_value if seed is None else (sampler.m_base_seed + int(seed)) & 0xffffffff
         # `active`: a masked ray never enters the loop -- zero radiance, invalid, and its sampler stream is not advanced (handled inside the call)
+        # the mask tensor must OUTLIVE the call: a temporary would go back to the allocator pool the moment its pointer is taken, and the workspace the call
+        # allocates through the same pool on first use could be handed its block (round 4's latent fault: the first masked sample() of an integrator read a
+        # mask that the workspace's counters had overwritten)
+        mask = _mask(active, n)
         check(lib().har_integrator_sample(scene._handle(), self._handle(), sd, 0, n, _ptr(ray.o), _ptr(ray.d), _ptr(ray.maxt), _ptr(sampler.state),
-                                          _ptr(_mask(active, n)), _ptr(rgb), _ptr(valid), _ptr(state_out), _stream()))
+                                          _ptr(mask), _ptr(rgb), _ptr(valid), _ptr(state_out), _stream()))
+        del mask
         if state_out is not None:
             sampler.state = state_out
         return rgb, valid.to(torch.bool)
@@ -1585,7 +1590,8 @@ class Scene:
         torch = _torch(); dev = _device(); n = len(ray)
         t = torch.empty(n, dtype=torch.float32, device=dev); u = torch.empty_like(t); v = torch.empty_like(t)
         prim = torch.empty(n, dtype=torch.int32, device=dev); shape = torch.empty_like(prim); inst = torch.empty_like(prim)
-        check(lib().har_ray_intersect_preliminary(self._handle(), n, _ptr(ray.o), _ptr(ray.d), _ptr(ray.maxt), _ptr(_mask(active, n)), 1 if naive else 0,
+        mask = _mask(active, n)          # kept alive across the call (see Integrator.sample)
+        check(lib().har_ray_intersect_preliminary(self._handle(), n, _ptr(ray.o), _ptr(ray.d), _ptr(ray.maxt), _ptr(mask), 1 if naive else 0,
                                                   _ptr(t), _ptr(u), _ptr(v), _ptr(prim), _ptr(shape), _ptr(inst), _stream()))
         return PreliminaryIntersection3f(self, t, u, v, prim, shape, inst)
 
@@ -1599,7 +1605,8 @@ class Scene:
         prim = torch.empty(n, dtype=torch.int32, device=dev); shape = torch.empty_like(prim); inst = torch.empty_like(prim)
         out = torch.empty((33, n), dtype=torch.float32, device=dev)
         flags = RayFlags.Default if ray_flags is None else int(ray_flags)
-        check(lib().har_ray_intersect(self._handle(), n, _ptr(ray.o), _ptr(ray.d), _ptr(ray.maxt), flags, _ptr(_mask(active, n)), 1 if naive else 0,
+        mask = _mask(active, n)          # kept alive across the call (see Integrator.sample)
+        check(lib().har_ray_intersect(self._handle(), n, _ptr(ray.o), _ptr(ray.d), _ptr(ray.maxt), flags, _ptr(mask), 1 if naive else 0,
                                       _ptr(t), _ptr(u), _ptr(v), _ptr(prim), _ptr(shape), _ptr(inst), _ptr(out), _stream()))
         si = SurfaceInteraction3f(out)
         si.prim_index = prim; si.shape_index = shape; si.instance = inst
@@ -1615,14 +1622,16 @@ class Scene:
     def ray_test(self, ray, coherent=False, active=True, naive=False):
         torch = _torch(); dev = _device(); n = len(ray)
         hit = torch.empty(n, dtype=torch.uint8, device=dev)
-        check(lib().har_ray_test(self._handle(), n, _ptr(ray.o), _ptr(ray.d), _ptr(ray.maxt), _ptr(_mask(active, n)), 1 if naive else 0, _ptr(hit), _stream()))
+        mask = _mask(active, n)          # kept alive across the call (see Integrator.sample)
+        check(lib().har_ray_test(self._handle(), n, _ptr(ray.o), _ptr(ray.d), _ptr(ray.maxt), _ptr(mask), 1 if naive else 0, _ptr(hit), _stream()))
         return hit.bool()
 
     def _compute_si(self, ray, pi, ray_flags=1, active=True):
         torch = _torch(); dev = _device(); n = len(ray)
         out = torch.empty((33, n), dtype=torch.float32, device=dev)
+        mask = _mask(active, n)          # kept alive across the call (see Integrator.sample)
         check(lib().har_compute_surface_interaction(self._handle(), n, _ptr(ray.o), _ptr(ray.d), _ptr(pi.t), _ptr(pi.prim_uv[0]), _ptr(pi.prim_uv[1]),
-                                                    _ptr(pi.prim_index), _ptr(pi.shape_index), _ptr(pi.instance), int(ray_flags), _ptr(_mask(active, n)),
+                                                    _ptr(pi.prim_index), _ptr(pi.shape_index), _ptr(pi.instance), int(ray_flags), _ptr(mask),
                                                     _ptr(out), _stream()))
         return SurfaceInteraction3f(out)
 
@@ -1733,11 +1742,29 @@ class Scene:
         return m
 
     def _set_instance_matrix(self, i, m4):
-        """params['<instance>.to_world'] = ...; params.update(): the instance-level acceleration structure is rebuilt with the next scene handle"""
-        m = np.asarray(m4, np.float64).reshape(4, 4); inv = np.linalg.inv(m)
-        self.instances[i] = (self.instances[i][0], [float(x) for x in m[:3, :].T.reshape(-1)], [float(x) for x in inv[:3, :].T.reshape(-1)])
-        if self._h is not None:
-            lib().har_scene_destroy(self._h); self._h = None
+        self._set_instance_matrices([(i, m4)])
+
+    def _set_instance_matrices(self, items):
+        """params['<instance>.to_world'] = ...; params.update(): the instance level of the acceleration structure is rebuilt IN PLACE (har_scene_update_instances:
+        the bottom-level BVHs, the scene handle and every workspace stay; Scene::parameters_changed, scene.cpp:517-540 / scene_optix.inl:351-372) -- one call per
+        run of consecutive instances"""
+        recs = {}
+        for i, m4 in items:
+            m = np.asarray(m4, np.float64).reshape(4, 4); inv = np.linalg.inv(m)
+            tw = _f32(m[:3, :].T.reshape(-1)); to = _f32(inv[:3, :].T.reshape(-1))
+            self.instances[i] = (self.instances[i][0], [float(x) for x in tw], [float(x) for x in to])
+            recs[int(i)] = (tw, to)
+        if self._h is None or not recs:
+            return
+        idx = sorted(recs); start = 0
+        while start < len(idx):
+            end = start
+            while end + 1 < len(idx) and idx[end + 1] == idx[end] + 1:
+                end += 1
+            tw = np.ascontiguousarray(np.concatenate([recs[i][0] for i in idx[start:end + 1]]), np.float32)
+            to = np.ascontiguousarray(np.concatenate([recs[i][1] for i in idx[start:end + 1]]), np.float32)
+            check(lib().har_scene_update_instances(self._h, idx[start], end - start + 1, _fp(tw), _fp(to), _stream()))
+            start = end + 1
 
     def _set_vertex_positions(self, mesh, positions):
         """params['<shape>.vertex_positions'] = ...; params.update(): the acceleration structure is rebuilt with the next scene handle"""
@@ -1750,7 +1777,25 @@ class Scene:
                 V = self.meshes[mesh]["V"] = np.ascontiguousarray(V)
             check(lib().har_mesh_compute_normals(V.shape[0], _fp(V), F.shape[0], _up(F)))
         if self._h is not None:
-            lib().har_scene_destroy(self._h); self._h = None
+            # the BLAS that holds the mesh is REFITTED on the device (har_scene_update_vertices); a new scene only when the library asks for one: the mesh carries
+            # an emitter (its sampling records are lowered from the positions), or the refitted tree has degraded (HAR_UPDATE_REBUILD_ADVISED: still valid, but a
+            # fresh build traces faster -- the next render creates it)
+            Vc = np.ascontiguousarray(self.meshes[mesh]["V"], np.float32)
+            rc = lib().har_scene_update_vertices(self._h, int(mesh), _fp(Vc), _stream())
+            if rc in (2, 3):
+                if os.environ.get("HAR_VERBOSE"):
+                    import sys
+                    sys.stderr.write("[mitsuba3_amd] vertex update of mesh %d: %s -> new scene at the next render\n" % (mesh, (lib().har_last_error() or b"").decode() if rc == 2 else "refit cost ratio %.2f: rebuild advised" % self.refit_info()["ratio"]))
+                self.accel_rebuilds = getattr(self, "accel_rebuilds", 0) + 1
+                lib().har_scene_destroy(self._h); self._h = None
+            else:
+                check(rc)
+
+    def refit_info(self):
+        """(refits since the scene handle was created, cost figure of the last refit, its ratio to the first refit's, nodes)"""
+        info = (C.c_double * 4)()
+        check(lib().har_scene_refit_info(self._handle(), info))
+        return dict(refits=int(info[0]), cost=info[1], ratio=info[2], nodes=int(info[3]), rebuilds=getattr(self, "accel_rebuilds", 0))
 
     @_static_table
     def _pose_keys(self):
@@ -1891,6 +1936,7 @@ class SceneParameters(dict):
         written, self._written = self._written, set()
         sc = self.scene
         changed = self._changed_keys(written)
+        moved = []
         for k, what, ref in self._host_kinds():
             if k not in changed:
                 continue
@@ -1903,13 +1949,15 @@ class SceneParameters(dict):
                     sc._set_vertex_positions(ref, v)
             elif what == "inst":
                 if not np.array_equal(v.reshape(4, 4), sc._instance_matrix(ref)):
-                    sc._set_instance_matrix(ref, v.reshape(4, 4))
+                    moved.append((ref, v.reshape(4, 4)))
             elif what == "pose":
                 if not np.array_equal(v.reshape(-1), sc._pose_value(*ref).reshape(-1)):
                     sc._set_pose(ref[0], ref[1], v)
             else:
                 if not np.array_equal(v.reshape(-1), np.asarray(sc._bsdf_param_value(*ref), np.float32).reshape(-1)):
                     sc._set_bsdf_param(ref[0], ref[1], v.reshape(-1))
+        if moved:
+            sc._set_instance_matrices(moved)
         stream = None
         for k, (kind, b) in self._colour_table:
             t = self[k]

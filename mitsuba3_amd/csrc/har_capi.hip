@@ -11,6 +11,7 @@
 #include "../../include/hip_ad_rgb.h"
 #include "har_kernels.h"
 #include "har_scene_host.h"
+#include "har_refit_launch.h"
 
 #include <algorithm>
 #include <cstddef>
@@ -140,6 +141,12 @@ struct HarSceneImpl {
     DBsdf *d_bsdfs = nullptr;
     /* har_scene_set_*_device: the host mirrors (hs.textures[k].data, hs.bsdfs, hs.emitters) that no longer hold the device's values */
     std::vector<uint8_t> tex_host_stale; bool bsdf_host_stale = false, emitter_host_stale = false;
+    /* incremental accel updates (har_scene_update_instances / har_scene_update_vertices): capacity of the node array (BLAS nodes + the largest TLAS the instances can
+     * need), scratch of the device refit -- boxes of the triangle records and of the nodes, the nodes of every BLAS by depth, one surface-area accumulator per BLAS
+     * (+ the root box read-back) */
+    size_t nodes_cap = 0;
+    RefitBox *tri_box = nullptr, *node_box = nullptr; uint32_t *d_refit_order = nullptr; float *d_area = nullptr;
+    double last_refit_cost = 0.0, last_refit_ratio = 1.0;
 };
 
 struct HarIntegratorImpl {
@@ -743,7 +750,16 @@ int har_scene_create(const HarSceneDesc *desc, HarScene *out) {
     HostScene &hs = S->hs; DScene &D = S->ds;
     hipError_t err = hipSuccess;
     auto up = [&](auto &vec, auto **dst) { if (err == hipSuccess) err = upload(vec, dst, S->owned); };
-    up(hs.nodes, &D.accel.nodes); up(hs.tris, &D.accel.tris); up(hs.inst_recs, &D.accel.insts);
+    /* the node array keeps room for the largest TLAS the scene's instances can need (a TLAS over n leaves has at most n nodes): an instance update rebuilds the
+     * TLAS on the host and rewrites the tail of this array in place */
+    S->nodes_cap = hs.nodes.size() + (hs.has_tlas ? hs.insts.size() + 2 : 0);
+    {
+        void *p = nullptr;
+        if (err == hipSuccess) err = dev_alloc(&p, std::max<size_t>(S->nodes_cap, 1) * sizeof(Node8));
+        if (err == hipSuccess) { S->owned.push_back(p); if (!hs.nodes.empty()) err = hipMemcpy(p, hs.nodes.data(), hs.nodes.size() * sizeof(Node8), hipMemcpyHostToDevice); }
+        D.accel.nodes = (const Node8 *) p;
+    }
+    up(hs.tris, &D.accel.tris); up(hs.inst_recs, &D.accel.insts);
     up(hs.blas_tri_ranges, &D.blas_tri_ranges); up(hs.verts, &D.verts); up(hs.faces, &D.faces);
 #if HAR_SHADING_TRIS
     up(hs.shade_tris, &D.shade_tris);
@@ -906,6 +922,114 @@ int har_scene_accel_info(HarScene S, uint64_t info[4]) {
     info[0] = S->hs.nodes.size(); info[1] = S->hs.tris.size();
     info[2] = S->hs.nodes.size() * sizeof(Node8) + S->hs.tris.size() * sizeof(TriRec) + S->hs.inst_recs.size() * sizeof(InstRec);
     info[3] = S->hs.stack_need();
+    return 0;
+}
+
+/* ---- incremental updates of the acceleration data (Scene::parameters_changed rebuilds only what a dirty shape needs, scene.cpp:517-540; scene_optix.inl:351-372) */
+static int stack_fits(const HostScene &hs) {
+    const uint32_t stack_cap = (uint32_t) std::min(HAR_LDS_STACK_DEPTH, HAR_LDS_STACK_SMALL + HAR_STACK_SPILL);
+    if (hs.stack_need() + HAR_STACK_MARGIN > stack_cap) return fail("the updated scene's BVH needs " + std::to_string(hs.stack_need() + HAR_STACK_MARGIN) + " traversal stack entries per ray, the kernels hold " + std::to_string(stack_cap));
+    return 0;
+}
+/* the arrays build_tlas / update_scene_bounds rewrote on the host -> device, in stream order; the copies read pageable host memory, so the call waits for them */
+static int upload_instance_level(HarSceneImpl *S, hipStream_t s) {
+    HostScene &hs = S->hs; DScene &D = S->ds;
+    if (hs.nodes.size() > S->nodes_cap) return fail("TLAS does not fit the node array");           /* cannot happen: capacity = BLAS nodes + instance count + 2 */
+    if (stack_fits(hs)) return 1;
+    const size_t tail = hs.nodes.size() - hs.tlas_first;
+    if (tail) HIP_TRY(hipMemcpyAsync(const_cast<Node8 *>(D.accel.nodes) + hs.tlas_first, hs.nodes.data() + hs.tlas_first, tail * sizeof(Node8), hipMemcpyHostToDevice, s));
+    if (!hs.inst_recs.empty()) HIP_TRY(hipMemcpyAsync(const_cast<InstRec *>(D.accel.insts), hs.inst_recs.data(), hs.inst_recs.size() * sizeof(InstRec), hipMemcpyHostToDevice, s));
+    if (!hs.blas_tri_ranges.empty()) HIP_TRY(hipMemcpyAsync(const_cast<uint32_t *>(D.blas_tri_ranges), hs.blas_tri_ranges.data(), hs.blas_tri_ranges.size() * sizeof(uint32_t), hipMemcpyHostToDevice, s));
+    if (!hs.insts.empty()) HIP_TRY(hipMemcpyAsync(const_cast<DInst *>(D.insts), hs.insts.data(), hs.insts.size() * sizeof(DInst), hipMemcpyHostToDevice, s));
+    D.accel.root = hs.root; D.accel.n_insts = (uint32_t) hs.inst_recs.size();
+    D.accel.top_root = hs.top_root; D.accel.top_first = hs.top_first; D.accel.top_count = hs.top_count; D.accel.top_last = hs.top_last;
+    return 0;
+}
+/* the records update_scene_bounds touches: the environment / directional emitters' bounding sphere */
+static int upload_scene_bounds(HarSceneImpl *S, hipStream_t s) {
+    HostScene &hs = S->hs;
+    bool any = hs.env_emitter >= 0; for (const DEmitter &E : hs.emitters) any = any || E.type == 6u;
+    if (!any) return 0;
+    if (S->emitter_host_stale) {          /* radiances pushed device-to-device are newer than the mirror: fetch them before the records are rewritten */
+        std::vector<DEmitter> cur(hs.emitters.size());
+        HIP_TRY(hipMemcpyAsync(cur.data(), S->ds.emitters, cur.size() * sizeof(DEmitter), hipMemcpyDeviceToHost, s)); HIP_TRY(hipStreamSynchronize(s));
+        for (size_t k = 0; k < cur.size(); ++k) std::memcpy(hs.emitters[k].radiance, cur[k].radiance, 12);
+        S->emitter_host_stale = false;
+    }
+    HIP_TRY(hipMemcpyAsync(const_cast<DEmitter *>(S->ds.emitters), hs.emitters.data(), hs.emitters.size() * sizeof(DEmitter), hipMemcpyHostToDevice, s));
+    if (hs.has_envmap && S->ds.envmap) {
+        DEnvmap E = hs.envmap;         /* tex / warp already hold the device pointers (har_scene_create) */
+        HIP_TRY(hipMemcpyAsync(const_cast<DEnvmap *>(S->ds.envmap), &E, sizeof(DEnvmap), hipMemcpyHostToDevice, s));
+        HIP_TRY(hipStreamSynchronize(s));
+    }
+    return 0;
+}
+int har_scene_update_instances(HarScene S, uint32_t first, uint32_t count, const float *to_world, const float *to_object, void *stream) {
+    if (!S || !to_world || !to_object) return fail("null argument");
+    if (count == 0) return 0;
+    std::string e;
+    if (!scene_set_instances_host(S->hs, first, count, to_world, to_object, e)) return fail(e);
+    hipStream_t s = (hipStream_t) stream;
+    if (upload_instance_level(S, s) || upload_scene_bounds(S, s)) return 1;
+    HIP_TRY(hipStreamSynchronize(s));
+    return 0;
+}
+int har_scene_update_vertices(HarScene S, uint32_t mesh, const float *vertices, void *stream) {
+    if (!S || !vertices) return fail("null argument");
+    HostScene &hs = S->hs; DScene &D = S->ds;
+    std::string e;
+    BlasInfo *B = scene_set_vertices_host(hs, mesh, vertices, e);
+    if (!B) { (void) fail(e); return HAR_UPDATE_NEEDS_NEW_SCENE; }
+    hipStream_t s = (hipStream_t) stream;
+    const DMesh &m = hs.meshes[mesh];
+    const size_t n_blas = 1 + hs.blas_groups.size();
+    if (!S->tri_box) {                   /* refit scratch, on first use */
+        void *p = nullptr;
+        HIP_TRY(dev_alloc(&p, std::max<size_t>(hs.tris.size(), 1) * sizeof(RefitBox))); S->owned.push_back(p); S->tri_box = (RefitBox *) p;
+        HIP_TRY(dev_alloc(&p, std::max<size_t>(S->nodes_cap, 1) * sizeof(RefitBox))); S->owned.push_back(p); S->node_box = (RefitBox *) p;
+        HIP_TRY(dev_alloc(&p, std::max<size_t>(hs.refit_order.size(), 1) * sizeof(uint32_t))); S->owned.push_back(p); S->d_refit_order = (uint32_t *) p;
+        if (!hs.refit_order.empty()) HIP_TRY(hipMemcpyAsync(S->d_refit_order, hs.refit_order.data(), hs.refit_order.size() * sizeof(uint32_t), hipMemcpyHostToDevice, s));
+        HIP_TRY(dev_alloc(&p, n_blas * sizeof(float))); S->owned.push_back(p); S->d_area = (float *) p;
+    }
+    const size_t bi = B == &hs.blas_top ? 0 : 1 + (size_t) (B - hs.blas_groups.data());
+    /* one refit pass of the BLAS on the device arrays as they are; cost = sum of the node areas over the root's area (the node term of the SAH) */
+    auto refit_pass = [&](double &cost) -> int {
+        HIP_TRY(hipMemsetAsync(S->d_area + bi, 0, sizeof(float), s));
+        launch_refit_triangles(s, D, B->first_tri, B->tri_count, S->tri_box);
+        for (size_t l = 0; l + 1 < B->level_begin.size(); ++l)
+            launch_refit_nodes(s, D, S->d_refit_order + B->order_first + B->level_begin[l], B->level_begin[l + 1] - B->level_begin[l], S->tri_box, S->node_box, S->d_area + bi);
+        HIP_TRY(hipGetLastError());
+        float area = 0.f; RefitBox root{};
+        HIP_TRY(hipMemcpyAsync(&area, S->d_area + bi, sizeof(float), hipMemcpyDeviceToHost, s));
+        HIP_TRY(hipMemcpyAsync(&root, S->node_box + B->root, sizeof(RefitBox), hipMemcpyDeviceToHost, s));
+        HIP_TRY(hipStreamSynchronize(s));
+        const float dx = root.hi[0] - root.lo[0], dy = root.hi[1] - root.lo[1], dz = root.hi[2] - root.lo[2];
+        const double root_area = 2.0 * ((double) dx * dy + (double) dy * dz + (double) dz * dx);
+        cost = root_area > 0.0 ? (double) area / root_area : 0.0;
+        return 0;
+    };
+    /* the figure of the tree AS BUILT: the first update of a BLAS refits it once on the old vertices (which reproduces the built nodes bit for bit) */
+    if (B->built_area == 0.0 && refit_pass(B->built_area)) return 1;
+    HIP_TRY(hipMemcpyAsync(const_cast<float *>(D.verts) + 8 * (size_t) m.voff, vertices, 32 * (size_t) m.vertex_count, hipMemcpyHostToDevice, s));
+#if HAR_SHADING_TRIS
+    HIP_TRY(hipMemcpyAsync(const_cast<float *>(D.shade_tris) + 24 * (size_t) m.foff, hs.shade_tris.data() + 24 * (size_t) m.foff, 96 * (size_t) m.face_count, hipMemcpyHostToDevice, s));
+#endif
+    double cost = 0.0;
+    if (refit_pass(cost)) return 1;
+    if (!scene_after_refit_host(hs, B, e)) return fail(e);
+    if (B != &hs.blas_top && upload_instance_level(S, s)) return 1;
+    if (upload_scene_bounds(S, s)) return 1;
+    HIP_TRY(hipStreamSynchronize(s));
+    static const double max_inflation = getenv("HAR_REFIT_MAX_INFLATION") ? atof(getenv("HAR_REFIT_MAX_INFLATION")) : 1.5;
+    static const uint32_t max_refits = getenv("HAR_REFIT_MAX_STEPS") ? (uint32_t) atoi(getenv("HAR_REFIT_MAX_STEPS")) : 0u;
+    S->last_refit_cost = cost; S->last_refit_ratio = B->built_area > 0.0 ? cost / B->built_area : 1.0;
+    if ((B->built_area > 0.0 && cost > max_inflation * B->built_area) || (max_refits && B->refits >= max_refits)) return HAR_UPDATE_REBUILD_ADVISED;
+    return 0;
+}
+int har_scene_refit_info(HarScene S, double info[4]) {
+    if (!S || !info) return fail("null argument");
+    uint32_t refits = S->hs.blas_top.refits; for (const BlasInfo &b : S->hs.blas_groups) refits += b.refits;
+    info[0] = (double) refits; info[1] = S->last_refit_cost; info[2] = S->last_refit_ratio; info[3] = (double) S->hs.nodes.size();
     return 0;
 }
 

@@ -1,0 +1,13 @@
+/* har_refit_launch.h -- launch wrappers of har_refit.hip */
+#pragma once
+#include <hip/hip_runtime.h>
+#include "har_refit.h"
+
+namespace har {
+
+/* triangle records [first, first + count) of S.accel.tris rewritten from S.verts / S.faces; their padded boxes -> tri_box[first ..] */
+void launch_refit_triangles(hipStream_t s, const DScene &S, uint32_t first, uint32_t count, RefitBox *tri_box);
+/* the nodes order[0 .. count) (one depth level of one BLAS, deepest level first): boxes, frames, child planes; their surface areas are added to *area */
+void launch_refit_nodes(hipStream_t s, const DScene &S, const uint32_t *order, uint32_t count, const RefitBox *tri_box, RefitBox *node_box, float *area);
+
+} // namespace har

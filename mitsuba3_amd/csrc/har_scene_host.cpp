@@ -5,6 +5,7 @@
  * identity entry for the top-level BLAS and one entry per Instance.
  */
 #include "har_scene_host.h"
+#include "har_refit.h"
 #include <algorithm>
 #include <cmath>
 #include <cstring>
@@ -477,6 +478,67 @@ bool build_tlas(HostScene &hs, std::string &err) {
     for (uint32_t k : order) { hs.inst_recs.push_back(recs[k]); hs.blas_tri_ranges.push_back(ranges[2 * k]); hs.blas_tri_ranges.push_back(ranges[2 * k + 1]); }
     (void) err;
     return true;
+}
+
+bool scene_set_instances_host(HostScene &hs, uint32_t first, uint32_t count, const float *to_world, const float *to_object, std::string &err) {
+    if ((uint64_t) first + count > hs.insts.size()) { err = "instance range out of bounds"; return false; }
+    if (!hs.has_tlas) { err = "the scene has no instances"; return false; }
+    for (uint32_t k = 0; k < count; ++k) {
+        for (int j = 0; j < 12; ++j) if (!std::isfinite(to_world[12 * k + j]) || !std::isfinite(to_object[12 * k + j])) { err = "instance transform is not finite"; return false; }
+        std::memcpy(hs.insts[first + k].to_world, to_world + 12 * (size_t) k, 48); std::memcpy(hs.insts[first + k].to_object, to_object + 12 * (size_t) k, 48);
+        hs.inst_box_valid[first + k] = 0;
+    }
+    if (!build_tlas(hs, err)) return false;
+    update_scene_bounds(hs);
+    return true;
+}
+
+BlasInfo *scene_set_vertices_host(HostScene &hs, uint32_t mesh, const float *vertices, std::string &err) {
+    if (mesh >= hs.meshes.size()) { err = "invalid mesh index"; return nullptr; }
+    const DMesh &m = hs.meshes[mesh];
+    if (m.emitter >= 0) { err = "the mesh carries an area emitter (its sampling records are lowered from the positions): create a new scene"; return nullptr; }
+    for (size_t k = 0; k < 8 * (size_t) m.vertex_count; ++k) if ((k & 7) < 3 && !std::isfinite(vertices[k])) { err = "vertex position is not finite"; return nullptr; }
+    std::memcpy(hs.verts.data() + 8 * (size_t) m.voff, vertices, 32 * (size_t) m.vertex_count);
+#if HAR_SHADING_TRIS
+    for (uint32_t f = 0; f < m.face_count; ++f)
+        for (int k = 0; k < 3; ++k) std::memcpy(hs.shade_tris.data() + 24 * ((size_t) m.foff + f) + 8 * k, vertices + 8 * (size_t) hs.faces[4 * ((size_t) m.foff + f) + k], 32);
+#endif
+    if (mesh < hs.top_mesh_count) return &hs.blas_top;
+    for (size_t g = 0; g < hs.groups.size(); ++g)
+        if (mesh >= hs.groups[g].first_mesh && mesh < hs.groups[g].first_mesh + hs.groups[g].mesh_count) return &hs.blas_groups[g];
+    err = "mesh belongs to no BLAS"; return nullptr;
+}
+
+bool scene_after_refit_host(HostScene &hs, BlasInfo *B, std::string &err) {
+    B->refits++;
+    if (B != &hs.blas_top) {
+        const size_t g = (size_t) (B - hs.blas_groups.data());
+        /* the group's box (corner bound of big groups, build_tlas) = union of the padded triangle boxes, as build_blas leaves it */
+        for (int a = 0; a < 3; ++a) { B->lo[a] = INFINITY; B->hi[a] = -INFINITY; }
+        const HarShapeGroup &sg = hs.groups[g];
+        for (uint32_t s = sg.first_mesh; s < sg.first_mesh + sg.mesh_count; ++s) {
+            const DMesh &m = hs.meshes[s];
+            for (uint32_t f = 0; f < m.face_count; ++f) {
+                PrimBox b; for (int a = 0; a < 3; ++a) { b.lo[a] = INFINITY; b.hi[a] = -INFINITY; }
+                for (int k = 0; k < 3; ++k) { const float *v = hs.verts.data() + 8 * ((size_t) m.voff + hs.faces[4 * ((size_t) m.foff + f) + k]); for (int a = 0; a < 3; ++a) { b.lo[a] = std::min(b.lo[a], v[a]); b.hi[a] = std::max(b.hi[a], v[a]); } }
+                pad_prim_box(b);
+                for (int a = 0; a < 3; ++a) { B->lo[a] = std::min(B->lo[a], b.lo[a]); B->hi[a] = std::max(B->hi[a], b.hi[a]); }
+            }
+        }
+        for (size_t i = 0; i < hs.insts.size(); ++i) if (hs.inst_group[i] == g) hs.inst_box_valid[i] = 0;
+        if (!build_tlas(hs, err)) return false;
+    }
+    update_scene_bounds(hs);
+    return true;
+}
+
+double refit_blas_host(HostScene &hs, BlasInfo &B) {
+    if (B.empty) return 0.0;
+    std::vector<RefitBox> tri_box(hs.tris.size()), node_box(hs.nodes.size());
+    for (uint32_t i = 0; i < B.tri_count; ++i) tri_box[B.first_tri + i] = refit_triangle(hs.meshes.data(), hs.verts.data(), hs.faces.data(), hs.tris.data(), B.first_tri + i);
+    double area = 0.0;
+    for (uint32_t k = 0; k < B.node_count; ++k) area += (double) refit_node(hs.nodes.data(), hs.refit_order[B.order_first + k], tri_box.data(), node_box.data());
+    return area;
 }
 
 static bool lower_sensor_filter(const HarSensor &in, DSensor &out, std::string &err) {

@@ -76,6 +76,17 @@ bool lower_scene(const HarSceneDesc &desc, HostScene &out, std::string &err);
  * instances that are not valid + TLAS over them (the BLAS arrays are untouched: hs.nodes is cut back to tlas_first and the new TLAS appended) */
 void update_scene_bounds(HostScene &hs);
 bool build_tlas(HostScene &hs, std::string &err);
+/* host half of an instance update: new transforms for instances [first, first + count) (column-major 3 x 4 each, with their inverses), their boxes invalidated,
+ * the TLAS rebuilt, the scene bounds refreshed */
+bool scene_set_instances_host(HostScene &hs, uint32_t first, uint32_t count, const float *to_world, const float *to_object, std::string &err);
+/* host half of a vertex update of mesh `mesh` (vertex_count x 8 packed records): the vertex buffer is overwritten and the BLAS that holds the mesh returned
+ * (NULL + err: the update needs a new scene -- the mesh carries an emitter, whose sampling tables are lowered from the positions).  The caller refits that BLAS
+ * (device: har_refit.hip; host harness: refit_blas_host), then calls scene_after_refit_host, which recomputes what hangs on it: the BLAS box, the boxes of the
+ * instances of its group + the TLAS, the scene bounds */
+BlasInfo *scene_set_vertices_host(HostScene &hs, uint32_t mesh, const float *vertices, std::string &err);
+bool scene_after_refit_host(HostScene &hs, BlasInfo *blas, std::string &err);
+/* the refit itself on the host arrays (sequential; what the kernels of har_refit.hip do): returns the sum of the node surface areas */
+double refit_blas_host(HostScene &hs, BlasInfo &blas);
 
 /* GaussianFilter ctor (src/rfilters/gaussian.cpp:48-93) + sensor repack */
 bool lower_sensor(const HarSensor &in, DSensor &out, std::string &err);

@@ -85,6 +85,23 @@ void hh_emitter_sample_direction(void *h, uint32_t index, uint32_t n, const floa
         weight[3 * i] = w.x; weight[3 * i + 1] = w.y; weight[3 * i + 2] = w.z;
     }
 }
+/* the incremental updates of include/hip_ad_rgb.h on the host arrays (the refit runs the kernels' HAR_HD code sequentially): 0 ok, 2 = needs a new scene, 1 = error */
+int hh_scene_update_instances(void *h, uint32_t first, uint32_t count, const float *to_world, const float *to_object, char *err, int errlen) {
+    HScene *H = (HScene *) h; std::string e;
+    if (!scene_set_instances_host(H->hs, first, count, to_world, to_object, e)) { snprintf(err, errlen, "%s", e.c_str()); return 1; }
+    bind(*H);
+    return 0;
+}
+int hh_scene_update_vertices(void *h, uint32_t mesh, const float *vertices, double *area, char *err, int errlen) {
+    HScene *H = (HScene *) h; std::string e;
+    BlasInfo *B = scene_set_vertices_host(H->hs, mesh, vertices, e);
+    if (!B) { snprintf(err, errlen, "%s", e.c_str()); return 2; }
+    const double a = refit_blas_host(H->hs, *B);
+    if (area) *area = a;
+    if (!scene_after_refit_host(H->hs, B, e)) { snprintf(err, errlen, "%s", e.c_str()); return 1; }
+    bind(*H);
+    return 0;
+}
 /* FNV-1a over the bytes of the node array, the triangle records and the instance records: the builder's output, for tests that compare builds */
 void hh_accel_hash(void *h, uint64_t out[3]) {
     HScene *H = (HScene *) h;

@@ -1,0 +1,153 @@
+"""Incremental accel updates on the device (row a5 `rebuild`; src/render/scene.cpp:517-540, scene_optix.inl:351-372) through mi.traverse / params.update():
+the scene handle survives, an instance edit rebuilds the instance level only, a vertex edit refits the BLAS with the kernels of har_refit.hip --
+ray queries equal the brute-force kernel and a freshly loaded scene bit for bit, renders equal a fresh scene's."""
+import copy
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+
+def rel_l2(a, b):
+    return float(np.linalg.norm(a.astype(np.float64) - b.astype(np.float64)) / np.linalg.norm(b.astype(np.float64)))
+
+
+def _rays(mi, n, seed=1):
+    rng = np.random.default_rng(seed)
+    o = rng.uniform(-0.9, 0.9, (3, n)).astype(np.float32); d = rng.normal(size=(3, n)).astype(np.float32); d /= np.linalg.norm(d, axis=0)
+    return mi.Ray3f(o, d.astype(np.float32))
+
+
+def _pi_equal(a, b):
+    import torch
+    return all(torch.equal(x, y) for x, y in ((a.t, b.t), (a.prim_uv[0], b.prim_uv[0]), (a.prim_uv[1], b.prim_uv[1]), (a.prim_index, b.prim_index),
+                                              (a.shape_index, b.shape_index), (a.instance, b.instance)))
+
+
+def _scene_dict(mi, flatten, sky=False, res=48):
+    d = mi.instanced_spheres_scene(width=res, height=res, spp=16, grid=4, n_u=40, n_v=20, flatten=flatten)
+    if sky:
+        d.pop("ceiling"); d["sky"] = {"type": "constant", "radiance": {"type": "rgb", "value": [0.4, 0.5, 0.6]}}
+    return d
+
+
+@pytest.mark.parametrize("flatten", [True, False])
+def test_vertex_update_refits_in_place(mi, O, flatten):
+    import torch
+    d = _scene_dict(mi, flatten, sky=not flatten)
+    scene = mi.load_dict(d)
+    mi.render(scene, spp=4, seed=0)                                   # the handle exists
+    handle = scene._h.value
+    params = mi.traverse(scene)
+    key = "ball005.vertex_positions" if flatten else "spheres.ball.vertex_positions"
+    rays = _rays(mi, 200000)
+    rng = np.random.default_rng(5)
+    base = params[key].cpu().numpy().reshape(-1, 3)
+    for step, amount in enumerate((0.05, 0.15, 0.3)):
+        # a smooth deformation (what an optimiser does): the mesh grows and wobbles, plus a jitter well below the triangle size
+        new = base * np.float32(1.0 + amount) + np.float32(0.01 * amount) * np.sin(np.float32(35.0) * base[:, ::-1]) + rng.normal(scale=2e-4, size=base.shape).astype(np.float32)
+        new = np.ascontiguousarray(new, np.float32).reshape(-1)
+        params[key] = torch.tensor(new, device="cuda"); params.update()
+        assert scene._h is not None and scene._h.value == handle      # same scene handle: nothing was destroyed
+        got = scene.ray_intersect_preliminary(rays)
+        brute = scene._intersect(rays, True)
+        assert int(got.is_valid().sum()) > 20000 and _pi_equal(got, brute), (step, amount)
+        # a freshly loaded scene with the same geometry: same intersections, same picture, and the oracle agrees
+        d2 = copy.deepcopy(d)
+        m = scene._position_keys()[key]
+        name = scene.meshes[m]["key"]
+        if flatten:
+            d2[name]["positions"] = scene.meshes[m]["V"][:, :3].copy(); d2[name]["normals"] = scene.meshes[m]["V"][:, 3:6].copy(); d2[name].pop("to_world", None)
+        else:
+            d2["spheres"]["ball"]["positions"] = scene.meshes[m]["V"][:, :3].copy(); d2["spheres"]["ball"]["normals"] = scene.meshes[m]["V"][:, 3:6].copy()
+        fresh = mi.load_dict(d2)
+        assert _pi_equal(got, fresh.ray_intersect_preliminary(rays))
+        a = mi.render(scene, spp=16, seed=3).cpu().numpy(); b = mi.render(fresh, spp=16, seed=3).cpu().numpy()
+        assert rel_l2(a, b) < 1e-6
+        osc, sensor = O.scene_from_product(scene)
+        ref, ost = osc.render_path(sensor, seed=3, spp=16, max_depth=scene.integrator().max_depth, rr_depth=scene.integrator().rr_depth)
+        assert rel_l2(a, ref) < 1e-4 and scene.integrator().stats()["vertices"] == ost.vertices
+    info = scene.refit_info()
+    assert info["refits"] == 3 and info["rebuilds"] == 0 and info["ratio"] >= 1.0
+
+
+def test_instance_update_rebuilds_the_instance_level_only(mi, O):
+    import torch
+    d = _scene_dict(mi, False, sky=True)
+    scene = mi.load_dict(d)
+    mi.render(scene, spp=4, seed=0)
+    handle = scene._h.value; nodes_before = scene.accel_info()["nodes"]
+    params = mi.traverse(scene)
+    T = mi.ScalarTransform4f
+    rays = _rays(mi, 200000)
+    moved = {"inst003.to_world": T().translate([0.3, 0.5, 0.2]).rotate([1, 0, 0], 40.0).scale(1.5),
+             "inst004.to_world": T().translate([-0.3, -0.2, 0.4]).rotate([0, 1, 0], 10.0).scale(0.7),
+             "inst011.to_world": T().translate([0.0, 0.1, -0.6]).scale(2.0)}
+    for k, t in moved.items():
+        params[k] = torch.tensor(np.asarray(t.matrix, np.float32), device="cuda")
+    params.update()
+    assert scene._h.value == handle
+    got = scene.ray_intersect_preliminary(rays)
+    assert _pi_equal(got, scene._intersect(rays, True))
+    # a fresh scene with the SAME instance records: a matrix assigned through params gets a numerically inverted to_object (Instance::parameters_changed), the
+    # transform chain of the dict composes analytic inverses -- both are valid, they differ in the last bit
+    d2 = copy.deepcopy(d)
+    for k in moved:
+        i = scene._instance_keys()[k]
+        tw = np.asarray(scene.instances[i][1], np.float32).reshape(4, 3).T; to = np.asarray(scene.instances[i][2], np.float32).reshape(4, 3).T
+        m4 = np.eye(4, dtype=np.float32); m4[:3, :] = tw; i4 = np.eye(4, dtype=np.float32); i4[:3, :] = to
+        d2[k.split(".")[0]]["to_world"] = T(np.concatenate([m4.ravel(), i4.T.ravel()]))
+    fresh = mi.load_dict(d2)
+    for k in moved:
+        i = scene._instance_keys()[k]
+        assert np.array_equal(np.asarray(fresh.instances[i][1], np.float32), np.asarray(scene.instances[i][1], np.float32))
+        assert np.array_equal(np.asarray(fresh.instances[i][2], np.float32), np.asarray(scene.instances[i][2], np.float32))
+    assert _pi_equal(got, fresh.ray_intersect_preliminary(rays))
+    a = mi.render(scene, spp=16, seed=3).cpu().numpy(); b = mi.render(fresh, spp=16, seed=3).cpu().numpy()
+    assert rel_l2(a, b) < 1e-6 and abs(scene.accel_info()["nodes"] - nodes_before) <= 16
+    osc, sensor = O.scene_from_product(scene)
+    ref, _ = osc.render_path(sensor, seed=3, spp=16, max_depth=scene.integrator().max_depth, rr_depth=scene.integrator().rr_depth)
+    assert rel_l2(a, ref) < 1e-4
+
+
+def test_degraded_refit_advises_a_rebuild_and_emitter_meshes_get_a_new_scene(mi):
+    import torch
+    d = _scene_dict(mi, True)
+    scene = mi.load_dict(d); mi.render(scene, spp=4, seed=0)
+    params = mi.traverse(scene)
+    key = "ball002.vertex_positions"
+    p = params[key].cpu().numpy().reshape(-1, 3)
+    params[key] = torch.tensor(p.reshape(-1), device="cuda"); params.update()            # first refit: the baseline of the cost figure
+    assert scene._h is not None and scene.refit_info()["refits"] == 1
+    big = p.copy(); big[::2] += np.float32(0.6)                                        # every other vertex flies off: long thin triangles through the whole box
+    params[key] = torch.tensor(big.reshape(-1), device="cuda"); params.update()
+    assert scene._h is None and scene.accel_rebuilds == 1                               # advised: the next render builds a fresh tree
+    rays = _rays(mi, 50000)
+    assert _pi_equal(scene.ray_intersect_preliminary(rays), scene._intersect(rays, True))
+    # a mesh with an area emitter: its sampling records are lowered from the positions -> new scene, not a refit
+    cb = mi.load_dict(mi.cornell_box()); mi.render(cb, spp=4, seed=0)
+    pc = mi.traverse(cb)
+    pc["light.vertex_positions"] = pc["light.vertex_positions"] * 1.0; pc.update()
+    assert cb._h is None
+
+
+def test_shape_optimisation_steps_keep_the_handle(mi):
+    """vertex positions through mi.render + autograd + an optimiser step + params.update(): the loop of examples/optimize_vertices.py, three steps"""
+    import torch
+    d = mi.cornell_box(); d["sensor"]["film"]["width"] = 32; d["sensor"]["film"]["height"] = 32
+    d["integrator"] = {"type": "prb", "max_depth": 4}
+    scene = mi.load_dict(d)
+    params = mi.traverse(scene)
+    key = "small-box.vertex_positions"
+    params[key] = params[key].clone().requires_grad_(True); params.update()
+    opt = torch.optim.SGD([params[key]], lr=1e-3)
+    mi.render(scene, spp=4, seed=0); handle = scene._h.value
+    for it in range(3):
+        opt.zero_grad()
+        img = mi.render(scene, params, spp=16, seed=it)
+        (img ** 2).mean().backward()
+        assert torch.isfinite(params[key].grad).all() and float(params[key].grad.abs().max()) > 0
+        opt.step(); params.update()
+        assert scene._h is not None and scene._h.value == handle
+    assert scene.refit_info()["refits"] == 3
