@@ -361,6 +361,11 @@ int har_integrator_set_hide_emitters(HarIntegrator integrator, int hide);
  * (path.cpp:114-115,307-308,341), `depth != 0` for prb (prb.py:332) -- with the same reconstruction-filter weights w as the radiance, so that
  * A = channel 3 / W of the film (hdrfilm.cpp:398-399).  NULL switches it off. */
 int har_integrator_set_alpha_film(HarIntegrator integrator, float *alpha_film);
+/* Film WINDOW of har_render (multi-GPU bands): with row_count > 0 the `film` (and alpha film) buffers of the following har_render calls hold only rows
+ * [row_begin, row_begin + row_count) of the crop window -- row_count x crop_width x 4 floats -- instead of the whole film.  A rank that renders a band of pixel rows
+ * needs its band plus the reconstruction filter's reach on either side (and the sample border); har_render checks that the lanes it is given cannot splat outside the
+ * window and fails otherwise.  row_count = 0: the whole film again (default).  A 4096^2 film is 256 MiB; an eighth of it plus the halo is what a rank of eight owns. */
+int har_integrator_set_film_window(HarIntegrator integrator, uint32_t row_begin, uint32_t row_count);
 /* the pass split har_render will use for `spp` samples per pixel of this sensor's crop window; fails like the reference
  * when spp is not a multiple of the pass size (integrator.cpp:177-179, sampler.cpp:93-94) */
 int har_render_pass_layout(HarIntegrator integrator, const HarSensor *sensor, uint32_t spp, uint32_t *spp_per_pass, uint32_t *n_passes);

@@ -97,6 +97,7 @@ SIGNATURES = {
     "har_integrator_set_grad_instances": (C.c_int, [vp, vp, vp]),
     "har_integrator_set_hide_emitters": (C.c_int, [vp, C.c_int]),
     "har_integrator_set_alpha_film": (C.c_int, [vp, vp]),
+    "har_integrator_set_film_window": (C.c_int, [vp, C.c_uint32, C.c_uint32]),
     "har_scene_set_texture": (C.c_int, [vp, C.c_uint32, f32p]),
     "har_scene_accel_info": (C.c_int, [vp, u64p]),
     "har_scene_update_instances": (C.c_int, [vp, C.c_uint32, C.c_uint32, f32p, f32p, vp]),

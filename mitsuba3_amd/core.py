@@ -579,6 +579,19 @@ class Film:
         self.sample_border_ = bool(props.get('sample_border', False))
         self.border_size_ = max(0, int(math.ceil(np.float32(np.float32(radius) - np.float32(0.5)) - np.float32(2.0 * 1500.0 * 2.0 ** -24)))) if self.sample_border_ else 0
 
+    def splat_reach(self):
+        """film rows a sample can reach above / below its own pixel row: the filter footprint of ImageBlock::put (imageblock.cpp:444-470), ceil(radius - 1/2) -- 0 for
+        the box filter (film_footprint, har_path.h)"""
+        if self.rfilter == 0:
+            return 0
+        radius = {1: 4.0 * self.stddev, 2: self.stddev, 3: 2.0, 4: 2.0, 5: self.stddev}[self.rfilter]
+        return int(math.ceil(np.float32(np.float32(radius) - np.float32(0.5))))
+
+    def band_rows(self, y0, y1):
+        """the rows [lo, hi) of the crop window that samples of the sample-grid rows [y0, y1) splat into (sample border + filter reach)"""
+        reach = self.splat_reach()
+        return max(0, y0 - self.border_size_ - reach), min(self.crop_size_[1], y1 - self.border_size_ + reach)
+
     def sample_grid(self):
         """pixels of the lane -> pixel map of render(): crop_size + 2 * border_size with sample_border (integrator.cpp:162-165), else the crop size"""
         return (self.crop_size_[0] + 2 * self.border_size_, self.crop_size_[1] + 2 * self.border_size_)
@@ -1119,9 +1132,10 @@ class Integrator:
     def _sensor(self, scene, sensor):
         return scene.sensors()[sensor] if isinstance(sensor, int) else sensor
 
-    def render_film(self, scene, sensor=0, seed=0, spp=0, lanes=None, film=None, alpha_film=None):
+    def render_film(self, scene, sensor=0, seed=0, spp=0, lanes=None, film=None, alpha_film=None, film_window=None):
         """Raw {R,G,B,W} accumulation of lanes [begin, end) (all when None); no develop.  `alpha_film` (H x W x 4 zeros): also accumulate
-        w * alpha into its channel 3 (`rgba` films, har_integrator_set_alpha_film)."""
+        w * alpha into its channel 3 (`rgba` films, har_integrator_set_alpha_film).  `film_window` = (first row, rows): `film` / `alpha_film` hold only those rows
+        of the crop window (har_integrator_set_film_window: a rank's band + the filter's reach)."""
         torch = _torch(); dev = _device()
         sensor = self._sensor(scene, sensor)
         if spp:
@@ -1132,12 +1146,18 @@ class Integrator:
             film = torch.zeros((h, w, 4), dtype=torch.float32, device=dev)
         lb, le = lanes if lanes else (0, 0)
         check(lib().har_integrator_set_alpha_film(self._handle(), _ptr(alpha_film) if alpha_film is not None else None))
+        if film_window is not None:
+            if film.shape[0] < film_window[1] or (alpha_film is not None and alpha_film.shape[0] < film_window[1]):
+                raise RuntimeError("render_film(): the film holds %d rows, the window %d" % (film.shape[0], film_window[1]))
+            check(lib().har_integrator_set_film_window(self._handle(), int(film_window[0]), int(film_window[1])))
         try:
             check(lib().har_render(scene._handle(), self._handle(), C.byref(sensor.har), (sensor.sampler().m_base_seed + int(seed)) & 0xffffffff,
                                    spp, lb, le, _ptr(film), _stream()))
         finally:
             if alpha_film is not None:        # the integrator must not keep a pointer into a tensor it does not own
                 check(lib().har_integrator_set_alpha_film(self._handle(), None))
+            if film_window is not None:
+                check(lib().har_integrator_set_film_window(self._handle(), 0, 0))
         return film
 
     def render(self, scene, sensor=0, seed=0, spp=0, develop=True, evaluate=True):
@@ -1811,6 +1831,8 @@ class Scene:
                 keys[key + ".position"] = ("position", i)
             elif t in (5, 6):
                 keys[key + ".to_world"] = ("emitter_to_world", i)
+            if t == 5:          # SpotLight::traverse (spot.cpp:115-116): the cone, in degrees -- updatable here; their gradient (the reference marks them Differentiable) is refused
+                keys[key + ".cutoff_angle"] = ("cutoff_angle", i); keys[key + ".beam_width"] = ("beam_width", i)
         return keys
 
     def _pose_value(self, kind, b):
@@ -1818,22 +1840,47 @@ class Scene:
             return np.asarray(b.to_world.matrix, np.float32).reshape(4, 4).copy()
         if kind == "position":
             return np.asarray(self.emitters[b]["to_world"][9:12], np.float32).copy()
+        if kind in ("cutoff_angle", "beam_width"):
+            return np.asarray([self.emitters[b]["normal"][0 if kind == "cutoff_angle" else 1]], np.float32)
         m = np.eye(4, dtype=np.float32); m[:3, :] = np.asarray(self.emitters[b]["to_world"], np.float32).reshape(4, 3).T
         return m
 
+    def _validate_spots(self):
+        for e in self.emitters:                                      # SpotLight::update, spot.cpp:300-306
+            if e.get("type") == 5 and not (e["normal"][0] >= e["normal"][1] and e["normal"][0] > 0):
+                raise RuntimeError("spot: cutoff_angle must be positive and not smaller than beam_width")
+
     def _set_pose(self, kind, b, value):
+        # validate first, assign last: a rejected value leaves the scene (and the params entry's counterpart) as it was
         if kind == "sensor":
             m = np.asarray(value, np.float64).reshape(4, 4)
-            b.to_world = ScalarTransform4f(np.concatenate([m.astype(np.float32).ravel(), np.linalg.inv(m).astype(np.float32).ravel()]))
-            if b.kind != 'orthographic' and b.to_world.has_scale():
+            if not np.isfinite(m).all() or abs(np.linalg.det(m)) < 1e-30:
+                raise RuntimeError("sensor to_world: the matrix is singular or not finite")
+            new = ScalarTransform4f(np.concatenate([m.astype(np.float32).ravel(), np.linalg.inv(m).T.astype(np.float32).ravel()]))
+            if b.kind != 'orthographic' and new.has_scale():
                 raise RuntimeError("Scale factors in the camera-to-world transformation are not allowed!")
-            b.update()                                           # the sensor record travels with every render call: no scene handle involved
+            old = b.to_world
+            b.to_world = new
+            try:
+                b.update()                                       # the sensor record travels with every render call: no scene handle involved
+            except Exception:
+                b.to_world = old; b.update()
+                raise
             return
         e = dict(self.emitters[b])
-        if kind == "position":
-            e["to_world"] = list(e["to_world"][:9]) + [float(x) for x in np.asarray(value, np.float32).reshape(3)]
+        if kind in ("cutoff_angle", "beam_width"):
+            nrm = [float(x) for x in e["normal"]]; nrm[0 if kind == "cutoff_angle" else 1] = float(np.asarray(value, np.float32).reshape(-1)[0])
+            e["normal"] = nrm                                        # the pair is validated once both values of an update() are in (_validate_spots)
+        elif kind == "position":
+            pos = np.asarray(value, np.float32).reshape(3)
+            if not np.isfinite(pos).all():
+                raise RuntimeError("emitter position is not finite")
+            e["to_world"] = list(e["to_world"][:9]) + [float(x) for x in pos]
         else:
-            m = np.asarray(value, np.float64).reshape(4, 4); inv = np.linalg.inv(m)
+            m = np.asarray(value, np.float64).reshape(4, 4)
+            if not np.isfinite(m).all() or abs(np.linalg.det(m)) < 1e-30:
+                raise RuntimeError("emitter to_world: the matrix is singular or not finite")
+            inv = np.linalg.inv(m)
             e["to_world"] = [float(x) for x in m[:3, :].T.reshape(-1)]; e["to_local"] = [float(x) for x in inv[:3, :].T.reshape(-1)]
         self.emitters[b] = e
         if self._h is not None:                                  # the emitter records are part of the scene handle: rebuilt with the next one
@@ -1958,6 +2005,7 @@ class SceneParameters(dict):
                     sc._set_bsdf_param(ref[0], ref[1], v.reshape(-1))
         if moved:
             sc._set_instance_matrices(moved)
+        sc._validate_spots()
         stream = None
         for k, (kind, b) in self._colour_table:
             t = self[k]
@@ -2205,7 +2253,8 @@ def render(scene, params=None, sensor=0, integrator=None, seed=0, seed_grad=0, s
     keys = [k for k, v in (params or {}).items() if getattr(v, 'requires_grad', False)]
     fixed = [k for k in keys if k in scene._pose_keys()]
     if fixed:       # ParamFlags::NonDifferentiable in the reference's traverse(): dr.enable_grad on them has no effect there; here it is said
-        raise RuntimeError("%s are not differentiable parameters (placement of sensors and delta emitters: ParamFlags::NonDifferentiable)" % fixed)
+        raise RuntimeError("%s are not differentiable parameters in hip_ad_rgb (placement of sensors and delta emitters: ParamFlags::NonDifferentiable in the reference; "
+                           "a spot light's cutoff_angle / beam_width: Differentiable there, updatable but without a gradient here)" % fixed)
     if not keys:
         return integrator.render(scene, sensor, seed, spp)
     params.update()

@@ -189,11 +189,16 @@ struct NoProbe {
 };
 
 /* (m << 1) | sign bit of x: v_alignbit_b32 on the device */
+/* The degenerate cases of that sign test, pinned so that host (harness, har_render_scalar) and device agree and neither drops a box that could hold a hit:
+ *  - NaN (inf - inf: an axis-parallel ray whose slab distances overflow on both sides): the device's fma returns the DEFAULT NaN, which is positive on gfx950 -> the slot
+ *    counts as hit (conservative); x86 produces a negative default NaN -> the host build maps every NaN to "hit" explicitly;
+ *  - tf = -0 with tn = 0 (the ray starts exactly on the far plane of a box and leaves it): fma(-0, c, -0) = -0 -> miss on both sides; a triangle that lies in that plane
+ *    is still found through a neighbouring box or not at all, exactly as with the reference's kd-tree whose split planes have the same measure-zero ambiguity. */
 HAR_HD uint32_t shift_in_sign(uint32_t m, float x) {
 #if defined(__HIP_DEVICE_COMPILE__)
     return __builtin_amdgcn_alignbit(m, as_u32(x), 31u);
 #else
-    return (m << 1) | (as_u32(x) >> 31);
+    return (m << 1) | ((x != x) ? 0u : (as_u32(x) >> 31));
 #endif
 }
 /* bit i of x moves to bit i ^ c (x: 8 bits, c: 3 bits) */

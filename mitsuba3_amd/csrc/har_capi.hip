@@ -158,6 +158,7 @@ struct HarIntegratorImpl {
     bool hide_emitters = false;           /* Integrator property (integrator.cpp:29) */
     bool forward_mode = false;            /* har_render_forward in progress: the adjoint kernels read tangents and accumulate differential radiance */
     float *alpha_film = nullptr;          /* user buffer (DEVICE, H x W x 4: channel 3 accumulates w * alpha) of har_integrator_set_alpha_film, or null */
+    uint32_t film_row0 = 0, film_rows = 0; /* har_integrator_set_film_window: the film buffers of har_render hold rows [film_row0, film_row0 + film_rows) of the crop window (0 rows = all) */
     float *alpha_lane = nullptr;          /* alpha value per lane of the chunk */
     uint32_t *skip_counters = nullptr;    /* hide_emitters: count + cursor of the two continuation lists of skip_area_emitters */
     uint32_t *pk_list = nullptr, *pk_counters = nullptr;      /* wave-shared descent of the camera rays (k_trace_packet): the packets left to the per-lane kernel, their count + cursor */
@@ -191,6 +192,7 @@ struct HarIntegratorImpl {
     bool material_queues = false;         /* har_integrator_set_material_queues */
     int packet_tracing = -1;              /* har_integrator_set_packet_tracing: -1 automatic, 0 off, 1 every first closest-hit launch */
     int bw_tape_max = 2; uint32_t bw_chunk_max = 0xffffffffu;      /* render_backward: what the last out-of-memory fallback settled on (tape kind, chunk lanes) */
+    uint64_t bw_job_key = 0; uint32_t bw_calls_since_stepdown = 0;   /* ... for which job (scene, film, lanes), and how many calls ago */
     uint32_t *mq_idx = nullptr, *mq_count = nullptr;      /* per-material shading queues (MaterialQueues): HAR_MAT_CLASSES index lists of ws_lanes entries, their counters */
     uint2 *stack_spill = nullptr;         /* HBM part of the traversal stacks: HAR_STACK_SPILL entries per thread of the largest traversal grid */
     /* multi-pass rendering: sampler state per lane of the rendered lane range, pixel jitter per chunk lane (see PassState) */
@@ -241,10 +243,13 @@ namespace {
 void prof_mark(HarIntegratorImpl *I, hipStream_t s, int cls);
 enum { CLS_RAYGEN = 0, CLS_TRACE = 1, CLS_SHADE = 2, CLS_RESOLVE = 3, CLS_SPLAT = 4, CLS_OTHER = 6, CLS_START = 7 };
 
+/* set by every failed workspace allocation, cleared by whoever handles it (render_backward's step-down): the condition "out of device memory", as a flag rather
+ * than as a substring of the error text */
+thread_local bool g_alloc_failed = false;
 template <typename T> int ws_alloc(HarIntegratorImpl *I, T **p, size_t count) {
     void *q = nullptr;
     hipError_t e = dev_alloc(&q, std::max<size_t>(count, 1) * sizeof(T));
-    if (e != hipSuccess) return fail(std::string("hipMalloc(workspace): ") + hipGetErrorString(e));
+    if (e != hipSuccess) { g_alloc_failed = true; return fail(std::string("hipMalloc(workspace): ") + hipGetErrorString(e)); }
     I->owned.push_back(q); *p = (T *) q;
     return 0;
 }
@@ -1303,8 +1308,42 @@ static int dual_join(HarIntegrator I, hipStream_t s) {
     return 0;
 }
 
+/* film window (har_integrator_set_film_window): the rows the lanes [lb, le) can splat into -- their pixel rows in the sample grid, moved by the sample border, widened by
+ * the reconstruction filter's footprint (film_footprint, har_path.h) -- must lie inside the window; the kernels then get the address row 0 WOULD have */
+static int apply_film_window(HarIntegrator I, const HarSensor *sensor, uint32_t spp, uint64_t lb, uint64_t le, float *&film) {
+    if (!I->film_rows) return 0;
+    DSensor C; std::string e;
+    if (!lower_sensor(*sensor, C, e)) return fail(e);
+    uint32_t spp_pass = spp, n_passes = 1;
+    if (I->type == HAR_INTEGRATOR_PATH && pass_layout(I, C.samp_w, C.samp_h, spp, spp_pass, n_passes)) return 1;
+    const uint64_t per_row = (uint64_t) C.samp_w * spp_pass;
+    if (lb == 0 && le == 0) le = per_row * C.samp_h;
+    if (le <= lb || per_row == 0) return 0;
+    const int64_t taps = C.rfilter == 0 ? 0 : (int64_t) ceilf(C.radius - .5f);
+    int64_t y0 = (int64_t) (lb / per_row) - (int64_t) C.border - taps, y1 = (int64_t) ((le - 1) / per_row) - (int64_t) C.border + taps;
+    y0 = std::max<int64_t>(y0, 0); y1 = std::min<int64_t>(y1, (int64_t) C.crop_h - 1);
+    if (y0 <= y1 && (y0 < (int64_t) I->film_row0 || y1 >= (int64_t) I->film_row0 + I->film_rows))
+        return fail("har_integrator_set_film_window: the lanes splat into film rows [" + std::to_string(y0) + ", " + std::to_string(y1) + "], the window holds [" +
+                    std::to_string(I->film_row0) + ", " + std::to_string(I->film_row0 + I->film_rows - 1) + "]");
+    film -= (size_t) I->film_row0 * C.crop_w * 4;
+    return 0;
+}
+
+int har_integrator_set_film_window(HarIntegrator I, uint32_t row_begin, uint32_t row_count) {
+    if (!I) return fail("null integrator");
+    I->film_row0 = row_count ? row_begin : 0; I->film_rows = row_count;
+    return 0;
+}
+
 int har_render(HarScene S, HarIntegrator I, const HarSensor *sensor, uint32_t seed, uint32_t spp, uint64_t lb, uint64_t le, float *film, void *stream) {
     if (!S || !I || !sensor) return fail("null scene / integrator / sensor");
+    if (!film) return fail("null film");
+    float *const alpha_saved = I->alpha_film;
+    if (I->film_rows) {
+        if (apply_film_window(I, sensor, spp, lb, le, film)) return 1;
+        if (I->alpha_film) { float *a = I->alpha_film; if (apply_film_window(I, sensor, spp, lb, le, a)) return 1; I->alpha_film = a; }
+    }
+    struct Restore { HarIntegrator I; float *a; ~Restore() { I->alpha_film = a; } } restore{ I, alpha_saved };
     uint64_t total_lb = lb, total_le = le;
     if (lb == 0 && le == 0) {                           /* "all lanes": resolve the range here so that it can be cut */
         uint32_t spp_pass = spp, n_passes = 1, grid_w = 0, grid_h = 0;
@@ -1459,6 +1498,10 @@ static int backward_range(HarScene S, HarIntegrator I, const HarSensor *sensor, 
      * asked for (their fifteen extra vectors per vertex stay with the re-shading replay).  HAR_PRB_TAPE=1: the state tape (A/B) */
     static const int tape_kind_env = getenv("HAR_PRB_TAPE") ? atoi(getenv("HAR_PRB_TAPE")) : 2;
     const bool tape_ok = tape_env && inline_env0 && I->use_cache && !I->shape_on && !I->hide_emitters && bounce_limit(I) <= HAR_REPLAY_CACHE_BOUNCES;
+    /* what an earlier out-of-memory step-down settled on applies to THAT job (scene, film, lane count): another job starts from the full configuration again, and the
+     * same job retries it every 16th call -- the failure may have been a transient state of the allocator pool the library shares with the caller's tensors */
+    const uint64_t job_key = S->serial * 0x9e3779b97f4a7c15ull ^ ((uint64_t) C.crop_w << 40) ^ ((uint64_t) C.crop_h << 20) ^ (le - lb);
+    if (I->bw_job_key != job_key || (++I->bw_calls_since_stepdown & 15u) == 0u) { I->bw_tape_max = 2; I->bw_chunk_max = 0xffffffffu; I->bw_job_key = job_key; }
     chunk = std::min(chunk, I->bw_chunk_max);
     int tape = !tape_ok ? 0 : (tape_kind_env >= 2 && !I->grad_bsdf_params && chunk <= (1u << 29)) ? 2 : 1;
     tape = std::min(tape, I->bw_tape_max);
@@ -1478,9 +1521,11 @@ static int backward_range(HarScene S, HarIntegrator I, const HarSensor *sensor, 
         return 0;
     };
     for (;;) {
+        g_alloc_failed = false;
         if (allocate() == 0) break;
         const std::string why = g_error;
-        if (why.find("hipMalloc") == std::string::npos) return 1;             /* not an allocation failure: the error stands */
+        if (!g_alloc_failed) return 1;                                         /* not an allocation failure: the error stands */
+        I->bw_calls_since_stepdown = 0;
         (void) hipDeviceSynchronize(); I->free_ws(); (void) hipGetLastError();
         if (tape != 0) { tape = 0; I->bw_tape_max = 0; }
         else if (chunk > (1u << 20)) { chunk = std::max<uint32_t>(1u << 20, (chunk / 2 + 2047) / 2048 * 2048); I->bw_chunk_max = chunk; }

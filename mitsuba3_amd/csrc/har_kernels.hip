@@ -659,6 +659,9 @@ __device__ __forceinline__ void packet_node_visit(const Accel &A, const PacketBo
     const float p[3] = { __uint_as_float(n0.x), __uint_as_float(n0.y), __uint_as_float(n0.z) };
     const float sc[3] = { __uint_as_float((n0.w & 0xffu) << 23), __uint_as_float(((n0.w >> 8) & 0xffu) << 23), __uint_as_float(((n0.w >> 16) & 0xffu) << 23) };
     float lb = 0.f, ub = tmax_wave;
+    /* the child planes are rebuilt in the node's coordinates (one rounding of ulp(|plane|) / 2 each) before the rays' origin bounds are subtracted; the per-ray test
+     * (node_visit) keeps (origin - o) and q * scale apart.  The difference stays far inside the padding every leaf box carries (pad_box: 2e-5 * |coordinate|, ~170 ulps,
+     * inherited by every ancestor through the union), so this test prunes at most what the per-ray test prunes: tests/test_gpu_packet.py at coordinates of 1e4 */
 #pragma unroll
     for (int a = 0; a < 3; ++a) {
         const float lo = fma_(q[a], sc[a], p[a]), hi = fma_(q[3 + a], sc[a], p[a]);

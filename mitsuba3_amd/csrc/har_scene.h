@@ -21,7 +21,10 @@ struct DTexture { const float *data; uint32_t w, h; uint32_t mode, pad; float uv
  * (DEnvmap); type 3: AreaLight on a triangle mesh: mesh, inv_area = 1 / surface area, to_world[0] / [1] = bit patterns of the offset of its
  * table in DScene::emitter_cdf and of its face count, to_world[2] = sum of the face areas */
 #ifndef HAR_SHADING_TRIS
-#define HAR_SHADING_TRIS 0      /* 1: compute_si reads pre-gathered per-face vertex records (what-if build, not measured yet) */
+/* 1 (default since round 5): compute_si reads ONE pre-gathered 96-byte block per face (its three vertex records, DScene::shade_tris) instead of face -> three scattered
+ * vertices: one level of dependent loads less, one or two cache lines instead of three or four.  Bracketed A/B on one box (profiles/r05_ab_shading_tris.txt): k_shade
+ * 10.5 -> 10.2 ms on instanced1m, 24.5 -> 23.85 ms on materials1m, flat1m unchanged; forward +0.5 %; GPU suite green on both builds.  Costs 96 B per face of HBM. */
+#define HAR_SHADING_TRIS 1
 #endif
 struct DEmitter { float radiance[3]; float inv_area; float to_world[12]; float normal[3]; uint32_t mesh; uint32_t type; };
 struct DInst    { float to_world[12]; float to_object[12]; };
@@ -42,7 +45,7 @@ struct DScene {
     const uint32_t *blas_tri_ranges;   /* per TLAS record: first, count (brute-force kernel) */
     const float    *verts;             /* packed vertices, 8 f32 each (mesh_utils.h:19-34) */
 #if HAR_SHADING_TRIS
-    const float    *shade_tris;        /* what-if build: the three vertex records of every face, 24 f32 per face in face order (see compute_si) */
+    const float    *shade_tris;        /* the three vertex records of every face, 24 f32 per face in face order (see compute_si) */
 #endif
     const uint32_t *faces;             /* packed faces, 4 u32 each */
     const DMesh    *meshes;
@@ -98,8 +101,8 @@ HAR_HD SurfInt compute_si(const DScene &S, Vec3 ray_d, float t, float bu, float 
     if (t == HAR_INF) { si.wi = -ray_d; return si; }
     const DMesh M = S.meshes[shape];
 #if HAR_SHADING_TRIS
-    /* what-if (A/B builds; docs/rounds/r05_plan.md item 1): the face's three vertex records pre-gathered into ONE 96-byte block -- hit -> mesh record -> block instead
-     * of hit -> mesh record -> face -> three scattered vertices: one level of dependent loads less, one or two cache lines instead of three or four */
+    /* the face's three vertex records pre-gathered into ONE 96-byte block -- hit -> mesh record -> block instead of hit -> mesh record -> face -> three scattered
+     * vertices */
     const float *r0 = S.shade_tris + 24 * (size_t) (M.foff + prim), *r1 = r0 + 8, *r2 = r0 + 16;
 #else
     const uint32_t *f = S.faces + 4 * (size_t) (M.foff + prim);

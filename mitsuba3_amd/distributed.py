@@ -115,8 +115,31 @@ def _world():
     return 0, 1
 
 
-def render_distributed(scene, integrator=None, sensor=0, seed=0, spp=0, develop=True, dst=0):
-    """Integrator.render across all ranks; the developed image is valid on rank `dst`."""
+BAND_FILM_MIN_BYTES = 32 << 20      # films at least this large are gathered as bands (render_distributed, film_mode=None)
+
+
+def _gather_bands(band, rows, h, w, dst, rank, world):
+    """`band` = this rank's rows [rows[rank][0], rows[rank][1]) of the film, padded to the common height: ONE gather to `dst`, which adds the bands (their halos overlap)
+    into the H x W x 4 film.  An eighth of the reduce's bytes per rank at eight ranks, and no rank but `dst` ever holds a full film."""
+    staged = band
+    if dist.get_backend() == "gloo" and band.is_cuda:          # rehearsal runs (ranks share a GPU): gloo moves host tensors
+        staged = band.cpu()
+    got = [torch.empty_like(staged) for _ in range(world)] if rank == dst else None
+    dist.gather(staged, got, dst=dst)
+    if rank != dst:
+        return None
+    film = torch.zeros((h, w, 4), dtype=band.dtype, device=band.device)
+    for r, (lo, hi) in enumerate(rows):
+        if hi > lo:
+            film[lo:hi] += got[r][:hi - lo].to(band.device)
+    return film
+
+
+def render_distributed(scene, integrator=None, sensor=0, seed=0, spp=0, develop=True, dst=0, film_mode=None):
+    """Integrator.render across all ranks; the developed image is valid on rank `dst`.
+    film_mode "full": every rank splats into a private full-size film, ONE sum-reduce (the default for ordinary films: a 512^2 film is 4 MiB, the reduce is latency);
+    "band": every rank owns the rows its band can reach (band + filter reach + sample border; har_integrator_set_film_window), ONE gather, `dst` adds the bands --
+    the default from BAND_FILM_MIN_BYTES up (BASELINE config 5: 256 MiB film -> 32 MiB + halo per rank at eight ranks)."""
     integrator = integrator or scene.integrator()
     s = scene.sensors()[sensor] if isinstance(sensor, int) else sensor
     if spp:
@@ -130,6 +153,26 @@ def render_distributed(scene, integrator=None, sensor=0, seed=0, spp=0, develop=
     y0, y1 = bal.band(rank)
     lanes = (y0 * gw * spp_pass, y1 * gw * spp_pass)
     adapt = bal.adapting()
+    if film_mode is None:
+        film_mode = "band" if world > 1 and h * w * 16 >= BAND_FILM_MIN_BYTES and hasattr(s.film(), "band_rows") else "full"
+    if film_mode == "band" and world > 1:
+        from . import core
+        rows = [s.film().band_rows(bal.bounds[r], bal.bounds[r + 1]) for r in range(world)]          # identical on every rank
+        lo, hi = rows[rank]
+        rows_max = max(1, max(b - a for a, b in rows))
+        dev = core._device() if torch.cuda.is_available() else torch.device("cpu")
+        band = torch.zeros((rows_max, w, 4), dtype=torch.float32, device=dev)
+        alpha = torch.zeros_like(band) if getattr(s.film(), "alpha", False) and develop else None
+        with _Timer(adapt) as timer:
+            if y1 > y0:
+                band = integrator.render_film(scene, s, seed, spp, lanes=lanes, film=band, alpha_film=alpha, film_window=(lo, max(hi - lo, 1)))
+        if adapt:
+            _share_times(bal, timer, band)
+        film = _gather_bands(band, rows, h, w, dst, rank, world)
+        alpha = _gather_bands(alpha, rows, h, w, dst, rank, world) if alpha is not None else None
+        if not develop:
+            return film
+        return develop_film(film, alpha, getattr(s.film(), "colour", 0)) if rank == dst else None
     alpha = None
     if getattr(s.film(), "alpha", False) and develop:             # `rgba` films: a second accumulator (w * alpha), reduced like the first
         from . import core

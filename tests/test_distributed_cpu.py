@@ -27,11 +27,18 @@ class OracleIntegrator:
         self.osc, self.sensor, self.per_pass = osc, sensor, samples_per_pass
     def pass_layout(self, sensor, spp=0):
         return (self.per_pass, spp // self.per_pass) if self.per_pass else (spp, 1)
-    def render_film(self, scene, sensor=0, seed=0, spp=0, lanes=None, film=None):
+    def render_film(self, scene, sensor=0, seed=0, spp=0, lanes=None, film=None, alpha_film=None, film_window=None):
         if self.per_pass:
             raw, _ = self.osc.render_path_passes(self.sensor, seed=seed, spp=spp, spp_per_pass=self.per_pass, max_depth=8, lanes=lanes, raw=True)
         else:
             raw, _ = self.osc.render_path(self.sensor, seed=seed, spp=spp, max_depth=8, lanes=lanes, raw=True)
+        if film_window is not None:
+            # the band film of har_integrator_set_film_window: the rows of the window; NOTHING of this band's splats may fall outside it (Film.band_rows)
+            lo, n = film_window
+            outside = np.concatenate([raw[:lo].ravel(), raw[lo + n:].ravel()])
+            assert not outside.any(), "a lane of rows %s splatted outside the film window %s" % (lanes, film_window)
+            film[:n] += torch.from_numpy(raw[lo:lo + n])
+            return film
         return torch.from_numpy(raw)
 
 dist.init_process_group(backend="gloo", rank=int(os.environ["RANK"]), world_size=int(os.environ["WORLD_SIZE"]))
@@ -52,6 +59,17 @@ if rank == 0:
     assert err < 1e-6, err
     # the weight channel is exactly the sum of the bands' weights: every lane rendered once
     assert abs(got[..., 3].sum() - whole[..., 3].sum()) / whole[..., 3].sum() < 1e-6
+# band films (the C5 layout: a rank owns its band + the filter's reach, one gather instead of the full-film reduce): same picture, for every filter width
+for rf in ("gaussian", "box", "tent"):
+    d2 = mi.cornell_box(); d2["sensor"]["film"]["width"] = res; d2["sensor"]["film"]["height"] = res; d2["sensor"]["film"]["rfilter"] = {"type": rf}
+    scene2 = mi.load_dict(d2)
+    sd2, osensor2 = O.scene_from_product(scene2)[0], O.scene_from_product(scene2)[1]
+    film = mi.render_distributed(scene2, integrator=OracleIntegrator(sd2, osensor2), seed=3, spp=spp, develop=False, film_mode="band")
+    if rank == 0:
+        whole2, _ = sd2.render_path(osensor2, seed=3, spp=spp, max_depth=8, raw=True)
+        assert film.shape == (res, res, 4) and np.abs(film.numpy() - whole2).max() / np.abs(whole2).max() < 1e-6, rf
+    else:
+        assert film is None
 # multi-pass job (the C5 shape of SURVEY.md 8e at test size): ranks own bands of the PER-PASS wavefront and run every pass on them
 film = mi.render_distributed(scene, integrator=OracleIntegrator(osc, osensor, samples_per_pass=2), seed=3, spp=8, develop=False)
 if rank == 0:

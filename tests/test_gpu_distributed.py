@@ -49,6 +49,23 @@ for frame in range(5):                                # BandBalancer adapts over
 assert not bal.adapting() and bal.bounds[0] == 0 and bal.bounds[-1] == res and all(y > x for x, y in zip(bal.bounds, bal.bounds[1:]))
 img = mi.render_distributed(scene, integ, seed=3, spp=spp)
 assert (img is not None) == (rank == 0)
+# band films (the layout of BASELINE config 5): every rank owns its band + the filter's reach (har_integrator_set_film_window), ONE gather, rank 0 adds the bands
+bfilm = mi.render_distributed(scene, integ, seed=3, spp=spp, develop=False, film_mode="band")
+assert (bfilm is not None) == (rank == 0)
+if rank == 0:
+    assert bfilm.is_cuda and bfilm.shape == whole.shape and rel(bfilm, whole) < 1e-5
+# a window that cannot hold the band's splats is refused, not overrun
+lo, hi = scene.sensors()[0].film().band_rows(10, 20)
+small = torch.zeros((hi - lo - 1, res, 4), device="cuda")
+try:
+    integ.render_film(scene, scene.sensors()[0], 3, spp, lanes=(10 * res * spp, 20 * res * spp), film=small, film_window=(lo + 1, hi - lo - 1))
+    raise SystemExit("a film window smaller than the band's reach was accepted")
+except mi.HarError as e:
+    assert "window" in str(e)
+exact = torch.zeros((hi - lo, res, 4), device="cuda")
+integ.render_film(scene, scene.sensors()[0], 3, spp, lanes=(10 * res * spp, 20 * res * spp), film=exact, film_window=(lo, hi - lo))
+part = integ.render_film(scene, scene.sensors()[0], 3, spp, lanes=(10 * res * spp, 20 * res * spp))
+assert rel(exact, part[lo:hi]) < 1e-6 and float(part[:lo].abs().sum()) == 0 and float(part[hi:].abs().sum()) == 0
 
 # adjoint: weight-film all-reduce + ONE flat all-reduce of every gradient buffer; every rank ends up with the whole frame's gradients
 grad_in = torch.from_numpy(np.random.default_rng(1).uniform(0.5, 1.5, (res, res, 3)).astype(np.float32)).cuda()

@@ -57,3 +57,26 @@ def test_packet_descent_render_equals_per_ray_render(mi, O):
             stats[packet] = scene.integrator().stats()
         assert rel_l2(imgs[None], imgs[False]) < 1e-6, name
         assert stats[None] == stats[False], (name, stats)
+
+
+def test_packet_descent_far_from_the_origin(mi):
+    """the packet's box test rebuilds the child planes in world coordinates (fma(q, scale, origin)) before it subtracts the rays' origin bounds, the per-ray test keeps
+    (origin - o) and q * scale apart: at coordinates of ~1e4 the two differ by ulp(1e4) ~ 1e-3 in the plane positions.  The boxes are padded by 2e-5 * |coordinate|
+    (pad_box: 0.2 there, ~170 ulps), so the packet test still only prunes less -- checked here: same radiance bit for bit with the scene moved to (1e4, -2e4, 3e4)"""
+    T = mi.ScalarTransform4f
+    off = T().translate([1.0e4, -2.0e4, 3.0e4])
+    d = mi.cornell_box(); d["sensor"]["film"]["width"] = 24; d["sensor"]["film"]["height"] = 24
+    for k, v in d.items():
+        if isinstance(v, dict) and v.get("type") in ("rectangle", "cube"):
+            v["to_world"] = off @ v["to_world"]
+    d["sensor"]["to_world"] = off @ d["sensor"]["to_world"]
+    outs = {}
+    for packet in (False, True):
+        d["integrator"] = {"type": "path", "max_depth": 4, "rr_depth": 3, "packet_tracing": packet}
+        scene = mi.load_dict(d)
+        ray = _camera_like_rays(scene, mi, 24, 64, 3)
+        sampler = mi.Sampler({"sample_count": 4, "seed": 1}); sampler.seed(7, len(ray))
+        spec, valid = scene.integrator().sample(scene, sampler, ray)
+        outs[packet] = (spec.cpu().numpy(), valid.cpu().numpy())
+    assert np.array_equal(outs[False][0], outs[True][0]) and np.array_equal(outs[False][1], outs[True][1])
+    assert outs[True][1].mean() > 0.9 and np.abs(outs[True][0]).max() > 0

@@ -66,3 +66,22 @@ def test_placement_is_not_differentiable(mi):
     p2["sensor.to_world"] = torch.diag(torch.tensor([2.0, 2.0, 2.0, 1.0]))
     with pytest.raises(RuntimeError, match="Scale factors"):            # perspective.cpp:143-146 holds for updates too
         p2.update()
+
+
+def test_spot_cone_parameters_are_updatable(mi, O):
+    """SpotLight::traverse exposes cutoff_angle / beam_width (spot.cpp:115-116): params.update() re-lowers the cone; an updated scene is a freshly loaded one"""
+    import torch
+    scene = mi.load_dict(scene_dict(mi))
+    params = mi.traverse(scene)
+    assert float(params["spot.cutoff_angle"]) == 40.0 and float(params["spot.beam_width"]) == 30.0
+    params["spot.cutoff_angle"] = torch.tensor([25.0]); params["spot.beam_width"] = torch.tensor([10.0]); params.update()
+    d = scene_dict(mi); d["spot"]["cutoff_angle"] = 25.0; d["spot"]["beam_width"] = 10.0
+    fresh = mi.load_dict(d)
+    a = [e for e in scene.emitters if e.get("type") == 5][0]; b = [e for e in fresh.emitters if e.get("type") == 5][0]
+    assert [float(x) for x in a["normal"]] == [float(x) for x in b["normal"]]
+    sa, sensor = O.scene_from_product(scene); sb, _ = O.scene_from_product(fresh)
+    ia, _ = sa.render_path(sensor, seed=1, spp=4, max_depth=4, raw=True); ib, _ = sb.render_path(sensor, seed=1, spp=4, max_depth=4, raw=True)
+    assert np.array_equal(ia, ib)
+    params["spot.beam_width"] = torch.tensor([30.0])
+    with pytest.raises(RuntimeError, match="cutoff_angle"):
+        params.update()
