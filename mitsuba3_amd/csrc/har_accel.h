@@ -101,7 +101,16 @@ struct Accel {
      * triangles (terrain under instanced trees) keep the top-level-first order, which enters the TLAS with tmax at the nearest top-level hit.
      * bit 0: any-hit rays walk the TLAS first, bit 1: closest-hit rays do. */
     uint32_t top_last;
+    /* per mesh {first face of the mesh in the packed face / shading-triangle arrays, material word}: what a finished closest-hit ray adds to its hit record so that the
+     * shading kernel starts its geometry and BSDF loads from the record instead of from a dependent load of the mesh record (HAR_HIT_MATINFO, har_kernels.h).
+     * material word: bits 0-19 BSDF record, 20-21 mesh flags (vertex normals, texcoords), 22 carries an emitter, 24-27 material class (HAR_MAT_*) */
+    const struct MeshInfo *mesh_info;
 };
+struct MeshInfo { uint32_t foff, matinfo; };
+#define HAR_MATINFO_BSDF(m)    ((m) & 0xfffffu)
+#define HAR_MATINFO_FLAGS(m)   (((m) >> 20) & 3u)
+#define HAR_MATINFO_EMITTER(m) (((m) >> 22) & 1u)
+#define HAR_MATINFO_CLASS(m)   (((m) >> 24) & 0xfu)
 #define HAR_NO_NODE 0xffffffffu
 
 struct Hit {

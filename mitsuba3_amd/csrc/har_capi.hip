@@ -783,6 +783,15 @@ int har_scene_create(const HarSceneDesc *desc, HarScene *out) {
     }
     S->mat_miss_class = 0; while (S->mat_miss_class < HAR_MAT_CLASSES && !(S->mat_classes & (1u << S->mat_miss_class))) ++S->mat_miss_class;
     up(hs.meshes, &D.meshes); up(hs.bsdfs, &D.bsdfs); up(hs.emitters, &D.emitters); up(hs.insts, &D.insts);
+    {   /* Accel::mesh_info: what a retiring closest-hit ray copies into its record (HAR_HIT_MATINFO) */
+        std::vector<MeshInfo> info(hs.meshes.size());
+        for (size_t k = 0; k < hs.meshes.size(); ++k) {
+            const DMesh &m = hs.meshes[k];
+            if (m.bsdf > 0xfffffu) { for (void *p : S->owned) dev_free(p); delete S; return fail("more than 2^20 BSDF records"); }
+            info[k] = MeshInfo{ m.foff, m.bsdf | ((m.flags & 3u) << 20) | ((m.emitter >= 0 ? 1u : 0u) << 22) | ((m.pad1 & 0xfu) << 24) };
+        }
+        up(info, &D.accel.mesh_info);
+    }
     std::vector<DTexture> dt;
     for (auto &t : hs.textures) {
         const float *p = nullptr; up(t.data, &p);

@@ -41,6 +41,15 @@
 #define HIT0(i) ((size_t) (i))
 #define HIT1(i) ((size_t) (i))
 #endif
+/* HAR_HIT_MATINFO = 1 (A/B build, default OFF): the two spare words of a closest-hit record carry {index of the face in the shading-triangle array, the mesh's
+ * material word} (Accel::mesh_info), added by the traversal kernels when a ray retires, so that the shading kernels start their geometry and BSDF loads from the record
+ * instead of from a dependent load of the mesh record.  The idea: the generic shading kernel waits on memory 63 % of its wave-cycles at four waves per SIMD, behind a
+ * chain hit -> mesh -> face data / mesh -> BSDF record -> tables; take the mesh record out of both chains.  Measured (profiles/r05_ab_hit_matinfo.txt, bracketed):
+ * k_shade 23.80 -> 23.59 ms on materials1m, 11.04 -> 10.94 on instanced1m -- and k_trace_closest 31.47 -> 31.96 ms (one 8-byte load per retiring ray costs more in
+ * the issue-bound traversal kernel than the shorter chain saves): forward 1 017 -> 1 012 Mpaths/s.  The chain's depth is not what the kernel waits for. */
+#ifndef HAR_HIT_MATINFO
+#define HAR_HIT_MATINFO 0
+#endif
 #ifndef HAR_CLOSEST_RETIRE
 #define HAR_CLOSEST_RETIRE 1     /* measured on MI355X (instanced 1M scene): 791.7 -> 797.9 Mpaths/s, k_trace_closest 39.16 -> 38.60 ms per frame */
 #endif

@@ -584,7 +584,13 @@ __global__ __launch_bounds__(kBlock, HAR_TRACE_MIN_WAVES) void k_trace_closest(A
         if (LIST && r >= n_rays) return;
         h0[HIT0(base + r)] = make_float4(T.hit.t, T.hit.u, T.hit.v, __uint_as_float(T.hit.prim));
 #if HAR_HIT_INTERLEAVED      /* the second half as ONE 16-byte store: the ray's 32-byte sector is written completely (no byte-masked partial write) */
+#if HAR_HIT_MATINFO
+        MeshInfo mi{ 0u, 0u };
+        if (T.hit.t != HAR_INF) mi = A.mesh_info[T.hit.shape];
+        *reinterpret_cast<uint4 *>(h1 + HIT1(base + r)) = make_uint4(T.hit.shape, T.hit.inst, mi.foff + T.hit.prim, mi.matinfo);
+#else
         *reinterpret_cast<uint4 *>(h1 + HIT1(base + r)) = make_uint4(T.hit.shape, T.hit.inst, 0u, 0u);
+#endif
 #else
         h1[HIT1(base + r)] = make_uint2(T.hit.shape, T.hit.inst);
 #endif
@@ -777,7 +783,13 @@ __global__ __launch_bounds__(kBlock, HAR_PACKET_MIN_WAVES) void k_trace_packet(A
         } else if (pk + lane < n) {
             h0[HIT0(base + idx)] = make_float4(hit.t, hit.u, hit.v, __uint_as_float(hit.prim));
 #if HAR_HIT_INTERLEAVED
+#if HAR_HIT_MATINFO
+            MeshInfo mi{ 0u, 0u };
+            if (hit.t != HAR_INF) mi = A.mesh_info[hit.shape];
+            *reinterpret_cast<uint4 *>(h1 + HIT1(base + idx)) = make_uint4(hit.shape, hit.inst, mi.foff + hit.prim, mi.matinfo);
+#else
             *reinterpret_cast<uint4 *>(h1 + HIT1(base + idx)) = make_uint4(hit.shape, hit.inst, 0u, 0u);
+#endif
 #else
             h1[HIT1(base + idx)] = make_uint2(hit.shape, hit.inst);
 #endif
@@ -1026,7 +1038,12 @@ __global__ __launch_bounds__(kBlock, HAR_SHADE_MIN_WAVES) void k_shade(DScene S,
                         hs = rc.h1[cl]; t = rc.h0[cl].x;
                     } else { hs = h1[HIT1(Q.base + l)]; t = h0[HIT0(Q.base + l)].x; }
                     /* the mesh's material class (DMesh::pad1, har_scene_create): diffuse 0, dielectric 1, rough conductor 2, rough plastic 3, conductor 4, plastic 5, generic 6 */
+#if HAR_HIT_MATINFO && HAR_HIT_INTERLEAVED
+                    const bool from_record = !(MODE == MODE_PRB_ADJOINT && rc.mode == 2);
+                    const uint32_t cls = t == HAR_INF ? 7u : min(from_record ? HAR_MATINFO_CLASS(h1[HIT1(Q.base + l) + 1].y) : S.meshes[hs.x].pad1, (uint32_t) HAR_MAT_GENERIC);
+#else
                     const uint32_t cls = t == HAR_INF ? 7u : min(S.meshes[hs.x].pad1, (uint32_t) HAR_MAT_GENERIC);
+#endif
                     key = (0x47326510u >> (4u * cls)) & 0xfu;               /* buckets: diffuse, dielectric, conductor, plastic, escaped | rough conductor, rough plastic, generic */
                 }
                 sort_tmp[r * kBlock + threadIdx.x] = (uint16_t) ((key << 12) | atomicAdd(&sort_cnt[key], 1u));      /* rank within the bucket (< 4096) */
@@ -1059,11 +1076,20 @@ __global__ __launch_bounds__(kBlock, HAR_SHADE_MIN_WAVES) void k_shade(DScene S,
         if (in_range) {
             PathState st = load_state(in, i);
             d_in = st.d; first_vertex = (st.flags & 0xffffu) == 0u;
-            if (MODE == MODE_PRB_ADJOINT && rc.mode == 2) { hh = rc.h0[st.lane - lane_base]; hs = rc.h1[st.lane - lane_base]; }      /* replay cache */
-            else { hh = h0[HIT0(i)]; hs = h1[HIT1(i)]; }
+            HitExtra hx{ 0u, 0u }; bool has_hx = false;
+            if (MODE == MODE_PRB_ADJOINT && rc.mode == 2) { hh = rc.h0[st.lane - lane_base]; hs = rc.h1[st.lane - lane_base]; }      /* replay cache: 24-byte records */
+            else {
+                hh = h0[HIT0(i)];
+#if HAR_HIT_MATINFO && HAR_HIT_INTERLEAVED
+                const uint4 q = *reinterpret_cast<const uint4 *>(h1 + HIT1(i));      /* {shape, inst, face in the shading-triangle array, material word} */
+                hs = make_uint2(q.x, q.y); hx.gface = q.z; hx.matinfo = q.w; has_hx = true;
+#else
+                hs = h1[HIT1(i)];
+#endif
+            }
             if (MODE == MODE_PRB_PRIMAL && rc.mode == 1) { rc.h0[st.lane - lane_base] = hh; rc.h1[st.lane - lane_base] = hs; }
             Hit hit; hit.t = hh.x; hit.u = hh.y; hit.v = hh.z; hit.prim = __float_as_uint(hh.w); hit.shape = hs.x; hit.inst = hs.y;
-            shade_lane<MODE, TYPES, EXTRA>(S, P, st, hit, R);
+            shade_lane<MODE, TYPES, EXTRA>(S, P, st, hit, R, has_hx ? &hx : nullptr);
             lane = st.lane - lane_base;
             if (MODE == MODE_PRB_ADJOINT && INLINE) {
                 if (tape_read) { const float4 a = tape.la_in[i]; const float2 c2 = tape.lb_in[i]; Lr = Vec3(a.x, a.y, a.z); dlr = Vec3(a.w, c2.x, c2.y); }
@@ -1466,7 +1492,16 @@ __global__ __launch_bounds__(kBlock) void k_skip_emitters(DScene S, int first, u
             const float4 d = ray_d[i];
             const float4 hh = first ? h0[HIT0(i)] : hit0[HIT0(i)]; const uint2 hs = first ? h1[HIT1(i)] : hit1[HIT1(i)];
             const uint32_t slot = first ? i : __float_as_uint(d.w);
-            if (!first) { h0[HIT0(slot)] = hh; h1[HIT1(slot)] = hs; }
+            if (!first) {
+                h0[HIT0(slot)] = hh;
+#if HAR_HIT_MATINFO && HAR_HIT_INTERLEAVED
+                MeshInfo mi{ 0u, 0u };
+                if (hh.x != HAR_INF) mi = S.accel.mesh_info[hs.x];
+                *reinterpret_cast<uint4 *>(h1 + HIT1(slot)) = make_uint4(hs.x, hs.y, mi.foff + __float_as_uint(hh.w), mi.matinfo);
+#else
+                h1[HIT1(slot)] = hs;
+#endif
+            }
             if (hh.x != HAR_INF && S.meshes[hs.x].emitter >= 0) {
                 const Vec3 dir(d.x, d.y, d.z);
                 const SurfInt si = compute_si(S, dir, hh.x, hh.y, hh.z, __float_as_uint(hh.w), hs.x, hs.y);

@@ -112,8 +112,11 @@ HAR_HD void film_footprint(const DSensor &C, const LaneSample &L, Footprint &F) 
     }
 }
 
+/* what a closest-hit record carries beyond the preliminary intersection (Accel::mesh_info; HAR_HIT_MATINFO): the face's index in the shading-triangle array, the mesh's material word */
+struct HitExtra { uint32_t gface, matinfo; };
+
 template <int MODE, uint32_t TYPES = HAR_BSDF_ALL_TYPES, bool EXTRA = false>
-HAR_HD void shade_lane(const DScene &S, const ShadeParams &P, const PathState &st, const Hit &hit, ShadeResult &R) {
+HAR_HD void shade_lane(const DScene &S, const ShadeParams &P, const PathState &st, const Hit &hit, ShadeResult &R, const HitExtra *hx = nullptr) {
     R.alive = false; R.add_emission = false; R.item = false; R.item_ray = false;
     if (MODE == MODE_PRB_ADJOINT && EXTRA) { for (int g = 0; g < 5; ++g) { R.x_dir[g] = Vec3(0.f); R.x_rel[g] = Vec3(0.f); } R.x_ind = false; }
     if (MODE == MODE_PRB_ADJOINT) { R.em_index = -1; R.nee_emitter = -1; R.em_unit = Vec3(0.f); R.contrib_unit = Vec3(0.f); R.nee_flags = 0u; R.cos_em = 0.f; R.nee_p = Vec3(0.f); R.nee_n = Vec3(0.f); R.nee_w = Vec3(0.f); }
@@ -122,9 +125,13 @@ HAR_HD void shade_lane(const DScene &S, const ShadeParams &P, const PathState &s
     const uint32_t depth = st.flags & 0xffffu;
     const bool prev_delta = (st.flags >> 16) & 1u;
 
-    SurfInt si = compute_si(S, st.d, hit.t, hit.u, hit.v, hit.prim, hit.shape, hit.inst);
+    /* with a hit record that carries the face index and the material word, nothing below waits for a load of the mesh record (only an emitter hit reads it) */
+    SurfInt si = hx ? compute_si_record(S, st.d, hit.t, hit.u, hit.v, hx->gface, HAR_MATINFO_FLAGS(hx->matinfo), hit.shape, hit.inst)
+                    : compute_si(S, st.d, hit.t, hit.u, hit.v, hit.prim, hit.shape, hit.inst);
     const bool valid = si.valid();
-    const DMesh M = valid ? S.meshes[si.mesh] : DMesh{};
+    DMesh M{};
+    if (valid && hx) { M.bsdf = HAR_MATINFO_BSDF(hx->matinfo); M.emitter = HAR_MATINFO_EMITTER(hx->matinfo) ? S.meshes[si.mesh].emitter : -1; }
+    else if (valid) M = S.meshes[si.mesh];
     const int emitter = valid ? M.emitter : S.env_emitter;          /* si.emitter(scene): the environment for a miss (scene.h:822-832) */
     const float pmf = S.n_emitters ? 1.f / (float) S.n_emitters : 0.f;   /* scene.cpp:139 */
     /* Scene::m_emitter_distr (scene.cpp:120-141): non-uniform emitter selection; only in the kernels of scenes that carry the generic emitter code */

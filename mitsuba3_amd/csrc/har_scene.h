@@ -148,6 +148,55 @@ HAR_HD SurfInt compute_si(const DScene &S, Vec3 ray_d, float t, float bu, float 
     return si;
 }
 
+/* the same interaction from a hit record that carries the face's index in the shading-triangle array and the mesh's flags (HAR_HIT_MATINFO): no load of the mesh record */
+HAR_HD SurfInt compute_si_record(const DScene &S, Vec3 ray_d, float t, float bu, float bv, uint32_t gface, uint32_t mesh_flags, uint32_t shape, uint32_t inst) {
+    SurfInt si;
+    si.t = t; si.uv_x = 0.f; si.uv_y = 0.f; si.mesh = 0;
+    if (t == HAR_INF) { si.wi = -ray_d; return si; }
+#if HAR_SHADING_TRIS
+    const float *r0 = S.shade_tris + 24 * (size_t) gface, *r1 = r0 + 8, *r2 = r0 + 16;
+#else
+    const uint32_t *f = S.faces + 4 * (size_t) gface; const uint32_t voff = S.meshes[shape].voff;
+    const float *r0 = S.verts + 8 * (size_t) (voff + f[0]), *r1 = S.verts + 8 * (size_t) (voff + f[1]), *r2 = S.verts + 8 * (size_t) (voff + f[2]);
+#endif
+#if defined(__HIP_DEVICE_COMPILE__)
+    const float4 qa0 = reinterpret_cast<const float4 *>(r0)[0], qa1 = reinterpret_cast<const float4 *>(r0)[1];
+    const float4 qb0 = reinterpret_cast<const float4 *>(r1)[0], qb1 = reinterpret_cast<const float4 *>(r1)[1];
+    const float4 qc0 = reinterpret_cast<const float4 *>(r2)[0], qc1 = reinterpret_cast<const float4 *>(r2)[1];
+    const float v0[8] = { qa0.x, qa0.y, qa0.z, qa0.w, qa1.x, qa1.y, qa1.z, qa1.w };
+    const float v1[8] = { qb0.x, qb0.y, qb0.z, qb0.w, qb1.x, qb1.y, qb1.z, qb1.w };
+    const float v2[8] = { qc0.x, qc0.y, qc0.z, qc0.w, qc1.x, qc1.y, qc1.z, qc1.w };
+#else
+    const float *v0 = r0, *v1 = r1, *v2 = r2;
+#endif
+    Vec3 p0(v0[0], v0[1], v0[2]), p1(v1[0], v1[1], v1[2]), p2(v2[0], v2[1], v2[2]);
+    float b1 = bu, b2 = bv, b0 = 1.f - b1 - b2;
+    Vec3 e1 = p1 - p0, e2 = p2 - p0;
+    si.p = fma3(p0, b0, fma3(p1, b1, p2 * b2));
+    si.n = normalize3(cross3(e1, e2));
+    if (mesh_flags & 1u) {
+        Vec3 n0(v0[3], v0[4], v0[5]), dn1 = Vec3(v1[3], v1[4], v1[5]) - n0, dn2 = Vec3(v2[3], v2[4], v2[5]) - n0;
+        Vec3 n = fma3(dn1, b1, fma3(dn2, b2, n0));
+        si.sn = n * rsqrt_(dot3(n, n));
+    } else si.sn = si.n;
+    if (mesh_flags & 2u) {
+        float u0 = v0[6], w0 = v0[7], du0 = v1[6] - u0, dv0 = v1[7] - w0, du1 = v2[6] - u0, dv1 = v2[7] - w0;
+        si.uv_x = fma_(du0, b1, fma_(du1, b2, u0));
+        si.uv_y = fma_(dv0, b1, fma_(dv1, b2, w0));
+    } else { si.uv_x = b1; si.uv_y = b2; }
+    si.mesh = shape;
+    if (inst != 0xffffffffu) {
+        const DInst &I = S.insts[inst];
+        si.p = xf_point(I.to_world, si.p);
+        si.n = normalize3(xf_normal(I.to_object, si.n));
+        Vec3 n = xf_normal(I.to_object, si.sn);
+        si.sn = n * rcp_(norm3(n));
+    }
+    coordinate_system(si.sn, si.ss, si.st);
+    si.wi = si.to_local(-ray_d);
+    return si;
+}
+
 /* RayFlags (include/mitsuba/render/interaction.h:19-87).  The wavefront kernels compute what RayFlags::Default asks for (compute_si above); the array-valued
  * Scene::ray_intersect / PreliminaryIntersection::compute_surface_interaction entry points honour the caller's flags through compute_si_flags.  FollowShape /
  * DetachShape only choose which AD dependence the reference tracks through the hit; the primal values are the same (the C ABI carries no AD graph). */

@@ -37,7 +37,7 @@ static void bind(HScene &H) {
     H.dtex.clear();
     for (size_t k = 0; k < hs.textures.size(); ++k) H.dtex.push_back(hs.device_texture(k, hs.textures[k].data.data()));
     DScene &S = H.ds;
-    S.accel.nodes = hs.nodes.data(); S.accel.tris = hs.tris.data(); S.accel.insts = hs.inst_recs.data();
+    S.accel.nodes = hs.nodes.data(); S.accel.tris = hs.tris.data(); S.accel.insts = hs.inst_recs.data(); S.accel.mesh_info = nullptr;
     S.accel.root = hs.root; S.accel.has_tlas = hs.has_tlas; S.accel.n_tris = (uint32_t) hs.tris.size(); S.accel.n_insts = (uint32_t) hs.inst_recs.size();
     S.accel.top_root = hs.top_root; S.accel.top_first = hs.top_first; S.accel.top_count = hs.top_count; S.accel.top_last = hs.top_last;
     S.blas_tri_ranges = hs.blas_tri_ranges.data();
