@@ -1943,11 +1943,14 @@ class SceneParameters(dict):
 
     def _changed_keys(self, written):
         """which host-updated keys hold other values than at the last update(): WRITTEN keys (SceneParameters.__setitem__ flags them, util.py) and tensors modified
-        in place (an optimiser step) -- found by comparing with the snapshot of the last update() ON THE TENSOR'S DEVICE, one flag per key, ONE read-back for all
-        of them (round 4 copied every parameter to the host, every step)"""
+        in place (an optimiser step).  A tensor that is the same object with the same version counter as at the last update() is unchanged without looking at it;
+        the others are compared with the snapshot of the last update() ON THE TENSOR'S DEVICE, one flag per key, ONE read-back for all of them (round 4 copied
+        every parameter to the host, every step).  (Writes that bypass the version counter -- `tensor.data.add_()`, raw pointers -- need `params[key] = params[key]`,
+        as every update does in the reference.)"""
         torch = _torch()
         table = self._host_kinds()
         snap = self.__dict__.setdefault("_snapshot", {})
+        seen = self.__dict__.setdefault("_seen", {})          # key -> (the tensor object, its version counter) at the last update()
         changed = set(k for k, _, _ in table if k in written or k not in snap)
         flags = []; names = []
         for k, _, _ in table:
@@ -1956,6 +1959,9 @@ class SceneParameters(dict):
             t = self[k]
             if not hasattr(t, "detach"):
                 changed.add(k); continue
+            mark = seen.get(k)
+            if mark is not None and mark[0] is t and mark[1] == t._version:
+                continue                    # the same tensor object, never written in place since (torch bumps _version on every in-place op): nothing to compare
             t = t.detach(); old = snap[k]
             if old.shape != t.shape or old.device != t.device or old.dtype != t.dtype:
                 changed.add(k); continue
@@ -1970,6 +1976,10 @@ class SceneParameters(dict):
         for k in changed:
             t = self[k]
             snap[k] = t.detach().clone() if hasattr(t, "detach") else torch.as_tensor(np.asarray(t, np.float32))
+        for k, _, _ in table:
+            t = self[k]
+            if hasattr(t, "_version"):
+                seen[k] = (t, t._version)
         return changed
 
     def update(self, values=None):
@@ -2007,8 +2017,13 @@ class SceneParameters(dict):
             sc._set_instance_matrices(moved)
         sc._validate_spots()
         stream = None
+        pushed = self.__dict__.setdefault("_pushed", {})      # key -> (tensor object, version counter, scene handle) of the last push
         for k, (kind, b) in self._colour_table:
             t = self[k]
+            mark = pushed.get(k)
+            if k not in written and mark is not None and mark[0] is t and mark[1] == getattr(t, "_version", None) and mark[2] == (sc._h.value if sc._h is not None else None):
+                continue                    # the value the scene already holds
+            pushed[k] = (t, getattr(t, "_version", None), sc._h.value if sc._h is not None else None)
             on_gpu = hasattr(t, "is_cuda") and t.is_cuda and sc._h is not None
             if on_gpu:
                 # the scene's copy is the value AT update(): snapshot on the device (a later in-place edit of the tensor is not an update), host mirror refreshed lazily
