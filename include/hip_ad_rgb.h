@@ -203,6 +203,16 @@ int har_scene_set_texture(HarScene scene, uint32_t texture, const float *data);
 int har_scene_set_texture_device(HarScene scene, uint32_t texture, const float *data, void *stream);
 int har_scene_set_reflectance_device(HarScene scene, uint32_t bsdf, const float *rgb, void *stream);
 int har_scene_set_emitter_radiance_device(HarScene scene, uint32_t emitter, const float *rgb, void *stream);
+/* Scene::sample_emitter(index_sample, active) -> (index, emitter_weight, reused sample) and Scene::pdf_emitter(index, active) (src/render/scene.cpp:248-279), array-valued,
+ * DEVICE arrays of n entries: uniform selection with sample re-use, or DiscreteDistribution::sample_reuse_pmf over the emitters' `sampling_weight`s when one of them
+ * differs from 1 (:120-141, :258-261).  A scene without emitters returns index 0xffffffff and weight 0 (:251-256); a masked lane zeros. */
+int har_scene_sample_emitter(HarScene scene, uint32_t n, const float *index_sample, const uint8_t *active, uint32_t *index, float *weight, float *reused_sample, void *stream);
+int har_scene_pdf_emitter(HarScene scene, uint32_t n, const uint32_t *index, const uint8_t *active, float *pdf, void *stream);
+/* params['<emitter>.sampling_weight'] + update() (Emitter::traverse, src/render/emitter.cpp:13; Scene::parameters_changed rebuilds the distribution, scene.cpp:523-528):
+ * `weights` = HOST array, one per emitter of the scene */
+int har_scene_set_emitter_sampling_weights(HarScene scene, const float *weights, uint32_t count);
+/* params['<texture>.to_uv'] + update() (BitmapTexture::traverse, src/textures/bitmap.cpp): the 2 x 3 rows of HarTexture::to_uv, HOST */
+int har_scene_set_texture_to_uv(HarScene scene, uint32_t texture, const float to_uv[6]);
 /* ------------------------------------------------------------------------
  *  Incremental updates of the acceleration data.  The reference rebuilds what a changed shape needs, not the scene: Scene::parameters_changed calls
  *  m_accel.rebuild only when a shape is dirty (src/render/scene.cpp:517-540); the OptiX backend re-builds the dirty geometry and refreshes the instance level

@@ -100,6 +100,10 @@ SIGNATURES = {
     "har_integrator_set_film_window": (C.c_int, [vp, C.c_uint32, C.c_uint32]),
     "har_scene_set_texture": (C.c_int, [vp, C.c_uint32, f32p]),
     "har_scene_accel_info": (C.c_int, [vp, u64p]),
+    "har_scene_sample_emitter": (C.c_int, [vp, C.c_uint32, vp, vp, vp, vp, vp, vp]),
+    "har_scene_pdf_emitter": (C.c_int, [vp, C.c_uint32, vp, vp, vp, vp]),
+    "har_scene_set_emitter_sampling_weights": (C.c_int, [vp, f32p, C.c_uint32]),
+    "har_scene_set_texture_to_uv": (C.c_int, [vp, C.c_uint32, f32p]),
     "har_scene_update_instances": (C.c_int, [vp, C.c_uint32, C.c_uint32, f32p, f32p, vp]),
     "har_scene_update_vertices": (C.c_int, [vp, C.c_uint32, f32p, vp]),
     "har_scene_refit_info": (C.c_int, [vp, C.POINTER(C.c_double)]),

@@ -1833,6 +1833,11 @@ class Scene:
                 keys[key + ".to_world"] = ("emitter_to_world", i)
             if t == 5:          # SpotLight::traverse (spot.cpp:115-116): the cone, in degrees -- updatable here; their gradient (the reference marks them Differentiable) is refused
                 keys[key + ".cutoff_angle"] = ("cutoff_angle", i); keys[key + ".beam_width"] = ("beam_width", i)
+            # Emitter::traverse (src/render/emitter.cpp:13): `sampling_weight`, NonDifferentiable; an area light is a child of its shape ('<shape>.emitter.*')
+            keys[key + (".emitter" if t in (0, 3) else "") + ".sampling_weight"] = ("sampling_weight", i)
+        for b in self.bsdf_objs:            # BitmapTexture::traverse: `to_uv` (src/textures/bitmap.cpp), NonDifferentiable
+            if b.texture is not None:
+                keys[(b.id if b.id else "bsdf%d" % b.index) + "." + b.slot0_name + ".to_uv"] = ("to_uv", b)
         return keys
 
     def _pose_value(self, kind, b):
@@ -1842,6 +1847,13 @@ class Scene:
             return np.asarray(self.emitters[b]["to_world"][9:12], np.float32).copy()
         if kind in ("cutoff_angle", "beam_width"):
             return np.asarray([self.emitters[b]["normal"][0 if kind == "cutoff_angle" else 1]], np.float32)
+        if kind == "sampling_weight":
+            return np.asarray([self.emitters[b].get("sampling_weight", 1.0)], np.float32)
+        if kind == "to_uv":
+            m = np.eye(3, dtype=np.float32)
+            if b.tex_to_uv is not None:
+                m[:2, :] = np.asarray(b.tex_to_uv, np.float32).reshape(2, 3)
+            return m
         m = np.eye(4, dtype=np.float32); m[:3, :] = np.asarray(self.emitters[b]["to_world"], np.float32).reshape(4, 3).T
         return m
 
@@ -1849,6 +1861,29 @@ class Scene:
         for e in self.emitters:                                      # SpotLight::update, spot.cpp:300-306
             if e.get("type") == 5 and not (e["normal"][0] >= e["normal"][1] and e["normal"][0] > 0):
                 raise RuntimeError("spot: cutoff_angle must be positive and not smaller than beam_width")
+        if getattr(self, "_weights_dirty", False):                   # Scene::parameters_changed -> update_emitter_sampling_distribution (scene.cpp:523-528)
+            self._weights_dirty = False
+            if self._h is not None:
+                w = _f32([e.get("sampling_weight", 1.0) for e in self.emitters])
+                check(lib().har_scene_set_emitter_sampling_weights(self._h, _fp(w), len(self.emitters)))
+
+    def sample_emitter(self, index_sample, active=True):
+        """Scene::sample_emitter(index_sample, active) -> (index, emitter_weight, reused sample) (src/render/scene.cpp:248-271), array-valued"""
+        torch = _torch(); dev = _device()
+        s = torch.as_tensor(index_sample, dtype=torch.float32, device=dev).reshape(-1).contiguous(); n = s.numel()
+        index = torch.empty(n, dtype=torch.int32, device=dev); weight = torch.empty(n, dtype=torch.float32, device=dev); reused = torch.empty_like(weight)
+        mask = _mask(active, n)
+        check(lib().har_scene_sample_emitter(self._handle(), n, _ptr(s), _ptr(mask), _ptr(index), _ptr(weight), _ptr(reused), _stream()))
+        return index, weight, reused
+
+    def pdf_emitter(self, index, active=True):
+        """Scene::pdf_emitter(index, active) (scene.cpp:273-279)"""
+        torch = _torch(); dev = _device()
+        i = torch.as_tensor(index, device=dev).to(torch.int32).reshape(-1).contiguous(); n = i.numel()
+        pdf = torch.empty(n, dtype=torch.float32, device=dev)
+        mask = _mask(active, n)
+        check(lib().har_scene_pdf_emitter(self._handle(), n, _ptr(i), _ptr(mask), _ptr(pdf), _stream()))
+        return pdf
 
     def _set_pose(self, kind, b, value):
         # validate first, assign last: a rejected value leaves the scene (and the params entry's counterpart) as it was
@@ -1866,6 +1901,25 @@ class Scene:
             except Exception:
                 b.to_world = old; b.update()
                 raise
+            return
+        if kind == "sampling_weight":
+            w = float(np.asarray(value, np.float32).reshape(-1)[0])
+            if not (w >= 0.0) or not math.isfinite(w):
+                raise RuntimeError("DiscreteDistribution: entries must be non-negative!")
+            e = dict(self.emitters[b]); e["sampling_weight"] = w; self.emitters[b] = e
+            self._weights_dirty = True               # the distribution is rebuilt once, after every weight of this update() is in (_validate_spots)
+            return
+        if kind == "to_uv":
+            m = np.asarray(value.matrix if isinstance(value, (ScalarTransform3f, ScalarTransform4f)) else value, np.float32)
+            if m.shape == (4, 4):
+                m = np.array([[m[0, 0], m[0, 1], m[0, 3]], [m[1, 0], m[1, 1], m[1, 3]], [0.0, 0.0, 1.0]], np.float32)
+            m = m.reshape(3, 3)
+            if not np.isfinite(m).all() or float(np.linalg.det(m[:2, :2].astype(np.float64))) == 0.0:
+                raise RuntimeError("bitmap: 'to_uv' is singular")
+            rows = [float(x) for x in m[:2, :].reshape(-1)]
+            b.tex_to_uv = rows; self.texture_to_uv[b.tex_index] = rows
+            if self._h is not None:
+                check(lib().har_scene_set_texture_to_uv(self._h, b.tex_index, _fp(_f32(rows))))
             return
         e = dict(self.emitters[b])
         if kind in ("cutoff_angle", "beam_width"):

@@ -147,6 +147,7 @@ struct HarSceneImpl {
     size_t nodes_cap = 0;
     RefitBox *tri_box = nullptr, *node_box = nullptr; uint32_t *d_refit_order = nullptr; float *d_area = nullptr;
     double last_refit_cost = 0.0, last_refit_ratio = 1.0;
+    float *d_emitter_distr = nullptr; DTexture *d_textures = nullptr;
 };
 
 struct HarIntegratorImpl {
@@ -798,7 +799,7 @@ int har_scene_create(const HarSceneDesc *desc, HarScene *out) {
         S->tex_dev.push_back(const_cast<float *>(p)); dt.push_back(hs.device_texture(dt.size(), p));
     }
     S->tex_host_stale.assign(hs.textures.size(), 0);
-    up(dt, &D.textures);
+    up(dt, &D.textures); S->d_textures = const_cast<DTexture *>(D.textures);
     up(hs.bsdf_tables, &D.bsdf_tables);
     D.envmap = nullptr;
     if (hs.has_envmap) {
@@ -807,7 +808,11 @@ int har_scene_create(const HarSceneDesc *desc, HarScene *out) {
         std::vector<DEnvmap> one(1, hs.envmap); up(one, &D.envmap);
     }
     up(hs.emitter_cdf, &D.emitter_cdf);
-    { const float *distr = nullptr; up(hs.emitter_distr, &distr); hs.bind_tables(D, distr); }
+    {   /* the emitter-selection table always gets room for 2 x emitter_count floats: har_scene_set_emitter_sampling_weights rewrites it in place */
+        std::vector<float> table(std::max<size_t>(2 * hs.emitters.size(), 1), 0.f);
+        std::copy(hs.emitter_distr.begin(), hs.emitter_distr.end(), table.begin());
+        const float *distr = nullptr; up(table, &distr); S->d_emitter_distr = const_cast<float *>(distr); hs.bind_tables(D, distr);
+    }
     if (err != hipSuccess) { for (void *p : S->owned) dev_free(p); delete S; return fail(std::string("scene upload: ") + hipGetErrorString(err)); }
     S->d_bsdfs = const_cast<DBsdf *>(D.bsdfs);
     D.accel.root = hs.root; D.accel.has_tlas = hs.has_tlas; D.accel.n_tris = (uint32_t) hs.tris.size(); D.accel.n_insts = (uint32_t) hs.inst_recs.size();
@@ -936,6 +941,55 @@ int har_scene_accel_info(HarScene S, uint64_t info[4]) {
     info[0] = S->hs.nodes.size(); info[1] = S->hs.tris.size();
     info[2] = S->hs.nodes.size() * sizeof(Node8) + S->hs.tris.size() * sizeof(TriRec) + S->hs.inst_recs.size() * sizeof(InstRec);
     info[3] = S->hs.stack_need();
+    return 0;
+}
+
+/* Scene::sample_emitter / pdf_emitter (src/render/scene.cpp:248-279), array-valued */
+int har_scene_sample_emitter(HarScene S, uint32_t n, const float *index_sample, const uint8_t *active, uint32_t *index, float *weight, float *reused_sample, void *stream) {
+    if (!S) return fail("null scene");
+    if (n == 0) return 0;
+    if (!index_sample || !index || !weight || !reused_sample) return fail("null sample / output arrays");
+    launch_api_sample_emitter((hipStream_t) stream, S->ds, n, index_sample, active, index, weight, reused_sample);
+    HIP_TRY(hipGetLastError());
+    return 0;
+}
+int har_scene_pdf_emitter(HarScene S, uint32_t n, const uint32_t *index, const uint8_t *active, float *pdf, void *stream) {
+    if (!S) return fail("null scene");
+    if (n == 0) return 0;
+    if (!index || !pdf) return fail("null index / output arrays");
+    launch_api_pdf_emitter((hipStream_t) stream, S->ds, n, index, active, pdf);
+    HIP_TRY(hipGetLastError());
+    return 0;
+}
+/* params['<emitter>.sampling_weight'] + update(): Scene::parameters_changed -> update_emitter_sampling_distribution (scene.cpp:120-141, 523-528) */
+int har_scene_set_emitter_sampling_weights(HarScene S, const float *weights, uint32_t count) {
+    if (!S || !weights) return fail("null argument");
+    if (count != S->hs.emitters.size()) return fail("one sampling weight per emitter of the scene");
+    std::string e;
+    if (!build_emitter_distribution(S->hs, weights, count, e)) return fail(e);
+    if (!S->hs.emitter_distr.empty()) HIP_TRY(hipMemcpy(S->d_emitter_distr, S->hs.emitter_distr.data(), S->hs.emitter_distr.size() * sizeof(float), hipMemcpyHostToDevice));
+    S->hs.bind_tables(S->ds, S->d_emitter_distr);
+    /* scenes with a distribution run the kernels that carry the generic emitter code */
+    const bool generic = S->hs.has_envmap || S->hs.has_mesh_emitters || S->hs.has_point_emitters || !S->hs.emitter_distr.empty();
+    S->ds.bsdf_types = generic ? (S->ds.bsdf_types | HAR_SCENE_ENVMAP) : (S->ds.bsdf_types & ~HAR_SCENE_ENVMAP);
+    return 0;
+}
+/* params['<texture>.to_uv'] + update(): BitmapTexture::parameters_changed with a new m_transform (bitmap.cpp:175); six zeros or the identity switch the transform off */
+int har_scene_set_texture_to_uv(HarScene S, uint32_t tex, const float to_uv[6]) {
+    if (!S || tex >= S->hs.textures.size() || !to_uv) return fail("invalid texture index");
+    HostTexture &t = S->hs.textures[tex];
+    const float id6[6] = { 1.f, 0.f, 0.f, 0.f, 1.f, 0.f };
+    bool zero = true, ident = true;
+    for (int k = 0; k < 6; ++k) { if (!std::isfinite(to_uv[k])) return fail("HarTexture::to_uv must be finite"); zero = zero && to_uv[k] == 0.f; ident = ident && to_uv[k] == id6[k]; }
+    t.mode &= ~HAR_TEX_HAS_UV_XF;
+    for (int k = 0; k < 6; ++k) t.uvm[k] = id6[k];
+    if (!zero && !ident) {
+        if (to_uv[0] * to_uv[4] - to_uv[1] * to_uv[3] == 0.f) return fail("HarTexture::to_uv is singular");
+        for (int k = 0; k < 6; ++k) t.uvm[k] = to_uv[k];
+        t.mode |= HAR_TEX_HAS_UV_XF;
+    }
+    const DTexture d = S->hs.device_texture(tex, S->tex_dev[tex]);
+    HIP_TRY(hipMemcpy(S->d_textures + tex, &d, sizeof(DTexture), hipMemcpyHostToDevice));
     return 0;
 }
 

@@ -193,6 +193,8 @@ void launch_api_intersect(hipStream_t s, const DScene &S, uint32_t n, const floa
 void launch_api_ray_test(hipStream_t s, const DScene &S, uint32_t n, const float *o, const float *d, const float *maxt, const uint8_t *active, int naive, uint8_t *out, int *status);
 void launch_api_si(hipStream_t s, const DScene &S, uint32_t n, const float *o, const float *d, const float *t, const float *u, const float *v,
                    const uint32_t *prim, const uint32_t *shape, const uint32_t *inst, uint32_t ray_flags, const uint8_t *active, float *out);
+void launch_api_sample_emitter(hipStream_t s, const DScene &S, uint32_t n, const float *sample, const uint8_t *active, uint32_t *index, float *weight, float *reused);
+void launch_api_pdf_emitter(hipStream_t s, const DScene &S, uint32_t n, const uint32_t *index, const uint8_t *active, float *pdf);
 void launch_api_sampler_seed(hipStream_t s, uint32_t seed, uint32_t lane_offset, uint32_t n, uint64_t *state, uint64_t *inc);
 void launch_api_sampler_next(hipStream_t s, uint32_t n, uint64_t *state, const uint64_t *inc, const uint8_t *active, float *out, int dims);
 void launch_api_bsdf_eval_pdf(hipStream_t s, const DScene &S, uint32_t bsdf, const BsdfCtx &ctx, uint32_t n, const float *wi, const float *uv, const float *wo, const uint8_t *active,

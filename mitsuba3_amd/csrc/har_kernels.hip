@@ -2166,6 +2166,25 @@ void launch_api_si(hipStream_t s, const DScene &S, uint32_t n, const float *o, c
 void launch_api_sampler_seed(hipStream_t s, uint32_t seed, uint32_t lane_offset, uint32_t n, uint64_t *state, uint64_t *inc) {
     hipLaunchKernelGGL(k_api_sampler_seed, dim3(blocks_for(n)), dim3(kBlock), 0, s, seed, lane_offset, n, state, inc);
 }
+/* Scene::sample_emitter(index_sample, active) / Scene::pdf_emitter(index, active) (src/render/scene.cpp:248-279), array-valued */
+__global__ void k_api_sample_emitter(DScene S, uint32_t n, const float *sample, const uint8_t *active, uint32_t *index, float *weight, float *reused) {
+    uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    if (active && !active[i]) { index[i] = 0u; weight[i] = 0.f; reused[i] = 0.f; return; }
+    float w, r;
+    index[i] = scene_sample_emitter(S, sample[i], true, w, r); weight[i] = w; reused[i] = r;
+}
+__global__ void k_api_pdf_emitter(DScene S, uint32_t n, const uint32_t *index, const uint8_t *active, float *pdf) {
+    uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    pdf[i] = ((active && !active[i]) || index[i] >= S.n_emitters) ? 0.f : scene_pdf_emitter(S, index[i]);
+}
+void launch_api_sample_emitter(hipStream_t s, const DScene &S, uint32_t n, const float *sample, const uint8_t *active, uint32_t *index, float *weight, float *reused) {
+    hipLaunchKernelGGL(k_api_sample_emitter, dim3(blocks_for(n)), dim3(kBlock), 0, s, S, n, sample, active, index, weight, reused);
+}
+void launch_api_pdf_emitter(hipStream_t s, const DScene &S, uint32_t n, const uint32_t *index, const uint8_t *active, float *pdf) {
+    hipLaunchKernelGGL(k_api_pdf_emitter, dim3(blocks_for(n)), dim3(kBlock), 0, s, S, n, index, active, pdf);
+}
 void launch_api_sampler_next(hipStream_t s, uint32_t n, uint64_t *state, const uint64_t *inc, const uint8_t *active, float *out, int dims) {
     hipLaunchKernelGGL(k_api_sampler_next, dim3(blocks_for(n)), dim3(kBlock), 0, s, n, state, inc, active, out, dims);
 }

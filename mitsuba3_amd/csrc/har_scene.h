@@ -579,6 +579,28 @@ HAR_HD uint32_t discrete_sample_reuse_pmf(const float *pmf, const float *cdf, ui
     reused = (value01 - cdf_n) / pmf_n; pmf_out = pmf_n;
     return start;
 }
+/* Scene::sample_emitter (src/render/scene.cpp:248-271) and Scene::pdf_emitter (:273-279): the emitter a uniform sample picks, the weight 1 / probability and the re-used
+ * sample.  Uniform choice unless the scene holds a distribution over the emitters' sampling weights (DScene::emitter_distr).  `jit`: the variant's predicate of
+ * DiscreteDistribution::sample.  No emitters: index 0xffffffff, weight 0 (:251-256). */
+HAR_HD uint32_t scene_sample_emitter(const DScene &S, float sample, bool jit, float &weight, float &reused) {
+    weight = 1.f; reused = sample;
+    if (S.n_emitters < 2u) { if (S.n_emitters == 0u) weight = 0.f; return S.n_emitters ? 0u : 0xffffffffu; }
+    if (S.emitter_distr != nullptr) {
+        float p;
+        const uint32_t index = discrete_sample_reuse_pmf(S.emitter_distr, S.emitter_distr + S.n_emitters, S.emitter_valid_lo, S.emitter_valid_hi, S.emitter_sum, S.emitter_norm,
+                                                         sample, jit, reused, p);
+        weight = rcp_(p);
+        return index;
+    }
+    const float scaled = sample * (float) S.n_emitters;
+    uint32_t index = (uint32_t) scaled; if (index > S.n_emitters - 1u) index = S.n_emitters - 1u;
+    weight = (float) S.n_emitters; reused = scaled - (float) index;
+    return index;
+}
+HAR_HD float scene_pdf_emitter(const DScene &S, uint32_t index) {
+    if (S.emitter_distr == nullptr) return S.n_emitters ? 1.f / (float) S.n_emitters : 0.f;      /* m_emitter_pmf, scene.cpp:139 */
+    return S.emitter_distr[index] * S.emitter_norm;                                             /* eval_pmf_normalized */
+}
 /* AreaLight::sample_direction on a triangle mesh: Mesh::sample_position (src/render/mesh.cpp:1662-1712) -- DiscreteDistribution::sample_reuse over the
  * face areas (distr_1d.h:117-183, JIT predicate, dr::binary_search over [0, n - 1]), warp::square_to_uniform_triangle (warp.h:153-156), interpolated
  * vertex normals when the mesh has them -- then Shape::sample_direction (shape.cpp:93-110) and the one-sided test of area.cpp:118-168 */

@@ -334,23 +334,10 @@ bool lower_scene(const HarSceneDesc &d, HostScene &hs, std::string &err) {
         }
         hs.emitters.push_back(de);
     }
-    /* Scene::update_emitter_sampling_distribution (scene.cpp:120-141): a DiscreteDistribution over the weights as soon as one differs from 1; its tables are built by
-     * compute_cdf_scalar (distr_1d.h:236-266: running sums in double, rounded to float per entry; first / last bin with mass) in every variant, because the
-     * constructor taking a ScalarFloat array is the one used */
-    bool non_uniform = false;
-    for (uint32_t i = 0; i < d.emitter_count; ++i) non_uniform = non_uniform || d.emitters[i].sampling_weight != 1.f;
-    if (non_uniform) {
-        const uint32_t n = d.emitter_count;
-        hs.emitter_distr.assign(2 * (size_t) n, 0.f);
-        double sum = 0.0; uint32_t lo = 0xffffffffu, hi = 0xffffffffu;
-        for (uint32_t i = 0; i < n; ++i) {
-            const double v = (double) d.emitters[i].sampling_weight;
-            sum += v; hs.emitter_distr[i] = d.emitters[i].sampling_weight; hs.emitter_distr[n + i] = (float) sum;
-            if (v > 0.0) { if (lo == 0xffffffffu) lo = i; hi = i; }
-        }
-        if (lo == 0xffffffffu) { err = "DiscreteDistribution: no probability mass found!"; return false; }
-        hs.emitter_valid_lo = lo; hs.emitter_valid_hi = hi;
-        hs.emitter_sum = hs.emitter_distr[n + hi]; hs.emitter_norm = rcp_(hs.emitter_sum);
+    {
+        std::vector<float> weights(d.emitter_count);
+        for (uint32_t i = 0; i < d.emitter_count; ++i) weights[i] = d.emitters[i].sampling_weight;
+        if (!build_emitter_distribution(hs, weights.data(), d.emitter_count, err)) return false;
     }
     for (uint32_t g = 0; g < d.group_count; ++g)
         if (d.groups[g].first_mesh < d.top_mesh_count || d.groups[g].first_mesh + d.groups[g].mesh_count > d.mesh_count) { err = "shapegroup mesh range invalid"; return false; }
@@ -477,6 +464,30 @@ bool build_tlas(HostScene &hs, std::string &err) {
     hs.inst_recs.clear(); hs.blas_tri_ranges.clear();
     for (uint32_t k : order) { hs.inst_recs.push_back(recs[k]); hs.blas_tri_ranges.push_back(ranges[2 * k]); hs.blas_tri_ranges.push_back(ranges[2 * k + 1]); }
     (void) err;
+    return true;
+}
+
+/* Scene::update_emitter_sampling_distribution (scene.cpp:120-141): a DiscreteDistribution over the weights as soon as one differs from 1; its tables are built by
+ * compute_cdf_scalar (distr_1d.h:236-266: running sums in double, rounded to float per entry; first / last bin with mass) in every variant, because the
+ * constructor taking a ScalarFloat array is the one used */
+bool build_emitter_distribution(HostScene &hs, const float *weights, uint32_t n, std::string &err) {
+    bool non_uniform = false;
+    for (uint32_t i = 0; i < n; ++i) {
+        if (!(weights[i] >= 0.f) || !std::isfinite(weights[i])) { err = "DiscreteDistribution: entries must be non-negative!"; return false; }      /* distr_1d.h:247-248 */
+        non_uniform = non_uniform || weights[i] != 1.f;
+    }
+    hs.emitter_distr.clear(); hs.emitter_sum = 0.f; hs.emitter_norm = 0.f; hs.emitter_valid_lo = 0; hs.emitter_valid_hi = 0;
+    if (!non_uniform) return true;
+    hs.emitter_distr.assign(2 * (size_t) n, 0.f);
+    double sum = 0.0; uint32_t lo = 0xffffffffu, hi = 0xffffffffu;
+    for (uint32_t i = 0; i < n; ++i) {
+        const double v = (double) weights[i];
+        sum += v; hs.emitter_distr[i] = weights[i]; hs.emitter_distr[n + i] = (float) sum;
+        if (v > 0.0) { if (lo == 0xffffffffu) lo = i; hi = i; }
+    }
+    if (lo == 0xffffffffu) { hs.emitter_distr.clear(); err = "DiscreteDistribution: no probability mass found!"; return false; }
+    hs.emitter_valid_lo = lo; hs.emitter_valid_hi = hi;
+    hs.emitter_sum = hs.emitter_distr[n + hi]; hs.emitter_norm = rcp_(hs.emitter_sum);
     return true;
 }
 

@@ -70,6 +70,9 @@ void update_roughplastic_sampling_weight(HostScene &hs, uint32_t bsdf);
 /* quad::gauss_legendre (include/mitsuba/core/quad.h:27-90): nodes / weights on [-1, 1] */
 void quad_gauss_legendre(int n, std::vector<float> &nodes, std::vector<float> &weights);
 
+/* Scene::update_emitter_sampling_distribution (src/render/scene.cpp:120-141) from `weights` (one per emitter): fills emitter_distr / _sum / _norm / _valid_* (empty table =
+ * uniform selection: every weight is 1) */
+bool build_emitter_distribution(HostScene &hs, const float *weights, uint32_t n, std::string &err);
 /* returns false and fills `err` on invalid input */
 bool lower_scene(const HarSceneDesc &desc, HostScene &out, std::string &err);
 /* the pieces of lower_scene an update re-runs: bounding sphere of the scene for the environment / directional emitters (constant.cpp:72-87), world boxes of the

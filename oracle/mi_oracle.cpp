@@ -583,6 +583,25 @@ static inline float mis_weight(float a, float b) {
     return std::isfinite(w) ? w : 0.f;
 }
 
+/* Scene::update_emitter_sampling_distribution (scene.cpp:120-141) -> DiscreteDistribution(const ScalarFloat *, size) -> compute_cdf_scalar (distr_1d.h:236-266); false: a
+ * negative weight or no probability mass at all (the reference throws) */
+static bool rebuild_emitter_choice(Scene &sc) {
+    Scene::EmitterChoice ch;
+    for (const OrcEmitter &e : sc.emitters) { if (!(e.sampling_weight >= 0.f)) return false; ch.weighted = ch.weighted || e.sampling_weight != 1.f; }
+    if (ch.weighted) {
+        double running = 0.0; bool seen = false;
+        for (uint32_t i = 0; i < sc.emitters.size(); ++i) {
+            const float w = sc.emitters[i].sampling_weight;
+            running += (double) w; ch.table.pmf.push_back(w); ch.table.cdf.push_back((float) running);
+            if (w > 0.f) { if (!seen) ch.first = i; ch.last = i; seen = true; }
+        }
+        if (!seen) return false;                                        /* "no probability mass found!" */
+        ch.table.sum = ch.table.cdf[ch.last]; ch.table.normalization = rcp(ch.table.sum);
+    }
+    sc.choice = ch;
+    return true;
+}
+
 /* Scene::pdf_emitter (scene.cpp:273-279) / the emitter_pmf of pdf_emitter_direction (:378-388): m_emitter_pmf = 1 / n, or weight * normalization of the distribution */
 static inline float emitter_choice_pmf(const Scene &sc, uint32_t index) {
     if (!sc.choice.weighted) return 1.f / (float) sc.emitters.size();
@@ -1805,20 +1824,7 @@ void *orc_scene_create(const OrcSceneDesc *d) {
     }
     sc->emitters.assign(d->emitters, d->emitters + d->emitter_count);
     sc->area_pmf.resize(sc->emitters.size());
-    {   /* Scene::update_emitter_sampling_distribution (scene.cpp:120-141) -> DiscreteDistribution(const ScalarFloat *, size) -> compute_cdf_scalar (distr_1d.h:236-266) */
-        Scene::EmitterChoice &ch = sc->choice;
-        for (const OrcEmitter &e : sc->emitters) { if (!(e.sampling_weight >= 0.f)) { delete sc; return nullptr; } ch.weighted = ch.weighted || e.sampling_weight != 1.f; }
-        if (ch.weighted) {
-            double running = 0.0; bool seen = false;
-            for (uint32_t i = 0; i < sc->emitters.size(); ++i) {
-                const float w = sc->emitters[i].sampling_weight;
-                running += (double) w; ch.table.pmf.push_back(w); ch.table.cdf.push_back((float) running);
-                if (w > 0.f) { if (!seen) ch.first = i; ch.last = i; seen = true; }
-            }
-            if (!seen) { delete sc; return nullptr; }                       /* "no probability mass found!" */
-            ch.table.sum = ch.table.cdf[ch.last]; ch.table.normalization = rcp(ch.table.sum);
-        }
-    }
+    if (!rebuild_emitter_choice(*sc)) { delete sc; return nullptr; }
     for (uint32_t i = 0; i < sc->emitters.size(); ++i) {
         const OrcEmitter e = sc->emitters[i];
         if (e.type == 1 || e.type == 2) sc->env = (int) i;
@@ -1858,6 +1864,39 @@ void orc_scene_set_reflectance(void *s, uint32_t b, const float rgb[3]) {
     Scene *sc = (Scene *) s; for (int i = 0; i < 3; ++i) sc->bsdfs[b].p.reflectance[i] = rgb[i];
     if (sc->bsdfs[b].p.type == 3) roughplastic_precompute(sc->bsdfs[b], slot0_mean(*sc, b));
     if (sc->bsdfs[b].p.type == 5) plastic_precompute(sc->bsdfs[b], slot0_mean(*sc, b));
+}
+/* Scene::sample_emitter / pdf_emitter as the JIT variants evaluate them (scene.cpp:248-279): n samples -> index, 1 / pmf, re-used sample; index -> pmf */
+void orc_scene_sample_emitter(void *s, uint32_t n, const float *sample, uint32_t *index, float *weight, float *reused) {
+    const Scene &sc = *(Scene *) s; const uint32_t ne = (uint32_t) sc.emitters.size();
+    for (uint32_t k = 0; k < n; ++k) {
+        if (ne < 2) { index[k] = ne ? 0u : 0xffffffffu; weight[k] = ne ? 1.f : 0.f; reused[k] = sample[k]; continue; }      /* :251-256 */
+        if (sc.choice.weighted) {
+            float p;
+            index[k] = discrete_sample_reuse(sc.choice.table.pmf.data(), sc.choice.table.cdf.data(), ne, sc.choice.table.sum, sc.choice.table.normalization, sample[k], reused[k], p,
+                                             sc.choice.first, sc.choice.last);
+            weight[k] = rcp(p);
+        } else {
+            const float scaled = sample[k] * (float) ne;
+            index[k] = std::min((uint32_t) scaled, ne - 1u); weight[k] = (float) ne; reused[k] = scaled - (float) index[k];
+        }
+    }
+}
+void orc_scene_pdf_emitter(void *s, uint32_t n, const uint32_t *index, float *pdf) {
+    const Scene &sc = *(Scene *) s;
+    for (uint32_t k = 0; k < n; ++k) pdf[k] = (sc.emitters.empty() || index[k] >= sc.emitters.size()) ? 0.f : emitter_choice_pmf(sc, index[k]);
+}
+int orc_scene_set_emitter_weights(void *s, const float *w, uint32_t n) {
+    Scene &sc = *(Scene *) s;
+    if (n != sc.emitters.size()) return 1;
+    std::vector<float> old(n);
+    for (uint32_t i = 0; i < n; ++i) { old[i] = sc.emitters[i].sampling_weight; sc.emitters[i].sampling_weight = w[i]; }
+    if (!rebuild_emitter_choice(sc)) { for (uint32_t i = 0; i < n; ++i) sc.emitters[i].sampling_weight = old[i]; return 2; }
+    return 0;
+}
+void orc_scene_set_texture_to_uv(void *s, uint32_t t, const float m[6]) {
+    Texture &x = ((Scene *) s)->textures[t];
+    x.moved = false;
+    for (int r = 0; r < 2; ++r) for (int c = 0; c < 3; ++c) { x.xf[r][c] = m[3 * r + c]; x.moved = x.moved || m[3 * r + c] != (r == c ? 1.f : 0.f); }
 }
 void orc_scene_set_texture(void *s, uint32_t t, const float *data) { Texture &x = ((Scene *) s)->textures[t]; x.data.assign(data, data + 3 * (size_t) x.w * x.h); }
 

@@ -130,6 +130,10 @@ void *orc_scene_create(const OrcSceneDesc *desc);
 void  orc_scene_destroy(void *scene);
 /* update a constant reflectance / a texture in place (for finite differences) */
 void  orc_scene_set_reflectance(void *scene, uint32_t bsdf, const float rgb[3]);
+void  orc_scene_sample_emitter(void *scene, uint32_t n, const float *sample, uint32_t *index, float *weight, float *reused);
+void  orc_scene_pdf_emitter(void *scene, uint32_t n, const uint32_t *index, float *pdf);
+int   orc_scene_set_emitter_weights(void *scene, const float *weights, uint32_t n);
+void  orc_scene_set_texture_to_uv(void *scene, uint32_t texture, const float to_uv[6]);
 void  orc_scene_set_texture(void *scene, uint32_t texture, const float *data);
 
 /* ---- Hierarchical2D<Float, 0> (distr_2d.h:370-860) and the environment-map emitter (src/emitters/envmap.cpp) as free functions ---- */

@@ -730,6 +730,33 @@ class OracleScene:
     def set_reflectance(self, bsdf, rgb):
         lib().orc_scene_set_reflectance(self.handle, bsdf, fp(f32(rgb)))
 
+    def sample_emitter(self, sample):
+        """Scene::sample_emitter (scene.cpp:248-271): (index, weight, reused sample) arrays"""
+        sample = f32(sample).reshape(-1); n = sample.size
+        index = np.zeros(n, np.uint32); weight = np.zeros(n, np.float32); reused = np.zeros(n, np.float32)
+        L = lib(); L.orc_scene_sample_emitter.restype = None
+        L.orc_scene_sample_emitter.argtypes = [C.c_void_p, C.c_uint32, c_f32p, c_u32p, c_f32p, c_f32p]
+        L.orc_scene_sample_emitter(self.handle, n, fp(sample), index.ctypes.data_as(c_u32p), fp(weight), fp(reused))
+        return index, weight, reused
+
+    def pdf_emitter(self, index):
+        index = np.ascontiguousarray(index, np.uint32).reshape(-1); pdf = np.zeros(index.size, np.float32)
+        L = lib(); L.orc_scene_pdf_emitter.restype = None; L.orc_scene_pdf_emitter.argtypes = [C.c_void_p, C.c_uint32, c_u32p, c_f32p]
+        L.orc_scene_pdf_emitter(self.handle, index.size, index.ctypes.data_as(c_u32p), fp(pdf))
+        return pdf
+
+    def set_emitter_weights(self, weights):
+        w = f32(weights).reshape(-1)
+        L = lib(); L.orc_scene_set_emitter_weights.restype = C.c_int; L.orc_scene_set_emitter_weights.argtypes = [C.c_void_p, c_f32p, C.c_uint32]
+        rc = L.orc_scene_set_emitter_weights(self.handle, fp(w), w.size)
+        if rc:
+            raise RuntimeError("DiscreteDistribution: invalid emitter weights (rc %d)" % rc)
+
+    def set_texture_to_uv(self, idx, rows):
+        m = f32(rows).reshape(-1)
+        L = lib(); L.orc_scene_set_texture_to_uv.restype = None; L.orc_scene_set_texture_to_uv.argtypes = [C.c_void_p, C.c_uint32, c_f32p]
+        L.orc_scene_set_texture_to_uv(self.handle, idx, fp(m))
+
     def set_texture(self, idx, data):
         lib().orc_scene_set_texture(self.handle, idx, fp(f32(data)))
 
@@ -767,5 +794,6 @@ def scene_from_product(scene):
     sd.textures = list(scene.textures); sd.texture_modes = list(getattr(scene, 'texture_modes', [])); sd.emitters = list(scene.emitters)
     sd.texture_to_uv = list(getattr(scene, 'texture_to_uv', []))
     s = Sensor()
-    C.memmove(C.byref(s), C.byref(scene.sensors()[0].har), C.sizeof(s))
+    if scene.sensors():          # (a scene without a sensor still answers ray and emitter queries)
+        C.memmove(C.byref(s), C.byref(scene.sensors()[0].har), C.sizeof(s))
     return OracleScene(sd), s

@@ -102,6 +102,22 @@ int hh_scene_update_vertices(void *h, uint32_t mesh, const float *vertices, doub
     bind(*H);
     return 0;
 }
+/* Scene::sample_emitter / pdf_emitter of the product's shading headers (scene_sample_emitter, har_scene.h) and the weight update of har_scene_set_emitter_sampling_weights */
+void hh_scene_sample_emitter(void *h, uint32_t n, const float *sample, int jit, uint32_t *index, float *weight, float *reused) {
+    const DScene &S = ((HScene *) h)->ds;
+    for (uint32_t k = 0; k < n; ++k) index[k] = scene_sample_emitter(S, sample[k], jit != 0, weight[k], reused[k]);
+}
+void hh_scene_pdf_emitter(void *h, uint32_t n, const uint32_t *index, float *pdf) {
+    const DScene &S = ((HScene *) h)->ds;
+    for (uint32_t k = 0; k < n; ++k) pdf[k] = index[k] < S.n_emitters ? scene_pdf_emitter(S, index[k]) : 0.f;
+}
+int hh_scene_set_emitter_weights(void *h, const float *w, uint32_t n, char *err, int errlen) {
+    HScene *H = (HScene *) h; std::string e;
+    if (n != H->hs.emitters.size()) { snprintf(err, errlen, "one weight per emitter"); return 1; }
+    if (!build_emitter_distribution(H->hs, w, n, e)) { snprintf(err, errlen, "%s", e.c_str()); return 1; }
+    bind(*H);
+    return 0;
+}
 /* FNV-1a over the bytes of the node array, the triangle records and the instance records: the builder's output, for tests that compare builds */
 void hh_accel_hash(void *h, uint64_t out[3]) {
     HScene *H = (HScene *) h;

@@ -139,3 +139,50 @@ def test_vertex_position_gradients_through_a_transformed_texture(mi, O):
     assert scale > 0 and np.abs(got - want[mesh]).max() < 2e-3 * scale, np.abs(got - want[mesh]).max() / scale
     k = [k for k, v in scene._param_keys().items() if v[0] == "tex"][0]
     assert rel_l2(grads[k].cpu().numpy(), w_tex[scene._param_keys()[k][1].tex_index]) < 1e-3
+
+
+@pytest.mark.parametrize("weights", [[1.0, 1.0, 1.0], [1.3, 3.8, 0.0]])
+def test_scene_sample_emitter_and_pdf_emitter_on_device(mi, O, weights):
+    """Scene::sample_emitter / pdf_emitter through the C ABI (src/render/tests/test_scene.py:162-201) == the oracle, entry for entry, incl. a mask"""
+    from tests.test_scene_properties_cpu import _three_emitter_scene
+    scene = _three_emitter_scene(mi, weights)
+    osc, _ = O.scene_from_product(scene)
+    pdf = np.array(weights) / np.sum(weights)
+    assert np.allclose(scene.pdf_emitter([0, 1, 2]).cpu().numpy(), pdf, rtol=1e-6)
+    u = ((np.arange(100001) + 0.5) / 100001).astype(np.float32)
+    active = np.random.default_rng(1).random(u.size) < 0.8
+    idx, w, r = scene.sample_emitter(u, active=active)
+    ri, rw, rr = osc.sample_emitter(u)
+    idx = idx.cpu().numpy().astype(np.uint32); w = w.cpu().numpy(); r = r.cpu().numpy()
+    assert np.array_equal(idx[active], ri[active]) and np.array_equal(w[active], rw[active]) and np.array_equal(r[active], rr[active])
+    assert not w[~active].any() and not r[~active].any()
+    freq = np.bincount(ri, minlength=3) / u.size
+    assert np.allclose(freq, pdf, atol=1e-4)
+
+
+def test_weight_and_to_uv_updates_through_traverse(mi, O):
+    """params['<emitter>.sampling_weight'] / params['<bsdf>.<slot>.to_uv'] + update(): the scene handle stays, the render is a freshly loaded scene's"""
+    import torch
+    T = mi.ScalarTransform3f
+    d = two_light_scene(mi, 1.0, 1.0, res=32)
+    tex = np.random.default_rng(2).uniform(0.2, 0.9, (8, 8, 3)).astype(np.float32)
+    d["white"] = {"type": "diffuse", "reflectance": {"type": "bitmap", "data": tex}}
+    scene = mi.load_dict(d); mi.render(scene, spp=4, seed=0); handle = scene._h.value
+    params = mi.traverse(scene)
+    params["light.emitter.sampling_weight"] = torch.tensor([0.5]); params["lamp2.emitter.sampling_weight"] = torch.tensor([2.5])
+    new_uv = T().rotate(30.0).scale([2.0, 3.0])
+    params["white.reflectance.to_uv"] = torch.tensor(new_uv.matrix)
+    params.update()
+    assert scene._h.value == handle
+    d2 = two_light_scene(mi, 0.5, 2.5, res=32); d2["white"] = {"type": "diffuse", "reflectance": {"type": "bitmap", "data": tex, "to_uv": new_uv}}
+    fresh = mi.load_dict(d2)
+    a = mi.render(scene, spp=16, seed=3).cpu().numpy(); b = mi.render(fresh, spp=16, seed=3).cpu().numpy()
+    assert rel_l2(a, b) < 1e-6
+    osc, sensor = O.scene_from_product(scene)
+    ref, ost = osc.render_path(sensor, seed=3, spp=16, max_depth=scene.integrator().max_depth, rr_depth=scene.integrator().rr_depth)
+    assert rel_l2(a, ref) < 1e-4 and scene.integrator().stats()["vertices"] == ost.vertices
+    # back to uniform weights: the distribution goes away again
+    params["light.emitter.sampling_weight"] = torch.tensor([1.0]); params["lamp2.emitter.sampling_weight"] = torch.tensor([1.0]); params.update()
+    d3 = two_light_scene(mi, 1.0, 1.0, res=32); d3["white"] = d2["white"]
+    c = mi.render(scene, spp=16, seed=3).cpu().numpy(); e = mi.render(mi.load_dict(d3), spp=16, seed=3).cpu().numpy()
+    assert rel_l2(c, e) < 1e-6 and rel_l2(c, a) > 1e-3

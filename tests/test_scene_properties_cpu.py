@@ -316,3 +316,101 @@ def test_to_uv_texel_gradients_oracle_vs_finite_differences(mi, O):
     osc.set_texture(ti, tex)
     fd = float(((imgs[0] - imgs[1]) / (2 * eps) * adj).sum())
     assert abs(analytic - fd) / abs(fd) < 0.05, (analytic, fd)
+
+
+# ------------------------------------------------------------------------------------------------ the reference's own scene tests (src/render/tests/test_scene.py)
+
+def _three_emitter_scene(mi, weights):
+    """test_scene.py:162-172 with a rectangle for the sphere (triangle scenes only): an area light, a point light and a constant environment"""
+    return mi.load_dict({'type': 'scene',
+                         'shape': {'type': 'rectangle', 'emitter': {'type': 'area', 'sampling_weight': weights[0]}},
+                         'emitter_0': {'type': 'point', 'sampling_weight': weights[1]},
+                         'emitter_1': {'type': 'constant', 'sampling_weight': weights[2]}})
+
+
+def _hh(O):
+    L = C.CDLL(os.path.join(ROOT, "tests", "host_harness", "libhost_harness.so")); L.hh_scene_create.restype = C.c_void_p
+    L.hh_scene_sample_emitter.argtypes = [C.c_void_p, C.c_uint32, O.c_f32p, C.c_int, O.c_u32p, O.c_f32p, O.c_f32p]
+    L.hh_scene_pdf_emitter.argtypes = [C.c_void_p, C.c_uint32, O.c_u32p, O.c_f32p]
+    L.hh_scene_set_emitter_weights.argtypes = [C.c_void_p, O.c_f32p, C.c_uint32, C.c_char_p, C.c_int]
+    return L
+
+
+def _hh_sample(L, O, h, sample):
+    s = O.f32(sample).reshape(-1); n = s.size
+    idx = np.zeros(n, np.uint32); w = np.zeros(n, np.float32); r = np.zeros(n, np.float32)
+    L.hh_scene_sample_emitter(h, n, O.fp(s), 1, idx.ctypes.data_as(O.c_u32p), O.fp(w), O.fp(r))
+    return idx, w, r
+
+
+@pytest.mark.parametrize("weights", [[1.0, 1.0, 1.0], [1.3, 3.8, 0.0]])
+def test_reference_emitter_pdf_and_sampling(mi, O, weights):
+    """test_scene.py:162-201 (test05_emitter_pdf, test06_emitter_sampling): pdf_emitter(i) = w_i / sum; sample_emitter(0.75) agrees with a DiscreteDistribution over the
+    weights (hand-evaluated here: index, 1 / pmf, re-used sample) -- on the oracle and on the product's host code"""
+    scene = _three_emitter_scene(mi, weights)
+    osc, _ = O.scene_from_product(scene)
+    L = _hh(O); desc = scene.desc(); err = C.create_string_buffer(256); h = C.c_void_p(L.hh_scene_create(C.byref(desc), err, 256)); assert h, err.value
+    pdf = np.array(weights) / np.sum(weights)
+    got_p = np.zeros(3, np.float32); L.hh_scene_pdf_emitter(h, 3, np.arange(3, dtype=np.uint32).ctypes.data_as(O.c_u32p), O.fp(got_p))
+    assert np.allclose(osc.pdf_emitter([0, 1, 2]), pdf, rtol=1e-6) and np.allclose(got_p, pdf, rtol=1e-6)
+    sample = 0.75
+    cdf = np.cumsum(weights) / np.sum(weights)
+    ref_index = int(np.searchsorted(cdf, sample, side="left")) if weights != [1.0, 1.0, 1.0] else min(int(sample * 3), 2)
+    ref_pmf = pdf[ref_index]; ref_reused = (sample - (cdf[ref_index - 1] if ref_index else 0.0)) / ref_pmf
+    for index, weight, reused in (osc.sample_emitter([sample]), _hh_sample(L, O, h, [sample])):
+        assert int(index[0]) == ref_index and np.isclose(weight[0], 1.0 / ref_pmf, rtol=1e-6) and np.isclose(reused[0], ref_reused, rtol=1e-5, atol=1e-6)
+    # ... and on a sweep of samples the two implementations agree exactly
+    u = ((np.arange(4097) + 0.5) / 4097).astype(np.float32)
+    a = osc.sample_emitter(u); b = _hh_sample(L, O, h, u)
+    assert np.array_equal(a[0], b[0]) and np.array_equal(a[1], b[1]) and np.array_equal(a[2], b[2])
+
+
+def test_reference_emitter_weight_update(mi, O):
+    """test_scene.py:204-233 (test07_emitter_weight_update): editing sampling_weight through traverse rebuilds the distribution"""
+    scene = mi.load_dict({'type': 'scene', 'emitter_0': {'type': 'point', 'sampling_weight': 2.0}, 'emitter_1': {'type': 'constant', 'sampling_weight': 1.0},
+                          'emitter_2': {'type': 'directional', 'sampling_weight': 0.5}})
+    params = mi.traverse(scene)
+    import torch
+    for k, v in (('emitter_0.sampling_weight', 0.8), ('emitter_1.sampling_weight', 0.05), ('emitter_2.sampling_weight', 1.2)):
+        assert k in params
+        params[k] = torch.tensor([v])
+    params.update()
+    weights = [e["sampling_weight"] for e in scene.emitters]
+    assert np.allclose(weights, [0.8, 0.05, 1.2])
+    osc, _ = O.scene_from_product(scene)                      # a freshly lowered scene with the new weights
+    L = _hh(O); desc = scene.desc(); err = C.create_string_buffer(256); h = C.c_void_p(L.hh_scene_create(C.byref(desc), err, 256)); assert h, err.value
+    pdf = np.array(weights) / np.sum(weights)
+    assert np.allclose(osc.pdf_emitter([0, 1, 2]), pdf, rtol=1e-6)
+    cdf = np.cumsum(weights) / np.sum(weights); ref_index = int(np.searchsorted(cdf, 0.75)); ref_pmf = pdf[ref_index]
+    for index, weight, reused in (osc.sample_emitter([0.75]), _hh_sample(L, O, h, [0.75])):
+        assert int(index[0]) == ref_index and np.isclose(weight[0], 1 / ref_pmf, rtol=1e-6) and np.isclose(reused[0], (0.75 - cdf[ref_index - 1]) / ref_pmf, rtol=1e-5)
+    # the in-place updates (oracle: orc_scene_set_emitter_weights; product host code: the path of har_scene_set_emitter_sampling_weights) equal the fresh lowering
+    old = mi.load_dict({'type': 'scene', 'emitter_0': {'type': 'point', 'sampling_weight': 2.0}, 'emitter_1': {'type': 'constant', 'sampling_weight': 1.0},
+                        'emitter_2': {'type': 'directional', 'sampling_weight': 0.5}})
+    osc2, _ = O.scene_from_product(old); osc2.set_emitter_weights(weights)
+    d2 = old.desc(); h2 = C.c_void_p(L.hh_scene_create(C.byref(d2), err, 256)); assert h2
+    assert L.hh_scene_set_emitter_weights(h2, O.fp(O.f32(weights)), 3, err, 256) == 0
+    u = ((np.arange(1025) + 0.5) / 1025).astype(np.float32)
+    ref = osc.sample_emitter(u)
+    for got in (osc2.sample_emitter(u), _hh_sample(L, O, h2, u)):
+        assert all(np.array_equal(x, y) for x, y in zip(got, ref))
+    assert L.hh_scene_set_emitter_weights(h2, O.fp(O.f32([0, 0, 0])), 3, err, 256) == 1 and b"no probability mass" in err.value
+
+
+def test_reference_to_uv_is_a_traversable_parameter(mi, O):
+    """src/textures/tests/test_bitmap.py:270-281 (test08_to_uv): `to_uv` shows up in traverse with the value it was given; an update re-lowers the lookup"""
+    T = mi.ScalarTransform3f
+    transform = T().translate([2, 4]).scale([3, 9]).rotate(45)
+    d, tex = textured_scene(mi, transform)
+    scene = mi.load_dict(d); params = mi.traverse(scene)
+    key = "white.reflectance.to_uv"
+    assert key in params and np.allclose(params[key].cpu().numpy(), transform.matrix, atol=1e-6)
+    import torch
+    new = T().rotate(-10).scale([1.5, 0.5])
+    params[key] = torch.tensor(new.matrix); params.update()
+    fresh_d, _ = textured_scene(mi, new); fresh = mi.load_dict(fresh_d)
+    assert np.allclose(scene.texture_to_uv[scene.bsdfs[0].tex_index if scene.bsdfs[0].texture is not None else [b for b in scene.bsdfs if b.texture is not None][0].tex_index],
+                       fresh.texture_to_uv[[b for b in fresh.bsdfs if b.texture is not None][0].tex_index])
+    a, sensor = O.scene_from_product(scene); b, _ = O.scene_from_product(fresh)
+    ia, _ = a.render_path(sensor, seed=2, spp=4, max_depth=4, raw=True); ib, _ = b.render_path(sensor, seed=2, spp=4, max_depth=4, raw=True)
+    assert np.array_equal(ia, ib)
