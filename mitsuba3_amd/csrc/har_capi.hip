@@ -818,7 +818,7 @@ int har_scene_create(const HarSceneDesc *desc, HarScene *out) {
     D.accel.root = hs.root; D.accel.has_tlas = hs.has_tlas; D.accel.n_tris = (uint32_t) hs.tris.size(); D.accel.n_insts = (uint32_t) hs.inst_recs.size();
     D.accel.top_root = hs.top_root; D.accel.top_first = hs.top_first; D.accel.top_count = hs.top_count; D.accel.top_last = hs.top_last;
     D.n_emitters = (uint32_t) hs.emitters.size(); D.n_meshes = (uint32_t) hs.meshes.size();
-    D.n_bsdfs = (uint32_t) hs.bsdfs.size(); D.n_textures = (uint32_t) hs.textures.size();
+    D.n_bsdfs = (uint32_t) hs.bsdfs.size(); D.n_insts = (uint32_t) hs.insts.size(); D.n_textures = (uint32_t) hs.textures.size();
     D.env_emitter = hs.env_emitter;
     D.bsdf_types = 0; for (const DBsdf &b : hs.bsdfs) D.bsdf_types |= (1u << b.type) | ((b.flags & BF_TWOSIDED) ? 0x80000000u : 0u);
     if (hs.has_envmap || hs.has_mesh_emitters || hs.has_point_emitters || !hs.emitter_distr.empty()) D.bsdf_types |= HAR_SCENE_ENVMAP;
@@ -865,6 +865,7 @@ int har_scene_set_emitter_radiance(HarScene S, uint32_t emitter, const float rgb
     if (e.type == 2u) return fail("an environment map has no constant radiance");
     e.radiance[0] = rgb[0]; e.radiance[1] = rgb[1]; e.radiance[2] = rgb[2];
     HIP_TRY(hipMemcpy(const_cast<DEmitter *>(S->ds.emitters) + emitter, &e, sizeof(DEmitter), hipMemcpyHostToDevice));
+    if (S->hs.emitters.size() == 1) { S->ds.emitter0 = e; S->ds.emitter0_valid = 1u; }
     return 0;
 }
 /* the records whose lobe-selection weight depends on the MEAN of texture `tex` (RoughPlastic / SmoothPlastic::parameters_changed, roughplastic.cpp:204-242,
@@ -934,6 +935,7 @@ int har_scene_set_emitter_radiance_device(HarScene S, uint32_t emitter, const fl
     HIP_TRY(hipMemcpyAsync(const_cast<float *>(S->ds.emitters[0].radiance) + (size_t) emitter * (sizeof(DEmitter) / sizeof(float)), dev_rgb, 3 * sizeof(float),
                            hipMemcpyDeviceToDevice, (hipStream_t) stream));
     S->emitter_host_stale = true;
+    S->ds.emitter0_valid = 0u;          /* the kernels read the array again (the argument copy no longer holds the radiance) */
     return 0;
 }
 int har_scene_accel_info(HarScene S, uint64_t info[4]) {
@@ -1025,6 +1027,7 @@ static int upload_scene_bounds(HarSceneImpl *S, hipStream_t s) {
         S->emitter_host_stale = false;
     }
     HIP_TRY(hipMemcpyAsync(const_cast<DEmitter *>(S->ds.emitters), hs.emitters.data(), hs.emitters.size() * sizeof(DEmitter), hipMemcpyHostToDevice, s));
+    if (hs.emitters.size() == 1) { S->ds.emitter0 = hs.emitters[0]; S->ds.emitter0_valid = 1u; }
     if (hs.has_envmap && S->ds.envmap) {
         DEnvmap E = hs.envmap;         /* tex / warp already hold the device pointers (har_scene_create) */
         HIP_TRY(hipMemcpyAsync(const_cast<DEnvmap *>(S->ds.envmap), &E, sizeof(DEnvmap), hipMemcpyHostToDevice, s));

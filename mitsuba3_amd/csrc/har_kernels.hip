@@ -988,13 +988,30 @@ __global__ __launch_bounds__(kBlock) void k_classify(DScene S, uint32_t shard_ca
 /* ------------------------------------------------------------------- shade */
 /* INLINE (adjoint replay of a bounce whose shadow-ray results sit in the replay cache): the visibility of the lane's emitter sample is known here,
  * so the vertex's adjoint is committed on the spot instead of going through an item (80 B written + read) and k_resolve_adjoint_cached */
-template <int MODE, uint32_t TYPES, bool SHAPE = false, bool INLINE = false, bool EXTRA = false, bool QUEUED = false, bool RECORD = false>
-__global__ __launch_bounds__(kBlock, HAR_SHADE_MIN_WAVES) void k_shade(DScene S, ShadeParams P, uint32_t lane_base, uint32_t shard_cap, const uint32_t *count_in, WaveState in,
+/* TAB: scenes whose mesh, BSDF and instance tables are small (HAR_TAB_MESHES / _BSDFS / _INSTS records: 17 KB) get a per-block copy of them in LDS.  The shading
+ * kernels are bound by the NUMBER of their memory transactions (k_shade at 76 % address-unit busy, docs/rounds/r04.md item 12): a vertex gathers two 16-byte pieces of its
+ * mesh record, two or three of its BSDF record and -- inside an instance -- six of the instance's transforms, which ds_read_b128 serves without the texture-address path. */
+#define HAR_TAB_MESHES 64
+#define HAR_TAB_BSDFS 32
+#define HAR_TAB_INSTS 128
+template <int MODE, uint32_t TYPES, bool SHAPE = false, bool INLINE = false, bool EXTRA = false, bool QUEUED = false, bool RECORD = false, bool TAB = false>
+__global__ __launch_bounds__(kBlock, HAR_SHADE_MIN_WAVES) void k_shade(DScene S_in, ShadeParams P, uint32_t lane_base, uint32_t shard_cap, const uint32_t *count_in, WaveState in,
                                                   const float4 *h0, const uint2 *h1, WaveState out, uint32_t *count_out,
                                                   ItemArrays items, uint32_t *item_count, float4 *result, ReplayCache rc, uint64_t *pass_rng,
                                                   const float4 *dL, float *grad_slots, ShapeArrays geo, float *const *grad_tex, TexelQueues tq, float *grad_extra,
                                                   MaterialQueues mq, uint32_t mat_class, TapeArrays tape) {
     __shared__ uint32_t lds_r[12];
+    __shared__ uint4 tab_mesh[TAB ? HAR_TAB_MESHES * sizeof(DMesh) / 16 : 1], tab_bsdf[TAB ? HAR_TAB_BSDFS * sizeof(DBsdf) / 16 : 1], tab_inst[TAB ? HAR_TAB_INSTS * sizeof(DInst) / 16 : 1];
+    DScene S = S_in;
+    if (TAB) {
+        static_assert(sizeof(DMesh) % 16 == 0 && sizeof(DBsdf) % 16 == 0 && sizeof(DInst) % 16 == 0, "table records are copied as 16-byte words");
+        const uint4 *gm = reinterpret_cast<const uint4 *>(S_in.meshes), *gb = reinterpret_cast<const uint4 *>(S_in.bsdfs), *gi = reinterpret_cast<const uint4 *>(S_in.insts);
+        for (uint32_t k = threadIdx.x; k < S_in.n_meshes * (uint32_t) (sizeof(DMesh) / 16); k += kBlock) tab_mesh[k] = gm[k];
+        for (uint32_t k = threadIdx.x; k < S_in.n_bsdfs * (uint32_t) (sizeof(DBsdf) / 16); k += kBlock) tab_bsdf[k] = gb[k];
+        for (uint32_t k = threadIdx.x; k < S_in.n_insts * (uint32_t) (sizeof(DInst) / 16); k += kBlock) tab_inst[k] = gi[k];
+        __syncthreads();
+        S.meshes = reinterpret_cast<const DMesh *>(tab_mesh); S.bsdfs = reinterpret_cast<const DBsdf *>(tab_bsdf); S.insts = reinterpret_cast<const DInst *>(tab_inst);
+    }
     /* EXTRA: gradients w.r.t. alpha_u, alpha_v, eta, k, colour slot 1 of the rough BSDF records (15 floats per record): per-block accumulators for
      * the first HAR_LDS_EXTRA_BSDFS records, global atomics beyond */
     __shared__ float xacc[EXTRA ? 15 * HAR_LDS_EXTRA_BSDFS : 1];
@@ -1997,6 +2014,9 @@ void launch_shade(int mode, hipStream_t s, uint32_t grid, const DScene &S, const
                   uint32_t *item_count, float4 *result, const ReplayCache &rc, uint64_t *pass_rng, const float4 *dL, float *grad_slots, const ShapeArrays *geo,
                   float *const *grad_tex, const TexelQueues *tq_in, float *grad_extra, const MaterialQueues *mq_in, uint32_t mat_class, const TapeArrays *tape_in) {
     dim3 g(grid), b(kBlock);
+    /* small scenes: mesh / BSDF / instance tables in LDS (k_shade<.., TAB>); HAR_SHADE_TABLES=0 switches it off (A/B) */
+    static const bool tab_env = !(getenv("HAR_SHADE_TABLES") && atoi(getenv("HAR_SHADE_TABLES")) == 0);
+    const bool tab = tab_env && S.n_meshes <= HAR_TAB_MESHES && S.n_bsdfs <= HAR_TAB_BSDFS && S.n_insts <= HAR_TAB_INSTS;
     const ShapeArrays no_geo{ nullptr, nullptr, nullptr, nullptr, nullptr };
     const TexelQueues no_tq{ nullptr, nullptr, nullptr, nullptr, 0u, 0u };
     const TexelQueues tq = tq_in ? *tq_in : no_tq;
@@ -2004,7 +2024,8 @@ void launch_shade(int mode, hipStream_t s, uint32_t grid, const DScene &S, const
     const TapeArrays tape = tape_in ? *tape_in : TapeArrays{ nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr };
     if (rc.mode == 5) {       /* record tape, primal pass: the adjoint flavour of the shading code, primal bookkeeping, one record per vertex (k_shade<.., RECORD>) */
         const bool env = (S.bsdf_types & HAR_SCENE_ENVMAP) != 0u, diffuse = S.bsdf_types == HAR_BSDF_ONLY_DIFFUSE, cls = (S.bsdf_types & 0x7fffffffu & ~HAR_BSDF_CLASSIC_TYPES) == 0u;
-#define HAR_LAUNCH_SHADE_RECORD(T) hipLaunchKernelGGL((k_shade<MODE_PRB_ADJOINT, T, false, false, false, false, true>), g, b, 0, s, S, P, lane_base, shard_cap, count_in, in, h0, h1, out, count_out, items, item_count, result, rc, pass_rng, dL, grad_slots, no_geo, nullptr, no_tq, nullptr, no_mq, 0u, tape)
+#define HAR_LAUNCH_SHADE_RECORD(T) do { if (tab) hipLaunchKernelGGL((k_shade<MODE_PRB_ADJOINT, T, false, false, false, false, true, true>), g, b, 0, s, S, P, lane_base, shard_cap, count_in, in, h0, h1, out, count_out, items, item_count, result, rc, pass_rng, dL, grad_slots, no_geo, nullptr, no_tq, nullptr, no_mq, 0u, tape); \
+        else hipLaunchKernelGGL((k_shade<MODE_PRB_ADJOINT, T, false, false, false, false, true>), g, b, 0, s, S, P, lane_base, shard_cap, count_in, in, h0, h1, out, count_out, items, item_count, result, rc, pass_rng, dL, grad_slots, no_geo, nullptr, no_tq, nullptr, no_mq, 0u, tape); } while (0)
         if (env) HAR_LAUNCH_SHADE_RECORD(HAR_BSDF_ALL_TYPES | HAR_SCENE_ENVMAP); else if (diffuse) HAR_LAUNCH_SHADE_RECORD(HAR_BSDF_ONLY_DIFFUSE);
         else if (cls) HAR_LAUNCH_SHADE_RECORD(HAR_BSDF_CLASSIC_TYPES); else HAR_LAUNCH_SHADE_RECORD(HAR_BSDF_ALL_TYPES);
 #undef HAR_LAUNCH_SHADE_RECORD
@@ -2056,7 +2077,8 @@ void launch_shade(int mode, hipStream_t s, uint32_t grid, const DScene &S, const
     }
     /* diffuse-only scenes (no twosided wrappers) run kernels in which the other BSDF models are compiled out */
     const bool only_diffuse = S.bsdf_types == HAR_BSDF_ONLY_DIFFUSE;
-#define HAR_LAUNCH_SHADE(M, T) hipLaunchKernelGGL((k_shade<M, T>), g, b, 0, s, S, P, lane_base, shard_cap, count_in, in, h0, h1, out, count_out, items, item_count, result, rc, pass_rng, dL, grad_slots, no_geo, nullptr, no_tq, nullptr, no_mq, 0u, tape)
+#define HAR_LAUNCH_SHADE(M, T) do { if (tab && M != MODE_PRB_ADJOINT) hipLaunchKernelGGL((k_shade<M, T, false, false, false, false, false, true>), g, b, 0, s, S, P, lane_base, shard_cap, count_in, in, h0, h1, out, count_out, items, item_count, result, rc, pass_rng, dL, grad_slots, no_geo, nullptr, no_tq, nullptr, no_mq, 0u, tape); \
+        else hipLaunchKernelGGL((k_shade<M, T>), g, b, 0, s, S, P, lane_base, shard_cap, count_in, in, h0, h1, out, count_out, items, item_count, result, rc, pass_rng, dL, grad_slots, no_geo, nullptr, no_tq, nullptr, no_mq, 0u, tape); } while (0)
     const bool envmap = (S.bsdf_types & HAR_SCENE_ENVMAP) != 0u;      /* generic BSDF code + environment-map sampling / lookup */
     const bool classic = (S.bsdf_types & 0x7fffffffu & ~HAR_BSDF_CLASSIC_TYPES) == 0u;
 #define HAR_LAUNCH_SHADE_MODE(M) do { if (envmap) HAR_LAUNCH_SHADE(M, HAR_BSDF_ALL_TYPES | HAR_SCENE_ENVMAP); else if (only_diffuse) HAR_LAUNCH_SHADE(M, HAR_BSDF_ONLY_DIFFUSE); else if (classic) HAR_LAUNCH_SHADE(M, HAR_BSDF_CLASSIC_TYPES); else HAR_LAUNCH_SHADE(M, HAR_BSDF_ALL_TYPES); } while (0)

@@ -60,7 +60,7 @@ struct BoundScene {
         S.verts = hs.verts.data(); S.faces = hs.faces.data(); S.meshes = hs.meshes.data(); S.bsdfs = hs.bsdfs.data();
         S.textures = dtex.data(); S.emitters = hs.emitters.data(); S.insts = hs.insts.data(); S.bsdf_tables = hs.bsdf_tables.data();
         S.n_emitters = (uint32_t) hs.emitters.size(); S.n_meshes = (uint32_t) hs.meshes.size();
-        S.n_bsdfs = (uint32_t) hs.bsdfs.size(); S.n_textures = (uint32_t) hs.textures.size();
+        S.n_bsdfs = (uint32_t) hs.bsdfs.size(); S.n_insts = (uint32_t) hs.insts.size(); S.n_textures = (uint32_t) hs.textures.size();
         S.env_emitter = hs.env_emitter;
         S.bsdf_types = 0; for (const DBsdf &b : hs.bsdfs) S.bsdf_types |= (1u << b.type) | ((b.flags & BF_TWOSIDED) ? 0x80000000u : 0u);
         S.envmap = nullptr; S.emitter_cdf = hs.emitter_cdf.data();

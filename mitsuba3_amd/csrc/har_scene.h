@@ -54,7 +54,7 @@ struct DScene {
     const DEmitter *emitters;
     const DInst    *insts;
     const float    *bsdf_tables;       /* roughplastic external transmittance tables, 64 floats each */
-    uint32_t n_emitters, n_meshes, n_bsdfs, n_textures;
+    uint32_t n_emitters, n_meshes, n_bsdfs, n_textures, n_insts;      /* n_insts: records of `insts` (the scene's instances) */
     int32_t  env_emitter;              /* index of the environment emitter (Scene::environment()), or -1 */
     uint32_t bsdf_types;               /* bit mask (1 << type) of the BSDF types present (+ bit 31: some record is twosided) */
     const DEnvmap *envmap;             /* device record of the environment map when emitters[env_emitter].type == 2 */
@@ -64,6 +64,9 @@ struct DScene {
     const float   *emitter_distr;
     float    emitter_sum, emitter_norm;
     uint32_t emitter_valid_lo, emitter_valid_hi;
+    /* copy of emitters[0] for scenes with exactly one emitter (kernel argument = scalar registers); emitter0_valid = 0: use the array (the record was updated on the
+     * device, har_scene_set_emitter_radiance_device) */
+    DEmitter emitter0; uint32_t emitter0_valid;
 };
 
 struct DSensor {

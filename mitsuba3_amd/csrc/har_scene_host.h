@@ -44,6 +44,8 @@ struct HostScene {
     void bind_tables(DScene &D, const float *distr_ptr) const {
         D.emitter_distr = emitter_distr.empty() ? nullptr : distr_ptr; D.emitter_sum = emitter_sum; D.emitter_norm = emitter_norm;
         D.emitter_valid_lo = emitter_valid_lo; D.emitter_valid_hi = emitter_valid_hi;
+        D.emitter0_valid = emitters.size() == 1 ? 1u : 0u;
+        if (D.emitter0_valid) D.emitter0 = emitters[0];
     }
     DTexture device_texture(size_t i, const float *data_ptr) const {
         const HostTexture &t = textures[i]; DTexture d{ data_ptr, t.w, t.h, t.mode, 0u, { t.uvm[0], t.uvm[1], t.uvm[2], t.uvm[3], t.uvm[4], t.uvm[5] } };
