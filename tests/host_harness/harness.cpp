@@ -434,11 +434,14 @@ int hh_render_backward_instances(void *h, const HarSensor *sensor, const float *
 enum { HS_RAYS = 0, HS_TOP_NODES, HS_TOP_TRIS, HS_TLAS_NODES, HS_INST_NODES, HS_INST_TRIS, HS_INST_ENTRIES, HS_EMPTY_NODES, HS_STALE_NODES, HS_FALSE_ENTRIES, HS_FALSE_ENTRY_NODES, HS_ENTRY_MARK };
 static unsigned long long g_host_stat[2][12] = { { 0 }, { 0 } };
 static int g_host_child_order = 0;      /* what-if: 1 = back-to-front */
+static std::vector<unsigned long long> g_node_hist[2];      /* visits per node index (closest-hit / any-hit): which nodes a per-block LDS copy would have to hold */
 struct StatHooks {
     int q = 0;
     void ray(bool any_hit) { q = any_hit ? 1 : 0; ++g_host_stat[q][HS_RAYS]; }
     void visited(const Accel &A, const RaySetup &R, float tmax, uint32_t child, uint32_t ng_y, uint32_t tg_y, int phase) {
         ++g_host_stat[q][phase == 0 ? HS_TOP_NODES : phase == 1 ? HS_TLAS_NODES : HS_INST_NODES];
+        if (g_node_hist[q].size() <= child) g_node_hist[q].resize((size_t) child + 1, 0ull);
+        ++g_node_hist[q][child];
         /* is the node's own (quantisation-frame) box beyond the current tmax, i.e. was it queued under an older tmax? */
         const Node8 &N = A.nodes[child];
         const float lo[3] = { N.px, N.py, N.pz }, sc[3] = { as_f32((uint32_t) N.ex << 23), as_f32((uint32_t) N.ey << 23), as_f32((uint32_t) N.ez << 23) };
@@ -489,6 +492,23 @@ extern "C" {
 void hh_set_order(int o) { g_order = o; g_max_sp = 0; }
 void hh_top_phase_stats(double out[24]) { for (int q = 0; q < 2; ++q) for (int k = 0; k < 12; ++k) out[12 * q + k] = (double) g_host_stat[q][k]; }
 int hh_max_sp() { return g_max_sp; }
+/* visits per node of query class q since the process started; returns the number of entries (call with out = nullptr first) */
+uint64_t hh_node_hist(int q, unsigned long long *out, uint64_t cap) {
+    const auto &h = g_node_hist[q ? 1 : 0];
+    if (out) for (size_t i = 0; i < h.size() && i < cap; ++i) out[i] = h[i];
+    return h.size();
+}
+/* layout of the node array for the same tool: first TLAS node (or 0xffffffff), BLAS count, then per BLAS root / node count */
+uint32_t hh_node_layout(void *h, uint32_t *out, uint32_t cap) {
+    HScene *H = (HScene *) h; const HostScene &hs = H->hs;
+    uint32_t k = 0;
+    auto put = [&](uint32_t v) { if (out && k < cap) out[k] = v; ++k; };
+    put(hs.has_tlas ? hs.tlas_first : 0xffffffffu); put((uint32_t) hs.nodes.size()); put((uint32_t) hs.blas_groups.size() + (hs.blas_top.node_count ? 1u : 0u));
+    if (hs.blas_top.node_count) { put(hs.blas_top.root); put(hs.blas_top.node_count); }
+    for (const auto &b : hs.blas_groups) { put(b.root); put(b.node_count); }
+    put(hs.stack_need());
+    return k;
+}
 int hh_trace_stats(void *h, const HarSensor *sensor, uint32_t seed, uint32_t spp, int32_t max_depth, int32_t rr_depth,
                    uint64_t lane_begin, uint64_t lane_end, uint32_t max_bounces, int policy, int refill, double *out) {
     HScene *H = (HScene *) h; const DScene &S = H->ds;
