@@ -971,6 +971,7 @@ int har_scene_set_emitter_sampling_weights(HarScene S, const float *weights, uin
     if (!build_emitter_distribution(S->hs, weights, count, e)) return fail(e);
     if (!S->hs.emitter_distr.empty()) HIP_TRY(hipMemcpy(S->d_emitter_distr, S->hs.emitter_distr.data(), S->hs.emitter_distr.size() * sizeof(float), hipMemcpyHostToDevice));
     S->hs.bind_tables(S->ds, S->d_emitter_distr);
+    if (S->emitter_host_stale) S->ds.emitter0_valid = 0u;      /* a radiance pushed device-to-device is newer than the mirror bind_tables copies */
     /* scenes with a distribution run the kernels that carry the generic emitter code */
     const bool generic = S->hs.has_envmap || S->hs.has_mesh_emitters || S->hs.has_point_emitters || !S->hs.emitter_distr.empty();
     S->ds.bsdf_types = generic ? (S->ds.bsdf_types | HAR_SCENE_ENVMAP) : (S->ds.bsdf_types & ~HAR_SCENE_ENVMAP);

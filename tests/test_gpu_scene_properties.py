@@ -186,3 +186,31 @@ def test_weight_and_to_uv_updates_through_traverse(mi, O):
     d3 = two_light_scene(mi, 1.0, 1.0, res=32); d3["white"] = d2["white"]
     c = mi.render(scene, spp=16, seed=3).cpu().numpy(); e = mi.render(mi.load_dict(d3), spp=16, seed=3).cpu().numpy()
     assert rel_l2(c, e) < 1e-6 and rel_l2(c, a) > 1e-3
+
+
+def test_single_emitter_record_follows_every_kind_of_update(mi, O):
+    """a scene with ONE emitter hands its record to the shading kernels as a kernel argument (DScene::emitter0): a radiance set from a device tensor, one set from the
+    host, and a weight update after a device-side radiance must all reach the render -- against freshly loaded scenes"""
+    import torch
+    def box(radiance, weight=1.0):
+        d = mi.cornell_box(); d["sensor"]["film"]["width"] = 32; d["sensor"]["film"]["height"] = 32
+        d["light"]["emitter"]["radiance"] = {"type": "rgb", "value": radiance}
+        if weight != 1.0:
+            d["light"]["emitter"]["sampling_weight"] = weight
+        return d
+    scene = mi.load_dict(box([18.387, 13.9873, 6.75357])); mi.render(scene, spp=4, seed=0); handle = scene._h.value
+    params = mi.traverse(scene)
+    key = "light.emitter.radiance.value"
+    for step, (value, weight) in enumerate([(torch.tensor([4.0, 9.0, 2.0], device="cuda"), None), (torch.tensor([7.0, 1.0, 3.0]), None),
+                                            (torch.tensor([2.0, 5.0, 8.0], device="cuda"), 2.0)]):
+        params[key] = value
+        if weight is not None:
+            params["light.emitter.sampling_weight"] = torch.tensor([weight])
+        params.update()
+        assert scene._h.value == handle
+        a = mi.render(scene, spp=16, seed=5).cpu().numpy()
+        b = mi.render(mi.load_dict(box([float(x) for x in value.cpu()], weight or 1.0)), spp=16, seed=5).cpu().numpy()
+        assert rel_l2(a, b) < 1e-6, step
+    osc, sensor = O.scene_from_product(scene)
+    ref, ost = osc.render_path(sensor, seed=5, spp=16, max_depth=scene.integrator().max_depth, rr_depth=scene.integrator().rr_depth)
+    assert rel_l2(a, ref) < 1e-4 and scene.integrator().stats()["vertices"] == ost.vertices
