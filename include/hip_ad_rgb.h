@@ -111,7 +111,12 @@ typedef struct HarEmitter {
                              transform and its inverse, normal[0] = cutoff_angle, normal[1] = beam_width in degrees (update(), spot.cpp:300-312),
                              6 = directional (src/emitters/directional.cpp): radiance = the irradiance, to_world = the emitter's transform -- light travels along
                              its +z axis (`direction` is lowered to look_at(0, direction, up) by the host, directional.cpp:69-78); delta direction, infinite,
-                             not an environment emitter (escaping rays do not see it) */
+                             not an environment emitter (escaping rays do not see it),
+                             7 = area on a rectangle whose `radiance` is a BITMAP (area.cpp:74, the spatially varying branches :133-165 and :185-191): `radiance_texture` =
+                             index of the bitmap in `textures`, `mesh` / to_world / normal as for type 0; `radiance` is not read.  The texture is importance-sampled
+                             (BitmapTexture::sample_position, bitmap.cpp:622-660, over a DiscreteDistribution2D of the texels' luminance) and the uv mapped onto the shape by
+                             Rectangle::eval_parameterization (rectangle.cpp:215-237).  The bitmap's to_uv must map the unit square onto itself (bitmap.cpp:976-992).  Its
+                             texels are parameters of the scene (har_scene_set_texture re-derives the distribution) but no gradient is produced for them */
     uint32_t mesh;
     float radiance[3];
     float to_world[12];   /* column-major 3x4 */
@@ -122,6 +127,7 @@ typedef struct HarEmitter {
                             * weight differs from 1 the scene picks emitters from a DiscreteDistribution over the weights instead of uniformly
                             * (Scene::update_emitter_sampling_distribution, src/render/scene.cpp:120-141; sample_emitter :248-271, pdf_emitter :273-279,
                             * pdf_emitter_direction :378-388).  Weights are non-negative and not all zero. */
+    uint32_t radiance_texture; /* type 7 only */
 } HarEmitter;
 
 typedef struct HarSceneDesc {

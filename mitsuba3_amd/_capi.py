@@ -43,7 +43,7 @@ class HarTexture(C.Structure):
 
 class HarEmitter(C.Structure):
     _fields_ = [("type", C.c_uint32), ("mesh", C.c_uint32), ("radiance", C.c_float * 3),
-                ("to_world", C.c_float * 12), ("normal", C.c_float * 3), ("inv_area", C.c_float), ("to_local", C.c_float * 12), ("sampling_weight", C.c_float)]
+                ("to_world", C.c_float * 12), ("normal", C.c_float * 3), ("inv_area", C.c_float), ("to_local", C.c_float * 12), ("sampling_weight", C.c_float), ("radiance_texture", C.c_uint32)]
 
 
 class HarMeshData(C.Structure):

@@ -730,6 +730,49 @@ _BSDF_SLOTS = {'diffuse': (('reflectance', 0.5), None), 'dielectric': (('specula
                'conductor': (('specular_reflectance', 1.0), None), 'plastic': (('diffuse_reflectance', 0.5), ('specular_reflectance', 1.0))}
 
 
+def _bitmap_from_props(refl):
+    """BitmapTexture(props) -> (H x W x 3 float32 texels, HarTexture::mode, to_uv rows or None)"""
+    # BitmapTexture (src/textures/bitmap.cpp:175-260): texels from a tensor (`data`), a Bitmap object (`bitmap`) or a file (`filename`:
+    # OpenEXR / PFM, read by the C++ host library).  Float data is linear; in RGB variants `raw` only silences the [0, 1] range warning.
+    if sum(k in refl for k in ('data', 'bitmap', 'filename')) != 1:
+        raise RuntimeError("bitmap: exactly one of 'filename', 'bitmap' and 'data' must be specified")
+    # filter_type / wrap_mode (bitmap.cpp:182-206) -> HarTexture::mode
+    ft = str(refl.get('filter_type', 'bilinear')); wm = str(refl.get('wrap_mode', 'repeat'))
+    if ft not in ('nearest', 'bilinear'):
+        raise RuntimeError("Invalid filter type \"%s\", must be one of: \"nearest\", or \"bilinear\"!" % ft)
+    if wm not in ('repeat', 'mirror', 'clamp'):
+        raise RuntimeError("Invalid wrap mode \"%s\", must be one of: \"repeat\", \"mirror\", or \"clamp\"!" % wm)
+    tex_mode = (1 if ft == 'nearest' else 0) | {'repeat': 0, 'mirror': 2, 'clamp': 4}[wm]
+    _check_props('bitmap', refl, _BITMAP_PROPS, unsupported=(('format', 'auto'),), free_children=False)
+    # to_uv (bitmap.cpp:175): uv = m_transform * si.uv before every lookup (:565,792,831,847) -> HarTexture::to_uv, row-major 2 x 3
+    tex_to_uv = None
+    if 'to_uv' in refl:
+        tuv = refl['to_uv']
+        if isinstance(tuv, ScalarTransform4f):        # Properties::get<AffineTransform3f> of a stored 4 x 4 (an XML <transform>): Transform::extract (transform.h:441-456)
+            m4 = tuv.matrix; tuv = ScalarTransform3f([[m4[0, 0], m4[0, 1], m4[0, 3]], [m4[1, 0], m4[1, 1], m4[1, 3]], [0.0, 0.0, 1.0]])
+        if not isinstance(tuv, ScalarTransform3f):
+            raise RuntimeError("bitmap: 'to_uv' must be a ScalarTransform3f")
+        if abs(float(np.linalg.det(tuv.matrix[:2, :2].astype(np.float64)))) == 0.0:
+            raise RuntimeError("bitmap: 'to_uv' is singular")
+        tex_to_uv = tuv.rows_2x3()
+    if 'data' in refl:
+        t = refl['data']
+        if hasattr(t, 'detach'):
+            t = t.detach().cpu().numpy()
+    else:
+        b = refl['bitmap'] if 'bitmap' in refl else Bitmap(refl['filename'])
+        if not isinstance(b, Bitmap):
+            raise RuntimeError("Property \"bitmap\" must be a Bitmap instance.")
+        t = b.data
+    t = _f32(t)
+    if t.ndim == 2:
+        t = t[:, :, None]
+    if t.ndim != 3 or t.shape[2] not in (1, 3, 4):
+        raise RuntimeError("Bitmap raw tensor has dimension %d, expected 3 (H x W x {1, 3, 4})" % t.ndim)
+    t = np.repeat(t, 3, axis=2) if t.shape[2] == 1 else t[:, :, :3]
+    return np.ascontiguousarray(t, np.float32), tex_mode, tex_to_uv
+
+
 class BSDF:
     """diffuse / dielectric / conductor / plastic / roughconductor / roughplastic (src/bsdfs/*.cpp), optionally wrapped by `twosided`.
     Colour parameters live in two slots (include/hip_ad_rgb.h HarBSDF); slot 0 may be a raw `bitmap`."""
@@ -750,45 +793,7 @@ class BSDF:
         if refl['type'] == 'rgb':
             self.value = _rgb_value(refl, def0)
         elif refl['type'] == 'bitmap':
-            # BitmapTexture (src/textures/bitmap.cpp:175-260): texels from a tensor (`data`), a Bitmap object (`bitmap`) or a file (`filename`:
-            # OpenEXR / PFM, read by the C++ host library).  Float data is linear; in RGB variants `raw` only silences the [0, 1] range warning.
-            if sum(k in refl for k in ('data', 'bitmap', 'filename')) != 1:
-                raise RuntimeError("bitmap: exactly one of 'filename', 'bitmap' and 'data' must be specified")
-            # filter_type / wrap_mode (bitmap.cpp:182-206) -> HarTexture::mode
-            ft = str(refl.get('filter_type', 'bilinear')); wm = str(refl.get('wrap_mode', 'repeat'))
-            if ft not in ('nearest', 'bilinear'):
-                raise RuntimeError("Invalid filter type \"%s\", must be one of: \"nearest\", or \"bilinear\"!" % ft)
-            if wm not in ('repeat', 'mirror', 'clamp'):
-                raise RuntimeError("Invalid wrap mode \"%s\", must be one of: \"repeat\", \"mirror\", or \"clamp\"!" % wm)
-            self.tex_mode = (1 if ft == 'nearest' else 0) | {'repeat': 0, 'mirror': 2, 'clamp': 4}[wm]
-            _check_props('bitmap', refl, _BITMAP_PROPS, unsupported=(('format', 'auto'),), free_children=False)
-            # to_uv (bitmap.cpp:175): uv = m_transform * si.uv before every lookup (:565,792,831,847) -> HarTexture::to_uv, row-major 2 x 3
-            self.tex_to_uv = None
-            if 'to_uv' in refl:
-                tuv = refl['to_uv']
-                if isinstance(tuv, ScalarTransform4f):        # Properties::get<AffineTransform3f> of a stored 4 x 4 (an XML <transform>): Transform::extract (transform.h:441-456)
-                    m4 = tuv.matrix; tuv = ScalarTransform3f([[m4[0, 0], m4[0, 1], m4[0, 3]], [m4[1, 0], m4[1, 1], m4[1, 3]], [0.0, 0.0, 1.0]])
-                if not isinstance(tuv, ScalarTransform3f):
-                    raise RuntimeError("bitmap: 'to_uv' must be a ScalarTransform3f")
-                if abs(float(np.linalg.det(tuv.matrix[:2, :2].astype(np.float64)))) == 0.0:
-                    raise RuntimeError("bitmap: 'to_uv' is singular")
-                self.tex_to_uv = tuv.rows_2x3()
-            if 'data' in refl:
-                t = refl['data']
-                if hasattr(t, 'detach'):
-                    t = t.detach().cpu().numpy()
-            else:
-                b = refl['bitmap'] if 'bitmap' in refl else Bitmap(refl['filename'])
-                if not isinstance(b, Bitmap):
-                    raise RuntimeError("Property \"bitmap\" must be a Bitmap instance.")
-                t = b.data
-            t = _f32(t)
-            if t.ndim == 2:
-                t = t[:, :, None]
-            if t.ndim != 3 or t.shape[2] not in (1, 3, 4):
-                raise RuntimeError("Bitmap raw tensor has dimension %d, expected 3 (H x W x {1, 3, 4})" % t.ndim)
-            t = np.repeat(t, 3, axis=2) if t.shape[2] == 1 else t[:, :, :3]
-            self.texture = np.ascontiguousarray(t, np.float32)
+            self.texture, self.tex_mode, self.tex_to_uv = _bitmap_from_props(refl)
             self.value = _f32([0.5, 0.5, 0.5])
         else:
             raise RuntimeError("Plugin \"%s\" not found for variant hip_ad_rgb (textures: rgb, bitmap)" % refl['type'])
@@ -933,14 +938,38 @@ def _emissive_rgb(plugin, name, v):
     return _rgb_value(v, 1.0, bounded=False)
 
 
+def _check_sampling_transform(rows):
+    """BitmapTextureImpl::check_sampling_transform (src/textures/bitmap.cpp:976-992): position sampling needs a to_uv that maps the unit square's corners onto themselves"""
+    m = np.asarray(rows if rows is not None else [1, 0, 0, 0, 1, 0], np.float32).reshape(2, 3)
+    corners = np.asarray([[0, 0], [1, 0], [1, 1], [0, 1]], np.float32)
+    hits = 0
+    for c in corners:
+        q = m[:, :2] @ c + m[:, 2]
+        for j, d in enumerate(corners):
+            if float(((q - d) ** 2).sum()) < 1e-8:
+                hits |= 1 << j
+    if hits != 0xF:
+        raise RuntimeError("Bitmap texture: position sampling (e.g. of an area emitter's radiance) requires a 'to_uv' transformation that maps the unit square onto "
+                           "itself, such as a flip, a transpose or a multiple of a 90 degree rotation.")
+
+
 class AreaLight:
-    """AreaLight (src/emitters/area.cpp) with a uniform `radiance`; it inherits the placement of its parent shape (a `to_world` is an error, :66-69)."""
+    """AreaLight (src/emitters/area.cpp): a uniform `radiance`, or a `bitmap` on a rectangle; it inherits the placement of its parent shape (a `to_world` is an error, :66-69)."""
 
     def __init__(self, props):
         if 'to_world' in props:
             raise RuntimeError("Found a 'to_world' transformation -- this is not allowed. The area light inherits this transformation from its parent shape.")
         _check_props('area', props, ('radiance', 'sampling_weight'), free_children=False)
-        self.radiance = _emissive_rgb('area', 'radiance', props.get('radiance', {'type': 'rgb', 'value': 1.0}))       # get_emissive_texture("radiance", 1.f), :71
+        rad = props.get('radiance', {'type': 'rgb', 'value': 1.0})
+        self.texture = None; self.tex_mode = 0; self.tex_to_uv = None; self.tex_index = None
+        if isinstance(rad, dict) and rad.get('type') == 'bitmap':
+            # a spatially varying radiance (is_spatially_varying(), area.cpp:74-75): the texture is importance-sampled and mapped onto the shape by
+            # Shape::eval_parameterization (:133-165) -- built for rectangles (HarEmitter type 7); the parent shape decides (Scene._add_mesh)
+            self.texture, self.tex_mode, self.tex_to_uv = _bitmap_from_props(rad)
+            _check_sampling_transform(self.tex_to_uv)
+            self.radiance = _f32([0.0, 0.0, 0.0])
+        else:
+            self.radiance = _emissive_rgb('area', 'radiance', rad)       # get_emissive_texture("radiance", 1.f), :71
         self.sampling_weight = _sampling_weight(props)
 
 
@@ -1509,7 +1538,16 @@ class Scene:
         em = -1
         if m.emitter is not None:
             em = self._emitter_order.index(key)
-            if hasattr(m, 'rect'):        # Rectangle::sample_position (analytic parameterisation)
+            light = getattr(m, 'emitter_light', None)
+            if light is not None and light.texture is not None:
+                if not hasattr(m, 'rect'):
+                    raise RuntimeError("area: a bitmap `radiance` is implemented on `rectangle` shapes (Rectangle::eval_parameterization, src/shapes/rectangle.cpp:215-237); on a "
+                                       "triangle mesh the reference maps the sampled uv through Mesh::eval_parameterization (a ray cast against the mesh in uv space, "
+                                       "src/render/mesh.cpp), which hip_ad_rgb does not have")
+                light.tex_index = len(self.textures); self.textures.append(light.texture); self.texture_modes.append(light.tex_mode); self.texture_to_uv.append(light.tex_to_uv)
+                self.emitters[em] = dict(type=7, mesh=len(self.meshes), radiance=[0.0, 0.0, 0.0], to_world=m.rect['to_world'].col_major_3x4(), normal=m.rect['normal'],
+                                         inv_area=m.rect['inv_area'], sampling_weight=getattr(m, 'emitter_weight', 1.0), radiance_texture=light.tex_index, light=light)
+            elif hasattr(m, 'rect'):        # Rectangle::sample_position (analytic parameterisation)
                 self.emitters[em] = (dict(type=0, mesh=len(self.meshes), radiance=m.emitter, to_world=m.rect['to_world'].col_major_3x4(),
                                           normal=m.rect['normal'], inv_area=m.rect['inv_area'], sampling_weight=getattr(m, 'emitter_weight', 1.0)))
             else:                         # any other triangle mesh: Mesh::sample_position (area-weighted face selection)
@@ -1565,7 +1603,7 @@ class Scene:
             ems[i].to_world = (C.c_float * 12)(*[float(x) for x in e["to_world"]])
             ems[i].normal = (C.c_float * 3)(*[float(x) for x in e["normal"]]); ems[i].inv_area = float(e["inv_area"])
             ems[i].to_local = (C.c_float * 12)(*[float(x) for x in e.get("to_local", [1, 0, 0, 0, 1, 0, 0, 0, 1, 0, 0, 0])])
-            ems[i].sampling_weight = float(e.get("sampling_weight", 1.0))
+            ems[i].sampling_weight = float(e.get("sampling_weight", 1.0)); ems[i].radiance_texture = int(e.get("radiance_texture", 0))
         d = M.HarSceneDesc()
         d.meshes = meshes; d.mesh_count = len(self.meshes); d.top_mesh_count = self.top_mesh_count
         d.groups = groups; d.group_count = len(self.groups)
@@ -1834,7 +1872,10 @@ class Scene:
             if t == 5:          # SpotLight::traverse (spot.cpp:115-116): the cone, in degrees -- updatable here; their gradient (the reference marks them Differentiable) is refused
                 keys[key + ".cutoff_angle"] = ("cutoff_angle", i); keys[key + ".beam_width"] = ("beam_width", i)
             # Emitter::traverse (src/render/emitter.cpp:13): `sampling_weight`, NonDifferentiable; an area light is a child of its shape ('<shape>.emitter.*')
-            keys[key + (".emitter" if t in (0, 3) else "") + ".sampling_weight"] = ("sampling_weight", i)
+            keys[key + (".emitter" if t in (0, 3, 7) else "") + ".sampling_weight"] = ("sampling_weight", i)
+            if t == 7:          # AreaLight::traverse -> "radiance" -> BitmapTexture::traverse: `data` and `to_uv` (bitmap.cpp:463-475).  The reference marks `data`
+                                # Differentiable; no gradient is produced for it here (requires_grad on this key is refused like any key outside the gradient tables)
+                keys[key + ".emitter.radiance.data"] = ("emitter_tex", i); keys[key + ".emitter.radiance.to_uv"] = ("emitter_to_uv", i)
         for b in self.bsdf_objs:            # BitmapTexture::traverse: `to_uv` (src/textures/bitmap.cpp), NonDifferentiable
             if b.texture is not None:
                 keys[(b.id if b.id else "bsdf%d" % b.index) + "." + b.slot0_name + ".to_uv"] = ("to_uv", b)
@@ -1849,7 +1890,11 @@ class Scene:
             return np.asarray([self.emitters[b]["normal"][0 if kind == "cutoff_angle" else 1]], np.float32)
         if kind == "sampling_weight":
             return np.asarray([self.emitters[b].get("sampling_weight", 1.0)], np.float32)
-        if kind == "to_uv":
+        if kind == "emitter_tex":
+            return np.array(self.emitters[b]["light"].texture, np.float32)
+        if kind in ("to_uv", "emitter_to_uv"):
+            if kind == "emitter_to_uv":
+                b = self.emitters[b]["light"]
             m = np.eye(3, dtype=np.float32)
             if b.tex_to_uv is not None:
                 m[:2, :] = np.asarray(b.tex_to_uv, np.float32).reshape(2, 3)
@@ -1909,7 +1954,20 @@ class Scene:
             e = dict(self.emitters[b]); e["sampling_weight"] = w; self.emitters[b] = e
             self._weights_dirty = True               # the distribution is rebuilt once, after every weight of this update() is in (_validate_spots)
             return
-        if kind == "to_uv":
+        if kind == "emitter_tex":      # BitmapTexture::parameters_changed -> rebuild_internals (bitmap.cpp:484-493): new texels, new texel distribution
+            light = self.emitters[b]["light"]
+            v = np.ascontiguousarray(np.asarray(value, np.float32))
+            if v.shape != light.texture.shape or not np.isfinite(v).all():
+                raise RuntimeError("area: the radiance bitmap must keep its shape %s and be finite" % (light.texture.shape,))
+            if not (v >= 0).all() or float(v.sum()) <= 0.0:
+                raise RuntimeError("area: the radiance bitmap must be non-negative with some luminance to sample")
+            light.texture = v; self.textures[light.tex_index] = v
+            if self._h is not None:
+                check(lib().har_scene_set_texture(self._h, light.tex_index, _fp(v)))
+            return
+        if kind in ("to_uv", "emitter_to_uv"):
+            if kind == "emitter_to_uv":
+                b = self.emitters[b]["light"]
             m = np.asarray(value.matrix if isinstance(value, (ScalarTransform3f, ScalarTransform4f)) else value, np.float32)
             if m.shape == (4, 4):
                 m = np.array([[m[0, 0], m[0, 1], m[0, 3]], [m[1, 0], m[1, 1], m[1, 3]], [0.0, 0.0, 1.0]], np.float32)
@@ -1917,6 +1975,8 @@ class Scene:
             if not np.isfinite(m).all() or float(np.linalg.det(m[:2, :2].astype(np.float64))) == 0.0:
                 raise RuntimeError("bitmap: 'to_uv' is singular")
             rows = [float(x) for x in m[:2, :].reshape(-1)]
+            if kind == "emitter_to_uv":
+                _check_sampling_transform(rows)
             b.tex_to_uv = rows; self.texture_to_uv[b.tex_index] = rows
             if self._h is not None:
                 check(lib().har_scene_set_texture_to_uv(self._h, b.tex_index, _fp(_f32(rows))))
@@ -2162,7 +2222,7 @@ def _shape_common(m, props, named):
             if m.emitter is not None:
                 raise RuntimeError("Only a single Emitter child object can be specified per shape.")       # shape.cpp:25-27
             a = AreaLight(v)
-            m.emitter = a.radiance; m.emitter_weight = a.sampling_weight
+            m.emitter = a.radiance; m.emitter_weight = a.sampling_weight; m.emitter_light = a
         elif isinstance(v, dict) and 'type' in v and k not in ('to_world',):
             if (v['type'], VARIANT) not in _REGISTRY:
                 raise RuntimeError("Plugin \"%s\" not found for variant \"%s\"" % (v['type'], VARIANT))

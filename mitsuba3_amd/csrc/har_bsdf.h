@@ -294,6 +294,9 @@ HAR_HD bool bsdf_is_smooth(const DBsdf &B) { return B.type != BSDF_DIELECTRIC &&
 #define HAR_BSDF_QUEUED 0x200u
 #define HAR_BSDF_SINGLE(TYPES) ((((TYPES) & 0xffu) != 0u) && ((((TYPES) & 0xffu) & (((TYPES) & 0xffu) - 1u)) == 0u))
 #define HAR_BSDF_SINGLE_TYPE(TYPES) ((((TYPES) & 0xffu) == 1u) ? 0u : (((TYPES) & 0xffu) == 2u) ? 1u : (((TYPES) & 0xffu) == 4u) ? 2u : (((TYPES) & 0xffu) == 8u) ? 3u : (((TYPES) & 0xffu) == 16u) ? 4u : 5u)
+/* ... and an area light that radiates a BITMAP (emitter type 7): its texel-distribution code costs the generic kernels registers they do not have (128, spills), so
+ * only scenes with such a light run kernels that carry it: TYPES = HAR_BSDF_ALL_TYPES | HAR_SCENE_ENVMAP | HAR_SCENE_TEXLIGHT */
+#define HAR_SCENE_TEXLIGHT 0x400u
 #define HAR_SCENE_ENVMAP 0x100u           /* the scene has an environment MAP (emitter type 2), a MESH area light (type 3) or a POINT light (type 4): kernels of other scenes compile that code out */
 
 /* fresnel_diffuse_reflectance (include/mitsuba/render/fresnel.h:327-355), evaluated on the host when a `plastic` record is (re)built */

@@ -822,6 +822,7 @@ int har_scene_create(const HarSceneDesc *desc, HarScene *out) {
     D.env_emitter = hs.env_emitter;
     D.bsdf_types = 0; for (const DBsdf &b : hs.bsdfs) D.bsdf_types |= (1u << b.type) | ((b.flags & BF_TWOSIDED) ? 0x80000000u : 0u);
     if (hs.has_envmap || hs.has_mesh_emitters || hs.has_point_emitters || !hs.emitter_distr.empty()) D.bsdf_types |= HAR_SCENE_ENVMAP;
+    for (const DEmitter &e : hs.emitters) if (e.type == 7u) D.bsdf_types |= HAR_SCENE_TEXLIGHT;      /* (has_mesh_emitters is set with it: the generic emitter kernels + the texel-distribution code) */
     /* the depth-first bound of the BVH must fit the traversal stacks (LDS entries + HBM spill columns): a deeper scene is refused here instead of
      * rendering with rays that overflow (an overflowing ray is a miss + a status word that only har_render_stats reads) */
     const uint32_t stack_cap = (uint32_t) std::min(HAR_LDS_STACK_DEPTH, HAR_LDS_STACK_SMALL + HAR_STACK_SPILL);
@@ -863,6 +864,7 @@ int har_scene_set_emitter_radiance(HarScene S, uint32_t emitter, const float rgb
     if (sync_host_records(S)) return 1;
     DEmitter &e = S->hs.emitters[emitter];
     if (e.type == 2u) return fail("an environment map has no constant radiance");
+    if (e.type == 7u) return fail("this area light radiates a bitmap: update the texture (har_scene_set_texture)");
     e.radiance[0] = rgb[0]; e.radiance[1] = rgb[1]; e.radiance[2] = rgb[2];
     HIP_TRY(hipMemcpy(const_cast<DEmitter *>(S->ds.emitters) + emitter, &e, sizeof(DEmitter), hipMemcpyHostToDevice));
     if (S->hs.emitters.size() == 1) { S->ds.emitter0 = e; S->ds.emitter0_valid = 1u; }
@@ -872,7 +874,22 @@ int har_scene_set_emitter_radiance(HarScene S, uint32_t emitter, const float rgb
  * plastic.cpp:188-205: m_specular_sampling_weight from the means of the two reflectances) */
 static bool texture_feeds_sampling_weight(const HostScene &hs, uint32_t tex) {
     for (const DBsdf &b : hs.bsdfs) if (b.texture == (int32_t) tex && (b.type == BSDF_ROUGHPLASTIC || b.type == BSDF_PLASTIC)) return true;
+    for (const DEmitter &e : hs.emitters) if (e.type == 7u && as_u32(e.radiance[0]) == tex) return true;      /* an area light radiates it: its texel distribution is derived on the host */
     return false;
+}
+/* the texel distributions of the area lights that radiate bitmap `tex` (BitmapTexture::parameters_changed -> rebuild_internals, bitmap.cpp:484-493): re-derived from the
+ * host mirror of the texels and copied over their slice of the device table */
+static int refresh_texel_tables(HarSceneImpl *S, uint32_t tex) {
+    for (const DEmitter &e : S->hs.emitters) {
+        if (e.type != 7u || as_u32(e.radiance[0]) != tex) continue;
+        const HostTexture &t = S->hs.textures[tex];
+        const uint32_t off = as_u32(e.radiance[1]);
+        std::string err;
+        if (!texel_table_fill(S->hs, t, off, err)) return fail(err);
+        const size_t n = HAR_TEXEL_TABLE_HEADER + (size_t) t.h + (size_t) t.w * t.h;
+        HIP_TRY(hipMemcpy(const_cast<float *>(S->ds.emitter_cdf) + off, S->hs.emitter_cdf.data() + off, n * sizeof(float), hipMemcpyHostToDevice));
+    }
+    return 0;
 }
 static int refresh_sampling_weights(HarSceneImpl *S, uint32_t tex) {
     for (uint32_t k = 0; k < S->hs.bsdfs.size(); ++k) {
@@ -881,7 +898,7 @@ static int refresh_sampling_weights(HarSceneImpl *S, uint32_t tex) {
         update_roughplastic_sampling_weight(S->hs, k);
         HIP_TRY(hipMemcpy(S->d_bsdfs + k, &b, sizeof(DBsdf), hipMemcpyHostToDevice));
     }
-    return 0;
+    return refresh_texel_tables(S, tex);
 }
 int har_scene_set_texture(HarScene S, uint32_t tex, const float *data) {
     if (!S || tex >= S->hs.textures.size()) return fail("invalid texture index");
@@ -932,6 +949,7 @@ int har_scene_set_emitter_radiance_device(HarScene S, uint32_t emitter, const fl
     if (!S || emitter >= S->hs.emitters.size()) return fail("invalid emitter index");
     if (!dev_rgb) return fail("null device pointer");
     if (S->hs.emitters[emitter].type == 2u) return fail("an environment map has no constant radiance");
+    if (S->hs.emitters[emitter].type == 7u) return fail("this area light radiates a bitmap: update the texture (har_scene_set_texture_device)");
     HIP_TRY(hipMemcpyAsync(const_cast<float *>(S->ds.emitters[0].radiance) + (size_t) emitter * (sizeof(DEmitter) / sizeof(float)), dev_rgb, 3 * sizeof(float),
                            hipMemcpyDeviceToDevice, (hipStream_t) stream));
     S->emitter_host_stale = true;
@@ -993,7 +1011,11 @@ int har_scene_set_texture_to_uv(HarScene S, uint32_t tex, const float to_uv[6]) 
     }
     const DTexture d = S->hs.device_texture(tex, S->tex_dev[tex]);
     HIP_TRY(hipMemcpy(S->d_textures + tex, &d, sizeof(DTexture), hipMemcpyHostToDevice));
-    return 0;
+    if (texture_feeds_sampling_weight(S->hs, tex) && S->tex_host_stale[tex]) {          /* the texel distribution below reads the host mirror */
+        HIP_TRY(hipMemcpy(t.data.data(), S->tex_dev[tex], t.data.size() * sizeof(float), hipMemcpyDeviceToHost));
+        S->tex_host_stale[tex] = 0;
+    }
+    return refresh_texel_tables(S, tex);
 }
 
 /* ---- incremental updates of the acceleration data (Scene::parameters_changed rebuilds only what a dirty shape needs, scene.cpp:517-540; scene_optix.inl:351-372) */
@@ -1716,7 +1738,7 @@ int har_integrator_set_grad_positions(HarIntegrator I, HarScene S, float *const 
         /* the hand-derived adjoint of har_shape_grad.h covers top-level meshes, flat-shaded or with (regenerated) vertex normals, carrying any BSDF with a non-delta lobe (the directional derivatives
          * of the models come from har_bsdf_dir.h); the rest of the scene may carry any model -- a vertex next to moving geometry contributes through its
          * attached si.wi (prb.py:128-140) */
-        if (S->ds.bsdf_types & HAR_SCENE_ENVMAP) return fail("vertex-position gradients are not implemented for scenes with an environment map, a mesh area light or a point light");
+        if (S->ds.bsdf_types & HAR_SCENE_ENVMAP) return fail("vertex-position gradients are not implemented for scenes with an environment map, a mesh or textured area light, a delta light or emitter sampling weights");
         const size_t nm = S->hs.meshes.size();
         offset.assign(nm, -1); user.assign(nm, nullptr); count.assign(nm, 0);
         for (size_t m = 0; m < nm; ++m) {          /* top-level meshes, then the meshes of the shape groups (vertex positions shared by all their instances) */
@@ -1757,7 +1779,7 @@ int har_integrator_set_grad_instances(HarIntegrator I, HarScene S, float *grad_t
     if (grad_to_world) {
         if (!S) return fail("null scene");
         /* as for the vertex positions: any BSDF with a non-delta lobe on the moving geometry, i.e. on the meshes of the shape groups */
-        if (S->ds.bsdf_types & HAR_SCENE_ENVMAP) return fail("instance to_world gradients are not implemented for scenes with an environment map, a mesh area light or a point light");
+        if (S->ds.bsdf_types & HAR_SCENE_ENVMAP) return fail("instance to_world gradients are not implemented for scenes with an environment map, a mesh or textured area light, a delta light or emitter sampling weights");
         for (size_t m = S->hs.top_mesh_count; m < S->hs.meshes.size(); ++m)
             if (!record_has_smooth_lobe(S->hs, S->hs.meshes[m].bsdf)) return fail("instance to_world gradients: an instanced mesh cannot carry a BSDF made of delta lobes only (`dielectric`, `conductor`); top-level meshes may");
         n = (uint32_t) S->hs.insts.size();

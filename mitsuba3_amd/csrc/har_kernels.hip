@@ -2026,7 +2026,8 @@ void launch_shade(int mode, hipStream_t s, uint32_t grid, const DScene &S, const
         const bool env = (S.bsdf_types & HAR_SCENE_ENVMAP) != 0u, diffuse = S.bsdf_types == HAR_BSDF_ONLY_DIFFUSE, cls = (S.bsdf_types & 0x7fffffffu & ~HAR_BSDF_CLASSIC_TYPES) == 0u;
 #define HAR_LAUNCH_SHADE_RECORD(T) do { if (tab) hipLaunchKernelGGL((k_shade<MODE_PRB_ADJOINT, T, false, false, false, false, true, true>), g, b, 0, s, S, P, lane_base, shard_cap, count_in, in, h0, h1, out, count_out, items, item_count, result, rc, pass_rng, dL, grad_slots, no_geo, nullptr, no_tq, nullptr, no_mq, 0u, tape); \
         else hipLaunchKernelGGL((k_shade<MODE_PRB_ADJOINT, T, false, false, false, false, true>), g, b, 0, s, S, P, lane_base, shard_cap, count_in, in, h0, h1, out, count_out, items, item_count, result, rc, pass_rng, dL, grad_slots, no_geo, nullptr, no_tq, nullptr, no_mq, 0u, tape); } while (0)
-        if (env) HAR_LAUNCH_SHADE_RECORD(HAR_BSDF_ALL_TYPES | HAR_SCENE_ENVMAP); else if (diffuse) HAR_LAUNCH_SHADE_RECORD(HAR_BSDF_ONLY_DIFFUSE);
+        if (env && (S.bsdf_types & HAR_SCENE_TEXLIGHT)) HAR_LAUNCH_SHADE_RECORD(HAR_BSDF_ALL_TYPES | HAR_SCENE_ENVMAP | HAR_SCENE_TEXLIGHT);
+        else if (env) HAR_LAUNCH_SHADE_RECORD(HAR_BSDF_ALL_TYPES | HAR_SCENE_ENVMAP); else if (diffuse) HAR_LAUNCH_SHADE_RECORD(HAR_BSDF_ONLY_DIFFUSE);
         else if (cls) HAR_LAUNCH_SHADE_RECORD(HAR_BSDF_CLASSIC_TYPES); else HAR_LAUNCH_SHADE_RECORD(HAR_BSDF_ALL_TYPES);
 #undef HAR_LAUNCH_SHADE_RECORD
         return;
@@ -2066,10 +2067,12 @@ void launch_shade(int mode, hipStream_t s, uint32_t grid, const DScene &S, const
 #define HAR_LAUNCH_SHADE_INLINE(T) hipLaunchKernelGGL((k_shade<MODE_PRB_ADJOINT, T, false, true>), g, b, 0, s, S, P, lane_base, shard_cap, count_in, in, h0, h1, out, count_out, items, item_count, result, rc, pass_rng, dL, grad_slots, no_geo, grad_tex, tq, nullptr, no_mq, 0u, tape)
 #define HAR_LAUNCH_SHADE_EXTRA(T) hipLaunchKernelGGL((k_shade<MODE_PRB_ADJOINT, T, false, true, true>), g, b, 0, s, S, P, lane_base, shard_cap, count_in, in, h0, h1, out, count_out, items, item_count, result, rc, pass_rng, dL, grad_slots, no_geo, grad_tex, tq, grad_extra, no_mq, 0u, tape)
         if (grad_extra && !diffuse) {         /* gradients w.r.t. alpha / eta / k / slot 1: the generic shading code with the extra derivative terms */
-            if (env) HAR_LAUNCH_SHADE_EXTRA(HAR_BSDF_ALL_TYPES | HAR_SCENE_ENVMAP); else HAR_LAUNCH_SHADE_EXTRA(HAR_BSDF_ALL_TYPES);
+            if (env && (S.bsdf_types & HAR_SCENE_TEXLIGHT)) HAR_LAUNCH_SHADE_EXTRA(HAR_BSDF_ALL_TYPES | HAR_SCENE_ENVMAP | HAR_SCENE_TEXLIGHT);
+            else if (env) HAR_LAUNCH_SHADE_EXTRA(HAR_BSDF_ALL_TYPES | HAR_SCENE_ENVMAP); else HAR_LAUNCH_SHADE_EXTRA(HAR_BSDF_ALL_TYPES);
             return;
         }
-        if (env) HAR_LAUNCH_SHADE_INLINE(HAR_BSDF_ALL_TYPES | HAR_SCENE_ENVMAP); else if (diffuse) HAR_LAUNCH_SHADE_INLINE(HAR_BSDF_ONLY_DIFFUSE);
+        if (env && (S.bsdf_types & HAR_SCENE_TEXLIGHT)) HAR_LAUNCH_SHADE_INLINE(HAR_BSDF_ALL_TYPES | HAR_SCENE_ENVMAP | HAR_SCENE_TEXLIGHT);
+        else if (env) HAR_LAUNCH_SHADE_INLINE(HAR_BSDF_ALL_TYPES | HAR_SCENE_ENVMAP); else if (diffuse) HAR_LAUNCH_SHADE_INLINE(HAR_BSDF_ONLY_DIFFUSE);
         else if (cls) HAR_LAUNCH_SHADE_INLINE(HAR_BSDF_CLASSIC_TYPES); else HAR_LAUNCH_SHADE_INLINE(HAR_BSDF_ALL_TYPES);
 #undef HAR_LAUNCH_SHADE_INLINE
 #undef HAR_LAUNCH_SHADE_EXTRA
@@ -2081,7 +2084,7 @@ void launch_shade(int mode, hipStream_t s, uint32_t grid, const DScene &S, const
         else hipLaunchKernelGGL((k_shade<M, T>), g, b, 0, s, S, P, lane_base, shard_cap, count_in, in, h0, h1, out, count_out, items, item_count, result, rc, pass_rng, dL, grad_slots, no_geo, nullptr, no_tq, nullptr, no_mq, 0u, tape); } while (0)
     const bool envmap = (S.bsdf_types & HAR_SCENE_ENVMAP) != 0u;      /* generic BSDF code + environment-map sampling / lookup */
     const bool classic = (S.bsdf_types & 0x7fffffffu & ~HAR_BSDF_CLASSIC_TYPES) == 0u;
-#define HAR_LAUNCH_SHADE_MODE(M) do { if (envmap) HAR_LAUNCH_SHADE(M, HAR_BSDF_ALL_TYPES | HAR_SCENE_ENVMAP); else if (only_diffuse) HAR_LAUNCH_SHADE(M, HAR_BSDF_ONLY_DIFFUSE); else if (classic) HAR_LAUNCH_SHADE(M, HAR_BSDF_CLASSIC_TYPES); else HAR_LAUNCH_SHADE(M, HAR_BSDF_ALL_TYPES); } while (0)
+#define HAR_LAUNCH_SHADE_MODE(M) do { if (envmap && (S.bsdf_types & HAR_SCENE_TEXLIGHT)) HAR_LAUNCH_SHADE(M, HAR_BSDF_ALL_TYPES | HAR_SCENE_ENVMAP | HAR_SCENE_TEXLIGHT); else if (envmap) HAR_LAUNCH_SHADE(M, HAR_BSDF_ALL_TYPES | HAR_SCENE_ENVMAP); else if (only_diffuse) HAR_LAUNCH_SHADE(M, HAR_BSDF_ONLY_DIFFUSE); else if (classic) HAR_LAUNCH_SHADE(M, HAR_BSDF_CLASSIC_TYPES); else HAR_LAUNCH_SHADE(M, HAR_BSDF_ALL_TYPES); } while (0)
     if (mode == MODE_PATH)            HAR_LAUNCH_SHADE_MODE(MODE_PATH);
     else if (mode == MODE_PRB_PRIMAL) HAR_LAUNCH_SHADE_MODE(MODE_PRB_PRIMAL);
     else                              HAR_LAUNCH_SHADE_MODE(MODE_PRB_ADJOINT);

@@ -149,10 +149,13 @@ HAR_HD void shade_lane(const DScene &S, const ShadeParams &P, const PathState &s
         /* pdf_direction: area light (area.cpp:170-197) or uniform sphere (constant.cpp:155-160) */
         /* Scene::pdf_emitter_direction (scene.cpp:378-388): emitter_pmf = m_emitter_pmf, or sampling_weight * normalization with a distribution */
         const float hit_pmf = distr ? S.emitter_distr[emitter] * S.emitter_norm : pmf;
-        float em_pdf = prev_delta ? 0.f : (envmap ? envmap_pdf_direction(*S.envmap, st.d) : env ? HAR_INV_FOUR_PI : emitter_pdf_direction(E, dd, si.sn, dist)) * hit_pmf;
+        const bool textured = (TYPES & HAR_SCENE_TEXLIGHT) != 0u && E.type == 7u;     /* bitmap radiance (area.cpp:83-90, 185-191): value and density depend on si.uv */
+        float em_pdf = prev_delta ? 0.f : (envmap ? envmap_pdf_direction(*S.envmap, st.d) : env ? HAR_INV_FOUR_PI :
+                                           textured ? textured_area_pdf_direction(S, E, dd, si.sn, dist, si.uv_x, si.uv_y) : emitter_pdf_direction(E, dd, si.sn, dist)) * hit_pmf;
         float mis = mis_weight(st.prev_bsdf_pdf, em_pdf);
         Vec3 rad(E.radiance[0], E.radiance[1], E.radiance[2]);
         if (envmap) rad = envmap_eval(*S.envmap, st.d);                              /* envmap.cpp:228-236: v = to_world^-1 * (-si.wi) */
+        if (textured) rad = texture_eval_uv(S.textures[as_u32(E.radiance[0])], si.uv_x, si.uv_y);
         const bool facing = env || si.wi.z > 0.f;                                      /* area.cpp:83-90 / constant.cpp:90-94 */
         if (MODE == MODE_PATH) {
             Vec3 Le = (facing && st.prev_bsdf_pdf > 0.f) ? rad : Vec3(0.f);
@@ -161,7 +164,7 @@ HAR_HD void shade_lane(const DScene &S, const ShadeParams &P, const PathState &s
             Vec3 ev = facing ? rad : Vec3(0.f);
             R.add_emission = true; R.em_a = Vec3(0.f); R.em_b = (st.throughput * mis) * ev;
             if (MODE == MODE_PRB_ADJOINT) {          /* prb.py:160-161 with the emitter's eval attached: d Le / d radiance = beta * mis */
-                R.em_index = (E.type != 2u && facing) ? emitter : -1;
+                R.em_index = (E.type != 2u && E.type != 7u && facing) ? emitter : -1;      /* (no colour parameter behind an environment map or a bitmap radiance) */
                 R.em_unit = st.throughput * mis;
             }
         }
@@ -214,6 +217,8 @@ HAR_HD void shade_lane(const DScene &S, const ShadeParams &P, const PathState &s
             spot_sample_direction(S.emitters[index], si.p, ds, em_weight, MODE == MODE_PRB_ADJOINT ? &em_unit : nullptr); em_delta = true;
         } else if ((TYPES & HAR_SCENE_ENVMAP) != 0u && S.emitters[index].type == 6u) {
             directional_sample_direction(S.emitters[index], si.p, ds, em_weight, MODE == MODE_PRB_ADJOINT ? &em_unit : nullptr); em_delta = true;
+        } else if ((TYPES & HAR_SCENE_TEXLIGHT) != 0u && S.emitters[index].type == 7u) {
+            textured_area_sample_direction(S, S.emitters[index], si.p, ex, ey, ds, em_weight);
         }
         /* a scene with ONE emitter (the bench scenes): its record travels with the kernel arguments (DScene::emitter0), i.e. in scalar registers, instead of being gathered
          * by every lane -- six vector loads less in a kernel that is bound by the number of its memory transactions (k_shade, docs/rounds/r05.md item 11) */
@@ -241,7 +246,7 @@ HAR_HD void shade_lane(const DScene &S, const ShadeParams &P, const PathState &s
             if (MODE == MODE_PRB_ADJOINT) {
                 R.dLr_drho = ((st.throughput * mis_em) * ev.d_slot0) * em_weight;
                 /* em_weight = radiance * em_unit for `area` / `constant` emitters (prb.py:198-206, attached eval_emitter_direction) */
-                R.nee_emitter = ((P.flags & HAR_SHADE_EMITTER_GRADS) && S.emitters[em_sampled].type != 2u) ? (int32_t) em_sampled : -1;
+                R.nee_emitter = ((P.flags & HAR_SHADE_EMITTER_GRADS) && S.emitters[em_sampled].type != 2u && S.emitters[em_sampled].type != 7u) ? (int32_t) em_sampled : -1;
                 R.contrib_unit = ((st.throughput * mis_em) * ev.value) * em_unit;
                 if (EXTRA && TYPES != HAR_BSDF_ONLY_DIFFUSE) {
                     BsdfEvalExtra x; bsdf_eval_extra(S, side, bin, side_ok, wo_em, x);
@@ -255,7 +260,7 @@ HAR_HD void shade_lane(const DScene &S, const ShadeParams &P, const PathState &s
             spawn_ray_to(si, ds.p, R.sh_o, R.sh_d, R.sh_maxt);
             if (MODE == MODE_PRB_ADJOINT) {
                 const uint32_t et = S.emitters[em_sampled].type;
-                const bool surface = et == 0u || et == 3u;           /* EmitterFlags::Surface (prb.py:178) */
+                const bool surface = et == 0u || et == 3u || et == 7u;           /* EmitterFlags::Surface (prb.py:178) */
                 R.nee_flags = 1u | (surface ? 2u : 0u);
                 R.nee_p = surface ? ds.p : ds.d; R.nee_n = ds.n; R.cos_em = wo_em.z * side.wo_sign;
                 R.nee_w = (st.throughput * mis_em) * em_weight;

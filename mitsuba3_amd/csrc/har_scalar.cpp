@@ -114,7 +114,7 @@ Vec3 sample_scalar(const DScene &S, const ShadeParams &P, uint64_t &rng, Vec3 o,
         accel_trace<false>(S.accel, st.o, st.d, st.maxt, hit, stack, status);
         ShadeResult R;
         R.next.rng = st.rng;                                      /* a path that ends before this iteration's draws (path.cpp:226-227 `break`) leaves the stream where it is */
-        shade_lane<MODE_PATH, HAR_BSDF_ALL_TYPES | HAR_SCENE_ENVMAP>(S, P, st, hit, R);
+        shade_lane<MODE_PATH, HAR_BSDF_ALL_TYPES | HAR_SCENE_ENVMAP | HAR_SCENE_TEXLIGHT>(S, P, st, hit, R);
         valid_ray = valid_ray || hit.t != HAR_INF;                /* path.cpp:307-308 */
         if (R.add_emission) result = Vec3(fma_(R.em_a.x, R.em_b.x, result.x), fma_(R.em_a.y, R.em_b.y, result.y), fma_(R.em_a.z, R.em_b.z, result.z));
         if (R.item && R.item_ray) {                                /* the emitter sample's shadow ray (path.cpp:271-281; ray_test inside sample_emitter_direction) */

@@ -27,6 +27,10 @@ struct DTexture { const float *data; uint32_t w, h; uint32_t mode, pad; float uv
 #define HAR_SHADING_TRIS 1
 #endif
 struct DEmitter { float radiance[3]; float inv_area; float to_world[12]; float normal[3]; uint32_t mesh; uint32_t type; };
+/* type 7 (area light on a rectangle with a BITMAP radiance): radiance[0] = bits of the texture index, radiance[1] = bits of the offset of its texel distribution in
+ * DScene::emitter_cdf, radiance[2] = |dp_du x dp_dv| of the rectangle; the table: HAR_TEXEL_TABLE_HEADER floats { sum, 1 / sum, inverse to_uv (2 x 3) }, the marginal
+ * running sums (h), the conditional ones (w * h) -- texel_table_fill in har_scene_host.cpp */
+#define HAR_TEXEL_TABLE_HEADER 8u
 struct DInst    { float to_world[12]; float to_object[12]; };
 /* EnvironmentMapEmitter (src/emitters/envmap.cpp), emitter type 2.  `tex` = H x (W + 2) x 3 radiance with one halo column on each side
  * (:140-172), `warp` = storage of the Hierarchical2D<Float, 0> over the (W + 1) x H luminance * sin(theta) grid (distr_2d.h:405-560):
@@ -653,6 +657,97 @@ HAR_HD float emitter_pdf_direction(const DEmitter &E, Vec3 d, Vec3 n, float dist
     float pdf = E.inv_area;
     pdf *= (adp != 0.f) ? (dist * dist) / adp : 0.f;
     return pdf;
+}
+
+/* ---- AreaLight with a spatially varying radiance (emitter type 7; area.cpp:133-165, 185-191) */
+/* dr::binary_search(0, last, cdf[i] < value) */
+HAR_HD uint32_t cdf_search(const float *cdf, uint32_t last, float value) {
+    uint32_t start = 0, end = last, iterations = 0;
+    if (start < end) { uint32_t span = end - start; iterations = 1; while (span >>= 1) ++iterations; }
+    for (uint32_t i = 0; i < iterations; ++i) {
+        const uint32_t middle = (start + end) >> 1;
+        if (cdf[middle] < value) start = middle + 1u < end ? middle + 1u : end; else end = middle;
+    }
+    return start;
+}
+/* DiscreteDistribution2D::pdf (distr_2d.h:121-131) of texel (x, y): difference of neighbouring conditional sums * normalization */
+HAR_HD float texel_pdf(const float *cond, uint32_t w, float normalization, uint32_t x, uint32_t y) {
+    const size_t i = (size_t) y * w + x;
+    return (cond[i] - (x > 0u ? cond[i - 1u] : 0.f)) * normalization;
+}
+/* BitmapTexture::pdf_texture (bitmap.cpp:673-703), position in the TEXTURE's parameterisation */
+HAR_HD float bitmap_pdf_texture(const DTexture &T, const float *tab, float u, float v) {
+    const float *cond = tab + HAR_TEXEL_TABLE_HEADER + T.h;
+    const float texels = (float) ((int32_t) T.w * (int32_t) T.h);
+    const int32_t W = (int32_t) T.w, H = (int32_t) T.h;
+    if (T.mode & 1u) {
+        const int32_t x = tex_wrap((int32_t) floorf(u * (float) T.w), W, T.mode), y = tex_wrap((int32_t) floorf(v * (float) T.h), H, T.mode);
+        return texel_pdf(cond, T.w, tab[1], (uint32_t) x, (uint32_t) y) * texels;
+    }
+    const float px = fma_(u, (float) T.w, -0.5f), py = fma_(v, (float) T.h, -0.5f), fx = floorf(px), fy = floorf(py);
+    const int32_t ix = (int32_t) fx, iy = (int32_t) fy;
+    const float w1x = px - fx, w1y = py - fy, w0x = 1.f - w1x, w0y = 1.f - w1y;
+    const uint32_t x0 = (uint32_t) tex_wrap(ix, W, T.mode), x1 = (uint32_t) tex_wrap(ix + 1, W, T.mode), y0 = (uint32_t) tex_wrap(iy, H, T.mode), y1 = (uint32_t) tex_wrap(iy + 1, H, T.mode);
+    const float v00 = texel_pdf(cond, T.w, tab[1], x0, y0), v10 = texel_pdf(cond, T.w, tab[1], x1, y0), v01 = texel_pdf(cond, T.w, tab[1], x0, y1), v11 = texel_pdf(cond, T.w, tab[1], x1, y1);
+    const float v0 = fma_(w0x, v00, w1x * v10), v1 = fma_(w0x, v01, w1x * v11);
+    return fma_(w0y, v0, w1y * v1) * texels;
+}
+/* warp::interval_to_tent (warp.h:196-200) */
+HAR_HD float interval_to_tent(float s) {
+    s -= 0.5f;
+    return mulsign_(1.f - sqrtf(fmaxf(fma_(fabsf(s), -2.f, 1.f), 0.f)), s);
+}
+/* BitmapTexture::sample_position (bitmap.cpp:622-660) over DiscreteDistribution2D::sample (distr_2d.h:141-180): surface uv + its density */
+HAR_HD void bitmap_sample_position(const DTexture &T, const float *tab, float sx, float sy, float &u, float &v, float &pdf) {
+    const float *marg = tab + HAR_TEXEL_TABLE_HEADER, *cond_all = marg + T.h;
+    sx = fminf(fmaxf(sx, 1.17549435e-38f), 0x1.fffffep-1f); sy = fminf(fmaxf(sy, 1.17549435e-38f), 0x1.fffffep-1f);
+    sy *= tab[0];
+    const uint32_t row = cdf_search(marg, T.h - 1u, sy);
+    const float *cond = cond_all + (size_t) row * T.w;
+    sx *= cond[T.w - 1u];
+    const uint32_t col = cdf_search(cond, T.w - 1u, sx);
+    const float c0 = col > 0u ? cond[col - 1u] : 0.f, c1 = cond[col], r0 = row > 0u ? marg[row - 1u] : 0.f, r1 = marg[row];
+    sx -= c0; sy -= r0;
+    if (c1 != c0) sx = sx / (c1 - c0);
+    if (r1 != r0) sy = sy / (r1 - r0);
+    const float inv_w = 1.f / (float) T.w, inv_h = 1.f / (float) T.h;
+    float qx, qy;
+    if (T.mode & 1u) { qx = ((float) col + sx) * inv_w; qy = ((float) row + sy) * inv_h; }
+    else {
+        qx = ((float) col + 0.5f + interval_to_tent(sx)) * inv_w; qy = ((float) row + 0.5f + interval_to_tent(sy)) * inv_h;
+        if (!(T.mode & 6u)) { if (qx < 0.f) qx += 1.f; if (qx > 1.f) qx -= 1.f; if (qy < 0.f) qy += 1.f; if (qy > 1.f) qy -= 1.f; }
+        else { if (qx < 0.f) qx = -qx; if (qx > 1.f) qx = 2.f - qx; if (qy < 0.f) qy = -qy; if (qy > 1.f) qy = 2.f - qy; }
+    }
+    u = fma_(tab[3], qy, fma_(tab[2], qx, tab[4])); v = fma_(tab[6], qy, fma_(tab[5], qx, tab[7]));
+    pdf = bitmap_pdf_texture(T, tab, qx, qy);
+}
+HAR_HD Vec3 texture_eval_uv(const DTexture &T, float u, float v) { TexTaps taps; tex_taps(T, u, v, taps); return tex_fetch(T, taps); }
+/* AreaLight::sample_direction, spatially varying branch (area.cpp:133-165) with Rectangle::eval_parameterization (rectangle.cpp:215-237) */
+HAR_HD void textured_area_sample_direction(const DScene &S, const DEmitter &E, Vec3 ref_p, float sx, float sy, DirSample &ds, Vec3 &spec) {
+    const DTexture T = S.textures[as_u32(E.radiance[0])];
+    const float *tab = S.emitter_cdf + as_u32(E.radiance[1]);
+    float u, v, pdf;
+    bitmap_sample_position(T, tab, sx, sy, u, v, pdf);
+    bool active = pdf != 0.f;
+    ds.p = xf_point(E.to_world, Vec3(fma_(u, 2.f, -1.f), fma_(v, 2.f, -1.f), 0.f));
+    ds.n = Vec3(E.normal[0], E.normal[1], E.normal[2]);
+    ds.d = ds.p - ref_p;
+    const float dist2 = dot3(ds.d, ds.d);
+    ds.dist = sqrtf(dist2);
+    ds.d = div3(ds.d, ds.dist);
+    const float dp = dot3(ds.d, ds.n);
+    active = active && dp < 0.f;
+    ds.pdf = active ? pdf / E.radiance[2] * dist2 / -dp : 0.f;
+    spec = active ? div3(texture_eval_uv(T, u, v), ds.pdf) : Vec3(0.f);
+}
+/* AreaLight::pdf_direction, spatially varying branch (area.cpp:185-191): pdf_position(ds.uv) * dist^2 / (|dp_du x dp_dv| * -dp) */
+HAR_HD float textured_area_pdf_direction(const DScene &S, const DEmitter &E, Vec3 d, Vec3 n, float dist, float u, float v) {
+    const float dp = dot3(d, n);
+    if (!(dp < 0.f)) return 0.f;
+    const DTexture T = S.textures[as_u32(E.radiance[0])];
+    float tu = u, tv = v;
+    if (T.mode & HAR_TEX_HAS_UV_XF) { tu = fma_(T.uvm[1], v, fma_(T.uvm[0], u, T.uvm[2])); tv = fma_(T.uvm[4], v, fma_(T.uvm[3], u, T.uvm[5])); }
+    return bitmap_pdf_texture(T, S.emitter_cdf + as_u32(E.radiance[1]), tu, tv) * (dist * dist) / (E.radiance[2] * -dp);
 }
 
 /* PerspectiveCamera::sample_ray (src/sensors/perspective.cpp:200-237) */

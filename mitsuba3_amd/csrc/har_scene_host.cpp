@@ -289,9 +289,9 @@ bool lower_scene(const HarSceneDesc &d, HostScene &hs, std::string &err) {
     }
     for (uint32_t i = 0; i < d.emitter_count; ++i) {
         const HarEmitter &e = d.emitters[i];
-        if (e.type > 6) { err = "unsupported emitter type (`area`, `constant`, `envmap`, `point`, `spot` and `directional` are implemented)"; return false; }
+        if (e.type > 7) { err = "unsupported emitter type (`area`, `constant`, `envmap`, `point`, `spot` and `directional` are implemented)"; return false; }
         if (!(e.sampling_weight >= 0.f) || !std::isfinite(e.sampling_weight)) { err = "DiscreteDistribution: entries must be non-negative!"; return false; }      /* distr_1d.h:247-248 */
-        const bool area = e.type == 0 || e.type == 3, point = e.type >= 4;      /* the delta emitters */
+        const bool area = e.type == 0 || e.type == 3 || e.type == 7, point = e.type >= 4 && e.type <= 6;      /* the delta emitters */
         if (area && e.mesh >= d.top_mesh_count) { err = "area emitter must be attached to a top-level mesh"; return false; }
         if (!area && !point && hs.env_emitter >= 0) { err = "Only one environment emitter can be specified per scene."; return false; }   /* scene.cpp:64-65 */
         if (!area && !point) hs.env_emitter = (int32_t) i;
@@ -313,6 +313,19 @@ bool lower_scene(const HarSceneDesc &d, HostScene &hs, std::string &err) {
         }
         if (e.type == 6) {            /* the record of a directional light keeps its direction of travel (third column of to_world) in [0..2]; [3..6] = the scene's bounding sphere (update_scene_bounds) */
             de.to_world[0] = e.to_world[6]; de.to_world[1] = e.to_world[7]; de.to_world[2] = e.to_world[8];
+        }
+        if (e.type == 7) {            /* AreaLight with a bitmap radiance: the texel distribution (see texel_table_fill) lives in emitter_cdf, the record holds where */
+            if (e.radiance_texture >= d.texture_count) { err = "area emitter references a bitmap that does not exist"; return false; }
+            const HostTexture &t = hs.textures[e.radiance_texture];
+            const uint32_t off = (uint32_t) hs.emitter_cdf.size(), tex = e.radiance_texture;
+            hs.emitter_cdf.resize(off + HAR_TEXEL_TABLE_HEADER + (size_t) t.h + (size_t) t.w * t.h);
+            std::memcpy(&de.radiance[0], &tex, 4); std::memcpy(&de.radiance[1], &off, 4);
+            /* Rectangle::update (rectangle.cpp:118-124): dp_du = to_world * (2, 0, 0), dp_dv = to_world * (0, 2, 0); |dp_du x dp_dv| = the surface area */
+            const Vec3 du(e.to_world[0] * 2.f, e.to_world[1] * 2.f, e.to_world[2] * 2.f), dv(e.to_world[3] * 2.f, e.to_world[4] * 2.f, e.to_world[5] * 2.f);
+            const Vec3 c = cross3(du, dv);
+            de.radiance[2] = sqrtf(dot3(c, c));
+            if (!texel_table_fill(hs, t, off, err)) return false;
+            hs.has_mesh_emitters = true;       /* = "emitter tables in emitter_cdf": the scene runs the kernels that carry the generic emitter code */
         }
         if (e.type == 3) {            /* Mesh::build_pmf (mesh.cpp:1358-1372): face areas of the (world-space) mesh + their running sum */
             const DMesh &M = hs.meshes[e.mesh];
@@ -405,6 +418,39 @@ void update_scene_bounds(HostScene &hs) {
         for (int a = 0; a < 3; ++a) hs.envmap.center[a] = E.to_world[a];
         hs.envmap.radius = E.to_world[3];
     }
+}
+
+/* Texel distribution of a bitmap that an area light radiates (emitter type 7), written to hs.emitter_cdf[off ..]:
+ *   [0] (float) sum, [1] (float) (1 / sum)   -- DiscreteDistribution2D::m_inv_normalization / m_normalization (include/mitsuba/core/distr_2d.h:93-118)
+ *   [2..7] the inverse of the bitmap's to_uv (row-major 2 x 3): sample_position returns m_transform.inverse() * sample (bitmap.cpp:658)
+ *   [8 ..] marginal running sums (h), then the conditional running sums row by row (w * h); both accumulated in double and stored per entry as float
+ * over the texels' luminance (rebuild_internals, bitmap.cpp:876-955; luminance(): spectrum.h:439-442).  to_uv has to map the unit square's corners onto themselves
+ * (check_sampling_transform, bitmap.cpp:976-992). */
+bool texel_table_fill(HostScene &hs, const HostTexture &t, uint32_t off, std::string &err) {
+    const float cx[4] = { 0.f, 1.f, 1.f, 0.f }, cy[4] = { 0.f, 0.f, 1.f, 1.f };
+    uint32_t found = 0;
+    for (int c = 0; c < 4; ++c) {
+        const float qx = fma_(t.uvm[1], cy[c], fma_(t.uvm[0], cx[c], t.uvm[2])), qy = fma_(t.uvm[4], cy[c], fma_(t.uvm[3], cx[c], t.uvm[5]));
+        for (uint32_t j = 0; j < 4; ++j) { const float dx = qx - cx[j], dy = qy - cy[j]; if (dx * dx + dy * dy < 1e-8f) found |= 1u << j; }
+    }
+    if (found != 0xFu) { err = "Bitmap texture: position sampling (e.g. of an area emitter's radiance) requires a 'to_uv' transformation that maps the unit square onto itself, such as a flip, a transpose or a multiple of a 90 degree rotation."; return false; }
+    float *tab = hs.emitter_cdf.data() + off, *marg = tab + HAR_TEXEL_TABLE_HEADER, *cond = marg + t.h;
+    double total = 0.0;
+    for (uint32_t y = 0; y < t.h; ++y) {
+        double row = 0.0;
+        for (uint32_t x = 0; x < t.w; ++x) {
+            const float *px = t.data.data() + 3 * ((size_t) y * t.w + x);
+            const float lum = px[0] * 0.212671f + px[1] * 0.715160f + px[2] * 0.072169f;
+            row += (double) lum; cond[(size_t) y * t.w + x] = (float) row;
+        }
+        total += row; marg[y] = (float) total;
+    }
+    if (!(total > 0.0)) { err = "area emitter: the radiance bitmap has no luminance to sample"; return false; }
+    tab[0] = (float) total; tab[1] = (float) (1.0 / total);
+    const float a = t.uvm[0], b = t.uvm[1], c = t.uvm[3], d = t.uvm[4], inv_det = 1.f / (a * d - b * c);
+    tab[2] = d * inv_det; tab[3] = -b * inv_det; tab[5] = -c * inv_det; tab[6] = a * inv_det;
+    tab[4] = -(tab[2] * t.uvm[2] + tab[3] * t.uvm[5]); tab[7] = -(tab[5] * t.uvm[2] + tab[6] * t.uvm[5]);
+    return true;
 }
 
 /* The instance level: one TLAS leaf per Instance whose group is not empty, over the world-space box of the instance; hs.nodes is cut back to tlas_first and the new

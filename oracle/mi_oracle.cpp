@@ -58,7 +58,11 @@ struct Texture {
     }
 };
 
+static inline uint32_t tex_wrap_pos(int64_t pos, int64_t res, uint32_t mode);
+#include "orc_texlight.h"
+
 struct Scene {
+    std::vector<TexelTable> texel_tables;  // indexed by emitter: AreaLight with a bitmap radiance (type 7)
     std::vector<Mesh> meshes; uint32_t top_count;
     std::vector<OrcShapeGroup> groups;
     std::vector<OrcInstance> instances;
@@ -548,6 +552,25 @@ static inline void emitter_sample_direction(const Scene &sc, uint32_t index, V3 
         if (unit) *unit = 1.f;
         return;
     }
+    if (e.type == 7) {          // AreaLight::sample_direction, spatially varying radiance (area.cpp:133-165)
+        const Texture &t = sc.textures[e.radiance_texture]; const TexelTable &tab = sc.texel_tables[index];
+        float uv[2], pdf;
+        bitmap_sample_position(t, tab, sx, sy, uv, pdf);
+        bool active = pdf != 0.f;
+        ds.p = xf_point(e.to_world, V3(fmadd(uv[0], 2.f, -1.f), fmadd(uv[1], 2.f, -1.f), 0.f));      // Rectangle::eval_parameterization (rectangle.cpp:215-237)
+        ds.n = V3(e.normal[0], e.normal[1], e.normal[2]);
+        ds.d = ds.p - ref_p;
+        const float dist2 = squared_norm(ds.d);
+        ds.dist = std::sqrt(dist2);
+        ds.d = div(ds.d, ds.dist);
+        const float dp = dot(ds.d, ds.n);
+        active = active && dp < 0.f;
+        ds.pdf = active ? pdf / tab.span * dist2 / -dp : 0.f;
+        TexLookup l; tex_lookup(t, uv, l);                                                           // m_radiance->eval(si) at si.uv = uv
+        spec = active ? div(tex_eval(t, l), ds.pdf) : V3(0.f);
+        if (unit) *unit = 0.f;                                                                       // no colour parameter to differentiate
+        return;
+    }
     if (e.type == 3) mesh_sample_position(sc.meshes[e.mesh], sc.area_pmf[index], sx, sy, ds.p, ds.n, ds.pdf);
     else {          // Rectangle::sample_position (rectangle.cpp:159-170)
         ds.p = xf_point(e.to_world, V3(fmadd(sx, 2.f, -1.f), fmadd(sy, 2.f, -1.f), 0.f));
@@ -574,6 +597,22 @@ static inline float emitter_pdf_direction(const OrcEmitter &e, const DS &ds) {
     float pdf = e.inv_area;
     pdf *= (adp != 0.f) ? (ds.dist * ds.dist) / adp : 0.f;
     return pdf;
+}
+
+/* the two quantities an emitter HIT needs, for every surface emitter: AreaLight::pdf_direction (area.cpp:170-197; the textured branch :185-191 evaluates
+ * pdf_position(ds.uv) * dist^2 / (|dp_du x dp_dv| * -dp)) and AreaLight::eval (area.cpp:83-90) */
+static inline float surface_emitter_pdf_direction(const Scene &sc, uint32_t index, const DS &ds, const float uv[2]) {
+    const OrcEmitter &e = sc.emitters[index];
+    if (e.type != 7) return emitter_pdf_direction(e, ds);
+    const float dp = dot(ds.d, ds.n);
+    if (!(dp < 0.f)) return 0.f;
+    const TexelTable &tab = sc.texel_tables[index];
+    return bitmap_pdf_position(sc.textures[e.radiance_texture], tab, uv) * sqr(ds.dist) / (tab.span * -dp);
+}
+static inline V3 surface_emitter_radiance(const Scene &sc, const OrcEmitter &e, const float uv[2]) {
+    if (e.type != 7) return V3(e.radiance[0], e.radiance[1], e.radiance[2]);
+    TexLookup l; tex_lookup(sc.textures[e.radiance_texture], uv, l);
+    return tex_eval(sc.textures[e.radiance_texture], l);
 }
 
 /* PathIntegrator::mis_weight (src/integrators/path.cpp:359-364), common.py:1344 */
@@ -836,10 +875,10 @@ static V3 path_sample(const Scene &sc, Pcg32 &rng, Ray ray, uint32_t max_depth, 
             V3 rel = si.p - prev_p; ds.dist = norm(rel); ds.d = si.valid() ? div(rel, ds.dist) : -si.wi;
             const OrcEmitter &e = sc.emitters[emitter];
             float em_pdf = 0.f;
-            if (!prev_bsdf_delta) em_pdf = (e.type == 1 ? InvFourPi : e.type == 2 ? sc.envmap.pdf_direction(ds.d) : emitter_pdf_direction(e, ds)) * emitter_choice_pmf(sc, (uint32_t) emitter);
+            if (!prev_bsdf_delta) em_pdf = (e.type == 1 ? InvFourPi : e.type == 2 ? sc.envmap.pdf_direction(ds.d) : surface_emitter_pdf_direction(sc, (uint32_t) emitter, ds, si.uv)) * emitter_choice_pmf(sc, (uint32_t) emitter);
             float mis_bsdf = mis_weight(prev_bsdf_pdf, em_pdf);
-            bool facing = (e.type != 0 && e.type != 3) || si.wi.z > 0.f;                                                                   // area.cpp:83-90, constant.cpp:90-94
-            V3 rad = e.type == 2 ? sc.envmap.eval(-si.wi) : V3(e.radiance[0], e.radiance[1], e.radiance[2]);             // envmap.cpp:228-236
+            bool facing = (e.type != 0 && e.type != 3 && e.type != 7) || si.wi.z > 0.f;                                                    // area.cpp:83-90, constant.cpp:90-94
+            V3 rad = e.type == 2 ? sc.envmap.eval(-si.wi) : surface_emitter_radiance(sc, e, si.uv);                       // envmap.cpp:228-236
             V3 Le = (facing && prev_bsdf_pdf > 0.f) ? rad : V3(0.f);
             result = fmadd(throughput, Le * mis_bsdf, result);
         }
@@ -1316,13 +1355,13 @@ static V3 prb_sample(const Scene &sc, Pcg32 &rng, Ray ray, uint32_t max_depth, u
             float em_pdf = 0.f;
             DS ds; ds.p = si.p; ds.n = si.sn;
             V3 rel = si.p - prev_p; ds.dist = norm(rel); ds.d = si.valid() ? div(rel, ds.dist) : -si.wi;
-            if (emitter >= 0 && !bsdf_delta_prev) em_pdf = (sc.emitters[emitter].type == 1 ? InvFourPi : sc.emitters[emitter].type == 2 ? sc.envmap.pdf_direction(ds.d) : emitter_pdf_direction(sc.emitters[emitter], ds)) * emitter_choice_pmf(sc, (uint32_t) emitter);
+            if (emitter >= 0 && !bsdf_delta_prev) em_pdf = (sc.emitters[emitter].type == 1 ? InvFourPi : sc.emitters[emitter].type == 2 ? sc.envmap.pdf_direction(ds.d) : surface_emitter_pdf_direction(sc, (uint32_t) emitter, ds, si.uv)) * emitter_choice_pmf(sc, (uint32_t) emitter);
             float mis = mis_weight(bsdf_pdf_prev, em_pdf);
             if (emitter >= 0 && !(sc.hide_emitters && depth == 0 && !si.valid())) {          // prb.py:146-148: active_next masks emitter.eval
                 const OrcEmitter &e = sc.emitters[emitter];
-                V3 ev = e.type == 2 ? sc.envmap.eval(-si.wi) : (e.type == 1 || si.wi.z > 0.f) ? V3(e.radiance[0], e.radiance[1], e.radiance[2]) : V3(0.f);
+                V3 ev = e.type == 2 ? sc.envmap.eval(-si.wi) : (e.type == 1 || si.wi.z > 0.f) ? surface_emitter_radiance(sc, e, si.uv) : V3(0.f);
                 Le = (beta * mis) * ev;
-                if (!primal && grad && grad->emit && e.type != 2 && (e.type == 1 || si.wi.z > 0.f)) {   // d Le / d radiance = beta * mis (prb.py:160-161, attached emitter.eval)
+                if (!primal && grad && grad->emit && e.type != 2 && e.type != 7 && (e.type == 1 || si.wi.z > 0.f)) {   // d Le / d radiance = beta * mis (prb.py:160-161, attached emitter.eval)
                     grad_commit(grad, grad->emit + 3 * (size_t) emitter, (beta * mis) * dL);
                 }
             }
@@ -1823,7 +1862,7 @@ void *orc_scene_create(const OrcSceneDesc *d) {
         sc->textures.push_back(std::move(t));
     }
     sc->emitters.assign(d->emitters, d->emitters + d->emitter_count);
-    sc->area_pmf.resize(sc->emitters.size());
+    sc->area_pmf.resize(sc->emitters.size()); sc->texel_tables.resize(sc->emitters.size());
     if (!rebuild_emitter_choice(*sc)) { delete sc; return nullptr; }
     for (uint32_t i = 0; i < sc->emitters.size(); ++i) {
         const OrcEmitter e = sc->emitters[i];
@@ -1841,6 +1880,11 @@ void *orc_scene_create(const OrcSceneDesc *d) {
             }
             d.sum = acc; d.normalization = rcp(acc);
             sc->emitters[i].inv_area = d.normalization;       // Mesh::pdf_position = m_area_pmf.normalization()
+        }
+        if (e.type == 7) {              // AreaLight with a bitmap radiance on a rectangle: the texel distribution is built up front (the reference builds it on first use, bitmap.cpp:963-971)
+            std::string why;
+            if (e.mesh >= sc->top_count || e.radiance_texture >= sc->textures.size() ||
+                !texel_table_build(sc->textures[e.radiance_texture], e.to_world, sc->texel_tables[i], why)) { delete sc; return nullptr; }
         }
         if (e.type == 2) {
             if (e.mesh >= sc->textures.size()) { delete sc; return nullptr; }
@@ -1893,12 +1937,43 @@ int orc_scene_set_emitter_weights(void *s, const float *w, uint32_t n) {
     if (!rebuild_emitter_choice(sc)) { for (uint32_t i = 0; i < n; ++i) sc.emitters[i].sampling_weight = old[i]; return 2; }
     return 0;
 }
+static void refresh_texel_tables(Scene &sc, uint32_t t);
 void orc_scene_set_texture_to_uv(void *s, uint32_t t, const float m[6]) {
     Texture &x = ((Scene *) s)->textures[t];
     x.moved = false;
     for (int r = 0; r < 2; ++r) for (int c = 0; c < 3; ++c) { x.xf[r][c] = m[3 * r + c]; x.moved = x.moved || m[3 * r + c] != (r == c ? 1.f : 0.f); }
+    refresh_texel_tables(*(Scene *) s, t);
 }
-void orc_scene_set_texture(void *s, uint32_t t, const float *data) { Texture &x = ((Scene *) s)->textures[t]; x.data.assign(data, data + 3 * (size_t) x.w * x.h); }
+/* the texel distributions of the area lights that read texture t (BitmapTexture::parameters_changed -> rebuild_internals, bitmap.cpp:484-493) */
+static void refresh_texel_tables(Scene &sc, uint32_t t) {
+    for (size_t i = 0; i < sc.emitters.size(); ++i)
+        if (sc.emitters[i].type == 7 && sc.emitters[i].radiance_texture == t) { std::string why; texel_table_build(sc.textures[t], sc.emitters[i].to_world, sc.texel_tables[i], why); }
+}
+void orc_scene_set_texture(void *s, uint32_t t, const float *data) {
+    Texture &x = ((Scene *) s)->textures[t]; x.data.assign(data, data + 3 * (size_t) x.w * x.h);
+    refresh_texel_tables(*(Scene *) s, t);
+}
+/* the two texture-side functions of a textured area light, for the known-answer and chi^2 tests: BitmapTexture::sample_position / pdf_position of the bitmap behind
+ * emitter `emitter` (type 7).  sample: n x 2 -> uv n x 2, pdf n;  pdf_only != 0: `sample` holds positions, only pdf is written */
+int orc_emitter_texture_sample_position(void *s, uint32_t emitter, const float *sample, uint32_t n, float *uv, float *pdf, int pdf_only) {
+    Scene &sc = *(Scene *) s;
+    if (emitter >= sc.emitters.size() || sc.emitters[emitter].type != 7) return -1;
+    const Texture &t = sc.textures[sc.emitters[emitter].radiance_texture]; const TexelTable &tab = sc.texel_tables[emitter];
+    for (uint32_t i = 0; i < n; ++i) {
+        if (pdf_only) pdf[i] = bitmap_pdf_position(t, tab, sample + 2 * (size_t) i);
+        else bitmap_sample_position(t, tab, sample[2 * (size_t) i], sample[2 * (size_t) i + 1], uv + 2 * (size_t) i, pdf[i]);
+    }
+    return 0;
+}
+/* DiscreteDistribution2D over a w x h array of values: sample n points -> col, row (n x 2 uint32), pmf (n), re-used sample (n x 2) */
+int orc_discrete_distribution_2d_sample(const float *values, uint32_t w, uint32_t h, const float *sample, uint32_t n, uint32_t *pos, float *pmf, float *reused) {
+    TexelTable tab; tab.w = w; tab.h = h; tab.marginal.assign(h, 0.f); tab.conditional.assign((size_t) w * h, 0.f);
+    double rows = 0.0;
+    for (uint32_t y = 0; y < h; ++y) { double row = 0.0; for (uint32_t x = 0; x < w; ++x) { row += (double) values[(size_t) y * w + x]; tab.conditional[(size_t) y * w + x] = (float) row; } rows += row; tab.marginal[y] = (float) rows; }
+    tab.inv_normalization = (float) rows; tab.normalization = (float) (1.0 / rows);
+    for (uint32_t i = 0; i < n; ++i) texel_table_sample(tab, sample[2 * (size_t) i], sample[2 * (size_t) i + 1], pos[2 * (size_t) i], pos[2 * (size_t) i + 1], pmf[i], reused[2 * (size_t) i], reused[2 * (size_t) i + 1]);
+    return 0;
+}
 
 /* `active` (nullable): the Mask argument of Scene::ray_intersect_preliminary / ray_test (scene.cpp:216-238) -- a masked lane is not traced and reports
  * dr::zeros<PreliminaryIntersection3f>() (t = inf) / false */
@@ -2197,7 +2272,7 @@ int orc_render_prb_backward_lanes(void *scene, const OrcSensor *sp, const float 
 }
 /* + d/d(vertex positions) of the meshes with pos_mask[m] != 0: grad_positions[m] = 3 doubles per vertex (accumulated into).
  * Returns -2 when the scene holds a BSDF other than plain `diffuse`, -3 for a mesh with vertex normals / inside a shape group. */
-static bool has_point_emitter(void *scene) { for (const OrcEmitter &e : ((Scene *) scene)->emitters) if (e.type >= 4) return true; return false; }
+static bool has_point_emitter(void *scene) { for (const OrcEmitter &e : ((Scene *) scene)->emitters) if (e.type >= 4) return true; return false; }      /* (also the textured area light, type 7: its shape-gradient terms are not restated) */
 int orc_render_prb_backward_shape(void *scene, const OrcSensor *sp, const float *grad_in, uint32_t seed, uint32_t spp,
                                   int32_t max_depth, int32_t rr_depth, float *grad_reflectance, float *const *grad_textures,
                                   const uint8_t *pos_mask, double *const *grad_positions, OrcStats *stats, int threads) {

@@ -91,6 +91,8 @@ typedef struct OrcEmitter {
     float inv_area;       /* m_inv_surface_area (rectangle.cpp:123) */
     float to_local[12];   /* inverse of to_world as the reference's Transform tracks it (type 2 only) */
     float sampling_weight; /* Emitter::m_sampling_weight (src/render/emitter.cpp:9) */
+    uint32_t radiance_texture; /* type 7 = area light on a rectangle whose `radiance` is a bitmap (area.cpp:74,133-165,185-191): index of the bitmap in `textures`;
+                                  `radiance` is not read, to_world / normal as for type 0 */
 } OrcEmitter;
 
 typedef struct OrcSceneDesc {
@@ -219,6 +221,9 @@ int orc_render_prb_backward(void *scene, const OrcSensor *s, const float *grad_i
                             float *const *grad_textures, OrcStats *stats, int threads);
 /* ... plus grad_emitters (emitter_count x 3, may be NULL): gradient w.r.t. the radiance of `area` / `constant` emitters
  * (prb.py:160-161 attached emitter.eval, :198-206 attached eval_emitter_direction) */
+/* textured area lights (emitter type 7): BitmapTexture::sample_position / pdf_position of the emitter's bitmap, and DiscreteDistribution2D::sample on its own */
+int orc_emitter_texture_sample_position(void *scene, uint32_t emitter, const float *sample, uint32_t n, float *uv, float *pdf, int pdf_only);
+int orc_discrete_distribution_2d_sample(const float *values, uint32_t w, uint32_t h, const float *sample, uint32_t n, uint32_t *pos, float *pmf, float *reused);
 int orc_render_prb_backward_ex(void *scene, const OrcSensor *s, const float *grad_in, uint32_t seed, uint32_t spp, int32_t max_depth,
                                int32_t rr_depth, float *grad_reflectance, float *const *grad_textures, float *grad_emitters,
                                OrcStats *stats, int threads);

@@ -43,7 +43,7 @@ class Texture(C.Structure):
 
 class Emitter(C.Structure):
     _fields_ = [("type", C.c_uint32), ("mesh", C.c_uint32), ("radiance", C.c_float * 3),
-                ("to_world", C.c_float * 12), ("normal", C.c_float * 3), ("inv_area", C.c_float), ("to_local", C.c_float * 12), ("sampling_weight", C.c_float)]
+                ("to_world", C.c_float * 12), ("normal", C.c_float * 3), ("inv_area", C.c_float), ("to_local", C.c_float * 12), ("sampling_weight", C.c_float), ("radiance_texture", C.c_uint32)]
 
 
 class SceneDesc(C.Structure):
@@ -336,6 +336,7 @@ class SceneData:
             ems[i].inv_area = float(e["inv_area"])
             ems[i].to_local = (C.c_float * 12)(*[float(x) for x in e.get("to_local", [1, 0, 0, 0, 1, 0, 0, 0, 1, 0, 0, 0])])
             ems[i].sampling_weight = float(e.get("sampling_weight", 1.0))
+            ems[i].radiance_texture = int(e.get("radiance_texture", 0))
         d = SD()
         d.meshes = meshes; d.mesh_count = len(self.meshes); d.top_mesh_count = self.top_mesh_count
         d.groups = groups; d.group_count = len(self.groups)

@@ -288,7 +288,7 @@ int hh_render(void *h, const HarSensor *sensor, int mode, uint32_t seed, uint32_
             Hit hit; HostStack stack;
             accel_trace<false>(S.accel, st.o, st.d, st.maxt, hit, stack, status);
             ShadeResult R;
-            constexpr uint32_t ENV = HAR_BSDF_ALL_TYPES | HAR_SCENE_ENVMAP;
+            constexpr uint32_t ENV = HAR_BSDF_ALL_TYPES | HAR_SCENE_ENVMAP | HAR_SCENE_TEXLIGHT;
             if (S.bsdf_types & HAR_SCENE_ENVMAP) { if (mode == MODE_PATH) shade_lane<MODE_PATH, ENV>(S, P, st, hit, R); else shade_lane<MODE_PRB_PRIMAL, ENV>(S, P, st, hit, R); }
             else if (mode == MODE_PATH) shade_lane<MODE_PATH>(S, P, st, hit, R); else shade_lane<MODE_PRB_PRIMAL>(S, P, st, hit, R);
             if (R.add_emission) result = mode == MODE_PATH ? fma3(R.em_a, R.em_b, result) : result + R.em_b;

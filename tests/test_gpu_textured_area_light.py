@@ -1,0 +1,89 @@
+"""An `area` emitter whose radiance is a bitmap, on a rectangle (src/emitters/area.cpp:74, 83-90, 133-165, 185-191; emitter type 7 of include/hip_ad_rgb.h), on the
+GPU against the oracle: forward images within 1e-4 with equal vertex counts, prb gradients of a reflectance bitmap lit by it within 1e-3, parameter updates,
+`Integrator.sample`, and several lights at once (selection probabilities)."""
+import numpy as np
+import pytest
+
+from tests.test_gpu_boundary import rel_l2
+from tests.test_textured_area_light_cpu import _bitmap, lit_box
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.mark.parametrize("props", [{}, {"filter_type": "nearest", "wrap_mode": "clamp"}, {"wrap_mode": "mirror", "to_uv": "transpose"}, {"filter_type": "nearest", "to_uv": "flip"}])
+def test_forward_parity_and_vertex_counts(mi, O, props):
+    props = dict(props)
+    if props.get("to_uv") == "transpose":
+        props["to_uv"] = mi.ScalarTransform3f([[0, 1, 0], [1, 0, 0], [0, 0, 1]])
+    elif props.get("to_uv") == "flip":
+        props["to_uv"] = mi.ScalarTransform3f([[-1, 0, 1], [0, 1, 0], [0, 0, 1]])
+    scene = mi.load_dict(lit_box(mi, _bitmap(5), 48, **props))
+    img = mi.render(scene, spp=32, seed=2).cpu().numpy()
+    osc, sensor = O.scene_from_product(scene)
+    ref, ost = osc.render_path(sensor, seed=2, spp=32, max_depth=scene.integrator().max_depth, rr_depth=scene.integrator().rr_depth)
+    assert np.isfinite(img).all() and img.max() > 0
+    assert rel_l2(img, ref) < 1e-4
+    st = scene.integrator().stats()
+    assert st["vertices"] == ost.vertices and st["paths"] == 48 * 48 * 32
+
+
+def test_two_lights_one_textured_with_weights(mi, O):
+    """a bitmap light next to a uniform one, unequal sampling weights: the emitter choice (scene.cpp:248-279) multiplies both strategies' densities"""
+    d = lit_box(mi, _bitmap(9), 32)
+    T = mi.ScalarTransform4f
+    d["lamp2"] = {"type": "rectangle", "to_world": T().translate([0.4, -0.3, 0.2]).rotate([0, 1, 0], -70.0).scale([0.15, 0.2, 1.0]),
+                  "emitter": {"type": "area", "radiance": {"type": "rgb", "value": [3.0, 6.0, 9.0]}, "sampling_weight": 0.5}}
+    d["light"]["emitter"]["sampling_weight"] = 2.0
+    scene = mi.load_dict(d)
+    assert sorted(e["type"] for e in scene.emitters) == [0, 7]
+    img = mi.render(scene, spp=32, seed=6).cpu().numpy()
+    osc, sensor = O.scene_from_product(scene)
+    ref, ost = osc.render_path(sensor, seed=6, spp=32, max_depth=scene.integrator().max_depth, rr_depth=scene.integrator().rr_depth)
+    assert rel_l2(img, ref) < 1e-4 and scene.integrator().stats()["vertices"] == ost.vertices
+
+
+def test_prb_reflectance_gradient_under_a_bitmap_light(mi, O):
+    """the light's texels are not differentiated, everything it lights is: texel gradients of a wall bitmap, image and gradient against the oracle"""
+    import torch
+    d = lit_box(mi, _bitmap(4), 32)
+    wall = np.random.default_rng(1).uniform(0.2, 0.8, (8, 8, 3)).astype(np.float32)
+    d["white"] = {"type": "diffuse", "reflectance": {"type": "bitmap", "data": wall}}
+    d["integrator"] = {"type": "prb", "max_depth": 5, "rr_depth": 3}
+    scene = mi.load_dict(d)
+    params = mi.traverse(scene)
+    key = "white.reflectance.data"
+    params[key].requires_grad_()
+    img = mi.render(scene, params, spp=32, seed=0)
+    (img ** 2).mean().backward()
+    g = params[key].grad.cpu().numpy()
+    osc, sensor = O.scene_from_product(scene)
+    ref, _ = osc.render_prb(sensor, seed=0, spp=32, max_depth=5, rr_depth=3)
+    assert rel_l2(img.detach().cpu().numpy(), ref) < 1e-4
+    grad_in = 2.0 * ref / ref.size
+    _, g_tex, _ = osc.render_prb_backward(sensor, grad_in, seed=mi.sample_tea_32(0, 1)[0], spp=32, max_depth=5, rr_depth=3)
+    wall_index = [b for b in scene.bsdf_objs if b.id == "white"][0].tex_index
+    assert np.abs(g).max() > 0 and rel_l2(g, g_tex[wall_index]) < 1e-3
+    # the light's own texels: a parameter, not a differentiable one
+    params["light.emitter.radiance.data"].requires_grad_()
+    with pytest.raises(RuntimeError, match="not differentiable|differentiable"):
+        mi.render(scene, params, spp=4, seed=1)
+
+
+def test_radiance_bitmap_updates_in_place(mi, O):
+    import torch
+    scene = mi.load_dict(lit_box(mi, _bitmap(5), 32)); mi.render(scene, spp=4, seed=0); handle = scene._h.value
+    params = mi.traverse(scene)
+    for tex2 in (torch.tensor(_bitmap(6)), torch.tensor(_bitmap(7), device="cuda")):
+        params["light.emitter.radiance.data"] = tex2; params.update()
+        assert scene._h.value == handle
+        a = mi.render(scene, spp=16, seed=5).cpu().numpy()
+        b = mi.render(mi.load_dict(lit_box(mi, tex2.cpu().numpy(), 32)), spp=16, seed=5).cpu().numpy()
+        assert rel_l2(a, b) < 1e-6
+    params["light.emitter.radiance.to_uv"] = torch.tensor(mi.ScalarTransform3f([[0, 1, 0], [1, 0, 0], [0, 0, 1]]).matrix); params.update()
+    assert scene._h.value == handle
+    a = mi.render(scene, spp=16, seed=5).cpu().numpy()
+    b = mi.render(mi.load_dict(lit_box(mi, _bitmap(7), 32, to_uv=mi.ScalarTransform3f([[0, 1, 0], [1, 0, 0], [0, 0, 1]]))), spp=16, seed=5).cpu().numpy()
+    assert rel_l2(a, b) < 1e-6
+    osc, sensor = O.scene_from_product(scene)
+    ref, ost = osc.render_path(sensor, seed=5, spp=16, max_depth=scene.integrator().max_depth, rr_depth=scene.integrator().rr_depth)
+    assert rel_l2(a, ref) < 1e-4 and scene.integrator().stats()["vertices"] == ost.vertices

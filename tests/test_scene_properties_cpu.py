@@ -3,7 +3,7 @@
  * `sampling_weight` of emitters: the DiscreteDistribution over the weights (src/render/scene.cpp:120-141, 248-279, 378-388) in the oracle and in the
    product's host-compiled shading code, against each other and against the estimator's expectation;
  * bitmap `to_uv` (src/textures/bitmap.cpp:175, 565, 847): oracle == product host code == an independent NumPy lookup;
- * spatially varying area-light radiance is refused by name (src/emitters/area.cpp:133-165 is a different sampling strategy), the default BSDF of an
+ * spatially varying area-light radiance: on rectangles (tests/test_textured_area_light_cpu.py), refused by name elsewhere; the default BSDF of an
    emitter shape is black (src/render/shape.cpp:50-57)."""
 import ctypes as C
 import os
@@ -93,8 +93,13 @@ def test_known_but_unimplemented_values_are_refused_not_ignored(mi):
 def test_area_light_placement_and_textured_radiance(mi):
     with pytest.raises(RuntimeError, match="to_world"):            # area.cpp:66-69
         mi.load_dict({"type": "rectangle", "emitter": {"type": "area", "to_world": mi.ScalarTransform4f()}})
-    with pytest.raises(RuntimeError, match="spatially varying"):   # area.cpp:74,133-165: texture importance sampling, not built -> named refusal
-        mi.load_dict({"type": "rectangle", "emitter": {"type": "area", "radiance": {"type": "bitmap", "data": np.ones((4, 4, 3), np.float32)}}})
+    # area.cpp:74,133-165: a bitmap radiance is importance-sampled and mapped through Shape::eval_parameterization -- built for rectangles
+    # (tests/test_textured_area_light_cpu.py), refused by name on triangle meshes and for the other emitters' emissive parameters
+    mi.load_dict({"type": "rectangle", "emitter": {"type": "area", "radiance": {"type": "bitmap", "data": np.ones((4, 4, 3), np.float32)}}})
+    with pytest.raises(RuntimeError, match="eval_parameterization"):
+        mi.load_dict({"type": "scene", "c": {"type": "cube", "emitter": {"type": "area", "radiance": {"type": "bitmap", "data": np.ones((4, 4, 3), np.float32)}}}})
+    with pytest.raises(RuntimeError, match="spatially varying"):
+        mi.load_dict({"type": "constant", "radiance": {"type": "bitmap", "data": np.ones((4, 4, 3), np.float32)}})
     with pytest.raises(RuntimeError, match="single Emitter"):      # shape.cpp:25-27
         mi.load_dict({"type": "rectangle", "e1": {"type": "area"}, "e2": {"type": "area"}})
 
