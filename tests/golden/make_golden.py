@@ -202,6 +202,20 @@ def oracle_fixtures():
     w4 = np.random.default_rng(11).uniform(0.5, 1.5, (32, 32, 3)).astype(np.float32)
     g_refl4, _, g_emit4, _ = osc.render_prb_backward_emitters(sensor, w4, seed=5, spp=8, max_depth=6)
     fx["r4_grad_in"] = w4; fx["r4_grad_refl"] = g_refl4; fx["r4_grad_emit"] = g_emit4
+    # round 5: the Cornell box lit by a BITMAP on its ceiling rectangle (emitter type 7; tests/test_textured_area_light_cpu.py: lit_box / _bitmap), 24 x 24, 16 spp, seed 3:
+    # forward image, prb image, and 4096 (uv, pdf) pairs of BitmapTexture::sample_position on a fixed grid of samples
+    from tests.test_textured_area_light_cpu import lit_box, _bitmap
+    scene = mi.load_dict(lit_box(mi, _bitmap(5), 24, wrap_mode="mirror"))
+    osc, sensor = O.scene_from_product(scene)
+    fx["texlight_path"], _ = osc.render_path(sensor, seed=3, spp=16, max_depth=6)
+    fx["texlight_prb"], _ = osc.render_prb(sensor, seed=3, spp=16, max_depth=5)
+    g = (np.arange(64, dtype=np.float32) + 0.5) / 64
+    s = np.ascontiguousarray(np.stack(np.meshgrid(g, g), -1).reshape(-1, 2), np.float32)
+    uv = np.zeros((len(s), 2), np.float32); pdf = np.zeros(len(s), np.float32)
+    import ctypes as C
+    vp = lambda a: a.ctypes.data_as(C.c_void_p)
+    assert O.lib().orc_emitter_texture_sample_position(osc.handle, 0, vp(s), len(s), vp(uv), vp(pdf), 0) == 0
+    fx["texlight_sample_uv"] = uv; fx["texlight_sample_pdf"] = pdf
     # the film is accumulated by several threads in an order that differs from run to run (1e-7 relative): arrays that are already committed stay as committed unless
     # they moved by more than that, so that regenerating the file only ADDS what is new
     path = os.path.join(HERE, "oracle_fixtures.npz")

@@ -1071,3 +1071,16 @@ def test_paths_through_rough_bsdfs_are_the_oracles_paths(mi, O, model):
     gst = scene.integrator().stats()
     assert gst["paths"] == st.paths and gst["vertices"] == st.vertices, (gst, st.vertices)
     assert rel_l2(img, ref) < 2e-6
+
+
+def test_golden_textured_area_light(mi):
+    """a rectangle light with a bitmap radiance against the committed oracle arrays (no oracle call at run time): forward image and prb image"""
+    from tests.test_textured_area_light_cpu import lit_box, _bitmap
+    fx = _fx()
+    d = lit_box(mi, _bitmap(5), 24, wrap_mode="mirror")
+    d["integrator"] = {"type": "path", "max_depth": 6}
+    img = mi.render(mi.load_dict(d), spp=16, seed=3).cpu().numpy()
+    assert rel_l2(img, fx["texlight_path"]) < 1e-4
+    d["integrator"] = {"type": "prb", "max_depth": 5}
+    img = mi.render(mi.load_dict(d), spp=16, seed=3).cpu().numpy()
+    assert rel_l2(img, fx["texlight_prb"]) < 1e-4
