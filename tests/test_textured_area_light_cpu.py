@@ -170,3 +170,17 @@ def test_parameters_and_refusals(mi, O):
     d = lit_box(mi, tex, 12); d["env"] = {"type": "constant", "radiance": {"type": "bitmap", "data": tex}}
     with pytest.raises(RuntimeError, match="spatially varying"):
         mi.load_dict(d)
+
+
+def test_xml_scene_with_a_bitmap_radiance(mi, tmp_path):
+    """<emitter type="area"><texture type="bitmap" name="radiance"> ... : the nested texture reaches the emitter through the XML parser like it does through load_dict"""
+    t = _bitmap(5)
+    path = tmp_path / "light.pfm"
+    mi.Bitmap(t).write(str(path))
+    xml = ('<scene version="3.0.0">'
+           '<shape type="rectangle" id="lamp"><emitter type="area"><texture type="bitmap" name="radiance"><string name="filename" value="%s"/>'
+           '<string name="wrap_mode" value="clamp"/><string name="filter_type" value="nearest"/></texture><float name="sampling_weight" value="2"/></emitter></shape>'
+           '<shape type="rectangle" id="floor"><transform name="to_world"><translate z="-1"/></transform></shape></scene>') % path
+    sc = mi.load_string(xml)
+    assert [e["type"] for e in sc.emitters] == [7] and sc.emitters[0]["sampling_weight"] == 2.0
+    assert sc.texture_modes[sc.emitters[0]["radiance_texture"]] == 5 and np.array_equal(sc.textures[sc.emitters[0]["radiance_texture"]], t)
