@@ -872,10 +872,13 @@ int har_scene_set_emitter_radiance(HarScene S, uint32_t emitter, const float rgb
 }
 /* the records whose lobe-selection weight depends on the MEAN of texture `tex` (RoughPlastic / SmoothPlastic::parameters_changed, roughplastic.cpp:204-242,
  * plastic.cpp:188-205: m_specular_sampling_weight from the means of the two reflectances) */
+static bool texture_lights_an_emitter(const HostScene &hs, uint32_t tex) {
+    for (const DEmitter &e : hs.emitters) if (e.type == 7u && as_u32(e.radiance[0]) == tex) return true;
+    return false;
+}
 static bool texture_feeds_sampling_weight(const HostScene &hs, uint32_t tex) {
     for (const DBsdf &b : hs.bsdfs) if (b.texture == (int32_t) tex && (b.type == BSDF_ROUGHPLASTIC || b.type == BSDF_PLASTIC)) return true;
-    for (const DEmitter &e : hs.emitters) if (e.type == 7u && as_u32(e.radiance[0]) == tex) return true;      /* an area light radiates it: its texel distribution is derived on the host */
-    return false;
+    return texture_lights_an_emitter(hs, tex);      /* an area light radiates it: its texel distribution is derived on the host */
 }
 /* the texel distributions of the area lights that radiate bitmap `tex` (BitmapTexture::parameters_changed -> rebuild_internals, bitmap.cpp:484-493): re-derived from the
  * host mirror of the texels and copied over their slice of the device table */
@@ -903,6 +906,7 @@ static int refresh_sampling_weights(HarSceneImpl *S, uint32_t tex) {
 int har_scene_set_texture(HarScene S, uint32_t tex, const float *data) {
     if (!S || tex >= S->hs.textures.size()) return fail("invalid texture index");
     HostTexture &t = S->hs.textures[tex];
+    if (texture_lights_an_emitter(S->hs, tex)) { std::string err; if (!texel_table_inputs_ok(t.uvm, data, t.w, t.h, err)) return fail(err); }      /* before anything changes */
     t.data.assign(data, data + t.data.size());
     HIP_TRY(hipMemcpy(S->tex_dev[tex], data, t.data.size() * sizeof(float), hipMemcpyHostToDevice));
     S->tex_host_stale[tex] = 0;
@@ -918,6 +922,13 @@ int har_scene_set_texture_device(HarScene S, uint32_t tex, const float *dev, voi
     if (!dev) return fail("null device pointer");
     HostTexture &t = S->hs.textures[tex];
     hipStream_t s = (hipStream_t) stream;
+    if (texture_lights_an_emitter(S->hs, tex)) {          /* its texel distribution is derived on the host; the new texels are checked before anything changes */
+        std::vector<float> incoming(t.data.size());
+        HIP_TRY(hipMemcpyAsync(incoming.data(), dev, incoming.size() * sizeof(float), hipMemcpyDeviceToHost, s));
+        HIP_TRY(hipStreamSynchronize(s));
+        std::string err;
+        if (!texel_table_inputs_ok(t.uvm, incoming.data(), t.w, t.h, err)) return fail(err);
+    }
     if (texture_feeds_sampling_weight(S->hs, tex)) {
         HIP_TRY(hipMemcpyAsync(t.data.data(), dev, t.data.size() * sizeof(float), hipMemcpyDeviceToHost, s));
         if (dev != S->tex_dev[tex]) HIP_TRY(hipMemcpyAsync(S->tex_dev[tex], dev, t.data.size() * sizeof(float), hipMemcpyDeviceToDevice, s));
@@ -1002,19 +1013,20 @@ int har_scene_set_texture_to_uv(HarScene S, uint32_t tex, const float to_uv[6]) 
     const float id6[6] = { 1.f, 0.f, 0.f, 0.f, 1.f, 0.f };
     bool zero = true, ident = true;
     for (int k = 0; k < 6; ++k) { if (!std::isfinite(to_uv[k])) return fail("HarTexture::to_uv must be finite"); zero = zero && to_uv[k] == 0.f; ident = ident && to_uv[k] == id6[k]; }
+    if (!zero && !ident && to_uv[0] * to_uv[4] - to_uv[1] * to_uv[3] == 0.f) return fail("HarTexture::to_uv is singular");
+    if (texture_lights_an_emitter(S->hs, tex)) {          /* the emitter's texel distribution needs a to_uv that keeps the unit square (bitmap.cpp:976-992): checked before anything changes */
+        if (S->tex_host_stale[tex]) { HIP_TRY(hipMemcpy(t.data.data(), S->tex_dev[tex], t.data.size() * sizeof(float), hipMemcpyDeviceToHost)); S->tex_host_stale[tex] = 0; }
+        std::string err;
+        if (!texel_table_inputs_ok((zero || ident) ? id6 : to_uv, t.data.data(), t.w, t.h, err)) return fail(err);
+    }
     t.mode &= ~HAR_TEX_HAS_UV_XF;
     for (int k = 0; k < 6; ++k) t.uvm[k] = id6[k];
     if (!zero && !ident) {
-        if (to_uv[0] * to_uv[4] - to_uv[1] * to_uv[3] == 0.f) return fail("HarTexture::to_uv is singular");
         for (int k = 0; k < 6; ++k) t.uvm[k] = to_uv[k];
         t.mode |= HAR_TEX_HAS_UV_XF;
     }
     const DTexture d = S->hs.device_texture(tex, S->tex_dev[tex]);
     HIP_TRY(hipMemcpy(S->d_textures + tex, &d, sizeof(DTexture), hipMemcpyHostToDevice));
-    if (texture_feeds_sampling_weight(S->hs, tex) && S->tex_host_stale[tex]) {          /* the texel distribution below reads the host mirror */
-        HIP_TRY(hipMemcpy(t.data.data(), S->tex_dev[tex], t.data.size() * sizeof(float), hipMemcpyDeviceToHost));
-        S->tex_host_stale[tex] = 0;
-    }
     return refresh_texel_tables(S, tex);
 }
 

@@ -426,14 +426,25 @@ void update_scene_bounds(HostScene &hs) {
  *   [8 ..] marginal running sums (h), then the conditional running sums row by row (w * h); both accumulated in double and stored per entry as float
  * over the texels' luminance (rebuild_internals, bitmap.cpp:876-955; luminance(): spectrum.h:439-442).  to_uv has to map the unit square's corners onto themselves
  * (check_sampling_transform, bitmap.cpp:976-992). */
-bool texel_table_fill(HostScene &hs, const HostTexture &t, uint32_t off, std::string &err) {
+bool texel_table_inputs_ok(const float uvm[6], const float *texels, uint32_t w, uint32_t h, std::string &err) {
     const float cx[4] = { 0.f, 1.f, 1.f, 0.f }, cy[4] = { 0.f, 0.f, 1.f, 1.f };
     uint32_t found = 0;
     for (int c = 0; c < 4; ++c) {
-        const float qx = fma_(t.uvm[1], cy[c], fma_(t.uvm[0], cx[c], t.uvm[2])), qy = fma_(t.uvm[4], cy[c], fma_(t.uvm[3], cx[c], t.uvm[5]));
+        const float qx = fma_(uvm[1], cy[c], fma_(uvm[0], cx[c], uvm[2])), qy = fma_(uvm[4], cy[c], fma_(uvm[3], cx[c], uvm[5]));
         for (uint32_t j = 0; j < 4; ++j) { const float dx = qx - cx[j], dy = qy - cy[j]; if (dx * dx + dy * dy < 1e-8f) found |= 1u << j; }
     }
     if (found != 0xFu) { err = "Bitmap texture: position sampling (e.g. of an area emitter's radiance) requires a 'to_uv' transformation that maps the unit square onto itself, such as a flip, a transpose or a multiple of a 90 degree rotation."; return false; }
+    double total = 0.0;
+    for (size_t i = 0; i < (size_t) w * h; ++i) {
+        const float lum = texels[3 * i] * 0.212671f + texels[3 * i + 1] * 0.715160f + texels[3 * i + 2] * 0.072169f;
+        if (!(lum >= 0.f) || !std::isfinite(lum)) { err = "area emitter: the radiance bitmap must be finite and non-negative"; return false; }
+        total += (double) lum;
+    }
+    if (!(total > 0.0)) { err = "area emitter: the radiance bitmap has no luminance to sample"; return false; }
+    return true;
+}
+bool texel_table_fill(HostScene &hs, const HostTexture &t, uint32_t off, std::string &err) {
+    if (!texel_table_inputs_ok(t.uvm, t.data.data(), t.w, t.h, err)) return false;
     float *tab = hs.emitter_cdf.data() + off, *marg = tab + HAR_TEXEL_TABLE_HEADER, *cond = marg + t.h;
     double total = 0.0;
     for (uint32_t y = 0; y < t.h; ++y) {

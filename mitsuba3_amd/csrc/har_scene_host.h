@@ -77,6 +77,8 @@ void quad_gauss_legendre(int n, std::vector<float> &nodes, std::vector<float> &w
 bool build_emitter_distribution(HostScene &hs, const float *weights, uint32_t n, std::string &err);
 /* (re)derive the texel distribution of a bitmap radiated by an area light (emitter type 7) into hs.emitter_cdf[off ..]; false: unusable to_uv / no luminance */
 bool texel_table_fill(HostScene &hs, const HostTexture &t, uint32_t off, std::string &err);
+/* what texel_table_fill needs of a to_uv (2 x 3) and of the texels (w * h * 3), checked BEFORE a setter changes anything */
+bool texel_table_inputs_ok(const float uvm[6], const float *texels, uint32_t w, uint32_t h, std::string &err);
 /* returns false and fills `err` on invalid input */
 bool lower_scene(const HarSceneDesc &desc, HostScene &out, std::string &err);
 /* the pieces of lower_scene an update re-runs: bounding sphere of the scene for the environment / directional emitters (constant.cpp:72-87), world boxes of the

@@ -87,3 +87,20 @@ def test_radiance_bitmap_updates_in_place(mi, O):
     osc, sensor = O.scene_from_product(scene)
     ref, ost = osc.render_path(sensor, seed=5, spp=16, max_depth=scene.integrator().max_depth, rr_depth=scene.integrator().rr_depth)
     assert rel_l2(a, ref) < 1e-4 and scene.integrator().stats()["vertices"] == ost.vertices
+
+
+def test_c_abi_setters_refuse_before_they_change_anything(mi, O):
+    """har_scene_set_texture / _set_texture_device / _set_texture_to_uv on a bitmap that an area light radiates: texels without luminance, negative texels and a to_uv
+    that does not keep the unit square are refused by the library itself, and the scene still renders what it rendered before"""
+    import torch
+    from mitsuba3_amd import _capi
+    from mitsuba3_amd.core import lib, _fp, _f32, _ptr
+    scene = mi.load_dict(lit_box(mi, _bitmap(5), 24)); before = mi.render(scene, spp=8, seed=1).cpu().numpy()
+    idx = scene.emitters[0]["radiance_texture"]
+    zero = np.zeros_like(scene.textures[idx]); neg = -np.ones_like(zero)
+    assert lib().har_scene_set_texture(scene._h, idx, _fp(zero)) != 0 and b"luminance" in lib().har_last_error()
+    assert lib().har_scene_set_texture(scene._h, idx, _fp(neg)) != 0 and b"non-negative" in lib().har_last_error()
+    z = torch.zeros(zero.shape, device="cuda")
+    assert lib().har_scene_set_texture_device(scene._h, idx, _ptr(z), None) != 0
+    assert lib().har_scene_set_texture_to_uv(scene._h, idx, _fp(_f32([2, 0, 0, 0, 1, 0]))) != 0 and b"unit square" in lib().har_last_error()
+    assert np.array_equal(mi.render(scene, spp=8, seed=1).cpu().numpy(), before) or rel_l2(mi.render(scene, spp=8, seed=1).cpu().numpy(), before) < 1e-6
