@@ -515,13 +515,20 @@ int run_chunk(HarSceneImpl *S, HarIntegratorImpl *I, const DSensor &C, int mode,
     HIP_TRY(hipMemsetAsync(cnt_items(I, 0), 0, used, s));
     HIP_TRY(hipMemsetAsync(cur_trace(I, 0), 0, used, s));
     HIP_TRY(hipMemsetAsync(cur_resolve(I, 0), 0, used, s));
+    /* FIRST VERTEX: the state of a path at bounce 0 is a function of its lane index -- the ray generation kernel stores only the rays (32 of 72 B per lane) and the first
+     * shading launch rebuilds the state instead of reading it (k_raygen<.., LITE>, k_shade<.., FIRST>; ShadeParams::sensor).  Plain forward renders and the recording pass of prb, of one pass, whose
+     * bounce-0 wavefront nobody else reads (no alpha / validity flags, no material queues, no tape).  HAR_FIRST_VERTEX=0 switches it off (A/B) */
+    static const bool first_env = !(getenv("HAR_FIRST_VERTEX") && atoi(getenv("HAR_FIRST_VERTEX")) == 0);
+    static const int mq_env0 = getenv("HAR_MATERIAL_QUEUES") ? atoi(getenv("HAR_MATERIAL_QUEUES")) : -1;
+    const bool first_regen = first_env && ((mode == MODE_PATH && cache_mode == 0) || (mode == MODE_PRB_PRIMAL && rec_w && I->adj && !I->forward_mode)) && !rays && !ps.rng && !valid_lane && !(I->alpha_film && I->alpha_lane) &&
+                             !(mq_env0 < 0 ? I->material_queues : mq_env0 != 0);
     if (tape_r) launch_tape_begin(s, C, seed, spp, log_spp, lane_base, n, I->shard_cap, I->result, I->adj, I->tape_la[0], I->tape_lb[0]);
     else if (rays) launch_raygen_rays(s, seed, lane_base, n, rays->n_total, rays->first, rays->o, rays->d, rays->maxt, rays->state, rays->active, I->shard_cap, I->st[0], I->result, cnt_alive(I, 0));
     /* forward mode: k_raygen<ADJOINT> takes `adj == nullptr` as "zero dL" -- a workspace that served render_backward before still holds that call's adjoint
      * image in I->adj (possibly of a smaller film), which must not be gathered here */
     /* the adjoint image goes to the adjoint raygen (dL per lane; not in forward mode: dL accumulates there) and to the primal raygen of the record tape (dL for its emission terms) */
     else launch_raygen(mode, s, C, seed, spp, log_spp, lane_base, n, I->shard_cap, tape_w ? I->tape_st[0] : I->st[0], I->result, cnt_alive(I, 0),
-                       (I->forward_mode || (mode == MODE_PRB_PRIMAL && !rec_w)) ? nullptr : I->adj, I->dL, ps);
+                       (I->forward_mode || (mode == MODE_PRB_PRIMAL && !rec_w)) ? nullptr : I->adj, I->dL, ps, first_regen);
     prof_mark(I, s, CLS_RAYGEN);
     const bool fwd = mode == MODE_PRB_ADJOINT && I->forward_mode;
     ShadeParams P{ seed, I->max_depth, I->rr_depth, (((mode == MODE_PRB_ADJOINT || rec_w) && I->grad_emitters) ? HAR_SHADE_EMITTER_GRADS : 0u) | (I->hide_emitters ? HAR_SHADE_HIDE_EMITTERS : 0u) |
@@ -529,6 +536,8 @@ int run_chunk(HarSceneImpl *S, HarIntegratorImpl *I, const DSensor &C, int mode,
     /* generic shading kernels: material-sort window in tiles of 256 paths (k_shade; HAR_SORT_WINDOW=1 is the round-3 kernel, A/B) */
     static const uint32_t sort_window_env = getenv("HAR_SORT_WINDOW") ? (uint32_t) std::max(1, atoi(getenv("HAR_SORT_WINDOW"))) : 8u;
     P.sort_window = sort_window_env;
+    ShadeParams P0 = P;           /* bounce 0 with first_regen */
+    if (first_regen) { P0.flags |= HAR_SHADE_FIRST_VERTEX; P0.spp = spp; P0.log_spp = log_spp; P0.sensor = C; }
     /* grid: a multiple of 8 so that block b serves shard b % 8; enough blocks to cover the chunk once */
     const uint32_t grid = std::max<uint32_t>(HAR_SHARDS, std::min<uint32_t>(((n + 255) / 256 + HAR_SHARDS - 1) / HAR_SHARDS * HAR_SHARDS, 4096u));
     /* persistent traversal kernels: enough blocks to fill the chip (<= 8 blocks/CU), never more than the work */
@@ -641,7 +650,7 @@ int run_chunk(HarSceneImpl *S, HarIntegratorImpl *I, const DSensor &C, int mode,
                     launch_shade(mode, s, grid, S->ds, P, lane_base, I->shard_cap, cnt_alive(I, b), st_in, h0, h1, st_out, cnt_alive(I, b + 1),
                                  items_b, cnt_items(I, b), I->result, rc, ps.rng, I->dL, grad_refl, nullptr, nullptr, nullptr, nullptr, &mq, c, tape ? &tp : nullptr);
         } else
-        launch_shade(mode, s, grid, S->ds, P, lane_base, I->shard_cap, cnt_alive(I, b), st_in, h0, h1, st_out, cnt_alive(I, b + 1),
+        launch_shade(mode, s, grid, S->ds, (b == 0 && first_regen) ? P0 : P, lane_base, I->shard_cap, cnt_alive(I, b), st_in, h0, h1, st_out, cnt_alive(I, b + 1),
                      items_b, cnt_items(I, b), I->result, rc, ps.rng, I->dL, grad_refl, shape ? &I->geo : nullptr, inline_commit && cached ? I->d_grad_tex : nullptr,
                      queued ? &I->tq : nullptr, (inline_commit && (rc.mode == 2 || rc.mode == 4)) ? I->grad_bsdf_params : nullptr, nullptr, 0, (tape || rec_w) ? &tp : nullptr);
         prof_mark(I, s, CLS_SHADE);

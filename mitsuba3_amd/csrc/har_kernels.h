@@ -129,7 +129,8 @@ struct ShapeTargets { const int32_t *offset; float *grad; uint32_t n_verts; cons
 #define HAR_LDS_GRAD_VERTS 1024       /* entries of the per-block direct-mapped LDS cache of vertex gradients (k_shape_adjoint; power of two) */
 
 void launch_raygen(int mode, hipStream_t s, const DSensor &C, uint32_t seed, uint32_t spp, uint32_t log_spp, uint32_t lane_base, uint32_t n,
-                   uint32_t shard_cap, const WaveState &out, float4 *result, uint32_t *count, const float *adj, float4 *dL, const PassState &ps = PassState{ nullptr, nullptr, 0 });
+                   uint32_t shard_cap, const WaveState &out, float4 *result, uint32_t *count, const float *adj, float4 *dL, const PassState &ps = PassState{ nullptr, nullptr, 0 },
+                   bool lite = false);      /* lite: only the rays are stored (k_raygen<.., LITE>; the first shading launch then carries HAR_SHADE_FIRST_VERTEX) */
 /* har_integrator_sample: the wavefront of n caller-supplied rays (SoA arrays of n_total rays, this chunk starts at `first`), see k_raygen_rays */
 void launch_raygen_rays(hipStream_t s, uint32_t seed, uint32_t lane_base, uint32_t n, uint32_t n_total, uint32_t first, const float *o, const float *d, const float *maxt,
                         const uint64_t *state, const uint8_t *active, uint32_t shard_cap, const WaveState &out, float4 *result, uint32_t *count);

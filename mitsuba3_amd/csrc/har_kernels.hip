@@ -250,7 +250,7 @@ __device__ __forceinline__ uint32_t shard_slot(uint32_t i, uint32_t shard_cap) {
     return (tile % HAR_SHARDS) * shard_cap + (tile / HAR_SHARDS) * kBlock + (i % kBlock);
 }
 
-template <int MODE>
+template <int MODE, bool LITE = false>      /* LITE: only the ray (a0, a1) is stored -- the first shading kernel rebuilds the rest of the state (ShadeParams::sensor) */
 __global__ __launch_bounds__(kBlock) void k_raygen(DSensor C, uint32_t seed, uint32_t spp, uint32_t log_spp, uint32_t lane_base,
                                                    uint32_t n, uint32_t shard_cap, WaveState out, float4 *result, uint32_t *count,
                                                    const float *adj, float4 *dL, PassState ps) {
@@ -270,7 +270,8 @@ __global__ __launch_bounds__(kBlock) void k_raygen(DSensor C, uint32_t seed, uin
         st = raygen_lane(C, seed, spp, log_spp, lane_base + i, ls, ps.pass ? ps.rng + i : nullptr, j);
         ps.jitter[i] = make_float2(j[0], j[1]);
     } else st = raygen_lane(C, seed, spp, log_spp, lane_base + i, ls);
-    store_state(out, shard_slot(i, shard_cap), st);
+    if (LITE) { const uint32_t slot = shard_slot(i, shard_cap); out.a0[slot] = make_float4(st.o.x, st.o.y, st.o.z, st.maxt); out.a1[slot] = make_float4(st.d.x, st.d.y, st.d.z, st.prev_bsdf_pdf); }
+    else store_state(out, shard_slot(i, shard_cap), st);
     if (MODE != MODE_PRB_ADJOINT) result[i] = make_float4(0.f, 0.f, 0.f, 0.f);
     if (MODE == MODE_PRB_ADJOINT || (MODE == MODE_PRB_PRIMAL && adj)) {      /* PRB_PRIMAL + adj: the primal pass of the record tape needs dL per lane for its emission terms */
         /* adjoint of ImageBlock::put + develop (common.py:696-746): gather grad_in / W over the footprint */
@@ -994,7 +995,7 @@ __global__ __launch_bounds__(kBlock) void k_classify(DScene S, uint32_t shard_ca
 #define HAR_TAB_MESHES 64
 #define HAR_TAB_BSDFS 32
 #define HAR_TAB_INSTS 128
-template <int MODE, uint32_t TYPES, bool SHAPE = false, bool INLINE = false, bool EXTRA = false, bool QUEUED = false, bool RECORD = false, bool TAB = false>
+template <int MODE, uint32_t TYPES, bool SHAPE = false, bool INLINE = false, bool EXTRA = false, bool QUEUED = false, bool RECORD = false, bool TAB = false, bool FIRST = false>
 __global__ __launch_bounds__(kBlock, HAR_SHADE_MIN_WAVES) void k_shade(DScene S_in, ShadeParams P, uint32_t lane_base, uint32_t shard_cap, const uint32_t *count_in, WaveState in,
                                                   const float4 *h0, const uint2 *h1, WaveState out, uint32_t *count_out,
                                                   ItemArrays items, uint32_t *item_count, float4 *result, ReplayCache rc, uint64_t *pass_rng,
@@ -1091,7 +1092,11 @@ __global__ __launch_bounds__(kBlock, HAR_SHADE_MIN_WAVES) void k_shade(DScene S_
         const bool tape_read = MODE == MODE_PRB_ADJOINT && INLINE && rc.mode == 4;
         bool eg_lds = false; uint32_t eg_slot = 0; Vec3 eg(0.f);          /* d L / d radiance of the emitter met by this lane (emission hit) */
         if (in_range) {
-            PathState st = load_state(in, i);
+            PathState st;
+            if (FIRST) {         /* slot `local` of shard s holds lane ((local / 256) * HAR_SHARDS + s) * 256 + local % 256 of the chunk (shard_slot) */
+                LaneSample ls;
+                st = raygen_lane(P.sensor, P.seed, P.spp, P.log_spp, lane_base + ((local / kBlock) * HAR_SHARDS + Q.shard) * kBlock + (local % kBlock), ls);
+            } else st = load_state(in, i);
             d_in = st.d; first_vertex = (st.flags & 0xffffu) == 0u;
             HitExtra hx{ 0u, 0u }; bool has_hx = false;
             if (MODE == MODE_PRB_ADJOINT && rc.mode == 2) { hh = rc.h0[st.lane - lane_base]; hs = rc.h1[st.lane - lane_base]; }      /* replay cache: 24-byte records */
@@ -1977,9 +1982,11 @@ __global__ void k_api_film_put(DSensor C, uint32_t n, const float *px, const flo
 static inline uint32_t blocks_for(uint32_t n) { return (n + kBlock - 1) / kBlock; }
 
 void launch_raygen(int mode, hipStream_t s, const DSensor &C, uint32_t seed, uint32_t spp, uint32_t log_spp, uint32_t lane_base, uint32_t n,
-                   uint32_t shard_cap, const WaveState &out, float4 *result, uint32_t *count, const float *adj, float4 *dL, const PassState &ps) {
+                   uint32_t shard_cap, const WaveState &out, float4 *result, uint32_t *count, const float *adj, float4 *dL, const PassState &ps, bool lite) {
     dim3 g(blocks_for(n)), b(kBlock);
-    if (mode == MODE_PRB_ADJOINT) hipLaunchKernelGGL(k_raygen<MODE_PRB_ADJOINT>, g, b, 0, s, C, seed, spp, log_spp, lane_base, n, shard_cap, out, result, count, adj, dL, ps);
+    if (lite && mode == MODE_PRB_PRIMAL && adj) hipLaunchKernelGGL((k_raygen<MODE_PRB_PRIMAL, true>), g, b, 0, s, C, seed, spp, log_spp, lane_base, n, shard_cap, out, result, count, adj, dL, ps);
+    else if (lite && mode == MODE_PATH) hipLaunchKernelGGL((k_raygen<MODE_PATH, true>), g, b, 0, s, C, seed, spp, log_spp, lane_base, n, shard_cap, out, result, count, adj, dL, ps);
+    else if (mode == MODE_PRB_ADJOINT) hipLaunchKernelGGL(k_raygen<MODE_PRB_ADJOINT>, g, b, 0, s, C, seed, spp, log_spp, lane_base, n, shard_cap, out, result, count, adj, dL, ps);
     else if (mode == MODE_PRB_PRIMAL && adj) hipLaunchKernelGGL(k_raygen<MODE_PRB_PRIMAL>, g, b, 0, s, C, seed, spp, log_spp, lane_base, n, shard_cap, out, result, count, adj, dL, ps);
     else hipLaunchKernelGGL(k_raygen<MODE_PATH>, g, b, 0, s, C, seed, spp, log_spp, lane_base, n, shard_cap, out, result, count, adj, dL, ps);
 }
@@ -2017,6 +2024,7 @@ void launch_shade(int mode, hipStream_t s, uint32_t grid, const DScene &S, const
     /* small scenes: mesh / BSDF / instance tables in LDS (k_shade<.., TAB>); HAR_SHADE_TABLES=0 switches it off (A/B) */
     static const bool tab_env = !(getenv("HAR_SHADE_TABLES") && atoi(getenv("HAR_SHADE_TABLES")) == 0);
     const bool tab = tab_env && S.n_meshes <= HAR_TAB_MESHES && S.n_bsdfs <= HAR_TAB_BSDFS && S.n_insts <= HAR_TAB_INSTS;
+    const bool first = (P.flags & HAR_SHADE_FIRST_VERTEX) != 0u;       /* bounce 0 after k_raygen<.., LITE>: only the plain forward flavours and the record flavour are instantiated for it (run_chunk decides) */
     const ShapeArrays no_geo{ nullptr, nullptr, nullptr, nullptr, nullptr };
     const TexelQueues no_tq{ nullptr, nullptr, nullptr, nullptr, 0u, 0u };
     const TexelQueues tq = tq_in ? *tq_in : no_tq;
@@ -2024,7 +2032,9 @@ void launch_shade(int mode, hipStream_t s, uint32_t grid, const DScene &S, const
     const TapeArrays tape = tape_in ? *tape_in : TapeArrays{ nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr };
     if (rc.mode == 5) {       /* record tape, primal pass: the adjoint flavour of the shading code, primal bookkeeping, one record per vertex (k_shade<.., RECORD>) */
         const bool env = (S.bsdf_types & HAR_SCENE_ENVMAP) != 0u, diffuse = S.bsdf_types == HAR_BSDF_ONLY_DIFFUSE, cls = (S.bsdf_types & 0x7fffffffu & ~HAR_BSDF_CLASSIC_TYPES) == 0u;
-#define HAR_LAUNCH_SHADE_RECORD(T) do { if (tab) hipLaunchKernelGGL((k_shade<MODE_PRB_ADJOINT, T, false, false, false, false, true, true>), g, b, 0, s, S, P, lane_base, shard_cap, count_in, in, h0, h1, out, count_out, items, item_count, result, rc, pass_rng, dL, grad_slots, no_geo, nullptr, no_tq, nullptr, no_mq, 0u, tape); \
+#define HAR_LAUNCH_SHADE_RECORD(T) do { if (first && tab) hipLaunchKernelGGL((k_shade<MODE_PRB_ADJOINT, T, false, false, false, false, true, true, true>), g, b, 0, s, S, P, lane_base, shard_cap, count_in, in, h0, h1, out, count_out, items, item_count, result, rc, pass_rng, dL, grad_slots, no_geo, nullptr, no_tq, nullptr, no_mq, 0u, tape); \
+        else if (first) hipLaunchKernelGGL((k_shade<MODE_PRB_ADJOINT, T, false, false, false, false, true, false, true>), g, b, 0, s, S, P, lane_base, shard_cap, count_in, in, h0, h1, out, count_out, items, item_count, result, rc, pass_rng, dL, grad_slots, no_geo, nullptr, no_tq, nullptr, no_mq, 0u, tape); \
+        else if (tab) hipLaunchKernelGGL((k_shade<MODE_PRB_ADJOINT, T, false, false, false, false, true, true>), g, b, 0, s, S, P, lane_base, shard_cap, count_in, in, h0, h1, out, count_out, items, item_count, result, rc, pass_rng, dL, grad_slots, no_geo, nullptr, no_tq, nullptr, no_mq, 0u, tape); \
         else hipLaunchKernelGGL((k_shade<MODE_PRB_ADJOINT, T, false, false, false, false, true>), g, b, 0, s, S, P, lane_base, shard_cap, count_in, in, h0, h1, out, count_out, items, item_count, result, rc, pass_rng, dL, grad_slots, no_geo, nullptr, no_tq, nullptr, no_mq, 0u, tape); } while (0)
         if (env && (S.bsdf_types & HAR_SCENE_TEXLIGHT)) HAR_LAUNCH_SHADE_RECORD(HAR_BSDF_ALL_TYPES | HAR_SCENE_ENVMAP | HAR_SCENE_TEXLIGHT);
         else if (env) HAR_LAUNCH_SHADE_RECORD(HAR_BSDF_ALL_TYPES | HAR_SCENE_ENVMAP); else if (diffuse) HAR_LAUNCH_SHADE_RECORD(HAR_BSDF_ONLY_DIFFUSE);
@@ -2080,7 +2090,9 @@ void launch_shade(int mode, hipStream_t s, uint32_t grid, const DScene &S, const
     }
     /* diffuse-only scenes (no twosided wrappers) run kernels in which the other BSDF models are compiled out */
     const bool only_diffuse = S.bsdf_types == HAR_BSDF_ONLY_DIFFUSE;
-#define HAR_LAUNCH_SHADE(M, T) do { if (tab && M != MODE_PRB_ADJOINT) hipLaunchKernelGGL((k_shade<M, T, false, false, false, false, false, true>), g, b, 0, s, S, P, lane_base, shard_cap, count_in, in, h0, h1, out, count_out, items, item_count, result, rc, pass_rng, dL, grad_slots, no_geo, nullptr, no_tq, nullptr, no_mq, 0u, tape); \
+#define HAR_LAUNCH_SHADE(M, T) do { if (first && M == MODE_PATH) { if (tab) hipLaunchKernelGGL((k_shade<MODE_PATH, T, false, false, false, false, false, true, true>), g, b, 0, s, S, P, lane_base, shard_cap, count_in, in, h0, h1, out, count_out, items, item_count, result, rc, pass_rng, dL, grad_slots, no_geo, nullptr, no_tq, nullptr, no_mq, 0u, tape); \
+            else hipLaunchKernelGGL((k_shade<MODE_PATH, T, false, false, false, false, false, false, true>), g, b, 0, s, S, P, lane_base, shard_cap, count_in, in, h0, h1, out, count_out, items, item_count, result, rc, pass_rng, dL, grad_slots, no_geo, nullptr, no_tq, nullptr, no_mq, 0u, tape); } \
+        else if (tab && M != MODE_PRB_ADJOINT) hipLaunchKernelGGL((k_shade<M, T, false, false, false, false, false, true>), g, b, 0, s, S, P, lane_base, shard_cap, count_in, in, h0, h1, out, count_out, items, item_count, result, rc, pass_rng, dL, grad_slots, no_geo, nullptr, no_tq, nullptr, no_mq, 0u, tape); \
         else hipLaunchKernelGGL((k_shade<M, T>), g, b, 0, s, S, P, lane_base, shard_cap, count_in, in, h0, h1, out, count_out, items, item_count, result, rc, pass_rng, dL, grad_slots, no_geo, nullptr, no_tq, nullptr, no_mq, 0u, tape); } while (0)
     const bool envmap = (S.bsdf_types & HAR_SCENE_ENVMAP) != 0u;      /* generic BSDF code + environment-map sampling / lookup */
     const bool classic = (S.bsdf_types & 0x7fffffffu & ~HAR_BSDF_CLASSIC_TYPES) == 0u;

@@ -34,7 +34,12 @@ struct ShadeParams {
     uint32_t seed, max_depth, rr_depth;
     uint32_t flags = 0;        /* bit 0 (adjoint): also accumulate the gradient w.r.t. the radiance of `area` / `constant` emitters; bit 1: hide_emitters */
     uint32_t sort_window = 1;  /* generic shading kernels: tiles of 256 paths per material-sort window (k_shade) */
+    /* HAR_SHADE_FIRST_VERTEX (bounce 0 of a wavefront that starts at the sensor): the path state of a slot is a function of its lane index alone -- the shading kernel
+     * rebuilds it (raygen_lane) instead of reading 72 bytes that the ray generation kernel would have to write first */
+    uint32_t spp = 0, log_spp = 0;
+    DSensor sensor{};
 };
+#define HAR_SHADE_FIRST_VERTEX 32u
 #define HAR_SHADE_EMITTER_GRADS 1u
 #define HAR_SHADE_FORWARD_MODE 4u    /* adjoint kernels in FORWARD mode (RBIntegrator.render_forward): parameter tangents in, differential radiance out */
 #define HAR_SHADE_EXTRA_GRADS 16u    /* adjoint: also differentiate w.r.t. alpha / eta / k / colour slot 1 of the rough BSDF models (ShadeResult::x_dir / x_rel) */
