@@ -232,8 +232,11 @@ __device__ __forceinline__ void store_state(const WaveState &W, uint32_t i, cons
     W.a3[i] = make_float4(s.prev_p.x, s.prev_p.y, s.prev_p.z, __uint_as_float(s.lane));
     W.a4[i] = make_uint2((uint32_t) s.rng, (uint32_t) (s.rng >> 32));
 }
+/* ETA_ONE: kernels of scenes whose BSDFs are all `diffuse` (eta of every sample = 1, so the path's eta stays 1) do not read the ray's origin quarter of the state --
+ * the shading code needs neither the origin nor maxt, only the accumulated eta that shares their 16 bytes */
+template <bool ETA_ONE = false>
 __device__ __forceinline__ PathState load_state(const WaveState &W, uint32_t i) {
-    float4 a0 = W.a0[i], a1 = W.a1[i], a2 = W.a2[i], a3 = W.a3[i]; uint2 a4 = W.a4[i];
+    float4 a0 = ETA_ONE ? make_float4(0.f, 0.f, 0.f, -1.f) : W.a0[i], a1 = W.a1[i], a2 = W.a2[i], a3 = W.a3[i]; uint2 a4 = W.a4[i];
     PathState s;
     s.o = Vec3(a0.x, a0.y, a0.z); s.maxt = a0.w < 0.f ? HAR_LARGEST : a0.w; s.eta = a0.w < 0.f ? -a0.w : 1.f;
     s.d = Vec3(a1.x, a1.y, a1.z); s.prev_bsdf_pdf = a1.w;
@@ -1096,7 +1099,7 @@ __global__ __launch_bounds__(kBlock, HAR_SHADE_MIN_WAVES) void k_shade(DScene S_
             if (FIRST) {         /* slot `local` of shard s holds lane ((local / 256) * HAR_SHARDS + s) * 256 + local % 256 of the chunk (shard_slot) */
                 LaneSample ls;
                 st = raygen_lane(P.sensor, P.seed, P.spp, P.log_spp, lane_base + ((local / kBlock) * HAR_SHARDS + Q.shard) * kBlock + (local % kBlock), ls);
-            } else st = load_state(in, i);
+            } else st = load_state<TYPES == HAR_BSDF_ONLY_DIFFUSE>(in, i);
             d_in = st.d; first_vertex = (st.flags & 0xffffu) == 0u;
             HitExtra hx{ 0u, 0u }; bool has_hx = false;
             if (MODE == MODE_PRB_ADJOINT && rc.mode == 2) { hh = rc.h0[st.lane - lane_base]; hs = rc.h1[st.lane - lane_base]; }      /* replay cache: 24-byte records */
