@@ -517,10 +517,10 @@ int run_chunk(HarSceneImpl *S, HarIntegratorImpl *I, const DSensor &C, int mode,
     HIP_TRY(hipMemsetAsync(cur_resolve(I, 0), 0, used, s));
     /* FIRST VERTEX: the state of a path at bounce 0 is a function of its lane index -- the ray generation kernel stores only the rays (32 of 72 B per lane) and the first
      * shading launch rebuilds the state instead of reading it (k_raygen<.., LITE>, k_shade<.., FIRST>; ShadeParams::sensor).  Plain forward renders and the recording pass of prb, of one pass, whose
-     * bounce-0 wavefront nobody else reads (no alpha / validity flags, no material queues, no tape).  HAR_FIRST_VERTEX=0 switches it off (A/B) */
+     * bounce-0 wavefront nobody else reads (no alpha / validity flags, no material queues, no tape); the passes of a multi-pass forward render resume their samplers from the pass state in both kernels.  HAR_FIRST_VERTEX=0 switches it off (A/B) */
     static const bool first_env = !(getenv("HAR_FIRST_VERTEX") && atoi(getenv("HAR_FIRST_VERTEX")) == 0);
     static const int mq_env0 = getenv("HAR_MATERIAL_QUEUES") ? atoi(getenv("HAR_MATERIAL_QUEUES")) : -1;
-    const bool first_regen = first_env && ((mode == MODE_PATH && cache_mode == 0) || (mode == MODE_PRB_PRIMAL && rec_w && I->adj && !I->forward_mode)) && !rays && !ps.rng && !valid_lane && !(I->alpha_film && I->alpha_lane) &&
+    const bool first_regen = first_env && ((mode == MODE_PATH && cache_mode == 0) || (mode == MODE_PRB_PRIMAL && rec_w && I->adj && !I->forward_mode && !ps.rng)) && !rays && !valid_lane && !(I->alpha_film && I->alpha_lane) &&
                              !(mq_env0 < 0 ? I->material_queues : mq_env0 != 0);
     if (tape_r) launch_tape_begin(s, C, seed, spp, log_spp, lane_base, n, I->shard_cap, I->result, I->adj, I->tape_la[0], I->tape_lb[0]);
     else if (rays) launch_raygen_rays(s, seed, lane_base, n, rays->n_total, rays->first, rays->o, rays->d, rays->maxt, rays->state, rays->active, I->shard_cap, I->st[0], I->result, cnt_alive(I, 0));
@@ -537,7 +537,7 @@ int run_chunk(HarSceneImpl *S, HarIntegratorImpl *I, const DSensor &C, int mode,
     static const uint32_t sort_window_env = getenv("HAR_SORT_WINDOW") ? (uint32_t) std::max(1, atoi(getenv("HAR_SORT_WINDOW"))) : 8u;
     P.sort_window = sort_window_env;
     ShadeParams P0 = P;           /* bounce 0 with first_regen */
-    if (first_regen) { P0.flags |= HAR_SHADE_FIRST_VERTEX; P0.spp = spp; P0.log_spp = log_spp; P0.sensor = C; }
+    if (first_regen) { P0.flags |= HAR_SHADE_FIRST_VERTEX; P0.spp = spp; P0.log_spp = log_spp; P0.sensor = C; P0.resume = (ps.rng && ps.pass) ? 1u : 0u; }
     /* grid: a multiple of 8 so that block b serves shard b % 8; enough blocks to cover the chunk once */
     const uint32_t grid = std::max<uint32_t>(HAR_SHARDS, std::min<uint32_t>(((n + 255) / 256 + HAR_SHARDS - 1) / HAR_SHARDS * HAR_SHARDS, 4096u));
     /* persistent traversal kernels: enough blocks to fill the chip (<= 8 blocks/CU), never more than the work */

@@ -1098,7 +1098,8 @@ __global__ __launch_bounds__(kBlock, HAR_SHADE_MIN_WAVES) void k_shade(DScene S_
             PathState st;
             if (FIRST) {         /* slot `local` of shard s holds lane ((local / 256) * HAR_SHARDS + s) * 256 + local % 256 of the chunk (shard_slot) */
                 LaneSample ls;
-                st = raygen_lane(P.sensor, P.seed, P.spp, P.log_spp, lane_base + ((local / kBlock) * HAR_SHARDS + Q.shard) * kBlock + (local % kBlock), ls);
+                const uint32_t li = ((local / kBlock) * HAR_SHARDS + Q.shard) * kBlock + (local % kBlock);
+                st = raygen_lane(P.sensor, P.seed, P.spp, P.log_spp, lane_base + li, ls, (P.resume && pass_rng) ? pass_rng + li : nullptr);
             } else st = load_state<TYPES == HAR_BSDF_ONLY_DIFFUSE>(in, i);
             d_in = st.d; first_vertex = (st.flags & 0xffffu) == 0u;
             HitExtra hx{ 0u, 0u }; bool has_hx = false;

@@ -36,7 +36,7 @@ struct ShadeParams {
     uint32_t sort_window = 1;  /* generic shading kernels: tiles of 256 paths per material-sort window (k_shade) */
     /* HAR_SHADE_FIRST_VERTEX (bounce 0 of a wavefront that starts at the sensor): the path state of a slot is a function of its lane index alone -- the shading kernel
      * rebuilds it (raygen_lane) instead of reading 72 bytes that the ray generation kernel would have to write first */
-    uint32_t spp = 0, log_spp = 0;
+    uint32_t spp = 0, log_spp = 0, resume = 0;      /* resume: pass > 0 of a multi-pass render -- the lane's sampler continues from its stored state (k_shade's pass_rng) */
     DSensor sensor{};
 };
 #define HAR_SHADE_FIRST_VERTEX 32u
