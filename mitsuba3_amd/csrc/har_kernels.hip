@@ -427,6 +427,9 @@ __global__ void k_sample_out(uint32_t n, uint32_t n_total, uint32_t first, const
 #ifndef HAR_REFILL_SELECT
 #define HAR_REFILL_SELECT 1     /* branch-free refill of the persistent traversal loop (trace_persistent); 0: the divergent `take` of rounds 1-4 */
 #endif
+#ifndef HAR_RESOLVE_RETIRE
+#define HAR_RESOLVE_RETIRE 1
+#endif
 #ifndef HAR_TRAV_ORDER
 #define HAR_TRAV_ORDER 0    /* measured: 0 (node, leaf, pop) 687, 2: 660, 1: 643 Mpaths/s on the 1M-tri scene */
 #endif
@@ -1455,18 +1458,26 @@ __global__ __launch_bounds__(kBlock, (MODE == MODE_PRB_ADJOINT ? 1 : HAR_TRACE_M
     };
     if (MODE == MODE_PATH || MODE == MODE_PRB_PRIMAL) {
         /* forward: an unoccluded item adds its contribution to its lane's radiance (one item per lane and bounce: no race) */
-        trace_persistent<true, false, WaveStack, FLAT>(S.accel, cursor + shard * HAR_COUNTER_STRIDE, n, stack, status, take,
-            [&](uint32_t idx, const Trav &T) {
-                const uint32_t i = base + idx;
-                if (rc.mode == 1) rc.vis[__float_as_uint(items.s1[i].w)] = T.found ? 0 : 1;      /* replay cache: per lane */
-                else if (rc.mode == 3 || rc.mode == 5) rc.vis[__float_as_uint(items.s2[i].w)] = T.found ? 0 : 1; /* replay / record tape: per vertex slot */
-                if (!T.found) {
-                    const uint32_t lane = __float_as_uint(items.s1[i].w);
-                    float4 s2 = items.s2[i], r = result[lane];
-                    result[lane] = make_float4(r.x + s2.x, r.y + s2.y, r.z + s2.z, 0.f);
-                }
-            },
+        auto commit = [&](uint32_t idx, const Trav &T) {
+            const uint32_t i = base + idx;
+            if (rc.mode == 1) rc.vis[__float_as_uint(items.s1[i].w)] = T.found ? 0 : 1;      /* replay cache: per lane */
+            else if (rc.mode == 3 || rc.mode == 5) rc.vis[__float_as_uint(items.s2[i].w)] = T.found ? 0 : 1; /* replay / record tape: per vertex slot */
+            if (!T.found) {
+                const uint32_t lane = __float_as_uint(items.s1[i].w);
+                float4 s2 = items.s2[i], r = result[lane];
+                result[lane] = make_float4(r.x + s2.x, r.y + s2.y, r.z + s2.z, 0.f);
+            }
+        };
+#if HAR_RESOLVE_RETIRE
+        /* results are committed at refill time by all the lanes that finished since the last refill -- one store instruction for several lanes instead of one per lane in
+         * the step it finishes in (as the closest-hit kernel does, HAR_CLOSEST_RETIRE): the record pass of prb stores a visibility byte for EVERY item */
+        trace_persistent<true, true, WaveStack, FLAT>(S.accel, cursor + shard * HAR_COUNTER_STRIDE, n, stack, status, take,
+            [&](uint32_t, const Trav &) { },
+            [&](bool pred, uint32_t idx, const Trav &T) { if (pred) commit(idx, T); });
+#else
+        trace_persistent<true, false, WaveStack, FLAT>(S.accel, cursor + shard * HAR_COUNTER_STRIDE, n, stack, status, take, commit,
             [&](bool, uint32_t, const Trav &) { });
+#endif
     } else {
         /* adjoint: L <- L - Lr_dir; g = dL * (dLr_dir/drho + [bsdf_val != 0] L / rho)  (prb.py:227,288-313);
          * gradients are committed at refill time by ALL lanes so that the wave pre-reduction can run */
