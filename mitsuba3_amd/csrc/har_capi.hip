@@ -238,6 +238,9 @@ void HarIntegratorImpl::free_ws() { if (!owned.empty()) (void) hipDeviceSynchron
 #define HAR_DUAL_MIN_LANES (1u << 20)
 #define HAR_DUAL_MAX_LANES (1u << 24)
 #define HAR_OVERLAP_MAX_LANES (1u << 25)
+#ifndef HAR_LATE_OVERLAP_DEFAULT          /* first bounce whose shadow rays run next to the following bounce's closest-hit rays in jobs above HAR_OVERLAP_MAX_LANES (run_chunk) */
+#define HAR_LATE_OVERLAP_DEFAULT(rr_depth) 0xffffffffu
+#endif
 
 namespace {
 
@@ -557,9 +560,17 @@ int run_chunk(HarSceneImpl *S, HarIntegratorImpl *I, const DSensor &C, int mode,
     if (use_mq && !I->mq_idx && (ws_alloc(I, &I->mq_idx, (size_t) HAR_MAT_CLASSES * I->ws_lanes) || ws_alloc(I, &I->mq_count, (size_t) HAR_MAT_CLASSES * HAR_SHARDS * HAR_COUNTER_STRIDE))) return 1;
     const MaterialQueues mq{ I->mq_idx, I->mq_count, I->ws_lanes, S->mat_miss_class };
     bool overlap = mode != MODE_PRB_ADJOINT && !rays && overlap_applies(S, I, n);
-    if (overlap && !I->aux_stream) {
+    /* LATE OVERLAP (jobs too large for the full overlap above): from bounce `late_from` on, bounce b's shadow rays run on the second stream NEXT TO bounce b + 1's
+     * closest-hit rays, and bounce b + 1's shading waits for them -- so both kernels keep writing the one `result` array (no second item set, no result2, no final add:
+     * what made the full overlap neutral on a 67 M-lane frame).  The launches past the Russian-roulette depth are short latency chains (the chip waits for a launch's
+     * longest rays: 0.4 - 1 ms each for a few per cent of the frame's rays); two of them side by side hide each other's tails.  HAR_LATE_OVERLAP=<first bounce> (-1: off) */
+    static const int late_env = getenv("HAR_LATE_OVERLAP") ? atoi(getenv("HAR_LATE_OVERLAP")) : -2;
+    const bool late_ok = !overlap && mode != MODE_PRB_ADJOINT && !rays && late_env != -1 && overlap_applies(S, I, 0);      /* n = 0: every condition of the full overlap but the job's size */
+    const uint32_t late_from = late_env >= 0 ? (uint32_t) late_env : (uint32_t) HAR_LATE_OVERLAP_DEFAULT(I->rr_depth);
+    bool late_on = late_ok && late_from < nb, late_pending = false;
+    if ((overlap || late_on) && !I->aux_stream) {
         if (hipStreamCreateWithFlags(&I->aux_stream, hipStreamNonBlocking) != hipSuccess || hipEventCreateWithFlags(&I->ev_shaded, hipEventDisableTiming) != hipSuccess ||
-            hipEventCreateWithFlags(&I->ev_resolved, hipEventDisableTiming) != hipSuccess || hipEventCreateWithFlags(&I->ev_resolved2, hipEventDisableTiming) != hipSuccess) { I->aux_stream = nullptr; overlap = false; }
+            hipEventCreateWithFlags(&I->ev_resolved, hipEventDisableTiming) != hipSuccess || hipEventCreateWithFlags(&I->ev_resolved2, hipEventDisableTiming) != hipSuccess) { I->aux_stream = nullptr; overlap = false; late_on = false; }
     }
     if (overlap && !I->result2 && (ws_alloc(I, &I->items2.s0, I->ws_lanes) || ws_alloc(I, &I->items2.s1, I->ws_lanes) || ws_alloc(I, &I->items2.s2, I->ws_lanes) || ws_alloc(I, &I->result2, I->ws_lanes))) {
         I->result2 = nullptr; overlap = false; (void) hipGetLastError();      /* no room for the second item set: one stream (an optimisation, not a requirement) */
@@ -636,6 +647,8 @@ int run_chunk(HarSceneImpl *S, HarIntegratorImpl *I, const DSensor &C, int mode,
         }
         /* bounce b - 2's shadow rays used the item set this bounce's shading is about to fill */
         if (resolve_pending[b & 1]) { HIP_TRY(hipStreamWaitEvent(s, ev_res[b & 1], 0)); resolve_pending[b & 1] = false; }
+        /* late overlap: bounce b - 1's shadow rays ran next to this bounce's closest-hit rays; shading touches `result` and refills the item set they read */
+        if (late_pending) { HIP_TRY(hipStreamWaitEvent(s, I->ev_resolved, 0)); late_pending = false; prof_mark(I, s, CLS_RESOLVE); }
         const ItemArrays &items_b = (overlap && (b & 1)) ? I->items2 : I->items;
         const bool cached = rc.mode == 2 || rc.mode == 4;                             /* adjoint replay of a cached / taped bounce */
         const bool queued = inline_commit && cached && I->tq.nq != 0;                 /* texel gradients of this bounce go through the band queues */
@@ -664,6 +677,12 @@ int run_chunk(HarSceneImpl *S, HarIntegratorImpl *I, const DSensor &C, int mode,
             launch_resolve(mode, I->aux_stream, tgrid, spill, S->ds, cnt_items(I, b), cur_resolve(I, b), I->shard_cap, items_b, I->result2, I->dL, grad_refl, I->d_grad_tex, I->status, rc, nullptr, 0);
             HIP_TRY(hipEventRecord(ev_res[b & 1], I->aux_stream));
             resolve_pending[b & 1] = true;
+        } else if (late_on && b >= late_from && b + 1 < nb) {
+            HIP_TRY(hipEventRecord(I->ev_shaded, s));
+            HIP_TRY(hipStreamWaitEvent(I->aux_stream, I->ev_shaded, 0));
+            launch_resolve(mode, I->aux_stream, tgrid, spill, S->ds, cnt_items(I, b), cur_resolve(I, b), I->shard_cap, I->items, I->result, I->dL, grad_refl, I->d_grad_tex, I->status, rc, nullptr, 0);
+            HIP_TRY(hipEventRecord(I->ev_resolved, I->aux_stream));
+            late_pending = true;
         } else if (!(inline_commit && cached)) {
             /* adjoint items of a cached bounce (the path vertex-position gradients take): texel gradients through the band queues, as in the in-place commit */
             const bool item_queued = mode == MODE_PRB_ADJOINT && rc.mode == 2 && !fwd && I->tq.nq != 0;
@@ -686,6 +705,7 @@ int run_chunk(HarSceneImpl *S, HarIntegratorImpl *I, const DSensor &C, int mode,
         }
     }
     for (int k = 0; k < 2; ++k) if (resolve_pending[k]) HIP_TRY(hipStreamWaitEvent(s, ev_res[k], 0));
+    if (late_pending) { HIP_TRY(hipStreamWaitEvent(s, I->ev_resolved, 0)); late_pending = false; prof_mark(I, s, CLS_RESOLVE); }
     if (overlap) launch_add(s, reinterpret_cast<const float *>(I->result2), reinterpret_cast<float *>(I->result), 4u * n);      /* the shadow rays' share of the radiance */
     if (shape && b > 0) {            /* the last bounce: no path continues */
         launch_shape_adjoint(s, grid, S->ds, cnt_items(I, b - 1), I->shard_cap, I->items, I->geo, I->result, I->dL, 0, I->st[cur], I->h0, I->h1, ReplayCache{ nullptr, nullptr, nullptr, 0 }, targets);
@@ -1098,13 +1118,14 @@ int har_scene_update_vertices(HarScene S, uint32_t mesh, const float *vertices, 
     hipStream_t s = (hipStream_t) stream;
     const DMesh &m = hs.meshes[mesh];
     const size_t n_blas = 1 + hs.blas_groups.size();
-    if (!S->tri_box) {                   /* refit scratch, on first use */
+    if (!S->tri_box) {                   /* refit scratch, on first use; S->tri_box (the "scratch exists" flag) is set last, so a failed allocation leaves no half-made set behind */
         void *p = nullptr;
-        HIP_TRY(dev_alloc(&p, std::max<size_t>(hs.tris.size(), 1) * sizeof(RefitBox))); S->owned.push_back(p); S->tri_box = (RefitBox *) p;
+        HIP_TRY(dev_alloc(&p, std::max<size_t>(hs.tris.size(), 1) * sizeof(RefitBox))); S->owned.push_back(p); RefitBox *tri_box = (RefitBox *) p;
         HIP_TRY(dev_alloc(&p, std::max<size_t>(S->nodes_cap, 1) * sizeof(RefitBox))); S->owned.push_back(p); S->node_box = (RefitBox *) p;
         HIP_TRY(dev_alloc(&p, std::max<size_t>(hs.refit_order.size(), 1) * sizeof(uint32_t))); S->owned.push_back(p); S->d_refit_order = (uint32_t *) p;
         if (!hs.refit_order.empty()) HIP_TRY(hipMemcpyAsync(S->d_refit_order, hs.refit_order.data(), hs.refit_order.size() * sizeof(uint32_t), hipMemcpyHostToDevice, s));
         HIP_TRY(dev_alloc(&p, n_blas * sizeof(float))); S->owned.push_back(p); S->d_area = (float *) p;
+        S->tri_box = tri_box;
     }
     const size_t bi = B == &hs.blas_top ? 0 : 1 + (size_t) (B - hs.blas_groups.data());
     /* one refit pass of the BLAS on the device arrays as they are; cost = sum of the node areas over the root's area (the node term of the SAH) */

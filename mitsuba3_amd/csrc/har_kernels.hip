@@ -96,6 +96,26 @@ __device__ __forceinline__ void block_reserve2(uint32_t *cnt_a, bool pa, uint32_
     __syncthreads();
 }
 
+/* the same reservation per WAVE: one returning atomic per predicate and wave, no barrier.  HAR_WAVE_RESERVE = 1 (default): the generic (all-BSDF) shading kernels, whose
+ * waves run material code of very different length between two reservations -- with block_reserve2 all four waves of a block wait at three barriers per round for the
+ * slowest one and for the round trip of the block's atomic: generic k_shade 22.5 -> 21.8 ms per frame on materials1m, forward +1 % in five bracketed runs, prb +-0.
+ * = 2: every shading kernel -- the diffuse kernels retire 4 - 5x the vertices per second and saturate the shard counters (8.2 -> 11.2 ms), as round 1 found.  = 0: block
+ * reservation everywhere (rounds 1 - 4).  profiles/r05_pmc_generic_shade_materials1m.txt */
+#ifndef HAR_WAVE_RESERVE
+#define HAR_WAVE_RESERVE 1
+#endif
+__device__ __forceinline__ void wave_reserve2(uint32_t *cnt_a, bool pa, uint32_t *cnt_b, bool pb, uint32_t &slot_a, uint32_t &slot_b) {
+    const uint64_t ma = __ballot(pa), mb = __ballot(pb);
+    uint32_t ba = 0u, bb = 0u;
+    if ((threadIdx.x & 63u) == 0u) {
+        const uint32_t ta = (uint32_t) __popcll(ma), tb = (uint32_t) __popcll(mb);
+        if (ta) ba = atomicAdd(cnt_a, ta);
+        if (tb) bb = atomicAdd(cnt_b, tb);
+    }
+    ba = (uint32_t) __builtin_amdgcn_readfirstlane((int) ba); bb = (uint32_t) __builtin_amdgcn_readfirstlane((int) bb);
+    slot_a = ba + wave_rank(ma); slot_b = bb + wave_rank(mb);
+}
+
 /* wave-wide float sum with DPP (no LDS): result valid in lane 63 */
 __device__ __forceinline__ float wave_sum_to_last(float v) {
     v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0xB1, 0xF, 0xF, true));  /* quad_perm [1,0,3,2] */
@@ -420,6 +440,9 @@ __global__ void k_sample_out(uint32_t n, uint32_t n_total, uint32_t first, const
 #endif
 #ifndef HAR_SORT_WINDOW_MAX
 #define HAR_SORT_WINDOW_MAX 8          /* tiles of 256 paths per material-sort window of the generic shading kernels (LDS: 1 KB per tile) */
+#endif
+#ifndef HAR_SORT_SCHEDULE
+#define HAR_SORT_SCHEDULE 0         /* generic shading kernels: 1 = the chunks of a sorted window are shaded in the order of their position in the wavefront (k_shade) */
 #endif
 #ifndef HAR_DEFER_INST
 #define HAR_DEFER_INST 4      /* persistent traversal: instance entries wait for this many lanes (0 = enter at once; host model tools/trace_stats.py HH_DEFER_INST: -3 %; measured 4 / 6 / 8: k_resolve 26.83 -> 26.27 / 26.31 / 26.43 ms, k_trace_closest +-0) */
@@ -1036,6 +1059,9 @@ __global__ __launch_bounds__(kBlock, HAR_SHADE_MIN_WAVES) void k_shade(DScene S_
     constexpr bool kSorted = !QUEUED && TYPES != HAR_BSDF_ONLY_DIFFUSE && HAR_MATERIAL_SORT;
     __shared__ uint32_t sort_cnt[kSortKeys];
     __shared__ uint16_t sort_perm[kSorted ? kBlock * HAR_SORT_WINDOW_MAX : 1], sort_tmp[kSorted ? kBlock * HAR_SORT_WINDOW_MAX : 1];
+#if HAR_SORT_SCHEDULE
+    __shared__ uint8_t sort_chunk[kSorted ? (kBlock / 64) * HAR_SORT_WINDOW_MAX : 1];       /* the window's 64-path chunks in the order they are shaded */
+#endif
     ShardLoop Q(count_in, shard_cap);
     /* QUEUED: the paths of ONE material class of this shard, through the index list k_classify built (MaterialQueues) */
     const uint32_t *q_idx = QUEUED ? mq.idx + (size_t) mat_class * mq.lanes + Q.base : nullptr;
@@ -1080,11 +1106,30 @@ __global__ __launch_bounds__(kBlock, HAR_SHADE_MIN_WAVES) void k_shade(DScene S_
                 sort_perm[off + (kp & 0xfffu)] = (uint16_t) (r * kBlock + threadIdx.x);
             }
             __syncthreads();
+#if HAR_SORT_SCHEDULE
+            /* CHUNK SCHEDULE.  Shading the sorted window front to back gives the four waves of a round four consecutive 64-path chunks of ONE class: paths that lie
+             * 1 / share apart in the wavefront, so a round's permuted 16-byte loads use one or two entries of every 128-byte line they touch, and the rest of the line
+             * is fetched again rounds later by the other classes' chunks -- after the windows of the XCD's other blocks (27 MB) have pushed it out of the 4 MB L2:
+             * 405 B read per vertex against 167 unsorted, the kernel at 5.8 TB/s (profiles/r05_pmc_generic_shade_materials1m.txt).  Within a class the sort keeps
+             * the wavefront's order, so every chunk covers an interval of the window; taking the chunks in the order of where their intervals START makes the waves
+             * of a round walk the same stretch of the window at the same time, each for its own class: a line is fetched once for all of them. */
+            if (threadIdx.x < 4u * win) {
+                const uint32_t me = threadIdx.x, key = sort_perm[64u * me];
+                uint32_t rank = 0;
+                for (uint32_t j = 0; j < 4u * win; ++j) { const uint32_t kj = sort_perm[64u * j]; rank += (kj < key || (kj == key && j < me)) ? 1u : 0u; }
+                sort_chunk[rank] = (uint8_t) me;
+            }
+            __syncthreads();
+#endif
         }
         /* the sorted window is shaded in rounds of 256 (the tail of the last round holds the out-of-range lanes) */
         const uint32_t rounds = kSorted ? win : 1u;
       for (uint32_t round = 0; round < rounds; ++round) {
+#if HAR_SORT_SCHEDULE
+        const uint32_t pos = kSorted ? 64u * sort_chunk[round * (kBlock / 64u) + (threadIdx.x >> 6)] + (threadIdx.x & 63u) : round * kBlock + threadIdx.x;
+#else
         const uint32_t pos = round * kBlock + threadIdx.x;
+#endif
         uint32_t local = kSorted ? tile0 * kBlock + sort_perm[pos] : tile0 * kBlock + threadIdx.x;
         if (QUEUED) local = local < Q.n ? q_idx[local] : 0xffffffffu;
         const bool in_range = QUEUED ? local != 0xffffffffu : local < Q.n;
@@ -1208,7 +1253,10 @@ __global__ __launch_bounds__(kBlock, HAR_SHADE_MIN_WAVES) void k_shade(DScene S_
         if (RECORD) item_pred = item_pred && R.item_ray;            /* the queue of the primal pass holds shadow rays only */
         const bool alive = in_range && R.alive, item = item_pred;
         uint32_t slot = 0, islot = 0;
-        if (!tape_read) block_reserve2(cnt_alive, alive, cnt_item, item, lds_r, slot, islot);      /* tape replay: the primal pass's slots stand, nothing is stored */
+        if (!tape_read) {                                                                          /* tape replay: the primal pass's slots stand, nothing is stored */
+            if ((HAR_WAVE_RESERVE == 1 && kSorted) || HAR_WAVE_RESERVE == 2) wave_reserve2(cnt_alive, alive, cnt_item, item, slot, islot);
+            else block_reserve2(cnt_alive, alive, cnt_item, item, lds_r, slot, islot);
+        }
         if (alive && !tape_read) store_state(out, Q.base + slot, R.next);
         if (MODE == MODE_PRB_PRIMAL && rc.mode == 3 && in_range) tape.next[i] = alive ? Q.base + slot : 0xffffffffu;
         if (RECORD && in_range) tape.next[i] = (alive ? Q.base + slot : HAR_TAPE_DEAD) | (item ? HAR_TAPE_HAS_RAY : 0u) | (has_rec ? HAR_TAPE_HAS_REC : 0u) | (R.add_emission ? HAR_TAPE_HAS_EM : 0u);
