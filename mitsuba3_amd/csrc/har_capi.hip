@@ -562,8 +562,9 @@ int run_chunk(HarSceneImpl *S, HarIntegratorImpl *I, const DSensor &C, int mode,
     bool overlap = mode != MODE_PRB_ADJOINT && !rays && overlap_applies(S, I, n);
     /* LATE OVERLAP (jobs too large for the full overlap above): from bounce `late_from` on, bounce b's shadow rays run on the second stream NEXT TO bounce b + 1's
      * closest-hit rays, and bounce b + 1's shading waits for them -- so both kernels keep writing the one `result` array (no second item set, no result2, no final add:
-     * what made the full overlap neutral on a 67 M-lane frame).  The launches past the Russian-roulette depth are short latency chains (the chip waits for a launch's
-     * longest rays: 0.4 - 1 ms each for a few per cent of the frame's rays); two of them side by side hide each other's tails.  HAR_LATE_OVERLAP=<first bounce> (-1: off) */
+     * what made the full overlap neutral on a 67 M-lane frame).  The idea was that the launches past the Russian-roulette depth (0.4 - 1 ms each for a few per cent of the
+     * frame's rays) would hide each other's tails; measured +0.7 % at best on the headline frame and -0.7 ... +0.4 % elsewhere (profiles/r05_ab_late_overlap.txt): two
+     * persistent launches share the same issue slots, there was no idle tail to fill.  DEFAULT OFF; HAR_LATE_OVERLAP=<first bounce> switches it on (A/B) */
     static const int late_env = getenv("HAR_LATE_OVERLAP") ? atoi(getenv("HAR_LATE_OVERLAP")) : -2;
     const bool late_ok = !overlap && mode != MODE_PRB_ADJOINT && !rays && late_env != -1 && overlap_applies(S, I, 0);      /* n = 0: every condition of the full overlap but the job's size */
     const uint32_t late_from = late_env >= 0 ? (uint32_t) late_env : (uint32_t) HAR_LATE_OVERLAP_DEFAULT(I->rr_depth);
