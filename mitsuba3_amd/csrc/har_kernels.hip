@@ -1056,7 +1056,12 @@ __global__ __launch_bounds__(kBlock, HAR_SHADE_MIN_WAVES) void k_shade(DScene S_
     if (emitter_grads) { for (uint32_t k = threadIdx.x; k < 3 * HAR_LDS_GRAD_EMITTERS; k += kBlock) eacc[k] = 0.f; __syncthreads(); }
     /* sort buckets: the models without microfacet code, escaped paths, the rough models, two-model pairs (HAR_MAT_GENERIC), lanes beyond the wavefront's end */
     constexpr uint32_t kSortKeys = HAR_MAT_CLASSES + 2;
-    constexpr bool kSorted = !QUEUED && TYPES != HAR_BSDF_ONLY_DIFFUSE && HAR_MATERIAL_SORT;
+#ifndef HAR_SORT_FIRST
+#define HAR_SORT_FIRST 0            /* 1: the first-vertex flavour sorts by material too.  Bounce 0 of a wavefront rebuilt from the lane index: a block's 256 paths are samples of one or a
+                                     * few pixels and meet one or two materials -- the sort's key pass (a second read of the hit records) and permuted loads bought nothing:
+                                     * generic k_shade 21.95 -> 21.35 ms per frame on materials1m, forward +0.8 %, prb +1.2 %, bracketed (profiles/r05_pmc_generic_shade_materials1m.txt) */
+#endif
+    constexpr bool kSorted = !QUEUED && TYPES != HAR_BSDF_ONLY_DIFFUSE && HAR_MATERIAL_SORT && (HAR_SORT_FIRST || !FIRST);
     __shared__ uint32_t sort_cnt[kSortKeys];
     __shared__ uint16_t sort_perm[kSorted ? kBlock * HAR_SORT_WINDOW_MAX : 1], sort_tmp[kSorted ? kBlock * HAR_SORT_WINDOW_MAX : 1];
 #if HAR_SORT_SCHEDULE
