@@ -406,10 +406,11 @@ class Mesh:
 # Shape(props) (src/render/shape.cpp:17-60) + Mesh(props) (src/render/mesh.cpp:160-175): rectangle and cube are Mesh plugins in this tree.
 # `silhouette_sampling_weight` only feeds the projective integrators' boundary sampling: queried, no effect on `path` / `prb`.
 _SHAPE_PROPS = ('to_world', 'flip_normals', 'face_normals', 'silhouette_sampling_weight')
+_SHAPE_CHILDREN = ('bsdf', 'emitter')       # Shape(props) (shape.cpp:22-49) also takes sensors, media and texture attributes: not part of this variant, refused
 
 
 def _rectangle(props):
-    _check_props('rectangle', props, _SHAPE_PROPS, unsupported=(('face_normals', False),))
+    _check_props('rectangle', props, _SHAPE_PROPS, unsupported=(('face_normals', False),), children=_SHAPE_CHILDREN)
     tw = props.get('to_world', ScalarTransform4f())
     m = Mesh("rectangle")
     V = np.empty((4, 8), np.float32); F = np.empty((2, 4), np.uint32); n = np.empty(3, np.float32); ia = C.c_float()
@@ -420,7 +421,7 @@ def _rectangle(props):
 
 
 def _cube(props):
-    _check_props('cube', props, _SHAPE_PROPS, unsupported=(('face_normals', False), ('flip_normals', False)))
+    _check_props('cube', props, _SHAPE_PROPS, unsupported=(('face_normals', False), ('flip_normals', False)), children=_SHAPE_CHILDREN)
     tw = props.get('to_world', ScalarTransform4f())
     m = Mesh("cube")
     V = np.empty((24, 8), np.float32); F = np.empty((12, 4), np.uint32)
@@ -429,19 +430,84 @@ def _cube(props):
     return m
 
 
-def _check_props(plugin, props, known, unsupported=(), free_children=True):
+# ObjectType of every plugin this variant has (include/mitsuba/core/object.h: ObjectType; PluginManager::create_object checks it, plugin.cpp:258-263).
+# `rgb` is the dict form of a colour property, which the reference's loader turns into an `srgb` texture object (src/core/python/parser.cpp) -- a texture here.
+_PLUGIN_KINDS = {
+    'scene': 'scene', 'path': 'integrator', 'prb': 'integrator', 'perspective': 'sensor', 'orthographic': 'sensor', 'hdrfilm': 'film', 'independent': 'sampler',
+    'diffuse': 'bsdf', 'dielectric': 'bsdf', 'conductor': 'bsdf', 'plastic': 'bsdf', 'roughconductor': 'bsdf', 'roughplastic': 'bsdf', 'twosided': 'bsdf',
+    'area': 'emitter', 'constant': 'emitter', 'envmap': 'emitter', 'point': 'emitter', 'spot': 'emitter', 'directional': 'emitter',
+    'rectangle': 'shape', 'cube': 'shape', 'mesh': 'shape', 'ply': 'shape', 'obj': 'shape', 'serialized': 'shape', 'shapegroup': 'shape', 'instance': 'shape',
+    'gaussian': 'rfilter', 'box': 'rfilter', 'tent': 'rfilter', 'mitchell': 'rfilter', 'catmullrom': 'rfilter', 'lanczos': 'rfilter',
+    'rgb': 'texture', 'bitmap': 'texture',
+}
+_ALL_KINDS = tuple(sorted(set(_PLUGIN_KINDS.values())))
+
+
+def _plugin_kind(t):
+    """The ObjectType of plugin `t`; an unknown name is the reference's `Plugin "..." could not be found` (plugin.cpp:189)."""
+    k = _PLUGIN_KINDS.get(t)
+    if k is None and (t, VARIANT) in _REGISTRY:
+        k = 'integrator'                     # mi.register_integrator is the only way a plugin gets into the registry from outside
+    if k is None:
+        raise RuntimeError("Plugin \"%s\" not found for variant \"%s\" (could not be found). Available: %s" % (t, VARIANT, sorted(_PLUGIN_KINDS)))
+    return k
+
+
+def _object_kind(v):
+    """ObjectType of a child value: a dict by its plugin name, an instantiated object by its class; None: not an object (a number, a transform, a `ref`)"""
+    if isinstance(v, dict):
+        if 'type' not in v or v['type'] == 'ref':
+            return None
+        return _plugin_kind(v['type'])
+    for cls, kind in ((Film, 'film'), (Sampler, 'sampler'), (BSDF, 'bsdf'), (Mesh, 'shape')):
+        if isinstance(v, cls):
+            return kind
+    g = globals()
+    for name, kind in (('Sensor', 'sensor'), ('Integrator', 'integrator'), ('ShapeGroup', 'shape'), ('Instance', 'shape'), ('Scene', 'scene'), ('AreaLight', 'emitter'),
+                       ('ConstantEmitter', 'emitter'), ('EnvmapEmitter', 'emitter'), ('PointLight', 'emitter'), ('SpotLight', 'emitter'), ('DirectionalEmitter', 'emitter')):
+        if name in g and isinstance(v, g[name]):
+            return kind
+    return None
+
+
+def _type_mismatch(v, actual, expected):
+    name = v.get('type') if isinstance(v, dict) else {'Film': 'hdrfilm', 'Sampler': 'independent'}.get(type(v).__name__, getattr(v, 'kind', None) or getattr(v, 'type', None) or type(v).__name__)
+    return RuntimeError("Type mismatch: the instantiated plugin \"%s\" is of type \"%s\", which does not match the expected type \"%s\"." % (name, actual, "|".join(expected)))
+
+
+def _check_props(plugin, props, known, unsupported=(), free_children=True, children=(), slots=None, slot_kind=('texture',)):
     """The reference's plugin loader rejects properties a plugin never queried ("Unreferenced property", src/core/plugin.cpp / properties.cpp)
     -- a silently ignored property would be a silently different picture.  `unsupported`: (name, neutral value) pairs the reference knows
-    but hip_ad_rgb does not implement; anything but the neutral value is refused."""
+    but hip_ad_rgb does not implement; anything but the neutral value is refused.
+
+    Child OBJECTS are held to the same rule by their plugin type (round 6): every dict with a `type` names a plugin that must exist
+    (plugin.cpp:189) and be of the ObjectType its position wants (plugin.cpp:258-263 "Type mismatch") --
+      * under a name of `known`: the kinds of `slots[name]`, else `slot_kind` (object-valued properties of BSDFs / emitters are textures);
+      * under a free name (`free_children`: plugins that walk props.objects()): one of `children`; another kind is an object the constructor
+        never casts successfully, i.e. an unreferenced property (properties.h:700-725)."""
     for name, neutral in unsupported:
         if name in props and props[name] != neutral:
             raise RuntimeError("%s: property \"%s\" = %r is not implemented by hip_ad_rgb" % (plugin, name, props[name]))
+    slots = slots or {}
     for k, v in props.items():
-        if k in ('type', 'id') or k in known or any(k == u[0] for u in unsupported) or k.startswith('_arg_'):
+        if k in ('type', 'id'):
             continue
-        # child objects: plugins that walk props.objects() (shapes, sensors, the scene, twosided) take them under any name; the others (BSDFs, emitters,
-        # textures) only mark the names they query (Properties::try_get marks a child queried only when the cast succeeds, properties.h:700-725)
-        if free_children and (isinstance(v, (dict, Film, Sampler, BSDF, Mesh)) or hasattr(v, 'har')):
+        kind = _object_kind(v)                               # raises for a plugin that does not exist, wherever it sits
+        if k in known or any(k == u[0] for u in unsupported):
+            want = slots.get(k, slot_kind)
+            if kind is not None and kind not in want:
+                raise _type_mismatch(v, kind, want)
+            continue
+        if kind is not None or (isinstance(v, dict) and v.get('type') == 'ref'):
+            if not free_children:
+                raise RuntimeError("Unreferenced property \"%s\" in plugin of type \"%s\"!" % (k, plugin))
+            if kind is not None and kind not in children:
+                raise RuntimeError("Unreferenced property \"%s\" in plugin of type \"%s\": an object of type \"%s\" (plugin \"%s\") is not a child this plugin takes (%s)"
+                                   % (k, plugin, kind, v.get('type') if isinstance(v, dict) else type(v).__name__, "|".join(children) or "none"))
+            continue
+        if k.startswith('_arg_'):
+            continue
+        if free_children and hasattr(v, 'har'):
             continue
         raise RuntimeError("Unreferenced property \"%s\" in plugin of type \"%s\"!" % (k, plugin))
 
@@ -451,7 +517,10 @@ class Sampler:
 
     def __init__(self, props=None):
         props = props or {}
-        _check_props(props.get('type', 'independent'), props, ('sample_count', 'seed'))
+        if props.get('type', 'independent') != 'independent':        # the other samplers of the reference (stratified, multijitter, orthogonal, ldsampler) draw DIFFERENT streams
+            _plugin_kind(props['type'])                               # not a plugin at all: plugin.cpp:189
+            raise _type_mismatch(props, _plugin_kind(props['type']), ('sampler',))
+        _check_props('independent', props, ('sample_count', 'seed'), free_children=False)
         self.m_sample_count = int(props.get('sample_count', 4))
         self.m_base_seed = int(props.get('seed', 0))
         self.m_samples_per_wavefront = 1
@@ -535,9 +604,11 @@ class Film:
 
     def __init__(self, props=None):
         props = props or {}
+        if props.get('type', 'hdrfilm') != 'hdrfilm':                 # specfilm is not part of an RGB variant's path
+            raise _type_mismatch(props, _plugin_kind(props['type']), ('film',))
         # hdrfilm.cpp:146-208; file_format / component_format only concern Film::write (har_image_write_*: float32 / half channels)
         _check_props('hdrfilm', props, ('width', 'height', 'crop_offset_x', 'crop_offset_y', 'crop_width', 'crop_height', 'pixel_format', 'file_format', 'component_format',
-                                        'sample_border', 'compensate', 'banner'))
+                                        'sample_border', 'compensate', 'banner'), children=('rfilter',))
         if 'compensate' in props:          # hdrfilm.cpp:218-225: marked as queried, warned about, ignored
             import warnings
             warnings.warn("The \"compensate\" (Kahan-style error-compensated accumulation) parameter has been removed and is now ignored.")
@@ -617,10 +688,12 @@ class Sensor:
         self.kind = props.get('type', 'perspective')
         # sensor.cpp:24-97, perspective.cpp:137-172, orthographic.cpp:93-97
         if self.kind == 'orthographic':
-            _check_props('orthographic', props, ('to_world', 'near_clip', 'far_clip', 'film', 'sampler', 'shutter_open', 'shutter_close'))
+            _check_props('orthographic', props, ('to_world', 'near_clip', 'far_clip', 'film', 'sampler', 'shutter_open', 'shutter_close'), children=('film', 'sampler'),
+                         slots={'film': ('film',), 'sampler': ('sampler',)}, slot_kind=())
         else:
             _check_props('perspective', props, ('to_world', 'fov', 'fov_axis', 'focal_length', 'near_clip', 'far_clip', 'film', 'sampler', 'shutter_open', 'shutter_close', 'focus_distance',
-                                                'principal_point_offset_x', 'principal_point_offset_y'))
+                                                'principal_point_offset_x', 'principal_point_offset_y'), children=('film', 'sampler'),
+                         slots={'film': ('film',), 'sampler': ('sampler',)}, slot_kind=())
         # child objects are recognised by their class, whatever the property is called (XML children are anonymous: `_arg_0`, ...)
         film = next((v for v in props.values() if isinstance(v, Film)), props.get('film'))
         sampler = next((v for v in props.values() if isinstance(v, Sampler)), props.get('sampler'))
@@ -897,7 +970,7 @@ class BSDF:
 
 def _mk_twosided(props, named, key):
     """TwoSidedBRDF (src/bsdfs/twosided.cpp:70-110): one or two nested BSDFs without a transmission component."""
-    _check_props('twosided', props, ('allow_transmission',), unsupported=(('allow_transmission', False),))      # twosided.cpp:76-104: nested BSDFs under any name
+    _check_props('twosided', props, ('allow_transmission',), unsupported=(('allow_transmission', False),), children=('bsdf',))      # twosided.cpp:76-104: nested BSDFs under any name
     nested = []
     for k, v in props.items():
         if k in ('type', 'id', 'allow_transmission'):
@@ -1083,7 +1156,7 @@ class Integrator:
         self.type = props['type']
         # integrator.cpp:26-33,128-147,539-550; block_size only shapes the scalar / LLVM-parallel drivers; the last four are hip_ad_rgb extensions
         _check_props(self.type, props, ('max_depth', 'rr_depth', 'hide_emitters', 'samples_per_pass', 'block_size', 'chunk_lanes', 'replay_cache', 'material_queues', 'packet_tracing', 'emitter_gradients', 'shape_gradients', 'bsdf_parameter_gradients'),
-                     unsupported=(('timeout', -1.0),))
+                     unsupported=(('timeout', -1.0),), free_children=False, slot_kind=())
         default_depth = -1 if self.type == 'path' else 6        # integrator.cpp:539, common.py:31
         self.max_depth = int(props.get('max_depth', default_depth))
         self.rr_depth = int(props.get('rr_depth', 5))
@@ -2224,13 +2297,13 @@ def _shape_common(m, props, named):
             a = AreaLight(v)
             m.emitter = a.radiance; m.emitter_weight = a.sampling_weight; m.emitter_light = a
         elif isinstance(v, dict) and 'type' in v and k not in ('to_world',):
-            if (v['type'], VARIANT) not in _REGISTRY:
-                raise RuntimeError("Plugin \"%s\" not found for variant \"%s\"" % (v['type'], VARIANT))
+            if _plugin_kind(v['type']) == 'emitter':     # Shape::initialize -> Emitter::set_shape: only surface emitters attach to a shape (point.cpp / spot.cpp / ... have no set_shape use)
+                raise RuntimeError("Plugin \"%s\" is not a surface emitter: only `area` can be the child of a shape" % v['type'])
     return m
 
 
 def _mk_scene(props, named, key):
-    _check_props('scene', props, ())                 # Scene(props) (scene.cpp:26-70) walks props.objects(): children under any name, no other property
+    _check_props('scene', props, (), children=_ALL_KINDS)                 # Scene(props) (scene.cpp:26-70) walks props.objects(): children under any name, no other property
     children = {}
     for k, v in props.items():
         if k == 'type':
@@ -2249,7 +2322,7 @@ def _mk_scene(props, named, key):
 
 
 def _mk_shapegroup(props, named, key):
-    _check_props('shapegroup', props, ())            # ShapeGroup(props) (src/shapes/shapegroup.cpp): the child shapes, nothing else
+    _check_props('shapegroup', props, (), children=('shape',))            # ShapeGroup(props) (src/shapes/shapegroup.cpp): the child shapes, nothing else
     shapes = []; keys = []
     for k, v in props.items():
         if isinstance(v, dict) and 'type' in v:
@@ -2265,7 +2338,7 @@ def _mk_shapegroup(props, named, key):
 
 
 def _mk_instance(props, named, key):
-    _check_props('instance', props, ('to_world',))   # Instance(props) (src/shapes/instance.cpp:60-77)
+    _check_props('instance', props, ('to_world',), children=('shape',))   # Instance(props) (src/shapes/instance.cpp:60-77)
     group = None
     for k, v in props.items():
         obj = _resolve(v, named, k) if isinstance(v, dict) else v
@@ -2279,7 +2352,7 @@ def _mk_instance(props, named, key):
 
 
 def _mk_ply(props, named, key):
-    _check_props('ply', props, _SHAPE_PROPS + ('filename', 'flip_tex_coords'))      # ply.cpp:113-118 over Mesh(props)
+    _check_props('ply', props, _SHAPE_PROPS + ('filename', 'flip_tex_coords'), children=_SHAPE_CHILDREN)      # ply.cpp:113-118 over Mesh(props)
     if 'filename' not in props:
         raise RuntimeError("ply: the `filename` parameter is required")
     m = Mesh(key or "ply").from_ply(props['filename'], props.get('face_normals', False), props.get('flip_tex_coords', False),
@@ -2288,7 +2361,7 @@ def _mk_ply(props, named, key):
 
 
 def _mk_obj(props, named, key):
-    _check_props('obj', props, _SHAPE_PROPS + ('filename', 'flip_tex_coords'))      # obj.cpp:98-113
+    _check_props('obj', props, _SHAPE_PROPS + ('filename', 'flip_tex_coords'), children=_SHAPE_CHILDREN)      # obj.cpp:98-113
     if 'filename' not in props:
         raise RuntimeError("obj: the `filename` parameter is required")
     m = Mesh(key or "obj").from_obj(props['filename'], props.get('face_normals', False), props.get('flip_tex_coords', True),
@@ -2297,7 +2370,7 @@ def _mk_obj(props, named, key):
 
 
 def _mk_serialized(props, named, key):
-    _check_props('serialized', props, _SHAPE_PROPS + ('filename', 'shape_index'))   # serialized.cpp:225-244
+    _check_props('serialized', props, _SHAPE_PROPS + ('filename', 'shape_index'), children=_SHAPE_CHILDREN)   # serialized.cpp:225-244
     if 'filename' not in props:
         raise RuntimeError("serialized: the `filename` parameter is required")
     m = Mesh(key or "serialized").from_serialized(props['filename'], props.get('shape_index', 0), props.get('face_normals', None),
@@ -2307,7 +2380,7 @@ def _mk_serialized(props, named, key):
 
 def _mk_mesh(props, named, key):
     # not a reference plugin: the dict form of mi.Mesh(...) + params (faces / positions / normals / texcoords arrays)
-    _check_props('mesh', props, ('faces', 'positions', 'normals', 'texcoords', 'to_world', 'silhouette_sampling_weight'))
+    _check_props('mesh', props, ('faces', 'positions', 'normals', 'texcoords', 'to_world', 'silhouette_sampling_weight'), children=_SHAPE_CHILDREN)
     m = Mesh(key or "mesh").from_fields(props['faces'], props['positions'], props.get('normals'), props.get('texcoords'))
     if 'to_world' in props:
         m.transform(props['to_world'])
@@ -2318,8 +2391,8 @@ for _name, _fn in {
     'scene': _mk_scene,
     'path': lambda p, n, k: Integrator(p),
     'prb': lambda p, n, k: Integrator(p),
-    'perspective': lambda p, n, k: Sensor({kk: (_resolve(v, n, kk) if isinstance(v, dict) and v.get('type') in ('hdrfilm', 'independent') else v) for kk, v in p.items()}),
-    'orthographic': lambda p, n, k: Sensor({kk: (_resolve(v, n, kk) if isinstance(v, dict) and v.get('type') in ('hdrfilm', 'independent') else v) for kk, v in p.items()}),
+    'perspective': lambda p, n, k: Sensor({kk: (_resolve(v, n, kk) if isinstance(v, dict) and 'type' in v else v) for kk, v in p.items()}),      # EVERY child object through the registry
+    'orthographic': lambda p, n, k: Sensor({kk: (_resolve(v, n, kk) if isinstance(v, dict) and 'type' in v else v) for kk, v in p.items()}),
     'hdrfilm': lambda p, n, k: Film(p),
     'independent': lambda p, n, k: Sampler(p),
     'diffuse': lambda p, n, k: BSDF(p, id=k), 'dielectric': lambda p, n, k: BSDF(p, id=k), 'roughconductor': lambda p, n, k: BSDF(p, id=k),
