@@ -61,6 +61,39 @@ def parse(argv=None):
     return ap.parse_args(argv)
 
 
+def shading_geometry_bytes(scene):
+    """unique bytes of the geometry a shading launch gathers from (96-byte shading triangles): L2 / Infinity-Cache resident, counted once per launch"""
+    try:
+        return 96 * int(sum(int(m["F"].shape[0]) for m in scene.meshes))
+    except Exception:
+        return 0
+
+
+def algorithmic_bytes(kernel, stats, accel, launches, overlapped=False, shading_bytes=0):
+    """Algorithmic HBM bytes of one frame's launches of a kernel class -- SURVEY.md section 8(d)'s per-unit figures with this implementation's record sizes
+    (DESIGN.md section 2), scene data cache-resident and counted ONCE PER LAUNCH:
+      trace_closest  56 B per ray (32 B ray in + 24 B hit out) + the accel's unique bytes per launch
+      resolve        33 B per shadow ray + the accel per launch
+      shade          32-B hit record per vertex in; 72-B path state in for every vertex past the first of its path (the first launch rebuilds the state from the
+                     lane index: `k_shade<..., FIRST>`) and 72 B out for every SURVIVOR (= the vertices of the next bounce: vertices - paths over the frame);
+                     one 48-B NEE item per shadow ray; the shading triangles once per launch.
+                     Round 5 charged 72 B out for EVERY vertex and 112 B of gathers per vertex as HBM bytes: 73 GB per frame = 8.3 TB/s, above the peak;
+                     the PMC counters say 41.4 GB (profiles/r05_traffic_instanced1m.json), this model 41.8 GB.
+      raygen, splat  32 B ray + 16 B result written per path; 16 B per path read + the film."""
+    v, p, sr = stats["vertices"], stats["paths"], stats["shadow_rays"]
+    if kernel == "trace_closest":
+        if overlapped:
+            return stats["closest_rays"] * 56 + sr * 33 + 2 * accel["bytes"] * launches
+        return stats["closest_rays"] * 56 + accel["bytes"] * launches
+    if kernel == "resolve":
+        return sr * 33 + accel["bytes"] * launches
+    if kernel == "shade":
+        return v * 32 + max(v - p, 0) * (72 + 72) + sr * 48 + shading_bytes * launches
+    if kernel == "raygen":
+        return p * (32 + 16)
+    return p * 16
+
+
 # --------------------------------------------------------------------------------------------- launcher
 
 def free_port():
@@ -413,16 +446,7 @@ def worker(args):
     # jobs of at most 2^25 lanes per rank (N > 1) run bounce b's shadow rays on a second stream NEXT TO bounce b + 1's closest-hit rays (har_capi.hip overlap_applies):
     # the interval the trace class times then holds both traversal kernels, so its bytes are the bytes of both
     overlapped = stats["shadow_rays"] > 0 and kern_ms["resolve"] < 0.05 * kern_ms["trace_closest"]
-    if dominant == "trace_closest" and overlapped:
-        alg_bytes = stats["closest_rays"] * 56 + stats["shadow_rays"] * 33 + 2 * accel["bytes"] * launches
-    elif dominant == "trace_closest":
-        alg_bytes = stats["closest_rays"] * 56 + accel["bytes"] * launches
-    elif dominant == "resolve":
-        alg_bytes = stats["shadow_rays"] * 33 + accel["bytes"] * launches
-    elif dominant == "shade":
-        alg_bytes = stats["vertices"] * (72 * 2 + 32 + 112)        # 72-B packed path state in and out (store_state), 32-B hit record, 112 B of face / vertex gathers
-    else:
-        alg_bytes = stats["paths"] * (152 + 16)
+    alg_bytes = algorithmic_bytes(dominant, stats, accel, launches, overlapped=overlapped, shading_bytes=shading_geometry_bytes(scene))
     achieved = alg_bytes / 1e9 / (kern_ms[dominant] / 1e3) if kern_ms[dominant] > 0 else 0.0
     # HBM traffic from the committed PMC passes (separate FETCH_SIZE / WRITE_SIZE runs of this command, tools/gpu_profile.sh ... mem):
     # bytes = (FETCH_SIZE x 2 [gfx950 correction, MI355X_MICROARCH.md "HBM"] + WRITE_SIZE) KiB x 1024; per launch for the dominant kernel,
