@@ -239,6 +239,18 @@ int har_scene_set_texture_to_uv(HarScene scene, uint32_t texture, const float to
 #define HAR_UPDATE_REBUILD_ADVISED 3
 int har_scene_update_instances(HarScene scene, uint32_t first, uint32_t count, const float *to_world, const float *to_object, void *stream);
 int har_scene_update_vertices(HarScene scene, uint32_t mesh, const float *vertices, void *stream);
+/* The same update with the positions ALREADY ON THE DEVICE -- what Mesh::parameters_changed does in the reference's JIT variants, where a position update never leaves
+ * the GPU (src/render/mesh.cpp:848-899: pack(regenerate_normals) -> compute_normals :1216-1267; Scene::parameters_changed hands the accel its new vertices,
+ * src/render/scene.cpp:517-540).  `positions` = DEVICE, vertex_count x 3 floats (the layout of '<shape>.vertex_positions', Mesh::traverse).  Enqueued on `stream`:
+ * positions -> packed vertex records, vertex normals regenerated if the mesh carries normals (Mesh::compute_normals as a deterministic per-vertex gather,
+ * har_vertex_update.h), the 96-byte shading triangles rewritten, the BLAS refitted.  For a top-level mesh in a scene without environment / directional emitters the
+ * call copies nothing between host and device and waits for nothing: the refit's cost figure and a "position not finite" flag land in a pinned record that the NEXT
+ * update call reads, so HAR_UPDATE_REBUILD_ADVISED (and the error for a non-finite position) arrive ONE CALL LATE.  An instanced mesh, or a scene whose emitters
+ * follow the scene's bounding sphere, additionally reads the mesh's vertex records back (device -> host) for the host build of the instance level / the bounds and
+ * waits for it.  The host mirror of the mesh is refreshed lazily (har_scene_get_vertices, or any later call that needs it).  Return codes as above. */
+int har_scene_update_vertices_device(HarScene scene, uint32_t mesh, const float *positions, void *stream);
+/* the packed vertex records (HOST out, vertex_count x 8 floats) of `mesh` as the device holds them -- after device-resident updates the only current copy */
+int har_scene_get_vertices(HarScene scene, uint32_t mesh, float *vertices, void *stream);
 /* info[0] = refits since the scene was created, info[1] = cost figure of the last refitted BLAS, info[2] = its ratio to the figure at the first refit, info[3] = nodes */
 int har_scene_refit_info(HarScene scene, double info[4]);
 /* accel statistics: node count, triangle count, bytes */

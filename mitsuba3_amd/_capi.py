@@ -106,6 +106,8 @@ SIGNATURES = {
     "har_scene_set_texture_to_uv": (C.c_int, [vp, C.c_uint32, f32p]),
     "har_scene_update_instances": (C.c_int, [vp, C.c_uint32, C.c_uint32, f32p, f32p, vp]),
     "har_scene_update_vertices": (C.c_int, [vp, C.c_uint32, f32p, vp]),
+    "har_scene_update_vertices_device": (C.c_int, [vp, C.c_uint32, vp, vp]),
+    "har_scene_get_vertices": (C.c_int, [vp, C.c_uint32, f32p, vp]),
     "har_scene_refit_info": (C.c_int, [vp, C.POINTER(C.c_double)]),
     "har_scene_set_texture_device": (C.c_int, [vp, C.c_uint32, vp, vp]),
     "har_scene_set_reflectance_device": (C.c_int, [vp, C.c_uint32, vp, vp]),

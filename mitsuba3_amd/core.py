@@ -1639,6 +1639,29 @@ class Scene:
             else:
                 b.value = np.ascontiguousarray(v.reshape(3))
         self._device_values.clear()
+        self._sync_host_geometry()
+
+    def _sync_host_geometry(self):
+        """the packed vertex records of the meshes whose positions were updated ON THE DEVICE (har_scene_update_vertices_device): positions and regenerated normals
+        back into meshes[i]['V'] -- needed before anything rebuilds the scene from the host mirrors or reads them"""
+        stale = getattr(self, "_stale_meshes", None)
+        if not stale:
+            return
+        if self._h is not None:
+            for i in sorted(stale):
+                V = self.meshes[i]["V"] = np.ascontiguousarray(self.meshes[i]["V"], np.float32)
+                check(lib().har_scene_get_vertices(self._h, int(i), _fp(V), _stream()))
+        stale.clear()
+
+    def _drop_handle(self, keep_geometry=True):
+        """the next render builds a new scene handle from the host mirrors: bring them up to date first (unless the handle is being dropped BECAUSE an update failed)"""
+        if self._h is None:
+            return
+        if keep_geometry:
+            self._sync_host_geometry()
+        else:
+            getattr(self, "_stale_meshes", set()).clear()
+        lib().har_scene_destroy(self._h); self._h = None
 
     # -- C ABI description
     def desc(self):
@@ -1826,8 +1849,7 @@ class Scene:
             b.k_c = _f32(v[:3])
         else:
             b.value2 = _f32(v[:3])
-        if self._h is not None:
-            lib().har_scene_destroy(self._h); self._h = None
+        self._drop_handle()
 
     @_static_table
     def _position_keys(self):
@@ -1855,7 +1877,7 @@ class Scene:
                 continue
             if not self._bsdf_has_smooth_lobe(m["bsdf"]):
                 continue
-            if m["flags"] & 1:
+            if (m["flags"] & 1) and i not in getattr(self, "_stale_meshes", ()):        # (a mesh updated on the device carries the normals that update regenerated)
                 V = np.ascontiguousarray(m["V"]).copy(); F = np.ascontiguousarray(m["F"])
                 check(lib().har_mesh_compute_normals(V.shape[0], _fp(V), F.shape[0], _up(F)))
                 if np.abs(V[:, 3:6] - m["V"][:, 3:6]).max() > 1e-4:
@@ -1894,7 +1916,11 @@ class Scene:
                 end += 1
             tw = np.ascontiguousarray(np.concatenate([recs[i][0] for i in idx[start:end + 1]]), np.float32)
             to = np.ascontiguousarray(np.concatenate([recs[i][1] for i in idx[start:end + 1]]), np.float32)
-            check(lib().har_scene_update_instances(self._h, idx[start], end - start + 1, _fp(tw), _fp(to), _stream()))
+            rc = lib().har_scene_update_instances(self._h, idx[start], end - start + 1, _fp(tw), _fp(to), _stream())
+            if rc != 0:          # the host mirror of the instance level may already differ from the device's: rebuild from self.instances at the next render
+                msg = (lib().har_last_error() or b"").decode()
+                self._drop_handle(keep_geometry=False)
+                raise RuntimeError(msg or "instance update failed")
             start = end + 1
 
     def _set_vertex_positions(self, mesh, positions):
@@ -1912,15 +1938,39 @@ class Scene:
             # an emitter (its sampling records are lowered from the positions), or the refitted tree has degraded (HAR_UPDATE_REBUILD_ADVISED: still valid, but a
             # fresh build traces faster -- the next render creates it)
             Vc = np.ascontiguousarray(self.meshes[mesh]["V"], np.float32)
-            rc = lib().har_scene_update_vertices(self._h, int(mesh), _fp(Vc), _stream())
-            if rc in (2, 3):
-                if os.environ.get("HAR_VERBOSE"):
-                    import sys
-                    sys.stderr.write("[mitsuba3_amd] vertex update of mesh %d: %s -> new scene at the next render\n" % (mesh, (lib().har_last_error() or b"").decode() if rc == 2 else "refit cost ratio %.2f: rebuild advised" % self.refit_info()["ratio"]))
-                self.accel_rebuilds = getattr(self, "accel_rebuilds", 0) + 1
-                lib().har_scene_destroy(self._h); self._h = None
-            else:
-                check(rc)
+            getattr(self, "_stale_meshes", set()).discard(mesh)
+            self._after_vertex_update(mesh, lib().har_scene_update_vertices(self._h, int(mesh), _fp(Vc), _stream()))
+
+    def _after_vertex_update(self, mesh, rc):
+        """return codes of har_scene_update_vertices(_device): 2 / 3 = valid scene, but the next render needs / is better off with a new handle; anything else but 0 is an
+        error AFTER the call may have touched the host mirror and the device arrays (allocation failure of the refit scratch, a HIP error mid-refit, a TLAS that no
+        longer fits the traversal stacks): the handle is dropped so that the next render rebuilds from self.meshes instead of tracing a half-updated BVH"""
+        if rc in (2, 3):
+            if os.environ.get("HAR_VERBOSE"):
+                import sys
+                sys.stderr.write("[mitsuba3_amd] vertex update of mesh %d: %s -> new scene at the next render\n" % (mesh, (lib().har_last_error() or b"").decode() if rc == 2 else "refit cost ratio %.2f: rebuild advised" % self.refit_info()["ratio"]))
+            self.accel_rebuilds = getattr(self, "accel_rebuilds", 0) + 1
+            self._drop_handle()
+        elif rc != 0:
+            msg = (lib().har_last_error() or b"").decode()
+            self._drop_handle(keep_geometry=False)
+            raise RuntimeError(msg or "vertex update failed")
+
+    def _set_vertex_positions_device(self, mesh, positions):
+        """params['<shape>.vertex_positions'] (a CUDA tensor) + params.update(): the positions stay on the GPU -- vertex records, regenerated normals, shading triangles and the
+        BLAS refit are kernels on the current stream (har_scene_update_vertices_device; Mesh::parameters_changed, mesh.cpp:848-899).  The numpy mirror meshes[mesh]['V'] is
+        refreshed lazily (sync_host)."""
+        torch = _torch()
+        V = self.meshes[mesh]["V"]
+        p = positions.detach().to(torch.float32).contiguous()
+        if p.numel() != 3 * V.shape[0]:
+            raise RuntimeError("vertex_positions: expected %d values" % (3 * V.shape[0]))
+        if not hasattr(self, "_stale_meshes"):
+            self._stale_meshes = set()
+        self._stale_meshes.add(mesh)
+        self.device_vertex_updates = getattr(self, "device_vertex_updates", 0) + 1
+        self._keep_positions = p                  # alive until the kernels that read it were enqueued on this stream (they were: the call below enqueues them)
+        self._after_vertex_update(mesh, lib().har_scene_update_vertices_device(self._h, int(mesh), _ptr(p), _stream()))
 
     def refit_info(self):
         """(refits since the scene handle was created, cost figure of the last refit, its ratio to the first refit's, nodes)"""
@@ -2070,8 +2120,7 @@ class Scene:
             inv = np.linalg.inv(m)
             e["to_world"] = [float(x) for x in m[:3, :].T.reshape(-1)]; e["to_local"] = [float(x) for x in inv[:3, :].T.reshape(-1)]
         self.emitters[b] = e
-        if self._h is not None:                                  # the emitter records are part of the scene handle: rebuilt with the next one
-            lib().har_scene_destroy(self._h); self._h = None
+        self._drop_handle()                                      # the emitter records are part of the scene handle: rebuilt with the next one
 
     def _gradients(self, g_refl, g_tex, g_emit=None):
         out = {}
@@ -2105,6 +2154,13 @@ class SceneParameters(dict):
         for k, (kind, b) in scene._pose_keys().items():
             self[k] = torch.tensor(scene._pose_value(kind, b), dtype=torch.float32, device=dev)
         self._written = set()           # keys assigned since the last update() (SceneParameters.__setitem__ flags them in the reference, util.py)
+        # the tensors above ARE the scene's values: recorded as applied, so that the first update() touches only what was written or stepped since (vertex positions on
+        # the GPU are never compared -- a mesh is updated when its tensor's version counter moved, see _changed_keys)
+        snap = self.__dict__.setdefault("_snapshot", {}); seen = self.__dict__.setdefault("_seen", {})
+        for k, what, _ in self._host_kinds():
+            t = self[k]
+            seen[k] = (t, t._version)
+            snap[k] = None if (what == "pos" and t.is_cuda) else t.detach().clone()
 
     def __setitem__(self, key, value):
         super().__setitem__(key, value)
@@ -2132,25 +2188,35 @@ class SceneParameters(dict):
         """which host-updated keys hold other values than at the last update(): WRITTEN keys (SceneParameters.__setitem__ flags them, util.py) and tensors modified
         in place (an optimiser step).  A tensor that is the same object with the same version counter as at the last update() is unchanged without looking at it;
         the others are compared with the snapshot of the last update() ON THE TENSOR'S DEVICE, one flag per key, ONE read-back for all of them (round 4 copied
-        every parameter to the host, every step).  (Writes that bypass the version counter -- `tensor.data.add_()`, raw pointers -- need `params[key] = params[key]`,
-        as every update does in the reference.)"""
+        every parameter to the host, every step).  Vertex positions that live on the GPU are not even compared: a new version counter IS the change (the device
+        update costs less than the comparison's synchronisation).  Values without a version counter (numpy arrays, lists) are compared every call.
+        (Writes that bypass the version counter -- `tensor.data.add_()`, raw pointers -- need `params[key] = params[key]`, as every update does in the reference.)
+        Returns (changed keys, marks): `marks[k]()` records key k as applied -- update() calls it AFTER the key's setter succeeded, so that a rejected value
+        (singular matrix, wrong size, a C error) is looked at again by the next update() instead of being remembered as pushed."""
         torch = _torch()
         table = self._host_kinds()
         snap = self.__dict__.setdefault("_snapshot", {})
         seen = self.__dict__.setdefault("_seen", {})          # key -> (the tensor object, its version counter) at the last update()
         changed = set(k for k, _, _ in table if k in written or k not in snap)
         flags = []; names = []
-        for k, _, _ in table:
+        device_pos = set()
+        for k, what, _ in table:
+            t = self[k]
+            if what == "pos" and getattr(t, "is_cuda", False) and self.scene._h is not None:
+                device_pos.add(k)
+                mark = seen.get(k)
+                if mark is None or mark[0] is not t or mark[1] != t._version:
+                    changed.add(k)
+                continue
             if k in changed:
                 continue
-            t = self[k]
-            if not hasattr(t, "detach"):
+            if not hasattr(t, "detach") or not hasattr(t, "_version"):
                 changed.add(k); continue
             mark = seen.get(k)
             if mark is not None and mark[0] is t and mark[1] == t._version:
                 continue                    # the same tensor object, never written in place since (torch bumps _version on every in-place op): nothing to compare
             t = t.detach(); old = snap[k]
-            if old.shape != t.shape or old.device != t.device or old.dtype != t.dtype:
+            if old is None or old.shape != t.shape or old.device != t.device or old.dtype != t.dtype:
                 changed.add(k); continue
             flags.append((t != old).any()); names.append(k)
         if flags:
@@ -2160,57 +2226,75 @@ class SceneParameters(dict):
             for dev, items in by_dev.items():
                 got = torch.stack([f for f, _ in items]).tolist()          # one synchronisation per device
                 changed.update(k for (_, k), g in zip(items, got) if g)
-        for k in changed:
+
+        def marker(k):
             t = self[k]
-            snap[k] = t.detach().clone() if hasattr(t, "detach") else torch.as_tensor(np.asarray(t, np.float32))
-        for k, _, _ in table:
-            t = self[k]
-            if hasattr(t, "_version"):
-                seen[k] = (t, t._version)
-        return changed
+
+            def apply():
+                if k in device_pos:
+                    snap[k] = None               # never compared (see above): no clone of a million vertices per step
+                else:
+                    snap[k] = t.detach().clone() if hasattr(t, "detach") else torch.as_tensor(np.array(t, np.float32, copy=True))
+                if hasattr(t, "_version"):
+                    seen[k] = (t, t._version)
+            return apply
+        marks = {k: marker(k) for k, _, _ in table}
+        return changed, marks
 
     def update(self, values=None):
-        """SceneParameters.update (src/python/python/util.py): push the values to the scene.  Colours, bitmaps and emitter radiances that live on the GPU go to the
-        scene's device arrays directly (har_scene_set_*_device: a device-to-device copy on the current stream, no host round trip, no synchronisation); geometry,
-        poses and the non-colour BSDF parameters are compared on their device and only the ones that changed travel to the host (accel update / re-lowering)."""
+        """SceneParameters.update (src/python/python/util.py): push the values to the scene.  Colours, bitmaps, emitter radiances AND VERTEX POSITIONS that live on the
+        GPU go to the scene's device arrays directly (har_scene_set_*_device, har_scene_update_vertices_device: device-to-device on the current stream, no host round
+        trip, no synchronisation); instance transforms, poses and the non-colour BSDF parameters are compared on their device and only the ones that changed travel to
+        the host (accel update / re-lowering)."""
         if values:
             for k, v in values.items():
                 self[k] = v
         torch = _torch()
         written, self._written = self._written, set()
         sc = self.scene
-        changed = self._changed_keys(written)
-        moved = []
+        changed, marks = self._changed_keys(written)
+        moved = []; moved_keys = []
         for k, what, ref in self._host_kinds():
             if k not in changed:
+                if what != "pos" or not getattr(self[k], "is_cuda", False):
+                    marks[k]()              # unchanged: remember the (possibly new) tensor object and version
                 continue
             v = self[k]
+            if what == "pos" and getattr(v, "is_cuda", False) and sc._h is not None and not os.environ.get("HAR_HOST_VERTEX_UPDATE"):
+                sc._set_vertex_positions_device(ref, v)
+                marks[k]()
+                continue
             v = v.detach().to("cpu").numpy().astype(np.float32) if hasattr(v, "detach") else np.asarray(v, np.float32)
             if what == "pos":
                 v = v.reshape(-1, 3)
+                sc._sync_host_geometry()
                 # a WRITTEN key notifies the mesh even when the values are the old ones: the vertex normals are regenerated (mesh.cpp:876-878)
                 if k in written or not np.array_equal(v, sc.meshes[ref]["V"][:, :3]):
                     sc._set_vertex_positions(ref, v)
             elif what == "inst":
                 if not np.array_equal(v.reshape(4, 4), sc._instance_matrix(ref)):
-                    moved.append((ref, v.reshape(4, 4)))
+                    moved.append((ref, v.reshape(4, 4))); moved_keys.append(k)
+                    continue                # marked once the whole run of instances went through
             elif what == "pose":
                 if not np.array_equal(v.reshape(-1), sc._pose_value(*ref).reshape(-1)):
                     sc._set_pose(ref[0], ref[1], v)
             else:
                 if not np.array_equal(v.reshape(-1), np.asarray(sc._bsdf_param_value(*ref), np.float32).reshape(-1)):
                     sc._set_bsdf_param(ref[0], ref[1], v.reshape(-1))
+            marks[k]()
         if moved:
             sc._set_instance_matrices(moved)
+            for k in moved_keys:
+                marks[k]()
         sc._validate_spots()
         stream = None
         pushed = self.__dict__.setdefault("_pushed", {})      # key -> (tensor object, version counter, scene handle) of the last push
         for k, (kind, b) in self._colour_table:
             t = self[k]
             mark = pushed.get(k)
-            if k not in written and mark is not None and mark[0] is t and mark[1] == getattr(t, "_version", None) and mark[2] == (sc._h.value if sc._h is not None else None):
-                continue                    # the value the scene already holds
-            pushed[k] = (t, getattr(t, "_version", None), sc._h.value if sc._h is not None else None)
+            if k not in written and mark is not None and hasattr(t, "_version") and mark[0] is t and mark[1] == t._version and mark[2] == (sc._h.value if sc._h is not None else None):
+                continue                    # the value the scene already holds (values without a version counter -- numpy arrays -- are pushed every call)
+            new_mark = (t, getattr(t, "_version", None), sc._h.value if sc._h is not None else None)      # recorded once the push below went through
             on_gpu = hasattr(t, "is_cuda") and t.is_cuda and sc._h is not None
             if on_gpu:
                 # the scene's copy is the value AT update(): snapshot on the device (a later in-place edit of the tensor is not an update), host mirror refreshed lazily
@@ -2229,6 +2313,7 @@ class SceneParameters(dict):
                         raise RuntimeError("%s: expected 3 values" % k)
                     check(lib().har_scene_set_reflectance_device(sc._h, b.index, _ptr(v), stream))
                 sc._device_values[(kind, b if kind == "emit" else (b.tex_index if kind == "tex" else b.index))] = (v if v.data_ptr() != t.data_ptr() else v.clone(), b)
+                pushed[k] = new_mark
                 continue
             v = t.detach().to("cpu").numpy().astype(np.float32) if hasattr(t, "detach") else np.asarray(t, np.float32)
             if kind == "emit":
@@ -2246,6 +2331,7 @@ class SceneParameters(dict):
                 b.value = np.ascontiguousarray(v.reshape(3))
                 if sc._h is not None:
                     check(lib().har_scene_set_reflectance(sc._h, b.index, _fp(b.value)))
+            pushed[k] = new_mark
 
 
 def traverse(scene):

@@ -148,6 +148,15 @@ struct HarSceneImpl {
     RefitBox *tri_box = nullptr, *node_box = nullptr; uint32_t *d_refit_order = nullptr; float *d_area = nullptr;
     double last_refit_cost = 0.0, last_refit_ratio = 1.0;
     float *d_emitter_distr = nullptr; DTexture *d_textures = nullptr;
+    /* device-resident vertex updates (har_scene_update_vertices_device): per mesh -- the host mirror of its vertex records (hs.verts, hs.shade_tris) is older than
+     * the device's; its normals are the ones k_vertex_normals regenerated; its corner list (har_vertex_update.h) on the device.  `pend`: one pinned record the last
+     * update's refit writes its figures to (surface-area sum, root box, non-finite flag) behind `pend_ev` -- read by the NEXT call, nothing waits for it */
+    std::vector<uint8_t> verts_host_stale, normals_regenerated;
+    std::vector<uint32_t *> d_corner_begin, d_corners;
+    struct PendingRefit { float area; RefitBox root; uint32_t bad; } *pend = nullptr;
+    hipEvent_t pend_ev = nullptr; bool pend_active = false; BlasInfo *pend_blas = nullptr; uint32_t *d_bad = nullptr;
+    hipStream_t last_push_stream = nullptr; bool last_push_valid = false;      /* stream of the last har_scene_set_*_device copy: the blocking host read-backs order themselves after it */
+    ~HarSceneImpl() { if (pend) (void) hipHostFree(pend); if (pend_ev) (void) hipEventDestroy(pend_ev); }
 };
 
 struct HarIntegratorImpl {
@@ -876,7 +885,13 @@ int har_scene_destroy(HarScene S) {
 }
 
 /* device -> host refresh of the mirrors that har_scene_set_*_device left stale (the host setters below rewrite whole records from the mirror) */
+/* The values were written by hipMemcpyAsync on the CALLER's stream (har_scene_set_*_device); the blocking copies below run on the null stream, which does not order
+ * itself against a non-blocking stream (torch side streams): wait for the last push first, or the mirror picks up the pre-update value and writes it back. */
+static void wait_for_device_pushes(HarSceneImpl *S) {
+    if (S->last_push_valid) { (void) hipStreamSynchronize(S->last_push_stream); S->last_push_valid = false; }
+}
 static int sync_host_records(HarSceneImpl *S) {
+    if (S->bsdf_host_stale || S->emitter_host_stale) wait_for_device_pushes(S);
     if (S->bsdf_host_stale) { HIP_TRY(hipMemcpy(S->hs.bsdfs.data(), S->d_bsdfs, S->hs.bsdfs.size() * sizeof(DBsdf), hipMemcpyDeviceToHost)); S->bsdf_host_stale = false; }
     if (S->emitter_host_stale) { HIP_TRY(hipMemcpy(S->hs.emitters.data(), S->ds.emitters, S->hs.emitters.size() * sizeof(DEmitter), hipMemcpyDeviceToHost)); S->emitter_host_stale = false; }
     return 0;
@@ -967,7 +982,7 @@ int har_scene_set_texture_device(HarScene S, uint32_t tex, const float *dev, voi
         return refresh_sampling_weights(S, tex);
     }
     if (dev != S->tex_dev[tex]) HIP_TRY(hipMemcpyAsync(S->tex_dev[tex], dev, t.data.size() * sizeof(float), hipMemcpyDeviceToDevice, s));
-    S->tex_host_stale[tex] = 1;
+    S->tex_host_stale[tex] = 1; S->last_push_stream = s; S->last_push_valid = true;
     return 0;
 }
 int har_scene_set_reflectance_device(HarScene S, uint32_t bsdf, const float *dev_rgb, void *stream) {
@@ -983,7 +998,7 @@ int har_scene_set_reflectance_device(HarScene S, uint32_t bsdf, const float *dev
     }
     static_assert(offsetof(DBsdf, g) == offsetof(DBsdf, r) + 4 && offsetof(DBsdf, b) == offsetof(DBsdf, r) + 8, "slot 0 is three consecutive floats");
     HIP_TRY(hipMemcpyAsync(&S->d_bsdfs[bsdf].r, dev_rgb, 3 * sizeof(float), hipMemcpyDeviceToDevice, s));
-    S->bsdf_host_stale = true;
+    S->bsdf_host_stale = true; S->last_push_stream = (hipStream_t) stream; S->last_push_valid = true;
     return 0;
 }
 int har_scene_set_emitter_radiance_device(HarScene S, uint32_t emitter, const float *dev_rgb, void *stream) {
@@ -993,7 +1008,7 @@ int har_scene_set_emitter_radiance_device(HarScene S, uint32_t emitter, const fl
     if (S->hs.emitters[emitter].type == 7u) return fail("this area light radiates a bitmap: update the texture (har_scene_set_texture_device)");
     HIP_TRY(hipMemcpyAsync(const_cast<float *>(S->ds.emitters[0].radiance) + (size_t) emitter * (sizeof(DEmitter) / sizeof(float)), dev_rgb, 3 * sizeof(float),
                            hipMemcpyDeviceToDevice, (hipStream_t) stream));
-    S->emitter_host_stale = true;
+    S->emitter_host_stale = true; S->last_push_stream = (hipStream_t) stream; S->last_push_valid = true;
     S->ds.emitter0_valid = 0u;          /* the kernels read the array again (the argument copy no longer holds the radiance) */
     return 0;
 }
@@ -1045,7 +1060,7 @@ int har_scene_set_texture_to_uv(HarScene S, uint32_t tex, const float to_uv[6]) 
     for (int k = 0; k < 6; ++k) { if (!std::isfinite(to_uv[k])) return fail("HarTexture::to_uv must be finite"); zero = zero && to_uv[k] == 0.f; ident = ident && to_uv[k] == id6[k]; }
     if (!zero && !ident && to_uv[0] * to_uv[4] - to_uv[1] * to_uv[3] == 0.f) return fail("HarTexture::to_uv is singular");
     if (texture_lights_an_emitter(S->hs, tex)) {          /* the emitter's texel distribution needs a to_uv that keeps the unit square (bitmap.cpp:976-992): checked before anything changes */
-        if (S->tex_host_stale[tex]) { HIP_TRY(hipMemcpy(t.data.data(), S->tex_dev[tex], t.data.size() * sizeof(float), hipMemcpyDeviceToHost)); S->tex_host_stale[tex] = 0; }
+        if (S->tex_host_stale[tex]) { wait_for_device_pushes(S); HIP_TRY(hipMemcpy(t.data.data(), S->tex_dev[tex], t.data.size() * sizeof(float), hipMemcpyDeviceToHost)); S->tex_host_stale[tex] = 0; }
         std::string err;
         if (!texel_table_inputs_ok((zero || ident) ? id6 : to_uv, t.data.data(), t.w, t.h, err)) return fail(err);
     }
@@ -1100,67 +1115,206 @@ static int upload_scene_bounds(HarSceneImpl *S, hipStream_t s) {
     }
     return 0;
 }
+static int refresh_host_vertices(HarSceneImpl *S, hipStream_t s, int only_mesh);
 int har_scene_update_instances(HarScene S, uint32_t first, uint32_t count, const float *to_world, const float *to_object, void *stream) {
     if (!S || !to_world || !to_object) return fail("null argument");
     if (count == 0) return 0;
     std::string e;
-    if (!scene_set_instances_host(S->hs, first, count, to_world, to_object, e)) return fail(e);
     hipStream_t s = (hipStream_t) stream;
+    if (refresh_host_vertices(S, s, -1)) return 1;          /* the instance boxes and the scene bounds are host builds over the vertex positions */
+    if (!scene_set_instances_host(S->hs, first, count, to_world, to_object, e)) return fail(e);
     if (upload_instance_level(S, s) || upload_scene_bounds(S, s)) return 1;
     HIP_TRY(hipStreamSynchronize(s));
     return 0;
 }
+/* refit scratch, on first use; S->tri_box (the "scratch exists" flag) is set last, so a failed allocation leaves no half-made set behind */
+static int ensure_refit_scratch(HarSceneImpl *S, hipStream_t s) {
+    if (S->tri_box) return 0;
+    HostScene &hs = S->hs;
+    const size_t n_blas = 1 + hs.blas_groups.size();
+    void *p = nullptr;
+    HIP_TRY(dev_alloc(&p, std::max<size_t>(hs.tris.size(), 1) * sizeof(RefitBox))); S->owned.push_back(p); RefitBox *tri_box = (RefitBox *) p;
+    HIP_TRY(dev_alloc(&p, std::max<size_t>(S->nodes_cap, 1) * sizeof(RefitBox))); S->owned.push_back(p); S->node_box = (RefitBox *) p;
+    HIP_TRY(dev_alloc(&p, std::max<size_t>(hs.refit_order.size(), 1) * sizeof(uint32_t))); S->owned.push_back(p); S->d_refit_order = (uint32_t *) p;
+    if (!hs.refit_order.empty()) { HIP_TRY(hipMemcpyAsync(S->d_refit_order, hs.refit_order.data(), hs.refit_order.size() * sizeof(uint32_t), hipMemcpyHostToDevice, s)); HIP_TRY(hipStreamSynchronize(s)); }
+    HIP_TRY(dev_alloc(&p, n_blas * sizeof(float))); S->owned.push_back(p); S->d_area = (float *) p;
+    S->tri_box = tri_box;
+    return 0;
+}
+static size_t blas_slot(const HostScene &hs, const BlasInfo *B) { return B == &hs.blas_top ? 0 : 1 + (size_t) (B - hs.blas_groups.data()); }
+/* the launches of one refit pass of BLAS `B` on the device arrays as they are (triangle records + boxes, then the nodes level by level, deepest first); the node-area
+ * sum accumulates in d_area[slot] */
+static int enqueue_refit(HarSceneImpl *S, BlasInfo *B, hipStream_t s) {
+    const size_t bi = blas_slot(S->hs, B);
+    HIP_TRY(hipMemsetAsync(S->d_area + bi, 0, sizeof(float), s));
+    launch_refit_triangles(s, S->ds, B->first_tri, B->tri_count, S->tri_box);
+    for (size_t l = 0; l + 1 < B->level_begin.size(); ++l)
+        launch_refit_nodes(s, S->ds, S->d_refit_order + B->order_first + B->level_begin[l], B->level_begin[l + 1] - B->level_begin[l], S->tri_box, S->node_box, S->d_area + bi);
+    HIP_TRY(hipGetLastError());
+    return 0;
+}
+static double refit_cost_figure(float area, const RefitBox &root) {
+    const float dx = root.hi[0] - root.lo[0], dy = root.hi[1] - root.lo[1], dz = root.hi[2] - root.lo[2];
+    const double root_area = 2.0 * ((double) dx * dy + (double) dy * dz + (double) dz * dx);
+    return root_area > 0.0 ? (double) area / root_area : 0.0;           /* sum of the node areas over the root's area (the node term of the SAH) */
+}
+/* one refit pass + its cost figure, waited for */
+static int refit_pass_sync(HarSceneImpl *S, BlasInfo *B, hipStream_t s, double &cost) {
+    if (enqueue_refit(S, B, s)) return 1;
+    float area = 0.f; RefitBox root{};
+    HIP_TRY(hipMemcpyAsync(&area, S->d_area + blas_slot(S->hs, B), sizeof(float), hipMemcpyDeviceToHost, s));
+    HIP_TRY(hipMemcpyAsync(&root, S->node_box + B->root, sizeof(RefitBox), hipMemcpyDeviceToHost, s));
+    HIP_TRY(hipStreamSynchronize(s));
+    cost = refit_cost_figure(area, root);
+    return 0;
+}
+static int refit_verdict(HarSceneImpl *S, const BlasInfo *B, double cost) {
+    static const double max_inflation = getenv("HAR_REFIT_MAX_INFLATION") ? atof(getenv("HAR_REFIT_MAX_INFLATION")) : 1.5;
+    static const uint32_t max_refits = getenv("HAR_REFIT_MAX_STEPS") ? (uint32_t) atoi(getenv("HAR_REFIT_MAX_STEPS")) : 0u;
+    S->last_refit_cost = cost; S->last_refit_ratio = B->built_area > 0.0 ? cost / B->built_area : 1.0;
+    if ((B->built_area > 0.0 && cost > max_inflation * B->built_area) || (max_refits && B->refits >= max_refits)) return HAR_UPDATE_REBUILD_ADVISED;
+    return 0;
+}
+/* device -> host refresh of the vertex records of the meshes a device-resident update left stale on the host (hs.verts, hs.shade_tris): before anything on the host
+ * reads positions again (group boxes, scene bounds, har_scene_get_vertices) */
+static int refresh_host_vertices(HarSceneImpl *S, hipStream_t s, int only_mesh) {
+    HostScene &hs = S->hs; bool any = false;
+    for (size_t k = 0; k < S->verts_host_stale.size(); ++k) {
+        if (!S->verts_host_stale[k] || (only_mesh >= 0 && (size_t) only_mesh != k)) continue;
+        const DMesh &m = hs.meshes[k];
+        HIP_TRY(hipMemcpyAsync(hs.verts.data() + 8 * (size_t) m.voff, S->ds.verts + 8 * (size_t) m.voff, 32 * (size_t) m.vertex_count, hipMemcpyDeviceToHost, s));
+        any = true;
+    }
+    if (!any) return 0;
+    HIP_TRY(hipStreamSynchronize(s));
+    for (size_t k = 0; k < S->verts_host_stale.size(); ++k) {
+        if (!S->verts_host_stale[k] || (only_mesh >= 0 && (size_t) only_mesh != k)) continue;
+        const DMesh &m = hs.meshes[k];
+#if HAR_SHADING_TRIS
+        for (uint32_t f = 0; f < m.face_count; ++f)
+            for (int c = 0; c < 3; ++c) std::memcpy(hs.shade_tris.data() + 24 * ((size_t) m.foff + f) + 8 * c, hs.verts.data() + 8 * ((size_t) m.voff + hs.faces[4 * ((size_t) m.foff + f) + c]), 32);
+#endif
+        S->verts_host_stale[k] = 0;
+    }
+    return 0;
+}
+/* the figures the LAST device-resident update left in the pinned record: 0, HAR_UPDATE_REBUILD_ADVISED, or 1 (a position was not finite) */
+static int collect_pending_refit(HarSceneImpl *S) {
+    if (!S->pend_active) return 0;
+    HIP_TRY(hipEventSynchronize(S->pend_ev));          /* recorded one update (= at least one frame) ago, or just synchronised by the caller */
+    S->pend_active = false;
+    if (S->pend->bad) return fail("har_scene_update_vertices_device: a vertex position of the last update was not finite (the scene holds it: create a new scene)");
+    return refit_verdict(S, S->pend_blas, refit_cost_figure(S->pend->area, S->pend->root));
+}
 int har_scene_update_vertices(HarScene S, uint32_t mesh, const float *vertices, void *stream) {
     if (!S || !vertices) return fail("null argument");
     HostScene &hs = S->hs; DScene &D = S->ds;
+    hipStream_t s = (hipStream_t) stream;
     std::string e;
+    if (!S->verts_host_stale.empty()) {         /* other meshes may have been updated on the device since: the host steps below read their positions */
+        if (mesh < S->verts_host_stale.size()) S->verts_host_stale[mesh] = 0;          /* this one is overwritten */
+        if (refresh_host_vertices(S, s, -1)) return 1;
+        if (collect_pending_refit(S) == 1) return 1;
+    }
     BlasInfo *B = scene_set_vertices_host(hs, mesh, vertices, e);
     if (!B) { (void) fail(e); return HAR_UPDATE_NEEDS_NEW_SCENE; }
-    hipStream_t s = (hipStream_t) stream;
+    if (mesh < S->normals_regenerated.size()) S->normals_regenerated[mesh] = 0;
     const DMesh &m = hs.meshes[mesh];
-    const size_t n_blas = 1 + hs.blas_groups.size();
-    if (!S->tri_box) {                   /* refit scratch, on first use; S->tri_box (the "scratch exists" flag) is set last, so a failed allocation leaves no half-made set behind */
-        void *p = nullptr;
-        HIP_TRY(dev_alloc(&p, std::max<size_t>(hs.tris.size(), 1) * sizeof(RefitBox))); S->owned.push_back(p); RefitBox *tri_box = (RefitBox *) p;
-        HIP_TRY(dev_alloc(&p, std::max<size_t>(S->nodes_cap, 1) * sizeof(RefitBox))); S->owned.push_back(p); S->node_box = (RefitBox *) p;
-        HIP_TRY(dev_alloc(&p, std::max<size_t>(hs.refit_order.size(), 1) * sizeof(uint32_t))); S->owned.push_back(p); S->d_refit_order = (uint32_t *) p;
-        if (!hs.refit_order.empty()) HIP_TRY(hipMemcpyAsync(S->d_refit_order, hs.refit_order.data(), hs.refit_order.size() * sizeof(uint32_t), hipMemcpyHostToDevice, s));
-        HIP_TRY(dev_alloc(&p, n_blas * sizeof(float))); S->owned.push_back(p); S->d_area = (float *) p;
-        S->tri_box = tri_box;
-    }
-    const size_t bi = B == &hs.blas_top ? 0 : 1 + (size_t) (B - hs.blas_groups.data());
-    /* one refit pass of the BLAS on the device arrays as they are; cost = sum of the node areas over the root's area (the node term of the SAH) */
-    auto refit_pass = [&](double &cost) -> int {
-        HIP_TRY(hipMemsetAsync(S->d_area + bi, 0, sizeof(float), s));
-        launch_refit_triangles(s, D, B->first_tri, B->tri_count, S->tri_box);
-        for (size_t l = 0; l + 1 < B->level_begin.size(); ++l)
-            launch_refit_nodes(s, D, S->d_refit_order + B->order_first + B->level_begin[l], B->level_begin[l + 1] - B->level_begin[l], S->tri_box, S->node_box, S->d_area + bi);
-        HIP_TRY(hipGetLastError());
-        float area = 0.f; RefitBox root{};
-        HIP_TRY(hipMemcpyAsync(&area, S->d_area + bi, sizeof(float), hipMemcpyDeviceToHost, s));
-        HIP_TRY(hipMemcpyAsync(&root, S->node_box + B->root, sizeof(RefitBox), hipMemcpyDeviceToHost, s));
-        HIP_TRY(hipStreamSynchronize(s));
-        const float dx = root.hi[0] - root.lo[0], dy = root.hi[1] - root.lo[1], dz = root.hi[2] - root.lo[2];
-        const double root_area = 2.0 * ((double) dx * dy + (double) dy * dz + (double) dz * dx);
-        cost = root_area > 0.0 ? (double) area / root_area : 0.0;
-        return 0;
-    };
+    if (ensure_refit_scratch(S, s)) return 1;
     /* the figure of the tree AS BUILT: the first update of a BLAS refits it once on the old vertices (which reproduces the built nodes bit for bit) */
-    if (B->built_area == 0.0 && refit_pass(B->built_area)) return 1;
+    if (B->built_area == 0.0 && refit_pass_sync(S, B, s, B->built_area)) return 1;
     HIP_TRY(hipMemcpyAsync(const_cast<float *>(D.verts) + 8 * (size_t) m.voff, vertices, 32 * (size_t) m.vertex_count, hipMemcpyHostToDevice, s));
 #if HAR_SHADING_TRIS
     HIP_TRY(hipMemcpyAsync(const_cast<float *>(D.shade_tris) + 24 * (size_t) m.foff, hs.shade_tris.data() + 24 * (size_t) m.foff, 96 * (size_t) m.face_count, hipMemcpyHostToDevice, s));
 #endif
     double cost = 0.0;
-    if (refit_pass(cost)) return 1;
+    if (refit_pass_sync(S, B, s, cost)) return 1;
     if (!scene_after_refit_host(hs, B, e)) return fail(e);
     if (B != &hs.blas_top && upload_instance_level(S, s)) return 1;
     if (upload_scene_bounds(S, s)) return 1;
     HIP_TRY(hipStreamSynchronize(s));
-    static const double max_inflation = getenv("HAR_REFIT_MAX_INFLATION") ? atof(getenv("HAR_REFIT_MAX_INFLATION")) : 1.5;
-    static const uint32_t max_refits = getenv("HAR_REFIT_MAX_STEPS") ? (uint32_t) atoi(getenv("HAR_REFIT_MAX_STEPS")) : 0u;
-    S->last_refit_cost = cost; S->last_refit_ratio = B->built_area > 0.0 ? cost / B->built_area : 1.0;
-    if ((B->built_area > 0.0 && cost > max_inflation * B->built_area) || (max_refits && B->refits >= max_refits)) return HAR_UPDATE_REBUILD_ADVISED;
+    return refit_verdict(S, B, cost);
+}
+static bool scene_needs_bounds(const HostScene &hs) {
+    bool any = hs.env_emitter >= 0; for (const DEmitter &E : hs.emitters) any = any || E.type == 6u;
+    return any;
+}
+/* corner list of a mesh (har_vertex_update.h), built on the host once and kept on the device */
+static int ensure_corner_list(HarSceneImpl *S, uint32_t mesh, hipStream_t s) {
+    HostScene &hs = S->hs;
+    if (S->d_corner_begin.size() != hs.meshes.size()) { S->d_corner_begin.assign(hs.meshes.size(), nullptr); S->d_corners.assign(hs.meshes.size(), nullptr); }
+    if (S->d_corner_begin[mesh]) return 0;
+    const DMesh &m = hs.meshes[mesh];
+    std::vector<uint32_t> begin((size_t) m.vertex_count + 1, 0u), corners(3 * (size_t) m.face_count);
+    const uint32_t *F = hs.faces.data() + 4 * (size_t) m.foff;
+    for (uint32_t f = 0; f < m.face_count; ++f) for (int k = 0; k < 3; ++k) ++begin[(size_t) F[4 * (size_t) f + k] + 1];
+    for (uint32_t v = 0; v < m.vertex_count; ++v) begin[v + 1] += begin[v];
+    std::vector<uint32_t> cursor(begin.begin(), begin.end() - 1);
+    for (uint32_t f = 0; f < m.face_count; ++f) for (int k = 0; k < 3; ++k) corners[cursor[F[4 * (size_t) f + k]]++] = f | ((uint32_t) k << 30);      /* (face, corner) ascending per vertex */
+    void *p = nullptr;
+    HIP_TRY(dev_alloc(&p, begin.size() * sizeof(uint32_t))); S->owned.push_back(p); uint32_t *d_begin = (uint32_t *) p;
+    HIP_TRY(dev_alloc(&p, std::max<size_t>(corners.size(), 1) * sizeof(uint32_t))); S->owned.push_back(p); uint32_t *d_corners = (uint32_t *) p;
+    HIP_TRY(hipMemcpyAsync(d_begin, begin.data(), begin.size() * sizeof(uint32_t), hipMemcpyHostToDevice, s));
+    if (!corners.empty()) HIP_TRY(hipMemcpyAsync(d_corners, corners.data(), corners.size() * sizeof(uint32_t), hipMemcpyHostToDevice, s));
+    HIP_TRY(hipStreamSynchronize(s));                  /* once per mesh: the vectors die here */
+    S->d_corners[mesh] = d_corners; S->d_corner_begin[mesh] = d_begin;
+    return 0;
+}
+int har_scene_update_vertices_device(HarScene S, uint32_t mesh, const float *positions, void *stream) {
+    if (!S || !positions) return fail("null argument");
+    HostScene &hs = S->hs; DScene &D = S->ds;
+    hipStream_t s = (hipStream_t) stream;
+    if (mesh >= hs.meshes.size()) { (void) fail("invalid mesh index"); return HAR_UPDATE_NEEDS_NEW_SCENE; }
+    const DMesh &m = hs.meshes[mesh];
+    if (m.emitter >= 0) { (void) fail("the mesh carries an area emitter (its sampling records are lowered from the positions): create a new scene"); return HAR_UPDATE_NEEDS_NEW_SCENE; }
+    BlasInfo *B = nullptr;
+    if (mesh < hs.top_mesh_count) B = &hs.blas_top;
+    else for (size_t g = 0; g < hs.groups.size(); ++g) if (mesh >= hs.groups[g].first_mesh && mesh < hs.groups[g].first_mesh + hs.groups[g].mesh_count) B = &hs.blas_groups[g];
+    if (!B) return fail("mesh belongs to no BLAS");
+    /* what the PREVIOUS update's refit reported (its launches finished a frame ago): acted on one step late, so that this call waits for nothing */
+    int verdict = collect_pending_refit(S);
+    if (verdict == 1) return 1;
+    if (S->verts_host_stale.size() != hs.meshes.size()) { S->verts_host_stale.assign(hs.meshes.size(), 0); S->normals_regenerated.assign(hs.meshes.size(), 0); }
+    if (ensure_refit_scratch(S, s)) return 1;
+    if (!S->pend) {
+        HIP_TRY(hipHostMalloc((void **) &S->pend, sizeof(*S->pend), hipHostMallocDefault));
+        HIP_TRY(hipEventCreateWithFlags(&S->pend_ev, hipEventDisableTiming));
+        void *p = nullptr; HIP_TRY(dev_alloc(&p, sizeof(uint32_t))); S->owned.push_back(p); S->d_bad = (uint32_t *) p;
+    }
+    if ((m.flags & 1u) && ensure_corner_list(S, mesh, s)) return 1;
+    if (B->built_area == 0.0 && refit_pass_sync(S, B, s, B->built_area)) return 1;          /* once per BLAS: the figure of the tree as built */
+    HIP_TRY(hipMemsetAsync(S->d_bad, 0, sizeof(uint32_t), s));
+    launch_set_positions(s, D, m.voff, m.vertex_count, positions, S->d_bad);
+    if (m.flags & 1u) { launch_vertex_normals(s, D, m.voff, m.foff, m.vertex_count, S->d_corner_begin[mesh], S->d_corners[mesh]); S->normals_regenerated[mesh] = 1; }
+#if HAR_SHADING_TRIS
+    launch_shading_triangles(s, D, m.voff, m.foff, m.face_count);
+#endif
+    if (enqueue_refit(S, B, s)) return 1;
+    HIP_TRY(hipMemcpyAsync(&S->pend->area, S->d_area + blas_slot(hs, B), sizeof(float), hipMemcpyDeviceToHost, s));
+    HIP_TRY(hipMemcpyAsync(&S->pend->root, S->node_box + B->root, sizeof(RefitBox), hipMemcpyDeviceToHost, s));
+    HIP_TRY(hipMemcpyAsync(&S->pend->bad, S->d_bad, sizeof(uint32_t), hipMemcpyDeviceToHost, s));
+    HIP_TRY(hipEventRecord(S->pend_ev, s));
+    S->pend_active = true; S->pend_blas = B;
+    S->verts_host_stale[mesh] = 1;
+    if (B == &hs.blas_top && !scene_needs_bounds(hs)) { B->refits++; return verdict; }
+    /* an instanced mesh moves the boxes of its instances, and environment / directional emitters follow the scene's bounding sphere: both are host builds over exact
+     * vertex bounds, so these updates read the mesh back (32 B per vertex, device -> host) and wait -- still no host -> device copy of geometry */
+    if (refresh_host_vertices(S, s, -1)) return 1;
+    const int now = collect_pending_refit(S);
+    if (now == 1) return 1;
+    std::string e;
+    if (!scene_after_refit_host(hs, B, e)) return fail(e);
+    if (B != &hs.blas_top && upload_instance_level(S, s)) return 1;
+    if (upload_scene_bounds(S, s)) return 1;
+    HIP_TRY(hipStreamSynchronize(s));
+    return now ? now : verdict;
+}
+int har_scene_get_vertices(HarScene S, uint32_t mesh, float *vertices, void *stream) {
+    if (!S || !vertices) return fail("null argument");
+    if (mesh >= S->hs.meshes.size()) return fail("invalid mesh index");
+    if (refresh_host_vertices(S, (hipStream_t) stream, (int) mesh)) return 1;
+    const DMesh &m = S->hs.meshes[mesh];
+    std::memcpy(vertices, S->hs.verts.data() + 8 * (size_t) m.voff, 32 * (size_t) m.vertex_count);
     return 0;
 }
 int har_scene_refit_info(HarScene S, double info[4]) {
@@ -1788,9 +1942,11 @@ int har_integrator_set_grad_positions(HarIntegrator I, HarScene S, float *const 
             if (!grad_positions[m]) continue;
             const DMesh &M = S->hs.meshes[m];
             if (m >= S->hs.top_mesh_count && I->inst_count) return fail("Cannot differentiate instance parameters and shapegroup internal parameters at the same time!");      /* instance.cpp:162-166 */
-            const bool known = I->pos_checked_scene == S->serial && m < I->pos_checked.size() && I->pos_checked[m];      /* an optimisation loop calls this every step */
+            const bool known = (I->pos_checked_scene == S->serial && m < I->pos_checked.size() && I->pos_checked[m]) ||      /* an optimisation loop calls this every step */
+                               (m < S->normals_regenerated.size() && S->normals_regenerated[m]);                             /* k_vertex_normals wrote them (har_scene_update_vertices_device) */
             if ((M.flags & 1u) && known) smooth = true;
             else if (M.flags & 1u) {
+                if (refresh_host_vertices(S, nullptr, (int) m)) return 1;
                 /* a position update regenerates the vertex normals (mesh.cpp:876-878 -> compute_normals): the gradient is that of the REGENERATED normals, so the
                  * mesh must carry them -- stored normals of another origin (file, analytic) would render one surface and differentiate another */
                 std::vector<float> copy(S->hs.verts.begin() + 8 * (size_t) M.voff, S->hs.verts.begin() + 8 * (size_t) (M.voff + M.vertex_count));

@@ -11,6 +11,7 @@
  */
 #include "../../include/hip_ad_rgb.h"
 #include "har_math.h"
+#include "har_vertex_update.h"
 
 #include <cstdio>
 #include <cstdlib>
@@ -65,14 +66,6 @@ struct Reader {
     }
 };
 
-/* dr::unit_angle (Dr.Jit, NOT IN TREE -- restated from its published definition) */
-float unit_angle(Vec3 a, Vec3 b) {
-    float dot_uv = dot3(a, b);
-    Vec3 am(mulsign_(a.x, dot_uv), mulsign_(a.y, dot_uv), mulsign_(a.z, dot_uv));
-    float temp = 2.f * asinf(.5f * norm3(b - am));
-    return dot_uv >= 0.f ? temp : HAR_PI - temp;
-}
-
 } // namespace
 
 extern "C" {
@@ -85,14 +78,11 @@ int har_mesh_compute_normals(uint32_t vertex_count, float *vertices, uint32_t fa
         uint32_t fi[3] = { faces[4 * (size_t) f], faces[4 * (size_t) f + 1], faces[4 * (size_t) f + 2] };
         Vec3 p[3];
         for (int k = 0; k < 3; ++k) { if (fi[k] >= vertex_count) return har_set_error("face index out of bounds"); const float *v = vertices + 8 * (size_t) fi[k]; p[k] = Vec3(v[0], v[1], v[2]); }
-        Vec3 n = cross3(p[1] - p[0], p[2] - p[0]);
-        float length_sqr = dot3(n, n);
-        if (!(length_sqr > 0.f)) continue;
-        n = n * rsqrt_(length_sqr);
         for (int k = 0; k < 3; ++k) {
-            float angle = unit_angle(normalize3(p[(k + 1) % 3] - p[k]), normalize3(p[(k + 2) % 3] - p[k]));
+            Vec3 t;
+            if (!mesh_corner_term(p, k, t)) break;          /* a face without area adds nothing */
             float *a = acc.data() + 3 * (size_t) fi[k];
-            a[0] += n.x * angle; a[1] += n.y * angle; a[2] += n.z * angle;
+            a[0] += t.x; a[1] += t.y; a[2] += t.z;
         }
     }
     for (uint32_t v = 0; v < vertex_count; ++v) {

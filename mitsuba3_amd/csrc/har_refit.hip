@@ -4,6 +4,7 @@
  * BLAS is 48 MB of records + 24 MB of boxes + 15.6 MB of nodes, i.e. tens of microseconds of traffic; the cost of a refit is its 1 + depth launches.
  */
 #include "har_refit_launch.h"
+#include "har_vertex_update.h"
 
 namespace har {
 
@@ -25,7 +26,41 @@ __global__ void k_refit_nodes(Node8 *nodes, const uint32_t *order, uint32_t coun
     if ((threadIdx.x & 63u) == 0u && a != 0.f) atomicAdd(area, a);
 }
 
+/* ---- device-resident vertex update (har_vertex_update.h): streaming passes, one thread per vertex / per corner record */
+__global__ void k_set_positions(float *verts, const float *positions, uint32_t n, uint32_t *bad) {
+    const uint32_t v = blockIdx.x * blockDim.x + threadIdx.x;
+    if (v >= n) return;
+    const float x = positions[3 * (size_t) v], y = positions[3 * (size_t) v + 1], z = positions[3 * (size_t) v + 2];
+    float *o = verts + 8 * (size_t) v; o[0] = x; o[1] = y; o[2] = z;
+    if (!(isfinite(x) && isfinite(y) && isfinite(z))) atomicOr(bad, 1u);          /* reported by the NEXT update call (nothing waits for this launch) */
+}
+__global__ void k_vertex_normals(float *verts, const uint32_t *faces, const uint32_t *corner_begin, const uint32_t *corners, uint32_t n) {
+    const uint32_t v = blockIdx.x * blockDim.x + threadIdx.x;
+    if (v < n) vertex_normal(verts, faces, corner_begin, corners, v);
+}
+/* one thread per 16 bytes of a shading triangle: 6 float4 per face, coalesced stores */
+__global__ void k_shading_triangles(const float *verts, const uint32_t *faces, float *shade_tris, uint32_t face_count) {
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= 6u * face_count) return;
+    const uint32_t f = i / 6u, q = i % 6u;
+    const float4 *src = reinterpret_cast<const float4 *>(verts + 8 * (size_t) faces[4 * (size_t) f + (q >> 1)]) + (q & 1u);
+    reinterpret_cast<float4 *>(shade_tris)[6 * (size_t) f + q] = *src;
+}
+
 } // namespace
+
+void launch_set_positions(hipStream_t s, const DScene &S, uint32_t voff, uint32_t vertex_count, const float *positions, uint32_t *bad) {
+    if (!vertex_count) return;
+    hipLaunchKernelGGL(k_set_positions, dim3((vertex_count + 255u) / 256u), dim3(256), 0, s, const_cast<float *>(S.verts) + 8 * (size_t) voff, positions, vertex_count, bad);
+}
+void launch_vertex_normals(hipStream_t s, const DScene &S, uint32_t voff, uint32_t foff, uint32_t vertex_count, const uint32_t *corner_begin, const uint32_t *corners) {
+    if (!vertex_count) return;
+    hipLaunchKernelGGL(k_vertex_normals, dim3((vertex_count + 255u) / 256u), dim3(256), 0, s, const_cast<float *>(S.verts) + 8 * (size_t) voff, S.faces + 4 * (size_t) foff, corner_begin, corners, vertex_count);
+}
+void launch_shading_triangles(hipStream_t s, const DScene &S, uint32_t voff, uint32_t foff, uint32_t face_count) {
+    if (!face_count || !S.shade_tris) return;
+    hipLaunchKernelGGL(k_shading_triangles, dim3((6u * face_count + 255u) / 256u), dim3(256), 0, s, S.verts + 8 * (size_t) voff, S.faces + 4 * (size_t) foff, const_cast<float *>(S.shade_tris) + 24 * (size_t) foff, face_count);
+}
 
 void launch_refit_triangles(hipStream_t s, const DScene &S, uint32_t first, uint32_t count, RefitBox *tri_box) {
     if (!count) return;

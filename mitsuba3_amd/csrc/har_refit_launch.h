@@ -10,4 +10,10 @@ void launch_refit_triangles(hipStream_t s, const DScene &S, uint32_t first, uint
 /* the nodes order[0 .. count) (one depth level of one BLAS, deepest level first): boxes, frames, child planes; their surface areas are added to *area */
 void launch_refit_nodes(hipStream_t s, const DScene &S, const uint32_t *order, uint32_t count, const RefitBox *tri_box, RefitBox *node_box, float *area);
 
+/* device-resident vertex update of one mesh (har_vertex_update.h): positions (DEVICE, 3 floats per vertex) into the packed vertex records (`bad` is OR-ed with 1 when a
+ * position is not finite), regenerated vertex normals from the mesh's corner list, the 96-byte shading triangles of its faces */
+void launch_set_positions(hipStream_t s, const DScene &S, uint32_t voff, uint32_t vertex_count, const float *positions, uint32_t *bad);
+void launch_vertex_normals(hipStream_t s, const DScene &S, uint32_t voff, uint32_t foff, uint32_t vertex_count, const uint32_t *corner_begin, const uint32_t *corners);
+void launch_shading_triangles(hipStream_t s, const DScene &S, uint32_t voff, uint32_t foff, uint32_t face_count);
+
 } // namespace har

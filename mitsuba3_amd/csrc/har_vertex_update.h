@@ -1,0 +1,69 @@
+/*
+ * har_vertex_update.h -- what Mesh::parameters_changed does to a mesh whose vertex positions were written (src/render/mesh.cpp:848-899), as per-element
+ * HAR_HD functions: the HIP kernels of har_refit.hip run them on the device arrays, the host harness runs the same code.
+ *
+ * In the reference's JIT variants the positions never leave the device: parameters_changed regenerates the vertex normals of a smooth mesh
+ * (pack(regenerate_normals) -> compute_normals, mesh.cpp:876-878, 1216-1267), recomputes the bounding box, and Scene::parameters_changed hands the accel its
+ * new vertices (scene.cpp:517-540).  Here (round 6, har_scene_update_vertices_device):
+ *   1. set_position           the 3 floats of every packed 32-byte vertex record from the caller's DEVICE array;
+ *   2. vertex_normal          Mesh::compute_normals as a GATHER: one thread per vertex walks the vertex's corners in (face, corner) order -- the order in which
+ *                             the serial host loop (har_mesh_compute_normals) reaches them -- and adds  n_face * angle  in float32, so the sum has the host
+ *                             loop's rounding sequence and does not depend on thread scheduling (the reference's scatter_reduce has no defined order at all);
+ *                             the corner list (4 B offset per vertex + 4 B per corner) is built once per mesh on the host;
+ *   3. shading_triangle       the face's three vertex records copied into its 96-byte shading triangle (DScene::shade_tris, what compute_si reads);
+ *   4. the BLAS refit of har_refit.h.
+ */
+#pragma once
+#include "har_scene.h"
+
+namespace har {
+
+/* dr::unit_angle (Dr.Jit, NOT IN TREE -- restated from its published definition): numerically robust angle between two unit vectors */
+HAR_HD float mesh_unit_angle(Vec3 a, Vec3 b) {
+    float dot_uv = dot3(a, b);
+    Vec3 am(mulsign_(a.x, dot_uv), mulsign_(a.y, dot_uv), mulsign_(a.z, dot_uv));
+    float temp = 2.f * asinf(.5f * norm3(b - am));
+    return dot_uv >= 0.f ? temp : HAR_PI - temp;
+}
+
+/* what face (p0, p1, p2) adds to the normal sum of its corner k (mesh.cpp:1237-1251); false: a face without area adds nothing */
+HAR_HD bool mesh_corner_term(const Vec3 p[3], int k, Vec3 &term) {
+    Vec3 n = cross3(p[1] - p[0], p[2] - p[0]);
+    const float length_sqr = dot3(n, n);
+    if (!(length_sqr > 0.f)) return false;
+    n = n * rsqrt_(length_sqr);
+    const float angle = mesh_unit_angle(normalize3(p[(k + 1) % 3] - p[k]), normalize3(p[(k + 2) % 3] - p[k]));
+    term = Vec3(n.x * angle, n.y * angle, n.z * angle);
+    return true;
+}
+
+/* corner list entry: face index | corner << 30 (a mesh has < 2^30 faces) */
+HAR_HD uint32_t corner_face(uint32_t e) { return e & 0x3fffffffu; }
+HAR_HD uint32_t corner_slot(uint32_t e) { return e >> 30; }
+
+/* vertex `v` of a mesh (verts / faces = the mesh's own records): normal = normalised sum over its corners, (1, 0, 0) without a valid contribution (mesh.cpp:1256-1264) */
+HAR_HD void vertex_normal(float *verts, const uint32_t *faces, const uint32_t *corner_begin, const uint32_t *corners, uint32_t v) {
+    float ax = 0.f, ay = 0.f, az = 0.f;
+    for (uint32_t e = corner_begin[v]; e < corner_begin[v + 1]; ++e) {
+        const uint32_t *fi = faces + 4 * (size_t) corner_face(corners[e]);
+        Vec3 p[3];
+        for (int k = 0; k < 3; ++k) { const float *q = verts + 8 * (size_t) fi[k]; p[k] = Vec3(q[0], q[1], q[2]); }
+        Vec3 t;
+        if (!mesh_corner_term(p, (int) corner_slot(corners[e]), t)) continue;
+        ax += t.x; ay += t.y; az += t.z;
+    }
+    Vec3 n(ax, ay, az);
+    const float length_sqr = dot3(n, n);
+    n = length_sqr > 0.f ? n * rsqrt_(length_sqr) : Vec3(1.f, 0.f, 0.f);
+    float *o = verts + 8 * (size_t) v; o[3] = n.x; o[4] = n.y; o[5] = n.z;
+}
+
+/* the 96-byte shading triangle of face `f` (three 32-byte vertex records in corner order) */
+HAR_HD void shading_triangle(const float *verts, const uint32_t *faces, float *shade_tris, uint32_t f) {
+    for (int k = 0; k < 3; ++k) {
+        const float *src = verts + 8 * (size_t) faces[4 * (size_t) f + k]; float *dst = shade_tris + 24 * (size_t) f + 8 * k;
+        for (int c = 0; c < 8; ++c) dst[c] = src[c];
+    }
+}
+
+} // namespace har

@@ -166,3 +166,56 @@ def test_refit_area_grows_when_the_tree_degrades(mi, O):
     assert L.hh_scene_update_vertices(h, m, O.fp(np.ascontiguousarray(W)), C.byref(a1), err, 256) == 0
     assert a1.value > 1.15 * a0.value             # one of four spheres (and the walls) of this BLAS
     L.hh_scene_destroy(h)
+
+
+def _lib_positions(O):
+    L = _lib(O)
+    L.hh_scene_update_positions.argtypes = [C.c_void_p, C.c_uint32, O.c_f32p, C.POINTER(C.c_double), C.c_char_p, C.c_int]
+    L.hh_scene_get_vertices.argtypes = [C.c_void_p, C.c_uint32, O.c_f32p]
+    return L
+
+
+@pytest.mark.parametrize("flatten", [True, False])
+def test_device_resident_update_code_equals_the_host_update_bit_for_bit(mi, O, flatten):
+    """har_scene_update_vertices_device's per-element code (har_vertex_update.h: positions -> records, Mesh::compute_normals as a per-vertex gather in (face, corner)
+    order, shading triangles) run on the host arrays == the host update (har_mesh_compute_normals' serial loop + har_scene_update_vertices): same vertex records,
+    same accel hash, same ray answers.  The gather adds a vertex's corner terms in the order the serial loop reaches them, so the float32 sums are the same numbers."""
+    import mitsuba3_amd as pkg
+    L = _lib_positions(O); rng = np.random.default_rng(11)
+    scene = mi.load_dict(spheres(mi, flatten))
+    name = "ball004.vertex_positions" if flatten else "spheres.ball.vertex_positions"
+    m = scene._position_keys()[name]
+    assert scene.meshes[m]["flags"] & 1                                   # the bumpy spheres carry vertex normals
+    V0 = np.ascontiguousarray(scene.meshes[m]["V"], np.float32); F = np.ascontiguousarray(scene.meshes[m]["F"])
+    P = np.ascontiguousarray(_move(V0, rng, 0.004)[:, :3])
+    err = C.create_string_buffer(256)
+    # (a) the host update: positions + har_mesh_compute_normals on the host, then the refit
+    Vh = V0.copy(); Vh[:, :3] = P
+    assert pkg.lib().har_mesh_compute_normals(Vh.shape[0], O.fp(Vh), F.shape[0], F.ctypes.data_as(O.c_u32p)) == 0
+    ha = _create(L, scene)
+    assert L.hh_scene_update_vertices(ha, m, O.fp(Vh), None, err, 256) == 0, err.value
+    # (b) the device-resident update's code
+    hb = _create(L, scene); area = C.c_double()
+    assert L.hh_scene_update_positions(hb, m, O.fp(P), C.byref(area), err, 256) == 0, err.value
+    Vb = np.zeros_like(V0); assert L.hh_scene_get_vertices(hb, m, O.fp(Vb)) == 0
+    assert np.array_equal(Vb.view(np.uint32), Vh.view(np.uint32))          # positions, regenerated normals, texcoords: bit for bit
+    assert np.abs(np.linalg.norm(Vb[:, 3:6], axis=1) - 1).max() < 1e-5 and np.abs(Vb[:, 3:6] - V0[:, 3:6]).max() > 1e-4
+    assert _hash(L, ha) == _hash(L, hb) and area.value > 0
+    o, d, maxt = _rays(4000, seed=5)
+    for x, y in zip(_trace(L, O, ha, o, d, maxt), _trace(L, O, hb, o, d, maxt)):
+        assert np.array_equal(x, y)
+    img_a = np.zeros((16, 16, 4), np.float32); img_b = np.zeros_like(img_a)           # RGBW film
+    sensor = scene.sensors()[0]
+    assert L.hh_render(ha, C.byref(sensor.har), 0, 0, 4, 6, 5, 0, 16 * 16 * 4, O.fp(img_a)) == 0
+    assert L.hh_render(hb, C.byref(sensor.har), 0, 0, 4, 6, 5, 0, 16 * 16 * 4, O.fp(img_b)) == 0
+    assert np.array_equal(img_a, img_b)                                    # shading reads the rewritten shading triangles
+    L.hh_scene_destroy(ha); L.hh_scene_destroy(hb)
+
+
+def test_device_resident_update_refuses_emitter_meshes(mi, O):
+    L = _lib_positions(O); scene = mi.load_dict(mi.cornell_box())
+    h = _create(L, scene); err = C.create_string_buffer(256)
+    m = scene._position_keys()["light.vertex_positions"]
+    P = np.ascontiguousarray(scene.meshes[m]["V"][:, :3], np.float32)
+    assert L.hh_scene_update_positions(h, m, O.fp(P), None, err, 256) == 2 and b"emitter" in err.value
+    L.hh_scene_destroy(h)

@@ -57,6 +57,9 @@ def test_vertex_update_refits_in_place(mi, O, flatten):
         d2 = copy.deepcopy(d)
         m = scene._position_keys()[key]
         name = scene.meshes[m]["key"]
+        assert m in scene._stale_meshes                               # a CUDA tensor: the update ran on the device, the numpy mirror was not touched
+        scene.sync_host()                                             # ... until someone asks for it (positions + the normals the device regenerated)
+        assert np.array_equal(scene.meshes[m]["V"][:, :3].reshape(-1), new)
         if flatten:
             d2[name]["positions"] = scene.meshes[m]["V"][:, :3].copy(); d2[name]["normals"] = scene.meshes[m]["V"][:, 3:6].copy(); d2[name].pop("to_world", None)
         else:
@@ -122,7 +125,21 @@ def test_degraded_refit_advises_a_rebuild_and_emitter_meshes_get_a_new_scene(mi)
     assert scene._h is not None and scene.refit_info()["refits"] == 1
     big = p.copy(); big[::2] += np.float32(0.6)                                        # every other vertex flies off: long thin triangles through the whole box
     params[key] = torch.tensor(big.reshape(-1), device="cuda"); params.update()
-    assert scene._h is None and scene.accel_rebuilds == 1                               # advised: the next render builds a fresh tree
+    # device-resident update: nothing waits for the refit's cost figure -- the advice arrives with the NEXT update call (include/hip_ad_rgb.h)
+    assert scene._h is not None and getattr(scene, "accel_rebuilds", 0) == 0
+    rays = _rays(mi, 50000)
+    assert _pi_equal(scene.ray_intersect_preliminary(rays), scene._intersect(rays, True))   # valid meanwhile: a refit is exact, only slower to trace
+    params[key] = torch.tensor(big.reshape(-1), device="cuda"); params.update()
+    assert scene._h is None and scene.accel_rebuilds == 1                               # advised: the next render builds a fresh tree from the refreshed mirror
+    assert np.array_equal(scene.meshes[scene._position_keys()[key]]["V"][:, :3], big)
+    assert _pi_equal(scene.ray_intersect_preliminary(rays), scene._intersect(rays, True))
+    # the same through the host path (a CPU tensor): the call waits for its own refit, the advice is immediate
+    scene2 = mi.load_dict(d); mi.render(scene2, spp=4, seed=0)
+    p2 = mi.traverse(scene2)
+    p2[key] = torch.tensor(p.reshape(-1)); p2.update()
+    assert scene2._h is not None and scene2.refit_info()["refits"] == 1
+    p2[key] = torch.tensor(big.reshape(-1)); p2.update()
+    assert scene2._h is None and scene2.accel_rebuilds == 1
     rays = _rays(mi, 50000)
     assert _pi_equal(scene.ray_intersect_preliminary(rays), scene._intersect(rays, True))
     # a mesh with an area emitter: its sampling records are lowered from the positions -> new scene, not a refit
@@ -151,3 +168,96 @@ def test_shape_optimisation_steps_keep_the_handle(mi):
         opt.step(); params.update()
         assert scene._h is not None and scene._h.value == handle
     assert scene.refit_info()["refits"] == 3
+
+
+
+@pytest.mark.parametrize("flatten", [True, False])
+def test_device_resident_vertex_update_equals_the_host_update(mi, O, flatten):
+    """params[key] as a CUDA tensor (har_scene_update_vertices_device: positions, regenerated normals, shading triangles, refit -- all kernels) against the same
+    values as a CPU tensor (har_mesh_compute_normals on the host + har_scene_update_vertices): same intersections bit for bit, same picture, same vertex records;
+    the instanced variant also carries a `constant` emitter, so the instance level and the scene's bounding sphere follow (the call's read-back path)."""
+    import torch
+    d = _scene_dict(mi, flatten, sky=not flatten)
+    key = "ball005.vertex_positions" if flatten else "spheres.ball.vertex_positions"
+    a = mi.load_dict(d); b = mi.load_dict(copy.deepcopy(d))
+    for sc in (a, b):
+        mi.render(sc, spp=4, seed=0)
+    pa = mi.traverse(a); pb = mi.traverse(b)
+    base = pa[key].cpu().numpy().reshape(-1, 3)
+    rays = _rays(mi, 100000, seed=2)
+    m = a._position_keys()[key]
+    mirror_before = a.meshes[m]["V"].copy()
+    for amount in (0.08, 0.2):
+        new = np.ascontiguousarray(base * np.float32(1.0 + amount) + np.float32(0.01) * np.sin(np.float32(30.0) * base[:, ::-1]), np.float32).reshape(-1)
+        pa[key] = torch.tensor(new, device="cuda"); pa.update()
+        pb[key] = torch.tensor(new); pb.update()                      # CPU tensor -> host path
+        assert np.array_equal(a.meshes[m]["V"], mirror_before)        # the device path never wrote (or read) the host mirror
+        ga = a.ray_intersect_preliminary(rays); gb = b.ray_intersect_preliminary(rays)
+        assert int(ga.is_valid().sum()) > 10000 and _pi_equal(ga, gb) and _pi_equal(ga, a._intersect(rays, True))
+        ia = mi.render(a, spp=16, seed=5).cpu().numpy(); ib = mi.render(b, spp=16, seed=5).cpu().numpy()
+        assert rel_l2(ia, ib) < 1e-6
+    a.sync_host()
+    Va, Vb = a.meshes[m]["V"], b.meshes[m]["V"]
+    assert np.array_equal(Va[:, :3], Vb[:, :3]) and np.array_equal(Va[:, 6:], Vb[:, 6:])
+    # regenerated normals: the device gathers a vertex's corner terms in the serial loop's order, asinf / sqrt are the device's -> equal to a few ulps
+    assert np.abs(Va[:, 3:6] - Vb[:, 3:6]).max() < 2e-6
+    assert a.refit_info()["refits"] == 2 and a.refit_info()["rebuilds"] == 0
+
+
+def test_device_resident_update_reports_a_non_finite_position_one_call_late(mi):
+    import torch
+    d = _scene_dict(mi, True)
+    scene = mi.load_dict(d); mi.render(scene, spp=4, seed=0)
+    params = mi.traverse(scene)
+    key = "ball002.vertex_positions"
+    p = params[key].clone()
+    bad = p.clone(); bad[7] = float("nan")
+    params[key] = bad; params.update()                                # enqueued; nothing has looked at the values yet
+    assert scene._h is not None
+    params[key] = p.clone()
+    with pytest.raises(RuntimeError, match="not finite"):
+        params.update()
+    assert scene._h is None                                           # the handle that held the bad geometry is gone; the next render builds from the mirror
+    params.update()                                                   # the rejected key is looked at again (no scene handle: the host path sets the good positions)
+    rays = _rays(mi, 20000)
+    assert _pi_equal(scene.ray_intersect_preliminary(rays), scene._intersect(rays, True))
+
+
+def test_vertex_loop_with_device_updates_matches_host_updates(mi):
+    """three optimiser steps over vertex positions on the GPU: mi.render + backward + SGD + params.update() with device-resident updates == the same loop forced
+    through the host path (HAR_HOST_VERTEX_UPDATE=1), gradients and positions"""
+    import os
+    import torch
+
+    def loop(host):
+        if host:
+            os.environ["HAR_HOST_VERTEX_UPDATE"] = "1"
+        try:
+            from mitsuba3_amd.scenes import bumpy_sphere
+            d = mi.cornell_box(); d["sensor"]["film"]["width"] = 32; d["sensor"]["film"]["height"] = 32
+            d["integrator"] = {"type": "prb", "max_depth": 4}
+            P, N, UV, F = bumpy_sphere(n_u=32, n_v=16, radius=0.35)
+            d.pop("small-box"); d.pop("large-box")
+            d["blob"] = {"type": "mesh", "positions": P + np.array([0.0, -0.45, 0.0], np.float32), "normals": N, "faces": F, "bsdf": {"type": "ref", "id": "white"}}
+            scene = mi.load_dict(d)
+            params = mi.traverse(scene)
+            key = "blob.vertex_positions"
+            params[key] = params[key].clone().requires_grad_(True); params.update()
+            opt = torch.optim.SGD([params[key]], lr=2e-7)               # gradients of mean(img^2) w.r.t. a vertex reach ~1e3: steps of ~1e-4 scene units
+            grads = []
+            for it in range(3):
+                opt.zero_grad()
+                img = mi.render(scene, params, spp=16, seed=it)
+                (img ** 2).mean().backward()
+                grads.append(params[key].grad.detach().cpu().numpy().copy())
+                opt.step(); params.update()
+            return grads, params[key].detach().cpu().numpy().copy(), scene
+        finally:
+            os.environ.pop("HAR_HOST_VERTEX_UPDATE", None)
+
+    gd, pd, sd = loop(False); gh, ph, sh = loop(True)
+    assert sd.device_vertex_updates == 3 and getattr(sh, "device_vertex_updates", 0) == 0
+    for a, b in zip(gd, gh):
+        assert np.isfinite(a).all() and np.abs(a).max() > 0
+        assert rel_l2(a, b) < 1e-3                                    # atomics order only (first step: identical geometry)
+    assert np.abs(pd - ph).max() < 1e-6

@@ -10,7 +10,7 @@ def short(name):
     m = re.search(r"har\d*(k_[a-z_]+)", name)
     # demangled names: the whole template-id (two flavours of k_shade differ in their LAST arguments -- cut at 60 characters they shared one key, and the second
     # overwrote the first's counters in the JSON summary: bench.py then found half the dispatches it expected and quoted no traffic figure)
-    base = m.group(1) if m else name.split("(")[0][:200]
+    base = m.group(1) if m else name.replace("(anonymous namespace)::", "").split("(")[0][:200]
     t = re.search(r"ILi(\d+)(?:EL[ij](\d+))?", name)
     if m and t:
         base += "<" + ",".join(x for x in t.groups() if x) + ">"
@@ -26,6 +26,9 @@ def main():
     launches_out = None
     if "--launches" in args:
         k = args.index("--launches"); launches_out = args[k + 1]; args = args[:k] + args[k + 2:]
+    busy_marker = None
+    if "--busy" in args:
+        k = args.index("--busy"); busy_marker = args[k + 1]; args = args[:k] + args[k + 2:]
     summary = {}
     for path in args:
         db = sqlite3.connect(path)
@@ -57,6 +60,42 @@ def main():
             print("(no counters: %s)" % e)
 
 
+    if busy_marker:
+        # GPU-busy analysis of an optimisation loop (bench.py --workload c4_loop / vertex_loop): one step = the interval between two launches of `busy_marker`
+        # (a kernel that runs once per step).  Per step: wall span, the UNION of all kernel intervals (kernels of two streams overlap: their sum is not a time),
+        # idle = span - union, and the kernel time by family (the library's har:: kernels, the update kernels, torch's, runtime copies / fills).
+        db = sqlite3.connect(args[0])
+        rows = db.execute("select name, start, end from kernels order by start").fetchall()
+        marks = [i for i, r in enumerate(rows) if busy_marker in r[0]]
+        steps = []
+        for a, b in zip(marks[:-1], marks[1:]):
+            seg = rows[a:b]
+            span = rows[b][1] - rows[a][1]
+            union = 0; cur_s, cur_e = seg[0][1], seg[0][2]
+            for _, st, en in seg[1:]:
+                if st > cur_e:
+                    union += cur_e - cur_s; cur_s, cur_e = st, en
+                else:
+                    cur_e = max(cur_e, en)
+            union += cur_e - cur_s
+            fam = {}
+            for n, st, en in seg:
+                sh = short(n)
+                key = ("update" if any(x in sh for x in ("k_set_positions", "k_vertex_normals", "k_shading_triangles", "k_refit")) else
+                       "library" if "har" in n else "torch" if "at::" in n else "runtime")
+                fam[key] = fam.get(key, 0) + (en - st)
+            steps.append((span, union, fam, len(seg)))
+        # drop the longest spans (the boundaries between the bench's phases hold host-side setup)
+        if steps:
+            med = sorted(s[0] for s in steps)[len(steps) // 2]
+            keep = [s for s in steps if s[0] < 1.5 * med]
+            n = len(keep)
+            print("-- GPU busy per step (%d steps between launches of %s; %d phase boundaries dropped)" % (n, busy_marker, len(steps) - n))
+            span = sum(s[0] for s in keep) / n / 1e6; union = sum(s[1] for s in keep) / n / 1e6
+            print("   span %.3f ms  union of kernel intervals %.3f ms  idle %.3f ms (%.1f %%)  launches %.0f" % (span, union, span - union, 100 * (span - union) / span, sum(s[3] for s in keep) / n))
+            fams = sorted(set(k for s in keep for k in s[2]))
+            print("   kernel time by family (sums; two streams overlap): " + ", ".join("%s %.3f ms" % (k, sum(s[2].get(k, 0) for s in keep) / n / 1e6) for k in fams))
+            summary["_busy"] = {"steps": n, "span_ms": span, "union_ms": union, "idle_ms": span - union, "by_family_ms": {k: sum(s[2].get(k, 0) for s in keep) / n / 1e6 for k in fams}}
     if launches_out:
         # per-launch table of the LAST frame (dispatch order): one line per kernel launch from the last k_raygen on
         db = sqlite3.connect(args[0])
