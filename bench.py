@@ -436,7 +436,13 @@ def worker(args):
     integ = scene.integrator()
     accel = scene.accel_info()
 
+    # HAR_BENCH_GROUP=k (single process, A/B only): the frame goes through the single-call multi-GPU entry of the C ABI (har_multi_render, mi.DeviceGroup) with k
+    # replicas on device 0 -- k = 1 measures what the entry adds to har_render (nothing: same launches), k > 1 rehearses the bands + the reduce on one GPU
+    group = mi.DeviceGroup(scene, devices=[0] * int(os.environ["HAR_BENCH_GROUP"])) if os.environ.get("HAR_BENCH_GROUP") and world == 1 else None
+
     def fwd():
+        if group is not None:
+            return group.render(seed=0, spp=args.spp)
         return mi.render_distributed(scene, integ, seed=0, spp=args.spp)
 
     log("first forward frame (workspace allocation, code object load)")

@@ -394,6 +394,27 @@ int har_integrator_set_alpha_film(HarIntegrator integrator, float *alpha_film);
  * needs its band plus the reconstruction filter's reach on either side (and the sample border); har_render checks that the lanes it is given cannot splat outside the
  * window and fails otherwise.  row_count = 0: the whole film again (default).  A 4096^2 film is 256 MiB; an eighth of it plus the halo is what a rank of eight owns. */
 int har_integrator_set_film_window(HarIntegrator integrator, uint32_t row_begin, uint32_t row_count);
+/* ------------------------------------------------------------------------
+ *  Multi-GPU render from ONE host thread (SURVEY.md section 8e behind the C ABI).  The reference's contract is a single Integrator::render call from one host
+ *  thread (include/mitsuba/render/integrator.h:74-79) and it has no multi-GPU path; a C++ host that binds this library as a variant (INTEGRATION.md Route A) reaches
+ *  N GPUs through a GROUP: per device a replica of the scene, an integrator with its workspace and a stream.  har_multi_render deals the pixel rows of the sample
+ *  grid to the devices as contiguous bands with all their samples (global lane indices: the union of the bands draws the samples of a single-GPU render), adds the
+ *  private films on devices[0] with ONE collective -- ncclReduce (RCCL, looked up at run time) inside one ncclGroupStart / End over ncclCommInitAll's communicators;
+ *  peer copies + add kernels when a device is named more than once or RCCL is not loadable -- and develops the film there.  Bands are re-cut from the measured device
+ *  times of the first frames (read one frame late: nothing waits).  The call returns when everything is enqueued; `image` / `film` are valid in `stream` order on
+ *  devices[0].  (mitsuba3_amd/distributed.py is the same partitioning as one process per GPU under torch.distributed: what bench.py --gpus N runs.)
+ *    har_multi_create   builds the replicas (scene description as for har_scene_create, integrator as for har_integrator_create) on devices[0 .. n_devices)
+ *    har_multi_replica  the k-th replica's handles, for parameter updates (har_scene_set_* / har_scene_update_* with that device current) and statistics
+ *    har_multi_render   image: DEVICE (devices[0]), H x W x 3 (x 1 for HAR_PIXEL_Y), or NULL; film: DEVICE (devices[0]), H x W x 4 accumulated RGBW, or NULL
+ *    har_multi_info     band_rows[n_devices + 1] boundaries of the current bands, band_ms[n_devices] device time of the last measured frame, which collective is in use */
+typedef struct HarMultiImpl *HarMulti;
+int har_multi_create(const HarSceneDesc *desc, int integrator_type, int32_t max_depth, int32_t rr_depth, uint32_t chunk_lanes, const int *devices, uint32_t n_devices,
+                     HarMulti *out);
+int har_multi_destroy(HarMulti group);
+int har_multi_replica(HarMulti group, uint32_t k, HarScene *scene, HarIntegrator *integrator, int *device);
+int har_multi_render(HarMulti group, const HarSensor *sensor, uint32_t seed, uint32_t spp, int pixel_format, float *image, float *film, void *stream);
+int har_multi_info(HarMulti group, uint32_t *n_devices, uint32_t *band_rows, float *band_ms, char *reduce, uint32_t reduce_len);
+
 /* the pass split har_render will use for `spp` samples per pixel of this sensor's crop window; fails like the reference
  * when spp is not a multiple of the pass size (integrator.cpp:177-179, sampler.cpp:93-94) */
 int har_render_pass_layout(HarIntegrator integrator, const HarSensor *sensor, uint32_t spp, uint32_t *spp_per_pass, uint32_t *n_passes);

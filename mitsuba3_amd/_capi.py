@@ -109,6 +109,11 @@ SIGNATURES = {
     "har_scene_update_vertices_device": (C.c_int, [vp, C.c_uint32, vp, vp]),
     "har_scene_get_vertices": (C.c_int, [vp, C.c_uint32, f32p, vp]),
     "har_scene_refit_info": (C.c_int, [vp, C.POINTER(C.c_double)]),
+    "har_multi_create": (C.c_int, [C.c_void_p, C.c_int, C.c_int32, C.c_int32, C.c_uint32, C.POINTER(C.c_int), C.c_uint32, C.POINTER(vp)]),
+    "har_multi_destroy": (C.c_int, [vp]),
+    "har_multi_replica": (C.c_int, [vp, C.c_uint32, C.POINTER(vp), C.POINTER(vp), C.POINTER(C.c_int)]),
+    "har_multi_render": (C.c_int, [vp, C.c_void_p, C.c_uint32, C.c_uint32, C.c_int, vp, vp, vp]),
+    "har_multi_info": (C.c_int, [vp, C.POINTER(C.c_uint32), C.POINTER(C.c_uint32), C.POINTER(C.c_float), C.c_char_p, C.c_uint32]),
     "har_scene_set_texture_device": (C.c_int, [vp, C.c_uint32, vp, vp]),
     "har_scene_set_reflectance_device": (C.c_int, [vp, C.c_uint32, vp, vp]),
     "har_scene_set_emitter_radiance_device": (C.c_int, [vp, C.c_uint32, vp, vp]),

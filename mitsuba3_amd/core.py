@@ -2338,6 +2338,69 @@ def traverse(scene):
     return SceneParameters(scene)
 
 
+class DeviceGroup:
+    """N GPUs driven by ONE host thread through the C ABI (har_multi_*: a replica of the scene, an integrator and a stream per device; row bands with global lane
+    indices; one RCCL reduce of the film on devices[0]).  The single-call counterpart of render_distributed (one process per GPU, torch.distributed), for hosts that
+    call Integrator::render once from one thread (include/mitsuba/render/integrator.h:74-79).  `path` renders; parameters are those of the scene at construction
+    (replica(k) hands out the per-device handles for updates)."""
+
+    def __init__(self, scene, devices=(0,), integrator=None):
+        integrator = integrator or scene.integrator()
+        if integrator is None:
+            raise Exception('No integrator specified!')
+        _device()
+        self.scene, self.integrator, self.devices = scene, integrator, [int(d) for d in devices]
+        d = scene.desc(); h = C.c_void_p()
+        devs = (C.c_int * len(self.devices))(*self.devices)
+        check(lib().har_multi_create(C.byref(d), 0 if integrator.type == 'path' else 1, integrator.max_depth, integrator.rr_depth, integrator.chunk_lanes or 0,
+                                     devs, len(self.devices), C.byref(h)))
+        self._h = h
+
+    def __del__(self):
+        try:
+            if getattr(self, "_h", None) is not None:
+                lib().har_multi_destroy(self._h); self._h = None
+        except Exception:
+            pass
+
+    def render(self, sensor=0, seed=0, spp=0, develop=True):
+        torch = _torch()
+        s = self.scene.sensors()[sensor] if isinstance(sensor, int) else sensor
+        if spp:
+            s.sampler().set_sample_count(spp)
+        spp = s.sampler().sample_count()
+        w, h = s.film().crop_size()
+        dev = torch.device("cuda", self.devices[0])
+        with torch.cuda.device(dev):
+            colour = getattr(s.film(), "colour", 0)
+            out = torch.empty((h, w, 1 if colour == 1 else 3) if develop else (h, w, 4), dtype=torch.float32, device=dev)
+            check(lib().har_multi_render(self._h, C.byref(s.har), (s.sampler().m_base_seed + int(seed)) & 0xffffffff, spp, colour,
+                                         _ptr(out) if develop else None, None if develop else _ptr(out), _stream()))
+        return out
+
+    def replica(self, k):
+        sc = C.c_void_p(); it = C.c_void_p(); dev = C.c_int()
+        check(lib().har_multi_replica(self._h, int(k), C.byref(sc), C.byref(it), C.byref(dev)))
+        return sc, it, dev.value
+
+    def stats(self):
+        """device counters summed over the replicas (paths, vertices, rays)"""
+        tot = {}
+        for k in range(len(self.devices)):
+            _, it, _ = self.replica(k)
+            st = _capi.HarStats()
+            check(lib().har_render_stats(it, C.byref(st)))
+            for f, _t in st._fields_:
+                tot[f] = tot.get(f, 0) + int(getattr(st, f))
+        return tot
+
+    def info(self):
+        n = len(self.devices)
+        rows = (C.c_uint32 * (n + 1))(); ms = (C.c_float * n)(); note = C.create_string_buffer(160); nd = C.c_uint32()
+        check(lib().har_multi_info(self._h, C.byref(nd), rows, ms, note, 160))
+        return dict(devices=list(self.devices), band_rows=list(rows), band_ms=list(ms), reduce=note.value.decode())
+
+
 # ---------------------------------------------------------------------------
 #  PluginManager (src/core/plugin.cpp:157-282): registry keyed by (name, variant)
 # ---------------------------------------------------------------------------

@@ -1,0 +1,285 @@
+/*
+ * har_multi.hip -- ONE host thread, N GPUs: the multi-GPU partitioning of SURVEY.md section 8(e) behind the C ABI.
+ *
+ * The reference's contract is one Integrator::render call from one host thread (include/mitsuba/render/integrator.h:74-79); it has no multi-GPU path, so the
+ * partitioning is this repository's design (mitsuba3_amd/distributed.py is the same design as one PROCESS per GPU under torch.distributed -- what bench.py --gpus N
+ * runs; this file is the route a C++ host takes, INTEGRATION.md Route A).  Per device: a replica of the scene (its own BVH, textures, records), an integrator with
+ * its own workspace, a stream.  A frame:
+ *   1. the sample grid's pixel rows are dealt to the devices as contiguous BANDS with all their samples; a device renders the lanes of its band with the GLOBAL lane
+ *      index (har_render's lane range), so the union of the bands draws exactly the samples of a single-GPU render;
+ *   2. every device splats into a private full-size film; ONE collective adds them on device 0: ncclReduce inside one ncclGroupStart / End over the communicators
+ *      of ncclCommInitAll (RCCL, resolved at run time -- librccl is looked up only when a group of more than one DISTINCT device is created; a group that names one
+ *      physical device several times, and a process without RCCL, add the films with peer copies + one add kernel per film instead);
+ *   3. device 0 develops the film (har_film_develop_format) on the caller's stream.
+ * Bands are re-cut from the measured device times of the previous frames (HIP events per device, read one frame late: nothing waits), like distributed.py's
+ * BandBalancer, and frozen after HAR_MULTI_ADAPT_FRAMES frames.
+ * Nothing here synchronises the host with a device: the call returns when everything is enqueued, the image is valid in `stream` order on device 0.
+ */
+#include "../../include/hip_ad_rgb.h"
+#include "har_kernels.h"
+#include "har_scene_host.h"
+
+#include <dlfcn.h>
+#include <algorithm>
+#include <cstdlib>
+#include <string>
+#include <vector>
+
+extern int har_set_error(const std::string &msg);
+
+namespace {
+
+using namespace har;
+
+#define MULTI_TRY(expr) do { hipError_t e_ = (expr); if (e_ != hipSuccess) return har_set_error(std::string(#expr) + ": " + hipGetErrorString(e_)); } while (0)
+
+/* the six RCCL entry points the reduce needs, looked up at run time (rccl.h:236,448-466,550: ncclCommInitAll, ncclReduce, ncclFloat = 7, ncclSum = 0) */
+struct Rccl {
+    void *lib = nullptr;
+    int (*CommInitAll)(void **comms, int ndev, const int *devlist) = nullptr;
+    int (*CommDestroy)(void *comm) = nullptr;
+    int (*GroupStart)() = nullptr;
+    int (*GroupEnd)() = nullptr;
+    int (*Reduce)(const void *send, void *recv, size_t count, int datatype, int op, int root, void *comm, hipStream_t stream) = nullptr;
+    const char *(*GetErrorString)(int) = nullptr;
+    bool load(std::string &why) {
+        if (lib) return true;
+        const char *names[] = { "librccl.so", "librccl.so.1", "/opt/rocm/lib/librccl.so.1" };
+        lib = dlopen(names[0], RTLD_NOW | RTLD_NOLOAD);                         /* a copy the process already holds (PyTorch's) comes first: two RCCLs in one process clash */
+        for (int k = 0; !lib && k < 3; ++k) lib = dlopen(names[k], RTLD_NOW | RTLD_LOCAL);
+        if (!lib) { why = std::string("librccl not found: ") + dlerror(); return false; }
+        CommInitAll = (decltype(CommInitAll)) dlsym(lib, "ncclCommInitAll"); CommDestroy = (decltype(CommDestroy)) dlsym(lib, "ncclCommDestroy");
+        GroupStart = (decltype(GroupStart)) dlsym(lib, "ncclGroupStart"); GroupEnd = (decltype(GroupEnd)) dlsym(lib, "ncclGroupEnd");
+        Reduce = (decltype(Reduce)) dlsym(lib, "ncclReduce"); GetErrorString = (decltype(GetErrorString)) dlsym(lib, "ncclGetErrorString");
+        if (!CommInitAll || !CommDestroy || !GroupStart || !GroupEnd || !Reduce) { why = "librccl lacks ncclCommInitAll / ncclReduce / ncclGroupStart"; lib = nullptr; return false; }
+        return true;
+    }
+};
+Rccl g_rccl;
+
+struct Replica {
+    int device = 0;
+    HarScene scene = nullptr; HarIntegrator integ = nullptr;
+    hipStream_t stream = nullptr;            /* private stream (device 0 renders on the caller's stream) */
+    float *film = nullptr, *staging = nullptr;   /* H x W x 4; staging: on device 0, the peer copy of this replica's film (copy reduce) */
+    hipEvent_t t0 = nullptr, t1 = nullptr, done = nullptr; bool timed = false;
+    void *comm = nullptr;
+};
+
+} // namespace
+
+struct HarMultiImpl {
+    std::vector<Replica> rep;
+    bool use_rccl = false; std::string reduce_note;
+    hipEvent_t start = nullptr;              /* recorded on the caller's stream: the other devices' streams begin after it */
+    size_t film_floats = 0;
+    /* bands (rows of the sample grid), distributed.py BandBalancer */
+    std::vector<uint32_t> bounds; uint32_t rows = 0, frames = 0, adapt_frames = 3; std::vector<float> last_ms;
+};
+
+namespace {
+
+void cut_bands(HarMultiImpl *M, uint32_t rows) {
+    const uint32_t n = (uint32_t) M->rep.size();
+    M->rows = rows; M->frames = 0; M->bounds.resize(n + 1);
+    for (uint32_t r = 0; r <= n; ++r) M->bounds[r] = (uint32_t) ((uint64_t) rows * r / n);
+}
+/* BandBalancer.update: boundaries that equalise the integral of the piecewise-constant cost per row measured on the last frame */
+void rebalance(HarMultiImpl *M, const std::vector<float> &ms) {
+    const uint32_t n = (uint32_t) M->rep.size();
+    if (n < 2 || M->rows < n) return;
+    for (float t : ms) if (!(t > 0.f)) return;
+    const std::vector<uint32_t> &b = M->bounds;
+    std::vector<double> dens(n); double total = 0.0;
+    for (uint32_t r = 0; r < n; ++r) { dens[r] = ms[r] / std::max<uint32_t>(b[r + 1] - b[r], 1u); total += ms[r]; }
+    std::vector<uint32_t> nb{ 0u }; uint32_t r = 0; double acc = 0.0;
+    for (uint32_t k = 1; k < n; ++k) {
+        const double target = total * k / n;
+        while (r < n - 1 && acc + ms[r] < target) { acc += ms[r]; ++r; }
+        double y = dens[r] > 0.0 ? b[r] + (target - acc) / dens[r] : b[r + 1];
+        const long yi = std::lround(y);
+        nb.push_back((uint32_t) std::min<long>(std::max<long>(yi, (long) nb.back() + 1), (long) M->rows - (long) (n - k)));      /* every device keeps at least one row */
+    }
+    nb.push_back(M->rows);
+    M->bounds = nb;
+}
+
+int destroy(HarMultiImpl *M) {
+    if (!M) return 0;
+    for (Replica &R : M->rep) {
+        (void) hipSetDevice(R.device);
+        (void) hipDeviceSynchronize();
+        if (R.comm && g_rccl.CommDestroy) (void) g_rccl.CommDestroy(R.comm);
+        if (R.integ) (void) har_integrator_destroy(R.integ);
+        if (R.scene) (void) har_scene_destroy(R.scene);
+        if (R.film) (void) hipFree(R.film);
+        if (R.t0) (void) hipEventDestroy(R.t0); if (R.t1) (void) hipEventDestroy(R.t1); if (R.done) (void) hipEventDestroy(R.done);
+        if (R.stream) (void) hipStreamDestroy(R.stream);
+    }
+    if (!M->rep.empty()) {
+        (void) hipSetDevice(M->rep[0].device);
+        for (Replica &R : M->rep) if (R.staging) (void) hipFree(R.staging);
+        if (M->start) (void) hipEventDestroy(M->start);
+    }
+    delete M;
+    return 0;
+}
+
+} // namespace
+
+extern "C" {
+
+int har_multi_create(const HarSceneDesc *desc, int integrator_type, int32_t max_depth, int32_t rr_depth, uint32_t chunk_lanes, const int *devices, uint32_t n_devices,
+                     HarMulti *out) {
+    if (!desc || !out || !devices || n_devices == 0) return har_set_error("har_multi_create: null argument / no device");
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev == 0) return har_set_error("hip_ad_rgb requires a HIP device (no CPU fallback)");
+    bool distinct = true;
+    for (uint32_t a = 0; a < n_devices; ++a) {
+        if (devices[a] < 0 || devices[a] >= ndev) return har_set_error("har_multi_create: device " + std::to_string(devices[a]) + " does not exist (" + std::to_string(ndev) + " visible)");
+        for (uint32_t b = 0; b < a; ++b) distinct = distinct && devices[a] != devices[b];
+    }
+    int caller_device = 0; (void) hipGetDevice(&caller_device);
+    HarMultiImpl *M = new HarMultiImpl();
+    M->rep.resize(n_devices);
+    if (getenv("HAR_MULTI_ADAPT_FRAMES")) M->adapt_frames = (uint32_t) atoi(getenv("HAR_MULTI_ADAPT_FRAMES"));
+    int rc = 0;
+    for (uint32_t k = 0; k < n_devices && !rc; ++k) {
+        Replica &R = M->rep[k]; R.device = devices[k];
+        if (hipSetDevice(R.device) != hipSuccess) { rc = har_set_error("hipSetDevice failed"); break; }
+        rc = har_scene_create(desc, &R.scene);                                   /* the replica: BVH build + upload on THIS device */
+        if (!rc) rc = har_integrator_create(integrator_type, max_depth, rr_depth, chunk_lanes, &R.integ);
+        if (!rc && k > 0 && hipStreamCreateWithFlags(&R.stream, hipStreamNonBlocking) != hipSuccess) rc = har_set_error("hipStreamCreate failed");
+        if (!rc && (hipEventCreate(&R.t0) != hipSuccess || hipEventCreate(&R.t1) != hipSuccess || hipEventCreateWithFlags(&R.done, hipEventDisableTiming) != hipSuccess))
+            rc = har_set_error("hipEventCreate failed");
+    }
+    if (!rc) { (void) hipSetDevice(devices[0]); if (hipEventCreateWithFlags(&M->start, hipEventDisableTiming) != hipSuccess) rc = har_set_error("hipEventCreate failed"); }
+    /* the collective: RCCL for a group of distinct devices; peer copies + adds otherwise (one physical device named several times cannot form a communicator) */
+    const char *force = getenv("HAR_MULTI_REDUCE");
+    if (!rc && n_devices > 1) {
+        std::string why;
+        if (force && std::string(force) == "copy") M->reduce_note = "peer copies + add (HAR_MULTI_REDUCE=copy)";
+        else if (!distinct) M->reduce_note = "peer copies + add (a device is named more than once: no communicator)";
+        else if (!g_rccl.load(why)) M->reduce_note = "peer copies + add (" + why + ")";
+        else {
+            std::vector<void *> comms(n_devices, nullptr);
+            const int e = g_rccl.CommInitAll(comms.data(), (int) n_devices, devices);
+            if (e != 0) M->reduce_note = std::string("peer copies + add (ncclCommInitAll: ") + (g_rccl.GetErrorString ? g_rccl.GetErrorString(e) : "error") + ")";
+            else { for (uint32_t k = 0; k < n_devices; ++k) M->rep[k].comm = comms[k]; M->use_rccl = true; M->reduce_note = "ncclReduce (RCCL), one group call"; }
+        }
+    } else if (!rc) M->reduce_note = "single device: no collective";
+    (void) hipSetDevice(caller_device);
+    if (rc) { destroy(M); return rc; }
+    *out = M;
+    return 0;
+}
+
+int har_multi_destroy(HarMulti M) { int dev = 0; (void) hipGetDevice(&dev); const int rc = destroy(M); (void) hipSetDevice(dev); return rc; }
+
+int har_multi_replica(HarMulti M, uint32_t k, HarScene *scene, HarIntegrator *integrator, int *device) {
+    if (!M || k >= M->rep.size()) return har_set_error("har_multi_replica: invalid index");
+    if (scene) *scene = M->rep[k].scene;
+    if (integrator) *integrator = M->rep[k].integ;
+    if (device) *device = M->rep[k].device;
+    return 0;
+}
+
+int har_multi_info(HarMulti M, uint32_t *n_devices, uint32_t *band_rows, float *band_ms, char *reduce, uint32_t reduce_len) {
+    if (!M) return har_set_error("null group");
+    const uint32_t n = (uint32_t) M->rep.size();
+    if (n_devices) *n_devices = n;
+    if (band_rows) for (uint32_t r = 0; r <= n; ++r) band_rows[r] = r < M->bounds.size() ? M->bounds[r] : 0u;
+    if (band_ms) for (uint32_t r = 0; r < n; ++r) band_ms[r] = r < M->last_ms.size() ? M->last_ms[r] : 0.f;
+    if (reduce && reduce_len) snprintf(reduce, reduce_len, "%s", M->reduce_note.c_str());
+    return 0;
+}
+
+int har_multi_render(HarMulti M, const HarSensor *sensor, uint32_t seed, uint32_t spp, int pixel_format, float *image, float *film_out, void *stream) {
+    if (!M || !sensor) return har_set_error("har_multi_render: null argument");
+    if (!image && !film_out) return har_set_error("har_multi_render: neither an image nor a film buffer");
+    const uint32_t n = (uint32_t) M->rep.size();
+    DSensor C; std::string e;
+    if (!lower_sensor(*sensor, C, e)) return har_set_error(e);
+    uint32_t spp_pass = spp, n_passes = 1;
+    if (har_render_pass_layout(M->rep[0].integ, sensor, spp, &spp_pass, &n_passes)) return 1;
+    const uint64_t row_lanes = (uint64_t) C.samp_w * spp_pass;                 /* lanes of one pixel row of the (per-pass) wavefront: bands are whole rows */
+    if (row_lanes * C.samp_h > 0xffffffffull) return har_set_error("the per-pass wavefront exceeds 2^32 - 1 lanes");
+    const size_t film_floats = (size_t) C.crop_w * C.crop_h * 4;
+    int caller_device = 0; (void) hipGetDevice(&caller_device);
+    struct Back { int d; ~Back() { (void) hipSetDevice(d); } } back{ caller_device };
+    hipStream_t s0 = (hipStream_t) stream;
+    /* (re)allocate the films when the sensor's crop window changed */
+    if (film_floats != M->film_floats) {
+        for (Replica &R : M->rep) {
+            MULTI_TRY(hipSetDevice(R.device));
+            MULTI_TRY(hipDeviceSynchronize());
+            if (R.film) { (void) hipFree(R.film); R.film = nullptr; }
+            MULTI_TRY(hipMalloc((void **) &R.film, film_floats * sizeof(float)));
+        }
+        MULTI_TRY(hipSetDevice(M->rep[0].device));
+        for (uint32_t k = 1; k < n; ++k) {
+            Replica &R = M->rep[k];
+            if (R.staging) { (void) hipFree(R.staging); R.staging = nullptr; }
+            if (!M->use_rccl) MULTI_TRY(hipMalloc((void **) &R.staging, film_floats * sizeof(float)));
+        }
+        M->film_floats = film_floats;
+    }
+    /* the previous frame's device times -> this frame's bands (events of a frame that finished: no waiting; a frame still in flight keeps the bands) */
+    if (M->rows != C.samp_h || M->bounds.size() != n + 1) cut_bands(M, C.samp_h);
+    else if (n > 1 && M->frames < M->adapt_frames) {
+        std::vector<float> ms(n, 0.f); bool ready = true;
+        for (uint32_t k = 0; k < n && ready; ++k) {
+            Replica &R = M->rep[k];
+            if (!R.timed) { ready = false; break; }
+            (void) hipSetDevice(R.device);
+            ready = hipEventQuery(R.t1) == hipSuccess && hipEventElapsedTime(&ms[k], R.t0, R.t1) == hipSuccess;
+        }
+        (void) hipGetLastError();
+        if (ready) { M->last_ms = ms; rebalance(M, ms); M->frames++; }
+    }
+    /* 1. every device renders its band */
+    MULTI_TRY(hipSetDevice(M->rep[0].device));
+    MULTI_TRY(hipEventRecord(M->start, s0));
+    int rc = 0;
+    for (uint32_t k = 0; k < n; ++k) {
+        Replica &R = M->rep[k];
+        MULTI_TRY(hipSetDevice(R.device));
+        hipStream_t s = k == 0 ? s0 : R.stream;
+        if (k > 0) MULTI_TRY(hipStreamWaitEvent(s, M->start, 0));                /* after whatever the caller enqueued before the call (parameter updates) */
+        MULTI_TRY(hipMemsetAsync(R.film, 0, film_floats * sizeof(float), s));
+        MULTI_TRY(hipEventRecord(R.t0, s));
+        const uint64_t lb = (uint64_t) M->bounds[k] * row_lanes, le = (uint64_t) M->bounds[k + 1] * row_lanes;
+        if (n == 1) rc = har_render(R.scene, R.integ, sensor, seed, spp, 0, 0, R.film, (void *) s);
+        else if (le > lb) rc = har_render(R.scene, R.integ, sensor, seed, spp, lb, le, R.film, (void *) s);
+        if (rc) return rc;
+        MULTI_TRY(hipEventRecord(R.t1, s)); R.timed = true;
+        if (k > 0) MULTI_TRY(hipEventRecord(R.done, s));
+    }
+    /* 2. ONE collective: the films meet on device 0 */
+    if (n > 1 && M->use_rccl) {
+        int e2 = g_rccl.GroupStart();
+        for (uint32_t k = 0; k < n && !e2; ++k) {
+            Replica &R = M->rep[k];
+            (void) hipSetDevice(R.device);
+            e2 = g_rccl.Reduce(R.film, R.film, film_floats, 7 /* ncclFloat */, 0 /* ncclSum */, 0, R.comm, k == 0 ? s0 : R.stream);
+        }
+        const int e3 = g_rccl.GroupEnd();
+        if (e2 || e3) return har_set_error(std::string("ncclReduce: ") + (g_rccl.GetErrorString ? g_rccl.GetErrorString(e2 ? e2 : e3) : "error"));
+    } else if (n > 1) {
+        MULTI_TRY(hipSetDevice(M->rep[0].device));
+        for (uint32_t k = 1; k < n; ++k) {
+            Replica &R = M->rep[k];
+            MULTI_TRY(hipStreamWaitEvent(s0, R.done, 0));
+            MULTI_TRY(hipMemcpyPeerAsync(R.staging, M->rep[0].device, R.film, R.device, film_floats * sizeof(float), s0));
+            launch_add(s0, R.staging, M->rep[0].film, (uint32_t) film_floats);
+        }
+        MULTI_TRY(hipGetLastError());
+    }
+    /* 3. device 0: the accumulated film and / or the developed image, in the caller's stream order */
+    MULTI_TRY(hipSetDevice(M->rep[0].device));
+    if (film_out) MULTI_TRY(hipMemcpyAsync(film_out, M->rep[0].film, film_floats * sizeof(float), hipMemcpyDeviceToDevice, s0));
+    if (image) rc = har_film_develop_format(M->rep[0].film, C.crop_w, C.crop_h, pixel_format, image, (void *) s0);
+    return rc;
+}
+
+} // extern "C"

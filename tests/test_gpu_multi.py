@@ -1,0 +1,81 @@
+"""Single-call multi-GPU entry of the C ABI (har_multi_*: one host thread, a scene replica + integrator + stream per device, row bands with global lane indices,
+ONE reduce of the film on devices[0]; the reference's contract is one Integrator::render call from one thread, integrator.h:74-79).
+On a one-GPU box: a group of one device equals har_render; a group that names the device twice / three times runs the whole band + reduce machinery on it (the
+collective then is the peer-copy + add path: one physical device cannot form an RCCL communicator).  The RCCL branch needs two devices and is skipped otherwise."""
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+
+def rel_l2(a, b):
+    return float(np.linalg.norm(a.astype(np.float64) - b.astype(np.float64)) / np.linalg.norm(b.astype(np.float64)))
+
+
+def _scene(mi, res=64, spp=16):
+    return mi.load_dict(mi.instanced_spheres_scene(width=res, height=res, spp=spp, grid=3, n_u=24, n_v=12))
+
+
+def test_group_of_one_device_is_har_render(mi, O):
+    scene = _scene(mi)
+    single = mi.render(scene, spp=16, seed=3).cpu().numpy()
+    st1 = scene.integrator().stats()
+    g = mi.DeviceGroup(scene, devices=[0])
+    img = g.render(spp=16, seed=3).cpu().numpy()
+    assert rel_l2(img, single) < 1e-6 and g.stats() == st1                      # same samples: same counters; the film's float atomics have no fixed order
+    assert g.info()["reduce"].startswith("single device")
+    osc, sensor = O.scene_from_product(scene)
+    ref, ost = osc.render_path(sensor, seed=3, spp=16, max_depth=scene.integrator().max_depth, rr_depth=scene.integrator().rr_depth)
+    assert rel_l2(img, ref) < 1e-4 and g.stats()["vertices"] == ost.vertices
+    film = g.render(spp=16, seed=3, develop=False)
+    want = scene.integrator().render_film(scene, 0, 3, 16)                     # RGBW accumulation, not developed
+    assert tuple(film.shape) == (64, 64, 4) and rel_l2(film.cpu().numpy(), want.cpu().numpy()) < 1e-6
+
+
+@pytest.mark.parametrize("n", [2, 3])
+def test_bands_on_replicas_sum_to_the_single_render(mi, n):
+    scene = _scene(mi)
+    single = mi.render(scene, spp=16, seed=5).cpu().numpy()
+    st1 = scene.integrator().stats()
+    g = mi.DeviceGroup(scene, devices=[0] * n)
+    for frame in range(5):                                                      # the bands are re-cut from the measured times of the first frames
+        img = g.render(spp=16, seed=5).cpu().numpy()
+        assert rel_l2(img, single) < 1e-6, frame
+        assert g.stats() == st1, frame                                          # the union of the bands draws exactly the single render's samples
+    info = g.info()
+    assert "peer copies" in info["reduce"] and info["band_rows"][0] == 0 and info["band_rows"][-1] == 64
+    assert all(b > a for a, b in zip(info["band_rows"], info["band_rows"][1:])) and all(t > 0 for t in info["band_ms"])
+
+
+def test_replica_handles_take_parameter_updates(mi):
+    import ctypes as C
+    import torch
+    scene = _scene(mi, res=32)
+    g = mi.DeviceGroup(scene, devices=[0, 0])
+    before = g.render(spp=8, seed=1).cpu().numpy()
+    params = mi.traverse(scene)
+    key = next(k for k in params.keys() if k.endswith("reflectance.value"))
+    kind, b = scene._param_keys()[key]
+    rgb = torch.tensor([0.9, 0.1, 0.1], device="cuda")
+    for k in range(2):
+        sc, _, dev = g.replica(k)
+        assert dev == 0
+        assert mi.lib().har_scene_set_reflectance_device(sc, b.index, rgb.data_ptr(), None) == 0
+    torch.cuda.synchronize()
+    after = g.render(spp=8, seed=1).cpu().numpy()
+    params[key] = rgb; params.update()
+    want = mi.render(scene, spp=8, seed=1).cpu().numpy()
+    assert rel_l2(after, want) < 1e-6 and rel_l2(after, before) > 1e-3
+
+
+def test_two_devices_reduce_over_rccl(mi):
+    import torch
+    if torch.cuda.device_count() < 2:
+        pytest.skip("needs two GPUs (the RCCL branch of har_multi_render: ncclCommInitAll + one ncclReduce)")
+    scene = _scene(mi)
+    single = mi.render(scene, spp=16, seed=7).cpu().numpy()
+    g = mi.DeviceGroup(scene, devices=[0, 1])
+    assert "ncclReduce" in g.info()["reduce"]
+    for _ in range(4):
+        assert rel_l2(g.render(spp=16, seed=7).cpu().numpy(), single) < 1e-6
+    assert g.stats() == scene.integrator().stats()
