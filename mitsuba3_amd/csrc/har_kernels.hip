@@ -429,6 +429,9 @@ __global__ void k_sample_out(uint32_t n, uint32_t n_total, uint32_t first, const
 #ifndef HAR_EXTRA_MIN
 #define HAR_EXTRA_MIN 8u
 #endif
+#ifndef HAR_RECORD_MIN_WAVES
+#define HAR_RECORD_MIN_WAVES 4    /* waves/SIMD the record flavour of the diffuse-only shading kernel (prb's primal pass) is bounded to: 110 - 112 VGPRs at 4 */
+#endif
 #ifndef HAR_SHADE_MIN_WAVES
 #define HAR_SHADE_MIN_WAVES 4     /* __launch_bounds__ waves/SIMD of the shading kernels: caps the generic (all-BSDF) kernel at 128 VGPRs; measured 28.4 -> 24.7 ms on the materials scene */
 #endif
@@ -452,6 +455,12 @@ __global__ void k_sample_out(uint32_t n, uint32_t n_total, uint32_t first, const
 #endif
 #ifndef HAR_RESOLVE_RETIRE
 #define HAR_RESOLVE_RETIRE 1
+#endif
+#ifndef HAR_RESOLVE_ATOMIC
+#define HAR_RESOLVE_ATOMIC 0        /* 1: forward k_resolve adds an unoccluded item's contribution with ONE 16-byte load + three no-return float atomics instead of two loads, an add and a
+                                     * store.  Same bits.  Measured (round 6): +- 0 on the 1M-triangle scenes, whose shadow-ray kernel is bound by instruction issue -- and 5.3 -> 14.4 ms per
+                                     * frame on the Cornell box, whose shadow rays cost next to nothing to trace: 500 M float atomics per frame run at the memory side's fixed rate (~57 G/s,
+                                     * see TexelQueues).  Default 0. */
 #endif
 #ifndef HAR_TRAV_ORDER
 #define HAR_TRAV_ORDER 0    /* measured: 0 (node, leaf, pop) 687, 2: 660, 1: 643 Mpaths/s on the 1M-tri scene */
@@ -1025,7 +1034,7 @@ __global__ __launch_bounds__(kBlock) void k_classify(DScene S, uint32_t shard_ca
 #define HAR_TAB_BSDFS 32
 #define HAR_TAB_INSTS 128
 template <int MODE, uint32_t TYPES, bool SHAPE = false, bool INLINE = false, bool EXTRA = false, bool QUEUED = false, bool RECORD = false, bool TAB = false, bool FIRST = false>
-__global__ __launch_bounds__(kBlock, HAR_SHADE_MIN_WAVES) void k_shade(DScene S_in, ShadeParams P, uint32_t lane_base, uint32_t shard_cap, const uint32_t *count_in, WaveState in,
+__global__ __launch_bounds__(kBlock, (RECORD && TYPES == HAR_BSDF_ONLY_DIFFUSE && !SHAPE && !EXTRA) ? HAR_RECORD_MIN_WAVES : HAR_SHADE_MIN_WAVES) void k_shade(DScene S_in, ShadeParams P, uint32_t lane_base, uint32_t shard_cap, const uint32_t *count_in, WaveState in,
                                                   const float4 *h0, const uint2 *h1, WaveState out, uint32_t *count_out,
                                                   ItemArrays items, uint32_t *item_count, float4 *result, ReplayCache rc, uint64_t *pass_rng,
                                                   const float4 *dL, float *grad_slots, ShapeArrays geo, float *const *grad_tex, TexelQueues tq, float *grad_extra,
@@ -1275,7 +1284,9 @@ __global__ __launch_bounds__(kBlock, HAR_SHADE_MIN_WAVES) void k_shade(DScene S_
                 const Vec3 c = fact ? R.contrib_unit : R.contrib;
                 const uint32_t tag = (R.bsdf & 0xfffffu) | ((fact ? (uint32_t) R.nee_emitter : HAR_ITEM_NO_EMITTER) << 20) | (R.ind_active ? 0x80000000u : 0u);
                 items.s2[islot] = make_float4(c.x, c.y, c.z, __uint_as_float(tag));
-            } else items.s2[islot] = make_float4(R.contrib.x, R.contrib.y, R.contrib.z, __uint_as_float(i));      /* .w: the vertex slot (tape: where k_resolve files the visibility) */
+            } else items.s2[islot] = make_float4(R.contrib.x, R.contrib.y, R.contrib.z, __uint_as_float((HAR_RESOLVE_ATOMIC && (rc.mode == 0 || rc.mode == 1)) ? lane : i));
+            /* .w: the vertex slot in tape modes (where k_resolve files the visibility); otherwise the LANE again (HAR_RESOLVE_ATOMIC), so that k_resolve's commit reads
+             * the contribution and its destination with ONE 16-byte load */
             if (MODE == MODE_PRB_ADJOINT && !RECORD) {
                 items.s3[islot] = make_float4(R.dLr_drho.x, R.dLr_drho.y, R.dLr_drho.z, R.uv_x);
                 items.s4[islot] = make_float4(R.rel_grad.x, R.rel_grad.y, R.rel_grad.z, R.uv_y);
@@ -1516,9 +1527,19 @@ __global__ __launch_bounds__(kBlock, (MODE == MODE_PRB_ADJOINT ? 1 : HAR_TRACE_M
             if (rc.mode == 1) rc.vis[__float_as_uint(items.s1[i].w)] = T.found ? 0 : 1;      /* replay cache: per lane */
             else if (rc.mode == 3 || rc.mode == 5) rc.vis[__float_as_uint(items.s2[i].w)] = T.found ? 0 : 1; /* replay / record tape: per vertex slot */
             if (!T.found) {
+#if HAR_RESOLVE_ATOMIC
+                /* one item per lane and bounce: the add has a single writer, so a no-return atomic gives the bits of load + add + store -- without the load's round
+                 * trip in the middle of the wave's refill (the commit used to be a chain of THREE dependent loads: s1.w -> result[lane], s2) and without reading
+                 * `result` into the CU at all (the add happens at the L2) */
+                const float4 s2 = items.s2[i];
+                const uint32_t lane = (rc.mode == 0 || rc.mode == 1) ? __float_as_uint(s2.w) : __float_as_uint(items.s1[i].w);
+                float *r = reinterpret_cast<float *>(result + lane);
+                atomicAdd(r, s2.x); atomicAdd(r + 1, s2.y); atomicAdd(r + 2, s2.z);
+#else
                 const uint32_t lane = __float_as_uint(items.s1[i].w);
                 float4 s2 = items.s2[i], r = result[lane];
                 result[lane] = make_float4(r.x + s2.x, r.y + s2.y, r.z + s2.z, 0.f);
+#endif
             }
         };
 #if HAR_RESOLVE_RETIRE

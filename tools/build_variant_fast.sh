@@ -7,4 +7,4 @@ NAME=$1; shift
 mkdir -p ../../tools/variants obj_variants
 FLAGS="-O3 -std=c++17 --offload-arch=gfx950 -ffp-contract=off -fno-slp-vectorize -munsafe-fp-atomics -fPIC -Wall -Wno-unused-function"
 /opt/rocm/bin/hipcc $FLAGS "$@" -c -o obj_variants/har_kernels_$NAME.o har_kernels.hip
-/opt/rocm/bin/hipcc $FLAGS -shared -o ../../tools/variants/lib_$NAME.so obj_variants/har_kernels_$NAME.o $(ls obj/*.o | grep -v har_kernels.o) -lz
+/opt/rocm/bin/hipcc $FLAGS -shared -o ../../tools/variants/lib_$NAME.so obj_variants/har_kernels_$NAME.o $(ls obj/*.o | grep -v har_kernels.o) -lz -ldl
