@@ -456,6 +456,9 @@ __global__ void k_sample_out(uint32_t n, uint32_t n_total, uint32_t first, const
 #ifndef HAR_RESOLVE_RETIRE
 #define HAR_RESOLVE_RETIRE 1
 #endif
+#ifndef HAR_RESOLVE_LANE_S2
+#define HAR_RESOLVE_LANE_S2 0       /* 1: the forward flavours repeat the lane in s2.w, so that k_resolve's commit reads contribution + destination with one 16-byte load (no second look at s1) */
+#endif
 #ifndef HAR_RESOLVE_ATOMIC
 #define HAR_RESOLVE_ATOMIC 0        /* 1: forward k_resolve adds an unoccluded item's contribution with ONE 16-byte load + three no-return float atomics instead of two loads, an add and a
                                      * store.  Same bits.  Measured (round 6): +- 0 on the 1M-triangle scenes, whose shadow-ray kernel is bound by instruction issue -- and 5.3 -> 14.4 ms per
@@ -1284,7 +1287,7 @@ __global__ __launch_bounds__(kBlock, (RECORD && TYPES == HAR_BSDF_ONLY_DIFFUSE &
                 const Vec3 c = fact ? R.contrib_unit : R.contrib;
                 const uint32_t tag = (R.bsdf & 0xfffffu) | ((fact ? (uint32_t) R.nee_emitter : HAR_ITEM_NO_EMITTER) << 20) | (R.ind_active ? 0x80000000u : 0u);
                 items.s2[islot] = make_float4(c.x, c.y, c.z, __uint_as_float(tag));
-            } else items.s2[islot] = make_float4(R.contrib.x, R.contrib.y, R.contrib.z, __uint_as_float((HAR_RESOLVE_ATOMIC && (rc.mode == 0 || rc.mode == 1)) ? lane : i));
+            } else items.s2[islot] = make_float4(R.contrib.x, R.contrib.y, R.contrib.z, __uint_as_float(((HAR_RESOLVE_ATOMIC || HAR_RESOLVE_LANE_S2) && (rc.mode == 0 || rc.mode == 1)) ? lane : i));
             /* .w: the vertex slot in tape modes (where k_resolve files the visibility); otherwise the LANE again (HAR_RESOLVE_ATOMIC), so that k_resolve's commit reads
              * the contribution and its destination with ONE 16-byte load */
             if (MODE == MODE_PRB_ADJOINT && !RECORD) {
@@ -1536,8 +1539,9 @@ __global__ __launch_bounds__(kBlock, (MODE == MODE_PRB_ADJOINT ? 1 : HAR_TRACE_M
                 float *r = reinterpret_cast<float *>(result + lane);
                 atomicAdd(r, s2.x); atomicAdd(r + 1, s2.y); atomicAdd(r + 2, s2.z);
 #else
-                const uint32_t lane = __float_as_uint(items.s1[i].w);
-                float4 s2 = items.s2[i], r = result[lane];
+                const float4 s2 = items.s2[i];
+                const uint32_t lane = (HAR_RESOLVE_LANE_S2 && (rc.mode == 0 || rc.mode == 1)) ? __float_as_uint(s2.w) : __float_as_uint(items.s1[i].w);
+                const float4 r = result[lane];
                 result[lane] = make_float4(r.x + s2.x, r.y + s2.y, r.z + s2.z, 0.f);
 #endif
             }
