@@ -456,6 +456,9 @@ __global__ void k_sample_out(uint32_t n, uint32_t n_total, uint32_t first, const
 #ifndef HAR_RESOLVE_RETIRE
 #define HAR_RESOLVE_RETIRE 1
 #endif
+#ifndef HAR_TAPE_COMPACT
+#define HAR_TAPE_COMPACT 1          /* record tape of diffuse-only scenes: 36-byte records {dLr_drho, tag | rho, u | v} instead of 48 (k_shade<.., RECORD>, k_commit<.., COMPACT>) */
+#endif
 #ifndef HAR_RESOLVE_LANE_S2
 #define HAR_RESOLVE_LANE_S2 0       /* 1: the forward flavours repeat the lane in s2.w, so that k_resolve's commit reads contribution + destination with one 16-byte load (no second look at s1) */
 #endif
@@ -1262,9 +1265,19 @@ __global__ __launch_bounds__(kBlock, (RECORD && TYPES == HAR_BSDF_ONLY_DIFFUSE &
             const bool fact = R.nee_emitter >= 0 && (uint32_t) R.nee_emitter < HAR_ITEM_NO_EMITTER;
             const Vec3 c = fact ? R.contrib_unit : R.contrib;
             const uint32_t tag = (R.bsdf & 0xfffffu) | ((fact ? (uint32_t) R.nee_emitter : HAR_ITEM_NO_EMITTER) << 20) | (R.ind_active ? 0x80000000u : 0u);
-            tape.rec0[i] = make_float4(c.x, c.y, c.z, __uint_as_float(tag));
-            tape.rec1[i] = make_float4(R.dLr_drho.x, R.dLr_drho.y, R.dLr_drho.z, R.uv_x);
-            tape.rec2[i] = make_float4(R.rel_grad.x, R.rel_grad.y, R.rel_grad.z, R.uv_y);
+            if (HAR_TAPE_COMPACT && TYPES == HAR_BSDF_ONLY_DIFFUSE && !EXTRA) {
+                /* COMPACT record of a diffuse vertex, 36 B instead of 48: Lr_dir = dLr_drho * rho and (df / d rho) / f = 1 / rho, so {dLr_drho (for a unit radiance when the
+                 * emitter is differentiated), rho} carries the three vectors -- also at rho = 0 and radiance = 0, where the ratios Lr_dir / rho and Lr_dir / radiance do not
+                 * exist; uv.y rides in the first quarter of the rec2 array (k_commit<.., COMPACT> rebuilds the three) */
+                const Vec3 d = fact ? R.dLr_drho_unit : R.dLr_drho;
+                tape.rec0[i] = make_float4(d.x, d.y, d.z, __uint_as_float(tag));
+                tape.rec1[i] = make_float4(R.rho.x, R.rho.y, R.rho.z, R.uv_x);
+                reinterpret_cast<float *>(tape.rec2)[i] = R.uv_y;
+            } else {
+                tape.rec0[i] = make_float4(c.x, c.y, c.z, __uint_as_float(tag));
+                tape.rec1[i] = make_float4(R.dLr_drho.x, R.dLr_drho.y, R.dLr_drho.z, R.uv_x);
+                tape.rec2[i] = make_float4(R.rel_grad.x, R.rel_grad.y, R.rel_grad.z, R.uv_y);
+            }
         }
         const bool has_rec = RECORD && item_pred;
         if (RECORD) item_pred = item_pred && R.item_ray;            /* the queue of the primal pass holds shadow rays only */
@@ -1339,7 +1352,7 @@ __global__ __launch_bounds__(kBlock, (RECORD && TYPES == HAR_BSDF_ONLY_DIFFUSE &
 /* Adjoint pass of the RECORD tape (TapeArrays): bounce b's vertices in the primal pass's slot order.  Per vertex: L <- L - emission met here - [visible] Lr_dir,
  * g = dL * ([visible] dLr_dir / d slot0 + L * (df / d slot0) / f) (prb.py:227,288-313) into the colour slot / the texel-gradient queues / the emitter's slot, then
  * L and dL move on to the survivor's slot of the next bounce.  No geometry, no sampling, no BSDF code: 133 B per vertex streamed. */
-template <bool FIRST>
+template <bool FIRST, bool COMPACT = false>
 __global__ __launch_bounds__(kBlock) void k_commit(DScene S, uint32_t shard_cap, const uint32_t *count_in, TapeArrays tape, const uint8_t *vis,
                                                    float *grad_slots, float *const *grad_tex, TexelQueues tq, const float4 *result, const float4 *dL) {
     __shared__ uint32_t tq_hist[HAR_TQ_MAX], tq_base[HAR_TQ_MAX], tq_gmax;
@@ -1368,7 +1381,22 @@ __global__ __launch_bounds__(kBlock) void k_commit(DScene S, uint32_t shard_cap,
             }
             if (nx & HAR_TAPE_HAS_EM) { const float4 e = tape.rec_em[i]; L = Vec3(L.x - e.x, L.y - e.y, L.z - e.z); }
             pred = (nx & HAR_TAPE_HAS_REC) != 0u;
-            if (pred) { s2 = tape.rec0[i]; s3 = tape.rec1[i]; s4 = tape.rec2[i]; visible = (nx & HAR_TAPE_HAS_RAY) != 0u && vis[i] != 0; }
+            if (pred) {
+                s2 = tape.rec0[i]; s3 = tape.rec1[i];
+                if (COMPACT) {
+                    /* the 36-byte record of a diffuse vertex (k_shade<.., RECORD>): {d = dLr_dir / d rho [per unit radiance], tag}, {rho, u}, v  ->  the three vectors */
+                    const float v = reinterpret_cast<const float *>(tape.rec2)[i];
+                    const uint32_t tag = __float_as_uint(s2.w), emitter = (tag >> 20) & 0x7ffu;
+                    const Vec3 d(s2.x, s2.y, s2.z), rho(s3.x, s3.y, s3.z);
+                    Vec3 dfull = d;
+                    if (emitter != HAR_ITEM_NO_EMITTER) { const float *rad = S.emitters[emitter].radiance; dfull = Vec3(d.x * rad[0], d.y * rad[1], d.z * rad[2]); }
+                    const float u = s3.w;
+                    s2 = make_float4(d.x * rho.x, d.y * rho.y, d.z * rho.z, s2.w);                     /* Lr_dir (per unit radiance when the emitter is differentiated) */
+                    s3 = make_float4(dfull.x, dfull.y, dfull.z, u);
+                    s4 = make_float4(rho.x != 0.f ? 1.f / rho.x : 0.f, rho.y != 0.f ? 1.f / rho.y : 0.f, rho.z != 0.f ? 1.f / rho.z : 0.f, v);      /* used under the record's indirect-term flag only */
+                } else s4 = tape.rec2[i];
+                visible = (nx & HAR_TAPE_HAS_RAY) != 0u && vis[i] != 0;
+            }
         }
         adjoint_commit_regs(S, pred, visible, s2, s3, s4, L, dirty, dl, grad_slots, grad_tex, gacc, tq.nq ? &tq : nullptr, &rec);
         if (in_range && (nx & HAR_TAPE_DEAD) != HAR_TAPE_DEAD) {
@@ -2203,8 +2231,15 @@ void launch_tape_begin(hipStream_t s, const DSensor &C, uint32_t seed, uint32_t 
 void launch_commit(hipStream_t s, uint32_t grid, const DScene &S, uint32_t shard_cap, const uint32_t *count_in, const TapeArrays &tape, const uint8_t *vis,
                    float *grad_slots, float *const *grad_tex, const TexelQueues *tq, const float4 *result, const float4 *dL) {
     const TexelQueues no_tq{ nullptr, nullptr, nullptr, nullptr, 0u, 0u };
-    if (result) hipLaunchKernelGGL(k_commit<true>, dim3(grid), dim3(kBlock), 0, s, S, shard_cap, count_in, tape, vis, grad_slots, grad_tex, tq ? *tq : no_tq, result, dL);
-    else hipLaunchKernelGGL(k_commit<false>, dim3(grid), dim3(kBlock), 0, s, S, shard_cap, count_in, tape, vis, grad_slots, grad_tex, tq ? *tq : no_tq, result, dL);
+    /* the record layout is the primal pass's choice (launch_shade, rc.mode == 5): diffuse-only scenes write the compact record */
+    const bool compact = HAR_TAPE_COMPACT && S.bsdf_types == HAR_BSDF_ONLY_DIFFUSE;
+    if (compact) {
+        if (result) hipLaunchKernelGGL((k_commit<true, true>), dim3(grid), dim3(kBlock), 0, s, S, shard_cap, count_in, tape, vis, grad_slots, grad_tex, tq ? *tq : no_tq, result, dL);
+        else hipLaunchKernelGGL((k_commit<false, true>), dim3(grid), dim3(kBlock), 0, s, S, shard_cap, count_in, tape, vis, grad_slots, grad_tex, tq ? *tq : no_tq, result, dL);
+        return;
+    }
+    if (result) hipLaunchKernelGGL((k_commit<true, false>), dim3(grid), dim3(kBlock), 0, s, S, shard_cap, count_in, tape, vis, grad_slots, grad_tex, tq ? *tq : no_tq, result, dL);
+    else hipLaunchKernelGGL((k_commit<false, false>), dim3(grid), dim3(kBlock), 0, s, S, shard_cap, count_in, tape, vis, grad_slots, grad_tex, tq ? *tq : no_tq, result, dL);
 }
 void launch_classify(hipStream_t s, uint32_t grid, const DScene &S, uint32_t shard_cap, const uint32_t *count_in, const float4 *h0, const uint2 *h1, const MaterialQueues &mq) {
     hipLaunchKernelGGL(k_classify, dim3(grid), dim3(kBlock), 0, s, S, shard_cap, count_in, h0, h1, mq);

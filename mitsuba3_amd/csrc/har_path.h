@@ -57,6 +57,9 @@ struct ShadeResult {
     Vec3 contrib;                         /* PATH: throughput*bsdf*em*mis; PRB: Lr_dir */
     /* MODE_PRB_ADJOINT only: d Lr_dir / d slot0, and (d f / d slot0) / f at the sampled direction */
     Vec3 dLr_drho, rel_grad; bool ind_active; uint32_t bsdf; float uv_x, uv_y;
+    /* ... for the COMPACT record of diffuse-only scenes (HAR_TAPE_COMPACT, k_shade<.., RECORD> / k_commit<.., COMPACT>): d Lr_dir / d slot0 for a UNIT radiance of
+     * `nee_emitter`, and the colour of slot 0 at the vertex -- for a diffuse vertex Lr_dir = dLr_drho * rho and (df / d rho) / f = 1 / rho */
+    Vec3 dLr_drho_unit, rho;
     /* ... with HAR_SHADE_EMITTER_GRADS: d em_b / d radiance of emitter `em_index` (emission hit; -1 = none), and the NEE contribution for a UNIT
      * radiance of emitter `nee_emitter` (contrib = contrib_unit * radiance; -1 = not factorable, e.g. an environment map) */
     Vec3 em_unit; int32_t em_index; Vec3 contrib_unit; int32_t nee_emitter;
@@ -242,7 +245,7 @@ HAR_HD void shade_lane(const DScene &S, const ShadeParams &P, const PathState &s
     if (MODE == MODE_PATH || active_next) bsdf_sample<TYPES>(S, side, bin, side_ok, s1, s2x, s2y, bs);
 
     /* ---- NEE contribution (path.cpp:271-281, prb.py:210-216); visibility is resolved by the shadow kernel */
-    R.contrib = Vec3(0.f); R.dLr_drho = Vec3(0.f);
+    R.contrib = Vec3(0.f); R.dLr_drho = Vec3(0.f); R.dLr_drho_unit = Vec3(0.f); R.rho = bin.slot0;
     if (active_em) {
         float mis_em = ((TYPES & HAR_SCENE_ENVMAP) != 0u && em_delta) ? 1.f : mis_weight(ds.pdf, ev.pdf);
         if (MODE == MODE_PATH) R.contrib = st.throughput * ((ev.value * em_weight) * mis_em);
@@ -250,6 +253,7 @@ HAR_HD void shade_lane(const DScene &S, const ShadeParams &P, const PathState &s
             R.contrib = ((st.throughput * mis_em) * ev.value) * em_weight;
             if (MODE == MODE_PRB_ADJOINT) {
                 R.dLr_drho = ((st.throughput * mis_em) * ev.d_slot0) * em_weight;
+                R.dLr_drho_unit = ((st.throughput * mis_em) * ev.d_slot0) * em_unit;
                 /* em_weight = radiance * em_unit for `area` / `constant` emitters (prb.py:198-206, attached eval_emitter_direction) */
                 R.nee_emitter = ((P.flags & HAR_SHADE_EMITTER_GRADS) && S.emitters[em_sampled].type != 2u && S.emitters[em_sampled].type != 7u) ? (int32_t) em_sampled : -1;
                 R.contrib_unit = ((st.throughput * mis_em) * ev.value) * em_unit;
