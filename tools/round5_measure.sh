@@ -1,7 +1,7 @@
 #!/bin/bash
 # Round-5 measurement on the GPU box (one gpurun call): everything tools/round_measure.sh collects, plus the BASELINE configurations (C2 - C5), the band table,
 # the optimisation loops (bench.py --workload c4_loop / vertex_loop, with a kernel trace of the c4 loop) and the 8-rank rehearsal.  Outputs under gpurun_out/.
-TAG=${1:-r05}
+TAG=${1:-r06}
 cd /tmp && export TMPDIR=/tmp && cd "${GRAFT_REPO_ROOT:-/root/repo}"
 bash tools/round_measure.sh $TAG
 bash tools/gpu_profile.sh $TAG ta -- --workload instanced1m
@@ -14,3 +14,6 @@ timeout -k 5 240 rocprofv3 --kernel-trace --stats -d /tmp/prof_${TAG}_c4 -o r --
 python3 tools/rocpd_summary.py $(find /tmp/prof_${TAG}_c4 -name '*.db') --json gpurun_out/prof/${TAG}_c4_loop_kt.json > gpurun_out/prof/${TAG}_c4_loop_kt.txt 2>&1
 HAR_BENCH_SHARE_GPU=1 HAR_BENCH_BACKEND=gloo timeout 400 python3 bench.py --gpus 8 --steps 3 --warmup 1 --no-cpu-baseline > gpurun_out/bench/${TAG}_n8_rehearsal.json 2> gpurun_out/bench/${TAG}_n8_rehearsal.err; echo "n8 rehearsal rc=$?"
 ls gpurun_out/bench gpurun_out/prof | grep ${TAG} | tr '\n' ' '
+# round 6: kernel trace of the 1M-triangle vertex loop with the GPU-busy analysis, the single-call multi-GPU entry with 1 / 2 replicas on this GPU
+bash tools/prof_vertex_loop.sh ${TAG} > gpurun_out/prof/${TAG}_vertex_loop_prof.log 2>&1; tail -3 gpurun_out/prof/${TAG}_vertex_loop_kt.txt
+for k in 1 2; do HAR_BENCH_GROUP=$k timeout 300 python3 bench.py --steps 10 --warmup 3 --no-cpu-baseline --no-prb --no-secondary > gpurun_out/bench/${TAG}_group$k.json 2> gpurun_out/bench/${TAG}_group$k.err; cut -c1-160 gpurun_out/bench/${TAG}_group$k.json; done
