@@ -414,6 +414,10 @@ int har_multi_destroy(HarMulti group);
 int har_multi_replica(HarMulti group, uint32_t k, HarScene *scene, HarIntegrator *integrator, int *device);
 int har_multi_render(HarMulti group, const HarSensor *sensor, uint32_t seed, uint32_t spp, int pixel_format, float *image, float *film, void *stream);
 int har_multi_info(HarMulti group, uint32_t *n_devices, uint32_t *band_rows, float *band_ms, char *reduce, uint32_t reduce_len);
+/* the band arithmetic on its own (host only, no device): bounds[n + 1] = the current row boundaries of n bands over `rows` rows, seconds[n] = what each band cost ->
+ * out[n + 1] = boundaries of equal measured cost (every band keeps at least one row; unchanged when a time is not positive).  The same numbers as BandBalancer.update of
+ * mitsuba3_amd/distributed.py, which the multi-process route uses: tests/test_distributed_cpu.py holds the two to each other. */
+int har_band_rebalance(uint32_t rows, uint32_t n, const uint32_t *bounds, const double *seconds, uint32_t *out);
 
 /* the pass split har_render will use for `spp` samples per pixel of this sensor's crop window; fails like the reference
  * when spp is not a multiple of the pass size (integrator.cpp:177-179, sampler.cpp:93-94) */

@@ -21,6 +21,7 @@
 
 #include <dlfcn.h>
 #include <algorithm>
+#include <cmath>
 #include <cstdlib>
 #include <string>
 #include <vector>
@@ -84,24 +85,29 @@ void cut_bands(HarMultiImpl *M, uint32_t rows) {
     M->rows = rows; M->frames = 0; M->bounds.resize(n + 1);
     for (uint32_t r = 0; r <= n; ++r) M->bounds[r] = (uint32_t) ((uint64_t) rows * r / n);
 }
-/* BandBalancer.update: boundaries that equalise the integral of the piecewise-constant cost per row measured on the last frame */
-void rebalance(HarMultiImpl *M, const std::vector<float> &ms) {
-    const uint32_t n = (uint32_t) M->rep.size();
-    if (n < 2 || M->rows < n) return;
-    for (float t : ms) if (!(t > 0.f)) return;
-    const std::vector<uint32_t> &b = M->bounds;
+/* BandBalancer.update (mitsuba3_amd/distributed.py): boundaries that equalise the integral of the piecewise-constant cost per row measured on the last frame;
+ * false = the bands stay (a time that is not positive, fewer rows than devices) */
+bool rebalance_bounds(uint32_t rows, const std::vector<uint32_t> &b, const std::vector<double> &ms, std::vector<uint32_t> &out) {
+    const uint32_t n = (uint32_t) ms.size();
+    if (n < 2 || rows < n || b.size() != n + 1) return false;
+    for (double t : ms) if (!(t > 0.0)) return false;
     std::vector<double> dens(n); double total = 0.0;
     for (uint32_t r = 0; r < n; ++r) { dens[r] = ms[r] / std::max<uint32_t>(b[r + 1] - b[r], 1u); total += ms[r]; }
     std::vector<uint32_t> nb{ 0u }; uint32_t r = 0; double acc = 0.0;
     for (uint32_t k = 1; k < n; ++k) {
         const double target = total * k / n;
         while (r < n - 1 && acc + ms[r] < target) { acc += ms[r]; ++r; }
-        double y = dens[r] > 0.0 ? b[r] + (target - acc) / dens[r] : b[r + 1];
-        const long yi = std::lround(y);
-        nb.push_back((uint32_t) std::min<long>(std::max<long>(yi, (long) nb.back() + 1), (long) M->rows - (long) (n - k)));      /* every device keeps at least one row */
+        const double y = dens[r] > 0.0 ? b[r] + (target - acc) / dens[r] : b[r + 1];
+        const long yi = (long) std::nearbyint(y);                                                /* Python's round(): half to even */
+        nb.push_back((uint32_t) std::min<long>(std::max<long>(yi, (long) nb.back() + 1), (long) rows - (long) (n - k)));      /* every device keeps at least one row */
     }
-    nb.push_back(M->rows);
-    M->bounds = nb;
+    nb.push_back(rows);
+    out = nb;
+    return true;
+}
+void rebalance(HarMultiImpl *M, const std::vector<float> &ms) {
+    std::vector<double> t(ms.begin(), ms.end()); std::vector<uint32_t> nb;
+    if (rebalance_bounds(M->rows, M->bounds, t, nb)) M->bounds = nb;
 }
 
 int destroy(HarMultiImpl *M) {
@@ -171,6 +177,14 @@ int har_multi_create(const HarSceneDesc *desc, int integrator_type, int32_t max_
     (void) hipSetDevice(caller_device);
     if (rc) { destroy(M); return rc; }
     *out = M;
+    return 0;
+}
+
+int har_band_rebalance(uint32_t rows, uint32_t n, const uint32_t *bounds, const double *seconds, uint32_t *out) {
+    if (!bounds || !seconds || !out || n == 0) return har_set_error("har_band_rebalance: null argument");
+    std::vector<uint32_t> b(bounds, bounds + n + 1), nb; std::vector<double> t(seconds, seconds + n);
+    if (!rebalance_bounds(rows, b, t, nb)) nb = b;
+    for (uint32_t k = 0; k <= n; ++k) out[k] = nb[k];
     return 0;
 }
 

@@ -218,3 +218,29 @@ def test_gloo_render_backward_distributed_equals_single_rank(world):
     """render_backward_distributed (weight-film all-reduce + gradient all-reduce) with 2 ranks and with 3 ranks over 25 rows (ragged bands):
     texel, constant-albedo and emitter gradients equal the single-rank oracle's whatever the band boundaries are"""
     assert "DIST_PRB_OK %d" % world in _run_ranks(WORKER_PRB, world)[0]
+
+
+def test_c_abi_band_arithmetic_equals_the_python_balancer():
+    """har_band_rebalance (the arithmetic har_multi_render re-cuts its bands with, csrc/har_multi.hip) == BandBalancer.update (the multi-process route), on random
+    band layouts and times -- the two routes to N GPUs cut the same bands from the same measurements"""
+    import ctypes as C
+    import random
+    import mitsuba3_amd as mi
+    from mitsuba3_amd.distributed import BandBalancer
+    L = mi.lib()
+    rng = random.Random(7)
+    for trial in range(400):
+        n = rng.choice([2, 3, 4, 8]); rows = rng.choice([n, n + 1, 17, 64, 512, 4096])
+        bal = BandBalancer(rows, n)
+        if trial % 3:                       # start from uneven bands
+            cuts = sorted(rng.sample(range(1, rows), n - 1)) if rows > n else list(range(1, n))
+            bal.bounds = [0] + cuts + [rows]
+        times = [rng.uniform(0.5, 20.0) * (1e-3 if trial % 2 else 1.0) for _ in range(n)]
+        if trial % 41 == 0:
+            times[rng.randrange(n)] = 0.0   # a band without a measurement: the bands stay
+        before = list(bal.bounds)
+        out = (C.c_uint32 * (n + 1))()
+        assert L.har_band_rebalance(rows, n, (C.c_uint32 * (n + 1))(*before), (C.c_double * n)(*times), out) == 0
+        bal.update(times)
+        assert list(out) == bal.bounds, (trial, rows, n, before, times, list(out), bal.bounds)
+        assert out[0] == 0 and out[n] == rows and all(b > a for a, b in zip(out, list(out)[1:]))
