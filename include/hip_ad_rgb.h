@@ -406,6 +406,7 @@ int har_integrator_set_film_window(HarIntegrator integrator, uint32_t row_begin,
  *    har_multi_create   builds the replicas (scene description as for har_scene_create, integrator as for har_integrator_create) on devices[0 .. n_devices)
  *    har_multi_replica  the k-th replica's handles, for parameter updates (har_scene_set_* / har_scene_update_* with that device current) and statistics
  *    har_multi_render   image: DEVICE (devices[0]), H x W x 3 (x 1 for HAR_PIXEL_Y), or NULL; film: DEVICE (devices[0]), H x W x 4 accumulated RGBW, or NULL
+ *    har_multi_render_backward  the prb adjoint over the group (below)
  *    har_multi_info     band_rows[n_devices + 1] boundaries of the current bands, band_ms[n_devices] device time of the last measured frame, which collective is in use */
 typedef struct HarMultiImpl *HarMulti;
 int har_multi_create(const HarSceneDesc *desc, int integrator_type, int32_t max_depth, int32_t rr_depth, uint32_t chunk_lanes, const int *devices, uint32_t n_devices,
@@ -413,6 +414,14 @@ int har_multi_create(const HarSceneDesc *desc, int integrator_type, int32_t max_
 int har_multi_destroy(HarMulti group);
 int har_multi_replica(HarMulti group, uint32_t k, HarScene *scene, HarIntegrator *integrator, int *device);
 int har_multi_render(HarMulti group, const HarSensor *sensor, uint32_t seed, uint32_t spp, int pixel_format, float *image, float *film, void *stream);
+/* RBIntegrator.render_backward (src/python/python/ad/integrators/common.py:625-783) over the group (integrator_type HAR_INTEGRATOR_PRB): every device splats the filter weights
+ * of its band, ONE all-reduce makes W[px] complete everywhere (the adjoint of develop divides by it), every device replays its band -- primal + adjoint pass -- into ONE flat gradient
+ * buffer, ONE reduce brings the buffers to devices[0], which adds them to the caller's: grad_in = DEVICE (devices[0]), H x W x 3; grad_reflectance (bsdf_count x 3), grad_textures
+ * (HOST array of texture_count DEVICE pointers, H_t x W_t x 3 each, NULL entries skipped), grad_emitters (emitter_count x 3, or NULL: no emitter gradients) = DEVICE (devices[0])
+ * buffers the call ACCUMULATES into, as har_render_backward does.  Its bands are cut separately from har_multi_render's (the adjoint's cost profile is not the forward render's).
+ * Vertex-position / instance / BSDF-parameter gradients are not routed through the group. */
+int har_multi_render_backward(HarMulti group, const HarSensor *sensor, const float *grad_in, uint32_t seed, uint32_t spp, float *grad_reflectance, float *const *grad_textures,
+                              float *grad_emitters, void *stream);
 int har_multi_info(HarMulti group, uint32_t *n_devices, uint32_t *band_rows, float *band_ms, char *reduce, uint32_t reduce_len);
 /* the band arithmetic on its own (host only, no device): bounds[n + 1] = the current row boundaries of n bands over `rows` rows, seconds[n] = what each band cost ->
  * out[n + 1] = boundaries of equal measured cost (every band keeps at least one row; unchanged when a time is not positive).  The same numbers as BandBalancer.update of

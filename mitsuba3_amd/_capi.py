@@ -113,6 +113,7 @@ SIGNATURES = {
     "har_multi_destroy": (C.c_int, [vp]),
     "har_multi_replica": (C.c_int, [vp, C.c_uint32, C.POINTER(vp), C.POINTER(vp), C.POINTER(C.c_int)]),
     "har_multi_render": (C.c_int, [vp, C.c_void_p, C.c_uint32, C.c_uint32, C.c_int, vp, vp, vp]),
+    "har_multi_render_backward": (C.c_int, [vp, C.c_void_p, vp, C.c_uint32, C.c_uint32, vp, C.POINTER(vp), vp, vp]),
     "har_band_rebalance": (C.c_int, [C.c_uint32, C.c_uint32, C.POINTER(C.c_uint32), C.POINTER(C.c_double), C.POINTER(C.c_uint32)]),
     "har_multi_info": (C.c_int, [vp, C.POINTER(C.c_uint32), C.POINTER(C.c_uint32), C.POINTER(C.c_float), C.c_char_p, C.c_uint32]),
     "har_scene_set_texture_device": (C.c_int, [vp, C.c_uint32, vp, vp]),

@@ -2378,6 +2378,31 @@ class DeviceGroup:
                                          _ptr(out) if develop else None, None if develop else _ptr(out), _stream()))
         return out
 
+    def render_backward(self, grad_in, sensor=0, seed=0, spp=0):
+        """RBIntegrator.render_backward over the group (har_multi_render_backward): {key: gradient tensor on devices[0]} for the colour, bitmap and -- with the
+        integrator's `emitter_gradients` -- emitter-radiance parameters"""
+        if self.integrator.type != 'prb':
+            raise RuntimeError("render_backward(): only the `prb` integrator implements the adjoint pass in hip_ad_rgb")
+        torch = _torch()
+        s = self.scene.sensors()[sensor] if isinstance(sensor, int) else sensor
+        if spp:
+            s.sampler().set_sample_count(spp)
+        spp = s.sampler().sample_count()
+        w, h = s.film().crop_size()
+        if getattr(s.film(), "colour", 0) or getattr(s.film(), "alpha", False):
+            raise RuntimeError("DeviceGroup.render_backward(): rgb films only")
+        sc = self.scene
+        dev = torch.device("cuda", self.devices[0])
+        with torch.cuda.device(dev):
+            g_in = torch.as_tensor(grad_in, dtype=torch.float32, device=dev).reshape(h, w, 3).contiguous()
+            g_refl = torch.zeros((len(sc.bsdfs), 3), dtype=torch.float32, device=dev)
+            g_tex = [torch.zeros(tuple(t.shape), dtype=torch.float32, device=dev) for t in sc.textures]
+            ptrs = (C.c_void_p * max(1, len(g_tex)))(*[t.data_ptr() for t in g_tex])
+            g_emit = torch.zeros((max(1, len(sc.emitters)), 3), dtype=torch.float32, device=dev) if self.integrator.emitter_gradients else None
+            check(lib().har_multi_render_backward(self._h, C.byref(s.har), _ptr(g_in), (s.sampler().m_base_seed + int(seed)) & 0xffffffff, spp, _ptr(g_refl), ptrs,
+                                                  _ptr(g_emit) if g_emit is not None else None, _stream()))
+        return sc._gradients(g_refl, g_tex, g_emit)
+
     def replica(self, k):
         sc = C.c_void_p(); it = C.c_void_p(); dev = C.c_int()
         check(lib().har_multi_replica(self._h, int(k), C.byref(sc), C.byref(it), C.byref(dev)))

@@ -42,6 +42,8 @@ struct Rccl {
     int (*GroupStart)() = nullptr;
     int (*GroupEnd)() = nullptr;
     int (*Reduce)(const void *send, void *recv, size_t count, int datatype, int op, int root, void *comm, hipStream_t stream) = nullptr;
+    int (*AllReduce)(const void *send, void *recv, size_t count, int datatype, int op, void *comm, hipStream_t stream) = nullptr;
+    int (*Broadcast)(const void *send, void *recv, size_t count, int datatype, int root, void *comm, hipStream_t stream) = nullptr;
     const char *(*GetErrorString)(int) = nullptr;
     bool load(std::string &why) {
         if (lib) return true;
@@ -52,7 +54,8 @@ struct Rccl {
         CommInitAll = (decltype(CommInitAll)) dlsym(lib, "ncclCommInitAll"); CommDestroy = (decltype(CommDestroy)) dlsym(lib, "ncclCommDestroy");
         GroupStart = (decltype(GroupStart)) dlsym(lib, "ncclGroupStart"); GroupEnd = (decltype(GroupEnd)) dlsym(lib, "ncclGroupEnd");
         Reduce = (decltype(Reduce)) dlsym(lib, "ncclReduce"); GetErrorString = (decltype(GetErrorString)) dlsym(lib, "ncclGetErrorString");
-        if (!CommInitAll || !CommDestroy || !GroupStart || !GroupEnd || !Reduce) { why = "librccl lacks ncclCommInitAll / ncclReduce / ncclGroupStart"; lib = nullptr; return false; }
+        AllReduce = (decltype(AllReduce)) dlsym(lib, "ncclAllReduce"); Broadcast = (decltype(Broadcast)) dlsym(lib, "ncclBroadcast");
+        if (!CommInitAll || !CommDestroy || !GroupStart || !GroupEnd || !Reduce || !AllReduce || !Broadcast) { why = "librccl lacks ncclCommInitAll / ncclReduce / ncclGroupStart"; lib = nullptr; return false; }
         return true;
     }
 };
@@ -65,6 +68,11 @@ struct Replica {
     float *film = nullptr, *staging = nullptr;   /* H x W x 4; staging: on device 0, the peer copy of this replica's film (copy reduce) */
     hipEvent_t t0 = nullptr, t1 = nullptr, done = nullptr; bool timed = false;
     void *comm = nullptr;
+    /* render_backward: the band's weight film (H x W x 4, then the complete one), the adjoint image, ONE flat gradient buffer {bsdf slots, emitter slots, texture 0, 1, ...} and
+     * its staging copy on device 0 (copy reduce), the texture pointer table into the flat buffer, this band's events */
+    float *wfilm = nullptr, *grad_in = nullptr, *grads = nullptr, *grads_staging = nullptr;
+    std::vector<float *> tex_ptrs;
+    hipEvent_t b0 = nullptr, b1 = nullptr, bdone = nullptr, wdone = nullptr; bool btimed = false;
 };
 
 } // namespace
@@ -76,6 +84,10 @@ struct HarMultiImpl {
     size_t film_floats = 0;
     /* bands (rows of the sample grid), distributed.py BandBalancer */
     std::vector<uint32_t> bounds; uint32_t rows = 0, frames = 0, adapt_frames = 3; std::vector<float> last_ms;
+    /* render_backward: its own bands (the adjoint's cost profile differs from the forward render's), the layout of the flat gradient buffer, events of device 0 */
+    std::vector<uint32_t> bbounds; uint32_t brows = 0, bframes = 0; std::vector<float> blast_ms;
+    uint32_t bsdf_count = 0, emitter_count = 0; std::vector<size_t> tex_floats; size_t grad_floats = 0, bfilm_floats = 0, bimg_floats = 0;
+    hipEvent_t wsum = nullptr, gin = nullptr;
 };
 
 namespace {
@@ -105,9 +117,9 @@ bool rebalance_bounds(uint32_t rows, const std::vector<uint32_t> &b, const std::
     out = nb;
     return true;
 }
-void rebalance(HarMultiImpl *M, const std::vector<float> &ms) {
+void rebalance(uint32_t rows, std::vector<uint32_t> &bounds, const std::vector<float> &ms) {
     std::vector<double> t(ms.begin(), ms.end()); std::vector<uint32_t> nb;
-    if (rebalance_bounds(M->rows, M->bounds, t, nb)) M->bounds = nb;
+    if (rebalance_bounds(rows, bounds, t, nb)) bounds = nb;
 }
 
 int destroy(HarMultiImpl *M) {
@@ -119,13 +131,16 @@ int destroy(HarMultiImpl *M) {
         if (R.integ) (void) har_integrator_destroy(R.integ);
         if (R.scene) (void) har_scene_destroy(R.scene);
         if (R.film) (void) hipFree(R.film);
+        if (R.wfilm) (void) hipFree(R.wfilm); if (R.grad_in) (void) hipFree(R.grad_in); if (R.grads) (void) hipFree(R.grads);
+        for (hipEvent_t ev : { R.b0, R.b1, R.bdone, R.wdone }) if (ev) (void) hipEventDestroy(ev);
         if (R.t0) (void) hipEventDestroy(R.t0); if (R.t1) (void) hipEventDestroy(R.t1); if (R.done) (void) hipEventDestroy(R.done);
         if (R.stream) (void) hipStreamDestroy(R.stream);
     }
     if (!M->rep.empty()) {
         (void) hipSetDevice(M->rep[0].device);
-        for (Replica &R : M->rep) if (R.staging) (void) hipFree(R.staging);
+        for (Replica &R : M->rep) { if (R.staging) (void) hipFree(R.staging); if (R.grads_staging) (void) hipFree(R.grads_staging); }
         if (M->start) (void) hipEventDestroy(M->start);
+        if (M->wsum) (void) hipEventDestroy(M->wsum); if (M->gin) (void) hipEventDestroy(M->gin);
     }
     delete M;
     return 0;
@@ -148,6 +163,10 @@ int har_multi_create(const HarSceneDesc *desc, int integrator_type, int32_t max_
     int caller_device = 0; (void) hipGetDevice(&caller_device);
     HarMultiImpl *M = new HarMultiImpl();
     M->rep.resize(n_devices);
+    M->bsdf_count = desc->bsdf_count; M->emitter_count = desc->emitter_count;
+    for (uint32_t t = 0; t < desc->texture_count; ++t) M->tex_floats.push_back((size_t) desc->textures[t].width * desc->textures[t].height * 3);
+    M->grad_floats = 3 * ((size_t) M->bsdf_count + M->emitter_count);
+    for (size_t f : M->tex_floats) M->grad_floats += f;
     if (getenv("HAR_MULTI_ADAPT_FRAMES")) M->adapt_frames = (uint32_t) atoi(getenv("HAR_MULTI_ADAPT_FRAMES"));
     int rc = 0;
     for (uint32_t k = 0; k < n_devices && !rc; ++k) {
@@ -249,7 +268,7 @@ int har_multi_render(HarMulti M, const HarSensor *sensor, uint32_t seed, uint32_
             ready = hipEventQuery(R.t1) == hipSuccess && hipEventElapsedTime(&ms[k], R.t0, R.t1) == hipSuccess;
         }
         (void) hipGetLastError();
-        if (ready) { M->last_ms = ms; rebalance(M, ms); M->frames++; }
+        if (ready) { M->last_ms = ms; rebalance(M->rows, M->bounds, ms); M->frames++; }
     }
     /* 1. every device renders its band */
     MULTI_TRY(hipSetDevice(M->rep[0].device));
@@ -294,6 +313,144 @@ int har_multi_render(HarMulti M, const HarSensor *sensor, uint32_t seed, uint32_
     if (film_out) MULTI_TRY(hipMemcpyAsync(film_out, M->rep[0].film, film_floats * sizeof(float), hipMemcpyDeviceToDevice, s0));
     if (image) rc = har_film_develop_format(M->rep[0].film, C.crop_w, C.crop_h, pixel_format, image, (void *) s0);
     return rc;
+}
+
+} // extern "C"
+
+/* the buffers of every device summed: on device 0 (root_only) or everywhere.  RCCL: one group call; otherwise peer copies + adds on device 0 (and copies back).
+ * `buf(k)` / `staging(k)`: replica k's buffer and its landing area on device 0; `ready(k)`: the event after which replica k's buffer is complete; `count` floats */
+template <typename Buf, typename Stage, typename Ready>
+static int sum_over_devices(HarMultiImpl *M, hipStream_t s0, size_t count, bool root_only, Buf buf, Stage staging, Ready ready, hipEvent_t done0) {
+    const uint32_t n = (uint32_t) M->rep.size();
+    if (n < 2 || count == 0) return 0;
+    if (M->use_rccl) {
+        int e2 = g_rccl.GroupStart();
+        for (uint32_t k = 0; k < n && !e2; ++k) {
+            Replica &R = M->rep[k];
+            (void) hipSetDevice(R.device);
+            hipStream_t s = k == 0 ? s0 : R.stream;
+            e2 = root_only ? g_rccl.Reduce(buf(k), buf(k), count, 7, 0, 0, R.comm, s) : g_rccl.AllReduce(buf(k), buf(k), count, 7, 0, R.comm, s);
+        }
+        const int e3 = g_rccl.GroupEnd();
+        if (e2 || e3) return har_set_error(std::string("RCCL reduce: ") + (g_rccl.GetErrorString ? g_rccl.GetErrorString(e2 ? e2 : e3) : "error"));
+        return 0;
+    }
+    MULTI_TRY(hipSetDevice(M->rep[0].device));
+    for (uint32_t k = 1; k < n; ++k) {
+        Replica &R = M->rep[k];
+        MULTI_TRY(hipStreamWaitEvent(s0, ready(k), 0));
+        MULTI_TRY(hipMemcpyPeerAsync(staging(k), M->rep[0].device, buf(k), R.device, count * sizeof(float), s0));
+        launch_add(s0, staging(k), buf(0), (uint32_t) count);
+    }
+    MULTI_TRY(hipGetLastError());
+    if (root_only) return 0;
+    MULTI_TRY(hipEventRecord(done0, s0));
+    for (uint32_t k = 1; k < n; ++k) {
+        Replica &R = M->rep[k];
+        MULTI_TRY(hipSetDevice(R.device));
+        MULTI_TRY(hipStreamWaitEvent(R.stream, done0, 0));
+        MULTI_TRY(hipMemcpyPeerAsync(buf(k), R.device, buf(0), M->rep[0].device, count * sizeof(float), R.stream));
+    }
+    MULTI_TRY(hipSetDevice(M->rep[0].device));
+    return 0;
+}
+
+extern "C" {
+
+int har_multi_render_backward(HarMulti M, const HarSensor *sensor, const float *grad_in, uint32_t seed, uint32_t spp, float *grad_reflectance, float *const *grad_textures,
+                              float *grad_emitters, void *stream) {
+    if (!M || !sensor || !grad_in) return har_set_error("har_multi_render_backward: null argument");
+    const uint32_t n = (uint32_t) M->rep.size();
+    DSensor C; std::string e;
+    if (!lower_sensor(*sensor, C, e)) return har_set_error(e);
+    const uint64_t row_lanes = (uint64_t) C.samp_w * spp;
+    if (row_lanes * C.samp_h > 0xffffffffull) return har_set_error("render_backward: the wavefront exceeds 2^32 - 1 lanes");       /* common.py:358-363 */
+    const size_t film_floats = (size_t) C.crop_w * C.crop_h * 4, img_floats = (size_t) C.crop_w * C.crop_h * 3;
+    int caller_device = 0; (void) hipGetDevice(&caller_device);
+    struct Back { int d; ~Back() { (void) hipSetDevice(d); } } back{ caller_device };
+    hipStream_t s0 = (hipStream_t) stream;
+    /* buffers, on first use / when the film changed */
+    if (film_floats != M->bfilm_floats || !M->rep[0].grads) {
+        for (uint32_t k = 0; k < n; ++k) {
+            Replica &R = M->rep[k];
+            MULTI_TRY(hipSetDevice(R.device));
+            MULTI_TRY(hipDeviceSynchronize());
+            for (float **p : { &R.wfilm, &R.grad_in, &R.grads }) if (*p) { (void) hipFree(*p); *p = nullptr; }
+            MULTI_TRY(hipMalloc((void **) &R.wfilm, film_floats * sizeof(float)));
+            if (k > 0) MULTI_TRY(hipMalloc((void **) &R.grad_in, img_floats * sizeof(float)));
+            MULTI_TRY(hipMalloc((void **) &R.grads, std::max<size_t>(M->grad_floats, 1) * sizeof(float)));
+            R.tex_ptrs.clear();
+            size_t off = 3 * ((size_t) M->bsdf_count + M->emitter_count);
+            for (size_t f : M->tex_floats) { R.tex_ptrs.push_back(R.grads + off); off += f; }
+            if (!R.b0) { MULTI_TRY(hipEventCreate(&R.b0)); MULTI_TRY(hipEventCreate(&R.b1)); MULTI_TRY(hipEventCreateWithFlags(&R.bdone, hipEventDisableTiming)); MULTI_TRY(hipEventCreateWithFlags(&R.wdone, hipEventDisableTiming)); }
+        }
+        MULTI_TRY(hipSetDevice(M->rep[0].device));
+        for (uint32_t k = 1; k < n; ++k) {
+            Replica &R = M->rep[k];
+            if (R.grads_staging) { (void) hipFree(R.grads_staging); R.grads_staging = nullptr; }
+            if (!M->use_rccl) MULTI_TRY(hipMalloc((void **) &R.grads_staging, std::max(std::max<size_t>(M->grad_floats, 1), film_floats) * sizeof(float)));
+        }
+        if (!M->wsum) { MULTI_TRY(hipEventCreateWithFlags(&M->wsum, hipEventDisableTiming)); MULTI_TRY(hipEventCreateWithFlags(&M->gin, hipEventDisableTiming)); }
+        M->bfilm_floats = film_floats;
+    }
+    /* bands of the adjoint (their own: its cost profile is not the forward render's), re-cut from the previous call's device times */
+    if (M->brows != C.samp_h || M->bbounds.size() != n + 1) {
+        M->brows = C.samp_h; M->bframes = 0; M->bbounds.resize(n + 1);
+        for (uint32_t r = 0; r <= n; ++r) M->bbounds[r] = (uint32_t) ((uint64_t) C.samp_h * r / n);
+    } else if (n > 1 && M->bframes < M->adapt_frames) {
+        std::vector<float> ms(n, 0.f); bool ready = true;
+        for (uint32_t k = 0; k < n && ready; ++k) {
+            Replica &R = M->rep[k];
+            if (!R.btimed) { ready = false; break; }
+            (void) hipSetDevice(R.device);
+            ready = hipEventQuery(R.b1) == hipSuccess && hipEventElapsedTime(&ms[k], R.b0, R.b1) == hipSuccess;
+        }
+        (void) hipGetLastError();
+        if (ready) { M->blast_ms = ms; rebalance(M->brows, M->bbounds, ms); M->bframes++; }
+    }
+    MULTI_TRY(hipSetDevice(M->rep[0].device));
+    MULTI_TRY(hipEventRecord(M->start, s0));
+    /* 1. the filter weights of every band's samples; their sum W[px] is needed by every device (the adjoint of develop divides by it: common.py:696-746) */
+    for (uint32_t k = 0; k < n; ++k) {
+        Replica &R = M->rep[k];
+        MULTI_TRY(hipSetDevice(R.device));
+        hipStream_t s = k == 0 ? s0 : R.stream;
+        if (k > 0) MULTI_TRY(hipStreamWaitEvent(s, M->start, 0));
+        MULTI_TRY(hipMemsetAsync(R.wfilm, 0, film_floats * sizeof(float), s));
+        const uint64_t lb = (uint64_t) M->bbounds[k] * row_lanes, le = (uint64_t) M->bbounds[k + 1] * row_lanes;
+        if (n == 1) { if (har_render_weights(sensor, seed, spp, 0, 0, R.wfilm, (void *) s)) return 1; }
+        else if (le > lb && har_render_weights(sensor, seed, spp, lb, le, R.wfilm, (void *) s)) return 1;
+        if (k > 0) { MULTI_TRY(hipEventRecord(R.wdone, s)); MULTI_TRY(hipMemcpyPeerAsync(R.grad_in, R.device, grad_in, M->rep[0].device, img_floats * sizeof(float), s)); }
+    }
+    if (sum_over_devices(M, s0, film_floats, false, [&](uint32_t k) { return M->rep[k].wfilm; }, [&](uint32_t k) { return M->rep[k].grads_staging; },
+                         [&](uint32_t k) { return M->rep[k].wdone; }, M->wsum)) return 1;
+    /* 2. every device replays its band: primal pass + adjoint pass, gradients into its own flat buffer */
+    for (uint32_t k = 0; k < n; ++k) {
+        Replica &R = M->rep[k];
+        MULTI_TRY(hipSetDevice(R.device));
+        hipStream_t s = k == 0 ? s0 : R.stream;
+        MULTI_TRY(hipEventRecord(R.b0, s));                 /* the band's own work: after the wait for every device's weights */
+        MULTI_TRY(hipMemsetAsync(R.grads, 0, std::max<size_t>(M->grad_floats, 1) * sizeof(float), s));
+        if (har_integrator_set_grad_emitters(R.integ, grad_emitters ? R.grads + 3 * (size_t) M->bsdf_count : nullptr)) return 1;
+        const uint64_t lb = (uint64_t) M->bbounds[k] * row_lanes, le = (uint64_t) M->bbounds[k + 1] * row_lanes;
+        const float *gi = k == 0 ? grad_in : R.grad_in;
+        int rc = 0;
+        if (n == 1) rc = har_render_backward(R.scene, R.integ, sensor, gi, R.wfilm, seed, spp, 0, 0, R.grads, R.tex_ptrs.empty() ? nullptr : R.tex_ptrs.data(), (void *) s);
+        else if (le > lb) rc = har_render_backward(R.scene, R.integ, sensor, gi, R.wfilm, seed, spp, lb, le, R.grads, R.tex_ptrs.empty() ? nullptr : R.tex_ptrs.data(), (void *) s);
+        if (rc) return rc;
+        MULTI_TRY(hipEventRecord(R.b1, s)); R.btimed = true;
+        if (k > 0) MULTI_TRY(hipEventRecord(R.bdone, s));
+    }
+    /* 3. ONE collective for all gradient buffers (they are one flat array per device), then device 0 adds the pieces to the caller's buffers */
+    if (sum_over_devices(M, s0, M->grad_floats, true, [&](uint32_t k) { return M->rep[k].grads; }, [&](uint32_t k) { return M->rep[k].grads_staging; },
+                         [&](uint32_t k) { return M->rep[k].bdone; }, M->gin)) return 1;
+    MULTI_TRY(hipSetDevice(M->rep[0].device));
+    Replica &R0 = M->rep[0];
+    if (grad_reflectance && M->bsdf_count) launch_add(s0, R0.grads, grad_reflectance, 3u * M->bsdf_count);
+    if (grad_emitters && M->emitter_count) launch_add(s0, R0.grads + 3 * (size_t) M->bsdf_count, grad_emitters, 3u * M->emitter_count);
+    if (grad_textures) for (size_t t = 0; t < M->tex_floats.size(); ++t) if (grad_textures[t]) launch_add(s0, R0.tex_ptrs[t], grad_textures[t], (uint32_t) M->tex_floats[t]);
+    MULTI_TRY(hipGetLastError());
+    return 0;
 }
 
 } // extern "C"
