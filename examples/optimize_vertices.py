@@ -42,7 +42,7 @@ def main():
         with torch.no_grad():                                                        # only heights move: in-plane sliding of a flat floor is a null space
             g = params[key].grad.reshape(-1, 3); g[:, 0] = 0; g[:, 2] = 0
         opt.step()
-        params.update()                                                              # the mesh's BVH is refitted in place on the GPU (har_scene_update_vertices)
+        params.update()                                                              # positions stay on the GPU: records, normals, shading triangles and the BVH refit are kernels (har_scene_update_vertices_device)
         err = (params[key].detach() - truth).reshape(-1, 3)[:, 1]
         # the corners are 40 units away; what the image constrains is the plane under the light: its height (mean of the corners) and slope
         print("iter %3d  loss %.6f  height error at the centre %.4f  slope error %.5f" % (it, float(loss), float(err.mean()), float((err[1:3].mean() - err[[0, 3]].mean()) / 80.0)))

@@ -66,13 +66,14 @@ struct Replica {
     HarScene scene = nullptr; HarIntegrator integ = nullptr;
     hipStream_t stream = nullptr;            /* private stream (device 0 renders on the caller's stream) */
     float *film = nullptr, *staging = nullptr;   /* H x W x 4; staging: on device 0, the peer copy of this replica's film (copy reduce) */
-    hipEvent_t t0 = nullptr, t1 = nullptr, done = nullptr; bool timed = false;
+    hipEvent_t done = nullptr;
+    hipEvent_t t0[2][4] = {}, t1[2][4] = {};   /* [0 = render, 1 = render_backward][slot of the BandState ring]: this replica's band, start / end */
     void *comm = nullptr;
     /* render_backward: the band's weight film (H x W x 4, then the complete one), the adjoint image, ONE flat gradient buffer {bsdf slots, emitter slots, texture 0, 1, ...} and
      * its staging copy on device 0 (copy reduce), the texture pointer table into the flat buffer, this band's events */
     float *wfilm = nullptr, *grad_in = nullptr, *grads = nullptr, *grads_staging = nullptr;
     std::vector<float *> tex_ptrs;
-    hipEvent_t b0 = nullptr, b1 = nullptr, bdone = nullptr, wdone = nullptr; bool btimed = false;
+    hipEvent_t bdone = nullptr, wdone = nullptr;
 };
 
 } // namespace
@@ -83,19 +84,30 @@ struct HarMultiImpl {
     hipEvent_t start = nullptr;              /* recorded on the caller's stream: the other devices' streams begin after it */
     size_t film_floats = 0;
     /* bands (rows of the sample grid), distributed.py BandBalancer */
-    std::vector<uint32_t> bounds; uint32_t rows = 0, frames = 0, adapt_frames = 3; std::vector<float> last_ms;
+    /* A host loop runs AHEAD of the devices: when frame f + 1 is enqueued, frame f has usually not finished, so "the previous frame's times" do not exist yet.  Every
+     * frame therefore records its bands' events into one of four slots together with the bounds it used; a call looks, newest first, for a slot whose events have all
+     * completed and re-cuts the bands from THAT frame's bounds and times (nothing waits; a synchronous caller simply finds the last frame).  After `adapt_frames`
+     * re-cuts the bands are frozen. */
+    struct BandState {
+        std::vector<uint32_t> bounds; uint32_t rows = 0, frames = 0; std::vector<float> last_ms;
+        struct Slot { std::vector<uint32_t> bounds; bool valid = false; } slot[4]; uint32_t next = 0;
+        uint32_t skip = 0;                     /* frames not to measure: the first frame on a new sample grid pays workspace allocation and code-object loads on every device */
+    } bands[2];                                /* 0 = render, 1 = render_backward (the adjoint's cost profile is not the forward render's) */
+    uint32_t adapt_frames = 3;
     /* render_backward: its own bands (the adjoint's cost profile differs from the forward render's), the layout of the flat gradient buffer, events of device 0 */
-    std::vector<uint32_t> bbounds; uint32_t brows = 0, bframes = 0; std::vector<float> blast_ms;
     uint32_t bsdf_count = 0, emitter_count = 0; std::vector<size_t> tex_floats; size_t grad_floats = 0, bfilm_floats = 0, bimg_floats = 0;
     hipEvent_t wsum = nullptr, gin = nullptr;
 };
 
 namespace {
 
-void cut_bands(HarMultiImpl *M, uint32_t rows) {
+void cut_bands(HarMultiImpl *M, int kind, uint32_t rows) {
     const uint32_t n = (uint32_t) M->rep.size();
-    M->rows = rows; M->frames = 0; M->bounds.resize(n + 1);
-    for (uint32_t r = 0; r <= n; ++r) M->bounds[r] = (uint32_t) ((uint64_t) rows * r / n);
+    HarMultiImpl::BandState &B = M->bands[kind];
+    B.rows = rows; B.frames = 0; B.bounds.resize(n + 1);
+    for (uint32_t r = 0; r <= n; ++r) B.bounds[r] = (uint32_t) ((uint64_t) rows * r / n);
+    for (auto &sl : B.slot) sl.valid = false;
+    B.skip = 1;
 }
 /* BandBalancer.update (mitsuba3_amd/distributed.py): boundaries that equalise the integral of the piecewise-constant cost per row measured on the last frame;
  * false = the bands stay (a time that is not positive, fewer rows than devices) */
@@ -117,9 +129,34 @@ bool rebalance_bounds(uint32_t rows, const std::vector<uint32_t> &b, const std::
     out = nb;
     return true;
 }
-void rebalance(uint32_t rows, std::vector<uint32_t> &bounds, const std::vector<float> &ms) {
-    std::vector<double> t(ms.begin(), ms.end()); std::vector<uint32_t> nb;
-    if (rebalance_bounds(rows, bounds, t, nb)) bounds = nb;
+/* the bands of this call: (re)cut for a new sample grid, else re-cut from the newest measured frame that has finished; returns the ring slot this call records into */
+uint32_t begin_bands(HarMultiImpl *M, int kind, uint32_t rows) {
+    const uint32_t n = (uint32_t) M->rep.size();
+    HarMultiImpl::BandState &B = M->bands[kind];
+    if (B.rows != rows || B.bounds.size() != n + 1) cut_bands(M, kind, rows);
+    else if (n > 1 && B.frames < M->adapt_frames) {
+        for (uint32_t age = 1; age <= 4; ++age) {
+            const uint32_t idx = (B.next + 4u - age) & 3u;
+            if (!B.slot[idx].valid) continue;
+            std::vector<float> ms(n, 0.f); bool ready = true;
+            for (uint32_t k = 0; k < n && ready; ++k) {
+                Replica &R = M->rep[k];
+                (void) hipSetDevice(R.device);
+                ready = hipEventQuery(R.t1[kind][idx]) == hipSuccess && hipEventElapsedTime(&ms[k], R.t0[kind][idx], R.t1[kind][idx]) == hipSuccess;
+            }
+            (void) hipGetLastError();
+            if (!ready) continue;                                  /* still in flight: try an older frame */
+            std::vector<double> t(ms.begin(), ms.end()); std::vector<uint32_t> nb;
+            if (rebalance_bounds(B.rows, B.slot[idx].bounds, t, nb)) B.bounds = nb;
+            B.last_ms = ms; B.frames++;
+            for (auto &sl : B.slot) sl.valid = false;              /* frames measured with older bounds are obsolete */
+            break;
+        }
+    }
+    const uint32_t idx = B.next; B.next = (B.next + 1u) & 3u;
+    B.slot[idx].bounds = B.bounds; B.slot[idx].valid = n > 1 && B.skip == 0;
+    if (B.skip) --B.skip;
+    return idx;
 }
 
 int destroy(HarMultiImpl *M) {
@@ -132,8 +169,8 @@ int destroy(HarMultiImpl *M) {
         if (R.scene) (void) har_scene_destroy(R.scene);
         if (R.film) (void) hipFree(R.film);
         if (R.wfilm) (void) hipFree(R.wfilm); if (R.grad_in) (void) hipFree(R.grad_in); if (R.grads) (void) hipFree(R.grads);
-        for (hipEvent_t ev : { R.b0, R.b1, R.bdone, R.wdone }) if (ev) (void) hipEventDestroy(ev);
-        if (R.t0) (void) hipEventDestroy(R.t0); if (R.t1) (void) hipEventDestroy(R.t1); if (R.done) (void) hipEventDestroy(R.done);
+        for (hipEvent_t ev : { R.bdone, R.wdone, R.done }) if (ev) (void) hipEventDestroy(ev);
+        for (int kind = 0; kind < 2; ++kind) for (int q = 0; q < 4; ++q) { if (R.t0[kind][q]) (void) hipEventDestroy(R.t0[kind][q]); if (R.t1[kind][q]) (void) hipEventDestroy(R.t1[kind][q]); }
         if (R.stream) (void) hipStreamDestroy(R.stream);
     }
     if (!M->rep.empty()) {
@@ -175,8 +212,9 @@ int har_multi_create(const HarSceneDesc *desc, int integrator_type, int32_t max_
         rc = har_scene_create(desc, &R.scene);                                   /* the replica: BVH build + upload on THIS device */
         if (!rc) rc = har_integrator_create(integrator_type, max_depth, rr_depth, chunk_lanes, &R.integ);
         if (!rc && k > 0 && hipStreamCreateWithFlags(&R.stream, hipStreamNonBlocking) != hipSuccess) rc = har_set_error("hipStreamCreate failed");
-        if (!rc && (hipEventCreate(&R.t0) != hipSuccess || hipEventCreate(&R.t1) != hipSuccess || hipEventCreateWithFlags(&R.done, hipEventDisableTiming) != hipSuccess))
-            rc = har_set_error("hipEventCreate failed");
+        if (!rc && hipEventCreateWithFlags(&R.done, hipEventDisableTiming) != hipSuccess) rc = har_set_error("hipEventCreate failed");
+        for (int kind = 0; kind < 2 && !rc; ++kind) for (int q = 0; q < 4 && !rc; ++q)
+            if (hipEventCreate(&R.t0[kind][q]) != hipSuccess || hipEventCreate(&R.t1[kind][q]) != hipSuccess) rc = har_set_error("hipEventCreate failed");
     }
     if (!rc) { (void) hipSetDevice(devices[0]); if (hipEventCreateWithFlags(&M->start, hipEventDisableTiming) != hipSuccess) rc = har_set_error("hipEventCreate failed"); }
     /* the collective: RCCL for a group of distinct devices; peer copies + adds otherwise (one physical device named several times cannot form a communicator) */
@@ -221,8 +259,9 @@ int har_multi_info(HarMulti M, uint32_t *n_devices, uint32_t *band_rows, float *
     if (!M) return har_set_error("null group");
     const uint32_t n = (uint32_t) M->rep.size();
     if (n_devices) *n_devices = n;
-    if (band_rows) for (uint32_t r = 0; r <= n; ++r) band_rows[r] = r < M->bounds.size() ? M->bounds[r] : 0u;
-    if (band_ms) for (uint32_t r = 0; r < n; ++r) band_ms[r] = r < M->last_ms.size() ? M->last_ms[r] : 0.f;
+    const HarMultiImpl::BandState &B = M->bands[0];
+    if (band_rows) for (uint32_t r = 0; r <= n; ++r) band_rows[r] = r < B.bounds.size() ? B.bounds[r] : 0u;
+    if (band_ms) for (uint32_t r = 0; r < n; ++r) band_ms[r] = r < B.last_ms.size() ? B.last_ms[r] : 0.f;
     if (reduce && reduce_len) snprintf(reduce, reduce_len, "%s", M->reduce_note.c_str());
     return 0;
 }
@@ -257,19 +296,8 @@ int har_multi_render(HarMulti M, const HarSensor *sensor, uint32_t seed, uint32_
         }
         M->film_floats = film_floats;
     }
-    /* the previous frame's device times -> this frame's bands (events of a frame that finished: no waiting; a frame still in flight keeps the bands) */
-    if (M->rows != C.samp_h || M->bounds.size() != n + 1) cut_bands(M, C.samp_h);
-    else if (n > 1 && M->frames < M->adapt_frames) {
-        std::vector<float> ms(n, 0.f); bool ready = true;
-        for (uint32_t k = 0; k < n && ready; ++k) {
-            Replica &R = M->rep[k];
-            if (!R.timed) { ready = false; break; }
-            (void) hipSetDevice(R.device);
-            ready = hipEventQuery(R.t1) == hipSuccess && hipEventElapsedTime(&ms[k], R.t0, R.t1) == hipSuccess;
-        }
-        (void) hipGetLastError();
-        if (ready) { M->last_ms = ms; rebalance(M->rows, M->bounds, ms); M->frames++; }
-    }
+    const uint32_t slot = begin_bands(M, 0, C.samp_h);
+    const std::vector<uint32_t> &bounds = M->bands[0].bounds;
     /* 1. every device renders its band */
     MULTI_TRY(hipSetDevice(M->rep[0].device));
     MULTI_TRY(hipEventRecord(M->start, s0));
@@ -280,12 +308,12 @@ int har_multi_render(HarMulti M, const HarSensor *sensor, uint32_t seed, uint32_
         hipStream_t s = k == 0 ? s0 : R.stream;
         if (k > 0) MULTI_TRY(hipStreamWaitEvent(s, M->start, 0));                /* after whatever the caller enqueued before the call (parameter updates) */
         MULTI_TRY(hipMemsetAsync(R.film, 0, film_floats * sizeof(float), s));
-        MULTI_TRY(hipEventRecord(R.t0, s));
-        const uint64_t lb = (uint64_t) M->bounds[k] * row_lanes, le = (uint64_t) M->bounds[k + 1] * row_lanes;
+        MULTI_TRY(hipEventRecord(R.t0[0][slot], s));
+        const uint64_t lb = (uint64_t) bounds[k] * row_lanes, le = (uint64_t) bounds[k + 1] * row_lanes;
         if (n == 1) rc = har_render(R.scene, R.integ, sensor, seed, spp, 0, 0, R.film, (void *) s);
         else if (le > lb) rc = har_render(R.scene, R.integ, sensor, seed, spp, lb, le, R.film, (void *) s);
         if (rc) return rc;
-        MULTI_TRY(hipEventRecord(R.t1, s)); R.timed = true;
+        MULTI_TRY(hipEventRecord(R.t1[0][slot], s));
         if (k > 0) MULTI_TRY(hipEventRecord(R.done, s));
     }
     /* 2. ONE collective: the films meet on device 0 */
@@ -382,7 +410,7 @@ int har_multi_render_backward(HarMulti M, const HarSensor *sensor, const float *
             R.tex_ptrs.clear();
             size_t off = 3 * ((size_t) M->bsdf_count + M->emitter_count);
             for (size_t f : M->tex_floats) { R.tex_ptrs.push_back(R.grads + off); off += f; }
-            if (!R.b0) { MULTI_TRY(hipEventCreate(&R.b0)); MULTI_TRY(hipEventCreate(&R.b1)); MULTI_TRY(hipEventCreateWithFlags(&R.bdone, hipEventDisableTiming)); MULTI_TRY(hipEventCreateWithFlags(&R.wdone, hipEventDisableTiming)); }
+            if (!R.bdone) { MULTI_TRY(hipEventCreateWithFlags(&R.bdone, hipEventDisableTiming)); MULTI_TRY(hipEventCreateWithFlags(&R.wdone, hipEventDisableTiming)); }
         }
         MULTI_TRY(hipSetDevice(M->rep[0].device));
         for (uint32_t k = 1; k < n; ++k) {
@@ -394,20 +422,8 @@ int har_multi_render_backward(HarMulti M, const HarSensor *sensor, const float *
         M->bfilm_floats = film_floats;
     }
     /* bands of the adjoint (their own: its cost profile is not the forward render's), re-cut from the previous call's device times */
-    if (M->brows != C.samp_h || M->bbounds.size() != n + 1) {
-        M->brows = C.samp_h; M->bframes = 0; M->bbounds.resize(n + 1);
-        for (uint32_t r = 0; r <= n; ++r) M->bbounds[r] = (uint32_t) ((uint64_t) C.samp_h * r / n);
-    } else if (n > 1 && M->bframes < M->adapt_frames) {
-        std::vector<float> ms(n, 0.f); bool ready = true;
-        for (uint32_t k = 0; k < n && ready; ++k) {
-            Replica &R = M->rep[k];
-            if (!R.btimed) { ready = false; break; }
-            (void) hipSetDevice(R.device);
-            ready = hipEventQuery(R.b1) == hipSuccess && hipEventElapsedTime(&ms[k], R.b0, R.b1) == hipSuccess;
-        }
-        (void) hipGetLastError();
-        if (ready) { M->blast_ms = ms; rebalance(M->brows, M->bbounds, ms); M->bframes++; }
-    }
+    const uint32_t slot = begin_bands(M, 1, C.samp_h);
+    const std::vector<uint32_t> &bbounds = M->bands[1].bounds;
     MULTI_TRY(hipSetDevice(M->rep[0].device));
     MULTI_TRY(hipEventRecord(M->start, s0));
     /* 1. the filter weights of every band's samples; their sum W[px] is needed by every device (the adjoint of develop divides by it: common.py:696-746) */
@@ -417,7 +433,7 @@ int har_multi_render_backward(HarMulti M, const HarSensor *sensor, const float *
         hipStream_t s = k == 0 ? s0 : R.stream;
         if (k > 0) MULTI_TRY(hipStreamWaitEvent(s, M->start, 0));
         MULTI_TRY(hipMemsetAsync(R.wfilm, 0, film_floats * sizeof(float), s));
-        const uint64_t lb = (uint64_t) M->bbounds[k] * row_lanes, le = (uint64_t) M->bbounds[k + 1] * row_lanes;
+        const uint64_t lb = (uint64_t) bbounds[k] * row_lanes, le = (uint64_t) bbounds[k + 1] * row_lanes;
         if (n == 1) { if (har_render_weights(sensor, seed, spp, 0, 0, R.wfilm, (void *) s)) return 1; }
         else if (le > lb && har_render_weights(sensor, seed, spp, lb, le, R.wfilm, (void *) s)) return 1;
         if (k > 0) { MULTI_TRY(hipEventRecord(R.wdone, s)); MULTI_TRY(hipMemcpyPeerAsync(R.grad_in, R.device, grad_in, M->rep[0].device, img_floats * sizeof(float), s)); }
@@ -429,16 +445,16 @@ int har_multi_render_backward(HarMulti M, const HarSensor *sensor, const float *
         Replica &R = M->rep[k];
         MULTI_TRY(hipSetDevice(R.device));
         hipStream_t s = k == 0 ? s0 : R.stream;
-        MULTI_TRY(hipEventRecord(R.b0, s));                 /* the band's own work: after the wait for every device's weights */
+        MULTI_TRY(hipEventRecord(R.t0[1][slot], s));                 /* the band's own work: after the wait for every device's weights */
         MULTI_TRY(hipMemsetAsync(R.grads, 0, std::max<size_t>(M->grad_floats, 1) * sizeof(float), s));
         if (har_integrator_set_grad_emitters(R.integ, grad_emitters ? R.grads + 3 * (size_t) M->bsdf_count : nullptr)) return 1;
-        const uint64_t lb = (uint64_t) M->bbounds[k] * row_lanes, le = (uint64_t) M->bbounds[k + 1] * row_lanes;
+        const uint64_t lb = (uint64_t) bbounds[k] * row_lanes, le = (uint64_t) bbounds[k + 1] * row_lanes;
         const float *gi = k == 0 ? grad_in : R.grad_in;
         int rc = 0;
         if (n == 1) rc = har_render_backward(R.scene, R.integ, sensor, gi, R.wfilm, seed, spp, 0, 0, R.grads, R.tex_ptrs.empty() ? nullptr : R.tex_ptrs.data(), (void *) s);
         else if (le > lb) rc = har_render_backward(R.scene, R.integ, sensor, gi, R.wfilm, seed, spp, lb, le, R.grads, R.tex_ptrs.empty() ? nullptr : R.tex_ptrs.data(), (void *) s);
         if (rc) return rc;
-        MULTI_TRY(hipEventRecord(R.b1, s)); R.btimed = true;
+        MULTI_TRY(hipEventRecord(R.t1[1][slot], s));
         if (k > 0) MULTI_TRY(hipEventRecord(R.bdone, s));
     }
     /* 3. ONE collective for all gradient buffers (they are one flat array per device), then device 0 adds the pieces to the caller's buffers */

@@ -104,3 +104,18 @@ def test_group_render_backward_equals_the_single_device_adjoint(mi, n):
     # the forward render of the same group still works between adjoint calls (separate bands, shared replicas)
     img = g.render(spp=16, seed=2).cpu().numpy()
     assert rel_l2(img, mi.render(scene, spp=16, seed=2).detach().cpu().numpy()) < 1e-6
+
+
+def test_bands_adapt_in_a_loop_that_never_synchronises(mi):
+    """a host loop runs ahead of the device: the frame before the one being enqueued has usually not finished, so the bands are re-cut from the newest frame that HAS
+    (a ring of four measured frames, csrc/har_multi.hip) -- twelve frames enqueued back to back must have adapted by the end"""
+    import torch
+    scene = _scene(mi, res=128, spp=64)
+    g = mi.DeviceGroup(scene, devices=[0, 0, 0])
+    imgs = [g.render(spp=64, seed=9) for _ in range(12)]             # no .cpu(), no synchronize between the calls
+    torch.cuda.synchronize()
+    info = g.info()
+    assert all(t > 0 for t in info["band_ms"]), info                    # at least one re-cut happened from measured times
+    single = mi.render(scene, spp=64, seed=9).cpu().numpy()
+    for img in (imgs[0], imgs[-1]):
+        assert rel_l2(img.cpu().numpy(), single) < 1e-6
