@@ -108,11 +108,11 @@ def test_group_render_backward_equals_the_single_device_adjoint(mi, n):
 
 def test_bands_adapt_in_a_loop_that_never_synchronises(mi):
     """a host loop runs ahead of the device: the frame before the one being enqueued has usually not finished, so the bands are re-cut from the newest frame that HAS
-    (a ring of four measured frames, csrc/har_multi.hip) -- twelve frames enqueued back to back must have adapted by the end"""
+    (a ring of four measured frames, csrc/har_multi.hip) -- two dozen frames enqueued back to back must have adapted by the end"""
     import torch
     scene = _scene(mi, res=128, spp=64)
     g = mi.DeviceGroup(scene, devices=[0, 0, 0])
-    imgs = [g.render(spp=64, seed=9) for _ in range(12)]             # no .cpu(), no synchronize between the calls
+    imgs = [g.render(spp=64, seed=9) for _ in range(24)]             # no .cpu(), no synchronize between the calls
     torch.cuda.synchronize()
     info = g.info()
     assert all(t > 0 for t in info["band_ms"]), info                    # at least one re-cut happened from measured times
