@@ -1009,7 +1009,7 @@ int har_scene_set_emitter_radiance_device(HarScene S, uint32_t emitter, const fl
     HIP_TRY(hipMemcpyAsync(const_cast<float *>(S->ds.emitters[0].radiance) + (size_t) emitter * (sizeof(DEmitter) / sizeof(float)), dev_rgb, 3 * sizeof(float),
                            hipMemcpyDeviceToDevice, (hipStream_t) stream));
     S->emitter_host_stale = true; S->last_push_stream = (hipStream_t) stream; S->last_push_valid = true;
-    S->ds.emitter0_valid = 0u;          /* the kernels read the array again (the argument copy no longer holds the radiance) */
+    if (S->ds.emitter0_valid) S->ds.emitter0_valid = 2u;      /* the argument copy no longer holds the radiance: the kernels take those three floats from the array, the rest of the record stays in scalar registers */
     return 0;
 }
 int har_scene_accel_info(HarScene S, uint64_t info[4]) {
@@ -1045,7 +1045,7 @@ int har_scene_set_emitter_sampling_weights(HarScene S, const float *weights, uin
     if (!build_emitter_distribution(S->hs, weights, count, e)) return fail(e);
     if (!S->hs.emitter_distr.empty()) HIP_TRY(hipMemcpy(S->d_emitter_distr, S->hs.emitter_distr.data(), S->hs.emitter_distr.size() * sizeof(float), hipMemcpyHostToDevice));
     S->hs.bind_tables(S->ds, S->d_emitter_distr);
-    if (S->emitter_host_stale) S->ds.emitter0_valid = 0u;      /* a radiance pushed device-to-device is newer than the mirror bind_tables copies */
+    if (S->emitter_host_stale && S->ds.emitter0_valid) S->ds.emitter0_valid = 2u;      /* a radiance pushed device-to-device is newer than the mirror bind_tables copies */
     /* scenes with a distribution run the kernels that carry the generic emitter code */
     const bool generic = S->hs.has_envmap || S->hs.has_mesh_emitters || S->hs.has_point_emitters || !S->hs.emitter_distr.empty();
     S->ds.bsdf_types = generic ? (S->ds.bsdf_types | HAR_SCENE_ENVMAP) : (S->ds.bsdf_types & ~HAR_SCENE_ENVMAP);

@@ -230,7 +230,14 @@ HAR_HD void shade_lane(const DScene &S, const ShadeParams &P, const PathState &s
         }
         /* a scene with ONE emitter (the bench scenes): its record travels with the kernel arguments (DScene::emitter0), i.e. in scalar registers, instead of being gathered
          * by every lane -- six vector loads less in a kernel that is bound by the number of its memory transactions (k_shade, docs/rounds/r05.md item 11) */
-        else if (S.n_emitters == 1u && S.emitter0_valid) emitter_sample_direction(S.emitter0, si.p, ex, ey, ds, em_weight, MODE == MODE_PRB_ADJOINT ? &em_unit : nullptr);
+        else if (S.n_emitters == 1u && S.emitter0_valid) {
+            if (S.emitter0_valid == 2u) {      /* its radiance was pushed device-to-device since (har_scene_set_emitter_radiance_device): three floats from the array, the rest from the arguments */
+                DEmitter E0 = S.emitter0;
+                const float *rad = S.emitters[0].radiance;
+                E0.radiance[0] = rad[0]; E0.radiance[1] = rad[1]; E0.radiance[2] = rad[2];
+                emitter_sample_direction(E0, si.p, ex, ey, ds, em_weight, MODE == MODE_PRB_ADJOINT ? &em_unit : nullptr);
+            } else emitter_sample_direction(S.emitter0, si.p, ex, ey, ds, em_weight, MODE == MODE_PRB_ADJOINT ? &em_unit : nullptr);
+        }
         else emitter_sample_direction(S.emitters[index], si.p, ex, ey, ds, em_weight, MODE == MODE_PRB_ADJOINT ? &em_unit : nullptr);
         ds.pdf *= sel_pmf; em_weight = em_weight * wgt; em_unit *= wgt; em_sampled = index;
         active_em = ds.pdf != 0.f;

@@ -68,8 +68,9 @@ struct DScene {
     const float   *emitter_distr;
     float    emitter_sum, emitter_norm;
     uint32_t emitter_valid_lo, emitter_valid_hi;
-    /* copy of emitters[0] for scenes with exactly one emitter (kernel argument = scalar registers); emitter0_valid = 0: use the array (the record was updated on the
-     * device, har_scene_set_emitter_radiance_device) */
+    /* copy of emitters[0] for scenes with exactly one emitter (kernel argument = scalar registers); emitter0_valid = 0: use the array; 2: the radiance was updated on the
+     * device (har_scene_set_emitter_radiance_device) -- those three floats come from the array, everything else from this copy (round 6: an emitter-optimisation loop
+     * keeps the scalar-register path) */
     DEmitter emitter0; uint32_t emitter0_valid;
 };
 
