@@ -67,7 +67,7 @@ struct Replica {
     hipStream_t stream = nullptr;            /* private stream (device 0 renders on the caller's stream) */
     float *film = nullptr, *staging = nullptr;   /* H x W x 4; staging: on device 0, the peer copy of this replica's film (copy reduce) */
     hipEvent_t done = nullptr;
-    hipEvent_t t0[2][4] = {}, t1[2][4] = {};   /* [0 = render, 1 = render_backward][slot of the BandState ring]: this replica's band, start / end */
+    hipEvent_t t0[2][5] = {}, t1[2][5] = {};   /* [0 = render, 1 = render_backward][slot of the BandState ring]: this replica's band, start / end */
     void *comm = nullptr;
     /* render_backward: the band's weight film (H x W x 4, then the complete one), the adjoint image, ONE flat gradient buffer {bsdf slots, emitter slots, texture 0, 1, ...} and
      * its staging copy on device 0 (copy reduce), the texture pointer table into the flat buffer, this band's events */
@@ -153,9 +153,13 @@ uint32_t begin_bands(HarMultiImpl *M, int kind, uint32_t rows) {
             break;
         }
     }
-    const uint32_t idx = B.next; B.next = (B.next + 1u) & 3u;
-    B.slot[idx].bounds = B.bounds; B.slot[idx].valid = n > 1 && B.skip == 0;
+    /* this frame's slot: a slot whose frame is still in flight is NOT recycled (a host far ahead of the devices would otherwise overwrite every measurement before it
+     * completes): when all four are pending the frame records into the spare slot 4, which is never read */
+    uint32_t idx = 4u;
+    const bool measure = n > 1 && B.skip == 0 && B.frames < M->adapt_frames;
     if (B.skip) --B.skip;
+    if (measure) for (uint32_t q = 0; q < 4u; ++q) { const uint32_t c = (B.next + q) & 3u; if (!B.slot[c].valid) { idx = c; break; } }
+    if (idx < 4u) { B.next = (idx + 1u) & 3u; B.slot[idx].bounds = B.bounds; B.slot[idx].valid = true; }
     return idx;
 }
 
@@ -170,7 +174,7 @@ int destroy(HarMultiImpl *M) {
         if (R.film) (void) hipFree(R.film);
         if (R.wfilm) (void) hipFree(R.wfilm); if (R.grad_in) (void) hipFree(R.grad_in); if (R.grads) (void) hipFree(R.grads);
         for (hipEvent_t ev : { R.bdone, R.wdone, R.done }) if (ev) (void) hipEventDestroy(ev);
-        for (int kind = 0; kind < 2; ++kind) for (int q = 0; q < 4; ++q) { if (R.t0[kind][q]) (void) hipEventDestroy(R.t0[kind][q]); if (R.t1[kind][q]) (void) hipEventDestroy(R.t1[kind][q]); }
+        for (int kind = 0; kind < 2; ++kind) for (int q = 0; q < 5; ++q) { if (R.t0[kind][q]) (void) hipEventDestroy(R.t0[kind][q]); if (R.t1[kind][q]) (void) hipEventDestroy(R.t1[kind][q]); }
         if (R.stream) (void) hipStreamDestroy(R.stream);
     }
     if (!M->rep.empty()) {
@@ -213,7 +217,7 @@ int har_multi_create(const HarSceneDesc *desc, int integrator_type, int32_t max_
         if (!rc) rc = har_integrator_create(integrator_type, max_depth, rr_depth, chunk_lanes, &R.integ);
         if (!rc && k > 0 && hipStreamCreateWithFlags(&R.stream, hipStreamNonBlocking) != hipSuccess) rc = har_set_error("hipStreamCreate failed");
         if (!rc && hipEventCreateWithFlags(&R.done, hipEventDisableTiming) != hipSuccess) rc = har_set_error("hipEventCreate failed");
-        for (int kind = 0; kind < 2 && !rc; ++kind) for (int q = 0; q < 4 && !rc; ++q)
+        for (int kind = 0; kind < 2 && !rc; ++kind) for (int q = 0; q < 5 && !rc; ++q)
             if (hipEventCreate(&R.t0[kind][q]) != hipSuccess || hipEventCreate(&R.t1[kind][q]) != hipSuccess) rc = har_set_error("hipEventCreate failed");
     }
     if (!rc) { (void) hipSetDevice(devices[0]); if (hipEventCreateWithFlags(&M->start, hipEventDisableTiming) != hipSuccess) rc = har_set_error("hipEventCreate failed"); }
