@@ -290,6 +290,40 @@ def optimisation_loop(args, mi, torch, timed, sync_barrier, world, rank):
     frames = max(1, int(timing["frames"][0]))
     kernel_ms = float(timing["total"][0]) * frames / n_prof            # timing() averages per frame; a step holds frames / n_prof of them
     # host-only cost of the step's non-render parts, measured alone: params.update() and the optimiser step with the GPU idle
+    # GPU-side account of a step from the kernel intervals themselves (torch.profiler = roctracer: every kernel of the process, the library's included): the UNION of the
+    # intervals is the time some kernel runs -- frames too large for the shadow-ray overlap run as two half-jobs on two streams (har_render), so the SUM of the launch
+    # durations above is not a time.  idle = span - union (no kernel at all); outside = span - union of the library's kernels and the runtime's fills / copies
+    # (what is left is torch's loss / optimiser kernels and the gaps)
+    busy = None
+    try:
+        from torch.profiler import profile, ProfilerActivity
+        n_trace = 5
+        sync_barrier()
+        with profile(activities=[ProfilerActivity.CUDA]) as prof:
+            for _ in range(n_trace):
+                step()
+            sync_barrier()
+        evs = sorted(((e.time_range.start, e.time_range.end, e.name) for e in prof.events() if e.device_type == torch.autograd.DeviceType.CUDA and e.time_range.end > e.time_range.start))
+
+        def union(items):
+            tot = 0.0; cs = ce = None
+            for a, b, _ in items:
+                if cs is None:
+                    cs, ce = a, b
+                elif a > ce:
+                    tot += ce - cs; cs, ce = a, b
+                else:
+                    ce = max(ce, b)
+            return tot + ((ce - cs) if cs is not None else 0.0)
+        if evs:
+            span = evs[-1][1] - evs[0][0]
+            lib = [e for e in evs if "har::" in e[2] or e[2].startswith("Memset") or e[2].startswith("Memcpy") or "rocclr" in e[2]]
+            busy = {"steps": n_trace, "span_ms_per_step": round(span / n_trace / 1e3, 3), "gpu_idle_ms_per_step": round((span - union(evs)) / n_trace / 1e3, 3),
+                    "outside_library_kernels_ms_per_step": round((span - union(lib)) / n_trace / 1e3, 3),
+                    "other_kernels_ms_per_step": round(sum(b - a for a, b, nme in evs if not ("har::" in nme or nme.startswith("Memset") or nme.startswith("Memcpy") or "rocclr" in nme)) / n_trace / 1e3, 3),
+                    "source": "torch.profiler kernel intervals of %d back-to-back steps (union, not sum)" % n_trace}
+    except Exception as ex:        # no profiler in this build: the field stays empty
+        busy = {"error": str(ex)[:200]}
     # (a) nothing changed since the last update(): the "same tensor, same version" early-out; (b) the parameter WAS written (what an optimiser step leaves behind:
     # a new version counter) -- the in-loop cost: device-to-device pushes / the device-resident vertex update with its refit, enqueue + execution
     torch.cuda.synchronize(); t0 = time.perf_counter()
@@ -329,8 +363,9 @@ def optimisation_loop(args, mi, torch, timed, sync_barrier, world, rank):
            # frames too large for the shadow-ray overlap run as two half-jobs on two streams (har_render): their kernels overlap in time, the sum of the
            # launch durations is then no longer a time and `outside_kernels` is left out -- profiles/rNN_kernel_trace_stats_vertex_loop.txt holds the step's
            # GPU-idle time from the union of the kernel intervals of a rocprofv3 trace (tools/rocpd_summary.py --busy)
-           "loop": {"library_kernel_ms_per_step": round(kernel_ms, 3), "outside_kernels_ms_per_step": round(ms - kernel_ms, 3) if kernel_ms <= ms else None,
-                    "outside_kernels_share": round((ms - kernel_ms) / ms, 4) if kernel_ms <= ms else None, "loop_minus_plain_ms": round(ms - plain_ms, 3), "params_update_ms": round(update_ms, 4), "params_update_host_enqueue_ms": round(update_host_ms, 4), "params_update_no_change_ms": round(update_nochange_ms, 4),
+           "loop": {"library_kernel_ms_per_step": round(kernel_ms, 3),
+                    "outside_kernels_ms_per_step": (busy["outside_library_kernels_ms_per_step"] if busy and "outside_library_kernels_ms_per_step" in busy else (round(ms - kernel_ms, 3) if kernel_ms <= ms else None)),
+                    "outside_kernels_share": (round(busy["outside_library_kernels_ms_per_step"] / ms, 4) if busy and "outside_library_kernels_ms_per_step" in busy else (round((ms - kernel_ms) / ms, 4) if kernel_ms <= ms else None)), "loop_minus_plain_ms": round(ms - plain_ms, 3), "gpu_busy": busy, "params_update_ms": round(update_ms, 4), "params_update_host_enqueue_ms": round(update_host_ms, 4), "params_update_no_change_ms": round(update_nochange_ms, 4),
                     "plain_primal_plus_backward_ms": round(plain_ms, 3), "loop_over_plain": round(ms / plain_ms, 3),
                     "mpaths_per_s_primal_plus_adjoint": round(res * res * spp / (ms / 1e3) / 1e6, 2),
                     "kernel_ms_per_frame": {k: round(v[0], 3) for k, v in timing.items() if k != "frames"}, "frames_per_step": frames / n_prof}}
