@@ -245,9 +245,10 @@ int har_scene_update_vertices(HarScene scene, uint32_t mesh, const float *vertic
  * positions -> packed vertex records, vertex normals regenerated if the mesh carries normals (Mesh::compute_normals as a deterministic per-vertex gather,
  * har_vertex_update.h), the 96-byte shading triangles rewritten, the BLAS refitted.  For a top-level mesh in a scene without environment / directional emitters the
  * call copies nothing between host and device and waits for nothing: the refit's cost figure and a "position not finite" flag land in a pinned record that the NEXT
- * update call reads, so HAR_UPDATE_REBUILD_ADVISED (and the error for a non-finite position) arrive ONE CALL LATE.  An instanced mesh, or a scene whose emitters
- * follow the scene's bounding sphere, additionally reads the mesh's vertex records back (device -> host) for the host build of the instance level / the bounds and
- * waits for it.  The host mirror of the mesh is refreshed lazily (har_scene_get_vertices, or any later call that needs it).  Return codes as above. */
+ * update call reads, so HAR_UPDATE_REBUILD_ADVISED (and the error for a non-finite position) arrive ONE CALL LATE.  A mesh inside a shape group also has the instance
+ * level REFITTED on the device (the exact world-space bounds of its instances, then the TLAS nodes; topology kept) -- no copy, no wait either.  Only a scene whose
+ * environment / directional emitters follow the scene's bounding sphere additionally reads the mesh's vertex records back (device -> host) for the host and waits.
+ * The host mirror of the mesh is refreshed lazily (har_scene_get_vertices, or any later call that needs it).  Return codes as above. */
 int har_scene_update_vertices_device(HarScene scene, uint32_t mesh, const float *positions, void *stream);
 /* the packed vertex records (HOST out, vertex_count x 8 floats) of `mesh` as the device holds them -- after device-resident updates the only current copy */
 int har_scene_get_vertices(HarScene scene, uint32_t mesh, float *vertices, void *stream);

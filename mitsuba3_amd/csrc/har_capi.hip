@@ -155,6 +155,8 @@ struct HarSceneImpl {
     std::vector<uint32_t *> d_corner_begin, d_corners;
     struct PendingRefit { float area; RefitBox root; uint32_t bad; } *pend = nullptr;
     hipEvent_t pend_ev = nullptr; bool pend_active = false; BlasInfo *pend_blas = nullptr; uint32_t *d_bad = nullptr;
+    /* device refit of the instance level (instanced meshes): TLAS nodes by depth, {first vertex, count} of every leaf record's group, the records' boxes; valid for tlas_serial */
+    uint32_t *d_tlas_order = nullptr; uint2 *d_inst_vrange = nullptr; RefitBox *d_inst_box = nullptr; uint64_t d_tlas_serial = 0; size_t d_tlas_cap = 0, d_inst_cap = 0;
     hipStream_t last_push_stream = nullptr; bool last_push_valid = false;      /* stream of the last har_scene_set_*_device copy: the blocking host read-backs order themselves after it */
     ~HarSceneImpl() { if (pend) (void) hipHostFree(pend); if (pend_ev) (void) hipEventDestroy(pend_ev); }
 };
@@ -1122,6 +1124,7 @@ int har_scene_update_instances(HarScene S, uint32_t first, uint32_t count, const
     std::string e;
     hipStream_t s = (hipStream_t) stream;
     if (refresh_host_vertices(S, s, -1)) return 1;          /* the instance boxes and the scene bounds are host builds over the vertex positions */
+    recompute_stale_group_boxes(S->hs);
     if (!scene_set_instances_host(S->hs, first, count, to_world, to_object, e)) return fail(e);
     if (upload_instance_level(S, s) || upload_scene_bounds(S, s)) return 1;
     HIP_TRY(hipStreamSynchronize(s));
@@ -1137,7 +1140,7 @@ static int ensure_refit_scratch(HarSceneImpl *S, hipStream_t s) {
     HIP_TRY(dev_alloc(&p, std::max<size_t>(S->nodes_cap, 1) * sizeof(RefitBox))); S->owned.push_back(p); S->node_box = (RefitBox *) p;
     HIP_TRY(dev_alloc(&p, std::max<size_t>(hs.refit_order.size(), 1) * sizeof(uint32_t))); S->owned.push_back(p); S->d_refit_order = (uint32_t *) p;
     if (!hs.refit_order.empty()) { HIP_TRY(hipMemcpyAsync(S->d_refit_order, hs.refit_order.data(), hs.refit_order.size() * sizeof(uint32_t), hipMemcpyHostToDevice, s)); HIP_TRY(hipStreamSynchronize(s)); }
-    HIP_TRY(dev_alloc(&p, n_blas * sizeof(float))); S->owned.push_back(p); S->d_area = (float *) p;
+    HIP_TRY(dev_alloc(&p, (n_blas + 1) * sizeof(float))); S->owned.push_back(p); S->d_area = (float *) p;          /* + 1: the instance level's sum (not watched) */
     S->tri_box = tri_box;
     return 0;
 }
@@ -1215,6 +1218,7 @@ int har_scene_update_vertices(HarScene S, uint32_t mesh, const float *vertices, 
         if (mesh < S->verts_host_stale.size()) S->verts_host_stale[mesh] = 0;          /* this one is overwritten */
         if (refresh_host_vertices(S, s, -1)) return 1;
         if (collect_pending_refit(S) == 1) return 1;
+        recompute_stale_group_boxes(hs);
     }
     BlasInfo *B = scene_set_vertices_host(hs, mesh, vertices, e);
     if (!B) { (void) fail(e); return HAR_UPDATE_NEEDS_NEW_SCENE; }
@@ -1260,6 +1264,30 @@ static int ensure_corner_list(HarSceneImpl *S, uint32_t mesh, hipStream_t s) {
     S->d_corners[mesh] = d_corners; S->d_corner_begin[mesh] = d_begin;
     return 0;
 }
+/* the device tables of the instance-level refit, for the TLAS as the host last built it (once per build_tlas: a small upload that waits) */
+static int ensure_tlas_refit_tables(HarSceneImpl *S, hipStream_t s) {
+    HostScene &hs = S->hs;
+    if (S->d_tlas_serial == hs.tlas_serial && S->d_tlas_order) return 0;
+    const size_t n_nodes = hs.tlas_order.size(), n_rec = hs.inst_recs.size();
+    void *p = nullptr;
+    if (n_nodes > S->d_tlas_cap) { HIP_TRY(dev_alloc(&p, n_nodes * sizeof(uint32_t))); S->owned.push_back(p); S->d_tlas_order = (uint32_t *) p; S->d_tlas_cap = n_nodes; }
+    if (n_rec > S->d_inst_cap) {
+        HIP_TRY(dev_alloc(&p, n_rec * sizeof(uint2))); S->owned.push_back(p); S->d_inst_vrange = (uint2 *) p;
+        HIP_TRY(dev_alloc(&p, n_rec * sizeof(RefitBox))); S->owned.push_back(p); S->d_inst_box = (RefitBox *) p;
+        S->d_inst_cap = n_rec;
+    }
+    std::vector<uint2> vr(n_rec);
+    for (size_t r = 0; r < n_rec; ++r) {
+        const HarShapeGroup &sg = hs.groups[hs.inst_group[hs.inst_recs[r].inst_index]];
+        uint32_t cnt = 0; for (uint32_t m = sg.first_mesh; m < sg.first_mesh + sg.mesh_count; ++m) cnt += hs.meshes[m].vertex_count;
+        vr[r] = make_uint2(hs.meshes[sg.first_mesh].voff, cnt);
+    }
+    if (n_nodes) HIP_TRY(hipMemcpyAsync(S->d_tlas_order, hs.tlas_order.data(), n_nodes * sizeof(uint32_t), hipMemcpyHostToDevice, s));
+    if (n_rec) HIP_TRY(hipMemcpyAsync(S->d_inst_vrange, vr.data(), n_rec * sizeof(uint2), hipMemcpyHostToDevice, s));
+    HIP_TRY(hipStreamSynchronize(s));
+    S->d_tlas_serial = hs.tlas_serial;
+    return 0;
+}
 int har_scene_update_vertices_device(HarScene S, uint32_t mesh, const float *positions, void *stream) {
     if (!S || !positions) return fail("null argument");
     HostScene &hs = S->hs; DScene &D = S->ds;
@@ -1297,9 +1325,29 @@ int har_scene_update_vertices_device(HarScene S, uint32_t mesh, const float *pos
     S->pend_active = true; S->pend_blas = B;
     S->verts_host_stale[mesh] = 1;
     if (B == &hs.blas_top && !scene_needs_bounds(hs)) { B->refits++; return verdict; }
-    /* an instanced mesh moves the boxes of its instances, and environment / directional emitters follow the scene's bounding sphere: both are host builds over exact
+    static const bool host_tlas = getenv("HAR_HOST_TLAS_UPDATE") != nullptr;
+    if (B != &hs.blas_top && !scene_needs_bounds(hs) && !host_tlas && hs.has_tlas && !hs.tlas_order.empty()) {
+        /* an instanced mesh: the boxes of the group's instances move with its vertices.  The instance level keeps its topology and is REFITTED on the device like the
+         * BLAS -- every leaf record's exact world-space bound (k_instance_boxes), then the TLAS nodes deepest level first -- so this update waits for nothing either.
+         * (The host's cached instance boxes and the group's box are marked stale and re-derived from the refreshed vertices before the next HOST build of the TLAS.) */
+        if (ensure_tlas_refit_tables(S, s)) return 1;
+        launch_instance_boxes(s, D, (uint32_t) hs.inst_recs.size(), S->d_inst_vrange, S->d_inst_box);
+        const size_t n_blas = 1 + hs.blas_groups.size();
+        HIP_TRY(hipMemsetAsync(S->d_area + n_blas, 0, sizeof(float), s));
+        for (size_t l = 0; l + 1 < hs.tlas_levels.size(); ++l)
+            launch_refit_nodes(s, D, S->d_tlas_order + hs.tlas_levels[l], hs.tlas_levels[l + 1] - hs.tlas_levels[l], S->d_inst_box, S->node_box, S->d_area + n_blas);
+        HIP_TRY(hipGetLastError());
+        const size_t g = (size_t) (B - hs.blas_groups.data());
+        if (hs.group_box_stale.size() != hs.groups.size()) hs.group_box_stale.assign(hs.groups.size(), 0);
+        hs.group_box_stale[g] = 1;
+        for (size_t i = 0; i < hs.insts.size(); ++i) if (hs.inst_group[i] == g) hs.inst_box_valid[i] = 0;
+        B->refits++;
+        return verdict;
+    }
+    /* environment / directional emitters follow the scene's bounding sphere (and HAR_HOST_TLAS_UPDATE keeps the instance level a host build): host builds over exact
      * vertex bounds, so these updates read the mesh back (32 B per vertex, device -> host) and wait -- still no host -> device copy of geometry */
     if (refresh_host_vertices(S, s, -1)) return 1;
+    recompute_stale_group_boxes(hs);
     const int now = collect_pending_refit(S);
     if (now == 1) return 1;
     std::string e;

@@ -47,8 +47,38 @@ __global__ void k_shading_triangles(const float *verts, const uint32_t *faces, f
     reinterpret_cast<float4 *>(shade_tris)[6 * (size_t) f + q] = *src;
 }
 
+/* one block per TLAS leaf record: the exact world-space bound of the record's group vertices (vrange[r] = first vertex, count) under its to_world */
+__global__ void k_instance_boxes(const InstRec *recs, const uint2 *vrange, const float *verts, RefitBox *out) {
+    __shared__ float red[6][256 / 64];
+    const uint32_t r = blockIdx.x;
+    const InstRec &I = recs[r];
+    const uint2 vr = vrange[r];
+    RefitBox b = instance_box_empty();
+    for (uint32_t v = threadIdx.x; v < vr.y; v += blockDim.x) instance_box_grow(b, I.to_world, verts + 8 * ((size_t) vr.x + v));
+    float m[6] = { b.lo[0], b.lo[1], b.lo[2], -b.hi[0], -b.hi[1], -b.hi[2] };        /* six minima */
+    for (int k = 0; k < 6; ++k) {
+        for (int off = 32; off > 0; off >>= 1) m[k] = fminf(m[k], __shfl_down(m[k], off, 64));
+        if ((threadIdx.x & 63u) == 0u) red[k][threadIdx.x >> 6] = m[k];
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        RefitBox o;
+        for (int k = 0; k < 3; ++k) {
+            float lo = red[k][0], hi = red[3 + k][0];
+            for (uint32_t w = 1; w < blockDim.x / 64u; ++w) { lo = fminf(lo, red[k][w]); hi = fminf(hi, red[3 + k][w]); }
+            o.lo[k] = lo; o.hi[k] = -hi;
+        }
+        instance_box_finish(o);
+        out[r] = o;
+    }
+}
+
 } // namespace
 
+void launch_instance_boxes(hipStream_t s, const DScene &S, uint32_t n_records, const uint2 *vrange, RefitBox *out) {
+    if (!n_records) return;
+    hipLaunchKernelGGL(k_instance_boxes, dim3(n_records), dim3(256), 0, s, S.accel.insts, vrange, S.verts, out);
+}
 void launch_set_positions(hipStream_t s, const DScene &S, uint32_t voff, uint32_t vertex_count, const float *positions, uint32_t *bad) {
     if (!vertex_count) return;
     hipLaunchKernelGGL(k_set_positions, dim3((vertex_count + 255u) / 256u), dim3(256), 0, s, const_cast<float *>(S.verts) + 8 * (size_t) voff, positions, vertex_count, bad);

@@ -15,5 +15,7 @@ void launch_refit_nodes(hipStream_t s, const DScene &S, const uint32_t *order, u
 void launch_set_positions(hipStream_t s, const DScene &S, uint32_t voff, uint32_t vertex_count, const float *positions, uint32_t *bad);
 void launch_vertex_normals(hipStream_t s, const DScene &S, uint32_t voff, uint32_t foff, uint32_t vertex_count, const uint32_t *corner_begin, const uint32_t *corners);
 void launch_shading_triangles(hipStream_t s, const DScene &S, uint32_t voff, uint32_t foff, uint32_t face_count);
+/* world-space boxes of the TLAS leaf records (S.accel.insts[0 .. n_records)): exact bound of the record's group vertices vrange[r] = {first vertex, count} under its to_world */
+void launch_instance_boxes(hipStream_t s, const DScene &S, uint32_t n_records, const uint2 *vrange, RefitBox *out);
 
 } // namespace har

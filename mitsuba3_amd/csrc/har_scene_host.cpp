@@ -6,6 +6,7 @@
  */
 #include "har_scene_host.h"
 #include "har_refit.h"
+#include "har_vertex_update.h"
 #include <algorithm>
 #include <cmath>
 #include <cstring>
@@ -32,6 +33,26 @@ void blas_refit_order(HostScene &hs, BlasInfo &B) {
     hs.refit_order.resize((size_t) B.order_first + B.node_count);
     std::vector<uint32_t> cursor(count.begin(), count.end() - 1);
     for (uint32_t i = 0; i < B.node_count; ++i) hs.refit_order[B.order_first + cursor[deepest - depth[i]]++] = B.root + i;
+}
+
+/* the same for the TLAS (its nodes are the tail of hs.nodes, root first) */
+void tlas_refit_order(HostScene &hs) {
+    hs.tlas_order.clear(); hs.tlas_levels.clear(); ++hs.tlas_serial;
+    const uint32_t first = hs.root, count = (uint32_t) hs.nodes.size() - first;
+    if (!hs.has_tlas || count == 0) return;
+    std::vector<uint32_t> depth(count, 0u); uint32_t deepest = 0;
+    for (uint32_t i = 0; i < count; ++i) {
+        const Node8 &n = hs.nodes[first + i];
+        uint32_t k = 0;
+        for (int s = 0; s < 8; ++s) if (n.imask & (1u << s)) { depth[n.child_base + k - first] = depth[i] + 1u; deepest = std::max(deepest, depth[i] + 1u); ++k; }
+    }
+    std::vector<uint32_t> cnt(deepest + 2, 0u);
+    for (uint32_t d : depth) cnt[deepest - d + 1]++;
+    for (uint32_t l = 0; l <= deepest; ++l) cnt[l + 1] += cnt[l];
+    hs.tlas_levels.assign(cnt.begin(), cnt.end());
+    hs.tlas_order.resize(count);
+    std::vector<uint32_t> cursor(cnt.begin(), cnt.end() - 1);
+    for (uint32_t i = 0; i < count; ++i) hs.tlas_order[cursor[deepest - depth[i]]++] = first + i;
 }
 
 BlasInfo build_blas(HostScene &hs, uint32_t first_mesh, uint32_t mesh_count, bool optimal_collapse = false) {
@@ -520,6 +541,7 @@ bool build_tlas(HostScene &hs, std::string &err) {
     hs.has_tlas = true;
     hs.inst_recs.clear(); hs.blas_tri_ranges.clear();
     for (uint32_t k : order) { hs.inst_recs.push_back(recs[k]); hs.blas_tri_ranges.push_back(ranges[2 * k]); hs.blas_tri_ranges.push_back(ranges[2 * k + 1]); }
+    tlas_refit_order(hs);
     (void) err;
     return true;
 }
@@ -577,23 +599,31 @@ BlasInfo *scene_set_vertices_host(HostScene &hs, uint32_t mesh, const float *ver
     err = "mesh belongs to no BLAS"; return nullptr;
 }
 
+/* the group's box (corner bound of big groups, build_tlas) = union of the padded triangle boxes, as build_blas leaves it; the cached boxes of its instances are dropped */
+static void recompute_group_box(HostScene &hs, size_t g) {
+    BlasInfo *B = &hs.blas_groups[g];
+    for (int a = 0; a < 3; ++a) { B->lo[a] = INFINITY; B->hi[a] = -INFINITY; }
+    const HarShapeGroup &sg = hs.groups[g];
+    for (uint32_t s = sg.first_mesh; s < sg.first_mesh + sg.mesh_count; ++s) {
+        const DMesh &m = hs.meshes[s];
+        for (uint32_t f = 0; f < m.face_count; ++f) {
+            PrimBox b; for (int a = 0; a < 3; ++a) { b.lo[a] = INFINITY; b.hi[a] = -INFINITY; }
+            for (int k = 0; k < 3; ++k) { const float *v = hs.verts.data() + 8 * ((size_t) m.voff + hs.faces[4 * ((size_t) m.foff + f) + k]); for (int a = 0; a < 3; ++a) { b.lo[a] = std::min(b.lo[a], v[a]); b.hi[a] = std::max(b.hi[a], v[a]); } }
+            pad_prim_box(b);
+            for (int a = 0; a < 3; ++a) { B->lo[a] = std::min(B->lo[a], b.lo[a]); B->hi[a] = std::max(B->hi[a], b.hi[a]); }
+        }
+    }
+    for (size_t i = 0; i < hs.insts.size(); ++i) if (hs.inst_group[i] == g) hs.inst_box_valid[i] = 0;
+    if (g < hs.group_box_stale.size()) hs.group_box_stale[g] = 0;
+}
+void recompute_stale_group_boxes(HostScene &hs) {
+    for (size_t g = 0; g < hs.group_box_stale.size(); ++g) if (hs.group_box_stale[g]) recompute_group_box(hs, g);
+}
+
 bool scene_after_refit_host(HostScene &hs, BlasInfo *B, std::string &err) {
     B->refits++;
     if (B != &hs.blas_top) {
-        const size_t g = (size_t) (B - hs.blas_groups.data());
-        /* the group's box (corner bound of big groups, build_tlas) = union of the padded triangle boxes, as build_blas leaves it */
-        for (int a = 0; a < 3; ++a) { B->lo[a] = INFINITY; B->hi[a] = -INFINITY; }
-        const HarShapeGroup &sg = hs.groups[g];
-        for (uint32_t s = sg.first_mesh; s < sg.first_mesh + sg.mesh_count; ++s) {
-            const DMesh &m = hs.meshes[s];
-            for (uint32_t f = 0; f < m.face_count; ++f) {
-                PrimBox b; for (int a = 0; a < 3; ++a) { b.lo[a] = INFINITY; b.hi[a] = -INFINITY; }
-                for (int k = 0; k < 3; ++k) { const float *v = hs.verts.data() + 8 * ((size_t) m.voff + hs.faces[4 * ((size_t) m.foff + f) + k]); for (int a = 0; a < 3; ++a) { b.lo[a] = std::min(b.lo[a], v[a]); b.hi[a] = std::max(b.hi[a], v[a]); } }
-                pad_prim_box(b);
-                for (int a = 0; a < 3; ++a) { B->lo[a] = std::min(B->lo[a], b.lo[a]); B->hi[a] = std::max(B->hi[a], b.hi[a]); }
-            }
-        }
-        for (size_t i = 0; i < hs.insts.size(); ++i) if (hs.inst_group[i] == g) hs.inst_box_valid[i] = 0;
+        recompute_group_box(hs, (size_t) (B - hs.blas_groups.data()));
         if (!build_tlas(hs, err)) return false;
     }
     update_scene_bounds(hs);
@@ -607,6 +637,21 @@ double refit_blas_host(HostScene &hs, BlasInfo &B) {
     double area = 0.0;
     for (uint32_t k = 0; k < B.node_count; ++k) area += (double) refit_node(hs.nodes.data(), hs.refit_order[B.order_first + k], tri_box.data(), node_box.data());
     return area;
+}
+
+void refit_tlas_host(HostScene &hs) {
+    if (!hs.has_tlas || hs.tlas_order.empty()) return;
+    std::vector<RefitBox> inst_box(hs.inst_recs.size()), node_box(hs.nodes.size());
+    for (size_t r = 0; r < hs.inst_recs.size(); ++r) {
+        const HarShapeGroup &sg = hs.groups[hs.inst_group[hs.inst_recs[r].inst_index]];
+        const uint32_t vfirst = hs.meshes[sg.first_mesh].voff; uint32_t vcount = 0;
+        for (uint32_t s = sg.first_mesh; s < sg.first_mesh + sg.mesh_count; ++s) vcount += hs.meshes[s].vertex_count;
+        RefitBox b = instance_box_empty();
+        for (uint32_t v = 0; v < vcount; ++v) instance_box_grow(b, hs.inst_recs[r].to_world, hs.verts.data() + 8 * ((size_t) vfirst + v));
+        instance_box_finish(b);
+        inst_box[r] = b;
+    }
+    for (uint32_t idx : hs.tlas_order) (void) refit_node(hs.nodes.data(), idx, inst_box.data(), node_box.data());
 }
 
 static bool lower_sensor_filter(const HarSensor &in, DSensor &out, std::string &err) {

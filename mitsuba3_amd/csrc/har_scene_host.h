@@ -65,6 +65,10 @@ struct HostScene {
     std::vector<uint32_t> refit_order;                                        /* node indices of every BLAS by depth (BlasInfo::level_begin) */
     std::vector<PrimBox> inst_boxes; std::vector<uint8_t> inst_box_valid;     /* world-space box of every instance (TLAS leaves), recomputed for the instances that moved */
     uint32_t tlas_first = 0;                                                  /* the TLAS nodes are the tail [tlas_first, nodes.size()) of `nodes` */
+    /* device refit of the instance level after a device-resident vertex update of an instanced mesh (har_scene_update_vertices_device): the TLAS nodes by depth, deepest
+     * first (tlas_levels[l] .. tlas_levels[l + 1] of tlas_order), re-derived by every build_tlas (tlas_serial counts them); the groups whose BlasInfo::lo / hi no longer
+     * bound their vertices because the positions changed on the device only (recompute_stale_group_boxes before the next host build) */
+    std::vector<uint32_t> tlas_order, tlas_levels; uint64_t tlas_serial = 0; std::vector<uint8_t> group_box_stale;
 };
 
 /* RoughPlastic::parameters_changed (src/bsdfs/roughplastic.cpp:204-242): m_specular_sampling_weight from the means of the colour slots */
@@ -94,6 +98,10 @@ bool scene_set_instances_host(HostScene &hs, uint32_t first, uint32_t count, con
  * instances of its group + the TLAS, the scene bounds */
 BlasInfo *scene_set_vertices_host(HostScene &hs, uint32_t mesh, const float *vertices, std::string &err);
 bool scene_after_refit_host(HostScene &hs, BlasInfo *blas, std::string &err);
+/* BlasInfo::lo / hi of the groups marked in group_box_stale from the (refreshed) host vertices; their instances' cached boxes are dropped */
+void recompute_stale_group_boxes(HostScene &hs);
+/* the instance level refitted on the host arrays with the code of the device path (harness): instance boxes from the vertices, then the TLAS nodes deepest level first */
+void refit_tlas_host(HostScene &hs);
 /* the refit itself on the host arrays (sequential; what the kernels of har_refit.hip do): returns the sum of the node surface areas */
 double refit_blas_host(HostScene &hs, BlasInfo &blas);
 

@@ -11,10 +11,12 @@
  *                             loop's rounding sequence and does not depend on thread scheduling (the reference's scatter_reduce has no defined order at all);
  *                             the corner list (4 B offset per vertex + 4 B per corner) is built once per mesh on the host;
  *   3. shading_triangle       the face's three vertex records copied into its 96-byte shading triangle (DScene::shade_tris, what compute_si reads);
- *   4. the BLAS refit of har_refit.h.
+ *   4. the BLAS refit of har_refit.h;
+ *   5. for a mesh inside a shape group: the world-space boxes of the group's instances (instance_box_*) and a refit of the instance level (the TLAS keeps its topology,
+ *      like the BLAS), so that an instanced mesh is updated without the host as well.
  */
 #pragma once
-#include "har_scene.h"
+#include "har_refit.h"
 
 namespace har {
 
@@ -65,5 +67,15 @@ HAR_HD void shading_triangle(const float *verts, const uint32_t *faces, float *s
         for (int c = 0; c < 8; ++c) dst[c] = src[c];
     }
 }
+
+/* world-space box of an instance (a TLAS leaf) from the object-space vertices of its group -- the exact bound of the transformed vertices, as build_tlas takes it
+ * (har_scene_host.cpp; Instance::bbox of the reference transforms the eight corners of the group's box, src/shapes/instance.cpp:93-103, which a TLAS leaf need not) */
+HAR_HD RefitBox instance_box_empty() { RefitBox b; for (int a = 0; a < 3; ++a) { b.lo[a] = HAR_INF; b.hi[a] = -HAR_INF; } return b; }
+HAR_HD void instance_box_grow(RefitBox &b, const float *to_world, const float *vertex_record) {
+    const Vec3 q = xf_point(to_world, Vec3(vertex_record[0], vertex_record[1], vertex_record[2]));
+    b.lo[0] = fminf(b.lo[0], q.x); b.lo[1] = fminf(b.lo[1], q.y); b.lo[2] = fminf(b.lo[2], q.z);
+    b.hi[0] = fmaxf(b.hi[0], q.x); b.hi[1] = fmaxf(b.hi[1], q.y); b.hi[2] = fmaxf(b.hi[2], q.z);
+}
+HAR_HD void instance_box_finish(RefitBox &b) { if (b.lo[0] <= b.hi[0]) pad_box(b.lo, b.hi); }
 
 } // namespace har

@@ -132,6 +132,33 @@ int hh_scene_update_positions(void *h, uint32_t mesh, const float *positions, do
     bind(*H);
     return 0;
 }
+/* the same for a mesh INSIDE a shape group as the device does it when no emitter follows the scene bounds: BLAS refit, then the instance level REFITTED (instance boxes from
+ * the vertices, TLAS nodes deepest level first: refit_tlas_host = the per-element code of k_instance_boxes / k_refit_nodes) instead of rebuilt */
+int hh_scene_update_positions_instanced(void *h, uint32_t mesh, const float *positions, char *err, int errlen) {
+    HScene *H = (HScene *) h; HostScene &hs = H->hs;
+    if (mesh < hs.top_mesh_count || mesh >= hs.meshes.size()) { snprintf(err, errlen, "not a mesh of a shape group"); return 1; }
+    const DMesh m = hs.meshes[mesh];
+    float *V = hs.verts.data() + 8 * (size_t) m.voff; const uint32_t *F = hs.faces.data() + 4 * (size_t) m.foff;
+    for (uint32_t v = 0; v < m.vertex_count; ++v) for (int a = 0; a < 3; ++a) V[8 * (size_t) v + a] = positions[3 * (size_t) v + a];
+    if (m.flags & 1u) {
+        std::vector<uint32_t> begin((size_t) m.vertex_count + 1, 0u), corners(3 * (size_t) m.face_count);
+        for (uint32_t f = 0; f < m.face_count; ++f) for (int k = 0; k < 3; ++k) ++begin[(size_t) F[4 * (size_t) f + k] + 1];
+        for (uint32_t v = 0; v < m.vertex_count; ++v) begin[v + 1] += begin[v];
+        std::vector<uint32_t> cursor(begin.begin(), begin.end() - 1);
+        for (uint32_t f = 0; f < m.face_count; ++f) for (int k = 0; k < 3; ++k) corners[cursor[F[4 * (size_t) f + k]]++] = f | ((uint32_t) k << 30);
+        for (uint32_t v = 0; v < m.vertex_count; ++v) vertex_normal(V, F, begin.data(), corners.data(), v);
+    }
+#if HAR_SHADING_TRIS
+    for (uint32_t f = 0; f < m.face_count; ++f) shading_triangle(V, F, hs.shade_tris.data() + 24 * (size_t) m.foff, f);
+#endif
+    BlasInfo *B = nullptr;
+    for (size_t g = 0; !B && g < hs.groups.size(); ++g) if (mesh >= hs.groups[g].first_mesh && mesh < hs.groups[g].first_mesh + hs.groups[g].mesh_count) B = &hs.blas_groups[g];
+    if (!B) { snprintf(err, errlen, "mesh belongs to no BLAS"); return 1; }
+    (void) refit_blas_host(hs, *B);
+    refit_tlas_host(hs);
+    bind(*H);
+    return 0;
+}
 /* packed vertex records of a mesh as the harness scene holds them */
 int hh_scene_get_vertices(void *h, uint32_t mesh, float *out) {
     HostScene &hs = ((HScene *) h)->hs;

@@ -219,3 +219,30 @@ def test_device_resident_update_refuses_emitter_meshes(mi, O):
     P = np.ascontiguousarray(scene.meshes[m]["V"][:, :3], np.float32)
     assert L.hh_scene_update_positions(h, m, O.fp(P), None, err, 256) == 2 and b"emitter" in err.value
     L.hh_scene_destroy(h)
+
+
+def test_instance_level_refit_equals_rebuild_when_nothing_moved_and_is_exact_after_a_move(mi, O):
+    """an instanced mesh updated the device's way: BLAS refit + instance boxes from the vertices + TLAS refit (the topology of the instance level stays).  Unmoved vertices:
+    the refitted TLAS is the built one bit for bit (the boxes are build_tlas's exact vertex bounds, the node arithmetic is the builder's).  After a move: ray queries equal
+    the brute-force loop and the host path's REBUILT instance level bit for bit (boxes only prune)."""
+    L = _lib_positions(O)
+    L.hh_scene_update_positions_instanced.argtypes = [C.c_void_p, C.c_uint32, O.c_f32p, C.c_char_p, C.c_int]
+    rng = np.random.default_rng(21)
+    scene = mi.load_dict(spheres(mi, False))
+    m = scene._position_keys()["spheres.ball.vertex_positions"]
+    V0 = np.ascontiguousarray(scene.meshes[m]["V"], np.float32)
+    err = C.create_string_buffer(256)
+    h = _create(L, scene); before = _hash(L, h)
+    # flat-shaded comparison needs the regenerated normals on both sides: first an update with the SAME positions through both paths
+    assert L.hh_scene_update_positions_instanced(h, m, O.fp(np.ascontiguousarray(V0[:, :3])), err, 256) == 0, err.value
+    assert _hash(L, h) == before                                              # nodes (BLAS + TLAS), triangle records, instance records
+    P = np.ascontiguousarray((V0[:, :3] * np.float32(1.25) + rng.normal(scale=3e-4, size=(V0.shape[0], 3))).astype(np.float32))
+    assert L.hh_scene_update_positions_instanced(h, m, O.fp(P), err, 256) == 0, err.value
+    h2 = _create(L, scene)
+    assert L.hh_scene_update_positions(h2, m, O.fp(P), None, err, 256) == 0, err.value      # host path: the instance level is REBUILT
+    o, d, maxt = _rays(6000, seed=8)
+    a = _trace(L, O, h, o, d, maxt); b = _trace(L, O, h2, o, d, maxt); c = _trace(L, O, h, o, d, maxt, naive=1)
+    assert int(np.isfinite(a[0]).sum()) > 500
+    for x, y, z in zip(a, b, c):
+        assert np.array_equal(x, y) and np.array_equal(x, z)
+    L.hh_scene_destroy(h); L.hh_scene_destroy(h2)

@@ -171,13 +171,14 @@ def test_shape_optimisation_steps_keep_the_handle(mi):
 
 
 
-@pytest.mark.parametrize("flatten", [True, False])
-def test_device_resident_vertex_update_equals_the_host_update(mi, O, flatten):
+@pytest.mark.parametrize("flatten,sky", [(True, False), (False, True), (False, False)], ids=["top-level", "instanced+sky", "instanced"])
+def test_device_resident_vertex_update_equals_the_host_update(mi, O, flatten, sky):
     """params[key] as a CUDA tensor (har_scene_update_vertices_device: positions, regenerated normals, shading triangles, refit -- all kernels) against the same
     values as a CPU tensor (har_mesh_compute_normals on the host + har_scene_update_vertices): same intersections bit for bit, same picture, same vertex records;
-    the instanced variant also carries a `constant` emitter, so the instance level and the scene's bounding sphere follow (the call's read-back path)."""
+    "instanced+sky" carries a `constant` emitter, so the instance level and the scene's bounding sphere follow on the host (the call's read-back path); "instanced" has the
+    instance level REFITTED on the device (k_instance_boxes + the TLAS levels: no read-back, no wait) where the host path rebuilds it -- same answers, boxes only prune."""
     import torch
-    d = _scene_dict(mi, flatten, sky=not flatten)
+    d = _scene_dict(mi, flatten, sky=sky)
     key = "ball005.vertex_positions" if flatten else "spheres.ball.vertex_positions"
     a = mi.load_dict(d); b = mi.load_dict(copy.deepcopy(d))
     for sc in (a, b):

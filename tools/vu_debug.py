@@ -1,17 +1,18 @@
 import os, sys, time
 sys.path.insert(0, os.getcwd())
-import torch
+import numpy as np, torch
 import mitsuba3_amd as mi
-from torch.profiler import profile, ProfilerActivity
 mi.set_variant("hip_ad_rgb")
-d = mi.cornell_box(); d["sensor"]["film"]["width"] = 128; d["sensor"]["film"]["height"] = 128
-scene = mi.load_dict(d)
-mi.render(scene, spp=16, seed=0); torch.cuda.synchronize()
-with profile(activities=[ProfilerActivity.CUDA, ProfilerActivity.CPU]) as prof:
-    for i in range(3):
-        img = mi.render(scene, spp=16, seed=i); (img * 2).sum()
-    torch.cuda.synchronize()
-evs = [e for e in prof.events() if e.device_type == torch.autograd.DeviceType.CUDA]
-print(len(evs), "device events")
-for e in evs[:12]:
-    print(e.name[:60], e.time_range.start, e.time_range.end)
+scene = mi.load_dict(mi.instanced_spheres_scene(width=64, height=64, spp=4))
+mi.render(scene, spp=4, seed=0)
+params = mi.traverse(scene)
+key = "spheres.ball.vertex_positions"
+m = scene._position_keys()[key]
+t = params[key]
+L = mi.lib()
+for rep in range(4):
+    torch.cuda.synchronize(); t0 = time.perf_counter()
+    rc = L.har_scene_update_vertices_device(scene._h, int(m), t.data_ptr(), None)
+    t1 = time.perf_counter(); torch.cuda.synchronize(); t2 = time.perf_counter()
+    print("instanced mesh (%d vertices, 100 instances): host %.3f ms, + gpu drain %.3f ms rc %d" % (t.numel() // 3, (t1 - t0) * 1e3, (t2 - t1) * 1e3, rc))
+os.environ["HAR_HOST_TLAS_UPDATE"] = "1"
