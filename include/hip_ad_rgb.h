@@ -250,6 +250,13 @@ int har_scene_update_vertices(HarScene scene, uint32_t mesh, const float *vertic
  * environment / directional emitters follow the scene's bounding sphere additionally reads the mesh's vertex records back (device -> host) for the host and waits.
  * The host mirror of the mesh is refreshed lazily (har_scene_get_vertices, or any later call that needs it).  Return codes as above. */
 int har_scene_update_vertices_device(HarScene scene, uint32_t mesh, const float *positions, void *stream);
+/* New `to_world` of instances [first, first + count) ALREADY ON THE DEVICE (Instance::parameters_changed of a JIT variant, src/shapes/instance.cpp:79-91): `to_world` = DEVICE,
+ * count x 12 floats (column-major 3 x 4 each, the layout of HarInstance::to_world).  Enqueued on `stream`: the inverses (formed in double, rounded once), the shading and TLAS leaf
+ * records, the instances' exact world-space bounds, a REFIT of the instance level (its topology stays that of the last host build) -- no copy, no wait; a singular / non-finite
+ * matrix leaves its instance as it was and is reported by the NEXT call.  Scenes whose environment / directional emitters follow the scene's bounding sphere take the host path
+ * (har_scene_update_instances) after reading the matrices back.  har_scene_get_instances: the transforms as the device holds them (HOST out, 12 floats each). */
+int har_scene_update_instances_device(HarScene scene, uint32_t first, uint32_t count, const float *to_world, void *stream);
+int har_scene_get_instances(HarScene scene, uint32_t first, uint32_t count, float *to_world, float *to_object, void *stream);
 /* the packed vertex records (HOST out, vertex_count x 8 floats) of `mesh` as the device holds them -- after device-resident updates the only current copy */
 int har_scene_get_vertices(HarScene scene, uint32_t mesh, float *vertices, void *stream);
 /* info[0] = refits since the scene was created, info[1] = cost figure of the last refitted BLAS, info[2] = its ratio to the figure at the first refit, info[3] = nodes */

@@ -108,6 +108,8 @@ SIGNATURES = {
     "har_scene_update_vertices": (C.c_int, [vp, C.c_uint32, f32p, vp]),
     "har_scene_update_vertices_device": (C.c_int, [vp, C.c_uint32, vp, vp]),
     "har_scene_get_vertices": (C.c_int, [vp, C.c_uint32, f32p, vp]),
+    "har_scene_update_instances_device": (C.c_int, [vp, C.c_uint32, C.c_uint32, vp, vp]),
+    "har_scene_get_instances": (C.c_int, [vp, C.c_uint32, C.c_uint32, f32p, f32p, vp]),
     "har_scene_refit_info": (C.c_int, [vp, C.POINTER(C.c_double)]),
     "har_multi_create": (C.c_int, [C.c_void_p, C.c_int, C.c_int32, C.c_int32, C.c_uint32, C.POINTER(C.c_int), C.c_uint32, C.POINTER(vp)]),
     "har_multi_destroy": (C.c_int, [vp]),

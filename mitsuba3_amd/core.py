@@ -1645,13 +1645,19 @@ class Scene:
         """the packed vertex records of the meshes whose positions were updated ON THE DEVICE (har_scene_update_vertices_device): positions and regenerated normals
         back into meshes[i]['V'] -- needed before anything rebuilds the scene from the host mirrors or reads them"""
         stale = getattr(self, "_stale_meshes", None)
-        if not stale:
-            return
-        if self._h is not None:
-            for i in sorted(stale):
-                V = self.meshes[i]["V"] = np.ascontiguousarray(self.meshes[i]["V"], np.float32)
-                check(lib().har_scene_get_vertices(self._h, int(i), _fp(V), _stream()))
-        stale.clear()
+        if stale:
+            if self._h is not None:
+                for i in sorted(stale):
+                    V = self.meshes[i]["V"] = np.ascontiguousarray(self.meshes[i]["V"], np.float32)
+                    check(lib().har_scene_get_vertices(self._h, int(i), _fp(V), _stream()))
+            stale.clear()
+        if getattr(self, "_stale_instances", False):       # to_world / to_object of the instances were updated on the device (har_scene_update_instances_device)
+            if self._h is not None and self.instances:
+                n = len(self.instances)
+                tw = np.zeros((n, 12), np.float32); to = np.zeros((n, 12), np.float32)
+                check(lib().har_scene_get_instances(self._h, 0, n, _fp(tw), _fp(to), _stream()))
+                self.instances = [(self.instances[i][0], [float(x) for x in tw[i]], [float(x) for x in to[i]]) for i in range(n)]
+            self._stale_instances = False
 
     def _drop_handle(self, keep_geometry=True):
         """the next render builds a new scene handle from the host mirrors: bring them up to date first (unless the handle is being dropped BECAUSE an update failed)"""
@@ -1660,7 +1666,7 @@ class Scene:
         if keep_geometry:
             self._sync_host_geometry()
         else:
-            getattr(self, "_stale_meshes", set()).clear()
+            getattr(self, "_stale_meshes", set()).clear(); self._stale_instances = False
         lib().har_scene_destroy(self._h); self._h = None
 
     # -- C ABI description
@@ -1890,7 +1896,22 @@ class Scene:
         """'<instance>.to_world' (4 x 4, Instance::traverse, instance.cpp:79-85)"""
         return {k + ".to_world": i for i, k in enumerate(self.instance_keys)}
 
+    def _set_instance_matrices_device(self, first, to_world):
+        """params['<instance>.to_world'] as CUDA tensors + params.update(): `to_world` = device tensor (count, 12), column-major 3 x 4 rows for instances first .. first + count - 1.
+        Inverses, shading / TLAS leaf records, instance bounds and the refit of the instance level are kernels on the current stream (har_scene_update_instances_device); the
+        Python mirror self.instances is refreshed lazily (sync_host)."""
+        torch = _torch()
+        t = to_world.detach().to(torch.float32).contiguous()
+        self._stale_instances = True
+        self.device_instance_updates = getattr(self, "device_instance_updates", 0) + 1
+        rc = lib().har_scene_update_instances_device(self._h, int(first), int(t.shape[0]), _ptr(t), _stream())
+        if rc != 0:
+            msg = (lib().har_last_error() or b"").decode()
+            self._drop_handle(keep_geometry=False)
+            raise RuntimeError(msg or "instance update failed")
+
     def _instance_matrix(self, i):
+        self._sync_host_geometry()
         m = np.eye(4, dtype=np.float32); m[:3, :] = np.asarray(self.instances[i][1], np.float32).reshape(4, 3).T
         return m
 
@@ -1901,6 +1922,7 @@ class Scene:
         """params['<instance>.to_world'] = ...; params.update(): the instance level of the acceleration structure is rebuilt IN PLACE (har_scene_update_instances:
         the bottom-level BVHs, the scene handle and every workspace stay; Scene::parameters_changed, scene.cpp:517-540 / scene_optix.inl:351-372) -- one call per
         run of consecutive instances"""
+        self._sync_host_geometry()          # other instances may have moved on the device since: the mirror is read and rewritten below
         recs = {}
         for i, m4 in items:
             m = np.asarray(m4, np.float64).reshape(4, 4); inv = np.linalg.inv(m)
@@ -2160,7 +2182,7 @@ class SceneParameters(dict):
         for k, what, _ in self._host_kinds():
             t = self[k]
             seen[k] = (t, t._version)
-            snap[k] = None if (what == "pos" and t.is_cuda) else t.detach().clone()
+            snap[k] = None if (what in ("pos", "inst") and t.is_cuda) else t.detach().clone()
 
     def __setitem__(self, key, value):
         super().__setitem__(key, value)
@@ -2202,7 +2224,7 @@ class SceneParameters(dict):
         device_pos = set()
         for k, what, _ in table:
             t = self[k]
-            if what == "pos" and getattr(t, "is_cuda", False) and self.scene._h is not None:
+            if what in ("pos", "inst") and getattr(t, "is_cuda", False) and self.scene._h is not None and not os.environ.get("HAR_HOST_VERTEX_UPDATE"):
                 device_pos.add(k)
                 mark = seen.get(k)
                 if mark is None or mark[0] is not t or mark[1] != t._version:
@@ -2232,7 +2254,7 @@ class SceneParameters(dict):
 
             def apply():
                 if k in device_pos:
-                    snap[k] = None               # never compared (see above): no clone of a million vertices per step
+                    snap[k] = None               # never compared (see above): no clone of a million vertices per step, no read-back of a flag
                 else:
                     snap[k] = t.detach().clone() if hasattr(t, "detach") else torch.as_tensor(np.array(t, np.float32, copy=True))
                 if hasattr(t, "_version"):
@@ -2253,13 +2275,16 @@ class SceneParameters(dict):
         written, self._written = self._written, set()
         sc = self.scene
         changed, marks = self._changed_keys(written)
-        moved = []; moved_keys = []
+        moved = []; moved_keys = []; moved_dev = []
         for k, what, ref in self._host_kinds():
             if k not in changed:
-                if what != "pos" or not getattr(self[k], "is_cuda", False):
+                if what not in ("pos", "inst") or not getattr(self[k], "is_cuda", False):
                     marks[k]()              # unchanged: remember the (possibly new) tensor object and version
                 continue
             v = self[k]
+            if what == "inst" and getattr(v, "is_cuda", False) and sc._h is not None and not os.environ.get("HAR_HOST_VERTEX_UPDATE"):
+                moved_dev.append((ref, k, v))
+                continue
             if what == "pos" and getattr(v, "is_cuda", False) and sc._h is not None and not os.environ.get("HAR_HOST_VERTEX_UPDATE"):
                 sc._set_vertex_positions_device(ref, v)
                 marks[k]()
@@ -2286,6 +2311,17 @@ class SceneParameters(dict):
             sc._set_instance_matrices(moved)
             for k in moved_keys:
                 marks[k]()
+        if moved_dev:          # instance transforms that live on the GPU: one call per run of consecutive instances, nothing leaves the device
+            moved_dev.sort(key=lambda e: e[0]); start = 0
+            while start < len(moved_dev):
+                end = start
+                while end + 1 < len(moved_dev) and moved_dev[end + 1][0] == moved_dev[end][0] + 1:
+                    end += 1
+                rows = torch.stack([e[2].detach().to(torch.float32).reshape(4, 4)[:3, :].T.reshape(-1) for e in moved_dev[start:end + 1]])
+                sc._set_instance_matrices_device(moved_dev[start][0], rows)
+                for e in moved_dev[start:end + 1]:
+                    marks[e[1]]()
+                start = end + 1
         sc._validate_spots()
         stream = None
         pushed = self.__dict__.setdefault("_pushed", {})      # key -> (tensor object, version counter, scene handle) of the last push

@@ -12,6 +12,7 @@
 #include "har_kernels.h"
 #include "har_scene_host.h"
 #include "har_refit_launch.h"
+#include "har_vertex_update.h"
 
 #include <algorithm>
 #include <cstddef>
@@ -157,8 +158,15 @@ struct HarSceneImpl {
     hipEvent_t pend_ev = nullptr; bool pend_active = false; BlasInfo *pend_blas = nullptr; uint32_t *d_bad = nullptr;
     /* device refit of the instance level (instanced meshes): TLAS nodes by depth, {first vertex, count} of every leaf record's group, the records' boxes; valid for tlas_serial */
     uint32_t *d_tlas_order = nullptr; uint2 *d_inst_vrange = nullptr; RefitBox *d_inst_box = nullptr; uint64_t d_tlas_serial = 0; size_t d_tlas_cap = 0, d_inst_cap = 0;
+    /* device-resident instance transforms (har_scene_update_instances_device): TLAS leaf record of every instance, the "singular / not finite" flag of the last update in a
+     * pinned word behind an event (read by the next call), and whether hs.insts (the host mirror of the transforms) is older than the device's */
+    uint32_t *d_rec_of = nullptr; size_t d_rec_of_cap = 0; uint32_t *pend_inst = nullptr, *d_bad_inst = nullptr; hipEvent_t pend_inst_ev = nullptr; bool pend_inst_active = false;
+    bool insts_host_stale = false;
     hipStream_t last_push_stream = nullptr; bool last_push_valid = false;      /* stream of the last har_scene_set_*_device copy: the blocking host read-backs order themselves after it */
-    ~HarSceneImpl() { if (pend) (void) hipHostFree(pend); if (pend_ev) (void) hipEventDestroy(pend_ev); }
+    ~HarSceneImpl() {
+        if (pend) (void) hipHostFree(pend); if (pend_ev) (void) hipEventDestroy(pend_ev);
+        if (pend_inst) (void) hipHostFree(pend_inst); if (pend_inst_ev) (void) hipEventDestroy(pend_inst_ev);
+    }
 };
 
 struct HarIntegratorImpl {
@@ -1118,13 +1126,13 @@ static int upload_scene_bounds(HarSceneImpl *S, hipStream_t s) {
     return 0;
 }
 static int refresh_host_vertices(HarSceneImpl *S, hipStream_t s, int only_mesh);
+static int refresh_host_geometry(HarSceneImpl *S, hipStream_t s);
 int har_scene_update_instances(HarScene S, uint32_t first, uint32_t count, const float *to_world, const float *to_object, void *stream) {
     if (!S || !to_world || !to_object) return fail("null argument");
     if (count == 0) return 0;
     std::string e;
     hipStream_t s = (hipStream_t) stream;
-    if (refresh_host_vertices(S, s, -1)) return 1;          /* the instance boxes and the scene bounds are host builds over the vertex positions */
-    recompute_stale_group_boxes(S->hs);
+    if (refresh_host_geometry(S, s)) return 1;              /* the instance boxes and the scene bounds are host builds over the vertex positions and the other instances' transforms */
     if (!scene_set_instances_host(S->hs, first, count, to_world, to_object, e)) return fail(e);
     if (upload_instance_level(S, s) || upload_scene_bounds(S, s)) return 1;
     HIP_TRY(hipStreamSynchronize(s));
@@ -1201,6 +1209,20 @@ static int refresh_host_vertices(HarSceneImpl *S, hipStream_t s, int only_mesh) 
     }
     return 0;
 }
+/* ... and of the instance transforms a device-resident update left stale on the host (hs.insts; build_tlas re-derives the leaf records from them) */
+static int refresh_host_instances(HarSceneImpl *S, hipStream_t s) {
+    if (!S->insts_host_stale || S->hs.insts.empty()) { S->insts_host_stale = false; return 0; }
+    HIP_TRY(hipMemcpyAsync(S->hs.insts.data(), S->ds.insts, S->hs.insts.size() * sizeof(DInst), hipMemcpyDeviceToHost, s));
+    HIP_TRY(hipStreamSynchronize(s));
+    S->insts_host_stale = false;
+    return 0;
+}
+/* everything a HOST build of the instance level / the scene bounds reads, brought up to date after device-resident updates */
+static int refresh_host_geometry(HarSceneImpl *S, hipStream_t s) {
+    if (refresh_host_vertices(S, s, -1) || refresh_host_instances(S, s)) return 1;
+    recompute_stale_group_boxes(S->hs);
+    return 0;
+}
 /* the figures the LAST device-resident update left in the pinned record: 0, HAR_UPDATE_REBUILD_ADVISED, or 1 (a position was not finite) */
 static int collect_pending_refit(HarSceneImpl *S) {
     if (!S->pend_active) return 0;
@@ -1216,10 +1238,10 @@ int har_scene_update_vertices(HarScene S, uint32_t mesh, const float *vertices, 
     std::string e;
     if (!S->verts_host_stale.empty()) {         /* other meshes may have been updated on the device since: the host steps below read their positions */
         if (mesh < S->verts_host_stale.size()) S->verts_host_stale[mesh] = 0;          /* this one is overwritten */
-        if (refresh_host_vertices(S, s, -1)) return 1;
+        if (refresh_host_geometry(S, s)) return 1;
         if (collect_pending_refit(S) == 1) return 1;
-        recompute_stale_group_boxes(hs);
     }
+    if (refresh_host_instances(S, s)) return 1;
     BlasInfo *B = scene_set_vertices_host(hs, mesh, vertices, e);
     if (!B) { (void) fail(e); return HAR_UPDATE_NEEDS_NEW_SCENE; }
     if (mesh < S->normals_regenerated.size()) S->normals_regenerated[mesh] = 0;
@@ -1276,6 +1298,11 @@ static int ensure_tlas_refit_tables(HarSceneImpl *S, hipStream_t s) {
         HIP_TRY(dev_alloc(&p, n_rec * sizeof(RefitBox))); S->owned.push_back(p); S->d_inst_box = (RefitBox *) p;
         S->d_inst_cap = n_rec;
     }
+    const size_t n_inst = hs.insts.size();
+    if (n_inst > S->d_rec_of_cap) { HIP_TRY(dev_alloc(&p, n_inst * sizeof(uint32_t))); S->owned.push_back(p); S->d_rec_of = (uint32_t *) p; S->d_rec_of_cap = n_inst; }
+    std::vector<uint32_t> rec_of(n_inst, 0xffffffffu);
+    for (size_t r = 0; r < n_rec; ++r) rec_of[hs.inst_recs[r].inst_index] = (uint32_t) r;
+    if (n_inst) HIP_TRY(hipMemcpyAsync(S->d_rec_of, rec_of.data(), n_inst * sizeof(uint32_t), hipMemcpyHostToDevice, s));
     std::vector<uint2> vr(n_rec);
     for (size_t r = 0; r < n_rec; ++r) {
         const HarShapeGroup &sg = hs.groups[hs.inst_group[hs.inst_recs[r].inst_index]];
@@ -1346,8 +1373,7 @@ int har_scene_update_vertices_device(HarScene S, uint32_t mesh, const float *pos
     }
     /* environment / directional emitters follow the scene's bounding sphere (and HAR_HOST_TLAS_UPDATE keeps the instance level a host build): host builds over exact
      * vertex bounds, so these updates read the mesh back (32 B per vertex, device -> host) and wait -- still no host -> device copy of geometry */
-    if (refresh_host_vertices(S, s, -1)) return 1;
-    recompute_stale_group_boxes(hs);
+    if (refresh_host_geometry(S, s)) return 1;
     const int now = collect_pending_refit(S);
     if (now == 1) return 1;
     std::string e;
@@ -1356,6 +1382,55 @@ int har_scene_update_vertices_device(HarScene S, uint32_t mesh, const float *pos
     if (upload_scene_bounds(S, s)) return 1;
     HIP_TRY(hipStreamSynchronize(s));
     return now ? now : verdict;
+}
+int har_scene_update_instances_device(HarScene S, uint32_t first, uint32_t count, const float *to_world, void *stream) {
+    if (!S || !to_world) return fail("null argument");
+    if (count == 0) return 0;
+    HostScene &hs = S->hs; DScene &D = S->ds;
+    hipStream_t s = (hipStream_t) stream;
+    if ((uint64_t) first + count > hs.insts.size()) return fail("instance range out of bounds");
+    if (!hs.has_tlas) return fail("the scene has no instances");
+    /* what the previous device-resident instance update reported (its launches finished a frame ago) */
+    if (S->pend_inst_active) {
+        HIP_TRY(hipEventSynchronize(S->pend_inst_ev)); S->pend_inst_active = false;
+        if (*S->pend_inst) return fail("har_scene_update_instances_device: an instance transform of the last update was singular or not finite (that instance kept its old transform)");
+    }
+    static const bool host_tlas = getenv("HAR_HOST_TLAS_UPDATE") != nullptr;
+    if (scene_needs_bounds(hs) || host_tlas || hs.tlas_order.empty()) {
+        /* emitters that follow the scene's bounding sphere: the host path (read the matrices back, invert, rebuild the instance level and the bounds) */
+        std::vector<float> tw(12 * (size_t) count), to(12 * (size_t) count);
+        HIP_TRY(hipMemcpyAsync(tw.data(), to_world, tw.size() * sizeof(float), hipMemcpyDeviceToHost, s)); HIP_TRY(hipStreamSynchronize(s));
+        for (uint32_t k = 0; k < count; ++k) if (!affine_inverse(tw.data() + 12 * (size_t) k, to.data() + 12 * (size_t) k)) return fail("instance transform is singular or not finite");
+        return har_scene_update_instances(S, first, count, tw.data(), to.data(), stream);
+    }
+    if (ensure_refit_scratch(S, s) || ensure_tlas_refit_tables(S, s)) return 1;
+    if (!S->pend_inst) {
+        HIP_TRY(hipHostMalloc((void **) &S->pend_inst, sizeof(uint32_t), hipHostMallocDefault)); *S->pend_inst = 0u;
+        HIP_TRY(hipEventCreateWithFlags(&S->pend_inst_ev, hipEventDisableTiming));
+        void *p = nullptr; HIP_TRY(dev_alloc(&p, sizeof(uint32_t))); S->owned.push_back(p); S->d_bad_inst = (uint32_t *) p;
+    }
+    /* transforms + inverses into the shading records and the TLAS leaf records, the instances' exact world-space bounds, the TLAS nodes deepest level first: the instance
+     * level keeps the topology of its last host build (a refit, like the BLAS after a vertex update) */
+    HIP_TRY(hipMemsetAsync(S->d_bad_inst, 0, sizeof(uint32_t), s));
+    launch_set_instances(s, D, S->d_rec_of, first, count, to_world, S->d_bad_inst);
+    launch_instance_boxes(s, D, (uint32_t) hs.inst_recs.size(), S->d_inst_vrange, S->d_inst_box);
+    const size_t n_blas = 1 + hs.blas_groups.size();
+    HIP_TRY(hipMemsetAsync(S->d_area + n_blas, 0, sizeof(float), s));
+    for (size_t l = 0; l + 1 < hs.tlas_levels.size(); ++l)
+        launch_refit_nodes(s, D, S->d_tlas_order + hs.tlas_levels[l], hs.tlas_levels[l + 1] - hs.tlas_levels[l], S->d_inst_box, S->node_box, S->d_area + n_blas);
+    HIP_TRY(hipGetLastError());
+    HIP_TRY(hipMemcpyAsync(S->pend_inst, S->d_bad_inst, sizeof(uint32_t), hipMemcpyDeviceToHost, s));
+    HIP_TRY(hipEventRecord(S->pend_inst_ev, s));
+    S->pend_inst_active = true; S->insts_host_stale = true;
+    for (uint32_t k = 0; k < count; ++k) hs.inst_box_valid[first + k] = 0;
+    return 0;
+}
+int har_scene_get_instances(HarScene S, uint32_t first, uint32_t count, float *to_world, float *to_object, void *stream) {
+    if (!S || !to_world || !to_object) return fail("null argument");
+    if ((uint64_t) first + count > S->hs.insts.size()) return fail("instance range out of bounds");
+    if (refresh_host_instances(S, (hipStream_t) stream)) return 1;
+    for (uint32_t k = 0; k < count; ++k) { std::memcpy(to_world + 12 * (size_t) k, S->hs.insts[first + k].to_world, 48); std::memcpy(to_object + 12 * (size_t) k, S->hs.insts[first + k].to_object, 48); }
+    return 0;
 }
 int har_scene_get_vertices(HarScene S, uint32_t mesh, float *vertices, void *stream) {
     if (!S || !vertices) return fail("null argument");

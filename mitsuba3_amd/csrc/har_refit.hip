@@ -73,8 +73,25 @@ __global__ void k_instance_boxes(const InstRec *recs, const uint2 *vrange, const
     }
 }
 
+/* new instance transforms (DEVICE, column-major 3 x 4 each) -> the shading records (DInst, by instance) and the TLAS leaf records (InstRec, rec_of[instance] or 0xffffffff) */
+__global__ void k_set_instances(DInst *insts, InstRec *recs, const uint32_t *rec_of, uint32_t first, uint32_t count, const float *to_world, uint32_t *bad) {
+    const uint32_t k = blockIdx.x * blockDim.x + threadIdx.x;
+    if (k >= count) return;
+    float m[12], inv[12];
+    for (int j = 0; j < 12; ++j) m[j] = to_world[12 * (size_t) k + j];
+    if (!affine_inverse(m, inv)) { atomicOr(bad, 2u); return; }          /* reported by the next update call; the old transform stays */
+    DInst &D = insts[first + k];
+    for (int j = 0; j < 12; ++j) { D.to_world[j] = m[j]; D.to_object[j] = inv[j]; }
+    const uint32_t r = rec_of[first + k];
+    if (r != 0xffffffffu) for (int j = 0; j < 12; ++j) { recs[r].to_world[j] = m[j]; recs[r].to_object[j] = inv[j]; }
+}
+
 } // namespace
 
+void launch_set_instances(hipStream_t s, const DScene &S, const uint32_t *rec_of, uint32_t first, uint32_t count, const float *to_world, uint32_t *bad) {
+    if (!count) return;
+    hipLaunchKernelGGL(k_set_instances, dim3((count + 63u) / 64u), dim3(64), 0, s, const_cast<DInst *>(S.insts), const_cast<InstRec *>(S.accel.insts), rec_of, first, count, to_world, bad);
+}
 void launch_instance_boxes(hipStream_t s, const DScene &S, uint32_t n_records, const uint2 *vrange, RefitBox *out) {
     if (!n_records) return;
     hipLaunchKernelGGL(k_instance_boxes, dim3(n_records), dim3(256), 0, s, S.accel.insts, vrange, S.verts, out);

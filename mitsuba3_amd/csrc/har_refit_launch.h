@@ -16,6 +16,9 @@ void launch_set_positions(hipStream_t s, const DScene &S, uint32_t voff, uint32_
 void launch_vertex_normals(hipStream_t s, const DScene &S, uint32_t voff, uint32_t foff, uint32_t vertex_count, const uint32_t *corner_begin, const uint32_t *corners);
 void launch_shading_triangles(hipStream_t s, const DScene &S, uint32_t voff, uint32_t foff, uint32_t face_count);
 /* world-space boxes of the TLAS leaf records (S.accel.insts[0 .. n_records)): exact bound of the record's group vertices vrange[r] = {first vertex, count} under its to_world */
+/* instances [first, first + count): to_world (DEVICE, column-major 3 x 4 each) and its inverse into the shading records and the TLAS leaf records (rec_of[instance]); a singular /
+ * non-finite matrix ORs 2 into *bad and leaves its instance as it was */
+void launch_set_instances(hipStream_t s, const DScene &S, const uint32_t *rec_of, uint32_t first, uint32_t count, const float *to_world, uint32_t *bad);
 void launch_instance_boxes(hipStream_t s, const DScene &S, uint32_t n_records, const uint2 *vrange, RefitBox *out);
 
 } // namespace har

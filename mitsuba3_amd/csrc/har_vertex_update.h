@@ -78,4 +78,25 @@ HAR_HD void instance_box_grow(RefitBox &b, const float *to_world, const float *v
 }
 HAR_HD void instance_box_finish(RefitBox &b) { if (b.lo[0] <= b.hi[0]) pad_box(b.lo, b.hi); }
 
+/* Instance::parameters_changed (src/shapes/instance.cpp:79-91): a new to_world and its inverse.  m, inv: column-major 3 x 4 ({column 0, column 1, column 2, translation}).
+ * The inverse is formed in double (cofactors of the 3 x 3 part) and rounded once; false: the matrix is singular or not finite (nothing is written) */
+HAR_HD bool affine_inverse(const float *m, float *inv) {
+    const double a = m[0], b = m[3], c = m[6], d = m[1], e = m[4], f = m[7], g = m[2], h = m[5], i = m[8];      /* rows of the 3 x 3 part: (a b c), (d e f), (g h i) */
+    const double A = e * i - f * h, B = -(d * i - f * g), Cc = d * h - e * g;
+    const double det = a * A + b * B + c * Cc;
+    bool ok = det != 0.0 && det == det && fabs(det) < 1e300;
+    for (int k = 0; k < 12; ++k) ok = ok && (m[k] - m[k] == 0.f);                        /* finite */
+    if (!ok) return false;
+    const double r = 1.0 / det;
+    const double n00 = A * r, n01 = -(b * i - c * h) * r, n02 = (b * f - c * e) * r;
+    const double n10 = B * r, n11 = (a * i - c * g) * r, n12 = -(a * f - c * d) * r;
+    const double n20 = Cc * r, n21 = -(a * h - b * g) * r, n22 = (a * e - b * d) * r;
+    const double tx = m[9], ty = m[10], tz = m[11];
+    inv[0] = (float) n00; inv[1] = (float) n10; inv[2] = (float) n20;
+    inv[3] = (float) n01; inv[4] = (float) n11; inv[5] = (float) n21;
+    inv[6] = (float) n02; inv[7] = (float) n12; inv[8] = (float) n22;
+    inv[9] = (float) -(n00 * tx + n01 * ty + n02 * tz); inv[10] = (float) -(n10 * tx + n11 * ty + n12 * tz); inv[11] = (float) -(n20 * tx + n21 * ty + n22 * tz);
+    return true;
+}
+
 } // namespace har

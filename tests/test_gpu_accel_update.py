@@ -96,6 +96,7 @@ def test_instance_update_rebuilds_the_instance_level_only(mi, O):
     # a fresh scene with the SAME instance records: a matrix assigned through params gets a numerically inverted to_object (Instance::parameters_changed), the
     # transform chain of the dict composes analytic inverses -- both are valid, they differ in the last bit
     d2 = copy.deepcopy(d)
+    scene.sync_host()                       # CUDA tensors: the transforms went to the library from the device; the Python mirror follows on request
     for k in moved:
         i = scene._instance_keys()[k]
         tw = np.asarray(scene.instances[i][1], np.float32).reshape(4, 3).T; to = np.asarray(scene.instances[i][2], np.float32).reshape(4, 3).T
@@ -262,3 +263,52 @@ def test_vertex_loop_with_device_updates_matches_host_updates(mi):
         assert np.isfinite(a).all() and np.abs(a).max() > 0
         assert rel_l2(a, b) < 1e-3                                    # atomics order only (first step: identical geometry)
     assert np.abs(pd - ph).max() < 1e-6
+
+
+@pytest.mark.parametrize("sky", [False, True], ids=["device", "sky: host fallback"])
+def test_device_resident_instance_update(mi, O, sky):
+    """params['<instance>.to_world'] as CUDA tensors (har_scene_update_instances_device: inverses, shading / TLAS leaf records, instance bounds and the REFIT of the instance level
+    are kernels; nothing is copied or waited for) against the same matrices through the host path (np.linalg.inv + har_scene_update_instances: the instance level is rebuilt):
+    the scene answers like the brute-force kernel bit for bit, and like the host-path scene up to the last bit of the two inverses (picture 1e-5).  With a `constant` emitter the
+    scene's bounding sphere follows the instances: the call reads the matrices back and takes the host path."""
+    import os
+    import torch
+    d = _scene_dict(mi, False, sky=sky)
+    T = mi.ScalarTransform4f
+    moved = {"inst003.to_world": T().translate([0.3, 0.5, 0.2]).rotate([1, 0, 0], 40.0).scale(1.5),
+             "inst004.to_world": T().translate([-0.3, -0.2, 0.4]).rotate([0, 1, 0], 10.0).scale(0.7),
+             "inst011.to_world": T().translate([0.0, 0.1, -0.6]).scale(2.0)}
+    a = mi.load_dict(d); b = mi.load_dict(copy.deepcopy(d))
+    for sc in (a, b):
+        mi.render(sc, spp=4, seed=0)
+    handle = a._h.value
+    pa = mi.traverse(a); pb = mi.traverse(b)
+    mirror_before = [list(x[1]) for x in a.instances]
+    for k, t in moved.items():
+        pa[k] = torch.tensor(np.asarray(t.matrix, np.float32), device="cuda")
+        pb[k] = torch.tensor(np.asarray(t.matrix, np.float32))                       # CPU tensor: host path
+    pa.update(); pb.update()
+    assert a._h.value == handle
+    if not sky:
+        assert a.device_instance_updates == 2 and a._stale_instances                 # two runs of consecutive instances (3-4, 11), mirror untouched
+        assert [list(x[1]) for x in a.instances] == mirror_before
+    rays = _rays(mi, 200000, seed=4)
+    ga = a.ray_intersect_preliminary(rays)
+    assert int(ga.is_valid().sum()) > 20000 and _pi_equal(ga, a._intersect(rays, True))
+    gb = b.ray_intersect_preliminary(rays)
+    same = (ga.is_valid() == gb.is_valid()).float().mean().item()
+    assert same > 0.9999                                                             # the two inverses differ in the last bit at most: grazing rays may flip
+    ia = mi.render(a, spp=16, seed=3).cpu().numpy(); ib = mi.render(b, spp=16, seed=3).cpu().numpy()
+    assert rel_l2(ia, ib) < 1e-5
+    a.sync_host()
+    for k in moved:
+        i = a._instance_keys()[k]
+        assert np.allclose(np.asarray(a.instances[i][1], np.float32), np.asarray(b.instances[i][1], np.float32), rtol=0, atol=0)
+        assert np.allclose(np.asarray(a.instances[i][2], np.float32), np.asarray(b.instances[i][2], np.float32), rtol=1e-6, atol=1e-7)
+    if not sky:
+        # a singular matrix keeps the instance where it was and is reported by the NEXT update
+        pa["inst003.to_world"] = torch.zeros((4, 4), device="cuda"); pa.update()
+        assert a._h is not None
+        pa["inst004.to_world"] = torch.tensor(np.asarray(moved["inst004.to_world"].matrix, np.float32), device="cuda")
+        with pytest.raises(RuntimeError, match="singular or not finite"):
+            pa.update()
