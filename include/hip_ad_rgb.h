@@ -199,6 +199,12 @@ int har_scene_destroy(HarScene scene);
 /* SceneParameters update of `<bsdf>.reflectance.value` / `<bsdf>.reflectance.data`
  * (mi.traverse + params.update(), src/python/python/util.py). HOST data. */
 int har_scene_set_reflectance(HarScene scene, uint32_t bsdf, const float rgb[3]);
+/* ... of the NON-colour parameters of a BSDF record -- `<bsdf>.alpha.value / .alpha_u / .alpha_v`, `.eta.value`, `.k.value`, `.specular_reflectance.value`
+ * (RoughConductor::traverse, src/bsdfs/roughconductor.cpp:213-225; RoughPlastic::traverse + parameters_changed, roughplastic.cpp:204-242; SmoothPlastic, plastic.cpp:188-205):
+ * alpha_u, alpha_v, eta, eta_c, k_c and reflectance2 of `params` replace the record's (type, flags, texture, slot 0 and back side stay), the derived quantities follow
+ * (roughplastic's transmittance table is rewritten in place, internal reflectance, lobe-selection weight).  The scene handle, the acceleration data and every workspace
+ * survive: an optimisation loop over a roughness does not rebuild a scene per step.  HOST data, the record is uploaded synchronously. */
+int har_scene_set_bsdf_params(HarScene scene, uint32_t bsdf, const HarBSDF *params);
 int har_scene_set_emitter_radiance(HarScene scene, uint32_t emitter, const float rgb[3]);   /* `area` / `constant` emitters */
 int har_scene_set_texture(HarScene scene, uint32_t texture, const float *data);
 /* The same updates from DEVICE memory, ordered on `stream` (NULL = default stream), with no host round trip and no synchronisation: the optimisation loop of

@@ -1855,7 +1855,19 @@ class Scene:
             b.k_c = _f32(v[:3])
         else:
             b.value2 = _f32(v[:3])
-        self._drop_handle()
+        if self._h is not None:
+            # the record is re-lowered IN PLACE (har_scene_set_bsdf_params: alpha / eta / k / slot 1 + roughplastic's table, internal reflectance, sampling weight); the scene
+            # handle and the acceleration data survive -- rounds 3-5 rebuilt the whole scene for every step of a roughness optimisation
+            rec = _capi.HarBSDF()
+            rec.type = BSDF_TYPES[b.kind]; rec.flags = b.flags
+            rec.reflectance2 = (C.c_float * 3)(*[float(x) for x in b.value2])
+            rec.alpha_u = b.alpha_u; rec.alpha_v = b.alpha_v; rec.eta = b.eta
+            rec.eta_c = (C.c_float * 3)(*[float(x) for x in b.eta_c]); rec.k_c = (C.c_float * 3)(*[float(x) for x in b.k_c])
+            rc = lib().har_scene_set_bsdf_params(self._h, int(b.index), C.byref(rec))
+            if rc != 0:
+                msg = (lib().har_last_error() or b"").decode()
+                self._drop_handle()
+                raise RuntimeError(msg or "BSDF parameter update failed")
 
     @_static_table
     def _position_keys(self):

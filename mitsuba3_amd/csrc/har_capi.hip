@@ -914,6 +914,17 @@ int har_scene_set_reflectance(HarScene S, uint32_t bsdf, const float rgb[3]) {
     HIP_TRY(hipMemcpy(S->d_bsdfs + bsdf, &b, sizeof(DBsdf), hipMemcpyHostToDevice));
     return 0;
 }
+int har_scene_set_bsdf_params(HarScene S, uint32_t bsdf, const HarBSDF *params) {
+    if (!S || !params || bsdf >= S->hs.bsdfs.size()) return fail("invalid bsdf index");
+    if (sync_host_records(S)) return 1;
+    std::string e;
+    if (!scene_set_bsdf_params_host(S->hs, bsdf, *params, e)) return fail(e);
+    const DBsdf &b = S->hs.bsdfs[bsdf];
+    if (b.type == BSDF_ROUGHPLASTIC && b.table >= 0)
+        HIP_TRY(hipMemcpy(const_cast<float *>(S->ds.bsdf_tables) + b.table, S->hs.bsdf_tables.data() + b.table, HAR_ROUGH_TRANSMITTANCE_RES * sizeof(float), hipMemcpyHostToDevice));
+    HIP_TRY(hipMemcpy(S->d_bsdfs + bsdf, &b, sizeof(DBsdf), hipMemcpyHostToDevice));
+    return 0;
+}
 int har_scene_set_emitter_radiance(HarScene S, uint32_t emitter, const float rgb[3]) {
     if (!S || emitter >= S->hs.emitters.size()) return fail("invalid emitter index");
     if (sync_host_records(S)) return 1;

@@ -152,12 +152,12 @@ void build_roughplastic_tables(HostScene &hs, uint32_t index) {
     DBsdf &b = hs.bsdfs[index];
     b.inv_eta_2 = 1.f / (b.eta * b.eta);
     Microfacet distr((b.flags & BF_GGX) != 0, b.alpha_u, b.alpha_u, true);
-    b.table = (int32_t) hs.bsdf_tables.size();
+    if (b.table < 0) { b.table = (int32_t) hs.bsdf_tables.size(); hs.bsdf_tables.resize(hs.bsdf_tables.size() + HAR_ROUGH_TRANSMITTANCE_RES); }      /* a parameter update rewrites the record's table in place */
     double mean = 0;
     for (int i = 0; i < HAR_ROUGH_TRANSMITTANCE_RES; ++i) {
         float mu = std::max(1e-6f, (float) i / (float) (HAR_ROUGH_TRANSMITTANCE_RES - 1));
         Vec3 wi(std::sqrt(1.f - mu * mu), 0.f, mu);
-        hs.bsdf_tables.push_back(rough_transmittance(distr, wi, b.eta, false));
+        hs.bsdf_tables[(size_t) b.table + i] = rough_transmittance(distr, wi, b.eta, false);
         mean += (double) (rough_transmittance(distr, wi, 1.f / b.eta, true) * wi.z);
     }
     b.internal_reflectance = (float) (mean / HAR_ROUGH_TRANSMITTANCE_RES) * 2.f;
@@ -166,6 +166,25 @@ void build_roughplastic_tables(HostScene &hs, uint32_t index) {
 } // namespace
 
 void quad_gauss_legendre(int n, std::vector<float> &nodes, std::vector<float> &weights) { gauss_legendre(n, nodes, weights); }
+
+/* the non-colour parameters of ONE record re-lowered in place (RoughConductor / RoughPlastic / SmoothPlastic / SmoothDielectric::parameters_changed): alpha, eta, the complex IOR and
+ * the colour of slot 1; the checks of lower_scene for them */
+bool scene_set_bsdf_params_host(HostScene &hs, uint32_t index, const HarBSDF &in, std::string &err) {
+    if (index >= hs.bsdfs.size()) { err = "invalid bsdf index"; return false; }
+    DBsdf &b = hs.bsdfs[index];
+    for (float v : { in.alpha_u, in.alpha_v, in.eta, in.eta_c[0], in.eta_c[1], in.eta_c[2], in.k_c[0], in.k_c[1], in.k_c[2], in.reflectance2[0], in.reflectance2[1], in.reflectance2[2] })
+        if (!std::isfinite(v)) { err = "BSDF parameter is not finite"; return false; }
+    const bool needs_eta = b.type == BSDF_DIELECTRIC || b.type == BSDF_ROUGHPLASTIC || b.type == BSDF_PLASTIC;
+    if (needs_eta && !(in.eta > 0.f)) { err = "The interior and exterior indices of refraction must be positive!"; return false; }
+    if (b.type == BSDF_ROUGHPLASTIC && in.eta == 1.f) { err = "The interior and exterior indices of refraction must be positive and differ!"; return false; }
+    if (b.type == BSDF_ROUGHPLASTIC && in.alpha_u != in.alpha_v) { err = "The 'roughplastic' plugin currently does not support anisotropic microfacet distributions!"; return false; }
+    b.alpha_u = in.alpha_u; b.alpha_v = in.alpha_v; b.eta = in.eta;
+    for (int k = 0; k < 3; ++k) { b.eta_c[k] = in.eta_c[k]; b.k_c[k] = in.k_c[k]; }
+    b.r2 = in.reflectance2[0]; b.g2 = in.reflectance2[1]; b.b2 = in.reflectance2[2];
+    if (b.type == BSDF_ROUGHPLASTIC) { build_roughplastic_tables(hs, index); update_roughplastic_sampling_weight(hs, index); }
+    if (b.type == BSDF_PLASTIC) { b.inv_eta_2 = 1.f / (b.eta * b.eta); b.internal_reflectance = fresnel_diffuse_reflectance(1.f / b.eta); update_roughplastic_sampling_weight(hs, index); }
+    return true;
+}
 
 void update_roughplastic_sampling_weight(HostScene &hs, uint32_t index) {
     DBsdf &b = hs.bsdfs[index];
