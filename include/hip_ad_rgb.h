@@ -205,6 +205,11 @@ int har_scene_set_reflectance(HarScene scene, uint32_t bsdf, const float rgb[3])
  * (roughplastic's transmittance table is rewritten in place, internal reflectance, lobe-selection weight).  The scene handle, the acceleration data and every workspace
  * survive: an optimisation loop over a roughness does not rebuild a scene per step.  HOST data, the record is uploaded synchronously. */
 int har_scene_set_bsdf_params(HarScene scene, uint32_t bsdf, const HarBSDF *params);
+/* ... of the placement / cone of a DELTA emitter -- `<emitter>.position` (PointLight::traverse, src/emitters/point.cpp:84-88), `<emitter>.to_world`, `.cutoff_angle`,
+ * `.beam_width` (SpotLight::traverse / parameters_changed -> update, spot.cpp:111-118, 300-312), `<emitter>.to_world` of a directional light (directional.cpp:93-109): the
+ * record of emitter `emitter` (HarEmitter type 4, 5 or 6, the type it had) is re-lowered in place from `record`; the scene handle and the acceleration data survive.  Area,
+ * environment and mesh lights are part of the scene's geometry / tables and need a new scene.  HOST data. */
+int har_scene_set_delta_emitter(HarScene scene, uint32_t emitter, const HarEmitter *record);
 int har_scene_set_emitter_radiance(HarScene scene, uint32_t emitter, const float rgb[3]);   /* `area` / `constant` emitters */
 int har_scene_set_texture(HarScene scene, uint32_t texture, const float *data);
 /* The same updates from DEVICE memory, ordered on `stream` (NULL = default stream), with no host round trip and no synchronisation: the optimisation loop of

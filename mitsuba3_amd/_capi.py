@@ -100,6 +100,7 @@ SIGNATURES = {
     "har_integrator_set_film_window": (C.c_int, [vp, C.c_uint32, C.c_uint32]),
     "har_scene_set_texture": (C.c_int, [vp, C.c_uint32, f32p]),
     "har_scene_set_bsdf_params": (C.c_int, [vp, C.c_uint32, C.c_void_p]),
+    "har_scene_set_delta_emitter": (C.c_int, [vp, C.c_uint32, C.c_void_p]),
     "har_scene_accel_info": (C.c_int, [vp, u64p]),
     "har_scene_sample_emitter": (C.c_int, [vp, C.c_uint32, vp, vp, vp, vp, vp, vp]),
     "har_scene_pdf_emitter": (C.c_int, [vp, C.c_uint32, vp, vp, vp, vp]),

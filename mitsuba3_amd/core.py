@@ -1700,12 +1700,7 @@ class Scene:
                 texs[i].to_uv = (C.c_float * 6)(*self.texture_to_uv[i])
         ems = (M.HarEmitter * max(1, len(self.emitters)))()
         for i, e in enumerate(self.emitters):
-            ems[i].type = e.get("type", 0); ems[i].mesh = e["mesh"]
-            ems[i].radiance = (C.c_float * 3)(*[float(x) for x in e["radiance"]])
-            ems[i].to_world = (C.c_float * 12)(*[float(x) for x in e["to_world"]])
-            ems[i].normal = (C.c_float * 3)(*[float(x) for x in e["normal"]]); ems[i].inv_area = float(e["inv_area"])
-            ems[i].to_local = (C.c_float * 12)(*[float(x) for x in e.get("to_local", [1, 0, 0, 0, 1, 0, 0, 0, 1, 0, 0, 0])])
-            ems[i].sampling_weight = float(e.get("sampling_weight", 1.0)); ems[i].radiance_texture = int(e.get("radiance_texture", 0))
+            self._fill_emitter_record(ems[i], e)
         d = M.HarSceneDesc()
         d.meshes = meshes; d.mesh_count = len(self.meshes); d.top_mesh_count = self.top_mesh_count
         d.groups = groups; d.group_count = len(self.groups)
@@ -1715,6 +1710,15 @@ class Scene:
         d.emitters = ems; d.emitter_count = len(self.emitters)
         self._keep = [meshes, groups, insts, bsdfs, texs, ems]
         return d
+
+    @staticmethod
+    def _fill_emitter_record(rec, e):
+        rec.type = e.get("type", 0); rec.mesh = e["mesh"]
+        rec.radiance = (C.c_float * 3)(*[float(x) for x in e["radiance"]])
+        rec.to_world = (C.c_float * 12)(*[float(x) for x in e["to_world"]])
+        rec.normal = (C.c_float * 3)(*[float(x) for x in e["normal"]]); rec.inv_area = float(e["inv_area"])
+        rec.to_local = (C.c_float * 12)(*[float(x) for x in e.get("to_local", [1, 0, 0, 0, 1, 0, 0, 0, 1, 0, 0, 0])])
+        rec.sampling_weight = float(e.get("sampling_weight", 1.0)); rec.radiance_texture = int(e.get("radiance_texture", 0))
 
     def _handle(self):
         if self._h is None:
@@ -2063,6 +2067,12 @@ class Scene:
         for e in self.emitters:                                      # SpotLight::update, spot.cpp:300-306
             if e.get("type") == 5 and not (e["normal"][0] >= e["normal"][1] and e["normal"][0] > 0):
                 raise RuntimeError("spot: cutoff_angle must be positive and not smaller than beam_width")
+        pending = self.__dict__.get("_emitters_to_push")
+        if pending:                                                  # spot cones whose pair of angles is complete and valid: the record goes to the scene in place
+            todo = sorted(pending); pending.clear()
+            if self._h is not None:
+                for b in todo:
+                    self._push_delta_emitter(b)
         if getattr(self, "_weights_dirty", False):                   # Scene::parameters_changed -> update_emitter_sampling_distribution (scene.cpp:523-528)
             self._weights_dirty = False
             if self._h is not None:
@@ -2154,7 +2164,23 @@ class Scene:
             inv = np.linalg.inv(m)
             e["to_world"] = [float(x) for x in m[:3, :].T.reshape(-1)]; e["to_local"] = [float(x) for x in inv[:3, :].T.reshape(-1)]
         self.emitters[b] = e
-        self._drop_handle()                                      # the emitter records are part of the scene handle: rebuilt with the next one
+        if self._h is not None and e.get("type", 0) in (4, 5, 6) and kind not in ("cutoff_angle", "beam_width"):
+            # the record of a delta emitter is re-lowered IN PLACE (har_scene_set_delta_emitter): the scene handle and the acceleration data survive a moved light.
+            # (cone values arrive one by one and are validated as a pair at the end of update(): _validate_spots pushes the record then)
+            self._push_delta_emitter(b)
+        elif self._h is not None and e.get("type", 0) in (4, 5, 6):
+            self.__dict__.setdefault("_emitters_to_push", set()).add(b)
+        else:
+            self._drop_handle()                                  # other emitter records are part of the scene's tables: rebuilt with the next handle
+
+    def _push_delta_emitter(self, b):
+        rec = _capi.HarEmitter()
+        self._fill_emitter_record(rec, self.emitters[b])
+        rc = lib().har_scene_set_delta_emitter(self._h, int(b), C.byref(rec))
+        if rc != 0:
+            msg = (lib().har_last_error() or b"").decode()
+            self._drop_handle()
+            raise RuntimeError(msg or "emitter update failed")
 
     def _gradients(self, g_refl, g_tex, g_emit=None):
         out = {}

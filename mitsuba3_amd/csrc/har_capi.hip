@@ -914,6 +914,17 @@ int har_scene_set_reflectance(HarScene S, uint32_t bsdf, const float rgb[3]) {
     HIP_TRY(hipMemcpy(S->d_bsdfs + bsdf, &b, sizeof(DBsdf), hipMemcpyHostToDevice));
     return 0;
 }
+static int refresh_host_geometry(HarSceneImpl *S, hipStream_t s);
+int har_scene_set_delta_emitter(HarScene S, uint32_t emitter, const HarEmitter *record) {
+    if (!S || !record || emitter >= S->hs.emitters.size()) return fail("invalid emitter index");
+    if (sync_host_records(S)) return 1;
+    if (refresh_host_geometry(S, nullptr)) return 1;            /* a directional light's record follows the scene's bounding sphere: the host's vertices / transforms must be current */
+    std::string e;
+    if (!scene_set_delta_emitter_host(S->hs, emitter, *record, e)) return fail(e);
+    HIP_TRY(hipMemcpy(const_cast<DEmitter *>(S->ds.emitters), S->hs.emitters.data(), S->hs.emitters.size() * sizeof(DEmitter), hipMemcpyHostToDevice));
+    if (S->hs.emitters.size() == 1) { S->ds.emitter0 = S->hs.emitters[0]; S->ds.emitter0_valid = 1u; }
+    return 0;
+}
 int har_scene_set_bsdf_params(HarScene S, uint32_t bsdf, const HarBSDF *params) {
     if (!S || !params || bsdf >= S->hs.bsdfs.size()) return fail("invalid bsdf index");
     if (sync_host_records(S)) return 1;

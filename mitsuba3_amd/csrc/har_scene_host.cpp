@@ -165,6 +165,38 @@ void build_roughplastic_tables(HostScene &hs, uint32_t index) {
 
 } // namespace
 
+/* the part of an emitter's record that depends on nothing but its own description: every field of the area / constant / point records, SpotLight::update, the direction of
+ * a directional light (lower_scene adds what hangs on the scene: texel tables, face tables, the bounding sphere) */
+bool lower_plain_emitter(const HarEmitter &e, DEmitter &de, std::string &err) {
+    de.type = e.type;
+    std::memcpy(de.radiance, e.radiance, 12); de.inv_area = e.inv_area;
+    std::memcpy(de.to_world, e.to_world, 48); std::memcpy(de.normal, e.normal, 12); de.mesh = e.mesh;
+    if (e.type == 5) {            /* SpotLight::update (spot.cpp:300-312); the record keeps what sample_direction reads: the inverse's linear part, the position, the cone */
+        const float deg = 0.017453292519943295f, cutoff_rad = e.normal[0] * deg, beam_rad = e.normal[1] * deg;
+        if (!(cutoff_rad >= beam_rad) || !(cutoff_rad > 0.f)) { err = "spot: cutoff_angle must be positive and not smaller than beam_width"; return false; }
+        float s_, cos_cutoff, cos_beam; sincos_(cutoff_rad, s_, cos_cutoff); sincos_(beam_rad, s_, cos_beam);
+        for (int k = 0; k < 9; ++k) de.to_world[k] = e.to_local[k];
+        de.to_world[9] = e.to_world[9]; de.to_world[10] = e.to_world[10]; de.to_world[11] = e.to_world[11];
+        de.normal[0] = cutoff_rad; de.normal[1] = cos_cutoff; de.normal[2] = cos_beam; de.inv_area = 1.0f / (cutoff_rad - beam_rad);
+    }
+    if (e.type == 6) {            /* the record of a directional light keeps its direction of travel (third column of to_world) in [0..2]; [3..6] = the scene's bounding sphere (update_scene_bounds) */
+        de.to_world[0] = e.to_world[6]; de.to_world[1] = e.to_world[7]; de.to_world[2] = e.to_world[8];
+    }
+    return true;
+}
+/* a DELTA emitter's record (point / spot / directional: HarEmitter types 4 - 6) re-lowered in place -- PointLight / SpotLight / DirectionalEmitter::parameters_changed after a
+ * `position` / `to_world` / cone update; the sampling weight stays the distribution's business (har_scene_set_emitter_sampling_weights) */
+bool scene_set_delta_emitter_host(HostScene &hs, uint32_t index, const HarEmitter &e, std::string &err) {
+    if (index >= hs.emitters.size()) { err = "invalid emitter index"; return false; }
+    if (e.type < 4 || e.type > 6 || hs.emitters[index].type != e.type) { err = "only the record of a point / spot / directional emitter can be replaced in place, by one of the same type"; return false; }
+    for (int k = 0; k < 12; ++k) if (!std::isfinite(e.to_world[k]) || !std::isfinite(e.to_local[k])) { err = "emitter transform is not finite"; return false; }
+    DEmitter de = hs.emitters[index];
+    if (!lower_plain_emitter(e, de, err)) return false;
+    hs.emitters[index] = de;
+    update_scene_bounds(hs);          /* a directional light's record carries the scene's bounding sphere */
+    return true;
+}
+
 void quad_gauss_legendre(int n, std::vector<float> &nodes, std::vector<float> &weights) { gauss_legendre(n, nodes, weights); }
 
 /* the non-colour parameters of ONE record re-lowered in place (RoughConductor / RoughPlastic / SmoothPlastic / SmoothDielectric::parameters_changed): alpha, eta, the complex IOR and
@@ -340,20 +372,8 @@ bool lower_scene(const HarSceneDesc &d, HostScene &hs, std::string &err) {
             if (e.mesh >= d.texture_count) { err = "envmap emitter references a bitmap that does not exist"; return false; }
             if (!build_envmap(hs, d.textures[e.mesh], e, err)) return false;
         }
-        DEmitter de{}; de.type = e.type;
-        std::memcpy(de.radiance, e.radiance, 12); de.inv_area = e.inv_area;
-        std::memcpy(de.to_world, e.to_world, 48); std::memcpy(de.normal, e.normal, 12); de.mesh = e.mesh;
-        if (e.type == 5) {            /* SpotLight::update (spot.cpp:300-312); the record keeps what sample_direction reads: the inverse's linear part, the position, the cone */
-            const float deg = 0.017453292519943295f, cutoff_rad = e.normal[0] * deg, beam_rad = e.normal[1] * deg;
-            if (!(cutoff_rad >= beam_rad) || !(cutoff_rad > 0.f)) { err = "spot: cutoff_angle must be positive and not smaller than beam_width"; return false; }
-            float s_, cos_cutoff, cos_beam; sincos_(cutoff_rad, s_, cos_cutoff); sincos_(beam_rad, s_, cos_beam);
-            for (int k = 0; k < 9; ++k) de.to_world[k] = e.to_local[k];
-            de.to_world[9] = e.to_world[9]; de.to_world[10] = e.to_world[10]; de.to_world[11] = e.to_world[11];
-            de.normal[0] = cutoff_rad; de.normal[1] = cos_cutoff; de.normal[2] = cos_beam; de.inv_area = 1.0f / (cutoff_rad - beam_rad);
-        }
-        if (e.type == 6) {            /* the record of a directional light keeps its direction of travel (third column of to_world) in [0..2]; [3..6] = the scene's bounding sphere (update_scene_bounds) */
-            de.to_world[0] = e.to_world[6]; de.to_world[1] = e.to_world[7]; de.to_world[2] = e.to_world[8];
-        }
+        DEmitter de{};
+        if (!lower_plain_emitter(e, de, err)) return false;
         if (e.type == 7) {            /* AreaLight with a bitmap radiance: the texel distribution (see texel_table_fill) lives in emitter_cdf, the record holds where */
             if (e.radiance_texture >= d.texture_count) { err = "area emitter references a bitmap that does not exist"; return false; }
             const HostTexture &t = hs.textures[e.radiance_texture];

@@ -98,6 +98,9 @@ bool scene_set_instances_host(HostScene &hs, uint32_t first, uint32_t count, con
  * instances of its group + the TLAS, the scene bounds */
 BlasInfo *scene_set_vertices_host(HostScene &hs, uint32_t mesh, const float *vertices, std::string &err);
 /* alpha_u / alpha_v / eta / eta_c / k_c / reflectance2 of `in` into record `index`, derived quantities (roughplastic table -- rewritten in place --, internal reflectance, sampling weight) with them */
+/* the record of delta emitter `index` (point / spot / directional, same type as before) re-lowered in place from `e`; the scene bounds of directional lights follow */
+bool scene_set_delta_emitter_host(HostScene &hs, uint32_t index, const HarEmitter &e, std::string &err);
+bool lower_plain_emitter(const HarEmitter &e, DEmitter &de, std::string &err);
 bool scene_set_bsdf_params_host(HostScene &hs, uint32_t index, const HarBSDF &in, std::string &err);
 bool scene_after_refit_host(HostScene &hs, BlasInfo *blas, std::string &err);
 /* BlasInfo::lo / hi of the groups marked in group_box_stale from the (refreshed) host vertices; their instances' cached boxes are dropped */
