@@ -538,6 +538,7 @@ struct EvProbe : StatHooks {
  * refill: 0 = static waves of 64 consecutive rays, R > 0 = persistent wave that refills when >= R lanes are idle */
 } // extern "C"
 static int g_max_sp = 0;
+static double g_regroup_stat[2][8] = { { 0 }, { 0 } };      /* [closest / shadow]: node issues, triangle issues, instance issues, rounds, rays, ops */
 template <bool AnyHit, typename T, int ORDER>
 static void run_traversal_o(const Accel &A, Vec3 o, Vec3 d, float maxt, Hit &hit, bool &found, std::vector<uint32_t> &ev, int &status) {
     T tr; HostStack stack; EvProbe pr{ &ev };
@@ -555,6 +556,7 @@ static void run_traversal(const Accel &A, Vec3 o, Vec3 d, float maxt, Hit &hit, 
 extern "C" {
 
 void hh_set_order(int o) { g_order = o; g_max_sp = 0; }
+void hh_regroup_stats(double out[16]) { for (int k = 0; k < 2; ++k) for (int j = 0; j < 8; ++j) { out[8 * k + j] = g_regroup_stat[k][j]; g_regroup_stat[k][j] = 0.0; } }
 void hh_top_phase_stats(double out[24]) { for (int q = 0; q < 2; ++q) for (int k = 0; k < 12; ++k) out[12 * q + k] = (double) g_host_stat[q][k]; }
 int hh_max_sp() { return g_max_sp; }
 /* visits per node of query class q since the process started; returns the number of entries (call with out = nullptr first) */
@@ -655,6 +657,38 @@ int hh_trace_stats(void *h, const HarSensor *sensor, uint32_t seed, uint32_t spp
                 (void) next_batch;
             }
             for (auto &v : evs) { q[0] += 1; q[1] += (double) v.size(); for (uint32_t x : v) { q[2] += x & 1u; q[4] += (x >> 1) & 1u; q[3] += x >> 8; } }
+            /* what-if (HH_REGROUP=R, tools/regroup_model.py): a block keeps R rays' states in LDS and, every round, deals them to its waves BY WHAT THEY DO NEXT -- each wave
+             * issue runs ONE block (node visit / triangle test / instance entry) for up to 64 rays that all need it.  Counted: issues per block type (a ray's step may hold a node
+             * visit AND a leaf item: two passes of the round) and rounds (each costs every wave of the block a sort + barrier).  Rays refill when a fifth of the block is idle. */
+            static const int regroup = getenv("HH_REGROUP") ? atoi(getenv("HH_REGROUP")) : 0;
+            if (regroup > 0 && n > 0) {
+                double *g = g_regroup_stat[q == o ? 0 : 1];
+                const size_t R = (size_t) regroup, W = std::max<size_t>(1, std::min<size_t>(n / (4 * R), 1024));
+                for (size_t w = 0; w < W; ++w) {
+                    std::vector<size_t> ray(R), pos(R); std::vector<char> busy(R, 0);
+                    size_t cursor = 0, pool = 0, pool_end = 0; bool exhausted = false;
+                    for (;;) {
+                        size_t idle = 0; for (size_t l = 0; l < R; ++l) idle += !busy[l];
+                        if (idle >= std::max<size_t>(1, R / 5)) {
+                            for (size_t l = 0; l < R; ++l) {
+                                if (busy[l]) continue;
+                                if (pool == pool_end && !exhausted) { const size_t bidx = w + W * cursor++; if (bidx * R >= n) exhausted = true; else { pool = bidx * R; pool_end = std::min(n, pool + R); } }
+                                if (pool < pool_end) { busy[l] = 1; ray[l] = pool++; pos[l] = 0; }
+                            }
+                            idle = 0; for (size_t l = 0; l < R; ++l) idle += !busy[l];
+                            if (idle == R) break;
+                        }
+                        size_t cn = 0, ct = 0, ci = 0;
+                        for (size_t l = 0; l < R; ++l) if (busy[l]) {
+                            const uint32_t v = evs[ray[l]][pos[l]++];
+                            cn += v & 1u; ci += (v >> 1) & 1u; ct += (v >> 8) ? 1u : 0u;       /* POLICY 0 steps hold at most one leaf item */
+                            if (pos[l] == evs[ray[l]].size()) busy[l] = 0;
+                        }
+                        g[0] += (double) ((cn + 63) / 64); g[1] += (double) ((ct + 63) / 64); g[2] += (double) ((ci + 63) / 64); g[3] += 1.0; g[5] += (double) (cn + ct + ci);
+                    }
+                }
+                g[4] += (double) n;
+            }
         };
         /* what-if (HH_SORT=1 origin Morton, 2 = direction octant + origin Morton): the wavefront re-ordered before each trace launch */
         static const int sort_mode = getenv("HH_SORT") ? atoi(getenv("HH_SORT")) : 0;
