@@ -481,7 +481,7 @@ int har_integrator_set_grad_emitters(HarIntegrator integrator, float *grad_emitt
  * The differentiated meshes are flat-shaded, or carry the vertex normals a position update regenerates (Mesh::compute_normals, mesh.cpp:876-878,
  * 1216-1267: the gradient then runs through the interpolated normal and the angle-weighted normal sums of the whole one-ring) -- and carry a BSDF with a non-delta lobe (diffuse, roughconductor, roughplastic, plastic; plain
  * or inside `twosided`) -- the attached si.wi / wo reach the BSDF value (prb.py:128-140, 276-288); the other meshes of the scene may carry any BSDF.  Fails otherwise.
- * New vertex positions are installed by creating a new scene (har_scene_create), which rebuilds the acceleration structure. */
+ * New vertex positions are installed in place: har_scene_update_vertices (host records) / har_scene_update_vertices_device (positions already on the device); the BLAS is refitted. */
 int har_integrator_set_grad_positions(HarIntegrator integrator, HarScene scene, float *const *grad_positions);
 
 /* Gradient w.r.t. the `to_world` of INSTANCES (params['<instance>.to_world']): Instance::compute_surface_interaction with an attached transform

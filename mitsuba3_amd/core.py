@@ -1844,7 +1844,7 @@ class Scene:
         return {"alpha": [b.alpha_u], "alpha_u": [b.alpha_u], "alpha_v": [b.alpha_v], "eta": b.eta_c, "k": b.k_c, "slot1": b.value2}[what]
 
     def _set_bsdf_param(self, what, b, v):
-        """params.update() of a non-slot-0 BSDF parameter: the record is re-lowered with the next scene handle (roughplastic's sampling weights and
+        """params.update() of a non-slot-0 BSDF parameter: the record is re-lowered IN PLACE when a scene handle exists (har_scene_set_bsdf_params), else with the first handle (roughplastic's sampling weights and
         transmittance tables depend on alpha / the colours: RoughPlastic::parameters_changed, roughplastic.cpp:204-242)"""
         v = np.asarray(v, np.float32).reshape(-1)
         if what == "alpha":
@@ -1962,7 +1962,8 @@ class Scene:
             start = end + 1
 
     def _set_vertex_positions(self, mesh, positions):
-        """params['<shape>.vertex_positions'] = ...; params.update(): the acceleration structure is rebuilt with the next scene handle"""
+        """params['<shape>.vertex_positions'] = ... (a host tensor / array) + params.update(): normals regenerated on the host, the BLAS refitted on the device
+        (har_scene_update_vertices); CUDA tensors take _set_vertex_positions_device instead"""
         V = self.meshes[mesh]["V"]
         V[:, :3] = np.asarray(positions, np.float32).reshape(V.shape[0], 3)
         if self.meshes[mesh]["flags"] & 1:
