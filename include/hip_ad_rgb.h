@@ -481,6 +481,10 @@ int har_integrator_set_grad_emitters(HarIntegrator integrator, float *grad_emitt
  * The differentiated meshes are flat-shaded, or carry the vertex normals a position update regenerates (Mesh::compute_normals, mesh.cpp:876-878,
  * 1216-1267: the gradient then runs through the interpolated normal and the angle-weighted normal sums of the whole one-ring) -- and carry a BSDF with a non-delta lobe (diffuse, roughconductor, roughplastic, plastic; plain
  * or inside `twosided`) -- the attached si.wi / wo reach the BSDF value (prb.py:128-140, 276-288); the other meshes of the scene may carry any BSDF.  Fails otherwise.
+ * The scene may be lit by ANY emitter of this variant (prb.py:176-216 is one code path for all of them): `area` on rectangles / triangle meshes / with a bitmap radiance
+ * (EmitterFlags::Surface: re-attached ds.d + Jacobian), `point` and `spot` (neither surface nor infinite: ds.d = normalize(ds.p - si.p) re-attached, :191-192; the point
+ * light's squared_norm(ds.p - it.p) follows it.p, point.cpp:155-165; the spot's falloff follows ds.d while its rcp(ds.dist) is detached, spot.cpp:252-274), `directional`,
+ * `constant`, `envmap` (EmitterFlags::Infinite: nothing re-attached), with or without sampling weights.
  * New vertex positions are installed in place: har_scene_update_vertices (host records) / har_scene_update_vertices_device (positions already on the device); the BLAS is refitted. */
 int har_integrator_set_grad_positions(HarIntegrator integrator, HarScene scene, float *const *grad_positions);
 

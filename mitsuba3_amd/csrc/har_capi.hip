@@ -2080,7 +2080,6 @@ int har_integrator_set_grad_positions(HarIntegrator I, HarScene S, float *const 
         /* the hand-derived adjoint of har_shape_grad.h covers top-level meshes, flat-shaded or with (regenerated) vertex normals, carrying any BSDF with a non-delta lobe (the directional derivatives
          * of the models come from har_bsdf_dir.h); the rest of the scene may carry any model -- a vertex next to moving geometry contributes through its
          * attached si.wi (prb.py:128-140) */
-        if (S->ds.bsdf_types & HAR_SCENE_ENVMAP) return fail("vertex-position gradients are not implemented for scenes with an environment map, a mesh or textured area light, a delta light or emitter sampling weights");
         const size_t nm = S->hs.meshes.size();
         offset.assign(nm, -1); user.assign(nm, nullptr); count.assign(nm, 0);
         for (size_t m = 0; m < nm; ++m) {          /* top-level meshes, then the meshes of the shape groups (vertex positions shared by all their instances) */
@@ -2123,7 +2122,6 @@ int har_integrator_set_grad_instances(HarIntegrator I, HarScene S, float *grad_t
     if (grad_to_world) {
         if (!S) return fail("null scene");
         /* as for the vertex positions: any BSDF with a non-delta lobe on the moving geometry, i.e. on the meshes of the shape groups */
-        if (S->ds.bsdf_types & HAR_SCENE_ENVMAP) return fail("instance to_world gradients are not implemented for scenes with an environment map, a mesh or textured area light, a delta light or emitter sampling weights");
         for (size_t m = S->hs.top_mesh_count; m < S->hs.meshes.size(); ++m)
             if (!record_has_smooth_lobe(S->hs, S->hs.meshes[m].bsdf)) return fail("instance to_world gradients: an instanced mesh cannot carry a BSDF made of delta lobes only (`dielectric`, `conductor`); top-level meshes may");
         n = (uint32_t) S->hs.insts.size();

@@ -1745,7 +1745,7 @@ __global__ __launch_bounds__(kBlock, HAR_SHAPE_MIN_WAVES) void k_shape_adjoint(D
                     }
                     /* the emitter sample: w_em = ds.d (surface emitters: normalize(ds.p - si.p), recomputed from the interpolated point) */
                     it.w_em = it.q;
-                    if (it.nee_flags & HAR_SHAPE_NEE_SURFACE) { const SurfInt si = compute_si(S, it.d_in, 0.f, it.b1, it.b2, it.prim, it.shape, it.inst); it.w_em = normalize3(it.q - si.p); }
+                    if (it.nee_flags & HAR_SHAPE_NEE_AT_POINT) { const SurfInt si = compute_si(S, it.d_in, 0.f, it.b1, it.b2, it.prim, it.shape, it.inst); it.w_em = normalize3(it.q - si.p); }
                     if (!shape_item_adjoint(S, it, off >= 0, poff >= 0, geo.vis[i] != 0, Vec3(L4.x, L4.y, L4.z), Vec3(dl4.x, dl4.y, dl4.z), nxt, next_valid, np, nn, nd, G, noff >= 0, npoff >= 0))
                         G.self_mesh = G.self_inst = G.prev_mesh = G.prev_inst = G.self_normals = false;
                 }
@@ -2181,8 +2181,16 @@ void launch_shade(int mode, hipStream_t s, uint32_t grid, const DScene &S, const
 #undef HAR_LAUNCH_SHADE_Q
         return;
     }
-    if (geo && mode == MODE_PRB_ADJOINT) {        /* vertex-position gradients: scenes of `diffuse` BSDFs, plain or `twosided` (checked by har_integrator_set_grad_positions) */
-        if (S.bsdf_types == HAR_BSDF_ONLY_DIFFUSE)
+    if (geo && mode == MODE_PRB_ADJOINT) {        /* vertex-position / instance gradients (har_integrator_set_grad_positions checks what can be differentiated) */
+        /* generic-emitter scenes (mesh / textured / delta lights, environment maps, sampling weights): the emitter sample's kind travels in the geometry record
+         * (HAR_SHAPE_NEE_SURFACE / _POINT / _SPOT, har_shape_grad.h) */
+        if ((S.bsdf_types & HAR_SCENE_ENVMAP) && (S.bsdf_types & HAR_SCENE_TEXLIGHT))
+            hipLaunchKernelGGL((k_shade<MODE_PRB_ADJOINT, HAR_BSDF_ALL_TYPES | HAR_SCENE_ENVMAP | HAR_SCENE_TEXLIGHT, true>), g, b, 0, s, S, P, lane_base, shard_cap, count_in, in, h0, h1, out, count_out, items, item_count,
+                               result, rc, pass_rng, dL, grad_slots, *geo, grad_tex, no_tq, nullptr, no_mq, 0u, tape);
+        else if (S.bsdf_types & HAR_SCENE_ENVMAP)
+            hipLaunchKernelGGL((k_shade<MODE_PRB_ADJOINT, HAR_BSDF_ALL_TYPES | HAR_SCENE_ENVMAP, true>), g, b, 0, s, S, P, lane_base, shard_cap, count_in, in, h0, h1, out, count_out, items, item_count,
+                               result, rc, pass_rng, dL, grad_slots, *geo, grad_tex, no_tq, nullptr, no_mq, 0u, tape);
+        else if (S.bsdf_types == HAR_BSDF_ONLY_DIFFUSE)
             hipLaunchKernelGGL((k_shade<MODE_PRB_ADJOINT, HAR_BSDF_ONLY_DIFFUSE, true>), g, b, 0, s, S, P, lane_base, shard_cap, count_in, in, h0, h1, out, count_out, items, item_count,
                                result, rc, pass_rng, dL, grad_slots, *geo, grad_tex, no_tq, nullptr, no_mq, 0u, tape);
         else if ((S.bsdf_types & 0x7fffffffu & ~HAR_BSDF_CLASSIC_TYPES) != 0u)      /* `conductor` / `plastic` records somewhere in the scene */

@@ -277,8 +277,11 @@ HAR_HD void shade_lane(const DScene &S, const ShadeParams &P, const PathState &s
             if (MODE == MODE_PRB_ADJOINT) {
                 const uint32_t et = S.emitters[em_sampled].type;
                 const bool surface = et == 0u || et == 3u || et == 7u;           /* EmitterFlags::Surface (prb.py:178) */
-                R.nee_flags = 1u | (surface ? 2u : 0u);
-                R.nee_p = surface ? ds.p : ds.d; R.nee_n = ds.n; R.cos_em = wo_em.z * side.wo_sign;
+                /* point / spot lights: neither a surface nor infinite -- prb.py:191-192 re-attaches ds.d = normalize(ds.p - si.p) for them as well (HAR_SHAPE_NEE_POINT /
+                 * _SPOT, har_shape_grad.h); the spot's record index rides in the (zero) normal */
+                const bool point = (TYPES & HAR_SCENE_ENVMAP) != 0u && et == 4u, spot = (TYPES & HAR_SCENE_ENVMAP) != 0u && et == 5u;
+                R.nee_flags = 1u | (surface ? 2u : 0u) | (point ? 16u : 0u) | (spot ? 32u : 0u);
+                R.nee_p = (surface || point || spot) ? ds.p : ds.d; R.nee_n = spot ? Vec3(as_f32(em_sampled), 0.f, 0.f) : ds.n; R.cos_em = wo_em.z * side.wo_sign;
                 R.nee_w = (st.throughput * mis_em) * em_weight;
             }
         }

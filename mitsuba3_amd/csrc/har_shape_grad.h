@@ -52,6 +52,24 @@ HAR_HD Vec3 dir_point_adjoint(Vec3 target, Vec3 normal, Vec3 p, Vec3 w_bar, floa
     const Vec3 proj = u_bar - u * dot3(u, u_bar);
     return u * (2.f * a / r) - proj * rcp_(r);
 }
+/* a * d log falloff_curve(to_world^-1 * -w) / d w of a spot light (spot.cpp:143-151, :252-259; record layout: spot_sample_direction in har_scene.h): zero inside the beam,
+ * where the curve is constant; in the transition  E = (cutoff - acos(cos_theta)) / (cutoff - beam),  cos_theta = l.z,  l = m / |m|,  m = A (-w)  (A = the inverse's linear part) */
+HAR_HD Vec3 spot_falloff_dir_adjoint(const DEmitter &E, Vec3 w, float a) {
+    const Vec3 m = xf_vector(E.to_world, -w);
+    const float len = norm3(m);
+    const Vec3 l = m * rcp_(len);
+    const float c = l.z;
+    if (c >= E.normal[2] || !(c > E.normal[1])) return Vec3(0.f);
+    const float fall = (E.normal[0] - acos_(c)) * E.inv_area;
+    if (!(fall > 0.f)) return Vec3(0.f);
+    const float dE_dc = E.inv_area * rcp_(sqrtf(fmaxf(1.f - c * c, 1e-30f)));        /* d (-acos c) / d c = 1 / sqrt(1 - c^2) */
+    const float k = a * dE_dc / (fall * len);
+    const Vec3 m_bar = (Vec3(0.f, 0.f, 1.f) - l * c) * k;                              /* d c / d m = (e_z - l c) / |m| */
+    /* m = -A w: w_bar = -A^T m_bar (column-major 3 x 3 in to_world[0..8]: column j = to_world[3 j ..]) */
+    return Vec3(-(E.to_world[0] * m_bar.x + E.to_world[1] * m_bar.y + E.to_world[2] * m_bar.z),
+                -(E.to_world[3] * m_bar.x + E.to_world[4] * m_bar.y + E.to_world[5] * m_bar.z),
+                -(E.to_world[6] * m_bar.x + E.to_world[7] * m_bar.y + E.to_world[8] * m_bar.z));
+}
 /* adjoint of coordinate_system(n) (vector.h:118-138): s = (sg nx^2 a + 1, sg b, -sg nx), t = (b, ny^2 a + sg, -ny), a = -1 / (sg + nz), b = nx ny a */
 HAR_HD Vec3 coordinate_system_adjoint(Vec3 n, Vec3 s_bar, Vec3 t_bar) {
     const float sg = n.z >= 0.f ? 1.f : -1.f, a = -1.f / (sg + n.z);
@@ -119,8 +137,13 @@ struct ShapeItem {
 };
 #define HAR_SHAPE_NEE         1u
 #define HAR_SHAPE_NEE_SURFACE 2u
+#define HAR_SHAPE_NEE_AT_POINT (HAR_SHAPE_NEE_SURFACE | HAR_SHAPE_NEE_POINT | HAR_SHAPE_NEE_SPOT)      /* ShapeItem::q is a POSITION (ds.p); otherwise it is the direction ds.d */
 #define HAR_SHAPE_LIT         4u          /* (kept in the records for diagnostics; the side is recomputed from the geometry) */
 #define HAR_SHAPE_FLIPPED     8u
+#define HAR_SHAPE_NEE_POINT   16u         /* the sample lies on a point light: ds.d = normalize(ds.p - si.p) is re-attached (prb.py:191-192), no Jacobian (not a surface), and
+                                           * PointLight::eval_direction divides by squared_norm(ds.p - it.p) with the attached it.p (point.cpp:155-165) */
+#define HAR_SHAPE_NEE_SPOT    32u         /* ... on a spot light: the re-attached ds.d reaches falloff_curve; rcp(ds.dist) stays DETACHED (spot.cpp:252-274; ds.dist takes the zero
+                                           * gradient of ds_diff, prb.py:188-193).  ShapeItem::n_e.x = bits of the emitter's record index */
 #define HAR_SHAPE_NO_NEXT     0xffffffffu
 #define HAR_SHAPE_NONE        0xffffffffu
 
@@ -179,7 +202,8 @@ HAR_HD bool shape_item_adjoint(const DScene &S, const ShapeItem &it, bool self_o
         BsdfEval e; e.value = Vec3(0.f); e.d_slot0 = Vec3(0.f);
         if (term == 0) {              /* emitter sampling: sum_c dl_c W_c (d f_c + f_c dlogJ) */
             if (!((it.nee_flags & HAR_SHAPE_NEE) && visible)) continue;
-            w = it.w_em; attached = (it.nee_flags & HAR_SHAPE_NEE_SURFACE) != 0u; target = it.q; normal = it.n_e;
+            w = it.w_em; attached = (it.nee_flags & HAR_SHAPE_NEE_AT_POINT) != 0u; target = it.q;
+            normal = (it.nee_flags & HAR_SHAPE_NEE_SURFACE) ? it.n_e : Vec3(0.f);           /* a zero normal: dir_point_adjoint keeps the direction and the -2 log r, drops the cosine */
         } else {                      /* continuation: sum_c dl_c L_c (d f_c / f_c + dlogJ) */
             if (!has_next) continue;
             w = next_d; attached = next_valid; target = next_p; normal = next_n;
@@ -202,7 +226,11 @@ HAR_HD bool shape_item_adjoint(const DScene &S, const ShapeItem &it, bool self_o
             const Vec3 c = A * e.d_slot0;                        /* colour slot 0 (uv) */
             uv_bar[0] += c.x * rho_du.x + c.y * rho_du.y + c.z * rho_du.z; uv_bar[1] += c.x * rho_dv.x + c.y * rho_dv.y + c.z * rho_dv.z;
         }
-        if (self_on && attached) p_bar = p_bar + dir_point_adjoint(target, normal, si.p, si.ss * gwo.x + si.st * gwo.y + si.sn * gwo.z, a);
+        if (self_on && attached) {
+            Vec3 w_bar = si.ss * gwo.x + si.st * gwo.y + si.sn * gwo.z;
+            if (term == 0 && (it.nee_flags & HAR_SHAPE_NEE_SPOT)) { w_bar = w_bar + spot_falloff_dir_adjoint(S.emitters[as_u32(it.n_e.x)], w, a); a = 0.f; }
+            p_bar = p_bar + dir_point_adjoint(target, normal, si.p, w_bar, a);
+        }
         /* wi */
         if (depth0) { if (self_mesh) { const Vec3 wv = -it.d_in; s_bar = s_bar + wv * gwi.x; t_bar = t_bar + wv * gwi.y; n_bar = n_bar + wv * gwi.z; } }
         else if (prev_on) { const Vec3 u_bar = si.ss * gwi.x + si.st * gwi.y + si.sn * gwi.z; pprev_bar = pprev_bar + (u_bar - u_prev * dot3(u_prev, u_bar)) * rcp_(r_prev); }

@@ -1488,17 +1488,39 @@ static V3 prb_sample(const Scene &sc, Pcg32 &rng, Ray ray, uint32_t max_depth, u
                 };
                 if (active_em) {
                     const uint32_t et = sc.emitters[ds.emitter].type;
-                    const bool is_surface = et == 0 || et == 3;
+                    const bool is_surface = et == 0 || et == 3 || et == 7;         // EmitterFlags::Surface (area.cpp:42)
+                    const bool is_infinite = et == 1 || et == 2 || et == 6;        // EmitterFlags::Infinite (constant.cpp, envmap.cpp, directional.cpp)
                     Dn3 dsd = dn3(ds.d); Dn J(1.0);
+                    Dn E(1.0);                                                     // the part of eval_emitter_direction(si, ds) that follows si.p (prb.py:203-206), up to a constant factor
                     if (is_surface) {                                              // prb.py:189-201: ds.d = normalize(ds.p - si.p), J(si.p, detach(ds.p), detach(ds.n))
                         Dn3 dir; dir_and_jacobian(a.p, dn3(ds.p), dn3(ds.n), dir, J);
                         dsd = replace_grad3(ds.d.x, ds.d.y, ds.d.z, dir);
+                    } else if (!is_infinite) {
+                        /* point / spot: prb.py:191-192 -- only ds.d = normalize(ds.p - si.p) is re-attached (ds.p, ds.dist, ds.n take the zero gradients of
+                         * ds_diff); J = 1 (not a surface).  PointLight::eval_direction (point.cpp:155-165) divides by squared_norm(ds.p - it.p) with the attached
+                         * it.p; SpotLight::eval_direction (spot.cpp:252-274) uses rcp(ds.dist) -- DETACHED -- and the falloff of the attached ds.d */
+                        const Dn3 dvec = dn3(ds.p) - a.p;
+                        dsd = replace_grad3(ds.d.x, ds.d.y, ds.d.z, dnormalize(dvec));
+                        const OrcEmitter &e = sc.emitters[ds.emitter];
+                        if (et == 4) E = Dn(1.0) / ddot(dvec, dvec);
+                        else {
+                            const float *T = e.to_local;                            // local_d = to_world.inverse() * -ds.d, then falloff_curve's normalize (spot.cpp:143-151)
+                            const Dn3 md = dsd * -1.0;
+                            const Dn3 ld = dnormalize(Dn3(md.x * (double) T[0] + md.y * (double) T[3] + md.z * (double) T[6], md.x * (double) T[1] + md.y * (double) T[4] + md.z * (double) T[7],
+                                                          md.x * (double) T[2] + md.y * (double) T[5] + md.z * (double) T[8]));
+                            const double deg = 0.017453292519943295, cutoff = (double) e.normal[0] * deg, beam = (double) e.normal[1] * deg;
+                            if (ld.z.v < std::cos(beam)) {                          // inside the beam the curve is constant; in the transition it is (cutoff - acos(cos_theta)) / (cutoff - beam)
+                                Dn ac; ac.v = std::acos(ld.z.v); const double k = -1.0 / std::sqrt(std::max(1.0 - ld.z.v * ld.z.v, 1e-300));
+                                for (int i = 0; i < kShapeSlots; ++i) ac.d[i] = ld.z.d[i] * k;
+                                E = (Dn(cutoff) - ac) * (1.0 / (cutoff - beam));
+                            }
+                        }
                     }
                     Dn f[3]; value_cos(dsd, wo_em, f);
                     const double w[3] = { (double) beta_cur.x * mis_em * em_weight.x, (double) beta_cur.y * mis_em * em_weight.y, (double) beta_cur.z * mis_em * em_weight.z };
                     for (int c = 0; c < 3; ++c) {
-                        if (w[c] == 0.0 || J.v == 0.0) continue;
-                        for (int k = 0; k < kShapeSlots; ++k) g[k] += dl[c] * w[c] * (f[c].d[k] + f[c].v * J.d[k] / J.v);      // em_weight *= relative_grad(J)
+                        if (w[c] == 0.0 || J.v == 0.0 || E.v == 0.0) continue;
+                        for (int k = 0; k < kShapeSlots; ++k) g[k] += dl[c] * w[c] * (f[c].d[k] + f[c].v * (J.d[k] / J.v + E.d[k] / E.v));      // em_weight = replace_grad(em_weight, em_val_diff / pdf) * relative_grad(J)
                     }
                 }
                 if (active_next) {                                                 // prb.py:261-297
@@ -2272,11 +2294,9 @@ int orc_render_prb_backward_lanes(void *scene, const OrcSensor *sp, const float 
 }
 /* + d/d(vertex positions) of the meshes with pos_mask[m] != 0: grad_positions[m] = 3 doubles per vertex (accumulated into).
  * Returns -2 when the scene holds a BSDF other than plain `diffuse`, -3 for a mesh with vertex normals / inside a shape group. */
-static bool has_point_emitter(void *scene) { for (const OrcEmitter &e : ((Scene *) scene)->emitters) if (e.type >= 4) return true; return false; }      /* (also the textured area light, type 7: its shape-gradient terms are not restated) */
 int orc_render_prb_backward_shape(void *scene, const OrcSensor *sp, const float *grad_in, uint32_t seed, uint32_t spp,
                                   int32_t max_depth, int32_t rr_depth, float *grad_reflectance, float *const *grad_textures,
                                   const uint8_t *pos_mask, double *const *grad_positions, OrcStats *stats, int threads) {
-    if (has_point_emitter(scene)) return -3;       /* the geometry-attached emitter terms are restated for surface and environment emitters only */
     return prb_backward_impl(scene, sp, grad_in, seed, spp, max_depth, rr_depth, grad_reflectance, grad_textures, nullptr, pos_mask, grad_positions, stats, threads);
 }
 /* + d/d(to_world) of the instances with inst_mask[i] != 0 (Instance::compute_surface_interaction, instance.cpp:150-266, with an attached transform):
@@ -2284,7 +2304,6 @@ int orc_render_prb_backward_shape(void *scene, const OrcSensor *sp, const float 
 int orc_render_prb_backward_instances(void *scene, const OrcSensor *sp, const float *grad_in, uint32_t seed, uint32_t spp,
                                       int32_t max_depth, int32_t rr_depth, float *grad_reflectance, float *const *grad_textures,
                                       const uint8_t *inst_mask, double *grad_to_world, OrcStats *stats, int threads) {
-    if (has_point_emitter(scene)) return -3;
     return prb_backward_impl(scene, sp, grad_in, seed, spp, max_depth, rr_depth, grad_reflectance, grad_textures, nullptr, nullptr, nullptr, stats, threads,
                              0, 0, nullptr, nullptr, inst_mask, grad_to_world);
 }

@@ -408,7 +408,9 @@ static int backward_shape_impl(void *h, const HarSensor *sensor, const float *ad
             PathState st = st0; bool alive = P.max_depth != 0;
             while (alive) {
                 Hit hit; HostStack stack; accel_trace<false>(S.accel, st.o, st.d, st.maxt, hit, stack, status);
-                ShadeResult R; shade_lane<MODE_PRB_PRIMAL, HAR_BSDF_ALL_TYPES>(S, P, st, hit, R);
+                ShadeResult R;
+                if (S.bsdf_types & HAR_SCENE_ENVMAP) shade_lane<MODE_PRB_PRIMAL, HAR_BSDF_ALL_TYPES | HAR_SCENE_ENVMAP | HAR_SCENE_TEXLIGHT>(S, P, st, hit, R);       /* mesh / delta / textured lights, environment maps, sampling weights */
+                else shade_lane<MODE_PRB_PRIMAL, HAR_BSDF_ALL_TYPES>(S, P, st, hit, R);
                 if (R.add_emission) L = L + R.em_b;
                 if (R.item && R.item_ray) { Hit sh; HostStack s2; if (!accel_trace<true>(S.accel, R.sh_o, R.sh_d, R.sh_maxt, sh, s2, status)) L = L + R.contrib; }
                 alive = R.alive; st = R.next;
@@ -422,7 +424,9 @@ static int backward_shape_impl(void *h, const HarSensor *sensor, const float *ad
         auto nested_on = [&](uint32_t shape, uint32_t inst) { return shape != HAR_SHAPE_NONE && inst != HAR_SHAPE_NONE && grad && grad[shape]; };
         auto moving = [&](uint32_t shape, uint32_t inst) { return shape != HAR_SHAPE_NONE && (inst == HAR_SHAPE_NONE ? (grad && grad[shape]) : (inst_grad != nullptr || nested_on(shape, inst))); };
         while (alive) {
-            ShadeResult R; shade_lane<MODE_PRB_ADJOINT, HAR_BSDF_ALL_TYPES>(S, P, st, hit, R);
+            ShadeResult R;
+            if (S.bsdf_types & HAR_SCENE_ENVMAP) shade_lane<MODE_PRB_ADJOINT, HAR_BSDF_ALL_TYPES | HAR_SCENE_ENVMAP | HAR_SCENE_TEXLIGHT>(S, P, st, hit, R);
+            else shade_lane<MODE_PRB_ADJOINT, HAR_BSDF_ALL_TYPES>(S, P, st, hit, R);
             if (R.add_emission) L = L - R.em_b;
             bool visible = false;
             if (R.item && R.item_ray) { Hit sh; HostStack s2; visible = !accel_trace<true>(S.accel, R.sh_o, R.sh_d, R.sh_maxt, sh, s2, status); if (visible) L = L - R.contrib; }
@@ -439,7 +443,7 @@ static int backward_shape_impl(void *h, const HarSensor *sensor, const float *ad
                 it.q = R.nee_p; it.n_e = R.nee_n; it.nee_flags = R.item_ray ? R.nee_flags : (R.nee_flags & HAR_SHAPE_LIT); it.W = R.nee_w;
                 it.prev_shape = prev.shape; it.prev_prim = prev.prim; it.prev_inst = prev.inst; it.prev_b1 = prev.u; it.prev_b2 = prev.v; it.prev_d = prev_d;
                 const SurfInt si = compute_si(S, st.d, hit.t, hit.u, hit.v, hit.prim, hit.shape, hit.inst);
-                it.w_em = (it.nee_flags & HAR_SHAPE_NEE_SURFACE) ? normalize3(it.q - si.p) : it.q;
+                it.w_em = (it.nee_flags & HAR_SHAPE_NEE_AT_POINT) ? normalize3(it.q - si.p) : it.q;
                 ShapeGrad G;
                 if (shape_item_adjoint(S, it, self_on, prev_on, visible, L, dl, R.alive, next_valid, np, nn, R.next.d, G, nested_on(hit.shape, hit.inst), nested_on(prev.shape, prev.inst))) {
                     if (G.self_mesh) { double *dst = grad[hit.shape]; for (int k = 0; k < 3; ++k) { dst[3 * (size_t) G.vid[k]] += G.g[k].x; dst[3 * (size_t) G.vid[k] + 1] += G.g[k].y; dst[3 * (size_t) G.vid[k] + 2] += G.g[k].z; } }

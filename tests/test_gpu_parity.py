@@ -794,6 +794,64 @@ def test_prb_vertex_position_gradients(mi, O, which):
         assert np.allclose(plain[k].cpu().numpy(), grads[k].cpu().numpy(), rtol=1e-4, atol=1e-7)
 
 
+@pytest.mark.parametrize("which", ["point", "spot", "directional", "spot_rough", "point_and_area", "meshlight", "texlight", "envmap", "weighted"])
+def test_prb_vertex_position_gradients_generic_emitters(mi, O, which):
+    """vertex-position gradients in scenes of the generic-emitter kernel class (round 6): point / spot lights (prb.py:191-192 re-attaches ds.d = normalize(ds.p - si.p);
+    the point light's 1 / r^2 follows si.p, point.cpp:155-165; the spot's falloff follows ds.d, its rcp(ds.dist) is detached, spot.cpp:252-274), directional lights and
+    environment maps (EmitterFlags::Infinite: nothing re-attached), triangle-mesh and bitmap-radiance area lights (surface: Jacobian + direction), weighted emitters --
+    k_shade<ADJOINT, ALL | ENVMAP (| TEXLIGHT), SHAPE> + k_shape_adjoint against the oracle's dual numbers, vertex by vertex"""
+    from tests.test_cpu_host import oracle_scene_from
+    from tests.test_shape_gradients_cpu import slab_scene, delta_slab_scene, generic_light_slab_scene, mesh_index
+    res = 24
+    if which in ("meshlight", "texlight", "envmap", "weighted"):
+        d = generic_light_slab_scene(mi, res, which)
+    else:
+        d = delta_slab_scene(mi, res, which.split("_")[0], which.endswith("_rough"))
+    if which == "point_and_area":
+        d["light"] = slab_scene(mi, res)["light"]
+    names = ["floor"] + (["ceiling"] if "ceiling" in d else [])
+    d["integrator"] = {"type": "prb", "max_depth": 5, "shape_gradients": [n + ".vertex_positions" for n in names]}
+    scene = mi.load_dict(d)
+    osc, sensor = oracle_scene_from(O, scene)
+    ids = [mesh_index(scene, n) for n in names]
+    grad_in = np.random.default_rng(4).uniform(0.5, 1.5, (res, res, 3)).astype(np.float32)
+    integ = scene.integrator()
+    grads = integ.render_backward(scene, None, grad_in, seed=3, spp=16)
+    want, w_refl, w_tex, _ = osc.render_prb_backward_shape(sensor, grad_in, ids, seed=3, spp=16, max_depth=5)
+    for n, m in zip(names, ids):
+        got = grads[n + ".vertex_positions"].cpu().numpy().reshape(-1, 3)
+        scale = np.abs(want[m]).max()
+        assert scale > 0 and np.abs(got - want[m]).max() < 2e-3 * scale, (which, n, np.abs(got - want[m]).max() / scale)
+    for k, (kind, b) in scene._param_keys().items():
+        if kind not in ("tex", "refl"):
+            continue
+        ref = w_tex[b.tex_index] if kind == "tex" else w_refl[b.index]
+        if not ref.any():
+            assert not grads[k].any(), k
+            continue
+        assert rel_l2(grads[k].cpu().numpy(), ref) < 1e-3, k
+
+
+def test_prb_instance_gradients_under_a_point_light(mi, O):
+    """instance to_world gradients (instance.cpp:150-266) with the point light's re-attached direction and 1 / r^2"""
+    from tests.test_shape_gradients_cpu import instanced_slab_scene
+    res = 24
+    d = instanced_slab_scene(mi, res)
+    d.pop("light")
+    d["lamp"] = {"type": "point", "position": [0.1, 2.5, 0.2], "intensity": {"type": "rgb", "value": [42.0, 39.0, 34.0]}}
+    keys = [k for k, v in d.items() if isinstance(v, dict) and v.get("type") == "instance"]
+    d["integrator"] = {"type": "prb", "max_depth": 5, "shape_gradients": [k + ".to_world" for k in keys]}
+    scene = mi.load_dict(d)
+    osc, sensor = O.scene_from_product(scene)
+    grad_in = np.random.default_rng(4).uniform(0.5, 1.5, (res, res, 3)).astype(np.float32)
+    grads = scene.integrator().render_backward(scene, None, grad_in, seed=3, spp=16)
+    want, _, _, _ = osc.render_prb_backward_instances(sensor, grad_in, None, seed=3, spp=16, max_depth=5)
+    for i, k in enumerate(keys):
+        got = grads[k + ".to_world"].cpu().numpy()
+        scale = np.abs(want[i]).max()
+        assert scale > 0 and np.abs(got[:3] - want[i]).max() < 2e-3 * scale, (k, np.abs(got[:3] - want[i]).max() / scale)
+
+
 def test_vertex_position_update_rebuilds_the_scene(mi, O):
     """params['floor.vertex_positions'] = ...; params.update(): the next render sees the moved mesh (and matches the oracle's)"""
     from tests.test_cpu_host import oracle_scene_from

@@ -253,6 +253,118 @@ def test_product_host_adjoint_matches_oracle(mi, O, which):
         assert scale > 0 and np.abs(got[m] - want[m]).max() < 2e-3 * scale, (which, m, np.abs(got[m] - want[m]).max() / scale)
 
 
+# ------------------------------------------------------------------ delta lights (prb.py:176-216 for emitters that are neither surfaces nor infinite)
+
+def delta_slab_scene(mi, res=16, kind="point", rough=False):
+    """the slab scene lit by a point / spot / directional light instead of the rectangle.  point and spot: prb.py:191-192 re-attaches ds.d = normalize(ds.p - si.p);
+    PointLight::eval_direction follows si.p through squared_norm(ds.p - it.p) (point.cpp:155-165), SpotLight::eval_direction through the falloff of ds.d only -- its
+    rcp(ds.dist) is detached (spot.cpp:252-274); directional: EmitterFlags::Infinite, nothing re-attached"""
+    T = mi.ScalarTransform4f
+    d = slab_scene(mi, res)
+    d.pop("light")
+    if kind == "point":
+        d["lamp"] = {"type": "point", "position": [0.1, 2.5, 0.2], "intensity": {"type": "rgb", "value": [42.0, 39.0, 34.0]}}
+    elif kind == "spot":      # a wide transition zone (beam 12 deg, cutoff 55 deg): most of the visible floor lies where the falloff has a slope
+        d["lamp"] = {"type": "spot", "to_world": T().look_at(origin=[0.5, 2.6, 0.4], target=[-0.1, 0.0, -0.2], up=[0, 0, 1]),
+                     "intensity": {"type": "rgb", "value": [60.0, 55.0, 50.0]}, "cutoff_angle": 55.0, "beam_width": 12.0}
+    else:
+        d["lamp"] = {"type": "directional", "direction": [0.3, -1.0, 0.2], "irradiance": {"type": "rgb", "value": [3.0, 2.8, 2.5]}}
+        d.pop("ceiling")        # (a directional light above an unbounded ceiling lights nothing)
+    if rough:
+        d["floor"]["bsdf"] = dict(ROUGH_BSDFS["roughplastic"])
+    return d
+
+
+@pytest.mark.parametrize("kind", ["point", "directional", "point_rough"])
+def test_oracle_delta_light_shape_gradient_vs_finite_differences(mi, O, kind):
+    """the oracle's dual numbers against finite differences of its own primal renders, as above.  The point light's 1 / r^2 and its direction follow the moving floor;
+    the `spot` is NOT in this list: the reference keeps its rcp(ds.dist) detached, so its PRB gradient is not the derivative of its render (compared product-to-oracle below)"""
+    from tests.test_cpu_host import oracle_scene_from
+    res = 12
+    rough = kind.endswith("_rough")
+    scene = mi.load_dict(delta_slab_scene(mi, res, kind.split("_")[0], rough))
+    osc, sensor = oracle_scene_from(O, scene)
+    kw = dict(seed=11, spp=4096 if rough else 1024, max_depth=4)
+    w = np.random.default_rng(2).uniform(0.5, 1.5, (res, res, 3)).astype(np.float32)
+    m = mesh_index(scene, "floor")
+    g_pos, _, _, _ = osc.render_prb_backward_shape(sensor, w, [m], **kw)
+    base = scene.meshes[m]["V"][:, :3].astype(np.float32).copy()
+    motions = {"lift": np.tile([0, 1, 0], (4, 1)), "tilt": np.array([[0, -1, 0], [0, 1, 0], [0, 1, 0], [0, -1, 0]])}
+    scale = max(abs(float((g_pos[m] * mo).sum())) for mo in motions.values())        # (lifting an unbounded floor under a directional light changes nothing: both sides ~ 0)
+    assert scale > 0
+    for label, direction in motions.items():
+        fd = directional_fd(osc, sensor, m, base, direction.astype(np.float32), w, 2e-3 if label == "lift" else 2e-2, **kw)
+        ad = float((g_pos[m] * direction.astype(np.float64)).sum())
+        assert abs(fd - ad) <= (0.04 if rough else 0.03) * abs(fd) + 0.005 * scale, (kind, label, fd, ad)
+
+
+def generic_light_slab_scene(mi, res, kind):
+    """the slab scene under the other emitters of the generic-emitter kernels: a triangle-mesh area light (Mesh::sample_position), a rectangle light with a bitmap
+    radiance (area.cpp:133-165), an environment map (EmitterFlags::Infinite: nothing re-attached), two weighted rectangle lights (emitter_distr)"""
+    T = mi.ScalarTransform4f
+    d = slab_scene(mi, res)
+    if kind == "meshlight":
+        d["light"] = {"type": "cube", "to_world": T().translate([0.1, 2.8, 0.2]).scale([0.05, 0.03, 0.04]),
+                      "bsdf": {"type": "diffuse", "reflectance": {"type": "rgb", "value": [0, 0, 0]}},
+                      "emitter": {"type": "area", "radiance": {"type": "rgb", "value": [900.0, 850.0, 800.0]}}}
+    elif kind == "texlight":
+        rng = np.random.default_rng(9)
+        d["light"]["emitter"] = {"type": "area", "radiance": {"type": "bitmap", "data": rng.uniform(500.0, 6000.0, (5, 4, 3)).astype(np.float32), "raw": True}}
+    elif kind == "envmap":
+        rng = np.random.default_rng(8)
+        d.pop("ceiling"); d.pop("light")
+        d["sky"] = {"type": "envmap", "bitmap": mi.Bitmap(rng.uniform(0.2, 1.5, (8, 16, 3)).astype(np.float32))}
+    elif kind == "weighted":
+        d["light"]["emitter"]["sampling_weight"] = 3.0
+        d["light2"] = {"type": "rectangle", "to_world": T().translate([-0.6, 2.9, -0.3]).rotate([1, 0, 0], 90).scale([0.05, 0.05, 0.05]),
+                       "bsdf": {"type": "diffuse", "reflectance": {"type": "rgb", "value": [0, 0, 0]}},
+                       "emitter": {"type": "area", "radiance": {"type": "rgb", "value": [2500.0, 2700.0, 3000.0]}}}
+    return d
+
+
+@pytest.mark.parametrize("which", ["point", "spot", "directional", "point_rough", "spot_rough", "point_and_area", "meshlight", "texlight", "envmap", "weighted"])
+def test_product_host_adjoint_matches_oracle_under_delta_lights(mi, O, which):
+    """har_shape_grad.h (HAR_SHAPE_NEE_POINT / _SPOT: re-attached direction, 1 / r^2 of the point light, falloff slope of the spot) against the oracle, vertex by vertex;
+    and the other emitters of the generic-emitter kernel class (surface: Jacobian + direction; infinite: nothing)"""
+    from tests.test_cpu_host import oracle_scene_from
+    res = 16
+    kind = which.split("_")[0]
+    if which in ("meshlight", "texlight", "envmap", "weighted"):
+        d = generic_light_slab_scene(mi, res, which)
+    else:
+        d = delta_slab_scene(mi, res, kind, which.endswith("_rough"))
+    if which == "point_and_area":         # two emitters: the choice of the emitter (uniform) and both kinds of re-attachment in one render
+        d["light"] = slab_scene(mi, res)["light"]
+    scene = mi.load_dict(d)
+    names = ["floor"] + (["ceiling"] if "ceiling" in d else [])
+    osc, sensor = oracle_scene_from(O, scene)
+    ids = [mesh_index(scene, n) for n in names]
+    w = np.random.default_rng(4).uniform(0.5, 1.5, (res, res, 3)).astype(np.float32)
+    kw = dict(seed=3, spp=16, max_depth=5)
+    want, _, _, _ = osc.render_prb_backward_shape(sensor, w, ids, **kw)
+    got = product_host_gradients(O, harness(O), scene, sensor, w, ids, **kw)
+    for m in ids:
+        scale = np.abs(want[m]).max()
+        assert scale > 0 and np.abs(got[m] - want[m]).max() < 2e-3 * scale, (which, m, np.abs(got[m] - want[m]).max() / scale)
+
+
+def test_spot_falloff_slope_reaches_the_gradient(mi, O):
+    """the spot's transition zone must matter: with the beam as wide as the cutoff allows the falloff is flat wherever the light reaches, and the floor's gradient differs"""
+    from tests.test_cpu_host import oracle_scene_from
+    res = 12; grads = []
+    for beam in (12.0, 54.9):
+        d = delta_slab_scene(mi, res, "spot"); d["lamp"]["beam_width"] = beam
+        scene = mi.load_dict(d)
+        osc, sensor = oracle_scene_from(O, scene)
+        m = mesh_index(scene, "floor")
+        w = np.ones((res, res, 3), np.float32)
+        g, _, _, _ = osc.render_prb_backward_shape(sensor, w, [m], seed=5, spp=64, max_depth=2)
+        grads.append(g[m].copy())
+    tilt = np.array([[0, -1, 0], [0, 1, 0], [0, 1, 0], [0, -1, 0]], np.float64)
+    a, b = float((grads[0] * tilt).sum()), float((grads[1] * tilt).sum())
+    assert abs(a - b) > 0.05 * max(abs(a), abs(b))
+
+
 # ------------------------------------------------------------------ instance to_world gradients (instance.cpp:150-266)
 
 def instanced_slab_scene(mi, res=24, env=False, model=None):
@@ -415,11 +527,14 @@ def test_product_host_nested_mesh_adjoint_matches_oracle(mi, O, which):
     assert scale > 0 and np.abs(got[m] - want[m]).max() < 2e-3 * scale, (which, np.abs(got[m] - want[m]).max() / scale)
 
 
-@pytest.mark.parametrize("which", ["slab", "slab_env", "cbox", "slab_roughplastic", "slab_roughconductor", "slab_plastic"])
+@pytest.mark.parametrize("which", ["slab", "slab_env", "cbox", "slab_roughplastic", "slab_roughconductor", "slab_plastic", "slab_point", "slab_spot"])
 def test_product_host_instance_adjoint_matches_oracle(mi, O, which):
     """instance_item_adjoint (har_shape_grad.h, fp32, hand-derived) against the oracle's dual numbers (fp64), instance by instance, same seed"""
     if which == "cbox":
         res = 20; scene = mi.load_dict(instanced_cbox_scene(mi, res))
+    elif which in ("slab_point", "slab_spot"):          # delta lights: the re-attached direction (and the point light's 1 / r^2) of a vertex on a moving instance
+        res = 16; d = instanced_slab_scene(mi, res); d.pop("light"); d["lamp"] = delta_slab_scene(mi, res, which[5:])["lamp"]
+        scene = mi.load_dict(d)
     else:
         res = 16; scene = mi.load_dict(instanced_slab_scene(mi, res, env=which == "slab_env", model=which[5:] if which[5:] in ROUGH_BSDFS else None))
     osc, sensor = O.scene_from_product(scene)
