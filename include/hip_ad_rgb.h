@@ -545,6 +545,13 @@ int har_sampler_advance(uint32_t n, uint64_t *state, const uint64_t *inc, void *
  * [12..14] colour slot 1 (roughplastic.specular_reflectance).  NULL switches it off (default).  Needs the replay cache (default) and
  * max_depth <= 12; delta lobes and the `eta` of plastic / rough plastic carry no gradient (as in the reference). */
 int har_integrator_set_grad_bsdf_params(HarIntegrator integrator, float *grad);
+
+/* `prb`: gradients w.r.t. the TEXELS of a bitmap `radiance` of area lights (src/emitters/area.cpp:64-70: `radiance` is a differentiable traverse entry; :83-90 eval at si.uv,
+ * :133-165 sample_direction with the bitmap evaluated at the sampled ds.uv) for the following har_render_backward calls: d Le / d radiance(si.uv) at emitter hits (prb.py:160-161),
+ * d Lr_dir / d radiance(ds.uv) at visible emitter samples with the sampling density detached (prb.py:174-175, 203-206), both through the transpose of the bitmap lookup, ACCUMULATED
+ * into the light's bitmap's entry of `grad_textures` (which har_render_backward takes for every texture of the scene).  0 switches it off (default).  Needs the replay cache
+ * (default) and max_depth <= 12; not combined with vertex-position gradients; reverse mode only. */
+int har_integrator_set_grad_light_texels(HarIntegrator integrator, int on);
 /* counters of the last har_render / har_render_backward on this integrator (synchronises) */
 int har_render_stats(HarIntegrator integrator, HarStats *out);
 /* HIP-event timing of the render calls ("frames") issued since har_integrator_set_profiling(.., 1): one event per kernel launch, recorded on

@@ -93,6 +93,7 @@ SIGNATURES = {
     "har_scene_set_emitter_radiance": (C.c_int, [vp, C.c_uint32, f32p]),
     "har_integrator_set_grad_emitters": (C.c_int, [vp, vp]),
     "har_integrator_set_grad_bsdf_params": (C.c_int, [vp, vp]),
+    "har_integrator_set_grad_light_texels": (C.c_int, [vp, C.c_int]),
     "har_integrator_set_grad_positions": (C.c_int, [vp, vp, vp]),
     "har_integrator_set_grad_instances": (C.c_int, [vp, vp, vp]),
     "har_integrator_set_hide_emitters": (C.c_int, [vp, C.c_int]),

@@ -1155,7 +1155,7 @@ class Integrator:
     def __init__(self, props):
         self.type = props['type']
         # integrator.cpp:26-33,128-147,539-550; block_size only shapes the scalar / LLVM-parallel drivers; the last four are hip_ad_rgb extensions
-        _check_props(self.type, props, ('max_depth', 'rr_depth', 'hide_emitters', 'samples_per_pass', 'block_size', 'chunk_lanes', 'replay_cache', 'material_queues', 'packet_tracing', 'emitter_gradients', 'shape_gradients', 'bsdf_parameter_gradients'),
+        _check_props(self.type, props, ('max_depth', 'rr_depth', 'hide_emitters', 'samples_per_pass', 'block_size', 'chunk_lanes', 'replay_cache', 'material_queues', 'packet_tracing', 'emitter_gradients', 'shape_gradients', 'bsdf_parameter_gradients', 'light_texel_gradients'),
                      unsupported=(('timeout', -1.0),), free_children=False, slot_kind=())
         default_depth = -1 if self.type == 'path' else 6        # integrator.cpp:539, common.py:31
         self.max_depth = int(props.get('max_depth', default_depth))
@@ -1176,6 +1176,8 @@ class Integrator:
         self.shape_gradients = props.get('shape_gradients', False)
         # gradients of `alpha` / `alpha_u` / `alpha_v`, `eta`, `k` (roughconductor) and `alpha`, `specular_reflectance` (roughplastic): har_integrator_set_grad_bsdf_params
         self.bsdf_parameter_gradients = bool(props.get('bsdf_parameter_gradients', False))
+        # gradients w.r.t. the texels of a bitmap `radiance` of area lights ('<shape>.emitter.radiance.data'; area.cpp:64-70): har_integrator_set_grad_light_texels
+        self.light_texel_gradients = bool(props.get('light_texel_gradients', False))
         # SamplingIntegrator property (integrator.cpp:140-147); the Python AD integrators do not query it, and an
         # unqueried property is an error in the reference's plugin loader
         self.samples_per_pass = props.get('samples_per_pass', None)
@@ -1378,6 +1380,7 @@ class Integrator:
             check(lib().har_integrator_set_grad_instances(self._handle(), None, None))
         g_extra = torch.zeros((max(1, len(scene.bsdfs)), 15), dtype=torch.float32, device=dev) if self.bsdf_parameter_gradients else None
         check(lib().har_integrator_set_grad_bsdf_params(self._handle(), _ptr(g_extra) if g_extra is not None else None))
+        check(lib().har_integrator_set_grad_light_texels(self._handle(), 1 if self.light_texel_gradients else 0))
         check(lib().har_render_backward(scene._handle(), self._handle(), C.byref(sensor.har), _ptr(grad_in), _ptr(weight_film), sd, spp,
                                         lb, le, _ptr(g_refl), ptrs, _stream()))
         out = scene._gradients(g_refl, g_tex, g_emit if self.emitter_gradients else None)
@@ -1386,6 +1389,10 @@ class Integrator:
                 rec = g_extra[b.index]
                 out[k] = {"alpha": rec[0:6].sum().reshape(1), "alpha_u": rec[0:3].sum().reshape(1), "alpha_v": rec[3:6].sum().reshape(1),
                           "eta": rec[6:9], "k": rec[9:12], "slot1": rec[12:15]}[what]
+        if self.light_texel_gradients:            # the light's bitmap is a texture of the scene like any other: its gradient sits in its entry of grad_textures
+            for k, (kind, i) in scene._pose_keys().items():
+                if kind == "emitter_tex":
+                    out[k] = g_tex[scene.emitters[i]["light"].tex_index]
         out.update(g_pos)
         for k, i in inst_wanted.items():                      # column-major 3x4 -> the reference's 4x4 (constant fourth row: zero gradient)
             m = torch.zeros((4, 4), dtype=torch.float32, device=dev); m[:3, :] = g_inst[i].reshape(4, 3).T
@@ -2035,8 +2042,8 @@ class Scene:
                 keys[key + ".cutoff_angle"] = ("cutoff_angle", i); keys[key + ".beam_width"] = ("beam_width", i)
             # Emitter::traverse (src/render/emitter.cpp:13): `sampling_weight`, NonDifferentiable; an area light is a child of its shape ('<shape>.emitter.*')
             keys[key + (".emitter" if t in (0, 3, 7) else "") + ".sampling_weight"] = ("sampling_weight", i)
-            if t == 7:          # AreaLight::traverse -> "radiance" -> BitmapTexture::traverse: `data` and `to_uv` (bitmap.cpp:463-475).  The reference marks `data`
-                                # Differentiable; no gradient is produced for it here (requires_grad on this key is refused like any key outside the gradient tables)
+            if t == 7:          # AreaLight::traverse -> "radiance" -> BitmapTexture::traverse: `data` and `to_uv` (bitmap.cpp:463-475).  `data` is Differentiable: the `prb`
+                                # integrator's `light_texel_gradients` (switched on by mi.render for a key with requires_grad) produces its gradient
                 keys[key + ".emitter.radiance.data"] = ("emitter_tex", i); keys[key + ".emitter.radiance.to_uv"] = ("emitter_to_uv", i)
         for b in self.bsdf_objs:            # BitmapTexture::traverse: `to_uv` (src/textures/bitmap.cpp), NonDifferentiable
             if b.texture is not None:
@@ -2702,7 +2709,7 @@ def render(scene, params=None, sensor=0, integrator=None, seed=0, seed_grad=0, s
             raise RuntimeError("scalar_rgb renders are not differentiable (the reference's scalar variants have no AD either); use hip_ad_rgb")
         return _render_scalar(scene, integrator, sensor, seed, spp)
     keys = [k for k, v in (params or {}).items() if getattr(v, 'requires_grad', False)]
-    fixed = [k for k in keys if k in scene._pose_keys()]
+    fixed = [k for k in keys if k in scene._pose_keys() and scene._pose_keys()[k][0] != "emitter_tex"]      # (a light's radiance bitmap IS differentiable: area.cpp:64-70)
     if fixed:       # ParamFlags::NonDifferentiable in the reference's traverse(): dr.enable_grad on them has no effect there; here it is said
         raise RuntimeError("%s are not differentiable parameters in hip_ad_rgb (placement of sensors and delta emitters: ParamFlags::NonDifferentiable in the reference; "
                            "a spot light's cutoff_angle / beam_width: Differentiable there, updatable but without a gradient here)" % fixed)
@@ -2719,6 +2726,8 @@ def render(scene, params=None, sensor=0, integrator=None, seed=0, seed_grad=0, s
             overrides['shape_gradients'] = sorted(set(list(integrator.shape_gradients or [])) | set(shape_keys))
         if any(k in scene._bsdf_param_keys() for k in keys) and not integrator.bsdf_parameter_gradients:
             overrides['bsdf_parameter_gradients'] = True
+        if any(scene._pose_keys().get(k, (None,))[0] == "emitter_tex" for k in keys) and not integrator.light_texel_gradients:
+            overrides['light_texel_gradients'] = True
         if any(v[0] == "emit" for k, v in scene._param_keys().items() if k in keys) and not integrator.emitter_gradients:
             overrides['emitter_gradients'] = True
 
@@ -2742,7 +2751,7 @@ def render(scene, params=None, sensor=0, integrator=None, seed=0, seed_grad=0, s
             missing = [k for k in keys if k not in grads]
             if missing:       # e.g. emitter radiance with emitter_gradients=False, vertex positions without shape_gradients
                 raise RuntimeError("mi.render(): the `prb` integrator cannot differentiate %s (integrator properties `emitter_gradients`, "
-                                   "`shape_gradients`, `bsdf_parameter_gradients`); differentiable keys of this render: %s" % (missing, sorted(grads)))
+                                   "`shape_gradients`, `bsdf_parameter_gradients`, `light_texel_gradients`); differentiable keys of this render: %s" % (missing, sorted(grads)))
             return tuple(grads[k].reshape(params[k].shape) for k in keys)
 
     return _RenderOp.apply(*[params[k] for k in keys])

@@ -201,6 +201,7 @@ struct HarIntegratorImpl {
     float *grad_slots = nullptr; size_t grad_slots_cap = 0;   /* adjoint accumulators: (bsdf_count + emitter_count) x 3 */
     float *grad_emitters = nullptr;       /* user buffer (DEVICE, emitter_count x 3) of har_integrator_set_grad_emitters, or null */
     float *grad_bsdf_params = nullptr;    /* user buffer (DEVICE, bsdf_count x 15) of har_integrator_set_grad_bsdf_params, or null */
+    bool grad_light_texels = false;       /* har_integrator_set_grad_light_texels: the texels of bitmap `radiance` textures of area lights are differentiated (into their entries of grad_textures) */
     /* vertex-position gradients (har_integrator_set_grad_positions): user buffers per top-level mesh, the flat accumulation buffer + offsets */
     bool shape_on = false; std::vector<float *> pos_user; std::vector<int32_t> pos_offset; std::vector<uint32_t> pos_count;
     int32_t *d_pos_offset = nullptr; float *grad_pos = nullptr; uint32_t pos_verts = 0; ShapeArrays geo{};
@@ -553,8 +554,10 @@ int run_chunk(HarSceneImpl *S, HarIntegratorImpl *I, const DSensor &C, int mode,
                        (I->forward_mode || (mode == MODE_PRB_PRIMAL && !rec_w)) ? nullptr : I->adj, I->dL, ps, first_regen);
     prof_mark(I, s, CLS_RAYGEN);
     const bool fwd = mode == MODE_PRB_ADJOINT && I->forward_mode;
-    ShadeParams P{ seed, I->max_depth, I->rr_depth, (((mode == MODE_PRB_ADJOINT || rec_w) && I->grad_emitters) ? HAR_SHADE_EMITTER_GRADS : 0u) | (I->hide_emitters ? HAR_SHADE_HIDE_EMITTERS : 0u) |
-                   (fwd ? HAR_SHADE_FORWARD_MODE : 0u) | ((mode == MODE_PRB_ADJOINT && I->grad_bsdf_params && !fwd) ? HAR_SHADE_EXTRA_GRADS : 0u) };
+    ShadeParams P{ seed, I->max_depth, I->rr_depth, ((mode != MODE_PATH && I->grad_emitters) ? HAR_SHADE_EMITTER_GRADS : 0u)      /* (the primal pass of a backward step too: it traces the shadow rays of samples that only carry a radiance gradient, shade_lane) */ | (I->hide_emitters ? HAR_SHADE_HIDE_EMITTERS : 0u) |
+                   (fwd ? HAR_SHADE_FORWARD_MODE : 0u) | ((mode == MODE_PRB_ADJOINT && I->grad_bsdf_params && !fwd) ? HAR_SHADE_EXTRA_GRADS : 0u) |
+                   /* both passes of a backward step: the primal pass traces the shadow rays whose visibility the adjoint pass reads (shade_lane: lt_item) */
+                   ((mode != MODE_PATH && I->grad_light_texels && !I->forward_mode && (S->ds.bsdf_types & HAR_SCENE_TEXLIGHT)) ? HAR_SHADE_LIGHT_TEXELS : 0u) };
     /* generic shading kernels: material-sort window in tiles of 256 paths (k_shade; HAR_SORT_WINDOW=1 is the round-3 kernel, A/B) */
     static const uint32_t sort_window_env = getenv("HAR_SORT_WINDOW") ? (uint32_t) std::max(1, atoi(getenv("HAR_SORT_WINDOW"))) : 8u;
     P.sort_window = sort_window_env;
@@ -1724,7 +1727,7 @@ static uint64_t dual_split(HarIntegrator I, uint64_t lb, uint64_t le, hipStream_
     }
     HarIntegratorImpl *T = I->twin;
     T->type = I->type; T->max_depth = I->max_depth; T->rr_depth = I->rr_depth; T->chunk = I->chunk; T->samples_per_pass = I->samples_per_pass;
-    T->grad_emitters = I->grad_emitters; T->grad_bsdf_params = I->grad_bsdf_params; T->profiling = I->profiling; T->hide_emitters = I->hide_emitters;
+    T->grad_emitters = I->grad_emitters; T->grad_bsdf_params = I->grad_bsdf_params; T->grad_light_texels = I->grad_light_texels; T->profiling = I->profiling; T->hide_emitters = I->hide_emitters;
     T->alpha_film = I->alpha_film;
     if (T->use_cache != I->use_cache) { (void) hipDeviceSynchronize(); T->free_ws(); T->use_cache = I->use_cache; }
     if (hipEventRecord(I->ev_fork, s) != hipSuccess || hipStreamWaitEvent(I->side_stream, I->ev_fork, 0) != hipSuccess) return le;
@@ -1934,7 +1937,9 @@ static int backward_range(HarScene S, HarIntegrator I, const HarSensor *sensor, 
     const uint64_t job_key = S->serial * 0x9e3779b97f4a7c15ull ^ ((uint64_t) C.crop_w << 40) ^ ((uint64_t) C.crop_h << 20) ^ (le - lb);
     if (I->bw_job_key != job_key || (++I->bw_calls_since_stepdown & 15u) == 0u) { I->bw_tape_max = 2; I->bw_chunk_max = 0xffffffffu; I->bw_job_key = job_key; }
     chunk = std::min(chunk, I->bw_chunk_max);
-    int tape = !tape_ok ? 0 : (tape_kind_env >= 2 && !I->grad_bsdf_params && chunk <= (1u << 29)) ? 2 : 1;
+    /* texels of a light's bitmap radiance: committed in place by the re-shading replay as well (the record tape holds neither the sampled uv nor the unit weight) */
+    const bool light_texels = I->grad_light_texels && (S->ds.bsdf_types & HAR_SCENE_TEXLIGHT) != 0u;
+    int tape = !tape_ok ? 0 : (tape_kind_env >= 2 && !I->grad_bsdf_params && !light_texels && chunk <= (1u << 29)) ? 2 : 1;
     tape = std::min(tape, I->bw_tape_max);
     /* The tapes are the large workspaces (record tape 69 B, state tape 115 B per lane and bounce against 25 B for the lane-indexed cache: 28 - 90 GB for a 2^26-lane chunk
      * at max_depth 6 - 12).  When the device -- or the host's allocator pool, shared with the caller's tensors -- cannot hold one, step down instead of failing: record
@@ -1968,6 +1973,12 @@ static int backward_range(HarScene S, HarIntegrator I, const HarSensor *sensor, 
         if (!grad_textures) return fail("grad_textures is null but the scene has bitmap textures");
         for (size_t k = 0; k < nt; ++k) if (!grad_textures[k]) return fail("null texture gradient buffer");
         if (upload_pointer_table(I, (const void *const *) grad_textures, nt, s)) return 1;
+    }
+    if (light_texels) {
+        if (!I->use_cache || I->shape_on) return fail("gradients of a light's texels need the replay cache and cannot be combined with vertex-position gradients");
+        if (bounce_limit(I) > HAR_REPLAY_CACHE_BOUNCES) return fail("gradients of a light's texels: max_depth must not exceed " + std::to_string(HAR_REPLAY_CACHE_BOUNCES) + " (the cached bounces)");
+        static const bool inline_env = getenv("HAR_ADJOINT_INLINE") ? atoi(getenv("HAR_ADJOINT_INLINE")) != 0 : true;
+        if (!inline_env) return fail("gradients of a light's texels need the in-place commit (HAR_ADJOINT_INLINE=0 is set)");
     }
     if (I->grad_bsdf_params) {
         /* the alpha / eta / k / slot-1 terms are committed in place by the cached-bounce shading kernel only */
@@ -2139,6 +2150,13 @@ int har_integrator_set_grad_bsdf_params(HarIntegrator I, float *grad) {
     if (!I) return fail("null integrator");
     if (I->type != HAR_INTEGRATOR_PRB) return fail("BSDF parameter gradients are computed by the `prb` integrator");
     I->grad_bsdf_params = grad;
+    return 0;
+}
+
+int har_integrator_set_grad_light_texels(HarIntegrator I, int on) {
+    if (!I) return fail("null integrator");
+    if (I->type != HAR_INTEGRATOR_PRB) return fail("gradients of a light's texels are computed by the `prb` integrator");
+    I->grad_light_texels = on != 0;
     return 0;
 }
 

@@ -906,6 +906,20 @@ __device__ __forceinline__ void adjoint_commit_regs(const DScene &S, bool pred, 
             wave_aggregated_add3(nz_direct && tex ? tdst + 3 * (size_t) taps.idx[k] : grad_refl, nz_direct && tex ? g * w[k] : Vec3(0.f), nz_direct && tex);
     }
 }
+/* g * d radiance(u, v) / d texels into the gradient buffer of emitter `index`'s bitmap (type 7): the transpose of the lookup (nearest: four coincident taps of weight 1, 0, 0, 0);
+ * called by whole waves */
+__device__ __forceinline__ void light_texel_commit(const DScene &S, float *const *grad_tex, bool pred, int32_t index, float u, float v, Vec3 g) {
+    pred = pred && (g.x != 0.f || g.y != 0.f || g.z != 0.f);
+    if (!__ballot(pred)) return;
+    TexTaps taps; float *dst = nullptr;
+    taps.idx[0] = taps.idx[1] = taps.idx[2] = taps.idx[3] = 0u; taps.w0x = taps.w1x = taps.w0y = taps.w1y = 0.f;
+    if (pred) { const uint32_t t = as_u32(S.emitters[index].radiance[0]); tex_taps(S.textures[t], u, v, taps); dst = grad_tex[t]; }
+    const float w[4] = { taps.w0x * taps.w0y, taps.w1x * taps.w0y, taps.w0x * taps.w1y, taps.w1x * taps.w1y };
+    for (int k = 0; k < 4; ++k) {
+        const bool on = pred && w[k] != 0.f;
+        wave_aggregated_add3(on ? dst + 3 * (size_t) taps.idx[k] : nullptr, on ? g * w[k] : Vec3(0.f), on);
+    }
+}
 template <bool FWD = false>
 __device__ __forceinline__ void adjoint_commit_values(const DScene &S, bool pred, bool visible, uint32_t lane, float4 s2, float4 s3, float4 s4, float4 *result, const float4 *dL,
                                                       float *grad_refl, float *const *grad_tex, float *gacc, const TexelQueues *tq = nullptr, TexelRecord *rec = nullptr) {
@@ -1162,6 +1176,7 @@ __global__ __launch_bounds__(kBlock, (RECORD && TYPES == HAR_BSDF_ONLY_DIFFUSE &
         Vec3 Lr(0.f), dlr(0.f); bool L_dirty = false;
         const bool tape_read = MODE == MODE_PRB_ADJOINT && INLINE && rc.mode == 4;
         bool eg_lds = false; uint32_t eg_slot = 0; Vec3 eg(0.f);          /* d L / d radiance of the emitter met by this lane (emission hit) */
+        bool lt_hit = false; Vec3 lt_hit_g(0.f);                            /* ... when that emitter's radiance is a bitmap and its texels are differentiated (HAR_SHADE_LIGHT_TEXELS) */
         if (in_range) {
             PathState st;
             if (FIRST) {         /* slot `local` of shard s holds lane ((local / 256) * HAR_SHARDS + s) * 256 + local % 256 of the chunk (shard_slot) */
@@ -1198,6 +1213,7 @@ __global__ __launch_bounds__(kBlock, (RECORD && TYPES == HAR_BSDF_ONLY_DIFFUSE &
             }
             if (R.add_emission && MODE == MODE_PRB_ADJOINT && INLINE) {
                 Lr = Vec3(Lr.x - R.em_b.x, Lr.y - R.em_b.y, Lr.z - R.em_b.z); L_dirty = true;
+                if ((TYPES & HAR_SCENE_TEXLIGHT) != 0u && R.lt_hit_emitter >= 0) { lt_hit = true; lt_hit_g = R.em_unit * dlr; }
                 if (emitter_grads && R.em_index >= 0) {
                     const Vec3 g = R.em_unit * dlr;
                     if ((uint32_t) R.em_index < HAR_LDS_GRAD_EMITTERS) { eg_lds = true; eg_slot = (uint32_t) R.em_index; eg = g; }      /* committed below by the whole wave */
@@ -1235,6 +1251,13 @@ __global__ __launch_bounds__(kBlock, (RECORD && TYPES == HAR_BSDF_ONLY_DIFFUSE &
             adjoint_commit_regs(S, item_pred, visible, make_float4(c.x, c.y, c.z, __uint_as_float(tag)), make_float4(R.dLr_drho.x, R.dLr_drho.y, R.dLr_drho.z, R.uv_x),
                                 make_float4(R.rel_grad.x, R.rel_grad.y, R.rel_grad.z, R.uv_y), Lr, L_dirty, dlr, grad_slots, grad_tex, gacc,      /* forward mode never commits in place (host) */
                                 tq.nq ? &tq : nullptr, &rec);
+            if ((TYPES & HAR_SCENE_TEXLIGHT) != 0u && (P.flags & HAR_SHADE_LIGHT_TEXELS)) {
+                /* the texels of a bitmap `radiance` (area.cpp:64-70): d Le / d radiance(si.uv) = beta mis at an emitter hit, d Lr_dir / d radiance(ds.uv) = beta mis f / pdf at a
+                 * VISIBLE emitter sample -- scattered through the transpose of the bilinear lookup, pre-reduced over the wave (all lanes of a block sample the same few texels) */
+                light_texel_commit(S, grad_tex, in_range && lt_hit, R.lt_hit_emitter, R.lt_hit_uv[0], R.lt_hit_uv[1], lt_hit_g);
+                const bool lt_nee = visible && R.lt_nee_emitter >= 0;
+                light_texel_commit(S, grad_tex, lt_nee, R.lt_nee_emitter, R.lt_nee_uv[0], R.lt_nee_uv[1], R.contrib_unit * dlr);
+            }
             if (EXTRA && item_pred) {
                 /* the same two terms as for slot 0 (adjoint_commit_regs), for the five other parameter groups: g = dL * ([visible] d Lr_dir / d theta
                  * + [path continues] L * (d f / d theta) / f), with L already reduced by this vertex's Lr_dir */

@@ -44,6 +44,7 @@ struct ShadeParams {
 #define HAR_SHADE_FORWARD_MODE 4u    /* adjoint kernels in FORWARD mode (RBIntegrator.render_forward): parameter tangents in, differential radiance out */
 #define HAR_SHADE_EXTRA_GRADS 16u    /* adjoint: also differentiate w.r.t. alpha / eta / k / colour slot 1 of the rough BSDF models (ShadeResult::x_dir / x_rel) */
 #define HAR_SHADE_SCALAR_DRAWS 8u    /* scalar variants: the two emitter samples are only drawn where the BSDF has a smooth lobe (path.cpp:244-249); JIT variants draw them on every lane */
+#define HAR_SHADE_LIGHT_TEXELS 64u    /* adjoint: also differentiate w.r.t. the texels of bitmap `radiance` textures of area lights (ShadeResult::lt_*; committed in place by the re-shading replay) */
 #define HAR_SHADE_HIDE_EMITTERS 2u   /* Integrator property `hide_emitters`: the environment is not seen by camera rays (path.cpp:114-115, prb.py:146-148) */
 #define HAR_ITEM_NO_EMITTER 0x7ffu   /* emitter field of an adjoint item's tag: contribution stored as is (no emitter gradient) */
 
@@ -71,6 +72,10 @@ struct ShadeResult {
      * complex IOR, per channel), 4 colour slot 1: x_dir[g] = d Lr_dir / d theta_g (per channel), x_rel[g] = (d f / d theta_g) / f at the sampled
      * direction -- what dLr_drho / rel_grad are for slot 0 (prb.py:288-313) */
     Vec3 x_dir[5], x_rel[5]; bool x_ind;
+    /* ... with HAR_SHADE_LIGHT_TEXELS (kernels of scenes with a bitmap-radiance area light only): the emitter met at the vertex / sampled from it when its radiance is a bitmap
+     * (-1: none), and the uv its bitmap is looked up at -- si.uv of the hit (area.cpp:83-90), ds.uv of the sample (:139-146).  d em_b / d radiance(uv) = em_unit, d contrib / d
+     * radiance(uv) = contrib_unit, as for the colour of a uniform light */
+    int32_t lt_hit_emitter, lt_nee_emitter; float lt_hit_uv[2], lt_nee_uv[2];
 };
 #define HAR_EXTRA_GROUPS 5
 
@@ -127,6 +132,7 @@ template <int MODE, uint32_t TYPES = HAR_BSDF_ALL_TYPES, bool EXTRA = false>
 HAR_HD void shade_lane(const DScene &S, const ShadeParams &P, const PathState &st, const Hit &hit, ShadeResult &R, const HitExtra *hx = nullptr) {
     R.alive = false; R.add_emission = false; R.item = false; R.item_ray = false;
     if (MODE == MODE_PRB_ADJOINT && EXTRA) { for (int g = 0; g < 5; ++g) { R.x_dir[g] = Vec3(0.f); R.x_rel[g] = Vec3(0.f); } R.x_ind = false; }
+    if (MODE == MODE_PRB_ADJOINT) { R.lt_hit_emitter = -1; R.lt_nee_emitter = -1; R.lt_hit_uv[0] = R.lt_hit_uv[1] = R.lt_nee_uv[0] = R.lt_nee_uv[1] = 0.f; }
     if (MODE == MODE_PRB_ADJOINT) { R.em_index = -1; R.nee_emitter = -1; R.em_unit = Vec3(0.f); R.contrib_unit = Vec3(0.f); R.nee_flags = 0u; R.cos_em = 0.f; R.nee_p = Vec3(0.f); R.nee_n = Vec3(0.f); R.nee_w = Vec3(0.f); }
     uint64_t rng = st.rng;
     const uint64_t inc = sampler_inc(P.seed, st.lane);
@@ -174,6 +180,7 @@ HAR_HD void shade_lane(const DScene &S, const ShadeParams &P, const PathState &s
             if (MODE == MODE_PRB_ADJOINT) {          /* prb.py:160-161 with the emitter's eval attached: d Le / d radiance = beta * mis */
                 R.em_index = (E.type != 2u && E.type != 7u && facing) ? emitter : -1;      /* (no colour parameter behind an environment map or a bitmap radiance) */
                 R.em_unit = st.throughput * mis;
+                if (textured && facing && (P.flags & HAR_SHADE_LIGHT_TEXELS)) { R.lt_hit_emitter = emitter; R.lt_hit_uv[0] = si.uv_x; R.lt_hit_uv[1] = si.uv_y; }
             }
         }
     }
@@ -198,6 +205,7 @@ HAR_HD void shade_lane(const DScene &S, const ShadeParams &P, const PathState &s
     if (!(P.flags & HAR_SHADE_SCALAR_DRAWS) || smooth) { ex = pcg32_next_float(rng, inc); ey = pcg32_next_float(rng, inc); }
     DirSample ds; ds.pdf = 0.f; ds.d = Vec3(0.f); ds.p = Vec3(0.f); ds.n = Vec3(0.f); ds.dist = 0.f;
     Vec3 em_weight(0.f); float em_unit = 0.f; uint32_t em_sampled = 0;
+    bool lt_sampled = false;                                     /* HAR_SHADE_LIGHT_TEXELS: the sample lies on a bitmap-radiance light */
     bool em_delta = false;                                       /* DirectionSample::delta: a point light's sample carries MIS weight 1 (path.cpp:274, prb.py:211) */
     bool active_em = active_next && S.n_emitters > 0 && smooth;
     if (active_em) {
@@ -218,15 +226,21 @@ HAR_HD void shade_lane(const DScene &S, const ShadeParams &P, const PathState &s
         else if (distr) sel_pmf = 1.f;
         if ((TYPES & HAR_SCENE_ENVMAP) != 0u && S.emitters[index].type == 2u) envmap_sample_direction(*S.envmap, si.p, ex, ey, ds, em_weight);
         else if ((TYPES & HAR_SCENE_ENVMAP) != 0u && S.emitters[index].type == 3u)
-            mesh_emitter_sample_direction(S, S.emitters[index], si.p, ex, ey, ds, em_weight, MODE == MODE_PRB_ADJOINT ? &em_unit : nullptr);
+            mesh_emitter_sample_direction(S, S.emitters[index], si.p, ex, ey, ds, em_weight, MODE != MODE_PATH ? &em_unit : nullptr);
         else if ((TYPES & HAR_SCENE_ENVMAP) != 0u && S.emitters[index].type == 4u) {
-            point_sample_direction(S.emitters[index], si.p, ds, em_weight, MODE == MODE_PRB_ADJOINT ? &em_unit : nullptr); em_delta = true;
+            point_sample_direction(S.emitters[index], si.p, ds, em_weight, MODE != MODE_PATH ? &em_unit : nullptr); em_delta = true;
         } else if ((TYPES & HAR_SCENE_ENVMAP) != 0u && S.emitters[index].type == 5u) {
-            spot_sample_direction(S.emitters[index], si.p, ds, em_weight, MODE == MODE_PRB_ADJOINT ? &em_unit : nullptr); em_delta = true;
+            spot_sample_direction(S.emitters[index], si.p, ds, em_weight, MODE != MODE_PATH ? &em_unit : nullptr); em_delta = true;
         } else if ((TYPES & HAR_SCENE_ENVMAP) != 0u && S.emitters[index].type == 6u) {
-            directional_sample_direction(S.emitters[index], si.p, ds, em_weight, MODE == MODE_PRB_ADJOINT ? &em_unit : nullptr); em_delta = true;
+            directional_sample_direction(S.emitters[index], si.p, ds, em_weight, MODE != MODE_PATH ? &em_unit : nullptr); em_delta = true;
         } else if ((TYPES & HAR_SCENE_TEXLIGHT) != 0u && S.emitters[index].type == 7u) {
-            textured_area_sample_direction(S, S.emitters[index], si.p, ex, ey, ds, em_weight);
+            /* (the PRIMAL pass of a texel-gradient step asks for the unit weight too: a sample over texels that are all ZERO contributes nothing and still has a derivative,
+             * so its shadow ray must be traced by the pass that fills the visibility bytes -- lt_item below) */
+            const bool lt = MODE != MODE_PATH && (P.flags & HAR_SHADE_LIGHT_TEXELS) != 0u;
+            float lt_uv[2] = { 0.f, 0.f };
+            textured_area_sample_direction(S, S.emitters[index], si.p, ex, ey, ds, em_weight, lt ? &em_unit : nullptr, lt ? lt_uv : nullptr);
+            if (lt) lt_sampled = true;
+            if (lt && MODE == MODE_PRB_ADJOINT) { R.lt_nee_emitter = (int32_t) index; R.lt_nee_uv[0] = lt_uv[0]; R.lt_nee_uv[1] = lt_uv[1]; }
         }
         /* a scene with ONE emitter (the bench scenes): its record travels with the kernel arguments (DScene::emitter0), i.e. in scalar registers, instead of being gathered
          * by every lane -- six vector loads less in a kernel that is bound by the number of its memory transactions (k_shade, docs/rounds/r05.md item 11) */
@@ -235,10 +249,10 @@ HAR_HD void shade_lane(const DScene &S, const ShadeParams &P, const PathState &s
                 DEmitter E0 = S.emitter0;
                 const float *rad = S.emitters[0].radiance;
                 E0.radiance[0] = rad[0]; E0.radiance[1] = rad[1]; E0.radiance[2] = rad[2];
-                emitter_sample_direction(E0, si.p, ex, ey, ds, em_weight, MODE == MODE_PRB_ADJOINT ? &em_unit : nullptr);
-            } else emitter_sample_direction(S.emitter0, si.p, ex, ey, ds, em_weight, MODE == MODE_PRB_ADJOINT ? &em_unit : nullptr);
+                emitter_sample_direction(E0, si.p, ex, ey, ds, em_weight, MODE != MODE_PATH ? &em_unit : nullptr);
+            } else emitter_sample_direction(S.emitter0, si.p, ex, ey, ds, em_weight, MODE != MODE_PATH ? &em_unit : nullptr);
         }
-        else emitter_sample_direction(S.emitters[index], si.p, ex, ey, ds, em_weight, MODE == MODE_PRB_ADJOINT ? &em_unit : nullptr);
+        else emitter_sample_direction(S.emitters[index], si.p, ex, ey, ds, em_weight, MODE != MODE_PATH ? &em_unit : nullptr);
         ds.pdf *= sel_pmf; em_weight = em_weight * wgt; em_unit *= wgt; em_sampled = index;
         active_em = ds.pdf != 0.f;
     }
@@ -271,7 +285,20 @@ HAR_HD void shade_lane(const DScene &S, const ShadeParams &P, const PathState &s
                 }
             }
         }
-        if (R.contrib.x != 0.f || R.contrib.y != 0.f || R.contrib.z != 0.f) {
+        /* prb: a sample whose contribution is ZERO can still have a derivative -- a black albedo (d Lr_dir / d rho = beta mis (cos / pi) em_weight at rho = 0), an emitter whose
+         * radiance is zero (d Lr_dir / d radiance = contrib_unit), zero texels of a light's bitmap.  The reference tests the visibility of every sample with a density
+         * (scene.cpp:338-346), so those gradients exist there; here their shadow ray is traced too -- by BOTH passes of a backward step, whose conditions must agree (the
+         * adjoint pass reads the visibility bytes the primal pass filled) */
+        bool grad_item = false;
+        if (MODE != MODE_PATH) {
+            const Vec3 d0 = ((st.throughput * mis_em) * ev.d_slot0) * em_weight;
+            grad_item = d0.x != 0.f || d0.y != 0.f || d0.z != 0.f;
+            if ((P.flags & HAR_SHADE_EMITTER_GRADS) || ((TYPES & HAR_SCENE_TEXLIGHT) != 0u && lt_sampled)) {
+                const Vec3 cu = ((st.throughput * mis_em) * ev.value) * em_unit;
+                grad_item = grad_item || cu.x != 0.f || cu.y != 0.f || cu.z != 0.f;
+            }
+        }
+        if (R.contrib.x != 0.f || R.contrib.y != 0.f || R.contrib.z != 0.f || grad_item) {
             R.item = true; R.item_ray = true;
             spawn_ray_to(si, ds.p, R.sh_o, R.sh_d, R.sh_maxt);
             if (MODE == MODE_PRB_ADJOINT) {

@@ -724,11 +724,14 @@ HAR_HD void bitmap_sample_position(const DTexture &T, const float *tab, float sx
 }
 HAR_HD Vec3 texture_eval_uv(const DTexture &T, float u, float v) { TexTaps taps; tex_taps(T, u, v, taps); return tex_fetch(T, taps); }
 /* AreaLight::sample_direction, spatially varying branch (area.cpp:133-165) with Rectangle::eval_parameterization (rectangle.cpp:215-237) */
-HAR_HD void textured_area_sample_direction(const DScene &S, const DEmitter &E, Vec3 ref_p, float sx, float sy, DirSample &ds, Vec3 &spec) {
+/* `unit` / `uv_out` (optional, prb adjoint w.r.t. the bitmap's texels -- `radiance` is a differentiable traverse entry, area.cpp:64-70): the weight the sample carries per unit of
+ * radiance(ds.uv), and ds.uv itself; the texel distribution the sample was drawn from stays detached (prb.py:174-175) */
+HAR_HD void textured_area_sample_direction(const DScene &S, const DEmitter &E, Vec3 ref_p, float sx, float sy, DirSample &ds, Vec3 &spec, float *unit = nullptr, float *uv_out = nullptr) {
     const DTexture T = S.textures[as_u32(E.radiance[0])];
     const float *tab = S.emitter_cdf + as_u32(E.radiance[1]);
     float u, v, pdf;
     bitmap_sample_position(T, tab, sx, sy, u, v, pdf);
+    if (uv_out) { uv_out[0] = u; uv_out[1] = v; }
     bool active = pdf != 0.f;
     ds.p = xf_point(E.to_world, Vec3(fma_(u, 2.f, -1.f), fma_(v, 2.f, -1.f), 0.f));
     ds.n = Vec3(E.normal[0], E.normal[1], E.normal[2]);
@@ -740,6 +743,7 @@ HAR_HD void textured_area_sample_direction(const DScene &S, const DEmitter &E, V
     active = active && dp < 0.f;
     ds.pdf = active ? pdf / E.radiance[2] * dist2 / -dp : 0.f;
     spec = active ? div3(texture_eval_uv(T, u, v), ds.pdf) : Vec3(0.f);
+    if (unit) *unit = active ? rcp_(ds.pdf) : 0.f;
 }
 /* AreaLight::pdf_direction, spatially varying branch (area.cpp:185-191): pdf_position(ds.uv) * dist^2 / (|dp_du x dp_dv| * -dp) */
 HAR_HD float textured_area_pdf_direction(const DScene &S, const DEmitter &E, Vec3 d, Vec3 n, float dist, float u, float v) {

@@ -444,7 +444,7 @@ static inline void diffuse_sample(V3 refl, V3 wi, float s2x, float s2y, V3 &wo, 
     weight = (wi.z > 0.f && pdf > 0.f) ? refl : V3(0.f);
 }
 
-struct DS { V3 p, n, d; float dist = 0, pdf = 0; int emitter = -1; bool delta = false; };
+struct DS { V3 p, n, d; float dist = 0, pdf = 0; int emitter = -1; bool delta = false; float uv[2] = { 0.f, 0.f }; /* ds.uv: where a bitmap radiance was sampled (area.cpp:139-146) */ };
 
 /* AreaLight::sample_direction (src/emitters/area.cpp:118-168) over
  * Shape::sample_direction (src/render/shape.cpp:93-110) and
@@ -568,7 +568,8 @@ static inline void emitter_sample_direction(const Scene &sc, uint32_t index, V3 
         ds.pdf = active ? pdf / tab.span * dist2 / -dp : 0.f;
         TexLookup l; tex_lookup(t, uv, l);                                                           // m_radiance->eval(si) at si.uv = uv
         spec = active ? div(tex_eval(t, l), ds.pdf) : V3(0.f);
-        if (unit) *unit = 0.f;                                                                       // no colour parameter to differentiate
+        ds.uv[0] = uv[0]; ds.uv[1] = uv[1];
+        if (unit) *unit = active ? rcp(ds.pdf) : 0.f;                                                // the weight per unit of radiance(ds.uv): the bitmap's texels are the parameter (area.cpp:64-70)
         return;
     }
     if (e.type == 3) mesh_sample_position(sc.meshes[e.mesh], sc.area_pmf[index], sx, sy, ds.p, ds.n, ds.pdf);
@@ -613,6 +614,16 @@ static inline V3 surface_emitter_radiance(const Scene &sc, const OrcEmitter &e, 
     if (e.type != 7) return V3(e.radiance[0], e.radiance[1], e.radiance[2]);
     TexLookup l; tex_lookup(sc.textures[e.radiance_texture], uv, l);
     return tex_eval(sc.textures[e.radiance_texture], l);
+}
+
+/* d (bitmap lookup at uv) / d texels, times g: the transpose of tex_eval -- what reverse mode sends to the texels of a bitmap `radiance` (area.cpp:64-70: a differentiable
+ * traverse entry; the texel distribution the samples were drawn from is detached, prb.py:174-175) */
+template <typename Commit>
+static inline void tex_scatter(const Texture &t, const float uv[2], Commit commit) {
+    TexLookup l; tex_lookup(t, uv, l);
+    if (t.mode & 1u) { commit(l.idx[0], 1.f); return; }
+    const float wts[4] = { l.w[0] * l.w[2], l.w[1] * l.w[2], l.w[0] * l.w[3], l.w[1] * l.w[3] };
+    for (int k = 0; k < 4; ++k) commit(l.idx[k], wts[k]);
 }
 
 /* PathIntegrator::mis_weight (src/integrators/path.cpp:359-364), common.py:1344 */
@@ -1251,7 +1262,9 @@ struct GradSink { float *refl; float *const *tex; float *emit; /* 3 per emitter 
                    * parameters' tangents (read only) and every derivative term is contracted with them into *fwd; the caller passes dL = 1 */
                   V3 *fwd = nullptr;
                   /* gradients w.r.t. alpha_u, alpha_v, eta (RGB), k (RGB), colour slot 1 of the rough models: 15 floats per BSDF record, may be null */
-                  float *extra = nullptr; };
+                  float *extra = nullptr;
+                  /* gradients w.r.t. the texels of bitmap `radiance` textures of area lights (their buffers are entries of `tex` like every bitmap's) */
+                  bool light_texels = false; };
 
 /* The specular part of RoughConductor::eval / RoughPlastic::eval (roughconductor.cpp:429-520, roughplastic.cpp:296-336, microfacet.h:185-207,341-365,
  * fresnel.h:93-116) in DOUBLE precision as a function of the parameters the adjoint differentiates: value_c(alpha_u, alpha_v, eta_c, k_c, slot1_c).
@@ -1364,6 +1377,10 @@ static V3 prb_sample(const Scene &sc, Pcg32 &rng, Ray ray, uint32_t max_depth, u
                 if (!primal && grad && grad->emit && e.type != 2 && e.type != 7 && (e.type == 1 || si.wi.z > 0.f)) {   // d Le / d radiance = beta * mis (prb.py:160-161, attached emitter.eval)
                     grad_commit(grad, grad->emit + 3 * (size_t) emitter, (beta * mis) * dL);
                 }
+                if (!primal && grad && grad->tex && grad->light_texels && e.type == 7 && si.wi.z > 0.f) {            // ... with a bitmap radiance: the four texels under si.uv (area.cpp:83-90)
+                    float *dst = grad->tex[e.radiance_texture]; const V3 g = (beta * mis) * dL;
+                    tex_scatter(sc.textures[e.radiance_texture], si.uv, [&](uint32_t idx, float w) { grad_commit(grad, dst + 3 * (size_t) idx, g, w); });
+                }
             }
         }
         active_next &= (depth + 1 < max_depth) && si.valid();  // prb.py:166
@@ -1382,8 +1399,13 @@ static V3 prb_sample(const Scene &sc, Pcg32 &rng, Ray ray, uint32_t max_depth, u
             mis_em = ds.delta ? 1.f : mis_weight(ds.pdf, ev.pdf);                   // prb.py:211
             Lr_dir = ((beta * mis_em) * ev.value) * em_weight;
             dLr_dir_drho = ((beta * mis_em) * ev.d_slot0) * em_weight;           // d/d slot0 of the line above
-            if (!primal && grad && grad->emit && sc.emitters[ds.emitter].type != 2) {   // em_weight = radiance * em_unit (prb.py:198-206, attached eval_emitter_direction)
+            if (!primal && grad && grad->emit && sc.emitters[ds.emitter].type != 2 && sc.emitters[ds.emitter].type != 7) {   // em_weight = radiance * em_unit (prb.py:198-206, attached eval_emitter_direction)
                 grad_commit(grad, grad->emit + 3 * (size_t) ds.emitter, (((beta * mis_em) * ev.value) * em_unit) * dL);
+            }
+            if (!primal && grad && grad->tex && grad->light_texels && sc.emitters[ds.emitter].type == 7) {                    // em_weight = radiance(ds.uv) * em_unit: the texels under the SAMPLED uv
+                const OrcEmitter &e = sc.emitters[ds.emitter];
+                float *dst = grad->tex[e.radiance_texture]; const V3 g = (((beta * mis_em) * ev.value) * em_unit) * dL;
+                tex_scatter(sc.textures[e.radiance_texture], ds.uv, [&](uint32_t idx, float w) { grad_commit(grad, dst + 3 * (size_t) idx, g, w); });
             }
         }
         // detached BSDF sampling, prb.py:220-223 (masked lanes return zeros)
@@ -2162,6 +2184,7 @@ static int prb_backward_impl(void *scene, const OrcSensor *sp, const float *grad
         std::vector<float> b_refl(g_refl[t].size()), b_emit(g_emit[t].size()), b_extra(g_extra[t].size());     /* sums of the current block of lanes */
         GradSink sink{ b_refl.data(), tp.data(), grad_emitters ? b_emit.data() : nullptr };
         sink.extra = grad_bsdf_params ? b_extra.data() : nullptr;
+        sink.light_texels = grad_emitters != nullptr;       /* emitter gradients: colours go to grad_emitters, the texels of a bitmap radiance to that bitmap's entry of grad_textures */
         auto flush_block = [&]() {
             for (size_t k = 0; k < b_refl.size(); ++k) { g_refl[t][k] += (double) b_refl[k]; b_refl[k] = 0.f; }
             for (size_t k = 0; k < b_emit.size(); ++k) { g_emit[t][k] += (double) b_emit[k]; b_emit[k] = 0.f; }

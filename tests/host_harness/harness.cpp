@@ -494,6 +494,45 @@ int hh_render_backward_instances(void *h, const HarSensor *sensor, const float *
     return backward_shape_impl(h, sensor, adj, seed, spp, max_depth, rr_depth, nullptr, inst_grad);
 }
 
+/* gradients w.r.t. the texels of bitmap-radiance area lights: what k_shade<ADJOINT, .. | TEXLIGHT, INLINE> commits under HAR_SHADE_LIGHT_TEXELS, lane by lane on the host --
+ * shade_lane's lt_* fields, em_unit / contrib_unit and the visibility of the emitter sample; grad_tex[t] = 3 doubles per texel of texture t or NULL.  adj = grad_in / W. */
+int hh_render_backward_light_texels(void *h, const HarSensor *sensor, const float *adj, uint32_t seed, uint32_t spp, int32_t max_depth, int32_t rr_depth, double *const *grad_tex) {
+    HScene *H = (HScene *) h; const DScene &S = H->ds;
+    DSensor C; std::string e; if (!lower_sensor(*sensor, C, e)) return -1;
+    const uint64_t total = (uint64_t) C.samp_w * C.samp_h * spp;
+    uint32_t log_spp = 0xffffffffu; for (uint32_t k = 0; k < 32; ++k) if ((1u << k) == spp) log_spp = k;
+    ShadeParams P{ seed, (uint32_t) max_depth, (uint32_t) rr_depth, HAR_SHADE_LIGHT_TEXELS };
+    int status = 0;
+    auto scatter = [&](int32_t index, const float uv[2], Vec3 g) {
+        const uint32_t t = as_u32(S.emitters[index].radiance[0]);
+        if (!grad_tex[t]) return;
+        TexTaps taps; tex_taps(S.textures[t], uv[0], uv[1], taps);
+        const float w[4] = { taps.w0x * taps.w0y, taps.w1x * taps.w0y, taps.w0x * taps.w1y, taps.w1x * taps.w1y };
+        for (int k = 0; k < 4; ++k) { double *q = grad_tex[t] + 3 * (size_t) taps.idx[k]; q[0] += (double) (g.x * w[k]); q[1] += (double) (g.y * w[k]); q[2] += (double) (g.z * w[k]); }
+    };
+    for (uint64_t lane = 0; lane < total; ++lane) {
+        LaneSample ls; PathState st = raygen_lane(C, seed, spp, log_spp, (uint32_t) lane, ls);
+        Footprint F; film_footprint(C, ls, F);
+        Vec3 dl(0.f);
+        for (uint32_t ys = 0; ys < F.count; ++ys) for (uint32_t xs = 0; xs < F.count; ++xs) {
+            uint32_t x = F.x0 + xs, y = F.y0 + ys;
+            if (x < C.crop_w && y < C.crop_h) { float w = F.wx[xs] * F.wy[ys]; const float *a = adj + 3 * ((size_t) y * C.crop_w + x); dl = Vec3(fma_(a[0], w, dl.x), fma_(a[1], w, dl.y), fma_(a[2], w, dl.z)); }
+        }
+        bool alive = P.max_depth != 0;
+        while (alive) {
+            Hit hit; HostStack stack; accel_trace<false>(S.accel, st.o, st.d, st.maxt, hit, stack, status);
+            ShadeResult R; shade_lane<MODE_PRB_ADJOINT, HAR_BSDF_ALL_TYPES | HAR_SCENE_ENVMAP | HAR_SCENE_TEXLIGHT>(S, P, st, hit, R);
+            if (R.add_emission && R.lt_hit_emitter >= 0) scatter(R.lt_hit_emitter, R.lt_hit_uv, R.em_unit * dl);
+            if (R.item && R.item_ray && R.lt_nee_emitter >= 0) {
+                Hit sh; HostStack s2;
+                if (!accel_trace<true>(S.accel, R.sh_o, R.sh_d, R.sh_maxt, sh, s2, status)) scatter(R.lt_nee_emitter, R.lt_nee_uv, R.contrib_unit * dl);
+            }
+            alive = R.alive; st = R.next;
+        }
+    }
+    return status;
+}
+
 /* --- traversal statistics (tools/trace_stats.py): per-ray event counts and a lock-step SIMT model of the
  * static traversal kernel.  Rays of bounce b are the rays of all lanes alive at bounce b, in lane order
  * (the order the compacting wavefront keeps), grouped into waves of 64. */

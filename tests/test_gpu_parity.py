@@ -852,6 +852,44 @@ def test_prb_instance_gradients_under_a_point_light(mi, O):
         assert scale > 0 and np.abs(got[:3] - want[i]).max() < 2e-3 * scale, (k, np.abs(got[:3] - want[i]).max() / scale)
 
 
+@pytest.mark.parametrize("which", ["black_walls", "black_texture", "dark_light", "black_walls_nocache"])
+def test_prb_gradients_at_zero_parameters(mi, O, which):
+    """a parameter that is exactly ZERO still has a derivative: d Lr_dir / d rho = beta mis (cos / pi) em_weight at rho = 0, d Lr_dir / d radiance at radiance = 0.  The reference tests
+    the visibility of every emitter sample with a density (scene.cpp:338-346), so the terms exist there; until round 6 the wavefront filed no shadow ray for a sample whose
+    CONTRIBUTION was zero and lost them (an albedo texture initialised to black would never have left black).  Record tape and replay cache, against the oracle"""
+    res = 24
+    d = mi.cornell_box(); d["sensor"]["film"]["width"] = res; d["sensor"]["film"]["height"] = res
+    d["integrator"] = {"type": "prb", "max_depth": 4}
+    if which.startswith("black_walls"):
+        d["white"]["reflectance"]["value"] = [0.0, 0.0, 0.0]
+    elif which == "black_texture":
+        t = np.random.default_rng(3).uniform(0.2, 0.8, (6, 6, 3)).astype(np.float32); t[:4, :4] = 0.0
+        d["white"] = {"type": "diffuse", "reflectance": {"type": "bitmap", "data": t, "raw": True, "filter_type": "nearest"}}
+    else:          # a second light that is switched off: its radiance gradient says what switching it on would do
+        T = mi.ScalarTransform4f
+        d["lamp2"] = {"type": "rectangle", "to_world": T().translate([0.4, -0.3, 0.2]).rotate([0, 1, 0], -70.0).scale([0.15, 0.2, 1.0]),
+                      "bsdf": {"type": "diffuse", "reflectance": {"type": "rgb", "value": [0.3, 0.3, 0.3]}},
+                      "emitter": {"type": "area", "radiance": {"type": "rgb", "value": [0.0, 0.0, 0.0]}}}
+    if which.endswith("nocache"):
+        d["integrator"]["replay_cache"] = False
+    scene = mi.load_dict(d)
+    osc, sensor = O.scene_from_product(scene)
+    grad_in = np.random.default_rng(4).uniform(0.5, 1.5, (res, res, 3)).astype(np.float32)
+    grads = scene.integrator().render_backward(scene, None, grad_in, seed=3, spp=32)
+    w_refl, w_tex, w_emit, _ = osc.render_prb_backward_emitters(sensor, grad_in, seed=3, spp=32, max_depth=4)
+    checked = 0
+    for k, (kind, b) in scene._param_keys().items():
+        ref = w_emit[b] if kind == "emit" else (w_tex[b.tex_index] if kind == "tex" else w_refl[b.index])
+        if np.any(ref):
+            assert rel_l2(grads[k].cpu().numpy(), ref) < 1e-3, (which, k, grads[k].cpu().numpy(), ref)
+            checked += 1
+    key = {"black_walls": "white.reflectance.value", "black_walls_nocache": "white.reflectance.value", "black_texture": "white.reflectance.data", "dark_light": "lamp2.emitter.radiance.value"}[which]
+    g = grads[key].cpu().numpy()
+    assert checked >= 2 and np.abs(g).max() > 0
+    if which == "black_texture":
+        assert np.abs(g[:3, :3]).max() > 0
+
+
 def test_vertex_position_update_rebuilds_the_scene(mi, O):
     """params['floor.vertex_positions'] = ...; params.update(): the next render sees the moved mesh (and matches the oracle's)"""
     from tests.test_cpu_host import oracle_scene_from

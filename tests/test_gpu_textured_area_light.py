@@ -43,7 +43,7 @@ def test_two_lights_one_textured_with_weights(mi, O):
 
 
 def test_prb_reflectance_gradient_under_a_bitmap_light(mi, O):
-    """the light's texels are not differentiated, everything it lights is: texel gradients of a wall bitmap, image and gradient against the oracle"""
+    """everything the bitmap light lights is differentiable: texel gradients of a wall bitmap, image and gradient against the oracle"""
     import torch
     d = lit_box(mi, _bitmap(4), 32)
     wall = np.random.default_rng(1).uniform(0.2, 0.8, (8, 8, 3)).astype(np.float32)
@@ -63,10 +63,84 @@ def test_prb_reflectance_gradient_under_a_bitmap_light(mi, O):
     _, g_tex, _ = osc.render_prb_backward(sensor, grad_in, seed=mi.sample_tea_32(0, 1)[0], spp=32, max_depth=5, rr_depth=3)
     wall_index = [b for b in scene.bsdf_objs if b.id == "white"][0].tex_index
     assert np.abs(g).max() > 0 and rel_l2(g, g_tex[wall_index]) < 1e-3
-    # the light's own texels: a parameter, not a differentiable one
+    # the light's own texels are differentiable too (area.cpp:64-70; test_prb_light_texel_gradients): requires_grad switches the integrator's term on for that call
     params["light.emitter.radiance.data"].requires_grad_()
-    with pytest.raises(RuntimeError, match="not differentiable|differentiable"):
-        mi.render(scene, params, spp=4, seed=1)
+    (mi.render(scene, params, spp=4, seed=1) ** 2).mean().backward()
+    assert float(params["light.emitter.radiance.data"].grad.abs().max()) > 0
+
+
+@pytest.mark.parametrize("props", [{}, {"filter_type": "nearest", "wrap_mode": "clamp"}, {"wrap_mode": "mirror", "to_uv": "transpose"}, {"zeros": True}, {"two_lights": True}, {"nocache": True}])
+def test_prb_light_texel_gradients(mi, O, props):
+    """`radiance` of an area light is a differentiable traverse entry (area.cpp:64-70): gradients w.r.t. the texels of its bitmap (`light_texel_gradients`, har_integrator_set_grad_light_texels) --
+    d Le / d radiance(si.uv) at emitter hits, d Lr_dir / d radiance(ds.uv) at visible emitter samples, committed in place by the re-shading replay -- against the oracle, texel by texel;
+    the other gradients of the same call are those of the plain adjoint"""
+    props = dict(props)
+    if props.get("to_uv") == "transpose":
+        props["to_uv"] = mi.ScalarTransform3f([[0, 1, 0], [1, 0, 0], [0, 0, 1]])
+    tex = _bitmap(5, 6, 5)
+    if props.pop("zeros", False):          # a sample over zero texels contributes nothing and still has a derivative (its shadow ray is traced in both passes)
+        tex[:3, :3] = 0.0
+    two = props.pop("two_lights", False); nocache = props.pop("nocache", False)
+    res = 32
+    d = lit_box(mi, tex, res, **props)
+    T = mi.ScalarTransform4f
+    if two:                                  # a uniform light next to it: emitter choice and the colour gradient of the other light in the same call
+        d["lamp2"] = {"type": "rectangle", "to_world": T().translate([0.4, -0.3, 0.2]).rotate([0, 1, 0], -70.0).scale([0.15, 0.2, 1.0]),
+                      "emitter": {"type": "area", "radiance": {"type": "rgb", "value": [3.0, 6.0, 9.0]}, "sampling_weight": 0.5}}
+    d["integrator"] = {"type": "prb", "max_depth": 5, "light_texel_gradients": True}
+    if nocache:                              # the lane-indexed replay cache instead of the state tape (hide_emitters forces it): the same in-place commit
+        d["integrator"]["hide_emitters"] = True
+    scene = mi.load_dict(d)
+    osc, sensor = O.scene_from_product(scene)
+    osc.set_hide_emitters(nocache)
+    grad_in = np.random.default_rng(4).uniform(0.5, 1.5, (res, res, 3)).astype(np.float32)
+    integ = scene.integrator()
+    grads = integ.render_backward(scene, None, grad_in, seed=3, spp=16)
+    w_refl, w_tex, w_emit, _ = osc.render_prb_backward_emitters(sensor, grad_in, seed=3, spp=16, max_depth=5)
+    key = "light.emitter.radiance.data"
+    ti = [e for e in scene.emitters if e["type"] == 7][0]["light"].tex_index
+    got = grads[key].cpu().numpy(); want = w_tex[ti]
+    assert got.shape == tex.shape and np.abs(want).max() > 0
+    assert rel_l2(got, want) < 1e-3, rel_l2(got, want)
+    if not tex[:3, :3].any():
+        assert np.abs(got[:2, :2]).max() > 0
+    for k, (kind, b) in scene._param_keys().items():
+        ref = w_emit[b] if kind == "emit" else (w_tex[b.tex_index] if kind == "tex" else w_refl[b.index])
+        if np.any(ref):
+            assert rel_l2(grads[k].cpu().numpy(), ref) < 1e-3, k
+    # off again: the key disappears, the other gradients do not change (record tape instead of the re-shading replay)
+    integ.light_texel_gradients = False
+    plain = integ.render_backward(scene, None, grad_in, seed=3, spp=16)
+    assert key not in plain
+    for k in plain:
+        assert np.allclose(plain[k].cpu().numpy(), grads[k].cpu().numpy(), rtol=2e-3, atol=1e-6 * max(1.0, float(np.abs(grads[k].cpu().numpy()).max()))), k
+
+
+def test_light_texels_through_autograd(mi, O):
+    """mi.render + loss.backward() with requires_grad on '<shape>.emitter.radiance.data': the integrator's switch is set for that call only; one Adam-free descent step on the texels
+    lowers a least-squares loss against a target rendered with other texels"""
+    import torch
+    tex = _bitmap(5, 6, 5); target_tex = _bitmap(6, 6, 5)
+    res = 24
+    d = lit_box(mi, tex, res); d["integrator"] = {"type": "prb", "max_depth": 4}
+    scene = mi.load_dict(d)
+    params = mi.traverse(scene)
+    key = "light.emitter.radiance.data"
+    params[key] = torch.tensor(target_tex, device="cuda"); params.update()
+    target = mi.render(scene, spp=64, seed=1).detach()
+    params[key] = torch.tensor(tex, device="cuda"); params.update()
+    losses = []
+    for step in range(2):
+        p = params[key].detach().clone().requires_grad_(True); params[key] = p
+        img = mi.render(scene, params, spp=64, seed=1, seed_grad=2)
+        loss = ((img - target) ** 2).mean(); loss.backward()
+        assert p.grad is not None and p.grad.shape == p.shape and float(p.grad.abs().max()) > 0
+        losses.append(float(loss.detach()))
+        with torch.no_grad():         # a small step against the gradient (2 % of the brightest texel for the steepest one)
+            params[key] = (p - 0.02 * p.abs().max() * p.grad / p.grad.abs().max()).clamp(min=1e-3).detach()
+        params.update()
+    assert not scene.integrator().light_texel_gradients
+    assert losses[1] < 0.9 * losses[0], losses          # (fixed-size normalised steps overshoot near the optimum: one step is the test)
 
 
 def test_radiance_bitmap_updates_in_place(mi, O):

@@ -138,6 +138,81 @@ def test_uniform_bitmap_equals_uniform_light_in_expectation(mi, O):
     assert np.abs(ab / bb - 1.0).max() < 0.07
 
 
+@pytest.mark.parametrize("props", [{}, {"filter_type": "nearest"}, {"wrap_mode": "mirror", "to_uv": "swap"}])
+def test_oracle_light_texel_gradients(mi, O, props):
+    """`radiance` of an area light is a differentiable traverse entry (area.cpp:64-70): the oracle's gradient w.r.t. the bitmap's texels -- emission term at si.uv (prb.py:160-161 with
+    emitter.eval attached), emitter-sampling term at the SAMPLED ds.uv with the sampling density detached (prb.py:174-175, 203-206).
+     * exact: the image is homogeneous of degree one in the texels and scaling them leaves the texel distribution alone, so  sum_j grad_j * texel_j == sum(w * image)  for the
+       same seed (the light is the scene's only emitter);
+     * finite differences of the oracle's own primal renders along a random direction in texel space (the samples follow the changed distribution there: two estimators of one
+       derivative, 4096 spp, 3 %)"""
+    from tests.test_cpu_host import oracle_scene_from
+    props = dict(props)
+    if props.get("to_uv") == "swap":
+        props["to_uv"] = mi.ScalarTransform3f([[0, 1, 0], [1, 0, 0], [0, 0, 1]])
+    res = 12
+    tex = _bitmap(5, 6, 5)
+    tex[0, :2] = 0.02               # (keep every texel sampled: a texel without mass has a gradient that no finite difference of ITS value can see through the sampled term ... it can: the hit term)
+    scene = mi.load_dict(lit_box(mi, tex, res, **props))
+    osc, sensor = oracle_scene_from(O, scene)
+    ti = [k for k, t in enumerate(osc.data.textures) if t.shape == tex.shape][-1]
+    w = np.random.default_rng(2).uniform(0.5, 1.5, (res, res, 3)).astype(np.float32)
+    kw = dict(seed=9, spp=4096, max_depth=3)
+    _, g_tex, g_emit, _ = osc.render_prb_backward_emitters(sensor, w, **kw)
+    g = g_tex[ti].astype(np.float64)
+    assert np.abs(g).max() > 0 and not g_emit.any()
+    img, _ = osc.render_prb(sensor, **kw)
+    total = float((img.astype(np.float64) * w).sum())
+    assert abs(float((g * tex).sum()) - total) < 2e-4 * abs(total), (float((g * tex).sum()), total)
+    direction = np.random.default_rng(3).uniform(-1.0, 1.0, tex.shape) * tex          # relative perturbations: texels stay non-negative
+    sums = []
+    for sgn in (+1, -1):
+        osc.set_texture(ti, (tex + sgn * 0.02 * direction).astype(np.float32))
+        im, _ = osc.render_prb(sensor, **kw)
+        sums.append(float((im.astype(np.float64) * w).sum()))
+    osc.set_texture(ti, tex)
+    fd = (sums[0] - sums[1]) / 0.04
+    ad = float((g * direction).sum())
+    assert abs(fd - ad) < 0.03 * abs(total) * 0.5 + 0.03 * abs(fd), (fd, ad, total)
+
+
+@pytest.mark.parametrize("props", [{}, {"filter_type": "nearest", "wrap_mode": "clamp"}, {"wrap_mode": "mirror", "to_uv": "swap"}, {"zeros": True}])
+def test_host_light_texel_adjoint_matches_oracle(mi, O, props):
+    """what k_shade commits under HAR_SHADE_LIGHT_TEXELS (shade_lane's lt_* fields, em_unit / contrib_unit, the sample's visibility), run lane by lane on the host, against the
+    oracle, texel by texel; `zeros`: a bitmap with a block of zero texels -- a sample over them contributes nothing and still has a derivative (its shadow ray is traced)"""
+    from tests.test_cpu_host import oracle_scene_from
+    props = dict(props)
+    if props.get("to_uv") == "swap":
+        props["to_uv"] = mi.ScalarTransform3f([[0, 1, 0], [1, 0, 0], [0, 0, 1]])
+    tex = _bitmap(5, 6, 5)
+    if props.pop("zeros", False):
+        tex[:3, :3] = 0.0
+    res = 16
+    scene = mi.load_dict(lit_box(mi, tex, res, **props))
+    osc, sensor = oracle_scene_from(O, scene)
+    ti = scene.emitters[0]["light"].tex_index
+    w = np.random.default_rng(2).uniform(0.5, 1.5, (res, res, 3)).astype(np.float32)
+    kw = dict(seed=3, spp=16, max_depth=5)
+    _, g_tex, _, _ = osc.render_prb_backward_emitters(sensor, w, **kw)
+    want = g_tex[ti].astype(np.float64)
+    L = C.CDLL(os.path.join(ROOT, "tests", "host_harness", "libhost_harness.so")); L.hh_scene_create.restype = C.c_void_p
+    L.hh_render.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_uint32, C.c_uint32, C.c_int32, C.c_int32, C.c_uint64, C.c_uint64, O.c_f32p]
+    dp = C.POINTER(C.c_double)
+    L.hh_render_backward_light_texels.argtypes = [C.c_void_p, C.c_void_p, O.c_f32p, C.c_uint32, C.c_uint32, C.c_int32, C.c_int32, C.POINTER(dp)]
+    desc = scene.desc(); err = C.create_string_buffer(256); h = C.c_void_p(L.hh_scene_create(C.byref(desc), err, 256)); assert h, err.value
+    film = np.zeros((res, res, 4), np.float32)
+    assert L.hh_render(h, C.byref(sensor), 1, kw["seed"], kw["spp"], kw["max_depth"], 5, 0, 0, O.fp(film)) == 0
+    wt = film[:, :, 3:4]; adj = np.ascontiguousarray(w / np.where(wt == 0, 1, wt), np.float32)
+    got = np.zeros(tex.shape, np.float64)
+    nt = len(scene.textures)
+    pp = (dp * nt)(*[got.ctypes.data_as(dp) if k == ti else dp() for k in range(nt)])
+    assert L.hh_render_backward_light_texels(h, C.byref(sensor), O.fp(adj), kw["seed"], kw["spp"], kw["max_depth"], 5, pp) == 0
+    scale = np.abs(want).max()
+    assert scale > 0 and np.abs(got - want).max() < 1e-3 * scale, np.abs(got - want).max() / scale
+    if "zeros" in str(props) or not tex[:3, :3].any():
+        assert np.abs(want[:2, :2]).max() > 0          # the zero block does receive a gradient
+
+
 def test_parameters_and_refusals(mi, O):
     from tests.test_cpu_host import oracle_scene_from, rel_l2
     tex = _bitmap(7)
