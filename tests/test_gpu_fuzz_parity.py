@@ -1,0 +1,292 @@
+"""Randomised parity: small scenes drawn from the whole plugin inventory of the variant (shapes, instances, every BSDF model incl. zero and bitmap colours, every emitter kind,
+both sensors, filters, crop windows, integrator depths) rendered by the HIP path and by the oracle with the same seed -- forward image (1e-4) with equal vertex counts, `prb`
+primal image, and EVERY gradient of one `render_backward` call (colours, texels, emitter radiances; 1e-3) -- plus vertex-position gradients of the eligible meshes on a second call.
+The hand-made scenes of the other files test what their author thought of; this file tests combinations nobody wrote down (round 6: the gradient at a black albedo was found by
+comparing every gradient of a two-light scene).  Seeds are fixed: a failure is reproducible by its parameter."""
+import numpy as np
+import pytest
+
+from tests.test_gpu_boundary import rel_l2
+
+pytestmark = pytest.mark.gpu
+
+
+def _colour(rng, allow_zero=True):
+    c = rng.uniform(0.05, 0.9, 3)
+    if allow_zero and rng.random() < 0.25:
+        c[rng.integers(0, 3)] = 0.0                      # a channel that is exactly zero
+    if allow_zero and rng.random() < 0.1:
+        c[:] = 0.0                                       # a black surface
+    return [float(x) for x in c]
+
+
+def _bitmap(rng, lo=0.05, hi=0.9, allow_zero=True):
+    h, w = int(rng.integers(2, 9)), int(rng.integers(2, 9))
+    t = rng.uniform(lo, hi, (h, w, 3)).astype(np.float32)
+    if allow_zero and rng.random() < 0.4:
+        t[: max(1, h // 2), : max(1, w // 2)] = 0.0
+    d = {"type": "bitmap", "data": t, "raw": True}
+    if rng.random() < 0.4:
+        d["filter_type"] = "nearest"
+    if rng.random() < 0.5:
+        d["wrap_mode"] = ["repeat", "mirror", "clamp"][int(rng.integers(0, 3))]
+    return d
+
+
+def _slot(rng, allow_zero=True):
+    """a colour slot.  allow_zero = False for the diffuse base of `plastic` / `roughplastic`: with a channel at zero the value of that channel is the specular lobe alone, tiny away from
+    the highlight, and prb's  L * (df / d rho) / f  multiplies the rounding noise of L (a difference of O(10) terms in fp32) by 1e15 -- in the reference as well; the product and the
+    oracle then both return noise, not the same noise (seeds 5, 14, 18, 23 of the first version of this file)"""
+    return _bitmap(rng, allow_zero=allow_zero) if rng.random() < 0.35 else {"type": "rgb", "value": _colour(rng, allow_zero)}
+
+
+def _bsdf(rng, smooth_only=False):
+    kinds = ["diffuse", "diffuse", "roughconductor", "roughplastic", "plastic", "twosided"] + ([] if smooth_only else ["dielectric", "conductor"])
+    k = kinds[int(rng.integers(0, len(kinds)))]
+    if k == "diffuse":
+        return {"type": "diffuse", "reflectance": _slot(rng)}
+    if k == "roughconductor":
+        d = {"type": "roughconductor", "distribution": ["ggx", "beckmann"][int(rng.integers(0, 2))], "eta": [0.2, 0.92, 1.1], "k": [3.9, 2.45, 2.14]}
+        if rng.random() < 0.5:
+            d["alpha"] = float(rng.uniform(0.1, 0.5))
+        else:
+            d["alpha_u"] = float(rng.uniform(0.1, 0.5)); d["alpha_v"] = float(rng.uniform(0.1, 0.5))
+        if rng.random() < 0.3:
+            d["specular_reflectance"] = {"type": "rgb", "value": _colour(rng, False)}
+        return d
+    if k == "roughplastic":
+        return {"type": "roughplastic", "alpha": float(rng.uniform(0.1, 0.4)), "diffuse_reflectance": _slot(rng, False), "nonlinear": bool(rng.random() < 0.3)}
+    if k == "plastic":
+        return {"type": "plastic", "diffuse_reflectance": _slot(rng, False), "int_ior": float(rng.uniform(1.3, 1.9))}
+    if k == "dielectric":
+        return {"type": "dielectric", "int_ior": float(rng.uniform(1.2, 1.8))}
+    if k == "conductor":
+        return {"type": "conductor", "eta": [0.143, 0.375, 1.442], "k": [3.983, 2.386, 1.603]}
+    inner = _bsdf(rng, smooth_only=True)
+    while inner["type"] == "twosided":
+        inner = _bsdf(rng, smooth_only=True)
+    if rng.random() < 0.5:
+        return {"type": "twosided", "m": inner}
+    back = _bsdf(rng, smooth_only=True)
+    while back["type"] == "twosided":
+        back = _bsdf(rng, smooth_only=True)
+    return {"type": "twosided", "front": inner, "back": back}
+
+
+def random_scene(mi, seed):
+    rng = np.random.default_rng(1000 + seed)
+    T = mi.ScalarTransform4f
+    W, H = int(rng.integers(20, 41)), int(rng.integers(20, 41))
+    film = {"type": "hdrfilm", "width": W, "height": H, "pixel_format": "rgb",
+            "rfilter": {"type": ["gaussian", "box", "tent"][int(rng.integers(0, 3))]}}
+    if rng.random() < 0.3:
+        cw, ch = int(rng.integers(8, W)), int(rng.integers(8, H))
+        film.update({"crop_width": cw, "crop_height": ch, "crop_offset_x": int(rng.integers(0, W - cw + 1)), "crop_offset_y": int(rng.integers(0, H - ch + 1))})
+    spp = int([4, 8, 16, 12][int(rng.integers(0, 4))])
+    cam = T().look_at(origin=[float(rng.uniform(-0.4, 0.4)), float(rng.uniform(0.6, 1.4)), 3.2], target=[0, 0.3, 0], up=[0, 1, 0])
+    if rng.random() < 0.2:
+        sensor = {"type": "orthographic", "to_world": cam @ T().scale([1.6, 1.6, 1.0])}
+    else:
+        sensor = {"type": "perspective", "fov": float(rng.uniform(35, 60)), "to_world": cam}
+    sensor.update({"film": film, "sampler": {"type": "independent", "sample_count": spp}})
+    d = {"type": "scene", "sensor": sensor,
+         "floor": {"type": "rectangle", "to_world": T().rotate([1, 0, 0], -90).scale([2.0, 2.0, 1.0]), "bsdf": _bsdf(rng, smooth_only=True)},
+         "back": {"type": "rectangle", "to_world": T().translate([0, 1.0, -1.6]).scale([2.0, 1.4, 1.0]), "bsdf": _bsdf(rng, smooth_only=True)}}
+    n_obj = int(rng.integers(1, 4))
+    for i in range(n_obj):
+        pos = [float(rng.uniform(-1.0, 1.0)), float(rng.uniform(0.25, 0.9)), float(rng.uniform(-0.9, 0.9))]
+        xf = T().translate(pos).rotate([0, 1, 0], float(rng.uniform(0, 90))).scale([float(rng.uniform(0.15, 0.35))] * 3)
+        kind = ["cube", "rectangle", "sphere"][int(rng.integers(0, 3))]
+        if kind == "sphere":
+            P, N, UV, F = mi.scenes.bumpy_sphere(10, 6, 1.0)
+            M = np.asarray(xf.matrix, np.float64)
+            Pw = (P.astype(np.float64) @ M[:3, :3].T + M[:3, 3]).astype(np.float32)
+            d["obj%d" % i] = {"type": "mesh", "positions": Pw, "faces": F, "texcoords": UV, "bsdf": _bsdf(rng)}        # flat-shaded
+        else:
+            d["obj%d" % i] = {"type": kind, "to_world": xf, "bsdf": _bsdf(rng)}
+    if rng.random() < 0.4:                     # a shape group with two or three instances
+        d["grp"] = {"type": "shapegroup", "c": {"type": "cube", "bsdf": _bsdf(rng, smooth_only=True)}}
+        for j in range(int(rng.integers(2, 4))):
+            pos = [float(rng.uniform(-1.2, 1.2)), float(rng.uniform(0.2, 0.8)), float(rng.uniform(-1.0, 0.6))]
+            d["inst%d" % j] = {"type": "instance", "shapegroup": {"type": "ref", "id": "grp"},
+                               "to_world": T().translate(pos).rotate([0.3, 1, 0.2], float(rng.uniform(0, 180))).scale([float(rng.uniform(0.08, 0.2))] * 3)}
+    # emitters
+    kinds = ["area", "area_bitmap", "area_mesh", "point", "spot", "directional", "env"]
+    n_em = int(rng.integers(1, 4)); chosen = []
+    for e in range(n_em):
+        k = kinds[int(rng.integers(0, len(kinds)))]
+        if k == "env" and "env" in chosen:
+            k = "area"
+        if k == "area_bitmap" and "area_bitmap" in chosen:
+            k = "area"
+        chosen.append(k)
+        sw = {"sampling_weight": float(rng.uniform(0.3, 3.0))} if rng.random() < 0.4 else {}
+        pos = [float(rng.uniform(-0.8, 0.8)), float(rng.uniform(1.5, 2.0)), float(rng.uniform(-0.6, 0.8))]
+        rad = [float(x) for x in rng.uniform(4.0, 12.0, 3)]
+        if rng.random() < 0.15:
+            rad = [0.0, 0.0, 0.0]                                  # a light that is switched off
+        if k == "area":
+            d["em%d" % e] = {"type": "rectangle", "to_world": T().translate(pos).rotate([1, 0, 0], 90).scale([0.25, 0.25, 1.0]),
+                             "emitter": dict({"type": "area", "radiance": {"type": "rgb", "value": rad}}, **sw)}
+        elif k == "area_bitmap":
+            bm = _bitmap(rng, 2.0, 14.0, allow_zero=True); bm.pop("raw")
+            if not bm["data"].any():
+                bm["data"][:] = 3.0
+            bm["data"][-1, -1] = 9.0                                # (some luminance to sample)
+            d["em%d" % e] = {"type": "rectangle", "to_world": T().translate(pos).rotate([1, 0, 0], 90).scale([0.3, 0.3, 1.0]),
+                             "emitter": dict({"type": "area", "radiance": bm}, **sw)}
+        elif k == "area_mesh":
+            d["em%d" % e] = {"type": "cube", "to_world": T().translate(pos).scale([0.12, 0.05, 0.12]), "bsdf": {"type": "diffuse", "reflectance": {"type": "rgb", "value": _colour(rng)}},
+                             "emitter": dict({"type": "area", "radiance": {"type": "rgb", "value": rad}}, **sw)}
+        elif k == "point":
+            d["em%d" % e] = dict({"type": "point", "position": pos, "intensity": {"type": "rgb", "value": rad}}, **sw)
+        elif k == "spot":
+            d["em%d" % e] = dict({"type": "spot", "to_world": T().look_at(origin=pos, target=[float(rng.uniform(-0.5, 0.5)), 0.0, float(rng.uniform(-0.5, 0.5))], up=[0, 0, 1]),
+                                  "intensity": {"type": "rgb", "value": [3.0 * r for r in rad]}, "cutoff_angle": float(rng.uniform(30, 60)), "beam_width": float(rng.uniform(8, 25))}, **sw)
+        elif k == "directional":
+            d["em%d" % e] = dict({"type": "directional", "direction": [float(rng.uniform(-0.5, 0.5)), -1.0, float(rng.uniform(-0.5, 0.5))],
+                                  "irradiance": {"type": "rgb", "value": [0.3 * r for r in rad]}}, **sw)
+        else:
+            if rng.random() < 0.5:
+                d["em%d" % e] = dict({"type": "constant", "radiance": {"type": "rgb", "value": [0.08 * r for r in rad]}}, **sw)
+            else:
+                eh = int(rng.integers(4, 9))
+                d["em%d" % e] = dict({"type": "envmap", "bitmap": mi.Bitmap(rng.uniform(0.1, 1.2, (eh, 2 * eh, 3)).astype(np.float32)), "scale": float(rng.uniform(0.5, 1.5))}, **sw)
+    md = int(rng.integers(2, 8)); rr = int(rng.integers(2, 6))
+    return d, dict(max_depth=md, rr_depth=rr, spp=spp, hide=bool(rng.random() < 0.15))
+
+
+def _compare(name, got, ref, tol):
+    got = np.asarray(got, np.float64); ref = np.asarray(ref, np.float64)
+    scale = np.sqrt((ref ** 2).sum())
+    err = np.sqrt(((got - ref) ** 2).sum())
+    assert np.isfinite(got).all(), name
+    assert err <= tol * scale + 1e-7 * max(1.0, np.abs(ref).max()), (name, err / max(scale, 1e-30), got.reshape(-1)[:6], ref.reshape(-1)[:6])
+
+
+@pytest.mark.parametrize("seed", list(range(int(__import__("os").environ.get("HAR_FUZZ_SEEDS", "32")))))
+def test_random_scene_parity(mi, O, seed):
+    d, cfg = random_scene(mi, seed)
+    spp, md, rr = cfg["spp"], cfg["max_depth"], cfg["rr_depth"]
+    # ---- forward
+    d["integrator"] = {"type": "path", "max_depth": md, "rr_depth": rr, "hide_emitters": cfg["hide"]}
+    scene = mi.load_dict(d)
+    osc, sensor = O.scene_from_product(scene); osc.set_hide_emitters(cfg["hide"])
+    img = mi.render(scene, spp=spp, seed=seed).cpu().numpy()
+    ref, ost = osc.render_path(sensor, seed=seed, spp=spp, max_depth=md, rr_depth=rr)
+    _compare("path image", img, ref, 1e-4)
+    st = scene.integrator().stats()
+    assert st["vertices"] == ost.vertices and st["paths"] == ost.paths, (st, ost.vertices, ost.paths)
+    # ---- prb: primal image and every gradient of one backward call
+    d["integrator"] = {"type": "prb", "max_depth": md, "rr_depth": rr, "hide_emitters": cfg["hide"], "light_texel_gradients": True}
+    scene = mi.load_dict(d)
+    osc, sensor = O.scene_from_product(scene); osc.set_hide_emitters(cfg["hide"])
+    img = mi.render(scene, spp=spp, seed=seed + 1).cpu().numpy()
+    ref, _ = osc.render_prb(sensor, seed=seed + 1, spp=spp, max_depth=md, rr_depth=rr)
+    _compare("prb image", img, ref, 1e-4)
+    grad_in = np.random.default_rng(seed).uniform(0.5, 1.5, ref.shape).astype(np.float32)
+    grads = scene.integrator().render_backward(scene, None, grad_in, seed=seed + 2, spp=spp)
+    w_refl, w_tex, w_emit, _ = osc.render_prb_backward_emitters(sensor, grad_in, seed=seed + 2, spp=spp, max_depth=md, rr_depth=rr)
+    for k, (kind, b) in scene._param_keys().items():
+        want = w_emit[b] if kind == "emit" else (w_tex[b.tex_index] if kind == "tex" else w_refl[b.index])
+        _compare(k, grads[k].cpu().numpy(), want, 1e-3)
+    for k, (kind, i) in scene._pose_keys().items():
+        if kind == "emitter_tex":
+            _compare(k, grads[k].cpu().numpy(), w_tex[scene.emitters[i]["light"].tex_index], 1e-3)
+    # ---- vertex-position gradients of every eligible top-level mesh (second call: item path instead of the tapes)
+    if cfg["hide"]:
+        return
+    integ = scene.integrator(); integ.light_texel_gradients = False; integ.shape_gradients = True
+    keys = scene._differentiable_position_keys()
+    if not keys:
+        return
+    grads = integ.render_backward(scene, None, grad_in, seed=seed + 2, spp=spp)
+    ids = sorted(keys.values())
+    want, _, _, _ = osc.render_prb_backward_shape(sensor, grad_in, ids, seed=seed + 2, spp=spp, max_depth=md, rr_depth=rr)
+    total = max(np.abs(want[m]).max() for m in ids)
+    for k, m in keys.items():
+        got = grads[k].cpu().numpy().reshape(-1, 3)
+        assert np.isfinite(got).all(), k
+        assert np.abs(got - want[m]).max() <= 2e-3 * max(np.abs(want[m]).max(), 1e-3 * total) + 1e-7, (k, np.abs(got - want[m]).max(), np.abs(want[m]).max())
+
+
+@pytest.mark.parametrize("seed", list(range(int(__import__("os").environ.get("HAR_FUZZ_SEEDS2", "24")))))
+def test_random_scene_options(mi, O, seed):
+    """the same scenes under the integrator's OTHER code paths: chunked wavefronts, multi-pass renders, the lane-indexed replay cache / no cache at all, per-material queues, the
+    forward-mode derivative (RBIntegrator.render_forward: random tangents on every colour / texel / radiance), gradients of alpha / eta / k / specular colours, and instance
+    transforms -- each against the oracle"""
+    d, cfg = random_scene(mi, seed + 500)
+    rng = np.random.default_rng(7000 + seed)
+    spp, md, rr = cfg["spp"], cfg["max_depth"], cfg["rr_depth"]
+    if spp == 12:
+        spp = 8
+    opts = {}
+    if rng.random() < 0.5:
+        opts["chunk_lanes"] = int(rng.integers(1, 5)) * 2048          # several chunks per frame
+    if rng.random() < 0.3:
+        opts["material_queues"] = True
+    # ---- forward, possibly in passes
+    popts = dict(opts)
+    if rng.random() < 0.4 and spp >= 4:
+        popts["samples_per_pass"] = spp // 2
+    d["integrator"] = dict({"type": "path", "max_depth": md, "rr_depth": rr}, **popts)
+    scene = mi.load_dict(d)
+    osc, sensor = O.scene_from_product(scene)
+    img = mi.render(scene, spp=spp, seed=seed).cpu().numpy()
+    if "samples_per_pass" in popts:
+        ref, _ = osc.render_path_passes(sensor, seed=seed, spp=spp, spp_per_pass=spp // 2, max_depth=md, rr_depth=rr)
+    else:
+        ref, _ = osc.render_path(sensor, seed=seed, spp=spp, max_depth=md, rr_depth=rr)
+    _compare("path image", img, ref, 1e-4)
+    # ---- prb backward through the replay cache / without any cache
+    if rng.random() < 0.5:
+        opts["replay_cache"] = False
+    d["integrator"] = dict({"type": "prb", "max_depth": md, "rr_depth": rr, "bsdf_parameter_gradients": bool(rng.random() < 0.5)}, **opts)
+    if d["integrator"]["bsdf_parameter_gradients"]:
+        d["integrator"].pop("replay_cache", None)                      # (those gradients need the cache)
+    scene = mi.load_dict(d)
+    osc, sensor = O.scene_from_product(scene)
+    grad_in = np.random.default_rng(seed).uniform(0.5, 1.5, ref.shape).astype(np.float32)
+    integ = scene.integrator()
+    grads = integ.render_backward(scene, None, grad_in, seed=seed + 2, spp=spp)
+    w_refl, w_tex, w_emit, _ = osc.render_prb_backward_emitters(sensor, grad_in, seed=seed + 2, spp=spp, max_depth=md, rr_depth=rr)
+    for k, (kind, b) in scene._param_keys().items():
+        want = w_emit[b] if kind == "emit" else (w_tex[b.tex_index] if kind == "tex" else w_refl[b.index])
+        _compare(k, grads[k].cpu().numpy(), want, 1e-3)
+    if integ.bsdf_parameter_gradients and scene._bsdf_param_keys():
+        gx = osc.render_prb_backward_bsdf_params(sensor, grad_in, seed=seed + 2, spp=spp, max_depth=md, rr_depth=rr)
+        gx = gx[0] if isinstance(gx, tuple) else gx
+        for k, (what, b) in scene._bsdf_param_keys().items():
+            rec = np.asarray(gx[b.index], np.float64).reshape(5, 3)
+            want = {"alpha": rec[0:2].sum(), "alpha_u": rec[0].sum(), "alpha_v": rec[1].sum(), "eta": rec[2], "k": rec[3], "slot1": rec[4]}[what]
+            got = grads[k].cpu().numpy().astype(np.float64)
+            scale = max(np.abs(np.atleast_1d(want)).max(), 1e-3 * float(np.abs(gx).max()), 1e-12)        # (a record only a handful of paths reach: L * (df / d theta) / f is noise at the 1e-6 level)
+            assert np.isfinite(got).all() and np.abs(got.reshape(-1) - np.atleast_1d(want).reshape(-1)).max() <= 2e-3 * scale, (k, got, want)
+    # ---- forward mode: random tangents on every key of the gradient tables
+    keys = scene._param_keys()
+    if keys:
+        trng = np.random.default_rng(seed + 11)
+        tangents, t_refl, t_emit = {}, np.zeros((len(scene.bsdfs), 3), np.float32), np.zeros((max(1, len(scene.emitters)), 3), np.float32)
+        t_tex = [np.zeros_like(np.asarray(t, np.float32)) for t in scene.textures]
+        for k, (kind, b) in keys.items():
+            if kind == "tex":
+                t_tex[b.tex_index] = trng.uniform(-1, 1, t_tex[b.tex_index].shape).astype(np.float32); tangents[k] = t_tex[b.tex_index]
+            elif kind == "emit":
+                t_emit[b] = trng.uniform(-1, 1, 3); tangents[k] = t_emit[b]
+            else:
+                t_refl[b.index] = trng.uniform(-1, 1, 3); tangents[k] = t_refl[b.index]
+        fimg = integ.render_forward(scene, None, seed=seed + 3, spp=spp, tangents=tangents).cpu().numpy()
+        fref = osc.render_prb_forward(sensor, t_refl, t_tex, t_emit, seed=seed + 3, spp=spp, max_depth=md, rr_depth=rr)
+        _compare("forward-mode image", fimg, fref, 1e-3)
+    # ---- instance transforms
+    ikeys = scene._instance_keys()
+    smooth = all(scene._bsdf_has_smooth_lobe(m["bsdf"]) for m in scene.meshes[scene.top_mesh_count:])
+    if ikeys and smooth:
+        integ.bsdf_parameter_gradients = False
+        integ.shape_gradients = sorted(ikeys)
+        grads = integ.render_backward(scene, None, grad_in, seed=seed + 2, spp=spp)
+        want, _, _, _ = osc.render_prb_backward_instances(sensor, grad_in, None, seed=seed + 2, spp=spp, max_depth=md, rr_depth=rr)
+        total = max(np.abs(want[i]).max() for i in ikeys.values())
+        for k, i in ikeys.items():
+            got = grads[k].cpu().numpy()
+            assert np.isfinite(got).all() and np.abs(got[:3] - want[i]).max() <= 2e-3 * max(np.abs(want[i]).max(), 1e-3 * total) + 1e-7, (k, np.abs(got[:3] - want[i]).max(), np.abs(want[i]).max())
