@@ -243,6 +243,7 @@ struct HarIntegratorImpl {
      * of one fill the CUs the other's tail leaves idle. */
     HarIntegratorImpl *twin = nullptr; bool twin_used = false;
     hipStream_t side_stream = nullptr; hipEvent_t ev_fork = nullptr, ev_join = nullptr;
+    hipEvent_t ev_stagger = nullptr; bool stagger_record = false;      /* staggered halves (HAR_DUAL_STAGGER): recorded behind the first half's first closest-hit launch, the second half starts there */
     /* shadow-ray overlap (small jobs): bounce b's shadow rays (k_resolve) do not depend on bounce b + 1's closest-hit rays (k_trace_closest) -- both only need
      * bounce b's shading -- so k_resolve runs on `aux_stream` next to the trace launch (and, with the second item set below, next to bounce b + 1's shading too).  One traversal
      * tail per bounce instead of two (see run_chunk). */
@@ -566,7 +567,8 @@ int run_chunk(HarSceneImpl *S, HarIntegratorImpl *I, const DSensor &C, int mode,
     /* grid: a multiple of 8 so that block b serves shard b % 8; enough blocks to cover the chunk once */
     const uint32_t grid = std::max<uint32_t>(HAR_SHARDS, std::min<uint32_t>(((n + 255) / 256 + HAR_SHARDS - 1) / HAR_SHARDS * HAR_SHARDS, 4096u));
     /* persistent traversal kernels: enough blocks to fill the chip (<= 8 blocks/CU), never more than the work */
-    const uint32_t tgrid = std::min<uint32_t>(grid, (uint32_t) HAR_MAX_TRAVERSAL_BLOCKS);
+    static const uint32_t tgrid_env = getenv("HAR_TRACE_GRID") ? (uint32_t) std::max(HAR_SHARDS, atoi(getenv("HAR_TRACE_GRID")) / HAR_SHARDS * HAR_SHARDS) : 0u;      /* A/B: blocks of a persistent launch */
+    const uint32_t tgrid = std::min<uint32_t>(grid, tgrid_env ? std::min<uint32_t>(tgrid_env, (uint32_t) HAR_MAX_TRAVERSAL_BLOCKS) : (uint32_t) HAR_MAX_TRAVERSAL_BLOCKS);
     /* scenes whose depth-first stack bound fits the LDS entries run the kernels without the HBM spill path */
     static const bool force_spill = getenv("HAR_FORCE_STACK_SPILL") != nullptr;
     uint2 *spill = (force_spill || S->hs.stack_need() + HAR_STACK_MARGIN > HAR_LDS_STACK_SMALL) ? I->stack_spill : nullptr;
@@ -632,6 +634,7 @@ int run_chunk(HarSceneImpl *S, HarIntegratorImpl *I, const DSensor &C, int mode,
             } else
             launch_trace_closest(s, tgrid, spill, S->ds.accel, cnt_alive(I, b), cur_trace(I, b), I->shard_cap, st_in, h0, h1, I->status);
             prof_mark(I, s, CLS_TRACE);
+            if (I->stagger_record && b == 0) { HIP_TRY(hipEventRecord(I->ev_stagger, s)); I->stagger_record = false; }
         }
         if (I->hide_emitters && b == 0 && rc.mode != 2 && rc.mode != 4) {
             /* Integrator::skip_area_emitters (integrator.cpp:96-124) for the camera rays: continuation rays are gathered into a list, traced, and
@@ -1627,6 +1630,7 @@ int har_integrator_destroy(HarIntegrator I) {
     if (I->twin) { I->twin->free_ws(); prof_destroy(I->twin); }
     if (I->ev_fork) (void) hipEventDestroy(I->ev_fork);
     if (I->ev_join) (void) hipEventDestroy(I->ev_join);
+    if (I->ev_stagger) (void) hipEventDestroy(I->ev_stagger);
     if (I->side_stream) (void) hipStreamDestroy(I->side_stream);
     for (HarIntegratorImpl *J : { I->twin, I })
         if (J) {
@@ -1791,7 +1795,14 @@ int har_render(HarScene S, HarIntegrator I, const HarSensor *sensor, uint32_t se
     const bool single = streams_env != 2 && overlap_applies(S, I, std::min<uint64_t>(total_le - total_lb, I->chunk));
     const uint64_t mid = (total_le > total_lb && !single) ? dual_split(I, total_lb, total_le, (hipStream_t) stream) : total_le;
     if (mid >= total_le) { I->twin_used = false; return render_range(S, I, sensor, seed, spp, lb, le, film, stream); }
+    /* HAR_DUAL_STAGGER=1 (A/B): the second half starts behind the first half's first closest-hit launch, so that one half's memory-bound shading launches
+     * run next to the other half's issue-bound traversal launches instead of next to their own kind */
+    static const bool stagger_env = getenv("HAR_DUAL_STAGGER") && atoi(getenv("HAR_DUAL_STAGGER")) != 0;
+    if (stagger_env && !I->ev_stagger && hipEventCreateWithFlags(&I->ev_stagger, hipEventDisableTiming) != hipSuccess) I->ev_stagger = nullptr;
+    I->stagger_record = stagger_env && I->ev_stagger;
     int rc = render_range(S, I, sensor, seed, spp, total_lb, mid, film, stream);
+    if (stagger_env && I->ev_stagger && !I->stagger_record) (void) hipStreamWaitEvent(I->side_stream, I->ev_stagger, 0);
+    I->stagger_record = false;
     rc |= render_range(S, I->twin, sensor, seed, spp, mid, total_le, film, (void *) I->side_stream);
     rc |= dual_join(I, (hipStream_t) stream);
     return rc;
