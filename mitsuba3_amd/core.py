@@ -988,6 +988,8 @@ def _mk_twosided(props, named, key):
         raise RuntimeError("twosided: nested BSDF is already two-sided")
     front.flags |= 1; front.id = front.id or key
     front.back = nested[1] if len(nested) == 2 and nested[1] is not nested[0] else None
+    if front.back is not None:
+        front.back.twosided_parent = front          # (its parameters are '<twosided>.brdf_1.*': Scene._bsdf_key_base)
     if key:
         front.id = key
     return front
@@ -1807,11 +1809,22 @@ class Scene:
         return SurfaceInteraction3f(out)
 
     # -- parameters (mi.traverse)
+    @staticmethod
+    def _bsdf_key_base(b):
+        """the prefix of a BSDF's parameters in mi.traverse(): its id -- the scene-level key, or '<shape>.bsdf' -- and, for the BSDFs nested in a `twosided`, the names
+        TwoSidedBRDF::traverse registers them under (twosided.cpp:106-109): '<twosided>.brdf_0' and, when the back side is a BSDF of its own, '<twosided>.brdf_1'
+        (util.py:320-334 walks an object once, so a twosided with ONE nested BSDF has no brdf_1 entries)"""
+        parent = getattr(b, 'twosided_parent', None)
+        if parent is not None:
+            return (parent.id if parent.id else "bsdf%d" % parent.index) + ".brdf_1"
+        base = b.id if b.id else "bsdf%d" % b.index
+        return base + ".brdf_0" if (b.flags & 1) else base
+
     @_static_table
     def _param_keys(self):
         keys = {}
         for b in self.bsdf_objs:
-            base = b.id if b.id else "bsdf%d" % b.index
+            base = self._bsdf_key_base(b)
             if b.texture is not None:
                 keys[base + "." + b.slot0_name + ".data"] = ("tex", b)
             else:
@@ -1832,11 +1845,13 @@ class Scene:
     @_static_table
     def _bsdf_param_keys(self):
         """the non-slot-0 parameters of the rough models: '<bsdf>.alpha.value' (or alpha_u / alpha_v), '<bsdf>.eta.value', '<bsdf>.k.value' of
-        roughconductor (roughconductor.cpp:226-250 traverse), '<bsdf>.alpha.value' and '<bsdf>.specular_reflectance.value' of roughplastic"""
+        roughconductor (roughconductor.cpp:212-225 traverse), '<bsdf>.alpha' and '<bsdf>.specular_reflectance.value' of roughplastic (roughplastic.cpp:208-215)"""
         keys = {}
         for b in self.bsdf_objs:
-            base = b.id if b.id else "bsdf%d" % b.index
-            if b.kind in ('roughconductor', 'roughplastic'):
+            base = self._bsdf_key_base(b)
+            if b.kind == 'roughplastic':
+                keys[base + ".alpha"] = ("alpha", b)                  # a Float member, not a texture: no '.value' (roughplastic.cpp:210, :534)
+            elif b.kind == 'roughconductor':
                 if b.anisotropic:
                     keys[base + ".alpha_u.value"] = ("alpha_u", b); keys[base + ".alpha_v.value"] = ("alpha_v", b)
                 else:
@@ -2047,7 +2062,7 @@ class Scene:
                 keys[key + ".emitter.radiance.data"] = ("emitter_tex", i); keys[key + ".emitter.radiance.to_uv"] = ("emitter_to_uv", i)
         for b in self.bsdf_objs:            # BitmapTexture::traverse: `to_uv` (src/textures/bitmap.cpp), NonDifferentiable
             if b.texture is not None:
-                keys[(b.id if b.id else "bsdf%d" % b.index) + "." + b.slot0_name + ".to_uv"] = ("to_uv", b)
+                keys[self._bsdf_key_base(b) + "." + b.slot0_name + ".to_uv"] = ("to_uv", b)
         return keys
 
     def _pose_value(self, kind, b):

@@ -305,7 +305,11 @@ HAR_HD bool tri_visit_at(const float *tp, const RaySetup &R, float &tmax, uint32
     if (moeller_trumbore(R.o, R.d, tmax, Vec3(f[0], f[1], f[2]), Vec3(f[3], f[4], f[5]), Vec3(f[6], f[7], f[8]), t, u, v)) {
         if (AnyHit) return true;
         hit_update(hit, t, u, v, as_u32(f[9]), as_u32(f[10]), cur_inst);
-        tmax = hit.t;
+        /* + 0.f: a hit at t = -0 (the origin lies in the triangle's plane and the ray looks along -n) must not leave tmax = -0 behind -- the box test's far distance would then be
+         * min(.., -0) = -0, its sign test  fma(-0, 1.0000005, -tn)  reads "miss" for tn = 0, and every box that holds an equal-t candidate (the tie rule's later primitive) would
+         * be pruned: the BVH would answer differently from the brute-force loop (found by tests/test_gpu_boundary.py::test_ray_queries_bitexact_on_adversarial_rays).  -0 + 0 = +0;
+         * the reported hit.t keeps its sign */
+        tmax = hit.t + 0.f;
     }
     return false;
 }
@@ -326,7 +330,7 @@ HAR_HD bool tri_visit(const Accel &A, const RaySetup &R, float &tmax, uint32_t i
 template <bool AnyHit, typename Stack, typename Probe = NoProbe>
 HAR_HD bool accel_trace(const Accel &A, Vec3 o_w, Vec3 d_w, float maxt, Hit &hit, Stack &stack, int &status, Probe probe = Probe()) {
     hit.t = HAR_INF; hit.u = 0.f; hit.v = 0.f; hit.prim = 0; hit.shape = 0; hit.inst = 0xffffffffu;
-    float tmax = maxt;
+    float tmax = maxt + 0.f;                       /* (-0 -> +0: see tri_visit_at) */
     RaySetup R = ray_setup(o_w, d_w);
     bool in_tlas = A.has_tlas != 0;
     uint32_t cur_inst = 0xffffffffu;
@@ -431,7 +435,7 @@ struct Traversal {
      * the top-level geometry goes first so that the TLAS is entered with tmax at the nearest wall; an occlusion query has no use for that, and on a
      * "box around instanced content" scene half of the shadow rays are occluded by an instance -- they never pay the 2.5 node visits of the walls */
     HAR_HD void begin(const Accel &A, Vec3 o, Vec3 d, float maxt, bool top_last = false) {
-        o_w = o; d_w = d; tmax = maxt; top_pending = false; this->top_last = top_last && POLICY != 2;
+        o_w = o; d_w = d; tmax = maxt + 0.f /* -0 -> +0: see tri_visit_at */; top_pending = false; this->top_last = top_last && POLICY != 2;
         hit.t = HAR_INF; hit.u = 0.f; hit.v = 0.f; hit.prim = 0; hit.shape = 0; hit.inst = 0xffffffffu;
         R = ray_setup(o, d);
         in_tlas = !FLAT && A.has_tlas != 0; cur_inst = 0xffffffffu; found = false;

@@ -754,7 +754,7 @@ __global__ __launch_bounds__(kBlock, HAR_PACKET_MIN_WAVES) void k_trace_packet(A
         const uint32_t idx = min(pk + lane, n - 1u);                    /* the lanes past the end of the last packet walk a copy of its last ray; their result is dropped */
         const float4 fo = a0[base + idx], fd = a1[base + idx];
         const Vec3 o_w(fo.x, fo.y, fo.z), d_w(fd.x, fd.y, fd.z);
-        float tmax = fo.w < 0.f ? HAR_LARGEST : fo.w;
+        float tmax = fo.w < 0.f ? HAR_LARGEST : fo.w + 0.f;
         Hit hit; hit.t = HAR_INF; hit.u = 0.f; hit.v = 0.f; hit.prim = 0; hit.shape = 0; hit.inst = 0xffffffffu;
         RaySetup R = ray_setup(o_w, d_w);
         const PacketBounds Bw = packet_bounds(R);

@@ -272,7 +272,7 @@ def test_bsdf_parameter_update_rebuilds_records(mi):
     scene = mi.load_dict(d)
     params = mi.traverse(scene)
     a = mi.render(scene, spp=8, seed=0).cpu().numpy()
-    params["green.alpha.value"] = torch.tensor([0.45], device="cuda"); params["green.eta.value"] = torch.tensor([1.2, 0.5, 0.3], device="cuda")
+    params["green.brdf_0.alpha.value"] = torch.tensor([0.45], device="cuda"); params["green.brdf_0.eta.value"] = torch.tensor([1.2, 0.5, 0.3], device="cuda")
     params.update()
     b = mi.render(scene, spp=8, seed=0).cpu().numpy()
     assert rel_l2(b, a) > 1e-3
@@ -417,13 +417,13 @@ def test_mi_render_autograd_new_parameter_kinds(mi, O):
     scene = mi.load_dict(d)
     target = mi.render(scene, spp=256, seed=50).detach()
     params = mi.traverse(scene)
-    true_alpha = params["white.alpha.value"].clone()
-    params["white.alpha.value"] = true_alpha * 2.0
-    for k in ("white.alpha.value", "green.eta.value"):
+    true_alpha = params["white.alpha"].clone()
+    params["white.alpha"] = true_alpha * 2.0
+    for k in ("white.alpha", "green.brdf_0.eta.value"):
         params[k].requires_grad_(True)
     img = mi.render(scene, params, spp=spp, seed=3)
     loss = ((img - target) ** 2).mean(); loss.backward()
-    ga, ge = params["white.alpha.value"].grad.clone(), params["green.eta.value"].grad.clone()
+    ga, ge = params["white.alpha"].grad.clone(), params["green.brdf_0.eta.value"].grad.clone()
     assert ga.abs().max() > 0 and ge.abs().max() > 0
     # the adjoint terms were switched on for THAT backward pass only: the caller's integrator keeps its properties (round-2 advisor finding)
     assert not scene.integrator().bsdf_parameter_gradients and not scene.integrator().shape_gradients
@@ -433,8 +433,8 @@ def test_mi_render_autograd_new_parameter_kinds(mi, O):
     from mitsuba3_amd.core import sample_tea_32
     _seed_grad = lambda seed: sample_tea_32(seed, 1)[0]
     grads = scene.integrator().render_backward(scene, None, adj, seed=_seed_grad(3), spp=spp)
-    assert torch.allclose(grads["white.alpha.value"].reshape(-1), ga.reshape(-1), rtol=1e-4, atol=1e-9)
-    assert torch.allclose(grads["green.eta.value"].reshape(-1), ge.reshape(-1), rtol=1e-4, atol=1e-9)
+    assert torch.allclose(grads["white.alpha"].reshape(-1), ga.reshape(-1), rtol=1e-4, atol=1e-9)
+    assert torch.allclose(grads["green.brdf_0.eta.value"].reshape(-1), ge.reshape(-1), rtol=1e-4, atol=1e-9)
     scene.integrator().bsdf_parameter_gradients = False
     # rougher than the target: the gradient points towards smaller alpha
     assert float(ga.reshape(-1)[0]) > 0
@@ -576,3 +576,100 @@ def test_reference_position_edits_reach_the_accel(mi):
         t = scene.ray_intersect_preliminary(mi.Ray3f(o + np.float32(v)[:, None], dd, maxt)).t.cpu().numpy()
         assert np.allclose(t, t0)
         assert not np.isfinite(scene.ray_intersect_preliminary(mi.Ray3f(o, dd, maxt)).t.cpu().numpy()).any()      # nothing is left at the old place
+
+
+def _lattice_mesh(n=6, size=1.0):
+    """axis-aligned quads on a lattice of exactly representable coordinates (k / 8): a floor grid, a wall grid and a column of stacked boxes -- every box plane of the BVH
+    coincides with lattice planes, every edge and vertex is shared by two to six triangles"""
+    V = []; F = []
+    def quad(p, du, dv):
+        b = len(V); V.extend([p, p + du, p + du + dv, p + dv]); F.extend([[b, b + 1, b + 2], [b, b + 2, b + 3]])
+    h = np.float32(size / n)
+    for i in range(n):
+        for j in range(n):
+            x, y = np.float32(-size / 2) + i * h, np.float32(-size / 2) + j * h
+            quad(np.array([x, y, -0.5], np.float32), np.array([h, 0, 0], np.float32), np.array([0, h, 0], np.float32))          # floor  z = -1/2
+            quad(np.array([x, 0.5, y], np.float32), np.array([h, 0, 0], np.float32), np.array([0, 0, h], np.float32))           # wall   y = +1/2
+    for k in range(3):                                                                                                          # stacked boxes around the origin
+        lo = np.array([-0.125, -0.125, -0.25 + 0.125 * k], np.float32); e = np.float32(0.25)
+        ex, ey, ez = np.array([e, 0, 0], np.float32), np.array([0, e, 0], np.float32), np.array([0, 0, 0.125], np.float32)
+        quad(lo, ex, ey); quad(lo + ez, ex, ey); quad(lo, ex, ez); quad(lo + ey, ex, ez); quad(lo, ey, ez); quad(lo + ex, ey, ez)
+    return np.asarray(V, np.float32), np.asarray(F, np.uint32)
+
+
+def _adversarial_rays(rng, V, F, n_each=20000):
+    """rays built to sit ON the degenerate cases of a slab test and of Moeller-Trumbore: axis-parallel directions (+0 and -0 in the other components) from origins on
+    the lattice planes, directions with one / two exact zeros, origins exactly on vertices / edge midpoints / inside triangles (t = 0 candidates), rays aimed exactly at
+    vertices and edge midpoints (ties between the triangles that share them), unnormalised directions over 24 orders of magnitude, nearly axis-parallel directions (components nine orders apart), maxt = 0 / tiny / inf"""
+    O = []; D = []
+    lat = (rng.integers(-5, 6, (n_each, 3)) / 8.0).astype(np.float32)
+    ax = rng.integers(0, 3, n_each); sg = rng.choice(np.array([-1.0, 1.0], np.float32), n_each)
+    d = np.zeros((n_each, 3), np.float32); d[np.arange(n_each), ax] = sg
+    neg0 = rng.random((n_each, 3)) < 0.5
+    d = np.where((d == 0) & neg0, np.float32(-0.0), d)
+    O.append(lat); D.append(d)                                                               # 1. axis-parallel, origins on lattice planes, signed zeros
+    d = rng.normal(size=(n_each, 3)).astype(np.float32); d[np.arange(n_each), ax] = 0.0
+    O.append(lat.copy()); D.append(d)                                                        # 2. one zero component
+    tri = V[F[rng.integers(0, len(F), n_each)]]                                              # (n, 3 corners, 3)
+    w = rng.dirichlet([1, 1, 1], n_each).astype(np.float32)
+    kind = rng.integers(0, 3, n_each)
+    p = np.where((kind == 0)[:, None], tri[:, 0], np.where((kind == 1)[:, None], np.float32(0.5) * (tri[:, 0] + tri[:, 1]), (w[:, :, None] * tri).sum(1))).astype(np.float32)
+    O.append(p); D.append(rng.normal(size=(n_each, 3)).astype(np.float32))                   # 3. origins on vertices / edge midpoints / faces
+    o = rng.uniform(-0.9, 0.9, (n_each, 3)).astype(np.float32)
+    O.append(o); D.append((p - o).astype(np.float32))                                        # 4. aimed at vertices / edge midpoints / faces (unnormalised: t = 1 at the target)
+    o = rng.uniform(-0.9, 0.9, (n_each, 3)).astype(np.float32)
+    d = rng.normal(size=(n_each, 3)).astype(np.float32) * (10.0 ** rng.uniform(-12, 12, (n_each, 1))).astype(np.float32)
+    O.append(o); D.append(d)                                                                 # 5. |d| from 1e-12 to 1e12
+    o = np.where(rng.random((n_each, 3)) < 0.5, lat, rng.uniform(-0.9, 0.9, (n_each, 3))).astype(np.float32)
+    d = (rng.normal(size=(n_each, 3)) * 10.0 ** rng.uniform(-9, 0, (n_each, 3))).astype(np.float32)
+    O.append(o); D.append(d)                                                                 # 6. nearly axis-parallel: components nine orders of magnitude apart
+    O = np.concatenate(O).T.copy(); D = np.concatenate(D).T.copy()
+    n = O.shape[1]
+    maxt = np.full(n, np.float32(np.inf)); r = rng.random(n)
+    maxt[r < 0.1] = np.float32(3.402823466e+38); maxt[(r >= 0.1) & (r < 0.15)] = 0.0
+    maxt[(r >= 0.15) & (r < 0.3)] = rng.uniform(0.0, 2.0, int(((r >= 0.15) & (r < 0.3)).sum())).astype(np.float32)
+    sel = (r >= 0.3) & (r < 0.35); maxt[sel] = np.float32(1.0)                               # (the aimed rays end exactly on their target)
+    return np.ascontiguousarray(O, np.float32), np.ascontiguousarray(D, np.float32), maxt.astype(np.float32)
+
+
+@pytest.mark.parametrize("instanced", [False, True])
+def test_ray_queries_bitexact_on_adversarial_rays(mi, O, instanced):
+    """accelerated == brute force == oracle, bit for bit, for rays that sit on the degenerate cases of the box test (axis-parallel rays inside box planes, signed zeros,
+    inf - inf) and of the triangle test (origins on the geometry, rays through shared vertices and edges): the BVH may only PRUNE -- a box test that drops one of these
+    candidates would show up as a missing or different hit"""
+    rng = np.random.default_rng(77 + int(instanced))
+    T = mi.ScalarTransform4f
+    d = {"type": "scene", "integrator": {"type": "path", "max_depth": 3},
+         "sensor": {"type": "perspective", "fov": 45, "to_world": T().look_at(origin=[0, 0, 4], target=[0, 0, 0], up=[0, 1, 0]),
+                    "film": {"type": "hdrfilm", "width": 16, "height": 16, "rfilter": {"type": "box"}, "pixel_format": "rgb"}, "sampler": {"type": "independent", "sample_count": 4}},
+         "white": {"type": "diffuse", "reflectance": {"type": "rgb", "value": [0.5, 0.5, 0.5]}}}
+    V, F = _lattice_mesh()
+    Vs, Fs = _soup(rng, 400)
+    d["lattice"] = {"type": "mesh", "positions": V, "faces": F, "bsdf": {"type": "ref", "id": "white"}}
+    d["soup"] = {"type": "mesh", "positions": (0.6 * Vs).astype(np.float32), "faces": Fs, "bsdf": {"type": "ref", "id": "white"}}
+    allV, allF = V, F
+    if instanced:
+        d["group"] = {"type": "shapegroup", "m": {"type": "mesh", "positions": (0.25 * V).astype(np.float32), "faces": F, "bsdf": {"type": "ref", "id": "white"}}}
+        for k, t in enumerate([T().translate([0.25, 0.0, 0.125]), T().translate([-0.25, 0.125, 0.0]).rotate([0, 0, 1], 90.0), T().scale([1.0, -1.0, 2.0]), T().translate([0.25, 0.0, 0.125])]):
+            d["inst%d" % k] = {"type": "instance", "to_world": t, "group": {"type": "ref", "id": "group"}}      # (the last one coincides with the first: ties between instances)
+    scene = mi.load_dict(d)
+    osc, _ = O.scene_from_product(scene)
+    o, dd, maxt = _adversarial_rays(rng, allV, allF)
+    ref = osc.ray_intersect(o, dd, maxt, naive=True)
+    hit = np.isfinite(ref[0])
+    assert 0.2 < hit.mean() < 0.95
+    for naive in (True, False):
+        pi = scene._intersect(mi.Ray3f(o, dd, maxt), naive)
+        t = pi.t.cpu().numpy()
+        bad = np.nonzero(~((t == ref[0]) | (np.isnan(t) & np.isnan(ref[0]))))[0]
+        assert bad.size == 0, (naive, bad[:8], t[bad[:8]], ref[0][bad[:8]], o[:, bad[:4]].T, dd[:, bad[:4]].T, maxt[bad[:4]])
+        assert np.array_equal(pi.prim_uv[0].cpu().numpy()[hit], ref[1][hit]) and np.array_equal(pi.prim_uv[1].cpu().numpy()[hit], ref[2][hit])
+        assert np.array_equal(pi.prim_index.cpu().numpy().astype(np.uint32)[hit], ref[3][hit])
+        assert np.array_equal(pi.shape_index.cpu().numpy().astype(np.uint32)[hit], ref[4][hit])
+        assert np.array_equal(pi.instance.cpu().numpy().astype(np.uint32)[hit], ref[5][hit])
+    fin = np.where(np.isfinite(maxt), maxt, np.float32(3.402823466e+38)).astype(np.float32)
+    want = osc.ray_test(o, dd, fin)
+    for naive in (True, False):
+        got = scene.ray_test(mi.Ray3f(o, dd, fin), naive=naive).cpu().numpy()
+        bad = np.nonzero(got != want)[0]
+        assert bad.size == 0, (naive, bad[:8], o[:, bad[:4]].T, dd[:, bad[:4]].T, fin[bad[:4]])

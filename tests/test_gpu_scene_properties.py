@@ -233,7 +233,7 @@ def test_bsdf_parameter_updates_keep_the_scene_handle(mi, O):
     mi.render(scene, spp=4, seed=0)
     handle = scene._h.value
     params = mi.traverse(scene)
-    new = {"metal.alpha.value": [0.35], "metal.eta.value": [0.4, 0.7, 1.3], "metal.k.value": [3.0, 2.0, 1.5], "coat.alpha.value": [0.3], "coat.specular_reflectance.value": [0.8, 0.9, 0.7]}
+    new = {"metal.alpha.value": [0.35], "metal.eta.value": [0.4, 0.7, 1.3], "metal.k.value": [3.0, 2.0, 1.5], "coat.alpha": [0.3], "coat.specular_reflectance.value": [0.8, 0.9, 0.7]}
     assert set(new) <= set(params.keys()), sorted(params.keys())
     for k, v in new.items():
         params[k] = torch.tensor(v, device="cuda")
@@ -250,7 +250,7 @@ def test_bsdf_parameter_updates_keep_the_scene_handle(mi, O):
     want, ost = osc.render_path(sensor, seed=5, spp=32, max_depth=scene.integrator().max_depth, rr_depth=scene.integrator().rr_depth)
     assert rel_l2(img, want) < 1e-4 and scene.integrator().stats()["vertices"] == ost.vertices
     # a value the plugin refuses is an error, not a silent no-op
-    params["coat.alpha.value"] = torch.tensor([float("nan")], device="cuda")
+    params["coat.alpha"] = torch.tensor([float("nan")], device="cuda")
     with pytest.raises(RuntimeError, match="not finite"):
         params.update()
 

@@ -419,3 +419,36 @@ def test_reference_to_uv_is_a_traversable_parameter(mi, O):
     a, sensor = O.scene_from_product(scene); b, _ = O.scene_from_product(fresh)
     ia, _ = a.render_path(sensor, seed=2, spp=4, max_depth=4, raw=True); ib, _ = b.render_path(sensor, seed=2, spp=4, max_depth=4, raw=True)
     assert np.array_equal(ia, ib)
+
+
+def test_traverse_names_of_twosided_children(mi):
+    """mi.traverse() names the BSDFs nested in a `twosided` the way TwoSidedBRDF::traverse registers them (twosided.cpp:106-109): '<twosided>.brdf_0.*' and -- when the back
+    side is a BSDF of its own -- '<twosided>.brdf_1.*'; a twosided with ONE nested BSDF has no brdf_1 entries (util.py:320-334 walks an object once).  Two twosided BSDFs
+    whose children carry the same dict key ('back') must not share a parameter name: round 6's randomised suite found 'back.specular_reflectance.value' naming the
+    roughconductor under one floor AND the specular colour of a roughplastic under another shape"""
+    T = mi.ScalarTransform4f
+    rgb = lambda *v: {"type": "rgb", "value": list(v)}
+    d = {"type": "scene", "integrator": {"type": "prb", "max_depth": 3},
+         "sensor": {"type": "perspective", "fov": 45, "to_world": T().look_at(origin=[0, 0, 4], target=[0, 0, 0], up=[0, 1, 0]),
+                    "film": {"type": "hdrfilm", "width": 8, "height": 8, "rfilter": {"type": "box"}, "pixel_format": "rgb"}, "sampler": {"type": "independent", "sample_count": 4}},
+         "wall": {"type": "twosided", "m": {"type": "diffuse", "reflectance": rgb(0.1, 0.2, 0.3)}},
+         "floor": {"type": "rectangle", "bsdf": {"type": "twosided", "front": {"type": "diffuse", "reflectance": rgb(0.5, 0.5, 0.5)},
+                                                  "back": {"type": "roughconductor", "alpha": 0.2, "specular_reflectance": rgb(0.9, 0.8, 0.7)}}},
+         "sheet": {"type": "rectangle", "to_world": T().translate([0, 0, 1]),
+                   "bsdf": {"type": "twosided", "front": {"type": "roughplastic", "alpha": 0.3, "diffuse_reflectance": rgb(0.2, 0.2, 0.2)},
+                            "back": {"type": "roughplastic", "alpha": 0.1, "diffuse_reflectance": rgb(0.4, 0.4, 0.4), "specular_reflectance": rgb(0.6, 0.6, 0.6)}}},
+         "side": {"type": "rectangle", "to_world": T().translate([2, 0, 0]), "bsdf": {"type": "ref", "id": "wall"}},
+         "light": {"type": "point", "position": [0, 0, 3], "intensity": rgb(1, 1, 1)}}
+    scene = mi.load_dict(d)
+    params = mi.traverse(scene)
+    keys = set(params.keys())
+    for k in ("wall.brdf_0.reflectance.value", "floor.bsdf.brdf_0.reflectance.value", "floor.bsdf.brdf_1.specular_reflectance.value", "floor.bsdf.brdf_1.alpha.value",
+              "floor.bsdf.brdf_1.eta.value", "floor.bsdf.brdf_1.k.value", "sheet.bsdf.brdf_0.diffuse_reflectance.value", "sheet.bsdf.brdf_0.alpha",
+              "sheet.bsdf.brdf_1.diffuse_reflectance.value", "sheet.bsdf.brdf_1.specular_reflectance.value", "sheet.bsdf.brdf_1.alpha"):
+        assert k in keys, (k, sorted(keys))
+    assert not any(k.startswith(("back.", "front.", "m.")) or ".brdf_1." in k and k.startswith("wall") for k in keys), sorted(keys)
+    # the two specular colours are two parameters with their own values
+    assert np.allclose(np.asarray(params["floor.bsdf.brdf_1.specular_reflectance.value"].cpu()), [0.9, 0.8, 0.7])
+    assert np.allclose(np.asarray(params["sheet.bsdf.brdf_1.specular_reflectance.value"].cpu()), [0.6, 0.6, 0.6])
+    # the colour table and the table of the other BSDF parameters never name the same key
+    assert not (set(scene._param_keys()) & set(scene._bsdf_param_keys()))

@@ -12,7 +12,7 @@ d["integrator"] = {"type": "prb", "max_depth": md, "rr_depth": 100, "bsdf_parame
 scene = mi.load_dict(d)
 osc, sensor = O.scene_from_product(scene)
 integ = scene.integrator()
-(key, (what, b)), = [(k, v) for k, v in scene._bsdf_param_keys().items() if k == "white.alpha.value"]
+(key, (what, b)), = [(k, v) for k, v in scene._bsdf_param_keys().items() if k == "white.alpha"]
 def both(g):
     got = float(integ.render_backward(scene, None, g, seed=4, spp=spp)[key].cpu().numpy()[0])
     gx, _ = osc.render_prb_backward_bsdf_params(sensor, g, seed=4, spp=spp, max_depth=md, rr_depth=100)
