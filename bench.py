@@ -255,7 +255,7 @@ def optimisation_loop(args, mi, torch, timed, sync_barrier, world, rank):
         P, N, UV, F = bumpy_sphere(n_u=n_u, n_v=n_u // 2, radius=0.35)         # every update regenerates them, Mesh::compute_normals); round 5 measured 102 400 flat-shaded ones
         d.pop("small-box"); d.pop("large-box")
         d["blob"] = {"type": "mesh", "positions": P + np.array([0.0, -0.45, 0.0], np.float32), "normals": N, "faces": F, "bsdf": {"type": "ref", "id": "white"}}
-        key = "blob.vertex_positions"
+        key = "blob.positions"
         what = "Cornell box + a %d-triangle mesh, %dx%dx%dspp prb max_depth=%d, gradients w.r.t. its %d vertex positions" % (F.shape[0], res, res, spp, args.max_depth, P.shape[0])
     log("optimisation loop: building the scene")
     scene = mi.load_dict(d)

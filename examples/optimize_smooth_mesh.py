@@ -20,7 +20,7 @@ from tests.test_shape_gradients_cpu import smooth_slab_scene      # noqa: E402
 def main():
     iterations = int(sys.argv[1]) if len(sys.argv) > 1 else 80
     mi.set_variant("hip_ad_rgb")
-    key = "floor.vertex_positions"
+    key = "floor.positions"
     d = smooth_slab_scene(mi, 96, n=25)
     d["integrator"] = {"type": "prb", "max_depth": 3, "shape_gradients": [key], "emitter_gradients": False}
     scene = mi.load_dict(d)

@@ -20,7 +20,7 @@ from tests.test_shape_gradients_cpu import slab_scene         # noqa: E402  (two
 def main():
     iterations = int(sys.argv[1]) if len(sys.argv) > 1 else 60
     mi.set_variant("hip_ad_rgb")
-    key = "floor.vertex_positions"
+    key = "floor.positions"
     d = slab_scene(mi, 64)
     d["integrator"] = {"type": "prb", "max_depth": 4, "shape_gradients": [key], "emitter_gradients": False}
     scene = mi.load_dict(d)
@@ -29,7 +29,7 @@ def main():
     truth = params[key].clone()
     start = truth.reshape(-1, 3).clone()
     start[:, 1] += 0.3; start[1:3, 1] += 0.4                                         # lifted and tilted
-    params[key] = start.reshape(-1).requires_grad_(True)
+    params[key] = start.clone().requires_grad_(True)                                 # N x 3, the shape of the reference's `positions` tensor
     params.update()
     opt = torch.optim.Adam([params[key]], lr=0.02)
     import time
@@ -43,7 +43,7 @@ def main():
             g = params[key].grad.reshape(-1, 3); g[:, 0] = 0; g[:, 2] = 0
         opt.step()
         params.update()                                                              # positions stay on the GPU: records, normals, shading triangles and the BVH refit are kernels (har_scene_update_vertices_device)
-        err = (params[key].detach() - truth).reshape(-1, 3)[:, 1]
+        err = (params[key].detach().reshape(-1, 3) - truth.reshape(-1, 3))[:, 1]
         # the corners are 40 units away; what the image constrains is the plane under the light: its height (mean of the corners) and slope
         print("iter %3d  loss %.6f  height error at the centre %.4f  slope error %.5f" % (it, float(loss), float(err.mean()), float((err[1:3].mean() - err[[0, 3]].mean()) / 80.0)))
     torch.cuda.synchronize()

@@ -252,7 +252,7 @@ int har_scene_update_instances(HarScene scene, uint32_t first, uint32_t count, c
 int har_scene_update_vertices(HarScene scene, uint32_t mesh, const float *vertices, void *stream);
 /* The same update with the positions ALREADY ON THE DEVICE -- what Mesh::parameters_changed does in the reference's JIT variants, where a position update never leaves
  * the GPU (src/render/mesh.cpp:848-899: pack(regenerate_normals) -> compute_normals :1216-1267; Scene::parameters_changed hands the accel its new vertices,
- * src/render/scene.cpp:517-540).  `positions` = DEVICE, vertex_count x 3 floats (the layout of '<shape>.vertex_positions', Mesh::traverse).  Enqueued on `stream`:
+ * src/render/scene.cpp:517-540).  `positions` = DEVICE, vertex_count x 3 floats (the layout of '<shape>.positions', Mesh::traverse).  Enqueued on `stream`:
  * positions -> packed vertex records, vertex normals regenerated if the mesh carries normals (Mesh::compute_normals as a deterministic per-vertex gather,
  * har_vertex_update.h), the 96-byte shading triangles rewritten, the BLAS refitted.  For a top-level mesh in a scene without environment / directional emitters the
  * call copies nothing between host and device and waits for nothing: the refit's cost figure and a "position not finite" flag land in a pinned record that the NEXT
@@ -469,7 +469,7 @@ int har_render_backward(HarScene scene, HarIntegrator integrator, const HarSenso
  * emitter_count x 3 floats is set, har_render_backward also accumulates into it; NULL switches it off again */
 int har_integrator_set_grad_emitters(HarIntegrator integrator, float *grad_emitters);
 
-/* Gradient w.r.t. VERTEX POSITIONS (params['<mesh>.vertex_positions'] of mi.traverse): the geometry-attached part of PRBIntegrator.sample
+/* Gradient w.r.t. VERTEX POSITIONS (params['<mesh>.positions'] of mi.traverse): the geometry-attached part of PRBIntegrator.sample
  * (src/python/python/ad/integrators/prb.py:124-141 attached surface interaction -- Mesh::compute_surface_interaction with AD-attached
  * vertices, src/render/mesh.cpp:2286-2323, and SurfaceInteraction::attach_motion, include/mitsuba/render/interaction.h:525-545 --,
  * :176-216 emitter sampling from the attached point, :261-297 attached outgoing direction and solid_angle_to_area_jacobian,

@@ -1173,7 +1173,7 @@ class Integrator:
         # hip_ad_rgb extension, see har_integrator_set_packet_tracing: None = automatic, False / True force the wave-shared descent of the camera rays off / on
         self.packet_tracing = props.get('packet_tracing', None)
         self.emitter_gradients = bool(props.get('emitter_gradients', True))   # d / d radiance of area / constant emitters (har_integrator_set_grad_emitters)
-        # d / d vertex positions (har_integrator_set_grad_positions): False, True (every eligible mesh) or a list of '<shape>.vertex_positions' keys --
+        # d / d vertex positions (har_integrator_set_grad_positions): False, True (every eligible mesh) or a list of '<shape>.positions' keys --
         # the stand-in for dr.enable_grad(params[key]) of the reference
         self.shape_gradients = props.get('shape_gradients', False)
         # gradients of `alpha` / `alpha_u` / `alpha_v`, `eta`, `k` (roughconductor) and `alpha`, `specular_reflectance` (roughplastic): har_integrator_set_grad_bsdf_params
@@ -1363,7 +1363,7 @@ class Integrator:
             else:
                 inst_wanted = {k: ikeys[k] for k in self.shape_gradients if k in ikeys}
                 wanted = {k: keys[k] for k in self.shape_gradients if k not in ikeys}    # KeyError: not a differentiable mesh / instance
-            g_pos = {k: torch.zeros(3 * scene.meshes[m]["V"].shape[0], dtype=torch.float32, device=dev) for k, m in wanted.items()}
+            g_pos = {k: torch.zeros((scene.meshes[m]["V"].shape[0], 3), dtype=torch.float32, device=dev) for k, m in wanted.items()}      # the parameter's shape: N x 3
             by_mesh = {wanted[k]: g for k, g in g_pos.items()}
             pp = (C.c_void_p * max(1, len(scene.meshes)))(*[by_mesh[m].data_ptr() if m in by_mesh else None for m in range(len(scene.meshes))])
             # what the previous call left on must not veto this call's selection (nested vertex positions and instance transforms exclude each other): instances
@@ -1897,10 +1897,10 @@ class Scene:
 
     @_static_table
     def _position_keys(self):
-        """'<shape>.vertex_positions' (flat 3 N floats as in the reference's Mesh::traverse) of the top-level meshes and, as '<group>.<child>.vertex_positions', of the
+        """'<shape>.positions' (an N x 3 tensor: Mesh::traverse, src/render/mesh.cpp:827; a flat array of 3 N floats is accepted on write) of the top-level meshes and, as '<group>.<child>.positions', of the
         meshes inside shape groups (object space, shared by all instances); writing them regenerates the vertex normals of a smooth-shaded mesh (mesh.cpp:876-878),
         see _set_vertex_positions"""
-        return {m["key"] + ".vertex_positions": i for i, m in enumerate(self.meshes) if m["V"].shape[0]}
+        return {m["key"] + ".positions": i for i, m in enumerate(self.meshes) if m["V"].shape[0]}
 
     def _bsdf_has_smooth_lobe(self, index):
         """BSDFFlags::Smooth on every side: models made of delta lobes only (`dielectric`, `conductor`) cannot sit on MOVING geometry -- their eval() is zero,
@@ -1984,7 +1984,7 @@ class Scene:
             start = end + 1
 
     def _set_vertex_positions(self, mesh, positions):
-        """params['<shape>.vertex_positions'] = ... (a host tensor / array) + params.update(): normals regenerated on the host, the BLAS refitted on the device
+        """params['<shape>.positions'] = ... (a host tensor / array) + params.update(): normals regenerated on the host, the BLAS refitted on the device
         (har_scene_update_vertices); CUDA tensors take _set_vertex_positions_device instead"""
         V = self.meshes[mesh]["V"]
         V[:, :3] = np.asarray(positions, np.float32).reshape(V.shape[0], 3)
@@ -2018,14 +2018,14 @@ class Scene:
             raise RuntimeError(msg or "vertex update failed")
 
     def _set_vertex_positions_device(self, mesh, positions):
-        """params['<shape>.vertex_positions'] (a CUDA tensor) + params.update(): the positions stay on the GPU -- vertex records, regenerated normals, shading triangles and the
+        """params['<shape>.positions'] (a CUDA tensor) + params.update(): the positions stay on the GPU -- vertex records, regenerated normals, shading triangles and the
         BLAS refit are kernels on the current stream (har_scene_update_vertices_device; Mesh::parameters_changed, mesh.cpp:848-899).  The numpy mirror meshes[mesh]['V'] is
         refreshed lazily (sync_host)."""
         torch = _torch()
         V = self.meshes[mesh]["V"]
         p = positions.detach().to(torch.float32).contiguous()
         if p.numel() != 3 * V.shape[0]:
-            raise RuntimeError("vertex_positions: expected %d values" % (3 * V.shape[0]))
+            raise RuntimeError("positions: expected %d rows of 3 values" % V.shape[0])
         if not hasattr(self, "_stale_meshes"):
             self._stale_meshes = set()
         self._stale_meshes.add(mesh)
@@ -2231,11 +2231,21 @@ class SceneParameters(dict):
         for k, (what, b) in scene._bsdf_param_keys().items():
             self[k] = torch.tensor(np.asarray(scene._bsdf_param_value(what, b), np.float32), dtype=torch.float32, device=dev)
         for k, m in scene._position_keys().items():
-            self[k] = torch.tensor(np.ascontiguousarray(scene.meshes[m]["V"][:, :3]).reshape(-1), dtype=torch.float32, device=dev)
+            self[k] = torch.tensor(np.ascontiguousarray(scene.meshes[m]["V"][:, :3]), dtype=torch.float32, device=dev)            # N x 3, as the reference's `positions` tensor
         for k, i in scene._instance_keys().items():
             self[k] = torch.tensor(scene._instance_matrix(i), dtype=torch.float32, device=dev)
         for k, (kind, b) in scene._pose_keys().items():
             self[k] = torch.tensor(scene._pose_value(kind, b), dtype=torch.float32, device=dev)
+        # what Mesh::traverse (src/render/mesh.cpp:822-843) also registers and this variant can only SHOW: the index buffer and the texture coordinates (N x 2) of the
+        # triangle meshes -- readable under the reference's names, refused on write like a ParamFlags::ReadOnly entry (util.py:59-60)
+        self._read_only = set()
+        for k, m in scene._position_keys().items():
+            mesh = scene.meshes[m]; base = k[:-len(".positions")]
+            self[base + ".faces"] = torch.tensor(np.ascontiguousarray(mesh["F"][:, :3]).astype(np.int64), dtype=torch.int64, device=dev)
+            self._read_only.add(base + ".faces")
+            if mesh["flags"] & 2:
+                self[base + ".texcoords"] = torch.tensor(np.ascontiguousarray(mesh["V"][:, 6:8]), dtype=torch.float32, device=dev)
+                self._read_only.add(base + ".texcoords")
         self._written = set()           # keys assigned since the last update() (SceneParameters.__setitem__ flags them in the reference, util.py)
         # the tensors above ARE the scene's values: recorded as applied, so that the first update() touches only what was written or stepped since (vertex positions on
         # the GPU are never compared -- a mesh is updated when its tensor's version counter moved, see _changed_keys)
@@ -2246,6 +2256,11 @@ class SceneParameters(dict):
             snap[k] = None if (what in ("pos", "inst") and t.is_cuda) else t.detach().clone()
 
     def __setitem__(self, key, value):
+        if hasattr(self, "_written"):                 # (the constructor fills the table before `_written` exists)
+            if key not in self:
+                raise KeyError(key)                   # util.py:57: `self.properties[key]` -- a name traverse() did not register is not a parameter
+            if key in self._read_only:
+                raise Exception("%s is a read-only parameter!" % key)      # util.py:59-60
         super().__setitem__(key, value)
         if hasattr(self, "_written"):
             self._written.add(key)

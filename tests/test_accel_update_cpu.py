@@ -67,7 +67,7 @@ def test_refit_of_unmoved_geometry_is_the_built_tree(mi, O, flatten):
     h = _create(L, scene); before = _hash(L, h)
     err = C.create_string_buffer(256); area = C.c_double()
     keys = scene._position_keys()
-    name = "ball004.vertex_positions" if flatten else "spheres.ball.vertex_positions"
+    name = "ball004.positions" if flatten else "spheres.ball.positions"
     m = keys[name]
     assert L.hh_scene_update_vertices(h, m, O.fp(np.ascontiguousarray(scene.meshes[m]["V"], np.float32)), C.byref(area), err, 256) == 0, err.value
     assert _hash(L, h) == before and area.value > 0              # nodes, triangle records, instance records: bit for bit
@@ -80,7 +80,7 @@ def test_refit_after_a_move_is_exact(mi, O, flatten):
     L = _lib(O); rng = np.random.default_rng(3)
     d = spheres(mi, flatten); scene = mi.load_dict(d)
     h = _create(L, scene)
-    name = "ball004.vertex_positions" if flatten else "spheres.ball.vertex_positions"
+    name = "ball004.positions" if flatten else "spheres.ball.positions"
     m = scene._position_keys()[name]
     o, dd, maxt = _rays(20000)
     err = C.create_string_buffer(256)
@@ -130,7 +130,7 @@ def test_vertex_update_of_an_instanced_mesh_moves_every_instance(mi, O):
     L = _lib(O); rng = np.random.default_rng(9)
     scene = mi.load_dict(spheres(mi, False, sky=True))
     h = _create(L, scene)
-    m = scene._position_keys()["spheres.ball.vertex_positions"]
+    m = scene._position_keys()["spheres.ball.positions"]
     V = scene.meshes[m]["V"].copy(); V[:, :3] *= 1.6; V = _move(V, rng, 0.004)       # grow the sphere: every instance box must grow
     scene.meshes[m]["V"] = V
     err = C.create_string_buffer(256)
@@ -148,7 +148,7 @@ def test_vertex_update_of_an_instanced_mesh_moves_every_instance(mi, O):
 def test_emitter_meshes_ask_for_a_new_scene(mi, O):
     L = _lib(O); scene = mi.load_dict(mi.cornell_box())
     h = _create(L, scene)
-    m = scene._position_keys()["light.vertex_positions"]
+    m = scene._position_keys()["light.positions"]
     err = C.create_string_buffer(256)
     assert L.hh_scene_update_vertices(h, m, O.fp(np.ascontiguousarray(scene.meshes[m]["V"], np.float32)), None, err, 256) == 2 and b"emitter" in err.value
     L.hh_scene_destroy(h)
@@ -158,7 +158,7 @@ def test_refit_area_grows_when_the_tree_degrades(mi, O):
     """the figure har_scene_update_vertices watches: shuffling vertices far from where the tree was built for inflates the sum of the node areas"""
     L = _lib(O); rng = np.random.default_rng(2)
     scene = mi.load_dict(spheres(mi, True, grid=2, n_u=32, n_v=16))
-    h = _create(L, scene); m = scene._position_keys()["ball001.vertex_positions"]
+    h = _create(L, scene); m = scene._position_keys()["ball001.positions"]
     err = C.create_string_buffer(256); a0 = C.c_double(); a1 = C.c_double()
     V = np.ascontiguousarray(scene.meshes[m]["V"], np.float32)
     assert L.hh_scene_update_vertices(h, m, O.fp(V), C.byref(a0), err, 256) == 0
@@ -183,7 +183,7 @@ def test_device_resident_update_code_equals_the_host_update_bit_for_bit(mi, O, f
     import mitsuba3_amd as pkg
     L = _lib_positions(O); rng = np.random.default_rng(11)
     scene = mi.load_dict(spheres(mi, flatten))
-    name = "ball004.vertex_positions" if flatten else "spheres.ball.vertex_positions"
+    name = "ball004.positions" if flatten else "spheres.ball.positions"
     m = scene._position_keys()[name]
     assert scene.meshes[m]["flags"] & 1                                   # the bumpy spheres carry vertex normals
     V0 = np.ascontiguousarray(scene.meshes[m]["V"], np.float32); F = np.ascontiguousarray(scene.meshes[m]["F"])
@@ -215,7 +215,7 @@ def test_device_resident_update_code_equals_the_host_update_bit_for_bit(mi, O, f
 def test_device_resident_update_refuses_emitter_meshes(mi, O):
     L = _lib_positions(O); scene = mi.load_dict(mi.cornell_box())
     h = _create(L, scene); err = C.create_string_buffer(256)
-    m = scene._position_keys()["light.vertex_positions"]
+    m = scene._position_keys()["light.positions"]
     P = np.ascontiguousarray(scene.meshes[m]["V"][:, :3], np.float32)
     assert L.hh_scene_update_positions(h, m, O.fp(P), None, err, 256) == 2 and b"emitter" in err.value
     L.hh_scene_destroy(h)
@@ -229,7 +229,7 @@ def test_instance_level_refit_equals_rebuild_when_nothing_moved_and_is_exact_aft
     L.hh_scene_update_positions_instanced.argtypes = [C.c_void_p, C.c_uint32, O.c_f32p, C.c_char_p, C.c_int]
     rng = np.random.default_rng(21)
     scene = mi.load_dict(spheres(mi, False))
-    m = scene._position_keys()["spheres.ball.vertex_positions"]
+    m = scene._position_keys()["spheres.ball.positions"]
     V0 = np.ascontiguousarray(scene.meshes[m]["V"], np.float32)
     err = C.create_string_buffer(256)
     h = _create(L, scene); before = _hash(L, h)

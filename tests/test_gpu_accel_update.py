@@ -40,7 +40,7 @@ def test_vertex_update_refits_in_place(mi, O, flatten):
     mi.render(scene, spp=4, seed=0)                                   # the handle exists
     handle = scene._h.value
     params = mi.traverse(scene)
-    key = "ball005.vertex_positions" if flatten else "spheres.ball.vertex_positions"
+    key = "ball005.positions" if flatten else "spheres.ball.positions"
     rays = _rays(mi, 200000)
     rng = np.random.default_rng(5)
     base = params[key].cpu().numpy().reshape(-1, 3)
@@ -120,7 +120,7 @@ def test_degraded_refit_advises_a_rebuild_and_emitter_meshes_get_a_new_scene(mi)
     d = _scene_dict(mi, True)
     scene = mi.load_dict(d); mi.render(scene, spp=4, seed=0)
     params = mi.traverse(scene)
-    key = "ball002.vertex_positions"
+    key = "ball002.positions"
     p = params[key].cpu().numpy().reshape(-1, 3)
     params[key] = torch.tensor(p.reshape(-1), device="cuda"); params.update()            # first refit: the baseline of the cost figure
     assert scene._h is not None and scene.refit_info()["refits"] == 1
@@ -146,7 +146,7 @@ def test_degraded_refit_advises_a_rebuild_and_emitter_meshes_get_a_new_scene(mi)
     # a mesh with an area emitter: its sampling records are lowered from the positions -> new scene, not a refit
     cb = mi.load_dict(mi.cornell_box()); mi.render(cb, spp=4, seed=0)
     pc = mi.traverse(cb)
-    pc["light.vertex_positions"] = pc["light.vertex_positions"] * 1.0; pc.update()
+    pc["light.positions"] = pc["light.positions"] * 1.0; pc.update()
     assert cb._h is None
 
 
@@ -157,7 +157,7 @@ def test_shape_optimisation_steps_keep_the_handle(mi):
     d["integrator"] = {"type": "prb", "max_depth": 4}
     scene = mi.load_dict(d)
     params = mi.traverse(scene)
-    key = "small-box.vertex_positions"
+    key = "small-box.positions"
     params[key] = params[key].clone().requires_grad_(True); params.update()
     opt = torch.optim.SGD([params[key]], lr=1e-3)
     mi.render(scene, spp=4, seed=0); handle = scene._h.value
@@ -180,7 +180,7 @@ def test_device_resident_vertex_update_equals_the_host_update(mi, O, flatten, sk
     instance level REFITTED on the device (k_instance_boxes + the TLAS levels: no read-back, no wait) where the host path rebuilds it -- same answers, boxes only prune."""
     import torch
     d = _scene_dict(mi, flatten, sky=sky)
-    key = "ball005.vertex_positions" if flatten else "spheres.ball.vertex_positions"
+    key = "ball005.positions" if flatten else "spheres.ball.positions"
     a = mi.load_dict(d); b = mi.load_dict(copy.deepcopy(d))
     for sc in (a, b):
         mi.render(sc, spp=4, seed=0)
@@ -211,7 +211,7 @@ def test_device_resident_update_reports_a_non_finite_position_one_call_late(mi):
     d = _scene_dict(mi, True)
     scene = mi.load_dict(d); mi.render(scene, spp=4, seed=0)
     params = mi.traverse(scene)
-    key = "ball002.vertex_positions"
+    key = "ball002.positions"
     p = params[key].clone()
     bad = p.clone(); bad[7] = float("nan")
     params[key] = bad; params.update()                                # enqueued; nothing has looked at the values yet
@@ -243,7 +243,7 @@ def test_vertex_loop_with_device_updates_matches_host_updates(mi):
             d["blob"] = {"type": "mesh", "positions": P + np.array([0.0, -0.45, 0.0], np.float32), "normals": N, "faces": F, "bsdf": {"type": "ref", "id": "white"}}
             scene = mi.load_dict(d)
             params = mi.traverse(scene)
-            key = "blob.vertex_positions"
+            key = "blob.positions"
             params[key] = params[key].clone().requires_grad_(True); params.update()
             opt = torch.optim.SGD([params[key]], lr=2e-7)               # gradients of mean(img^2) w.r.t. a vertex reach ~1e3: steps of ~1e-4 scene units
             grads = []

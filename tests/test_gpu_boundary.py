@@ -301,7 +301,7 @@ def test_prb_instance_to_world_gradients(mi, O, which):
     if which == "cbox_with_positions":                  # the floor as a flat-shaded top-level mesh, differentiated too
         floor = mi.load_dict({"type": "rectangle", "to_world": d["floor"]["to_world"]})
         d["floor"] = {"type": "mesh", "positions": floor.V[:, :3].copy(), "faces": floor.F[:, :3].copy(), "bsdf": {"type": "ref", "id": "white"}}
-        pos_names = ["floor"]; wanted = wanted + ["floor.vertex_positions"]
+        pos_names = ["floor"]; wanted = wanted + ["floor.positions"]
     d["integrator"] = {"type": "prb", "max_depth": 5, "shape_gradients": wanted}
     if which == "cbox_nocache":
         d["integrator"]["replay_cache"] = False
@@ -321,7 +321,7 @@ def test_prb_instance_to_world_gradients(mi, O, which):
         ids = [mesh_index(scene, n) for n in pos_names]
         wp, _, _, _ = osc.render_prb_backward_shape(sensor, grad_in, ids, seed=3, spp=spp, max_depth=5)
         for n, m in zip(pos_names, ids):
-            got = grads[n + ".vertex_positions"].cpu().numpy().reshape(-1, 3)
+            got = grads[n + ".positions"].cpu().numpy().reshape(-1, 3)
             scale = np.abs(wp[m]).max()
             assert scale > 0 and np.abs(got - wp[m]).max() < 2e-3 * scale, (which, n)
     for k, (kind, b) in scene._param_keys().items():
@@ -337,7 +337,7 @@ def test_prb_instance_to_world_gradients(mi, O, which):
 
 @pytest.mark.parametrize("which", ["slab", "slab_roughplastic", "cbox_boxes", "smooth", "smooth_roughplastic"])
 def test_prb_nested_mesh_vertex_position_gradients(mi, O, which):
-    """'<group>.<child>.vertex_positions': vertex positions of a mesh INSIDE a shape group, shared by all its instances (Instance::compute_surface_interaction with a
+    """'<group>.<child>.positions': vertex positions of a mesh INSIDE a shape group, shared by all its instances (Instance::compute_surface_interaction with a
     detached to_world, instance.cpp:150-204): the kernels (geometry records carrying the instance, k_shape_adjoint in object space, k_normals_adjoint for nested vertex
     normals) vs the oracle, vertex by vertex; combining them with instance transforms is refused like in the reference (:162-166); an update moves every instance"""
     from tests.test_shape_gradients_cpu import instanced_slab_scene, instanced_cbox_scene, instanced_smooth_scene
@@ -347,31 +347,31 @@ def test_prb_nested_mesh_vertex_position_gradients(mi, O, which):
         res = 24; d = instanced_smooth_scene(mi, res, model=which[7:] or None); key = "group.grid"
     else:
         res = 24; d = instanced_slab_scene(mi, res, model=which[5:] or None); key = "group.quad"
-    d["integrator"] = {"type": "prb", "max_depth": 5, "shape_gradients": [key + ".vertex_positions"]}
+    d["integrator"] = {"type": "prb", "max_depth": 5, "shape_gradients": [key + ".positions"]}
     scene = mi.load_dict(d)
     m = [i for i, x in enumerate(scene.meshes) if x["key"] == key][0]
     assert m >= scene.top_mesh_count
     params = mi.traverse(scene)
     if scene.meshes[m]["flags"] & 1:
-        params[key + ".vertex_positions"] = params[key + ".vertex_positions"].clone(); params.update()
+        params[key + ".positions"] = params[key + ".positions"].clone(); params.update()
     osc, sensor = O.scene_from_product(scene)
     grad_in = np.random.default_rng(4).uniform(0.5, 1.5, (res, res, 3)).astype(np.float32)
     integ = scene.integrator()
     grads = integ.render_backward(scene, None, grad_in, seed=3, spp=16)
     want, w_refl, _, _ = osc.render_prb_backward_shape(sensor, grad_in, [m], seed=3, spp=16, max_depth=5)
-    got = grads[key + ".vertex_positions"].cpu().numpy().reshape(-1, 3)
+    got = grads[key + ".positions"].cpu().numpy().reshape(-1, 3)
     scale = np.abs(want[m]).max()
     assert scale > 0 and np.abs(got - want[m]).max() < 2e-3 * scale, (which, np.abs(got - want[m]).max() / scale)
     inst_key = next(iter(scene._instance_keys()))          # '<instance>.to_world' (the sensor's and the delta emitters' placement keys end in .to_world too)
-    integ.shape_gradients = [key + ".vertex_positions", inst_key]
+    integ.shape_gradients = [key + ".positions", inst_key]
     with pytest.raises(RuntimeError, match="at the same time"):
         integ.render_backward(scene, None, grad_in, seed=3, spp=16)
     integ.shape_gradients = [inst_key]                  # and the other way round on the same integrator: the earlier selection does not linger
     assert inst_key in integ.render_backward(scene, None, grad_in, seed=3, spp=16)
     integ.shape_gradients = False
     before = mi.render(scene, spp=8, seed=1).cpu().numpy()
-    p = params[key + ".vertex_positions"].clone().reshape(-1, 3); p[:, 1] -= 0.04           # (object space: the floor sinks, the turned-over ceiling instance RISES by the same amount and stays above the light)
-    params[key + ".vertex_positions"] = p.reshape(-1); params.update()
+    p = params[key + ".positions"].clone().reshape(-1, 3); p[:, 1] -= 0.04           # (object space: the floor sinks, the turned-over ceiling instance RISES by the same amount and stays above the light)
+    params[key + ".positions"] = p.reshape(-1); params.update()
     after = mi.render(scene, spp=8, seed=1).cpu().numpy()
     osc2, sensor2 = O.scene_from_product(scene)
     ref, _ = osc2.render_prb(sensor2, seed=1, spp=8, max_depth=5)
@@ -564,7 +564,7 @@ def test_reference_position_edits_reach_the_accel(mi):
                                    "texcoords": np.float32([[0, 0], [1, 0], [1, 1], [0, 1]])}}
     scene = mi.load_dict(d)
     params = mi.traverse(scene)
-    init = params["rect.vertex_positions"].clone().reshape(-1, 3)
+    init = params["rect.positions"].clone().reshape(-1, 3)
     g = np.arange(16)
     px = 1.9 * ((g % 4) / 3.0 - 0.5); pz = 1.9 * ((g // 4) / 3.0 - 0.5)
     o = np.stack([px, np.full(16, -5.0), pz]).astype(np.float32); dd = np.tile(np.float32([[0], [1], [0]]), (1, 16)); maxt = np.full(16, 3.402823466e+38, np.float32)
@@ -572,7 +572,7 @@ def test_reference_position_edits_reach_the_accel(mi):
     assert np.allclose(t0, 5.0)
     import torch
     for v in ([0, 0, 10], [-5, 0, 10]):
-        params["rect.vertex_positions"] = (init + torch.tensor(v, dtype=init.dtype, device=init.device)).reshape(-1); params.update()
+        params["rect.positions"] = (init + torch.tensor(v, dtype=init.dtype, device=init.device)).reshape(-1); params.update()
         t = scene.ray_intersect_preliminary(mi.Ray3f(o + np.float32(v)[:, None], dd, maxt)).t.cpu().numpy()
         assert np.allclose(t, t0)
         assert not np.isfinite(scene.ray_intersect_preliminary(mi.Ray3f(o, dd, maxt)).t.cpu().numpy()).any()      # nothing is left at the old place

@@ -284,7 +284,7 @@ def test_golden_shape_gradients(mi):
     scene = mi.load_dict(d)
     grads = scene.integrator().render_backward(scene, None, fx["shape_grad_in"], seed=3, spp=16)
     for name in ("floor", "ceiling"):
-        got = grads[name + ".vertex_positions"].cpu().numpy().reshape(-1, 3); want = fx["shape_grad_" + name]
+        got = grads[name + ".positions"].cpu().numpy().reshape(-1, 3); want = fx["shape_grad_" + name]
         assert np.abs(got - want).max() < 2e-3 * np.abs(want).max(), name
 
 
@@ -760,14 +760,14 @@ def test_prb_vertex_position_gradients(mi, O, which):
     if which == "slab_crop_box":          # ragged case: crop window, box filter, sample count that is not a power of two
         d["sensor"]["film"].update({"width": 40, "height": 30, "crop_offset_x": 9, "crop_offset_y": 4, "crop_width": res, "crop_height": res, "rfilter": {"type": "box"}})
         spp = 12
-    d["integrator"] = {"type": "prb", "max_depth": 5, "shape_gradients": [n + ".vertex_positions" for n in names]}
+    d["integrator"] = {"type": "prb", "max_depth": 5, "shape_gradients": [n + ".positions" for n in names]}
     if which == "cbox_nocache":
         d["integrator"]["replay_cache"] = False
     scene = mi.load_dict(d)
     if which == "smooth_spheres":             # writing the positions regenerates the vertex normals (mesh.cpp:876-878): the analytic normals of the scene give way
         params = mi.traverse(scene)
         for n in names[:3]:
-            params[n + ".vertex_positions"] = params[n + ".vertex_positions"].clone()
+            params[n + ".positions"] = params[n + ".positions"].clone()
         params.update()
     osc, sensor = oracle_scene_from(O, scene)
     ids = [mesh_index(scene, n) for n in names]
@@ -776,7 +776,7 @@ def test_prb_vertex_position_gradients(mi, O, which):
     grads = integ.render_backward(scene, None, grad_in, seed=3, spp=spp)
     want, w_refl, w_tex, _ = osc.render_prb_backward_shape(sensor, grad_in, ids, seed=3, spp=spp, max_depth=5)
     for n, m in zip(names, ids):
-        got = grads[n + ".vertex_positions"].cpu().numpy().reshape(-1, 3)
+        got = grads[n + ".positions"].cpu().numpy().reshape(-1, 3)
         scale = np.abs(want[m]).max()
         assert scale > 0 and np.abs(got - want[m]).max() < 2e-3 * scale, (which, n, np.abs(got - want[m]).max() / scale)
     keys = {k: v for k, v in scene._param_keys().items() if v[0] != "emit"}
@@ -789,7 +789,7 @@ def test_prb_vertex_position_gradients(mi, O, which):
     # switching the feature off again restores the plain adjoint
     integ.shape_gradients = False
     plain = integ.render_backward(scene, None, grad_in, seed=3, spp=spp)
-    assert not any(k.endswith("vertex_positions") for k in plain)
+    assert not any(k.endswith(".positions") for k in plain)
     for k in keys:
         assert np.allclose(plain[k].cpu().numpy(), grads[k].cpu().numpy(), rtol=1e-4, atol=1e-7)
 
@@ -810,7 +810,7 @@ def test_prb_vertex_position_gradients_generic_emitters(mi, O, which):
     if which == "point_and_area":
         d["light"] = slab_scene(mi, res)["light"]
     names = ["floor"] + (["ceiling"] if "ceiling" in d else [])
-    d["integrator"] = {"type": "prb", "max_depth": 5, "shape_gradients": [n + ".vertex_positions" for n in names]}
+    d["integrator"] = {"type": "prb", "max_depth": 5, "shape_gradients": [n + ".positions" for n in names]}
     scene = mi.load_dict(d)
     osc, sensor = oracle_scene_from(O, scene)
     ids = [mesh_index(scene, n) for n in names]
@@ -819,7 +819,7 @@ def test_prb_vertex_position_gradients_generic_emitters(mi, O, which):
     grads = integ.render_backward(scene, None, grad_in, seed=3, spp=16)
     want, w_refl, w_tex, _ = osc.render_prb_backward_shape(sensor, grad_in, ids, seed=3, spp=16, max_depth=5)
     for n, m in zip(names, ids):
-        got = grads[n + ".vertex_positions"].cpu().numpy().reshape(-1, 3)
+        got = grads[n + ".positions"].cpu().numpy().reshape(-1, 3)
         scale = np.abs(want[m]).max()
         assert scale > 0 and np.abs(got - want[m]).max() < 2e-3 * scale, (which, n, np.abs(got - want[m]).max() / scale)
     for k, (kind, b) in scene._param_keys().items():
@@ -891,12 +891,12 @@ def test_prb_gradients_at_zero_parameters(mi, O, which):
 
 
 def test_vertex_position_update_rebuilds_the_scene(mi, O):
-    """params['floor.vertex_positions'] = ...; params.update(): the next render sees the moved mesh (and matches the oracle's)"""
+    """params['floor.positions'] = ...; params.update(): the next render sees the moved mesh (and matches the oracle's)"""
     from tests.test_cpu_host import oracle_scene_from
     from tests.test_shape_gradients_cpu import slab_scene, mesh_index
     scene = mi.load_dict(slab_scene(mi, 24))
     params = mi.traverse(scene)
-    key = "floor.vertex_positions"
+    key = "floor.positions"
     assert key in params and params[key].numel() == 12
     before = mi.render(scene, spp=8, seed=1).cpu().numpy()
     p = params[key].clone().reshape(-1, 3); p[:, 1] += 0.4
@@ -915,38 +915,38 @@ def test_vertex_position_gradients_refused_outside_their_domain(mi):
     # accepted once its positions have been written (params.update() regenerates the normals, mesh.cpp:876-878)
     g = np.ones((32, 32, 3), np.float32)
     d = mi.instanced_spheres_scene(width=32, height=32, spp=4, grid=2, n_u=12, n_v=6, flatten=True)
-    d["integrator"] = {"type": "prb", "max_depth": 3, "shape_gradients": ["ball000.vertex_positions"]}
+    d["integrator"] = {"type": "prb", "max_depth": 3, "shape_gradients": ["ball000.positions"]}
     scene = mi.load_dict(d)
     with pytest.raises(RuntimeError, match="regenerates"):
         scene.integrator().render_backward(scene, None, g, seed=0, spp=4)
     scene.integrator().shape_gradients = True
     out = scene.integrator().render_backward(scene, None, g, seed=0, spp=4)
-    assert "ball000.vertex_positions" not in out and "floor.vertex_positions" in out          # the box's rectangles: flat faces, regenerated == stored
+    assert "ball000.positions" not in out and "floor.positions" in out          # the box's rectangles: flat faces, regenerated == stored
     params = mi.traverse(scene)
     for k in range(4):
-        params["ball%03d.vertex_positions" % k] = params["ball%03d.vertex_positions" % k].clone()
+        params["ball%03d.positions" % k] = params["ball%03d.positions" % k].clone()
     params.update()
     out = scene.integrator().render_backward(scene, None, g, seed=0, spp=16)
-    assert all("ball%03d.vertex_positions" % k in out for k in range(4)) and max(float(out["ball%03d.vertex_positions" % k].abs().max()) for k in range(4)) > 0
+    assert all("ball%03d.positions" % k in out for k in range(4)) and max(float(out["ball%03d.positions" % k].abs().max()) for k in range(4)) > 0
     with pytest.raises(KeyError):
-        scene.integrator().shape_gradients = ["nonexistent.vertex_positions"]
+        scene.integrator().shape_gradients = ["nonexistent.positions"]
         scene.integrator().render_backward(scene, None, g, seed=0, spp=4)
     from tests.test_shape_gradients_cpu import slab_scene
     g = np.ones((16, 16, 3), np.float32)
     # a mesh with only delta lobes may be PART of the scene; asking for ITS vertex positions is refused (eval() is zero: prb.py:288 would form relative_grad(0)),
     # `True` selects the meshes the adjoint can differentiate -- rough models included
     d = slab_scene(mi, 16); d["ceiling"]["bsdf"] = {"type": "conductor", "eta": [0.2, 0.92, 1.1], "k": [3.9, 2.45, 2.14]}
-    d["integrator"] = {"type": "prb", "max_depth": 3, "shape_gradients": ["ceiling.vertex_positions"]}
+    d["integrator"] = {"type": "prb", "max_depth": 3, "shape_gradients": ["ceiling.positions"]}
     scene = mi.load_dict(d)
     with pytest.raises(RuntimeError, match="delta lobes"):
         scene.integrator().render_backward(scene, None, g, seed=0, spp=4)
     scene.integrator().shape_gradients = True
     out = scene.integrator().render_backward(scene, None, g, seed=0, spp=4)
-    assert "floor.vertex_positions" in out and "ceiling.vertex_positions" not in out
+    assert "floor.positions" in out and "ceiling.positions" not in out
     d["ceiling"]["bsdf"] = {"type": "roughconductor", "alpha": 0.2}
     scene = mi.load_dict(d); scene.integrator().shape_gradients = True
     out = scene.integrator().render_backward(scene, None, g, seed=0, spp=4)
-    assert "floor.vertex_positions" in out and "ceiling.vertex_positions" in out
+    assert "floor.positions" in out and "ceiling.positions" in out
 
 
 def test_hide_emitters_parity(mi, O):
@@ -1041,14 +1041,14 @@ def test_sample_border_parity(mi, O, rf, crop, spp):
 
 def test_vertex_position_optimisation_converges(mi):
     """end to end: a floor displaced by 0.35 is pulled back to the height that produced the target image by gradient descent on
-    '<mesh>.vertex_positions' (render -> d loss / d image -> render_backward -> params.update(), which rebuilds the acceleration structure)"""
+    '<mesh>.positions' (render -> d loss / d image -> render_backward -> params.update(), which rebuilds the acceleration structure)"""
     import torch
     from tests.test_shape_gradients_cpu import slab_scene
     res, spp = 32, 32
-    d = slab_scene(mi, res); d["integrator"] = {"type": "prb", "max_depth": 4, "shape_gradients": ["floor.vertex_positions"], "emitter_gradients": False}
+    d = slab_scene(mi, res); d["integrator"] = {"type": "prb", "max_depth": 4, "shape_gradients": ["floor.positions"], "emitter_gradients": False}
     scene = mi.load_dict(d); integ = scene.integrator()
     target = mi.render(scene, integrator=integ, spp=256, seed=100)
-    params = mi.traverse(scene); key = "floor.vertex_positions"
+    params = mi.traverse(scene); key = "floor.positions"
     base = params[key].clone().reshape(-1, 3)
     height = torch.tensor(0.35, device=base.device)
     losses, heights = [], []

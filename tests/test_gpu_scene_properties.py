@@ -127,14 +127,14 @@ def test_vertex_position_gradients_through_a_transformed_texture(mi, O):
     res, spp, md = 32, 64, 4
     T = mi.ScalarTransform3f
     d, tex = textured_scene(mi, T().rotate(30.0).scale([1.5, 2.5]), res=res, tex_res=8)
-    d["integrator"] = {"type": "prb", "max_depth": md, "shape_gradients": ["floor.vertex_positions"]}
+    d["integrator"] = {"type": "prb", "max_depth": md, "shape_gradients": ["floor.positions"]}
     scene = mi.load_dict(d)
     osc, sensor = O.scene_from_product(scene)
     grad_in = np.random.default_rng(8).uniform(0.5, 1.5, (res, res, 3)).astype(np.float32)
     grads = scene.integrator().render_backward(scene, None, grad_in, seed=3, spp=spp)
-    mesh = scene._position_keys()["floor.vertex_positions"]
+    mesh = scene._position_keys()["floor.positions"]
     want, _, w_tex, _ = osc.render_prb_backward_shape(sensor, grad_in, [mesh], seed=3, spp=spp, max_depth=md)
-    got = grads["floor.vertex_positions"].cpu().numpy().reshape(-1, 3)
+    got = grads["floor.positions"].cpu().numpy().reshape(-1, 3)
     scale = np.abs(want[mesh]).max()
     assert scale > 0 and np.abs(got - want[mesh]).max() < 2e-3 * scale, np.abs(got - want[mesh]).max() / scale
     k = [k for k, v in scene._param_keys().items() if v[0] == "tex"][0]

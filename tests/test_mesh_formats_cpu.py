@@ -396,12 +396,12 @@ def test_reference_normal_weighting_and_regeneration_kats(mi, O):
     L.orc_mesh_compute_normals.argtypes = [C.c_uint32, C.c_void_p, C.c_uint32, C.c_void_p]
     L.orc_mesh_compute_normals(5, V.ctypes.data, 2, F4.ctypes.data)
     assert np.allclose(V[:, 3:6], want, atol=5e-4) and np.abs(V[:, 3:6] - m.V[:, 3:6]).max() < 1e-6
-    # test02: a unit quad; tilting it through its 'vertex_positions' regenerates the normals
+    # test02: a unit quad; tilting it through its 'positions' regenerates the normals
     quad = {"type": "mesh", "positions": np.float32([[0, 0, 0], [1, 0, 0], [1, 1, 0], [0, 1, 0]]), "faces": np.uint32([[0, 1, 2], [0, 2, 3]]),
             "normals": np.tile([0, 0, 1], (4, 1)).astype(np.float32)}
     d = mi.cornell_box(); d["quad"] = quad
     scene = mi.load_dict(d)
-    i = scene._position_keys()["quad.vertex_positions"]
+    i = scene._position_keys()["quad.positions"]
     assert np.allclose(scene.meshes[i]["V"][:, 3:6], [0, 0, 1])
     p = scene.meshes[i]["V"][:, :3].copy(); p[:, 2] = p[:, 0]
     scene._set_vertex_positions(i, p)

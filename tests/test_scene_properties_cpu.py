@@ -452,3 +452,33 @@ def test_traverse_names_of_twosided_children(mi):
     assert np.allclose(np.asarray(params["sheet.bsdf.brdf_1.specular_reflectance.value"].cpu()), [0.6, 0.6, 0.6])
     # the colour table and the table of the other BSDF parameters never name the same key
     assert not (set(scene._param_keys()) & set(scene._bsdf_param_keys()))
+
+
+def test_traverse_mesh_entries_and_unknown_keys(mi):
+    """Mesh::traverse (src/render/mesh.cpp:822-843) names the vertex positions '<shape>.positions' (an N x 3 tensor) and also registers 'faces' / 'texcoords': the
+    positions are the updatable / differentiable entry here, the other two are shown and refused on write like a read-only parameter (util.py:59-60); a key that
+    traverse() did not register is a KeyError on write (util.py:57), not a silently ignored entry"""
+    import torch
+    T = mi.ScalarTransform4f
+    P = np.array([[-1, -1, 0], [1, -1, 0], [1, 1, 0], [-1, 1, 0]], np.float32); F = np.array([[0, 1, 2], [0, 2, 3]], np.uint32)
+    uv = np.array([[0, 0], [1, 0], [1, 1], [0, 1]], np.float32)
+    d = {"type": "scene", "integrator": {"type": "prb", "max_depth": 3},
+         "sensor": {"type": "perspective", "fov": 45, "to_world": T().look_at(origin=[0, 0, 4], target=[0, 0, 0], up=[0, 1, 0]),
+                    "film": {"type": "hdrfilm", "width": 8, "height": 8, "rfilter": {"type": "box"}, "pixel_format": "rgb"}, "sampler": {"type": "independent", "sample_count": 4}},
+         "quad": {"type": "mesh", "positions": P, "faces": F, "texcoords": uv, "bsdf": {"type": "diffuse"}},
+         "bare": {"type": "mesh", "positions": P + np.float32(3.0), "faces": F, "bsdf": {"type": "diffuse"}},
+         "light": {"type": "point", "position": [0, 0, 3], "intensity": {"type": "rgb", "value": [1, 1, 1]}}}
+    scene = mi.load_dict(d)
+    params = mi.traverse(scene)
+    assert tuple(params["quad.positions"].shape) == (4, 3) and np.array_equal(params["quad.positions"].cpu().numpy(), P)
+    assert np.array_equal(params["quad.faces"].cpu().numpy(), F) and np.array_equal(params["quad.texcoords"].cpu().numpy(), uv)
+    assert "bare.faces" in params and "bare.texcoords" not in params and not any(k.endswith("vertex_positions") for k in params)
+    with pytest.raises(Exception, match="read-only"):
+        params["quad.faces"] = params["quad.faces"].clone()
+    with pytest.raises(KeyError):
+        params["quad.vertex_positions"] = torch.zeros(12)
+    with pytest.raises(KeyError):
+        params.update({"nonsense": torch.zeros(3)})
+    # positions: N x 3 or flat on write
+    params["quad.positions"] = torch.as_tensor((P * np.float32(0.5)).reshape(-1)); params.update()
+    assert np.array_equal(scene.meshes[scene._position_keys()["quad.positions"]]["V"][:, :3], P * np.float32(0.5))

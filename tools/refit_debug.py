@@ -7,7 +7,7 @@ d = mi.instanced_spheres_scene(width=48, height=48, spp=16, grid=4, n_u=40, n_v=
 d.pop("ceiling"); d["sky"] = {"type": "constant", "radiance": {"type": "rgb", "value": [0.4, 0.5, 0.6]}}
 scene = mi.load_dict(d); mi.render(scene, spp=4, seed=0)
 params = mi.traverse(scene)
-key = "spheres.ball.vertex_positions"
+key = "spheres.ball.positions"
 rng = np.random.default_rng(5)
 for amount in (0.002, 0.01, 0.04):
     new = params[key].cpu().numpy() + rng.normal(scale=amount, size=params[key].shape).astype(np.float32)

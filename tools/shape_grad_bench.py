@@ -9,7 +9,7 @@ from tests.test_shape_gradients_cpu import cbox_mesh_scene, smooth_slab_scene
 for name, d, keys in (("cbox_mesh", cbox_mesh_scene(mi, 256), ["small-box", "large-box", "floor"]), ("smooth_floor", smooth_slab_scene(mi, 256, n=65), ["floor"])):
     d["sensor"]["sampler"]["sample_count"] = 64
     for on in (False, True):
-        d["integrator"] = {"type": "prb", "max_depth": 6, "shape_gradients": [k + ".vertex_positions" for k in keys] if on else False}
+        d["integrator"] = {"type": "prb", "max_depth": 6, "shape_gradients": [k + ".positions" for k in keys] if on else False}
         scene = mi.load_dict(d); integ = scene.integrator()
         g = torch.full((256, 256, 3), 1.0 / (256 * 256 * 3), device="cuda")
         for _ in range(2): integ.render_backward(scene, None, g, seed=1, spp=64)

@@ -6,7 +6,7 @@ mi.set_variant("hip_ad_rgb")
 scene = mi.load_dict(mi.instanced_spheres_scene(width=64, height=64, spp=4))
 mi.render(scene, spp=4, seed=0)
 params = mi.traverse(scene)
-key = "spheres.ball.vertex_positions"
+key = "spheres.ball.positions"
 m = scene._position_keys()[key]
 t = params[key]
 L = mi.lib()
