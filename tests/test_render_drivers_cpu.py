@@ -2,6 +2,7 @@
 scalar-variant driver -- spiral block order, Morton pixel order, per-pixel reseeding, discretised reconstruction filter,
 block borders (integrator.cpp:190-274,398-446; spiral.cpp:27-73; imageblock.cpp:283-375)."""
 import ctypes as C
+import os
 
 import numpy as np
 import pytest
@@ -221,3 +222,27 @@ def test_hip_variant_never_falls_back_to_the_scalar_path():
     with pytest.raises(Exception) as e:
         mi.render(mi.load_dict(d), spp=1)
     assert "HIP device" in str(e.value) or "no CPU fallback" in str(e.value)
+
+
+@pytest.mark.parametrize("seed", list(range(int(os.environ.get("HAR_SCALAR_SEEDS", "24")))))
+def test_product_scalar_path_on_random_scenes(O, seed):
+    """the randomised scenes of tests/test_gpu_fuzz_parity.py (every shape / BSDF / emitter / sensor / filter of the variant in random combinations) through config 1's
+    driver: har_render_scalar -- the HOST compilation of the kernels' path code with scalar draw semantics -- against the oracle's scalar driver, same streams; no GPU"""
+    import mitsuba3_amd as mi
+    from mitsuba3_amd import core
+    from tests.test_gpu_fuzz_parity import random_scene
+    mi.set_variant("scalar_rgb")
+    try:
+        d, cfg = random_scene(mi, int(os.environ.get("HAR_FUZZ_SEED0", "0")) + 300 + seed)
+        d["integrator"] = {"type": "path", "max_depth": cfg["max_depth"], "rr_depth": cfg["rr_depth"]}
+        scene = mi.load_dict(d)
+        osc, sensor = O.scene_from_product(scene)
+        spp = min(cfg["spp"], 8)
+        nt = 1 + 7 * (seed % 2)                          # (the block size follows the thread count, integrator.cpp:200-216: both sides get the same)
+        ref, st, _ = osc.render_path_scalar(sensor, seed=seed, spp=spp, max_depth=cfg["max_depth"], rr_depth=cfg["rr_depth"], n_threads=nt)
+        img = core._render_scalar(scene, scene.integrator(), scene.sensors()[0], seed, spp, threads=nt)
+        assert np.isfinite(img).all()
+        err = float(np.linalg.norm(img.astype(np.float64) - ref.astype(np.float64))); scale = float(np.linalg.norm(ref.astype(np.float64)))
+        assert err <= 1e-5 * scale + 1e-9, (err / max(scale, 1e-30), cfg)
+    finally:
+        mi.set_variant("hip_ad_rgb")
