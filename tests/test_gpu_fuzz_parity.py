@@ -387,3 +387,48 @@ def test_random_parameter_updates(mi, O, seed):
     for k, (kind, b) in scene._param_keys().items():
         want = w_emit[b] if kind == "emit" else (w_tex[b.tex_index] if kind == "tex" else w_refl[b.index])
         _compare(k, grads[k].cpu().numpy(), want, 1e-3)
+
+
+@pytest.mark.parametrize("seed", _seeds("HAR_FUZZ_SEEDS4", 16))
+def test_random_scene_bands(mi, O, seed):
+    """the multi-GPU partition on random scenes (contiguous row bands of the reference's lane order, global lane indices, additive films and gradients): the frame cut
+    into two to four random row bands, each rendered on its own (lanes = [begin, end), as a rank does) -- the band films add up to the single render's raw film with equal
+    path / vertex / ray counters, the bands' weight films to the weight film, and the bands' `prb` gradients (every colour, texel and radiance key, each band against the
+    SUMMED weight film: render_distributed's two-phase adjoint) to the single call's; the sum is then held to the oracle once"""
+    import torch
+    d, cfg = random_scene(mi, seed + 1700)
+    rng = np.random.default_rng(9000 + seed)
+    spp, md, rr = cfg["spp"], cfg["max_depth"], cfg["rr_depth"]
+    d["integrator"] = {"type": "prb", "max_depth": md, "rr_depth": rr}
+    scene = mi.load_dict(d)
+    integ = scene.integrator(); sensor = scene.sensors()[0]
+    w, h = sensor.film().crop_size()
+    per_row = w * spp
+    cuts = sorted(set(int(x) for x in rng.integers(1, h, int(rng.integers(1, 4)))))
+    rows = [0] + cuts + [h]
+    bands = [(rows[i] * per_row, rows[i + 1] * per_row) for i in range(len(rows) - 1)]
+    full = integ.render_film(scene, seed=seed, spp=spp); st_full = integ.stats()
+    acc = torch.zeros_like(full); st_sum = dict.fromkeys(st_full, 0)
+    for b in bands:
+        acc += integ.render_film(scene, seed=seed, spp=spp, lanes=b)
+        for k, v in integ.stats().items():
+            st_sum[k] += v
+    assert st_sum == st_full, (bands, st_sum, st_full)
+    _compare("sum of the band films", acc.cpu().numpy(), full.cpu().numpy(), 2e-6)
+    wf = integ.render_weights(scene, seed=seed + 2, spp=spp)
+    wsum = sum(integ.render_weights(scene, seed=seed + 2, spp=spp, lanes=b) for b in bands)
+    _compare("sum of the band weight films", wsum.cpu().numpy(), wf.cpu().numpy(), 2e-6)
+    grad_in = np.random.default_rng(seed).uniform(0.5, 1.5, (h, w, 3)).astype(np.float32)
+    g_full = integ.render_backward(scene, None, grad_in, seed=seed + 2, spp=spp)
+    g_sum = None
+    for b in bands:
+        g = integ.render_backward(scene, None, grad_in, seed=seed + 2, spp=spp, lanes=b, weight_film=wsum)
+        g_sum = {k: v.clone() for k, v in g.items()} if g_sum is None else {k: g_sum[k] + g[k] for k in g_sum}
+    assert set(g_sum) == set(g_full)
+    for k in g_full:
+        _compare("band gradients " + k, g_sum[k].cpu().numpy(), g_full[k].cpu().numpy(), 1e-4)
+    osc, osensor = O.scene_from_product(scene)
+    w_refl, w_tex, w_emit, _ = osc.render_prb_backward_emitters(osensor, grad_in, seed=seed + 2, spp=spp, max_depth=md, rr_depth=rr)
+    for k, (kind, b) in scene._param_keys().items():
+        want = w_emit[b] if kind == "emit" else (w_tex[b.tex_index] if kind == "tex" else w_refl[b.index])
+        _compare(k, g_sum[k].cpu().numpy(), want, 1e-3)
