@@ -432,3 +432,56 @@ def test_random_scene_bands(mi, O, seed):
     for k, (kind, b) in scene._param_keys().items():
         want = w_emit[b] if kind == "emit" else (w_tex[b.tex_index] if kind == "tex" else w_refl[b.index])
         _compare(k, g_sum[k].cpu().numpy(), want, 1e-3)
+
+
+@pytest.mark.parametrize("seed", _seeds("HAR_FUZZ_SEEDS5", 12))
+def test_random_scene_boundary_calls(mi, O, seed):
+    """the array-valued entry points of the boundary on random scenes (the hand-made tests use three): Scene::ray_intersect_preliminary / ray_test (accelerated and brute force,
+    bit for bit against the oracle's brute force), PreliminaryIntersection::compute_surface_interaction, SamplingIntegrator::sample of `path` and `prb` with a random `active`
+    mask (masked lanes: zero radiance, invalid, sampler untouched)"""
+    from tests.test_gpu_parity import random_rays
+    d, cfg = random_scene(mi, seed + 2600)
+    md, rr = cfg["max_depth"], cfg["rr_depth"]
+    n = 20000
+    o, dd = random_rays(n, seed=seed); o = (1.5 * o).astype(np.float32); o[1] += 0.6
+    rng = np.random.default_rng(seed)
+    maxt = np.where(rng.random(n) < 0.3, rng.uniform(0.05, 3.0, n), 3.402823466e+38).astype(np.float32)
+    for kind in ("path", "prb"):
+        d["integrator"] = {"type": kind, "max_depth": md, "rr_depth": rr}
+        scene = mi.load_dict(d)
+        osc, _ = O.scene_from_product(scene)
+        ray = mi.Ray3f(o, dd, maxt)
+        if kind == "path":
+            ref = osc.ray_intersect(o, dd, maxt, naive=True); hit = np.isfinite(ref[0])
+            for naive in (False, True):
+                pi = scene._intersect(ray, naive)
+                assert np.array_equal(pi.t.cpu().numpy(), ref[0])
+                for got, want in ((pi.prim_uv[0], ref[1]), (pi.prim_uv[1], ref[2]), (pi.prim_index, ref[3]), (pi.shape_index, ref[4]), (pi.instance, ref[5])):
+                    g = got.cpu().numpy(); g = g.astype(np.uint32) if want.dtype == np.uint32 else g
+                    assert np.array_equal(g[hit], want[hit])
+                assert np.array_equal(scene.ray_test(ray, naive=naive).cpu().numpy(), osc.ray_test(o, dd, maxt))
+            pi = scene.ray_intersect_preliminary(ray); si = pi.compute_surface_interaction(ray)
+            t = pi.t.cpu().numpy(); u = pi.prim_uv[0].cpu().numpy(); v = pi.prim_uv[1].cpu().numpy()
+            prim = pi.prim_index.cpu().numpy().astype(np.uint32); shape = pi.shape_index.cpu().numpy().astype(np.uint32); inst = pi.instance.cpu().numpy().astype(np.uint32)
+            got = {k: getattr(si, k).cpu().numpy() for k in ("p", "n", "wi", "uv")}
+            got["sn"] = si.sh_frame.n.cpu().numpy(); got["ss"] = si.sh_frame.s.cpu().numpy(); got["st"] = si.sh_frame.t.cpu().numpy()
+            out = np.empty(24, np.float32)
+            for i in np.flatnonzero(hit)[:600]:
+                O.lib().orc_surface_interaction(osc.handle, O.fp(np.ascontiguousarray(o[:, i])), O.fp(np.ascontiguousarray(dd[:, i])), float(t[i]), float(u[i]), float(v[i]),
+                                                int(prim[i]), int(shape[i]), int(inst[i]), O.fp(out))
+                for key, sl in (("p", slice(0, 3)), ("n", slice(3, 6)), ("sn", slice(6, 9)), ("ss", slice(9, 12)), ("st", slice(12, 15)), ("wi", slice(15, 18)), ("uv", slice(18, 20))):
+                    assert np.allclose(got[key][:, i], out[sl], rtol=4e-6, atol=4e-7), (key, int(i), got[key][:, i], out[sl])
+        # SamplingIntegrator::sample with a mask
+        active = rng.random(n) < 0.8
+        sampler = mi.Sampler({"sample_count": 4, "seed": 5}); sampler.seed(3, n)
+        before = sampler.state.cpu().numpy().view(np.uint64).copy()
+        full = np.full(n, 3.402823466e+38, np.float32)
+        spec, valid = scene.integrator().sample(scene, sampler, mi.Ray3f(o, dd, full), active=active)
+        ref, rvalid, rstate = osc.integrator_sample(o, dd, full, seed=5 + 3, max_depth=md, rr_depth=rr, prb=(kind == "prb"))
+        spec = spec.cpu().numpy(); valid = valid.cpu().numpy().astype(np.uint8)
+        assert np.array_equal(valid[active], rvalid[active]) and not valid[~active].any() and not spec[:, ~active].any()
+        _compare(kind + " sample()", spec[:, active], ref[:, active], 1e-4)
+        after = sampler.state.cpu().numpy().view(np.uint64).reshape(-1)
+        assert np.array_equal(after[~active], before.reshape(-1)[~active])                     # a masked lane's stream is where it was
+        if kind == "path":
+            assert np.array_equal(after[active], np.asarray(rstate).reshape(-1)[active])       # the others advanced exactly as the oracle's
