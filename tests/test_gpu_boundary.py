@@ -632,12 +632,15 @@ def _adversarial_rays(rng, V, F, n_each=20000):
     return np.ascontiguousarray(O, np.float32), np.ascontiguousarray(D, np.float32), maxt.astype(np.float32)
 
 
+@pytest.mark.parametrize("scale,offset", [(1.0, 0.0), (1e-4, 0.0), (1.0, 16384.0), (1e3, 1e6)])
 @pytest.mark.parametrize("instanced", [False, True])
-def test_ray_queries_bitexact_on_adversarial_rays(mi, O, instanced):
+def test_ray_queries_bitexact_on_adversarial_rays(mi, O, instanced, scale, offset):
     """accelerated == brute force == oracle, bit for bit, for rays that sit on the degenerate cases of the box test (axis-parallel rays inside box planes, signed zeros,
     inf - inf) and of the triangle test (origins on the geometry, rays through shared vertices and edges): the BVH may only PRUNE -- a box test that drops one of these
-    candidates would show up as a missing or different hit"""
+    candidates would show up as a missing or different hit.  (scale, offset): the same scene shrunk to 1e-4, moved to coordinates of 16 384 (an ulp of 2e-3 against boxes of
+    1e-2) and blown up to 1e3 at coordinates of 1e6 -- the slack of the box test and the padding of the leaf boxes are relative, the answers must not depend on the frame"""
     rng = np.random.default_rng(77 + int(instanced))
+    xf = lambda P: (np.float32(scale) * np.asarray(P, np.float32) + np.float32(offset)).astype(np.float32)
     T = mi.ScalarTransform4f
     d = {"type": "scene", "integrator": {"type": "path", "max_depth": 3},
          "sensor": {"type": "perspective", "fov": 45, "to_world": T().look_at(origin=[0, 0, 4], target=[0, 0, 0], up=[0, 1, 0]),
@@ -645,16 +648,20 @@ def test_ray_queries_bitexact_on_adversarial_rays(mi, O, instanced):
          "white": {"type": "diffuse", "reflectance": {"type": "rgb", "value": [0.5, 0.5, 0.5]}}}
     V, F = _lattice_mesh()
     Vs, Fs = _soup(rng, 400)
-    d["lattice"] = {"type": "mesh", "positions": V, "faces": F, "bsdf": {"type": "ref", "id": "white"}}
-    d["soup"] = {"type": "mesh", "positions": (0.6 * Vs).astype(np.float32), "faces": Fs, "bsdf": {"type": "ref", "id": "white"}}
+    d["lattice"] = {"type": "mesh", "positions": xf(V), "faces": F, "bsdf": {"type": "ref", "id": "white"}}
+    d["soup"] = {"type": "mesh", "positions": xf((0.6 * Vs).astype(np.float32)), "faces": Fs, "bsdf": {"type": "ref", "id": "white"}}
     allV, allF = V, F
     if instanced:
         d["group"] = {"type": "shapegroup", "m": {"type": "mesh", "positions": (0.25 * V).astype(np.float32), "faces": F, "bsdf": {"type": "ref", "id": "white"}}}
+        place = T().translate([offset] * 3).scale(scale)
         for k, t in enumerate([T().translate([0.25, 0.0, 0.125]), T().translate([-0.25, 0.125, 0.0]).rotate([0, 0, 1], 90.0), T().scale([1.0, -1.0, 2.0]), T().translate([0.25, 0.0, 0.125])]):
-            d["inst%d" % k] = {"type": "instance", "to_world": t, "group": {"type": "ref", "id": "group"}}      # (the last one coincides with the first: ties between instances)
+            d["inst%d" % k] = {"type": "instance", "to_world": place @ t, "group": {"type": "ref", "id": "group"}}      # (the last one coincides with the first: ties between instances)
     scene = mi.load_dict(d)
     osc, _ = O.scene_from_product(scene)
     o, dd, maxt = _adversarial_rays(rng, allV, allF)
+    o = np.ascontiguousarray(xf(o.T).T)
+    with np.errstate(over="ignore"):
+        maxt = np.where(np.isfinite(maxt) & (maxt < 1e30), maxt * np.float32(scale), maxt).astype(np.float32)
     ref = osc.ray_intersect(o, dd, maxt, naive=True)
     hit = np.isfinite(ref[0])
     assert 0.2 < hit.mean() < 0.95
