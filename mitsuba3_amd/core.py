@@ -772,11 +772,14 @@ def _lookup_ior(props, name, default):
     return float(v)
 
 
-def _rgb_value(v, default, bounded=True):
-    """Properties colour value: float, list or {'type': 'rgb', 'value': ...} -> float32[3]"""
+def _rgb_value(v, default, bounded=True, uniform=None):
+    """Properties colour value: float, list or {'type': 'rgb', 'value': ...} -> float32[3].  `uniform` = the quantity's name where the reference itself refuses a
+    spatially varying texture (point.cpp:80-81, spot.cpp:96-97, directional.cpp:84-85, constant.cpp:60-61): same words"""
     if v is None:
         v = default
     if isinstance(v, dict):
+        if v.get('type') != 'rgb' and uniform:
+            raise RuntimeError("Expected a non-spatially varying %s spectra!" % uniform)
         if v.get('type') != 'rgb':
             raise RuntimeError("only `rgb` values are implemented for this parameter")
         v = v['value']
@@ -1007,6 +1010,8 @@ def _sampling_weight(props):
 def _emissive_rgb(plugin, name, v):
     """Properties::get_emissive_texture in RGB variants: a float, an `rgb` colour (unbounded) -- spatially varying textures are refused where the path needs the
     texture-importance-sampling branch (area.cpp:133-165) or is not written for them"""
+    if isinstance(v, dict) and v.get('type') not in (None, 'rgb') and plugin == 'constant':
+        raise RuntimeError("Expected a non-spatially varying radiance spectra!")           # the reference's own refusal: constant.cpp:60-61
     if isinstance(v, dict) and v.get('type') not in (None, 'rgb'):
         raise RuntimeError("%s: a spatially varying \"%s\" (texture plugin \"%s\") is not implemented by hip_ad_rgb -- the reference then importance-samples the "
                            "texture and maps the sample through Shape::eval_parameterization (src/emitters/area.cpp:133-165); use an `rgb` value" % (plugin, name, v.get('type')))
@@ -1070,7 +1075,7 @@ class PointLight:
             self.position = _f32(list(props['position'])).reshape(3)
         else:
             self.position = _f32(props.get('to_world', ScalarTransform4f()).col_major_3x4()[9:12])      # m_to_world.translation(), point.cpp:72
-        self.intensity = _rgb_value(props.get('intensity', {'type': 'rgb', 'value': 1.0}), 1.0, bounded=False)   # get_emissive_texture("intensity", 1.f), :77
+        self.intensity = _rgb_value(props.get('intensity', {'type': 'rgb', 'value': 1.0}), 1.0, bounded=False, uniform='intensity')   # get_emissive_texture("intensity", 1.f), :77
 
 
 class SpotLight:
@@ -1083,7 +1088,7 @@ class SpotLight:
         if 'texture' in props:
             raise RuntimeError("spot: property \"texture\" is not implemented by hip_ad_rgb")
         self.to_world = props.get('to_world', ScalarTransform4f())
-        self.intensity = _rgb_value(props.get('intensity', {'type': 'rgb', 'value': 1.0}), 1.0, bounded=False)      # get_emissive_texture("intensity", 1.f), :93
+        self.intensity = _rgb_value(props.get('intensity', {'type': 'rgb', 'value': 1.0}), 1.0, bounded=False, uniform='intensity')      # get_emissive_texture("intensity", 1.f), :93
         self.cutoff_angle = float(np.float32(props.get('cutoff_angle', 20.0)))                                        # :105-107
         self.beam_width = float(np.float32(props.get('beam_width', np.float32(self.cutoff_angle) * np.float32(3.0) / np.float32(4.0))))
         if not (self.cutoff_angle >= self.beam_width and self.cutoff_angle > 0):
@@ -1108,7 +1113,7 @@ class DirectionalEmitter:
             self.to_world = ScalarTransform4f().look_at(origin=[0.0, 0.0, 0.0], target=[float(x) for x in d], up=[float(x) for x in up])
         else:
             self.to_world = props.get('to_world', ScalarTransform4f())
-        self.irradiance = _rgb_value(props.get('irradiance', {'type': 'rgb', 'value': 1.0}), 1.0, bounded=False)      # get_emissive_texture("irradiance", 1.f), :80
+        self.irradiance = _rgb_value(props.get('irradiance', {'type': 'rgb', 'value': 1.0}), 1.0, bounded=False, uniform='irradiance')      # get_emissive_texture("irradiance", 1.f), :80
 
 
 class EnvmapEmitter:

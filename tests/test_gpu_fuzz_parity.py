@@ -173,9 +173,39 @@ def _compare(name, got, ref, tol):
     assert err <= tol * scale + 5e-7 * max(1.0, np.abs(ref).max()), (name, err / max(scale, 1e-30), got.reshape(-1)[:6], ref.reshape(-1)[:6])
 
 
-@pytest.mark.parametrize("seed", _seeds("HAR_FUZZ_SEEDS", 32))
-def test_random_scene_parity(mi, O, seed):
-    d, cfg = random_scene(mi, seed)
+def extend_scene(mi, d, seed):
+    """what random_scene() does not draw, applied on top of its scenes with a stream of its own (the scenes of the other tests keep their seeds): all six reconstruction
+    filters, `sample_border`, a smooth-shaded mesh (vertex normals) under a rotation, `to_uv` on the BSDFs' bitmaps, a rotated environment map, a shape group with a second
+    child placed by its own transform"""
+    rng = np.random.default_rng(31337 + seed)
+    T = mi.ScalarTransform4f
+    film = d["sensor"]["film"]
+    film["rfilter"] = {"type": ["gaussian", "box", "tent", "mitchell", "catmullrom", "lanczos"][int(rng.integers(0, 6))]}
+    if rng.random() < 0.25:
+        film["sample_border"] = True
+    if rng.random() < 0.7:
+        P, N, UV, F = mi.scenes.bumpy_sphere(12, 8, 1.0)
+        xf = T().translate([float(rng.uniform(-0.9, 0.9)), float(rng.uniform(0.3, 0.8)), float(rng.uniform(-0.6, 0.8))]).rotate([0.2, 1, 0.4], float(rng.uniform(0, 180))).scale(float(rng.uniform(0.15, 0.3)))
+        M = np.asarray(xf.matrix, np.float64); R = M[:3, :3] / np.cbrt(np.linalg.det(M[:3, :3]))
+        d["smooth"] = {"type": "mesh", "positions": (P.astype(np.float64) @ M[:3, :3].T + M[:3, 3]).astype(np.float32), "normals": (lambda n: (n / np.linalg.norm(n, axis=1, keepdims=True)).astype(np.float32))(N.astype(np.float64) @ R.T),
+                       "faces": F, "texcoords": UV, "bsdf": _bsdf(rng, smooth_only=True)}
+
+    def walk(x, under_emitter=False):
+        for k, v in list(x.items()):
+            if not isinstance(v, dict):
+                continue
+            if v.get("type") == "bitmap" and not under_emitter and rng.random() < 0.4:
+                v["to_uv"] = mi.ScalarTransform3f().translate([float(rng.uniform(-0.5, 0.5)), float(rng.uniform(-0.5, 0.5))]).rotate(float(rng.uniform(0, 90))).scale([float(rng.uniform(0.5, 2.5)), float(rng.uniform(0.5, 2.5))])
+            if v.get("type") == "envmap" and rng.random() < 0.7:
+                v["to_world"] = T().rotate([0, 1, 0], float(rng.uniform(0, 360))).rotate([1, 0, 0], float(rng.uniform(-40, 40)))
+            walk(v, under_emitter or k == "emitter")
+    walk(d)
+    if "grp" in d and rng.random() < 0.6:
+        d["grp"]["r"] = {"type": "rectangle", "to_world": T().translate([0.0, 1.6, 0.0]).rotate([1, 0, 0], float(rng.uniform(20, 160))).scale([1.4, 0.8, 1.0]), "bsdf": _bsdf(rng, smooth_only=True)}
+    return d
+
+
+def _check_scene(mi, O, d, cfg, seed):
     spp, md, rr = cfg["spp"], cfg["max_depth"], cfg["rr_depth"]
     # ---- forward
     d["integrator"] = {"type": "path", "max_depth": md, "rr_depth": rr, "hide_emitters": cfg["hide"]}
@@ -217,6 +247,19 @@ def test_random_scene_parity(mi, O, seed):
         got = grads[k].cpu().numpy().reshape(-1, 3)
         assert np.isfinite(got).all(), k
         assert np.abs(got - want[m]).max() <= 2e-3 * max(np.abs(want[m]).max(), 1e-3 * total) + 1e-7, (k, np.abs(got - want[m]).max(), np.abs(want[m]).max())
+
+
+@pytest.mark.parametrize("seed", _seeds("HAR_FUZZ_SEEDS", 32))
+def test_random_scene_parity(mi, O, seed):
+    d, cfg = random_scene(mi, seed)
+    _check_scene(mi, O, d, cfg, seed)
+
+
+@pytest.mark.parametrize("seed", _seeds("HAR_FUZZ_SEEDS6", 24))
+def test_random_scene_extended(mi, O, seed):
+    """the same checks (forward, prb, every gradient, vertex positions) on scenes with the features extend_scene() adds"""
+    d, cfg = random_scene(mi, seed + 4000)
+    _check_scene(mi, O, extend_scene(mi, d, seed), cfg, seed)
 
 
 @pytest.mark.parametrize("seed", _seeds("HAR_FUZZ_SEEDS2", 24))
@@ -270,7 +313,7 @@ def test_random_scene_options(mi, O, seed):
             want = {"alpha": rec[0:2].sum(), "alpha_u": rec[0].sum(), "alpha_v": rec[1].sum(), "eta": rec[2], "k": rec[3], "slot1": rec[4]}[what]
             got = grads[k].cpu().numpy().astype(np.float64)
             scale = max(np.abs(np.atleast_1d(want)).max(), 1e-3 * float(np.abs(gx).max()), 1e-12)        # (a record only a handful of paths reach: L * (df / d theta) / f is noise at the 1e-6 level)
-            assert np.isfinite(got).all() and np.abs(got.reshape(-1) - np.atleast_1d(want).reshape(-1)).max() <= 2e-3 * scale + 1e-7, (k, got, want)      # (+ the residue floor of _compare: seeds 2091, 2094)
+            assert np.isfinite(got).all() and np.abs(got.reshape(-1) - np.atleast_1d(want).reshape(-1)).max() <= 2e-3 * scale + 5e-7, (k, got, want)      # (+ the residue floor of _compare: seeds 2091, 2094, 5258)
     # ---- forward mode: random tangents on every key of the gradient tables
     keys = scene._param_keys()
     if keys:
