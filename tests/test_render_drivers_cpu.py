@@ -224,8 +224,9 @@ def test_hip_variant_never_falls_back_to_the_scalar_path():
     assert "HIP device" in str(e.value) or "no CPU fallback" in str(e.value)
 
 
-@pytest.mark.parametrize("seed", list(range(int(os.environ.get("HAR_SCALAR_SEEDS", "24")))))
-def test_product_scalar_path_on_random_scenes(O, seed):
+@pytest.mark.parametrize("extended", [False, True])
+@pytest.mark.parametrize("seed", list(range(int(os.environ.get("HAR_SCALAR_SEEDS", "12")))))
+def test_product_scalar_path_on_random_scenes(O, seed, extended):
     """the randomised scenes of tests/test_gpu_fuzz_parity.py (every shape / BSDF / emitter / sensor / filter of the variant in random combinations) through config 1's
     driver: har_render_scalar -- the HOST compilation of the kernels' path code with scalar draw semantics -- against the oracle's scalar driver, same streams; no GPU"""
     import mitsuba3_amd as mi
@@ -234,6 +235,9 @@ def test_product_scalar_path_on_random_scenes(O, seed):
     mi.set_variant("scalar_rgb")
     try:
         d, cfg = random_scene(mi, int(os.environ.get("HAR_FUZZ_SEED0", "0")) + 300 + seed)
+        if extended:
+            from tests.test_gpu_fuzz_parity import extend_scene
+            d = extend_scene(mi, d, seed)
         d["integrator"] = {"type": "path", "max_depth": cfg["max_depth"], "rr_depth": cfg["rr_depth"]}
         scene = mi.load_dict(d)
         osc, sensor = O.scene_from_product(scene)
