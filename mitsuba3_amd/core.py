@@ -2251,6 +2251,15 @@ class SceneParameters(dict):
             if mesh["flags"] & 2:
                 self[base + ".texcoords"] = torch.tensor(np.ascontiguousarray(mesh["V"][:, 6:8]), dtype=torch.float32, device=dev)
                 self._read_only.add(base + ".texcoords")
+        # ... and of the sensors: what ProjectiveCamera / Sensor / Film register next to `to_world` (sensor.h:135-141,206-210, film.cpp:55-57), all NonDifferentiable there;
+        # shown, not updatable here (a new film size is a new scene description)
+        for k, sn in zip(scene.sensor_keys, scene.m_sensors):
+            f = sn.film()
+            for name, val in (("near_clip", [sn.near_clip]), ("far_clip", [sn.far_clip]), ("shutter_open", [0.0]), ("shutter_open_time", [0.0]),
+                              ("film.size", [f.width, f.height]), ("film.crop_size", list(f.crop_size_)), ("film.crop_offset", list(f.crop_offset_))):
+                key = k + "." + name
+                self[key] = torch.tensor(val, dtype=torch.float32 if "clip" in name or "shutter" in name else torch.int64, device=dev)
+                self._read_only.add(key)
         self._written = set()           # keys assigned since the last update() (SceneParameters.__setitem__ flags them in the reference, util.py)
         # the tensors above ARE the scene's values: recorded as applied, so that the first update() touches only what was written or stepped since (vertex positions on
         # the GPU are never compared -- a mesh is updated when its tensor's version counter moved, see _changed_keys)

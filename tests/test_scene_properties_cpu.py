@@ -482,3 +482,14 @@ def test_traverse_mesh_entries_and_unknown_keys(mi):
     # positions: N x 3 or flat on write
     params["quad.positions"] = torch.as_tensor((P * np.float32(0.5)).reshape(-1)); params.update()
     assert np.array_equal(scene.meshes[scene._position_keys()["quad.positions"]]["V"][:, :3], P * np.float32(0.5))
+
+
+def test_traverse_shows_the_sensors_plain_parameters(mi):
+    """what ProjectiveCamera / Sensor / Film register next to `to_world` (sensor.h:135-141,206-210, film.cpp:55-57) is readable under the reference's names and read-only"""
+    d = mi.cornell_box(); f = d["sensor"]["film"]; f["width"] = 48; f["height"] = 32; f["crop_offset_x"] = 4; f["crop_offset_y"] = 2; f["crop_width"] = 20; f["crop_height"] = 10
+    params = mi.traverse(mi.load_dict(d))
+    assert params["sensor.film.size"].tolist() == [48, 32] and params["sensor.film.crop_size"].tolist() == [20, 10] and params["sensor.film.crop_offset"].tolist() == [4, 2]
+    assert abs(float(params["sensor.near_clip"]) - 0.001) < 1e-9 and float(params["sensor.far_clip"]) == 100.0
+    with pytest.raises(Exception, match="read-only"):
+        params["sensor.film.size"] = params["sensor.film.size"]
+    params["sensor.to_world"] = params["sensor.to_world"].clone(); params.update()          # the placement stays updatable
