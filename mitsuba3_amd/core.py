@@ -416,7 +416,7 @@ def _rectangle(props):
     V = np.empty((4, 8), np.float32); F = np.empty((2, 4), np.uint32); n = np.empty(3, np.float32); ia = C.c_float()
     check(lib().har_shape_rectangle(_fp(tw.data), 1 if props.get('flip_normals', False) else 0, _fp(V), _up(F), _fp(n), C.byref(ia)))
     m.V, m.F, m.flags = V, F, 3
-    m.rect = dict(to_world=tw, normal=n, inv_area=ia.value)
+    m.rect = dict(to_world=tw, normal=n, inv_area=ia.value, flip=bool(props.get('flip_normals', False)))
     return m
 
 
@@ -1640,7 +1640,7 @@ class Scene:
             else:                         # any other triangle mesh: Mesh::sample_position (area-weighted face selection)
                 self.emitters[em] = dict(type=3, mesh=len(self.meshes), radiance=m.emitter, to_world=[0.0] * 12, normal=[0.0] * 3, inv_area=0.0,
                                          sampling_weight=getattr(m, 'emitter_weight', 1.0))
-        self.meshes.append(dict(key=key, V=np.ascontiguousarray(m.V), F=np.ascontiguousarray(m.F), bsdf=bi, emitter=em, flags=m.flags))
+        self.meshes.append(dict(key=key, V=np.ascontiguousarray(m.V), F=np.ascontiguousarray(m.F), bsdf=bi, emitter=em, flags=m.flags, rect=getattr(m, 'rect', None)))
 
     def sync_host(self):
         """refresh the host mirrors (Scene.textures, BSDF.value / .texture, emitters[i]['radiance']) from the values params.update() pushed device-to-device"""
@@ -1933,6 +1933,35 @@ class Scene:
                     continue
             out[k] = i
         return out
+
+    @_static_table
+    def _rect_keys(self):
+        """'<rectangle>.to_world' (4 x 4, Rectangle::traverse, src/shapes/rectangle.cpp:197-200 -- the one entry that plugin registers besides its BSDF / emitter) of the
+        top-level rectangles"""
+        return {m["key"] + ".to_world": i for i, m in enumerate(self.meshes[:self.top_mesh_count]) if m.get("rect") is not None}
+
+    def _rect_matrix(self, i):
+        return np.asarray(self.meshes[i]["rect"]["to_world"].matrix, np.float32).reshape(4, 4).copy()
+
+    def _set_rect_to_world(self, i, m4):
+        """params['<rectangle>.to_world'] = ...; params.update(): Rectangle::parameters_changed (rectangle.cpp:202-214) re-initialises the shape from the new transform --
+        here the four vertex records (positions, normal, uv), the winding, and for a rectangle that carries an area light its sampling record (frame, normal, 1 / area)
+        are re-baked by the code that built them (har_shape_rectangle); the next render builds a new scene handle from them"""
+        m4 = np.asarray(m4, np.float64).reshape(4, 4)
+        if abs(np.linalg.det(m4[:3, :3])) == 0.0 or not np.isfinite(m4).all():
+            raise RuntimeError("rectangle: 'to_world' is singular or not finite")
+        tw = ScalarTransform4f(np.concatenate([m4.ravel(), np.linalg.inv(m4).T.ravel()]).astype(np.float32))
+        mesh = self.meshes[i]; rect = mesh["rect"]
+        V = np.empty((4, 8), np.float32); F = np.empty((2, 4), np.uint32); n = np.empty(3, np.float32); ia = C.c_float()
+        check(lib().har_shape_rectangle(_fp(tw.data), 1 if rect.get("flip") else 0, _fp(V), _up(F), _fp(n), C.byref(ia)))
+        self._drop_handle()
+        mesh["V"], mesh["F"] = V, F
+        rect.update(to_world=tw, normal=n, inv_area=ia.value)
+        em = mesh["emitter"]
+        if em >= 0:
+            e = self.emitters[em]
+            e["to_world"] = tw.col_major_3x4(); e["normal"] = n; e["inv_area"] = ia.value
+        self._drop_handle()
 
     @_static_table
     def _instance_keys(self):
@@ -2239,6 +2268,8 @@ class SceneParameters(dict):
             self[k] = torch.tensor(np.ascontiguousarray(scene.meshes[m]["V"][:, :3]), dtype=torch.float32, device=dev)            # N x 3, as the reference's `positions` tensor
         for k, i in scene._instance_keys().items():
             self[k] = torch.tensor(scene._instance_matrix(i), dtype=torch.float32, device=dev)
+        for k, i in scene._rect_keys().items():
+            self[k] = torch.tensor(scene._rect_matrix(i), dtype=torch.float32, device=dev)
         for k, (kind, b) in scene._pose_keys().items():
             self[k] = torch.tensor(scene._pose_value(kind, b), dtype=torch.float32, device=dev)
         # what Mesh::traverse (src/render/mesh.cpp:822-843) also registers and this variant can only SHOW: the index buffer and the texture coordinates (N x 2) of the
@@ -2288,6 +2319,8 @@ class SceneParameters(dict):
                 t.append((k, "pos", m))
             for k, i in sc._instance_keys().items():
                 t.append((k, "inst", i))
+            for k, i in sc._rect_keys().items():
+                t.append((k, "rect", i))
             for k, (kind, b) in sc._pose_keys().items():
                 t.append((k, "pose", (kind, b)))
             for k, (what, b) in sc._bsdf_param_keys().items():
@@ -2390,6 +2423,9 @@ class SceneParameters(dict):
                 if not np.array_equal(v.reshape(4, 4), sc._instance_matrix(ref)):
                     moved.append((ref, v.reshape(4, 4))); moved_keys.append(k)
                     continue                # marked once the whole run of instances went through
+            elif what == "rect":
+                if not np.array_equal(v.reshape(4, 4), sc._rect_matrix(ref)):
+                    sc._set_rect_to_world(ref, v.reshape(4, 4))
             elif what == "pose":
                 if not np.array_equal(v.reshape(-1), sc._pose_value(*ref).reshape(-1)):
                     sc._set_pose(ref[0], ref[1], v)
@@ -2754,6 +2790,9 @@ def render(scene, params=None, sensor=0, integrator=None, seed=0, seed_grad=0, s
         return _render_scalar(scene, integrator, sensor, seed, spp)
     keys = [k for k, v in (params or {}).items() if getattr(v, 'requires_grad', False)]
     fixed = [k for k in keys if k in scene._pose_keys() and scene._pose_keys()[k][0] != "emitter_tex"]      # (a light's radiance bitmap IS differentiable: area.cpp:64-70)
+    if any(k in scene._rect_keys() for k in keys):
+        raise RuntimeError("%s: a rectangle's 'to_world' is updatable in hip_ad_rgb but carries no gradient (Differentiable in the reference, rectangle.cpp:199); differentiate its "
+                           "'<shape>.positions' instead -- d loss / d to_world = sum over the four vertices of  d loss / d position (x) (local corner, 1)" % [k for k in keys if k in scene._rect_keys()])
     if fixed:       # ParamFlags::NonDifferentiable in the reference's traverse(): dr.enable_grad on them has no effect there; here it is said
         raise RuntimeError("%s are not differentiable parameters in hip_ad_rgb (placement of sensors and delta emitters: ParamFlags::NonDifferentiable in the reference; "
                            "a spot light's cutoff_angle / beam_width: Differentiable there, updatable but without a gradient here)" % fixed)

@@ -349,7 +349,7 @@ def test_random_scene_options(mi, O, seed):
 def _perturb(mi, scene, params, rng, torch):
     """new values for a random subset of the keys of mi.traverse(scene), of every kind an update path exists for; returns the list of keys written"""
     written = []
-    pose = scene._pose_keys(); bsdfp = scene._bsdf_param_keys(); pos = scene._position_keys(); inst = scene._instance_keys(); colour = scene._param_keys()
+    pose = scene._pose_keys(); bsdfp = scene._bsdf_param_keys(); pos = scene._position_keys(); inst = scene._instance_keys(); colour = scene._param_keys(); rect = scene._rect_keys()
     for k in list(params.keys()):
         if rng.random() > 0.5:
             continue
@@ -370,6 +370,13 @@ def _perturb(mi, scene, params, rng, torch):
         elif k in inst:
             m = v.clone(); m[:3, 3] += torch.as_tensor(rng.uniform(-0.05, 0.05, 3), dtype=v.dtype, device=v.device)
             params[k] = m if rng.random() < 0.5 else m.cpu()
+        elif k in rect:                                           # Rectangle's own parameter: the shape (and its area light's sampling record) is re-baked from it
+            if k[:-len(".to_world")] + ".positions" in written:
+                continue                                          # (one way of moving a shape per round)
+            m = v.clone(); m[:3, 3] += torch.as_tensor(rng.uniform(-0.04, 0.04, 3), dtype=v.dtype, device=v.device)
+            if rng.random() < 0.3:
+                m[:3, 0] *= float(rng.uniform(0.8, 1.2))          # stretched along its first axis
+            params[k] = m
         elif k in bsdfp:
             what = bsdfp[k][0]
             if what in ("alpha", "alpha_u", "alpha_v"):

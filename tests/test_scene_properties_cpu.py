@@ -493,3 +493,36 @@ def test_traverse_shows_the_sensors_plain_parameters(mi):
     with pytest.raises(Exception, match="read-only"):
         params["sensor.film.size"] = params["sensor.film.size"]
     params["sensor.to_world"] = params["sensor.to_world"].clone(); params.update()          # the placement stays updatable
+
+
+def test_rectangle_to_world_is_an_updatable_parameter(mi, O):
+    """Rectangle::traverse registers 'to_world' (src/shapes/rectangle.cpp:197-200; the reference's tests write params['shape.to_world'], test_rectangle.py:243-406): writing it +
+    params.update() re-bakes the vertex records, the winding (a mirroring transform) and, for a rectangle that carries an area light, its sampling record -- the scene then equals
+    a freshly loaded one with that transform, bit for bit (oracle render of the host mirrors)"""
+    import torch
+    T = mi.ScalarTransform4f
+    d = mi.cornell_box(); f = d["sensor"]["film"]; f["width"] = 24; f["height"] = 24
+    moves = {"floor": T().translate([0.0, -0.8, 0.1]).rotate([1, 0, 0], -80.0).scale([1.2, 0.9, 1.0]),
+             "light": T().translate([0.1, 0.95, 0.05]).rotate([1, 0, 0], 90.0).scale([0.3, -0.2, 1.0]),          # (a mirrored light: the winding flips)
+             "back": T().translate([0.0, 0.0, -1.0]).scale([1.0, 1.1, 1.0])}
+    scene = mi.load_dict(d)
+    params = mi.traverse(scene)
+    for k in moves:
+        assert tuple(params[k + ".to_world"].shape) == (4, 4)
+    fresh = dict(d)
+    for k, t in moves.items():
+        params[k + ".to_world"] = torch.as_tensor(np.asarray(t.matrix, np.float32))
+        fresh[k] = dict(d[k]); fresh[k]["to_world"] = T(np.concatenate([np.asarray(t.matrix, np.float64).ravel(), np.linalg.inv(np.asarray(t.matrix, np.float64)).T.ravel()]).astype(np.float32))
+    params.update()
+    want = mi.load_dict(fresh)
+    for a, b in zip(scene.meshes, want.meshes):
+        assert np.array_equal(a["V"], b["V"]) and np.array_equal(a["F"], b["F"]), a["key"]
+    for a, b in zip(scene.emitters, want.emitters):
+        for key in ("to_world", "normal", "inv_area"):
+            assert np.array_equal(np.asarray(a[key]), np.asarray(b[key])), key
+    o1, s1 = O.scene_from_product(scene); o2, s2 = O.scene_from_product(want)
+    a, st1 = o1.render_path(s1, seed=3, spp=4, max_depth=5, threads=1); b, st2 = o2.render_path(s2, seed=3, spp=4, max_depth=5, threads=1)
+    assert np.array_equal(a, b) and st1.vertices == st2.vertices
+    assert np.allclose(mi.traverse(scene)["light.to_world"].cpu().numpy(), np.asarray(moves["light"].matrix, np.float32))
+    with pytest.raises(RuntimeError, match="singular"):
+        params["floor.to_world"] = torch.zeros((4, 4)); params.update()
