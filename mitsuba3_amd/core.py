@@ -2437,6 +2437,11 @@ class SceneParameters(dict):
             sc._set_instance_matrices(moved)
             for k in moved_keys:
                 marks[k]()
+        if moved_dev and sc._h is None:          # a later key of this update() (a rectangle's to_world) asked for a new scene: the matrices go to the host mirrors it is built from
+            sc._set_instance_matrices([(ref, v.detach().to("cpu").numpy().astype(np.float32).reshape(4, 4)) for ref, _, v in moved_dev])
+            for _, k, _ in moved_dev:
+                marks[k]()
+            moved_dev = []
         if moved_dev:          # instance transforms that live on the GPU: one call per run of consecutive instances, nothing leaves the device
             moved_dev.sort(key=lambda e: e[0]); start = 0
             while start < len(moved_dev):
