@@ -1359,7 +1359,7 @@ class Integrator:
         ptrs = (C.c_void_p * max(1, len(g_tex)))(*[t.data_ptr() for t in g_tex])
         g_emit = torch.zeros((max(1, len(scene.emitters)), 3), dtype=torch.float32, device=dev)
         check(lib().har_integrator_set_grad_emitters(self._handle(), _ptr(g_emit) if self.emitter_gradients else None))
-        g_pos = {}; g_inst = None; inst_wanted = {}
+        g_pos = {}; g_inst = None; inst_wanted = {}; rect_wanted = {}
         if self.shape_gradients:
             keys = scene._position_keys(); ikeys = scene._instance_keys()
             if self.shape_gradients is True:         # "every eligible mesh / instance": the meshes the adjoint can differentiate, instances if no instanced mesh is purely specular
@@ -1367,7 +1367,16 @@ class Integrator:
                 inst_wanted = ikeys if all(scene._bsdf_has_smooth_lobe(m["bsdf"]) for m in scene.meshes[scene.top_mesh_count:]) else {}
             else:
                 inst_wanted = {k: ikeys[k] for k in self.shape_gradients if k in ikeys}
-                wanted = {k: keys[k] for k in self.shape_gradients if k not in ikeys}    # KeyError: not a differentiable mesh / instance
+                # a rectangle's 'to_world' (rectangle.cpp:199: Differentiable): its four vertices ARE to_world * (+-1, +-1, 0), so the matrix gradient is the chain rule over
+                # the vertex-position gradients (rect_wanted: key -> (mesh, its positions key, whether the caller asked for the positions too))
+                rkeys = scene._rect_keys()
+                for k in self.shape_gradients:
+                    if k in rkeys:
+                        pk = scene.meshes[rkeys[k]]["key"] + ".positions"
+                        if scene.meshes[rkeys[k]]["emitter"] >= 0 or pk not in scene._differentiable_position_keys():
+                            raise RuntimeError("%s: only a rectangle without an area light and with a non-delta BSDF lobe can be differentiated through its 'to_world' in hip_ad_rgb" % k)
+                        rect_wanted[k] = (rkeys[k], pk, pk in self.shape_gradients)
+                wanted = {k: keys[k] for k in list(self.shape_gradients) + [v[1] for v in rect_wanted.values()] if k not in ikeys and k not in rkeys}    # KeyError: not a differentiable mesh / instance
             g_pos = {k: torch.zeros((scene.meshes[m]["V"].shape[0], 3), dtype=torch.float32, device=dev) for k, m in wanted.items()}      # the parameter's shape: N x 3
             by_mesh = {wanted[k]: g for k, g in g_pos.items()}
             pp = (C.c_void_p * max(1, len(scene.meshes)))(*[by_mesh[m].data_ptr() if m in by_mesh else None for m in range(len(scene.meshes))])
@@ -1401,6 +1410,15 @@ class Integrator:
                 if kind == "emitter_tex":
                     out[k] = g_tex[scene.emitters[i]["light"].tex_index]
         out.update(g_pos)
+        for k, (mi_, pk, keep) in rect_wanted.items():         # d loss / d to_world[r, :] = sum over the vertices of  d loss / d p_v[r] * (local corner of v, 1);  fourth row constant
+            rect = scene.meshes[mi_]["rect"]
+            M = np.asarray(rect["to_world"].matrix, np.float64).reshape(4, 4)
+            Pw = np.concatenate([scene.meshes[mi_]["V"][:, :3].astype(np.float64), np.ones((4, 1))], axis=1)
+            local = torch.as_tensor((np.linalg.inv(M) @ Pw.T).T, dtype=torch.float32, device=dev)              # 4 vertices x (x, y, 0, 1)
+            g = torch.zeros((4, 4), dtype=torch.float32, device=dev); g[:3, :] = g_pos[pk].reshape(4, 3).T @ local
+            out[k] = g
+            if not keep:
+                out.pop(pk, None)
         for k, i in inst_wanted.items():                      # column-major 3x4 -> the reference's 4x4 (constant fourth row: zero gradient)
             m = torch.zeros((4, 4), dtype=torch.float32, device=dev); m[:3, :] = g_inst[i].reshape(4, 3).T
             out[k] = m
@@ -2795,9 +2813,6 @@ def render(scene, params=None, sensor=0, integrator=None, seed=0, seed_grad=0, s
         return _render_scalar(scene, integrator, sensor, seed, spp)
     keys = [k for k, v in (params or {}).items() if getattr(v, 'requires_grad', False)]
     fixed = [k for k in keys if k in scene._pose_keys() and scene._pose_keys()[k][0] != "emitter_tex"]      # (a light's radiance bitmap IS differentiable: area.cpp:64-70)
-    if any(k in scene._rect_keys() for k in keys):
-        raise RuntimeError("%s: a rectangle's 'to_world' is updatable in hip_ad_rgb but carries no gradient (Differentiable in the reference, rectangle.cpp:199); differentiate its "
-                           "'<shape>.positions' instead -- d loss / d to_world = sum over the four vertices of  d loss / d position (x) (local corner, 1)" % [k for k in keys if k in scene._rect_keys()])
     if fixed:       # ParamFlags::NonDifferentiable in the reference's traverse(): dr.enable_grad on them has no effect there; here it is said
         raise RuntimeError("%s are not differentiable parameters in hip_ad_rgb (placement of sensors and delta emitters: ParamFlags::NonDifferentiable in the reference; "
                            "a spot light's cutoff_angle / beam_width: Differentiable there, updatable but without a gradient here)" % fixed)
@@ -2809,7 +2824,7 @@ def render(scene, params=None, sensor=0, integrator=None, seed=0, seed_grad=0, s
     # second with one integrator must not leave `shape_gradients` on for the second render)
     overrides = {}
     if integrator.type == 'prb':
-        shape_keys = [k for k in keys if k in scene._position_keys() or k in scene._instance_keys()]
+        shape_keys = [k for k in keys if k in scene._position_keys() or k in scene._instance_keys() or k in scene._rect_keys()]
         if shape_keys and integrator.shape_gradients is not True:
             overrides['shape_gradients'] = sorted(set(list(integrator.shape_gradients or [])) | set(shape_keys))
         if any(k in scene._bsdf_param_keys() for k in keys) and not integrator.bsdf_parameter_gradients:

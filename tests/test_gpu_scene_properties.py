@@ -295,3 +295,50 @@ def test_delta_emitter_pose_updates_keep_the_scene_handle(mi, O):
     params["spot.cutoff_angle"] = torch.tensor([10.0])
     with pytest.raises(RuntimeError, match="cutoff_angle"):
         params.update()
+
+
+def test_rectangle_to_world_gradient_is_the_chain_rule_over_its_vertices(mi, O):
+    """`'<rectangle>.to_world'` is Differentiable in the reference (rectangle.cpp:199).  A rectangle's four vertices ARE to_world * (+-1, +-1, 0), so  d loss / d to_world[r, c] =
+    sum_v d loss / d p_v[r] * (local corner of v, 1)[c]:  held to the ORACLE's vertex-position gradients (dual numbers through prb.py:124-297) folded the same way, through
+    render_backward and through mi.render + autograd; a rectangle that carries the light is refused by name; an optimiser step through params.update() moves the floor"""
+    import torch
+    res, spp, md = 32, 64, 4
+    d, tex = textured_scene(mi, None, res=res, tex_res=8)
+    d["integrator"] = {"type": "prb", "max_depth": md, "shape_gradients": ["floor.to_world"]}
+    scene = mi.load_dict(d)
+    osc, sensor = O.scene_from_product(scene)
+    grad_in = np.random.default_rng(8).uniform(0.5, 1.5, (res, res, 3)).astype(np.float32)
+    grads = scene.integrator().render_backward(scene, None, grad_in, seed=3, spp=spp)
+    assert "floor.to_world" in grads and "floor.positions" not in grads
+    mesh = scene._position_keys()["floor.positions"]
+    want_v, _, _, _ = osc.render_prb_backward_shape(sensor, grad_in, [mesh], seed=3, spp=spp, max_depth=md)
+    M = np.asarray(scene.meshes[mesh]["rect"]["to_world"].matrix, np.float64)
+    P = np.concatenate([scene.meshes[mesh]["V"][:, :3].astype(np.float64), np.ones((4, 1))], axis=1)
+    local = (np.linalg.inv(M) @ P.T).T
+    assert np.allclose(np.abs(local[:, :2]), 1.0, atol=1e-5) and np.allclose(local[:, 2], 0.0, atol=1e-5)          # the corners of the unit square
+    want = np.zeros((4, 4)); want[:3, :] = want_v[mesh].astype(np.float64).T @ local
+    got = grads["floor.to_world"].cpu().numpy()
+    scale = np.abs(want).max()
+    assert scale > 0 and np.abs(got - want).max() < 2e-3 * scale and not got[3].any(), (got, want)
+    # both keys at once: the positions stay in the result
+    scene.integrator().shape_gradients = ["floor.to_world", "floor.positions"]
+    both = scene.integrator().render_backward(scene, None, grad_in, seed=3, spp=spp)
+    assert np.abs(both["floor.to_world"].cpu().numpy() - got).max() < 1e-4 * scale and np.abs(both["floor.positions"].cpu().numpy() - want_v[mesh]).max() < 2e-3 * np.abs(want_v[mesh]).max()
+    # the autograd route, and one descent step through params.update()
+    scene.integrator().shape_gradients = False
+    params = mi.traverse(scene)
+    params["floor.to_world"].requires_grad_(True)
+    img = mi.render(scene, params, spp=spp, seed=3)
+    (img * torch.as_tensor(grad_in, device=img.device)).sum().backward()
+    g = params["floor.to_world"].grad.cpu().numpy()
+    assert g.shape == (4, 4) and np.isfinite(g).all() and np.abs(g).max() > 0
+    before = scene.meshes[mesh]["V"][:, :3].copy()
+    with torch.no_grad():
+        params["floor.to_world"][1, 3] -= 0.05
+    params.update()
+    assert np.allclose(scene.meshes[mesh]["V"][:, 1], before[:, 1] - 0.05, atol=1e-6)
+    mi.render(scene, spp=4, seed=1)
+    with pytest.raises(RuntimeError, match="area light"):
+        scene.integrator().shape_gradients = ["light.to_world"]
+        scene.integrator().render_backward(scene, None, grad_in, seed=3, spp=4)
+    scene.integrator().shape_gradients = False
