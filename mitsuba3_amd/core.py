@@ -2105,6 +2105,9 @@ class Scene:
                 keys[key + ".position"] = ("position", i)
             elif t in (5, 6):
                 keys[key + ".to_world"] = ("emitter_to_world", i)
+            elif t == 2:        # EnvironmentMapEmitter::traverse (envmap.cpp:204-208): `scale`, `to_world` -- updatable here (the record is rebuilt with the next scene handle);
+                                # `data` (the texel tensor, differentiable there) is not exposed
+                keys[key + ".scale"] = ("env_scale", i); keys[key + ".to_world"] = ("emitter_to_world", i)
             if t == 5:          # SpotLight::traverse (spot.cpp:115-116): the cone, in degrees -- updatable here; their gradient (the reference marks them Differentiable) is refused
                 keys[key + ".cutoff_angle"] = ("cutoff_angle", i); keys[key + ".beam_width"] = ("beam_width", i)
             # Emitter::traverse (src/render/emitter.cpp:13): `sampling_weight`, NonDifferentiable; an area light is a child of its shape ('<shape>.emitter.*')
@@ -2126,6 +2129,8 @@ class Scene:
             return np.asarray([self.emitters[b]["normal"][0 if kind == "cutoff_angle" else 1]], np.float32)
         if kind == "sampling_weight":
             return np.asarray([self.emitters[b].get("sampling_weight", 1.0)], np.float32)
+        if kind == "env_scale":
+            return np.asarray([self.emitters[b]["radiance"][0]], np.float32)
         if kind == "emitter_tex":
             return np.array(self.emitters[b]["light"].texture, np.float32)
         if kind in ("to_uv", "emitter_to_uv"):
@@ -2224,7 +2229,12 @@ class Scene:
                 check(lib().har_scene_set_texture_to_uv(self._h, b.tex_index, _fp(_f32(rows))))
             return
         e = dict(self.emitters[b])
-        if kind in ("cutoff_angle", "beam_width"):
+        if kind == "env_scale":
+            sc = float(np.asarray(value, np.float32).reshape(-1)[0])
+            if not math.isfinite(sc):
+                raise RuntimeError("envmap: 'scale' is not finite")
+            e["radiance"] = [sc] + [float(x) for x in e["radiance"][1:]]
+        elif kind in ("cutoff_angle", "beam_width"):
             nrm = [float(x) for x in e["normal"]]; nrm[0 if kind == "cutoff_angle" else 1] = float(np.asarray(value, np.float32).reshape(-1)[0])
             e["normal"] = nrm                                        # the pair is validated once both values of an update() are in (_validate_spots)
         elif kind == "position":

@@ -325,3 +325,29 @@ def test_reference_envmap_pixel_shift_seam_and_poles(mi, O, H, which):
     img = np.zeros((Hh, W, 3), np.float32); img[0] = 10.0; img[Hh - 1] = 20.0
     em = make(img)
     assert abs(_eval_uv(em, 0.0, 0.0)[0, 0] - 10.0) < 1e-3 and abs(_eval_uv(em, 0.0, 1.0)[0, 0] - 20.0) < 1e-3
+
+
+def test_envmap_scale_and_to_world_are_updatable_parameters(mi, O):
+    """EnvironmentMapEmitter::traverse registers `scale` and `to_world` (envmap.cpp:204-208): written + params.update(), the scene equals a freshly loaded one with those
+    values (oracle render of the host mirrors, bit for bit)"""
+    import torch
+    T = mi.ScalarTransform4f
+    rng = np.random.default_rng(3)
+    bm = mi.Bitmap(rng.uniform(0.1, 1.5, (6, 12, 3)).astype(np.float32))
+    def make(scale, tw):
+        d = mi.cornell_box(); d["sensor"]["film"]["width"] = 20; d["sensor"]["film"]["height"] = 20
+        d.pop("light"); d.pop("ceiling")
+        d["env"] = {"type": "envmap", "bitmap": bm, "scale": scale, "to_world": tw}
+        return d
+    tw0 = T().rotate([0, 1, 0], 30.0); tw1 = T().rotate([0, 1, 0], 140.0).rotate([1, 0, 0], 25.0)
+    scene = mi.load_dict(make(1.0, tw0))
+    params = mi.traverse(scene)
+    assert float(params["env.scale"]) == 1.0 and tuple(params["env.to_world"].shape) == (4, 4)
+    params["env.scale"] = torch.tensor([2.5]); params["env.to_world"] = torch.as_tensor(np.asarray(tw1.matrix, np.float32)); params.update()
+    m = np.asarray(tw1.matrix, np.float64)
+    want = mi.load_dict(make(2.5, T(np.concatenate([m.ravel(), np.linalg.inv(m).T.ravel()]).astype(np.float32))))
+    o1, s1 = O.scene_from_product(scene); o2, s2 = O.scene_from_product(want)
+    a, st1 = o1.render_path(s1, seed=2, spp=4, max_depth=4, threads=1); b, st2 = o2.render_path(s2, seed=2, spp=4, max_depth=4, threads=1)
+    assert st1.vertices == st2.vertices and np.allclose(a, b, rtol=2e-6, atol=1e-7) and a.mean() > 0
+    base, _ = O.scene_from_product(mi.load_dict(make(1.0, tw0)))[0].render_path(s1, seed=2, spp=4, max_depth=4, threads=1)
+    assert np.linalg.norm(a - base) > 0.1 * np.linalg.norm(base)          # the update did change the picture

@@ -390,7 +390,11 @@ def _perturb(mi, scene, params, rng, torch):
             if kind == "position":
                 params[k] = v + torch.as_tensor(rng.uniform(-0.1, 0.1, 3), dtype=v.dtype, device=v.device)
             elif kind in ("emitter_to_world", "sensor"):
-                m = v.clone(); m[:3, 3] += torch.as_tensor(rng.uniform(-0.05, 0.05, 3), dtype=v.dtype, device=v.device); params[k] = m
+                m = v.clone(); m[:3, 3] += torch.as_tensor(rng.uniform(-0.05, 0.05, 3), dtype=v.dtype, device=v.device)
+                if kind == "emitter_to_world" and scene.emitters[pose[k][1]].get("type") == 2:      # an environment map: turned about the y axis
+                    a = float(rng.uniform(0.2, 1.0)); c, sn = np.cos(a), np.sin(a)
+                    m = torch.as_tensor(np.array([[c, 0, sn, 0], [0, 1, 0, 0], [-sn, 0, c, 0], [0, 0, 0, 1]], np.float32), device=v.device) @ v
+                params[k] = m
             elif kind == "cutoff_angle":
                 continue                                          # (cutoff and beam width move together below)
             elif kind == "beam_width":
@@ -398,6 +402,8 @@ def _perturb(mi, scene, params, rng, torch):
                 params[k] = v * f; params[ck] = params[ck] * f; written.append(ck)
             elif kind == "sampling_weight":
                 params[k] = v * float(rng.uniform(0.5, 2.0))
+            elif kind == "env_scale":
+                params[k] = v * float(rng.uniform(0.5, 1.5))
             elif kind == "emitter_tex":
                 params[k] = v * torch.as_tensor(rng.uniform(0.5, 1.5, tuple(v.shape)), dtype=v.dtype, device=v.device)
             else:
