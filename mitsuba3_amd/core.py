@@ -741,6 +741,28 @@ class Sensor:
             raise RuntimeError("invalid sensor parameters")
         self.har = s
 
+    def x_fov(self):
+        """the horizontal field of view in degrees: parse_fov (src/render/sensor.cpp:142-195) of the sensor's `fov` / `fov_axis` / `focal_length` at the film's aspect ratio --
+        what PerspectiveCamera::traverse registers as 'x_fov' (perspective.cpp:157)"""
+        w, h = self.m_film.width, self.m_film.height
+        aspect = w / float(h)
+        axis = str(self.props.get('fov_axis', 'x')).lower()
+        if 'fov' in self.props:
+            fov = float(self.props['fov'])
+            if axis == 'smaller':
+                axis = 'y' if aspect > 1 else 'x'
+            elif axis == 'larger':
+                axis = 'x' if aspect > 1 else 'y'
+        else:
+            fl = str(self.props.get('focal_length', '50mm'))
+            fov = 2.0 * math.degrees(math.atan(math.sqrt(36 * 36 + 24 * 24) / (2.0 * float(fl[:-2] if fl.endswith('mm') else fl)))); axis = 'diagonal'
+        if axis == 'x':
+            return fov
+        if axis == 'y':
+            return math.degrees(2.0 * math.atan(math.tan(0.5 * math.radians(fov)) * aspect))
+        width = 2.0 * math.tan(0.5 * math.radians(fov)) / math.sqrt(1.0 + 1.0 / (aspect * aspect))
+        return math.degrees(2.0 * math.atan(width * 0.5))
+
     def film(self):
         return self.m_film
 
@@ -2099,6 +2121,8 @@ class Scene:
         keys = {}
         for k, s in zip(self.sensor_keys, self.m_sensors):
             keys[k + ".to_world"] = ("sensor", s)
+            if s.kind != 'orthographic':          # PerspectiveCamera::traverse (perspective.cpp:155-160)
+                keys[k + ".x_fov"] = ("x_fov", s)
         for i, key in enumerate(self._emitter_order):
             t = self.emitters[i].get("type", 0)
             if t == 4:
@@ -2123,6 +2147,8 @@ class Scene:
     def _pose_value(self, kind, b):
         if kind == "sensor":
             return np.asarray(b.to_world.matrix, np.float32).reshape(4, 4).copy()
+        if kind == "x_fov":
+            return np.asarray([b.x_fov()], np.float32)
         if kind == "position":
             return np.asarray(self.emitters[b]["to_world"][9:12], np.float32).copy()
         if kind in ("cutoff_angle", "beam_width"):
@@ -2192,6 +2218,18 @@ class Scene:
                 b.update()                                       # the sensor record travels with every render call: no scene handle involved
             except Exception:
                 b.to_world = old; b.update()
+                raise
+            return
+        if kind == "x_fov":                  # PerspectiveCamera::parameters_changed -> update_camera_transforms (perspective.cpp:163-198): the projection follows the new angle
+            fov = float(np.asarray(value, np.float32).reshape(-1)[0])
+            if not (0.0 < fov < 180.0):
+                raise RuntimeError("The horizontal field of view must be in the range [0, 180]!")
+            old = dict(b.props)
+            b.props.pop('focal_length', None); b.props['fov'] = fov; b.props['fov_axis'] = 'x'
+            try:
+                b.update()
+            except Exception:
+                b.props = old; b.update()
                 raise
             return
         if kind == "sampling_weight":

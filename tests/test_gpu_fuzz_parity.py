@@ -404,6 +404,8 @@ def _perturb(mi, scene, params, rng, torch):
                 params[k] = v * float(rng.uniform(0.5, 2.0))
             elif kind == "env_scale":
                 params[k] = v * float(rng.uniform(0.5, 1.5))
+            elif kind == "x_fov":
+                params[k] = v * float(rng.uniform(0.8, 1.2))
             elif kind == "emitter_tex":
                 params[k] = v * torch.as_tensor(rng.uniform(0.5, 1.5, tuple(v.shape)), dtype=v.dtype, device=v.device)
             else:

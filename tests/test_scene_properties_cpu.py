@@ -526,3 +526,35 @@ def test_rectangle_to_world_is_an_updatable_parameter(mi, O):
     assert np.allclose(mi.traverse(scene)["light.to_world"].cpu().numpy(), np.asarray(moves["light"].matrix, np.float32))
     with pytest.raises(RuntimeError, match="singular"):
         params["floor.to_world"] = torch.zeros((4, 4)); params.update()
+
+
+def test_x_fov_is_a_parameter_of_the_perspective_sensor(mi, O):
+    """PerspectiveCamera::traverse registers 'x_fov' (perspective.cpp:157): the value is parse_fov's (sensor.cpp:142-195: `fov_axis` x / y / diagonal / smaller / larger and
+    `focal_length` at the film's aspect ratio); writing it re-lowers the projection -- the sensor then equals one created with that horizontal angle"""
+    import math, torch
+    def cbox(w, h, **sensor):
+        d = mi.cornell_box(); f = d["sensor"]["film"]; f["width"] = w; f["height"] = h
+        for k in ("fov", "fov_axis"):
+            d["sensor"].pop(k, None)
+        d["sensor"].update(sensor)
+        return d
+    for w, h, kw, want in ((40, 20, dict(fov=40.0), 40.0),
+                           (40, 20, dict(fov=40.0, fov_axis="y"), math.degrees(2 * math.atan(math.tan(math.radians(20.0)) * 2.0))),
+                           (40, 20, dict(fov=40.0, fov_axis="smaller"), math.degrees(2 * math.atan(math.tan(math.radians(20.0)) * 2.0))),
+                           (20, 40, dict(fov=40.0, fov_axis="larger"), math.degrees(2 * math.atan(math.tan(math.radians(20.0)) * 0.5))),
+                           (30, 30, dict(fov=50.0, fov_axis="diagonal"), math.degrees(2 * math.atan(math.tan(math.radians(25.0)) / math.sqrt(2.0)))),
+                           (36, 24, dict(focal_length="50mm"), math.degrees(2 * math.atan(18.0 / 50.0)))):
+        scene = mi.load_dict(cbox(w, h, **kw))
+        got = float(mi.traverse(scene)["sensor.x_fov"])
+        assert abs(got - want) < 1e-4, (kw, got, want)
+        ref = mi.load_dict(cbox(w, h, fov=want)).sensors()[0]
+        assert np.allclose(np.asarray(list(scene.sensors()[0].har.sample_to_camera)), np.asarray(list(ref.har.sample_to_camera)), rtol=1e-6, atol=1e-7)
+    scene = mi.load_dict(cbox(32, 24, fov=35.0, fov_axis="y"))
+    params = mi.traverse(scene)
+    params["sensor.x_fov"] = torch.tensor([60.0]); params.update()
+    ref = mi.load_dict(cbox(32, 24, fov=60.0)).sensors()[0]
+    assert bytes(scene.sensors()[0].har) == bytes(ref.har)
+    with pytest.raises(RuntimeError, match="field of view"):
+        params["sensor.x_fov"] = torch.tensor([190.0]); params.update()
+    assert bytes(scene.sensors()[0].har) == bytes(ref.har)          # a rejected value leaves the sensor as it was
+    assert "cam.x_fov" not in mi.traverse(mi.load_dict({"type": "scene", "cam": {"type": "orthographic", "film": {"type": "hdrfilm", "width": 8, "height": 8}}})).keys()
