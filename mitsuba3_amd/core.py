@@ -1424,6 +1424,8 @@ class Integrator:
         out = scene._gradients(g_refl, g_tex, g_emit if self.emitter_gradients else None)
         if g_extra is not None:
             for k, (what, b) in scene._bsdf_param_keys().items():
+                if what == "ior":
+                    continue                  # (no gradient w.r.t. the scalar index of refraction)
                 rec = g_extra[b.index]
                 out[k] = {"alpha": rec[0:6].sum().reshape(1), "alpha_u": rec[0:3].sum().reshape(1), "alpha_v": rec[3:6].sum().reshape(1),
                           "eta": rec[6:9], "k": rec[9:12], "slot1": rec[12:15]}[what]
@@ -1905,15 +1907,25 @@ class Scene:
                 keys[base + ".eta.value"] = ("eta", b); keys[base + ".k.value"] = ("k", b)
             if b.kind == 'roughplastic' and b.slot1_name:
                 keys[base + "." + b.slot1_name + ".value"] = ("slot1", b)
+            if b.kind in ('dielectric', 'plastic', 'roughplastic'):
+                # the relative index of refraction int_ior / ext_ior, a plain float: dielectric.cpp:238, plastic.cpp:185 (NonDifferentiable), roughplastic.cpp:211 (Differentiable
+                # there; updatable without a gradient here)
+                keys[base + ".eta"] = ("ior", b)
         return keys
 
     def _bsdf_param_value(self, what, b):
-        return {"alpha": [b.alpha_u], "alpha_u": [b.alpha_u], "alpha_v": [b.alpha_v], "eta": b.eta_c, "k": b.k_c, "slot1": b.value2}[what]
+        return {"alpha": [b.alpha_u], "alpha_u": [b.alpha_u], "alpha_v": [b.alpha_v], "eta": b.eta_c, "k": b.k_c, "slot1": b.value2, "ior": [b.eta]}[what]
 
     def _set_bsdf_param(self, what, b, v):
         """params.update() of a non-slot-0 BSDF parameter: the record is re-lowered IN PLACE when a scene handle exists (har_scene_set_bsdf_params), else with the first handle (roughplastic's sampling weights and
         transmittance tables depend on alpha / the colours: RoughPlastic::parameters_changed, roughplastic.cpp:204-242)"""
         v = np.asarray(v, np.float32).reshape(-1)
+        if what == "ior":              # Dielectric / SmoothPlastic / RoughPlastic::parameters_changed: Fresnel terms, plastic's internal reflectance and tables follow eta --
+            if not (float(v[0]) > 0.0) or not math.isfinite(float(v[0])) or (b.kind == 'roughplastic' and float(v[0]) == 1.0):      # all re-derived when the next scene handle lowers the record
+                raise RuntimeError("The interior and exterior indices of refraction must be positive" + (" and differ!" if b.kind == 'roughplastic' else "!"))
+            b.eta = float(v[0])
+            self._drop_handle()
+            return
         if what == "alpha":
             b.alpha_u = b.alpha_v = float(v[0])
         elif what == "alpha_u":

@@ -252,6 +252,8 @@ def test_prb_bsdf_parameter_gradients_vs_oracle(mi, O):
     gx, g_refl = osc.render_prb_backward_bsdf_params(sensor, grad_in, seed=4, spp=spp, max_depth=6)
     checked = 0
     for key, (what, b) in scene._bsdf_param_keys().items():
+        if what == "ior":
+            continue
         rec = gx[b.index]
         ref = {"alpha": rec[0:2].sum().reshape(1), "alpha_u": rec[0].sum(keepdims=True), "alpha_v": rec[1].sum(keepdims=True), "eta": rec[2], "k": rec[3], "slot1": rec[4]}[what]
         got = grads[key].cpu().numpy().reshape(-1)

@@ -309,6 +309,8 @@ def test_random_scene_options(mi, O, seed):
         gx = osc.render_prb_backward_bsdf_params(sensor, grad_in, seed=seed + 2, spp=spp, max_depth=md, rr_depth=rr)
         gx = gx[0] if isinstance(gx, tuple) else gx
         for k, (what, b) in scene._bsdf_param_keys().items():
+            if what == "ior":
+                continue                                                  # (the scalar index of refraction: updatable, no gradient)
             rec = np.asarray(gx[b.index], np.float64).reshape(5, 3)
             want = {"alpha": rec[0:2].sum(), "alpha_u": rec[0].sum(), "alpha_v": rec[1].sum(), "eta": rec[2], "k": rec[3], "slot1": rec[4]}[what]
             got = grads[k].cpu().numpy().astype(np.float64)
@@ -383,6 +385,8 @@ def _perturb(mi, scene, params, rng, torch):
                 params[k] = (v * float(rng.uniform(0.7, 1.3))).clamp(0.05, 0.9)
             elif what in ("eta", "k"):
                 params[k] = v * torch.as_tensor(rng.uniform(0.9, 1.1, tuple(v.shape)), dtype=v.dtype, device=v.device)
+            elif what == "ior":
+                params[k] = (v * float(rng.uniform(0.95, 1.08))).clamp(1.05, 2.5)
             else:
                 params[k] = (v * float(rng.uniform(0.6, 1.2))).clamp(0.0, 1.0)
         elif k in pose:

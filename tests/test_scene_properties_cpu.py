@@ -558,3 +558,29 @@ def test_x_fov_is_a_parameter_of_the_perspective_sensor(mi, O):
         params["sensor.x_fov"] = torch.tensor([190.0]); params.update()
     assert bytes(scene.sensors()[0].har) == bytes(ref.har)          # a rejected value leaves the sensor as it was
     assert "cam.x_fov" not in mi.traverse(mi.load_dict({"type": "scene", "cam": {"type": "orthographic", "film": {"type": "hdrfilm", "width": 8, "height": 8}}})).keys()
+
+
+def test_scalar_eta_is_a_parameter_of_the_dielectric_models(mi, O):
+    """'<bsdf>.eta' -- int_ior / ext_ior, a plain float -- is registered by dielectric.cpp:238, plastic.cpp:185 and roughplastic.cpp:211: readable, and written + params.update()
+    the scene equals a freshly loaded one with that index (Fresnel terms, plastic's internal reflectance, roughplastic's tables are lowered from it)"""
+    import torch
+    def make(iors):
+        d = mi.cornell_box(); f = d["sensor"]["film"]; f["width"] = 20; f["height"] = 20
+        d["glass"] = {"type": "dielectric", "int_ior": iors[0], "ext_ior": 1.0}
+        d["coat"] = {"type": "plastic", "int_ior": iors[1], "ext_ior": 1.0, "diffuse_reflectance": {"type": "rgb", "value": [0.2, 0.4, 0.6]}}
+        d["rough"] = {"type": "roughplastic", "int_ior": iors[2], "ext_ior": 1.0, "alpha": 0.2, "diffuse_reflectance": {"type": "rgb", "value": [0.5, 0.3, 0.2]}}
+        d["small-box"]["bsdf"] = {"type": "ref", "id": "glass"}; d["large-box"]["bsdf"] = {"type": "ref", "id": "coat"}; d["floor"]["bsdf"] = {"type": "ref", "id": "rough"}
+        return d
+    scene = mi.load_dict(make([1.5, 1.49, 1.6]))
+    params = mi.traverse(scene)
+    assert abs(float(params["glass.eta"]) - 1.5) < 1e-6 and abs(float(params["coat.eta"]) - 1.49) < 1e-6 and abs(float(params["rough.eta"]) - 1.6) < 1e-6
+    new = [1.33, 1.7, 1.45]
+    for k, v in zip(("glass.eta", "coat.eta", "rough.eta"), new):
+        params[k] = torch.tensor([v])
+    params.update()
+    want = mi.load_dict(make(new))
+    o1, s1 = O.scene_from_product(scene); o2, s2 = O.scene_from_product(want)
+    a, st1 = o1.render_path(s1, seed=5, spp=4, max_depth=6, threads=1); b, st2 = o2.render_path(s2, seed=5, spp=4, max_depth=6, threads=1)
+    assert st1.vertices == st2.vertices and np.array_equal(a, b)
+    with pytest.raises(RuntimeError, match="indices of refraction"):
+        params["rough.eta"] = torch.tensor([1.0]); params.update()
