@@ -14,7 +14,7 @@ from .core import (                                    # noqa: F401
     set_variant, variant, variants, ScalarTransform4f, Transform4f, ScalarTransform3f, Transform3f, AreaLight, cornell_box, load_dict, render, traverse,
     register_plugin, register_integrator, Scene, Sensor, Film, Sampler, BSDF, BSDFContext, BSDFFlags, TransportMode, RayFlags, Mesh, ShapeGroup, Instance,
     Integrator, Ray3f, PreliminaryIntersection3f, SurfaceInteraction3f, SceneParameters, develop_film, sample_tea_32,
-    Bitmap, write_bitmap, ConstantEmitter, EnvmapEmitter, PointLight, SpotLight, DirectionalEmitter, DeviceGroup,
+    Bitmap, write_bitmap, ConstantEmitter, EnvmapEmitter, PointLight, SpotLight, DirectionalEmitter, DeviceGroup, ParamFlags,
 )
 from . import core                                     # noqa: F401
 from .distributed import render_distributed, render_backward_distributed, lane_range   # noqa: F401

@@ -2328,8 +2328,51 @@ class Scene:
         return out
 
 
+class ParamFlags:
+    """include/mitsuba/core/object.h:363-372"""
+    Differentiable = 0
+    NonDifferentiable = 1
+    Discontinuous = 2
+    ReadOnly = 4
+
+
 class SceneParameters(dict):
     """mi.traverse(scene): differentiable parameters as torch tensors (util.py SceneParameters)."""
+
+    def flags(self, key):
+        """SceneParameters.flags (util.py:146-148): what THIS variant can do with the entry -- Differentiable where `prb` produces its gradient (| Discontinuous where the
+        reference's traverse() says so: geometry, roughness, complex IOR, texels of a light), NonDifferentiable for placements and plain values, ReadOnly for what is only shown"""
+        if key not in self:
+            raise KeyError(key)
+        sc = self.scene
+        if key in self._read_only:
+            return ParamFlags.ReadOnly | ParamFlags.NonDifferentiable
+        if key in sc._param_keys():
+            return ParamFlags.Differentiable
+        if key in sc._bsdf_param_keys():
+            return ParamFlags.NonDifferentiable if sc._bsdf_param_keys()[key][0] == "ior" else (ParamFlags.Differentiable if sc._bsdf_param_keys()[key][0] == "slot1" else ParamFlags.Differentiable | ParamFlags.Discontinuous)
+        if key in sc._position_keys() or key in sc._instance_keys() or key in sc._rect_keys():
+            return ParamFlags.Differentiable | ParamFlags.Discontinuous
+        if sc._pose_keys().get(key, (None,))[0] == "emitter_tex":
+            return ParamFlags.Differentiable | ParamFlags.Discontinuous
+        return ParamFlags.NonDifferentiable
+
+    def set_dirty(self, key):
+        """SceneParameters.set_dirty (util.py:150-185): the next update() treats the entry as written (for writes the version counter does not see)"""
+        if key not in self:
+            raise KeyError(key)
+        self._written.add(key)
+
+    def keep(self, keys):
+        """SceneParameters.keep (util.py:238-256): only the entries whose names match one of `keys` (regular expressions, `re.match`) stay in the table"""
+        import re
+        if not isinstance(keys, list):
+            keys = [keys]
+        regexps = [re.compile(k).match for k in keys]
+        for k in [k for k in list(self.keys()) if not any(r(k) for r in regexps)]:
+            dict.__delitem__(self, k)
+            self._read_only.discard(k); self._written.discard(k)
+        self._host_table = None            # the update tables are rebuilt over the entries that are left
 
     def __init__(self, scene):
         super().__init__()
@@ -2403,8 +2446,8 @@ class SceneParameters(dict):
                 t.append((k, "pose", (kind, b)))
             for k, (what, b) in sc._bsdf_param_keys().items():
                 t.append((k, "bsdf", (what, b)))
-            self._host_table = t
-            self._colour_table = list(sc._param_keys().items())
+            self._host_table = [e for e in t if e[0] in self]                      # (keep() may have dropped entries)
+            self._colour_table = [e for e in sc._param_keys().items() if e[0] in self]
         return self._host_table
 
     def _changed_keys(self, written):
@@ -2471,7 +2514,8 @@ class SceneParameters(dict):
         the host (accel update / re-lowering)."""
         if values:
             for k, v in values.items():
-                self[k] = v
+                if k in self:                  # util.py:210-213: names that are not parameters are skipped
+                    self[k] = v
         torch = _torch()
         written, self._written = self._written, set()
         sc = self.scene

@@ -477,8 +477,8 @@ def test_traverse_mesh_entries_and_unknown_keys(mi):
         params["quad.faces"] = params["quad.faces"].clone()
     with pytest.raises(KeyError):
         params["quad.vertex_positions"] = torch.zeros(12)
-    with pytest.raises(KeyError):
-        params.update({"nonsense": torch.zeros(3)})
+    params.update({"nonsense": torch.zeros(3)})                  # update(values) skips names that are not parameters (util.py:210-213)
+    assert "nonsense" not in params
     # positions: N x 3 or flat on write
     params["quad.positions"] = torch.as_tensor((P * np.float32(0.5)).reshape(-1)); params.update()
     assert np.array_equal(scene.meshes[scene._position_keys()["quad.positions"]]["V"][:, :3], P * np.float32(0.5))
@@ -584,3 +584,26 @@ def test_scalar_eta_is_a_parameter_of_the_dielectric_models(mi, O):
     assert st1.vertices == st2.vertices and np.array_equal(a, b)
     with pytest.raises(RuntimeError, match="indices of refraction"):
         params["rough.eta"] = torch.tensor([1.0]); params.update()
+
+
+def test_scene_parameters_keep_flags_set_dirty(mi):
+    """the rest of SceneParameters' interface (util.py:146-256): flags(key), keep(keys) with regular expressions, set_dirty(key); update() keeps working on a reduced table"""
+    import torch
+    scene = mi.load_dict(mi.cornell_box())
+    params = mi.traverse(scene)
+    F = mi.ParamFlags
+    assert params.flags("red.reflectance.value") == F.Differentiable
+    assert params.flags("floor.positions") == F.Differentiable | F.Discontinuous
+    assert params.flags("sensor.to_world") & F.NonDifferentiable and params.flags("sensor.film.size") & F.ReadOnly
+    with pytest.raises(KeyError):
+        params.flags("nonsense")
+    params.keep([r".*\.reflectance\.value", "sensor.to_world"])
+    assert sorted(params.keys()) == ["green.reflectance.value", "red.reflectance.value", "sensor.to_world", "white.reflectance.value"]
+    params["red.reflectance.value"] = torch.tensor([0.1, 0.2, 0.3]); params.update()
+    assert np.allclose(scene.bsdf_objs[scene._param_keys()["red.reflectance.value"][1].index].value, [0.1, 0.2, 0.3])
+    params.keep("green.*")
+    assert list(params.keys()) == ["green.reflectance.value"]
+    with torch.no_grad():
+        params["green.reflectance.value"].data[0] = 0.9            # a write the version counter does not see
+    params.set_dirty("green.reflectance.value"); params.update()
+    assert abs(float(scene.bsdf_objs[scene._param_keys()["green.reflectance.value"][1].index].value[0]) - 0.9) < 1e-7
