@@ -2135,6 +2135,7 @@ class Scene:
             keys[k + ".to_world"] = ("sensor", s)
             if s.kind != 'orthographic':          # PerspectiveCamera::traverse (perspective.cpp:155-160)
                 keys[k + ".x_fov"] = ("x_fov", s)
+                keys[k + ".principal_point_offset_x"] = ("ppo_x", s); keys[k + ".principal_point_offset_y"] = ("ppo_y", s)
         for i, key in enumerate(self._emitter_order):
             t = self.emitters[i].get("type", 0)
             if t == 4:
@@ -2161,6 +2162,8 @@ class Scene:
             return np.asarray(b.to_world.matrix, np.float32).reshape(4, 4).copy()
         if kind == "x_fov":
             return np.asarray([b.x_fov()], np.float32)
+        if kind in ("ppo_x", "ppo_y"):
+            return np.asarray([float(b.props.get('principal_point_offset_' + kind[-1], 0.0))], np.float32)
         if kind == "position":
             return np.asarray(self.emitters[b]["to_world"][9:12], np.float32).copy()
         if kind in ("cutoff_angle", "beam_width"):
@@ -2231,6 +2234,13 @@ class Scene:
             except Exception:
                 b.to_world = old; b.update()
                 raise
+            return
+        if kind in ("ppo_x", "ppo_y"):       # perspective.cpp:158-159: the principal point, a fraction of the film size; the projection is re-lowered
+            v = float(np.asarray(value, np.float32).reshape(-1)[0])
+            if not math.isfinite(v):
+                raise RuntimeError("perspective: the principal point offset is not finite")
+            b.props['principal_point_offset_' + kind[-1]] = v
+            b.update()
             return
         if kind == "x_fov":                  # PerspectiveCamera::parameters_changed -> update_camera_transforms (perspective.cpp:163-198): the projection follows the new angle
             fov = float(np.asarray(value, np.float32).reshape(-1)[0])

@@ -557,6 +557,13 @@ def test_x_fov_is_a_parameter_of_the_perspective_sensor(mi, O):
     with pytest.raises(RuntimeError, match="field of view"):
         params["sensor.x_fov"] = torch.tensor([190.0]); params.update()
     assert bytes(scene.sensors()[0].har) == bytes(ref.har)          # a rejected value leaves the sensor as it was
+    # the principal point (perspective.cpp:158-159)
+    d = cbox(32, 24, fov=40.0); d["sensor"]["principal_point_offset_x"] = 0.1
+    scene = mi.load_dict(d); params = mi.traverse(scene)
+    assert abs(float(params["sensor.principal_point_offset_x"]) - 0.1) < 1e-7 and float(params["sensor.principal_point_offset_y"]) == 0.0
+    params["sensor.principal_point_offset_x"] = torch.tensor([-0.05]); params["sensor.principal_point_offset_y"] = torch.tensor([0.2]); params.update()
+    d["sensor"]["principal_point_offset_x"] = -0.05; d["sensor"]["principal_point_offset_y"] = 0.2
+    assert bytes(scene.sensors()[0].har) == bytes(mi.load_dict(d).sensors()[0].har)
     assert "cam.x_fov" not in mi.traverse(mi.load_dict({"type": "scene", "cam": {"type": "orthographic", "film": {"type": "hdrfilm", "width": 8, "height": 8}}})).keys()
 
 
