@@ -2143,8 +2143,9 @@ class Scene:
             elif t in (5, 6):
                 keys[key + ".to_world"] = ("emitter_to_world", i)
             elif t == 2:        # EnvironmentMapEmitter::traverse (envmap.cpp:204-208): `scale`, `to_world` -- updatable here (the record is rebuilt with the next scene handle);
-                                # `data` (the texel tensor, differentiable there) is not exposed
+                                # and so is `data` (differentiable there, without a gradient here)
                 keys[key + ".scale"] = ("env_scale", i); keys[key + ".to_world"] = ("emitter_to_world", i)
+                keys[key + ".data"] = ("env_data", i)          # the texel tensor in the reference's layout: H x (W + 2) x 3, real column x at x + 1 (envmap.cpp:146-188)
             if t == 5:          # SpotLight::traverse (spot.cpp:115-116): the cone, in degrees -- updatable here; their gradient (the reference marks them Differentiable) is refused
                 keys[key + ".cutoff_angle"] = ("cutoff_angle", i); keys[key + ".beam_width"] = ("beam_width", i)
             # Emitter::traverse (src/render/emitter.cpp:13): `sampling_weight`, NonDifferentiable; an area light is a child of its shape ('<shape>.emitter.*')
@@ -2172,6 +2173,9 @@ class Scene:
             return np.asarray([self.emitters[b].get("sampling_weight", 1.0)], np.float32)
         if kind == "env_scale":
             return np.asarray([self.emitters[b]["radiance"][0]], np.float32)
+        if kind == "env_data":             # one halo column on each side carrying a copy of the opposite edge (envmap.cpp:146-188, refresh_halo)
+            t = np.asarray(self.textures[self.emitters[b]["mesh"]], np.float32)
+            return np.ascontiguousarray(np.concatenate([t[:, -1:], t, t[:, :1]], axis=1))
         if kind == "emitter_tex":
             return np.array(self.emitters[b]["light"].texture, np.float32)
         if kind in ("to_uv", "emitter_to_uv"):
@@ -2287,6 +2291,18 @@ class Scene:
             b.tex_to_uv = rows; self.texture_to_uv[b.tex_index] = rows
             if self._h is not None:
                 check(lib().har_scene_set_texture_to_uv(self._h, b.tex_index, _fp(_f32(rows))))
+            return
+        if kind == "env_data":             # EnvironmentMapEmitter::parameters_changed (envmap.cpp:208-256): the real columns are what was written, the halo is refreshed from
+            v = np.asarray(value, np.float32)  # them, the sampling distribution is rebuilt (here: with the next scene handle, from the texture table)
+            if v.ndim != 3:
+                raise RuntimeError("Environment map data has dimension %d, expected 3" % v.ndim)
+            if v.shape[2] != 3:
+                raise RuntimeError("Environment map data has %d channels, expected 3" % v.shape[2])
+            if v.shape[1] < 4 or v.shape[0] < 3 or not np.isfinite(v).all():
+                raise RuntimeError("Environment map data: at least 3 rows and 2 real columns of finite values")
+            self._drop_handle()
+            self.textures[self.emitters[b]["mesh"]] = np.ascontiguousarray(v[:, 1:-1, :])
+            self._drop_handle()
             return
         e = dict(self.emitters[b])
         if kind == "env_scale":

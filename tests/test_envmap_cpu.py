@@ -351,3 +351,30 @@ def test_envmap_scale_and_to_world_are_updatable_parameters(mi, O):
     assert st1.vertices == st2.vertices and np.allclose(a, b, rtol=2e-6, atol=1e-7) and a.mean() > 0
     base, _ = O.scene_from_product(mi.load_dict(make(1.0, tw0)))[0].render_path(s1, seed=2, spp=4, max_depth=4, threads=1)
     assert np.linalg.norm(a - base) > 0.1 * np.linalg.norm(base)          # the update did change the picture
+
+
+def test_envmap_data_is_a_parameter_in_the_references_layout(mi, O):
+    """EnvironmentMapEmitter::traverse registers `data` = the texel tensor with a one-column halo on each side (H x (W + 2) x 3, real column x at x + 1: envmap.cpp:146-188);
+    written + params.update(), the real columns are the new texels (the halo is refreshed from them, whatever the caller put there: :226-246) and the scene equals a freshly
+    loaded one with that bitmap"""
+    import torch
+    rng = np.random.default_rng(5)
+    a0 = rng.uniform(0.1, 1.5, (6, 10, 3)).astype(np.float32); a1 = rng.uniform(0.1, 2.5, (6, 10, 3)).astype(np.float32)
+    def make(a):
+        d = mi.cornell_box(); d["sensor"]["film"]["width"] = 20; d["sensor"]["film"]["height"] = 20
+        d.pop("light"); d.pop("ceiling")
+        d["env"] = {"type": "envmap", "bitmap": mi.Bitmap(a)}
+        return d
+    scene = mi.load_dict(make(a0))
+    params = mi.traverse(scene)
+    t = params["env.data"].cpu().numpy()
+    assert t.shape == (6, 12, 3) and np.array_equal(t[:, 1:-1], a0) and np.array_equal(t[:, 0], a0[:, -1]) and np.array_equal(t[:, -1], a0[:, 0])
+    new = np.concatenate([np.zeros((6, 1, 3), np.float32), a1, np.full((6, 1, 3), 7.0, np.float32)], axis=1)       # a stale halo: ignored
+    params["env.data"] = torch.as_tensor(new); params.update()
+    o1, s1 = O.scene_from_product(scene); o2, s2 = O.scene_from_product(mi.load_dict(make(a1)))
+    a, st1 = o1.render_path(s1, seed=2, spp=4, max_depth=4, threads=1); b, st2 = o2.render_path(s2, seed=2, spp=4, max_depth=4, threads=1)
+    assert st1.vertices == st2.vertices and np.array_equal(a, b)
+    t = mi.traverse(scene)["env.data"].cpu().numpy()
+    assert np.array_equal(t[:, 1:-1], a1) and np.array_equal(t[:, 0], a1[:, -1])
+    with pytest.raises(RuntimeError, match="channels"):
+        params["env.data"] = torch.zeros((6, 12, 4)); params.update()

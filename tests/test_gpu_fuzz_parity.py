@@ -410,7 +410,7 @@ def _perturb(mi, scene, params, rng, torch):
                 params[k] = v * float(rng.uniform(0.5, 1.5))
             elif kind == "x_fov":
                 params[k] = v * float(rng.uniform(0.8, 1.2))
-            elif kind == "emitter_tex":
+            elif kind in ("emitter_tex", "env_data"):
                 params[k] = v * torch.as_tensor(rng.uniform(0.5, 1.5, tuple(v.shape)), dtype=v.dtype, device=v.device)
             else:
                 continue                                          # to_uv: constrained (a light's must keep the unit square), covered by its own tests
