@@ -198,12 +198,15 @@ static inline bool moeller_trumbore(const Ray &ray, const Tri &tr, float &t, flo
     return active;
 }
 
+/* std::fmin / std::fmax (a NaN operand is dropped) without the call into libm that -fno-fast-math leaves in place: twelve of them per box were most of a ray query's time */
+static inline float fmin_nan(float a, float b) { return b != b ? a : (a < b ? a : b); }
+static inline float fmax_nan(float a, float b) { return b != b ? a : (a > b ? a : b); }
 static inline bool slab(const float *lo, const float *hi, const V3 &o, const V3 &id, float tmax, float &tnear) {
     float t0 = 0.f, t1 = tmax;
     for (int a = 0; a < 3; ++a) {
         float ta = (lo[a] - o[a]) * id[a], tb = (hi[a] - o[a]) * id[a];
-        float mn = std::fmin(ta, tb), mx = std::fmax(ta, tb);
-        t0 = std::fmax(t0, mn); t1 = std::fmin(t1, mx);   // fmin/fmax drop NaNs (0*inf)
+        float mn = fmin_nan(ta, tb), mx = fmax_nan(ta, tb);
+        t0 = fmax_nan(t0, mn); t1 = fmin_nan(t1, mx);   // fmin / fmax drop NaNs (0 * inf)
     }
     tnear = t0;
     return t0 <= t1 * 1.0000005f;
@@ -228,22 +231,37 @@ static inline void consider(const Ray &ray, const Tri &tr, PI &pi, uint32_t inst
     pi.t = t; pi.u = u; pi.v = v; pi.prim = tr.prim; pi.shape = tr.shape; pi.inst = inst;
 }
 
+/* Depth first, NEARER child first (the entry distance of a child's box rides on the stack; a popped entry is dropped when the closest hit found since lies in front of it).  The order
+ * only decides how soon the closest hit shrinks the interval: `consider` resolves equal distances by the primitives' keys, not by the order they are met in, and an occlusion
+ * query is a yes / no -- the answers are those of any other visiting order, and of `brute` (the first version of this loop pushed left, then right, whatever the ray's direction:
+ * same answers, three times the node visits of a closest-hit query). */
+struct StackEntry { uint32_t node; float tnear; };
 template <bool Shadow>
 static bool traverse(const Bvh &bvh, const Ray &ray, PI &pi, uint32_t inst) {
     if (bvh.empty()) return false;
     V3 id(rcp(ray.d.x), rcp(ray.d.y), rcp(ray.d.z));
-    uint32_t stack[128]; int sp = 0; stack[sp++] = 0;
+    StackEntry stack[128]; int sp = 0;
+    { float tn; if (!slab(bvh.nodes[0].lo, bvh.nodes[0].hi, ray.o, id, std::fmin(ray.maxt, pi.t), tn)) return false; stack[sp++] = StackEntry{ 0u, tn }; }
     while (sp) {
-        const BvhNode &n = bvh.nodes[stack[--sp]];
-        float tn;
-        if (!slab(n.lo, n.hi, ray.o, id, std::fmin(ray.maxt, pi.t), tn)) continue;
+        const StackEntry e = stack[--sp];
+        if (!(e.tnear <= std::fmin(ray.maxt, pi.t) * 1.0000005f)) continue;      /* what slab() would answer now: its far distance only shrank through the interval's end */
+        const BvhNode &n = bvh.nodes[e.node];
         if (n.count) {
             for (uint32_t i = 0; i < n.count; ++i) {
                 const Tri &tr = bvh.tris[n.left + i];
                 if (Shadow) { float t, u, v; if (moeller_trumbore(ray, tr, t, u, v)) return true; }
                 else consider(ray, tr, pi, inst);
             }
-        } else { stack[sp++] = n.left; stack[sp++] = n.right; }
+        } else {
+            const float tmax = std::fmin(ray.maxt, pi.t);
+            float tl, tr;
+            const bool hl = slab(bvh.nodes[n.left].lo, bvh.nodes[n.left].hi, ray.o, id, tmax, tl), hr = slab(bvh.nodes[n.right].lo, bvh.nodes[n.right].hi, ray.o, id, tmax, tr);
+            if (hl && hr) {
+                if (tl <= tr) { stack[sp++] = StackEntry{ n.right, tr }; stack[sp++] = StackEntry{ n.left, tl }; }
+                else          { stack[sp++] = StackEntry{ n.left, tl };  stack[sp++] = StackEntry{ n.right, tr }; }
+            } else if (hl) stack[sp++] = StackEntry{ n.left, tl };
+            else if (hr) stack[sp++] = StackEntry{ n.right, tr };
+        }
     }
     return false;
 }
@@ -274,13 +292,23 @@ static bool scene_trace(const Scene &sc, const Ray &ray, PI &pi, int mode) {
         for (uint32_t i = 0; i < sc.instances.size(); ++i) if (do_inst(i) && Shadow) return true;
     } else {
         V3 id(rcp(ray.d.x), rcp(ray.d.y), rcp(ray.d.z));
-        uint32_t stack[64]; int sp = 0; stack[sp++] = 0;
-        while (sp) {
-            const BvhNode &n = sc.inst_nodes[stack[--sp]];
-            float tn;
-            if (!slab(n.lo, n.hi, ray.o, id, std::fmin(ray.maxt, pi.t), tn)) continue;
+        StackEntry stack[64]; int sp = 0;
+        { float tn; if (slab(sc.inst_nodes[0].lo, sc.inst_nodes[0].hi, ray.o, id, std::fmin(ray.maxt, pi.t), tn)) stack[sp++] = StackEntry{ 0u, tn }; }
+        while (sp) {                        /* nearer instance boxes first, as in traverse() */
+            const StackEntry e = stack[--sp];
+            if (!(e.tnear <= std::fmin(ray.maxt, pi.t) * 1.0000005f)) continue;
+            const BvhNode &n = sc.inst_nodes[e.node];
             if (n.count) { for (uint32_t i = 0; i < n.count; ++i) if (do_inst(sc.inst_order[n.left + i]) && Shadow) return true; }
-            else { stack[sp++] = n.left; stack[sp++] = n.right; }
+            else {
+                const float tmax = std::fmin(ray.maxt, pi.t);
+                float tl, tr;
+                const bool hl = slab(sc.inst_nodes[n.left].lo, sc.inst_nodes[n.left].hi, ray.o, id, tmax, tl), hr = slab(sc.inst_nodes[n.right].lo, sc.inst_nodes[n.right].hi, ray.o, id, tmax, tr);
+                if (hl && hr) {
+                    if (tl <= tr) { stack[sp++] = StackEntry{ n.right, tr }; stack[sp++] = StackEntry{ n.left, tl }; }
+                    else          { stack[sp++] = StackEntry{ n.left, tl };  stack[sp++] = StackEntry{ n.right, tr }; }
+                } else if (hl) stack[sp++] = StackEntry{ n.left, tl };
+                else if (hr) stack[sp++] = StackEntry{ n.right, tr };
+            }
         }
     }
     return Shadow ? false : pi.valid();
