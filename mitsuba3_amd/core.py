@@ -10,6 +10,7 @@ used for device memory, streams and torch.distributed only.
 import ctypes as C
 import math
 import os
+import re
 
 import numpy as np
 
@@ -2649,8 +2650,69 @@ class SceneParameters(dict):
             pushed[k] = new_mark
 
 
-def traverse(scene):
-    return SceneParameters(scene)
+class ObjectParameters:
+    """mi.traverse(<a plugin object>): the reference walks any Object (util.py:263-341); its tests traverse emitters, shapes and BSDFs on their own and read the entries without
+    a prefix (`params['cutoff_angle']`, test_spot.py:189-212).  The object is placed in a private scene under the name `obj`; this view strips and adds that prefix."""
+
+    def __init__(self, obj):
+        if isinstance(obj, BSDF):
+            if obj.scene is None:
+                Scene({'obj': obj})
+            self.scene = obj.scene
+            self._prefix = (obj.id if obj.id else "bsdf%d" % obj.index) + "."
+        else:
+            # one private scene per object, kept with it: a second traverse() of the same object sees what the first one's update() did (the reference updates the object itself)
+            sc = getattr(obj, '_traverse_scene', None)
+            if sc is None:
+                sc = Scene({'obj': obj})
+                try:
+                    obj._traverse_scene = sc
+                except AttributeError:
+                    pass
+            self.scene = sc
+            self._prefix = "obj."
+        self._inner = SceneParameters(self.scene)
+        self._inner.keep(["^" + re.escape(self._prefix)])
+
+    def keys(self):
+        return [k[len(self._prefix):] for k in self._inner.keys()]
+
+    def items(self):
+        return [(k[len(self._prefix):], v) for k, v in self._inner.items()]
+
+    def __iter__(self):
+        return iter(self.items())
+
+    def __len__(self):
+        return len(self._inner)
+
+    def __contains__(self, key):
+        return self._prefix + key in self._inner
+
+    def __getitem__(self, key):
+        return self._inner[self._prefix + key]
+
+    def __setitem__(self, key, value):
+        self._inner[self._prefix + key] = value
+
+    def flags(self, key):
+        return self._inner.flags(self._prefix + key)
+
+    def set_dirty(self, key):
+        self._inner.set_dirty(self._prefix + key)
+
+    def keep(self, keys):
+        keys = keys if isinstance(keys, list) else [keys]
+        regexps = [re.compile(k).match for k in keys]
+        self._inner.keep(["^" + re.escape(self._prefix + k) + "$" for k in self.keys() if any(r(k) for r in regexps)])
+
+    def update(self, values=None):
+        return self._inner.update({self._prefix + k: v for k, v in values.items()} if values else None)
+
+
+def traverse(node):
+    """mi.traverse (util.py:263-341): the parameter table of a scene, or of a single plugin object (names without a prefix)"""
+    return SceneParameters(node) if isinstance(node, Scene) else ObjectParameters(node)
 
 
 class DeviceGroup:

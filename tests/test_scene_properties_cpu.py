@@ -614,3 +614,29 @@ def test_scene_parameters_keep_flags_set_dirty(mi):
         params["green.reflectance.value"].data[0] = 0.9            # a write the version counter does not see
     params.set_dirty("green.reflectance.value"); params.update()
     assert abs(float(scene.bsdf_objs[scene._param_keys()["green.reflectance.value"][1].index].value[0]) - 0.9) < 1e-7
+
+
+def test_traverse_of_a_single_plugin_object(mi):
+    """mi.traverse(<object>) (util.py:263-341): the reference's plugin tests traverse emitters, shapes and BSDFs on their own and use the names without a prefix -- the
+    spot light's cone as in src/emitters/tests/test_spot.py:189-212, a rectangle's `to_world` as in src/shapes/tests/test_rectangle.py:234-243, a BSDF's colour"""
+    import torch
+    e = mi.load_dict({"type": "spot", "cutoff_angle": 20.0, "intensity": {"type": "rgb", "value": [1, 2, 3]}})
+    params = mi.traverse(e)
+    assert "cutoff_angle" in params and "beam_width" in params
+    assert abs(float(params["cutoff_angle"]) - 20.0) < 1e-6 and abs(float(params["beam_width"]) - 15.0) < 1e-6          # beam_width defaults to 3/4 of the cutoff (spot.cpp:105-107)
+    params["cutoff_angle"] = 30.0; params["beam_width"] = 20.0; params.update()
+    again = mi.traverse(e)
+    assert abs(float(again["cutoff_angle"]) - 30.0) < 1e-6 and abs(float(again["beam_width"]) - 20.0) < 1e-6
+    with pytest.raises(RuntimeError, match="cutoff_angle"):
+        again["beam_width"] = 45.0; again.update()
+    r = mi.load_dict({"type": "rectangle"})
+    rp = mi.traverse(r)
+    assert "to_world" in rp and tuple(rp["to_world"].shape) == (4, 4)
+    rp["to_world"] = torch.as_tensor(np.asarray(mi.ScalarTransform4f().scale([2.0, 2.0, 1.0]).matrix, np.float32)); rp.update()
+    assert np.allclose(np.abs(mi.traverse(r)["positions"].cpu().numpy()[:, :2]), 2.0)
+    b = mi.load_dict({"type": "roughplastic", "alpha": 0.2, "diffuse_reflectance": {"type": "rgb", "value": [0.1, 0.2, 0.3]}})
+    bp = mi.traverse(b)
+    assert sorted(bp.keys()) == ["alpha", "diffuse_reflectance.value", "eta", "specular_reflectance.value"] and abs(float(bp["alpha"]) - 0.2) < 1e-7
+    bp.keep("alpha"); assert bp.keys() == ["alpha"]
+    with pytest.raises(KeyError):
+        bp["nonsense"] = 1.0
