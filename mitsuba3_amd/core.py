@@ -2524,6 +2524,9 @@ class SceneParameters(dict):
             t = self[k]
 
             def apply():
+                mark = seen.get(k)
+                if mark is not None and mark[0] is t and hasattr(t, "_version") and mark[1] == t._version and k in snap:
+                    return                       # the same tensor at the same version as at the last update(): the snapshot and the mark are current (no clone per key and step)
                 if k in device_pos:
                     snap[k] = None               # never compared (see above): no clone of a million vertices per step, no read-back of a flag
                 else:
